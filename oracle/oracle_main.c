@@ -1,0 +1,154 @@
+/* TEST INFRASTRUCTURE — command-line driver of the parity oracle (see oracle_fe.c).
+ *
+ *   oracle_readtape [options] tape.tbin
+ *     -nrzi|-pe|-gcr  -ntrks=N -bpi=N -ips=N   override the TBIN header (src/readtape.c:1330-1343)
+ *     -zeros -differentiate -invert -correct -m -even -revparity=N
+ *     -skew=a,b,..      per-track deskew delays in SAMPLES
+ *     -parms=FILE       parameter sets in the reference's .parms grammar
+ *     -out=BASE         writes BASE.tap (SIMH) and BASE.log
+ *     -evt=FILE         event dump, same 48-byte records as oracle/ref_event_shim.c
+ *     -time             print front-end wall time and Msamples/s (the bench's cpu_baseline)
+ *     -blklimit=N
+ */
+#include "oracle_fe.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+struct rec {
+   uint32_t kind, trk; int32_t peakcount, parmset;
+   double t_peak; int64_t timenow_ns;
+   float v_peak, agc_gain, v_avg_height; uint32_t pad; };
+
+static FILE *evtf;
+static struct ofe *g_fe;
+
+static void on_transition(struct rt_dec *d, struct rt_trk *t, int is_top, void *user) {
+   (void)user;
+   if (!evtf) return;
+   struct rec r; memset(&r, 0, sizeof r);
+   r.kind = is_top ? 0 : 1;
+   r.trk = (uint32_t)t->trknum;
+   r.peakcount = t->peakcount;
+   r.parmset = d->parmset;
+   r.t_peak = is_top ? t->t_top : t->t_bot;
+   r.timenow_ns = g_fe->timenow_ns;
+   r.v_peak = is_top ? t->v_top : t->v_bot;
+   r.agc_gain = t->agc_gain;
+   r.v_avg_height = t->v_avg_height;
+   fwrite(&r, sizeof r, 1, evtf); }
+
+static void on_attempt(struct rt_dec *d, void *user) {
+   (void)user;
+   if (!evtf) return;
+   struct rec r; memset(&r, 0, sizeof r);
+   r.kind = 2;
+   r.parmset = d->parmset;
+   r.t_peak = d->timenow;
+   r.timenow_ns = g_fe->timenow_ns;
+   fwrite(&r, sizeof r, 1, evtf); }
+
+static unsigned char *slurp(const char *path, size_t *len) {
+   FILE *f = fopen(path, "rb");
+   if (!f) return NULL;
+   fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+   unsigned char *b = (unsigned char *)malloc((size_t)n + 16);
+   if (fread(b, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(b); return NULL; }
+   fclose(f); *len = (size_t)n; return b; }
+
+static uint32_t rd32(const unsigned char *p) { return p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24; }
+static float rdf(const unsigned char *p) { uint32_t u = rd32(p); float f; memcpy(&f, &u, 4); return f; }
+
+int main(int argc, char **argv) {
+   struct rt_options opt; memset(&opt, 0, sizeof opt);
+   opt.specified_parity = 1;
+   const char *infile = NULL, *outbase = NULL, *evtname = NULL, *parmfile = NULL, *skewarg = NULL;
+   int ntrks_arg = 0, invert = 0, timing = 0, blklimit = 0x7fffffff;
+   float bpi_arg = -1, ips_arg = -1;
+   int mode_arg = 0;
+   for (int i = 1; i < argc; ++i) {
+      const char *a = argv[i];
+      if (!strcmp(a, "-nrzi")) mode_arg = RT_NRZI;
+      else if (!strcmp(a, "-pe")) mode_arg = RT_PE;
+      else if (!strcmp(a, "-gcr")) mode_arg = RT_GCR;
+      else if (!strncmp(a, "-ntrks=", 7)) ntrks_arg = atoi(a + 7);
+      else if (!strncmp(a, "-bpi=", 5)) bpi_arg = (float)atof(a + 5);
+      else if (!strncmp(a, "-ips=", 5)) ips_arg = (float)atof(a + 5);
+      else if (!strcmp(a, "-zeros")) opt.find_zeros = 1;
+      else if (!strcmp(a, "-differentiate")) opt.do_differentiate = 1;
+      else if (!strcmp(a, "-invert")) invert = 1;
+      else if (!strcmp(a, "-correct")) opt.do_correction = 1;
+      else if (!strcmp(a, "-m")) opt.multiple_tries = 1;
+      else if (!strcmp(a, "-even")) opt.specified_parity = 0;
+      else if (!strncmp(a, "-revparity=", 11)) opt.revparity = atoi(a + 11);
+      else if (!strcmp(a, "-v")) opt.verbose = 1;
+      else if (!strcmp(a, "-tap")) opt.tap_format = 1;
+      else if (!strcmp(a, "-time")) timing = 1;
+      else if (!strncmp(a, "-skew=", 6)) skewarg = a + 6;
+      else if (!strncmp(a, "-parms=", 7)) parmfile = a + 7;
+      else if (!strncmp(a, "-out=", 5)) outbase = a + 5;
+      else if (!strncmp(a, "-evt=", 5)) evtname = a + 5;
+      else if (!strncmp(a, "-blklimit=", 10)) blklimit = atoi(a + 10);
+      else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a); return 2; }
+      else infile = a; }
+   if (!infile) { fprintf(stderr, "usage: oracle_readtape [options] tape.tbin\n"); return 2; }
+   opt.tap_format = 1;
+
+   size_t len; unsigned char *buf = slurp(infile, &len);
+   if (!buf || len < 256 || memcmp(buf, "TBINHDR", 8)) { fprintf(stderr, "not a .tbin file: %s\n", infile); return 2; }
+   uint32_t flags = rd32(buf + 204), ntrks = rd32(buf + 208), tdelta = rd32(buf + 212);
+   float maxvolts = rdf(buf + 216);
+   uint32_t mode = rd32(buf + 228); float bpi = rdf(buf + 232), ips = rdf(buf + 236);
+   size_t off = 240;
+   if (flags & 2) off += 28;
+   if (memcmp(buf + off, "DAT", 4)) { fprintf(stderr, "missing DAT tag\n"); return 2; }
+   uint64_t tstart; memcpy(&tstart, buf + off + 8, 8);
+   off += 16;
+   opt.mode = mode_arg ? (enum rt_mode)mode_arg : (enum rt_mode)mode;
+   opt.ntrks = ntrks_arg ? ntrks_arg : (int)ntrks;
+   opt.bpi = bpi_arg >= 0 ? bpi_arg : bpi;
+   opt.ips = ips_arg >= 0 ? ips_arg : ips;
+   if (opt.ips == 0) opt.ips = 50;
+   if (opt.mode == RT_GCR) opt.bpi = 9042;                   /* src/readtape.c:1652-1654 */
+   int nheads = (int)ntrks;
+   const int16_t *rows = (const int16_t *)(buf + off);       /* off is even: 256 or 284 */
+   int64_t navail = (int64_t)((len - off) / 2 / (size_t)nheads), nrows = navail;
+   for (int64_t i = 0; i < navail; ++i) if (rows[i * nheads] == -32768) { nrows = i; break; }
+   if ((len - off) / 2 > (size_t)(navail * nheads) && nrows == navail) {
+      /* the end marker is the lone int16 after the last full row */ }
+
+   float sample_deltat = (float)(int64_t)tdelta / 1e9f;      /* src/readtape.c:1345 */
+   struct rt_dec *d = rt_dec_new(&opt, sample_deltat, (int64_t)tdelta);
+   if (parmfile) {
+      size_t plen; unsigned char *ptxt = slurp(parmfile, &plen);
+      if (!ptxt) { fprintf(stderr, "can't read %s\n", parmfile); return 2; }
+      ptxt[plen] = 0;
+      if (rt_parse_parms_text(opt.mode, (const char *)ptxt, d->parmsets) <= 0) { fprintf(stderr, "bad parms file\n"); return 2; }
+      free(ptxt); }
+   struct ofe *fe = ofe_new(d, rows, nrows, nheads, maxvolts, (int64_t)tstart);
+   g_fe = fe;
+   fe->invert = invert;
+   if (skewarg) {
+      int t = 0; const char *p = skewarg;
+      while (*p && t < RT_MAXTRKS) { fe->skew_delaycnt[t++] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+   char name[1024];
+   if (outbase) {
+      snprintf(name, sizeof name, "%s.tap", outbase); d->tapf = fopen(name, "wb");
+      snprintf(name, sizeof name, "%s.log", outbase); d->logf = fopen(name, "w"); }
+   if (evtname) { evtf = fopen(evtname, "wb"); d->on_transition = on_transition; d->on_attempt = on_attempt; }
+
+   struct rt_reader rd = { ofe_readblock, ofe_save_pos, ofe_restore_pos, fe };
+   struct timespec t0, t1;
+   clock_gettime(CLOCK_MONOTONIC, &t0);
+   int ok = rt_process_blocks(d, &rd, blklimit);
+   clock_gettime(CLOCK_MONOTONIC, &t1);
+   double secs = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+   if (d->logf) fprintf(d->logf, "decoded %d tape marks and %d blocks with %lld bytes; %d with errors, %d with warnings\n",
+                        d->numtapemarks, d->numblks, d->numdatabytes, d->numblks_err, d->numblks_warn);
+   if (timing) printf("{\"samples\": %lld, \"seconds\": %.6f, \"msamples_per_s\": %.4f, \"blocks\": %d, \"tapemarks\": %d, \"bytes\": %lld, \"ok\": %d}\n",
+                      fe->lines_in, secs, fe->lines_in / secs / 1e6, d->numblks, d->numtapemarks, d->numdatabytes, ok);
+   if (d->tapf) fclose(d->tapf);
+   if (d->logf) fclose(d->logf);
+   if (evtf) fclose(evtf);
+   return fe->fatal ? 99 : 0; }

@@ -1,0 +1,223 @@
+/* rt_decode.h — host-side block decoders that consume the front end's flux-transition events.
+ *
+ * This is the part of the pipeline that stays sequential on the host:
+ * the per-format bit/clock recovery machines, the AGC / clock-average helpers they own, the
+ * parameter sets, the retry/selection driver and the SIMH .tap writer.  It is a from-scratch
+ * restatement organised around one explicit decoder context (`rt_dec`) instead of the reference's
+ * process-wide globals, so that any number of decoders (one per parmset of a batched sweep, one per
+ * time shard) can run side by side.
+ *
+ * Every function cites the reference lines whose behaviour it reproduces; float/double promotion
+ * points are kept exactly as written there (parity depends on them).
+ *
+ * Two front ends drive it through the same calls:
+ *   - the HIP front end (product): events replayed by rt_replay.c
+ *   - the scalar CPU restatement in oracle/ (test infrastructure only)
+ */
+#ifndef RT_DECODE_H
+#define RT_DECODE_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_MAXTRKS        19      /* src/csvtbin.h:29 */
+#define RT_MAXBLOCK       131072  /* src/decoder.h:91 */
+#define RT_MAXPARMSETS    15      /* src/decoder.h:92 */
+#define RT_CLKRATE_WINDOW 50      /* src/decoder.h:142 */
+#define RT_AGC_MAX_WINDOW 10      /* src/decoder.h:152 */
+#define RT_PKWW_MAX_WIDTH 50      /* src/decoder.h:132 */
+#define RT_MAXSKEWSAMP    50      /* src/decoder.h:97 */
+
+enum rt_mode { RT_UNKNOWN = 0, RT_PE = 1, RT_NRZI = 2, RT_GCR = 4, RT_WW = 8 };   /* src/csvtbin.h:47-49 */
+
+enum rt_bstate {            /* src/decoder.h:318-325 */
+   RT_BS_NONE, RT_BS_TAPEMARK, RT_BS_NOISE, RT_BS_BADBLOCK, RT_BS_BLOCK, RT_BS_ABORTED };
+
+struct rt_parms {           /* src/decoder.h:290-310 (the fields that matter) */
+   int   active;
+   int   clk_window;
+   float clk_alpha;
+   int   agc_window;
+   float agc_alpha;
+   float min_peak;
+   float clk_factor;
+   float pulse_adj;
+   float pkww_bitfrac;
+   float pkww_rise;
+   float midbit;
+   float z1pt;
+   float z2pt;
+   int   tried, chosen;
+};
+
+struct rt_clkavg {          /* src/decoder.h:185-192 */
+   float t_bitspacing[RT_CLKRATE_WINDOW];
+   int   bitndx;
+   float t_bitspaceavg;
+};
+
+/* Per-track state shared between the front end and the block decoders
+ * (the subset of src/decoder.h:194-255 that crosses the seam, plus decoder-private fields).
+ * Detector-private state (window, countdown, deskew FIFO, zero-cross FSM) is NOT here: it lives in
+ * the front end (device, or oracle/). */
+struct rt_trk {
+   int    trknum;
+   float  v_now;            /* written by the front end; PE/GCR idle code copies it to v_lastpeak */
+   float  v_top;   double t_top;   float v_lasttop;
+   float  v_bot;   double t_bot;   float v_lastbot;  double t_lastbot;
+   float  v_lastpeak;
+   double t_lastpeak, t_prevlastpeak;
+   float  t_peakdelta, t_peakdeltaprev;
+   double t_lastpulsestart, t_lastpulseend;
+   float  v_avg_height, v_avg_height_sum;
+   int    v_avg_height_count;
+   float  agc_gain, max_agc_gain, min_agc_gain;
+   float  v_heights[RT_AGC_MAX_WINDOW];
+   int    heightndx;
+   double t_lastbit, t_firstbit, t_lastclock;
+   int    consecutive_zeroes;
+   float  t_clkwindow, t_pulse_adj;
+   uint8_t bit1_up;
+   struct rt_clkavg clkavg;
+   int    datacount, peakcount;
+   uint8_t lastdatabit, idle, clknext, datablock;
+   uint8_t lastbits;
+   int    resync_bitcount;
+};
+
+struct rt_results {         /* src/decoder.h:333-358 */
+   enum rt_bstate blktype;
+   int   minbits, maxbits;
+   float avg_bit_spacing;
+   int   warncount, missed_midbits, corrected_bits, gcr_bad_dgroups;
+   int   ww_leading_clock, ww_missing_onebit, ww_missing_clock;
+   uint16_t faked_tracks;
+   int   errcount, track_mismatch, vparity_errs, ecc_errs, crc_errs, lrc_errs;
+   int   gcr_bad_sequence, ww_bad_length, ww_speed_err;
+   int   first_error, crc, lrc;
+   float alltrk_max_agc_gain, alltrk_min_agc_gain;
+};
+
+struct rt_nrzi {            /* src/decoder.h:266-273 */
+   double t_lastclock, t_last_midbit;
+   struct rt_clkavg clkavg;
+   uint8_t datablock, reset_speed;
+   int    post_counter;
+};
+
+struct rt_options {         /* the command-line switches that reach the decoders (src/readtape.c:936-1022) */
+   enum rt_mode mode;
+   int   ntrks;
+   float bpi, ips;
+   int   specified_parity;  /* 1 = odd (default) */
+   int   revparity;
+   int   do_correction;     /* -correct */
+   int   find_zeros;        /* -zeros */
+   int   do_differentiate;  /* -differentiate */
+   int   multiple_tries;    /* -m */
+   int   tap_format;        /* -tap */
+   int   add_parity;
+   int   verbose;           /* -v: log every block */
+};
+
+struct rt_dec {
+   struct rt_options opt;
+   struct rt_parms   parmsets[RT_MAXPARMSETS];
+   float   sample_deltat;           /* seconds, float (src/readtape.c:1345) */
+   int64_t sample_deltat_ns;
+   /* run state */
+   double  timenow;                 /* time of the sample being processed (src/decoder.c:92) */
+   int     interblock_counter;      /* src/decoder.c:97 */
+   int     num_trks_idle;
+   int     expected_parity;
+   struct rt_trk trk[RT_MAXTRKS];
+   struct rt_nrzi nrzi;
+   /* block state (src/decoder.h:327-359) */
+   int     tries, parmset;
+   uint8_t window_set, endblock_done;
+   double  t_blockstart;
+   struct rt_results results[RT_MAXPARMSETS];
+   uint16_t *data, *data_faked;     /* [RT_MAXBLOCK+1] */
+   double   *data_time;
+   /* output / bookkeeping (src/readtape.c:497-520) */
+   FILE   *tapf;
+   long long numoutbytes, numdatabytes;
+   int     numblks, numtapemarks, numblks_err, numblks_warn, numblks_unusable;
+   int     numblks_goodmultiple, numblks_trksmismatched, numblks_midbiterrs, numblks_corrected;
+   FILE   *logf;                    /* block log lines (NULL = quiet) */
+   /* optional observer: called at the top of every up/down transition, before the format callback
+    * (the same seam oracle/ref_event_shim.c wraps in the reference) */
+   void  (*on_transition)(struct rt_dec *d, struct rt_trk *t, int is_top, void *user);
+   void  (*on_attempt)(struct rt_dec *d, void *user);
+   void   *user;
+};
+#define RT_PARM(d) ((d)->parmsets[(d)->parmset])
+
+/* ---- lifetime ---- */
+struct rt_dec *rt_dec_new(const struct rt_options *opt, float sample_deltat, int64_t sample_deltat_ns);
+void rt_dec_free(struct rt_dec *d);
+void rt_default_parmsets(enum rt_mode mode, struct rt_parms out[RT_MAXPARMSETS]);   /* src/parmsets.c:77-118 */
+int  rt_parse_parms_text(enum rt_mode mode, const char *text, struct rt_parms out[RT_MAXPARMSETS]); /* src/parmsets.c:236-327 */
+int  rt_pkww_width(const struct rt_dec *d, int parmset);            /* src/readtape.c:1455-1457 */
+int  rt_samples_per_bit(const struct rt_dec *d);                    /* src/readtape.c:1402 */
+
+/* ---- shared helpers (src/decoder.c:401-609) ---- */
+void rt_init_blockstate(struct rt_dec *d);
+void rt_init_trackstate(struct rt_dec *d);
+void rt_init_clkavg(struct rt_clkavg *c, float init_avg);
+void rt_adjust_clock(struct rt_dec *d, struct rt_clkavg *c, float delta, int trk);
+void rt_force_clock(struct rt_clkavg *c, float delta);
+void rt_adjust_agc(struct rt_dec *d, struct rt_trk *t);
+void rt_up_transition(struct rt_dec *d, struct rt_trk *t);     /* t->v_top / t->t_top already set */
+void rt_down_transition(struct rt_dec *d, struct rt_trk *t);   /* t->v_bot / t->t_bot already set */
+void rt_set_expected_parity(struct rt_dec *d, int blklength);
+int  rt_parity9(uint16_t w);
+
+/* ---- per-sample control: the timers of process_sample (src/decoder.c:841-894), split into
+ *      predicates (pure) and actions so an event-driven replay can schedule them ---- */
+int  rt_nrzi_zerocheck_due(const struct rt_dec *d);            /* src/decoder.c:844 */
+void rt_nrzi_zerocheck(struct rt_dec *d);                      /* src/decode_nrzi.c:232-314 */
+void rt_nrzi_end_of_block(struct rt_dec *d);                   /* src/decode_nrzi.c:77-113 */
+int  rt_pe_idle_due(const struct rt_dec *d, const struct rt_trk *t);   /* src/decoder.c:868 */
+void rt_pe_go_idle(struct rt_dec *d, struct rt_trk *t);        /* src/decoder.c:871-877 */
+void rt_pe_end_of_block(struct rt_dec *d);                     /* src/decode_pe.c:33-102 */
+int  rt_gcr_idle_due(const struct rt_dec *d, const struct rt_trk *t);  /* src/decoder.c:879-880 */
+int  rt_gcr_go_idle(struct rt_dec *d, struct rt_trk *t);       /* src/decoder.c:881-888; returns 1 if block ended */
+void rt_gcr_end_of_block(struct rt_dec *d);                    /* src/decode_gcr.c:682-729 */
+void rt_force_end_of_block(struct rt_dec *d);                  /* src/readtape.c:1378-1381 */
+void rt_finish_attempt(struct rt_dec *d);                      /* src/readtape.c:1508-1515 */
+
+/* format callbacks (src/decode_*.c) */
+void rt_nrzi_top(struct rt_dec *d, struct rt_trk *t);
+void rt_nrzi_bot(struct rt_dec *d, struct rt_trk *t);
+void rt_pe_top(struct rt_dec *d, struct rt_trk *t);
+void rt_pe_bot(struct rt_dec *d, struct rt_trk *t);
+void rt_pe_generate_fake_bits(struct rt_dec *d, struct rt_trk *t);
+void rt_gcr_top(struct rt_dec *d, struct rt_trk *t);
+void rt_gcr_bot(struct rt_dec *d, struct rt_trk *t);
+void rt_gcr_preprocess(struct rt_dec *d);
+
+/* ---- output (src/readtape.c:1076-1111, 1160-1313, 1885) ---- */
+void rt_got_tapemark(struct rt_dec *d);
+void rt_got_datablock(struct rt_dec *d, int badblock);
+void rt_tap_end(struct rt_dec *d);
+
+/* ---- the block retry / selection driver (src/readtape.c:1720-1882) over an abstract block reader.
+ * `readblock(ctx, retry)` must run one attempt with d->parmset from the saved position and return
+ * 0 at end of data (like !readblock()); `save_pos` / `restore_pos` mirror save/restore_file_position. */
+struct rt_reader {
+   int  (*readblock)(void *ctx, int retry);
+   void (*save_pos)(void *ctx);
+   void (*restore_pos)(void *ctx);
+   void *ctx;
+};
+int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit);   /* returns 1 if all blocks clean */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

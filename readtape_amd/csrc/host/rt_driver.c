@@ -1,0 +1,176 @@
+/* rt_driver.c — block retry / best-decoding selection and the SIMH .tap writer.
+ * Restates the block loop of src/readtape.c:1720-1882 and the writers of src/readtape.c:1076-1082,
+ * 1160-1176, 1212-1313, 1885 over an abstract block reader, so the same decisions are taken whether
+ * the attempts are re-read one at a time (scalar path) or looked up in a batched parmset sweep. */
+#include "rt_decode.h"
+
+#include <float.h>
+#include <limits.h>
+#include <stdarg.h>
+#include <string.h>
+
+static void rlog(struct rt_dec *d, const char *fmt, ...) {
+   if (!d->logf) return;
+   va_list ap; va_start(ap, fmt); vfprintf(d->logf, fmt, ap); va_end(ap); }
+
+static void output_tap_marker(struct rt_dec *d, uint32_t num) {   /* src/readtape.c:1076-1082 */
+   for (int i = 0; i < 4; ++i) {
+      unsigned char lsb = num & 0xff;
+      if (d->tapf) fwrite(&lsb, 1, 1, d->tapf);
+      num >>= 8; }
+   d->numoutbytes += 4; }
+
+void rt_tap_end(struct rt_dec *d) {   /* src/readtape.c:1885 */
+   if (d->opt.tap_format && d->tapf) output_tap_marker(d, 0xffffffffu); }
+
+void rt_got_tapemark(struct rt_dec *d) {   /* src/readtape.c:1160-1176 */
+   ++d->numtapemarks;
+   rlog(d, "  tapemark at time %.8lf, tap offset %lld, %d blocks written so far\n", d->timenow, d->numoutbytes, d->numblks);
+   if (d->opt.tap_format) output_tap_marker(d, 0x00000000); }
+
+static const char *format_block_errors(struct rt_dec *d, struct rt_results *result, char *buf) {   /* src/readtape.c:1179-1209 */
+   char *p = buf;
+   if (result->errcount > 0) {
+      p += sprintf(p, "%d err%s", result->errcount, result->errcount > 1 ? "s" : "");
+      if (result->track_mismatch) p += sprintf(p, ", %d bit track mismatch", result->track_mismatch);
+      if (result->vparity_errs) p += sprintf(p, ", %d parity", result->vparity_errs);
+      if (result->crc_errs) p += sprintf(p, ", %d CRC", result->crc_errs);
+      if (result->lrc_errs) p += sprintf(p, ", 1 LRC");
+      if (result->ecc_errs) p += sprintf(p, ", %d ECC", result->ecc_errs); }
+   else p += sprintf(p, "ok");
+   if (result->warncount > 0) {
+      p += sprintf(p, ", %d warning%s", result->warncount, result->warncount > 1 ? "s" : "");
+      if (d->opt.mode == RT_NRZI && result->corrected_bits > 0) {
+         int trkcount = 0; uint16_t tracks = result->faked_tracks;
+         for (; tracks; ++trkcount) tracks &= tracks - 1;
+         p += sprintf(p, ", %d bits corrected on %d trks", result->corrected_bits, trkcount); }
+      if (result->gcr_bad_dgroups) p += sprintf(p, ", %d bad dgroups", result->gcr_bad_dgroups);
+      if (result->corrected_bits > 0) p += sprintf(p, ", %d corrected bits", result->corrected_bits);
+      if (d->opt.mode == RT_PE) {
+         int length = result->minbits, nbits = 0, ntrk = 0; uint16_t faked = 0;
+         for (int i = 0; i < length; ++i) { uint16_t v = d->data_faked[i]; faked |= v; for (; v; ++nbits) v &= v - 1; }
+         for (; faked; ++ntrk) faked &= faked - 1;
+         if (nbits > 0) p += sprintf(p, ", %d faked bits on %d trks", nbits, ntrk); } }
+   return buf; }
+
+void rt_got_datablock(struct rt_dec *d, int badblock) {   /* src/readtape.c:1212-1313 (no labels, no text file) */
+   struct rt_results *result = &d->results[d->parmset];
+   int length = result->minbits;
+   if (length > 0) {
+      if (badblock) {
+         ++d->numblks_unusable;
+         rlog(d, "ERROR: unusable block, ");
+         if (result->track_mismatch) rlog(d, "tracks mismatched with lengths %d to %d", result->minbits, result->maxbits);
+         else rlog(d, "unknown reason");
+         rlog(d, ", %d tries, parmset %d, at time %.8lf\n", d->tries, d->parmset, d->timenow); }
+      else {
+         uint32_t errflag = result->errcount ? 0x80000000u : 0;
+         if (d->opt.tap_format) output_tap_marker(d, (uint32_t)length | errflag);
+         for (int i = 0; i < length; ++i) {
+            unsigned char b = (unsigned char)(d->data[i] >> 1);
+            if (d->opt.add_parity) b |= (d->data[i] & 1) << (d->opt.ntrks - 1);
+            if (d->tapf) fwrite(&b, 1, 1, d->tapf); }
+         if (d->opt.tap_format) {
+            unsigned char zero = 0;
+            if (length & 1) {
+               if (d->tapf) fwrite(&zero, 1, 1, d->tapf);
+               d->numoutbytes += 1; }
+            output_tap_marker(d, (uint32_t)length | errflag); }
+         if (result->errcount != 0) ++d->numblks_err;
+         if (result->warncount != 0) ++d->numblks_warn;
+         if (d->opt.verbose || d->numblks == 0 || result->errcount > 0 || result->warncount > 0) {
+            char buf[400];
+            rlog(d, "wrote block %3d, %4d bytes, %d %s, parmset %d, ", d->numblks + 1, length, d->tries, d->tries > 1 ? "tries" : "try", d->parmset);
+            if (result->alltrk_min_agc_gain == FLT_MAX) rlog(d, "max AGC %.2f, ", result->alltrk_max_agc_gain);
+            else rlog(d, "AGC %.2f-%.2f, ", result->alltrk_min_agc_gain, result->alltrk_max_agc_gain);
+            rlog(d, "%s", format_block_errors(d, result, buf));
+            rlog(d, ", avg speed %.2f IPS at time %.8lf", 1 / (result->avg_bit_spacing * d->opt.bpi), d->timenow);
+            rlog(d, ", tap offset %lld\n", d->numoutbytes); }
+         if (result->track_mismatch) ++d->numblks_trksmismatched;
+         if (result->missed_midbits > 0) {
+            ++d->numblks_midbiterrs;
+            rlog(d, "   WARNING: %d bits were before the midbit using parmset %d for block %d at %.8lf\n",
+                 result->missed_midbits, d->parmset, d->numblks + 1, d->timenow); }
+         if (result->corrected_bits > 0) ++d->numblks_corrected;
+         d->numoutbytes += length;
+         d->numdatabytes += length;
+         ++d->numblks; } } }
+
+int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit) {   /* src/readtape.c:1719-1889 */
+   int ok = 1;
+   int endfile = 0;
+   d->interblock_counter = 0;
+   while (!endfile && d->numblks < blklimit) {
+      rt_init_blockstate(d);
+      d->parmset = 0;
+      r->save_pos(r->ctx);
+      int keep_trying, last_parmset;
+      d->tries = 0;
+      do {
+         keep_trying = 0;
+         last_parmset = d->parmset;
+         rt_init_trackstate(d);
+         endfile = !r->readblock(r->ctx, d->tries > 0);
+         struct rt_results *result = &d->results[d->parmset];
+         if (result->blktype == RT_BS_NONE) goto endfile;
+         ++d->tries;
+         ++RT_PARM(d).tried;
+         if (result->blktype == RT_BS_TAPEMARK) goto done;
+         if (result->blktype == RT_BS_NOISE) goto done;                 /* SKIP_NOISE, src/decoder.h:146 */
+         if (result->blktype == RT_BS_BLOCK && result->errcount == 0 && result->warncount == 0) {
+            if (d->tries > 1) ++d->numblks_goodmultiple;
+            goto done; }
+         if (d->opt.multiple_tries && (d->opt.mode != RT_PE || result->minbits != 0)) {
+            int next_parmset = d->parmset;
+            do { if (++next_parmset >= RT_MAXPARMSETS) next_parmset = 0; }
+            while (next_parmset != d->parmset &&
+                   (d->parmsets[next_parmset].active == 0 || d->results[next_parmset].blktype != RT_BS_NONE));
+            if (next_parmset != d->parmset) {
+               keep_trying = 1;
+               d->parmset = next_parmset;
+               r->restore_pos(r->ctx);
+               d->interblock_counter = 0; } } }
+      while (keep_trying);
+
+      if (d->tries == 1) {
+         if (d->results[d->parmset].errcount > 0) ok = 0; }
+      else {
+         int min_warnings = INT_MAX;
+         for (int i = 0; i < RT_MAXPARMSETS; ++i) {
+            struct rt_results *res = &d->results[i];
+            if (res->blktype == RT_BS_BLOCK && res->errcount == 0 && res->warncount < min_warnings) {
+               min_warnings = res->warncount; d->parmset = i; } }
+         if (min_warnings < INT_MAX) goto done;
+         ok = 0;
+         int min_errors = INT_MAX;
+         for (int i = 0; i < RT_MAXPARMSETS; ++i) {
+            struct rt_results *res = &d->results[i];
+            if (res->blktype == RT_BS_BLOCK && res->errcount < min_errors) {
+               min_errors = res->errcount; d->parmset = i; } }
+         if (min_errors < INT_MAX) goto done;
+         int min_track_diff = INT_MAX;
+         for (int i = 0; i < RT_MAXPARMSETS; ++i) {
+            struct rt_results *res = &d->results[i];
+            if (res->blktype == RT_BS_BADBLOCK && res->track_mismatch < min_track_diff) {
+               min_track_diff = res->track_mismatch; d->parmset = i; } }
+         if (min_track_diff < INT_MAX) goto done;
+         for (int i = 0; i < RT_MAXPARMSETS; ++i)
+            if (d->results[i].blktype == RT_BS_NOISE) { d->parmset = i; goto done; }
+         return 0; }
+done:;
+      struct rt_results *result = &d->results[d->parmset];
+      if (result->blktype != RT_BS_NOISE) {
+         ++RT_PARM(d).chosen;
+         if (d->tries > 1 && last_parmset != d->parmset) {
+            r->restore_pos(r->ctx);
+            d->interblock_counter = 0;
+            rt_init_trackstate(d);
+            endfile = !r->readblock(r->ctx, 1); }
+         switch (d->results[d->parmset].blktype) {
+         case RT_BS_TAPEMARK: rt_got_tapemark(d); break;
+         case RT_BS_BLOCK:    rt_got_datablock(d, 0); break;
+         case RT_BS_BADBLOCK: rt_got_datablock(d, 1); break;
+         default: return 0; } } }
+endfile:
+   rt_tap_end(d);
+   return ok; }
