@@ -1,0 +1,53 @@
+"""The parity case table shared by the golden-vector generator (tools/make_goldens.py), the
+oracle-vs-reference tests and the GPU parity tests.  Each case = a synthetic tape recipe + the
+reference command-line options it is decoded with (option coverage follows the reference's own
+examples/*/Makefile test commands)."""
+import numpy as np
+
+from readtape_amd import synth, tbin
+
+
+def _nrzi_small(seed, **kw):
+    return synth.nrzi_tape(seed=seed, nblocks=2, minlen=40, maxlen=90, marks_every=2, gap_samples=1500, **kw)
+
+
+def case_nrzi9(seed=11):
+    return _nrzi_small(seed)
+
+
+def case_nrzi9_weak(seed=12):
+    # one weak track + more noise so that parmset 0 fails on some blocks and -m retries
+    t = synth.nrzi_tape(seed=seed, nblocks=3, minlen=40, maxlen=80, gap_samples=1500,
+                        amplitude=0.9, amp_slope=0.12, noise_mv=60.0, jitter=0.06)
+    return t
+
+
+def case_nrzi7(seed=13):
+    return synth.nrzi_tape(seed=seed, nblocks=2, minlen=40, maxlen=90, marks_every=2, ntrks=7, gap_samples=1500)
+
+
+def case_nrzi9_skew(seed=14):
+    return _nrzi_small(seed, skew_cells=(0.0, 0.10, 0.05, 0.15, 0.0, 0.20, 0.10, 0.05, 0.12))
+
+
+def case_pe(seed=15):
+    return synth.pe_tape(seed=seed, nblocks=2, minlen=30, maxlen=60, gap_samples=1500)
+
+
+# name -> (tape builder, reference options, oracle options)
+CASES = {
+    "nrzi9":        (case_nrzi9,      ["-nrzi"],                       []),
+    "nrzi9_m":      (case_nrzi9_weak, ["-nrzi", "-m"],                 ["-m"]),
+    "nrzi9_correct":(case_nrzi9_weak, ["-nrzi", "-m", "-correct"],     ["-m", "-correct"]),
+    "nrzi7":        (case_nrzi7,      ["-nrzi", "-ntrks=7"],           []),
+    "nrzi9_skew":   (case_nrzi9_skew, ["-nrzi", "-ntrks=9", "-skew=3,1,2,0,3,0,1,2,1"], ["-skew=3,1,2,0,3,0,1,2,1"]),
+    "nrzi9_invert": (case_nrzi9,      ["-nrzi", "-invert"],            ["-invert"]),
+    "nrzi9_zeros":  (case_nrzi9,      ["-nrzi", "-zeros"],             ["-zeros"]),
+    "nrzi9_diffz":  (case_nrzi9,      ["-nrzi", "-zeros", "-differentiate"], ["-zeros", "-differentiate"]),
+    "nrzi9_diffpk": (case_nrzi9,      ["-nrzi", "-differentiate"],     ["-differentiate"]),
+    "pe":           (case_pe,         ["-pe"],                         []),
+    "pe_m":         (case_pe,         ["-pe", "-m"],                   ["-m"]),
+    "pe_zeros":     (case_pe,         ["-pe", "-zeros"],               ["-zeros"]),
+}
+# every reference run also gets: -v -tap -nolabels (SIMH .tap output, no IBM label handling);
+# "-nm" is added when "-m" is absent because the reference retries by default (src/readtape.c:511)
