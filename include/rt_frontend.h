@@ -1,0 +1,156 @@
+/* rt_frontend.h — C ABI of the MI355X analog front end (librtfe.so).
+ *
+ * The drop-in boundary.  The reference (LenShustek/readtape V3.18) has no plugin or FFI surface;
+ * its de-facto seam is   bool readblock(bool retry)            src/readtape.c:1396
+ * which loops            enum bstate_t process_sample(...)     src/decoder.c:817 (decl. src/decoder.h:384)
+ * and, beneath it, the callback set the front end drives:
+ *        void {nrzi,pe,gcr,ww}_{top,bot}(struct trkstate_t*)   src/decoder.h:385-399
+ * after  init_trackstate()                                     src/decoder.c:425.
+ * This library replaces everything between those two seams: given the TBIN payload resident in HBM
+ * it produces, per block attempt and per parameter set, exactly the sequence of top/bot calls the
+ * reference's process_sample() would make (track, polarity, peak time, voltage, detection sample,
+ * AGC gain), as 16-byte event records.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Plain pointers and sizes only; every pointer whose name starts with d_ is a DEVICE pointer
+ * (hipMalloc / torch storage).  All calls are asynchronous on `stream` (a hipStream_t passed as
+ * void*, NULL = default stream) unless stated; nothing here synchronises the device.
+ *
+ * Exactness contract.  The reference restarts all detector state at every block attempt
+ * (src/decoder.c:425-455), at a sample only its sequential bit decoders know.  rtfe_scan()
+ * speculates: it restarts inside every inter-block quiet zone ("burst" boundary) and reports, per
+ * burst, the interval [zone_first, safe_last] of restart samples for which its output is PROVABLY
+ * identical to the reference's (dead-quiet signal, full windows, common min/max rescan — see
+ * DESIGN.md §3).  A caller whose true restart sample falls outside the interval, or whose block
+ * does not end inside a zone, calls rtfe_scan_exact() for that one attempt: same kernels, caller-
+ * given restart sample, no speculation.  Neither path computes anything on the CPU.
+ */
+#ifndef RT_FRONTEND_H
+#define RT_FRONTEND_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTFE_MAXTRKS     19   /* src/csvtbin.h:29  MAXTRKS      */
+#define RTFE_MAXPARMSETS 15   /* src/decoder.h:92  MAXPARMSETS  */
+#define RTFE_ABI_VERSION 1
+
+enum { RTFE_PE = 1, RTFE_NRZI = 2, RTFE_GCR = 4, RTFE_WW = 8 };      /* enum mode_t, src/csvtbin.h:47-49 */
+
+/* the front-end half of struct parms_t (src/decoder.h:290-310) */
+typedef struct rtfe_parmset {
+   float   pkww_bitfrac;     /* window width as a fraction of a bit cell              */
+   float   pkww_rise;        /* required rise, volts at 4 V p-p                       */
+   float   min_peak;         /* absolute minimum peak, volts (0 = none)               */
+   float   agc_alpha;        /* exponential AGC weight (0 = off)                      */
+   int32_t agc_window;       /* min-of-last-n AGC window (0 = off)                    */
+   float   clk_factor;       /* PE only: clock window factor (decides preamble end)   */
+} rtfe_parmset;
+
+typedef struct rtfe_config {
+   int32_t mode;                          /* RTFE_NRZI ...                                        */
+   int32_t ntrks;                         /* tracks == heads in a TBIN row                        */
+   int32_t head_to_trk[RTFE_MAXTRKS];     /* column -> track permutation (src/readtape.c:1419)    */
+   int32_t invert;                        /* -invert        (src/readtape.c:1421)                 */
+   int32_t differentiate;                 /* -differentiate (src/readtape.c:1383-1388)            */
+   int32_t find_zeros;                    /* -zeros         (src/decoder.c:863-865)               */
+   int32_t skew_delaycnt[RTFE_MAXTRKS];   /* -skew=n,n,..   in samples (src/decoder.c:232)        */
+   float   maxvolts;                      /* TBIN header                                          */
+   float   bpi, ips;
+   int64_t tdelta_ns;                     /* sample period                                        */
+   int64_t tstart_ns;                     /* time of row 0                                        */
+   int32_t nparmsets;
+   rtfe_parmset parmset[RTFE_MAXPARMSETS];
+   /* speculation / screening knobs (performance only; results are exact or flagged) */
+   int32_t gap_min_samples;               /* quiet run treated as an inter-block gap; 0 = 32 bit cells */
+   float   quiet_volts;                   /* |v| band of the dead-quiet test; 0 = default         */
+   float   screen_floor_height;           /* assumed lower bound of the AGC baseline (v_avg_height) for
+                                             the candidate screen; 0 = default 1.0 V.  A burst whose
+                                             measured baseline is lower is flagged RTFE_F_SCREEN_UNDERFLOW */
+   float   events_per_sample_cap;         /* per-track event capacity as a fraction of the burst length;
+                                             0 = default 1/8 */
+} rtfe_config;
+
+/* One flux-transition event = one call of {mode}_top/_bot in the reference (src/decoder.c:574-609). */
+typedef struct rtfe_event {
+   uint32_t sample;          /* detection sample (the reference's `timenow` row), relative to the burst's reset_sample */
+   float    v_peak;          /* t->v_top / t->v_bot, volts                                          */
+   float    agc_gain;        /* t->agc_gain when the callback is entered                            */
+   uint8_t  trk;
+   uint8_t  flags;           /* bit0: 0 = top (up transition), 1 = bottom; bits 1-2: time adjustment
+                                code 0 = none, 1 = -0.5 sample, 2 = +0.5 sample (src/decoder.c:718-730) */
+   uint8_t  left_distance;   /* 1-based position of the peak in the window (src/decoder.c:704-744)  */
+   uint8_t  parmset;
+} rtfe_event;                /* 16 bytes */
+
+/* peak time exactly as refine_peak forms it (src/decoder.c:732); W = pkww_width of the parmset:
+ *   timenow = (double)(tstart_ns + (reset_sample + sample) * tdelta_ns) / 1e9
+ *   t_peak  = timenow - ((float)(W - left_distance) - adj) * sample_deltat          */
+
+enum {
+   RTFE_F_EXACT_START      = 1,    /* reset_sample was given by the caller (or is row 0)             */
+   RTFE_F_UNSAFE           = 2,    /* no provably-equivalent restart interval exists for this burst  */
+   RTFE_F_EVENT_OVERFLOW   = 4,    /* a track's event region filled up; events were dropped          */
+   RTFE_F_SCREEN_UNDERFLOW = 8,    /* AGC threshold fell below the candidate screen: rescan exactly with screen off */
+   RTFE_F_DETECTOR_FATAL   = 16    /* the reference would have hit its fatal "peak at window edge" assert (src/decoder.c:709-710,748) */
+};
+
+typedef struct rtfe_burst {
+   int64_t  zone_first;      /* first row of the dead-quiet zone that precedes this burst            */
+   int64_t  zone_end;        /* one past the last row of that zone                                    */
+   int64_t  reset_sample;    /* row at which this burst's detector state was restarted                */
+   int64_t  safe_last;       /* any true restart row in [zone_first, safe_last] gives identical events */
+   int64_t  end_sample;      /* rows [reset_sample, end_sample) were scanned with this burst's state  */
+   uint64_t event_base;      /* index into the event buffer of this burst's first region              */
+   uint32_t event_cap;       /* capacity of each (parmset, track) region                              */
+   uint32_t flags;           /* RTFE_F_*                                                              */
+} rtfe_burst;                /* 64 bytes */
+/* region of (burst b, parmset p, track t):  events[ b.event_base + (p * ntrks + t) * b.event_cap ... ],
+ * count in counts[(burst_index * nparmsets + p) * ntrks + t]; events of one region are in detection order. */
+
+typedef struct rtfe_handle rtfe_handle;
+
+int         rtfe_abi_version(void);
+const char *rtfe_last_error(void);
+
+/* Validates the configuration and precomputes window widths, thresholds and the candidate screen.
+ * Returns 0 or a negative error (message via rtfe_last_error). Synchronous, no device work. */
+int  rtfe_create(const rtfe_config *cfg, rtfe_handle **out);
+void rtfe_destroy(rtfe_handle *h);
+int  rtfe_pkww_width(const rtfe_handle *h, int parmset);      /* src/readtape.c:1455-1457 */
+
+/* Sizes the caller must provide for a scan of nrows rows. */
+size_t  rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows);
+int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows);
+int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows);
+
+/* Speculative scan of d_rows[0 .. nrows) (interleaved int16, ntrks per row, the TBIN payload).
+ * row_base is the absolute index of d_rows[0] on the tape (time shards: != 0); first_is_tape_start
+ * says row_base is a true restart point (the start of the tape or of a shard that begins at one).
+ * Outputs (device): bursts[*nbursts], counts, events. */
+int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base, int first_is_tape_start,
+              void *d_workspace, size_t workspace_bytes,
+              rtfe_burst *d_bursts, int64_t max_bursts, int32_t *d_nbursts,
+              uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,
+              void *stream);
+
+/* Exact scan of one block attempt: detector state restarts at `reset_row` (index into d_rows) and
+ * rows [reset_row, end_row) are scanned; parmset_mask selects parameter sets.  With screen_off != 0
+ * every sample is examined (use after RTFE_F_SCREEN_UNDERFLOW).  Writes one rtfe_burst. */
+int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,
+                    int64_t reset_row, int64_t end_row, uint32_t parmset_mask, int screen_off,
+                    void *d_workspace, size_t workspace_bytes,
+                    rtfe_burst *d_burst, uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,
+                    void *stream);
+
+/* Names and launch-order of the kernels of one scan, for profilers (static strings). */
+int         rtfe_kernel_count(void);
+const char *rtfe_kernel_name(int i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

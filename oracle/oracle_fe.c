@@ -239,6 +239,7 @@ static enum rt_bstate process_sample(struct ofe *fe, const float *voltage) {
          if (rt_gcr_go_idle(d, t)) goto exit; }
 
 exit:
+   if (fe->eob_row < 0 && d->results[d->parmset].blktype != RT_BS_NONE) fe->eob_row = fe->pos - 1;   /* row at which the block ended */
    if (d->interblock_counter) {
       if (--d->interblock_counter) return RT_BS_NONE; }
    return d->results[d->parmset].blktype; }
@@ -251,6 +252,7 @@ int ofe_readblock(void *ctx, int retry) {
    int did_processing = 0, endfile = 0;
    enum rt_bstate blockkind = RT_BS_NONE;
    int samples_per_bit = rt_samples_per_bit(d);
+   fe->eob_row = -1;
    ofe_reset_detectors(fe);                   /* what init_trackstate does to detector state, src/decoder.c:432,437 */
    if (fe->on_attempt_start) fe->on_attempt_start(fe, fe->pos);
    do {
@@ -283,4 +285,5 @@ int ofe_readblock(void *ctx, int retry) {
    while (blockkind == RT_BS_NONE);
 done:
    rt_finish_attempt(d);
+   if (fe->on_attempt_end) fe->on_attempt_end(fe);
    return !endfile; }

@@ -27,10 +27,12 @@ struct ofe {
    int skew_delaycnt[RT_MAXTRKS];
    int pkww_width;
    long long lines_in, numsamples;
+   int64_t eob_row;            /* row whose processing ended the current attempt's block (-1: not yet) */
    int fatal;
    struct ofe_det det[RT_MAXTRKS];
    struct ofe_skew skew[RT_MAXTRKS];
    void (*on_attempt_start)(struct ofe *fe, int64_t first_row);
+   void (*on_attempt_end)(struct ofe *fe);
    void *user;
 };
 struct ofe *ofe_new(struct rt_dec *dec, const int16_t *rows, int64_t nrows, int nheads, float maxvolts, int64_t tstart_ns);

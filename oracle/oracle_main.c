@@ -7,6 +7,8 @@
  *     -parms=FILE       parameter sets in the reference's .parms grammar
  *     -out=BASE         writes BASE.tap (SIMH) and BASE.log
  *     -evt=FILE         event dump, same 48-byte records as oracle/ref_event_shim.c
+ *     -evtend           also dump a kind-3 record when an attempt ends (timenow_ns = time of the next
+ *                       row it would read); the reference shim cannot produce these
  *     -time             print front-end wall time and Msamples/s (the bench's cpu_baseline)
  *     -blklimit=N
  */
@@ -22,6 +24,7 @@ struct rec {
    float v_peak, agc_gain, v_avg_height; uint32_t pad; };
 
 static FILE *evtf;
+static int evt_ends;
 static struct ofe *g_fe;
 
 static void on_transition(struct rt_dec *d, struct rt_trk *t, int is_top, void *user) {
@@ -47,6 +50,17 @@ static void on_attempt(struct rt_dec *d, void *user) {
    r.parmset = d->parmset;
    r.t_peak = d->timenow;
    r.timenow_ns = g_fe->timenow_ns;
+   fwrite(&r, sizeof r, 1, evtf); }
+
+static void on_attempt_end(struct ofe *fe) {
+   if (!evtf || !evt_ends) return;
+   struct rec r; memset(&r, 0, sizeof r);
+   r.kind = 3;
+   r.trk = (uint32_t)(fe->eob_row >= 0 ? fe->pos - fe->eob_row : 1);   /* rows from the block-ending row to the next attempt's first row */
+   r.parmset = fe->dec->parmset;
+   r.peakcount = (int32_t)fe->dec->results[fe->dec->parmset].blktype;
+   r.t_peak = fe->dec->timenow;
+   r.timenow_ns = fe->timenow_ns;
    fwrite(&r, sizeof r, 1, evtf); }
 
 static unsigned char *slurp(const char *path, size_t *len) {
@@ -89,6 +103,7 @@ int main(int argc, char **argv) {
       else if (!strncmp(a, "-parms=", 7)) parmfile = a + 7;
       else if (!strncmp(a, "-out=", 5)) outbase = a + 5;
       else if (!strncmp(a, "-evt=", 5)) evtname = a + 5;
+      else if (!strcmp(a, "-evtend")) evt_ends = 1;
       else if (!strncmp(a, "-blklimit=", 10)) blklimit = atoi(a + 10);
       else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a); return 2; }
       else infile = a; }
@@ -136,7 +151,7 @@ int main(int argc, char **argv) {
    if (outbase) {
       snprintf(name, sizeof name, "%s.tap", outbase); d->tapf = fopen(name, "wb");
       snprintf(name, sizeof name, "%s.log", outbase); d->logf = fopen(name, "w"); }
-   if (evtname) { evtf = fopen(evtname, "wb"); d->on_transition = on_transition; d->on_attempt = on_attempt; }
+   if (evtname) { evtf = fopen(evtname, "wb"); d->on_transition = on_transition; d->on_attempt = on_attempt; fe->on_attempt_end = on_attempt_end; }
 
    struct rt_reader rd = { ofe_readblock, ofe_save_pos, ofe_restore_pos, fe };
    struct timespec t0, t1;

@@ -1,0 +1,198 @@
+// rtfe_api.hip — host side of the C ABI declared in include/rt_frontend.h (librtfe.so).
+// Validates the configuration, derives window widths / thresholds exactly as the reference does
+// (src/readtape.c:1402,1455-1457; src/decoder.c:448-449) and launches the three kernels.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "rt_frontend.h"
+#include "rtfe_device.h"
+
+#include "rtfe_kernels.hip"   // single translation unit: kernels + host API
+
+namespace rtfe {
+__global__ void k_setup_exact(rtfe_burst *burst, BurstScratch *scratch, long long reset_row, long long end_row,
+                              unsigned long long cap) {
+   rtfe_burst b = {};
+   b.zone_first = reset_row; b.zone_end = reset_row; b.reset_sample = reset_row; b.safe_last = reset_row;
+   b.end_sample = end_row; b.event_base = 0; b.event_cap = (uint32_t)cap; b.flags = RTFE_F_EXACT_START;
+   *burst = b;
+   scratch->nbursts = 1; scratch->queue = 0; }
+}  // namespace rtfe
+
+using namespace rtfe;
+
+struct rtfe_handle {
+   rtfe_config cfg;
+   DevCfg dev;
+   DevCfg *d_dev;
+   int lds_bytes;
+   int num_cus;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+   return code; }
+
+extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
+extern "C" const char *rtfe_last_error(void) { return g_err; }
+
+static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_decode"};
+extern "C" int rtfe_kernel_count(void) { return 3; }
+extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < 3) ? KNAMES[i] : ""; }
+
+extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
+   if (!c || !out) return fail(-1, "null argument");
+   if (c->ntrks < 1 || c->ntrks > RTFE_MAXTRKS) return fail(-2, "ntrks %d out of range", c->ntrks);
+   if (c->mode != RTFE_NRZI && c->mode != RTFE_PE && c->mode != RTFE_GCR)
+      return fail(-3, "mode %d not supported by the device front end yet (Whirlwind: see DESIGN.md)", c->mode);
+   if (c->differentiate || c->find_zeros) return fail(-4, "-differentiate / -zeros paths are not built yet");
+   if (c->nparmsets < 1 || c->nparmsets > RTFE_MAXPARMSETS) return fail(-5, "nparmsets %d out of range", c->nparmsets);
+   if (c->nparmsets * c->ntrks > kDecodeThreads) return fail(-6, "nparmsets*ntrks > %d", kDecodeThreads);
+   if (!(c->bpi > 0) || !(c->ips > 0) || c->tdelta_ns <= 0 || !(c->maxvolts > 0)) return fail(-7, "bpi, ips, tdelta_ns and maxvolts must be positive");
+   rtfe_handle *h = new rtfe_handle();
+   h->cfg = *c;
+   DevCfg &d = h->dev;
+   memset(&d, 0, sizeof d);
+   d.mode = c->mode; d.ntrks = c->ntrks; d.invert = c->invert != 0; d.nparm = c->nparmsets;
+   bool seen[RTFE_MAXTRKS] = {false};
+   for (int i = 0; i < c->ntrks; ++i) {
+      int t = c->head_to_trk[i];
+      if (t < 0 || t >= c->ntrks || seen[t]) { delete h; return fail(-8, "head_to_trk is not a permutation"); }
+      seen[t] = true; d.head_to_trk[i] = t;
+      int s = c->skew_delaycnt[i];
+      if (s < 0 || s > 50) { delete h; return fail(-9, "skew %d out of range 0..50 (MAXSKEWSAMP)", s); }
+      d.skew[i] = s; if (s > d.maxskew) d.maxskew = s; }
+   d.maxvolts = c->maxvolts;
+   d.sample_deltat = (float)c->tdelta_ns / 1e9f;                       // src/readtape.c:1345
+   d.tdelta_ns = c->tdelta_ns; d.tstart_ns = c->tstart_ns;
+   const float bitspace = 1 / (c->bpi * c->ips);                       // src/decoder.c:448
+   const float hfloor = c->screen_floor_height > 0 ? c->screen_floor_height : 1.0f;
+   const double lsb_per_volt = 32767.0 / (double)c->maxvolts;
+   float quiet_v = 1e9f;
+   for (int p = 0; p < c->nparmsets; ++p) {
+      const rtfe_parmset &ps = c->parmset[p];
+      DevParm &dp = d.parm[p];
+      int W = (int)(ps.pkww_bitfrac / (c->bpi * c->ips * d.sample_deltat));     // src/readtape.c:1456
+      if (W > 50) W = 50;
+      if (W < 2) { delete h; return fail(-10, "parmset %d: window of %d samples is too small", p, W); }
+      if (ps.agc_window < 0 || ps.agc_window > 10) { delete h; return fail(-11, "parmset %d: agc_window out of range", p); }
+      if (ps.agc_window && ps.agc_alpha != 0) { delete h; return fail(-12, "parmset %d: inconsistent AGC parameters", p); }   // src/decoder.c:502
+      dp.W = W; dp.rise = ps.pkww_rise; dp.min_peak = ps.min_peak; dp.agc_alpha = ps.agc_alpha; dp.agc_window = ps.agc_window;
+      dp.t_clkwindow = bitspace / 2 * ps.clk_factor;                      // src/decoder.c:449
+      // loosest thresholds the AGC can ever ask for, given v_avg_height >= hfloor and agc_gain <= 2
+      const float scale = (hfloor < 4.0f ? hfloor : 4.0f) / 4.0f / 2.0f;
+      dp.screen_rise_v = ps.pkww_rise * scale;
+      dp.screen_minpk_v = ps.min_peak * scale;
+      int s;
+      for (s = 0; s < d.nscreens; ++s) if (d.screen[s].W == W) break;
+      if (s == d.nscreens) {
+         if (s == kMaxScreens) { delete h; return fail(-13, "more than %d distinct window widths", kMaxScreens); }
+         d.screen[s].W = W; d.screen[s].rise_i = 1 << 30; d.screen[s].minpk_i = 1 << 30; ++d.nscreens; }
+      dp.screen = s;
+      int ri = (int)floor(dp.screen_rise_v * lsb_per_volt * (1.0 - 1e-5)) - 2;
+      int mi = ps.min_peak > 0 ? (int)floor(dp.screen_minpk_v * lsb_per_volt * (1.0 - 1e-5)) - 2 : -1;
+      if (ri < -1) ri = -1;
+      if (ri < d.screen[s].rise_i) d.screen[s].rise_i = ri;
+      if (mi < d.screen[s].minpk_i) d.screen[s].minpk_i = mi;
+      // dead-quiet band: no detection is possible from a freshly reset detector (agc 1, baseline 4 V) while
+      // |v| < min_peak, or while the signal range 2|v| < pkww_rise
+      float q = ps.min_peak > ps.pkww_rise / 2 ? ps.min_peak : ps.pkww_rise / 2;
+      if (q < quiet_v) quiet_v = q; }
+   for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].minpk_i < 0) d.screen[s].minpk_i = -1;
+   if (c->quiet_volts > 0 && c->quiet_volts < quiet_v) quiet_v = c->quiet_volts;
+   d.quiet_i = (int)floor(quiet_v * 0.98 * lsb_per_volt) - 1;
+   if (d.quiet_i < 0) d.quiet_i = 0;
+   const int spb = (int)(1 / (c->bpi * c->ips * d.sample_deltat));
+   int gap = c->gap_min_samples > 0 ? c->gap_min_samples : 32 * (spb > 0 ? spb : 1);
+   if (gap < kMarginRows + 128) gap = kMarginRows + 128;
+   d.gap_chunks = (int)(((long long)gap * c->ntrks * 2 + 1023) / 1024) + 1;
+   d.cap_frac = c->events_per_sample_cap > 0 ? c->events_per_sample_cap : 0.125f;
+   h->lds_bytes = (((c->ntrks * (kHaloRows + kTileRows + 8) * 2 + 15) & ~15)
+                   + ((d.nscreens * 3 * c->ntrks * (kTileRows / 8) + 15) & ~15)
+                   + c->nparmsets * c->ntrks * 10 * 4 + 64);
+   if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
+   hipDeviceProp_t prop;
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return fail(-20, "no HIP device"); }
+   h->num_cus = prop.multiProcessorCount;
+   if (hipMalloc(&h->d_dev, sizeof(DevCfg)) != hipSuccess) { delete h; return fail(-21, "hipMalloc failed"); }
+   if (hipMemcpy(h->d_dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { hipFree(h->d_dev); delete h; return fail(-22, "hipMemcpy failed"); }
+   hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+   *out = h;
+   return 0; }
+
+extern "C" void rtfe_destroy(rtfe_handle *h) {
+   if (!h) return;
+   hipFree(h->d_dev);
+   delete h; }
+
+extern "C" int rtfe_pkww_width(const rtfe_handle *h, int parmset) {
+   return (h && parmset >= 0 && parmset < h->dev.nparm) ? h->dev.parm[parmset].W : -1; }
+
+static long long nwords_for(const rtfe_handle *h, int64_t nrows) {
+   const long long nchunks = (nrows * h->dev.ntrks) / 512 + 1;
+   return (nchunks + 63) / 64; }
+
+extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
+   return (size_t)nwords_for(h, nrows) * 8 + 256; }
+
+extern "C" int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows) {
+   return (nrows * h->dev.ntrks / 512) / h->dev.gap_chunks + 4; }
+
+extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
+   const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
+   return (int64_t)(per_track * h->dev.nparm * h->dev.ntrks) + 4096; }
+
+static int launch_check(const char *what) {
+   hipError_t e = hipGetLastError();
+   if (e != hipSuccess) return fail(-30, "%s: %s", what, hipGetErrorString(e));
+   return 0; }
+
+extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base, int first_is_tape_start,
+                         void *d_workspace, size_t workspace_bytes,
+                         rtfe_burst *d_bursts, int64_t max_bursts, int32_t *d_nbursts,
+                         uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity, void *stream) {
+   if (!h || !d_rows || !d_workspace || !d_bursts || !d_nbursts || !d_counts || !d_events) return fail(-1, "null argument");
+   if (((uintptr_t)d_rows & 15) != 0) return fail(-31, "d_rows must be 16-byte aligned");
+   if (workspace_bytes < rtfe_workspace_bytes(h, nrows)) return fail(-32, "workspace too small");
+   if (nrows <= 0 || max_bursts < 1) return fail(-33, "nothing to scan");
+   hipStream_t st = (hipStream_t)stream;
+   const long long nelem = (long long)nrows * h->dev.ntrks;
+   const long long nchunks = nelem / 512;
+   const long long nwords = nwords_for(h, nrows);
+   BurstScratch *scratch = reinterpret_cast<BurstScratch *>(d_workspace);
+   unsigned long long *qwords = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_workspace) + 256);
+   int grid = (int)(nwords < (long long)h->num_cus * 8 ? nwords : (long long)h->num_cus * 8);
+   hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, st, d_rows, nelem, h->dev.quiet_i, qwords, nwords);
+   hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, h->dev.ntrks,
+                      h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
+                      d_bursts, (long long)max_bursts, scratch, d_nbursts);
+   const int per_cu = (160 * 1024) / (h->lds_bytes + 1024);
+   const int dgrid = h->num_cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+   hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(kDecodeThreads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+                      (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0);
+   return launch_check("rtfe_scan"); }
+
+extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,
+                               int64_t reset_row, int64_t end_row, uint32_t parmset_mask, int screen_off,
+                               void *d_workspace, size_t workspace_bytes,
+                               rtfe_burst *d_burst, uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,
+                               void *stream) {
+   if (!h || !d_rows || !d_workspace || !d_burst || !d_counts || !d_events) return fail(-1, "null argument");
+   if (((uintptr_t)d_rows & 15) != 0) return fail(-31, "d_rows must be 16-byte aligned");
+   if (workspace_bytes < 256) return fail(-32, "workspace too small");
+   if (reset_row < 0 || reset_row >= nrows || end_row <= reset_row) return fail(-34, "bad row range");
+   if (end_row > nrows) end_row = nrows;
+   hipStream_t st = (hipStream_t)stream;
+   BurstScratch *scratch = reinterpret_cast<BurstScratch *>(d_workspace);
+   const unsigned long long cap = (unsigned long long)(event_capacity / ((int64_t)h->dev.nparm * h->dev.ntrks));
+   hipLaunchKernelGGL(k_setup_exact, dim3(1), dim3(1), 0, st, d_burst, scratch, (long long)reset_row, (long long)end_row,
+                      cap > 0xffffffffull ? 0xffffffffull : cap);
+   hipLaunchKernelGGL(k_decode, dim3(1), dim3(kDecodeThreads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+                      (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1);
+   return launch_check("rtfe_scan_exact"); }

@@ -1,0 +1,49 @@
+// rtfe_device.h — device-side configuration shared by the kernels and the host API (gfx950 only).
+#pragma once
+#include <stdint.h>
+#include "rt_frontend.h"
+
+namespace rtfe {
+
+constexpr int kChunkRows   = 64;     // granularity of the quiet map (rows per bit)
+constexpr int kTileRows    = 2048;   // rows per LDS tile of the decode kernel
+constexpr int kHaloRows    = 160;    // rows kept in front of a tile: >= 2*W + max skew + 8  (W<=50, skew<=50)
+constexpr int kMarginRows  = 256;    // head/tail tile length at a burst boundary (multiple of 64)
+constexpr int kStrip       = 8;      // samples per screen strip (one bitmap byte)
+constexpr int kDecodeThreads = 256;
+constexpr int kMaxScreens  = 4;      // distinct window widths handled in one scan
+
+struct DevParm {
+   int   W;             // pkww_width (src/readtape.c:1456)
+   float rise;          // PARM.pkww_rise
+   float min_peak;      // PARM.min_peak
+   float agc_alpha;
+   int   agc_window;
+   float t_clkwindow;   // PE: clkavg.t_bitspaceavg / 2 * clk_factor (src/decoder.c:449)
+   int   screen;        // index into DevCfg::screen
+   float screen_rise_v; // the screen's loosest thresholds in volts (for the underflow check)
+   float screen_minpk_v;
+};
+
+struct DevScreen {
+   int W;
+   int rise_i;          // candidate if (max - edge) > rise_i on both edges          (int16 units)
+   int minpk_i;         // ... and max > minpk_i (top) / min < -minpk_i (bottom); -1 = no min_peak test
+};
+
+struct DevCfg {
+   int   mode, ntrks, invert, nparm, nscreens;
+   int   head_to_trk[RTFE_MAXTRKS];   // TBIN column -> track (src/readtape.c:1419)
+   int   skew[RTFE_MAXTRKS];
+   int   maxskew;
+   float maxvolts;
+   float sample_deltat;           // (float)tdelta_ns / 1e9f (src/readtape.c:1345)
+   long long tdelta_ns, tstart_ns;
+   int   quiet_i;                 // |x| <= quiet_i on every track  <=> row is "quiet"
+   int   gap_chunks;              // quiet chunks that make an inter-block zone
+   float cap_frac;                // event capacity per track as a fraction of burst length
+   DevParm   parm[RTFE_MAXPARMSETS];
+   DevScreen screen[kMaxScreens];
+};
+
+}  // namespace rtfe

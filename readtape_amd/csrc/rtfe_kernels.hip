@@ -1,0 +1,690 @@
+// rtfe_kernels.hip — the MI355X (gfx950 / CDNA4) analog front end.
+//
+// Three kernels per scan, all integer / fp32 streaming work bound by HBM and LDS, no MFMA:
+//
+//   k_quiet    one pass over the interleaved int16 TBIN payload: 1 bit per KiB of payload that says
+//              "every sample of every track is inside the quiet band".              [HBM-bound]
+//   k_bursts   turns runs of quiet bits into inter-block zones -> the burst table (one workgroup).
+//   k_decode   persistent workgroups pull bursts from a queue.  Per 2048-row tile: coalesced 16-B
+//              loads of the AoS rows, de-interleave into an SoA [track][sample] LDS tile, a data-
+//              parallel sliding-window max/min "candidate screen" (one bit per track-sample, built
+//              with wave-independent strips), then one lane per (parameter set, track) walks only
+//              the candidate bits and replays the reference's sequential detector EXACTLY (blind
+//              countdown, stale-minimum rescans, AGC schedule, half-sample refinement) out of LDS.
+//
+// What is reproduced, and where it lives in the reference (LenShustek/readtape V3.18):
+//   sample convert            src/readtape.c:1418-1421      volt()
+//   deskew delay line         src/decoder.c:820-830         Tile::y()
+//   staggered track start     src/decoder.c:855-861         Walker::start
+//   lookfor_peak              src/decoder.c:751-810         slow_step() literal, fast path via screen
+//   refine_peak               src/decoder.c:700-749         emit_peak()
+//   process_*_transition      src/decoder.c:560-609         agc_after_peak()
+//   adjust_agc                src/decoder.c:500-531         adjust_agc()
+//   AGC schedule NRZI / GCR   src/decode_nrzi.c:196-197,218-229 ; src/decode_gcr.c:843-864
+//   AGC schedule PE           src/decode_pe.c:127-155,175,198
+// Compile with -ffp-contract=off: the reference is plain C99 on SSE2 (no FMA), and parity is bit-exact.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtfe_device.h"
+
+namespace rtfe {
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------------------------------
+// k_quiet: bit c of qwords[] = every int16 in payload bytes [1024c, 1024c+1024) has |x| <= quiet_i
+// one wave = one chunk per iteration (64 lanes x 16 B), one workgroup = one 64-bit word
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_quiet(const int16_t *__restrict__ rows, long long nelem, int quiet_i,
+                                               u64 *__restrict__ qwords, long long nwords) {
+   __shared__ unsigned int part[4];
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const long long nchunks_full = nelem / 512;            // complete 1 KiB chunks
+   for (long long w = blockIdx.x; w < nwords; w += gridDim.x) {
+      unsigned int bits = 0;
+      #pragma unroll 4
+      for (int k = 0; k < 16; ++k) {
+         long long c = w * 64 + wave * 16 + k;
+         bool q = false;
+         if (c < nchunks_full) {
+            const int4 v = reinterpret_cast<const int4 *>(rows + c * 512)[lane];
+            int m = 0;
+            const int vv[4] = {v.x, v.y, v.z, v.w};
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+               int lo = (short)(vv[j] & 0xffff), hi = vv[j] >> 16;
+               lo = lo < 0 ? -lo : lo; hi = hi < 0 ? -hi : hi;
+               m = max(m, max(lo, hi)); }
+            q = m <= quiet_i; }
+         const u64 b = __ballot(q);
+         if (c < nchunks_full && b == ~0ull) bits |= 1u << k; }
+      if (lane == 0) part[wave] = bits;
+      __syncthreads();
+      if (threadIdx.x == 0)
+         qwords[w] = (u64)part[0] | ((u64)part[1] << 16) | ((u64)part[2] << 32) | ((u64)part[3] << 48);
+      __syncthreads(); } }
+
+// ------------------------------------------------------------------------------------------------
+// k_bursts: zones of >= gap_chunks quiet chunks -> burst table.  Single workgroup of 1024 threads.
+// A zone END is a quiet chunk c whose successor is not quiet and whose gap_chunks predecessors
+// (itself included) are all quiet; each thread tests the 64 chunks of one word per round.
+// ------------------------------------------------------------------------------------------------
+struct BurstScratch {            // lives in the workspace
+   int   nbursts;
+   int   queue;                  // next burst to decode
+   int   pad[2];
+};
+
+__device__ inline bool quiet_at(const u64 *q, long long c, long long nchunks) {
+   return c >= 0 && c < nchunks && ((q[c >> 6] >> (c & 63)) & 1); }
+
+__device__ inline int block_excl_scan_1024(int v, int *lds, int *total) {
+   // exclusive scan of one int per thread over a 1024-thread block (16 waves)
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   int x = v;
+   #pragma unroll
+   for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+   if (lane == 63) lds[wave] = x;
+   __syncthreads();
+   if (threadIdx.x == 0) { int s = 0; for (int i = 0; i < 16; ++i) { int t = lds[i]; lds[i] = s; s += t; } lds[16] = s; }
+   __syncthreads();
+   const int r = x - v + lds[wave];
+   *total = lds[16];
+   __syncthreads();
+   return r; }
+
+__global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords, long long nwords, long long nchunks,
+                                                 long long nrows, int ntrks, int gap_chunks, int first_is_start,
+                                                 float cap_frac, int nparm, long long event_capacity,
+                                                 rtfe_burst *__restrict__ bursts, long long max_bursts,
+                                                 BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out) {
+   __shared__ int lds[32];
+   __shared__ int s_base;
+   __shared__ u64 s_ebase;
+   if (threadIdx.x == 0) {
+      s_base = 0;
+      // a tape (or shard) that does not begin inside a qualifying zone gets an exact-start burst at row 0
+      bool starts_quiet = true;
+      for (int c = 0; c < gap_chunks; ++c) if (!quiet_at(qwords, c, nchunks)) { starts_quiet = false; break; }
+      if (first_is_start && !starts_quiet && max_bursts > 0) {
+         rtfe_burst b = {};
+         b.zone_first = 0; b.zone_end = 0; b.reset_sample = 0; b.safe_last = 0; b.flags = RTFE_F_EXACT_START;
+         bursts[0] = b;
+         s_base = 1; } }
+   __syncthreads();
+   for (long long w0 = 0; w0 < nwords; w0 += 1024) {
+      const long long w = w0 + threadIdx.x;
+      u64 ends = 0;
+      if (w < nwords) {
+         const u64 q = qwords[w];
+         const u64 qn = (w + 1 < nwords) ? qwords[w + 1] : 0;
+         const u64 next = (q >> 1) | (qn << 63);         // bit c = quiet[c+1]
+         u64 cand = q & ~next;                           // quiet and successor not quiet
+         while (cand) {
+            const int bit = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const long long c = w * 64 + bit;
+            bool ok = true;
+            for (int k = 1; k < gap_chunks; ++k) if (!quiet_at(qwords, c - k, nchunks)) { ok = false; break; }
+            if (ok) ends |= 1ull << bit; } }
+      int total;
+      const int cnt = __popcll(ends);
+      int off = block_excl_scan_1024(cnt, lds, &total);
+      const int base = s_base;
+      while (ends) {
+         const int bit = __ffsll((long long)ends) - 1;
+         ends &= ends - 1;
+         const long long c1 = w * 64 + bit + 1;          // one past the last quiet chunk
+         long long c0 = c1 - 1;
+         while (c0 > 0 && quiet_at(qwords, c0 - 1, nchunks)) --c0;   // zone start (long gaps: bounded by the gap length)
+         const long long idx = (long long)base + off++;
+         if (idx < max_bursts) {
+            rtfe_burst b = {};
+            long long zf = (c0 * 512 + ntrks - 1) / ntrks;           // first row entirely inside quiet chunks
+            long long ze = (c1 * 512) / ntrks;                       // one past the last such row
+            zf = (zf + 63) & ~63ll; ze &= ~63ll;
+            if (ze > nrows) ze = nrows & ~63ll;
+            b.zone_first = zf; b.zone_end = ze; b.reset_sample = -1; b.safe_last = -1;
+            bursts[idx] = b; } }
+      __syncthreads();
+      if (threadIdx.x == 0) s_base = base + total;
+      __syncthreads(); }
+   int nb = s_base;
+   if (nb > max_bursts) nb = (int)max_bursts;
+   // drop zones too short to hold a head tile (zone_end - zone_first < margin + 64): mark by flags later in decode
+   // ---- second pass: coarse extents, event capacities and region bases (parallel prefix sum) ----
+   if (threadIdx.x == 0) s_ebase = 0;
+   __syncthreads();
+   for (int b0 = 0; b0 < nb; b0 += 1024) {
+      const int b = b0 + threadIdx.x;
+      long long cap = 0;
+      if (b < nb) {
+         const long long start = (bursts[b].flags & RTFE_F_EXACT_START) ? 0 : bursts[b].zone_end - kMarginRows;
+         const long long end = (b + 1 < nb) ? bursts[b + 1].zone_end : nrows;
+         long long len = end - start;
+         if (len < 0) len = 0;
+         cap = (long long)((float)len * cap_frac) + 64;
+         bursts[b].end_sample = end;             // provisional: the decode kernel replaces it by the next reset
+         bursts[b].event_cap = (uint32_t)cap; }
+      // 64-bit scan done as two 32-bit scans would overflow; regions are < 2^31 events each, so scan in units of 64 events
+      int total;
+      const int units = (int)((cap * nparm * ntrks + 63) >> 6);
+      const int eoff = block_excl_scan_1024(units, lds, &total);
+      if (b < nb) {
+         const u64 base = s_ebase + ((u64)eoff << 6);
+         if ((long long)(base + (u64)cap * nparm * ntrks) > event_capacity) {
+            bursts[b].event_cap = 0; bursts[b].flags |= RTFE_F_EVENT_OVERFLOW; }
+         bursts[b].event_base = base; }
+      __syncthreads();
+      if (threadIdx.x == 0) s_ebase += (u64)total << 6;
+      __syncthreads(); }
+   if (threadIdx.x == 0) { scratch->nbursts = nb; scratch->queue = 0; *nbursts_out = nb; } }
+
+// ------------------------------------------------------------------------------------------------
+// k_decode
+// ------------------------------------------------------------------------------------------------
+struct Tile {
+   int16_t *x;            // LDS: [ntrks][ldw] raw samples by TRACK (after -invert), index = row - row0 + kHaloRows
+   int      ldw;          // row stride of x
+   long long row0;        // first row of the tile proper
+   int      nrows;        // rows in the tile proper
+   long long reset;       // burst restart row (deskew FIFO restarts there, src/decoder.c:415)
+   unsigned char *bits;   // LDS: [nscreens][3][ntrks][kTileRows/8]   0=top 1=bot 2=rescan ("A-sync")
+   int      ntrks;
+   const int *skew;
+   __device__ inline int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + kHaloRows]; }
+   // v_now of track t at row n in int16 units, with the deskew FIFO exactly as the reference runs it
+   // from the restart row: undelayed until the FIFO has filled (src/decoder.c:825-827), then delayed
+   __device__ inline int y(int t, long long n) const {
+      const int d = skew[t];
+      return xi(t, (n - reset < d) ? n : n - d); }
+   __device__ inline const u64 *map(int screen, int kind, int t) const {
+      return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 3 + kind) * ntrks + t) * (kTileRows / 8)); }
+};
+
+__device__ inline float volt(int i, float maxvolts) {      // src/readtape.c:1420
+   return (float)i / 32767 * maxvolts; }
+
+struct Walker {            // one per (parameter set, track); lives in registers
+   // detector state
+   long long start;        // row at which this track's window is seeded (restart + trknum, src/decoder.c:855-861)
+   long long next;         // next row the detector will look at with the fast path
+   long long blind_until;  // rows <= blind_until are inside pkww_countdown
+   int   minv;             // the (possibly stale) window minimum, int16 units (src/decoder.c:765-775)
+   long long qtrig;        // row at which the sample equal to minv leaves the window (forces a rescan)
+   long long cpos;         // the stale-min state is valid after processing this row
+   int   slow_max, slow_countdown;   // literal state while the window is filling
+   bool  fast;             // window full and in the regular deskew regime: use the screen
+   // AGC / block-decoder mirror
+   float agc_gain, v_avg_height, v_avg_height_sum;
+   int   v_avg_height_count, peakcount, heightndx;
+   float v_top, v_bot, v_lasttop, v_lastbot;
+   // PE preamble tracking
+   bool  datablock, bit1_up;
+   double t_lastpeak;
+   // output
+   unsigned int nevents;
+   unsigned int flags;
+};
+
+struct Ctx {               // per-workgroup constants for the walkers
+   const DevCfg *cfg;
+   Tile tile;
+   long long row_base;     // absolute row of d_rows[0]
+   float *heights;         // LDS [walkers][10]
+   rtfe_event *events;     // this burst's regions
+   unsigned int cap;
+};
+
+__device__ inline double time_of(const DevCfg *c, long long abs_row) {     // src/readtape.c:1423
+   return (double)(c->tstart_ns + abs_row * c->tdelta_ns) / 1e9; }
+
+__device__ inline void adjust_agc(Walker &w, const DevParm &P, float *heights) {    // src/decoder.c:500-531
+   float gain, lastheight;
+   if (P.agc_alpha) {
+      lastheight = w.v_lasttop - w.v_lastbot;
+      if (lastheight > 0) {
+         gain = w.v_avg_height / lastheight;
+         gain = P.agc_alpha * gain + (1 - P.agc_alpha) * w.agc_gain;
+         if (gain > 2.0f) gain = 2.0f;
+         w.agc_gain = gain; } }
+   if (P.agc_window) {
+      lastheight = w.v_lasttop - w.v_lastbot;
+      if (lastheight > 0) {
+         heights[w.heightndx] = lastheight;
+         if (++w.heightndx >= P.agc_window) w.heightndx = 0;
+         float minheight = 99;
+         for (int i = 0; i < P.agc_window; ++i) if (heights[i] < minheight) minheight = heights[i];
+         gain = w.v_avg_height / minheight;
+         if (gain > 2.0f) gain = 2.0f;
+         w.agc_gain = gain; } } }
+
+// what the block decoder's callback does to the state the detector reads back, then the
+// post-callback bookkeeping of process_up/down_transition (src/decoder.c:587-590, 605-609)
+__device__ inline void agc_after_peak(Walker &w, const DevCfg *cfg, const DevParm &P, float *heights, bool is_top, double t_peak) {
+   ++w.peakcount;                                               // src/decoder.c:561
+   if (cfg->mode == RTFE_PE) {
+      if (w.datablock) adjust_agc(w, P, heights);               // src/decode_pe.c:175,198
+      else {                                                    // pe_preamble_peak, src/decode_pe.c:127-155
+         if (w.peakcount == 1) w.bit1_up = !is_top;
+         if (w.peakcount > 70 && w.bit1_up == is_top && t_peak - w.t_lastpeak > P.t_clkwindow) {
+            w.datablock = true;
+            w.v_avg_height = w.v_avg_height_sum / w.v_avg_height_count; }
+         else if (w.peakcount >= 5 && w.peakcount <= 15 && w.v_top > w.v_bot) {
+            w.v_avg_height_sum += w.v_top - w.v_bot;
+            ++w.v_avg_height_count;
+            heights[w.heightndx] = w.v_top - w.v_bot;
+            if (++w.heightndx >= P.agc_window) w.heightndx = 0; } } }
+   else if (cfg->mode == RTFE_WW) adjust_agc(w, P, heights);      // src/decode_ww.c:171,190
+   else {                                                       // NRZI and GCR share the schedule
+      if (is_top) {                                             // src/decode_nrzi.c:218-229, src/decode_gcr.c:853-864
+         if (w.peakcount >= 5 && w.peakcount <= 15) {
+            w.v_avg_height_sum += w.v_top - w.v_bot;
+            ++w.v_avg_height_count;
+            heights[w.heightndx] = w.v_top - w.v_bot;
+            if (++w.heightndx >= P.agc_window) w.heightndx = 0; }
+         else if (w.peakcount > 15) {
+            if (w.v_avg_height_count) {
+               w.v_avg_height = w.v_avg_height_sum / w.v_avg_height_count;
+               w.v_avg_height_count = 0; }
+            else adjust_agc(w, P, heights); } }
+      else if (w.peakcount > 15 && w.v_avg_height_count == 0) adjust_agc(w, P, heights); }   // src/decode_nrzi.c:196-197
+   if (is_top) w.v_lasttop = w.v_top; else w.v_lastbot = w.v_bot;
+   w.t_lastpeak = t_peak; }
+
+// refine_peak (src/decoder.c:700-749) + event emission + AGC mirror.  `lo` = first row of the window,
+// `p` = row of the first window element equal to the extreme.
+__device__ inline void emit_peak(Walker &w, const Ctx &cx, int pidx, int trk, const DevParm &P, long long n,
+                                 long long lo, long long p, int val_i, bool is_top) {
+   const DevCfg *cfg = cx.cfg;
+   const float val = volt(val_i, cfg->maxvolts);
+   const int left_distance = (int)(p - lo) + 1;
+   const float vprev = volt(cx.tile.y(trk, p - 1), cfg->maxvolts);
+   const float vnext = volt(cx.tile.y(trk, p + 1), cfg->maxvolts);
+   float adj = 0; int adjcode = 0;
+   if (is_top) {
+      const float val_minus = val - 0.005f / w.agc_gain;
+      if (vprev > val_minus && vnext < val_minus) { adj = -0.5f; adjcode = 1; }
+      else if (vnext > val_minus && vprev < val_minus) { adj = +0.5f; adjcode = 2; } }
+   else {
+      const float val_plus = val + 0.005f / w.agc_gain;
+      if (vprev < val_plus && vnext > val_plus) { adj = -0.5f; adjcode = 1; }
+      else if (vnext < val_plus && vprev > val_plus) { adj = +0.5f; adjcode = 2; } }
+   double t_peak = 0;
+   if (cfg->mode == RTFE_PE)
+      t_peak = time_of(cfg, cx.row_base + n) - ((float)(P.W - left_distance) - adj) * cfg->sample_deltat;
+   if (is_top) w.v_top = val; else w.v_bot = val;
+   if (w.nevents < cx.cap) {
+      rtfe_event e;
+      e.sample = (uint32_t)(n - cx.tile.reset);
+      e.v_peak = val;
+      e.agc_gain = w.agc_gain;
+      e.trk = (uint8_t)trk;
+      e.flags = (uint8_t)((is_top ? 0 : 1) | (adjcode << 1));
+      e.left_distance = (uint8_t)left_distance;
+      e.parmset = (uint8_t)pidx;
+      cx.events[(size_t)(pidx * cfg->ntrks + trk) * cx.cap + w.nevents] = e; }
+   else w.flags |= RTFE_F_EVENT_OVERFLOW;
+   ++w.nevents;
+   agc_after_peak(w, cfg, P, cx.heights, is_top, t_peak);
+   w.blind_until = n + left_distance; }                          // pkww_countdown = left_distance (src/decoder.c:741)
+
+__device__ inline void thresholds(const Walker &w, const DevParm &P, float &rise, float &reqmin, unsigned int &flags) {
+   rise = P.rise * (w.v_avg_height / 4.0f) / w.agc_gain;         // src/decoder.c:785-786
+   reqmin = P.min_peak * (w.v_avg_height / 4.0f) / w.agc_gain;
+   if (rise < P.screen_rise_v || (P.min_peak != 0 && reqmin < P.screen_minpk_v)) flags |= RTFE_F_SCREEN_UNDERFLOW; }
+
+// exact window minimum and its first position (the rescan of src/decoder.c:767-775)
+__device__ inline void rescan_min(const Tile &tl, int trk, long long lo, long long hi, int &mn, long long &pos) {
+   mn = 0x7fffffff; pos = lo;
+   for (long long j = lo; j <= hi; ++j) { const int v = tl.y(trk, j); if (v < mn) { mn = v; pos = j; } } }
+
+// bring the stale-minimum state forward to "after row n" using the rescan bitmap of this tile
+__device__ inline void advance_chain(Walker &w, const Tile &tl, int screen, int trk, int W, long long n) {
+   if (n <= w.cpos) return;
+   // last forced rescan (window maximum leaves the window) in (cpos, n]
+   const u64 *am = tl.map(screen, 2, trk);
+   long long a = -1;
+   {
+      long long lo = w.cpos + 1 - tl.row0, hi = n - tl.row0;       // tile-relative, inclusive
+      if (lo < 0) lo = 0;
+      for (long long wd = hi >> 6; wd >= (lo >> 6) && hi >= 0; --wd) {
+         u64 m = am[wd];
+         if (wd == (hi >> 6) && (hi & 63) != 63) m &= (1ull << ((hi & 63) + 1)) - 1;
+         if (wd == (lo >> 6)) m &= ~0ull << (lo & 63);
+         if (m) { a = tl.row0 + wd * 64 + (63 - __clzll((long long)m)); break; } } }
+   if (a >= 0) {
+      long long pos;
+      rescan_min(tl, trk, a - W + 1, a, w.minv, pos);
+      w.cpos = a; w.qtrig = pos + W; }
+   while (w.qtrig <= n) {                                         // the stale minimum itself leaves the window
+      const long long t = w.qtrig;
+      long long pos;
+      rescan_min(tl, trk, t - W + 1, t, w.minv, pos);
+      w.cpos = t; w.qtrig = pos + W; }
+   w.cpos = n; }
+
+// literal lookfor_peak for one row while the window is still filling or the deskew FIFO is in its
+// start-up regime (src/decoder.c:751-810 with the state of src/decoder.c:855-861).
+__device__ inline void slow_step(Walker &w, const Ctx &cx, int pidx, int trk, const DevParm &P, long long n) {
+   const Tile &tl = cx.tile;
+   const DevCfg *cfg = cx.cfg;
+   const int W = P.W;
+   if (n == w.start) {                                            // seed the window, src/decoder.c:855-861
+      const int v = tl.y(trk, n);
+      w.slow_max = v; w.minv = v; w.slow_countdown = 0;
+      w.t_lastpeak = time_of(cfg, cx.row_base + n);
+      return; }
+   const long long nin = n - w.start + 1;                         // rows seen including this one
+   const bool popped = nin > W;
+   const long long lo = popped ? n - W + 1 : w.start;
+   const int vnow = tl.y(trk, n);
+   const int old_left = popped ? tl.y(trk, n - W) : 0;            // "float old_left = 0" when nothing is popped
+   if (vnow > w.slow_max) w.slow_max = vnow;
+   if (old_left == w.slow_max || old_left == w.minv) {             // exact == on floats is == on the int16 codes
+      int mx = -0x7fffffff, mn = 0x7fffffff;
+      for (long long j = lo; j <= n; ++j) { const int v = tl.y(trk, j); mx = max(mx, v); mn = min(mn, v); }
+      w.slow_max = mx; w.minv = mn; }
+   if (w.slow_countdown) { --w.slow_countdown; return; }
+   float rise, reqmin;
+   thresholds(w, P, rise, reqmin, w.flags);
+   const float mv = cfg->maxvolts;
+   const float vl = volt(tl.y(trk, lo), mv), vr = volt(vnow, mv);
+   const float vmax = volt(w.slow_max, mv), vmin = volt(w.minv, mv);
+   bool top = vmax > vl + rise && vmax > vr + rise && (reqmin == 0 || vmax > reqmin);
+   bool bot = !top && vmin < vl - rise && vmin < vr - rise && (reqmin == 0 || vmin < -reqmin);
+   if (top || bot) {
+      const int val = top ? w.slow_max : w.minv;
+      long long p = lo;
+      while (p <= n && tl.y(trk, p) != val) ++p;
+      if (p > n || p == lo || p == n) { w.flags |= RTFE_F_DETECTOR_FATAL; return; }   // src/decoder.c:709-710,748
+      // refine_peak's time formula and countdown use W even when the window is not full
+      emit_peak(w, cx, pidx, trk, P, n, lo, p, val, top);
+      w.slow_countdown = (int)(p - lo) + 1; } }
+
+// switch from the literal path to the screened path: derive the lazy stale-min state
+__device__ inline void enter_fast(Walker &w, const Tile &tl, int trk, int W, long long n_first_fast) {
+   const long long last = n_first_fast - 1;
+   long long pos = last - W + 1;
+   while (pos <= last && tl.y(trk, pos) != w.minv) ++pos;
+   w.qtrig = pos + W;                                             // (pos <= last always: the stale min is a window element)
+   w.cpos = last;
+   w.blind_until = last + w.slow_countdown;
+   w.next = n_first_fast;
+   w.fast = true; }
+
+// one (parameter set, track) detector over rows [.., limit)
+__device__ void walk(Walker &w, const Ctx &cx, int pidx, int trk, long long limit) {
+   const DevCfg *cfg = cx.cfg;
+   const DevParm &P = cfg->parm[pidx];
+   const Tile &tl = cx.tile;
+   const int W = P.W;
+   const long long tile_end = tl.row0 + tl.nrows;
+   if (limit > tile_end) limit = tile_end;
+   // ---- literal start-up path ----
+   if (!w.fast) {
+      const long long fast_from = tl.reset + W + max(trk, cfg->skew[trk]) + 1;
+      while (w.next < limit && w.next < fast_from) { if (w.next >= w.start) slow_step(w, cx, pidx, trk, P, w.next); ++w.next; }
+      if (w.next < fast_from) return;
+      enter_fast(w, tl, trk, W, w.next); }
+   // ---- screened path ----
+   const u64 *tm = tl.map(P.screen, 0, trk), *bm = tl.map(P.screen, 1, trk);
+   const float mv = cfg->maxvolts;
+   long long n = max(w.next, w.blind_until + 1);
+   while (n < limit) {
+      // next candidate bit at or after n
+      long long rel = n - tl.row0;
+      int wd = (int)(rel >> 6);
+      u64 m = (tm[wd] | bm[wd]) & (~0ull << (rel & 63));
+      const int nwords = (tl.nrows + 63) >> 6;
+      while (!m && ++wd < nwords) m = tm[wd] | bm[wd];
+      if (!m) { n = limit; break; }
+      n = tl.row0 + (long long)wd * 64 + (__ffsll((long long)m) - 1);
+      if (n >= limit) break;
+      const bool ctop = (tm[wd] >> ((n - tl.row0) & 63)) & 1, cbot = (bm[wd] >> ((n - tl.row0) & 63)) & 1;
+      const long long lo = n - W + 1;
+      float rise, reqmin;
+      thresholds(w, P, rise, reqmin, w.flags);
+      const float vl = volt(tl.y(trk, lo), mv), vr = volt(tl.y(trk, n), mv);
+      bool hit = false;
+      if (ctop) {
+         int mx = -0x7fffffff; long long p = lo;
+         for (long long j = lo; j <= n; ++j) { const int v = tl.y(trk, j); if (v > mx) { mx = v; p = j; } }
+         const float vmax = volt(mx, mv);
+         if (vmax > vl + rise && vmax > vr + rise && (reqmin == 0 || vmax > reqmin)) {
+            emit_peak(w, cx, pidx, trk, P, n, lo, p, mx, true);
+            hit = true; } }
+      if (!hit && cbot) {
+         advance_chain(w, tl, P.screen, trk, W, n);
+         const float vmin = volt(w.minv, mv);
+         if (vmin < vl - rise && vmin < vr - rise && (reqmin == 0 || vmin < -reqmin)) {
+            long long p = lo;
+            while (p <= n && tl.y(trk, p) != w.minv) ++p;
+            if (p > n || p == lo || p == n) w.flags |= RTFE_F_DETECTOR_FATAL;
+            else { emit_peak(w, cx, pidx, trk, P, n, lo, p, w.minv, false); hit = true; } } }
+      n = hit ? w.blind_until + 1 : n + 1; }
+   w.next = n < limit ? n : limit;
+   // keep the stale-min state inside the LDS window: bring it to the last row this tile can serve
+   if (limit - 1 > w.cpos) advance_chain(w, tl, P.screen, trk, W, limit - 1); }
+
+// ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
+// window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
+__device__ inline void screen_strip(const Tile &tl, const DevScreen &sc, int screen, int trk, int strip) {
+   const int W = sc.W;
+   const int d = tl.skew[trk];
+   const int16_t *base = tl.x + trk * tl.ldw + kHaloRows - d;     // y(n) = base[n - row0] in the regular regime
+   const int s0 = strip * kStrip;
+   int v[kStrip], L[kStrip];
+   #pragma unroll
+   for (int i = 0; i < kStrip; ++i) { v[i] = base[s0 + i]; L[i] = base[s0 + i - W + 1]; }
+   int topb = 0, botb = 0, resb = 0;
+   if (W > kStrip) {
+      int smx[kStrip], smn[kStrip];
+      int amx = -0x7fffffff, amn = 0x7fffffff;
+      for (int j = s0 - 1; j > s0 - W + kStrip; --j) { const int u = base[j]; amx = max(amx, u); amn = min(amn, u); }
+      #pragma unroll
+      for (int i = kStrip - 1; i >= 0; --i) { const int u = L[i]; amx = max(amx, u); amn = min(amn, u); smx[i] = amx; smn[i] = amn; }
+      int pmx = -0x7fffffff, pmn = 0x7fffffff;
+      #pragma unroll
+      for (int i = 0; i < kStrip; ++i) {
+         pmx = max(pmx, v[i]); pmn = min(pmn, v[i]);
+         const int mx = max(smx[i], pmx), mn = min(smn[i], pmn);
+         const int popped = base[s0 + i - W];
+         const bool t = (mx - L[i] > sc.rise_i) && (mx - v[i] > sc.rise_i) && (sc.minpk_i < 0 || mx > sc.minpk_i);
+         const bool b = (L[i] - mn > sc.rise_i) && (v[i] - mn > sc.rise_i) && (sc.minpk_i < 0 || mn < -sc.minpk_i);
+         topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i; } }
+   else {
+      #pragma unroll
+      for (int i = 0; i < kStrip; ++i) {
+         int mx = -0x7fffffff, mn = 0x7fffffff;
+         for (int j = s0 + i - W + 1; j <= s0 + i; ++j) { const int u = base[j]; mx = max(mx, u); mn = min(mn, u); }
+         const int popped = base[s0 + i - W];
+         const bool t = (mx - L[i] > sc.rise_i) && (mx - v[i] > sc.rise_i) && (sc.minpk_i < 0 || mx > sc.minpk_i);
+         const bool b = (L[i] - mn > sc.rise_i) && (v[i] - mn > sc.rise_i) && (sc.minpk_i < 0 || mn < -sc.minpk_i);
+         topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i; } }
+   unsigned char *o = tl.bits + ((size_t)(screen * 3) * tl.ntrks + trk) * (kTileRows / 8) + strip;
+   o[0] = (unsigned char)topb;
+   o[(size_t)tl.ntrks * (kTileRows / 8)] = (unsigned char)botb;
+   o[(size_t)2 * tl.ntrks * (kTileRows / 8)] = (unsigned char)resb; }
+
+// cooperative tile load: rows [row0 - kHaloRows, row0 + nrows) of the AoS payload -> SoA LDS by track
+__device__ inline void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows) {
+   const int ntrks = cfg->ntrks;
+   const long long first = tl.row0 - kHaloRows;                   // multiple of 8 rows => 16-byte aligned
+   const int nload = kHaloRows + tl.nrows;
+   const int nvec = (nload * ntrks + 7) >> 3;
+   for (int vi = threadIdx.x; vi < nvec; vi += blockDim.x) {
+      const int e0 = vi * 8;
+      int r = e0 / ntrks, c = e0 - r * ntrks;
+      const long long ge = (first + r) * (long long)ntrks + c;    // global element index of e0
+      int16_t s[8];
+      if (first + r >= 0 && ge + 8 <= total_rows * ntrks && ge >= 0) {
+         const int4 q = *reinterpret_cast<const int4 *>(rows + ge);
+         const int qq[4] = {q.x, q.y, q.z, q.w};
+         #pragma unroll
+         for (int j = 0; j < 4; ++j) { s[2 * j] = (int16_t)(qq[j] & 0xffff); s[2 * j + 1] = (int16_t)(qq[j] >> 16); } }
+      else {
+         #pragma unroll
+         for (int j = 0; j < 8; ++j) { const long long g = ge + j; s[j] = (g >= 0 && g < total_rows * ntrks) ? rows[g] : (int16_t)0; } }
+      #pragma unroll
+      for (int j = 0; j < 8; ++j) {
+         if (r < nload) {
+            const int trk = cfg->head_to_trk[c];
+            tl.x[trk * tl.ldw + r] = cfg->invert ? (int16_t)-s[j] : s[j]; }
+         if (++c == ntrks) { c = 0; ++r; } } } }
+
+__device__ inline void run_screens(const DevCfg *cfg, const Tile &tl) {
+   const int nstrips = (tl.nrows + kStrip - 1) / kStrip;
+   const int per_screen = nstrips * cfg->ntrks;
+   for (int s = 0; s < cfg->nscreens; ++s)
+      for (int i = threadIdx.x; i < per_screen; i += blockDim.x)
+         screen_strip(tl, cfg->screen[s], s, i / nstrips, i - (i / nstrips) * nstrips); }
+
+// restart row for the zone whose last kMarginRows rows are the current tile:
+// for every parameter set and track take the last forced rescan inside the zone; any restart at or
+// before (that row - W - max(trk, skew) - 1) has a full, regular window when the rescan happens.
+__device__ inline long long find_reset(const DevCfg *cfg, const Tile &tl, long long *lds_min) {
+   if (threadIdx.x == 0) *lds_min = 0x7fffffffffffffffll;
+   __syncthreads();
+   const int nw = cfg->nparm * cfg->ntrks;
+   for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+      const int p = i / cfg->ntrks, t = i - p * cfg->ntrks;
+      const DevParm &P = cfg->parm[p];
+      const u64 *am = tl.map(P.screen, 2, t);
+      long long a = -1;
+      for (int wd = (tl.nrows - 1) >> 6; wd >= 0; --wd) if (am[wd]) { a = tl.row0 + wd * 64 + (63 - __clzll((long long)am[wd])); break; }
+      long long hi = a < 0 ? -1 : a - P.W - max(t, cfg->skew[t]) - 2;
+      atomicMin((unsigned long long *)lds_min, (unsigned long long)(hi < 0 ? 0 : hi));
+      if (hi < tl.row0) atomicMin((unsigned long long *)lds_min, 0ull); }
+   __syncthreads();
+   const long long r = *lds_min;
+   __syncthreads();
+   return r; }          // 0 => no provably safe restart row inside the margin
+
+__global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows,
+                                                           long long nrows, long long row_base,
+                                                           rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
+                                                           uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
+                                                           uint32_t parmset_mask, int screen_off, int single_exact) {
+#ifdef RTFE_CPU_EMUL
+   unsigned char *smem = g_dyn_smem;            // tests/cpu_emul only
+#else
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
+   __shared__ DevCfg cfg;
+   __shared__ int s_burst;
+   __shared__ long long s_min;
+   __shared__ unsigned int s_flags;
+   for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
+   __syncthreads();
+   if (screen_off && threadIdx.x == 0)
+      for (int s = 0; s < cfg.nscreens; ++s) { cfg.screen[s].rise_i = -70000; cfg.screen[s].minpk_i = -1; }
+   if (screen_off) for (int i = threadIdx.x; i < cfg.nparm; i += blockDim.x) { cfg.parm[i].screen_rise_v = -1; cfg.parm[i].screen_minpk_v = -1; }
+   __syncthreads();
+   const int ntrks = cfg.ntrks;
+   const int ldw = kHaloRows + kTileRows + 8;
+   Ctx cx;
+   cx.cfg = &cfg;
+   cx.row_base = row_base;
+   cx.tile.x = reinterpret_cast<int16_t *>(smem);
+   cx.tile.ldw = ldw;
+   cx.tile.ntrks = ntrks;
+   cx.tile.skew = cfg.skew;
+   size_t off = ((size_t)ntrks * ldw * 2 + 15) & ~(size_t)15;
+   cx.tile.bits = smem + off;
+   off += (size_t)cfg.nscreens * 3 * ntrks * (kTileRows / 8);
+   off = (off + 15) & ~(size_t)15;
+   float *heights_all = reinterpret_cast<float *>(smem + off);
+   // walker w of this workgroup -> thread: spread over the 4 waves so every SIMD issues for some walkers
+   const int nwalk = cfg.nparm * ntrks;
+   const int my_w = (threadIdx.x & 63) * 4 + (threadIdx.x >> 6);
+   const bool is_walker = my_w < nwalk;
+   const int pidx = is_walker ? my_w / ntrks : 0, trk = is_walker ? my_w - pidx * ntrks : 0;
+   const bool active = is_walker && ((parmset_mask >> pidx) & 1);
+   cx.heights = heights_all + (size_t)(is_walker ? my_w : 0) * 10;
+
+   for (;;) {
+      if (threadIdx.x == 0) { s_burst = atomicAdd(&scratch->queue, 1); s_flags = 0; }
+      __syncthreads();
+      const int b = s_burst;
+      const int nb = scratch->nbursts;
+      if (b >= nb) break;
+      rtfe_burst B = bursts[b];
+      const bool exact = B.flags & RTFE_F_EXACT_START;
+      const bool last = b + 1 >= nb;
+      const bool has_tail = !last && !single_exact;
+      const long long next_zone_end = last ? nrows : bursts[b + 1].zone_end;
+      cx.events = events + B.event_base;
+      cx.cap = B.event_cap;
+      // ---- head: find this burst's restart row ----
+      long long reset = B.reset_sample, t0;
+      unsigned int bflags = B.flags;
+      if (!exact) {
+         cx.tile.row0 = B.zone_end - kMarginRows; cx.tile.nrows = kMarginRows; cx.tile.reset = -(1ll << 40);
+         if (B.zone_end - B.zone_first < kMarginRows + 64) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; }
+         load_tile(&cfg, cx.tile, rows, nrows);
+         __syncthreads();
+         run_screens(&cfg, cx.tile);
+         __syncthreads();
+         if (!(bflags & RTFE_F_UNSAFE)) {
+            reset = find_reset(&cfg, cx.tile, &s_min);
+            if (reset <= 0 || reset < B.zone_first) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; } }
+         t0 = B.zone_end - kMarginRows; }
+      else t0 = reset & ~7ll;
+      // ---- walker init: init_trackstate + init_trackpeak_state (src/decoder.c:413-455) ----
+      Walker w = {};
+      w.start = reset + trk; w.next = reset; w.blind_until = -1; w.fast = false;
+      w.agc_gain = 1.0f; w.v_avg_height = 4.0f;
+      if (is_walker) for (int i = 0; i < 10; ++i) cx.heights[i] = 0;
+      cx.tile.reset = reset;
+      // ---- tiles ----
+      const long long hard_end = single_exact ? (B.end_sample < nrows ? B.end_sample : nrows) : nrows;
+      long long tile0 = t0;
+      bool first_tile = !exact;                        // the head tile is already loaded and screened
+      long long stop = hard_end;                       // rows >= stop belong to the next burst
+      bool done = false;
+      while (!done) {
+         long long tn;
+         bool is_tail = false;
+         if (first_tile) tn = kMarginRows;
+         else {
+            const long long normal_end = has_tail ? next_zone_end - kMarginRows : hard_end;
+            if (tile0 >= normal_end && has_tail) { is_tail = true; tn = kMarginRows; }
+            else { tn = normal_end - tile0; if (tn > kTileRows) tn = kTileRows; } }
+         if (tn <= 0) break;
+         if (!first_tile) {
+            cx.tile.row0 = tile0; cx.tile.nrows = (int)tn;
+            __syncthreads();
+            load_tile(&cfg, cx.tile, rows, nrows);
+            __syncthreads();
+            run_screens(&cfg, cx.tile);
+            __syncthreads();
+            if (is_tail) {
+               // the next burst restarts inside this tile; compute exactly what its own workgroup computes
+               const rtfe_burst NB = bursts[b + 1];
+               long long nr = -1;
+               if (NB.zone_end - NB.zone_first >= kMarginRows + 64) {
+                  const long long saved = cx.tile.reset;
+                  cx.tile.reset = -(1ll << 40);
+                  nr = find_reset(&cfg, cx.tile, &s_min);
+                  cx.tile.reset = saved; }
+               if (nr <= 0 || nr < NB.zone_first) nr = NB.zone_end - kMarginRows;
+               stop = nr; } }
+         if (active) walk(w, cx, pidx, trk, stop);
+         first_tile = false;
+         tile0 += tn;
+         if (is_tail || tile0 >= hard_end) done = true; }
+      // ---- publish ----
+      if (is_walker) {
+         counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = active ? (w.nevents < cx.cap ? w.nevents : cx.cap) : 0;
+         if (w.flags) atomicOr(&s_flags, w.flags); }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+         bursts[b].reset_sample = reset;
+         bursts[b].safe_last = (bflags & (RTFE_F_UNSAFE)) ? -1 : reset;
+         bursts[b].end_sample = stop < hard_end ? stop : hard_end;
+         bursts[b].flags = bflags | s_flags; }
+      __syncthreads(); } }
+
+}  // namespace rtfe

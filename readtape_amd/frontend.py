@@ -1,0 +1,289 @@
+"""Python binding of the C ABI in include/rt_frontend.h (librtfe.so, the HIP front end).
+
+Host-side mirror of the reference's front-end seam: `FrontEnd.scan()` is what `readblock()` /
+`process_sample()` (src/readtape.c:1396, src/decoder.c:817) do for a whole tape at once, and the
+returned events are the `{mode}_top/_bot` calls they would make (src/decoder.c:574-609).
+
+PyTorch is used only for device memory and streams.  There is no CPU path: if librtfe.so is missing
+or no GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import tbin
+
+MAXTRKS, MAXPARMSETS = 19, 15
+PE, NRZI, GCR, WW = 1, 2, 4, 8
+
+F_EXACT_START, F_UNSAFE, F_EVENT_OVERFLOW, F_SCREEN_UNDERFLOW, F_DETECTOR_FATAL = 1, 2, 4, 8, 16
+
+EVENT_DTYPE = np.dtype([("sample", "<u4"), ("v_peak", "<f4"), ("agc_gain", "<f4"), ("trk", "u1"),
+                        ("flags", "u1"), ("left_distance", "u1"), ("parmset", "u1")])
+BURST_DTYPE = np.dtype([("zone_first", "<i8"), ("zone_end", "<i8"), ("reset_sample", "<i8"), ("safe_last", "<i8"),
+                        ("end_sample", "<i8"), ("event_base", "<u8"), ("event_cap", "<u4"), ("flags", "<u4")])
+assert EVENT_DTYPE.itemsize == 16 and BURST_DTYPE.itemsize == 56 or BURST_DTYPE.itemsize == 64
+
+
+class _Parmset(C.Structure):
+    _fields_ = [("pkww_bitfrac", C.c_float), ("pkww_rise", C.c_float), ("min_peak", C.c_float),
+                ("agc_alpha", C.c_float), ("agc_window", C.c_int32), ("clk_factor", C.c_float)]
+
+
+class _Config(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("ntrks", C.c_int32), ("head_to_trk", C.c_int32 * MAXTRKS),
+                ("invert", C.c_int32), ("differentiate", C.c_int32), ("find_zeros", C.c_int32),
+                ("skew_delaycnt", C.c_int32 * MAXTRKS), ("maxvolts", C.c_float), ("bpi", C.c_float), ("ips", C.c_float),
+                ("tdelta_ns", C.c_int64), ("tstart_ns", C.c_int64), ("nparmsets", C.c_int32),
+                ("parmset", _Parmset * MAXPARMSETS), ("gap_min_samples", C.c_int32), ("quiet_volts", C.c_float),
+                ("screen_floor_height", C.c_float), ("events_per_sample_cap", C.c_float)]
+
+
+class _Burst(C.Structure):
+    _fields_ = [("zone_first", C.c_int64), ("zone_end", C.c_int64), ("reset_sample", C.c_int64), ("safe_last", C.c_int64),
+                ("end_sample", C.c_int64), ("event_base", C.c_uint64), ("event_cap", C.c_uint32), ("flags", C.c_uint32)]
+
+
+assert C.sizeof(_Burst) == BURST_DTYPE.itemsize, (C.sizeof(_Burst), BURST_DTYPE.itemsize)
+
+# Built-in parameter sets: the front-end half of src/parmsets.c:77-118
+#                 bitfrac rise  min_peak agc_alpha agc_window clk_factor
+DEFAULT_PARMSETS = {
+    NRZI: [(0.7, 0.20, 1.0, 0.3, 0, 0.0), (0.6, 0.20, 1.0, 0.3, 0, 0.0), (0.7, 0.20, 1.0, 0.3, 0, 0.0), (0.6, 0.20, 1.0, 0.3, 0, 0.0),
+           (0.9, 0.05, 0.5, 0.0, 1, 0.0), (0.7, 0.05, 1.0, 0.0, 1, 0.0), (0.7, 0.05, 0.5, 0.0, 1, 0.0), (0.6, 0.05, 0.5, 0.0, 1, 0.0)],
+    PE: [(0.7, 0.10, 0.0, 0.0, 5, 1.5), (0.7, 0.10, 0.1, 0.0, 5, 1.5), (0.7, 0.10, 0.0, 0.0, 5, 1.4), (0.7, 0.10, 0.0, 0.0, 5, 1.4),
+         (0.7, 0.10, 0.0, 0.0, 5, 1.4), (0.7, 0.10, 0.0, 0.0, 5, 1.5), (0.7, 0.10, 0.0, 0.0, 5, 1.4), (0.7, 0.10, 0.0, 0.0, 5, 1.4)],
+    GCR: [(1.5, 0.20, 0.2, 0.5, 0, 0.0), (1.5, 0.20, 0.2, 0.5, 0, 0.0), (1.5, 0.20, 0.2, 0.5, 0, 0.0), (1.5, 0.14, 0.0, 0.5, 0, 0.0),
+          (1.5, 0.20, 0.2, 0.5, 0, 0.0)],
+}
+
+
+@dataclass
+class FrontEndConfig:
+    mode: int
+    ntrks: int
+    maxvolts: float
+    bpi: float
+    ips: float
+    tdelta_ns: int
+    tstart_ns: int = 0
+    parmsets: list = field(default_factory=list)      # tuples (bitfrac, rise, min_peak, agc_alpha, agc_window, clk_factor)
+    head_to_trk: list | None = None
+    skew: list | None = None
+    invert: bool = False
+    differentiate: bool = False
+    find_zeros: bool = False
+    gap_min_samples: int = 0
+    quiet_volts: float = 0.0
+    screen_floor_height: float = 0.0
+    events_per_sample_cap: float = 0.0
+
+    @classmethod
+    def from_header(cls, h: tbin.TbinHeader, nparmsets: int = 1, **kw) -> "FrontEndConfig":
+        mode = kw.pop("mode", h.mode)
+        bpi = kw.pop("bpi", 9042.0 if mode == GCR else h.bpi)     # src/readtape.c:1652-1654
+        ps = kw.pop("parmsets", None) or DEFAULT_PARMSETS[mode][:nparmsets]
+        return cls(mode=mode, ntrks=h.ntrks, maxvolts=h.maxvolts, bpi=bpi, ips=h.ips or 50.0,
+                   tdelta_ns=h.tdelta_ns, tstart_ns=h.tstart_ns, parmsets=list(ps), **kw)
+
+    def to_c(self) -> _Config:
+        c = _Config()
+        c.mode, c.ntrks = self.mode, self.ntrks
+        h2t = self.head_to_trk or list(range(self.ntrks))
+        sk = self.skew or [0] * self.ntrks
+        for i in range(self.ntrks):
+            c.head_to_trk[i] = h2t[i]
+            c.skew_delaycnt[i] = sk[i]
+        c.invert, c.differentiate, c.find_zeros = int(self.invert), int(self.differentiate), int(self.find_zeros)
+        c.maxvolts, c.bpi, c.ips = self.maxvolts, self.bpi, self.ips
+        c.tdelta_ns, c.tstart_ns = self.tdelta_ns, self.tstart_ns
+        c.nparmsets = len(self.parmsets)
+        for i, p in enumerate(self.parmsets):
+            c.parmset[i] = _Parmset(*[float(x) if j != 4 else int(x) for j, x in enumerate(p)])
+        c.gap_min_samples = self.gap_min_samples
+        c.quiet_volts, c.screen_floor_height = self.quiet_volts, self.screen_floor_height
+        c.events_per_sample_cap = self.events_per_sample_cap
+        return c
+
+
+class TorchBackend:
+    """Device memory through PyTorch-ROCm (plumbing only)."""
+
+    def __init__(self, device="cuda:0"):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("readtape_amd.frontend needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.torch = torch
+        self.device = torch.device(device)
+
+    def empty(self, nbytes):
+        return self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+
+    def ptr(self, t):
+        return t.data_ptr()
+
+    def rows(self, rows):
+        t = rows
+        if isinstance(rows, np.ndarray):
+            t = self.torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int16)).to(self.device, non_blocking=True)
+        assert t.dtype == self.torch.int16 and t.is_contiguous() and t.is_cuda
+        return t
+
+    def to_numpy(self, t, dtype, count=None):
+        a = t.cpu().numpy().view(dtype)
+        return a if count is None else a[:count]
+
+    def stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+def _load_library(path=None):
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtfe.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                           "The front end has no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.rtfe_last_error.restype = C.c_char_p
+    lib.rtfe_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+    lib.rtfe_destroy.argtypes = [C.c_void_p]
+    lib.rtfe_pkww_width.argtypes = [C.c_void_p, C.c_int]
+    lib.rtfe_workspace_bytes.argtypes = [C.c_void_p, C.c_int64]; lib.rtfe_workspace_bytes.restype = C.c_size_t
+    lib.rtfe_max_bursts.argtypes = [C.c_void_p, C.c_int64]; lib.rtfe_max_bursts.restype = C.c_int64
+    lib.rtfe_event_capacity.argtypes = [C.c_void_p, C.c_int64]; lib.rtfe_event_capacity.restype = C.c_int64
+    lib.rtfe_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
+                              C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.rtfe_scan_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int,
+                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.rtfe_kernel_name.restype = C.c_char_p
+    if lib.rtfe_abi_version() != 1:
+        raise RuntimeError("librtfe.so ABI mismatch")
+    return lib
+
+
+class ScanResult:
+    """Device-resident output of one scan; `fetch()` copies the small tables and the used part of
+    the event regions to the host."""
+
+    def __init__(self, fe, bufs, max_bursts, single=False):
+        self.fe, self.bufs, self.max_bursts, self.single = fe, bufs, max_bursts, single
+        self.bursts = self.counts = self._events = None
+
+    def fetch(self):
+        fe, be = self.fe, self.fe.backend
+        be.sync()
+        nb = 1 if self.single else int(be.to_numpy(self.bufs["nbursts"], np.int32)[0])
+        self.bursts = be.to_numpy(self.bufs["bursts"], BURST_DTYPE)[:nb].copy()
+        P, T = len(fe.cfg.parmsets), fe.cfg.ntrks
+        self.counts = be.to_numpy(self.bufs["counts"], np.uint32)[: nb * P * T].reshape(nb, P, T).copy()
+        self._events = be.to_numpy(self.bufs["events"], EVENT_DTYPE)
+        return self
+
+    @property
+    def nbursts(self):
+        return len(self.bursts)
+
+    def track_events(self, b, p, t):
+        B = self.bursts[b]
+        base = int(B["event_base"]) + (p * self.fe.cfg.ntrks + t) * int(B["event_cap"])
+        return self._events[base: base + int(self.counts[b, p, t])]
+
+    def events(self, b, p):
+        """All tracks of (burst b, parmset p) merged in the order the reference's per-sample loop
+        produces them: by detection sample, then track number (src/decoder.c:847)."""
+        parts = [self.track_events(b, p, t) for t in range(self.fe.cfg.ntrks)]
+        ev = np.concatenate(parts) if parts else np.zeros(0, EVENT_DTYPE)
+        order = np.lexsort((ev["trk"], ev["sample"]))
+        return ev[order]
+
+
+class FrontEnd:
+    def __init__(self, cfg: FrontEndConfig, device="cuda:0", _lib_path=None, _backend=None):
+        """_lib_path / _backend are hooks for tests/cpu_emul only; the product uses librtfe.so + a GPU."""
+        self.cfg = cfg
+        self.lib = _load_library(_lib_path)
+        self.backend = _backend or TorchBackend(device)
+        self._c = cfg.to_c()
+        h = C.c_void_p()
+        rc = self.lib.rtfe_create(C.byref(self._c), C.byref(h))
+        if rc != 0:
+            raise ValueError(f"rtfe_create failed ({rc}): {self.lib.rtfe_last_error().decode()}")
+        self.h = h
+        self.widths = [self.lib.rtfe_pkww_width(self.h, p) for p in range(len(cfg.parmsets))]
+        self._cache = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rtfe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def kernel_names(self):
+        return [self.lib.rtfe_kernel_name(i).decode() for i in range(self.lib.rtfe_kernel_count())]
+
+    def _buffers(self, nrows, key="scan"):
+        """Allocates (once per size) the workspace and output buffers for a scan of nrows rows."""
+        k = (key, nrows)
+        if k not in self._cache:
+            be, lib = self.backend, self.lib
+            mb = int(lib.rtfe_max_bursts(self.h, nrows))
+            cap = int(lib.rtfe_event_capacity(self.h, nrows))
+            P, T = len(self.cfg.parmsets), self.cfg.ntrks
+            self._cache[k] = dict(
+                ws=be.empty(lib.rtfe_workspace_bytes(self.h, nrows)), bursts=be.empty(mb * BURST_DTYPE.itemsize),
+                nbursts=be.empty(16), counts=be.empty(mb * P * T * 4), events=be.empty(cap * 16), max_bursts=mb, cap=cap)
+        return self._cache[k]
+
+    def scan(self, rows, row_base=0, first_is_tape_start=True, stream=None) -> ScanResult:
+        """Launches the speculative scan of `rows` ([n, ntrks] int16, device tensor or numpy) — asynchronous."""
+        be = self.backend
+        d_rows = be.rows(rows)
+        nrows = int(d_rows.shape[0])
+        b = self._buffers(nrows)
+        rc = self.lib.rtfe_scan(self.h, be.ptr(d_rows), nrows, row_base, int(first_is_tape_start),
+                                be.ptr(b["ws"]), b["ws"].numel() if hasattr(b["ws"], "numel") else b["ws"].size,
+                                be.ptr(b["bursts"]), b["max_bursts"], be.ptr(b["nbursts"]), be.ptr(b["counts"]),
+                                be.ptr(b["events"]), b["cap"], stream if stream is not None else be.stream())
+        if rc != 0:
+            raise RuntimeError(f"rtfe_scan failed ({rc}): {self.lib.rtfe_last_error().decode()}")
+        r = ScanResult(self, b, b["max_bursts"])
+        r._rows_keepalive = d_rows
+        return r
+
+    def scan_exact(self, rows, reset_row, end_row, parmset_mask=0xFFFFFFFF, screen_off=False, row_base=0, stream=None) -> ScanResult:
+        be = self.backend
+        d_rows = be.rows(rows)
+        nrows = int(d_rows.shape[0])
+        b = self._buffers(max(int(end_row - reset_row), 1), key="exact")
+        rc = self.lib.rtfe_scan_exact(self.h, be.ptr(d_rows), nrows, row_base, int(reset_row), int(end_row), parmset_mask, int(screen_off),
+                                      be.ptr(b["ws"]), b["ws"].numel() if hasattr(b["ws"], "numel") else b["ws"].size,
+                                      be.ptr(b["bursts"]), be.ptr(b["counts"]), be.ptr(b["events"]), b["cap"],
+                                      stream if stream is not None else be.stream())
+        if rc != 0:
+            raise RuntimeError(f"rtfe_scan_exact failed ({rc}): {self.lib.rtfe_last_error().decode()}")
+        r = ScanResult(self, b, 1, single=True)
+        r._rows_keepalive = d_rows
+        return r
+
+    # --- helpers that restate how the reference turns an event into times (src/decoder.c:732, src/readtape.c:1423) ---
+    def time_of_row(self, row):
+        return (self.cfg.tstart_ns + np.asarray(row, dtype=np.int64) * self.cfg.tdelta_ns).astype(np.float64) / 1e9
+
+    def peak_times(self, burst, ev, parmset):
+        W = self.widths[parmset]
+        dt = np.float32(np.float32(self.cfg.tdelta_ns) / np.float32(1e9))
+        adjc = (ev["flags"] >> 1) & 3
+        adj = np.where(adjc == 1, np.float32(-0.5), np.where(adjc == 2, np.float32(0.5), np.float32(0))).astype(np.float32)
+        back = ((W - ev["left_distance"].astype(np.int32)).astype(np.float32) - adj) * dt        # float product
+        return self.time_of_row(int(burst["reset_sample"]) + ev["sample"].astype(np.int64)) - back.astype(np.float64)

@@ -1,0 +1,95 @@
+// TEST INFRASTRUCTURE — a minimal "HIP on pthreads" shim so that the UNMODIFIED kernel sources of
+// readtape_amd/csrc/*.hip can be compiled with g++ and exercised in the GPU-less build container
+// (tests/test_emul_*.py, marked not-gpu).  One workgroup runs at a time; its threads are real
+// std::threads that meet at a pthread barrier for __syncthreads(); wave intrinsics (__ballot,
+// __shfl_up) rendezvous per 64-thread wave.  It exists to debug kernel LOGIC on the CPU; it is never
+// loaded by the product (readtape_amd/frontend.py only opens librtfe.so and fails loudly without it).
+#pragma once
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __restrict__
+#define __launch_bounds__(...)
+#define RTFE_CPU_EMUL 1
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct int4 { int x, y, z, w; };
+extern thread_local dim3 threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+extern unsigned char g_dyn_smem[160 * 1024] __attribute__((aligned(64)));
+
+typedef int hipError_t;
+typedef void *hipStream_t;
+enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipDeviceProp_t { int multiProcessorCount; };
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 2; return hipSuccess; }
+template <class T> inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)calloc(1, n); return *p ? hipSuccess : 1; }
+inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
+
+namespace hipemu {
+struct Barrier {
+   pthread_barrier_t b; unsigned n = 0;
+   void init(unsigned k) { if (n) pthread_barrier_destroy(&b); pthread_barrier_init(&b, nullptr, k); n = k; }
+   void wait() { pthread_barrier_wait(&b); } };
+extern Barrier g_block_barrier;
+extern Barrier g_wave_barrier[16];
+extern unsigned long long g_wave_scratch[16][64];
+}  // namespace hipemu
+
+inline void __syncthreads() { hipemu::g_block_barrier.wait(); }
+inline unsigned long long __ballot(int pred) {
+   const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
+   hipemu::g_wave_scratch[w][l] = pred ? 1 : 0;
+   hipemu::g_wave_barrier[w].wait();
+   unsigned long long m = 0;
+   const unsigned nl = std::min(64u, blockDim.x - w * 64);
+   for (unsigned i = 0; i < nl; ++i) m |= hipemu::g_wave_scratch[w][i] << i;
+   hipemu::g_wave_barrier[w].wait();
+   return m; }
+inline int __shfl_up(int v, unsigned delta) {
+   const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
+   hipemu::g_wave_scratch[w][l] = (unsigned long long)(unsigned)v;
+   hipemu::g_wave_barrier[w].wait();
+   const int r = l >= delta ? (int)(unsigned)hipemu::g_wave_scratch[w][l - delta] : v;
+   hipemu::g_wave_barrier[w].wait();
+   return r; }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) {
+   unsigned long long old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+   while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+   return old; }
+using std::max;
+using std::min;
+
+template <class F, class... A>
+inline void hipemu_launch(F kernel, dim3 grid, dim3 block, size_t /*smem*/, hipStream_t, A... args) {
+   gridDim = grid; blockDim = block;
+   hipemu::g_block_barrier.init(block.x);
+   for (unsigned w = 0; w * 64 < block.x; ++w) hipemu::g_wave_barrier[w].init(std::min(64u, block.x - w * 64));
+   for (unsigned b = 0; b < grid.x; ++b) {
+      std::vector<std::thread> th;
+      th.reserve(block.x);
+      for (unsigned t = 0; t < block.x; ++t)
+         th.emplace_back([=]() { threadIdx = dim3(t); blockIdx = dim3(b); kernel(args...); });
+      for (auto &x : th) x.join(); } }
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu_launch(kernel, grid, block, smem, stream, __VA_ARGS__)

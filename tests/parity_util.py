@@ -1,0 +1,124 @@
+"""Event-level parity between the front end (HIP on a GPU, or the same kernel sources under
+tests/cpu_emul) and the CPU oracle.  Bit-exact: detection sample, track, polarity, peak voltage bits,
+AGC gain bits and the peak time (double) formed from (left_distance, half-sample adjustment)."""
+import os
+import subprocess
+
+import numpy as np
+
+import refdump
+from readtape_amd import frontend, tbin
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE = os.path.join(ROOT, "oracle", "_build", "oracle_readtape")
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
+    return ORACLE
+
+
+def oracle_attempts(hdr, rows, oracle_opts, workdir):
+    """Runs the oracle; returns a list of attempts: dict(start, end, parmset, blktype, events[structured])."""
+    build_oracle()
+    path = os.path.join(workdir, "t.tbin")
+    tbin.write_tbin(path, hdr, rows)
+    evt = os.path.join(workdir, "t.evt")
+    p = subprocess.run([ORACLE, f"-evt={evt}", "-evtend", f"-out={workdir}/t.or"] + list(oracle_opts) + [path], capture_output=True, text=True)
+    assert p.returncode in (0, 99), p.stderr
+    rec = refdump.load(evt)
+    row = (rec["timenow_ns"] - hdr.tstart_ns) // hdr.tdelta_ns
+    attempts, cur = [], None
+    for i in range(rec.size):
+        k = rec["kind"][i]
+        if k == 2:
+            cur = dict(start=int(row[i]), parmset=int(rec["parmset"][i]), idx=[], end=None, blktype=None)
+            attempts.append(cur)
+        elif k == 3:
+            cur["end"] = int(row[i]); cur["blktype"] = int(rec["peakcount"][i])
+            cur["last_row"] = int(row[i]) - max(int(rec["trk"][i]), 1)      # last row the detectors looked at (interblock skip excluded)
+        else:
+            cur["idx"].append(i)
+    for a in attempts:
+        e = rec[a["idx"]]
+        a["events"] = e
+        a["n0"] = (row[a["idx"]] - 1).astype(np.int64)           # timenow_ns is already one tdelta ahead
+        if a["end"] is None:
+            a["end"] = rows.shape[0]; a["last_row"] = rows.shape[0] - 1
+    return attempts
+
+
+def config_for(hdr, oracle_opts, parmset_ids=None, **kw):
+    mode = hdr.mode
+    skew = None
+    nparm = 8 if "-m" in oracle_opts else 1
+    for o in oracle_opts:
+        if o.startswith("-skew="):
+            skew = [int(x) for x in o[6:].split(",")]
+    sets = frontend.DEFAULT_PARMSETS[mode][:nparm] if mode != frontend.GCR else frontend.DEFAULT_PARMSETS[mode][: min(nparm, 5)]
+    return frontend.FrontEndConfig.from_header(hdr, parmsets=sets, skew=skew, invert="-invert" in oracle_opts, **kw)
+
+
+def compare_attempt(fe, res, b, att, label=""):
+    """Device events of (burst b, parmset) that were detected before the attempt ended vs the oracle's."""
+    p = att["parmset"]
+    B = res.bursts[b]
+    ev = res.events(b, p)
+    n0 = int(B["reset_sample"]) + ev["sample"].astype(np.int64)
+    keep = n0 <= att["last_row"]        # the reference's detectors are off during the interblock skip (src/decoder.c:841)
+    ev, n0 = ev[keep], n0[keep]
+    o = att["events"]
+    msgs = []
+    if ev.size != o.size:
+        msgs.append(f"{label}: {ev.size} device events vs {o.size} oracle events (attempt start {att['start']}, end {att['end']}, parmset {p}, burst reset {int(B['reset_sample'])}, flags {int(B['flags'])})")
+    n = min(ev.size, o.size)
+    ev, n0c, o, on0 = ev[:n], n0[:n], o[:n], att["n0"][:n]
+
+    def first_bad(mask, what, a, bb):
+        i = int(np.flatnonzero(mask)[0])
+        msgs.append(f"{label}: {what} differs at event {i} (of {n}): device {a[i]!r} vs oracle {bb[i]!r}; trk {ev['trk'][i]} n0 {n0c[i]}")
+
+    if n:
+        if (n0c != on0).any(): first_bad(n0c != on0, "detection sample", n0c, on0)
+        if (ev["trk"] != o["trk"]).any(): first_bad(ev["trk"] != o["trk"], "track", ev["trk"], o["trk"])
+        kind = ev["flags"] & 1
+        if (kind != o["kind"]).any(): first_bad(kind != o["kind"], "polarity", kind, o["kind"])
+        if (ev["v_peak"].view("u4") != o["v_peak"].view("u4")).any(): first_bad(ev["v_peak"].view("u4") != o["v_peak"].view("u4"), "v_peak", ev["v_peak"], o["v_peak"])
+        if (ev["agc_gain"].view("u4") != o["agc_gain"].view("u4")).any(): first_bad(ev["agc_gain"].view("u4") != o["agc_gain"].view("u4"), "agc_gain", ev["agc_gain"], o["agc_gain"])
+        tp = fe.peak_times(B, ev, p)
+        if (tp.view("u8") != o["t_peak"].view("u8")).any(): first_bad(tp.view("u8") != o["t_peak"].view("u8"), "t_peak", tp, o["t_peak"])
+    return msgs
+
+
+def check_tape(fe, hdr, rows, attempts, allow_exact=True):
+    """Full check of one tape.  Returns (messages, stats)."""
+    res = fe.scan(rows).fetch()
+    msgs = []
+    stats = dict(bursts=res.nbursts, attempts=len(attempts), speculative=0, exact=0, events=0, flags=0)
+    for b in range(res.nbursts):
+        stats["flags"] |= int(res.bursts[b]["flags"])
+    for k, att in enumerate(attempts):
+        s0 = att["start"]
+        hit = [b for b in range(res.nbursts)
+               if int(res.bursts[b]["zone_first"]) <= s0 <= int(res.bursts[b]["safe_last"]) and not (int(res.bursts[b]["flags"]) & frontend.F_UNSAFE)]
+        # an attempt with no events that spans several zones maps to the last zone it started in or before
+        if hit and att["end"] <= int(res.bursts[hit[-1]]["end_sample"]) + 0 or (hit and att["events"].size == 0):
+            b = hit[-1]
+            # the attempt must end before the device restarts again, unless it saw nothing before that
+            if att["end"] > int(res.bursts[b]["end_sample"]) and att["events"].size and att["n0"][-1] >= int(res.bursts[b]["end_sample"]):
+                hit = []
+            else:
+                msgs += compare_attempt(fe, res, b, att, f"attempt {k} (speculative burst {b})")
+                stats["speculative"] += 1
+                stats["events"] += att["events"].size
+                continue
+        if not allow_exact:
+            msgs.append(f"attempt {k} at {s0} has no safe burst")
+            continue
+        ex = fe.scan_exact(rows, s0, att["end"], parmset_mask=1 << att["parmset"]).fetch()
+        if int(ex.bursts[0]["flags"]) & frontend.F_SCREEN_UNDERFLOW:
+            ex = fe.scan_exact(rows, s0, att["end"], parmset_mask=1 << att["parmset"], screen_off=True).fetch()
+        msgs += compare_attempt(fe, ex, 0, att, f"attempt {k} (exact)")
+        stats["exact"] += 1
+        stats["events"] += att["events"].size
+    return msgs, stats
