@@ -146,6 +146,12 @@ int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_
                     rtfe_burst *d_burst, uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,
                     void *stream);
 
+/* Per-kernel timing of the most recent rtfe_scan on this handle: with enable != 0, rtfe_scan records
+ * HIP events on `stream` around each of its kernels; rtfe_kernel_ms synchronises those events and
+ * returns the elapsed milliseconds per kernel (out[rtfe_kernel_count()]).  Used by bench.py. */
+int rtfe_set_timing(rtfe_handle *h, int enable);
+int rtfe_kernel_ms(rtfe_handle *h, float *out);
+
 /* Names and launch-order of the kernels of one scan, for profilers (static strings). */
 int         rtfe_kernel_count(void);
 const char *rtfe_kernel_name(int i);

@@ -31,6 +31,8 @@ struct rtfe_handle {
    DevCfg *d_dev;
    int lds_bytes;
    int num_cus;
+   int timing;
+   hipEvent_t ev[4];
 };
 
 static thread_local char g_err[512] = "";
@@ -56,6 +58,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (!(c->bpi > 0) || !(c->ips > 0) || c->tdelta_ns <= 0 || !(c->maxvolts > 0)) return fail(-7, "bpi, ips, tdelta_ns and maxvolts must be positive");
    rtfe_handle *h = new rtfe_handle();
    h->cfg = *c;
+   h->timing = 0;
    DevCfg &d = h->dev;
    memset(&d, 0, sizeof d);
    d.mode = c->mode; d.ntrks = c->ntrks; d.invert = c->invert != 0; d.nparm = c->nparmsets;
@@ -121,14 +124,28 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return fail(-20, "no HIP device"); }
    h->num_cus = prop.multiProcessorCount;
    if (hipMalloc(&h->d_dev, sizeof(DevCfg)) != hipSuccess) { delete h; return fail(-21, "hipMalloc failed"); }
-   if (hipMemcpy(h->d_dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { hipFree(h->d_dev); delete h; return fail(-22, "hipMemcpy failed"); }
-   hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+   if (hipMemcpy(h->d_dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->d_dev); delete h; return fail(-22, "hipMemcpy failed"); }
+   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
    *out = h;
+   return 0; }
+
+extern "C" int rtfe_set_timing(rtfe_handle *h, int enable) {
+   if (!h) return fail(-1, "null argument");
+   if (enable && !h->timing) for (int i = 0; i < 4; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
+   if (!enable && h->timing) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(h->ev[i]);
+   h->timing = enable != 0;
+   return 0; }
+
+extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
+   if (!h || !out || !h->timing) return fail(-41, "timing is not enabled");
+   if (hipEventSynchronize(h->ev[3]) != hipSuccess) return fail(-42, "hipEventSynchronize failed");
+   for (int i = 0; i < 3; ++i) if (hipEventElapsedTime(&out[i], h->ev[i], h->ev[i + 1]) != hipSuccess) return fail(-43, "hipEventElapsedTime failed");
    return 0; }
 
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
-   hipFree(h->d_dev);
+   if (h->timing) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(h->ev[i]);
+   (void)hipFree(h->d_dev);
    delete h; }
 
 extern "C" int rtfe_pkww_width(const rtfe_handle *h, int parmset) {
@@ -168,14 +185,18 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    BurstScratch *scratch = reinterpret_cast<BurstScratch *>(d_workspace);
    unsigned long long *qwords = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_workspace) + 256);
    int grid = (int)(nwords < (long long)h->num_cus * 8 ? nwords : (long long)h->num_cus * 8);
+   if (h->timing) (void)hipEventRecord(h->ev[0], st);
    hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, st, d_rows, nelem, h->dev.quiet_i, qwords, nwords);
+   if (h->timing) (void)hipEventRecord(h->ev[1], st);
    hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, h->dev.ntrks,
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
                       d_bursts, (long long)max_bursts, scratch, d_nbursts);
+   if (h->timing) (void)hipEventRecord(h->ev[2], st);
    const int per_cu = (160 * 1024) / (h->lds_bytes + 1024);
    const int dgrid = h->num_cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
    hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(kDecodeThreads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                       (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0);
+   if (h->timing) (void)hipEventRecord(h->ev[3], st);
    return launch_check("rtfe_scan"); }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

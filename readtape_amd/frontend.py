@@ -162,6 +162,8 @@ def _load_library(path=None):
     lib.rtfe_scan_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.rtfe_kernel_name.restype = C.c_char_p
+    lib.rtfe_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.rtfe_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     if lib.rtfe_abi_version() != 1:
         raise RuntimeError("librtfe.so ABI mismatch")
     return lib
@@ -231,6 +233,17 @@ class FrontEnd:
 
     def kernel_names(self):
         return [self.lib.rtfe_kernel_name(i).decode() for i in range(self.lib.rtfe_kernel_count())]
+
+    def set_timing(self, enable=True):
+        if self.lib.rtfe_set_timing(self.h, int(enable)) != 0:
+            raise RuntimeError(self.lib.rtfe_last_error().decode())
+
+    def kernel_ms(self):
+        """Per-kernel elapsed ms of the last scan (HIP events on the scan's stream); synchronises."""
+        out = (C.c_float * 3)()
+        if self.lib.rtfe_kernel_ms(self.h, out) != 0:
+            raise RuntimeError(self.lib.rtfe_last_error().decode())
+        return dict(zip(self.kernel_names(), [float(x) for x in out]))
 
     def _buffers(self, nrows, key="scan"):
         """Allocates (once per size) the workspace and output buffers for a scan of nrows rows."""

@@ -39,6 +39,12 @@ template <class T> inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)call
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+typedef void *hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 
