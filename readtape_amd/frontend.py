@@ -119,6 +119,11 @@ class TorchBackend:
             raise RuntimeError("readtape_amd.frontend needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU path")
         self.torch = torch
         self.device = torch.device(device)
+        # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be the one resident in
+        # the process before librtfe.so is dlopen'ed, otherwise the extension binds a second, uninitialised
+        # runtime and sees no device.  Touch the device here so the context exists.
+        torch.cuda.init()
+        torch.empty(1, device=self.device)
 
     def empty(self, nbytes):
         return self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
@@ -209,8 +214,8 @@ class FrontEnd:
     def __init__(self, cfg: FrontEndConfig, device="cuda:0", _lib_path=None, _backend=None):
         """_lib_path / _backend are hooks for tests/cpu_emul only; the product uses librtfe.so + a GPU."""
         self.cfg = cfg
+        self.backend = _backend or TorchBackend(device)      # first: see TorchBackend.__init__
         self.lib = _load_library(_lib_path)
-        self.backend = _backend or TorchBackend(device)
         self._c = cfg.to_c()
         h = C.c_void_p()
         rc = self.lib.rtfe_create(C.byref(self._c), C.byref(h))
