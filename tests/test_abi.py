@@ -50,8 +50,9 @@ def test_product_fails_loudly_without_gpu_or_library(tmp_path):
     import torch
     from readtape_amd import frontend, synth
     cfg = frontend.FrontEndConfig.from_header(synth.nrzi_spec().header())
+    from emul_util import NumpyBackend
     with pytest.raises(RuntimeError, match="missing"):
-        frontend.FrontEnd(cfg, _lib_path=str(tmp_path / "nope.so"))
+        frontend.FrontEnd(cfg, _lib_path=str(tmp_path / "nope.so"), _backend=NumpyBackend())
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU path"):
             frontend.FrontEnd(cfg)
