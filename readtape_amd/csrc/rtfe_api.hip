@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "rt_frontend.h"
@@ -115,8 +116,16 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (gap < kMarginRows + 128) gap = kMarginRows + 128;
    d.gap_chunks = (int)(((long long)gap * c->ntrks * 2 + 1023) / 1024) + 1;
    d.cap_frac = c->events_per_sample_cap > 0 ? c->events_per_sample_cap : 0.125f;
-   h->lds_bytes = (((c->ntrks * (kHaloRows + kTileRows + 8) * 2 + 15) & ~15)
-                   + ((d.nscreens * 3 * c->ntrks * (kTileRows / 8) + 15) & ~15)
+   {
+      const char *e = getenv("RTFE_TILE_ROWS");            // tuning knob; the default is what bench.py measures
+      int tr = e ? atoi(e) : 512;
+      tr = (tr / 64) * 64;
+      if (tr < kMarginRows) tr = kMarginRows;
+      if (tr > kMaxTileRows) tr = kMaxTileRows;
+      d.tile_rows = tr; }
+   d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
+   h->lds_bytes = (((c->ntrks * (kHaloRows + d.tile_rows + 8) * 2 + 15) & ~15)
+                   + ((d.nscreens * 3 * c->ntrks * (d.tile_rows / 8) + 15) & ~15)
                    + c->nparmsets * c->ntrks * 10 * 4 + 64);
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
    hipDeviceProp_t prop;
@@ -192,9 +201,16 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
                       d_bursts, (long long)max_bursts, scratch, d_nbursts);
    if (h->timing) (void)hipEventRecord(h->ev[2], st);
-   const int per_cu = (160 * 1024) / (h->lds_bytes + 1024);
-   const int dgrid = h->num_cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
-   hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(kDecodeThreads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+   // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
+   // beat wide ones; k_decode holds ~180 VGPRs => 2 waves/SIMD => 8 waves per CU
+   const int nwalk = h->dev.nparm * h->dev.ntrks;
+   const int threads = nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256);
+   int per_cu = (160 * 1024) / (h->lds_bytes + 1024);
+   const int wave_lim = 8 / (threads / 64);
+   if (per_cu > wave_lim) per_cu = wave_lim;
+   if (per_cu < 1) per_cu = 1;
+   const int dgrid = h->num_cus * per_cu;
+   hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                       (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0);
    if (h->timing) (void)hipEventRecord(h->ev[3], st);
    return launch_check("rtfe_scan"); }
@@ -214,6 +230,7 @@ extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nr
    const unsigned long long cap = (unsigned long long)(event_capacity / ((int64_t)h->dev.nparm * h->dev.ntrks));
    hipLaunchKernelGGL(k_setup_exact, dim3(1), dim3(1), 0, st, d_burst, scratch, (long long)reset_row, (long long)end_row,
                       cap > 0xffffffffull ? 0xffffffffull : cap);
-   hipLaunchKernelGGL(k_decode, dim3(1), dim3(kDecodeThreads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+   const int nwalk = h->dev.nparm * h->dev.ntrks;
+   hipLaunchKernelGGL(k_decode, dim3(1), dim3(nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256)), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                       (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1);
    return launch_check("rtfe_scan_exact"); }

@@ -6,7 +6,7 @@
 namespace rtfe {
 
 constexpr int kChunkRows   = 64;     // granularity of the quiet map (rows per bit)
-constexpr int kTileRows    = 2048;   // rows per LDS tile of the decode kernel
+constexpr int kMaxTileRows = 2048;   // upper bound of DevCfg::tile_rows (rows per LDS tile of the decode kernel)
 constexpr int kHaloRows    = 160;    // rows kept in front of a tile: >= 2*W + max skew + 8  (W<=50, skew<=50)
 constexpr int kMarginRows  = 256;    // head/tail tile length at a burst boundary (multiple of 64)
 constexpr int kStrip       = 8;      // samples per screen strip (one bitmap byte)
@@ -42,6 +42,8 @@ struct DevCfg {
    int   quiet_i;                 // |x| <= quiet_i on every track  <=> row is "quiet"
    int   gap_chunks;              // quiet chunks that make an inter-block zone
    float cap_frac;                // event capacity per track as a fraction of burst length
+   int   tile_rows;               // rows per LDS tile (multiple of 64, kMarginRows..kMaxTileRows)
+   float lsb_per_volt;            // 32767 / maxvolts, for the walkers' integer guard bands
    DevParm   parm[RTFE_MAXPARMSETS];
    DevScreen screen[kMaxScreens];
 };

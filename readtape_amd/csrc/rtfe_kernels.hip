@@ -136,8 +136,17 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
          const int bit = __ffsll((long long)ends) - 1;
          ends &= ends - 1;
          const long long c1 = w * 64 + bit + 1;          // one past the last quiet chunk
+         // zone start: walk back over quiet chunks a 64-bit word at a time
          long long c0 = c1 - 1;
-         while (c0 > 0 && quiet_at(qwords, c0 - 1, nchunks)) --c0;   // zone start (long gaps: bounded by the gap length)
+         for (;;) {
+            if (c0 == 0) break;
+            const long long pw = (c0 - 1) >> 6; const int pb = (int)((c0 - 1) & 63);
+            // bits pb..0 of word pw, shifted so that bit pb becomes bit 63: count the leading run of ones
+            const u64 run = ~(qwords[pw] << (63 - pb));
+            const int ones = run ? __clzll((long long)run) : 64;
+            const int take = ones < pb + 1 ? ones : pb + 1;
+            c0 -= take;
+            if (take < pb + 1) break; }
          const long long idx = (long long)base + off++;
          if (idx < max_bursts) {
             rtfe_burst b = {};
@@ -190,7 +199,8 @@ struct Tile {
    long long row0;        // first row of the tile proper
    int      nrows;        // rows in the tile proper
    long long reset;       // burst restart row (deskew FIFO restarts there, src/decoder.c:415)
-   unsigned char *bits;   // LDS: [nscreens][3][ntrks][kTileRows/8]   0=top 1=bot 2=rescan ("A-sync")
+   unsigned char *bits;   // LDS: [nscreens][3][ntrks][bstride]   0=top 1=bot 2=rescan ("A-sync")
+   int      bstride;      // bytes per bitmap row = tile_rows / 8
    int      ntrks;
    const int *skew;
    __device__ inline int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + kHaloRows]; }
@@ -200,7 +210,7 @@ struct Tile {
       const int d = skew[t];
       return xi(t, (n - reset < d) ? n : n - d); }
    __device__ inline const u64 *map(int screen, int kind, int t) const {
-      return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 3 + kind) * ntrks + t) * (kTileRows / 8)); }
+      return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 3 + kind) * ntrks + t) * bstride); }
 };
 
 __device__ inline float volt(int i, float maxvolts) {      // src/readtape.c:1420
@@ -223,6 +233,12 @@ struct Walker {            // one per (parameter set, track); lives in registers
    // PE preamble tracking
    bool  datablock, bit1_up;
    double t_lastpeak;
+   // thresholds, recomputed whenever the AGC state changes (src/decoder.c:785-786)
+   float rise, reqmin;
+   int   rise_lo, rise_hi;     // integer guard bands around rise / reqmin (int16 units): a difference <= lo fails
+   int   min_lo, min_hi;       //   the float test for sure, >= hi passes for sure, in between the float test decides
+   // cached window maximum of the fast path (valid while its position stays inside the window)
+   int   cmax, cmax_pos_rel, cmax_at_rel;
    // output
    unsigned int nevents;
    unsigned int flags;
@@ -293,6 +309,30 @@ __device__ inline void agc_after_peak(Walker &w, const DevCfg *cfg, const DevPar
    if (is_top) w.v_lasttop = w.v_top; else w.v_lastbot = w.v_bot;
    w.t_lastpeak = t_peak; }
 
+__device__ inline void update_thresholds(Walker &w, const DevParm &P, float lsb_per_volt) {
+   w.rise = P.rise * (w.v_avg_height / 4.0f) / w.agc_gain;       // src/decoder.c:785-786
+   w.reqmin = P.min_peak * (w.v_avg_height / 4.0f) / w.agc_gain;
+   if (w.rise < P.screen_rise_v || (P.min_peak != 0 && w.reqmin < P.screen_minpk_v)) w.flags |= RTFE_F_SCREEN_UNDERFLOW;
+   // |(vM - vL) - (M - L) * volts_per_lsb| < 0.02 lsb for |v| <= maxvolts (three fp32 roundings), so one lsb
+   // of guard on either side of the converted threshold is ample
+   const int r = (int)floorf(w.rise * lsb_per_volt);
+   w.rise_lo = r - 1; w.rise_hi = r + 2;
+   const int m = (int)floorf(w.reqmin * lsb_per_volt);
+   w.min_lo = m - 1; w.min_hi = m + 2; }
+
+// 1 = passes, 0 = fails: "v(a) > v(b) + thr" decided on the int16 codes when clear, else in floats
+__device__ inline bool above_by(int a, int b, float thr, int lo, int hi, float mv) {
+   const int d = a - b;
+   if (d >= hi) return true;
+   if (d <= lo) return false;
+   return volt(a, mv) > volt(b, mv) + thr; }
+__device__ inline bool below_by(int a, int b, float thr, int lo, int hi, float mv) {   // v(a) < v(b) - thr
+   const int d = b - a;
+   if (d >= hi) return true;
+   if (d <= lo) return false;
+   return volt(a, mv) < volt(b, mv) - thr; }
+
+
 // refine_peak (src/decoder.c:700-749) + event emission + AGC mirror.  `lo` = first row of the window,
 // `p` = row of the first window element equal to the extreme.
 __device__ inline void emit_peak(Walker &w, const Ctx &cx, int pidx, int trk, const DevParm &P, long long n,
@@ -300,17 +340,22 @@ __device__ inline void emit_peak(Walker &w, const Ctx &cx, int pidx, int trk, co
    const DevCfg *cfg = cx.cfg;
    const float val = volt(val_i, cfg->maxvolts);
    const int left_distance = (int)(p - lo) + 1;
-   const float vprev = volt(cx.tile.y(trk, p - 1), cfg->maxvolts);
-   const float vnext = volt(cx.tile.y(trk, p + 1), cfg->maxvolts);
+   const int iprev = cx.tile.y(trk, p - 1), inext = cx.tile.y(trk, p + 1);
+   const float mv = cfg->maxvolts;
+   const float thr = 0.005f / w.agc_gain;                          // PEAK_THRESHOLD / agc_gain (src/decoder.c:715,724)
+   const int ti = (int)floorf(thr * cfg->lsb_per_volt);
    float adj = 0; int adjcode = 0;
-   if (is_top) {
-      const float val_minus = val - 0.005f / w.agc_gain;
-      if (vprev > val_minus && vnext < val_minus) { adj = -0.5f; adjcode = 1; }
-      else if (vnext > val_minus && vprev < val_minus) { adj = +0.5f; adjcode = 2; } }
-   else {
-      const float val_plus = val + 0.005f / w.agc_gain;
-      if (vprev < val_plus && vnext > val_plus) { adj = -0.5f; adjcode = 1; }
-      else if (vnext < val_plus && vprev > val_plus) { adj = +0.5f; adjcode = 2; } }
+   // "close" = within thr of the extreme, "far" = beyond it; decided on the codes unless within a guard band
+   const int dp = is_top ? val_i - iprev : iprev - val_i, dn = is_top ? val_i - inext : inext - val_i;
+   bool pclose, pfar, nclose, nfar;
+   if (dp <= ti - 1) { pclose = true; pfar = false; } else if (dp >= ti + 2) { pclose = false; pfar = true; }
+   else { const float lim_v = is_top ? val - thr : val + thr, vp = volt(iprev, mv);
+          pclose = is_top ? vp > lim_v : vp < lim_v; pfar = is_top ? vp < lim_v : vp > lim_v; }
+   if (dn <= ti - 1) { nclose = true; nfar = false; } else if (dn >= ti + 2) { nclose = false; nfar = true; }
+   else { const float lim_v = is_top ? val - thr : val + thr, vn = volt(inext, mv);
+          nclose = is_top ? vn > lim_v : vn < lim_v; nfar = is_top ? vn < lim_v : vn > lim_v; }
+   if (pclose && nfar) { adj = -0.5f; adjcode = 1; }               // src/decoder.c:716-721, 725-730
+   else if (nclose && pfar) { adj = +0.5f; adjcode = 2; }
    double t_peak = 0;
    if (cfg->mode == RTFE_PE)
       t_peak = time_of(cfg, cx.row_base + n) - ((float)(P.W - left_distance) - adj) * cfg->sample_deltat;
@@ -328,12 +373,8 @@ __device__ inline void emit_peak(Walker &w, const Ctx &cx, int pidx, int trk, co
    else w.flags |= RTFE_F_EVENT_OVERFLOW;
    ++w.nevents;
    agc_after_peak(w, cfg, P, cx.heights, is_top, t_peak);
+   update_thresholds(w, P, cfg->lsb_per_volt);
    w.blind_until = n + left_distance; }                          // pkww_countdown = left_distance (src/decoder.c:741)
-
-__device__ inline void thresholds(const Walker &w, const DevParm &P, float &rise, float &reqmin, unsigned int &flags) {
-   rise = P.rise * (w.v_avg_height / 4.0f) / w.agc_gain;         // src/decoder.c:785-786
-   reqmin = P.min_peak * (w.v_avg_height / 4.0f) / w.agc_gain;
-   if (rise < P.screen_rise_v || (P.min_peak != 0 && reqmin < P.screen_minpk_v)) flags |= RTFE_F_SCREEN_UNDERFLOW; }
 
 // exact window minimum and its first position (the rescan of src/decoder.c:767-775)
 __device__ inline void rescan_min(const Tile &tl, int trk, long long lo, long long hi, int &mn, long long &pos) {
@@ -387,8 +428,7 @@ __device__ inline void slow_step(Walker &w, const Ctx &cx, int pidx, int trk, co
       for (long long j = lo; j <= n; ++j) { const int v = tl.y(trk, j); mx = max(mx, v); mn = min(mn, v); }
       w.slow_max = mx; w.minv = mn; }
    if (w.slow_countdown) { --w.slow_countdown; return; }
-   float rise, reqmin;
-   thresholds(w, P, rise, reqmin, w.flags);
+   const float rise = w.rise, reqmin = w.reqmin;
    const float mv = cfg->maxvolts;
    const float vl = volt(tl.y(trk, lo), mv), vr = volt(vnow, mv);
    const float vmax = volt(w.slow_max, mv), vmin = volt(w.minv, mv);
@@ -428,43 +468,59 @@ __device__ void walk(Walker &w, const Ctx &cx, int pidx, int trk, long long limi
       while (w.next < limit && w.next < fast_from) { if (w.next >= w.start) slow_step(w, cx, pidx, trk, P, w.next); ++w.next; }
       if (w.next < fast_from) return;
       enter_fast(w, tl, trk, W, w.next); }
-   // ---- screened path ----
-   const u64 *tm = tl.map(P.screen, 0, trk), *bm = tl.map(P.screen, 1, trk);
+   // ---- screened path ----  (regular deskew regime: y(n) = yb[n - row0])
+   const u64 *tm = tl.map(P.screen, 0, trk), *bm = tl.map(P.screen, 1, trk), *am = tl.map(P.screen, 2, trk);
    const float mv = cfg->maxvolts;
-   long long n = max(w.next, w.blind_until + 1);
-   while (n < limit) {
+   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
+   const int nwords = (tl.nrows + 63) >> 6;
+   const int lim = (int)(limit - tl.row0);
+   long long n64 = max(w.next, w.blind_until + 1);
+   int n = (int)(n64 - tl.row0);
+   if (n64 - tl.row0 > lim) n = lim;
+   w.cmax_at_rel = -0x40000000;
+   while (n < lim) {
       // next candidate bit at or after n
-      long long rel = n - tl.row0;
-      int wd = (int)(rel >> 6);
-      u64 m = (tm[wd] | bm[wd]) & (~0ull << (rel & 63));
-      const int nwords = (tl.nrows + 63) >> 6;
+      int wd = n >> 6;
+      u64 m = (tm[wd] | bm[wd]) & (~0ull << (n & 63));
       while (!m && ++wd < nwords) m = tm[wd] | bm[wd];
-      if (!m) { n = limit; break; }
-      n = tl.row0 + (long long)wd * 64 + (__ffsll((long long)m) - 1);
-      if (n >= limit) break;
-      const bool ctop = (tm[wd] >> ((n - tl.row0) & 63)) & 1, cbot = (bm[wd] >> ((n - tl.row0) & 63)) & 1;
-      const long long lo = n - W + 1;
-      float rise, reqmin;
-      thresholds(w, P, rise, reqmin, w.flags);
-      const float vl = volt(tl.y(trk, lo), mv), vr = volt(tl.y(trk, n), mv);
+      if (!m) { n = lim; break; }
+      n = wd * 64 + (__ffsll((long long)m) - 1);
+      if (n >= lim) break;
+      const bool ctop = (tm[wd] >> (n & 63)) & 1, cbot = (bm[wd] >> (n & 63)) & 1;
+      const int lo = n - W + 1;
+      const int vl = yb[lo], vr = yb[n];
       bool hit = false;
       if (ctop) {
-         int mx = -0x7fffffff; long long p = lo;
-         for (long long j = lo; j <= n; ++j) { const int v = tl.y(trk, j); if (v > mx) { mx = v; p = j; } }
-         const float vmax = volt(mx, mv);
-         if (vmax > vl + rise && vmax > vr + rise && (reqmin == 0 || vmax > reqmin)) {
-            emit_peak(w, cx, pidx, trk, P, n, lo, p, mx, true);
+         // window maximum and its first position; reuse the previous candidate's while it is still inside
+         int mx, pos;
+         if (w.cmax_at_rel == n - 1 && w.cmax_pos_rel >= lo && vr <= w.cmax) { mx = w.cmax; pos = w.cmax_pos_rel; }
+         else {
+            mx = -0x7fffffff; pos = lo;
+            for (int j = lo; j <= n; ++j) { const int v = yb[j]; if (v > mx) { mx = v; pos = j; } } }
+         w.cmax = mx; w.cmax_pos_rel = pos; w.cmax_at_rel = n;
+         if (above_by(mx, vl, w.rise, w.rise_lo, w.rise_hi, mv) && above_by(mx, vr, w.rise, w.rise_lo, w.rise_hi, mv)
+               && (w.reqmin == 0 || (mx >= w.min_hi) || (mx > w.min_lo && volt(mx, mv) > w.reqmin))) {
+            emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, tl.row0 + pos, mx, true);
             hit = true; } }
       if (!hit && cbot) {
-         advance_chain(w, tl, P.screen, trk, W, n);
-         const float vmin = volt(w.minv, mv);
-         if (vmin < vl - rise && vmin < vr - rise && (reqmin == 0 || vmin < -reqmin)) {
-            long long p = lo;
-            while (p <= n && tl.y(trk, p) != w.minv) ++p;
-            if (p > n || p == lo || p == n) w.flags |= RTFE_F_DETECTOR_FATAL;
-            else { emit_peak(w, cx, pidx, trk, P, n, lo, p, w.minv, false); hit = true; } } }
-      n = hit ? w.blind_until + 1 : n + 1; }
-   w.next = n < limit ? n : limit;
+         int mn; long long pabs;
+         if ((am[wd] >> (n & 63)) & 1) {
+            // the window maximum left the window at this very row: the reference rescans here, so its
+            // minimum is the true window minimum (src/decoder.c:767-775)
+            rescan_min(tl, trk, tl.row0 + lo, tl.row0 + n, mn, pabs);
+            w.minv = mn; w.cpos = tl.row0 + n; w.qtrig = pabs + W; }
+         else {
+            advance_chain(w, tl, P.screen, trk, W, tl.row0 + n);
+            mn = w.minv; pabs = -1; }
+         if (below_by(mn, vl, w.rise, w.rise_lo, w.rise_hi, mv) && below_by(mn, vr, w.rise, w.rise_lo, w.rise_hi, mv)
+               && (w.reqmin == 0 || (-mn >= w.min_hi) || (-mn > w.min_lo && volt(mn, mv) < -w.reqmin))) {
+            if (pabs < 0) { pabs = tl.row0 + lo; while (pabs <= tl.row0 + n && tl.y(trk, pabs) != mn) ++pabs; }
+            if (pabs > tl.row0 + n || pabs == tl.row0 + lo || pabs == tl.row0 + n) w.flags |= RTFE_F_DETECTOR_FATAL;
+            else { emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, pabs, mn, false); hit = true; } } }
+      n = hit ? (int)(w.blind_until + 1 - tl.row0) : n + 1; }
+   n64 = tl.row0 + n;
+   w.next = n64 < limit ? n64 : limit;
+   const long long n_unused = 0; (void)n_unused;
    // keep the stale-min state inside the LDS window: bring it to the last row this tile can serve
    if (limit - 1 > w.cpos) advance_chain(w, tl, P.screen, trk, W, limit - 1); }
 
@@ -503,10 +559,10 @@ __device__ inline void screen_strip(const Tile &tl, const DevScreen &sc, int scr
          const bool t = (mx - L[i] > sc.rise_i) && (mx - v[i] > sc.rise_i) && (sc.minpk_i < 0 || mx > sc.minpk_i);
          const bool b = (L[i] - mn > sc.rise_i) && (v[i] - mn > sc.rise_i) && (sc.minpk_i < 0 || mn < -sc.minpk_i);
          topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i; } }
-   unsigned char *o = tl.bits + ((size_t)(screen * 3) * tl.ntrks + trk) * (kTileRows / 8) + strip;
+   unsigned char *o = tl.bits + ((size_t)(screen * 3) * tl.ntrks + trk) * tl.bstride + strip;
    o[0] = (unsigned char)topb;
-   o[(size_t)tl.ntrks * (kTileRows / 8)] = (unsigned char)botb;
-   o[(size_t)2 * tl.ntrks * (kTileRows / 8)] = (unsigned char)resb; }
+   o[(size_t)tl.ntrks * tl.bstride] = (unsigned char)botb;
+   o[(size_t)2 * tl.ntrks * tl.bstride] = (unsigned char)resb; }
 
 // cooperative tile load: rows [row0 - kHaloRows, row0 + nrows) of the AoS payload -> SoA LDS by track
 __device__ inline void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows) {
@@ -583,7 +639,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
    if (screen_off) for (int i = threadIdx.x; i < cfg.nparm; i += blockDim.x) { cfg.parm[i].screen_rise_v = -1; cfg.parm[i].screen_minpk_v = -1; }
    __syncthreads();
    const int ntrks = cfg.ntrks;
-   const int ldw = kHaloRows + kTileRows + 8;
+   const int ldw = kHaloRows + cfg.tile_rows + 8;
    Ctx cx;
    cx.cfg = &cfg;
    cx.row_base = row_base;
@@ -593,12 +649,14 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
    cx.tile.skew = cfg.skew;
    size_t off = ((size_t)ntrks * ldw * 2 + 15) & ~(size_t)15;
    cx.tile.bits = smem + off;
-   off += (size_t)cfg.nscreens * 3 * ntrks * (kTileRows / 8);
+   cx.tile.bstride = cfg.tile_rows / 8;
+   off += (size_t)cfg.nscreens * 3 * ntrks * (cfg.tile_rows / 8);
    off = (off + 15) & ~(size_t)15;
    float *heights_all = reinterpret_cast<float *>(smem + off);
    // walker w of this workgroup -> thread: spread over the 4 waves so every SIMD issues for some walkers
    const int nwalk = cfg.nparm * ntrks;
-   const int my_w = (threadIdx.x & 63) * 4 + (threadIdx.x >> 6);
+   const int nwaves = blockDim.x >> 6;
+   const int my_w = (threadIdx.x & 63) * nwaves + (threadIdx.x >> 6);
    const bool is_walker = my_w < nwalk;
    const int pidx = is_walker ? my_w / ntrks : 0, trk = is_walker ? my_w - pidx * ntrks : 0;
    const bool active = is_walker && ((parmset_mask >> pidx) & 1);
@@ -636,6 +694,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
       Walker w = {};
       w.start = reset + trk; w.next = reset; w.blind_until = -1; w.fast = false;
       w.agc_gain = 1.0f; w.v_avg_height = 4.0f;
+      update_thresholds(w, cfg.parm[pidx], cfg.lsb_per_volt);
       if (is_walker) for (int i = 0; i < 10; ++i) cx.heights[i] = 0;
       cx.tile.reset = reset;
       // ---- tiles ----
@@ -651,7 +710,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
          else {
             const long long normal_end = has_tail ? next_zone_end - kMarginRows : hard_end;
             if (tile0 >= normal_end && has_tail) { is_tail = true; tn = kMarginRows; }
-            else { tn = normal_end - tile0; if (tn > kTileRows) tn = kTileRows; } }
+            else { tn = normal_end - tile0; if (tn > cfg.tile_rows) tn = cfg.tile_rows; } }
          if (tn <= 0) break;
          if (!first_tile) {
             cx.tile.row0 = tile0; cx.tile.nrows = (int)tn;
