@@ -201,6 +201,7 @@ struct Tile {
    long long reset;       // burst restart row (deskew FIFO restarts there, src/decoder.c:415)
    unsigned char *bits;   // LDS: [nscreens][3][ntrks][bstride]   0=top 1=bot 2=rescan ("A-sync")
    int      bstride;      // bytes per bitmap row = tile_rows / 8
+   unsigned char *ldpos;  // LDS: [nscreens][2][ntrks][tile_rows] left_distance of the first window max (0) / true min (1)
    int      ntrks;
    const int *skew;
    __device__ inline int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + kHaloRows]; }
@@ -209,6 +210,8 @@ struct Tile {
    __device__ inline int y(int t, long long n) const {
       const int d = skew[t];
       return xi(t, (n - reset < d) ? n : n - d); }
+   __device__ inline const unsigned char *ldmap(int screen, int kind, int t) const {
+      return ldpos + ((size_t)(screen * 2 + kind) * ntrks + t) * (bstride * 8); }
    __device__ inline const u64 *map(int screen, int kind, int t) const {
       return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 3 + kind) * ntrks + t) * bstride); }
 };
@@ -237,8 +240,6 @@ struct Walker {            // one per (parameter set, track); lives in registers
    float rise, reqmin;
    int   rise_lo, rise_hi;     // integer guard bands around rise / reqmin (int16 units): a difference <= lo fails
    int   min_lo, min_hi;       //   the float test for sure, >= hi passes for sure, in between the float test decides
-   // cached window maximum of the fast path (valid while its position stays inside the window)
-   int   cmax, cmax_pos_rel, cmax_at_rel;
    // output
    unsigned int nevents;
    unsigned int flags;
@@ -472,12 +473,12 @@ __device__ void walk(Walker &w, const Ctx &cx, int pidx, int trk, long long limi
    const u64 *tm = tl.map(P.screen, 0, trk), *bm = tl.map(P.screen, 1, trk), *am = tl.map(P.screen, 2, trk);
    const float mv = cfg->maxvolts;
    const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
+   const unsigned char *ldt = tl.ldmap(P.screen, 0, trk), *ldb = tl.ldmap(P.screen, 1, trk);
    const int nwords = (tl.nrows + 63) >> 6;
    const int lim = (int)(limit - tl.row0);
    long long n64 = max(w.next, w.blind_until + 1);
    int n = (int)(n64 - tl.row0);
    if (n64 - tl.row0 > lim) n = lim;
-   w.cmax_at_rel = -0x40000000;
    while (n < lim) {
       // next candidate bit at or after n
       int wd = n >> 6;
@@ -491,13 +492,9 @@ __device__ void walk(Walker &w, const Ctx &cx, int pidx, int trk, long long limi
       const int vl = yb[lo], vr = yb[n];
       bool hit = false;
       if (ctop) {
-         // window maximum and its first position; reuse the previous candidate's while it is still inside
-         int mx, pos;
-         if (w.cmax_at_rel == n - 1 && w.cmax_pos_rel >= lo && vr <= w.cmax) { mx = w.cmax; pos = w.cmax_pos_rel; }
-         else {
-            mx = -0x7fffffff; pos = lo;
-            for (int j = lo; j <= n; ++j) { const int v = yb[j]; if (v > mx) { mx = v; pos = j; } } }
-         w.cmax = mx; w.cmax_pos_rel = pos; w.cmax_at_rel = n;
+         // window maximum and its first position come from the screen (left_distance byte)
+         const int pos = lo + ldt[n] - 1;
+         const int mx = yb[pos];
          if (above_by(mx, vl, w.rise, w.rise_lo, w.rise_hi, mv) && above_by(mx, vr, w.rise, w.rise_lo, w.rise_hi, mv)
                && (w.reqmin == 0 || (mx >= w.min_hi) || (mx > w.min_lo && volt(mx, mv) > w.reqmin))) {
             emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, tl.row0 + pos, mx, true);
@@ -506,8 +503,9 @@ __device__ void walk(Walker &w, const Ctx &cx, int pidx, int trk, long long limi
          int mn; long long pabs;
          if ((am[wd] >> (n & 63)) & 1) {
             // the window maximum left the window at this very row: the reference rescans here, so its
-            // minimum is the true window minimum (src/decoder.c:767-775)
-            rescan_min(tl, trk, tl.row0 + lo, tl.row0 + n, mn, pabs);
+            // minimum is the true window minimum (src/decoder.c:767-775), whose position the screen recorded
+            const int pr = lo + ldb[n] - 1;
+            mn = yb[pr]; pabs = tl.row0 + pr;
             w.minv = mn; w.cpos = tl.row0 + n; w.qtrig = pabs + W; }
          else {
             advance_chain(w, tl, P.screen, trk, W, tl.row0 + n);
@@ -527,6 +525,10 @@ __device__ void walk(Walker &w, const Ctx &cx, int pidx, int trk, long long limi
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
 __device__ inline void screen_strip(const Tile &tl, const DevScreen &sc, int screen, int trk, int strip) {
+   // Keys carry the position so that max/min also yield the FIRST window element equal to the extreme
+   // (what refine_peak looks for, src/decoder.c:707-708): r = index relative to the strip's leftmost
+   // window element (s0 - W + 1);  kmax = v<<8 | (255 - r)  (max -> largest v, then smallest r),
+   // kmin = v<<8 | r  (min -> smallest v, then smallest r).
    const int W = sc.W;
    const int d = tl.skew[trk];
    const int16_t *base = tl.x + trk * tl.ldw + kHaloRows - d;     // y(n) = base[n - row0] in the regular regime
@@ -535,34 +537,50 @@ __device__ inline void screen_strip(const Tile &tl, const DevScreen &sc, int scr
    #pragma unroll
    for (int i = 0; i < kStrip; ++i) { v[i] = base[s0 + i]; L[i] = base[s0 + i - W + 1]; }
    int topb = 0, botb = 0, resb = 0;
+   u64 ldt = 0, ldb = 0;
    if (W > kStrip) {
       int smx[kStrip], smn[kStrip];
-      int amx = -0x7fffffff, amn = 0x7fffffff;
-      for (int j = s0 - 1; j > s0 - W + kStrip; --j) { const int u = base[j]; amx = max(amx, u); amn = min(amn, u); }
+      int amx = (int)0x80000000, amn = 0x7fffffff;
+      for (int j = s0 - 1; j > s0 - W + kStrip; --j) {
+         const int u = base[j], r = j - (s0 - W + 1);
+         amx = max(amx, (u << 8) | (255 - r)); amn = min(amn, (u << 8) | r); }
       #pragma unroll
-      for (int i = kStrip - 1; i >= 0; --i) { const int u = L[i]; amx = max(amx, u); amn = min(amn, u); smx[i] = amx; smn[i] = amn; }
-      int pmx = -0x7fffffff, pmn = 0x7fffffff;
+      for (int i = kStrip - 1; i >= 0; --i) {
+         const int u = L[i];
+         amx = max(amx, (u << 8) | (255 - i)); amn = min(amn, (u << 8) | i); smx[i] = amx; smn[i] = amn; }
+      int pmx = (int)0x80000000, pmn = 0x7fffffff;
       #pragma unroll
       for (int i = 0; i < kStrip; ++i) {
-         pmx = max(pmx, v[i]); pmn = min(pmn, v[i]);
-         const int mx = max(smx[i], pmx), mn = min(smn[i], pmn);
+         const int r = W - 1 + i;
+         pmx = max(pmx, (v[i] << 8) | (255 - r)); pmn = min(pmn, (v[i] << 8) | r);
+         const int kx = max(smx[i], pmx), kn = min(smn[i], pmn);
+         const int mx = kx >> 8, mn = kn >> 8;
          const int popped = base[s0 + i - W];
          const bool t = (mx - L[i] > sc.rise_i) && (mx - v[i] > sc.rise_i) && (sc.minpk_i < 0 || mx > sc.minpk_i);
          const bool b = (L[i] - mn > sc.rise_i) && (v[i] - mn > sc.rise_i) && (sc.minpk_i < 0 || mn < -sc.minpk_i);
-         topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i; } }
+         topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i;
+         ldt |= (u64)((255 - (kx & 255)) - i + 1) << (8 * i);        // left_distance of the first maximum
+         ldb |= (u64)((kn & 255) - i + 1) << (8 * i); } }             // ... and of the first (true) minimum
    else {
       #pragma unroll
       for (int i = 0; i < kStrip; ++i) {
-         int mx = -0x7fffffff, mn = 0x7fffffff;
-         for (int j = s0 + i - W + 1; j <= s0 + i; ++j) { const int u = base[j]; mx = max(mx, u); mn = min(mn, u); }
+         int kx = (int)0x80000000, kn = 0x7fffffff;
+         for (int j = s0 + i - W + 1; j <= s0 + i; ++j) {
+            const int u = base[j], r = j - (s0 + i - W + 1);
+            kx = max(kx, (u << 8) | (255 - r)); kn = min(kn, (u << 8) | r); }
+         const int mx = kx >> 8, mn = kn >> 8;
          const int popped = base[s0 + i - W];
          const bool t = (mx - L[i] > sc.rise_i) && (mx - v[i] > sc.rise_i) && (sc.minpk_i < 0 || mx > sc.minpk_i);
          const bool b = (L[i] - mn > sc.rise_i) && (v[i] - mn > sc.rise_i) && (sc.minpk_i < 0 || mn < -sc.minpk_i);
-         topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i; } }
+         topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i;
+         ldt |= (u64)((255 - (kx & 255)) + 1) << (8 * i);
+         ldb |= (u64)((kn & 255) + 1) << (8 * i); } }
    unsigned char *o = tl.bits + ((size_t)(screen * 3) * tl.ntrks + trk) * tl.bstride + strip;
    o[0] = (unsigned char)topb;
    o[(size_t)tl.ntrks * tl.bstride] = (unsigned char)botb;
-   o[(size_t)2 * tl.ntrks * tl.bstride] = (unsigned char)resb; }
+   o[(size_t)2 * tl.ntrks * tl.bstride] = (unsigned char)resb;
+   reinterpret_cast<u64 *>(tl.ldpos + ((size_t)(screen * 2) * tl.ntrks + trk) * (tl.bstride * 8))[strip] = ldt;
+   reinterpret_cast<u64 *>(tl.ldpos + ((size_t)(screen * 2 + 1) * tl.ntrks + trk) * (tl.bstride * 8))[strip] = ldb; }
 
 // cooperative tile load: rows [row0 - kHaloRows, row0 + nrows) of the AoS payload -> SoA LDS by track
 __device__ inline void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows) {
@@ -570,25 +588,31 @@ __device__ inline void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__r
    const long long first = tl.row0 - kHaloRows;                   // multiple of 8 rows => 16-byte aligned
    const int nload = kHaloRows + tl.nrows;
    const int nvec = (nload * ntrks + 7) >> 3;
-   for (int vi = threadIdx.x; vi < nvec; vi += blockDim.x) {
-      const int e0 = vi * 8;
-      int r = e0 / ntrks, c = e0 - r * ntrks;
-      const long long ge = (first + r) * (long long)ntrks + c;    // global element index of e0
-      int16_t s[8];
-      if (first + r >= 0 && ge + 8 <= total_rows * ntrks && ge >= 0) {
-         const int4 q = *reinterpret_cast<const int4 *>(rows + ge);
-         const int qq[4] = {q.x, q.y, q.z, q.w};
-         #pragma unroll
-         for (int j = 0; j < 4; ++j) { s[2 * j] = (int16_t)(qq[j] & 0xffff); s[2 * j + 1] = (int16_t)(qq[j] >> 16); } }
-      else {
-         #pragma unroll
-         for (int j = 0; j < 8; ++j) { const long long g = ge + j; s[j] = (g >= 0 && g < total_rows * ntrks) ? rows[g] : (int16_t)0; } }
+   const long long total_elem = total_rows * ntrks;
+   constexpr int kBatch = 6;                                      // independent 16-B loads in flight per lane
+   for (int vbase = 0; vbase < nvec; vbase += kBatch * (int)blockDim.x) {
+      int4 q[kBatch];
       #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-         if (r < nload) {
-            const int trk = cfg->head_to_trk[c];
-            tl.x[trk * tl.ldw + r] = cfg->invert ? (int16_t)-s[j] : s[j]; }
-         if (++c == ntrks) { c = 0; ++r; } } } }
+      for (int k = 0; k < kBatch; ++k) {
+         const int vi = vbase + k * (int)blockDim.x + (int)threadIdx.x;
+         const long long ge = first * ntrks + (long long)vi * 8;
+         q[k] = make_int4(0, 0, 0, 0);
+         if (vi < nvec && ge >= 0 && ge + 8 <= total_elem) q[k] = *reinterpret_cast<const int4 *>(rows + ge); }
+      #pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+         const int vi = vbase + k * (int)blockDim.x + (int)threadIdx.x;
+         if (vi >= nvec) continue;
+         const int e0 = vi * 8;
+         int r = e0 / ntrks, c = e0 - r * ntrks;
+         const long long ge = first * ntrks + e0;
+         const bool whole = ge >= 0 && ge + 8 <= total_elem;
+         const int qq[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+         #pragma unroll
+         for (int j = 0; j < 8; ++j) {
+            int sv = (j & 1) ? (qq[j >> 1] >> 16) : (int)(short)(qq[j >> 1] & 0xffff);
+            if (!whole) { const long long g = ge + j; sv = (g >= 0 && g < total_elem) ? rows[g] : 0; }   // tape ends only
+            if (r < nload) tl.x[cfg->head_to_trk[c] * tl.ldw + r] = (int16_t)(cfg->invert ? -sv : sv);
+            if (++c == ntrks) { c = 0; ++r; } } } } }
 
 __device__ inline void run_screens(const DevCfg *cfg, const Tile &tl) {
    const int nstrips = (tl.nrows + kStrip - 1) / kStrip;
@@ -651,6 +675,9 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
    cx.tile.bits = smem + off;
    cx.tile.bstride = cfg.tile_rows / 8;
    off += (size_t)cfg.nscreens * 3 * ntrks * (cfg.tile_rows / 8);
+   off = (off + 15) & ~(size_t)15;
+   cx.tile.ldpos = smem + off;
+   off += (size_t)cfg.nscreens * 2 * ntrks * cfg.tile_rows;
    off = (off + 15) & ~(size_t)15;
    float *heights_all = reinterpret_cast<float *>(smem + off);
    // walker w of this workgroup -> thread: spread over the 4 waves so every SIMD issues for some walkers

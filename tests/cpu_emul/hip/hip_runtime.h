@@ -25,6 +25,7 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct int4 { int x, y, z, w; };
+inline int4 make_int4(int a, int b, int c, int d) { int4 r = {a, b, c, d}; return r; }
 extern thread_local dim3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
 extern unsigned char g_dyn_smem[160 * 1024] __attribute__((aligned(64)));
