@@ -124,6 +124,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       if (tr > kMaxTileRows) tr = kMaxTileRows;
       d.tile_rows = tr; }
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
+   d.debug = getenv("RTFE_DEBUG") != nullptr;
    h->lds_bytes = (((c->ntrks * (kHaloRows + d.tile_rows + 8) * 2 + 15) & ~15)
                    + ((d.nscreens * 3 * c->ntrks * (d.tile_rows / 8) + 15) & ~15)
                    + ((d.nscreens * 2 * c->ntrks * d.tile_rows + 15) & ~15)

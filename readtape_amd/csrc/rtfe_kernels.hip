@@ -73,8 +73,12 @@ __global__ void __launch_bounds__(256) k_quiet(const int16_t *__restrict__ rows,
 struct BurstScratch {            // lives in the workspace
    int   nbursts;
    int   queue;                  // next burst to decode
-   int   pad[2];
+   int   pad[14];
+   unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
 };
+#ifdef RTFE_CPU_EMUL
+static inline long long clock64() { return 0; }
+#endif
 
 __device__ inline bool quiet_at(const u64 *q, long long c, long long nchunks) {
    return c >= 0 && c < nchunks && ((q[c >> 6] >> (c & 63)) & 1); }
@@ -188,7 +192,8 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
       __syncthreads();
       if (threadIdx.x == 0) s_ebase += (u64)total << 6;
       __syncthreads(); }
-   if (threadIdx.x == 0) { scratch->nbursts = nb; scratch->queue = 0; *nbursts_out = nb; } }
+   if (threadIdx.x == 0) { scratch->nbursts = nb; scratch->queue = 0; *nbursts_out = nb; }
+   if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0; }
 
 // ------------------------------------------------------------------------------------------------
 // k_decode
@@ -739,13 +744,17 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
             if (tile0 >= normal_end && has_tail) { is_tail = true; tn = kMarginRows; }
             else { tn = normal_end - tile0; if (tn > cfg.tile_rows) tn = cfg.tile_rows; } }
          if (tn <= 0) break;
+         long long c0 = 0, c1 = 0, c2 = 0;
          if (!first_tile) {
             cx.tile.row0 = tile0; cx.tile.nrows = (int)tn;
             __syncthreads();
+            if (cfg.debug) c0 = clock64();
             load_tile(&cfg, cx.tile, rows, nrows);
             __syncthreads();
+            if (cfg.debug) c1 = clock64();
             run_screens(&cfg, cx.tile);
             __syncthreads();
+            if (cfg.debug) c2 = clock64();
             if (is_tail) {
                // the next burst restarts inside this tile; compute exactly what its own workgroup computes
                const rtfe_burst NB = bursts[b + 1];
@@ -758,6 +767,12 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
                if (nr <= 0 || nr < NB.zone_first) nr = NB.zone_end - kMarginRows;
                stop = nr; } }
          if (active) walk(w, cx, pidx, trk, stop);
+         if (cfg.debug && !first_tile) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+               const long long c3 = clock64();
+               atomicAdd(&scratch->dbg[0], (unsigned long long)(c1 - c0)); atomicAdd(&scratch->dbg[1], (unsigned long long)(c2 - c1));
+               atomicAdd(&scratch->dbg[2], (unsigned long long)(c3 - c2)); atomicAdd(&scratch->dbg[3], 1ull); } }
          first_tile = false;
          tile0 += tn;
          if (is_tail || tile0 >= hard_end) done = true; }

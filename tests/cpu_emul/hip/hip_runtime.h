@@ -80,6 +80,7 @@ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) {
    unsigned long long old = __atomic_load_n(p, __ATOMIC_SEQ_CST);

@@ -1,0 +1,24 @@
+"""GPU box helper: per-phase cycle counters of k_decode (RTFE_DEBUG=1) on the bench tape."""
+import os, sys, json
+os.environ["RTFE_DEBUG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from readtape_amd import frontend
+rows_target = float(sys.argv[1]) if len(sys.argv) > 1 else 1e8
+tape = bench.make_base_tape(1000, 5_000_000)
+base = torch.from_numpy(tape.rows).cuda()
+copies = max(1, int(round(rows_target / base.shape[0])))
+rows = base.repeat(copies, 1).contiguous()
+fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(tape.spec.header(), nparmsets=1))
+fe.set_timing(True)
+for _ in range(2):
+    r = fe.scan(rows)
+ms = fe.kernel_ms()
+r.fetch()
+ws = r.bufs["ws"].cpu().numpy()
+dbg = ws[64:128].view(np.uint64)
+lens = (r.bursts["end_sample"] - r.bursts["reset_sample"])
+print(json.dumps({"rows": int(rows.shape[0]), "kernel_ms": ms, "bursts": int(r.nbursts), "burst_len_max": int(lens.max()), "burst_len_mean": float(lens.mean()),
+                  "tiles": int(dbg[3]), "cyc_per_tile": {"load": float(dbg[0]) / max(int(dbg[3]), 1), "screen": float(dbg[1]) / max(int(dbg[3]), 1), "walk": float(dbg[2]) / max(int(dbg[3]), 1)},
+                  "events": int(r.counts.sum())}))
