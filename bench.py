@@ -153,6 +153,13 @@ def main():
         dom = max(kms, key=kms.get)
         alg_bytes = 2 * cfg.ntrks * nrows + 16 * nevents        # 18 B per sample instant + 16 B per event
         achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
+        traffic = None
+        try:                                         # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            if dom in pm and abs(pm["workload_rows"] - nrows) < 0.01 * nrows:
+                traffic = pm[dom]["fetch_bytes"] + pm[dom]["write_bytes"]
+        except Exception:
+            pass
         line = {
             "metric": "Msamples/sec (all tracks) 9-trk TBIN", "value": round(nrows * world * args.steps / dt / 1e6, 1),
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,7 +170,7 @@ def main():
                        "flagged_bursts": bad, "sharding": "time shards, neighbour halo only" if world > 1 else "none"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes": alg_bytes},
         }
         if not args.no_cpu_baseline and world == 1:
