@@ -250,6 +250,10 @@ struct Walker {            // one per (parameter set, track); lives in registers
    unsigned int flags;
 };
 
+// A detection whose (cheap-to-defer) half-sample refinement, volt conversion and event store are done
+// after the walk by all lanes (finalize_tile): the sequential walker keeps only what feeds back.
+struct Rec { unsigned int idx; unsigned short n_rel; unsigned char ld, kind; float g; };
+
 struct Ctx {               // per-workgroup constants for the walkers
    const DevCfg *cfg;
    Tile tile;
@@ -257,6 +261,9 @@ struct Ctx {               // per-workgroup constants for the walkers
    float *heights;         // LDS [walkers][10]
    rtfe_event *events;     // this burst's regions
    unsigned int cap;
+   struct Rec *recs;       // LDS [rec_cap] deferred events of this lane's walker for the current tile
+   int     rec_cap;
+   int     nrec;           // records queued in this tile
 };
 
 __device__ inline double time_of(const DevCfg *c, long long abs_row) {     // src/readtape.c:1423
@@ -339,18 +346,12 @@ __device__ inline bool below_by(int a, int b, float thr, int lo, int hi, float m
    return volt(a, mv) < volt(b, mv) - thr; }
 
 
-// refine_peak (src/decoder.c:700-749) + event emission + AGC mirror.  `lo` = first row of the window,
-// `p` = row of the first window element equal to the extreme.
-__device__ inline void emit_peak(Walker &w, const Ctx &cx, int pidx, int trk, const DevParm &P, long long n,
-                                 long long lo, long long p, int val_i, bool is_top) {
-   const DevCfg *cfg = cx.cfg;
-   const float val = volt(val_i, cfg->maxvolts);
-   const int left_distance = (int)(p - lo) + 1;
-   const int iprev = cx.tile.y(trk, p - 1), inext = cx.tile.y(trk, p + 1);
+// the half-sample refinement of refine_peak (src/decoder.c:712-731): 0 none, 1 = -0.5, 2 = +0.5
+__device__ inline int refine_code(const DevCfg *cfg, int val_i, int iprev, int inext, float agc_gain, bool is_top) {
    const float mv = cfg->maxvolts;
-   const float thr = 0.005f / w.agc_gain;                          // PEAK_THRESHOLD / agc_gain (src/decoder.c:715,724)
+   const float val = volt(val_i, mv);
+   const float thr = 0.005f / agc_gain;                            // PEAK_THRESHOLD / agc_gain (src/decoder.c:715,724)
    const int ti = (int)floorf(thr * cfg->lsb_per_volt);
-   float adj = 0; int adjcode = 0;
    // "close" = within thr of the extreme, "far" = beyond it; decided on the codes unless within a guard band
    const int dp = is_top ? val_i - iprev : iprev - val_i, dn = is_top ? val_i - inext : inext - val_i;
    bool pclose, pfar, nclose, nfar;
@@ -360,27 +361,63 @@ __device__ inline void emit_peak(Walker &w, const Ctx &cx, int pidx, int trk, co
    if (dn <= ti - 1) { nclose = true; nfar = false; } else if (dn >= ti + 2) { nclose = false; nfar = true; }
    else { const float lim_v = is_top ? val - thr : val + thr, vn = volt(inext, mv);
           nclose = is_top ? vn > lim_v : vn < lim_v; nfar = is_top ? vn < lim_v : vn > lim_v; }
-   if (pclose && nfar) { adj = -0.5f; adjcode = 1; }               // src/decoder.c:716-721, 725-730
-   else if (nclose && pfar) { adj = +0.5f; adjcode = 2; }
+   if (pclose && nfar) return 1;                                   // src/decoder.c:716-721, 725-730
+   if (nclose && pfar) return 2;
+   return 0; }
+
+__device__ inline void store_event(const Ctx &cx, int pidx, int trk, unsigned int idx, long long n, float val, float g,
+                                   bool is_top, int adjcode, int left_distance) {
+   rtfe_event e;
+   e.sample = (uint32_t)(n - cx.tile.reset);
+   e.v_peak = val;
+   e.agc_gain = g;
+   e.trk = (uint8_t)trk;
+   e.flags = (uint8_t)((is_top ? 0 : 1) | (adjcode << 1));
+   e.left_distance = (uint8_t)left_distance;
+   e.parmset = (uint8_t)pidx;
+   cx.events[(size_t)(pidx * cx.cfg->ntrks + trk) * cx.cap + idx] = e; }
+
+// refine_peak (src/decoder.c:700-749) + event emission + AGC mirror.  `lo` = first row of the window,
+// `p` = row of the first window element equal to the extreme.  With defer != 0 the refinement and the
+// event store are queued for finalize_tile() (possible whenever nothing downstream needs the peak time).
+__device__ inline void emit_peak(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, long long n,
+                                 long long lo, long long p, int val_i, bool is_top, bool defer) {
+   const DevCfg *cfg = cx.cfg;
+   const float val = volt(val_i, cfg->maxvolts);
+   const int left_distance = (int)(p - lo) + 1;
+   // PE decides the end of the preamble from peak times (src/decode_pe.c:136-138): only then is the time needed here
+   const bool need_time = cfg->mode == RTFE_PE && !w.datablock && w.peakcount >= 68;
    double t_peak = 0;
-   if (cfg->mode == RTFE_PE)
-      t_peak = time_of(cfg, cx.row_base + n) - ((float)(P.W - left_distance) - adj) * cfg->sample_deltat;
+   if (w.nevents >= cx.cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
+   else if (defer && !need_time && cx.nrec < cx.rec_cap) {
+      Rec r; r.idx = w.nevents; r.n_rel = (unsigned short)(n - cx.tile.row0); r.ld = (unsigned char)left_distance;
+      r.kind = is_top ? 0 : 1; r.g = w.agc_gain;
+      cx.recs[cx.nrec++] = r; }
+   else {
+      const int adjcode = refine_code(cfg, val_i, cx.tile.y(trk, p - 1), cx.tile.y(trk, p + 1), w.agc_gain, is_top);
+      const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
+      if (cfg->mode == RTFE_PE)
+         t_peak = time_of(cfg, cx.row_base + n) - ((float)(P.W - left_distance) - adj) * cfg->sample_deltat;
+      store_event(cx, pidx, trk, w.nevents, n, val, w.agc_gain, is_top, adjcode, left_distance); }
    if (is_top) w.v_top = val; else w.v_bot = val;
-   if (w.nevents < cx.cap) {
-      rtfe_event e;
-      e.sample = (uint32_t)(n - cx.tile.reset);
-      e.v_peak = val;
-      e.agc_gain = w.agc_gain;
-      e.trk = (uint8_t)trk;
-      e.flags = (uint8_t)((is_top ? 0 : 1) | (adjcode << 1));
-      e.left_distance = (uint8_t)left_distance;
-      e.parmset = (uint8_t)pidx;
-      cx.events[(size_t)(pidx * cfg->ntrks + trk) * cx.cap + w.nevents] = e; }
-   else w.flags |= RTFE_F_EVENT_OVERFLOW;
    ++w.nevents;
    agc_after_peak(w, cfg, P, cx.heights, is_top, t_peak);
    update_thresholds(w, P, cfg->lsb_per_volt);
    w.blind_until = n + left_distance; }                          // pkww_countdown = left_distance (src/decoder.c:741)
+
+// all lanes: turn this tile's queued records of one walker into events
+__device__ inline void finalize_records(const Ctx &cx, const Rec *recs, int nrec, int pidx, int trk, int lane, int nlanes) {
+   const DevCfg *cfg = cx.cfg;
+   const Tile &tl = cx.tile;
+   const int W = cfg->parm[pidx].W;
+   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
+   for (int i = lane; i < nrec; i += nlanes) {
+      const Rec r = recs[i];
+      const int n = r.n_rel, pos = n - W + r.ld;              // lo + ld - 1
+      const int val_i = yb[pos];
+      const bool is_top = r.kind == 0;
+      const int adjcode = refine_code(cfg, val_i, yb[pos - 1], yb[pos + 1], r.g, is_top);
+      store_event(cx, pidx, trk, r.idx, tl.row0 + n, volt(val_i, cfg->maxvolts), r.g, is_top, adjcode, r.ld); } }
 
 // exact window minimum and its first position (the rescan of src/decoder.c:767-775)
 __device__ inline void rescan_min(const Tile &tl, int trk, long long lo, long long hi, int &mn, long long &pos) {
@@ -414,7 +451,7 @@ __device__ inline void advance_chain(Walker &w, const Tile &tl, int screen, int 
 
 // literal lookfor_peak for one row while the window is still filling or the deskew FIFO is in its
 // start-up regime (src/decoder.c:751-810 with the state of src/decoder.c:855-861).
-__device__ inline void slow_step(Walker &w, const Ctx &cx, int pidx, int trk, const DevParm &P, long long n) {
+__device__ inline void slow_step(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, long long n) {
    const Tile &tl = cx.tile;
    const DevCfg *cfg = cx.cfg;
    const int W = P.W;
@@ -446,7 +483,7 @@ __device__ inline void slow_step(Walker &w, const Ctx &cx, int pidx, int trk, co
       while (p <= n && tl.y(trk, p) != val) ++p;
       if (p > n || p == lo || p == n) { w.flags |= RTFE_F_DETECTOR_FATAL; return; }   // src/decoder.c:709-710,748
       // refine_peak's time formula and countdown use W even when the window is not full
-      emit_peak(w, cx, pidx, trk, P, n, lo, p, val, top);
+      emit_peak(w, cx, pidx, trk, P, n, lo, p, val, top, false);
       w.slow_countdown = (int)(p - lo) + 1; } }
 
 // switch from the literal path to the screened path: derive the lazy stale-min state
@@ -461,7 +498,7 @@ __device__ inline void enter_fast(Walker &w, const Tile &tl, int trk, int W, lon
    w.fast = true; }
 
 // one (parameter set, track) detector over rows [.., limit)
-__device__ void walk(Walker &w, const Ctx &cx, int pidx, int trk, long long limit) {
+__device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit) {
    const DevCfg *cfg = cx.cfg;
    const DevParm &P = cfg->parm[pidx];
    const Tile &tl = cx.tile;
@@ -495,31 +532,31 @@ __device__ void walk(Walker &w, const Ctx &cx, int pidx, int trk, long long limi
       const bool ctop = (tm[wd] >> (n & 63)) & 1, cbot = (bm[wd] >> (n & 63)) & 1;
       const int lo = n - W + 1;
       const int vl = yb[lo], vr = yb[n];
-      bool hit = false;
+      // one flat decision per candidate row keeps the walker lanes of a wave in lockstep
+      bool hit = false, is_top = false;
+      int pos = 0, val = 0;
       if (ctop) {
          // window maximum and its first position come from the screen (left_distance byte)
-         const int pos = lo + ldt[n] - 1;
-         const int mx = yb[pos];
-         if (above_by(mx, vl, w.rise, w.rise_lo, w.rise_hi, mv) && above_by(mx, vr, w.rise, w.rise_lo, w.rise_hi, mv)
-               && (w.reqmin == 0 || (mx >= w.min_hi) || (mx > w.min_lo && volt(mx, mv) > w.reqmin))) {
-            emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, tl.row0 + pos, mx, true);
-            hit = true; } }
+         pos = lo + ldt[n] - 1;
+         val = yb[pos];
+         hit = above_by(val, vl, w.rise, w.rise_lo, w.rise_hi, mv) && above_by(val, vr, w.rise, w.rise_lo, w.rise_hi, mv)
+               && (w.reqmin == 0 || (val >= w.min_hi) || (val > w.min_lo && volt(val, mv) > w.reqmin));
+         is_top = hit; }
       if (!hit && cbot) {
-         int mn; long long pabs;
          if ((am[wd] >> (n & 63)) & 1) {
             // the window maximum left the window at this very row: the reference rescans here, so its
             // minimum is the true window minimum (src/decoder.c:767-775), whose position the screen recorded
-            const int pr = lo + ldb[n] - 1;
-            mn = yb[pr]; pabs = tl.row0 + pr;
-            w.minv = mn; w.cpos = tl.row0 + n; w.qtrig = pabs + W; }
+            pos = lo + ldb[n] - 1;
+            val = yb[pos];
+            w.minv = val; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + pos + W; }
          else {
             advance_chain(w, tl, P.screen, trk, W, tl.row0 + n);
-            mn = w.minv; pabs = -1; }
-         if (below_by(mn, vl, w.rise, w.rise_lo, w.rise_hi, mv) && below_by(mn, vr, w.rise, w.rise_lo, w.rise_hi, mv)
-               && (w.reqmin == 0 || (-mn >= w.min_hi) || (-mn > w.min_lo && volt(mn, mv) < -w.reqmin))) {
-            if (pabs < 0) { pabs = tl.row0 + lo; while (pabs <= tl.row0 + n && tl.y(trk, pabs) != mn) ++pabs; }
-            if (pabs > tl.row0 + n || pabs == tl.row0 + lo || pabs == tl.row0 + n) w.flags |= RTFE_F_DETECTOR_FATAL;
-            else { emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, pabs, mn, false); hit = true; } } }
+            val = w.minv; pos = -1; }
+         hit = below_by(val, vl, w.rise, w.rise_lo, w.rise_hi, mv) && below_by(val, vr, w.rise, w.rise_lo, w.rise_hi, mv)
+               && (w.reqmin == 0 || (-val >= w.min_hi) || (-val > w.min_lo && volt(val, mv) < -w.reqmin));
+         if (hit && pos < 0) { pos = lo; while (pos <= n && yb[pos] != val) ++pos; }
+         if (hit && (pos > n || pos == lo || pos == n)) { w.flags |= RTFE_F_DETECTOR_FATAL; hit = false; } }
+      if (hit) emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, tl.row0 + pos, val, is_top, true);
       n = hit ? (int)(w.blind_until + 1 - tl.row0) : n + 1; }
    n64 = tl.row0 + n;
    w.next = n64 < limit ? n64 : limit;
@@ -693,6 +730,13 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
    const int pidx = is_walker ? my_w / ntrks : 0, trk = is_walker ? my_w - pidx * ntrks : 0;
    const bool active = is_walker && ((parmset_mask >> pidx) & 1);
    cx.heights = heights_all + (size_t)(is_walker ? my_w : 0) * 10;
+   off += (size_t)nwalk * 10 * 4;
+   off = (off + 15) & ~(size_t)15;
+   Rec *recs_all = reinterpret_cast<Rec *>(smem + off);
+   off += (size_t)nwalk * cfg.rec_cap * sizeof(Rec);
+   int *nrec_all = reinterpret_cast<int *>(smem + off);
+   cx.rec_cap = cfg.rec_cap;
+   cx.recs = recs_all + (size_t)(is_walker ? my_w : 0) * cfg.rec_cap;
 
    for (;;) {
       if (threadIdx.x == 0) { s_burst = atomicAdd(&scratch->queue, 1); s_flags = 0; }
@@ -766,7 +810,12 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
                   cx.tile.reset = saved; }
                if (nr <= 0 || nr < NB.zone_first) nr = NB.zone_end - kMarginRows;
                stop = nr; } }
+         cx.nrec = 0;
          if (active) walk(w, cx, pidx, trk, stop);
+         if (is_walker) nrec_all[my_w] = cx.nrec;
+         __syncthreads();
+         for (int w2 = 0; w2 < nwalk; ++w2)                      // all lanes: refinement, volt conversion, event stores
+            finalize_records(cx, recs_all + (size_t)w2 * cfg.rec_cap, nrec_all[w2], w2 / ntrks, w2 % ntrks, threadIdx.x, blockDim.x);
          if (cfg.debug && !first_tile) {
             __syncthreads();
             if (threadIdx.x == 0) {
