@@ -232,6 +232,7 @@ struct Walker {            // one per (parameter set, track); lives in registers
    int   minv;             // the (possibly stale) window minimum, int16 units (src/decoder.c:765-775)
    long long qtrig;        // row at which the sample equal to minv leaves the window (forces a rescan)
    long long cpos;         // the stale-min state is valid after processing this row
+   bool  chain_pending;    // ... except that the forced rescan AT row cpos has not been carried out yet (lazy)
    int   slow_max, slow_countdown;   // literal state while the window is filling
    bool  fast;             // window full and in the regular deskew regime: use the screen
    // AGC / block-decoder mirror
@@ -424,30 +425,32 @@ __device__ inline void rescan_min(const Tile &tl, int trk, long long lo, long lo
    mn = 0x7fffffff; pos = lo;
    for (long long j = lo; j <= hi; ++j) { const int v = tl.y(trk, j); if (v < mn) { mn = v; pos = j; } } }
 
+// last forced rescan ("window maximum leaves the window") in rows (after, upto] of the current tile, or -1
+__device__ inline long long last_forced_rescan(const Tile &tl, int screen, int trk, long long after, long long upto) {
+   const u64 *am = tl.map(screen, 2, trk);
+   long long lo = after + 1 - tl.row0, hi = upto - tl.row0;          // tile-relative, inclusive
+   if (lo < 0) lo = 0;
+   if (hi < lo) return -1;
+   for (long long wd = hi >> 6; wd >= (lo >> 6); --wd) {
+      u64 m = am[wd];
+      if (wd == (hi >> 6) && (hi & 63) != 63) m &= (1ull << ((hi & 63) + 1)) - 1;
+      if (wd == (lo >> 6)) m &= ~0ull << (lo & 63);
+      if (m) return tl.row0 + wd * 64 + (63 - __clzll((long long)m)); }
+   return -1; }
+
 // bring the stale-minimum state forward to "after row n" using the rescan bitmap of this tile
 __device__ inline void advance_chain(Walker &w, const Tile &tl, int screen, int trk, int W, long long n) {
-   if (n <= w.cpos) return;
-   // last forced rescan (window maximum leaves the window) in (cpos, n]
-   const u64 *am = tl.map(screen, 2, trk);
-   long long a = -1;
-   {
-      long long lo = w.cpos + 1 - tl.row0, hi = n - tl.row0;       // tile-relative, inclusive
-      if (lo < 0) lo = 0;
-      for (long long wd = hi >> 6; wd >= (lo >> 6) && hi >= 0; --wd) {
-         u64 m = am[wd];
-         if (wd == (hi >> 6) && (hi & 63) != 63) m &= (1ull << ((hi & 63) + 1)) - 1;
-         if (wd == (lo >> 6)) m &= ~0ull << (lo & 63);
-         if (m) { a = tl.row0 + wd * 64 + (63 - __clzll((long long)m)); break; } } }
-   if (a >= 0) {
-      long long pos;
-      rescan_min(tl, trk, a - W + 1, a, w.minv, pos);
-      w.cpos = a; w.qtrig = pos + W; }
+   if (n <= w.cpos && !w.chain_pending) return;
+   const long long a = last_forced_rescan(tl, screen, trk, w.cpos, n);
+   long long pos;
+   if (a >= 0) { rescan_min(tl, trk, a - W + 1, a, w.minv, pos); w.cpos = a; w.qtrig = pos + W; }
+   else if (w.chain_pending) { rescan_min(tl, trk, w.cpos - W + 1, w.cpos, w.minv, pos); w.qtrig = pos + W; }
+   w.chain_pending = false;
    while (w.qtrig <= n) {                                         // the stale minimum itself leaves the window
       const long long t = w.qtrig;
-      long long pos;
       rescan_min(tl, trk, t - W + 1, t, w.minv, pos);
       w.cpos = t; w.qtrig = pos + W; }
-   w.cpos = n; }
+   if (n > w.cpos) w.cpos = n; }
 
 // literal lookfor_peak for one row while the window is still filling or the deskew FIFO is in its
 // start-up regime (src/decoder.c:751-810 with the state of src/decoder.c:855-861).
@@ -492,7 +495,7 @@ __device__ inline void enter_fast(Walker &w, const Tile &tl, int trk, int W, lon
    long long pos = last - W + 1;
    while (pos <= last && tl.y(trk, pos) != w.minv) ++pos;
    w.qtrig = pos + W;                                             // (pos <= last always: the stale min is a window element)
-   w.cpos = last;
+   w.cpos = last; w.chain_pending = false;
    w.blind_until = last + w.slow_countdown;
    w.next = n_first_fast;
    w.fast = true; }
@@ -548,7 +551,7 @@ __device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit) {
             // minimum is the true window minimum (src/decoder.c:767-775), whose position the screen recorded
             pos = lo + ldb[n] - 1;
             val = yb[pos];
-            w.minv = val; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + pos + W; }
+            w.minv = val; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + pos + W; w.chain_pending = false; }
          else {
             advance_chain(w, tl, P.screen, trk, W, tl.row0 + n);
             val = w.minv; pos = -1; }
@@ -561,8 +564,13 @@ __device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit) {
    n64 = tl.row0 + n;
    w.next = n64 < limit ? n64 : limit;
    const long long n_unused = 0; (void)n_unused;
-   // keep the stale-min state inside the LDS window: bring it to the last row this tile can serve
-   if (limit - 1 > w.cpos) advance_chain(w, tl, P.screen, trk, W, limit - 1); }
+   // keep the stale-min state inside the reach of the next tile's halo, lazily: remember the last forced
+   // rescan of this tile (its window is re-read only if a later bottom needs it); walk the chain eagerly
+   // only when that rescan lies too far back (no falling slope for ~100 rows: rare)
+   if (limit - 1 > w.cpos) {
+      const long long a = last_forced_rescan(tl, P.screen, trk, w.cpos, limit - 1);
+      if (a >= 0) { w.cpos = a; w.chain_pending = true; }
+      if (limit - 1 - w.cpos > kHaloRows - 2 * W - 8 - cfg->maxskew) advance_chain(w, tl, P.screen, trk, W, limit - 1); } }
 
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
