@@ -44,6 +44,7 @@ struct DevCfg {
    float cap_frac;                // event capacity per track as a fraction of burst length
    int   tile_rows;               // rows per LDS tile (multiple of 64, kMarginRows..kMaxTileRows)
    float lsb_per_volt;            // 32767 / maxvolts, for the walkers' integer guard bands
+   int   run_cap;                 // candidate-run records per (screen, track) per tile (LDS)
    int   rec_cap;                 // deferred-event records per walker per tile (LDS)
    int   debug;                   // RTFE_DEBUG=1: per-phase cycle counters in the workspace (tools/ only)
    DevParm   parm[RTFE_MAXPARMSETS];

@@ -382,9 +382,8 @@ __device__ inline void store_event(const Ctx &cx, int pidx, int trk, unsigned in
 // `p` = row of the first window element equal to the extreme.  With defer != 0 the refinement and the
 // event store are queued for finalize_tile() (possible whenever nothing downstream needs the peak time).
 __device__ inline void emit_peak(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, long long n,
-                                 long long lo, long long p, int val_i, bool is_top, bool defer) {
+                                 long long lo, long long p, float val, int val_i, bool is_top, bool defer) {
    const DevCfg *cfg = cx.cfg;
-   const float val = volt(val_i, cfg->maxvolts);
    const int left_distance = (int)(p - lo) + 1;
    // PE decides the end of the preamble from peak times (src/decode_pe.c:136-138): only then is the time needed here
    const bool need_time = cfg->mode == RTFE_PE && !w.datablock && w.peakcount >= 68;
@@ -486,7 +485,7 @@ __device__ inline void slow_step(Walker &w, Ctx &cx, int pidx, int trk, const De
       while (p <= n && tl.y(trk, p) != val) ++p;
       if (p > n || p == lo || p == n) { w.flags |= RTFE_F_DETECTOR_FATAL; return; }   // src/decoder.c:709-710,748
       // refine_peak's time formula and countdown use W even when the window is not full
-      emit_peak(w, cx, pidx, trk, P, n, lo, p, val, top, false);
+      emit_peak(w, cx, pidx, trk, P, n, lo, p, volt(val, mv), val, top, false);
       w.slow_countdown = (int)(p - lo) + 1; } }
 
 // switch from the literal path to the screened path: derive the lazy stale-min state
@@ -501,7 +500,57 @@ __device__ inline void enter_fast(Walker &w, const Tile &tl, int trk, int W, lon
    w.fast = true; }
 
 // one (parameter set, track) detector over rows [.., limit)
-__device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit) {
+// run records: what the candidate screen knows about one run of consecutive candidate rows of one kind,
+// prepared by all lanes (build_records) so that the sequential walker only has to compare integers.
+struct RunRec {
+   unsigned short n_s;        // first candidate row of the run (tile-relative)
+   short          p;          // row of the extreme (tile-relative, may be negative: in the halo)
+   short          m;          // the extreme, int16 code
+   unsigned char  kind;       // 0 top, 1 bottom
+   unsigned char  fast;       // bit k: row n_s+k can be decided from marg[k] (same extreme; bottoms: forced rescan at that row)
+   unsigned short len;        // candidate rows in the run
+   unsigned short pad;
+   short          marg[4];    // min(|m - left edge|, |m - right edge|) at rows n_s .. n_s+3
+   float          v;          // volt(m)
+};                            // 24 bytes
+constexpr int kRunFast = 4;
+
+// exact evaluation of one candidate row (the flat body of the screened walker); returns true on a detection
+__device__ inline bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, int n, bool ctop, bool cbot, bool async) {
+   const DevCfg *cfg = cx.cfg;
+   const Tile &tl = cx.tile;
+   const int W = P.W;
+   const float mv = cfg->maxvolts;
+   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
+   const int lo = n - W + 1;
+   const int vl = yb[lo], vr = yb[n];
+   bool hit = false, is_top = false;
+   int pos = 0, val = 0;
+   if (ctop) {
+      pos = lo + tl.ldmap(P.screen, 0, trk)[n] - 1;               // first window maximum, from the screen
+      val = yb[pos];
+      hit = above_by(val, vl, w.rise, w.rise_lo, w.rise_hi, mv) && above_by(val, vr, w.rise, w.rise_lo, w.rise_hi, mv)
+            && (w.reqmin == 0 || (val >= w.min_hi) || (val > w.min_lo && volt(val, mv) > w.reqmin));
+      is_top = hit; }
+   if (!hit && cbot) {
+      if (async) {
+         // the window maximum left the window at this very row: the reference rescans here, so its
+         // minimum is the true window minimum (src/decoder.c:767-775), whose position the screen recorded
+         pos = lo + tl.ldmap(P.screen, 1, trk)[n] - 1;
+         val = yb[pos];
+         w.minv = val; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + pos + W; w.chain_pending = false; }
+      else {
+         advance_chain(w, tl, P.screen, trk, W, tl.row0 + n);
+         val = w.minv; pos = -1; }
+      hit = below_by(val, vl, w.rise, w.rise_lo, w.rise_hi, mv) && below_by(val, vr, w.rise, w.rise_lo, w.rise_hi, mv)
+            && (w.reqmin == 0 || (-val >= w.min_hi) || (-val > w.min_lo && volt(val, mv) < -w.reqmin));
+      if (hit && pos < 0) { pos = lo; while (pos <= n && yb[pos] != val) ++pos; }
+      if (hit && (pos > n || pos == lo || pos == n)) { w.flags |= RTFE_F_DETECTOR_FATAL; hit = false; } }
+   if (hit) emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, tl.row0 + pos, volt(val, mv), val, is_top, true);
+   return hit; }
+
+// one (parameter set, track) detector over rows [.., limit)
+__device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit, const RunRec *runs, int nruns, int nruns_total) {
    const DevCfg *cfg = cx.cfg;
    const DevParm &P = cfg->parm[pidx];
    const Tile &tl = cx.tile;
@@ -514,56 +563,50 @@ __device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit) {
       while (w.next < limit && w.next < fast_from) { if (w.next >= w.start) slow_step(w, cx, pidx, trk, P, w.next); ++w.next; }
       if (w.next < fast_from) return;
       enter_fast(w, tl, trk, W, w.next); }
-   // ---- screened path ----  (regular deskew regime: y(n) = yb[n - row0])
+   // ---- screened path: one iteration per candidate RUN; lanes of a wave stay in lockstep ----
    const u64 *tm = tl.map(P.screen, 0, trk), *bm = tl.map(P.screen, 1, trk), *am = tl.map(P.screen, 2, trk);
    const float mv = cfg->maxvolts;
-   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
-   const unsigned char *ldt = tl.ldmap(P.screen, 0, trk), *ldb = tl.ldmap(P.screen, 1, trk);
-   const int nwords = (tl.nrows + 63) >> 6;
    const int lim = (int)(limit - tl.row0);
    long long n64 = max(w.next, w.blind_until + 1);
-   int n = (int)(n64 - tl.row0);
-   if (n64 - tl.row0 > lim) n = lim;
-   while (n < lim) {
-      // next candidate bit at or after n
-      int wd = n >> 6;
-      u64 m = (tm[wd] | bm[wd]) & (~0ull << (n & 63));
-      while (!m && ++wd < nwords) m = tm[wd] | bm[wd];
-      if (!m) { n = lim; break; }
-      n = wd * 64 + (__ffsll((long long)m) - 1);
-      if (n >= lim) break;
-      const bool ctop = (tm[wd] >> (n & 63)) & 1, cbot = (bm[wd] >> (n & 63)) & 1;
-      const int lo = n - W + 1;
-      const int vl = yb[lo], vr = yb[n];
-      // one flat decision per candidate row keeps the walker lanes of a wave in lockstep
-      bool hit = false, is_top = false;
-      int pos = 0, val = 0;
-      if (ctop) {
-         // window maximum and its first position come from the screen (left_distance byte)
-         pos = lo + ldt[n] - 1;
-         val = yb[pos];
-         hit = above_by(val, vl, w.rise, w.rise_lo, w.rise_hi, mv) && above_by(val, vr, w.rise, w.rise_lo, w.rise_hi, mv)
-               && (w.reqmin == 0 || (val >= w.min_hi) || (val > w.min_lo && volt(val, mv) > w.reqmin));
-         is_top = hit; }
-      if (!hit && cbot) {
-         if ((am[wd] >> (n & 63)) & 1) {
-            // the window maximum left the window at this very row: the reference rescans here, so its
-            // minimum is the true window minimum (src/decoder.c:767-775), whose position the screen recorded
-            pos = lo + ldb[n] - 1;
-            val = yb[pos];
-            w.minv = val; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + pos + W; w.chain_pending = false; }
-         else {
-            advance_chain(w, tl, P.screen, trk, W, tl.row0 + n);
-            val = w.minv; pos = -1; }
-         hit = below_by(val, vl, w.rise, w.rise_lo, w.rise_hi, mv) && below_by(val, vr, w.rise, w.rise_lo, w.rise_hi, mv)
-               && (w.reqmin == 0 || (-val >= w.min_hi) || (-val > w.min_lo && volt(val, mv) < -w.reqmin));
-         if (hit && pos < 0) { pos = lo; while (pos <= n && yb[pos] != val) ++pos; }
-         if (hit && (pos > n || pos == lo || pos == n)) { w.flags |= RTFE_F_DETECTOR_FATAL; hit = false; } }
-      if (hit) emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, tl.row0 + pos, val, is_top, true);
-      n = hit ? (int)(w.blind_until + 1 - tl.row0) : n + 1; }
-   n64 = tl.row0 + n;
+   int cur = (n64 - tl.row0 > lim) ? lim : (int)(n64 - tl.row0);       // first row not yet looked at
+   for (int i = 0; i < nruns; ++i) {
+      const RunRec r = runs[i];
+      const int n_e = min((int)r.n_s + (int)r.len, lim);                // one past the last candidate row of this run
+      int n = max((int)r.n_s, cur);
+      // rows decidable from the record: integer margins against the guard-banded thresholds
+      const bool is_top = r.kind == 0;
+      const bool peak_ok = w.reqmin == 0 || (is_top ? r.m >= w.min_hi : -r.m >= w.min_hi);
+      const bool peak_no = !(w.reqmin == 0) && (is_top ? r.m <= w.min_lo : -r.m <= w.min_lo);
+      while (n < n_e && n - r.n_s < kRunFast && ((r.fast >> (n - r.n_s)) & 1)) {
+         const int mg = r.marg[n - r.n_s];
+         if (mg <= w.rise_lo || peak_no) { ++n; continue; }            // fails for sure
+         if (mg >= w.rise_hi && peak_ok) {                              // passes for sure
+            if (!is_top) { w.minv = r.m; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + r.p + W; w.chain_pending = false; }
+            emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + n - W + 1, tl.row0 + r.p, r.v, r.m, is_top, true);
+            n = (int)(w.blind_until + 1 - tl.row0); }
+         break; }
+      // anything else (guard band, rows past the record, another extreme took over, stale minimum, rows after a
+      // detection inside a long run): the exact per-row path
+      while (n < n_e) {
+         const int wd = n >> 6, bit = n & 63;
+         const bool ctop = (tm[wd] >> bit) & 1, cbot = (bm[wd] >> bit) & 1;
+         const bool hit = (ctop || cbot) && eval_at(w, cx, pidx, trk, P, n, ctop, cbot, (am[wd] >> bit) & 1);
+         n = hit ? (int)(w.blind_until + 1 - tl.row0) : n + 1; }
+      cur = max(cur, n);
+      if (cur > lim) cur = lim; }
+   // rows after the last recorded run hold candidates only if the run list overflowed: exact per-row path
+   {
+      int n = cur;
+      if (nruns_total <= nruns) n = lim;
+      else if (nruns > 0) n = max(cur, min(lim, (int)runs[nruns - 1].n_s + (int)runs[nruns - 1].len));
+      while (n < lim) {
+         const int wd = n >> 6, bit = n & 63;
+         const bool ctop = (tm[wd] >> bit) & 1, cbot = (bm[wd] >> bit) & 1;
+         const bool hit = (ctop || cbot) && eval_at(w, cx, pidx, trk, P, n, ctop, cbot, (am[wd] >> bit) & 1);
+         n = hit ? (int)(w.blind_until + 1 - tl.row0) : n + 1; }
+      cur = max(cur, n); }
+   n64 = tl.row0 + cur;
    w.next = n64 < limit ? n64 : limit;
-   const long long n_unused = 0; (void)n_unused;
    // keep the stale-min state inside the reach of the next tile's halo, lazily: remember the last forced
    // rescan of this tile (its window is re-read only if a later bottom needs it); walk the chain eagerly
    // only when that rescan lies too far back (no falling slope for ~100 rows: rare)
@@ -571,6 +614,55 @@ __device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit) {
       const long long a = last_forced_rescan(tl, P.screen, trk, w.cpos, limit - 1);
       if (a >= 0) { w.cpos = a; w.chain_pending = true; }
       if (limit - 1 - w.cpos > kHaloRows - 2 * W - 8 - cfg->maxskew) advance_chain(w, tl, P.screen, trk, W, limit - 1); } }
+
+// all lanes: list the candidate runs of one (screen, track) of the current tile in row order.  A run = consecutive
+// rows with ANY candidate bit set; its record describes the extreme of the kind seen at its first row.
+__device__ inline u64 run_starts(const Tile &tl, int screen, int trk, int wd) {
+   const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk);
+   const int nwords = (tl.nrows + 63) >> 6;
+   const u64 valid = (wd == nwords - 1 && (tl.nrows & 63)) ? ((1ull << (tl.nrows & 63)) - 1) : ~0ull;
+   const u64 c = (tm[wd] | bm[wd]) & valid;
+   const u64 prev = wd ? (tm[wd - 1] | bm[wd - 1]) >> 63 : 0;
+   return c & ~((c << 1) | prev); }
+
+__device__ inline void build_runs_word(const Tile &tl, const DevCfg *cfg, int screen, int trk, int wd, int W,
+                                       RunRec *out, int base, int cap) {
+   const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk), *am = tl.map(screen, 2, trk);
+   const unsigned char *ldt = tl.ldmap(screen, 0, trk), *ldb = tl.ldmap(screen, 1, trk);
+   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
+   u64 starts = run_starts(tl, screen, trk, wd);
+   int k = base;
+   while (starts) {
+      const int bit = __ffsll((long long)starts) - 1;
+      starts &= starts - 1;
+      if (k >= cap) break;
+      const int n_s = wd * 64 + bit;
+      const int kind = ((tm[wd] >> bit) & 1) ? 0 : 1;              // top has priority at a row with both bits
+      const unsigned char *ld = kind ? ldb : ldt;
+      RunRec r;
+      r.n_s = (unsigned short)n_s; r.kind = (unsigned char)kind;
+      const int p = n_s - W + ld[n_s];                            // lo + left_distance - 1
+      r.p = (short)p; r.m = yb[p];
+      int len = 0;
+      for (int n = n_s; n < tl.nrows; ++n) { if (!(((tm[n >> 6] | bm[n >> 6]) >> (n & 63)) & 1)) break; ++len; }
+      r.len = (unsigned short)len;
+      unsigned fast = 0;
+      #pragma unroll
+      for (int j = 0; j < kRunFast; ++j) {
+         const int n = n_s + j;
+         int mg = 0;
+         if (j < len) {
+            const bool tb = (tm[n >> 6] >> (n & 63)) & 1, bb = (bm[n >> 6] >> (n & 63)) & 1;
+            const bool only_this = kind ? (bb && !tb) : (tb && !bb);
+            if (only_this && n - W + ld[n] == p && (kind == 0 || ((am[n >> 6] >> (n & 63)) & 1))) {
+               const int a = kind ? yb[n - W + 1] - r.m : r.m - yb[n - W + 1];
+               const int c = kind ? yb[n] - r.m : r.m - yb[n];
+               mg = min(min(a, c), 32767);
+               fast |= 1u << j; } }
+         r.marg[j] = (short)mg; }
+      r.fast = (unsigned char)fast; r.pad = 0;
+      r.v = volt(r.m, cfg->maxvolts);
+      out[k++] = r; } }
 
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
@@ -743,6 +835,11 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
    Rec *recs_all = reinterpret_cast<Rec *>(smem + off);
    off += (size_t)nwalk * cfg.rec_cap * sizeof(Rec);
    int *nrec_all = reinterpret_cast<int *>(smem + off);
+   off += (size_t)nwalk * 4;
+   off = (off + 15) & ~(size_t)15;
+   RunRec *runs_all = reinterpret_cast<RunRec *>(smem + off);
+   off += (size_t)cfg.nscreens * ntrks * cfg.run_cap * sizeof(RunRec);
+   int *runcnt = reinterpret_cast<int *>(smem + off);              // [nscreens*ntrks][32 words]
    cx.rec_cap = cfg.rec_cap;
    cx.recs = recs_all + (size_t)(is_walker ? my_w : 0) * cfg.rec_cap;
 
@@ -818,8 +915,28 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
                   cx.tile.reset = saved; }
                if (nr <= 0 || nr < NB.zone_first) nr = NB.zone_end - kMarginRows;
                stop = nr; } }
+         // run records for every (screen, track), by all lanes
+         {
+            const int nwords = (cx.tile.nrows + 63) >> 6;
+            const int nitems = cfg.nscreens * ntrks * nwords;
+            for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
+               const int st = i / nwords, wd = i - st * nwords;
+               runcnt[st * 32 + wd] = __popcll(run_starts(cx.tile, st / ntrks, st - (st / ntrks) * ntrks, wd)); }
+            __syncthreads();
+            for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
+               const int st = i / nwords, wd = i - st * nwords;
+               int base = 0;
+               for (int k = 0; k < wd; ++k) base += runcnt[st * 32 + k];
+               const int sc = st / ntrks;
+               build_runs_word(cx.tile, &cfg, sc, st - sc * ntrks, wd, cfg.screen[sc].W, runs_all + (size_t)st * cfg.run_cap, base, cfg.run_cap); }
+            __syncthreads(); }
          cx.nrec = 0;
-         if (active) walk(w, cx, pidx, trk, stop);
+         if (active) {
+            const int st = cfg.parm[pidx].screen * ntrks + trk;
+            const int nwords = (cx.tile.nrows + 63) >> 6;
+            int total = 0;
+            for (int k = 0; k < nwords; ++k) total += runcnt[st * 32 + k];
+            walk(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, total < cfg.run_cap ? total : cfg.run_cap, total); }
          if (is_walker) nrec_all[my_w] = cx.nrec;
          __syncthreads();
          for (int w2 = 0; w2 < nwalk; ++w2)                      // all lanes: refinement, volt conversion, event stores
