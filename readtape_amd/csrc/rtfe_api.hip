@@ -134,7 +134,8 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
                    + ((d.nscreens * 3 * c->ntrks * (d.tile_rows / 8) + 15) & ~15)
                    + ((d.nscreens * 2 * c->ntrks * d.tile_rows + 15) & ~15)
                    + c->nparmsets * c->ntrks * (10 * 4 + d.rec_cap * 12 + 4) + 128
-                   + d.nscreens * c->ntrks * (d.run_cap * 24 + 32 * 4) + 64);
+                   + d.nscreens * c->ntrks * (d.run_cap * 24 + 32 * 4) + 64
+                   + c->nparmsets * c->ntrks * 192 + 64);
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
    hipDeviceProp_t prop;
    int dev = 0;

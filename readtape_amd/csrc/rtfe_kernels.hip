@@ -80,10 +80,10 @@ struct BurstScratch {            // lives in the workspace
 static inline long long clock64() { return 0; }
 #endif
 
-__device__ inline bool quiet_at(const u64 *q, long long c, long long nchunks) {
+__device__ __forceinline__ bool quiet_at(const u64 *q, long long c, long long nchunks) {
    return c >= 0 && c < nchunks && ((q[c >> 6] >> (c & 63)) & 1); }
 
-__device__ inline int block_excl_scan_1024(int v, int *lds, int *total) {
+__device__ __forceinline__ int block_excl_scan_1024(int v, int *lds, int *total) {
    // exclusive scan of one int per thread over a 1024-thread block (16 waves)
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    int x = v;
@@ -209,19 +209,19 @@ struct Tile {
    unsigned char *ldpos;  // LDS: [nscreens][2][ntrks][tile_rows] left_distance of the first window max (0) / true min (1)
    int      ntrks;
    const int *skew;
-   __device__ inline int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + kHaloRows]; }
+   __device__ __forceinline__ int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + kHaloRows]; }
    // v_now of track t at row n in int16 units, with the deskew FIFO exactly as the reference runs it
    // from the restart row: undelayed until the FIFO has filled (src/decoder.c:825-827), then delayed
-   __device__ inline int y(int t, long long n) const {
+   __device__ __forceinline__ int y(int t, long long n) const {
       const int d = skew[t];
       return xi(t, (n - reset < d) ? n : n - d); }
-   __device__ inline const unsigned char *ldmap(int screen, int kind, int t) const {
+   __device__ __forceinline__ const unsigned char *ldmap(int screen, int kind, int t) const {
       return ldpos + ((size_t)(screen * 2 + kind) * ntrks + t) * (bstride * 8); }
-   __device__ inline const u64 *map(int screen, int kind, int t) const {
+   __device__ __forceinline__ const u64 *map(int screen, int kind, int t) const {
       return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 3 + kind) * ntrks + t) * bstride); }
 };
 
-__device__ inline float volt(int i, float maxvolts) {      // src/readtape.c:1420
+__device__ __forceinline__ float volt(int i, float maxvolts) {      // src/readtape.c:1420
    return (float)i / 32767 * maxvolts; }
 
 struct Walker {            // one per (parameter set, track); lives in registers
@@ -267,10 +267,10 @@ struct Ctx {               // per-workgroup constants for the walkers
    int     nrec;           // records queued in this tile
 };
 
-__device__ inline double time_of(const DevCfg *c, long long abs_row) {     // src/readtape.c:1423
+__device__ __forceinline__ double time_of(const DevCfg *c, long long abs_row) {     // src/readtape.c:1423
    return (double)(c->tstart_ns + abs_row * c->tdelta_ns) / 1e9; }
 
-__device__ inline void adjust_agc(Walker &w, const DevParm &P, float *heights) {    // src/decoder.c:500-531
+__device__ __forceinline__ void adjust_agc(Walker &w, const DevParm &P, float *heights) {    // src/decoder.c:500-531
    float gain, lastheight;
    if (P.agc_alpha) {
       lastheight = w.v_lasttop - w.v_lastbot;
@@ -292,7 +292,7 @@ __device__ inline void adjust_agc(Walker &w, const DevParm &P, float *heights) {
 
 // what the block decoder's callback does to the state the detector reads back, then the
 // post-callback bookkeeping of process_up/down_transition (src/decoder.c:587-590, 605-609)
-__device__ inline void agc_after_peak(Walker &w, const DevCfg *cfg, const DevParm &P, float *heights, bool is_top, double t_peak) {
+__device__ __forceinline__ void agc_after_peak(Walker &w, const DevCfg *cfg, const DevParm &P, float *heights, bool is_top, double t_peak) {
    ++w.peakcount;                                               // src/decoder.c:561
    if (cfg->mode == RTFE_PE) {
       if (w.datablock) adjust_agc(w, P, heights);               // src/decode_pe.c:175,198
@@ -323,7 +323,7 @@ __device__ inline void agc_after_peak(Walker &w, const DevCfg *cfg, const DevPar
    if (is_top) w.v_lasttop = w.v_top; else w.v_lastbot = w.v_bot;
    w.t_lastpeak = t_peak; }
 
-__device__ inline void update_thresholds(Walker &w, const DevParm &P, float lsb_per_volt) {
+__device__ __forceinline__ void update_thresholds(Walker &w, const DevParm &P, float lsb_per_volt) {
    w.rise = P.rise * (w.v_avg_height / 4.0f) / w.agc_gain;       // src/decoder.c:785-786
    w.reqmin = P.min_peak * (w.v_avg_height / 4.0f) / w.agc_gain;
    if (w.rise < P.screen_rise_v || (P.min_peak != 0 && w.reqmin < P.screen_minpk_v)) w.flags |= RTFE_F_SCREEN_UNDERFLOW;
@@ -335,12 +335,12 @@ __device__ inline void update_thresholds(Walker &w, const DevParm &P, float lsb_
    w.min_lo = m - 1; w.min_hi = m + 2; }
 
 // 1 = passes, 0 = fails: "v(a) > v(b) + thr" decided on the int16 codes when clear, else in floats
-__device__ inline bool above_by(int a, int b, float thr, int lo, int hi, float mv) {
+__device__ __forceinline__ bool above_by(int a, int b, float thr, int lo, int hi, float mv) {
    const int d = a - b;
    if (d >= hi) return true;
    if (d <= lo) return false;
    return volt(a, mv) > volt(b, mv) + thr; }
-__device__ inline bool below_by(int a, int b, float thr, int lo, int hi, float mv) {   // v(a) < v(b) - thr
+__device__ __forceinline__ bool below_by(int a, int b, float thr, int lo, int hi, float mv) {   // v(a) < v(b) - thr
    const int d = b - a;
    if (d >= hi) return true;
    if (d <= lo) return false;
@@ -348,7 +348,7 @@ __device__ inline bool below_by(int a, int b, float thr, int lo, int hi, float m
 
 
 // the half-sample refinement of refine_peak (src/decoder.c:712-731): 0 none, 1 = -0.5, 2 = +0.5
-__device__ inline int refine_code(const DevCfg *cfg, int val_i, int iprev, int inext, float agc_gain, bool is_top) {
+__device__ __forceinline__ int refine_code(const DevCfg *cfg, int val_i, int iprev, int inext, float agc_gain, bool is_top) {
    const float mv = cfg->maxvolts;
    const float val = volt(val_i, mv);
    const float thr = 0.005f / agc_gain;                            // PEAK_THRESHOLD / agc_gain (src/decoder.c:715,724)
@@ -366,7 +366,7 @@ __device__ inline int refine_code(const DevCfg *cfg, int val_i, int iprev, int i
    if (nclose && pfar) return 2;
    return 0; }
 
-__device__ inline void store_event(const Ctx &cx, int pidx, int trk, unsigned int idx, long long n, float val, float g,
+__device__ __forceinline__ void store_event(const Ctx &cx, int pidx, int trk, unsigned int idx, long long n, float val, float g,
                                    bool is_top, int adjcode, int left_distance) {
    rtfe_event e;
    e.sample = (uint32_t)(n - cx.tile.reset);
@@ -381,7 +381,7 @@ __device__ inline void store_event(const Ctx &cx, int pidx, int trk, unsigned in
 // refine_peak (src/decoder.c:700-749) + event emission + AGC mirror.  `lo` = first row of the window,
 // `p` = row of the first window element equal to the extreme.  With defer != 0 the refinement and the
 // event store are queued for finalize_tile() (possible whenever nothing downstream needs the peak time).
-__device__ inline void emit_peak(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, long long n,
+__device__ __forceinline__ void emit_peak(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, long long n,
                                  long long lo, long long p, float val, int val_i, bool is_top, bool defer) {
    const DevCfg *cfg = cx.cfg;
    const int left_distance = (int)(p - lo) + 1;
@@ -406,7 +406,7 @@ __device__ inline void emit_peak(Walker &w, Ctx &cx, int pidx, int trk, const De
    w.blind_until = n + left_distance; }                          // pkww_countdown = left_distance (src/decoder.c:741)
 
 // all lanes: turn this tile's queued records of one walker into events
-__device__ inline void finalize_records(const Ctx &cx, const Rec *recs, int nrec, int pidx, int trk, int lane, int nlanes) {
+__device__ __forceinline__ void finalize_records(const Ctx &cx, const Rec *recs, int nrec, int pidx, int trk, int lane, int nlanes) {
    const DevCfg *cfg = cx.cfg;
    const Tile &tl = cx.tile;
    const int W = cfg->parm[pidx].W;
@@ -420,12 +420,12 @@ __device__ inline void finalize_records(const Ctx &cx, const Rec *recs, int nrec
       store_event(cx, pidx, trk, r.idx, tl.row0 + n, volt(val_i, cfg->maxvolts), r.g, is_top, adjcode, r.ld); } }
 
 // exact window minimum and its first position (the rescan of src/decoder.c:767-775)
-__device__ inline void rescan_min(const Tile &tl, int trk, long long lo, long long hi, int &mn, long long &pos) {
+__device__ __forceinline__ void rescan_min(const Tile &tl, int trk, long long lo, long long hi, int &mn, long long &pos) {
    mn = 0x7fffffff; pos = lo;
    for (long long j = lo; j <= hi; ++j) { const int v = tl.y(trk, j); if (v < mn) { mn = v; pos = j; } } }
 
 // last forced rescan ("window maximum leaves the window") in rows (after, upto] of the current tile, or -1
-__device__ inline long long last_forced_rescan(const Tile &tl, int screen, int trk, long long after, long long upto) {
+__device__ __forceinline__ long long last_forced_rescan(const Tile &tl, int screen, int trk, long long after, long long upto) {
    const u64 *am = tl.map(screen, 2, trk);
    long long lo = after + 1 - tl.row0, hi = upto - tl.row0;          // tile-relative, inclusive
    if (lo < 0) lo = 0;
@@ -438,7 +438,7 @@ __device__ inline long long last_forced_rescan(const Tile &tl, int screen, int t
    return -1; }
 
 // bring the stale-minimum state forward to "after row n" using the rescan bitmap of this tile
-__device__ inline void advance_chain(Walker &w, const Tile &tl, int screen, int trk, int W, long long n) {
+__device__ __forceinline__ void advance_chain(Walker &w, const Tile &tl, int screen, int trk, int W, long long n) {
    if (n <= w.cpos && !w.chain_pending) return;
    const long long a = last_forced_rescan(tl, screen, trk, w.cpos, n);
    long long pos;
@@ -453,7 +453,7 @@ __device__ inline void advance_chain(Walker &w, const Tile &tl, int screen, int 
 
 // literal lookfor_peak for one row while the window is still filling or the deskew FIFO is in its
 // start-up regime (src/decoder.c:751-810 with the state of src/decoder.c:855-861).
-__device__ inline void slow_step(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, long long n) {
+__device__ __forceinline__ void slow_step(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, long long n) {
    const Tile &tl = cx.tile;
    const DevCfg *cfg = cx.cfg;
    const int W = P.W;
@@ -489,7 +489,7 @@ __device__ inline void slow_step(Walker &w, Ctx &cx, int pidx, int trk, const De
       w.slow_countdown = (int)(p - lo) + 1; } }
 
 // switch from the literal path to the screened path: derive the lazy stale-min state
-__device__ inline void enter_fast(Walker &w, const Tile &tl, int trk, int W, long long n_first_fast) {
+__device__ __forceinline__ void enter_fast(Walker &w, const Tile &tl, int trk, int W, long long n_first_fast) {
    const long long last = n_first_fast - 1;
    long long pos = last - W + 1;
    while (pos <= last && tl.y(trk, pos) != w.minv) ++pos;
@@ -516,7 +516,7 @@ struct RunRec {
 constexpr int kRunFast = 4;
 
 // exact evaluation of one candidate row (the flat body of the screened walker); returns true on a detection
-__device__ inline bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, int n, bool ctop, bool cbot, bool async) {
+__device__ __forceinline__ bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, int n, bool ctop, bool cbot, bool async) {
    const DevCfg *cfg = cx.cfg;
    const Tile &tl = cx.tile;
    const int W = P.W;
@@ -550,7 +550,7 @@ __device__ inline bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, const DevP
    return hit; }
 
 // one (parameter set, track) detector over rows [.., limit)
-__device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit, const RunRec *runs, int nruns, int nruns_total) {
+__device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit, const RunRec *runs, int nruns, int nruns_total) {
    const DevCfg *cfg = cx.cfg;
    const DevParm &P = cfg->parm[pidx];
    const Tile &tl = cx.tile;
@@ -570,7 +570,7 @@ __device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit, con
    long long n64 = max(w.next, w.blind_until + 1);
    int cur = (n64 - tl.row0 > lim) ? lim : (int)(n64 - tl.row0);       // first row not yet looked at
    for (int i = 0; i < nruns; ++i) {
-      const RunRec r = runs[i];
+      const RunRec &r = runs[i];                                     // stays in LDS: marg[] is indexed dynamically
       const int n_e = min((int)r.n_s + (int)r.len, lim);                // one past the last candidate row of this run
       int n = max((int)r.n_s, cur);
       // rows decidable from the record: integer margins against the guard-banded thresholds
@@ -617,7 +617,7 @@ __device__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit, con
 
 // all lanes: list the candidate runs of one (screen, track) of the current tile in row order.  A run = consecutive
 // rows with ANY candidate bit set; its record describes the extreme of the kind seen at its first row.
-__device__ inline u64 run_starts(const Tile &tl, int screen, int trk, int wd) {
+__device__ __forceinline__ u64 run_starts(const Tile &tl, int screen, int trk, int wd) {
    const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk);
    const int nwords = (tl.nrows + 63) >> 6;
    const u64 valid = (wd == nwords - 1 && (tl.nrows & 63)) ? ((1ull << (tl.nrows & 63)) - 1) : ~0ull;
@@ -625,7 +625,7 @@ __device__ inline u64 run_starts(const Tile &tl, int screen, int trk, int wd) {
    const u64 prev = wd ? (tm[wd - 1] | bm[wd - 1]) >> 63 : 0;
    return c & ~((c << 1) | prev); }
 
-__device__ inline void build_runs_word(const Tile &tl, const DevCfg *cfg, int screen, int trk, int wd, int W,
+__device__ __forceinline__ void build_runs_word(const Tile &tl, const DevCfg *cfg, int screen, int trk, int wd, int W,
                                        RunRec *out, int base, int cap) {
    const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk), *am = tl.map(screen, 2, trk);
    const unsigned char *ldt = tl.ldmap(screen, 0, trk), *ldb = tl.ldmap(screen, 1, trk);
@@ -666,7 +666,7 @@ __device__ inline void build_runs_word(const Tile &tl, const DevCfg *cfg, int sc
 
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
-__device__ inline void screen_strip(const Tile &tl, const DevScreen &sc, int screen, int trk, int strip) {
+__device__ __forceinline__ void screen_strip(const Tile &tl, const DevScreen &sc, int screen, int trk, int strip) {
    // Keys carry the position so that max/min also yield the FIRST window element equal to the extreme
    // (what refine_peak looks for, src/decoder.c:707-708): r = index relative to the strip's leftmost
    // window element (s0 - W + 1);  kmax = v<<8 | (255 - r)  (max -> largest v, then smallest r),
@@ -725,7 +725,7 @@ __device__ inline void screen_strip(const Tile &tl, const DevScreen &sc, int scr
    reinterpret_cast<u64 *>(tl.ldpos + ((size_t)(screen * 2 + 1) * tl.ntrks + trk) * (tl.bstride * 8))[strip] = ldb; }
 
 // cooperative tile load: rows [row0 - kHaloRows, row0 + nrows) of the AoS payload -> SoA LDS by track
-__device__ inline void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows) {
+__device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows) {
    const int ntrks = cfg->ntrks;
    const long long first = tl.row0 - kHaloRows;                   // multiple of 8 rows => 16-byte aligned
    const int nload = kHaloRows + tl.nrows;
@@ -756,7 +756,7 @@ __device__ inline void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__r
             if (r < nload) tl.x[cfg->head_to_trk[c] * tl.ldw + r] = (int16_t)(cfg->invert ? -sv : sv);
             if (++c == ntrks) { c = 0; ++r; } } } } }
 
-__device__ inline void run_screens(const DevCfg *cfg, const Tile &tl) {
+__device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl) {
    const int nstrips = (tl.nrows + kStrip - 1) / kStrip;
    const int per_screen = nstrips * cfg->ntrks;
    for (int s = 0; s < cfg->nscreens; ++s)
@@ -766,7 +766,7 @@ __device__ inline void run_screens(const DevCfg *cfg, const Tile &tl) {
 // restart row for the zone whose last kMarginRows rows are the current tile:
 // for every parameter set and track take the last forced rescan inside the zone; any restart at or
 // before (that row - W - max(trk, skew) - 1) has a full, regular window when the rescan happens.
-__device__ inline long long find_reset(const DevCfg *cfg, const Tile &tl, long long *lds_min) {
+__device__ __forceinline__ long long find_reset(const DevCfg *cfg, const Tile &tl, long long *lds_min) {
    if (threadIdx.x == 0) *lds_min = 0x7fffffffffffffffll;
    __syncthreads();
    const int nw = cfg->nparm * cfg->ntrks;
@@ -840,6 +840,9 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
    RunRec *runs_all = reinterpret_cast<RunRec *>(smem + off);
    off += (size_t)cfg.nscreens * ntrks * cfg.run_cap * sizeof(RunRec);
    int *runcnt = reinterpret_cast<int *>(smem + off);              // [nscreens*ntrks][32 words]
+   off += (size_t)cfg.nscreens * ntrks * 32 * 4;
+   off = (off + 15) & ~(size_t)15;
+   Walker *walkers = reinterpret_cast<Walker *>(smem + off);       // [nwalk]
    cx.rec_cap = cfg.rec_cap;
    cx.recs = recs_all + (size_t)(is_walker ? my_w : 0) * cfg.rec_cap;
 
@@ -872,11 +875,14 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
          t0 = B.zone_end - kMarginRows; }
       else t0 = reset & ~7ll;
       // ---- walker init: init_trackstate + init_trackpeak_state (src/decoder.c:413-455) ----
-      Walker w = {};
-      w.start = reset + trk; w.next = reset; w.blind_until = -1; w.fast = false;
-      w.agc_gain = 1.0f; w.v_avg_height = 4.0f;
-      update_thresholds(w, cfg.parm[pidx], cfg.lsb_per_volt);
-      if (is_walker) for (int i = 0; i < 10; ++i) cx.heights[i] = 0;
+      // (the walker's state lives in LDS between tiles so that the all-lane phases do not carry it in registers)
+      if (is_walker) {
+         Walker w = {};
+         w.start = reset + trk; w.next = reset; w.blind_until = -1; w.fast = false;
+         w.agc_gain = 1.0f; w.v_avg_height = 4.0f;
+         update_thresholds(w, cfg.parm[pidx], cfg.lsb_per_volt);
+         walkers[my_w] = w;
+         for (int i = 0; i < 10; ++i) cx.heights[i] = 0; }
       cx.tile.reset = reset;
       // ---- tiles ----
       const long long hard_end = single_exact ? (B.end_sample < nrows ? B.end_sample : nrows) : nrows;
@@ -936,7 +942,9 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
             const int nwords = (cx.tile.nrows + 63) >> 6;
             int total = 0;
             for (int k = 0; k < nwords; ++k) total += runcnt[st * 32 + k];
-            walk(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, total < cfg.run_cap ? total : cfg.run_cap, total); }
+            Walker w = walkers[my_w];
+            walk(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, total < cfg.run_cap ? total : cfg.run_cap, total);
+            walkers[my_w] = w; }
          if (is_walker) nrec_all[my_w] = cx.nrec;
          __syncthreads();
          for (int w2 = 0; w2 < nwalk; ++w2)                      // all lanes: refinement, volt conversion, event stores
@@ -952,8 +960,9 @@ __global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restr
          if (is_tail || tile0 >= hard_end) done = true; }
       // ---- publish ----
       if (is_walker) {
-         counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = active ? (w.nevents < cx.cap ? w.nevents : cx.cap) : 0;
-         if (w.flags) atomicOr(&s_flags, w.flags); }
+         const unsigned int ne = walkers[my_w].nevents, wf = walkers[my_w].flags;
+         counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = active ? (ne < cx.cap ? ne : cx.cap) : 0;
+         if (wf) atomicOr(&s_flags, wf); }
       __syncthreads();
       if (threadIdx.x == 0) {
          bursts[b].reset_sample = reset;

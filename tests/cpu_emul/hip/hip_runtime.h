@@ -21,6 +21,7 @@
 #define __shared__ static
 #define __restrict__
 #define __launch_bounds__(...)
+#define __forceinline__ inline
 #define RTFE_CPU_EMUL 1
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
