@@ -784,7 +784,7 @@ __device__ __forceinline__ long long find_reset(const DevCfg *cfg, const Tile &t
    __syncthreads();
    return r; }          // 0 => no provably safe restart row inside the margin
 
-__global__ void __launch_bounds__(kDecodeThreads) k_decode(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows,
+__global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows,
                                                            long long nrows, long long row_base,
                                                            rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
                                                            uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
