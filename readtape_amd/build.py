@@ -18,7 +18,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
              "-ffp-contract=off",            # bit-exact parity: the reference is C99 on SSE2, no FMA
              "-fno-fast-math", "-Wall", "-Wno-unused-function",
              f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
-HOST_SRCS = ["rt_decode_common.c", "rt_decode_nrzi.c", "rt_decode_pe.c", "rt_decode_gcr.c", "rt_parmsets.c", "rt_driver.c"]
+HOST_SRCS = ["rt_decode_common.c", "rt_decode_nrzi.c", "rt_decode_pe.c", "rt_decode_gcr.c", "rt_parmsets.c", "rt_driver.c", "rt_replay.c"]
 
 
 def _newer(target, deps):
@@ -42,9 +42,9 @@ def build_frontend(force=False, verbose=False):
 def build_host(force=False):
     out = os.path.join(HERE, "librtdecode.so")
     srcs = [os.path.join(CSRC, "host", f) for f in HOST_SRCS]
-    if force or _newer(out, srcs + [os.path.join(CSRC, "host", "rt_decode.h")]):
+    if force or _newer(out, srcs + [os.path.join(CSRC, "host", "rt_decode.h"), os.path.join(CSRC, "host", "rt_replay.h")]):
         subprocess.run(["gcc", "-std=gnu99", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-D_DEFAULT_SOURCE",
-                        "-Wall", f"-I{os.path.join(CSRC, 'host')}", "-o", out] + srcs + ["-lm"], check=True)
+                        "-Wall", f"-I{os.path.join(CSRC, 'host')}", f"-I{os.path.join(ROOT, 'include')}", "-o", out] + srcs + ["-lm"], check=True)
     return out
 
 

@@ -1,0 +1,266 @@
+/* rt_replay.c — drives the host block decoders from the device front end's event lists.
+ *
+ * This is the counterpart of the reference's readblock()/process_sample() control flow
+ * (src/readtape.c:1396-1517, src/decoder.c:817-905) with the per-sample detectors removed: the
+ * detectors ran on the GPU (include/rt_frontend.h) and left, per block attempt and parameter set, the
+ * exact sequence of top/bottom detections.  What remains sequential — and is reproduced here row for
+ * row, but only at rows where something happens — is:
+ *   - the staggered track start (t_lastpeak = time of row s0+trk, src/decoder.c:855-861),
+ *   - the NRZI mid-bit timer (src/decoder.c:844-845), the PE and GCR idle timers (:868-888),
+ *   - the interblock skip (src/decoder.c:841-842, 901-904),
+ *   - end of data (src/readtape.c:1410-1413),
+ * in exactly the order process_sample() interleaves them with the detections of a row.
+ *
+ * Speculation check: an attempt that starts at row s0 may use burst b only if
+ * zone_first <= s0 <= safe_last and the burst is not flagged; it may run past the burst's end only
+ * while it has not seen a single event (fresh state == the next burst's fresh state).  Otherwise the
+ * `exact` callback is asked for an exact device scan of this one attempt.  No detector code runs here.
+ */
+#include "rt_replay.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static double time_of_row(const struct rt_replay *rp, int64_t row) {        /* src/readtape.c:1423 */
+   return (double)(rp->tstart_ns + row * rp->tdelta_ns) / 1e9; }
+
+/* smallest row >= from with pred(time_of_row(row)) true, for a predicate that is monotone in time;
+ * `guess_time` is where it is expected to flip.  Returns limit if not before limit. */
+typedef int (*time_pred)(const struct rt_dec *d, const struct rt_trk *t, double timenow);
+static int64_t first_row_where(const struct rt_replay *rp, time_pred pred, const struct rt_trk *t,
+                               double guess_time, int64_t from, int64_t limit) {
+   double g = (guess_time * 1e9 - (double)rp->tstart_ns) / (double)rp->tdelta_ns;
+   int64_t r = (g < (double)from) ? from : (g > (double)limit ? limit : (int64_t)g);
+   if (r < from) r = from;
+   if (r > limit) r = limit;
+   struct rt_dec *d = rp->d;
+   /* walk down while the predicate still holds just below, then up until it holds */
+   while (r > from && pred(d, t, time_of_row(rp, r - 1))) --r;
+   while (r < limit && !pred(d, t, time_of_row(rp, r))) ++r;
+   return r; }
+
+static int pred_nrzi(const struct rt_dec *d, const struct rt_trk *t, double timenow) {
+   (void)t;
+   return timenow > d->nrzi.t_lastclock + 2 * d->nrzi.clkavg.t_bitspaceavg; }     /* src/decoder.c:844 */
+static int pred_pe(const struct rt_dec *d, const struct rt_trk *t, double timenow) {
+   (void)d;
+   return timenow - t->t_lastpeak > t->clkavg.t_bitspaceavg * 2.5f; }            /* src/decoder.c:868 */
+static int pred_gcr(const struct rt_dec *d, const struct rt_trk *t, double timenow) {
+   (void)d;
+   return timenow > t->t_lastpeak + 6.00 * t->clkavg.t_bitspaceavg; }            /* src/decoder.c:880 */
+
+/* ---- the event source of one attempt: per-track lists of one (burst, parmset) ---- */
+struct evsrc {
+   const rtfe_event *list[RT_MAXTRKS];
+   uint32_t n[RT_MAXTRKS], at[RT_MAXTRKS];
+   int64_t reset;           /* absolute row of sample 0 */
+   int64_t end;             /* rows >= end are not covered by this source */
+};
+
+static void evsrc_from_burst(struct evsrc *s, const struct rt_replay *rp, int64_t b, int parmset) {
+   const rtfe_burst *B = &rp->bursts[b];
+   for (int t = 0; t < rp->ntrks; ++t) {
+      s->list[t] = rp->events + B->event_base + (uint64_t)(parmset * rp->ntrks + t) * B->event_cap;
+      s->n[t] = rp->counts[((size_t)b * rp->nparm + parmset) * rp->ntrks + t];
+      s->at[t] = 0; }
+   s->reset = B->reset_sample - rp->row_base;
+   s->end = B->end_sample - rp->row_base; }
+
+static int64_t evsrc_next_row(const struct evsrc *s, int ntrks) {
+   int64_t best = INT64_MAX;
+   for (int t = 0; t < ntrks; ++t)
+      if (s->at[t] < s->n[t]) { int64_t r = s->reset + s->list[t][s->at[t]].sample; if (r < best) best = r; }
+   return best; }
+
+static void evsrc_skip_before(struct evsrc *s, int ntrks, int64_t row) {
+   for (int t = 0; t < ntrks; ++t)
+      while (s->at[t] < s->n[t] && s->reset + s->list[t][s->at[t]].sample < row) ++s->at[t]; }
+
+static int64_t find_burst(const struct rt_replay *rp, int64_t s0) {
+   /* last burst whose zone starts at or before s0 */
+   int64_t lo = 0, hi = rp->nbursts - 1, ans = -1;
+   const int64_t a = s0 + rp->row_base;
+   while (lo <= hi) {
+      int64_t mid = (lo + hi) / 2;
+      if (rp->bursts[mid].zone_first <= a) { ans = mid; lo = mid + 1; } else hi = mid - 1; }
+   if (ans < 0) return -1;
+   const rtfe_burst *B = &rp->bursts[ans];
+   if ((B->flags & (RTFE_F_UNSAFE | RTFE_F_EVENT_OVERFLOW | RTFE_F_SCREEN_UNDERFLOW | RTFE_F_DETECTOR_FATAL)) || a > B->safe_last) return -1;
+   return ans; }
+
+static int burst_usable(const struct rt_replay *rp, int64_t b) {
+   if (b < 0 || b >= rp->nbursts) return 0;
+   return !(rp->bursts[b].flags & (RTFE_F_UNSAFE | RTFE_F_EVENT_OVERFLOW | RTFE_F_SCREEN_UNDERFLOW | RTFE_F_DETECTOR_FATAL)); }
+
+void rt_replay_save_pos(void *ctx) {
+   struct rt_replay *rp = (struct rt_replay *)ctx;
+   rp->saved_pos = rp->pos; rp->saved_time = rp->d->timenow; }
+
+void rt_replay_restore_pos(void *ctx) {
+   struct rt_replay *rp = (struct rt_replay *)ctx;
+   rp->pos = rp->saved_pos; rp->d->timenow = rp->saved_time; }
+
+/* one transition, exactly as lookfor_peak/refine_peak hand it to process_*_transition */
+static void deliver(struct rt_replay *rp, const struct evsrc *s, int trk, const rtfe_event *e, int W) {
+   struct rt_dec *d = rp->d;
+   struct rt_trk *t = &d->trk[trk];
+   const int adjc = (e->flags >> 1) & 3;
+   const float adj = adjc == 1 ? -0.5f : (adjc == 2 ? 0.5f : 0.0f);
+   (void)s;
+   const double tp = d->timenow - ((float)(W - e->left_distance) - adj) * d->sample_deltat;   /* src/decoder.c:732 */
+   uint32_t ga, gb;
+   memcpy(&ga, &t->agc_gain, 4); memcpy(&gb, &e->agc_gain, 4);
+   if (ga != gb) ++rp->agc_mismatches;        /* the device's AGC mirror and the decoder's own AGC must agree bit for bit */
+   if (e->flags & 1) { t->v_bot = e->v_peak; t->t_bot = tp; rt_down_transition(d, t); }
+   else { t->v_top = e->v_peak; t->t_top = tp; rt_up_transition(d, t); }
+   ++rp->events_delivered; }
+
+int rt_replay_readblock(void *ctx, int retry) {
+   struct rt_replay *rp = (struct rt_replay *)ctx;
+   struct rt_dec *d = rp->d;
+   const int ntrks = rp->ntrks, parmset = d->parmset;
+   const int W = rp->W[parmset];
+   const int64_t s0 = rp->pos;
+   const int64_t nrows = rp->nrows;
+   int endfile = 0;
+   (void)retry;
+   ++rp->attempts;
+   if (s0 >= nrows) { rt_finish_attempt(d); return 0; }     /* no row was processed: no forced end of block */
+
+   struct evsrc src;
+   int64_t b = find_burst(rp, s0);
+   rtfe_event *exact_events = NULL;
+   int using_exact = 0;
+   int restarted = 0;
+   /* an exact scan covers this attempt only: up to the end of the device burst after the one s0 lies in,
+    * extended (x4) in the rare case the attempt runs longer */
+   int64_t exact_len = 1 << 16;
+   for (int64_t k = 0; k < rp->nbursts; ++k)
+      if (rp->bursts[k].zone_first - rp->row_base > s0) { exact_len = rp->bursts[k].end_sample - rp->row_base - s0; break; }
+   if (exact_len < (1 << 12)) exact_len = 1 << 12;
+restart:
+   if (b < 0) {                                               /* outside every proven-safe zone: exact device scan */
+      if (!rp->exact) { d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
+      uint32_t cnt[RT_MAXTRKS]; rtfe_burst eb; uint32_t cap = 0;
+      if (exact_events && rp->exact_free) { rp->exact_free(rp->exact_user, exact_events); exact_events = NULL; }
+      const int64_t ex_end = s0 + exact_len < nrows ? s0 + exact_len : nrows;
+      if (rp->exact(rp->exact_user, s0, ex_end, parmset, &eb, cnt, &exact_events, &cap) != 0) {
+         d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
+      for (int t = 0; t < ntrks; ++t) { src.list[t] = exact_events + (uint64_t)t * cap; src.n[t] = cnt[t]; src.at[t] = 0; }
+      src.reset = s0; src.end = ex_end;
+      using_exact = 1; ++rp->exact_scans; }
+   else { evsrc_from_burst(&src, rp, b, parmset); evsrc_skip_before(&src, ntrks, s0); }
+
+   int64_t events_seen = 0;
+   int64_t row = s0;                 /* next row to "process" */
+   int ntrk_started = 0;             /* tracks whose staggered start row has passed */
+   for (;;) {
+      /* ---- the next row at which anything can happen ---- */
+      int64_t next = nrows;
+      if (d->interblock_counter) {                          /* rows are skipped; the attempt returns when it reaches 0 */
+         next = row + d->interblock_counter - 1; if (next > nrows) next = nrows; }
+      else {
+         if (ntrk_started < ntrks) { int64_t r = s0 + ntrk_started; if (r < next) next = r; }
+         int64_t r = evsrc_next_row(&src, ntrks); if (r < next) next = r;
+         if (d->opt.mode == RT_NRZI && d->nrzi.datablock) {
+            r = first_row_where(rp, pred_nrzi, NULL, d->nrzi.t_lastclock + 2 * d->nrzi.clkavg.t_bitspaceavg, row, next);
+            if (r < next) next = r; }
+         if (d->opt.mode == RT_PE)
+            for (int t = 0; t < ntrks; ++t) {
+               struct rt_trk *tk = &d->trk[t];
+               if (!tk->idle && tk->t_lastpeak != 0) {
+                  r = first_row_where(rp, pred_pe, tk, tk->t_lastpeak + tk->clkavg.t_bitspaceavg * 2.5f, row, next);
+                  if (r < next) next = r; } }
+         if (d->opt.mode == RT_GCR)
+            for (int t = 0; t < ntrks; ++t) {
+               struct rt_trk *tk = &d->trk[t];
+               if (tk->datablock) {
+                  r = first_row_where(rp, pred_gcr, tk, tk->t_lastpeak + 6.00 * tk->clkavg.t_bitspaceavg, row, next);
+                  if (r < next) next = r; } } }
+      /* the event source ends before anything else happens? */
+      if (using_exact && !d->interblock_counter && next >= src.end && src.end < nrows) {
+         exact_len *= 4;                                       /* the attempt is longer than the exact scan: rescan further */
+         rt_init_trackstate(d); d->interblock_counter = 0;
+         goto restart; }
+      if (!using_exact && !d->interblock_counter && next >= src.end && src.end < nrows) {
+         if (events_seen == 0 && burst_usable(rp, b + 1)) {   /* still fresh: the next burst's fresh state is the same state */
+            ++b; evsrc_from_burst(&src, rp, b, parmset); evsrc_skip_before(&src, ntrks, row); ++rp->chained;
+            continue; }
+         if (restarted) { d->results[parmset].blktype = RT_BS_ABORTED; break; }
+         /* this attempt crosses a device restart with state: redo it from s0 with an exact scan */
+         restarted = 1; b = -1;
+         rt_init_trackstate(d);
+         d->interblock_counter = 0;
+         goto restart; }
+      if (next >= nrows) {                                   /* end of data, src/readtape.c:1410-1413 */
+         d->timenow = time_of_row(rp, nrows - 1);
+         rt_force_end_of_block(d);
+         rp->pos = nrows;
+         endfile = 1;
+         break; }
+      row = next;
+      d->timenow = time_of_row(rp, row);
+      /* ---- process_sample for this row (src/decoder.c:841-904) ---- */
+      if (d->interblock_counter) {                          /* we jumped to the row on which the countdown ends */
+         d->interblock_counter = 0;
+         rp->pos = row + 1;
+         break; }
+      if (d->opt.mode == RT_NRZI && rt_nrzi_zerocheck_due(d)) rt_nrzi_zerocheck(d);
+      int stop_row = 0;
+      for (int t = 0; t < ntrks && !stop_row; ++t) {
+         struct rt_trk *tk = &d->trk[t];
+         if (tk->t_lastpeak == 0) {                          /* first row of this track, src/decoder.c:855-861 */
+            tk->v_lastpeak = 0;
+            tk->t_lastpeak = d->timenow;
+            if (t >= ntrk_started) ntrk_started = t + 1;
+            break; }
+         while (src.at[t] < src.n[t] && src.reset + src.list[t][src.at[t]].sample == row) {
+            deliver(rp, &src, t, &src.list[t][src.at[t]], W);
+            ++src.at[t]; ++events_seen; }
+         if (d->opt.mode == RT_PE && rt_pe_idle_due(d, tk)) rt_pe_go_idle(d, tk);
+         if (d->opt.mode == RT_GCR && rt_gcr_idle_due(d, tk)) if (rt_gcr_go_idle(d, tk)) stop_row = 1; }
+      /* events of tracks the reference did not reach on this row cannot exist; drop anything stale */
+      evsrc_skip_before(&src, ntrks, row + 1);
+      /* exit: (src/decoder.c:900-904) */
+      if (d->interblock_counter) {
+         if (--d->interblock_counter) { ++row; continue; }
+         rp->pos = row + 1; break; }
+      if (d->results[parmset].blktype != RT_BS_NONE) { rp->pos = row + 1; break; }
+      ++row; }
+   if (exact_events && rp->exact_free) rp->exact_free(rp->exact_user, exact_events);
+   rt_finish_attempt(d);
+   return !endfile; }
+
+int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *tap_path, const char *log_path, struct rt_replay_stats *stats) {
+   const float sample_deltat = (float)tdelta_ns / 1e9f;              /* src/readtape.c:1345 */
+   struct rt_dec *d = rt_dec_new(opt, sample_deltat, tdelta_ns);
+   if (!d) return -1;
+   if (parmsets) {
+      memset(d->parmsets, 0, sizeof d->parmsets);
+      memcpy(d->parmsets, parmsets, sizeof(struct rt_parms) * (size_t)nparm); }
+   else for (int i = nparm; i < RT_MAXPARMSETS; ++i) d->parmsets[i].active = 0;   /* only the scanned sets are usable */
+   if (tap_path) d->tapf = fopen(tap_path, "wb");
+   if (log_path) d->logf = fopen(log_path, "w");
+   struct rt_replay rp; memset(&rp, 0, sizeof rp);
+   rp.d = d; rp.ntrks = opt->ntrks; rp.nparm = nparm;
+   for (int i = 0; i < nparm; ++i) rp.W[i] = W[i];
+   rp.nrows = nrows; rp.row_base = row_base; rp.tstart_ns = tstart_ns; rp.tdelta_ns = tdelta_ns;
+   rp.bursts = bursts; rp.nbursts = nbursts; rp.counts = counts; rp.events = events;
+   rp.exact = exact; rp.exact_free = exact_free; rp.exact_user = user;
+   struct rt_reader rd = { rt_replay_readblock, rt_replay_save_pos, rt_replay_restore_pos, &rp };
+   const int ok = rt_process_blocks(d, &rd, 0x7fffffff);
+   if (stats) {
+      stats->attempts = rp.attempts; stats->exact_scans = rp.exact_scans; stats->chained = rp.chained;
+      stats->events_delivered = rp.events_delivered; stats->agc_mismatches = rp.agc_mismatches;
+      stats->blocks = d->numblks; stats->tapemarks = d->numtapemarks; stats->blocks_with_errors = d->numblks_err;
+      stats->blocks_with_warnings = d->numblks_warn; stats->blocks_unusable = d->numblks_unusable; stats->all_ok = ok;
+      stats->data_bytes = d->numdatabytes; }
+   if (d->tapf) fclose(d->tapf);
+   if (d->logf) fclose(d->logf);
+   rt_dec_free(d);
+   return 0; }

@@ -1,0 +1,53 @@
+/* rt_replay.h — event replay: device front-end output -> host block decoders -> SIMH .tap (see rt_replay.c) */
+#ifndef RT_REPLAY_H
+#define RT_REPLAY_H
+#include "rt_decode.h"
+#include "rt_frontend.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* asks the caller for an exact device scan (rtfe_scan_exact) of one attempt: rows [reset_row, end_row) of the
+ * scanned slice, one parameter set.  On success fills *burst, counts[ntrks], *events (regions of *cap events per
+ * track, track-major) and returns 0. */
+typedef int  (*rt_exact_fn)(void *user, int64_t reset_row, int64_t end_row, int parmset,
+                            rtfe_burst *burst, uint32_t *counts, rtfe_event **events, uint32_t *cap);
+typedef void (*rt_exact_free_fn)(void *user, rtfe_event *events);
+
+struct rt_replay {
+   struct rt_dec *d;
+   int     ntrks, nparm;
+   int     W[RT_MAXPARMSETS];          /* rtfe_pkww_width() per parameter set */
+   int64_t nrows, row_base, tstart_ns, tdelta_ns;
+   const rtfe_burst *bursts; int64_t nbursts;
+   const uint32_t   *counts;
+   const rtfe_event *events;
+   rt_exact_fn exact; rt_exact_free_fn exact_free; void *exact_user;
+   int64_t pos, saved_pos; double saved_time;
+   /* statistics */
+   int64_t attempts, exact_scans, chained, events_delivered, agc_mismatches;
+};
+
+int  rt_replay_readblock(void *ctx, int retry);
+void rt_replay_save_pos(void *ctx);
+void rt_replay_restore_pos(void *ctx);
+
+struct rt_replay_stats {
+   int64_t attempts, exact_scans, chained, events_delivered, agc_mismatches;
+   int32_t blocks, tapemarks, blocks_with_errors, blocks_with_warnings, blocks_unusable, all_ok;
+   int64_t data_bytes;
+};
+
+/* Decodes a whole scanned tape: builds a decoder for `opt` (+ `parmsets`, NULL = built-in sets), replays the
+ * device output through the retry/selection driver and writes tap_path / log_path (NULL = none). */
+int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *tap_path, const char *log_path, struct rt_replay_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,147 @@
+"""End-to-end decode: TBIN rows -> HIP front end (librtfe.so) -> event replay + block decoders
+(librtdecode.so) -> SIMH .tap.  The counterpart of the reference's `process_file()` for one tape
+(src/readtape.c:1564-1889), with `readblock()` replaced by the device scan + replay.
+
+The analog front end runs only on the GPU; the host code below never looks at a sample."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import frontend
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Options(C.Structure):          # struct rt_options (csrc/host/rt_decode.h)
+    _fields_ = [("mode", C.c_int), ("ntrks", C.c_int), ("bpi", C.c_float), ("ips", C.c_float),
+                ("specified_parity", C.c_int), ("revparity", C.c_int), ("do_correction", C.c_int),
+                ("find_zeros", C.c_int), ("do_differentiate", C.c_int), ("multiple_tries", C.c_int),
+                ("tap_format", C.c_int), ("add_parity", C.c_int), ("verbose", C.c_int)]
+
+
+class _Parms(C.Structure):            # struct rt_parms
+    _fields_ = [("active", C.c_int), ("clk_window", C.c_int), ("clk_alpha", C.c_float), ("agc_window", C.c_int),
+                ("agc_alpha", C.c_float), ("min_peak", C.c_float), ("clk_factor", C.c_float), ("pulse_adj", C.c_float),
+                ("pkww_bitfrac", C.c_float), ("pkww_rise", C.c_float), ("midbit", C.c_float), ("z1pt", C.c_float),
+                ("z2pt", C.c_float), ("tried", C.c_int), ("chosen", C.c_int)]
+
+
+class _Stats(C.Structure):            # struct rt_replay_stats
+    _fields_ = [("attempts", C.c_int64), ("exact_scans", C.c_int64), ("chained", C.c_int64),
+                ("events_delivered", C.c_int64), ("agc_mismatches", C.c_int64),
+                ("blocks", C.c_int32), ("tapemarks", C.c_int32), ("blocks_with_errors", C.c_int32),
+                ("blocks_with_warnings", C.c_int32), ("blocks_unusable", C.c_int32), ("all_ok", C.c_int32),
+                ("data_bytes", C.c_int64)]
+
+
+_EXACT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_uint32),
+                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
+_FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+def _load_decode_lib():
+    path = os.path.join(HERE, "librtdecode.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
+    lib.rt_default_parmsets.argtypes = [C.c_int, C.POINTER(_Parms)]
+    lib.rt_parse_parms_text.argtypes = [C.c_int, C.c_char_p, C.POINTER(_Parms)]
+    lib.rt_replay_run.argtypes = [C.POINTER(_Options), C.POINTER(_Parms), C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                  C.POINTER(C.c_int), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _EXACT_FN, _FREE_FN, C.c_void_p,
+                                  C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
+    return lib
+
+
+@dataclass
+class DecodeOptions:
+    """The reference's command-line switches that matter after the front end (src/readtape.c:936-1022)."""
+    multiple_tries: bool = False      # -m
+    correct: bool = False             # -correct
+    even_parity: bool = False         # -even
+    revparity: int = 0                # -revparity=n
+    verbose: bool = True              # -v
+    nparmsets: int | None = None      # how many built-in parameter sets to scan (default: 1, or all with -m)
+
+
+def default_parmsets(mode, n):
+    lib = _load_decode_lib()
+    arr = (_Parms * 15)()
+    lib.rt_default_parmsets(mode, arr)
+    return [arr[i] for i in range(15) if arr[i].active][:n]
+
+
+def frontend_parmsets(full):
+    """The front-end half of full parameter sets."""
+    return [(p.pkww_bitfrac, p.pkww_rise, p.min_peak, p.agc_alpha, p.agc_window, p.clk_factor) for p in full]
+
+
+def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
+                skew=None, invert=False, parms_text: str | None = None):
+    """Decodes one tape; returns (stats dict, ScanResult).  `fe_factory(cfg)` builds the front end
+    (default: the GPU one; tests/cpu_emul passes the emulated library)."""
+    opts = opts or DecodeOptions()
+    lib = _load_decode_lib()
+    mode = hdr.mode
+    nsets = opts.nparmsets or (15 if opts.multiple_tries else 1)
+    if parms_text:
+        arr = (_Parms * 15)()
+        n = lib.rt_parse_parms_text(mode, parms_text.encode(), arr)
+        if n <= 0:
+            raise ValueError("bad .parms text")
+        full = [arr[i] for i in range(n)][:nsets]
+    else:
+        full = default_parmsets(mode, nsets)
+    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert)
+    fe = (fe_factory or frontend.FrontEnd)(cfg)
+    res = fe.scan(rows).fetch()
+    nrows = int(rows.shape[0])
+
+    o = _Options(mode=mode, ntrks=hdr.ntrks, bpi=cfg.bpi, ips=cfg.ips, specified_parity=0 if opts.even_parity else 1,
+                 revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=0, do_differentiate=0,
+                 multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
+    parr = (_Parms * len(full))(*full)
+    W = (C.c_int * len(full))(*fe.widths)
+    keep = {}
+
+    def exact(user, reset_row, end_row, parmset, burst_out, counts_out, events_out, cap_out):
+        try:
+            ex = fe.scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset).fetch()
+            if int(ex.bursts[0]["flags"]) & frontend.F_SCREEN_UNDERFLOW:
+                ex = fe.scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset, screen_off=True).fetch()
+            B = ex.bursts[0]
+            if int(B["flags"]) & (frontend.F_EVENT_OVERFLOW | frontend.F_DETECTOR_FATAL):
+                return 1
+            cap = int(B["event_cap"])
+            T = hdr.ntrks
+            base = int(B["event_base"]) + parmset * T * cap
+            ev = np.ascontiguousarray(ex._events[base: base + T * cap])
+            C.memmove(burst_out, B.tobytes(), frontend.BURST_DTYPE.itemsize)
+            for t in range(T):
+                counts_out[t] = int(ex.counts[0, parmset, t])
+            events_out[0] = ev.ctypes.data
+            cap_out[0] = cap
+            keep[ev.ctypes.data] = ev
+            return 0
+        except Exception:
+            return 2
+
+    def free(user, ptr):
+        keep.pop(ptr, None)
+
+    st = _Stats()
+    bursts = np.ascontiguousarray(res.bursts)
+    counts = np.ascontiguousarray(res.counts)
+    events = res._events
+    rc = lib.rt_replay_run(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, nrows, 0, W,
+                           bursts.ctypes.data, len(bursts), counts.ctypes.data, events.ctypes.data,
+                           _EXACT_FN(exact), _FREE_FN(free), None,
+                           tap_path.encode() if tap_path else None, log_path.encode() if log_path else None, C.byref(st))
+    if rc != 0:
+        raise RuntimeError("rt_replay_run failed")
+    stats = {k: getattr(st, k) for k, _ in _Stats._fields_}
+    stats["bursts"] = res.nbursts
+    return stats, res

@@ -1,0 +1,31 @@
+"""End-to-end on the CPU (kernel sources under tests/cpu_emul): front end -> event replay -> block decoders
+-> SIMH .tap, byte-compared with the UNMODIFIED reference's .tap stored in the golden vectors."""
+import os
+
+import pytest
+
+from emul_util import emul_frontend
+from golden_util import load_case
+from readtape_amd import pipeline
+
+CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m"]
+
+
+def decode_case(g, tmp_path, fe_factory):
+    o = g["oracle_opts"]
+    skew = next(([int(x) for x in a[6:].split(",")] for a in o if a.startswith("-skew=")), None)
+    opts = pipeline.DecodeOptions(multiple_tries="-m" in o, correct="-correct" in o)
+    tap = os.path.join(str(tmp_path), "out.tap")
+    stats, res = pipeline.decode_tape(g["hdr"], g["rows"], tap, log_path=tap + ".log", opts=opts, fe_factory=fe_factory,
+                                      skew=skew, invert="-invert" in o)
+    return open(tap, "rb").read(), stats
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_tap_bytes_match_reference(name, tmp_path):
+    g = load_case(name)
+    tap, stats = decode_case(g, tmp_path, emul_frontend)
+    print(name, stats)
+    assert tap == g["tap"], f"{name}: .tap differs from the reference's ({len(tap)} vs {len(g['tap'])} bytes)"
+    assert stats["agc_mismatches"] == 0
+    assert stats["events_delivered"] > 0

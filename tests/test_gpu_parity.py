@@ -99,3 +99,28 @@ def test_large_tape_properties(gpu):
     for j in (0, 1, k // 2, k - 1):
         got = flat(rk, j * n, (j + 1) * n)
         assert got.shape == ref.shape and (got == ref).all(), f"copy {j}"
+
+
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m"])
+def test_end_to_end_tap_bytes_match_reference(name, tmp_path, gpu):
+    """GPU front end -> event replay -> block decoders -> SIMH .tap == the unmodified reference's .tap (golden)."""
+    from test_emul_replay import decode_case
+    g = load_case(name)
+    tap, stats = decode_case(g, tmp_path, None)
+    assert tap == g["tap"]
+    assert stats["agc_mismatches"] == 0 and stats["events_delivered"] > 0
+
+
+def test_end_to_end_fresh_tape_vs_oracle_tap(tmp_path, gpu):
+    """A fresh 60-block tape: .tap from the GPU pipeline == .tap from the CPU oracle; every block start speculative."""
+    import subprocess
+    from parity_util import ORACLE, build_oracle
+    from readtape_amd import pipeline, tbin
+    tape = synth.nrzi_tape(seed=61, nblocks=60, minlen=16, maxlen=3000, marks_every=7, gap_samples=5000)
+    hdr = tape.spec.header()
+    build_oracle()
+    tbin.write_tbin(str(tmp_path / "t.tbin"), hdr, tape.rows)
+    subprocess.run([ORACLE, f"-out={tmp_path}/o", str(tmp_path / "t.tbin")], check=True)
+    stats, _ = pipeline.decode_tape(hdr, tape.rows, str(tmp_path / "g.tap"))
+    assert open(tmp_path / "g.tap", "rb").read() == open(tmp_path / "o.tap", "rb").read()
+    assert stats["exact_scans"] == 0 and stats["agc_mismatches"] == 0 and stats["blocks"] == 60
