@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 static double time_of_row(const struct rt_replay *rp, int64_t row) {        /* src/readtape.c:1423 */
    return (double)(rp->tstart_ns + row * rp->tdelta_ns) / 1e9; }
@@ -60,6 +61,7 @@ struct evsrc {
 
 static void evsrc_from_burst(struct evsrc *s, const struct rt_replay *rp, int64_t b, int parmset) {
    const rtfe_burst *B = &rp->bursts[b];
+   if (rp->find_zeros) parmset = 0;           /* the zero-crossing front end does not depend on the parameter set */
    for (int t = 0; t < rp->ntrks; ++t) {
       s->list[t] = rp->events + B->event_base + (uint64_t)(parmset * rp->ntrks + t) * B->event_cap;
       s->n[t] = rp->counts[((size_t)b * rp->nparm + parmset) * rp->ntrks + t];
@@ -105,9 +107,21 @@ void rt_replay_restore_pos(void *ctx) {
 static void deliver(struct rt_replay *rp, const struct evsrc *s, int trk, const rtfe_event *e, int W) {
    struct rt_dec *d = rp->d;
    struct rt_trk *t = &d->trk[trk];
+   if (rp->find_zeros) {
+      /* a confirmed zero crossing (src/decoder.c:625-630, 639-644): the extreme is new, the opposite excursion
+       * restarts, and the transition counts only if the excursion was reached soon enough after the crossing */
+      uint32_t delay; memcpy(&delay, &e->agc_gain, 4);
+      const int64_t cross_row = s->reset + (int64_t)e->sample - (int64_t)delay;
+      const double t_cross = (double)(rp->tstart_ns + cross_row * rp->tdelta_ns) / 1e9;
+      if (e->flags & 1) {
+         t->v_bot = e->v_peak; t->t_bot = t_cross; t->v_top = 0;
+         if (d->timenow - t->t_bot <= t->clkavg.t_bitspaceavg * 1.5f) { rt_down_transition(d, t); ++rp->events_delivered; } }
+      else {
+         t->v_top = e->v_peak; t->t_top = t_cross; t->v_bot = 0;
+         if (d->timenow - t->t_top <= t->clkavg.t_bitspaceavg * 1.5f) { rt_up_transition(d, t); ++rp->events_delivered; } }
+      return; }
    const int adjc = (e->flags >> 1) & 3;
    const float adj = adjc == 1 ? -0.5f : (adjc == 2 ? 0.5f : 0.0f);
-   (void)s;
    const double tp = d->timenow - ((float)(W - e->left_distance) - adj) * d->sample_deltat;   /* src/decoder.c:732 */
    uint32_t ga, gb;
    memcpy(&ga, &t->agc_gain, 4); memcpy(&gb, &e->agc_gain, 4);
@@ -115,6 +129,22 @@ static void deliver(struct rt_replay *rp, const struct evsrc *s, int trk, const 
    if (e->flags & 1) { t->v_bot = e->v_peak; t->t_bot = tp; rt_down_transition(d, t); }
    else { t->v_top = e->v_peak; t->t_top = tp; rt_up_transition(d, t); }
    ++rp->events_delivered; }
+
+/* optional dump of what the decoders are handed, in the record format of oracle/ref_event_shim.c */
+struct dump_rec { uint32_t kind, trk; int32_t peakcount, parmset; double t_peak; int64_t timenow_ns; float v_peak, agc_gain, v_avg_height; uint32_t pad; };
+static void dump_transition(struct rt_dec *d, struct rt_trk *t, int is_top, void *user) {
+   struct rt_replay *rp = (struct rt_replay *)user;
+   struct dump_rec r; memset(&r, 0, sizeof r);
+   r.kind = is_top ? 0 : 1; r.trk = (uint32_t)t->trknum; r.peakcount = t->peakcount; r.parmset = d->parmset;
+   r.t_peak = is_top ? t->t_top : t->t_bot;
+   r.timenow_ns = rp->tstart_ns + (rp->cur_row + 1) * rp->tdelta_ns;          /* the reference has already advanced it, src/readtape.c:1424 */
+   r.v_peak = is_top ? t->v_top : t->v_bot; r.agc_gain = t->agc_gain; r.v_avg_height = t->v_avg_height;
+   fwrite(&r, sizeof r, 1, rp->evtf); }
+static void dump_attempt(struct rt_dec *d, void *user) {
+   struct rt_replay *rp = (struct rt_replay *)user;
+   struct dump_rec r; memset(&r, 0, sizeof r);
+   r.kind = 2; r.parmset = d->parmset; r.timenow_ns = rp->tstart_ns + rp->pos * rp->tdelta_ns;
+   fwrite(&r, sizeof r, 1, rp->evtf); }
 
 int rt_replay_readblock(void *ctx, int retry) {
    struct rt_replay *rp = (struct rt_replay *)ctx;
@@ -129,6 +159,7 @@ int rt_replay_readblock(void *ctx, int retry) {
    if (s0 >= nrows) { rt_finish_attempt(d); return 0; }     /* no row was processed: no forced end of block */
 
    struct evsrc src;
+   const long dump_pos = rp->evtf ? ftell(rp->evtf) : 0;      /* a restarted attempt rewinds the optional dump */
    int64_t b = find_burst(rp, s0);
    rtfe_event *exact_events = NULL;
    int using_exact = 0;
@@ -140,12 +171,13 @@ int rt_replay_readblock(void *ctx, int retry) {
       if (rp->bursts[k].zone_first - rp->row_base > s0) { exact_len = rp->bursts[k].end_sample - rp->row_base - s0; break; }
    if (exact_len < (1 << 12)) exact_len = 1 << 12;
 restart:
+   if (rp->evtf && (restarted || using_exact)) fseek(rp->evtf, dump_pos, SEEK_SET);
    if (b < 0) {                                               /* outside every proven-safe zone: exact device scan */
       if (!rp->exact) { d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
       uint32_t cnt[RT_MAXTRKS]; rtfe_burst eb; uint32_t cap = 0;
       if (exact_events && rp->exact_free) { rp->exact_free(rp->exact_user, exact_events); exact_events = NULL; }
       const int64_t ex_end = s0 + exact_len < nrows ? s0 + exact_len : nrows;
-      if (rp->exact(rp->exact_user, s0, ex_end, parmset, &eb, cnt, &exact_events, &cap) != 0) {
+      if (rp->exact(rp->exact_user, s0, ex_end, rp->find_zeros ? 0 : parmset, &eb, cnt, &exact_events, &cap) != 0) {
          d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
       for (int t = 0; t < ntrks; ++t) { src.list[t] = exact_events + (uint64_t)t * cap; src.n[t] = cnt[t]; src.at[t] = 0; }
       src.reset = s0; src.end = ex_end;
@@ -181,7 +213,8 @@ restart:
       /* the event source ends before anything else happens? */
       if (using_exact && !d->interblock_counter && next >= src.end && src.end < nrows) {
          exact_len *= 4;                                       /* the attempt is longer than the exact scan: rescan further */
-         rt_init_trackstate(d); d->interblock_counter = 0;
+         { void (*oa)(struct rt_dec *, void *) = d->on_attempt; d->on_attempt = NULL; rt_init_trackstate(d); d->on_attempt = oa; }
+         d->interblock_counter = 0;
          goto restart; }
       if (!using_exact && !d->interblock_counter && next >= src.end && src.end < nrows) {
          if (events_seen == 0 && burst_usable(rp, b + 1)) {   /* still fresh: the next burst's fresh state is the same state */
@@ -190,7 +223,7 @@ restart:
          if (restarted) { d->results[parmset].blktype = RT_BS_ABORTED; break; }
          /* this attempt crosses a device restart with state: redo it from s0 with an exact scan */
          restarted = 1; b = -1;
-         rt_init_trackstate(d);
+         { void (*oa)(struct rt_dec *, void *) = d->on_attempt; d->on_attempt = NULL; rt_init_trackstate(d); d->on_attempt = oa; }
          d->interblock_counter = 0;
          goto restart; }
       if (next >= nrows) {                                   /* end of data, src/readtape.c:1410-1413 */
@@ -200,6 +233,7 @@ restart:
          endfile = 1;
          break; }
       row = next;
+      rp->cur_row = row;
       d->timenow = time_of_row(rp, row);
       /* ---- process_sample for this row (src/decoder.c:841-904) ---- */
       if (d->interblock_counter) {                          /* we jumped to the row on which the countdown ends */
@@ -236,7 +270,7 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
-                  const char *tap_path, const char *log_path, struct rt_replay_stats *stats) {
+                  const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
    const float sample_deltat = (float)tdelta_ns / 1e9f;              /* src/readtape.c:1345 */
    struct rt_dec *d = rt_dec_new(opt, sample_deltat, tdelta_ns);
    if (!d) return -1;
@@ -252,6 +286,8 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
    rp.nrows = nrows; rp.row_base = row_base; rp.tstart_ns = tstart_ns; rp.tdelta_ns = tdelta_ns;
    rp.bursts = bursts; rp.nbursts = nbursts; rp.counts = counts; rp.events = events;
    rp.exact = exact; rp.exact_free = exact_free; rp.exact_user = user;
+   rp.find_zeros = opt->find_zeros;
+   if (evt_path) { rp.evtf = fopen(evt_path, "wb"); if (rp.evtf) { d->on_transition = dump_transition; d->on_attempt = dump_attempt; d->user = &rp; } }
    struct rt_reader rd = { rt_replay_readblock, rt_replay_save_pos, rt_replay_restore_pos, &rp };
    const int ok = rt_process_blocks(d, &rd, 0x7fffffff);
    if (stats) {
@@ -262,5 +298,6 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
       stats->data_bytes = d->numdatabytes; }
    if (d->tapf) fclose(d->tapf);
    if (d->logf) fclose(d->logf);
+   if (rp.evtf) { fflush(rp.evtf); if (ftruncate(fileno(rp.evtf), ftell(rp.evtf))) {} fclose(rp.evtf); }
    rt_dec_free(d);
    return 0; }

@@ -24,7 +24,9 @@ struct rt_replay {
    const uint32_t   *counts;
    const rtfe_event *events;
    rt_exact_fn exact; rt_exact_free_fn exact_free; void *exact_user;
-   int64_t pos, saved_pos; double saved_time;
+   int64_t pos, saved_pos, cur_row; double saved_time;
+   int     find_zeros;                 /* events are confirmed zero crossings: the slope gate is applied here */
+   FILE   *evtf;                       /* optional dump of every delivered transition (oracle/ref_event_shim.c record format) */
    /* statistics */
    int64_t attempts, exact_scans, chained, events_delivered, agc_mismatches;
 };
@@ -45,7 +47,7 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
-                  const char *tap_path, const char *log_path, struct rt_replay_stats *stats);
+                  const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -53,7 +53,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (c->ntrks < 1 || c->ntrks > RTFE_MAXTRKS) return fail(-2, "ntrks %d out of range", c->ntrks);
    if (c->mode != RTFE_NRZI && c->mode != RTFE_PE && c->mode != RTFE_GCR)
       return fail(-3, "mode %d not supported by the device front end yet (Whirlwind: see DESIGN.md)", c->mode);
-   if (c->differentiate || c->find_zeros) return fail(-4, "-differentiate / -zeros paths are not built yet");
+   if (c->differentiate) return fail(-4, "the -differentiate paths are not built yet");
    if (c->nparmsets < 1 || c->nparmsets > RTFE_MAXPARMSETS) return fail(-5, "nparmsets %d out of range", c->nparmsets);
    if (c->nparmsets * c->ntrks > kDecodeThreads) return fail(-6, "nparmsets*ntrks > %d", kDecodeThreads);
    if (!(c->bpi > 0) || !(c->ips > 0) || c->tdelta_ns <= 0 || !(c->maxvolts > 0)) return fail(-7, "bpi, ips, tdelta_ns and maxvolts must be positive");
@@ -63,6 +63,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    DevCfg &d = h->dev;
    memset(&d, 0, sizeof d);
    d.mode = c->mode; d.ntrks = c->ntrks; d.invert = c->invert != 0; d.nparm = c->nparmsets;
+   d.find_zeros = c->find_zeros != 0;
    bool seen[RTFE_MAXTRKS] = {false};
    for (int i = 0; i < c->ntrks; ++i) {
       int t = c->head_to_trk[i];
@@ -108,6 +109,13 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       float q = ps.min_peak > ps.pkww_rise / 2 ? ps.min_peak : ps.pkww_rise / 2;
       if (q < quiet_v) quiet_v = q; }
    for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].minpk_i < 0) d.screen[s].minpk_i = -1;
+   if (d.find_zeros) {
+      // the zero-crossing detector has no amplitude feedback and no parameter-set dependence (adjust_agc returns
+      // at once, src/decoder.c:501): one walker per track; nothing can become pending while |v| <= 0.2 V
+      quiet_v = 0.2f;
+      int code = 1;
+      while (code < 32767 && !((float)code / 32767 * c->maxvolts > 0.2f)) ++code;     // exact, same expression as the device's volt()
+      d.zc_peak_i = code; }
    if (c->quiet_volts > 0 && c->quiet_volts < quiet_v) quiet_v = c->quiet_volts;
    d.quiet_i = (int)floor(quiet_v * 0.98 * lsb_per_volt) - 1;
    if (d.quiet_i < 0) d.quiet_i = 0;

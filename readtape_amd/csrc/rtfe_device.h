@@ -33,6 +33,8 @@ struct DevScreen {
 
 struct DevCfg {
    int   mode, ntrks, invert, nparm, nscreens;
+   int   find_zeros;              // -zeros: zero-crossing detector instead of the peak detector (src/decoder.c:863-865)
+   int   zc_peak_i;               // smallest positive int16 code c with volt(c) > ZEROCROSS_PEAK (0.2 V, src/decoder.h:138)
    int   head_to_trk[RTFE_MAXTRKS];   // TBIN column -> track (src/readtape.c:1419)
    int   skew[RTFE_MAXTRKS];
    int   maxskew;

@@ -239,6 +239,10 @@ struct Walker {            // one per (parameter set, track); lives in registers
    float agc_gain, v_avg_height, v_avg_height_sum;
    int   v_avg_height_count, peakcount, heightndx;
    float v_top, v_bot, v_lasttop, v_lastbot;
+   // zero-crossing detector (-zeros), int16 codes (src/decoder.c:617-649)
+   int   z_prev, z_top, z_bot;
+   bool  z_up_pending, z_dn_pending;
+   long long z_ttop_row, z_tbot_row;
    // PE preamble tracking
    bool  datablock, bit1_up;
    double t_lastpeak;
@@ -615,6 +619,50 @@ __device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long
       if (a >= 0) { w.cpos = a; w.chain_pending = true; }
       if (limit - 1 - w.cpos > kHaloRows - 2 * W - 8 - cfg->maxskew) advance_chain(w, tl, P.screen, trk, W, limit - 1); } }
 
+// lookfor_zerocrossing (src/decoder.c:617-649) on the int16 codes: every row, one lane per track.  Emits every
+// CONFIRMED crossing; the slope gate of :629/:643 needs the decoder's clock average and is applied by the host
+// replay, which gets the crossing row as (confirmation row - delay).  Event: sample = confirmation row,
+// v_peak = the new extreme, agc_gain bits = delay in rows, left_distance = min(delay, 255).
+__device__ __forceinline__ void walk_zeros(Walker &w, Ctx &cx, int trk, long long limit) {
+   const DevCfg *cfg = cx.cfg;
+   const Tile &tl = cx.tile;
+   const long long tile_end = tl.row0 + tl.nrows;
+   if (limit > tile_end) limit = tile_end;
+   const int P = cfg->zc_peak_i;
+   long long n = w.next;
+   if (n <= w.start) n = w.start + 1;                              // row `start` only seeds the track (src/decoder.c:855-861)
+   for (; n < limit; ++n) {
+      const int v = tl.y(trk, n);
+      bool emit = false, up = false; long long cross = 0;
+      if (v > 0) {
+         w.z_dn_pending = false;
+         if (w.z_top < v) {
+            w.z_top = v;
+            if (w.z_up_pending && w.z_top >= P) { w.z_up_pending = false; w.z_bot = 0; emit = true; up = true; cross = w.z_ttop_row; } }
+         if (w.z_prev < 0 && w.z_bot <= -P) { w.z_ttop_row = n; w.z_up_pending = true; } }
+      else if (v < 0) {
+         w.z_up_pending = false;
+         if (w.z_bot > v) {
+            w.z_bot = v;
+            if (w.z_dn_pending && w.z_bot <= -P) { w.z_dn_pending = false; w.z_top = 0; emit = true; up = false; cross = w.z_tbot_row; } }
+         if (w.z_prev > 0 && w.z_top >= P) { w.z_tbot_row = n; w.z_dn_pending = true; } }
+      w.z_prev = v;
+      if (emit) {
+         if (w.nevents < cx.cap) {
+            rtfe_event e;
+            const unsigned int delay = (unsigned int)(n - cross);
+            e.sample = (uint32_t)(n - tl.reset);
+            e.v_peak = volt(v, cfg->maxvolts);
+            e.agc_gain = __uint_as_float(delay);
+            e.trk = (uint8_t)trk;
+            e.flags = (uint8_t)(up ? 0 : 1);
+            e.left_distance = (uint8_t)(delay < 255 ? delay : 255);
+            e.parmset = 0;
+            cx.events[(size_t)trk * cx.cap + w.nevents] = e; }
+         else w.flags |= RTFE_F_EVENT_OVERFLOW;
+         ++w.nevents; } }
+   w.next = n; }
+
 // all lanes: list the candidate runs of one (screen, track) of the current tile in row order.  A run = consecutive
 // rows with ANY candidate bit set; its record describes the extreme of the kind seen at its first row.
 __device__ __forceinline__ u64 run_starts(const Tile &tl, int screen, int trk, int wd) {
@@ -869,7 +917,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          __syncthreads();
          run_screens(&cfg, cx.tile);
          __syncthreads();
-         if (!(bflags & RTFE_F_UNSAFE)) {
+         if (cfg.find_zeros) reset = B.zone_end - kMarginRows;    // any restart inside the zone is equivalent
+         else if (!(bflags & RTFE_F_UNSAFE)) {
             reset = find_reset(&cfg, cx.tile, &s_min);
             if (reset <= 0 || reset < B.zone_first) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; } }
          t0 = B.zone_end - kMarginRows; }
@@ -917,7 +966,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                if (NB.zone_end - NB.zone_first >= kMarginRows + 64) {
                   const long long saved = cx.tile.reset;
                   cx.tile.reset = -(1ll << 40);
-                  nr = find_reset(&cfg, cx.tile, &s_min);
+                  nr = cfg.find_zeros ? NB.zone_end - kMarginRows : find_reset(&cfg, cx.tile, &s_min);
                   cx.tile.reset = saved; }
                if (nr <= 0 || nr < NB.zone_first) nr = NB.zone_end - kMarginRows;
                stop = nr; } }
@@ -943,7 +992,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
             int total = 0;
             for (int k = 0; k < nwords; ++k) total += runcnt[st * 32 + k];
             Walker w = walkers[my_w];
-            walk(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, total < cfg.run_cap ? total : cfg.run_cap, total);
+            if (cfg.find_zeros) { if (pidx == 0) walk_zeros(w, cx, trk, stop); }
+            else walk(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, total < cfg.run_cap ? total : cfg.run_cap, total);
             walkers[my_w] = w; }
          if (is_walker) nrec_all[my_w] = cx.nrec;
          __syncthreads();
@@ -966,7 +1016,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       __syncthreads();
       if (threadIdx.x == 0) {
          bursts[b].reset_sample = reset;
-         bursts[b].safe_last = (bflags & (RTFE_F_UNSAFE)) ? -1 : reset;
+         bursts[b].safe_last = (bflags & (RTFE_F_UNSAFE)) ? -1 : ((cfg.find_zeros && !exact) ? B.zone_end - ntrks - 2 : reset);
          bursts[b].end_sample = stop < hard_end ? stop : hard_end;
          bursts[b].flags = bflags | s_flags; }
       __syncthreads(); } }

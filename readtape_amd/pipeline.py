@@ -52,7 +52,7 @@ def _load_decode_lib():
     lib.rt_parse_parms_text.argtypes = [C.c_int, C.c_char_p, C.POINTER(_Parms)]
     lib.rt_replay_run.argtypes = [C.POINTER(_Options), C.POINTER(_Parms), C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                   C.POINTER(C.c_int), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _EXACT_FN, _FREE_FN, C.c_void_p,
-                                  C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
+                                  C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
     return lib
 
 
@@ -80,7 +80,7 @@ def frontend_parmsets(full):
 
 
 def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
-                skew=None, invert=False, parms_text: str | None = None):
+                skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None):
     """Decodes one tape; returns (stats dict, ScanResult).  `fe_factory(cfg)` builds the front end
     (default: the GPU one; tests/cpu_emul passes the emulated library)."""
     opts = opts or DecodeOptions()
@@ -95,13 +95,13 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
         full = [arr[i] for i in range(n)][:nsets]
     else:
         full = default_parmsets(mode, nsets)
-    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert)
+    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert, find_zeros=find_zeros)
     fe = (fe_factory or frontend.FrontEnd)(cfg)
     res = fe.scan(rows).fetch()
     nrows = int(rows.shape[0])
 
     o = _Options(mode=mode, ntrks=hdr.ntrks, bpi=cfg.bpi, ips=cfg.ips, specified_parity=0 if opts.even_parity else 1,
-                 revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=0, do_differentiate=0,
+                 revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=int(find_zeros), do_differentiate=0,
                  multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
     parr = (_Parms * len(full))(*full)
     W = (C.c_int * len(full))(*fe.widths)
@@ -139,7 +139,8 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     rc = lib.rt_replay_run(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, nrows, 0, W,
                            bursts.ctypes.data, len(bursts), counts.ctypes.data, events.ctypes.data,
                            _EXACT_FN(exact), _FREE_FN(free), None,
-                           tap_path.encode() if tap_path else None, log_path.encode() if log_path else None, C.byref(st))
+                           tap_path.encode() if tap_path else None, log_path.encode() if log_path else None,
+                           evt_path.encode() if evt_path else None, C.byref(st))
     if rc != 0:
         raise RuntimeError("rt_replay_run failed")
     stats = {k: getattr(st, k) for k, _ in _Stats._fields_}

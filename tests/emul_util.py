@@ -52,5 +52,14 @@ class NumpyBackend:
         pass
 
 
-def emul_frontend(cfg):
-    return frontend.FrontEnd(cfg, _lib_path=build_emul(), _backend=NumpyBackend())
+def emul_frontend(cfg, tile_rows=512):
+    # big tiles = few barrier rendezvous: the thread emulation pays ~0.1 ms per __syncthreads
+    old = os.environ.get("RTFE_TILE_ROWS")
+    os.environ["RTFE_TILE_ROWS"] = str(tile_rows)
+    try:
+        return frontend.FrontEnd(cfg, _lib_path=build_emul(), _backend=NumpyBackend())
+    finally:
+        if old is None:
+            os.environ.pop("RTFE_TILE_ROWS", None)
+        else:
+            os.environ["RTFE_TILE_ROWS"] = old

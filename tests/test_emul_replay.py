@@ -8,7 +8,8 @@ from emul_util import emul_frontend
 from golden_util import load_case
 from readtape_amd import pipeline
 
-CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m"]
+CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "nrzi9_zeros", "pe_zeros"]
+EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "pe", "nrzi9_zeros", "pe_zeros"]     # the thread emulation is slow: a subset here, all on the GPU
 
 
 def decode_case(g, tmp_path, fe_factory):
@@ -17,11 +18,14 @@ def decode_case(g, tmp_path, fe_factory):
     opts = pipeline.DecodeOptions(multiple_tries="-m" in o, correct="-correct" in o)
     tap = os.path.join(str(tmp_path), "out.tap")
     stats, res = pipeline.decode_tape(g["hdr"], g["rows"], tap, log_path=tap + ".log", opts=opts, fe_factory=fe_factory,
-                                      skew=skew, invert="-invert" in o)
+                                      skew=skew, invert="-invert" in o, find_zeros="-zeros" in o, evt_path=tap + ".evt")
+    import refdump
+    # every transition the decoders were handed == what the reference's front end handed its decoders
+    stats["event_diffs"] = refdump.compare(refdump.load(tap + ".evt"), g["events"])
     return open(tap, "rb").read(), stats
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", EMUL_CASES)
 def test_tap_bytes_match_reference(name, tmp_path):
     g = load_case(name)
     tap, stats = decode_case(g, tmp_path, emul_frontend)
@@ -29,3 +33,4 @@ def test_tap_bytes_match_reference(name, tmp_path):
     assert tap == g["tap"], f"{name}: .tap differs from the reference's ({len(tap)} vs {len(g['tap'])} bytes)"
     assert stats["agc_mismatches"] == 0
     assert stats["events_delivered"] > 0
+    assert not stats["event_diffs"], stats["event_diffs"]

@@ -101,7 +101,7 @@ def test_large_tape_properties(gpu):
         assert got.shape == ref.shape and (got == ref).all(), f"copy {j}"
 
 
-@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m"])
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "nrzi9_zeros", "pe_zeros"])
 def test_end_to_end_tap_bytes_match_reference(name, tmp_path, gpu):
     """GPU front end -> event replay -> block decoders -> SIMH .tap == the unmodified reference's .tap (golden)."""
     from test_emul_replay import decode_case
@@ -109,6 +109,7 @@ def test_end_to_end_tap_bytes_match_reference(name, tmp_path, gpu):
     tap, stats = decode_case(g, tmp_path, None)
     assert tap == g["tap"]
     assert stats["agc_mismatches"] == 0 and stats["events_delivered"] > 0
+    assert not stats["event_diffs"], stats["event_diffs"]
 
 
 def test_end_to_end_fresh_tape_vs_oracle_tap(tmp_path, gpu):
