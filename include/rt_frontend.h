@@ -95,6 +95,7 @@ enum {
    RTFE_F_UNSAFE           = 2,    /* no provably-equivalent restart interval exists for this burst  */
    RTFE_F_EVENT_OVERFLOW   = 4,    /* a track's event region filled up; events were dropped          */
    RTFE_F_SCREEN_UNDERFLOW = 8,    /* AGC threshold fell below the candidate screen: rescan exactly with screen off */
+   RTFE_F_TRUNCATED        = 32,   /* time shard: the halo ended before this burst's successor zone did          */
    RTFE_F_DETECTOR_FATAL   = 16    /* the reference would have hit its fatal "peak at window edge" assert (src/decoder.c:709-710,748) */
 };
 
@@ -128,10 +129,15 @@ int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows);
 int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows);
 
 /* Speculative scan of d_rows[0 .. nrows) (interleaved int16, ntrks per row, the TBIN payload).
- * row_base is the absolute index of d_rows[0] on the tape (time shards: != 0); first_is_tape_start
- * says row_base is a true restart point (the start of the tape or of a shard that begins at one).
- * Outputs (device): bursts[*nbursts], counts, events. */
-int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base, int first_is_tape_start,
+ * Time shards: row_base is the absolute index of d_rows[0] on the tape (used for times only; all rows in
+ * the outputs are relative to d_rows[0]); first_is_tape_start says row 0 is a true restart point (the
+ * start of the tape); own_rows <= nrows is the part of the slice this scan OWNS — rows
+ * [own_rows, nrows) are the halo received from the right neighbour.  A burst is decoded here iff its
+ * zone ends at or before own_rows; the last owned burst runs on into the halo up to the next zone's
+ * restart row.  If the halo holds no further zone the last owned burst is flagged RTFE_F_TRUNCATED
+ * (pass a longer halo).  own_rows == nrows: no halo (single GPU, or the last shard).
+ * Outputs (device): bursts[*nbursts] (owned bursts only), counts, events. */
+int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t own_rows, int64_t row_base, int first_is_tape_start,
               void *d_workspace, size_t workspace_bytes,
               rtfe_burst *d_bursts, int64_t max_bursts, int32_t *d_nbursts,
               uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,

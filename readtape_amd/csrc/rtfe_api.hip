@@ -21,7 +21,7 @@ __global__ void k_setup_exact(rtfe_burst *burst, BurstScratch *scratch, long lon
    b.zone_first = reset_row; b.zone_end = reset_row; b.reset_sample = reset_row; b.safe_last = reset_row;
    b.end_sample = end_row; b.event_base = 0; b.event_cap = (uint32_t)cap; b.flags = RTFE_F_EXACT_START;
    *burst = b;
-   scratch->nbursts = 1; scratch->queue = 0; }
+   scratch->nbursts = 1; scratch->nbursts_total = 1; scratch->queue = 0; }
 }  // namespace rtfe
 
 using namespace rtfe;
@@ -196,7 +196,7 @@ static int launch_check(const char *what) {
    if (e != hipSuccess) return fail(-30, "%s: %s", what, hipGetErrorString(e));
    return 0; }
 
-extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base, int first_is_tape_start,
+extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t own_rows, int64_t row_base, int first_is_tape_start,
                          void *d_workspace, size_t workspace_bytes,
                          rtfe_burst *d_bursts, int64_t max_bursts, int32_t *d_nbursts,
                          uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity, void *stream) {
@@ -204,6 +204,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (((uintptr_t)d_rows & 15) != 0) return fail(-31, "d_rows must be 16-byte aligned");
    if (workspace_bytes < rtfe_workspace_bytes(h, nrows)) return fail(-32, "workspace too small");
    if (nrows <= 0 || max_bursts < 1) return fail(-33, "nothing to scan");
+   if (own_rows <= 0 || own_rows > nrows) return fail(-35, "own_rows must be in (0, nrows]");
    hipStream_t st = (hipStream_t)stream;
    const long long nelem = (long long)nrows * h->dev.ntrks;
    const long long nchunks = nelem / 512;
@@ -214,7 +215,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (h->timing) (void)hipEventRecord(h->ev[0], st);
    hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, st, d_rows, nelem, h->dev.quiet_i, qwords, nwords);
    if (h->timing) (void)hipEventRecord(h->ev[1], st);
-   hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, h->dev.ntrks,
+   hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
                       d_bursts, (long long)max_bursts, scratch, d_nbursts);
    if (h->timing) (void)hipEventRecord(h->ev[2], st);

@@ -71,9 +71,10 @@ __global__ void __launch_bounds__(256) k_quiet(const int16_t *__restrict__ rows,
 // (itself included) are all quiet; each thread tests the 64 chunks of one word per round.
 // ------------------------------------------------------------------------------------------------
 struct BurstScratch {            // lives in the workspace
-   int   nbursts;
+   int   nbursts;                // bursts to decode (owned by this scan)
    int   queue;                  // next burst to decode
-   int   pad[14];
+   int   nbursts_total;          // owned bursts + (time shards) the first burst of the halo, which only bounds the last owned one
+   int   pad[13];
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
 };
 #ifdef RTFE_CPU_EMUL
@@ -99,7 +100,7 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int *lds, int *total)
    return r; }
 
 __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords, long long nwords, long long nchunks,
-                                                 long long nrows, int ntrks, int gap_chunks, int first_is_start,
+                                                 long long nrows, long long own_rows, int ntrks, int gap_chunks, int first_is_start,
                                                  float cap_frac, int nparm, long long event_capacity,
                                                  rtfe_burst *__restrict__ bursts, long long max_bursts,
                                                  BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out) {
@@ -165,6 +166,16 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
       __syncthreads(); }
    int nb = s_base;
    if (nb > max_bursts) nb = (int)max_bursts;
+   // time shards: keep the bursts that start in the owned rows, plus one more as the bound of the last of them
+   __shared__ int s_owned;
+   if (threadIdx.x == 0) s_owned = nb;
+   __syncthreads();
+   for (int b0 = 0; b0 < nb; b0 += 1024) {
+      const int b = b0 + threadIdx.x;
+      if (b < nb && bursts[b].zone_end > own_rows && !(bursts[b].flags & RTFE_F_EXACT_START)) atomicMin(&s_owned, b); }
+   __syncthreads();
+   const int n_owned = s_owned;
+   if (nb > n_owned + 1) nb = n_owned + 1;
    // drop zones too short to hold a head tile (zone_end - zone_first < margin + 64): mark by flags later in decode
    // ---- second pass: coarse extents, event capacities and region bases (parallel prefix sum) ----
    if (threadIdx.x == 0) s_ebase = 0;
@@ -192,7 +203,9 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
       __syncthreads();
       if (threadIdx.x == 0) s_ebase += (u64)total << 6;
       __syncthreads(); }
-   if (threadIdx.x == 0) { scratch->nbursts = nb; scratch->queue = 0; *nbursts_out = nb; }
+   if (threadIdx.x == 0) {
+      scratch->nbursts = n_owned; scratch->nbursts_total = nb; scratch->queue = 0; *nbursts_out = n_owned;
+      if (n_owned == nb && own_rows < nrows && n_owned > 0) bursts[n_owned - 1].flags |= RTFE_F_TRUNCATED; }
    if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -898,8 +911,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       if (threadIdx.x == 0) { s_burst = atomicAdd(&scratch->queue, 1); s_flags = 0; }
       __syncthreads();
       const int b = s_burst;
-      const int nb = scratch->nbursts;
-      if (b >= nb) break;
+      if (b >= scratch->nbursts) break;
+      const int nb = scratch->nbursts_total;
       rtfe_burst B = bursts[b];
       const bool exact = B.flags & RTFE_F_EXACT_START;
       const bool last = b + 1 >= nb;

@@ -20,7 +20,7 @@ from . import tbin
 MAXTRKS, MAXPARMSETS = 19, 15
 PE, NRZI, GCR, WW = 1, 2, 4, 8
 
-F_EXACT_START, F_UNSAFE, F_EVENT_OVERFLOW, F_SCREEN_UNDERFLOW, F_DETECTOR_FATAL = 1, 2, 4, 8, 16
+F_EXACT_START, F_UNSAFE, F_EVENT_OVERFLOW, F_SCREEN_UNDERFLOW, F_DETECTOR_FATAL, F_TRUNCATED = 1, 2, 4, 8, 16, 32
 
 EVENT_DTYPE = np.dtype([("sample", "<u4"), ("v_peak", "<f4"), ("agc_gain", "<f4"), ("trk", "u1"),
                         ("flags", "u1"), ("left_distance", "u1"), ("parmset", "u1")])
@@ -162,7 +162,7 @@ def _load_library(path=None):
     lib.rtfe_workspace_bytes.argtypes = [C.c_void_p, C.c_int64]; lib.rtfe_workspace_bytes.restype = C.c_size_t
     lib.rtfe_max_bursts.argtypes = [C.c_void_p, C.c_int64]; lib.rtfe_max_bursts.restype = C.c_int64
     lib.rtfe_event_capacity.argtypes = [C.c_void_p, C.c_int64]; lib.rtfe_event_capacity.restype = C.c_int64
-    lib.rtfe_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
+    lib.rtfe_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.rtfe_scan_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -263,13 +263,14 @@ class FrontEnd:
                 nbursts=be.empty(16), counts=be.empty(mb * P * T * 4), events=be.empty(cap * 16), max_bursts=mb, cap=cap)
         return self._cache[k]
 
-    def scan(self, rows, row_base=0, first_is_tape_start=True, stream=None) -> ScanResult:
-        """Launches the speculative scan of `rows` ([n, ntrks] int16, device tensor or numpy) — asynchronous."""
+    def scan(self, rows, row_base=0, first_is_tape_start=True, stream=None, own_rows=None) -> ScanResult:
+        """Launches the speculative scan of `rows` ([n, ntrks] int16, device tensor or numpy) — asynchronous.
+        Time shards pass own_rows < n: the trailing rows are the right neighbour's halo (include/rt_frontend.h)."""
         be = self.backend
         d_rows = be.rows(rows)
         nrows = int(d_rows.shape[0])
         b = self._buffers(nrows)
-        rc = self.lib.rtfe_scan(self.h, be.ptr(d_rows), nrows, row_base, int(first_is_tape_start),
+        rc = self.lib.rtfe_scan(self.h, be.ptr(d_rows), nrows, nrows if own_rows is None else int(own_rows), row_base, int(first_is_tape_start),
                                 be.ptr(b["ws"]), b["ws"].numel() if hasattr(b["ws"], "numel") else b["ws"].size,
                                 be.ptr(b["bursts"]), b["max_bursts"], be.ptr(b["nbursts"]), be.ptr(b["counts"]),
                                 be.ptr(b["events"]), b["cap"], stream if stream is not None else be.stream())
