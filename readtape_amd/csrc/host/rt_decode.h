@@ -136,6 +136,7 @@ struct rt_dec {
    int     expected_parity;
    struct rt_trk trk[RT_MAXTRKS];
    struct rt_nrzi nrzi;
+   struct { int bitnum, bytenum; uint8_t sgroup[9]; int bad_parity_in_dgroup; } gcr;   /* src/decode_gcr.c:37,444-445 */
    /* block state (src/decoder.h:327-359) */
    int     tries, parmset;
    uint8_t window_set, endblock_done;

@@ -1,11 +1,204 @@
-/* rt_decode_gcr.c — 6250 BPI GCR bit recovery (placeholder until the GCR row lands).
- * The entry points exist so the library links; calling them reports the block as unusable. */
+/* rt_decode_gcr.c — 6250 BPI group-coded recording: bit recovery from flux-transition events, then
+ * 5-to-4 group recoding, ECC and parity checks.  Restates src/decode_gcr.c (V3.18) on an explicit
+ * context.  Every track is self-clocked: a transition is a 1, and the time since the previous
+ * transition says whether one or two 0 bits lie in between (src/decode_gcr.c:789-834).
+ *
+ * Not restated: the -correct path that repairs one or two tracks from the ECC syndrome
+ * (src/decode_gcr.c:151-341).  With -correct a group with bad parity is left as the reference leaves
+ * it when its corrector reports failure; without -correct (the default here) behaviour is identical.
+ */
 #include "rt_decode.h"
 
-void rt_gcr_preprocess(struct rt_dec *d) { (void)d; }
-void rt_gcr_top(struct rt_dec *d, struct rt_trk *t) { (void)d; (void)t; }
-void rt_gcr_bot(struct rt_dec *d, struct rt_trk *t) { (void)d; (void)t; }
-void rt_gcr_end_of_block(struct rt_dec *d) {
+#include <string.h>
+
+#define GCR_IBG_SECS  200e-6       /* src/decoder.h:113 */
+#define AGC_STARTBASE 5
+#define AGC_ENDBASE   15
+
+/* 5-bit storage-group codes with a meaning of their own (src/decode_gcr.c:419-425) */
+enum { SG_MARK1 = 0x07, SG_MARK2 = 0x1c, SG_SYNC = 0x1f };
+
+/* storage group -> data nibble; values >= 16 mark an invalid code and carry the nearest valid nibble
+ * in the low 4 bits (src/decode_gcr.c:427-436) */
+static const unsigned char SG_TO_NIBBLE[32] = {
+   26, 25, 18, 19, 21, 21, 22, 23, 26, 9, 10, 11, 29, 13, 14, 15,
+   18, 21, 2, 3, 21, 5, 6, 7, 16, 0, 8, 1, 28, 4, 12, 31 };
+
+void rt_gcr_preprocess(struct rt_dec *d) {           /* src/decode_gcr.c:404-408 */
+   d->gcr.bitnum = d->gcr.bytenum = 0;
+   d->results[d->parmset].first_error = -1; }
+
+/* ---- bit recovery (src/decode_gcr.c:731-865) ---- */
+static void gcr_addbit(struct rt_dec *d, struct rt_trk *t, int bit, double t_bit) {
+   t->t_lastbit = t_bit;
+   if (t->datacount == 0) {
+      d->t_blockstart = t_bit;
+      t->t_firstbit = t_bit;
+      t->max_agc_gain = t->agc_gain; }
+   if (!t->datablock) {
+      t->t_lastclock = t_bit - t->clkavg.t_bitspaceavg;
+      t->datablock = 1; }
+   const uint16_t mask = 1 << (d->opt.ntrks - 1 - t->trknum);
+   d->data[t->datacount] = bit ? d->data[t->datacount] | mask : d->data[t->datacount] & ~mask;
+   d->data_time[t->datacount] = t_bit;
+   if (t->datacount < RT_MAXBLOCK) ++t->datacount;
+   t->lastbits = (uint8_t)((t->lastbits << 1) | bit);
+   if (t->datacount % 5 == 0) {                       /* a resync burst starts with MARK2 and ends with MARK1 */
+      if ((t->lastbits & 0x1f) == SG_MARK2) t->resync_bitcount = 1;
+      if ((t->lastbits & 0x1f) == SG_MARK1 && t->resync_bitcount > 0) t->resync_bitcount = 0; }
+   if (t->resync_bitcount > 0) {
+      if (t->resync_bitcount == 5) rt_force_clock(&t->clkavg, t->t_peakdelta);      /* mid-burst: trust the all-ones spacing */
+      ++t->resync_bitcount; } }
+
+static int gcr_checkzeros(struct rt_dec *d, struct rt_trk *t, float delta) {        /* src/decode_gcr.c:789-834 */
+   int numbits = 1;
+   if (t->datablock) {
+      const struct rt_parms *P = &RT_PARM(d);
+      t->t_peakdeltaprev = t->t_peakdelta;
+      t->t_peakdelta = delta;
+      if (delta - t->t_pulse_adj > P->z1pt * t->clkavg.t_bitspaceavg) {
+         ++numbits;
+         double zerobitloc = t->t_lastpeak + t->clkavg.t_bitspaceavg;
+         gcr_addbit(d, t, 0, zerobitloc);
+         if (delta - t->t_pulse_adj > P->z2pt * t->clkavg.t_bitspaceavg) {
+            ++numbits;
+            zerobitloc += t->clkavg.t_bitspaceavg;
+            gcr_addbit(d, t, 0, zerobitloc); } }
+      if (t->datacount > 3 && numbits == 1
+            && d->data[t->datacount - 2] & (1 << (d->opt.ntrks - 1 - t->trknum)))
+         rt_adjust_clock(d, &t->clkavg, t->t_peakdeltaprev, t->trknum);
+      t->t_pulse_adj = P->pulse_adj * (numbits * t->clkavg.t_bitspaceavg - delta); }
+   return numbits; }
+
+void rt_gcr_bot(struct rt_dec *d, struct rt_trk *t) {      /* src/decode_gcr.c:836-844 */
+   gcr_checkzeros(d, t, (float)(t->t_bot - t->t_lastpeak));
+   gcr_addbit(d, t, 1, t->t_bot);
+   if (t->peakcount > AGC_ENDBASE && t->v_avg_height_count == 0) rt_adjust_agc(d, t); }
+
+void rt_gcr_top(struct rt_dec *d, struct rt_trk *t) {      /* src/decode_gcr.c:846-865 */
+   gcr_checkzeros(d, t, (float)(t->t_top - t->t_lastpeak));
+   gcr_addbit(d, t, 1, t->t_top);
+   if (t->peakcount >= AGC_STARTBASE && t->peakcount <= AGC_ENDBASE) {
+      t->v_avg_height_sum += t->v_top - t->v_bot;
+      ++t->v_avg_height_count;
+      t->v_heights[t->heightndx] = t->v_top - t->v_bot;
+      if (++t->heightndx >= RT_PARM(d).agc_window) t->heightndx = 0; }
+   else if (t->peakcount > AGC_ENDBASE) {
+      if (t->v_avg_height_count) {
+         t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count;
+         t->v_avg_height_count = 0; }
+      else rt_adjust_agc(d, t); } }
+
+/* ---- group recoding (src/decode_gcr.c:448-674) ---- */
+
+/* expected ECC character of the seven data characters that precede position `end-1`
+ * (src/decode_gcr.c:118-144): bit i = parity of (56-bit data word AND row i) */
+static unsigned gcr_ecc_of(const uint16_t *chars7) {
+   static const uint64_t ROW[8] = {
+      0x0f6a71994c5230ULL, 0x70110840108004ULL, 0x5a701108401080ULL, 0x372be95d5a7011ULL,
+      0xe95d5a70110840ULL, 0x4c523001884412ULL, 0x2be95d5a701108ULL, 0x5d5a7011084010ULL };
+   uint64_t word = 0;
+   for (int i = 0; i < 7; ++i) word = (word << 8) | (uint64_t)(chars7[i] >> 1);
+   unsigned ecc = 0;
+   for (int i = 0; i < 8; ++i) ecc |= (unsigned)(__builtin_parityll(word & ROW[i] & 0x00ffffffffffffffULL)) << i;
+   return ecc; }
+
+/* gather the next 5 cells of every track into per-track storage groups (src/decode_gcr.c:448-459) */
+static void gather_sgroups(struct rt_dec *d) {
+   for (int cell = 0; cell < 5; ++cell) {
+      uint16_t w = d->data[d->gcr.bitnum + cell];
+      for (int trk = 8; trk >= 0; --trk) {
+         d->gcr.sgroup[trk] = (uint8_t)(((d->gcr.sgroup[trk] << 1) & 0x1f) | (w & 1));
+         w >>= 1; } } }
+
+/* one storage group per track -> 4 data cells (one bit per track each) written at bytenum
+ * (src/decode_gcr.c:464-493) */
+static void store_dgroup(struct rt_dec *d) {
+   struct rt_results *result = &d->results[d->parmset];
+   uint16_t mask = 1;
+   for (int trk = 8; trk >= 0; --trk, mask <<= 1) {
+      unsigned nib = SG_TO_NIBBLE[d->gcr.sgroup[trk]];
+      if (nib >= 16) { ++result->gcr_bad_dgroups; nib -= 16; }
+      for (int bit = 3; bit >= 0; --bit, nib >>= 1) {
+         if (nib & 1) d->data[d->gcr.bytenum + bit] |= mask;
+         else d->data[d->gcr.bytenum + bit] &= ~mask; } }
+   for (int k = 0; k <= 3; ++k)
+      if (rt_parity9(d->data[d->gcr.bytenum + k]) != d->expected_parity) {
+         ++d->gcr.bad_parity_in_dgroup;
+         if (result->first_error < 0) result->first_error = d->gcr.bytenum + k; }
+   d->gcr.bytenum += 4; }
+
+static void gcr_postprocess(struct rt_dec *d) {             /* src/decode_gcr.c:503-674 */
+   struct rt_results *result = &d->results[d->parmset];
+   enum { S_PREAMBLE, S_DATA_A, S_DATA_B, S_RESYNC, S_RESID_A, S_RESID_B, S_CRC_A, S_CRC_B, S_POSTAMBLE } state = S_PREAMBLE;
+   result->blktype = RT_BS_BLOCK;
+   result->first_error = -1;
+   d->gcr.bitnum = 0;
+   while (d->gcr.bitnum <= result->maxbits - 5) {
+      gather_sgroups(d);
+      d->gcr.bitnum += 5;
+      const unsigned master = d->gcr.sgroup[0];            /* track 0 tells what kind of subgroup this is */
+      switch (state) {
+      case S_PREAMBLE:
+         if (master == SG_MARK1) { state = S_DATA_A; d->gcr.bytenum = 0; }
+         break;
+      case S_DATA_A:
+         if (master == SG_MARK2) state = S_RESYNC;
+         else if (master == SG_SYNC) state = S_RESID_A;
+         else { d->gcr.bad_parity_in_dgroup = 0; store_dgroup(d); state = S_DATA_B; }
+         break;
+      case S_DATA_B:
+         store_dgroup(d);
+         if (gcr_ecc_of(&d->data[d->gcr.bytenum - 8]) != (unsigned)(d->data[d->gcr.bytenum - 1] >> 1)) {
+            ++result->ecc_errs;
+            if (result->first_error < 0) result->first_error = d->gcr.bytenum - 1; }
+         if (d->gcr.bad_parity_in_dgroup)                   /* (the -correct repair of src/decode_gcr.c:588-611 is not restated) */
+            result->vparity_errs += d->gcr.bad_parity_in_dgroup;
+         d->gcr.bytenum -= 1;                               /* drop the ECC character */
+         state = S_DATA_A;
+         break;
+      case S_RESYNC:
+         if (master == SG_MARK1) state = S_DATA_A;
+         else if (master != SG_SYNC) ++result->gcr_bad_dgroups;
+         break;
+      case S_RESID_A: store_dgroup(d); state = S_RESID_B; break;
+      case S_RESID_B: store_dgroup(d); state = S_CRC_A; break;
+      case S_CRC_A:   store_dgroup(d); state = S_CRC_B; break;
+      case S_CRC_B: {
+         store_dgroup(d);
+         const int residual_count = d->data[d->gcr.bytenum - 2] >> (5 + 1);     /* top 3 bits of the residual character */
+         d->gcr.bytenum -= (16 - residual_count);
+         state = S_POSTAMBLE;
+         break; }
+      case S_POSTAMBLE:
+         break; } }
+   result->minbits = result->maxbits = d->gcr.bytenum;
+   d->interblock_counter = (int)(GCR_IBG_SECS / d->sample_deltat); }
+
+void rt_gcr_end_of_block(struct rt_dec *d) {                /* src/decode_gcr.c:682-729 */
+   struct rt_results *result = &d->results[d->parmset];
+   struct rt_trk *T = d->trk;
+   const int ntrks = d->opt.ntrks;
    if (d->endblock_done) return;
    d->endblock_done = 1;
-   d->results[d->parmset].blktype = RT_BS_BADBLOCK; }
+   float avg_bit_spacing = 0;
+   result->minbits = RT_MAXBLOCK;
+   result->maxbits = 0;
+   for (int trk = 0; trk < ntrks; ++trk) {
+      struct rt_trk *t = &T[trk];
+      avg_bit_spacing += (float)(t->t_lastbit - t->t_firstbit) / t->datacount;
+      if (t->datacount > result->maxbits) result->maxbits = t->datacount;
+      if (t->datacount < result->minbits) result->minbits = t->datacount;
+      if (result->alltrk_max_agc_gain < t->max_agc_gain) result->alltrk_max_agc_gain = t->max_agc_gain;
+      if (result->alltrk_min_agc_gain > t->min_agc_gain) result->alltrk_min_agc_gain = t->min_agc_gain; }
+   result->avg_bit_spacing = avg_bit_spacing / ntrks;
+   rt_set_expected_parity(d, result->maxbits);
+   static const int MARK_TRKS[6] = {0, 2, 5, 6, 7, 8};
+   int mark = T[1].peakcount <= 2 && T[3].peakcount <= 2 && T[4].peakcount <= 2;
+   for (int i = 0; i < 6 && mark; ++i) mark = T[MARK_TRKS[i]].datacount >= 250 && T[MARK_TRKS[i]].datacount <= 400;
+   if (result->maxbits <= 10) result->blktype = RT_BS_NOISE;
+   else if (mark) result->blktype = RT_BS_TAPEMARK;
+   else if (result->maxbits - result->minbits > 2) {
+      result->track_mismatch = result->maxbits - result->minbits;
+      result->blktype = RT_BS_BADBLOCK; }
+   else gcr_postprocess(d); }

@@ -283,12 +283,60 @@ def pe_tapemark(ntrks: int = 9, nflux: int = 90):
 # 4 -> 5 bit map, the inverse of the decoder's table (src/decode_gcr.c:430-436)
 GCR_4TO5 = [0b11001, 0b11011, 0b10010, 0b10011, 0b11101, 0b10101, 0b10110, 0b10111,
             0b11010, 0b01001, 0b01010, 0b01011, 0b11110, 0b01101, 0b01110, 0b01111]
-# ECC matrix rows (src/decode_gcr.c:128-136) are filled in by gcr_ecc(); see tests for pinning.
-_GCR_ECC_ROWS = None
+# ECC: bit i of the check character = parity of (56-bit big-endian data word AND row i)
+# (the matrix the decoder checks against, src/decode_gcr.c:128-136)
+_GCR_ECC_ROWS = [0x0f6a71994c5230, 0x70110840108004, 0x5a701108401080, 0x372be95d5a7011,
+                 0xe95d5a70110840, 0x4c523001884412, 0x2be95d5a701108, 0x5d5a7011084010]
+
+
+def gcr_ecc(seven: bytes) -> int:
+    word = int.from_bytes(bytes(seven), "big")
+    return sum((bin(word & row).count("1") & 1) << i for i, row in enumerate(_GCR_ECC_ROWS))
+
+
+def _gcr_group_cells(chars8: list[int]) -> list[list[int]]:
+    """8 characters (7 data + check) -> 10 cells per track (two 5-bit storage groups), as 9-bit words."""
+    words = [((c & 0xFF) << 1) | (_parity9(c & 0xFF) ^ 1) for c in chars8]         # odd parity on track 8
+    cells = [0] * 10
+    for trk in range(9):
+        bits = [(w >> (8 - trk)) & 1 for w in words]
+        for half in range(2):
+            nib = (bits[4 * half] << 3) | (bits[4 * half + 1] << 2) | (bits[4 * half + 2] << 1) | bits[4 * half + 3]
+            code = GCR_4TO5[nib]
+            for k in range(5):                                                        # MSB first
+                if (code >> (4 - k)) & 1:
+                    cells[5 * half + k] |= 1 << (8 - trk)
+    return cells
 
 
 def gcr_encode(payload: bytes):
-    raise NotImplementedError("GCR generator lands with the GCR decoder row (SURVEY f1)")
+    """One 6250 block: preamble, data groups, end mark, residual group, CRC group, postamble
+    (what src/decode_gcr.c:503-674 walks through).  Same cells on every track
+    for the control subgroups."""
+    ALL = 0x1FF
+
+    def ctl(code):                     # a 5-bit control subgroup on all nine tracks
+        return [ALL if (code >> (4 - k)) & 1 else 0 for k in range(5)]
+
+    cells = []
+    cells += ctl(0b10101) + ctl(0b01111)
+    for _ in range(14):
+        cells += ctl(0b11111)
+    cells += ctl(0b00111)                                            # MARK1: data starts
+    nfull, left = divmod(len(payload), 7)
+    for g in range(nfull):
+        seven = payload[7 * g: 7 * g + 7]
+        cells += _gcr_group_cells(list(seven) + [gcr_ecc(seven)])
+    cells += ctl(0b11111)                                            # end of data groups
+    resid = list(payload[7 * nfull:]) + [0] * (6 - left) + [0]       # H H H H H H N
+    cells += _gcr_group_cells(resid + [gcr_ecc(bytes(resid))])
+    crc = [0, 0, 0, 0, 0, 0, (left << 5) & 0xFF]                     # B C C C C C X ; X's top 3 bits = residual count
+    cells += _gcr_group_cells(crc + [gcr_ecc(bytes(crc))])
+    cells += ctl(0b11100)                                            # MARK2
+    for _ in range(14):
+        cells += ctl(0b11111)
+    cells += ctl(0b11110) + ctl(0b10101)
+    return _words_to_transitions(cells, 9), float(len(cells)), None
 
 
 # --------------------------------------------------------------------------------------------
@@ -298,6 +346,19 @@ def gcr_encode(payload: bytes):
 def nrzi_spec(seed: int = 1, ntrks: int = 9, **kw) -> TapeSpec:
     return TapeSpec(mode=tbin.MODE_NRZI, ntrks=ntrks, bpi=800.0, ips=50.0, tdelta_ns=1280,
                     maxvolts=4.4, pulse_w=0.22, seed=seed, **kw)
+
+
+def gcr_spec(seed: int = 1, **kw) -> TapeSpec:
+    kw.setdefault("pulse_w", 0.4)
+    kw.setdefault("amplitude", 1.8)
+    return TapeSpec(mode=tbin.MODE_GCR, ntrks=9, bpi=9042.0, ips=50.0, tdelta_ns=160, maxvolts=3.3, seed=seed, **kw)
+
+
+def gcr_tape(seed: int = 1, nblocks: int = 3, minlen: int = 100, maxlen: int = 1000, gap_samples: int = 6000, **kw) -> Tape:
+    spec = gcr_spec(seed=seed, **kw)
+    rng = np.random.default_rng(seed + 3000)
+    items = [("block", p) for p in random_payloads(rng, nblocks, minlen, maxlen)]
+    return make_tape(spec, items, gap_samples=gap_samples)
 
 
 def pe_spec(seed: int = 1, **kw) -> TapeSpec:

@@ -34,6 +34,14 @@ def case_pe(seed=15):
     return synth.pe_tape(seed=seed, nblocks=2, minlen=30, maxlen=60, gap_samples=1500)
 
 
+def case_gcr(seed=16):
+    return synth.gcr_tape(seed=seed, nblocks=2, minlen=40, maxlen=160, gap_samples=2500)
+
+
+def case_gcr_noisy(seed=17):
+    return synth.gcr_tape(seed=seed, nblocks=2, minlen=40, maxlen=120, gap_samples=2500, noise_mv=45.0, jitter=0.05, amplitude=1.2)
+
+
 # name -> (tape builder, reference options, oracle options)
 CASES = {
     "nrzi9":        (case_nrzi9,      ["-nrzi"],                       []),
@@ -48,6 +56,9 @@ CASES = {
     "pe":           (case_pe,         ["-pe"],                         []),
     "pe_m":         (case_pe,         ["-pe", "-m"],                   ["-m"]),
     "pe_zeros":     (case_pe,         ["-pe", "-zeros"],               ["-zeros"]),
+    "gcr":          (case_gcr,        ["-gcr"],                        []),
+    "gcr_m":        (case_gcr_noisy,  ["-gcr", "-m"],                  ["-m"]),
+    "gcr_zeros":    (case_gcr,        ["-gcr", "-zeros"],              ["-zeros"]),
 }
 # every reference run also gets: -v -tap -nolabels (SIMH .tap output, no IBM label handling);
 # "-nm" is added when "-m" is absent because the reference retries by default (src/readtape.c:511)

@@ -100,7 +100,8 @@ def check_tape(fe, hdr, rows, attempts, allow_exact=True):
     for k, att in enumerate(attempts):
         s0 = att["start"]
         hit = [b for b in range(res.nbursts)
-               if int(res.bursts[b]["zone_first"]) <= s0 <= int(res.bursts[b]["safe_last"]) and not (int(res.bursts[b]["flags"]) & frontend.F_UNSAFE)]
+               if int(res.bursts[b]["zone_first"]) <= s0 <= int(res.bursts[b]["safe_last"])
+               and not (int(res.bursts[b]["flags"]) & (frontend.F_UNSAFE | frontend.F_SCREEN_UNDERFLOW | frontend.F_EVENT_OVERFLOW | frontend.F_DETECTOR_FATAL))]
         # an attempt with no events that spans several zones maps to the last zone it started in or before
         if hit and att["end"] <= int(res.bursts[hit[-1]]["end_sample"]) + 0 or (hit and att["events"].size == 0):
             b = hit[-1]

@@ -8,8 +8,8 @@ from emul_util import emul_frontend
 from golden_util import load_case
 from readtape_amd import pipeline
 
-CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "nrzi9_zeros", "pe_zeros"]
-EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "pe", "nrzi9_zeros", "pe_zeros"]     # the thread emulation is slow: a subset here, all on the GPU
+CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros"]
+EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "pe", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_zeros"]     # the thread emulation is slow: a subset here, all on the GPU
 
 
 def decode_case(g, tmp_path, fe_factory):
