@@ -125,3 +125,71 @@ def test_end_to_end_fresh_tape_vs_oracle_tap(tmp_path, gpu):
     stats, _ = pipeline.decode_tape(hdr, tape.rows, str(tmp_path / "g.tap"))
     assert open(tmp_path / "g.tap", "rb").read() == open(tmp_path / "o.tap", "rb").read()
     assert stats["exact_scans"] == 0 and stats["agc_mismatches"] == 0 and stats["blocks"] == 60
+
+
+def _flat_all(r, p, lo, hi):
+    out = []
+    for b in range(r.nbursts):
+        ev = r.events(b, p)
+        a = r.bursts[b]["reset_sample"] + ev["sample"].astype(np.int64)
+        m = (a >= lo) & (a < hi)
+        out.append(np.stack([a[m] - lo, ev["trk"][m].astype(np.int64), ev["flags"][m].astype(np.int64), ev["v_peak"][m].view("u4").astype(np.int64),
+                             ev["agc_gain"][m].view("u4").astype(np.int64), ev["left_distance"][m].astype(np.int64)], 1))
+    return np.concatenate(out)
+
+
+def test_config_c3_pe_zero_cross_at_scale(tmp_path, gpu):
+    """BASELINE config 3 shape (9-track 1600 BPI PE, 640 ns, zero-cross path), scaled to ~2e7 rows by tiling:
+    the base tape decodes to the oracle's .tap, and every copy of it yields the base tape's events."""
+    import subprocess
+    from parity_util import ORACLE, build_oracle
+    from readtape_amd import pipeline, tbin
+    torch = gpu
+    base = synth.pe_tape(seed=71, nblocks=12, minlen=200, maxlen=1500, gap_samples=6000)
+    hdr = base.spec.header()
+    build_oracle()
+    tbin.write_tbin(str(tmp_path / "t.tbin"), hdr, base.rows)
+    subprocess.run([ORACLE, "-zeros", f"-out={tmp_path}/o", str(tmp_path / "t.tbin")], check=True)
+    stats, r1 = pipeline.decode_tape(hdr, base.rows, str(tmp_path / "g.tap"), find_zeros=True)
+    assert open(tmp_path / "g.tap", "rb").read() == open(tmp_path / "o.tap", "rb").read()
+    fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr, nparmsets=1, find_zeros=True))
+    n = base.rows.shape[0]
+    k = int(2e7 // n) + 1
+    rk = fe.scan(torch.from_numpy(base.rows).cuda().repeat(k, 1).contiguous()).fetch()
+    ref = _flat_all(r1, 0, 0, n)
+    for j in (0, k // 2, k - 1):
+        got = _flat_all(rk, 0, j * n, (j + 1) * n)
+        assert got.shape == ref.shape and (got == ref).all(), f"copy {j}"
+
+
+def test_config_c4_gcr_eight_parmset_sweep_at_scale(tmp_path, gpu):
+    """BASELINE config 4 shape (9-track GCR 9042 BPI, 160 ns, 8-parmset batched sweep from a .parms text), tiled to
+    ~1e7 rows: one scan yields, for every parameter set, k copies of the base tape's events; the base tape's events per
+    set equal the oracle's single-set runs."""
+    from parity_util import oracle_attempts
+    torch = gpu
+    base = synth.gcr_tape(seed=81, nblocks=6, minlen=300, maxlen=1500, gap_samples=8000)
+    hdr = base.spec.header()
+    sets = [(bf, rise, mp, al, 0, 0.0) for bf in (1.2, 1.5) for rise, mp in ((0.14, 0.0), (0.2, 0.2)) for al in (0.3, 0.5)]
+    assert len(sets) == 8
+    fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr, parmsets=sets))
+    r1 = fe.scan(base.rows).fetch()
+    n = base.rows.shape[0]
+    k = int(1e7 // n) + 1
+    rk = fe.scan(torch.from_numpy(base.rows).cuda().repeat(k, 1).contiguous()).fetch()
+    for p in range(8):
+        ref = _flat_all(r1, p, 0, n)
+        assert ref.shape[0] > 1000
+        for j in (0, k - 1):
+            got = _flat_all(rk, p, j * n, (j + 1) * n)
+            assert got.shape == ref.shape and (got == ref).all(), f"parmset {p} copy {j}"
+    # oracle cross-check of two of the sets on the base tape (each as the only set of a .parms file)
+    for p in (0, 5):
+        bf, rise, mp, al, _, _ = sets[p]
+        parms = ("parms active, clk_window, clk_alpha, agc_window, agc_alpha, min_peak, pulse_adj, pkww_bitfrac, pkww_rise, z1pt, z2pt, id\n"
+                 f"{{1, 0, 0.015, 0, {al}, {mp}, 0.3, {bf}, {rise}, 1.45, 2.35, PRM}}\n")
+        (tmp_path / f"p{p}.parms").write_text(parms)
+        att = oracle_attempts(hdr, base.rows, [f"-parms={tmp_path}/p{p}.parms"], str(tmp_path))
+        fe1 = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr, parmsets=[sets[p]]))
+        msgs, stats = check_tape(fe1, hdr, base.rows, att)
+        assert not msgs, "\n".join(msgs[:8])
