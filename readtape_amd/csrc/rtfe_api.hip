@@ -33,7 +33,8 @@ struct rtfe_handle {
    int lds_bytes;
    int num_cus;
    int timing;
-   hipEvent_t ev[4];
+   hipEvent_t ev[5];
+   int screen_lds_bytes;
 };
 
 static thread_local char g_err[512] = "";
@@ -44,9 +45,9 @@ static int fail(int code, const char *fmt, ...) {
 extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
-static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_decode"};
-extern "C" int rtfe_kernel_count(void) { return 3; }
-extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < 3) ? KNAMES[i] : ""; }
+static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_screen", "k_decode"};
+extern "C" int rtfe_kernel_count(void) { return 4; }
+extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < 4) ? KNAMES[i] : ""; }
 
 extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (!c || !out) return fail(-1, "null argument");
@@ -135,14 +136,14 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    d.debug = getenv("RTFE_DEBUG") != nullptr;
    {
       const int nwalk = c->nparmsets * c->ntrks;
-      int rc = (24 * 1024) / (nwalk * 12);
+      int rc = (24 * 1024) / (nwalk * 20);
       d.rec_cap = rc > 64 ? 64 : (rc < 8 ? 8 : rc);
       d.run_cap = d.tile_rows / 16 < 16 ? 16 : d.tile_rows / 16; }
    h->lds_bytes = (((c->ntrks * (kHaloRows + d.tile_rows + 8) * 2 + 15) & ~15)
                    + ((d.nscreens * 3 * c->ntrks * (d.tile_rows / 8) + 15) & ~15)
                    + ((d.nscreens * 2 * c->ntrks * d.tile_rows + 15) & ~15)
-                   + c->nparmsets * c->ntrks * (10 * 4 + d.rec_cap * 12 + 4) + 128
-                   + d.nscreens * c->ntrks * (d.run_cap * 24 + 32 * 4) + 64
+                   + c->nparmsets * c->ntrks * (10 * 4 + d.rec_cap * 20 + 4) + 128
+                   + d.nscreens * c->ntrks * (d.run_cap * 32 + 32 * 4) + 64
                    + c->nparmsets * c->ntrks * 192 + 64);
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
    hipDeviceProp_t prop;
@@ -151,26 +152,32 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    h->num_cus = prop.multiProcessorCount;
    if (hipMalloc(&h->d_dev, sizeof(DevCfg)) != hipSuccess) { delete h; return fail(-21, "hipMalloc failed"); }
    if (hipMemcpy(h->d_dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->d_dev); delete h; return fail(-22, "hipMemcpy failed"); }
+   h->lds_bytes += c->nparmsets * c->ntrks * (192 + 40) + 64;   // second walker array + AGC ring backup (optimistic commit)
+   h->screen_lds_bytes = (((c->ntrks * (kHaloRows + d.tile_rows + 8) * 2 + 15) & ~15)
+                          + ((d.nscreens * 3 * c->ntrks * (d.tile_rows / 8) + 15) & ~15)
+                          + ((d.nscreens * 2 * c->ntrks * d.tile_rows + 15) & ~15)
+                          + d.nscreens * c->ntrks * (d.run_cap * 32 + 32 * 4) + 128);
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen), hipFuncAttributeMaxDynamicSharedMemorySize, h->screen_lds_bytes);
    *out = h;
    return 0; }
 
 extern "C" int rtfe_set_timing(rtfe_handle *h, int enable) {
    if (!h) return fail(-1, "null argument");
-   if (enable && !h->timing) for (int i = 0; i < 4; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
-   if (!enable && h->timing) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(h->ev[i]);
+   if (enable && !h->timing) for (int i = 0; i < 5; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
+   if (!enable && h->timing) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(h->ev[i]);
    h->timing = enable != 0;
    return 0; }
 
 extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
    if (!h || !out || !h->timing) return fail(-41, "timing is not enabled");
-   if (hipEventSynchronize(h->ev[3]) != hipSuccess) return fail(-42, "hipEventSynchronize failed");
-   for (int i = 0; i < 3; ++i) if (hipEventElapsedTime(&out[i], h->ev[i], h->ev[i + 1]) != hipSuccess) return fail(-43, "hipEventElapsedTime failed");
+   if (hipEventSynchronize(h->ev[4]) != hipSuccess) return fail(-42, "hipEventSynchronize failed");
+   for (int i = 0; i < 4; ++i) if (hipEventElapsedTime(&out[i], h->ev[i], h->ev[i + 1]) != hipSuccess) return fail(-43, "hipEventElapsedTime failed");
    return 0; }
 
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
-   if (h->timing) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(h->ev[i]);
+   if (h->timing) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(h->ev[i]);
    (void)hipFree(h->d_dev);
    delete h; }
 
@@ -181,8 +188,16 @@ static long long nwords_for(const rtfe_handle *h, int64_t nrows) {
    const long long nchunks = (nrows * h->dev.ntrks) / 512 + 1;
    return (nchunks + 63) / 64; }
 
+static long long ntiles_for(const rtfe_handle *h, int64_t nrows) { return (nrows + h->dev.tile_rows - 1) / h->dev.tile_rows; }
+static long long pool_cap_for(const rtfe_handle *h, int64_t nrows) {
+   return (long long)((double)nrows * h->dev.ntrks * h->dev.nscreens / 20.0) + 65536; }
+// workspace: [0,256) scratch | quiet words | tile directory | run pool
+static size_t ws_dir_off(const rtfe_handle *h, int64_t nrows) { return (256 + (size_t)nwords_for(h, nrows) * 8 + 255) & ~(size_t)255; }
+static size_t ws_pool_off(const rtfe_handle *h, int64_t nrows) {
+   return (ws_dir_off(h, nrows) + (size_t)ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(TileDir) + 255) & ~(size_t)255; }
+
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return (size_t)nwords_for(h, nrows) * 8 + 256; }
+   return ws_pool_off(h, nrows) + (size_t)pool_cap_for(h, nrows) * sizeof(PackedRun) + 256; }
 
 extern "C" int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows) {
    return (nrows * h->dev.ntrks / 512) / h->dev.gap_chunks + 4; }
@@ -219,6 +234,19 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
                       d_bursts, (long long)max_bursts, scratch, d_nbursts);
    if (h->timing) (void)hipEventRecord(h->ev[2], st);
+   TileDir *dirp = reinterpret_cast<TileDir *>(reinterpret_cast<char *>(d_workspace) + ws_dir_off(h, nrows));
+   PackedRun *poolp = reinterpret_cast<PackedRun *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
+   const bool use_screen = !h->dev.find_zeros && getenv("RTFE_NO_SCREEN_PASS") == nullptr;
+   if (use_screen) {
+      const long long ntiles = ntiles_for(h, nrows);
+      int spc = (160 * 1024) / (h->screen_lds_bytes + 1024);
+      if (spc > 8) spc = 8;
+      if (spc < 1) spc = 1;
+      long long sgrid = (long long)h->num_cus * spc;
+      if (sgrid > ntiles) sgrid = ntiles;
+      hipLaunchKernelGGL(k_screen, dim3((unsigned)sgrid), dim3(256), h->screen_lds_bytes, st, h->d_dev, d_rows, (long long)nrows, dirp, poolp,
+                         (unsigned long long)pool_cap_for(h, nrows), &scratch->pool_cursor, ntiles); }
+   if (h->timing) (void)hipEventRecord(h->ev[3], st);
    // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
    // beat wide ones; k_decode holds ~180 VGPRs => 2 waves/SIMD => 8 waves per CU
    const int nwalk = h->dev.nparm * h->dev.ntrks;
@@ -229,8 +257,9 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (per_cu < 1) per_cu = 1;
    const int dgrid = h->num_cus * per_cu;
    hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
-                      (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0);
-   if (h->timing) (void)hipEventRecord(h->ev[3], st);
+                      (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
+                      use_screen ? (const TileDir *)dirp : (const TileDir *)nullptr, (const PackedRun *)poolp);
+   if (h->timing) (void)hipEventRecord(h->ev[4], st);
    return launch_check("rtfe_scan"); }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,
@@ -250,5 +279,6 @@ extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nr
                       cap > 0xffffffffull ? 0xffffffffull : cap);
    const int nwalk = h->dev.nparm * h->dev.ntrks;
    hipLaunchKernelGGL(k_decode, dim3(1), dim3(nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256)), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
-                      (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1);
+                      (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1,
+                      (const TileDir *)nullptr, (const PackedRun *)nullptr);
    return launch_check("rtfe_scan_exact"); }

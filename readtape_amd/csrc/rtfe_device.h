@@ -53,4 +53,19 @@ struct DevCfg {
    DevScreen screen[kMaxScreens];
 };
 
+// ---- what the dense screen pass (k_screen) leaves in HBM for the sequential pass (k_decode) ----
+struct PackedRun {             // one candidate run of one (screen, track) of one tile: 20 bytes
+   uint16_t n_s;               // first candidate row, tile-relative
+   uint16_t len;               // candidate rows in the run
+   int16_t  m, prev, next;     // the extreme and its two neighbours (int16 codes)
+   uint8_t  ld;                // left_distance of the extreme at row n_s
+   uint8_t  kindfast;          // bit 7: 0 top / 1 bottom; bits 0-3: rows n_s+k decidable from marg[k]
+   int16_t  marg[4];
+};
+struct TileDir {               // per (tile, screen, track): 8 bytes
+   uint32_t offset;            // index of the first PackedRun in the pool
+   uint16_t count;             // 0xFFFF: not available (pool full / more runs than the tile list holds)
+   int16_t  last_rescan;       // tile-relative row of the last forced rescan ("window maximum leaves"), -1 if none
+};
+
 }  // namespace rtfe

@@ -76,6 +76,7 @@ struct BurstScratch {            // lives in the workspace
    int   nbursts_total;          // owned bursts + (time shards) the first burst of the halo, which only bounds the last owned one
    int   pad[13];
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
+   unsigned long long pool_cursor;   // at byte 128: next free PackedRun of the pool (k_screen)
 };
 #ifdef RTFE_CPU_EMUL
 static inline long long clock64() { return 0; }
@@ -206,7 +207,8 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
    if (threadIdx.x == 0) {
       scratch->nbursts = n_owned; scratch->nbursts_total = nb; scratch->queue = 0; *nbursts_out = n_owned;
       if (n_owned == nb && own_rows < nrows && n_owned > 0) bursts[n_owned - 1].flags |= RTFE_F_TRUNCATED; }
-   if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0; }
+   if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0;
+   if (threadIdx.x == 8) scratch->pool_cursor = 0; }
 
 // ------------------------------------------------------------------------------------------------
 // k_decode
@@ -270,7 +272,7 @@ struct Walker {            // one per (parameter set, track); lives in registers
 
 // A detection whose (cheap-to-defer) half-sample refinement, volt conversion and event store are done
 // after the walk by all lanes (finalize_tile): the sequential walker keeps only what feeds back.
-struct Rec { unsigned int idx; unsigned short n_rel; unsigned char ld, kind; float g; };
+struct Rec { unsigned int idx; unsigned short n_rel; unsigned char ld, kind; float g; short val, prev, next, pad; };   // 20 bytes
 
 struct Ctx {               // per-workgroup constants for the walkers
    const DevCfg *cfg;
@@ -399,7 +401,7 @@ __device__ __forceinline__ void store_event(const Ctx &cx, int pidx, int trk, un
 // `p` = row of the first window element equal to the extreme.  With defer != 0 the refinement and the
 // event store are queued for finalize_tile() (possible whenever nothing downstream needs the peak time).
 __device__ __forceinline__ void emit_peak(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, long long n,
-                                 long long lo, long long p, float val, int val_i, bool is_top, bool defer) {
+                                 long long lo, long long p, float val, int val_i, bool is_top, bool defer, const short *nbr = nullptr) {
    const DevCfg *cfg = cx.cfg;
    const int left_distance = (int)(p - lo) + 1;
    // PE decides the end of the preamble from peak times (src/decode_pe.c:136-138): only then is the time needed here
@@ -408,7 +410,8 @@ __device__ __forceinline__ void emit_peak(Walker &w, Ctx &cx, int pidx, int trk,
    if (w.nevents >= cx.cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
    else if (defer && !need_time && cx.nrec < cx.rec_cap) {
       Rec r; r.idx = w.nevents; r.n_rel = (unsigned short)(n - cx.tile.row0); r.ld = (unsigned char)left_distance;
-      r.kind = is_top ? 0 : 1; r.g = w.agc_gain;
+      r.kind = is_top ? 0 : 1; r.g = w.agc_gain; r.val = (short)val_i; r.pad = 0;
+      if (nbr) { r.prev = nbr[0]; r.next = nbr[1]; } else { r.prev = (short)cx.tile.y(trk, p - 1); r.next = (short)cx.tile.y(trk, p + 1); }
       cx.recs[cx.nrec++] = r; }
    else {
       const int adjcode = refine_code(cfg, val_i, cx.tile.y(trk, p - 1), cx.tile.y(trk, p + 1), w.agc_gain, is_top);
@@ -422,19 +425,14 @@ __device__ __forceinline__ void emit_peak(Walker &w, Ctx &cx, int pidx, int trk,
    update_thresholds(w, P, cfg->lsb_per_volt);
    w.blind_until = n + left_distance; }                          // pkww_countdown = left_distance (src/decoder.c:741)
 
-// all lanes: turn this tile's queued records of one walker into events
+// all lanes: turn this tile's queued records of one walker into events (no tile data needed)
 __device__ __forceinline__ void finalize_records(const Ctx &cx, const Rec *recs, int nrec, int pidx, int trk, int lane, int nlanes) {
    const DevCfg *cfg = cx.cfg;
-   const Tile &tl = cx.tile;
-   const int W = cfg->parm[pidx].W;
-   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
    for (int i = lane; i < nrec; i += nlanes) {
       const Rec r = recs[i];
-      const int n = r.n_rel, pos = n - W + r.ld;              // lo + ld - 1
-      const int val_i = yb[pos];
       const bool is_top = r.kind == 0;
-      const int adjcode = refine_code(cfg, val_i, yb[pos - 1], yb[pos + 1], r.g, is_top);
-      store_event(cx, pidx, trk, r.idx, tl.row0 + n, volt(val_i, cfg->maxvolts), r.g, is_top, adjcode, r.ld); } }
+      const int adjcode = refine_code(cfg, r.val, r.prev, r.next, r.g, is_top);
+      store_event(cx, pidx, trk, r.idx, cx.tile.row0 + r.n_rel, volt(r.val, cfg->maxvolts), r.g, is_top, adjcode, r.ld); } }
 
 // exact window minimum and its first position (the rescan of src/decoder.c:767-775)
 __device__ __forceinline__ void rescan_min(const Tile &tl, int trk, long long lo, long long hi, int &mn, long long &pos) {
@@ -526,7 +524,8 @@ struct RunRec {
    unsigned char  kind;       // 0 top, 1 bottom
    unsigned char  fast;       // bit k: row n_s+k can be decided from marg[k] (same extreme; bottoms: forced rescan at that row)
    unsigned short len;        // candidate rows in the run
-   unsigned short pad;
+   unsigned char  ld, pad;    // left_distance of the extreme at row n_s
+   short          prev, next; // the extreme's neighbours (for the half-sample refinement)
    short          marg[4];    // min(|m - left edge|, |m - right edge|) at rows n_s .. n_s+3
    float          v;          // volt(m)
 };                            // 24 bytes
@@ -721,7 +720,7 @@ __device__ __forceinline__ void build_runs_word(const Tile &tl, const DevCfg *cf
                mg = min(min(a, c), 32767);
                fast |= 1u << j; } }
          r.marg[j] = (short)mg; }
-      r.fast = (unsigned char)fast; r.pad = 0;
+      r.fast = (unsigned char)fast; r.pad = 0; r.ld = ld[n_s]; r.prev = yb[p - 1]; r.next = yb[p + 1];
       r.v = volt(r.m, cfg->maxvolts);
       out[k++] = r; } }
 
@@ -845,11 +844,157 @@ __device__ __forceinline__ long long find_reset(const DevCfg *cfg, const Tile &t
    __syncthreads();
    return r; }          // 0 => no provably safe restart row inside the margin
 
+// ---- optimistic walk: the tile's run records come from HBM (k_screen wrote them); no sample is in LDS.  Decides
+// every candidate row from integer margins alone; returns false the moment anything needs the samples (guard band,
+// a row past the record's margins, overlapping kinds, a bottom without a forced rescan, PE preamble timing, a full
+// record list, the start-up path) — the caller then redoes the tile with the full path from the untouched state.
+__device__ __forceinline__ bool walk_optimistic(Walker &w, Ctx &cx, int pidx, int trk, long long limit,
+                                                const RunRec *runs, int nruns, int last_rescan_rel) {
+   const DevCfg *cfg = cx.cfg;
+   const DevParm &P = cfg->parm[pidx];
+   const Tile &tl = cx.tile;
+   const int W = P.W;
+   if (!w.fast) return false;
+   const long long tile_end = tl.row0 + tl.nrows;
+   if (limit > tile_end) limit = tile_end;
+   const int lim = (int)(limit - tl.row0);
+   long long n64 = max(w.next, w.blind_until + 1);
+   int cur = (n64 - tl.row0 > lim) ? lim : (int)(n64 - tl.row0);
+   if (cur < 0) cur = 0;
+   for (int i = 0; i < nruns; ++i) {
+      const RunRec &r = runs[i];
+      const int n_e = min((int)r.n_s + (int)r.len, lim);
+      int n = max((int)r.n_s, cur);
+      const bool is_top = r.kind == 0;
+      const bool peak_ok = w.reqmin == 0 || (is_top ? r.m >= w.min_hi : -r.m >= w.min_hi);
+      const bool peak_no = !(w.reqmin == 0) && (is_top ? r.m <= w.min_lo : -r.m <= w.min_lo);
+      while (n < n_e) {
+         const int k = n - r.n_s;
+         if (k >= kRunFast || !((r.fast >> k) & 1)) return false;
+         const int mg = r.marg[k];
+         if (mg <= w.rise_lo || peak_no) { ++n; continue; }            // fails for sure
+         if (!(mg >= w.rise_hi && peak_ok)) return false;               // guard band: needs the float test
+         if (cfg->mode == RTFE_PE && !w.datablock && w.peakcount >= 68) return false;   // peak time needed (src/decode_pe.c:136-138)
+         if (cx.nrec >= cx.rec_cap || w.nevents >= cx.cap) return false;
+         if (!is_top) { w.minv = r.m; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + r.p + W; w.chain_pending = false; }
+         const short nbr[2] = {r.prev, r.next};
+         emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + n - W + 1, tl.row0 + r.p, r.v, r.m, is_top, true, nbr);
+         n = (int)(w.blind_until + 1 - tl.row0); }
+      cur = max(cur, n);
+      if (cur > lim) cur = lim; }
+   cur = max(cur, lim);
+   n64 = tl.row0 + cur;
+   w.next = n64 < limit ? n64 : limit;
+   if (limit - 1 > w.cpos) {                                         // lazy stale-minimum bookkeeping (see walk())
+      const long long a = last_rescan_rel >= 0 ? tl.row0 + last_rescan_rel : -1;
+      if (a > w.cpos && a <= limit - 1) { w.cpos = a; w.chain_pending = true; }
+      else if (a > limit - 1) return false;                          // the burst stops inside this tile: let the full path look
+      if (limit - 1 - w.cpos > kHaloRows - 2 * W - 8 - cfg->maxskew) return false; }
+   return true; }
+
+__device__ __forceinline__ void unpack_run(RunRec &r, const PackedRun &q, int W, float maxvolts) {
+   r.n_s = q.n_s; r.len = q.len; r.m = q.m; r.prev = q.prev; r.next = q.next; r.ld = q.ld; r.pad = 0;
+   r.kind = q.kindfast >> 7; r.fast = q.kindfast & 15;
+   r.p = (short)((int)q.n_s - W + (int)q.ld);
+   #pragma unroll
+   for (int j = 0; j < kRunFast; ++j) r.marg[j] = q.marg[j];
+   r.v = volt(q.m, maxvolts); }
+
+// ------------------------------------------------------------------------------------------------
+// k_screen: the dense, stateless pass.  One workgroup per tile of the tape-global grid: coalesced loads of the
+// AoS rows -> SoA LDS tile, sliding-window screen, candidate-run records -> HBM (TileDir + PackedRun pool).
+// Everything the sequential pass needs in the common case; it never has to touch the samples again.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_screen(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
+                                                TileDir *__restrict__ dir, PackedRun *__restrict__ pool, unsigned long long pool_cap,
+                                                unsigned long long *__restrict__ pool_cursor, long long ntiles) {
+#ifdef RTFE_CPU_EMUL
+   unsigned char *smem = g_dyn_smem;
+#else
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
+   __shared__ DevCfg cfg;
+   __shared__ unsigned long long s_base;
+   __shared__ int s_off[kMaxScreens * RTFE_MAXTRKS + 1];
+   for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
+   __syncthreads();
+   const int ntrks = cfg.ntrks, nst = cfg.nscreens * ntrks;
+   Tile tl;
+   tl.x = reinterpret_cast<int16_t *>(smem);
+   tl.ldw = kHaloRows + cfg.tile_rows + 8;
+   tl.ntrks = ntrks; tl.skew = cfg.skew; tl.reset = -(1ll << 40);
+   size_t off = ((size_t)ntrks * tl.ldw * 2 + 15) & ~(size_t)15;
+   tl.bits = smem + off; tl.bstride = cfg.tile_rows / 8;
+   off += (size_t)cfg.nscreens * 3 * ntrks * (cfg.tile_rows / 8); off = (off + 15) & ~(size_t)15;
+   tl.ldpos = smem + off;
+   off += (size_t)cfg.nscreens * 2 * ntrks * cfg.tile_rows; off = (off + 15) & ~(size_t)15;
+   RunRec *runs_all = reinterpret_cast<RunRec *>(smem + off);
+   off += (size_t)nst * cfg.run_cap * sizeof(RunRec);
+   int *runcnt = reinterpret_cast<int *>(smem + off);
+   const long long T = cfg.tile_rows;
+   for (long long g = blockIdx.x; g < ntiles; g += gridDim.x) {
+      tl.row0 = g * T; tl.nrows = (int)((tl.row0 + T <= nrows) ? T : nrows - tl.row0);
+      __syncthreads();
+      load_tile(&cfg, tl, rows, nrows);
+      __syncthreads();
+      run_screens(&cfg, tl);
+      __syncthreads();
+      const int nwords = (tl.nrows + 63) >> 6;
+      const int nitems = nst * nwords;
+      for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
+         const int st = i / nwords, wd = i - st * nwords;
+         runcnt[st * 32 + wd] = __popcll(run_starts(tl, st / ntrks, st - (st / ntrks) * ntrks, wd)); }
+      __syncthreads();
+      for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
+         const int st = i / nwords, wd = i - st * nwords;
+         int base = 0;
+         for (int k = 0; k < wd; ++k) base += runcnt[st * 32 + k];
+         const int sc = st / ntrks;
+         build_runs_word(tl, &cfg, sc, st - sc * ntrks, wd, cfg.screen[sc].W, runs_all + (size_t)st * cfg.run_cap, base, cfg.run_cap); }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+         int tot = 0;
+         for (int st = 0; st < nst; ++st) {
+            int c = 0;
+            for (int k = 0; k < nwords; ++k) c += runcnt[st * 32 + k];
+            s_off[st] = (c > cfg.run_cap) ? -1 - tot : tot;          // negative: this list overflowed the tile's capacity
+            if (c <= cfg.run_cap) tot += c; }
+         s_off[nst] = tot;
+         const unsigned long long b = atomicAdd(pool_cursor, (unsigned long long)tot);
+         s_base = (b + tot <= pool_cap) ? b : ~0ull; }
+      __syncthreads();
+      const unsigned long long base = s_base;
+      if (threadIdx.x < nst) {
+         const int st = threadIdx.x, sc = st / ntrks, trk = st - sc * ntrks;
+         TileDir d;
+         const bool ovf = s_off[st] < 0 || base == ~0ull;
+         int cnt = 0;
+         for (int k = 0; k < nwords; ++k) cnt += runcnt[st * 32 + k];
+         d.offset = ovf ? 0u : (uint32_t)(base + (unsigned long long)s_off[st]);
+         d.count = ovf ? (uint16_t)0xFFFF : (uint16_t)cnt;
+         const long long a = last_forced_rescan(tl, sc, trk, tl.row0 - 1, tl.row0 + tl.nrows - 1);
+         d.last_rescan = (int16_t)(a < 0 ? -1 : a - tl.row0);
+         dir[g * nst + st] = d; }
+      if (base != ~0ull)
+         for (int st = 0; st < nst; ++st) {
+            if (s_off[st] < 0) continue;
+            int cnt = 0;
+            for (int k = 0; k < nwords; ++k) cnt += runcnt[st * 32 + k];
+            for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
+               const RunRec &r = runs_all[(size_t)st * cfg.run_cap + k];
+               PackedRun q;
+               q.n_s = r.n_s; q.len = r.len; q.m = r.m; q.prev = r.prev; q.next = r.next; q.ld = r.ld;
+               q.kindfast = (uint8_t)((r.kind << 7) | (r.fast & 15));
+               for (int j = 0; j < kRunFast; ++j) q.marg[j] = r.marg[j];
+               pool[base + (unsigned long long)s_off[st] + k] = q; } }
+      __syncthreads(); } }
+
 __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows,
                                                            long long nrows, long long row_base,
                                                            rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
                                                            uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
-                                                           uint32_t parmset_mask, int screen_off, int single_exact) {
+                                                           uint32_t parmset_mask, int screen_off, int single_exact,
+                                                           const TileDir *__restrict__ dir, const PackedRun *__restrict__ pool) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;            // tests/cpu_emul only
 #else
@@ -859,6 +1004,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    __shared__ int s_burst;
    __shared__ long long s_min;
    __shared__ unsigned int s_flags;
+   __shared__ int s_needfull;
+   __shared__ TileDir s_dir[kMaxScreens * RTFE_MAXTRKS];
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
    if (screen_off && threadIdx.x == 0)
@@ -904,8 +1051,29 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    off += (size_t)cfg.nscreens * ntrks * 32 * 4;
    off = (off + 15) & ~(size_t)15;
    Walker *walkers = reinterpret_cast<Walker *>(smem + off);       // [nwalk]
+   off += (size_t)nwalk * sizeof(Walker);
+   off = (off + 15) & ~(size_t)15;
+   Walker *walkers_next = reinterpret_cast<Walker *>(smem + off);  // [nwalk] result of an optimistic tile, committed only if all lanes agree
+   off += (size_t)nwalk * sizeof(Walker);
+   off = (off + 15) & ~(size_t)15;
+   float *heights_bak = reinterpret_cast<float *>(smem + off);     // [nwalk][10]
    cx.rec_cap = cfg.rec_cap;
    cx.recs = recs_all + (size_t)(is_walker ? my_w : 0) * cfg.rec_cap;
+
+   // restart row of a zone-started burst: load the last kMarginRows rows of its zone, screen them, find the last
+   // forced rescan per (parmset, track) (find_reset).  Both the burst itself and its predecessor (which must know
+   // where to stop) evaluate this, on the same rows, so they agree.  Returns -1 when no safe row exists.
+   auto zone_reset = [&](const rtfe_burst &Z) -> long long {
+      if (Z.zone_end - Z.zone_first < kMarginRows + 64) return -1;
+      if (cfg.find_zeros) return Z.zone_end - kMarginRows;       // any restart inside the zone is equivalent
+      cx.tile.row0 = Z.zone_end - kMarginRows; cx.tile.nrows = kMarginRows; cx.tile.reset = -(1ll << 40);
+      __syncthreads();
+      load_tile(&cfg, cx.tile, rows, nrows);
+      __syncthreads();
+      run_screens(&cfg, cx.tile);
+      __syncthreads();
+      const long long r = find_reset(&cfg, cx.tile, &s_min);
+      return (r <= 0 || r < Z.zone_first) ? -1 : r; };
 
    for (;;) {
       if (threadIdx.x == 0) { s_burst = atomicAdd(&scratch->queue, 1); s_flags = 0; }
@@ -913,29 +1081,24 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       const int b = s_burst;
       if (b >= scratch->nbursts) break;
       const int nb = scratch->nbursts_total;
-      rtfe_burst B = bursts[b];
+      const rtfe_burst B = bursts[b];
       const bool exact = B.flags & RTFE_F_EXACT_START;
       const bool last = b + 1 >= nb;
       const bool has_tail = !last && !single_exact;
-      const long long next_zone_end = last ? nrows : bursts[b + 1].zone_end;
       cx.events = events + B.event_base;
       cx.cap = B.event_cap;
-      // ---- head: find this burst's restart row ----
-      long long reset = B.reset_sample, t0;
+      // ---- where this burst restarts, and where the next one does (= where this one stops) ----
       unsigned int bflags = B.flags;
+      long long reset = B.reset_sample;
       if (!exact) {
-         cx.tile.row0 = B.zone_end - kMarginRows; cx.tile.nrows = kMarginRows; cx.tile.reset = -(1ll << 40);
-         if (B.zone_end - B.zone_first < kMarginRows + 64) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; }
-         load_tile(&cfg, cx.tile, rows, nrows);
-         __syncthreads();
-         run_screens(&cfg, cx.tile);
-         __syncthreads();
-         if (cfg.find_zeros) reset = B.zone_end - kMarginRows;    // any restart inside the zone is equivalent
-         else if (!(bflags & RTFE_F_UNSAFE)) {
-            reset = find_reset(&cfg, cx.tile, &s_min);
-            if (reset <= 0 || reset < B.zone_first) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; } }
-         t0 = B.zone_end - kMarginRows; }
-      else t0 = reset & ~7ll;
+         reset = zone_reset(B);
+         if (reset < 0) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; } }
+      const long long hard_end = single_exact ? (B.end_sample < nrows ? B.end_sample : nrows) : nrows;
+      long long stop = hard_end;
+      if (has_tail) {
+         const rtfe_burst NB = bursts[b + 1];
+         stop = zone_reset(NB);
+         if (stop < 0) stop = NB.zone_end - kMarginRows; }
       // ---- walker init: init_trackstate + init_trackpeak_state (src/decoder.c:413-455) ----
       // (the walker's state lives in LDS between tiles so that the all-lane phases do not carry it in registers)
       if (is_walker) {
@@ -946,43 +1109,57 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          walkers[my_w] = w;
          for (int i = 0; i < 10; ++i) cx.heights[i] = 0; }
       cx.tile.reset = reset;
-      // ---- tiles ----
-      const long long hard_end = single_exact ? (B.end_sample < nrows ? B.end_sample : nrows) : nrows;
-      long long tile0 = t0;
-      bool first_tile = !exact;                        // the head tile is already loaded and screened
-      long long stop = hard_end;                       // rows >= stop belong to the next burst
-      bool done = false;
-      while (!done) {
-         long long tn;
-         bool is_tail = false;
-         if (first_tile) tn = kMarginRows;
-         else {
-            const long long normal_end = has_tail ? next_zone_end - kMarginRows : hard_end;
-            if (tile0 >= normal_end && has_tail) { is_tail = true; tn = kMarginRows; }
-            else { tn = normal_end - tile0; if (tn > cfg.tile_rows) tn = cfg.tile_rows; } }
+      // ---- tiles of the tape-global grid that intersect [reset, stop) ----
+      const long long T = cfg.tile_rows;
+      for (long long g = reset / T; g * T < stop; ++g) {
+         const long long tile0 = g * T;
+         const long long tn = (tile0 + T <= nrows) ? T : nrows - tile0;
          if (tn <= 0) break;
          long long c0 = 0, c1 = 0, c2 = 0;
-         if (!first_tile) {
-            cx.tile.row0 = tile0; cx.tile.nrows = (int)tn;
+         cx.tile.row0 = tile0; cx.tile.nrows = (int)tn;
+         __syncthreads();
+         if (cfg.debug) c0 = clock64();
+         // ---- optimistic: decide the whole tile from the run records k_screen left in HBM ----
+         bool done_tile = false;
+         if (dir && !screen_off && !cfg.find_zeros) {
+            const int nst = cfg.nscreens * ntrks;
+            if (threadIdx.x == 0) s_needfull = 0;
+            if (threadIdx.x < nst) s_dir[threadIdx.x] = dir[g * nst + threadIdx.x];
             __syncthreads();
-            if (cfg.debug) c0 = clock64();
-            load_tile(&cfg, cx.tile, rows, nrows);
-            __syncthreads();
-            if (cfg.debug) c1 = clock64();
-            run_screens(&cfg, cx.tile);
-            __syncthreads();
-            if (cfg.debug) c2 = clock64();
-            if (is_tail) {
-               // the next burst restarts inside this tile; compute exactly what its own workgroup computes
-               const rtfe_burst NB = bursts[b + 1];
-               long long nr = -1;
-               if (NB.zone_end - NB.zone_first >= kMarginRows + 64) {
-                  const long long saved = cx.tile.reset;
-                  cx.tile.reset = -(1ll << 40);
-                  nr = cfg.find_zeros ? NB.zone_end - kMarginRows : find_reset(&cfg, cx.tile, &s_min);
-                  cx.tile.reset = saved; }
-               if (nr <= 0 || nr < NB.zone_first) nr = NB.zone_end - kMarginRows;
-               stop = nr; } }
+            bool avail = true;
+            for (int st = 0; st < nst; ++st) if (s_dir[st].count == 0xFFFF || s_dir[st].count > cfg.run_cap) avail = false;
+            if (avail) {
+               for (int st = 0; st < nst; ++st) {
+                  const int cnt = s_dir[st].count, W = cfg.screen[st / ntrks].W;
+                  for (int k = threadIdx.x; k < cnt; k += blockDim.x)
+                     unpack_run(runs_all[(size_t)st * cfg.run_cap + k], pool[(size_t)s_dir[st].offset + k], W, cfg.maxvolts); }
+               __syncthreads();
+               cx.nrec = 0;
+               if (active) {
+                  const int st = cfg.parm[pidx].screen * ntrks + trk;
+                  Walker w = walkers[my_w];
+                  for (int i = 0; i < 10; ++i) heights_bak[my_w * 10 + i] = cx.heights[i];     // part of the walker's state
+                  if (walk_optimistic(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, s_dir[st].count, s_dir[st].last_rescan))
+                     walkers_next[my_w] = w;
+                  else atomicOr((unsigned int *)&s_needfull, 1u); }
+               if (is_walker) nrec_all[my_w] = cx.nrec;
+               __syncthreads();
+               if (s_needfull && active) for (int i = 0; i < 10; ++i) cx.heights[i] = heights_bak[my_w * 10 + i];
+               if (!s_needfull) {
+                  if (is_walker && active) walkers[my_w] = walkers_next[my_w];
+                  for (int w2 = 0; w2 < nwalk; ++w2)
+                     finalize_records(cx, recs_all + (size_t)w2 * cfg.rec_cap, nrec_all[w2], w2 / ntrks, w2 % ntrks, threadIdx.x, blockDim.x);
+                  done_tile = true;
+                  if (cfg.debug && threadIdx.x == 0) atomicAdd(&scratch->dbg[7], 1ull); }
+               __syncthreads(); } }
+         if (done_tile) continue;
+         // ---- full path: samples into LDS, screen, run records, exact walkers ----
+         load_tile(&cfg, cx.tile, rows, nrows);
+         __syncthreads();
+         if (cfg.debug) c1 = clock64();
+         run_screens(&cfg, cx.tile);
+         __syncthreads();
+         if (cfg.debug) c2 = clock64();
          // run records for every (screen, track), by all lanes
          {
             const int nwords = (cx.tile.nrows + 63) >> 6;
@@ -998,6 +1175,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                const int sc = st / ntrks;
                build_runs_word(cx.tile, &cfg, sc, st - sc * ntrks, wd, cfg.screen[sc].W, runs_all + (size_t)st * cfg.run_cap, base, cfg.run_cap); }
             __syncthreads(); }
+         long long c2b = 0, c2c = 0;
+         if (cfg.debug) c2b = clock64();
          cx.nrec = 0;
          if (active) {
             const int st = cfg.parm[pidx].screen * ntrks + trk;
@@ -1010,17 +1189,17 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
             walkers[my_w] = w; }
          if (is_walker) nrec_all[my_w] = cx.nrec;
          __syncthreads();
+         if (cfg.debug) c2c = clock64();
          for (int w2 = 0; w2 < nwalk; ++w2)                      // all lanes: refinement, volt conversion, event stores
             finalize_records(cx, recs_all + (size_t)w2 * cfg.rec_cap, nrec_all[w2], w2 / ntrks, w2 % ntrks, threadIdx.x, blockDim.x);
-         if (cfg.debug && !first_tile) {
+         if (cfg.debug) {
             __syncthreads();
             if (threadIdx.x == 0) {
                const long long c3 = clock64();
                atomicAdd(&scratch->dbg[0], (unsigned long long)(c1 - c0)); atomicAdd(&scratch->dbg[1], (unsigned long long)(c2 - c1));
-               atomicAdd(&scratch->dbg[2], (unsigned long long)(c3 - c2)); atomicAdd(&scratch->dbg[3], 1ull); } }
-         first_tile = false;
-         tile0 += tn;
-         if (is_tail || tile0 >= hard_end) done = true; }
+               atomicAdd(&scratch->dbg[2], (unsigned long long)(c3 - c2)); atomicAdd(&scratch->dbg[3], 1ull);
+               atomicAdd(&scratch->dbg[4], (unsigned long long)(c2b - c2)); atomicAdd(&scratch->dbg[5], (unsigned long long)(c2c - c2b));
+               atomicAdd(&scratch->dbg[6], (unsigned long long)(c3 - c2c)); } } }
       // ---- publish ----
       if (is_walker) {
          const unsigned int ne = walkers[my_w].nevents, wf = walkers[my_w].flags;

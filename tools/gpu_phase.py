@@ -20,5 +20,5 @@ ws = r.bufs["ws"].cpu().numpy()
 dbg = ws[64:128].view(np.uint64)
 lens = (r.bursts["end_sample"] - r.bursts["reset_sample"])
 print(json.dumps({"rows": int(rows.shape[0]), "kernel_ms": ms, "bursts": int(r.nbursts), "burst_len_max": int(lens.max()), "burst_len_mean": float(lens.mean()),
-                  "tiles": int(dbg[3]), "cyc_per_tile": {"load": float(dbg[0]) / max(int(dbg[3]), 1), "screen": float(dbg[1]) / max(int(dbg[3]), 1), "walk": float(dbg[2]) / max(int(dbg[3]), 1)},
-                  "events": int(r.counts.sum())}))
+                  "tiles": int(dbg[3]), "cyc_per_tile": {"load": float(dbg[0]) / max(int(dbg[3]), 1), "screen": float(dbg[1]) / max(int(dbg[3]), 1), "walk": float(dbg[2]) / max(int(dbg[3]), 1), "walk_build": float(dbg[4]) / max(int(dbg[3]), 1), "walk_chain": float(dbg[5]) / max(int(dbg[3]), 1), "walk_final": float(dbg[6]) / max(int(dbg[3]), 1)},
+                  "events": int(r.counts.sum()), "optimistic_tiles": int(dbg[7])}))
