@@ -905,7 +905,7 @@ __device__ __forceinline__ void unpack_run(RunRec &r, const PackedRun &q, int W,
 // AoS rows -> SoA LDS tile, sliding-window screen, candidate-run records -> HBM (TileDir + PackedRun pool).
 // Everything the sequential pass needs in the common case; it never has to touch the samples again.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_screen(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
+__global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
                                                 TileDir *__restrict__ dir, PackedRun *__restrict__ pool, unsigned long long pool_cap,
                                                 unsigned long long *__restrict__ pool_cursor, long long ntiles) {
 #ifdef RTFE_CPU_EMUL
@@ -1129,10 +1129,14 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
             bool avail = true;
             for (int st = 0; st < nst; ++st) if (s_dir[st].count == 0xFFFF || s_dir[st].count > cfg.run_cap) avail = false;
             if (avail) {
-               for (int st = 0; st < nst; ++st) {
-                  const int cnt = s_dir[st].count, W = cfg.screen[st / ntrks].W;
-                  for (int k = threadIdx.x; k < cnt; k += blockDim.x)
-                     unpack_run(runs_all[(size_t)st * cfg.run_cap + k], pool[(size_t)s_dir[st].offset + k], W, cfg.maxvolts); }
+               // the tile's records are contiguous in the pool, list after list: one flat pass, all loads in flight together
+               int total = 0;
+               for (int st = 0; st < nst; ++st) total += s_dir[st].count;
+               const size_t pbase = s_dir[0].offset;
+               for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                  int st = 0, k = i;
+                  while (k >= (int)s_dir[st].count) { k -= s_dir[st].count; ++st; }
+                  unpack_run(runs_all[(size_t)st * cfg.run_cap + k], pool[pbase + i], cfg.screen[st / ntrks].W, cfg.maxvolts); }
                __syncthreads();
                cx.nrec = 0;
                if (active) {
