@@ -127,7 +127,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    d.cap_frac = c->events_per_sample_cap > 0 ? c->events_per_sample_cap : 0.125f;
    {
       const char *e = getenv("RTFE_TILE_ROWS");            // tuning knob; the default is what bench.py measures
-      int tr = e ? atoi(e) : 256;
+      int tr = e ? atoi(e) : 512;
       tr = (tr / 64) * 64;
       if (tr < kMarginRows) tr = kMarginRows;
       if (tr > kMaxTileRows) tr = kMaxTileRows;

@@ -77,6 +77,7 @@ struct BurstScratch {            // lives in the workspace
    int   pad[13];
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
    unsigned long long pool_cursor;   // at byte 128: next free PackedRun of the pool (k_screen)
+   unsigned long long dbg2[8];   // dbg[8..15] (contiguous with dbg through pool_cursor is NOT assumed: indexed separately)
 };
 #ifdef RTFE_CPU_EMUL
 static inline long long clock64() { return 0; }
@@ -208,7 +209,8 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
       scratch->nbursts = n_owned; scratch->nbursts_total = nb; scratch->queue = 0; *nbursts_out = n_owned;
       if (n_owned == nb && own_rows < nrows && n_owned > 0) bursts[n_owned - 1].flags |= RTFE_F_TRUNCATED; }
    if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0;
-   if (threadIdx.x == 8) scratch->pool_cursor = 0; }
+   if (threadIdx.x == 8) scratch->pool_cursor = 0;
+   if (threadIdx.x >= 16 && threadIdx.x < 24) scratch->dbg2[threadIdx.x - 16] = 0; }
 
 // ------------------------------------------------------------------------------------------------
 // k_decode
@@ -1126,6 +1128,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
             if (threadIdx.x == 0) s_needfull = 0;
             if (threadIdx.x < nst) s_dir[threadIdx.x] = dir[g * nst + threadIdx.x];
             __syncthreads();
+            long long o1 = 0, o2 = 0, o3 = 0;
+            if (cfg.debug) o1 = clock64();
             bool avail = true;
             for (int st = 0; st < nst; ++st) if (s_dir[st].count == 0xFFFF || s_dir[st].count > cfg.run_cap) avail = false;
             if (avail) {
@@ -1138,6 +1142,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                   while (k >= (int)s_dir[st].count) { k -= s_dir[st].count; ++st; }
                   unpack_run(runs_all[(size_t)st * cfg.run_cap + k], pool[pbase + i], cfg.screen[st / ntrks].W, cfg.maxvolts); }
                __syncthreads();
+               if (cfg.debug) o2 = clock64();
                cx.nrec = 0;
                if (active) {
                   const int st = cfg.parm[pidx].screen * ntrks + trk;
@@ -1148,13 +1153,18 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                   else atomicOr((unsigned int *)&s_needfull, 1u); }
                if (is_walker) nrec_all[my_w] = cx.nrec;
                __syncthreads();
+               if (cfg.debug) o3 = clock64();
                if (s_needfull && active) for (int i = 0; i < 10; ++i) cx.heights[i] = heights_bak[my_w * 10 + i];
                if (!s_needfull) {
                   if (is_walker && active) walkers[my_w] = walkers_next[my_w];
                   for (int w2 = 0; w2 < nwalk; ++w2)
                      finalize_records(cx, recs_all + (size_t)w2 * cfg.rec_cap, nrec_all[w2], w2 / ntrks, w2 % ntrks, threadIdx.x, blockDim.x);
                   done_tile = true;
-                  if (cfg.debug && threadIdx.x == 0) atomicAdd(&scratch->dbg[7], 1ull); }
+                  if (cfg.debug && threadIdx.x == 0) {
+                     const long long o4 = clock64();
+                     atomicAdd(&scratch->dbg[7], 1ull);
+                     atomicAdd(&scratch->dbg2[0], (unsigned long long)(o1 - c0)); atomicAdd(&scratch->dbg2[1], (unsigned long long)(o2 - o1));
+                     atomicAdd(&scratch->dbg2[2], (unsigned long long)(o3 - o2)); atomicAdd(&scratch->dbg2[3], (unsigned long long)(o4 - o3)); } }
                __syncthreads(); } }
          if (done_tile) continue;
          // ---- full path: samples into LDS, screen, run records, exact walkers ----
