@@ -107,6 +107,18 @@ void rt_replay_restore_pos(void *ctx) {
 static void deliver(struct rt_replay *rp, const struct evsrc *s, int trk, const rtfe_event *e, int W) {
    struct rt_dec *d = rp->d;
    struct rt_trk *t = &d->trk[trk];
+   if (rp->find_zeros && d->opt.do_differentiate) {
+      /* differentiated signal (src/decoder.c:657-663, 670-676): the crossing is the centre of the run of exact
+       * zeros if there was one, else half a sample before the confirming row; no slope gate */
+      uint32_t dd; memcpy(&dd, &e->agc_gain, 4);
+      const int64_t row = s->reset + (int64_t)e->sample;
+      const uint32_t d1 = dd >> 16, d2 = dd & 0xffff;
+      const double tz = d1 ? ((double)(rp->tstart_ns + (row - d1) * rp->tdelta_ns) / 1e9 + (double)(rp->tstart_ns + (row - d2) * rp->tdelta_ns) / 1e9) / 2
+                           : d->timenow - d->sample_deltat / 2;
+      if (e->flags & 1) { t->v_bot = e->v_peak; t->t_bot = tz; rt_down_transition(d, t); }
+      else { t->v_top = e->v_peak; t->t_top = tz; rt_up_transition(d, t); }
+      ++rp->events_delivered;
+      return; }
    if (rp->find_zeros) {
       /* a confirmed zero crossing (src/decoder.c:625-630, 639-644): the extreme is new, the opposite excursion
        * restarts, and the transition counts only if the excursion was reached soon enough after the crossing */

@@ -54,7 +54,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (c->ntrks < 1 || c->ntrks > RTFE_MAXTRKS) return fail(-2, "ntrks %d out of range", c->ntrks);
    if (c->mode != RTFE_NRZI && c->mode != RTFE_PE && c->mode != RTFE_GCR)
       return fail(-3, "mode %d not supported by the device front end yet (Whirlwind: see DESIGN.md)", c->mode);
-   if (c->differentiate) return fail(-4, "the -differentiate paths are not built yet");
+   if (c->differentiate && !c->find_zeros) return fail(-4, "-differentiate without -zeros (peak detection on the differentiated signal) is not built on the device");
    if (c->nparmsets < 1 || c->nparmsets > RTFE_MAXPARMSETS) return fail(-5, "nparmsets %d out of range", c->nparmsets);
    if (c->nparmsets * c->ntrks > kDecodeThreads) return fail(-6, "nparmsets*ntrks > %d", kDecodeThreads);
    if (!(c->bpi > 0) || !(c->ips > 0) || c->tdelta_ns <= 0 || !(c->maxvolts > 0)) return fail(-7, "bpi, ips, tdelta_ns and maxvolts must be positive");
@@ -65,6 +65,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    memset(&d, 0, sizeof d);
    d.mode = c->mode; d.ntrks = c->ntrks; d.invert = c->invert != 0; d.nparm = c->nparmsets;
    d.find_zeros = c->find_zeros != 0;
+   d.differentiate = c->differentiate != 0;
    bool seen[RTFE_MAXTRKS] = {false};
    for (int i = 0; i < c->ntrks; ++i) {
       int t = c->head_to_trk[i];
@@ -114,6 +115,10 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       // the zero-crossing detector has no amplitude feedback and no parameter-set dependence (adjust_agc returns
       // at once, src/decoder.c:501): one walker per track; nothing can become pending while |v| <= 0.2 V
       quiet_v = 0.2f;
+      d.samples_per_bit = (int)(1 / (c->bpi * c->ips * d.sample_deltat));          // src/readtape.c:1402
+      // differentiated: a restart differentiates against 0 and consecutive samples differ by up to 2q, and neither
+      // may reach 0.2 V after the x0.4 x samples_per_bit scaling (src/readtape.c:1388)
+      if (d.differentiate) quiet_v = 0.24f / (float)(d.samples_per_bit > 0 ? d.samples_per_bit : 1);
       int code = 1;
       while (code < 32767 && !((float)code / 32767 * c->maxvolts > 0.2f)) ++code;     // exact, same expression as the device's volt()
       d.zc_peak_i = code; }

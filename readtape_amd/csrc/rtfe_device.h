@@ -34,6 +34,8 @@ struct DevScreen {
 struct DevCfg {
    int   mode, ntrks, invert, nparm, nscreens;
    int   find_zeros;              // -zeros: zero-crossing detector instead of the peak detector (src/decoder.c:863-865)
+   int   differentiate;           // -differentiate (only with -zeros on the device: src/decoder.c:654-683)
+   int   samples_per_bit;         // (int)(1/(bpi*ips*sample_deltat)), src/readtape.c:1402
    int   zc_peak_i;               // smallest positive int16 code c with volt(c) > ZEROCROSS_PEAK (0.2 V, src/decoder.h:138)
    int   head_to_trk[RTFE_MAXTRKS];   // TBIN column -> track (src/readtape.c:1419)
    int   skew[RTFE_MAXTRKS];

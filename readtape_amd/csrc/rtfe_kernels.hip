@@ -258,6 +258,8 @@ struct Walker {            // one per (parameter set, track); lives in registers
    float v_top, v_bot, v_lasttop, v_lastbot;
    // zero-crossing detector (-zeros), int16 codes (src/decoder.c:617-649)
    int   z_prev, z_top, z_bot;
+   float zf_top, zf_bot, zf_lastraw;     // differentiated variant (src/decoder.c:654-683): volts
+   long long z_firstzero, z_lastzero;   // rows of the first / last exact zero since the last arming (-1: none)
    bool  z_up_pending, z_dn_pending;
    long long z_ttop_row, z_tbot_row;
    // PE preamble tracking
@@ -671,6 +673,58 @@ __device__ __forceinline__ void walk_zeros(Walker &w, Ctx &cx, int trk, long lon
             e.trk = (uint8_t)trk;
             e.flags = (uint8_t)(up ? 0 : 1);
             e.left_distance = (uint8_t)(delay < 255 ? delay : 255);
+            e.parmset = 0;
+            cx.events[(size_t)trk * cx.cap + w.nevents] = e; }
+         else w.flags |= RTFE_F_EVENT_OVERFLOW;
+         ++w.nevents; } }
+   w.next = n; }
+
+// lookfor_differentiated_zerocrossing (src/decoder.c:654-683) on differentiate()'s output (src/readtape.c:1383-1388),
+// every row, one lane per track.  The differentiator restarts against 0 at the burst's restart row.
+// Event: sample = row at which the pending crossing is confirmed, v_peak = v_top / v_bot at that moment,
+// agc_gain bits = (rows back to the first exact zero) << 16 | (rows back to the last one); 0 = no zero seen: the
+// crossing then lies half a sample before the confirmation row (src/decoder.c:658-660).
+__device__ __forceinline__ void walk_diffzeros(Walker &w, Ctx &cx, int trk, long long limit) {
+   const DevCfg *cfg = cx.cfg;
+   const Tile &tl = cx.tile;
+   const long long tile_end = tl.row0 + tl.nrows;
+   if (limit > tile_end) limit = tile_end;
+   const float mv = cfg->maxvolts;
+   const int d = cfg->skew[trk];
+   const int spb = cfg->samples_per_bit;
+   long long n = w.next;
+   if (n <= w.start) n = w.start + 1;                              // row `start` only seeds the track (src/decoder.c:855-861)
+   for (; n < limit; ++n) {
+      // what the detector sees at row n: the differentiated sample of row src (deskew FIFO, src/decoder.c:825-828)
+      const long long src = (n - tl.reset < d) ? n : n - d;
+      const float vraw = volt(tl.xi(trk, src), mv);
+      const float vprev = src == tl.reset ? 0.0f : volt(tl.xi(trk, src - 1), mv);   // v_last_raw = 0 at the restart (src/decoder.c:437)
+      float delta = vraw - vprev;
+      if (delta < 0.05f && delta > -0.05f) delta = 0;
+      const float v = delta * 0.4f * spb;
+      bool emit = false, up = false; float vpk = 0; unsigned int d1 = 0, d2 = 0;
+      if (v > 0) {
+         if (w.zf_top < v) w.zf_top = v;
+         if (w.z_up_pending) {
+            if (w.z_firstzero >= 0) { d1 = (unsigned int)(n - w.z_firstzero); d2 = (unsigned int)(n - w.z_lastzero); }
+            w.z_up_pending = false; w.z_firstzero = -1; emit = true; up = true; vpk = w.zf_top; }
+         if (v > 0.2f) { w.z_dn_pending = true; w.z_firstzero = -1; w.zf_bot = 0; } }
+      else if (v < 0) {
+         if (w.zf_bot > v) w.zf_bot = v;
+         if (w.z_dn_pending) {
+            if (w.z_firstzero >= 0) { d1 = (unsigned int)(n - w.z_firstzero); d2 = (unsigned int)(n - w.z_lastzero); }
+            w.z_dn_pending = false; w.z_firstzero = -1; emit = true; up = false; vpk = w.zf_bot; }
+         if (v < -0.2f) { w.z_up_pending = true; w.z_firstzero = -1; w.zf_top = 0; } }
+      else { w.z_lastzero = n; if (w.z_firstzero < 0) w.z_firstzero = n; }
+      if (emit) {
+         if (w.nevents < cx.cap && d1 < 65536u) {
+            rtfe_event e;
+            e.sample = (uint32_t)(n - tl.reset);
+            e.v_peak = vpk;
+            e.agc_gain = __uint_as_float((d1 << 16) | d2);
+            e.trk = (uint8_t)trk;
+            e.flags = (uint8_t)(up ? 0 : 1);
+            e.left_distance = (uint8_t)(d1 < 255 ? d1 : 255);
             e.parmset = 0;
             cx.events[(size_t)trk * cx.cap + w.nevents] = e; }
          else w.flags |= RTFE_F_EVENT_OVERFLOW;
@@ -1106,7 +1160,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       if (is_walker) {
          Walker w = {};
          w.start = reset + trk; w.next = reset; w.blind_until = -1; w.fast = false;
-         w.agc_gain = 1.0f; w.v_avg_height = 4.0f;
+         w.agc_gain = 1.0f; w.v_avg_height = 4.0f; w.z_firstzero = -1; w.z_lastzero = -1;
          update_thresholds(w, cfg.parm[pidx], cfg.lsb_per_volt);
          walkers[my_w] = w;
          for (int i = 0; i < 10; ++i) cx.heights[i] = 0; }
@@ -1198,7 +1252,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
             int total = 0;
             for (int k = 0; k < nwords; ++k) total += runcnt[st * 32 + k];
             Walker w = walkers[my_w];
-            if (cfg.find_zeros) { if (pidx == 0) walk_zeros(w, cx, trk, stop); }
+            if (cfg.find_zeros) { if (pidx == 0) { if (cfg.differentiate) walk_diffzeros(w, cx, trk, stop); else walk_zeros(w, cx, trk, stop); } }
             else walk(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, total < cfg.run_cap ? total : cfg.run_cap, total);
             walkers[my_w] = w; }
          if (is_walker) nrec_all[my_w] = cx.nrec;

@@ -80,7 +80,7 @@ def frontend_parmsets(full):
 
 
 def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
-                skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None):
+                skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None, differentiate=False):
     """Decodes one tape; returns (stats dict, ScanResult).  `fe_factory(cfg)` builds the front end
     (default: the GPU one; tests/cpu_emul passes the emulated library)."""
     opts = opts or DecodeOptions()
@@ -95,13 +95,13 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
         full = [arr[i] for i in range(n)][:nsets]
     else:
         full = default_parmsets(mode, nsets)
-    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert, find_zeros=find_zeros)
+    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert, find_zeros=find_zeros, differentiate=differentiate)
     fe = (fe_factory or frontend.FrontEnd)(cfg)
     res = fe.scan(rows).fetch()
     nrows = int(rows.shape[0])
 
     o = _Options(mode=mode, ntrks=hdr.ntrks, bpi=cfg.bpi, ips=cfg.ips, specified_parity=0 if opts.even_parity else 1,
-                 revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=int(find_zeros), do_differentiate=0,
+                 revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=int(find_zeros), do_differentiate=int(differentiate),
                  multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
     parr = (_Parms * len(full))(*full)
     W = (C.c_int * len(full))(*fe.widths)

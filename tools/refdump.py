@@ -12,7 +12,7 @@ def load(path):
     return np.fromfile(path, dtype=REC)
 
 
-def compare(a, b, ignore_attempt_time=True):
+def compare(a, b, ignore_attempt_time=True, ignore_fields=()):
     """Returns a list of human-readable differences (empty = identical)."""
     out = []
     if a.size != b.size:
@@ -25,6 +25,8 @@ def compare(a, b, ignore_attempt_time=True):
         a["t_peak"][a["kind"] == 2] = 0
         b["t_peak"][b["kind"] == 2] = 0
     for name in REC.names:
+        if name in ignore_fields:
+            continue
         va, vb = a[name], b[name]
         if va.dtype.kind == "f":
             neq = va.view(f"u{va.dtype.itemsize}") != vb.view(f"u{vb.dtype.itemsize}")
