@@ -267,6 +267,7 @@ struct Walker {            // one per (parameter set, track); lives in registers
    double t_lastpeak;
    // thresholds, recomputed whenever the AGC state changes (src/decoder.c:785-786)
    float rise, reqmin;
+   bool  thr_dirty;            // rise/reqmin (exact floats) are stale: only the integer bands were refreshed (optimistic walk)
    int   rise_lo, rise_hi;     // integer guard bands around rise / reqmin (int16 units): a difference <= lo fails
    int   min_lo, min_hi;       //   the float test for sure, >= hi passes for sure, in between the float test decides
    // output
@@ -355,7 +356,28 @@ __device__ __forceinline__ void update_thresholds(Walker &w, const DevParm &P, f
    const int r = (int)floorf(w.rise * lsb_per_volt);
    w.rise_lo = r - 1; w.rise_hi = r + 2;
    const int m = (int)floorf(w.reqmin * lsb_per_volt);
-   w.min_lo = m - 1; w.min_hi = m + 2; }
+   w.min_lo = m - 1; w.min_hi = m + 2;
+   w.thr_dirty = false; }
+
+#ifdef RTFE_CPU_EMUL
+static inline float fast_rcp(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+// the optimistic walk only needs the integer bands: thresholds from a 1-ulp reciprocal instead of two IEEE divisions,
+// with one more lsb of guard on either side (the approximation moves the converted threshold by << 0.01 lsb).
+// Returns false when the threshold is too close to the candidate screen's to rule out an underflow here.
+__device__ __forceinline__ bool approx_thresholds(Walker &w, const DevParm &P, float lsb_per_volt) {
+   const float s = w.v_avg_height * 0.25f * fast_rcp(w.agc_gain);
+   const float ra = P.rise * s, ma = P.min_peak * s;
+   if (ra < P.screen_rise_v * 1.001f || (P.min_peak != 0 && ma < P.screen_minpk_v * 1.001f)) return false;
+   const int r = (int)(ra * lsb_per_volt), m = (int)(ma * lsb_per_volt);
+   w.rise_lo = r - 2; w.rise_hi = r + 3;
+   w.min_lo = m - 2; w.min_hi = m + 3;
+   w.reqmin = P.min_peak == 0 ? 0.0f : 1.0f;                       // only "is there a min_peak test" is read before the next exact refresh
+   w.thr_dirty = true;
+   return true; }
+
 
 // 1 = passes, 0 = fails: "v(a) > v(b) + thr" decided on the int16 codes when clear, else in floats
 __device__ __forceinline__ bool above_by(int a, int b, float thr, int lo, int hi, float mv) {
@@ -577,6 +599,7 @@ __device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long
    const int W = P.W;
    const long long tile_end = tl.row0 + tl.nrows;
    if (limit > tile_end) limit = tile_end;
+   if (w.thr_dirty) update_thresholds(w, P, cfg->lsb_per_volt);
    // ---- literal start-up path ----
    if (!w.fast) {
       const long long fast_from = tl.reset + W + max(trk, cfg->skew[trk]) + 1;
@@ -933,8 +956,17 @@ __device__ __forceinline__ bool walk_optimistic(Walker &w, Ctx &cx, int pidx, in
          if (cfg->mode == RTFE_PE && !w.datablock && w.peakcount >= 68) return false;   // peak time needed (src/decode_pe.c:136-138)
          if (cx.nrec >= cx.rec_cap || w.nevents >= cx.cap) return false;
          if (!is_top) { w.minv = r.m; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + r.p + W; w.chain_pending = false; }
-         const short nbr[2] = {r.prev, r.next};
-         emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + n - W + 1, tl.row0 + r.p, r.v, r.m, is_top, true, nbr);
+         // lean detection bookkeeping: queue the event (refinement and volt conversion happen in finalize_records),
+         // mirror the AGC exactly, refresh only the integer threshold bands
+         const int left_distance = r.p - (n - W + 1) + 1;
+         Rec q; q.idx = w.nevents; q.n_rel = (unsigned short)n; q.ld = (unsigned char)left_distance; q.kind = r.kind; q.g = w.agc_gain;
+         q.val = r.m; q.prev = r.prev; q.next = r.next; q.pad = 0;
+         cx.recs[cx.nrec++] = q;
+         ++w.nevents;
+         if (is_top) w.v_top = r.v; else w.v_bot = r.v;
+         agc_after_peak(w, cfg, P, cx.heights, is_top, 0.0);
+         w.blind_until = tl.row0 + n + left_distance;
+         if (!approx_thresholds(w, P, cfg->lsb_per_volt)) return false;
          n = (int)(w.blind_until + 1 - tl.row0); }
       cur = max(cur, n);
       if (cur > lim) cur = lim; }
