@@ -940,24 +940,41 @@ __device__ __forceinline__ bool walk_optimistic(Walker &w, Ctx &cx, int pidx, in
    long long n64 = max(w.next, w.blind_until + 1);
    int cur = (n64 - tl.row0 > lim) ? lim : (int)(n64 - tl.row0);
    if (cur < 0) cur = 0;
-   for (int i = 0; i < nruns; ++i) {
-      const RunRec &r = runs[i];
-      const int n_e = min((int)r.n_s + (int)r.len, lim);
-      int n = max((int)r.n_s, cur);
-      const bool is_top = r.kind == 0;
-      const bool peak_ok = w.reqmin == 0 || (is_top ? r.m >= w.min_hi : -r.m >= w.min_hi);
-      const bool peak_no = !(w.reqmin == 0) && (is_top ? r.m <= w.min_lo : -r.m <= w.min_lo);
-      while (n < n_e) {
-         const int k = n - r.n_s;
-         if (k >= kRunFast || !((r.fast >> k) & 1)) return false;
-         const int mg = r.marg[k];
-         if (mg <= w.rise_lo || peak_no) { ++n; continue; }            // fails for sure
-         if (!(mg >= w.rise_hi && peak_ok)) return false;               // guard band: needs the float test
-         if (cfg->mode == RTFE_PE && !w.datablock && w.peakcount >= 68) return false;   // peak time needed (src/decode_pe.c:136-138)
+   const bool pe_preamble = cfg->mode == RTFE_PE;
+   int i = 0;
+   // Two-phase rounds keep the walker lanes of a wave together: (A) every lane searches its records for its next
+   // sure detection with a few integer compares per row; (B) the lanes that found one run the detection
+   // bookkeeping side by side.  Anything that is not a sure pass / sure fail ends the optimistic attempt.
+   for (;;) {
+      int hit_n = -1;
+      bool fail = false;
+      while (i < nruns) {                                           // (A)
+         const RunRec &r = runs[i];
+         const int n_e = min((int)r.n_s + (int)r.len, lim);
+         int n = max((int)r.n_s, cur);
+         const bool is_top = r.kind == 0;
+         const bool peak_ok = w.reqmin == 0 || (is_top ? r.m >= w.min_hi : -r.m >= w.min_hi);
+         const bool peak_no = !(w.reqmin == 0) && (is_top ? r.m <= w.min_lo : -r.m <= w.min_lo);
+         while (n < n_e) {
+            const int k = n - r.n_s;
+            if (k >= kRunFast || !((r.fast >> k) & 1)) { fail = true; break; }
+            const int mg = r.marg[k];
+            if (mg <= w.rise_lo || peak_no) { ++n; continue; }       // fails for sure
+            if (mg >= w.rise_hi && peak_ok) hit_n = n; else fail = true;   // passes for sure / guard band
+            break; }
+         if (fail || hit_n >= 0) break;
+         cur = max(cur, n); ++i; }
+      if (fail) return false;
+      if (hit_n < 0) break;
+      {                                                             // (B)
+         const RunRec &r = runs[i];
+         const int n = hit_n;
+         const bool is_top = r.kind == 0;
+         if (pe_preamble && !w.datablock && w.peakcount >= 68) return false;    // peak time needed (src/decode_pe.c:136-138)
          if (cx.nrec >= cx.rec_cap || w.nevents >= cx.cap) return false;
          if (!is_top) { w.minv = r.m; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + r.p + W; w.chain_pending = false; }
-         // lean detection bookkeeping: queue the event (refinement and volt conversion happen in finalize_records),
-         // mirror the AGC exactly, refresh only the integer threshold bands
+         // queue the event (refinement and volt conversion happen in finalize_records), mirror the AGC exactly,
+         // refresh only the integer threshold bands
          const int left_distance = r.p - (n - W + 1) + 1;
          Rec q; q.idx = w.nevents; q.n_rel = (unsigned short)n; q.ld = (unsigned char)left_distance; q.kind = r.kind; q.g = w.agc_gain;
          q.val = r.m; q.prev = r.prev; q.next = r.next; q.pad = 0;
@@ -967,11 +984,9 @@ __device__ __forceinline__ bool walk_optimistic(Walker &w, Ctx &cx, int pidx, in
          agc_after_peak(w, cfg, P, cx.heights, is_top, 0.0);
          w.blind_until = tl.row0 + n + left_distance;
          if (!approx_thresholds(w, P, cfg->lsb_per_volt)) return false;
-         n = (int)(w.blind_until + 1 - tl.row0); }
-      cur = max(cur, n);
-      if (cur > lim) cur = lim; }
-   cur = max(cur, lim);
-   n64 = tl.row0 + cur;
+         cur = n + left_distance + 1;
+         if (cur > lim) cur = lim; } }
+   n64 = tl.row0 + lim;
    w.next = n64 < limit ? n64 : limit;
    if (limit - 1 > w.cpos) {                                         // lazy stale-minimum bookkeeping (see walk())
       const long long a = last_rescan_rel >= 0 ? tl.row0 + last_rescan_rel : -1;
