@@ -138,16 +138,16 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       if (tr > kMaxTileRows) tr = kMaxTileRows;
       d.tile_rows = tr; }
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
-   d.debug = getenv("RTFE_DEBUG") != nullptr;
+   d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
    {
       const int nwalk = c->nparmsets * c->ntrks;
-      int rc = (24 * 1024) / (nwalk * 20);
+      int rc = (24 * 1024) / (nwalk * 24);
       d.rec_cap = rc > 64 ? 64 : (rc < 8 ? 8 : rc);
       d.run_cap = d.tile_rows / 16 < 16 ? 16 : d.tile_rows / 16; }
    h->lds_bytes = (((c->ntrks * (kHaloRows + d.tile_rows + 8) * 2 + 15) & ~15)
                    + ((d.nscreens * 3 * c->ntrks * (d.tile_rows / 8) + 15) & ~15)
                    + ((d.nscreens * 2 * c->ntrks * d.tile_rows + 15) & ~15)
-                   + c->nparmsets * c->ntrks * (10 * 4 + d.rec_cap * 20 + 4) + 128
+                   + c->nparmsets * c->ntrks * (10 * 4 + d.rec_cap * 24 + 4) + 128
                    + d.nscreens * c->ntrks * (d.run_cap * 32 + 32 * 4) + 64
                    + c->nparmsets * c->ntrks * 192 + 64);
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }

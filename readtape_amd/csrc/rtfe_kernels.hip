@@ -277,7 +277,7 @@ struct Walker {            // one per (parameter set, track); lives in registers
 
 // A detection whose (cheap-to-defer) half-sample refinement, volt conversion and event store are done
 // after the walk by all lanes (finalize_tile): the sequential walker keeps only what feeds back.
-struct Rec { unsigned int idx; unsigned short n_rel; unsigned char ld, kind; float g; short val, prev, next, pad; };   // 20 bytes
+struct alignas(8) Rec { unsigned int idx; unsigned short n_rel; unsigned char ld, kind; float g; short val, prev, next, pad; int pad2; };   // 24 bytes
 
 struct Ctx {               // per-workgroup constants for the walkers
    const DevCfg *cfg;
@@ -436,7 +436,7 @@ __device__ __forceinline__ void emit_peak(Walker &w, Ctx &cx, int pidx, int trk,
    if (w.nevents >= cx.cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
    else if (defer && !need_time && cx.nrec < cx.rec_cap) {
       Rec r; r.idx = w.nevents; r.n_rel = (unsigned short)(n - cx.tile.row0); r.ld = (unsigned char)left_distance;
-      r.kind = is_top ? 0 : 1; r.g = w.agc_gain; r.val = (short)val_i; r.pad = 0;
+      r.kind = is_top ? 0 : 1; r.g = w.agc_gain; r.val = (short)val_i; r.pad = 0; r.pad2 = 0;
       if (nbr) { r.prev = nbr[0]; r.next = nbr[1]; } else { r.prev = (short)cx.tile.y(trk, p - 1); r.next = (short)cx.tile.y(trk, p + 1); }
       cx.recs[cx.nrec++] = r; }
    else {
@@ -543,18 +543,19 @@ __device__ __forceinline__ void enter_fast(Walker &w, const Tile &tl, int trk, i
 // one (parameter set, track) detector over rows [.., limit)
 // run records: what the candidate screen knows about one run of consecutive candidate rows of one kind,
 // prepared by all lanes (build_records) so that the sequential walker only has to compare integers.
-struct RunRec {
+struct alignas(16) RunRec {     // 32 bytes: two 16-byte halves, each fetched with one ds_read_b128 by the optimistic walker
    unsigned short n_s;        // first candidate row of the run (tile-relative)
+   unsigned short len;        // candidate rows in the run
    short          p;          // row of the extreme (tile-relative, may be negative: in the halo)
    short          m;          // the extreme, int16 code
+   short          prev, next; // the extreme's neighbours (for the half-sample refinement)
    unsigned char  kind;       // 0 top, 1 bottom
    unsigned char  fast;       // bit k: row n_s+k can be decided from marg[k] (same extreme; bottoms: forced rescan at that row)
-   unsigned short len;        // candidate rows in the run
    unsigned char  ld, pad;    // left_distance of the extreme at row n_s
-   short          prev, next; // the extreme's neighbours (for the half-sample refinement)
    short          marg[4];    // min(|m - left edge|, |m - right edge|) at rows n_s .. n_s+3
    float          v;          // volt(m)
-};                            // 24 bytes
+   int            pad2;
+};
 constexpr int kRunFast = 4;
 
 // exact evaluation of one candidate row (the flat body of the screened walker); returns true on a detection
@@ -799,7 +800,7 @@ __device__ __forceinline__ void build_runs_word(const Tile &tl, const DevCfg *cf
                mg = min(min(a, c), 32767);
                fast |= 1u << j; } }
          r.marg[j] = (short)mg; }
-      r.fast = (unsigned char)fast; r.pad = 0; r.ld = ld[n_s]; r.prev = yb[p - 1]; r.next = yb[p + 1];
+      r.fast = (unsigned char)fast; r.pad = 0; r.pad2 = 0; r.ld = ld[n_s]; r.prev = yb[p - 1]; r.next = yb[p + 1];
       r.v = volt(r.m, cfg->maxvolts);
       out[k++] = r; } }
 
@@ -945,20 +946,27 @@ __device__ __forceinline__ bool walk_optimistic(Walker &w, Ctx &cx, int pidx, in
    // Two-phase rounds keep the walker lanes of a wave together: (A) every lane searches its records for its next
    // sure detection with a few integer compares per row; (B) the lanes that found one run the detection
    // bookkeeping side by side.  Anything that is not a sure pass / sure fail ends the optimistic attempt.
+   // A record is fetched from LDS as two 16-byte loads and picked apart in registers.
+   int4 A = make_int4(0, 0, 0, 0), B = make_int4(0, 0, 0, 0);
    for (;;) {
       int hit_n = -1;
       bool fail = false;
       while (i < nruns) {                                           // (A)
-         const RunRec &r = runs[i];
-         const int n_e = min((int)r.n_s + (int)r.len, lim);
-         int n = max((int)r.n_s, cur);
-         const bool is_top = r.kind == 0;
-         const bool peak_ok = w.reqmin == 0 || (is_top ? r.m >= w.min_hi : -r.m >= w.min_hi);
-         const bool peak_no = !(w.reqmin == 0) && (is_top ? r.m <= w.min_lo : -r.m <= w.min_lo);
+         A = reinterpret_cast<const int4 *>(&runs[i])[0];
+         B = reinterpret_cast<const int4 *>(&runs[i])[1];
+         const int n_s = A.x & 0xffff, len = (int)((unsigned)A.x >> 16);
+         const int m = A.y >> 16;
+         const bool is_top = (A.w & 0xff) == 0;
+         const int fast = (A.w >> 8) & 0xff;
+         const unsigned long long M = (unsigned long long)(unsigned)B.x | ((unsigned long long)(unsigned)B.y << 32);
+         const int n_e = min(n_s + len, lim);
+         int n = max(n_s, cur);
+         const bool peak_ok = w.reqmin == 0 || (is_top ? m >= w.min_hi : -m >= w.min_hi);
+         const bool peak_no = !(w.reqmin == 0) && (is_top ? m <= w.min_lo : -m <= w.min_lo);
          while (n < n_e) {
-            const int k = n - r.n_s;
-            if (k >= kRunFast || !((r.fast >> k) & 1)) { fail = true; break; }
-            const int mg = r.marg[k];
+            const int k = n - n_s;
+            if (k >= kRunFast || !((fast >> k) & 1)) { fail = true; break; }
+            const int mg = (int)(short)((M >> (16 * k)) & 0xffff);
             if (mg <= w.rise_lo || peak_no) { ++n; continue; }       // fails for sure
             if (mg >= w.rise_hi && peak_ok) hit_n = n; else fail = true;   // passes for sure / guard band
             break; }
@@ -967,23 +975,30 @@ __device__ __forceinline__ bool walk_optimistic(Walker &w, Ctx &cx, int pidx, in
       if (fail) return false;
       if (hit_n < 0) break;
       {                                                             // (B)
-         const RunRec &r = runs[i];
          const int n = hit_n;
-         const bool is_top = r.kind == 0;
+         const int p = (int)(short)(A.y & 0xffff), m = A.y >> 16;
+         const bool is_top = (A.w & 0xff) == 0;
+         const float v = __int_as_float(B.z);
          if (pe_preamble && !w.datablock && w.peakcount >= 68) return false;    // peak time needed (src/decode_pe.c:136-138)
          if (cx.nrec >= cx.rec_cap || w.nevents >= cx.cap) return false;
-         if (!is_top) { w.minv = r.m; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + r.p + W; w.chain_pending = false; }
+         if (!is_top) { w.minv = m; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + p + W; w.chain_pending = false; }
          // queue the event (refinement and volt conversion happen in finalize_records), mirror the AGC exactly,
          // refresh only the integer threshold bands
-         const int left_distance = r.p - (n - W + 1) + 1;
-         Rec q; q.idx = w.nevents; q.n_rel = (unsigned short)n; q.ld = (unsigned char)left_distance; q.kind = r.kind; q.g = w.agc_gain;
-         q.val = r.m; q.prev = r.prev; q.next = r.next; q.pad = 0;
-         cx.recs[cx.nrec++] = q;
+         const int left_distance = p - (n - W + 1) + 1;
+         {
+            // Rec as three 8-byte LDS stores: {idx, n_rel|ld|kind} {g, val|prev} {next|pad, pad2}
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&cx.recs[cx.nrec++]);
+            const unsigned int w1 = (unsigned)n | ((unsigned)left_distance << 16) | ((unsigned)(A.w & 0xff) << 24);
+            const unsigned int w3 = (unsigned)(m & 0xffff) | ((unsigned)A.z << 16);            // val | prev
+            const unsigned int w4 = ((unsigned)A.z >> 16);                                       // next
+            dst[0] = (unsigned long long)w.nevents | ((unsigned long long)w1 << 32);
+            dst[1] = (unsigned long long)__float_as_uint(w.agc_gain) | ((unsigned long long)w3 << 32);
+            dst[2] = (unsigned long long)w4; }
          ++w.nevents;
-         if (is_top) w.v_top = r.v; else w.v_bot = r.v;
-         agc_after_peak(w, cfg, P, cx.heights, is_top, 0.0);
+         if (is_top) w.v_top = v; else w.v_bot = v;
+         if (!(cfg->debug & 2)) agc_after_peak(w, cfg, P, cx.heights, is_top, 0.0);      // (debug bit 1: timing experiment without the AGC mirror)
          w.blind_until = tl.row0 + n + left_distance;
-         if (!approx_thresholds(w, P, cfg->lsb_per_volt)) return false;
+         if (!(cfg->debug & 2)) if (!approx_thresholds(w, P, cfg->lsb_per_volt)) return false;
          cur = n + left_distance + 1;
          if (cur > lim) cur = lim; } }
    n64 = tl.row0 + lim;
@@ -996,7 +1011,7 @@ __device__ __forceinline__ bool walk_optimistic(Walker &w, Ctx &cx, int pidx, in
    return true; }
 
 __device__ __forceinline__ void unpack_run(RunRec &r, const PackedRun &q, int W, float maxvolts) {
-   r.n_s = q.n_s; r.len = q.len; r.m = q.m; r.prev = q.prev; r.next = q.next; r.ld = q.ld; r.pad = 0;
+   r.n_s = q.n_s; r.len = q.len; r.m = q.m; r.prev = q.prev; r.next = q.next; r.ld = q.ld; r.pad = 0; r.pad2 = 0;
    r.kind = q.kindfast >> 7; r.fast = q.kindfast & 15;
    r.p = (short)((int)q.n_s - W + (int)q.ld);
    #pragma unroll

@@ -77,6 +77,8 @@ inline int __shfl_up(int v, unsigned delta) {
    const int r = l >= delta ? (int)(unsigned)hipemu::g_wave_scratch[w][l - delta] : v;
    hipemu::g_wave_barrier[w].wait();
    return r; }
+inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+inline unsigned int __float_as_uint(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }

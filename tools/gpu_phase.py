@@ -1,6 +1,6 @@
 """GPU box helper: per-phase cycle counters of k_decode (RTFE_DEBUG=1) on the bench tape."""
 import os, sys, json
-os.environ["RTFE_DEBUG"] = "1"
+os.environ.setdefault("RTFE_DEBUG", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
