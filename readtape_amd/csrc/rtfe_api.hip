@@ -144,12 +144,8 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       int rc = (24 * 1024) / (nwalk * 24);
       d.rec_cap = rc > 64 ? 64 : (rc < 8 ? 8 : rc);
       d.run_cap = d.tile_rows / 16 < 16 ? 16 : d.tile_rows / 16; }
-   h->lds_bytes = (((c->ntrks * (kHaloRows + d.tile_rows + 8) * 2 + 15) & ~15)
-                   + ((d.nscreens * 3 * c->ntrks * (d.tile_rows / 8) + 15) & ~15)
-                   + ((d.nscreens * 2 * c->ntrks * d.tile_rows + 15) & ~15)
-                   + c->nparmsets * c->ntrks * (10 * 4 + d.rec_cap * 24 + 4) + 128
-                   + d.nscreens * c->ntrks * (d.run_cap * 32 + 32 * 4) + 64
-                   + c->nparmsets * c->ntrks * 192 + 64);
+   h->lds_bytes = (int)lds_layout(d, true).total + 64;
+   h->screen_lds_bytes = (int)lds_layout(d, false).total + 64;
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
    hipDeviceProp_t prop;
    int dev = 0;
@@ -157,11 +153,6 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    h->num_cus = prop.multiProcessorCount;
    if (hipMalloc(&h->d_dev, sizeof(DevCfg)) != hipSuccess) { delete h; return fail(-21, "hipMalloc failed"); }
    if (hipMemcpy(h->d_dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->d_dev); delete h; return fail(-22, "hipMemcpy failed"); }
-   h->lds_bytes += c->nparmsets * c->ntrks * (192 + 40) + 64;   // second walker array + AGC ring backup (optimistic commit)
-   h->screen_lds_bytes = (((c->ntrks * (kHaloRows + d.tile_rows + 8) * 2 + 15) & ~15)
-                          + ((d.nscreens * 3 * c->ntrks * (d.tile_rows / 8) + 15) & ~15)
-                          + ((d.nscreens * 2 * c->ntrks * d.tile_rows + 15) & ~15)
-                          + d.nscreens * c->ntrks * (d.run_cap * 32 + 32 * 4) + 128);
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen), hipFuncAttributeMaxDynamicSharedMemorySize, h->screen_lds_bytes);
    *out = h;

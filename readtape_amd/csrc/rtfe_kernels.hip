@@ -1018,6 +1018,28 @@ __device__ __forceinline__ void unpack_run(RunRec &r, const PackedRun &q, int W,
    for (int j = 0; j < kRunFast; ++j) r.marg[j] = q.marg[j];
    r.v = volt(q.m, maxvolts); }
 
+// LDS carve of k_screen / k_decode.  ONE definition, used by the kernels and by the host when it sizes the dynamic
+// LDS allocation (rtfe_api.hip): an under-sized allocation does not fault on the GPU, out-of-range LDS reads return 0.
+struct LdsLayout {
+   unsigned bits, ldpos, heights, recs, nrec, runs, runcnt, walkers, walkers_next, heights_bak, total; };
+__host__ __device__ inline unsigned lds_align16(unsigned v) { return (v + 15u) & ~15u; }
+__host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
+   LdsLayout L;
+   const unsigned ntrks = (unsigned)c.ntrks, nst = (unsigned)c.nscreens * ntrks, nwalk = (unsigned)c.nparm * ntrks;
+   unsigned off = lds_align16(ntrks * (unsigned)(kHaloRows + c.tile_rows + 8) * 2u);
+   L.bits = off;      off = lds_align16(off + nst * 3u * (unsigned)(c.tile_rows / 8));
+   L.ldpos = off;     off = lds_align16(off + nst * 2u * (unsigned)c.tile_rows);
+   L.heights = off;   if (decode) off = lds_align16(off + nwalk * 10u * 4u);
+   L.recs = off;      if (decode) off = lds_align16(off + nwalk * (unsigned)c.rec_cap * (unsigned)sizeof(Rec));
+   L.nrec = off;      if (decode) off = lds_align16(off + nwalk * 4u);
+   L.runs = off;      off = lds_align16(off + nst * (unsigned)c.run_cap * (unsigned)sizeof(RunRec));
+   L.runcnt = off;    off = lds_align16(off + nst * 32u * 4u);
+   L.walkers = off;   if (decode) off = lds_align16(off + nwalk * (unsigned)sizeof(Walker));
+   L.walkers_next = off; if (decode) off = lds_align16(off + nwalk * (unsigned)sizeof(Walker));
+   L.heights_bak = off;  if (decode) off = lds_align16(off + nwalk * 10u * 4u);
+   L.total = off;
+   return L; }
+
 // ------------------------------------------------------------------------------------------------
 // k_screen: the dense, stateless pass.  One workgroup per tile of the tape-global grid: coalesced loads of the
 // AoS rows -> SoA LDS tile, sliding-window screen, candidate-run records -> HBM (TileDir + PackedRun pool).
@@ -1041,14 +1063,11 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    tl.x = reinterpret_cast<int16_t *>(smem);
    tl.ldw = kHaloRows + cfg.tile_rows + 8;
    tl.ntrks = ntrks; tl.skew = cfg.skew; tl.reset = -(1ll << 40);
-   size_t off = ((size_t)ntrks * tl.ldw * 2 + 15) & ~(size_t)15;
-   tl.bits = smem + off; tl.bstride = cfg.tile_rows / 8;
-   off += (size_t)cfg.nscreens * 3 * ntrks * (cfg.tile_rows / 8); off = (off + 15) & ~(size_t)15;
-   tl.ldpos = smem + off;
-   off += (size_t)cfg.nscreens * 2 * ntrks * cfg.tile_rows; off = (off + 15) & ~(size_t)15;
-   RunRec *runs_all = reinterpret_cast<RunRec *>(smem + off);
-   off += (size_t)nst * cfg.run_cap * sizeof(RunRec);
-   int *runcnt = reinterpret_cast<int *>(smem + off);
+   const LdsLayout L = lds_layout(cfg, false);
+   tl.bits = smem + L.bits; tl.bstride = cfg.tile_rows / 8;
+   tl.ldpos = smem + L.ldpos;
+   RunRec *runs_all = reinterpret_cast<RunRec *>(smem + L.runs);
+   int *runcnt = reinterpret_cast<int *>(smem + L.runcnt);
    const long long T = cfg.tile_rows;
    for (long long g = blockIdx.x; g < ntiles; g += gridDim.x) {
       tl.row0 = g * T; tl.nrows = (int)((tl.row0 + T <= nrows) ? T : nrows - tl.row0);
@@ -1139,15 +1158,11 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    cx.tile.ldw = ldw;
    cx.tile.ntrks = ntrks;
    cx.tile.skew = cfg.skew;
-   size_t off = ((size_t)ntrks * ldw * 2 + 15) & ~(size_t)15;
-   cx.tile.bits = smem + off;
+   const LdsLayout L = lds_layout(cfg, true);
+   cx.tile.bits = smem + L.bits;
    cx.tile.bstride = cfg.tile_rows / 8;
-   off += (size_t)cfg.nscreens * 3 * ntrks * (cfg.tile_rows / 8);
-   off = (off + 15) & ~(size_t)15;
-   cx.tile.ldpos = smem + off;
-   off += (size_t)cfg.nscreens * 2 * ntrks * cfg.tile_rows;
-   off = (off + 15) & ~(size_t)15;
-   float *heights_all = reinterpret_cast<float *>(smem + off);
+   cx.tile.ldpos = smem + L.ldpos;
+   float *heights_all = reinterpret_cast<float *>(smem + L.heights);
    // walker w of this workgroup -> thread: spread over the 4 waves so every SIMD issues for some walkers
    const int nwalk = cfg.nparm * ntrks;
    const int nwaves = blockDim.x >> 6;
@@ -1156,25 +1171,13 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    const int pidx = is_walker ? my_w / ntrks : 0, trk = is_walker ? my_w - pidx * ntrks : 0;
    const bool active = is_walker && ((parmset_mask >> pidx) & 1);
    cx.heights = heights_all + (size_t)(is_walker ? my_w : 0) * 10;
-   off += (size_t)nwalk * 10 * 4;
-   off = (off + 15) & ~(size_t)15;
-   Rec *recs_all = reinterpret_cast<Rec *>(smem + off);
-   off += (size_t)nwalk * cfg.rec_cap * sizeof(Rec);
-   int *nrec_all = reinterpret_cast<int *>(smem + off);
-   off += (size_t)nwalk * 4;
-   off = (off + 15) & ~(size_t)15;
-   RunRec *runs_all = reinterpret_cast<RunRec *>(smem + off);
-   off += (size_t)cfg.nscreens * ntrks * cfg.run_cap * sizeof(RunRec);
-   int *runcnt = reinterpret_cast<int *>(smem + off);              // [nscreens*ntrks][32 words]
-   off += (size_t)cfg.nscreens * ntrks * 32 * 4;
-   off = (off + 15) & ~(size_t)15;
-   Walker *walkers = reinterpret_cast<Walker *>(smem + off);       // [nwalk]
-   off += (size_t)nwalk * sizeof(Walker);
-   off = (off + 15) & ~(size_t)15;
-   Walker *walkers_next = reinterpret_cast<Walker *>(smem + off);  // [nwalk] result of an optimistic tile, committed only if all lanes agree
-   off += (size_t)nwalk * sizeof(Walker);
-   off = (off + 15) & ~(size_t)15;
-   float *heights_bak = reinterpret_cast<float *>(smem + off);     // [nwalk][10]
+   Rec *recs_all = reinterpret_cast<Rec *>(smem + L.recs);
+   int *nrec_all = reinterpret_cast<int *>(smem + L.nrec);
+   RunRec *runs_all = reinterpret_cast<RunRec *>(smem + L.runs);
+   int *runcnt = reinterpret_cast<int *>(smem + L.runcnt);              // [nscreens*ntrks][32 words]
+   Walker *walkers = reinterpret_cast<Walker *>(smem + L.walkers);       // [nwalk]
+   Walker *walkers_next = reinterpret_cast<Walker *>(smem + L.walkers_next);  // [nwalk] result of an optimistic tile, committed only if all lanes agree
+   float *heights_bak = reinterpret_cast<float *>(smem + L.heights_bak);     // [nwalk][10]
    cx.rec_cap = cfg.rec_cap;
    cx.recs = recs_all + (size_t)(is_walker ? my_w : 0) * cfg.rec_cap;
 
