@@ -143,7 +143,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       const int nwalk = c->nparmsets * c->ntrks;
       int rc = (24 * 1024) / (nwalk * 24);
       d.rec_cap = rc > 64 ? 64 : (rc < 8 ? 8 : rc);
-      d.run_cap = d.tile_rows / 16 < 16 ? 16 : d.tile_rows / 16; }
+      d.run_cap = d.tile_rows / 8 < 16 ? 16 : d.tile_rows / 8; }
    h->lds_bytes = (int)lds_layout(d, true).total + 64;
    h->screen_lds_bytes = (int)lds_layout(d, false).total + 64;
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
@@ -185,15 +185,15 @@ static long long nwords_for(const rtfe_handle *h, int64_t nrows) {
    return (nchunks + 63) / 64; }
 
 static long long ntiles_for(const rtfe_handle *h, int64_t nrows) { return (nrows + h->dev.tile_rows - 1) / h->dev.tile_rows; }
-static long long pool_cap_for(const rtfe_handle *h, int64_t nrows) {
-   return (long long)((double)nrows * h->dev.ntrks * h->dev.nscreens / 20.0) + 65536; }
-// workspace: [0,256) scratch | quiet words | tile directory | run pool
-static size_t ws_dir_off(const rtfe_handle *h, int64_t nrows) { return (256 + (size_t)nwords_for(h, nrows) * 8 + 255) & ~(size_t)255; }
+static long long pool_cap_for(const rtfe_handle *h, int64_t nrows) {       // a fixed slot of run_cap records per (tile, screen, track)
+   return ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * h->dev.run_cap; }
+// workspace: [0,kScratchBytes) scratch | quiet words | tile directory | run pool
+static size_t ws_dir_off(const rtfe_handle *h, int64_t nrows) { return (kScratchBytes + (size_t)nwords_for(h, nrows) * 8 + 255) & ~(size_t)255; }
 static size_t ws_pool_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_dir_off(h, nrows) + (size_t)ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(TileDir) + 255) & ~(size_t)255; }
 
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pool_off(h, nrows) + (size_t)pool_cap_for(h, nrows) * sizeof(PackedRun) + 256; }
+   return ws_pool_off(h, nrows) + (size_t)pool_cap_for(h, nrows) * sizeof(Cand) + 256; }
 
 extern "C" int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows) {
    return (nrows * h->dev.ntrks / 512) / h->dev.gap_chunks + 4; }
@@ -221,7 +221,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    const long long nchunks = nelem / 512;
    const long long nwords = nwords_for(h, nrows);
    BurstScratch *scratch = reinterpret_cast<BurstScratch *>(d_workspace);
-   unsigned long long *qwords = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_workspace) + 256);
+   unsigned long long *qwords = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_workspace) + kScratchBytes);
    int grid = (int)(nwords < (long long)h->num_cus * 8 ? nwords : (long long)h->num_cus * 8);
    if (h->timing) (void)hipEventRecord(h->ev[0], st);
    hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, st, d_rows, nelem, h->dev.quiet_i, qwords, nwords);
@@ -231,7 +231,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                       d_bursts, (long long)max_bursts, scratch, d_nbursts);
    if (h->timing) (void)hipEventRecord(h->ev[2], st);
    TileDir *dirp = reinterpret_cast<TileDir *>(reinterpret_cast<char *>(d_workspace) + ws_dir_off(h, nrows));
-   PackedRun *poolp = reinterpret_cast<PackedRun *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
+   Cand *poolp = reinterpret_cast<Cand *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
    const bool use_screen = !h->dev.find_zeros && getenv("RTFE_NO_SCREEN_PASS") == nullptr;
    if (use_screen) {
       const long long ntiles = ntiles_for(h, nrows);
@@ -241,7 +241,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       long long sgrid = (long long)h->num_cus * spc;
       if (sgrid > ntiles) sgrid = ntiles;
       hipLaunchKernelGGL(k_screen, dim3((unsigned)sgrid), dim3(256), h->screen_lds_bytes, st, h->d_dev, d_rows, (long long)nrows, dirp, poolp,
-                         (unsigned long long)pool_cap_for(h, nrows), &scratch->pool_cursor, ntiles); }
+                         ntiles, scratch->scr); }
    if (h->timing) (void)hipEventRecord(h->ev[3], st);
    // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
    // beat wide ones; k_decode holds ~180 VGPRs => 2 waves/SIMD => 8 waves per CU
@@ -254,7 +254,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    const int dgrid = h->num_cus * per_cu;
    hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                       (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
-                      use_screen ? (const TileDir *)dirp : (const TileDir *)nullptr, (const PackedRun *)poolp);
+                      use_screen ? (const TileDir *)dirp : (const TileDir *)nullptr, (const Cand *)poolp);
    if (h->timing) (void)hipEventRecord(h->ev[4], st);
    return launch_check("rtfe_scan"); }
 
@@ -265,7 +265,7 @@ extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nr
                                void *stream) {
    if (!h || !d_rows || !d_workspace || !d_burst || !d_counts || !d_events) return fail(-1, "null argument");
    if (((uintptr_t)d_rows & 15) != 0) return fail(-31, "d_rows must be 16-byte aligned");
-   if (workspace_bytes < 256) return fail(-32, "workspace too small");
+   if (workspace_bytes < kScratchBytes) return fail(-32, "workspace too small");
    if (reset_row < 0 || reset_row >= nrows || end_row <= reset_row) return fail(-34, "bad row range");
    if (end_row > nrows) end_row = nrows;
    hipStream_t st = (hipStream_t)stream;
@@ -276,5 +276,5 @@ extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nr
    const int nwalk = h->dev.nparm * h->dev.ntrks;
    hipLaunchKernelGGL(k_decode, dim3(1), dim3(nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256)), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                       (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1,
-                      (const TileDir *)nullptr, (const PackedRun *)nullptr);
+                      (const TileDir *)nullptr, (const Cand *)nullptr);
    return launch_check("rtfe_scan_exact"); }

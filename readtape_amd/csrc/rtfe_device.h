@@ -7,7 +7,7 @@ namespace rtfe {
 
 constexpr int kChunkRows   = 64;     // granularity of the quiet map (rows per bit)
 constexpr int kMaxTileRows = 2048;   // upper bound of DevCfg::tile_rows (rows per LDS tile of the decode kernel)
-constexpr int kHaloRows    = 160;    // rows kept in front of a tile: >= 2*W + max skew + 8  (W<=50, skew<=50)
+constexpr int kHaloRows    = 176;    // rows kept in front of a tile: >= kScreenHalo + W + 1 + max skew  (W<=50, skew<=50)
 constexpr int kMarginRows  = 256;    // head/tail tile length at a burst boundary (multiple of 64)
 constexpr int kStrip       = 8;      // samples per screen strip (one bitmap byte)
 constexpr int kDecodeThreads = 256;
@@ -56,18 +56,31 @@ struct DevCfg {
 };
 
 // ---- what the dense screen pass (k_screen) leaves in HBM for the sequential pass (k_decode) ----
-struct PackedRun {             // one candidate run of one (screen, track) of one tile: 20 bytes
-   uint16_t n_s;               // first candidate row, tile-relative
-   uint16_t len;               // candidate rows in the run
-   int16_t  m, prev, next;     // the extreme and its two neighbours (int16 codes)
-   uint8_t  ld;                // left_distance of the extreme at row n_s
-   uint8_t  kindfast;          // bit 7: 0 top / 1 bottom; bits 0-3: rows n_s+k decidable from marg[k]
-   int16_t  marg[4];
+// One candidate record = up to 4 consecutive candidate rows of one kind that share the same extreme (rows never
+// straddle a multiple of 4, so records never straddle bitmap words).  It carries everything the sequential
+// detector needs to decide those rows EXACTLY without the samples: the extreme, its neighbours (half-sample
+// refinement) and the distance of the extreme from both window edges at every row (int16 code differences, from
+// which the float comparisons of src/decoder.c:788-805 can be re-evaluated bit for bit).
+struct Cand {                  // 32 bytes = two 16-byte halves
+   uint16_t n_s;               // first row, tile-relative
+   uint8_t  nrows;             // 1..4
+   uint8_t  kind;              // 0 top, 1 bottom
+   int16_t  m;                 // the extreme (tops: true window maximum; bottoms: the reference's possibly stale minimum)
+   uint8_t  ld;                // left_distance of the extreme at row n_s (one less at each following row)
+   uint8_t  flags;             // bit 0: the reference's minimum could not be derived here (no rescan within reach)
+   int16_t  prev, next;        // the extreme's neighbours
+   float    v;                 // volt(m)
+   uint16_t dL[4];             // |m - left window edge| at rows n_s .. n_s+3 (clamped at 0)
+   uint16_t dR[4];             // |m - right window edge|
 };
+static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 struct TileDir {               // per (tile, screen, track): 8 bytes
-   uint32_t offset;            // index of the first PackedRun in the pool
-   uint16_t count;             // 0xFFFF: not available (pool full / more runs than the tile list holds)
-   int16_t  last_rescan;       // tile-relative row of the last forced rescan ("window maximum leaves"), -1 if none
+   uint16_t count;             // records in this list; 0xFFFF: more than run_cap (list not stored)
+   uint8_t  end_ld;            // left_distance of the reference's minimum after the tile's last row; 0 = unknown
+   uint8_t  pad;
+   int16_t  end_min;           // that minimum (int16 code)
+   uint16_t pad2;
 };
+constexpr int kScreenHalo = 64;      // rows in front of a tile that the screen also covers (one bitmap word)
 
 }  // namespace rtfe

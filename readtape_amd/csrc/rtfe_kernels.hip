@@ -70,7 +70,8 @@ __global__ void __launch_bounds__(256) k_quiet(const int16_t *__restrict__ rows,
 // A zone END is a quiet chunk c whose successor is not quiet and whose gap_chunks predecessors
 // (itself included) are all quiet; each thread tests the 64 chunks of one word per round.
 // ------------------------------------------------------------------------------------------------
-struct BurstScratch {            // lives in the workspace
+constexpr int kScratchBytes = 512;
+struct BurstScratch {            // lives in the workspace (first kScratchBytes bytes)
    int   nbursts;                // bursts to decode (owned by this scan)
    int   queue;                  // next burst to decode
    int   nbursts_total;          // owned bursts + (time shards) the first burst of the halo, which only bounds the last owned one
@@ -78,7 +79,10 @@ struct BurstScratch {            // lives in the workspace
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
    unsigned long long pool_cursor;   // at byte 128: next free PackedRun of the pool (k_screen)
    unsigned long long dbg2[8];   // dbg[8..15] (contiguous with dbg through pool_cursor is NOT assumed: indexed separately)
+   unsigned long long why[8];    // optimistic-walk failure reasons (debug)
+   unsigned long long scr[8];    // k_screen per-phase cycle counters (debug)
 };
+static_assert(sizeof(BurstScratch) <= kScratchBytes, "scratch region too small");
 #ifdef RTFE_CPU_EMUL
 static inline long long clock64() { return 0; }
 #endif
@@ -210,7 +214,9 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
       if (n_owned == nb && own_rows < nrows && n_owned > 0) bursts[n_owned - 1].flags |= RTFE_F_TRUNCATED; }
    if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0;
    if (threadIdx.x == 8) scratch->pool_cursor = 0;
-   if (threadIdx.x >= 16 && threadIdx.x < 24) scratch->dbg2[threadIdx.x - 16] = 0; }
+   if (threadIdx.x >= 16 && threadIdx.x < 24) scratch->dbg2[threadIdx.x - 16] = 0;
+   if (threadIdx.x >= 24 && threadIdx.x < 32) scratch->why[threadIdx.x - 24] = 0;
+   if (threadIdx.x >= 32 && threadIdx.x < 40) scratch->scr[threadIdx.x - 32] = 0; }
 
 // ------------------------------------------------------------------------------------------------
 // k_decode
@@ -221,9 +227,10 @@ struct Tile {
    long long row0;        // first row of the tile proper
    int      nrows;        // rows in the tile proper
    long long reset;       // burst restart row (deskew FIFO restarts there, src/decoder.c:415)
+   // the bitmaps and left_distance maps also cover the kScreenHalo rows in front of the tile (word -1 / rows -64..-1)
    unsigned char *bits;   // LDS: [nscreens][3][ntrks][bstride]   0=top 1=bot 2=rescan ("A-sync")
-   int      bstride;      // bytes per bitmap row = tile_rows / 8
-   unsigned char *ldpos;  // LDS: [nscreens][2][ntrks][tile_rows] left_distance of the first window max (0) / true min (1)
+   int      bstride;      // bytes per bitmap row = (tile_rows + kScreenHalo) / 8
+   unsigned char *ldpos;  // LDS: [nscreens][2][ntrks][tile_rows + kScreenHalo] left_distance of the first window max (0) / min (1)
    int      ntrks;
    const int *skew;
    __device__ __forceinline__ int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + kHaloRows]; }
@@ -232,10 +239,10 @@ struct Tile {
    __device__ __forceinline__ int y(int t, long long n) const {
       const int d = skew[t];
       return xi(t, (n - reset < d) ? n : n - d); }
-   __device__ __forceinline__ const unsigned char *ldmap(int screen, int kind, int t) const {
-      return ldpos + ((size_t)(screen * 2 + kind) * ntrks + t) * (bstride * 8); }
-   __device__ __forceinline__ const u64 *map(int screen, int kind, int t) const {
-      return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 3 + kind) * ntrks + t) * bstride); }
+   __device__ __forceinline__ unsigned char *ldmap(int screen, int kind, int t) const {       // [row], rows >= -kScreenHalo
+      return ldpos + ((size_t)(screen * 2 + kind) * ntrks + t) * (bstride * 8) + kScreenHalo; }
+   __device__ __forceinline__ const u64 *map(int screen, int kind, int t) const {               // [word], words >= -1
+      return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 3 + kind) * ntrks + t) * bstride + kScreenHalo / 8); }
 };
 
 __device__ __forceinline__ float volt(int i, float maxvolts) {      // src/readtape.c:1420
@@ -252,6 +259,7 @@ struct Walker {            // one per (parameter set, track); lives in registers
    bool  chain_pending;    // ... except that the forced rescan AT row cpos has not been carried out yet (lazy)
    int   slow_max, slow_countdown;   // literal state while the window is filling
    bool  fast;             // window full and in the regular deskew regime: use the screen
+   long long trust_from;   // first row from which k_screen's view of this track (regular regime, full window) is the detector's
    // AGC / block-decoder mirror
    float agc_gain, v_avg_height, v_avg_height_sum;
    int   v_avg_height_count, peakcount, heightndx;
@@ -538,25 +546,8 @@ __device__ __forceinline__ void enter_fast(Walker &w, const Tile &tl, int trk, i
    w.cpos = last; w.chain_pending = false;
    w.blind_until = last + w.slow_countdown;
    w.next = n_first_fast;
+   w.trust_from = n_first_fast;
    w.fast = true; }
-
-// one (parameter set, track) detector over rows [.., limit)
-// run records: what the candidate screen knows about one run of consecutive candidate rows of one kind,
-// prepared by all lanes (build_records) so that the sequential walker only has to compare integers.
-struct alignas(16) RunRec {     // 32 bytes: two 16-byte halves, each fetched with one ds_read_b128 by the optimistic walker
-   unsigned short n_s;        // first candidate row of the run (tile-relative)
-   unsigned short len;        // candidate rows in the run
-   short          p;          // row of the extreme (tile-relative, may be negative: in the halo)
-   short          m;          // the extreme, int16 code
-   short          prev, next; // the extreme's neighbours (for the half-sample refinement)
-   unsigned char  kind;       // 0 top, 1 bottom
-   unsigned char  fast;       // bit k: row n_s+k can be decided from marg[k] (same extreme; bottoms: forced rescan at that row)
-   unsigned char  ld, pad;    // left_distance of the extreme at row n_s
-   short          marg[4];    // min(|m - left edge|, |m - right edge|) at rows n_s .. n_s+3
-   float          v;          // volt(m)
-   int            pad2;
-};
-constexpr int kRunFast = 4;
 
 // exact evaluation of one candidate row (the flat body of the screened walker); returns true on a detection
 __device__ __forceinline__ bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, int n, bool ctop, bool cbot, bool async) {
@@ -592,8 +583,8 @@ __device__ __forceinline__ bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, c
    if (hit) emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, tl.row0 + pos, volt(val, mv), val, is_top, true);
    return hit; }
 
-// one (parameter set, track) detector over rows [.., limit)
-__device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit, const RunRec *runs, int nruns, int nruns_total) {
+// one (parameter set, track) detector over rows [.., limit): the exact path on the samples in LDS
+__device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long long limit) {
    const DevCfg *cfg = cx.cfg;
    const DevParm &P = cfg->parm[pidx];
    const Tile &tl = cx.tile;
@@ -607,49 +598,22 @@ __device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long
       while (w.next < limit && w.next < fast_from) { if (w.next >= w.start) slow_step(w, cx, pidx, trk, P, w.next); ++w.next; }
       if (w.next < fast_from) return;
       enter_fast(w, tl, trk, W, w.next); }
-   // ---- screened path: one iteration per candidate RUN; lanes of a wave stay in lockstep ----
+   // ---- screened path: every candidate row that is not inside a blind countdown, exactly ----
    const u64 *tm = tl.map(P.screen, 0, trk), *bm = tl.map(P.screen, 1, trk), *am = tl.map(P.screen, 2, trk);
-   const float mv = cfg->maxvolts;
    const int lim = (int)(limit - tl.row0);
    long long n64 = max(w.next, w.blind_until + 1);
-   int cur = (n64 - tl.row0 > lim) ? lim : (int)(n64 - tl.row0);       // first row not yet looked at
-   for (int i = 0; i < nruns; ++i) {
-      const RunRec &r = runs[i];                                     // stays in LDS: marg[] is indexed dynamically
-      const int n_e = min((int)r.n_s + (int)r.len, lim);                // one past the last candidate row of this run
-      int n = max((int)r.n_s, cur);
-      // rows decidable from the record: integer margins against the guard-banded thresholds
-      const bool is_top = r.kind == 0;
-      const bool peak_ok = w.reqmin == 0 || (is_top ? r.m >= w.min_hi : -r.m >= w.min_hi);
-      const bool peak_no = !(w.reqmin == 0) && (is_top ? r.m <= w.min_lo : -r.m <= w.min_lo);
-      while (n < n_e && n - r.n_s < kRunFast && ((r.fast >> (n - r.n_s)) & 1)) {
-         const int mg = r.marg[n - r.n_s];
-         if (mg <= w.rise_lo || peak_no) { ++n; continue; }            // fails for sure
-         if (mg >= w.rise_hi && peak_ok) {                              // passes for sure
-            if (!is_top) { w.minv = r.m; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + r.p + W; w.chain_pending = false; }
-            emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + n - W + 1, tl.row0 + r.p, r.v, r.m, is_top, true);
-            n = (int)(w.blind_until + 1 - tl.row0); }
-         break; }
-      // anything else (guard band, rows past the record, another extreme took over, stale minimum, rows after a
-      // detection inside a long run): the exact per-row path
-      while (n < n_e) {
-         const int wd = n >> 6, bit = n & 63;
-         const bool ctop = (tm[wd] >> bit) & 1, cbot = (bm[wd] >> bit) & 1;
-         const bool hit = (ctop || cbot) && eval_at(w, cx, pidx, trk, P, n, ctop, cbot, (am[wd] >> bit) & 1);
-         n = hit ? (int)(w.blind_until + 1 - tl.row0) : n + 1; }
-      cur = max(cur, n);
-      if (cur > lim) cur = lim; }
-   // rows after the last recorded run hold candidates only if the run list overflowed: exact per-row path
-   {
-      int n = cur;
-      if (nruns_total <= nruns) n = lim;
-      else if (nruns > 0) n = max(cur, min(lim, (int)runs[nruns - 1].n_s + (int)runs[nruns - 1].len));
-      while (n < lim) {
-         const int wd = n >> 6, bit = n & 63;
-         const bool ctop = (tm[wd] >> bit) & 1, cbot = (bm[wd] >> bit) & 1;
-         const bool hit = (ctop || cbot) && eval_at(w, cx, pidx, trk, P, n, ctop, cbot, (am[wd] >> bit) & 1);
-         n = hit ? (int)(w.blind_until + 1 - tl.row0) : n + 1; }
-      cur = max(cur, n); }
-   n64 = tl.row0 + cur;
+   int n = (n64 - tl.row0 > lim) ? lim : (int)(n64 - tl.row0);       // first row not yet looked at
+   while (n < lim) {
+      int wd = n >> 6;
+      const u64 c = (tm[wd] | bm[wd]) >> (n & 63);
+      if (!c) { n = (wd + 1) << 6; continue; }
+      n += __ffsll((long long)c) - 1;
+      if (n >= lim) break;
+      const int bit = n & 63;
+      const bool ctop = (tm[wd] >> bit) & 1, cbot = (bm[wd] >> bit) & 1;
+      const bool hit = eval_at(w, cx, pidx, trk, P, n, ctop, cbot, (am[wd] >> bit) & 1);
+      n = hit ? (int)(w.blind_until + 1 - tl.row0) : n + 1; }
+   n64 = tl.row0 + n;
    w.next = n64 < limit ? n64 : limit;
    // keep the stale-min state inside the reach of the next tile's halo, lazily: remember the last forced
    // rescan of this tile (its window is re-read only if a later bottom needs it); walk the chain eagerly
@@ -755,54 +719,79 @@ __device__ __forceinline__ void walk_diffzeros(Walker &w, Ctx &cx, int trk, long
          ++w.nevents; } }
    w.next = n; }
 
-// all lanes: list the candidate runs of one (screen, track) of the current tile in row order.  A run = consecutive
-// rows with ANY candidate bit set; its record describes the extreme of the kind seen at its first row.
-__device__ __forceinline__ u64 run_starts(const Tile &tl, int screen, int trk, int wd) {
-   const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk);
-   const int nwords = (tl.nrows + 63) >> 6;
-   const u64 valid = (wd == nwords - 1 && (tl.nrows & 63)) ? ((1ull << (tl.nrows & 63)) - 1) : ~0ull;
-   const u64 c = (tm[wd] | bm[wd]) & valid;
-   const u64 prev = wd ? (tm[wd - 1] | bm[wd - 1]) >> 63 : 0;
-   return c & ~((c << 1) | prev); }
+// ---- k_screen only: the reference's (possibly stale) window minimum at every row ----
+// The detector's min/max tracking does not depend on its decisions (src/decoder.c:760-775 runs before the countdown
+// test): the maximum is always exact, and the minimum is refreshed exactly at the rows where the sample leaving the
+// window equals the tracked maximum ("A-sync" rows: data alone decides, the screen's bitmap 2) or the tracked minimum.
+// Between two A-sync rows the minimum therefore follows a chain that starts from the true minimum at the first of
+// them: it stays the same sample until that sample leaves the window, where a rescan makes it the true minimum again.
+// This pass rewrites ldmap(screen,1,trk)[row] from "left_distance of the true minimum" into "left_distance of the
+// reference's minimum" for the rows between A-sync rows (0 where no A-sync row lies within reach: unknown).
+// One call handles the gaps that START in one 8-row strip.
+__device__ __forceinline__ void chain_gaps(const Tile &tl, int screen, int trk, int strip) {
+   const unsigned char *ab = reinterpret_cast<const unsigned char *>(tl.map(screen, 2, trk));      // [row >> 3], rows >= -kScreenHalo
+   unsigned char *ldb = tl.ldmap(screen, 1, trk);
+   const int nrows = tl.nrows;
+   const unsigned a = ab[strip];
+   for (int j = 0; j < 8; ++j) {
+      const int r = strip * 8 + j;
+      if (r + 1 >= nrows) break;
+      const bool ar = (a >> j) & 1;
+      if (r == -kScreenHalo && !ar)                                 // in front of the first A-sync row: unknown
+         for (int q = r; q < nrows && !((ab[q >> 3] >> (q & 7)) & 1); ++q) ldb[q] = 0;
+      if (ar && !((ab[(r + 1) >> 3] >> ((r + 1) & 7)) & 1)) {
+         int ld = ldb[r];                                           // true minimum at the A-sync row
+         for (int q = r + 1; q < nrows && !((ab[q >> 3] >> (q & 7)) & 1); ++q) {
+            --ld;                                                   // the same sample, one place closer to the left edge
+            if (ld == 0) ld = ldb[q];                               // it left the window at this row: rescan (ldb[q] is still the true one)
+            else ldb[q] = (unsigned char)ld; } } } }
 
-__device__ __forceinline__ void build_runs_word(const Tile &tl, const DevCfg *cfg, int screen, int trk, int wd, int W,
-                                       RunRec *out, int base, int cap) {
-   const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk), *am = tl.map(screen, 2, trk);
+// ---- k_screen only: the candidate records of one bitmap word of one (screen, track), in row order ----
+// kBuild = false only counts them (same walk, so the two passes agree by construction).
+template <bool kBuild>
+__device__ __forceinline__ int build_word(const Tile &tl, const DevCfg *cfg, int screen, int trk, int wd, int W, Cand *out, int base, int cap) {
+   const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk);
    const unsigned char *ldt = tl.ldmap(screen, 0, trk), *ldb = tl.ldmap(screen, 1, trk);
    const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
-   u64 starts = run_starts(tl, screen, trk, wd);
+   const int nwords = (tl.nrows + 63) >> 6;
+   const u64 valid = (wd == nwords - 1 && (tl.nrows & 63)) ? ((1ull << (tl.nrows & 63)) - 1) : ~0ull;
+   const u64 tw = tm[wd] & valid, bw = bm[wd] & valid;
+   u64 any = tw | bw;
    int k = base;
-   while (starts) {
-      const int bit = __ffsll((long long)starts) - 1;
-      starts &= starts - 1;
-      if (k >= cap) break;
-      const int n_s = wd * 64 + bit;
-      const int kind = ((tm[wd] >> bit) & 1) ? 0 : 1;              // top has priority at a row with both bits
-      const unsigned char *ld = kind ? ldb : ldt;
-      RunRec r;
-      r.n_s = (unsigned short)n_s; r.kind = (unsigned char)kind;
-      const int p = n_s - W + ld[n_s];                            // lo + left_distance - 1
-      r.p = (short)p; r.m = yb[p];
-      int len = 0;
-      for (int n = n_s; n < tl.nrows; ++n) { if (!(((tm[n >> 6] | bm[n >> 6]) >> (n & 63)) & 1)) break; ++len; }
-      r.len = (unsigned short)len;
-      unsigned fast = 0;
-      #pragma unroll
-      for (int j = 0; j < kRunFast; ++j) {
-         const int n = n_s + j;
-         int mg = 0;
-         if (j < len) {
-            const bool tb = (tm[n >> 6] >> (n & 63)) & 1, bb = (bm[n >> 6] >> (n & 63)) & 1;
-            const bool only_this = kind ? (bb && !tb) : (tb && !bb);
-            if (only_this && n - W + ld[n] == p && (kind == 0 || ((am[n >> 6] >> (n & 63)) & 1))) {
-               const int a = kind ? yb[n - W + 1] - r.m : r.m - yb[n - W + 1];
-               const int c = kind ? yb[n] - r.m : r.m - yb[n];
-               mg = min(min(a, c), 32767);
-               fast |= 1u << j; } }
-         r.marg[j] = (short)mg; }
-      r.fast = (unsigned char)fast; r.pad = 0; r.pad2 = 0; r.ld = ld[n_s]; r.prev = yb[p - 1]; r.next = yb[p + 1];
-      r.v = volt(r.m, cfg->maxvolts);
-      out[k++] = r; } }
+   while (any) {
+      const int bit = __ffsll((long long)any) - 1;
+      const int n = wd * 64 + bit;
+      const bool tb = (tw >> bit) & 1, bb = (bw >> bit) & 1;
+      int nr = 1;
+      const bool both = tb && bb;
+      for (int pass = 0; pass < (both ? 2 : 1); ++pass) {
+         const int kind = both ? pass : (bb ? 1 : 0);              // top first at a row with both bits (src/decoder.c:788-805)
+         const unsigned char *ld = kind ? ldb : ldt;
+         const int l0 = ld[n];
+         if (!both && l0 != 0) {
+            const u64 same = kind ? (bw & ~tw) : (tw & ~bw);
+            while (((n + nr) & 3) != 0 && ((same >> (bit + nr)) & 1) && ld[n + nr] == l0 - nr) ++nr; }
+         if (kBuild && k < cap) {
+            Cand c;
+            c.n_s = (uint16_t)n; c.nrows = (uint8_t)nr; c.kind = (uint8_t)kind; c.ld = (uint8_t)l0; c.flags = l0 == 0 ? 1 : 0;
+            const int p = n - W + l0;                               // lo + left_distance - 1
+            const int m = l0 ? yb[p] : 0;
+            c.m = (int16_t)m; c.prev = l0 ? yb[p - 1] : 0; c.next = l0 ? yb[p + 1] : 0;
+            c.v = volt(m, cfg->maxvolts);
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+               int dl = 0, dr = 0;
+               if (j < nr && l0) {
+                  const int L = yb[n + j - W + 1], R = yb[n + j];
+                  dl = kind ? L - m : m - L; dr = kind ? R - m : m - R;
+                  dl = dl < 0 ? 0 : dl; dr = dr < 0 ? 0 : dr; }
+               c.dL[j] = (uint16_t)dl; c.dR[j] = (uint16_t)dr; }
+            int4 *dst = reinterpret_cast<int4 *>(out + k);
+            dst[0] = reinterpret_cast<const int4 *>(&c)[0];
+            dst[1] = reinterpret_cast<const int4 *>(&c)[1]; }
+         ++k; }
+      any &= ~(((nr >= 64 ? 0ull : (1ull << nr)) - 1) << bit); }
+   return k - base; }
 
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
@@ -857,12 +846,12 @@ __device__ __forceinline__ void screen_strip(const Tile &tl, const DevScreen &sc
          topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i;
          ldt |= (u64)((255 - (kx & 255)) + 1) << (8 * i);
          ldb |= (u64)((kn & 255) + 1) << (8 * i); } }
-   unsigned char *o = tl.bits + ((size_t)(screen * 3) * tl.ntrks + trk) * tl.bstride + strip;
+   unsigned char *o = tl.bits + ((size_t)(screen * 3) * tl.ntrks + trk) * tl.bstride + kScreenHalo / 8 + strip;     // strip >= -kScreenHalo/8
    o[0] = (unsigned char)topb;
    o[(size_t)tl.ntrks * tl.bstride] = (unsigned char)botb;
    o[(size_t)2 * tl.ntrks * tl.bstride] = (unsigned char)resb;
-   reinterpret_cast<u64 *>(tl.ldpos + ((size_t)(screen * 2) * tl.ntrks + trk) * (tl.bstride * 8))[strip] = ldt;
-   reinterpret_cast<u64 *>(tl.ldpos + ((size_t)(screen * 2 + 1) * tl.ntrks + trk) * (tl.bstride * 8))[strip] = ldb; }
+   reinterpret_cast<u64 *>(tl.ldmap(screen, 0, trk))[strip] = ldt;
+   reinterpret_cast<u64 *>(tl.ldmap(screen, 1, trk))[strip] = ldb; }
 
 // cooperative tile load: rows [row0 - kHaloRows, row0 + nrows) of the AoS payload -> SoA LDS by track
 __device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows) {
@@ -896,12 +885,13 @@ __device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int
             if (r < nload) tl.x[cfg->head_to_trk[c] * tl.ldw + r] = (int16_t)(cfg->invert ? -sv : sv);
             if (++c == ntrks) { c = 0; ++r; } } } } }
 
-__device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl) {
-   const int nstrips = (tl.nrows + kStrip - 1) / kStrip;
+__device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl, bool with_halo) {
+   const int hs = with_halo ? kScreenHalo / kStrip : 0;            // k_screen also screens the rows in front of the tile
+   const int nstrips = (tl.nrows + kStrip - 1) / kStrip + hs;
    const int per_screen = nstrips * cfg->ntrks;
    for (int s = 0; s < cfg->nscreens; ++s)
       for (int i = threadIdx.x; i < per_screen; i += blockDim.x)
-         screen_strip(tl, cfg->screen[s], s, i / nstrips, i - (i / nstrips) * nstrips); }
+         screen_strip(tl, cfg->screen[s], s, i / nstrips, i - (i / nstrips) * nstrips - hs); }
 
 // restart row for the zone whose last kMarginRows rows are the current tile:
 // for every parameter set and track take the last forced rescan inside the zone; any restart at or
@@ -924,99 +914,90 @@ __device__ __forceinline__ long long find_reset(const DevCfg *cfg, const Tile &t
    __syncthreads();
    return r; }          // 0 => no provably safe restart row inside the margin
 
-// ---- optimistic walk: the tile's run records come from HBM (k_screen wrote them); no sample is in LDS.  Decides
-// every candidate row from integer margins alone; returns false the moment anything needs the samples (guard band,
-// a row past the record's margins, overlapping kinds, a bottom without a forced rescan, PE preamble timing, a full
-// record list, the start-up path) — the caller then redoes the tile with the full path from the untouched state.
-__device__ __forceinline__ bool walk_optimistic(Walker &w, Ctx &cx, int pidx, int trk, long long limit,
-                                                const RunRec *runs, int nruns, int last_rescan_rel) {
+// ---- record walk: the tile's candidate records come from HBM (k_screen wrote them); no sample is in LDS.
+// The same sequential detector as walk(), one iteration per record: rows inside a blind countdown are skipped, the
+// others are decided from the integer distances against the guard-banded thresholds and, inside the guard band, by
+// re-evaluating the reference's float comparisons on the reconstructed codes.  Returns false (state untouched by the
+// caller) only when the records cannot describe what the detector would see: the literal start-up path, a minimum
+// k_screen could not derive, a full event list.
+__device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int trk, long long limit,
+                                             const Cand *recs, int nrecs, const TileDir &td, int &why) {
    const DevCfg *cfg = cx.cfg;
    const DevParm &P = cfg->parm[pidx];
    const Tile &tl = cx.tile;
    const int W = P.W;
-   if (!w.fast) return false;
+   why = 0;
+   if (!w.fast || tl.row0 - kScreenHalo < w.trust_from) { why = 1; return false; }
    const long long tile_end = tl.row0 + tl.nrows;
+   const bool whole = limit >= tile_end;
    if (limit > tile_end) limit = tile_end;
+   if (whole && td.end_ld == 0) { why = 7; return false; }        // the next tile needs the minimum's state
    const int lim = (int)(limit - tl.row0);
    long long n64 = max(w.next, w.blind_until + 1);
    int cur = (n64 - tl.row0 > lim) ? lim : (int)(n64 - tl.row0);
    if (cur < 0) cur = 0;
-   const bool pe_preamble = cfg->mode == RTFE_PE;
-   int i = 0;
-   // Two-phase rounds keep the walker lanes of a wave together: (A) every lane searches its records for its next
-   // sure detection with a few integer compares per row; (B) the lanes that found one run the detection
-   // bookkeeping side by side.  Anything that is not a sure pass / sure fail ends the optimistic attempt.
-   // A record is fetched from LDS as two 16-byte loads and picked apart in registers.
-   int4 A = make_int4(0, 0, 0, 0), B = make_int4(0, 0, 0, 0);
-   for (;;) {
-      int hit_n = -1;
-      bool fail = false;
-      while (i < nruns) {                                           // (A)
-         A = reinterpret_cast<const int4 *>(&runs[i])[0];
-         B = reinterpret_cast<const int4 *>(&runs[i])[1];
-         const int n_s = A.x & 0xffff, len = (int)((unsigned)A.x >> 16);
-         const int m = A.y >> 16;
-         const bool is_top = (A.w & 0xff) == 0;
-         const int fast = (A.w >> 8) & 0xff;
-         const unsigned long long M = (unsigned long long)(unsigned)B.x | ((unsigned long long)(unsigned)B.y << 32);
-         const int n_e = min(n_s + len, lim);
-         int n = max(n_s, cur);
-         const bool peak_ok = w.reqmin == 0 || (is_top ? m >= w.min_hi : -m >= w.min_hi);
-         const bool peak_no = !(w.reqmin == 0) && (is_top ? m <= w.min_lo : -m <= w.min_lo);
-         while (n < n_e) {
-            const int k = n - n_s;
-            if (k >= kRunFast || !((fast >> k) & 1)) { fail = true; break; }
-            const int mg = (int)(short)((M >> (16 * k)) & 0xffff);
-            if (mg <= w.rise_lo || peak_no) { ++n; continue; }       // fails for sure
-            if (mg >= w.rise_hi && peak_ok) hit_n = n; else fail = true;   // passes for sure / guard band
-            break; }
-         if (fail || hit_n >= 0) break;
-         cur = max(cur, n); ++i; }
-      if (fail) return false;
-      if (hit_n < 0) break;
-      {                                                             // (B)
-         const int n = hit_n;
-         const int p = (int)(short)(A.y & 0xffff), m = A.y >> 16;
-         const bool is_top = (A.w & 0xff) == 0;
-         const float v = __int_as_float(B.z);
-         if (pe_preamble && !w.datablock && w.peakcount >= 68) return false;    // peak time needed (src/decode_pe.c:136-138)
-         if (cx.nrec >= cx.rec_cap || w.nevents >= cx.cap) return false;
-         if (!is_top) { w.minv = m; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + p + W; w.chain_pending = false; }
-         // queue the event (refinement and volt conversion happen in finalize_records), mirror the AGC exactly,
-         // refresh only the integer threshold bands
-         const int left_distance = p - (n - W + 1) + 1;
-         {
-            // Rec as three 8-byte LDS stores: {idx, n_rel|ld|kind} {g, val|prev} {next|pad, pad2}
-            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&cx.recs[cx.nrec++]);
-            const unsigned int w1 = (unsigned)n | ((unsigned)left_distance << 16) | ((unsigned)(A.w & 0xff) << 24);
-            const unsigned int w3 = (unsigned)(m & 0xffff) | ((unsigned)A.z << 16);            // val | prev
-            const unsigned int w4 = ((unsigned)A.z >> 16);                                       // next
-            dst[0] = (unsigned long long)w.nevents | ((unsigned long long)w1 << 32);
-            dst[1] = (unsigned long long)__float_as_uint(w.agc_gain) | ((unsigned long long)w3 << 32);
-            dst[2] = (unsigned long long)w4; }
-         ++w.nevents;
-         if (is_top) w.v_top = v; else w.v_bot = v;
-         if (!(cfg->debug & 2)) agc_after_peak(w, cfg, P, cx.heights, is_top, 0.0);      // (debug bit 1: timing experiment without the AGC mirror)
-         w.blind_until = tl.row0 + n + left_distance;
-         if (!(cfg->debug & 2)) if (!approx_thresholds(w, P, cfg->lsb_per_volt)) return false;
-         cur = n + left_distance + 1;
-         if (cur > lim) cur = lim; } }
+   const float mv = cfg->maxvolts, lsb = cfg->lsb_per_volt;
+   const bool pe = cfg->mode == RTFE_PE;
+   for (int i = 0; i < nrecs; ++i) {
+      const int4 A = reinterpret_cast<const int4 *>(&recs[i])[0];
+      const int n_s = A.x & 0xffff, nr = (A.x >> 16) & 0xff;
+      if (n_s >= lim) break;
+      if (n_s + nr <= cur) continue;                               // inside the countdown of the last detection
+      const int4 B = reinterpret_cast<const int4 *>(&recs[i])[1];
+      const bool is_top = ((A.x >> 24) & 1) == 0;
+      const int m = (int)(short)(A.y & 0xffff), ld0 = (A.y >> 16) & 0xff;
+      if (((unsigned)A.y >> 24) & 1) { why = 4; return false; }
+      // min_peak test: the same for every row of the record
+      if (w.reqmin != 0) {
+         const int a = is_top ? m : -m;
+         if (a <= w.min_lo) continue;
+         if (a < w.min_hi) {
+            if (w.thr_dirty) update_thresholds(w, P, lsb);
+            if (!(is_top ? volt(m, mv) > w.reqmin : volt(m, mv) < -w.reqmin)) continue; } }
+      const unsigned long long DL = (unsigned long long)(unsigned)B.x | ((unsigned long long)(unsigned)B.y << 32);
+      const unsigned long long DR = (unsigned long long)(unsigned)B.z | ((unsigned long long)(unsigned)B.w << 32);
+      int hit = -1;
+      for (int k = max(0, cur - n_s); k < nr && n_s + k < lim; ++k) {
+         const int dl = (int)((DL >> (16 * k)) & 0xffff), dr = (int)((DR >> (16 * k)) & 0xffff);
+         const int mg = min(dl, dr);
+         if (mg <= w.rise_lo) continue;                             // fails for sure
+         if (mg >= w.rise_hi) { hit = k; break; }                   // passes for sure
+         if (w.thr_dirty) update_thresholds(w, P, lsb);              // guard band: the reference's own comparison
+         const float vm = volt(m, mv);
+         const float vl = volt(is_top ? m - dl : m + dl, mv), vr = volt(is_top ? m - dr : m + dr, mv);
+         if (is_top ? (vm > vl + w.rise && vm > vr + w.rise) : (vm < vl - w.rise && vm < vr - w.rise)) { hit = k; break; } }
+      if (hit < 0) continue;
+      // ---- a detection at row n_s + hit (the bookkeeping of emit_peak) ----
+      const int n = n_s + hit, left_distance = ld0 - hit;
+      const float v = __int_as_float(A.w);
+      double t_peak = 0;
+      if (pe && !w.datablock && w.peakcount >= 68) {               // the end of the PE preamble is decided on peak times
+         const int adjcode = refine_code(cfg, m, (int)(short)(A.z & 0xffff), A.z >> 16, w.agc_gain, is_top);
+         const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
+         t_peak = time_of(cfg, cx.row_base + tl.row0 + n) - ((float)(W - left_distance) - adj) * cfg->sample_deltat; }
+      if (w.nevents >= cx.cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
+      else {
+         if (cx.nrec >= cx.rec_cap) { why = 6; return false; }
+         // Rec as three 8-byte LDS stores: {idx, n_rel|ld|kind} {g, val|prev} {next, -}
+         unsigned long long *dst = reinterpret_cast<unsigned long long *>(&cx.recs[cx.nrec++]);
+         const unsigned int w1 = (unsigned)n | ((unsigned)left_distance << 16) | ((unsigned)(is_top ? 0 : 1) << 24);
+         const unsigned int w3 = (unsigned)(m & 0xffff) | ((unsigned)A.z << 16);            // val | prev
+         const unsigned int w4 = ((unsigned)A.z >> 16);                                       // next
+         dst[0] = (unsigned long long)w.nevents | ((unsigned long long)w1 << 32);
+         dst[1] = (unsigned long long)__float_as_uint(w.agc_gain) | ((unsigned long long)w3 << 32);
+         dst[2] = (unsigned long long)w4; }
+      if (is_top) w.v_top = v; else w.v_bot = v;
+      ++w.nevents;
+      agc_after_peak(w, cfg, P, cx.heights, is_top, t_peak);
+      if (!approx_thresholds(w, P, lsb)) update_thresholds(w, P, lsb);
+      w.blind_until = tl.row0 + n + left_distance;                 // pkww_countdown = left_distance (src/decoder.c:741)
+      cur = n + left_distance + 1; }
    n64 = tl.row0 + lim;
    w.next = n64 < limit ? n64 : limit;
-   if (limit - 1 > w.cpos) {                                         // lazy stale-minimum bookkeeping (see walk())
-      const long long a = last_rescan_rel >= 0 ? tl.row0 + last_rescan_rel : -1;
-      if (a > w.cpos && a <= limit - 1) { w.cpos = a; w.chain_pending = true; }
-      else if (a > limit - 1) return false;                          // the burst stops inside this tile: let the full path look
-      if (limit - 1 - w.cpos > kHaloRows - 2 * W - 8 - cfg->maxskew) return false; }
+   if (whole) {                                                     // the minimum's state after the tile's last row, from k_screen
+      const int last = tl.nrows - 1;
+      w.minv = td.end_min; w.cpos = tl.row0 + last; w.qtrig = tl.row0 + last + td.end_ld; w.chain_pending = false; }
    return true; }
-
-__device__ __forceinline__ void unpack_run(RunRec &r, const PackedRun &q, int W, float maxvolts) {
-   r.n_s = q.n_s; r.len = q.len; r.m = q.m; r.prev = q.prev; r.next = q.next; r.ld = q.ld; r.pad = 0; r.pad2 = 0;
-   r.kind = q.kindfast >> 7; r.fast = q.kindfast & 15;
-   r.p = (short)((int)q.n_s - W + (int)q.ld);
-   #pragma unroll
-   for (int j = 0; j < kRunFast; ++j) r.marg[j] = q.marg[j];
-   r.v = volt(q.m, maxvolts); }
 
 // LDS carve of k_screen / k_decode.  ONE definition, used by the kernels and by the host when it sizes the dynamic
 // LDS allocation (rtfe_api.hip): an under-sized allocation does not fault on the GPU, out-of-range LDS reads return 0.
@@ -1026,14 +1007,18 @@ __host__ __device__ inline unsigned lds_align16(unsigned v) { return (v + 15u) &
 __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    LdsLayout L;
    const unsigned ntrks = (unsigned)c.ntrks, nst = (unsigned)c.nscreens * ntrks, nwalk = (unsigned)c.nparm * ntrks;
+   const unsigned T = (unsigned)c.tile_rows;
    unsigned off = lds_align16(ntrks * (unsigned)(kHaloRows + c.tile_rows + 8) * 2u);
-   L.bits = off;      off = lds_align16(off + nst * 3u * (unsigned)(c.tile_rows / 8));
-   L.ldpos = off;     off = lds_align16(off + nst * 2u * (unsigned)c.tile_rows);
+   L.bits = off;      off = lds_align16(off + nst * 3u * ((T + kScreenHalo) / 8));
+   L.ldpos = off;     off = lds_align16(off + nst * 2u * (T + kScreenHalo));
+   // k_decode: the candidate records of a tile share the space of the sample tile (a tile is decided either from
+   // its records or from its samples, never both)
+   L.runs = 0;
+   if (decode) { const unsigned r = lds_align16(nst * (unsigned)c.run_cap * (unsigned)sizeof(Cand)); if (r > off) off = r; }
+   L.runcnt = off;    if (!decode) off = lds_align16(off + nst * 32u * 4u);
    L.heights = off;   if (decode) off = lds_align16(off + nwalk * 10u * 4u);
    L.recs = off;      if (decode) off = lds_align16(off + nwalk * (unsigned)c.rec_cap * (unsigned)sizeof(Rec));
    L.nrec = off;      if (decode) off = lds_align16(off + nwalk * 4u);
-   L.runs = off;      off = lds_align16(off + nst * (unsigned)c.run_cap * (unsigned)sizeof(RunRec));
-   L.runcnt = off;    off = lds_align16(off + nst * 32u * 4u);
    L.walkers = off;   if (decode) off = lds_align16(off + nwalk * (unsigned)sizeof(Walker));
    L.walkers_next = off; if (decode) off = lds_align16(off + nwalk * (unsigned)sizeof(Walker));
    L.heights_bak = off;  if (decode) off = lds_align16(off + nwalk * 10u * 4u);
@@ -1042,96 +1027,84 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
 
 // ------------------------------------------------------------------------------------------------
 // k_screen: the dense, stateless pass.  One workgroup per tile of the tape-global grid: coalesced loads of the
-// AoS rows -> SoA LDS tile, sliding-window screen, candidate-run records -> HBM (TileDir + PackedRun pool).
+// AoS rows -> SoA LDS tile, sliding-window screen (tile + kScreenHalo rows in front), the stale-minimum chain,
+// candidate records -> HBM (TileDir + a fixed slot of run_cap records per (tile, screen, track)).
 // Everything the sequential pass needs in the common case; it never has to touch the samples again.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
-                                                TileDir *__restrict__ dir, PackedRun *__restrict__ pool, unsigned long long pool_cap,
-                                                unsigned long long *__restrict__ pool_cursor, long long ntiles) {
+                                                TileDir *__restrict__ dir, Cand *__restrict__ pool, long long ntiles,
+                                                unsigned long long *__restrict__ scr) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;
 #else
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
    __shared__ DevCfg cfg;
-   __shared__ unsigned long long s_base;
-   __shared__ int s_off[kMaxScreens * RTFE_MAXTRKS + 1];
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
    const int ntrks = cfg.ntrks, nst = cfg.nscreens * ntrks;
+   const LdsLayout L = lds_layout(cfg, false);
    Tile tl;
    tl.x = reinterpret_cast<int16_t *>(smem);
    tl.ldw = kHaloRows + cfg.tile_rows + 8;
    tl.ntrks = ntrks; tl.skew = cfg.skew; tl.reset = -(1ll << 40);
-   const LdsLayout L = lds_layout(cfg, false);
-   tl.bits = smem + L.bits; tl.bstride = cfg.tile_rows / 8;
+   tl.bits = smem + L.bits; tl.bstride = (cfg.tile_rows + kScreenHalo) / 8;
    tl.ldpos = smem + L.ldpos;
-   RunRec *runs_all = reinterpret_cast<RunRec *>(smem + L.runs);
-   int *runcnt = reinterpret_cast<int *>(smem + L.runcnt);
+   int *runcnt = reinterpret_cast<int *>(smem + L.runcnt);          // [nst][32 words]
    const long long T = cfg.tile_rows;
    for (long long g = blockIdx.x; g < ntiles; g += gridDim.x) {
       tl.row0 = g * T; tl.nrows = (int)((tl.row0 + T <= nrows) ? T : nrows - tl.row0);
       __syncthreads();
+      long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+      if (cfg.debug) k0 = clock64();
       load_tile(&cfg, tl, rows, nrows);
       __syncthreads();
-      run_screens(&cfg, tl);
+      if (cfg.debug) k1 = clock64();
+      run_screens(&cfg, tl, true);
+      __syncthreads();
+      if (cfg.debug) k2 = clock64();
+      {
+         const int nstrips = (tl.nrows + kStrip - 1) / kStrip + kScreenHalo / kStrip;
+         for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {
+            const int st = i / nstrips, sc = st / ntrks;
+            chain_gaps(tl, sc, st - sc * ntrks, i - st * nstrips - kScreenHalo / kStrip); } }
       __syncthreads();
       const int nwords = (tl.nrows + 63) >> 6;
       const int nitems = nst * nwords;
       for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
-         const int st = i / nwords, wd = i - st * nwords;
-         runcnt[st * 32 + wd] = __popcll(run_starts(tl, st / ntrks, st - (st / ntrks) * ntrks, wd)); }
+         const int st = i / nwords, wd = i - st * nwords, sc = st / ntrks;
+         runcnt[st * 32 + wd] = build_word<false>(tl, &cfg, sc, st - sc * ntrks, wd, cfg.screen[sc].W, nullptr, 0, 0); }
       __syncthreads();
+      if (cfg.debug) k3 = clock64();
       for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
-         const int st = i / nwords, wd = i - st * nwords;
+         const int st = i / nwords, wd = i - st * nwords, sc = st / ntrks;
          int base = 0;
          for (int k = 0; k < wd; ++k) base += runcnt[st * 32 + k];
-         const int sc = st / ntrks;
-         build_runs_word(tl, &cfg, sc, st - sc * ntrks, wd, cfg.screen[sc].W, runs_all + (size_t)st * cfg.run_cap, base, cfg.run_cap); }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-         int tot = 0;
-         for (int st = 0; st < nst; ++st) {
-            int c = 0;
-            for (int k = 0; k < nwords; ++k) c += runcnt[st * 32 + k];
-            s_off[st] = (c > cfg.run_cap) ? -1 - tot : tot;          // negative: this list overflowed the tile's capacity
-            if (c <= cfg.run_cap) tot += c; }
-         s_off[nst] = tot;
-         const unsigned long long b = atomicAdd(pool_cursor, (unsigned long long)tot);
-         s_base = (b + tot <= pool_cap) ? b : ~0ull; }
-      __syncthreads();
-      const unsigned long long base = s_base;
+         build_word<true>(tl, &cfg, sc, st - sc * ntrks, wd, cfg.screen[sc].W, pool + ((size_t)g * nst + st) * cfg.run_cap, base, cfg.run_cap); }
       if (threadIdx.x < nst) {
          const int st = threadIdx.x, sc = st / ntrks, trk = st - sc * ntrks;
-         TileDir d;
-         const bool ovf = s_off[st] < 0 || base == ~0ull;
          int cnt = 0;
          for (int k = 0; k < nwords; ++k) cnt += runcnt[st * 32 + k];
-         d.offset = ovf ? 0u : (uint32_t)(base + (unsigned long long)s_off[st]);
-         d.count = ovf ? (uint16_t)0xFFFF : (uint16_t)cnt;
-         const long long a = last_forced_rescan(tl, sc, trk, tl.row0 - 1, tl.row0 + tl.nrows - 1);
-         d.last_rescan = (int16_t)(a < 0 ? -1 : a - tl.row0);
+         TileDir d;
+         d.count = cnt > cfg.run_cap ? (uint16_t)0xFFFF : (uint16_t)cnt;
+         const int last = tl.nrows - 1;
+         const int eld = tl.ldmap(sc, 1, trk)[last];
+         d.end_ld = (uint8_t)eld; d.pad = 0; d.pad2 = 0;
+         d.end_min = eld ? tl.x[trk * tl.ldw + kHaloRows - cfg.skew[trk] + last - cfg.screen[sc].W + eld] : (int16_t)0;
          dir[g * nst + st] = d; }
-      if (base != ~0ull)
-         for (int st = 0; st < nst; ++st) {
-            if (s_off[st] < 0) continue;
-            int cnt = 0;
-            for (int k = 0; k < nwords; ++k) cnt += runcnt[st * 32 + k];
-            for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
-               const RunRec &r = runs_all[(size_t)st * cfg.run_cap + k];
-               PackedRun q;
-               q.n_s = r.n_s; q.len = r.len; q.m = r.m; q.prev = r.prev; q.next = r.next; q.ld = r.ld;
-               q.kindfast = (uint8_t)((r.kind << 7) | (r.fast & 15));
-               for (int j = 0; j < kRunFast; ++j) q.marg[j] = r.marg[j];
-               pool[base + (unsigned long long)s_off[st] + k] = q; } }
-      __syncthreads(); } }
+      if (cfg.debug) {
+         __syncthreads();
+         if (threadIdx.x == 0) {
+            const long long k4 = clock64();
+            atomicAdd(&scr[0], (unsigned long long)(k1 - k0)); atomicAdd(&scr[1], (unsigned long long)(k2 - k1));
+            atomicAdd(&scr[2], (unsigned long long)(k3 - k2)); atomicAdd(&scr[3], (unsigned long long)(k4 - k3)); atomicAdd(&scr[4], 1ull); } } } }
 
 __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows,
                                                            long long nrows, long long row_base,
                                                            rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
                                                            uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                                            uint32_t parmset_mask, int screen_off, int single_exact,
-                                                           const TileDir *__restrict__ dir, const PackedRun *__restrict__ pool) {
+                                                           const TileDir *__restrict__ dir, const Cand *__restrict__ pool) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;            // tests/cpu_emul only
 #else
@@ -1160,7 +1133,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    cx.tile.skew = cfg.skew;
    const LdsLayout L = lds_layout(cfg, true);
    cx.tile.bits = smem + L.bits;
-   cx.tile.bstride = cfg.tile_rows / 8;
+   cx.tile.bstride = (cfg.tile_rows + kScreenHalo) / 8;
    cx.tile.ldpos = smem + L.ldpos;
    float *heights_all = reinterpret_cast<float *>(smem + L.heights);
    // walker w of this workgroup -> thread: spread over the 4 waves so every SIMD issues for some walkers
@@ -1173,8 +1146,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    cx.heights = heights_all + (size_t)(is_walker ? my_w : 0) * 10;
    Rec *recs_all = reinterpret_cast<Rec *>(smem + L.recs);
    int *nrec_all = reinterpret_cast<int *>(smem + L.nrec);
-   RunRec *runs_all = reinterpret_cast<RunRec *>(smem + L.runs);
-   int *runcnt = reinterpret_cast<int *>(smem + L.runcnt);              // [nscreens*ntrks][32 words]
+   Cand *runs_all = reinterpret_cast<Cand *>(smem + L.runs);             // [nscreens*ntrks][run_cap], over the sample tile
    Walker *walkers = reinterpret_cast<Walker *>(smem + L.walkers);       // [nwalk]
    Walker *walkers_next = reinterpret_cast<Walker *>(smem + L.walkers_next);  // [nwalk] result of an optimistic tile, committed only if all lanes agree
    float *heights_bak = reinterpret_cast<float *>(smem + L.heights_bak);     // [nwalk][10]
@@ -1191,7 +1163,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       __syncthreads();
       load_tile(&cfg, cx.tile, rows, nrows);
       __syncthreads();
-      run_screens(&cfg, cx.tile);
+      run_screens(&cfg, cx.tile, false);
       __syncthreads();
       const long long r = find_reset(&cfg, cx.tile, &s_min);
       return (r <= 0 || r < Z.zone_first) ? -1 : r; };
@@ -1240,7 +1212,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          cx.tile.row0 = tile0; cx.tile.nrows = (int)tn;
          __syncthreads();
          if (cfg.debug) c0 = clock64();
-         // ---- optimistic: decide the whole tile from the run records k_screen left in HBM ----
+         // ---- decide the whole tile from the candidate records k_screen left in HBM ----
          bool done_tile = false;
          if (dir && !screen_off && !cfg.find_zeros) {
             const int nst = cfg.nscreens * ntrks;
@@ -1250,16 +1222,13 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
             long long o1 = 0, o2 = 0, o3 = 0;
             if (cfg.debug) o1 = clock64();
             bool avail = true;
-            for (int st = 0; st < nst; ++st) if (s_dir[st].count == 0xFFFF || s_dir[st].count > cfg.run_cap) avail = false;
+            for (int st = 0; st < nst; ++st) if (s_dir[st].count == 0xFFFF) avail = false;
             if (avail) {
-               // the tile's records are contiguous in the pool, list after list: one flat pass, all loads in flight together
-               int total = 0;
-               for (int st = 0; st < nst; ++st) total += s_dir[st].count;
-               const size_t pbase = s_dir[0].offset;
-               for (int i = threadIdx.x; i < total; i += blockDim.x) {
-                  int st = 0, k = i;
-                  while (k >= (int)s_dir[st].count) { k -= s_dir[st].count; ++st; }
-                  unpack_run(runs_all[(size_t)st * cfg.run_cap + k], pool[pbase + i], cfg.screen[st / ntrks].W, cfg.maxvolts); }
+               const int4 *src = reinterpret_cast<const int4 *>(pool + (size_t)g * nst * cfg.run_cap);
+               for (int st = 0; st < nst; ++st) {
+                  const int n2 = 2 * (int)s_dir[st].count;
+                  for (int i = threadIdx.x; i < n2; i += blockDim.x)
+                     reinterpret_cast<int4 *>(runs_all + (size_t)st * cfg.run_cap)[i] = src[(size_t)st * cfg.run_cap * 2 + i]; }
                __syncthreads();
                if (cfg.debug) o2 = clock64();
                cx.nrec = 0;
@@ -1267,9 +1236,10 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                   const int st = cfg.parm[pidx].screen * ntrks + trk;
                   Walker w = walkers[my_w];
                   for (int i = 0; i < 10; ++i) heights_bak[my_w * 10 + i] = cx.heights[i];     // part of the walker's state
-                  if (walk_optimistic(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, s_dir[st].count, s_dir[st].last_rescan))
+                  int why = 0;
+                  if (walk_records(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, s_dir[st].count, s_dir[st], why))
                      walkers_next[my_w] = w;
-                  else atomicOr((unsigned int *)&s_needfull, 1u); }
+                  else { atomicOr((unsigned int *)&s_needfull, 1u); if (cfg.debug) atomicAdd(&scratch->why[why & 7], 1ull); } }
                if (is_walker) nrec_all[my_w] = cx.nrec;
                __syncthreads();
                if (cfg.debug) o3 = clock64();
@@ -1286,39 +1256,19 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                      atomicAdd(&scratch->dbg2[2], (unsigned long long)(o3 - o2)); atomicAdd(&scratch->dbg2[3], (unsigned long long)(o4 - o3)); } }
                __syncthreads(); } }
          if (done_tile) continue;
-         // ---- full path: samples into LDS, screen, run records, exact walkers ----
+         // ---- full path: samples into LDS, screen, exact walkers ----
          load_tile(&cfg, cx.tile, rows, nrows);
          __syncthreads();
          if (cfg.debug) c1 = clock64();
-         run_screens(&cfg, cx.tile);
+         run_screens(&cfg, cx.tile, false);
          __syncthreads();
          if (cfg.debug) c2 = clock64();
-         // run records for every (screen, track), by all lanes
-         {
-            const int nwords = (cx.tile.nrows + 63) >> 6;
-            const int nitems = cfg.nscreens * ntrks * nwords;
-            for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
-               const int st = i / nwords, wd = i - st * nwords;
-               runcnt[st * 32 + wd] = __popcll(run_starts(cx.tile, st / ntrks, st - (st / ntrks) * ntrks, wd)); }
-            __syncthreads();
-            for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
-               const int st = i / nwords, wd = i - st * nwords;
-               int base = 0;
-               for (int k = 0; k < wd; ++k) base += runcnt[st * 32 + k];
-               const int sc = st / ntrks;
-               build_runs_word(cx.tile, &cfg, sc, st - sc * ntrks, wd, cfg.screen[sc].W, runs_all + (size_t)st * cfg.run_cap, base, cfg.run_cap); }
-            __syncthreads(); }
-         long long c2b = 0, c2c = 0;
-         if (cfg.debug) c2b = clock64();
+         long long c2c = 0;
          cx.nrec = 0;
          if (active) {
-            const int st = cfg.parm[pidx].screen * ntrks + trk;
-            const int nwords = (cx.tile.nrows + 63) >> 6;
-            int total = 0;
-            for (int k = 0; k < nwords; ++k) total += runcnt[st * 32 + k];
             Walker w = walkers[my_w];
             if (cfg.find_zeros) { if (pidx == 0) { if (cfg.differentiate) walk_diffzeros(w, cx, trk, stop); else walk_zeros(w, cx, trk, stop); } }
-            else walk(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, total < cfg.run_cap ? total : cfg.run_cap, total);
+            else walk(w, cx, pidx, trk, stop);
             walkers[my_w] = w; }
          if (is_walker) nrec_all[my_w] = cx.nrec;
          __syncthreads();
@@ -1331,7 +1281,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                const long long c3 = clock64();
                atomicAdd(&scratch->dbg[0], (unsigned long long)(c1 - c0)); atomicAdd(&scratch->dbg[1], (unsigned long long)(c2 - c1));
                atomicAdd(&scratch->dbg[2], (unsigned long long)(c3 - c2)); atomicAdd(&scratch->dbg[3], 1ull);
-               atomicAdd(&scratch->dbg[4], (unsigned long long)(c2b - c2)); atomicAdd(&scratch->dbg[5], (unsigned long long)(c2c - c2b));
+               atomicAdd(&scratch->dbg[5], (unsigned long long)(c2c - c2));
                atomicAdd(&scratch->dbg[6], (unsigned long long)(c3 - c2c)); } } }
       // ---- publish ----
       if (is_walker) {
