@@ -143,7 +143,13 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       const int nwalk = c->nparmsets * c->ntrks;
       int rc = (24 * 1024) / (nwalk * 24);
       d.rec_cap = rc > 64 ? 64 : (rc < 8 ? 8 : rc);
-      d.run_cap = d.tile_rows / 8 < 16 ? 16 : d.tile_rows / 8; }
+      d.run_cap = d.tile_rows / 2 < 64 ? 64 : d.tile_rows / 2;
+      // LDS of the sequential pass: room for a typical tile's lists (a quarter of the worst case, at most 24 KiB);
+      // a tile with more candidates than that is decided from its samples instead
+      int lu = d.nscreens * c->ntrks * d.run_cap / 4;
+      if (lu > 1536) lu = 1536;
+      if (lu < 256) lu = 256;
+      d.lds_units = lu; }
    h->lds_bytes = (int)lds_layout(d, true).total + 64;
    h->screen_lds_bytes = (int)lds_layout(d, false).total + 64;
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
@@ -193,7 +199,7 @@ static size_t ws_pool_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_dir_off(h, nrows) + (size_t)ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(TileDir) + 255) & ~(size_t)255; }
 
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pool_off(h, nrows) + (size_t)pool_cap_for(h, nrows) * sizeof(Cand) + 256; }
+   return ws_pool_off(h, nrows) + (size_t)pool_cap_for(h, nrows) * sizeof(CandUnit) + 256; }
 
 extern "C" int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows) {
    return (nrows * h->dev.ntrks / 512) / h->dev.gap_chunks + 4; }
@@ -231,7 +237,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                       d_bursts, (long long)max_bursts, scratch, d_nbursts);
    if (h->timing) (void)hipEventRecord(h->ev[2], st);
    TileDir *dirp = reinterpret_cast<TileDir *>(reinterpret_cast<char *>(d_workspace) + ws_dir_off(h, nrows));
-   Cand *poolp = reinterpret_cast<Cand *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
+   CandUnit *poolp = reinterpret_cast<CandUnit *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
    const bool use_screen = !h->dev.find_zeros && getenv("RTFE_NO_SCREEN_PASS") == nullptr;
    if (use_screen) {
       const long long ntiles = ntiles_for(h, nrows);
@@ -254,7 +260,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    const int dgrid = h->num_cus * per_cu;
    hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                       (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
-                      use_screen ? (const TileDir *)dirp : (const TileDir *)nullptr, (const Cand *)poolp);
+                      use_screen ? (const TileDir *)dirp : (const TileDir *)nullptr, (const CandUnit *)poolp);
    if (h->timing) (void)hipEventRecord(h->ev[4], st);
    return launch_check("rtfe_scan"); }
 
@@ -276,5 +282,5 @@ extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nr
    const int nwalk = h->dev.nparm * h->dev.ntrks;
    hipLaunchKernelGGL(k_decode, dim3(1), dim3(nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256)), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                       (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1,
-                      (const TileDir *)nullptr, (const Cand *)nullptr);
+                      (const TileDir *)nullptr, (const CandUnit *)nullptr);
    return launch_check("rtfe_scan_exact"); }

@@ -50,36 +50,42 @@ struct DevCfg {
    float lsb_per_volt;            // 32767 / maxvolts, for the walkers' integer guard bands
    int   run_cap;                 // candidate-run records per (screen, track) per tile (LDS)
    int   rec_cap;                 // deferred-event records per walker per tile (LDS)
+   int   lds_units;               // candidate units of ONE tile (all lists, packed) that fit the LDS of the sequential pass
    int   debug;                   // RTFE_DEBUG=1: per-phase cycle counters in the workspace (tools/ only)
    DevParm   parm[RTFE_MAXPARMSETS];
    DevScreen screen[kMaxScreens];
 };
 
-// ---- what the dense screen pass (k_screen) leaves in HBM for the sequential pass (k_decode) ----
-// One candidate record = up to 4 consecutive candidate rows of one kind that share the same extreme (rows never
-// straddle a multiple of 4, so records never straddle bitmap words).  It carries everything the sequential
+// ---- what the dense screen pass (k_screen) leaves in HBM for the sequential pass (k_walk / k_decode) ----
+// A list is a sequence of 16-byte units.  One RUN = consecutive candidate rows of one kind that share the same
+// extreme (rows where both kinds are candidates form one-row runs, top first, so list order = the detector's order).
+// A run is 1 header unit + ceil((nrows-1)/4) units of four (dL,dR) pairs.  It carries everything the sequential
 // detector needs to decide those rows EXACTLY without the samples: the extreme, its neighbours (half-sample
-// refinement) and the distance of the extreme from both window edges at every row (int16 code differences, from
-// which the float comparisons of src/decoder.c:788-805 can be re-evaluated bit for bit).
-struct Cand {                  // 32 bytes = two 16-byte halves
-   uint16_t n_s;               // first row, tile-relative
-   uint8_t  nrows;             // 1..4
-   uint8_t  kind;              // 0 top, 1 bottom
-   int16_t  m;                 // the extreme (tops: true window maximum; bottoms: the reference's possibly stale minimum)
-   uint8_t  ld;                // left_distance of the extreme at row n_s (one less at each following row)
-   uint8_t  flags;             // bit 0: the reference's minimum could not be derived here (no rescan within reach)
-   int16_t  prev, next;        // the extreme's neighbours
-   float    v;                 // volt(m)
-   uint16_t dL[4];             // |m - left window edge| at rows n_s .. n_s+3 (clamped at 0)
-   uint16_t dR[4];             // |m - right window edge|
-};
-static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
+// refinement) and its distance from both window edges at every row (int16 code differences, from which the float
+// comparisons of src/decoder.c:788-805 can be re-evaluated bit for bit).
+//   header  .x = n_s | nrows << 16 | kind << 24      n_s tile-relative; kind 0 top / 1 bottom
+//           .y = (m & 0xffff) | ld0 << 16            m = the extreme (tops: true window maximum; bottoms: the reference's
+//                                                    possibly stale minimum); ld0 = its left_distance at row n_s (one less
+//                                                    per row); ld0 = 0 (bottoms): the reference's minimum is unknown here
+//           .z = prev | next << 16                   the extreme's neighbours
+//           .w = dL | dR << 16                       row n_s: |m - left window edge|, |m - right edge| (clamped at 0)
+//   margins .x .y .z .w = dL | dR << 16              rows n_s + 1 + 4u .. n_s + 4 + 4u of margin unit u
+typedef struct { int32_t x, y, z, w; } CandUnit;
 struct TileDir {               // per (tile, screen, track): 8 bytes
-   uint16_t count;             // records in this list; 0xFFFF: more than run_cap (list not stored)
+   uint16_t count;             // 16-byte units in this list; 0xFFFF: more than run_cap (list incomplete)
    uint8_t  end_ld;            // left_distance of the reference's minimum after the tile's last row; 0 = unknown
    uint8_t  pad;
    int16_t  end_min;           // that minimum (int16 code)
    uint16_t pad2;
+};
+// ---- burst hand-over between the kernels of one scan (workspace) ----
+enum { kBurstNew = 0, kBurstNeedsFull = 1, kBurstReady = 2, kBurstDone = 3 };
+struct BurstCtl {              // 32 bytes per burst
+   long long reset, stop;      // restart row / first row of the next burst's span
+   int       next_tile;        // tile of the tape-global grid to continue with
+   int       status;           // kBurst*
+   unsigned  bflags;           // burst flags collected so far
+   int       pad;
 };
 constexpr int kScreenHalo = 64;      // rows in front of a tile that the screen also covers (one bitmap word)
 

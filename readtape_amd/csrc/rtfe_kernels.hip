@@ -228,9 +228,10 @@ struct Tile {
    int      nrows;        // rows in the tile proper
    long long reset;       // burst restart row (deskew FIFO restarts there, src/decoder.c:415)
    // the bitmaps and left_distance maps also cover the kScreenHalo rows in front of the tile (word -1 / rows -64..-1)
-   unsigned char *bits;   // LDS: [nscreens][3][ntrks][bstride]   0=top 1=bot 2=rescan ("A-sync")
-   int      bstride;      // bytes per bitmap row = (tile_rows + kScreenHalo) / 8
-   unsigned char *ldpos;  // LDS: [nscreens][2][ntrks][tile_rows + kScreenHalo] left_distance of the first window max (0) / min (1)
+   unsigned char *bits;   // LDS: [nscreens][5][ntrks][bstride]   0=top 1=bot 2=rescan ("A-sync") 3/4=run starts (k_screen)
+   int      bstride;      // bytes per bitmap row = (tile_rows + kScreenHalo) / 8 + 8 (one spare word)
+   unsigned char *ldpos;  // LDS: [nscreens][2][ntrks][ldstride] left_distance of the first window max (0) / min (1)
+   int      ldstride;     // tile_rows + kScreenHalo
    int      ntrks;
    const int *skew;
    __device__ __forceinline__ int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + kHaloRows]; }
@@ -240,9 +241,9 @@ struct Tile {
       const int d = skew[t];
       return xi(t, (n - reset < d) ? n : n - d); }
    __device__ __forceinline__ unsigned char *ldmap(int screen, int kind, int t) const {       // [row], rows >= -kScreenHalo
-      return ldpos + ((size_t)(screen * 2 + kind) * ntrks + t) * (bstride * 8) + kScreenHalo; }
+      return ldpos + ((size_t)(screen * 2 + kind) * ntrks + t) * ldstride + kScreenHalo; }
    __device__ __forceinline__ const u64 *map(int screen, int kind, int t) const {               // [word], words >= -1
-      return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 3 + kind) * ntrks + t) * bstride + kScreenHalo / 8); }
+      return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 5 + kind) * ntrks + t) * bstride + kScreenHalo / 8); }
 };
 
 __device__ __forceinline__ float volt(int i, float maxvolts) {      // src/readtape.c:1420
@@ -728,70 +729,117 @@ __device__ __forceinline__ void walk_diffzeros(Walker &w, Ctx &cx, int trk, long
 // This pass rewrites ldmap(screen,1,trk)[row] from "left_distance of the true minimum" into "left_distance of the
 // reference's minimum" for the rows between A-sync rows (0 where no A-sync row lies within reach: unknown).
 // One call handles the gaps that START in one 8-row strip.
-__device__ __forceinline__ void chain_gaps(const Tile &tl, int screen, int trk, int strip) {
-   const unsigned char *ab = reinterpret_cast<const unsigned char *>(tl.map(screen, 2, trk));      // [row >> 3], rows >= -kScreenHalo
-   unsigned char *ldb = tl.ldmap(screen, 1, trk);
-   const int nrows = tl.nrows;
-   const unsigned a = ab[strip];
-   for (int j = 0; j < 8; ++j) {
-      const int r = strip * 8 + j;
-      if (r + 1 >= nrows) break;
-      const bool ar = (a >> j) & 1;
-      if (r == -kScreenHalo && !ar)                                 // in front of the first A-sync row: unknown
-         for (int q = r; q < nrows && !((ab[q >> 3] >> (q & 7)) & 1); ++q) ldb[q] = 0;
-      if (ar && !((ab[(r + 1) >> 3] >> ((r + 1) & 7)) & 1)) {
-         int ld = ldb[r];                                           // true minimum at the A-sync row
-         for (int q = r + 1; q < nrows && !((ab[q >> 3] >> (q & 7)) & 1); ++q) {
-            --ld;                                                   // the same sample, one place closer to the left edge
-            if (ld == 0) ld = ldb[q];                               // it left the window at this row: rescan (ldb[q] is still the true one)
-            else ldb[q] = (unsigned char)ld; } } } }
+__device__ __forceinline__ u64 bits_from(const u64 *map, int n) {       // bit k of the result = bit (n + k) of the bitmap, n >= -kScreenHalo
+   const int wd = n >> 6, sh = n & 63;
+   const u64 lo = map[wd] >> sh;
+   return sh ? (lo | (map[wd + 1] << (64 - sh))) : lo; }              // (one spare word behind every bitmap row)
 
-// ---- k_screen only: the candidate records of one bitmap word of one (screen, track), in row order ----
-// kBuild = false only counts them (same walk, so the two passes agree by construction).
-template <bool kBuild>
-__device__ __forceinline__ int build_word(const Tile &tl, const DevCfg *cfg, int screen, int trk, int wd, int W, Cand *out, int base, int cap) {
-   const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk);
-   const unsigned char *ldt = tl.ldmap(screen, 0, trk), *ldb = tl.ldmap(screen, 1, trk);
-   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
-   const int nwords = (tl.nrows + 63) >> 6;
-   const u64 valid = (wd == nwords - 1 && (tl.nrows & 63)) ? ((1ull << (tl.nrows & 63)) - 1) : ~0ull;
-   const u64 tw = tm[wd] & valid, bw = bm[wd] & valid;
-   u64 any = tw | bw;
-   int k = base;
+// the left_distance of the reference's minimum at row q (0 = unknown: no A-sync row within reach of the tile's halo)
+__device__ __forceinline__ int stale_ld(const u64 *am, const unsigned char *ldb, int q) {
+   int wd = q >> 6;
+   u64 m = am[wd] & (~0ull >> (63 - (q & 63)));                     // A-sync rows <= q in q's word
+   #pragma nounroll
+   while (!m) { if (--wd < -1) return 0; m = am[wd]; }
+   int h = wd * 64 + 63 - __clzll((long long)m);                     // last A-sync row: the minimum is the true one there
+   #pragma nounroll
+   for (;;) {
+      const int l = ldb[h];                                          // (a rescan row: its byte is never rewritten with another value)
+      if (h + l > q) return l - (q - h);                             // still the same sample at row q
+      h += l; } }                                                    // it left the window at row h + l: rescan there
+
+// rewrite the bytes of the bottom-candidate rows of one strip that are not A-sync rows
+__device__ __forceinline__ void fill_stale(const Tile &tl, int screen, int trk, int strip) {
+   const u64 *am = tl.map(screen, 2, trk), *bm = tl.map(screen, 1, trk);
+   const int sh = (strip & 7) * 8;
+   unsigned need = (unsigned)((bm[strip >> 3] & ~am[strip >> 3]) >> sh) & 0xffu;
+   if (strip * 8 + 8 > tl.nrows) need &= (1u << (tl.nrows - strip * 8)) - 1;
+   unsigned char *ldb = tl.ldmap(screen, 1, trk);
+   #pragma nounroll
+   while (need) {
+      const int j = __ffs((int)need) - 1;
+      need &= need - 1;
+      const int n = strip * 8 + j;
+      ldb[n] = (unsigned char)stale_ld(am, ldb, n); } }
+
+// ---- k_screen only: run starts.  A RUN = consecutive candidate rows of one kind sharing the same extreme; a row where
+// both kinds are candidates is a one-row run of each kind.  One call = the 8 rows of one strip of one (screen, track):
+// start bytes into the two extra bitmaps (kinds 3 and 4).
+__device__ __forceinline__ void run_starts(const Tile &tl, int screen, int trk, int strip) {
+   const int ntb = tl.ntrks * tl.bstride;
+   unsigned char *row = tl.bits + ((size_t)(screen * 5) * tl.ntrks + trk) * tl.bstride + kScreenHalo / 8 + strip;
+   const int r0 = strip * 8;
+   const int nvalid = tl.nrows - r0 >= 8 ? 8 : tl.nrows - r0;
+   const unsigned vm = (1u << nvalid) - 1;
+   const unsigned t = row[0] & vm, b = row[ntb] & vm;
+   // bit j+1 of t9/b9 = row r0+j, bit 0 = the row in front of the strip (never a predecessor at the tile's first row)
+   const unsigned t9 = (t << 1) | (strip > 0 ? (row[-1] >> 7) & 1u : 0u), b9 = (b << 1) | (strip > 0 ? (row[ntb - 1] >> 7) & 1u : 0u);
+   const unsigned ot = t9 & ~b9, ob = b9 & ~t9;                     // single-kind rows
+   unsigned st = 0, sb = 0;
+   if (t | b) {
+      const unsigned char *ldt = tl.ldmap(screen, 0, trk) + r0, *ldb = tl.ldmap(screen, 1, trk) + r0;
+      #pragma unroll
+      for (int j = 0; j < 8; ++j) {
+         const bool ct = ((ot >> j) & (ot >> (j + 1)) & 1) && ldt[j] != 0 && ldt[j] == ldt[j - 1] - 1;
+         const bool cb = ((ob >> j) & (ob >> (j + 1)) & 1) && ldb[j] != 0 && ldb[j] == ldb[j - 1] - 1;
+         st |= (unsigned)(((t >> j) & 1) && !ct) << j;
+         sb |= (unsigned)(((b >> j) & 1) && !cb) << j; } }
+   row[3 * ntb] = (unsigned char)st;
+   row[4 * ntb] = (unsigned char)sb; }
+
+// rows in the run that starts at row n of kind `kind` (cm = candidate bitmap of that kind, sm = its start bitmap)
+__device__ __forceinline__ int run_length(const u64 *cm, const u64 *sm, int n, int nrows) {
+   const u64 c = bits_from(cm, n + 1) & ~bits_from(sm, n + 1);       // continuation rows behind n
+   int len = 1 + (~c ? __ffsll((long long)~c) - 1 : 64);
+   if (n + len > nrows) len = nrows - n;
+   return len; }
+
+// ---- k_screen only: the runs that start in one strip of one (screen, track), in the detector's order (row, top
+// before bottom): one descriptor each into the tile's run table, and the strip's unit count as the result.
+// descriptor: st | kind << 8 | n << 16 | (u64)nr << 32 | (u64)rel << 40   (rel = unit offset inside the strip)
+__device__ __forceinline__ int list_runs(const Tile &tl, int st, int screen, int trk, int strip, u64 *runtab, int *nruns, int tabcap) {
+   const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk), *stm = tl.map(screen, 3, trk), *sbm = tl.map(screen, 4, trk);
+   const int sh = (strip & 7) * 8;
+   const unsigned stt = (unsigned)(stm[strip >> 3] >> sh) & 0xffu, sb = (unsigned)(sbm[strip >> 3] >> sh) & 0xffu;
+   unsigned any = stt | sb;
+   int rel = 0;
+   #pragma nounroll
    while (any) {
-      const int bit = __ffsll((long long)any) - 1;
-      const int n = wd * 64 + bit;
-      const bool tb = (tw >> bit) & 1, bb = (bw >> bit) & 1;
-      int nr = 1;
-      const bool both = tb && bb;
-      for (int pass = 0; pass < (both ? 2 : 1); ++pass) {
-         const int kind = both ? pass : (bb ? 1 : 0);              // top first at a row with both bits (src/decoder.c:788-805)
-         const unsigned char *ld = kind ? ldb : ldt;
-         const int l0 = ld[n];
-         if (!both && l0 != 0) {
-            const u64 same = kind ? (bw & ~tw) : (tw & ~bw);
-            while (((n + nr) & 3) != 0 && ((same >> (bit + nr)) & 1) && ld[n + nr] == l0 - nr) ++nr; }
-         if (kBuild && k < cap) {
-            Cand c;
-            c.n_s = (uint16_t)n; c.nrows = (uint8_t)nr; c.kind = (uint8_t)kind; c.ld = (uint8_t)l0; c.flags = l0 == 0 ? 1 : 0;
-            const int p = n - W + l0;                               // lo + left_distance - 1
-            const int m = l0 ? yb[p] : 0;
-            c.m = (int16_t)m; c.prev = l0 ? yb[p - 1] : 0; c.next = l0 ? yb[p + 1] : 0;
-            c.v = volt(m, cfg->maxvolts);
-            #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-               int dl = 0, dr = 0;
-               if (j < nr && l0) {
-                  const int L = yb[n + j - W + 1], R = yb[n + j];
-                  dl = kind ? L - m : m - L; dr = kind ? R - m : m - R;
-                  dl = dl < 0 ? 0 : dl; dr = dr < 0 ? 0 : dr; }
-               c.dL[j] = (uint16_t)dl; c.dR[j] = (uint16_t)dr; }
-            int4 *dst = reinterpret_cast<int4 *>(out + k);
-            dst[0] = reinterpret_cast<const int4 *>(&c)[0];
-            dst[1] = reinterpret_cast<const int4 *>(&c)[1]; }
-         ++k; }
-      any &= ~(((nr >= 64 ? 0ull : (1ull << nr)) - 1) << bit); }
-   return k - base; }
+      const int j = __ffs((int)any) - 1;
+      any &= any - 1;
+      const int n = strip * 8 + j;
+      #pragma nounroll
+      for (int kind = (stt >> j) & 1 ? 0 : 1; kind <= (int)((sb >> j) & 1); ++kind) {
+         const int nr = run_length(kind ? bm : tm, kind ? sbm : stm, n, tl.nrows);
+         const int slot = atomicAdd(nruns, 1);
+         if (slot < tabcap) runtab[slot] = (u64)(unsigned)(st | (kind << 8) | (n << 16)) | ((u64)nr << 32) | ((u64)rel << 40);
+         rel += 1 + ((nr + 2) >> 2); } }
+   return rel; }
+
+// ---- k_screen only: the units of one run -> its place in the list (HBM) ----
+__device__ __forceinline__ void build_run(const Tile &tl, const DevCfg *cfg, int screen, int trk, int W, int n, int kind, int nr, int4 *out) {
+   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
+   const int ld0 = tl.ldmap(screen, kind, trk)[n];
+   int m = 0, prev = 0, next = 0;
+   if (ld0) { const int p = n - W + ld0; m = yb[p]; prev = yb[p - 1]; next = yb[p + 1]; }
+   int4 q;
+   q.x = n | (nr << 16) | (kind << 24);
+   q.y = (m & 0xffff) | (ld0 << 16);
+   q.z = (prev & 0xffff) | (next << 16);
+   int4 u = make_int4(0, 0, 0, 0);
+   int slot = 0;
+   #pragma nounroll
+   for (int jj = 0; jj < nr; ++jj) {
+      int dl = 0, dr = 0;
+      if (ld0) {
+         const int L = yb[n + jj - W + 1], R = yb[n + jj];
+         dl = kind ? L - m : m - L; dr = kind ? R - m : m - R;
+         dl = dl < 0 ? 0 : dl; dr = dr < 0 ? 0 : dr; }
+      const int pr = dl | (dr << 16);
+      if (jj == 0) { q.w = pr; out[slot++] = q; }
+      else {
+         const int c = (jj - 1) & 3;
+         if (c == 0) u.x = pr; else if (c == 1) u.y = pr; else if (c == 2) u.z = pr; else u.w = pr;
+         if (c == 3 || jj == nr - 1) { out[slot++] = u; u = make_int4(0, 0, 0, 0); } } } }
 
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
@@ -846,7 +894,7 @@ __device__ __forceinline__ void screen_strip(const Tile &tl, const DevScreen &sc
          topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i;
          ldt |= (u64)((255 - (kx & 255)) + 1) << (8 * i);
          ldb |= (u64)((kn & 255) + 1) << (8 * i); } }
-   unsigned char *o = tl.bits + ((size_t)(screen * 3) * tl.ntrks + trk) * tl.bstride + kScreenHalo / 8 + strip;     // strip >= -kScreenHalo/8
+   unsigned char *o = tl.bits + ((size_t)(screen * 5) * tl.ntrks + trk) * tl.bstride + kScreenHalo / 8 + strip;     // strip >= -kScreenHalo/8
    o[0] = (unsigned char)topb;
    o[(size_t)tl.ntrks * tl.bstride] = (unsigned char)botb;
    o[(size_t)2 * tl.ntrks * tl.bstride] = (unsigned char)resb;
@@ -915,13 +963,13 @@ __device__ __forceinline__ long long find_reset(const DevCfg *cfg, const Tile &t
    return r; }          // 0 => no provably safe restart row inside the margin
 
 // ---- record walk: the tile's candidate records come from HBM (k_screen wrote them); no sample is in LDS.
-// The same sequential detector as walk(), one iteration per record: rows inside a blind countdown are skipped, the
-// others are decided from the integer distances against the guard-banded thresholds and, inside the guard band, by
-// re-evaluating the reference's float comparisons on the reconstructed codes.  Returns false (state untouched by the
-// caller) only when the records cannot describe what the detector would see: the literal start-up path, a minimum
-// k_screen could not derive, a full event list.
+// The same sequential detector as walk(), one iteration per candidate (row, kind): rows inside a blind countdown
+// are skipped, the others are decided from the integer edge distances against the guard-banded thresholds and,
+// inside the guard band, by re-evaluating the reference's float comparisons on the reconstructed codes.
+// Returns false (the caller discards the state) only when the records cannot describe what the detector would see:
+// the literal start-up path, a minimum k_screen could not derive, a full event list.
 __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int trk, long long limit,
-                                             const Cand *recs, int nrecs, const TileDir &td, int &why) {
+                                             const CandUnit *recs, int nrecs, const TileDir &td, int &why) {
    const DevCfg *cfg = cx.cfg;
    const DevParm &P = cfg->parm[pidx];
    const Tile &tl = cx.tile;
@@ -938,49 +986,62 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
    if (cur < 0) cur = 0;
    const float mv = cfg->maxvolts, lsb = cfg->lsb_per_volt;
    const bool pe = cfg->mode == RTFE_PE;
-   for (int i = 0; i < nrecs; ++i) {
-      const int4 A = reinterpret_cast<const int4 *>(&recs[i])[0];
+   const int4 *units = reinterpret_cast<const int4 *>(recs);
+   int i = 0;
+   #pragma nounroll
+   while (i < nrecs) {
+      const int4 A = units[i];                                     // run header
       const int n_s = A.x & 0xffff, nr = (A.x >> 16) & 0xff;
+      const int ibase = i + 1;                                     // first margin unit of this run
+      i += 1 + ((nr + 2) >> 2);
       if (n_s >= lim) break;
-      if (n_s + nr <= cur) continue;                               // inside the countdown of the last detection
-      const int4 B = reinterpret_cast<const int4 *>(&recs[i])[1];
+      int k = cur > n_s ? cur - n_s : 0;                            // rows inside the countdown of the last detection are skipped
+      if (k >= nr) continue;
+      const int ld0 = (A.y >> 16) & 0xff;
       const bool is_top = ((A.x >> 24) & 1) == 0;
-      const int m = (int)(short)(A.y & 0xffff), ld0 = (A.y >> 16) & 0xff;
-      if (((unsigned)A.y >> 24) & 1) { why = 4; return false; }
-      // min_peak test: the same for every row of the record
-      if (w.reqmin != 0) {
+      const int m = (int)(short)(A.y & 0xffff);
+      if (ld0 == 0) { why = 4; return false; }
+      if (w.reqmin != 0) {                                         // min_peak test: the same for every row of the run
          const int a = is_top ? m : -m;
          if (a <= w.min_lo) continue;
          if (a < w.min_hi) {
             if (w.thr_dirty) update_thresholds(w, P, lsb);
             if (!(is_top ? volt(m, mv) > w.reqmin : volt(m, mv) < -w.reqmin)) continue; } }
-      const unsigned long long DL = (unsigned long long)(unsigned)B.x | ((unsigned long long)(unsigned)B.y << 32);
-      const unsigned long long DR = (unsigned long long)(unsigned)B.z | ((unsigned long long)(unsigned)B.w << 32);
       int hit = -1;
-      for (int k = max(0, cur - n_s); k < nr && n_s + k < lim; ++k) {
-         const int dl = (int)((DL >> (16 * k)) & 0xffff), dr = (int)((DR >> (16 * k)) & 0xffff);
+      int4 M = make_int4(0, 0, 0, 0);
+      int mu = -1;
+      #pragma nounroll
+      for (; k < nr && n_s + k < lim; ++k) {
+         int pr;
+         if (k == 0) pr = A.w;
+         else {
+            const int u = (k - 1) >> 2, c = (k - 1) & 3;
+            if (u != mu) { M = units[ibase + u]; mu = u; }
+            pr = c == 0 ? M.x : (c == 1 ? M.y : (c == 2 ? M.z : M.w)); }
+         const int dl = pr & 0xffff, dr = (int)((unsigned)pr >> 16);
          const int mg = min(dl, dr);
          if (mg <= w.rise_lo) continue;                             // fails for sure
-         if (mg >= w.rise_hi) { hit = k; break; }                   // passes for sure
-         if (w.thr_dirty) update_thresholds(w, P, lsb);              // guard band: the reference's own comparison
-         const float vm = volt(m, mv);
-         const float vl = volt(is_top ? m - dl : m + dl, mv), vr = volt(is_top ? m - dr : m + dr, mv);
-         if (is_top ? (vm > vl + w.rise && vm > vr + w.rise) : (vm < vl - w.rise && vm < vr - w.rise)) { hit = k; break; } }
+         if (mg < w.rise_hi) {                                      // guard band: the reference's own comparison
+            if (w.thr_dirty) update_thresholds(w, P, lsb);
+            const float vm = volt(m, mv);
+            const float vl = volt(is_top ? m - dl : m + dl, mv), vr = volt(is_top ? m - dr : m + dr, mv);
+            if (!(is_top ? (vm > vl + w.rise && vm > vr + w.rise) : (vm < vl - w.rise && vm < vr - w.rise))) continue; }
+         hit = k; break; }
       if (hit < 0) continue;
-      // ---- a detection at row n_s + hit (the bookkeeping of emit_peak) ----
-      const int n = n_s + hit, left_distance = ld0 - hit;
-      const float v = __int_as_float(A.w);
+      // ---- a detection at row n (the bookkeeping of emit_peak) ----
+      const int n = n_s + hit, ld = ld0 - hit;
+      const float v = volt(m, mv);
       double t_peak = 0;
       if (pe && !w.datablock && w.peakcount >= 68) {               // the end of the PE preamble is decided on peak times
          const int adjcode = refine_code(cfg, m, (int)(short)(A.z & 0xffff), A.z >> 16, w.agc_gain, is_top);
          const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
-         t_peak = time_of(cfg, cx.row_base + tl.row0 + n) - ((float)(W - left_distance) - adj) * cfg->sample_deltat; }
+         t_peak = time_of(cfg, cx.row_base + tl.row0 + n) - ((float)(W - ld) - adj) * cfg->sample_deltat; }
       if (w.nevents >= cx.cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
       else {
          if (cx.nrec >= cx.rec_cap) { why = 6; return false; }
          // Rec as three 8-byte LDS stores: {idx, n_rel|ld|kind} {g, val|prev} {next, -}
          unsigned long long *dst = reinterpret_cast<unsigned long long *>(&cx.recs[cx.nrec++]);
-         const unsigned int w1 = (unsigned)n | ((unsigned)left_distance << 16) | ((unsigned)(is_top ? 0 : 1) << 24);
+         const unsigned int w1 = (unsigned)n | ((unsigned)ld << 16) | ((unsigned)(is_top ? 0 : 1) << 24);
          const unsigned int w3 = (unsigned)(m & 0xffff) | ((unsigned)A.z << 16);            // val | prev
          const unsigned int w4 = ((unsigned)A.z >> 16);                                       // next
          dst[0] = (unsigned long long)w.nevents | ((unsigned long long)w1 << 32);
@@ -990,8 +1051,8 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
       ++w.nevents;
       agc_after_peak(w, cfg, P, cx.heights, is_top, t_peak);
       if (!approx_thresholds(w, P, lsb)) update_thresholds(w, P, lsb);
-      w.blind_until = tl.row0 + n + left_distance;                 // pkww_countdown = left_distance (src/decoder.c:741)
-      cur = n + left_distance + 1; }
+      w.blind_until = tl.row0 + n + ld;                            // pkww_countdown = left_distance (src/decoder.c:741)
+      cur = n + ld + 1; }
    n64 = tl.row0 + lim;
    w.next = n64 < limit ? n64 : limit;
    if (whole) {                                                     // the minimum's state after the tile's last row, from k_screen
@@ -1002,20 +1063,24 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
 // LDS carve of k_screen / k_decode.  ONE definition, used by the kernels and by the host when it sizes the dynamic
 // LDS allocation (rtfe_api.hip): an under-sized allocation does not fault on the GPU, out-of-range LDS reads return 0.
 struct LdsLayout {
-   unsigned bits, ldpos, heights, recs, nrec, runs, runcnt, walkers, walkers_next, heights_bak, total; };
+   unsigned bits, ldpos, heights, recs, nrec, runs, runcnt, runtab, walkers, walkers_next, heights_bak, total; };
+__host__ __device__ inline unsigned lds_runtab_cap(const DevCfg &c) {        // run descriptors of one tile (k_screen)
+   const unsigned n = (unsigned)(c.nscreens * c.ntrks * c.tile_rows) / 8u;
+   return n > 2048u ? 2048u : n; }
 __host__ __device__ inline unsigned lds_align16(unsigned v) { return (v + 15u) & ~15u; }
 __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    LdsLayout L;
    const unsigned ntrks = (unsigned)c.ntrks, nst = (unsigned)c.nscreens * ntrks, nwalk = (unsigned)c.nparm * ntrks;
    const unsigned T = (unsigned)c.tile_rows;
    unsigned off = lds_align16(ntrks * (unsigned)(kHaloRows + c.tile_rows + 8) * 2u);
-   L.bits = off;      off = lds_align16(off + nst * 3u * ((T + kScreenHalo) / 8));
+   L.bits = off;      off = lds_align16(off + nst * 5u * ((T + kScreenHalo) / 8 + 8));
    L.ldpos = off;     off = lds_align16(off + nst * 2u * (T + kScreenHalo));
    // k_decode: the candidate records of a tile share the space of the sample tile (a tile is decided either from
    // its records or from its samples, never both)
    L.runs = 0;
-   if (decode) { const unsigned r = lds_align16(nst * (unsigned)c.run_cap * (unsigned)sizeof(Cand)); if (r > off) off = r; }
-   L.runcnt = off;    if (!decode) off = lds_align16(off + nst * 32u * 4u);
+   if (decode) { const unsigned r = lds_align16((unsigned)c.lds_units * (unsigned)sizeof(CandUnit)); if (r > off) off = r; }
+   L.runcnt = off;    if (!decode) off = lds_align16(off + nst * (T / 8) * 2u);
+   L.runtab = off;    if (!decode) off = lds_align16(off + lds_runtab_cap(c) * 8u);
    L.heights = off;   if (decode) off = lds_align16(off + nwalk * 10u * 4u);
    L.recs = off;      if (decode) off = lds_align16(off + nwalk * (unsigned)c.rec_cap * (unsigned)sizeof(Rec));
    L.nrec = off;      if (decode) off = lds_align16(off + nwalk * 4u);
@@ -1032,7 +1097,7 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
 // Everything the sequential pass needs in the common case; it never has to touch the samples again.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
-                                                TileDir *__restrict__ dir, Cand *__restrict__ pool, long long ntiles,
+                                                TileDir *__restrict__ dir, CandUnit *__restrict__ pool, long long ntiles,
                                                 unsigned long long *__restrict__ scr) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;
@@ -1048,9 +1113,13 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    tl.x = reinterpret_cast<int16_t *>(smem);
    tl.ldw = kHaloRows + cfg.tile_rows + 8;
    tl.ntrks = ntrks; tl.skew = cfg.skew; tl.reset = -(1ll << 40);
-   tl.bits = smem + L.bits; tl.bstride = (cfg.tile_rows + kScreenHalo) / 8;
-   tl.ldpos = smem + L.ldpos;
-   int *runcnt = reinterpret_cast<int *>(smem + L.runcnt);          // [nst][32 words]
+   tl.bits = smem + L.bits; tl.bstride = (cfg.tile_rows + kScreenHalo) / 8 + 8;
+   tl.ldpos = smem + L.ldpos; tl.ldstride = cfg.tile_rows + kScreenHalo;
+   unsigned short *stripcnt = reinterpret_cast<unsigned short *>(smem + L.runcnt);     // [nst][tile_rows / 8] units per strip
+   u64 *runtab = reinterpret_cast<u64 *>(smem + L.runtab);           // the tile's run descriptors
+   const int tabcap = (int)lds_runtab_cap(cfg);
+   __shared__ int s_nruns;
+   __shared__ int s_total[kMaxScreens * RTFE_MAXTRKS];
    const long long T = cfg.tile_rows;
    for (long long g = blockIdx.x; g < ntiles; g += gridDim.x) {
       tl.row0 = g * T; tl.nrows = (int)((tl.row0 + T <= nrows) ? T : nrows - tl.row0);
@@ -1060,35 +1129,62 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
       load_tile(&cfg, tl, rows, nrows);
       __syncthreads();
       if (cfg.debug) k1 = clock64();
+      if (cfg.debug & 4) continue;
       run_screens(&cfg, tl, true);
       __syncthreads();
       if (cfg.debug) k2 = clock64();
-      {
-         const int nstrips = (tl.nrows + kStrip - 1) / kStrip + kScreenHalo / kStrip;
-         for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {
-            const int st = i / nstrips, sc = st / ntrks;
-            chain_gaps(tl, sc, st - sc * ntrks, i - st * nstrips - kScreenHalo / kStrip); } }
+      if (cfg.debug & 8) continue;
+      const int nstrips = (tl.nrows + kStrip - 1) / kStrip;
+      const int smax = cfg.tile_rows / kStrip;
+      if (threadIdx.x == 0) s_nruns = 0;
+      for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {      // the reference's minimum at the bottom candidates
+         const int st = i / nstrips, sc = st / ntrks;
+         fill_stale(tl, sc, st - sc * ntrks, i - st * nstrips); }
       __syncthreads();
-      const int nwords = (tl.nrows + 63) >> 6;
-      const int nitems = nst * nwords;
-      for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
-         const int st = i / nwords, wd = i - st * nwords, sc = st / ntrks;
-         runcnt[st * 32 + wd] = build_word<false>(tl, &cfg, sc, st - sc * ntrks, wd, cfg.screen[sc].W, nullptr, 0, 0); }
+      long long k2a = 0, k2b = 0;
+      if (cfg.debug) k2a = clock64();
+      for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {
+         const int st = i / nstrips, sc = st / ntrks;
+         run_starts(tl, sc, st - sc * ntrks, i - st * nstrips); }
+      __syncthreads();
+      if (cfg.debug) k2b = clock64();
+      if (cfg.debug & 16) continue;
+      for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {
+         const int st = i / nstrips, sc = st / ntrks, strip = i - st * nstrips;
+         stripcnt[st * smax + strip] = (unsigned short)list_runs(tl, st, sc, st - sc * ntrks, strip, runtab, &s_nruns, tabcap); }
+      __syncthreads();
+      // exclusive scan of the strips' unit counts, list by list (one wave per list at a time)
+      {
+         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+         for (int st = wave; st < nst; st += nwaves) {
+            int carry = 0;
+            for (int s0 = 0; s0 < nstrips; s0 += 64) {
+               const int v = s0 + lane < nstrips ? stripcnt[st * smax + s0 + lane] : 0;
+               int x = v;
+               #pragma unroll
+               for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+               if (s0 + lane < nstrips) stripcnt[st * smax + s0 + lane] = (unsigned short)(carry + x - v);
+               carry += __shfl(x, 63); }
+            if (lane == 0) s_total[st] = carry; } }
       __syncthreads();
       if (cfg.debug) k3 = clock64();
-      for (int i = threadIdx.x; i < nitems; i += blockDim.x) {
-         const int st = i / nwords, wd = i - st * nwords, sc = st / ntrks;
-         int base = 0;
-         for (int k = 0; k < wd; ++k) base += runcnt[st * 32 + k];
-         build_word<true>(tl, &cfg, sc, st - sc * ntrks, wd, cfg.screen[sc].W, pool + ((size_t)g * nst + st) * cfg.run_cap, base, cfg.run_cap); }
+      if (cfg.debug & 32) continue;
+      const bool tab_ok = s_nruns <= tabcap;
+      if (tab_ok)
+         for (int r = threadIdx.x; r < s_nruns; r += blockDim.x) {
+            const u64 d = runtab[r];
+            const int st = (int)(d & 0xff), kind = (int)((d >> 8) & 1), n = (int)((d >> 16) & 0xffff), nr = (int)((d >> 32) & 0xff), rel = (int)(d >> 40);
+            const int sc = st / ntrks;
+            const int off = stripcnt[st * smax + (n >> 3)] + rel;
+            if (s_total[st] <= cfg.run_cap)
+               build_run(tl, &cfg, sc, st - sc * ntrks, cfg.screen[sc].W, n, kind, nr,
+                         reinterpret_cast<int4 *>(pool) + ((size_t)g * nst + st) * cfg.run_cap + off); }
       if (threadIdx.x < nst) {
          const int st = threadIdx.x, sc = st / ntrks, trk = st - sc * ntrks;
-         int cnt = 0;
-         for (int k = 0; k < nwords; ++k) cnt += runcnt[st * 32 + k];
          TileDir d;
-         d.count = cnt > cfg.run_cap ? (uint16_t)0xFFFF : (uint16_t)cnt;
+         d.count = (!tab_ok || s_total[st] > cfg.run_cap) ? (uint16_t)0xFFFF : (uint16_t)s_total[st];
          const int last = tl.nrows - 1;
-         const int eld = tl.ldmap(sc, 1, trk)[last];
+         const int eld = stale_ld(tl.map(sc, 2, trk), tl.ldmap(sc, 1, trk), last);
          d.end_ld = (uint8_t)eld; d.pad = 0; d.pad2 = 0;
          d.end_min = eld ? tl.x[trk * tl.ldw + kHaloRows - cfg.skew[trk] + last - cfg.screen[sc].W + eld] : (int16_t)0;
          dir[g * nst + st] = d; }
@@ -1097,14 +1193,15 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
          if (threadIdx.x == 0) {
             const long long k4 = clock64();
             atomicAdd(&scr[0], (unsigned long long)(k1 - k0)); atomicAdd(&scr[1], (unsigned long long)(k2 - k1));
-            atomicAdd(&scr[2], (unsigned long long)(k3 - k2)); atomicAdd(&scr[3], (unsigned long long)(k4 - k3)); atomicAdd(&scr[4], 1ull); } } } }
+            atomicAdd(&scr[2], (unsigned long long)(k3 - k2)); atomicAdd(&scr[3], (unsigned long long)(k4 - k3)); atomicAdd(&scr[4], 1ull);
+            atomicAdd(&scr[5], (unsigned long long)(k2a - k2)); atomicAdd(&scr[6], (unsigned long long)(k2b - k2a)); } } } }
 
 __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows,
                                                            long long nrows, long long row_base,
                                                            rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
                                                            uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                                            uint32_t parmset_mask, int screen_off, int single_exact,
-                                                           const TileDir *__restrict__ dir, const Cand *__restrict__ pool) {
+                                                           const TileDir *__restrict__ dir, const CandUnit *__restrict__ pool) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;            // tests/cpu_emul only
 #else
@@ -1116,6 +1213,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    __shared__ unsigned int s_flags;
    __shared__ int s_needfull;
    __shared__ TileDir s_dir[kMaxScreens * RTFE_MAXTRKS];
+   __shared__ int s_off[kMaxScreens * RTFE_MAXTRKS + 1];
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
    if (screen_off && threadIdx.x == 0)
@@ -1133,8 +1231,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    cx.tile.skew = cfg.skew;
    const LdsLayout L = lds_layout(cfg, true);
    cx.tile.bits = smem + L.bits;
-   cx.tile.bstride = (cfg.tile_rows + kScreenHalo) / 8;
-   cx.tile.ldpos = smem + L.ldpos;
+   cx.tile.bstride = (cfg.tile_rows + kScreenHalo) / 8 + 8;
+   cx.tile.ldpos = smem + L.ldpos; cx.tile.ldstride = cfg.tile_rows + kScreenHalo;
    float *heights_all = reinterpret_cast<float *>(smem + L.heights);
    // walker w of this workgroup -> thread: spread over the 4 waves so every SIMD issues for some walkers
    const int nwalk = cfg.nparm * ntrks;
@@ -1146,7 +1244,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    cx.heights = heights_all + (size_t)(is_walker ? my_w : 0) * 10;
    Rec *recs_all = reinterpret_cast<Rec *>(smem + L.recs);
    int *nrec_all = reinterpret_cast<int *>(smem + L.nrec);
-   Cand *runs_all = reinterpret_cast<Cand *>(smem + L.runs);             // [nscreens*ntrks][run_cap], over the sample tile
+   CandUnit *runs_all = reinterpret_cast<CandUnit *>(smem + L.runs);     // the tile's lists, packed (lds_units), over the sample tile
    Walker *walkers = reinterpret_cast<Walker *>(smem + L.walkers);       // [nwalk]
    Walker *walkers_next = reinterpret_cast<Walker *>(smem + L.walkers_next);  // [nwalk] result of an optimistic tile, committed only if all lanes agree
    float *heights_bak = reinterpret_cast<float *>(smem + L.heights_bak);     // [nwalk][10]
@@ -1221,14 +1319,18 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
             __syncthreads();
             long long o1 = 0, o2 = 0, o3 = 0;
             if (cfg.debug) o1 = clock64();
-            bool avail = true;
-            for (int st = 0; st < nst; ++st) if (s_dir[st].count == 0xFFFF) avail = false;
+            if (threadIdx.x <= nst) {                                  // where each list goes in LDS (packed)
+               int o = 0; bool bad = false;
+               for (int st = 0; st < (int)threadIdx.x; ++st) { if (s_dir[st].count == 0xFFFF) bad = true; o += s_dir[st].count; }
+               s_off[threadIdx.x] = bad ? (1 << 30) : o; }
+            __syncthreads();
+            const bool avail = s_off[nst] <= cfg.lds_units;
             if (avail) {
-               const int4 *src = reinterpret_cast<const int4 *>(pool + (size_t)g * nst * cfg.run_cap);
+               const int4 *src = reinterpret_cast<const int4 *>(pool) + (size_t)g * nst * cfg.run_cap;
                for (int st = 0; st < nst; ++st) {
-                  const int n2 = 2 * (int)s_dir[st].count;
+                  const int n2 = (int)s_dir[st].count;
                   for (int i = threadIdx.x; i < n2; i += blockDim.x)
-                     reinterpret_cast<int4 *>(runs_all + (size_t)st * cfg.run_cap)[i] = src[(size_t)st * cfg.run_cap * 2 + i]; }
+                     reinterpret_cast<int4 *>(runs_all)[s_off[st] + i] = src[(size_t)st * cfg.run_cap + i]; }
                __syncthreads();
                if (cfg.debug) o2 = clock64();
                cx.nrec = 0;
@@ -1237,7 +1339,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                   Walker w = walkers[my_w];
                   for (int i = 0; i < 10; ++i) heights_bak[my_w * 10 + i] = cx.heights[i];     // part of the walker's state
                   int why = 0;
-                  if (walk_records(w, cx, pidx, trk, stop, runs_all + (size_t)st * cfg.run_cap, s_dir[st].count, s_dir[st], why))
+                  if (walk_records(w, cx, pidx, trk, stop, runs_all + s_off[st], s_dir[st].count, s_dir[st], why))
                      walkers_next[my_w] = w;
                   else { atomicOr((unsigned int *)&s_needfull, 1u); if (cfg.debug) atomicAdd(&scratch->why[why & 7], 1ull); } }
                if (is_walker) nrec_all[my_w] = cx.nrec;

@@ -77,10 +77,19 @@ inline int __shfl_up(int v, unsigned delta) {
    const int r = l >= delta ? (int)(unsigned)hipemu::g_wave_scratch[w][l - delta] : v;
    hipemu::g_wave_barrier[w].wait();
    return r; }
+inline int __shfl(int v, int src) {
+   const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
+   hipemu::g_wave_scratch[w][l] = (unsigned long long)(unsigned)v;
+   hipemu::g_wave_barrier[w].wait();
+   const int r = (int)(unsigned)hipemu::g_wave_scratch[w][src & 63];
+   hipemu::g_wave_barrier[w].wait();
+   return r; }
 inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 inline unsigned int __float_as_uint(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __popc(unsigned int v) { return __builtin_popcount(v); }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

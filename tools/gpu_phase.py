@@ -25,4 +25,4 @@ no = max(int(dbg[7]), 1)
 lens = (r.bursts["end_sample"] - r.bursts["reset_sample"])
 print(json.dumps({"rows": int(rows.shape[0]), "kernel_ms": ms, "bursts": int(r.nbursts), "burst_len_max": int(lens.max()), "burst_len_mean": float(lens.mean()),
                   "tiles": int(dbg[3]), "cyc_per_tile": {"load": float(dbg[0]) / max(int(dbg[3]), 1), "screen": float(dbg[1]) / max(int(dbg[3]), 1), "walk": float(dbg[2]) / max(int(dbg[3]), 1), "walk_build": float(dbg[4]) / max(int(dbg[3]), 1), "walk_chain": float(dbg[5]) / max(int(dbg[3]), 1), "walk_final": float(dbg[6]) / max(int(dbg[3]), 1)},
-                  "events": int(r.counts.sum()), "optimistic_tiles": int(dbg[7]), "opt_cyc": {"dir": float(d2[0]) / no, "unpack": float(d2[1]) / no, "walk": float(d2[2]) / no, "final": float(d2[3]) / no}, "why(0?,1 notfast,2 k>=4,3 top!fast,4 bot!fast,5 guard,6 misc,7 chain)": [int(x) for x in why], "screen_cyc_per_tile(load,screen,build,write)": [float(scr[i]) / max(int(scr[4]), 1) for i in range(4)], "screen_tiles": int(scr[4])}))
+                  "events": int(r.counts.sum()), "optimistic_tiles": int(dbg[7]), "opt_cyc": {"dir": float(d2[0]) / no, "unpack": float(d2[1]) / no, "walk": float(d2[2]) / no, "final": float(d2[3]) / no}, "why(0?,1 notfast,2 k>=4,3 top!fast,4 bot!fast,5 guard,6 misc,7 chain)": [int(x) for x in why], "screen_cyc_per_tile(load,screen,build,write)": [float(scr[i]) / max(int(scr[4]), 1) for i in range(4)], "screen_chain_starts": [float(scr[5]) / max(int(scr[4]), 1), float(scr[6]) / max(int(scr[4]), 1)], "screen_tiles": int(scr[4])}))
