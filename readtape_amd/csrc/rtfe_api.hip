@@ -33,8 +33,9 @@ struct rtfe_handle {
    int lds_bytes;
    int num_cus;
    int timing;
-   hipEvent_t ev[5];
+   hipEvent_t ev[7];
    int screen_lds_bytes;
+   int walk_lds_bytes;
 };
 
 static thread_local char g_err[512] = "";
@@ -45,9 +46,11 @@ static int fail(int code, const char *fmt, ...) {
 extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
-static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_screen", "k_decode"};
-extern "C" int rtfe_kernel_count(void) { return 4; }
-extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < 4) ? KNAMES[i] : ""; }
+// the kernels of one rtfe_scan, in launch order (k_decode runs twice: burst heads, then whatever k_walk gave back)
+static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_screen", "k_decode_head", "k_walk", "k_decode_resume"};
+constexpr int kNumKernels = 6;
+extern "C" int rtfe_kernel_count(void) { return kNumKernels; }
+extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < kNumKernels) ? KNAMES[i] : ""; }
 
 extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (!c || !out) return fail(-1, "null argument");
@@ -146,10 +149,12 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       d.run_cap = d.tile_rows / 2 < 64 ? 64 : d.tile_rows / 2;
       // LDS of the sequential pass: room for a typical tile's lists (a quarter of the worst case, at most 24 KiB);
       // a tile with more candidates than that is decided from its samples instead
-      int lu = d.nscreens * c->ntrks * d.run_cap / 4;
+      int lu = d.nscreens * c->ntrks * d.run_cap / 2;
       if (lu > 1536) lu = 1536;
       if (lu < 256) lu = 256;
-      d.lds_units = lu; }
+      d.lds_units = lu;
+      int r16 = (12 * 1024) / (nwalk * 16);
+      d.rec_cap16 = r16 > 64 ? 64 : (r16 < 8 ? 8 : r16); }
    h->lds_bytes = (int)lds_layout(d, true).total + 64;
    h->screen_lds_bytes = (int)lds_layout(d, false).total + 64;
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
@@ -161,25 +166,27 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (hipMemcpy(h->d_dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->d_dev); delete h; return fail(-22, "hipMemcpy failed"); }
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen), hipFuncAttributeMaxDynamicSharedMemorySize, h->screen_lds_bytes);
+   h->walk_lds_bytes = (int)lds_layout_walk(d).total + 64;
+   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, h->walk_lds_bytes);
    *out = h;
    return 0; }
 
 extern "C" int rtfe_set_timing(rtfe_handle *h, int enable) {
    if (!h) return fail(-1, "null argument");
-   if (enable && !h->timing) for (int i = 0; i < 5; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
-   if (!enable && h->timing) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(h->ev[i]);
+   if (enable && !h->timing) for (int i = 0; i <= kNumKernels; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
+   if (!enable && h->timing) for (int i = 0; i <= kNumKernels; ++i) (void)hipEventDestroy(h->ev[i]);
    h->timing = enable != 0;
    return 0; }
 
 extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
    if (!h || !out || !h->timing) return fail(-41, "timing is not enabled");
-   if (hipEventSynchronize(h->ev[4]) != hipSuccess) return fail(-42, "hipEventSynchronize failed");
-   for (int i = 0; i < 4; ++i) if (hipEventElapsedTime(&out[i], h->ev[i], h->ev[i + 1]) != hipSuccess) return fail(-43, "hipEventElapsedTime failed");
+   if (hipEventSynchronize(h->ev[kNumKernels]) != hipSuccess) return fail(-42, "hipEventSynchronize failed");
+   for (int i = 0; i < kNumKernels; ++i) if (hipEventElapsedTime(&out[i], h->ev[i], h->ev[i + 1]) != hipSuccess) return fail(-43, "hipEventElapsedTime failed");
    return 0; }
 
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
-   if (h->timing) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(h->ev[i]);
+   if (h->timing) for (int i = 0; i <= kNumKernels; ++i) (void)hipEventDestroy(h->ev[i]);
    (void)hipFree(h->d_dev);
    delete h; }
 
@@ -198,11 +205,17 @@ static size_t ws_dir_off(const rtfe_handle *h, int64_t nrows) { return (kScratch
 static size_t ws_pool_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_dir_off(h, nrows) + (size_t)ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(TileDir) + 255) & ~(size_t)255; }
 
-extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pool_off(h, nrows) + (size_t)pool_cap_for(h, nrows) * sizeof(CandUnit) + 256; }
-
 extern "C" int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows) {
    return (nrows * h->dev.ntrks / 512) / h->dev.gap_chunks + 4; }
+
+// ... | burst control blocks | walker states (hand-over between k_decode and k_walk)
+static size_t ws_ctl_off(const rtfe_handle *h, int64_t nrows) {
+   return (ws_pool_off(h, nrows) + (size_t)pool_cap_for(h, nrows) * sizeof(CandUnit) + 255) & ~(size_t)255; }
+static size_t ws_state_off(const rtfe_handle *h, int64_t nrows) {
+   return (ws_ctl_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * sizeof(BurstCtl) + 255) & ~(size_t)255; }
+
+extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
+   return ws_state_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -234,7 +247,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (h->timing) (void)hipEventRecord(h->ev[1], st);
    hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
-                      d_bursts, (long long)max_bursts, scratch, d_nbursts);
+                      d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts);
    if (h->timing) (void)hipEventRecord(h->ev[2], st);
    TileDir *dirp = reinterpret_cast<TileDir *>(reinterpret_cast<char *>(d_workspace) + ws_dir_off(h, nrows));
    CandUnit *poolp = reinterpret_cast<CandUnit *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
@@ -250,7 +263,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                          ntiles, scratch->scr); }
    if (h->timing) (void)hipEventRecord(h->ev[3], st);
    // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
-   // beat wide ones; k_decode holds ~180 VGPRs => 2 waves/SIMD => 8 waves per CU
+   // beat wide ones; k_decode holds ~250 VGPRs => 2 waves/SIMD => 8 waves per CU
    const int nwalk = h->dev.nparm * h->dev.ntrks;
    const int threads = nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256);
    int per_cu = (160 * 1024) / (h->lds_bytes + 1024);
@@ -258,10 +271,30 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (per_cu > wave_lim) per_cu = wave_lim;
    if (per_cu < 1) per_cu = 1;
    const int dgrid = h->num_cus * per_cu;
-   hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
-                      (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
-                      use_screen ? (const TileDir *)dirp : (const TileDir *)nullptr, (const CandUnit *)poolp);
-   if (h->timing) (void)hipEventRecord(h->ev[4], st);
+   BurstCtl *ctlp = reinterpret_cast<BurstCtl *>(reinterpret_cast<char *>(d_workspace) + ws_ctl_off(h, nrows));
+   WalkState *statep = reinterpret_cast<WalkState *>(reinterpret_cast<char *>(d_workspace) + ws_state_off(h, nrows));
+   if (!use_screen) {                                                 // -zeros: the whole burst in one pass over the samples
+      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
+                         (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeAll, ctlp, statep);
+      if (h->timing) for (int i = 4; i <= kNumKernels; ++i) (void)hipEventRecord(h->ev[i], st); }
+   else {
+      // burst heads from the samples (start-up path) -> the record walk -> whatever the records could not decide
+      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
+                         (const TileDir *)dirp, (const CandUnit *)poolp, (int)kDecodeHead, ctlp, statep);
+      if (h->timing) (void)hipEventRecord(h->ev[4], st);
+      int wpc = (160 * 1024) / (h->walk_lds_bytes + 1024);
+      const int wlim = 16 / (threads / 64);
+      if (wpc > wlim) wpc = wlim;
+      if (wpc < 1) wpc = 1;
+      hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(threads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
+                         d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep);
+      if (h->timing) (void)hipEventRecord(h->ev[5], st);
+      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
+                         (const TileDir *)dirp, (const CandUnit *)poolp, (int)kDecodeResume, ctlp, statep);
+      if (h->timing) (void)hipEventRecord(h->ev[6], st); }
    return launch_check("rtfe_scan"); }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,
@@ -282,5 +315,5 @@ extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nr
    const int nwalk = h->dev.nparm * h->dev.ntrks;
    hipLaunchKernelGGL(k_decode, dim3(1), dim3(nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256)), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                       (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1,
-                      (const TileDir *)nullptr, (const CandUnit *)nullptr);
+                      (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeAll, (BurstCtl *)nullptr, (WalkState *)nullptr);
    return launch_check("rtfe_scan_exact"); }

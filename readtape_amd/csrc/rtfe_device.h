@@ -50,6 +50,7 @@ struct DevCfg {
    float lsb_per_volt;            // 32767 / maxvolts, for the walkers' integer guard bands
    int   run_cap;                 // candidate-run records per (screen, track) per tile (LDS)
    int   rec_cap;                 // deferred-event records per walker per tile (LDS)
+   int   rec_cap16;               // deferred detections per walker per tile of k_walk (LDS)
    int   lds_units;               // candidate units of ONE tile (all lists, packed) that fit the LDS of the sequential pass
    int   debug;                   // RTFE_DEBUG=1: per-phase cycle counters in the workspace (tools/ only)
    DevParm   parm[RTFE_MAXPARMSETS];
@@ -80,6 +81,7 @@ struct TileDir {               // per (tile, screen, track): 8 bytes
 };
 // ---- burst hand-over between the kernels of one scan (workspace) ----
 enum { kBurstNew = 0, kBurstNeedsFull = 1, kBurstReady = 2, kBurstDone = 3 };
+enum { kDecodeAll = 0, kDecodeHead = 1, kDecodeResume = 2 };
 struct BurstCtl {              // 32 bytes per burst
    long long reset, stop;      // restart row / first row of the next burst's span
    int       next_tile;        // tile of the tape-global grid to continue with

@@ -75,7 +75,9 @@ struct BurstScratch {            // lives in the workspace (first kScratchBytes 
    int   nbursts;                // bursts to decode (owned by this scan)
    int   queue;                  // next burst to decode
    int   nbursts_total;          // owned bursts + (time shards) the first burst of the halo, which only bounds the last owned one
-   int   pad[13];
+   int   queue_walk;             // ... of k_walk
+   int   queue_resume;           // ... of the second k_decode pass
+   int   pad[11];
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
    unsigned long long pool_cursor;   // at byte 128: next free PackedRun of the pool (k_screen)
    unsigned long long dbg2[8];   // dbg[8..15] (contiguous with dbg through pool_cursor is NOT assumed: indexed separately)
@@ -210,7 +212,7 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
       if (threadIdx.x == 0) s_ebase += (u64)total << 6;
       __syncthreads(); }
    if (threadIdx.x == 0) {
-      scratch->nbursts = n_owned; scratch->nbursts_total = nb; scratch->queue = 0; *nbursts_out = n_owned;
+      scratch->nbursts = n_owned; scratch->nbursts_total = nb; scratch->queue = 0; scratch->queue_walk = 0; scratch->queue_resume = 0; *nbursts_out = n_owned;
       if (n_owned == nb && own_rows < nrows && n_owned > 0) bursts[n_owned - 1].flags |= RTFE_F_TRUNCATED; }
    if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0;
    if (threadIdx.x == 8) scratch->pool_cursor = 0;
@@ -284,9 +286,15 @@ struct Walker {            // one per (parameter set, track); lives in registers
    unsigned int flags;
 };
 
+// what a burst's walkers are between the kernels of one scan (workspace, one per (burst, walker))
+struct WalkState { Walker w; float heights[10]; };
+
 // A detection whose (cheap-to-defer) half-sample refinement, volt conversion and event store are done
 // after the walk by all lanes (finalize_tile): the sequential walker keeps only what feeds back.
 struct alignas(8) Rec { unsigned int idx; unsigned short n_rel; unsigned char ld, kind; float g; short val, prev, next, pad; int pad2; };   // 24 bytes
+
+// the record walk's deferred detections: 16 bytes, event index = (walker's event count at the tile's start) + position
+struct alignas(8) Rec16 { unsigned short n_rel; unsigned char ld, kind; float g; short val, prev, next, pad; };
 
 struct Ctx {               // per-workgroup constants for the walkers
    const DevCfg *cfg;
@@ -297,6 +305,7 @@ struct Ctx {               // per-workgroup constants for the walkers
    unsigned int cap;
    struct Rec *recs;       // LDS [rec_cap] deferred events of this lane's walker for the current tile
    int     rec_cap;
+   int     rec_cap16;      // ... in Rec16 units (the same LDS space)
    int     nrec;           // records queued in this tile
 };
 
@@ -468,6 +477,26 @@ __device__ __forceinline__ void finalize_records(const Ctx &cx, const Rec *recs,
       const bool is_top = r.kind == 0;
       const int adjcode = refine_code(cfg, r.val, r.prev, r.next, r.g, is_top);
       store_event(cx, pidx, trk, r.idx, cx.tile.row0 + r.n_rel, volt(r.val, cfg->maxvolts), r.g, is_top, adjcode, r.ld); } }
+
+// all lanes: the record walk's queued detections of ALL walkers of one tile -> events.  off[w] = first record of walker w
+// in the flattened numbering (off[nwalk] = total), idx0[w] = its event count at the tile's start.
+__device__ __forceinline__ void finalize_records16(const Ctx &cx, const unsigned char *recs_all, int stride_bytes, const int *off, const int *idx0,
+                                                   int nwalk, int lane, int nlanes) {
+   const DevCfg *cfg = cx.cfg;
+   const int total = off[nwalk];
+   for (int i = lane; i < total; i += nlanes) {
+      int w2 = 0;
+      while (off[w2 + 1] <= i) ++w2;
+      const int k = i - off[w2];
+      const unsigned long long *src = reinterpret_cast<const unsigned long long *>(recs_all + (size_t)w2 * stride_bytes) + 2 * k;
+      const unsigned long long r0 = src[0], r1 = src[1];
+      const int n_rel = (int)(r0 & 0xffff), ld = (int)((r0 >> 16) & 0xff);
+      const bool is_top = ((r0 >> 24) & 0xff) == 0;
+      const float g = __uint_as_float((unsigned)(r0 >> 32));
+      const int val = (int)(short)(r1 & 0xffff), prev = (int)(short)((r1 >> 16) & 0xffff), next = (int)(short)((r1 >> 32) & 0xffff);
+      const int pidx = w2 / cfg->ntrks, trk = w2 - pidx * cfg->ntrks;
+      const int adjcode = refine_code(cfg, val, prev, next, g, is_top);
+      store_event(cx, pidx, trk, (unsigned)(idx0[w2] + k), cx.tile.row0 + n_rel, volt(val, cfg->maxvolts), g, is_top, adjcode, ld); } }
 
 // exact window minimum and its first position (the rescan of src/decoder.c:767-775)
 __device__ __forceinline__ void rescan_min(const Tile &tl, int trk, long long lo, long long hi, int &mn, long long &pos) {
@@ -988,71 +1017,81 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
    const bool pe = cfg->mode == RTFE_PE;
    const int4 *units = reinterpret_cast<const int4 *>(recs);
    int i = 0;
+   // Two-phase rounds keep the walker lanes of a wave together: (A) every lane scans its runs up to its next detection
+   // (a few integer compares per row), (B) the lanes that found one do the detection bookkeeping side by side.
    #pragma nounroll
-   while (i < nrecs) {
-      const int4 A = units[i];                                     // run header
-      const int n_s = A.x & 0xffff, nr = (A.x >> 16) & 0xff;
-      const int ibase = i + 1;                                     // first margin unit of this run
-      i += 1 + ((nr + 2) >> 2);
-      if (n_s >= lim) break;
-      int k = cur > n_s ? cur - n_s : 0;                            // rows inside the countdown of the last detection are skipped
-      if (k >= nr) continue;
-      const int ld0 = (A.y >> 16) & 0xff;
-      const bool is_top = ((A.x >> 24) & 1) == 0;
-      const int m = (int)(short)(A.y & 0xffff);
-      if (ld0 == 0) { why = 4; return false; }
-      if (w.reqmin != 0) {                                         // min_peak test: the same for every row of the run
-         const int a = is_top ? m : -m;
-         if (a <= w.min_lo) continue;
-         if (a < w.min_hi) {
-            if (w.thr_dirty) update_thresholds(w, P, lsb);
-            if (!(is_top ? volt(m, mv) > w.reqmin : volt(m, mv) < -w.reqmin)) continue; } }
-      int hit = -1;
-      int4 M = make_int4(0, 0, 0, 0);
-      int mu = -1;
+   for (;;) {
+      int hit_n = -1, hit_ld = 0, hit_m = 0, hit_z = 0;
+      bool hit_top = false, fail = false;
       #pragma nounroll
-      for (; k < nr && n_s + k < lim; ++k) {
-         int pr;
-         if (k == 0) pr = A.w;
+      while (i < nrecs) {                                           // (A)
+         const int4 A = units[i];                                   // run header
+         const int n_s = A.x & 0xffff, nr = (A.x >> 16) & 0xff;
+         const int ibase = i + 1;                                   // first margin unit of this run
+         i += 1 + ((nr + 2) >> 2);
+         if (n_s >= lim) { i = nrecs; break; }
+         int k = cur > n_s ? cur - n_s : 0;                          // rows inside the countdown of the last detection are skipped
+         if (k >= nr) continue;
+         const int ld0 = (A.y >> 16) & 0xff;
+         const bool is_top = ((A.x >> 24) & 1) == 0;
+         const int m = (int)(short)(A.y & 0xffff);
+         if (ld0 == 0) { why = 4; fail = true; break; }
+         if (w.reqmin != 0) {                                       // min_peak test: the same for every row of the run
+            const int a = is_top ? m : -m;
+            if (a <= w.min_lo) continue;
+            if (a < w.min_hi) {
+               if (w.thr_dirty) update_thresholds(w, P, lsb);
+               if (!(is_top ? volt(m, mv) > w.reqmin : volt(m, mv) < -w.reqmin)) continue; } }
+         int hit = -1;
+         int4 M = make_int4(0, 0, 0, 0);
+         int mu = -1;
+         #pragma nounroll
+         for (; k < nr && n_s + k < lim; ++k) {
+            int pr;
+            if (k == 0) pr = A.w;
+            else {
+               const int u = (k - 1) >> 2, c = (k - 1) & 3;
+               if (u != mu) { M = units[ibase + u]; mu = u; }
+               pr = c == 0 ? M.x : (c == 1 ? M.y : (c == 2 ? M.z : M.w)); }
+            const int dl = pr & 0xffff, dr = (int)((unsigned)pr >> 16);
+            const int mg = min(dl, dr);
+            if (mg <= w.rise_lo) continue;                          // fails for sure
+            if (mg < w.rise_hi) {                                   // guard band: the reference's own comparison
+               if (w.thr_dirty) update_thresholds(w, P, lsb);
+               const float vm = volt(m, mv);
+               const float vl = volt(is_top ? m - dl : m + dl, mv), vr = volt(is_top ? m - dr : m + dr, mv);
+               if (!(is_top ? (vm > vl + w.rise && vm > vr + w.rise) : (vm < vl - w.rise && vm < vr - w.rise))) continue; }
+            hit = k; break; }
+         if (hit < 0) continue;
+         hit_n = n_s + hit; hit_ld = ld0 - hit; hit_m = m; hit_z = A.z; hit_top = is_top;
+         break; }
+      if (fail) return false;
+      if (hit_n < 0) break;
+      {                                                             // (B) a detection at row hit_n: the bookkeeping of emit_peak
+         const int n = hit_n, ld = hit_ld, m = hit_m;
+         const bool is_top = hit_top;
+         const float v = volt(m, mv);
+         double t_peak = 0;
+         if (pe && !w.datablock && w.peakcount >= 68) {            // the end of the PE preamble is decided on peak times
+            const int adjcode = refine_code(cfg, m, (int)(short)(hit_z & 0xffff), hit_z >> 16, w.agc_gain, is_top);
+            const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
+            t_peak = time_of(cfg, cx.row_base + tl.row0 + n) - ((float)(W - ld) - adj) * cfg->sample_deltat; }
+         if (w.nevents >= cx.cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
          else {
-            const int u = (k - 1) >> 2, c = (k - 1) & 3;
-            if (u != mu) { M = units[ibase + u]; mu = u; }
-            pr = c == 0 ? M.x : (c == 1 ? M.y : (c == 2 ? M.z : M.w)); }
-         const int dl = pr & 0xffff, dr = (int)((unsigned)pr >> 16);
-         const int mg = min(dl, dr);
-         if (mg <= w.rise_lo) continue;                             // fails for sure
-         if (mg < w.rise_hi) {                                      // guard band: the reference's own comparison
-            if (w.thr_dirty) update_thresholds(w, P, lsb);
-            const float vm = volt(m, mv);
-            const float vl = volt(is_top ? m - dl : m + dl, mv), vr = volt(is_top ? m - dr : m + dr, mv);
-            if (!(is_top ? (vm > vl + w.rise && vm > vr + w.rise) : (vm < vl - w.rise && vm < vr - w.rise))) continue; }
-         hit = k; break; }
-      if (hit < 0) continue;
-      // ---- a detection at row n (the bookkeeping of emit_peak) ----
-      const int n = n_s + hit, ld = ld0 - hit;
-      const float v = volt(m, mv);
-      double t_peak = 0;
-      if (pe && !w.datablock && w.peakcount >= 68) {               // the end of the PE preamble is decided on peak times
-         const int adjcode = refine_code(cfg, m, (int)(short)(A.z & 0xffff), A.z >> 16, w.agc_gain, is_top);
-         const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
-         t_peak = time_of(cfg, cx.row_base + tl.row0 + n) - ((float)(W - ld) - adj) * cfg->sample_deltat; }
-      if (w.nevents >= cx.cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
-      else {
-         if (cx.nrec >= cx.rec_cap) { why = 6; return false; }
-         // Rec as three 8-byte LDS stores: {idx, n_rel|ld|kind} {g, val|prev} {next, -}
-         unsigned long long *dst = reinterpret_cast<unsigned long long *>(&cx.recs[cx.nrec++]);
-         const unsigned int w1 = (unsigned)n | ((unsigned)ld << 16) | ((unsigned)(is_top ? 0 : 1) << 24);
-         const unsigned int w3 = (unsigned)(m & 0xffff) | ((unsigned)A.z << 16);            // val | prev
-         const unsigned int w4 = ((unsigned)A.z >> 16);                                       // next
-         dst[0] = (unsigned long long)w.nevents | ((unsigned long long)w1 << 32);
-         dst[1] = (unsigned long long)__float_as_uint(w.agc_gain) | ((unsigned long long)w3 << 32);
-         dst[2] = (unsigned long long)w4; }
-      if (is_top) w.v_top = v; else w.v_bot = v;
-      ++w.nevents;
-      agc_after_peak(w, cfg, P, cx.heights, is_top, t_peak);
-      if (!approx_thresholds(w, P, lsb)) update_thresholds(w, P, lsb);
-      w.blind_until = tl.row0 + n + ld;                            // pkww_countdown = left_distance (src/decoder.c:741)
-      cur = n + ld + 1; }
+            if (cx.nrec >= cx.rec_cap16) { why = 6; return false; }
+            // Rec16 as two 8-byte LDS stores: {n_rel|ld|kind, g} {val|prev, next}
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(reinterpret_cast<Rec16 *>(cx.recs) + cx.nrec++);
+            const unsigned int w1 = (unsigned)n | ((unsigned)ld << 16) | ((unsigned)(is_top ? 0 : 1) << 24);
+            const unsigned int w3 = (unsigned)(m & 0xffff) | ((unsigned)hit_z << 16);        // val | prev
+            const unsigned int w4 = ((unsigned)hit_z >> 16);                                   // next
+            dst[0] = (unsigned long long)w1 | ((unsigned long long)__float_as_uint(w.agc_gain) << 32);
+            dst[1] = (unsigned long long)w3 | ((unsigned long long)w4 << 32); }
+         if (is_top) w.v_top = v; else w.v_bot = v;
+         ++w.nevents;
+         agc_after_peak(w, cfg, P, cx.heights, is_top, t_peak);
+         if (!approx_thresholds(w, P, lsb)) update_thresholds(w, P, lsb);
+         w.blind_until = tl.row0 + n + ld;                         // pkww_countdown = left_distance (src/decoder.c:741)
+         cur = n + ld + 1; } }
    n64 = tl.row0 + lim;
    w.next = n64 < limit ? n64 : limit;
    if (whole) {                                                     // the minimum's state after the tile's last row, from k_screen
@@ -1087,6 +1126,20 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    L.walkers = off;   if (decode) off = lds_align16(off + nwalk * (unsigned)sizeof(Walker));
    L.walkers_next = off; if (decode) off = lds_align16(off + nwalk * (unsigned)sizeof(Walker));
    L.heights_bak = off;  if (decode) off = lds_align16(off + nwalk * 10u * 4u);
+   L.total = off;
+   return L; }
+
+struct WalkLds { unsigned units, heights, heights_bak, recs, nrec, idx0, total; };
+__host__ __device__ inline WalkLds lds_layout_walk(const DevCfg &c) {
+   WalkLds L;
+   const unsigned nwalk = (unsigned)(c.nparm * c.ntrks);
+   unsigned off = 0;
+   L.units = off;        off = lds_align16(off + (unsigned)c.lds_units * (unsigned)sizeof(CandUnit));
+   L.heights = off;      off = lds_align16(off + nwalk * 10u * 4u);
+   L.heights_bak = off;  off = lds_align16(off + nwalk * 10u * 4u);
+   L.recs = off;         off = lds_align16(off + nwalk * (unsigned)c.rec_cap16 * (unsigned)sizeof(Rec16));
+   L.nrec = off;         off = lds_align16(off + (nwalk + 1) * 4u);
+   L.idx0 = off;         off = lds_align16(off + nwalk * 4u);
    L.total = off;
    return L; }
 
@@ -1169,20 +1222,22 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
       __syncthreads();
       if (cfg.debug) k3 = clock64();
       if (cfg.debug & 32) continue;
-      const bool tab_ok = s_nruns <= tabcap;
+      int tile_units = 0;
+      for (int s2 = 0; s2 < nst; ++s2) tile_units += s_total[s2];
+      const bool tab_ok = s_nruns <= tabcap && tile_units <= nst * cfg.run_cap;
       if (tab_ok)
          for (int r = threadIdx.x; r < s_nruns; r += blockDim.x) {
             const u64 d = runtab[r];
             const int st = (int)(d & 0xff), kind = (int)((d >> 8) & 1), n = (int)((d >> 16) & 0xffff), nr = (int)((d >> 32) & 0xff), rel = (int)(d >> 40);
             const int sc = st / ntrks;
-            const int off = stripcnt[st * smax + (n >> 3)] + rel;
-            if (s_total[st] <= cfg.run_cap)
-               build_run(tl, &cfg, sc, st - sc * ntrks, cfg.screen[sc].W, n, kind, nr,
-                         reinterpret_cast<int4 *>(pool) + ((size_t)g * nst + st) * cfg.run_cap + off); }
+            int off = stripcnt[st * smax + (n >> 3)] + rel;
+            for (int s2 = 0; s2 < st; ++s2) off += s_total[s2];     // the tile's lists are packed one behind the other
+            build_run(tl, &cfg, sc, st - sc * ntrks, cfg.screen[sc].W, n, kind, nr,
+                      reinterpret_cast<int4 *>(pool) + (size_t)g * nst * cfg.run_cap + off); }
       if (threadIdx.x < nst) {
          const int st = threadIdx.x, sc = st / ntrks, trk = st - sc * ntrks;
          TileDir d;
-         d.count = (!tab_ok || s_total[st] > cfg.run_cap) ? (uint16_t)0xFFFF : (uint16_t)s_total[st];
+         d.count = (!tab_ok || s_total[st] >= 0xFFFF) ? (uint16_t)0xFFFF : (uint16_t)s_total[st];
          const int last = tl.nrows - 1;
          const int eld = stale_ld(tl.map(sc, 2, trk), tl.ldmap(sc, 1, trk), last);
          d.end_ld = (uint8_t)eld; d.pad = 0; d.pad2 = 0;
@@ -1196,12 +1251,178 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
             atomicAdd(&scr[2], (unsigned long long)(k3 - k2)); atomicAdd(&scr[3], (unsigned long long)(k4 - k3)); atomicAdd(&scr[4], 1ull);
             atomicAdd(&scr[5], (unsigned long long)(k2a - k2)); atomicAdd(&scr[6], (unsigned long long)(k2b - k2a)); } } } }
 
+// ------------------------------------------------------------------------------------------------
+// k_walk: the sequential pass in the common case.  One small workgroup per burst (a lane per (parameter set, track)),
+// tile after tile of the tape-global grid: the tile's candidate runs HBM -> LDS, walk_records(), events.  No samples,
+// little LDS, few registers: many bursts resident per CU.  A tile the records cannot decide hands the burst (state
+// as of that tile's start) to the second k_decode pass.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_walk_fields(Walker &w, const Walker &s) {
+   w.fast = s.fast; w.trust_from = s.trust_from; w.next = s.next; w.blind_until = s.blind_until;
+   w.agc_gain = s.agc_gain; w.v_avg_height = s.v_avg_height; w.v_avg_height_sum = s.v_avg_height_sum;
+   w.v_avg_height_count = s.v_avg_height_count; w.peakcount = s.peakcount; w.heightndx = s.heightndx;
+   w.v_top = s.v_top; w.v_bot = s.v_bot; w.v_lasttop = s.v_lasttop; w.v_lastbot = s.v_lastbot;
+   w.datablock = s.datablock; w.bit1_up = s.bit1_up; w.t_lastpeak = s.t_lastpeak;
+   w.rise = s.rise; w.reqmin = s.reqmin; w.thr_dirty = s.thr_dirty;
+   w.rise_lo = s.rise_lo; w.rise_hi = s.rise_hi; w.min_lo = s.min_lo; w.min_hi = s.min_hi;
+   w.minv = s.minv; w.qtrig = s.qtrig; w.cpos = s.cpos; w.chain_pending = s.chain_pending;
+   w.nevents = s.nevents; w.flags = s.flags; }
+
+__global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restrict__ cfgp, long long nrows, long long row_base,
+                                                       rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
+                                                       uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
+                                                       const TileDir *__restrict__ dir, const CandUnit *__restrict__ pool,
+                                                       BurstCtl *__restrict__ ctl, WalkState *__restrict__ wstate) {
+#ifdef RTFE_CPU_EMUL
+   unsigned char *smem = g_dyn_smem;            // tests/cpu_emul only
+#else
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
+   __shared__ DevCfg cfg;
+   __shared__ int s_burst;
+   __shared__ unsigned int s_flags;
+   __shared__ int s_needfull;
+   __shared__ TileDir s_dir[kMaxScreens * RTFE_MAXTRKS];
+   __shared__ int s_off[kMaxScreens * RTFE_MAXTRKS + 1];
+   for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
+   __syncthreads();
+   const int ntrks = cfg.ntrks, nst = cfg.nscreens * ntrks, nwalk = cfg.nparm * ntrks;
+   const WalkLds L = lds_layout_walk(cfg);
+   int4 *units = reinterpret_cast<int4 *>(smem + L.units);
+   float *heights_all = reinterpret_cast<float *>(smem + L.heights), *heights_bak = reinterpret_cast<float *>(smem + L.heights_bak);
+   unsigned char *recs_all = smem + L.recs;                          // [nwalk][rec_cap16] Rec16
+   int *nrec_all = reinterpret_cast<int *>(smem + L.nrec);          // [nwalk + 1] -> exclusive scan
+   int *idx0_all = reinterpret_cast<int *>(smem + L.idx0);          // [nwalk]
+   const int rstride = cfg.rec_cap16 * (int)sizeof(Rec16);
+   const int nwaves = blockDim.x >> 6;
+   const int my_w = (threadIdx.x & 63) * nwaves + (threadIdx.x >> 6);
+   const bool is_walker = my_w < nwalk;
+   const int pidx = is_walker ? my_w / ntrks : 0, trk = is_walker ? my_w - pidx * ntrks : 0;
+   Ctx cx;
+   cx.cfg = &cfg;
+   cx.row_base = row_base;
+   cx.tile.x = nullptr; cx.tile.ldw = 0; cx.tile.ntrks = ntrks; cx.tile.skew = cfg.skew;
+   cx.tile.bits = nullptr; cx.tile.bstride = 0; cx.tile.ldpos = nullptr; cx.tile.ldstride = 0;
+   cx.heights = heights_all + (size_t)(is_walker ? my_w : 0) * 10;
+   cx.rec_cap = 0; cx.rec_cap16 = cfg.rec_cap16;
+   cx.recs = reinterpret_cast<Rec *>(recs_all + (size_t)(is_walker ? my_w : 0) * rstride);
+   const long long T = cfg.tile_rows;
+   for (;;) {
+      if (threadIdx.x == 0) { s_burst = atomicAdd(&scratch->queue_walk, 1); s_flags = 0; }
+      __syncthreads();
+      const int b = s_burst;
+      if (b >= scratch->nbursts) break;
+      if (ctl[b].status != kBurstReady) { __syncthreads(); continue; }
+      const rtfe_burst B = bursts[b];
+      cx.events = events + B.event_base;
+      cx.cap = B.event_cap;
+      const long long reset = ctl[b].reset, stop = ctl[b].stop;
+      const unsigned int bflags = ctl[b].bflags;
+      cx.tile.reset = reset;
+      Walker w;                                                        // (only the fields of load_walk_fields are ever touched)
+      load_walk_fields(w, wstate[(size_t)b * nwalk + (is_walker ? my_w : 0)].w);
+      if (is_walker) {
+         const WalkState &ws = wstate[(size_t)b * nwalk + my_w];
+         for (int i = 0; i < 10; ++i) cx.heights[i] = ws.heights[i]; }
+      long long g = ctl[b].next_tile;
+      bool give_back = false;
+      long long acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, ntl = 0;
+      for (; g * T < stop; ++g) {
+         const long long tile0 = g * T;
+         const long long tn = (tile0 + T <= nrows) ? T : nrows - tile0;
+         if (tn <= 0) break;
+         cx.tile.row0 = tile0; cx.tile.nrows = (int)tn;
+         __syncthreads();
+         long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+         if (cfg.debug) t0 = clock64();
+         if (threadIdx.x == 0) s_needfull = 0;
+         if (threadIdx.x < nst) s_dir[threadIdx.x] = dir[g * nst + threadIdx.x];
+         __syncthreads();
+         if (threadIdx.x <= nst) {                                  // where each list goes in LDS (packed)
+            int o = 0; bool bad = false;
+            for (int st = 0; st < (int)threadIdx.x; ++st) { if (s_dir[st].count == 0xFFFF) bad = true; o += s_dir[st].count; }
+            s_off[threadIdx.x] = bad ? (1 << 30) : o; }
+         __syncthreads();
+         if (s_off[nst] > cfg.lds_units) { give_back = true; break; }
+         if (cfg.debug) t1 = clock64();
+         {
+            // the tile's lists are contiguous in the pool: independent 16-byte loads, eight in flight per lane
+            const int4 *src = reinterpret_cast<const int4 *>(pool) + (size_t)g * nst * cfg.run_cap;
+            const int total = s_off[nst];
+            for (int i0 = threadIdx.x; i0 < total; i0 += 8 * (int)blockDim.x) {
+               int4 q0, q1, q2, q3, q4, q5, q6, q7;
+               const int bd = (int)blockDim.x;
+               q0 = src[i0];
+               q1 = i0 + bd < total ? src[i0 + bd] : q0;
+               q2 = i0 + 2 * bd < total ? src[i0 + 2 * bd] : q0;
+               q3 = i0 + 3 * bd < total ? src[i0 + 3 * bd] : q0;
+               q4 = i0 + 4 * bd < total ? src[i0 + 4 * bd] : q0;
+               q5 = i0 + 5 * bd < total ? src[i0 + 5 * bd] : q0;
+               q6 = i0 + 6 * bd < total ? src[i0 + 6 * bd] : q0;
+               q7 = i0 + 7 * bd < total ? src[i0 + 7 * bd] : q0;
+               units[i0] = q0;
+               if (i0 + bd < total) units[i0 + bd] = q1;
+               if (i0 + 2 * bd < total) units[i0 + 2 * bd] = q2;
+               if (i0 + 3 * bd < total) units[i0 + 3 * bd] = q3;
+               if (i0 + 4 * bd < total) units[i0 + 4 * bd] = q4;
+               if (i0 + 5 * bd < total) units[i0 + 5 * bd] = q5;
+               if (i0 + 6 * bd < total) units[i0 + 6 * bd] = q6;
+               if (i0 + 7 * bd < total) units[i0 + 7 * bd] = q7; } }
+         __syncthreads();
+         if (cfg.debug) t2 = clock64();
+         cx.nrec = 0;
+         if (is_walker) idx0_all[my_w] = (int)w.nevents;
+         Walker w0;
+         load_walk_fields(w0, w);
+         if (is_walker) {
+            const int st = cfg.parm[pidx].screen * ntrks + trk;
+            for (int i = 0; i < 10; ++i) heights_bak[my_w * 10 + i] = cx.heights[i];
+            int why = 0;
+            if (!walk_records(w, cx, pidx, trk, stop, reinterpret_cast<const CandUnit *>(units + s_off[st]), s_dir[st].count, s_dir[st], why))
+               atomicOr((unsigned int *)&s_needfull, 1u);
+            nrec_all[my_w] = cx.nrec; }
+         __syncthreads();
+         if (cfg.debug) t3 = clock64();
+         if (s_needfull) {
+            if (is_walker) { load_walk_fields(w, w0); for (int i = 0; i < 10; ++i) cx.heights[i] = heights_bak[my_w * 10 + i]; }
+            give_back = true;
+            break; }
+         if (threadIdx.x == 0) { int o = 0; for (int w2 = 0; w2 < nwalk; ++w2) { const int c = nrec_all[w2]; nrec_all[w2] = o; o += c; } nrec_all[nwalk] = o; }
+         __syncthreads();
+         finalize_records16(cx, recs_all, rstride, nrec_all, idx0_all, nwalk, threadIdx.x, blockDim.x);
+         if (cfg.debug) { const long long t4 = clock64(); acc0 += t1 - t0; acc1 += t2 - t1; acc2 += t3 - t2; acc3 += t4 - t3; ++ntl; } }
+      if (cfg.debug && threadIdx.x == 0) {
+         atomicAdd(&scratch->dbg2[0], (unsigned long long)acc0); atomicAdd(&scratch->dbg2[1], (unsigned long long)acc1);
+         atomicAdd(&scratch->dbg2[2], (unsigned long long)acc2); atomicAdd(&scratch->dbg2[3], (unsigned long long)acc3);
+         atomicAdd(&scratch->dbg[7], (unsigned long long)ntl); }
+      if (give_back) {                                                // the state as of the start of tile g
+         if (is_walker) {
+            WalkState &ws = wstate[(size_t)b * nwalk + my_w];
+            load_walk_fields(ws.w, w);
+            for (int i = 0; i < 10; ++i) ws.heights[i] = cx.heights[i]; }
+         if (threadIdx.x == 0) { ctl[b].next_tile = (int)g; ctl[b].status = kBurstNeedsFull; }
+         __syncthreads();
+         continue; }
+      // ---- publish (as k_decode does) ----
+      if (is_walker) {
+         counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = w.nevents < cx.cap ? w.nevents : cx.cap;
+         if (w.flags) atomicOr(&s_flags, w.flags); }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+         bursts[b].reset_sample = reset;
+         bursts[b].safe_last = (bflags & RTFE_F_UNSAFE) ? -1 : reset;
+         bursts[b].end_sample = stop < nrows ? stop : nrows;
+         bursts[b].flags = bflags | s_flags;
+         ctl[b].status = kBurstDone; }
+      __syncthreads(); } }
+
 __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows,
                                                            long long nrows, long long row_base,
                                                            rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
                                                            uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                                            uint32_t parmset_mask, int screen_off, int single_exact,
-                                                           const TileDir *__restrict__ dir, const CandUnit *__restrict__ pool) {
+                                                           const TileDir *__restrict__ dir, const CandUnit *__restrict__ pool,
+                                                           int mode, BurstCtl *__restrict__ ctl, WalkState *__restrict__ wstate) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;            // tests/cpu_emul only
 #else
@@ -1214,6 +1435,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    __shared__ int s_needfull;
    __shared__ TileDir s_dir[kMaxScreens * RTFE_MAXTRKS];
    __shared__ int s_off[kMaxScreens * RTFE_MAXTRKS + 1];
+   __shared__ int s_recoff[kDecodeThreads + 1], s_idx0[kDecodeThreads];
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
    if (screen_off && threadIdx.x == 0)
@@ -1248,7 +1470,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    Walker *walkers = reinterpret_cast<Walker *>(smem + L.walkers);       // [nwalk]
    Walker *walkers_next = reinterpret_cast<Walker *>(smem + L.walkers_next);  // [nwalk] result of an optimistic tile, committed only if all lanes agree
    float *heights_bak = reinterpret_cast<float *>(smem + L.heights_bak);     // [nwalk][10]
-   cx.rec_cap = cfg.rec_cap;
+   cx.rec_cap = cfg.rec_cap; cx.rec_cap16 = cfg.rec_cap * (int)sizeof(Rec) / (int)sizeof(Rec16);
    cx.recs = recs_all + (size_t)(is_walker ? my_w : 0) * cfg.rec_cap;
 
    // restart row of a zone-started burst: load the last kMarginRows rows of its zone, screen them, find the last
@@ -1266,11 +1488,14 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       const long long r = find_reset(&cfg, cx.tile, &s_min);
       return (r <= 0 || r < Z.zone_first) ? -1 : r; };
 
+   // mode: kDecodeAll = whole bursts (exact scans, -zeros); kDecodeHead = start every burst and hand it to k_walk as
+   // soon as its walkers are on the screened path; kDecodeResume = finish the bursts k_walk had to give back
    for (;;) {
-      if (threadIdx.x == 0) { s_burst = atomicAdd(&scratch->queue, 1); s_flags = 0; }
+      if (threadIdx.x == 0) { s_burst = atomicAdd(mode == kDecodeResume ? &scratch->queue_resume : &scratch->queue, 1); s_flags = 0; }
       __syncthreads();
       const int b = s_burst;
       if (b >= scratch->nbursts) break;
+      if (mode == kDecodeResume && ctl[b].status != kBurstNeedsFull) { __syncthreads(); continue; }
       const int nb = scratch->nbursts_total;
       const rtfe_burst B = bursts[b];
       const bool exact = B.flags & RTFE_F_EXACT_START;
@@ -1278,37 +1503,64 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       const bool has_tail = !last && !single_exact;
       cx.events = events + B.event_base;
       cx.cap = B.event_cap;
-      // ---- where this burst restarts, and where the next one does (= where this one stops) ----
       unsigned int bflags = B.flags;
-      long long reset = B.reset_sample;
-      if (!exact) {
-         reset = zone_reset(B);
-         if (reset < 0) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; } }
+      long long reset, stop;
       const long long hard_end = single_exact ? (B.end_sample < nrows ? B.end_sample : nrows) : nrows;
-      long long stop = hard_end;
-      if (has_tail) {
-         const rtfe_burst NB = bursts[b + 1];
-         stop = zone_reset(NB);
-         if (stop < 0) stop = NB.zone_end - kMarginRows; }
-      // ---- walker init: init_trackstate + init_trackpeak_state (src/decoder.c:413-455) ----
-      // (the walker's state lives in LDS between tiles so that the all-lane phases do not carry it in registers)
-      if (is_walker) {
-         Walker w = {};
-         w.start = reset + trk; w.next = reset; w.blind_until = -1; w.fast = false;
-         w.agc_gain = 1.0f; w.v_avg_height = 4.0f; w.z_firstzero = -1; w.z_lastzero = -1;
-         update_thresholds(w, cfg.parm[pidx], cfg.lsb_per_volt);
-         walkers[my_w] = w;
-         for (int i = 0; i < 10; ++i) cx.heights[i] = 0; }
+      long long g_first;
+      if (mode == kDecodeResume) {
+         reset = ctl[b].reset; stop = ctl[b].stop; bflags = ctl[b].bflags; g_first = ctl[b].next_tile;
+         if (is_walker) {
+            const WalkState &ws = wstate[(size_t)b * nwalk + my_w];
+            walkers[my_w] = ws.w;
+            for (int i = 0; i < 10; ++i) cx.heights[i] = ws.heights[i]; } }
+      else {
+         // ---- where this burst restarts, and where the next one does (= where this one stops) ----
+         reset = B.reset_sample;
+         if (!exact) {
+            reset = zone_reset(B);
+            if (reset < 0) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; } }
+         stop = hard_end;
+         if (has_tail) {
+            const rtfe_burst NB = bursts[b + 1];
+            stop = zone_reset(NB);
+            if (stop < 0) stop = NB.zone_end - kMarginRows; }
+         // ---- walker init: init_trackstate + init_trackpeak_state (src/decoder.c:413-455) ----
+         // (the walker's state lives in LDS between tiles so that the all-lane phases do not carry it in registers)
+         if (is_walker) {
+            Walker w = {};
+            w.start = reset + trk; w.next = reset; w.blind_until = -1; w.fast = false;
+            w.agc_gain = 1.0f; w.v_avg_height = 4.0f; w.z_firstzero = -1; w.z_lastzero = -1;
+            update_thresholds(w, cfg.parm[pidx], cfg.lsb_per_volt);
+            walkers[my_w] = w;
+            for (int i = 0; i < 10; ++i) cx.heights[i] = 0; }
+         g_first = reset / cfg.tile_rows; }
       cx.tile.reset = reset;
+      bool handed_over = false;
       // ---- tiles of the tape-global grid that intersect [reset, stop) ----
       const long long T = cfg.tile_rows;
-      for (long long g = reset / T; g * T < stop; ++g) {
+      for (long long g = g_first; g * T < stop; ++g) {
          const long long tile0 = g * T;
          const long long tn = (tile0 + T <= nrows) ? T : nrows - tile0;
          if (tn <= 0) break;
          long long c0 = 0, c1 = 0, c2 = 0;
          cx.tile.row0 = tile0; cx.tile.nrows = (int)tn;
          __syncthreads();
+         if (mode == kDecodeHead) {                               // can k_walk take over from this tile on?
+            if (threadIdx.x == 0) s_needfull = 0;
+            __syncthreads();
+            if (active && !(walkers[my_w].fast && tile0 - kScreenHalo >= walkers[my_w].trust_from)) atomicOr((unsigned int *)&s_needfull, 1u);
+            __syncthreads();
+            if (!s_needfull) {
+               if (is_walker) {
+                  WalkState &ws = wstate[(size_t)b * nwalk + my_w];
+                  ws.w = walkers[my_w];
+                  for (int i = 0; i < 10; ++i) ws.heights[i] = cx.heights[i]; }
+               if (threadIdx.x == 0) {
+                  BurstCtl c; c.reset = reset; c.stop = stop; c.next_tile = (int)g; c.status = kBurstReady; c.bflags = bflags; c.pad = 0;
+                  ctl[b] = c; }
+               handed_over = true;
+               break; }
+            __syncthreads(); }
          if (cfg.debug) c0 = clock64();
          // ---- decide the whole tile from the candidate records k_screen left in HBM ----
          bool done_tile = false;
@@ -1327,10 +1579,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
             const bool avail = s_off[nst] <= cfg.lds_units;
             if (avail) {
                const int4 *src = reinterpret_cast<const int4 *>(pool) + (size_t)g * nst * cfg.run_cap;
-               for (int st = 0; st < nst; ++st) {
-                  const int n2 = (int)s_dir[st].count;
-                  for (int i = threadIdx.x; i < n2; i += blockDim.x)
-                     reinterpret_cast<int4 *>(runs_all)[s_off[st] + i] = src[(size_t)st * cfg.run_cap + i]; }
+               for (int i = threadIdx.x; i < s_off[nst]; i += blockDim.x) reinterpret_cast<int4 *>(runs_all)[i] = src[i];
                __syncthreads();
                if (cfg.debug) o2 = clock64();
                cx.nrec = 0;
@@ -1338,6 +1587,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                   const int st = cfg.parm[pidx].screen * ntrks + trk;
                   Walker w = walkers[my_w];
                   for (int i = 0; i < 10; ++i) heights_bak[my_w * 10 + i] = cx.heights[i];     // part of the walker's state
+                  s_idx0[my_w] = (int)w.nevents;
                   int why = 0;
                   if (walk_records(w, cx, pidx, trk, stop, runs_all + s_off[st], s_dir[st].count, s_dir[st], why))
                      walkers_next[my_w] = w;
@@ -1348,8 +1598,9 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                if (s_needfull && active) for (int i = 0; i < 10; ++i) cx.heights[i] = heights_bak[my_w * 10 + i];
                if (!s_needfull) {
                   if (is_walker && active) walkers[my_w] = walkers_next[my_w];
-                  for (int w2 = 0; w2 < nwalk; ++w2)
-                     finalize_records(cx, recs_all + (size_t)w2 * cfg.rec_cap, nrec_all[w2], w2 / ntrks, w2 % ntrks, threadIdx.x, blockDim.x);
+                  if (threadIdx.x == 0) { int o = 0; for (int w2 = 0; w2 < nwalk; ++w2) { const int c = (parmset_mask >> (w2 / ntrks)) & 1 ? nrec_all[w2] : 0; s_recoff[w2] = o; o += c; } s_recoff[nwalk] = o; }
+                  __syncthreads();
+                  finalize_records16(cx, reinterpret_cast<const unsigned char *>(recs_all), cfg.rec_cap * (int)sizeof(Rec), s_recoff, s_idx0, nwalk, threadIdx.x, blockDim.x);
                   done_tile = true;
                   if (cfg.debug && threadIdx.x == 0) {
                      const long long o4 = clock64();
@@ -1385,7 +1636,9 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                atomicAdd(&scratch->dbg[2], (unsigned long long)(c3 - c2)); atomicAdd(&scratch->dbg[3], 1ull);
                atomicAdd(&scratch->dbg[5], (unsigned long long)(c2c - c2));
                atomicAdd(&scratch->dbg[6], (unsigned long long)(c3 - c2c)); } } }
+      if (handed_over) { __syncthreads(); continue; }
       // ---- publish ----
+      if (mode != kDecodeAll && threadIdx.x == 0) ctl[b].status = kBurstDone;
       if (is_walker) {
          const unsigned int ne = walkers[my_w].nevents, wf = walkers[my_w].flags;
          counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = active ? (ne < cx.cap ? ne : cx.cap) : 0;

@@ -245,7 +245,7 @@ class FrontEnd:
 
     def kernel_ms(self):
         """Per-kernel elapsed ms of the last scan (HIP events on the scan's stream); synchronises."""
-        out = (C.c_float * 4)()
+        out = (C.c_float * self.lib.rtfe_kernel_count())()
         if self.lib.rtfe_kernel_ms(self.h, out) != 0:
             raise RuntimeError(self.lib.rtfe_last_error().decode())
         return dict(zip(self.kernel_names(), [float(x) for x in out]))
