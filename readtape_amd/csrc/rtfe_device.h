@@ -58,26 +58,28 @@ struct DevCfg {
 };
 
 // ---- what the dense screen pass (k_screen) leaves in HBM for the sequential pass (k_walk / k_decode) ----
-// A list is a sequence of 16-byte units.  One RUN = consecutive candidate rows of one kind that share the same
-// extreme (rows where both kinds are candidates form one-row runs, top first, so list order = the detector's order).
-// A run is 1 header unit + ceil((nrows-1)/4) units of four (dL,dR) pairs.  It carries everything the sequential
-// detector needs to decide those rows EXACTLY without the samples: the extreme, its neighbours (half-sample
-// refinement) and its distance from both window edges at every row (int16 code differences, from which the float
-// comparisons of src/decoder.c:788-805 can be re-evaluated bit for bit).
-//   header  .x = n_s | nrows << 16 | kind << 24      n_s tile-relative; kind 0 top / 1 bottom
+// A list is a sequence of 16-byte units: first one HEADER per run, in the detector's order, then the margin units.
+// One RUN = consecutive candidate rows of one kind that share the same extreme (rows where both kinds are candidates
+// form one-row runs, top first, so header order = the detector's order).  A run owns ceil((nrows-1)/4) margin units of
+// four (dL,dR) pairs.  It carries everything the sequential detector needs to decide those rows EXACTLY without the
+// samples: the extreme, its neighbours (half-sample refinement) and its distance from both window edges at every row
+// (int16 code differences, from which the float comparisons of src/decoder.c:788-805 can be re-evaluated bit for bit).
+//   header  .x = n_s | nrows << 11 | kind << 17 | moff << 18
+//                                                    n_s tile-relative (< 2048); kind 0 top / 1 bottom; moff = index of the
+//                                                    run's first margin unit behind the list's headers
 //           .y = (m & 0xffff) | ld0 << 16            m = the extreme (tops: true window maximum; bottoms: the reference's
 //                                                    possibly stale minimum); ld0 = its left_distance at row n_s (one less
 //                                                    per row); ld0 = 0 (bottoms): the reference's minimum is unknown here
 //           .z = prev | next << 16                   the extreme's neighbours
 //           .w = dL | dR << 16                       row n_s: |m - left window edge|, |m - right edge| (clamped at 0)
-//   margins .x .y .z .w = dL | dR << 16              rows n_s + 1 + 4u .. n_s + 4 + 4u of margin unit u
+//   margins .x .y .z .w = dL | dR << 16              rows n_s + 1 + 4u .. n_s + 4 + 4u of the run's margin unit u
 typedef struct { int32_t x, y, z, w; } CandUnit;
 struct TileDir {               // per (tile, screen, track): 8 bytes
-   uint16_t count;             // 16-byte units in this list; 0xFFFF: more than run_cap (list incomplete)
+   uint16_t count;             // 16-byte units in this list (headers + margins); 0xFFFF: list incomplete
+   uint16_t nruns;             // of which headers
    uint8_t  end_ld;            // left_distance of the reference's minimum after the tile's last row; 0 = unknown
    uint8_t  pad;
    int16_t  end_min;           // that minimum (int16 code)
-   uint16_t pad2;
 };
 // ---- burst hand-over between the kernels of one scan (workspace) ----
 enum { kBurstNew = 0, kBurstNeedsFull = 1, kBurstReady = 2, kBurstDone = 3 };

@@ -824,13 +824,14 @@ __device__ __forceinline__ int run_length(const u64 *cm, const u64 *sm, int n, i
 
 // ---- k_screen only: the runs that start in one strip of one (screen, track), in the detector's order (row, top
 // before bottom): one descriptor each into the tile's run table, and the strip's unit count as the result.
-// descriptor: st | kind << 8 | n << 16 | (u64)nr << 32 | (u64)rel << 40   (rel = unit offset inside the strip)
+// descriptor: st | kind << 8 | n << 16 | (u64)nr << 32 | (u64)relrun << 40 | (u64)relmarg << 50   (run / margin-unit index inside the strip)
+// result: runs | margin units << 16
 __device__ __forceinline__ int list_runs(const Tile &tl, int st, int screen, int trk, int strip, u64 *runtab, int *nruns, int tabcap) {
    const u64 *tm = tl.map(screen, 0, trk), *bm = tl.map(screen, 1, trk), *stm = tl.map(screen, 3, trk), *sbm = tl.map(screen, 4, trk);
    const int sh = (strip & 7) * 8;
    const unsigned stt = (unsigned)(stm[strip >> 3] >> sh) & 0xffu, sb = (unsigned)(sbm[strip >> 3] >> sh) & 0xffu;
    unsigned any = stt | sb;
-   int rel = 0;
+   int relrun = 0, relmarg = 0;
    #pragma nounroll
    while (any) {
       const int j = __ffs((int)any) - 1;
@@ -840,18 +841,19 @@ __device__ __forceinline__ int list_runs(const Tile &tl, int st, int screen, int
       for (int kind = (stt >> j) & 1 ? 0 : 1; kind <= (int)((sb >> j) & 1); ++kind) {
          const int nr = run_length(kind ? bm : tm, kind ? sbm : stm, n, tl.nrows);
          const int slot = atomicAdd(nruns, 1);
-         if (slot < tabcap) runtab[slot] = (u64)(unsigned)(st | (kind << 8) | (n << 16)) | ((u64)nr << 32) | ((u64)rel << 40);
-         rel += 1 + ((nr + 2) >> 2); } }
-   return rel; }
+         if (slot < tabcap) runtab[slot] = (u64)(unsigned)(st | (kind << 8) | (n << 16)) | ((u64)nr << 32) | ((u64)relrun << 40) | ((u64)relmarg << 50);
+         ++relrun; relmarg += (nr + 2) >> 2; } }
+   return relrun | (relmarg << 16); }
 
 // ---- k_screen only: the units of one run -> its place in the list (HBM) ----
-__device__ __forceinline__ void build_run(const Tile &tl, const DevCfg *cfg, int screen, int trk, int W, int n, int kind, int nr, int4 *out) {
+__device__ __forceinline__ void build_run(const Tile &tl, const DevCfg *cfg, int screen, int trk, int W, int n, int kind, int nr,
+                                          int4 *hdr, int moff, int4 *marg) {
    const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
    const int ld0 = tl.ldmap(screen, kind, trk)[n];
    int m = 0, prev = 0, next = 0;
    if (ld0) { const int p = n - W + ld0; m = yb[p]; prev = yb[p - 1]; next = yb[p + 1]; }
    int4 q;
-   q.x = n | (nr << 16) | (kind << 24);
+   q.x = n | (nr << 11) | (kind << 17) | (moff << 18);
    q.y = (m & 0xffff) | (ld0 << 16);
    q.z = (prev & 0xffff) | (next << 16);
    int4 u = make_int4(0, 0, 0, 0);
@@ -864,11 +866,11 @@ __device__ __forceinline__ void build_run(const Tile &tl, const DevCfg *cfg, int
          dl = kind ? L - m : m - L; dr = kind ? R - m : m - R;
          dl = dl < 0 ? 0 : dl; dr = dr < 0 ? 0 : dr; }
       const int pr = dl | (dr << 16);
-      if (jj == 0) { q.w = pr; out[slot++] = q; }
+      if (jj == 0) { q.w = pr; *hdr = q; }
       else {
          const int c = (jj - 1) & 3;
          if (c == 0) u.x = pr; else if (c == 1) u.y = pr; else if (c == 2) u.z = pr; else u.w = pr;
-         if (c == 3 || jj == nr - 1) { out[slot++] = u; u = make_int4(0, 0, 0, 0); } } } }
+         if (c == 3 || jj == nr - 1) { marg[slot++] = u; u = make_int4(0, 0, 0, 0); } } } }
 
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
@@ -1026,14 +1028,14 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
       #pragma nounroll
       while (i < nrecs) {                                           // (A)
          const int4 A = units[i];                                   // run header
-         const int n_s = A.x & 0xffff, nr = (A.x >> 16) & 0xff;
-         const int ibase = i + 1;                                   // first margin unit of this run
-         i += 1 + ((nr + 2) >> 2);
+         const int n_s = A.x & 0x7ff, nr = (A.x >> 11) & 0x3f;
+         const int ibase = nrecs + (int)((unsigned)A.x >> 18);      // first margin unit of this run (behind the headers)
+         ++i;
          if (n_s >= lim) { i = nrecs; break; }
          int k = cur > n_s ? cur - n_s : 0;                          // rows inside the countdown of the last detection are skipped
          if (k >= nr) continue;
          const int ld0 = (A.y >> 16) & 0xff;
-         const bool is_top = ((A.x >> 24) & 1) == 0;
+         const bool is_top = ((A.x >> 17) & 1) == 0;
          const int m = (int)(short)(A.y & 0xffff);
          if (ld0 == 0) { why = 4; fail = true; break; }
          if (w.reqmin != 0) {                                       // min_peak test: the same for every row of the run
@@ -1118,7 +1120,7 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    // its records or from its samples, never both)
    L.runs = 0;
    if (decode) { const unsigned r = lds_align16((unsigned)c.lds_units * (unsigned)sizeof(CandUnit)); if (r > off) off = r; }
-   L.runcnt = off;    if (!decode) off = lds_align16(off + nst * (T / 8) * 2u);
+   L.runcnt = off;    if (!decode) off = lds_align16(off + nst * (T / 8) * 4u);
    L.runtab = off;    if (!decode) off = lds_align16(off + lds_runtab_cap(c) * 8u);
    L.heights = off;   if (decode) off = lds_align16(off + nwalk * 10u * 4u);
    L.recs = off;      if (decode) off = lds_align16(off + nwalk * (unsigned)c.rec_cap * (unsigned)sizeof(Rec));
@@ -1168,7 +1170,7 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    tl.ntrks = ntrks; tl.skew = cfg.skew; tl.reset = -(1ll << 40);
    tl.bits = smem + L.bits; tl.bstride = (cfg.tile_rows + kScreenHalo) / 8 + 8;
    tl.ldpos = smem + L.ldpos; tl.ldstride = cfg.tile_rows + kScreenHalo;
-   unsigned short *stripcnt = reinterpret_cast<unsigned short *>(smem + L.runcnt);     // [nst][tile_rows / 8] units per strip
+   unsigned int *stripcnt = reinterpret_cast<unsigned int *>(smem + L.runcnt);         // [nst][tile_rows / 8] runs | margin units << 16 per strip
    u64 *runtab = reinterpret_cast<u64 *>(smem + L.runtab);           // the tile's run descriptors
    const int tabcap = (int)lds_runtab_cap(cfg);
    __shared__ int s_nruns;
@@ -1204,7 +1206,7 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
       if (cfg.debug & 16) continue;
       for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {
          const int st = i / nstrips, sc = st / ntrks, strip = i - st * nstrips;
-         stripcnt[st * smax + strip] = (unsigned short)list_runs(tl, st, sc, st - sc * ntrks, strip, runtab, &s_nruns, tabcap); }
+         stripcnt[st * smax + strip] = (unsigned int)list_runs(tl, st, sc, st - sc * ntrks, strip, runtab, &s_nruns, tabcap); }
       __syncthreads();
       // exclusive scan of the strips' unit counts, list by list (one wave per list at a time)
       {
@@ -1212,35 +1214,41 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
          for (int st = wave; st < nst; st += nwaves) {
             int carry = 0;
             for (int s0 = 0; s0 < nstrips; s0 += 64) {
-               const int v = s0 + lane < nstrips ? stripcnt[st * smax + s0 + lane] : 0;
+               const int v = s0 + lane < nstrips ? (int)stripcnt[st * smax + s0 + lane] : 0;
                int x = v;
                #pragma unroll
                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
-               if (s0 + lane < nstrips) stripcnt[st * smax + s0 + lane] = (unsigned short)(carry + x - v);
+               if (s0 + lane < nstrips) stripcnt[st * smax + s0 + lane] = (unsigned int)(carry + x - v);
                carry += __shfl(x, 63); }
             if (lane == 0) s_total[st] = carry; } }
       __syncthreads();
       if (cfg.debug) k3 = clock64();
       if (cfg.debug & 32) continue;
       int tile_units = 0;
-      for (int s2 = 0; s2 < nst; ++s2) tile_units += s_total[s2];
+      for (int s2 = 0; s2 < nst; ++s2) tile_units += (s_total[s2] & 0xffff) + (s_total[s2] >> 16);
       const bool tab_ok = s_nruns <= tabcap && tile_units <= nst * cfg.run_cap;
       if (tab_ok)
          for (int r = threadIdx.x; r < s_nruns; r += blockDim.x) {
             const u64 d = runtab[r];
-            const int st = (int)(d & 0xff), kind = (int)((d >> 8) & 1), n = (int)((d >> 16) & 0xffff), nr = (int)((d >> 32) & 0xff), rel = (int)(d >> 40);
+            const int st = (int)(d & 0xff), kind = (int)((d >> 8) & 1), n = (int)((d >> 16) & 0xffff), nr = (int)((d >> 32) & 0xff);
+            const int relrun = (int)((d >> 40) & 0x3ff), relmarg = (int)(d >> 50);
             const int sc = st / ntrks;
-            int off = stripcnt[st * smax + (n >> 3)] + rel;
-            for (int s2 = 0; s2 < st; ++s2) off += s_total[s2];     // the tile's lists are packed one behind the other
-            build_run(tl, &cfg, sc, st - sc * ntrks, cfg.screen[sc].W, n, kind, nr,
-                      reinterpret_cast<int4 *>(pool) + (size_t)g * nst * cfg.run_cap + off); }
+            const unsigned sb = stripcnt[st * smax + (n >> 3)];
+            int lbase = 0;
+            for (int s2 = 0; s2 < st; ++s2) lbase += (s_total[s2] & 0xffff) + (s_total[s2] >> 16);     // the tile's lists are packed one behind the other
+            int4 *list = reinterpret_cast<int4 *>(pool) + (size_t)g * nst * cfg.run_cap + lbase;
+            const int moff = (int)(sb >> 16) + relmarg;
+            build_run(tl, &cfg, sc, st - sc * ntrks, cfg.screen[sc].W, n, kind, nr, list + (sb & 0xffff) + relrun, moff,
+                      list + (s_total[st] & 0xffff) + moff); }
       if (threadIdx.x < nst) {
          const int st = threadIdx.x, sc = st / ntrks, trk = st - sc * ntrks;
          TileDir d;
-         d.count = (!tab_ok || s_total[st] >= 0xFFFF) ? (uint16_t)0xFFFF : (uint16_t)s_total[st];
+         const int units_l = (s_total[st] & 0xffff) + (s_total[st] >> 16);
+         d.count = (!tab_ok || units_l >= 0xFFFF || (s_total[st] >> 16) >= (1 << 14)) ? (uint16_t)0xFFFF : (uint16_t)units_l;
+         d.nruns = (uint16_t)(s_total[st] & 0xffff);
          const int last = tl.nrows - 1;
          const int eld = stale_ld(tl.map(sc, 2, trk), tl.ldmap(sc, 1, trk), last);
-         d.end_ld = (uint8_t)eld; d.pad = 0; d.pad2 = 0;
+         d.end_ld = (uint8_t)eld; d.pad = 0;
          d.end_min = eld ? tl.x[trk * tl.ldw + kHaloRows - cfg.skew[trk] + last - cfg.screen[sc].W + eld] : (int16_t)0;
          dir[g * nst + st] = d; }
       if (cfg.debug) {
@@ -1378,7 +1386,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
             const int st = cfg.parm[pidx].screen * ntrks + trk;
             for (int i = 0; i < 10; ++i) heights_bak[my_w * 10 + i] = cx.heights[i];
             int why = 0;
-            if (!walk_records(w, cx, pidx, trk, stop, reinterpret_cast<const CandUnit *>(units + s_off[st]), s_dir[st].count, s_dir[st], why))
+            if (!walk_records(w, cx, pidx, trk, stop, reinterpret_cast<const CandUnit *>(units + s_off[st]), s_dir[st].nruns, s_dir[st], why))
                atomicOr((unsigned int *)&s_needfull, 1u);
             nrec_all[my_w] = cx.nrec; }
          __syncthreads();
@@ -1589,7 +1597,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                   for (int i = 0; i < 10; ++i) heights_bak[my_w * 10 + i] = cx.heights[i];     // part of the walker's state
                   s_idx0[my_w] = (int)w.nevents;
                   int why = 0;
-                  if (walk_records(w, cx, pidx, trk, stop, runs_all + s_off[st], s_dir[st].count, s_dir[st], why))
+                  if (walk_records(w, cx, pidx, trk, stop, runs_all + s_off[st], s_dir[st].nruns, s_dir[st], why))
                      walkers_next[my_w] = w;
                   else { atomicOr((unsigned int *)&s_needfull, 1u); if (cfg.debug) atomicAdd(&scratch->why[why & 7], 1ull); } }
                if (is_walker) nrec_all[my_w] = cx.nrec;
