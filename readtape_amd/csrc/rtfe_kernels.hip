@@ -1131,7 +1131,8 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    L.total = off;
    return L; }
 
-struct WalkLds { unsigned units, heights, heights_bak, recs, nrec, idx0, total; };
+struct WalkLds { unsigned units, heights, heights_bak, recs, nrec, idx0, band, pmoff, hoff, wst, pm, pmmap, hmap, total; };
+constexpr int kPassMaskCap = 2048;      // (walker, run) verdicts of one tile in k_walk's parallel path
 __host__ __device__ inline WalkLds lds_layout_walk(const DevCfg &c) {
    WalkLds L;
    const unsigned nwalk = (unsigned)(c.nparm * c.ntrks);
@@ -1142,6 +1143,13 @@ __host__ __device__ inline WalkLds lds_layout_walk(const DevCfg &c) {
    L.recs = off;         off = lds_align16(off + nwalk * (unsigned)c.rec_cap16 * (unsigned)sizeof(Rec16));
    L.nrec = off;         off = lds_align16(off + (nwalk + 1) * 4u);
    L.idx0 = off;         off = lds_align16(off + nwalk * 4u);
+   L.band = off;         off = lds_align16(off + nwalk * 16u);
+   L.pmoff = off;        off = lds_align16(off + (nwalk + 1) * 4u);
+   L.hoff = off;         off = lds_align16(off + (nwalk + 1) * 4u);
+   L.wst = off;          off = lds_align16(off + nwalk * 16u);
+   L.pm = off;           off = lds_align16(off + (unsigned)kPassMaskCap * 2u);
+   L.pmmap = off;        off = lds_align16(off + (unsigned)kPassMaskCap);
+   L.hmap = off;         off = lds_align16(off + nwalk * (unsigned)c.rec_cap16);
    L.total = off;
    return L; }
 
@@ -1301,6 +1309,17 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
    unsigned char *recs_all = smem + L.recs;                          // [nwalk][rec_cap16] Rec16
    int *nrec_all = reinterpret_cast<int *>(smem + L.nrec);          // [nwalk + 1] -> exclusive scan
    int *idx0_all = reinterpret_cast<int *>(smem + L.idx0);          // [nwalk]
+   int *band = reinterpret_cast<int *>(smem + L.band);              // [nwalk][4] parallel path: rise lo/hi, min_peak lo/hi (wide)
+   int *pmoff = reinterpret_cast<int *>(smem + L.pmoff);            // [nwalk + 1]
+   int *hoff = reinterpret_cast<int *>(smem + L.hoff);              // [nwalk + 1]
+   float *wst = reinterpret_cast<float *>(smem + L.wst);            // [nwalk][4] v_lasttop, v_lastbot, v_avg_height, alpha
+   unsigned short *pm = reinterpret_cast<unsigned short *>(smem + L.pm);     // [kPassMaskCap] last sure row + 1 | (last possible row + 1) << 8
+   unsigned char *pmmap = smem + L.pmmap;                           // [kPassMaskCap] walker of a verdict slot
+   unsigned char *hmap = smem + L.hmap;                             // [nwalk * rec_cap16] walker of a detection slot
+   __shared__ unsigned int s_seq;
+   // the parallel tile path covers the alpha-filter AGC (NRZI / GCR parameter sets); everything else walks sequentially
+   bool par_mode = cfg.mode != RTFE_PE;
+   for (int p = 0; p < cfg.nparm; ++p) if (cfg.parm[p].agc_alpha == 0 || cfg.parm[p].agc_window != 0) par_mode = false;
    const int rstride = cfg.rec_cap16 * (int)sizeof(Rec16);
    const int nwaves = blockDim.x >> 6;
    const int my_w = (threadIdx.x & 63) * nwaves + (threadIdx.x >> 6);
@@ -1378,8 +1397,227 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                if (i0 + 7 * bd < total) units[i0 + 7 * bd] = q7; } }
          __syncthreads();
          if (cfg.debug) t2 = clock64();
-         cx.nrec = 0;
          if (is_walker) idx0_all[my_w] = (int)w.nevents;
+         // ================= parallel tile path ("decisions first, gains after") =================
+         // In the steady state of a block the detector's decisions depend on the AGC only through thresholds that move
+         // slowly, and WHICH row of a run fires changes nothing downstream: the countdown ends when the extreme leaves the
+         // window (row n_s + ld0 whatever the row), and the AGC sees the extreme's value.  So:
+         // (1) every lane classifies runs against WIDE bands around the thresholds at the tile's start: the last row that
+         //     passes for every threshold inside the band, and the last row that passes for some;
+         // (2) one lane per walker follows the countdown chain: a run fires if a sure row is still ahead of the countdown;
+         // (3) all lanes prepare volt() and the AGC quotients of the detections;
+         // (4) one lane per walker runs the three-flop gain recurrence and checks that every threshold it produced stayed
+         //     inside the band;
+         // (5) all lanes find each detection's row with the reference's own comparisons at the now known gain, and write
+         //     the events.
+         // Any doubt (a run that fires for some thresholds of the band only, a walker not in steady state, a band left)
+         // redoes the tile with the sequential walk below: the result is the reference's either way.
+         bool done_par = false;
+         if (par_mode) {
+            const long long tile_end = tile0 + tn;
+            const long long limit = stop < tile_end ? stop : tile_end;
+            const int lim = (int)(limit - tile0);
+            const bool whole = stop >= tile_end;
+            const float lsb = cfg.lsb_per_volt;
+            if (threadIdx.x == 0) s_seq = 0;
+            __syncthreads();
+            int my_st = 0, my_nruns = 0;
+            if (is_walker) {
+               const DevParm &P = cfg.parm[pidx];
+               my_st = P.screen * ntrks + trk; my_nruns = s_dir[my_st].nruns;
+               bool ok = w.fast && tile0 - kScreenHalo >= w.trust_from && whole && s_dir[my_st].end_ld != 0
+                         && w.peakcount >= 16 && w.v_avg_height_count == 0 && w.agc_gain > 0 && w.nevents + (unsigned)cfg.rec_cap16 < cx.cap;
+               if (ok) {
+                  const float s4 = w.v_avg_height * 0.25f * fast_rcp(w.agc_gain);
+                  const float rv = P.rise * s4, mv4 = P.min_peak * s4;
+                  if (rv < P.screen_rise_v * 1.25f || (P.min_peak != 0 && mv4 < P.screen_minpk_v * 1.25f)) ok = false;   // near the screen's own thresholds
+                  band[my_w * 4 + 0] = (int)(rv * lsb * 0.875f) - 4; band[my_w * 4 + 1] = (int)(rv * lsb * 1.125f) + 5;
+                  band[my_w * 4 + 2] = P.min_peak != 0 ? (int)(mv4 * lsb * 0.875f) - 4 : -1;
+                  band[my_w * 4 + 3] = (int)(mv4 * lsb * 1.125f) + 5;
+                  wst[my_w * 4 + 0] = w.v_lasttop; wst[my_w * 4 + 1] = w.v_lastbot; wst[my_w * 4 + 2] = w.v_avg_height; wst[my_w * 4 + 3] = P.agc_alpha; }
+               if (!ok) atomicOr(&s_seq, 1u);
+               hoff[my_w] = my_nruns; }                                       // (hoff doubles as scratch for the scan)
+            __syncthreads();
+            if (!s_seq && is_walker) {                                        // exclusive scan, every walker lane for itself
+               int o = 0;
+               for (int w2 = 0; w2 < my_w; ++w2) o += hoff[w2];
+               pmoff[my_w] = o;
+               if (my_w == nwalk - 1) { pmoff[nwalk] = o + my_nruns; if (o + my_nruns > kPassMaskCap) atomicOr(&s_seq, 1u); }
+               if (o + my_nruns <= kPassMaskCap) for (int r = 0; r < my_nruns; ++r) pmmap[o + r] = (unsigned char)my_w; }
+            __syncthreads();
+            if (!s_seq) {
+               // ---- (1) all lanes: the pass mask of every (walker, run) ----
+               const int total = pmoff[nwalk];
+               for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+                  const int w2 = pmmap[idx];
+                  const int r = idx - pmoff[w2];
+                  const int p2 = w2 / ntrks, st2 = cfg.parm[p2].screen * ntrks + (w2 - p2 * ntrks);
+                  const int4 *lst = units + s_off[st2];
+                  const int4 A = lst[r];
+                  const int nr = (A.x >> 11) & 0x3f, ld0 = (A.y >> 16) & 0xff;
+                  const bool is_top = ((A.x >> 17) & 1) == 0;
+                  const int m = (int)(short)(A.y & 0xffff);
+                  const int lo = band[w2 * 4], hi = band[w2 * 4 + 1], mlo = band[w2 * 4 + 2], mhi = band[w2 * 4 + 3];
+                  int ks = 0, km = 0;                                          // (last sure row + 1), (last possible row + 1)
+                  bool doubt = ld0 == 0, pk = true;
+                  if (mlo >= 0) { const int a = is_top ? m : -m; if (a <= mlo) pk = false; else if (a < mhi) doubt = true; }
+                  if (pk && !doubt) {
+                     const int4 *mg4 = lst + s_dir[st2].nruns + (int)((unsigned)A.x >> 18);
+                     int4 M = make_int4(0, 0, 0, 0);
+                     #pragma nounroll
+                     for (int k = 0; k < nr; ++k) {
+                        int pr;
+                        if (k == 0) pr = A.w;
+                        else {
+                           const int c = (k - 1) & 3;
+                           if (c == 0) M = mg4[(k - 1) >> 2];
+                           pr = c == 0 ? M.x : (c == 1 ? M.y : (c == 2 ? M.z : M.w)); }
+                        const int mg = min(pr & 0xffff, (int)((unsigned)pr >> 16));
+                        if (mg >= hi) ks = k + 1;
+                        if (mg > lo) km = k + 1; } }
+                  if (doubt) km = 255;                                         // undecidable here whatever the countdown
+                  pm[idx] = (unsigned short)(ks | (km << 8)); } }
+            __syncthreads();
+            int nh = 0, last_blind = -1;
+            if (!s_seq) {
+               // ---- (2) one lane per walker: the countdown chain over the pass masks -> this tile's detections ----
+               if (is_walker) {
+                  long long n64 = max(w.next, w.blind_until + 1);
+                  int cur = (n64 - tile0 > lim) ? lim : (int)(n64 - tile0);
+                  if (cur < 0) cur = 0;
+                  const int2 *lst = reinterpret_cast<const int2 *>(units + s_off[my_st]);
+                  unsigned int *hits = reinterpret_cast<unsigned int *>(recs_all + (size_t)my_w * rstride);      // 16-byte slots: rk, v, a, gain before
+                  const unsigned short *mypm = pm + pmoff[my_w];
+                  #pragma nounroll
+                  for (int r = 0; r < my_nruns; ++r) {
+                     const int2 A = lst[2 * r];
+                     const int n_s = A.x & 0x7ff, nr = (A.x >> 11) & 0x3f;
+                     const int k0 = cur > n_s ? cur - n_s : 0;
+                     if (k0 >= nr) continue;
+                     const int v2 = mypm[r];
+                     if ((v2 & 0xff) <= k0) {                               // no sure row ahead of the countdown
+                        if ((v2 >> 8) > k0) { atomicOr(&s_seq, 1u); break; }   // ... but a possible one: undecidable here
+                        continue; }
+                     if (nh >= cfg.rec_cap16) { atomicOr(&s_seq, 1u); break; }
+                     hits[nh * 4] = (unsigned)r | ((unsigned)k0 << 16) | ((unsigned)((A.x >> 17) & 1) << 31);
+                     ++nh;
+                     last_blind = n_s + ((A.y >> 16) & 0xff);               // row n + left_distance, whichever row of the run fires
+                     cur = last_blind + 1; }
+                  nrec_all[my_w] = nh; } }
+            __syncthreads();
+            if (!s_seq && is_walker) {
+               int o = 0;
+               for (int w2 = 0; w2 < my_w; ++w2) o += nrec_all[w2];
+               hoff[my_w] = o;
+               if (my_w == nwalk - 1) hoff[nwalk] = o + nh;
+               for (int j = 0; j < nh; ++j) hmap[o + j] = (unsigned char)my_w; }
+            __syncthreads();
+            if (!s_seq) {
+               // ---- (3a) all lanes: volt() of every detection ----
+               const int total = hoff[nwalk];
+               for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+                  const int w2 = hmap[idx];
+                  const int p2 = w2 / ntrks, st2 = cfg.parm[p2].screen * ntrks + (w2 - p2 * ntrks);
+                  unsigned int *slot = reinterpret_cast<unsigned int *>(recs_all + (size_t)w2 * rstride) + 4 * (idx - hoff[w2]);
+                  const int r = (int)(slot[0] & 0xffff);
+                  const int m = (int)(short)(units[s_off[st2] + r].y & 0xffff);
+                  slot[1] = __float_as_uint(volt(m, cfg.maxvolts)); } }
+            __syncthreads();
+            if (!s_seq) {
+               // ---- (3b) all lanes: what adjust_agc (src/decoder.c:500-531) will blend in at every detection ----
+               const int total = hoff[nwalk];
+               for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+                  const int w2 = hmap[idx];
+                  const int j = idx - hoff[w2];
+                  unsigned int *base = reinterpret_cast<unsigned int *>(recs_all + (size_t)w2 * rstride);
+                  float vt = wst[w2 * 4 + 0], vb = wst[w2 * 4 + 1];                  // v_lasttop / v_lastbot as of this detection
+                  bool ft = false, fb = false;
+                  #pragma nounroll
+                  for (int jj = j - 1; jj >= 0 && !(ft && fb); --jj) {
+                     const bool bot = base[4 * jj] >> 31;
+                     if (bot && !fb) { vb = __uint_as_float(base[4 * jj + 1]); fb = true; }
+                     if (!bot && !ft) { vt = __uint_as_float(base[4 * jj + 1]); ft = true; } }
+                  const float lastheight = vt - vb;
+                  float a = -1.0f;
+                  if (lastheight > 0) { const float gq = wst[w2 * 4 + 2] / lastheight; a = wst[w2 * 4 + 3] * gq; }
+                  base[4 * j + 2] = __float_as_uint(a); } }
+            __syncthreads();
+            float g_end = 0, vt_last = 0, vb_last = 0;
+            bool any_t = false, any_b = false;
+            if (!s_seq && is_walker) {
+               // ---- (4) one lane per walker: the gain recurrence; did every threshold stay inside the bands? ----
+               const DevParm &P = cfg.parm[pidx];
+               unsigned int *hits = reinterpret_cast<unsigned int *>(recs_all + (size_t)my_w * rstride);
+               const float c1 = 1 - P.agc_alpha;
+               float g = w.agc_gain, gmin = g, gmax = g;
+               #pragma nounroll
+               for (int j = 0; j < nh; ++j) {
+                  const uint2 q = *reinterpret_cast<const uint2 *>(hits + 4 * j + 1);       // v, a
+                  hits[4 * j + 3] = __float_as_uint(g);
+                  const float a = __uint_as_float(q.y);
+                  if (a >= 0) { g = a + c1 * g; if (g > 2.0f) g = 2.0f; }
+                  gmin = fminf(gmin, g); gmax = fmaxf(gmax, g);
+                  if (hits[4 * j] >> 31) { vb_last = __uint_as_float(q.x); any_b = true; } else { vt_last = __uint_as_float(q.x); any_t = true; } }
+               g_end = g;
+               const float s_hi = w.v_avg_height * 0.25f * fast_rcp(gmin), s_lo = w.v_avg_height * 0.25f * fast_rcp(gmax);
+               bool ok = gmin > 0 && (int)(P.rise * s_hi * lsb) + 4 <= band[my_w * 4 + 1] && (int)(P.rise * s_lo * lsb) - 3 >= band[my_w * 4 + 0]
+                         && P.rise * s_lo >= P.screen_rise_v * 1.01f;
+                if (P.min_peak != 0) ok = ok && (int)(P.min_peak * s_hi * lsb) + 4 <= band[my_w * 4 + 3] && (int)(P.min_peak * s_lo * lsb) - 3 >= band[my_w * 4 + 2]
+                                          && P.min_peak * s_lo >= P.screen_minpk_v * 1.01f;
+               if (!ok) atomicOr(&s_seq, 1u); }
+            __syncthreads();
+            if (!s_seq) {
+               // ---- (5) all lanes: the events; walker lanes: the state after the tile ----
+               const int total = hoff[nwalk];
+               for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+                  const int w2 = hmap[idx];
+                  const int j = idx - hoff[w2];
+                  const int p2 = w2 / ntrks, t2 = w2 - p2 * ntrks, st2 = cfg.parm[p2].screen * ntrks + t2;
+                  const uint4 sl = *reinterpret_cast<const uint4 *>(recs_all + (size_t)w2 * rstride + 16 * j);
+                  const int r = (int)(sl.x & 0xffff), k0 = (int)((sl.x >> 16) & 0x3f);
+                  const bool is_top = !(sl.x >> 31);
+                  const int4 *lst = units + s_off[st2];
+                  const int4 A = lst[r];
+                  const int nr = (A.x >> 11) & 0x3f, m = (int)(short)(A.y & 0xffff);
+                  const float gb = __uint_as_float(sl.w);
+                  // the thresholds in effect at this detection (src/decoder.c:785-786), and the first row from k0 on that passes
+                  const DevParm &P2 = cfg.parm[p2];
+                  const float rise = P2.rise * (wst[w2 * 4 + 2] / 4.0f) / gb;
+                  const int ri = (int)floorf(rise * lsb);
+                  const int4 *mg4 = lst + s_dir[st2].nruns + (int)((unsigned)A.x >> 18);
+                  int k = k0;
+                  #pragma nounroll
+                  for (; k < nr - 1; ++k) {
+                     const int pr = k == 0 ? A.w : reinterpret_cast<const int *>(mg4)[k - 1];
+                     const int dl = pr & 0xffff, dr = (int)((unsigned)pr >> 16);
+                     const int mg = min(dl, dr);
+                     if (mg <= ri - 1) continue;
+                     if (mg >= ri + 2) break;
+                     const float vm = volt(m, cfg.maxvolts);
+                     const float vl = volt(is_top ? m - dl : m + dl, cfg.maxvolts), vr = volt(is_top ? m - dr : m + dr, cfg.maxvolts);
+                     if (is_top ? (vm > vl + rise && vm > vr + rise) : (vm < vl - rise && vm < vr - rise)) break; }
+                  const int n = (A.x & 0x7ff) + k, ld = ((A.y >> 16) & 0xff) - k;
+                  const int adjcode = refine_code(&cfg, m, (int)(short)(A.z & 0xffff), A.z >> 16, gb, is_top);
+                  store_event(cx, p2, t2, (unsigned)(idx0_all[w2] + j), tile0 + n, __uint_as_float(sl.y), gb, is_top, adjcode, ld); }
+               if (is_walker) {
+                  const DevParm &P = cfg.parm[pidx];
+                  if (nh > 0) {
+                     if (any_t) { w.v_top = vt_last; w.v_lasttop = vt_last; }
+                     if (any_b) { w.v_bot = vb_last; w.v_lastbot = vb_last; }
+                     w.peakcount += nh; w.nevents += (unsigned)nh; w.agc_gain = g_end; w.t_lastpeak = 0;
+                     w.blind_until = tile0 + last_blind;
+                     if (!approx_thresholds(w, P, lsb)) update_thresholds(w, P, lsb); }
+                  w.next = limit;
+                  if (whole) {
+                     const int last = (int)tn - 1;
+                     w.minv = s_dir[my_st].end_min; w.cpos = tile0 + last; w.qtrig = tile0 + last + s_dir[my_st].end_ld; w.chain_pending = false; } }
+               done_par = true; }
+            if (cfg.debug && threadIdx.x == 0) atomicAdd(&scratch->why[done_par ? 0 : 1], 1ull); }
+         if (done_par) {
+            if (cfg.debug) { const long long t4 = clock64(); acc0 += t1 - t0; acc1 += t2 - t1; acc2 += t4 - t2; ++ntl; }
+            continue; }
+         // ================= sequential walk =================
+         cx.nrec = 0;
          Walker w0;
          load_walk_fields(w0, w);
          if (is_walker) {

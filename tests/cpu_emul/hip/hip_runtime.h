@@ -26,6 +26,9 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct int4 { int x, y, z, w; };
+struct int2 { int x, y; };
+struct uint2 { unsigned int x, y; };
+struct uint4 { unsigned int x, y, z, w; };
 inline int4 make_int4(int a, int b, int c, int d) { int4 r = {a, b, c, d}; return r; }
 extern thread_local dim3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
