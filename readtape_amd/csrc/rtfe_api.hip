@@ -142,6 +142,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       d.tile_rows = tr; }
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
+   d.cut = getenv("RTFE_CUT") ? atoi(getenv("RTFE_CUT")) : 0;
    {
       const int nwalk = c->nparmsets * c->ntrks;
       int rc = (24 * 1024) / (nwalk * 24);

@@ -53,6 +53,7 @@ struct DevCfg {
    int   rec_cap16;               // deferred detections per walker per tile of k_walk (LDS)
    int   lds_units;               // candidate units of ONE tile (all lists, packed) that fit the LDS of the sequential pass
    int   debug;                   // RTFE_DEBUG=1: per-phase cycle counters in the workspace (tools/ only)
+   int   cut;                     // RTFE_CUT: k_screen stops after a phase (timing experiments, tools/ only; results are then garbage)
    DevParm   parm[RTFE_MAXPARMSETS];
    DevScreen screen[kMaxScreens];
 };

@@ -803,15 +803,14 @@ __device__ __forceinline__ void run_starts(const Tile &tl, int screen, int trk, 
    // bit j+1 of t9/b9 = row r0+j, bit 0 = the row in front of the strip (never a predecessor at the tile's first row)
    const unsigned t9 = (t << 1) | (strip > 0 ? (row[-1] >> 7) & 1u : 0u), b9 = (b << 1) | (strip > 0 ? (row[ntb - 1] >> 7) & 1u : 0u);
    const unsigned ot = t9 & ~b9, ob = b9 & ~t9;                     // single-kind rows
-   unsigned st = 0, sb = 0;
-   if (t | b) {
+   unsigned st = t, sb = b;                                         // a candidate row starts a run unless it continues one
+   unsigned ct = (ot >> 1) & ot & 0xffu, cb = (ob >> 1) & ob & 0xffu;    // bit j: rows r0+j-1 and r0+j are single-kind candidates
+   if (ct | cb) {
       const unsigned char *ldt = tl.ldmap(screen, 0, trk) + r0, *ldb = tl.ldmap(screen, 1, trk) + r0;
-      #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-         const bool ct = ((ot >> j) & (ot >> (j + 1)) & 1) && ldt[j] != 0 && ldt[j] == ldt[j - 1] - 1;
-         const bool cb = ((ob >> j) & (ob >> (j + 1)) & 1) && ldb[j] != 0 && ldb[j] == ldb[j - 1] - 1;
-         st |= (unsigned)(((t >> j) & 1) && !ct) << j;
-         sb |= (unsigned)(((b >> j) & 1) && !cb) << j; } }
+      #pragma nounroll
+      while (ct) { const int j = __ffs((int)ct) - 1; ct &= ct - 1; if (ldt[j] != 0 && ldt[j] == ldt[j - 1] - 1) st &= ~(1u << j); }
+      #pragma nounroll
+      while (cb) { const int j = __ffs((int)cb) - 1; cb &= cb - 1; if (ldb[j] != 0 && ldb[j] == ldb[j - 1] - 1) sb &= ~(1u << j); } }
    row[3 * ntb] = (unsigned char)st;
    row[4 * ntb] = (unsigned char)sb; }
 
@@ -871,6 +870,12 @@ __device__ __forceinline__ void build_run(const Tile &tl, const DevCfg *cfg, int
          const int c = (jj - 1) & 3;
          if (c == 0) u.x = pr; else if (c == 1) u.y = pr; else if (c == 2) u.z = pr; else u.w = pr;
          if (c == 3 || jj == nr - 1) { marg[slot++] = u; u = make_int4(0, 0, 0, 0); } } } }
+
+// i / n for the item loops (n fixed per tile, i < 2^24): one multiply instead of an integer division
+struct FastDiv {
+   unsigned n, M;
+   __device__ __forceinline__ explicit FastDiv(int d) : n((unsigned)d), M(d > 1 ? 0xFFFFFFFFu / (unsigned)d + 1u : 0u) {}
+   __device__ __forceinline__ int div(int i) const { return n > 1 ? (int)__umulhi((unsigned)i, M) : i; } };
 
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
@@ -968,9 +973,11 @@ __device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl, b
    const int hs = with_halo ? kScreenHalo / kStrip : 0;            // k_screen also screens the rows in front of the tile
    const int nstrips = (tl.nrows + kStrip - 1) / kStrip + hs;
    const int per_screen = nstrips * cfg->ntrks;
+   const FastDiv fd(nstrips);
    for (int s = 0; s < cfg->nscreens; ++s)
-      for (int i = threadIdx.x; i < per_screen; i += blockDim.x)
-         screen_strip(tl, cfg->screen[s], s, i / nstrips, i - (i / nstrips) * nstrips - hs); }
+      for (int i = threadIdx.x; i < per_screen; i += blockDim.x) {
+         const int t = fd.div(i);
+         screen_strip(tl, cfg->screen[s], s, t, i - t * nstrips - hs); } }
 
 // restart row for the zone whose last kMarginRows rows are the current tile:
 // for every parameter set and track take the last forced rescan inside the zone; any restart at or
@@ -1192,28 +1199,30 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
       load_tile(&cfg, tl, rows, nrows);
       __syncthreads();
       if (cfg.debug) k1 = clock64();
-      if (cfg.debug & 4) continue;
+      if (cfg.cut == 1) continue;
       run_screens(&cfg, tl, true);
       __syncthreads();
       if (cfg.debug) k2 = clock64();
-      if (cfg.debug & 8) continue;
+      if (cfg.cut == 2) continue;
       const int nstrips = (tl.nrows + kStrip - 1) / kStrip;
       const int smax = cfg.tile_rows / kStrip;
       if (threadIdx.x == 0) s_nruns = 0;
+      const FastDiv fds(nstrips), fdt(ntrks);
       for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {      // the reference's minimum at the bottom candidates
-         const int st = i / nstrips, sc = st / ntrks;
+         const int st = fds.div(i), sc = fdt.div(st);
          fill_stale(tl, sc, st - sc * ntrks, i - st * nstrips); }
       __syncthreads();
+      if (cfg.cut == 3) continue;
       long long k2a = 0, k2b = 0;
       if (cfg.debug) k2a = clock64();
       for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {
-         const int st = i / nstrips, sc = st / ntrks;
+         const int st = fds.div(i), sc = fdt.div(st);
          run_starts(tl, sc, st - sc * ntrks, i - st * nstrips); }
       __syncthreads();
       if (cfg.debug) k2b = clock64();
-      if (cfg.debug & 16) continue;
+      if (cfg.cut == 4) continue;
       for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {
-         const int st = i / nstrips, sc = st / ntrks, strip = i - st * nstrips;
+         const int st = fds.div(i), sc = fdt.div(st), strip = i - st * nstrips;
          stripcnt[st * smax + strip] = (unsigned int)list_runs(tl, st, sc, st - sc * ntrks, strip, runtab, &s_nruns, tabcap); }
       __syncthreads();
       // exclusive scan of the strips' unit counts, list by list (one wave per list at a time)
@@ -1231,7 +1240,7 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
             if (lane == 0) s_total[st] = carry; } }
       __syncthreads();
       if (cfg.debug) k3 = clock64();
-      if (cfg.debug & 32) continue;
+      if (cfg.cut == 5) continue;
       int tile_units = 0;
       for (int s2 = 0; s2 < nst; ++s2) tile_units += (s_total[s2] & 0xffff) + (s_total[s2] >> 16);
       const bool tab_ok = s_nruns <= tabcap && tile_units <= nst * cfg.run_cap;
@@ -1240,7 +1249,7 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
             const u64 d = runtab[r];
             const int st = (int)(d & 0xff), kind = (int)((d >> 8) & 1), n = (int)((d >> 16) & 0xffff), nr = (int)((d >> 32) & 0xff);
             const int relrun = (int)((d >> 40) & 0x3ff), relmarg = (int)(d >> 50);
-            const int sc = st / ntrks;
+            const int sc = fdt.div(st);
             const unsigned sb = stripcnt[st * smax + (n >> 3)];
             int lbase = 0;
             for (int s2 = 0; s2 < st; ++s2) lbase += (s_total[s2] & 0xffff) + (s_total[s2] >> 16);     // the tile's lists are packed one behind the other

@@ -92,6 +92,7 @@ inline unsigned int __float_as_uint(float f) { unsigned int u; memcpy(&u, &f, 4)
 inline float __uint_as_float(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
+inline unsigned int __umulhi(unsigned int a, unsigned int b) { return (unsigned int)(((unsigned long long)a * b) >> 32); }
 inline int __popc(unsigned int v) { return __builtin_popcount(v); }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
