@@ -148,13 +148,20 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       int rc = (24 * 1024) / (nwalk * 24);
       d.rec_cap = rc > 64 ? 64 : (rc < 8 ? 8 : rc);
       d.run_cap = d.tile_rows / 2 < 64 ? 64 : d.tile_rows / 2;
-      // LDS of the sequential pass: room for a typical tile's lists (a quarter of the worst case, at most 24 KiB);
-      // a tile with more candidates than that is decided from its samples instead
-      int lu = d.nscreens * c->ntrks * d.run_cap / 2;
+      // LDS of k_walk, sized for a typical tile (its lists go through LDS in groups, so a dense tile only costs time):
+      // peaks per track per tile from the bit cell, ~4.75 units per run of W<=13 rows plus as much again for runs that
+      // do not fire; detections per walker per tile bounded by the peak count
+      const float spbf = 1.0f / (c->bpi * c->ips * d.sample_deltat);
+      const float ppb = c->mode == RTFE_PE ? 1.5f : 0.6f;                 // flux transitions per bit cell, typical
+      int peaks = (int)((float)d.tile_rows / (spbf > 1 ? spbf : 1) * ppb) + 4;
+      int lu = (int)((float)(d.nscreens * c->ntrks) * (float)peaks * 3.2f);
+      if (lu < d.run_cap) lu = d.run_cap;                               // one list always fits
       if (lu > 1536) lu = 1536;
-      if (lu < 256) lu = 256;
-      d.lds_units = lu;
-      int r16 = (12 * 1024) / (nwalk * 16);
+      d.lds_units = (lu + 63) & ~63;
+      d.pm_cap = d.lds_units / 2 * ((c->nparmsets + d.nscreens - 1) / d.nscreens);
+      int r16 = 2 * peaks + 8;
+      const int r16max = (16 * 1024) / (nwalk * 16);
+      if (r16 > r16max) r16 = r16max;
       d.rec_cap16 = r16 > 64 ? 64 : (r16 < 8 ? 8 : r16); }
    h->lds_bytes = (int)lds_layout(d, true).total + 64;
    h->screen_lds_bytes = (int)lds_layout(d, false).total + 64;

@@ -51,6 +51,7 @@ struct DevCfg {
    int   run_cap;                 // candidate-run records per (screen, track) per tile (LDS)
    int   rec_cap;                 // deferred-event records per walker per tile (LDS)
    int   rec_cap16;               // deferred detections per walker per tile of k_walk (LDS)
+   int   pm_cap;                  // (walker, run) verdict slots of one tile of k_walk's parallel path (LDS)
    int   lds_units;               // candidate units of ONE tile (all lists, packed) that fit the LDS of the sequential pass
    int   debug;                   // RTFE_DEBUG=1: per-phase cycle counters in the workspace (tools/ only)
    int   cut;                     // RTFE_CUT: k_screen stops after a phase (timing experiments, tools/ only; results are then garbage)

@@ -1139,7 +1139,6 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    return L; }
 
 struct WalkLds { unsigned units, heights, heights_bak, recs, nrec, idx0, band, pmoff, hoff, wst, pm, pmmap, hmap, total; };
-constexpr int kPassMaskCap = 2048;      // (walker, run) verdicts of one tile in k_walk's parallel path
 __host__ __device__ inline WalkLds lds_layout_walk(const DevCfg &c) {
    WalkLds L;
    const unsigned nwalk = (unsigned)(c.nparm * c.ntrks);
@@ -1154,8 +1153,8 @@ __host__ __device__ inline WalkLds lds_layout_walk(const DevCfg &c) {
    L.pmoff = off;        off = lds_align16(off + (nwalk + 1) * 4u);
    L.hoff = off;         off = lds_align16(off + (nwalk + 1) * 4u);
    L.wst = off;          off = lds_align16(off + nwalk * 16u);
-   L.pm = off;           off = lds_align16(off + (unsigned)kPassMaskCap * 2u);
-   L.pmmap = off;        off = lds_align16(off + (unsigned)kPassMaskCap);
+   L.pm = off;           off = lds_align16(off + (unsigned)c.pm_cap * 2u);
+   L.pmmap = off;        off = lds_align16(off + (unsigned)c.pm_cap);
    L.hmap = off;         off = lds_align16(off + nwalk * (unsigned)c.rec_cap16);
    L.total = off;
    return L; }
@@ -1322,8 +1321,8 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
    int *pmoff = reinterpret_cast<int *>(smem + L.pmoff);            // [nwalk + 1]
    int *hoff = reinterpret_cast<int *>(smem + L.hoff);              // [nwalk + 1]
    float *wst = reinterpret_cast<float *>(smem + L.wst);            // [nwalk][4] v_lasttop, v_lastbot, v_avg_height, alpha
-   unsigned short *pm = reinterpret_cast<unsigned short *>(smem + L.pm);     // [kPassMaskCap] last sure row + 1 | (last possible row + 1) << 8
-   unsigned char *pmmap = smem + L.pmmap;                           // [kPassMaskCap] walker of a verdict slot
+   unsigned short *pm = reinterpret_cast<unsigned short *>(smem + L.pm);     // [pm_cap] last sure row + 1 | (last possible row + 1) << 8
+   unsigned char *pmmap = smem + L.pmmap;                           // [pm_cap] walker of a verdict slot
    unsigned char *hmap = smem + L.hmap;                             // [nwalk * rec_cap16] walker of a detection slot
    __shared__ unsigned int s_seq;
    // the parallel tile path covers the alpha-filter AGC (NRZI / GCR parameter sets); everything else walks sequentially
@@ -1374,17 +1373,26 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
          if (threadIdx.x == 0) s_needfull = 0;
          if (threadIdx.x < nst) s_dir[threadIdx.x] = dir[g * nst + threadIdx.x];
          __syncthreads();
-         if (threadIdx.x <= nst) {                                  // where each list goes in LDS (packed)
+         if (threadIdx.x <= nst) {                                  // where each list starts inside the tile's slot of the pool
             int o = 0; bool bad = false;
             for (int st = 0; st < (int)threadIdx.x; ++st) { if (s_dir[st].count == 0xFFFF) bad = true; o += s_dir[st].count; }
             s_off[threadIdx.x] = bad ? (1 << 30) : o; }
          __syncthreads();
-         if (s_off[nst] > cfg.lds_units) { give_back = true; break; }
+         if (s_off[nst] >= (1 << 30)) { give_back = true; break; }
          if (cfg.debug) t1 = clock64();
+         // the lists go through LDS in groups of consecutive lists that fit (usually one group = the whole tile); the
+         // walkers are independent of each other, so each group is walked to the end of the tile before the next
+         for (int st_lo = 0, st_hi; st_lo < nst && !give_back; st_lo = st_hi) {
+         st_hi = st_lo + 1;
+         while (st_hi < nst && s_off[st_hi + 1] - s_off[st_lo] <= cfg.lds_units) ++st_hi;
+         const int gbase = s_off[st_lo];
+         const int my_st0 = cfg.parm[pidx].screen * ntrks + trk;
+         const bool active = is_walker && my_st0 >= st_lo && my_st0 < st_hi;
+         __syncthreads();
          {
             // the tile's lists are contiguous in the pool: independent 16-byte loads, eight in flight per lane
-            const int4 *src = reinterpret_cast<const int4 *>(pool) + (size_t)g * nst * cfg.run_cap;
-            const int total = s_off[nst];
+            const int4 *src = reinterpret_cast<const int4 *>(pool) + (size_t)g * nst * cfg.run_cap + gbase;
+            const int total = s_off[st_hi] - gbase;
             for (int i0 = threadIdx.x; i0 < total; i0 += 8 * (int)blockDim.x) {
                int4 q0, q1, q2, q3, q4, q5, q6, q7;
                const int bd = (int)blockDim.x;
@@ -1431,9 +1439,10 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
             if (threadIdx.x == 0) s_seq = 0;
             __syncthreads();
             int my_st = 0, my_nruns = 0;
-            if (is_walker) {
+            if (is_walker) hoff[my_w] = 0;
+            if (active) {
                const DevParm &P = cfg.parm[pidx];
-               my_st = P.screen * ntrks + trk; my_nruns = s_dir[my_st].nruns;
+               my_st = my_st0; my_nruns = s_dir[my_st].nruns;
                bool ok = w.fast && tile0 - kScreenHalo >= w.trust_from && whole && s_dir[my_st].end_ld != 0
                          && w.peakcount >= 16 && w.v_avg_height_count == 0 && w.agc_gain > 0 && w.nevents + (unsigned)cfg.rec_cap16 < cx.cap;
                if (ok) {
@@ -1447,12 +1456,12 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                if (!ok) atomicOr(&s_seq, 1u);
                hoff[my_w] = my_nruns; }                                       // (hoff doubles as scratch for the scan)
             __syncthreads();
-            if (!s_seq && is_walker) {                                        // exclusive scan, every walker lane for itself
+            if (!s_seq && is_walker) {                                        // exclusive scan, every walker lane for itself (idle walkers: 0 runs)
                int o = 0;
                for (int w2 = 0; w2 < my_w; ++w2) o += hoff[w2];
                pmoff[my_w] = o;
-               if (my_w == nwalk - 1) { pmoff[nwalk] = o + my_nruns; if (o + my_nruns > kPassMaskCap) atomicOr(&s_seq, 1u); }
-               if (o + my_nruns <= kPassMaskCap) for (int r = 0; r < my_nruns; ++r) pmmap[o + r] = (unsigned char)my_w; }
+               if (my_w == nwalk - 1) { pmoff[nwalk] = o + my_nruns; if (o + my_nruns > cfg.pm_cap) atomicOr(&s_seq, 1u); }
+               if (o + my_nruns <= cfg.pm_cap) for (int r = 0; r < my_nruns; ++r) pmmap[o + r] = (unsigned char)my_w; }
             __syncthreads();
             if (!s_seq) {
                // ---- (1) all lanes: the pass mask of every (walker, run) ----
@@ -1461,7 +1470,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                   const int w2 = pmmap[idx];
                   const int r = idx - pmoff[w2];
                   const int p2 = w2 / ntrks, st2 = cfg.parm[p2].screen * ntrks + (w2 - p2 * ntrks);
-                  const int4 *lst = units + s_off[st2];
+                  const int4 *lst = units + (s_off[st2] - gbase);
                   const int4 A = lst[r];
                   const int nr = (A.x >> 11) & 0x3f, ld0 = (A.y >> 16) & 0xff;
                   const bool is_top = ((A.x >> 17) & 1) == 0;
@@ -1490,11 +1499,12 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
             int nh = 0, last_blind = -1;
             if (!s_seq) {
                // ---- (2) one lane per walker: the countdown chain over the pass masks -> this tile's detections ----
-               if (is_walker) {
+               if (is_walker) nrec_all[my_w] = 0;
+               if (active) {
                   long long n64 = max(w.next, w.blind_until + 1);
                   int cur = (n64 - tile0 > lim) ? lim : (int)(n64 - tile0);
                   if (cur < 0) cur = 0;
-                  const int2 *lst = reinterpret_cast<const int2 *>(units + s_off[my_st]);
+                  const int2 *lst = reinterpret_cast<const int2 *>(units + (s_off[my_st] - gbase));
                   unsigned int *hits = reinterpret_cast<unsigned int *>(recs_all + (size_t)my_w * rstride);      // 16-byte slots: rk, v, a, gain before
                   const unsigned short *mypm = pm + pmoff[my_w];
                   #pragma nounroll
@@ -1529,7 +1539,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                   const int p2 = w2 / ntrks, st2 = cfg.parm[p2].screen * ntrks + (w2 - p2 * ntrks);
                   unsigned int *slot = reinterpret_cast<unsigned int *>(recs_all + (size_t)w2 * rstride) + 4 * (idx - hoff[w2]);
                   const int r = (int)(slot[0] & 0xffff);
-                  const int m = (int)(short)(units[s_off[st2] + r].y & 0xffff);
+                  const int m = (int)(short)(units[s_off[st2] - gbase + r].y & 0xffff);
                   slot[1] = __float_as_uint(volt(m, cfg.maxvolts)); } }
             __syncthreads();
             if (!s_seq) {
@@ -1553,7 +1563,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
             __syncthreads();
             float g_end = 0, vt_last = 0, vb_last = 0;
             bool any_t = false, any_b = false;
-            if (!s_seq && is_walker) {
+            if (!s_seq && active) {
                // ---- (4) one lane per walker: the gain recurrence; did every threshold stay inside the bands? ----
                const DevParm &P = cfg.parm[pidx];
                unsigned int *hits = reinterpret_cast<unsigned int *>(recs_all + (size_t)my_w * rstride);
@@ -1585,7 +1595,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                   const uint4 sl = *reinterpret_cast<const uint4 *>(recs_all + (size_t)w2 * rstride + 16 * j);
                   const int r = (int)(sl.x & 0xffff), k0 = (int)((sl.x >> 16) & 0x3f);
                   const bool is_top = !(sl.x >> 31);
-                  const int4 *lst = units + s_off[st2];
+                  const int4 *lst = units + (s_off[st2] - gbase);
                   const int4 A = lst[r];
                   const int nr = (A.x >> 11) & 0x3f, m = (int)(short)(A.y & 0xffff);
                   const float gb = __uint_as_float(sl.w);
@@ -1608,7 +1618,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                   const int n = (A.x & 0x7ff) + k, ld = ((A.y >> 16) & 0xff) - k;
                   const int adjcode = refine_code(&cfg, m, (int)(short)(A.z & 0xffff), A.z >> 16, gb, is_top);
                   store_event(cx, p2, t2, (unsigned)(idx0_all[w2] + j), tile0 + n, __uint_as_float(sl.y), gb, is_top, adjcode, ld); }
-               if (is_walker) {
+               if (active) {
                   const DevParm &P = cfg.parm[pidx];
                   if (nh > 0) {
                      if (any_t) { w.v_top = vt_last; w.v_lasttop = vt_last; }
@@ -1624,28 +1634,30 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
             if (cfg.debug && threadIdx.x == 0) atomicAdd(&scratch->why[done_par ? 0 : 1], 1ull); }
          if (done_par) {
             if (cfg.debug) { const long long t4 = clock64(); acc0 += t1 - t0; acc1 += t2 - t1; acc2 += t4 - t2; ++ntl; }
-            continue; }
+            continue; }                                               // next group of lists / next tile
          // ================= sequential walk =================
          cx.nrec = 0;
          Walker w0;
          load_walk_fields(w0, w);
-         if (is_walker) {
-            const int st = cfg.parm[pidx].screen * ntrks + trk;
+         if (is_walker) nrec_all[my_w] = 0;
+         if (active) {
+            const int st = my_st0;
             for (int i = 0; i < 10; ++i) heights_bak[my_w * 10 + i] = cx.heights[i];
             int why = 0;
-            if (!walk_records(w, cx, pidx, trk, stop, reinterpret_cast<const CandUnit *>(units + s_off[st]), s_dir[st].nruns, s_dir[st], why))
+            if (!walk_records(w, cx, pidx, trk, stop, reinterpret_cast<const CandUnit *>(units + (s_off[st] - gbase)), s_dir[st].nruns, s_dir[st], why))
                atomicOr((unsigned int *)&s_needfull, 1u);
             nrec_all[my_w] = cx.nrec; }
          __syncthreads();
          if (cfg.debug) t3 = clock64();
          if (s_needfull) {
-            if (is_walker) { load_walk_fields(w, w0); for (int i = 0; i < 10; ++i) cx.heights[i] = heights_bak[my_w * 10 + i]; }
+            if (active) { load_walk_fields(w, w0); for (int i = 0; i < 10; ++i) cx.heights[i] = heights_bak[my_w * 10 + i]; }
             give_back = true;
             break; }
          if (threadIdx.x == 0) { int o = 0; for (int w2 = 0; w2 < nwalk; ++w2) { const int c = nrec_all[w2]; nrec_all[w2] = o; o += c; } nrec_all[nwalk] = o; }
          __syncthreads();
          finalize_records16(cx, recs_all, rstride, nrec_all, idx0_all, nwalk, threadIdx.x, blockDim.x);
-         if (cfg.debug) { const long long t4 = clock64(); acc0 += t1 - t0; acc1 += t2 - t1; acc2 += t3 - t2; acc3 += t4 - t3; ++ntl; } }
+         if (cfg.debug) { const long long t4 = clock64(); acc0 += t1 - t0; acc1 += t2 - t1; acc2 += t3 - t2; acc3 += t4 - t3; ++ntl; } }     // groups
+         if (give_back) break; }
       if (cfg.debug && threadIdx.x == 0) {
          atomicAdd(&scratch->dbg2[0], (unsigned long long)acc0); atomicAdd(&scratch->dbg2[1], (unsigned long long)acc1);
          atomicAdd(&scratch->dbg2[2], (unsigned long long)acc2); atomicAdd(&scratch->dbg2[3], (unsigned long long)acc3);
