@@ -162,7 +162,10 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       int r16 = 2 * peaks + 8;
       const int r16max = (16 * 1024) / (nwalk * 16);
       if (r16 > r16max) r16 = r16max;
-      d.rec_cap16 = r16 > 64 ? 64 : (r16 < 8 ? 8 : r16); }
+      d.rec_cap16 = r16 > 64 ? 64 : (r16 < 8 ? 8 : r16);
+      // test knobs (tests/ only): force the rare paths - lists through LDS in several groups, tiles handed back to k_decode
+      if (getenv("RTFE_LDS_UNITS")) { int v = atoi(getenv("RTFE_LDS_UNITS")); if (v >= d.run_cap && v <= 1536) { d.lds_units = v & ~63; d.pm_cap = d.lds_units / 2 * ((c->nparmsets + d.nscreens - 1) / d.nscreens); } }
+      if (getenv("RTFE_REC_CAP16")) { int v = atoi(getenv("RTFE_REC_CAP16")); if (v >= 2 && v <= d.rec_cap16) d.rec_cap16 = v; } }
    h->lds_bytes = (int)lds_layout(d, true).total + 64;
    h->screen_lds_bytes = (int)lds_layout(d, false).total + 64;
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }

@@ -19,3 +19,20 @@ def test_emulated_kernels_match_oracle(name, tmp_path):
     print(name, stats)
     assert not msgs, "\n".join(msgs[:12])
     assert stats["events"] > 0
+
+
+@pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_LDS_UNITS": "256"}),            # lists through LDS in several groups
+                                        ("nrzi9", {"RTFE_REC_CAP16": "4"}),             # k_walk hands tiles back to k_decode
+                                        ("gcr", {"RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}),
+                                        ("pe", {"RTFE_REC_CAP16": "8"})])
+def test_emulated_rare_paths_of_the_record_walk(name, knobs, tmp_path, monkeypatch):
+    """Small LDS budgets force k_walk's rare paths (grouped lists, the sequential walk, give-back to the second
+    k_decode pass): the events must not change."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g = load_case(name)
+    att = oracle_attempts(g["hdr"], g["rows"], g["oracle_opts"], str(tmp_path))
+    fe = emul_frontend(config_for(g["hdr"], g["oracle_opts"]))
+    msgs, stats = check_tape(fe, g["hdr"], g["rows"], att)
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["events"] > 0

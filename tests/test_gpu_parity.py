@@ -30,6 +30,22 @@ def test_golden_tapes(name, tmp_path, gpu):
     assert stats["events"] > 0
 
 
+@pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_LDS_UNITS": "256"}), ("nrzi9", {"RTFE_REC_CAP16": "4"}),
+                                        ("gcr", {"RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}), ("pe_m", {"RTFE_REC_CAP16": "8"}),
+                                        ("nrzi9_m", {"RTFE_LDS_UNITS": "512"})])
+def test_rare_paths_of_the_record_walk(name, knobs, tmp_path, gpu, monkeypatch):
+    """Small LDS budgets force k_walk's rare paths (grouped lists, the sequential walk, give-back to the second
+    k_decode pass): the events must not change."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g = load_case(name)
+    att = oracle_attempts(g["hdr"], g["rows"], g["oracle_opts"], str(tmp_path))
+    fe = frontend.FrontEnd(config_for(g["hdr"], g["oracle_opts"]))
+    msgs, stats = check_tape(fe, g["hdr"], g["rows"], att)
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["events"] > 0
+
+
 @pytest.mark.parametrize("seed,nblocks,maxlen", [(21, 12, 600), (22, 30, 2000), (23, 6, 4096)])
 def test_fresh_nrzi_tapes(seed, nblocks, maxlen, tmp_path, gpu):
     tape = synth.nrzi_tape(seed=seed, nblocks=nblocks, minlen=16, maxlen=maxlen, marks_every=5, gap_samples=4000)
