@@ -295,11 +295,13 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
                          (const TileDir *)dirp, (const CandUnit *)poolp, (int)kDecodeHead, ctlp, statep);
       if (h->timing) (void)hipEventRecord(h->ev[4], st);
+      int wthreads = threads;
+      if (getenv("RTFE_WALK_THREADS")) { const int v = atoi(getenv("RTFE_WALK_THREADS")); if (v >= threads && v <= 256 && v % 64 == 0) wthreads = v; }
       int wpc = (160 * 1024) / (h->walk_lds_bytes + 1024);
-      const int wlim = 16 / (threads / 64);
+      const int wlim = 16 / (wthreads / 64);
       if (wpc > wlim) wpc = wlim;
       if (wpc < 1) wpc = 1;
-      hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(threads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
+      hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
                          d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep);
       if (h->timing) (void)hipEventRecord(h->ev[5], st);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,

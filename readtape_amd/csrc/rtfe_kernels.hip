@@ -894,28 +894,30 @@ __device__ __forceinline__ void screen_strip(const Tile &tl, const DevScreen &sc
    int topb = 0, botb = 0, resb = 0;
    u64 ldt = 0, ldb = 0;
    if (W > kStrip) {
+      // keys: kmin = v << 8 | r, kmax = kmin ^ 0xff (= v << 8 | (255 - r)): one shift-or per sample serves both
       int smx[kStrip], smn[kStrip];
       int amx = (int)0x80000000, amn = 0x7fffffff;
       for (int j = s0 - 1; j > s0 - W + kStrip; --j) {
-         const int u = base[j], r = j - (s0 - W + 1);
-         amx = max(amx, (u << 8) | (255 - r)); amn = min(amn, (u << 8) | r); }
+         const int kk = (base[j] << 8) | (j - (s0 - W + 1));
+         amx = max(amx, kk ^ 0xff); amn = min(amn, kk); }
       #pragma unroll
       for (int i = kStrip - 1; i >= 0; --i) {
-         const int u = L[i];
-         amx = max(amx, (u << 8) | (255 - i)); amn = min(amn, (u << 8) | i); smx[i] = amx; smn[i] = amn; }
+         const int kk = (L[i] << 8) | i;
+         amx = max(amx, kk ^ 0xff); amn = min(amn, kk); smx[i] = amx; smn[i] = amn; }
       int pmx = (int)0x80000000, pmn = 0x7fffffff;
+      int popped = base[s0 - W];                                   // the sample that leaves the window at row s0 (then L[i-1])
       #pragma unroll
       for (int i = 0; i < kStrip; ++i) {
-         const int r = W - 1 + i;
-         pmx = max(pmx, (v[i] << 8) | (255 - r)); pmn = min(pmn, (v[i] << 8) | r);
+         const int kk = (v[i] << 8) | (W - 1 + i);
+         pmx = max(pmx, kk ^ 0xff); pmn = min(pmn, kk);
          const int kx = max(smx[i], pmx), kn = min(smn[i], pmn);
          const int mx = kx >> 8, mn = kn >> 8;
-         const int popped = base[s0 + i - W];
          const bool t = (mx - L[i] > sc.rise_i) && (mx - v[i] > sc.rise_i) && (sc.minpk_i < 0 || mx > sc.minpk_i);
          const bool b = (L[i] - mn > sc.rise_i) && (v[i] - mn > sc.rise_i) && (sc.minpk_i < 0 || mn < -sc.minpk_i);
          topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i;
          ldt |= (u64)((255 - (kx & 255)) - i + 1) << (8 * i);        // left_distance of the first maximum
-         ldb |= (u64)((kn & 255) - i + 1) << (8 * i); } }             // ... and of the first (true) minimum
+         ldb |= (u64)((kn & 255) - i + 1) << (8 * i);                 // ... and of the first (true) minimum
+         popped = L[i]; } }
    else {
       #pragma unroll
       for (int i = 0; i < kStrip; ++i) {
@@ -938,19 +940,24 @@ __device__ __forceinline__ void screen_strip(const Tile &tl, const DevScreen &sc
    reinterpret_cast<u64 *>(tl.ldmap(screen, 1, trk))[strip] = ldb; }
 
 // cooperative tile load: rows [row0 - kHaloRows, row0 + nrows) of the AoS payload -> SoA LDS by track
-__device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows) {
+// (trkoff[c] = head_to_trk[c] * ldw, a per-workgroup LDS table)
+__device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows, const int *trkoff) {
    const int ntrks = cfg->ntrks;
    const long long first = tl.row0 - kHaloRows;                   // multiple of 8 rows => 16-byte aligned
    const int nload = kHaloRows + tl.nrows;
-   const int nvec = (nload * ntrks + 7) >> 3;
+   const int nelem = nload * ntrks;
+   const int nvec = (nelem + 7) >> 3;
    const long long total_elem = total_rows * ntrks;
+   const long long e_first = first * ntrks;
+   const int inv = cfg->invert ? -1 : 0;
+   const FastDiv fd(ntrks);
    constexpr int kBatch = 6;                                      // independent 16-B loads in flight per lane
    for (int vbase = 0; vbase < nvec; vbase += kBatch * (int)blockDim.x) {
       int4 q[kBatch];
       #pragma unroll
       for (int k = 0; k < kBatch; ++k) {
          const int vi = vbase + k * (int)blockDim.x + (int)threadIdx.x;
-         const long long ge = first * ntrks + (long long)vi * 8;
+         const long long ge = e_first + (long long)vi * 8;
          q[k] = make_int4(0, 0, 0, 0);
          if (vi < nvec && ge >= 0 && ge + 8 <= total_elem) q[k] = *reinterpret_cast<const int4 *>(rows + ge); }
       #pragma unroll
@@ -958,16 +965,24 @@ __device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int
          const int vi = vbase + k * (int)blockDim.x + (int)threadIdx.x;
          if (vi >= nvec) continue;
          const int e0 = vi * 8;
-         int r = e0 / ntrks, c = e0 - r * ntrks;
-         const long long ge = first * ntrks + e0;
-         const bool whole = ge >= 0 && ge + 8 <= total_elem;
+         int r = fd.div(e0), c = e0 - r * ntrks;
+         const long long ge = e_first + e0;
          const int qq[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-         #pragma unroll
-         for (int j = 0; j < 8; ++j) {
-            int sv = (j & 1) ? (qq[j >> 1] >> 16) : (int)(short)(qq[j >> 1] & 0xffff);
-            if (!whole) { const long long g = ge + j; sv = (g >= 0 && g < total_elem) ? rows[g] : 0; }   // tape ends only
-            if (r < nload) tl.x[cfg->head_to_trk[c] * tl.ldw + r] = (int16_t)(cfg->invert ? -sv : sv);
-            if (++c == ntrks) { c = 0; ++r; } } } } }
+         if (ge >= 0 && ge + 8 <= total_elem && e0 + 8 <= nelem) {      // the common case: all eight samples wanted and present
+            #pragma unroll
+            for (int j = 0; j < 8; ++j) {
+               int sv = (j & 1) ? (qq[j >> 1] >> 16) : (int)(short)(qq[j >> 1] & 0xffff);
+               sv = (sv ^ inv) - inv;                                  // -invert
+               tl.x[trkoff[c] + r] = (int16_t)sv;
+               if (++c == ntrks) { c = 0; ++r; } } }
+         else {
+            #pragma nounroll
+            for (int j = 0; j < 8; ++j) {                              // tape ends / the tile's last vector
+               const long long g = ge + j;
+               int sv = (g >= 0 && g < total_elem) ? rows[g] : 0;
+               sv = (sv ^ inv) - inv;
+               if (r < nload) tl.x[trkoff[c] + r] = (int16_t)sv;
+               if (++c == ntrks) { c = 0; ++r; } } } } } }
 
 __device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl, bool with_halo) {
    const int hs = with_halo ? kScreenHalo / kStrip : 0;            // k_screen also screens the rows in front of the tile
@@ -1174,8 +1189,10 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
    __shared__ DevCfg cfg;
+   __shared__ int s_trkoff[RTFE_MAXTRKS];
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
+   if (threadIdx.x < cfg.ntrks) s_trkoff[threadIdx.x] = cfg.head_to_trk[threadIdx.x] * (kHaloRows + cfg.tile_rows + 8);
    const int ntrks = cfg.ntrks, nst = cfg.nscreens * ntrks;
    const LdsLayout L = lds_layout(cfg, false);
    Tile tl;
@@ -1195,7 +1212,7 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
       __syncthreads();
       long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
       if (cfg.debug) k0 = clock64();
-      load_tile(&cfg, tl, rows, nrows);
+      load_tile(&cfg, tl, rows, nrows, s_trkoff);
       __syncthreads();
       if (cfg.debug) k1 = clock64();
       if (cfg.cut == 1) continue;
@@ -1362,6 +1379,9 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
       long long g = ctl[b].next_tile;
       bool give_back = false;
       long long acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, ntl = 0;
+      long long pa[6] = {0, 0, 0, 0, 0, 0};
+      TileDir nd; nd.count = 0; nd.nruns = 0; nd.end_ld = 0; nd.pad = 0; nd.end_min = 0;
+      const long long g_first = g;
       for (; g * T < stop; ++g) {
          const long long tile0 = g * T;
          const long long tn = (tile0 + T <= nrows) ? T : nrows - tile0;
@@ -1371,7 +1391,9 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
          long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
          if (cfg.debug) t0 = clock64();
          if (threadIdx.x == 0) s_needfull = 0;
-         if (threadIdx.x < nst) s_dir[threadIdx.x] = dir[g * nst + threadIdx.x];
+         if (threadIdx.x < nst) {
+            s_dir[threadIdx.x] = g == g_first ? dir[g * nst + threadIdx.x] : nd;
+            if ((g + 1) * T < nrows) nd = dir[(g + 1) * nst + threadIdx.x]; }      // the next tile's entry, in flight during this tile
          __syncthreads();
          if (threadIdx.x <= nst) {                                  // where each list starts inside the tile's slot of the pool
             int o = 0; bool bad = false;
@@ -1463,6 +1485,8 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                if (my_w == nwalk - 1) { pmoff[nwalk] = o + my_nruns; if (o + my_nruns > cfg.pm_cap) atomicOr(&s_seq, 1u); }
                if (o + my_nruns <= cfg.pm_cap) for (int r = 0; r < my_nruns; ++r) pmmap[o + r] = (unsigned char)my_w; }
             __syncthreads();
+            long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+            if (cfg.debug) p0 = clock64();
             if (!s_seq) {
                // ---- (1) all lanes: the pass mask of every (walker, run) ----
                const int total = pmoff[nwalk];
@@ -1496,6 +1520,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                   if (doubt) km = 255;                                         // undecidable here whatever the countdown
                   pm[idx] = (unsigned short)(ks | (km << 8)); } }
             __syncthreads();
+            if (cfg.debug) p1 = clock64();
             int nh = 0, last_blind = -1;
             if (!s_seq) {
                // ---- (2) one lane per walker: the countdown chain over the pass masks -> this tile's detections ----
@@ -1507,21 +1532,26 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                   const int2 *lst = reinterpret_cast<const int2 *>(units + (s_off[my_st] - gbase));
                   unsigned int *hits = reinterpret_cast<unsigned int *>(recs_all + (size_t)my_w * rstride);      // 16-byte slots: rk, v, a, gain before
                   const unsigned short *mypm = pm + pmoff[my_w];
+                  // (the next run's header and verdict are fetched while this one is looked at)
+                  int2 A; A.x = 0; A.y = 0;
+                  int v2 = 0;
+                  if (my_nruns > 0) { A = lst[0]; v2 = mypm[0]; }
                   #pragma nounroll
                   for (int r = 0; r < my_nruns; ++r) {
-                     const int2 A = lst[2 * r];
+                     int2 An = A; int v2n = 0;
+                     if (r + 1 < my_nruns) { An = lst[2 * (r + 1)]; v2n = mypm[r + 1]; }
                      const int n_s = A.x & 0x7ff, nr = (A.x >> 11) & 0x3f;
                      const int k0 = cur > n_s ? cur - n_s : 0;
-                     if (k0 >= nr) continue;
-                     const int v2 = mypm[r];
-                     if ((v2 & 0xff) <= k0) {                               // no sure row ahead of the countdown
-                        if ((v2 >> 8) > k0) { atomicOr(&s_seq, 1u); break; }   // ... but a possible one: undecidable here
-                        continue; }
-                     if (nh >= cfg.rec_cap16) { atomicOr(&s_seq, 1u); break; }
-                     hits[nh * 4] = (unsigned)r | ((unsigned)k0 << 16) | ((unsigned)((A.x >> 17) & 1) << 31);
-                     ++nh;
-                     last_blind = n_s + ((A.y >> 16) & 0xff);               // row n + left_distance, whichever row of the run fires
-                     cur = last_blind + 1; }
+                     if (k0 < nr) {
+                        if ((v2 & 0xff) <= k0) {                            // no sure row ahead of the countdown
+                           if ((v2 >> 8) > k0) { atomicOr(&s_seq, 1u); break; } }   // ... but a possible one: undecidable here
+                        else {
+                           if (nh >= cfg.rec_cap16) { atomicOr(&s_seq, 1u); break; }
+                           hits[nh * 4] = (unsigned)r | ((unsigned)k0 << 16) | ((unsigned)((A.x >> 17) & 1) << 31);
+                           ++nh;
+                           last_blind = n_s + ((A.y >> 16) & 0xff);         // row n + left_distance, whichever row of the run fires
+                           cur = last_blind + 1; } }
+                     A = An; v2 = v2n; }
                   nrec_all[my_w] = nh; } }
             __syncthreads();
             if (!s_seq && is_walker) {
@@ -1531,6 +1561,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                if (my_w == nwalk - 1) hoff[nwalk] = o + nh;
                for (int j = 0; j < nh; ++j) hmap[o + j] = (unsigned char)my_w; }
             __syncthreads();
+            if (cfg.debug) p2 = clock64();
             if (!s_seq) {
                // ---- (3a) all lanes: volt() of every detection ----
                const int total = hoff[nwalk];
@@ -1561,6 +1592,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                   if (lastheight > 0) { const float gq = wst[w2 * 4 + 2] / lastheight; a = wst[w2 * 4 + 3] * gq; }
                   base[4 * j + 2] = __float_as_uint(a); } }
             __syncthreads();
+            if (cfg.debug) p3 = clock64();
             float g_end = 0, vt_last = 0, vb_last = 0;
             bool any_t = false, any_b = false;
             if (!s_seq && active) {
@@ -1569,14 +1601,18 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                unsigned int *hits = reinterpret_cast<unsigned int *>(recs_all + (size_t)my_w * rstride);
                const float c1 = 1 - P.agc_alpha;
                float g = w.agc_gain, gmin = g, gmax = g;
+               uint4 q; q.x = 0; q.y = 0; q.z = 0; q.w = 0;
+               if (nh > 0) q = *reinterpret_cast<const uint4 *>(hits);                       // rk, v, a, -
                #pragma nounroll
                for (int j = 0; j < nh; ++j) {
-                  const uint2 q = *reinterpret_cast<const uint2 *>(hits + 4 * j + 1);       // v, a
+                  uint4 qn = q;
+                  if (j + 1 < nh) qn = *reinterpret_cast<const uint4 *>(hits + 4 * (j + 1));
                   hits[4 * j + 3] = __float_as_uint(g);
-                  const float a = __uint_as_float(q.y);
+                  const float a = __uint_as_float(q.z);
                   if (a >= 0) { g = a + c1 * g; if (g > 2.0f) g = 2.0f; }
                   gmin = fminf(gmin, g); gmax = fmaxf(gmax, g);
-                  if (hits[4 * j] >> 31) { vb_last = __uint_as_float(q.x); any_b = true; } else { vt_last = __uint_as_float(q.x); any_t = true; } }
+                  if (q.x >> 31) { vb_last = __uint_as_float(q.y); any_b = true; } else { vt_last = __uint_as_float(q.y); any_t = true; }
+                  q = qn; }
                g_end = g;
                const float s_hi = w.v_avg_height * 0.25f * fast_rcp(gmin), s_lo = w.v_avg_height * 0.25f * fast_rcp(gmax);
                bool ok = gmin > 0 && (int)(P.rise * s_hi * lsb) + 4 <= band[my_w * 4 + 1] && (int)(P.rise * s_lo * lsb) - 3 >= band[my_w * 4 + 0]
@@ -1585,6 +1621,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                                           && P.min_peak * s_lo >= P.screen_minpk_v * 1.01f;
                if (!ok) atomicOr(&s_seq, 1u); }
             __syncthreads();
+            if (cfg.debug) p4 = clock64();
             if (!s_seq) {
                // ---- (5) all lanes: the events; walker lanes: the state after the tile ----
                const int total = hoff[nwalk];
@@ -1630,7 +1667,8 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                   if (whole) {
                      const int last = (int)tn - 1;
                      w.minv = s_dir[my_st].end_min; w.cpos = tile0 + last; w.qtrig = tile0 + last + s_dir[my_st].end_ld; w.chain_pending = false; } }
-               done_par = true; }
+               done_par = true;
+               if (cfg.debug) { const long long p5 = clock64(); pa[0] += p0 - t2; pa[1] += p1 - p0; pa[2] += p2 - p1; pa[3] += p3 - p2; pa[4] += p4 - p3; pa[5] += p5 - p4; } }
             if (cfg.debug && threadIdx.x == 0) atomicAdd(&scratch->why[done_par ? 0 : 1], 1ull); }
          if (done_par) {
             if (cfg.debug) { const long long t4 = clock64(); acc0 += t1 - t0; acc1 += t2 - t1; acc2 += t4 - t2; ++ntl; }
@@ -1661,7 +1699,8 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
       if (cfg.debug && threadIdx.x == 0) {
          atomicAdd(&scratch->dbg2[0], (unsigned long long)acc0); atomicAdd(&scratch->dbg2[1], (unsigned long long)acc1);
          atomicAdd(&scratch->dbg2[2], (unsigned long long)acc2); atomicAdd(&scratch->dbg2[3], (unsigned long long)acc3);
-         atomicAdd(&scratch->dbg[7], (unsigned long long)ntl); }
+         atomicAdd(&scratch->dbg[7], (unsigned long long)ntl);
+         for (int i = 0; i < 6; ++i) atomicAdd(&scratch->why[2 + i], (unsigned long long)pa[i]); }
       if (give_back) {                                                // the state as of the start of tile g
          if (is_walker) {
             WalkState &ws = wstate[(size_t)b * nwalk + my_w];
@@ -1708,6 +1747,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    if (screen_off && threadIdx.x == 0)
       for (int s = 0; s < cfg.nscreens; ++s) { cfg.screen[s].rise_i = -70000; cfg.screen[s].minpk_i = -1; }
    if (screen_off) for (int i = threadIdx.x; i < cfg.nparm; i += blockDim.x) { cfg.parm[i].screen_rise_v = -1; cfg.parm[i].screen_minpk_v = -1; }
+   __shared__ int s_trkoff[RTFE_MAXTRKS];
+   if (threadIdx.x < cfg.ntrks) s_trkoff[threadIdx.x] = cfg.head_to_trk[threadIdx.x] * (kHaloRows + cfg.tile_rows + 8);
    __syncthreads();
    const int ntrks = cfg.ntrks;
    const int ldw = kHaloRows + cfg.tile_rows + 8;
@@ -1748,7 +1789,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       if (cfg.find_zeros) return Z.zone_end - kMarginRows;       // any restart inside the zone is equivalent
       cx.tile.row0 = Z.zone_end - kMarginRows; cx.tile.nrows = kMarginRows; cx.tile.reset = -(1ll << 40);
       __syncthreads();
-      load_tile(&cfg, cx.tile, rows, nrows);
+      load_tile(&cfg, cx.tile, rows, nrows, s_trkoff);
       __syncthreads();
       run_screens(&cfg, cx.tile, false);
       __syncthreads();
@@ -1877,7 +1918,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                __syncthreads(); } }
          if (done_tile) continue;
          // ---- full path: samples into LDS, screen, exact walkers ----
-         load_tile(&cfg, cx.tile, rows, nrows);
+         load_tile(&cfg, cx.tile, rows, nrows, s_trkoff);
          __syncthreads();
          if (cfg.debug) c1 = clock64();
          run_screens(&cfg, cx.tile, false);
