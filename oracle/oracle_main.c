@@ -11,6 +11,7 @@
  *                       row it would read); the reference shim cannot produce these
  *     -time             print front-end wall time and Msamples/s (the bench's cpu_baseline)
  *     -blklimit=N
+ *     -subsample=N   use only every Nth row (src/readtape.c:1407: reads N rows, keeps the last; the time base is NOT stretched)
  */
 #include "oracle_fe.h"
 
@@ -78,7 +79,7 @@ int main(int argc, char **argv) {
    struct rt_options opt; memset(&opt, 0, sizeof opt);
    opt.specified_parity = 1;
    const char *infile = NULL, *outbase = NULL, *evtname = NULL, *parmfile = NULL, *skewarg = NULL;
-   int ntrks_arg = 0, invert = 0, timing = 0, blklimit = 0x7fffffff;
+   int ntrks_arg = 0, invert = 0, timing = 0, blklimit = 0x7fffffff, subsample = 1;
    float bpi_arg = -1, ips_arg = -1;
    int mode_arg = 0;
    for (int i = 1; i < argc; ++i) {
@@ -105,6 +106,7 @@ int main(int argc, char **argv) {
       else if (!strncmp(a, "-evt=", 5)) evtname = a + 5;
       else if (!strcmp(a, "-evtend")) evt_ends = 1;
       else if (!strncmp(a, "-blklimit=", 10)) blklimit = atoi(a + 10);
+      else if (!strncmp(a, "-subsample=", 11)) { subsample = atoi(a + 11); if (subsample < 1) subsample = 1; }
       else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a); return 2; }
       else infile = a; }
    if (!infile) { fprintf(stderr, "usage: oracle_readtape [options] tape.tbin\n"); return 2; }
@@ -133,6 +135,11 @@ int main(int argc, char **argv) {
    if ((len - off) / 2 > (size_t)(navail * nheads) && nrows == navail) {
       /* the end marker is the lone int16 after the last full row */ }
 
+   if (subsample > 1) {                                       /* src/readtape.c:1407-1414: of every `subsample` rows the last one is used */
+      const int64_t nkeep = nrows / subsample;
+      int16_t *dec = (int16_t *)malloc((size_t)(nkeep > 0 ? nkeep : 1) * (size_t)nheads * 2);
+      for (int64_t k = 0; k < nkeep; ++k) memcpy(dec + k * nheads, rows + ((k + 1) * subsample - 1) * nheads, (size_t)nheads * 2);
+      rows = dec; nrows = nkeep; }
    float sample_deltat = (float)(int64_t)tdelta / 1e9f;      /* src/readtape.c:1345 */
    struct rt_dec *d = rt_dec_new(&opt, sample_deltat, (int64_t)tdelta);
    if (parmfile) {

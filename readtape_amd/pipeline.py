@@ -80,11 +80,20 @@ def frontend_parmsets(full):
 
 
 def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
-                skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None, differentiate=False):
+                skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None, differentiate=False,
+                subsample: int = 1):
     """Decodes one tape; returns (stats dict, ScanResult).  `fe_factory(cfg)` builds the front end
     (default: the GPU one; tests/cpu_emul passes the emulated library)."""
     opts = opts or DecodeOptions()
     lib = _load_decode_lib()
+    if subsample > 1:
+        # -subsample=n (src/readtape.c:1407-1414): of every n rows the LAST one is used and the time base is not
+        # stretched (timenow_ns still advances by tdelta per used row, :1424) - a strided view of the resident tape
+        rows = rows[subsample - 1::subsample][: rows.shape[0] // subsample]
+        if hasattr(rows, "contiguous"):
+            rows = rows.contiguous()
+        else:
+            rows = np.ascontiguousarray(rows)
     mode = hdr.mode
     nsets = opts.nparmsets or (15 if opts.multiple_tries else 1)
     if parms_text:

@@ -42,6 +42,17 @@ def case_gcr_noisy(seed=17):
     return synth.gcr_tape(seed=seed, nblocks=2, minlen=40, maxlen=120, gap_samples=2500, noise_mv=45.0, jitter=0.05, amplitude=1.2)
 
 
+def case_nrzi9_oversampled(seed=18):
+    # sampled at 640 ns (39 samples per bit) while the header says 1280 ns: what "-subsample=2" is for
+    import dataclasses
+    spec = synth.TapeSpec(mode=tbin.MODE_NRZI, ntrks=9, bpi=800.0, ips=50.0, tdelta_ns=640, maxvolts=4.4, pulse_w=0.22, seed=seed)
+    rng = np.random.default_rng(seed + 1000)
+    items = [("block", p) for p in synth.random_payloads(rng, 2, 40, 90, databits=8)] + [("mark",)]
+    t = synth.make_tape(spec, items, gap_samples=3000)
+    t.spec = dataclasses.replace(spec, tdelta_ns=1280)
+    return t
+
+
 # name -> (tape builder, reference options, oracle options)
 CASES = {
     "nrzi9":        (case_nrzi9,      ["-nrzi"],                       []),
@@ -50,6 +61,7 @@ CASES = {
     "nrzi7":        (case_nrzi7,      ["-nrzi", "-ntrks=7"],           []),
     "nrzi9_skew":   (case_nrzi9_skew, ["-nrzi", "-ntrks=9", "-skew=3,1,2,0,3,0,1,2,1"], ["-skew=3,1,2,0,3,0,1,2,1"]),
     "nrzi9_invert": (case_nrzi9,      ["-nrzi", "-invert"],            ["-invert"]),
+    "nrzi9_sub2":   (case_nrzi9_oversampled, ["-nrzi", "-subsample=2"], ["-subsample=2"]),
     "nrzi9_zeros":  (case_nrzi9,      ["-nrzi", "-zeros"],             ["-zeros"]),
     "nrzi9_diffz":  (case_nrzi9,      ["-nrzi", "-zeros", "-differentiate"], ["-zeros", "-differentiate"]),
     "nrzi9_diffpk": (case_nrzi9,      ["-nrzi", "-differentiate"],     ["-differentiate"]),

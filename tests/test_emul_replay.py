@@ -8,17 +8,19 @@ from emul_util import emul_frontend
 from golden_util import load_case
 from readtape_amd import pipeline
 
-CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "nrzi9_diffz"]
-EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "pe", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_zeros", "nrzi9_diffz"]     # the thread emulation is slow: a subset here, all on the GPU
+CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "nrzi9_diffz"]
+EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "nrzi9_sub2", "pe", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_zeros", "nrzi9_diffz"]     # the thread emulation is slow: a subset here, all on the GPU
 
 
 def decode_case(g, tmp_path, fe_factory):
     o = g["oracle_opts"]
     skew = next(([int(x) for x in a[6:].split(",")] for a in o if a.startswith("-skew=")), None)
     opts = pipeline.DecodeOptions(multiple_tries="-m" in o, correct="-correct" in o)
+    subsample = next((int(a[11:]) for a in o if a.startswith("-subsample=")), 1)
     tap = os.path.join(str(tmp_path), "out.tap")
     stats, res = pipeline.decode_tape(g["hdr"], g["rows"], tap, log_path=tap + ".log", opts=opts, fe_factory=fe_factory,
-                                      skew=skew, invert="-invert" in o, find_zeros="-zeros" in o, evt_path=tap + ".evt", differentiate="-differentiate" in o)
+                                      skew=skew, invert="-invert" in o, find_zeros="-zeros" in o, evt_path=tap + ".evt", differentiate="-differentiate" in o,
+                                      subsample=subsample)
     import refdump
     # every transition the decoders were handed == what the reference's front end handed its decoders
     # (differentiated zero-crossing: the decoder-side baseline bookkeeping v_avg_height depends on the opposite
