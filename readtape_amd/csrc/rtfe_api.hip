@@ -140,6 +140,14 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       if (tr < kMarginRows) tr = kMarginRows;
       if (tr > kMaxTileRows) tr = kMaxTileRows;
       d.tile_rows = tr; }
+   {
+      int wmax = 0;
+      for (int sidx = 0; sidx < d.nscreens; ++sidx) if (d.screen[sidx].W > wmax) wmax = d.screen[sidx].W;
+      d.halo_rows = (kScreenHalo + wmax + 1 + d.maxskew + 7) & ~7;
+      if (d.halo_rows > kMaxHaloRows) d.halo_rows = kMaxHaloRows;
+      int pad = 16;                                                   // (measured: a row stride of halo+tile+8 elements costs 20 % in LDS bank conflicts)
+      if (getenv("RTFE_LDW_PAD")) { pad = atoi(getenv("RTFE_LDW_PAD")); if (pad < 8 || pad > 256 || (pad & 7)) pad = 16; }
+      d.ldw = d.halo_rows + d.tile_rows + pad; }
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
    d.cut = getenv("RTFE_CUT") ? atoi(getenv("RTFE_CUT")) : 0;

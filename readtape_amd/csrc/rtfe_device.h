@@ -7,7 +7,7 @@ namespace rtfe {
 
 constexpr int kChunkRows   = 64;     // granularity of the quiet map (rows per bit)
 constexpr int kMaxTileRows = 2048;   // upper bound of DevCfg::tile_rows (rows per LDS tile of the decode kernel)
-constexpr int kHaloRows    = 176;    // rows kept in front of a tile: >= kScreenHalo + W + 1 + max skew  (W<=50, skew<=50)
+constexpr int kMaxHaloRows = 176;    // upper bound of DevCfg::halo_rows = kScreenHalo + W + 1 + max skew, rounded up to 8  (W<=50, skew<=50)
 constexpr int kMarginRows  = 256;    // head/tail tile length at a burst boundary (multiple of 64)
 constexpr int kStrip       = 8;      // samples per screen strip (one bitmap byte)
 constexpr int kDecodeThreads = 256;
@@ -47,6 +47,8 @@ struct DevCfg {
    int   gap_chunks;              // quiet chunks that make an inter-block zone
    float cap_frac;                // event capacity per track as a fraction of burst length
    int   tile_rows;               // rows per LDS tile (multiple of 64, kMarginRows..kMaxTileRows)
+   int   halo_rows;               // rows kept in front of a tile: kScreenHalo + widest window + 1 + max skew, rounded up to 8
+   int   ldw;                     // int16 elements per track row of the LDS sample tile (halo_rows + tile_rows + padding)
    float lsb_per_volt;            // 32767 / maxvolts, for the walkers' integer guard bands
    int   run_cap;                 // candidate-run records per (screen, track) per tile (LDS)
    int   rec_cap;                 // deferred-event records per walker per tile (LDS)

@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
 // k_decode
 // ------------------------------------------------------------------------------------------------
 struct Tile {
-   int16_t *x;            // LDS: [ntrks][ldw] raw samples by TRACK (after -invert), index = row - row0 + kHaloRows
+   int16_t *x;            // LDS: [ntrks][ldw] raw samples by TRACK (after -invert), index = row - row0 + halo
+   int      halo;         // rows kept in front of the tile (DevCfg::halo_rows)
    int      ldw;          // row stride of x
    long long row0;        // first row of the tile proper
    int      nrows;        // rows in the tile proper
@@ -236,7 +237,7 @@ struct Tile {
    int      ldstride;     // tile_rows + kScreenHalo
    int      ntrks;
    const int *skew;
-   __device__ __forceinline__ int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + kHaloRows]; }
+   __device__ __forceinline__ int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + halo]; }
    // v_now of track t at row n in int16 units, with the deskew FIFO exactly as the reference runs it
    // from the restart row: undelayed until the FIFO has filled (src/decoder.c:825-827), then delayed
    __device__ __forceinline__ int y(int t, long long n) const {
@@ -585,7 +586,7 @@ __device__ __forceinline__ bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, c
    const Tile &tl = cx.tile;
    const int W = P.W;
    const float mv = cfg->maxvolts;
-   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
+   const int16_t *yb = tl.x + trk * tl.ldw + tl.halo - cfg->skew[trk];
    const int lo = n - W + 1;
    const int vl = yb[lo], vr = yb[n];
    bool hit = false, is_top = false;
@@ -651,7 +652,7 @@ __device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long
    if (limit - 1 > w.cpos) {
       const long long a = last_forced_rescan(tl, P.screen, trk, w.cpos, limit - 1);
       if (a >= 0) { w.cpos = a; w.chain_pending = true; }
-      if (limit - 1 - w.cpos > kHaloRows - 2 * W - 8 - cfg->maxskew) advance_chain(w, tl, P.screen, trk, W, limit - 1); } }
+      if (limit - 1 - w.cpos > tl.halo - 2 * W - 8 - cfg->maxskew) advance_chain(w, tl, P.screen, trk, W, limit - 1); } }
 
 // lookfor_zerocrossing (src/decoder.c:617-649) on the int16 codes: every row, one lane per track.  Emits every
 // CONFIRMED crossing; the slope gate of :629/:643 needs the decoder's clock average and is applied by the host
@@ -847,7 +848,7 @@ __device__ __forceinline__ int list_runs(const Tile &tl, int st, int screen, int
 // ---- k_screen only: the units of one run -> its place in the list (HBM) ----
 __device__ __forceinline__ void build_run(const Tile &tl, const DevCfg *cfg, int screen, int trk, int W, int n, int kind, int nr,
                                           int4 *hdr, int moff, int4 *marg) {
-   const int16_t *yb = tl.x + trk * tl.ldw + kHaloRows - cfg->skew[trk];
+   const int16_t *yb = tl.x + trk * tl.ldw + tl.halo - cfg->skew[trk];
    const int ld0 = tl.ldmap(screen, kind, trk)[n];
    int m = 0, prev = 0, next = 0;
    if (ld0) { const int p = n - W + ld0; m = yb[p]; prev = yb[p - 1]; next = yb[p + 1]; }
@@ -886,7 +887,7 @@ __device__ __forceinline__ void screen_strip(const Tile &tl, const DevScreen &sc
    // kmin = v<<8 | r  (min -> smallest v, then smallest r).
    const int W = sc.W;
    const int d = tl.skew[trk];
-   const int16_t *base = tl.x + trk * tl.ldw + kHaloRows - d;     // y(n) = base[n - row0] in the regular regime
+   const int16_t *base = tl.x + trk * tl.ldw + tl.halo - d;     // y(n) = base[n - row0] in the regular regime
    const int s0 = strip * kStrip;
    int v[kStrip], L[kStrip];
    #pragma unroll
@@ -939,12 +940,12 @@ __device__ __forceinline__ void screen_strip(const Tile &tl, const DevScreen &sc
    reinterpret_cast<u64 *>(tl.ldmap(screen, 0, trk))[strip] = ldt;
    reinterpret_cast<u64 *>(tl.ldmap(screen, 1, trk))[strip] = ldb; }
 
-// cooperative tile load: rows [row0 - kHaloRows, row0 + nrows) of the AoS payload -> SoA LDS by track
+// cooperative tile load: rows [row0 - halo, row0 + nrows) of the AoS payload -> SoA LDS by track
 // (trkoff[c] = head_to_trk[c] * ldw, a per-workgroup LDS table)
 __device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows, const int *trkoff) {
    const int ntrks = cfg->ntrks;
-   const long long first = tl.row0 - kHaloRows;                   // multiple of 8 rows => 16-byte aligned
-   const int nload = kHaloRows + tl.nrows;
+   const long long first = tl.row0 - tl.halo;                     // multiple of 8 rows => 16-byte aligned
+   const int nload = tl.halo + tl.nrows;
    const int nelem = nload * ntrks;
    const int nvec = (nelem + 7) >> 3;
    const long long total_elem = total_rows * ntrks;
@@ -1135,7 +1136,7 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    LdsLayout L;
    const unsigned ntrks = (unsigned)c.ntrks, nst = (unsigned)c.nscreens * ntrks, nwalk = (unsigned)c.nparm * ntrks;
    const unsigned T = (unsigned)c.tile_rows;
-   unsigned off = lds_align16(ntrks * (unsigned)(kHaloRows + c.tile_rows + 8) * 2u);
+   unsigned off = lds_align16(ntrks * (unsigned)c.ldw * 2u);
    L.bits = off;      off = lds_align16(off + nst * 5u * ((T + kScreenHalo) / 8 + 8));
    L.ldpos = off;     off = lds_align16(off + nst * 2u * (T + kScreenHalo));
    // k_decode: the candidate records of a tile share the space of the sample tile (a tile is decided either from
@@ -1192,12 +1193,12 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    __shared__ int s_trkoff[RTFE_MAXTRKS];
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
-   if (threadIdx.x < cfg.ntrks) s_trkoff[threadIdx.x] = cfg.head_to_trk[threadIdx.x] * (kHaloRows + cfg.tile_rows + 8);
+   if (threadIdx.x < cfg.ntrks) s_trkoff[threadIdx.x] = cfg.head_to_trk[threadIdx.x] * cfg.ldw;
    const int ntrks = cfg.ntrks, nst = cfg.nscreens * ntrks;
    const LdsLayout L = lds_layout(cfg, false);
    Tile tl;
    tl.x = reinterpret_cast<int16_t *>(smem);
-   tl.ldw = kHaloRows + cfg.tile_rows + 8;
+   tl.ldw = cfg.ldw; tl.halo = cfg.halo_rows;
    tl.ntrks = ntrks; tl.skew = cfg.skew; tl.reset = -(1ll << 40);
    tl.bits = smem + L.bits; tl.bstride = (cfg.tile_rows + kScreenHalo) / 8 + 8;
    tl.ldpos = smem + L.ldpos; tl.ldstride = cfg.tile_rows + kScreenHalo;
@@ -1282,7 +1283,7 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
          const int last = tl.nrows - 1;
          const int eld = stale_ld(tl.map(sc, 2, trk), tl.ldmap(sc, 1, trk), last);
          d.end_ld = (uint8_t)eld; d.pad = 0;
-         d.end_min = eld ? tl.x[trk * tl.ldw + kHaloRows - cfg.skew[trk] + last - cfg.screen[sc].W + eld] : (int16_t)0;
+         d.end_min = eld ? tl.x[trk * tl.ldw + tl.halo - cfg.skew[trk] + last - cfg.screen[sc].W + eld] : (int16_t)0;
          dir[g * nst + st] = d; }
       if (cfg.debug) {
          __syncthreads();
@@ -1748,15 +1749,15 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       for (int s = 0; s < cfg.nscreens; ++s) { cfg.screen[s].rise_i = -70000; cfg.screen[s].minpk_i = -1; }
    if (screen_off) for (int i = threadIdx.x; i < cfg.nparm; i += blockDim.x) { cfg.parm[i].screen_rise_v = -1; cfg.parm[i].screen_minpk_v = -1; }
    __shared__ int s_trkoff[RTFE_MAXTRKS];
-   if (threadIdx.x < cfg.ntrks) s_trkoff[threadIdx.x] = cfg.head_to_trk[threadIdx.x] * (kHaloRows + cfg.tile_rows + 8);
+   if (threadIdx.x < cfg.ntrks) s_trkoff[threadIdx.x] = cfg.head_to_trk[threadIdx.x] * cfg.ldw;
    __syncthreads();
    const int ntrks = cfg.ntrks;
-   const int ldw = kHaloRows + cfg.tile_rows + 8;
+   const int ldw = cfg.ldw;
    Ctx cx;
    cx.cfg = &cfg;
    cx.row_base = row_base;
    cx.tile.x = reinterpret_cast<int16_t *>(smem);
-   cx.tile.ldw = ldw;
+   cx.tile.ldw = ldw; cx.tile.halo = cfg.halo_rows;
    cx.tile.ntrks = ntrks;
    cx.tile.skew = cfg.skew;
    const LdsLayout L = lds_layout(cfg, true);
