@@ -146,7 +146,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       d.halo_rows = (kScreenHalo + wmax + 1 + d.maxskew + 7) & ~7;
       if (d.halo_rows > kMaxHaloRows) d.halo_rows = kMaxHaloRows;
       int pad = 16;                                                   // (measured: a row stride of halo+tile+8 elements costs 20 % in LDS bank conflicts)
-      if (getenv("RTFE_LDW_PAD")) { pad = atoi(getenv("RTFE_LDW_PAD")); if (pad < 8 || pad > 256 || (pad & 7)) pad = 16; }
+      if (getenv("RTFE_LDW_PAD")) { pad = atoi(getenv("RTFE_LDW_PAD")); if (pad < 8 || pad > 256 || (pad & 1)) pad = 16; }
       d.ldw = d.halo_rows + d.tile_rows + pad; }
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
