@@ -880,7 +880,7 @@ struct FastDiv {
 
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
-__device__ __forceinline__ void screen_strip(const Tile &tl, const DevScreen &sc, int screen, int trk, int strip) {
+__device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc, int screen, int trk, int strip) {
    // Keys carry the position so that max/min also yield the FIRST window element equal to the extreme
    // (what refine_peak looks for, src/decoder.c:707-708): r = index relative to the strip's leftmost
    // window element (s0 - W + 1);  kmax = v<<8 | (255 - r)  (max -> largest v, then smallest r),
@@ -938,7 +938,8 @@ __device__ __forceinline__ void screen_strip(const Tile &tl, const DevScreen &sc
    o[(size_t)tl.ntrks * tl.bstride] = (unsigned char)botb;
    o[(size_t)2 * tl.ntrks * tl.bstride] = (unsigned char)resb;
    reinterpret_cast<u64 *>(tl.ldmap(screen, 0, trk))[strip] = ldt;
-   reinterpret_cast<u64 *>(tl.ldmap(screen, 1, trk))[strip] = ldb; }
+   reinterpret_cast<u64 *>(tl.ldmap(screen, 1, trk))[strip] = ldb;
+   return topb | botb; }
 
 // cooperative tile load: rows [row0 - halo, row0 + nrows) of the AoS payload -> SoA LDS by track
 // (trkoff[c] = head_to_trk[c] * ldw, a per-workgroup LDS table)
@@ -985,15 +986,33 @@ __device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int
                if (r < nload) tl.x[trkoff[c] + r] = (int16_t)sv;
                if (++c == ntrks) { c = 0; ++r; } } } } } }
 
-__device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl, bool with_halo) {
+// act / nact (k_screen only): the strips of the tile proper that hold candidates, compacted (st << 16 | strip) so that
+// the sparse passes behind the screen keep every lane busy; stripcnt of every strip is cleared on the way
+__device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl, bool with_halo, unsigned int *act = nullptr, int *nact = nullptr,
+                                            unsigned int *stripcnt = nullptr, int smax = 0) {
    const int hs = with_halo ? kScreenHalo / kStrip : 0;            // k_screen also screens the rows in front of the tile
    const int nstrips = (tl.nrows + kStrip - 1) / kStrip + hs;
    const int per_screen = nstrips * cfg->ntrks;
    const FastDiv fd(nstrips);
    for (int s = 0; s < cfg->nscreens; ++s)
-      for (int i = threadIdx.x; i < per_screen; i += blockDim.x) {
-         const int t = fd.div(i);
-         screen_strip(tl, cfg->screen[s], s, t, i - t * nstrips - hs); } }
+      for (int i0 = 0; i0 < per_screen; i0 += blockDim.x) {         // (uniform trip count: the ballot below needs whole waves)
+         const int i = i0 + (int)threadIdx.x;
+         const bool valid = i < per_screen;
+         int t = 0, strip = 0, any = 0;
+         if (valid) {
+            t = fd.div(i); strip = i - t * nstrips - hs;
+            any = screen_strip(tl, cfg->screen[s], s, t, strip); }
+         if (act) {
+            const int st = s * cfg->ntrks + t;
+            const bool mine = valid && strip >= 0;
+            if (mine) stripcnt[st * smax + strip] = 0;
+            const bool on = mine && any != 0;
+            const u64 bal = __ballot(on);
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0 && bal) base = atomicAdd(nact, __popcll(bal));
+            base = __shfl(base, 0);
+            if (on) act[base + __popcll(bal & ((1ull << lane) - 1))] = ((unsigned)st << 16) | (unsigned)strip; } } }
 
 // restart row for the zone whose last kMarginRows rows are the current tile:
 // for every parameter set and track take the last forced rescan inside the zone; any restart at or
@@ -1127,7 +1146,7 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
 // LDS carve of k_screen / k_decode.  ONE definition, used by the kernels and by the host when it sizes the dynamic
 // LDS allocation (rtfe_api.hip): an under-sized allocation does not fault on the GPU, out-of-range LDS reads return 0.
 struct LdsLayout {
-   unsigned bits, ldpos, heights, recs, nrec, runs, runcnt, runtab, walkers, walkers_next, heights_bak, total; };
+   unsigned bits, ldpos, heights, recs, nrec, runs, runcnt, runtab, act, walkers, walkers_next, heights_bak, total; };
 __host__ __device__ inline unsigned lds_runtab_cap(const DevCfg &c) {        // run descriptors of one tile (k_screen)
    const unsigned n = (unsigned)(c.nscreens * c.ntrks * c.tile_rows) / 8u;
    return n > 2048u ? 2048u : n; }
@@ -1145,6 +1164,7 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    if (decode) { const unsigned r = lds_align16((unsigned)c.lds_units * (unsigned)sizeof(CandUnit)); if (r > off) off = r; }
    L.runcnt = off;    if (!decode) off = lds_align16(off + nst * (T / 8) * 4u);
    L.runtab = off;    if (!decode) off = lds_align16(off + lds_runtab_cap(c) * 8u);
+   L.act = off;       if (!decode) off = lds_align16(off + nst * (T / 8) * 4u);
    L.heights = off;   if (decode) off = lds_align16(off + nwalk * 10u * 4u);
    L.recs = off;      if (decode) off = lds_align16(off + nwalk * (unsigned)c.rec_cap * (unsigned)sizeof(Rec));
    L.nrec = off;      if (decode) off = lds_align16(off + nwalk * 4u);
@@ -1205,7 +1225,8 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    unsigned int *stripcnt = reinterpret_cast<unsigned int *>(smem + L.runcnt);         // [nst][tile_rows / 8] runs | margin units << 16 per strip
    u64 *runtab = reinterpret_cast<u64 *>(smem + L.runtab);           // the tile's run descriptors
    const int tabcap = (int)lds_runtab_cap(cfg);
-   __shared__ int s_nruns;
+   __shared__ int s_nruns, s_nact;
+   unsigned int *act = reinterpret_cast<unsigned int *>(smem + L.act);                  // strips with candidates
    __shared__ int s_total[kMaxScreens * RTFE_MAXTRKS];
    const long long T = cfg.tile_rows;
    for (long long g = blockIdx.x; g < ntiles; g += gridDim.x) {
@@ -1217,29 +1238,34 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
       __syncthreads();
       if (cfg.debug) k1 = clock64();
       if (cfg.cut == 1) continue;
-      run_screens(&cfg, tl, true);
+      if (threadIdx.x == 0) { s_nact = 0; s_nruns = 0; }
+      __syncthreads();
+      run_screens(&cfg, tl, true, act, &s_nact, stripcnt, cfg.tile_rows / kStrip);
       __syncthreads();
       if (cfg.debug) k2 = clock64();
       if (cfg.cut == 2) continue;
       const int nstrips = (tl.nrows + kStrip - 1) / kStrip;
       const int smax = cfg.tile_rows / kStrip;
-      if (threadIdx.x == 0) s_nruns = 0;
-      const FastDiv fds(nstrips), fdt(ntrks);
-      for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {      // the reference's minimum at the bottom candidates
-         const int st = fds.div(i), sc = fdt.div(st);
-         fill_stale(tl, sc, st - sc * ntrks, i - st * nstrips); }
+      const FastDiv fdt(ntrks);
+      const int nactive = s_nact;
+      for (int k = threadIdx.x; k < nactive; k += blockDim.x) {      // the reference's minimum at the bottom candidates
+         const unsigned a = act[k];
+         const int st = (int)(a >> 16), sc = fdt.div(st);
+         fill_stale(tl, sc, st - sc * ntrks, (int)(a & 0xffff)); }
       __syncthreads();
       if (cfg.cut == 3) continue;
       long long k2a = 0, k2b = 0;
       if (cfg.debug) k2a = clock64();
-      for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {
-         const int st = fds.div(i), sc = fdt.div(st);
-         run_starts(tl, sc, st - sc * ntrks, i - st * nstrips); }
+      for (int k = threadIdx.x; k < nactive; k += blockDim.x) {
+         const unsigned a = act[k];
+         const int st = (int)(a >> 16), sc = fdt.div(st);
+         run_starts(tl, sc, st - sc * ntrks, (int)(a & 0xffff)); }
       __syncthreads();
       if (cfg.debug) k2b = clock64();
       if (cfg.cut == 4) continue;
-      for (int i = threadIdx.x; i < nst * nstrips; i += blockDim.x) {
-         const int st = fds.div(i), sc = fdt.div(st), strip = i - st * nstrips;
+      for (int k = threadIdx.x; k < nactive; k += blockDim.x) {
+         const unsigned a = act[k];
+         const int st = (int)(a >> 16), sc = fdt.div(st), strip = (int)(a & 0xffff);
          stripcnt[st * smax + strip] = (unsigned int)list_runs(tl, st, sc, st - sc * ntrks, strip, runtab, &s_nruns, tabcap); }
       __syncthreads();
       // exclusive scan of the strips' unit counts, list by list (one wave per list at a time)
