@@ -846,31 +846,36 @@ __device__ __forceinline__ int list_runs(const Tile &tl, int st, int screen, int
    return relrun | (relmarg << 16); }
 
 // ---- k_screen only: the units of one run -> its place in the list (HBM) ----
+// Four lanes share a run: item 0 = the header, item k = margin unit k-1 (rows n + 4k-3 .. n + 4k); lane `sub` builds
+// items sub, sub+4, ...
 __device__ __forceinline__ void build_run(const Tile &tl, const DevCfg *cfg, int screen, int trk, int W, int n, int kind, int nr,
-                                          int4 *hdr, int moff, int4 *marg) {
+                                          int4 *hdr, int moff, int4 *marg, int sub) {
    const int16_t *yb = tl.x + trk * tl.ldw + tl.halo - cfg->skew[trk];
    const int ld0 = tl.ldmap(screen, kind, trk)[n];
-   int m = 0, prev = 0, next = 0;
-   if (ld0) { const int p = n - W + ld0; m = yb[p]; prev = yb[p - 1]; next = yb[p + 1]; }
-   int4 q;
-   q.x = n | (nr << 11) | (kind << 17) | (moff << 18);
-   q.y = (m & 0xffff) | (ld0 << 16);
-   q.z = (prev & 0xffff) | (next << 16);
-   int4 u = make_int4(0, 0, 0, 0);
-   int slot = 0;
+   const int m = ld0 ? yb[n - W + ld0] : 0;                         // the extreme: lo + left_distance - 1
+   const int nitems = 1 + ((nr + 2) >> 2);
    #pragma nounroll
-   for (int jj = 0; jj < nr; ++jj) {
-      int dl = 0, dr = 0;
+   for (int it = sub; it < nitems; it += 4) {
+      int pr[4] = {0, 0, 0, 0};
+      const int j0 = it == 0 ? 0 : 4 * it - 3, nj = it == 0 ? 1 : min(4, nr - j0);
       if (ld0) {
-         const int L = yb[n + jj - W + 1], R = yb[n + jj];
-         dl = kind ? L - m : m - L; dr = kind ? R - m : m - R;
-         dl = dl < 0 ? 0 : dl; dr = dr < 0 ? 0 : dr; }
-      const int pr = dl | (dr << 16);
-      if (jj == 0) { q.w = pr; *hdr = q; }
-      else {
-         const int c = (jj - 1) & 3;
-         if (c == 0) u.x = pr; else if (c == 1) u.y = pr; else if (c == 2) u.z = pr; else u.w = pr;
-         if (c == 3 || jj == nr - 1) { marg[slot++] = u; u = make_int4(0, 0, 0, 0); } } } }
+         #pragma unroll
+         for (int c = 0; c < 4; ++c) {
+            if (c < nj) {
+               const int L = yb[n + j0 + c - W + 1], R = yb[n + j0 + c];
+               int dl = kind ? L - m : m - L, dr = kind ? R - m : m - R;
+               dl = dl < 0 ? 0 : dl; dr = dr < 0 ? 0 : dr;
+               pr[c] = dl | (dr << 16); } } }
+      if (it == 0) {
+         int prev = 0, next = 0;
+         if (ld0) { const int p = n - W + ld0; prev = yb[p - 1]; next = yb[p + 1]; }
+         int4 q;
+         q.x = n | (nr << 11) | (kind << 17) | (moff << 18);
+         q.y = (m & 0xffff) | (ld0 << 16);
+         q.z = (prev & 0xffff) | (next << 16);
+         q.w = pr[0];
+         *hdr = q; }
+      else marg[it - 1] = make_int4(pr[0], pr[1], pr[2], pr[3]); } }
 
 // i / n for the item loops (n fixed per tile, i < 2^24): one multiply instead of an integer division
 struct FastDiv {
@@ -1227,7 +1232,7 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    const int tabcap = (int)lds_runtab_cap(cfg);
    __shared__ int s_nruns, s_nact;
    unsigned int *act = reinterpret_cast<unsigned int *>(smem + L.act);                  // strips with candidates
-   __shared__ int s_total[kMaxScreens * RTFE_MAXTRKS];
+   __shared__ int s_total[kMaxScreens * RTFE_MAXTRKS], s_lbase[kMaxScreens * RTFE_MAXTRKS];
    const long long T = cfg.tile_rows;
    for (long long g = blockIdx.x; g < ntiles; g += gridDim.x) {
       tl.row0 = g * T; tl.nrows = (int)((tl.row0 + T <= nrows) ? T : nrows - tl.row0);
@@ -1285,21 +1290,20 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
       if (cfg.debug) k3 = clock64();
       if (cfg.cut == 5) continue;
       int tile_units = 0;
-      for (int s2 = 0; s2 < nst; ++s2) tile_units += (s_total[s2] & 0xffff) + (s_total[s2] >> 16);
+      for (int s2 = 0; s2 < nst; ++s2) { if (threadIdx.x == 0) s_lbase[s2] = tile_units; tile_units += (s_total[s2] & 0xffff) + (s_total[s2] >> 16); }
+      __syncthreads();
       const bool tab_ok = s_nruns <= tabcap && tile_units <= nst * cfg.run_cap;
       if (tab_ok)
-         for (int r = threadIdx.x; r < s_nruns; r += blockDim.x) {
+         for (int r = threadIdx.x >> 2; r < s_nruns; r += blockDim.x >> 2) {
             const u64 d = runtab[r];
             const int st = (int)(d & 0xff), kind = (int)((d >> 8) & 1), n = (int)((d >> 16) & 0xffff), nr = (int)((d >> 32) & 0xff);
             const int relrun = (int)((d >> 40) & 0x3ff), relmarg = (int)(d >> 50);
             const int sc = fdt.div(st);
             const unsigned sb = stripcnt[st * smax + (n >> 3)];
-            int lbase = 0;
-            for (int s2 = 0; s2 < st; ++s2) lbase += (s_total[s2] & 0xffff) + (s_total[s2] >> 16);     // the tile's lists are packed one behind the other
-            int4 *list = reinterpret_cast<int4 *>(pool) + (size_t)g * nst * cfg.run_cap + lbase;
+            int4 *list = reinterpret_cast<int4 *>(pool) + (size_t)g * nst * cfg.run_cap + s_lbase[st];      // the tile's lists are packed one behind the other
             const int moff = (int)(sb >> 16) + relmarg;
             build_run(tl, &cfg, sc, st - sc * ntrks, cfg.screen[sc].W, n, kind, nr, list + (sb & 0xffff) + relrun, moff,
-                      list + (s_total[st] & 0xffff) + moff); }
+                      list + (s_total[st] & 0xffff) + moff, (int)(threadIdx.x & 3)); }
       if (threadIdx.x < nst) {
          const int st = threadIdx.x, sc = st / ntrks, trk = st - sc * ntrks;
          TileDir d;
