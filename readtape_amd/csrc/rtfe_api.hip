@@ -73,7 +73,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    for (int i = 0; i < c->ntrks; ++i) {
       int t = c->head_to_trk[i];
       if (t < 0 || t >= c->ntrks || seen[t]) { delete h; return fail(-8, "head_to_trk is not a permutation"); }
-      seen[t] = true; d.head_to_trk[i] = t;
+      seen[t] = true; d.head_to_trk[i] = t; d.trk_to_head[t] = i;
       int s = c->skew_delaycnt[i];
       if (s < 0 || s > 50) { delete h; return fail(-9, "skew %d out of range 0..50 (MAXSKEWSAMP)", s); }
       d.skew[i] = s; if (s > d.maxskew) d.maxskew = s; }
@@ -145,9 +145,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       for (int sidx = 0; sidx < d.nscreens; ++sidx) if (d.screen[sidx].W > wmax) wmax = d.screen[sidx].W;
       d.halo_rows = (kScreenHalo + wmax + 1 + d.maxskew + 7) & ~7;
       if (d.halo_rows > kMaxHaloRows) d.halo_rows = kMaxHaloRows;
-      int pad = 16;                                                   // (measured: a row stride of halo+tile+8 elements costs 20 % in LDS bank conflicts)
-      if (getenv("RTFE_LDW_PAD")) { pad = atoi(getenv("RTFE_LDW_PAD")); if (pad < 8 || pad > 256 || (pad & 1)) pad = 16; }
-      d.ldw = d.halo_rows + d.tile_rows + pad; }
+      d.ldw = d.halo_rows + d.tile_rows + 8; }
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
    d.cut = getenv("RTFE_CUT") ? atoi(getenv("RTFE_CUT")) : 0;

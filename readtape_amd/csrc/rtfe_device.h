@@ -38,6 +38,7 @@ struct DevCfg {
    int   samples_per_bit;         // (int)(1/(bpi*ips*sample_deltat)), src/readtape.c:1402
    int   zc_peak_i;               // smallest positive int16 code c with volt(c) > ZEROCROSS_PEAK (0.2 V, src/decoder.h:138)
    int   head_to_trk[RTFE_MAXTRKS];   // TBIN column -> track (src/readtape.c:1419)
+   int   trk_to_head[RTFE_MAXTRKS];   // ... and back: the column of the sample tile that holds a track
    int   skew[RTFE_MAXTRKS];
    int   maxskew;
    float maxvolts;
@@ -48,7 +49,7 @@ struct DevCfg {
    float cap_frac;                // event capacity per track as a fraction of burst length
    int   tile_rows;               // rows per LDS tile (multiple of 64, kMarginRows..kMaxTileRows)
    int   halo_rows;               // rows kept in front of a tile: kScreenHalo + widest window + 1 + max skew, rounded up to 8
-   int   ldw;                     // int16 elements per track row of the LDS sample tile (halo_rows + tile_rows + padding)
+   int   ldw;                     // rows of the LDS sample tile (halo_rows + tile_rows + 8)
    float lsb_per_volt;            // 32767 / maxvolts, for the walkers' integer guard bands
    int   run_cap;                 // candidate-run records per (screen, track) per tile (LDS)
    int   rec_cap;                 // deferred-event records per walker per tile (LDS)

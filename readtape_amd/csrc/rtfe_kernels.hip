@@ -224,9 +224,10 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
 // k_decode
 // ------------------------------------------------------------------------------------------------
 struct Tile {
-   int16_t *x;            // LDS: [ntrks][ldw] raw samples by TRACK (after -invert), index = row - row0 + halo
+   int16_t *x;            // LDS: [halo + tile rows][ntrks] the tape's rows as they are (head order, after -invert): a flat copy
    int      halo;         // rows kept in front of the tile (DevCfg::halo_rows)
-   int      ldw;          // row stride of x
+   int      ldw;          // (unused)
+   const int *colof;      // track -> head column (DevCfg::trk_to_head)
    long long row0;        // first row of the tile proper
    int      nrows;        // rows in the tile proper
    long long reset;       // burst restart row (deskew FIFO restarts there, src/decoder.c:415)
@@ -237,7 +238,7 @@ struct Tile {
    int      ldstride;     // tile_rows + kScreenHalo
    int      ntrks;
    const int *skew;
-   __device__ __forceinline__ int xi(int t, long long n) const { return x[t * ldw + (int)(n - row0) + halo]; }
+   __device__ __forceinline__ int xi(int t, long long n) const { return x[((int)(n - row0) + halo) * ntrks + colof[t]]; }
    // v_now of track t at row n in int16 units, with the deskew FIFO exactly as the reference runs it
    // from the restart row: undelayed until the FIFO has filled (src/decoder.c:825-827), then delayed
    __device__ __forceinline__ int y(int t, long long n) const {
@@ -248,6 +249,13 @@ struct Tile {
    __device__ __forceinline__ const u64 *map(int screen, int kind, int t) const {               // [word], words >= -1
       return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 5 + kind) * ntrks + t) * bstride + kScreenHalo / 8); }
 };
+
+// one track's column of the sample tile, indexed by tile-relative row (after the deskew delay)
+struct Col {
+   const int16_t *p; int P;
+   __device__ __forceinline__ int operator[](int i) const { return p[i * P]; } };
+__device__ __forceinline__ Col tile_col(const Tile &tl, int trk, int delay) {
+   Col c; c.P = tl.ntrks; c.p = tl.x + (tl.halo - delay) * tl.ntrks + tl.colof[trk]; return c; }
 
 __device__ __forceinline__ float volt(int i, float maxvolts) {      // src/readtape.c:1420
    return (float)i / 32767 * maxvolts; }
@@ -586,7 +594,7 @@ __device__ __forceinline__ bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, c
    const Tile &tl = cx.tile;
    const int W = P.W;
    const float mv = cfg->maxvolts;
-   const int16_t *yb = tl.x + trk * tl.ldw + tl.halo - cfg->skew[trk];
+   const Col yb = tile_col(tl, trk, cfg->skew[trk]);
    const int lo = n - W + 1;
    const int vl = yb[lo], vr = yb[n];
    bool hit = false, is_top = false;
@@ -850,7 +858,7 @@ __device__ __forceinline__ int list_runs(const Tile &tl, int st, int screen, int
 // items sub, sub+4, ...
 __device__ __forceinline__ void build_run(const Tile &tl, const DevCfg *cfg, int screen, int trk, int W, int n, int kind, int nr,
                                           int4 *hdr, int moff, int4 *marg, int sub) {
-   const int16_t *yb = tl.x + trk * tl.ldw + tl.halo - cfg->skew[trk];
+   const Col yb = tile_col(tl, trk, cfg->skew[trk]);
    const int ld0 = tl.ldmap(screen, kind, trk)[n];
    const int m = ld0 ? yb[n - W + ld0] : 0;                         // the extreme: lo + left_distance - 1
    const int nitems = 1 + ((nr + 2) >> 2);
@@ -892,7 +900,7 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
    // kmin = v<<8 | r  (min -> smallest v, then smallest r).
    const int W = sc.W;
    const int d = tl.skew[trk];
-   const int16_t *base = tl.x + trk * tl.ldw + tl.halo - d;     // y(n) = base[n - row0] in the regular regime
+   const Col base = tile_col(tl, trk, d);                          // y(n) = base[n - row0] in the regular regime
    const int s0 = strip * kStrip;
    int v[kStrip], L[kStrip];
    #pragma unroll
@@ -946,18 +954,17 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
    reinterpret_cast<u64 *>(tl.ldmap(screen, 1, trk))[strip] = ldb;
    return topb | botb; }
 
-// cooperative tile load: rows [row0 - halo, row0 + nrows) of the AoS payload -> SoA LDS by track
-// (trkoff[c] = head_to_trk[c] * ldw, a per-workgroup LDS table)
-__device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows, const int *trkoff) {
+// cooperative tile load: rows [row0 - halo, row0 + nrows) of the AoS payload -> LDS, as they are (16-byte vectors;
+// the tile starts on a multiple of 8 rows, so vectors are aligned in HBM and in LDS).  -invert negates on the way.
+__device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows) {
    const int ntrks = cfg->ntrks;
-   const long long first = tl.row0 - tl.halo;                     // multiple of 8 rows => 16-byte aligned
-   const int nload = tl.halo + tl.nrows;
-   const int nelem = nload * ntrks;
+   const long long first = tl.row0 - tl.halo;
+   const int nelem = (tl.halo + tl.nrows) * ntrks;
    const int nvec = (nelem + 7) >> 3;
    const long long total_elem = total_rows * ntrks;
    const long long e_first = first * ntrks;
-   const int inv = cfg->invert ? -1 : 0;
-   const FastDiv fd(ntrks);
+   const bool inv = cfg->invert != 0;
+   int4 *dst = reinterpret_cast<int4 *>(tl.x);
    constexpr int kBatch = 6;                                      // independent 16-B loads in flight per lane
    for (int vbase = 0; vbase < nvec; vbase += kBatch * (int)blockDim.x) {
       int4 q[kBatch];
@@ -966,30 +973,24 @@ __device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int
          const int vi = vbase + k * (int)blockDim.x + (int)threadIdx.x;
          const long long ge = e_first + (long long)vi * 8;
          q[k] = make_int4(0, 0, 0, 0);
-         if (vi < nvec && ge >= 0 && ge + 8 <= total_elem) q[k] = *reinterpret_cast<const int4 *>(rows + ge); }
+         if (vi < nvec) {
+            if (ge >= 0 && ge + 8 <= total_elem) q[k] = *reinterpret_cast<const int4 *>(rows + ge);
+            else {                                                    // tape ends: sample by sample, zeros outside
+               int e[8];
+               #pragma unroll
+               for (int j = 0; j < 8; ++j) { const long long g = ge + j; e[j] = (g >= 0 && g < total_elem) ? (int)(unsigned short)rows[g] : 0; }
+               q[k] = make_int4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)); } } }
       #pragma unroll
       for (int k = 0; k < kBatch; ++k) {
          const int vi = vbase + k * (int)blockDim.x + (int)threadIdx.x;
          if (vi >= nvec) continue;
-         const int e0 = vi * 8;
-         int r = fd.div(e0), c = e0 - r * ntrks;
-         const long long ge = e_first + e0;
-         const int qq[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-         if (ge >= 0 && ge + 8 <= total_elem && e0 + 8 <= nelem) {      // the common case: all eight samples wanted and present
-            #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-               int sv = (j & 1) ? (qq[j >> 1] >> 16) : (int)(short)(qq[j >> 1] & 0xffff);
-               sv = (sv ^ inv) - inv;                                  // -invert
-               tl.x[trkoff[c] + r] = (int16_t)sv;
-               if (++c == ntrks) { c = 0; ++r; } } }
-         else {
-            #pragma nounroll
-            for (int j = 0; j < 8; ++j) {                              // tape ends / the tile's last vector
-               const long long g = ge + j;
-               int sv = (g >= 0 && g < total_elem) ? rows[g] : 0;
-               sv = (sv ^ inv) - inv;
-               if (r < nload) tl.x[trkoff[c] + r] = (int16_t)sv;
-               if (++c == ntrks) { c = 0; ++r; } } } } } }
+         int4 v = q[k];
+         if (inv) {                                                   // two int16 per dword: 0 - x, halves independently
+            v.x = (int)((((unsigned)(-(v.x << 16))) >> 16) | ((unsigned)(-(v.x >> 16)) << 16));
+            v.y = (int)((((unsigned)(-(v.y << 16))) >> 16) | ((unsigned)(-(v.y >> 16)) << 16));
+            v.z = (int)((((unsigned)(-(v.z << 16))) >> 16) | ((unsigned)(-(v.z >> 16)) << 16));
+            v.w = (int)((((unsigned)(-(v.w << 16))) >> 16) | ((unsigned)(-(v.w >> 16)) << 16)); }
+         dst[vi] = v; } } }
 
 // act / nact (k_screen only): the strips of the tile proper that hold candidates, compacted (st << 16 | strip) so that
 // the sparse passes behind the screen keep every lane busy; stripcnt of every strip is cleared on the way
@@ -998,14 +999,15 @@ __device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl, b
    const int hs = with_halo ? kScreenHalo / kStrip : 0;            // k_screen also screens the rows in front of the tile
    const int nstrips = (tl.nrows + kStrip - 1) / kStrip + hs;
    const int per_screen = nstrips * cfg->ntrks;
-   const FastDiv fd(nstrips);
+   const FastDiv fd(cfg->ntrks);
    for (int s = 0; s < cfg->nscreens; ++s)
       for (int i0 = 0; i0 < per_screen; i0 += blockDim.x) {         // (uniform trip count: the ballot below needs whole waves)
          const int i = i0 + (int)threadIdx.x;
          const bool valid = i < per_screen;
          int t = 0, strip = 0, any = 0;
-         if (valid) {
-            t = fd.div(i); strip = i - t * nstrips - hs;
+         if (valid) {                                               // consecutive lanes = the tracks of one strip: consecutive LDS words
+            const int q = fd.div(i);
+            t = i - q * cfg->ntrks; strip = q - hs;
             any = screen_strip(tl, cfg->screen[s], s, t, strip); }
          if (act) {
             const int st = s * cfg->ntrks + t;
@@ -1160,7 +1162,7 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    LdsLayout L;
    const unsigned ntrks = (unsigned)c.ntrks, nst = (unsigned)c.nscreens * ntrks, nwalk = (unsigned)c.nparm * ntrks;
    const unsigned T = (unsigned)c.tile_rows;
-   unsigned off = lds_align16(ntrks * (unsigned)c.ldw * 2u);
+   unsigned off = lds_align16(ntrks * (unsigned)c.ldw * 2u + 16u);          // (ldw rows of ntrks samples, + one vector of slack)
    L.bits = off;      off = lds_align16(off + nst * 5u * ((T + kScreenHalo) / 8 + 8));
    L.ldpos = off;     off = lds_align16(off + nst * 2u * (T + kScreenHalo));
    // k_decode: the candidate records of a tile share the space of the sample tile (a tile is decided either from
@@ -1215,15 +1217,13 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
    __shared__ DevCfg cfg;
-   __shared__ int s_trkoff[RTFE_MAXTRKS];
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
-   if (threadIdx.x < cfg.ntrks) s_trkoff[threadIdx.x] = cfg.head_to_trk[threadIdx.x] * cfg.ldw;
    const int ntrks = cfg.ntrks, nst = cfg.nscreens * ntrks;
    const LdsLayout L = lds_layout(cfg, false);
    Tile tl;
    tl.x = reinterpret_cast<int16_t *>(smem);
-   tl.ldw = cfg.ldw; tl.halo = cfg.halo_rows;
+   tl.ldw = cfg.ldw; tl.halo = cfg.halo_rows; tl.colof = cfg.trk_to_head;
    tl.ntrks = ntrks; tl.skew = cfg.skew; tl.reset = -(1ll << 40);
    tl.bits = smem + L.bits; tl.bstride = (cfg.tile_rows + kScreenHalo) / 8 + 8;
    tl.ldpos = smem + L.ldpos; tl.ldstride = cfg.tile_rows + kScreenHalo;
@@ -1239,7 +1239,7 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
       __syncthreads();
       long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
       if (cfg.debug) k0 = clock64();
-      load_tile(&cfg, tl, rows, nrows, s_trkoff);
+      load_tile(&cfg, tl, rows, nrows);
       __syncthreads();
       if (cfg.debug) k1 = clock64();
       if (cfg.cut == 1) continue;
@@ -1313,7 +1313,7 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
          const int last = tl.nrows - 1;
          const int eld = stale_ld(tl.map(sc, 2, trk), tl.ldmap(sc, 1, trk), last);
          d.end_ld = (uint8_t)eld; d.pad = 0;
-         d.end_min = eld ? tl.x[trk * tl.ldw + tl.halo - cfg.skew[trk] + last - cfg.screen[sc].W + eld] : (int16_t)0;
+         d.end_min = eld ? (int16_t)tile_col(tl, trk, cfg.skew[trk])[last - cfg.screen[sc].W + eld] : (int16_t)0;
          dir[g * nst + st] = d; }
       if (cfg.debug) {
          __syncthreads();
@@ -1384,7 +1384,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
    Ctx cx;
    cx.cfg = &cfg;
    cx.row_base = row_base;
-   cx.tile.x = nullptr; cx.tile.ldw = 0; cx.tile.ntrks = ntrks; cx.tile.skew = cfg.skew;
+   cx.tile.x = nullptr; cx.tile.ldw = 0; cx.tile.halo = 0; cx.tile.colof = cfg.trk_to_head; cx.tile.ntrks = ntrks; cx.tile.skew = cfg.skew;
    cx.tile.bits = nullptr; cx.tile.bstride = 0; cx.tile.ldpos = nullptr; cx.tile.ldstride = 0;
    cx.heights = heights_all + (size_t)(is_walker ? my_w : 0) * 10;
    cx.rec_cap = 0; cx.rec_cap16 = cfg.rec_cap16;
@@ -1778,8 +1778,6 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    if (screen_off && threadIdx.x == 0)
       for (int s = 0; s < cfg.nscreens; ++s) { cfg.screen[s].rise_i = -70000; cfg.screen[s].minpk_i = -1; }
    if (screen_off) for (int i = threadIdx.x; i < cfg.nparm; i += blockDim.x) { cfg.parm[i].screen_rise_v = -1; cfg.parm[i].screen_minpk_v = -1; }
-   __shared__ int s_trkoff[RTFE_MAXTRKS];
-   if (threadIdx.x < cfg.ntrks) s_trkoff[threadIdx.x] = cfg.head_to_trk[threadIdx.x] * cfg.ldw;
    __syncthreads();
    const int ntrks = cfg.ntrks;
    const int ldw = cfg.ldw;
@@ -1787,7 +1785,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    cx.cfg = &cfg;
    cx.row_base = row_base;
    cx.tile.x = reinterpret_cast<int16_t *>(smem);
-   cx.tile.ldw = ldw; cx.tile.halo = cfg.halo_rows;
+   cx.tile.ldw = ldw; cx.tile.halo = cfg.halo_rows; cx.tile.colof = cfg.trk_to_head;
    cx.tile.ntrks = ntrks;
    cx.tile.skew = cfg.skew;
    const LdsLayout L = lds_layout(cfg, true);
@@ -1820,7 +1818,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       if (cfg.find_zeros) return Z.zone_end - kMarginRows;       // any restart inside the zone is equivalent
       cx.tile.row0 = Z.zone_end - kMarginRows; cx.tile.nrows = kMarginRows; cx.tile.reset = -(1ll << 40);
       __syncthreads();
-      load_tile(&cfg, cx.tile, rows, nrows, s_trkoff);
+      load_tile(&cfg, cx.tile, rows, nrows);
       __syncthreads();
       run_screens(&cfg, cx.tile, false);
       __syncthreads();
@@ -1949,7 +1947,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
                __syncthreads(); } }
          if (done_tile) continue;
          // ---- full path: samples into LDS, screen, exact walkers ----
-         load_tile(&cfg, cx.tile, rows, nrows, s_trkoff);
+         load_tile(&cfg, cx.tile, rows, nrows);
          __syncthreads();
          if (cfg.debug) c1 = clock64();
          run_screens(&cfg, cx.tile, false);
