@@ -1501,7 +1501,8 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                const DevParm &P = cfg.parm[pidx];
                my_st = my_st0; my_nruns = s_dir[my_st].nruns;
                bool ok = w.fast && tile0 - kScreenHalo >= w.trust_from && whole && s_dir[my_st].end_ld != 0
-                         && w.peakcount >= 16 && w.v_avg_height_count == 0 && w.agc_gain > 0 && w.nevents + (unsigned)cfg.rec_cap16 < cx.cap;
+                         && ((w.peakcount >= 16 && w.v_avg_height_count == 0) || my_nruns == 0)       // steady state, or nothing to decide (a silent track)
+                         && w.agc_gain > 0 && w.nevents + (unsigned)cfg.rec_cap16 < cx.cap;
                if (ok) {
                   const float s4 = w.v_avg_height * 0.25f * fast_rcp(w.agc_gain);
                   const float rv = P.rise * s4, mv4 = P.min_peak * s4;

@@ -58,6 +58,21 @@ def test_fresh_nrzi_tapes(seed, nblocks, maxlen, tmp_path, gpu):
     assert stats["flags"] == 0
 
 
+def test_text_tape_with_a_silent_track(tmp_path, gpu):
+    """7-bit text: one track carries no flux transitions inside the blocks (its walker never reaches the AGC's steady
+    state); the other eight must still take the parallel tile path, and every event must match."""
+    spec = synth.nrzi_spec(seed=51)
+    rng = np.random.default_rng(51)
+    items = [("block", bytes(rng.integers(0, 128, size=int(n), dtype=np.int64).astype(np.uint8))) for n in (700, 1500, 90, 2500)]
+    tape = synth.make_tape(spec, items, gap_samples=4000)
+    hdr = tape.spec.header()
+    att = oracle_attempts(hdr, tape.rows, [], str(tmp_path))
+    fe = frontend.FrontEnd(config_for(hdr, []))
+    msgs, stats = check_tape(fe, hdr, tape.rows, att)
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["events"] > 0
+
+
 def test_fresh_pe_tape(tmp_path, gpu):
     tape = synth.pe_tape(seed=31, nblocks=8, minlen=64, maxlen=1500, gap_samples=4000)
     hdr = tape.spec.header()
