@@ -166,7 +166,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       d.lds_units = (lu + 63) & ~63;
       d.pm_cap = d.lds_units / 2 * ((c->nparmsets + d.nscreens - 1) / d.nscreens);
       int r16 = 2 * peaks + 8;
-      const int r16max = (16 * 1024) / (nwalk * 16);
+      const int r16max = (40 * 1024) / (nwalk * 16);                    // (parameter-set sweeps: many walkers, fewer bursts resident)
       if (r16 > r16max) r16 = r16max;
       d.rec_cap16 = r16 > 64 ? 64 : (r16 < 8 ? 8 : r16);
       // test knobs (tests/ only): force the rare paths - lists through LDS in several groups, tiles handed back to k_decode
