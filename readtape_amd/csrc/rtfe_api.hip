@@ -268,7 +268,12 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (h->timing) (void)hipEventRecord(h->ev[2], st);
    TileDir *dirp = reinterpret_cast<TileDir *>(reinterpret_cast<char *>(d_workspace) + ws_dir_off(h, nrows));
    CandUnit *poolp = reinterpret_cast<CandUnit *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
-   const bool use_screen = !h->dev.find_zeros && getenv("RTFE_NO_SCREEN_PASS") == nullptr;
+   // The record path (k_screen -> k_walk) pays when flux transitions are at least a bit cell apart (NRZI): then a run of
+   // candidate rows has one kind.  PE and GCR put a top and a bottom into the window at the same time; their candidate
+   // lists degenerate into one-row runs and overflow, so they take the sample path for the whole burst.
+   // RTFE_RECORD_PATH=0/1 overrides (tests keep both paths covered for every format).
+   bool use_screen = !h->dev.find_zeros && h->dev.mode == RTFE_NRZI;
+   if (const char *e = getenv("RTFE_RECORD_PATH")) use_screen = !h->dev.find_zeros && atoi(e) != 0;
    if (use_screen) {
       const long long ntiles = ntiles_for(h, nrows);
       int spc = (160 * 1024) / (h->screen_lds_bytes + 1024);
@@ -290,7 +295,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    const int dgrid = h->num_cus * per_cu;
    BurstCtl *ctlp = reinterpret_cast<BurstCtl *>(reinterpret_cast<char *>(d_workspace) + ws_ctl_off(h, nrows));
    WalkState *statep = reinterpret_cast<WalkState *>(reinterpret_cast<char *>(d_workspace) + ws_state_off(h, nrows));
-   if (!use_screen) {                                                 // -zeros: the whole burst in one pass over the samples
+   if (!use_screen) {                                                 // -zeros, PE, GCR: the whole burst in one pass over the samples
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
                          (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeAll, ctlp, statep);

@@ -23,8 +23,9 @@ def test_emulated_kernels_match_oracle(name, tmp_path):
 
 @pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_LDS_UNITS": "256"}),            # lists through LDS in several groups
                                         ("nrzi9", {"RTFE_REC_CAP16": "4"}),             # k_walk hands tiles back to k_decode
-                                        ("gcr", {"RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}),
-                                        ("pe", {"RTFE_REC_CAP16": "8"})])
+                                        ("gcr", {"RTFE_RECORD_PATH": "1", "RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}),
+                                        ("pe", {"RTFE_RECORD_PATH": "1", "RTFE_REC_CAP16": "8"}),
+                                        ("gcr", {"RTFE_RECORD_PATH": "1"}), ("nrzi9", {"RTFE_RECORD_PATH": "0"})])
 def test_emulated_rare_paths_of_the_record_walk(name, knobs, tmp_path, monkeypatch):
     """Small LDS budgets force k_walk's rare paths (grouped lists, the sequential walk, give-back to the second
     k_decode pass): the events must not change."""

@@ -31,8 +31,10 @@ def test_golden_tapes(name, tmp_path, gpu):
 
 
 @pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_LDS_UNITS": "256"}), ("nrzi9", {"RTFE_REC_CAP16": "4"}),
-                                        ("gcr", {"RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}), ("pe_m", {"RTFE_REC_CAP16": "8"}),
-                                        ("nrzi9_m", {"RTFE_LDS_UNITS": "512"})])
+                                        ("gcr", {"RTFE_RECORD_PATH": "1", "RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}),
+                                        ("pe_m", {"RTFE_RECORD_PATH": "1", "RTFE_REC_CAP16": "8"}),
+                                        ("pe", {"RTFE_RECORD_PATH": "1"}), ("gcr_m", {"RTFE_RECORD_PATH": "1"}),
+                                        ("nrzi9", {"RTFE_RECORD_PATH": "0"}), ("nrzi9_m", {"RTFE_LDS_UNITS": "512"})])
 def test_rare_paths_of_the_record_walk(name, knobs, tmp_path, gpu, monkeypatch):
     """Small LDS budgets force k_walk's rare paths (grouped lists, the sequential walk, give-back to the second
     k_decode pass): the events must not change."""
