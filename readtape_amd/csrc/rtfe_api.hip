@@ -33,7 +33,7 @@ struct rtfe_handle {
    int lds_bytes;
    int num_cus;
    int timing;
-   hipEvent_t ev[7];
+   hipEvent_t ev0[6], ev1[6];          // start / stop of each kernel of the last scan (on the stream it ran on)
    int screen_lds_bytes;
    int walk_lds_bytes;
 };
@@ -190,20 +190,21 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
 
 extern "C" int rtfe_set_timing(rtfe_handle *h, int enable) {
    if (!h) return fail(-1, "null argument");
-   if (enable && !h->timing) for (int i = 0; i <= kNumKernels; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
-   if (!enable && h->timing) for (int i = 0; i <= kNumKernels; ++i) (void)hipEventDestroy(h->ev[i]);
+   if (enable && !h->timing) for (int i = 0; i < kNumKernels; ++i) if (hipEventCreate(&h->ev0[i]) != hipSuccess || hipEventCreate(&h->ev1[i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
+   if (!enable && h->timing) for (int i = 0; i < kNumKernels; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
    h->timing = enable != 0;
    return 0; }
 
 extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
    if (!h || !out || !h->timing) return fail(-41, "timing is not enabled");
-   if (hipEventSynchronize(h->ev[kNumKernels]) != hipSuccess) return fail(-42, "hipEventSynchronize failed");
-   for (int i = 0; i < kNumKernels; ++i) if (hipEventElapsedTime(&out[i], h->ev[i], h->ev[i + 1]) != hipSuccess) return fail(-43, "hipEventElapsedTime failed");
+   for (int i = 0; i < kNumKernels; ++i) {
+      if (hipEventSynchronize(h->ev1[i]) != hipSuccess) return fail(-42, "hipEventSynchronize failed");
+      if (hipEventElapsedTime(&out[i], h->ev0[i], h->ev1[i]) != hipSuccess) return fail(-43, "hipEventElapsedTime failed"); }
    return 0; }
 
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
-   if (h->timing) for (int i = 0; i <= kNumKernels; ++i) (void)hipEventDestroy(h->ev[i]);
+   if (h->timing) for (int i = 0; i < kNumKernels; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
    (void)hipFree(h->d_dev);
    delete h; }
 
@@ -259,31 +260,16 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    BurstScratch *scratch = reinterpret_cast<BurstScratch *>(d_workspace);
    unsigned long long *qwords = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_workspace) + kScratchBytes);
    int grid = (int)(nwords < (long long)h->num_cus * 8 ? nwords : (long long)h->num_cus * 8);
-   if (h->timing) (void)hipEventRecord(h->ev[0], st);
-   hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, st, d_rows, nelem, h->dev.quiet_i, qwords, nwords);
-   if (h->timing) (void)hipEventRecord(h->ev[1], st);
-   hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
-                      h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
-                      d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts);
-   if (h->timing) (void)hipEventRecord(h->ev[2], st);
    TileDir *dirp = reinterpret_cast<TileDir *>(reinterpret_cast<char *>(d_workspace) + ws_dir_off(h, nrows));
    CandUnit *poolp = reinterpret_cast<CandUnit *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
+   BurstCtl *ctlp = reinterpret_cast<BurstCtl *>(reinterpret_cast<char *>(d_workspace) + ws_ctl_off(h, nrows));
+   WalkState *statep = reinterpret_cast<WalkState *>(reinterpret_cast<char *>(d_workspace) + ws_state_off(h, nrows));
    // The record path (k_screen -> k_walk) pays when flux transitions are at least a bit cell apart (NRZI): then a run of
    // candidate rows has one kind.  PE and GCR put a top and a bottom into the window at the same time; their candidate
    // lists degenerate into one-row runs and overflow, so they take the sample path for the whole burst.
    // RTFE_RECORD_PATH=0/1 overrides (tests keep both paths covered for every format).
    bool use_screen = !h->dev.find_zeros && h->dev.mode == RTFE_NRZI;
    if (const char *e = getenv("RTFE_RECORD_PATH")) use_screen = !h->dev.find_zeros && atoi(e) != 0;
-   if (use_screen) {
-      const long long ntiles = ntiles_for(h, nrows);
-      int spc = (160 * 1024) / (h->screen_lds_bytes + 1024);
-      if (spc > 8) spc = 8;
-      if (spc < 1) spc = 1;
-      long long sgrid = (long long)h->num_cus * spc;
-      if (sgrid > ntiles) sgrid = ntiles;
-      hipLaunchKernelGGL(k_screen, dim3((unsigned)sgrid), dim3(256), h->screen_lds_bytes, st, h->d_dev, d_rows, (long long)nrows, dirp, poolp,
-                         ntiles, scratch->scr); }
-   if (h->timing) (void)hipEventRecord(h->ev[3], st);
    // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
    // beat wide ones; k_decode holds ~250 VGPRs => 2 waves/SIMD => 8 waves per CU
    const int nwalk = h->dev.nparm * h->dev.ntrks;
@@ -293,32 +279,55 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (per_cu > wave_lim) per_cu = wave_lim;
    if (per_cu < 1) per_cu = 1;
    const int dgrid = h->num_cus * per_cu;
-   BurstCtl *ctlp = reinterpret_cast<BurstCtl *>(reinterpret_cast<char *>(d_workspace) + ws_ctl_off(h, nrows));
-   WalkState *statep = reinterpret_cast<WalkState *>(reinterpret_cast<char *>(d_workspace) + ws_state_off(h, nrows));
+   // (k_quiet, k_bursts and the burst heads do not depend on k_screen, but running them beside it on a second stream
+   //  loses: the single-workgroup k_bursts starves behind k_screen's workgroups - measured 9.6 vs 10.7 Gsamples/s)
+   hipStream_t sq = st;
+   auto t0 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev0[k], s2); };
+   auto t1 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev1[k], s2); };
+   t0(0, sq);
+   hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, sq, d_rows, nelem, h->dev.quiet_i, qwords, nwords);
+   t1(0, sq); t0(1, sq);
+   hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, sq, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
+                      h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
+                      d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts);
+   t1(1, sq);
    if (!use_screen) {                                                 // -zeros, PE, GCR: the whole burst in one pass over the samples
+      t0(2, st); t1(2, st); t0(3, st);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
                          (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeAll, ctlp, statep);
-      if (h->timing) for (int i = 4; i <= kNumKernels; ++i) (void)hipEventRecord(h->ev[i], st); }
+      t1(3, st); t0(4, st); t1(4, st); t0(5, st); t1(5, st); }
    else {
       // burst heads from the samples (start-up path) -> the record walk -> whatever the records could not decide
-      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+      t0(3, sq);
+      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, sq, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
                          (const TileDir *)dirp, (const CandUnit *)poolp, (int)kDecodeHead, ctlp, statep);
-      if (h->timing) (void)hipEventRecord(h->ev[4], st);
+      t1(3, sq);
+      const long long ntiles = ntiles_for(h, nrows);
+      int spc = (160 * 1024) / (h->screen_lds_bytes + 1024);
+      if (spc > 8) spc = 8;
+      if (spc < 1) spc = 1;
+      long long sgrid = (long long)h->num_cus * spc;
+      if (sgrid > ntiles) sgrid = ntiles;
+      t0(2, st);
+      hipLaunchKernelGGL(k_screen, dim3((unsigned)sgrid), dim3(256), h->screen_lds_bytes, st, h->d_dev, d_rows, (long long)nrows, dirp, poolp,
+                         ntiles, scratch->scr);
+      t1(2, st);
       int wthreads = threads;
       if (getenv("RTFE_WALK_THREADS")) { const int v = atoi(getenv("RTFE_WALK_THREADS")); if (v >= threads && v <= 256 && v % 64 == 0) wthreads = v; }
       int wpc = (160 * 1024) / (h->walk_lds_bytes + 1024);
       const int wlim = 16 / (wthreads / 64);
       if (wpc > wlim) wpc = wlim;
       if (wpc < 1) wpc = 1;
+      t0(4, st);
       hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
                          d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep);
-      if (h->timing) (void)hipEventRecord(h->ev[5], st);
+      t1(4, st); t0(5, st);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
                          (const TileDir *)dirp, (const CandUnit *)poolp, (int)kDecodeResume, ctlp, statep);
-      if (h->timing) (void)hipEventRecord(h->ev[6], st); }
+      t1(5, st); }
    return launch_check("rtfe_scan"); }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

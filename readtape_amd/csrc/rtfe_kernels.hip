@@ -1906,7 +1906,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          if (cfg.debug) c0 = clock64();
          // ---- decide the whole tile from the candidate records k_screen left in HBM ----
          bool done_tile = false;
-         if (dir && !screen_off && !cfg.find_zeros) {
+         if (dir && !screen_off && !cfg.find_zeros && mode != kDecodeHead) {     // (the heads may run beside k_screen: no lists yet)
             const int nst = cfg.nscreens * ntrks;
             if (threadIdx.x == 0) s_needfull = 0;
             if (threadIdx.x < nst) s_dir[threadIdx.x] = dir[g * nst + threadIdx.x];
