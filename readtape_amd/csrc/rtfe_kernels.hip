@@ -130,49 +130,58 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
          bursts[0] = b;
          s_base = 1; } }
    __syncthreads();
-   for (long long w0 = 0; w0 < nwords; w0 += 1024) {
-      const long long w = w0 + threadIdx.x;
-      u64 ends = 0;
-      if (w < nwords) {
-         const u64 q = qwords[w];
-         const u64 qn = (w + 1 < nwords) ? qwords[w + 1] : 0;
-         const u64 next = (q >> 1) | (qn << 63);         // bit c = quiet[c+1]
-         u64 cand = q & ~next;                           // quiet and successor not quiet
-         while (cand) {
-            const int bit = __ffsll((long long)cand) - 1;
-            cand &= cand - 1;
-            const long long c = w * 64 + bit;
-            bool ok = true;
-            for (int k = 1; k < gap_chunks; ++k) if (!quiet_at(qwords, c - k, nchunks)) { ok = false; break; }
-            if (ok) ends |= 1ull << bit; } }
+   constexpr int kPer = 4;                                          // consecutive words per thread per round (fewer block scans)
+   for (long long w0 = 0; w0 < nwords; w0 += 1024 * kPer) {
+      u64 ends[kPer];
+      int cnt = 0;
+      #pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+         const long long w = w0 + (long long)threadIdx.x * kPer + j;
+         ends[j] = 0;
+         if (w < nwords) {
+            const u64 q = qwords[w];
+            const u64 qn = (w + 1 < nwords) ? qwords[w + 1] : 0;
+            const u64 next = (q >> 1) | (qn << 63);         // bit c = quiet[c+1]
+            u64 cand = q & ~next;                           // quiet and successor not quiet
+            while (cand) {
+               const int bit = __ffsll((long long)cand) - 1;
+               cand &= cand - 1;
+               const long long c = w * 64 + bit;
+               bool ok = true;
+               for (int k = 1; k < gap_chunks; ++k) if (!quiet_at(qwords, c - k, nchunks)) { ok = false; break; }
+               if (ok) ends[j] |= 1ull << bit; } }
+         cnt += __popcll(ends[j]); }
       int total;
-      const int cnt = __popcll(ends);
       int off = block_excl_scan_1024(cnt, lds, &total);
       const int base = s_base;
-      while (ends) {
-         const int bit = __ffsll((long long)ends) - 1;
-         ends &= ends - 1;
-         const long long c1 = w * 64 + bit + 1;          // one past the last quiet chunk
-         // zone start: walk back over quiet chunks a 64-bit word at a time
-         long long c0 = c1 - 1;
-         for (;;) {
-            if (c0 == 0) break;
-            const long long pw = (c0 - 1) >> 6; const int pb = (int)((c0 - 1) & 63);
-            // bits pb..0 of word pw, shifted so that bit pb becomes bit 63: count the leading run of ones
-            const u64 run = ~(qwords[pw] << (63 - pb));
-            const int ones = run ? __clzll((long long)run) : 64;
-            const int take = ones < pb + 1 ? ones : pb + 1;
-            c0 -= take;
-            if (take < pb + 1) break; }
-         const long long idx = (long long)base + off++;
-         if (idx < max_bursts) {
-            rtfe_burst b = {};
-            long long zf = (c0 * 512 + ntrks - 1) / ntrks;           // first row entirely inside quiet chunks
-            long long ze = (c1 * 512) / ntrks;                       // one past the last such row
-            zf = (zf + 63) & ~63ll; ze &= ~63ll;
-            if (ze > nrows) ze = nrows & ~63ll;
-            b.zone_first = zf; b.zone_end = ze; b.reset_sample = -1; b.safe_last = -1;
-            bursts[idx] = b; } }
+      #pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+         const long long w = w0 + (long long)threadIdx.x * kPer + j;
+         u64 e = ends[j];
+         while (e) {
+            const int bit = __ffsll((long long)e) - 1;
+            e &= e - 1;
+            const long long c1 = w * 64 + bit + 1;          // one past the last quiet chunk
+            // zone start: walk back over quiet chunks a 64-bit word at a time
+            long long c0 = c1 - 1;
+            for (;;) {
+               if (c0 == 0) break;
+               const long long pw = (c0 - 1) >> 6; const int pb = (int)((c0 - 1) & 63);
+               // bits pb..0 of word pw, shifted so that bit pb becomes bit 63: count the leading run of ones
+               const u64 run = ~(qwords[pw] << (63 - pb));
+               const int ones = run ? __clzll((long long)run) : 64;
+               const int take = ones < pb + 1 ? ones : pb + 1;
+               c0 -= take;
+               if (take < pb + 1) break; }
+            const long long idx = (long long)base + off++;
+            if (idx < max_bursts) {
+               rtfe_burst b = {};
+               long long zf = (c0 * 512 + ntrks - 1) / ntrks;           // first row entirely inside quiet chunks
+               long long ze = (c1 * 512) / ntrks;                       // one past the last such row
+               zf = (zf + 63) & ~63ll; ze &= ~63ll;
+               if (ze > nrows) ze = nrows & ~63ll;
+               b.zone_first = zf; b.zone_end = ze; b.reset_sample = -1; b.safe_last = -1;
+               bursts[idx] = b; } } }
       __syncthreads();
       if (threadIdx.x == 0) s_base = base + total;
       __syncthreads(); }
