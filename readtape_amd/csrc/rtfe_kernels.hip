@@ -916,23 +916,29 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
    const Col base = tile_col(tl, trk, d);                          // y(n) = base[n - row0] in the regular regime
    const int s0 = strip * kStrip;
    int v[kStrip], L[kStrip];
-   #pragma unroll
-   for (int i = 0; i < kStrip; ++i) { v[i] = base[s0 + i]; L[i] = base[s0 + i - W + 1]; }
    int topb = 0, botb = 0, resb = 0;
    u64 ldt = 0, ldb = 0;
    if (W > kStrip) {
+      // the W + 8 samples s0-W .. s0+7 are read in ascending order through one running pointer (the column stride is
+      // a run-time value: one multiply for the start, additions from there)
+      const int16_t *rp = base.p + (s0 - W) * base.P;
+      const int P = base.P;
+      int popped = *rp; rp += P;                                   // the sample that leaves the window at row s0 (then L[i-1])
+      #pragma unroll
+      for (int i = 0; i < kStrip; ++i) { L[i] = *rp; rp += P; }
       // keys: kmin = v << 8 | r, kmax = kmin ^ 0xff (= v << 8 | (255 - r)): one shift-or per sample serves both
       int smx[kStrip], smn[kStrip];
       int amx = (int)0x80000000, amn = 0x7fffffff;
-      for (int j = s0 - 1; j > s0 - W + kStrip; --j) {
-         const int kk = (base[j] << 8) | (j - (s0 - W + 1));
+      for (int r = kStrip; r < W - 1; ++r) {                         // the samples between L[7] and v[0]
+         const int kk = ((int)*rp << 8) | r; rp += P;
          amx = max(amx, kk ^ 0xff); amn = min(amn, kk); }
+      #pragma unroll
+      for (int i = 0; i < kStrip; ++i) { v[i] = *rp; rp += P; }
       #pragma unroll
       for (int i = kStrip - 1; i >= 0; --i) {
          const int kk = (L[i] << 8) | i;
          amx = max(amx, kk ^ 0xff); amn = min(amn, kk); smx[i] = amx; smn[i] = amn; }
       int pmx = (int)0x80000000, pmn = 0x7fffffff;
-      int popped = base[s0 - W];                                   // the sample that leaves the window at row s0 (then L[i-1])
       #pragma unroll
       for (int i = 0; i < kStrip; ++i) {
          const int kk = (v[i] << 8) | (W - 1 + i);
@@ -946,6 +952,8 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
          ldb |= (u64)((kn & 255) - i + 1) << (8 * i);                 // ... and of the first (true) minimum
          popped = L[i]; } }
    else {
+      #pragma unroll
+      for (int i = 0; i < kStrip; ++i) { v[i] = base[s0 + i]; L[i] = base[s0 + i - W + 1]; }
       #pragma unroll
       for (int i = 0; i < kStrip; ++i) {
          int kx = (int)0x80000000, kn = 0x7fffffff;
