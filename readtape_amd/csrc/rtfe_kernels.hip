@@ -880,10 +880,12 @@ __device__ __forceinline__ void build_run(const Tile &tl, const DevCfg *cfg, int
       int pr[4] = {0, 0, 0, 0};
       const int j0 = it == 0 ? 0 : 4 * it - 3, nj = it == 0 ? 1 : min(4, nr - j0);
       if (ld0) {
+         const int16_t *pr_ = yb.p + (n + j0) * yb.P, *pl_ = pr_ - (W - 1) * yb.P;      // right / left window edge at the item's first row
          #pragma unroll
          for (int c = 0; c < 4; ++c) {
             if (c < nj) {
-               const int L = yb[n + j0 + c - W + 1], R = yb[n + j0 + c];
+               const int L = *pl_, R = *pr_;
+               pl_ += yb.P; pr_ += yb.P;
                int dl = kind ? L - m : m - L, dr = kind ? R - m : m - R;
                dl = dl < 0 ? 0 : dl; dr = dr < 0 ? 0 : dr;
                pr[c] = dl | (dr << 16); } } }
