@@ -258,9 +258,9 @@ struct Tile {
       const int d = skew[t];
       return xi(t, (n - reset < d) ? n : n - d); }
    __device__ __forceinline__ unsigned char *ldmap(int screen, int kind, int t) const {       // [row], rows >= -kScreenHalo
-      return ldpos + ((size_t)(screen * 2 + kind) * ntrks + t) * ldstride + kScreenHalo; }
+      return ldpos + (screen * 2 + kind) * (ntrks * ldstride) + t * ldstride + kScreenHalo; }    // (32-bit LDS offsets; ntrks * stride is loop invariant)
    __device__ __forceinline__ const u64 *map(int screen, int kind, int t) const {               // [word], words >= -1
-      return reinterpret_cast<const u64 *>(bits + ((size_t)(screen * 5 + kind) * ntrks + t) * bstride + kScreenHalo / 8); }
+      return reinterpret_cast<const u64 *>(bits + (screen * 5 + kind) * (ntrks * bstride) + t * bstride + kScreenHalo / 8); }
 };
 
 // one track's column of the sample tile, indexed by tile-relative row (after the deskew delay)
@@ -817,7 +817,7 @@ __device__ __forceinline__ void fill_stale(const Tile &tl, int screen, int trk, 
 // start bytes into the two extra bitmaps (kinds 3 and 4).
 __device__ __forceinline__ void run_starts(const Tile &tl, int screen, int trk, int strip) {
    const int ntb = tl.ntrks * tl.bstride;
-   unsigned char *row = tl.bits + ((size_t)(screen * 5) * tl.ntrks + trk) * tl.bstride + kScreenHalo / 8 + strip;
+   unsigned char *row = tl.bits + (screen * 5) * ntb + trk * tl.bstride + kScreenHalo / 8 + strip;
    const int r0 = strip * 8;
    const int nvalid = tl.nrows - r0 >= 8 ? 8 : tl.nrows - r0;
    const unsigned vm = (1u << nvalid) - 1;
@@ -969,10 +969,11 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
          topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i;
          ldt |= (u64)((255 - (kx & 255)) + 1) << (8 * i);
          ldb |= (u64)((kn & 255) + 1) << (8 * i); } }
-   unsigned char *o = tl.bits + ((size_t)(screen * 5) * tl.ntrks + trk) * tl.bstride + kScreenHalo / 8 + strip;     // strip >= -kScreenHalo/8
+   const int ntb2 = tl.ntrks * tl.bstride;
+   unsigned char *o = tl.bits + (screen * 5) * ntb2 + trk * tl.bstride + kScreenHalo / 8 + strip;     // strip >= -kScreenHalo/8
    o[0] = (unsigned char)topb;
-   o[(size_t)tl.ntrks * tl.bstride] = (unsigned char)botb;
-   o[(size_t)2 * tl.ntrks * tl.bstride] = (unsigned char)resb;
+   o[ntb2] = (unsigned char)botb;
+   o[2 * ntb2] = (unsigned char)resb;
    reinterpret_cast<u64 *>(tl.ldmap(screen, 0, trk))[strip] = ldt;
    reinterpret_cast<u64 *>(tl.ldmap(screen, 1, trk))[strip] = ldb;
    return topb | botb; }
