@@ -1205,7 +1205,7 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    L.total = off;
    return L; }
 
-struct WalkLds { unsigned units, heights, heights_bak, recs, nrec, idx0, band, pmoff, hoff, wst, pm, pmmap, hmap, total; };
+struct WalkLds { unsigned units, heights, heights_bak, recs, nrec, idx0, band, pmoff, hoff, wst, pm, pmmap, hmap, wtab, total; };
 __host__ __device__ inline WalkLds lds_layout_walk(const DevCfg &c) {
    WalkLds L;
    const unsigned nwalk = (unsigned)(c.nparm * c.ntrks);
@@ -1223,6 +1223,7 @@ __host__ __device__ inline WalkLds lds_layout_walk(const DevCfg &c) {
    L.pm = off;           off = lds_align16(off + (unsigned)c.pm_cap * 2u);
    L.pmmap = off;        off = lds_align16(off + (unsigned)c.pm_cap);
    L.hmap = off;         off = lds_align16(off + nwalk * (unsigned)c.rec_cap16);
+   L.wtab = off;         off = lds_align16(off + nwalk * 4u);
    L.total = off;
    return L; }
 
@@ -1395,6 +1396,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
    float *wst = reinterpret_cast<float *>(smem + L.wst);            // [nwalk][4] v_lasttop, v_lastbot, v_avg_height, alpha
    unsigned short *pm = reinterpret_cast<unsigned short *>(smem + L.pm);     // [pm_cap] last sure row + 1 | (last possible row + 1) << 8
    unsigned char *pmmap = smem + L.pmmap;                           // [pm_cap] walker of a verdict slot
+   unsigned int *s_wtab = reinterpret_cast<unsigned int *>(smem + L.wtab);      // [nwalk] walker -> list (screen, track) | parameter set << 8 | track << 16
    unsigned char *hmap = smem + L.hmap;                             // [nwalk * rec_cap16] walker of a detection slot
    __shared__ unsigned int s_seq;
    // the parallel tile path covers the alpha-filter AGC (NRZI / GCR parameter sets); everything else walks sequentially
@@ -1405,6 +1407,8 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
    const int my_w = (threadIdx.x & 63) * nwaves + (threadIdx.x >> 6);
    const bool is_walker = my_w < nwalk;
    const int pidx = is_walker ? my_w / ntrks : 0, trk = is_walker ? my_w - pidx * ntrks : 0;
+   if (is_walker) s_wtab[my_w] = (unsigned)(cfg.parm[pidx].screen * ntrks + trk) | ((unsigned)pidx << 8) | ((unsigned)trk << 16);
+   __syncthreads();
    Ctx cx;
    cx.cfg = &cfg;
    cx.row_base = row_base;
@@ -1549,7 +1553,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
                   const int w2 = pmmap[idx];
                   const int r = idx - pmoff[w2];
-                  const int p2 = w2 / ntrks, st2 = cfg.parm[p2].screen * ntrks + (w2 - p2 * ntrks);
+                  const int st2 = (int)(s_wtab[w2] & 0xff);
                   const int4 *lst = units + (s_off[st2] - gbase);
                   const int4 A = lst[r];
                   const int nr = (A.x >> 11) & 0x3f, ld0 = (A.y >> 16) & 0xff;
@@ -1623,7 +1627,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                const int total = hoff[nwalk];
                for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
                   const int w2 = hmap[idx];
-                  const int p2 = w2 / ntrks, st2 = cfg.parm[p2].screen * ntrks + (w2 - p2 * ntrks);
+                  const int st2 = (int)(s_wtab[w2] & 0xff);
                   unsigned int *slot = reinterpret_cast<unsigned int *>(recs_all + (size_t)w2 * rstride) + 4 * (idx - hoff[w2]);
                   const int r = (int)(slot[0] & 0xffff);
                   const int m = (int)(short)(units[s_off[st2] - gbase + r].y & 0xffff);
@@ -1684,7 +1688,8 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
                   const int w2 = hmap[idx];
                   const int j = idx - hoff[w2];
-                  const int p2 = w2 / ntrks, t2 = w2 - p2 * ntrks, st2 = cfg.parm[p2].screen * ntrks + t2;
+                  const unsigned wt = s_wtab[w2];
+                  const int st2 = (int)(wt & 0xff), p2 = (int)((wt >> 8) & 0xff), t2 = (int)(wt >> 16);
                   const uint4 sl = *reinterpret_cast<const uint4 *>(recs_all + (size_t)w2 * rstride + 16 * j);
                   const int r = (int)(sl.x & 0xffff), k0 = (int)((sl.x >> 16) & 0x3f);
                   const bool is_top = !(sl.x >> 31);
