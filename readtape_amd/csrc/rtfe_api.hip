@@ -165,7 +165,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       if (lu > 1536) lu = 1536;
       d.lds_units = (lu + 63) & ~63;
       d.pm_cap = d.lds_units / 2 * ((c->nparmsets + d.nscreens - 1) / d.nscreens);
-      int r16 = 2 * peaks + 8;
+      int r16 = (int)((float)d.tile_rows / (spbf > 1 ? spbf : 1) * (c->mode == RTFE_PE ? 2.0f : 1.0f)) + 6;      // no more flux transitions than that fit a tile
       const int r16max = (40 * 1024) / (nwalk * 16);                    // (parameter-set sweeps: many walkers, fewer bursts resident)
       if (r16 > r16max) r16 = r16max;
       d.rec_cap16 = r16 > 64 ? 64 : (r16 < 8 ? 8 : r16);
