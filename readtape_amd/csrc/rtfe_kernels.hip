@@ -601,8 +601,11 @@ __device__ __forceinline__ void enter_fast(Walker &w, const Tile &tl, int trk, i
    w.trust_from = n_first_fast;
    w.fast = true; }
 
+__device__ __forceinline__ int stale_ld(const u64 *am, const unsigned char *ldb, int q);
 // exact evaluation of one candidate row (the flat body of the screened walker); returns true on a detection
-__device__ __forceinline__ bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, int n, bool ctop, bool cbot, bool async) {
+// (the detection itself - emit_peak - is left to the caller: walk() runs it for all lanes of a wave together)
+__device__ __forceinline__ bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, const DevParm &P, int n, bool ctop, bool cbot, bool async, bool trusted,
+                                        bool &is_top_out, int &pos_out, int &val_out) {
    const DevCfg *cfg = cx.cfg;
    const Tile &tl = cx.tile;
    const int W = P.W;
@@ -626,13 +629,16 @@ __device__ __forceinline__ bool eval_at(Walker &w, Ctx &cx, int pidx, int trk, c
          val = yb[pos];
          w.minv = val; w.cpos = tl.row0 + n; w.qtrig = tl.row0 + pos + W; w.chain_pending = false; }
       else {
-         advance_chain(w, tl, P.screen, trk, W, tl.row0 + n);
-         val = w.minv; pos = -1; }
+         // the reference's (possibly stale) minimum: from the last A-sync row within reach of the tile's screened halo
+         // (stale_ld), else from the walker's own chain state
+         const int l = trusted ? stale_ld(tl.map(P.screen, 2, trk), tl.ldmap(P.screen, 1, trk), n) : 0;
+         if (l) { pos = lo + l - 1; val = yb[pos]; }
+         else { advance_chain(w, tl, P.screen, trk, W, tl.row0 + n); val = w.minv; pos = -1; } }
       hit = below_by(val, vl, w.rise, w.rise_lo, w.rise_hi, mv) && below_by(val, vr, w.rise, w.rise_lo, w.rise_hi, mv)
             && (w.reqmin == 0 || (-val >= w.min_hi) || (-val > w.min_lo && volt(val, mv) < -w.reqmin));
       if (hit && pos < 0) { pos = lo; while (pos <= n && yb[pos] != val) ++pos; }
       if (hit && (pos > n || pos == lo || pos == n)) { w.flags |= RTFE_F_DETECTOR_FATAL; hit = false; } }
-   if (hit) emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + lo, tl.row0 + pos, volt(val, mv), val, is_top, true);
+   is_top_out = is_top; pos_out = pos; val_out = val;
    return hit; }
 
 // one (parameter set, track) detector over rows [.., limit): the exact path on the samples in LDS
@@ -655,16 +661,30 @@ __device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long
    const int lim = (int)(limit - tl.row0);
    long long n64 = max(w.next, w.blind_until + 1);
    int n = (n64 - tl.row0 > lim) ? lim : (int)(n64 - tl.row0);       // first row not yet looked at
-   while (n < lim) {
-      int wd = n >> 6;
-      const u64 c = (tm[wd] | bm[wd]) >> (n & 63);
-      if (!c) { n = (wd + 1) << 6; continue; }
-      n += __ffsll((long long)c) - 1;
-      if (n >= lim) break;
-      const int bit = n & 63;
-      const bool ctop = (tm[wd] >> bit) & 1, cbot = (bm[wd] >> bit) & 1;
-      const bool hit = eval_at(w, cx, pidx, trk, P, n, ctop, cbot, (am[wd] >> bit) & 1);
-      n = hit ? (int)(w.blind_until + 1 - tl.row0) : n + 1; }
+   // Two-phase rounds keep the walker lanes of a wave together: (A) every lane scans to its next detection, (B) the lanes
+   // that found one do the detection bookkeeping (event, AGC mirror, thresholds) side by side.  In dense formats this is
+   // the difference between one bookkeeping pass per round and one per lane per detection.
+   const float mv = cfg->maxvolts;
+   const bool trusted = tl.row0 - kScreenHalo >= w.trust_from;       // (the screened halo lies in the regular regime)
+   #pragma nounroll
+   for (;;) {
+      bool hit = false, is_top = false;
+      int pos = 0, val = 0;
+      #pragma nounroll
+      while (n < lim) {                                             // (A)
+         int wd = n >> 6;
+         const u64 c = (tm[wd] | bm[wd]) >> (n & 63);
+         if (!c) { n = (wd + 1) << 6; continue; }
+         n += __ffsll((long long)c) - 1;
+         if (n >= lim) break;
+         const int bit = n & 63;
+         const bool ctop = (tm[wd] >> bit) & 1, cbot = (bm[wd] >> bit) & 1;
+         hit = eval_at(w, cx, pidx, trk, P, n, ctop, cbot, (am[wd] >> bit) & 1, trusted, is_top, pos, val);
+         if (hit) break;
+         ++n; }
+      if (!hit) break;
+      emit_peak(w, cx, pidx, trk, P, tl.row0 + n, tl.row0 + n - W + 1, tl.row0 + pos, volt(val, mv), val, is_top, true);     // (B)
+      n = (int)(w.blind_until + 1 - tl.row0); }
    n64 = tl.row0 + n;
    w.next = n64 < limit ? n64 : limit;
    // keep the stale-min state inside the reach of the next tile's halo, lazily: remember the last forced
@@ -1980,7 +2000,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          load_tile(&cfg, cx.tile, rows, nrows);
          __syncthreads();
          if (cfg.debug) c1 = clock64();
-         run_screens(&cfg, cx.tile, false);
+         run_screens(&cfg, cx.tile, !cfg.find_zeros);
          __syncthreads();
          if (cfg.debug) c2 = clock64();
          long long c2c = 0;
