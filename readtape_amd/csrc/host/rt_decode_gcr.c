@@ -3,9 +3,9 @@
  * context.  Every track is self-clocked: a transition is a 1, and the time since the previous
  * transition says whether one or two 0 bits lie in between (src/decode_gcr.c:789-834).
  *
- * Not restated: the -correct path that repairs one or two tracks from the ECC syndrome
- * (src/decode_gcr.c:151-341).  With -correct a group with bad parity is left as the reference leaves
- * it when its corrector reports failure; without -correct (the default here) behaviour is identical.
+ * -correct: the single-track repair the reference's decoder invokes (src/decode_gcr.c:588-611 always passes the
+ * pointer 0x01, i.e. the one-track branch of src/decode_gcr.c:262-295); its two-track branch is unreachable from the
+ * decoder and is not restated.
  */
 #include "rt_decode.h"
 
@@ -103,6 +103,39 @@ static unsigned gcr_ecc_of(const uint16_t *chars7) {
    for (int i = 0; i < 8; ++i) ecc |= (unsigned)(__builtin_parityll(word & ROW[i] & 0x00ffffffffffffffULL)) << i;
    return ecc; }
 
+/* -correct: repair ONE bad track of a data group from its syndrome (what src/decode_gcr.c:205-341 does when it is
+ * called with a single track pointer, the only way the decoder calls it, :593).  The eight characters (seven data +
+ * check) of a group form a code word over GF(2^8), generator x^8+x^5+x^4+x^3+1: with the tracks taken in "ECC order"
+ *     E(c) = sum over the 8 data tracks of c's bit on that track * x^(ecc position of the track)
+ * a good group has  sum_i E(c_i) * x^(7-i) = 0  and odd parity in every character.  If all errors lie on one track at
+ * ECC position t, then with e_i = 1 where character i has even parity,
+ *     S2 = sum_i E(c_i) x^(7-i) = x^t * P,   P = sum_i e_i x^(7-i)
+ * so t is found by stepping P through the powers of x; S2 == 0 with P != 0 means the parity track itself.
+ * Faithful details: parity is taken as odd whatever -even says; P == 0 "succeeds" without changing anything; the
+ * smallest t in 0..7 wins; no t -> failure (group left as it is).  g[i] = (msb)...(lsb)(p).  Returns 1 on success. */
+static int gcr_repair_track(uint16_t *g) {
+   static const unsigned char ECC_POS[8] = {4, 2, 1, 5, 7, 3, 6, 0};    /* data bit k (lsb = 0) sits at x^ECC_POS[k] */
+   unsigned S2 = 0, P = 0;
+   for (int i = 0; i < 8; ++i) {
+      unsigned e = 0;
+      for (int k = 0; k < 8; ++k) e |= ((g[i] >> (k + 1)) & 1u) << ECC_POS[k];
+      S2 = ((S2 << 1) ^ ((S2 & 0x80) ? 0x139u : 0u)) ^ e;                /* Horner: S2 = S2 * x + E(c_i)  (mod the generator) */
+      P = (P << 1) | (rt_parity9(g[i]) ^ 1u); }                          /* character i -> coefficient of x^(7-i) */
+   if (P == 0) return 1;
+   unsigned flip;                                                       /* the bad track, as a bit of g[] */
+   if (S2 == 0) flip = 1u;                                              /* the parity track */
+   else {
+      int t = 0;
+      unsigned q = P;
+      while (t < 8 && q != S2) { q = ((q << 1) ^ ((q & 0x80) ? 0x139u : 0u)); ++t; }
+      if (t == 8) return 0;
+      int k = 0;
+      while (ECC_POS[k] != t) ++k;
+      flip = 2u << k; }
+   for (int i = 0; i < 8; ++i)
+      if ((P >> (7 - i)) & 1u) g[i] ^= (uint16_t)flip;
+   return 1; }
+
 /* gather the next 5 cells of every track into per-track storage groups (src/decode_gcr.c:448-459) */
 static void gather_sgroups(struct rt_dec *d) {
    for (int cell = 0; cell < 5; ++cell) {
@@ -152,8 +185,14 @@ static void gcr_postprocess(struct rt_dec *d) {             /* src/decode_gcr.c:
          if (gcr_ecc_of(&d->data[d->gcr.bytenum - 8]) != (unsigned)(d->data[d->gcr.bytenum - 1] >> 1)) {
             ++result->ecc_errs;
             if (result->first_error < 0) result->first_error = d->gcr.bytenum - 1; }
-         if (d->gcr.bad_parity_in_dgroup)                   /* (the -correct repair of src/decode_gcr.c:588-611 is not restated) */
-            result->vparity_errs += d->gcr.bad_parity_in_dgroup;
+         if (d->gcr.bad_parity_in_dgroup) {
+            if (d->opt.do_correction && gcr_repair_track(&d->data[d->gcr.bytenum - 8])) {      /* src/decode_gcr.c:589-606 */
+               d->gcr.bad_parity_in_dgroup = 0;
+               for (int k = 0; k < 8; ++k)
+                  if (rt_parity9(d->data[d->gcr.bytenum - 8 + k]) != d->expected_parity) ++d->gcr.bad_parity_in_dgroup;
+               ++result->corrected_bits;
+               if (gcr_ecc_of(&d->data[d->gcr.bytenum - 8]) != (unsigned)(d->data[d->gcr.bytenum - 1] >> 1)) ++result->ecc_errs; }
+            result->vparity_errs += d->gcr.bad_parity_in_dgroup; }
          d->gcr.bytenum -= 1;                               /* drop the ECC character */
          state = S_DATA_A;
          break;

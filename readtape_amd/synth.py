@@ -163,7 +163,7 @@ def _render_block(spec: TapeSpec, rng, per_track_cells: list[np.ndarray], ncells
 
 
 def make_tape(spec: TapeSpec, items: list, gap_samples: int = 5000) -> Tape:
-    """items: list of ("block", payload_bytes) | ("mark",) | ("gap", nsamples) | ("raw", cells_per_track, ncells).
+    """items: list of ("block", payload_bytes) | ("block", payload_bytes, gcr_flips) | ("mark",) | ("gap", nsamples) | ("raw", cells_per_track, ncells).
     A gap of `gap_samples` is placed before, between and after items."""
     rng = np.random.default_rng(spec.seed)
     pieces = []
@@ -182,7 +182,7 @@ def make_tape(spec: TapeSpec, items: list, gap_samples: int = 5000) -> Tape:
             add_gap(int(it[1]))
             continue
         if kind == "block":
-            cells, ncells, fs = encode_block(spec, it[1])
+            cells, ncells, fs = encode_block(spec, it[1]) if len(it) < 3 else gcr_encode(it[1], it[2])
         elif kind == "mark":
             cells, ncells, fs = encode_mark(spec)
         elif kind == "raw":
@@ -294,9 +294,13 @@ def gcr_ecc(seven: bytes) -> int:
     return sum((bin(word & row).count("1") & 1) << i for i, row in enumerate(_GCR_ECC_ROWS))
 
 
-def _gcr_group_cells(chars8: list[int]) -> list[list[int]]:
-    """8 characters (7 data + check) -> 10 cells per track (two 5-bit storage groups), as 9-bit words."""
+def _gcr_group_cells(chars8: list[int], flips=()) -> list[list[int]]:
+    """8 characters (7 data + check) -> 10 cells per track (two 5-bit storage groups), as 9-bit words.
+    flips: (character 0..7, track 0..8) pairs whose recorded bit is wrong (written after the ECC and parity were formed:
+    what the decoder's -correct repair is for, src/decode_gcr.c:588-611)."""
     words = [((c & 0xFF) << 1) | (_parity9(c & 0xFF) ^ 1) for c in chars8]         # odd parity on track 8
+    for ch, trk in flips:
+        words[ch] ^= 1 << (8 - trk)
     cells = [0] * 10
     for trk in range(9):
         bits = [(w >> (8 - trk)) & 1 for w in words]
@@ -309,10 +313,11 @@ def _gcr_group_cells(chars8: list[int]) -> list[list[int]]:
     return cells
 
 
-def gcr_encode(payload: bytes):
+def gcr_encode(payload: bytes, flips=None):
     """One 6250 block: preamble, data groups, end mark, residual group, CRC group, postamble
     (what src/decode_gcr.c:503-674 walks through).  Same cells on every track
-    for the control subgroups."""
+    for the control subgroups.  flips: {data group index: [(character, track), ...]} recorded-bit errors."""
+    flips = flips or {}
     ALL = 0x1FF
 
     def ctl(code):                     # a 5-bit control subgroup on all nine tracks
@@ -326,7 +331,7 @@ def gcr_encode(payload: bytes):
     nfull, left = divmod(len(payload), 7)
     for g in range(nfull):
         seven = payload[7 * g: 7 * g + 7]
-        cells += _gcr_group_cells(list(seven) + [gcr_ecc(seven)])
+        cells += _gcr_group_cells(list(seven) + [gcr_ecc(seven)], flips.get(g, ()))
     cells += ctl(0b11111)                                            # end of data groups
     resid = list(payload[7 * nfull:]) + [0] * (6 - left) + [0]       # H H H H H H N
     cells += _gcr_group_cells(resid + [gcr_ecc(bytes(resid))])

@@ -42,6 +42,19 @@ def case_gcr_noisy(seed=17):
     return synth.gcr_tape(seed=seed, nblocks=2, minlen=40, maxlen=120, gap_samples=2500, noise_mv=45.0, jitter=0.05, amplitude=1.2)
 
 
+def case_gcr_errors(seed=19):
+    # recorded-bit errors inside data groups (written after ECC/parity were formed): what -correct repairs
+    # (src/decode_gcr.c:588-611).  One track in several characters, the parity track, the check character, two tracks
+    # (in one character: parity still good; in different characters: not a one-track pattern), three tracks.
+    rng = np.random.default_rng(seed + 3000)
+    spec = synth.gcr_spec(seed=seed)
+    pay = synth.random_payloads(rng, 2, 130, 170)
+    flips0 = {1: [(0, 3), (2, 3), (5, 3)], 3: [(1, 8)], 5: [(7, 2)], 7: [(0, 1), (0, 6)], 9: [(1, 1), (4, 5)],
+              11: [(2, 0), (2, 4), (2, 7)], 13: [(6, 0)], 15: [(0, 7), (1, 7), (2, 7), (3, 7), (4, 7), (5, 7), (6, 7), (7, 7)]}
+    flips1 = {0: [(3, 5)], 2: [(3, 4), (7, 4)], 4: [(0, 8), (5, 8)], 6: [(2, 2), (3, 6), (4, 2)]}
+    return synth.make_tape(spec, [("block", pay[0], flips0), ("block", pay[1], flips1)], gap_samples=2500)
+
+
 def case_nrzi9_oversampled(seed=18):
     # sampled at 640 ns (39 samples per bit) while the header says 1280 ns: what "-subsample=2" is for
     import dataclasses
@@ -71,6 +84,8 @@ CASES = {
     "gcr":          (case_gcr,        ["-gcr"],                        []),
     "gcr_m":        (case_gcr_noisy,  ["-gcr", "-m"],                  ["-m"]),
     "gcr_zeros":    (case_gcr,        ["-gcr", "-zeros"],              ["-zeros"]),
+    "gcr_errs":     (case_gcr_errors, ["-gcr"],                        []),
+    "gcr_correct":  (case_gcr_errors, ["-gcr", "-correct"],            ["-correct"]),
 }
 # every reference run also gets: -v -tap -nolabels (SIMH .tap output, no IBM label handling);
 # "-nm" is added when "-m" is absent because the reference retries by default (src/readtape.c:511)
