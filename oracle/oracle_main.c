@@ -4,6 +4,7 @@
  *     -nrzi|-pe|-gcr  -ntrks=N -bpi=N -ips=N   override the TBIN header (src/readtape.c:1330-1343)
  *     -zeros -differentiate -invert -correct -m -even -revparity=N
  *     -skew=a,b,..      per-track deskew delays in SAMPLES
+ *     -deskew           calibrate the delays on the first blocks (NRZI, GCR)
  *     -parms=FILE       parameter sets in the reference's .parms grammar
  *     -out=BASE         writes BASE.tap (SIMH) and BASE.log
  *     -evt=FILE         event dump, same 48-byte records as oracle/ref_event_shim.c
@@ -79,7 +80,7 @@ int main(int argc, char **argv) {
    struct rt_options opt; memset(&opt, 0, sizeof opt);
    opt.specified_parity = 1;
    const char *infile = NULL, *outbase = NULL, *evtname = NULL, *parmfile = NULL, *skewarg = NULL;
-   int ntrks_arg = 0, invert = 0, timing = 0, blklimit = 0x7fffffff, subsample = 1;
+   int ntrks_arg = 0, invert = 0, timing = 0, blklimit = 0x7fffffff, subsample = 1, deskew = 0;
    float bpi_arg = -1, ips_arg = -1;
    int mode_arg = 0;
    for (int i = 1; i < argc; ++i) {
@@ -101,6 +102,7 @@ int main(int argc, char **argv) {
       else if (!strcmp(a, "-tap")) opt.tap_format = 1;
       else if (!strcmp(a, "-time")) timing = 1;
       else if (!strncmp(a, "-skew=", 6)) skewarg = a + 6;
+      else if (!strcmp(a, "-deskew")) deskew = 1;
       else if (!strncmp(a, "-parms=", 7)) parmfile = a + 7;
       else if (!strncmp(a, "-out=", 5)) outbase = a + 5;
       else if (!strncmp(a, "-evt=", 5)) evtname = a + 5;
@@ -161,6 +163,12 @@ int main(int argc, char **argv) {
    if (evtname) { evtf = fopen(evtname, "wb"); d->on_transition = on_transition; d->on_attempt = on_attempt; fe->on_attempt_end = on_attempt_end; }
 
    struct rt_reader rd = { ofe_readblock, ofe_save_pos, ofe_restore_pos, fe };
+   if (deskew && opt.mode != RT_PE && !skewarg) {            /* src/readtape.c:1675-1717: calibrate on the first blocks, then rewind */
+      int delays[RT_MAXTRKS] = {0}, hit_end = 0;
+      ofe_save_pos(fe);
+      if (rt_deskew_prepass(d, &rd, delays, &hit_end) < 0) { fprintf(stderr, "Some tracks have no transitions\n"); return 99; }
+      ofe_restore_pos(fe);
+      for (int t = 0; t < opt.ntrks; ++t) fe->skew_delaycnt[t] = delays[t]; }
    struct timespec t0, t1;
    clock_gettime(CLOCK_MONOTONIC, &t0);
    int ok = rt_process_blocks(d, &rd, blklimit);

@@ -124,6 +124,11 @@ struct rt_options {         /* the command-line switches that reach the decoders
    int   verbose;           /* -v: log every block */
 };
 
+#define RT_PEAKSTAT_BUCKETS 50     /* src/decoder.c:121 */
+#define RT_MAXSKEWSAMP 50          /* src/decoder.h:97-99 */
+#define RT_MAXSKEWBLKS 100
+#define RT_MINSKEWTRANS 1000
+
 struct rt_dec {
    struct rt_options opt;
    struct rt_parms   parmsets[RT_MAXPARMSETS];
@@ -150,6 +155,10 @@ struct rt_dec {
    int     numblks, numtapemarks, numblks_err, numblks_warn, numblks_unusable;
    int     numblks_goodmultiple, numblks_trksmismatched, numblks_midbiterrs, numblks_corrected;
    FILE   *logf;                    /* block log lines (NULL = quiet) */
+   /* flux-transition position statistics of the -deskew pre-pass (src/decoder.c:121-173): only gathered while
+    * doing_deskew (in the reference they also feed a .csv report, which is out of scope) */
+   int     doing_deskew;
+   struct { int initialized; float leftbin, binwidth; int counts[RT_MAXTRKS][RT_PEAKSTAT_BUCKETS]; int trksums[RT_MAXTRKS]; } peakstat;
    /* optional observer: called at the top of every up/down transition, before the format callback
     * (the same seam oracle/ref_event_shim.c wraps in the reference) */
    void  (*on_transition)(struct rt_dec *d, struct rt_trk *t, int is_top, void *user);
@@ -217,6 +226,13 @@ struct rt_reader {
    void *ctx;
 };
 int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit);   /* returns 1 if all blocks clean */
+
+/* ---- the -deskew pre-pass (src/readtape.c:1675-1717, NRZI and GCR): decodes the first blocks with no deskew while the
+ * decoders record where each track's transitions fall, then turns the per-track averages into delays (in samples).
+ * Returns the number of blocks used (>= 0), or -1 if some track saw no transition; *hit_end = 1 if the reader ran out
+ * of data before the reference's stopping rule was met (the caller may then retry on a longer prefix of the tape). */
+void rt_record_peakstat(struct rt_dec *d, float bitspacing, float peaktime, int trknum);   /* src/decoder.c:136-173 */
+int  rt_deskew_prepass(struct rt_dec *d, struct rt_reader *r, int delays[RT_MAXTRKS], int *hit_end);
 
 #ifdef __cplusplus
 }

@@ -198,3 +198,21 @@ int rt_gcr_go_idle(struct rt_dec *d, struct rt_trk *t) {
       rt_gcr_end_of_block(d);
       return 1; }
    return 0; }
+
+/* ---- flux-transition position statistics (src/decoder.c:136-173; the adjdeskew averages are experimental there
+ *      and not restated) ---- */
+void rt_record_peakstat(struct rt_dec *d, float bitspacing, float peaktime, int trknum) {
+   if (!d->peakstat.initialized) {                            /* the first transition fixes the bins */
+      memset(&d->peakstat, 0, sizeof(d->peakstat));
+      const enum rt_mode m = d->opt.mode;
+      float range = bitspacing * (m == RT_NRZI ? 1.0f : m == RT_PE ? 1.2f : m == RT_GCR ? 3.0f : 1.0f);
+      float bw = range / RT_PEAKSTAT_BUCKETS;
+      bw = (float)((int)(bw * 10e6 + 0.5) * 1e-6) / 10.0f;   /* to the nearest 0.1 usec (double product, int, double, float) */
+      float left = bitspacing - range / 2;
+      left = (float)(int)(left / bw) * bw;                   /* next lower multiple of the bin width */
+      d->peakstat.binwidth = bw; d->peakstat.leftbin = left;
+      d->peakstat.initialized = 1; }
+   const int bucket = (int)((peaktime - d->peakstat.leftbin) / d->peakstat.binwidth);
+   if (bucket < 0) ++d->peakstat.counts[trknum][0];
+   else if (bucket >= RT_PEAKSTAT_BUCKETS) ++d->peakstat.counts[trknum][RT_PEAKSTAT_BUCKETS - 1];
+   else { ++d->peakstat.counts[trknum][bucket]; ++d->peakstat.trksums[trknum]; } }

@@ -71,11 +71,15 @@ static int gcr_checkzeros(struct rt_dec *d, struct rt_trk *t, float delta) {    
    return numbits; }
 
 void rt_gcr_bot(struct rt_dec *d, struct rt_trk *t) {      /* src/decode_gcr.c:836-844 */
+   if (d->doing_deskew && t->t_lastclock != 0)
+      rt_record_peakstat(d, t->clkavg.t_bitspaceavg, (float)(t->t_bot - t->t_lastpeak), t->trknum);
    gcr_checkzeros(d, t, (float)(t->t_bot - t->t_lastpeak));
    gcr_addbit(d, t, 1, t->t_bot);
    if (t->peakcount > AGC_ENDBASE && t->v_avg_height_count == 0) rt_adjust_agc(d, t); }
 
 void rt_gcr_top(struct rt_dec *d, struct rt_trk *t) {      /* src/decode_gcr.c:846-865 */
+   if (d->doing_deskew && t->t_lastclock != 0)
+      rt_record_peakstat(d, t->clkavg.t_bitspaceavg, (float)(t->t_top - t->t_lastpeak), t->trknum);
    gcr_checkzeros(d, t, (float)(t->t_top - t->t_lastpeak));
    gcr_addbit(d, t, 1, t->t_top);
    if (t->peakcount >= AGC_STARTBASE && t->peakcount <= AGC_ENDBASE) {

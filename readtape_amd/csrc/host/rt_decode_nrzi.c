@@ -109,6 +109,8 @@ static void nrzi_addbit(struct rt_dec *d, struct rt_trk *t, int bit, double t_bi
          nrzi->t_lastclock = t_bit - 2 * nrzi->clkavg.t_bitspaceavg; } }
 
 void rt_nrzi_bot(struct rt_dec *d, struct rt_trk *t) {   /* src/decode_nrzi.c:184-197 */
+   if (d->doing_deskew && d->nrzi.t_lastclock != 0 && d->nrzi.datablock && d->nrzi.post_counter == 0)
+      rt_record_peakstat(d, d->nrzi.clkavg.t_bitspaceavg, (float)(t->t_bot - d->nrzi.t_lastclock), t->trknum);
    if (t->t_bot < d->nrzi.t_last_midbit && d->nrzi.post_counter == 0)
       ++d->results[d->parmset].missed_midbits;
    nrzi_addbit(d, t, 1, t->t_bot);
@@ -116,6 +118,8 @@ void rt_nrzi_bot(struct rt_dec *d, struct rt_trk *t) {   /* src/decode_nrzi.c:18
       rt_adjust_agc(d, t); }
 
 void rt_nrzi_top(struct rt_dec *d, struct rt_trk *t) {   /* src/decode_nrzi.c:199-230 */
+   if (d->doing_deskew && d->nrzi.t_lastclock != 0 && d->nrzi.datablock && d->nrzi.post_counter == 0)
+      rt_record_peakstat(d, d->nrzi.clkavg.t_bitspaceavg, (float)(t->t_top - d->nrzi.t_lastclock), t->trknum);
    if (t->t_top < d->nrzi.t_last_midbit && d->nrzi.post_counter == 0)
       ++d->results[d->parmset].missed_midbits;
    nrzi_addbit(d, t, 1, t->t_top);

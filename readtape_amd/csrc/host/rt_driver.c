@@ -174,3 +174,44 @@ done:;
 endfile:
    rt_tap_end(d);
    return ok; }
+
+/* ---- -deskew pre-pass (src/readtape.c:1675-1717 + skew_compute_deskew / skew_set_delay, src/decoder.c:235-281) ---- */
+int rt_deskew_prepass(struct rt_dec *d, struct rt_reader *r, int delays[RT_MAXTRKS], int *hit_end) {
+   const int ntrks = d->opt.ntrks;
+   int nblks = 0, min_transitions = 0;
+   *hit_end = 0;
+   d->doing_deskew = 1;
+   d->peakstat.initialized = 0;
+   d->interblock_counter = 0;
+   do {                                                      /* one block at a time, first parameter set only */
+      rt_init_blockstate(d);
+      d->parmset = 0;
+      rt_init_trackstate(d);
+      if (!r->readblock(r->ctx, 1)) { *hit_end = 1; break; }
+      if (d->results[d->parmset].blktype != RT_BS_NOISE) {
+         min_transitions = INT_MAX;
+         for (int t = 0; t < ntrks; ++t) if (d->peakstat.trksums[t] < min_transitions) min_transitions = d->peakstat.trksums[t];
+         ++nblks; } }
+   while (nblks < RT_MAXSKEWBLKS && min_transitions < RT_MINSKEWTRANS);
+   d->doing_deskew = 0;
+   d->interblock_counter = 0;
+   if (!d->peakstat.initialized) { d->peakstat.initialized = 0; return -1; }
+   if (min_transitions <= 0) { d->peakstat.initialized = 0; return -1; }   /* "Some tracks have no transitions" (fatal there) */
+   /* the average transition position of each track, over the buckets between the two catch-alls */
+   float avg[RT_MAXTRKS], maxavg = 0;
+   const float bw = d->peakstat.binwidth, left = d->peakstat.leftbin;
+   for (int t = 0; t < ntrks; ++t) {
+      long long sum = 0;
+      for (int b = 1; b < RT_PEAKSTAT_BUCKETS - 1; ++b)        /* (each term is truncated to an integer number of usec) */
+         sum += (long long)(d->peakstat.counts[t][b] * (bw * 1e6 * b + left * 1e6));
+      avg[t] = (float)sum / (float)d->peakstat.trksums[t];
+      if (avg[t] > maxavg) maxavg = avg[t]; }
+   /* delay every track up to the latest one, rounded to whole samples */
+   for (int t = 0; t < ntrks; ++t) {
+      const float time = d->peakstat.trksums[t] > 0 ? (maxavg - avg[t]) / 1e6f : 0;
+      int delay = (int)((time + d->sample_deltat / 2) / d->sample_deltat);
+      delays[t] = delay < RT_MAXSKEWSAMP ? delay : RT_MAXSKEWSAMP;
+      rlog(d, "  track %d delayed by %d clocks (%.2f usec) based on %d observed flux transitions\n",
+           t, delays[t], delays[t] * d->sample_deltat * 1e6, d->peakstat.trksums[t]); }
+   d->peakstat.initialized = 0;
+   return nblks; }

@@ -278,11 +278,15 @@ restart:
    rt_finish_attempt(d);
    return !endfile; }
 
-int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+/* prepass != NULL: run the -deskew pre-pass instead of the decode (no .tap); append: keep what is already in the log
+ * and event-dump files (the decode that follows a pre-pass continues both, as the reference's single run does) */
+struct deskew_out { int *delays; int *nblks; int *hit_end; };
+static int replay_any(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
-                  const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
+                  const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
+                  int append, struct deskew_out *prepass) {
    const float sample_deltat = (float)tdelta_ns / 1e9f;              /* src/readtape.c:1345 */
    struct rt_dec *d = rt_dec_new(opt, sample_deltat, tdelta_ns);
    if (!d) return -1;
@@ -291,7 +295,7 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
       memcpy(d->parmsets, parmsets, sizeof(struct rt_parms) * (size_t)nparm); }
    else for (int i = nparm; i < RT_MAXPARMSETS; ++i) d->parmsets[i].active = 0;   /* only the scanned sets are usable */
    if (tap_path) d->tapf = fopen(tap_path, "wb");
-   if (log_path) d->logf = fopen(log_path, "w");
+   if (log_path) d->logf = fopen(log_path, append ? "a" : "w");
    struct rt_replay rp; memset(&rp, 0, sizeof rp);
    rp.d = d; rp.ntrks = opt->ntrks; rp.nparm = nparm;
    for (int i = 0; i < nparm; ++i) rp.W[i] = W[i];
@@ -299,9 +303,11 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
    rp.bursts = bursts; rp.nbursts = nbursts; rp.counts = counts; rp.events = events;
    rp.exact = exact; rp.exact_free = exact_free; rp.exact_user = user;
    rp.find_zeros = opt->find_zeros;
-   if (evt_path) { rp.evtf = fopen(evt_path, "wb"); if (rp.evtf) { d->on_transition = dump_transition; d->on_attempt = dump_attempt; d->user = &rp; } }
+   if (evt_path) { rp.evtf = fopen(evt_path, append ? "ab" : "wb"); if (rp.evtf) { d->on_transition = dump_transition; d->on_attempt = dump_attempt; d->user = &rp; } }
    struct rt_reader rd = { rt_replay_readblock, rt_replay_save_pos, rt_replay_restore_pos, &rp };
-   const int ok = rt_process_blocks(d, &rd, 0x7fffffff);
+   int ok = 1;
+   if (prepass) *prepass->nblks = rt_deskew_prepass(d, &rd, prepass->delays, prepass->hit_end);
+   else ok = rt_process_blocks(d, &rd, 0x7fffffff);
    if (stats) {
       stats->attempts = rp.attempts; stats->exact_scans = rp.exact_scans; stats->chained = rp.chained;
       stats->events_delivered = rp.events_delivered; stats->agc_mismatches = rp.agc_mismatches;
@@ -310,6 +316,31 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
       stats->data_bytes = d->numdatabytes; }
    if (d->tapf) fclose(d->tapf);
    if (d->logf) fclose(d->logf);
-   if (rp.evtf) { fflush(rp.evtf); if (ftruncate(fileno(rp.evtf), ftell(rp.evtf))) {} fclose(rp.evtf); }
+   if (rp.evtf) { fflush(rp.evtf); if (!append && ftruncate(fileno(rp.evtf), ftell(rp.evtf))) {} fclose(rp.evtf); }
    rt_dec_free(d);
    return 0; }
+
+int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
+   return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
+                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 0, NULL); }
+
+int rt_replay_run_after_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
+   return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
+                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 1, NULL); }
+
+int rt_replay_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *log_path, const char *evt_path, int *delays, int *nblks, int *hit_end) {
+   struct deskew_out o = { delays, nblks, hit_end };
+   return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
+                     exact, exact_free, user, NULL, log_path, evt_path, NULL, 0, &o); }

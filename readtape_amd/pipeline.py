@@ -11,7 +11,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from . import frontend
+from . import frontend, tbin
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -53,6 +53,8 @@ def _load_decode_lib():
     lib.rt_replay_run.argtypes = [C.POINTER(_Options), C.POINTER(_Parms), C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                   C.POINTER(C.c_int), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _EXACT_FN, _FREE_FN, C.c_void_p,
                                   C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
+    lib.rt_replay_run_after_deskew.argtypes = lib.rt_replay_run.argtypes
+    lib.rt_replay_deskew.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return lib
 
 
@@ -79,9 +81,76 @@ def frontend_parmsets(full):
     return [(p.pkww_bitfrac, p.pkww_rise, p.min_peak, p.agc_alpha, p.agc_window, p.clk_factor) for p in full]
 
 
+def _exact_callbacks(fe, rows, ntrks):
+    """The callbacks through which the host replay asks for an exact device scan of one attempt (rtfe_scan_exact)."""
+    keep = {}
+
+    def exact(user, reset_row, end_row, parmset, burst_out, counts_out, events_out, cap_out):
+        try:
+            ex = fe.scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset).fetch()
+            if int(ex.bursts[0]["flags"]) & frontend.F_SCREEN_UNDERFLOW:
+                ex = fe.scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset, screen_off=True).fetch()
+            B = ex.bursts[0]
+            if int(B["flags"]) & (frontend.F_EVENT_OVERFLOW | frontend.F_DETECTOR_FATAL):
+                return 1
+            cap = int(B["event_cap"])
+            base = int(B["event_base"]) + parmset * ntrks * cap
+            ev = np.ascontiguousarray(ex._events[base: base + ntrks * cap])
+            C.memmove(burst_out, B.tobytes(), frontend.BURST_DTYPE.itemsize)
+            for t in range(ntrks):
+                counts_out[t] = int(ex.counts[0, parmset, t])
+            events_out[0] = ev.ctypes.data
+            cap_out[0] = cap
+            keep[ev.ctypes.data] = ev
+            return 0
+        except Exception:
+            return 2
+
+    def free(user, ptr):
+        keep.pop(ptr, None)
+
+    return _EXACT_FN(exact), _FREE_FN(free), keep
+
+
+def calibrate_deskew(hdr, rows, full, o, fe_factory, invert=False, find_zeros=False, differentiate=False,
+                     log_path=None, evt_path=None, first_prefix_rows=1 << 22):
+    """The -deskew pre-pass (src/readtape.c:1675-1717) on the device front end: scans a prefix of the resident tape with
+    NO deskew delays and the first parameter set, lets the host decoders record where each track's transitions fall,
+    and returns the per-track delays in samples.  The prefix grows until the reference's stopping rule (1000
+    transitions on every track, or 100 blocks) is met inside it, or it is the whole tape."""
+    lib = _load_decode_lib()
+    nrows = int(rows.shape[0])
+    n0 = min(nrows, first_prefix_rows)
+    cfg0 = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full[:1]), skew=None, invert=invert,
+                                               find_zeros=find_zeros, differentiate=differentiate)
+    fe0 = (fe_factory or frontend.FrontEnd)(cfg0)
+    parr = (_Parms * 1)(full[0])
+    W = (C.c_int * 1)(fe0.widths[0])
+    while True:
+        prefix = rows[:n0]
+        res = fe0.scan(prefix).fetch()
+        exact, free, keep = _exact_callbacks(fe0, prefix, hdr.ntrks)
+        bursts = np.ascontiguousarray(res.bursts)
+        counts = np.ascontiguousarray(res.counts)
+        delays = (C.c_int * 19)()
+        nblks, hit_end = C.c_int(0), C.c_int(0)
+        rc = lib.rt_replay_deskew(C.byref(o), parr, 1, hdr.tdelta_ns, hdr.tstart_ns, n0, 0, W,
+                                  bursts.ctypes.data, len(bursts), counts.ctypes.data, res._events.ctypes.data,
+                                  exact, free, None, log_path.encode() if log_path else None,
+                                  evt_path.encode() if evt_path else None, delays, C.byref(nblks), C.byref(hit_end))
+        if rc != 0:
+            raise RuntimeError("rt_replay_deskew failed")
+        if hit_end.value and n0 < nrows:
+            n0 = min(nrows, n0 * 4)
+            continue
+        if nblks.value < 0:
+            raise RuntimeError("deskew: some tracks have no transitions (is ntrks right?)")
+        return [int(delays[t]) for t in range(hdr.ntrks)]
+
+
 def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
                 skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None, differentiate=False,
-                subsample: int = 1):
+                subsample: int = 1, deskew: bool = False, deskew_prefix_rows: int = 1 << 22):
     """Decodes one tape; returns (stats dict, ScanResult).  `fe_factory(cfg)` builds the front end
     (default: the GPU one; tests/cpu_emul passes the emulated library)."""
     opts = opts or DecodeOptions()
@@ -105,6 +174,14 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     else:
         full = default_parmsets(mode, nsets)
     cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert, find_zeros=find_zeros, differentiate=differentiate)
+    o = _Options(mode=mode, ntrks=hdr.ntrks, bpi=cfg.bpi, ips=cfg.ips, specified_parity=0 if opts.even_parity else 1,
+                 revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=int(find_zeros), do_differentiate=int(differentiate),
+                 multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
+    calibrated = deskew and skew is None and mode != tbin.MODE_PE        # "-deskew option is ignored for PE", src/readtape.c:1677
+    if calibrated:
+        skew = calibrate_deskew(hdr, rows, full, o, fe_factory, invert=invert, find_zeros=find_zeros, differentiate=differentiate,
+                                log_path=log_path, evt_path=evt_path, first_prefix_rows=deskew_prefix_rows)
+        cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert, find_zeros=find_zeros, differentiate=differentiate)
     fe = (fe_factory or frontend.FrontEnd)(cfg)
     res = fe.scan(rows).fetch()
     nrows = int(rows.shape[0])
@@ -114,44 +191,21 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
                  multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
     parr = (_Parms * len(full))(*full)
     W = (C.c_int * len(full))(*fe.widths)
-    keep = {}
-
-    def exact(user, reset_row, end_row, parmset, burst_out, counts_out, events_out, cap_out):
-        try:
-            ex = fe.scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset).fetch()
-            if int(ex.bursts[0]["flags"]) & frontend.F_SCREEN_UNDERFLOW:
-                ex = fe.scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset, screen_off=True).fetch()
-            B = ex.bursts[0]
-            if int(B["flags"]) & (frontend.F_EVENT_OVERFLOW | frontend.F_DETECTOR_FATAL):
-                return 1
-            cap = int(B["event_cap"])
-            T = hdr.ntrks
-            base = int(B["event_base"]) + parmset * T * cap
-            ev = np.ascontiguousarray(ex._events[base: base + T * cap])
-            C.memmove(burst_out, B.tobytes(), frontend.BURST_DTYPE.itemsize)
-            for t in range(T):
-                counts_out[t] = int(ex.counts[0, parmset, t])
-            events_out[0] = ev.ctypes.data
-            cap_out[0] = cap
-            keep[ev.ctypes.data] = ev
-            return 0
-        except Exception:
-            return 2
-
-    def free(user, ptr):
-        keep.pop(ptr, None)
+    exact, free, keep = _exact_callbacks(fe, rows, hdr.ntrks)
 
     st = _Stats()
     bursts = np.ascontiguousarray(res.bursts)
     counts = np.ascontiguousarray(res.counts)
     events = res._events
-    rc = lib.rt_replay_run(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, nrows, 0, W,
+    run = lib.rt_replay_run_after_deskew if calibrated else lib.rt_replay_run      # (continues the pre-pass's log / event dump)
+    rc = run(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, nrows, 0, W,
                            bursts.ctypes.data, len(bursts), counts.ctypes.data, events.ctypes.data,
-                           _EXACT_FN(exact), _FREE_FN(free), None,
+                           exact, free, None,
                            tap_path.encode() if tap_path else None, log_path.encode() if log_path else None,
                            evt_path.encode() if evt_path else None, C.byref(st))
     if rc != 0:
         raise RuntimeError("rt_replay_run failed")
     stats = {k: getattr(st, k) for k, _ in _Stats._fields_}
     stats["bursts"] = res.nbursts
+    stats["skew"] = list(skew) if skew is not None else None
     return stats, res

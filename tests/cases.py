@@ -55,6 +55,18 @@ def case_gcr_errors(seed=19):
     return synth.make_tape(spec, [("block", pay[0], flips0), ("block", pay[1], flips1)], gap_samples=2500)
 
 
+def case_nrzi9_skew_long(seed=20):
+    # enough transitions per track for the -deskew calibration to stop by itself (1000 per track, src/decoder.h:99)
+    # before the tape ends: the blocks after that are decoded with the calibrated delays only
+    return synth.nrzi_tape(seed=seed, nblocks=6, minlen=380, maxlen=520, marks_every=4, gap_samples=1500,
+                           skew_cells=(0.0, 0.30, 0.12, 0.45, 0.05, 0.38, 0.20, 0.08, 0.26))
+
+
+def case_gcr_skew(seed=21):
+    return synth.gcr_tape(seed=seed, nblocks=3, minlen=60, maxlen=200, gap_samples=2500,
+                          skew_cells=(0.0, 0.9, 0.3, 1.4, 0.2, 1.1, 0.6, 0.1, 0.8))
+
+
 def case_nrzi9_oversampled(seed=18):
     # sampled at 640 ns (39 samples per bit) while the header says 1280 ns: what "-subsample=2" is for
     import dataclasses
@@ -84,6 +96,9 @@ CASES = {
     "gcr":          (case_gcr,        ["-gcr"],                        []),
     "gcr_m":        (case_gcr_noisy,  ["-gcr", "-m"],                  ["-m"]),
     "gcr_zeros":    (case_gcr,        ["-gcr", "-zeros"],              ["-zeros"]),
+    "nrzi9_deskew": (case_nrzi9_skew, ["-nrzi", "-deskew"],            ["-deskew"]),
+    "nrzi9_deskew_long": (case_nrzi9_skew_long, ["-nrzi", "-deskew"],  ["-deskew"]),
+    "gcr_deskew":   (case_gcr_skew,   ["-gcr", "-deskew"],             ["-deskew"]),
     "gcr_errs":     (case_gcr_errors, ["-gcr"],                        []),
     "gcr_correct":  (case_gcr_errors, ["-gcr", "-correct"],            ["-correct"]),
 }

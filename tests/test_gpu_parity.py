@@ -134,7 +134,7 @@ def test_large_tape_properties(gpu):
         assert got.shape == ref.shape and (got == ref).all(), f"copy {j}"
 
 
-@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_diffz"])
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "gcr_deskew", "nrzi9_diffz"])
 def test_end_to_end_tap_bytes_match_reference(name, tmp_path, gpu):
     """GPU front end -> event replay -> block decoders -> SIMH .tap == the unmodified reference's .tap (golden)."""
     from test_emul_replay import decode_case
@@ -143,6 +143,19 @@ def test_end_to_end_tap_bytes_match_reference(name, tmp_path, gpu):
     assert tap == g["tap"]
     assert stats["agc_mismatches"] == 0 and stats["events_delivered"] > 0
     assert not stats["event_diffs"], stats["event_diffs"]
+
+
+def test_deskew_calibration_on_a_growing_prefix(tmp_path, gpu):
+    """-deskew: the pre-pass scans a prefix of the tape and grows it until the reference's stopping rule is met inside
+    it; whatever the first prefix size, delays and .tap are the reference's."""
+    from readtape_amd import pipeline
+    g = load_case("nrzi9_deskew_long")
+    ref_delays = [int(l.split("delayed by")[1].split()[0]) for l in g["blocklog"] if "observed flux transitions" in l]
+    for first in (8192, 1 << 22):
+        tap = str(tmp_path / f"d{first}.tap")
+        stats, _ = pipeline.decode_tape(g["hdr"], g["rows"], tap, deskew=True, deskew_prefix_rows=first)
+        assert stats["skew"] == ref_delays
+        assert open(tap, "rb").read() == g["tap"]
 
 
 def test_end_to_end_fresh_tape_vs_oracle_tap(tmp_path, gpu):
