@@ -59,7 +59,8 @@ typedef struct rtfe_config {
    int32_t find_zeros;                    /* -zeros         (src/decoder.c:863-865)               */
    int32_t skew_delaycnt[RTFE_MAXTRKS];   /* -skew=n,n,..   in samples (src/decoder.c:232)        */
    float   maxvolts;                      /* TBIN header                                          */
-   float   bpi, ips;
+   float   bpi, ips;                      /* bpi = 0: density unknown -> the front end of the reference's density pre-pass
+                                           * (window of 8 samples, no AGC feedback; src/readtape.c:1457,1656-1672; NRZI peaks only) */
    int64_t tdelta_ns;                     /* sample period                                        */
    int64_t tstart_ns;                     /* time of row 0                                        */
    int32_t nparmsets;

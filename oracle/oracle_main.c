@@ -163,6 +163,12 @@ int main(int argc, char **argv) {
    if (evtname) { evtf = fopen(evtname, "wb"); d->on_transition = on_transition; d->on_attempt = on_attempt; fe->on_attempt_end = on_attempt_end; }
 
    struct rt_reader rd = { ofe_readblock, ofe_save_pos, ofe_restore_pos, fe };
+   if (d->opt.bpi == 0) {                                    /* src/readtape.c:1656-1672: density from the first transitions, then rewind */
+      float implied; int nb, hit_end;
+      ofe_save_pos(fe);
+      if (rt_density_prepass(d, &rd, &implied, &nb, &hit_end) == 0) {
+         fprintf(stderr, "The detected density of %.0f is non-standard; please specify it.\n", implied); return 99; }
+      ofe_restore_pos(fe); }
    if (deskew && opt.mode != RT_PE && !skewarg) {            /* src/readtape.c:1675-1717: calibrate on the first blocks, then rewind */
       int delays[RT_MAXTRKS] = {0}, hit_end = 0;
       ofe_save_pos(fe);

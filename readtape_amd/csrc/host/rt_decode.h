@@ -124,6 +124,8 @@ struct rt_options {         /* the command-line switches that reach the decoders
    int   verbose;           /* -v: log every block */
 };
 
+#define RT_ESTDEN_NUMBINS 150      /* src/decoder.c:333-338 */
+#define RT_ESTDEN_COUNTNEEDED 9999
 #define RT_PEAKSTAT_BUCKETS 50     /* src/decoder.c:121 */
 #define RT_MAXSKEWSAMP 50          /* src/decoder.h:97-99 */
 #define RT_MAXSKEWBLKS 100
@@ -158,6 +160,10 @@ struct rt_dec {
    /* flux-transition position statistics of the -deskew pre-pass (src/decoder.c:121-173): only gathered while
     * doing_deskew (in the reference they also feed a .csv report, which is out of scope) */
    int     doing_deskew;
+   /* density detection (src/decoder.c:329-394, src/readtape.c:1656-1672): while bpi is unknown every transition goes
+    * to a histogram of transition distances instead of a block decoder */
+   int     doing_density_detection;
+   struct { int deltas[RT_ESTDEN_NUMBINS], counts[RT_ESTDEN_NUMBINS], binsused, totalcount; } estden;
    struct { int initialized; float leftbin, binwidth; int counts[RT_MAXTRKS][RT_PEAKSTAT_BUCKETS]; int trksums[RT_MAXTRKS]; } peakstat;
    /* optional observer: called at the top of every up/down transition, before the format callback
     * (the same seam oracle/ref_event_shim.c wraps in the reference) */
@@ -232,6 +238,12 @@ int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit);   /*
  * Returns the number of blocks used (>= 0), or -1 if some track saw no transition; *hit_end = 1 if the reader ran out
  * of data before the reference's stopping rule was met (the caller may then retry on a longer prefix of the tape). */
 void rt_record_peakstat(struct rt_dec *d, float bitspacing, float peaktime, int trknum);   /* src/decoder.c:136-173 */
+
+/* ---- density detection (src/readtape.c:1656-1672): reads attempts with bpi = 0 until RT_ESTDEN_COUNTNEEDED transition
+ * distances are in the histogram (or the data ends), then picks the standard density.  Returns the density (d->opt.bpi
+ * is set to it), 0 if the implied density is not close to a standard one (fatal in the reference); *implied = the raw
+ * estimate, *nblks = non-noise attempts read, *hit_end = the reader ran out of data first. */
+float rt_density_prepass(struct rt_dec *d, struct rt_reader *r, float *implied, int *nblks, int *hit_end);
 int  rt_deskew_prepass(struct rt_dec *d, struct rt_reader *r, int delays[RT_MAXTRKS], int *hit_end);
 
 #ifdef __cplusplus

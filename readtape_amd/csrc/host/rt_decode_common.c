@@ -74,11 +74,11 @@ void rt_init_trackstate(struct rt_dec *d) {       /* src/decoder.c:425-455 */
       t->max_agc_gain = 0.0;
       t->min_agc_gain = FLT_MAX;
       t->v_avg_height = PKWW_PEAKHEIGHT;
-      rt_init_clkavg(&t->clkavg, 1 / (bpi * ips));
+      if (!d->doing_density_detection) rt_init_clkavg(&t->clkavg, 1 / (bpi * ips));
       t->t_clkwindow = t->clkavg.t_bitspaceavg / 2 * RT_PARM(d).clk_factor; }
    if (d->opt.mode == RT_NRZI) {
       memset(&d->nrzi, 0, sizeof d->nrzi);
-      rt_init_clkavg(&d->nrzi.clkavg, 1 / (bpi * ips)); } }
+      if (!d->doing_density_detection) rt_init_clkavg(&d->nrzi.clkavg, 1 / (bpi * ips)); } }
 
 void rt_set_expected_parity(struct rt_dec *d, int blklength) {   /* src/decoder.c:457-460 */
    d->expected_parity = blklength > 0 && blklength == d->opt.revparity
@@ -137,10 +137,25 @@ static void process_transition(struct rt_dec *d, struct rt_trk *t) {   /* src/de
       if (d->opt.mode == RT_PE && t->datablock && t->datacount > 1)
          rt_pe_generate_fake_bits(d, t); } }
 
+/* one transition distance into the histogram (src/decoder.c:351-367); returns 1 when enough have been seen */
+static int estden_transition(struct rt_dec *d, float deltasecs) {
+   const int delta = (int)(deltasecs / 0.5e-6);                /* ESTDEN_BINWIDTH: float / double, truncated */
+   if (deltasecs > 0 && deltasecs <= 120e-6) {                 /* ESTDEN_MAXDELTA (a delta <= 0 is fatal in the reference) */
+      int ndx = 0;
+      while (ndx < d->estden.binsused && d->estden.deltas[ndx] != delta) ++ndx;
+      if (ndx >= d->estden.binsused) {
+         if (d->estden.binsused >= RT_ESTDEN_NUMBINS) return d->estden.totalcount >= RT_ESTDEN_COUNTNEEDED;   /* (fatal there) */
+         d->estden.deltas[d->estden.binsused++] = delta; }
+      ++d->estden.counts[ndx];
+      ++d->estden.totalcount; }
+   return d->estden.totalcount >= RT_ESTDEN_COUNTNEEDED; }
+
 void rt_up_transition(struct rt_dec *d, struct rt_trk *t) {   /* src/decoder.c:574-590 */
    process_transition(d, t);
-   if (d->on_transition) d->on_transition(d, t, 1, d->user);
-   switch (d->opt.mode) {
+   if (d->on_transition && !d->doing_density_detection) d->on_transition(d, t, 1, d->user);   /* (the observer sits at the format callbacks) */
+   if (d->doing_density_detection) {                        /* src/decoder.c:578-581, 596-599 */
+      if (estden_transition(d, (float)(t->t_top - t->t_lastpeak))) d->results[d->parmset].blktype = RT_BS_ABORTED; }
+   else switch (d->opt.mode) {
    case RT_PE:   rt_pe_top(d, t); break;
    case RT_NRZI: rt_nrzi_top(d, t); break;
    case RT_GCR:  rt_gcr_top(d, t); break;
@@ -152,8 +167,10 @@ void rt_up_transition(struct rt_dec *d, struct rt_trk *t) {   /* src/decoder.c:5
 
 void rt_down_transition(struct rt_dec *d, struct rt_trk *t) {   /* src/decoder.c:592-609 */
    process_transition(d, t);
-   if (d->on_transition) d->on_transition(d, t, 0, d->user);
-   switch (d->opt.mode) {
+   if (d->on_transition && !d->doing_density_detection) d->on_transition(d, t, 0, d->user);   /* (the observer sits at the format callbacks) */
+   if (d->doing_density_detection) {                        /* src/decoder.c:578-581, 596-599 */
+      if (estden_transition(d, (float)(t->t_bot - t->t_lastpeak))) d->results[d->parmset].blktype = RT_BS_ABORTED; }
+   else switch (d->opt.mode) {
    case RT_PE:   rt_pe_bot(d, t); break;
    case RT_NRZI: rt_nrzi_bot(d, t); break;
    case RT_GCR:  rt_gcr_bot(d, t); break;

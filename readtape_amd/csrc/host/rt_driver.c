@@ -7,6 +7,7 @@
 #include <float.h>
 #include <limits.h>
 #include <stdarg.h>
+#include <stdio.h>
 #include <string.h>
 
 static void rlog(struct rt_dec *d, const char *fmt, ...) {
@@ -215,3 +216,42 @@ int rt_deskew_prepass(struct rt_dec *d, struct rt_reader *r, int delays[RT_MAXTR
            t, delays[t], delays[t] * d->sample_deltat * 1e6, d->peakstat.trksums[t]); }
    d->peakstat.initialized = 0;
    return nblks; }
+
+/* ---- density detection (src/readtape.c:1656-1672 + estden_setdensity, src/decoder.c:374-399) ---- */
+static const char *with_commas(int n, char *buf) {             /* 12345 -> "12,345", as the reference's log prints counts */
+   char raw[16]; int len = snprintf(raw, sizeof raw, "%d", n), o = 0;
+   for (int i = 0; i < len; ++i) { buf[o++] = raw[i]; if ((len - 1 - i) % 3 == 0 && i != len - 1) buf[o++] = ','; }
+   buf[o] = 0; return buf; }
+float rt_density_prepass(struct rt_dec *d, struct rt_reader *r, float *implied, int *nblks, int *hit_end) {
+   *nblks = 0; *hit_end = 0; *implied = 0;
+   d->doing_density_detection = 1;
+   d->opt.bpi = 0;
+   memset(&d->estden, 0, sizeof d->estden);
+   d->interblock_counter = 0;
+   do {
+      rt_init_blockstate(d);
+      d->parmset = 0;
+      rt_init_trackstate(d);
+      if (!r->readblock(r->ctx, 1)) { *hit_end = 1; break; }
+      if (d->results[d->parmset].blktype != RT_BS_NOISE) ++*nblks; }
+   while (d->estden.totalcount < RT_ESTDEN_COUNTNEEDED);
+   d->doing_density_detection = 0;
+   d->interblock_counter = 0;
+   /* the smallest transition distance seen at least 5 % of the time (ESTDEN_MINPERCENT) */
+   int mindist = INT_MAX;
+   for (int i = 0; i < d->estden.binsused; ++i)
+      if (d->estden.counts[i] > d->estden.totalcount * 5 / 100 && d->estden.deltas[i] < mindist) mindist = d->estden.deltas[i];
+   float density = 1.0f / (d->opt.ips * (float)(mindist + 0.5f) * (float)0.5e-6);
+   if (d->opt.mode == RT_PE) density /= 2;                     /* twice the transitions */
+   *implied = density;
+   static const float standard[] = { 200, 556, 800, 1600, 9042 };
+   for (int i = 0; i < 5; ++i) {
+      float diff = density - standard[i];
+      if (diff < 0) diff = -diff;
+      if (diff < standard[i] * 20 / 100) {                     /* ESTDEN_CLOSEPERCENT */
+         d->opt.bpi = standard[i];
+         char cb[24];
+         rlog(d, "  density was set to %.0f BPI (%.2f usec/bit) after reading the first %d blocks and seeing %s transitions in %d bins that imply %.0f BPI\n",
+              d->opt.bpi, 1e6 / (d->opt.bpi * d->opt.ips), *nblks, with_commas(d->estden.totalcount, cb), d->estden.binsused, density);
+         return d->opt.bpi; } }
+   return 0; }

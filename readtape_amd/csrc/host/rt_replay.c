@@ -229,7 +229,9 @@ restart:
          d->interblock_counter = 0;
          goto restart; }
       if (!using_exact && !d->interblock_counter && next >= src.end && src.end < nrows) {
-         if (events_seen == 0 && burst_usable(rp, b + 1)) {   /* still fresh: the next burst's fresh state is the same state */
+         /* still fresh: the next burst's fresh state is the same state.  During density detection the detector never
+          * leaves its fresh AGC / baseline state (no decoder runs), so every proven restart is the same state */
+         if ((events_seen == 0 || d->doing_density_detection) && burst_usable(rp, b + 1)) {
             ++b; evsrc_from_burst(&src, rp, b, parmset); evsrc_skip_before(&src, ntrks, row); ++rp->chained;
             continue; }
          if (restarted) { d->results[parmset].blktype = RT_BS_ABORTED; break; }
@@ -280,7 +282,7 @@ restart:
 
 /* prepass != NULL: run the -deskew pre-pass instead of the decode (no .tap); append: keep what is already in the log
  * and event-dump files (the decode that follows a pre-pass continues both, as the reference's single run does) */
-struct deskew_out { int *delays; int *nblks; int *hit_end; };
+struct deskew_out { int *delays; int *nblks; int *hit_end; float *bpi, *implied; };
 static int replay_any(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
@@ -306,7 +308,8 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
    if (evt_path) { rp.evtf = fopen(evt_path, append ? "ab" : "wb"); if (rp.evtf) { d->on_transition = dump_transition; d->on_attempt = dump_attempt; d->user = &rp; } }
    struct rt_reader rd = { rt_replay_readblock, rt_replay_save_pos, rt_replay_restore_pos, &rp };
    int ok = 1;
-   if (prepass) *prepass->nblks = rt_deskew_prepass(d, &rd, prepass->delays, prepass->hit_end);
+   if (prepass && prepass->bpi) *prepass->bpi = rt_density_prepass(d, &rd, prepass->implied, prepass->nblks, prepass->hit_end);
+   else if (prepass) *prepass->nblks = rt_deskew_prepass(d, &rd, prepass->delays, prepass->hit_end);
    else ok = rt_process_blocks(d, &rd, 0x7fffffff);
    if (stats) {
       stats->attempts = rp.attempts; stats->exact_scans = rp.exact_scans; stats->chained = rp.chained;
@@ -340,7 +343,17 @@ int rt_replay_deskew(const struct rt_options *opt, const struct rt_parms *parmse
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
-                  const char *log_path, const char *evt_path, int *delays, int *nblks, int *hit_end) {
-   struct deskew_out o = { delays, nblks, hit_end };
+                  const char *log_path, const char *evt_path, int append, int *delays, int *nblks, int *hit_end) {
+   struct deskew_out o = { delays, nblks, hit_end, NULL, NULL };
+   return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
+                     exact, exact_free, user, NULL, log_path, evt_path, NULL, append, &o); }
+
+
+int rt_replay_density(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *log_path, const char *evt_path, float *bpi, float *implied, int *nblks, int *hit_end) {
+   struct deskew_out o = { NULL, nblks, hit_end, bpi, implied };
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
                      exact, exact_free, user, NULL, log_path, evt_path, NULL, 0, &o); }

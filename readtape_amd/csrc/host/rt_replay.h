@@ -52,12 +52,20 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
 
 /* -deskew (src/readtape.c:1675-1717): the pre-pass over a scan made WITHOUT deskew delays -> delays[ntrks] in samples,
  * *nblks = blocks used (-1: a track without transitions), *hit_end = the scan ended before the stopping rule was met.
- * The decode of the re-scanned tape then continues the same log / event-dump files (rt_replay_run_after_deskew). */
+ * The decode of the re-scanned tape then continues the same log / event-dump files (rt_replay_run_after_deskew);
+ * append != 0: the pre-pass itself continues files a density detection started. */
 int rt_replay_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
-                  const char *log_path, const char *evt_path, int *delays, int *nblks, int *hit_end);
+                  const char *log_path, const char *evt_path, int append, int *delays, int *nblks, int *hit_end);
+/* density detection (src/readtape.c:1656-1672) over a scan made with bpi = 0 (window of 8, no AGC feedback):
+ * *bpi = the standard density chosen (0: the implied density *implied is not close to one), *nblks, *hit_end as above. */
+int rt_replay_density(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *log_path, const char *evt_path, float *bpi, float *implied, int *nblks, int *hit_end);
 int rt_replay_run_after_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,

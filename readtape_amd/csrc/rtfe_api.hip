@@ -60,7 +60,12 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (c->differentiate && !c->find_zeros) return fail(-4, "-differentiate without -zeros (peak detection on the differentiated signal) is not built on the device");
    if (c->nparmsets < 1 || c->nparmsets > RTFE_MAXPARMSETS) return fail(-5, "nparmsets %d out of range", c->nparmsets);
    if (c->nparmsets * c->ntrks > kDecodeThreads) return fail(-6, "nparmsets*ntrks > %d", kDecodeThreads);
-   if (!(c->bpi > 0) || !(c->ips > 0) || c->tdelta_ns <= 0 || !(c->maxvolts > 0)) return fail(-7, "bpi, ips, tdelta_ns and maxvolts must be positive");
+   if (!(c->bpi >= 0) || !(c->ips > 0) || c->tdelta_ns <= 0 || !(c->maxvolts > 0)) return fail(-7, "ips, tdelta_ns and maxvolts must be positive, bpi >= 0");
+   // bpi == 0: the density is unknown - the front end of the reference's density pre-pass (src/readtape.c:1656-1672):
+   // window of 8 samples, no AGC / baseline feedback (no decoder runs).  Sizing heuristics then assume 12 samples per bit.
+   const bool density_mode = c->bpi == 0;
+   if (density_mode && (c->find_zeros || c->mode != RTFE_NRZI)) return fail(-7, "bpi = 0 (density detection) is built for the NRZI peak detector only");
+   const float bpi_s = density_mode ? 1.0f / (c->ips * ((float)c->tdelta_ns / 1e9f) * 12.0f) : c->bpi;
    rtfe_handle *h = new rtfe_handle();
    h->cfg = *c;
    h->timing = 0;
@@ -69,6 +74,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    d.mode = c->mode; d.ntrks = c->ntrks; d.invert = c->invert != 0; d.nparm = c->nparmsets;
    d.find_zeros = c->find_zeros != 0;
    d.differentiate = c->differentiate != 0;
+   d.agc_off = density_mode;
    bool seen[RTFE_MAXTRKS] = {false};
    for (int i = 0; i < c->ntrks; ++i) {
       int t = c->head_to_trk[i];
@@ -80,14 +86,14 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    d.maxvolts = c->maxvolts;
    d.sample_deltat = (float)c->tdelta_ns / 1e9f;                       // src/readtape.c:1345
    d.tdelta_ns = c->tdelta_ns; d.tstart_ns = c->tstart_ns;
-   const float bitspace = 1 / (c->bpi * c->ips);                       // src/decoder.c:448
+   const float bitspace = density_mode ? 0.0f : 1 / (c->bpi * c->ips);  // src/decoder.c:448 (not initialised during density detection)
    const float hfloor = c->screen_floor_height > 0 ? c->screen_floor_height : 1.0f;
    const double lsb_per_volt = 32767.0 / (double)c->maxvolts;
    float quiet_v = 1e9f;
    for (int p = 0; p < c->nparmsets; ++p) {
       const rtfe_parmset &ps = c->parmset[p];
       DevParm &dp = d.parm[p];
-      int W = (int)(ps.pkww_bitfrac / (c->bpi * c->ips * d.sample_deltat));     // src/readtape.c:1456
+      int W = density_mode ? 8 : (int)(ps.pkww_bitfrac / (c->bpi * c->ips * d.sample_deltat));     // src/readtape.c:1455-1457
       if (W > 50) W = 50;
       if (W < 2) { delete h; return fail(-10, "parmset %d: window of %d samples is too small", p, W); }
       if (ps.agc_window < 0 || ps.agc_window > 10) { delete h; return fail(-11, "parmset %d: agc_window out of range", p); }
@@ -118,7 +124,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       // the zero-crossing detector has no amplitude feedback and no parameter-set dependence (adjust_agc returns
       // at once, src/decoder.c:501): one walker per track; nothing can become pending while |v| <= 0.2 V
       quiet_v = 0.2f;
-      d.samples_per_bit = (int)(1 / (c->bpi * c->ips * d.sample_deltat));          // src/readtape.c:1402
+      d.samples_per_bit = (int)(1 / (bpi_s * c->ips * d.sample_deltat));          // src/readtape.c:1402
       // differentiated: a restart differentiates against 0 and consecutive samples differ by up to 2q, and neither
       // may reach 0.2 V after the x0.4 x samples_per_bit scaling (src/readtape.c:1388)
       if (d.differentiate) quiet_v = 0.24f / (float)(d.samples_per_bit > 0 ? d.samples_per_bit : 1);
@@ -128,7 +134,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (c->quiet_volts > 0 && c->quiet_volts < quiet_v) quiet_v = c->quiet_volts;
    d.quiet_i = (int)floor(quiet_v * 0.98 * lsb_per_volt) - 1;
    if (d.quiet_i < 0) d.quiet_i = 0;
-   const int spb = (int)(1 / (c->bpi * c->ips * d.sample_deltat));
+   const int spb = (int)(1 / (bpi_s * c->ips * d.sample_deltat));
    int gap = c->gap_min_samples > 0 ? c->gap_min_samples : 32 * (spb > 0 ? spb : 1);
    if (gap < kMarginRows + 128) gap = kMarginRows + 128;
    d.gap_chunks = (int)(((long long)gap * c->ntrks * 2 + 1023) / 1024) + 1;
@@ -157,7 +163,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       // LDS of k_walk, sized for a typical tile (its lists go through LDS in groups, so a dense tile only costs time):
       // peaks per track per tile from the bit cell, ~4.75 units per run of W<=13 rows plus as much again for runs that
       // do not fire; detections per walker per tile bounded by the peak count
-      const float spbf = 1.0f / (c->bpi * c->ips * d.sample_deltat);
+      const float spbf = 1.0f / (bpi_s * c->ips * d.sample_deltat);
       const float ppb = c->mode == RTFE_PE ? 1.5f : 0.6f;                 // flux transitions per bit cell, typical
       int peaks = (int)((float)d.tile_rows / (spbf > 1 ? spbf : 1) * ppb) + 4;
       int lu = (int)((float)(d.nscreens * c->ntrks) * (float)peaks * 3.2f);
@@ -270,6 +276,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    // RTFE_RECORD_PATH=0/1 overrides (tests keep both paths covered for every format).
    bool use_screen = !h->dev.find_zeros && h->dev.mode == RTFE_NRZI;
    if (const char *e = getenv("RTFE_RECORD_PATH")) use_screen = !h->dev.find_zeros && atoi(e) != 0;
+   if (h->dev.agc_off) use_screen = false;                            // density detection: the sample path (the record walk's AGC schedule does not apply)
    // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
    // beat wide ones; k_decode holds ~250 VGPRs => 2 waves/SIMD => 8 waves per CU
    const int nwalk = h->dev.nparm * h->dev.ntrks;

@@ -34,6 +34,8 @@ struct DevScreen {
 struct DevCfg {
    int   mode, ntrks, invert, nparm, nscreens;
    int   find_zeros;              // -zeros: zero-crossing detector instead of the peak detector (src/decoder.c:863-865)
+   int   agc_off;                 // density detection (bpi unknown, src/decoder.c:578,596): no decoder runs, so nothing ever
+                                  // adjusts the AGC or the baseline; the window is 8 samples (src/readtape.c:1457)
    int   differentiate;           // -differentiate (only with -zeros on the device: src/decoder.c:654-683)
    int   samples_per_bit;         // (int)(1/(bpi*ips*sample_deltat)), src/readtape.c:1402
    int   zc_peak_i;               // smallest positive int16 code c with volt(c) > ZEROCROSS_PEAK (0.2 V, src/decoder.h:138)

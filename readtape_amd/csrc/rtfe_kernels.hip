@@ -358,7 +358,8 @@ __device__ __forceinline__ void adjust_agc(Walker &w, const DevParm &P, float *h
 // post-callback bookkeeping of process_up/down_transition (src/decoder.c:587-590, 605-609)
 __device__ __forceinline__ void agc_after_peak(Walker &w, const DevCfg *cfg, const DevParm &P, float *heights, bool is_top, double t_peak) {
    ++w.peakcount;                                               // src/decoder.c:561
-   if (cfg->mode == RTFE_PE) {
+   if (cfg->agc_off) { }                                         // density detection: no decoder callback (src/decoder.c:578-581)
+   else if (cfg->mode == RTFE_PE) {
       if (w.datablock) adjust_agc(w, P, heights);               // src/decode_pe.c:175,198
       else {                                                    // pe_preamble_peak, src/decode_pe.c:127-155
          if (w.peakcount == 1) w.bit1_up = !is_top;

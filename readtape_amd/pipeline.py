@@ -54,7 +54,8 @@ def _load_decode_lib():
                                   C.POINTER(C.c_int), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _EXACT_FN, _FREE_FN, C.c_void_p,
                                   C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
     lib.rt_replay_run_after_deskew.argtypes = lib.rt_replay_run.argtypes
-    lib.rt_replay_deskew.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.rt_replay_deskew.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.rt_replay_density.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return lib
 
 
@@ -113,7 +114,7 @@ def _exact_callbacks(fe, rows, ntrks):
 
 
 def calibrate_deskew(hdr, rows, full, o, fe_factory, invert=False, find_zeros=False, differentiate=False,
-                     log_path=None, evt_path=None, first_prefix_rows=1 << 22):
+                     log_path=None, evt_path=None, first_prefix_rows=1 << 22, append=False, **cfgkw):
     """The -deskew pre-pass (src/readtape.c:1675-1717) on the device front end: scans a prefix of the resident tape with
     NO deskew delays and the first parameter set, lets the host decoders record where each track's transitions fall,
     and returns the per-track delays in samples.  The prefix grows until the reference's stopping rule (1000
@@ -122,7 +123,7 @@ def calibrate_deskew(hdr, rows, full, o, fe_factory, invert=False, find_zeros=Fa
     nrows = int(rows.shape[0])
     n0 = min(nrows, first_prefix_rows)
     cfg0 = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full[:1]), skew=None, invert=invert,
-                                               find_zeros=find_zeros, differentiate=differentiate)
+                                               find_zeros=find_zeros, differentiate=differentiate, **cfgkw)
     fe0 = (fe_factory or frontend.FrontEnd)(cfg0)
     parr = (_Parms * 1)(full[0])
     W = (C.c_int * 1)(fe0.widths[0])
@@ -137,7 +138,7 @@ def calibrate_deskew(hdr, rows, full, o, fe_factory, invert=False, find_zeros=Fa
         rc = lib.rt_replay_deskew(C.byref(o), parr, 1, hdr.tdelta_ns, hdr.tstart_ns, n0, 0, W,
                                   bursts.ctypes.data, len(bursts), counts.ctypes.data, res._events.ctypes.data,
                                   exact, free, None, log_path.encode() if log_path else None,
-                                  evt_path.encode() if evt_path else None, delays, C.byref(nblks), C.byref(hit_end))
+                                  evt_path.encode() if evt_path else None, int(append), delays, C.byref(nblks), C.byref(hit_end))
         if rc != 0:
             raise RuntimeError("rt_replay_deskew failed")
         if hit_end.value and n0 < nrows:
@@ -146,6 +147,44 @@ def calibrate_deskew(hdr, rows, full, o, fe_factory, invert=False, find_zeros=Fa
         if nblks.value < 0:
             raise RuntimeError("deskew: some tracks have no transitions (is ntrks right?)")
         return [int(delays[t]) for t in range(hdr.ntrks)]
+
+
+def detect_density(hdr, rows, full, o, fe_factory, invert=False, log_path=None, evt_path=None, first_prefix_rows=1 << 22):
+    """Density detection (src/readtape.c:1656-1672) when the tape's header carries no bpi: a prefix of the resident tape
+    is scanned with the front end in its bpi = 0 configuration (window of 8 samples, no AGC feedback), the host builds
+    the histogram of transition distances from the first 9999 of them and picks the standard density.  NRZI only
+    (for PE and GCR the reference's own pre-pass degenerates: with a zero clock estimate every track goes idle at each
+    peak, src/decoder.c:868,880; give bpi for those)."""
+    if hdr.mode != tbin.MODE_NRZI:
+        raise NotImplementedError("density detection is built for NRZI only: pass bpi")
+    lib = _load_decode_lib()
+    nrows = int(rows.shape[0])
+    n0 = min(nrows, first_prefix_rows)
+    cfg0 = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full[:1]), skew=None, invert=invert, bpi=0.0)
+    fe0 = (fe_factory or frontend.FrontEnd)(cfg0)
+    parr = (_Parms * 1)(full[0])
+    W = (C.c_int * 1)(fe0.widths[0])
+    o0 = _Options.from_buffer_copy(o)
+    o0.bpi = 0.0
+    while True:
+        prefix = rows[:n0]
+        res = fe0.scan(prefix).fetch()
+        exact, free, keep = _exact_callbacks(fe0, prefix, hdr.ntrks)
+        bursts = np.ascontiguousarray(res.bursts)
+        counts = np.ascontiguousarray(res.counts)
+        bpi, implied, nblks, hit_end = C.c_float(0), C.c_float(0), C.c_int(0), C.c_int(0)
+        rc = lib.rt_replay_density(C.byref(o0), parr, 1, hdr.tdelta_ns, hdr.tstart_ns, n0, 0, W,
+                                   bursts.ctypes.data, len(bursts), counts.ctypes.data, res._events.ctypes.data,
+                                   exact, free, None, log_path.encode() if log_path else None,
+                                   evt_path.encode() if evt_path else None, C.byref(bpi), C.byref(implied), C.byref(nblks), C.byref(hit_end))
+        if rc != 0:
+            raise RuntimeError("rt_replay_density failed")
+        if hit_end.value and n0 < nrows:
+            n0 = min(nrows, n0 * 4)
+            continue
+        if bpi.value == 0:
+            raise RuntimeError(f"the detected density of {implied.value:.0f} BPI is non-standard; please specify it")
+        return float(bpi.value)
 
 
 def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
@@ -173,15 +212,24 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
         full = [arr[i] for i in range(n)][:nsets]
     else:
         full = default_parmsets(mode, nsets)
-    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert, find_zeros=find_zeros, differentiate=differentiate)
+    bpi_kw = {}
+    detected = False
+    if hdr.mode != tbin.MODE_GCR and not hdr.bpi > 0:                   # density unknown: estimate it from the first transitions
+        o_probe = _Options(mode=mode, ntrks=hdr.ntrks, bpi=0.0, ips=hdr.ips or 50.0, specified_parity=0 if opts.even_parity else 1,
+                           revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=int(find_zeros), do_differentiate=int(differentiate),
+                           multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
+        bpi_kw = {"bpi": detect_density(hdr, rows, full, o_probe, fe_factory, invert=invert, log_path=log_path, evt_path=evt_path,
+                                        first_prefix_rows=deskew_prefix_rows)}
+        detected = True
+    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert, find_zeros=find_zeros, differentiate=differentiate, **bpi_kw)
     o = _Options(mode=mode, ntrks=hdr.ntrks, bpi=cfg.bpi, ips=cfg.ips, specified_parity=0 if opts.even_parity else 1,
                  revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=int(find_zeros), do_differentiate=int(differentiate),
                  multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
     calibrated = deskew and skew is None and mode != tbin.MODE_PE        # "-deskew option is ignored for PE", src/readtape.c:1677
     if calibrated:
         skew = calibrate_deskew(hdr, rows, full, o, fe_factory, invert=invert, find_zeros=find_zeros, differentiate=differentiate,
-                                log_path=log_path, evt_path=evt_path, first_prefix_rows=deskew_prefix_rows)
-        cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert, find_zeros=find_zeros, differentiate=differentiate)
+                                log_path=log_path, evt_path=evt_path, first_prefix_rows=deskew_prefix_rows, append=detected, **bpi_kw)
+        cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), skew=skew, invert=invert, find_zeros=find_zeros, differentiate=differentiate, **bpi_kw)
     fe = (fe_factory or frontend.FrontEnd)(cfg)
     res = fe.scan(rows).fetch()
     nrows = int(rows.shape[0])
@@ -197,7 +245,7 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     bursts = np.ascontiguousarray(res.bursts)
     counts = np.ascontiguousarray(res.counts)
     events = res._events
-    run = lib.rt_replay_run_after_deskew if calibrated else lib.rt_replay_run      # (continues the pre-pass's log / event dump)
+    run = lib.rt_replay_run_after_deskew if (calibrated or detected) else lib.rt_replay_run      # (continues the pre-passes' log / event dump)
     rc = run(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, nrows, 0, W,
                            bursts.ctypes.data, len(bursts), counts.ctypes.data, events.ctypes.data,
                            exact, free, None,
@@ -208,4 +256,5 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     stats = {k: getattr(st, k) for k, _ in _Stats._fields_}
     stats["bursts"] = res.nbursts
     stats["skew"] = list(skew) if skew is not None else None
+    stats["bpi"] = cfg.bpi
     return stats, res

@@ -67,6 +67,22 @@ def case_gcr_skew(seed=21):
                           skew_cells=(0.0, 0.9, 0.3, 1.4, 0.2, 1.1, 0.6, 0.1, 0.8))
 
 
+def _without_bpi(t):
+    import dataclasses
+    t.spec = dataclasses.replace(t.spec, bpi=0.0)            # the header says "density unknown": the decoder estimates it
+    return t
+
+
+def case_nrzi9_nobpi(seed=22):
+    # > 9999 transitions: the density pre-pass stops by itself (ESTDEN_COUNTNEEDED, src/decoder.c:336)
+    return _without_bpi(synth.nrzi_tape(seed=seed, nblocks=5, minlen=600, maxlen=900, marks_every=3, gap_samples=1500))
+
+
+def case_nrzi9_nobpi_short(seed=23):
+    # the tape ends before the pre-pass has seen enough: it uses what there is
+    return _without_bpi(_nrzi_small(seed))
+
+
 def case_nrzi9_oversampled(seed=18):
     # sampled at 640 ns (39 samples per bit) while the header says 1280 ns: what "-subsample=2" is for
     import dataclasses
@@ -99,6 +115,8 @@ CASES = {
     "nrzi9_deskew": (case_nrzi9_skew, ["-nrzi", "-deskew"],            ["-deskew"]),
     "nrzi9_deskew_long": (case_nrzi9_skew_long, ["-nrzi", "-deskew"],  ["-deskew"]),
     "gcr_deskew":   (case_gcr_skew,   ["-gcr", "-deskew"],             ["-deskew"]),
+    "nrzi9_nobpi":  (case_nrzi9_nobpi, ["-nrzi"],                      []),
+    "nrzi9_nobpi_short": (case_nrzi9_nobpi_short, ["-nrzi"],           []),
     "gcr_errs":     (case_gcr_errors, ["-gcr"],                        []),
     "gcr_correct":  (case_gcr_errors, ["-gcr", "-correct"],            ["-correct"]),
 }

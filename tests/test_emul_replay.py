@@ -8,8 +8,8 @@ from emul_util import emul_frontend
 from golden_util import load_case
 from readtape_amd import pipeline
 
-CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "gcr_deskew", "nrzi9_diffz"]
-EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "nrzi9_sub2", "pe", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_zeros", "gcr_correct", "nrzi9_deskew", "nrzi9_diffz"]     # the thread emulation is slow: a subset here, all on the GPU
+CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "gcr_deskew", "nrzi9_nobpi", "nrzi9_nobpi_short", "nrzi9_diffz"]
+EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "nrzi9_sub2", "pe", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_zeros", "gcr_correct", "nrzi9_deskew", "nrzi9_nobpi_short", "nrzi9_diffz"]     # the thread emulation is slow: a subset here, all on the GPU
 
 
 def decode_case(g, tmp_path, fe_factory):
@@ -28,7 +28,7 @@ def decode_case(g, tmp_path, fe_factory):
     ign = ("v_avg_height",) if ("-zeros" in o and "-differentiate" in o) else ()
     stats["event_diffs"] = refdump.compare(refdump.load(tap + ".evt"), g["events"], ignore_fields=ign)
     if g["returncode"] == 0:   # the reference's per-block result lines: error / parity / ECC / corrected-bit counts, AGC range, offsets
-        mine = [l.strip() for l in open(tap + ".log").read().splitlines() if l.startswith("wrote block") or "tapemark at" in l or "observed flux transitions" in l]
+        mine = [l.strip() for l in open(tap + ".log").read().splitlines() if l.startswith("wrote block") or "tapemark at" in l or "observed flux transitions" in l or "density was set to" in l]
         assert mine == list(g["blocklog"]), (mine, list(g["blocklog"]))
     return open(tap, "rb").read(), stats
 
