@@ -57,7 +57,6 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (c->ntrks < 1 || c->ntrks > RTFE_MAXTRKS) return fail(-2, "ntrks %d out of range", c->ntrks);
    if (c->mode != RTFE_NRZI && c->mode != RTFE_PE && c->mode != RTFE_GCR)
       return fail(-3, "mode %d not supported by the device front end yet (Whirlwind: see DESIGN.md)", c->mode);
-   if (c->differentiate && !c->find_zeros) return fail(-4, "-differentiate without -zeros (peak detection on the differentiated signal) is not built on the device");
    if (c->nparmsets < 1 || c->nparmsets > RTFE_MAXPARMSETS) return fail(-5, "nparmsets %d out of range", c->nparmsets);
    if (c->nparmsets * c->ntrks > kDecodeThreads) return fail(-6, "nparmsets*ntrks > %d", kDecodeThreads);
    if (!(c->bpi >= 0) || !(c->ips > 0) || c->tdelta_ns <= 0 || !(c->maxvolts > 0)) return fail(-7, "ips, tdelta_ns and maxvolts must be positive, bpi >= 0");
@@ -131,6 +130,13 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       int code = 1;
       while (code < 32767 && !((float)code / 32767 * c->maxvolts > 0.2f)) ++code;     // exact, same expression as the device's volt()
       d.zc_peak_i = code; }
+   if (d.differentiate && !d.find_zeros) {
+      // peak detection on the differentiated signal (src/readtape.c:1383-1394): a zone is safe where the dead band
+      // (|delta| < 0.05 V -> 0) makes the detector's input exact zeros: |v| < 0.024 V covers both the restart (delta
+      // against 0) and consecutive samples.  No candidate screen runs in this mode.
+      if (quiet_v > 0.024f) quiet_v = 0.024f;
+      d.samples_per_bit = (int)(1 / (bpi_s * c->ips * d.sample_deltat));          // src/readtape.c:1402
+      for (int p = 0; p < c->nparmsets; ++p) { d.parm[p].screen_rise_v = -1; d.parm[p].screen_minpk_v = -1; } }
    if (c->quiet_volts > 0 && c->quiet_volts < quiet_v) quiet_v = c->quiet_volts;
    d.quiet_i = (int)floor(quiet_v * 0.98 * lsb_per_volt) - 1;
    if (d.quiet_i < 0) d.quiet_i = 0;
@@ -276,7 +282,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    // RTFE_RECORD_PATH=0/1 overrides (tests keep both paths covered for every format).
    bool use_screen = !h->dev.find_zeros && h->dev.mode == RTFE_NRZI;
    if (const char *e = getenv("RTFE_RECORD_PATH")) use_screen = !h->dev.find_zeros && atoi(e) != 0;
-   if (h->dev.agc_off) use_screen = false;                            // density detection: the sample path (the record walk's AGC schedule does not apply)
+   if (h->dev.agc_off || h->dev.differentiate) use_screen = false;                            // density detection: the sample path (the record walk's AGC schedule does not apply)
    // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
    // beat wide ones; k_decode holds ~250 VGPRs => 2 waves/SIMD => 8 waves per CU
    const int nwalk = h->dev.nparm * h->dev.ntrks;

@@ -251,6 +251,11 @@ struct Tile {
    int      ldstride;     // tile_rows + kScreenHalo
    int      ntrks;
    const int *skew;
+   float   *fd;           // LDS (-differentiate peak path only): differentiate()'s output for every element of x
+   __device__ __forceinline__ float fy(int t, long long n) const {       // the detector's input at row n: differentiated, then deskewed
+      const int d = skew[t];
+      const long long m = (n - reset < d) ? n : n - d;
+      return fd[((int)(m - row0) + halo) * ntrks + colof[t]]; }
    __device__ __forceinline__ int xi(int t, long long n) const { return x[((int)(n - row0) + halo) * ntrks + colof[t]]; }
    // v_now of track t at row n in int16 units, with the deskew FIFO exactly as the reference runs it
    // from the restart row: undelayed until the FIFO has filled (src/decoder.c:825-827), then delayed
@@ -740,6 +745,79 @@ __device__ __forceinline__ void walk_zeros(Walker &w, Ctx &cx, int trk, long lon
          ++w.nevents; } }
    w.next = n; }
 
+// differentiate() (src/readtape.c:1383-1394) for every element of the tile, all lanes: delta against the previous row of
+// the same head (0 at the burst's restart row: v_last_raw is zeroed by init_trackstate, src/decoder.c:437), the
+// +-0.05 V dead band, then x 0.4f x samples_per_bit (float x float, then x int).  Rows in front of the restart row
+// are never read by the walker.
+__device__ __forceinline__ void differentiate_tile(const DevCfg *cfg, const Tile &tl) {
+   const int ntrks = cfg->ntrks, nelem = (tl.halo + tl.nrows) * ntrks;
+   const int reset_row = (int)(tl.reset - (tl.row0 - tl.halo));        // tile-LDS row of the restart (may lie outside)
+   const float mv = cfg->maxvolts;
+   const int spb = cfg->samples_per_bit;
+   for (int i = threadIdx.x; i < nelem; i += blockDim.x) {
+      const int row = i / ntrks;
+      const float v = volt(tl.x[i], mv);
+      const float vprev = (row == reset_row || i < ntrks) ? 0.0f : volt(tl.x[i - ntrks], mv);
+      float delta = v - vprev;
+      if (delta < 0.05f && delta > -0.05f) delta = 0;
+      tl.fd[i] = delta * 0.4f * spb; } }
+
+// lookfor_peak + refine_peak (src/decoder.c:700-810) on the differentiated signal (-differentiate without -zeros): the
+// literal per-row detector on the float tile - the window is rows [n-W+1, n] of the tile, maximum exact, minimum stale
+// (src/decoder.c:765), rescan when the leaving sample equals either, blind countdown, top before bottom.
+__device__ __forceinline__ void walk_diffpeak(Walker &w, Ctx &cx, int pidx, int trk, long long limit) {
+   const DevCfg *cfg = cx.cfg;
+   const DevParm &P = cfg->parm[pidx];
+   const Tile &tl = cx.tile;
+   const int W = P.W;
+   const long long tile_end = tl.row0 + tl.nrows;
+   if (limit > tile_end) limit = tile_end;
+   long long n = w.next;
+   if (n < w.start) n = w.start;
+   for (; n < limit; ++n) {
+      const float vnow = tl.fy(trk, n);
+      if (n == w.start) {                                          // seed the window, src/decoder.c:855-861
+         w.zf_top = vnow; w.zf_bot = vnow; w.slow_countdown = 0;
+         w.t_lastpeak = time_of(cfg, cx.row_base + n);
+         continue; }
+      const bool popped = n - w.start + 1 > W;
+      const long long lo = popped ? n - W + 1 : w.start;
+      const float old_left = popped ? tl.fy(trk, n - W) : 0.0f;
+      if (vnow > w.zf_top) w.zf_top = vnow;
+      if (old_left == w.zf_top || old_left == w.zf_bot) {
+         float mx = tl.fy(trk, lo), mn = mx;
+         for (long long j = lo + 1; j <= n; ++j) { const float v = tl.fy(trk, j); if (v > mx) mx = v; if (v < mn) mn = v; }
+         w.zf_top = mx; w.zf_bot = mn; }
+      if (w.slow_countdown) { --w.slow_countdown; continue; }
+      const float rise = w.rise, reqmin = w.reqmin;
+      const float vl = tl.fy(trk, lo);
+      const bool top = w.zf_top > vl + rise && w.zf_top > vnow + rise && (reqmin == 0 || w.zf_top > reqmin);
+      const bool bot = !top && w.zf_bot < vl - rise && w.zf_bot < vnow - rise && (reqmin == 0 || w.zf_bot < -reqmin);
+      if (!(top || bot)) continue;
+      const float val = top ? w.zf_top : w.zf_bot;
+      long long p = lo;
+      while (p <= n && tl.fy(trk, p) != val) ++p;
+      if (p > n || p == lo || p == n) { w.flags |= RTFE_F_DETECTOR_FATAL; continue; }      // src/decoder.c:709-710,748
+      const int left_distance = (int)(p - lo) + 1;
+      const float prev = tl.fy(trk, p - 1), next = tl.fy(trk, p + 1);
+      int adjcode = 0;                                             // 1 = -0.5, 2 = +0.5 (src/decoder.c:712-731)
+      if (top) {
+         const float lim = val - 0.005f / w.agc_gain;
+         if (prev > lim && next < lim) adjcode = 1; else if (next > lim && prev < lim) adjcode = 2; }
+      else {
+         const float lim = val + 0.005f / w.agc_gain;
+         if (prev < lim && next > lim) adjcode = 1; else if (next < lim && prev > lim) adjcode = 2; }
+      const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
+      const double t_peak = time_of(cfg, cx.row_base + n) - ((float)(W - left_distance) - adj) * cfg->sample_deltat;
+      if (w.nevents >= cx.cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
+      else store_event(cx, pidx, trk, w.nevents, n, val, w.agc_gain, top, adjcode, left_distance);
+      if (top) w.v_top = val; else w.v_bot = val;
+      ++w.nevents;
+      agc_after_peak(w, cfg, P, cx.heights, top, t_peak);
+      update_thresholds(w, P, cfg->lsb_per_volt);
+      w.slow_countdown = left_distance; }
+   w.next = n; }
+
 // lookfor_differentiated_zerocrossing (src/decoder.c:654-683) on differentiate()'s output (src/readtape.c:1383-1388),
 // every row, one lane per track.  The differentiator restarts against 0 at the burst's restart row.
 // Event: sample = row at which the pending crossing is confirmed, v_peak = v_top / v_bot at that moment,
@@ -1198,7 +1276,7 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
 // LDS carve of k_screen / k_decode.  ONE definition, used by the kernels and by the host when it sizes the dynamic
 // LDS allocation (rtfe_api.hip): an under-sized allocation does not fault on the GPU, out-of-range LDS reads return 0.
 struct LdsLayout {
-   unsigned bits, ldpos, heights, recs, nrec, runs, runcnt, runtab, act, walkers, walkers_next, heights_bak, total; };
+   unsigned bits, ldpos, heights, recs, nrec, runs, runcnt, runtab, act, walkers, walkers_next, heights_bak, fdiff, total; };
 __host__ __device__ inline unsigned lds_runtab_cap(const DevCfg &c) {        // run descriptors of one tile (k_screen)
    const unsigned n = (unsigned)(c.nscreens * c.ntrks * c.tile_rows) / 8u;
    return n > 2048u ? 2048u : n; }
@@ -1217,6 +1295,7 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    L.runcnt = off;    if (!decode) off = lds_align16(off + nst * (T / 8) * 4u);
    L.runtab = off;    if (!decode) off = lds_align16(off + lds_runtab_cap(c) * 8u);
    L.act = off;       if (!decode) off = lds_align16(off + nst * (T / 8) * 4u);
+   L.fdiff = off;     if (decode && c.differentiate && !c.find_zeros) off = lds_align16(off + ntrks * (unsigned)c.ldw * 4u + 32u);
    L.heights = off;   if (decode) off = lds_align16(off + nwalk * 10u * 4u);
    L.recs = off;      if (decode) off = lds_align16(off + nwalk * (unsigned)c.rec_cap * (unsigned)sizeof(Rec));
    L.nrec = off;      if (decode) off = lds_align16(off + nwalk * 4u);
@@ -1840,7 +1919,9 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    cx.tile.ntrks = ntrks;
    cx.tile.skew = cfg.skew;
    const LdsLayout L = lds_layout(cfg, true);
+   const bool diffpeak = cfg.differentiate && !cfg.find_zeros;     // -differentiate without -zeros: literal float detector
    cx.tile.bits = smem + L.bits;
+   cx.tile.fd = reinterpret_cast<float *>(smem + L.fdiff);
    cx.tile.bstride = (cfg.tile_rows + kScreenHalo) / 8 + 8;
    cx.tile.ldpos = smem + L.ldpos; cx.tile.ldstride = cfg.tile_rows + kScreenHalo;
    float *heights_all = reinterpret_cast<float *>(smem + L.heights);
@@ -1866,7 +1947,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    // where to stop) evaluate this, on the same rows, so they agree.  Returns -1 when no safe row exists.
    auto zone_reset = [&](const rtfe_burst &Z) -> long long {
       if (Z.zone_end - Z.zone_first < kMarginRows + 64) return -1;
-      if (cfg.find_zeros) return Z.zone_end - kMarginRows;       // any restart inside the zone is equivalent
+      if (cfg.find_zeros || cfg.differentiate) return Z.zone_end - kMarginRows;       // any restart inside the zone is equivalent
       cx.tile.row0 = Z.zone_end - kMarginRows; cx.tile.nrows = kMarginRows; cx.tile.reset = -(1ll << 40);
       __syncthreads();
       load_tile(&cfg, cx.tile, rows, nrows);
@@ -2001,7 +2082,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          load_tile(&cfg, cx.tile, rows, nrows);
          __syncthreads();
          if (cfg.debug) c1 = clock64();
-         run_screens(&cfg, cx.tile, !cfg.find_zeros);
+         if (diffpeak) differentiate_tile(&cfg, cx.tile);         // (no candidate screen on the differentiated signal)
+         else run_screens(&cfg, cx.tile, !cfg.find_zeros);
          __syncthreads();
          if (cfg.debug) c2 = clock64();
          long long c2c = 0;
@@ -2009,6 +2091,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          if (active) {
             Walker w = walkers[my_w];
             if (cfg.find_zeros) { if (pidx == 0) { if (cfg.differentiate) walk_diffzeros(w, cx, trk, stop); else walk_zeros(w, cx, trk, stop); } }
+            else if (diffpeak) walk_diffpeak(w, cx, pidx, trk, stop);
             else walk(w, cx, pidx, trk, stop);
             walkers[my_w] = w; }
          if (is_walker) nrec_all[my_w] = cx.nrec;
@@ -2034,7 +2117,14 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       __syncthreads();
       if (threadIdx.x == 0) {
          bursts[b].reset_sample = reset;
-         bursts[b].safe_last = (bflags & (RTFE_F_UNSAFE)) ? -1 : ((cfg.find_zeros && !exact) ? B.zone_end - ntrks - 2 : reset);
+         // last attempt-start row this burst stands for.  Peak detector: the restart row itself.  -zeros: any row of the
+         // zone (no window).  Differentiated peaks: the zone is exact zeros after the dead band, so any start that leaves the
+         // window time to fill (the timestamp formula depends on a full window, src/decoder.c:732) before the zone ends.
+         int wmax = 0;
+         for (int sidx = 0; sidx < cfg.nscreens; ++sidx) wmax = max(wmax, cfg.screen[sidx].W);
+         bursts[b].safe_last = (bflags & (RTFE_F_UNSAFE)) ? -1
+                             : ((cfg.find_zeros && !exact) ? B.zone_end - ntrks - 2
+                             : ((diffpeak && !exact) ? max((long long)reset, (long long)B.zone_end - (wmax + cfg.maxskew + ntrks + 4)) : reset));
          bursts[b].end_sample = stop < hard_end ? stop : hard_end;
          bursts[b].flags = bflags | s_flags; }
       __syncthreads(); } }

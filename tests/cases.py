@@ -83,6 +83,11 @@ def case_nrzi9_nobpi_short(seed=23):
     return _without_bpi(_nrzi_small(seed))
 
 
+def case_nrzi9_clean(seed=24):
+    # no noise: the gaps differentiate to exact zeros (dead band, src/readtape.c:1387), so the device may restart in them
+    return synth.nrzi_tape(seed=seed, nblocks=4, minlen=40, maxlen=120, marks_every=3, gap_samples=1500, noise_mv=0.0)
+
+
 def case_nrzi9_oversampled(seed=18):
     # sampled at 640 ns (39 samples per bit) while the header says 1280 ns: what "-subsample=2" is for
     import dataclasses
@@ -106,6 +111,10 @@ CASES = {
     "nrzi9_zeros":  (case_nrzi9,      ["-nrzi", "-zeros"],             ["-zeros"]),
     "nrzi9_diffz":  (case_nrzi9,      ["-nrzi", "-zeros", "-differentiate"], ["-zeros", "-differentiate"]),
     "nrzi9_diffpk": (case_nrzi9,      ["-nrzi", "-differentiate"],     ["-differentiate"]),
+    "nrzi9_diffpk_clean": (case_nrzi9_clean, ["-nrzi", "-differentiate", "-m"], ["-differentiate", "-m"]),
+    "nrzi9_diffpk_skew": (case_nrzi9_clean, ["-nrzi", "-ntrks=9", "-differentiate", "-skew=3,1,2,0,3,0,1,2,1"], ["-differentiate", "-skew=3,1,2,0,3,0,1,2,1"]),
+    "gcr_diffpk":   (case_gcr,        ["-gcr", "-differentiate"],      ["-differentiate"]),
+    "pe_diffpk":    (case_pe,         ["-pe", "-differentiate"],       ["-differentiate"]),
     "pe":           (case_pe,         ["-pe"],                         []),
     "pe_m":         (case_pe,         ["-pe", "-m"],                   ["-m"]),
     "pe_zeros":     (case_pe,         ["-pe", "-zeros"],               ["-zeros"]),

@@ -134,7 +134,7 @@ def test_large_tape_properties(gpu):
         assert got.shape == ref.shape and (got == ref).all(), f"copy {j}"
 
 
-@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "gcr_deskew", "nrzi9_nobpi", "nrzi9_nobpi_short", "nrzi9_diffz"])
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "gcr_deskew", "nrzi9_nobpi", "nrzi9_nobpi_short", "nrzi9_diffz", "nrzi9_diffpk", "nrzi9_diffpk_clean", "nrzi9_diffpk_skew", "gcr_diffpk", "pe_diffpk"])
 def test_end_to_end_tap_bytes_match_reference(name, tmp_path, gpu):
     """GPU front end -> event replay -> block decoders -> SIMH .tap == the unmodified reference's .tap (golden)."""
     from test_emul_replay import decode_case
@@ -143,6 +143,18 @@ def test_end_to_end_tap_bytes_match_reference(name, tmp_path, gpu):
     assert tap == g["tap"]
     assert stats["agc_mismatches"] == 0 and stats["events_delivered"] > 0
     assert not stats["event_diffs"], stats["event_diffs"]
+
+
+def test_differentiated_peak_path_restarts_in_exact_zero_gaps(tmp_path, gpu):
+    """-differentiate without -zeros: on a noise-free tape the gaps differentiate to exact zeros (dead band), every block
+    becomes its own device burst and no attempt needs an exact rescan; with noise the whole tape is one burst."""
+    from test_emul_replay import decode_case
+    g = load_case("nrzi9_diffpk_clean")
+    tap, stats = decode_case(g, tmp_path, None)
+    assert tap == g["tap"] and stats["bursts"] >= 5 and stats["exact_scans"] == 0
+    g = load_case("nrzi9_diffpk")
+    tap, stats = decode_case(g, tmp_path, None)
+    assert tap == g["tap"] and stats["bursts"] == 1
 
 
 def test_deskew_calibration_on_a_growing_prefix(tmp_path, gpu):
