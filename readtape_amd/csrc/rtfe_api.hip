@@ -144,6 +144,8 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    int gap = c->gap_min_samples > 0 ? c->gap_min_samples : 32 * (spb > 0 ? spb : 1);
    if (gap < kMarginRows + 128) gap = kMarginRows + 128;
    d.gap_chunks = (int)(((long long)gap * c->ntrks * 2 + 1023) / 1024) + 1;
+   d.tail_rows = 48 * (spb > 0 ? spb : 1);                              // 48 bit cells of silence: every format has ended its block (NRZI ~10, PE 2.5, GCR 6)
+   if (const char *e = getenv("RTFE_TAIL_ROWS")) d.tail_rows = atoi(e);   // (tests: 0 = walk the whole gap)
    d.cap_frac = c->events_per_sample_cap > 0 ? c->events_per_sample_cap : 0.125f;
    {
       const char *e = getenv("RTFE_TILE_ROWS");            // tuning knob; the default is what bench.py measures
@@ -230,8 +232,9 @@ static long long nwords_for(const rtfe_handle *h, int64_t nrows) {
 static long long ntiles_for(const rtfe_handle *h, int64_t nrows) { return (nrows + h->dev.tile_rows - 1) / h->dev.tile_rows; }
 static long long pool_cap_for(const rtfe_handle *h, int64_t nrows) {       // a fixed slot of run_cap records per (tile, screen, track)
    return ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * h->dev.run_cap; }
-// workspace: [0,kScratchBytes) scratch | quiet words | tile directory | run pool
-static size_t ws_dir_off(const rtfe_handle *h, int64_t nrows) { return (kScratchBytes + (size_t)nwords_for(h, nrows) * 8 + 255) & ~(size_t)255; }
+// workspace: [0,kScratchBytes) scratch | quiet words | dead-tile bitmap | tile directory | run pool
+static size_t ws_dead_off(const rtfe_handle *h, int64_t nrows) { return (kScratchBytes + (size_t)nwords_for(h, nrows) * 8 + 255) & ~(size_t)255; }
+static size_t ws_dir_off(const rtfe_handle *h, int64_t nrows) { return (ws_dead_off(h, nrows) + (size_t)((ntiles_for(h, nrows) + 31) / 32) * 4 + 255) & ~(size_t)255; }
 static size_t ws_pool_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_dir_off(h, nrows) + (size_t)ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(TileDir) + 255) & ~(size_t)255; }
 
@@ -272,6 +275,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    BurstScratch *scratch = reinterpret_cast<BurstScratch *>(d_workspace);
    unsigned long long *qwords = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_workspace) + kScratchBytes);
    int grid = (int)(nwords < (long long)h->num_cus * 8 ? nwords : (long long)h->num_cus * 8);
+   unsigned int *deadp = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(d_workspace) + ws_dead_off(h, nrows));
    TileDir *dirp = reinterpret_cast<TileDir *>(reinterpret_cast<char *>(d_workspace) + ws_dir_off(h, nrows));
    CandUnit *poolp = reinterpret_cast<CandUnit *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
    BurstCtl *ctlp = reinterpret_cast<BurstCtl *>(reinterpret_cast<char *>(d_workspace) + ws_ctl_off(h, nrows));
@@ -302,7 +306,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    t1(0, sq); t0(1, sq);
    hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, sq, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
-                      d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts);
+                      d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts,
+                      deadp, ntiles_for(h, nrows), h->dev.tile_rows, h->dev.tail_rows);
    t1(1, sq);
    if (!use_screen) {                                                 // -zeros, PE, GCR: the whole burst in one pass over the samples
       t0(2, st); t1(2, st); t0(3, st);
@@ -325,7 +330,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (sgrid > ntiles) sgrid = ntiles;
       t0(2, st);
       hipLaunchKernelGGL(k_screen, dim3((unsigned)sgrid), dim3(256), h->screen_lds_bytes, st, h->d_dev, d_rows, (long long)nrows, dirp, poolp,
-                         ntiles, scratch->scr);
+                         ntiles, scratch->scr, (const unsigned int *)deadp);
       t1(2, st);
       int wthreads = threads;
       if (getenv("RTFE_WALK_THREADS")) { const int v = atoi(getenv("RTFE_WALK_THREADS")); if (v >= threads && v <= 256 && v % 64 == 0) wthreads = v; }

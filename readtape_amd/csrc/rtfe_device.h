@@ -48,6 +48,8 @@ struct DevCfg {
    long long tdelta_ns, tstart_ns;
    int   quiet_i;                 // |x| <= quiet_i on every track  <=> row is "quiet"
    int   gap_chunks;              // quiet chunks that make an inter-block zone
+   int   tail_rows;               // a burst's walkers stop this many rows into the next zone (the block decoders have long ended
+                                  // the block by then; an attempt that has not falls back to an exact rescan in the replay)
    float cap_frac;                // event capacity per track as a fraction of burst length
    int   tile_rows;               // rows per LDS tile (multiple of 64, kMarginRows..kMaxTileRows)
    int   halo_rows;               // rows kept in front of a tile: kScreenHalo + widest window + 1 + max skew, rounded up to 8

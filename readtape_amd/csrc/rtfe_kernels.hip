@@ -115,8 +115,10 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
                                                  long long nrows, long long own_rows, int ntrks, int gap_chunks, int first_is_start,
                                                  float cap_frac, int nparm, long long event_capacity,
                                                  rtfe_burst *__restrict__ bursts, long long max_bursts,
-                                                 BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out) {
+                                                 BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out,
+                                                 unsigned int *__restrict__ dead, long long ntiles, int tile_rows, int tail_rows) {
    __shared__ int lds[32];
+   for (long long i = threadIdx.x; i < (ntiles + 31) / 32; i += blockDim.x) dead[i] = 0;
    __shared__ int s_base;
    __shared__ u64 s_ebase;
    if (threadIdx.x == 0) {
@@ -211,7 +213,14 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
          if (len < 0) len = 0;
          cap = (long long)((float)len * cap_frac) + 64;
          bursts[b].end_sample = end;             // provisional: the decode kernel replaces it by the next reset
-         bursts[b].event_cap = (uint32_t)cap; }
+         bursts[b].event_cap = (uint32_t)cap;
+         // the dead part of the gap in front of this burst: the previous burst's walkers stop tail_rows into the zone
+         // (k_decode), this burst's restart lies in the zone's last kMarginRows rows; tiles entirely in between are
+         // never walked, so k_screen need not screen them
+         if (tail_rows > 0 && !(bursts[b].flags & RTFE_F_EXACT_START)) {
+            const long long T = tile_rows;
+            const long long g0 = (bursts[b].zone_first + tail_rows + T - 1) / T, g1 = (bursts[b].zone_end - kMarginRows) / T;   // [g0, g1)
+            for (long long g = g0; g < g1 && g < ntiles; ++g) atomicOr(&dead[g >> 5], 1u << (g & 31)); } }
       // 64-bit scan done as two 32-bit scans would overflow; regions are < 2^31 events each, so scan in units of 64 events
       int total;
       const int units = (int)((cap * nparm * ntrks + 63) >> 6);
@@ -1335,7 +1344,7 @@ __host__ __device__ inline WalkLds lds_layout_walk(const DevCfg &c) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
                                                 TileDir *__restrict__ dir, CandUnit *__restrict__ pool, long long ntiles,
-                                                unsigned long long *__restrict__ scr) {
+                                                unsigned long long *__restrict__ scr, const unsigned int *__restrict__ dead) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;
 #else
@@ -1361,6 +1370,9 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    const long long T = cfg.tile_rows;
    for (long long g = blockIdx.x; g < ntiles; g += gridDim.x) {
       tl.row0 = g * T; tl.nrows = (int)((tl.row0 + T <= nrows) ? T : nrows - tl.row0);
+      if ((dead[g >> 5] >> (g & 31)) & 1) {                           // deep inside an inter-block gap: no walker comes here (k_bursts)
+         if ((int)threadIdx.x < nst) { TileDir d0; d0.count = 0xFFFF; d0.nruns = 0; d0.end_ld = 0; d0.pad = 0; d0.end_min = 0; dir[g * nst + threadIdx.x] = d0; }   // (if one ever did: "no list" = sample path)
+         continue; }
       __syncthreads();
       long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
       if (cfg.debug) k0 = clock64();
@@ -1992,7 +2004,9 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          if (has_tail) {
             const rtfe_burst NB = bursts[b + 1];
             stop = zone_reset(NB);
-            if (stop < 0) stop = NB.zone_end - kMarginRows; }
+            if (stop < 0) stop = NB.zone_end - kMarginRows;
+            // the dead part of the gap: nothing a block decoder still listens to lies more than tail_rows into the quiet zone
+            if (cfg.tail_rows > 0 && NB.zone_first + cfg.tail_rows < stop) stop = NB.zone_first + cfg.tail_rows; }
          // ---- walker init: init_trackstate + init_trackpeak_state (src/decoder.c:413-455) ----
          // (the walker's state lives in LDS between tiles so that the all-lane phases do not carry it in registers)
          if (is_walker) {
