@@ -42,3 +42,14 @@ def test_tap_bytes_match_reference(name, tmp_path):
     assert stats["agc_mismatches"] == 0
     assert stats["events_delivered"] > 0
     assert not stats["event_diffs"], stats["event_diffs"]
+
+
+def test_short_burst_tails_do_not_change_the_tap(tmp_path, monkeypatch):
+    """A burst's walkers stop tail_rows into the next quiet zone.  Even with an absurdly short tail
+    the .tap must not change: a zone only starts a whole quiet KiB after the last flux transition, by when the block
+    decoders have ended the block - and if one had not, the replay would ask for an exact rescan."""
+    monkeypatch.setenv("RTFE_TAIL_ROWS", "8")
+    g = load_case("nrzi9")
+    tap, stats = decode_case(g, tmp_path, emul_frontend)
+    assert tap == g["tap"]
+    assert not stats["event_diffs"]

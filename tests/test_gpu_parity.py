@@ -157,6 +157,17 @@ def test_differentiated_peak_path_restarts_in_exact_zero_gaps(tmp_path, gpu):
     assert tap == g["tap"] and stats["bursts"] == 1
 
 
+@pytest.mark.parametrize("name", ["nrzi9", "pe", "gcr"])
+def test_short_burst_tails_do_not_change_the_tap(name, tmp_path, gpu, monkeypatch):
+    """tail_rows absurdly short: the .tap does not change (a zone starts a whole quiet KiB after the last transition, by
+    when the block has ended; otherwise the replay falls back to an exact rescan) - DESIGN.md §3 item 5."""
+    from test_emul_replay import decode_case
+    monkeypatch.setenv("RTFE_TAIL_ROWS", "8")
+    g = load_case(name)
+    tap, stats = decode_case(g, tmp_path, None)
+    assert tap == g["tap"] and not stats["event_diffs"]
+
+
 def test_deskew_calibration_on_a_growing_prefix(tmp_path, gpu):
     """-deskew: the pre-pass scans a prefix of the tape and grows it until the reference's stopping rule is met inside
     it; whatever the first prefix size, delays and .tap are the reference's."""
