@@ -144,6 +144,11 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    int gap = c->gap_min_samples > 0 ? c->gap_min_samples : 32 * (spb > 0 ? spb : 1);
    if (gap < kMarginRows + 128) gap = kMarginRows + 128;
    d.gap_chunks = (int)(((long long)gap * c->ntrks * 2 + 1023) / 1024) + 1;
+   d.seg_tiles = 48;                                                  // the record walk of a long block runs as concurrent segments of 48 tiles
+   d.seg_warm = kSegWarmup;
+   if (const char *e = getenv("RTFE_SEG_WARMUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) d.seg_warm = v; }
+   if (const char *e = getenv("RTFE_SEG_TILES")) { const int v = atoi(e); d.seg_tiles = v <= 0 ? 0 : v; }
+   if (d.seg_tiles > 0 && d.seg_tiles < d.seg_warm) d.seg_tiles = d.seg_warm;
    d.tail_rows = 48 * (spb > 0 ? spb : 1);                              // 48 bit cells of silence: every format has ended its block (NRZI ~10, PE 2.5, GCR 6)
    if (const char *e = getenv("RTFE_TAIL_ROWS")) d.tail_rows = atoi(e);   // (tests: 0 = walk the whole gap)
    d.cap_frac = c->events_per_sample_cap > 0 ? c->events_per_sample_cap : 0.125f;
@@ -154,6 +159,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       if (tr < kMarginRows) tr = kMarginRows;
       if (tr > kMaxTileRows) tr = kMaxTileRows;
       d.tile_rows = tr; }
+   d.seg_evcap = (int)((float)d.seg_tiles * (float)d.tile_rows * d.cap_frac) + 16;
    {
       int wmax = 0;
       for (int sidx = 0; sidx < d.nscreens; ++sidx) if (d.screen[sidx].W > wmax) wmax = d.screen[sidx].W;
@@ -247,8 +253,19 @@ static size_t ws_ctl_off(const rtfe_handle *h, int64_t nrows) {
 static size_t ws_state_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_ctl_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * sizeof(BurstCtl) + 255) & ~(size_t)255; }
 
+// ... | segment table (per burst) | segment -> burst | segment status | segment start states | segment end states
+static long long max_segs_for(const rtfe_handle *h, int64_t nrows) {
+   return h->dev.seg_tiles > 0 ? ntiles_for(h, nrows) / h->dev.seg_tiles + rtfe_max_bursts(h, nrows) + 8 : 0; }
+static size_t ws_segtab_off(const rtfe_handle *h, int64_t nrows) {
+   return (ws_state_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
+static size_t ws_segburst_off(const rtfe_handle *h, int64_t nrows) { return (ws_segtab_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * sizeof(SegTab) + 255) & ~(size_t)255; }
+static size_t ws_segstat_off(const rtfe_handle *h, int64_t nrows) { return (ws_segburst_off(h, nrows) + (size_t)max_segs_for(h, nrows) * 4 + 255) & ~(size_t)255; }
+static size_t ws_segstart_off(const rtfe_handle *h, int64_t nrows) { return (ws_segstat_off(h, nrows) + (size_t)max_segs_for(h, nrows) * 4 + 255) & ~(size_t)255; }
+static size_t ws_segend_off(const rtfe_handle *h, int64_t nrows) {
+   return (ws_segstart_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
+
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_state_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 256; }
+   return ws_segend_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -280,6 +297,10 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    CandUnit *poolp = reinterpret_cast<CandUnit *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
    BurstCtl *ctlp = reinterpret_cast<BurstCtl *>(reinterpret_cast<char *>(d_workspace) + ws_ctl_off(h, nrows));
    WalkState *statep = reinterpret_cast<WalkState *>(reinterpret_cast<char *>(d_workspace) + ws_state_off(h, nrows));
+   char *wsb = reinterpret_cast<char *>(d_workspace);
+   SegTab *segtabp = reinterpret_cast<SegTab *>(wsb + ws_segtab_off(h, nrows));
+   int *segburstp = reinterpret_cast<int *>(wsb + ws_segburst_off(h, nrows)), *segstatp = reinterpret_cast<int *>(wsb + ws_segstat_off(h, nrows));
+   WalkState *segstartp = reinterpret_cast<WalkState *>(wsb + ws_segstart_off(h, nrows)), *segendp = reinterpret_cast<WalkState *>(wsb + ws_segend_off(h, nrows));
    // The record path (k_screen -> k_walk) pays when flux transitions are at least a bit cell apart (NRZI): then a run of
    // candidate rows has one kind.  PE and GCR put a top and a bottom into the window at the same time; their candidate
    // lists degenerate into one-row runs and overflow, so they take the sample path for the whole burst.
@@ -339,8 +360,23 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (wpc > wlim) wpc = wlim;
       if (wpc < 1) wpc = 1;
       t0(4, st);
+      if (h->dev.seg_tiles > 0 && h->dev.mode != RTFE_PE) {
+         // long blocks: the walk runs as concurrent segments.  (1) every burst until its walkers have left the AGC start-up,
+         // (2) cut, (3) all segments, (4) join them (or hand the burst to the pass below)
+         hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
+                            d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
+                            (int)kWalkPre, (const SegTab *)segtabp, (const int *)segburstp, segstartp, segendp, segstatp);
+         hipLaunchKernelGGL(k_segs, dim3(1), dim3(1024), 0, st, h->d_dev, (long long)nrows, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp,
+                            (const WalkState *)statep, segtabp, segburstp, segstatp, max_segs_for(h, nrows));
+         hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
+                            d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
+                            (int)kWalkSegs, (const SegTab *)segtabp, (const int *)segburstp, segstartp, segendp, segstatp);
+         hipLaunchKernelGGL(k_stitch, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, d_counts, d_events, ctlp,
+                            statep, (const SegTab *)segtabp, (const WalkState *)segstartp, (const WalkState *)segendp, (const int *)segstatp); }
+      else
       hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
-                         d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep);
+                         d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
+                         (int)kWalkWhole, (const SegTab *)nullptr, (const int *)nullptr, (WalkState *)nullptr, (WalkState *)nullptr, (int *)nullptr);
       t1(4, st); t0(5, st);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,

@@ -48,6 +48,9 @@ struct DevCfg {
    long long tdelta_ns, tstart_ns;
    int   quiet_i;                 // |x| <= quiet_i on every track  <=> row is "quiet"
    int   gap_chunks;              // quiet chunks that make an inter-block zone
+   int   seg_tiles;               // tiles per segment of the record walk (0 = whole bursts); seg_evcap = events per (segment, walker) slot
+   int   seg_evcap;
+   int   seg_warm;                // warm-up tiles in front of every segment but the first
    int   tail_rows;               // a burst's walkers stop this many rows into the next zone (the block decoders have long ended
                                   // the block by then; an attempt that has not falls back to an exact rescan in the replay)
    float cap_frac;                // event capacity per track as a fraction of burst length
@@ -90,9 +93,15 @@ struct TileDir {               // per (tile, screen, track): 8 bytes
    uint8_t  pad;
    int16_t  end_min;           // that minimum (int16 code)
 };
+// ---- segments: a long burst's record walk is cut into runs of seg_tiles tiles that are walked concurrently; every
+// segment but the first starts kSegWarmup tiles early from a guessed state, and k_stitch accepts the result only if the
+// state each segment had at its first own tile is, bit for bit, the state its predecessor ended with ----
+constexpr int kSegWarmup = 8;      // tiles: the alpha-filter AGC needs ~90 detections per track to forget its start value to the last bit
+struct SegTab { int first; int nseg; int t0; int tend; };      // per burst: global index of segment 0, segments, first tile, end tile (excl.)
 // ---- burst hand-over between the kernels of one scan (workspace) ----
 enum { kBurstNew = 0, kBurstNeedsFull = 1, kBurstReady = 2, kBurstDone = 3 };
 enum { kDecodeAll = 0, kDecodeHead = 1, kDecodeResume = 2 };
+enum { kWalkWhole = 0, kWalkPre = 1, kWalkSegs = 2 };
 struct BurstCtl {              // 32 bytes per burst
    long long reset, stop;      // restart row / first row of the next burst's span
    int       next_tile;        // tile of the tape-global grid to continue with

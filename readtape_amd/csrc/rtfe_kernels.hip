@@ -81,7 +81,10 @@ struct BurstScratch {            // lives in the workspace (first kScratchBytes 
    int   nbursts_total;          // owned bursts + (time shards) the first burst of the halo, which only bounds the last owned one
    int   queue_walk;             // ... of k_walk
    int   queue_resume;           // ... of the second k_decode pass
-   int   pad[11];
+   int   queue_seg, nsegs;       // segment queue of k_walk (segment mode), segments of this scan (k_segs)
+   int   queue_stitch;           // ... of k_stitch
+   int   seg_failed;             // bursts whose segments did not join (statistics)
+   int   pad[7];
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
    unsigned long long pool_cursor;   // at byte 128: next free PackedRun of the pool (k_screen)
    unsigned long long dbg2[8];   // dbg[8..15] (contiguous with dbg through pool_cursor is NOT assumed: indexed separately)
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
       if (threadIdx.x == 0) s_ebase += (u64)total << 6;
       __syncthreads(); }
    if (threadIdx.x == 0) {
-      scratch->nbursts = n_owned; scratch->nbursts_total = nb; scratch->queue = 0; scratch->queue_walk = 0; scratch->queue_resume = 0; *nbursts_out = n_owned;
+      scratch->nbursts = n_owned; scratch->nbursts_total = nb; scratch->queue = 0; scratch->queue_walk = 0; scratch->queue_resume = 0; scratch->queue_seg = 0; scratch->nsegs = 0; scratch->queue_stitch = 0; scratch->seg_failed = 0; *nbursts_out = n_owned;
       if (n_owned == nb && own_rows < nrows && n_owned > 0) bursts[n_owned - 1].flags |= RTFE_F_TRUNCATED; }
    if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0;
    if (threadIdx.x == 8) scratch->pool_cursor = 0;
@@ -1481,7 +1484,9 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                                                        rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
                                                        uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                                        const TileDir *__restrict__ dir, const CandUnit *__restrict__ pool,
-                                                       BurstCtl *__restrict__ ctl, WalkState *__restrict__ wstate) {
+                                                       BurstCtl *__restrict__ ctl, WalkState *__restrict__ wstate,
+                                                       int walk_mode, const SegTab *__restrict__ segtab, const int *__restrict__ segburst,
+                                                       WalkState *__restrict__ seg_start, WalkState *__restrict__ seg_end, int *__restrict__ seg_status) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;            // tests/cpu_emul only
 #else
@@ -1530,11 +1535,16 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
    cx.rec_cap = 0; cx.rec_cap16 = cfg.rec_cap16;
    cx.recs = reinterpret_cast<Rec *>(recs_all + (size_t)(is_walker ? my_w : 0) * rstride);
    const long long T = cfg.tile_rows;
+   // walk_mode: kWalkWhole = every ready burst from its hand-over tile to its end; kWalkPre = the same, but only until
+   // every walker has left the AGC start-up (then the burst goes back to "ready" for the segment pass); kWalkSegs = the
+   // work items are segments (k_segs): tiles [t0 + s*seg_tiles, ...) of a burst, walked from a guessed state after
+   // kSegWarmup tiles of warm-up (segment 0: from the burst's true state)
    for (;;) {
-      if (threadIdx.x == 0) { s_burst = atomicAdd(&scratch->queue_walk, 1); s_flags = 0; }
+      if (threadIdx.x == 0) { s_burst = atomicAdd(walk_mode == kWalkSegs ? &scratch->queue_seg : &scratch->queue_walk, 1); s_flags = 0; }
       __syncthreads();
-      const int b = s_burst;
-      if (b >= scratch->nbursts) break;
+      const int item = s_burst;
+      if (item >= (walk_mode == kWalkSegs ? scratch->nsegs : scratch->nbursts)) break;
+      const int b = walk_mode == kWalkSegs ? segburst[item] : item;
       if (ctl[b].status != kBurstReady) { __syncthreads(); continue; }
       const rtfe_burst B = bursts[b];
       cx.events = events + B.event_base;
@@ -1552,13 +1562,57 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
       long long acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, ntl = 0;
       long long pa[6] = {0, 0, 0, 0, 0, 0};
       TileDir nd; nd.count = 0; nd.nruns = 0; nd.end_ld = 0; nd.pad = 0; nd.end_min = 0;
+      // ---- segment mode: which tiles, from which state, into which slot of the burst's event regions ----
+      long long g_hi = (stop + T - 1) / T, seg_lo = g;              // tiles [g, g_hi); seg_lo = first tile whose events count
+      int seg = 0, nseg = 1;
+      unsigned int ev_base = 0, ev_limit = cx.cap;                  // this segment's slot [ev_base, ev_limit) of the walker's event region
+      bool pre_done = false;
+      if (walk_mode == kWalkSegs) {
+         const SegTab stb = segtab[b];
+         seg = item - stb.first; nseg = stb.nseg;
+         seg_lo = stb.t0 + (long long)seg * cfg.seg_tiles;
+         g_hi = seg + 1 < nseg ? seg_lo + cfg.seg_tiles : stb.tend;
+         g = seg_lo;
+         if (nseg > 1) {
+            ev_base = w.nevents + (unsigned)seg * (unsigned)cfg.seg_evcap; ev_limit = ev_base + (unsigned)cfg.seg_evcap;
+            if (ev_limit > cx.cap) ev_limit = cx.cap;
+            if (seg > 0) {
+               // a guess of the state kSegWarmup tiles ahead of the segment: the burst's steady state as of its hand-over, no
+               // countdown pending.  Decisions re-join the true sequence at the first stretch of W+1 rows without a candidate,
+               // the peak memory after two detections, the AGC filter geometrically - k_stitch verifies that all did.
+               g = seg_lo - cfg.seg_warm;
+               w.blind_until = -1; w.next = g * T; w.trust_from = -(1ll << 40); w.flags = 0;
+               w.cpos = g * T - 1; w.chain_pending = false;
+               w.nevents = ev_base; } } }
       const long long g_first = g;
-      for (; g * T < stop; ++g) {
+      for (; g < g_hi && g * T < stop; ++g) {
          const long long tile0 = g * T;
          const long long tn = (tile0 + T <= nrows) ? T : nrows - tile0;
          if (tn <= 0) break;
          cx.tile.row0 = tile0; cx.tile.nrows = (int)tn;
          __syncthreads();
+         if (walk_mode == kWalkSegs && seg > 0 && g == seg_lo && is_walker) {
+            // end of the warm-up: this is the state the segment really starts from (its detections so far are dropped)
+            w.nevents = ev_base;
+            const DevParm &P = cfg.parm[pidx];
+            update_thresholds(w, P, cfg.lsb_per_volt);               // (exact thresholds are a function of the AGC state: normal form)
+            WalkState &ws = seg_start[(size_t)item * nwalk + my_w];
+            load_walk_fields(ws.w, w);
+            for (int i = 0; i < 10; ++i) ws.heights[i] = cx.heights[i]; }
+         if (walk_mode == kWalkPre && g > g_first) {                 // has every walker left the AGC start-up (or never entered it)?
+            if (threadIdx.x == 0) s_needfull = 0;
+            __syncthreads();
+            if (is_walker && !((w.peakcount >= 16 && w.v_avg_height_count == 0) || w.peakcount == 0)) atomicOr((unsigned int *)&s_needfull, 1u);
+            __syncthreads();
+            if (!s_needfull || g - g_first >= 6) { pre_done = true; break; }
+            __syncthreads(); }
+         if (walk_mode == kWalkSegs && nseg > 1) {                    // room left in this segment's event slot?
+            if (threadIdx.x == 0) s_needfull = 0;
+            __syncthreads();
+            if (is_walker && w.nevents + 2u * (unsigned)cfg.rec_cap16 + 8u >= ev_limit) atomicOr((unsigned int *)&s_needfull, 1u);
+            __syncthreads();
+            if (s_needfull) { give_back = true; break; }
+            __syncthreads(); }
          long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
          if (cfg.debug) t0 = clock64();
          if (threadIdx.x == 0) s_needfull = 0;
@@ -1874,12 +1928,22 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
          atomicAdd(&scratch->dbg2[2], (unsigned long long)acc2); atomicAdd(&scratch->dbg2[3], (unsigned long long)acc3);
          atomicAdd(&scratch->dbg[7], (unsigned long long)ntl);
          for (int i = 0; i < 6; ++i) atomicAdd(&scratch->why[2 + i], (unsigned long long)pa[i]); }
-      if (give_back) {                                                // the state as of the start of tile g
+      if (walk_mode == kWalkSegs && nseg > 1) {                       // one of several segments: k_stitch joins them (or rejects them all)
+         if (is_walker) {
+            const DevParm &P = cfg.parm[pidx];
+            if (!give_back) update_thresholds(w, P, cfg.lsb_per_volt);
+            WalkState &ws = seg_end[(size_t)item * nwalk + my_w];
+            load_walk_fields(ws.w, w);
+            for (int i = 0; i < 10; ++i) ws.heights[i] = cx.heights[i]; }
+         if (threadIdx.x == 0) seg_status[item] = give_back ? 1 : 0;
+         __syncthreads();
+         continue; }
+      if (give_back || pre_done) {                                    // the state as of the start of tile g
          if (is_walker) {
             WalkState &ws = wstate[(size_t)b * nwalk + my_w];
             load_walk_fields(ws.w, w);
             for (int i = 0; i < 10; ++i) ws.heights[i] = cx.heights[i]; }
-         if (threadIdx.x == 0) { ctl[b].next_tile = (int)g; ctl[b].status = kBurstNeedsFull; }
+         if (threadIdx.x == 0) { ctl[b].next_tile = (int)g; if (give_back) ctl[b].status = kBurstNeedsFull; }
          __syncthreads();
          continue; }
       // ---- publish (as k_decode does) ----
@@ -1893,6 +1957,152 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
          bursts[b].end_sample = stop < nrows ? stop : nrows;
          bursts[b].flags = bflags | s_flags;
          ctl[b].status = kBurstDone; }
+      __syncthreads(); } }
+
+// ------------------------------------------------------------------------------------------------
+// k_segs: cuts the bursts that are ready for the record walk into segments (single workgroup, one lane per burst).
+// A burst is cut only if every walker has left the AGC start-up (the guess of a later segment's state copies the
+// steady baseline) and the segments' event slots fit the burst's event regions.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_segs(const DevCfg *__restrict__ cfgp, long long nrows, const rtfe_burst *__restrict__ bursts,
+                                               BurstScratch *__restrict__ scratch, const BurstCtl *__restrict__ ctl,
+                                               const WalkState *__restrict__ wstate, SegTab *__restrict__ segtab,
+                                               int *__restrict__ segburst, int *__restrict__ seg_status, long long max_segs) {
+   __shared__ int lds[32];
+   __shared__ int s_base;
+   const DevCfg &cfg = *cfgp;
+   const int nwalk = cfg.nparm * cfg.ntrks, S = cfg.seg_tiles;
+   const long long T = cfg.tile_rows;
+   if (threadIdx.x == 0) s_base = 0;
+   __syncthreads();
+   const int nb = scratch->nbursts;
+   for (int b0 = 0; b0 < nb; b0 += 1024) {
+      const int b = b0 + threadIdx.x;
+      int nseg = 0; SegTab st; st.first = 0; st.nseg = 0; st.t0 = 0; st.tend = 0;
+      if (b < nb && ctl[b].status == kBurstReady) {
+         long long tend = (ctl[b].stop + T - 1) / T;
+         const long long tmax = (nrows + T - 1) / T;
+         if (tend > tmax) tend = tmax;
+         st.t0 = ctl[b].next_tile; st.tend = (int)tend;
+         const long long ntl = tend - st.t0;
+         nseg = 1;
+         if (S > 0 && cfg.mode != RTFE_PE && ntl >= S + S / 2) {
+            int want = (int)((ntl + S - 1) / S);
+            for (int w2 = 0; w2 < nwalk && want > 1; ++w2) {
+               const Walker &w = wstate[(size_t)b * nwalk + w2].w;
+               if (!((w.peakcount >= 16 && w.v_avg_height_count == 0) || w.peakcount == 0) || !w.fast) want = 1;
+               const unsigned long long last_cap = (unsigned long long)((float)((ntl - (long long)(want - 1) * S) * T) * cfg.cap_frac) + 16;     // the last slot only needs room for its own tiles
+               if ((unsigned long long)w.nevents + (unsigned long long)(want - 1) * (unsigned)cfg.seg_evcap + last_cap > bursts[b].event_cap) want = 1; }
+            nseg = want; } }
+      int total;
+      const int off = block_excl_scan_1024(nseg, lds, &total);
+      const int base = s_base;
+      if (nseg > 0) {
+         if ((long long)base + off + nseg > max_segs) nseg = 0;      // (cannot happen: max_segs covers one segment per seg_tiles tiles + one per burst)
+         st.first = base + off; st.nseg = nseg;
+         for (int k = 0; k < nseg; ++k) { segburst[st.first + k] = b; seg_status[st.first + k] = 1; } }
+      if (b < nb) segtab[b] = st;
+      __syncthreads();
+      if (threadIdx.x == 0) s_base = base + total;
+      __syncthreads(); }
+   if (threadIdx.x == 0) { scratch->nsegs = s_base < max_segs ? s_base : (int)max_segs; scratch->queue_seg = 0; scratch->queue_stitch = 0; } }
+
+// two walker states are "the same state" if every field the continuation reads is bit-identical (the event index and
+// the accumulated flags are bookkeeping; the transition count only matters below 16, src/decode_nrzi.c:196-229)
+__device__ __forceinline__ unsigned int walk_state_diff(const WalkState &a, const WalkState &b) {      // 0 = the same state
+   const Walker &x = a.w, &y = b.w;
+   unsigned int d = 0;
+   if (x.next != y.next) d |= 1u;
+   if (x.blind_until != y.blind_until) d |= 2u;
+   if (__float_as_uint(x.agc_gain) != __float_as_uint(y.agc_gain)) d |= 4u;
+   if (__float_as_uint(x.v_avg_height) != __float_as_uint(y.v_avg_height) || __float_as_uint(x.v_avg_height_sum) != __float_as_uint(y.v_avg_height_sum)
+       || x.v_avg_height_count != y.v_avg_height_count || x.heightndx != y.heightndx) d |= 8u;
+   if (__float_as_uint(x.v_top) != __float_as_uint(y.v_top) || __float_as_uint(x.v_bot) != __float_as_uint(y.v_bot)
+       || __float_as_uint(x.v_lasttop) != __float_as_uint(y.v_lasttop) || __float_as_uint(x.v_lastbot) != __float_as_uint(y.v_lastbot)) d |= 16u;
+   if (__float_as_uint(x.rise) != __float_as_uint(y.rise) || __float_as_uint(x.reqmin) != __float_as_uint(y.reqmin) || x.thr_dirty != y.thr_dirty
+       || x.rise_lo != y.rise_lo || x.rise_hi != y.rise_hi || x.min_lo != y.min_lo || x.min_hi != y.min_hi) d |= 32u;
+   if (x.minv != y.minv || x.qtrig != y.qtrig || x.cpos != y.cpos || x.chain_pending != y.chain_pending) d |= 64u;
+   if (x.datablock != y.datablock || x.bit1_up != y.bit1_up || x.fast != y.fast
+       || !((x.peakcount >= 16 && y.peakcount >= 16) || x.peakcount == y.peakcount)) d |= 128u;
+   for (int i = 0; i < 10; ++i) if (__float_as_uint(a.heights[i]) != __float_as_uint(b.heights[i])) d |= 128u;
+   return d; }
+
+// ------------------------------------------------------------------------------------------------
+// k_stitch: one 64-lane workgroup per segmented burst.  Accepts the segments only if each one's state at its first own
+// tile equals its predecessor's final state (then, by induction from segment 0, every segment ran from the true
+// state); moves the events of segments 1.. down behind their predecessors' and publishes the burst.  Otherwise the
+// burst goes to the second k_decode pass with the state it had when it was cut.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_stitch(const DevCfg *__restrict__ cfgp, long long nrows, rtfe_burst *__restrict__ bursts,
+                                               BurstScratch *__restrict__ scratch, uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
+                                               BurstCtl *__restrict__ ctl, WalkState *__restrict__ wstate, const SegTab *__restrict__ segtab,
+                                               const WalkState *__restrict__ seg_start, const WalkState *__restrict__ seg_end,
+                                               const int *__restrict__ seg_status) {
+   __shared__ int s_burst, s_firstbad;
+   __shared__ unsigned int s_flags;
+   const DevCfg &cfg = *cfgp;
+   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
+   for (;;) {
+      if (threadIdx.x == 0) { s_burst = atomicAdd(&scratch->queue_stitch, 1); s_firstbad = 0x7fffffff; s_flags = 0; }
+      __syncthreads();
+      const int b = s_burst;
+      if (b >= scratch->nbursts) break;
+      const SegTab st = segtab[b];
+      if (ctl[b].status != kBurstReady || st.nseg <= 1) { __syncthreads(); continue; }
+      // ---- the first segment that did not finish, or whose start is not its predecessor's end ----
+      for (int i = threadIdx.x; i < st.nseg * nwalk; i += blockDim.x) {
+         const int sg = i / nwalk, w2 = i - sg * nwalk;
+         unsigned int d = seg_status[st.first + sg] != 0 ? 256u : 0u;
+         if (sg > 0) d |= walk_state_diff(seg_end[(size_t)(st.first + sg - 1) * nwalk + w2], seg_start[(size_t)(st.first + sg) * nwalk + w2]);
+         if (d) {
+            atomicMin(&s_firstbad, sg);
+            for (int k = 0; k < 8; ++k) if ((d >> k) & 1) atomicAdd(&scratch->why[k], 1ull);          // statistics (tools/gpu_segs.py)
+            if (d & 256u) atomicAdd(&scratch->dbg2[7], 1ull); } }
+      __syncthreads();
+      const int ngood = s_firstbad < st.nseg ? s_firstbad : st.nseg;  // segments 0 .. ngood-1 ran from the true state
+      if (ngood == 0) {                                               // (segment 0 itself gave up: the burst as it was cut)
+         if (threadIdx.x == 0) { ctl[b].status = kBurstNeedsFull; atomicAdd(&scratch->seg_failed, 1); }
+         __syncthreads();
+         continue; }
+      // ---- the events of segments 1 .. ngood-1 move down behind their predecessors' ----
+      const rtfe_burst B = bursts[b];
+      for (int w2 = 0; w2 < nwalk; ++w2) {
+         const unsigned int n0 = wstate[(size_t)b * nwalk + w2].w.nevents;
+         rtfe_event *reg = events + B.event_base + (size_t)w2 * B.event_cap;       // (w2 = parmset * ntrks + track)
+         unsigned int dst = seg_end[(size_t)st.first * nwalk + w2].w.nevents;
+         unsigned int fl = seg_end[(size_t)st.first * nwalk + w2].w.flags;
+         for (int sg = 1; sg < ngood; ++sg) {
+            const Walker &e = seg_end[(size_t)(st.first + sg) * nwalk + w2].w;
+            const unsigned int base = n0 + (unsigned)sg * (unsigned)cfg.seg_evcap;
+            const unsigned int cnt = e.nevents - base;
+            fl |= e.flags;
+            for (unsigned int k0 = 0; k0 < cnt; k0 += blockDim.x) {               // left to right, a row of lanes at a time: dst < base always
+               const unsigned int k = k0 + threadIdx.x;
+               rtfe_event ev;
+               if (k < cnt) ev = reg[base + k];
+               __syncthreads();
+               if (k < cnt) reg[dst + k] = ev;
+               __syncthreads(); }
+            dst += cnt; }
+         if (threadIdx.x == 0) {
+            if (ngood == st.nseg) { counts[(size_t)b * nwalk + w2] = dst < B.event_cap ? dst : B.event_cap; if (fl) s_flags |= fl; }
+            else {                                                    // the second k_decode pass continues behind the last good segment
+               const WalkState &src = seg_end[(size_t)(st.first + ngood - 1) * nwalk + w2];
+               WalkState &out = wstate[(size_t)b * nwalk + w2];          // (the fields the record walk never touches stay as they were)
+               const long long trust = out.w.trust_from;
+               load_walk_fields(out.w, src.w);
+               for (int i = 0; i < 10; ++i) out.heights[i] = src.heights[i];
+               out.w.nevents = dst; out.w.flags = fl; out.w.trust_from = trust; } } }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+         if (ngood == st.nseg) {
+            const long long stop = ctl[b].stop;
+            bursts[b].reset_sample = ctl[b].reset;
+            bursts[b].safe_last = (ctl[b].bflags & RTFE_F_UNSAFE) ? -1 : ctl[b].reset;
+            bursts[b].end_sample = stop < nrows ? stop : nrows;
+            bursts[b].flags = ctl[b].bflags | s_flags;
+            ctl[b].status = kBurstDone; }
+         else { ctl[b].next_tile = st.t0 + ngood * cfg.seg_tiles; ctl[b].status = kBurstNeedsFull; atomicAdd(&scratch->seg_failed, 1); } }
       __syncthreads(); } }
 
 __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows,

@@ -37,3 +37,23 @@ def test_emulated_rare_paths_of_the_record_walk(name, knobs, tmp_path, monkeypat
     msgs, stats = check_tape(fe, g["hdr"], g["rows"], att)
     assert not msgs, "\n".join(msgs[:12])
     assert stats["events"] > 0
+
+
+@pytest.mark.parametrize("knobs", [{"RTFE_SEG_TILES": "4", "RTFE_SEG_WARMUP": "1"},      # warm-up too short: joins fail, the tail goes to the second k_decode pass
+                                   {"RTFE_SEG_TILES": "4", "RTFE_SEG_WARMUP": "4"},
+                                   {"RTFE_SEG_TILES": "0"}])                             # unsegmented walk
+def test_emulated_segmented_record_walk(knobs, tmp_path, monkeypatch):
+    """The record walk of a long block runs as concurrent segments started from guessed states and is accepted only where
+    every segment's start state equals its predecessor's end state: whatever the segment size, the warm-up
+    and the outcome of the joins, the events are the oracle's."""
+    from readtape_amd import synth
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    tape = synth.nrzi_tape(seed=31, nblocks=2, minlen=500, maxlen=640, gap_samples=1500)
+    hdr = tape.spec.header()
+    att = oracle_attempts(hdr, tape.rows, [], str(tmp_path))
+    fe = emul_frontend(config_for(hdr, []))
+    msgs, stats = check_tape(fe, hdr, tape.rows, att)
+    print(knobs, stats)
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["events"] > 4000

@@ -48,6 +48,24 @@ def test_rare_paths_of_the_record_walk(name, knobs, tmp_path, gpu, monkeypatch):
     assert stats["events"] > 0
 
 
+@pytest.mark.parametrize("knobs", [{"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "1"}, {"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "3"},
+                                   {"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "8"}, {"RTFE_SEG_TILES": "16", "RTFE_SEG_WARMUP": "8", "RTFE_REC_CAP16": "14"},
+                                   {}, {"RTFE_SEG_TILES": "0"}])
+def test_segmented_record_walk(knobs, tmp_path, gpu, monkeypatch):
+    """Long blocks: the record walk runs as concurrent segments from guessed states, accepted only where each segment's
+    start state is bit for bit its predecessor's end state; the rest goes to the second k_decode pass.  Whatever the
+    segment size, the warm-up and the outcome of the joins, the events are the oracle's."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    tape = synth.nrzi_tape(seed=33, nblocks=10, minlen=1500, maxlen=4096, marks_every=4, gap_samples=4000)
+    hdr = tape.spec.header()
+    att = oracle_attempts(hdr, tape.rows, [], str(tmp_path))
+    fe = frontend.FrontEnd(config_for(hdr, []))
+    msgs, stats = check_tape(fe, hdr, tape.rows, att)
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["speculative"] == len(att) and stats["flags"] == 0
+
+
 @pytest.mark.parametrize("seed,nblocks,maxlen", [(21, 12, 600), (22, 30, 2000), (23, 6, 4096)])
 def test_fresh_nrzi_tapes(seed, nblocks, maxlen, tmp_path, gpu):
     tape = synth.nrzi_tape(seed=seed, nblocks=nblocks, minlen=16, maxlen=maxlen, marks_every=5, gap_samples=4000)
