@@ -371,7 +371,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
                             d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
                             (int)kWalkSegs, (const SegTab *)segtabp, (const int *)segburstp, segstartp, segendp, segstatp);
-         hipLaunchKernelGGL(k_stitch, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, d_counts, d_events, ctlp,
+         hipLaunchKernelGGL(k_stitch, dim3(h->num_cus * 4), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, d_counts, d_events, ctlp,
                             statep, (const SegTab *)segtabp, (const WalkState *)segstartp, (const WalkState *)segendp, (const int *)segstatp); }
       else
       hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,

@@ -2028,12 +2028,12 @@ __device__ __forceinline__ unsigned int walk_state_diff(const WalkState &a, cons
    return d; }
 
 // ------------------------------------------------------------------------------------------------
-// k_stitch: one 64-lane workgroup per segmented burst.  Accepts the segments only if each one's state at its first own
+// k_stitch: one 256-lane workgroup per segmented burst.  Accepts the segments only if each one's state at its first own
 // tile equals its predecessor's final state (then, by induction from segment 0, every segment ran from the true
 // state); moves the events of segments 1.. down behind their predecessors' and publishes the burst.  Otherwise the
 // burst goes to the second k_decode pass with the state it had when it was cut.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_stitch(const DevCfg *__restrict__ cfgp, long long nrows, rtfe_burst *__restrict__ bursts,
+__global__ void __launch_bounds__(256) k_stitch(const DevCfg *__restrict__ cfgp, long long nrows, rtfe_burst *__restrict__ bursts,
                                                BurstScratch *__restrict__ scratch, uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                                BurstCtl *__restrict__ ctl, WalkState *__restrict__ wstate, const SegTab *__restrict__ segtab,
                                                const WalkState *__restrict__ seg_start, const WalkState *__restrict__ seg_end,

@@ -25,11 +25,12 @@ def same(a, b):
 
 nblocks = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 maxlen = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-tape = synth.nrzi_tape(seed=5, nblocks=nblocks, minlen=512, maxlen=maxlen, marks_every=16, gap_samples=6000)
+minlen = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+tape = synth.nrzi_tape(seed=5, nblocks=nblocks, minlen=minlen, maxlen=maxlen, marks_every=16, gap_samples=6000)
 hdr = tape.spec.header()
 rows = torch.from_numpy(tape.rows).cuda()
 ref, ms0, st0 = scan(rows, hdr, 0)
-for seg, warm in ((8, 1), (8, 3), (48, 8), (64, 8), (96, 8)):
+for seg, warm in ((48, 8),):
     os.environ['RTFE_SEG_WARMUP'] = str(warm)
     r, ms, st = scan(rows, hdr, seg)
     ok = r.nbursts == ref.nbursts and (r.counts == ref.counts).all() and (r.bursts["flags"] == ref.bursts["flags"]).all()
