@@ -311,7 +311,10 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
    // beat wide ones; k_decode holds ~250 VGPRs => 2 waves/SIMD => 8 waves per CU
    const int nwalk = h->dev.nparm * h->dev.ntrks;
-   const int threads = nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256);
+   int threads = nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256);
+   if (h->dev.find_zeros && !h->dev.differentiate) {                 // -zeros: a lane per (track, 64-row sub-segment) of the tile
+      const int lanes = h->dev.ntrks * (h->dev.tile_rows / 64);
+      while (threads < lanes && threads < 256) threads *= 2; }
    int per_cu = (160 * 1024) / (h->lds_bytes + 1024);
    const int wave_lim = 8 / (threads / 64);
    if (per_cu > wave_lim) per_cu = wave_lim;

@@ -717,6 +717,41 @@ __device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long
 // CONFIRMED crossing; the slope gate of :629/:643 needs the decoder's clock average and is applied by the host
 // replay, which gets the crossing row as (confirmation row - delay).  Event: sample = confirmation row,
 // v_peak = the new extreme, agc_gain bits = delay in rows, left_distance = min(delay, 255).
+// the detector's state between rows, and one row of it
+struct ZcState { int prev, top, bot; bool up, dn; long long ttop, tbot; };
+__device__ __forceinline__ void zc_load(ZcState &z, const Walker &w) {
+   z.prev = w.z_prev; z.top = w.z_top; z.bot = w.z_bot; z.up = w.z_up_pending; z.dn = w.z_dn_pending; z.ttop = w.z_ttop_row; z.tbot = w.z_tbot_row; }
+__device__ __forceinline__ void zc_store(Walker &w, const ZcState &z) {
+   w.z_prev = z.prev; w.z_top = z.top; w.z_bot = z.bot; w.z_up_pending = z.up; w.z_dn_pending = z.dn; w.z_ttop_row = z.ttop; w.z_tbot_row = z.tbot; }
+// returns true when row n (code v) confirms a crossing: `up` its direction, `cross` the row of the sign change
+__device__ __forceinline__ bool zc_row(ZcState &z, int v, long long n, int P, bool &up, long long &cross) {
+   bool emit = false;
+   if (v > 0) {
+      z.dn = false;
+      if (z.top < v) {
+         z.top = v;
+         if (z.up && z.top >= P) { z.up = false; z.bot = 0; emit = true; up = true; cross = z.ttop; } }
+      if (z.prev < 0 && z.bot <= -P) { z.ttop = n; z.up = true; } }
+   else if (v < 0) {
+      z.up = false;
+      if (z.bot > v) {
+         z.bot = v;
+         if (z.dn && z.bot <= -P) { z.dn = false; z.top = 0; emit = true; up = false; cross = z.tbot; } }
+      if (z.prev > 0 && z.top >= P) { z.tbot = n; z.dn = true; } }
+   z.prev = v;
+   return emit; }
+__device__ __forceinline__ void zc_event(const Ctx &cx, int trk, unsigned int idx, long long n, int v, bool up, long long cross) {
+   const unsigned int delay = (unsigned int)(n - cross);
+   rtfe_event e;
+   e.sample = (uint32_t)(n - cx.tile.reset);
+   e.v_peak = volt(v, cx.cfg->maxvolts);
+   e.agc_gain = __uint_as_float(delay);
+   e.trk = (uint8_t)trk;
+   e.flags = (uint8_t)(up ? 0 : 1);
+   e.left_distance = (uint8_t)(delay < 255 ? delay : 255);
+   e.parmset = 0;
+   cx.events[(size_t)trk * cx.cap + idx] = e; }
+
 __device__ __forceinline__ void walk_zeros(Walker &w, Ctx &cx, int trk, long long limit) {
    const DevCfg *cfg = cx.cfg;
    const Tile &tl = cx.tile;
@@ -725,37 +760,97 @@ __device__ __forceinline__ void walk_zeros(Walker &w, Ctx &cx, int trk, long lon
    const int P = cfg->zc_peak_i;
    long long n = w.next;
    if (n <= w.start) n = w.start + 1;                              // row `start` only seeds the track (src/decoder.c:855-861)
+   ZcState z; zc_load(z, w);
    for (; n < limit; ++n) {
       const int v = tl.y(trk, n);
-      bool emit = false, up = false; long long cross = 0;
-      if (v > 0) {
-         w.z_dn_pending = false;
-         if (w.z_top < v) {
-            w.z_top = v;
-            if (w.z_up_pending && w.z_top >= P) { w.z_up_pending = false; w.z_bot = 0; emit = true; up = true; cross = w.z_ttop_row; } }
-         if (w.z_prev < 0 && w.z_bot <= -P) { w.z_ttop_row = n; w.z_up_pending = true; } }
-      else if (v < 0) {
-         w.z_up_pending = false;
-         if (w.z_bot > v) {
-            w.z_bot = v;
-            if (w.z_dn_pending && w.z_bot <= -P) { w.z_dn_pending = false; w.z_top = 0; emit = true; up = false; cross = w.z_tbot_row; } }
-         if (w.z_prev > 0 && w.z_top >= P) { w.z_tbot_row = n; w.z_dn_pending = true; } }
-      w.z_prev = v;
-      if (emit) {
-         if (w.nevents < cx.cap) {
-            rtfe_event e;
-            const unsigned int delay = (unsigned int)(n - cross);
-            e.sample = (uint32_t)(n - tl.reset);
-            e.v_peak = volt(v, cfg->maxvolts);
-            e.agc_gain = __uint_as_float(delay);
-            e.trk = (uint8_t)trk;
-            e.flags = (uint8_t)(up ? 0 : 1);
-            e.left_distance = (uint8_t)(delay < 255 ? delay : 255);
-            e.parmset = 0;
-            cx.events[(size_t)trk * cx.cap + w.nevents] = e; }
+      bool up = false; long long cross = 0;
+      if (zc_row(z, v, n, P, up, cross)) {
+         if (w.nevents < cx.cap) zc_event(cx, trk, w.nevents, n, v, up, cross);
          else w.flags |= RTFE_F_EVENT_OVERFLOW;
          ++w.nevents; } }
+   zc_store(w, z);
    w.next = n; }
+
+// -zeros, one whole tile, all tracks: the 512 rows of a track are cut into sub-segments of kZcSub rows that run
+// concurrently, one lane each.  Sub-segment 0 continues from the walker's true state; the others start kZcWarm rows early
+// from a fresh state (what a restart would be) and note the state they reach at their first own row.  The detector
+// forgets: after a confirmed crossing in each direction its state is a function of the samples since.  A track's result
+// stands only if every sub-segment's noted state equals its predecessor's final state in every field; otherwise that
+// track is walked again sequentially (walk_zeros) from the untouched walker.  ok[trk] = 1 where the result stands.
+constexpr int kZcSub = 64, kZcWarm = 64, kZcMaxEv = 8;
+struct ZcLane { ZcState start, end; int count; unsigned int ev[kZcMaxEv][2]; };      // ev: n_rel | code << 16 , delay | up << 31
+__device__ __forceinline__ bool zc_same(const ZcState &a, const ZcState &b) {
+   return a.prev == b.prev && a.top == b.top && a.bot == b.bot && a.up == b.up && a.dn == b.dn
+       && (!a.up || a.ttop == b.ttop) && (!a.dn || a.tbot == b.tbot); }       // (the crossing rows are only read while pending)
+__device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, ZcLane *lanes, int *ok, long long stop) {
+   const DevCfg *cfg = cx.cfg;
+   const Tile &tl = cx.tile;
+   const int ntrks = cfg->ntrks, nsub = tl.nrows / kZcSub;
+   const int P = cfg->zc_peak_i;
+   const int L = threadIdx.x, trk = L / nsub, j = L - trk * nsub;
+   const bool mine = L < ntrks * nsub;
+   if (L < ntrks) {                                                  // a whole tile in the regular regime?
+      const Walker &w = walkers[L];
+      ok[L] = (tl.nrows % kZcSub == 0 && nsub >= 2 && stop >= tl.row0 + tl.nrows && w.next == tl.row0 && w.start < tl.row0
+               && tl.row0 - kZcWarm - 1 - tl.reset >= cfg->skew[L]          // every row read is behind the deskew FIFO's start-up
+               && w.nevents + (unsigned)(nsub * kZcMaxEv) < cx.cap) ? 1 : 0; }
+   __syncthreads();
+   if (mine && ok[trk]) {
+      ZcLane &me = lanes[L];
+      ZcState z;
+      const Col yb = tile_col(tl, trk, cfg->skew[trk]);              // y(n) = yb[n - row0] in the regular regime
+      if (j == 0) zc_load(z, walkers[trk]);
+      else {
+         const int q0 = j * kZcSub - kZcWarm;
+         z.prev = yb[q0 - 1]; z.top = 0; z.bot = 0; z.up = false; z.dn = false; z.ttop = 0; z.tbot = 0;
+         #pragma nounroll
+         for (int q = q0; q < j * kZcSub; q += 8) {                   // (eight samples in flight, then the eight dependent steps)
+            int v8[8];
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) v8[k] = yb[q + k];
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) { bool up; long long cross; (void)zc_row(z, v8[k], tl.row0 + q + k, P, up, cross); } } }
+      me.start = z;
+      int cnt = 0;
+      #pragma nounroll
+      for (int q = j * kZcSub; q < (j + 1) * kZcSub; q += 8) {
+         int v8[8];
+         #pragma unroll
+         for (int k = 0; k < 8; ++k) v8[k] = yb[q + k];
+         #pragma unroll
+         for (int k = 0; k < 8; ++k) {
+            const long long n = tl.row0 + q + k;
+            const int v = v8[k];
+            bool up = false; long long cross = 0;
+            if (zc_row(z, v, n, P, up, cross)) {
+               if (cnt < kZcMaxEv && (unsigned long long)(n - cross) < 0x80000000ull) {
+                  me.ev[cnt][0] = (unsigned)(q + k) | ((unsigned)(v & 0xffff) << 16); me.ev[cnt][1] = (unsigned)(n - cross) | (up ? 0x80000000u : 0u); ++cnt; }
+               else cnt = kZcMaxEv + 1; } } }
+      me.end = z; me.count = cnt; }
+   __syncthreads();
+   if (mine && ok[trk]) {                                            // does every sub-segment start where its predecessor ended?
+      const ZcLane &me = lanes[L];
+      bool bad = me.count > kZcMaxEv;
+      if (j > 0 && !zc_same(me.start, lanes[L - 1].end)) bad = true;
+      if (bad) atomicAnd(&ok[trk], 0); }
+   __syncthreads();
+   if (mine && ok[trk]) {                                            // events in row order; the walker moves to the tile's end
+      const ZcLane &me = lanes[L];
+      unsigned int idx = walkers[trk].nevents;
+      for (int k = 0; k < j; ++k) idx += (unsigned)lanes[L - j + k].count;
+      for (int k = 0; k < me.count && k < kZcMaxEv; ++k) {
+         const long long n = tl.row0 + (long long)(me.ev[k][0] & 0xffff);
+         const int v = (int)(short)(me.ev[k][0] >> 16);
+         zc_event(cx, trk, idx + k, n, v, (me.ev[k][1] >> 31) != 0, n - (long long)(me.ev[k][1] & 0x7fffffffu)); } }
+   __syncthreads();
+   if (L < ntrks && ok[L]) {
+      Walker &w = walkers[L];
+      unsigned int total = 0;
+      for (int k = 0; k < nsub; ++k) total += (unsigned)lanes[L * nsub + k].count;
+      zc_store(w, lanes[L * nsub + nsub - 1].end);
+      w.nevents += total; w.next = tl.row0 + tl.nrows; }
+   __syncthreads(); }
+
 
 // differentiate() (src/readtape.c:1383-1394) for every element of the tile, all lanes: delta against the previous row of
 // the same head (0 at the burst's restart row: v_last_raw is zeroed by init_trackstate, src/decoder.c:437), the
@@ -2307,14 +2402,19 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          __syncthreads();
          if (cfg.debug) c1 = clock64();
          if (diffpeak) differentiate_tile(&cfg, cx.tile);         // (no candidate screen on the differentiated signal)
-         else run_screens(&cfg, cx.tile, !cfg.find_zeros);
+         else if (!cfg.find_zeros) run_screens(&cfg, cx.tile, true);       // (nor for the zero-crossing detectors)
          __syncthreads();
          if (cfg.debug) c2 = clock64();
          long long c2c = 0;
          cx.nrec = 0;
+         const bool zc_par = cfg.find_zeros && !cfg.differentiate && (parmset_mask & 1u)
+                             && (size_t)ntrks * (cfg.tile_rows / kZcSub) * sizeof(ZcLane) <= (size_t)nwalk * cfg.rec_cap * sizeof(Rec)
+                             && ntrks * (cfg.tile_rows / kZcSub) <= (int)blockDim.x;
+         if (zc_par) zeros_tile_parallel(cx, walkers, reinterpret_cast<ZcLane *>(recs_all), s_off, stop);     // (s_off: per-track verdicts)
+         if (zc_par && cfg.debug && (int)threadIdx.x < ntrks) { atomicAdd(&scratch->dbg2[4], 1ull); if (s_off[threadIdx.x]) atomicAdd(&scratch->dbg2[5], 1ull); }
          if (active) {
             Walker w = walkers[my_w];
-            if (cfg.find_zeros) { if (pidx == 0) { if (cfg.differentiate) walk_diffzeros(w, cx, trk, stop); else walk_zeros(w, cx, trk, stop); } }
+            if (cfg.find_zeros) { if (pidx == 0 && !(zc_par && s_off[trk])) { if (cfg.differentiate) walk_diffzeros(w, cx, trk, stop); else walk_zeros(w, cx, trk, stop); } }
             else if (diffpeak) walk_diffpeak(w, cx, pidx, trk, stop);
             else walk(w, cx, pidx, trk, stop);
             walkers[my_w] = w; }

@@ -100,6 +100,7 @@ inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_S
 inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline int atomicAnd(int *p, int v) { return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicMin(int *p, int v) { int old = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return old; }
 inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) {
    unsigned long long old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
