@@ -1382,6 +1382,10 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
 
 // LDS carve of k_screen / k_decode.  ONE definition, used by the kernels and by the host when it sizes the dynamic
 // LDS allocation (rtfe_api.hip): an under-sized allocation does not fault on the GPU, out-of-range LDS reads return 0.
+// row strides of the screen's bitmaps / left_distance maps: consecutive tracks' rows start an odd number of 8-byte words
+// apart (mod the 32 LDS banks), so that the per-track 8-byte stores of one strip's lanes do not pile up on two banks
+__host__ __device__ inline unsigned lds_bstride(int tile_rows) { unsigned v = (unsigned)(tile_rows + kScreenHalo) / 8 + 8; while ((v / 4) % 32 != 22) v += 8; return v; }
+__host__ __device__ inline unsigned lds_ldstride(int tile_rows) { unsigned v = (unsigned)(tile_rows + kScreenHalo); while ((v / 4) % 32 != 18) v += 8; return v; }
 struct LdsLayout {
    unsigned bits, ldpos, heights, recs, nrec, runs, runcnt, runtab, act, walkers, walkers_next, heights_bak, fdiff, total; };
 __host__ __device__ inline unsigned lds_runtab_cap(const DevCfg &c) {        // run descriptors of one tile (k_screen)
@@ -1393,8 +1397,8 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    const unsigned ntrks = (unsigned)c.ntrks, nst = (unsigned)c.nscreens * ntrks, nwalk = (unsigned)c.nparm * ntrks;
    const unsigned T = (unsigned)c.tile_rows;
    unsigned off = lds_align16(ntrks * (unsigned)c.ldw * 2u + 16u);          // (ldw rows of ntrks samples, + one vector of slack)
-   L.bits = off;      off = lds_align16(off + nst * 5u * ((T + kScreenHalo) / 8 + 8));
-   L.ldpos = off;     off = lds_align16(off + nst * 2u * (T + kScreenHalo));
+   L.bits = off;      off = lds_align16(off + nst * 5u * lds_bstride((int)T));
+   L.ldpos = off;     off = lds_align16(off + nst * 2u * lds_ldstride((int)T));
    // k_decode: the candidate records of a tile share the space of the sample tile (a tile is decided either from
    // its records or from its samples, never both)
    L.runs = 0;
@@ -1457,8 +1461,8 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
    tl.x = reinterpret_cast<int16_t *>(smem);
    tl.ldw = cfg.ldw; tl.halo = cfg.halo_rows; tl.colof = cfg.trk_to_head;
    tl.ntrks = ntrks; tl.skew = cfg.skew; tl.reset = -(1ll << 40);
-   tl.bits = smem + L.bits; tl.bstride = (cfg.tile_rows + kScreenHalo) / 8 + 8;
-   tl.ldpos = smem + L.ldpos; tl.ldstride = cfg.tile_rows + kScreenHalo;
+   tl.bits = smem + L.bits; tl.bstride = (int)lds_bstride(cfg.tile_rows);
+   tl.ldpos = smem + L.ldpos; tl.ldstride = (int)lds_ldstride(cfg.tile_rows);
    unsigned int *stripcnt = reinterpret_cast<unsigned int *>(smem + L.runcnt);         // [nst][tile_rows / 8] runs | margin units << 16 per strip
    u64 *runtab = reinterpret_cast<u64 *>(smem + L.runtab);           // the tile's run descriptors
    const int tabcap = (int)lds_runtab_cap(cfg);
@@ -2239,8 +2243,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    const bool diffpeak = cfg.differentiate && !cfg.find_zeros;     // -differentiate without -zeros: literal float detector
    cx.tile.bits = smem + L.bits;
    cx.tile.fd = reinterpret_cast<float *>(smem + L.fdiff);
-   cx.tile.bstride = (cfg.tile_rows + kScreenHalo) / 8 + 8;
-   cx.tile.ldpos = smem + L.ldpos; cx.tile.ldstride = cfg.tile_rows + kScreenHalo;
+   cx.tile.bstride = (int)lds_bstride(cfg.tile_rows);
+   cx.tile.ldpos = smem + L.ldpos; cx.tile.ldstride = (int)lds_ldstride(cfg.tile_rows);
    float *heights_all = reinterpret_cast<float *>(smem + L.heights);
    // walker w of this workgroup -> thread: spread over the 4 waves so every SIMD issues for some walkers
    const int nwalk = cfg.nparm * ntrks;
