@@ -1,20 +1,25 @@
 // rtfe_kernels.hip — the MI355X (gfx950 / CDNA4) analog front end.
 //
-// Five kernels, six launches per scan, all integer / fp32 streaming work bound by HBM and LDS, no MFMA:
+// Seven kernels, all integer / fp32 streaming work bound by HBM and LDS, no MFMA:
 //
 //   k_quiet    one pass over the interleaved int16 TBIN payload: 1 bit per KiB of payload that says
 //              "every sample of every track is inside the quiet band".              [HBM-bound]
-//   k_bursts   turns runs of quiet bits into inter-block zones -> the burst table (one workgroup).
+//   k_bursts   turns runs of quiet bits into inter-block zones -> the burst table; marks the tiles deep inside a gap
+//              that nothing will ever walk (one workgroup).
 //   k_screen   dense and stateless, one workgroup per 512-row tile: flat copy of the rows into LDS, a data-
 //              parallel sliding-window max/min "candidate screen", the reference's stale window minimum,
 //              candidate RUNS (everything the sequential detector reads, as int16 codes) -> HBM.
 //   k_decode   (a) burst heads: restart row inside the quiet zone, the literal start-up path, hand-over to
-//              k_walk; (c) whatever k_walk gives back; and the whole job for -zeros and for exact re-scans:
-//              one lane per (parameter set, track) replays the reference's sequential detector EXACTLY
+//              k_walk; (c) whatever k_walk gives back; and the whole job for PE / GCR, -zeros, -differentiate and exact
+//              re-scans: one lane per (parameter set, track) replays the reference's sequential detector EXACTLY
 //              (blind countdown, stale-minimum rescans, AGC schedule, half-sample refinement) on samples in LDS.
-//   k_walk     (b) the sequential pass in the common case: one small workgroup per burst walks the candidate runs
-//              tile after tile - decisions for all runs in parallel against wide threshold bands, the countdown
+//              -zeros: a lane per (track, 64-row sub-segment) with a verified warm-up instead.
+//   k_walk     (b) the sequential pass in the common case: one small workgroup per burst SEGMENT walks the candidate
+//              runs tile after tile - decisions for all runs in parallel against wide threshold bands, the countdown
 //              chain and the three-flop AGC recurrence per walker, events by all lanes.
+//   k_segs     cuts long bursts into 48-tile segments that k_walk walks concurrently from guessed states,
+//   k_stitch   accepts them where each segment's start state equals its predecessor's end state bit for bit, and
+//              compacts their event slots.
 //
 // What is reproduced, and where it lives in the reference (LenShustek/readtape V3.18):
 //   sample convert            src/readtape.c:1418-1421      volt()
