@@ -97,7 +97,10 @@ enum {
    RTFE_F_EVENT_OVERFLOW   = 4,    /* a track's event region filled up; events were dropped          */
    RTFE_F_SCREEN_UNDERFLOW = 8,    /* AGC threshold fell below the candidate screen: rescan exactly with screen off */
    RTFE_F_TRUNCATED        = 32,   /* time shard: the halo ended before this burst's successor zone did          */
-   RTFE_F_DETECTOR_FATAL   = 16    /* the reference would have hit its fatal "peak at window edge" assert (src/decoder.c:709-710,748) */
+   RTFE_F_DETECTOR_FATAL   = 16,   /* the reference would have hit its fatal "peak at window edge" assert (src/decoder.c:709-710,748) */
+   RTFE_F_STATE_AT_END     = 64    /* -zeros: at end_sample a track still holds an excursion beyond the 0.2 V threshold or a pending
+                                    * crossing - history a restart would not have, even if no event was emitted: an attempt that
+                                    * reaches the end of this burst must not continue into the next one */
 };
 
 typedef struct rtfe_burst {

@@ -231,7 +231,8 @@ restart:
       if (!using_exact && !d->interblock_counter && next >= src.end && src.end < nrows) {
          /* still fresh: the next burst's fresh state is the same state.  During density detection the detector never
           * leaves its fresh AGC / baseline state (no decoder runs), so every proven restart is the same state */
-         if ((events_seen == 0 || d->doing_density_detection) && burst_usable(rp, b + 1)) {
+         if ((events_seen == 0 || d->doing_density_detection) && burst_usable(rp, b + 1)
+             && !(rp->find_zeros && (rp->bursts[b].flags & RTFE_F_STATE_AT_END))) {     /* (-zeros: an excursion without an event is history too) */
             ++b; evsrc_from_burst(&src, rp, b, parmset); evsrc_skip_before(&src, ntrks, row); ++rp->chained;
             continue; }
          if (restarted) { d->results[parmset].blktype = RT_BS_ABORTED; break; }

@@ -146,6 +146,8 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    d.gap_chunks = (int)(((long long)gap * c->ntrks * 2 + 1023) / 1024) + 1;
    d.seg_tiles = 48;                                                  // the record walk of a long block runs as concurrent segments of 48 tiles
    d.seg_warm = kSegWarmup;
+   d.zc_parallel = 1;
+   if (const char *e = getenv("RTFE_ZC_PARALLEL")) d.zc_parallel = atoi(e) != 0;
    if (const char *e = getenv("RTFE_SEG_WARMUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) d.seg_warm = v; }
    if (const char *e = getenv("RTFE_SEG_TILES")) { const int v = atoi(e); d.seg_tiles = v <= 0 ? 0 : v; }
    if (d.seg_tiles > 0 && d.seg_tiles < d.seg_warm) d.seg_tiles = d.seg_warm;

@@ -2416,7 +2416,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          if (cfg.debug) c2 = clock64();
          long long c2c = 0;
          cx.nrec = 0;
-         const bool zc_par = cfg.find_zeros && !cfg.differentiate && (parmset_mask & 1u)
+         const bool zc_par = cfg.find_zeros && !cfg.differentiate && cfg.zc_parallel && (parmset_mask & 1u)
                              && (size_t)ntrks * (cfg.tile_rows / kZcSub) * sizeof(ZcLane) <= (size_t)nwalk * cfg.rec_cap * sizeof(Rec)
                              && ntrks * (cfg.tile_rows / kZcSub) <= (int)blockDim.x;
          if (zc_par) zeros_tile_parallel(cx, walkers, reinterpret_cast<ZcLane *>(recs_all), s_off, stop);     // (s_off: per-track verdicts)
@@ -2444,7 +2444,13 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       // ---- publish ----
       if (mode != kDecodeAll && threadIdx.x == 0) ctl[b].status = kBurstDone;
       if (is_walker) {
-         const unsigned int ne = walkers[my_w].nevents, wf = walkers[my_w].flags;
+         const unsigned int ne = walkers[my_w].nevents;
+         unsigned int wf = walkers[my_w].flags;
+         if (cfg.find_zeros && pidx == 0 && active) {                  // history a restart would not have
+            const Walker &wz = walkers[my_w];
+            const bool dirty = cfg.differentiate ? (wz.z_up_pending || wz.z_dn_pending)
+                                                 : (wz.z_up_pending || wz.z_dn_pending || wz.z_top >= cfg.zc_peak_i || wz.z_bot <= -cfg.zc_peak_i);
+            if (dirty) wf |= RTFE_F_STATE_AT_END; }
          counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = active ? (ne < cx.cap ? ne : cx.cap) : 0;
          if (wf) atomicOr(&s_flags, wf); }
       __syncthreads();

@@ -20,7 +20,7 @@ from . import tbin
 MAXTRKS, MAXPARMSETS = 19, 15
 PE, NRZI, GCR, WW = 1, 2, 4, 8
 
-F_EXACT_START, F_UNSAFE, F_EVENT_OVERFLOW, F_SCREEN_UNDERFLOW, F_DETECTOR_FATAL, F_TRUNCATED = 1, 2, 4, 8, 16, 32
+F_EXACT_START, F_UNSAFE, F_EVENT_OVERFLOW, F_SCREEN_UNDERFLOW, F_DETECTOR_FATAL, F_TRUNCATED, F_STATE_AT_END = 1, 2, 4, 8, 16, 32, 64
 
 EVENT_DTYPE = np.dtype([("sample", "<u4"), ("v_peak", "<f4"), ("agc_gain", "<f4"), ("trk", "u1"),
                         ("flags", "u1"), ("left_distance", "u1"), ("parmset", "u1")])

@@ -53,3 +53,27 @@ def test_short_burst_tails_do_not_change_the_tap(tmp_path, monkeypatch):
     tap, stats = decode_case(g, tmp_path, emul_frontend)
     assert tap == g["tap"]
     assert not stats["event_diffs"]
+
+
+def _noisy_pe_zeros_case(tmp_path, fe_factory):
+    """-zeros on a PE tape whose gap noise (50 mV rms) now and then crosses the 0.2 V threshold: such an excursion is
+    detector history without any event, so an attempt must not be continued into the next device burst as if it were
+    fresh (RTFE_F_STATE_AT_END).  Found by tools/gpu_stress.py."""
+    import subprocess
+    import refdump
+    from parity_util import ORACLE, build_oracle
+    from readtape_amd import synth, tbin
+    build_oracle()
+    tape = synth.pe_tape(seed=833875458, nblocks=2, minlen=30, maxlen=200, gap_samples=3000, amplitude=2.5, noise_mv=50.0, jitter=0.08)
+    hdr = tape.spec.header()
+    wd = str(tmp_path)
+    tbin.write_tbin(os.path.join(wd, "t.tbin"), hdr, tape.rows)
+    subprocess.run([ORACLE, "-v", f"-out={wd}/o", f"-evt={wd}/o.evt", "-zeros", os.path.join(wd, "t.tbin")], check=True)
+    st, res = pipeline.decode_tape(hdr, tape.rows, os.path.join(wd, "g.tap"), evt_path=os.path.join(wd, "g.evt"), find_zeros=True, fe_factory=fe_factory)
+    assert not refdump.compare(refdump.load(os.path.join(wd, "g.evt")), refdump.load(os.path.join(wd, "o.evt")))
+    assert open(os.path.join(wd, "g.tap"), "rb").read() == open(os.path.join(wd, "o.tap"), "rb").read()
+    assert any(int(f) & 64 for f in res.bursts["flags"])
+
+
+def test_zeros_excursions_without_events_are_history(tmp_path):
+    _noisy_pe_zeros_case(tmp_path, emul_frontend)

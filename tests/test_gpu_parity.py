@@ -186,6 +186,11 @@ def test_short_burst_tails_do_not_change_the_tap(name, tmp_path, gpu, monkeypatc
     assert tap == g["tap"] and not stats["event_diffs"]
 
 
+def test_zeros_excursions_without_events_are_history(tmp_path, gpu):
+    from test_emul_replay import _noisy_pe_zeros_case
+    _noisy_pe_zeros_case(tmp_path, None)
+
+
 def test_deskew_calibration_on_a_growing_prefix(tmp_path, gpu):
     """-deskew: the pre-pass scans a prefix of the tape and grows it until the reference's stopping rule is met inside
     it; whatever the first prefix size, delays and .tap are the reference's."""

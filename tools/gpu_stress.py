@@ -6,7 +6,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from parity_util import check_tape, config_for, oracle_attempts
-from readtape_amd import frontend, synth
+from readtape_amd import frontend, synth, pipeline, tbin
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import refdump, subprocess
+from parity_util import ORACLE, build_oracle
+build_oracle()
+
+def e2e_check(hdr, rows, opts, wd):
+    """-zeros: the device emits every confirmed crossing and the host replay applies the slope gate, so the comparison is
+    end to end: .tap bytes and the stream of transitions the decoders were handed, against the oracle's."""
+    tbin.write_tbin(os.path.join(wd, "t.tbin"), hdr, rows)
+    p = subprocess.run([ORACLE, "-v", f"-out={wd}/o", f"-evt={wd}/o.evt"] + opts + [os.path.join(wd, "t.tbin")], capture_output=True, text=True)
+    skew = next(([int(x) for x in a[6:].split(",")] for a in opts if a.startswith("-skew=")), None)
+    st, _ = pipeline.decode_tape(hdr, rows, os.path.join(wd, "g.tap"), log_path=os.path.join(wd, "g.log"), evt_path=os.path.join(wd, "g.evt"),
+                                 opts=pipeline.DecodeOptions(multiple_tries="-m" in opts), skew=skew, invert="-invert" in opts, find_zeros=True)
+    msgs = []
+    a, b = refdump.load(os.path.join(wd, "g.evt")), refdump.load(os.path.join(wd, "o.evt"))
+    if p.returncode == 0:
+        if open(os.path.join(wd, "g.tap"), "rb").read() != open(os.path.join(wd, "o.tap"), "rb").read(): msgs.append(".tap differs")
+    else:
+        n = min(a.size, b.size); a, b = a[:n], b[:n]
+    msgs += refdump.compare(a, b)
+    return msgs, {"events": int(st["events_delivered"]), "speculative": None, "flags": None, "exact_scans": int(st["exact_scans"])}
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ntapes = int(sys.argv[2]) if len(sys.argv) > 2 else 16
@@ -27,22 +48,29 @@ for i in range(ntapes):
         if rng.random() < 0.3: opts.append("-m")
         if rng.random() < 0.2: opts.append("-invert")
         if rng.random() < 0.25 and ntrks == 9: opts.append("-skew=" + ",".join(str(int(x)) for x in rng.integers(0, 6, size=9)))
+        if rng.random() < 0.15 and "-m" not in opts: opts.append("-zeros")
     elif kind == "pe":
         tape = synth.pe_tape(seed=seed, nblocks=int(rng.integers(2, 5)), minlen=30, maxlen=int(rng.choice([200, 900])), gap_samples=3000, **kw)
         if rng.random() < 0.3: opts.append("-m")
+        elif rng.random() < 0.3: opts.append("-zeros")
     else:
         kw["amplitude"] = max(amp, 1.0)
         tape = synth.gcr_tape(seed=seed, nblocks=int(rng.integers(2, 4)), minlen=40, maxlen=int(rng.choice([200, 900])), gap_samples=4000, **kw)
         if rng.random() < 0.3: opts.append("-m")
     hdr = tape.spec.header()
+    # the segmented record walk and its join failures: random segment size / warm-up
+    seg, warm = int(rng.choice([0, 8, 16, 48])), int(rng.choice([1, 3, 8]))
+    os.environ["RTFE_SEG_TILES"] = str(seg); os.environ["RTFE_SEG_WARMUP"] = str(warm)
     with tempfile.TemporaryDirectory() as wd:
-        att = oracle_attempts(hdr, tape.rows, opts, wd)
+        att = oracle_attempts(hdr, tape.rows, opts, wd) if "-zeros" not in opts else []
         for rec in ("default", "1"):
             if rec == "1": os.environ["RTFE_RECORD_PATH"] = "1"
             else: os.environ.pop("RTFE_RECORD_PATH", None)
-            fe = frontend.FrontEnd(config_for(hdr, opts))
-            msgs, stats = check_tape(fe, hdr, tape.rows, att)
-            tag = f"{i:3d} {kind} seed {seed} amp {amp} noise {noise} jit {jit} opts {opts} record_path {rec}: attempts {len(att)} events {stats['events']} speculative {stats.get('speculative')} flags {stats.get('flags')}"
+            if "-zeros" in opts: msgs, stats = e2e_check(hdr, tape.rows, opts, wd)
+            else:
+                fe = frontend.FrontEnd(config_for(hdr, opts))
+                msgs, stats = check_tape(fe, hdr, tape.rows, att)
+            tag = f"{i:3d} {kind} seed {seed} amp {amp} noise {noise} jit {jit} opts {opts} seg {seg}/{warm} record_path {rec}: attempts {len(att)} events {stats['events']} speculative {stats.get('speculative')} flags {stats.get('flags')}"
             print(("FAIL " if msgs else "ok   ") + tag, flush=True)
             if msgs:
                 print("\n".join(msgs[:6]))
