@@ -9,6 +9,7 @@
 
 #define PKWW_PEAKHEIGHT 4.0f      /* src/decoder.h:133 */
 #define AGC_MAX_VALUE   2.0f      /* src/decoder.h:153 */
+#define RT_DATA_GUARD   64
 
 struct rt_dec *rt_dec_new(const struct rt_options *opt, float sample_deltat, int64_t sample_deltat_ns) {
    struct rt_dec *d = (struct rt_dec *)calloc(1, sizeof *d);
@@ -16,16 +17,20 @@ struct rt_dec *rt_dec_new(const struct rt_options *opt, float sample_deltat, int
    d->opt = *opt;
    d->sample_deltat = sample_deltat;
    d->sample_deltat_ns = sample_deltat_ns;
-   d->data = (uint16_t *)calloc(RT_MAXBLOCK + 1, sizeof(uint16_t));
-   d->data_faked = (uint16_t *)calloc(RT_MAXBLOCK + 1, sizeof(uint16_t));
-   d->data_time = (double *)calloc(RT_MAXBLOCK + 1, sizeof(double));
+   /* The reference's data[] / data_time[] are static arrays, and its NRZI mid-bit check can take a track's datacount to
+    * -1 (src/decode_nrzi.c:265 with datacount == 0: garbage in, e.g. noise on a differentiated signal), after which one
+    * bit is written in front of the array - harmless there, a smashed heap header here.  RT_DATA_GUARD elements in front
+    * of each array make it harmless here too (what lands there is never part of a block). */
+   d->data = (uint16_t *)calloc(RT_MAXBLOCK + 1 + RT_DATA_GUARD, sizeof(uint16_t)) + RT_DATA_GUARD;
+   d->data_faked = (uint16_t *)calloc(RT_MAXBLOCK + 1 + RT_DATA_GUARD, sizeof(uint16_t)) + RT_DATA_GUARD;
+   d->data_time = (double *)calloc(RT_MAXBLOCK + 1 + RT_DATA_GUARD, sizeof(double)) + RT_DATA_GUARD;
    d->expected_parity = opt->specified_parity;
    rt_default_parmsets(opt->mode, d->parmsets);
    return d; }
 
 void rt_dec_free(struct rt_dec *d) {
    if (!d) return;
-   free(d->data); free(d->data_faked); free(d->data_time);
+   free(d->data - RT_DATA_GUARD); free(d->data_faked - RT_DATA_GUARD); free(d->data_time - RT_DATA_GUARD);
    free(d); }
 
 int rt_samples_per_bit(const struct rt_dec *d) {   /* src/readtape.c:1402 */

@@ -153,13 +153,13 @@ void rt_nrzi_zerocheck(struct rt_dec *d) {   /* src/decode_nrzi.c:232-314 */
       if (lastpeak_in_window) {
          avg_pos += t->t_lastpeak;
          ++numbits;
-         if (prevlastpeak_in_window) --t->datacount; }
+         if (prevlastpeak_in_window && t->datacount > -32) --t->datacount; }      /* (may reach -1: see rt_dec_new) */
       else if (prevlastpeak_in_window) {
          avg_pos += t->t_prevlastpeak;
          ++numbits; }
       else {
          if (t->t_lastpeak > right_edge) {
-            --t->datacount;
+            if (t->datacount > -32) --t->datacount;
             nrzi_addbit(d, t, 0, nrzi->t_lastclock + nrzi->clkavg.t_bitspaceavg);
             nrzi_addbit(d, t, 1, t->t_lastpeak);
             ++numlaterbits; }

@@ -306,7 +306,11 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
    rp.bursts = bursts; rp.nbursts = nbursts; rp.counts = counts; rp.events = events;
    rp.exact = exact; rp.exact_free = exact_free; rp.exact_user = user;
    rp.find_zeros = opt->find_zeros;
-   if (evt_path) { rp.evtf = fopen(evt_path, append ? "ab" : "wb"); if (rp.evtf) { d->on_transition = dump_transition; d->on_attempt = dump_attempt; d->user = &rp; } }
+   if (evt_path) {
+      /* (not "ab": a restarted attempt rewinds the dump, and O_APPEND ignores seeks) */
+      rp.evtf = append ? fopen(evt_path, "r+b") : fopen(evt_path, "wb");
+      if (rp.evtf && append) fseek(rp.evtf, 0, SEEK_END);
+      if (rp.evtf) { d->on_transition = dump_transition; d->on_attempt = dump_attempt; d->user = &rp; } }
    struct rt_reader rd = { rt_replay_readblock, rt_replay_save_pos, rt_replay_restore_pos, &rp };
    int ok = 1;
    if (prepass && prepass->bpi) *prepass->bpi = rt_density_prepass(d, &rd, prepass->implied, prepass->nblks, prepass->hit_end);
@@ -320,7 +324,7 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
       stats->data_bytes = d->numdatabytes; }
    if (d->tapf) fclose(d->tapf);
    if (d->logf) fclose(d->logf);
-   if (rp.evtf) { fflush(rp.evtf); if (!append && ftruncate(fileno(rp.evtf), ftell(rp.evtf))) {} fclose(rp.evtf); }
+   if (rp.evtf) { fflush(rp.evtf); if (ftruncate(fileno(rp.evtf), ftell(rp.evtf))) {} fclose(rp.evtf); }
    rt_dec_free(d);
    return 0; }
 
