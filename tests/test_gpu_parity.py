@@ -191,6 +191,42 @@ def test_zeros_excursions_without_events_are_history(tmp_path, gpu):
     _noisy_pe_zeros_case(tmp_path, None)
 
 
+@pytest.mark.parametrize("kind,world", [("nrzi", 2), ("nrzi", 3), ("nrzi", 8), ("pe", 4), ("gcr", 3), ("nrzi_zeros", 4)])
+def test_time_shards_on_one_gpu_equal_the_whole_scan(kind, world, gpu):
+    """What the N ranks of `bench.py --gpus N` / readtape_amd.shard do, run one after another on this GPU: each shard scans
+    its rows plus the right neighbour's halo and owns the bursts whose zone ends in its rows; together they must
+    reproduce the whole-tape scan's events bit for bit (the seams fall wherever they fall: in blocks, in gaps)."""
+    import torch
+    from readtape_amd import shard
+    if kind == "pe":
+        tape = synth.pe_tape(seed=41, nblocks=14, minlen=200, maxlen=1500, gap_samples=5000)
+    elif kind == "gcr":
+        tape = synth.gcr_tape(seed=42, nblocks=10, minlen=400, maxlen=2500, gap_samples=7000)
+    else:
+        tape = synth.nrzi_tape(seed=43, nblocks=40, minlen=64, maxlen=3000, marks_every=6, gap_samples=5000)
+    hdr = tape.spec.header()
+    zeros = kind.endswith("_zeros")
+    cfg = frontend.FrontEndConfig.from_header(hdr, find_zeros=zeros)
+    fe = frontend.FrontEnd(cfg)
+    rows = torch.from_numpy(tape.rows).cuda()
+    whole = fe.scan(rows).fetch()
+    wb = shard.absolute_bursts(whole, 0)
+    we = shard.flatten_events(whole, wb, 0)
+    halo = 1 << 18                                             # > the longest block + gap of these tapes
+    parts_b, parts_e = [], []
+    for rank, (lo, hi) in enumerate(shard.plan_shards(int(rows.shape[0]), world)):
+        end = min(int(rows.shape[0]), hi + halo) if rank < world - 1 else hi
+        res = fe.scan(rows[lo:end].contiguous(), row_base=lo, first_is_tape_start=(rank == 0), own_rows=hi - lo).fetch()
+        b = shard.absolute_bursts(res, lo)
+        parts_b.append(b); parts_e.append(shard.flatten_events(res, b, 0))
+    got_b, got_e = np.concatenate(parts_b), np.concatenate(parts_e)
+    for f in ("zone_end", "reset_sample", "safe_last", "end_sample"):
+        assert list(got_b[f]) == list(wb[f]), f
+    key = lambda e: e[np.lexsort((e[:, 1], e[:, 0]))]
+    assert got_e.shape == we.shape and (key(got_e) == key(we)).all()
+    assert we.shape[0] > 10000
+
+
 def test_deskew_calibration_on_a_growing_prefix(tmp_path, gpu):
     """-deskew: the pre-pass scans a prefix of the tape and grows it until the reference's stopping rule is met inside
     it; whatever the first prefix size, delays and .tap are the reference's."""
