@@ -88,6 +88,26 @@ def case_nrzi9_clean(seed=24):
     return synth.nrzi_tape(seed=seed, nblocks=4, minlen=40, maxlen=120, marks_every=3, gap_samples=1500, noise_mv=0.0)
 
 
+def case_nrzi9_cut(seed=25):
+    # ragged input: the recording starts and ends in the middle of a block
+    import dataclasses
+    t = synth.nrzi_tape(seed=seed, nblocks=3, minlen=100, maxlen=300, gap_samples=2000)
+    return dataclasses.replace(t, rows=np.ascontiguousarray(t.rows[3000:t.rows.shape[0] - 4500]))
+
+
+def case_noise_only(seed=26):
+    import dataclasses
+    t = _nrzi_small(seed)
+    rng = np.random.default_rng(seed)
+    return dataclasses.replace(t, rows=rng.normal(0, 60, size=(6000, 9)).astype(np.int16))
+
+
+def case_tiny(seed=27):
+    import dataclasses
+    t = _nrzi_small(seed)
+    return dataclasses.replace(t, rows=np.ascontiguousarray(t.rows[:7]))
+
+
 def case_nrzi9_oversampled(seed=18):
     # sampled at 640 ns (39 samples per bit) while the header says 1280 ns: what "-subsample=2" is for
     import dataclasses
@@ -126,6 +146,10 @@ CASES = {
     "gcr_deskew":   (case_gcr_skew,   ["-gcr", "-deskew"],             ["-deskew"]),
     "nrzi9_nobpi":  (case_nrzi9_nobpi, ["-nrzi"],                      []),
     "nrzi9_nobpi_short": (case_nrzi9_nobpi_short, ["-nrzi"],           []),
+    "nrzi9_cut":    (case_nrzi9_cut,  ["-nrzi"],                       []),
+    "nrzi9_cut_zeros": (case_nrzi9_cut, ["-nrzi", "-zeros"],            ["-zeros"]),
+    "noise_only":   (case_noise_only, ["-nrzi"],                       []),
+    "tiny":         (case_tiny,       ["-nrzi"],                       []),
     "gcr_errs":     (case_gcr_errors, ["-gcr"],                        []),
     "gcr_correct":  (case_gcr_errors, ["-gcr", "-correct"],            ["-correct"]),
 }
