@@ -69,6 +69,11 @@ def compare_attempt(fe, res, b, att, label=""):
     ev, n0 = ev[keep], n0[keep]
     o = att["events"]
     msgs = []
+    # GCR: the track that makes the last one go idle ends the block in the middle of the row's track loop ("goto exit",
+    # src/decoder.c:886-888), so detections of higher-numbered tracks on that very row are never delivered.  The replay
+    # reproduces that (rt_replay.c: stop_row); this helper only sees rows, so it drops them here.
+    if fe.cfg.mode == frontend.GCR and ev.size > o.size and (n0[o.size:] == att["last_row"]).all():
+        ev, n0 = ev[:o.size], n0[:o.size]
     if ev.size != o.size:
         msgs.append(f"{label}: {ev.size} device events vs {o.size} oracle events (attempt start {att['start']}, end {att['end']}, parmset {p}, burst reset {int(B['reset_sample'])}, flags {int(B['flags'])})")
     n = min(ev.size, o.size)

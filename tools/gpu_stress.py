@@ -20,8 +20,9 @@ def e2e_check(hdr, rows, opts, wd):
     skew = next(([int(x) for x in a[6:].split(",")] for a in opts if a.startswith("-skew=")), None)
     try:
         st, _ = pipeline.decode_tape(hdr, rows, os.path.join(wd, "g.tap"), log_path=os.path.join(wd, "g.log"), evt_path=os.path.join(wd, "g.evt"),
-                                     opts=pipeline.DecodeOptions(multiple_tries="-m" in opts, correct="-correct" in opts), skew=skew, invert="-invert" in opts,
-                                     find_zeros="-zeros" in opts, differentiate="-differentiate" in opts, deskew="-deskew" in opts)
+                                     opts=pipeline.DecodeOptions(multiple_tries="-m" in opts, correct="-correct" in opts, even_parity="-even" in opts), skew=skew, invert="-invert" in opts,
+                                     find_zeros="-zeros" in opts, differentiate="-differentiate" in opts, deskew="-deskew" in opts,
+                                     subsample=next((int(a[11:]) for a in opts if a.startswith("-subsample=")), 1))
     except RuntimeError as e:                                  # what is fatal in the reference (exit 99) must be fatal here too
         ok = p.returncode == 99 and ("no transitions" in str(e) or "non-standard" in str(e))
         return ([] if ok else [f"pipeline raised {e!r}, oracle rc {p.returncode}"]), {"events": 0, "speculative": None, "flags": None}
@@ -62,6 +63,8 @@ for i in range(ntapes):
             import dataclasses
             tape.spec = dataclasses.replace(tape.spec, bpi=0.0); opts.append("(nobpi)")
         elif r < 0.32: opts.append("-correct")
+        elif r < 0.38: opts.append("-even")
+        elif r < 0.44: opts.append("-subsample=2")
     elif kind == "pe":
         tape = synth.pe_tape(seed=seed, nblocks=int(rng.integers(2, 5)), minlen=30, maxlen=int(rng.choice([200, 900])), gap_samples=3000, **kw)
         if rng.random() < 0.3: opts.append("-m")
@@ -80,14 +83,17 @@ for i in range(ntapes):
         print(i, kind, "seed", seed, "amp", amp, "noise", noise, "jit", jit, "opts", opts, "seg", seg, warm, "rows", tape.rows.shape[0], "spec", tape.spec.bpi, flush=True)
         continue
     with tempfile.TemporaryDirectory() as wd:
-        att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct")) else []
+        att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2")) else []
         for rec in ("default", "1"):
             if rec == "1": os.environ["RTFE_RECORD_PATH"] = "1"
             else: os.environ.pop("RTFE_RECORD_PATH", None)
-            e2e = any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct"))
+            e2e = any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2"))
             if e2e: msgs, stats = e2e_check(hdr, tape.rows, [o for o in opts if o != "(nobpi)"], wd)
             else:
-                fe = frontend.FrontEnd(config_for(hdr, opts))
+                if os.environ.get("STRESS_EMUL"):
+                    from emul_util import emul_frontend
+                    fe = emul_frontend(config_for(hdr, opts))
+                else: fe = frontend.FrontEnd(config_for(hdr, opts))
                 msgs, stats = check_tape(fe, hdr, tape.rows, att)
             tag = f"{i:3d} {kind} seed {seed} amp {amp} noise {noise} jit {jit} opts {opts} seg {seg}/{warm} record_path {rec}: attempts {len(att)} events {stats['events']} speculative {stats.get('speculative')} flags {stats.get('flags')}"
             print(("FAIL " if msgs else "ok   ") + tag, flush=True)
