@@ -108,6 +108,12 @@ def case_tiny(seed=27):
     return dataclasses.replace(t, rows=np.ascontiguousarray(t.rows[:7]))
 
 
+def case_nrzi9_nobpi_skew(seed=28):
+    # both pre-passes in one run: the density is estimated first, then the head skew is calibrated with it
+    return _without_bpi(synth.nrzi_tape(seed=seed, nblocks=5, minlen=500, maxlen=800, marks_every=3, gap_samples=1500,
+                                        skew_cells=(0.0, 0.30, 0.12, 0.45, 0.05, 0.38, 0.20, 0.08, 0.26)))
+
+
 def case_nrzi9_oversampled(seed=18):
     # sampled at 640 ns (39 samples per bit) while the header says 1280 ns: what "-subsample=2" is for
     import dataclasses
@@ -146,6 +152,7 @@ CASES = {
     "gcr_deskew":   (case_gcr_skew,   ["-gcr", "-deskew"],             ["-deskew"]),
     "nrzi9_nobpi":  (case_nrzi9_nobpi, ["-nrzi"],                      []),
     "nrzi9_nobpi_short": (case_nrzi9_nobpi_short, ["-nrzi"],           []),
+    "nrzi9_nobpi_deskew": (case_nrzi9_nobpi_skew, ["-nrzi", "-deskew", "-m"], ["-deskew", "-m"]),
     "nrzi9_cut":    (case_nrzi9_cut,  ["-nrzi"],                       []),
     "nrzi9_cut_zeros": (case_nrzi9_cut, ["-nrzi", "-zeros"],            ["-zeros"]),
     "noise_only":   (case_noise_only, ["-nrzi"],                       []),
