@@ -1620,9 +1620,10 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
    unsigned int *s_wtab = reinterpret_cast<unsigned int *>(smem + L.wtab);      // [nwalk] walker -> list (screen, track) | parameter set << 8 | track << 16
    unsigned char *hmap = smem + L.hmap;                             // [nwalk * rec_cap16] walker of a detection slot
    __shared__ unsigned int s_seq;
-   // the parallel tile path covers the alpha-filter AGC (NRZI / GCR parameter sets); everything else walks sequentially
+   // the parallel tile path covers the NRZI / GCR AGC schedule with either AGC flavour (alpha filter, or the minimum of the
+   // last agc_window heights); PE's preamble logic walks sequentially
    bool par_mode = cfg.mode != RTFE_PE;
-   for (int p = 0; p < cfg.nparm; ++p) if (cfg.parm[p].agc_alpha == 0 || cfg.parm[p].agc_window != 0) par_mode = false;
+   for (int p = 0; p < cfg.nparm; ++p) if ((cfg.parm[p].agc_alpha != 0) == (cfg.parm[p].agc_window != 0)) par_mode = false;
    const int rstride = cfg.rec_cap16 * (int)sizeof(Rec16);
    const int nwaves = blockDim.x >> 6;
    const int my_w = (threadIdx.x & 63) * nwaves + (threadIdx.x >> 6);
@@ -1919,17 +1920,25 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                      if (!bot && !ft) { vt = __uint_as_float(base[4 * jj + 1]); ft = true; } }
                   const float lastheight = vt - vb;
                   float a = -1.0f;
-                  if (lastheight > 0) { const float gq = wst[w2 * 4 + 2] / lastheight; a = wst[w2 * 4 + 3] * gq; }
+                  if (lastheight > 0) {
+                     const float alpha = wst[w2 * 4 + 3];
+                     if (alpha != 0) { const float gq = wst[w2 * 4 + 2] / lastheight; a = alpha * gq; }
+                     else a = lastheight; }                                   // window AGC: the height itself goes into the ring
                   base[4 * j + 2] = __float_as_uint(a); } }
             __syncthreads();
             if (cfg.debug) p3 = clock64();
             float g_end = 0, vt_last = 0, vb_last = 0;
             bool any_t = false, any_b = false;
+            int ndx_end = 0;
             if (!s_seq && active) {
                // ---- (4) one lane per walker: the gain recurrence; did every threshold stay inside the bands? ----
                const DevParm &P = cfg.parm[pidx];
                unsigned int *hits = reinterpret_cast<unsigned int *>(recs_all + (size_t)my_w * rstride);
                const float c1 = 1 - P.agc_alpha;
+               const int N = P.agc_window;
+               float *ring = heights_bak + my_w * 10;                         // window AGC: a working copy of the ring (committed with the tile)
+               int ndx = w.heightndx;
+               if (N) for (int i = 0; i < 10; ++i) ring[i] = cx.heights[i];
                float g = w.agc_gain, gmin = g, gmax = g;
                uint4 q; q.x = 0; q.y = 0; q.z = 0; q.w = 0;
                if (nh > 0) q = *reinterpret_cast<const uint4 *>(hits);                       // rk, v, a, -
@@ -1939,11 +1948,19 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                   if (j + 1 < nh) qn = *reinterpret_cast<const uint4 *>(hits + 4 * (j + 1));
                   hits[4 * j + 3] = __float_as_uint(g);
                   const float a = __uint_as_float(q.z);
-                  if (a >= 0) { g = a + c1 * g; if (g > 2.0f) g = 2.0f; }
+                  if (a >= 0) {
+                     if (N) {                                                 // src/decoder.c:519-529
+                        ring[ndx] = a;
+                        if (++ndx >= N) ndx = 0;
+                        float minheight = 99;
+                        for (int i = 0; i < N; ++i) if (ring[i] < minheight) minheight = ring[i];
+                        g = w.v_avg_height / minheight; }
+                     else g = a + c1 * g;                                     // src/decoder.c:511-512
+                     if (g > 2.0f) g = 2.0f; }
                   gmin = fminf(gmin, g); gmax = fmaxf(gmax, g);
                   if (q.x >> 31) { vb_last = __uint_as_float(q.y); any_b = true; } else { vt_last = __uint_as_float(q.y); any_t = true; }
                   q = qn; }
-               g_end = g;
+               g_end = g; ndx_end = ndx;
                const float s_hi = w.v_avg_height * 0.25f * fast_rcp(gmin), s_lo = w.v_avg_height * 0.25f * fast_rcp(gmax);
                bool ok = gmin > 0 && (int)(P.rise * s_hi * lsb) + 4 <= band[my_w * 4 + 1] && (int)(P.rise * s_lo * lsb) - 3 >= band[my_w * 4 + 0]
                          && P.rise * s_lo >= P.screen_rise_v * 1.01f;
@@ -1992,6 +2009,7 @@ __global__ void __launch_bounds__(kDecodeThreads) k_walk(const DevCfg *__restric
                      if (any_t) { w.v_top = vt_last; w.v_lasttop = vt_last; }
                      if (any_b) { w.v_bot = vb_last; w.v_lastbot = vb_last; }
                      w.peakcount += nh; w.nevents += (unsigned)nh; w.agc_gain = g_end; w.t_lastpeak = 0;
+                     if (P.agc_window) { w.heightndx = ndx_end; for (int i = 0; i < 10; ++i) cx.heights[i] = heights_bak[my_w * 10 + i]; }
                      w.blind_until = tile0 + last_blind;
                      if (!approx_thresholds(w, P, lsb)) update_thresholds(w, P, lsb); }
                   w.next = limit;
