@@ -1230,12 +1230,12 @@ __device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int
 // act / nact (k_screen only): the strips of the tile proper that hold candidates, compacted (st << 16 | strip) so that
 // the sparse passes behind the screen keep every lane busy; stripcnt of every strip is cleared on the way
 __device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl, bool with_halo, unsigned int *act = nullptr, int *nact = nullptr,
-                                            unsigned int *stripcnt = nullptr, int smax = 0) {
+                                            unsigned int *stripcnt = nullptr, int smax = 0, int only = -1) {      // only >= 0: that screen alone, into LDS slot 0 (k_screen)
    const int hs = with_halo ? kScreenHalo / kStrip : 0;            // k_screen also screens the rows in front of the tile
    const int nstrips = (tl.nrows + kStrip - 1) / kStrip + hs;
    const int per_screen = nstrips * cfg->ntrks;
    const FastDiv fd(cfg->ntrks);
-   for (int s = 0; s < cfg->nscreens; ++s)
+   for (int s = only >= 0 ? only : 0; s < (only >= 0 ? only + 1 : cfg->nscreens); ++s)
       for (int i0 = 0; i0 < per_screen; i0 += blockDim.x) {         // (uniform trip count: the ballot below needs whole waves)
          const int i = i0 + (int)threadIdx.x;
          const bool valid = i < per_screen;
@@ -1243,9 +1243,9 @@ __device__ __forceinline__ void run_screens(const DevCfg *cfg, const Tile &tl, b
          if (valid) {                                               // consecutive lanes = the tracks of one strip: consecutive LDS words
             const int q = fd.div(i);
             t = i - q * cfg->ntrks; strip = q - hs;
-            any = screen_strip(tl, cfg->screen[s], s, t, strip); }
+            any = screen_strip(tl, cfg->screen[s], only >= 0 ? 0 : s, t, strip); }
          if (act) {
-            const int st = s * cfg->ntrks + t;
+            const int st = (only >= 0 ? 0 : s) * cfg->ntrks + t;
             const bool mine = valid && strip >= 0;
             if (mine) stripcnt[st * smax + strip] = 0;
             const bool on = mine && any != 0;
@@ -1393,8 +1393,8 @@ __host__ __device__ inline unsigned lds_bstride(int tile_rows) { unsigned v = (u
 __host__ __device__ inline unsigned lds_ldstride(int tile_rows) { unsigned v = (unsigned)(tile_rows + kScreenHalo); while ((v / 4) % 32 != 18) v += 8; return v; }
 struct LdsLayout {
    unsigned bits, ldpos, heights, recs, nrec, runs, runcnt, runtab, act, walkers, walkers_next, heights_bak, fdiff, total; };
-__host__ __device__ inline unsigned lds_runtab_cap(const DevCfg &c) {        // run descriptors of one tile (k_screen)
-   const unsigned n = (unsigned)(c.nscreens * c.ntrks * c.tile_rows) / 8u;
+__host__ __device__ inline unsigned lds_runtab_cap(const DevCfg &c) {        // run descriptors of one (tile, screen) (k_screen)
+   const unsigned n = (unsigned)(c.ntrks * c.tile_rows) / 8u;
    return n > 2048u ? 2048u : n; }
 __host__ __device__ inline unsigned lds_align16(unsigned v) { return (v + 15u) & ~15u; }
 __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
@@ -1402,15 +1402,16 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    const unsigned ntrks = (unsigned)c.ntrks, nst = (unsigned)c.nscreens * ntrks, nwalk = (unsigned)c.nparm * ntrks;
    const unsigned T = (unsigned)c.tile_rows;
    unsigned off = lds_align16(ntrks * (unsigned)c.ldw * 2u + 16u);          // (ldw rows of ntrks samples, + one vector of slack)
-   L.bits = off;      off = lds_align16(off + nst * 5u * lds_bstride((int)T));
-   L.ldpos = off;     off = lds_align16(off + nst * 2u * lds_ldstride((int)T));
+   const unsigned nsl = decode ? nst : ntrks;                                  // k_screen works through the screens one at a time
+   L.bits = off;      off = lds_align16(off + nsl * 5u * lds_bstride((int)T));
+   L.ldpos = off;     off = lds_align16(off + nsl * 2u * lds_ldstride((int)T));
    // k_decode: the candidate records of a tile share the space of the sample tile (a tile is decided either from
    // its records or from its samples, never both)
    L.runs = 0;
    if (decode) { const unsigned r = lds_align16((unsigned)c.lds_units * (unsigned)sizeof(CandUnit)); if (r > off) off = r; }
-   L.runcnt = off;    if (!decode) off = lds_align16(off + nst * (T / 8) * 4u);
+   L.runcnt = off;    if (!decode) off = lds_align16(off + ntrks * (T / 8) * 4u);
    L.runtab = off;    if (!decode) off = lds_align16(off + lds_runtab_cap(c) * 8u);
-   L.act = off;       if (!decode) off = lds_align16(off + nst * (T / 8) * 4u);
+   L.act = off;       if (!decode) off = lds_align16(off + ntrks * (T / 8) * 4u);
    L.fdiff = off;     if (decode && c.differentiate && !c.find_zeros) off = lds_align16(off + ntrks * (unsigned)c.ldw * 4u + 32u);
    L.heights = off;   if (decode) off = lds_align16(off + nwalk * 10u * 4u);
    L.recs = off;      if (decode) off = lds_align16(off + nwalk * (unsigned)c.rec_cap * (unsigned)sizeof(Rec));
@@ -1487,78 +1488,81 @@ __global__ void __launch_bounds__(256, 4) k_screen(const DevCfg *__restrict__ cf
       __syncthreads();
       if (cfg.debug) k1 = clock64();
       if (cfg.cut == 1) continue;
+      // the screens (distinct window widths of a parameter-set sweep) one after the other through the same LDS arrays:
+      // a sweep then costs occupancy no more than a single set does.  Lists are packed screen-major, track-minor.
+      int units_before = 0;
+      long long k2a = 0, k2b = 0;
+      for (int sc_real = 0; sc_real < cfg.nscreens; ++sc_real) {
+      const int W_sc = cfg.screen[sc_real].W;
+      __syncthreads();
       if (threadIdx.x == 0) { s_nact = 0; s_nruns = 0; }
       __syncthreads();
-      run_screens(&cfg, tl, true, act, &s_nact, stripcnt, cfg.tile_rows / kStrip);
+      run_screens(&cfg, tl, true, act, &s_nact, stripcnt, cfg.tile_rows / kStrip, sc_real);
       __syncthreads();
       if (cfg.debug) k2 = clock64();
       if (cfg.cut == 2) continue;
       const int nstrips = (tl.nrows + kStrip - 1) / kStrip;
       const int smax = cfg.tile_rows / kStrip;
-      const FastDiv fdt(ntrks);
       const int nactive = s_nact;
       for (int k = threadIdx.x; k < nactive; k += blockDim.x) {      // the reference's minimum at the bottom candidates
          const unsigned a = act[k];
-         const int st = (int)(a >> 16), sc = fdt.div(st);
-         fill_stale(tl, sc, st - sc * ntrks, (int)(a & 0xffff)); }
+         fill_stale(tl, 0, (int)(a >> 16), (int)(a & 0xffff)); }
       __syncthreads();
       if (cfg.cut == 3) continue;
-      long long k2a = 0, k2b = 0;
       if (cfg.debug) k2a = clock64();
       for (int k = threadIdx.x; k < nactive; k += blockDim.x) {
          const unsigned a = act[k];
-         const int st = (int)(a >> 16), sc = fdt.div(st);
-         run_starts(tl, sc, st - sc * ntrks, (int)(a & 0xffff)); }
+         run_starts(tl, 0, (int)(a >> 16), (int)(a & 0xffff)); }
       __syncthreads();
       if (cfg.debug) k2b = clock64();
       if (cfg.cut == 4) continue;
       for (int k = threadIdx.x; k < nactive; k += blockDim.x) {
          const unsigned a = act[k];
-         const int st = (int)(a >> 16), sc = fdt.div(st), strip = (int)(a & 0xffff);
-         stripcnt[st * smax + strip] = (unsigned int)list_runs(tl, st, sc, st - sc * ntrks, strip, runtab, &s_nruns, tabcap); }
+         const int lt = (int)(a >> 16), strip = (int)(a & 0xffff);
+         stripcnt[lt * smax + strip] = (unsigned int)list_runs(tl, lt, 0, lt, strip, runtab, &s_nruns, tabcap); }
       __syncthreads();
       // exclusive scan of the strips' unit counts, list by list (one wave per list at a time)
       {
          const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-         for (int st = wave; st < nst; st += nwaves) {
+         for (int lt = wave; lt < ntrks; lt += nwaves) {
             int carry = 0;
             for (int s0 = 0; s0 < nstrips; s0 += 64) {
-               const int v = s0 + lane < nstrips ? (int)stripcnt[st * smax + s0 + lane] : 0;
+               const int v = s0 + lane < nstrips ? (int)stripcnt[lt * smax + s0 + lane] : 0;
                int x = v;
                #pragma unroll
                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
-               if (s0 + lane < nstrips) stripcnt[st * smax + s0 + lane] = (unsigned int)(carry + x - v);
+               if (s0 + lane < nstrips) stripcnt[lt * smax + s0 + lane] = (unsigned int)(carry + x - v);
                carry += __shfl(x, 63); }
-            if (lane == 0) s_total[st] = carry; } }
+            if (lane == 0) s_total[lt] = carry; } }
       __syncthreads();
       if (cfg.debug) k3 = clock64();
       if (cfg.cut == 5) continue;
-      int tile_units = 0;
-      for (int s2 = 0; s2 < nst; ++s2) { if (threadIdx.x == 0) s_lbase[s2] = tile_units; tile_units += (s_total[s2] & 0xffff) + (s_total[s2] >> 16); }
+      int tile_units = units_before;
+      for (int s2 = 0; s2 < ntrks; ++s2) { if (threadIdx.x == 0) s_lbase[s2] = tile_units; tile_units += (s_total[s2] & 0xffff) + (s_total[s2] >> 16); }
       __syncthreads();
       const bool tab_ok = s_nruns <= tabcap && tile_units <= nst * cfg.run_cap;
       if (tab_ok)
          for (int r = threadIdx.x >> 2; r < s_nruns; r += blockDim.x >> 2) {
             const u64 d = runtab[r];
-            const int st = (int)(d & 0xff), kind = (int)((d >> 8) & 1), n = (int)((d >> 16) & 0xffff), nr = (int)((d >> 32) & 0xff);
+            const int lt = (int)(d & 0xff), kind = (int)((d >> 8) & 1), n = (int)((d >> 16) & 0xffff), nr = (int)((d >> 32) & 0xff);
             const int relrun = (int)((d >> 40) & 0x3ff), relmarg = (int)(d >> 50);
-            const int sc = fdt.div(st);
-            const unsigned sb = stripcnt[st * smax + (n >> 3)];
-            int4 *list = reinterpret_cast<int4 *>(pool) + (size_t)g * nst * cfg.run_cap + s_lbase[st];      // the tile's lists are packed one behind the other
+            const unsigned sb = stripcnt[lt * smax + (n >> 3)];
+            int4 *list = reinterpret_cast<int4 *>(pool) + (size_t)g * nst * cfg.run_cap + s_lbase[lt];      // the tile's lists are packed one behind the other
             const int moff = (int)(sb >> 16) + relmarg;
-            build_run(tl, &cfg, sc, st - sc * ntrks, cfg.screen[sc].W, n, kind, nr, list + (sb & 0xffff) + relrun, moff,
-                      list + (s_total[st] & 0xffff) + moff, (int)(threadIdx.x & 3)); }
-      if (threadIdx.x < nst) {
-         const int st = threadIdx.x, sc = st / ntrks, trk = st - sc * ntrks;
+            build_run(tl, &cfg, 0, lt, W_sc, n, kind, nr, list + (sb & 0xffff) + relrun, moff,
+                      list + (s_total[lt] & 0xffff) + moff, (int)(threadIdx.x & 3)); }
+      if ((int)threadIdx.x < ntrks) {
+         const int trk = threadIdx.x;
          TileDir d;
-         const int units_l = (s_total[st] & 0xffff) + (s_total[st] >> 16);
-         d.count = (!tab_ok || units_l >= 0xFFFF || (s_total[st] >> 16) >= (1 << 14)) ? (uint16_t)0xFFFF : (uint16_t)units_l;
-         d.nruns = (uint16_t)(s_total[st] & 0xffff);
+         const int units_l = (s_total[trk] & 0xffff) + (s_total[trk] >> 16);
+         d.count = (!tab_ok || units_l >= 0xFFFF || (s_total[trk] >> 16) >= (1 << 14)) ? (uint16_t)0xFFFF : (uint16_t)units_l;
+         d.nruns = (uint16_t)(s_total[trk] & 0xffff);
          const int last = tl.nrows - 1;
-         const int eld = stale_ld(tl.map(sc, 2, trk), tl.ldmap(sc, 1, trk), last);
+         const int eld = stale_ld(tl.map(0, 2, trk), tl.ldmap(0, 1, trk), last);
          d.end_ld = (uint8_t)eld; d.pad = 0;
-         d.end_min = eld ? (int16_t)tile_col(tl, trk, cfg.skew[trk])[last - cfg.screen[sc].W + eld] : (int16_t)0;
-         dir[g * nst + st] = d; }
+         d.end_min = eld ? (int16_t)tile_col(tl, trk, cfg.skew[trk])[last - W_sc + eld] : (int16_t)0;
+         dir[g * nst + sc_real * ntrks + trk] = d; }
+      units_before = tab_ok ? tile_units : nst * cfg.run_cap + 1; }      // (an overflowing screen poisons the rest of the tile's slot)
       if (cfg.debug) {
          __syncthreads();
          if (threadIdx.x == 0) {
