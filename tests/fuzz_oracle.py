@@ -1,8 +1,8 @@
 """Build-container helper (needs /root/reference): randomized sweep of the CPU oracle against the UNMODIFIED reference
 compiled by oracle/Makefile - .tap bytes, the event stream handed to the block decoders, and the per-block result lines -
-over tape parameters and option combinations the committed cases do not pin.  usage: oracle_fuzz.py <seed> <ntapes>"""
+over tape parameters and option combinations the committed cases do not pin.  usage: tests/fuzz_oracle.py <seed> <ntapes>"""
 import os, subprocess, sys, tempfile, dataclasses
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (this file lives in tests/: it runs the oracle, which only tests may)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import refdump

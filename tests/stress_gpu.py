@@ -2,8 +2,8 @@
 not pin: amplitudes, noise, jitter, track counts, skews, parameter-set sweeps.  Prints one line per tape; exits non-zero
 on the first mismatch."""
 import os, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (this file lives in tests/: it runs the oracle, which only tests may)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 from parity_util import check_tape, config_for, oracle_attempts
 from readtape_amd import frontend, synth, pipeline, tbin

@@ -58,7 +58,7 @@ def test_short_burst_tails_do_not_change_the_tap(tmp_path, monkeypatch):
 def _noisy_pe_zeros_case(tmp_path, fe_factory):
     """-zeros on a PE tape whose gap noise (50 mV rms) now and then crosses the 0.2 V threshold: such an excursion is
     detector history without any event, so an attempt must not be continued into the next device burst as if it were
-    fresh (RTFE_F_STATE_AT_END).  Found by tools/gpu_stress.py."""
+    fresh (RTFE_F_STATE_AT_END).  Found by tests/stress_gpu.py."""
     import subprocess
     import refdump
     from parity_util import ORACLE, build_oracle
