@@ -1,4 +1,4 @@
-"""The parity case table shared by the golden-vector generator (tools/make_goldens.py), the
+"""The parity case table shared by the golden-vector generator (tests/make_goldens.py), the
 oracle-vs-reference tests and the GPU parity tests.  Each case = a synthetic tape recipe + the
 reference command-line options it is decoded with (option coverage follows the reference's own
 examples/*/Makefile test commands)."""

@@ -1,4 +1,4 @@
-"""Loads the committed golden vectors (tests/golden/, made by tools/make_goldens.py)."""
+"""Loads the committed golden vectors (tests/golden/, made by tests/make_goldens.py)."""
 import glob
 import os
 

@@ -1,7 +1,7 @@
 """Generates tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref/readtape_evt, built by
 oracle/Makefile from /root/reference/src).  Run in the build container only:
 
-    python tools/make_goldens.py
+    python tests/make_goldens.py
 
 Each vector holds: the synthetic tape (int16 rows + header fields), the reference command line, the
 reference's SIMH .tap bytes, its exit code and its front-end event dump (oracle/ref_event_shim.c).

@@ -1,5 +1,5 @@
 """The CPU oracle against the committed golden vectors (outputs of the unmodified reference, made by
-tools/make_goldens.py): identical .tap bytes and identical event streams.  Needs no reference, so it
+tests/make_goldens.py): identical .tap bytes and identical event streams.  Needs no reference, so it
 also runs on the GPU box."""
 import os
 import subprocess
