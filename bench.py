@@ -174,7 +174,7 @@ def main():
 
     res.fetch()
     nevents = int(res.counts.sum())
-    bad = int((res.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START)).any())
+    bad = int((res.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START | frontend.F_STATE_AT_END)).any())
     if world > 1:
         tot = torch.tensor([nevents, bad], device=dev, dtype=torch.int64)
         dist.all_reduce(tot)

@@ -24,7 +24,7 @@ def run(name, base, target_rows, **cfgkw):
     r.fetch()
     print(json.dumps({"config": name, "rows": int(rows.shape[0]), "parmsets": len(fe.cfg.parmsets), "ms_per_scan": round(dt * 1e3, 3),
                       "Msamples_per_s": round(rows.shape[0] / dt / 1e6, 1), "events": int(r.counts.sum()), "bursts": int(r.nbursts),
-                      "flagged": int((r.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START)).astype(bool).sum()),
+                      "flagged": int((r.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START | frontend.F_STATE_AT_END)).astype(bool).sum()),
                       "kernel_ms": {k2: round(v, 3) for k2, v in ms.items()}}))
     del rows, fe
 
