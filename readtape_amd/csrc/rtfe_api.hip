@@ -175,6 +175,10 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       const int nwalk = c->nparmsets * c->ntrks;
       int rc = (24 * 1024) / (nwalk * 24);
       d.rec_cap = rc > 64 ? 64 : (rc < 8 ? 8 : rc);
+      // deferred detections per walker and tile (beyond that they are finished on the spot): 24 keeps a k_decode workgroup under
+      // 40 KB of LDS = four per CU instead of three (PE +13 %, GCR +25 %); the -zeros sub-segments use the space themselves
+      if (!d.find_zeros && d.rec_cap > 24) d.rec_cap = 24;
+      if (const char *e = getenv("RTFE_REC_CAP")) { const int v = atoi(e); if (v >= 4 && v <= d.rec_cap) d.rec_cap = v; }      // (experiments: LDS per k_decode workgroup)
       d.run_cap = d.tile_rows / 2 < 64 ? 64 : d.tile_rows / 2;
       // LDS of k_walk, sized for a typical tile (its lists go through LDS in groups, so a dense tile only costs time):
       // peaks per track per tile from the bit cell, ~4.75 units per run of W<=13 rows plus as much again for runs that
