@@ -201,6 +201,10 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    h->lds_bytes = (int)lds_layout(d, true).total + 64;
    h->screen_lds_bytes = (int)lds_layout(d, false).total + 64;
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
+   if (getenv("RTFE_VERBOSE")) {
+      const LdsLayout Ld = lds_layout(d, true);
+      fprintf(stderr, "rtfe: LDS k_decode %d (tile..bits %u, bits..ldpos %u, ldpos..heights %u, recs %u, walkers %u) k_screen %d\n", h->lds_bytes, Ld.bits, Ld.ldpos - Ld.bits,
+              Ld.heights - Ld.ldpos, Ld.nrec - Ld.recs, Ld.walkers_next - Ld.walkers, h->screen_lds_bytes); }
    hipDeviceProp_t prop;
    int dev = 0;
    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return fail(-20, "no HIP device"); }
