@@ -147,6 +147,9 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    d.seg_tiles = 48;                                                  // the record walk of a long block runs as concurrent segments of 48 tiles
    d.seg_warm = kSegWarmup;
    d.zc_parallel = 1;
+   d.record_path = !d.find_zeros && d.mode == RTFE_NRZI;
+   if (const char *e = getenv("RTFE_RECORD_PATH")) d.record_path = !d.find_zeros && atoi(e) != 0;
+   if (d.agc_off || d.differentiate) d.record_path = 0;               // density detection / differentiated peaks: the sample path
    if (const char *e = getenv("RTFE_ZC_PARALLEL")) d.zc_parallel = atoi(e) != 0;
    if (const char *e = getenv("RTFE_SEG_WARMUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) d.seg_warm = v; }
    if (const char *e = getenv("RTFE_SEG_TILES")) { const int v = atoi(e); d.seg_tiles = v <= 0 ? 0 : v; }
@@ -175,9 +178,8 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       const int nwalk = c->nparmsets * c->ntrks;
       int rc = (24 * 1024) / (nwalk * 24);
       d.rec_cap = rc > 64 ? 64 : (rc < 8 ? 8 : rc);
-      // deferred detections per walker and tile (beyond that they are finished on the spot): 24 keeps a k_decode workgroup under
-      // 40 KB of LDS = four per CU instead of three (PE +13 %, GCR +25 %); the -zeros sub-segments use the space themselves
-      if (!d.find_zeros && d.rec_cap > 24) d.rec_cap = 24;
+      // deferred detections per walker and tile (beyond that they are finished on the spot) - sized below, once the rest of
+      // k_decode's LDS is known, so that one more workgroup fits a CU where a smaller buffer buys that
       if (const char *e = getenv("RTFE_REC_CAP")) { const int v = atoi(e); if (v >= 4 && v <= d.rec_cap) d.rec_cap = v; }      // (experiments: LDS per k_decode workgroup)
       d.run_cap = d.tile_rows / 2 < 64 ? 64 : d.tile_rows / 2;
       // LDS of k_walk, sized for a typical tile (its lists go through LDS in groups, so a dense tile only costs time):
@@ -198,6 +200,12 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       // test knobs (tests/ only): force the rare paths - lists through LDS in several groups, tiles handed back to k_decode
       if (getenv("RTFE_LDS_UNITS")) { int v = atoi(getenv("RTFE_LDS_UNITS")); if (v >= d.run_cap && v <= 1536) { d.lds_units = v & ~63; d.pm_cap = d.lds_units / 2 * ((c->nparmsets + d.nscreens - 1) / d.nscreens); } }
       if (getenv("RTFE_REC_CAP16")) { int v = atoi(getenv("RTFE_REC_CAP16")); if (v >= 2 && v <= d.rec_cap16) d.rec_cap16 = v; } }
+   if (!d.find_zeros) {                                               // (the -zeros sub-segments use the record space themselves)
+      // k_decode is latency bound: workgroups per CU are what counts.  A smaller record buffer is taken only if it lets one more workgroup reside.
+      auto per_cu = [&](int rc) { DevCfg t = d; t.rec_cap = rc; return (160 * 1024) / ((int)lds_layout(t, true).total + 64 + 5500); };      // (static LDS ~ 4 KB, allocation granularity, margin)
+      int best = d.rec_cap;
+      for (int rc = d.rec_cap; rc >= 8; --rc) if (per_cu(rc) > per_cu(best)) best = rc;
+      d.rec_cap = best; }
    h->lds_bytes = (int)lds_layout(d, true).total + 64;
    h->screen_lds_bytes = (int)lds_layout(d, false).total + 64;
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
@@ -315,9 +323,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    // candidate rows has one kind.  PE and GCR put a top and a bottom into the window at the same time; their candidate
    // lists degenerate into one-row runs and overflow, so they take the sample path for the whole burst.
    // RTFE_RECORD_PATH=0/1 overrides (tests keep both paths covered for every format).
-   bool use_screen = !h->dev.find_zeros && h->dev.mode == RTFE_NRZI;
-   if (const char *e = getenv("RTFE_RECORD_PATH")) use_screen = !h->dev.find_zeros && atoi(e) != 0;
-   if (h->dev.agc_off || h->dev.differentiate) use_screen = false;                            // density detection: the sample path (the record walk's AGC schedule does not apply)
+   const bool use_screen = h->dev.record_path != 0;                  // (decided in rtfe_create: it sizes k_decode's LDS)
    // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
    // beat wide ones; k_decode holds ~250 VGPRs => 2 waves/SIMD => 8 waves per CU
    const int nwalk = h->dev.nparm * h->dev.ntrks;

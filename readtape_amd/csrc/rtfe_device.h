@@ -52,6 +52,7 @@ struct DevCfg {
    int   seg_evcap;
    int   seg_warm;                // warm-up tiles in front of every segment but the first
    int   zc_parallel;             // -zeros: concurrent sub-segments per tile (0 = one lane per track, sequential)
+   int   record_path;             // k_screen -> k_walk runs (NRZI peak detection; RTFE_RECORD_PATH overrides): k_decode then keeps LDS for record tiles
    int   tail_rows;               // a burst's walkers stop this many rows into the next zone (the block decoders have long ended
                                   // the block by then; an attempt that has not falls back to an exact rescan in the replay)
    float cap_frac;                // event capacity per track as a fraction of burst length

@@ -1417,8 +1417,10 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    L.recs = off;      if (decode) off = lds_align16(off + nwalk * (unsigned)c.rec_cap * (unsigned)sizeof(Rec));
    L.nrec = off;      if (decode) off = lds_align16(off + nwalk * 4u);
    L.walkers = off;   if (decode) off = lds_align16(off + nwalk * (unsigned)sizeof(Walker));
-   L.walkers_next = off; if (decode) off = lds_align16(off + nwalk * (unsigned)sizeof(Walker));
-   L.heights_bak = off;  if (decode) off = lds_align16(off + nwalk * 10u * 4u);
+   // (the optimistic copies exist for the record tiles of k_decode only: without a record path a sweep's workgroup is
+   //  20 KB lighter and two fit a CU)
+   L.walkers_next = off; if (decode && c.record_path) off = lds_align16(off + nwalk * (unsigned)sizeof(Walker));
+   L.heights_bak = off;  if (decode && c.record_path) off = lds_align16(off + nwalk * 10u * 4u);
    L.total = off;
    return L; }
 
