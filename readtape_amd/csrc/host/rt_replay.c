@@ -185,12 +185,12 @@ int rt_replay_readblock(void *ctx, int retry) {
 restart:
    if (rp->evtf && (restarted || using_exact)) fseek(rp->evtf, dump_pos, SEEK_SET);
    if (b < 0) {                                               /* outside every proven-safe zone: exact device scan */
-      if (!rp->exact) { d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
+      if (!rp->exact) { ++rp->device_failures; d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
       uint32_t cnt[RT_MAXTRKS]; rtfe_burst eb; uint32_t cap = 0;
       if (exact_events && rp->exact_free) { rp->exact_free(rp->exact_user, exact_events); exact_events = NULL; }
       const int64_t ex_end = s0 + exact_len < nrows ? s0 + exact_len : nrows;
       if (rp->exact(rp->exact_user, s0, ex_end, rp->find_zeros ? 0 : parmset, &eb, cnt, &exact_events, &cap) != 0) {
-         d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
+         ++rp->device_failures; d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
       for (int t = 0; t < ntrks; ++t) { src.list[t] = exact_events + (uint64_t)t * cap; src.n[t] = cnt[t]; src.at[t] = 0; }
       src.reset = s0; src.end = ex_end;
       using_exact = 1; ++rp->exact_scans; }
@@ -235,7 +235,7 @@ restart:
              && !(rp->find_zeros && (rp->bursts[b].flags & RTFE_F_STATE_AT_END))) {     /* (-zeros: an excursion without an event is history too) */
             ++b; evsrc_from_burst(&src, rp, b, parmset); evsrc_skip_before(&src, ntrks, row); ++rp->chained;
             continue; }
-         if (restarted) { d->results[parmset].blktype = RT_BS_ABORTED; break; }
+         if (restarted) { ++rp->device_failures; d->results[parmset].blktype = RT_BS_ABORTED; break; }
          /* this attempt crosses a device restart with state: redo it from s0 with an exact scan */
          restarted = 1; b = -1;
          { void (*oa)(struct rt_dec *, void *) = d->on_attempt; d->on_attempt = NULL; rt_init_trackstate(d); d->on_attempt = oa; }
@@ -321,7 +321,7 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
       stats->events_delivered = rp.events_delivered; stats->agc_mismatches = rp.agc_mismatches;
       stats->blocks = d->numblks; stats->tapemarks = d->numtapemarks; stats->blocks_with_errors = d->numblks_err;
       stats->blocks_with_warnings = d->numblks_warn; stats->blocks_unusable = d->numblks_unusable; stats->all_ok = ok;
-      stats->data_bytes = d->numdatabytes; }
+      stats->data_bytes = d->numdatabytes; stats->device_failures = rp.device_failures; }
    if (d->tapf) fclose(d->tapf);
    if (d->logf) fclose(d->logf);
    if (rp.evtf) { fflush(rp.evtf); if (ftruncate(fileno(rp.evtf), ftell(rp.evtf))) {} fclose(rp.evtf); }

@@ -29,6 +29,7 @@ struct rt_replay {
    FILE   *evtf;                       /* optional dump of every delivered transition (oracle/ref_event_shim.c record format) */
    /* statistics */
    int64_t attempts, exact_scans, chained, events_delivered, agc_mismatches;
+   int64_t device_failures;            /* attempts the device could not deliver (exact scan refused / overflowed): the decode stops there */
 };
 
 int  rt_replay_readblock(void *ctx, int retry);
@@ -39,6 +40,7 @@ struct rt_replay_stats {
    int64_t attempts, exact_scans, chained, events_delivered, agc_mismatches;
    int32_t blocks, tapemarks, blocks_with_errors, blocks_with_warnings, blocks_unusable, all_ok;
    int64_t data_bytes;
+   int64_t device_failures;            /* > 0: the decode stopped early because the device could not deliver an attempt */
 };
 
 /* Decodes a whole scanned tape: builds a decoder for `opt` (+ `parmsets`, NULL = built-in sets), replays the

@@ -35,7 +35,7 @@ class _Stats(C.Structure):            # struct rt_replay_stats
                 ("events_delivered", C.c_int64), ("agc_mismatches", C.c_int64),
                 ("blocks", C.c_int32), ("tapemarks", C.c_int32), ("blocks_with_errors", C.c_int32),
                 ("blocks_with_warnings", C.c_int32), ("blocks_unusable", C.c_int32), ("all_ok", C.c_int32),
-                ("data_bytes", C.c_int64)]
+                ("data_bytes", C.c_int64), ("device_failures", C.c_int64)]
 
 
 _EXACT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_uint32),
@@ -82,15 +82,26 @@ def frontend_parmsets(full):
     return [(p.pkww_bitfrac, p.pkww_rise, p.min_peak, p.agc_alpha, p.agc_window, p.clk_factor) for p in full]
 
 
-def _exact_callbacks(fe, rows, ntrks):
+def _exact_callbacks(fe, rows, ntrks, fe_factory=None):
     """The callbacks through which the host replay asks for an exact device scan of one attempt (rtfe_scan_exact)."""
+    import dataclasses
     keep = {}
+    big = []                                          # a front end with room for an event every other row (noise): built on demand
 
     def exact(user, reset_row, end_row, parmset, burst_out, counts_out, events_out, cap_out):
         try:
             ex = fe.scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset).fetch()
             if int(ex.bursts[0]["flags"]) & frontend.F_SCREEN_UNDERFLOW:
                 ex = fe.scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset, screen_off=True).fetch()
+            if int(ex.bursts[0]["flags"]) & frontend.F_EVENT_OVERFLOW:
+                # far more events than a recording holds (e.g. noise above the dead band on a differentiated signal): the
+                # reference plods through them, so does the device - with event regions sized for the worst case
+                if not big:
+                    big.append((fe_factory or frontend.FrontEnd)(dataclasses.replace(fe.cfg, events_per_sample_cap=0.6)))
+                under = bool(int(ex.bursts[0]["flags"]) & frontend.F_SCREEN_UNDERFLOW)
+                ex = big[0].scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset, screen_off=under).fetch()
+                if int(ex.bursts[0]["flags"]) & frontend.F_SCREEN_UNDERFLOW and not under:
+                    ex = big[0].scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset, screen_off=True).fetch()
             B = ex.bursts[0]
             if int(B["flags"]) & (frontend.F_EVENT_OVERFLOW | frontend.F_DETECTOR_FATAL):
                 return 1
@@ -130,7 +141,7 @@ def calibrate_deskew(hdr, rows, full, o, fe_factory, invert=False, find_zeros=Fa
     while True:
         prefix = rows[:n0]
         res = fe0.scan(prefix).fetch()
-        exact, free, keep = _exact_callbacks(fe0, prefix, hdr.ntrks)
+        exact, free, keep = _exact_callbacks(fe0, prefix, hdr.ntrks, fe_factory)
         bursts = np.ascontiguousarray(res.bursts)
         counts = np.ascontiguousarray(res.counts)
         delays = (C.c_int * 19)()
@@ -169,7 +180,7 @@ def detect_density(hdr, rows, full, o, fe_factory, invert=False, log_path=None, 
     while True:
         prefix = rows[:n0]
         res = fe0.scan(prefix).fetch()
-        exact, free, keep = _exact_callbacks(fe0, prefix, hdr.ntrks)
+        exact, free, keep = _exact_callbacks(fe0, prefix, hdr.ntrks, fe_factory)
         bursts = np.ascontiguousarray(res.bursts)
         counts = np.ascontiguousarray(res.counts)
         bpi, implied, nblks, hit_end = C.c_float(0), C.c_float(0), C.c_int(0), C.c_int(0)
@@ -239,7 +250,7 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
                  multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
     parr = (_Parms * len(full))(*full)
     W = (C.c_int * len(full))(*fe.widths)
-    exact, free, keep = _exact_callbacks(fe, rows, hdr.ntrks)
+    exact, free, keep = _exact_callbacks(fe, rows, hdr.ntrks, fe_factory)
 
     st = _Stats()
     bursts = np.ascontiguousarray(res.bursts)
@@ -254,6 +265,9 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     if rc != 0:
         raise RuntimeError("rt_replay_run failed")
     stats = {k: getattr(st, k) for k, _ in _Stats._fields_}
+    if stats["device_failures"]:
+        raise RuntimeError(f"the device front end could not deliver {stats['device_failures']} attempt(s) (event regions overflowed even at "
+                           "their largest, or an exact rescan failed): the decode is incomplete")
     stats["bursts"] = res.nbursts
     stats["skew"] = list(skew) if skew is not None else None
     stats["bpi"] = cfg.bpi

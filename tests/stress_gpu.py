@@ -22,7 +22,8 @@ def e2e_check(hdr, rows, opts, wd):
         st, _ = pipeline.decode_tape(hdr, rows, os.path.join(wd, "g.tap"), log_path=os.path.join(wd, "g.log"), evt_path=os.path.join(wd, "g.evt"),
                                      opts=pipeline.DecodeOptions(multiple_tries="-m" in opts, correct="-correct" in opts, even_parity="-even" in opts), skew=skew, invert="-invert" in opts,
                                      find_zeros="-zeros" in opts, differentiate="-differentiate" in opts, deskew="-deskew" in opts,
-                                     subsample=next((int(a[11:]) for a in opts if a.startswith("-subsample=")), 1))
+                                     subsample=next((int(a[11:]) for a in opts if a.startswith("-subsample=")), 1),
+                                     fe_factory=(__import__("emul_util").emul_frontend if os.environ.get("STRESS_EMUL") else None))
     except RuntimeError as e:                                  # what is fatal in the reference (exit 99) must be fatal here too
         ok = p.returncode == 99 and ("no transitions" in str(e) or "non-standard" in str(e))
         return ([] if ok else [f"pipeline raised {e!r}, oracle rc {p.returncode}"]), {"events": 0, "speculative": None, "flags": None}
@@ -49,7 +50,7 @@ for i in range(ntapes):
     seed = int(rng.integers(1, 1 << 30))
     if kind == "nrzi":
         ntrks = int(rng.choice([9, 9, 7]))
-        tape = synth.nrzi_tape(seed=seed, nblocks=int(rng.integers(2, 9)), minlen=16, maxlen=int(rng.choice([200, 1200, 3000])),
+        tape = synth.nrzi_tape(seed=seed, nblocks=int(rng.integers(2, 9)), minlen=16, maxlen=int(rng.choice([200, 1200, 3000, 3000, 7000])),
                                marks_every=int(rng.choice([0, 3])), ntrks=ntrks, gap_samples=int(rng.choice([1500, 4000])), **kw)
         if ntrks == 7: opts.append("-ntrks=7")
         if rng.random() < 0.3: opts.append("-m")

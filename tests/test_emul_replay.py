@@ -77,3 +77,29 @@ def _noisy_pe_zeros_case(tmp_path, fe_factory):
 
 def test_zeros_excursions_without_events_are_history(tmp_path):
     _noisy_pe_zeros_case(tmp_path, emul_frontend)
+
+
+def _event_flood_case(tmp_path, fe_factory):
+    """-zeros -differentiate on a tape whose noise (80 mV rms) is above the differentiator's dead band: a confirmed crossing
+    on almost every other row, three times what the event regions are sized for.  The reference plods through them; the
+    pipeline must too (exact rescans with worst-case event regions), not stop quietly.  Found by tests/stress_gpu.py."""
+    import subprocess
+    import refdump
+    from parity_util import ORACLE, build_oracle
+    from readtape_amd import synth, tbin
+    build_oracle()
+    tape = synth.nrzi_tape(seed=615258906, nblocks=2, minlen=16, maxlen=200, ntrks=7, gap_samples=1500, amplitude=1.8, noise_mv=80.0, jitter=0.0)
+    hdr = tape.spec.header()
+    wd = str(tmp_path)
+    tbin.write_tbin(os.path.join(wd, "t.tbin"), hdr, tape.rows)
+    subprocess.run([ORACLE, "-v", f"-out={wd}/o", f"-evt={wd}/o.evt", "-ntrks=7", "-zeros", "-differentiate", os.path.join(wd, "t.tbin")], check=True)
+    st, res = pipeline.decode_tape(hdr, tape.rows, os.path.join(wd, "g.tap"), evt_path=os.path.join(wd, "g.evt"), find_zeros=True, differentiate=True,
+                                   fe_factory=fe_factory)
+    a, b = refdump.load(os.path.join(wd, "g.evt")), refdump.load(os.path.join(wd, "o.evt"))
+    assert not refdump.compare(a, b, ignore_fields=("v_avg_height",))
+    assert open(os.path.join(wd, "g.tap"), "rb").read() == open(os.path.join(wd, "o.tap"), "rb").read()
+    assert st["events_delivered"] > 0.2 * tape.rows.shape[0] * 7 and st["exact_scans"] > 0
+
+
+def test_event_floods_are_decoded_not_dropped(tmp_path):
+    _event_flood_case(tmp_path, emul_frontend)

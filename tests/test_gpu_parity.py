@@ -227,6 +227,11 @@ def test_time_shards_on_one_gpu_equal_the_whole_scan(kind, world, gpu):
     assert we.shape[0] > 10000
 
 
+def test_event_floods_are_decoded_not_dropped(tmp_path, gpu):
+    from test_emul_replay import _event_flood_case
+    _event_flood_case(tmp_path, None)
+
+
 def test_deskew_calibration_on_a_growing_prefix(tmp_path, gpu):
     """-deskew: the pre-pass scans a prefix of the tape and grows it until the reference's stopping rule is met inside
     it; whatever the first prefix size, delays and .tap are the reference's."""
