@@ -55,7 +55,7 @@ for i in range(ntapes):
         if ntrks == 7: opts.append("-ntrks=7")
         if rng.random() < 0.3: opts.append("-m")
         if rng.random() < 0.2: opts.append("-invert")
-        if rng.random() < 0.25 and ntrks == 9: opts.append("-skew=" + ",".join(str(int(x)) for x in rng.integers(0, 6, size=9)))
+        if rng.random() < 0.25 and ntrks == 9: opts.append("-skew=" + ",".join(str(int(x)) for x in rng.integers(0, int(rng.choice([6, 6, 20, 51])), size=9)))
         if rng.random() < 0.15 and "-m" not in opts: opts.append("-zeros")
         r = rng.random()
         if r < 0.08: opts.append("-differentiate")
@@ -65,7 +65,7 @@ for i in range(ntapes):
             tape.spec = dataclasses.replace(tape.spec, bpi=0.0); opts.append("(nobpi)")
         elif r < 0.32: opts.append("-correct")
         elif r < 0.38: opts.append("-even")
-        elif r < 0.44: opts.append("-subsample=2")
+        elif r < 0.44: opts.append("-subsample=" + str(int(rng.choice([2, 3]))))
     elif kind == "pe":
         tape = synth.pe_tape(seed=seed, nblocks=int(rng.integers(2, 5)), minlen=30, maxlen=int(rng.choice([200, 900])), gap_samples=3000, **kw)
         if rng.random() < 0.3: opts.append("-m")
@@ -75,6 +75,10 @@ for i in range(ntapes):
         tape = synth.gcr_tape(seed=seed, nblocks=int(rng.integers(2, 4)), minlen=40, maxlen=int(rng.choice([200, 900])), gap_samples=4000, **kw)
         if rng.random() < 0.3: opts.append("-m")
         if rng.random() < 0.3: opts.append("-correct")
+    if rng.random() < 0.15:                                     # ragged: a recording that starts and ends anywhere
+        import dataclasses
+        n = tape.rows.shape[0]; a, b = sorted(int(x) for x in rng.integers(0, n, size=2))
+        if b - a > 2000: tape = dataclasses.replace(tape, rows=np.ascontiguousarray(tape.rows[a:b]))
     hdr = tape.spec.header()
     # the segmented record walk and its join failures: random segment size / warm-up
     seg, warm = int(rng.choice([0, 8, 16, 48])), int(rng.choice([1, 3, 8]))
@@ -84,11 +88,11 @@ for i in range(ntapes):
         print(i, kind, "seed", seed, "amp", amp, "noise", noise, "jit", jit, "opts", opts, "seg", seg, warm, "rows", tape.rows.shape[0], "spec", tape.spec.bpi, flush=True)
         continue
     with tempfile.TemporaryDirectory() as wd:
-        att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2")) else []
+        att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3")) else []
         for rec in ("default", "1"):
             if rec == "1": os.environ["RTFE_RECORD_PATH"] = "1"
             else: os.environ.pop("RTFE_RECORD_PATH", None)
-            e2e = any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2"))
+            e2e = any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3"))
             if e2e: msgs, stats = e2e_check(hdr, tape.rows, [o for o in opts if o != "(nobpi)"], wd)
             else:
                 if os.environ.get("STRESS_EMUL"):
