@@ -12,17 +12,20 @@ import refdump, subprocess
 from parity_util import ORACLE, build_oracle
 build_oracle()
 
-def e2e_check(hdr, rows, opts, wd):
+def e2e_check(hdr, rows, opts, wd, parms_text=None):
     """-zeros: the device emits every confirmed crossing and the host replay applies the slope gate, so the comparison is
     end to end: .tap bytes and the stream of transitions the decoders were handed, against the oracle's."""
     tbin.write_tbin(os.path.join(wd, "t.tbin"), hdr, rows)
-    p = subprocess.run([ORACLE, "-v", f"-out={wd}/o", f"-evt={wd}/o.evt"] + opts + [os.path.join(wd, "t.tbin")], capture_output=True, text=True)
+    popt = []
+    if parms_text:
+        open(os.path.join(wd, "p.parms"), "w").write(parms_text); popt = [f"-parms={wd}/p.parms"]
+    p = subprocess.run([ORACLE, "-v", f"-out={wd}/o", f"-evt={wd}/o.evt"] + opts + popt + [os.path.join(wd, "t.tbin")], capture_output=True, text=True)
     skew = next(([int(x) for x in a[6:].split(",")] for a in opts if a.startswith("-skew=")), None)
     try:
         st, _ = pipeline.decode_tape(hdr, rows, os.path.join(wd, "g.tap"), log_path=os.path.join(wd, "g.log"), evt_path=os.path.join(wd, "g.evt"),
                                      opts=pipeline.DecodeOptions(multiple_tries="-m" in opts, correct="-correct" in opts, even_parity="-even" in opts), skew=skew, invert="-invert" in opts,
                                      find_zeros="-zeros" in opts, differentiate="-differentiate" in opts, deskew="-deskew" in opts,
-                                     subsample=next((int(a[11:]) for a in opts if a.startswith("-subsample=")), 1),
+                                     subsample=next((int(a[11:]) for a in opts if a.startswith("-subsample=")), 1), parms_text=parms_text,
                                      fe_factory=(__import__("emul_util").emul_frontend if os.environ.get("STRESS_EMUL") else None))
     except RuntimeError as e:                                  # what is fatal in the reference (exit 99) must be fatal here too
         ok = p.returncode == 99 and ("no transitions" in str(e) or "non-standard" in str(e))
@@ -75,6 +78,22 @@ for i in range(ntapes):
         tape = synth.gcr_tape(seed=seed, nblocks=int(rng.integers(2, 4)), minlen=40, maxlen=int(rng.choice([200, 900])), gap_samples=4000, **kw)
         if rng.random() < 0.3: opts.append("-m")
         if rng.random() < 0.3: opts.append("-correct")
+    parms_text = None
+    if rng.random() < 0.2:                                      # a .parms file with random front-end parameters (window 3..47 samples, either AGC flavour)
+        base = {"nrzi": [0, 0.2, None, None, None, 0, 0.3, None, None, 0.5, 0, 0], "pe": [0, 0.2, None, None, None, 1.5, 0.4, None, None, 0, 0, 0],
+                "gcr": [0, 0.015, None, None, None, 0, 0.3, None, None, 0, 1.45, 2.35]}[kind]
+        spb = {"nrzi": 19.5, "pe": 19.5, "gcr": 13.8}[kind]
+        lines = ["parms active, clk_window, clk_alpha, agc_window, agc_alpha, min_peak, clk_factor, pulse_adj, pkww_bitfrac, pkww_rise, midbit, z1pt, z2pt, id"]
+        for _ in range(int(rng.integers(1, 5)) if "-m" in opts else 1):
+            v = list(base)
+            if rng.random() < 0.5: v[2], v[3] = 0, float(rng.choice([0.2, 0.3, 0.5, 0.8]))
+            else: v[2], v[3] = int(rng.choice([1, 3, 5, 10])), 0.0
+            v[4] = float(rng.choice([0.0, 0.1, 0.2, 0.5, 1.0]))
+            v[7] = round(float(rng.choice([3, 5, 8, 9, 13, 20, 33, 47])) / spb + 0.01, 3)
+            v[8] = float(rng.choice([0.05, 0.1, 0.14, 0.2, 0.3]))
+            lines.append("{1, " + ", ".join(str(x) for x in v) + ", PRM}")
+        parms_text = "\n".join(lines) + "\n"
+        opts.append("(parms)")
     if rng.random() < 0.15:                                     # ragged: a recording that starts and ends anywhere
         import dataclasses
         n = tape.rows.shape[0]; a, b = sorted(int(x) for x in rng.integers(0, n, size=2))
@@ -88,12 +107,12 @@ for i in range(ntapes):
         print(i, kind, "seed", seed, "amp", amp, "noise", noise, "jit", jit, "opts", opts, "seg", seg, warm, "rows", tape.rows.shape[0], "spec", tape.spec.bpi, flush=True)
         continue
     with tempfile.TemporaryDirectory() as wd:
-        att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3")) else []
+        att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3")) else []
         for rec in ("default", "1"):
             if rec == "1": os.environ["RTFE_RECORD_PATH"] = "1"
             else: os.environ.pop("RTFE_RECORD_PATH", None)
-            e2e = any(o in opts for o in ("-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3"))
-            if e2e: msgs, stats = e2e_check(hdr, tape.rows, [o for o in opts if o != "(nobpi)"], wd)
+            e2e = any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3"))
+            if e2e: msgs, stats = e2e_check(hdr, tape.rows, [o for o in opts if o not in ("(nobpi)", "(parms)")], wd, parms_text)
             else:
                 if os.environ.get("STRESS_EMUL"):
                     from emul_util import emul_frontend
