@@ -51,11 +51,11 @@ void rt_default_parmsets(enum rt_mode mode, struct rt_parms out[RT_MAXPARMSETS])
 /* ---- .parms text: "parms name, name, ..." then "{ v, v, ..., PRM }" lines; "//" comments.
  * Unknown (obsolete) names are skipped with their values; names missing from the file take the
  * value of the FIRST built-in set in every parsed set (src/parmsets.c:311-327). ---- */
-struct pdesc { const char *name; int is_int; size_t off; };
-#define PD(n, i) {#n, i, offsetof(struct rt_parms, n)}
+struct pdesc { const char *name; int is_int; size_t off; float min, max; };      /* value ranges: src/parmsets.c:61-73 */
+#define PD(n, i, lo, hi) {#n, i, offsetof(struct rt_parms, n), lo, hi}
 static const struct pdesc PDESC[] = {
-   PD(active, 1), PD(clk_window, 1), PD(clk_alpha, 0), PD(agc_window, 1), PD(agc_alpha, 0), PD(min_peak, 0),
-   PD(clk_factor, 0), PD(pulse_adj, 0), PD(pkww_bitfrac, 0), PD(pkww_rise, 0), PD(midbit, 0), PD(z1pt, 0), PD(z2pt, 0) };
+   PD(active, 1, 0, 1), PD(clk_window, 1, 0, 50), PD(clk_alpha, 0, 0, 1), PD(agc_window, 1, 0, 10), PD(agc_alpha, 0, 0, 1), PD(min_peak, 0, 0, 5),
+   PD(clk_factor, 0, 0, 2), PD(pulse_adj, 0, 0, 1), PD(pkww_bitfrac, 0, 0, 2), PD(pkww_rise, 0, 0, 5), PD(midbit, 0, 0, 1), PD(z1pt, 0, 1, 2), PD(z2pt, 0, 2, 3) };
 #define NPDESC ((int)(sizeof PDESC / sizeof PDESC[0]))
 
 static void skipb(const char **p) { while (**p == ' ' || **p == '\t') ++*p; }
@@ -102,6 +102,9 @@ int rt_parse_parms_text(enum rt_mode mode, const char *text, struct rt_parms out
             char *end; float v = strtof(q, &end);
             if (end == q) return -1;
             q = end;
+            /* a value outside its range is fatal in the reference - also for a parameter the mode does not use, and 0..99 for
+             * names it no longer knows (src/parmsets.c:286-297) */
+            if (map[f] >= 0 ? (v < PDESC[map[f]].min || v > PDESC[map[f]].max) : (v < 0 || v > 99)) return -1;
             if (map[f] >= 0) {
                if (PDESC[map[f]].is_int) *(int *)((char *)s + PDESC[map[f]].off) = (int)v;
                else *(float *)((char *)s + PDESC[map[f]].off) = v; }

@@ -59,12 +59,29 @@ for i in range(ntapes):
         if r < 0.15: both("-zeros")
         elif r < 0.25: both("-differentiate")
         if rng.random() < 0.15: both("-deskew")
+    parms_text = None
+    if rng.random() < 0.25:                                     # a <basename>.parms file with random front-end parameters (src/parmsets.c:337-372)
+        base = {"nrzi": [0, 0.2, None, None, None, 0, 0.3, None, None, 0.5, 1.45, 2.35], "pe": [0, 0.2, None, None, None, 1.5, 0.4, None, None, 0, 1.45, 2.35],
+                "gcr": [0, 0.015, None, None, None, 0, 0.3, None, None, 0, 1.45, 2.35]}[kind]
+        spb = {"nrzi": 19.5, "pe": 19.5, "gcr": 13.8}[kind]
+        lines = ["parms active, clk_window, clk_alpha, agc_window, agc_alpha, min_peak, clk_factor, pulse_adj, pkww_bitfrac, pkww_rise, midbit, z1pt, z2pt, id"]
+        for _ in range(int(rng.integers(1, 5)) if "-m" in ref else 1):
+            v = list(base)
+            if rng.random() < 0.5: v[2], v[3] = 0, float(rng.choice([0.2, 0.3, 0.5, 0.8]))
+            else: v[2], v[3] = int(rng.choice([1, 3, 5, 10])), 0.0
+            v[4] = float(rng.choice([0.0, 0.1, 0.2, 0.5, 1.0]))
+            v[7] = min(2.0, round(float(rng.choice([3, 5, 8, 9, 13, 20, 27, 38])) / spb + 0.01, 3))        # (pkww_bitfrac <= 2, src/parmsets.c:69)
+            v[8] = float(rng.choice([0.05, 0.1, 0.14, 0.2, 0.3]))
+            lines.append("{1, " + ", ".join(str(x) for x in v) + ", PRM}")
+        parms_text = "\n".join(lines) + "\n"
     if rng.random() < 0.15:                                     # ragged: cut somewhere
         n = tape.rows.shape[0]; a, b = sorted(int(x) for x in rng.integers(0, n, size=2))
         if b - a > 50: tape = dataclasses.replace(tape, rows=np.ascontiguousarray(tape.rows[a:b]))
     with tempfile.TemporaryDirectory() as wd:
         tape.write(os.path.join(wd, "t.tbin"))
-        ropts = ["-v", "-tap", "-nolabels"] + ref + ([] if "-m" in ref else ["-nm"])
+        if parms_text:
+            open(os.path.join(wd, "t.parms"), "w").write(parms_text); ora.append(f"-parms={wd}/t.parms"); ref.append("(t.parms)")
+        ropts = ["-v", "-tap", "-nolabels"] + [o for o in ref if o != "(t.parms)"] + ([] if "-m" in ref else ["-nm"])
         pr = subprocess.run([REF] + ropts + ["t"], cwd=wd, env=dict(os.environ, RT_EVENT_DUMP=os.path.join(wd, "t.ref.evt")), capture_output=True, text=True)
         po = subprocess.run([ORA, "-v", f"-out={wd}/o", f"-evt={wd}/o.evt"] + ora + [os.path.join(wd, "t.tbin")], capture_output=True, text=True)
         msgs = []

@@ -80,7 +80,7 @@ for i in range(ntapes):
         if rng.random() < 0.3: opts.append("-correct")
     parms_text = None
     if rng.random() < 0.2:                                      # a .parms file with random front-end parameters (window 3..47 samples, either AGC flavour)
-        base = {"nrzi": [0, 0.2, None, None, None, 0, 0.3, None, None, 0.5, 0, 0], "pe": [0, 0.2, None, None, None, 1.5, 0.4, None, None, 0, 0, 0],
+        base = {"nrzi": [0, 0.2, None, None, None, 0, 0.3, None, None, 0.5, 1.45, 2.35], "pe": [0, 0.2, None, None, None, 1.5, 0.4, None, None, 0, 1.45, 2.35],
                 "gcr": [0, 0.015, None, None, None, 0, 0.3, None, None, 0, 1.45, 2.35]}[kind]
         spb = {"nrzi": 19.5, "pe": 19.5, "gcr": 13.8}[kind]
         lines = ["parms active, clk_window, clk_alpha, agc_window, agc_alpha, min_peak, clk_factor, pulse_adj, pkww_bitfrac, pkww_rise, midbit, z1pt, z2pt, id"]
@@ -89,7 +89,7 @@ for i in range(ntapes):
             if rng.random() < 0.5: v[2], v[3] = 0, float(rng.choice([0.2, 0.3, 0.5, 0.8]))
             else: v[2], v[3] = int(rng.choice([1, 3, 5, 10])), 0.0
             v[4] = float(rng.choice([0.0, 0.1, 0.2, 0.5, 1.0]))
-            v[7] = round(float(rng.choice([3, 5, 8, 9, 13, 20, 33, 47])) / spb + 0.01, 3)
+            v[7] = min(2.0, round(float(rng.choice([3, 5, 8, 9, 13, 20, 27, 38])) / spb + 0.01, 3))        # (pkww_bitfrac <= 2, src/parmsets.c:69)
             v[8] = float(rng.choice([0.05, 0.1, 0.14, 0.2, 0.3]))
             lines.append("{1, " + ", ".join(str(x) for x in v) + ", PRM}")
         parms_text = "\n".join(lines) + "\n"
