@@ -26,6 +26,13 @@ for i in range(ntapes):
         skc = tuple(float(x) for x in rng.choice([0.0, 0.1, 0.25, 0.4], size=ntrks)) if rng.random() < 0.3 else ()
         tape = synth.nrzi_tape(seed=seed, nblocks=int(rng.integers(1, 7)), minlen=8, maxlen=int(rng.choice([60, 300, 1500])), marks_every=int(rng.choice([0, 2])),
                                ntrks=ntrks, gap_samples=int(rng.choice([1200, 4000])), skew_cells=skc, **kw)
+        if rng.random() < 0.15:                                 # another digitiser: 12..31 samples per bit cell, another full scale
+            from readtape_amd import tbin as _tb
+            spec = synth.TapeSpec(mode=_tb.MODE_NRZI, ntrks=ntrks, bpi=800.0, ips=50.0, tdelta_ns=int(rng.choice([800, 1000, 1600, 2000])),
+                                  maxvolts=float(rng.choice([2.5, 4.4, 10.0])), pulse_w=0.22, seed=seed, **kw)
+            r2 = np.random.default_rng(seed + 1000)
+            items = [("block", pl) for pl in synth.random_payloads(r2, int(rng.integers(2, 6)), 16, int(rng.choice([200, 1200])), databits=ntrks - 1)]
+            tape = synth.make_tape(spec, items, gap_samples=int(3000 * 1280 / spec.tdelta_ns))
         ref += ["-nrzi", f"-ntrks={ntrks}"]
         if ntrks == 7: ora.append("-ntrks=7")
         if rng.random() < 0.3: both("-m")

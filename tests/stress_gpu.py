@@ -55,6 +55,13 @@ for i in range(ntapes):
         ntrks = int(rng.choice([9, 9, 7]))
         tape = synth.nrzi_tape(seed=seed, nblocks=int(rng.integers(2, 9)), minlen=16, maxlen=int(rng.choice([200, 1200, 3000, 3000, 7000])),
                                marks_every=int(rng.choice([0, 3])), ntrks=ntrks, gap_samples=int(rng.choice([1500, 4000])), **kw)
+        if rng.random() < 0.15:                                 # another digitiser: 12..31 samples per bit cell, another full scale
+            from readtape_amd import tbin as _tb
+            spec = synth.TapeSpec(mode=_tb.MODE_NRZI, ntrks=ntrks, bpi=800.0, ips=50.0, tdelta_ns=int(rng.choice([800, 1000, 1600, 2000])),
+                                  maxvolts=float(rng.choice([2.5, 4.4, 10.0])), pulse_w=0.22, seed=seed, **kw)
+            r2 = np.random.default_rng(seed + 1000)
+            items = [("block", pl) for pl in synth.random_payloads(r2, int(rng.integers(2, 6)), 16, int(rng.choice([200, 1200])), databits=ntrks - 1)]
+            tape = synth.make_tape(spec, items, gap_samples=int(3000 * 1280 / spec.tdelta_ns))
         if ntrks == 7: opts.append("-ntrks=7")
         if rng.random() < 0.3: opts.append("-m")
         if rng.random() < 0.2: opts.append("-invert")
