@@ -166,7 +166,9 @@ int main(int argc, char **argv) {
    if (d->opt.bpi == 0) {                                    /* src/readtape.c:1656-1672: density from the first transitions, then rewind */
       float implied; int nb, hit_end;
       ofe_save_pos(fe);
-      if (rt_density_prepass(d, &rd, &implied, &nb, &hit_end) == 0) {
+      const float found = rt_density_prepass(d, &rd, &implied, &nb, &hit_end);
+      if (found < 0) { fprintf(stderr, "density detection: a transition distance was not positive, or too many distinct ones\n"); return 99; }
+      if (found == 0) {
          fprintf(stderr, "The detected density of %.0f is non-standard; please specify it.\n", implied); return 99; }
       ofe_restore_pos(fe); }
    if (deskew && opt.mode != RT_PE && !skewarg) {            /* src/readtape.c:1675-1717: calibrate on the first blocks, then rewind */

@@ -163,7 +163,7 @@ struct rt_dec {
    /* density detection (src/decoder.c:329-394, src/readtape.c:1656-1672): while bpi is unknown every transition goes
     * to a histogram of transition distances instead of a block decoder */
    int     doing_density_detection;
-   struct { int deltas[RT_ESTDEN_NUMBINS], counts[RT_ESTDEN_NUMBINS], binsused, totalcount; } estden;
+   struct { int deltas[RT_ESTDEN_NUMBINS], counts[RT_ESTDEN_NUMBINS], binsused, totalcount, fatal; } estden;
    struct { int initialized; float leftbin, binwidth; int counts[RT_MAXTRKS][RT_PEAKSTAT_BUCKETS]; int trksums[RT_MAXTRKS]; } peakstat;
    /* optional observer: called at the top of every up/down transition, before the format callback
     * (the same seam oracle/ref_event_shim.c wraps in the reference) */
@@ -241,7 +241,8 @@ void rt_record_peakstat(struct rt_dec *d, float bitspacing, float peaktime, int 
 
 /* ---- density detection (src/readtape.c:1656-1672): reads attempts with bpi = 0 until RT_ESTDEN_COUNTNEEDED transition
  * distances are in the histogram (or the data ends), then picks the standard density.  Returns the density (d->opt.bpi
- * is set to it), 0 if the implied density is not close to a standard one (fatal in the reference); *implied = the raw
+ * is set to it), 0 if the implied density is not close to a standard one, -1 if a transition distance was not positive or the
+ * histogram ran out of bins (all three are fatal in the reference, src/decoder.c:355,362,397); *implied = the raw
  * estimate, *nblks = non-noise attempts read, *hit_end = the reader ran out of data first. */
 float rt_density_prepass(struct rt_dec *d, struct rt_reader *r, float *implied, int *nblks, int *hit_end);
 int  rt_deskew_prepass(struct rt_dec *d, struct rt_reader *r, int delays[RT_MAXTRKS], int *hit_end);

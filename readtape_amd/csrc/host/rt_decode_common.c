@@ -145,11 +145,12 @@ static void process_transition(struct rt_dec *d, struct rt_trk *t) {   /* src/de
 /* one transition distance into the histogram (src/decoder.c:351-367); returns 1 when enough have been seen */
 static int estden_transition(struct rt_dec *d, float deltasecs) {
    const int delta = (int)(deltasecs / 0.5e-6);                /* ESTDEN_BINWIDTH: float / double, truncated */
-   if (deltasecs > 0 && deltasecs <= 120e-6) {                 /* ESTDEN_MAXDELTA (a delta <= 0 is fatal in the reference) */
+   if (!(deltasecs > 0)) { d->estden.fatal = 1; return 1; }    /* "negative delta ... in estden_transition": fatal in the reference (:355) */
+   if (deltasecs > 0 && deltasecs <= 120e-6) {                 /* ESTDEN_MAXDELTA */
       int ndx = 0;
       while (ndx < d->estden.binsused && d->estden.deltas[ndx] != delta) ++ndx;
       if (ndx >= d->estden.binsused) {
-         if (d->estden.binsused >= RT_ESTDEN_NUMBINS) return d->estden.totalcount >= RT_ESTDEN_COUNTNEEDED;   /* (fatal there) */
+         if (d->estden.binsused >= RT_ESTDEN_NUMBINS) { d->estden.fatal = 1; return 1; }   /* "too many transition delta values": fatal (:362) */
          d->estden.deltas[d->estden.binsused++] = delta; }
       ++d->estden.counts[ndx];
       ++d->estden.totalcount; }

@@ -233,10 +233,12 @@ float rt_density_prepass(struct rt_dec *d, struct rt_reader *r, float *implied, 
       d->parmset = 0;
       rt_init_trackstate(d);
       if (!r->readblock(r->ctx, 1)) { *hit_end = 1; break; }
+      if (d->estden.fatal) break;
       if (d->results[d->parmset].blktype != RT_BS_NOISE) ++*nblks; }
    while (d->estden.totalcount < RT_ESTDEN_COUNTNEEDED);
    d->doing_density_detection = 0;
    d->interblock_counter = 0;
+   if (d->estden.fatal) return -1;
    /* the smallest transition distance seen at least 5 % of the time (ESTDEN_MINPERCENT) */
    int mindist = INT_MAX;
    for (int i = 0; i < d->estden.binsused; ++i)

@@ -190,9 +190,11 @@ def detect_density(hdr, rows, full, o, fe_factory, invert=False, log_path=None, 
                                    evt_path.encode() if evt_path else None, C.byref(bpi), C.byref(implied), C.byref(nblks), C.byref(hit_end))
         if rc != 0:
             raise RuntimeError("rt_replay_density failed")
-        if hit_end.value and n0 < nrows:
+        if hit_end.value and n0 < nrows and bpi.value >= 0:
             n0 = min(nrows, n0 * 4)
             continue
+        if bpi.value < 0:
+            raise RuntimeError("density detection met a non-positive transition distance (or too many distinct ones): non-standard input, fatal in the reference too; please specify bpi")
         if bpi.value == 0:
             raise RuntimeError(f"the detected density of {implied.value:.0f} BPI is non-standard; please specify it")
         return float(bpi.value)

@@ -84,6 +84,7 @@ for i in range(ntapes):
     if rng.random() < 0.15:                                     # ragged: cut somewhere
         n = tape.rows.shape[0]; a, b = sorted(int(x) for x in rng.integers(0, n, size=2))
         if b - a > 50: tape = dataclasses.replace(tape, rows=np.ascontiguousarray(tape.rows[a:b]))
+    if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != i: continue
     with tempfile.TemporaryDirectory() as wd:
         tape.write(os.path.join(wd, "t.tbin"))
         if parms_text:
@@ -107,6 +108,7 @@ for i in range(ntapes):
         tag = f"{i:3d} {kind} seed {seed} amp {amp} noise {noise} jit {jit} rows {tape.rows.shape[0]} bpi {tape.spec.bpi} ref {ref} rc {pr.returncode}"
         print(("FAIL " if msgs else "ok   ") + tag, flush=True)
         for m in msgs: print("     ", m[:300])
+        if msgs and os.environ.get("FUZZ_ONLY"): print(pr.stdout[-1500:]); print(pr.stderr[-500:]); print(parms_text); print(po.stderr[-300:])
         bad += bool(msgs)
 print(f"{ntapes - bad}/{ntapes} identical")
 sys.exit(1 if bad else 0)
