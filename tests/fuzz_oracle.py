@@ -66,6 +66,13 @@ for i in range(ntapes):
         if r < 0.15: both("-zeros")
         elif r < 0.25: both("-differentiate")
         if rng.random() < 0.15: both("-deskew")
+    if rng.random() < 0.2:                                      # dropouts: stretches of a track at a fraction of its amplitude (AGC at its clamp,
+        import dataclasses                                       # thresholds below the candidate screen, PE fake bits, NRZI corrections)
+        rows2 = tape.rows.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            t0 = int(rng.integers(0, rows2.shape[1])); a = int(rng.integers(0, max(1, rows2.shape[0] - 200))); b = min(rows2.shape[0], a + int(rng.choice([200, 800, 3000])))
+            rows2[a:b, t0] = (rows2[a:b, t0].astype(np.float32) * float(rng.choice([0.5, 0.25, 0.1, 0.0]))).astype(np.int16)
+        tape = dataclasses.replace(tape, rows=rows2)
     parms_text = None
     if rng.random() < 0.25:                                     # a <basename>.parms file with random front-end parameters (src/parmsets.c:337-372)
         base = {"nrzi": [0, 0.2, None, None, None, 0, 0.3, None, None, 0.5, 1.45, 2.35], "pe": [0, 0.2, None, None, None, 1.5, 0.4, None, None, 0, 1.45, 2.35],

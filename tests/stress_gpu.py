@@ -1,7 +1,7 @@
 """GPU box helper: randomized parity sweep (device events vs the CPU oracle) over tape parameters the committed tests do
 not pin: amplitudes, noise, jitter, track counts, skews, parameter-set sweeps.  Prints one line per tape; exits non-zero
 on the first mismatch."""
-import os, sys, tempfile
+import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (this file lives in tests/: it runs the oracle, which only tests may)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
@@ -68,7 +68,13 @@ for i in range(ntapes):
         if rng.random() < 0.25 and ntrks == 9: opts.append("-skew=" + ",".join(str(int(x)) for x in rng.integers(0, int(rng.choice([6, 6, 20, 51])), size=9)))
         if rng.random() < 0.15 and "-m" not in opts: opts.append("-zeros")
         r = rng.random()
-        if r < 0.08: opts.append("-differentiate")
+        if r < 0.08:
+            opts.append("-differentiate")
+            # (peak detection on the differentiated signal with noise above the dead band is one sequential burst per
+            #  attempt - exact but slow, DESIGN.md §8: keep those tapes short and single-set so a sweep stays in minutes)
+            if "-zeros" not in opts and noise >= 10.0:
+                if "-m" in opts: opts.remove("-m")
+                tape = synth.nrzi_tape(seed=seed, nblocks=2, minlen=16, maxlen=200, ntrks=ntrks, gap_samples=1500, **kw)
         elif r < 0.16 and not any(o.startswith("-skew") for o in opts) and "-zeros" not in opts: opts.append("-deskew")
         elif r < 0.24 and "-zeros" not in opts:
             import dataclasses
@@ -85,6 +91,13 @@ for i in range(ntapes):
         tape = synth.gcr_tape(seed=seed, nblocks=int(rng.integers(2, 4)), minlen=40, maxlen=int(rng.choice([200, 900])), gap_samples=4000, **kw)
         if rng.random() < 0.3: opts.append("-m")
         if rng.random() < 0.3: opts.append("-correct")
+    if rng.random() < 0.2:                                      # dropouts: stretches of a track at a fraction of its amplitude (AGC at its clamp,
+        import dataclasses                                       # thresholds below the candidate screen, PE fake bits, NRZI corrections)
+        rows2 = tape.rows.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            t0 = int(rng.integers(0, rows2.shape[1])); a = int(rng.integers(0, max(1, rows2.shape[0] - 200))); b = min(rows2.shape[0], a + int(rng.choice([200, 800, 3000])))
+            rows2[a:b, t0] = (rows2[a:b, t0].astype(np.float32) * float(rng.choice([0.5, 0.25, 0.1, 0.0]))).astype(np.int16)
+        tape = dataclasses.replace(tape, rows=rows2)
     parms_text = None
     if rng.random() < 0.2:                                      # a .parms file with random front-end parameters (window 3..47 samples, either AGC flavour)
         base = {"nrzi": [0, 0.2, None, None, None, 0, 0.3, None, None, 0.5, 1.45, 2.35], "pe": [0, 0.2, None, None, None, 1.5, 0.4, None, None, 0, 1.45, 2.35],
@@ -116,6 +129,7 @@ for i in range(ntapes):
     with tempfile.TemporaryDirectory() as wd:
         att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3")) else []
         for rec in ("default", "1"):
+            t_case = time.perf_counter()
             if rec == "1": os.environ["RTFE_RECORD_PATH"] = "1"
             else: os.environ.pop("RTFE_RECORD_PATH", None)
             e2e = any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3"))
@@ -127,7 +141,7 @@ for i in range(ntapes):
                 else: fe = frontend.FrontEnd(config_for(hdr, opts))
                 msgs, stats = check_tape(fe, hdr, tape.rows, att)
             tag = f"{i:3d} {kind} seed {seed} amp {amp} noise {noise} jit {jit} opts {opts} seg {seg}/{warm} record_path {rec}: attempts {len(att)} events {stats['events']} speculative {stats.get('speculative')} flags {stats.get('flags')}"
-            print(("FAIL " if msgs else "ok   ") + tag, flush=True)
+            print(("FAIL " if msgs else "ok   ") + tag + f" [{time.perf_counter() - t_case:.1f} s]", flush=True)
             if msgs:
                 print("\n".join(msgs[:6]))
                 bad += 1
