@@ -478,7 +478,8 @@ __device__ __forceinline__ void store_event(const Ctx &cx, int pidx, int trk, un
                                    bool is_top, int adjcode, int left_distance) {
    rtfe_event e;
    e.sample = (uint32_t)(n - cx.tile.reset);
-   e.v_peak = val;
+   // -invert negates the VOLTAGE (src/readtape.c:1421): a zero sample is -0.0f there (the differentiator's dead band makes it +0 again)
+   e.v_peak = (cx.cfg->invert && !cx.cfg->differentiate && val == 0.0f) ? -0.0f : val;
    e.agc_gain = g;
    e.trk = (uint8_t)trk;
    e.flags = (uint8_t)((is_top ? 0 : 1) | (adjcode << 1));
@@ -749,7 +750,7 @@ __device__ __forceinline__ void zc_event(const Ctx &cx, int trk, unsigned int id
    const unsigned int delay = (unsigned int)(n - cross);
    rtfe_event e;
    e.sample = (uint32_t)(n - cx.tile.reset);
-   e.v_peak = volt(v, cx.cfg->maxvolts);
+   e.v_peak = (cx.cfg->invert && v == 0) ? -0.0f : volt(v, cx.cfg->maxvolts);
    e.agc_gain = __uint_as_float(delay);
    e.trk = (uint8_t)trk;
    e.flags = (uint8_t)(up ? 0 : 1);
