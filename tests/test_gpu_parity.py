@@ -66,6 +66,27 @@ def test_segmented_record_walk(knobs, tmp_path, gpu, monkeypatch):
     assert stats["speculative"] == len(att) and stats["flags"] == 0
 
 
+def test_long_blocks_segmented_walk_equals_whole_burst_walk(gpu, monkeypatch):
+    """32 KB blocks (1 250 tiles each): the default segmented record walk (13 concurrent segments per block, joined by
+    k_stitch) and the whole-burst walk (RTFE_SEG_TILES=0) must produce the same bursts, counts and events, byte for byte."""
+    import torch
+    tape = synth.nrzi_tape(seed=35, nblocks=5, minlen=30000, maxlen=32768, gap_samples=6000)
+    hdr = tape.spec.header()
+    rows = torch.from_numpy(tape.rows).cuda()
+    out = []
+    for seg in (None, "0"):
+        if seg is None: monkeypatch.delenv("RTFE_SEG_TILES", raising=False)
+        else: monkeypatch.setenv("RTFE_SEG_TILES", seg)
+        fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr))
+        out.append(fe.scan(rows).fetch())
+    a, b = out
+    assert a.nbursts == b.nbursts >= 5 and (a.counts == b.counts).all() and (a.bursts["flags"] == b.bursts["flags"]).all()
+    for i in range(a.nbursts):
+        for t in range(hdr.ntrks):
+            assert a.events(i, 0)[a.events(i, 0)["trk"] == t].tobytes() == b.events(i, 0)[b.events(i, 0)["trk"] == t].tobytes()
+    assert int(a.counts.sum()) > 500_000
+
+
 @pytest.mark.parametrize("seed,nblocks,maxlen", [(21, 12, 600), (22, 30, 2000), (23, 6, 4096)])
 def test_fresh_nrzi_tapes(seed, nblocks, maxlen, tmp_path, gpu):
     tape = synth.nrzi_tape(seed=seed, nblocks=nblocks, minlen=16, maxlen=maxlen, marks_every=5, gap_samples=4000)
