@@ -162,6 +162,11 @@ int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_
 int rtfe_set_timing(rtfe_handle *h, int enable);
 int rtfe_kernel_ms(rtfe_handle *h, float *out);
 
+/* Statistics of the most recent rtfe_scan that used d_workspace (synchronous, call after the stream has finished):
+ * out[0] = bursts decoded, out[1] = of which the record chains handed to the exact sample path, out[2] = bytes of peak
+ * records written.  Diagnostics for bench.py and the tests; no effect on results. */
+int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out);
+
 /* Names and launch-order of the kernels of one scan, for profilers (static strings). */
 int         rtfe_kernel_count(void);
 const char *rtfe_kernel_name(int i);

@@ -12,7 +12,9 @@
 #include "rt_frontend.h"
 #include "rtfe_device.h"
 
-#include "rtfe_kernels.hip"   // single translation unit: kernels + host API
+#include "rtfe_peaks.hip"     // single translation unit: kernels + host API
+#include "rtfe_kernels.hip"
+#include "rtfe_chain.hip"
 
 namespace rtfe {
 __global__ void k_setup_exact(rtfe_burst *burst, BurstScratch *scratch, long long reset_row, long long end_row,
@@ -33,7 +35,7 @@ struct rtfe_handle {
    int lds_bytes;
    int num_cus;
    int timing;
-   hipEvent_t ev0[6], ev1[6];          // start / stop of each kernel of the last scan (on the stream it ran on)
+   hipEvent_t ev0[8], ev1[8];          // start / stop of each kernel of the last scan (on the stream it ran on)
    int screen_lds_bytes;
    int walk_lds_bytes;
 };
@@ -47,8 +49,9 @@ extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
 // the kernels of one rtfe_scan, in launch order (k_decode runs twice: burst heads, then whatever k_walk gave back)
-static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_screen", "k_decode_head", "k_walk", "k_decode_resume"};
-constexpr int kNumKernels = 6;
+// (the peak-record path fills k_peaks [quiet map included], k_bursts, k_chain [k_zones + k_chain + k_publish] and k_decode_resume [bursts redone on the samples])
+static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_screen", "k_decode_head", "k_walk", "k_decode_resume", "k_peaks", "k_chain"};
+constexpr int kNumKernels = 8;
 extern "C" int rtfe_kernel_count(void) { return kNumKernels; }
 extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < kNumKernels) ? KNAMES[i] : ""; }
 
@@ -119,6 +122,16 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       float q = ps.min_peak > ps.pkww_rise / 2 ? ps.min_peak : ps.pkww_rise / 2;
       if (q < quiet_v) quiet_v = q; }
    for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].minpk_i < 0) d.screen[s].minpk_i = -1;
+   // k_peaks: a row whose margin reaches sure_i passes the rise test for every threshold the chains accept without asking
+   // (tightest: baseline 1.5 x full scale at half gain); k_chain hands a burst whose threshold climbs beyond that to the sample path
+   for (int s = 0; s < d.nscreens; ++s) {
+      float hi_v = 0;
+      for (int p = 0; p < c->nparmsets; ++p) if (d.parm[p].screen == s) { const float v = c->parmset[p].pkww_rise * (1.5f * c->maxvolts / 4.0f) / 0.5f; if (v > hi_v) hi_v = v; }
+      long long si = (long long)ceil((double)hi_v * lsb_per_volt) + 3;
+      if (si > 65535) si = 65535;
+      if (si <= d.screen[s].rise_i + 1) si = d.screen[s].rise_i + 2;
+      d.screen[s].sure_i = (int)si;
+      d.screen[s].nb = d.screen[s].W <= 18 ? 4 : (d.screen[s].W <= 34 ? 8 : 12); }
    if (d.find_zeros) {
       // the zero-crossing detector has no amplitude feedback and no parameter-set dependence (adjust_agc returns
       // at once, src/decoder.c:501): one walker per track; nothing can become pending while |v| <= 0.2 V
@@ -143,7 +156,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    const int spb = (int)(1 / (bpi_s * c->ips * d.sample_deltat));
    int gap = c->gap_min_samples > 0 ? c->gap_min_samples : 32 * (spb > 0 ? spb : 1);
    if (gap < kMarginRows + 128) gap = kMarginRows + 128;
-   d.gap_chunks = (int)(((long long)gap * c->ntrks * 2 + 1023) / 1024) + 1;
+   d.gap_chunks = (gap + kChunkRows - 1) / kChunkRows + 1;                 // quiet-map chunks are groups of 64 rows
    d.seg_tiles = 48;                                                  // the record walk of a long block runs as concurrent segments of 48 tiles
    d.seg_warm = kSegWarmup;
    d.zc_parallel = 1;
@@ -174,6 +187,32 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
    d.cut = getenv("RTFE_CUT") ? atoi(getenv("RTFE_CUT")) : 0;
+   {  // the peak-record path (k_peaks -> k_chain): every peak-detection scan on the undifferentiated signal
+      d.peak_path = !d.find_zeros && !d.differentiate;
+      if (const char *e = getenv("RTFE_PEAK_PATH")) d.peak_path = d.peak_path && atoi(e) != 0;
+      d.pk_parallel = 1;
+      if (const char *e = getenv("RTFE_CHAIN_PARALLEL")) d.pk_parallel = atoi(e) != 0;
+      int wmax = 0, nbmax = 0;
+      for (int sidx = 0; sidx < d.nscreens; ++sidx) { if (d.screen[sidx].W > wmax) wmax = d.screen[sidx].W; if (d.screen[sidx].nb > nbmax) nbmax = d.screen[sidx].nb; }
+      const int xb = (nbmax + 3) / 4;
+      int hl = kPkBack + 2 * wmax + 6; if (hl < 16 * xb + 16) hl = 16 * xb + 16;
+      int hr = wmax + 2;               if (hr < 16 * xb) hr = 16 * xb;
+      d.pk_hl = (hl + 15) & ~15; d.pk_hr = (hr + 15) & ~15;
+      // staging: flux transitions per tile from the bit cell (PE: up to two per cell), both polarities, all tracks, plus noise candidates
+      const float spbf = 1.0f / (bpi_s * c->ips * d.sample_deltat);
+      const float ppb = c->mode == RTFE_PE ? 2.0f : 1.0f;
+      int cand = (int)((float)kPkTile / (spbf > 2 ? spbf : 2) * ppb * (float)c->ntrks * 1.5f) + 192;
+      // a screen below the noise floor (small pkww_rise at the assumed baseline floor) makes candidates of noise wiggles: up to a third of all samples
+      int lo_min = 1 << 30;
+      for (int sidx = 0; sidx < d.nscreens; ++sidx) if (d.screen[sidx].rise_i < lo_min) lo_min = d.screen[sidx].rise_i;
+      const bool noisy_screen = (double)lo_min / lsb_per_volt < 0.03;
+      if (noisy_screen && cand < 2 * kPkTile) cand = 2 * kPkTile;          // (a tile's heads go through the staging area in groups; one head always fits)
+      if (cand < kPkTile + 64) cand = kPkTile + 64;
+      if (cand > 4096) cand = 4096;
+      if (const char *e = getenv("RTFE_PK_CAND_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 4096) cand = v; }      // (tests: force the capacity path)
+      d.pk_cand_cap = cand; d.pk_rec_cap = noisy_screen ? cand + 64 : cand + cand / 4 + 16; d.pk_ent_cap = d.pk_rec_cap * (noisy_screen ? 6 : 3);      // (noise runs never reach the sure level: every row explicit)
+      d.pk_lds = (int)pk_lds_layout(c->ntrks, d.pk_hl, d.pk_hr, nbmax, d.pk_cand_cap, d.pk_rec_cap, d.pk_ent_cap).total + 64;
+      if (d.pk_lds > 150 * 1024) d.peak_path = 0; }
    {
       const int nwalk = c->nparmsets * c->ntrks;
       int rc = (24 * 1024) / (nwalk * 24);
@@ -212,7 +251,9 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (getenv("RTFE_VERBOSE")) {
       const LdsLayout Ld = lds_layout(d, true);
       fprintf(stderr, "rtfe: LDS k_decode %d (tile..bits %u, bits..ldpos %u, ldpos..heights %u, recs %u, walkers %u) k_screen %d\n", h->lds_bytes, Ld.bits, Ld.ldpos - Ld.bits,
-              Ld.heights - Ld.ldpos, Ld.nrec - Ld.recs, Ld.walkers_next - Ld.walkers, h->screen_lds_bytes); }
+              Ld.heights - Ld.ldpos, Ld.nrec - Ld.recs, Ld.walkers_next - Ld.walkers, h->screen_lds_bytes);
+      fprintf(stderr, "rtfe: peak path %d, k_peaks LDS %d (halo %d/%d rows, caps %d/%d/%d)\n", d.peak_path, d.pk_lds, d.pk_hl, d.pk_hr, d.pk_cand_cap, d.pk_rec_cap, d.pk_ent_cap);
+      for (int sidx = 0; sidx < d.nscreens; ++sidx) fprintf(stderr, "rtfe: screen %d W %d rise_i %d minpk_i %d sure_i %d nb %d\n", sidx, d.screen[sidx].W, d.screen[sidx].rise_i, d.screen[sidx].minpk_i, d.screen[sidx].sure_i, d.screen[sidx].nb); }
    hipDeviceProp_t prop;
    int dev = 0;
    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return fail(-20, "no HIP device"); }
@@ -223,6 +264,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen), hipFuncAttributeMaxDynamicSharedMemorySize, h->screen_lds_bytes);
    h->walk_lds_bytes = (int)lds_layout_walk(d).total + 64;
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, h->walk_lds_bytes);
+   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_peaks), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
    *out = h;
    return 0; }
 
@@ -250,8 +292,9 @@ extern "C" int rtfe_pkww_width(const rtfe_handle *h, int parmset) {
    return (h && parmset >= 0 && parmset < h->dev.nparm) ? h->dev.parm[parmset].W : -1; }
 
 static long long nwords_for(const rtfe_handle *h, int64_t nrows) {
-   const long long nchunks = (nrows * h->dev.ntrks) / 512 + 1;
-   return (nchunks + 63) / 64; }
+   (void)h;
+   const long long nchunks = nrows / kChunkRows + 1;
+   return (nchunks + 63) / 64 + 1; }
 
 static long long ntiles_for(const rtfe_handle *h, int64_t nrows) { return (nrows + h->dev.tile_rows - 1) / h->dev.tile_rows; }
 static long long pool_cap_for(const rtfe_handle *h, int64_t nrows) {       // a fixed slot of run_cap records per (tile, screen, track)
@@ -263,7 +306,7 @@ static size_t ws_pool_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_dir_off(h, nrows) + (size_t)ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(TileDir) + 255) & ~(size_t)255; }
 
 extern "C" int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows) {
-   return (nrows * h->dev.ntrks / 512) / h->dev.gap_chunks + 4; }
+   return (nrows / kChunkRows) / h->dev.gap_chunks + 4; }
 
 // ... | burst control blocks | walker states (hand-over between k_decode and k_walk)
 static size_t ws_ctl_off(const rtfe_handle *h, int64_t nrows) {
@@ -282,8 +325,21 @@ static size_t ws_segstart_off(const rtfe_handle *h, int64_t nrows) { return (ws_
 static size_t ws_segend_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_segstart_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
 
+// ... | peak-record path: directory of the tiles' own lists | of the lists spilled into them | record pool
+static long long pk_tiles_for(int64_t nrows) { return (nrows + kPkTile - 1) / kPkTile; }
+static size_t ws_pkdir_off(const rtfe_handle *h, int64_t nrows) {
+   return (ws_segend_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
+static size_t pk_dir_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)(pk_tiles_for(nrows) + 1) * h->dev.nscreens * h->dev.ntrks * sizeof(PeakDir) + 255) & ~(size_t)255; }
+static size_t ws_pkpool_off(const rtfe_handle *h, int64_t nrows) { return ws_pkdir_off(h, nrows) + (h->dev.peak_path ? 2 * pk_dir_bytes(h, nrows) : 0); }
+static size_t pk_pool_bytes(const rtfe_handle *h, int64_t nrows) {
+   if (!h->dev.peak_path) return 0;
+   // ~12 bytes per flux transition and screen (8-byte record + two margins), twice that for noise and weak peaks
+   const double spb = 1.0 / ((h->dev.agc_off ? 1.0 / (h->cfg.ips * ((double)h->cfg.tdelta_ns / 1e9) * 12.0) : (double)h->cfg.bpi) * h->cfg.ips * ((double)h->cfg.tdelta_ns / 1e9));
+   const double per_row = (h->dev.mode == RTFE_PE ? 2.0 : 1.0) / (spb > 2 ? spb : 2) * h->dev.ntrks * 24.0 * h->dev.nscreens;
+   return (((size_t)((double)nrows * per_row) + (size_t)pk_tiles_for(nrows) * 32 + (1u << 20)) + 255) & ~(size_t)255; }
+
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_segend_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 256; }
+   return ws_pkpool_off(h, nrows) + pk_pool_bytes(h, nrows) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -304,8 +360,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (nrows <= 0 || max_bursts < 1) return fail(-33, "nothing to scan");
    if (own_rows <= 0 || own_rows > nrows) return fail(-35, "own_rows must be in (0, nrows]");
    hipStream_t st = (hipStream_t)stream;
-   const long long nelem = (long long)nrows * h->dev.ntrks;
-   const long long nchunks = nelem / 512;
+   const long long nchunks = nrows / kChunkRows;                      // complete groups of 64 rows
    const long long nwords = nwords_for(h, nrows);
    BurstScratch *scratch = reinterpret_cast<BurstScratch *>(d_workspace);
    unsigned long long *qwords = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_workspace) + kScratchBytes);
@@ -341,8 +396,42 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    hipStream_t sq = st;
    auto t0 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev0[k], s2); };
    auto t1 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev1[k], s2); };
+   if (h->dev.peak_path) {
+      // ---- the peak-record path: k_peaks (quiet map + records) -> k_bursts -> k_zones -> k_chain -> k_publish -> whatever the chains gave up ----
+      PeakDir *dirm = reinterpret_cast<PeakDir *>(wsb + ws_pkdir_off(h, nrows));
+      PeakDir *dirs = reinterpret_cast<PeakDir *>(wsb + ws_pkdir_off(h, nrows) + pk_dir_bytes(h, nrows));
+      unsigned char *pkpool = reinterpret_cast<unsigned char *>(wsb + ws_pkpool_off(h, nrows));
+      const unsigned long long pool_units = pk_pool_bytes(h, nrows) / 16;
+      const long long ptiles = pk_tiles_for(nrows);
+      (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
+      t0(0, st); t1(0, st); t0(2, st); t1(2, st); t0(3, st); t1(3, st); t0(4, st); t1(4, st);
+      t0(6, st);
+      const int pthreads = 64 * ((h->dev.ntrks + 1) / 2 + 1);
+      const long long pgrid = ((ptiles + 7) / 8) * 8;
+      hipLaunchKernelGGL(k_peaks, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, h->d_dev, d_rows, (long long)nrows, ptiles,
+                         reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pool_units, &scratch->pool_cursor, 0, (const unsigned int *)deadp);
+      t1(6, st); t0(1, st);
+      hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
+                         h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
+                         d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts,
+                         deadp, ptiles, (int)kPkTile, h->dev.tail_rows);
+      t1(1, st); t0(7, st);
+      hipLaunchKernelGGL(k_peaks, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, h->d_dev, d_rows, (long long)nrows, ptiles,
+                         reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pool_units, &scratch->pool_cursor, 1, (const unsigned int *)deadp);
+      hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
+                         (const BurstScratch *)scratch, ctlp);
+      hipLaunchKernelGGL(k_chain, dim3(h->num_cus * 16), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+                         scratch, ctlp, d_counts, d_events, (const PeakDir *)dirm, (const PeakDir *)dirs, (const unsigned char *)pkpool, ptiles);
+      hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
+      t1(7, st); t0(5, st);
+      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
+                         (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeRedo, ctlp, statep);
+      t1(5, st);
+      return launch_check("rtfe_scan"); }
+   t0(6, sq); t1(6, sq); t0(7, sq); t1(7, sq);
    t0(0, sq);
-   hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, sq, d_rows, nelem, h->dev.quiet_i, qwords, nwords);
+   hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, sq, d_rows, (long long)nrows, h->dev.ntrks, h->dev.quiet_i, qwords, nwords);
    t1(0, sq); t0(1, sq);
    hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, sq, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
@@ -402,6 +491,14 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                          (const TileDir *)dirp, (const CandUnit *)poolp, (int)kDecodeResume, ctlp, statep);
       t1(5, st); }
    return launch_check("rtfe_scan"); }
+
+// Synchronous (copies three words back): what the last rtfe_scan on this workspace did.
+extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out) {
+   if (!h || !d_workspace || !out) return fail(-1, "null argument");
+   BurstScratch sc;
+   if (hipMemcpy(&sc, d_workspace, sizeof sc, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
+   out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.pool_cursor * 16;
+   return 0; }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,
                                int64_t reset_row, int64_t end_row, uint32_t parmset_mask, int screen_off,

@@ -1,0 +1,302 @@
+// rtfe_chain.hip — the sparse half of the peak-record path: k_zones, k_chain, k_publish (see rtfe_peaks.hip).
+// Included behind rtfe_kernels.hip (it reuses the walker state, the AGC mirror and the threshold code of the sample path).
+
+namespace rtfe {
+
+// ------------------------------------------------------------------------------------------------
+// k_zones: where every burst restarts.  For a zone-started burst: per (window width, track) the last forced rescan
+// (the sample leaving the window is its maximum and the entering one does not exceed it, src/decoder.c:763-767) inside the zone's last kMarginRows rows; a restart
+// at or before (that row - W - max(trk, skew) - 2) has a full, regular window when the rescan happens.
+// One wave per burst, a lane per (screen, track); the samples come straight from HBM (a zone's tail is 4.6 KB).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_zones(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
+                                              const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl) {
+   const DevCfg &cfg = *cfgp;
+   const int ntrks = cfg.ntrks;
+   const int nb = scratch->nbursts_total;
+   for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+      const rtfe_burst B = bursts[b];
+      long long reset;
+      unsigned int bflags = B.flags;
+      int status = kBurstReady;
+      if (B.flags & RTFE_F_EXACT_START) { reset = B.reset_sample; status = kBurstNeedsFull; }      // the window fills on live signal: sample path
+      else if (B.zone_end - B.zone_first < kMarginRows + 64) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; status = kBurstNeedsFull; }
+      else {
+         const long long z0 = B.zone_end - kMarginRows;
+         long long lo = 0x7fffffffffffffffll;
+         for (int i = threadIdx.x; i < cfg.nscreens * ntrks; i += 64) {
+            const int sc = i / ntrks, t = i - sc * ntrks;
+            const int W = cfg.screen[sc].W, d = cfg.skew[t], col = cfg.trk_to_head[t];
+            const int sgn = cfg.invert ? -1 : 1;
+            long long a = -1;
+            for (long long n = B.zone_end - 1; n >= z0; --n) {                 // detector row n reads sample n - d of the column
+               const long long s = n - d - W;
+               if (s < 0) break;
+               const int v = sgn * (int)rows[s * ntrks + col];
+               bool dom = true;
+               for (int k = 1; k <= W; ++k) if (sgn * (int)rows[(s + k) * ntrks + col] > v) { dom = false; break; }      // (incl. the entering sample: src/decoder.c:763-767)
+               if (dom) { a = n; break; } }
+            long long hi = a < 0 ? -1 : a - W - max(t, d) - 2;
+            if (hi < z0) hi = -1;
+            lo = min(lo, hi); }
+         #pragma unroll
+         for (int o = 32; o >= 1; o >>= 1) {
+            const int l2 = __shfl((int)(lo & 0xffffffffll), (threadIdx.x + o) & 63), h2 = __shfl((int)(lo >> 32), (threadIdx.x + o) & 63);
+            const long long other = ((long long)h2 << 32) | (unsigned int)l2;
+            lo = min(lo, other); }
+         if (lo < 0 || lo < B.zone_first) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; status = kBurstNeedsFull; }
+         else reset = lo; }
+      if (threadIdx.x == 0) {
+         BurstCtl c; c.reset = reset; c.stop = 0; c.next_tile = 0; c.status = status; c.bflags = bflags; c.pad = 0;
+         ctl[b] = c; } } }
+
+// where burst b stops: the next burst's restart row, but no further than tail_rows into its quiet zone
+__device__ __forceinline__ long long chain_stop(const DevCfg &cfg, const rtfe_burst *bursts, const BurstCtl *ctl, int b, int nb_total, long long nrows) {
+   if (b + 1 >= nb_total) return nrows;
+   long long stop = ctl[b + 1].reset;
+   const long long zf = bursts[b + 1].zone_first;
+   if (cfg.tail_rows > 0 && zf + cfg.tail_rows < stop) stop = zf + cfg.tail_rows;
+   return stop; }
+
+// ------------------------------------------------------------------------------------------------
+// k_chain
+// ------------------------------------------------------------------------------------------------
+constexpr int kChRecCap = 384;        // records of one tile's list (own + spilled) a wave keeps in LDS
+constexpr int kChEntCap = 2048;
+
+struct Run {
+   long long pos, f;                 // column rows
+   int nlead, nsure, ntail, val, dprev, dnext, e0;
+   bool top, unknown; };
+
+__device__ __forceinline__ Run run_decode(const PeakRec r, long long tile0, int e0) {
+   Run u;
+   u.pos = tile0 - 64 + (long long)(r.w0 & 0x7ffu);
+   u.top = !((r.w0 >> 11) & 1u);
+   u.f = u.pos + (long long)((r.w0 >> 12) & 63u);
+   u.nlead = (int)((r.w0 >> 18) & 15u);
+   u.nsure = (int)((r.w0 >> 22) & 63u);
+   u.ntail = (int)((r.w0 >> 28) & 15u);
+   u.unknown = r.w1 == 0xffff8000u;
+   if (u.nsure == 63) { u.nlead = u.nlead << 4 | u.ntail; u.nsure = 0; u.ntail = 0; }      // every row explicit
+   u.val = (int)(int16_t)(r.w1 & 0xffffu);
+   u.dprev = (int)((r.w1 >> 16) & 0xffu) - 1;
+   u.dnext = (int)((r.w1 >> 24) & 0xffu) - 1;
+   u.e0 = e0;
+   return u; }
+
+// the rise test of src/decoder.c:790-791 / 800-801 for a row whose margin is m (int16 code difference to the nearer edge)
+__device__ __forceinline__ bool rise_pass(const Walker &w, const Run &u, int m, float mv) {
+   if (m >= w.rise_hi) return true;
+   if (m <= w.rise_lo) return false;
+   return u.top ? volt(u.val, mv) > volt(u.val - m, mv) + w.rise : volt(u.val, mv) < volt(u.val + m, mv) - w.rise; }
+// ... and its min_peak half (src/decoder.c:792, 802)
+__device__ __forceinline__ bool amp_pass(const Walker &w, const Run &u, float mv) {
+   if (w.reqmin == 0) return true;
+   const int a = u.top ? u.val : -u.val;
+   if (a >= w.min_hi) return true;
+   if (a <= w.min_lo) return false;
+   return u.top ? volt(u.val, mv) > w.reqmin : volt(u.val, mv) < -w.reqmin; }
+
+constexpr long long kNoRow = 0x7fffffffffffffffll;
+// first row >= c (and < limit) at which this run makes the detector fire, or kNoRow; doubt = first row >= c that the record cannot decide
+__device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, const uint16_t *ents, long long c, long long limit, int W, int sure_i, float mv, long long &doubt) {
+   doubt = kNoRow;
+   const long long last_row = u.pos + W - 2;                         // the owner is strictly inside the window up to here
+   if (last_row < c || u.f >= limit) return kNoRow;
+   if (!amp_pass(w, u, mv)) return kNoRow;
+   if (u.unknown) { const long long n = max(c, u.f); if (n < u.f + u.nsure && n < limit) doubt = n; return kNoRow; }
+   for (int i = 0; i < u.nlead; ++i) {
+      const long long n = u.f + i;
+      if (n < c) continue;
+      if (n >= limit) return kNoRow;
+      if (rise_pass(w, u, (int)ents[u.e0 + i], mv)) return n; }
+   const long long s0 = u.f + u.nlead;
+   if (u.nsure) {
+      const long long n = max(c, s0);
+      if (n < s0 + u.nsure) {
+         if (n >= limit) return kNoRow;
+         if (w.rise_hi > sure_i) { doubt = n; return kNoRow; }
+         return n; } }
+   for (int i = 0; i < u.ntail; ++i) {
+      const long long n = s0 + u.nsure + i;
+      if (n < c) continue;
+      if (n >= limit) return kNoRow;
+      if (rise_pass(w, u, (int)ents[u.e0 + u.nlead + i], mv)) return n; }
+   return kNoRow; }
+
+__global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, long long nrows, long long row_base,
+                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
+                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
+                                              const PeakDir *__restrict__ dir_main, const PeakDir *__restrict__ dir_spill,
+                                              const unsigned char *__restrict__ pool, long long ntiles) {
+   __shared__ PeakRec s_recs[kChRecCap];
+   __shared__ uint16_t s_eoff[kChRecCap];
+   __shared__ uint16_t s_ents[kChEntCap];
+   __shared__ float s_heights[64 * 10];
+   const DevCfg &cfg = *cfgp;
+   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
+   const int lane = threadIdx.x;
+   const float mv = cfg.maxvolts;
+   for (;;) {
+      int idx = 0;
+      if (lane == 0) idx = atomicAdd(&scratch->queue_walk, 1);
+      idx = __shfl(idx, 0);
+      const int b = idx / nwalk;
+      if (b >= scratch->nbursts) break;
+      const int wi = idx - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
+      if (ctl[b].status != kBurstReady) continue;
+      const rtfe_burst B = bursts[b];
+      const DevParm &P = cfg.parm[pidx];
+      const DevScreen &S = cfg.screen[P.screen];
+      const int W = P.W, d = cfg.skew[trk], head = cfg.trk_to_head[trk];
+      const long long reset = ctl[b].reset;
+      const long long stop = chain_stop(cfg, bursts, ctl, b, scratch->nbursts_total, nrows);
+      Walker w = {};
+      w.agc_gain = 1.0f; w.v_avg_height = 4.0f;
+      update_thresholds(w, P, cfg.lsb_per_volt);
+      for (int i = 0; i < 10; ++i) s_heights[lane * 10 + i] = 0;
+      // column rows: the detector's row n reads sample n - d.  Before fast_from the window is filling on zone samples only.
+      long long c = reset + W + max(trk, d) + 1 - d;
+      const long long limit = stop - d;
+      rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
+      const unsigned int cap = B.event_cap;
+      bool failed = false;
+      int why = 0;
+      for (long long g = c / kPkTile; g * kPkTile < limit && g < ntiles && !failed; ++g) {
+         const long long tile0 = g * kPkTile;
+         // ---- the tile's lists: what the previous tile spilled, then its own, as one list ordered by the row of the sample that
+         // made each record (every record's first row lies behind that sample: a record further down the list cannot start
+         // more than W - 2 rows before this one) ----
+         const PeakDir ds = dir_spill[(g * cfg.nscreens + P.screen) * ntrks + head], dm = dir_main[(g * cfg.nscreens + P.screen) * ntrks + head];
+         if (ds.nrec >= 0xfffe || dm.nrec >= 0xfffe) { failed = true; why = 1; break; }                  // (capacity, or a quiet tile nobody was expected to need)
+         const int nrec_all = (int)ds.nrec + dm.nrec;
+         if (nrec_all == 0) continue;
+         const PeakRec *r0 = reinterpret_cast<const PeakRec *>(pool + (size_t)ds.blob * 16) + ds.rec_rel;
+         const PeakRec *r1 = reinterpret_cast<const PeakRec *>(pool + (size_t)dm.blob * 16) + dm.rec_rel;
+         const uint16_t *e0 = reinterpret_cast<const uint16_t *>(pool + (size_t)ds.blob * 16 + (size_t)ds.ents8 * 8) + ds.ent_rel;
+         const uint16_t *e1 = reinterpret_cast<const uint16_t *>(pool + (size_t)dm.blob * 16 + (size_t)dm.ents8 * 8) + dm.ent_rel;
+         int base = 0, ent_base = 0;                                          // the window of the list held in LDS starts here
+         while (base < nrec_all && !failed) {
+         int nrec = min(kChRecCap, nrec_all - base);
+         __syncthreads();
+         for (int i = lane; i < nrec; i += 64) { const int j = base + i; s_recs[i] = j < (int)ds.nrec ? r0[j] : r1[j - ds.nrec]; }
+         __syncthreads();
+         int carry = 0;
+         for (int b0 = 0; b0 < nrec; b0 += 64) {                             // first entry of every record of the window
+            const int i = b0 + lane;
+            const int v = i < nrec ? pk_nent(s_recs[i].w0) : 0;
+            int incl = v;
+            #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+            if (i < nrec) s_eoff[i] = (uint16_t)(carry + incl - v);
+            carry += __shfl(incl, 63); }
+         __syncthreads();
+         if (carry > kChEntCap) {                                              // keep the records whose margins fit
+            int keep = 0;
+            while (keep < nrec && (int)s_eoff[keep] + pk_nent(s_recs[keep].w0) <= kChEntCap) ++keep;
+            nrec = keep; carry = nrec ? (int)s_eoff[nrec - 1] + pk_nent(s_recs[nrec - 1].w0) : 0; }
+         for (int i = lane; i < carry; i += 64) { const int j = ent_base + i; s_ents[i] = j < (int)ds.nent ? e0[j] : e1[j - ds.nent]; }
+         __syncthreads();
+         // rows this window decides: up to the earliest row a record behind it could start at
+         long long wlimit = limit;
+         if (base + nrec < nrec_all) {
+            const int j = base + nrec;
+            const PeakRec rn = j < (int)ds.nrec ? r0[j] : r1[j - ds.nrec];
+            const long long fb = run_decode(rn, tile0, 0).f - W + 2;
+            if (fb < wlimit) wlimit = fb; }
+         // ---- the sequential walk (every lane runs it; lane 0 stores): earliest firing run among the tops and the bottoms ----
+         int alive = 0;
+         for (;;) {
+            while (alive < nrec && run_decode(s_recs[alive], tile0, 0).pos + W - 2 < c) ++alive;
+            long long best = kNoRow, best_doubt = kNoRow;
+            int best_k = -1;
+            bool best_top = false, top_done = false, bot_done = false;
+            for (int k = alive; k < nrec && !(top_done && bot_done); ++k) {
+               const Run u = run_decode(s_recs[k], tile0, s_eoff[k]);
+               if (u.top ? top_done : bot_done) continue;
+               if (u.f > best || u.f >= wlimit) { if (u.top) top_done = true; else bot_done = true; continue; }
+               long long dr;
+               const long long n = run_fire(w, u, s_ents, c, wlimit, W, S.sure_i, mv, dr);
+               if (dr < best_doubt) { best_doubt = dr;
+#ifdef RTFE_CPU_EMUL
+                  if (lane == 0 && getenv("RTFE_PK_DEBUG")) fprintf(stderr, "  doubt row %lld rec k %d pos %lld f %lld top %d nlead %d nsure %d ntail %d unknown %d val %d c %lld\n", dr, k, u.pos, u.f, (int)u.top, u.nlead, u.nsure, u.ntail, (int)u.unknown, u.val, c);
+#endif
+               }
+               if (n != kNoRow) {
+                  if (u.top) top_done = true; else bot_done = true;         // (runs of one kind are ordered by row)
+                  if (n < best || (n == best && u.top && !best_top)) { best = n; best_k = k; best_top = u.top; } } }
+            if (best_doubt != kNoRow && best_doubt <= best) { failed = true; why = 2; break; }
+            if (best_k < 0) break;
+            // ---- detection: refine_peak + the callback's effect on AGC state (src/decoder.c:700-749, 574-609) ----
+            const Run u = run_decode(s_recs[best_k], tile0, s_eoff[best_k]);
+            const long long ndet = best + d;                                 // the detector's row
+            const int ld = (int)(u.pos - best) + W;                           // left_distance
+            const float g = w.agc_gain;
+            const float thr = 0.005f / g;
+            const int ti = (int)floorf(thr * cfg.lsb_per_volt);
+            if (ti + 2 > 254) { failed = true; why = 3; break; }                       // (neighbour distances are stored up to 254)
+            const int val_i = u.val;
+            const int iprev = u.top ? val_i - u.dprev : val_i + u.dprev, inext = u.top ? val_i - u.dnext : val_i + u.dnext;
+            const int adjcode = refine_code(&cfg, val_i, iprev, inext, g, u.top);
+            const float val = volt(val_i, mv);
+            double t_peak = 0;
+            if (cfg.mode == RTFE_PE && !w.datablock && w.peakcount >= 68) {
+               const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
+               t_peak = time_of(&cfg, row_base + ndet) - ((float)(W - ld) - adj) * cfg.sample_deltat; }
+            if (w.nevents >= cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
+            else if (lane == 0) {
+               rtfe_event e;
+               e.sample = (uint32_t)(ndet - reset);
+               e.v_peak = (cfg.invert && val == 0.0f) ? -0.0f : val;
+               e.agc_gain = g;
+               e.trk = (uint8_t)trk;
+               e.flags = (uint8_t)((u.top ? 0 : 1) | (adjcode << 1));
+               e.left_distance = (uint8_t)ld;
+               e.parmset = (uint8_t)pidx;
+               ev[w.nevents] = e; }
+            if (u.top) w.v_top = val; else w.v_bot = val;
+            ++w.nevents;
+            agc_after_peak(w, &cfg, P, s_heights + lane * 10, u.top, t_peak);      // (every lane keeps the same state; the window AGC's ring is per lane)
+            if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; break; }      // src/decoder.c:782
+            update_thresholds(w, P, cfg.lsb_per_volt);
+            if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; break; }
+            c = u.pos + W + 1; }
+         if (failed) break;
+         // ---- next window: everything in front of wlimit is decided ----
+         if (base + nrec >= nrec_all) break;
+         if (c < wlimit) c = wlimit;
+         int adv = 0;
+         while (adv < nrec && run_decode(s_recs[adv], tile0, 0).pos + W - 2 < c) ++adv;
+         if (adv == 0) { failed = true; why = 6; break; }                      // (hundreds of live records inside two window lengths: not a tape)
+         ent_base += adv < nrec ? (int)s_eoff[adv] : carry;
+         base += adv; } }
+      // ---- publish ----
+#ifdef RTFE_CPU_EMUL
+      if (lane == 0 && failed && getenv("RTFE_PK_DEBUG")) fprintf(stderr, "chain b %d p %d t %d failed why %d at c %lld (rise %f hi %d sure %d)\n", b, pidx, trk, why, c, w.rise, w.rise_hi, S.sure_i);
+#endif
+      if (lane == 0) {
+         if (failed) atomicExch(&ctl[b].status, (int)kBurstNeedsFull);
+         counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = w.nevents < cap ? w.nevents : cap;
+         if (w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW) atomicOr(&ctl[b].bflags, w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW); } } }
+
+// ------------------------------------------------------------------------------------------------
+// k_publish: burst table entries of the bursts the chains finished; stop rows for the ones the sample path redoes
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_publish(const DevCfg *__restrict__ cfgp, long long nrows, rtfe_burst *__restrict__ bursts,
+                                                 BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl) {
+   const DevCfg &cfg = *cfgp;
+   const int nb = scratch->nbursts;
+   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+      const long long stop = chain_stop(cfg, bursts, ctl, b, scratch->nbursts_total, nrows);
+      ctl[b].stop = stop;
+      if (ctl[b].status == kBurstReady) {
+         bursts[b].reset_sample = ctl[b].reset;
+         bursts[b].safe_last = ctl[b].reset;
+         bursts[b].end_sample = stop < nrows ? stop : nrows;
+         bursts[b].flags = ctl[b].bflags;
+         ctl[b].status = kBurstDone; }
+      else atomicAdd(&scratch->seg_failed, 1); }                    // (statistics: bursts the sample path redoes)
+   if (blockIdx.x == 0 && threadIdx.x == 0) scratch->queue_resume = 0; }
+
+}  // namespace rtfe

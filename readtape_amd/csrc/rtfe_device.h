@@ -5,6 +5,8 @@
 
 namespace rtfe {
 
+typedef unsigned long long u64;
+
 constexpr int kChunkRows   = 64;     // granularity of the quiet map (rows per bit)
 constexpr int kMaxTileRows = 2048;   // upper bound of DevCfg::tile_rows (rows per LDS tile of the decode kernel)
 constexpr int kMaxHaloRows = 176;    // upper bound of DevCfg::halo_rows = kScreenHalo + W + 1 + max skew, rounded up to 8  (W<=50, skew<=50)
@@ -29,6 +31,8 @@ struct DevScreen {
    int W;
    int rise_i;          // candidate if (max - edge) > rise_i on both edges          (int16 units)
    int minpk_i;         // ... and max > minpk_i (top) / min < -minpk_i (bottom); -1 = no min_peak test
+   int sure_i;          // k_peaks: a row whose margin is >= sure_i passes the rise test for every threshold k_chain accepts
+   int nb;              // k_peaks: blocks of 4 rows on either side of a sample's block in the prominence pre-filter (4 nb >= W - 2)
 };
 
 struct DevCfg {
@@ -67,6 +71,11 @@ struct DevCfg {
    int   lds_units;               // candidate units of ONE tile (all lists, packed) that fit the LDS of the sequential pass
    int   debug;                   // RTFE_DEBUG=1: per-phase cycle counters in the workspace (tools/ only)
    int   cut;                     // RTFE_CUT: k_screen stops after a phase (timing experiments, tools/ only; results are then garbage)
+   int   peak_path;               // k_peaks -> k_chain serve rtfe_scan (peak detection on the undifferentiated signal)
+   int   pk_hl, pk_hr;            // rows kept in front of / behind a k_peaks tile in LDS (multiples of 16)
+   int   pk_cand_cap, pk_rec_cap, pk_ent_cap;   // k_peaks LDS staging: candidates, records, margin entries per tile and screen
+   int   pk_lds;                  // dynamic LDS bytes of k_peaks
+   int   pk_parallel;             // k_chain: decide clean stretches of 64 runs in parallel (0: always the sequential walk; tests)
    DevParm   parm[RTFE_MAXPARMSETS];
    DevScreen screen[kMaxScreens];
 };
@@ -102,7 +111,7 @@ constexpr int kSegWarmup = 8;      // tiles: the alpha-filter AGC needs ~90 dete
 struct SegTab { int first; int nseg; int t0; int tend; };      // per burst: global index of segment 0, segments, first tile, end tile (excl.)
 // ---- burst hand-over between the kernels of one scan (workspace) ----
 enum { kBurstNew = 0, kBurstNeedsFull = 1, kBurstReady = 2, kBurstDone = 3 };
-enum { kDecodeAll = 0, kDecodeHead = 1, kDecodeResume = 2 };
+enum { kDecodeAll = 0, kDecodeHead = 1, kDecodeResume = 2, kDecodeRedo = 3 };     // kDecodeRedo: whole bursts the record chains gave up (restart / stop rows from k_zones)
 enum { kWalkWhole = 0, kWalkPre = 1, kWalkSegs = 2 };
 struct BurstCtl {              // 32 bytes per burst
    long long reset, stop;      // restart row / first row of the next burst's span
@@ -112,5 +121,32 @@ struct BurstCtl {              // 32 bytes per burst
    int       pad;
 };
 constexpr int kScreenHalo = 64;      // rows in front of a tile that the screen also covers (one bitmap word)
+
+// ---- the peak-record path: k_peaks (dense, stateless) -> k_zones -> k_chain (one wave per (burst, parmset, track)) ----
+constexpr int kPkTile    = 1024;     // rows per k_peaks tile (64 strips of 16 rows; 16 quiet-map groups of 64 rows)
+constexpr int kPkStrip   = 16;       // rows per lane strip
+constexpr int kPkBack    = 64;       // rows k_peaks looks back for the last forced rescan in front of a bottom candidate
+// One candidate RUN = the rows of one tile at which one sample (the "owner": the window maximum, or the reference's
+// possibly stale window minimum) is what lookfor_peak would test (src/decoder.c:788-805), clipped to the tile.
+//   w0  bits  0-10  pos  - (tile row0 - 64)        the owner's row (a run of tile g+1 may be owned by a sample of tile g)
+//       bit   11    kind  0 top / 1 bottom
+//       bits 12-17  f - pos                         first row of the run with a margin above the screen (1 .. W-2)
+//       bits 18-21  nlead                           rows f .. f+nlead-1 carry explicit margins (uint16 entries)
+//       bits 22-27  nsure                           the next nsure rows all have margins >= DevScreen::sure_i
+//       bits 28-31  ntail                           the next ntail rows carry explicit margins again; no row behind them passes the screen
+//                   nsure == 63: every row explicit, (nlead << 4 | ntail) of them from f
+//   w1  val (int16) | clamp(d(prev), -1, 254) + 1 (8 bits) | clamp(d(next), -1, 254) + 1 (8 bits)       d = |val - neighbour| signed towards "beyond the extreme"
+//       0xffff8000: k_peaks could not derive the reference's minimum; rows f .. f+nsure-1 are undecidable from the record
+// margin of a row = val - max(left edge, right edge) (tops) / min(edges) - val (bottoms), int16 code differences.
+struct PeakRec { uint32_t w0, w1; };
+struct PeakDir {               // per (tile, screen, head): 16 bytes; one array for the tile's own runs, one for the runs spilled into it
+   uint32_t blob;              // the writing tile's blob in the pool, 16-byte units
+   uint16_t rec_rel;           // this list's first record, in records from the blob's start
+   uint16_t nrec;              // 0xFFFF: list not available (capacity)
+   uint16_t ent_rel;           // this list's first margin entry, in entries from the blob's entry area
+   uint16_t nent;
+   uint16_t ents8;             // the blob's entry area, 8-byte units from the blob's start
+   uint16_t pad;
+};
 
 }  // namespace rtfe

@@ -39,43 +39,8 @@
 
 namespace rtfe {
 
-typedef unsigned long long u64;
-
 // ------------------------------------------------------------------------------------------------
-// k_quiet: bit c of qwords[] = every int16 in payload bytes [1024c, 1024c+1024) has |x| <= quiet_i
-// one wave = one chunk per iteration (64 lanes x 16 B), one workgroup = one 64-bit word
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_quiet(const int16_t *__restrict__ rows, long long nelem, int quiet_i,
-                                               u64 *__restrict__ qwords, long long nwords) {
-   __shared__ unsigned int part[4];
-   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   const long long nchunks_full = nelem / 512;            // complete 1 KiB chunks
-   for (long long w = blockIdx.x; w < nwords; w += gridDim.x) {
-      unsigned int bits = 0;
-      #pragma unroll 4
-      for (int k = 0; k < 16; ++k) {
-         long long c = w * 64 + wave * 16 + k;
-         bool q = false;
-         if (c < nchunks_full) {
-            const int4 v = reinterpret_cast<const int4 *>(rows + c * 512)[lane];
-            int m = 0;
-            const int vv[4] = {v.x, v.y, v.z, v.w};
-            #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-               int lo = (short)(vv[j] & 0xffff), hi = vv[j] >> 16;
-               lo = lo < 0 ? -lo : lo; hi = hi < 0 ? -hi : hi;
-               m = max(m, max(lo, hi)); }
-            q = m <= quiet_i; }
-         const u64 b = __ballot(q);
-         if (c < nchunks_full && b == ~0ull) bits |= 1u << k; }
-      if (lane == 0) part[wave] = bits;
-      __syncthreads();
-      if (threadIdx.x == 0)
-         qwords[w] = (u64)part[0] | ((u64)part[1] << 16) | ((u64)part[2] << 32) | ((u64)part[3] << 48);
-      __syncthreads(); } }
-
-// ------------------------------------------------------------------------------------------------
-// k_bursts: zones of >= gap_chunks quiet chunks -> burst table.  Single workgroup of 1024 threads.
+// k_bursts: zones of >= gap_chunks quiet chunks (groups of 64 rows) -> burst table.  Single workgroup of 1024 threads.
 // A zone END is a quiet chunk c whose successor is not quiet and whose gap_chunks predecessors
 // (itself included) are all quiet; each thread tests the 64 chunks of one word per round.
 // ------------------------------------------------------------------------------------------------
@@ -186,9 +151,8 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
             const long long idx = (long long)base + off++;
             if (idx < max_bursts) {
                rtfe_burst b = {};
-               long long zf = (c0 * 512 + ntrks - 1) / ntrks;           // first row entirely inside quiet chunks
-               long long ze = (c1 * 512) / ntrks;                       // one past the last such row
-               zf = (zf + 63) & ~63ll; ze &= ~63ll;
+               long long zf = c0 * kChunkRows;                          // first row of the zone (chunks are groups of 64 rows)
+               long long ze = c1 * kChunkRows;                          // one past its last row
                if (ze > nrows) ze = nrows & ~63ll;
                b.zone_first = zf; b.zone_end = ze; b.reset_sample = -1; b.safe_last = -1;
                bursts[idx] = b; } } }
@@ -203,7 +167,9 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
    __syncthreads();
    for (int b0 = 0; b0 < nb; b0 += 1024) {
       const int b = b0 + threadIdx.x;
-      if (b < nb && bursts[b].zone_end > own_rows && !(bursts[b].flags & RTFE_F_EXACT_START)) atomicMin(&s_owned, b); }
+      // a zone that ends fewer than gap_chunks chunks behind the seam cannot qualify in the right neighbour's slice (it sees
+      // fewer than gap_chunks of its chunks), so it belongs here; one that ends later qualifies there and belongs there
+      if (b < nb && own_rows < nrows && bursts[b].zone_end >= own_rows + (long long)gap_chunks * kChunkRows && !(bursts[b].flags & RTFE_F_EXACT_START)) atomicMin(&s_owned, b); }
    __syncthreads();
    const int n_owned = s_owned;
    if (nb > n_owned + 1) nb = n_owned + 1;
@@ -245,7 +211,6 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
       scratch->nbursts = n_owned; scratch->nbursts_total = nb; scratch->queue = 0; scratch->queue_walk = 0; scratch->queue_resume = 0; scratch->queue_seg = 0; scratch->nsegs = 0; scratch->queue_stitch = 0; scratch->seg_failed = 0; *nbursts_out = n_owned;
       if (n_owned == nb && own_rows < nrows && n_owned > 0) bursts[n_owned - 1].flags |= RTFE_F_TRUNCATED; }
    if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0;
-   if (threadIdx.x == 8) scratch->pool_cursor = 0;
    if (threadIdx.x >= 16 && threadIdx.x < 24) scratch->dbg2[threadIdx.x - 16] = 0;
    if (threadIdx.x >= 24 && threadIdx.x < 32) scratch->why[threadIdx.x - 24] = 0;
    if (threadIdx.x >= 32 && threadIdx.x < 40) scratch->scr[threadIdx.x - 32] = 0; }
@@ -2311,11 +2276,11 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
    // mode: kDecodeAll = whole bursts (exact scans, -zeros); kDecodeHead = start every burst and hand it to k_walk as
    // soon as its walkers are on the screened path; kDecodeResume = finish the bursts k_walk had to give back
    for (;;) {
-      if (threadIdx.x == 0) { s_burst = atomicAdd(mode == kDecodeResume ? &scratch->queue_resume : &scratch->queue, 1); s_flags = 0; }
+      if (threadIdx.x == 0) { s_burst = atomicAdd((mode == kDecodeResume || mode == kDecodeRedo) ? &scratch->queue_resume : &scratch->queue, 1); s_flags = 0; }
       __syncthreads();
       const int b = s_burst;
       if (b >= scratch->nbursts) break;
-      if (mode == kDecodeResume && ctl[b].status != kBurstNeedsFull) { __syncthreads(); continue; }
+      if ((mode == kDecodeResume || mode == kDecodeRedo) && ctl[b].status != kBurstNeedsFull) { __syncthreads(); continue; }
       const int nb = scratch->nbursts_total;
       const rtfe_burst B = bursts[b];
       const bool exact = B.flags & RTFE_F_EXACT_START;
@@ -2336,11 +2301,13 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
       else {
          // ---- where this burst restarts, and where the next one does (= where this one stops) ----
          reset = B.reset_sample;
-         if (!exact) {
+         if (mode == kDecodeRedo) { reset = ctl[b].reset; bflags = ctl[b].bflags; }          // k_zones decided (the chains' neighbours rely on it)
+         else if (!exact) {
             reset = zone_reset(B);
             if (reset < 0) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; } }
          stop = hard_end;
-         if (has_tail) {
+         if (mode == kDecodeRedo) stop = ctl[b].stop;
+         else if (has_tail) {
             const rtfe_burst NB = bursts[b + 1];
             stop = zone_reset(NB);
             if (stop < 0) stop = NB.zone_end - kMarginRows;

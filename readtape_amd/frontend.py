@@ -167,6 +167,7 @@ def _load_library(path=None):
     lib.rtfe_scan_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.rtfe_kernel_name.restype = C.c_char_p
+    lib.rtfe_scan_stats.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.rtfe_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rtfe_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     if lib.rtfe_abi_version() != 1:
@@ -250,9 +251,25 @@ class FrontEnd:
             raise RuntimeError(self.lib.rtfe_last_error().decode())
         return dict(zip(self.kernel_names(), [float(x) for x in out]))
 
+    def scan_stats(self, result):
+        """{'bursts', 'redone', 'record_bytes'} of the scan that produced `result` (synchronises; diagnostics)."""
+        self.backend.sync()
+        out = (C.c_int64 * 4)()
+        if self.lib.rtfe_scan_stats(self.h, self.backend.ptr(result.bufs["ws"]), out) != 0:
+            raise RuntimeError(self.lib.rtfe_last_error().decode())
+        return dict(bursts=int(out[0]), redone=int(out[1]), record_bytes=int(out[2]))
+
     def _buffers(self, nrows, key="scan"):
-        """Allocates (once per size) the workspace and output buffers for a scan of nrows rows."""
+        """Allocates (once per size) the workspace and output buffers for a scan of nrows rows.  Exact rescans share ONE
+        grow-only set (their lengths are almost always distinct: a per-length cache would grow without bound)."""
         k = (key, nrows)
+        if key == "exact":
+            k = (key, 0)
+            old = self._cache.get(k)
+            if old is not None and old["nrows"] >= nrows:
+                return old
+            nrows = max(nrows, 2 * old["nrows"] if old is not None else 1 << 16)
+            self._cache.pop(k, None)
         if k not in self._cache:
             be, lib = self.backend, self.lib
             mb = int(lib.rtfe_max_bursts(self.h, nrows))
@@ -260,7 +277,7 @@ class FrontEnd:
             P, T = len(self.cfg.parmsets), self.cfg.ntrks
             self._cache[k] = dict(
                 ws=be.empty(lib.rtfe_workspace_bytes(self.h, nrows)), bursts=be.empty(mb * BURST_DTYPE.itemsize),
-                nbursts=be.empty(16), counts=be.empty(mb * P * T * 4), events=be.empty(cap * 16), max_bursts=mb, cap=cap)
+                nbursts=be.empty(16), counts=be.empty(mb * P * T * 4), events=be.empty(cap * 16), max_bursts=mb, cap=cap, nrows=nrows)
         return self._cache[k]
 
     def scan(self, rows, row_base=0, first_is_tape_start=True, stream=None, own_rows=None) -> ScanResult:

@@ -43,6 +43,7 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProc
 template <class T> inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)calloc(1, n); return *p ? hipSuccess : 1; }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 typedef void *hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
@@ -99,6 +100,7 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline int atomicExch(int *p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicAnd(int *p, int v) { return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicMin(int *p, int v) { int old = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return old; }
