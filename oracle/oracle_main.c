@@ -79,7 +79,7 @@ static float rdf(const unsigned char *p) { uint32_t u = rd32(p); float f; memcpy
 int main(int argc, char **argv) {
    struct rt_options opt; memset(&opt, 0, sizeof opt);
    opt.specified_parity = 1;
-   const char *infile = NULL, *outbase = NULL, *evtname = NULL, *parmfile = NULL, *skewarg = NULL;
+   const char *infile = NULL, *outbase = NULL, *evtname = NULL, *parmfile = NULL, *skewarg = NULL, *orderarg = NULL;
    int ntrks_arg = 0, invert = 0, timing = 0, blklimit = 0x7fffffff, subsample = 1, deskew = 0;
    float bpi_arg = -1, ips_arg = -1;
    int mode_arg = 0;
@@ -103,6 +103,7 @@ int main(int argc, char **argv) {
       else if (!strcmp(a, "-time")) timing = 1;
       else if (!strncmp(a, "-skew=", 6)) skewarg = a + 6;
       else if (!strcmp(a, "-deskew")) deskew = 1;
+      else if (!strncmp(a, "-order=", 7)) orderarg = a + 7;
       else if (!strncmp(a, "-parms=", 7)) parmfile = a + 7;
       else if (!strncmp(a, "-out=", 5)) outbase = a + 5;
       else if (!strncmp(a, "-evt=", 5)) evtname = a + 5;
@@ -153,6 +154,21 @@ int main(int argc, char **argv) {
    struct ofe *fe = ofe_new(d, rows, nrows, nheads, maxvolts, (int64_t)tstart);
    g_fe = fe;
    fe->invert = invert;
+   {  /* head -> track permutation: "-order=" wins over the TBINORD header extension (src/readtape.c:877-915, 1346-1355).
+         One character per head: a digit = that track (0 = msb), p/P = the parity track (last). */
+      char hdr_order[21] = {0};
+      if (flags & 2) memcpy(hdr_order, buf + 240 + 8, 20);
+      const char *ord = orderarg ? orderarg : (hdr_order[0] ? hdr_order : NULL);
+      /* a file without TBIN_NO_REORDER (0x01) "had a permutation applied to it": every track order is ignored (src/readtape.c:1646-1648) */
+      if (ord && (flags & 1)) {
+         const int n = (int)strlen(ord);
+         unsigned seen = 0;
+         if (n != nheads) { fprintf(stderr, "-order length doesn't match the number of heads\n"); return 99; }
+         for (int i = 0; i < n; ++i) {
+            int t = (ord[i] == 'p' || ord[i] == 'P') ? n - 1 : ((ord[i] >= '0' && ord[i] <= '9' && ord[i] - '0' <= n - 2) ? ord[i] - '0' : -1);
+            if (t < 0) { fprintf(stderr, "bad -order string\n"); return 99; }
+            fe->head_to_trk[i] = t; seen |= 1u << t; }
+         if (seen + 1 != (1u << n)) { fprintf(stderr, "-order is not a permutation\n"); return 99; } } }
    if (skewarg) {
       int t = 0; const char *p = skewarg;
       while (*p && t < RT_MAXTRKS) { fe->skew_delaycnt[t++] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }

@@ -45,6 +45,13 @@ static int fail(int code, const char *fmt, ...) {
    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
    return code; }
 
+// the k_peaks instantiation for a block-window size and a workgroup size
+typedef void (*pk_kernel_t)(const DevCfg *, const int16_t *, long long, long long, uint16_t *, PeakDir *, PeakDir *, unsigned char *, unsigned long long,
+                            unsigned long long *, int, const unsigned int *);
+static pk_kernel_t pk_kernel(int nb, int threads) {
+   if (threads <= 448) return nb <= 4 ? k_peaks<4, 448> : (nb <= 8 ? k_peaks<8, 448> : k_peaks<12, 448>);
+   return nb <= 4 ? k_peaks<4, 704> : (nb <= 8 ? k_peaks<8, 704> : k_peaks<12, 704>); }
+
 extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
@@ -132,6 +139,9 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       if (si <= d.screen[s].rise_i + 1) si = d.screen[s].rise_i + 2;
       d.screen[s].sure_i = (int)si;
       d.screen[s].nb = d.screen[s].W <= 18 ? 4 : (d.screen[s].W <= 34 ? 8 : 12); }
+   {  int nbm = 0;                                                   // one k_peaks instantiation per scan: the widest window's block count for all
+      for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].nb > nbm) nbm = d.screen[s].nb;
+      for (int s = 0; s < d.nscreens; ++s) d.screen[s].nb = nbm; }
    if (d.find_zeros) {
       // the zero-crossing detector has no amplitude feedback and no parameter-set dependence (adjust_agc returns
       // at once, src/decoder.c:501): one walker per track; nothing can become pending while |v| <= 0.2 V
@@ -264,7 +274,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen), hipFuncAttributeMaxDynamicSharedMemorySize, h->screen_lds_bytes);
    h->walk_lds_bytes = (int)lds_layout_walk(d).total + 64;
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, h->walk_lds_bytes);
-   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_peaks), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
+   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pk_kernel(d.screen[0].nb, 64 * ((c->ntrks + 1) / 2 + 1))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
    *out = h;
    return 0; }
 
@@ -408,7 +418,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t0(6, st);
       const int pthreads = 64 * ((h->dev.ntrks + 1) / 2 + 1);
       const long long pgrid = ((ptiles + 7) / 8) * 8;
-      hipLaunchKernelGGL(k_peaks, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, h->d_dev, d_rows, (long long)nrows, ptiles,
+      const pk_kernel_t pkk = pk_kernel(h->dev.screen[0].nb, pthreads);
+      hipLaunchKernelGGL(pkk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                          reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pool_units, &scratch->pool_cursor, 0, (const unsigned int *)deadp);
       t1(6, st); t0(1, st);
       hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
@@ -416,7 +427,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                          d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts,
                          deadp, ptiles, (int)kPkTile, h->dev.tail_rows);
       t1(1, st); t0(7, st);
-      hipLaunchKernelGGL(k_peaks, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, h->d_dev, d_rows, (long long)nrows, ptiles,
+      hipLaunchKernelGGL(pkk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                          reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pool_units, &scratch->pool_cursor, 1, (const unsigned int *)deadp);
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);
@@ -497,7 +508,7 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
    if (!h || !d_workspace || !out) return fail(-1, "null argument");
    BurstScratch sc;
    if (hipMemcpy(&sc, d_workspace, sizeof sc, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
-   out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.pool_cursor * 16;
+   out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.pool_cursor * 16; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
    return 0; }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

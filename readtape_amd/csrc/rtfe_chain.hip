@@ -125,6 +125,190 @@ __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, con
       if (rise_pass(w, u, (int)ents[u.e0 + u.nlead + i], mv)) return n; }
    return kNoRow; }
 
+// ---- the parallel path of k_chain: up to 64 consecutive records of the window, one per lane ----------------------------------
+// In steady state (baseline fixed, alpha-filter AGC) WHICH runs fire does not depend on the exact gain as long as every
+// threshold of the stretch stays inside a band around the current one: a run with a row whose margin clears the band fires,
+// one without a row that reaches the band does not, and the blind countdown ends when the fired run's owner leaves the window,
+// whatever row it fired at (pos + W + 1).  So: (1) every lane classifies its run against the band, the blind rows follow from
+// the fired lanes in front of it (iterated to a fixed point), (2) the gains follow from the fired runs' heights - three flops
+// per detection, the only sequential part, (3) every lane re-evaluates its run with ITS exact thresholds: the exact firing row,
+// and that every threshold stayed in the band.  Anything that does not fit (a margin or an amplitude inside the band with nothing
+// clearer behind it, runs that could fire out of list order, a threshold leaving the band) returns -1 and the caller takes
+// one sequential step instead.  Returns the number of detections (>= 0) after advancing c and w.
+struct LaneRun { int pos, f, nlead, nsure, ntail, e0, val, dprev, dnext; bool top, unknown; };
+constexpr int kNone = 0x3fffffff;
+
+__device__ __forceinline__ int wave_excl_max(int v, int lane) {           // max over lanes in front of this one (kNone-free: -kNone = none)
+   int x = __shfl_up(v, 1); if (lane == 0) x = -kNone;
+   #pragma unroll
+   for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o && y > x) x = y; }
+   return x; }
+
+// first row >= cmin and < L whose margin is >= hi.  maybe: a row in front of it (>= cmin) has a margin in (lo, hi), or lies in the sure
+// stretch while the band reaches above the sure level.
+__device__ __forceinline__ int lane_first(const LaneRun &u, const uint16_t *ents, int cmin, int L, int lo, int hi, bool sure_ok, bool &maybe) {
+   maybe = false;
+   for (int i = 0; i < u.nlead; ++i) {
+      const int n = u.f + i;
+      if (n < cmin) continue;
+      if (n >= L) return kNone;
+      const int m = ents[u.e0 + i];
+      if (m >= hi) return n;
+      if (m > lo) maybe = true; }
+   const int s0 = u.f + u.nlead;
+   if (u.nsure) {
+      const int n = cmin > s0 ? cmin : s0;
+      if (n < s0 + u.nsure) { if (n >= L) return kNone; if (sure_ok) return n; maybe = true; } }
+   for (int i = 0; i < u.ntail; ++i) {
+      const int n = s0 + u.nsure + i;
+      if (n < cmin) continue;
+      if (n >= L) return kNone;
+      const int m = ents[u.e0 + u.nlead + i];
+      if (m >= hi) return n;
+      if (m > lo) maybe = true; }
+   return kNone; }
+
+__device__ __forceinline__ int chain_parallel(const DevCfg &cfg, const DevParm &P, const DevScreen &S, Walker &w, long long &c, long long tile0, long long wlimit,
+                                              const PeakRec *recs, const uint16_t *eoff, const uint16_t *ents, int k0, int nrec, int lane,
+                                              rtfe_event *ev, unsigned int cap, long long reset, int d, int trk, int pidx) {
+   const int W = P.W;
+   const float mv = cfg.maxvolts;
+   const int n = nrec - k0 < 64 ? nrec - k0 : 64;
+   const bool have = lane < n;
+   LaneRun u = {};
+   if (have) {
+      const PeakRec r = recs[k0 + lane];
+      u.pos = (int)(r.w0 & 0x7ffu) - 64; u.top = !((r.w0 >> 11) & 1u); u.f = u.pos + (int)((r.w0 >> 12) & 63u);
+      u.nlead = (int)((r.w0 >> 18) & 15u); u.nsure = (int)((r.w0 >> 22) & 63u); u.ntail = (int)((r.w0 >> 28) & 15u);
+      u.unknown = r.w1 == 0xffff8000u;
+      if (u.nsure == 63) { u.nlead = u.nlead << 4 | u.ntail; u.nsure = 0; u.ntail = 0; }
+      u.val = (int)(int16_t)(r.w1 & 0xffffu); u.dprev = (int)((r.w1 >> 16) & 0xffu) - 1; u.dnext = (int)((r.w1 >> 24) & 0xffu) - 1;
+      u.e0 = eoff[k0 + lane]; }
+   // rows relative to tile0.  L: rows below it are decided by this stretch (a record behind it cannot start earlier)
+   long long Ll = wlimit - tile0;
+   if (k0 + n < nrec) { const PeakRec rn = recs[k0 + n]; const long long fb = (long long)(rn.w0 & 0x7ffu) - 64 + (long long)((rn.w0 >> 12) & 63u) - W + 2; if (fb < Ll) Ll = fb; }
+   const long long crel_l = c - tile0;
+   if (Ll <= crel_l) return -1;
+   const int L = Ll > kNone ? kNone : (int)Ll, c0 = crel_l < -4096 ? -4096 : (int)crel_l;
+   // ---- the band ----
+   const float rs = w.rise * cfg.lsb_per_volt, ms = w.reqmin * cfg.lsb_per_volt;
+   const int b_lo = (int)floorf(rs * 0.8f) - 2, b_hi = (int)floorf(rs * 1.25f) + 3;
+   const int a_lo = (int)floorf(ms * 0.8f) - 2, a_hi = (int)floorf(ms * 1.25f) + 3;
+   const bool sure_ok = b_hi <= S.sure_i;
+   const int amp = w.reqmin == 0 ? 2 : ((u.top ? u.val : -u.val) >= a_hi ? 2 : ((u.top ? u.val : -u.val) <= a_lo ? 0 : 1));
+   // ---- (1) which runs fire ----
+   bool fired = false, maybe = false;
+   int ck = c0, nk = kNone;
+   bool stable = false;
+   for (int it = 0; it < 5 && !stable; ++it) {
+      const int pf = wave_excl_max(fired ? u.pos : -kNone, lane);
+      ck = pf > -kNone && pf + W + 1 > c0 ? pf + W + 1 : c0;
+      bool mb = false;
+      nk = have && !u.unknown && amp != 0 && u.pos + W - 2 >= ck ? lane_first(u, ents, ck, L, b_lo, b_hi, sure_ok, mb) : kNone;
+      maybe = mb;
+      const bool nf = nk != kNone;
+      stable = __ballot(nf != fired) == 0;
+      fired = nf; }
+   if (!stable) return -1;
+   // undecidable inside the band: a margin or the amplitude between the band's edges with nothing clearer behind it; an unknown minimum in range
+   const bool in_range = have && u.pos + W - 2 >= ck && u.f < L;
+   bool bad = false;
+   if (in_range) {
+      if (u.unknown) bad = (ck > u.f ? ck : u.f) < u.f + u.nsure;
+      else if (amp == 1) { bool mb; const int t = lane_first(u, ents, ck, L, b_lo, b_lo + 1, true, mb); bad = t != kNone; }      // any row above the band's lower edge
+      else if (amp == 2 && !fired) bad = maybe; }
+   // list order = firing order: owners and firing rows increase along the fired lanes, and no run starts at or before a detection in front of it
+   const int pfx = wave_excl_max(fired ? u.pos : -kNone, lane);
+   if (fired && pfx > -kNone && u.pos <= pfx) bad = true;
+   if (__ballot(bad)) return -1;
+   const u64 fm = __ballot(fired);
+   const int nf = __popcll(fm);
+   if (nf == 0) { c = tile0 + L > c ? tile0 + L : c; return 0; }
+   if (w.nevents + (unsigned)nf > cap) return -1;
+   // ---- (2) gains: v_lasttop / v_lastbot as each callback finds them (one event late, src/decoder.c:587-590), then the recurrence ----
+   const float val = volt(u.val, mv);
+   float lt = 0, lb = 0; bool ht = false, hb = false;                      // last fired top / bottom value at or before this lane
+   if (fired) { if (u.top) { lt = val; ht = true; } else { lb = val; hb = true; } }
+   #pragma unroll
+   for (int o = 1; o < 64; o <<= 1) {
+      const float yt = __uint_as_float((unsigned)__shfl_up((int)__float_as_uint(lt), o)), yb = __uint_as_float((unsigned)__shfl_up((int)__float_as_uint(lb), o));
+      const int yh = __shfl_up((ht ? 1 : 0) | (hb ? 2 : 0), o);
+      if (lane >= o) { if (!ht && (yh & 1)) { lt = yt; ht = true; } if (!hb && (yh & 2)) { lb = yb; hb = true; } } }
+   // exclusive: what the lane in front holds
+   float plt = __uint_as_float((unsigned)__shfl_up((int)__float_as_uint(lt), 1)), plb = __uint_as_float((unsigned)__shfl_up((int)__float_as_uint(lb), 1));
+   int ph = __shfl_up((ht ? 1 : 0) | (hb ? 2 : 0), 1);
+   if (lane == 0) ph = 0;
+   const float lasttop = (ph & 1) ? plt : w.v_lasttop, lastbot = (ph & 2) ? plb : w.v_lastbot;
+   const float lastheight = lasttop - lastbot;
+   const bool adj = fired && !cfg.agc_off && lastheight > 0;
+   const float a = adj ? P.agc_alpha * (w.v_avg_height / lastheight) : 0.0f;
+   const float beta = 1 - P.agc_alpha;
+   float g = w.agc_gain, gbefore = g;
+   const u64 am = __ballot(adj);
+   for (u64 m = fm; m; m &= m - 1) {
+      const int i = __ffsll((long long)m) - 1;
+      if (lane == i) gbefore = g;
+      if ((am >> i) & 1ull) {
+         const float ai = __uint_as_float((unsigned)__shfl((int)__float_as_uint(a), i));
+         float g2 = ai + beta * g;                                            // src/decoder.c:510-512
+         if (g2 > 2.0f) g2 = 2.0f;
+         g = g2; } }
+   if (!(g > 0)) return -1;
+   // ---- (3) exact thresholds per detection: the firing row, and that the band held ----
+   Walker wk = w;
+   wk.agc_gain = fired ? gbefore : g; wk.flags = 0;
+   update_thresholds(wk, P, cfg.lsb_per_volt);
+   // (lanes that did not fire evaluate the thresholds behind the last detection: the rows up to L were decided against the band, too)
+   bool viol = wk.rise_lo < b_lo || wk.rise_hi > b_hi || (w.reqmin != 0 && (wk.min_lo < a_lo || wk.min_hi > a_hi)) || (wk.flags & RTFE_F_SCREEN_UNDERFLOW);
+   int nx = kNone;
+   if (fired) {
+      // rows in front of nk have margins at or below the band (fail for every threshold in it) or inside it (decided here, exactly)
+      Run r2; r2.top = u.top; r2.val = u.val;
+      for (int i = 0; i < u.nlead && nx == kNone; ++i) { const int row = u.f + i; if (row < ck) continue; if (row > nk) break; if (rise_pass(wk, r2, (int)ents[u.e0 + i], mv)) nx = row; }
+      const int s0 = u.f + u.nlead;
+      if (nx == kNone && u.nsure) { const int row = ck > s0 ? ck : s0; if (row < s0 + u.nsure && row <= nk) { if (wk.rise_hi > S.sure_i) viol = true; nx = row; } }
+      for (int i = 0; i < u.ntail && nx == kNone; ++i) { const int row = s0 + u.nsure + i; if (row < ck) continue; if (row > nk) break; if (rise_pass(wk, r2, (int)ents[u.e0 + u.nlead + i], mv)) nx = row; }
+      if (nx == kNone) viol = true;
+      const int ti = (int)floorf(0.005f / gbefore * cfg.lsb_per_volt);
+      if (ti + 2 > 254) viol = true; }
+   // order: a run with a row that reaches the band, at or before a detection in front of it in the list, might have fired first
+   const int pn = wave_excl_max(fired ? nx : -kNone, lane);
+   if (have && amp != 0 && !u.unknown && pn > -kNone && u.f <= pn) {
+      bool mb; const int t = lane_first(u, ents, c0, L, b_lo, b_lo + 1, true, mb);
+      if (t <= pn) viol = true; }
+   if (__ballot(viol)) return -1;
+   // ---- commit ----
+   if (fired) {
+      const int eidx = __popcll(fm & ((1ull << lane) - 1));
+      const long long nrow = tile0 + nx, ndet = nrow + d;
+      const int ld = u.pos - nx + W;
+      const int iprev = u.top ? u.val - u.dprev : u.val + u.dprev, inext = u.top ? u.val - u.dnext : u.val + u.dnext;
+      const int adjcode = refine_code(&cfg, u.val, iprev, inext, gbefore, u.top);
+      rtfe_event e;
+      e.sample = (uint32_t)(ndet - reset);
+      e.v_peak = (cfg.invert && val == 0.0f) ? -0.0f : val;
+      e.agc_gain = gbefore;
+      e.trk = (uint8_t)trk;
+      e.flags = (uint8_t)((u.top ? 0 : 1) | (adjcode << 1));
+      e.left_distance = (uint8_t)ld;
+      e.parmset = (uint8_t)pidx;
+      ev[w.nevents + eidx] = e; }
+   // state behind the last detection (lane 63 holds the inclusive scans; the last fired lane its row)
+   const int lastl = 63 - __clzll((long long)fm);
+   const int lastpos = __shfl(u.pos, lastl);
+   const float flt = __uint_as_float((unsigned)__shfl((int)__float_as_uint(lt), 63)), flb = __uint_as_float((unsigned)__shfl((int)__float_as_uint(lb), 63));
+   const int fh = __shfl((ht ? 1 : 0) | (hb ? 2 : 0), 63);
+   if (fh & 1) { w.v_lasttop = flt; w.v_top = flt; }
+   if (fh & 2) { w.v_lastbot = flb; w.v_bot = flb; }
+   w.agc_gain = g;
+   w.peakcount += nf;
+   w.nevents += (unsigned)nf;
+   update_thresholds(w, P, cfg.lsb_per_volt);
+   long long cn = tile0 + lastpos + W + 1;
+   if (tile0 + L > cn) cn = tile0 + L;
+   c = cn;
+   return nf; }
+
 __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, long long nrows, long long row_base,
                                               const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                               uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
@@ -163,6 +347,7 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
       const unsigned int cap = B.event_cap;
       bool failed = false;
       int why = 0;
+      unsigned int n_par = 0, n_seq = 0;                                   // detections decided by all lanes at once / one at a time (statistics)
       for (long long g = c / kPkTile; g * kPkTile < limit && g < ntiles && !failed; ++g) {
          const long long tile0 = g * kPkTile;
          // ---- the tile's lists: what the previous tile spilled, then its own, as one list ordered by the row of the sample that
@@ -199,7 +384,7 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
          for (int i = lane; i < carry; i += 64) { const int j = ent_base + i; s_ents[i] = j < (int)ds.nent ? e0[j] : e1[j - ds.nent]; }
          __syncthreads();
          // rows this window decides: up to the earliest row a record behind it could start at
-         long long wlimit = limit;
+         long long wlimit = limit < tile0 + kPkTile ? limit : tile0 + kPkTile;      // (a list holds rows of its tile only)
          if (base + nrec < nrec_all) {
             const int j = base + nrec;
             const PeakRec rn = j < (int)ds.nrec ? r0[j] : r1[j - ds.nrec];
@@ -209,6 +394,12 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
          int alive = 0;
          for (;;) {
             while (alive < nrec && run_decode(s_recs[alive], tile0, 0).pos + W - 2 < c) ++alive;
+            if (alive >= nrec) break;
+            // clean stretches: all lanes at once (steady state of the block decoder's AGC schedule, alpha filter)
+            const bool steady = cfg.agc_off || (cfg.mode == RTFE_PE ? w.datablock : (w.peakcount > 15 && w.v_avg_height_count == 0));
+            if (cfg.pk_parallel && steady && (cfg.agc_off || (P.agc_window == 0 && P.agc_alpha != 0))) {
+               const int got = chain_parallel(cfg, P, S, w, c, tile0, wlimit, s_recs, s_eoff, s_ents, alive, nrec, lane, ev, cap, reset, d, trk, pidx);
+               if (got >= 0) { n_par += (unsigned)got; if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; break; } continue; } }
             long long best = kNoRow, best_doubt = kNoRow;
             int best_k = -1;
             bool best_top = false, top_done = false, bot_done = false;
@@ -256,7 +447,7 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
                e.parmset = (uint8_t)pidx;
                ev[w.nevents] = e; }
             if (u.top) w.v_top = val; else w.v_bot = val;
-            ++w.nevents;
+            ++w.nevents; ++n_seq;
             agc_after_peak(w, &cfg, P, s_heights + lane * 10, u.top, t_peak);      // (every lane keeps the same state; the window AGC's ring is per lane)
             if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; break; }      // src/decoder.c:782
             update_thresholds(w, P, cfg.lsb_per_volt);
@@ -276,6 +467,8 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
       if (lane == 0 && failed && getenv("RTFE_PK_DEBUG")) fprintf(stderr, "chain b %d p %d t %d failed why %d at c %lld (rise %f hi %d sure %d)\n", b, pidx, trk, why, c, w.rise, w.rise_hi, S.sure_i);
 #endif
       if (lane == 0) {
+         if (n_par) atomicAdd(&scratch->dbg[0], (unsigned long long)n_par);
+         if (n_seq) atomicAdd(&scratch->dbg[1], (unsigned long long)n_seq);
          if (failed) atomicExch(&ctl[b].status, (int)kBurstNeedsFull);
          counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = w.nevents < cap ? w.nevents : cap;
          if (w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW) atomicOr(&ctl[b].bflags, w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW); } } }

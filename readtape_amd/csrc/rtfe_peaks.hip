@@ -263,7 +263,8 @@ __device__ __forceinline__ void pk_dense(const uint32_t *x, const uint32_t *bmn,
          bm = (bm >> 1) | (b & kPkSigns); } }
    tmask = tm; bmask = bm; }
 
-__global__ void __launch_bounds__(704) k_peaks(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
+template <int NB, int MAXT>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 448 ? 4 : 3)) k_peaks(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
                                                uint16_t *__restrict__ qmap, PeakDir *__restrict__ dir_main, PeakDir *__restrict__ dir_spill,
                                                unsigned char *__restrict__ pool, unsigned long long pool_units, unsigned long long *__restrict__ pool_cursor,
                                                int pass, const unsigned int *__restrict__ dead) {
@@ -285,8 +286,7 @@ __global__ void __launch_bounds__(704) k_peaks(const DevCfg *__restrict__ cfgp, 
    const int HL = cfg.pk_hl, HR = cfg.pk_hr;
    const int row_bytes = ntrks * 2, strip_bytes = 16 * row_bytes + 8;
    const int nstrips = (HL + kPkTile + HR) >> 4, xls = HL >> 4;
-   int nbmax = 0;
-   for (int s = 0; s < cfg.nscreens; ++s) nbmax = max(nbmax, cfg.screen[s].nb);
+   const int nbmax = NB;
    const int xb = (nbmax + 3) >> 2;
    const int nblk = 4 * (64 + 2 * xb);
    const PkLds L = pk_lds_layout(ntrks, HL, HR, nbmax, cfg.pk_cand_cap, cfg.pk_rec_cap, cfg.pk_ent_cap);
@@ -409,23 +409,13 @@ __global__ void __launch_bounds__(704) k_peaks(const DevCfg *__restrict__ cfgp, 
          // ---- 3. candidate samples: local extremum, prominence against the block windows, amplitude ----
          uint32_t tm = 0, bm = 0;
          if (dense) {
-            const int NB = S.nb;
-            uint32_t bmn[4 + 2 * 12], bmx[4 + 2 * 12];
+            uint32_t bmn[4 + 2 * NB], bmx[4 + 2 * NB];                      // (NB is the widest screen's: a longer window only loosens the pre-filter)
             const uint32_t *bi0 = blk + (pair * 2) * nblk + 4 * (strip + xb) - NB;
             const uint32_t lo_pk = pk_dup(S.rise_i);
             const uint32_t mt = S.minpk_i < 0 ? pk_dup(-32768) : pk_dup(S.minpk_i), mb = S.minpk_i < 0 ? pk_dup(32767) : pk_dup(-S.minpk_i);
-            if (NB == 4) {
-               #pragma unroll
-               for (int i = 0; i < 12; ++i) { bmn[i] = bi0[i]; bmx[i] = bi0[nblk + i]; }
-               pk_dense<4>(x, bmn, bmx, lo_pk, mt, mb, tm, bm); }
-            else if (NB == 8) {
-               #pragma unroll
-               for (int i = 0; i < 20; ++i) { bmn[i] = bi0[i]; bmx[i] = bi0[nblk + i]; }
-               pk_dense<8>(x, bmn, bmx, lo_pk, mt, mb, tm, bm); }
-            else {
-               #pragma unroll
-               for (int i = 0; i < 28; ++i) { bmn[i] = bi0[i]; bmx[i] = bi0[nblk + i]; }
-               pk_dense<12>(x, bmn, bmx, lo_pk, mt, mb, tm, bm); }
+            #pragma unroll
+            for (int i = 0; i < 4 + 2 * NB; ++i) { bmn[i] = bi0[i]; bmx[i] = bi0[nblk + i]; }
+            pk_dense<NB>(x, bmn, bmx, lo_pk, mt, mb, tm, bm);
             if (2 * pair + 1 >= ntrks) { tm &= 0xffffu; bm &= 0xffffu; }       // odd track count: the last pair's upper half is the next row
             // rows that do not exist, and the tape's first / last sample, cannot own a run
             const long long r0 = t0 + 16 * strip;

@@ -62,6 +62,23 @@ DEFAULT_PARMSETS = {
 }
 
 
+def parse_track_order(order: str):
+    """head -> track permutation of the reference's -order= string / TBINORD header extension for PE, NRZI and GCR
+    (src/readtape.c:877-915): one character per head, a digit = that track (0 = msb), p/P = the parity track (last)."""
+    n = len(order)
+    h2t = []
+    for ch in order:
+        if ch in "pP":
+            h2t.append(n - 1)
+        elif ch.isdigit() and int(ch) <= n - 2:
+            h2t.append(int(ch))
+        else:
+            raise ValueError(f"bad track order string {order!r}")
+    if sorted(h2t) != list(range(n)):
+        raise ValueError(f"track order {order!r} is not a permutation")
+    return h2t
+
+
 @dataclass
 class FrontEndConfig:
     mode: int
@@ -87,6 +104,12 @@ class FrontEndConfig:
         mode = kw.pop("mode", h.mode)
         bpi = kw.pop("bpi", 9042.0 if mode == GCR else h.bpi)     # src/readtape.c:1652-1654
         ps = kw.pop("parmsets", None) or DEFAULT_PARMSETS[mode][:nparmsets]
+        # the header's TBINORD extension (src/readtape.c:1346-1355).  A file without TBIN_NO_REORDER "had a permutation applied to
+        # it" when it was made: the reference then ignores every track order, the command line's included (src/readtape.c:1646-1648)
+        if kw.get("head_to_trk") is None and h.trkorder:
+            kw["head_to_trk"] = parse_track_order(h.trkorder)
+        if not (h.flags & tbin.FLAG_NO_REORDER):
+            kw["head_to_trk"] = None
         return cls(mode=mode, ntrks=h.ntrks, maxvolts=h.maxvolts, bpi=bpi, ips=h.ips or 50.0,
                    tdelta_ns=h.tdelta_ns, tstart_ns=h.tstart_ns, parmsets=list(ps), **kw)
 
@@ -254,10 +277,10 @@ class FrontEnd:
     def scan_stats(self, result):
         """{'bursts', 'redone', 'record_bytes'} of the scan that produced `result` (synchronises; diagnostics)."""
         self.backend.sync()
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 8)()
         if self.lib.rtfe_scan_stats(self.h, self.backend.ptr(result.bufs["ws"]), out) != 0:
             raise RuntimeError(self.lib.rtfe_last_error().decode())
-        return dict(bursts=int(out[0]), redone=int(out[1]), record_bytes=int(out[2]))
+        return dict(bursts=int(out[0]), redone=int(out[1]), record_bytes=int(out[2]), parallel=int(out[3]), sequential=int(out[4]))
 
     def _buffers(self, nrows, key="scan"):
         """Allocates (once per size) the workspace and output buffers for a scan of nrows rows.  Exact rescans share ONE

@@ -202,11 +202,14 @@ def detect_density(hdr, rows, full, o, fe_factory, invert=False, log_path=None, 
 
 def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
                 skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None, differentiate=False,
-                subsample: int = 1, deskew: bool = False, deskew_prefix_rows: int = 1 << 22):
+                subsample: int = 1, deskew: bool = False, deskew_prefix_rows: int = 1 << 22, trkorder: str | None = None):
     """Decodes one tape; returns (stats dict, ScanResult).  `fe_factory(cfg)` builds the front end
     (default: the GPU one; tests/cpu_emul passes the emulated library)."""
     opts = opts or DecodeOptions()
     lib = _load_decode_lib()
+    if trkorder:                                                           # -order= wins over the header's TBINORD extension (src/readtape.c:1346-1355)
+        import dataclasses
+        hdr = dataclasses.replace(hdr, trkorder=trkorder)
     if subsample > 1:
         # -subsample=n (src/readtape.c:1407-1414): of every n rows the LAST one is used and the time base is not
         # stretched (timenow_ns still advances by tdelta per used row, :1424) - a strided view of the resident tape

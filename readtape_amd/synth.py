@@ -71,6 +71,8 @@ class TapeSpec:
     skew_cells: tuple = ()          # optional per-track static skew, in bit cells
     tstart_ns: int = 1_000_000
     seed: int = 1
+    flags: int = 0                  # TBIN header flags (tbin.FLAG_NO_REORDER: the columns are in head order, -order= applies)
+    trkorder: str = ""              # TBINORD header extension
 
     @property
     def samples_per_bit(self) -> float:
@@ -78,7 +80,7 @@ class TapeSpec:
 
     def header(self) -> tbin.TbinHeader:
         return tbin.TbinHeader(ntrks=self.ntrks, tdelta_ns=self.tdelta_ns, maxvolts=self.maxvolts,
-                               mode=self.mode, bpi=self.bpi, ips=self.ips, tstart_ns=self.tstart_ns,
+                               mode=self.mode, bpi=self.bpi, ips=self.ips, tstart_ns=self.tstart_ns, flags=self.flags, trkorder=self.trkorder,
                                descr=f"synthetic {tbin.MODE_NAMES.get(self.mode)} seed {self.seed}")
 
 

@@ -125,6 +125,39 @@ def case_nrzi9_oversampled(seed=18):
     return t
 
 
+def _reorder(t, order):
+    """The same recording with its heads wired in another order: column i of the file carries the track `order[i]` names
+    (a digit = that track, p = the parity track), which is what the reference's -order= undoes (src/readtape.c:877-915)."""
+    import dataclasses
+    n = t.rows.shape[1]
+    h2t = [n - 1 if ch in "pP" else int(ch) for ch in order]
+    # TBIN_NO_REORDER: "the columns were NOT put into canonical order when the file was made" - without it the reference
+    # ignores -order= and the TBINORD extension altogether (src/readtape.c:1646-1648)
+    return dataclasses.replace(t, rows=np.ascontiguousarray(t.rows[:, h2t]), spec=dataclasses.replace(t.spec, flags=t.spec.flags | tbin.FLAG_NO_REORDER))
+
+
+def case_nrzi7_order(seed=13):
+    return _reorder(case_nrzi7(seed), "543210p")           # examples/7trk_NRZI/Makefile:7
+
+
+def case_pe_order(seed=15):
+    return _reorder(case_pe(seed), "01234576p")            # examples/9trk_PE/Makefile:8
+
+
+def case_gcr_order(seed=16):
+    # the order travels in the file (TBINORD header extension), no -order= on the command line
+    import dataclasses
+    t = _reorder(case_gcr(seed), "p76543210")
+    return dataclasses.replace(t, spec=dataclasses.replace(t.spec, trkorder="p76543210"))
+
+
+def case_nrzi7_order_ignored(seed=13):
+    # the same columns but WITHOUT TBIN_NO_REORDER: the reference ignores -order= (and decodes garbage)
+    import dataclasses
+    t = case_nrzi7_order(seed)
+    return dataclasses.replace(t, spec=dataclasses.replace(t.spec, flags=0))
+
+
 # name -> (tape builder, reference options, oracle options)
 CASES = {
     "nrzi9":        (case_nrzi9,      ["-nrzi"],                       []),
@@ -157,6 +190,10 @@ CASES = {
     "nrzi9_cut_zeros": (case_nrzi9_cut, ["-nrzi", "-zeros"],            ["-zeros"]),
     "noise_only":   (case_noise_only, ["-nrzi"],                       []),
     "tiny":         (case_tiny,       ["-nrzi"],                       []),
+    "nrzi7_order":  (case_nrzi7_order, ["-nrzi", "-ntrks=7", "-order=543210p"], ["-order=543210p"]),
+    "pe_order":     (case_pe_order,   ["-pe", "-order=01234576p"],     ["-order=01234576p"]),
+    "gcr_order_m":  (case_gcr_order,  ["-gcr", "-m"],                  ["-m"]),
+    "nrzi7_order_ignored": (case_nrzi7_order_ignored, ["-nrzi", "-ntrks=7", "-order=543210p"], ["-order=543210p"]),
     "gcr_errs":     (case_gcr_errors, ["-gcr"],                        []),
     "gcr_correct":  (case_gcr_errors, ["-gcr", "-correct"],            ["-correct"]),
 }

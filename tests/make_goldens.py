@@ -1,7 +1,7 @@
 """Generates tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref/readtape_evt, built by
 oracle/Makefile from /root/reference/src).  Run in the build container only:
 
-    python tests/make_goldens.py
+    python tests/make_goldens.py [case ...]        (no names: all cases)
 
 Each vector holds: the synthetic tape (int16 rows + header fields), the reference command line, the
 reference's SIMH .tap bytes, its exit code and its front-end event dump (oracle/ref_event_shim.c).
@@ -28,15 +28,18 @@ def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
     os.makedirs(OUT, exist_ok=True)
     tapes = {}
+    only = set(sys.argv[1:])
     for name in sorted(CASES):
+        if only and name not in only:
+            continue
         build, ref_opts, or_opts = CASES[name]
         tape = build()
         tkey = build.__name__
-        if tkey not in tapes:
+        if tkey not in tapes and not (only and os.path.exists(os.path.join(OUT, f"tape_{tkey}.npz")) and tkey in ("case_nrzi7", "case_pe", "case_gcr")):
             tapes[tkey] = tape
             s = tape.spec
             np.savez_compressed(os.path.join(OUT, f"tape_{tkey}.npz"), rows=tape.rows,
-                                hdr=np.array([s.ntrks, s.tdelta_ns, s.mode, s.tstart_ns], dtype=np.int64),
+                                hdr=np.array([s.ntrks, s.tdelta_ns, s.mode, s.tstart_ns, s.flags], dtype=np.int64), trkorder=np.array(s.trkorder),
                                 hdrf=np.array([s.maxvolts, s.bpi, s.ips], dtype=np.float32))
         with tempfile.TemporaryDirectory() as wd:
             tape.write(os.path.join(wd, "t.tbin"))

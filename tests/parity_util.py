@@ -55,6 +55,8 @@ def config_for(hdr, oracle_opts, parmset_ids=None, **kw):
     for o in oracle_opts:
         if o.startswith("-skew="):
             skew = [int(x) for x in o[6:].split(",")]
+        if o.startswith("-order="):
+            kw.setdefault("head_to_trk", frontend.parse_track_order(o[7:]))
     sets = frontend.DEFAULT_PARMSETS[mode][:nparm] if mode != frontend.GCR else frontend.DEFAULT_PARMSETS[mode][: min(nparm, 5)]
     return frontend.FrontEndConfig.from_header(hdr, parmsets=sets, skew=skew, invert="-invert" in oracle_opts, **kw)
 

@@ -7,7 +7,7 @@ from emul_util import emul_frontend
 from golden_util import load_case
 from parity_util import check_tape, config_for, oracle_attempts
 
-PEAK_CASES = ["nrzi9", "nrzi9_m", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "gcr", "gcr_m"]
+PEAK_CASES = ["nrzi9", "nrzi9_m", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "gcr", "gcr_m", "nrzi7_order", "pe_order"]
 
 
 @pytest.mark.parametrize("name", PEAK_CASES)
