@@ -415,6 +415,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       const long long ptiles = pk_tiles_for(nrows);
       (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
       t0(0, st); t1(0, st); t0(2, st); t1(2, st); t0(3, st); t1(3, st); t0(4, st); t1(4, st);
+      const int stop_after = getenv("RTFE_PEAK_STOP") ? atoi(getenv("RTFE_PEAK_STOP")) : 99;      // (debugging: launch only the first n kernels of the path)
       t0(6, st);
       const int pthreads = 64 * ((h->dev.ntrks + 1) / 2 + 1);
       const long long pgrid = ((ptiles + 7) / 8) * 8;
@@ -422,19 +423,25 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(pkk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                          reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pool_units, &scratch->pool_cursor, 0, (const unsigned int *)deadp);
       t1(6, st); t0(1, st);
+      if (stop_after < 2) { t1(1, st); t0(7, st); t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                          h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
                          d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts,
                          deadp, ptiles, (int)kPkTile, h->dev.tail_rows);
       t1(1, st); t0(7, st);
+      if (stop_after < 3) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(pkk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                          reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pool_units, &scratch->pool_cursor, 1, (const unsigned int *)deadp);
+      if (stop_after < 4) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);
+      if (stop_after < 5) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_chain, dim3(h->num_cus * 16), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                          scratch, ctlp, d_counts, d_events, (const PeakDir *)dirm, (const PeakDir *)dirs, (const unsigned char *)pkpool, ptiles);
+      if (stop_after < 6) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(7, st); t0(5, st);
+      if (stop_after < 7) { t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
                          (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeRedo, ctlp, statep);
@@ -503,12 +510,20 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t1(5, st); }
    return launch_check("rtfe_scan"); }
 
+// Debugging aid (tools/pk_dump.py): where the peak-record path keeps its directories and its pool inside the workspace.
+extern "C" int rtfe_debug_layout(const rtfe_handle *h, int64_t nrows, int64_t *out) {
+   if (!h || !out) return fail(-1, "null argument");
+   out[0] = (int64_t)ws_pkdir_off(h, nrows); out[1] = (int64_t)(ws_pkdir_off(h, nrows) + pk_dir_bytes(h, nrows)); out[2] = (int64_t)ws_pkpool_off(h, nrows);
+   out[3] = (int64_t)pk_tiles_for(nrows); out[4] = h->dev.nscreens; out[5] = (int64_t)ws_ctl_off(h, nrows);
+   return 0; }
+
 // Synchronous (copies three words back): what the last rtfe_scan on this workspace did.
 extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out) {
    if (!h || !d_workspace || !out) return fail(-1, "null argument");
    BurstScratch sc;
    if (hipMemcpy(&sc, d_workspace, sizeof sc, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
    out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.pool_cursor * 16; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
+   for (int i = 0; i < 8; ++i) out[5 + i] = (int64_t)sc.why[i];
    return 0; }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

@@ -170,7 +170,7 @@ __device__ __forceinline__ int lane_first(const LaneRun &u, const uint16_t *ents
 
 __device__ __forceinline__ int chain_parallel(const DevCfg &cfg, const DevParm &P, const DevScreen &S, Walker &w, long long &c, long long tile0, long long wlimit,
                                               const PeakRec *recs, const uint16_t *eoff, const uint16_t *ents, int k0, int nrec, int lane,
-                                              rtfe_event *ev, unsigned int cap, long long reset, int d, int trk, int pidx) {
+                                              rtfe_event *ev, unsigned int cap, long long reset, int d, int trk, int pidx, float *ring, float *hv) {
    const int W = P.W;
    const float mv = cfg.maxvolts;
    const int n = nrec - k0 < 64 ? nrec - k0 : 64;
@@ -241,18 +241,50 @@ __device__ __forceinline__ int chain_parallel(const DevCfg &cfg, const DevParm &
    const float lasttop = (ph & 1) ? plt : w.v_lasttop, lastbot = (ph & 2) ? plb : w.v_lastbot;
    const float lastheight = lasttop - lastbot;
    const bool adj = fired && !cfg.agc_off && lastheight > 0;
-   const float a = adj ? P.agc_alpha * (w.v_avg_height / lastheight) : 0.0f;
-   const float beta = 1 - P.agc_alpha;
    float g = w.agc_gain, gbefore = g;
    const u64 am = __ballot(adj);
-   for (u64 m = fm; m; m &= m - 1) {
-      const int i = __ffsll((long long)m) - 1;
-      if (lane == i) gbefore = g;
-      if ((am >> i) & 1ull) {
-         const float ai = __uint_as_float((unsigned)__shfl((int)__float_as_uint(a), i));
-         float g2 = ai + beta * g;                                            // src/decoder.c:510-512
-         if (g2 > 2.0f) g2 = 2.0f;
-         g = g2; } }
+   const int NW = P.agc_window;
+   if (NW == 0) {                                                           // exponential AGC: g = alpha (h / lastheight) + (1 - alpha) g, clamped (src/decoder.c:505-512)
+      const float a = adj ? P.agc_alpha * (w.v_avg_height / lastheight) : 0.0f;
+      const float beta = 1 - P.agc_alpha;
+      for (u64 m = fm; m; m &= m - 1) {
+         const int i = __ffsll((long long)m) - 1;
+         if (lane == i) gbefore = g;
+         if ((am >> i) & 1ull) {
+            const float ai = __uint_as_float((unsigned)__shfl((int)__float_as_uint(a), i));
+            float g2 = ai + beta * g;
+            if (g2 > 2.0f) g2 = 2.0f;
+            g = g2; } } }
+   else {                                                                    // window AGC: g = h / min(last NW heights), clamped (src/decoder.c:516-529): no recurrence at all
+      const int nv = __popcll(am), jv = __popcll(am & ((1ull << lane) - 1));
+      __syncthreads();
+      if (adj) hv[jv] = lastheight;
+      __syncthreads();
+      float ga = 0; bool hg = false;
+      if (adj) {
+         float mn = lastheight;
+         for (int i = 1; i < NW; ++i) {
+            const int idx = jv - i;                                          // the i-th height before this one: of this stretch, or from the ring as it stood
+            const float v = idx >= 0 ? hv[idx] : ring[(w.heightndx + NW + idx) % NW];
+            if (v < mn) mn = v; }
+         ga = w.v_avg_height / mn;
+         if (ga > 2.0f) ga = 2.0f;
+         hg = true; }
+      // gain in force when each detection's callback starts = the one the last adjustment in front of it left
+      float xg = ga; bool xh = hg;
+      #pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+         const float yg = __uint_as_float((unsigned)__shfl_up((int)__float_as_uint(xg), o));
+         const int yh = __shfl_up(xh ? 1 : 0, o);
+         if (lane >= o && !xh && yh) { xg = yg; xh = true; } }
+      const float pg = __uint_as_float((unsigned)__shfl_up((int)__float_as_uint(xg), 1));
+      int ph2 = __shfl_up(xh ? 1 : 0, 1);
+      if (lane == 0) ph2 = 0;
+      gbefore = ph2 ? pg : w.agc_gain;
+      const float fg = __uint_as_float((unsigned)__shfl((int)__float_as_uint(xg), 63));
+      g = __shfl(xh ? 1 : 0, 63) ? fg : w.agc_gain;
+      // (the ring itself is brought up to date at the commit)
+      (void)nv; }
    if (!(g > 0)) return -1;
    // ---- (3) exact thresholds per detection: the firing row, and that the band held ----
    Walker wk = w;
@@ -300,6 +332,10 @@ __device__ __forceinline__ int chain_parallel(const DevCfg &cfg, const DevParm &
    const int fh = __shfl((ht ? 1 : 0) | (hb ? 2 : 0), 63);
    if (fh & 1) { w.v_lasttop = flt; w.v_top = flt; }
    if (fh & 2) { w.v_lastbot = flb; w.v_bot = flb; }
+   if (NW > 0) {                                                             // the ring: the last heights of the stretch, where the one-at-a-time walk would have left them
+      const int nv = __popcll(am);
+      for (int t = 0; t < nv && t < NW; ++t) ring[(w.heightndx + nv - 1 - t) % NW] = hv[nv - 1 - t];
+      w.heightndx = (w.heightndx + nv) % NW; }
    w.agc_gain = g;
    w.peakcount += nf;
    w.nevents += (unsigned)nf;
@@ -318,11 +354,14 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
    __shared__ uint16_t s_eoff[kChRecCap];
    __shared__ uint16_t s_ents[kChEntCap];
    __shared__ float s_heights[64 * 10];
+   __shared__ float s_hv[64];
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
    const int lane = threadIdx.x;
    const float mv = cfg.maxvolts;
+   unsigned int g_outer = 0;
    for (;;) {
+      if (++g_outer > 100000u) { break; }
       int idx = 0;
       if (lane == 0) idx = atomicAdd(&scratch->queue_walk, 1);
       idx = __shfl(idx, 0);
@@ -347,7 +386,7 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
       const unsigned int cap = B.event_cap;
       bool failed = false;
       int why = 0;
-      unsigned int n_par = 0, n_seq = 0;                                   // detections decided by all lanes at once / one at a time (statistics)
+      unsigned int n_par = 0, n_seq = 0, guard = 0;                                   // detections decided by all lanes at once / one at a time (statistics)
       for (long long g = c / kPkTile; g * kPkTile < limit && g < ntiles && !failed; ++g) {
          const long long tile0 = g * kPkTile;
          // ---- the tile's lists: what the previous tile spilled, then its own, as one list ordered by the row of the sample that
@@ -362,7 +401,9 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
          const uint16_t *e0 = reinterpret_cast<const uint16_t *>(pool + (size_t)ds.blob * 16 + (size_t)ds.ents8 * 8) + ds.ent_rel;
          const uint16_t *e1 = reinterpret_cast<const uint16_t *>(pool + (size_t)dm.blob * 16 + (size_t)dm.ents8 * 8) + dm.ent_rel;
          int base = 0, ent_base = 0;                                          // the window of the list held in LDS starts here
+         unsigned int g_win = 0;
          while (base < nrec_all && !failed) {
+         if (++g_win > 5000u) { failed = true; why = 7; break; }
          int nrec = min(kChRecCap, nrec_all - base);
          __syncthreads();
          for (int i = lane; i < nrec; i += 64) { const int j = base + i; s_recs[i] = j < (int)ds.nrec ? r0[j] : r1[j - ds.nrec]; }
@@ -393,12 +434,13 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
          // ---- the sequential walk (every lane runs it; lane 0 stores): earliest firing run among the tops and the bottoms ----
          int alive = 0;
          for (;;) {
+            if (++guard > 200000u) { failed = true; why = 7; break; }           // (cannot happen: every round moves c forward; a safety net against spinning on a GPU)
             while (alive < nrec && run_decode(s_recs[alive], tile0, 0).pos + W - 2 < c) ++alive;
             if (alive >= nrec) break;
             // clean stretches: all lanes at once (steady state of the block decoder's AGC schedule, alpha filter)
             const bool steady = cfg.agc_off || (cfg.mode == RTFE_PE ? w.datablock : (w.peakcount > 15 && w.v_avg_height_count == 0));
-            if (cfg.pk_parallel && steady && (cfg.agc_off || (P.agc_window == 0 && P.agc_alpha != 0))) {
-               const int got = chain_parallel(cfg, P, S, w, c, tile0, wlimit, s_recs, s_eoff, s_ents, alive, nrec, lane, ev, cap, reset, d, trk, pidx);
+            if (cfg.pk_parallel && steady) {
+               const int got = chain_parallel(cfg, P, S, w, c, tile0, wlimit, s_recs, s_eoff, s_ents, alive, nrec, lane, ev, cap, reset, d, trk, pidx, s_heights + lane * 10, s_hv);
                if (got >= 0) { n_par += (unsigned)got; if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; break; } continue; } }
             long long best = kNoRow, best_doubt = kNoRow;
             int best_k = -1;
@@ -469,7 +511,7 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
       if (lane == 0) {
          if (n_par) atomicAdd(&scratch->dbg[0], (unsigned long long)n_par);
          if (n_seq) atomicAdd(&scratch->dbg[1], (unsigned long long)n_seq);
-         if (failed) atomicExch(&ctl[b].status, (int)kBurstNeedsFull);
+         if (failed) { atomicExch(&ctl[b].status, (int)kBurstNeedsFull); atomicAdd(&scratch->why[why & 7], 1ull); }
          counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = w.nevents < cap ? w.nevents : cap;
          if (w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW) atomicOr(&ctl[b].bflags, w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW); } } }
 
