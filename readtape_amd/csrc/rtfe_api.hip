@@ -46,8 +46,8 @@ static int fail(int code, const char *fmt, ...) {
    return code; }
 
 // the k_peaks instantiation for a block-window size and a workgroup size
-typedef void (*pk_kernel_t)(const DevCfg *, const int16_t *, long long, long long, uint16_t *, PeakDir *, PeakDir *, unsigned char *, unsigned long long,
-                            unsigned long long *, int, const unsigned int *);
+typedef void (*pk_kernel_t)(const DevCfg *, const int16_t *, long long, long long, uint16_t *, PeakDir *, PeakDir *, unsigned char *, unsigned char *,
+                            unsigned long long *, int, const unsigned int *, unsigned long long *);
 static pk_kernel_t pk_kernel(int nb, int threads) {
    if (threads <= 448) return nb <= 4 ? k_peaks<4, 448> : (nb <= 8 ? k_peaks<8, 448> : k_peaks<12, 448>);
    return nb <= 4 ? k_peaks<4, 704> : (nb <= 8 ? k_peaks<8, 704> : k_peaks<12, 704>); }
@@ -198,8 +198,10 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
    d.cut = getenv("RTFE_CUT") ? atoi(getenv("RTFE_CUT")) : 0;
    {  // the peak-record path (k_peaks -> k_chain): every peak-detection scan on the undifferentiated signal
-      d.peak_path = !d.find_zeros && !d.differentiate;
-      if (const char *e = getenv("RTFE_PEAK_PATH")) d.peak_path = d.peak_path && atoi(e) != 0;
+      // opt-in (RTFE_PEAK_PATH=1): bit-identical to the sample / candidate-run kernels on every tape tried, but not yet faster than them
+      // on an MI355X (what was measured, and why) - the default scan keeps the kernels of rtfe_kernels.hip
+      d.peak_path = 0;
+      if (const char *e = getenv("RTFE_PEAK_PATH")) d.peak_path = !d.find_zeros && !d.differentiate && atoi(e) != 0;
       d.pk_parallel = 1;
       if (const char *e = getenv("RTFE_CHAIN_PARALLEL")) d.pk_parallel = atoi(e) != 0;
       int wmax = 0, nbmax = 0;
@@ -208,20 +210,20 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       int hl = kPkBack + 2 * wmax + 6; if (hl < 16 * xb + 16) hl = 16 * xb + 16;
       int hr = wmax + 2;               if (hr < 16 * xb) hr = 16 * xb;
       d.pk_hl = (hl + 15) & ~15; d.pk_hr = (hr + 15) & ~15;
-      // staging: flux transitions per tile from the bit cell (PE: up to two per cell), both polarities, all tracks, plus noise candidates
+      // pool slots: flux transitions per tile and head from the bit cell (PE: up to two per cell), ~14 bytes each (a record and three
+      // margins), half as much again for noise and weak peaks.  RTFE_PK_SLOT: tests force the capacity path.
       const float spbf = 1.0f / (bpi_s * c->ips * d.sample_deltat);
       const float ppb = c->mode == RTFE_PE ? 2.0f : 1.0f;
-      int cand = (int)((float)kPkTile / (spbf > 2 ? spbf : 2) * ppb * (float)c->ntrks * 1.5f) + 192;
-      // a screen below the noise floor (small pkww_rise at the assumed baseline floor) makes candidates of noise wiggles: up to a third of all samples
+      int slot = (int)((float)kPkTile / (spbf > 2 ? spbf : 2) * ppb * 14.0f * 1.5f) + 160;
       int lo_min = 1 << 30;
       for (int sidx = 0; sidx < d.nscreens; ++sidx) if (d.screen[sidx].rise_i < lo_min) lo_min = d.screen[sidx].rise_i;
       const bool noisy_screen = (double)lo_min / lsb_per_volt < 0.03;
-      if (noisy_screen && cand < 2 * kPkTile) cand = 2 * kPkTile;          // (a tile's heads go through the staging area in groups; one head always fits)
-      if (cand < kPkTile + 64) cand = kPkTile + 64;
-      if (cand > 4096) cand = 4096;
-      if (const char *e = getenv("RTFE_PK_CAND_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 4096) cand = v; }      // (tests: force the capacity path)
-      d.pk_cand_cap = cand; d.pk_rec_cap = noisy_screen ? cand + 64 : cand + cand / 4 + 16; d.pk_ent_cap = d.pk_rec_cap * (noisy_screen ? 6 : 3);      // (noise runs never reach the sure level: every row explicit)
-      d.pk_lds = (int)pk_lds_layout(c->ntrks, d.pk_hl, d.pk_hr, nbmax, d.pk_cand_cap, d.pk_rec_cap, d.pk_ent_cap).total + 64;
+      if (noisy_screen) slot *= 3;                                        // a screen below the noise floor: noise wiggles become runs, every row explicit
+      d.pk_wave_cap = noisy_screen ? 2048 : 512;
+      if (const char *e = getenv("RTFE_PK_SLOT")) { const int v = atoi(e); if (v >= 32 && v <= 65536) slot = v; }
+      d.pk_slot = (slot + 15) & ~15;
+      d.pk_sslot = 16 * (8 + 2 * 8);                                      // runs that continue from the previous tile's last W - 2 rows: a handful
+      d.pk_lds = (int)pk_lds_layout(c->ntrks, d.pk_hl, d.pk_hr, nbmax, d.pk_wave_cap).total + 64;
       if (d.pk_lds > 150 * 1024) d.peak_path = 0; }
    {
       const int nwalk = c->nparmsets * c->ntrks;
@@ -262,7 +264,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       const LdsLayout Ld = lds_layout(d, true);
       fprintf(stderr, "rtfe: LDS k_decode %d (tile..bits %u, bits..ldpos %u, ldpos..heights %u, recs %u, walkers %u) k_screen %d\n", h->lds_bytes, Ld.bits, Ld.ldpos - Ld.bits,
               Ld.heights - Ld.ldpos, Ld.nrec - Ld.recs, Ld.walkers_next - Ld.walkers, h->screen_lds_bytes);
-      fprintf(stderr, "rtfe: peak path %d, k_peaks LDS %d (halo %d/%d rows, caps %d/%d/%d)\n", d.peak_path, d.pk_lds, d.pk_hl, d.pk_hr, d.pk_cand_cap, d.pk_rec_cap, d.pk_ent_cap);
+      fprintf(stderr, "rtfe: peak path %d, k_peaks LDS %d (halo %d/%d rows, slots %d/%d bytes)\n", d.peak_path, d.pk_lds, d.pk_hl, d.pk_hr, d.pk_slot, d.pk_sslot);
       for (int sidx = 0; sidx < d.nscreens; ++sidx) fprintf(stderr, "rtfe: screen %d W %d rise_i %d minpk_i %d sure_i %d nb %d\n", sidx, d.screen[sidx].W, d.screen[sidx].rise_i, d.screen[sidx].minpk_i, d.screen[sidx].sure_i, d.screen[sidx].nb); }
    hipDeviceProp_t prop;
    int dev = 0;
@@ -341,12 +343,11 @@ static size_t ws_pkdir_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_segend_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
 static size_t pk_dir_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)(pk_tiles_for(nrows) + 1) * h->dev.nscreens * h->dev.ntrks * sizeof(PeakDir) + 255) & ~(size_t)255; }
 static size_t ws_pkpool_off(const rtfe_handle *h, int64_t nrows) { return ws_pkdir_off(h, nrows) + (h->dev.peak_path ? 2 * pk_dir_bytes(h, nrows) : 0); }
+static size_t pk_own_bytes(const rtfe_handle *h, int64_t nrows) {      // one slot per (tile, screen, head)
+   return (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * (size_t)h->dev.pk_slot) + 255) & ~(size_t)255; }
 static size_t pk_pool_bytes(const rtfe_handle *h, int64_t nrows) {
    if (!h->dev.peak_path) return 0;
-   // ~12 bytes per flux transition and screen (8-byte record + two margins), twice that for noise and weak peaks
-   const double spb = 1.0 / ((h->dev.agc_off ? 1.0 / (h->cfg.ips * ((double)h->cfg.tdelta_ns / 1e9) * 12.0) : (double)h->cfg.bpi) * h->cfg.ips * ((double)h->cfg.tdelta_ns / 1e9));
-   const double per_row = (h->dev.mode == RTFE_PE ? 2.0 : 1.0) / (spb > 2 ? spb : 2) * h->dev.ntrks * 24.0 * h->dev.nscreens;
-   return (((size_t)((double)nrows * per_row) + (size_t)pk_tiles_for(nrows) * 32 + (1u << 20)) + 255) & ~(size_t)255; }
+   return pk_own_bytes(h, nrows) + ((((size_t)pk_tiles_for(nrows) + 1) * h->dev.nscreens * h->dev.ntrks * (size_t)h->dev.pk_sslot + 255) & ~(size_t)255); }
 
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
    return ws_pkpool_off(h, nrows) + pk_pool_bytes(h, nrows) + 256; }
@@ -411,7 +412,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       PeakDir *dirm = reinterpret_cast<PeakDir *>(wsb + ws_pkdir_off(h, nrows));
       PeakDir *dirs = reinterpret_cast<PeakDir *>(wsb + ws_pkdir_off(h, nrows) + pk_dir_bytes(h, nrows));
       unsigned char *pkpool = reinterpret_cast<unsigned char *>(wsb + ws_pkpool_off(h, nrows));
-      const unsigned long long pool_units = pk_pool_bytes(h, nrows) / 16;
+      unsigned char *pkspill = pkpool + pk_own_bytes(h, nrows);
       const long long ptiles = pk_tiles_for(nrows);
       (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
       t0(0, st); t1(0, st); t0(2, st); t1(2, st); t0(3, st); t1(3, st); t0(4, st); t1(4, st);
@@ -421,7 +422,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       const long long pgrid = ((ptiles + 7) / 8) * 8;
       const pk_kernel_t pkk = pk_kernel(h->dev.screen[0].nb, pthreads);
       hipLaunchKernelGGL(pkk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
-                         reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pool_units, &scratch->pool_cursor, 0, (const unsigned int *)deadp);
+                         reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pkspill, &scratch->pool_cursor, 0, (const unsigned int *)deadp, scratch->scr);
       t1(6, st); t0(1, st);
       if (stop_after < 2) { t1(1, st); t0(7, st); t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
@@ -431,13 +432,13 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t1(1, st); t0(7, st);
       if (stop_after < 3) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(pkk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
-                         reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pool_units, &scratch->pool_cursor, 1, (const unsigned int *)deadp);
+                         reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pkspill, &scratch->pool_cursor, 1, (const unsigned int *)deadp, scratch->scr);
       if (stop_after < 4) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);
       if (stop_after < 5) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_chain, dim3(h->num_cus * 16), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                         scratch, ctlp, d_counts, d_events, (const PeakDir *)dirm, (const PeakDir *)dirs, (const unsigned char *)pkpool, ptiles);
+                         scratch, ctlp, d_counts, d_events, (const PeakDir *)dirm, (const PeakDir *)dirs, (const unsigned char *)pkpool, (const unsigned char *)pkspill, ptiles);
       if (stop_after < 6) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(7, st); t0(5, st);
@@ -447,6 +448,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                          (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeRedo, ctlp, statep);
       t1(5, st);
       return launch_check("rtfe_scan"); }
+   (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
    t0(6, sq); t1(6, sq); t0(7, sq); t1(7, sq);
    t0(0, sq);
    hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, sq, d_rows, (long long)nrows, h->dev.ntrks, h->dev.quiet_i, qwords, nwords);
@@ -522,8 +524,9 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
    if (!h || !d_workspace || !out) return fail(-1, "null argument");
    BurstScratch sc;
    if (hipMemcpy(&sc, d_workspace, sizeof sc, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
-   out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.pool_cursor * 16; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
+   out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.pool_cursor; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
    for (int i = 0; i < 8; ++i) out[5 + i] = (int64_t)sc.why[i];
+   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)sc.scr[i];      // RTFE_DEBUG=3: k_peaks cycles per phase (copy, blocks, dense, compaction, candidates, copy-out, -, tiles)
    return 0; }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

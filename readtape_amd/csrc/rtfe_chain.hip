@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
                                               const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                               uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                               const PeakDir *__restrict__ dir_main, const PeakDir *__restrict__ dir_spill,
-                                              const unsigned char *__restrict__ pool, long long ntiles) {
+                                              const unsigned char *__restrict__ pool_own, const unsigned char *__restrict__ pool_spill, long long ntiles) {
    __shared__ PeakRec s_recs[kChRecCap];
    __shared__ uint16_t s_eoff[kChRecCap];
    __shared__ uint16_t s_ents[kChEntCap];
@@ -396,10 +396,10 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
          if (ds.nrec >= 0xfffe || dm.nrec >= 0xfffe) { failed = true; why = 1; break; }                  // (capacity, or a quiet tile nobody was expected to need)
          const int nrec_all = (int)ds.nrec + dm.nrec;
          if (nrec_all == 0) continue;
-         const PeakRec *r0 = reinterpret_cast<const PeakRec *>(pool + (size_t)ds.blob * 16) + ds.rec_rel;
-         const PeakRec *r1 = reinterpret_cast<const PeakRec *>(pool + (size_t)dm.blob * 16) + dm.rec_rel;
-         const uint16_t *e0 = reinterpret_cast<const uint16_t *>(pool + (size_t)ds.blob * 16 + (size_t)ds.ents8 * 8) + ds.ent_rel;
-         const uint16_t *e1 = reinterpret_cast<const uint16_t *>(pool + (size_t)dm.blob * 16 + (size_t)dm.ents8 * 8) + dm.ent_rel;
+         // (a slot holds its records at the front and its margin entries from the back: entry e at end[-(e + 1)])
+         const size_t li = (size_t)(g * cfg.nscreens + P.screen) * ntrks + head;
+         const PeakRec *r0 = reinterpret_cast<const PeakRec *>(pool_spill + li * cfg.pk_sslot), *r1 = reinterpret_cast<const PeakRec *>(pool_own + li * cfg.pk_slot);
+         const uint16_t *e0 = reinterpret_cast<const uint16_t *>(pool_spill + (li + 1) * cfg.pk_sslot), *e1 = reinterpret_cast<const uint16_t *>(pool_own + (li + 1) * cfg.pk_slot);
          int base = 0, ent_base = 0;                                          // the window of the list held in LDS starts here
          unsigned int g_win = 0;
          while (base < nrec_all && !failed) {
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
          int carry = 0;
          for (int b0 = 0; b0 < nrec; b0 += 64) {                             // first entry of every record of the window
             const int i = b0 + lane;
-            const int v = i < nrec ? pk_nent(s_recs[i].w0) : 0;
+            const int v = i < nrec ? pk_nent(s_recs[i].w0, s_recs[i].w1) : 0;
             int incl = v;
             #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
@@ -420,9 +420,9 @@ __global__ void __launch_bounds__(64) k_chain(const DevCfg *__restrict__ cfgp, l
          __syncthreads();
          if (carry > kChEntCap) {                                              // keep the records whose margins fit
             int keep = 0;
-            while (keep < nrec && (int)s_eoff[keep] + pk_nent(s_recs[keep].w0) <= kChEntCap) ++keep;
-            nrec = keep; carry = nrec ? (int)s_eoff[nrec - 1] + pk_nent(s_recs[nrec - 1].w0) : 0; }
-         for (int i = lane; i < carry; i += 64) { const int j = ent_base + i; s_ents[i] = j < (int)ds.nent ? e0[j] : e1[j - ds.nent]; }
+            while (keep < nrec && (int)s_eoff[keep] + pk_nent(s_recs[keep].w0, s_recs[keep].w1) <= kChEntCap) ++keep;
+            nrec = keep; carry = nrec ? (int)s_eoff[nrec - 1] + pk_nent(s_recs[nrec - 1].w0, s_recs[nrec - 1].w1) : 0; }
+         for (int i = lane; i < carry; i += 64) { const int j = ent_base + i; s_ents[i] = j < (int)ds.nent ? e0[-(j + 1)] : e1[-(j - (int)ds.nent + 1)]; }
          __syncthreads();
          // rows this window decides: up to the earliest row a record behind it could start at
          long long wlimit = limit < tile0 + kPkTile ? limit : tile0 + kPkTile;      // (a list holds rows of its tile only)

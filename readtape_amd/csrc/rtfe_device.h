@@ -73,7 +73,8 @@ struct DevCfg {
    int   cut;                     // RTFE_CUT: k_screen stops after a phase (timing experiments, tools/ only; results are then garbage)
    int   peak_path;               // k_peaks -> k_chain serve rtfe_scan (peak detection on the undifferentiated signal)
    int   pk_hl, pk_hr;            // rows kept in front of / behind a k_peaks tile in LDS (multiples of 16)
-   int   pk_cand_cap, pk_rec_cap, pk_ent_cap;   // k_peaks LDS staging: candidates, records, margin entries per tile and screen
+   int   pk_slot, pk_sslot;       // bytes of the pool's slots: a tile's own list of one head, the list spilled into it
+   int   pk_wave_cap;             // candidates of one wave (two heads of a tile) k_peaks can list in LDS; beyond: lists unavailable
    int   pk_lds;                  // dynamic LDS bytes of k_peaks
    int   pk_parallel;             // k_chain: decide clean stretches of 64 runs in parallel (0: always the sequential walk; tests)
    DevParm   parm[RTFE_MAXPARMSETS];
@@ -139,14 +140,11 @@ constexpr int kPkBack    = 64;       // rows k_peaks looks back for the last for
 //       0xffff8000: k_peaks could not derive the reference's minimum; rows f .. f+nsure-1 are undecidable from the record
 // margin of a row = val - max(left edge, right edge) (tops) / min(edges) - val (bottoms), int16 code differences.
 struct PeakRec { uint32_t w0, w1; };
-struct PeakDir {               // per (tile, screen, head): 16 bytes; one array for the tile's own runs, one for the runs spilled into it
-   uint32_t blob;              // the writing tile's blob in the pool, 16-byte units
-   uint16_t rec_rel;           // this list's first record, in records from the blob's start
-   uint16_t nrec;              // 0xFFFF: list not available (capacity)
-   uint16_t ent_rel;           // this list's first margin entry, in entries from the blob's entry area
+// The pool: one fixed slot per (tile, screen, head) for the tile's own list (pk_slot bytes) and one for the list the previous tile
+// spills into it (pk_sslot bytes).  Inside a slot the records grow from the front, the margin entries from the back (entry e at
+// slot_end - 2 (e + 1)); a list that does not fit is marked unavailable in the directory.
+struct PeakDir {               // per (tile, screen, head): 4 bytes; one array for the tile's own lists, one for the lists spilled into it
+   uint16_t nrec;              // 0xFFFF: not available (capacity); 0xFFFE: a quiet tile nobody was expected to need
    uint16_t nent;
-   uint16_t ents8;             // the blob's entry area, 8-byte units from the blob's start
-   uint16_t pad;
 };
-
 }  // namespace rtfe

@@ -62,9 +62,6 @@ struct BurstScratch {            // lives in the workspace (first kScratchBytes 
    unsigned long long scr[8];    // k_screen per-phase cycle counters (debug)
 };
 static_assert(sizeof(BurstScratch) <= kScratchBytes, "scratch region too small");
-#ifdef RTFE_CPU_EMUL
-static inline long long clock64() { return 0; }
-#endif
 
 __device__ __forceinline__ bool quiet_at(const u64 *q, long long c, long long nchunks) {
    return c >= 0 && c < nchunks && ((q[c >> 6] >> (c & 63)) & 1); }
@@ -213,7 +210,7 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
    if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0;
    if (threadIdx.x >= 16 && threadIdx.x < 24) scratch->dbg2[threadIdx.x - 16] = 0;
    if (threadIdx.x >= 24 && threadIdx.x < 32) scratch->why[threadIdx.x - 24] = 0;
-   if (threadIdx.x >= 32 && threadIdx.x < 40) scratch->scr[threadIdx.x - 32] = 0; }
+   }       // (scratch->scr: cleared with the rest of the scratch block when rtfe_scan starts)
 
 // ------------------------------------------------------------------------------------------------
 // k_decode

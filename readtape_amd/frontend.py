@@ -277,10 +277,10 @@ class FrontEnd:
     def scan_stats(self, result):
         """{'bursts', 'redone', 'record_bytes'} of the scan that produced `result` (synchronises; diagnostics)."""
         self.backend.sync()
-        out = (C.c_int64 * 16)()
+        out = (C.c_int64 * 24)()
         if self.lib.rtfe_scan_stats(self.h, self.backend.ptr(result.bufs["ws"]), out) != 0:
             raise RuntimeError(self.lib.rtfe_last_error().decode())
-        return dict(bursts=int(out[0]), redone=int(out[1]), record_bytes=int(out[2]), parallel=int(out[3]), sequential=int(out[4]), gave_up=[int(out[5 + i]) for i in range(8)])
+        return dict(bursts=int(out[0]), redone=int(out[1]), record_bytes=int(out[2]), parallel=int(out[3]), sequential=int(out[4]), gave_up=[int(out[5 + i]) for i in range(8)], phase_cycles=[int(out[13 + i]) for i in range(8)])
 
     def _buffers(self, nrows, key="scan"):
         """Allocates (once per size) the workspace and output buffers for a scan of nrows rows.  Exact rescans share ONE

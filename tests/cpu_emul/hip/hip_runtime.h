@@ -64,6 +64,7 @@ extern Barrier g_wave_barrier[16];
 extern unsigned long long g_wave_scratch[16][64];
 }  // namespace hipemu
 
+inline long long clock64() { return 0; }
 inline void __syncthreads() { hipemu::g_block_barrier.wait(); }
 inline unsigned long long __ballot(int pred) {
    const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -95,6 +96,7 @@ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline unsigned int __umulhi(unsigned int a, unsigned int b) { return (unsigned int)(((unsigned long long)a * b) >> 32); }
 inline int __popc(unsigned int v) { return __builtin_popcount(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

@@ -21,6 +21,43 @@ def test_emulated_kernels_match_oracle(name, tmp_path):
     assert stats["events"] > 0
 
 
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "gcr", "nrzi7_order", "pe_order"])
+@pytest.mark.parametrize("parallel", ["1", "0"])
+def test_emulated_peak_record_path_matches_oracle(name, parallel, tmp_path, monkeypatch):
+    """The opt-in peak-record path (k_peaks -> k_zones -> k_chain, rtfe_peaks.hip / rtfe_chain.hip): same events as the oracle,
+    with the chains deciding stretches of 64 runs at once and one run at a time."""
+    monkeypatch.setenv("RTFE_PEAK_PATH", "1")
+    monkeypatch.setenv("RTFE_CHAIN_PARALLEL", parallel)
+    g = load_case(name)
+    att = oracle_attempts(g["hdr"], g["rows"], g["oracle_opts"], str(tmp_path))
+    fe = emul_frontend(config_for(g["hdr"], g["oracle_opts"]))
+    res = fe.scan(g["rows"]).fetch()
+    st = fe.scan_stats(res)
+    msgs, stats = check_tape(fe, g["hdr"], g["rows"], att)
+    print(name, stats, st)
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["events"] > 0
+    assert st["parallel"] + st["sequential"] > 0, "the record chains did not run"
+    if parallel == "0":
+        assert st["parallel"] == 0
+
+
+@pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_PK_SLOT": "64"}), ("gcr", {"RTFE_PK_SLOT": "256"})])
+def test_emulated_peak_record_path_gives_up_cleanly(name, knobs, tmp_path, monkeypatch):
+    """Lists that outgrow their pool slot are marked unavailable; the bursts that need them are redone on the samples: same events."""
+    monkeypatch.setenv("RTFE_PEAK_PATH", "1")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g = load_case(name)
+    att = oracle_attempts(g["hdr"], g["rows"], g["oracle_opts"], str(tmp_path))
+    fe = emul_frontend(config_for(g["hdr"], g["oracle_opts"]))
+    res = fe.scan(g["rows"]).fetch()
+    st = fe.scan_stats(res)
+    msgs, stats = check_tape(fe, g["hdr"], g["rows"], att)
+    assert not msgs, "\n".join(msgs[:12])
+    assert st["redone"] > 0
+
+
 @pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_LDS_UNITS": "256"}),            # lists through LDS in several groups
                                         ("nrzi9", {"RTFE_REC_CAP16": "4"}),             # k_walk hands tiles back to k_decode
                                         ("gcr", {"RTFE_RECORD_PATH": "1", "RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}),
