@@ -82,7 +82,10 @@ typedef struct rtfe_event {
    float    agc_gain;        /* t->agc_gain when the callback is entered                            */
    uint8_t  trk;
    uint8_t  flags;           /* bit0: 0 = top (up transition), 1 = bottom; bits 1-2: time adjustment
-                                code 0 = none, 1 = -0.5 sample, 2 = +0.5 sample (src/decoder.c:718-730) */
+                                code 0 = none, 1 = -0.5 sample, 2 = +0.5 sample (src/decoder.c:718-730).
+                                bit 7 (RTFE_EV_FATAL): not a transition - at this row the reference's
+                                "AGC gain bad in lookfor_peak" assert (src/decoder.c:782) fires on this track,
+                                which ends the whole run there (exit 99); nothing follows it on the track */
    uint8_t  left_distance;   /* 1-based position of the peak in the window (src/decoder.c:704-744)  */
    uint8_t  parmset;
 } rtfe_event;                /* 16 bytes */
@@ -98,10 +101,13 @@ enum {
    RTFE_F_SCREEN_UNDERFLOW = 8,    /* AGC threshold fell below the candidate screen: rescan exactly with screen off */
    RTFE_F_TRUNCATED        = 32,   /* time shard: the halo ended before this burst's successor zone did          */
    RTFE_F_DETECTOR_FATAL   = 16,   /* the reference would have hit its fatal "peak at window edge" assert (src/decoder.c:709-710,748) */
+   RTFE_F_AGC_FATAL        = 128,  /* informational: a track's event list ends in an RTFE_EV_FATAL marker                     */
    RTFE_F_STATE_AT_END     = 64    /* -zeros: at end_sample a track still holds an excursion beyond the 0.2 V threshold or a pending
                                     * crossing - history a restart would not have, even if no event was emitted: an attempt that
                                     * reaches the end of this burst must not continue into the next one */
 };
+
+#define RTFE_EV_FATAL 0x80
 
 typedef struct rtfe_burst {
    int64_t  zone_first;      /* first row of the dead-quiet zone that precedes this burst            */
@@ -112,7 +118,7 @@ typedef struct rtfe_burst {
    uint64_t event_base;      /* index into the event buffer of this burst's first region              */
    uint32_t event_cap;       /* capacity of each (parmset, track) region                              */
    uint32_t flags;           /* RTFE_F_*                                                              */
-} rtfe_burst;                /* 64 bytes */
+} rtfe_burst;                /* 56 bytes */
 /* region of (burst b, parmset p, track t):  events[ b.event_base + (p * ntrks + t) * b.event_cap ... ],
  * count in counts[(burst_index * nparmsets + p) * ntrks + t]; events of one region are in detection order. */
 

@@ -119,6 +119,7 @@ static void lookfor_peak(struct ofe *fe, struct rt_trk *t, struct ofe_det *w) {
    if (w->pkww_countdown) {
       --w->pkww_countdown; }
    else {
+      if (!(t->agc_gain > 0)) { fe->fatal = 1; return; }              /* "AGC gain bad in lookfor_peak" (src/decoder.c:782): the reference asserts and exits */
       float required_rise = RT_PARM(d).pkww_rise * (t->v_avg_height / (float)PKWW_PEAKHEIGHT) / t->agc_gain;
       float required_min = RT_PARM(d).min_peak * (t->v_avg_height / (float)PKWW_PEAKHEIGHT) / t->agc_gain;
       if (w->pkww_maxv > w->pkww_v[w->pkww_left] + required_rise

@@ -265,6 +265,12 @@ restart:
             if (t >= ntrk_started) ntrk_started = t + 1;
             break; }
          while (src.at[t] < src.n[t] && src.reset + src.list[t][src.at[t]].sample == row) {
+            if (src.list[t][src.at[t]].flags & RTFE_EV_FATAL) {    /* "AGC gain bad in lookfor_peak" (src/decoder.c:782): the reference exits here */
+               rp->reference_fatal = 1; rp->fatal_row = row; rp->fatal_trk = t;
+               d->results[parmset].blktype = RT_BS_ABORTED;
+               if (exact_events && rp->exact_free) rp->exact_free(rp->exact_user, exact_events);
+               rt_finish_attempt(d);
+               return 0; }
             deliver(rp, &src, t, &src.list[t][src.at[t]], W);
             ++src.at[t]; ++events_seen; }
          if (d->opt.mode == RT_PE && rt_pe_idle_due(d, tk)) rt_pe_go_idle(d, tk);
@@ -321,7 +327,8 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
       stats->events_delivered = rp.events_delivered; stats->agc_mismatches = rp.agc_mismatches;
       stats->blocks = d->numblks; stats->tapemarks = d->numtapemarks; stats->blocks_with_errors = d->numblks_err;
       stats->blocks_with_warnings = d->numblks_warn; stats->blocks_unusable = d->numblks_unusable; stats->all_ok = ok;
-      stats->data_bytes = d->numdatabytes; stats->device_failures = rp.device_failures; }
+      stats->data_bytes = d->numdatabytes; stats->device_failures = rp.device_failures;
+      stats->reference_fatal = rp.reference_fatal; stats->fatal_row = rp.fatal_row; stats->fatal_trk = rp.fatal_trk; }
    if (d->tapf) fclose(d->tapf);
    if (d->logf) fclose(d->logf);
    if (rp.evtf) { fflush(rp.evtf); if (ftruncate(fileno(rp.evtf), ftell(rp.evtf))) {} fclose(rp.evtf); }

@@ -30,6 +30,7 @@ struct rt_replay {
    /* statistics */
    int64_t attempts, exact_scans, chained, events_delivered, agc_mismatches;
    int64_t device_failures;            /* attempts the device could not deliver (exact scan refused / overflowed): the decode stops there */
+   int64_t reference_fatal, fatal_row, fatal_trk;   /* an RTFE_EV_FATAL marker was reached: the reference exits there (src/decoder.c:782) */
 };
 
 int  rt_replay_readblock(void *ctx, int retry);
@@ -41,6 +42,7 @@ struct rt_replay_stats {
    int32_t blocks, tapemarks, blocks_with_errors, blocks_with_warnings, blocks_unusable, all_ok;
    int64_t data_bytes;
    int64_t device_failures;            /* > 0: the decode stopped early because the device could not deliver an attempt */
+   int64_t reference_fatal, fatal_row, fatal_trk;   /* != 0: the decode stopped where the reference's "AGC gain bad" assert ends its run */
 };
 
 /* Decodes a whole scanned tape: builds a decoder for `opt` (+ `parmsets`, NULL = built-in sets), replays the

@@ -449,6 +449,20 @@ __device__ __forceinline__ void store_event(const Ctx &cx, int pidx, int trk, un
    e.parmset = (uint8_t)pidx;
    cx.events[(size_t)(pidx * cx.cfg->ntrks + trk) * cx.cap + idx] = e; }
 
+// src/decoder.c:782: the reference asserts agc_gain > 0 whenever it looks at the window's shape, i.e. from the first row behind the
+// blind countdown on - and the assert is fatal for the whole run.  The track's event list gets a marker at that row (RTFE_EV_FATAL);
+// the host replay delivers everything that comes before it in (row, track) order and then stops as the reference does.
+__device__ __forceinline__ bool agc_fatal(Walker &w, Ctx &cx, int pidx, int trk, long long death_row) {
+   if (w.agc_gain > 0) return false;
+   w.flags |= RTFE_F_AGC_FATAL;
+   if (w.nevents < cx.cap) {
+      rtfe_event e = {};
+      e.sample = (uint32_t)(death_row - cx.tile.reset); e.trk = (uint8_t)trk; e.flags = RTFE_EV_FATAL; e.parmset = (uint8_t)pidx;
+      cx.events[(size_t)(pidx * cx.cfg->ntrks + trk) * cx.cap + w.nevents] = e; }
+   else w.flags |= RTFE_F_EVENT_OVERFLOW;
+   ++w.nevents;
+   return true; }
+
 // refine_peak (src/decoder.c:700-749) + event emission + AGC mirror.  `lo` = first row of the window,
 // `p` = row of the first window element equal to the extreme.  With defer != 0 the refinement and the
 // event store are queued for finalize_tile() (possible whenever nothing downstream needs the peak time).
@@ -474,6 +488,7 @@ __device__ __forceinline__ void emit_peak(Walker &w, Ctx &cx, int pidx, int trk,
    if (is_top) w.v_top = val; else w.v_bot = val;
    ++w.nevents;
    agc_after_peak(w, cfg, P, cx.heights, is_top, t_peak);
+   if (agc_fatal(w, cx, pidx, trk, n + left_distance + 1)) { w.blind_until = 1ll << 60; w.slow_countdown = 1 << 30; return; }
    update_thresholds(w, P, cfg->lsb_per_volt);
    w.blind_until = n + left_distance; }                          // pkww_countdown = left_distance (src/decoder.c:741)
 
@@ -573,7 +588,7 @@ __device__ __forceinline__ void slow_step(Walker &w, Ctx &cx, int pidx, int trk,
       if (p > n || p == lo || p == n) { w.flags |= RTFE_F_DETECTOR_FATAL; return; }   // src/decoder.c:709-710,748
       // refine_peak's time formula and countdown use W even when the window is not full
       emit_peak(w, cx, pidx, trk, P, n, lo, p, volt(val, mv), val, top, false);
-      w.slow_countdown = (int)(p - lo) + 1; } }
+      if (!(w.flags & RTFE_F_AGC_FATAL)) w.slow_countdown = (int)(p - lo) + 1; } }
 
 // switch from the literal path to the screened path: derive the lazy stale-min state
 __device__ __forceinline__ void enter_fast(Walker &w, const Tile &tl, int trk, int W, long long n_first_fast) {
@@ -889,6 +904,7 @@ __device__ __forceinline__ void walk_diffpeak(Walker &w, Ctx &cx, int pidx, int 
       if (top) w.v_top = val; else w.v_bot = val;
       ++w.nevents;
       agc_after_peak(w, cfg, P, cx.heights, top, t_peak);
+      if (agc_fatal(w, cx, pidx, trk, n + left_distance + 1)) { w.slow_countdown = 1 << 30; continue; }
       update_thresholds(w, P, cfg->lsb_per_volt);
       w.slow_countdown = left_distance; }
    w.next = n; }
@@ -1338,6 +1354,7 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
          if (is_top) w.v_top = v; else w.v_bot = v;
          ++w.nevents;
          agc_after_peak(w, cfg, P, cx.heights, is_top, t_peak);
+         if (!(w.agc_gain > 0)) { why = 7; return false; }         // (src/decoder.c:782 is about to fire: the sample path writes the marker)
          if (!approx_thresholds(w, P, lsb)) update_thresholds(w, P, lsb);
          w.blind_until = tl.row0 + n + ld;                         // pkww_countdown = left_distance (src/decoder.c:741)
          cur = n + ld + 1; } }

@@ -20,13 +20,14 @@ from . import tbin
 MAXTRKS, MAXPARMSETS = 19, 15
 PE, NRZI, GCR, WW = 1, 2, 4, 8
 
-F_EXACT_START, F_UNSAFE, F_EVENT_OVERFLOW, F_SCREEN_UNDERFLOW, F_DETECTOR_FATAL, F_TRUNCATED, F_STATE_AT_END = 1, 2, 4, 8, 16, 32, 64
+F_EXACT_START, F_UNSAFE, F_EVENT_OVERFLOW, F_SCREEN_UNDERFLOW, F_DETECTOR_FATAL, F_TRUNCATED, F_STATE_AT_END, F_AGC_FATAL = 1, 2, 4, 8, 16, 32, 64, 128
+EV_FATAL = 0x80       # event flag: the reference's "AGC gain bad in lookfor_peak" assert fires here (include/rt_frontend.h)
 
 EVENT_DTYPE = np.dtype([("sample", "<u4"), ("v_peak", "<f4"), ("agc_gain", "<f4"), ("trk", "u1"),
                         ("flags", "u1"), ("left_distance", "u1"), ("parmset", "u1")])
 BURST_DTYPE = np.dtype([("zone_first", "<i8"), ("zone_end", "<i8"), ("reset_sample", "<i8"), ("safe_last", "<i8"),
                         ("end_sample", "<i8"), ("event_base", "<u8"), ("event_cap", "<u4"), ("flags", "<u4")])
-assert EVENT_DTYPE.itemsize == 16 and BURST_DTYPE.itemsize == 56 or BURST_DTYPE.itemsize == 64
+assert EVENT_DTYPE.itemsize == 16 and BURST_DTYPE.itemsize == 56
 
 
 class _Parmset(C.Structure):
@@ -106,10 +107,9 @@ class FrontEndConfig:
         ps = kw.pop("parmsets", None) or DEFAULT_PARMSETS[mode][:nparmsets]
         # the header's TBINORD extension (src/readtape.c:1346-1355).  A file without TBIN_NO_REORDER "had a permutation applied to
         # it" when it was made: the reference then ignores every track order, the command line's included (src/readtape.c:1646-1648)
-        if kw.get("head_to_trk") is None and h.trkorder:
+        # (an explicit head_to_trk= is the caller's business and is taken as given)
+        if kw.get("head_to_trk") is None and h.trkorder and (h.flags & tbin.FLAG_NO_REORDER):
             kw["head_to_trk"] = parse_track_order(h.trkorder)
-        if not (h.flags & tbin.FLAG_NO_REORDER):
-            kw["head_to_trk"] = None
         return cls(mode=mode, ntrks=h.ntrks, maxvolts=h.maxvolts, bpi=bpi, ips=h.ips or 50.0,
                    tdelta_ns=h.tdelta_ns, tstart_ns=h.tstart_ns, parmsets=list(ps), **kw)
 

@@ -35,7 +35,8 @@ class _Stats(C.Structure):            # struct rt_replay_stats
                 ("events_delivered", C.c_int64), ("agc_mismatches", C.c_int64),
                 ("blocks", C.c_int32), ("tapemarks", C.c_int32), ("blocks_with_errors", C.c_int32),
                 ("blocks_with_warnings", C.c_int32), ("blocks_unusable", C.c_int32), ("all_ok", C.c_int32),
-                ("data_bytes", C.c_int64), ("device_failures", C.c_int64)]
+                ("data_bytes", C.c_int64), ("device_failures", C.c_int64),
+                ("reference_fatal", C.c_int64), ("fatal_row", C.c_int64), ("fatal_trk", C.c_int64)]
 
 
 _EXACT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_uint32),
@@ -200,6 +201,14 @@ def detect_density(hdr, rows, full, o, fe_factory, invert=False, log_path=None, 
         return float(bpi.value)
 
 
+class ReferenceFatal(RuntimeError):
+    """The input drives the reference into one of its fatal asserts (exit 99): the decode stops where the reference stops."""
+
+    def __init__(self, msg, stats):
+        super().__init__(msg)
+        self.stats = stats
+
+
 def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
                 skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None, differentiate=False,
                 subsample: int = 1, deskew: bool = False, deskew_prefix_rows: int = 1 << 22, trkorder: str | None = None):
@@ -270,6 +279,9 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     if rc != 0:
         raise RuntimeError("rt_replay_run failed")
     stats = {k: getattr(st, k) for k, _ in _Stats._fields_}
+    if stats["reference_fatal"]:
+        raise ReferenceFatal(f"AGC gain bad in lookfor_peak on track {stats['fatal_trk']} at sample {stats['fatal_row']}: the reference asserts and exits "
+                             "here (src/decoder.c:782); the blocks in front of it are in the .tap", stats)
     if stats["device_failures"]:
         raise RuntimeError(f"the device front end could not deliver {stats['device_failures']} attempt(s) (event regions overflowed even at "
                            "their largest, or an exact rescan failed): the decode is incomplete")

@@ -11,11 +11,17 @@ from __future__ import annotations
 import numpy as np
 
 
-def plan_shards(nrows: int, world: int, align: int = 512):
-    """[start, end) per rank.  Starts are multiples of 512 rows: 16-byte aligned, and on the 1 KiB grid of the
-    quiet map for every track count, so a sharded scan finds exactly the zones of the whole-tape scan."""
-    cuts = [(nrows * r // world) // align * align for r in range(world)] + [nrows]
-    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+def plan_shards(nrows: int, world: int, align: int = 1024):
+    """[start, end) per rank.  Starts are multiples of `align` rows (a multiple of 64): 16-byte aligned for every track count, and
+    on the 64-row grid of the quiet map, so a sharded scan finds exactly the zones of the whole-tape scan.  A tape too short to
+    give every rank rows leaves the last ranks empty: (n, n)."""
+    assert align % 64 == 0
+    cuts = [min(nrows, (nrows * r // world) // align * align) for r in range(world)] + [nrows]
+    for r in range(1, world):                       # (monotone; a rank whose slice would be empty gets (nrows, nrows) at the end)
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    spans = [(cuts[r], cuts[r + 1]) for r in range(world)]
+    live = [sp for sp in spans if sp[1] > sp[0]]
+    return live + [(nrows, nrows)] * (world - len(live))
 
 
 def exchange_halo(own, halo_rows: int, rank: int, world: int, dist):

@@ -158,7 +158,21 @@ def case_nrzi7_order_ignored(seed=13):
     return dataclasses.replace(t, spec=dataclasses.replace(t.spec, flags=0))
 
 
-# name -> (tape builder, reference options, oracle options)
+AGCFATAL_PARMS = ("parms active, clk_window, clk_alpha, agc_window, agc_alpha, min_peak, clk_factor, pulse_adj, pkww_bitfrac, pkww_rise, midbit, z1pt, z2pt, id\n"
+                  "{1, 0, 0.2, 10, 0.0, 0.0, 0, 0.3, 0.164, 0.1, 0.5, 1.45, 2.35, PRM}\n")
+
+
+def case_nrzi7_agcfatal(seed=416690828):
+    # (found by tests/stress_gpu.py) a window AGC of 10 heights over a 3-sample peak window on the differentiated signal: the
+    # ring still holds a start-up entry <= 0 when the first adjustment divides by its minimum, the gain goes negative and the
+    # reference dies with "AGC gain bad in lookfor_peak" (src/decoder.c:782) after some 100 transitions
+    return synth.nrzi_tape(seed=seed, nblocks=2, minlen=16, maxlen=200, ntrks=7, gap_samples=1500, amplitude=3.2, noise_mv=10.0, jitter=0.02)
+
+
+case_nrzi7_agcfatal.parms_text = AGCFATAL_PARMS
+
+
+# name -> (tape builder, reference options, oracle options); a builder's .parms_text, if any, is the NRZI/PE/GCR.parms file of the run
 CASES = {
     "nrzi9":        (case_nrzi9,      ["-nrzi"],                       []),
     "nrzi9_m":      (case_nrzi9_weak, ["-nrzi", "-m"],                 ["-m"]),
@@ -194,6 +208,7 @@ CASES = {
     "pe_order":     (case_pe_order,   ["-pe", "-order=01234576p"],     ["-order=01234576p"]),
     "gcr_order_m":  (case_gcr_order,  ["-gcr", "-m"],                  ["-m"]),
     "nrzi7_order_ignored": (case_nrzi7_order_ignored, ["-nrzi", "-ntrks=7", "-order=543210p"], ["-order=543210p"]),
+    "nrzi7_agcfatal": (case_nrzi7_agcfatal, ["-nrzi", "-ntrks=7", "-invert", "-differentiate"], ["-invert", "-differentiate"]),
     "gcr_errs":     (case_gcr_errors, ["-gcr"],                        []),
     "gcr_correct":  (case_gcr_errors, ["-gcr", "-correct"],            ["-correct"]),
 }

@@ -23,4 +23,5 @@ def load_case(name):
     hdr = tbin.TbinHeader(ntrks=ntrks, tdelta_ns=tdelta, maxvolts=maxvolts, mode=mode, bpi=bpi, ips=ips, tstart_ns=tstart, flags=flags, trkorder=trkorder)
     return dict(name=name, hdr=hdr, rows=t["rows"], ref_opts=[str(x) for x in c["ref_opts"]],
                 oracle_opts=[str(x) for x in c["oracle_opts"]], tap=c["tap"].tobytes(), events=c["events"],
-                returncode=int(c["returncode"]), blocklog=[str(x) for x in c["blocklog"]])
+                returncode=int(c["returncode"]), blocklog=[str(x) for x in c["blocklog"]],
+                parms_text=(str(c["parms_text"]) if "parms_text" in c.files else "") or None)

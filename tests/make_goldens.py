@@ -43,6 +43,9 @@ def main():
                                 hdrf=np.array([s.maxvolts, s.bpi, s.ips], dtype=np.float32))
         with tempfile.TemporaryDirectory() as wd:
             tape.write(os.path.join(wd, "t.tbin"))
+            parms_text = getattr(build, "parms_text", "")
+            if parms_text:
+                open(os.path.join(wd, "t.parms"), "w").write(parms_text)       # the reference looks for <basename>.parms first (src/parmsets.c:337-377)
             opts = ["-v", "-tap", "-nolabels"] + list(ref_opts)
             if "-m" not in opts:
                 opts.append("-nm")
@@ -53,7 +56,7 @@ def main():
             blocks = [l.strip() for l in p.stdout.splitlines() if l.startswith("wrote block") or "tapemark at" in l or (l.startswith("  track ") and "observed flux transitions" in l) or "density was set to" in l]
         np.savez_compressed(os.path.join(OUT, f"case_{name}.npz"), tape=tkey, ref_opts=np.array(opts),
                             oracle_opts=np.array(list(or_opts), dtype="U64"), tap=np.frombuffer(tap, dtype=np.uint8),
-                            events=evt, returncode=p.returncode, blocklog=np.array(blocks))
+                            events=evt, returncode=p.returncode, blocklog=np.array(blocks), parms_text=np.array(parms_text))
         print(f"{name}: {tape.rows.shape[0]} rows, {evt.size} records, tap {len(tap)} bytes, rc {p.returncode}")
 
 

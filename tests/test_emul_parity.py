@@ -1,6 +1,7 @@
 """Kernel-logic parity on the CPU: the HIP kernel sources compiled against tests/cpu_emul and run
 on threads, checked event-for-event against the oracle on the golden tapes.  (The real GPU run of
 the same checks is tests/test_gpu_parity.py, marked gpu.)"""
+import numpy as np
 import pytest
 
 from emul_util import emul_frontend
@@ -94,3 +95,32 @@ def test_emulated_segmented_record_walk(knobs, tmp_path, monkeypatch):
     print(knobs, stats)
     assert not msgs, "\n".join(msgs[:12])
     assert stats["events"] > 4000
+
+
+def test_every_seam_position_inside_a_gap_keeps_every_burst(tmp_path):
+    """Time shards: wherever the seam falls relative to an inter-block zone - in front of it, inside it (a few quiet
+    chunks before its end: the right rank cannot qualify the zone, the left rank must own the burst), behind it - the two ranks'
+    bursts and events together are the whole-tape scan's.  (k_bursts' ownership rule: a zone that ends fewer than gap_chunks chunks
+    behind the seam belongs to the left rank.)"""
+    from readtape_amd import shard
+    g = load_case("nrzi9")
+    rows = g["rows"]
+    cfg = config_for(g["hdr"], g["oracle_opts"])
+    fe = emul_frontend(cfg)
+    whole = fe.scan(rows).fetch()
+    wb = shard.absolute_bursts(whole, 0)
+    we = shard.flatten_events(whole, wb, 0)
+    key = lambda e: e[np.lexsort((e[:, 1], e[:, 0]))]
+    zone = wb[1]                                                   # the zone between the first two blocks
+    lo, hi = int(zone["zone_first"]) - 256, int(zone["zone_end"]) + 512
+    cuts = list(range(lo // 64 * 64, hi, 64))
+    assert len(cuts) > 20
+    for cut in cuts:
+        left = fe.scan(rows[: cut + 4096], row_base=0, first_is_tape_start=True, own_rows=cut).fetch()
+        lb = shard.absolute_bursts(left, 0); le = shard.flatten_events(left, lb, 0)
+        right = fe.scan(rows[cut:], row_base=cut, first_is_tape_start=False).fetch()
+        rb = shard.absolute_bursts(right, cut); re_ = shard.flatten_events(right, rb, 0)
+        assert left.nbursts + right.nbursts == whole.nbursts, (cut, left.nbursts, right.nbursts, whole.nbursts)
+        assert not ((np.concatenate([lb["flags"], rb["flags"]]) & ~np.uint32(1)).any()), cut
+        got = np.concatenate([le, re_])
+        assert got.shape == we.shape and (key(got) == key(we)).all(), cut

@@ -21,7 +21,7 @@ def decode_case(g, tmp_path, fe_factory):
     tap = os.path.join(str(tmp_path), "out.tap")
     stats, res = pipeline.decode_tape(g["hdr"], g["rows"], tap, log_path=tap + ".log", opts=opts, fe_factory=fe_factory,
                                       skew=skew, invert="-invert" in o, find_zeros="-zeros" in o, evt_path=tap + ".evt", differentiate="-differentiate" in o,
-                                      subsample=subsample, deskew="-deskew" in o, trkorder=trkorder)
+                                      subsample=subsample, deskew="-deskew" in o, trkorder=trkorder, parms_text=g.get("parms_text"))
     import refdump
     # every transition the decoders were handed == what the reference's front end handed its decoders
     # (differentiated zero-crossing: the decoder-side baseline bookkeeping v_avg_height depends on the opposite
@@ -43,6 +43,24 @@ def test_tap_bytes_match_reference(name, tmp_path):
     assert stats["agc_mismatches"] == 0
     assert stats["events_delivered"] > 0 or g["events"].size <= 1          # (noise only / a few rows: nothing to deliver)
     assert not stats["event_diffs"], stats["event_diffs"]
+
+
+def test_reference_agc_assert_stops_the_decode_where_the_reference_stops(tmp_path):
+    """src/decoder.c:782 ("AGC gain bad in lookfor_peak") kills the reference after 104 transitions of this tape (found by
+    tests/stress_gpu.py).  The device marks the row in the track's event list, the replay delivers everything in front of it -
+    the very transitions the reference's callbacks saw - and the pipeline raises where the reference exits."""
+    import refdump
+    g = load_case("nrzi7_agcfatal")
+    assert g["returncode"] == 99
+    tap = os.path.join(str(tmp_path), "out.tap")
+    with pytest.raises(pipeline.ReferenceFatal) as ei:
+        pipeline.decode_tape(g["hdr"], g["rows"], tap, fe_factory=emul_frontend, invert=True, differentiate=True, evt_path=tap + ".evt",
+                             parms_text=g["parms_text"])
+    mine = refdump.load(tap + ".evt")
+    n = min(mine.size, g["events"].size)
+    assert mine.size == g["events"].size and n > 50, (mine.size, g["events"].size)
+    assert not refdump.compare(mine[:n], g["events"][:n])
+    assert ei.value.stats["reference_fatal"]
 
 
 def test_short_burst_tails_do_not_change_the_tap(tmp_path, monkeypatch):

@@ -16,7 +16,11 @@ def test_oracle_matches_golden(name, tmp_path, oracle_bin):
     g = load_case(name)
     wd = str(tmp_path)
     tbin.write_tbin(os.path.join(wd, "t.tbin"), g["hdr"], g["rows"])
-    p = subprocess.run([oracle_bin, "-v", f"-out={wd}/o", f"-evt={wd}/o.evt"] + g["oracle_opts"] + [f"{wd}/t.tbin"],
+    popt = []
+    if g.get("parms_text"):
+        open(os.path.join(wd, "t.parms"), "w").write(g["parms_text"])
+        popt = [f"-parms={wd}/t.parms"]
+    p = subprocess.run([oracle_bin, "-v", f"-out={wd}/o", f"-evt={wd}/o.evt"] + g["oracle_opts"] + popt + [f"{wd}/t.tbin"],
                        capture_output=True, text=True)
     assert p.returncode in (0, 99), p.stderr
     a = refdump.load(f"{wd}/o.evt")

@@ -10,7 +10,7 @@ from readtape_amd import frontend, synth
 
 pytestmark = pytest.mark.gpu
 
-PEAK_CASES = ["nrzi9", "nrzi9_m", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "gcr", "gcr_m"]
+PEAK_CASES = ["nrzi9", "nrzi9_m", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "gcr", "gcr_m", "nrzi7_order", "pe_order", "gcr_order_m", "nrzi7_order_ignored"]
 
 
 @pytest.fixture(scope="module")
@@ -173,7 +173,7 @@ def test_large_tape_properties(gpu):
         assert got.shape == ref.shape and (got == ref).all(), f"copy {j}"
 
 
-@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "gcr_deskew", "nrzi9_nobpi", "nrzi9_nobpi_short", "nrzi9_diffz", "nrzi9_diffpk", "nrzi9_diffpk_clean", "nrzi9_diffpk_skew", "gcr_diffpk", "pe_diffpk", "nrzi9_cut", "nrzi9_cut_zeros", "noise_only", "tiny", "nrzi9_nobpi_deskew"])
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "gcr_deskew", "nrzi9_nobpi", "nrzi9_nobpi_short", "nrzi9_diffz", "nrzi9_diffpk", "nrzi9_diffpk_clean", "nrzi9_diffpk_skew", "gcr_diffpk", "pe_diffpk", "nrzi9_cut", "nrzi9_cut_zeros", "noise_only", "tiny", "nrzi9_nobpi_deskew", "nrzi7_order", "pe_order", "gcr_order_m", "nrzi7_order_ignored"])
 def test_end_to_end_tap_bytes_match_reference(name, tmp_path, gpu):
     """GPU front end -> event replay -> block decoders -> SIMH .tap == the unmodified reference's .tap (golden)."""
     from test_emul_replay import decode_case
@@ -182,6 +182,43 @@ def test_end_to_end_tap_bytes_match_reference(name, tmp_path, gpu):
     assert tap == g["tap"]
     assert stats["agc_mismatches"] == 0 and (stats["events_delivered"] > 0 or g["events"].size <= 1)
     assert not stats["event_diffs"], stats["event_diffs"]
+
+
+def test_reference_agc_assert_stops_the_decode_where_the_reference_stops(tmp_path, gpu):
+    """src/decoder.c:782: see tests/test_emul_replay.py (the same check on the real kernels)."""
+    import os
+    import refdump
+    from readtape_amd import pipeline
+    g = load_case("nrzi7_agcfatal")
+    tap = os.path.join(str(tmp_path), "out.tap")
+    with pytest.raises(pipeline.ReferenceFatal):
+        pipeline.decode_tape(g["hdr"], g["rows"], tap, invert=True, differentiate=True, evt_path=tap + ".evt", parms_text=g["parms_text"])
+    mine = refdump.load(tap + ".evt")
+    assert mine.size == g["events"].size and not refdump.compare(mine, g["events"])
+
+
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "pe", "gcr", "gcr_m", "nrzi9_skew", "nrzi9_nobpi", "nrzi7_order"])
+def test_peak_record_path_equals_the_sample_path(name, gpu, monkeypatch):
+    """The opt-in peak-record path (RTFE_PEAK_PATH=1: k_peaks -> k_zones -> k_chain) against the default kernels: the same burst
+    table and, per (burst, parameter set, track), the same events byte for byte - also behind the block ends, where no oracle
+    attempt looks."""
+    g = load_case(name)
+    cfg = config_for(g["hdr"], g["oracle_opts"])
+    res = []
+    for pp in ("0", "1"):
+        monkeypatch.setenv("RTFE_PEAK_PATH", pp)
+        fe = frontend.FrontEnd(cfg)
+        res.append((fe, fe.scan(g["rows"]).fetch()))
+    (f0, r0), (f1, r1) = res
+    st = f1.scan_stats(r1)
+    assert r0.nbursts == r1.nbursts
+    for k in ("zone_first", "zone_end", "reset_sample", "safe_last", "end_sample", "flags"):
+        assert (r0.bursts[k] == r1.bursts[k]).all(), k
+    for b in range(r0.nbursts):
+        for p in range(len(cfg.parmsets)):
+            for t in range(cfg.ntrks):
+                assert r0.track_events(b, p, t).tobytes() == r1.track_events(b, p, t).tobytes(), (b, p, t)
+    assert st["parallel"] + st["sequential"] > 0 or st["redone"] == st["bursts"]
 
 
 def test_differentiated_peak_path_restarts_in_exact_zero_gaps(tmp_path, gpu):

@@ -33,6 +33,9 @@ def test_oracle_matches_reference(name, tmp_path, oracle_bin, ref_bin):
     tape = build()
     wd = str(tmp_path)
     tape.write(os.path.join(wd, "t.tbin"))
+    if getattr(build, "parms_text", ""):
+        open(os.path.join(wd, "t.parms"), "w").write(build.parms_text)
+        or_opts = list(or_opts) + [f"-parms={wd}/t.parms"]
     pr = run_reference(ref_bin, wd, "t", ref_opts)
     po = run_oracle(oracle_bin, wd, "t", or_opts)
     assert po.returncode in (0, 99), po.stderr
