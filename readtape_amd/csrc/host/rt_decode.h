@@ -154,6 +154,7 @@ struct rt_dec {
    /* output / bookkeeping (src/readtape.c:497-520) */
    FILE   *tapf;
    long long numoutbytes, numdatabytes;
+   int no_tap_end;                    /* fragment decode: the caller writes the end-of-medium marker behind the last fragment */
    int     numblks, numtapemarks, numblks_err, numblks_warn, numblks_unusable;
    int     numblks_goodmultiple, numblks_trksmismatched, numblks_midbiterrs, numblks_corrected;
    FILE   *logf;                    /* block log lines (NULL = quiet) */

@@ -22,7 +22,7 @@ static void output_tap_marker(struct rt_dec *d, uint32_t num) {   /* src/readtap
    d->numoutbytes += 4; }
 
 void rt_tap_end(struct rt_dec *d) {   /* src/readtape.c:1885: only if the output file was ever created (:1091, lazily) */
-   if (d->opt.tap_format && d->tapf && d->numoutbytes > 0) output_tap_marker(d, 0xffffffffu); }
+   if (d->opt.tap_format && d->tapf && d->numoutbytes > 0 && !d->no_tap_end) output_tap_marker(d, 0xffffffffu); }
 
 void rt_got_tapemark(struct rt_dec *d) {   /* src/readtape.c:1160-1176 */
    ++d->numtapemarks;

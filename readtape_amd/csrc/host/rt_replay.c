@@ -169,6 +169,7 @@ int rt_replay_readblock(void *ctx, int retry) {
    (void)retry;
    ++rp->attempts;
    if (s0 >= nrows) { rt_finish_attempt(d); return 0; }     /* no row was processed: no forced end of block */
+   if (s0 >= rp->stop_row) { rt_finish_attempt(d); return 0; }   /* fragment decode: the next attempt starts in a zone the next fragment owns */
 
    struct evsrc src;
    const long dump_pos = rp->evtf ? ftell(rp->evtf) : 0;      /* a restarted attempt rewinds the optional dump */
@@ -179,8 +180,10 @@ int rt_replay_readblock(void *ctx, int retry) {
    /* an exact scan covers this attempt only: up to the end of the device burst after the one s0 lies in,
     * extended (x4) in the rare case the attempt runs longer */
    int64_t exact_len = 1 << 16;
-   for (int64_t k = 0; k < rp->nbursts; ++k)
-      if (rp->bursts[k].zone_first - rp->row_base > s0) { exact_len = rp->bursts[k].end_sample - rp->row_base - s0; break; }
+   {  /* first burst whose zone starts behind s0 (the table is ordered: binary search) */
+      int64_t lo = 0, hi = rp->nbursts;
+      while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (rp->bursts[mid].zone_first - rp->row_base > s0) hi = mid; else lo = mid + 1; }
+      if (lo < rp->nbursts) exact_len = rp->bursts[lo].end_sample - rp->row_base - s0; }
    if (exact_len < (1 << 12)) exact_len = 1 << 12;
 restart:
    if (rp->evtf && (restarted || using_exact)) fseek(rp->evtf, dump_pos, SEEK_SET);
@@ -295,7 +298,7 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
-                  int append, struct deskew_out *prepass) {
+                  int append, struct deskew_out *prepass, int64_t start_row, int64_t stop_row, int fragment) {
    const float sample_deltat = (float)tdelta_ns / 1e9f;              /* src/readtape.c:1345 */
    struct rt_dec *d = rt_dec_new(opt, sample_deltat, tdelta_ns);
    if (!d) return -1;
@@ -312,6 +315,8 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
    rp.bursts = bursts; rp.nbursts = nbursts; rp.counts = counts; rp.events = events;
    rp.exact = exact; rp.exact_free = exact_free; rp.exact_user = user;
    rp.find_zeros = opt->find_zeros;
+   rp.pos = start_row; rp.stop_row = stop_row;
+   d->no_tap_end = fragment;                      /* a fragment's .tap is concatenated with its neighbours': the caller ends the file */
    if (evt_path) {
       /* (not "ab": a restarted attempt rewinds the dump, and O_APPEND ignores seeks) */
       rp.evtf = append ? fopen(evt_path, "r+b") : fopen(evt_path, "wb");
@@ -341,7 +346,21 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
-                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 0, NULL); }
+                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 0, NULL, 0, INT64_MAX, 0); }
+
+/* One fragment of a tape (a time shard, or one window of a streamed file): rows are relative to the fragment's first row
+ * (row_base = its absolute index; the bursts carry absolute rows).  The decode starts at start_row (0, or the start of the zone
+ * in front of the fragment's first own burst: any start inside a zone is the same detector state) and ends when an
+ * attempt would start at or behind stop_row (the start of the first zone the next fragment owns; INT64_MAX: run to the end of
+ * the data).  No end-of-medium marker is written: the fragments' .tap files are concatenated by the caller. */
+int rt_replay_run_fragment(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
+                  int64_t start_row, int64_t stop_row) {
+   return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
+                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 0, NULL, start_row, stop_row, 1); }
 
 int rt_replay_run_after_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
@@ -349,7 +368,7 @@ int rt_replay_run_after_deskew(const struct rt_options *opt, const struct rt_par
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
-                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 1, NULL); }
+                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 1, NULL, 0, INT64_MAX, 0); }
 
 int rt_replay_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
@@ -358,7 +377,7 @@ int rt_replay_deskew(const struct rt_options *opt, const struct rt_parms *parmse
                   const char *log_path, const char *evt_path, int append, int *delays, int *nblks, int *hit_end) {
    struct deskew_out o = { delays, nblks, hit_end, NULL, NULL };
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
-                     exact, exact_free, user, NULL, log_path, evt_path, NULL, append, &o); }
+                     exact, exact_free, user, NULL, log_path, evt_path, NULL, append, &o, 0, INT64_MAX, 0); }
 
 
 int rt_replay_density(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
@@ -368,4 +387,4 @@ int rt_replay_density(const struct rt_options *opt, const struct rt_parms *parms
                   const char *log_path, const char *evt_path, float *bpi, float *implied, int *nblks, int *hit_end) {
    struct deskew_out o = { NULL, nblks, hit_end, bpi, implied };
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
-                     exact, exact_free, user, NULL, log_path, evt_path, NULL, 0, &o); }
+                     exact, exact_free, user, NULL, log_path, evt_path, NULL, 0, &o, 0, INT64_MAX, 0); }

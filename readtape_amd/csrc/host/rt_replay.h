@@ -25,6 +25,7 @@ struct rt_replay {
    const rtfe_event *events;
    rt_exact_fn exact; rt_exact_free_fn exact_free; void *exact_user;
    int64_t pos, saved_pos, cur_row; double saved_time;
+   int64_t stop_row;                   /* fragment decode: no attempt starts at or behind this row */
    int     find_zeros;                 /* events are confirmed zero crossings: the slope gate is applied here */
    FILE   *evtf;                       /* optional dump of every delivered transition (oracle/ref_event_shim.c record format) */
    /* statistics */
@@ -70,6 +71,12 @@ int rt_replay_density(const struct rt_options *opt, const struct rt_parms *parms
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *log_path, const char *evt_path, float *bpi, float *implied, int *nblks, int *hit_end);
+int rt_replay_run_fragment(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
+                  int64_t start_row, int64_t stop_row);
 int rt_replay_run_after_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,

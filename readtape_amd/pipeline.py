@@ -55,6 +55,7 @@ def _load_decode_lib():
                                   C.POINTER(C.c_int), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _EXACT_FN, _FREE_FN, C.c_void_p,
                                   C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
     lib.rt_replay_run_after_deskew.argtypes = lib.rt_replay_run.argtypes
+    lib.rt_replay_run_fragment.argtypes = lib.rt_replay_run.argtypes + [C.c_int64, C.c_int64]
     lib.rt_replay_deskew.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.rt_replay_density.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return lib
@@ -289,3 +290,99 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     stats["skew"] = list(skew) if skew is not None else None
     stats["bpi"] = cfg.bpi
     return stats, res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fragments: time shards of one tape (one per GPU) and the windows of a tape streamed from disk are decoded the same way.
+# A fragment owns the bursts whose zone ends in its own rows (rtfe_scan's own_rows rule); its decode starts at the start of the
+# zone in front of its first own burst and stops where an attempt would start in the first zone its right neighbour owns.  Blocks
+# are independent (every attempt restarts all state, src/decoder.c:425-455), so the fragments' .tap files concatenate to the
+# whole tape's; the end-of-medium marker goes behind the last one.  (SURVEY.md 8e "Host side".)
+# ---------------------------------------------------------------------------------------------------------------------
+I64MAX = (1 << 63) - 1
+
+
+def scan_fragment(fe, rows_with_halo, own_rows, lo, is_first, is_last, stream=None):
+    """Scans one fragment (async) -> a function that fetches (result, absolute bursts incl. the bounding one, stop_row or None)."""
+    res = fe.scan(rows_with_halo, row_base=lo, first_is_tape_start=is_first, own_rows=own_rows, stream=stream)
+
+    def finish():
+        res.fetch()
+        be = fe.backend
+        nb = res.nbursts
+        bound = None
+        if not is_last:
+            tab = be.to_numpy(res.bufs["bursts"], frontend.BURST_DTYPE)[: nb + 1].copy()
+            truncated = nb > 0 and bool(int(res.bursts[nb - 1]["flags"]) & frontend.F_TRUNCATED)
+            if truncated or nb + 1 > tab.shape[0]:
+                return res, None, None                 # the halo holds no further zone: the caller retries with a longer one
+            bound = int(tab[nb]["zone_first"])          # relative to the fragment
+        return res, nb, bound
+    return finish
+
+
+def decode_fragment(hdr, cfg, fe, res, rows_with_halo, lo, start_row, stop_row, tap_path, full, opts, fe_factory=None, log_path=None, evt_path=None):
+    """Host replay of one scanned fragment -> its piece of the .tap (no end marker).  Returns the replay statistics."""
+    from readtape_amd import shard
+    lib = _load_decode_lib()
+    o = _Options(mode=hdr.mode, ntrks=hdr.ntrks, bpi=cfg.bpi, ips=cfg.ips, specified_parity=0 if opts.even_parity else 1,
+                 revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=int(cfg.find_zeros), do_differentiate=int(cfg.differentiate),
+                 multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
+    parr = (_Parms * len(full))(*full)
+    W = (C.c_int * len(full))(*fe.widths)
+    exact, free, keep = _exact_callbacks(fe, rows_with_halo, hdr.ntrks, fe_factory)
+    st = _Stats()
+    bursts = np.ascontiguousarray(shard.absolute_bursts(res, lo))
+    counts = np.ascontiguousarray(res.counts)
+    nrows = int(rows_with_halo.shape[0])
+    rc = lib.rt_replay_run_fragment(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, nrows, lo, W,
+                                    bursts.ctypes.data, len(bursts), counts.ctypes.data, res._events.ctypes.data, exact, free, None,
+                                    tap_path.encode(), log_path.encode() if log_path else None, evt_path.encode() if evt_path else None, C.byref(st),
+                                    int(start_row), I64MAX if stop_row is None else int(stop_row))
+    if rc != 0:
+        raise RuntimeError("rt_replay_run_fragment failed")
+    stats = {k: getattr(st, k) for k, _ in _Stats._fields_}
+    if stats["reference_fatal"] or stats["device_failures"]:
+        raise RuntimeError(f"fragment at row {lo}: the decode stopped early ({stats})")
+    return stats
+
+
+def decode_tape_fragments(hdr, rows, tap_path, spans, opts: DecodeOptions | None = None, fe_factory=None, halo_rows=1 << 16, cfgkw=None):
+    """Decodes one resident tape as the fragments `spans` = [(lo, hi), ...] (contiguous, cuts on the 64-row grid), one after the other
+    on this process' device, and concatenates their .tap pieces: what N ranks do with shard.plan_shards + the halo exchange, and what
+    the streaming reader does window by window.  Returns a list of per-fragment statistics."""
+    opts = opts or DecodeOptions()
+    full = default_parmsets(hdr.mode, opts.nparmsets or (15 if opts.multiple_tries else 1))
+    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend_parmsets(full), **(cfgkw or {}))
+    fe = (fe_factory or frontend.FrontEnd)(cfg)
+    n = int(rows.shape[0])
+    out, total = [], 0
+    with open(tap_path, "wb") as tapf:
+        for k, (lo, hi) in enumerate(spans):
+            if hi <= lo:
+                continue
+            is_last = hi >= n
+            halo = halo_rows
+            while True:
+                end = n if is_last else min(n, hi + halo)
+                piece = rows[lo:end]
+                res, nb, bound = scan_fragment(fe, piece, hi - lo, lo, lo == 0, is_last)()
+                if nb is not None or end >= n:
+                    break
+                halo *= 4                                   # the last own burst runs past the halo: ask the neighbour for more
+            # (nb None with the halo at the end of the tape: no further zone exists, the last own burst runs to the end of the data)
+            if res.nbursts == 0:
+                continue
+            start = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
+            frag = tap_path + f".frag{k}"
+            st = decode_fragment(hdr, cfg, fe, res, piece, lo, start, bound, frag, full, opts, fe_factory)
+            data = open(frag, "rb").read()
+            os.remove(frag)
+            tapf.write(data)
+            total += len(data)
+            st["span"] = (lo, hi)
+            out.append(st)
+        if total > 0:
+            tapf.write(b"\xff\xff\xff\xff")                 # src/readtape.c:1885
+    fe.close()
+    return out

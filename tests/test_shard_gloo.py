@@ -75,3 +75,50 @@ def test_two_rank_time_shards_equal_single_scan(case, cut_frac, align, tmp_path)
     # any cut: the union of the ranks' events is the single-scan event list, bit for bit
     key = lambda e: e[np.lexsort((e[:, 1], e[:, 0]))]
     assert got_e.shape == we.shape and (key(got_e) == key(we)).all()
+
+
+TAP_WORKER = r'''
+import os, sys, pickle
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "tools"))
+import numpy as np, torch, torch.distributed as dist
+from emul_util import emul_frontend
+from golden_util import load_case
+from readtape_amd import shard
+case, out, cutrow = sys.argv[2], sys.argv[3], int(sys.argv[4])
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = load_case(case)
+rows = np.ascontiguousarray(g["rows"])
+n = rows.shape[0]
+spans = [(0, cutrow), (cutrow, n)] if cutrow else shard.plan_shards(n, world, align=64)
+lo, hi = spans[rank]
+table = shard.decode_sharded(g["hdr"], torch.from_numpy(rows[lo:hi].copy()), lo, n, rank, world, dist, out if rank == 0 else None,
+                             fe_factory=emul_frontend, halo_rows=1024)
+if rank == 0:
+    pickle.dump(table, open(out + ".tab", "wb"))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("case,cutrow", [("nrzi9", 0), ("nrzi9", 2496), ("gcr", 0), ("pe", 0)])      # (2496: inside the first block of nrzi9; 0: nrows / 2)
+def test_two_ranks_write_the_single_rank_tap(case, cutrow, tmp_path):
+    """Two gloo ranks decode ONE tape: halo exchange, scans, all-gather of the per-rank tables, per-rank replay, rank 0 assembles the
+    .tap - byte for byte the reference's (the golden), wherever the seam falls.  The starting halo (1024 rows) is shorter than a
+    block + gap, so the halo-growing round trip runs too."""
+    import pickle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emul_util import build_emul
+    from golden_util import load_case
+    build_emul()
+    out = str(tmp_path / "sharded.tap")
+    wfile = tmp_path / "tap_worker.py"
+    wfile.write_text(TAP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 1000), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(wfile), ROOT, case, out, str(cutrow)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    g = load_case(case)
+    assert open(out, "rb").read() == g["tap"]
+    table = pickle.load(open(out + ".tab", "rb"))
+    assert [t["rank"] for t in table] == [0, 1] and table[1]["tap_offset"] == table[0]["tap_len"]
+    assert sum(t["blocks"] + t["tapemarks"] for t in table) > 0 and all(t["bursts"] > 0 for t in table)
