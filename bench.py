@@ -14,7 +14,11 @@ N > 1: the sample timeline is time-sharded — every rank holds its own 1e8-row 
 the only exchange is one neighbour halo per step (the rows a block straddling the seam needs), no
 data-path collective.
 
-Also on the line:  roofline (dominant kernel, algorithmic bytes / measured kernel time, HIP events)
+--config C3 | C4 | C5 selects BASELINE.json's other configurations (PE -zeros, 1e9 rows; GCR, 1e9 rows, 8 parameter sets; one 10 GB
+NRZI tape time-sharded over the ranks, strong scaling).  The driver's default line is C2.
+
+Also on the line:  e2e (a bounded sample of the same tape from a .tbin file through the pinned double-buffered reader to the .tap),
+roofline (dominant kernel, algorithmic bytes / measured kernel time, HIP events)
 and cpu_baseline (the reference compiled by oracle/Makefile when it travelled with the snapshot,
 else the oracle port; single core; bounded sample of the same tape).
 """
@@ -34,18 +38,34 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def make_base_tape(seed, target_rows):
-    """Unique synthetic NRZI tape of about target_rows rows: 512..4096-byte blocks, >= 6 ms gaps,
-    a tapemark every 16 blocks."""
+# BASELINE.json configs[1..4].  window_rows: the resident tape is scanned as consecutive fragments of this many rows through ONE
+# workspace (the ownership rule of rtfe_scan makes fragments exact) - at 1e9 rows a whole-tape workspace plus the
+# 8-parmset event arena would not fit beside the tape.
+CONFIGS = {
+    "C2": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[],
+               workload="C2: synthetic 9-track 800 BPI NRZI, 781.25 kHz, 1 parmset"),
+    "C3": dict(kind="pe", rows=1e9, nparmsets=1, find_zeros=True, window_rows=1 << 28, ref_opts=["-nm", "-zeros"], port_opts=["-zeros"],
+               workload="C3: synthetic 9-track 1600 BPI PE, 1.5625 MHz, -zeros (zero-crossing path), 1 parmset"),
+    "C4": dict(kind="gcr", rows=1e9, nparmsets=8, find_zeros=False, window_rows=1 << 28, ref_opts=[], port_opts=["-m"],
+               workload="C4: synthetic 9-track 6250 BPI GCR (9042 fci), 6.25 MHz, 8-parmset batched sweep"),
+    "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True,
+               workload="C5: ONE 10 GB synthetic 9-track 800 BPI NRZI tape, time-sharded over the ranks (strong scaling)"),
+}
+
+
+def make_base_tape(seed, target_rows, kind="nrzi"):
+    """Unique synthetic tape of about target_rows rows: 512..4096-byte blocks, >= 6 ms gaps (NRZI: a tapemark every 16 blocks)
+    (SURVEY.md 8d)."""
     from readtape_amd import synth
-    rng = np.random.default_rng(seed)
-    spb = synth.nrzi_spec().samples_per_bit
-    nblocks = max(4, int(target_rows / ((2304 + 8 + 16) * spb + 6000)))
-    tape = synth.nrzi_tape(seed=seed, nblocks=nblocks, minlen=512, maxlen=4096, marks_every=16, gap_samples=6000)
-    return tape
+    make = {"nrzi": lambda n: synth.nrzi_tape(seed=seed, nblocks=n, minlen=512, maxlen=4096, marks_every=16, gap_samples=6000),
+            "pe": lambda n: synth.pe_tape(seed=seed, nblocks=n, minlen=512, maxlen=4096, gap_samples=8000),
+            "gcr": lambda n: synth.gcr_tape(seed=seed, nblocks=n, minlen=512, maxlen=4096, gap_samples=30000)}[kind]
+    probe = make(4)
+    nblocks = max(4, int(target_rows / (probe.rows.shape[0] / 4)))
+    return make(nblocks)
 
 
-def cpu_baseline(tape, copies):
+def cpu_baseline(tape, copies, conf):
     """Times the CPU path on `copies` concatenated copies of the base tape (single core)."""
     from readtape_amd import tbin
     hdr = tape.spec.header()
@@ -60,21 +80,47 @@ def cpu_baseline(tape, copies):
         del rows
         if not os.path.exists(port):
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
-        p = subprocess.run([port, "-time", f"-out={wd}/o", path], capture_output=True, text=True)
+        p = subprocess.run([port, "-time", f"-out={wd}/o", *conf["port_opts"], path], capture_output=True, text=True)
         j = json.loads(p.stdout.strip().splitlines()[-1])
         out["port_msamples_per_s"] = j["msamples_per_s"]
         port_tap = open(f"{wd}/o.tap", "rb").read()
         value, kind = j["msamples_per_s"], "port"
         if os.path.exists(ref) and os.access(ref, os.X_OK):
             t0 = time.perf_counter()
-            p = subprocess.run([ref, "-nm", "-tap", "-nolabels", "-q", "b"], cwd=wd, capture_output=True, text=True)
+            p = subprocess.run([ref, *conf["ref_opts"], "-tap", "-nolabels", "-q", "b"], cwd=wd, capture_output=True, text=True)
             dt = time.perf_counter() - t0
             if p.returncode == 0 and os.path.exists(f"{wd}/b.tap"):
                 value, kind = nrows / dt / 1e6, "reference"
                 out["tap_identical_to_reference"] = open(f"{wd}/b.tap", "rb").read() == port_tap
     out.update(value=round(value, 3), unit="Msamples/s", cores=1, kind=kind,
-               sample=f"{nrows} rows ({copies} copies of the base tape) of the same synthetic NRZI tape, whole pipeline incl. bit decoding, single thread")
+               sample=f"{nrows} rows ({copies} copies of the base tape) of the same synthetic tape, whole pipeline incl. bit decoding, single thread"
+                      + (f", options {' '.join(conf['ref_opts'])}" if conf["ref_opts"] else ""))
     return out
+
+
+def e2e_line(tape, copies, conf, dev):
+    """End to end on a bounded sample of the same tape: .tbin file -> pinned double-buffered reader -> device windows -> events ->
+    host replay -> SIMH .tap (readtape_amd/ingest.py).  The .tap must be the CPU port's."""
+    from readtape_amd import ingest, pipeline, tbin
+    hdr = tape.spec.header()
+    rows = np.tile(tape.rows, (copies, 1))
+    with tempfile.TemporaryDirectory() as wd:
+        path = os.path.join(wd, "e.tbin")
+        tbin.write_tbin(path, hdr, rows)
+        del rows
+        opts = pipeline.DecodeOptions(multiple_tries=conf["nparmsets"] > 1, verbose=False)      # (-m: the reference's built-in sets)
+        st = ingest.decode_file_streaming(path, os.path.join(wd, "e.tap"), window_rows=1 << 23, halo_rows=1 << 18, opts=opts,
+                                          cfgkw=dict(find_zeros=True) if conf["find_zeros"] else None, device=str(dev))
+        same = None
+        port = os.path.join(ROOT, "oracle", "_build", "oracle_readtape")
+        if os.path.exists(port):
+            subprocess.run([port, f"-out={wd}/o", *conf["port_opts"], path], capture_output=True, text=True)
+            same = open(f"{wd}/o.tap", "rb").read() == open(f"{wd}/e.tap", "rb").read()
+    return {"value": round(st["msamples_per_s"], 2), "unit": "Msamples/s", "rows": st["rows"], "windows": st["windows"], "seconds": round(st["seconds"], 3),
+            "host_replay_seconds": round(st["replay_seconds"], 3), "host_replay_events_per_s": round(st["replay_events_per_s"] or 0),
+            "file_read_seconds_overlapped": round(st["read_seconds"], 3), "scan_wait_seconds": round(st["scan_wait_seconds"], 3),
+            "blocks": st["blocks"], "tapemarks": st["tapemarks"], "exact_rescans": st["exact_scans"], "tap_identical_to_cpu_port": same,
+            "path": ".tbin in the page cache -> pinned double buffers -> hipMemcpyAsync on a copy stream -> rtfe_scan -> host replay (1 thread) -> .tap"}
 
 
 def main():
@@ -82,15 +128,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=float, default=1e8, help="sample instants per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2", help="BASELINE.json configs[1..4]; the driver's default line is C2")
+    ap.add_argument("--rows", type=float, default=None, help="sample instants per GPU (C5: of the whole tape); default: the config's")
+    ap.add_argument("--window-rows", type=float, default=None)
     ap.add_argument("--base-rows", type=float, default=5e6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="alternate two front-end contexts on two HIP streams (steps overlap; per-kernel times then include contention)")
     args = ap.parse_args()
+    conf = CONFIGS[args.config]
 
     import torch
     import torch.distributed as dist
-    from readtape_amd import frontend
+    from readtape_amd import frontend, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,27 +151,55 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     dev = torch.device(f"cuda:{local}")
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    strong = bool(conf.get("strong"))
+    total_rows = float(args.rows or conf["rows"])
 
     # ---- synthetic tape, resident in HBM ----
-    tape = make_base_tape(seed=1000 + rank, target_rows=int(args.base_rows))
+    # weak (C2..C4): every rank holds its own tape of `rows` rows (its own seed) - N tapes of a collection decoded side by side is
+    # what the shards of a longer tape look like; strong (C5): ONE tape (same seed everywhere), rank r holds plan_shards()[r].
+    tape = make_base_tape(seed=1000 + (0 if strong else rank), target_rows=int(args.base_rows), kind=conf["kind"])
     hdr = tape.spec.header()
     base = torch.from_numpy(tape.rows).to(dev)
-    copies = max(1, int(round(args.rows / base.shape[0])))
-    rows = base.repeat(copies, 1).contiguous()
+    copies = max(1, int(round(total_rows / base.shape[0])))
+    if strong:
+        n_tape = copies * int(base.shape[0])
+        lo, hi = shard.plan_shards(n_tape, world)[rank]
+        idx0 = lo % base.shape[0]
+        reps = (hi - lo + idx0) // base.shape[0] + 2
+        rows = base.repeat(reps, 1)[idx0: idx0 + (hi - lo)].contiguous()
+        row_base = lo
+    else:
+        rows = base.repeat(copies, 1).contiguous()
+        row_base = rank * int(rows.shape[0])
     nrows = int(rows.shape[0])
     del base
-    cfg = frontend.FrontEndConfig.from_header(hdr, nparmsets=1)
+    parmsets = None
+    if conf["nparmsets"] > len(frontend.DEFAULT_PARMSETS[hdr.mode]):
+        # the reference ships 5 GCR sets (src/parmsets.c:104-110); a .parms file may hold more - the sweep is filled up to 8 with
+        # variations of the window width, the rise threshold and the minimum peak, as such a file would
+        extra = [(1.4, 0.20, 0.2, 0.5, 0, 0.0), (1.6, 0.14, 0.0, 0.5, 0, 0.0), (1.5, 0.10, 0.1, 0.5, 0, 0.0), (1.3, 0.25, 0.2, 0.5, 0, 0.0)]
+        parmsets = (list(frontend.DEFAULT_PARMSETS[hdr.mode]) + extra)[: conf["nparmsets"]]
+    cfg = frontend.FrontEndConfig.from_header(hdr, nparmsets=conf["nparmsets"], find_zeros=conf["find_zeros"], parmsets=parmsets)
     fe = frontend.FrontEnd(cfg, device=str(dev))
     fe.set_timing(True)
 
     # time shards: this rank owns `nrows` rows; the tail of the buffer receives the right neighbour's first rows
-    halo_rows = (1 << 18) if (world > 1 and rank < world - 1) else 0
+    HALO = 1 << 18
+    halo_rows = HALO if (world > 1 and rank < world - 1) else 0
     if halo_rows:
         buf = torch.empty((nrows + halo_rows, rows.shape[1]), dtype=rows.dtype, device=dev)
         buf[:nrows].copy_(rows)
         rows = buf
         del buf
     own_view = rows[:nrows]
+    ntot = int(rows.shape[0])
+    # fragments of the resident rows (one when the workspace fits)
+    wrows = int(args.window_rows or conf["window_rows"] or 0)
+    if wrows and wrows < nrows:
+        wrows = wrows // 1024 * 1024
+        frags = [(a, min(nrows, a + wrows)) for a in range(0, nrows, wrows)]
+    else:
+        frags = [(0, nrows)]
 
     # Default: one stream, steps back to back (the per-kernel HIP-event times are then contention-free, which is what the
     # roofline line needs).  --pipeline alternates two front-end contexts (own HIP stream, workspace and outputs) so that
@@ -133,35 +211,46 @@ def main():
     else:
         fes = [fe, fe]
         streams = [torch.cuda.current_stream(dev)] * 2
+    kms = {k: 0.0 for k in fe.kernel_names()}
 
-    def step(i):
+    def scan_frag(f, s, a, b):
+        last = b >= nrows
+        end = ntot if last else min(ntot, b + HALO)
+        return f.scan(rows[a:end], row_base=row_base + a, first_is_tape_start=(rank == 0 and a == 0), own_rows=b - a, stream=s.cuda_stream)
+
+    def step(i, timed=False, each=None):
         s = streams[i & 1]
+        f = fes[i & 1]
         with torch.cuda.stream(s):
             if world > 1:
                 # the seam halo is the only exchange: neighbour isend/irecv over RCCL (xGMI), no collective on the data path
                 ops = []
-                if rank > 0: ops.append(dist.P2POp(dist.isend, own_view[:1 << 18], rank - 1))
+                if rank > 0: ops.append(dist.P2POp(dist.isend, own_view[:HALO], rank - 1))
                 if rank < world - 1: ops.append(dist.P2POp(dist.irecv, rows[nrows:], rank + 1))
                 for w in dist.batch_isend_irecv(ops): w.wait()
-            return fes[i & 1].scan(rows, row_base=rank * nrows, first_is_tape_start=(rank == 0), own_rows=nrows, stream=s.cuda_stream)
+            res = None
+            for k, (a, b) in enumerate(frags):
+                res = scan_frag(f, s, a, b)
+                if each is not None:
+                    each(res)
+                if timed and (len(frags) > 1 or not args.pipeline):
+                    ms = f.kernel_ms()               # HIP events on the scan's stream (synchronises this scan)
+                    for kk in kms: kms[kk] += ms[kk]
+            return res
 
     torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         res = step(i)
     torch.cuda.synchronize(dev)
     if world > 1: dist.barrier()
-    kms = {k: 0.0 for k in fe.kernel_names()}
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        res = step(i)
-        if not args.pipeline:
-            ms = fe.kernel_ms()                      # HIP events on the scan's stream (synchronises this scan)
-            for k in kms: kms[k] += ms[k]
-        elif i > 0:
+        res = step(i, timed=True)
+        if args.pipeline and len(frags) == 1 and i > 0:
             ms = fes[(i - 1) & 1].kernel_ms()    # the previous step's events, on its own stream (waits for that step only)
             for k in kms: kms[k] += ms[k]
-    if args.pipeline and args.steps > 0:
+    if args.pipeline and len(frags) == 1 and args.steps > 0:
         ms = fes[(args.steps - 1) & 1].kernel_ms()
         for k in kms: kms[k] += ms[k]
     torch.cuda.synchronize(dev)
@@ -172,15 +261,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    res.fetch()
-    nevents = int(res.counts.sum())
-    bad = int((res.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START | frontend.F_STATE_AT_END)).any())
+    # what the step produced (one more, untimed pass: every fragment's tables are fetched before the next one reuses the buffers)
+    tally = dict(events=0, bursts=0, bad=0, redone=0)
+
+    def count(r):
+        r.fetch(events=False)
+        tally["events"] += int(r.counts.sum())
+        tally["bursts"] += int(r.nbursts)
+        tally["bad"] += int(((r.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START | frontend.F_STATE_AT_END)) != 0).sum())
+    step(0, each=count)
+    nevents, bad = tally["events"], tally["bad"]
     if world > 1:
-        tot = torch.tensor([nevents, bad], device=dev, dtype=torch.int64)
+        tot = torch.tensor([nevents, bad, nrows], device=dev, dtype=torch.int64)
         dist.all_reduce(tot)
-        nevents_all, bad = int(tot[0].item()), int(tot[1].item())
+        nevents_all, bad, rows_all = int(tot[0].item()), int(tot[1].item()), int(tot[2].item())
     else:
-        nevents_all = nevents
+        nevents_all, rows_all = nevents, nrows
     if rank == 0:
         for k in kms: kms[k] /= max(args.steps, 1)
         dom = max(kms, key=kms.get)
@@ -189,25 +285,35 @@ def main():
         traffic = None
         try:                                         # HBM bytes per launch from the committed rocprofv3 --pmc passes
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if dom in pm and abs(pm["workload_rows"] - nrows) < 0.01 * nrows:
+            if args.config == pm.get("config", "C2") and dom in pm and abs(pm["workload_rows"] - nrows) < 0.01 * nrows:
                 traffic = pm[dom]["fetch_bytes"] + pm[dom]["write_bytes"]
         except Exception:
             pass
         line = {
-            "metric": "Msamples/sec (all tracks) 9-trk TBIN", "value": round(nrows * world * args.steps / dt / 1e6, 1),
+            "metric": "Msamples/sec (all tracks) 9-trk TBIN", "value": round(rows_all * args.steps / dt / 1e6, 1),
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "i16/f32", "data": "synthetic",
-            "config": {"workload": "C2: synthetic 9-track 800 BPI NRZI, 781.25 kHz, 1 parmset", "rows_per_gpu": nrows,
-                       "bytes_per_gpu": nrows * cfg.ntrks * 2, "events_per_gpu": nevents, "events_total": nevents_all, "bursts": int(res.nbursts),
-                       "flagged_bursts": bad, "sharding": "time shards, neighbour halo only" if world > 1 else "none"},
+            "config": {"workload": conf["workload"], "rows_per_gpu": nrows, "rows_total": rows_all,
+                       "bytes_per_gpu": nrows * cfg.ntrks * 2, "events_per_gpu": nevents, "events_total": nevents_all, "bursts": tally["bursts"],
+                       "flagged_bursts": bad, "parmsets": conf["nparmsets"], "launches_per_step": len(frags),
+                       "sharding": ("one tape, time shards (plan_shards), neighbour halo only" if strong else "time shards, neighbour halo only") if world > 1 else "none"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes": alg_bytes},
         }
+        ncopies = max(1, min(copies, 4))
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(tape, copies=max(1, min(copies, 4)))
+            line["cpu_baseline"] = cpu_baseline(tape, ncopies, conf)
+        if not args.no_e2e and world == 1:
+            fe.close()
+            del rows, own_view
+            torch.cuda.empty_cache()
+            try:
+                line["e2e"] = e2e_line(tape, ncopies, conf, dev)
+            except Exception as e:                    # the headline number must not depend on the bounded end-to-end sample
+                line["e2e"] = {"error": repr(e)[:300]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

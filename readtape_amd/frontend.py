@@ -206,14 +206,16 @@ class ScanResult:
         self.fe, self.bufs, self.max_bursts, self.single = fe, bufs, max_bursts, single
         self.bursts = self.counts = self._events = None
 
-    def fetch(self):
+    def fetch(self, events=True):
         fe, be = self.fe, self.fe.backend
         be.sync()
         nb = 1 if self.single else int(be.to_numpy(self.bufs["nbursts"], np.int32)[0])
         self.bursts = be.to_numpy(self.bufs["bursts"], BURST_DTYPE)[:nb].copy()
         P, T = len(fe.cfg.parmsets), fe.cfg.ntrks
         self.counts = be.to_numpy(self.bufs["counts"], np.uint32)[: nb * P * T].reshape(nb, P, T).copy()
-        self._events = be.to_numpy(self.bufs["events"], EVENT_DTYPE)
+        # the used part of the event arena: bursts are laid out one after the other (event_base, P*T regions of event_cap each)
+        used = int((self.bursts["event_base"].astype(np.int64) + P * T * self.bursts["event_cap"].astype(np.int64)).max()) if nb else 0
+        self._events = be.to_numpy(self.bufs["events"][: max(used, 1) * EVENT_DTYPE.itemsize], EVENT_DTYPE) if events else None
         return self
 
     @property
@@ -293,6 +295,10 @@ class FrontEnd:
                 return old
             nrows = max(nrows, 2 * old["nrows"] if old is not None else 1 << 16)
             self._cache.pop(k, None)
+        if key == "scan" and k not in self._cache:         # fragments of one tape differ in length: the largest buffer set serves them all
+            fit = [kk for kk in self._cache if kk[0] == "scan" and kk[1] >= nrows]
+            if fit:
+                return self._cache[min(fit, key=lambda kk: kk[1])]
         if k not in self._cache:
             be, lib = self.backend, self.lib
             mb = int(lib.rtfe_max_bursts(self.h, nrows))

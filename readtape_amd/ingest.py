@@ -1,0 +1,142 @@
+"""Streaming ingest: a .tbin file larger than the device window is decoded window by window.
+
+Replaces the reference's read loop (two fread()s per row into a stack buffer, src/readtape.c:1405-1414) with
+
+    disk --(reader thread, readinto)--> pinned host buffer --(hipMemcpyAsync, copy stream)--> device window
+         --(rtfe_scan, compute stream)--> events --(host replay of the window's own bursts)--> piece of the .tap
+
+Two pinned buffers and two device windows: while window k is scanned and replayed, window k+1 is read and copied.  A window is a
+FRAGMENT in the sense of pipeline.decode_fragment: it carries a halo of the following rows, owns the bursts whose zone ends inside
+it, and its .tap piece concatenates with its neighbours' (DESIGN.md 6).  PyTorch supplies the pinned allocation (hipHostMalloc),
+the streams and the events; nothing here computes on the CPU except the block decoders.
+"""
+from __future__ import annotations
+
+import os
+import threading
+import time
+
+import numpy as np
+
+from . import frontend, pipeline, tbin
+
+
+def _payload_geometry(path):
+    """(header, payload offset, whole rows in the file).  The data end at the first row whose head-0 sample is 0x8000
+    (src/readtape.c:1410) - normally the lone int16 behind the last row; the reader also looks for it inside every window."""
+    hdr, off = tbin.read_header(path)
+    nrows = (os.path.getsize(path) - off) // (2 * hdr.ntrks)
+    return hdr, off, int(nrows)
+
+
+def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17, opts: pipeline.DecodeOptions | None = None, cfgkw=None,
+                          device="cuda:0"):
+    """Decodes the .tbin file `path` to the SIMH file `tap_path` through device windows of `window_rows` rows (a multiple of 1024).
+    Returns statistics incl. the end-to-end rate (disk -> .tap), the time spent in the host replay and the rows the halos re-read."""
+    import torch
+    assert window_rows % 1024 == 0
+    opts = opts or pipeline.DecodeOptions()
+    hdr, off, nrows = _payload_geometry(path)
+    ntrks = hdr.ntrks
+    full = pipeline.default_parmsets(hdr.mode, opts.nparmsets or (15 if opts.multiple_tries else 1))
+    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=pipeline.frontend_parmsets(full), **(cfgkw or {}))
+    fe = frontend.FrontEnd(cfg, device=device)
+    dev = torch.device(device)
+    spans = [(lo, min(nrows, lo + window_rows)) for lo in range(0, nrows, window_rows)]
+    cap = window_rows + halo_rows
+    pinned = [torch.empty((cap, ntrks), dtype=torch.int16, pin_memory=True) for _ in range(2)]       # hipHostMalloc
+    dwin = [torch.empty((cap, ntrks), dtype=torch.int16, device=dev) for _ in range(2)]
+    copy_stream, scan_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    copied = [torch.cuda.Event() for _ in range(2)]
+    fd = os.open(path, os.O_RDONLY)
+    t_read = [0.0]
+    data_end = [nrows]
+
+    def read_rows(dst, lo, end):
+        """rows [lo, end) of the payload -> the pinned tensor dst (positional reads: safe beside the other thread's)."""
+        t0 = time.perf_counter()
+        view = memoryview(dst.numpy()).cast("B")[: (end - lo) * 2 * ntrks]
+        pos, done = off + lo * 2 * ntrks, 0
+        while done < len(view):
+            got = os.preadv(fd, [view[done: done + (1 << 30)]], pos + done)
+            if got <= 0:
+                raise IOError("short read")
+            done += got
+        t_read[0] += time.perf_counter() - t0
+
+    def read_window(k):
+        lo, hi = spans[k]
+        end = min(nrows, hi + halo_rows)
+        read_rows(pinned[k & 1], lo, end)
+        marks = np.flatnonzero(pinned[k & 1].numpy()[: end - lo, 0] == tbin.END_MARK)
+        if marks.size:                                    # an end marker inside the payload: the tape ends there
+            data_end[0] = min(data_end[0], lo + int(marks[0]))
+        return min(end, data_end[0])
+
+    def launch(k, end):
+        lo, hi = spans[k]
+        hi = min(hi, data_end[0])
+        if hi <= lo:
+            return None, None, lo
+        with torch.cuda.stream(copy_stream):
+            dwin[k & 1][: end - lo].copy_(pinned[k & 1][: end - lo], non_blocking=True)
+            copied[k & 1].record(copy_stream)
+        scan_stream.wait_event(copied[k & 1])
+        piece = dwin[k & 1][: end - lo]
+        fin = pipeline.scan_fragment(fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0], stream=scan_stream.cuda_stream)
+        return piece, fin, end
+
+    stats = dict(rows=nrows, windows=len(spans), halo_rows_read=0, blocks=0, tapemarks=0, events_delivered=0, exact_scans=0, retries=0)
+    t_replay = t_wait = 0.0
+    t_start = time.perf_counter()
+    total = 0
+    with open(tap_path, "wb") as tapf:
+        pend = launch(0, read_window(0)) if spans else None
+        for k, (lo, hi) in enumerate(spans):
+            if lo >= data_end[0]:
+                break
+            hi = min(hi, data_end[0])
+            piece, fin, end_k = pend
+            reader, nxt = None, [0]
+            if k + 1 < len(spans):                        # window k+1 is read while window k is scanned and replayed
+                def work(kk=k + 1):
+                    nxt[0] = read_window(kk)
+                reader = threading.Thread(target=work)
+                reader.start()
+            t0 = time.perf_counter()
+            res, nb, bound = fin()
+            t_wait += time.perf_counter() - t0
+            halo = halo_rows
+            while nb is None and end_k < data_end[0]:    # the last own burst runs past the halo: read more (rare; synchronous)
+                halo *= 4
+                stats["retries"] += 1
+                end_k = min(data_end[0], hi + halo)
+                host = torch.empty((end_k - lo, ntrks), dtype=torch.int16, pin_memory=True)
+                read_rows(host, lo, end_k)
+                piece = host.to(dev)
+                res, nb, bound = pipeline.scan_fragment(fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
+            stats["halo_rows_read"] += end_k - hi
+            if res.nbursts:
+                t0 = time.perf_counter()
+                frag = tap_path + ".frag"
+                st = pipeline.decode_fragment(hdr, cfg, fe, res, piece, lo, 0 if lo == 0 else int(res.bursts[0]["zone_first"]), bound, frag, full, opts)
+                t_replay += time.perf_counter() - t0
+                with open(frag, "rb") as g:
+                    data = g.read()
+                os.remove(frag)
+                tapf.write(data)
+                total += len(data)
+                for key in ("blocks", "tapemarks", "events_delivered", "exact_scans"):
+                    stats[key] += int(st[key])
+            if reader is not None:
+                reader.join()
+                pend = launch(k + 1, nxt[0])              # (its buffers were window k-1's: both copies of it are finished)
+        if total > 0:
+            tapf.write(b"\xff\xff\xff\xff")                   # src/readtape.c:1885
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t_start
+    os.close(fd)
+    fe.close()
+    stats.update(rows=data_end[0], seconds=dt, msamples_per_s=data_end[0] / dt / 1e6, replay_seconds=t_replay, read_seconds=t_read[0], scan_wait_seconds=t_wait,
+                 replay_events_per_s=(stats["events_delivered"] / t_replay) if t_replay > 0 else None, tap_bytes=total + (4 if total else 0))
+    return stats

@@ -116,6 +116,12 @@ def parse_header(buf: bytes) -> tuple[TbinHeader, int]:
     return h, off
 
 
+def read_header(path: str) -> tuple[TbinHeader, int]:
+    """(header, payload byte offset) of a .tbin file without reading the payload."""
+    with open(path, "rb") as f:
+        return parse_header(f.read(4096))
+
+
 def read_tbin(path: str) -> tuple[TbinHeader, np.ndarray]:
     """Returns (header, rows[nsamples, ntrks] int16), rows cut at the 0x8000 end marker
     (src/readtape.c:1410: only the head-0 slot is tested)."""

@@ -1,0 +1,49 @@
+"""GPU: the streaming reader (readtape_amd/ingest.py) — a .tbin file decoded through device windows much smaller than the tape
+writes the .tap the whole-tape decode writes (which the replay tests pin to the reference's)."""
+import numpy as np
+import pytest
+
+from readtape_amd import ingest, pipeline, synth, tbin
+
+pytestmark = pytest.mark.gpu
+
+
+def _whole(hdr, rows, path):
+    pipeline.decode_tape(hdr, rows, path)
+    return open(path, "rb").read()
+
+
+@pytest.mark.parametrize("kind,window,halo", [("nrzi", 1 << 16, 1 << 12), ("nrzi", 1 << 14, 1 << 10), ("pe", 1 << 15, 1 << 13), ("gcr", 1 << 15, 1 << 13)])
+def test_streamed_windows_write_the_whole_tape_tap(kind, window, halo, tmp_path):
+    """Windows far shorter than the tape, halos shorter than a block (so the halo has to grow): same bytes."""
+    if kind == "nrzi":
+        tape = synth.nrzi_tape(seed=71, nblocks=40, minlen=200, maxlen=1500, marks_every=7, gap_samples=3000)
+    elif kind == "pe":
+        tape = synth.pe_tape(seed=72, nblocks=12, minlen=200, maxlen=900, gap_samples=3000)
+    else:
+        tape = synth.gcr_tape(seed=73, nblocks=8, minlen=300, maxlen=1200, gap_samples=3000)
+    hdr = tape.spec.header()
+    want = _whole(hdr, tape.rows, str(tmp_path / "whole.tap"))
+    path = str(tmp_path / "t.tbin")
+    tbin.write_tbin(path, hdr, tape.rows)
+    st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=window, halo_rows=halo)
+    got = open(tmp_path / "s.tap", "rb").read()
+    assert got == want
+    assert st["rows"] == tape.rows.shape[0] and st["windows"] >= 3 and st["blocks"] > 0
+
+
+def test_end_marker_inside_the_payload_ends_the_tape(tmp_path):
+    """src/readtape.c:1410: the data end at the first row whose head-0 sample is 0x8000, wherever it is."""
+    tape = synth.nrzi_tape(seed=74, nblocks=20, minlen=200, maxlen=900, gap_samples=3000)
+    hdr = tape.spec.header()
+    cut = tape.rows.shape[0] * 5 // 8
+    want = _whole(hdr, tape.rows[:cut], str(tmp_path / "whole.tap"))
+    path = str(tmp_path / "t.tbin")
+    rows = tape.rows.copy()
+    with open(path, "wb") as f:
+        f.write(tbin.pack_header(hdr))
+        rows[cut, 0] = tbin.END_MARK
+        f.write(rows.tobytes())
+    st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=1 << 15, halo_rows=1 << 12)
+    assert st["rows"] == cut
+    assert open(tmp_path / "s.tap", "rb").read() == want
