@@ -1,125 +1,138 @@
-/* rt_decode_pe.c — 1600 BPI phase-encoded bit recovery from flux-transition events.
- * Restates src/decode_pe.c (V3.18) on an explicit context.  Each track is self-clocking: a
- * transition inside the clock window after the previous one is a phase (clock) transition,
- * otherwise it carries a data bit. */
+/* rt_decode_pe.c — 1600 BPI phase encoding: bits from flux-transition events.
+ *
+ * What the reference's src/decode_pe.c (V3.18) computes.  Every track clocks itself, so the decoder is one small machine
+ * per track with two phases:
+ *
+ *   preamble   count transitions, learn the nominal pulse height (peaks 5..15) and the polarity of a one; the first
+ *              transition of that polarity that comes a full bit after its predecessor (behind >= 70 peaks) is the
+ *              all-ones marker that ends the preamble                                     (src/decode_pe.c:127-155)
+ *   data       a transition either sits on the cell boundary (phase transition: no information) or mid-cell (a bit whose
+ *              value is its direction); which one is decided by the clock window          (src/decode_pe.c:157-201)
+ *
+ * and a block-level verdict (tapemark pattern, noise, data with the postamble stripped; src/decode_pe.c:33-102).
+ * Float/double promotion and the order of accumulation are the reference's: the .tap has to be byte-identical.
+ */
 #include "rt_decode.h"
 
 #include <limits.h>
 
-#define PE_IBG_SECS        200e-6   /* src/decoder.h:116 */
-#define PE_IGNORE_POSTBITS 5        /* src/decoder.h:117 */
-#define PE_MIN_PREBITS     70       /* src/decoder.h:118 */
-#define PE_MAX_POSTBITS    40       /* src/decoder.h:119 */
-#define AGC_STARTBASE      5
-#define AGC_ENDBASE        15
+static const double GAP_SECS = 200e-6;          /* PE_IBG_SECS, src/decoder.h:116 */
+enum { POSTAMBLE_ZEROS_KEPT_OUT = 5,            /* PE_IGNORE_POSTBITS: postamble bits that may be garbage, src/decoder.h:117 */
+       PREAMBLE_PEAKS = 70,                     /* PE_MIN_PREBITS,  src/decoder.h:118 */
+       POSTAMBLE_LIMIT = 40,                    /* PE_MAX_POSTBITS, src/decoder.h:119 */
+       LEARN_FROM = 5, LEARN_TO = 15 };         /* AGC_STARTBASE / AGC_ENDBASE */
+
+#define TRKBIT(d, trk) ((uint16_t)(1u << ((d)->opt.ntrks - 1 - (trk))))
+
+/* ---- verdict ---- */
+
+/* A PE tapemark: flux reversals at the preamble rate on tracks 0 2 5 6 7 8 (P 0 2 5 6 7 in ANSI numbering), tracks 1 3 4
+ * erased (src/decode_pe.c:40-50).  "Recorded" = many peaks and practically no data bits; "erased" = practically no peaks. */
+static int looks_like_tapemark(const struct rt_trk *T) {
+   static const unsigned recorded = 0x1e5, erased = 0x01a;      /* bit k = track k */
+   for (int k = 0; k < 9; ++k) {
+      if ((recorded >> k & 1) && !(T[k].datacount <= 2 && T[k].peakcount > 75)) return 0;
+      if ((erased >> k & 1) && T[k].peakcount > 2) return 0; }
+   return 1; }
+
+/* take the postamble (zeros, then the all-ones marker) off one track: walk back over at most 41 bits until a one that is
+ * not among the first 6 (those may be garbage); faked bits that go away are no longer corrections (src/decode_pe.c:62-70) */
+static void strip_postamble(struct rt_dec *d, struct rt_trk *t) {
+   const uint16_t m = TRKBIT(d, t->trknum);
+   for (int gone = 0; gone <= POSTAMBLE_LIMIT; ++gone) {
+      const int at = --t->datacount;
+      if (d->data_faked[at] & m) --d->results[d->parmset].corrected_bits;
+      if (gone > POSTAMBLE_ZEROS_KEPT_OUT && (d->data[at] & m)) return; } }
 
 void rt_pe_end_of_block(struct rt_dec *d) {   /* src/decode_pe.c:33-102 */
-   struct rt_results *result = &d->results[d->parmset];
-   struct rt_trk *T = d->trk;
-   int ntrks = d->opt.ntrks;
    if (d->endblock_done) return;
    d->endblock_done = 1;
-   if (T[0].datacount <= 2 && T[0].peakcount > 75 &&
-         T[2].datacount <= 2 && T[2].peakcount > 75 &&
-         T[5].datacount <= 2 && T[5].peakcount > 75 &&
-         T[6].datacount <= 2 && T[6].peakcount > 75 &&
-         T[7].datacount <= 2 && T[7].peakcount > 75 &&
-         T[8].datacount <= 2 && T[8].peakcount > 75 &&
-         T[1].peakcount <= 2 && T[3].peakcount <= 2 && T[4].peakcount <= 2) {
-      result->blktype = RT_BS_TAPEMARK;
-      return; }
-   float avg_bit_spacing = 0;
-   result->minbits = RT_MAXBLOCK;
-   result->maxbits = 0;
-   for (int trk = 0; trk < ntrks; ++trk) {
-      struct rt_trk *t = &T[trk];
-      avg_bit_spacing += (float)(t->t_lastbit - t->t_firstbit) / t->datacount;
-      int postamble_bits;
+   struct rt_results *res = &d->results[d->parmset];
+   if (looks_like_tapemark(d->trk)) { res->blktype = RT_BS_TAPEMARK; return; }
+   const int ntrks = d->opt.ntrks;
+   int shortest = RT_MAXBLOCK, longest = 0;
+   float spacing_sum = 0;
+   for (int k = 0; k < ntrks; ++k) {
+      struct rt_trk *t = &d->trk[k];
+      spacing_sum += (float)(t->t_lastbit - t->t_firstbit) / t->datacount;          /* (before the postamble goes) */
       if (t->datacount > 0) {
-         for (postamble_bits = 0; postamble_bits <= PE_MAX_POSTBITS; ++postamble_bits) {
-            --t->datacount;
-            if ((d->data_faked[t->datacount] & (1 << (ntrks - 1 - trk))) != 0)
-               --d->results[d->parmset].corrected_bits;
-            if (postamble_bits > PE_IGNORE_POSTBITS && (d->data[t->datacount] & (1 << (ntrks - 1 - trk))) != 0)
-               break; }
-         if (result->alltrk_max_agc_gain < t->max_agc_gain) result->alltrk_max_agc_gain = t->max_agc_gain;
-         if (result->alltrk_min_agc_gain > t->min_agc_gain) result->alltrk_min_agc_gain = t->min_agc_gain; }
-      if (t->datacount > result->maxbits) result->maxbits = t->datacount;
-      if (t->datacount < result->minbits) result->minbits = t->datacount; }
-   result->avg_bit_spacing = avg_bit_spacing / ntrks;
-   rt_set_expected_parity(d, result->maxbits);
-   if (result->maxbits == 0) {
-      result->blktype = RT_BS_NOISE; }
-   else {
-      result->blktype = RT_BS_BLOCK;
-      d->interblock_counter = (int)(PE_IBG_SECS / d->sample_deltat);
-      if (result->minbits != result->maxbits)
-         result->track_mismatch = result->maxbits - result->minbits;
-      result->vparity_errs = 0;
-      for (int i = 0; i < result->minbits; ++i)
-         if (rt_parity9(d->data[i]) != d->expected_parity) ++result->vparity_errs; } }
+         strip_postamble(d, t);
+         if (res->alltrk_max_agc_gain < t->max_agc_gain) res->alltrk_max_agc_gain = t->max_agc_gain;
+         if (res->alltrk_min_agc_gain > t->min_agc_gain) res->alltrk_min_agc_gain = t->min_agc_gain; }
+      if (longest < t->datacount) longest = t->datacount;
+      if (shortest > t->datacount) shortest = t->datacount; }
+   res->minbits = shortest;
+   res->maxbits = longest;
+   res->avg_bit_spacing = spacing_sum / ntrks;
+   rt_set_expected_parity(d, longest);
+   if (longest == 0) { res->blktype = RT_BS_NOISE; return; }
+   res->blktype = RT_BS_BLOCK;
+   d->interblock_counter = (int)(GAP_SECS / d->sample_deltat);
+   if (shortest != longest) res->track_mismatch = longest - shortest;
+   int bad = 0;
+   for (int i = 0; i < shortest; ++i) bad += rt_parity9(d->data[i]) != d->expected_parity;
+   res->vparity_errs = bad; }
 
-static void pe_addbit(struct rt_dec *d, struct rt_trk *t, int bit, int faked, double t_bit) {   /* src/decode_pe.c:104-125 */
-   if (t->t_lastbit == 0) t->t_lastbit = t_bit - 1 / (d->opt.bpi * d->opt.ips);
-   if (t->datablock) {
-      t->lastdatabit = (uint8_t)bit;
-      if (!t->idle && !faked) {
-         float delta = (float)(t_bit - t->t_lastbit);
-         rt_adjust_clock(d, &t->clkavg, delta, t->trknum);
-         t->t_clkwindow = t->clkavg.t_bitspaceavg / 2 * RT_PARM(d).clk_factor; }
-      t->t_lastbit = t_bit;
-      if (t->datacount == 0) t->t_firstbit = t_bit;
-      uint16_t mask = 1 << (d->opt.ntrks - 1 - t->trknum);
-      d->data[t->datacount] = bit ? d->data[t->datacount] | mask : d->data[t->datacount] & ~mask;
-      d->data_faked[t->datacount] = faked ? d->data_faked[t->datacount] | mask : d->data_faked[t->datacount] & ~mask;
-      if (faked) ++d->results[d->parmset].corrected_bits;
-      d->data_time[t->datacount] = t_bit;
-      if (t->datacount < RT_MAXBLOCK) ++t->datacount; } }
+/* ---- data phase ---- */
 
-static void pe_preamble_peak(struct rt_dec *d, struct rt_trk *t, int is_top) {   /* src/decode_pe.c:127-155 */
-   if (t->peakcount == 1) {
+/* one data bit of one track (src/decode_pe.c:104-125).  A real bit also feeds the track's clock average, which in turn
+ * sizes the window that tells phase transitions from data transitions. */
+static void put_bit(struct rt_dec *d, struct rt_trk *t, int bit, int faked, double when) {
+   if (t->t_lastbit == 0) t->t_lastbit = when - 1 / (d->opt.bpi * d->opt.ips);
+   if (!t->datablock) return;
+   t->lastdatabit = (uint8_t)bit;
+   if (!faked && !t->idle) {
+      rt_adjust_clock(d, &t->clkavg, (float)(when - t->t_lastbit), t->trknum);
+      t->t_clkwindow = t->clkavg.t_bitspaceavg / 2 * RT_PARM(d).clk_factor; }
+   t->t_lastbit = when;
+   const int at = t->datacount;
+   if (at == 0) t->t_firstbit = when;
+   const uint16_t m = TRKBIT(d, t->trknum);
+   d->data[at] = bit ? (uint16_t)(d->data[at] | m) : (uint16_t)(d->data[at] & ~m);
+   d->data_faked[at] = faked ? (uint16_t)(d->data_faked[at] | m) : (uint16_t)(d->data_faked[at] & ~m);
+   d->results[d->parmset].corrected_bits += faked != 0;
+   d->data_time[at] = when;
+   if (at < RT_MAXBLOCK) t->datacount = at + 1; }
+
+/* ---- preamble phase (src/decode_pe.c:127-155) ---- */
+static void preamble_transition(struct rt_dec *d, struct rt_trk *t, int is_top, double when) {
+   if (t->peakcount == 1) {                      /* the very first transition of the block: a one goes the other way */
       t->bit1_up = !is_top;
       d->t_blockstart = d->timenow; }
-   if (t->peakcount > PE_MIN_PREBITS
-         && t->bit1_up == is_top
-         && (is_top ? t->t_top : t->t_bot) - t->t_lastpeak > t->t_clkwindow) {
-      t->datablock = 1;
-      t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count; }
-   else {
-      t->clknext = is_top != t->bit1_up;
-      if (t->peakcount >= AGC_STARTBASE && t->peakcount <= AGC_ENDBASE) {
-         if (t->v_top > t->v_bot) {
-            t->v_avg_height_sum += t->v_top - t->v_bot;
-            ++t->v_avg_height_count;
-            t->v_heights[t->heightndx] = t->v_top - t->v_bot;
-            if (++t->heightndx >= RT_PARM(d).agc_window) t->heightndx = 0; } } } }
+   const int a_one = t->bit1_up == is_top;
+   if (a_one && t->peakcount > PREAMBLE_PEAKS && when - t->t_lastpeak > t->t_clkwindow) {
+      t->datablock = 1;                          /* the marker: data follow */
+      t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count;
+      return; }
+   t->clknext = !a_one;
+   if (t->peakcount < LEARN_FROM || t->peakcount > LEARN_TO || !(t->v_top > t->v_bot)) return;
+   const float h = t->v_top - t->v_bot;
+   t->v_avg_height_sum += h;
+   ++t->v_avg_height_count;
+   t->v_heights[t->heightndx] = h;
+   if (++t->heightndx >= RT_PARM(d).agc_window) t->heightndx = 0; }
 
-void rt_pe_top(struct rt_dec *d, struct rt_trk *t) {   /* src/decode_pe.c:157-178 */
-   if (t->datablock) {
-      int missed_transition = (t->t_top + t->t_pulse_adj) - t->t_lastpeak > t->t_clkwindow;
-      if (!t->clknext || missed_transition) {
-         pe_addbit(d, t, t->bit1_up, 0, t->t_top);
-         t->clknext = 1; }
-      else t->clknext = 0;
-      t->t_pulse_adj = ((float)(t->t_top - t->t_lastpeak) - t->clkavg.t_bitspaceavg / (missed_transition ? 1 : 2)) * RT_PARM(d).pulse_adj;
-      rt_adjust_agc(d, t); }
-   else pe_preamble_peak(d, t, 1); }
+static void transition(struct rt_dec *d, struct rt_trk *t, int is_top) {   /* src/decode_pe.c:157-201 */
+   const double when = is_top ? t->t_top : t->t_bot;
+   if (!t->datablock) { preamble_transition(d, t, is_top, when); return; }
+   /* more than a clock window after the previous transition (the last pulse's shift taken out): the cell-boundary
+    * transition is missing, so this one carries data whatever was expected */
+   const int boundary_missing = (when + t->t_pulse_adj) - t->t_lastpeak > t->t_clkwindow;
+   if (boundary_missing || !t->clknext) {
+      put_bit(d, t, is_top ? t->bit1_up : !t->bit1_up, 0, when);
+      t->clknext = 1; }
+   else t->clknext = 0;
+   t->t_pulse_adj = ((float)(when - t->t_lastpeak) - t->clkavg.t_bitspaceavg / (boundary_missing ? 1 : 2)) * RT_PARM(d).pulse_adj;
+   rt_adjust_agc(d, t); }
 
-void rt_pe_bot(struct rt_dec *d, struct rt_trk *t) {   /* src/decode_pe.c:180-201 */
-   if (t->datablock) {
-      int missed_transition = (t->t_bot + t->t_pulse_adj) - t->t_lastpeak > t->t_clkwindow;
-      if (!t->clknext || missed_transition) {
-         pe_addbit(d, t, !t->bit1_up, 0, t->t_bot);
-         t->clknext = 1; }
-      else t->clknext = 0;
-      t->t_pulse_adj = ((float)(t->t_bot - t->t_lastpeak) - t->clkavg.t_bitspaceavg / (missed_transition ? 1 : 2)) * RT_PARM(d).pulse_adj;
-      rt_adjust_agc(d, t); }
-   else pe_preamble_peak(d, t, 0); }
+void rt_pe_top(struct rt_dec *d, struct rt_trk *t) { transition(d, t, 1); }
+void rt_pe_bot(struct rt_dec *d, struct rt_trk *t) { transition(d, t, 0); }
 
-void rt_pe_generate_fake_bits(struct rt_dec *d, struct rt_trk *t) {   /* src/decode_pe.c:204-258, strategy 1 */
-   int numbits = (int)((float)(d->timenow - t->t_lastbit) / t->clkavg.t_bitspaceavg);
-   if (numbits > 0) {
-      while (numbits--) pe_addbit(d, t, t->lastdatabit, 1, d->timenow);
-      t->t_lastbit = 0;
-      if (t->lastdatabit == 0) t->clknext = 0;
-      else t->clknext = 1; } }
+/* a track went silent inside a block: fill in copies of its last bit for the time that passed, marked as faked
+ * (src/decode_pe.c:204-258, the strategy the reference compiles in) */
+void rt_pe_generate_fake_bits(struct rt_dec *d, struct rt_trk *t) {
+   int missing = (int)((float)(d->timenow - t->t_lastbit) / t->clkavg.t_bitspaceavg);
+   if (missing <= 0) return;
+   for (; missing > 0; --missing) put_bit(d, t, t->lastdatabit, 1, d->timenow);
+   t->t_lastbit = 0;
+   t->clknext = t->lastdatabit != 0; }
