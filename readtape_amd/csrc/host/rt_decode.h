@@ -155,6 +155,13 @@ struct rt_dec {
    FILE   *tapf;
    long long numoutbytes, numdatabytes;
    int no_tap_end;                    /* fragment decode: the caller writes the end-of-medium marker behind the last fragment */
+   /* output files by name (src/readtape.c:1084-1111): with outbase set, <outbase>.tap (-tap) or the numbered <outbase>.NNN.bin
+    * files (one per tape file, i.e. a new one behind every tapemark) are created when the first block wants them, and logged */
+   char    outbase[1024], outname[1100];
+   int     numfiles, numfileblks;
+   long long numfilebytes;
+   long long lines_in;                /* sample rows read by first attempts (src/readtape.c:1404): what the summary calls "samples" */
+   double  data_start_time, last_block_time;
    int     numblks, numtapemarks, numblks_err, numblks_warn, numblks_unusable;
    int     numblks_goodmultiple, numblks_trksmismatched, numblks_midbiterrs, numblks_corrected;
    FILE   *logf;                    /* block log lines (NULL = quiet) */
@@ -222,6 +229,8 @@ void rt_gcr_preprocess(struct rt_dec *d);
 void rt_got_tapemark(struct rt_dec *d);
 void rt_got_datablock(struct rt_dec *d, int badblock);
 void rt_tap_end(struct rt_dec *d);
+void rt_close_output(struct rt_dec *d);                       /* src/readtape.c:1084-1089 */
+void rt_write_summary(struct rt_dec *d, const char *infilename, double elapsed_seconds);   /* src/readtape.c:2021-2044 */
 
 /* ---- the block retry / selection driver (src/readtape.c:1720-1882) over an abstract block reader.
  * `readblock(ctx, retry)` must run one attempt with d->parmset from the saved position and return

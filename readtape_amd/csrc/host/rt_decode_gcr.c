@@ -28,70 +28,78 @@ void rt_gcr_preprocess(struct rt_dec *d) {           /* src/decode_gcr.c:404-408
    d->gcr.bitnum = d->gcr.bytenum = 0;
    d->results[d->parmset].first_error = -1; }
 
-/* ---- bit recovery (src/decode_gcr.c:731-865) ---- */
-static void gcr_addbit(struct rt_dec *d, struct rt_trk *t, int bit, double t_bit) {
-   t->t_lastbit = t_bit;
-   if (t->datacount == 0) {
-      d->t_blockstart = t_bit;
-      t->t_firstbit = t_bit;
-      t->max_agc_gain = t->agc_gain; }
-   if (!t->datablock) {
-      t->t_lastclock = t_bit - t->clkavg.t_bitspaceavg;
-      t->datablock = 1; }
-   const uint16_t mask = 1 << (d->opt.ntrks - 1 - t->trknum);
-   d->data[t->datacount] = bit ? d->data[t->datacount] | mask : d->data[t->datacount] & ~mask;
-   d->data_time[t->datacount] = t_bit;
-   if (t->datacount < RT_MAXBLOCK) ++t->datacount;
-   t->lastbits = (uint8_t)((t->lastbits << 1) | bit);
-   if (t->datacount % 5 == 0) {                       /* a resync burst starts with MARK2 and ends with MARK1 */
-      if ((t->lastbits & 0x1f) == SG_MARK2) t->resync_bitcount = 1;
-      if ((t->lastbits & 0x1f) == SG_MARK1 && t->resync_bitcount > 0) t->resync_bitcount = 0; }
-   if (t->resync_bitcount > 0) {
-      if (t->resync_bitcount == 5) rt_force_clock(&t->clkavg, t->t_peakdelta);      /* mid-burst: trust the all-ones spacing */
-      ++t->resync_bitcount; } }
+/* ---- bit recovery (src/decode_gcr.c:731-865) ----
+ * Every track clocks itself.  A transition is a one; the time since the previous transition, less the shift the last pulse
+ * is believed to have suffered, says whether no, one or two zeros lie in between (at most two: that is what the group code
+ * guarantees).  The cell length follows the spacing of adjacent ones, and is re-seeded in the middle of every resync burst. */
 
-static int gcr_checkzeros(struct rt_dec *d, struct rt_trk *t, float delta) {        /* src/decode_gcr.c:789-834 */
-   int numbits = 1;
-   if (t->datablock) {
-      const struct rt_parms *P = &RT_PARM(d);
-      t->t_peakdeltaprev = t->t_peakdelta;
-      t->t_peakdelta = delta;
-      if (delta - t->t_pulse_adj > P->z1pt * t->clkavg.t_bitspaceavg) {
-         ++numbits;
-         double zerobitloc = t->t_lastpeak + t->clkavg.t_bitspaceavg;
-         gcr_addbit(d, t, 0, zerobitloc);
-         if (delta - t->t_pulse_adj > P->z2pt * t->clkavg.t_bitspaceavg) {
-            ++numbits;
-            zerobitloc += t->clkavg.t_bitspaceavg;
-            gcr_addbit(d, t, 0, zerobitloc); } }
-      if (t->datacount > 3 && numbits == 1
-            && d->data[t->datacount - 2] & (1 << (d->opt.ntrks - 1 - t->trknum)))
-         rt_adjust_clock(d, &t->clkavg, t->t_peakdeltaprev, t->trknum);
-      t->t_pulse_adj = P->pulse_adj * (numbits * t->clkavg.t_bitspaceavg - delta); }
-   return numbits; }
+#define TRKBIT(d, trk) ((uint16_t)(1u << ((d)->opt.ntrks - 1 - (trk))))
 
-void rt_gcr_bot(struct rt_dec *d, struct rt_trk *t) {      /* src/decode_gcr.c:836-844 */
-   if (d->doing_deskew && t->t_lastclock != 0)
-      rt_record_peakstat(d, t->clkavg.t_bitspaceavg, (float)(t->t_bot - t->t_lastpeak), t->trknum);
-   gcr_checkzeros(d, t, (float)(t->t_bot - t->t_lastpeak));
-   gcr_addbit(d, t, 1, t->t_bot);
-   if (t->peakcount > AGC_ENDBASE && t->v_avg_height_count == 0) rt_adjust_agc(d, t); }
+/* resync bursts: MARK2, a run of SYNC (all ones), MARK1 - on a 5-cell grid.  Five cells into the burst the spacing of the
+ * all-ones pattern is as good a cell length as the tape offers (src/decode_gcr.c:768-786) */
+static void watch_resync(struct rt_trk *t) {
+   if (t->datacount % 5 == 0) {
+      const unsigned group = t->lastbits & 0x1f;
+      if (group == SG_MARK2) t->resync_bitcount = 1;
+      if (group == SG_MARK1 && t->resync_bitcount > 0) t->resync_bitcount = 0; }
+   if (t->resync_bitcount <= 0) return;
+   if (t->resync_bitcount == 5) rt_force_clock(&t->clkavg, t->t_peakdelta);
+   ++t->resync_bitcount; }
 
-void rt_gcr_top(struct rt_dec *d, struct rt_trk *t) {      /* src/decode_gcr.c:846-865 */
-   if (d->doing_deskew && t->t_lastclock != 0)
-      rt_record_peakstat(d, t->clkavg.t_bitspaceavg, (float)(t->t_top - t->t_lastpeak), t->trknum);
-   gcr_checkzeros(d, t, (float)(t->t_top - t->t_lastpeak));
-   gcr_addbit(d, t, 1, t->t_top);
-   if (t->peakcount >= AGC_STARTBASE && t->peakcount <= AGC_ENDBASE) {
-      t->v_avg_height_sum += t->v_top - t->v_bot;
-      ++t->v_avg_height_count;
-      t->v_heights[t->heightndx] = t->v_top - t->v_bot;
-      if (++t->heightndx >= RT_PARM(d).agc_window) t->heightndx = 0; }
-   else if (t->peakcount > AGC_ENDBASE) {
-      if (t->v_avg_height_count) {
-         t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count;
-         t->v_avg_height_count = 0; }
-      else rt_adjust_agc(d, t); } }
+static void put_bit(struct rt_dec *d, struct rt_trk *t, int bit, double when) {      /* src/decode_gcr.c:731-787 */
+   const int at = t->datacount;
+   if (at == 0) { d->t_blockstart = when; t->t_firstbit = when; t->max_agc_gain = t->agc_gain; }
+   t->t_lastbit = when;
+   if (!t->datablock) { t->datablock = 1; t->t_lastclock = when - t->clkavg.t_bitspaceavg; }
+   const uint16_t m = TRKBIT(d, t->trknum);
+   d->data[at] = bit ? (uint16_t)(d->data[at] | m) : (uint16_t)(d->data[at] & ~m);
+   d->data_time[at] = when;
+   if (at < RT_MAXBLOCK) t->datacount = at + 1;
+   t->lastbits = (uint8_t)(t->lastbits << 1 | bit);
+   watch_resync(t); }
+
+/* the zeros in front of a transition that comes `gap` after the previous one (src/decode_gcr.c:789-834) */
+static void zeros_before(struct rt_dec *d, struct rt_trk *t, float gap) {
+   if (!t->datablock) return;
+   const struct rt_parms *P = &RT_PARM(d);
+   const float limit[2] = { P->z1pt, P->z2pt };              /* in cells: more than z1pt = one zero, more than z2pt = two */
+   const float seen = gap - t->t_pulse_adj;
+   t->t_peakdeltaprev = t->t_peakdelta;
+   t->t_peakdelta = gap;
+   int cells = 1;
+   double at = t->t_lastpeak;
+   while (cells <= 2 && seen > limit[cells - 1] * t->clkavg.t_bitspaceavg) {     /* (the cell length may be re-seeded by put_bit) */
+      at += t->clkavg.t_bitspaceavg;
+      put_bit(d, t, 0, at);
+      ++cells; }
+   /* two ones in adjacent cells, twice in a row: the spacing before this one is a clean sample of the cell length */
+   if (cells == 1 && t->datacount > 3 && (d->data[t->datacount - 2] & TRKBIT(d, t->trknum)))
+      rt_adjust_clock(d, &t->clkavg, t->t_peakdeltaprev, t->trknum);
+   t->t_pulse_adj = P->pulse_adj * (cells * t->clkavg.t_bitspaceavg - gap); }
+
+/* AGC schedule: the tops of peaks 5..15 are averaged into the nominal height, then every peak adjusts the gain
+ * (src/decode_gcr.c:843,853-864; the same schedule as NRZI) */
+static void transition(struct rt_dec *d, struct rt_trk *t, int is_top) {
+   const double when = is_top ? t->t_top : t->t_bot;
+   const float gap = (float)(when - t->t_lastpeak);
+   if (d->doing_deskew && t->t_lastclock != 0) rt_record_peakstat(d, t->clkavg.t_bitspaceavg, gap, t->trknum);
+   zeros_before(d, t, gap);
+   put_bit(d, t, 1, when);
+   const int settled = t->peakcount > AGC_ENDBASE;
+   if (!is_top) { if (settled && t->v_avg_height_count == 0) rt_adjust_agc(d, t); return; }
+   if (settled) {
+      if (t->v_avg_height_count == 0) rt_adjust_agc(d, t);
+      else { t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count; t->v_avg_height_count = 0; }
+      return; }
+   if (t->peakcount < AGC_STARTBASE) return;
+   const float h = t->v_top - t->v_bot;
+   t->v_avg_height_sum += h;
+   ++t->v_avg_height_count;
+   t->v_heights[t->heightndx] = h;
+   if (++t->heightndx >= RT_PARM(d).agc_window) t->heightndx = 0; }
+
+void rt_gcr_bot(struct rt_dec *d, struct rt_trk *t) { transition(d, t, 0); }
+void rt_gcr_top(struct rt_dec *d, struct rt_trk *t) { transition(d, t, 1); }
 
 /* ---- group recoding (src/decode_gcr.c:448-674) ---- */
 
@@ -218,30 +226,34 @@ static void gcr_postprocess(struct rt_dec *d) {             /* src/decode_gcr.c:
    result->minbits = result->maxbits = d->gcr.bytenum;
    d->interblock_counter = (int)(GCR_IBG_SECS / d->sample_deltat); }
 
+/* A GCR tapemark is the PE one at GCR density: 250..400 cells of reversals on tracks 0 2 5 6 7 8, tracks 1 3 4 erased
+ * (src/decode_gcr.c:706-716) */
+static int looks_like_tapemark(const struct rt_trk *T) {
+   static const unsigned recorded = 0x1e5, erased = 0x01a;      /* bit k = track k */
+   for (int k = 0; k < 9; ++k) {
+      if ((erased >> k & 1) && T[k].peakcount > 2) return 0;
+      if ((recorded >> k & 1) && (T[k].datacount < 250 || T[k].datacount > 400)) return 0; }
+   return 1; }
+
 void rt_gcr_end_of_block(struct rt_dec *d) {                /* src/decode_gcr.c:682-729 */
-   struct rt_results *result = &d->results[d->parmset];
-   struct rt_trk *T = d->trk;
-   const int ntrks = d->opt.ntrks;
    if (d->endblock_done) return;
    d->endblock_done = 1;
-   float avg_bit_spacing = 0;
-   result->minbits = RT_MAXBLOCK;
-   result->maxbits = 0;
-   for (int trk = 0; trk < ntrks; ++trk) {
-      struct rt_trk *t = &T[trk];
-      avg_bit_spacing += (float)(t->t_lastbit - t->t_firstbit) / t->datacount;
-      if (t->datacount > result->maxbits) result->maxbits = t->datacount;
-      if (t->datacount < result->minbits) result->minbits = t->datacount;
-      if (result->alltrk_max_agc_gain < t->max_agc_gain) result->alltrk_max_agc_gain = t->max_agc_gain;
-      if (result->alltrk_min_agc_gain > t->min_agc_gain) result->alltrk_min_agc_gain = t->min_agc_gain; }
-   result->avg_bit_spacing = avg_bit_spacing / ntrks;
-   rt_set_expected_parity(d, result->maxbits);
-   static const int MARK_TRKS[6] = {0, 2, 5, 6, 7, 8};
-   int mark = T[1].peakcount <= 2 && T[3].peakcount <= 2 && T[4].peakcount <= 2;
-   for (int i = 0; i < 6 && mark; ++i) mark = T[MARK_TRKS[i]].datacount >= 250 && T[MARK_TRKS[i]].datacount <= 400;
-   if (result->maxbits <= 10) result->blktype = RT_BS_NOISE;
-   else if (mark) result->blktype = RT_BS_TAPEMARK;
-   else if (result->maxbits - result->minbits > 2) {
-      result->track_mismatch = result->maxbits - result->minbits;
-      result->blktype = RT_BS_BADBLOCK; }
+   struct rt_results *res = &d->results[d->parmset];
+   const int ntrks = d->opt.ntrks;
+   int shortest = RT_MAXBLOCK, longest = 0;
+   float spacing_sum = 0;
+   for (int k = 0; k < ntrks; ++k) {
+      const struct rt_trk *t = &d->trk[k];
+      spacing_sum += (float)(t->t_lastbit - t->t_firstbit) / t->datacount;
+      if (longest < t->datacount) longest = t->datacount;
+      if (shortest > t->datacount) shortest = t->datacount;
+      if (res->alltrk_max_agc_gain < t->max_agc_gain) res->alltrk_max_agc_gain = t->max_agc_gain;
+      if (res->alltrk_min_agc_gain > t->min_agc_gain) res->alltrk_min_agc_gain = t->min_agc_gain; }
+   res->minbits = shortest;
+   res->maxbits = longest;
+   res->avg_bit_spacing = spacing_sum / ntrks;
+   rt_set_expected_parity(d, longest);
+   if (longest <= 10) res->blktype = RT_BS_NOISE;
+   else if (looks_like_tapemark(d->trk)) res->blktype = RT_BS_TAPEMARK;
+   else if (longest - shortest > 2) { res->blktype = RT_BS_BADBLOCK; res->track_mismatch = longest - shortest; }
    else gcr_postprocess(d); }

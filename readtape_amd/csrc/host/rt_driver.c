@@ -21,13 +21,49 @@ static void output_tap_marker(struct rt_dec *d, uint32_t num) {   /* src/readtap
       num >>= 8; }
    d->numoutbytes += 4; }
 
-void rt_tap_end(struct rt_dec *d) {   /* src/readtape.c:1885: only if the output file was ever created (:1091, lazily) */
-   if (d->opt.tap_format && d->tapf && d->numoutbytes > 0 && !d->no_tap_end) output_tap_marker(d, 0xffffffffu); }
+/* 1234567 -> "1,234,567": how the reference prints byte and sample counts (src/readtape.c:707-718) */
+static const char *commas(long long n, char buf[32]) {
+   char raw[24];
+   const int len = snprintf(raw, sizeof raw, "%lld", n);
+   int o = 0;
+   for (int i = 0; i < len; ++i) { buf[o++] = raw[i]; if ((len - 1 - i) % 3 == 0 && i != len - 1) buf[o++] = ','; }
+   buf[o] = 0;
+   return buf; }
+
+/* ---- output files (src/readtape.c:1084-1111).  Two ways to use the writers: the caller opens d->tapf itself (one .tap, nothing
+ * logged about it), or it sets d->outbase and the files are made here, by the reference's names and with its log lines ---- */
+void rt_close_output(struct rt_dec *d) {
+   if (!d->tapf) return;
+   fclose(d->tapf);
+   d->tapf = NULL;
+   if (!d->outbase[0]) return;
+   char cb[32];
+   rlog(d, "%s was closed at time %.8lf after %s data bytes were extracted from %d blocks\n", d->outname, d->timenow, commas(d->numfilebytes, cb), d->numfileblks); }
+
+static void open_output(struct rt_dec *d) {
+   if (!d->outbase[0]) return;
+   if (d->tapf) rt_close_output(d);
+   if (d->opt.tap_format) snprintf(d->outname, sizeof d->outname, "%s.tap", d->outbase);
+   else snprintf(d->outname, sizeof d->outname, "%s.%03d.bin", d->outbase, d->numfiles + 1);
+   rlog(d, "creating file \"%s\"\n", d->outname);
+   d->tapf = fopen(d->outname, "wb");
+   ++d->numfiles;
+   d->numfilebytes = 0;
+   d->numfileblks = 0;
+   if (d->data_start_time == 0) d->data_start_time = d->timenow; }
+
+void rt_tap_end(struct rt_dec *d) {   /* src/readtape.c:1885-1887: the end-of-medium marker only if the file was ever created */
+   const int created = d->outbase[0] ? d->tapf != NULL : (d->tapf && d->numoutbytes > 0);
+   if (d->opt.tap_format && created && !d->no_tap_end) output_tap_marker(d, 0xffffffffu);
+   if (d->outbase[0]) rt_close_output(d); }
 
 void rt_got_tapemark(struct rt_dec *d) {   /* src/readtape.c:1160-1176 */
    ++d->numtapemarks;
    rlog(d, "  tapemark at time %.8lf, tap offset %lld, %d blocks written so far\n", d->timenow, d->numoutbytes, d->numblks);
-   if (d->opt.tap_format) output_tap_marker(d, 0x00000000); }
+   if (d->opt.tap_format) {
+      if (!d->tapf) open_output(d);
+      output_tap_marker(d, 0x00000000); }
+   else rt_close_output(d); }                 /* plain data files: a tapemark ends the file (no label processing here) */
 
 static const char *format_block_errors(struct rt_dec *d, struct rt_results *result, char *buf) {   /* src/readtape.c:1179-1209 */
    char *p = buf;
@@ -66,6 +102,8 @@ void rt_got_datablock(struct rt_dec *d, int badblock) {   /* src/readtape.c:1212
          rlog(d, ", %d tries, parmset %d, at time %.8lf\n", d->tries, d->parmset, d->timenow); }
       else {
          uint32_t errflag = result->errcount ? 0x80000000u : 0;
+         d->last_block_time = d->timenow;
+         if (!d->tapf) open_output(d);
          if (d->opt.tap_format) output_tap_marker(d, (uint32_t)length | errflag);
          for (int i = 0; i < length; ++i) {
             unsigned char b = (unsigned char)(d->data[i] >> 1);
@@ -93,88 +131,119 @@ void rt_got_datablock(struct rt_dec *d, int badblock) {   /* src/readtape.c:1212
             rlog(d, "   WARNING: %d bits were before the midbit using parmset %d for block %d at %.8lf\n",
                  result->missed_midbits, d->parmset, d->numblks + 1, d->timenow); }
          if (result->corrected_bits > 0) ++d->numblks_corrected;
+         d->numfilebytes += length;
          d->numoutbytes += length;
          d->numdatabytes += length;
+         ++d->numfileblks;
          ++d->numblks; } } }
 
-int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit) {   /* src/readtape.c:1719-1889 */
-   int ok = 1;
-   int endfile = 0;
+/* the end-of-run report (src/readtape.c:2021-2044) */
+void rt_write_summary(struct rt_dec *d, const char *infilename, double elapsed) {
+   char cb[32];
+   rlog(d, "\n");
+   rlog(d, "summary for file \"%s\":\n", infilename);
+   rlog(d, "  %s samples were processed in %.0lf seconds (%.3lf seconds/block)\n", commas(d->lines_in, cb), elapsed, d->numblks == 0 ? 0 : elapsed / d->numblks);
+   rlog(d, "  created %d output file%s with a total of %s bytes\n", d->numfiles, d->numfiles != 1 ? "s" : "", commas(d->numoutbytes, cb));
+   rlog(d, "  decoded %d tape marks and %d blocks with %s bytes from %.2lf seconds of tape data\n",
+        d->numtapemarks, d->numblks, commas(d->numdatabytes, cb), d->timenow - d->data_start_time);
+   if (d->last_block_time) rlog(d, "  the last block written was %.8lf seconds into the tape\n", d->last_block_time);
+   rlog(d, "  %d block%s had errors, %d had warnings", d->numblks_err, d->numblks_err != 1 ? "s" : "", d->numblks_warn);
+   rlog(d, ", %d had mismatched tracks, %d had bits corrected", d->numblks_trksmismatched, d->numblks_corrected);
+   if (d->opt.mode == RT_NRZI) rlog(d, ", %d had midbit timing errors", d->numblks_midbiterrs);
+   rlog(d, "\n");
+   if (d->numblks_unusable > 0) rlog(d, "  %d blocks were unusable and were not written\n", d->numblks_unusable);
+   if (!d->opt.multiple_tries) return;
+   rlog(d, "  %d good blocks had to try more than one parmset\n", d->numblks_goodmultiple);
+   for (int i = 0; i < RT_MAXPARMSETS; ++i)
+      if (d->parmsets[i].tried > 0)
+         rlog(d, "  parmset %d was tried %4d times and used %4d times, or %5.1f%%\n", i, d->parmsets[i].tried, d->parmsets[i].chosen,
+              100. * d->parmsets[i].chosen / d->parmsets[i].tried); }
+
+/* ---- one block, possibly many attempts (src/readtape.c:1720-1882) ----
+ * An attempt is FINAL when nothing could improve on it: a tapemark, noise (the reference skips noise at once, SKIP_NOISE), or
+ * a block without errors or warnings.  Otherwise, with -m, the next parameter set that has not been tried on this block gets
+ * its turn; when none is left the attempts are RANKED and the best one is (if it was not the last one run) decoded again so
+ * that the bit matrix holds its data. */
+static int attempt_is_final(const struct rt_results *a) {
+   return a->blktype == RT_BS_TAPEMARK || a->blktype == RT_BS_NOISE
+          || (a->blktype == RT_BS_BLOCK && a->errcount == 0 && a->warncount == 0); }
+
+/* the parameter set to try next: the first active, untried one behind the current one (cyclically), or -1 */
+static int untried_parmset(const struct rt_dec *d) {
+   for (int step = 1; step < RT_MAXPARMSETS; ++step) {
+      const int p = (d->parmset + step) % RT_MAXPARMSETS;
+      if (d->parmsets[p].active != 0 && d->results[p].blktype == RT_BS_NONE) return p; }
+   return -1; }
+
+/* rank of an attempt among the imperfect ones, smaller is better (src/readtape.c:1805-1845): error-free blocks by their
+ * warnings, then blocks by their errors, then ragged blocks by their raggedness, then noise; the earlier parameter set wins
+ * a tie.  Returns 0 for an attempt that cannot be chosen. */
+static int attempt_rank(const struct rt_results *a, int *tier, int *badness) {
+   switch (a->blktype) {
+   case RT_BS_BLOCK:    *tier = a->errcount == 0 ? 0 : 1; *badness = a->errcount == 0 ? a->warncount : a->errcount; return 1;
+   case RT_BS_BADBLOCK: *tier = 2; *badness = a->track_mismatch; return 1;
+   case RT_BS_NOISE:    *tier = 3; *badness = 0; return 1;
+   default: return 0; } }
+
+static int best_attempt(const struct rt_dec *d, int *tier_out) {
+   int best = -1, best_tier = INT_MAX, best_badness = INT_MAX;
+   for (int p = 0; p < RT_MAXPARMSETS; ++p) {
+      int tier, badness;
+      if (!attempt_rank(&d->results[p], &tier, &badness)) continue;
+      if (badness == INT_MAX) continue;                         /* (the reference's "< INT_MAX" searches cannot pick such a value either) */
+      if (tier < best_tier || (tier == best_tier && badness < best_badness)) { best = p; best_tier = tier; best_badness = badness; } }
+   *tier_out = best_tier;
+   return best; }
+
+int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit) {
+   int all_clean = 1, out_of_data = 0;
    d->interblock_counter = 0;
-   while (!endfile && d->numblks < blklimit) {
+   while (!out_of_data && d->numblks < blklimit) {
       rt_init_blockstate(d);
       d->parmset = 0;
-      r->save_pos(r->ctx);
-      int keep_trying, last_parmset;
       d->tries = 0;
-      do {
-         keep_trying = 0;
-         last_parmset = d->parmset;
+      r->save_pos(r->ctx);
+      int decoded_last, final = 0;
+      for (;;) {                                                  /* attempts */
+         decoded_last = d->parmset;
          rt_init_trackstate(d);
-         endfile = !r->readblock(r->ctx, d->tries > 0);
-         struct rt_results *result = &d->results[d->parmset];
-         if (result->blktype == RT_BS_NONE) goto endfile;
+         out_of_data = !r->readblock(r->ctx, d->tries > 0);
+         const struct rt_results *a = &d->results[d->parmset];
+         if (a->blktype == RT_BS_NONE) { rt_tap_end(d); return all_clean; }      /* what was left of the data was no block */
          ++d->tries;
          ++RT_PARM(d).tried;
-         if (result->blktype == RT_BS_TAPEMARK) goto done;
-         if (result->blktype == RT_BS_NOISE) goto done;                 /* SKIP_NOISE, src/decoder.h:146 */
-         if (result->blktype == RT_BS_BLOCK && result->errcount == 0 && result->warncount == 0) {
-            if (d->tries > 1) ++d->numblks_goodmultiple;
-            goto done; }
-         if (d->opt.multiple_tries && (d->opt.mode != RT_PE || result->minbits != 0)) {
-            int next_parmset = d->parmset;
-            do { if (++next_parmset >= RT_MAXPARMSETS) next_parmset = 0; }
-            while (next_parmset != d->parmset &&
-                   (d->parmsets[next_parmset].active == 0 || d->results[next_parmset].blktype != RT_BS_NONE));
-            if (next_parmset != d->parmset) {
-               keep_trying = 1;
-               d->parmset = next_parmset;
-               r->restore_pos(r->ctx);
-               d->interblock_counter = 0; } } }
-      while (keep_trying);
-
-      if (d->tries == 1) {
-         if (d->results[d->parmset].errcount > 0) ok = 0; }
-      else {
-         int min_warnings = INT_MAX;
-         for (int i = 0; i < RT_MAXPARMSETS; ++i) {
-            struct rt_results *res = &d->results[i];
-            if (res->blktype == RT_BS_BLOCK && res->errcount == 0 && res->warncount < min_warnings) {
-               min_warnings = res->warncount; d->parmset = i; } }
-         if (min_warnings < INT_MAX) goto done;
-         ok = 0;
-         int min_errors = INT_MAX;
-         for (int i = 0; i < RT_MAXPARMSETS; ++i) {
-            struct rt_results *res = &d->results[i];
-            if (res->blktype == RT_BS_BLOCK && res->errcount < min_errors) {
-               min_errors = res->errcount; d->parmset = i; } }
-         if (min_errors < INT_MAX) goto done;
-         int min_track_diff = INT_MAX;
-         for (int i = 0; i < RT_MAXPARMSETS; ++i) {
-            struct rt_results *res = &d->results[i];
-            if (res->blktype == RT_BS_BADBLOCK && res->track_mismatch < min_track_diff) {
-               min_track_diff = res->track_mismatch; d->parmset = i; } }
-         if (min_track_diff < INT_MAX) goto done;
-         for (int i = 0; i < RT_MAXPARMSETS; ++i)
-            if (d->results[i].blktype == RT_BS_NOISE) { d->parmset = i; goto done; }
-         return 0; }
-done:;
-      struct rt_results *result = &d->results[d->parmset];
-      if (result->blktype != RT_BS_NOISE) {
-         ++RT_PARM(d).chosen;
-         if (d->tries > 1 && last_parmset != d->parmset) {
-            r->restore_pos(r->ctx);
-            d->interblock_counter = 0;
-            rt_init_trackstate(d);
-            endfile = !r->readblock(r->ctx, 1); }
-         switch (d->results[d->parmset].blktype) {
-         case RT_BS_TAPEMARK: rt_got_tapemark(d); break;
-         case RT_BS_BLOCK:    rt_got_datablock(d, 0); break;
-         case RT_BS_BADBLOCK: rt_got_datablock(d, 1); break;
-         default: return 0; } } }
-endfile:
+         if (attempt_is_final(a)) {
+            final = 1;
+            if (a->blktype == RT_BS_BLOCK && d->tries > 1) ++d->numblks_goodmultiple;
+            break; }
+         /* (a PE attempt with a dead track was most likely noise: no second opinion) */
+         const int next = d->opt.multiple_tries && (d->opt.mode != RT_PE || a->minbits != 0) ? untried_parmset(d) : -1;
+         if (next < 0) break;
+         d->parmset = next;
+         r->restore_pos(r->ctx);
+         d->interblock_counter = 0; }
+      if (!final) {
+         if (d->tries == 1) { if (d->results[d->parmset].errcount > 0) all_clean = 0; }
+         else {
+            int tier;
+            const int pick = best_attempt(d, &tier);
+            if (tier > 0) all_clean = 0;
+            if (pick < 0) return 0;                                /* ("block state error in process_file()") */
+            d->parmset = pick; } }
+      if (d->results[d->parmset].blktype == RT_BS_NOISE) continue;
+      ++RT_PARM(d).chosen;
+      if (d->tries > 1 && decoded_last != d->parmset) {           /* the bit matrix holds another attempt's data */
+         r->restore_pos(r->ctx);
+         d->interblock_counter = 0;
+         rt_init_trackstate(d);
+         out_of_data = !r->readblock(r->ctx, 1); }
+      switch (d->results[d->parmset].blktype) {
+      case RT_BS_TAPEMARK: rt_got_tapemark(d); break;
+      case RT_BS_BLOCK:    rt_got_datablock(d, 0); break;
+      case RT_BS_BADBLOCK: rt_got_datablock(d, 1); break;
+      default: return 0; } }
    rt_tap_end(d);
-   return ok; }
+   return all_clean; }
 
 /* ---- -deskew pre-pass (src/readtape.c:1675-1717 + skew_compute_deskew / skew_set_delay, src/decoder.c:235-281) ---- */
 int rt_deskew_prepass(struct rt_dec *d, struct rt_reader *r, int delays[RT_MAXTRKS], int *hit_end) {
@@ -218,10 +287,6 @@ int rt_deskew_prepass(struct rt_dec *d, struct rt_reader *r, int delays[RT_MAXTR
    return nblks; }
 
 /* ---- density detection (src/readtape.c:1656-1672 + estden_setdensity, src/decoder.c:374-399) ---- */
-static const char *with_commas(int n, char *buf) {             /* 12345 -> "12,345", as the reference's log prints counts */
-   char raw[16]; int len = snprintf(raw, sizeof raw, "%d", n), o = 0;
-   for (int i = 0; i < len; ++i) { buf[o++] = raw[i]; if ((len - 1 - i) % 3 == 0 && i != len - 1) buf[o++] = ','; }
-   buf[o] = 0; return buf; }
 float rt_density_prepass(struct rt_dec *d, struct rt_reader *r, float *implied, int *nblks, int *hit_end) {
    *nblks = 0; *hit_end = 0; *implied = 0;
    d->doing_density_detection = 1;
@@ -252,8 +317,8 @@ float rt_density_prepass(struct rt_dec *d, struct rt_reader *r, float *implied, 
       if (diff < 0) diff = -diff;
       if (diff < standard[i] * 20 / 100) {                     /* ESTDEN_CLOSEPERCENT */
          d->opt.bpi = standard[i];
-         char cb[24];
+         char cb[32];
          rlog(d, "  density was set to %.0f BPI (%.2f usec/bit) after reading the first %d blocks and seeing %s transitions in %d bins that imply %.0f BPI\n",
-              d->opt.bpi, 1e6 / (d->opt.bpi * d->opt.ips), *nblks, with_commas(d->estden.totalcount, cb), d->estden.binsused, density);
+              d->opt.bpi, 1e6 / (d->opt.bpi * d->opt.ips), *nblks, commas(d->estden.totalcount, cb), d->estden.binsused, density);
          return d->opt.bpi; } }
    return 0; }

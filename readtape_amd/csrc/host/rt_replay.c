@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 static double time_of_row(const struct rt_replay *rp, int64_t row) {        /* src/readtape.c:1423 */
@@ -158,7 +159,7 @@ static void dump_attempt(struct rt_dec *d, void *user) {
    r.kind = 2; r.parmset = d->parmset; r.timenow_ns = rp->tstart_ns + rp->pos * rp->tdelta_ns;
    fwrite(&r, sizeof r, 1, rp->evtf); }
 
-int rt_replay_readblock(void *ctx, int retry) {
+static int readblock_once(void *ctx, int retry) {
    struct rt_replay *rp = (struct rt_replay *)ctx;
    struct rt_dec *d = rp->d;
    const int ntrks = rp->ntrks, parmset = d->parmset;
@@ -290,6 +291,14 @@ restart:
    rt_finish_attempt(d);
    return !endfile; }
 
+int rt_replay_readblock(void *ctx, int retry) {
+   struct rt_replay *rp = (struct rt_replay *)ctx;
+   const int64_t from = rp->pos;
+   const int more = readblock_once(ctx, retry);
+   /* src/readtape.c:1404 counts every pass of the read loop of a first attempt, the one that finds the end marker included */
+   if (!retry) rp->d->lines_in += (rp->pos - from) + (more ? 0 : 1);
+   return more; }
+
 /* prepass != NULL: run the -deskew pre-pass instead of the decode (no .tap); append: keep what is already in the log
  * and event-dump files (the decode that follows a pre-pass continues both, as the reference's single run does) */
 struct deskew_out { int *delays; int *nblks; int *hit_end; float *bpi, *implied; };
@@ -298,7 +307,8 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
-                  int append, struct deskew_out *prepass, int64_t start_row, int64_t stop_row, int fragment) {
+                  int append, struct deskew_out *prepass, int64_t start_row, int64_t stop_row, int fragment,
+                  const char *out_base, const char *in_name) {
    const float sample_deltat = (float)tdelta_ns / 1e9f;              /* src/readtape.c:1345 */
    struct rt_dec *d = rt_dec_new(opt, sample_deltat, tdelta_ns);
    if (!d) return -1;
@@ -306,8 +316,10 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
       memset(d->parmsets, 0, sizeof d->parmsets);
       memcpy(d->parmsets, parmsets, sizeof(struct rt_parms) * (size_t)nparm); }
    else for (int i = nparm; i < RT_MAXPARMSETS; ++i) d->parmsets[i].active = 0;   /* only the scanned sets are usable */
-   if (tap_path) d->tapf = fopen(tap_path, "wb");
+   if (out_base) snprintf(d->outbase, sizeof d->outbase, "%s", out_base);      /* files by the reference's names, made when first needed */
+   else if (tap_path) d->tapf = fopen(tap_path, "wb");
    if (log_path) d->logf = fopen(log_path, append ? "a" : "w");
+   const double wall0 = (double)time(NULL);
    struct rt_replay rp; memset(&rp, 0, sizeof rp);
    rp.d = d; rp.ntrks = opt->ntrks; rp.nparm = nparm;
    for (int i = 0; i < nparm; ++i) rp.W[i] = W[i];
@@ -327,6 +339,7 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
    if (prepass && prepass->bpi) *prepass->bpi = rt_density_prepass(d, &rd, prepass->implied, prepass->nblks, prepass->hit_end);
    else if (prepass) *prepass->nblks = rt_deskew_prepass(d, &rd, prepass->delays, prepass->hit_end);
    else ok = rt_process_blocks(d, &rd, 0x7fffffff);
+   if (in_name && !prepass) rt_write_summary(d, in_name, difftime(time(NULL), (time_t)wall0));
    if (stats) {
       stats->attempts = rp.attempts; stats->exact_scans = rp.exact_scans; stats->chained = rp.chained;
       stats->events_delivered = rp.events_delivered; stats->agc_mismatches = rp.agc_mismatches;
@@ -346,7 +359,7 @@ int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets,
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
-                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 0, NULL, 0, INT64_MAX, 0); }
+                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 0, NULL, 0, INT64_MAX, 0, NULL, NULL); }
 
 /* One fragment of a tape (a time shard, or one window of a streamed file): rows are relative to the fragment's first row
  * (row_base = its absolute index; the bursts carry absolute rows).  The decode starts at start_row (0, or the start of the zone
@@ -360,7 +373,7 @@ int rt_replay_run_fragment(const struct rt_options *opt, const struct rt_parms *
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
                   int64_t start_row, int64_t stop_row) {
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
-                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 0, NULL, start_row, stop_row, 1); }
+                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 0, NULL, start_row, stop_row, 1, NULL, NULL); }
 
 int rt_replay_run_after_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
@@ -368,7 +381,7 @@ int rt_replay_run_after_deskew(const struct rt_options *opt, const struct rt_par
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
-                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 1, NULL, 0, INT64_MAX, 0); }
+                     exact, exact_free, user, tap_path, log_path, evt_path, stats, 1, NULL, 0, INT64_MAX, 0, NULL, NULL); }
 
 int rt_replay_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
@@ -377,7 +390,7 @@ int rt_replay_deskew(const struct rt_options *opt, const struct rt_parms *parmse
                   const char *log_path, const char *evt_path, int append, int *delays, int *nblks, int *hit_end) {
    struct deskew_out o = { delays, nblks, hit_end, NULL, NULL };
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
-                     exact, exact_free, user, NULL, log_path, evt_path, NULL, append, &o, 0, INT64_MAX, 0); }
+                     exact, exact_free, user, NULL, log_path, evt_path, NULL, append, &o, 0, INT64_MAX, 0, NULL, NULL); }
 
 
 int rt_replay_density(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
@@ -387,4 +400,14 @@ int rt_replay_density(const struct rt_options *opt, const struct rt_parms *parms
                   const char *log_path, const char *evt_path, float *bpi, float *implied, int *nblks, int *hit_end) {
    struct deskew_out o = { NULL, nblks, hit_end, bpi, implied };
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
-                     exact, exact_free, user, NULL, log_path, evt_path, NULL, 0, &o, 0, INT64_MAX, 0); }
+                     exact, exact_free, user, NULL, log_path, evt_path, NULL, 0, &o, 0, INT64_MAX, 0, NULL, NULL); }
+
+/* ... with the output files made by name as the reference makes them (<out_base>.tap with opt->tap_format, else the numbered
+ * <out_base>.NNN.bin files, src/readtape.c:1091-1111) and the end-of-run summary (src/readtape.c:2021-2044) in the log */
+int rt_replay_run_named(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *out_base, const char *in_name, const char *log_path, const char *evt_path, int append, struct rt_replay_stats *stats) {
+   return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
+                     exact, exact_free, user, NULL, log_path, evt_path, stats, append, NULL, 0, INT64_MAX, 0, out_base, in_name); }

@@ -77,6 +77,11 @@ int rt_replay_run_fragment(const struct rt_options *opt, const struct rt_parms *
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
                   int64_t start_row, int64_t stop_row);
+int rt_replay_run_named(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  const char *out_base, const char *in_name, const char *log_path, const char *evt_path, int append, struct rt_replay_stats *stats);
 int rt_replay_run_after_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,

@@ -55,6 +55,7 @@ def _load_decode_lib():
                                   C.POINTER(C.c_int), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _EXACT_FN, _FREE_FN, C.c_void_p,
                                   C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
     lib.rt_replay_run_after_deskew.argtypes = lib.rt_replay_run.argtypes
+    lib.rt_replay_run_named.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_Stats)]
     lib.rt_replay_run_fragment.argtypes = lib.rt_replay_run.argtypes + [C.c_int64, C.c_int64]
     lib.rt_replay_deskew.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.rt_replay_density.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -212,9 +213,13 @@ class ReferenceFatal(RuntimeError):
 
 def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
                 skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None, differentiate=False,
-                subsample: int = 1, deskew: bool = False, deskew_prefix_rows: int = 1 << 22, trkorder: str | None = None):
+                subsample: int = 1, deskew: bool = False, deskew_prefix_rows: int = 1 << 22, trkorder: str | None = None,
+                out_base: str | None = None, in_name: str | None = None, tap_format: bool = True):
     """Decodes one tape; returns (stats dict, ScanResult).  `fe_factory(cfg)` builds the front end
-    (default: the GPU one; tests/cpu_emul passes the emulated library)."""
+    (default: the GPU one; tests/cpu_emul passes the emulated library).
+    Output: tap_path = one SIMH .tap file; or out_base = the reference's own naming - <out_base>.tap, or with tap_format=False
+    the numbered <out_base>.NNN.bin data files, one per tape file (src/readtape.c:1091-1111) - with the files' creation/closing
+    and the end-of-run summary (src/readtape.c:2021-2044; in_name = the input's name in it) in the log."""
     opts = opts or DecodeOptions()
     lib = _load_decode_lib()
     if trkorder:                                                           # -order= wins over the header's TBINORD extension (src/readtape.c:1346-1355)
@@ -262,7 +267,7 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
 
     o = _Options(mode=mode, ntrks=hdr.ntrks, bpi=cfg.bpi, ips=cfg.ips, specified_parity=0 if opts.even_parity else 1,
                  revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=int(find_zeros), do_differentiate=int(differentiate),
-                 multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
+                 multiple_tries=int(opts.multiple_tries), tap_format=int(tap_format), add_parity=0, verbose=int(opts.verbose))
     parr = (_Parms * len(full))(*full)
     W = (C.c_int * len(full))(*fe.widths)
     exact, free, keep = _exact_callbacks(fe, rows, hdr.ntrks, fe_factory)
@@ -271,12 +276,18 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     bursts = np.ascontiguousarray(res.bursts)
     counts = np.ascontiguousarray(res.counts)
     events = res._events
-    run = lib.rt_replay_run_after_deskew if (calibrated or detected) else lib.rt_replay_run      # (continues the pre-passes' log / event dump)
-    rc = run(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, nrows, 0, W,
-                           bursts.ctypes.data, len(bursts), counts.ctypes.data, events.ctypes.data,
-                           exact, free, None,
-                           tap_path.encode() if tap_path else None, log_path.encode() if log_path else None,
-                           evt_path.encode() if evt_path else None, C.byref(st))
+    if out_base:
+        rc = lib.rt_replay_run_named(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, nrows, 0, W,
+                                     bursts.ctypes.data, len(bursts), counts.ctypes.data, events.ctypes.data, exact, free, None,
+                                     out_base.encode(), (in_name or out_base + ".tbin").encode(), log_path.encode() if log_path else None,
+                                     evt_path.encode() if evt_path else None, int(calibrated or detected), C.byref(st))
+    else:
+        run = lib.rt_replay_run_after_deskew if (calibrated or detected) else lib.rt_replay_run      # (continues the pre-passes' log / event dump)
+        rc = run(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, nrows, 0, W,
+                 bursts.ctypes.data, len(bursts), counts.ctypes.data, events.ctypes.data,
+                 exact, free, None,
+                 tap_path.encode() if tap_path else None, log_path.encode() if log_path else None,
+                 evt_path.encode() if evt_path else None, C.byref(st))
     if rc != 0:
         raise RuntimeError("rt_replay_run failed")
     stats = {k: getattr(st, k) for k, _ in _Stats._fields_}

@@ -24,9 +24,56 @@ REF = os.path.join(ROOT, "oracle", "_ref", "readtape_evt")
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+# Output files and the end-of-run report (src/readtape.c:1084-1111, 2021-2044): name -> (tape of this case, reference options).
+# Without -tap the reference writes numbered .bin files, one per tape file.
+def _three_files():
+    from readtape_amd import synth
+    return synth.nrzi_tape(seed=21, nblocks=5, minlen=40, maxlen=90, marks_every=2, gap_samples=1500)
+
+
+FILE_CASES = {
+    "files_nrzi9_bin": (_three_files, ["-v", "-nolabels", "-nm"]),           # blocks, mark, blocks, mark, block: three .bin files
+    "files_nrzi9_tap": (_three_files, ["-nolabels", "-nm", "-tap"]),        # (no -v: only the first block is logged)
+    "files_nrzi7_bin": (CASES["nrzi7"][0], ["-v", "-nolabels", "-nm"]),
+    "files_pe_m_tap": (CASES["pe_m"][0], ["-v", "-nolabels", "-tap", "-m"]),
+    "files_gcr_bin": (CASES["gcr"][0], ["-nolabels", "-nm"]),
+}
+
+
+def report_lines(text):
+    """The lines of the reference's log that are about its output files and its summary."""
+    keep = []
+    for l in text.splitlines():
+        if (l.startswith('creating file "') or " was closed at time " in l or l.startswith("summary for file") or " samples were processed in " in l
+                or (l.startswith("  created ") and "output file" in l) or l.startswith("  decoded ") or l.startswith("  the last block written")
+                or " had errors, " in l or "blocks were unusable" in l or "good blocks had to try" in l or (l.startswith("  parmset ") and "was tried" in l)):
+            keep.append(l.rstrip())
+    return keep
+
+
+def make_file_cases(only):
+    for name, (build, opts) in sorted(FILE_CASES.items()):
+        if only and name not in only:
+            continue
+        tape = build()
+        sp = tape.spec
+        with tempfile.TemporaryDirectory() as wd:
+            tape.write(os.path.join(wd, "t.tbin"))
+            p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "readtape_ref")] + opts + ["t"], cwd=wd, capture_output=True, text=True)
+            outs = sorted(f for f in os.listdir(wd) if f.endswith(".bin") or f.endswith(".tap"))
+            blobs = {f"file{i}": np.frombuffer(open(os.path.join(wd, f), "rb").read(), dtype=np.uint8) for i, f in enumerate(outs)}
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), rows=tape.rows, hdr=np.array([sp.ntrks, sp.tdelta_ns, sp.mode, sp.tstart_ns, sp.flags], dtype=np.int64),
+                            hdrf=np.array([sp.maxvolts, sp.bpi, sp.ips], dtype=np.float32), trkorder=np.array(sp.trkorder), ref_opts=np.array(opts), names=np.array(outs), report=np.array(report_lines(p.stdout)),
+                            returncode=p.returncode, **blobs)
+        print(f"{name}: {outs}, {len(report_lines(p.stdout))} report lines, rc {p.returncode}")
+
+
 def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
     os.makedirs(OUT, exist_ok=True)
+    make_file_cases(set(a for a in sys.argv[1:] if a.startswith("files_")) if sys.argv[1:] else set())
+    if sys.argv[1:] and all(a.startswith("files_") for a in sys.argv[1:]):
+        return
     tapes = {}
     only = set(sys.argv[1:])
     for name in sorted(CASES):

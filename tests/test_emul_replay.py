@@ -146,3 +146,20 @@ def test_fragments_concatenate_to_the_whole_tap(name, nshards, tmp_path):
     else:
         assert got == g["tap"], (len(got), len(g["tap"]))
     assert sum(s["blocks"] + s["tapemarks"] for s in sts) > 0
+
+
+@pytest.mark.parametrize("name", ["files_nrzi9_bin", "files_nrzi9_tap", "files_nrzi7_bin", "files_pe_m_tap", "files_gcr_bin"])
+def test_output_files_and_summary_match_the_reference(name, tmp_path, monkeypatch):
+    """f3: the numbered .bin files (a new one behind every tapemark, src/readtape.c:1091-1111), the lazily created .tap, and the log
+    lines about them + the end-of-run summary incl. the "samples were processed" count (src/readtape.c:2021-2044)."""
+    from golden_util import load_files_case, report_lines
+    g = load_files_case(name)
+    o = g["ref_opts"]
+    monkeypatch.chdir(tmp_path)
+    opts = pipeline.DecodeOptions(multiple_tries="-m" in o, verbose="-v" in o)
+    pipeline.decode_tape(g["hdr"], g["rows"], None, log_path="t.log", opts=opts, fe_factory=emul_frontend, out_base="t", in_name="t.tbin", tap_format="-tap" in o)
+    made = sorted(f for f in os.listdir(".") if f.endswith(".bin") or f.endswith(".tap"))
+    assert made == sorted(g["files"])
+    for f in made:
+        assert open(f, "rb").read() == g["files"][f], f
+    assert report_lines(open("t.log").read()) == g["report"]

@@ -384,3 +384,21 @@ def test_config_c4_gcr_eight_parmset_sweep_at_scale(tmp_path, gpu):
         fe1 = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr, parmsets=[sets[p]]))
         msgs, stats = check_tape(fe1, hdr, base.rows, att)
         assert not msgs, "\n".join(msgs[:8])
+
+
+@pytest.mark.parametrize("name", ["files_nrzi9_bin", "files_nrzi9_tap", "files_nrzi7_bin", "files_pe_m_tap", "files_gcr_bin"])
+def test_output_files_and_summary_match_the_reference(name, tmp_path, monkeypatch, gpu):
+    """The numbered .bin files / the lazily created .tap and the end-of-run report (src/readtape.c:1091-1111, 2021-2044)."""
+    import os
+    from golden_util import load_files_case, report_lines
+    from readtape_amd import pipeline
+    g = load_files_case(name)
+    o = g["ref_opts"]
+    monkeypatch.chdir(tmp_path)
+    opts = pipeline.DecodeOptions(multiple_tries="-m" in o, verbose="-v" in o)
+    pipeline.decode_tape(g["hdr"], g["rows"], None, log_path="t.log", opts=opts, out_base="t", in_name="t.tbin", tap_format="-tap" in o)
+    made = sorted(f for f in os.listdir(".") if f.endswith(".bin") or f.endswith(".tap"))
+    assert made == sorted(g["files"])
+    for f in made:
+        assert open(f, "rb").read() == g["files"][f], f
+    assert report_lines(open("t.log").read()) == g["report"]
