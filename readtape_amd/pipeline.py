@@ -124,7 +124,15 @@ def _exact_callbacks(fe, rows, ntrks, fe_factory=None):
     def free(user, ptr):
         keep.pop(ptr, None)
 
+    keep["__big__"] = big
     return _EXACT_FN(exact), _FREE_FN(free), keep
+
+
+def _release(keep):
+    """Ends what the exact-scan callbacks built on demand (the worst-case front end holds device buffers)."""
+    for b in keep.pop("__big__", []):
+        b.close()
+    keep.clear()
 
 
 def calibrate_deskew(hdr, rows, full, o, fe_factory, invert=False, find_zeros=False, differentiate=False,
@@ -153,6 +161,7 @@ def calibrate_deskew(hdr, rows, full, o, fe_factory, invert=False, find_zeros=Fa
                                   bursts.ctypes.data, len(bursts), counts.ctypes.data, res._events.ctypes.data,
                                   exact, free, None, log_path.encode() if log_path else None,
                                   evt_path.encode() if evt_path else None, int(append), delays, C.byref(nblks), C.byref(hit_end))
+        _release(keep)
         if rc != 0:
             raise RuntimeError("rt_replay_deskew failed")
         if hit_end.value and n0 < nrows:
@@ -191,6 +200,7 @@ def detect_density(hdr, rows, full, o, fe_factory, invert=False, log_path=None, 
                                    bursts.ctypes.data, len(bursts), counts.ctypes.data, res._events.ctypes.data,
                                    exact, free, None, log_path.encode() if log_path else None,
                                    evt_path.encode() if evt_path else None, C.byref(bpi), C.byref(implied), C.byref(nblks), C.byref(hit_end))
+        _release(keep)
         if rc != 0:
             raise RuntimeError("rt_replay_density failed")
         if hit_end.value and n0 < nrows and bpi.value >= 0:
@@ -288,6 +298,7 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
                  exact, free, None,
                  tap_path.encode() if tap_path else None, log_path.encode() if log_path else None,
                  evt_path.encode() if evt_path else None, C.byref(st))
+    _release(keep)
     if rc != 0:
         raise RuntimeError("rt_replay_run failed")
     stats = {k: getattr(st, k) for k, _ in _Stats._fields_}
@@ -350,6 +361,7 @@ def decode_fragment(hdr, cfg, fe, res, rows_with_halo, lo, start_row, stop_row, 
                                     bursts.ctypes.data, len(bursts), counts.ctypes.data, res._events.ctypes.data, exact, free, None,
                                     tap_path.encode(), log_path.encode() if log_path else None, evt_path.encode() if evt_path else None, C.byref(st),
                                     int(start_row), I64MAX if stop_row is None else int(stop_row))
+    _release(keep)
     if rc != 0:
         raise RuntimeError("rt_replay_run_fragment failed")
     stats = {k: getattr(st, k) for k, _ in _Stats._fields_}

@@ -191,9 +191,11 @@ CASES = {
     "pe":           (case_pe,         ["-pe"],                         []),
     "pe_m":         (case_pe,         ["-pe", "-m"],                   ["-m"]),
     "pe_zeros":     (case_pe,         ["-pe", "-zeros"],               ["-zeros"]),
+    "pe_diffz":     (case_pe,         ["-pe", "-zeros", "-differentiate"], ["-zeros", "-differentiate"]),
     "gcr":          (case_gcr,        ["-gcr"],                        []),
     "gcr_m":        (case_gcr_noisy,  ["-gcr", "-m"],                  ["-m"]),
     "gcr_zeros":    (case_gcr,        ["-gcr", "-zeros"],              ["-zeros"]),
+    "gcr_diffz":    (case_gcr,        ["-gcr", "-zeros", "-differentiate"], ["-zeros", "-differentiate"]),
     "nrzi9_deskew": (case_nrzi9_skew, ["-nrzi", "-deskew"],            ["-deskew"]),
     "nrzi9_deskew_long": (case_nrzi9_skew_long, ["-nrzi", "-deskew"],  ["-deskew"]),
     "gcr_deskew":   (case_gcr_skew,   ["-gcr", "-deskew"],             ["-deskew"]),
