@@ -14,6 +14,7 @@
 
 #include "rtfe_peaks.hip"     // single translation unit: kernels + host API
 #include "rtfe_kernels.hip"
+#include "rtfe_lwalk.hip"
 #include "rtfe_chain.hip"
 
 namespace rtfe {
@@ -38,6 +39,7 @@ struct rtfe_handle {
    hipEvent_t ev0[8], ev1[8];          // start / stop of each kernel of the last scan (on the stream it ran on)
    int screen_lds_bytes;
    int walk_lds_bytes;
+   int lane_walk;                      // the record walk runs one lane per walker (k_lwalk) where that fits; RTFE_LWALK=0/1
 };
 
 static thread_local char g_err[512] = "";
@@ -275,7 +277,10 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen), hipFuncAttributeMaxDynamicSharedMemorySize, h->screen_lds_bytes);
    h->walk_lds_bytes = (int)lds_layout_walk(d).total + 64;
+   h->lane_walk = getenv("RTFE_LWALK") ? atoi(getenv("RTFE_LWALK")) != 0 : 0;      // (measured: no faster than k_walk)
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, h->walk_lds_bytes);
+   if (c->nparmsets * c->ntrks <= 32)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lwalk), hipFuncAttributeMaxDynamicSharedMemorySize, (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16);
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pk_kernel(d.screen[0].nb, 64 * ((c->ntrks + 1) / 2 + 1))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
    *out = h;
    return 0; }
@@ -488,23 +493,34 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (wpc > wlim) wpc = wlim;
       if (wpc < 1) wpc = 1;
       t0(4, st);
+      // the walkers: a lane each (k_lwalk, lists straight from HBM) when two or more work items fit a wave, else k_walk's
+      // workgroup per item.  RTFE_LWALK=0/1 overrides (tests keep both alive).
+      const bool lanes = h->lane_walk && nwalk <= 32;
+      const int lw_lds = (64 / nwalk) * h->dev.lds_units * 16;                 // the lists of one tile of every item of a wave
+      int lwpc = (160 * 1024) / (lw_lds + 6 * 1024);
+      if (lwpc < 1) lwpc = 1;
+      if (lwpc > 16) lwpc = 16;
+      auto walk = [&](int mode, bool with_segs) {
+         const SegTab *stp = with_segs ? (const SegTab *)segtabp : (const SegTab *)nullptr;
+         const int *sbp = with_segs ? (const int *)segburstp : (const int *)nullptr;
+         if (lanes)
+            hipLaunchKernelGGL(k_lwalk, dim3(h->num_cus * lwpc), dim3(64), lw_lds, st, (const DevCfg *)h->d_dev, (long long)nrows, (long long)row_base,
+                               d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
+                               mode, stp, sbp, with_segs ? segstartp : (WalkState *)nullptr, with_segs ? segendp : (WalkState *)nullptr, with_segs ? segstatp : (int *)nullptr);
+         else
+            hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
+                               d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
+                               mode, stp, sbp, with_segs ? segstartp : (WalkState *)nullptr, with_segs ? segendp : (WalkState *)nullptr, with_segs ? segstatp : (int *)nullptr); };
       if (h->dev.seg_tiles > 0 && h->dev.mode != RTFE_PE) {
          // long blocks: the walk runs as concurrent segments.  (1) every burst until its walkers have left the AGC start-up,
          // (2) cut, (3) all segments, (4) join them (or hand the burst to the pass below)
-         hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
-                            d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
-                            (int)kWalkPre, (const SegTab *)segtabp, (const int *)segburstp, segstartp, segendp, segstatp);
+         walk((int)kWalkPre, true);
          hipLaunchKernelGGL(k_segs, dim3(1), dim3(1024), 0, st, h->d_dev, (long long)nrows, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp,
                             (const WalkState *)statep, segtabp, segburstp, segstatp, max_segs_for(h, nrows));
-         hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
-                            d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
-                            (int)kWalkSegs, (const SegTab *)segtabp, (const int *)segburstp, segstartp, segendp, segstatp);
+         walk((int)kWalkSegs, true);
          hipLaunchKernelGGL(k_stitch, dim3(h->num_cus * 4), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, d_counts, d_events, ctlp,
                             statep, (const SegTab *)segtabp, (const WalkState *)segstartp, (const WalkState *)segendp, (const int *)segstatp); }
-      else
-      hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
-                         d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
-                         (int)kWalkWhole, (const SegTab *)nullptr, (const int *)nullptr, (WalkState *)nullptr, (WalkState *)nullptr, (int *)nullptr);
+      else walk((int)kWalkWhole, false);
       t1(4, st); t0(5, st);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,

@@ -765,12 +765,31 @@ struct ZcLane { ZcState start, end; int count; unsigned int ev[kZcMaxEv][2]; }; 
 __device__ __forceinline__ bool zc_same(const ZcState &a, const ZcState &b) {
    return a.prev == b.prev && a.top == b.top && a.bot == b.bot && a.up == b.up && a.dn == b.dn
        && (!a.up || a.ttop == b.ttop) && (!a.dn || a.tbot == b.tbot); }       // (the crossing rows are only read while pending)
+// the own rows of sub-segment j from state z: events into the lane's record, the end state
+__device__ __forceinline__ void zc_own_rows(ZcLane &me, ZcState z, const Col &yb, long long row0, int j, int P) {
+   int cnt = 0;
+   #pragma nounroll
+   for (int q = j * kZcSub; q < (j + 1) * kZcSub; q += 8) {
+      int v8[8];
+      #pragma unroll
+      for (int k = 0; k < 8; ++k) v8[k] = yb[q + k];
+      #pragma unroll
+      for (int k = 0; k < 8; ++k) {
+         const long long n = row0 + q + k;
+         const int v = v8[k];
+         bool up = false; long long cross = 0;
+         if (zc_row(z, v, n, P, up, cross)) {
+            if (cnt < kZcMaxEv && (unsigned long long)(n - cross) < 0x80000000ull) {
+               me.ev[cnt][0] = (unsigned)(q + k) | ((unsigned)(v & 0xffff) << 16); me.ev[cnt][1] = (unsigned)(n - cross) | (up ? 0x80000000u : 0u); ++cnt; }
+            else cnt = kZcMaxEv + 1; } } }
+   me.end = z; me.count = cnt; }
+
 __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, ZcLane *lanes, int *ok, long long stop) {
    const DevCfg *cfg = cx.cfg;
    const Tile &tl = cx.tile;
    const int ntrks = cfg->ntrks, nsub = tl.nrows / kZcSub;
    const int P = cfg->zc_peak_i;
-   const int L = threadIdx.x, trk = L / nsub, j = L - trk * nsub;
+   const int L = threadIdx.x, trk = L / (nsub > 0 ? nsub : 1), j = L - trk * nsub;
    const bool mine = L < ntrks * nsub;
    if (L < ntrks) {                                                  // a whole tile in the regular regime?
       const Walker &w = walkers[L];
@@ -794,29 +813,30 @@ __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, Zc
             #pragma unroll
             for (int k = 0; k < 8; ++k) { bool up; long long cross; (void)zc_row(z, v8[k], tl.row0 + q + k, P, up, cross); } } }
       me.start = z;
-      int cnt = 0;
-      #pragma nounroll
-      for (int q = j * kZcSub; q < (j + 1) * kZcSub; q += 8) {
-         int v8[8];
-         #pragma unroll
-         for (int k = 0; k < 8; ++k) v8[k] = yb[q + k];
-         #pragma unroll
-         for (int k = 0; k < 8; ++k) {
-            const long long n = tl.row0 + q + k;
-            const int v = v8[k];
-            bool up = false; long long cross = 0;
-            if (zc_row(z, v, n, P, up, cross)) {
-               if (cnt < kZcMaxEv && (unsigned long long)(n - cross) < 0x80000000ull) {
-                  me.ev[cnt][0] = (unsigned)(q + k) | ((unsigned)(v & 0xffff) << 16); me.ev[cnt][1] = (unsigned)(n - cross) | (up ? 0x80000000u : 0u); ++cnt; }
-               else cnt = kZcMaxEv + 1; } } }
-      me.end = z; me.count = cnt; }
+      zc_own_rows(me, z, yb, tl.row0, j, P); }
    __syncthreads();
-   if (mine && ok[trk]) {                                            // does every sub-segment start where its predecessor ended?
-      const ZcLane &me = lanes[L];
-      bool bad = me.count > kZcMaxEv;
-      if (j > 0 && !zc_same(me.start, lanes[L - 1].end)) bad = true;
-      if (bad) atomicAnd(&ok[trk], 0); }
-   __syncthreads();
+   // Does every sub-segment start where its predecessor ended?  Where one does not, it alone is run again (its own 64 rows) from
+   // the predecessor's end state - which is the true state, by induction from sub-segment 0 - and the check moves on to the next
+   // join; a track costs one repair per join that failed, not a sequential walk of the whole tile.
+   int *first_bad = ok + RTFE_MAXTRKS;                               // [ntrks] sub-segment to repair in this round (nsub: none)
+   for (int round = 0; round < nsub; ++round) {
+      if (L < ntrks) {
+         int fb = nsub;
+         if (ok[L]) {
+            for (int k = 0; k < nsub; ++k) if (lanes[L * nsub + k].count > kZcMaxEv) { ok[L] = 0; break; }
+            if (ok[L]) for (int k = 1; k < nsub; ++k) if (!zc_same(lanes[L * nsub + k].start, lanes[L * nsub + k - 1].end)) { fb = k; break; } }
+         first_bad[L] = fb; }
+      __syncthreads();
+      bool any = false;
+      for (int t = 0; t < ntrks; ++t) any = any || (ok[t] && first_bad[t] < nsub);
+      if (!any) break;
+      if (mine && ok[trk] && first_bad[trk] == j) {
+         ZcLane &me = lanes[L];
+         const Col yb = tile_col(tl, trk, cfg->skew[trk]);
+         ZcState z = lanes[L - 1].end;
+         me.start = z;
+         zc_own_rows(me, z, yb, tl.row0, j, P); }
+      __syncthreads(); }
    if (mine && ok[trk]) {                                            // events in row order; the walker moves to the tile's end
       const ZcLane &me = lanes[L];
       unsigned int idx = walkers[trk].nevents;
@@ -1262,8 +1282,11 @@ __device__ __forceinline__ long long find_reset(const DevCfg *cfg, const Tile &t
 // inside the guard band, by re-evaluating the reference's float comparisons on the reconstructed codes.
 // Returns false (the caller discards the state) only when the records cannot describe what the detector would see:
 // the literal start-up path, a minimum k_screen could not derive, a full event list.
+// kDirect (k_lwalk: one lane per walker, lists read straight from HBM): a detection's event is refined and stored at once,
+// into [.., ev_limit) of the walker's region, instead of being queued in LDS for finalize_records16.
+template <bool kDirect = false>
 __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int trk, long long limit,
-                                             const CandUnit *recs, int nrecs, const TileDir &td, int &why) {
+                                             const CandUnit *recs, int nrecs, const TileDir &td, int &why, unsigned int ev_limit = 0xffffffffu) {
    const DevCfg *cfg = cx.cfg;
    const DevParm &P = cfg->parm[pidx];
    const Tile &tl = cx.tile;
@@ -1342,6 +1365,10 @@ __device__ __forceinline__ bool walk_records(Walker &w, Ctx &cx, int pidx, int t
             const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
             t_peak = time_of(cfg, cx.row_base + tl.row0 + n) - ((float)(W - ld) - adj) * cfg->sample_deltat; }
          if (w.nevents >= cx.cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
+         else if (kDirect) {
+            if (w.nevents >= ev_limit) { why = 6; return false; }
+            const int adjcode = refine_code(cfg, m, (int)(short)(hit_z & 0xffff), hit_z >> 16, w.agc_gain, is_top);
+            store_event(cx, pidx, trk, w.nevents, tl.row0 + n, v, w.agc_gain, is_top, adjcode, ld); }
          else {
             if (cx.nrec >= cx.rec_cap16) { why = 6; return false; }
             // Rec16 as two 8-byte LDS stores: {n_rel|ld|kind, g} {val|prev, next}

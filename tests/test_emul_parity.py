@@ -79,6 +79,8 @@ def test_emulated_rare_paths_of_the_record_walk(name, knobs, tmp_path, monkeypat
 
 @pytest.mark.parametrize("knobs", [{"RTFE_SEG_TILES": "4", "RTFE_SEG_WARMUP": "1"},      # warm-up too short: joins fail, the tail goes to the second k_decode pass
                                    {"RTFE_SEG_TILES": "4", "RTFE_SEG_WARMUP": "4"},
+                                   {"RTFE_SEG_TILES": "4", "RTFE_SEG_WARMUP": "4", "RTFE_LWALK": "1"},      # k_walk (a workgroup per item) instead of k_lwalk (a lane per walker)
+                                   {"RTFE_SEG_TILES": "0", "RTFE_LWALK": "1"},
                                    {"RTFE_SEG_TILES": "0"}])                             # unsegmented walk
 def test_emulated_segmented_record_walk(knobs, tmp_path, monkeypatch):
     """The record walk of a long block runs as concurrent segments started from guessed states and is accepted only where

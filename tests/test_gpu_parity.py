@@ -34,7 +34,8 @@ def test_golden_tapes(name, tmp_path, gpu):
                                         ("gcr", {"RTFE_RECORD_PATH": "1", "RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}),
                                         ("pe_m", {"RTFE_RECORD_PATH": "1", "RTFE_REC_CAP16": "8"}),
                                         ("pe", {"RTFE_RECORD_PATH": "1"}), ("gcr_m", {"RTFE_RECORD_PATH": "1"}),
-                                        ("nrzi9", {"RTFE_RECORD_PATH": "0"}), ("nrzi9_m", {"RTFE_LDS_UNITS": "512"})])
+                                        ("nrzi9", {"RTFE_RECORD_PATH": "0"}), ("nrzi9_m", {"RTFE_LDS_UNITS": "512"}),
+                                        ("nrzi9", {"RTFE_LWALK": "1"}), ("nrzi9_m", {"RTFE_LWALK": "1"}), ("nrzi7", {"RTFE_LWALK": "1"})])
 def test_rare_paths_of_the_record_walk(name, knobs, tmp_path, gpu, monkeypatch):
     """Small LDS budgets force k_walk's rare paths (grouped lists, the sequential walk, give-back to the second
     k_decode pass): the events must not change."""
@@ -50,7 +51,8 @@ def test_rare_paths_of_the_record_walk(name, knobs, tmp_path, gpu, monkeypatch):
 
 @pytest.mark.parametrize("knobs", [{"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "1"}, {"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "3"},
                                    {"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "8"}, {"RTFE_SEG_TILES": "16", "RTFE_SEG_WARMUP": "8", "RTFE_REC_CAP16": "14"},
-                                   {}, {"RTFE_SEG_TILES": "0"}])
+                                   {}, {"RTFE_SEG_TILES": "0"}, {"RTFE_LWALK": "1"}, {"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "3", "RTFE_LWALK": "1"},
+                                   {"RTFE_SEG_TILES": "0", "RTFE_LWALK": "1"}])
 def test_segmented_record_walk(knobs, tmp_path, gpu, monkeypatch):
     """Long blocks: the record walk runs as concurrent segments from guessed states, accepted only where each segment's
     start state is bit for bit its predecessor's end state; the rest goes to the second k_decode pass.  Whatever the
