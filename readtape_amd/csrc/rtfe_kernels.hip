@@ -761,13 +761,43 @@ __device__ __forceinline__ void walk_zeros(Walker &w, Ctx &cx, int trk, long lon
 // stands only if every sub-segment's noted state equals its predecessor's final state in every field; otherwise that
 // track is walked again sequentially (walk_zeros) from the untouched walker.  ok[trk] = 1 where the result stands.
 constexpr int kZcSub = 64, kZcWarm = 64, kZcMaxEv = 8;
-struct ZcLane { ZcState start, end; int count; unsigned int ev[kZcMaxEv][2]; };      // ev: n_rel | code << 16 , delay | up << 31
+struct ZcLane { ZcState start, end; int count, bad; unsigned int ev[kZcMaxEv][2]; };      // ev: n_rel | code << 16 , delay | up << 31
 __device__ __forceinline__ bool zc_same(const ZcState &a, const ZcState &b) {
    return a.prev == b.prev && a.top == b.top && a.bot == b.bot && a.up == b.up && a.dn == b.dn
        && (!a.up || a.ttop == b.ttop) && (!a.dn || a.tbot == b.tbot); }       // (the crossing rows are only read while pending)
+// lookfor_zerocrossing's step (zc_row) on 32-bit state with selects instead of branches: rows are tile-relative (q), flags are ints.
+// The order of the reference's statements is kept (clear the other side's pending flag, new extreme and confirmation, arming),
+// so the state after every row is zc_row's.  Returns 0 / 1 (up confirmed) / 2 (down confirmed); cross = tile-relative row of the sign change.
+struct Zc32 { int prev, top, bot, up, dn, ttop, tbot; };
+__device__ __forceinline__ int zc_step32(Zc32 &z, int v, int q, int P, int &cross) {
+   const bool pos = v > 0, neg = v < 0;
+   z.dn = pos ? 0 : z.dn;
+   z.up = neg ? 0 : z.up;
+   const bool newtop = pos && z.top < v, newbot = neg && z.bot > v;
+   z.top = newtop ? v : z.top;
+   z.bot = newbot ? v : z.bot;
+   const bool e_up = newtop && z.up && v >= P, e_dn = newbot && z.dn && v <= -P;
+   cross = e_up ? z.ttop : z.tbot;
+   z.up = e_up ? 0 : z.up;   z.bot = e_up ? 0 : z.bot;
+   z.dn = e_dn ? 0 : z.dn;   z.top = e_dn ? 0 : z.top;
+   const bool arm_up = pos && z.prev < 0 && z.bot <= -P, arm_dn = neg && z.prev > 0 && z.top >= P;
+   z.ttop = arm_up ? q : z.ttop;  z.up = arm_up ? 1 : z.up;
+   z.tbot = arm_dn ? q : z.tbot;  z.dn = arm_dn ? 1 : z.dn;
+   z.prev = v;
+   return e_up ? 1 : (e_dn ? 2 : 0); }
+__device__ __forceinline__ Zc32 zc_to32(const ZcState &s, long long row0) {
+   Zc32 z; z.prev = s.prev; z.top = s.top; z.bot = s.bot; z.up = s.up ? 1 : 0; z.dn = s.dn ? 1 : 0;
+   const long long a = s.ttop - row0, b2 = s.tbot - row0;               // (only read while pending: a pending crossing is recent)
+   z.ttop = (int)(a < -(1ll << 30) ? -(1ll << 30) : a); z.tbot = (int)(b2 < -(1ll << 30) ? -(1ll << 30) : b2);
+   return z; }
+__device__ __forceinline__ ZcState zc_from32(const Zc32 &z, long long row0) {
+   ZcState s; s.prev = z.prev; s.top = z.top; s.bot = z.bot; s.up = z.up != 0; s.dn = z.dn != 0; s.ttop = row0 + z.ttop; s.tbot = row0 + z.tbot;
+   return s; }
+
 // the own rows of sub-segment j from state z: events into the lane's record, the end state
-__device__ __forceinline__ void zc_own_rows(ZcLane &me, ZcState z, const Col &yb, long long row0, int j, int P) {
+__device__ __forceinline__ void zc_own_rows(ZcLane &me, const ZcState z0, const Col &yb, long long row0, int j, int P) {
    int cnt = 0;
+   Zc32 z = zc_to32(z0, row0);
    #pragma nounroll
    for (int q = j * kZcSub; q < (j + 1) * kZcSub; q += 8) {
       int v8[8];
@@ -775,16 +805,25 @@ __device__ __forceinline__ void zc_own_rows(ZcLane &me, ZcState z, const Col &yb
       for (int k = 0; k < 8; ++k) v8[k] = yb[q + k];
       #pragma unroll
       for (int k = 0; k < 8; ++k) {
-         const long long n = row0 + q + k;
-         const int v = v8[k];
-         bool up = false; long long cross = 0;
-         if (zc_row(z, v, n, P, up, cross)) {
-            if (cnt < kZcMaxEv && (unsigned long long)(n - cross) < 0x80000000ull) {
-               me.ev[cnt][0] = (unsigned)(q + k) | ((unsigned)(v & 0xffff) << 16); me.ev[cnt][1] = (unsigned)(n - cross) | (up ? 0x80000000u : 0u); ++cnt; }
+         int cross;
+         const int e = zc_step32(z, v8[k], q + k, P, cross);
+         if (e) {
+            const int delay = q + k - cross;
+            if (cnt < kZcMaxEv && delay >= 0) {
+               me.ev[cnt][0] = (unsigned)(q + k) | ((unsigned)(v8[k] & 0xffff) << 16); me.ev[cnt][1] = (unsigned)delay | (e == 1 ? 0x80000000u : 0u); ++cnt; }
             else cnt = kZcMaxEv + 1; } } }
-   me.end = z; me.count = cnt; }
+   me.end = zc_from32(z, row0); me.count = cnt; }
 
-__device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, ZcLane *lanes, int *ok, long long stop) {
+// 0: sub-segment L of the lanes starts where its predecessor ended; 1: it does not; 2: it holds more events than its record can
+// (a function of its own: inlined into k_decode the 64-bit compares ran into a register-pair spill the gfx950 backend rejects)
+__device__ __attribute__((noinline)) int zc_join_verdict(const ZcLane *lanes, int L, int j) {
+   const ZcLane &me = lanes[L];
+   if (me.count > kZcMaxEv) return 2;
+   return (j > 0 && !zc_same(me.start, lanes[L - 1].end)) ? 1 : 0; }
+
+__device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, ZcLane *lanes, int *ok, long long stop, unsigned long long *dbgp = nullptr) {
+   long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0;
+   if (dbgp) k0 = clock64();
    const DevCfg *cfg = cx.cfg;
    const Tile &tl = cx.tile;
    const int ntrks = cfg->ntrks, nsub = tl.nrows / kZcSub;
@@ -804,27 +843,31 @@ __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, Zc
       if (j == 0) zc_load(z, walkers[trk]);
       else {
          const int q0 = j * kZcSub - kZcWarm;
-         z.prev = yb[q0 - 1]; z.top = 0; z.bot = 0; z.up = false; z.dn = false; z.ttop = 0; z.tbot = 0;
+         Zc32 zw; zw.prev = yb[q0 - 1]; zw.top = 0; zw.bot = 0; zw.up = 0; zw.dn = 0; zw.ttop = -tl.row0 < -(1ll << 30) ? -(1 << 30) : (int)-tl.row0; zw.tbot = zw.ttop;
          #pragma nounroll
          for (int q = q0; q < j * kZcSub; q += 8) {                   // (eight samples in flight, then the eight dependent steps)
             int v8[8];
             #pragma unroll
             for (int k = 0; k < 8; ++k) v8[k] = yb[q + k];
             #pragma unroll
-            for (int k = 0; k < 8; ++k) { bool up; long long cross; (void)zc_row(z, v8[k], tl.row0 + q + k, P, up, cross); } } }
+            for (int k = 0; k < 8; ++k) { int cross; (void)zc_step32(zw, v8[k], q + k, P, cross); } }
+         z = zc_from32(zw, tl.row0); }
       me.start = z;
       zc_own_rows(me, z, yb, tl.row0, j, P); }
    __syncthreads();
+   if (dbgp) k1 = clock64();
    // Does every sub-segment start where its predecessor ended?  Where one does not, it alone is run again (its own 64 rows) from
    // the predecessor's end state - which is the true state, by induction from sub-segment 0 - and the check moves on to the next
    // join; a track costs one repair per join that failed, not a sequential walk of the whole tile.
    int *first_bad = ok + RTFE_MAXTRKS;                               // [ntrks] sub-segment to repair in this round (nsub: none)
    for (int round = 0; round < nsub; ++round) {
+      if (mine && ok[trk]) {                                         // every lane checks its own join
+         ZcLane &me = lanes[L];
+         me.bad = zc_join_verdict(lanes, L, j); }
+      __syncthreads();
       if (L < ntrks) {
          int fb = nsub;
-         if (ok[L]) {
-            for (int k = 0; k < nsub; ++k) if (lanes[L * nsub + k].count > kZcMaxEv) { ok[L] = 0; break; }
-            if (ok[L]) for (int k = 1; k < nsub; ++k) if (!zc_same(lanes[L * nsub + k].start, lanes[L * nsub + k - 1].end)) { fb = k; break; } }
+         if (ok[L]) for (int k = nsub - 1; k >= 0; --k) { const int bd = lanes[L * nsub + k].bad; if (bd == 2) ok[L] = 0; else if (bd == 1) fb = k; }
          first_bad[L] = fb; }
       __syncthreads();
       bool any = false;
@@ -833,10 +876,10 @@ __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, Zc
       if (mine && ok[trk] && first_bad[trk] == j) {
          ZcLane &me = lanes[L];
          const Col yb = tile_col(tl, trk, cfg->skew[trk]);
-         ZcState z = lanes[L - 1].end;
-         me.start = z;
-         zc_own_rows(me, z, yb, tl.row0, j, P); }
+         me.start = lanes[L - 1].end;
+         zc_own_rows(me, lanes[L - 1].end, yb, tl.row0, j, P); }
       __syncthreads(); }
+   if (dbgp) k2 = clock64();
    if (mine && ok[trk]) {                                            // events in row order; the walker moves to the tile's end
       const ZcLane &me = lanes[L];
       unsigned int idx = walkers[trk].nevents;
@@ -852,7 +895,9 @@ __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, Zc
       for (int k = 0; k < nsub; ++k) total += (unsigned)lanes[L * nsub + k].count;
       zc_store(w, lanes[L * nsub + nsub - 1].end);
       w.nevents += total; w.next = tl.row0 + tl.nrows; }
-   __syncthreads(); }
+   if (dbgp) k3 = clock64();
+   __syncthreads();
+   if (dbgp && threadIdx.x == 0) { k4 = clock64(); atomicAdd(&dbgp[0], (unsigned long long)(k1 - k0)); atomicAdd(&dbgp[1], (unsigned long long)(k2 - k1)); atomicAdd(&dbgp[2], (unsigned long long)(k3 - k2)); atomicAdd(&dbgp[3], (unsigned long long)(k4 - k3)); } }
 
 
 // differentiate() (src/readtape.c:1383-1394) for every element of the tile, all lanes: delta against the previous row of
@@ -2452,7 +2497,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          const bool zc_par = cfg.find_zeros && !cfg.differentiate && cfg.zc_parallel && (parmset_mask & 1u)
                              && (size_t)ntrks * (cfg.tile_rows / kZcSub) * sizeof(ZcLane) <= (size_t)nwalk * cfg.rec_cap * sizeof(Rec)
                              && ntrks * (cfg.tile_rows / kZcSub) <= (int)blockDim.x;
-         if (zc_par) zeros_tile_parallel(cx, walkers, reinterpret_cast<ZcLane *>(recs_all), s_off, stop);     // (s_off: per-track verdicts)
+         if (zc_par) zeros_tile_parallel(cx, walkers, reinterpret_cast<ZcLane *>(recs_all), s_off, stop, cfg.debug ? scratch->dbg2 : nullptr);     // (s_off: per-track verdicts)
          if (zc_par && cfg.debug && (int)threadIdx.x < ntrks) { atomicAdd(&scratch->dbg2[4], 1ull); if (s_off[threadIdx.x]) atomicAdd(&scratch->dbg2[5], 1ull); }
          if (active) {
             Walker w = walkers[my_w];

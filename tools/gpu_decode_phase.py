@@ -14,5 +14,5 @@ def run(name, base, target, **kw):
     dbg = ws[64:128].view(np.uint64)
     nt = max(int(dbg[3]), 1)
     d2 = ws[136:200].view(np.uint64)
-    print(name, "ms", {k2: round(v, 2) for k2, v in ms.items() if v > 0.01}, "tiles", int(dbg[3]), "cyc/tile load", int(dbg[0] / nt), "screen", int(dbg[1] / nt), "walk", int(dbg[5] / nt), "final", int(dbg[6] / nt), "zc tracks", int(d2[4]), "zc ok", int(d2[5]))
+    print(name, "ms", {k2: round(v, 2) for k2, v in ms.items() if v > 0.01}, "tiles", int(dbg[3]), "cyc/tile load", int(dbg[0] / nt), "screen", int(dbg[1] / nt), "walk", int(dbg[5] / nt), "final", int(dbg[6] / nt), "zc tracks", int(d2[4]), "zc ok", int(d2[5]), "zc phases (pass, verify+repair, events+store, tail barrier)", [int(d2[i] / nt) for i in range(4)])
 run("PEz", synth.pe_tape(seed=71, nblocks=40, minlen=500, maxlen=4000, gap_samples=6000), 2e7, nparmsets=1, find_zeros=True)
