@@ -1,10 +1,10 @@
 #!/bin/bash
-# GPU box: k_lwalk sweep of segment size / warm-up (C2 bench line without the CPU legs)
+# GPU box, one call: the full -m gpu suite, smoke, the bench lines of every config, the rocprofv3 summaries.
 mkdir -p gpurun_out
-run() { env "$@" timeout 600 python bench.py --steps 5 --warmup 2 --no-e2e --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=j['kernel_ms']; print('$*', j['value'], 'walk', k['k_walk'], 'resume', k['k_decode_resume'], 'screen', k['k_screen'], 'flagged', j['config']['flagged_bursts'])"; }
-run RTFE_LWALK=1
-run RTFE_LWALK=0
-for st in 8 16 32; do for wm in 2 4 8; do if [ $wm -le $st ]; then run RTFE_SEG_TILES=$st RTFE_SEG_WARMUP=$wm; fi; done; done
-RTFE_DEBUG=1 timeout 300 python tools/gpu_segs.py 2>&1 | tail -12
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "segmented or rare_paths or golden_tapes or long_blocks" > gpurun_out/gpu_tests_walk.log 2>&1; echo "tests rc $?"; tail -3 gpurun_out/gpu_tests_walk.log
+timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; echo "gpu tests rc $?"; tail -3 gpurun_out/gpu_tests.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1; echo "smoke rc $?"; tail -1 gpurun_out/smoke.log
+timeout 600 python bench.py > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err; echo "C2 rc $?"; tail -c 3000 gpurun_out/bench_c2.json
+timeout 900 python bench.py --config C3 --steps 3 --warmup 1 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err; echo "C3 rc $?"; tail -c 1500 gpurun_out/bench_c3.json | cut -c1-1500
+timeout 900 python bench.py --config C4 --steps 3 --warmup 1 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err; echo "C4 rc $?"; tail -c 1500 gpurun_out/bench_c4.json | cut -c1-1200
+timeout 900 python bench.py --config C5 --steps 5 --warmup 1 --no-e2e --no-cpu-baseline > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err; echo "C5 (1 GPU) rc $?"; tail -c 1200 gpurun_out/bench_c5.json
+timeout 1200 bash tools/gpu_profile.sh r02 > gpurun_out/profile.log 2>&1; echo "profile rc $?"; tail -28 gpurun_out/profile.log
