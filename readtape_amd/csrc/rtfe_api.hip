@@ -15,6 +15,7 @@
 #include "rtfe_peaks.hip"     // single translation unit: kernels + host API
 #include "rtfe_kernels.hip"
 #include "rtfe_lwalk.hip"
+#include "rtfe_zeros.hip"
 #include "rtfe_chain.hip"
 
 namespace rtfe {
@@ -39,6 +40,7 @@ struct rtfe_handle {
    hipEvent_t ev0[8], ev1[8];          // start / stop of each kernel of the last scan (on the stream it ran on)
    int screen_lds_bytes;
    int walk_lds_bytes;
+   int zeros_kernel;                   // -zeros scans run k_zeros (RTFE_ZEROS_KERNEL=0: k_decode's zero-crossing mode, kept for tests)
    int lane_walk;                      // the record walk runs one lane per walker (k_lwalk) where that fits; RTFE_LWALK=0/1
 };
 
@@ -176,6 +178,12 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (const char *e = getenv("RTFE_RECORD_PATH")) d.record_path = !d.find_zeros && atoi(e) != 0;
    if (d.agc_off || d.differentiate) d.record_path = 0;               // density detection / differentiated peaks: the sample path
    if (const char *e = getenv("RTFE_ZC_PARALLEL")) d.zc_parallel = atoi(e) != 0;
+   {  // rows a -zeros sub-segment starts early from a fresh state: two bit cells hold a confirmed crossing in each direction wherever
+      // the signal is live; where that is not enough the join check sees it and the sub-segment is run again (exact either way)
+      const float spbw = (bpi_s > 0 && c->ips > 0) ? 1.0f / (bpi_s * c->ips * d.sample_deltat) : 32.0f;
+      int w = ((int)(2.0f * spbw) + 7) & ~7;
+      d.zc_warm = w < 16 ? 16 : (w > 64 ? 64 : w); }
+   if (const char *e = getenv("RTFE_ZC_WARM")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= 64) d.zc_warm = v; }
    if (const char *e = getenv("RTFE_SEG_WARMUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) d.seg_warm = v; }
    if (const char *e = getenv("RTFE_SEG_TILES")) { const int v = atoi(e); d.seg_tiles = v <= 0 ? 0 : v; }
    if (d.seg_tiles > 0 && d.seg_tiles < d.seg_warm) d.seg_tiles = d.seg_warm;
@@ -184,7 +192,8 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    d.cap_frac = c->events_per_sample_cap > 0 ? c->events_per_sample_cap : 0.125f;
    {
       const char *e = getenv("RTFE_TILE_ROWS");            // tuning knob; the default is what bench.py measures
-      int tr = e ? atoi(e) : 512;
+      // (-zeros: a lane per (track, 64-row sub-segment) - 14 sub-segments x 9 tracks fill two waves, 8 leave 44 % of them idle)
+      int tr = e ? atoi(e) : ((c->find_zeros && !c->differentiate) ? 64 * (128 / (c->ntrks > 0 ? c->ntrks : 9)) : 512);
       tr = (tr / 64) * 64;
       if (tr < kMarginRows) tr = kMarginRows;
       if (tr > kMaxTileRows) tr = kMaxTileRows;
@@ -253,7 +262,8 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
       // test knobs (tests/ only): force the rare paths - lists through LDS in several groups, tiles handed back to k_decode
       if (getenv("RTFE_LDS_UNITS")) { int v = atoi(getenv("RTFE_LDS_UNITS")); if (v >= d.run_cap && v <= 1536) { d.lds_units = v & ~63; d.pm_cap = d.lds_units / 2 * ((c->nparmsets + d.nscreens - 1) / d.nscreens); } }
       if (getenv("RTFE_REC_CAP16")) { int v = atoi(getenv("RTFE_REC_CAP16")); if (v >= 2 && v <= d.rec_cap16) d.rec_cap16 = v; } }
-   if (!d.find_zeros) {                                               // (the -zeros sub-segments use the record space themselves)
+   if (d.find_zeros) d.rec_cap = 8;                                   // (the zero-crossing walkers store their events at once)
+   if (!d.find_zeros) {
       // k_decode is latency bound: workgroups per CU are what counts.  A smaller record buffer is taken only if it lets one more workgroup reside.
       auto per_cu = [&](int rc) { DevCfg t = d; t.rec_cap = rc; return (160 * 1024) / ((int)lds_layout(t, true).total + 64 + 5500); };      // (static LDS ~ 4 KB, allocation granularity, margin)
       int best = d.rec_cap;
@@ -277,10 +287,14 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen), hipFuncAttributeMaxDynamicSharedMemorySize, h->screen_lds_bytes);
    h->walk_lds_bytes = (int)lds_layout_walk(d).total + 64;
+   h->zeros_kernel = getenv("RTFE_ZEROS_KERNEL") ? atoi(getenv("RTFE_ZEROS_KERNEL")) != 0 : 1;
+   if (d.ntrks * (d.tile_rows / 64) > 128) h->zeros_kernel = 0;      // (its workgroup is two waves)
+   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zeros), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout_zeros(d).total + 64);
    h->lane_walk = getenv("RTFE_LWALK") ? atoi(getenv("RTFE_LWALK")) != 0 : 0;      // (measured: no faster than k_walk)
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, h->walk_lds_bytes);
-   if (c->nparmsets * c->ntrks <= 32)
+   if (c->nparmsets * c->ntrks <= 32 && (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16 <= 150 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lwalk), hipFuncAttributeMaxDynamicSharedMemorySize, (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16);
+   (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pk_kernel(d.screen[0].nb, 64 * ((c->ntrks + 1) / 2 + 1))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
    *out = h;
    return 0; }
@@ -463,7 +477,16 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                       d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts,
                       deadp, ntiles_for(h, nrows), h->dev.tile_rows, h->dev.tail_rows);
    t1(1, sq);
-   if (!use_screen) {                                                 // -zeros, PE, GCR: the whole burst in one pass over the samples
+   if (h->dev.find_zeros && !h->dev.differentiate && h->zeros_kernel) {          // -zeros: the lean kernel of its own (rtfe_zeros.hip)
+      const int zlds = (int)lds_layout_zeros(h->dev).total + 64;
+      int zpc = (160 * 1024) / (zlds + 4096);
+      if (zpc > 16) zpc = 16;
+      if (zpc < 1) zpc = 1;
+      t0(2, st); t1(2, st); t0(3, st);
+      hipLaunchKernelGGL(k_zeros, dim3(h->num_cus * zpc), dim3(128), zlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base,
+                         d_bursts, scratch, d_counts, d_events);
+      t1(3, st); t0(4, st); t1(4, st); t0(5, st); t1(5, st); }
+   else if (!use_screen) {                                            // -zeros, PE, GCR: the whole burst in one pass over the samples
       t0(2, st); t1(2, st); t0(3, st);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
@@ -495,7 +518,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t0(4, st);
       // the walkers: a lane each (k_lwalk, lists straight from HBM) when two or more work items fit a wave, else k_walk's
       // workgroup per item.  RTFE_LWALK=0/1 overrides (tests keep both alive).
-      const bool lanes = h->lane_walk && nwalk <= 32;
+      const bool lanes = h->lane_walk && nwalk <= 32 && (64 / nwalk) * h->dev.lds_units * 16 <= 150 * 1024;
       const int lw_lds = (64 / nwalk) * h->dev.lds_units * 16;                 // the lists of one tile of every item of a wave
       int lwpc = (160 * 1024) / (lw_lds + 6 * 1024);
       if (lwpc < 1) lwpc = 1;

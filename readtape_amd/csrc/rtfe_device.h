@@ -56,6 +56,7 @@ struct DevCfg {
    int   seg_evcap;
    int   seg_warm;                // warm-up tiles in front of every segment but the first
    int   zc_parallel;             // -zeros: concurrent sub-segments per tile (0 = one lane per track, sequential)
+   int   zc_warm;                 // ... rows a sub-segment starts early from a fresh state (multiple of 8, <= 64; RTFE_ZC_WARM)
    int   record_path;             // k_screen -> k_walk runs (NRZI peak detection; RTFE_RECORD_PATH overrides): k_decode then keeps LDS for record tiles
    int   tail_rows;               // a burst's walkers stop this many rows into the next zone (the block decoders have long ended
                                   // the block by then; an attempt that has not falls back to an exact rescan in the replay)

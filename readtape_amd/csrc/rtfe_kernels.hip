@@ -702,9 +702,9 @@ __device__ __forceinline__ void walk(Walker &w, Ctx &cx, int pidx, int trk, long
 // v_peak = the new extreme, agc_gain bits = delay in rows, left_distance = min(delay, 255).
 // the detector's state between rows, and one row of it
 struct ZcState { int prev, top, bot; bool up, dn; long long ttop, tbot; };
-__device__ __forceinline__ void zc_load(ZcState &z, const Walker &w) {
+template <class WT> __device__ __forceinline__ void zc_load(ZcState &z, const WT &w) {
    z.prev = w.z_prev; z.top = w.z_top; z.bot = w.z_bot; z.up = w.z_up_pending; z.dn = w.z_dn_pending; z.ttop = w.z_ttop_row; z.tbot = w.z_tbot_row; }
-__device__ __forceinline__ void zc_store(Walker &w, const ZcState &z) {
+template <class WT> __device__ __forceinline__ void zc_store(WT &w, const ZcState &z) {
    w.z_prev = z.prev; w.z_top = z.top; w.z_bot = z.bot; w.z_up_pending = z.up; w.z_dn_pending = z.dn; w.z_ttop_row = z.ttop; w.z_tbot_row = z.tbot; }
 // returns true when row n (code v) confirms a crossing: `up` its direction, `cross` the row of the sign change
 __device__ __forceinline__ bool zc_row(ZcState &z, int v, long long n, int P, bool &up, long long &cross) {
@@ -735,7 +735,7 @@ __device__ __forceinline__ void zc_event(const Ctx &cx, int trk, unsigned int id
    e.parmset = 0;
    cx.events[(size_t)trk * cx.cap + idx] = e; }
 
-__device__ __forceinline__ void walk_zeros(Walker &w, Ctx &cx, int trk, long long limit) {
+template <class WT> __device__ __forceinline__ void walk_zeros(WT &w, Ctx &cx, int trk, long long limit) {
    const DevCfg *cfg = cx.cfg;
    const Tile &tl = cx.tile;
    const long long tile_end = tl.row0 + tl.nrows;
@@ -821,7 +821,7 @@ __device__ __attribute__((noinline)) int zc_join_verdict(const ZcLane *lanes, in
    if (me.count > kZcMaxEv) return 2;
    return (j > 0 && !zc_same(me.start, lanes[L - 1].end)) ? 1 : 0; }
 
-__device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, ZcLane *lanes, int *ok, long long stop, unsigned long long *dbgp = nullptr) {
+template <class WT> __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, WT *walkers, ZcLane *lanes, int *ok, long long stop, unsigned long long *dbgp = nullptr) {
    long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0;
    if (dbgp) k0 = clock64();
    const DevCfg *cfg = cx.cfg;
@@ -831,7 +831,7 @@ __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, Zc
    const int L = threadIdx.x, trk = L / (nsub > 0 ? nsub : 1), j = L - trk * nsub;
    const bool mine = L < ntrks * nsub;
    if (L < ntrks) {                                                  // a whole tile in the regular regime?
-      const Walker &w = walkers[L];
+      const WT &w = walkers[L];
       ok[L] = (tl.nrows % kZcSub == 0 && nsub >= 2 && stop >= tl.row0 + tl.nrows && w.next == tl.row0 && w.start < tl.row0
                && tl.row0 - kZcWarm - 1 - tl.reset >= cfg->skew[L]          // every row read is behind the deskew FIFO's start-up
                && w.nevents + (unsigned)(nsub * kZcMaxEv) < cx.cap) ? 1 : 0; }
@@ -842,7 +842,7 @@ __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, Zc
       const Col yb = tile_col(tl, trk, cfg->skew[trk]);              // y(n) = yb[n - row0] in the regular regime
       if (j == 0) zc_load(z, walkers[trk]);
       else {
-         const int q0 = j * kZcSub - kZcWarm;
+         const int q0 = j * kZcSub - cfg->zc_warm;
          Zc32 zw; zw.prev = yb[q0 - 1]; zw.top = 0; zw.bot = 0; zw.up = 0; zw.dn = 0; zw.ttop = -tl.row0 < -(1ll << 30) ? -(1 << 30) : (int)-tl.row0; zw.tbot = zw.ttop;
          #pragma nounroll
          for (int q = q0; q < j * kZcSub; q += 8) {                   // (eight samples in flight, then the eight dependent steps)
@@ -890,7 +890,7 @@ __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, Walker *walkers, Zc
          zc_event(cx, trk, idx + k, n, v, (me.ev[k][1] >> 31) != 0, n - (long long)(me.ev[k][1] & 0x7fffffffu)); } }
    __syncthreads();
    if (L < ntrks && ok[L]) {
-      Walker &w = walkers[L];
+      WT &w = walkers[L];
       unsigned int total = 0;
       for (int k = 0; k < nsub; ++k) total += (unsigned)lanes[L * nsub + k].count;
       zc_store(w, lanes[L * nsub + nsub - 1].end);
@@ -1455,8 +1455,9 @@ __host__ __device__ inline LdsLayout lds_layout(const DevCfg &c, bool decode) {
    const unsigned T = (unsigned)c.tile_rows;
    unsigned off = lds_align16(ntrks * (unsigned)c.ldw * 2u + 16u);          // (ldw rows of ntrks samples, + one vector of slack)
    const unsigned nsl = decode ? nst : ntrks;                                  // k_screen works through the screens one at a time
-   L.bits = off;      off = lds_align16(off + nsl * 5u * lds_bstride((int)T));
-   L.ldpos = off;     off = lds_align16(off + nsl * 2u * lds_ldstride((int)T));
+   const bool zeros = decode && c.find_zeros && !c.differentiate;             // no screen: the space holds the sub-segment records of zeros_tile_parallel
+   L.bits = off;      off = lds_align16(off + (zeros ? ntrks * (T / (unsigned)kZcSub) * (unsigned)sizeof(ZcLane) : nsl * 5u * lds_bstride((int)T)));
+   L.ldpos = off;     off = lds_align16(off + (zeros ? 0u : nsl * 2u * lds_ldstride((int)T)));
    // k_decode: the candidate records of a tile share the space of the sample tile (a tile is decided either from
    // its records or from its samples, never both)
    L.runs = 0;
@@ -2495,9 +2496,10 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
          long long c2c = 0;
          cx.nrec = 0;
          const bool zc_par = cfg.find_zeros && !cfg.differentiate && cfg.zc_parallel && (parmset_mask & 1u)
-                             && (size_t)ntrks * (cfg.tile_rows / kZcSub) * sizeof(ZcLane) <= (size_t)nwalk * cfg.rec_cap * sizeof(Rec)
+                             && (size_t)ntrks * (cfg.tile_rows / kZcSub) * sizeof(ZcLane) <= (size_t)(L.heights - L.bits)
                              && ntrks * (cfg.tile_rows / kZcSub) <= (int)blockDim.x;
-         if (zc_par) zeros_tile_parallel(cx, walkers, reinterpret_cast<ZcLane *>(recs_all), s_off, stop, cfg.debug ? scratch->dbg2 : nullptr);     // (s_off: per-track verdicts)
+         // (the sub-segment records live where the peak path keeps its screen maps: -zeros has no screen)
+         if (zc_par) zeros_tile_parallel(cx, walkers, reinterpret_cast<ZcLane *>(smem + L.bits), s_off, stop, cfg.debug ? scratch->dbg2 : nullptr);     // (s_off: per-track verdicts)
          if (zc_par && cfg.debug && (int)threadIdx.x < ntrks) { atomicAdd(&scratch->dbg2[4], 1ull); if (s_off[threadIdx.x]) atomicAdd(&scratch->dbg2[5], 1ull); }
          if (active) {
             Walker w = walkers[my_w];

@@ -163,3 +163,17 @@ def test_output_files_and_summary_match_the_reference(name, tmp_path, monkeypatc
     for f in made:
         assert open(f, "rb").read() == g["files"][f], f
     assert report_lines(open("t.log").read()) == g["report"]
+
+
+@pytest.mark.parametrize("name", ["nrzi9_zeros", "pe_zeros", "gcr_zeros", "nrzi9_cut_zeros"])
+@pytest.mark.parametrize("knobs", [{}, {"RTFE_ZEROS_KERNEL": "0"}, {"RTFE_ZC_WARM": "16"}, {"RTFE_ZC_PARALLEL": "0"}])
+def test_zeros_with_the_gpu_default_tile(name, knobs, tmp_path, monkeypatch):
+    """-zeros runs 896-row tiles on the GPU (14 sub-segments x 9 tracks = two full waves): the same tiles on the emulator - through
+    k_zeros (default) and through k_decode's zero-crossing mode, with a warm-up too short to converge (the joins fail and are
+    repaired) and without the concurrent sub-segments."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g = load_case(name)
+    tap, stats = decode_case(g, tmp_path, lambda cfg: emul_frontend(cfg, tile_rows=896))
+    assert tap == g["tap"]
+    assert not stats["event_diffs"], stats["event_diffs"]

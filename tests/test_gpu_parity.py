@@ -404,3 +404,50 @@ def test_output_files_and_summary_match_the_reference(name, tmp_path, monkeypatc
     for f in made:
         assert open(f, "rb").read() == g["files"][f], f
     assert report_lines(open("t.log").read()) == g["report"]
+
+
+@pytest.mark.parametrize("name", ["nrzi9_zeros", "pe_zeros", "gcr_zeros", "nrzi9_cut_zeros"])
+@pytest.mark.parametrize("knobs", [{}, {"RTFE_ZEROS_KERNEL": "0"}, {"RTFE_ZC_WARM": "16"}, {"RTFE_ZC_WARM": "64", "RTFE_TILE_ROWS": "512"}, {"RTFE_ZC_PARALLEL": "0"}])
+def test_zeros_kernel_variants(name, knobs, tmp_path, gpu, monkeypatch):
+    """-zeros: k_zeros (default) against the oracle is in test_golden_tapes / the replay tests; here the same tapes through k_decode's
+    zero-crossing mode, with a warm-up too short to converge (joins fail and are repaired in place), with 512-row tiles, and with
+    the sequential walk only: the events must not change."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    from test_emul_replay import decode_case
+    g = load_case(name)
+    tap, stats = decode_case(g, tmp_path, None)          # (the delivered transitions against the reference's event dump, and the .tap)
+    assert tap == g["tap"]
+    assert not stats["event_diffs"], stats["event_diffs"]
+
+
+@pytest.mark.parametrize("kind", ["pe", "nrzi", "gcr"])
+def test_zeros_kernel_equals_the_decode_mode_on_long_tapes(kind, gpu, monkeypatch):
+    """k_zeros (896-row tiles, samples read from HBM, short warm-up with repairs) against k_decode's zero-crossing mode (512-row tiles in
+    LDS, 64-row warm-up) and against the purely sequential walk, on tapes of a few million rows with weak and noisy stretches: the same
+    burst table and the same events, byte for byte."""
+    import torch
+    make = {"pe": lambda: synth.pe_tape(seed=91, nblocks=60, minlen=300, maxlen=3000, gap_samples=7000, noise_mv=40.0, amp_slope=0.1),
+            "nrzi": lambda: synth.nrzi_tape(seed=92, nblocks=60, minlen=300, maxlen=3000, marks_every=9, gap_samples=5000, noise_mv=40.0),
+            "gcr": lambda: synth.gcr_tape(seed=93, nblocks=30, minlen=300, maxlen=3000, gap_samples=20000, noise_mv=40.0)}[kind]
+    tape = make()
+    hdr = tape.spec.header()
+    rows = torch.from_numpy(tape.rows).cuda()
+    cfg = frontend.FrontEndConfig.from_header(hdr, find_zeros=True)
+    out = []
+    for knobs in ({}, {"RTFE_ZEROS_KERNEL": "0", "RTFE_TILE_ROWS": "512", "RTFE_ZC_WARM": "64"}, {"RTFE_ZC_PARALLEL": "0"}):
+        for k in ("RTFE_ZEROS_KERNEL", "RTFE_TILE_ROWS", "RTFE_ZC_WARM", "RTFE_ZC_PARALLEL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        fe = frontend.FrontEnd(cfg)
+        out.append(fe.scan(rows).fetch())
+    r0 = out[0]
+    assert r0.nbursts > 20 and int(r0.counts.sum()) > 100000
+    for r in out[1:]:
+        assert r.nbursts == r0.nbursts and (r.counts == r0.counts).all()
+        for k in ("zone_first", "zone_end", "reset_sample", "safe_last", "end_sample", "flags"):
+            assert (r.bursts[k] == r0.bursts[k]).all(), k
+        for b in range(r0.nbursts):
+            for t in range(cfg.ntrks):
+                assert r.track_events(b, 0, t).tobytes() == r0.track_events(b, 0, t).tobytes(), (b, t)
