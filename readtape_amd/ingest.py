@@ -30,9 +30,12 @@ def _payload_geometry(path):
 
 
 def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17, opts: pipeline.DecodeOptions | None = None, cfgkw=None,
-                          device="cuda:0"):
+                          device="cuda:0", replay_threads: int = 1):
     """Decodes the .tbin file `path` to the SIMH file `tap_path` through device windows of `window_rows` rows (a multiple of 1024).
-    Returns statistics incl. the end-to-end rate (disk -> .tap), the time spent in the host replay and the rows the halos re-read."""
+    Returns statistics incl. the end-to-end rate (disk -> .tap), the time spent in the host replay and the rows the halos re-read.
+    replay_threads > 1: the windows' host replays run side by side (fragments are independent: each has its own decoder context
+    and writes its own piece of the .tap; the pieces are concatenated in window order).  A window's device buffer is kept until
+    its replay is done (exact rescans read it), so replay_threads + 2 device windows are held."""
     import torch
     assert window_rows % 1024 == 0
     opts = opts or pipeline.DecodeOptions()
@@ -44,8 +47,14 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     dev = torch.device(device)
     spans = [(lo, min(nrows, lo + window_rows)) for lo in range(0, nrows, window_rows)]
     cap = window_rows + halo_rows
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, int(replay_threads))
+    depth = 2 if nthreads == 1 else nthreads + 2
     pinned = [torch.empty((cap, ntrks), dtype=torch.int16, pin_memory=True) for _ in range(2)]       # hipHostMalloc
-    dwin = [torch.empty((cap, ntrks), dtype=torch.int16, device=dev) for _ in range(2)]
+    dwin = [torch.empty((cap, ntrks), dtype=torch.int16, device=dev) for _ in range(depth)]
+    pool = ThreadPoolExecutor(nthreads) if nthreads > 1 else None
+    fe_exact = frontend.FrontEnd(cfg, device=device) if pool else fe       # exact rescans of concurrent replays: their own context, one at a time
+    exact_lock = threading.Lock()
     copy_stream, scan_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     copied = [torch.cuda.Event() for _ in range(2)]
     fd = os.open(path, os.O_RDONLY)
@@ -78,15 +87,31 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         hi = min(hi, data_end[0])
         if hi <= lo:
             return None, None, lo
+        if busy[k % depth] is not None:                   # the replay that still reads this device window
+            busy[k % depth].result()
+            busy[k % depth] = None
         with torch.cuda.stream(copy_stream):
-            dwin[k & 1][: end - lo].copy_(pinned[k & 1][: end - lo], non_blocking=True)
+            dwin[k % depth][: end - lo].copy_(pinned[k & 1][: end - lo], non_blocking=True)
             copied[k & 1].record(copy_stream)
         scan_stream.wait_event(copied[k & 1])
-        piece = dwin[k & 1][: end - lo]
+        piece = dwin[k % depth][: end - lo]
         fin = pipeline.scan_fragment(fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0], stream=scan_stream.cuda_stream)
         return piece, fin, end
 
-    stats = dict(rows=nrows, windows=len(spans), halo_rows_read=0, blocks=0, tapemarks=0, events_delivered=0, exact_scans=0, retries=0)
+    busy = [None] * depth
+    pieces = []                                           # per window: bytes, or the future that returns (bytes, replay stats, seconds)
+
+    def replay(k, res, piece, lo, bound):
+        t0 = time.perf_counter()
+        frag = f"{tap_path}.frag{k}"
+        start = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
+        st = pipeline.decode_fragment(hdr, cfg, fe_exact, res, piece, lo, start, bound, frag, full, opts, exact_lock=exact_lock if pool else None)
+        with open(frag, "rb") as g:
+            data = g.read()
+        os.remove(frag)
+        return data, st, time.perf_counter() - t0
+
+    stats = dict(rows=nrows, windows=len(spans), halo_rows_read=0, blocks=0, tapemarks=0, events_delivered=0, exact_scans=0, retries=0, replay_threads=nthreads)
     t_replay = t_wait = 0.0
     t_start = time.perf_counter()
     total = 0
@@ -117,25 +142,30 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                 res, nb, bound = pipeline.scan_fragment(fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
             stats["halo_rows_read"] += end_k - hi
             if res.nbursts:
-                t0 = time.perf_counter()
-                frag = tap_path + ".frag"
-                st = pipeline.decode_fragment(hdr, cfg, fe, res, piece, lo, 0 if lo == 0 else int(res.bursts[0]["zone_first"]), bound, frag, full, opts)
-                t_replay += time.perf_counter() - t0
-                with open(frag, "rb") as g:
-                    data = g.read()
-                os.remove(frag)
-                tapf.write(data)
-                total += len(data)
-                for key in ("blocks", "tapemarks", "events_delivered", "exact_scans"):
-                    stats[key] += int(st[key])
+                if pool:
+                    fut = pool.submit(replay, k, res, piece, lo, bound)
+                    busy[k % depth] = fut
+                    pieces.append(fut)
+                else:
+                    pieces.append(replay(k, res, piece, lo, bound))
             if reader is not None:
                 reader.join()
                 pend = launch(k + 1, nxt[0])              # (its buffers were window k-1's: both copies of it are finished)
+        for pc in pieces:                                 # in window order
+            data, st, secs = pc.result() if hasattr(pc, "result") else pc
+            t_replay += secs
+            tapf.write(data)
+            total += len(data)
+            for key in ("blocks", "tapemarks", "events_delivered", "exact_scans"):
+                stats[key] += int(st[key])
         if total > 0:
             tapf.write(b"\xff\xff\xff\xff")                   # src/readtape.c:1885
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t_start
     os.close(fd)
+    if pool:
+        pool.shutdown()
+        fe_exact.close()
     fe.close()
     stats.update(rows=data_end[0], seconds=dt, msamples_per_s=data_end[0] / dt / 1e6, replay_seconds=t_replay, read_seconds=t_read[0], scan_wait_seconds=t_wait,
                  replay_events_per_s=(stats["events_delivered"] / t_replay) if t_replay > 0 else None, tap_bytes=total + (4 if total else 0))

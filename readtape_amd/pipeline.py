@@ -85,13 +85,18 @@ def frontend_parmsets(full):
     return [(p.pkww_bitfrac, p.pkww_rise, p.min_peak, p.agc_alpha, p.agc_window, p.clk_factor) for p in full]
 
 
-def _exact_callbacks(fe, rows, ntrks, fe_factory=None):
+def _exact_callbacks(fe, rows, ntrks, fe_factory=None, lock=None):
     """The callbacks through which the host replay asks for an exact device scan of one attempt (rtfe_scan_exact)."""
+    import contextlib
     import dataclasses
     keep = {}
     big = []                                          # a front end with room for an event every other row (noise): built on demand
 
     def exact(user, reset_row, end_row, parmset, burst_out, counts_out, events_out, cap_out):
+        with (lock or contextlib.nullcontext()):
+            return exact_locked(reset_row, end_row, parmset, burst_out, counts_out, events_out, cap_out)
+
+    def exact_locked(reset_row, end_row, parmset, burst_out, counts_out, events_out, cap_out):
         try:
             ex = fe.scan_exact(rows, reset_row, end_row, parmset_mask=1 << parmset).fetch()
             if int(ex.bursts[0]["flags"]) & frontend.F_SCREEN_UNDERFLOW:
@@ -343,8 +348,10 @@ def scan_fragment(fe, rows_with_halo, own_rows, lo, is_first, is_last, stream=No
     return finish
 
 
-def decode_fragment(hdr, cfg, fe, res, rows_with_halo, lo, start_row, stop_row, tap_path, full, opts, fe_factory=None, log_path=None, evt_path=None):
-    """Host replay of one scanned fragment -> its piece of the .tap (no end marker).  Returns the replay statistics."""
+def decode_fragment(hdr, cfg, fe, res, rows_with_halo, lo, start_row, stop_row, tap_path, full, opts, fe_factory=None, log_path=None, evt_path=None,
+                    exact_lock=None):
+    """Host replay of one scanned fragment -> its piece of the .tap (no end marker).  Returns the replay statistics.
+    exact_lock: several fragments are replayed side by side and share `fe` for their exact rescans: one at a time."""
     from readtape_amd import shard
     lib = _load_decode_lib()
     o = _Options(mode=hdr.mode, ntrks=hdr.ntrks, bpi=cfg.bpi, ips=cfg.ips, specified_parity=0 if opts.even_parity else 1,
@@ -352,7 +359,7 @@ def decode_fragment(hdr, cfg, fe, res, rows_with_halo, lo, start_row, stop_row, 
                  multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
     parr = (_Parms * len(full))(*full)
     W = (C.c_int * len(full))(*fe.widths)
-    exact, free, keep = _exact_callbacks(fe, rows_with_halo, hdr.ntrks, fe_factory)
+    exact, free, keep = _exact_callbacks(fe, rows_with_halo, hdr.ntrks, fe_factory, lock=exact_lock)
     st = _Stats()
     bursts = np.ascontiguousarray(shard.absolute_bursts(res, lo))
     counts = np.ascontiguousarray(res.counts)

@@ -13,8 +13,9 @@ def _whole(hdr, rows, path):
     return open(path, "rb").read()
 
 
+@pytest.mark.parametrize("threads", [1, 4])
 @pytest.mark.parametrize("kind,window,halo", [("nrzi", 1 << 16, 1 << 12), ("nrzi", 1 << 14, 1 << 10), ("pe", 1 << 15, 1 << 13), ("gcr", 1 << 15, 1 << 13)])
-def test_streamed_windows_write_the_whole_tape_tap(kind, window, halo, tmp_path):
+def test_streamed_windows_write_the_whole_tape_tap(kind, window, halo, threads, tmp_path):
     """Windows far shorter than the tape, halos shorter than a block (so the halo has to grow): same bytes."""
     if kind == "nrzi":
         tape = synth.nrzi_tape(seed=71, nblocks=40, minlen=200, maxlen=1500, marks_every=7, gap_samples=3000)
@@ -26,7 +27,7 @@ def test_streamed_windows_write_the_whole_tape_tap(kind, window, halo, tmp_path)
     want = _whole(hdr, tape.rows, str(tmp_path / "whole.tap"))
     path = str(tmp_path / "t.tbin")
     tbin.write_tbin(path, hdr, tape.rows)
-    st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=window, halo_rows=halo)
+    st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=window, halo_rows=halo, replay_threads=threads)
     got = open(tmp_path / "s.tap", "rb").read()
     assert got == want
     assert st["rows"] == tape.rows.shape[0] and st["windows"] >= 3 and st["blocks"] > 0
