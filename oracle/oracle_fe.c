@@ -239,6 +239,8 @@ static enum rt_bstate process_sample(struct ofe *fe, const float *voltage) {
       if (d->opt.mode == RT_GCR && rt_gcr_idle_due(d, t))
          if (rt_gcr_go_idle(d, t)) goto exit; }
 
+   if (d->opt.mode == RT_WW && rt_ww_end_due(d)) rt_ww_end_of_block(d);      /* the clock has stopped (src/decoder.c:892-894) */
+
 exit:
    if (fe->eob_row < 0 && d->results[d->parmset].blktype != RT_BS_NONE) fe->eob_row = fe->pos - 1;   /* row at which the block ended */
    if (d->interblock_counter) {
@@ -254,7 +256,7 @@ int ofe_readblock(void *ctx, int retry) {
    enum rt_bstate blockkind = RT_BS_NONE;
    int samples_per_bit = rt_samples_per_bit(d);
    fe->eob_row = -1;
-   ofe_reset_detectors(fe);                   /* what init_trackstate does to detector state, src/decoder.c:432,437 */
+   if (d->opt.mode != RT_WW) ofe_reset_detectors(fe);     /* what init_trackstate does to detector state, src/decoder.c:432,437 (Whirlwind: once per tape, src/readtape.c:1674) */
    if (fe->on_attempt_start) fe->on_attempt_start(fe, fe->pos);
    do {
       if (!retry) ++fe->lines_in;

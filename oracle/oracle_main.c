@@ -88,6 +88,11 @@ int main(int argc, char **argv) {
       if (!strcmp(a, "-nrzi")) mode_arg = RT_NRZI;
       else if (!strcmp(a, "-pe")) mode_arg = RT_PE;
       else if (!strcmp(a, "-gcr")) mode_arg = RT_GCR;
+      else if (!strcmp(a, "-whirlwind")) { mode_arg = RT_WW; bpi_arg = 100; }          /* src/readtape.c:947-948 */
+      else if (!strcmp(a, "-fluxdir=pos")) opt.ww_fluxdir = RT_FLUX_POS;
+      else if (!strcmp(a, "-fluxdir=neg")) opt.ww_fluxdir = RT_FLUX_NEG;
+      else if (!strcmp(a, "-fluxdir=auto")) opt.ww_fluxdir = RT_FLUX_AUTO;
+      else if (!strcmp(a, "-reverse")) opt.ww_reverse = 1;
       else if (!strncmp(a, "-ntrks=", 7)) ntrks_arg = atoi(a + 7);
       else if (!strncmp(a, "-bpi=", 5)) bpi_arg = (float)atof(a + 5);
       else if (!strncmp(a, "-ips=", 5)) ips_arg = (float)atof(a + 5);
@@ -143,8 +148,18 @@ int main(int argc, char **argv) {
       int16_t *dec = (int16_t *)malloc((size_t)(nkeep > 0 ? nkeep : 1) * (size_t)nheads * 2);
       for (int64_t k = 0; k < nkeep; ++k) memcpy(dec + k * nheads, rows + ((k + 1) * subsample - 1) * nheads, (size_t)nheads * 2);
       rows = dec; nrows = nkeep; }
+   if (opt.mode == RT_WW) {                                  /* the roles of the heads: -order= or the TBINORD extension (src/readtape.c:883-902) */
+      char hdr_order[21] = {0};
+      if (flags & 2) memcpy(hdr_order, buf + 240 + 8, 20);
+      const char *ord = orderarg ? orderarg : (hdr_order[0] ? hdr_order : "CMLcml");
+      if ((int)strlen(ord) != nheads || strchr(ord, 'x')) { fprintf(stderr, "Whirlwind -order must name every head\n"); return 2; }
+      snprintf(opt.ww_order, sizeof opt.ww_order, "%s", ord);
+      opt.ntrks = nheads;
+      orderarg = NULL; flags &= ~3u;                         /* (no permutation below: head h is track h) */
+      if (opt.bpi == 0) opt.bpi = 100; }
    float sample_deltat = (float)(int64_t)tdelta / 1e9f;      /* src/readtape.c:1345 */
    struct rt_dec *d = rt_dec_new(&opt, sample_deltat, (int64_t)tdelta);
+   if (!d) { fprintf(stderr, "bad decoder options\n"); return 2; }
    if (parmfile) {
       size_t plen; unsigned char *ptxt = slurp(parmfile, &plen);
       if (!ptxt) { fprintf(stderr, "can't read %s\n", parmfile); return 2; }

@@ -18,7 +18,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
              "-ffp-contract=off",            # bit-exact parity: the reference is C99 on SSE2, no FMA
              "-fno-fast-math", "-Wall", "-Wno-unused-function",
              f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
-HOST_SRCS = ["rt_decode_common.c", "rt_decode_nrzi.c", "rt_decode_pe.c", "rt_decode_gcr.c", "rt_parmsets.c", "rt_driver.c", "rt_replay.c", "rt_csv.c"]
+HOST_SRCS = ["rt_decode_common.c", "rt_decode_nrzi.c", "rt_decode_pe.c", "rt_decode_gcr.c", "rt_decode_ww.c", "rt_parmsets.c", "rt_driver.c", "rt_replay.c", "rt_csv.c"]
 
 
 def _newer(target, deps):

@@ -109,6 +109,15 @@ struct rt_nrzi {            /* src/decoder.h:266-273 */
    int    post_counter;
 };
 
+struct rt_ww {              /* src/decoder.h:275-287: what survives from block to block */
+   struct rt_clkavg clkavg;
+   uint8_t datablock, blockmark_queued;
+   int    datacount;        /* 2-bit characters so far */
+   double t_lastpeak;       /* last peak on any track */
+   double t_lastclkpulsestart, t_lastclkpulseend, t_lastpriclkpulsestart, t_lastaltclkpulsestart, t_lastpriclkpulseend, t_lastblockmark;
+};
+enum { RT_FLUX_NEG = 0, RT_FLUX_POS = 1, RT_FLUX_AUTO = 2 };      /* -fluxdir= (src/readtape.c:966-968) */
+
 struct rt_options {         /* the command-line switches that reach the decoders (src/readtape.c:936-1022) */
    enum rt_mode mode;
    int   ntrks;
@@ -122,6 +131,9 @@ struct rt_options {         /* the command-line switches that reach the decoders
    int   tap_format;        /* -tap */
    int   add_parity;
    int   verbose;           /* -v: log every block */
+   int   ww_fluxdir;        /* Whirlwind: RT_FLUX_NEG (default) / POS / AUTO */
+   int   ww_reverse;        /* Whirlwind -reverse: the tape was read backwards */
+   char  ww_order[24];      /* Whirlwind -order=: a role letter per head (CLMclm, x = unused) */
 };
 
 #define RT_ESTDEN_NUMBINS 150      /* src/decoder.c:333-338 */
@@ -143,6 +155,9 @@ struct rt_dec {
    int     expected_parity;
    struct rt_trk trk[RT_MAXTRKS];
    struct rt_nrzi nrzi;
+   struct rt_ww ww;
+   int     ww_type_to_trk[6], ww_trk_to_type[RT_MAXTRKS];      /* role <-> track (src/readtape.c:521-522) */
+   int     flux_current, num_flux_polarity_changes;
    struct { int bitnum, bytenum; uint8_t sgroup[9]; int bad_parity_in_dgroup; } gcr;   /* src/decode_gcr.c:37,444-445 */
    /* block state (src/decoder.h:327-359) */
    int     tries, parmset;
@@ -214,6 +229,15 @@ int  rt_gcr_go_idle(struct rt_dec *d, struct rt_trk *t);       /* src/decoder.c:
 void rt_gcr_end_of_block(struct rt_dec *d);                    /* src/decode_gcr.c:682-729 */
 void rt_force_end_of_block(struct rt_dec *d);                  /* src/readtape.c:1378-1381 */
 void rt_finish_attempt(struct rt_dec *d);                      /* src/readtape.c:1508-1515 */
+
+/* Whirlwind (src/decode_ww.c) */
+int  rt_ww_assign_roles(struct rt_dec *d, const char *order, int *head_to_trk);   /* src/readtape.c:869-902; returns ntrks or -1 */
+void rt_ww_init_blockstate(struct rt_dec *d);                 /* src/decode_ww.c:33-49 */
+int  rt_ww_end_due(const struct rt_dec *d);                   /* src/decoder.c:892-894 */
+void rt_ww_end_of_block(struct rt_dec *d);                    /* src/decode_ww.c:141-161 */
+void rt_ww_blockmark(struct rt_dec *d);                       /* src/decode_ww.c:163-167 */
+void rt_ww_top(struct rt_dec *d, struct rt_trk *t);
+void rt_ww_bot(struct rt_dec *d, struct rt_trk *t);
 
 /* format callbacks (src/decode_*.c) */
 void rt_nrzi_top(struct rt_dec *d, struct rt_trk *t);

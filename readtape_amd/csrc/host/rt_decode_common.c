@@ -26,6 +26,8 @@ struct rt_dec *rt_dec_new(const struct rt_options *opt, float sample_deltat, int
    d->data_time = (double *)calloc(RT_MAXBLOCK + 1 + RT_DATA_GUARD, sizeof(double)) + RT_DATA_GUARD;
    d->expected_parity = opt->specified_parity;
    rt_default_parmsets(opt->mode, d->parmsets);
+   d->flux_current = RT_FLUX_AUTO;                            /* src/readtape.c:515 */
+   if (opt->mode == RT_WW && rt_ww_assign_roles(d, d->opt.ww_order[0] ? d->opt.ww_order : "CMLcml", NULL) != opt->ntrks) { rt_dec_free(d); return NULL; }
    return d; }
 
 void rt_dec_free(struct rt_dec *d) {
@@ -83,7 +85,10 @@ void rt_init_trackstate(struct rt_dec *d) {       /* src/decoder.c:425-455 */
       t->t_clkwindow = t->clkavg.t_bitspaceavg / 2 * RT_PARM(d).clk_factor; }
    if (d->opt.mode == RT_NRZI) {
       memset(&d->nrzi, 0, sizeof d->nrzi);
-      if (!d->doing_density_detection) rt_init_clkavg(&d->nrzi.clkavg, 1 / (bpi * ips)); } }
+      if (!d->doing_density_detection) rt_init_clkavg(&d->nrzi.clkavg, 1 / (bpi * ips)); }
+   if (d->opt.mode == RT_WW) {                                /* (Whirlwind: once per tape, src/readtape.c:1674) */
+      memset(&d->ww, 0, sizeof d->ww);
+      if (!d->doing_density_detection) rt_init_clkavg(&d->ww.clkavg, 1 / (bpi * ips)); } }
 
 void rt_set_expected_parity(struct rt_dec *d, int blklength) {   /* src/decoder.c:457-460 */
    d->expected_parity = blklength > 0 && blklength == d->opt.revparity
@@ -165,6 +170,7 @@ void rt_up_transition(struct rt_dec *d, struct rt_trk *t) {   /* src/decoder.c:5
    case RT_PE:   rt_pe_top(d, t); break;
    case RT_NRZI: rt_nrzi_top(d, t); break;
    case RT_GCR:  rt_gcr_top(d, t); break;
+   case RT_WW:   rt_ww_top(d, t); break;
    default: break; }
    t->v_lasttop = t->v_top;
    t->v_lastpeak = t->v_top;
@@ -180,6 +186,7 @@ void rt_down_transition(struct rt_dec *d, struct rt_trk *t) {   /* src/decoder.c
    case RT_PE:   rt_pe_bot(d, t); break;
    case RT_NRZI: rt_nrzi_bot(d, t); break;
    case RT_GCR:  rt_gcr_bot(d, t); break;
+   case RT_WW:   rt_ww_bot(d, t); break;
    default: break; }
    t->v_lastbot = t->v_bot;
    t->t_lastbot = t->t_bot;

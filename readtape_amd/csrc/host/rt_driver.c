@@ -73,7 +73,9 @@ static const char *format_block_errors(struct rt_dec *d, struct rt_results *resu
       if (result->vparity_errs) p += sprintf(p, ", %d parity", result->vparity_errs);
       if (result->crc_errs) p += sprintf(p, ", %d CRC", result->crc_errs);
       if (result->lrc_errs) p += sprintf(p, ", 1 LRC");
-      if (result->ecc_errs) p += sprintf(p, ", %d ECC", result->ecc_errs); }
+      if (result->ecc_errs) p += sprintf(p, ", %d ECC", result->ecc_errs);
+      if (result->ww_bad_length) p += sprintf(p, ", bad length");
+      if (result->ww_speed_err) p += sprintf(p, ", bad speed"); }
    else p += sprintf(p, "ok");
    if (result->warncount > 0) {
       p += sprintf(p, ", %d warning%s", result->warncount, result->warncount > 1 ? "s" : "");
@@ -87,7 +89,10 @@ static const char *format_block_errors(struct rt_dec *d, struct rt_results *resu
          int length = result->minbits, nbits = 0, ntrk = 0; uint16_t faked = 0;
          for (int i = 0; i < length; ++i) { uint16_t v = d->data_faked[i]; faked |= v; for (; v; ++nbits) v &= v - 1; }
          for (; faked; ++ntrk) faked &= faked - 1;
-         if (nbits > 0) p += sprintf(p, ", %d faked bits on %d trks", nbits, ntrk); } }
+         if (nbits > 0) p += sprintf(p, ", %d faked bits on %d trks", nbits, ntrk); }
+      if (result->ww_leading_clock) p += sprintf(p, ", leading clk");
+      if (result->ww_missing_onebit) p += sprintf(p, ", missing 1-bit");
+      if (result->ww_missing_clock) p += sprintf(p, ", missing clk"); }
    return buf; }
 
 void rt_got_datablock(struct rt_dec *d, int badblock) {   /* src/readtape.c:1212-1313 (no labels, no text file) */
@@ -148,9 +153,11 @@ void rt_write_summary(struct rt_dec *d, const char *infilename, double elapsed) 
         d->numtapemarks, d->numblks, commas(d->numdatabytes, cb), d->timenow - d->data_start_time);
    if (d->last_block_time) rlog(d, "  the last block written was %.8lf seconds into the tape\n", d->last_block_time);
    rlog(d, "  %d block%s had errors, %d had warnings", d->numblks_err, d->numblks_err != 1 ? "s" : "", d->numblks_warn);
-   rlog(d, ", %d had mismatched tracks, %d had bits corrected", d->numblks_trksmismatched, d->numblks_corrected);
+   if (d->opt.mode != RT_WW) rlog(d, ", %d had mismatched tracks, %d had bits corrected", d->numblks_trksmismatched, d->numblks_corrected);
    if (d->opt.mode == RT_NRZI) rlog(d, ", %d had midbit timing errors", d->numblks_midbiterrs);
    rlog(d, "\n");
+   if (d->opt.mode == RT_WW && d->num_flux_polarity_changes > 0)
+      rlog(d, "  the flux polarity changed %d time%s during decoding\n", d->num_flux_polarity_changes, d->num_flux_polarity_changes > 1 ? "s" : "");
    if (d->numblks_unusable > 0) rlog(d, "  %d blocks were unusable and were not written\n", d->numblks_unusable);
    if (!d->opt.multiple_tries) return;
    rlog(d, "  %d good blocks had to try more than one parmset\n", d->numblks_goodmultiple);
@@ -197,7 +204,9 @@ static int best_attempt(const struct rt_dec *d, int *tier_out) {
 
 int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit) {
    int all_clean = 1, out_of_data = 0;
+   const int ww = d->opt.mode == RT_WW;
    d->interblock_counter = 0;
+   if (ww) rt_init_trackstate(d);                                 /* Whirlwind: once per tape - blocks may be one bit apart (src/readtape.c:1674) */
    while (!out_of_data && d->numblks < blklimit) {
       rt_init_blockstate(d);
       d->parmset = 0;
@@ -206,8 +215,11 @@ int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit) {
       int decoded_last, final = 0;
       for (;;) {                                                  /* attempts */
          decoded_last = d->parmset;
-         rt_init_trackstate(d);
-         out_of_data = !r->readblock(r->ctx, d->tries > 0);
+         if (ww) rt_ww_init_blockstate(d); else rt_init_trackstate(d);
+         if (ww && d->ww.blockmark_queued) {                      /* the block mark seen while the last block's end was being noticed */
+            rt_ww_blockmark(d);
+            d->t_blockstart = d->timenow - d->ww.clkavg.t_bitspaceavg; }
+         else out_of_data = !r->readblock(r->ctx, d->tries > 0);
          const struct rt_results *a = &d->results[d->parmset];
          if (a->blktype == RT_BS_NONE) { rt_tap_end(d); return all_clean; }      /* what was left of the data was no block */
          ++d->tries;

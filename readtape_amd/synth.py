@@ -188,7 +188,7 @@ def make_tape(spec: TapeSpec, items: list, gap_samples: int = 5000) -> Tape:
         elif kind == "mark":
             cells, ncells, fs = encode_mark(spec)
         elif kind == "raw":
-            cells, ncells, fs = it[1], it[2], None
+            cells, ncells, fs = it[1], it[2], (it[3] if len(it) > 3 else None)
         else:
             raise ValueError(kind)
         v = _render_block(spec, rng, cells, ncells, per_track_first_sign=fs)
@@ -398,4 +398,61 @@ def pe_tape(seed: int = 1, nblocks: int = 3, minlen: int = 64, maxlen: int = 300
     spec = pe_spec(seed=seed, **kw)
     rng = np.random.default_rng(seed + 2000)
     items = [("block", p) for p in random_payloads(rng, nblocks, minlen, maxlen)]
+    return make_tape(spec, items, gap_samples=gap_samples)
+
+
+# --------------------------------------------------------------------------------------------
+# Whirlwind I (6 tracks, 100 BPI): two data tracks (the MSB and LSB of a 2-bit character) and a clock track, each recorded
+# twice (src/decode_ww.c, src/readtape.c:367).  A bit is a PULSE - a flux change and its return, here 0.35 cell apart, the
+# negative half first (-fluxdir=neg, the reference's default).  Every cell has a clock pulse; a data track has a pulse where its
+# bit is one.  A block is a run of 16-bit words, eight characters each, most significant first; a block mark is a lone pulse on
+# the LSB tracks while the clock is silent.
+# --------------------------------------------------------------------------------------------
+WW_ORDER = "CMLcml"
+
+
+def ww_spec(seed: int = 1, **kw) -> TapeSpec:
+    kw.setdefault("pulse_w", 0.07)
+    kw.setdefault("amplitude", 2.0)
+    kw.setdefault("amp_slope", 0.02)
+    kw.setdefault("jitter", 0.01)
+    return TapeSpec(mode=tbin.MODE_WW, ntrks=6, bpi=100.0, ips=50.0, tdelta_ns=5000, maxvolts=4.4, seed=seed,
+                    flags=tbin.FLAG_NO_REORDER, trkorder=WW_ORDER, **kw)
+
+
+def _ww_pulses(cells_with_pulse):
+    c = np.asarray(cells_with_pulse, dtype=np.float64)
+    return np.sort(np.concatenate([c, c + 0.35]))
+
+
+def ww_block_cells(words: list[int]):
+    """per-track transition positions (cell units) of a block of 16-bit words, tracks in WW_ORDER; -> (cells, ncells, first signs)"""
+    chars = []
+    for w in words:
+        for k in range(8):
+            chars.append((w >> (14 - 2 * k)) & 3)
+    n = len(chars)
+    clk = list(range(n))
+    msb = [i for i, c in enumerate(chars) if c & 2]
+    lsb = [i for i, c in enumerate(chars) if c & 1]
+    by_type = {"C": clk, "c": clk, "M": msb, "m": msb, "L": lsb, "l": lsb}
+    return [_ww_pulses(by_type[ch]) for ch in WW_ORDER], float(n), [-1] * 6
+
+
+def ww_mark_cells():
+    by_type = {"C": [], "c": [], "M": [], "m": [], "L": [0], "l": [0]}
+    return [_ww_pulses(by_type[ch]) for ch in WW_ORDER], 1.0, [-1] * 6
+
+
+def ww_tape(seed: int = 1, nblocks: int = 4, minwords: int = 4, maxwords: int = 24, marks_every: int = 0, gap_samples: int = 800, **kw) -> Tape:
+    spec = ww_spec(seed=seed, **kw)
+    rng = np.random.default_rng(seed + 4000)
+    items = []
+    for i in range(nblocks):
+        words = [int(x) for x in rng.integers(0, 1 << 16, size=int(rng.integers(minwords, maxwords + 1)))]
+        cells, n, fs = ww_block_cells(words)
+        items.append(("raw", cells, n, fs))
+        if marks_every and (i + 1) % marks_every == 0:
+            cells, n, fs = ww_mark_cells()
+            items.append(("raw", cells, n, fs))
     return make_tape(spec, items, gap_samples=gap_samples)

@@ -38,6 +38,27 @@ def case_gcr(seed=16):
     return synth.gcr_tape(seed=seed, nblocks=2, minlen=40, maxlen=160, gap_samples=2500)
 
 
+def case_ww(seed=41):
+    return synth.ww_tape(seed=seed, nblocks=5, minwords=3, maxwords=14, marks_every=2, gap_samples=700)
+
+
+def case_ww_pos(seed=42):
+    # the other polarity: the positive half of every pulse first
+    t = synth.ww_tape(seed=seed, nblocks=4, minwords=3, maxwords=12, marks_every=3, gap_samples=700)
+    t.rows = (-t.rows.astype(np.int32)).clip(-32767, 32767).astype(np.int16)
+    return t
+
+
+def case_ww_rough(seed=43):
+    # noise, jitter and a weak alternate set of tracks: missing-bit / missing-clock warnings, odd lengths
+    return synth.ww_tape(seed=seed, nblocks=6, minwords=2, maxwords=10, marks_every=2, gap_samples=500, noise_mv=60.0, jitter=0.05, amp_slope=-0.1)
+
+
+def case_ww_close(seed=44):
+    # blocks and block marks only a few bit times apart (the state that survives from block to block matters most here)
+    return synth.ww_tape(seed=seed, nblocks=8, minwords=1, maxwords=4, marks_every=1, gap_samples=130)
+
+
 def case_gcr_noisy(seed=17):
     return synth.gcr_tape(seed=seed, nblocks=2, minlen=40, maxlen=120, gap_samples=2500, noise_mv=45.0, jitter=0.05, amplitude=1.2)
 
@@ -206,6 +227,14 @@ CASES = {
     "nrzi9_cut_zeros": (case_nrzi9_cut, ["-nrzi", "-zeros"],            ["-zeros"]),
     "noise_only":   (case_noise_only, ["-nrzi"],                       []),
     "tiny":         (case_tiny,       ["-nrzi"],                       []),
+    "ww":           (case_ww,         [],                              []),
+    "ww_auto":      (case_ww,         ["-fluxdir=auto"],               ["-fluxdir=auto"]),
+    "ww_pos":       (case_ww_pos,     ["-fluxdir=pos"],                ["-fluxdir=pos"]),
+    "ww_pos_auto":  (case_ww_pos,     ["-fluxdir=auto"],               ["-fluxdir=auto"]),
+    "ww_wrongdir":  (case_ww_pos,     [],                              []),
+    "ww_reverse":   (case_ww,         ["-reverse"],                    ["-reverse"]),
+    "ww_rough":     (case_ww_rough,   [],                              []),
+    "ww_close":     (case_ww_close,   ["-fluxdir=auto"],               ["-fluxdir=auto"]),
     "nrzi7_order":  (case_nrzi7_order, ["-nrzi", "-ntrks=7", "-order=543210p"], ["-order=543210p"]),
     "pe_order":     (case_pe_order,   ["-pe", "-order=01234576p"],     ["-order=01234576p"]),
     "gcr_order_m":  (case_gcr_order,  ["-gcr", "-m"],                  ["-m"]),
