@@ -178,6 +178,27 @@ int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out);
 int         rtfe_kernel_count(void);
 const char *rtfe_kernel_name(int i);
 
+/* ---- Whirlwind (mode RTFE_WW): detector state that survives block attempts ----
+ * The reference never restarts its detector between Whirlwind blocks (src/readtape.c:1674, src/decode_ww.c:31-49); a new attempt
+ * only re-seeds every track's window (ring slot 0 and both extremes, src/decoder.c:855-861), one track per sample.  Where an
+ * attempt starts is the host decoder's decision, so the host hands the state in and gets it back:
+ *   rtfe_ww_scan: rows [first_row, first_row + nscan) of d_rows from the state d_state_in (one rtfe_ww_track per track; a tape
+ *   starts from rtfe_ww_initial_state), the attempt they belong to having started at seed_row0 (<= first_row: track t sits out
+ *   rows < seed_row0 + t and is re-seeded at seed_row0 + t).  Out: per-track event lists (event.sample relative to first_row;
+ *   d_events[t * event_capacity ...], d_counts[t]), the state after the last row (d_state_out, may alias d_state_in), *d_flags |=
+ *   RTFE_F_* conditions.  One parameter set (the reference forbids -m for Whirlwind), no deskew delays, peak detection only.
+ * Replaces: the per-sample lookfor_peak of src/decoder.c:751-810 for mode WW, at the seam of src/decoder.c:586,604. */
+typedef struct rtfe_ww_track {
+   int16_t ring[64];                /* pkww_v as int16 codes (after -invert) */
+   int32_t left, right, maxv, minv, countdown, peakcount, heightndx, pad;
+   float   agc_gain, v_avg_height, v_lasttop, v_lastbot, v_top, v_bot;
+   float   heights[10];
+} rtfe_ww_track;                     /* 224 bytes */
+void rtfe_ww_initial_state(rtfe_ww_track *tracks, int ntrks);        /* init_trackstate, src/decoder.c:425-455 (host memory) */
+int rtfe_ww_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base, int64_t first_row, int64_t nscan, int64_t seed_row0,
+                 const rtfe_ww_track *d_state_in, rtfe_ww_track *d_state_out, uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,
+                 uint32_t *d_flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

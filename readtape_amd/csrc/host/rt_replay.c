@@ -411,3 +411,127 @@ int rt_replay_run_named(const struct rt_options *opt, const struct rt_parms *par
                   const char *out_base, const char *in_name, const char *log_path, const char *evt_path, int append, struct rt_replay_stats *stats) {
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
                      exact, exact_free, user, NULL, log_path, evt_path, stats, append, NULL, 0, INT64_MAX, 0, out_base, in_name); }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Whirlwind: one chain per tape.  The device detector's state is handed from attempt to attempt (and from chunk to chunk of
+ * an attempt); an attempt starts by re-seeding the tracks one per row (src/decoder.c:855-861, after src/decode_ww.c:45 zeroed
+ * t_lastpeak) and ends where the host decoder says the clock has stopped (src/decoder.c:892-894) or a block mark was seen.
+ * --------------------------------------------------------------------------------------------------------------------- */
+static int pred_ww(const struct rt_dec *d, const struct rt_trk *t, double timenow) {
+   (void)t;
+   return timenow - d->ww.t_lastclkpulseend > d->ww.clkavg.t_bitspaceavg * 1.5f; }             /* WW_CLKSTOP_BITS */
+
+static int ww_readblock(void *ctx, int retry) {
+   struct rt_replay *rp = (struct rt_replay *)ctx;
+   struct rt_dec *d = rp->d;
+   const int ntrks = rp->ntrks, W = rp->W[0];
+   const size_t sbytes = (size_t)ntrks * sizeof(rtfe_ww_track);
+   const int64_t s0 = rp->pos, nrows = rp->nrows, L = rp->ww_chunk_rows;
+   int endfile = 0;
+   (void)retry;
+   ++rp->attempts;
+   if (s0 >= nrows) { rt_finish_attempt(d); return 0; }
+   int64_t chunk_first = s0;
+   memcpy(rp->ww_chunk_state, rp->ww_state, sbytes);
+   struct evsrc src; memset(&src, 0, sizeof src);
+   int have_chunk = 0;
+   int64_t row = s0;
+   for (;;) {
+      if (!have_chunk) {                                      /* the events of rows [chunk_first, chunk_first + L) */
+         if (rp->ww_scan(rp->ww_user, chunk_first, L, s0, rp->ww_chunk_state, rp->ww_chunk_end, rp->ww_counts, rp->ww_events, rp->ww_cap) != 0) {
+            ++rp->device_failures; d->results[d->parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
+         for (int t = 0; t < ntrks; ++t) { src.list[t] = rp->ww_events + (size_t)t * rp->ww_cap; src.n[t] = rp->ww_counts[t]; src.at[t] = 0; }
+         src.reset = chunk_first; src.end = chunk_first + L;
+         ++rp->exact_scans;
+         have_chunk = 1; }
+      /* ---- the next row at which anything can happen ---- */
+      int64_t next = nrows;
+      if (row < s0 + ntrks) next = row;                       /* the rows on which the tracks are re-seeded, one by one */
+      { const int64_t r = evsrc_next_row(&src, ntrks); if (r < next) next = r; }
+      if (d->ww.datablock && d->ww.t_lastclkpulseend > 0) {
+         const int64_t r = first_row_where(rp, pred_ww, NULL, d->ww.t_lastclkpulseend + d->ww.clkavg.t_bitspaceavg * 1.5f, row, next);
+         if (r < next) next = r; }
+      if (next >= src.end && src.end < nrows) {               /* nothing more in this chunk: the next one starts from the state behind it */
+         chunk_first = src.end;
+         memcpy(rp->ww_chunk_state, rp->ww_chunk_end, sbytes);
+         have_chunk = 0;
+         if (row < chunk_first) row = chunk_first;
+         continue; }
+      if (next >= nrows) {                                    /* end of data (src/readtape.c:1410-1413; force_end_of_block has no Whirlwind branch) */
+         d->timenow = time_of_row(rp, nrows - 1);
+         rp->pos = nrows;
+         endfile = 1;
+         break; }
+      row = next;
+      rp->cur_row = row;
+      d->timenow = time_of_row(rp, row);
+      for (int t = 0; t < ntrks; ++t) {                       /* process_sample, src/decoder.c:846-866 */
+         struct rt_trk *tk = &d->trk[t];
+         if (tk->t_lastpeak == 0) {                            /* first sample of this track in this attempt */
+            tk->v_lastpeak = 0;
+            tk->t_lastpeak = d->timenow;
+            break; }
+         while (src.at[t] < src.n[t] && src.reset + src.list[t][src.at[t]].sample == row) {
+            if (src.list[t][src.at[t]].flags & RTFE_EV_FATAL) {
+               rp->reference_fatal = 1; rp->fatal_row = row; rp->fatal_trk = t;
+               d->results[d->parmset].blktype = RT_BS_ABORTED;
+               rt_finish_attempt(d);
+               return 0; }
+            deliver(rp, &src, t, &src.list[t][src.at[t]], W);
+            ++src.at[t]; } }
+      evsrc_skip_before(&src, ntrks, row + 1);
+      if (rt_ww_end_due(d)) rt_ww_end_of_block(d);             /* src/decoder.c:892-894 */
+      if (d->results[d->parmset].blktype != RT_BS_NONE) { rp->pos = row + 1; break; }
+      ++row; }
+   if (!endfile) {
+      /* where the next attempt starts: the detector's state behind the block's last row */
+      const int64_t last = rp->pos - 1;
+      if (rp->ww_scan(rp->ww_user, chunk_first, last - chunk_first + 1, s0, rp->ww_chunk_state, rp->ww_state, rp->ww_counts, rp->ww_events, rp->ww_cap) != 0) {
+         ++rp->device_failures; d->results[d->parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; } }
+   rt_finish_attempt(d);
+   return !endfile; }
+
+int rt_replay_run_ww(const struct rt_options *opt, const struct rt_parms *parmsets,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int W0, rt_ww_scan_fn scan, void *user, const void *initial_state, int64_t chunk_rows,
+                  const char *tap_path, const char *out_base, const char *in_name, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
+   const float sample_deltat = (float)tdelta_ns / 1e9f;
+   struct rt_options o = *opt;
+   o.multiple_tries = 0;                                       /* "not implemented yet for Whirlwind" (src/readtape.c:1987) */
+   struct rt_dec *d = rt_dec_new(&o, sample_deltat, tdelta_ns);
+   if (!d) return -1;
+   if (parmsets) { memset(d->parmsets, 0, sizeof d->parmsets); memcpy(d->parmsets, parmsets, sizeof(struct rt_parms)); }
+   else for (int i = 1; i < RT_MAXPARMSETS; ++i) d->parmsets[i].active = 0;
+   if (out_base) snprintf(d->outbase, sizeof d->outbase, "%s", out_base);
+   else if (tap_path) d->tapf = fopen(tap_path, "wb");
+   if (log_path) d->logf = fopen(log_path, "w");
+   struct rt_replay rp; memset(&rp, 0, sizeof rp);
+   rp.d = d; rp.ntrks = o.ntrks; rp.nparm = 1; rp.W[0] = W0;
+   rp.nrows = nrows; rp.tstart_ns = tstart_ns; rp.tdelta_ns = tdelta_ns; rp.stop_row = INT64_MAX;
+   rp.ww_scan = scan; rp.ww_user = user;
+   rp.ww_chunk_rows = chunk_rows > 64 ? chunk_rows : 64;
+   rp.ww_cap = (uint32_t)rp.ww_chunk_rows;                     /* (no more events than rows) */
+   const size_t sbytes = (size_t)o.ntrks * sizeof(rtfe_ww_track);
+   rp.ww_state = (unsigned char *)malloc(3 * sbytes); rp.ww_chunk_state = rp.ww_state + sbytes; rp.ww_chunk_end = rp.ww_state + 2 * sbytes;
+   memcpy(rp.ww_state, initial_state, sbytes);
+   rp.ww_events = (rtfe_event *)malloc((size_t)o.ntrks * rp.ww_cap * sizeof(rtfe_event));
+   rp.ww_counts = (uint32_t *)calloc((size_t)o.ntrks, sizeof(uint32_t));
+   if (evt_path) {
+      rp.evtf = fopen(evt_path, "wb");
+      if (rp.evtf) { d->on_transition = dump_transition; d->on_attempt = dump_attempt; d->user = &rp; } }
+   const double wall0 = (double)time(NULL);
+   struct rt_reader rd = { ww_readblock, rt_replay_save_pos, rt_replay_restore_pos, &rp };
+   const int ok = rt_process_blocks(d, &rd, 0x7fffffff);
+   if (in_name) rt_write_summary(d, in_name, difftime(time(NULL), (time_t)wall0));
+   if (stats) {
+      memset(stats, 0, sizeof *stats);
+      stats->attempts = rp.attempts; stats->exact_scans = rp.exact_scans; stats->events_delivered = rp.events_delivered; stats->agc_mismatches = rp.agc_mismatches;
+      stats->blocks = d->numblks; stats->tapemarks = d->numtapemarks; stats->blocks_with_errors = d->numblks_err;
+      stats->blocks_with_warnings = d->numblks_warn; stats->blocks_unusable = d->numblks_unusable; stats->all_ok = ok;
+      stats->data_bytes = d->numdatabytes; stats->device_failures = rp.device_failures;
+      stats->reference_fatal = rp.reference_fatal; stats->fatal_row = rp.fatal_row; stats->fatal_trk = rp.fatal_trk; }
+   if (d->tapf) fclose(d->tapf);
+   if (d->logf) fclose(d->logf);
+   if (rp.evtf) fclose(rp.evtf);
+   free(rp.ww_state); free(rp.ww_events); free(rp.ww_counts);
+   rt_dec_free(d);
+   return 0; }

@@ -15,6 +15,13 @@ typedef int  (*rt_exact_fn)(void *user, int64_t reset_row, int64_t end_row, int 
                             rtfe_burst *burst, uint32_t *counts, rtfe_event **events, uint32_t *cap);
 typedef void (*rt_exact_free_fn)(void *user, rtfe_event *events);
 
+/* Whirlwind: the device's peak detector keeps its state across attempts, so the replay fetches its events in chunks of rows, handing the
+ * state in and getting it back (include/rt_frontend.h: rtfe_ww_scan).  first_row / nscan / seed_row0 as there; state blobs are
+ * ntrks rtfe_ww_track each (host memory); events: [ntrks][cap] (sample relative to first_row), counts[ntrks].  Returns 0, or the
+ * RTFE_F_* flags of a scan that could not be delivered. */
+typedef int (*rt_ww_scan_fn)(void *user, int64_t first_row, int64_t nscan, int64_t seed_row0, const void *state_in, void *state_out,
+                             uint32_t *counts, rtfe_event *events, uint32_t cap);
+
 struct rt_replay {
    struct rt_dec *d;
    int     ntrks, nparm;
@@ -26,6 +33,10 @@ struct rt_replay {
    rt_exact_fn exact; rt_exact_free_fn exact_free; void *exact_user;
    int64_t pos, saved_pos, cur_row; double saved_time;
    int64_t stop_row;                   /* fragment decode: no attempt starts at or behind this row */
+   /* Whirlwind */
+   rt_ww_scan_fn ww_scan; void *ww_user;
+   unsigned char *ww_state, *ww_chunk_state, *ww_chunk_end;   /* ntrks rtfe_ww_track each: at the attempt's start / at the chunk's first row / behind the chunk */
+   rtfe_event *ww_events; uint32_t *ww_counts; uint32_t ww_cap; int64_t ww_chunk_rows;
    int     find_zeros;                 /* events are confirmed zero crossings: the slope gate is applied here */
    FILE   *evtf;                       /* optional dump of every delivered transition (oracle/ref_event_shim.c record format) */
    /* statistics */
@@ -77,6 +88,9 @@ int rt_replay_run_fragment(const struct rt_options *opt, const struct rt_parms *
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
                   int64_t start_row, int64_t stop_row);
+int rt_replay_run_ww(const struct rt_options *opt, const struct rt_parms *parmsets,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int W0, rt_ww_scan_fn scan, void *user, const void *initial_state, int64_t chunk_rows,
+                  const char *tap_path, const char *out_base, const char *in_name, const char *log_path, const char *evt_path, struct rt_replay_stats *stats);
 int rt_replay_run_named(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,

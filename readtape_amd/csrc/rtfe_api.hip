@@ -16,6 +16,7 @@
 #include "rtfe_kernels.hip"
 #include "rtfe_lwalk.hip"
 #include "rtfe_zeros.hip"
+#include "rtfe_ww.hip"
 #include "rtfe_chain.hip"
 
 namespace rtfe {
@@ -69,8 +70,10 @@ extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < kNumKerne
 extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (!c || !out) return fail(-1, "null argument");
    if (c->ntrks < 1 || c->ntrks > RTFE_MAXTRKS) return fail(-2, "ntrks %d out of range", c->ntrks);
-   if (c->mode != RTFE_NRZI && c->mode != RTFE_PE && c->mode != RTFE_GCR)
-      return fail(-3, "mode %d not supported by the device front end yet (Whirlwind: see DESIGN.md)", c->mode);
+   if (c->mode != RTFE_NRZI && c->mode != RTFE_PE && c->mode != RTFE_GCR && c->mode != RTFE_WW)
+      return fail(-3, "mode %d not known", c->mode);
+   if (c->mode == RTFE_WW && (c->nparmsets != 1 || c->find_zeros || c->differentiate))
+      return fail(-3, "Whirlwind: one parameter set, peak detection on the undifferentiated signal (rtfe_ww_scan)");
    if (c->nparmsets < 1 || c->nparmsets > RTFE_MAXPARMSETS) return fail(-5, "nparmsets %d out of range", c->nparmsets);
    if (c->nparmsets * c->ntrks > kDecodeThreads) return fail(-6, "nparmsets*ntrks > %d", kDecodeThreads);
    if (!(c->bpi >= 0) || !(c->ips > 0) || c->tdelta_ns <= 0 || !(c->maxvolts > 0)) return fail(-7, "ips, tdelta_ns and maxvolts must be positive, bpi >= 0");
@@ -385,6 +388,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                          rtfe_burst *d_bursts, int64_t max_bursts, int32_t *d_nbursts,
                          uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity, void *stream) {
    if (!h || !d_rows || !d_workspace || !d_bursts || !d_nbursts || !d_counts || !d_events) return fail(-1, "null argument");
+   if (h->dev.mode == RTFE_WW) return fail(-44, "Whirlwind tapes have no independent bursts: use rtfe_ww_scan");
    if (((uintptr_t)d_rows & 15) != 0) return fail(-31, "d_rows must be 16-byte aligned");
    if (workspace_bytes < rtfe_workspace_bytes(h, nrows)) return fail(-32, "workspace too small");
    if (nrows <= 0 || max_bursts < 1) return fail(-33, "nothing to scan");
@@ -588,3 +592,20 @@ extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nr
                       (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1,
                       (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeAll, (BurstCtl *)nullptr, (WalkState *)nullptr);
    return launch_check("rtfe_scan_exact"); }
+
+// ---- Whirlwind (include/rt_frontend.h) ----
+extern "C" void rtfe_ww_initial_state(rtfe_ww_track *tracks, int ntrks) {
+   memset(tracks, 0, sizeof(rtfe_ww_track) * (size_t)ntrks);
+   for (int t = 0; t < ntrks; ++t) { tracks[t].agc_gain = 1.0f; tracks[t].v_avg_height = 4.0f; } }
+
+extern "C" int rtfe_ww_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base, int64_t first_row, int64_t nscan, int64_t seed_row0,
+                            const rtfe_ww_track *d_state_in, rtfe_ww_track *d_state_out, uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,
+                            uint32_t *d_flags, void *stream) {
+   if (!h || !d_rows || !d_state_in || !d_state_out || !d_counts || !d_events || !d_flags) return fail(-1, "null argument");
+   if (h->dev.mode != RTFE_WW) return fail(-40, "rtfe_ww_scan: the handle was not made for mode RTFE_WW");
+   if (h->dev.find_zeros || h->dev.differentiate || h->dev.maxskew > 0 || h->dev.nparm != 1) return fail(-41, "rtfe_ww_scan: peak detection, one parameter set, no deskew delays");
+   if (h->dev.parm[0].W > kWwRing) return fail(-42, "window wider than the state's ring");
+   if (first_row < 0 || nscan <= 0 || first_row >= nrows || seed_row0 > first_row || event_capacity < 1) return fail(-43, "bad row range");
+   hipLaunchKernelGGL(k_ww, dim3(1), dim3(64), 0, (hipStream_t)stream, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base,
+                      (long long)first_row, (long long)nscan, (long long)seed_row0, d_state_in, d_state_out, d_counts, d_events, (long long)event_capacity, d_flags);
+   return launch_check("rtfe_ww_scan"); }

@@ -165,6 +165,9 @@ class TorchBackend:
         a = t.cpu().numpy().view(dtype)
         return a if count is None else a[:count]
 
+    def upload(self, t, host_bytes):
+        t[: len(host_bytes)].copy_(self.torch.frombuffer(bytearray(host_bytes), dtype=self.torch.uint8))
+
     def stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
@@ -190,6 +193,9 @@ def _load_library(path=None):
     lib.rtfe_scan_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.rtfe_kernel_name.restype = C.c_char_p
+    lib.rtfe_ww_initial_state.argtypes = [C.c_void_p, C.c_int]
+    lib.rtfe_ww_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.rtfe_scan_stats.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.rtfe_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rtfe_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -340,6 +346,36 @@ class FrontEnd:
         r = ScanResult(self, b, 1, single=True)
         r._rows_keepalive = d_rows
         return r
+
+    # --- Whirlwind: the detector's state goes in and comes back (include/rt_frontend.h: rtfe_ww_scan) ---
+    WW_TRACK_BYTES = 224
+
+    def ww_initial_state(self) -> bytes:
+        buf = (C.c_ubyte * (self.WW_TRACK_BYTES * self.cfg.ntrks))()
+        self.lib.rtfe_ww_initial_state(buf, self.cfg.ntrks)
+        return bytes(buf)
+
+    def ww_scan(self, rows, first_row, nscan, seed_row0, state: bytes, cap: int):
+        """-> (counts[ntrks], events[ntrks, cap] (EVENT_DTYPE, sample relative to first_row), state after the last row, flags)"""
+        be, T = self.backend, self.cfg.ntrks
+        d_rows = be.rows(rows)
+        b = self._cache.get(("ww", cap))
+        if b is None:
+            b = self._cache[("ww", cap)] = dict(st_in=be.empty(T * self.WW_TRACK_BYTES), st_out=be.empty(T * self.WW_TRACK_BYTES), counts=be.empty(T * 4),
+                                                events=be.empty(T * cap * 16), flags=be.empty(16))
+        assert len(state) == T * self.WW_TRACK_BYTES
+        be.upload(b["st_in"], state)
+        be.upload(b["flags"], b"\0" * 16)
+        rc = self.lib.rtfe_ww_scan(self.h, be.ptr(d_rows), int(d_rows.shape[0]), 0, int(first_row), int(nscan), int(seed_row0), be.ptr(b["st_in"]), be.ptr(b["st_out"]),
+                                   be.ptr(b["counts"]), be.ptr(b["events"]), int(cap), be.ptr(b["flags"]), be.stream())
+        if rc != 0:
+            raise RuntimeError(f"rtfe_ww_scan failed ({rc}): {self.lib.rtfe_last_error().decode()}")
+        be.sync()
+        counts = be.to_numpy(b["counts"], np.uint32)[:T].copy()
+        events = be.to_numpy(b["events"], EVENT_DTYPE)[: T * cap].reshape(T, cap).copy()
+        st = bytes(be.to_numpy(b["st_out"], np.uint8)[: T * self.WW_TRACK_BYTES])
+        flags = int(be.to_numpy(b["flags"], np.uint32)[0])
+        return counts, events, st, flags
 
     # --- helpers that restate how the reference turns an event into times (src/decoder.c:732, src/readtape.c:1423) ---
     def time_of_row(self, row):

@@ -20,7 +20,8 @@ class _Options(C.Structure):          # struct rt_options (csrc/host/rt_decode.h
     _fields_ = [("mode", C.c_int), ("ntrks", C.c_int), ("bpi", C.c_float), ("ips", C.c_float),
                 ("specified_parity", C.c_int), ("revparity", C.c_int), ("do_correction", C.c_int),
                 ("find_zeros", C.c_int), ("do_differentiate", C.c_int), ("multiple_tries", C.c_int),
-                ("tap_format", C.c_int), ("add_parity", C.c_int), ("verbose", C.c_int)]
+                ("tap_format", C.c_int), ("add_parity", C.c_int), ("verbose", C.c_int),
+                ("ww_fluxdir", C.c_int), ("ww_reverse", C.c_int), ("ww_order", C.c_char * 24)]
 
 
 class _Parms(C.Structure):            # struct rt_parms
@@ -42,6 +43,7 @@ class _Stats(C.Structure):            # struct rt_replay_stats
 _EXACT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_uint32),
                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
 _FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_WW_SCAN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32)
 
 
 def _load_decode_lib():
@@ -55,6 +57,8 @@ def _load_decode_lib():
                                   C.POINTER(C.c_int), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _EXACT_FN, _FREE_FN, C.c_void_p,
                                   C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
     lib.rt_replay_run_after_deskew.argtypes = lib.rt_replay_run.argtypes
+    lib.rt_replay_run_ww.argtypes = [C.POINTER(_Options), C.POINTER(_Parms), C.c_int64, C.c_int64, C.c_int64, C.c_int, _WW_SCAN_FN, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
     lib.rt_replay_run_named.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_Stats)]
     lib.rt_replay_run_fragment.argtypes = lib.rt_replay_run.argtypes + [C.c_int64, C.c_int64]
     lib.rt_replay_deskew.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -317,6 +321,64 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     stats["skew"] = list(skew) if skew is not None else None
     stats["bpi"] = cfg.bpi
     return stats, res
+
+
+FLUX = {"neg": 0, "pos": 1, "auto": 2}
+
+
+def decode_tape_ww(hdr, rows, tap_path, log_path=None, order: str | None = None, fluxdir: str = "neg", reverse: bool = False, verbose: bool = True,
+                   evt_path=None, fe_factory=None, invert=False, chunk_rows: int = 4096, out_base=None, in_name=None):
+    """Decodes a Whirlwind tape (6 tracks, 100 BPI; mode WW in the header or by the caller).  order = the heads' roles (-order=CMLcml,
+    default: the header's TBINORD string); fluxdir neg / pos / auto.  The device detector keeps its state across block attempts, so
+    the host replay fetches its events in chunks and hands the state back in (rtfe_ww_scan).  Returns the statistics."""
+    lib = _load_decode_lib()
+    order = order or hdr.trkorder or "CMLcml"
+    if len(order) != hdr.ntrks or "x" in order:
+        raise ValueError("the Whirlwind order string must name every head of the file")
+    bpi, ips = (hdr.bpi or 100.0), (hdr.ips or 50.0)
+    full = default_parmsets(tbin.MODE_WW, 1)
+    import dataclasses
+    h2 = dataclasses.replace(hdr, mode=tbin.MODE_WW, bpi=bpi, ips=ips, trkorder="", flags=hdr.flags & ~tbin.FLAG_NO_REORDER)
+    cfg = frontend.FrontEndConfig.from_header(h2, parmsets=frontend_parmsets(full), invert=invert)
+    fe = (fe_factory or frontend.FrontEnd)(cfg)
+    o = _Options(mode=tbin.MODE_WW, ntrks=hdr.ntrks, bpi=bpi, ips=ips, specified_parity=1, revparity=0, do_correction=0, find_zeros=0, do_differentiate=0,
+                 multiple_tries=0, tap_format=1, add_parity=0, verbose=int(verbose), ww_fluxdir=FLUX[fluxdir], ww_reverse=int(reverse), ww_order=order.encode())
+    d_rows = fe.backend.rows(rows)
+    cap = int(chunk_rows)
+    bad = []
+
+    def scan(user, first_row, nscan, seed_row0, state_in, state_out, counts_out, events_out, cap_in):
+        try:
+            st_in = C.string_at(state_in, hdr.ntrks * fe.WW_TRACK_BYTES)
+            counts, events, st, flags = fe.ww_scan(d_rows, first_row, nscan, seed_row0, st_in, int(cap_in))
+            if flags & (frontend.F_DETECTOR_FATAL | frontend.F_EVENT_OVERFLOW):
+                bad.append(flags)
+                return int(flags) or 1
+            for t in range(hdr.ntrks):
+                counts_out[t] = int(counts[t])
+            C.memmove(events_out, events.ctypes.data, events.nbytes)
+            C.memmove(state_out, st, len(st))
+            return 0
+        except Exception as e:          # (a ctypes callback must not raise)
+            bad.append(repr(e))
+            return 2
+
+    cb = _WW_SCAN_FN(scan)
+    st = _Stats()
+    init = fe.ww_initial_state()
+    rc = lib.rt_replay_run_ww(C.byref(o), (_Parms * 1)(full[0]), hdr.tdelta_ns, hdr.tstart_ns, int(d_rows.shape[0]), fe.widths[0], cb, None, init, cap,
+                              tap_path.encode() if tap_path and not out_base else None, out_base.encode() if out_base else None,
+                              (in_name or "").encode() if (out_base and in_name) else None, log_path.encode() if log_path else None,
+                              evt_path.encode() if evt_path else None, C.byref(st))
+    fe.close()
+    if rc != 0:
+        raise RuntimeError("rt_replay_run_ww failed")
+    stats = {k: getattr(st, k) for k, _ in _Stats._fields_}
+    if stats["reference_fatal"]:
+        raise ReferenceFatal(f"AGC gain bad in lookfor_peak on track {stats['fatal_trk']} at sample {stats['fatal_row']}", stats)
+    if stats["device_failures"]:
+        raise RuntimeError(f"the device front end could not deliver an attempt ({bad[:2]})")
+    return stats
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -177,3 +177,32 @@ def test_zeros_with_the_gpu_default_tile(name, knobs, tmp_path, monkeypatch):
     tap, stats = decode_case(g, tmp_path, lambda cfg: emul_frontend(cfg, tile_rows=896))
     assert tap == g["tap"]
     assert not stats["event_diffs"], stats["event_diffs"]
+
+
+WW_CASES = ["ww", "ww_auto", "ww_pos", "ww_pos_auto", "ww_wrongdir", "ww_reverse", "ww_rough", "ww_close"]
+
+
+def decode_ww_case(g, tmp_path, fe_factory, chunk_rows):
+    import refdump
+    o = g["oracle_opts"]
+    tap = os.path.join(str(tmp_path), "out.tap")
+    stats = pipeline.decode_tape_ww(g["hdr"], g["rows"], tap, log_path=tap + ".log", evt_path=tap + ".evt", fe_factory=fe_factory, chunk_rows=chunk_rows,
+                                    fluxdir=next((a[9:] for a in o if a.startswith("-fluxdir=")), "neg"), reverse="-reverse" in o)
+    stats["event_diffs"] = refdump.compare(refdump.load(tap + ".evt"), g["events"])
+    mine = [l.strip() for l in open(tap + ".log").read().splitlines() if l.startswith("wrote block") or "tapemark at" in l]
+    assert mine == list(g["blocklog"]), (mine, list(g["blocklog"]))
+    return open(tap, "rb").read(), stats
+
+
+@pytest.mark.parametrize("chunk_rows", [4096, 300])
+@pytest.mark.parametrize("name", WW_CASES)
+def test_whirlwind_tap_bytes_match_reference(name, chunk_rows, tmp_path):
+    """Whirlwind: the device detector's state is handed from attempt to attempt (rtfe_ww_scan), incl. the re-seeding of the tracks at
+    every attempt start; the events the decoder is handed, the block lines and the .tap are the reference's - both polarities,
+    -fluxdir=auto, the wrong polarity, -reverse, a rough tape (missing-bit / missing-clock warnings), blocks and block marks a few bit
+    times apart - whether an attempt's rows come in one chunk or in many."""
+    g = load_case(name)
+    tap, stats = decode_ww_case(g, tmp_path, emul_frontend, chunk_rows)
+    assert tap == g["tap"]
+    assert stats["agc_mismatches"] == 0 and stats["events_delivered"] > 0
+    assert not stats["event_diffs"], stats["event_diffs"]

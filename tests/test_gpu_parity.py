@@ -451,3 +451,15 @@ def test_zeros_kernel_equals_the_decode_mode_on_long_tapes(kind, gpu, monkeypatc
         for b in range(r0.nbursts):
             for t in range(cfg.ntrks):
                 assert r.track_events(b, 0, t).tobytes() == r0.track_events(b, 0, t).tobytes(), (b, t)
+
+
+@pytest.mark.parametrize("chunk_rows", [4096, 300])
+@pytest.mark.parametrize("name", ["ww", "ww_auto", "ww_pos", "ww_pos_auto", "ww_wrongdir", "ww_reverse", "ww_rough", "ww_close"])
+def test_whirlwind_tap_bytes_match_reference(name, chunk_rows, tmp_path, gpu):
+    """Whirlwind through k_ww (rtfe_ww_scan: detector state handed from attempt to attempt): see tests/test_emul_replay.py."""
+    from test_emul_replay import decode_ww_case
+    g = load_case(name)
+    tap, stats = decode_ww_case(g, tmp_path, None, chunk_rows)
+    assert tap == g["tap"]
+    assert stats["agc_mismatches"] == 0 and stats["events_delivered"] > 0
+    assert not stats["event_diffs"], stats["event_diffs"]
