@@ -281,12 +281,15 @@ def main():
         nevents_all, rows_all = nevents, nrows
     if rank == 0:
         for k in kms: kms[k] /= max(args.steps, 1)
+        if conf["find_zeros"]:                       # -zeros scans run k_zeros in the timing slot of the burst-head pass
+            kms = {("k_zeros" if k == "k_decode_head" else k): v for k, v in kms.items()}
         dom = max(kms, key=kms.get)
         alg_bytes = 2 * cfg.ntrks * nrows + 16 * nevents        # 18 B per sample instant + 16 B per event
         achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         traffic = None
         try:                                         # HBM bytes per launch from the committed rocprofv3 --pmc passes
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            own = os.path.join(ROOT, "profiles", f"pmc_{args.config}.json")
+            pm = json.load(open(own if os.path.exists(own) else os.path.join(ROOT, "profiles", "pmc_latest.json")))
             if args.config == pm.get("config", "C2") and dom in pm and abs(pm["workload_rows"] - nrows) < 0.01 * nrows:
                 traffic = pm[dom]["fetch_bytes"] + pm[dom]["write_bytes"]
         except Exception:

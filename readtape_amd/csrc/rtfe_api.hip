@@ -555,13 +555,6 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t1(5, st); }
    return launch_check("rtfe_scan"); }
 
-// Debugging aid (tools/pk_dump.py): where the peak-record path keeps its directories and its pool inside the workspace.
-extern "C" int rtfe_debug_layout(const rtfe_handle *h, int64_t nrows, int64_t *out) {
-   if (!h || !out) return fail(-1, "null argument");
-   out[0] = (int64_t)ws_pkdir_off(h, nrows); out[1] = (int64_t)(ws_pkdir_off(h, nrows) + pk_dir_bytes(h, nrows)); out[2] = (int64_t)ws_pkpool_off(h, nrows);
-   out[3] = (int64_t)pk_tiles_for(nrows); out[4] = h->dev.nscreens; out[5] = (int64_t)ws_ctl_off(h, nrows);
-   return 0; }
-
 // Synchronous (copies three words back): what the last rtfe_scan on this workspace did.
 extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out) {
    if (!h || !d_workspace || !out) return fail(-1, "null argument");

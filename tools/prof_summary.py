@@ -6,7 +6,8 @@ root = sys.argv[1]
 def dbs(sub):
     return sorted(glob.glob(os.path.join(root, sub, "**", "*.db"), recursive=True))
 
-print("== kernel stats: rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline ==")
+cmd = sys.argv[2] if len(sys.argv) > 2 else "--steps 5 --warmup 2"
+print(f"== kernel stats: rocprofv3 --kernel-trace --stats -- python bench.py {cmd} --no-cpu-baseline --no-e2e ==")
 for f in dbs("trace"):
     db = sqlite3.connect(f)
     for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
