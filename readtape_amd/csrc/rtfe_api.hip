@@ -67,8 +67,32 @@ constexpr int kNumKernels = 8;
 extern "C" int rtfe_kernel_count(void) { return kNumKernels; }
 extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < kNumKernels) ? KNAMES[i] : ""; }
 
+static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_override);
+static int sample_path_workgroups_per_cu(const rtfe_handle *h) {     // as rtfe_scan sizes k_decode's grid
+   const int nwalk = h->dev.nparm * h->dev.ntrks;
+   const int threads = nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256);
+   int per_cu = (160 * 1024) / (h->lds_bytes + 1024);
+   const int wave_lim = 8 / (threads / 64);
+   return per_cu > wave_lim ? wave_lim : (per_cu < 1 ? 1 : per_cu); }
+
 extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (!c || !out) return fail(-1, "null argument");
+   rtfe_handle *h = nullptr;
+   int rc = create_impl(c, &h, 0);
+   if (rc != 0) return rc;
+   // The sample path (PE, GCR, parameter-set sweeps with several window widths) keeps a tile, its screen maps and its walkers in
+   // LDS: with 512-row tiles a sweep's workgroup can be the only one on its CU.  Shorter tiles that let more workgroups reside win
+   // (C4: 98 KB -> 75 KB, one -> two per CU, +35 %); the record path and -zeros have their own tile sizes.
+   // (only then: where several workgroups already share a CU the longer tile is better - GCR, one set: 18.4 vs 22.9 ms per 5e7 rows)
+   if (!getenv("RTFE_TILE_ROWS") && !h->dev.record_path && !h->dev.find_zeros && h->dev.mode != RTFE_WW && sample_path_workgroups_per_cu(h) == 1) {
+      rtfe_handle *h2 = nullptr;
+      if (create_impl(c, &h2, kMarginRows) == 0) {
+         if (sample_path_workgroups_per_cu(h2) > sample_path_workgroups_per_cu(h)) { rtfe_destroy(h); h = h2; }
+         else rtfe_destroy(h2); } }
+   *out = h;
+   return 0; }
+
+static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_override) {
    if (c->ntrks < 1 || c->ntrks > RTFE_MAXTRKS) return fail(-2, "ntrks %d out of range", c->ntrks);
    if (c->mode != RTFE_NRZI && c->mode != RTFE_PE && c->mode != RTFE_GCR && c->mode != RTFE_WW)
       return fail(-3, "mode %d not known", c->mode);
@@ -196,7 +220,7 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    {
       const char *e = getenv("RTFE_TILE_ROWS");            // tuning knob; the default is what bench.py measures
       // (-zeros: a lane per (track, 64-row sub-segment) - 14 sub-segments x 9 tracks fill two waves, 8 leave 44 % of them idle)
-      int tr = e ? atoi(e) : ((c->find_zeros && !c->differentiate) ? 64 * (128 / (c->ntrks > 0 ? c->ntrks : 9)) : 512);
+      int tr = tile_override > 0 ? tile_override : (e ? atoi(e) : ((c->find_zeros && !c->differentiate) ? 64 * (128 / (c->ntrks > 0 ? c->ntrks : 9)) : 512));
       tr = (tr / 64) * 64;
       if (tr < kMarginRows) tr = kMarginRows;
       if (tr > kMaxTileRows) tr = kMaxTileRows;
