@@ -1,6 +1,6 @@
 """Randomized Whirlwind sweep (build container: needs oracle/_ref): random tapes (block lengths, gaps down to a few bit times, block
 marks, noise, jitter, weak alternate tracks, either polarity) and options (-fluxdir, -reverse) through the compiled reference, the
-oracle, and - every `emul_every`-th tape - the emulated device path (pipeline.decode_tape_ww).  .tap bytes and block lines must agree.
+oracle, and - every `emul_every`-th tape - the device path (pipeline.decode_tape_ww; emulated kernels, or the GPU with FUZZ_GPU=1).  .tap bytes and block lines must agree.
     python tests/fuzz_ww.py [seed] [ntapes] [emul_every]"""
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,7 +41,7 @@ def main():
             if p.returncode == 0 and (rtap != otap or lines(p.stdout) != lines(open(os.path.join(wd, "o.log")).read())):
                 msgs.append("oracle != reference")
             if p.returncode == 0 and i % emul_every == 0:
-                from emul_util import emul_frontend
+                emul_frontend = None if os.environ.get("FUZZ_GPU") else __import__("emul_util").emul_frontend      # (FUZZ_GPU=1: the real kernels)
                 try:
                     pipeline.decode_tape_ww(tape.spec.header(), tape.rows, os.path.join(wd, "g.tap"), log_path=os.path.join(wd, "g.log"), fluxdir=fd, reverse=rev,
                                             fe_factory=emul_frontend, chunk_rows=int(rng.choice([256, 1000, 4096])))
