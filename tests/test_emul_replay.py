@@ -124,7 +124,7 @@ def test_event_floods_are_decoded_not_dropped(tmp_path):
     _event_flood_case(tmp_path, emul_frontend)
 
 
-@pytest.mark.parametrize("name,nshards", [("nrzi9", 2), ("nrzi9", 3), ("gcr", 2), ("pe", 2), ("nrzi9_deskew_long", 4)])
+@pytest.mark.parametrize("name,nshards", [("nrzi9", 2), ("nrzi9", 3), ("gcr", 2), ("pe", 2)])
 def test_fragments_concatenate_to_the_whole_tap(name, nshards, tmp_path):
     """Time shards / streamed windows: every fragment scans its rows + a halo, replays the bursts it owns and writes its piece of
     the .tap; the pieces concatenated (+ the end-of-medium marker) are the reference's .tap.  The cuts fall wherever nrows / nshards

@@ -463,3 +463,42 @@ def test_whirlwind_tap_bytes_match_reference(name, chunk_rows, tmp_path, gpu):
     assert tap == g["tap"]
     assert stats["agc_mismatches"] == 0 and stats["events_delivered"] > 0
     assert not stats["event_diffs"], stats["event_diffs"]
+
+
+def test_every_seam_position_inside_a_gap_keeps_every_burst(tmp_path, gpu):
+    """Time shards: the cut swept chunk by chunk from in front of an inter-block zone to behind it - the two ranks'
+    bursts and events together are the whole-tape scan's at every position (tests/test_emul_parity.py sweeps a subset on the emulator)."""
+    from readtape_amd import shard
+    g = load_case("nrzi9")
+    rows = g["rows"]
+    fe = frontend.FrontEnd(config_for(g["hdr"], g["oracle_opts"]))
+    whole = fe.scan(rows).fetch()
+    wb = shard.absolute_bursts(whole, 0)
+    we = shard.flatten_events(whole, wb, 0)
+    key = lambda e: e[np.lexsort((e[:, 1], e[:, 0]))]
+    for zi in (1, 2):
+        zone = wb[zi]
+        lo, hi = int(zone["zone_first"]) - 256, int(zone["zone_end"]) + 512
+        for cut in range(lo // 64 * 64, hi, 64):
+            left = fe.scan(np.ascontiguousarray(rows[: cut + 4096]), row_base=0, first_is_tape_start=True, own_rows=cut).fetch()
+            lb = shard.absolute_bursts(left, 0); le = shard.flatten_events(left, lb, 0)
+            right = fe.scan(np.ascontiguousarray(rows[cut:]), row_base=cut, first_is_tape_start=False).fetch()
+            rb = shard.absolute_bursts(right, cut); re_ = shard.flatten_events(right, rb, 0)
+            assert left.nbursts + right.nbursts == whole.nbursts, (cut, left.nbursts, right.nbursts, whole.nbursts)
+            got = np.concatenate([le, re_])
+            assert got.shape == we.shape and (key(got) == key(we)).all(), cut
+
+
+@pytest.mark.parametrize("name,nshards", [("nrzi9_deskew_long", 4), ("nrzi9", 3), ("gcr", 2), ("pe", 3)])
+def test_fragments_concatenate_to_the_whole_tap(name, nshards, tmp_path, gpu):
+    """pipeline.decode_tape_fragments on the GPU: the fragments' pieces concatenate to the reference's .tap."""
+    from readtape_amd import pipeline, shard
+    g = load_case(name)
+    tap = str(tmp_path / "f.tap")
+    spans = shard.plan_shards(g["rows"].shape[0], nshards, align=64)
+    pipeline.decode_tape_fragments(g["hdr"], g["rows"], tap, spans, halo_rows=1024)
+    want = g["tap"]
+    if name == "nrzi9_deskew_long":                       # (its golden was made with -deskew: compare with the unsharded decode)
+        pipeline.decode_tape(g["hdr"], g["rows"], str(tmp_path / "w.tap"))
+        want = open(tmp_path / "w.tap", "rb").read()
+    assert open(tap, "rb").read() == want
