@@ -115,58 +115,60 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     t_replay = t_wait = 0.0
     t_start = time.perf_counter()
     total = 0
-    with open(tap_path, "wb") as tapf:
-        pend = launch(0, read_window(0)) if spans else None
-        for k, (lo, hi) in enumerate(spans):
-            if lo >= data_end[0]:
-                break
-            hi = min(hi, data_end[0])
-            piece, fin, end_k = pend
-            reader, nxt = None, [0]
-            if k + 1 < len(spans):                        # window k+1 is read while window k is scanned and replayed
-                def work(kk=k + 1):
-                    nxt[0] = read_window(kk)
-                reader = threading.Thread(target=work)
-                reader.start()
-            t0 = time.perf_counter()
-            res, nb, bound = fin()
-            t_wait += time.perf_counter() - t0
-            halo = halo_rows
-            while nb is None and end_k < data_end[0]:    # the last own burst runs past the halo: read more (rare; synchronous)
-                halo *= 4
-                stats["retries"] += 1
-                end_k = min(data_end[0], hi + halo)
-                host = torch.empty((end_k - lo, ntrks), dtype=torch.int16, pin_memory=True)
-                read_rows(host, lo, end_k)
-                piece = host.to(dev)
-                res, nb, bound = pipeline.scan_fragment(fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
-            stats["halo_rows_read"] += end_k - hi
-            if res.nbursts:
-                if pool:
-                    fut = pool.submit(replay, k, res, piece, lo, bound)
-                    busy[k % depth] = fut
-                    pieces.append(fut)
-                else:
-                    pieces.append(replay(k, res, piece, lo, bound))
-            if reader is not None:
-                reader.join()
-                pend = launch(k + 1, nxt[0])              # (its buffers were window k-1's: both copies of it are finished)
-        for pc in pieces:                                 # in window order
-            data, st, secs = pc.result() if hasattr(pc, "result") else pc
-            t_replay += secs
-            tapf.write(data)
-            total += len(data)
-            for key in ("blocks", "tapemarks", "events_delivered", "exact_scans"):
-                stats[key] += int(st[key])
-        if total > 0:
-            tapf.write(b"\xff\xff\xff\xff")                   # src/readtape.c:1885
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t_start
-    os.close(fd)
-    if pool:
-        pool.shutdown()
-        fe_exact.close()
-    fe.close()
+    try:
+        with open(tap_path, "wb") as tapf:
+            pend = launch(0, read_window(0)) if spans else None
+            for k, (lo, hi) in enumerate(spans):
+                if lo >= data_end[0]:
+                    break
+                hi = min(hi, data_end[0])
+                piece, fin, end_k = pend
+                reader, nxt = None, [0]
+                if k + 1 < len(spans):                        # window k+1 is read while window k is scanned and replayed
+                    def work(kk=k + 1):
+                        nxt[0] = read_window(kk)
+                    reader = threading.Thread(target=work)
+                    reader.start()
+                t0 = time.perf_counter()
+                res, nb, bound = fin()
+                t_wait += time.perf_counter() - t0
+                halo = halo_rows
+                while nb is None and end_k < data_end[0]:    # the last own burst runs past the halo: read more (rare; synchronous)
+                    halo *= 4
+                    stats["retries"] += 1
+                    end_k = min(data_end[0], hi + halo)
+                    host = torch.empty((end_k - lo, ntrks), dtype=torch.int16, pin_memory=True)
+                    read_rows(host, lo, end_k)
+                    piece = host.to(dev)
+                    res, nb, bound = pipeline.scan_fragment(fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
+                stats["halo_rows_read"] += end_k - hi
+                if res.nbursts:
+                    if pool:
+                        fut = pool.submit(replay, k, res, piece, lo, bound)
+                        busy[k % depth] = fut
+                        pieces.append(fut)
+                    else:
+                        pieces.append(replay(k, res, piece, lo, bound))
+                if reader is not None:
+                    reader.join()
+                    pend = launch(k + 1, nxt[0])              # (its buffers were window k-1's: both copies of it are finished)
+            for pc in pieces:                                 # in window order
+                data, st, secs = pc.result() if hasattr(pc, "result") else pc
+                t_replay += secs
+                tapf.write(data)
+                total += len(data)
+                for key in ("blocks", "tapemarks", "events_delivered", "exact_scans"):
+                    stats[key] += int(st[key])
+            if total > 0:
+                tapf.write(b"\xff\xff\xff\xff")                   # src/readtape.c:1885
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t_start
+    finally:                                              # (also when a replay raised: no thread, file or device context is left behind)
+        os.close(fd)
+        if pool:
+            pool.shutdown(wait=True, cancel_futures=True)
+            fe_exact.close()
+        fe.close()
     stats.update(rows=data_end[0], seconds=dt, msamples_per_s=data_end[0] / dt / 1e6, replay_seconds=t_replay, read_seconds=t_read[0], scan_wait_seconds=t_wait,
                  replay_events_per_s=(stats["events_delivered"] / t_replay) if t_replay > 0 else None, tap_bytes=total + (4 if total else 0))
     return stats
