@@ -40,6 +40,8 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     assert window_rows % 1024 == 0
     opts = opts or pipeline.DecodeOptions()
     hdr, off, nrows = _payload_geometry(path)
+    if hdr.mode == tbin.MODE_WW:
+        raise NotImplementedError("Whirlwind tapes are one chain (no independent fragments): read the file and use pipeline.decode_tape_ww")
     ntrks = hdr.ntrks
     full = pipeline.default_parmsets(hdr.mode, opts.nparmsets or (15 if opts.multiple_tries else 1))
     cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=pipeline.frontend_parmsets(full), **(cfgkw or {}))

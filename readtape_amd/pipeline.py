@@ -240,6 +240,10 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     the numbered <out_base>.NNN.bin data files, one per tape file (src/readtape.c:1091-1111) - with the files' creation/closing
     and the end-of-run summary (src/readtape.c:2021-2044; in_name = the input's name in it) in the log."""
     opts = opts or DecodeOptions()
+    if hdr.mode == tbin.MODE_WW:                                           # one chain per tape, detector state handed back and forth: its own path
+        st = decode_tape_ww(hdr, rows, tap_path, log_path=log_path, order=trkorder, verbose=opts.verbose, evt_path=evt_path, fe_factory=fe_factory,
+                            invert=invert, out_base=out_base, in_name=in_name)
+        return st, None
     lib = _load_decode_lib()
     if trkorder:                                                           # -order= wins over the header's TBINORD extension (src/readtape.c:1346-1355)
         import dataclasses
