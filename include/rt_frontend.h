@@ -186,11 +186,15 @@ const char *rtfe_kernel_name(int i);
  *   starts from rtfe_ww_initial_state), the attempt they belong to having started at seed_row0 (<= first_row: track t sits out
  *   rows < seed_row0 + t and is re-seeded at seed_row0 + t).  Out: per-track event lists (event.sample relative to first_row;
  *   d_events[t * event_capacity ...], d_counts[t]), the state after the last row (d_state_out, may alias d_state_in), *d_flags |=
- *   RTFE_F_* conditions.  One parameter set (the reference forbids -m for Whirlwind), no deskew delays, peak detection only.
+ *   RTFE_F_* conditions.  One parameter set (the reference forbids -m for Whirlwind), peak detection only.  -deskew: the reference
+ *   learns the delays AND the pulse heights in a pre-pass over the first blocks, then clears the windows and starts over
+ *   (src/readtape.c:1676-1716): the host replay does the same with this call - pre-pass from the initial state, then left/right/
+ *   maxv/minv/countdown = 0, v_avg_height and delay set per track in the blob, and the decode from row 0.
  * Replaces: the per-sample lookfor_peak of src/decoder.c:751-810 for mode WW, at the seam of src/decoder.c:586,604. */
 typedef struct rtfe_ww_track {
    int16_t ring[64];                /* pkww_v as int16 codes (after -invert) */
-   int32_t left, right, maxv, minv, countdown, peakcount, heightndx, pad;
+   int32_t left, right, maxv, minv, countdown, peakcount, heightndx;
+   int32_t delay;                   /* -deskew: this track's delay in samples (0..50; the FIFO of src/decoder.c:820-830 starts at row 0 of the tape) */
    float   agc_gain, v_avg_height, v_lasttop, v_lastbot, v_top, v_bot;
    float   heights[10];
 } rtfe_ww_track;                     /* 224 bytes */

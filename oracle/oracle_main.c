@@ -4,7 +4,7 @@
  *     -nrzi|-pe|-gcr  -ntrks=N -bpi=N -ips=N   override the TBIN header (src/readtape.c:1330-1343)
  *     -zeros -differentiate -invert -correct -m -even -revparity=N
  *     -skew=a,b,..      per-track deskew delays in SAMPLES
- *     -deskew           calibrate the delays on the first blocks (NRZI, GCR)
+ *     -deskew           calibrate the delays on the first blocks (NRZI, GCR, Whirlwind)
  *     -parms=FILE       parameter sets in the reference's .parms grammar
  *     -out=BASE         writes BASE.tap (SIMH) and BASE.log
  *     -evt=FILE         event dump, same 48-byte records as oracle/ref_event_shim.c
@@ -207,7 +207,13 @@ int main(int argc, char **argv) {
       ofe_save_pos(fe);
       if (rt_deskew_prepass(d, &rd, delays, &hit_end) < 0) { fprintf(stderr, "Some tracks have no transitions\n"); return 99; }
       ofe_restore_pos(fe);
-      for (int t = 0; t < opt.ntrks; ++t) fe->skew_delaycnt[t] = delays[t]; }
+      for (int t = 0; t < opt.ntrks; ++t) fe->skew_delaycnt[t] = delays[t];
+      if (opt.mode == RT_WW) {                                /* init_trackpeak_state (src/readtape.c:1707, src/decoder.c:413-423): the delay lines and
+                                                                 the windows' indices, extremes and countdown - not the rings, not the AGC */
+         memset(fe->skew, 0, sizeof fe->skew);
+         for (int t = 0; t < opt.ntrks; ++t) {
+            fe->det[t].pkww_left = fe->det[t].pkww_right = fe->det[t].pkww_countdown = 0;
+            fe->det[t].pkww_minv = fe->det[t].pkww_maxv = 0; } } }
    struct timespec t0, t1;
    clock_gettime(CLOCK_MONOTONIC, &t0);
    int ok = rt_process_blocks(d, &rd, blklimit);

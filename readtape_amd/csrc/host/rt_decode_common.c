@@ -235,7 +235,7 @@ void rt_record_peakstat(struct rt_dec *d, float bitspacing, float peaktime, int 
    if (!d->peakstat.initialized) {                            /* the first transition fixes the bins */
       memset(&d->peakstat, 0, sizeof(d->peakstat));
       const enum rt_mode m = d->opt.mode;
-      float range = bitspacing * (m == RT_NRZI ? 1.0f : m == RT_PE ? 1.2f : m == RT_GCR ? 3.0f : 1.0f);
+      float range = bitspacing * (m == RT_NRZI ? 1.0f : m == RT_PE ? 1.2f : m == RT_GCR ? 3.0f : m == RT_WW ? 0.75f : 1.0f);
       float bw = range / RT_PEAKSTAT_BUCKETS;
       bw = (float)((int)(bw * 10e6 + 0.5) * 1e-6) / 10.0f;   /* to the nearest 0.1 usec (double product, int, double, float) */
       float left = bitspacing - range / 2;

@@ -110,8 +110,19 @@ static void trailing_edge(struct rt_dec *d, struct rt_trk *t, double when) {   /
    struct rt_ww *w = &d->ww;
    struct rt_results *res = &d->results[d->parmset];
    const int role = d->ww_trk_to_type[t->trknum];
+   if (d->doing_deskew && t->v_top > t->v_bot) {        /* the -deskew pre-pass is also where the pulse heights are learned (src/decoder.c:482-487) */
+      t->v_avg_height_sum += t->v_top - t->v_bot;
+      ++t->v_avg_height_count;
+      t->v_heights[t->heightndx] = t->v_top - t->v_bot;
+      if (++t->heightndx >= RT_PARM(d).agc_window) t->heightndx = 0; }
    rt_adjust_agc(d, t);
    t->t_lastpulseend = when;
+   if (w->t_lastpriclkpulseend > 0) {                   /* skew statistics: this pulse end against the primary clock's last one (src/decode_ww.c:197-208) */
+      float delta = (float)(when - w->t_lastpriclkpulseend);
+      const float cell = w->clkavg.t_bitspaceavg;
+      if (delta > -cell * 1.5 && delta < cell * 1.5) {
+         if (delta <= 0 || delta < cell * 0.5) delta += cell;       /* fold onto "one cell later" */
+         rt_record_peakstat(d, cell, delta, t->trknum); } }
    if (is_clock(role)) {
       if (when - w->t_lastclkpulseend > w->clkavg.t_bitspaceavg * SAME_BIT_WITHIN) close_cell(d, when);     /* (else: the other clock track of the same cell) */
       w->t_lastclkpulseend = when;

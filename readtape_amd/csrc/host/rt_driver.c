@@ -206,7 +206,7 @@ int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit) {
    int all_clean = 1, out_of_data = 0;
    const int ww = d->opt.mode == RT_WW;
    d->interblock_counter = 0;
-   if (ww) rt_init_trackstate(d);                                 /* Whirlwind: once per tape - blocks may be one bit apart (src/readtape.c:1674) */
+   if (ww && !d->ww_prepassed) rt_init_trackstate(d);             /* Whirlwind: once per tape - blocks may be one bit apart (src/readtape.c:1674); a -deskew pre-pass has done it */
    while (!out_of_data && d->numblks < blklimit) {
       rt_init_blockstate(d);
       d->parmset = 0;
@@ -265,10 +265,12 @@ int rt_deskew_prepass(struct rt_dec *d, struct rt_reader *r, int delays[RT_MAXTR
    d->doing_deskew = 1;
    d->peakstat.initialized = 0;
    d->interblock_counter = 0;
+   const int ww = d->opt.mode == RT_WW;
+   if (ww) { d->parmset = 0; rt_init_trackstate(d); d->ww_prepassed = 1; }   /* src/readtape.c:1674 */
    do {                                                      /* one block at a time, first parameter set only */
       rt_init_blockstate(d);
       d->parmset = 0;
-      rt_init_trackstate(d);
+      if (ww) rt_ww_init_blockstate(d); else rt_init_trackstate(d);
       if (!r->readblock(r->ctx, 1)) { *hit_end = 1; break; }
       if (d->results[d->parmset].blktype != RT_BS_NOISE) {
          min_transitions = INT_MAX;
@@ -296,6 +298,16 @@ int rt_deskew_prepass(struct rt_dec *d, struct rt_reader *r, int delays[RT_MAXTR
       rlog(d, "  track %d delayed by %d clocks (%.2f usec) based on %d observed flux transitions\n",
            t, delays[t], delays[t] * d->sample_deltat * 1e6, d->peakstat.trksums[t]); }
    d->peakstat.initialized = 0;
+   if (ww) {                                                 /* the pulse heights learned on the way (src/readtape.c:1706-1716); the caller resets the detector */
+      rlog(d, "\n");
+      d->ww.t_lastblockmark = 0;
+      d->ww.blockmark_queued = 0;
+      for (int t = 0; t < ntrks; ++t) {
+         struct rt_trk *k = &d->trk[t];
+         const int count = k->v_avg_height_count;
+         if (count) { k->v_avg_height = k->v_avg_height_sum / count; k->v_avg_height_count = 0; k->v_avg_height_sum = 0; }
+         rlog(d, "  trk %d average peak height is %.2fV and AGC is %.2f, based on %d measurements\n", t, k->v_avg_height / 2, k->agc_gain, count); }
+      rlog(d, "\n"); }
    return nblks; }
 
 /* ---- density detection (src/readtape.c:1656-1672 + estden_setdensity, src/decoder.c:374-399) ---- */

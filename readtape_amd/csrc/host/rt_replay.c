@@ -493,7 +493,8 @@ static int ww_readblock(void *ctx, int retry) {
 
 int rt_replay_run_ww(const struct rt_options *opt, const struct rt_parms *parmsets,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int W0, rt_ww_scan_fn scan, void *user, const void *initial_state, int64_t chunk_rows,
-                  const char *tap_path, const char *out_base, const char *in_name, const char *log_path, const char *evt_path, struct rt_replay_stats *stats) {
+                  const char *tap_path, const char *out_base, const char *in_name, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
+                  int deskew, int *delays_out) {
    const float sample_deltat = (float)tdelta_ns / 1e9f;
    struct rt_options o = *opt;
    o.multiple_tries = 0;                                       /* "not implemented yet for Whirlwind" (src/readtape.c:1987) */
@@ -520,7 +521,24 @@ int rt_replay_run_ww(const struct rt_options *opt, const struct rt_parms *parmse
       if (rp.evtf) { d->on_transition = dump_transition; d->on_attempt = dump_attempt; d->user = &rp; } }
    const double wall0 = (double)time(NULL);
    struct rt_reader rd = { ww_readblock, rt_replay_save_pos, rt_replay_restore_pos, &rp };
-   const int ok = rt_process_blocks(d, &rd, 0x7fffffff);
+   int prepass_failed = 0;
+   if (deskew) {
+      /* -deskew (src/readtape.c:1676-1716): the first blocks are read once to learn the heads' skew and the pulse heights; then the
+       * windows and the delay lines are cleared (init_trackpeak_state) - NOT the rings, the AGC or the decoder's track state -
+       * and the tape is read again from its first row, every track behind its delay */
+      int delays[RT_MAXTRKS] = { 0 }, hit_end = 0;
+      rt_replay_save_pos(&rp);
+      const int nblks = rt_deskew_prepass(d, &rd, delays, &hit_end);
+      rt_replay_restore_pos(&rp);
+      if (nblks < 0 || rp.device_failures || rp.reference_fatal) prepass_failed = 1;
+      else {
+         rtfe_ww_track *st = (rtfe_ww_track *)rp.ww_state;
+         for (int t = 0; t < o.ntrks; ++t) {
+            st[t].left = st[t].right = st[t].maxv = st[t].minv = st[t].countdown = 0;
+            st[t].v_avg_height = d->trk[t].v_avg_height;
+            st[t].delay = delays[t]; }
+         if (delays_out) memcpy(delays_out, delays, sizeof(int) * (size_t)o.ntrks); } }
+   const int ok = prepass_failed ? 0 : rt_process_blocks(d, &rd, 0x7fffffff);
    if (in_name) rt_write_summary(d, in_name, difftime(time(NULL), (time_t)wall0));
    if (stats) {
       memset(stats, 0, sizeof *stats);
@@ -534,4 +552,4 @@ int rt_replay_run_ww(const struct rt_options *opt, const struct rt_parms *parmse
    if (rp.evtf) fclose(rp.evtf);
    free(rp.ww_state); free(rp.ww_events); free(rp.ww_counts);
    rt_dec_free(d);
-   return 0; }
+   return (prepass_failed && !rp.device_failures && !rp.reference_fatal) ? -2 : 0; }

@@ -90,7 +90,8 @@ int rt_replay_run_fragment(const struct rt_options *opt, const struct rt_parms *
                   int64_t start_row, int64_t stop_row);
 int rt_replay_run_ww(const struct rt_options *opt, const struct rt_parms *parmsets,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int W0, rt_ww_scan_fn scan, void *user, const void *initial_state, int64_t chunk_rows,
-                  const char *tap_path, const char *out_base, const char *in_name, const char *log_path, const char *evt_path, struct rt_replay_stats *stats);
+                  const char *tap_path, const char *out_base, const char *in_name, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
+                  int deskew, int *delays_out);
 int rt_replay_run_named(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,

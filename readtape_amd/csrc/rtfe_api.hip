@@ -620,7 +620,7 @@ extern "C" int rtfe_ww_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows
                             uint32_t *d_flags, void *stream) {
    if (!h || !d_rows || !d_state_in || !d_state_out || !d_counts || !d_events || !d_flags) return fail(-1, "null argument");
    if (h->dev.mode != RTFE_WW) return fail(-40, "rtfe_ww_scan: the handle was not made for mode RTFE_WW");
-   if (h->dev.find_zeros || h->dev.differentiate || h->dev.maxskew > 0 || h->dev.nparm != 1) return fail(-41, "rtfe_ww_scan: peak detection, one parameter set, no deskew delays");
+   if (h->dev.find_zeros || h->dev.differentiate || h->dev.maxskew > 0 || h->dev.nparm != 1) return fail(-41, "rtfe_ww_scan: peak detection, one parameter set, deskew delays in the state (not in the configuration)");
    if (h->dev.parm[0].W > kWwRing) return fail(-42, "window wider than the state's ring");
    if (first_row < 0 || nscan <= 0 || first_row >= nrows || seed_row0 > first_row || event_capacity < 1) return fail(-43, "bad row range");
    hipLaunchKernelGGL(k_ww, dim3(1), dim3(64), 0, (hipStream_t)stream, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base,

@@ -40,12 +40,14 @@ __global__ void __launch_bounds__(64) k_ww(const DevCfg *__restrict__ cfgp, cons
    w.agc_gain = S.agc_gain; w.v_avg_height = S.v_avg_height; w.v_lasttop = S.v_lasttop; w.v_lastbot = S.v_lastbot;
    w.v_top = S.v_top; w.v_bot = S.v_bot; w.peakcount = S.peakcount; w.heightndx = S.heightndx;
    int left = S.left, right = S.right, maxv = S.maxv, minv = S.minv, countdown = S.countdown;
+   const int delay = S.delay < 0 ? 0 : (S.delay > 50 ? 50 : S.delay);      // (MAXSKEWSAMP)
    unsigned int nev = 0, fl = 0;
    rtfe_event *out = events + (size_t)t * cap;
    const long long end = first_row + nscan < nrows_total ? first_row + nscan : nrows_total;
    for (long long n = first_row; n < end && !(fl & (RTFE_F_DETECTOR_FATAL | RTFE_F_AGC_FATAL)); ++n) {
       if (n < seed_row0 + t) continue;                               // the tracks in front of this one are being re-seeded: it sits the row out
-      const int v = sgn * (int)rows[n * cfg.ntrks + col];
+      const long long src = (row_base + n < delay || n < delay) ? n : n - delay;    // the deskew FIFO runs from the tape's first row: undelayed until it has filled (src/decoder.c:820-830)
+      const int v = sgn * (int)rows[src * cfg.ntrks + col];
       if (n == seed_row0 + t) {                                      // src/decoder.c:855-861: slot 0, both extremes; indices and the other slots stay
          ring[0] = (short)v; maxv = minv = v;
          continue; }

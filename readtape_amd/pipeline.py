@@ -58,7 +58,7 @@ def _load_decode_lib():
                                   C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
     lib.rt_replay_run_after_deskew.argtypes = lib.rt_replay_run.argtypes
     lib.rt_replay_run_ww.argtypes = [C.POINTER(_Options), C.POINTER(_Parms), C.c_int64, C.c_int64, C.c_int64, C.c_int, _WW_SCAN_FN, C.c_void_p, C.c_void_p, C.c_int64,
-                                     C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats)]
+                                     C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats), C.c_int, C.POINTER(C.c_int)]
     lib.rt_replay_run_named.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_Stats)]
     lib.rt_replay_run_fragment.argtypes = lib.rt_replay_run.argtypes + [C.c_int64, C.c_int64]
     lib.rt_replay_deskew.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -331,10 +331,12 @@ FLUX = {"neg": 0, "pos": 1, "auto": 2}
 
 
 def decode_tape_ww(hdr, rows, tap_path, log_path=None, order: str | None = None, fluxdir: str = "neg", reverse: bool = False, verbose: bool = True,
-                   evt_path=None, fe_factory=None, invert=False, chunk_rows: int = 4096, out_base=None, in_name=None):
+                   evt_path=None, fe_factory=None, invert=False, chunk_rows: int = 4096, out_base=None, in_name=None, deskew: bool = False):
     """Decodes a Whirlwind tape (6 tracks, 100 BPI; mode WW in the header or by the caller).  order = the heads' roles (-order=CMLcml,
     default: the header's TBINORD string); fluxdir neg / pos / auto.  The device detector keeps its state across block attempts, so
-    the host replay fetches its events in chunks and hands the state back in (rtfe_ww_scan).  Returns the statistics."""
+    the host replay fetches its events in chunks and hands the state back in (rtfe_ww_scan).  deskew: the reference's
+    -deskew (a pre-pass over the first blocks learns every head's delay and the pulse heights, src/readtape.c:1676-1716; the delays
+    come back as stats["skew_delays"]).  Returns the statistics."""
     lib = _load_decode_lib()
     order = order or hdr.trkorder or "CMLcml"
     if len(order) != hdr.ntrks or "x" in order:
@@ -370,14 +372,19 @@ def decode_tape_ww(hdr, rows, tap_path, log_path=None, order: str | None = None,
     cb = _WW_SCAN_FN(scan)
     st = _Stats()
     init = fe.ww_initial_state()
+    delays = (C.c_int * hdr.ntrks)()
     rc = lib.rt_replay_run_ww(C.byref(o), (_Parms * 1)(full[0]), hdr.tdelta_ns, hdr.tstart_ns, int(d_rows.shape[0]), fe.widths[0], cb, None, init, cap,
                               tap_path.encode() if tap_path and not out_base else None, out_base.encode() if out_base else None,
                               (in_name or "").encode() if (out_base and in_name) else None, log_path.encode() if log_path else None,
-                              evt_path.encode() if evt_path else None, C.byref(st))
+                              evt_path.encode() if evt_path else None, C.byref(st), int(bool(deskew)), delays)
     fe.close()
+    if rc == -2 and not bad:
+        raise RuntimeError("the -deskew pre-pass found tracks without flux transitions (is the order string right?)")
     if rc != 0:
-        raise RuntimeError("rt_replay_run_ww failed")
+        raise RuntimeError(f"rt_replay_run_ww failed ({bad[:2]})")
     stats = {k: getattr(st, k) for k, _ in _Stats._fields_}
+    if deskew:
+        stats["skew_delays"] = list(delays)
     if stats["reference_fatal"]:
         raise ReferenceFatal(f"AGC gain bad in lookfor_peak on track {stats['fatal_trk']} at sample {stats['fatal_row']}", stats)
     if stats["device_failures"]:

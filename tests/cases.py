@@ -59,6 +59,17 @@ def case_ww_close(seed=44):
     return synth.ww_tape(seed=seed, nblocks=8, minwords=1, maxwords=4, marks_every=1, gap_samples=130)
 
 
+def case_ww_skew(seed=45):
+    # heads out of line by up to 0.3 cell; the tape ends before the -deskew calibration has its 1000 transitions per track
+    return synth.ww_tape(seed=seed, nblocks=5, minwords=3, maxwords=12, marks_every=2, gap_samples=600, skew_cells=(0.0, 0.22, 0.10, 0.30, 0.05, 0.16))
+
+
+def case_ww_skew_long(seed=46):
+    # enough blocks for the calibration to stop by itself (block limit or transitions), with blocks and marks left over
+    return synth.ww_tape(seed=seed, nblocks=16, minwords=12, maxwords=30, marks_every=5, gap_samples=400, noise_mv=25.0,
+                         skew_cells=(0.12, 0.0, 0.28, 0.07, 0.2, 0.33))
+
+
 def case_gcr_noisy(seed=17):
     return synth.gcr_tape(seed=seed, nblocks=2, minlen=40, maxlen=120, gap_samples=2500, noise_mv=45.0, jitter=0.05, amplitude=1.2)
 
@@ -235,6 +246,9 @@ CASES = {
     "ww_reverse":   (case_ww,         ["-reverse"],                    ["-reverse"]),
     "ww_rough":     (case_ww_rough,   [],                              []),
     "ww_close":     (case_ww_close,   ["-fluxdir=auto"],               ["-fluxdir=auto"]),
+    "ww_deskew":    (case_ww_skew,    ["-fluxdir=auto", "-deskew"],    ["-fluxdir=auto", "-deskew"]),
+    "ww_deskew_long": (case_ww_skew_long, ["-deskew"],                 ["-deskew"]),
+    "ww_deskew_pos":  (case_ww_pos,   ["-fluxdir=pos", "-deskew"],     ["-fluxdir=pos", "-deskew"]),
     "nrzi7_order":  (case_nrzi7_order, ["-nrzi", "-ntrks=7", "-order=543210p"], ["-order=543210p"]),
     "pe_order":     (case_pe_order,   ["-pe", "-order=01234576p"],     ["-order=01234576p"]),
     "gcr_order_m":  (case_gcr_order,  ["-gcr", "-m"],                  ["-m"]),

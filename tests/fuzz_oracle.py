@@ -14,7 +14,7 @@ subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ntapes = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 bad = 0
-LINES = lambda txt: [l.strip() for l in txt.splitlines() if l.startswith("wrote block") or "tapemark at" in l or "observed flux transitions" in l or "density was set to" in l]
+LINES = lambda txt: [l.strip() for l in txt.splitlines() if l.startswith("wrote block") or "tapemark at" in l or "observed flux transitions" in l or "density was set to" in l or "average peak height is" in l]
 for i in range(ntapes):
     kind = ["nrzi", "nrzi", "nrzi", "pe", "gcr"][int(rng.integers(0, 5))]
     amp = float(rng.choice([0.6, 1.0, 1.8, 2.5, 3.2])); noise = float(rng.choice([0.0, 5.0, 10.0, 25.0, 50.0, 80.0])); jit = float(rng.choice([0.0, 0.02, 0.05, 0.08]))

@@ -100,7 +100,7 @@ def main():
             p = subprocess.run([REF] + opts + ["t"], cwd=wd, env=env, capture_output=True, text=True)
             tap = open(os.path.join(wd, "t.tap"), "rb").read() if os.path.exists(os.path.join(wd, "t.tap")) else b""
             evt = refdump.load(os.path.join(wd, "t.evt"))
-            blocks = [l.strip() for l in p.stdout.splitlines() if l.startswith("wrote block") or "tapemark at" in l or (l.startswith("  track ") and "observed flux transitions" in l) or "density was set to" in l]
+            blocks = [l.strip() for l in p.stdout.splitlines() if l.startswith("wrote block") or "tapemark at" in l or (l.startswith("  track ") and "observed flux transitions" in l) or "density was set to" in l or "average peak height is" in l]
         np.savez_compressed(os.path.join(OUT, f"case_{name}.npz"), tape=tkey, ref_opts=np.array(opts),
                             oracle_opts=np.array(list(or_opts), dtype="U64"), tap=np.frombuffer(tap, dtype=np.uint8),
                             events=evt, returncode=p.returncode, blocklog=np.array(blocks), parms_text=np.array(parms_text))

@@ -29,7 +29,7 @@ def decode_case(g, tmp_path, fe_factory):
     ign = ("v_avg_height",) if ("-zeros" in o and "-differentiate" in o) else ()
     stats["event_diffs"] = refdump.compare(refdump.load(tap + ".evt"), g["events"], ignore_fields=ign)
     if g["returncode"] == 0:   # the reference's per-block result lines: error / parity / ECC / corrected-bit counts, AGC range, offsets
-        mine = [l.strip() for l in open(tap + ".log").read().splitlines() if l.startswith("wrote block") or "tapemark at" in l or "observed flux transitions" in l or "density was set to" in l]
+        mine = [l.strip() for l in open(tap + ".log").read().splitlines() if l.startswith("wrote block") or "tapemark at" in l or "observed flux transitions" in l or "density was set to" in l or "average peak height is" in l]
         assert mine == list(g["blocklog"]), (mine, list(g["blocklog"]))
     return open(tap, "rb").read(), stats
 
@@ -179,7 +179,7 @@ def test_zeros_with_the_gpu_default_tile(name, knobs, tmp_path, monkeypatch):
     assert not stats["event_diffs"], stats["event_diffs"]
 
 
-WW_CASES = ["ww", "ww_auto", "ww_pos", "ww_pos_auto", "ww_wrongdir", "ww_reverse", "ww_rough", "ww_close"]
+WW_CASES = ["ww", "ww_auto", "ww_pos", "ww_pos_auto", "ww_wrongdir", "ww_reverse", "ww_rough", "ww_close", "ww_deskew", "ww_deskew_long", "ww_deskew_pos"]
 
 
 def decode_ww_case(g, tmp_path, fe_factory, chunk_rows):
@@ -187,9 +187,9 @@ def decode_ww_case(g, tmp_path, fe_factory, chunk_rows):
     o = g["oracle_opts"]
     tap = os.path.join(str(tmp_path), "out.tap")
     stats = pipeline.decode_tape_ww(g["hdr"], g["rows"], tap, log_path=tap + ".log", evt_path=tap + ".evt", fe_factory=fe_factory, chunk_rows=chunk_rows,
-                                    fluxdir=next((a[9:] for a in o if a.startswith("-fluxdir=")), "neg"), reverse="-reverse" in o)
+                                    fluxdir=next((a[9:] for a in o if a.startswith("-fluxdir=")), "neg"), reverse="-reverse" in o, deskew="-deskew" in o)
     stats["event_diffs"] = refdump.compare(refdump.load(tap + ".evt"), g["events"])
-    mine = [l.strip() for l in open(tap + ".log").read().splitlines() if l.startswith("wrote block") or "tapemark at" in l]
+    mine = [l.strip() for l in open(tap + ".log").read().splitlines() if l.startswith("wrote block") or "tapemark at" in l or "observed flux transitions" in l or "average peak height is" in l]
     assert mine == list(g["blocklog"]), (mine, list(g["blocklog"]))
     return open(tap, "rb").read(), stats
 

@@ -31,7 +31,7 @@ def test_oracle_matches_golden(name, tmp_path, oracle_bin):
         ot = open(f"{wd}/o.tap", "rb").read()
         assert ot == g["tap"]
         # the reference's per-block result lines (error / parity / ECC / corrected-bit counts, AGC range, speed, offsets)
-        mine = [l.strip() for l in open(f"{wd}/o.log").read().splitlines() if l.startswith("wrote block") or "tapemark at" in l or "observed flux transitions" in l or "density was set to" in l]
+        mine = [l.strip() for l in open(f"{wd}/o.log").read().splitlines() if l.startswith("wrote block") or "tapemark at" in l or "observed flux transitions" in l or "density was set to" in l or "average peak height is" in l]
         assert mine == list(g["blocklog"])
     diffs = refdump.compare(a, b)
     assert not diffs, "; ".join(diffs)
