@@ -157,6 +157,7 @@ struct rt_dec {
    struct rt_nrzi nrzi;
    struct rt_ww ww;
    int     ww_type_to_trk[6], ww_trk_to_type[RT_MAXTRKS];      /* role <-> track (src/readtape.c:521-522) */
+   int     fatal;                 /* the reader met a condition on which the reference exits (assert in lookfor_peak / refine_peak): nothing more is attempted */
    int     ww_prepassed;          /* a -deskew pre-pass has set up the track state (src/readtape.c:1674 happens once per tape) */
    int     flux_current, num_flux_polarity_changes;
    struct { int bitnum, bytenum; uint8_t sgroup[9]; int bad_parity_in_dgroup; } gcr;   /* src/decode_gcr.c:37,444-445 */

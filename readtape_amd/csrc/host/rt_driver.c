@@ -220,6 +220,7 @@ int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit) {
             rt_ww_blockmark(d);
             d->t_blockstart = d->timenow - d->ww.clkavg.t_bitspaceavg; }
          else out_of_data = !r->readblock(r->ctx, d->tries > 0);
+         if (d->fatal) return 0;                                  /* the reference has exited (src/decoder.c:709-710,748,782): no other parameter set is tried */
          const struct rt_results *a = &d->results[d->parmset];
          if (a->blktype == RT_BS_NONE) { rt_tap_end(d); return all_clean; }      /* what was left of the data was no block */
          ++d->tries;
@@ -248,7 +249,8 @@ int rt_process_blocks(struct rt_dec *d, struct rt_reader *r, int blklimit) {
          r->restore_pos(r->ctx);
          d->interblock_counter = 0;
          rt_init_trackstate(d);
-         out_of_data = !r->readblock(r->ctx, 1); }
+         out_of_data = !r->readblock(r->ctx, 1);
+         if (d->fatal) return 0; }
       switch (d->results[d->parmset].blktype) {
       case RT_BS_TAPEMARK: rt_got_tapemark(d); break;
       case RT_BS_BLOCK:    rt_got_datablock(d, 0); break;

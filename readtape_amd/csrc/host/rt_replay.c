@@ -270,7 +270,7 @@ restart:
             break; }
          while (src.at[t] < src.n[t] && src.reset + src.list[t][src.at[t]].sample == row) {
             if (src.list[t][src.at[t]].flags & RTFE_EV_FATAL) {    /* "AGC gain bad in lookfor_peak" (src/decoder.c:782): the reference exits here */
-               rp->reference_fatal = 1; rp->fatal_row = row; rp->fatal_trk = t;
+               rp->reference_fatal = 1; d->fatal = 1; rp->fatal_row = row; rp->fatal_trk = t;
                d->results[parmset].blktype = RT_BS_ABORTED;
                if (exact_events && rp->exact_free) rp->exact_free(rp->exact_user, exact_events);
                rt_finish_attempt(d);
@@ -473,7 +473,7 @@ static int ww_readblock(void *ctx, int retry) {
             break; }
          while (src.at[t] < src.n[t] && src.reset + src.list[t][src.at[t]].sample == row) {
             if (src.list[t][src.at[t]].flags & RTFE_EV_FATAL) {
-               rp->reference_fatal = 1; rp->fatal_row = row; rp->fatal_trk = t;
+               rp->reference_fatal = 1; d->fatal = 1; rp->fatal_row = row; rp->fatal_trk = t;
                d->results[d->parmset].blktype = RT_BS_ABORTED;
                rt_finish_attempt(d);
                return 0; }

@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 448 ? 4 : 3)) k_peaks(const Dev
       if (tid == 0) { s_noisy = 0; }
       __syncthreads();
       const bool prof = cfg.debug == 3 && tid == 0;
-      long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0;
+      long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
       if (prof) tk0 = clock64();
       // ---- 1. the tape's bytes -> LDS strips; quiet groups on the way ----
       {

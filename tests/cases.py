@@ -204,6 +204,29 @@ def case_nrzi7_agcfatal(seed=416690828):
 case_nrzi7_agcfatal.parms_text = AGCFATAL_PARMS
 
 
+AGCFATAL_M_PARMS = ("parms active, clk_window, clk_alpha, agc_window, agc_alpha, min_peak, clk_factor, pulse_adj, pkww_bitfrac, pkww_rise, midbit, z1pt, z2pt, id\n"
+                    "{1, 0, 0.2, 3, 0.0, 0.5, 0, 0.3, 0.266, 0.3, 0.5, 1.45, 2.35, PRM}\n"
+                    "{1, 0, 0.2, 3, 0.0, 0.0, 0, 0.3, 0.266, 0.05, 0.5, 1.45, 2.35, PRM}\n"
+                    "{1, 0, 0.2, 10, 0.0, 0.0, 0, 0.3, 0.42, 0.2, 0.5, 1.45, 2.35, PRM}\n"
+                    "{1, 0, 0.2, 3, 0.0, 0.1, 0, 0.3, 0.266, 0.2, 0.5, 1.45, 2.35, PRM}\n")
+
+
+def case_nrzi9_agcfatal_m(seed=412346456):
+    # (found by tests/stress_gpu.py, seed 704 tape 59: the GPU hung) a 2 us digitiser (3- and 5-sample windows), 50 mV of noise, a
+    # sweep of four sets with window AGC and no min_peak: the gain of the SECOND set goes negative in an attempt that other sets
+    # have already been through, and the reference dies there (src/decoder.c:782) - no further set is tried.  The screened walk's
+    # "blind for ever" row (1 << 60) must not be narrowed to an int.
+    import dataclasses
+    spec = synth.TapeSpec(mode=tbin.MODE_NRZI, ntrks=9, bpi=800.0, ips=50.0, tdelta_ns=2000, maxvolts=4.4, pulse_w=0.22, seed=seed,
+                          amplitude=2.5, noise_mv=50.0, jitter=0.02)
+    items = [("block", pl) for pl in synth.random_payloads(np.random.default_rng(seed + 1000), 2, 16, 1200, databits=8)]
+    t = synth.make_tape(spec, items, gap_samples=1920)
+    return dataclasses.replace(t, rows=np.ascontiguousarray(t.rows[:3000]))
+
+
+case_nrzi9_agcfatal_m.parms_text = AGCFATAL_M_PARMS
+
+
 # name -> (tape builder, reference options, oracle options); a builder's .parms_text, if any, is the NRZI/PE/GCR.parms file of the run
 CASES = {
     "nrzi9":        (case_nrzi9,      ["-nrzi"],                       []),
@@ -254,6 +277,7 @@ CASES = {
     "gcr_order_m":  (case_gcr_order,  ["-gcr", "-m"],                  ["-m"]),
     "nrzi7_order_ignored": (case_nrzi7_order_ignored, ["-nrzi", "-ntrks=7", "-order=543210p"], ["-order=543210p"]),
     "nrzi7_agcfatal": (case_nrzi7_agcfatal, ["-nrzi", "-ntrks=7", "-invert", "-differentiate"], ["-invert", "-differentiate"]),
+    "nrzi9_agcfatal_m": (case_nrzi9_agcfatal_m, ["-nrzi", "-m", "-even"],  ["-m", "-even"]),
     "gcr_errs":     (case_gcr_errors, ["-gcr"],                        []),
     "gcr_correct":  (case_gcr_errors, ["-gcr", "-correct"],            ["-correct"]),
 }

@@ -132,7 +132,10 @@ for i in range(ntapes):
     if os.environ.get("STRESS_DRY"):
         print(i, kind, "seed", seed, "amp", amp, "noise", noise, "jit", jit, "opts", opts, "seg", seg, warm, "rows", tape.rows.shape[0], "spec", tape.spec.bpi, "parms", repr(parms_text), flush=True)
         continue
-    with tempfile.TemporaryDirectory() as wd:
+    import contextlib
+    keep = os.environ.get("STRESS_KEEP")                        # (debugging: leave the oracle's and the pipeline's files in this directory)
+    if keep: os.makedirs(keep, exist_ok=True)
+    with (contextlib.nullcontext(keep) if keep else tempfile.TemporaryDirectory()) as wd:
         att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3")) else []
         for rec in ("default", "1"):
             t_case = time.perf_counter()

@@ -63,6 +63,24 @@ def test_reference_agc_assert_stops_the_decode_where_the_reference_stops(tmp_pat
     assert ei.value.stats["reference_fatal"]
 
 
+@pytest.mark.parametrize("record_path", ["0", "1"])
+def test_agc_assert_inside_a_parameter_sweep_ends_everything(record_path, tmp_path, monkeypatch):
+    """-m: the second set's gain goes negative in an attempt other sets have been through (stress seed 704 tape 59: the GPU hung,
+    the emulator crashed - the screened walk narrowed its "blind for ever" row to an int).  The reference exits at the assert: no
+    further set is tried, and the transitions delivered up to there are the reference's."""
+    import refdump
+    monkeypatch.setenv("RTFE_RECORD_PATH", record_path)
+    g = load_case("nrzi9_agcfatal_m")
+    assert g["returncode"] == 99
+    tap = os.path.join(str(tmp_path), "out.tap")
+    with pytest.raises(pipeline.ReferenceFatal):
+        pipeline.decode_tape(g["hdr"], g["rows"], tap, fe_factory=emul_frontend, evt_path=tap + ".evt", parms_text=g["parms_text"],
+                             opts=pipeline.DecodeOptions(multiple_tries=True, even_parity=True))
+    mine = refdump.load(tap + ".evt")
+    assert mine.size == g["events"].size and mine.size > 10000, (mine.size, g["events"].size)
+    assert not refdump.compare(mine, g["events"])
+
+
 def test_short_burst_tails_do_not_change_the_tap(tmp_path, monkeypatch):
     """A burst's walkers stop tail_rows into the next quiet zone.  Even with an absurdly short tail
     the .tap must not change: a zone only starts a whole quiet KiB after the last flux transition, by when the block

@@ -199,6 +199,22 @@ def test_reference_agc_assert_stops_the_decode_where_the_reference_stops(tmp_pat
     assert mine.size == g["events"].size and not refdump.compare(mine, g["events"])
 
 
+@pytest.mark.parametrize("record_path", ["0", "1"])
+def test_agc_assert_inside_a_parameter_sweep_ends_everything(record_path, tmp_path, gpu, monkeypatch):
+    """-m, the gain of the second set goes negative (stress seed 704 tape 59 hung the GPU): see tests/test_emul_replay.py."""
+    import os
+    import refdump
+    from readtape_amd import pipeline
+    monkeypatch.setenv("RTFE_RECORD_PATH", record_path)
+    g = load_case("nrzi9_agcfatal_m")
+    tap = os.path.join(str(tmp_path), "out.tap")
+    with pytest.raises(pipeline.ReferenceFatal):
+        pipeline.decode_tape(g["hdr"], g["rows"], tap, evt_path=tap + ".evt", parms_text=g["parms_text"],
+                             opts=pipeline.DecodeOptions(multiple_tries=True, even_parity=True))
+    mine = refdump.load(tap + ".evt")
+    assert mine.size == g["events"].size and not refdump.compare(mine, g["events"])
+
+
 @pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "pe", "gcr", "gcr_m", "nrzi9_skew", "nrzi9_nobpi", "nrzi7_order"])
 def test_peak_record_path_equals_the_sample_path(name, gpu, monkeypatch):
     """The opt-in peak-record path (RTFE_PEAK_PATH=1: k_peaks -> k_zones -> k_chain) against the default kernels: the same burst
