@@ -253,6 +253,28 @@ struct Col {
    __device__ __forceinline__ int operator[](int i) const { return p[i * P]; } };
 __device__ __forceinline__ Col tile_col(const Tile &tl, int trk, int delay) {
    Col c; c.P = tl.ntrks; c.p = tl.x + (tl.halo - delay) * tl.ntrks + tl.colof[trk]; return c; }
+// the same column where the caller knows that the tile's rows lie in HBM (k_zeros reads the tape in place): loads through a generic
+// pointer are FLAT instructions - they count against both the vector-memory and the LDS counter and may return out of order, so every
+// use waits for ALL of them and nothing can be kept in flight across a batch of detector steps; through a global pointer they are
+// global_load with in-order returns (s_waitcnt vmcnt(n))
+#ifdef RTFE_CPU_EMUL
+typedef const int16_t *gptr16;
+#else
+typedef const __attribute__((address_space(1))) int16_t *gptr16;
+#endif
+struct GCol {             // a uniform base pointer (the tile in HBM) + a 32-bit element offset per lane: global_load with a scalar base, one add per load
+   gptr16 base; int off, P;
+   __device__ __forceinline__ int operator[](int i) const {
+#ifdef RTFE_CPU_EMUL
+      return base[off + i * P];
+#else
+      // (a 32-bit unsigned BYTE offset from the uniform base: the address mode "scalar base + vector offset" of global_load)
+      return *(gptr16)((const __attribute__((address_space(1))) char *)base + (unsigned)((off + i * P) << 1));
+#endif
+   } };
+template <bool kGlobal> __device__ __forceinline__ auto zc_col(const Tile &tl, int trk, int delay) {
+   if constexpr (kGlobal) { GCol g; g.base = (gptr16)tl.x; g.off = (tl.halo - delay) * tl.ntrks + tl.colof[trk]; g.P = tl.ntrks; return g; }
+   else return tile_col(tl, trk, delay); }
 
 __device__ __forceinline__ float volt(int i, float maxvolts) {      // src/readtape.c:1420
    return (float)i / 32767 * maxvolts; }
@@ -762,10 +784,6 @@ template <class WT> __device__ __forceinline__ void walk_zeros(WT &w, Ctx &cx, i
 // stands only if every sub-segment's noted state equals its predecessor's final state in every field; otherwise that
 // track is walked again sequentially (walk_zeros) from the untouched walker.  ok[trk] = 1 where the result stands.
 constexpr int kZcSub = 64, kZcWarm = 64, kZcMaxEv = 8;
-struct ZcLane { ZcState start, end; int count, bad; unsigned int ev[kZcMaxEv][2]; };      // ev: n_rel | code << 16 , delay | up << 31
-__device__ __forceinline__ bool zc_same(const ZcState &a, const ZcState &b) {
-   return a.prev == b.prev && a.top == b.top && a.bot == b.bot && a.up == b.up && a.dn == b.dn
-       && (!a.up || a.ttop == b.ttop) && (!a.dn || a.tbot == b.tbot); }       // (the crossing rows are only read while pending)
 // lookfor_zerocrossing's step (zc_row) on 32-bit state with selects instead of branches: rows are tile-relative (q).  The order of
 // the reference's statements is kept (clear the other side's pending flag, new extreme and confirmation, arming), so the state after
 // every row is zc_row's.  The two pending flags live in the crossing rows themselves (kZcNone = not pending: a crossing row is only
@@ -800,66 +818,101 @@ __device__ __forceinline__ ZcState zc_from32(const Zc32 &z, long long row0) {
    ZcState s; s.prev = z.prev; s.top = z.top; s.bot = z.bot; s.up = z.ttop != kZcNone; s.dn = z.tbot != kZcNone; s.ttop = row0 + z.ttop; s.tbot = row0 + z.tbot;
    return s; }
 
-// the own rows of sub-segment j from state z: events into the lane's record, the end state
-__device__ __forceinline__ void zc_own_rows(ZcLane &me, const ZcState z0, const Col &yb, long long row0, int j, int P) {
+// one sub-segment's record: the state it started from (as assumed) and ended in, its events (ev: n_rel | code << 16 , delay | up << 31;
+// slot kZcMaxEv takes what does not fit: count > kZcMaxEv says so)
+struct ZcLane { Zc32 start, end; int count, bad; unsigned int ev[kZcMaxEv + 1][2]; };
+__device__ __forceinline__ bool zc_same(const Zc32 &a, const Zc32 &b) {         // (a crossing row that is not pending is kZcNone on both sides)
+   return a.prev == b.prev && a.top == b.top && a.bot == b.bot && a.ttop == b.ttop && a.tbot == b.tbot; }
+// the own rows of sub-segment j from state z: events into the lane's record, the end state.  The samples are read kZcAhead batches of
+// eight rows ahead of the steps that use them (pre = the batches already on their way, or nullptr): a batch's load latency hides
+// behind the dependent steps of the batches in front of it instead of stalling every lane of the wave.
+constexpr int kZcAhead = 2;
+template <class ColT> __device__ __forceinline__ void zc_load8(int (&v)[8], const ColT &yb, int q) {
+   #pragma unroll
+   for (int k = 0; k < 8; ++k) v[k] = yb[q + k]; }
+struct ZcAhead { int v[kZcAhead][8]; };
+template <class ColT> __device__ __forceinline__ void zc_own_rows(ZcLane &me, const Zc32 z0, const ColT &yb, int j, int P, const ZcAhead *pre = nullptr) {
    int cnt = 0;
-   Zc32 z = zc_to32(z0, row0);
+   Zc32 z = z0;
+   const int qend = (j + 1) * kZcSub;
+   ZcAhead nx;
+   if (pre) nx = *pre;
+   else {
+      #pragma unroll
+      for (int a = 0; a < kZcAhead; ++a) zc_load8(nx.v[a], yb, j * kZcSub + 8 * a); }
    #pragma nounroll
-   for (int q = j * kZcSub; q < (j + 1) * kZcSub; q += 8) {
+   for (int q = j * kZcSub; q < qend; q += 8) {
       int v8[8];
       #pragma unroll
-      for (int k = 0; k < 8; ++k) v8[k] = yb[q + k];
+      for (int k = 0; k < 8; ++k) v8[k] = nx.v[0][k];
+      #pragma unroll
+      for (int a = 0; a + 1 < kZcAhead; ++a) {
+         #pragma unroll
+         for (int k = 0; k < 8; ++k) nx.v[a][k] = nx.v[a + 1][k]; }
+      zc_load8(nx.v[kZcAhead - 1], yb, min(q + 8 * kZcAhead, qend - 8));       // (behind the last batch: that batch again - no branch, no row outside the tile)
       #pragma unroll
       for (int k = 0; k < 8; ++k) {
          int cross;
          const int e = zc_step32(z, v8[k], q + k, P, cross);
          if (e) {
-            const int delay = q + k - cross;
-            if (cnt < kZcMaxEv && delay >= 0) {
-               me.ev[cnt][0] = (unsigned)(q + k) | ((unsigned)(v8[k] & 0xffff) << 16); me.ev[cnt][1] = (unsigned)delay | (e == 1 ? 0x80000000u : 0u); ++cnt; }
-            else cnt = kZcMaxEv + 1; } } }
-   me.end = zc_from32(z, row0); me.count = cnt; }
+            const int slot = cnt < kZcMaxEv ? cnt : kZcMaxEv;
+            me.ev[slot][0] = (unsigned)(q + k) | ((unsigned)(v8[k] & 0xffff) << 16); me.ev[slot][1] = (unsigned)(q + k - cross) | (e == 1 ? 0x80000000u : 0u);
+            ++cnt; } } }
+   me.end = z; me.count = cnt; }
 
 // 0: sub-segment L of the lanes starts where its predecessor ended; 1: it does not; 2: it holds more events than its record can
-// (a function of its own: inlined into k_decode the 64-bit compares ran into a register-pair spill the gfx950 backend rejects)
-__device__ __attribute__((noinline)) int zc_join_verdict(const ZcLane *lanes, int L, int j) {
+__device__ __forceinline__ int zc_join_verdict(const ZcLane *lanes, int L, int j) {
    const ZcLane &me = lanes[L];
    if (me.count > kZcMaxEv) return 2;
    return (j > 0 && !zc_same(me.start, lanes[L - 1].end)) ? 1 : 0; }
 
-template <class WT> __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, WT *walkers, ZcLane *lanes, int *ok, long long stop, unsigned long long *dbgp = nullptr) {
+template <class WT, bool kGlobal = false> __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx, WT *walkers, ZcLane *lanes, int *ok, long long stop, unsigned long long *dbgp = nullptr) {
    long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0;
    if (dbgp) k0 = clock64();
    const DevCfg *cfg = cx.cfg;
    const Tile &tl = cx.tile;
    const int ntrks = cfg->ntrks, nsub = tl.nrows / kZcSub;
    const int P = cfg->zc_peak_i;
-   const int L = threadIdx.x, trk = L / (nsub > 0 ? nsub : 1), j = L - trk * nsub;
-   const bool mine = L < ntrks * nsub;
-   if (L < ntrks) {                                                  // a whole tile in the regular regime?
-      const WT &w = walkers[L];
-      ok[L] = (tl.nrows % kZcSub == 0 && nsub >= 2 && stop >= tl.row0 + tl.nrows && w.next == tl.row0 && w.start < tl.row0
-               && tl.row0 - kZcWarm - 1 - tl.reset >= cfg->skew[L]          // every row read is behind the deskew FIFO's start-up
+   // thread -> (sub-segment, track), the tracks of a sub-segment side by side: neighbouring lanes then read the 18 bytes of one row
+   // (one or two cache lines per sub-segment and load, not one per lane); the lanes' records stay track-major (L)
+   const int T = threadIdx.x, j = T / ntrks, trk = T - j * ntrks;
+   const bool mine = T < ntrks * nsub;
+   const int L = trk * nsub + j;
+   if (T < ntrks) {                                                  // a whole tile in the regular regime?
+      const WT &w = walkers[T];
+      ok[T] = (tl.nrows % kZcSub == 0 && nsub >= 2 && stop >= tl.row0 + tl.nrows && w.next == tl.row0 && w.start < tl.row0
+               && tl.row0 - kZcWarm - 1 - tl.reset >= cfg->skew[T]          // every row read is behind the deskew FIFO's start-up
                && w.nevents + (unsigned)(nsub * kZcMaxEv) < cx.cap) ? 1 : 0; }
    __syncthreads();
    if (mine && ok[trk]) {
       ZcLane &me = lanes[L];
-      ZcState z;
-      const Col yb = tile_col(tl, trk, cfg->skew[trk]);              // y(n) = yb[n - row0] in the regular regime
-      if (j == 0) zc_load(z, walkers[trk]);
+      Zc32 z;
+      const auto yb = zc_col<kGlobal>(tl, trk, cfg->skew[trk]);              // y(n) = yb[n - row0] in the regular regime
+      ZcAhead nx;
+      if (j == 0) {
+         ZcState zs; zc_load(zs, walkers[trk]); z = zc_to32(zs, tl.row0);
+         #pragma unroll
+         for (int a = 0; a < kZcAhead; ++a) zc_load8(nx.v[a], yb, 8 * a); }
       else {
          const int q0 = j * kZcSub - cfg->zc_warm;
          Zc32 zw; zw.prev = yb[q0 - 1]; zw.top = 0; zw.bot = 0; zw.ttop = kZcNone; zw.tbot = kZcNone;
+         #pragma unroll
+         for (int a = 0; a < kZcAhead; ++a) zc_load8(nx.v[a], yb, q0 + 8 * a);
          #pragma nounroll
-         for (int q = q0; q < j * kZcSub; q += 8) {                   // (eight samples in flight, then the eight dependent steps)
+         for (int q = q0; q < j * kZcSub; q += 8) {                   // (the batches behind this one are in flight during its eight dependent steps; the ones read last are the first of the own rows)
             int v8[8];
             #pragma unroll
-            for (int k = 0; k < 8; ++k) v8[k] = yb[q + k];
+            for (int k = 0; k < 8; ++k) v8[k] = nx.v[0][k];
+            #pragma unroll
+            for (int a = 0; a + 1 < kZcAhead; ++a) {
+               #pragma unroll
+               for (int k = 0; k < 8; ++k) nx.v[a][k] = nx.v[a + 1][k]; }
+            zc_load8(nx.v[kZcAhead - 1], yb, q + 8 * kZcAhead);
             #pragma unroll
             for (int k = 0; k < 8; ++k) { int cross; (void)zc_step32(zw, v8[k], q + k, P, cross); } }
-         z = zc_from32(zw, tl.row0); }
+         z = zw; }
       me.start = z;
-      zc_own_rows(me, z, yb, tl.row0, j, P); }
+      zc_own_rows(me, z, yb, j, P, &nx); }
    __syncthreads();
    if (dbgp) k1 = clock64();
    // Does every sub-segment start where its predecessor ended?  Where one does not, it alone is run again (its own 64 rows) from
@@ -871,19 +924,20 @@ template <class WT> __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx,
          ZcLane &me = lanes[L];
          me.bad = zc_join_verdict(lanes, L, j); }
       __syncthreads();
-      if (L < ntrks) {
+      if (T < ntrks) {
          int fb = nsub;
-         if (ok[L]) for (int k = nsub - 1; k >= 0; --k) { const int bd = lanes[L * nsub + k].bad; if (bd == 2) ok[L] = 0; else if (bd == 1) fb = k; }
-         first_bad[L] = fb; }
+         if (ok[T]) for (int k = nsub - 1; k >= 0; --k) { const int bd = lanes[T * nsub + k].bad; if (bd == 2) ok[T] = 0; else if (bd == 1) fb = k; }
+         first_bad[T] = fb; }
       __syncthreads();
       bool any = false;
       for (int t = 0; t < ntrks; ++t) any = any || (ok[t] && first_bad[t] < nsub);
       if (!any) break;
       if (mine && ok[trk] && first_bad[trk] == j) {
          ZcLane &me = lanes[L];
-         const Col yb = tile_col(tl, trk, cfg->skew[trk]);
-         me.start = lanes[L - 1].end;
-         zc_own_rows(me, lanes[L - 1].end, yb, tl.row0, j, P); }
+         const auto yb = zc_col<kGlobal>(tl, trk, cfg->skew[trk]);
+         const Zc32 zp = lanes[L - 1].end;
+         me.start = zp;
+         zc_own_rows(me, zp, yb, j, P); }
       __syncthreads(); }
    if (dbgp) k2 = clock64();
    if (mine && ok[trk]) {                                            // events in row order; the walker moves to the tile's end
@@ -895,11 +949,11 @@ template <class WT> __device__ __forceinline__ void zeros_tile_parallel(Ctx &cx,
          const int v = (int)(short)(me.ev[k][0] >> 16);
          zc_event(cx, trk, idx + k, n, v, (me.ev[k][1] >> 31) != 0, n - (long long)(me.ev[k][1] & 0x7fffffffu)); } }
    __syncthreads();
-   if (L < ntrks && ok[L]) {
-      WT &w = walkers[L];
+   if (T < ntrks && ok[T]) {
+      WT &w = walkers[T];
       unsigned int total = 0;
-      for (int k = 0; k < nsub; ++k) total += (unsigned)lanes[L * nsub + k].count;
-      zc_store(w, lanes[L * nsub + nsub - 1].end);
+      for (int k = 0; k < nsub; ++k) total += (unsigned)lanes[T * nsub + k].count;
+      zc_store(w, zc_from32(lanes[T * nsub + nsub - 1].end, tl.row0));
       w.nevents += total; w.next = tl.row0 + tl.nrows; }
    if (dbgp) k3 = clock64();
    __syncthreads();

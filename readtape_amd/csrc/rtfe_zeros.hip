@@ -93,7 +93,10 @@ __global__ void __launch_bounds__(128, 4) k_zeros(const DevCfg *__restrict__ cfg
          __syncthreads();
          if (cfg.invert) { load_tile(&cfg, cx.tile, rows, nrows); __syncthreads(); }
          else cx.tile.x = const_cast<int16_t *>(rows) + (tile0 - cx.tile.halo) * ntrks;      // (rows in front of the restart row are never read)
-         if (par) zeros_tile_parallel(cx, walkers, lanes, s_ok, stop, (unsigned long long *)nullptr);
+         if (par) {
+            if (cfg.invert) zeros_tile_parallel<ZWalker, false>(cx, walkers, lanes, s_ok, stop, cfg.debug ? scratch->dbg2 : (unsigned long long *)nullptr);
+            else zeros_tile_parallel<ZWalker, true>(cx, walkers, lanes, s_ok, stop, cfg.debug ? scratch->dbg2 : (unsigned long long *)nullptr); }      // (the rows where they lie in HBM)
+         if (par && cfg.debug && (int)threadIdx.x < ntrks) { atomicAdd(&scratch->dbg2[4], 1ull); if (s_ok[threadIdx.x]) atomicAdd(&scratch->dbg2[5], 1ull); if (threadIdx.x == 0) atomicAdd(&scratch->dbg2[6], 1ull); }      // (RTFE_DEBUG=1: tools/gpu_zeros_phase.py)
          else { if (threadIdx.x < (unsigned)ntrks) s_ok[threadIdx.x] = 0; __syncthreads(); }
          if (is_walker && !s_ok[trk]) {                              // the burst's first and last tile, partial tiles: row by row
             ZWalker w = walkers[trk];
