@@ -518,3 +518,23 @@ def test_fragments_concatenate_to_the_whole_tap(name, nshards, tmp_path, gpu):
         pipeline.decode_tape(g["hdr"], g["rows"], str(tmp_path / "w.tap"))
         want = open(tmp_path / "w.tap", "rb").read()
     assert open(tap, "rb").read() == want
+
+
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "pe_zeros", "gcr_m"])
+def test_packed_event_fetch_holds_the_same_lists(name, gpu, monkeypatch):
+    """ScanResult.fetch packs the event arena on the device before the copy (every burst's lists to the burst's longest list) and
+    re-bases the host copy of the burst table: every (burst, parameter set, track) list is what the unpacked fetch returns."""
+    g = load_case(name)
+    cfg = config_for(g["hdr"], g["oracle_opts"])
+    fe = frontend.FrontEnd(cfg)
+    r = fe.scan(g["rows"])
+    monkeypatch.setenv("RTFE_PACK_EVENTS", "0")
+    r.fetch()
+    plain = {(b, p, t): r.track_events(b, p, t).tobytes() for b in range(r.nbursts) for p in range(len(cfg.parmsets)) for t in range(cfg.ntrks)}
+    cap_plain = r.bursts["event_cap"].copy()
+    monkeypatch.setenv("RTFE_PACK_EVENTS", "1")
+    r.fetch()
+    assert r.nbursts and (r.bursts["event_cap"] <= cap_plain).all() and len(r._events) <= int(cap_plain.astype("int64").sum()) * len(cfg.parmsets) * cfg.ntrks
+    for key, blob in plain.items():
+        assert r.track_events(*key).tobytes() == blob, key
+    assert sum(len(v) for v in plain.values()) > 0
