@@ -233,7 +233,7 @@ class ReferenceFatal(RuntimeError):
 def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None = None, fe_factory=None,
                 skew=None, invert=False, parms_text: str | None = None, find_zeros=False, evt_path=None, differentiate=False,
                 subsample: int = 1, deskew: bool = False, deskew_prefix_rows: int = 1 << 22, trkorder: str | None = None,
-                out_base: str | None = None, in_name: str | None = None, tap_format: bool = True):
+                out_base: str | None = None, in_name: str | None = None, tap_format: bool = True, fluxdir: str = "neg", reverse: bool = False):
     """Decodes one tape; returns (stats dict, ScanResult).  `fe_factory(cfg)` builds the front end
     (default: the GPU one; tests/cpu_emul passes the emulated library).
     Output: tap_path = one SIMH .tap file; or out_base = the reference's own naming - <out_base>.tap, or with tap_format=False
@@ -242,7 +242,7 @@ def decode_tape(hdr, rows, tap_path, log_path=None, opts: DecodeOptions | None =
     opts = opts or DecodeOptions()
     if hdr.mode == tbin.MODE_WW:                                           # one chain per tape, detector state handed back and forth: its own path
         st = decode_tape_ww(hdr, rows, tap_path, log_path=log_path, order=trkorder, verbose=opts.verbose, evt_path=evt_path, fe_factory=fe_factory,
-                            invert=invert, out_base=out_base, in_name=in_name)
+                            invert=invert, out_base=out_base, in_name=in_name, deskew=deskew, fluxdir=fluxdir, reverse=reverse)      # (-fluxdir, -reverse: Whirlwind only)
         return st, None
     lib = _load_decode_lib()
     if trkorder:                                                           # -order= wins over the header's TBINORD extension (src/readtape.c:1346-1355)
