@@ -351,7 +351,7 @@ static int replay_any(const struct rt_options *opt, const struct rt_parms *parms
    if (d->logf) fclose(d->logf);
    if (rp.evtf) { fflush(rp.evtf); if (ftruncate(fileno(rp.evtf), ftell(rp.evtf))) {} fclose(rp.evtf); }
    rt_dec_free(d);
-   return 0; }
+   return (prepass && rp.reference_fatal) ? -3 : 0; }      /* (a pre-pass has no statistics to carry it: the reference died inside the pre-pass) */
 
 int rt_replay_run(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,

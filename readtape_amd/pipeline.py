@@ -171,6 +171,8 @@ def calibrate_deskew(hdr, rows, full, o, fe_factory, invert=False, find_zeros=Fa
                                   exact, free, None, log_path.encode() if log_path else None,
                                   evt_path.encode() if evt_path else None, int(append), delays, C.byref(nblks), C.byref(hit_end))
         _release(keep)
+        if rc == -3:
+            raise ReferenceFatal("a fatal assert of the reference's detector inside the -deskew pre-pass", {"reference_fatal": 1, "events_delivered": 0})
         if rc != 0:
             raise RuntimeError("rt_replay_deskew failed")
         if hit_end.value and n0 < nrows:
@@ -210,6 +212,8 @@ def detect_density(hdr, rows, full, o, fe_factory, invert=False, log_path=None, 
                                    exact, free, None, log_path.encode() if log_path else None,
                                    evt_path.encode() if evt_path else None, C.byref(bpi), C.byref(implied), C.byref(nblks), C.byref(hit_end))
         _release(keep)
+        if rc == -3:
+            raise ReferenceFatal("a fatal assert of the reference's detector inside the density pre-pass", {"reference_fatal": 1, "events_delivered": 0})
         if rc != 0:
             raise RuntimeError("rt_replay_density failed")
         if hit_end.value and n0 < nrows and bpi.value >= 0:
