@@ -109,7 +109,7 @@ def e2e_line(tape, copies, conf, dev):
         tbin.write_tbin(path, hdr, rows)
         del rows
         opts = pipeline.DecodeOptions(multiple_tries=conf["nparmsets"] > 1, verbose=False)      # (-m: the reference's built-in sets)
-        threads = max(1, min(12, (os.cpu_count() or 1) - 1))
+        threads = max(1, min(16, (os.cpu_count() or 1) - 1))
         st = ingest.decode_file_streaming(path, os.path.join(wd, "e.tap"), window_rows=1 << 21, halo_rows=1 << 18, opts=opts,
                                           cfgkw=dict(find_zeros=True) if conf["find_zeros"] else None, device=str(dev), replay_threads=threads)
         same = None

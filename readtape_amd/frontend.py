@@ -190,6 +190,18 @@ class TorchBackend:
     def stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
+    def record(self, stream_handle):
+        """An event behind what has been queued on the stream so far (ScanResult.fetch waits for it instead of for the whole device:
+        a second scan may already be queued behind the one that is fetched)."""
+        torch = self.torch
+        st = torch.cuda.current_stream(self.device) if stream_handle is None else torch.cuda.ExternalStream(int(stream_handle), device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        return ev
+
+    def wait(self, ev):
+        ev.synchronize()
+
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -233,7 +245,10 @@ class ScanResult:
 
     def fetch(self, events=True):
         fe, be = self.fe, self.fe.backend
-        be.sync()
+        if getattr(self, "done", None) is not None:
+            be.wait(self.done)
+        else:
+            be.sync()
         nb = 1 if self.single else int(be.to_numpy(self.bufs["nbursts"], np.int32)[0])
         self.bursts = be.to_numpy(self.bufs["bursts"], BURST_DTYPE)[:nb].copy()
         P, T = len(fe.cfg.parmsets), fe.cfg.ntrks
@@ -366,6 +381,8 @@ class FrontEnd:
             raise RuntimeError(f"rtfe_scan failed ({rc}): {self.lib.rtfe_last_error().decode()}")
         r = ScanResult(self, b, b["max_bursts"])
         r._rows_keepalive = d_rows
+        if hasattr(be, "record"):
+            r.done = be.record(stream)
         return r
 
     def scan_exact(self, rows, reset_row, end_row, parmset_mask=0xFFFFFFFF, screen_off=False, row_base=0, stream=None) -> ScanResult:

@@ -30,7 +30,7 @@ def _payload_geometry(path):
 
 
 def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17, opts: pipeline.DecodeOptions | None = None, cfgkw=None,
-                          device="cuda:0", replay_threads: int = 1):
+                          device="cuda:0", replay_threads: int = 1, read_threads: int = 4):
     """Decodes the .tbin file `path` to the SIMH file `tap_path` through device windows of `window_rows` rows (a multiple of 1024).
     Returns statistics incl. the end-to-end rate (disk -> .tap), the time spent in the host replay and the rows the halos re-read.
     replay_threads > 1: the windows' host replays run side by side (fragments are independent: each has its own decoder context
@@ -45,43 +45,64 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     ntrks = hdr.ntrks
     full = pipeline.default_parmsets(hdr.mode, opts.nparmsets or (15 if opts.multiple_tries else 1))
     cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=pipeline.frontend_parmsets(full), **(cfgkw or {}))
-    fe = frontend.FrontEnd(cfg, device=device)
+    fes = [frontend.FrontEnd(cfg, device=device) for _ in range(2)]      # two scans are in flight: window k is fetched while k + 1 is copied and scanned
+    fe = fes[0]
     dev = torch.device(device)
     spans = [(lo, min(nrows, lo + window_rows)) for lo in range(0, nrows, window_rows)]
     cap = window_rows + halo_rows
     from concurrent.futures import ThreadPoolExecutor
     nthreads = max(1, int(replay_threads))
     depth = 2 if nthreads == 1 else nthreads + 2
-    pinned = [torch.empty((cap, ntrks), dtype=torch.int16, pin_memory=True) for _ in range(2)]       # hipHostMalloc
+    NP = 3                                                # pinned buffers: one being read into, one being copied from, one in between
+    pinned = [torch.empty((cap, ntrks), dtype=torch.int16, pin_memory=True) for _ in range(NP)]      # hipHostMalloc
     dwin = [torch.empty((cap, ntrks), dtype=torch.int16, device=dev) for _ in range(depth)]
     pool = ThreadPoolExecutor(nthreads) if nthreads > 1 else None
-    fe_exact = frontend.FrontEnd(cfg, device=device) if pool else fe       # exact rescans of concurrent replays: their own context, one at a time
+    read_threads = max(1, int(read_threads))
+    readers = ThreadPoolExecutor(read_threads) if read_threads > 1 else None
+    fe_exact = frontend.FrontEnd(cfg, device=device)       # exact rescans of the replays: their own context, one at a time
     exact_lock = threading.Lock()
     copy_stream, scan_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    copied = [torch.cuda.Event() for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(NP)]
     fd = os.open(path, os.O_RDONLY)
     t_read = [0.0]
     data_end = [nrows]
 
-    def read_rows(dst, lo, end):
-        """rows [lo, end) of the payload -> the pinned tensor dst (positional reads: safe beside the other thread's)."""
-        t0 = time.perf_counter()
-        view = memoryview(dst.numpy()).cast("B")[: (end - lo) * 2 * ntrks]
-        pos, done = off + lo * 2 * ntrks, 0
+    def read_span(arr, r0, r1, lo):
+        """rows [lo + r0, lo + r1) of the payload -> arr[r0:r1]; returns the first row (relative to lo) whose head-0 sample is the end
+        marker, or -1 (looked for here, by the thread that has just read the rows: a strided pass over the whole window in one
+        thread had become the longest stage of the pipeline)."""
+        view = memoryview(arr).cast("B")[r0 * 2 * ntrks: r1 * 2 * ntrks]
+        pos, done = off + (lo + r0) * 2 * ntrks, 0
         while done < len(view):
             got = os.preadv(fd, [view[done: done + (1 << 30)]], pos + done)
             if got <= 0:
                 raise IOError("short read")
             done += got
+        marks = np.flatnonzero(arr[r0:r1, 0] == tbin.END_MARK)
+        return r0 + int(marks[0]) if marks.size else -1
+
+    def read_rows(dst, lo, end):
+        """rows [lo, end) of the payload -> the pinned tensor dst (positional reads: safe beside the other thread's), in `read_threads`
+        pieces side by side (from the page cache one thread copies ~13 GB/s).  Returns the first end-marker row (relative to lo) or -1."""
+        t0 = time.perf_counter()
+        arr = dst.numpy()
+        n = end - lo
+        if readers is None or n * 2 * ntrks < (8 << 20):
+            first = read_span(arr, 0, n, lo)
+        else:
+            step = -(-n // read_threads)
+            futs = [readers.submit(read_span, arr, a, min(n, a + step), lo) for a in range(0, n, step)]
+            hits = [h for h in (f.result() for f in futs) if h >= 0]
+            first = min(hits) if hits else -1
         t_read[0] += time.perf_counter() - t0
+        return first
 
     def read_window(k):
         lo, hi = spans[k]
         end = min(nrows, hi + halo_rows)
-        read_rows(pinned[k & 1], lo, end)
-        marks = np.flatnonzero(pinned[k & 1].numpy()[: end - lo, 0] == tbin.END_MARK)
-        if marks.size:                                    # an end marker inside the payload: the tape ends there
-            data_end[0] = min(data_end[0], lo + int(marks[0]))
+        first = read_rows(pinned[k % NP], lo, end)
+        if first >= 0:                                    # an end marker inside the payload: the tape ends there
+            data_end[0] = min(data_end[0], lo + first)
         return min(end, data_end[0])
 
     def launch(k, end):
@@ -93,11 +114,11 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
             busy[k % depth].result()
             busy[k % depth] = None
         with torch.cuda.stream(copy_stream):
-            dwin[k % depth][: end - lo].copy_(pinned[k & 1][: end - lo], non_blocking=True)
-            copied[k & 1].record(copy_stream)
-        scan_stream.wait_event(copied[k & 1])
+            dwin[k % depth][: end - lo].copy_(pinned[k % NP][: end - lo], non_blocking=True)
+            copied[k % NP].record(copy_stream)
+        scan_stream.wait_event(copied[k % NP])
         piece = dwin[k % depth][: end - lo]
-        fin = pipeline.scan_fragment(fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0], stream=scan_stream.cuda_stream)
+        fin = pipeline.scan_fragment(fes[k & 1], piece, hi - lo, lo, lo == 0, hi >= data_end[0], stream=scan_stream.cuda_stream)
         return piece, fin, end
 
     busy = [None] * depth
@@ -119,18 +140,32 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     total = 0
     try:
         with open(tap_path, "wb") as tapf:
-            pend = launch(0, read_window(0)) if spans else None
+            # software pipeline: while window k is fetched and handed to its replay, window k + 1 is being copied and scanned (queued
+            # behind k on the device) and window k + 2 is being read
+            pend = {0: launch(0, read_window(0))} if spans else {}
+            reader, nxt, reading = None, [0], -1
+
+            def start_read(kk):
+                def work():
+                    nxt[0] = read_window(kk)
+                th = threading.Thread(target=work)
+                th.start()
+                return th
+            if len(spans) > 1:
+                reader, reading = start_read(1), 1
             for k, (lo, hi) in enumerate(spans):
                 if lo >= data_end[0]:
                     break
                 hi = min(hi, data_end[0])
-                piece, fin, end_k = pend
-                reader, nxt = None, [0]
-                if k + 1 < len(spans):                        # window k+1 is read while window k is scanned and replayed
-                    def work(kk=k + 1):
-                        nxt[0] = read_window(kk)
-                    reader = threading.Thread(target=work)
-                    reader.start()
+                if reader is not None and reading == k + 1:     # window k + 1 has been read: queue its copy and scan behind window k's
+                    reader.join()
+                    reader = None
+                    pend[k + 1] = launch(k + 1, nxt[0])          # (its device window and scan context were window k - 1's: fetched and replayed, or waited for in launch)
+                    if k + 2 < len(spans):
+                        reader, reading = start_read(k + 2), k + 2      # (its pinned buffer was window k - 1's: copied long ago)
+                piece, fin, end_k = pend.pop(k)
+                if fin is None:
+                    continue
                 t0 = time.perf_counter()
                 res, nb, bound = fin()
                 t_wait += time.perf_counter() - t0
@@ -142,7 +177,7 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                     host = torch.empty((end_k - lo, ntrks), dtype=torch.int16, pin_memory=True)
                     read_rows(host, lo, end_k)
                     piece = host.to(dev)
-                    res, nb, bound = pipeline.scan_fragment(fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
+                    res, nb, bound = pipeline.scan_fragment(fes[k & 1], piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
                 stats["halo_rows_read"] += end_k - hi
                 if res.nbursts:
                     if pool:
@@ -151,9 +186,8 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                         pieces.append(fut)
                     else:
                         pieces.append(replay(k, res, piece, lo, bound))
-                if reader is not None:
-                    reader.join()
-                    pend = launch(k + 1, nxt[0])              # (its buffers were window k-1's: both copies of it are finished)
+            if reader is not None:
+                reader.join()
             for pc in pieces:                                 # in window order
                 data, st, secs = pc.result() if hasattr(pc, "result") else pc
                 t_replay += secs
@@ -166,11 +200,14 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t_start
     finally:                                              # (also when a replay raised: no thread, file or device context is left behind)
+        if readers:
+            readers.shutdown(wait=True)
         os.close(fd)
         if pool:
             pool.shutdown(wait=True, cancel_futures=True)
-            fe_exact.close()
-        fe.close()
+        fe_exact.close()
+        for f in fes:
+            f.close()
     stats.update(rows=data_end[0], seconds=dt, msamples_per_s=data_end[0] / dt / 1e6, replay_seconds=t_replay, read_seconds=t_read[0], scan_wait_seconds=t_wait,
                  replay_events_per_s=(stats["events_delivered"] / t_replay) if t_replay > 0 else None, tap_bytes=total + (4 if total else 0))
     return stats

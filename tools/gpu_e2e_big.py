@@ -10,7 +10,7 @@ with tempfile.TemporaryDirectory() as wd:
     path = os.path.join(wd, "big.tbin")
     tbin.write_tbin(path, tape.spec.header(), np.tile(tape.rows, (copies, 1)))
     ref = None
-    for th, wr in ((1, 21), (8, 21), (8, 22), (8, 23), (12, 22), (16, 22)):
+    for th, wr in ((1, 21), (8, 22), (12, 22), (16, 22), (24, 22)):
         st = ingest.decode_file_streaming(path, os.path.join(wd, f"o{th}.tap"), window_rows=1 << wr, halo_rows=1 << 18, replay_threads=th)
         data = open(os.path.join(wd, f"o{th}.tap"), "rb").read()
         ref = ref or data
