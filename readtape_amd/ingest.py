@@ -5,10 +5,12 @@ Replaces the reference's read loop (two fread()s per row into a stack buffer, sr
     disk --(reader thread, readinto)--> pinned host buffer --(hipMemcpyAsync, copy stream)--> device window
          --(rtfe_scan, compute stream)--> events --(host replay of the window's own bursts)--> piece of the .tap
 
-Two pinned buffers and two device windows: while window k is scanned and replayed, window k+1 is read and copied.  A window is a
-FRAGMENT in the sense of pipeline.decode_fragment: it carries a halo of the following rows, owns the bursts whose zone ends inside
-it, and its .tap piece concatenates with its neighbours' (DESIGN.md 6).  PyTorch supplies the pinned allocation (hipHostMalloc),
-the streams and the events; nothing here computes on the CPU except the block decoders.
+A three-stage software pipeline: window k + 2 is being read (three pinned buffers; the read itself in `read_threads` pieces side by
+side), window k + 1 is being copied and scanned behind window k on the device (two scan contexts), window k is fetched - event arena
+packed on the device first - and handed to the replay threads.  A window is a FRAGMENT in the sense of pipeline.decode_fragment: it
+carries a halo of the following rows, owns the bursts whose zone ends inside it, and its .tap piece concatenates with its
+neighbours' (DESIGN.md 6).  PyTorch supplies the pinned allocation (hipHostMalloc), the streams and the events; nothing here
+computes on the CPU except the block decoders.
 """
 from __future__ import annotations
 
