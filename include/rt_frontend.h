@@ -13,7 +13,9 @@
  *
  * Plain pointers and sizes only; every pointer whose name starts with d_ is a DEVICE pointer
  * (hipMalloc / torch storage).  All calls are asynchronous on `stream` (a hipStream_t passed as
- * void*, NULL = default stream) unless stated; nothing here synchronises the device.
+ * void*, NULL = default stream) unless stated; nothing here synchronises the device.  (rtfe_scan may run one of
+ * its kernels - the burst heads - on a stream of its own beside the dense pass; it forks from and joins back into
+ * `stream` with events, so everything rtfe_scan wrote is complete when `stream` reaches the point behind the call.)
  *
  * Exactness contract.  The reference restarts all detector state at every block attempt
  * (src/decoder.c:425-455), at a sample only its sequential bit decoders know.  rtfe_scan()

@@ -174,6 +174,12 @@ static int readblock_once(void *ctx, int retry) {
 
    struct evsrc src;
    const long dump_pos = rp->evtf ? ftell(rp->evtf) : 0;      /* a restarted attempt rewinds the optional dump */
+   /* ... and what a pre-pass accumulates ACROSS attempts (the -deskew peak statistics, the density histogram): the reference reads
+    * the block once, a restarted attempt must not count its transitions twice (found by tests/stress_gpu.py, seed 810 tape 100:
+    * the pre-pass had its 1000 transitions per track one block early) */
+   const int prepass_stats = d->doing_deskew || d->doing_density_detection;
+   __typeof__(d->peakstat) saved_peakstat; __typeof__(d->estden) saved_estden;
+   if (prepass_stats) { saved_peakstat = d->peakstat; saved_estden = d->estden; }
    int64_t b = find_burst(rp, s0);
    rtfe_event *exact_events = NULL;
    int using_exact = 0;
@@ -188,6 +194,7 @@ static int readblock_once(void *ctx, int retry) {
    if (exact_len < (1 << 12)) exact_len = 1 << 12;
 restart:
    if (rp->evtf && (restarted || using_exact)) fseek(rp->evtf, dump_pos, SEEK_SET);
+   if (prepass_stats && (restarted || using_exact)) { d->peakstat = saved_peakstat; d->estden = saved_estden; }
    if (b < 0) {                                               /* outside every proven-safe zone: exact device scan */
       if (!rp->exact) { ++rp->device_failures; d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
       uint32_t cnt[RT_MAXTRKS]; rtfe_burst eb; uint32_t cap = 0;

@@ -43,6 +43,9 @@ struct rtfe_handle {
    int walk_lds_bytes;
    int zeros_kernel;                   // -zeros scans run k_zeros (RTFE_ZEROS_KERNEL=0: k_decode's zero-crossing mode, kept for tests)
    int lane_walk;                      // the record walk runs one lane per walker (k_lwalk) where that fits; RTFE_LWALK=0/1
+   hipStream_t side;                   // the burst heads run beside k_screen (both only need k_bursts' table): RTFE_OVERLAP_HEADS=0 puts them back in line
+   hipEvent_t ev_fork, ev_join;
+   int overlap_heads;
 };
 
 static thread_local char g_err[512] = "";
@@ -318,6 +321,8 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (d.ntrks * (d.tile_rows / 64) > 128) h->zeros_kernel = 0;      // (its workgroup is two waves)
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zeros), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout_zeros(d).total + 64);
    h->lane_walk = getenv("RTFE_LWALK") ? atoi(getenv("RTFE_LWALK")) != 0 : 0;      // (measured: no faster than k_walk)
+   h->overlap_heads = getenv("RTFE_OVERLAP_HEADS") ? atoi(getenv("RTFE_OVERLAP_HEADS")) != 0 : 1;
+   h->side = nullptr;
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, h->walk_lds_bytes);
    if (c->nparmsets * c->ntrks <= 32 && (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16 <= 150 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lwalk), hipFuncAttributeMaxDynamicSharedMemorySize, (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16);
@@ -343,6 +348,7 @@ extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
    if (h->timing) for (int i = 0; i < kNumKernels; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
+   if (h->side) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->side); }
    (void)hipFree(h->d_dev);
    delete h; }
 
@@ -522,11 +528,18 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t1(3, st); t0(4, st); t1(4, st); t0(5, st); t1(5, st); }
    else {
       // burst heads from the samples (start-up path) -> the record walk -> whatever the records could not decide
-      t0(3, sq);
-      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, sq, h->d_dev, d_rows, (long long)nrows,
+      hipStream_t sh = st;
+      if (h->overlap_heads) {                                          // fork: the heads on the side stream, behind k_bursts
+         if (!h->side) {
+            if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; h->overlap_heads = 0; }
+            else { (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming); } }
+         if (h->side) { sh = h->side; (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(sh, h->ev_fork, 0); } }
+      t0(3, sh);
+      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, sh, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
                          (const TileDir *)dirp, (const CandUnit *)poolp, (int)kDecodeHead, ctlp, statep);
-      t1(3, sq);
+      t1(3, sh);
+      if (sh != st) (void)hipEventRecord(h->ev_join, sh);
       const long long ntiles = ntiles_for(h, nrows);
       int spc = (160 * 1024) / (h->screen_lds_bytes + 1024);
       if (spc > 8) spc = 8;
@@ -537,6 +550,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_screen, dim3((unsigned)sgrid), dim3(256), h->screen_lds_bytes, st, h->d_dev, d_rows, (long long)nrows, dirp, poolp,
                          ntiles, scratch->scr, (const unsigned int *)deadp);
       t1(2, st);
+      if (sh != st) (void)hipStreamWaitEvent(st, h->ev_join, 0);       // join: the walk needs both
       int wthreads = threads;
       if (getenv("RTFE_WALK_THREADS")) { const int v = atoi(getenv("RTFE_WALK_THREADS")); if (v >= threads && v <= 256 && v % 64 == 0) wthreads = v; }
       int wpc = (160 * 1024) / (h->walk_lds_bytes + 1024);

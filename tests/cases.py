@@ -70,6 +70,20 @@ def case_ww_skew_long(seed=46):
                          skew_cells=(0.12, 0.0, 0.28, 0.07, 0.2, 0.33))
 
 
+DESKEW_RESTART_PARMS = ("parms active, clk_window, clk_alpha, agc_window, agc_alpha, min_peak, clk_factor, pulse_adj, pkww_bitfrac, pkww_rise, midbit, z1pt, z2pt, id\n"
+                        "{1, 0, 0.2, 0, 0.8, 0.5, 0, 0.3, 1.395, 0.3, 0.5, 1.45, 2.35, PRM}\n")
+
+
+def case_nrzi7_deskew_restart(seed=619833729):
+    # (found by tests/stress_gpu.py, seed 810 tape 100) weak, noisy 7-track tape, a window of 27 samples: the first block's attempt
+    # of the -deskew pre-pass crosses a device restart and is replayed a second time from an exact scan - the pre-pass' peak
+    # statistics must not count its transitions twice (the reference goes on to the second block: the first has < 1000 per track)
+    return synth.nrzi_tape(seed=seed, nblocks=3, minlen=16, maxlen=3000, marks_every=0, ntrks=7, gap_samples=4000, amplitude=0.6, noise_mv=50.0, jitter=0.0)
+
+
+case_nrzi7_deskew_restart.parms_text = DESKEW_RESTART_PARMS
+
+
 def case_gcr_noisy(seed=17):
     return synth.gcr_tape(seed=seed, nblocks=2, minlen=40, maxlen=120, gap_samples=2500, noise_mv=45.0, jitter=0.05, amplitude=1.2)
 
@@ -253,6 +267,7 @@ CASES = {
     "gcr_diffz":    (case_gcr,        ["-gcr", "-zeros", "-differentiate"], ["-zeros", "-differentiate"]),
     "nrzi9_deskew": (case_nrzi9_skew, ["-nrzi", "-deskew"],            ["-deskew"]),
     "nrzi9_deskew_long": (case_nrzi9_skew_long, ["-nrzi", "-deskew"],  ["-deskew"]),
+    "nrzi7_deskew_restart": (case_nrzi7_deskew_restart, ["-nrzi", "-ntrks=7", "-deskew"], ["-ntrks=7", "-deskew"]),
     "gcr_deskew":   (case_gcr_skew,   ["-gcr", "-deskew"],             ["-deskew"]),
     "nrzi9_nobpi":  (case_nrzi9_nobpi, ["-nrzi"],                      []),
     "nrzi9_nobpi_short": (case_nrzi9_nobpi_short, ["-nrzi"],           []),

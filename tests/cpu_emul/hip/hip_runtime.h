@@ -50,6 +50,11 @@ inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSucces
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;       // (launches are synchronous here: a second stream is the first)
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return 1; }      // "no side stream": the caller stays in line
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "emulated"; }

@@ -8,8 +8,8 @@ from emul_util import emul_frontend
 from golden_util import load_case
 from readtape_amd import pipeline
 
-CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "gcr_deskew", "nrzi9_nobpi", "nrzi9_nobpi_short", "nrzi9_diffz", "pe_diffz", "gcr_diffz", "nrzi9_diffpk", "nrzi9_diffpk_clean", "nrzi9_diffpk_skew", "gcr_diffpk", "pe_diffpk", "nrzi9_cut", "nrzi9_cut_zeros", "noise_only", "tiny", "nrzi9_nobpi_deskew", "nrzi7_order", "pe_order", "gcr_order_m", "nrzi7_order_ignored"]
-EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "nrzi9_sub2", "pe", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_zeros", "gcr_correct", "nrzi9_deskew", "nrzi9_nobpi_short", "nrzi9_diffz", "pe_diffz", "gcr_diffz", "nrzi9_diffpk", "nrzi9_cut", "nrzi9_cut_zeros", "noise_only", "tiny", "nrzi7_order", "pe_order", "nrzi7_order_ignored"]     # the thread emulation is slow: a subset here, all on the GPU
+CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "nrzi7_deskew_restart", "gcr_deskew", "nrzi9_nobpi", "nrzi9_nobpi_short", "nrzi9_diffz", "pe_diffz", "gcr_diffz", "nrzi9_diffpk", "nrzi9_diffpk_clean", "nrzi9_diffpk_skew", "gcr_diffpk", "pe_diffpk", "nrzi9_cut", "nrzi9_cut_zeros", "noise_only", "tiny", "nrzi9_nobpi_deskew", "nrzi7_order", "pe_order", "gcr_order_m", "nrzi7_order_ignored"]
+EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "nrzi9_sub2", "pe", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_zeros", "gcr_correct", "nrzi9_deskew", "nrzi7_deskew_restart", "nrzi9_nobpi_short", "nrzi9_diffz", "pe_diffz", "gcr_diffz", "nrzi9_diffpk", "nrzi9_cut", "nrzi9_cut_zeros", "noise_only", "tiny", "nrzi7_order", "pe_order", "nrzi7_order_ignored"]     # the thread emulation is slow: a subset here, all on the GPU
 
 
 def decode_case(g, tmp_path, fe_factory):

@@ -48,3 +48,25 @@ def test_end_marker_inside_the_payload_ends_the_tape(tmp_path):
     st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=1 << 15, halo_rows=1 << 12)
     assert st["rows"] == cut
     assert open(tmp_path / "s.tap", "rb").read() == want
+
+
+@pytest.mark.parametrize("threads", [1, 6])
+def test_windows_read_in_parallel_pieces_with_an_end_marker_in_one_of_them(threads, tmp_path):
+    """Windows of 9.4 MB are read as four pieces side by side, each piece looks for the end marker in its own rows; two scans are in
+    flight while a third window is read.  Same bytes as the whole-tape decode of the rows in front of the marker."""
+    tape = synth.nrzi_tape(seed=75, nblocks=40, minlen=200, maxlen=1500, marks_every=9, gap_samples=3000)
+    hdr = tape.spec.header()
+    rows = np.tile(tape.rows, (4, 1))
+    win = 1 << 19
+    cut = 3 * win + win * 5 // 8 + 12345                  # inside the third piece of the fourth window
+    assert cut < rows.shape[0] and win * 2 * hdr.ntrks >= (8 << 20)
+    want = _whole(hdr, rows[:cut], str(tmp_path / "whole.tap"))
+    rows = rows.copy()
+    rows[cut, 0] = tbin.END_MARK
+    path = str(tmp_path / "t.tbin")
+    with open(path, "wb") as f:
+        f.write(tbin.pack_header(hdr))
+        f.write(rows.tobytes())
+    st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=win, halo_rows=1 << 15, replay_threads=threads, read_threads=4)
+    assert st["rows"] == cut and st["windows"] >= 4
+    assert open(tmp_path / "s.tap", "rb").read() == want
