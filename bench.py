@@ -289,7 +289,11 @@ def main():
         for k in kms: kms[k] /= max(args.steps, 1)
         if conf["find_zeros"]:                       # -zeros scans run k_zeros in the timing slot of the burst-head pass
             kms = {("k_zeros" if k == "k_decode_head" else k): v for k, v in kms.items()}
-        dom = max(kms, key=kms.get)
+        # the dominant kernel.  On the record path the burst heads run BESIDE k_screen on a stream of their own (rtfe_scan forks and
+        # joins): their events bracket the time they shared the device with it, not work of their own (0.36 ms when run in line)
+        # - they are never the dominant kernel there.
+        cand = {k: v for k, v in kms.items() if not (k == "k_decode_head" and kms.get("k_screen", 0) > 0.5 * v and kms.get("k_screen", 0) > 0.1)}
+        dom = max(cand, key=cand.get)
         alg_bytes = 2 * cfg.ntrks * nrows + 16 * nevents        # 18 B per sample instant + 16 B per event
         achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         traffic = None

@@ -455,8 +455,10 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (per_cu > wave_lim) per_cu = wave_lim;
    if (per_cu < 1) per_cu = 1;
    const int dgrid = h->num_cus * per_cu;
-   // (k_quiet, k_bursts and the burst heads do not depend on k_screen, but running them beside it on a second stream
-   //  loses: the single-workgroup k_bursts starves behind k_screen's workgroups - measured 9.6 vs 10.7 Gsamples/s)
+   // (k_quiet, k_bursts and the burst heads do not depend on k_screen.  Running all three beside it on a second stream loses: the
+   //  single-workgroup k_bursts starves behind k_screen's workgroups - measured 9.6 vs 10.7 Gsamples/s, and k_screen would have to
+   //  do without the dead-tile map.  The heads alone, forked behind k_bursts and joined in front of the walk (below), win:
+   //  8.71 -> 8.19 ms per C2 scan - they are latency-bound start-up walks that fit beside the VALU-bound dense pass.)
    hipStream_t sq = st;
    auto t0 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev0[k], s2); };
    auto t1 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev1[k], s2); };
