@@ -23,7 +23,7 @@ def test_emulated_kernels_match_oracle(name, tmp_path):
 
 
 @pytest.mark.parametrize("name,parallel", [("nrzi9", "1"), ("nrzi9", "0"), ("nrzi7", "1"), ("nrzi9_skew", "1"), ("nrzi9_skew", "0"), ("nrzi9_invert", "1"),
-                                           ("pe", "0"), ("gcr", "0"), ("gcr", "1"), ("nrzi7_order", "1"), ("nrzi7_order", "0")])     # (all of them x both on the GPU)
+                                           ("gcr", "0"), ("nrzi7_order", "1"), ("nrzi7_order", "0")])     # (all of them, pe and gcr x both too, on the GPU: the thread emulation needs 30-50 s for those)
 def test_emulated_peak_record_path_matches_oracle(name, parallel, tmp_path, monkeypatch):
     """The opt-in peak-record path (k_peaks -> k_zones -> k_chain, rtfe_peaks.hip / rtfe_chain.hip): same events as the oracle,
     with the chains deciding stretches of 64 runs at once and one run at a time."""
@@ -115,10 +115,10 @@ def test_every_seam_position_inside_a_gap_keeps_every_burst(tmp_path):
     key = lambda e: e[np.lexsort((e[:, 1], e[:, 0]))]
     zone = wb[1]                                                   # the zone between the first two blocks
     lo, hi = int(zone["zone_first"]) - 256, int(zone["zone_end"]) + 512
-    # every chunk position around the zone's two ends (where the ownership rule decides), every fourth one in between (the thread
+    # every chunk position around the zone's two ends (where the ownership rule decides), every eighth one in between (the thread
     # emulation takes seconds per scan; the GPU test of the same name sweeps every position)
     ze, zf = int(zone["zone_end"]) // 64 * 64, int(zone["zone_first"]) // 64 * 64
-    cuts = sorted(set(range(lo // 64 * 64, hi, 256)) | set(range(ze - 10 * 64, ze + 4 * 64, 64)) | set(range(zf - 128, zf + 192, 64)))
+    cuts = sorted(set(range(lo // 64 * 64, hi, 512)) | set(range(ze - 10 * 64, ze + 4 * 64, 64)) | set(range(zf - 128, zf + 192, 64)))
     assert len(cuts) > 16
     for cut in cuts:
         left = fe.scan(rows[: cut + 4096], row_base=0, first_is_tape_start=True, own_rows=cut).fetch()
