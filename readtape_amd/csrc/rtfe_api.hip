@@ -12,12 +12,12 @@
 #include "rt_frontend.h"
 #include "rtfe_device.h"
 
-#include "rtfe_peaks.hip"     // single translation unit: kernels + host API
+#include "rtfe_sift.hip"      // single translation unit: kernels + host API
 #include "rtfe_kernels.hip"
 #include "rtfe_lwalk.hip"
 #include "rtfe_zeros.hip"
 #include "rtfe_ww.hip"
-#include "rtfe_chain.hip"
+#include "rtfe_gain.hip"
 
 namespace rtfe {
 __global__ void k_setup_exact(rtfe_burst *burst, BurstScratch *scratch, long long reset_row, long long end_row,
@@ -38,7 +38,7 @@ struct rtfe_handle {
    int lds_bytes;
    int num_cus;
    int timing;
-   hipEvent_t ev0[8], ev1[8];          // start / stop of each kernel of the last scan (on the stream it ran on)
+   hipEvent_t ev0[12], ev1[12];          // start / stop of each kernel of the last scan (on the stream it ran on)
    int screen_lds_bytes;
    int walk_lds_bytes;
    int zeros_kernel;                   // -zeros scans run k_zeros (RTFE_ZEROS_KERNEL=0: k_decode's zero-crossing mode, kept for tests)
@@ -53,20 +53,24 @@ static int fail(int code, const char *fmt, ...) {
    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
    return code; }
 
-// the k_peaks instantiation for a block-window size and a workgroup size
-typedef void (*pk_kernel_t)(const DevCfg *, const int16_t *, long long, long long, uint16_t *, PeakDir *, PeakDir *, unsigned char *, unsigned char *,
-                            unsigned long long *, int, const unsigned int *, unsigned long long *);
-static pk_kernel_t pk_kernel(int nb, int threads) {
-   if (threads <= 448) return nb <= 4 ? k_peaks<4, 448> : (nb <= 8 ? k_peaks<8, 448> : k_peaks<12, 448>);
-   return nb <= 4 ? k_peaks<4, 704> : (nb <= 8 ? k_peaks<8, 704> : k_peaks<12, 704>); }
+// the k_sift instantiation for a window width, a workgroup size and the vectors a thread prefetches
+typedef void (*sf_kernel_t)(const DevCfg *, const int16_t *, long long, long long, unsigned int *, PeakDir *, unsigned char *, unsigned long long *);
+template <int WM, int MAXT> static sf_kernel_t sf_kernel_nv(int nv) { return nv <= 4 ? k_sift<WM, MAXT, 4> : k_sift<WM, MAXT, 6>; }
+template <int WM> static sf_kernel_t sf_kernel_t2(int threads, int nv) { return threads <= 320 ? sf_kernel_nv<WM, 320>(nv) : sf_kernel_nv<WM, 640>(nv); }
+static sf_kernel_t sf_kernel(int wmax, int threads, int nv) {
+   return wmax <= 18 ? sf_kernel_t2<18>(threads, nv) : (wmax <= 34 ? sf_kernel_t2<34>(threads, nv) : sf_kernel_t2<50>(threads, nv)); }
+static int sf_wmax(const DevCfg &d) { int w = 0; for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].W > w) w = d.screen[s].W; return w; }
+static int sf_threads(const DevCfg &d) { return 64 * ((d.ntrks + 1) / 2); }
+static int sf_nvec(const DevCfg &d) { return (d.pk_hl + kSfTile + d.pk_hr) * d.ntrks / 8; }
+static int sf_nv(const DevCfg &d) { return (sf_nvec(d) + sf_threads(d) - 1) / sf_threads(d); }
 
 extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
 // the kernels of one rtfe_scan, in launch order (k_decode runs twice: burst heads, then whatever k_walk gave back)
 // (the peak-record path fills k_peaks [quiet map included], k_bursts, k_chain [k_zones + k_chain + k_publish] and k_decode_resume [bursts redone on the samples])
-static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_screen", "k_decode_head", "k_walk", "k_decode_resume", "k_peaks", "k_chain"};
-constexpr int kNumKernels = 8;
+static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_screen", "k_decode_head", "k_walk", "k_decode_resume", "k_sift", "k_gain", "k_emit"};
+constexpr int kNumKernels = 9;
 extern "C" int rtfe_kernel_count(void) { return kNumKernels; }
 extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < kNumKernels) ? KNAMES[i] : ""; }
 
@@ -171,11 +175,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       long long si = (long long)ceil((double)hi_v * lsb_per_volt) + 3;
       if (si > 65535) si = 65535;
       if (si <= d.screen[s].rise_i + 1) si = d.screen[s].rise_i + 2;
-      d.screen[s].sure_i = (int)si;
-      d.screen[s].nb = d.screen[s].W <= 18 ? 4 : (d.screen[s].W <= 34 ? 8 : 12); }
-   {  int nbm = 0;                                                   // one k_peaks instantiation per scan: the widest window's block count for all
-      for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].nb > nbm) nbm = d.screen[s].nb;
-      for (int s = 0; s < d.nscreens; ++s) d.screen[s].nb = nbm; }
+      d.screen[s].sure_i = (int)si; }
    if (d.find_zeros) {
       // the zero-crossing detector has no amplitude feedback and no parameter-set dependence (adjust_agc returns
       // at once, src/decoder.c:501): one walker per track; nothing can become pending while |v| <= 0.2 V
@@ -238,34 +238,28 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
    d.cut = getenv("RTFE_CUT") ? atoi(getenv("RTFE_CUT")) : 0;
-   {  // the peak-record path (k_peaks -> k_chain): every peak-detection scan on the undifferentiated signal
-      // opt-in (RTFE_PEAK_PATH=1): bit-identical to the sample / candidate-run kernels on every tape tried, but not yet faster than them
-      // on an MI355X (what was measured, and why) - the default scan keeps the kernels of rtfe_kernels.hip
+   {  // the peak path (k_sift -> k_gain -> k_emit): peak detection on the undifferentiated signal
       d.peak_path = 0;
       if (const char *e = getenv("RTFE_PEAK_PATH")) d.peak_path = !d.find_zeros && !d.differentiate && atoi(e) != 0;
-      d.pk_parallel = 1;
-      if (const char *e = getenv("RTFE_CHAIN_PARALLEL")) d.pk_parallel = atoi(e) != 0;
-      int wmax = 0, nbmax = 0;
-      for (int sidx = 0; sidx < d.nscreens; ++sidx) { if (d.screen[sidx].W > wmax) wmax = d.screen[sidx].W; if (d.screen[sidx].nb > nbmax) nbmax = d.screen[sidx].nb; }
-      const int xb = (nbmax + 3) / 4;
-      int hl = kPkBack + 2 * wmax + 6; if (hl < 16 * xb + 16) hl = 16 * xb + 16;
-      int hr = wmax + 2;               if (hr < 16 * xb) hr = 16 * xb;
-      d.pk_hl = (hl + 15) & ~15; d.pk_hr = (hr + 15) & ~15;
+      d.pk_fast = 1;
+      if (const char *e = getenv("RTFE_GAIN_FAST")) d.pk_fast = atoi(e) != 0;
+      const int wmax = sf_wmax(d);
+      d.pk_hl = (kPkBack + 2 * wmax + 6 + 7) & ~7;
+      d.pk_hr = (wmax + 2 + 7) & ~7;
       // pool slots: flux transitions per tile and head from the bit cell (PE: up to two per cell), ~14 bytes each (a record and three
       // margins), half as much again for noise and weak peaks.  RTFE_PK_SLOT: tests force the capacity path.
       const float spbf = 1.0f / (bpi_s * c->ips * d.sample_deltat);
       const float ppb = c->mode == RTFE_PE ? 2.0f : 1.0f;
-      int slot = (int)((float)kPkTile / (spbf > 2 ? spbf : 2) * ppb * 14.0f * 1.5f) + 160;
+      int slot = (int)((float)kSfTile / (spbf > 2 ? spbf : 2) * ppb * 14.0f * 1.5f) + 160;
       int lo_min = 1 << 30;
       for (int sidx = 0; sidx < d.nscreens; ++sidx) if (d.screen[sidx].rise_i < lo_min) lo_min = d.screen[sidx].rise_i;
       const bool noisy_screen = (double)lo_min / lsb_per_volt < 0.03;
       if (noisy_screen) slot *= 3;                                        // a screen below the noise floor: noise wiggles become runs, every row explicit
-      d.pk_wave_cap = noisy_screen ? 2048 : 512;
+      d.pk_wave_cap = noisy_screen ? 1792 : 512;                          // (a wave's two heads have 2 x 896 samples)
       if (const char *e = getenv("RTFE_PK_SLOT")) { const int v = atoi(e); if (v >= 32 && v <= 65536) slot = v; }
       d.pk_slot = (slot + 15) & ~15;
-      d.pk_sslot = 16 * (8 + 2 * 8);                                      // runs that continue from the previous tile's last W - 2 rows: a handful
-      d.pk_lds = (int)pk_lds_layout(c->ntrks, d.pk_hl, d.pk_hr, nbmax, d.pk_wave_cap).total + 64;
-      if (d.pk_lds > 150 * 1024) d.peak_path = 0; }
+      d.pk_lds = (int)sf_lds_layout(c->ntrks, d.pk_hl, d.pk_hr, d.pk_wave_cap, d.pk_slot).total + 64;
+      if (d.pk_lds > 150 * 1024 || sf_nv(d) > 6) d.peak_path = 0; }
    {
       const int nwalk = c->nparmsets * c->ntrks;
       int rc = (24 * 1024) / (nwalk * 24);
@@ -306,8 +300,8 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       const LdsLayout Ld = lds_layout(d, true);
       fprintf(stderr, "rtfe: LDS k_decode %d (tile..bits %u, bits..ldpos %u, ldpos..heights %u, recs %u, walkers %u) k_screen %d\n", h->lds_bytes, Ld.bits, Ld.ldpos - Ld.bits,
               Ld.heights - Ld.ldpos, Ld.nrec - Ld.recs, Ld.walkers_next - Ld.walkers, h->screen_lds_bytes);
-      fprintf(stderr, "rtfe: peak path %d, k_peaks LDS %d (halo %d/%d rows, slots %d/%d bytes)\n", d.peak_path, d.pk_lds, d.pk_hl, d.pk_hr, d.pk_slot, d.pk_sslot);
-      for (int sidx = 0; sidx < d.nscreens; ++sidx) fprintf(stderr, "rtfe: screen %d W %d rise_i %d minpk_i %d sure_i %d nb %d\n", sidx, d.screen[sidx].W, d.screen[sidx].rise_i, d.screen[sidx].minpk_i, d.screen[sidx].sure_i, d.screen[sidx].nb); }
+      fprintf(stderr, "rtfe: peak path %d, k_sift LDS %d (halo %d/%d rows, slots %d bytes, %d vectors per thread)\n", d.peak_path, d.pk_lds, d.pk_hl, d.pk_hr, d.pk_slot, sf_nv(d));
+      for (int sidx = 0; sidx < d.nscreens; ++sidx) fprintf(stderr, "rtfe: screen %d W %d rise_i %d minpk_i %d sure_i %d\n", sidx, d.screen[sidx].W, d.screen[sidx].rise_i, d.screen[sidx].minpk_i, d.screen[sidx].sure_i); }
    hipDeviceProp_t prop;
    int dev = 0;
    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return fail(-20, "no HIP device"); }
@@ -327,7 +321,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (c->nparmsets * c->ntrks <= 32 && (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16 <= 150 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lwalk), hipFuncAttributeMaxDynamicSharedMemorySize, (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
-   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pk_kernel(d.screen[0].nb, 64 * ((c->ntrks + 1) / 2 + 1))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
+   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
    *out = h;
    return 0; }
 
@@ -389,17 +383,17 @@ static size_t ws_segstart_off(const rtfe_handle *h, int64_t nrows) { return (ws_
 static size_t ws_segend_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_segstart_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
 
-// ... | peak-record path: directory of the tiles' own lists | of the lists spilled into them | record pool
-static long long pk_tiles_for(int64_t nrows) { return (nrows + kPkTile - 1) / kPkTile; }
+// ... | peak path: directory of the tiles' lists | per-chain baseline (k_gain -> k_emit) | record pool
+static long long pk_tiles_for(int64_t nrows) { return (nrows + kSfTile - 1) / kSfTile; }
 static size_t ws_pkdir_off(const rtfe_handle *h, int64_t nrows) {
    return (ws_segend_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
 static size_t pk_dir_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)(pk_tiles_for(nrows) + 1) * h->dev.nscreens * h->dev.ntrks * sizeof(PeakDir) + 255) & ~(size_t)255; }
-static size_t ws_pkpool_off(const rtfe_handle *h, int64_t nrows) { return ws_pkdir_off(h, nrows) + (h->dev.peak_path ? 2 * pk_dir_bytes(h, nrows) : 0); }
-static size_t pk_own_bytes(const rtfe_handle *h, int64_t nrows) {      // one slot per (tile, screen, head)
-   return (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * (size_t)h->dev.pk_slot) + 255) & ~(size_t)255; }
-static size_t pk_pool_bytes(const rtfe_handle *h, int64_t nrows) {
+static size_t pk_chain_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(float) + 255) & ~(size_t)255; }
+static size_t ws_pkchain_off(const rtfe_handle *h, int64_t nrows) { return ws_pkdir_off(h, nrows) + (h->dev.peak_path ? pk_dir_bytes(h, nrows) : 0); }
+static size_t ws_pkpool_off(const rtfe_handle *h, int64_t nrows) { return ws_pkchain_off(h, nrows) + (h->dev.peak_path ? pk_chain_bytes(h, nrows) : 0); }
+static size_t pk_pool_bytes(const rtfe_handle *h, int64_t nrows) {      // one slot per (tile, screen, head)
    if (!h->dev.peak_path) return 0;
-   return pk_own_bytes(h, nrows) + ((((size_t)pk_tiles_for(nrows) + 1) * h->dev.nscreens * h->dev.ntrks * (size_t)h->dev.pk_sslot + 255) & ~(size_t)255); }
+   return (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * (size_t)h->dev.pk_slot) + 255) & ~(size_t)255; }
 
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
    return ws_pkpool_off(h, nrows) + pk_pool_bytes(h, nrows) + 256; }
@@ -463,48 +457,52 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    auto t0 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev0[k], s2); };
    auto t1 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev1[k], s2); };
    if (h->dev.peak_path) {
-      // ---- the peak-record path: k_peaks (quiet map + records) -> k_bursts -> k_zones -> k_chain -> k_publish -> whatever the chains gave up ----
+      // ---- the peak path: k_sift (quiet map + records) -> k_bursts -> k_zones -> k_gain -> k_emit -> k_publish -> whatever the chains gave up ----
       PeakDir *dirm = reinterpret_cast<PeakDir *>(wsb + ws_pkdir_off(h, nrows));
-      PeakDir *dirs = reinterpret_cast<PeakDir *>(wsb + ws_pkdir_off(h, nrows) + pk_dir_bytes(h, nrows));
+      float *chainh = reinterpret_cast<float *>(wsb + ws_pkchain_off(h, nrows));
       unsigned char *pkpool = reinterpret_cast<unsigned char *>(wsb + ws_pkpool_off(h, nrows));
-      unsigned char *pkspill = pkpool + pk_own_bytes(h, nrows);
       const long long ptiles = pk_tiles_for(nrows);
       (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
+      (void)hipMemsetAsync(qwords, 0, (size_t)nwords * 8, st);           // (k_sift ORs the quiet bits of its tiles into the map)
       t0(0, st); t1(0, st); t0(2, st); t1(2, st); t0(3, st); t1(3, st); t0(4, st); t1(4, st);
       const int stop_after = getenv("RTFE_PEAK_STOP") ? atoi(getenv("RTFE_PEAK_STOP")) : 99;      // (debugging: launch only the first n kernels of the path)
       t0(6, st);
-      const int pthreads = 64 * ((h->dev.ntrks + 1) / 2 + 1);
-      const long long pgrid = ((ptiles + 7) / 8) * 8;
-      const pk_kernel_t pkk = pk_kernel(h->dev.screen[0].nb, pthreads);
-      hipLaunchKernelGGL(pkk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
-                         reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pkspill, &scratch->pool_cursor, 0, (const unsigned int *)deadp, scratch->scr);
+      const int pthreads = sf_threads(h->dev);
+      int spc = (160 * 1024) / (h->dev.pk_lds + 512);
+      if (spc * (pthreads / 64) > 32) spc = 32 / (pthreads / 64);
+      if (const char *e = getenv("RTFE_SIFT_WGS")) { const int v = atoi(e); if (v >= 1 && v < spc) spc = v; }
+      if (spc < 1) spc = 1;
+      long long pgrid = (long long)h->num_cus * spc;
+      if (pgrid > ptiles) pgrid = ptiles;
+      const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev));
+      hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
+                         reinterpret_cast<unsigned int *>(qwords), dirm, pkpool, scratch->scr);
       t1(6, st); t0(1, st);
-      if (stop_after < 2) { t1(1, st); t0(7, st); t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
+      if (stop_after < 2) { t1(1, st); t0(7, st); t1(7, st); t0(8, st); t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                          h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
                          d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts,
-                         deadp, ptiles, (int)kPkTile, h->dev.tail_rows);
+                         deadp, ptiles, (int)kSfTile, h->dev.tail_rows);
       t1(1, st); t0(7, st);
-      if (stop_after < 3) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
-      hipLaunchKernelGGL(pkk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
-                         reinterpret_cast<uint16_t *>(qwords), dirm, dirs, pkpool, pkspill, &scratch->pool_cursor, 1, (const unsigned int *)deadp, scratch->scr);
-      if (stop_after < 4) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
+      if (stop_after < 3) { t1(7, st); t0(8, st); t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);
-      if (stop_after < 5) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
-      hipLaunchKernelGGL(k_chain, dim3(h->num_cus * 16), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                         scratch, ctlp, d_counts, d_events, (const PeakDir *)dirm, (const PeakDir *)dirs, (const unsigned char *)pkpool, (const unsigned char *)pkspill, ptiles);
-      if (stop_after < 6) { t1(7, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
+      hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+                         scratch, ctlp, d_counts, d_events, chainh, (const PeakDir *)dirm, (const unsigned char *)pkpool, ptiles);
+      t1(7, st); t0(8, st);
+      if (stop_after < 4) { t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
+      hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
+                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const unsigned char *)pkpool);
       hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
-      t1(7, st); t0(5, st);
-      if (stop_after < 7) { t1(5, st); return launch_check("rtfe_scan"); }
+      t1(8, st); t0(5, st);
+      if (stop_after < 5) { t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
                          (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeRedo, ctlp, statep);
       t1(5, st);
       return launch_check("rtfe_scan"); }
    (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
-   t0(6, sq); t1(6, sq); t0(7, sq); t1(7, sq);
+   t0(6, sq); t1(6, sq); t0(7, sq); t1(7, sq); t0(8, sq); t1(8, sq);
    t0(0, sq);
    hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, sq, d_rows, (long long)nrows, h->dev.ntrks, h->dev.quiet_i, qwords, nwords);
    t1(0, sq); t0(1, sq);
@@ -600,9 +598,9 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
    if (!h || !d_workspace || !out) return fail(-1, "null argument");
    BurstScratch sc;
    if (hipMemcpy(&sc, d_workspace, sizeof sc, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
-   out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.pool_cursor; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
+   out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.scr[3]; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
    for (int i = 0; i < 8; ++i) out[5 + i] = (int64_t)sc.why[i];
-   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)sc.scr[i];      // RTFE_DEBUG=3: k_peaks cycles per phase (copy, blocks, dense, compaction, candidates, copy-out, -, tiles)
+   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)sc.scr[i];      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
    return 0; }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

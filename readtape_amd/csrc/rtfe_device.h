@@ -31,8 +31,7 @@ struct DevScreen {
    int W;
    int rise_i;          // candidate if (max - edge) > rise_i on both edges          (int16 units)
    int minpk_i;         // ... and max > minpk_i (top) / min < -minpk_i (bottom); -1 = no min_peak test
-   int sure_i;          // k_peaks: a row whose margin is >= sure_i passes the rise test for every threshold k_chain accepts
-   int nb;              // k_peaks: blocks of 4 rows on either side of a sample's block in the prominence pre-filter (4 nb >= W - 2)
+   int sure_i;          // k_sift: a row whose margin is >= sure_i passes the rise test for every threshold k_gain accepts without asking
 };
 
 struct DevCfg {
@@ -72,12 +71,12 @@ struct DevCfg {
    int   lds_units;               // candidate units of ONE tile (all lists, packed) that fit the LDS of the sequential pass
    int   debug;                   // RTFE_DEBUG=1: per-phase cycle counters in the workspace (tools/ only)
    int   cut;                     // RTFE_CUT: k_screen stops after a phase (timing experiments, tools/ only; results are then garbage)
-   int   peak_path;               // k_peaks -> k_chain serve rtfe_scan (peak detection on the undifferentiated signal)
-   int   pk_hl, pk_hr;            // rows kept in front of / behind a k_peaks tile in LDS (multiples of 16)
-   int   pk_slot, pk_sslot;       // bytes of the pool's slots: a tile's own list of one head, the list spilled into it
-   int   pk_wave_cap;             // candidates of one wave (two heads of a tile) k_peaks can list in LDS; beyond: lists unavailable
-   int   pk_lds;                  // dynamic LDS bytes of k_peaks
-   int   pk_parallel;             // k_chain: decide clean stretches of 64 runs in parallel (0: always the sequential walk; tests)
+   int   peak_path;               // k_sift -> k_gain -> k_emit serve rtfe_scan (peak detection on the undifferentiated signal)
+   int   pk_hl, pk_hr;            // rows kept in front of / behind a k_sift tile in LDS (multiples of 8)
+   int   pk_slot;                 // bytes of a pool slot: the list of one (tile, screen, head); multiple of 16
+   int   pk_wave_cap;             // candidates of one wave (two heads of a tile) k_sift can list in LDS; beyond: lists unavailable
+   int   pk_lds;                  // dynamic LDS bytes of k_sift
+   int   pk_fast;                 // k_gain: the steady-state fast path (0: every detection through the general step; tests)
    DevParm   parm[RTFE_MAXPARMSETS];
    DevScreen screen[kMaxScreens];
 };
@@ -124,28 +123,30 @@ struct BurstCtl {              // 32 bytes per burst
 };
 constexpr int kScreenHalo = 64;      // rows in front of a tile that the screen also covers (one bitmap word)
 
-// ---- the peak-record path: k_peaks (dense, stateless) -> k_zones -> k_chain (one wave per (burst, parmset, track)) ----
-constexpr int kPkTile    = 1024;     // rows per k_peaks tile (64 strips of 16 rows; 16 quiet-map groups of 64 rows)
-constexpr int kPkStrip   = 16;       // rows per lane strip
-constexpr int kPkBack    = 64;       // rows k_peaks looks back for the last forced rescan in front of a bottom candidate
-// One candidate RUN = the rows of one tile at which one sample (the "owner": the window maximum, or the reference's
-// possibly stale window minimum) is what lookfor_peak would test (src/decoder.c:788-805), clipped to the tile.
-//   w0  bits  0-10  pos  - (tile row0 - 64)        the owner's row (a run of tile g+1 may be owned by a sample of tile g)
+// ---- the peak path: k_sift (dense, stateless) -> k_zones -> k_gain (one LANE per (burst, parmset, track)) -> k_emit ----
+constexpr int kSfStrip   = 14;       // rows per lane strip: 14 rows x 2 ntrks bytes is an odd number of dwords for 9 tracks (no LDS bank conflicts)
+constexpr int kSfTile    = 64 * kSfStrip;      // 896 rows per k_sift tile
+constexpr int kSfGroups  = kSfTile / 64;       // quiet-map groups of 64 rows per tile
+constexpr int kSfPosBias = 128;      // a record's owner may lie up to kPkBack + W rows in front of its tile
+constexpr int kPkBack    = 64;       // rows k_sift looks back for the last forced rescan in front of a bottom candidate
+// One candidate RUN = the rows at which one sample (the "owner": the window maximum, or the reference's
+// possibly stale window minimum) is what lookfor_peak would test (src/decoder.c:788-805).
+//   w0  bits  0-10  pos - tile row0 + kSfPosBias   the owner's row (the run of a stale minimum may be owned by a sample of the tile in front)
 //       bit   11    kind  0 top / 1 bottom
-//       bits 12-17  f - pos                         first row of the run with a margin above the screen (1 .. W-2)
+//       bits 12-17  f - pos                         first row of the run with a margin above the screen (1 .. W-1)
 //       bits 18-21  nlead                           rows f .. f+nlead-1 carry explicit margins (uint16 entries)
 //       bits 22-27  nsure                           the next nsure rows all have margins >= DevScreen::sure_i
 //       bits 28-31  ntail                           the next ntail rows carry explicit margins again; no row behind them passes the screen
 //                   nsure == 63: every row explicit, (nlead << 4 | ntail) of them from f
 //   w1  val (int16) | clamp(d(prev), -1, 254) + 1 (8 bits) | clamp(d(next), -1, 254) + 1 (8 bits)       d = |val - neighbour| signed towards "beyond the extreme"
-//       0xffff8000: k_peaks could not derive the reference's minimum; rows f .. f+nsure-1 are undecidable from the record
+//       0xffff8000: k_sift could not derive the reference's minimum; rows f .. f+nsure-1 are undecidable from the record
 // margin of a row = val - max(left edge, right edge) (tops) / min(edges) - val (bottoms), int16 code differences.
+// A list holds the records of the candidates of ONE tile in candidate order; their rows may run on into the next tile.
 struct PeakRec { uint32_t w0, w1; };
-// The pool: one fixed slot per (tile, screen, head) for the tile's own list (pk_slot bytes) and one for the list the previous tile
-// spills into it (pk_sslot bytes).  Inside a slot the records grow from the front, the margin entries from the back (entry e at
-// slot_end - 2 (e + 1)); a list that does not fit is marked unavailable in the directory.
-struct PeakDir {               // per (tile, screen, head): 4 bytes; one array for the tile's own lists, one for the lists spilled into it
-   uint16_t nrec;              // 0xFFFF: not available (capacity); 0xFFFE: a quiet tile nobody was expected to need
+// The pool: one fixed slot of pk_slot bytes per (tile, screen, head).  Inside a slot the records grow from the front, the margin
+// entries from the back (entry e at slot_end - 2 (e + 1)); a list that does not fit is marked unavailable in the directory.
+struct PeakDir {               // per (tile, screen, head): 4 bytes
+   uint16_t nrec;              // 0xFFFF: not available (capacity)
    uint16_t nent;
 };
 }  // namespace rtfe

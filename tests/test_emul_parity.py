@@ -25,10 +25,10 @@ def test_emulated_kernels_match_oracle(name, tmp_path):
 @pytest.mark.parametrize("name,parallel", [("nrzi9", "1"), ("nrzi9", "0"), ("nrzi7", "1"), ("nrzi9_skew", "1"), ("nrzi9_skew", "0"), ("nrzi9_invert", "1"),
                                            ("gcr", "0"), ("nrzi7_order", "1"), ("nrzi7_order", "0")])     # (all of them, pe and gcr x both too, on the GPU: the thread emulation needs 30-50 s for those)
 def test_emulated_peak_record_path_matches_oracle(name, parallel, tmp_path, monkeypatch):
-    """The opt-in peak-record path (k_peaks -> k_zones -> k_chain, rtfe_peaks.hip / rtfe_chain.hip): same events as the oracle,
-    with the chains deciding stretches of 64 runs at once and one run at a time."""
+    """The peak path (k_sift -> k_zones -> k_gain -> k_emit, rtfe_sift.hip / rtfe_gain.hip): same events as the oracle, with the
+    chains' steady-state fast path (events noted by k_gain, finished by k_emit) and with every detection through the general step."""
     monkeypatch.setenv("RTFE_PEAK_PATH", "1")
-    monkeypatch.setenv("RTFE_CHAIN_PARALLEL", parallel)
+    monkeypatch.setenv("RTFE_GAIN_FAST", parallel)
     g = load_case(name)
     att = oracle_attempts(g["hdr"], g["rows"], g["oracle_opts"], str(tmp_path))
     fe = emul_frontend(config_for(g["hdr"], g["oracle_opts"]))
