@@ -54,8 +54,9 @@ static int fail(int code, const char *fmt, ...) {
    return code; }
 
 // the k_sift instantiation for a window width, a workgroup size and the vectors a thread prefetches
-typedef void (*sf_kernel_t)(const DevCfg *, const int16_t *, long long, long long, unsigned int *, PeakDir *, unsigned char *, unsigned long long *);
-template <int WM, int MAXT> static sf_kernel_t sf_kernel_nv(int nv) { return nv <= 4 ? k_sift<WM, MAXT, 4> : k_sift<WM, MAXT, 6>; }
+typedef void (*sf_kernel_t)(const DevCfg *, const int16_t *, long long, long long, unsigned int *, PeakDir *, unsigned char *, SfHard *, int, int *, unsigned long long *);
+constexpr int kSfWps = 5;          // waves per SIMD k_sift's register allocation is held to: four 5-wave workgroups per CU
+template <int WM, int MAXT> static sf_kernel_t sf_kernel_nv(int nv) { return nv <= 4 ? k_sift<WM, MAXT, 4, kSfWps> : k_sift<WM, MAXT, 6, kSfWps>; }
 template <int WM> static sf_kernel_t sf_kernel_t2(int threads, int nv) { return threads <= 320 ? sf_kernel_nv<WM, 320>(nv) : sf_kernel_nv<WM, 640>(nv); }
 static sf_kernel_t sf_kernel(int wmax, int threads, int nv) {
    return wmax <= 18 ? sf_kernel_t2<18>(threads, nv) : (wmax <= 34 ? sf_kernel_t2<34>(threads, nv) : sf_kernel_t2<50>(threads, nv)); }
@@ -394,9 +395,14 @@ static size_t ws_pkpool_off(const rtfe_handle *h, int64_t nrows) { return ws_pkc
 static size_t pk_pool_bytes(const rtfe_handle *h, int64_t nrows) {      // one slot per (tile, screen, head)
    if (!h->dev.peak_path) return 0;
    return (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * (size_t)h->dev.pk_slot) + 255) & ~(size_t)255; }
+// ... | the candidates k_sift deferred (k_sift_hard) | their overflow slots
+static long long pk_hard_cap(const rtfe_handle *h, int64_t nrows) { const long long c = pk_tiles_for(nrows) * h->dev.nscreens * 2 + 1024; return c > 0x3fffffffll ? 0x3fffffffll : c; }
+static size_t ws_pkhard_off(const rtfe_handle *h, int64_t nrows) { return ws_pkpool_off(h, nrows) + pk_pool_bytes(h, nrows); }
+static size_t ws_pkovf_off(const rtfe_handle *h, int64_t nrows) { return ws_pkhard_off(h, nrows) + (h->dev.peak_path ? (((size_t)pk_hard_cap(h, nrows) * sizeof(SfHard) + 255) & ~(size_t)255) : 0); }
+static size_t pk_ovf_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (size_t)pk_hard_cap(h, nrows) * kSfOvfBytes : 0; }
 
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pkpool_off(h, nrows) + pk_pool_bytes(h, nrows) + 256; }
+   return ws_pkovf_off(h, nrows) + pk_ovf_bytes(h, nrows) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -461,6 +467,9 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       PeakDir *dirm = reinterpret_cast<PeakDir *>(wsb + ws_pkdir_off(h, nrows));
       float *chainh = reinterpret_cast<float *>(wsb + ws_pkchain_off(h, nrows));
       unsigned char *pkpool = reinterpret_cast<unsigned char *>(wsb + ws_pkpool_off(h, nrows));
+      SfHard *hardp = reinterpret_cast<SfHard *>(wsb + ws_pkhard_off(h, nrows));
+      unsigned char *ovfp = reinterpret_cast<unsigned char *>(wsb + ws_pkovf_off(h, nrows));
+      const int hard_cap = (int)pk_hard_cap(h, nrows);
       const long long ptiles = pk_tiles_for(nrows);
       (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
       (void)hipMemsetAsync(qwords, 0, (size_t)nwords * 8, st);           // (k_sift ORs the quiet bits of its tiles into the map)
@@ -476,7 +485,9 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (pgrid > ptiles) pgrid = ptiles;
       const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev));
       hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
-                         reinterpret_cast<unsigned int *>(qwords), dirm, pkpool, scratch->scr);
+                         reinterpret_cast<unsigned int *>(qwords), dirm, pkpool, hardp, hard_cap, &scratch->hard_count, scratch->scr);
+      hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus), dim3(64), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
+                         (const int *)&scratch->hard_count, ovfp);
       t1(6, st); t0(1, st);
       if (stop_after < 2) { t1(1, st); t0(7, st); t1(7, st); t0(8, st); t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
@@ -488,7 +499,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);
       hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                         scratch, ctlp, d_counts, d_events, chainh, (const PeakDir *)dirm, (const unsigned char *)pkpool, ptiles);
+                         scratch, ctlp, d_counts, d_events, chainh, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp, ptiles);
       t1(7, st); t0(8, st);
       if (stop_after < 4) { t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,

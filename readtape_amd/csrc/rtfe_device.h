@@ -145,6 +145,9 @@ constexpr int kPkBack    = 64;       // rows k_sift looks back for the last forc
 struct PeakRec { uint32_t w0, w1; };
 // The pool: one fixed slot of pk_slot bytes per (tile, screen, head).  Inside a slot the records grow from the front, the margin
 // entries from the back (entry e at slot_end - 2 (e + 1)); a list that does not fit is marked unavailable in the directory.
+//   w1 == 0xffff8001: a candidate k_sift deferred; w0 = its index in the hard list = its overflow slot (k_sift_hard)
+struct SfHard { uint32_t tile; uint16_t pos; uint8_t head, screen; };      // a deferred candidate: tile, row within it, head, screen
+constexpr int kSfOvfBytes = 128;     // an overflow slot: int32 records (-1: not representable), pad, <= 4 records from byte 8, margin entries from the back
 struct PeakDir {               // per (tile, screen, head): 4 bytes
    uint16_t nrec;              // 0xFFFF: not available (capacity)
    uint16_t nent;

@@ -136,19 +136,37 @@ __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, con
       if (rise_pass(w, u.top, u.val, (int)eend[-(u.e0 + u.nlead + i + 1)], mv)) return n; }
    return kNoRow; }
 
-// a lane's place in its record stream: record k of tile g's list (of one screen and head); e0 = margin entries in front of it
+// a lane's place in its record stream: record k of tile g's list (of one screen and head); e0 = margin entries in front of it.
+// A deferred candidate's placeholder (w1 == 0xffff8001) opens its overflow slot: sub = the record of the slot the lane stands on.
 struct RecIt {
    long long g;
    int k, nrec, e0;
    const unsigned char *slot;
    uint32_t w0, w1;
-   bool end, bad; };
+   bool end, bad;
+   int sub, nsub, se0;
+   const unsigned char *ovf; };
 struct RecSrc {                      // the stream: this chain's head and screen
-   const PeakDir *dir; const unsigned char *pool;
+   const PeakDir *dir; const unsigned char *pool, *ovf;
    int nscreens, ntrks, screen, head, hcap;
    long long g_end; };               // tiles at or behind g_end hold no row of the chain
+__device__ __forceinline__ const uint16_t *it_eend(const RecIt &it, const RecSrc &S) {      // entry e of the record's list lives at eend[-(e + 1)]
+   return reinterpret_cast<const uint16_t *>(it.sub >= 0 ? it.ovf + kSfOvfBytes : it.slot + S.hcap); }
+__device__ __forceinline__ int it_e0(const RecIt &it) { return it.sub >= 0 ? it.se0 : it.e0; }
+__device__ __forceinline__ void it_open(RecIt &it, const RecSrc &S, long long g);
+// the lane has just moved onto record k of its list: read it; a placeholder opens its overflow slot
+__device__ __forceinline__ void it_land(RecIt &it, const RecSrc &S) {
+   for (;;) {
+      const uint2 r = *reinterpret_cast<const uint2 *>(it.slot + 8 * it.k);
+      it.w0 = r.x; it.w1 = r.y; it.sub = -1;
+      if (r.y != 0xffff8001u) return;
+      it.ovf = S.ovf + (size_t)r.x * kSfOvfBytes;
+      const int n = *reinterpret_cast<const int *>(it.ovf);
+      if (n < 0) { it.end = true; it.bad = true; return; }                        // (not representable: whoever needs it takes the sample path)
+      if (n > 0) { it.sub = 0; it.nsub = n; it.se0 = 0; const uint2 r2 = *reinterpret_cast<const uint2 *>(it.ovf + 8); it.w0 = r2.x; it.w1 = r2.y; return; }
+      if (++it.k >= it.nrec) { it_open(it, S, it.g + 1); return; } } }         // (a candidate that turned out to have no row above the screen)
 __device__ __forceinline__ void it_open(RecIt &it, const RecSrc &S, long long g) {
-   it.end = false; it.bad = false; it.k = 0; it.e0 = 0; it.nrec = 0; it.w0 = 0; it.w1 = 0; it.slot = nullptr;
+   it.end = false; it.bad = false; it.k = 0; it.e0 = 0; it.nrec = 0; it.w0 = 0; it.w1 = 0; it.slot = nullptr; it.sub = -1; it.nsub = 0; it.se0 = 0; it.ovf = nullptr;
    for (;; ++g) {
       it.g = g;
       if (g >= S.g_end) { it.end = true; return; }
@@ -157,12 +175,15 @@ __device__ __forceinline__ void it_open(RecIt &it, const RecSrc &S, long long g)
       if (d.nrec == 0xffffu) { it.end = true; it.bad = true; return; }             // (capacity: the burst takes the sample path)
       if (d.nrec == 0) continue;
       it.nrec = d.nrec; it.slot = S.pool + li * (size_t)S.hcap;
-      const uint2 r = *reinterpret_cast<const uint2 *>(it.slot);
-      it.w0 = r.x; it.w1 = r.y;
+      it_land(it, S);
       return; } }
 __device__ __forceinline__ void it_next(RecIt &it, const RecSrc &S) {
-   it.e0 += pk_nent(it.w0, it.w1);
-   if (++it.k < it.nrec) { const uint2 r = *reinterpret_cast<const uint2 *>(it.slot + 8 * it.k); it.w0 = r.x; it.w1 = r.y; }
+   if (it.sub >= 0) {
+      it.se0 += pk_nent(it.w0, it.w1);
+      if (++it.sub < it.nsub) { const uint2 r = *reinterpret_cast<const uint2 *>(it.ovf + 8 + 8 * it.sub); it.w0 = r.x; it.w1 = r.y; return; }
+      it.sub = -1; }                                                             // (the placeholder itself carries no entries)
+   else it.e0 += pk_nent(it.w0, it.w1);
+   if (++it.k < it.nrec) it_land(it, S);
    else it_open(it, S, it.g + 1); }
 
 // an event the fast path only noted (k_emit finishes it): where its record is, and the gain in force
@@ -174,7 +195,7 @@ __device__ __forceinline__ rtfe_event note_event(const RecIt &it, float g) {
 __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
-                                             const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool, long long ntiles) {
+                                             const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool, const unsigned char *__restrict__ ovf, long long ntiles) {
    __shared__ float s_heights[64 * 10];
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
@@ -205,7 +226,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       int why = 0;
       unsigned int n_fast = 0, n_slow = 0, guard = 0;
       RecSrc src;
-      src.dir = dir; src.pool = pool; src.nscreens = cfg.nscreens; src.ntrks = ntrks; src.screen = P.screen; src.head = head; src.hcap = cfg.pk_slot;
+      src.dir = dir; src.pool = pool; src.ovf = ovf; src.nscreens = cfg.nscreens; src.ntrks = ntrks; src.screen = P.screen; src.head = head; src.hcap = cfg.pk_slot;
       {  long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;       // first tile whose candidates all lie at or behind the limit
          src.g_end = ge < ntiles ? ge : ntiles; }
       RecIt alive;
@@ -215,14 +236,14 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          if (++guard > 4000000u) { failed = true; why = 7; break; }              // (cannot happen: every round moves the stream or c forward)
          if (alive.end) { if (alive.bad) { failed = true; why = 1; } break; }
          const long long tile0 = alive.g * kSfTile;
-         const Run ua = run_decode(alive.w0, alive.w1, tile0, alive.e0);
+         const Run ua = run_decode(alive.w0, alive.w1, tile0, it_e0(alive));
          if (ua.pos + W - 2 < c) { it_next(alive, src); continue; }             // its rows are behind the countdown for good
          const bool steady = cfg.agc_off || (cfg.mode == RTFE_PE ? w.datablock : (w.peakcount > 15 && w.v_avg_height_count == 0));
          // ---- the fast path: steady state, a record with a sure stretch, the countdown over before its first row, the thresholds inside
          // the band the sure level stands for, a clear amplitude, and nothing else that could fire before this record's owner has left
          // the window.  Then it fires - at one of its lead rows or at its first sure row, k_emit will say which - and all that
          // feeds back is the extreme's value. ----
-         if (cfg.pk_fast && steady && !ua.unknown && ua.nsure > 0 && c <= ua.f && ua.f + ua.nlead < limit && w.rise_hi <= S.sure_i && w.nevents < cap) {
+         if (cfg.pk_fast && steady && alive.sub < 0 && !ua.unknown && ua.nsure > 0 && c <= ua.f && ua.f + ua.nlead < limit && w.rise_hi <= S.sure_i && w.nevents < cap) {
             const int a = ua.top ? ua.val : -ua.val;
             if (w.reqmin == 0 || a >= w.min_hi) {
                RecIt nx = alive;
@@ -254,11 +275,11 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          Run bu = ua;
          for (RecIt j = alive; !(top_done && bot_done); it_next(j, src)) {
             if (j.end) { if (j.bad) bad_row0 = j.g * kSfTile; break; }
-            const Run u = run_decode(j.w0, j.w1, j.g * kSfTile, j.e0);
+            const Run u = run_decode(j.w0, j.w1, j.g * kSfTile, it_e0(j));
             if (u.top ? top_done : bot_done) continue;
             if (u.f > best || u.f >= limit) { if (u.top) top_done = true; else bot_done = true; continue; }
             long long dr;
-            const long long n = run_fire(w, u, reinterpret_cast<const uint16_t *>(j.slot + src.hcap), c, limit, W, S.sure_i, mv, dr);
+            const long long n = run_fire(w, u, it_eend(j, src), c, limit, W, S.sure_i, mv, dr);
             if (dr < best_doubt) best_doubt = dr;
             if (n != kNoRow) {
                if (u.top) top_done = true; else bot_done = true;         // (runs of one kind are ordered by row)

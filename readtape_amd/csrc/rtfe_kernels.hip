@@ -54,7 +54,8 @@ struct BurstScratch {            // lives in the workspace (first kScratchBytes 
    int   queue_seg, nsegs;       // segment queue of k_walk (segment mode), segments of this scan (k_segs)
    int   queue_stitch;           // ... of k_stitch
    int   seg_failed;             // bursts whose segments did not join (statistics)
-   int   pad[7];
+   int   hard_count;             // candidates k_sift deferred to k_sift_hard (cleared with the scratch block when rtfe_scan starts)
+   int   pad[6];
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
    unsigned long long pool_cursor;   // at byte 128: next free PackedRun of the pool (k_screen)
    unsigned long long dbg2[8];   // dbg[8..15] (contiguous with dbg through pool_cursor is NOT assumed: indexed separately)

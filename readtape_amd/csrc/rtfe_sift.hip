@@ -80,17 +80,23 @@ __device__ __forceinline__ uint32_t lds_u32u(lds_cp p) { return reinterpret_cast
 __device__ __forceinline__ void rtfe_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #endif
 
+// the samples a candidate's derivation reads: a tile in LDS (k_sift) ...
 struct PkTile {
    lds_cp xs;                   // LDS: the tape's rows as they are, row_bytes apart
    int row_bytes;
    int hl;                      // rows in front of the tile
-   __device__ __forceinline__ int at(int r, int head) const {      // r relative to the tile's first row (>= -hl); after -invert
-      return sg * lds_i16(xs + (r + hl) * row_bytes + head * 2); }
    int sg;                      // -invert: -1 (the detector sees 0 - x, src/readtape.c:1421)
-};
+   __device__ __forceinline__ int at(int r, int head) const {      // r relative to the tile's first row (>= -hl); after -invert
+      return sg * lds_i16(xs + (r + hl) * row_bytes + head * 2); } };
+// ... or the tape in HBM (k_sift_hard: the few candidates that need the general walk); rows outside the tape read as zeros
+struct PkTape {
+   const int16_t *rows; long long t0, nrows; int ntrks, sg;
+   __device__ __forceinline__ int at(int r, int head) const {
+      const long long n = t0 + r;
+      return (n >= 0 && n < nrows) ? sg * (int)rows[n * ntrks + head] : 0; } };
 
 // LDS carve of k_sift.  ONE definition for the kernel and for the host's sizing.
-struct SfLds { unsigned xs, wl, stage, tot, total; };
+struct SfLds { unsigned xs, wl, stage, total; };
 __host__ __device__ inline SfLds sf_lds_layout(int ntrks, int hl, int hr, int wave_cap, int hcap) {
    SfLds L;
    const int npairs = (ntrks + 1) / 2;
@@ -98,18 +104,17 @@ __host__ __device__ inline SfLds sf_lds_layout(int ntrks, int hl, int hr, int wa
    L.xs = o;    o += (unsigned)(hl + kSfTile + hr) * (unsigned)(ntrks * 2) + 32;  o = (o + 15) & ~15u;
    L.wl = o;    o += (unsigned)npairs * wave_cap * 2;  o = (o + 15) & ~15u;      // [pair][wave_cap] candidates of a wave, ordered by (head, row)
    L.stage = o; o += (unsigned)ntrks * hcap;                                      // [head][hcap] the tile's lists as they go to HBM
-   L.tot = o;   o += (unsigned)ntrks * 8;                                         // [head] records, entries
    L.total = (o + 15) & ~15u;
    return L; }
 
-struct PkCtx {
-   PkTile t;
+template <class TileT> struct PkCtxT {
+   TileT t;
    int W, lo_i, hi_i;            // window, screen threshold (margin > lo_i), sure threshold (margin >= hi_i)
    int last;                     // last row that exists, relative to the tile's first row (the tape's end; else far away)
 };
+typedef PkCtxT<PkTile> PkCtx;
 
-// What one candidate turns into: up to four records (without their margin entries), kept in registers until the wave knows where
-// they go.  n > 4: more than fit.
+// What one candidate of the general walk turns into: up to four records, each with its margin entries.  n > 4: more than fit.
 struct PkSink { uint32_t w0[4], w1[4]; int n; };
 __device__ __forceinline__ void sink_add(PkSink &s, uint32_t w0, uint32_t w1) {
    #pragma unroll
@@ -117,13 +122,13 @@ __device__ __forceinline__ void sink_add(PkSink &s, uint32_t w0, uint32_t w1) {
    ++s.n; }
 
 // margin of owner value `val` at row n: tops val - max(edges), bottoms min(edges) - val
-__device__ __forceinline__ int pk_margin(const PkCtx &c, int head, int n, int val, bool top) {
+template <class C> __device__ __forceinline__ int pk_margin(const C &c, int head, int n, int val, bool top) {
    const int xl = c.t.at(n - c.W + 1, head), xr = c.t.at(n, head);
    return top ? val - max(xl, xr) : min(xl, xr) - val; }
 
 // number of margin entries a record carries (the walkers read the same encoding)
 __host__ __device__ __forceinline__ int pk_nent(uint32_t w0, uint32_t w1) {
-   if (w1 == 0xffff8000u) return 0;
+   if ((w1 & 0xfffffffeu) == 0xffff8000u) return 0;                    // unknown minimum / deferred candidate
    const int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u), ntail = (int)((w0 >> 28) & 15u);
    return nsure == 63 ? (nlead << 4 | ntail) : nlead + ntail; }
 
@@ -137,8 +142,9 @@ __device__ __forceinline__ uint32_t pk_w1(int val, int prev, int nxt, bool top) 
 // One record for owner `pos` over rows [ra, rb] (all of them rows at which the owner is what the detector tests): from the
 // first row above the screen, explicit margins up to the first row at the sure level, the sure stretch, explicit margins
 // for what is left up to the last row above the screen; if either explicit part exceeds 15 rows, every row is explicit.
-__device__ __forceinline__ void pk_describe(const PkCtx &c, PkSink &o, int head, int pos, int val, bool top, int ra, int rb, bool unknown) {
+template <class C> __device__ __forceinline__ void pk_emit(const C &c, PkSink &o, int head, int pos, int val, bool top, int ra, int rb, bool unknown) {
    if (rb > c.last) rb = c.last;
+   if (ra > rb) return;
    int n = ra;
    while (n <= rb && pk_margin(c, head, n, val, top) <= c.lo_i) ++n;
    if (n > rb) return;
@@ -154,24 +160,15 @@ __device__ __forceinline__ void pk_describe(const PkCtx &c, PkSink &o, int head,
       if (nlead > 15 || ntail > 15 || nsure > 62) { const int all = l - f + 1; nlead = all >> 4; ntail = all & 15; nsure = 63; } }
    sink_add(o, pk_w0(pos, top, f, nlead, nsure, ntail), unknown ? 0xffff8000u : pk_w1(val, c.t.at(pos - 1, head), c.t.at(pos + 1, head), top)); }
 
-__device__ __forceinline__ void pk_emit(const PkCtx &c, PkSink &o, int head, int pos, int val, bool top, int ra, int rb, bool unknown) {
-   if (ra > rb) return;
-   pk_describe(c, o, head, pos, val, top, ra, rb, unknown); }
-
 // the margin entries of a record (lead rows, then tail rows; or every row), recomputed from the samples where the record goes:
 // entry i of the record lives at end[-(i + 1)] (the entries of a slot grow from its back)
-__device__ __forceinline__ void pk_entries(const PkCtx &c, int head, uint32_t w0, uint32_t w1, lds_p end) {
-   if (w1 == 0xffff8000u) return;
+template <class C, class P16> __device__ __forceinline__ void pk_entries(const C &c, int head, uint32_t w0, uint32_t w1, P16 e16) {
+   if ((w1 & 0xfffffffeu) == 0xffff8000u) return;
    const int pos = (int)(w0 & 0x7ffu) - kSfPosBias, f = pos + (int)((w0 >> 12) & 63u);
    const bool top = !((w0 >> 11) & 1u);
    const int val = (int)(int16_t)(w1 & 0xffffu);
    int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u), ntail = (int)((w0 >> 28) & 15u);
    if (nsure == 63) { nlead = nlead << 4 | ntail; nsure = 0; ntail = 0; }
-#ifdef RTFE_CPU_EMUL
-   uint16_t *e16 = reinterpret_cast<uint16_t *>(end);
-#else
-   __attribute__((address_space(3))) uint16_t *e16 = reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(end);
-#endif
    for (int i = 0; i < nlead; ++i) { const int m = pk_margin(c, head, f + i, val, top); e16[-(i + 1)] = (uint16_t)(m < 0 ? 0 : m); }
    for (int i = 0; i < ntail; ++i) { const int m = pk_margin(c, head, f + nlead + nsure + i, val, top); e16[-(nlead + i + 1)] = (uint16_t)(m < 0 ? 0 : m); } }
 
@@ -182,7 +179,7 @@ __device__ __forceinline__ void pk_entries(const PkCtx &c, int head, uint32_t w0
 //       minimum, and it was the minimum of an earlier window that already held the leaving sample (a sample that entered
 //       later would have to be to the right of it), hence <= it: equal, and old_left == pkww_minv fires.
 // x[r-W] >= all of x[r-W+1 .. r], or <= all of x[r-W+1 .. r-1].
-__device__ __forceinline__ bool pk_async(const PkCtx &c, int head, int r) {
+template <class C> __device__ __forceinline__ bool pk_async(const C &c, int head, int r) {
    const int s = r - c.W;
    const int v = c.t.at(s, head);
    bool dom = true, sub = true;
@@ -191,14 +188,14 @@ __device__ __forceinline__ bool pk_async(const PkCtx &c, int head, int r) {
       dom = dom && y <= v; sub = sub && y >= v; }
    return sub || (dom && c.t.at(r, head) <= v); }
 // leftmost minimum of the window that ends at row r (the rescan of src/decoder.c:768-775)
-__device__ __forceinline__ int pk_argmin(const PkCtx &c, int head, int r) {
+template <class C> __device__ __forceinline__ int pk_argmin(const C &c, int head, int r) {
    int best = r - c.W + 1, bv = c.t.at(best, head);
    for (int j = best + 1; j <= r; ++j) { const int v = c.t.at(j, head); if (v < bv) { bv = v; best = j; } }
    return best; }
 
 // a bottom candidate, general walk: sample q is the true window minimum (first from the left) at rows [ra, rb]; what the
 // reference tests there is its own minimum, refreshed only by rescans (src/decoder.c:765-775).
-__device__ __attribute__((noinline)) void pk_bot(const PkCtx &c, PkSink &out, int head, int q) {
+template <class C> __device__ __forceinline__ void pk_bot(const C &c, PkSink &out, int head, int q) {
    const int W = c.W;
    const int val = c.t.at(q, head);
    int J = 0;                                                       // x[q-1..q-J] > val
@@ -238,10 +235,11 @@ __device__ __forceinline__ int pk_clz(uint32_t m) { return m ? __clz((int)m) : 3
 __device__ __forceinline__ int pk_clz(uint64_t m) { return m ? __clzll((long long)m) : 64; }
 
 // ---- the common case in registers: every sample a candidate's rows can see is loaded with independent LDS reads, and the run
-// and its record follow from bit masks over the rows.
-// WM >= W.  Returns false when the candidate needs the general walk above (a bottom whose first rows precede every forced rescan).
+// and its record follow from bit masks over the rows.  WM >= W.
+// Returns 0: no record; 1: the record (w0, w1); 2: the candidate needs the general walk (a bottom whose first rows precede every
+// forced rescan) - k_sift_hard.
 template <int WM>
-__device__ __forceinline__ bool pk_fast(const PkCtx &c, PkSink &o, int head, int p, bool bot) {
+__device__ __forceinline__ int pk_fast(const PkCtx &c, int head, int p, bool bot, uint32_t &w0, uint32_t &w1) {
    const int W = c.W;
    const int rb_ = c.t.row_bytes;
    const int sg = bot ? -c.t.sg : c.t.sg;                             // bottoms: the same on the negated signal
@@ -272,21 +270,21 @@ __device__ __forceinline__ bool pk_fast(const PkCtx &c, PkSink &o, int head, int
    int D = pk_ctz((mask_t)~(rm >> 1));                                  // consecutive right samples not above it, from k = 1
    if (D > W - 2) D = W - 2;
    const int ra = W - 1 - J > 1 ? W - 1 - J : 1;
-   if (ra > D) return true;
+   if (ra > D) return 0;
    mask_t V = (((one << D) << 1) - 1) & ~((one << ra) - 1);
    mask_t C = V & lom;
    // rows behind the tape's end do not exist
    const int klast = c.last - p;
    if (klast < MB - 1) C &= klast < 0 ? (mask_t)0 : (mask_t)(((one << klast) << 1) - 1);
-   if (!C) return true;
+   if (!C) return 0;
    if (bot) {
       // the reference's minimum is this sample from the first forced rescan at or behind aq = q + max(0, W-1-J) on: the common case is
       // a rescan at the very first candidate row
       const int n0 = pk_ctz(C);
-      if (!pk_async(c, head, p + n0)) return false;
+      if (!pk_async(c, head, p + n0)) return 2;
       C &= ~((one << n0) - 1); }
    const int val = bot ? -v2 : v2;                                      // (the sample as the detector sees it)
-   const uint32_t w1 = pk_w1(val, c.t.sg * lds_i16(pr - rb_), c.t.sg * lds_i16(pr + rb_), !bot);
+   w1 = pk_w1(val, c.t.sg * lds_i16(pr - rb_), c.t.sg * lds_i16(pr + rb_), !bot);
    const int f = pk_ctz(C), l = MB - 1 - pk_clz(C);
    const int span = l - f + 1;
    int nlead = pk_ctz((mask_t)(him >> f));
@@ -295,239 +293,298 @@ __device__ __forceinline__ bool pk_fast(const PkCtx &c, PkSink &o, int head, int
    if (nsure > span - nlead) nsure = span - nlead;
    int ntail = span - nlead - nsure;
    if (nlead > 15 || ntail > 15 || nsure > 62) { nlead = span >> 4; ntail = span & 15; nsure = 63; }
-   sink_add(o, pk_w0(p, !bot, p + f, nlead, nsure, ntail), w1);
-   return true; }
+   w0 = pk_w0(p, !bot, p + f, nlead, nsure, ntail);
+   return 1; }
 
-template <int WM>
-__device__ __forceinline__ bool pk_eval(const PkCtx &c, PkSink &o, int head, int p, bool bot) {
-   o.n = 0;
-   if (pk_fast<WM>(c, o, head, p, bot)) return true;
-   o.n = 0; pk_bot(c, o, head, p);
-   return false; }
+// ---- wave-wide inclusive prefix sum: DPP row shifts and broadcasts (seven dependent VALU operations; __shfl_up would be six
+// ds_bpermute round trips through the LDS pipeline) ----
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#ifdef RTFE_CPU_EMUL
+   for (int s2 = 1; s2 < 64; s2 <<= 1) { const int y = __shfl_up(v, s2); if (lane >= s2) v += y; }
+   return v;
+#else
+   (void)lane;
+   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+   return v;
+#endif
+}
+__device__ __forceinline__ int wave_last(int v) {
+#ifdef RTFE_CPU_EMUL
+   return __shfl(v, 63);
+#else
+   return __builtin_amdgcn_readlane(v, 63);
+#endif
+}
+
+#ifdef RTFE_CPU_EMUL
+typedef uint16_t *lds_u16p;
+typedef uint32_t *lds_u32p;
+#else
+typedef __attribute__((address_space(3))) uint16_t *lds_u16p;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // k_sift
 // ------------------------------------------------------------------------------------------------
-
-// the tape's bytes of tile `tile` (with its halo) into registers; rows outside the tape read as zeros
+// the tape's bytes of a tile (with its halo) into registers: 16-byte loads, consecutive lanes consecutive vectors.  Only for tiles
+// whose rows all exist (e_first >= 0, the last vector inside the tape); the tape's two ends go through sf_fill_edge.
 template <int kSfVec>
-__device__ __forceinline__ void sf_fetch(int4 (&q)[kSfVec], const int16_t *__restrict__ rows, long long e_first, long long total_elem, int nvec, int tid, int nthreads) {
+__device__ __forceinline__ void sf_fetch(int4 (&q)[kSfVec], const int16_t *__restrict__ rows, long long e_first, int nvec, int tid, int nthreads) {
+   const int4 *src = reinterpret_cast<const int4 *>(rows + e_first);
    #pragma unroll
    for (int k = 0; k < kSfVec; ++k) {
       const int vi = k * nthreads + tid;
-      const long long ge = e_first + (long long)vi * 8;
-      q[k] = make_int4(0, 0, 0, 0);
-      if (vi < nvec) {
-         if (ge >= 0 && ge + 8 <= total_elem) q[k] = *reinterpret_cast<const int4 *>(rows + ge);
-         else if (ge + 8 > 0 && ge < total_elem) {                 // the tape's ends: sample by sample, zeros outside
-            int e[8];
-            #pragma unroll
-            for (int j = 0; j < 8; ++j) { const long long g = ge + j; e[j] = (g >= 0 && g < total_elem) ? (int)(unsigned short)rows[g] : 0; }
-            q[k] = make_int4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)); } } } }
+      if (vi < nvec) q[k] = src[vi]; } }
+// a tile at one of the tape's ends: sample by sample into LDS, zeros for the rows that do not exist (twice per scan)
+__device__ __attribute__((noinline)) void sf_fill_edge(lds_p xs, const int16_t *__restrict__ rows, long long e_first, long long total_elem, int nelem, int tid, int nthreads) {
+#ifdef RTFE_CPU_EMUL
+   int16_t *d = reinterpret_cast<int16_t *>(xs);
+#else
+   __attribute__((address_space(3))) int16_t *d = reinterpret_cast<__attribute__((address_space(3))) int16_t *>(xs);
+#endif
+   for (int i = tid; i < nelem; i += nthreads) { const long long g = e_first + i; d[i] = (g >= 0 && g < total_elem) ? rows[g] : (int16_t)0; } }
 
-// WM >= the widest window; NV = 16-byte vectors of the next tile a thread holds in registers (>= tile vectors / threads)
-template <int WM, int MAXT, int NV>
-__global__ void __launch_bounds__(MAXT) k_sift(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
-                                               unsigned int *__restrict__ qbits, PeakDir *__restrict__ dir, unsigned char *__restrict__ pool,
-                                               unsigned long long *__restrict__ dbg) {
+// the tile's quiet bits -> bit (14 tile + g) of the tape's bit string (only complete groups can be quiet)
+__device__ __forceinline__ void sf_publish_quiet(unsigned int noisy, long long tile, long long nrows, unsigned int *qbits) {
+   unsigned int quiet = ~noisy & ((1u << kSfGroups) - 1u);
+   const long long left = nrows - tile * kSfTile;
+   if (left < kSfTile) quiet &= left < 64 ? 0u : ((1u << (int)(left / 64)) - 1u);
+   if (quiet) {
+      const long long bit0 = tile * kSfGroups;
+      const u64 v = (u64)quiet << (bit0 & 31);
+      atomicOr(&qbits[bit0 >> 5], (unsigned int)v);
+      if (v >> 32) atomicOr(&qbits[(bit0 >> 5) + 1], (unsigned int)(v >> 32)); } }
+
+// WM >= the widest window; NV = 16-byte vectors of the next tile a thread holds in registers (>= tile vectors / threads);
+// WPS = waves per SIMD the register allocation is held to (workgroups per CU x waves per workgroup / 4)
+template <int WM, int MAXT, int NV, int WPS>
+__global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
+                                                    unsigned int *__restrict__ qbits, PeakDir *__restrict__ dir, unsigned char *__restrict__ pool,
+                                                    SfHard *__restrict__ hard, int hard_cap, int *__restrict__ hard_count, unsigned long long *__restrict__ dbg) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;
 #else
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
-   __shared__ unsigned int s_noisy;
-   __shared__ unsigned int s_bad[kMaxScreens];
-   const DevCfg &cfg = *cfgp;
-   const int ntrks = cfg.ntrks, npairs = (ntrks + 1) >> 1;
+   __shared__ unsigned int s_noisy[2];
+   const int ntrks = cfgp->ntrks, nscreens = cfgp->nscreens;
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
-   const int HL = cfg.pk_hl, HR = cfg.pk_hr;
+   const int HL = cfgp->pk_hl, HR = cfgp->pk_hr;
    const int row_bytes = ntrks * 2;
-   const int hcap = cfg.pk_slot;
-   const SfLds L = sf_lds_layout(ntrks, HL, HR, cfg.pk_wave_cap, hcap);
+   const int hcap = cfgp->pk_slot, wave_cap = cfgp->pk_wave_cap;
+   const int cut = cfgp->cut;
+   const bool inv = cfgp->invert != 0;
+   const SfLds L = sf_lds_layout(ntrks, HL, HR, wave_cap, hcap);
    unsigned char *xs = smem + L.xs;
    const lds_p xsl = to_lds(xs);
-   const lds_p stage = to_lds(smem + L.stage);
-   int *s_tot = reinterpret_cast<int *>(smem + L.tot);                 // [head][2]
    PkCtx cx;
-   cx.t.xs = xsl; cx.t.row_bytes = row_bytes; cx.t.hl = HL; cx.t.sg = cfg.invert ? -1 : 1;
+   cx.t.xs = xsl; cx.t.row_bytes = row_bytes; cx.t.hl = HL; cx.t.sg = inv ? -1 : 1;
    const int nvec = (HL + kSfTile + HR) * ntrks / 8;                    // 16-byte vectors of a tile with its halo (HL, HR: multiples of 8)
    const int vpg = 8 * ntrks;                                           // ... per quiet group of 64 rows
    const int v_own0 = HL * ntrks / 8;
-   const uint32_t qpk = pk_dup(cfg.quiet_i), q2 = 2u * (uint32_t)cfg.quiet_i;
-   const long long total_elem = nrows * ntrks;
+   const int quiet_i = cfgp->quiet_i;
    // every workgroup walks a contiguous run of tiles (the halo rows a tile shares with its neighbour are then still in its CU's L1 / its XCD's L2)
-   const long long per = (ntiles + gridDim.x - 1) / gridDim.x;
+   const int per = ((int)ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
    const long long tile_lo = (long long)blockIdx.x * per, tile_hi = tile_lo + per < ntiles ? tile_lo + per : ntiles;
-   const bool prof = cfg.debug == 3 && tid == 0;
-   constexpr int kSfVec = NV;
-   int4 q[kSfVec];
-   if (tile_lo < tile_hi) sf_fetch(q, rows, (tile_lo * kSfTile - HL) * ntrks, total_elem, nvec, tid, nthreads);
+   // a tile is "inside" when every row of it and of its halo exists (its bytes then come as 16-byte vectors, one tile ahead)
+   const long long inside_lo = (HL + kSfTile - 1) / kSfTile, inside_hi = (nrows - HR - 15) / kSfTile - 1;      // tiles inside_lo .. inside_hi
+   const bool prof = cfgp->debug == 3;
+   long long pc_copy = 0, pc_dense = 0, pc_own = 0;                     // cycles per phase (RTFE_DEBUG=3; lane 0 of every wave adds its own up)
+   unsigned int pn_hard = 0, pn_rounds = 0, pn_bytes = 0;
+   // this wave's pair of heads, its candidate list and its two staging slots
+   const int pair = wave, h_lo = 2 * pair, h_hi = 2 * pair + 1;
+   const bool has_hi = h_hi < ntrks;
+   const lds_u16p wlist = reinterpret_cast<lds_u16p>(to_lds(smem + L.wl)) + wave * wave_cap;
+   const lds_p slot_lo = to_lds(smem + L.stage) + h_lo * hcap, slot_hi = slot_lo + hcap;
+   int4 q[NV];
+   #pragma unroll
+   for (int k = 0; k < NV; ++k) q[k] = make_int4(0, 0, 0, 0);
+   if (tile_lo < tile_hi && tile_lo >= inside_lo && tile_lo <= inside_hi) sf_fetch(q, rows, (tile_lo * kSfTile - HL) * ntrks, nvec, tid, nthreads);
+   if (tid < 2) s_noisy[tid] = 0;
    for (long long tile = tile_lo; tile < tile_hi; ++tile) {
       const long long t0 = tile * kSfTile;
       const long long lastl = nrows - 1 - t0;
       cx.last = lastl > 0x3fffffff ? 0x3fffffff : (int)lastl;
-      long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+      const int par = (int)(tile & 1);
+      long long tk0 = 0, tk1 = 0;
       if (prof) tk0 = clock64();
-      // ---- 1. the prefetched bytes -> LDS; the next tile's loads go out at once ----
-      #pragma unroll
-      for (int k = 0; k < kSfVec; ++k) { const int vi = k * nthreads + tid; if (vi < nvec) reinterpret_cast<int4 *>(xs)[vi] = q[k]; }
-      if (tid == 0) s_noisy = 0;
-      if (tid < kMaxScreens) s_bad[tid] = 0;
+      // ---- 1. the prefetched bytes -> LDS (every wave is done with the tile in front: the barrier at the end of the round before);
+      // the next tile's loads go out at once and travel while this tile is worked on ----
+      if (tile >= inside_lo && tile <= inside_hi) {
+         #pragma unroll
+         for (int k = 0; k < NV; ++k) { const int vi = k * nthreads + tid; if (vi < nvec) reinterpret_cast<int4 *>(xs)[vi] = q[k]; } }
+      else sf_fill_edge(xsl, rows, (t0 - HL) * ntrks, nrows * ntrks, nvec * 8, tid, nthreads);
       __syncthreads();
-      if (tile + 1 < tile_hi) sf_fetch(q, rows, ((tile + 1) * kSfTile - HL) * ntrks, total_elem, nvec, tid, nthreads);
-      if (prof) { tk1 = clock64(); atomicAdd(&dbg[0], (unsigned long long)(tk1 - tk0)); atomicAdd(&dbg[7], 1ull); }
+      if (tile + 1 < tile_hi && tile + 1 >= inside_lo && tile + 1 <= inside_hi) sf_fetch(q, rows, ((tile + 1) * kSfTile - HL) * ntrks, nvec, tid, nthreads);
+      // the quiet map of the tile in front (its bits were complete at the barrier)
+      if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - 1, nrows, qbits); s_noisy[par ^ 1] = 0; }
       // ---- 2. quiet groups: 14 x 64 rows, flat 16-byte reads of the tile proper ----
-      for (int vb = 0; vb < kSfGroups * vpg; vb += nthreads) {
-         const int vi = vb + tid;
-         bool noisy = false;
-         if (vi < kSfGroups * vpg) {
-            const int4 v = reinterpret_cast<const int4 *>(xs)[v_own0 + vi];
-            const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)v.x, qpk), pk_addu((uint32_t)v.y, qpk)),
-                                       pk_maxu(pk_addu((uint32_t)v.z, qpk), pk_addu((uint32_t)v.w, qpk)));
-            noisy = (m & 0xffffu) > q2 || (m >> 16) > q2; }
-         const u64 nb = __ballot(noisy);
-         if (lane == 0 && nb) {                                           // the 64 vectors of this ballot lie in at most three groups
-            const int vfirst = vb + wave * 64;
-            unsigned int bits = 0;
-            for (int g = vfirst / vpg; g <= (vfirst + 63) / vpg && g < kSfGroups; ++g) {
-               const int a = g * vpg - vfirst, b = a + vpg;
-               const u64 ma = a <= 0 ? ~0ull : (a >= 64 ? 0ull : ~0ull << a), mb = b >= 64 ? ~0ull : (b <= 0 ? 0ull : ~(~0ull << b));
-               if (nb & ma & mb) bits |= 1u << g; }
-            if (bits) atomicOr(&s_noisy, bits); } }
-      if (cfg.cut == 1) { __syncthreads(); continue; }                  // (RTFE_CUT, timing experiments: the copy + quiet map alone)
-      for (int sc = 0; sc < cfg.nscreens; ++sc) {
-         const DevScreen S = cfg.screen[sc];
-         cx.W = S.W; cx.lo_i = S.rise_i; cx.hi_i = S.sure_i;
-         if (prof) tk1 = clock64();
+      {
+         const uint32_t qpk = pk_dup(quiet_i), q2 = 2u * (uint32_t)quiet_i;
+         for (int vb = 0; vb < kSfGroups * vpg; vb += nthreads) {
+            const int vi = vb + tid;
+            bool noisy = false;
+            if (vi < kSfGroups * vpg) {
+               const int4 v = reinterpret_cast<const int4 *>(xs)[v_own0 + vi];
+               const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)v.x, qpk), pk_addu((uint32_t)v.y, qpk)),
+                                          pk_maxu(pk_addu((uint32_t)v.z, qpk), pk_addu((uint32_t)v.w, qpk)));
+               noisy = (m & 0xffffu) > q2 || (m >> 16) > q2; }
+            const u64 nb = __ballot(noisy);
+            if (lane == 0 && nb) {                                           // the 64 vectors of this ballot lie in a few groups
+               const int vfirst = vb + wave * 64;
+               unsigned int bits = 0;
+               for (int g = vfirst / vpg; g <= (vfirst + 63) / vpg && g < kSfGroups; ++g) {
+                  const int a = g * vpg - vfirst, b = a + vpg;
+                  const u64 ma = a <= 0 ? ~0ull : (a >= 64 ? 0ull : ~0ull << a), mb = b >= 64 ? ~0ull : (b <= 0 ? 0ull : ~(~0ull << b));
+                  if (nb & ma & mb) bits |= 1u << g; }
+               if (bits) atomicOr(&s_noisy[par], bits); } } }
+      if (prof) { tk1 = clock64(); pc_copy += tk1 - tk0; }
+      if (cut != 1)
+      for (int sc = 0; sc < nscreens; ++sc) {
+         cx.W = cfgp->screen[sc].W; cx.lo_i = cfgp->screen[sc].rise_i; cx.hi_i = cfgp->screen[sc].sure_i;
+         const int minpk_i = cfgp->screen[sc].minpk_i;
+         if (prof) tk0 = clock64();
          // ---- 3. candidate samples: local extremum + amplitude, one lane per 14-row strip of a pair of heads ----
          uint32_t tm = 0, bm = 0;
-         const int pair = wave, strip = lane;
          {
-            const lds_cp base = xsl + (HL + kSfStrip * strip) * row_bytes + 4 * pair;
+            const lds_cp base = xsl + (HL + kSfStrip * lane) * row_bytes + 4 * pair;
             // (-invert: tops and bottoms swap on the raw codes; "x > A" becomes "x < -A")
-            const uint32_t at = S.minpk_i < 0 ? pk_dup(-32768) : pk_dup(S.minpk_i), ab = S.minpk_i < 0 ? pk_dup(32767) : pk_dup(-S.minpk_i);
-            uint32_t yp = pk_max(lds_u32u(base - row_bytes), at), zp = pk_min(lds_u32u(base - row_bytes), ab);
-            const uint32_t x0 = lds_u32u(base);
-            uint32_t yc = pk_max(x0, at), zc = pk_min(x0, ab);
-            uint32_t uy = pk_subs(yp, yc), dz = pk_subs(zc, zp);           // sign: rising into this row above the floor / falling into it below the ceiling
+            const uint32_t at = minpk_i < 0 ? pk_dup(-32768) : pk_dup(minpk_i), ab = minpk_i < 0 ? pk_dup(32767) : pk_dup(-minpk_i);
+            uint32_t x[kSfStrip + 2];
+            #pragma unroll
+            for (int i = 0; i < kSfStrip + 2; ++i) x[i] = lds_u32u(base + (i - 1) * row_bytes);
+            uint32_t yc = pk_max(x[1], at), zc = pk_min(x[1], ab);
+            uint32_t uy = pk_subs(pk_max(x[0], at), yc), dz = pk_subs(zc, pk_min(x[0], ab));      // sign: rising into this row above the floor / falling into it below the ceiling
             #pragma unroll
             for (int i = 0; i < kSfStrip; ++i) {
-               const uint32_t xn = lds_u32u(base + (i + 1) * row_bytes);
-               const uint32_t yn = pk_max(xn, at), zn = pk_min(xn, ab);
+               const uint32_t yn = pk_max(x[i + 2], at), zn = pk_min(x[i + 2], ab);
                const uint32_t uyn = pk_subs(yc, yn), dzn = pk_subs(zn, zc);
-               const uint32_t t = uy & ~uyn, b = dz & ~dzn;
-               tm = (tm >> 1) | (t & kPkSigns);
-               bm = (bm >> 1) | (b & kPkSigns);
+               tm = (tm >> 1) | (uy & ~uyn & kPkSigns);
+               bm = (bm >> 1) | (dz & ~dzn & kPkSigns);
                yc = yn; zc = zn; uy = uyn; dz = dzn; }
             tm = (tm >> (16 - kSfStrip)) & 0x3fff3fffu; bm = (bm >> (16 - kSfStrip)) & 0x3fff3fffu;
-            if (cfg.invert) { const uint32_t s2 = tm; tm = bm; bm = s2; }
-            if (2 * pair + 1 >= ntrks) { tm &= 0xffffu; bm &= 0xffffu; }       // odd track count: the last pair's upper half is the next row
+            if (inv) { const uint32_t s2 = tm; tm = bm; bm = s2; }
+            if (!has_hi) { tm &= 0xffffu; bm &= 0xffffu; }                  // odd track count: the last pair's upper half is the next row
             // rows that do not exist cannot own a run
-            const long long r0 = t0 + kSfStrip * strip;
+            const long long r0 = t0 + kSfStrip * lane;
             if (r0 + kSfStrip > nrows) { const int keep = (int)(nrows - r0 > 0 ? nrows - r0 : 0); const uint32_t mk = (1u << keep) - 1u; tm &= mk | (mk << 16); bm &= mk | (mk << 16); } }
-         if (prof) { tk2 = clock64(); atomicAdd(&dbg[1], (unsigned long long)(tk2 - tk1)); }
-         // ---- 4. every wave on its own (one pair of heads).  The candidates of its 64 strips are compacted (prefix sums of the per-lane
+         if (prof) { tk1 = clock64(); pc_dense += tk1 - tk0; }
+         // ---- 4. every wave on its own (one pair of heads).  The candidates of its 64 strips are compacted (a prefix sum of the per-lane
          // counts) into a list ordered by (head, row); in rounds of 64 lane i evaluates candidate i, prefix sums number the records within
          // their lists, and records and margin entries go to the lists' staging slots in LDS.  More than pk_wave_cap candidates (noise
-         // above the screen), or a list that outgrows its slot: the list is marked unavailable and the bursts that need it take the sample path. ----
-         if (cfg.cut != 2) {                                               // (RTFE_CUT=2: stop behind the dense pre-filter)
-            const int h_lo = 2 * pair, h_hi = 2 * pair + 1;
-            const bool has_hi = h_hi < ntrks;
-            const uint32_t mlo = (tm | bm) & 0xffffu, mhi = has_hi ? (tm | bm) >> 16 : 0u;
-            int tot_lo = 0, tot_hi = 0, tote_lo = 0, tote_hi = 0;                 // records / entries per list
+         // above the screen), or a list that outgrows its slot: the list is marked unavailable and the bursts that need it take the sample path.
+         // A candidate that needs the general walk leaves a placeholder that k_sift_hard resolves. ----
+         int rec_lo = 0, rec_hi = 0, ent_lo = 0, ent_hi = 0;                   // records / margin entries in this wave's two lists
+         bool bad = false;
+         if (cut != 2) {                                                   // (RTFE_CUT=2: stop behind the dense pre-filter)
+            uint32_t mlo = (tm | bm) & 0xffffu, mhi = (tm | bm) >> 16;
             const int cnt = __popc(mlo) | (__popc(mhi) << 16);
-            int incl = cnt;
-            #pragma unroll
-            for (int s2 = 1; s2 < 64; s2 <<= 1) { const int y = __shfl_up(incl, s2); if (lane >= s2) incl += y; }
-            const int totc = __shfl(incl, 63);
+            const int incl = wave_incl_scan(cnt, lane);
+            const int totc = wave_last(incl);
             const int n_lo = totc & 0xffff, ncw = n_lo + (totc >> 16);
-            bool bad = ncw > cfg.pk_wave_cap;
-#ifdef RTFE_CPU_EMUL
-            uint16_t *wlist = reinterpret_cast<uint16_t *>(smem + L.wl) + wave * cfg.pk_wave_cap;
-#else
-            __attribute__((address_space(3))) uint16_t *wlist = reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(to_lds(smem + L.wl)) + wave * cfg.pk_wave_cap;
-#endif
-            const lds_p slot_lo = stage + h_lo * hcap, slot_hi = slot_lo + hcap;
+            bad = ncw > wave_cap;
             if (!bad && ncw > 0) {
                const int excl = incl - cnt;
                int o2 = excl & 0xffff;
-               for (uint32_t m = mlo; m; m &= m - 1) { const int b2 = __ffs((int)m) - 1; wlist[o2++] = (uint16_t)((kSfStrip * strip + b2) | (((bm >> b2) & 1u) << 14)); }
+               for (; mlo; mlo &= mlo - 1) { const int b2 = __ffs((int)mlo) - 1; wlist[o2++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> b2) & 1u) << 14)); }
                o2 = n_lo + (excl >> 16);
-               for (uint32_t m = mhi; m; m &= m - 1) { const int b2 = __ffs((int)m) - 1; wlist[o2++] = (uint16_t)((kSfStrip * strip + b2) | (((bm >> (16 + b2)) & 1u) << 14) | 0x8000u); }
+               for (; mhi; mhi &= mhi - 1) { const int b2 = __ffs((int)mhi) - 1; wlist[o2++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> (16 + b2)) & 1u) << 14) | 0x8000u); }
                rtfe_wave_sync();
                #pragma nounroll
                for (int r0 = 0; r0 < ncw; r0 += 64) {
                   const int i = r0 + lane;
-                  PkSink sk; sk.n = 0;
-                  int half = 0;
-                  bool easy = true;
+                  uint32_t w0 = 0, w1 = 0;
+                  int half = 0, st = 0, cpos = 0, ckind = 0;
                   if (i < ncw) {
                      const uint32_t cd = wlist[i];
-                     half = (int)(cd >> 15);
-                     easy = pk_eval<WM>(cx, sk, half ? h_hi : h_lo, (int)(cd & 0x3ffu), (cd >> 14) & 1u); }
-                  if (cfg.debug == 3) { const u64 hb = __ballot(!easy); if (lane == 0) { atomicAdd(&dbg[4], (unsigned long long)__popcll(hb)); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)(hb != 0)); } }
-                  if (sk.n > 4) { bad = true; sk.n = 4; }
-                  // records / entries this lane adds to its head's list: the two heads in the two halves of a word
-                  int vr = 0, ve = 0;
-                  #pragma unroll
-                  for (int j = 0; j < 4; ++j) if (j < sk.n) { vr += 1; ve += pk_nent(sk.w0[j], sk.w1[j]); }
+                     half = (int)(cd >> 15); cpos = (int)(cd & 0x3ffu); ckind = (int)((cd >> 14) & 1u);
+                     st = pk_fast<WM>(cx, half ? h_hi : h_lo, cpos, ckind != 0, w0, w1); }
+                  if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
+                     const int hidx = atomicAdd(hard_count, 1);
+                     if (hidx < hard_cap) {
+                        SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)(half ? h_hi : h_lo); hd.screen = (uint8_t)sc;
+                        hard[hidx] = hd;
+                        w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
+                     else { w0 = pk_w0(cpos, false, cpos + 1, 0, 1, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" - the chain that gets here gives up)
+                     st = 1; }
+                  if (prof) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
+                  const int vr = st, ve = st ? pk_nent(w0, w1) : 0;
                   const int sh = 16 * half;
-                  int ir = vr << sh, ie = ve << sh;
-                  #pragma unroll
-                  for (int s2 = 1; s2 < 64; s2 <<= 1) {
-                     const int y0 = __shfl_up(ir, s2), y1 = __shfl_up(ie, s2);
-                     if (lane >= s2) { ir += y0; ie += y1; } }
-                  int myr = (((ir >> sh) & 0xffff) - vr) + (half ? tot_hi : tot_lo), mye = (((ie >> sh) & 0xffff) - ve) + (half ? tote_hi : tote_lo);
-                  const lds_p slot = half ? slot_hi : slot_lo;
-                  #pragma unroll
-                  for (int j = 0; j < 4; ++j)
-                     if (j < sk.n) {
-                        const int nen = pk_nent(sk.w0[j], sk.w1[j]);
-                        if (8 * (myr + 1) + 2 * (mye + nen) <= hcap) {
-#ifdef RTFE_CPU_EMUL
-                           uint32_t *rp = reinterpret_cast<uint32_t *>(slot) + 2 * myr;
-#else
-                           __attribute__((address_space(3))) uint32_t *rp = reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(slot) + 2 * myr;
-#endif
-                           rp[0] = sk.w0[j]; rp[1] = sk.w1[j];
-                           pk_entries(cx, half ? h_hi : h_lo, sk.w0[j], sk.w1[j], slot + hcap - 2 * mye); }
-                        ++myr; mye += nen; }
-                  const int tr = __shfl(ir, 63), te = __shfl(ie, 63);
-                  tot_lo += tr & 0xffff; tot_hi += (tr >> 16) & 0xffff; tote_lo += te & 0xffff; tote_hi += (te >> 16) & 0xffff; } }
-            bad = __ballot(bad) != 0;
-            if (lane < 2 && (lane == 0 || has_hi)) {
-               const int nr = lane ? tot_hi : tot_lo, ne = lane ? tote_hi : tote_lo;
-               const bool over = bad || 8 * nr + 2 * ne > hcap || nr >= 0xff00 || ne >= 0xff00;
-               s_tot[2 * (h_lo + lane)] = over ? -1 : nr; s_tot[2 * (h_lo + lane) + 1] = over ? 0 : ne; } }
-         if (prof) { tk3 = clock64(); atomicAdd(&dbg[2], (unsigned long long)(tk3 - tk2)); }
-         __syncthreads();
-         // ---- 5. the lists leave: records from the front of each head's slot, margin entries from its back, 16 bytes per lane;
-         // the directory ----
+                  const int ir = wave_incl_scan(vr << sh, lane), ie = wave_incl_scan(ve << sh, lane);
+                  const int myr = (((ir >> sh) & 0xffff) - vr) + (half ? rec_hi : rec_lo), mye = (((ie >> sh) & 0xffff) - ve) + (half ? ent_hi : ent_lo);
+                  if (vr && 8 * (myr + 1) + 2 * (mye + ve) <= hcap) {
+                     const lds_p slot = half ? slot_hi : slot_lo;
+                     lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 2 * myr;
+                     rp[0] = w0; rp[1] = w1;
+                     pk_entries(cx, half ? h_hi : h_lo, w0, w1, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye)); }
+                  const int tr = wave_last(ir), te = wave_last(ie);
+                  rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; ent_lo += te & 0xffff; ent_hi += (te >> 16) & 0xffff; } } }
+         if (prof) { tk0 = clock64(); pc_own += tk0 - tk1; }
+         // ---- 5. this wave's two lists leave: records from the front of each head's slot, margin entries from its back, 16 bytes per
+         // lane; the directory ----
+         rtfe_wave_sync();
          {
-            unsigned char *gslot0 = pool + ((size_t)(tile * cfg.nscreens + sc) * ntrks) * (size_t)hcap;
             const int vps = hcap >> 4;                                         // 16-byte vectors per slot
-            for (int vi = tid; vi < ntrks * vps; vi += nthreads) {
-               const int h = vi / vps, v = vi - h * vps;
-               const int nr = s_tot[2 * h], ne = s_tot[2 * h + 1];
-               if (nr <= 0) continue;
-               const int fv = (8 * nr + 15) >> 4, bv = (2 * ne + 15) >> 4;        // vectors in use at the front / at the back
-               if (v < fv || v >= vps - bv)
-                  reinterpret_cast<int4 *>(gslot0 + (size_t)h * hcap)[v] = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap)[v]; }
-            if (tid < ntrks) {
-               PeakDir d; const int nr = s_tot[2 * tid];
-               d.nrec = nr < 0 ? (uint16_t)0xffff : (uint16_t)nr; d.nent = (uint16_t)s_tot[2 * tid + 1];
-               dir[(size_t)(tile * cfg.nscreens + sc) * ntrks + tid] = d;
-               if (cfg.debug && nr > 0) atomicAdd(&dbg[3], (unsigned long long)(8 * nr + 2 * s_tot[2 * tid + 1])); } }
-         __syncthreads(); }
-      // ---- 6. the quiet map: bit (14 tile + g) of the tape's bit string (only complete groups can be quiet) ----
-      if (tid == 0) {
-         unsigned int quiet = ~s_noisy & ((1u << kSfGroups) - 1u);
-         for (int g = 0; g < kSfGroups; ++g) if (t0 + 64 * (g + 1) > nrows) quiet &= ~(1u << g);
-         if (quiet) {
-            const long long bit0 = tile * kSfGroups;
-            const u64 v = (u64)quiet << (bit0 & 31);
-            atomicOr(&qbits[bit0 >> 5], (unsigned int)v);
-            if (v >> 32) atomicOr(&qbits[(bit0 >> 5) + 1], (unsigned int)(v >> 32)); } }
-      if (prof) { const long long tk4 = clock64(); atomicAdd(&dbg[8], (unsigned long long)(tk4 - tk0)); } } }
+            #pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+               if (hh && !has_hi) break;
+               const int h = h_lo + hh;
+               const int nr = hh ? rec_hi : rec_lo, ne = hh ? ent_hi : ent_lo;
+               const bool over = bad || 8 * nr + 2 * ne > hcap || nr >= 0xff00 || ne >= 0xff00;
+               unsigned char *gslot = pool + ((size_t)(tile * nscreens + sc) * ntrks + h) * (size_t)hcap;
+               if (!over && nr > 0) {
+                  const int fv = (8 * nr + 15) >> 4, bv = (2 * ne + 15) >> 4;        // vectors in use at the front / at the back
+                  const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
+                  for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
+                  if (prof) pn_bytes += (unsigned)(8 * nr + 2 * ne); }
+               if (lane == 0) {
+                  PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = over ? (uint16_t)0 : (uint16_t)ne;
+                  dir[(size_t)(tile * nscreens + sc) * ntrks + h] = d; } } }
+         rtfe_wave_sync(); }
+      __syncthreads(); }
+   if (tid == 0 && tile_hi > tile_lo) sf_publish_quiet(s_noisy[(int)((tile_hi - 1) & 1)], tile_hi - 1, nrows, qbits);
+   if (prof && lane == 0) {
+      atomicAdd(&dbg[0], (unsigned long long)pc_copy); atomicAdd(&dbg[1], (unsigned long long)pc_dense); atomicAdd(&dbg[2], (unsigned long long)pc_own);
+      atomicAdd(&dbg[3], (unsigned long long)pn_bytes); atomicAdd(&dbg[4], (unsigned long long)pn_hard); atomicAdd(&dbg[5], (unsigned long long)pn_rounds);
+      if (wave == 0) atomicAdd(&dbg[7], (unsigned long long)(tile_hi > tile_lo ? tile_hi - tile_lo : 0)); } }
+
+// ------------------------------------------------------------------------------------------------
+// k_sift_hard: the candidates k_sift deferred (bottoms whose first candidate rows precede every forced rescan: the reference's
+// stale minimum has to be followed through its chain of rescans).  One lane per candidate, the samples straight from
+// HBM (a few hundred 2-byte reads each; 0.06 % of the candidates of a clean tape).  Out: the candidate's overflow slot - up to
+// four records and their margin entries in the layout of a list slot.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_sift_hard(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
+                                                  const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf) {
+   const DevCfg &cfg = *cfgp;
+   int n = *hard_count;
+   if (n > hard_cap) n = hard_cap;
+   for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
+      const SfHard hd = hard[i];
+      PkCtxT<PkTape> cx;
+      cx.t.rows = rows; cx.t.t0 = (long long)hd.tile * kSfTile; cx.t.nrows = nrows; cx.t.ntrks = cfg.ntrks; cx.t.sg = cfg.invert ? -1 : 1;
+      const DevScreen &S = cfg.screen[hd.screen];
+      cx.W = S.W; cx.lo_i = S.rise_i; cx.hi_i = S.sure_i;
+      const long long lastl = nrows - 1 - cx.t.t0;
+      cx.last = lastl > 0x3fffffff ? 0x3fffffff : (int)lastl;
+      PkSink sk; sk.n = 0;
+      pk_bot(cx, sk, (int)hd.head, (int)hd.pos);
+      unsigned char *slot = ovf + (size_t)i * kSfOvfBytes;
+      int nrec = sk.n, ne = 0;
+      if (nrec > 4) nrec = -1;                                              // (more epochs than a slot holds: the chain that gets here gives up)
+      for (int j = 0; j < nrec; ++j) ne += pk_nent(sk.w0[j], sk.w1[j]);
+      if (nrec > 0 && 8 + 8 * nrec + 2 * ne > kSfOvfBytes) nrec = -1;
+      *reinterpret_cast<int *>(slot) = nrec;
+      int e0 = 0;
+      for (int j = 0; j < nrec; ++j) {
+         reinterpret_cast<uint32_t *>(slot + 8)[2 * j] = sk.w0[j]; reinterpret_cast<uint32_t *>(slot + 8)[2 * j + 1] = sk.w1[j];
+         pk_entries(cx, (int)hd.head, sk.w0[j], sk.w1[j], reinterpret_cast<uint16_t *>(slot + kSfOvfBytes) - e0);
+         e0 += pk_nent(sk.w0[j], sk.w1[j]); } } }
 
 }  // namespace rtfe

@@ -1,8 +1,9 @@
-"""k_peaks phase split (RTFE_DEBUG=3 cycle counters) and k_chain statistics on the bench tape."""
-import os, sys, json
+"""k_sift phase split (RTFE_DEBUG=3 cycle counters, summed over the waves) and k_gain statistics on the bench tape."""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
-os.environ.setdefault("RTFE_DEBUG", sys.argv[2] if len(sys.argv) > 2 else "3")
+os.environ.setdefault("RTFE_DEBUG", "3")
+os.environ.setdefault("RTFE_PEAK_PATH", "1")
 import torch
 import bench
 from readtape_amd import frontend
@@ -20,8 +21,7 @@ for i in range(3):
 st = fe.scan_stats(r)
 ph = st["phase_cycles"]
 tiles = max(ph[7], 1)
-names = ["copy+quiet", "blocks", "dense", "sparse (per wave)", "hard candidates", "rounds", "rounds with a hard one"]
 print("rows", rows.shape[0], {k: round(v, 3) for k, v in ms.items() if v > 0.01})
-print("k_peaks cycles per tile:", {n: ph[i] // tiles for i, n in enumerate(names)}, "tiles", tiles)
-print({k: st[k] for k in ("bursts", "redone", "record_bytes", "parallel", "sequential", "gave_up")})
-print("record bytes per row %.2f" % (st["record_bytes"] / rows.shape[0]))
+print("k_sift wave-cycles per tile (5 waves): copy+quiet %d dense %d owners %d; deferred candidates %d, rounds %d, tiles %d" % (ph[0] // tiles, ph[1] // tiles, ph[2] // tiles, ph[4], ph[5], tiles))
+print({k: st[k] for k in ("bursts", "redone", "parallel", "sequential", "gave_up")})
+print("record bytes per row %.2f" % (ph[3] / rows.shape[0]))
