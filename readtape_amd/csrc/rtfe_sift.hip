@@ -389,9 +389,13 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
    const int vpg = 8 * ntrks;                                           // ... per quiet group of 64 rows
    const int v_own0 = HL * ntrks / 8;
    const int quiet_i = cfgp->quiet_i;
-   // every workgroup walks a contiguous run of tiles (the halo rows a tile shares with its neighbour are then still in its CU's L1 / its XCD's L2)
-   const int per = ((int)ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-   const long long tile_lo = (long long)blockIdx.x * per, tile_hi = tile_lo + per < ntiles ? tile_lo + per : ntiles;
+   // Tile order: round `it` of the grid covers tiles [it G, (it + 1) G) - at any moment the chip works on ONE compact window of the
+   // tape (G tiles = 16 MB), which is what the address translation and the HBM channels like (a contiguous run of tiles per
+   // workgroup - 1024 streams 1.8 MB apart - streams at 1.4 TB/s, this at several times that).  Inside a round the workgroups of
+   // an XCD (block b runs on XCD b % 8) take a contiguous eighth, so the halo rows neighbours share are in that XCD's L2.
+   const long long G = gridDim.x;
+   const long long tile_first = (G & 7) ? (long long)blockIdx.x : (long long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+   const long long tile_lo = tile_first, tile_hi = ntiles;
    // a tile is "inside" when every row of it and of its halo exists (its bytes then come as 16-byte vectors, one tile ahead)
    const long long inside_lo = (HL + kSfTile - 1) / kSfTile, inside_hi = (nrows - HR - 15) / kSfTile - 1;      // tiles inside_lo .. inside_hi
    const bool prof = cfgp->debug == 3;
@@ -407,11 +411,13 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
    for (int k = 0; k < NV; ++k) q[k] = make_int4(0, 0, 0, 0);
    if (tile_lo < tile_hi && tile_lo >= inside_lo && tile_lo <= inside_hi) sf_fetch(q, rows, (tile_lo * kSfTile - HL) * ntrks, nvec, tid, nthreads);
    if (tid < 2) s_noisy[tid] = 0;
-   for (long long tile = tile_lo; tile < tile_hi; ++tile) {
+   int par = 0;
+   long long last_tile = -1;
+   for (long long tile = tile_lo; tile < tile_hi; tile += G, par ^= 1) {
+      last_tile = tile;
       const long long t0 = tile * kSfTile;
       const long long lastl = nrows - 1 - t0;
       cx.last = lastl > 0x3fffffff ? 0x3fffffff : (int)lastl;
-      const int par = (int)(tile & 1);
       long long tk0 = 0, tk1 = 0;
       if (prof) tk0 = clock64();
       // ---- 1. the prefetched bytes -> LDS (every wave is done with the tile in front: the barrier at the end of the round before);
@@ -421,9 +427,9 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
          for (int k = 0; k < NV; ++k) { const int vi = k * nthreads + tid; if (vi < nvec) reinterpret_cast<int4 *>(xs)[vi] = q[k]; } }
       else sf_fill_edge(xsl, rows, (t0 - HL) * ntrks, nrows * ntrks, nvec * 8, tid, nthreads);
       __syncthreads();
-      if (tile + 1 < tile_hi && tile + 1 >= inside_lo && tile + 1 <= inside_hi) sf_fetch(q, rows, ((tile + 1) * kSfTile - HL) * ntrks, nvec, tid, nthreads);
+      if (tile + G < tile_hi && tile + G >= inside_lo && tile + G <= inside_hi) sf_fetch(q, rows, ((tile + G) * kSfTile - HL) * ntrks, nvec, tid, nthreads);
       // the quiet map of the tile in front (its bits were complete at the barrier)
-      if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - 1, nrows, qbits); s_noisy[par ^ 1] = 0; }
+      if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, nrows, qbits); s_noisy[par ^ 1] = 0; }
       // ---- 2. quiet groups: 14 x 64 rows, flat 16-byte reads of the tile proper ----
       {
          const uint32_t qpk = pk_dup(quiet_i), q2 = 2u * (uint32_t)quiet_i;
@@ -548,11 +554,11 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                   dir[(size_t)(tile * nscreens + sc) * ntrks + h] = d; } } }
          rtfe_wave_sync(); }
       __syncthreads(); }
-   if (tid == 0 && tile_hi > tile_lo) sf_publish_quiet(s_noisy[(int)((tile_hi - 1) & 1)], tile_hi - 1, nrows, qbits);
+   if (tid == 0 && last_tile >= 0) sf_publish_quiet(s_noisy[par ^ 1], last_tile, nrows, qbits);
    if (prof && lane == 0) {
       atomicAdd(&dbg[0], (unsigned long long)pc_copy); atomicAdd(&dbg[1], (unsigned long long)pc_dense); atomicAdd(&dbg[2], (unsigned long long)pc_own);
       atomicAdd(&dbg[3], (unsigned long long)pn_bytes); atomicAdd(&dbg[4], (unsigned long long)pn_hard); atomicAdd(&dbg[5], (unsigned long long)pn_rounds);
-      if (wave == 0) atomicAdd(&dbg[7], (unsigned long long)(tile_hi > tile_lo ? tile_hi - tile_lo : 0)); } }
+      if (wave == 0) atomicAdd(&dbg[7], (unsigned long long)(last_tile >= 0 ? (last_tile - tile_lo) / G + 1 : 0)); } }
 
 // ------------------------------------------------------------------------------------------------
 // k_sift_hard: the candidates k_sift deferred (bottoms whose first candidate rows precede every forced rescan: the reference's
