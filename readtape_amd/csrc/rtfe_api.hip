@@ -56,14 +56,24 @@ static int fail(int code, const char *fmt, ...) {
 // the k_sift instantiation for a window width, a workgroup size and the vectors a thread prefetches
 typedef void (*sf_kernel_t)(const DevCfg *, const int16_t *, long long, long long, unsigned int *, PeakDir *, unsigned char *, SfHard *, int, int *, unsigned long long *);
 constexpr int kSfWps = 5;          // waves per SIMD k_sift's register allocation is held to: four 5-wave workgroups per CU
-template <int WM, int MAXT> static sf_kernel_t sf_kernel_nv(int nv) { return nv <= 4 ? k_sift<WM, MAXT, 4, kSfWps> : k_sift<WM, MAXT, 6, kSfWps>; }
+template <int WM, int MAXT> static sf_kernel_t sf_kernel_nv(int nv) { return nv <= 4 ? k_sift<0, WM, MAXT, 4, kSfWps> : k_sift<0, WM, MAXT, 6, kSfWps>; }
 template <int WM> static sf_kernel_t sf_kernel_t2(int threads, int nv) { return threads <= 320 ? sf_kernel_nv<WM, 320>(nv) : sf_kernel_nv<WM, 640>(nv); }
-static sf_kernel_t sf_kernel(int wmax, int threads, int nv) {
-   return wmax <= 18 ? sf_kernel_t2<18>(threads, nv) : (wmax <= 34 ? sf_kernel_t2<34>(threads, nv) : sf_kernel_t2<50>(threads, nv)); }
+// wc > 0: one screen of exactly that width, a sure level that fits 16 bits, <= 10 tracks: the compile-time-width kernels
+static sf_kernel_t sf_kernel(int wmax, int threads, int nv, int wc) {
+   if (wc > 0 && threads <= 320 && nv <= 4) {
+      switch (wc) {
+         case 8:  return k_sift<8, 18, 320, 4, kSfWps>;
+         case 11: return k_sift<11, 18, 320, 4, kSfWps>;
+         case 13: return k_sift<13, 18, 320, 4, kSfWps>;
+         case 17: return k_sift<17, 18, 320, 4, kSfWps>;
+         case 20: return k_sift<20, 34, 320, 4, kSfWps>;
+         default: break; } }
+   return wmax <= 18 ? sf_kernel_t2<18>(threads, nv) : sf_kernel_t2<50>(threads, nv); }
 static int sf_wmax(const DevCfg &d) { int w = 0; for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].W > w) w = d.screen[s].W; return w; }
 static int sf_threads(const DevCfg &d) { return 64 * ((d.ntrks + 1) / 2); }
 static int sf_nvec(const DevCfg &d) { return (d.pk_hl + kSfTile + d.pk_hr) * d.ntrks / 8; }
 static int sf_nv(const DevCfg &d) { return (sf_nvec(d) + sf_threads(d) - 1) / sf_threads(d); }
+static int sf_wc(const DevCfg &d) { return (d.nscreens == 1 && d.screen[0].sure_i <= 32767 && !getenv("RTFE_SIFT_GENERIC")) ? d.screen[0].W : 0; }
 
 extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
@@ -252,11 +262,13 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       const float spbf = 1.0f / (bpi_s * c->ips * d.sample_deltat);
       const float ppb = c->mode == RTFE_PE ? 2.0f : 1.0f;
       int slot = (int)((float)kSfTile / (spbf > 2 ? spbf : 2) * ppb * 14.0f * 1.5f) + 160;
-      int lo_min = 1 << 30;
-      for (int sidx = 0; sidx < d.nscreens; ++sidx) if (d.screen[sidx].rise_i < lo_min) lo_min = d.screen[sidx].rise_i;
-      const bool noisy_screen = (double)lo_min / lsb_per_volt < 0.03;
-      if (noisy_screen) slot *= 3;                                        // a screen below the noise floor: noise wiggles become runs, every row explicit
-      d.pk_wave_cap = noisy_screen ? 1792 : 512;                          // (a wave's two heads have 2 x 896 samples)
+      // a screen below the noise floor - no amplitude test, or one as low as the rise test: noise wiggles become runs, every row explicit
+      bool noisy_screen = false;
+      for (int sidx = 0; sidx < d.nscreens; ++sidx) {
+         const bool rise_low = (double)d.screen[sidx].rise_i / lsb_per_volt < 0.03, amp_low = d.screen[sidx].minpk_i < 0 || (double)d.screen[sidx].minpk_i / lsb_per_volt < 0.03;
+         if (rise_low && amp_low) noisy_screen = true; }
+      if (noisy_screen) slot *= 3;
+      d.pk_wave_cap = noisy_screen ? 1792 : 384;                          // (a wave's two heads have 2 x 896 samples)
       if (const char *e = getenv("RTFE_PK_SLOT")) { const int v = atoi(e); if (v >= 32 && v <= 65536) slot = v; }
       d.pk_slot = (slot + 15) & ~15;
       d.pk_lds = (int)sf_lds_layout(c->ntrks, d.pk_hl, d.pk_hr, d.pk_wave_cap, d.pk_slot).total + 64;
@@ -322,7 +334,11 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (c->nparmsets * c->ntrks <= 32 && (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16 <= 150 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lwalk), hipFuncAttributeMaxDynamicSharedMemorySize, (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
-   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
+   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d), sf_wc(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
+   if (getenv("RTFE_VERBOSE")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d), sf_wc(d))), sf_threads(d), (size_t)d.pk_lds);
+      fprintf(stderr, "rtfe: k_sift %d threads, %d bytes of LDS: %d workgroups per CU (occupancy API), %d CUs\n", sf_threads(d), d.pk_lds, nb, h->num_cus); }
    *out = h;
    return 0; }
 
@@ -483,7 +499,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (spc < 1) spc = 1;
       long long pgrid = (long long)h->num_cus * spc;
       if (pgrid > ptiles) pgrid = ptiles;
-      const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev));
+      const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev), sf_wc(h->dev));
       hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                          reinterpret_cast<unsigned int *>(qwords), dirm, pkpool, hardp, hard_cap, &scratch->hard_count, scratch->scr);
       hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus), dim3(64), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,

@@ -87,7 +87,8 @@ struct PkTile {
    int hl;                      // rows in front of the tile
    int sg;                      // -invert: -1 (the detector sees 0 - x, src/readtape.c:1421)
    __device__ __forceinline__ int at(int r, int head) const {      // r relative to the tile's first row (>= -hl); after -invert
-      return sg * lds_i16(xs + (r + hl) * row_bytes + head * 2); } };
+      const int m = sg >> 1;                                        // 0 / -1: (x ^ m) - m = x / -x without a multiplication
+      return (lds_i16(xs + (r + hl) * row_bytes + head * 2) ^ m) - m; } };
 // ... or the tape in HBM (k_sift_hard: the few candidates that need the general walk); rows outside the tape read as zeros
 struct PkTape {
    const int16_t *rows; long long t0, nrows; int ntrks, sg;
@@ -296,6 +297,81 @@ __device__ __forceinline__ int pk_fast(const PkCtx &c, int head, int p, bool bot
    w0 = pk_w0(p, !bot, p + f, nlead, nsure, ntail);
    return 1; }
 
+// ---- the same for a window width known at compile time, two samples per operation: row k's left and right window edge share a
+// register (v_perm_b32), a bottom is a top of y = ~x (order-reversing, no overflow), and every test is the sign bit of a packed
+// saturating difference (v_pk_sub_i16 clamp) shifted into a mask.  Needs sure_i <= 32767 (margins below the sure level are then exact
+// in 16 bits).  mm[k] = the margin of row k in both halves (what the record's explicit entries hold).
+template <int W>
+__device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool bot, uint32_t &w0, uint32_t &w1, uint32_t (&mm)[W - 1]) {
+   const int rb_ = c.t.row_bytes;
+   const uint32_t m2 = (bot != (c.t.sg < 0)) ? 0xffffffffu : 0u;
+   lds_cp pr = c.t.xs + head * 2 + (p + c.t.hl) * rb_, pl = pr - (W - 1) * rb_;
+   uint32_t LR[W - 1];                                                 // low half: x[p + k - W + 1], high half: x[p + k]   (as y)
+   #pragma unroll
+   for (int k = 0; k < W - 1; ++k) LR[k] = ((uint32_t)(uint16_t)lds_i16(pl + k * rb_) | ((uint32_t)(uint16_t)lds_i16(pr + k * rb_) << 16)) ^ m2;
+   const uint32_t vv = (LR[0] >> 16) | (LR[0] & 0xffff0000u);          // the extreme in both halves
+   const uint32_t c10 = 1u, thr = (uint32_t)(uint16_t)(c.lo_i + 1) | ((uint32_t)(uint16_t)c.hi_i << 16);
+   uint32_t a1 = 0, a2 = 0;
+   #pragma unroll
+   for (int k = 0; k < W - 1; ++k) {
+      const uint32_t d = pk_subs(vv, LR[k]);                           // (extreme - left edge, extreme - right edge)
+      a1 = (a1 >> 1) | (pk_subs(d, c10) & kPkSigns);                   // sign: left edge not strictly below / right edge above the extreme
+      const uint32_t mn = pk_min(d, (d >> 16) | (d << 16));            // the margin of row k, in both halves
+      mm[k] = mn;
+      a2 = (a2 >> 1) | (pk_subs(mn, thr) & kPkSigns); }                // sign: margin not above the screen / below the sure level
+   constexpr int SH = 17 - W;                                          // bit k of a half sits at 17 - W + k
+   constexpr uint32_t ALL = (1u << (W - 1)) - 1u;
+   const uint32_t lm = ~((a1 & 0xffffu) >> SH) & ALL, rm = ~(a1 >> (16 + SH)) & ALL & ~1u;
+   const uint32_t lom = ~((a2 & 0xffffu) >> SH) & ALL, him = ~(a2 >> (16 + SH)) & ALL;
+   // J: consecutive left samples below the extreme, from distance 1 (k = W-2) outwards (tops: up to W-2, bottoms: W-1, i.e. k = 0 too)
+   const uint32_t lsh = lm << (31 - (W - 2));                          // top bit = k = W-2
+   int J = pk_clz((uint32_t)~lsh);
+   const int jmax = bot ? W - 1 : W - 2;
+   if (J > jmax) J = jmax;
+   int D = pk_ctz((uint32_t)~(rm >> 1));                               // consecutive right samples not above it, from k = 1
+   if (D > W - 2) D = W - 2;
+   const int ra = W - 1 - J > 1 ? W - 1 - J : 1;
+   if (ra > D) return 0;
+   const uint32_t V = ((2u << D) - 1u) & ~((1u << ra) - 1u);
+   uint32_t C = V & lom;
+   const int klast = c.last - p;                                       // rows behind the tape's end do not exist
+   if (klast < 31) C &= klast < 0 ? 0u : ((2u << klast) - 1u);
+   if (!C) return 0;
+   if (bot) {
+      const int n0 = pk_ctz(C);
+      if (!pk_async(c, head, p + n0)) return 2;
+      C &= ~((1u << n0) - 1u); }
+   const int raw = lds_i16(pr);
+   const int val = c.t.sg < 0 ? -raw : raw;                            // the sample as the detector sees it
+   int dp = (int)(int16_t)(mm[W - 2] & 0xffffu), dn;                   // (mm[W-2] = min(extreme - x[p-1], ...): not what is needed; the differences proper:)
+   {  const uint32_t dl = pk_subs(vv, LR[W - 2]), dr = pk_subs(vv, LR[1]);
+      dp = (int)(int16_t)(dl & 0xffffu); dn = (int)(int16_t)(dr >> 16); }
+   dp = dp < -1 ? -1 : (dp > 254 ? 254 : dp); dn = dn < -1 ? -1 : (dn > 254 ? 254 : dn);
+   w1 = (uint32_t)(uint16_t)val | ((uint32_t)(dp + 1) << 16) | ((uint32_t)(dn + 1) << 24);
+   const int f = pk_ctz(C), l = 31 - pk_clz(C);
+   const int span = l - f + 1;
+   int nlead = pk_ctz((uint32_t)(him >> f));
+   if (nlead > span) nlead = span;
+   int nsure = nlead >= span ? 0 : pk_ctz((uint32_t)~(him >> (f + nlead)));
+   if (nsure > span - nlead) nsure = span - nlead;
+   int ntail = span - nlead - nsure;
+   if (nlead > 15 || ntail > 15 || nsure > 62) { nlead = span >> 4; ntail = span & 15; nsure = 63; }
+   w0 = pk_w0(p, !bot, p + f, nlead, nsure, ntail);
+   return 1; }
+
+// the explicit margins of a record built by pk_fast_w, from the registers they are in: entry i lives at e16[-(i + 1)]
+template <int W, class P16>
+__device__ __forceinline__ void pk_entries_w(uint32_t w0, uint32_t w1, const uint32_t (&mm)[W - 1], P16 e16) {
+   if ((w1 & 0xfffffffeu) == 0xffff8000u) return;
+   const int fo = (int)((w0 >> 12) & 63u);                              // first row above the screen, as an offset from the owner
+   int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u), ntail = (int)((w0 >> 28) & 15u);
+   if (nsure == 63) { nlead = nlead << 4 | ntail; nsure = 0; ntail = 0; }
+   #pragma unroll
+   for (int k = 1; k < W - 1; ++k) {
+      const int i = k - fo;                                              // position in the run
+      const bool lead = (unsigned)i < (unsigned)nlead, tail = (unsigned)(i - nlead - nsure) < (unsigned)ntail;
+      if (lead || tail) { const int m = (int)(int16_t)(mm[k] & 0xffffu); e16[-((lead ? i : i - nsure) + 1)] = (uint16_t)(m < 0 ? 0 : m); } } }
+
 // ---- wave-wide inclusive prefix sum: DPP row shifts and broadcasts (seven dependent VALU operations; __shfl_up would be six
 // ds_bpermute round trips through the LDS pipeline) ----
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
@@ -363,7 +439,8 @@ __device__ __forceinline__ void sf_publish_quiet(unsigned int noisy, long long t
 
 // WM >= the widest window; NV = 16-byte vectors of the next tile a thread holds in registers (>= tile vectors / threads);
 // WPS = waves per SIMD the register allocation is held to (workgroups per CU x waves per workgroup / 4)
-template <int WM, int MAXT, int NV, int WPS>
+// WC > 0: the scan has ONE window width, WC, known at compile time (pk_fast_w); WC = 0: any widths up to WM (pk_fast)
+template <int WC, int WM, int MAXT, int NV, int WPS>
 __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
                                                     unsigned int *__restrict__ qbits, PeakDir *__restrict__ dir, unsigned char *__restrict__ pool,
                                                     SfHard *__restrict__ hard, int hard_cap, int *__restrict__ hard_count, unsigned long long *__restrict__ dbg) {
@@ -506,11 +583,13 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                for (int r0 = 0; r0 < ncw; r0 += 64) {
                   const int i = r0 + lane;
                   uint32_t w0 = 0, w1 = 0;
+                  uint32_t mm[WC > 0 ? WC - 1 : 1];
                   int half = 0, st = 0, cpos = 0, ckind = 0;
                   if (i < ncw) {
                      const uint32_t cd = wlist[i];
                      half = (int)(cd >> 15); cpos = (int)(cd & 0x3ffu); ckind = (int)((cd >> 14) & 1u);
-                     st = pk_fast<WM>(cx, half ? h_hi : h_lo, cpos, ckind != 0, w0, w1); }
+                     if constexpr (WC > 0) st = pk_fast_w<WC>(cx, half ? h_hi : h_lo, cpos, ckind != 0, w0, w1, mm);
+                     else st = pk_fast<WM>(cx, half ? h_hi : h_lo, cpos, ckind != 0, w0, w1); }
                   if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
                      const int hidx = atomicAdd(hard_count, 1);
                      if (hidx < hard_cap) {
@@ -528,7 +607,8 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                      const lds_p slot = half ? slot_hi : slot_lo;
                      lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 2 * myr;
                      rp[0] = w0; rp[1] = w1;
-                     pk_entries(cx, half ? h_hi : h_lo, w0, w1, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye)); }
+                     if constexpr (WC > 0) pk_entries_w<WC>(w0, w1, mm, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye));
+                     else pk_entries(cx, half ? h_hi : h_lo, w0, w1, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye)); }
                   const int tr = wave_last(ir), te = wave_last(ie);
                   rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; ent_lo += te & 0xffff; ent_hi += (te >> 16) & 0xffff; } } }
          if (prof) { tk0 = clock64(); pc_own += tk0 - tk1; }

@@ -45,6 +45,7 @@ inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 1; return hipSuccess; }
 typedef void *hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
