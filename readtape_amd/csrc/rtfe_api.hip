@@ -54,26 +54,32 @@ static int fail(int code, const char *fmt, ...) {
    return code; }
 
 // the k_sift instantiation for a window width, a workgroup size and the vectors a thread prefetches
-typedef void (*sf_kernel_t)(const DevCfg *, const int16_t *, long long, long long, unsigned int *, PeakDir *, unsigned char *, SfHard *, int, int *, unsigned long long *);
+typedef void (*sf_kernel_t)(const DevCfg *, const int16_t *, long long, long long, uint16_t *, PeakDir *, unsigned char *, SfHard *, int, int *, unsigned long long *);
+typedef void (*sfs_kernel_t)(const SfArgs);
 constexpr int kSfWps = 5;          // waves per SIMD k_sift's register allocation is held to: four 5-wave workgroups per CU
-template <int WM, int MAXT> static sf_kernel_t sf_kernel_nv(int nv) { return nv <= 4 ? k_sift<0, WM, MAXT, 4, kSfWps> : k_sift<0, WM, MAXT, 6, kSfWps>; }
+template <int WM, int MAXT> static sf_kernel_t sf_kernel_nv(int nv) { return nv <= 4 ? k_sift<WM, MAXT, 4, kSfWps> : k_sift<WM, MAXT, 6, kSfWps>; }
 template <int WM> static sf_kernel_t sf_kernel_t2(int threads, int nv) { return threads <= 320 ? sf_kernel_nv<WM, 320>(nv) : sf_kernel_nv<WM, 640>(nv); }
-// wc > 0: one screen of exactly that width, a sure level that fits 16 bits, <= 10 tracks: the compile-time-width kernels
-static sf_kernel_t sf_kernel(int wmax, int threads, int nv, int wc) {
-   if (wc > 0 && threads <= 320 && nv <= 4) {
-      switch (wc) {
-         case 8:  return k_sift<8, 18, 320, 4, kSfWps>;
-         case 11: return k_sift<11, 18, 320, 4, kSfWps>;
-         case 13: return k_sift<13, 18, 320, 4, kSfWps>;
-         case 17: return k_sift<17, 18, 320, 4, kSfWps>;
-         case 20: return k_sift<20, 34, 320, 4, kSfWps>;
-         default: break; } }
+static sf_kernel_t sf_kernel(int wmax, int threads, int nv) {
    return wmax <= 18 ? sf_kernel_t2<18>(threads, nv) : sf_kernel_t2<50>(threads, nv); }
+// one screen of a width and a track count the lean kernel is built for, a sure level that fits 16 bits: k_sift_s
+static sfs_kernel_t sfs_kernel(int w, int ntrks) {
+   if (ntrks == 9) switch (w) {
+      case 8:  return k_sift_s<8, 9, kSfWps>;
+      case 11: return k_sift_s<11, 9, kSfWps>;
+      case 13: return k_sift_s<13, 9, kSfWps>;
+      case 17: return k_sift_s<17, 9, kSfWps>;
+      case 20: return k_sift_s<20, 9, kSfWps>;
+      default: break; }
+   if (ntrks == 7) switch (w) {
+      case 11: return k_sift_s<11, 7, kSfWps>;
+      case 13: return k_sift_s<13, 7, kSfWps>;
+      default: break; }
+   return nullptr; }
 static int sf_wmax(const DevCfg &d) { int w = 0; for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].W > w) w = d.screen[s].W; return w; }
 static int sf_threads(const DevCfg &d) { return 64 * ((d.ntrks + 1) / 2); }
 static int sf_nvec(const DevCfg &d) { return (d.pk_hl + kSfTile + d.pk_hr) * d.ntrks / 8; }
 static int sf_nv(const DevCfg &d) { return (sf_nvec(d) + sf_threads(d) - 1) / sf_threads(d); }
-static int sf_wc(const DevCfg &d) { return (d.nscreens == 1 && d.screen[0].sure_i <= 32767 && !getenv("RTFE_SIFT_GENERIC")) ? d.screen[0].W : 0; }
+static sfs_kernel_t sf_special(const DevCfg &d) { return (d.nscreens == 1 && d.screen[0].sure_i <= 32767 && !getenv("RTFE_SIFT_GENERIC")) ? sfs_kernel(d.screen[0].W, d.ntrks) : nullptr; }
 
 extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
@@ -334,11 +340,12 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (c->nparmsets * c->ntrks <= 32 && (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16 <= 150 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lwalk), hipFuncAttributeMaxDynamicSharedMemorySize, (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
-   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d), sf_wc(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
+   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
+   if (sf_special(d)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_special(d)), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
    if (getenv("RTFE_VERBOSE")) {
       int nb = -1;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d), sf_wc(d))), sf_threads(d), (size_t)d.pk_lds);
-      fprintf(stderr, "rtfe: k_sift %d threads, %d bytes of LDS: %d workgroups per CU (occupancy API), %d CUs\n", sf_threads(d), d.pk_lds, nb, h->num_cus); }
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sf_special(d) ? reinterpret_cast<const void *>(sf_special(d)) : reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), sf_threads(d), (size_t)d.pk_lds);
+      fprintf(stderr, "rtfe: k_sift%s %d threads, %d bytes of LDS: %d workgroups per CU (occupancy API), %d CUs\n", sf_special(d) ? "_s" : "", sf_threads(d), d.pk_lds, nb, h->num_cus); }
    *out = h;
    return 0; }
 
@@ -414,11 +421,15 @@ static size_t pk_pool_bytes(const rtfe_handle *h, int64_t nrows) {      // one s
 // ... | the candidates k_sift deferred (k_sift_hard) | their overflow slots
 static long long pk_hard_cap(const rtfe_handle *h, int64_t nrows) { const long long c = pk_tiles_for(nrows) * h->dev.nscreens * 2 + 1024; return c > 0x3fffffffll ? 0x3fffffffll : c; }
 static size_t ws_pkhard_off(const rtfe_handle *h, int64_t nrows) { return ws_pkpool_off(h, nrows) + pk_pool_bytes(h, nrows); }
+static size_t ws_pkqtile_off(const rtfe_handle *h, int64_t nrows);
 static size_t ws_pkovf_off(const rtfe_handle *h, int64_t nrows) { return ws_pkhard_off(h, nrows) + (h->dev.peak_path ? (((size_t)pk_hard_cap(h, nrows) * sizeof(SfHard) + 255) & ~(size_t)255) : 0); }
 static size_t pk_ovf_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (size_t)pk_hard_cap(h, nrows) * kSfOvfBytes : 0; }
+// ... | the tiles' quiet bits (k_sift -> k_qpack)
+static size_t ws_pkqtile_off(const rtfe_handle *h, int64_t nrows) { return (ws_pkovf_off(h, nrows) + pk_ovf_bytes(h, nrows) + 255) & ~(size_t)255; }
+static size_t pk_qtile_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_tiles_for(nrows) * 2 + 255) & ~(size_t)255) : 0; }
 
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pkovf_off(h, nrows) + pk_ovf_bytes(h, nrows) + 256; }
+   return ws_pkqtile_off(h, nrows) + pk_qtile_bytes(h, nrows) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -488,7 +499,6 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       const int hard_cap = (int)pk_hard_cap(h, nrows);
       const long long ptiles = pk_tiles_for(nrows);
       (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
-      (void)hipMemsetAsync(qwords, 0, (size_t)nwords * 8, st);           // (k_sift ORs the quiet bits of its tiles into the map)
       t0(0, st); t1(0, st); t0(2, st); t1(2, st); t0(3, st); t1(3, st); t0(4, st); t1(4, st);
       const int stop_after = getenv("RTFE_PEAK_STOP") ? atoi(getenv("RTFE_PEAK_STOP")) : 99;      // (debugging: launch only the first n kernels of the path)
       t0(6, st);
@@ -499,9 +509,19 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (spc < 1) spc = 1;
       long long pgrid = (long long)h->num_cus * spc;
       if (pgrid > ptiles) pgrid = ptiles;
-      const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev), sf_wc(h->dev));
-      hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
-                         reinterpret_cast<unsigned int *>(qwords), dirm, pkpool, hardp, hard_cap, &scratch->hard_count, scratch->scr);
+      uint16_t *qtile = reinterpret_cast<uint16_t *>(wsb + ws_pkqtile_off(h, nrows));
+      if (const sfs_kernel_t sfs = sf_special(h->dev)) {
+         SfArgs a;
+         a.rows = d_rows; a.nrows = nrows; a.ntiles = (int)ptiles; a.qtile = qtile; a.dir = dirm; a.pool = pkpool; a.hard = hardp; a.hard_cap = hard_cap;
+         a.hard_count = &scratch->hard_count; a.dbg = scratch->scr; a.hcap = h->dev.pk_slot; a.wave_cap = h->dev.pk_wave_cap; a.invert = h->dev.invert;
+         a.quiet_i = h->dev.quiet_i; a.lo_i = h->dev.screen[0].rise_i; a.hi_i = h->dev.screen[0].sure_i; a.minpk_i = h->dev.screen[0].minpk_i;
+         a.cut = h->dev.cut; a.debug = h->dev.debug;
+         hipLaunchKernelGGL(sfs, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, a); }
+      else {
+         const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev));
+         hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
+                            qtile, dirm, pkpool, hardp, hard_cap, &scratch->hard_count, scratch->scr); }
+      hipLaunchKernelGGL(k_qpack, dim3(64), dim3(256), 0, st, (const uint16_t *)qtile, ptiles, qwords, nwords);
       hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus), dim3(64), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
                          (const int *)&scratch->hard_count, ovfp);
       t1(6, st); t0(1, st);

@@ -426,23 +426,28 @@ __device__ __attribute__((noinline)) void sf_fill_edge(lds_p xs, const int16_t *
 #endif
    for (int i = tid; i < nelem; i += nthreads) { const long long g = e_first + i; d[i] = (g >= 0 && g < total_elem) ? rows[g] : (int16_t)0; } }
 
-// the tile's quiet bits -> bit (14 tile + g) of the tape's bit string (only complete groups can be quiet)
-__device__ __forceinline__ void sf_publish_quiet(unsigned int noisy, long long tile, long long nrows, unsigned int *qbits) {
+// the tile's quiet bits: one 16-bit word per tile (only complete groups can be quiet); k_qpack strings them together
+__device__ __forceinline__ void sf_publish_quiet(unsigned int noisy, long long tile, long long nrows, uint16_t *qtile) {
    unsigned int quiet = ~noisy & ((1u << kSfGroups) - 1u);
    const long long left = nrows - tile * kSfTile;
    if (left < kSfTile) quiet &= left < 64 ? 0u : ((1u << (int)(left / 64)) - 1u);
-   if (quiet) {
-      const long long bit0 = tile * kSfGroups;
-      const u64 v = (u64)quiet << (bit0 & 31);
-      atomicOr(&qbits[bit0 >> 5], (unsigned int)v);
-      if (v >> 32) atomicOr(&qbits[(bit0 >> 5) + 1], (unsigned int)(v >> 32)); } }
+   qtile[tile] = (uint16_t)quiet; }
+// the quiet map k_bursts reads: bit c of word c >> 6 = group c of 64 rows is quiet; group c is bit c % 14 of tile c / 14
+__global__ void __launch_bounds__(256) k_qpack(const uint16_t *__restrict__ qtile, long long ntiles, u64 *__restrict__ qwords, long long nwords) {
+   for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (long long)gridDim.x * blockDim.x) {
+      u64 word = 0;
+      const long long c0 = w * 64;
+      for (long long t = c0 / kSfGroups; t <= (c0 + 63) / kSfGroups && t < ntiles; ++t) {
+         const u64 bits = qtile[t];
+         const long long rel = t * kSfGroups - c0;
+         word |= rel >= 0 ? bits << rel : bits >> -rel; }
+      qwords[w] = word; } }
 
 // WM >= the widest window; NV = 16-byte vectors of the next tile a thread holds in registers (>= tile vectors / threads);
 // WPS = waves per SIMD the register allocation is held to (workgroups per CU x waves per workgroup / 4)
-// WC > 0: the scan has ONE window width, WC, known at compile time (pk_fast_w); WC = 0: any widths up to WM (pk_fast)
-template <int WC, int WM, int MAXT, int NV, int WPS>
+template <int WM, int MAXT, int NV, int WPS>
 __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
-                                                    unsigned int *__restrict__ qbits, PeakDir *__restrict__ dir, unsigned char *__restrict__ pool,
+                                                    uint16_t *__restrict__ qtile, PeakDir *__restrict__ dir, unsigned char *__restrict__ pool,
                                                     SfHard *__restrict__ hard, int hard_cap, int *__restrict__ hard_count, unsigned long long *__restrict__ dbg) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;
@@ -506,7 +511,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
       __syncthreads();
       if (tile + G < tile_hi && tile + G >= inside_lo && tile + G <= inside_hi) sf_fetch(q, rows, ((tile + G) * kSfTile - HL) * ntrks, nvec, tid, nthreads);
       // the quiet map of the tile in front (its bits were complete at the barrier)
-      if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, nrows, qbits); s_noisy[par ^ 1] = 0; }
+      if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, nrows, qtile); s_noisy[par ^ 1] = 0; }
       // ---- 2. quiet groups: 14 x 64 rows, flat 16-byte reads of the tile proper ----
       {
          const uint32_t qpk = pk_dup(quiet_i), q2 = 2u * (uint32_t)quiet_i;
@@ -580,16 +585,14 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                for (; mhi; mhi &= mhi - 1) { const int b2 = __ffs((int)mhi) - 1; wlist[o2++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> (16 + b2)) & 1u) << 14) | 0x8000u); }
                rtfe_wave_sync();
                #pragma nounroll
-               for (int r0 = 0; r0 < ncw; r0 += 64) {
+               for (int r0 = 0; r0 < (cut == 3 ? 0 : ncw); r0 += 64) {
                   const int i = r0 + lane;
                   uint32_t w0 = 0, w1 = 0;
-                  uint32_t mm[WC > 0 ? WC - 1 : 1];
                   int half = 0, st = 0, cpos = 0, ckind = 0;
                   if (i < ncw) {
                      const uint32_t cd = wlist[i];
                      half = (int)(cd >> 15); cpos = (int)(cd & 0x3ffu); ckind = (int)((cd >> 14) & 1u);
-                     if constexpr (WC > 0) st = pk_fast_w<WC>(cx, half ? h_hi : h_lo, cpos, ckind != 0, w0, w1, mm);
-                     else st = pk_fast<WM>(cx, half ? h_hi : h_lo, cpos, ckind != 0, w0, w1); }
+                     st = pk_fast<WM>(cx, half ? h_hi : h_lo, cpos, ckind != 0, w0, w1); }
                   if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
                      const int hidx = atomicAdd(hard_count, 1);
                      if (hidx < hard_cap) {
@@ -599,6 +602,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                      else { w0 = pk_w0(cpos, false, cpos + 1, 0, 1, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" - the chain that gets here gives up)
                      st = 1; }
                   if (prof) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
+                  if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
                   const int vr = st, ve = st ? pk_nent(w0, w1) : 0;
                   const int sh = 16 * half;
                   const int ir = wave_incl_scan(vr << sh, lane), ie = wave_incl_scan(ve << sh, lane);
@@ -607,8 +611,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                      const lds_p slot = half ? slot_hi : slot_lo;
                      lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 2 * myr;
                      rp[0] = w0; rp[1] = w1;
-                     if constexpr (WC > 0) pk_entries_w<WC>(w0, w1, mm, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye));
-                     else pk_entries(cx, half ? h_hi : h_lo, w0, w1, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye)); }
+                     if (cut != 5) pk_entries(cx, half ? h_hi : h_lo, w0, w1, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye)); }
                   const int tr = wave_last(ir), te = wave_last(ie);
                   rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; ent_lo += te & 0xffff; ent_hi += (te >> 16) & 0xffff; } } }
          if (prof) { tk0 = clock64(); pc_own += tk0 - tk1; }
@@ -624,7 +627,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                const int nr = hh ? rec_hi : rec_lo, ne = hh ? ent_hi : ent_lo;
                const bool over = bad || 8 * nr + 2 * ne > hcap || nr >= 0xff00 || ne >= 0xff00;
                unsigned char *gslot = pool + ((size_t)(tile * nscreens + sc) * ntrks + h) * (size_t)hcap;
-               if (!over && nr > 0) {
+               if (!over && nr > 0 && cut != 6) {
                   const int fv = (8 * nr + 15) >> 4, bv = (2 * ne + 15) >> 4;        // vectors in use at the front / at the back
                   const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
                   for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
@@ -634,11 +637,200 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                   dir[(size_t)(tile * nscreens + sc) * ntrks + h] = d; } } }
          rtfe_wave_sync(); }
       __syncthreads(); }
-   if (tid == 0 && last_tile >= 0) sf_publish_quiet(s_noisy[par ^ 1], last_tile, nrows, qbits);
+   if (tid == 0 && last_tile >= 0) sf_publish_quiet(s_noisy[par ^ 1], last_tile, nrows, qtile);
    if (prof && lane == 0) {
       atomicAdd(&dbg[0], (unsigned long long)pc_copy); atomicAdd(&dbg[1], (unsigned long long)pc_dense); atomicAdd(&dbg[2], (unsigned long long)pc_own);
       atomicAdd(&dbg[3], (unsigned long long)pn_bytes); atomicAdd(&dbg[4], (unsigned long long)pn_hard); atomicAdd(&dbg[5], (unsigned long long)pn_rounds);
       if (wave == 0) atomicAdd(&dbg[7], (unsigned long long)(last_tile >= 0 ? (last_tile - tile_lo) / G + 1 : 0)); } }
+
+// ------------------------------------------------------------------------------------------------
+// k_sift_s: k_sift for ONE window width W and a track count NT known at compile time (every LDS address an immediate offset, no
+// loop over screens, no division), straight-line predicated code in the per-candidate part.  Same tile order, same lists.
+// ------------------------------------------------------------------------------------------------
+struct SfArgs {
+   const int16_t *rows; long long nrows; int ntiles;
+   uint16_t *qtile; PeakDir *dir; unsigned char *pool; SfHard *hard; int hard_cap; int *hard_count; unsigned long long *dbg;
+   int hcap, wave_cap, invert, quiet_i, lo_i, hi_i, minpk_i, cut, debug; };
+
+template <int W, int NT, int WPS>
+__global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArgs a) {
+#ifdef RTFE_CPU_EMUL
+   unsigned char *smem = g_dyn_smem;
+#else
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
+   __shared__ unsigned int s_noisy[2];
+   constexpr int NP = (NT + 1) / 2, NTH = 64 * NP, RB = 2 * NT;
+   constexpr int HL = (kPkBack + 2 * W + 6 + 7) & ~7, HR = (W + 2 + 7) & ~7;
+   constexpr int NVEC = (HL + kSfTile + HR) * NT / 8, VPG = 8 * NT, VOWN0 = HL * NT / 8, NQ = kSfGroups * VPG;
+   constexpr int NV = (NVEC + NTH - 1) / NTH, NQIT = (NQ + NTH - 1) / NTH;
+   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef RTFE_CPU_EMUL
+   const int wave = tid >> 6;
+#else
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+   const int hcap = a.hcap, wave_cap = a.wave_cap, cut = a.cut;
+   const SfLds L = sf_lds_layout(NT, HL, HR, wave_cap, hcap);
+   unsigned char *xs = smem + L.xs;
+   const lds_p xsl = to_lds(xs);
+   PkCtx cx;
+   cx.t.xs = xsl; cx.t.row_bytes = RB; cx.t.hl = HL; cx.t.sg = a.invert ? -1 : 1;
+   cx.W = W; cx.lo_i = a.lo_i; cx.hi_i = a.hi_i;
+   const int G = (int)gridDim.x, ntiles = a.ntiles;
+   const int tile_lo = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+   // a tile is "inside" when every row of it and of its halo exists (its bytes then come as 16-byte vectors, one tile ahead)
+   const int inside_lo = (HL + kSfTile - 1) / kSfTile;
+   const long long ih = (a.nrows - HR - 15) / kSfTile - 1;
+   const int inside_hi = ih > 0x7ffffff0 ? 0x7ffffff0 : (int)ih;
+   // the quiet pass: which group(s) of 64 rows the 64 vectors of this wave's round `it` lie in (wave-uniform)
+   int qg[NQIT], qsplit[NQIT];
+   #pragma unroll
+   for (int it = 0; it < NQIT; ++it) { const int vfirst = it * NTH + wave * 64; qg[it] = vfirst / VPG; qsplit[it] = (qg[it] + 1) * VPG - vfirst; }
+   const int pair = wave, h_lo = 2 * pair, h_hi = 2 * pair + 1;
+   const bool has_hi = h_hi < NT;
+   const lds_u16p wlist = reinterpret_cast<lds_u16p>(to_lds(smem + L.wl)) + wave * wave_cap;
+   const lds_p slot_lo = to_lds(smem + L.stage) + h_lo * hcap, slot_hi = slot_lo + hcap;
+   const uint32_t at = a.minpk_i < 0 ? pk_dup(-32768) : pk_dup(a.minpk_i), ab = a.minpk_i < 0 ? pk_dup(32767) : pk_dup(-a.minpk_i);
+   const uint32_t qpk = pk_dup(a.quiet_i), q2 = 2u * (uint32_t)a.quiet_i;
+   int4 q[NV];
+   #pragma unroll
+   for (int k = 0; k < NV; ++k) q[k] = make_int4(0, 0, 0, 0);
+   auto fetch = [&](int tile) {
+      const int4 *src = reinterpret_cast<const int4 *>(a.rows + ((long long)tile * kSfTile - HL) * NT);
+      #pragma unroll
+      for (int k = 0; k < NV; ++k) if (k * NTH + tid < NVEC) q[k] = src[k * NTH + tid]; };
+   if (tile_lo < ntiles && tile_lo >= inside_lo && tile_lo <= inside_hi) fetch(tile_lo);
+   if (tid < 2) s_noisy[tid] = 0;
+   int par = 0, last_tile = -1;
+   unsigned int pn_hard = 0, pn_rounds = 0, pn_bytes = 0;
+   for (int tile = tile_lo; tile < ntiles; tile += G, par ^= 1) {
+      last_tile = tile;
+      const long long lastl = a.nrows - 1 - (long long)tile * kSfTile;
+      cx.last = lastl > 0x3fffffff ? 0x3fffffff : (int)lastl;
+      // ---- 1. the prefetched bytes -> LDS; the next tile's loads go out at once and travel while this tile is worked on ----
+      if (tile >= inside_lo && tile <= inside_hi) {
+         #pragma unroll
+         for (int k = 0; k < NV; ++k) if (k * NTH + tid < NVEC) reinterpret_cast<int4 *>(xs)[k * NTH + tid] = q[k]; }
+      else sf_fill_edge(xsl, a.rows, ((long long)tile * kSfTile - HL) * NT, a.nrows * NT, NVEC * 8, tid, NTH);
+      __syncthreads();
+      if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G);
+      if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
+      // ---- 2. quiet groups: flat 16-byte reads of the tile proper; a ballot of 64 vectors lies in one or two groups ----
+      #pragma unroll
+      for (int it = 0; it < NQIT; ++it) {
+         bool noisy = false;
+         if (it * NTH + tid < NQ) {
+            const int4 v = reinterpret_cast<const int4 *>(xs)[VOWN0 + it * NTH + tid];
+            const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)v.x, qpk), pk_addu((uint32_t)v.y, qpk)),
+                                       pk_maxu(pk_addu((uint32_t)v.z, qpk), pk_addu((uint32_t)v.w, qpk)));
+            noisy = (m & 0xffffu) > q2 || (m >> 16) > q2; }
+         const u64 nb = __ballot(noisy);
+         if (nb) {
+            const u64 lowm = qsplit[it] >= 64 ? ~0ull : ((1ull << qsplit[it]) - 1ull);
+            const unsigned int bits = ((nb & lowm) ? 1u << qg[it] : 0u) | ((nb & ~lowm) ? 2u << qg[it] : 0u);
+            if (lane == 0) atomicOr(&s_noisy[par], bits); } }
+      if (cut != 1) {
+         // ---- 3. candidate samples: local extremum + amplitude, one lane per 14-row strip of a pair of heads.  The rows of a pair are
+         // only 2-byte aligned in LDS (rows are 2 NT bytes apart), and a misaligned ds_read_b32 costs 33 cycles a wave: two aligned
+         // 16-bit reads per row instead ----
+         uint32_t tm = 0, bm = 0;
+         {
+            const lds_cp base = xsl + (HL + kSfStrip * lane) * RB + 4 * pair;
+            uint32_t x[kSfStrip + 2];
+            #pragma unroll
+            for (int i = 0; i < kSfStrip + 2; ++i) x[i] = (uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB) | ((uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB + 2) << 16);
+            uint32_t yc = pk_max(x[1], at), zc = pk_min(x[1], ab);
+            uint32_t uy = pk_subs(pk_max(x[0], at), yc), dz = pk_subs(zc, pk_min(x[0], ab));      // sign: rising into this row above the floor / falling into it below the ceiling
+            #pragma unroll
+            for (int i = 0; i < kSfStrip; ++i) {
+               const uint32_t yn = pk_max(x[i + 2], at), zn = pk_min(x[i + 2], ab);
+               const uint32_t uyn = pk_subs(yc, yn), dzn = pk_subs(zn, zc);
+               tm = (tm >> 1) | (uy & ~uyn & kPkSigns);
+               bm = (bm >> 1) | (dz & ~dzn & kPkSigns);
+               yc = yn; zc = zn; uy = uyn; dz = dzn; }
+            tm = (tm >> (16 - kSfStrip)) & 0x3fff3fffu; bm = (bm >> (16 - kSfStrip)) & 0x3fff3fffu;
+            if (a.invert) { const uint32_t s2 = tm; tm = bm; bm = s2; }
+            if (!has_hi) { tm &= 0xffffu; bm &= 0xffffu; }                  // odd track count: the last pair's upper half is the next row
+            if (cx.last < kSfTile - 1) {                                      // rows that do not exist cannot own a run
+               const int keep = cx.last + 1 - kSfStrip * lane;
+               const uint32_t mk = keep >= kSfStrip ? 0x3fffu : (keep <= 0 ? 0u : ((1u << keep) - 1u));
+               tm &= mk | (mk << 16); bm &= mk | (mk << 16); } }
+         // ---- 4. the wave's candidates, compacted into a list ordered by (head, row); rounds of 64 ----
+         int rec_lo = 0, rec_hi = 0, ent_lo = 0, ent_hi = 0;                   // records / margin entries in this wave's two lists
+         bool bad = false;
+         if (cut != 2) {
+            uint32_t mlo = (tm | bm) & 0xffffu, mhi = (tm | bm) >> 16;
+            const int cnt = __popc(mlo) | (__popc(mhi) << 16);
+            const int incl = wave_incl_scan(cnt, lane);
+            const int totc = wave_last(incl);
+            const int n_lo = totc & 0xffff, ncw = n_lo + (totc >> 16);
+            bad = ncw > wave_cap;
+            if (!bad && ncw > 0) {
+               const int excl = incl - cnt;
+               int o2 = excl & 0xffff;
+               for (; mlo; mlo &= mlo - 1) { const int b2 = __ffs((int)mlo) - 1; wlist[o2++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> b2) & 1u) << 14)); }
+               o2 = n_lo + (excl >> 16);
+               for (; mhi; mhi &= mhi - 1) { const int b2 = __ffs((int)mhi) - 1; wlist[o2++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> (16 + b2)) & 1u) << 14) | 0x8000u); }
+               rtfe_wave_sync();
+               #pragma nounroll
+               for (int r0 = 0; r0 < (cut == 3 ? 0 : ncw); r0 += 64) {
+                  const int i = r0 + lane;
+                  const bool live = i < ncw;
+                  const uint32_t cd = live ? wlist[i] : 0u;
+                  const int half = (int)(cd >> 15), cpos = (int)(cd & 0x3ffu);
+                  const bool cbot = (cd >> 14) & 1u;
+                  uint32_t w0 = 0, w1 = 0;
+                  uint32_t mm[W - 1];
+                  int st = pk_fast_w<W>(cx, half ? h_hi : h_lo, cpos, cbot, w0, w1, mm);
+                  if (!live) st = 0;
+                  if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
+                     const int hidx = atomicAdd(a.hard_count, 1);
+                     if (hidx < a.hard_cap) {
+                        SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)(half ? h_hi : h_lo); hd.screen = 0;
+                        a.hard[hidx] = hd;
+                        w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
+                     else { w0 = pk_w0(cpos, false, cpos + 1, 0, 1, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" - the chain that gets here gives up)
+                     st = 1; }
+                  if (a.debug == 3) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
+                  if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
+                  const int vr = st, ve = st ? pk_nent(w0, w1) : 0;
+                  const int sh = 16 * half;
+                  const int ir = wave_incl_scan(vr << sh, lane), ie = wave_incl_scan(ve << sh, lane);
+                  const int myr = (((ir >> sh) & 0xffff) - vr) + (half ? rec_hi : rec_lo), mye = (((ie >> sh) & 0xffff) - ve) + (half ? ent_hi : ent_lo);
+                  if (vr && 8 * (myr + 1) + 2 * (mye + ve) <= hcap) {
+                     const lds_p slot = half ? slot_hi : slot_lo;
+                     lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 2 * myr;
+                     rp[0] = w0; rp[1] = w1;
+                     if (cut != 5) pk_entries_w<W>(w0, w1, mm, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye)); }
+                  const int tr = wave_last(ir), te = wave_last(ie);
+                  rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; ent_lo += te & 0xffff; ent_hi += (te >> 16) & 0xffff; } } }
+         // ---- 5. this wave's two lists leave: records from the front of each head's slot, margin entries from its back, 16 bytes per
+         // lane; the directory ----
+         rtfe_wave_sync();
+         {
+            const int vps = hcap >> 4;                                         // 16-byte vectors per slot
+            #pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+               if (hh && !has_hi) break;
+               const int h = h_lo + hh;
+               const int nr = hh ? rec_hi : rec_lo, ne = hh ? ent_hi : ent_lo;
+               const bool over = bad || 8 * nr + 2 * ne > hcap || nr >= 0xff00 || ne >= 0xff00;
+               unsigned char *gslot = a.pool + ((size_t)tile * NT + h) * (size_t)hcap;
+               if (!over && nr > 0 && cut != 6) {
+                  const int fv = (8 * nr + 15) >> 4, bv = (2 * ne + 15) >> 4;        // vectors in use at the front / at the back
+                  const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
+                  for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
+                  if (a.debug == 3) pn_bytes += (unsigned)(8 * nr + 2 * ne); }
+               if (lane == 0) {
+                  PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = over ? (uint16_t)0 : (uint16_t)ne;
+                  a.dir[(size_t)tile * NT + h] = d; } } }
+         rtfe_wave_sync(); }
+      __syncthreads(); }
+   if (tid == 0 && last_tile >= 0) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);
+   if (a.debug == 3 && lane == 0) {
+      atomicAdd(&a.dbg[3], (unsigned long long)pn_bytes); atomicAdd(&a.dbg[4], (unsigned long long)pn_hard); atomicAdd(&a.dbg[5], (unsigned long long)pn_rounds);
+      if (wave == 0) atomicAdd(&a.dbg[7], (unsigned long long)(last_tile >= 0 ? (last_tile - tile_lo) / G + 1 : 0)); } }
 
 // ------------------------------------------------------------------------------------------------
 // k_sift_hard: the candidates k_sift deferred (bottoms whose first candidate rows precede every forced rescan: the reference's
