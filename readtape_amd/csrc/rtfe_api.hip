@@ -427,9 +427,17 @@ static size_t pk_ovf_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.
 // ... | the tiles' quiet bits (k_sift -> k_qpack)
 static size_t ws_pkqtile_off(const rtfe_handle *h, int64_t nrows) { return (ws_pkovf_off(h, nrows) + pk_ovf_bytes(h, nrows) + 255) & ~(size_t)255; }
 static size_t pk_qtile_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_tiles_for(nrows) * 2 + 255) & ~(size_t)255) : 0; }
+// ... | the streams' tile offsets and totals (k_pscan) | the streams (k_prep): 16-byte records, entry references
+static long long pk_ccap(const rtfe_handle *h, int64_t nrows) { return pk_tiles_for(nrows) * (h->dev.pk_slot / 8 + 1) + 64; }
+static size_t ws_pktstart_off(const rtfe_handle *h, int64_t nrows) { return ws_pkqtile_off(h, nrows) + pk_qtile_bytes(h, nrows); }
+static size_t pk_tstart_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? ((((size_t)pk_tiles_for(nrows) + 1) * h->dev.nscreens * h->dev.ntrks * 4 + 1024 + 255) & ~(size_t)255) : 0; }
+static size_t ws_pkcrec_off(const rtfe_handle *h, int64_t nrows) { return ws_pktstart_off(h, nrows) + pk_tstart_bytes(h, nrows); }
+static size_t pk_crec_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(CRec) + 255) & ~(size_t)255) : 0; }
+static size_t ws_pkeref_off(const rtfe_handle *h, int64_t nrows) { return ws_pkcrec_off(h, nrows) + pk_crec_bytes(h, nrows); }
+static size_t pk_eref_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * 4 + 255) & ~(size_t)255) : 0; }
 
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pkqtile_off(h, nrows) + pk_qtile_bytes(h, nrows) + 256; }
+   return ws_pkeref_off(h, nrows) + pk_eref_bytes(h, nrows) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -522,6 +530,15 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                             qtile, dirm, pkpool, hardp, hard_cap, &scratch->hard_count, scratch->scr); }
       hipLaunchKernelGGL(k_qpack, dim3(64), dim3(256), 0, st, (const uint16_t *)qtile, ptiles, qwords, nwords);
+      const int nlists = h->dev.nscreens * h->dev.ntrks;
+      uint32_t *tstartp = reinterpret_cast<uint32_t *>(wsb + ws_pktstart_off(h, nrows));
+      uint32_t *ctotp = tstartp + (size_t)ptiles * nlists;
+      CRec *crecp = reinterpret_cast<CRec *>(wsb + ws_pkcrec_off(h, nrows));
+      uint32_t *erefp = reinterpret_cast<uint32_t *>(wsb + ws_pkeref_off(h, nrows));
+      const long long ccap = pk_ccap(h, nrows);
+      hipLaunchKernelGGL(k_pscan, dim3(nlists), dim3(1024), 0, st, (const PeakDir *)dirm, (int)ptiles, nlists, tstartp, ctotp);
+      hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const SfHard *)hardp,
+                         (const uint32_t *)tstartp, ptiles, ccap, crecp, erefp);
       hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus), dim3(64), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
                          (const int *)&scratch->hard_count, ovfp);
       t1(6, st); t0(1, st);
@@ -535,11 +552,12 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);
       hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                         scratch, ctlp, d_counts, d_events, chainh, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp, ptiles);
+                         scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)ctotp, ccap,
+                         (const unsigned char *)pkpool, (const unsigned char *)ovfp, ptiles);
       t1(7, st); t0(8, st);
       if (stop_after < 4) { t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
-                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const unsigned char *)pkpool);
+                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint32_t *)erefp, ccap, (const unsigned char *)pkpool);
       hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(8, st); t0(5, st);
       if (stop_after < 5) { t1(5, st); return launch_check("rtfe_scan"); }

@@ -72,16 +72,74 @@ __device__ __forceinline__ long long chain_stop(const DevCfg &cfg, const rtfe_bu
    return stop; }
 
 // ------------------------------------------------------------------------------------------------
+// k_pscan / k_prep: k_sift's lists (one fixed slot per tile and head) -> ONE contiguous stream of 16-byte records per (screen, head),
+// in row order, with everything a chain's lane would otherwise recompute per record on its critical path: the owner's absolute
+// row, volt() of its value, where its margin entries are.  k_pscan: the streams' tile offsets (a prefix sum per stream over the
+// tile directory); k_prep: a wave per list copies its records over.
+// ------------------------------------------------------------------------------------------------
+// flags in CRec::w0 bits 0-10 (the tile-relative row of PeakRec::w0 is replaced by the absolute CRec::pos)
+enum { kCrBad = 1, kCrDeferred = 2 };     // the tile's list is not there (capacity) / a deferred candidate: w1 = its overflow slot
+struct CRec { uint32_t pos, w0, w1; float volt; };
+
+__global__ void __launch_bounds__(1024) k_pscan(const PeakDir *__restrict__ dir, int ntiles, int nlists, uint32_t *__restrict__ tstart, uint32_t *__restrict__ ctot) {
+   __shared__ int lds[32];
+   const int li = blockIdx.x;                                            // stream = (screen, head)
+   const int per = (ntiles + 1023) / 1024;
+   const int t0 = threadIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+   int sum = 0;
+   for (int t = t0; t < t1; ++t) { const int n = dir[(size_t)t * nlists + li].nrec; sum += n == 0xffff ? 1 : n; }
+   int total;
+   int off = block_excl_scan_1024(sum, lds, &total);
+   for (int t = t0; t < t1; ++t) { const int n = dir[(size_t)t * nlists + li].nrec; tstart[(size_t)t * nlists + li] = (uint32_t)off; off += n == 0xffff ? 1 : n; }
+   if (threadIdx.x == 0) ctot[li] = (uint32_t)total; }
+
+__global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
+                                              const SfHard *__restrict__ hard, const uint32_t *__restrict__ tstart, long long ntiles, long long ccap,
+                                              CRec *__restrict__ crec, uint32_t *__restrict__ eref) {
+   const DevCfg &cfg = *cfgp;
+   const int nlists = cfg.nscreens * cfg.ntrks, hcap = cfg.pk_slot;
+   const int lane = threadIdx.x & 63;
+   const long long nall = ntiles * nlists;
+   for (long long li = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); li < nall; li += (long long)gridDim.x * 4) {
+      const PeakDir d = dir[li];
+      if (d.nrec == 0) continue;
+      const long long tile = li / nlists;
+      const int sl = (int)(li - tile * nlists);
+      const long long base = (long long)sl * ccap + tstart[li];
+      if (d.nrec == 0xffffu) {                                          // a list that did not fit: one marker at the tile's first row
+         if (lane == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; eref[base] = 0; }
+         continue; }
+      const unsigned char *slot = pool + (size_t)li * hcap;
+      int ebase = 0;
+      for (int k0 = 0; k0 < (int)d.nrec; k0 += 64) {
+         const int k = k0 + lane;
+         uint32_t w0 = 0, w1 = 0;
+         if (k < (int)d.nrec) { const uint2 r = *reinterpret_cast<const uint2 *>(slot + 8 * k); w0 = r.x; w1 = r.y; }
+         const int ne = k < (int)d.nrec ? pk_nent(w0, w1) : 0;
+         const int incl = wave_incl_scan(ne, lane);
+         if (k < (int)d.nrec) {
+            CRec c;
+            if (w1 == 0xffff8001u) {                                      // deferred: the candidate's row, "first possible row" right behind it
+               const SfHard hd = hard[w0];
+               c.pos = (uint32_t)(tile * kSfTile + hd.pos); c.w0 = kCrDeferred | (1u << 11) | (1u << 12); c.w1 = w0; c.volt = 0; }
+            else {
+               c.pos = (uint32_t)(tile * kSfTile - kSfPosBias + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1;
+               c.volt = volt((int)(int16_t)(w1 & 0xffffu), cfg.maxvolts); }
+            crec[base + k] = c;
+            eref[base + k] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(ebase + incl - ne)); }
+         ebase += wave_last(incl); } } }
+
+// ------------------------------------------------------------------------------------------------
 // k_gain
 // ------------------------------------------------------------------------------------------------
 struct Run {
    long long pos, f;                 // column rows
-   int nlead, nsure, ntail, val, dprev, dnext, e0;
+   int nlead, nsure, ntail, val, dprev, dnext;
    bool top, unknown; };
 
-__device__ __forceinline__ Run run_decode(uint32_t w0, uint32_t w1, long long tile0, int e0) {
+__device__ __forceinline__ Run run_decode(uint32_t w0, uint32_t w1, long long pos) {
    Run u;
-   u.pos = tile0 - kSfPosBias + (long long)(w0 & 0x7ffu);
+   u.pos = pos;
    u.top = !((w0 >> 11) & 1u);
    u.f = u.pos + (long long)((w0 >> 12) & 63u);
    u.nlead = (int)((w0 >> 18) & 15u);
@@ -92,7 +150,6 @@ __device__ __forceinline__ Run run_decode(uint32_t w0, uint32_t w1, long long ti
    u.val = (int)(int16_t)(w1 & 0xffffu);
    u.dprev = (int)((w1 >> 16) & 0xffu) - 1;
    u.dnext = (int)((w1 >> 24) & 0xffu) - 1;
-   u.e0 = e0;
    return u; }
 
 // the rise test of src/decoder.c:790-791 / 800-801 for a row whose margin is m (int16 code difference to the nearer edge)
@@ -110,7 +167,7 @@ __device__ __forceinline__ bool amp_pass(const Walker &w, const Run &u, float mv
 
 constexpr long long kNoRow = 0x7fffffffffffffffll;
 // first row >= c (and < limit) at which this run makes the detector fire, or kNoRow; doubt = first row >= c that the record cannot decide.
-// eend: the end of the list's slot (entry e lives at eend[-(e + 1)])
+// eend: entry e of the record lives at eend[-(e + 1)]
 __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, const uint16_t *eend, long long c, long long limit, int W, int sure_i, float mv, long long &doubt) {
    doubt = kNoRow;
    const long long last_row = u.pos + W - 2;                         // the owner is strictly inside the window up to here
@@ -121,7 +178,7 @@ __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, con
       const long long n = u.f + i;
       if (n < c) continue;
       if (n >= limit) return kNoRow;
-      if (rise_pass(w, u.top, u.val, (int)eend[-(u.e0 + i + 1)], mv)) return n; }
+      if (rise_pass(w, u.top, u.val, (int)eend[-(i + 1)], mv)) return n; }
    const long long s0 = u.f + u.nlead;
    if (u.nsure) {
       const long long n = max(c, s0);
@@ -133,74 +190,65 @@ __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, con
       const long long n = s0 + u.nsure + i;
       if (n < c) continue;
       if (n >= limit) return kNoRow;
-      if (rise_pass(w, u.top, u.val, (int)eend[-(u.e0 + u.nlead + i + 1)], mv)) return n; }
+      if (rise_pass(w, u.top, u.val, (int)eend[-(u.nlead + i + 1)], mv)) return n; }
    return kNoRow; }
 
-// a lane's place in its record stream: record k of tile g's list (of one screen and head); e0 = margin entries in front of it.
-// A deferred candidate's placeholder (w1 == 0xffff8001) opens its overflow slot: sub = the record of the slot the lane stands on.
+// a lane's place in its stream for the general step: record i; inside a deferred candidate's overflow slot, sub = the record of the slot
 struct RecIt {
-   long long g;
-   int k, nrec, e0;
-   const unsigned char *slot;
-   uint32_t w0, w1;
+   long long i;
+   uint32_t w0, w1; long long pos;
+   const uint16_t *eend;
    bool end, bad;
    int sub, nsub, se0;
    const unsigned char *ovf; };
-struct RecSrc {                      // the stream: this chain's head and screen
-   const PeakDir *dir; const unsigned char *pool, *ovf;
-   int nscreens, ntrks, screen, head, hcap;
-   long long g_end; };               // tiles at or behind g_end hold no row of the chain
-__device__ __forceinline__ const uint16_t *it_eend(const RecIt &it, const RecSrc &S) {      // entry e of the record's list lives at eend[-(e + 1)]
-   return reinterpret_cast<const uint16_t *>(it.sub >= 0 ? it.ovf + kSfOvfBytes : it.slot + S.hcap); }
-__device__ __forceinline__ int it_e0(const RecIt &it) { return it.sub >= 0 ? it.se0 : it.e0; }
-__device__ __forceinline__ void it_open(RecIt &it, const RecSrc &S, long long g);
-// the lane has just moved onto record k of its list: read it; a placeholder opens its overflow slot
+struct RecSrc { const CRec *rec; const uint32_t *eref; const unsigned char *pool, *ovf; long long iend; };
 __device__ __forceinline__ void it_land(RecIt &it, const RecSrc &S) {
    for (;;) {
-      const uint2 r = *reinterpret_cast<const uint2 *>(it.slot + 8 * it.k);
-      it.w0 = r.x; it.w1 = r.y; it.sub = -1;
-      if (r.y != 0xffff8001u) return;
-      it.ovf = S.ovf + (size_t)r.x * kSfOvfBytes;
+      it.sub = -1;
+      if (it.i >= S.iend) { it.end = true; return; }
+      const CRec r = S.rec[it.i];
+      it.pos = r.pos; it.w0 = r.w0; it.w1 = r.w1;
+      if (r.w0 & kCrBad) { it.end = true; it.bad = true; return; }
+      if (!(r.w0 & kCrDeferred)) { it.eend = reinterpret_cast<const uint16_t *>(S.pool) + S.eref[it.i]; return; }
+      it.ovf = S.ovf + (size_t)r.w1 * kSfOvfBytes;
       const int n = *reinterpret_cast<const int *>(it.ovf);
       if (n < 0) { it.end = true; it.bad = true; return; }                        // (not representable: whoever needs it takes the sample path)
-      if (n > 0) { it.sub = 0; it.nsub = n; it.se0 = 0; const uint2 r2 = *reinterpret_cast<const uint2 *>(it.ovf + 8); it.w0 = r2.x; it.w1 = r2.y; return; }
-      if (++it.k >= it.nrec) { it_open(it, S, it.g + 1); return; } } }         // (a candidate that turned out to have no row above the screen)
-__device__ __forceinline__ void it_open(RecIt &it, const RecSrc &S, long long g) {
-   it.end = false; it.bad = false; it.k = 0; it.e0 = 0; it.nrec = 0; it.w0 = 0; it.w1 = 0; it.slot = nullptr; it.sub = -1; it.nsub = 0; it.se0 = 0; it.ovf = nullptr;
-   for (;; ++g) {
-      it.g = g;
-      if (g >= S.g_end) { it.end = true; return; }
-      const size_t li = (size_t)(g * S.nscreens + S.screen) * S.ntrks + S.head;
-      const PeakDir d = S.dir[li];
-      if (d.nrec == 0xffffu) { it.end = true; it.bad = true; return; }             // (capacity: the burst takes the sample path)
-      if (d.nrec == 0) continue;
-      it.nrec = d.nrec; it.slot = S.pool + li * (size_t)S.hcap;
-      it_land(it, S);
-      return; } }
+      if (n > 0) {
+         const uint2 r2 = *reinterpret_cast<const uint2 *>(it.ovf + 8);
+         it.sub = 0; it.nsub = n; it.se0 = 0; it.w0 = r2.x; it.w1 = r2.y;
+         it.pos = (long long)(r.pos / kSfTile) * kSfTile - kSfPosBias + (long long)(r2.x & 0x7ffu);      // (its records count from the candidate's tile)
+         it.eend = reinterpret_cast<const uint16_t *>(it.ovf + kSfOvfBytes); return; }
+      ++it.i; } }                                                                // (a candidate that turned out to have no row above the screen)
+__device__ __forceinline__ void it_open(RecIt &it, const RecSrc &S, long long i) {
+   it.end = false; it.bad = false; it.i = i; it.sub = -1; it.nsub = 0; it.se0 = 0; it.ovf = nullptr; it.eend = nullptr; it.w0 = 0; it.w1 = 0; it.pos = 0;
+   it_land(it, S); }
 __device__ __forceinline__ void it_next(RecIt &it, const RecSrc &S) {
    if (it.sub >= 0) {
       it.se0 += pk_nent(it.w0, it.w1);
-      if (++it.sub < it.nsub) { const uint2 r = *reinterpret_cast<const uint2 *>(it.ovf + 8 + 8 * it.sub); it.w0 = r.x; it.w1 = r.y; return; }
-      it.sub = -1; }                                                             // (the placeholder itself carries no entries)
-   else it.e0 += pk_nent(it.w0, it.w1);
-   if (++it.k < it.nrec) it_land(it, S);
-   else it_open(it, S, it.g + 1); }
+      if (++it.sub < it.nsub) {
+         const uint2 r = *reinterpret_cast<const uint2 *>(it.ovf + 8 + 8 * it.sub);
+         const long long tile0 = it.pos - (long long)(it.w0 & 0x7ffu);                // (pos = tile0 - bias + field)
+         it.w0 = r.x; it.w1 = r.y; it.pos = tile0 + (long long)(r.x & 0x7ffu);
+         it.eend = reinterpret_cast<const uint16_t *>(it.ovf + kSfOvfBytes) - it.se0; return; } }
+   ++it.i;
+   it_land(it, S); }
 
-// an event the fast path only noted (k_emit finishes it): where its record is, and the gain in force
-__device__ __forceinline__ rtfe_event note_event(const RecIt &it, float g) {
+// an event the fast path only noted (k_emit finishes it): its record's place in the stream, and the gain in force
+__device__ __forceinline__ rtfe_event note_event(long long i, float g) {
    union { rtfe_event e; uint32_t w[4]; } u;
-   u.w[0] = (uint32_t)it.g; u.w[1] = __float_as_uint(g); u.w[2] = (uint32_t)it.k | ((uint32_t)it.e0 << 16); u.w[3] = 0xffffffffu;
+   u.w[0] = (uint32_t)i; u.w[1] = __float_as_uint(g); u.w[2] = 0; u.w[3] = 0xffffffffu;
    return u.e; }
 
 __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
-                                             const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool, const unsigned char *__restrict__ ovf, long long ntiles) {
+                                             const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ ctot,
+                                             long long ccap, const unsigned char *__restrict__ pool, const unsigned char *__restrict__ ovf, long long ntiles) {
    __shared__ float s_heights[64 * 10];
    const DevCfg &cfg = *cfgp;
-   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
+   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks, nlists = cfg.nscreens * ntrks;
    const int lane = threadIdx.x;
-   const float mv = cfg.maxvolts;
+   const float mv = cfg.maxvolts, lsb = cfg.lsb_per_volt;
    const int nchains = scratch->nbursts * nwalk;
    float *heights = s_heights + lane * 10;
    for (int ci = blockIdx.x * 64 + lane; ci < nchains; ci += gridDim.x * 64) {
@@ -215,7 +263,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       const long long stop = chain_stop(cfg, bursts, ctl, b, scratch->nbursts_total, nrows);
       Walker w = {};
       w.agc_gain = 1.0f; w.v_avg_height = 4.0f;
-      update_thresholds(w, P, cfg.lsb_per_volt);
+      update_thresholds(w, P, lsb);
       for (int i = 0; i < 10; ++i) heights[i] = 0;
       // column rows: the detector's row n reads sample n - d.  Before c the window is filling on zone samples only.
       long long c = reset + W + max(trk, d) + 1 - d;
@@ -225,61 +273,79 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       bool failed = false;
       int why = 0;
       unsigned int n_fast = 0, n_slow = 0, guard = 0;
+      // this chain's piece of its head's stream: from the tile that holds row c - W to the tile behind the limit
+      const int sl = P.screen * ntrks + head;
       RecSrc src;
-      src.dir = dir; src.pool = pool; src.ovf = ovf; src.nscreens = cfg.nscreens; src.ntrks = ntrks; src.screen = P.screen; src.head = head; src.hcap = cfg.pk_slot;
-      {  long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;       // first tile whose candidates all lie at or behind the limit
-         src.g_end = ge < ntiles ? ge : ntiles; }
-      RecIt alive;
-      {  long long g0 = (c - W) / kSfTile; if (c - W < 0) g0 = 0;                // (a candidate up to W - 2 rows in front of c still has rows at or behind it)
-         it_open(alive, src, g0); }
+      src.rec = crec + (size_t)sl * ccap; src.eref = eref + (size_t)sl * ccap; src.pool = pool; src.ovf = ovf;
+      long long i;
+      {  long long g0 = (c - W) / kSfTile; if (c - W < 0) g0 = 0; if (g0 >= ntiles) g0 = ntiles - 1;
+         long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;       // first tile whose candidates all lie at or behind the limit
+         i = tstart[(size_t)g0 * nlists + sl];
+         src.iend = ge < ntiles ? tstart[(size_t)ge * nlists + sl] : ctot[sl]; }
+      const bool lean = cfg.pk_fast && !cfg.agc_off && cfg.mode != RTFE_PE && P.agc_window == 0;      // steady state = the three-flop alpha filter
+      const float alpha = P.agc_alpha, beta = 1 - P.agc_alpha;
+      // the records the lane stands on and the two behind it (the loads of a step are used two steps later)
+      CRec cur = {}, nxt = {}, nn = {};
+      bool reload = true;
       while (!failed) {
-         if (++guard > 4000000u) { failed = true; why = 7; break; }              // (cannot happen: every round moves the stream or c forward)
-         if (alive.end) { if (alive.bad) { failed = true; why = 1; } break; }
-         const long long tile0 = alive.g * kSfTile;
-         const Run ua = run_decode(alive.w0, alive.w1, tile0, it_e0(alive));
-         if (ua.pos + W - 2 < c) { it_next(alive, src); continue; }             // its rows are behind the countdown for good
-         const bool steady = cfg.agc_off || (cfg.mode == RTFE_PE ? w.datablock : (w.peakcount > 15 && w.v_avg_height_count == 0));
-         // ---- the fast path: steady state, a record with a sure stretch, the countdown over before its first row, the thresholds inside
-         // the band the sure level stands for, a clear amplitude, and nothing else that could fire before this record's owner has left
-         // the window.  Then it fires - at one of its lead rows or at its first sure row, k_emit will say which - and all that
-         // feeds back is the extreme's value. ----
-         if (cfg.pk_fast && steady && alive.sub < 0 && !ua.unknown && ua.nsure > 0 && c <= ua.f && ua.f + ua.nlead < limit && w.rise_hi <= S.sure_i && w.nevents < cap) {
-            const int a = ua.top ? ua.val : -ua.val;
-            if (w.reqmin == 0 || a >= w.min_hi) {
-               RecIt nx = alive;
-               it_next(nx, src);
-               bool clear = nx.end && !nx.bad;
-               if (!nx.end) { const long long fn = nx.g * kSfTile - kSfPosBias + (long long)(nx.w0 & 0x7ffu) + (long long)((nx.w0 >> 12) & 63u); clear = fn > ua.pos + W; }
+         if (++guard > 8000000u) { failed = true; why = 7; break; }              // (cannot happen: every round moves the stream or c forward)
+         if (i >= src.iend) break;
+         if (reload) {
+            cur = src.rec[i];
+            if (i + 1 < src.iend) nxt = src.rec[i + 1];
+            if (i + 2 < src.iend) nn = src.rec[i + 2];
+            reload = false; }
+         const long long pos = cur.pos;
+         if ((cur.w0 & kCrBad) ? pos + kSfTile + W < c : (pos + W - 2 < c && !(cur.w0 & kCrDeferred))) {      // its rows are behind the countdown for good
+            ++i; cur = nxt; nxt = nn; if (i + 2 < src.iend) nn = src.rec[i + 2];
+            continue; }
+         // ---- the fast path: steady state (peakcount > 15, the baseline fixed), a record with a sure stretch, the countdown over before its
+         // first row, the thresholds inside the band the sure level stands for, a clear amplitude, and nothing else that could fire before
+         // this record's owner has left the window.  Then it fires - at one of its lead rows or at its first sure row, k_emit will say
+         // which - and all that feeds back is the extreme's value: g = alpha h / lastheight + (1 - alpha) g (src/decoder.c:505-512). ----
+         if (lean && w.peakcount > 15 && w.v_avg_height_count == 0) {
+            const uint32_t w0 = cur.w0;
+            const long long f = pos + (long long)((w0 >> 12) & 63u);
+            const int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u);
+            const bool top = !((w0 >> 11) & 1u);
+            const int val = (int)(int16_t)(cur.w1 & 0xffffu);
+            const int a = top ? val : -val;
+            const long long fn = i + 1 < src.iend ? (long long)nxt.pos + (long long)((nxt.w0 >> 12) & 63u) : kNoRow;
+            if ((w0 & (kCrBad | kCrDeferred)) == 0 && cur.w1 != 0xffff8000u && (unsigned)(nsure - 1) < 62u && c <= f && f + nlead < limit && fn > pos + W
+                && w.rise_hi <= S.sure_i && (w.reqmin == 0 || a >= w.min_hi) && w.nevents < cap) {
                const float g = w.agc_gain;
-               const int ti = (int)(0.005f * fast_rcp(g) * cfg.lsb_per_volt);
-               if (clear && ti + 4 <= 254) {
-                  ev[w.nevents] = note_event(alive, g);
-                  const float val = volt(ua.val, mv);
-                  if (ua.top) w.v_top = val; else w.v_bot = val;
-                  ++w.nevents; ++n_fast;
-                  agc_after_peak(w, &cfg, P, heights, ua.top, 0.0);
+               if ((int)(0.005f * fast_rcp(g) * lsb) + 4 <= 254) {
+                  ev[w.nevents] = note_event(i, g);
+                  ++w.nevents; ++n_fast; ++w.peakcount;
+                  const float lastheight = w.v_lasttop - w.v_lastbot;        // (the callback sees the heights of the peaks BEFORE this one, src/decoder.c:587-590)
+                  if (lastheight > 0) { float g2 = alpha * (w.v_avg_height / lastheight) + beta * g; if (g2 > 2.0f) g2 = 2.0f; w.agc_gain = g2; }
+                  if (top) { w.v_top = cur.volt; w.v_lasttop = cur.volt; } else { w.v_bot = cur.volt; w.v_lastbot = cur.volt; }
                   if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; break; }      // src/decoder.c:782
-                  if (!approx_thresholds(w, P, cfg.lsb_per_volt)) {
-                     update_thresholds(w, P, cfg.lsb_per_volt);
+                  if (!approx_thresholds(w, P, lsb)) {
+                     update_thresholds(w, P, lsb);
                      if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; break; } }
-                  c = ua.pos + W + 1;
-                  alive = nx;
+                  c = pos + W + 1;
+                  ++i; cur = nxt; nxt = nn; if (i + 2 < src.iend) nn = src.rec[i + 2];
                   continue; } } }
          // ---- the general step: earliest firing run among the tops and the bottoms from the first live record on ----
          if (w.thr_dirty) {
-            update_thresholds(w, P, cfg.lsb_per_volt);
+            update_thresholds(w, P, lsb);
             if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; break; } }
+         RecIt alive;
+         it_open(alive, src, i);
+         while (!alive.end && alive.pos + W - 2 < c) it_next(alive, src);      // records (of an overflow slot, too) whose rows are behind the countdown
+         if (alive.end) { if (alive.bad) { failed = true; why = 1; } break; }
          long long best = kNoRow, best_doubt = kNoRow;
          bool have = false, best_top = false, top_done = false, bot_done = false;
          long long bad_row0 = kNoRow;                                       // first row of a tile whose list is not there
-         Run bu = ua;
+         Run bu = {};
          for (RecIt j = alive; !(top_done && bot_done); it_next(j, src)) {
-            if (j.end) { if (j.bad) bad_row0 = j.g * kSfTile; break; }
-            const Run u = run_decode(j.w0, j.w1, j.g * kSfTile, it_e0(j));
+            if (j.end) { if (j.bad) bad_row0 = j.pos; break; }
+            const Run u = run_decode(j.w0, j.w1, j.pos);
             if (u.top ? top_done : bot_done) continue;
             if (u.f > best || u.f >= limit) { if (u.top) top_done = true; else bot_done = true; continue; }
             long long dr;
-            const long long n = run_fire(w, u, it_eend(j, src), c, limit, W, S.sure_i, mv, dr);
+            const long long n = run_fire(w, u, j.eend, c, limit, W, S.sure_i, mv, dr);
             if (dr < best_doubt) best_doubt = dr;
             if (n != kNoRow) {
                if (u.top) top_done = true; else bot_done = true;         // (runs of one kind are ordered by row)
@@ -293,7 +359,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          const int ld = (int)(u.pos - best) + W;                           // left_distance
          const float g = w.agc_gain;
          const float thr = 0.005f / g;
-         const int ti = (int)floorf(thr * cfg.lsb_per_volt);
+         const int ti = (int)floorf(thr * lsb);
          if (ti + 2 > 254) { failed = true; why = 3; break; }                       // (neighbour distances are stored up to 254)
          const int val_i = u.val;
          const int iprev = u.top ? val_i - u.dprev : val_i + u.dprev, inext = u.top ? val_i - u.dnext : val_i + u.dnext;
@@ -318,9 +384,10 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          ++w.nevents; ++n_slow;
          agc_after_peak(w, &cfg, P, heights, u.top, t_peak);
          if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; break; }      // src/decoder.c:782
-         update_thresholds(w, P, cfg.lsb_per_volt);
+         update_thresholds(w, P, lsb);
          if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; break; }
-         c = u.pos + W + 1; }
+         c = u.pos + W + 1;
+         i = alive.i; reload = true; }
       // ---- publish ----
       if (n_fast) atomicAdd(&scratch->dbg[0], (unsigned long long)n_fast);
       if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
@@ -335,7 +402,8 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch,
                                               const BurstCtl *__restrict__ ctl, const uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
-                                              const float *__restrict__ chain_h, const unsigned char *__restrict__ pool) {
+                                              const float *__restrict__ chain_h, const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap,
+                                              const unsigned char *__restrict__ pool) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
    const int nchains = scratch->nbursts * nwalk;
@@ -350,27 +418,25 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
       const long long reset = ctl[b].reset;
       const unsigned int nev = counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk];
       rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
+      const size_t sbase = (size_t)(P.screen * ntrks + head) * ccap;
       Walker wk = {};
       wk.v_avg_height = chain_h[(size_t)b * nwalk + wi];
       for (unsigned int i = threadIdx.x; i < nev; i += blockDim.x) {
          union { rtfe_event e; uint32_t w[4]; } in;
          in.e = ev[i];
          if (in.w[3] != 0xffffffffu) continue;                            // the general step wrote it out in full
-         const long long g = (long long)in.w[0];
          const float gain = __uint_as_float(in.w[1]);
-         const int k = (int)(in.w[2] & 0xffffu), e0 = (int)(in.w[2] >> 16);
-         const unsigned char *slot = pool + ((size_t)(g * cfg.nscreens + P.screen) * ntrks + head) * (size_t)cfg.pk_slot;
-         const uint2 r = *reinterpret_cast<const uint2 *>(slot + 8 * k);
-         const uint16_t *eend = reinterpret_cast<const uint16_t *>(slot + cfg.pk_slot);
-         const Run u = run_decode(r.x, r.y, g * kSfTile, e0);
+         const CRec r = crec[sbase + in.w[0]];
+         const uint16_t *eend = reinterpret_cast<const uint16_t *>(pool) + eref[sbase + in.w[0]];
+         const Run u = run_decode(r.w0, r.w1, (long long)r.pos);
          wk.agc_gain = gain; wk.flags = 0;
          update_thresholds(wk, P, cfg.lsb_per_volt);                      // the exact thresholds of src/decoder.c:785-786 at that gain
          long long n = u.f + u.nlead;                                     // the first sure row, unless a lead row passes
-         for (int j = u.nlead - 1; j >= 0; --j) if (rise_pass(wk, u.top, u.val, (int)eend[-(u.e0 + j + 1)], mv)) n = u.f + j;
+         for (int j = u.nlead - 1; j >= 0; --j) if (rise_pass(wk, u.top, u.val, (int)eend[-(j + 1)], mv)) n = u.f + j;
          const int ld = (int)(u.pos - n) + W;
          const int iprev = u.top ? u.val - u.dprev : u.val + u.dprev, inext = u.top ? u.val - u.dnext : u.val + u.dnext;
          const int adjcode = refine_code(&cfg, u.val, iprev, inext, gain, u.top);
-         const float val = volt(u.val, mv);
+         const float val = r.volt;
          rtfe_event e;
          e.sample = (uint32_t)(n + d - reset);
          e.v_peak = (cfg.invert && val == 0.0f) ? -0.0f : val;
