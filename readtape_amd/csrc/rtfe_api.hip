@@ -68,7 +68,6 @@ static sfs_kernel_t sfs_kernel(int w, int ntrks) {
       case 11: return k_sift_s<11, 9, kSfWps>;
       case 13: return k_sift_s<13, 9, kSfWps>;
       case 17: return k_sift_s<17, 9, kSfWps>;
-      case 20: return k_sift_s<20, 9, kSfWps>;
       default: break; }
    if (ntrks == 7) switch (w) {
       case 11: return k_sift_s<11, 7, kSfWps>;
@@ -430,7 +429,9 @@ static size_t pk_qtile_bytes(const rtfe_handle *h, int64_t nrows) { return h->de
 // ... | the streams' tile offsets and totals (k_pscan) | the streams (k_prep): 16-byte records, entry references
 static long long pk_ccap(const rtfe_handle *h, int64_t nrows) { return pk_tiles_for(nrows) * (h->dev.pk_slot / 8 + 1) + 64; }
 static size_t ws_pktstart_off(const rtfe_handle *h, int64_t nrows) { return ws_pkqtile_off(h, nrows) + pk_qtile_bytes(h, nrows); }
-static size_t pk_tstart_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? ((((size_t)pk_tiles_for(nrows) + 1) * h->dev.nscreens * h->dev.ntrks * 4 + 1024 + 255) & ~(size_t)255) : 0; }
+static size_t pk_tstart_bytes(const rtfe_handle *h, int64_t nrows) {      // tile offsets | chunk totals | chunk offsets | stream totals
+   const size_t nl = (size_t)h->dev.nscreens * h->dev.ntrks, nch = (size_t)(pk_tiles_for(nrows) + 1023) / 1024;
+   return h->dev.peak_path ? ((((size_t)pk_tiles_for(nrows) + 2 * nch + 2) * nl * 4 + 255) & ~(size_t)255) : 0; }
 static size_t ws_pkcrec_off(const rtfe_handle *h, int64_t nrows) { return ws_pktstart_off(h, nrows) + pk_tstart_bytes(h, nrows); }
 static size_t pk_crec_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(CRec) + 255) & ~(size_t)255) : 0; }
 static size_t ws_pkeref_off(const rtfe_handle *h, int64_t nrows) { return ws_pkcrec_off(h, nrows) + pk_crec_bytes(h, nrows); }
@@ -532,13 +533,15 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_qpack, dim3(64), dim3(256), 0, st, (const uint16_t *)qtile, ptiles, qwords, nwords);
       const int nlists = h->dev.nscreens * h->dev.ntrks;
       uint32_t *tstartp = reinterpret_cast<uint32_t *>(wsb + ws_pktstart_off(h, nrows));
-      uint32_t *ctotp = tstartp + (size_t)ptiles * nlists;
+      const int nsc = (int)((ptiles + 1023) / 1024);                    // chunks of 1024 tiles (k_pscan)
+      uint32_t *ctotcp = tstartp + (size_t)ptiles * nlists, *coffp = ctotcp + (size_t)nsc * nlists, *ctotp = coffp + (size_t)nsc * nlists;
       CRec *crecp = reinterpret_cast<CRec *>(wsb + ws_pkcrec_off(h, nrows));
       uint32_t *erefp = reinterpret_cast<uint32_t *>(wsb + ws_pkeref_off(h, nrows));
       const long long ccap = pk_ccap(h, nrows);
-      hipLaunchKernelGGL(k_pscan, dim3(nlists), dim3(1024), 0, st, (const PeakDir *)dirm, (int)ptiles, nlists, tstartp, ctotp);
+      hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (int)ptiles, nlists, tstartp, ctotcp);
+      hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
       hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const SfHard *)hardp,
-                         (const uint32_t *)tstartp, ptiles, ccap, crecp, erefp);
+                         (const uint32_t *)tstartp, (const uint32_t *)coffp, ptiles, ccap, crecp, erefp);
       hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus), dim3(64), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
                          (const int *)&scratch->hard_count, ovfp);
       t1(6, st); t0(1, st);
@@ -552,7 +555,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);
       hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                         scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)ctotp, ccap,
+                         scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
                          (const unsigned char *)pkpool, (const unsigned char *)ovfp, ptiles);
       t1(7, st); t0(8, st);
       if (stop_after < 4) { t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }

@@ -81,20 +81,35 @@ __device__ __forceinline__ long long chain_stop(const DevCfg &cfg, const rtfe_bu
 enum { kCrBad = 1, kCrDeferred = 2 };     // the tile's list is not there (capacity) / a deferred candidate: w1 = its overflow slot
 struct CRec { uint32_t pos, w0, w1; float volt; };
 
-__global__ void __launch_bounds__(1024) k_pscan(const PeakDir *__restrict__ dir, int ntiles, int nlists, uint32_t *__restrict__ tstart, uint32_t *__restrict__ ctot) {
+// k_pscan1: a workgroup per chunk of 1024 tiles, a thread per tile: per stream the prefix within the chunk and the chunk's total;
+// k_pscan2: the chunks' offsets (one workgroup).  A stream's position of tile t = tstart[t][stream] + coff[t >> 10][stream].
+__global__ void __launch_bounds__(1024) k_pscan1(const PeakDir *__restrict__ dir, int ntiles, int nlists, uint32_t *__restrict__ tstart, uint32_t *__restrict__ ctotc) {
    __shared__ int lds[32];
-   const int li = blockIdx.x;                                            // stream = (screen, head)
-   const int per = (ntiles + 1023) / 1024;
-   const int t0 = threadIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
-   int sum = 0;
-   for (int t = t0; t < t1; ++t) { const int n = dir[(size_t)t * nlists + li].nrec; sum += n == 0xffff ? 1 : n; }
-   int total;
-   int off = block_excl_scan_1024(sum, lds, &total);
-   for (int t = t0; t < t1; ++t) { const int n = dir[(size_t)t * nlists + li].nrec; tstart[(size_t)t * nlists + li] = (uint32_t)off; off += n == 0xffff ? 1 : n; }
-   if (threadIdx.x == 0) ctot[li] = (uint32_t)total; }
+   const int t = blockIdx.x * 1024 + threadIdx.x;
+   for (int li = 0; li < nlists; ++li) {
+      int n = 0;
+      if (t < ntiles) { n = dir[(size_t)t * nlists + li].nrec; if (n == 0xffff) n = 1; }
+      int total;
+      const int off = block_excl_scan_1024(n, lds, &total);
+      if (t < ntiles) tstart[(size_t)t * nlists + li] = (uint32_t)off;
+      if (threadIdx.x == 0) ctotc[(size_t)blockIdx.x * nlists + li] = (uint32_t)total; } }
+__global__ void __launch_bounds__(1024) k_pscan2(int nchunks, int nlists, const uint32_t *__restrict__ ctotc, uint32_t *__restrict__ coff, uint32_t *__restrict__ ctot) {
+   __shared__ int lds[32];
+   for (int li = 0; li < nlists; ++li) {
+      int run = 0;
+      for (int c0 = 0; c0 < nchunks; c0 += 1024) {
+         const int c = c0 + threadIdx.x;
+         const int n = c < nchunks ? (int)ctotc[(size_t)c * nlists + li] : 0;
+         int total;
+         const int off = block_excl_scan_1024(n, lds, &total);
+         if (c < nchunks) coff[(size_t)c * nlists + li] = (uint32_t)(run + off);
+         run += total; }
+      if (threadIdx.x == 0) ctot[li] = (uint32_t)run; } }
+__device__ __forceinline__ long long stream_pos(const uint32_t *tstart, const uint32_t *coff, int nlists, long long tile, int li) {
+   return (long long)tstart[(size_t)tile * nlists + li] + (long long)coff[(size_t)(tile >> 10) * nlists + li]; }
 
 __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
-                                              const SfHard *__restrict__ hard, const uint32_t *__restrict__ tstart, long long ntiles, long long ccap,
+                                              const SfHard *__restrict__ hard, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, long long ntiles, long long ccap,
                                               CRec *__restrict__ crec, uint32_t *__restrict__ eref) {
    const DevCfg &cfg = *cfgp;
    const int nlists = cfg.nscreens * cfg.ntrks, hcap = cfg.pk_slot;
@@ -105,7 +120,7 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
       if (d.nrec == 0) continue;
       const long long tile = li / nlists;
       const int sl = (int)(li - tile * nlists);
-      const long long base = (long long)sl * ccap + tstart[li];
+      const long long base = (long long)sl * ccap + stream_pos(tstart, coff, nlists, tile, sl);
       if (d.nrec == 0xffffu) {                                          // a list that did not fit: one marker at the tile's first row
          if (lane == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; eref[base] = 0; }
          continue; }
@@ -242,7 +257,7 @@ __device__ __forceinline__ rtfe_event note_event(long long i, float g) {
 __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
-                                             const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ ctot,
+                                             const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
                                              long long ccap, const unsigned char *__restrict__ pool, const unsigned char *__restrict__ ovf, long long ntiles) {
    __shared__ float s_heights[64 * 10];
    const DevCfg &cfg = *cfgp;
@@ -280,25 +295,26 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       long long i;
       {  long long g0 = (c - W) / kSfTile; if (c - W < 0) g0 = 0; if (g0 >= ntiles) g0 = ntiles - 1;
          long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;       // first tile whose candidates all lie at or behind the limit
-         i = tstart[(size_t)g0 * nlists + sl];
-         src.iend = ge < ntiles ? tstart[(size_t)ge * nlists + sl] : ctot[sl]; }
+         i = stream_pos(tstart, coff, nlists, g0, sl);
+         src.iend = ge < ntiles ? stream_pos(tstart, coff, nlists, ge, sl) : (long long)ctot[sl]; }
       const bool lean = cfg.pk_fast && !cfg.agc_off && cfg.mode != RTFE_PE && P.agc_window == 0;      // steady state = the three-flop alpha filter
       const float alpha = P.agc_alpha, beta = 1 - P.agc_alpha;
-      // the records the lane stands on and the two behind it (the loads of a step are used two steps later)
-      CRec cur = {}, nxt = {}, nn = {};
-      bool reload = true;
-      while (!failed) {
-         if (++guard > 8000000u) { failed = true; why = 7; break; }              // (cannot happen: every round moves the stream or c forward)
-         if (i >= src.iend) break;
-         if (reload) {
-            cur = src.rec[i];
-            if (i + 1 < src.iend) nxt = src.rec[i + 1];
-            if (i + 2 < src.iend) nn = src.rec[i + 2];
-            reload = false; }
+      // The lane keeps the record it stands on and the three behind it in four register sets that take turns (r0 r1 r2 r3 -> r1 r2 r3 r0:
+      // no copies, so a step waits for a load issued three steps earlier, not for the one it has just issued).
+      // step(): 0 = one record on, in lock step; 1 = the general step moved the lane somewhere else (reload all four); 2 = the chain is done.
+      CRec r0 = {}, r1 = {}, r2 = {}, r3 = {};
+      auto load4 = [&]() {
+         if (i < src.iend) r0 = src.rec[i];
+         if (i + 1 < src.iend) r1 = src.rec[i + 1];
+         if (i + 2 < src.iend) r2 = src.rec[i + 2];
+         if (i + 3 < src.iend) r3 = src.rec[i + 3]; };
+      auto step = [&](CRec &cur, const CRec &nxt) -> int {
+         if (++guard > 8000000u) { failed = true; why = 7; return 2; }           // (cannot happen: every round moves the stream or c forward)
+         if (i >= src.iend) return 2;
          const long long pos = cur.pos;
          if ((cur.w0 & kCrBad) ? pos + kSfTile + W < c : (pos + W - 2 < c && !(cur.w0 & kCrDeferred))) {      // its rows are behind the countdown for good
-            ++i; cur = nxt; nxt = nn; if (i + 2 < src.iend) nn = src.rec[i + 2];
-            continue; }
+            ++i; if (i + 3 < src.iend) cur = src.rec[i + 3];
+            return 0; }
          // ---- the fast path: steady state (peakcount > 15, the baseline fixed), a record with a sure stretch, the countdown over before its
          // first row, the thresholds inside the band the sure level stands for, a clear amplitude, and nothing else that could fire before
          // this record's owner has left the window.  Then it fires - at one of its lead rows or at its first sure row, k_emit will say
@@ -320,21 +336,21 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
                   const float lastheight = w.v_lasttop - w.v_lastbot;        // (the callback sees the heights of the peaks BEFORE this one, src/decoder.c:587-590)
                   if (lastheight > 0) { float g2 = alpha * (w.v_avg_height / lastheight) + beta * g; if (g2 > 2.0f) g2 = 2.0f; w.agc_gain = g2; }
                   if (top) { w.v_top = cur.volt; w.v_lasttop = cur.volt; } else { w.v_bot = cur.volt; w.v_lastbot = cur.volt; }
-                  if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; break; }      // src/decoder.c:782
+                  if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
                   if (!approx_thresholds(w, P, lsb)) {
                      update_thresholds(w, P, lsb);
-                     if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; break; } }
+                     if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; } }
                   c = pos + W + 1;
-                  ++i; cur = nxt; nxt = nn; if (i + 2 < src.iend) nn = src.rec[i + 2];
-                  continue; } } }
+                  ++i; if (i + 3 < src.iend) cur = src.rec[i + 3];
+                  return 0; } } }
          // ---- the general step: earliest firing run among the tops and the bottoms from the first live record on ----
          if (w.thr_dirty) {
             update_thresholds(w, P, lsb);
-            if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; break; } }
+            if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; } }
          RecIt alive;
          it_open(alive, src, i);
          while (!alive.end && alive.pos + W - 2 < c) it_next(alive, src);      // records (of an overflow slot, too) whose rows are behind the countdown
-         if (alive.end) { if (alive.bad) { failed = true; why = 1; } break; }
+         if (alive.end) { if (alive.bad) { failed = true; why = 1; } return 2; }
          long long best = kNoRow, best_doubt = kNoRow;
          bool have = false, best_top = false, top_done = false, bot_done = false;
          long long bad_row0 = kNoRow;                                       // first row of a tile whose list is not there
@@ -350,9 +366,9 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
             if (n != kNoRow) {
                if (u.top) top_done = true; else bot_done = true;         // (runs of one kind are ordered by row)
                if (n < best || (n == best && u.top && !best_top)) { best = n; bu = u; best_top = u.top; have = true; } } }
-         if (bad_row0 != kNoRow && !(have && best < bad_row0)) { failed = true; why = 1; break; }      // (a list that is not there, and something in it might fire first)
-         if (best_doubt != kNoRow && best_doubt <= best) { failed = true; why = 2; break; }
-         if (!have) break;                                                  // nothing fires any more: the chain is done
+         if (bad_row0 != kNoRow && !(have && best < bad_row0)) { failed = true; why = 1; return 2; }      // (a list that is not there, and something in it might fire first)
+         if (best_doubt != kNoRow && best_doubt <= best) { failed = true; why = 2; return 2; }
+         if (!have) return 2;                                               // nothing fires any more: the chain is done
          // ---- detection: refine_peak + the callback's effect on AGC state (src/decoder.c:700-749, 574-609) ----
          const Run &u = bu;
          const long long ndet = best + d;                                 // the detector's row
@@ -360,7 +376,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          const float g = w.agc_gain;
          const float thr = 0.005f / g;
          const int ti = (int)floorf(thr * lsb);
-         if (ti + 2 > 254) { failed = true; why = 3; break; }                       // (neighbour distances are stored up to 254)
+         if (ti + 2 > 254) { failed = true; why = 3; return 2; }                    // (neighbour distances are stored up to 254)
          const int val_i = u.val;
          const int iprev = u.top ? val_i - u.dprev : val_i + u.dprev, inext = u.top ? val_i - u.dnext : val_i + u.dnext;
          const int adjcode = refine_code(&cfg, val_i, iprev, inext, g, u.top);
@@ -383,11 +399,20 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          if (u.top) w.v_top = val; else w.v_bot = val;
          ++w.nevents; ++n_slow;
          agc_after_peak(w, &cfg, P, heights, u.top, t_peak);
-         if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; break; }      // src/decoder.c:782
+         if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
          update_thresholds(w, P, lsb);
-         if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; break; }
+         if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; }
          c = u.pos + W + 1;
-         i = alive.i; reload = true; }
+         i = alive.i;
+         return 1; };
+      load4();
+      for (;;) {
+         int st2 = step(r0, r1);
+         if (st2 == 0) st2 = step(r1, r2);
+         if (st2 == 0) st2 = step(r2, r3);
+         if (st2 == 0) st2 = step(r3, r0);
+         if (st2 == 2) break;
+         if (st2 == 1) load4(); }
       // ---- publish ----
       if (n_fast) atomicAdd(&scratch->dbg[0], (unsigned long long)n_fast);
       if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);

@@ -303,6 +303,7 @@ __device__ __forceinline__ int pk_fast(const PkCtx &c, int head, int p, bool bot
 // in 16 bits).  mm[k] = the margin of row k in both halves (what the record's explicit entries hold).
 template <int W>
 __device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool bot, uint32_t &w0, uint32_t &w1, uint32_t (&mm)[W - 1]) {
+   static_assert(W >= 4 && W <= 17, "the row masks live in the 16-bit halves of a register");
    const int rb_ = c.t.row_bytes;
    const uint32_t m2 = (bot != (c.t.sg < 0)) ? 0xffffffffu : 0u;
    lds_cp pr = c.t.xs + head * 2 + (p + c.t.hl) * rb_, pl = pr - (W - 1) * rb_;
