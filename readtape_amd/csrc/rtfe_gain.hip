@@ -181,6 +181,7 @@ __device__ __forceinline__ bool amp_pass(const Walker &w, const Run &u, float mv
    return u.top ? volt(u.val, mv) > w.reqmin : volt(u.val, mv) < -w.reqmin; }
 
 constexpr long long kNoRow = 0x7fffffffffffffffll;
+constexpr int kGainRound = 64;      // steps of a wave between two general steps (multiple of 4)
 // first row >= c (and < limit) at which this run makes the detector fire, or kNoRow; doubt = first row >= c that the record cannot decide.
 // eend: entry e of the record lives at eend[-(e + 1)]
 __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, const uint16_t *eend, long long c, long long limit, int W, int sure_i, float mv, long long &doubt) {
@@ -249,9 +250,9 @@ __device__ __forceinline__ void it_next(RecIt &it, const RecSrc &S) {
    it_land(it, S); }
 
 // an event the fast path only noted (k_emit finishes it): its record's place in the stream, and the gain in force
-__device__ __forceinline__ rtfe_event note_event(long long i, float g) {
+__device__ __forceinline__ rtfe_event note_event(long long i, float g, float h) {
    union { rtfe_event e; uint32_t w[4]; } u;
-   u.w[0] = (uint32_t)i; u.w[1] = __float_as_uint(g); u.w[2] = 0; u.w[3] = 0xffffffffu;
+   u.w[0] = (uint32_t)i; u.w[1] = __float_as_uint(g); u.w[2] = __float_as_uint(h); u.w[3] = 0xffffffffu;
    return u.e; }
 
 __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, long long nrows, long long row_base,
@@ -266,10 +267,12 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
    const float mv = cfg.maxvolts, lsb = cfg.lsb_per_volt;
    const int nchains = scratch->nbursts * nwalk;
    float *heights = s_heights + lane * 10;
-   for (int ci = blockIdx.x * 64 + lane; ci < nchains; ci += gridDim.x * 64) {
+   // (every lane of a wave goes through the same rounds - the wave votes on them - so a lane without a chain walks a finished one)
+   for (int cbase = blockIdx.x * 64; cbase < nchains; cbase += gridDim.x * 64) {
+      const int ci = cbase + lane < nchains ? cbase + lane : nchains - 1;
       const int b = ci / nwalk;
       const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
-      if (ctl[b].status != kBurstReady) continue;
+      const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady;
       const rtfe_burst B = bursts[b];
       const DevParm &P = cfg.parm[pidx];
       const DevScreen &S = cfg.screen[P.screen];
@@ -297,7 +300,8 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;       // first tile whose candidates all lie at or behind the limit
          i = stream_pos(tstart, coff, nlists, g0, sl);
          src.iend = ge < ntiles ? stream_pos(tstart, coff, nlists, ge, sl) : (long long)ctot[sl]; }
-      const bool lean = cfg.pk_fast && !cfg.agc_off && cfg.mode != RTFE_PE && P.agc_window == 0;      // steady state = the three-flop alpha filter
+      const bool lean = cfg.pk_fast && cfg.mode != RTFE_PE;                // (PE decides the end of its preamble from peak TIMES: the general step)
+      const bool alpha_agc = !cfg.agc_off && P.agc_window == 0;           // steady state = the three-flop alpha filter
       const float alpha = P.agc_alpha, beta = 1 - P.agc_alpha;
       // The lane keeps the record it stands on and the three behind it in four register sets that take turns (r0 r1 r2 r3 -> r1 r2 r3 r0:
       // no copies, so a step waits for a load issued three steps earlier, not for the one it has just issued).
@@ -319,7 +323,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          // first row, the thresholds inside the band the sure level stands for, a clear amplitude, and nothing else that could fire before
          // this record's owner has left the window.  Then it fires - at one of its lead rows or at its first sure row, k_emit will say
          // which - and all that feeds back is the extreme's value: g = alpha h / lastheight + (1 - alpha) g (src/decoder.c:505-512). ----
-         if (lean && w.peakcount > 15 && w.v_avg_height_count == 0) {
+         if (lean) {
             const uint32_t w0 = cur.w0;
             const long long f = pos + (long long)((w0 >> 12) & 63u);
             const int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u);
@@ -331,11 +335,16 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
                 && w.rise_hi <= S.sure_i && (w.reqmin == 0 || a >= w.min_hi) && w.nevents < cap) {
                const float g = w.agc_gain;
                if ((int)(0.005f * fast_rcp(g) * lsb) + 4 <= 254) {
-                  ev[w.nevents] = note_event(i, g);
-                  ++w.nevents; ++n_fast; ++w.peakcount;
-                  const float lastheight = w.v_lasttop - w.v_lastbot;        // (the callback sees the heights of the peaks BEFORE this one, src/decoder.c:587-590)
-                  if (lastheight > 0) { float g2 = alpha * (w.v_avg_height / lastheight) + beta * g; if (g2 > 2.0f) g2 = 2.0f; w.agc_gain = g2; }
-                  if (top) { w.v_top = cur.volt; w.v_lasttop = cur.volt; } else { w.v_bot = cur.volt; w.v_lastbot = cur.volt; }
+                  ev[w.nevents] = note_event(i, g, w.v_avg_height);
+                  ++w.nevents; ++n_fast;
+                  if (alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) {      // steady state: the alpha filter alone (src/decoder.c:505-512)
+                     ++w.peakcount;
+                     const float lastheight = w.v_lasttop - w.v_lastbot;     // (the callback sees the heights of the peaks BEFORE this one, src/decoder.c:587-590)
+                     if (lastheight > 0) { float g2 = alpha * (w.v_avg_height / lastheight) + beta * g; if (g2 > 2.0f) g2 = 2.0f; w.agc_gain = g2; }
+                     if (top) { w.v_top = cur.volt; w.v_lasttop = cur.volt; } else { w.v_bot = cur.volt; w.v_lastbot = cur.volt; } }
+                  else {                                                       // the block decoder's whole AGC schedule (start-up, window AGC, density detection)
+                     if (top) w.v_top = cur.volt; else w.v_bot = cur.volt;
+                     agc_after_peak(w, &cfg, P, heights, top, 0.0); }
                   if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
                   if (!approx_thresholds(w, P, lsb)) {
                      update_thresholds(w, P, lsb);
@@ -343,7 +352,10 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
                   c = pos + W + 1;
                   ++i; if (i + 3 < src.iend) cur = src.rec[i + 3];
                   return 0; } } }
-         // ---- the general step: earliest firing run among the tops and the bottoms from the first live record on ----
+         return 1; };
+      // ---- the general step (a lane that cannot take the fast path waits for the round's end: the wave pays for it once per round, not once per step) ----
+      auto general = [&]() -> int {
+         // earliest firing run among the tops and the bottoms from the first live record on
          if (w.thr_dirty) {
             update_thresholds(w, P, lsb);
             if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; } }
@@ -405,15 +417,20 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          c = u.pos + W + 1;
          i = alive.i;
          return 1; };
-      load4();
+      if (active) load4();
+      int st2 = active ? 0 : 2;                                            // 0: in lock step, 1: waiting for the general step, 2: done
       for (;;) {
-         int st2 = step(r0, r1);
-         if (st2 == 0) st2 = step(r1, r2);
-         if (st2 == 0) st2 = step(r2, r3);
-         if (st2 == 0) st2 = step(r3, r0);
-         if (st2 == 2) break;
-         if (st2 == 1) load4(); }
+         #pragma nounroll
+         for (int rep = 0; rep < kGainRound / 4; ++rep) {
+            if (st2 == 0) st2 = step(r0, r1);
+            if (st2 == 0) st2 = step(r1, r2);
+            if (st2 == 0) st2 = step(r2, r3);
+            if (st2 == 0) st2 = step(r3, r0);
+            if (__ballot(st2 == 0) == 0) break; }
+         if (st2 == 1) { st2 = general(); if (st2 != 2) { st2 = 0; load4(); } }
+         if (__ballot(st2 != 2) == 0) break; }
       // ---- publish ----
+      if (!active) continue;
       if (n_fast) atomicAdd(&scratch->dbg[0], (unsigned long long)n_fast);
       if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
       if (failed) { atomicExch(&ctl[b].status, (int)kBurstNeedsFull); atomicAdd(&scratch->why[why & 7], 1ull); }
@@ -451,6 +468,7 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
          in.e = ev[i];
          if (in.w[3] != 0xffffffffu) continue;                            // the general step wrote it out in full
          const float gain = __uint_as_float(in.w[1]);
+         wk.v_avg_height = __uint_as_float(in.w[2]);
          const CRec r = crec[sbase + in.w[0]];
          const uint16_t *eend = reinterpret_cast<const uint16_t *>(pool) + eref[sbase + in.w[0]];
          const Run u = run_decode(r.w0, r.w1, (long long)r.pos);
