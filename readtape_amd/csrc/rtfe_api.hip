@@ -435,10 +435,15 @@ static size_t pk_tstart_bytes(const rtfe_handle *h, int64_t nrows) {      // til
 static size_t ws_pkcrec_off(const rtfe_handle *h, int64_t nrows) { return ws_pktstart_off(h, nrows) + pk_tstart_bytes(h, nrows); }
 static size_t pk_crec_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(CRec) + 255) & ~(size_t)255) : 0; }
 static size_t ws_pkeref_off(const rtfe_handle *h, int64_t nrows) { return ws_pkcrec_off(h, nrows) + pk_crec_bytes(h, nrows); }
+// ... | how many records a list's deferred candidates add to (or take from) its stream (k_sift_hard -> k_pscan)
+static size_t ws_pkextra_off(const rtfe_handle *h, int64_t nrows);
+static size_t pk_extra_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * 4 + 255) & ~(size_t)255) : 0; }
 static size_t pk_eref_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * 4 + 255) & ~(size_t)255) : 0; }
 
+static size_t ws_pkextra_off(const rtfe_handle *h, int64_t nrows) { return ws_pkeref_off(h, nrows) + pk_eref_bytes(h, nrows); }
+
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pkeref_off(h, nrows) + pk_eref_bytes(h, nrows) + 256; }
+   return ws_pkextra_off(h, nrows) + pk_extra_bytes(h, nrows) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -508,6 +513,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       const int hard_cap = (int)pk_hard_cap(h, nrows);
       const long long ptiles = pk_tiles_for(nrows);
       (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
+      (void)hipMemsetAsync(wsb + ws_pkextra_off(h, nrows), 0, pk_extra_bytes(h, nrows), st);
       t0(0, st); t1(0, st); t0(2, st); t1(2, st); t0(3, st); t1(3, st); t0(4, st); t1(4, st);
       const int stop_after = getenv("RTFE_PEAK_STOP") ? atoi(getenv("RTFE_PEAK_STOP")) : 99;      // (debugging: launch only the first n kernels of the path)
       t0(6, st);
@@ -531,19 +537,22 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                             qtile, dirm, pkpool, hardp, hard_cap, &scratch->hard_count, scratch->scr); }
       hipLaunchKernelGGL(k_qpack, dim3(64), dim3(256), 0, st, (const uint16_t *)qtile, ptiles, qwords, nwords);
+      // the lists -> one stream of 16-byte records per (screen, head): the deferred candidates resolved (k_sift_hard), the streams' tile
+      // offsets (k_pscan), the records copied over with their absolute rows, volts and entry references (k_prep)
       const int nlists = h->dev.nscreens * h->dev.ntrks;
       uint32_t *tstartp = reinterpret_cast<uint32_t *>(wsb + ws_pktstart_off(h, nrows));
       const int nsc = (int)((ptiles + 1023) / 1024);                    // chunks of 1024 tiles (k_pscan)
       uint32_t *ctotcp = tstartp + (size_t)ptiles * nlists, *coffp = ctotcp + (size_t)nsc * nlists, *ctotp = coffp + (size_t)nsc * nlists;
       CRec *crecp = reinterpret_cast<CRec *>(wsb + ws_pkcrec_off(h, nrows));
       uint32_t *erefp = reinterpret_cast<uint32_t *>(wsb + ws_pkeref_off(h, nrows));
+      int *extrap = reinterpret_cast<int *>(wsb + ws_pkextra_off(h, nrows));
       const long long ccap = pk_ccap(h, nrows);
-      hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (int)ptiles, nlists, tstartp, ctotcp);
-      hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
-      hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const SfHard *)hardp,
-                         (const uint32_t *)tstartp, (const uint32_t *)coffp, ptiles, ccap, crecp, erefp);
       hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus), dim3(64), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
-                         (const int *)&scratch->hard_count, ovfp);
+                         (const int *)&scratch->hard_count, ovfp, extrap);
+      hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (const int *)extrap, (int)ptiles, nlists, tstartp, ctotcp);
+      hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
+      hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
+                         (const uint32_t *)tstartp, (const uint32_t *)coffp, ptiles, ccap, crecp, erefp);
       t1(6, st); t0(1, st);
       if (stop_after < 2) { t1(1, st); t0(7, st); t1(7, st); t0(8, st); t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
@@ -556,7 +565,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                          (const BurstScratch *)scratch, ctlp);
       hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                          scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
-                         (const unsigned char *)pkpool, (const unsigned char *)ovfp, ptiles);
+                         (const unsigned char *)pkpool, ptiles);
       t1(7, st); t0(8, st);
       if (stop_after < 4) { t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,

@@ -78,17 +78,17 @@ __device__ __forceinline__ long long chain_stop(const DevCfg &cfg, const rtfe_bu
 // tile directory); k_prep: a wave per list copies its records over.
 // ------------------------------------------------------------------------------------------------
 // flags in CRec::w0 bits 0-10 (the tile-relative row of PeakRec::w0 is replaced by the absolute CRec::pos)
-enum { kCrBad = 1, kCrDeferred = 2 };     // the tile's list is not there (capacity) / a deferred candidate: w1 = its overflow slot
+enum { kCrBad = 1 };                      // the tile's list is not there (capacity)
 struct CRec { uint32_t pos, w0, w1; float volt; };
 
 // k_pscan1: a workgroup per chunk of 1024 tiles, a thread per tile: per stream the prefix within the chunk and the chunk's total;
 // k_pscan2: the chunks' offsets (one workgroup).  A stream's position of tile t = tstart[t][stream] + coff[t >> 10][stream].
-__global__ void __launch_bounds__(1024) k_pscan1(const PeakDir *__restrict__ dir, int ntiles, int nlists, uint32_t *__restrict__ tstart, uint32_t *__restrict__ ctotc) {
+__global__ void __launch_bounds__(1024) k_pscan1(const PeakDir *__restrict__ dir, const int *__restrict__ extra, int ntiles, int nlists, uint32_t *__restrict__ tstart, uint32_t *__restrict__ ctotc) {
    __shared__ int lds[32];
    const int t = blockIdx.x * 1024 + threadIdx.x;
    for (int li = 0; li < nlists; ++li) {
       int n = 0;
-      if (t < ntiles) { n = dir[(size_t)t * nlists + li].nrec; if (n == 0xffff) n = 1; }
+      if (t < ntiles) { n = dir[(size_t)t * nlists + li].nrec; n = n == 0xffff ? 1 : n + extra[(size_t)t * nlists + li]; }      // (a deferred candidate stands for 0..4 records)
       int total;
       const int off = block_excl_scan_1024(n, lds, &total);
       if (t < ntiles) tstart[(size_t)t * nlists + li] = (uint32_t)off;
@@ -109,40 +109,50 @@ __device__ __forceinline__ long long stream_pos(const uint32_t *tstart, const ui
    return (long long)tstart[(size_t)tile * nlists + li] + (long long)coff[(size_t)(tile >> 10) * nlists + li]; }
 
 __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
-                                              const SfHard *__restrict__ hard, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, long long ntiles, long long ccap,
-                                              CRec *__restrict__ crec, uint32_t *__restrict__ eref) {
+                                              const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff,
+                                              long long ntiles, long long ccap, CRec *__restrict__ crec, uint32_t *__restrict__ eref) {
    const DevCfg &cfg = *cfgp;
    const int nlists = cfg.nscreens * cfg.ntrks, hcap = cfg.pk_slot;
+   const float mv = cfg.maxvolts;
    const int lane = threadIdx.x & 63;
    const long long nall = ntiles * nlists;
+   const size_t ovf16 = (size_t)(ovf - pool) / 2;                         // the overflow slots, in the 2-byte units eref counts from the pool's start
    for (long long li = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); li < nall; li += (long long)gridDim.x * 4) {
       const PeakDir d = dir[li];
       if (d.nrec == 0) continue;
       const long long tile = li / nlists;
       const int sl = (int)(li - tile * nlists);
-      const long long base = (long long)sl * ccap + stream_pos(tstart, coff, nlists, tile, sl);
+      long long base = (long long)sl * ccap + stream_pos(tstart, coff, nlists, tile, sl);
       if (d.nrec == 0xffffu) {                                          // a list that did not fit: one marker at the tile's first row
          if (lane == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; eref[base] = 0; }
          continue; }
       const unsigned char *slot = pool + (size_t)li * hcap;
+      const long long pos0 = tile * kSfTile - kSfPosBias;
       int ebase = 0;
       for (int k0 = 0; k0 < (int)d.nrec; k0 += 64) {
          const int k = k0 + lane;
+         const bool have = k < (int)d.nrec;
          uint32_t w0 = 0, w1 = 0;
-         if (k < (int)d.nrec) { const uint2 r = *reinterpret_cast<const uint2 *>(slot + 8 * k); w0 = r.x; w1 = r.y; }
-         const int ne = k < (int)d.nrec ? pk_nent(w0, w1) : 0;
-         const int incl = wave_incl_scan(ne, lane);
-         if (k < (int)d.nrec) {
-            CRec c;
-            if (w1 == 0xffff8001u) {                                      // deferred: the candidate's row, "first possible row" right behind it
-               const SfHard hd = hard[w0];
-               c.pos = (uint32_t)(tile * kSfTile + hd.pos); c.w0 = kCrDeferred | (1u << 11) | (1u << 12); c.w1 = w0; c.volt = 0; }
-            else {
-               c.pos = (uint32_t)(tile * kSfTile - kSfPosBias + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1;
-               c.volt = volt((int)(int16_t)(w1 & 0xffffu), cfg.maxvolts); }
-            crec[base + k] = c;
-            eref[base + k] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(ebase + incl - ne)); }
-         ebase += wave_last(incl); } } }
+         if (have) { const uint2 r = *reinterpret_cast<const uint2 *>(slot + 8 * k); w0 = r.x; w1 = r.y; }
+         const bool deferred = have && w1 == 0xffff8001u;                  // its records are in overflow slot w0 (k_sift_hard): they take its place
+         const unsigned char *os = ovf + (size_t)w0 * kSfOvfBytes;
+         const int cnt = deferred ? *reinterpret_cast<const int *>(os) : (have ? 1 : 0);
+         const int ne = deferred || !have ? 0 : pk_nent(w0, w1);
+         const int ie = wave_incl_scan(ne, lane), ic = wave_incl_scan(cnt, lane);
+         long long o = base + ic - cnt;
+         if (deferred) {
+            int se0 = 0;
+            for (int j = 0; j < cnt; ++j) {
+               const uint2 r = *reinterpret_cast<const uint2 *>(os + 8 + 8 * j);
+               CRec c; c.pos = (uint32_t)(pos0 + (long long)(r.x & 0x7ffu)); c.w0 = r.x & ~0x7ffu; c.w1 = r.y; c.volt = volt((int)(int16_t)(r.y & 0xffffu), mv);
+               crec[o + j] = c;
+               eref[o + j] = (uint32_t)(ovf16 + ((size_t)w0 * kSfOvfBytes + kSfOvfBytes) / 2 - (size_t)se0);
+               se0 += pk_nent(r.x, r.y); } }
+         else if (have) {
+            CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
+            crec[o] = c;
+            eref[o] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(ebase + ie - ne)); }
+         ebase += wave_last(ie); base += wave_last(ic); } } }
 
 // ------------------------------------------------------------------------------------------------
 // k_gain
@@ -181,7 +191,7 @@ __device__ __forceinline__ bool amp_pass(const Walker &w, const Run &u, float mv
    return u.top ? volt(u.val, mv) > w.reqmin : volt(u.val, mv) < -w.reqmin; }
 
 constexpr long long kNoRow = 0x7fffffffffffffffll;
-constexpr int kGainRound = 64;      // steps of a wave between two general steps (multiple of 4)
+constexpr int kGainChunk = 16;      // records a lane steps through between two general steps (multiple of 4)
 // first row >= c (and < limit) at which this run makes the detector fire, or kNoRow; doubt = first row >= c that the record cannot decide.
 // eend: entry e of the record lives at eend[-(e + 1)]
 __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, const uint16_t *eend, long long c, long long limit, int W, int sure_i, float mv, long long &doubt) {
@@ -209,45 +219,23 @@ __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, con
       if (rise_pass(w, u.top, u.val, (int)eend[-(u.nlead + i + 1)], mv)) return n; }
    return kNoRow; }
 
-// a lane's place in its stream for the general step: record i; inside a deferred candidate's overflow slot, sub = the record of the slot
+// a lane's place in its stream for the general step
 struct RecIt {
    long long i;
    uint32_t w0, w1; long long pos;
    const uint16_t *eend;
-   bool end, bad;
-   int sub, nsub, se0;
-   const unsigned char *ovf; };
-struct RecSrc { const CRec *rec; const uint32_t *eref; const unsigned char *pool, *ovf; long long iend; };
+   bool end, bad; };
+struct RecSrc { const CRec *rec; const uint32_t *eref; const unsigned char *pool; long long iend; };
 __device__ __forceinline__ void it_land(RecIt &it, const RecSrc &S) {
-   for (;;) {
-      it.sub = -1;
-      if (it.i >= S.iend) { it.end = true; return; }
-      const CRec r = S.rec[it.i];
-      it.pos = r.pos; it.w0 = r.w0; it.w1 = r.w1;
-      if (r.w0 & kCrBad) { it.end = true; it.bad = true; return; }
-      if (!(r.w0 & kCrDeferred)) { it.eend = reinterpret_cast<const uint16_t *>(S.pool) + S.eref[it.i]; return; }
-      it.ovf = S.ovf + (size_t)r.w1 * kSfOvfBytes;
-      const int n = *reinterpret_cast<const int *>(it.ovf);
-      if (n < 0) { it.end = true; it.bad = true; return; }                        // (not representable: whoever needs it takes the sample path)
-      if (n > 0) {
-         const uint2 r2 = *reinterpret_cast<const uint2 *>(it.ovf + 8);
-         it.sub = 0; it.nsub = n; it.se0 = 0; it.w0 = r2.x; it.w1 = r2.y;
-         it.pos = (long long)(r.pos / kSfTile) * kSfTile - kSfPosBias + (long long)(r2.x & 0x7ffu);      // (its records count from the candidate's tile)
-         it.eend = reinterpret_cast<const uint16_t *>(it.ovf + kSfOvfBytes); return; }
-      ++it.i; } }                                                                // (a candidate that turned out to have no row above the screen)
+   if (it.i >= S.iend) { it.end = true; return; }
+   const CRec r = S.rec[it.i];
+   it.pos = r.pos; it.w0 = r.w0; it.w1 = r.w1;
+   if (r.w0 & kCrBad) { it.end = true; it.bad = true; return; }
+   it.eend = reinterpret_cast<const uint16_t *>(S.pool) + S.eref[it.i]; }
 __device__ __forceinline__ void it_open(RecIt &it, const RecSrc &S, long long i) {
-   it.end = false; it.bad = false; it.i = i; it.sub = -1; it.nsub = 0; it.se0 = 0; it.ovf = nullptr; it.eend = nullptr; it.w0 = 0; it.w1 = 0; it.pos = 0;
+   it.end = false; it.bad = false; it.i = i; it.eend = nullptr; it.w0 = 0; it.w1 = 0; it.pos = 0;
    it_land(it, S); }
-__device__ __forceinline__ void it_next(RecIt &it, const RecSrc &S) {
-   if (it.sub >= 0) {
-      it.se0 += pk_nent(it.w0, it.w1);
-      if (++it.sub < it.nsub) {
-         const uint2 r = *reinterpret_cast<const uint2 *>(it.ovf + 8 + 8 * it.sub);
-         const long long tile0 = it.pos - (long long)(it.w0 & 0x7ffu);                // (pos = tile0 - bias + field)
-         it.w0 = r.x; it.w1 = r.y; it.pos = tile0 + (long long)(r.x & 0x7ffu);
-         it.eend = reinterpret_cast<const uint16_t *>(it.ovf + kSfOvfBytes) - it.se0; return; } }
-   ++it.i;
-   it_land(it, S); }
+__device__ __forceinline__ void it_next(RecIt &it, const RecSrc &S) { ++it.i; it_land(it, S); }
 
 // an event the fast path only noted (k_emit finishes it): its record's place in the stream, and the gain in force
 __device__ __forceinline__ rtfe_event note_event(long long i, float g, float h) {
@@ -259,8 +247,10 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
                                              const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
-                                             long long ccap, const unsigned char *__restrict__ pool, const unsigned char *__restrict__ ovf, long long ntiles) {
+                                             long long ccap, const unsigned char *__restrict__ pool, long long ntiles) {
    __shared__ float s_heights[64 * 10];
+   __shared__ uint4 s_notes[kGainChunk][64];                           // the events the fast path notes, until the chunk's end
+   __shared__ uint4 s_rec[kGainChunk + 1][64];                         // the lanes' records of the current chunk
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks, nlists = cfg.nscreens * ntrks;
    const int lane = threadIdx.x;
@@ -274,8 +264,11 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
       const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady;
       const rtfe_burst B = bursts[b];
-      const DevParm &P = cfg.parm[pidx];
-      const DevScreen &S = cfg.screen[P.screen];
+      // (the chain's constants by value: a reference into the configuration block would be loaded again - a vector load, the lanes'
+      //  parameter sets differ - at every use, and each such load waits for everything in flight)
+      const DevParm P = cfg.parm[pidx];
+      const DevScreen S = cfg.screen[P.screen];
+      const int cmode = cfg.mode, agc_off = cfg.agc_off;
       const int W = P.W, d = cfg.skew[trk], head = cfg.trk_to_head[trk];
       const long long reset = ctl[b].reset;
       const long long stop = chain_stop(cfg, bursts, ctl, b, scratch->nbursts_total, nrows);
@@ -294,31 +287,35 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       // this chain's piece of its head's stream: from the tile that holds row c - W to the tile behind the limit
       const int sl = P.screen * ntrks + head;
       RecSrc src;
-      src.rec = crec + (size_t)sl * ccap; src.eref = eref + (size_t)sl * ccap; src.pool = pool; src.ovf = ovf;
+      src.rec = crec + (size_t)sl * ccap; src.eref = eref + (size_t)sl * ccap; src.pool = pool;
       long long i;
       {  long long g0 = (c - W) / kSfTile; if (c - W < 0) g0 = 0; if (g0 >= ntiles) g0 = ntiles - 1;
          long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;       // first tile whose candidates all lie at or behind the limit
          i = stream_pos(tstart, coff, nlists, g0, sl);
          src.iend = ge < ntiles ? stream_pos(tstart, coff, nlists, ge, sl) : (long long)ctot[sl]; }
-      const bool lean = cfg.pk_fast && cfg.mode != RTFE_PE;                // (PE decides the end of its preamble from peak TIMES: the general step)
-      const bool alpha_agc = !cfg.agc_off && P.agc_window == 0;           // steady state = the three-flop alpha filter
+      const bool lean = cfg.pk_fast && cmode != RTFE_PE;                // (PE decides the end of its preamble from peak TIMES: the general step)
+      const bool alpha_agc = !agc_off && P.agc_window == 0;           // steady state = the three-flop alpha filter
       const float alpha = P.agc_alpha, beta = 1 - P.agc_alpha;
-      // The lane keeps the record it stands on and the three behind it in four register sets that take turns (r0 r1 r2 r3 -> r1 r2 r3 r0:
-      // no copies, so a step waits for a load issued three steps earlier, not for the one it has just issued).
-      // step(): 0 = one record on, in lock step; 1 = the general step moved the lane somewhere else (reload all four); 2 = the chain is done.
-      CRec r0 = {}, r1 = {}, r2 = {}, r3 = {};
-      auto load4 = [&]() {
-         if (i < src.iend) r0 = src.rec[i];
-         if (i + 1 < src.iend) r1 = src.rec[i + 1];
-         if (i + 2 < src.iend) r2 = src.rec[i + 2];
-         if (i + 3 < src.iend) r3 = src.rec[i + 3]; };
-      auto step = [&](CRec &cur, const CRec &nxt) -> int {
+      // The stream goes through LDS a chunk of kGainChunk records a lane at a time (+ one: the record behind the chunk's last is what
+      // its fast path looks at).  While the lanes step through a chunk - LDS reads only, and the notes they take go to LDS too - the
+      // next chunk's 16-byte loads travel into registers; at the chunk's end they go to LDS.  (Loads issued inside the steps would
+      // each be waited for in full: hipcc does not keep count across the round's branches.)
+      // step(): 0 = one record on, in lock step; 1 = this record needs the general step (the lane waits for the chunk's end);
+      // 2 = the chain is done.
+      int nbuf = 0;
+      auto flush_notes = [&]() {
+         #pragma unroll
+         for (int j = 0; j < kGainChunk; ++j) if (j < nbuf) reinterpret_cast<uint4 *>(ev)[w.nevents - (unsigned)nbuf + (unsigned)j] = s_notes[j][lane];
+         nbuf = 0; };
+      auto step = [&](const uint4 cur4, const uint4 nxt4, const long long idx) -> int {
          if (++guard > 8000000u) { failed = true; why = 7; return 2; }           // (cannot happen: every round moves the stream or c forward)
-         if (i >= src.iend) return 2;
+         if (idx >= src.iend) return 2;
+         CRec cur, nxt;
+         cur.pos = cur4.x; cur.w0 = cur4.y; cur.w1 = cur4.z; cur.volt = __uint_as_float(cur4.w);
+         nxt.pos = nxt4.x; nxt.w0 = nxt4.y; nxt.w1 = nxt4.z; nxt.volt = 0;
+         const long long i = idx;
          const long long pos = cur.pos;
-         if ((cur.w0 & kCrBad) ? pos + kSfTile + W < c : (pos + W - 2 < c && !(cur.w0 & kCrDeferred))) {      // its rows are behind the countdown for good
-            ++i; if (i + 3 < src.iend) cur = src.rec[i + 3];
-            return 0; }
+         if ((cur.w0 & kCrBad) ? pos + kSfTile + W < c : pos + W - 2 < c) return 0;      // its rows are behind the countdown for good
          // ---- the fast path: steady state (peakcount > 15, the baseline fixed), a record with a sure stretch, the countdown over before its
          // first row, the thresholds inside the band the sure level stands for, a clear amplitude, and nothing else that could fire before
          // this record's owner has left the window.  Then it fires - at one of its lead rows or at its first sure row, k_emit will say
@@ -331,12 +328,15 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
             const int val = (int)(int16_t)(cur.w1 & 0xffffu);
             const int a = top ? val : -val;
             const long long fn = i + 1 < src.iend ? (long long)nxt.pos + (long long)((nxt.w0 >> 12) & 63u) : kNoRow;
-            if ((w0 & (kCrBad | kCrDeferred)) == 0 && cur.w1 != 0xffff8000u && (unsigned)(nsure - 1) < 62u && c <= f && f + nlead < limit && fn > pos + W
+            // (a record whose extreme is below the amplitude test for sure cannot fire while the thresholds stand, and they stand until something
+            //  fires - behind which all of this record's rows are blind: it is passed over)
+            if ((w0 & kCrBad) == 0 && cur.w1 != 0xffff8000u && w.reqmin != 0 && a <= w.min_lo && true) return 0;
+            if ((w0 & kCrBad) == 0 && cur.w1 != 0xffff8000u && (unsigned)(nsure - 1) < 62u && c <= f && f + nlead < limit && fn > pos + W
                 && w.rise_hi <= S.sure_i && (w.reqmin == 0 || a >= w.min_hi) && w.nevents < cap) {
                const float g = w.agc_gain;
                if ((int)(0.005f * fast_rcp(g) * lsb) + 4 <= 254) {
-                  ev[w.nevents] = note_event(i, g, w.v_avg_height);
-                  ++w.nevents; ++n_fast;
+                  s_notes[nbuf][lane] = make_uint4((uint32_t)i, __float_as_uint(g), __float_as_uint(w.v_avg_height), 0xffffffffu);
+                  ++nbuf; ++w.nevents; ++n_fast;
                   if (alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) {      // steady state: the alpha filter alone (src/decoder.c:505-512)
                      ++w.peakcount;
                      const float lastheight = w.v_lasttop - w.v_lastbot;     // (the callback sees the heights of the peaks BEFORE this one, src/decoder.c:587-590)
@@ -344,14 +344,23 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
                      if (top) { w.v_top = cur.volt; w.v_lasttop = cur.volt; } else { w.v_bot = cur.volt; w.v_lastbot = cur.volt; } }
                   else {                                                       // the block decoder's whole AGC schedule (start-up, window AGC, density detection)
                      if (top) w.v_top = cur.volt; else w.v_bot = cur.volt;
-                     agc_after_peak(w, &cfg, P, heights, top, 0.0); }
+                     agc_after_peak_m(w, cmode, agc_off, P, heights, top, 0.0); }
                   if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
                   if (!approx_thresholds(w, P, lsb)) {
                      update_thresholds(w, P, lsb);
                      if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; } }
                   c = pos + W + 1;
-                  ++i; if (i + 3 < src.iend) cur = src.rec[i + 3];
                   return 0; } } }
+#ifdef RTFE_CPU_EMUL
+         if (getenv("RTFE_GAIN_WHY")) {                                      // (tests/cpu_emul only: why the fast path did not take this record)
+            const uint32_t w0 = cur.w0; const long long f = pos + (long long)((w0 >> 12) & 63u);
+            const int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u); const bool top = !((w0 >> 11) & 1u);
+            const int val = (int)(int16_t)(cur.w1 & 0xffffu), a = top ? val : -val;
+            const long long fn = i + 1 < src.iend ? (long long)nxt.pos + (long long)((nxt.w0 >> 12) & 63u) : kNoRow;
+            const int r = !lean ? 10 : (w0 & kCrBad) ? 1 : cur.w1 == 0xffff8000u ? 2 : !((unsigned)(nsure - 1) < 62u) ? 3 : !(c <= f) ? 4 : !(f + nlead < limit) ? 5
+                        : !(fn > pos + W) ? 6 : !(w.rise_hi <= S.sure_i) ? 7 : !(w.reqmin == 0 || a >= w.min_hi) ? 8 : 9;
+            fprintf(stderr, "why %d pc %d pos %lld f %lld fn %lld nlead %d nsure %d a %d min_hi %d c %lld limit %lld\n", r, w.peakcount, pos, f, fn, nlead, nsure, a, w.min_hi, c, limit); }
+#endif
          return 1; };
       // ---- the general step (a lane that cannot take the fast path waits for the round's end: the wave pays for it once per round, not once per step) ----
       auto general = [&]() -> int {
@@ -394,7 +403,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          const int adjcode = refine_code(&cfg, val_i, iprev, inext, g, u.top);
          const float val = volt(val_i, mv);
          double t_peak = 0;
-         if (cfg.mode == RTFE_PE && !w.datablock && w.peakcount >= 68) {
+         if (cmode == RTFE_PE && !w.datablock && w.peakcount >= 68) {
             const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
             t_peak = time_of(&cfg, row_base + ndet) - ((float)(W - ld) - adj) * cfg.sample_deltat; }
          if (w.nevents >= cap) w.flags |= RTFE_F_EVENT_OVERFLOW;
@@ -410,25 +419,43 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
             ev[w.nevents] = e; }
          if (u.top) w.v_top = val; else w.v_bot = val;
          ++w.nevents; ++n_slow;
-         agc_after_peak(w, &cfg, P, heights, u.top, t_peak);
+         agc_after_peak_m(w, cmode, agc_off, P, heights, u.top, t_peak);
          if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
          update_thresholds(w, P, lsb);
          if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; }
          c = u.pos + W + 1;
          i = alive.i;
          return 1; };
-      if (active) load4();
+      uint4 q[kGainChunk + 1];
+      #pragma unroll
+      for (int j = 0; j <= kGainChunk; ++j) q[j] = make_uint4(0, 0, 0, 0);
+      const uint4 *rec4 = reinterpret_cast<const uint4 *>(src.rec);
+      auto fetch = [&](long long i0) {
+         #pragma unroll
+         for (int j = 0; j <= kGainChunk; ++j) if (i0 + j < src.iend) q[j] = rec4[i0 + j]; };
+      auto put = [&]() {
+         #pragma unroll
+         for (int j = 0; j <= kGainChunk; ++j) s_rec[j][lane] = q[j]; };
       int st2 = active ? 0 : 2;                                            // 0: in lock step, 1: waiting for the general step, 2: done
+      if (st2 == 0) fetch(i);
+      put();
+      if (st2 == 0) fetch(i + kGainChunk);
       for (;;) {
+         int jp = 0;                                                       // records of the chunk this lane is through with
          #pragma nounroll
-         for (int rep = 0; rep < kGainRound / 4; ++rep) {
-            if (st2 == 0) st2 = step(r0, r1);
-            if (st2 == 0) st2 = step(r1, r2);
-            if (st2 == 0) st2 = step(r2, r3);
-            if (st2 == 0) st2 = step(r3, r0);
+         for (int j0 = 0; j0 < kGainChunk; j0 += 4) {
+            #pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+               if (st2 == 0) { st2 = step(s_rec[j0 + jj][lane], s_rec[j0 + jj + 1][lane], i + j0 + jj); if (st2 == 0) jp = j0 + jj + 1; }
             if (__ballot(st2 == 0) == 0) break; }
-         if (st2 == 1) { st2 = general(); if (st2 != 2) { st2 = 0; load4(); } }
-         if (__ballot(st2 != 2) == 0) break; }
+         flush_notes();
+         bool resync = false;
+         if (st2 == 1) { i += jp; st2 = general(); if (st2 != 2) st2 = 0; resync = true; }
+         else if (st2 == 0) i += kGainChunk;
+         if (__ballot(st2 != 2) == 0) break;
+         if (resync && st2 == 0) fetch(i);                                   // (a lane the general step moved: its chunk afresh - the wave waits for it)
+         put();
+         if (st2 == 0) fetch(i + kGainChunk); }
       // ---- publish ----
       if (!active) continue;
       if (n_fast) atomicAdd(&scratch->dbg[0], (unsigned long long)n_fast);

@@ -363,10 +363,14 @@ __device__ __forceinline__ void adjust_agc(Walker &w, const DevParm &P, float *h
 
 // what the block decoder's callback does to the state the detector reads back, then the
 // post-callback bookkeeping of process_up/down_transition (src/decoder.c:587-590, 605-609)
+__device__ __forceinline__ void agc_after_peak_m(Walker &w, int mode, int agc_off, const DevParm &P, float *heights, bool is_top, double t_peak);
 __device__ __forceinline__ void agc_after_peak(Walker &w, const DevCfg *cfg, const DevParm &P, float *heights, bool is_top, double t_peak) {
+   agc_after_peak_m(w, cfg->mode, cfg->agc_off, P, heights, is_top, t_peak); }
+// (mode and agc_off by value: a caller that keeps them in registers does not go back to the configuration block in HBM per detection)
+__device__ __forceinline__ void agc_after_peak_m(Walker &w, int mode, int agc_off, const DevParm &P, float *heights, bool is_top, double t_peak) {
    ++w.peakcount;                                               // src/decoder.c:561
-   if (cfg->agc_off) { }                                         // density detection: no decoder callback (src/decoder.c:578-581)
-   else if (cfg->mode == RTFE_PE) {
+   if (agc_off) { }                                              // density detection: no decoder callback (src/decoder.c:578-581)
+   else if (mode == RTFE_PE) {
       if (w.datablock) adjust_agc(w, P, heights);               // src/decode_pe.c:175,198
       else {                                                    // pe_preamble_peak, src/decode_pe.c:127-155
          if (w.peakcount == 1) w.bit1_up = !is_top;
@@ -378,7 +382,7 @@ __device__ __forceinline__ void agc_after_peak(Walker &w, const DevCfg *cfg, con
             ++w.v_avg_height_count;
             heights[w.heightndx] = w.v_top - w.v_bot;
             if (++w.heightndx >= P.agc_window) w.heightndx = 0; } } }
-   else if (cfg->mode == RTFE_WW) adjust_agc(w, P, heights);      // src/decode_ww.c:171,190
+   else if (mode == RTFE_WW) adjust_agc(w, P, heights);           // src/decode_ww.c:171,190
    else {                                                       // NRZI and GCR share the schedule
       if (is_top) {                                             // src/decode_nrzi.c:218-229, src/decode_gcr.c:853-864
          if (w.peakcount >= 5 && w.peakcount <= 15) {

@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
 // four records and their margin entries in the layout of a list slot.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_sift_hard(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
-                                                  const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf) {
+                                                  const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf, int *__restrict__ extra) {
    const DevCfg &cfg = *cfgp;
    int n = *hard_count;
    if (n > hard_cap) n = hard_cap;
@@ -856,10 +856,12 @@ __global__ void __launch_bounds__(64) k_sift_hard(const DevCfg *__restrict__ cfg
       pk_bot(cx, sk, (int)hd.head, (int)hd.pos);
       unsigned char *slot = ovf + (size_t)i * kSfOvfBytes;
       int nrec = sk.n, ne = 0;
-      if (nrec > 4) nrec = -1;                                              // (more epochs than a slot holds: the chain that gets here gives up)
+      if (nrec > 4) nrec = -1;
       for (int j = 0; j < nrec; ++j) ne += pk_nent(sk.w0[j], sk.w1[j]);
       if (nrec > 0 && 8 + 8 * nrec + 2 * ne > kSfOvfBytes) nrec = -1;
+      if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, 1, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs or margins than a slot holds: "minimum unknown" - the chain that gets here gives up)
       *reinterpret_cast<int *>(slot) = nrec;
+      if (nrec != 1) atomicAdd(&extra[((size_t)hd.tile * cfg.nscreens + hd.screen) * cfg.ntrks + hd.head], nrec - 1);      // the list's length in its stream (k_pscan)
       int e0 = 0;
       for (int j = 0; j < nrec; ++j) {
          reinterpret_cast<uint32_t *>(slot + 8)[2 * j] = sk.w0[j]; reinterpret_cast<uint32_t *>(slot + 8)[2 * j + 1] = sk.w1[j];
