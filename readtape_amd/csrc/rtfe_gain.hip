@@ -307,61 +307,78 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          #pragma unroll
          for (int j = 0; j < kGainChunk; ++j) if (j < nbuf) reinterpret_cast<uint4 *>(ev)[w.nevents - (unsigned)nbuf + (unsigned)j] = s_notes[j][lane];
          nbuf = 0; };
+      // (rows fit 32 bits here: rtfe_scan takes fragments of less than 2^31 rows through this path)
+      const int limit32 = limit > 0x7ffffff0ll ? 0x7ffffff0 : (int)limit;
+      const bool amp_on = P.min_peak != 0;
+      // steady state (NRZI / GCR: peakcount > 15, the baseline fixed; the alpha filter): thresholds straight from 1 / g
+      bool steady = false;
+      float kr = 0, km = 0, rg_min = 0;                                    // rise / min_peak thresholds in int16 units per unit of 1 / g; below rg_min = 1 / g they come near the screen's
+      const float g_min = 0.005f * lsb / 249.0f;                         // below it the half-sample refinement's threshold outgrows the records' neighbour distances (254)
       auto step = [&](const uint4 cur4, const uint4 nxt4, const long long idx) -> int {
-         if (++guard > 8000000u) { failed = true; why = 7; return 2; }           // (cannot happen: every round moves the stream or c forward)
          if (idx >= src.iend) return 2;
-         CRec cur, nxt;
-         cur.pos = cur4.x; cur.w0 = cur4.y; cur.w1 = cur4.z; cur.volt = __uint_as_float(cur4.w);
-         nxt.pos = nxt4.x; nxt.w0 = nxt4.y; nxt.w1 = nxt4.z; nxt.volt = 0;
-         const long long i = idx;
-         const long long pos = cur.pos;
-         if ((cur.w0 & kCrBad) ? pos + kSfTile + W < c : pos + W - 2 < c) return 0;      // its rows are behind the countdown for good
-         // ---- the fast path: steady state (peakcount > 15, the baseline fixed), a record with a sure stretch, the countdown over before its
-         // first row, the thresholds inside the band the sure level stands for, a clear amplitude, and nothing else that could fire before
-         // this record's owner has left the window.  Then it fires - at one of its lead rows or at its first sure row, k_emit will say
-         // which - and all that feeds back is the extreme's value: g = alpha h / lastheight + (1 - alpha) g (src/decoder.c:505-512). ----
-         if (lean) {
-            const uint32_t w0 = cur.w0;
-            const long long f = pos + (long long)((w0 >> 12) & 63u);
-            const int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u);
-            const bool top = !((w0 >> 11) & 1u);
-            const int val = (int)(int16_t)(cur.w1 & 0xffffu);
-            const int a = top ? val : -val;
-            const long long fn = i + 1 < src.iend ? (long long)nxt.pos + (long long)((nxt.w0 >> 12) & 63u) : kNoRow;
-            // (a record whose extreme is below the amplitude test for sure cannot fire while the thresholds stand, and they stand until something
-            //  fires - behind which all of this record's rows are blind: it is passed over)
-            if ((w0 & kCrBad) == 0 && cur.w1 != 0xffff8000u && w.reqmin != 0 && a <= w.min_lo && true) return 0;
-            if ((w0 & kCrBad) == 0 && cur.w1 != 0xffff8000u && (unsigned)(nsure - 1) < 62u && c <= f && f + nlead < limit && fn > pos + W
-                && w.rise_hi <= S.sure_i && (w.reqmin == 0 || a >= w.min_hi) && w.nevents < cap) {
-               const float g = w.agc_gain;
-               if ((int)(0.005f * fast_rcp(g) * lsb) + 4 <= 254) {
-                  s_notes[nbuf][lane] = make_uint4((uint32_t)i, __float_as_uint(g), __float_as_uint(w.v_avg_height), 0xffffffffu);
-                  ++nbuf; ++w.nevents; ++n_fast;
-                  if (alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) {      // steady state: the alpha filter alone (src/decoder.c:505-512)
-                     ++w.peakcount;
-                     const float lastheight = w.v_lasttop - w.v_lastbot;     // (the callback sees the heights of the peaks BEFORE this one, src/decoder.c:587-590)
-                     if (lastheight > 0) { float g2 = alpha * (w.v_avg_height / lastheight) + beta * g; if (g2 > 2.0f) g2 = 2.0f; w.agc_gain = g2; }
-                     if (top) { w.v_top = cur.volt; w.v_lasttop = cur.volt; } else { w.v_bot = cur.volt; w.v_lastbot = cur.volt; } }
-                  else {                                                       // the block decoder's whole AGC schedule (start-up, window AGC, density detection)
-                     if (top) w.v_top = cur.volt; else w.v_bot = cur.volt;
-                     agc_after_peak_m(w, cmode, agc_off, P, heights, top, 0.0); }
-                  if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
-                  if (!approx_thresholds(w, P, lsb)) {
-                     update_thresholds(w, P, lsb);
-                     if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; } }
-                  c = pos + W + 1;
-                  return 0; } } }
+         const int pos = (int)cur4.x;
+         const uint32_t w0 = cur4.y, w1 = cur4.z;
+         const int c32 = (int)c;
+         const bool plain = !(w0 & kCrBad) && w1 != 0xffff8000u;
+         if (plain ? pos + W - 2 < c32 : ((w0 & kCrBad) && pos + kSfTile + W < c32)) return 0;      // its rows are behind the countdown for good
+         const int f = pos + (int)((w0 >> 12) & 63u), nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u);
+         const bool top = !(w0 & 0x800u);
+         const int val = (int)(int16_t)(w1 & 0xffffu);
+         const int a = top ? val : -val;
+         // (a record whose extreme is below the amplitude test for sure cannot fire while the thresholds stand, and they stand until something
+         //  fires - behind which all of this record's rows are blind: it is passed over)
+         if (lean && plain && amp_on && a <= w.min_lo) return 0;
+         const int fn = idx + 1 < src.iend ? (int)nxt4.x + (int)((nxt4.y >> 12) & 63u) : 0x7fffffff;
+         // ---- the fast path: a record with a sure stretch, the countdown over before its first row, the thresholds inside the band the sure
+         // level stands for, a clear amplitude, and nothing else that could fire before this record's owner has left the window.  Then it
+         // fires - at one of its lead rows or at its first sure row, k_emit will say which - and all that feeds back is the extreme's value. ----
+         const float g = w.agc_gain;
+         const bool fire = lean && plain && (unsigned)(nsure - 1) < 62u && c32 <= f && f + nlead < limit32 && fn > pos + W
+                           && w.rise_hi <= S.sure_i && (!amp_on || a >= w.min_hi) && w.nevents < cap && g >= g_min;
+         if (!fire) {
 #ifdef RTFE_CPU_EMUL
-         if (getenv("RTFE_GAIN_WHY")) {                                      // (tests/cpu_emul only: why the fast path did not take this record)
-            const uint32_t w0 = cur.w0; const long long f = pos + (long long)((w0 >> 12) & 63u);
-            const int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u); const bool top = !((w0 >> 11) & 1u);
-            const int val = (int)(int16_t)(cur.w1 & 0xffffu), a = top ? val : -val;
-            const long long fn = i + 1 < src.iend ? (long long)nxt.pos + (long long)((nxt.w0 >> 12) & 63u) : kNoRow;
-            const int r = !lean ? 10 : (w0 & kCrBad) ? 1 : cur.w1 == 0xffff8000u ? 2 : !((unsigned)(nsure - 1) < 62u) ? 3 : !(c <= f) ? 4 : !(f + nlead < limit) ? 5
-                        : !(fn > pos + W) ? 6 : !(w.rise_hi <= S.sure_i) ? 7 : !(w.reqmin == 0 || a >= w.min_hi) ? 8 : 9;
-            fprintf(stderr, "why %d pc %d pos %lld f %lld fn %lld nlead %d nsure %d a %d min_hi %d c %lld limit %lld\n", r, w.peakcount, pos, f, fn, nlead, nsure, a, w.min_hi, c, limit); }
+            if (getenv("RTFE_GAIN_WHY")) fprintf(stderr, "why: pc %d pos %d f %d fn %d nlead %d nsure %d a %d min_hi %d c %d limit %d plain %d\n", w.peakcount, pos, f, fn, nlead, nsure, a, w.min_hi, c32, limit32, (int)plain);
 #endif
-         return 1; };
+            return 1; }
+         const float v = __uint_as_float(cur4.w);
+         s_notes[nbuf][lane] = make_uint4((uint32_t)idx, __float_as_uint(g), __float_as_uint(w.v_avg_height), 0xffffffffu);
+         ++nbuf; ++w.nevents;
+         c = pos + W + 1;
+         if (steady) {
+            // g = alpha h / lastheight + (1 - alpha) g, clamped (src/decoder.c:505-512); the callback sees the heights of the peaks BEFORE this one (:587-590)
+            ++w.peakcount;
+            const float lastheight = w.v_lasttop - w.v_lastbot;
+            float g2 = g;
+            if (lastheight > 0) { g2 = alpha * (w.v_avg_height / lastheight) + beta * g; if (g2 > 2.0f) g2 = 2.0f; }
+            if (top) { w.v_top = v; w.v_lasttop = v; } else { w.v_bot = v; w.v_lastbot = v; }
+            w.agc_gain = g2;
+            // the integer bands around the thresholds of src/decoder.c:785-786 from a 1-ulp reciprocal (approx_thresholds: two more lsb of guard)
+            const float rg = fast_rcp(g2);
+            if (!(g2 > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
+            if (rg < rg_min) {                                                 // thresholds near the screen's: exactly
+               update_thresholds(w, P, lsb);
+               if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; }
+               return 0; }
+            const int r = (int)(kr * rg), m = (int)(km * rg);
+            w.rise_lo = r - 2; w.rise_hi = r + 3; w.min_lo = m - 2; w.min_hi = m + 3;
+            w.thr_dirty = true;
+            return 0; }
+         // the block decoder's whole AGC schedule (start-up, window AGC, density detection)
+         if (top) w.v_top = v; else w.v_bot = v;
+         agc_after_peak_m(w, cmode, agc_off, P, heights, top, 0.0);
+         if (!(w.agc_gain > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
+         if (!approx_thresholds(w, P, lsb)) {
+            update_thresholds(w, P, lsb);
+            if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; } }
+         if (alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0 && !steady) {         // from here on the baseline is fixed
+            steady = true;
+            const float hs = w.v_avg_height * 0.25f;
+            kr = P.rise * hs * lsb; km = P.min_peak * hs * lsb;
+            // thresholds stay clear of the screen's while rise * hs / g >= 1.001 screen_rise_v (and the same for min_peak): a bound on 1 / g
+            rg_min = 0;
+            if (P.rise * hs > 0) rg_min = P.screen_rise_v * 1.002f / (P.rise * hs);
+            if (amp_on && P.min_peak * hs > 0) { const float b2 = P.screen_minpk_v * 1.002f / (P.min_peak * hs); if (b2 > rg_min) rg_min = b2; } }
+         return 0; };
       // ---- the general step (a lane that cannot take the fast path waits for the round's end: the wave pays for it once per round, not once per step) ----
       auto general = [&]() -> int {
          // earliest firing run among the tops and the bottoms from the first live record on
@@ -458,6 +475,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          if (st2 == 0) fetch(i + kGainChunk); }
       // ---- publish ----
       if (!active) continue;
+      n_fast = w.nevents - n_slow;
       if (n_fast) atomicAdd(&scratch->dbg[0], (unsigned long long)n_fast);
       if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
       if (failed) { atomicExch(&ctl[b].status, (int)kBurstNeedsFull); atomicAdd(&scratch->why[why & 7], 1ull); }
