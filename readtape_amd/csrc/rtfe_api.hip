@@ -427,7 +427,9 @@ static size_t pk_ovf_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.
 static size_t ws_pkqtile_off(const rtfe_handle *h, int64_t nrows) { return (ws_pkovf_off(h, nrows) + pk_ovf_bytes(h, nrows) + 255) & ~(size_t)255; }
 static size_t pk_qtile_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_tiles_for(nrows) * 2 + 255) & ~(size_t)255) : 0; }
 // ... | the streams' tile offsets and totals (k_pscan) | the streams (k_prep): 16-byte records, entry references
-static long long pk_ccap(const rtfe_handle *h, int64_t nrows) { return pk_tiles_for(nrows) * (h->dev.pk_slot / 8 + 1) + 64; }
+static long long pk_hard_cap(const rtfe_handle *h, int64_t nrows);
+// (a stream holds at most every slot's worth of records, a marker per tile, and three more records per deferred candidate)
+static long long pk_ccap(const rtfe_handle *h, int64_t nrows) { return pk_tiles_for(nrows) * (h->dev.pk_slot / 8 + 1) + 3 * pk_hard_cap(h, nrows) + 64; }
 static size_t ws_pktstart_off(const rtfe_handle *h, int64_t nrows) { return ws_pkqtile_off(h, nrows) + pk_qtile_bytes(h, nrows); }
 static size_t pk_tstart_bytes(const rtfe_handle *h, int64_t nrows) {      // tile offsets | chunk totals | chunk offsets | stream totals
    const size_t nl = (size_t)h->dev.nscreens * h->dev.ntrks, nch = (size_t)(pk_tiles_for(nrows) + 1023) / 1024;

@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          const uint32_t w0 = cur4.y, w1 = cur4.z;
          const int c32 = (int)c;
          const bool plain = !(w0 & kCrBad) && w1 != 0xffff8000u;
-         if (plain ? pos + W - 2 < c32 : ((w0 & kCrBad) && pos + kSfTile + W < c32)) return 0;      // its rows are behind the countdown for good
+         if ((w0 & kCrBad) ? pos + kSfTile + W < c32 : pos + W - 2 < c32) return 0;      // its rows are behind the countdown for good
          const int f = pos + (int)((w0 >> 12) & 63u), nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u);
          const bool top = !(w0 & 0x800u);
          const int val = (int)(int16_t)(w1 & 0xffffu);
@@ -340,6 +340,9 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
             if (getenv("RTFE_GAIN_WHY")) fprintf(stderr, "why: pc %d pos %d f %d fn %d nlead %d nsure %d a %d min_hi %d c %d limit %d plain %d\n", w.peakcount, pos, f, fn, nlead, nsure, a, w.min_hi, c32, limit32, (int)plain);
 #endif
             return 1; }
+#ifdef RTFE_CPU_EMUL
+         if (getenv("RTFE_GAIN_TRACE") && b == atoi(getenv("RTFE_GAIN_TRACE")) && wi == 0) fprintf(stderr, "F ev %u f %d %s pos %d c %d g %.6f\n", w.nevents, f, top ? "top" : "bot", pos, c32, g);
+#endif
          const float v = __uint_as_float(cur4.w);
          s_notes[nbuf][lane] = make_uint4((uint32_t)idx, __float_as_uint(g), __float_as_uint(w.v_avg_height), 0xffffffffu);
          ++nbuf; ++w.nevents;
@@ -400,6 +403,10 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
             if (u.f > best || u.f >= limit) { if (u.top) top_done = true; else bot_done = true; continue; }
             long long dr;
             const long long n = run_fire(w, u, j.eend, c, limit, W, S.sure_i, mv, dr);
+#ifdef RTFE_CPU_EMUL
+            if (getenv("RTFE_GAIN_TRACE") && b == atoi(getenv("RTFE_GAIN_TRACE")) && wi == 0 && w.nevents >= 4 && w.nevents <= 6)
+               fprintf(stderr, "   scan i %lld pos %lld f %lld %s nlead %d nsure %d ntail %d unk %d val %d -> n %lld dr %lld (c %lld)\n", j.i, u.pos, u.f, u.top ? "top" : "bot", u.nlead, u.nsure, u.ntail, (int)u.unknown, u.val, n == kNoRow ? -1 : n, dr == kNoRow ? -1 : dr, c);
+#endif
             if (dr < best_doubt) best_doubt = dr;
             if (n != kNoRow) {
                if (u.top) top_done = true; else bot_done = true;         // (runs of one kind are ordered by row)
@@ -434,6 +441,9 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
             e.left_distance = (uint8_t)ld;
             e.parmset = (uint8_t)pidx;
             ev[w.nevents] = e; }
+#ifdef RTFE_CPU_EMUL
+         if (getenv("RTFE_GAIN_TRACE") && b == atoi(getenv("RTFE_GAIN_TRACE")) && wi == 0) fprintf(stderr, "G ev %u row %lld %s ld %d pos %lld c %lld g %.6f rise %.4f\n", w.nevents, ndet - reset, u.top ? "top" : "bot", ld, u.pos, c, g, w.rise);
+#endif
          if (u.top) w.v_top = val; else w.v_bot = val;
          ++w.nevents; ++n_slow;
          agc_after_peak_m(w, cmode, agc_off, P, heights, u.top, t_peak);

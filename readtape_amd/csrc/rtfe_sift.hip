@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                         SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)(half ? h_hi : h_lo); hd.screen = (uint8_t)sc;
                         hard[hidx] = hd;
                         w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
-                     else { w0 = pk_w0(cpos, false, cpos + 1, 0, 1, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" - the chain that gets here gives up)
+                     else { w0 = pk_w0(cpos, false, cpos + 1, 0, cx.W - 2, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
                      st = 1; }
                   if (prof) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
                   if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                         SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)(half ? h_hi : h_lo); hd.screen = 0;
                         a.hard[hidx] = hd;
                         w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
-                     else { w0 = pk_w0(cpos, false, cpos + 1, 0, 1, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" - the chain that gets here gives up)
+                     else { w0 = pk_w0(cpos, false, cpos + 1, 0, cx.W - 2, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
                      st = 1; }
                   if (a.debug == 3) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
                   if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
@@ -859,7 +859,7 @@ __global__ void __launch_bounds__(64) k_sift_hard(const DevCfg *__restrict__ cfg
       if (nrec > 4) nrec = -1;
       for (int j = 0; j < nrec; ++j) ne += pk_nent(sk.w0[j], sk.w1[j]);
       if (nrec > 0 && 8 + 8 * nrec + 2 * ne > kSfOvfBytes) nrec = -1;
-      if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, 1, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs or margins than a slot holds: "minimum unknown" - the chain that gets here gives up)
+      if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, cx.W - 2, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs or margins than a slot holds: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
       *reinterpret_cast<int *>(slot) = nrec;
       if (nrec != 1) atomicAdd(&extra[((size_t)hd.tile * cfg.nscreens + hd.screen) * cfg.ntrks + hd.head], nrec - 1);      // the list's length in its stream (k_pscan)
       int e0 = 0;
