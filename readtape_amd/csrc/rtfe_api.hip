@@ -555,6 +555,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
       hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
                          (const uint32_t *)tstartp, (const uint32_t *)coffp, ptiles, ccap, crecp, erefp);
+      hipLaunchKernelGGL(k_prep2, dim3(nlists * ((h->num_cus * 8 + nlists - 1) / nlists)), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, crecp);
       t1(6, st); t0(1, st);
       if (stop_after < 2) { t1(1, st); t0(7, st); t1(7, st); t0(8, st); t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,

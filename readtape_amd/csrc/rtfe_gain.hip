@@ -78,7 +78,9 @@ __device__ __forceinline__ long long chain_stop(const DevCfg &cfg, const rtfe_bu
 // tile directory); k_prep: a wave per list copies its records over.
 // ------------------------------------------------------------------------------------------------
 // flags in CRec::w0 bits 0-10 (the tile-relative row of PeakRec::w0 is replaced by the absolute CRec::pos)
-enum { kCrBad = 1 };                      // the tile's list is not there (capacity)
+enum { kCrBad = 1,                        // the tile's list is not there (capacity)
+       kCrClear = 2 };                    // a record with a sure stretch (1..62 rows), its minimum known, and no other record's first row at or before the row
+                                          // its owner leaves the window at (pos + W): whatever fires in it fires before anything else can (k_prep's second pass)
 struct CRec { uint32_t pos, w0, w1; float volt; };
 
 // k_pscan1: a workgroup per chunk of 1024 tiles, a thread per tile: per stream the prefix within the chunk and the chunk's total;
@@ -153,6 +155,22 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
             crec[o] = c;
             eref[o] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(ebase + ie - ne)); }
          ebase += wave_last(ie); base += wave_last(ic); } } }
+
+// k_prep2: the kCrClear flags - a lane per record, its successor right behind it in the stream
+__global__ void __launch_bounds__(256) k_prep2(const DevCfg *__restrict__ cfgp, const uint32_t *__restrict__ ctot, long long ccap, CRec *__restrict__ crec) {
+   const DevCfg &cfg = *cfgp;
+   const int nlists = cfg.nscreens * cfg.ntrks;
+   const int nper = (int)gridDim.x / nlists;                             // workgroups per stream (the grid is a multiple of the streams)
+   {  const int sl = (int)blockIdx.x / nper, bx = (int)blockIdx.x - sl * nper;
+      const int W = cfg.screen[sl / cfg.ntrks].W;
+      const long long n = ctot[sl];
+      CRec *r = crec + (size_t)sl * ccap;
+      for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < n; i += (long long)nper * blockDim.x) {
+         const uint32_t w0 = r[i].w0, w1 = r[i].w1;
+         const int nsure = (int)((w0 >> 22) & 63u);
+         bool ok = !(w0 & kCrBad) && w1 != 0xffff8000u && (unsigned)(nsure - 1) < 62u;
+         if (ok && i + 1 < n) { const long long fn = (long long)r[i + 1].pos + (long long)((r[i + 1].w0 >> 12) & 63u); ok = fn > (long long)r[i].pos + W; }
+         if (ok) r[i].w0 = w0 | kCrClear; } } }
 
 // ------------------------------------------------------------------------------------------------
 // k_gain
@@ -316,6 +334,39 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       const float g_min = 0.005f * lsb / 249.0f;                         // below it the half-sample refinement's threshold outgrows the records' neighbour distances (254)
       auto step = [&](const uint4 cur4, const uint4 nxt4, const long long idx) -> int {
          if (idx >= src.iend) return 2;
+         if (steady) {
+            // ---- steady state, the common record: everything static about it is in its kCrClear flag ----
+            const int pos = (int)cur4.x, c32 = (int)c;
+            const uint32_t w0 = cur4.y;
+            if ((w0 & kCrBad) ? pos + kSfTile + W < c32 : pos + W - 2 < c32) return 0;      // its rows are behind the countdown for good
+            const int val = (int)(int16_t)(cur4.z & 0xffffu);
+            const bool top = !(w0 & 0x800u);
+            const int a = top ? val : -val;
+            if (!(w0 & kCrBad) && cur4.z != 0xffff8000u && amp_on && a <= w.min_lo) return 0;      // below the amplitude test for sure: passed over (see below)
+            const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
+            const float g = w.agc_gain;
+            if ((w0 & kCrClear) && c32 <= f && fl < limit32 && w.rise_hi <= S.sure_i && (!amp_on || a >= w.min_hi) && w.nevents < cap && g >= g_min) {
+               s_notes[nbuf][lane] = make_uint4((uint32_t)idx, __float_as_uint(g), __float_as_uint(w.v_avg_height), 0xffffffffu);
+               ++nbuf; ++w.nevents; ++w.peakcount;
+               c = pos + W + 1;
+               // g = alpha h / lastheight + (1 - alpha) g, clamped (src/decoder.c:505-512); the callback sees the heights of the peaks BEFORE this one (:587-590)
+               const float lastheight = w.v_lasttop - w.v_lastbot, v = __uint_as_float(cur4.w);
+               float g2 = g;
+               if (lastheight > 0) { g2 = alpha * (w.v_avg_height / lastheight) + beta * g; if (g2 > 2.0f) g2 = 2.0f; }
+               if (top) { w.v_top = v; w.v_lasttop = v; } else { w.v_bot = v; w.v_lastbot = v; }
+               w.agc_gain = g2;
+               // the integer bands around the thresholds of src/decoder.c:785-786 from a 1-ulp reciprocal (approx_thresholds: two more lsb of guard)
+               const float rg = fast_rcp(g2);
+               if (g2 > 0 && rg >= rg_min) {
+                  const int r = (int)(kr * rg), m = (int)(km * rg);
+                  w.rise_lo = r - 2; w.rise_hi = r + 3; w.min_lo = m - 2; w.min_hi = m + 3;
+                  w.thr_dirty = true;
+                  return 0; }
+               if (!(g2 > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
+               update_thresholds(w, P, lsb);                                 // thresholds near the screen's: exactly
+               if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; }
+               return 0; }
+            return 1; }
          const int pos = (int)cur4.x;
          const uint32_t w0 = cur4.y, w1 = cur4.z;
          const int c32 = (int)c;
@@ -347,25 +398,6 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          s_notes[nbuf][lane] = make_uint4((uint32_t)idx, __float_as_uint(g), __float_as_uint(w.v_avg_height), 0xffffffffu);
          ++nbuf; ++w.nevents;
          c = pos + W + 1;
-         if (steady) {
-            // g = alpha h / lastheight + (1 - alpha) g, clamped (src/decoder.c:505-512); the callback sees the heights of the peaks BEFORE this one (:587-590)
-            ++w.peakcount;
-            const float lastheight = w.v_lasttop - w.v_lastbot;
-            float g2 = g;
-            if (lastheight > 0) { g2 = alpha * (w.v_avg_height / lastheight) + beta * g; if (g2 > 2.0f) g2 = 2.0f; }
-            if (top) { w.v_top = v; w.v_lasttop = v; } else { w.v_bot = v; w.v_lastbot = v; }
-            w.agc_gain = g2;
-            // the integer bands around the thresholds of src/decoder.c:785-786 from a 1-ulp reciprocal (approx_thresholds: two more lsb of guard)
-            const float rg = fast_rcp(g2);
-            if (!(g2 > 0)) { w.flags |= RTFE_F_DETECTOR_FATAL; failed = true; why = 4; return 2; }      // src/decoder.c:782
-            if (rg < rg_min) {                                                 // thresholds near the screen's: exactly
-               update_thresholds(w, P, lsb);
-               if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; }
-               return 0; }
-            const int r = (int)(kr * rg), m = (int)(km * rg);
-            w.rise_lo = r - 2; w.rise_hi = r + 3; w.min_lo = m - 2; w.min_hi = m + 3;
-            w.thr_dirty = true;
-            return 0; }
          // the block decoder's whole AGC schedule (start-up, window AGC, density detection)
          if (top) w.v_top = v; else w.v_bot = v;
          agc_after_peak_m(w, cmode, agc_off, P, heights, top, 0.0);
@@ -373,7 +405,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          if (!approx_thresholds(w, P, lsb)) {
             update_thresholds(w, P, lsb);
             if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; } }
-         if (alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0 && !steady) {         // from here on the baseline is fixed
+         if (lean && alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) {         // from here on the baseline is fixed: the steady path above
             steady = true;
             const float hs = w.v_avg_height * 0.25f;
             kr = P.rise * hs * lsb; km = P.min_peak * hs * lsb;
@@ -390,7 +422,10 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
             if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; } }
          RecIt alive;
          it_open(alive, src, i);
-         while (!alive.end && alive.pos + W - 2 < c) it_next(alive, src);      // records (of an overflow slot, too) whose rows are behind the countdown
+         for (;;) {                                                        // records whose rows are behind the countdown (a list that is not there: its whole tile)
+            if (alive.end) { if (alive.bad && alive.pos + kSfTile + W < c) { alive.end = false; alive.bad = false; ++alive.i; it_land(alive, src); continue; } break; }
+            if (alive.pos + W - 2 >= c) break;
+            it_next(alive, src); }
          if (alive.end) { if (alive.bad) { failed = true; why = 1; } return 2; }
          long long best = kNoRow, best_doubt = kNoRow;
          bool have = false, best_top = false, top_done = false, bot_done = false;
