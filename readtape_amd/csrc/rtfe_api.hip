@@ -443,9 +443,12 @@ static size_t pk_extra_bytes(const rtfe_handle *h, int64_t nrows) { return h->de
 static size_t pk_eref_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * 4 + 255) & ~(size_t)255) : 0; }
 
 static size_t ws_pkextra_off(const rtfe_handle *h, int64_t nrows) { return ws_pkeref_off(h, nrows) + pk_eref_bytes(h, nrows); }
+// ... | the chains between k_gain (heads), k_gain_s (steady stretches) and k_gain (tails)
+static size_t ws_pkcst_off(const rtfe_handle *h, int64_t nrows) { return ws_pkextra_off(h, nrows) + pk_extra_bytes(h, nrows); }
+static size_t pk_cst_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(ChainSt) + 255) & ~(size_t)255) : 0; }
 
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pkextra_off(h, nrows) + pk_extra_bytes(h, nrows) + 256; }
+   return ws_pkcst_off(h, nrows) + pk_cst_bytes(h, nrows) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -566,9 +569,15 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (stop_after < 3) { t1(7, st); t0(8, st); t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);
-      hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                         scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
-                         (const unsigned char *)pkpool, ptiles);
+      ChainSt *cstp = reinterpret_cast<ChainSt *>(wsb + ws_pkcst_off(h, nrows));
+      // the chains: from the restart row until the baseline is fixed (k_gain, mode 0), the steady stretch (k_gain_s), whatever that stopped at (k_gain, mode 1)
+      for (int mode = 0; mode < 2; ++mode) {
+         hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+                            scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
+                            (const unsigned char *)pkpool, ptiles);
+         if (mode == 0)
+            hipLaunchKernelGGL(k_gain_s, dim3(h->num_cus * 4), dim3(64), 0, st, (const DevCfg *)h->d_dev, cstp, (long long)nrows, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp,
+                               d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap, ptiles); }
       t1(7, st); t0(8, st);
       if (stop_after < 4) { t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
@@ -680,7 +689,7 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
    if (hipMemcpy(&sc, d_workspace, sizeof sc, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
    out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.scr[3]; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
    for (int i = 0; i < 8; ++i) out[5 + i] = (int64_t)sc.why[i];
-   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)sc.scr[i];      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
+   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)(h->dev.debug == 4 ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
    return 0; }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

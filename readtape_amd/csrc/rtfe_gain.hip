@@ -209,7 +209,7 @@ __device__ __forceinline__ bool amp_pass(const Walker &w, const Run &u, float mv
    return u.top ? volt(u.val, mv) > w.reqmin : volt(u.val, mv) < -w.reqmin; }
 
 constexpr long long kNoRow = 0x7fffffffffffffffll;
-constexpr int kGainChunk = 16;      // records a lane steps through between two general steps (multiple of 4)
+constexpr int kGainChunk = 32;      // records a lane steps through between two general steps (multiple of 4)
 // first row >= c (and < limit) at which this run makes the detector fire, or kNoRow; doubt = first row >= c that the record cannot decide.
 // eend: entry e of the record lives at eend[-(e + 1)]
 __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, const uint16_t *eend, long long c, long long limit, int W, int sure_i, float mv, long long &doubt) {
@@ -261,7 +261,12 @@ __device__ __forceinline__ rtfe_event note_event(long long i, float g, float h) 
    u.w[0] = (uint32_t)i; u.w[1] = __float_as_uint(g); u.w[2] = __float_as_uint(h); u.w[3] = 0xffffffffu;
    return u.e; }
 
-__global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, long long nrows, long long row_base,
+// A chain between the kernels that walk it: k_gain (mode 0: from the burst's restart row until the baseline is fixed) -> k_gain_s (the
+// steady stretch: nothing but the common record) -> k_gain (mode 1: whatever k_gain_s stopped at, to the chain's end).
+enum { kChNone = 0, kChSteady = 1, kChGeneral = 2, kChDone = 3 };
+struct ChainSt { Walker w; float heights[10]; long long i, c; int status, pad; };
+
+__global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
                                              const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       const int ci = cbase + lane < nchains ? cbase + lane : nchains - 1;
       const int b = ci / nwalk;
       const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
-      const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady;
+      const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady && (mode == 0 || cst[ci].status == kChGeneral);
       const rtfe_burst B = bursts[b];
       // (the chain's constants by value: a reference into the configuration block would be loaded again - a vector load, the lanes'
       //  parameter sets differ - at every use, and each such load waits for everything in flight)
@@ -296,6 +301,10 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       for (int i = 0; i < 10; ++i) heights[i] = 0;
       // column rows: the detector's row n reads sample n - d.  Before c the window is filling on zone samples only.
       long long c = reset + W + max(trk, d) + 1 - d;
+      if (mode == 1 && active) {                                          // where k_gain_s stopped
+         w = cst[ci].w; c = cst[ci].c;
+         for (int i = 0; i < 10; ++i) heights[i] = cst[ci].heights[i];
+         update_thresholds(w, P, lsb); }
       const long long limit = stop - d;
       rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
       const unsigned int cap = B.event_cap;
@@ -310,6 +319,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       {  long long g0 = (c - W) / kSfTile; if (c - W < 0) g0 = 0; if (g0 >= ntiles) g0 = ntiles - 1;
          long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;       // first tile whose candidates all lie at or behind the limit
          i = stream_pos(tstart, coff, nlists, g0, sl);
+         if (mode == 1 && active) i = cst[ci].i;
          src.iend = ge < ntiles ? stream_pos(tstart, coff, nlists, ge, sl) : (long long)ctot[sl]; }
       const bool lean = cfg.pk_fast && cmode != RTFE_PE;                // (PE decides the end of its preamble from peak TIMES: the general step)
       const bool alpha_agc = !agc_off && P.agc_window == 0;           // steady state = the three-flop alpha filter
@@ -332,8 +342,19 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       bool steady = false;
       float kr = 0, km = 0, rg_min = 0;                                    // rise / min_peak thresholds in int16 units per unit of 1 / g; below rg_min = 1 / g they come near the screen's
       const float g_min = 0.005f * lsb / 249.0f;                         // below it the half-sample refinement's threshold outgrows the records' neighbour distances (254)
-      auto step = [&](const uint4 cur4, const uint4 nxt4, const long long idx) -> int {
+      // from here on the baseline is fixed: the steady path's constants
+      auto enter_steady = [&]() {
+         steady = true;
+         const float hs = w.v_avg_height * 0.25f;
+         kr = P.rise * hs * lsb; km = P.min_peak * hs * lsb;
+         // thresholds stay clear of the screen's while rise * hs / g >= 1.002 screen_rise_v (and the same for min_peak): a bound on 1 / g
+         rg_min = 0;
+         if (P.rise * hs > 0) rg_min = P.screen_rise_v * 1.002f / (P.rise * hs);
+         if (amp_on && P.min_peak * hs > 0) { const float b2 = P.screen_minpk_v * 1.002f / (P.min_peak * hs); if (b2 > rg_min) rg_min = b2; } };
+      if (lean && alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) enter_steady();      // (mode 1: a chain that comes back from k_gain_s)
+      auto step = [&](const int j, const long long idx) -> int {
          if (idx >= src.iend) return 2;
+         const uint4 cur4 = s_rec[j][lane];
          if (steady) {
             // ---- steady state, the common record: everything static about it is in its kCrClear flag ----
             const int pos = (int)cur4.x, c32 = (int)c;
@@ -367,6 +388,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
                if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; }
                return 0; }
             return 1; }
+         const uint4 nxt4 = s_rec[j + 1][lane];                             // (the record behind it: only the start-up path looks at it itself)
          const int pos = (int)cur4.x;
          const uint32_t w0 = cur4.y, w1 = cur4.z;
          const int c32 = (int)c;
@@ -405,14 +427,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          if (!approx_thresholds(w, P, lsb)) {
             update_thresholds(w, P, lsb);
             if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; } }
-         if (lean && alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) {         // from here on the baseline is fixed: the steady path above
-            steady = true;
-            const float hs = w.v_avg_height * 0.25f;
-            kr = P.rise * hs * lsb; km = P.min_peak * hs * lsb;
-            // thresholds stay clear of the screen's while rise * hs / g >= 1.001 screen_rise_v (and the same for min_peak): a bound on 1 / g
-            rg_min = 0;
-            if (P.rise * hs > 0) rg_min = P.screen_rise_v * 1.002f / (P.rise * hs);
-            if (amp_on && P.min_peak * hs > 0) { const float b2 = P.screen_minpk_v * 1.002f / (P.min_peak * hs); if (b2 > rg_min) rg_min = b2; } }
+         if (lean && alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) { enter_steady(); if (mode == 0) return 3; }      // (the steady stretch is k_gain_s's)
          return 0; };
       // ---- the general step (a lane that cannot take the fast path waits for the round's end: the wave pays for it once per round, not once per step) ----
       auto general = [&]() -> int {
@@ -487,6 +502,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
          if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; }
          c = u.pos + W + 1;
          i = alive.i;
+         if (!steady && lean && alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) enter_steady();
          return 1; };
       uint4 q[kGainChunk + 1];
       #pragma unroll
@@ -498,35 +514,174 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, lo
       auto put = [&]() {
          #pragma unroll
          for (int j = 0; j <= kGainChunk; ++j) s_rec[j][lane] = q[j]; };
-      int st2 = active ? 0 : 2;                                            // 0: in lock step, 1: waiting for the general step, 2: done
+      int st2 = active ? 0 : 2;                                            // 0: in lock step, 1: waiting for the general step, 2: done, 3: (mode 0) steady from here
+      bool handed = false;
       if (st2 == 0) fetch(i);
       put();
       if (st2 == 0) fetch(i + kGainChunk);
+      const bool prof = cfg.debug == 4 && lane == 0;
+      long long pc_steps = 0, pc_gen = 0, pc_bound = 0, pn_chunks = 0, pn_gen = 0;
       for (;;) {
+         long long tk0 = 0, tk1 = 0, tk2 = 0;
+         if (prof) tk0 = clock64();
          int jp = 0;                                                       // records of the chunk this lane is through with
          #pragma nounroll
          for (int j0 = 0; j0 < kGainChunk; j0 += 4) {
             #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-               if (st2 == 0) { st2 = step(s_rec[j0 + jj][lane], s_rec[j0 + jj + 1][lane], i + j0 + jj); if (st2 == 0) jp = j0 + jj + 1; }
+               if (st2 == 0) { st2 = step(j0 + jj, i + j0 + jj); if (st2 == 0 || st2 == 3) jp = j0 + jj + 1; }
             if (__ballot(st2 == 0) == 0) break; }
-         flush_notes();
          bool resync = false;
-         if (st2 == 1) { i += jp; st2 = general(); if (st2 != 2) st2 = 0; resync = true; }
+         if (prof) { tk1 = clock64(); pc_steps += tk1 - tk0; ++pn_chunks; if (__ballot(st2 == 1)) ++pn_gen; }
+         if (st2 == 1) { i += jp; flush_notes(); st2 = general(); if (st2 != 2) st2 = 0; resync = true; if (st2 == 0 && mode == 0 && steady) st2 = 3; }
          else if (st2 == 0) i += kGainChunk;
-         if (__ballot(st2 != 2) == 0) break;
+         if (st2 == 3) { i += jp; flush_notes(); handed = true; st2 = 2; }      // the baseline is fixed: the chain waits for k_gain_s
+         if (prof) { tk2 = clock64(); pc_gen += tk2 - tk1; }
+         if (__ballot(st2 != 2) == 0) { flush_notes(); break; }
          if (resync && st2 == 0) fetch(i);                                   // (a lane the general step moved: its chunk afresh - the wave waits for it)
          put();
-         if (st2 == 0) fetch(i + kGainChunk); }
+         if (st2 == 0) fetch(i + kGainChunk);
+         flush_notes();                                                     // (behind the loads: the wait for them at the next chunk's end finds the stores long done)
+         if (prof) pc_bound += clock64() - tk2; }
+      if (prof) { atomicAdd(&scratch->dbg2[0], (unsigned long long)pc_steps); atomicAdd(&scratch->dbg2[1], (unsigned long long)pc_gen); atomicAdd(&scratch->dbg2[2], (unsigned long long)pc_bound);
+                  atomicAdd(&scratch->dbg2[3], (unsigned long long)pn_chunks); atomicAdd(&scratch->dbg2[4], (unsigned long long)pn_gen); atomicAdd(&scratch->dbg2[5], 1ull); }
       // ---- publish ----
       if (!active) continue;
-      n_fast = w.nevents - n_slow;
+      if (handed && !failed) {                                             // (steady: everything the walker is, for k_gain_s)
+         ChainSt &cs = cst[ci];
+         cs.w = w; cs.i = i; cs.c = c; cs.status = kChSteady;
+         for (int k = 0; k < 10; ++k) cs.heights[k] = heights[k];
+         if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
+         continue; }
+      cst[ci].status = kChDone;
+      n_fast = w.nevents - n_slow - (mode == 1 ? cst[ci].w.nevents : 0u);
       if (n_fast) atomicAdd(&scratch->dbg[0], (unsigned long long)n_fast);
       if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
       if (failed) { atomicExch(&ctl[b].status, (int)kBurstNeedsFull); atomicAdd(&scratch->why[why & 7], 1ull); }
       counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = w.nevents < cap ? w.nevents : cap;
       chain_h[(size_t)b * nwalk + wi] = w.v_avg_height;
       if (w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW) atomicOr(&ctl[b].bflags, w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW); } }
+
+// ------------------------------------------------------------------------------------------------
+// k_gain_s: the steady stretch of every chain (NRZI / GCR, alpha-filter AGC: peakcount > 15, the baseline fixed), and nothing but the
+// common record - straight-line code, every decision a select.  A lane per chain, 32 records at a time through LDS (the next 32 in
+// flight in registers), its notes through LDS too.  Per record: its rows are behind the countdown -> on; its extreme is below the
+// amplitude test for sure -> on (it cannot fire while the thresholds stand, and they stand until something fires - behind which all its
+// rows are blind); kCrClear and the countdown over before its first row, the thresholds inside the band its sure stretch stands for,
+// amplitude clear -> it fires: note (k_emit finds the row), g = alpha h / lastheight + (1 - alpha) g (src/decoder.c:505-512), the
+// integer bands around the thresholds of src/decoder.c:785-786 from 1 / g.  Anything else: the lane stops there and k_gain (mode 1)
+// takes the chain from that record on.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGsChunk = 32;
+__global__ void __launch_bounds__(64) k_gain_s(const DevCfg *__restrict__ cfgp, ChainSt *__restrict__ cst, long long nrows,
+                                               const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, const BurstCtl *__restrict__ ctl,
+                                               uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
+                                               const CRec *__restrict__ crec, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
+                                               long long ccap, long long ntiles) {
+   __shared__ uint4 s_notes[kGsChunk][64];
+   __shared__ uint4 s_rec[kGsChunk][64];
+   const DevCfg &cfg = *cfgp;
+   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks, nlists = cfg.nscreens * ntrks;
+   const int lane = threadIdx.x;
+   const float lsb = cfg.lsb_per_volt;
+   const int nchains = scratch->nbursts * nwalk;
+   for (int cbase = blockIdx.x * 64; cbase < nchains; cbase += gridDim.x * 64) {
+      const int ci = cbase + lane < nchains ? cbase + lane : nchains - 1;
+      const int b = ci / nwalk;
+      const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
+      const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady && cst[ci].status == kChSteady;
+      const rtfe_burst B = bursts[b];
+      const DevParm P = cfg.parm[pidx];
+      const int sure_i = cfg.screen[P.screen].sure_i;
+      const int W = P.W, d = cfg.skew[trk], head = cfg.trk_to_head[trk];
+      const long long stop = chain_stop(cfg, bursts, ctl, b, scratch->nbursts_total, nrows);
+      const long long limit = stop - d;
+      const int limit32 = limit > 0x7ffffff0ll ? 0x7ffffff0 : (int)limit;
+      rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
+      const unsigned int cap = B.event_cap;
+      const int sl = P.screen * ntrks + head;
+      const uint4 *rec4 = reinterpret_cast<const uint4 *>(crec + (size_t)sl * ccap);
+      long long iend;
+      {  long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;
+         iend = ge < ntiles ? stream_pos(tstart, coff, nlists, ge, sl) : (long long)ctot[sl]; }
+      // the chain as k_gain (mode 0) left it
+      long long i = active ? cst[ci].i : iend;
+      int c = active ? (int)cst[ci].c : 0;
+      float g = cst[ci].w.agc_gain, vlt = cst[ci].w.v_lasttop, vlb = cst[ci].w.v_lastbot;
+      const float h = cst[ci].w.v_avg_height;
+      unsigned int nev = cst[ci].w.nevents;
+      const unsigned int nev0 = nev;
+      int rise_hi = cst[ci].w.rise_hi, min_lo = cst[ci].w.min_lo, min_hi = cst[ci].w.min_hi;
+      const bool amp_on = P.min_peak != 0;
+      const float alpha = P.agc_alpha, beta = 1 - P.agc_alpha;
+      const float hs = h * 0.25f;
+      const float kr = P.rise * hs * lsb, km = P.min_peak * hs * lsb;
+      float rg_min = 0;
+      if (P.rise * hs > 0) rg_min = P.screen_rise_v * 1.002f / (P.rise * hs);
+      if (amp_on && P.min_peak * hs > 0) { const float b2 = P.screen_minpk_v * 1.002f / (P.min_peak * hs); if (b2 > rg_min) rg_min = b2; }
+      const float g_min = 0.005f * lsb / 249.0f;
+      // run: 1 = in lock step; 0 = stopped at record i (k_gain, mode 1, goes on there) or at the chain's end
+      bool run = active, done = false;
+      uint4 q[kGsChunk];
+      #pragma unroll
+      for (int j = 0; j < kGsChunk; ++j) q[j] = make_uint4(0, kCrBad, 0, 0);
+      if (run) {
+         #pragma unroll
+         for (int j = 0; j < kGsChunk; ++j) if (i + j < iend) q[j] = rec4[i + j]; }
+      for (;;) {
+         #pragma unroll
+         for (int j = 0; j < kGsChunk; ++j) s_rec[j][lane] = q[j];
+         if (run) {                                                          // the next chunk travels while this one is stepped through
+            #pragma unroll
+            for (int j = 0; j < kGsChunk; ++j) if (i + kGsChunk + j < iend) q[j] = rec4[i + kGsChunk + j]; }
+         int nbuf = 0, adv = 0;
+         #pragma unroll 4
+         for (int j = 0; j < kGsChunk; ++j) {
+            const uint4 r = s_rec[j][lane];
+            const bool inr = run && i + j < iend;
+            const int pos = (int)r.x;
+            const uint32_t w0 = r.y;
+            const bool bad = w0 & kCrBad;
+            const bool dead = bad ? pos + kSfTile + W < c : pos + W - 2 < c;
+            const int val = (int)(int16_t)(r.z & 0xffffu);
+            const bool top = !(w0 & 0x800u);
+            const int a = top ? val : -val;
+            const bool ampdead = !bad && r.z != 0xffff8000u && amp_on && a <= min_lo;
+            const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
+            const bool fire = (w0 & kCrClear) && c <= f && fl < limit32 && rise_hi <= sure_i && (!amp_on || a >= min_hi) && nev < cap && g >= g_min;
+            const float lh = vlt - vlb, v = __uint_as_float(r.w);
+            float g2 = alpha * (h / lh) + beta * g;
+            g2 = g2 > 2.0f ? 2.0f : g2;
+            g2 = lh > 0 ? g2 : g;
+            const float rg = fast_rcp(g2);
+            const bool ok = inr && !dead && !ampdead && fire && g2 > 0 && rg >= rg_min;
+            if (ok) s_notes[nbuf][lane] = make_uint4((uint32_t)(i + j), __float_as_uint(g), __float_as_uint(h), 0xffffffffu);
+            nbuf += ok ? 1 : 0; nev += ok ? 1u : 0u;
+            c = ok ? pos + W + 1 : c;
+            vlt = ok && top ? v : vlt; vlb = ok && !top ? v : vlb;
+            g = ok ? g2 : g;
+            const int rr = (int)(kr * rg), mm = (int)(km * rg);
+            rise_hi = ok ? rr + 3 : rise_hi; min_lo = ok ? mm - 2 : min_lo; min_hi = ok ? mm + 3 : min_hi;
+            const bool on = inr && (dead || ampdead || ok);
+            if (run && !on) { run = false; done = i + j >= iend; adv = j; }
+            }
+         if (run) adv = kGsChunk;
+         // the notes leave; the lanes still running move on a chunk
+         #pragma unroll 4
+         for (int j = 0; j < kGsChunk; ++j) if (j < nbuf) reinterpret_cast<uint4 *>(ev)[nev - (unsigned)nbuf + (unsigned)j] = s_notes[j][lane];
+         i += adv;
+         if (__ballot(run) == 0) break; }
+      if (!active) continue;
+      // ---- the chain's end: publish; or hand the rest to k_gain (mode 1) ----
+      ChainSt &cs = cst[ci];
+      if (nev > nev0) atomicAdd(&scratch->dbg[0], (unsigned long long)(nev - nev0));
+      if (done) {
+         cs.status = kChDone;
+         counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = nev < cap ? nev : cap;
+         chain_h[(size_t)b * nwalk + wi] = h; }
+      else {
+         cs.w.agc_gain = g; cs.w.v_lasttop = vlt; cs.w.v_lastbot = vlb; cs.w.v_top = vlt; cs.w.v_bot = vlb;
+         cs.w.peakcount += (int)(nev - nev0); cs.w.nevents = nev; cs.i = i; cs.c = c; cs.status = kChGeneral; } } }
 
 // ------------------------------------------------------------------------------------------------
 // k_emit: the events the fast path noted -> the events the reference's callbacks see.  One workgroup per chain at a time,
