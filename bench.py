@@ -6,8 +6,8 @@
 
 Workload at N = 1 (BASELINE.json configs[1], "C2"): synthetic 9-track 800 BPI NRZI, 781.25 kHz,
 1e8 sample instants (1.8 GB of interleaved int16, resident in HBM before the timed region),
-1 parameter set.  One "step" = one full pass of the hot path over that tape:
-k_quiet -> k_bursts -> k_decode, events written to HBM.  Metric = sample instants per second
+1 parameter set.  One "step" = one full pass of the hot path over that tape (peak path: k_sift -> k_prep -> k_bursts -> k_gain ->
+k_gain_s -> k_emit -> k_decode for whatever the chains gave up), events written to HBM.  Metric = sample instants per second
 (the reference's own unit: "N samples were processed", src/readtape.c:2024), whole job.
 
 N > 1: the sample timeline is time-sharded — every rank holds its own 1e8-row shard (weak scaling);
@@ -287,21 +287,16 @@ def main():
         nevents_all, rows_all = nevents, nrows
     if rank == 0:
         for k in kms: kms[k] /= max(args.steps, 1)
-        if conf["find_zeros"]:                       # -zeros scans run k_zeros in the timing slot of the burst-head pass
-            kms = {("k_zeros" if k == "k_decode_head" else k): v for k, v in kms.items()}
-        # the dominant kernel.  On the record path the burst heads run BESIDE k_screen on a stream of their own (rtfe_scan forks and
-        # joins): their events bracket the time they shared the device with it, not work of their own (0.36 ms when run in line)
-        # - they are never the dominant kernel there.
-        cand = {k: v for k, v in kms.items() if not (k == "k_decode_head" and kms.get("k_screen", 0) > 0.5 * v and kms.get("k_screen", 0) > 0.1)}
-        dom = max(cand, key=cand.get)
+        # the dominant span: all spans of a scan run in line on one stream; each is bracketed by its own pair of HIP events there
+        dom = max(kms, key=kms.get)
         alg_bytes = 2 * cfg.ntrks * nrows + 16 * nevents        # 18 B per sample instant + 16 B per event
         achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         traffic = None
         try:                                         # HBM bytes per launch from the committed rocprofv3 --pmc passes
             own = os.path.join(ROOT, "profiles", f"pmc_{args.config}.json")
             pm = json.load(open(own if os.path.exists(own) else os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if args.config == pm.get("config", "C2") and dom in pm and abs(pm["workload_rows"] - nrows) < 0.01 * nrows:
-                traffic = pm[dom]["fetch_bytes"] + pm[dom]["write_bytes"]
+            if args.config == pm.get("config", "C2") and dom in pm and abs(pm["workload_rows"] - nrows) < 0.01 * nrows:      # (tools/gpu_traffic.sh wrote it)
+                traffic = (pm[dom]["fetch_bytes"] + pm[dom]["write_bytes"]) * len(frags)      # (per scan in the file; a step = len(frags) scans)
         except Exception:
             pass
         line = {

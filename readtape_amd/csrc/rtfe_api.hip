@@ -1,6 +1,6 @@
 // rtfe_api.hip — host side of the C ABI declared in include/rt_frontend.h (librtfe.so).
 // Validates the configuration, derives window widths / thresholds exactly as the reference does
-// (src/readtape.c:1402,1455-1457; src/decoder.c:448-449) and launches the three kernels.
+// (src/readtape.c:1402,1455-1457; src/decoder.c:448-449) and launches the kernels of a scan.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
@@ -14,7 +14,6 @@
 
 #include "rtfe_sift.hip"      // single translation unit: kernels + host API
 #include "rtfe_kernels.hip"
-#include "rtfe_lwalk.hip"
 #include "rtfe_zeros.hip"
 #include "rtfe_ww.hip"
 #include "rtfe_gain.hip"
@@ -39,13 +38,7 @@ struct rtfe_handle {
    int num_cus;
    int timing;
    hipEvent_t ev0[12], ev1[12];          // start / stop of each kernel of the last scan (on the stream it ran on)
-   int screen_lds_bytes;
-   int walk_lds_bytes;
    int zeros_kernel;                   // -zeros scans run k_zeros (RTFE_ZEROS_KERNEL=0: k_decode's zero-crossing mode, kept for tests)
-   int lane_walk;                      // the record walk runs one lane per walker (k_lwalk) where that fits; RTFE_LWALK=0/1
-   hipStream_t side;                   // the burst heads run beside k_screen (both only need k_bursts' table): RTFE_OVERLAP_HEADS=0 puts them back in line
-   hipEvent_t ev_fork, ev_join;
-   int overlap_heads;
 };
 
 static thread_local char g_err[512] = "";
@@ -83,10 +76,14 @@ static sfs_kernel_t sf_special(const DevCfg &d) { return (d.nscreens == 1 && d.s
 extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
-// the kernels of one rtfe_scan, in launch order (k_decode runs twice: burst heads, then whatever k_walk gave back)
-// (the peak-record path fills k_peaks [quiet map included], k_bursts, k_chain [k_zones + k_chain + k_publish] and k_decode_resume [bursts redone on the samples])
-static const char *KNAMES[] = {"k_quiet", "k_bursts", "k_screen", "k_decode_head", "k_walk", "k_decode_resume", "k_sift", "k_gain", "k_emit"};
-constexpr int kNumKernels = 9;
+// The timed spans of one rtfe_scan (rtfe_kernel_ms), in launch order.  The peak path (NRZI peak detection) runs
+//   k_sift | k_prep [k_qpack, k_sift_hard, k_pscan1/2, k_prep, k_prep2] | k_bursts | k_gain [k_zones, the chains' heads] | k_gain_s |
+//   k_gain_tail | k_emit [k_emit, k_publish] | k_decode [the bursts the chains gave up, on the samples]
+// the sample path (PE, GCR, differentiated peaks, density detection, parameter-set sweeps with too many widths) k_quiet | k_bursts | k_decode,
+// -zeros k_quiet | k_bursts | k_zeros.  A span a scan does not run reads 0.
+static const char *KNAMES[] = {"k_quiet", "k_sift", "k_prep", "k_bursts", "k_gain", "k_gain_s", "k_gain_tail", "k_emit", "k_decode", "k_zeros"};
+enum { kTQuiet, kTSift, kTPrep, kTBursts, kTGain, kTGainS, kTGainTail, kTEmit, kTDecode, kTZeros };
+constexpr int kNumKernels = 10;
 extern "C" int rtfe_kernel_count(void) { return kNumKernels; }
 extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < kNumKernels) ? KNAMES[i] : ""; }
 
@@ -105,9 +102,9 @@ extern "C" int rtfe_create(const rtfe_config *c, rtfe_handle **out) {
    if (rc != 0) return rc;
    // The sample path (PE, GCR, parameter-set sweeps with several window widths) keeps a tile, its screen maps and its walkers in
    // LDS: with 512-row tiles a sweep's workgroup can be the only one on its CU.  Shorter tiles that let more workgroups reside win
-   // (C4: 98 KB -> 75 KB, one -> two per CU, +35 %); the record path and -zeros have their own tile sizes.
+   // (C4: 98 KB -> 75 KB, one -> two per CU, +35 %); the peak path and -zeros have their own tile sizes.
    // (only then: where several workgroups already share a CU the longer tile is better - GCR, one set: 18.4 vs 22.9 ms per 5e7 rows)
-   if (!getenv("RTFE_TILE_ROWS") && !h->dev.record_path && !h->dev.find_zeros && h->dev.mode != RTFE_WW && sample_path_workgroups_per_cu(h) == 1) {
+   if (!getenv("RTFE_TILE_ROWS") && !h->dev.find_zeros && h->dev.mode != RTFE_WW && sample_path_workgroups_per_cu(h) == 1) {
       rtfe_handle *h2 = nullptr;
       if (create_impl(c, &h2, kMarginRows) == 0) {
          if (sample_path_workgroups_per_cu(h2) > sample_path_workgroups_per_cu(h)) { rtfe_destroy(h); h = h2; }
@@ -217,12 +214,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    int gap = c->gap_min_samples > 0 ? c->gap_min_samples : 32 * (spb > 0 ? spb : 1);
    if (gap < kMarginRows + 128) gap = kMarginRows + 128;
    d.gap_chunks = (gap + kChunkRows - 1) / kChunkRows + 1;                 // quiet-map chunks are groups of 64 rows
-   d.seg_tiles = 48;                                                  // the record walk of a long block runs as concurrent segments of 48 tiles
-   d.seg_warm = kSegWarmup;
    d.zc_parallel = 1;
-   d.record_path = !d.find_zeros && d.mode == RTFE_NRZI;
-   if (const char *e = getenv("RTFE_RECORD_PATH")) d.record_path = !d.find_zeros && atoi(e) != 0;
-   if (d.agc_off || d.differentiate) d.record_path = 0;               // density detection / differentiated peaks: the sample path
    if (const char *e = getenv("RTFE_ZC_PARALLEL")) d.zc_parallel = atoi(e) != 0;
    {  // rows a -zeros sub-segment starts early from a fresh state: two bit cells hold a confirmed crossing in each direction wherever
       // the signal is live; where that is not enough the join check sees it and the sub-segment is run again (exact either way)
@@ -230,9 +222,6 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       int w = ((int)(2.0f * spbw) + 7) & ~7;
       d.zc_warm = w < 16 ? 16 : (w > 64 ? 64 : w); }
    if (const char *e = getenv("RTFE_ZC_WARM")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= 64) d.zc_warm = v; }
-   if (const char *e = getenv("RTFE_SEG_WARMUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) d.seg_warm = v; }
-   if (const char *e = getenv("RTFE_SEG_TILES")) { const int v = atoi(e); d.seg_tiles = v <= 0 ? 0 : v; }
-   if (d.seg_tiles > 0 && d.seg_tiles < d.seg_warm) d.seg_tiles = d.seg_warm;
    d.tail_rows = 48 * (spb > 0 ? spb : 1);                              // 48 bit cells of silence: every format has ended its block (NRZI ~10, PE 2.5, GCR 6)
    if (const char *e = getenv("RTFE_TAIL_ROWS")) d.tail_rows = atoi(e);   // (tests: 0 = walk the whole gap)
    d.cap_frac = c->events_per_sample_cap > 0 ? c->events_per_sample_cap : 0.125f;
@@ -244,7 +233,6 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       if (tr < kMarginRows) tr = kMarginRows;
       if (tr > kMaxTileRows) tr = kMaxTileRows;
       d.tile_rows = tr; }
-   d.seg_evcap = (int)((float)d.seg_tiles * (float)d.tile_rows * d.cap_frac) + 16;
    {
       int wmax = 0;
       for (int sidx = 0; sidx < d.nscreens; ++sidx) if (d.screen[sidx].W > wmax) wmax = d.screen[sidx].W;
@@ -254,9 +242,12 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
    d.cut = getenv("RTFE_CUT") ? atoi(getenv("RTFE_CUT")) : 0;
-   {  // the peak path (k_sift -> k_gain -> k_emit): peak detection on the undifferentiated signal
-      d.peak_path = 0;
-      if (const char *e = getenv("RTFE_PEAK_PATH")) d.peak_path = !d.find_zeros && !d.differentiate && atoi(e) != 0;
+   {  // The peak path (k_sift -> k_gain -> k_emit): peak detection on the undifferentiated signal.  It pays where flux transitions are a
+      // bit cell apart (NRZI): most peaks then have the window to themselves and the chains stay on their steady path.  PE and GCR put
+      // a top and a bottom into one window; their bursts take the sample path (k_decode) - RTFE_PEAK_PATH=0/1 overrides (tests keep both
+      // paths covered for every format).
+      d.peak_path = !d.find_zeros && !d.differentiate && d.mode == RTFE_NRZI;
+      if (const char *e = getenv("RTFE_PEAK_PATH")) d.peak_path = !d.find_zeros && !d.differentiate && d.mode != RTFE_WW && atoi(e) != 0;
       d.pk_fast = 1;
       if (const char *e = getenv("RTFE_GAIN_FAST")) d.pk_fast = atoi(e) != 0;
       const int wmax = sf_wmax(d);
@@ -284,40 +275,20 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       d.rec_cap = rc > 64 ? 64 : (rc < 8 ? 8 : rc);
       // deferred detections per walker and tile (beyond that they are finished on the spot) - sized below, once the rest of
       // k_decode's LDS is known, so that one more workgroup fits a CU where a smaller buffer buys that
-      if (const char *e = getenv("RTFE_REC_CAP")) { const int v = atoi(e); if (v >= 4 && v <= d.rec_cap) d.rec_cap = v; }      // (experiments: LDS per k_decode workgroup)
-      d.run_cap = d.tile_rows / 2 < 64 ? 64 : d.tile_rows / 2;
-      // LDS of k_walk, sized for a typical tile (its lists go through LDS in groups, so a dense tile only costs time):
-      // peaks per track per tile from the bit cell, ~4.75 units per run of W<=13 rows plus as much again for runs that
-      // do not fire; detections per walker per tile bounded by the peak count
-      const float spbf = 1.0f / (bpi_s * c->ips * d.sample_deltat);
-      const float ppb = c->mode == RTFE_PE ? 1.5f : 0.6f;                 // flux transitions per bit cell, typical
-      int peaks = (int)((float)d.tile_rows / (spbf > 1 ? spbf : 1) * ppb) + 4;
-      int lu = (int)((float)(d.nscreens * c->ntrks) * (float)peaks * 3.2f);
-      if (lu < d.run_cap) lu = d.run_cap;                               // one list always fits
-      if (lu > 1536) lu = 1536;
-      d.lds_units = (lu + 63) & ~63;
-      d.pm_cap = d.lds_units / 2 * ((c->nparmsets + d.nscreens - 1) / d.nscreens);
-      int r16 = (int)((float)d.tile_rows / (spbf > 1 ? spbf : 1) * (c->mode == RTFE_PE ? 2.0f : 1.0f)) + 6;      // no more flux transitions than that fit a tile
-      const int r16max = (40 * 1024) / (nwalk * 16);                    // (parameter-set sweeps: many walkers, fewer bursts resident)
-      if (r16 > r16max) r16 = r16max;
-      d.rec_cap16 = r16 > 64 ? 64 : (r16 < 8 ? 8 : r16);
-      // test knobs (tests/ only): force the rare paths - lists through LDS in several groups, tiles handed back to k_decode
-      if (getenv("RTFE_LDS_UNITS")) { int v = atoi(getenv("RTFE_LDS_UNITS")); if (v >= d.run_cap && v <= 1536) { d.lds_units = v & ~63; d.pm_cap = d.lds_units / 2 * ((c->nparmsets + d.nscreens - 1) / d.nscreens); } }
-      if (getenv("RTFE_REC_CAP16")) { int v = atoi(getenv("RTFE_REC_CAP16")); if (v >= 2 && v <= d.rec_cap16) d.rec_cap16 = v; } }
+      if (const char *e = getenv("RTFE_REC_CAP")) { const int v = atoi(e); if (v >= 4 && v <= d.rec_cap) d.rec_cap = v; } }      // (experiments: LDS per k_decode workgroup)
    if (d.find_zeros) d.rec_cap = 8;                                   // (the zero-crossing walkers store their events at once)
    if (!d.find_zeros) {
       // k_decode is latency bound: workgroups per CU are what counts.  A smaller record buffer is taken only if it lets one more workgroup reside.
-      auto per_cu = [&](int rc) { DevCfg t = d; t.rec_cap = rc; return (160 * 1024) / ((int)lds_layout(t, true).total + 64 + 5500); };      // (static LDS ~ 4 KB, allocation granularity, margin)
+      auto per_cu = [&](int rc) { DevCfg t = d; t.rec_cap = rc; return (160 * 1024) / ((int)lds_layout(t).total + 64 + 5500); };      // (static LDS ~ 4 KB, allocation granularity, margin)
       int best = d.rec_cap;
       for (int rc = d.rec_cap; rc >= 8; --rc) if (per_cu(rc) > per_cu(best)) best = rc;
       d.rec_cap = best; }
-   h->lds_bytes = (int)lds_layout(d, true).total + 64;
-   h->screen_lds_bytes = (int)lds_layout(d, false).total + 64;
+   h->lds_bytes = (int)lds_layout(d).total + 64;
    if (h->lds_bytes > 160 * 1024 - 2048) { delete h; return fail(-14, "configuration needs %d bytes of LDS", h->lds_bytes); }
    if (getenv("RTFE_VERBOSE")) {
-      const LdsLayout Ld = lds_layout(d, true);
-      fprintf(stderr, "rtfe: LDS k_decode %d (tile..bits %u, bits..ldpos %u, ldpos..heights %u, recs %u, walkers %u) k_screen %d\n", h->lds_bytes, Ld.bits, Ld.ldpos - Ld.bits,
-              Ld.heights - Ld.ldpos, Ld.nrec - Ld.recs, Ld.walkers_next - Ld.walkers, h->screen_lds_bytes);
+      const LdsLayout Ld = lds_layout(d);
+      fprintf(stderr, "rtfe: LDS k_decode %d (tile..bits %u, bits..ldpos %u, ldpos..heights %u, recs %u, walkers %u)\n", h->lds_bytes, Ld.bits, Ld.ldpos - Ld.bits,
+              Ld.heights - Ld.ldpos, Ld.nrec - Ld.recs, Ld.fdiff - Ld.walkers);
       fprintf(stderr, "rtfe: peak path %d, k_sift LDS %d (halo %d/%d rows, slots %d bytes, %d vectors per thread)\n", d.peak_path, d.pk_lds, d.pk_hl, d.pk_hr, d.pk_slot, sf_nv(d));
       for (int sidx = 0; sidx < d.nscreens; ++sidx) fprintf(stderr, "rtfe: screen %d W %d rise_i %d minpk_i %d sure_i %d\n", sidx, d.screen[sidx].W, d.screen[sidx].rise_i, d.screen[sidx].minpk_i, d.screen[sidx].sure_i); }
    hipDeviceProp_t prop;
@@ -327,17 +298,9 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (hipMalloc(&h->d_dev, sizeof(DevCfg)) != hipSuccess) { delete h; return fail(-21, "hipMalloc failed"); }
    if (hipMemcpy(h->d_dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->d_dev); delete h; return fail(-22, "hipMemcpy failed"); }
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen), hipFuncAttributeMaxDynamicSharedMemorySize, h->screen_lds_bytes);
-   h->walk_lds_bytes = (int)lds_layout_walk(d).total + 64;
    h->zeros_kernel = getenv("RTFE_ZEROS_KERNEL") ? atoi(getenv("RTFE_ZEROS_KERNEL")) != 0 : 1;
    if (d.ntrks * (d.tile_rows / 64) > 128) h->zeros_kernel = 0;      // (its workgroup is two waves)
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zeros), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout_zeros(d).total + 64);
-   h->lane_walk = getenv("RTFE_LWALK") ? atoi(getenv("RTFE_LWALK")) != 0 : 0;      // (measured: no faster than k_walk)
-   h->overlap_heads = getenv("RTFE_OVERLAP_HEADS") ? atoi(getenv("RTFE_OVERLAP_HEADS")) != 0 : 1;
-   h->side = nullptr;
-   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, h->walk_lds_bytes);
-   if (c->nparmsets * c->ntrks <= 32 && (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16 <= 150 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lwalk), hipFuncAttributeMaxDynamicSharedMemorySize, (64 / (c->nparmsets * c->ntrks)) * d.lds_units * 16);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
    if (sf_special(d)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_special(d)), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
@@ -365,7 +328,6 @@ extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
    if (h->timing) for (int i = 0; i < kNumKernels; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
-   if (h->side) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->side); }
    (void)hipFree(h->d_dev);
    delete h; }
 
@@ -378,38 +340,16 @@ static long long nwords_for(const rtfe_handle *h, int64_t nrows) {
    return (nchunks + 63) / 64 + 1; }
 
 static long long ntiles_for(const rtfe_handle *h, int64_t nrows) { return (nrows + h->dev.tile_rows - 1) / h->dev.tile_rows; }
-static long long pool_cap_for(const rtfe_handle *h, int64_t nrows) {       // a fixed slot of run_cap records per (tile, screen, track)
-   return ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * h->dev.run_cap; }
-// workspace: [0,kScratchBytes) scratch | quiet words | dead-tile bitmap | tile directory | run pool
-static size_t ws_dead_off(const rtfe_handle *h, int64_t nrows) { return (kScratchBytes + (size_t)nwords_for(h, nrows) * 8 + 255) & ~(size_t)255; }
-static size_t ws_dir_off(const rtfe_handle *h, int64_t nrows) { return (ws_dead_off(h, nrows) + (size_t)((ntiles_for(h, nrows) + 31) / 32) * 4 + 255) & ~(size_t)255; }
-static size_t ws_pool_off(const rtfe_handle *h, int64_t nrows) {
-   return (ws_dir_off(h, nrows) + (size_t)ntiles_for(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(TileDir) + 255) & ~(size_t)255; }
+// workspace: [0,kScratchBytes) scratch | quiet words | burst control blocks | the peak path's pieces
+static long long pk_tiles_for(int64_t nrows) { return (nrows + kSfTile - 1) / kSfTile; }
+static size_t ws_ctl_off(const rtfe_handle *h, int64_t nrows) { return (kScratchBytes + (size_t)nwords_for(h, nrows) * 8 + 255) & ~(size_t)255; }
 
 extern "C" int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows) {
    return (nrows / kChunkRows) / h->dev.gap_chunks + 4; }
 
-// ... | burst control blocks | walker states (hand-over between k_decode and k_walk)
-static size_t ws_ctl_off(const rtfe_handle *h, int64_t nrows) {
-   return (ws_pool_off(h, nrows) + (size_t)pool_cap_for(h, nrows) * sizeof(CandUnit) + 255) & ~(size_t)255; }
-static size_t ws_state_off(const rtfe_handle *h, int64_t nrows) {
-   return (ws_ctl_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * sizeof(BurstCtl) + 255) & ~(size_t)255; }
-
-// ... | segment table (per burst) | segment -> burst | segment status | segment start states | segment end states
-static long long max_segs_for(const rtfe_handle *h, int64_t nrows) {
-   return h->dev.seg_tiles > 0 ? ntiles_for(h, nrows) / h->dev.seg_tiles + rtfe_max_bursts(h, nrows) + 8 : 0; }
-static size_t ws_segtab_off(const rtfe_handle *h, int64_t nrows) {
-   return (ws_state_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
-static size_t ws_segburst_off(const rtfe_handle *h, int64_t nrows) { return (ws_segtab_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * sizeof(SegTab) + 255) & ~(size_t)255; }
-static size_t ws_segstat_off(const rtfe_handle *h, int64_t nrows) { return (ws_segburst_off(h, nrows) + (size_t)max_segs_for(h, nrows) * 4 + 255) & ~(size_t)255; }
-static size_t ws_segstart_off(const rtfe_handle *h, int64_t nrows) { return (ws_segstat_off(h, nrows) + (size_t)max_segs_for(h, nrows) * 4 + 255) & ~(size_t)255; }
-static size_t ws_segend_off(const rtfe_handle *h, int64_t nrows) {
-   return (ws_segstart_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
-
 // ... | peak path: directory of the tiles' lists | per-chain baseline (k_gain -> k_emit) | record pool
-static long long pk_tiles_for(int64_t nrows) { return (nrows + kSfTile - 1) / kSfTile; }
 static size_t ws_pkdir_off(const rtfe_handle *h, int64_t nrows) {
-   return (ws_segend_off(h, nrows) + (size_t)max_segs_for(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(WalkState) + 255) & ~(size_t)255; }
+   return (ws_ctl_off(h, nrows) + (size_t)rtfe_max_bursts(h, nrows) * sizeof(BurstCtl) + 255) & ~(size_t)255; }
 static size_t pk_dir_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)(pk_tiles_for(nrows) + 1) * h->dev.nscreens * h->dev.ntrks * sizeof(PeakDir) + 255) & ~(size_t)255; }
 static size_t pk_chain_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(float) + 255) & ~(size_t)255; }
 static size_t ws_pkchain_off(const rtfe_handle *h, int64_t nrows) { return ws_pkdir_off(h, nrows) + (h->dev.peak_path ? pk_dir_bytes(h, nrows) : 0); }
@@ -475,22 +415,10 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    BurstScratch *scratch = reinterpret_cast<BurstScratch *>(d_workspace);
    unsigned long long *qwords = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_workspace) + kScratchBytes);
    int grid = (int)(nwords < (long long)h->num_cus * 8 ? nwords : (long long)h->num_cus * 8);
-   unsigned int *deadp = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(d_workspace) + ws_dead_off(h, nrows));
-   TileDir *dirp = reinterpret_cast<TileDir *>(reinterpret_cast<char *>(d_workspace) + ws_dir_off(h, nrows));
-   CandUnit *poolp = reinterpret_cast<CandUnit *>(reinterpret_cast<char *>(d_workspace) + ws_pool_off(h, nrows));
    BurstCtl *ctlp = reinterpret_cast<BurstCtl *>(reinterpret_cast<char *>(d_workspace) + ws_ctl_off(h, nrows));
-   WalkState *statep = reinterpret_cast<WalkState *>(reinterpret_cast<char *>(d_workspace) + ws_state_off(h, nrows));
    char *wsb = reinterpret_cast<char *>(d_workspace);
-   SegTab *segtabp = reinterpret_cast<SegTab *>(wsb + ws_segtab_off(h, nrows));
-   int *segburstp = reinterpret_cast<int *>(wsb + ws_segburst_off(h, nrows)), *segstatp = reinterpret_cast<int *>(wsb + ws_segstat_off(h, nrows));
-   WalkState *segstartp = reinterpret_cast<WalkState *>(wsb + ws_segstart_off(h, nrows)), *segendp = reinterpret_cast<WalkState *>(wsb + ws_segend_off(h, nrows));
-   // The record path (k_screen -> k_walk) pays when flux transitions are at least a bit cell apart (NRZI): then a run of
-   // candidate rows has one kind.  PE and GCR put a top and a bottom into the window at the same time; their candidate
-   // lists degenerate into one-row runs and overflow, so they take the sample path for the whole burst.
-   // RTFE_RECORD_PATH=0/1 overrides (tests keep both paths covered for every format).
-   const bool use_screen = h->dev.record_path != 0;                  // (decided in rtfe_create: it sizes k_decode's LDS)
-   // one wave per 64 walkers: the walk phase is latency bound, so small workgroups (many resident per CU)
-   // beat wide ones; k_decode holds ~250 VGPRs => 2 waves/SIMD => 8 waves per CU
+   // one wave per 64 walkers: k_decode's walk phase is latency bound, so small workgroups (many resident per CU)
+   // beat wide ones; it holds ~250 VGPRs => 2 waves/SIMD => 8 waves per CU
    const int nwalk = h->dev.nparm * h->dev.ntrks;
    int threads = nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256);
    if (h->dev.find_zeros && !h->dev.differentiate) {                 // -zeros: a lane per (track, 64-row sub-segment) of the tile
@@ -501,13 +429,11 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (per_cu > wave_lim) per_cu = wave_lim;
    if (per_cu < 1) per_cu = 1;
    const int dgrid = h->num_cus * per_cu;
-   // (k_quiet, k_bursts and the burst heads do not depend on k_screen.  Running all three beside it on a second stream loses: the
-   //  single-workgroup k_bursts starves behind k_screen's workgroups - measured 9.6 vs 10.7 Gsamples/s, and k_screen would have to
-   //  do without the dead-tile map.  The heads alone, forked behind k_bursts and joined in front of the walk (below), win:
-   //  8.71 -> 8.19 ms per C2 scan - they are latency-bound start-up walks that fit beside the VALU-bound dense pass.)
-   hipStream_t sq = st;
-   auto t0 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev0[k], s2); };
-   auto t1 = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev1[k], s2); };
+   // every span's events are recorded by every scan (a span that does not run reads ~0)
+   bool ran[kNumKernels] = {false};
+   auto t0 = [&](int k) { ran[k] = true; if (h->timing) (void)hipEventRecord(h->ev0[k], st); };
+   auto t1 = [&](int k) { if (h->timing) (void)hipEventRecord(h->ev1[k], st); };
+   auto skip_rest = [&]() { for (int k = 0; k < kNumKernels; ++k) if (!ran[k]) { t0(k); t1(k); } };
    if (h->dev.peak_path) {
       // ---- the peak path: k_sift (quiet map + records) -> k_bursts -> k_zones -> k_gain -> k_emit -> k_publish -> whatever the chains gave up ----
       PeakDir *dirm = reinterpret_cast<PeakDir *>(wsb + ws_pkdir_off(h, nrows));
@@ -519,9 +445,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       const long long ptiles = pk_tiles_for(nrows);
       (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
       (void)hipMemsetAsync(wsb + ws_pkextra_off(h, nrows), 0, pk_extra_bytes(h, nrows), st);
-      t0(0, st); t1(0, st); t0(2, st); t1(2, st); t0(3, st); t1(3, st); t0(4, st); t1(4, st);
       const int stop_after = getenv("RTFE_PEAK_STOP") ? atoi(getenv("RTFE_PEAK_STOP")) : 99;      // (debugging: launch only the first n kernels of the path)
-      t0(6, st);
+      t0(kTSift);
       const int pthreads = sf_threads(h->dev);
       int spc = (160 * 1024) / (h->dev.pk_lds + 512);
       if (spc * (pthreads / 64) > 32) spc = 32 / (pthreads / 64);
@@ -541,6 +466,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev));
          hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                             qtile, dirm, pkpool, hardp, hard_cap, &scratch->hard_count, scratch->scr); }
+      t1(kTSift); t0(kTPrep);
       hipLaunchKernelGGL(k_qpack, dim3(64), dim3(256), 0, st, (const uint16_t *)qtile, ptiles, qwords, nwords);
       // the lists -> one stream of 16-byte records per (screen, head): the deferred candidates resolved (k_sift_hard), the streams' tile
       // offsets (k_pscan), the records copied over with their absolute rows, volts and entry references (k_prep)
@@ -559,127 +485,67 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
                          (const uint32_t *)tstartp, (const uint32_t *)coffp, ptiles, ccap, crecp, erefp);
       hipLaunchKernelGGL(k_prep2, dim3(nlists * ((h->num_cus * 8 + nlists - 1) / nlists)), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, crecp);
-      t1(6, st); t0(1, st);
-      if (stop_after < 2) { t1(1, st); t0(7, st); t1(7, st); t0(8, st); t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
+      t1(kTPrep);
+      if (stop_after < 2) { skip_rest(); return launch_check("rtfe_scan"); }
+      t0(kTBursts);
       hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                          h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
-                         d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts,
-                         deadp, ptiles, (int)kSfTile, h->dev.tail_rows);
-      t1(1, st); t0(7, st);
-      if (stop_after < 3) { t1(7, st); t0(8, st); t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
+                         d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts);
+      t1(kTBursts);
+      if (stop_after < 3) { skip_rest(); return launch_check("rtfe_scan"); }
+      t0(kTGain);
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);
       ChainSt *cstp = reinterpret_cast<ChainSt *>(wsb + ws_pkcst_off(h, nrows));
       // the chains: from the restart row until the baseline is fixed (k_gain, mode 0), the steady stretch (k_gain_s), whatever that stopped at (k_gain, mode 1)
       for (int mode = 0; mode < 2; ++mode) {
+         if (mode == 1) t0(kTGainTail);
          hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                             scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
                             (const unsigned char *)pkpool, ptiles);
-         if (mode == 0)
+         if (mode == 0) {
+            t1(kTGain); t0(kTGainS);
             hipLaunchKernelGGL(k_gain_s, dim3(h->num_cus * 4), dim3(64), 0, st, (const DevCfg *)h->d_dev, cstp, (long long)nrows, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp,
-                               d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap, ptiles); }
-      t1(7, st); t0(8, st);
-      if (stop_after < 4) { t1(8, st); t0(5, st); t1(5, st); return launch_check("rtfe_scan"); }
+                               d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap, ptiles);
+            t1(kTGainS); } }
+      t1(kTGainTail);
+      if (stop_after < 4) { skip_rest(); return launch_check("rtfe_scan"); }
+      t0(kTEmit);
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
                          (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint32_t *)erefp, ccap, (const unsigned char *)pkpool);
       hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
-      t1(8, st); t0(5, st);
-      if (stop_after < 5) { t1(5, st); return launch_check("rtfe_scan"); }
+      t1(kTEmit);
+      if (stop_after < 5) { skip_rest(); return launch_check("rtfe_scan"); }
+      t0(kTDecode);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
-                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
-                         (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeRedo, ctlp, statep);
-      t1(5, st);
+                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0, (int)kDecodeRedo, ctlp);
+      t1(kTDecode);
+      skip_rest();
       return launch_check("rtfe_scan"); }
+   // ---- the sample path: quiet map -> bursts -> every burst in one pass over its samples ----
    (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
-   t0(6, sq); t1(6, sq); t0(7, sq); t1(7, sq); t0(8, sq); t1(8, sq);
-   t0(0, sq);
-   hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, sq, d_rows, (long long)nrows, h->dev.ntrks, h->dev.quiet_i, qwords, nwords);
-   t1(0, sq); t0(1, sq);
-   hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, sq, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
+   t0(kTQuiet);
+   hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, st, d_rows, (long long)nrows, h->dev.ntrks, h->dev.quiet_i, qwords, nwords);
+   t1(kTQuiet); t0(kTBursts);
+   hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
-                      d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts,
-                      deadp, ntiles_for(h, nrows), h->dev.tile_rows, h->dev.tail_rows);
-   t1(1, sq);
+                      d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts);
+   t1(kTBursts);
    if (h->dev.find_zeros && !h->dev.differentiate && h->zeros_kernel) {          // -zeros: the lean kernel of its own (rtfe_zeros.hip)
       const int zlds = (int)lds_layout_zeros(h->dev).total + 64;
       int zpc = (160 * 1024) / (zlds + 4096);
       if (zpc > 16) zpc = 16;
       if (zpc < 1) zpc = 1;
-      t0(2, st); t1(2, st); t0(3, st);
+      t0(kTZeros);
       hipLaunchKernelGGL(k_zeros, dim3(h->num_cus * zpc), dim3(128), zlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base,
                          d_bursts, scratch, d_counts, d_events);
-      t1(3, st); t0(4, st); t1(4, st); t0(5, st); t1(5, st); }
-   else if (!use_screen) {                                            // -zeros, PE, GCR: the whole burst in one pass over the samples
-      t0(2, st); t1(2, st); t0(3, st);
+      t1(kTZeros); }
+   else {                                                             // PE, GCR, differentiated peaks, density detection
+      t0(kTDecode);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
-                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
-                         (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeAll, ctlp, statep);
-      t1(3, st); t0(4, st); t1(4, st); t0(5, st); t1(5, st); }
-   else {
-      // burst heads from the samples (start-up path) -> the record walk -> whatever the records could not decide
-      hipStream_t sh = st;
-      if (h->overlap_heads) {                                          // fork: the heads on the side stream, behind k_bursts
-         if (!h->side) {
-            if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; h->overlap_heads = 0; }
-            else { (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming); } }
-         if (h->side) { sh = h->side; (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(sh, h->ev_fork, 0); } }
-      t0(3, sh);
-      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, sh, h->d_dev, d_rows, (long long)nrows,
-                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
-                         (const TileDir *)dirp, (const CandUnit *)poolp, (int)kDecodeHead, ctlp, statep);
-      t1(3, sh);
-      if (sh != st) (void)hipEventRecord(h->ev_join, sh);
-      const long long ntiles = ntiles_for(h, nrows);
-      int spc = (160 * 1024) / (h->screen_lds_bytes + 1024);
-      if (spc > 8) spc = 8;
-      if (spc < 1) spc = 1;
-      long long sgrid = (long long)h->num_cus * spc;
-      if (sgrid > ntiles) sgrid = ntiles;
-      t0(2, st);
-      hipLaunchKernelGGL(k_screen, dim3((unsigned)sgrid), dim3(256), h->screen_lds_bytes, st, h->d_dev, d_rows, (long long)nrows, dirp, poolp,
-                         ntiles, scratch->scr, (const unsigned int *)deadp);
-      t1(2, st);
-      if (sh != st) (void)hipStreamWaitEvent(st, h->ev_join, 0);       // join: the walk needs both
-      int wthreads = threads;
-      if (getenv("RTFE_WALK_THREADS")) { const int v = atoi(getenv("RTFE_WALK_THREADS")); if (v >= threads && v <= 256 && v % 64 == 0) wthreads = v; }
-      int wpc = (160 * 1024) / (h->walk_lds_bytes + 1024);
-      const int wlim = 16 / (wthreads / 64);
-      if (wpc > wlim) wpc = wlim;
-      if (wpc < 1) wpc = 1;
-      t0(4, st);
-      // the walkers: a lane each (k_lwalk, lists straight from HBM) when two or more work items fit a wave, else k_walk's
-      // workgroup per item.  RTFE_LWALK=0/1 overrides (tests keep both alive).
-      const bool lanes = h->lane_walk && nwalk <= 32 && (64 / nwalk) * h->dev.lds_units * 16 <= 150 * 1024;
-      const int lw_lds = (64 / nwalk) * h->dev.lds_units * 16;                 // the lists of one tile of every item of a wave
-      int lwpc = (160 * 1024) / (lw_lds + 6 * 1024);
-      if (lwpc < 1) lwpc = 1;
-      if (lwpc > 16) lwpc = 16;
-      auto walk = [&](int mode, bool with_segs) {
-         const SegTab *stp = with_segs ? (const SegTab *)segtabp : (const SegTab *)nullptr;
-         const int *sbp = with_segs ? (const int *)segburstp : (const int *)nullptr;
-         if (lanes)
-            hipLaunchKernelGGL(k_lwalk, dim3(h->num_cus * lwpc), dim3(64), lw_lds, st, (const DevCfg *)h->d_dev, (long long)nrows, (long long)row_base,
-                               d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
-                               mode, stp, sbp, with_segs ? segstartp : (WalkState *)nullptr, with_segs ? segendp : (WalkState *)nullptr, with_segs ? segstatp : (int *)nullptr);
-         else
-            hipLaunchKernelGGL(k_walk, dim3(h->num_cus * wpc), dim3(wthreads), h->walk_lds_bytes, st, h->d_dev, (long long)nrows, (long long)row_base,
-                               d_bursts, scratch, d_counts, d_events, (const TileDir *)dirp, (const CandUnit *)poolp, ctlp, statep,
-                               mode, stp, sbp, with_segs ? segstartp : (WalkState *)nullptr, with_segs ? segendp : (WalkState *)nullptr, with_segs ? segstatp : (int *)nullptr); };
-      if (h->dev.seg_tiles > 0 && h->dev.mode != RTFE_PE) {
-         // long blocks: the walk runs as concurrent segments.  (1) every burst until its walkers have left the AGC start-up,
-         // (2) cut, (3) all segments, (4) join them (or hand the burst to the pass below)
-         walk((int)kWalkPre, true);
-         hipLaunchKernelGGL(k_segs, dim3(1), dim3(1024), 0, st, h->d_dev, (long long)nrows, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp,
-                            (const WalkState *)statep, segtabp, segburstp, segstatp, max_segs_for(h, nrows));
-         walk((int)kWalkSegs, true);
-         hipLaunchKernelGGL(k_stitch, dim3(h->num_cus * 4), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, d_counts, d_events, ctlp,
-                            statep, (const SegTab *)segtabp, (const WalkState *)segstartp, (const WalkState *)segendp, (const int *)segstatp); }
-      else walk((int)kWalkWhole, false);
-      t1(4, st); t0(5, st);
-      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
-                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0,
-                         (const TileDir *)dirp, (const CandUnit *)poolp, (int)kDecodeResume, ctlp, statep);
-      t1(5, st); }
+                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0, (int)kDecodeAll, ctlp);
+      t1(kTDecode); }
+   skip_rest();
    return launch_check("rtfe_scan"); }
 
 // Synchronous (copies three words back): what the last rtfe_scan on this workspace did.
@@ -709,8 +575,7 @@ extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nr
                       cap > 0xffffffffull ? 0xffffffffull : cap);
    const int nwalk = h->dev.nparm * h->dev.ntrks;
    hipLaunchKernelGGL(k_decode, dim3(1), dim3(nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256)), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
-                      (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1,
-                      (const TileDir *)nullptr, (const CandUnit *)nullptr, (int)kDecodeAll, (BurstCtl *)nullptr, (WalkState *)nullptr);
+                      (long long)row_base, d_burst, scratch, d_counts, d_events, parmset_mask, screen_off, 1, (int)kDecodeAll, (BurstCtl *)nullptr);
    return launch_check("rtfe_scan_exact"); }
 
 // ---- Whirlwind (include/rt_frontend.h) ----

@@ -51,12 +51,8 @@ struct DevCfg {
    long long tdelta_ns, tstart_ns;
    int   quiet_i;                 // |x| <= quiet_i on every track  <=> row is "quiet"
    int   gap_chunks;              // quiet chunks that make an inter-block zone
-   int   seg_tiles;               // tiles per segment of the record walk (0 = whole bursts); seg_evcap = events per (segment, walker) slot
-   int   seg_evcap;
-   int   seg_warm;                // warm-up tiles in front of every segment but the first
    int   zc_parallel;             // -zeros: concurrent sub-segments per tile (0 = one lane per track, sequential)
    int   zc_warm;                 // ... rows a sub-segment starts early from a fresh state (multiple of 8, <= 64; RTFE_ZC_WARM)
-   int   record_path;             // k_screen -> k_walk runs (NRZI peak detection; RTFE_RECORD_PATH overrides): k_decode then keeps LDS for record tiles
    int   tail_rows;               // a burst's walkers stop this many rows into the next zone (the block decoders have long ended
                                   // the block by then; an attempt that has not falls back to an exact rescan in the replay)
    float cap_frac;                // event capacity per track as a fraction of burst length
@@ -64,13 +60,9 @@ struct DevCfg {
    int   halo_rows;               // rows kept in front of a tile: kScreenHalo + widest window + 1 + max skew, rounded up to 8
    int   ldw;                     // rows of the LDS sample tile (halo_rows + tile_rows + 8)
    float lsb_per_volt;            // 32767 / maxvolts, for the walkers' integer guard bands
-   int   run_cap;                 // candidate-run records per (screen, track) per tile (LDS)
    int   rec_cap;                 // deferred-event records per walker per tile (LDS)
-   int   rec_cap16;               // deferred detections per walker per tile of k_walk (LDS)
-   int   pm_cap;                  // (walker, run) verdict slots of one tile of k_walk's parallel path (LDS)
-   int   lds_units;               // candidate units of ONE tile (all lists, packed) that fit the LDS of the sequential pass
    int   debug;                   // RTFE_DEBUG=1: per-phase cycle counters in the workspace (tools/ only)
-   int   cut;                     // RTFE_CUT: k_screen stops after a phase (timing experiments, tools/ only; results are then garbage)
+   int   cut;                     // RTFE_CUT: k_sift stops after a phase (timing experiments, tools/ only; results are then garbage)
    int   peak_path;               // k_sift -> k_gain -> k_emit serve rtfe_scan (peak detection on the undifferentiated signal)
    int   pk_hl, pk_hr;            // rows kept in front of / behind a k_sift tile in LDS (multiples of 8)
    int   pk_slot;                 // bytes of a pool slot: the list of one (tile, screen, head); multiple of 16
@@ -81,39 +73,9 @@ struct DevCfg {
    DevScreen screen[kMaxScreens];
 };
 
-// ---- what the dense screen pass (k_screen) leaves in HBM for the sequential pass (k_walk / k_decode) ----
-// A list is a sequence of 16-byte units: first one HEADER per run, in the detector's order, then the margin units.
-// One RUN = consecutive candidate rows of one kind that share the same extreme (rows where both kinds are candidates
-// form one-row runs, top first, so header order = the detector's order).  A run owns ceil((nrows-1)/4) margin units of
-// four (dL,dR) pairs.  It carries everything the sequential detector needs to decide those rows EXACTLY without the
-// samples: the extreme, its neighbours (half-sample refinement) and its distance from both window edges at every row
-// (int16 code differences, from which the float comparisons of src/decoder.c:788-805 can be re-evaluated bit for bit).
-//   header  .x = n_s | nrows << 11 | kind << 17 | moff << 18
-//                                                    n_s tile-relative (< 2048); kind 0 top / 1 bottom; moff = index of the
-//                                                    run's first margin unit behind the list's headers
-//           .y = (m & 0xffff) | ld0 << 16            m = the extreme (tops: true window maximum; bottoms: the reference's
-//                                                    possibly stale minimum); ld0 = its left_distance at row n_s (one less
-//                                                    per row); ld0 = 0 (bottoms): the reference's minimum is unknown here
-//           .z = prev | next << 16                   the extreme's neighbours
-//           .w = dL | dR << 16                       row n_s: |m - left window edge|, |m - right edge| (clamped at 0)
-//   margins .x .y .z .w = dL | dR << 16              rows n_s + 1 + 4u .. n_s + 4 + 4u of the run's margin unit u
-typedef struct { int32_t x, y, z, w; } CandUnit;
-struct TileDir {               // per (tile, screen, track): 8 bytes
-   uint16_t count;             // 16-byte units in this list (headers + margins); 0xFFFF: list incomplete
-   uint16_t nruns;             // of which headers
-   uint8_t  end_ld;            // left_distance of the reference's minimum after the tile's last row; 0 = unknown
-   uint8_t  pad;
-   int16_t  end_min;           // that minimum (int16 code)
-};
-// ---- segments: a long burst's record walk is cut into runs of seg_tiles tiles that are walked concurrently; every
-// segment but the first starts kSegWarmup tiles early from a guessed state, and k_stitch accepts the result only if the
-// state each segment had at its first own tile is, bit for bit, the state its predecessor ended with ----
-constexpr int kSegWarmup = 8;      // tiles: the alpha-filter AGC needs ~90 detections per track to forget its start value to the last bit
-struct SegTab { int first; int nseg; int t0; int tend; };      // per burst: global index of segment 0, segments, first tile, end tile (excl.)
 // ---- burst hand-over between the kernels of one scan (workspace) ----
 enum { kBurstNew = 0, kBurstNeedsFull = 1, kBurstReady = 2, kBurstDone = 3 };
-enum { kDecodeAll = 0, kDecodeHead = 1, kDecodeResume = 2, kDecodeRedo = 3 };     // kDecodeRedo: whole bursts the record chains gave up (restart / stop rows from k_zones)
-enum { kWalkWhole = 0, kWalkPre = 1, kWalkSegs = 2 };
+enum { kDecodeAll = 0, kDecodeRedo = 3 };     // kDecodeRedo: whole bursts the record chains gave up (restart / stop rows from k_zones)
 struct BurstCtl {              // 32 bytes per burst
    long long reset, stop;      // restart row / first row of the next burst's span
    int       next_tile;        // tile of the tape-global grid to continue with

@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       const unsigned int cap = B.event_cap;
       bool failed = false;
       int why = 0;
-      unsigned int n_fast = 0, n_slow = 0, guard = 0;
+      unsigned int n_fast = 0, n_slow = 0;
       // this chain's piece of its head's stream: from the tile that holds row c - W to the tile behind the limit
       const int sl = P.screen * ntrks + head;
       RecSrc src;

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(128, 4) k_zeros(const DevCfg *__restrict__ cfg
    cx.tile.x = reinterpret_cast<int16_t *>(smem + L.tile);
    cx.tile.ldw = cfg.ldw; cx.tile.halo = cfg.halo_rows; cx.tile.colof = cfg.trk_to_head; cx.tile.ntrks = ntrks; cx.tile.skew = cfg.skew;
    cx.tile.bits = nullptr; cx.tile.bstride = 0; cx.tile.ldpos = nullptr; cx.tile.ldstride = 0; cx.tile.fd = nullptr;
-   cx.heights = nullptr; cx.recs = nullptr; cx.rec_cap = 0; cx.rec_cap16 = 0; cx.nrec = 0;
+   cx.heights = nullptr; cx.recs = nullptr; cx.rec_cap = 0; cx.nrec = 0;
    ZcLane *lanes = reinterpret_cast<ZcLane *>(smem + L.lanes);
    ZWalker *walkers = reinterpret_cast<ZWalker *>(smem + L.walkers);
    const int trk = threadIdx.x;
@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(128, 4) k_zeros(const DevCfg *__restrict__ cfg
          if (par) {
             if (cfg.invert) zeros_tile_parallel<ZWalker, false>(cx, walkers, lanes, s_ok, stop, cfg.debug ? scratch->dbg2 : (unsigned long long *)nullptr);
             else zeros_tile_parallel<ZWalker, true>(cx, walkers, lanes, s_ok, stop, cfg.debug ? scratch->dbg2 : (unsigned long long *)nullptr); }      // (the rows where they lie in HBM)
-         if (par && cfg.debug && (int)threadIdx.x < ntrks) { atomicAdd(&scratch->dbg2[4], 1ull); if (s_ok[threadIdx.x]) atomicAdd(&scratch->dbg2[5], 1ull); if (threadIdx.x == 0) atomicAdd(&scratch->dbg2[6], 1ull); }      // (RTFE_DEBUG=1: tools/gpu_zeros_phase.py)
+         if (par) {
+            if (cfg.debug && (int)threadIdx.x < ntrks) { atomicAdd(&scratch->dbg2[4], 1ull); if (s_ok[threadIdx.x]) atomicAdd(&scratch->dbg2[5], 1ull); if (threadIdx.x == 0) atomicAdd(&scratch->dbg2[6], 1ull); } }      // (RTFE_DEBUG=1: tools/gpu_zeros_phase.py)
          else { if (threadIdx.x < (unsigned)ntrks) s_ok[threadIdx.x] = 0; __syncthreads(); }
          if (is_walker && !s_ok[trk]) {                              // the burst's first and last tile, partial tiles: row by row
             ZWalker w = walkers[trk];

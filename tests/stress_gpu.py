@@ -125,9 +125,11 @@ for i in range(ntapes):
         n = tape.rows.shape[0]; a, b = sorted(int(x) for x in rng.integers(0, n, size=2))
         if b - a > 2000: tape = dataclasses.replace(tape, rows=np.ascontiguousarray(tape.rows[a:b]))
     hdr = tape.spec.header()
-    # the segmented record walk and its join failures: random segment size / warm-up
-    seg, warm = int(rng.choice([0, 8, 16, 48])), int(rng.choice([1, 3, 8]))
-    os.environ["RTFE_SEG_TILES"] = str(seg); os.environ["RTFE_SEG_WARMUP"] = str(warm)
+    # the peak path's knobs: the chains' general step for every detection / the general sift kernel, at random
+    seg, warm = int(rng.choice([0, 1])), int(rng.choice([0, 1]))
+    os.environ["RTFE_GAIN_FAST"] = str(1 - seg)
+    if warm: os.environ["RTFE_SIFT_GENERIC"] = "1"
+    else: os.environ.pop("RTFE_SIFT_GENERIC", None)
     if os.environ.get("STRESS_ONLY") and int(os.environ["STRESS_ONLY"]) != i: continue
     if os.environ.get("STRESS_DRY"):
         print(i, kind, "seed", seed, "amp", amp, "noise", noise, "jit", jit, "opts", opts, "seg", seg, warm, "rows", tape.rows.shape[0], "spec", tape.spec.bpi, "parms", repr(parms_text), flush=True)
@@ -137,10 +139,10 @@ for i in range(ntapes):
     if keep: os.makedirs(keep, exist_ok=True)
     with (contextlib.nullcontext(keep) if keep else tempfile.TemporaryDirectory()) as wd:
         att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3")) else []
-        for rec in ("default", "1"):
+        for rec in ("default", "1", "0"):                       # every format on both paths (peak path / sample path)
             t_case = time.perf_counter()
-            if rec == "1": os.environ["RTFE_RECORD_PATH"] = "1"
-            else: os.environ.pop("RTFE_RECORD_PATH", None)
+            if rec != "default": os.environ["RTFE_PEAK_PATH"] = rec
+            else: os.environ.pop("RTFE_PEAK_PATH", None)
             e2e = any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3"))
             if e2e: msgs, stats = e2e_check(hdr, tape.rows, [o for o in opts if o not in ("(nobpi)", "(parms)")], wd, parms_text)
             else:
@@ -149,7 +151,7 @@ for i in range(ntapes):
                     fe = emul_frontend(config_for(hdr, opts))
                 else: fe = frontend.FrontEnd(config_for(hdr, opts))
                 msgs, stats = check_tape(fe, hdr, tape.rows, att)
-            tag = f"{i:3d} {kind} seed {seed} amp {amp} noise {noise} jit {jit} opts {opts} seg {seg}/{warm} record_path {rec}: attempts {len(att)} events {stats['events']} speculative {stats.get('speculative')} flags {stats.get('flags')}"
+            tag = f"{i:3d} {kind} seed {seed} amp {amp} noise {noise} jit {jit} opts {opts} general_step {seg} generic_sift {warm} peak_path {rec}: attempts {len(att)} events {stats['events']} speculative {stats.get('speculative')} flags {stats.get('flags')}"
             print(("FAIL " if msgs else "ok   ") + tag + f" [{time.perf_counter() - t_case:.1f} s]", flush=True)
             if msgs:
                 print("\n".join(msgs[:6]))

@@ -29,7 +29,7 @@ def test_frontend_library_exports_every_declared_symbol(built):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert lib.rtfe_abi_version() == 1
-    assert lib.rtfe_kernel_count() == 8
+    assert lib.rtfe_kernel_count() == 10
 
 
 def test_host_decode_library_exports_every_declared_symbol(built):

@@ -59,14 +59,10 @@ def test_emulated_peak_record_path_gives_up_cleanly(name, knobs, tmp_path, monke
     assert st["redone"] > 0
 
 
-@pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_LDS_UNITS": "256"}),            # lists through LDS in several groups
-                                        ("nrzi9", {"RTFE_REC_CAP16": "4"}),             # k_walk hands tiles back to k_decode
-                                        ("gcr", {"RTFE_RECORD_PATH": "1", "RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}),
-                                        ("pe", {"RTFE_RECORD_PATH": "1", "RTFE_REC_CAP16": "8"}),
-                                        ("gcr", {"RTFE_RECORD_PATH": "1"}), ("nrzi9", {"RTFE_RECORD_PATH": "0"})])
-def test_emulated_rare_paths_of_the_record_walk(name, knobs, tmp_path, monkeypatch):
-    """Small LDS budgets force k_walk's rare paths (grouped lists, the sequential walk, give-back to the second
-    k_decode pass): the events must not change."""
+@pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_SIFT_GENERIC": "1"}),           # the general k_sift where k_sift_s would run
+                                        ("nrzi9", {"RTFE_PEAK_PATH": "0"}),             # NRZI on the sample path (k_decode walks every sample)
+                                        ("nrzi9_m", {"RTFE_PEAK_PATH": "0"})])
+def test_emulated_paths_that_are_not_the_default(name, knobs, tmp_path, monkeypatch):
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     g = load_case(name)
@@ -77,15 +73,9 @@ def test_emulated_rare_paths_of_the_record_walk(name, knobs, tmp_path, monkeypat
     assert stats["events"] > 0
 
 
-@pytest.mark.parametrize("knobs", [{"RTFE_SEG_TILES": "4", "RTFE_SEG_WARMUP": "1"},      # warm-up too short: joins fail, the tail goes to the second k_decode pass
-                                   {"RTFE_SEG_TILES": "4", "RTFE_SEG_WARMUP": "4"},
-                                   {"RTFE_SEG_TILES": "4", "RTFE_SEG_WARMUP": "4", "RTFE_LWALK": "1"},      # k_walk (a workgroup per item) instead of k_lwalk (a lane per walker)
-                                   {"RTFE_SEG_TILES": "0", "RTFE_LWALK": "1"},
-                                   {"RTFE_SEG_TILES": "0"}])                             # unsegmented walk
-def test_emulated_segmented_record_walk(knobs, tmp_path, monkeypatch):
-    """The record walk of a long block runs as concurrent segments started from guessed states and is accepted only where
-    every segment's start state equals its predecessor's end state: whatever the segment size, the warm-up
-    and the outcome of the joins, the events are the oracle's."""
+@pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}])
+def test_emulated_long_blocks(knobs, tmp_path, monkeypatch):
+    """Blocks of 500-640 bytes: chains that cross many tiles (k_gain's heads, k_gain_s' steady stretches, the tails)."""
     from readtape_amd import synth
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)

@@ -63,13 +63,13 @@ def test_reference_agc_assert_stops_the_decode_where_the_reference_stops(tmp_pat
     assert ei.value.stats["reference_fatal"]
 
 
-@pytest.mark.parametrize("record_path", ["0", "1"])
-def test_agc_assert_inside_a_parameter_sweep_ends_everything(record_path, tmp_path, monkeypatch):
+@pytest.mark.parametrize("peak_path", ["0", "1"])
+def test_agc_assert_inside_a_parameter_sweep_ends_everything(peak_path, tmp_path, monkeypatch):
     """-m: the second set's gain goes negative in an attempt other sets have been through (stress seed 704 tape 59: the GPU hung,
     the emulator crashed - the screened walk narrowed its "blind for ever" row to an int).  The reference exits at the assert: no
     further set is tried, and the transitions delivered up to there are the reference's."""
     import refdump
-    monkeypatch.setenv("RTFE_RECORD_PATH", record_path)
+    monkeypatch.setenv("RTFE_PEAK_PATH", peak_path)
     g = load_case("nrzi9_agcfatal_m")
     assert g["returncode"] == 99
     tap = os.path.join(str(tmp_path), "out.tap")

@@ -30,33 +30,37 @@ def test_golden_tapes(name, tmp_path, gpu):
     assert stats["events"] > 0
 
 
-@pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_LDS_UNITS": "256"}), ("nrzi9", {"RTFE_REC_CAP16": "4"}),
-                                        ("gcr", {"RTFE_RECORD_PATH": "1", "RTFE_LDS_UNITS": "256", "RTFE_REC_CAP16": "6"}),
-                                        ("pe_m", {"RTFE_RECORD_PATH": "1", "RTFE_REC_CAP16": "8"}),
-                                        ("pe", {"RTFE_RECORD_PATH": "1"}), ("gcr_m", {"RTFE_RECORD_PATH": "1"}),
-                                        ("nrzi9", {"RTFE_RECORD_PATH": "0"}), ("nrzi9_m", {"RTFE_LDS_UNITS": "512"}),
-                                        ("nrzi9", {"RTFE_LWALK": "1"}), ("nrzi9_m", {"RTFE_LWALK": "1"}), ("nrzi7", {"RTFE_LWALK": "1"})])
-def test_rare_paths_of_the_record_walk(name, knobs, tmp_path, gpu, monkeypatch):
-    """Small LDS budgets force k_walk's rare paths (grouped lists, the sequential walk, give-back to the second
-    k_decode pass): the events must not change."""
+@pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_PK_SLOT": "64"}), ("nrzi9_m", {"RTFE_PK_SLOT": "96"}),      # lists that outgrow their slot: bursts redone on the samples
+                                        ("nrzi9", {"RTFE_SIFT_GENERIC": "1"}), ("nrzi7", {"RTFE_SIFT_GENERIC": "1"}),  # the general k_sift where k_sift_s would run
+                                        ("nrzi9", {"RTFE_GAIN_FAST": "0"}), ("nrzi9_m", {"RTFE_GAIN_FAST": "0"}),      # every detection through the chains' general step
+                                        ("nrzi9_skew", {"RTFE_GAIN_FAST": "0", "RTFE_SIFT_GENERIC": "1"}),
+                                        ("gcr", {"RTFE_PEAK_PATH": "1"}), ("gcr_m", {"RTFE_PEAK_PATH": "1", "RTFE_PK_SLOT": "256"}),
+                                        ("pe", {"RTFE_PEAK_PATH": "1"}), ("pe_m", {"RTFE_PEAK_PATH": "1", "RTFE_GAIN_FAST": "0"}),
+                                        ("nrzi9", {"RTFE_PEAK_PATH": "0"}), ("nrzi9_m", {"RTFE_PEAK_PATH": "0"}), ("nrzi7", {"RTFE_PEAK_PATH": "0"})])
+def test_rare_paths_of_the_peak_path(name, knobs, tmp_path, gpu, monkeypatch):
+    """The peak path's (k_sift -> k_gain -> k_emit) rare branches forced by knobs - pool slots too small (the burst is redone by
+    k_decode), the general sift kernel, the chains' general step for every detection - and each format on the path that is not its
+    default: the events must not change."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     g = load_case(name)
     att = oracle_attempts(g["hdr"], g["rows"], g["oracle_opts"], str(tmp_path))
     fe = frontend.FrontEnd(config_for(g["hdr"], g["oracle_opts"]))
+    res = fe.scan(g["rows"]).fetch()
+    st = fe.scan_stats(res)
     msgs, stats = check_tape(fe, g["hdr"], g["rows"], att)
     assert not msgs, "\n".join(msgs[:12])
     assert stats["events"] > 0
+    if "RTFE_PK_SLOT" in knobs and name.startswith("nrzi"):
+        assert st["redone"] > 0
+    if knobs.get("RTFE_GAIN_FAST") == "0":
+        assert st["parallel"] == 0 and st["sequential"] > 0
 
 
-@pytest.mark.parametrize("knobs", [{"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "1"}, {"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "3"},
-                                   {"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "8"}, {"RTFE_SEG_TILES": "16", "RTFE_SEG_WARMUP": "8", "RTFE_REC_CAP16": "14"},
-                                   {}, {"RTFE_SEG_TILES": "0"}, {"RTFE_LWALK": "1"}, {"RTFE_SEG_TILES": "8", "RTFE_SEG_WARMUP": "3", "RTFE_LWALK": "1"},
-                                   {"RTFE_SEG_TILES": "0", "RTFE_LWALK": "1"}])
-def test_segmented_record_walk(knobs, tmp_path, gpu, monkeypatch):
-    """Long blocks: the record walk runs as concurrent segments from guessed states, accepted only where each segment's
-    start state is bit for bit its predecessor's end state; the rest goes to the second k_decode pass.  Whatever the
-    segment size, the warm-up and the outcome of the joins, the events are the oracle's."""
+@pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}, {"RTFE_SIFT_GENERIC": "1"}, {"RTFE_PK_SLOT": "128"}, {"RTFE_PEAK_PATH": "0"}])
+def test_long_blocks(knobs, tmp_path, gpu, monkeypatch):
+    """Blocks of 1500-4096 bytes (chains of tens of thousands of records: k_gain's heads, k_gain_s' steady stretches across many
+    tiles, the tails): the events are the oracle's, every block start speculative."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     tape = synth.nrzi_tape(seed=33, nblocks=10, minlen=1500, maxlen=4096, marks_every=4, gap_samples=4000)
@@ -68,19 +72,22 @@ def test_segmented_record_walk(knobs, tmp_path, gpu, monkeypatch):
     assert stats["speculative"] == len(att) and stats["flags"] == 0
 
 
-def test_long_blocks_segmented_walk_equals_whole_burst_walk(gpu, monkeypatch):
-    """32 KB blocks (1 250 tiles each): the default segmented record walk (13 concurrent segments per block, joined by
-    k_stitch) and the whole-burst walk (RTFE_SEG_TILES=0) must produce the same bursts, counts and events, byte for byte."""
+def test_long_blocks_peak_path_equals_sample_path(gpu, monkeypatch):
+    """32 KB blocks (~1 M rows each): the peak path and the sample path (RTFE_PEAK_PATH=0: k_decode walks every sample) must
+    produce the same bursts, counts and events, byte for byte."""
     import torch
     tape = synth.nrzi_tape(seed=35, nblocks=5, minlen=30000, maxlen=32768, gap_samples=6000)
     hdr = tape.spec.header()
     rows = torch.from_numpy(tape.rows).cuda()
     out = []
-    for seg in (None, "0"):
-        if seg is None: monkeypatch.delenv("RTFE_SEG_TILES", raising=False)
-        else: monkeypatch.setenv("RTFE_SEG_TILES", seg)
+    for pp in (None, "0"):
+        if pp is None: monkeypatch.delenv("RTFE_PEAK_PATH", raising=False)
+        else: monkeypatch.setenv("RTFE_PEAK_PATH", pp)
         fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr))
         out.append(fe.scan(rows).fetch())
+        if pp is None:
+            st = fe.scan_stats(out[-1])
+            assert st["redone"] == 0 and st["parallel"] > 500_000, st
     a, b = out
     assert a.nbursts == b.nbursts >= 5 and (a.counts == b.counts).all() and (a.bursts["flags"] == b.bursts["flags"]).all()
     for i in range(a.nbursts):
@@ -199,13 +206,13 @@ def test_reference_agc_assert_stops_the_decode_where_the_reference_stops(tmp_pat
     assert mine.size == g["events"].size and not refdump.compare(mine, g["events"])
 
 
-@pytest.mark.parametrize("record_path", ["0", "1"])
-def test_agc_assert_inside_a_parameter_sweep_ends_everything(record_path, tmp_path, gpu, monkeypatch):
+@pytest.mark.parametrize("peak_path", ["0", "1"])
+def test_agc_assert_inside_a_parameter_sweep_ends_everything(peak_path, tmp_path, gpu, monkeypatch):
     """-m, the gain of the second set goes negative (stress seed 704 tape 59 hung the GPU): see tests/test_emul_replay.py."""
     import os
     import refdump
     from readtape_amd import pipeline
-    monkeypatch.setenv("RTFE_RECORD_PATH", record_path)
+    monkeypatch.setenv("RTFE_PEAK_PATH", peak_path)
     g = load_case("nrzi9_agcfatal_m")
     tap = os.path.join(str(tmp_path), "out.tap")
     with pytest.raises(pipeline.ReferenceFatal):
@@ -217,7 +224,7 @@ def test_agc_assert_inside_a_parameter_sweep_ends_everything(record_path, tmp_pa
 
 @pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "pe", "gcr", "gcr_m", "nrzi9_skew", "nrzi9_nobpi", "nrzi7_order"])
 def test_peak_record_path_equals_the_sample_path(name, gpu, monkeypatch):
-    """The opt-in peak-record path (RTFE_PEAK_PATH=1: k_peaks -> k_zones -> k_chain) against the default kernels: the same burst
+    """The peak path (RTFE_PEAK_PATH=1: k_sift -> k_gain -> k_emit) against the sample path (RTFE_PEAK_PATH=0: k_decode): the same burst
     table and, per (burst, parameter set, track), the same events byte for byte - also behind the block ends, where no oracle
     attempt looks."""
     g = load_case(name)
