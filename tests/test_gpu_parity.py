@@ -54,7 +54,32 @@ def test_rare_paths_of_the_peak_path(name, knobs, tmp_path, gpu, monkeypatch):
     if "RTFE_PK_SLOT" in knobs and name.startswith("nrzi"):
         assert st["redone"] > 0
     if knobs.get("RTFE_GAIN_FAST") == "0":
-        assert st["parallel"] == 0 and st["sequential"] > 0
+        assert st["parallel"] == 0 and (st["sequential"] > 0 or st["redone"] == st["bursts"])
+
+
+@pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}])
+def test_parameter_sweep_on_the_peak_path(knobs, gpu, monkeypatch):
+    """-m on NRZI: 8 parameter sets with three window widths go through the general k_sift (a list per width and head) and 72 chains
+    per burst; bursts, counts and events are the sample path's, byte for byte, and no burst needs the sample path."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    tape = synth.nrzi_tape(seed=47, nblocks=12, minlen=64, maxlen=1500, gap_samples=4000, noise_mv=10.0)
+    hdr = tape.spec.header()
+    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=frontend.DEFAULT_PARMSETS[frontend.NRZI])
+    out = []
+    for pp in ("1", "0"):
+        monkeypatch.setenv("RTFE_PEAK_PATH", pp)
+        fe = frontend.FrontEnd(cfg)
+        out.append(fe.scan(tape.rows).fetch())
+        if pp == "1":
+            st = fe.scan_stats(out[-1])
+            assert st["redone"] == 0 and st["parallel"] + st["sequential"] > 50_000, st
+    a, b = out
+    assert a.nbursts == b.nbursts >= 12 and (a.counts == b.counts).all() and (a.bursts["flags"] == b.bursts["flags"]).all()
+    for i in range(a.nbursts):
+        for p in range(len(cfg.parmsets)):
+            for t in range(hdr.ntrks):
+                assert a.track_events(i, p, t).tobytes() == b.track_events(i, p, t).tobytes(), (i, p, t)
 
 
 @pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}, {"RTFE_SIFT_GENERIC": "1"}, {"RTFE_PK_SLOT": "128"}, {"RTFE_PEAK_PATH": "0"}])
