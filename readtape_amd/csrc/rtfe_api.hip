@@ -358,7 +358,9 @@ static size_t pk_pool_bytes(const rtfe_handle *h, int64_t nrows) {      // one s
    if (!h->dev.peak_path) return 0;
    return (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * (size_t)h->dev.pk_slot) + 255) & ~(size_t)255; }
 // ... | the candidates k_sift deferred (k_sift_hard) | their overflow slots
-static long long pk_hard_cap(const rtfe_handle *h, int64_t nrows) { const long long c = pk_tiles_for(nrows) * h->dev.nscreens * 2 + 1024; return c > 0x3fffffffll ? 0x3fffffffll : c; }
+// (two per tile and list: a clean NRZI tape defers 0.05 % of its candidates, a noisy parameter sweep with wide windows one or two per tile and list;
+//  past the capacity a candidate becomes a "minimum unknown" record, and the chain that gets there gives up)
+static long long pk_hard_cap(const rtfe_handle *h, int64_t nrows) { const long long c = pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * 2 + 4096; return c > 0x3fffffffll ? 0x3fffffffll : c; }
 static size_t ws_pkhard_off(const rtfe_handle *h, int64_t nrows) { return ws_pkpool_off(h, nrows) + pk_pool_bytes(h, nrows); }
 static size_t ws_pkqtile_off(const rtfe_handle *h, int64_t nrows);
 static size_t ws_pkovf_off(const rtfe_handle *h, int64_t nrows) { return ws_pkhard_off(h, nrows) + (h->dev.peak_path ? (((size_t)pk_hard_cap(h, nrows) * sizeof(SfHard) + 255) & ~(size_t)255) : 0); }
@@ -368,8 +370,10 @@ static size_t ws_pkqtile_off(const rtfe_handle *h, int64_t nrows) { return (ws_p
 static size_t pk_qtile_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_tiles_for(nrows) * 2 + 255) & ~(size_t)255) : 0; }
 // ... | the streams' tile offsets and totals (k_pscan) | the streams (k_prep): 16-byte records, entry references
 static long long pk_hard_cap(const rtfe_handle *h, int64_t nrows);
-// (a stream holds at most every slot's worth of records, a marker per tile, and three more records per deferred candidate)
-static long long pk_ccap(const rtfe_handle *h, int64_t nrows) { return pk_tiles_for(nrows) * (h->dev.pk_slot / 8 + 1) + 3 * pk_hard_cap(h, nrows) + 64; }
+// (a stream's capacity: every slot's worth of records and a marker per tile.  Deferred candidates add up to three records each; a stream
+//  that outgrows the capacity through them - its slots would have to be full of records without margins as well - is not built, and its
+//  chains give up)
+static long long pk_ccap(const rtfe_handle *h, int64_t nrows) { return pk_tiles_for(nrows) * (h->dev.pk_slot / 8 + 1) + 64; }
 static size_t ws_pktstart_off(const rtfe_handle *h, int64_t nrows) { return ws_pkqtile_off(h, nrows) + pk_qtile_bytes(h, nrows); }
 static size_t pk_tstart_bytes(const rtfe_handle *h, int64_t nrows) {      // tile offsets | chunk totals | chunk offsets | stream totals
    const size_t nl = (size_t)h->dev.nscreens * h->dev.ntrks, nch = (size_t)(pk_tiles_for(nrows) + 1023) / 1024;
@@ -483,7 +487,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (const int *)extrap, (int)ptiles, nlists, tstartp, ctotcp);
       hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
       hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
-                         (const uint32_t *)tstartp, (const uint32_t *)coffp, ptiles, ccap, crecp, erefp);
+                         (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, crecp, erefp);
       hipLaunchKernelGGL(k_prep2, dim3(nlists * ((h->num_cus * 8 + nlists - 1) / nlists)), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, crecp);
       t1(kTPrep);
       if (stop_after < 2) { skip_rest(); return launch_check("rtfe_scan"); }

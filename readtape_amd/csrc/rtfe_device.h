@@ -100,7 +100,7 @@ constexpr int kPkBack    = 64;       // rows k_sift looks back for the last forc
 //       bits 22-27  nsure                           the next nsure rows all have margins >= DevScreen::sure_i
 //       bits 28-31  ntail                           the next ntail rows carry explicit margins again; no row behind them passes the screen
 //                   nsure == 63: every row explicit, (nlead << 4 | ntail) of them from f
-//   w1  val (int16) | clamp(d(prev), -1, 254) + 1 (8 bits) | clamp(d(next), -1, 254) + 1 (8 bits)       d = |val - neighbour| signed towards "beyond the extreme"
+//   w1  val (int16) | clamp(d(prev), -1, 253) + 1 (8 bits) | clamp(d(next), -1, 253) + 1 (8 bits)       d = |val - neighbour| signed towards "beyond the extreme"
 //       0xffff8000: k_sift could not derive the reference's minimum; rows f .. f+nsure-1 are undecidable from the record
 // margin of a row = val - max(left edge, right edge) (tops) / min(edges) - val (bottoms), int16 code differences.
 // A list holds the records of the candidates of ONE tile in candidate order; their rows may run on into the next tile.

@@ -112,7 +112,7 @@ __device__ __forceinline__ long long stream_pos(const uint32_t *tstart, const ui
 
 __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
                                               const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff,
-                                              long long ntiles, long long ccap, CRec *__restrict__ crec, uint32_t *__restrict__ eref) {
+                                              const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint32_t *__restrict__ eref) {
    const DevCfg &cfg = *cfgp;
    const int nlists = cfg.nscreens * cfg.ntrks, hcap = cfg.pk_slot;
    const float mv = cfg.maxvolts;
@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
       if (d.nrec == 0) continue;
       const long long tile = li / nlists;
       const int sl = (int)(li - tile * nlists);
+      if ((long long)ctot[sl] > ccap) continue;                          // a stream that outgrew its capacity is not built: its chains give up (k_gain)
       long long base = (long long)sl * ccap + stream_pos(tstart, coff, nlists, tile, sl);
       if (d.nrec == 0xffffu) {                                          // a list that did not fit: one marker at the tile's first row
          if (lane == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; eref[base] = 0; }
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(256) k_prep2(const DevCfg *__restrict__ cfgp, 
    const int nper = (int)gridDim.x / nlists;                             // workgroups per stream (the grid is a multiple of the streams)
    {  const int sl = (int)blockIdx.x / nper, bx = (int)blockIdx.x - sl * nper;
       const int W = cfg.screen[sl / cfg.ntrks].W;
-      const long long n = ctot[sl];
+      const long long n = (long long)ctot[sl] > ccap ? 0 : (long long)ctot[sl];
       CRec *r = crec + (size_t)sl * ccap;
       for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < n; i += (long long)nper * blockDim.x) {
          const uint32_t w0 = r[i].w0, w1 = r[i].w1;
@@ -320,7 +321,8 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;       // first tile whose candidates all lie at or behind the limit
          i = stream_pos(tstart, coff, nlists, g0, sl);
          if (mode == 1 && active) i = cst[ci].i;
-         src.iend = ge < ntiles ? stream_pos(tstart, coff, nlists, ge, sl) : (long long)ctot[sl]; }
+         src.iend = ge < ntiles ? stream_pos(tstart, coff, nlists, ge, sl) : (long long)ctot[sl];
+         if ((long long)ctot[sl] > ccap) { failed = true; why = 6; src.iend = i; } }      // (the stream was not built: k_prep)
       const bool lean = cfg.pk_fast && cmode != RTFE_PE;                // (PE decides the end of its preamble from peak TIMES: the general step)
       const bool alpha_agc = !agc_off && P.agc_window == 0;           // steady state = the three-flop alpha filter
       const float alpha = P.agc_alpha, beta = 1 - P.agc_alpha;
@@ -341,7 +343,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       // steady state (NRZI / GCR: peakcount > 15, the baseline fixed; the alpha filter): thresholds straight from 1 / g
       bool steady = false;
       float kr = 0, km = 0, rg_min = 0;                                    // rise / min_peak thresholds in int16 units per unit of 1 / g; below rg_min = 1 / g they come near the screen's
-      const float g_min = 0.005f * lsb / 249.0f;                         // below it the half-sample refinement's threshold outgrows the records' neighbour distances (254)
+      const float g_min = 0.005f * lsb / 249.0f;                         // below it the half-sample refinement's threshold outgrows the records' neighbour distances (253)
       // from here on the baseline is fixed: the steady path's constants
       auto enter_steady = [&]() {
          steady = true;
@@ -471,7 +473,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          const float g = w.agc_gain;
          const float thr = 0.005f / g;
          const int ti = (int)floorf(thr * lsb);
-         if (ti + 2 > 254) { failed = true; why = 3; return 2; }                    // (neighbour distances are stored up to 254)
+         if (ti + 2 > 253) { failed = true; why = 3; return 2; }                    // (neighbour distances are stored up to 253)
          const int val_i = u.val;
          const int iprev = u.top ? val_i - u.dprev : val_i + u.dprev, inext = u.top ? val_i - u.dnext : val_i + u.dnext;
          const int adjcode = refine_code(&cfg, val_i, iprev, inext, g, u.top);

@@ -137,7 +137,7 @@ __device__ __forceinline__ uint32_t pk_w0(int pos, bool top, int f, int nlead, i
    return (uint32_t)(pos + kSfPosBias) | ((top ? 0u : 1u) << 11) | ((uint32_t)(f - pos) << 12) | ((uint32_t)nlead << 18) | ((uint32_t)nsure << 22) | ((uint32_t)ntail << 28); }
 __device__ __forceinline__ uint32_t pk_w1(int val, int prev, int nxt, bool top) {
    int dp = top ? val - prev : prev - val, dn = top ? val - nxt : nxt - val;
-   dp = dp < -1 ? -1 : (dp > 254 ? 254 : dp); dn = dn < -1 ? -1 : (dn > 254 ? 254 : dn);
+   dp = dp < -1 ? -1 : (dp > 253 ? 253 : dp); dn = dn < -1 ? -1 : (dn > 253 ? 253 : dn);      // (253: a bottom at -32768 between far neighbours must not read as 0xffff8000, "minimum unknown")
    return (uint32_t)(uint16_t)val | ((uint32_t)(dp + 1) << 16) | ((uint32_t)(dn + 1) << 24); }
 
 // One record for owner `pos` over rows [ra, rb] (all of them rows at which the owner is what the detector tests): from the
@@ -347,7 +347,7 @@ __device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool b
    int dp = (int)(int16_t)(mm[W - 2] & 0xffffu), dn;                   // (mm[W-2] = min(extreme - x[p-1], ...): not what is needed; the differences proper:)
    {  const uint32_t dl = pk_subs(vv, LR[W - 2]), dr = pk_subs(vv, LR[1]);
       dp = (int)(int16_t)(dl & 0xffffu); dn = (int)(int16_t)(dr >> 16); }
-   dp = dp < -1 ? -1 : (dp > 254 ? 254 : dp); dn = dn < -1 ? -1 : (dn > 254 ? 254 : dn);
+   dp = dp < -1 ? -1 : (dp > 253 ? 253 : dp); dn = dn < -1 ? -1 : (dn > 253 ? 253 : dn);      // (253: a bottom at -32768 between far neighbours must not read as 0xffff8000, "minimum unknown")
    w1 = (uint32_t)(uint16_t)val | ((uint32_t)(dp + 1) << 16) | ((uint32_t)(dn + 1) << 24);
    const int f = pk_ctz(C), l = 31 - pk_clz(C);
    const int span = l - f + 1;
@@ -596,6 +596,9 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                      st = pk_fast<WM>(cx, half ? h_hi : h_lo, cpos, ckind != 0, w0, w1); }
                   if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
                      const int hidx = atomicAdd(hard_count, 1);
+#ifdef RTFE_CPU_EMUL
+                     if (getenv("RTFE_HARD_WHY")) fprintf(stderr, "defer: tile %lld pos %d half %d screen %d hidx %d cap %d\n", (long long)tile, cpos, half, (int)sc, hidx, hard_cap);
+#endif
                      if (hidx < hard_cap) {
                         SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)(half ? h_hi : h_lo); hd.screen = (uint8_t)sc;
                         hard[hidx] = hd;
@@ -859,6 +862,9 @@ __global__ void __launch_bounds__(64) k_sift_hard(const DevCfg *__restrict__ cfg
       if (nrec > 4) nrec = -1;
       for (int j = 0; j < nrec; ++j) ne += pk_nent(sk.w0[j], sk.w1[j]);
       if (nrec > 0 && 8 + 8 * nrec + 2 * ne > kSfOvfBytes) nrec = -1;
+#ifdef RTFE_CPU_EMUL
+      if (getenv("RTFE_HARD_WHY")) { bool unk = false; for (int j = 0; j < nrec; ++j) unk = unk || sk.w1[j] == 0xffff8000u; fprintf(stderr, "hard: tile %u pos %d head %d screen %d W %d: sink %d nrec %d ne %d unknown-in-sink %d\n", hd.tile, (int)hd.pos, (int)hd.head, (int)hd.screen, cx.W, sk.n, nrec, ne, (int)unk); }
+#endif
       if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, cx.W - 2, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs or margins than a slot holds: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
       *reinterpret_cast<int *>(slot) = nrec;
       if (nrec != 1) atomicAdd(&extra[((size_t)hd.tile * cfg.nscreens + hd.screen) * cfg.ntrks + hd.head], nrec - 1);      // the list's length in its stream (k_pscan)
