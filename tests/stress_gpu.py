@@ -139,6 +139,7 @@ for i in range(ntapes):
     if keep: os.makedirs(keep, exist_ok=True)
     with (contextlib.nullcontext(keep) if keep else tempfile.TemporaryDirectory()) as wd:
         att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3")) else []
+        r_peak = None
         for rec in ("default", "1", "0"):                       # every format on both paths (peak path / sample path)
             t_case = time.perf_counter()
             if rec != "default": os.environ["RTFE_PEAK_PATH"] = rec
@@ -151,6 +152,17 @@ for i in range(ntapes):
                     fe = emul_frontend(config_for(hdr, opts))
                 else: fe = frontend.FrontEnd(config_for(hdr, opts))
                 msgs, stats = check_tape(fe, hdr, tape.rows, att)
+                if rec != "default":                                # the two paths against each other, byte for byte, everywhere (not only where an attempt looks)
+                    r = fe.scan(tape.rows).fetch()
+                    if rec == "1": r_peak = r
+                    elif r_peak is not None:
+                        cfgp = config_for(hdr, opts)
+                        if r.nbursts != r_peak.nbursts or any((r.bursts[k] != r_peak.bursts[k]).any() for k in ("zone_end", "reset_sample", "safe_last", "end_sample", "flags")): msgs.append("burst tables of the two paths differ")
+                        else:
+                            for bb in range(r.nbursts):
+                                for pp in range(len(cfgp.parmsets)):
+                                    for tt in range(cfgp.ntrks):
+                                        if r.track_events(bb, pp, tt).tobytes() != r_peak.track_events(bb, pp, tt).tobytes(): msgs.append(f"paths differ: burst {bb} parmset {pp} track {tt}")
             tag = f"{i:3d} {kind} seed {seed} amp {amp} noise {noise} jit {jit} opts {opts} general_step {seg} generic_sift {warm} peak_path {rec}: attempts {len(att)} events {stats['events']} speculative {stats.get('speculative')} flags {stats.get('flags')}"
             print(("FAIL " if msgs else "ok   ") + tag + f" [{time.perf_counter() - t_case:.1f} s]", flush=True)
             if msgs:

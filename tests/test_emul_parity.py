@@ -73,6 +73,29 @@ def test_emulated_paths_that_are_not_the_default(name, knobs, tmp_path, monkeypa
     assert stats["events"] > 0
 
 
+@pytest.mark.parametrize("name", ["gcr", "nrzi9_skew"])
+def test_emulated_peak_path_equals_the_sample_path(name, monkeypatch):
+    """Both paths on one tape: the same burst table and, per (burst, parameter set, track), the same events byte for byte - also where no
+    oracle attempt looks (behind the block ends; bursts the replay would rescan exactly).  gcr: a chain that reaches its steady state
+    in the middle of a chunk (the hand-over to k_gain_s once skipped the records it had stepped over)."""
+    g = load_case(name)
+    cfg = config_for(g["hdr"], g["oracle_opts"])
+    res = []
+    for pp in ("0", "1"):
+        monkeypatch.setenv("RTFE_PEAK_PATH", pp)
+        fe = emul_frontend(cfg)
+        res.append((fe, fe.scan(g["rows"]).fetch()))
+    (f0, r0), (f1, r1) = res
+    st = f1.scan_stats(r1)
+    assert r0.nbursts == r1.nbursts and st["redone"] == 0 and st["parallel"] > 0, st
+    for k in ("zone_first", "zone_end", "reset_sample", "safe_last", "end_sample", "flags"):
+        assert (r0.bursts[k] == r1.bursts[k]).all(), k
+    for b in range(r0.nbursts):
+        for p in range(len(cfg.parmsets)):
+            for t in range(cfg.ntrks):
+                assert r0.track_events(b, p, t).tobytes() == r1.track_events(b, p, t).tobytes(), (b, p, t)
+
+
 @pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}])
 def test_emulated_long_blocks(knobs, tmp_path, monkeypatch):
     """Blocks of 500-640 bytes: chains that cross many tiles (k_gain's heads, k_gain_s' steady stretches, the tails)."""

@@ -247,7 +247,7 @@ def test_agc_assert_inside_a_parameter_sweep_ends_everything(peak_path, tmp_path
     assert mine.size == g["events"].size and not refdump.compare(mine, g["events"])
 
 
-@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "pe", "gcr", "gcr_m", "nrzi9_skew", "nrzi9_nobpi", "nrzi7_order"])
+@pytest.mark.parametrize("name", PEAK_CASES + ["nrzi9_nobpi", "nrzi9_cut", "noise_only", "tiny", "gcr_errs"])
 def test_peak_record_path_equals_the_sample_path(name, gpu, monkeypatch):
     """The peak path (RTFE_PEAK_PATH=1: k_sift -> k_gain -> k_emit) against the sample path (RTFE_PEAK_PATH=0: k_decode): the same burst
     table and, per (burst, parameter set, track), the same events byte for byte - also behind the block ends, where no oracle
