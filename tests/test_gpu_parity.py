@@ -268,7 +268,7 @@ def test_peak_record_path_equals_the_sample_path(name, gpu, monkeypatch):
         for p in range(len(cfg.parmsets)):
             for t in range(cfg.ntrks):
                 assert r0.track_events(b, p, t).tobytes() == r1.track_events(b, p, t).tobytes(), (b, p, t)
-    assert st["parallel"] + st["sequential"] > 0 or st["redone"] == st["bursts"]
+    assert st["parallel"] + st["sequential"] > 0 or st["redone"] == st["bursts"] or int(r1.counts.sum()) == 0
 
 
 def test_differentiated_peak_path_restarts_in_exact_zero_gaps(tmp_path, gpu):
