@@ -131,12 +131,105 @@ def e2e_line(tape, copies, conf, dev):
             "path": ".tbin in the page cache -> parallel positional reads into pinned buffers -> hipMemcpyAsync on a copy stream -> rtfe_scan (two contexts in flight) -> event arena packed on the device -> host replay of the windows (fragments) side by side -> .tap"}
 
 
+class Workload:
+    """What one rank times: its rows resident in device memory (tail = room for the seam halo), the front end, and step() - one pass of
+    the hot path over those rows, the halo exchange included.  main() builds it on cuda:LOCAL_RANK; tests/test_shard_gloo.py builds the
+    same object on CPU tensors with the emulated kernels and two gloo ranks, and drives the same step()."""
+
+    HALO = 1 << 18
+
+    def __init__(self, conf, rank, world, dev, dist, total_rows, base_rows, window_rows=None, pipeline=False, fe_factory=None, halo=None, tape=None):
+        import torch
+        from readtape_amd import frontend, shard
+        self.torch, self.dist, self.shard = torch, dist, shard
+        self.conf, self.rank, self.world, self.dev, self.pipeline = conf, rank, world, dev, pipeline
+        self.cuda = dev.type == "cuda"
+        self.halo_rows = int(halo or self.HALO)
+        self.strong = bool(conf.get("strong"))
+        # weak (C2..C4): every rank holds its own tape of `rows` rows (its own seed) - N tapes of a collection decoded side by side is
+        # what the shards of a longer tape look like; strong (C5): ONE tape (same seed everywhere), rank r holds plan_shards()[r].
+        self.tape = tape or make_base_tape(seed=1000 + (0 if self.strong else rank), target_rows=int(base_rows), kind=conf["kind"])
+        hdr = self.tape.spec.header()
+        base = torch.from_numpy(self.tape.rows).to(dev)
+        self.copies = max(1, int(round(total_rows / base.shape[0])))
+        if self.strong:
+            n_tape = self.copies * int(base.shape[0])
+            spans = shard.plan_shards(n_tape, world)
+            lo, hi = spans[rank]
+            idx0 = lo % base.shape[0]
+            reps = (hi - lo + idx0) // base.shape[0] + 2
+            own = base.repeat(reps, 1)[idx0: idx0 + (hi - lo)]
+            self.row_base = lo
+            self.lens = [b - a for a, b in spans]
+        else:
+            own = base.repeat(self.copies, 1)
+            self.row_base = rank * int(own.shape[0])
+            self.lens = [int(own.shape[0])] * world
+        self.nrows = int(own.shape[0])
+        # time shards: this rank owns `nrows` rows; the tail of the ONE buffer receives the first rows of the rank(s) behind it
+        self.sr = shard.ShardRows(own, self.halo_rows if (world > 1 and rank < world - 1) else 0)
+        del own, base
+        parmsets = None
+        if conf["nparmsets"] > len(frontend.DEFAULT_PARMSETS[hdr.mode]):
+            # the reference ships 5 GCR sets (src/parmsets.c:104-110); a .parms file may hold more - the sweep is filled up to 8 with
+            # variations of the window width, the rise threshold and the minimum peak, as such a file would
+            extra = [(1.4, 0.20, 0.2, 0.5, 0, 0.0), (1.6, 0.14, 0.0, 0.5, 0, 0.0), (1.5, 0.10, 0.1, 0.5, 0, 0.0), (1.3, 0.25, 0.2, 0.5, 0, 0.0)]
+            parmsets = (list(frontend.DEFAULT_PARMSETS[hdr.mode]) + extra)[: conf["nparmsets"]]
+        self.cfg = frontend.FrontEndConfig.from_header(hdr, nparmsets=conf["nparmsets"], find_zeros=conf["find_zeros"], parmsets=parmsets)
+        make = (lambda: frontend.FrontEnd(self.cfg, device=str(dev))) if fe_factory is None else (lambda: fe_factory(self.cfg))
+        self.fe = make()
+        # fragments of the resident rows (one when the workspace fits)
+        wrows = int(window_rows or conf["window_rows"] or 0)
+        if wrows and wrows < self.nrows:
+            wrows = wrows // 1024 * 1024
+            self.frags = [(a, min(self.nrows, a + wrows)) for a in range(0, self.nrows, wrows)]
+        else:
+            self.frags = [(0, self.nrows)]
+        # Default: one stream, steps back to back (the per-kernel HIP-event times are then contention-free, which is what the
+        # roofline line needs).  --pipeline alternates two front-end contexts (own HIP stream, workspace and outputs) so that
+        # the latency-bound sequential pass of step i overlaps the dense pass of step i+1.
+        if pipeline and self.cuda:
+            self.fes = [self.fe, make()]
+            self.streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        else:
+            self.fes = [self.fe, self.fe]
+            self.streams = [torch.cuda.current_stream(dev)] * 2 if self.cuda else [None, None]
+        if self.cuda:
+            for f in set(self.fes): f.set_timing(True)
+        self.kms = {k: 0.0 for k in self.fe.kernel_names()} if self.cuda else {}
+
+    def scan_frag(self, f, s, a, b):
+        last = b >= self.nrows
+        ntot = self.nrows + self.sr.got
+        end = ntot if last else min(ntot, b + self.halo_rows)
+        rows = self.sr.buf[a:end]
+        if not self.cuda: rows = rows.numpy()
+        kw = dict(stream=s.cuda_stream) if self.cuda else {}
+        return f.scan(rows, row_base=self.row_base + a, first_is_tape_start=(self.rank == 0 and a == 0), own_rows=b - a, **kw)
+
+    def step(self, i, timed=False, each=None):
+        import contextlib
+        s, f = self.streams[i & 1], self.fes[i & 1]
+        with (self.torch.cuda.stream(s) if self.cuda else contextlib.nullcontext()):
+            # the seam halo is the only exchange: neighbour isend/irecv over RCCL (xGMI), no collective on the data path
+            self.shard.exchange_halo(self.sr, self.halo_rows, self.rank, self.world, self.dist, lens=self.lens)
+            res = None
+            for a, b in self.frags:
+                res = self.scan_frag(f, s, a, b)
+                if each is not None:
+                    each(res)
+                if timed and self.cuda and (len(self.frags) > 1 or not self.pipeline):
+                    ms = f.kernel_ms()               # HIP events on the scan's stream (synchronises this scan)
+                    for kk in self.kms: self.kms[kk] += ms[kk]
+            return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2", help="BASELINE.json configs[1..4]; the driver's default line is C2")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="BASELINE.json configs[1..4]; default: C2 on one GPU, C5 (one tape, time-sharded: strong scaling) on several")
     ap.add_argument("--rows", type=float, default=None, help="sample instants per GPU (C5: of the whole tape); default: the config's")
     ap.add_argument("--window-rows", type=float, default=None)
     ap.add_argument("--base-rows", type=float, default=5e6)
@@ -144,6 +237,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="alternate two front-end contexts on two HIP streams (steps overlap; per-kernel times then include contention)")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = "C2" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "C5"
     conf = CONFIGS[args.config]
 
     import torch
@@ -162,89 +257,9 @@ def main():
     strong = bool(conf.get("strong"))
     total_rows = float(args.rows or conf["rows"])
 
-    # ---- synthetic tape, resident in HBM ----
-    # weak (C2..C4): every rank holds its own tape of `rows` rows (its own seed) - N tapes of a collection decoded side by side is
-    # what the shards of a longer tape look like; strong (C5): ONE tape (same seed everywhere), rank r holds plan_shards()[r].
-    tape = make_base_tape(seed=1000 + (0 if strong else rank), target_rows=int(args.base_rows), kind=conf["kind"])
-    hdr = tape.spec.header()
-    base = torch.from_numpy(tape.rows).to(dev)
-    copies = max(1, int(round(total_rows / base.shape[0])))
-    if strong:
-        n_tape = copies * int(base.shape[0])
-        lo, hi = shard.plan_shards(n_tape, world)[rank]
-        idx0 = lo % base.shape[0]
-        reps = (hi - lo + idx0) // base.shape[0] + 2
-        rows = base.repeat(reps, 1)[idx0: idx0 + (hi - lo)].contiguous()
-        row_base = lo
-    else:
-        rows = base.repeat(copies, 1).contiguous()
-        row_base = rank * int(rows.shape[0])
-    nrows = int(rows.shape[0])
-    del base
-    parmsets = None
-    if conf["nparmsets"] > len(frontend.DEFAULT_PARMSETS[hdr.mode]):
-        # the reference ships 5 GCR sets (src/parmsets.c:104-110); a .parms file may hold more - the sweep is filled up to 8 with
-        # variations of the window width, the rise threshold and the minimum peak, as such a file would
-        extra = [(1.4, 0.20, 0.2, 0.5, 0, 0.0), (1.6, 0.14, 0.0, 0.5, 0, 0.0), (1.5, 0.10, 0.1, 0.5, 0, 0.0), (1.3, 0.25, 0.2, 0.5, 0, 0.0)]
-        parmsets = (list(frontend.DEFAULT_PARMSETS[hdr.mode]) + extra)[: conf["nparmsets"]]
-    cfg = frontend.FrontEndConfig.from_header(hdr, nparmsets=conf["nparmsets"], find_zeros=conf["find_zeros"], parmsets=parmsets)
-    fe = frontend.FrontEnd(cfg, device=str(dev))
-    fe.set_timing(True)
-
-    # time shards: this rank owns `nrows` rows; the tail of the buffer receives the right neighbour's first rows
-    HALO = 1 << 18
-    halo_rows = HALO if (world > 1 and rank < world - 1) else 0
-    if halo_rows:
-        buf = torch.empty((nrows + halo_rows, rows.shape[1]), dtype=rows.dtype, device=dev)
-        buf[:nrows].copy_(rows)
-        rows = buf
-        del buf
-    own_view = rows[:nrows]
-    ntot = int(rows.shape[0])
-    # fragments of the resident rows (one when the workspace fits)
-    wrows = int(args.window_rows or conf["window_rows"] or 0)
-    if wrows and wrows < nrows:
-        wrows = wrows // 1024 * 1024
-        frags = [(a, min(nrows, a + wrows)) for a in range(0, nrows, wrows)]
-    else:
-        frags = [(0, nrows)]
-
-    # Default: one stream, steps back to back (the per-kernel HIP-event times are then contention-free, which is what the
-    # roofline line needs).  --pipeline alternates two front-end contexts (own HIP stream, workspace and outputs) so that
-    # the latency-bound sequential pass of step i overlaps the dense pass of step i+1 (about 10 % more throughput).
-    if args.pipeline:
-        fes = [fe, frontend.FrontEnd(cfg, device=str(dev))]
-        fes[1].set_timing(True)
-        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-    else:
-        fes = [fe, fe]
-        streams = [torch.cuda.current_stream(dev)] * 2
-    kms = {k: 0.0 for k in fe.kernel_names()}
-
-    def scan_frag(f, s, a, b):
-        last = b >= nrows
-        end = ntot if last else min(ntot, b + HALO)
-        return f.scan(rows[a:end], row_base=row_base + a, first_is_tape_start=(rank == 0 and a == 0), own_rows=b - a, stream=s.cuda_stream)
-
-    def step(i, timed=False, each=None):
-        s = streams[i & 1]
-        f = fes[i & 1]
-        with torch.cuda.stream(s):
-            if world > 1:
-                # the seam halo is the only exchange: neighbour isend/irecv over RCCL (xGMI), no collective on the data path
-                ops = []
-                if rank > 0: ops.append(dist.P2POp(dist.isend, own_view[:HALO], rank - 1))
-                if rank < world - 1: ops.append(dist.P2POp(dist.irecv, rows[nrows:], rank + 1))
-                for w in dist.batch_isend_irecv(ops): w.wait()
-            res = None
-            for k, (a, b) in enumerate(frags):
-                res = scan_frag(f, s, a, b)
-                if each is not None:
-                    each(res)
-                if timed and (len(frags) > 1 or not args.pipeline):
-                    ms = f.kernel_ms()               # HIP events on the scan's stream (synchronises this scan)
-                    for kk in kms: kms[kk] += ms[kk]
-            return res
+    # ---- synthetic tape, resident in HBM; the front end; step() ----
+    wl = Workload(conf, rank, world, dev, dist, total_rows, args.base_rows, window_rows=args.window_rows, pipeline=args.pipeline)
+    tape, cfg, fe, fes, frags, kms, nrows, copies, step = wl.tape, wl.cfg, wl.fe, wl.fes, wl.frags, wl.kms, wl.nrows, wl.copies, wl.step
 
     torch.cuda.synchronize(dev)
     for i in range(args.warmup):
@@ -317,8 +332,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(tape, ncopies, conf)
         if not args.no_e2e and world == 1:
-            fe.close()
-            del rows, own_view
+            for f in set(fes): f.close()
+            del wl.sr
             torch.cuda.empty_cache()
             try:
                 # (C2, the driver's line: a sample long enough for the reader's pipeline to fill - 16 copies, ~9e7 rows, 1.6 GB; the

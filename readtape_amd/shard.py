@@ -24,30 +24,85 @@ def plan_shards(nrows: int, world: int, align: int = 1024):
     return live + [(nrows, nrows)] * (world - len(live))
 
 
-def exchange_halo(own, halo_rows: int, rank: int, world: int, dist):
-    """own: [n, ntrks] int16 tensor holding this rank's rows.  Sends its first `halo_rows` rows to the left
-    neighbour, receives the right neighbour's, and returns (rows_with_halo, own_rows)."""
+class ShardRows:
+    """This rank's rows with room for the halo behind them: ONE buffer [n + halo_cap, ntrks], allocated once (the halo exchange
+    receives straight into its tail; no concatenation per step)."""
+
+    def __init__(self, own, halo_cap: int):
+        import torch
+        self.n = int(own.shape[0])
+        self.cap = int(halo_cap)
+        self.buf = torch.empty((self.n + self.cap, own.shape[1]), dtype=own.dtype, device=own.device)
+        self.buf[: self.n].copy_(own)
+        self.got = 0                                   # halo rows the last exchange delivered
+
+    def own(self):
+        return self.buf[: self.n]
+
+    def rows(self):
+        return self.buf[: self.n + self.got]
+
+    def reserve(self, halo_cap: int):
+        """A longer halo (the rare retry of decode_sharded): a new buffer, the own rows copied over once."""
+        import torch
+        if halo_cap > self.cap:
+            nb = torch.empty((self.n + int(halo_cap), self.buf.shape[1]), dtype=self.buf.dtype, device=self.buf.device)
+            nb[: self.n].copy_(self.buf[: self.n])
+            self.buf, self.cap = nb, int(halo_cap)
+
+
+def gather_lens(n: int, device, world: int, dist):
+    """Every rank's row count, as a tensor all-gather (8 bytes per rank)."""
     import torch
-    n = own.shape[0]
+    t = torch.tensor([int(n)], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [int(x.item()) for x in out]
+
+
+def halo_plan(lens, halo_rows: int):
+    """Who sends what to whom: rank d's halo is the tape rows [hi_d, hi_d + halo_rows) (cut at the tape's end), which may span several
+    of the ranks behind it (a short shard, a long halo).  Returns [(src, dst, first row in src's range, rows, offset in dst's halo)]."""
+    starts = [0]
+    for n in lens:
+        starts.append(starts[-1] + int(n))
+    total = starts[-1]
+    plan = []
+    for d in range(len(lens) - 1):
+        if lens[d] == 0:
+            continue
+        a, b = starts[d + 1], min(total, starts[d + 1] + int(halo_rows))
+        for s in range(d + 1, len(lens)):
+            lo, hi = max(a, starts[s]), min(b, starts[s + 1])
+            if hi > lo:
+                plan.append((s, d, lo - starts[s], hi - lo, lo - a))
+    return plan
+
+
+def exchange_halo(sr, halo_rows: int, rank: int, world: int, dist, lens=None):
+    """sr: this rank's ShardRows (or a [n, ntrks] tensor: a ShardRows is made for it).  Fills the halo - the first rows of the ranks
+    behind this one, as many of them as halo_rows reaches - by neighbour isend/irecv (RCCL over xGMI, or gloo), no collective on the
+    data path; `lens` (every rank's row count) saves the 8-byte all-gather when the caller knows it.  Returns (rows_with_halo, own_rows)."""
+    if not isinstance(sr, ShardRows):
+        sr = ShardRows(sr, halo_rows if rank < world - 1 else 0)
     if world == 1:
-        return own, n
-    h = min(halo_rows, n)
-    send = own[:h].contiguous()
-    recv = torch.empty((halo_rows, own.shape[1]), dtype=own.dtype, device=own.device) if rank < world - 1 else None
-    # neighbours may own fewer rows than the halo: agree on the length first (tiny, host side)
-    lens = [None] * world
-    dist.all_gather_object(lens, int(h))
-    ops = []
-    if rank > 0:
-        ops.append(dist.P2POp(dist.isend, send, rank - 1))
-    if rank < world - 1:
-        recv = recv[: lens[rank + 1]]
-        ops.append(dist.P2POp(dist.irecv, recv, rank + 1))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    if rank == world - 1:
-        return own, n
-    return torch.cat([own, recv], 0).contiguous(), n
+        sr.got = 0
+        return sr.rows(), sr.n
+    if lens is None:
+        lens = gather_lens(sr.n, sr.buf.device, world, dist)
+    sr.reserve(halo_rows if rank < world - 1 else 0)
+    ops, got = [], 0
+    for s, d, first, cnt, off in halo_plan(lens, halo_rows):
+        if s == rank:
+            ops.append(dist.P2POp(dist.isend, sr.buf[first: first + cnt], d))
+        elif d == rank:
+            ops.append(dist.P2POp(dist.irecv, sr.buf[sr.n + off: sr.n + off + cnt], s))
+            got = max(got, off + cnt)
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    sr.got = got
+    return sr.rows(), sr.n
 
 
 def absolute_bursts(res, start_row: int):
@@ -73,12 +128,14 @@ def flatten_events(res, bursts_abs, parmset: int):
 def decode_sharded(hdr, own, lo: int, n_total: int, rank: int, world: int, dist, tap_path: str | None, opts=None, fe_factory=None,
                    halo_rows: int = 1 << 16, cfgkw=None):
     """The whole multi-rank decode of ONE tape: `own` = this rank's rows [lo, lo + len(own)) of the n_total-row tape.
-      1. neighbour halo exchange (isend/irecv; repeated with a longer halo while some rank's last own burst runs past it),
+      1. halo exchange (isend/irecv; repeated with a four times longer halo - it may then span several of the ranks behind - while some
+         rank's last own burst runs past it; the halo stops growing at the tape's end, so the loop ends),
       2. rtfe_scan of own + halo with the own_rows ownership rule,
-      3. all-gather of one small record per rank {own range, bursts, events per parameter set, .tap bytes} (the only collective),
-      4. host replay of the own bursts -> this rank's piece of the .tap,
-      5. rank 0 gathers the pieces in rank order, concatenates them and ends the file (tap_path; other ranks pass None or the same path).
-    Returns the list of per-rank records (every rank) - their 'tap_offset' fields are the prefix sums of the pieces."""
+      3. host replay of the own bursts -> this rank's piece of the .tap,
+      4. tensor all-gather of one small record per rank {own range, bursts, events per parameter set, .tap bytes} (the only collectives),
+      5. rank 0 gathers the pieces (uint8 tensors, padded to the longest) in rank order, concatenates them and ends the file.
+    A failure on one rank (a fatal reference condition in its replay, a device error) is agreed on by all ranks before the next
+    collective: every rank raises, none is left waiting.  Returns the list of per-rank records (every rank)."""
     import torch
     from . import frontend, pipeline
     opts = opts or pipeline.DecodeOptions()
@@ -86,42 +143,73 @@ def decode_sharded(hdr, own, lo: int, n_total: int, rank: int, world: int, dist,
     cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=pipeline.frontend_parmsets(full), **(cfgkw or {}))
     fe = (fe_factory or frontend.FrontEnd)(cfg)
     n = int(own.shape[0])
+    dev = own.device
     is_last = lo + n >= n_total
-    halo = halo_rows
+    lens = gather_lens(n, dev, world, dist)
+    sr = ShardRows(own, min(halo_rows, max(0, n_total - lo - n)))
+    halo = int(halo_rows)
+    err = None
+
+    def agree(more):
+        """[someone needs a longer halo, someone failed] - one 16-byte all-reduce, every rank in the same place"""
+        t = torch.tensor([1 if more else 0, 1 if err is not None else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t[1].item()):
+            fe.close()
+            if err is not None:
+                raise RuntimeError(f"decode_sharded: rank {rank} failed: {err!r}") from err
+            raise RuntimeError("decode_sharded: another rank failed; this rank stops with it")
+        return bool(int(t[0].item()))
+
+    res, nb, bound, piece = None, 0, None, None
     while True:
-        with_halo, own_rows = exchange_halo(own, halo, rank, world, dist)
-        piece = with_halo if isinstance(with_halo, np.ndarray) or fe_factory is None else with_halo.numpy()
-        res, nb, bound = pipeline.scan_fragment(fe, piece, own_rows, lo, lo == 0, is_last)() if n > 0 else (None, 0, None)
-        got_all = lo + int(piece.shape[0]) >= n_total
-        more = torch.tensor([1 if (n > 0 and nb is None and not got_all) else 0])
-        dist.all_reduce(more, op=dist.ReduceOp.MAX)          # (host-side agreement, a few bytes)
-        if int(more.item()) == 0:
+        with_halo, own_rows = exchange_halo(sr, halo, rank, world, dist, lens=lens)
+        more = False
+        try:
+            piece = with_halo if fe_factory is None else with_halo.numpy()
+            res, nb, bound = pipeline.scan_fragment(fe, piece, own_rows, lo, lo == 0, is_last)() if n > 0 else (None, 0, None)
+            got_all = lo + int(piece.shape[0]) >= n_total
+            more = n > 0 and nb is None and not got_all
+        except Exception as e:                                # (agreed on below: no rank is left in a collective)
+            err = e
+        if not agree(more):
             break
-        halo *= 4
+        halo = min(halo * 4, n_total)                         # (a halo as long as the tape reaches its end from anywhere)
     tap_bytes = b""
     stats = dict(blocks=0, tapemarks=0, events_delivered=0)
-    if n > 0 and res.nbursts > 0:
-        import os, tempfile
-        with tempfile.TemporaryDirectory() as wd:
-            frag = os.path.join(wd, f"r{rank}.tap")
-            start = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
-            stats = pipeline.decode_fragment(hdr, cfg, fe, res, piece, lo, start, bound, frag, full, opts, fe_factory)
-            tap_bytes = open(frag, "rb").read()
-    mine = dict(rank=rank, lo=lo, hi=lo + n, bursts=int(res.nbursts) if n > 0 else 0,
-                events=[int(x) for x in res.counts.sum(axis=(0, 2))] if n > 0 and res.nbursts else [0] * len(full),
-                blocks=int(stats["blocks"]), tapemarks=int(stats["tapemarks"]), tap_len=len(tap_bytes))
-    table = [None] * world
-    dist.all_gather_object(table, mine)
-    off = 0
-    for rec in table:
-        rec["tap_offset"] = off
-        off += rec["tap_len"]
-    pieces = [None] * world if rank == 0 else None
-    dist.gather_object(tap_bytes, pieces, dst=0)
+    try:
+        if n > 0 and res.nbursts > 0:
+            import os, tempfile
+            with tempfile.TemporaryDirectory() as wd:
+                frag = os.path.join(wd, f"r{rank}.tap")
+                start = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
+                stats = pipeline.decode_fragment(hdr, cfg, fe, res, piece, lo, start, bound, frag, full, opts, fe_factory)
+                tap_bytes = open(frag, "rb").read()
+    except Exception as e:
+        err = e
+    agree(False)
+    # the per-rank records: int64 tensors, all-gathered
+    ev = [int(x) for x in res.counts.sum(axis=(0, 2))] if n > 0 and res.nbursts else [0] * len(full)
+    mine = torch.tensor([rank, lo, lo + n, int(res.nbursts) if n > 0 else 0, int(stats["blocks"]), int(stats["tapemarks"]), len(tap_bytes)] + ev,
+                        dtype=torch.int64, device=dev)
+    recs = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(recs, mine)
+    table, off = [], 0
+    for t in recs:
+        v = [int(x) for x in t.tolist()]
+        table.append(dict(rank=v[0], lo=v[1], hi=v[2], bursts=v[3], blocks=v[4], tapemarks=v[5], tap_len=v[6], events=v[7:], tap_offset=off))
+        off += v[6]
+    # the .tap pieces: uint8 tensors padded to the longest piece, gathered on rank 0
+    longest = max(1, max(r["tap_len"] for r in table))
+    mine_b = torch.zeros(longest, dtype=torch.uint8, device=dev)
+    if tap_bytes:
+        mine_b[: len(tap_bytes)] = torch.frombuffer(bytearray(tap_bytes), dtype=torch.uint8).to(dev)
+    pieces = [torch.zeros_like(mine_b) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine_b, pieces, dst=0)
     if rank == 0 and tap_path:
         with open(tap_path, "wb") as f:
-            for pc in pieces:
-                f.write(pc)
+            for r, pc in zip(table, pieces):
+                f.write(pc[: r["tap_len"]].cpu().numpy().tobytes())
             if off > 0:
                 f.write(b"\xff\xff\xff\xff")                # src/readtape.c:1885
     fe.close()

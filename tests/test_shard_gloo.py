@@ -122,3 +122,76 @@ def test_two_ranks_write_the_single_rank_tap(case, cutrow, tmp_path):
     table = pickle.load(open(out + ".tab", "rb"))
     assert [t["rank"] for t in table] == [0, 1] and table[1]["tap_offset"] == table[0]["tap_len"]
     assert sum(t["blocks"] + t["tapemarks"] for t in table) > 0 and all(t["bursts"] > 0 for t in table)
+
+
+BENCH_WORKER = r'''
+import os, sys, pickle
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "tools"))
+import numpy as np, torch, torch.distributed as dist
+import bench
+from emul_util import emul_frontend
+from readtape_amd import shard, synth
+config, out, halo = sys.argv[2], sys.argv[3], int(sys.argv[4])
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+tape = synth.nrzi_tape(seed=77, nblocks=5, minlen=64, maxlen=300, marks_every=3, gap_samples=3000)
+wl = bench.Workload(bench.CONFIGS[config], rank, world, torch.device("cpu"), dist, total_rows=3 * tape.rows.shape[0], base_rows=0,
+                    fe_factory=emul_frontend, halo=halo, tape=tape)
+parts = []
+for i in range(2):                                   # two steps: the halo exchange repeats into the same buffer
+    res = wl.step(i).fetch()
+    b = shard.absolute_bursts(res, wl.row_base)
+    parts.append(dict(bursts=b, events=shard.flatten_events(res, b, 0), lo=wl.row_base, n=wl.nrows, got=wl.sr.got))
+allr = [None] * world
+dist.all_gather_object(allr, parts)                  # (test plumbing only)
+if rank == 0:
+    pickle.dump(allr, open(out, "wb"))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("config,halo", [("C5", 1 << 14), ("C2", 1 << 14)])
+def test_two_ranks_drive_the_step_of_bench_py(config, halo, tmp_path):
+    """bench.py's own Workload.step() - what `bench.py --gpus N` times - on two gloo ranks with the emulated kernels.  C5 (the default
+    for N > 1): ONE tape cut by plan_shards, the seam halo received into the tail of the rank's one buffer, rtfe_scan with the ownership
+    rule; the ranks' bursts and events together are the single scan of the whole tape.  C2 with N > 1 (weak): every rank's own tape."""
+    import pickle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import bench
+    from emul_util import build_emul, emul_frontend
+    from readtape_amd import frontend, shard, synth
+    build_emul()
+    out = str(tmp_path / "res.pkl")
+    wfile = tmp_path / "bench_worker.py"
+    wfile.write_text(BENCH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 1000), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(wfile), ROOT, config, out, str(halo)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    parts = pickle.load(open(out, "rb"))
+    tape = synth.nrzi_tape(seed=77, nblocks=5, minlen=64, maxlen=300, marks_every=3, gap_samples=3000)
+    fe = emul_frontend(frontend.FrontEndConfig.from_header(tape.spec.header()))
+    key = lambda e: e[np.lexsort((e[:, 1], e[:, 0]))]
+    if config == "C5":
+        rows = np.tile(tape.rows, (3, 1))
+        assert [(p[0]["lo"], p[0]["lo"] + p[0]["n"]) for p in parts] == shard.plan_shards(rows.shape[0], 2)
+        assert parts[0][0]["got"] == halo and parts[1][0]["got"] == 0
+        whole = fe.scan(rows).fetch()
+        wb = shard.absolute_bursts(whole, 0)
+        we = shard.flatten_events(whole, wb, 0)
+        for i in range(2):
+            got_b = np.concatenate([p[i]["bursts"] for p in parts])
+            got_e = np.concatenate([p[i]["events"] for p in parts])
+            for f in ("zone_end", "reset_sample", "safe_last", "end_sample"):
+                assert list(got_b[f]) == list(wb[f]), f
+            assert got_e.shape == we.shape and (key(got_e) == key(we)).all()
+        assert we.shape[0] > 5000
+    else:
+        # weak: rank r scans its own 3 copies (+ the first rows of rank r + 1's tape as halo); its own bursts are the single scan's
+        # except the one that straddles the end of its rows
+        assert parts[0][0]["n"] == parts[1][0]["n"] == 3 * tape.rows.shape[0]
+        whole = fe.scan(np.tile(tape.rows, (3, 1))).fetch()
+        assert parts[1][0]["bursts"].shape[0] == whole.nbursts and parts[0][0]["bursts"].shape[0] >= whole.nbursts - 1
+        assert parts[0][0]["got"] == halo and parts[1][0]["got"] == 0 and parts[1][0]["lo"] == parts[0][0]["n"]
+        assert parts[0][1]["events"].shape == parts[0][0]["events"].shape and (parts[0][1]["events"] == parts[0][0]["events"]).all()
