@@ -84,14 +84,18 @@ import numpy as np, torch, torch.distributed as dist
 from emul_util import emul_frontend
 from golden_util import load_case
 from readtape_amd import shard
-case, out, cutrow = sys.argv[2], sys.argv[3], int(sys.argv[4])
+case, out, cuts = sys.argv[2], sys.argv[3], [int(x) for x in sys.argv[4].split(",") if int(x)]
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 g = load_case(case)
 rows = np.ascontiguousarray(g["rows"])
 n = rows.shape[0]
-spans = [(0, cutrow), (cutrow, n)] if cutrow else shard.plan_shards(n, world, align=64)
+spans = list(zip([0] + cuts, cuts + [n])) if cuts else shard.plan_shards(n, world, align=64)
 lo, hi = spans[rank]
+if os.environ.get("TEST_FAIL_RANK") == str(rank):          # (a fatal reference condition in one rank's replay)
+    from readtape_amd import pipeline
+    def boom(*a, **k): raise pipeline.ReferenceFatal("injected")
+    pipeline.decode_fragment = boom
 table = shard.decode_sharded(g["hdr"], torch.from_numpy(rows[lo:hi].copy()), lo, n, rank, world, dist, out if rank == 0 else None,
                              fe_factory=emul_frontend, halo_rows=1024)
 if rank == 0:
@@ -122,6 +126,39 @@ def test_two_ranks_write_the_single_rank_tap(case, cutrow, tmp_path):
     table = pickle.load(open(out + ".tab", "rb"))
     assert [t["rank"] for t in table] == [0, 1] and table[1]["tap_offset"] == table[0]["tap_len"]
     assert sum(t["blocks"] + t["tapemarks"] for t in table) > 0 and all(t["bursts"] > 0 for t in table)
+
+
+def test_three_ranks_with_a_shard_shorter_than_the_halo(tmp_path):
+    """The middle rank owns 640 rows: the first rank's burst runs through all of them into the third rank's rows, so its halo must span
+    two ranks (the retry loop of decode_sharded once waited for ever for rows its neighbour did not have)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emul_util import build_emul
+    from golden_util import load_case
+    build_emul()
+    out = str(tmp_path / "sharded.tap")
+    wfile = tmp_path / "tap_worker.py"
+    wfile.write_text(TAP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 1000), WORLD_SIZE="3")
+    procs = [subprocess.Popen([sys.executable, str(wfile), ROOT, "nrzi9", out, "2496,3136"], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(3)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    assert open(out, "rb").read() == load_case("nrzi9")["tap"]
+
+
+def test_a_failing_rank_stops_every_rank(tmp_path):
+    """One rank's replay raises: the ranks agree on the failure before the next collective, and every process ends with an error
+    instead of one waiting in a gather for ever."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emul_util import build_emul
+    build_emul()
+    out = str(tmp_path / "sharded.tap")
+    wfile = tmp_path / "tap_worker.py"
+    wfile.write_text(TAP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 1000), WORLD_SIZE="2", TEST_FAIL_RANK="1")
+    procs = [subprocess.Popen([sys.executable, str(wfile), ROOT, "nrzi9", out, "0"], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stderr=subprocess.PIPE, text=True) for r in range(2)]
+    errs = [p.communicate(timeout=600)[1] for p in procs]
+    assert all(p.returncode != 0 for p in procs)
+    assert "rank 1 failed" in errs[1] and "another rank failed" in errs[0]
 
 
 BENCH_WORKER = r'''
