@@ -80,6 +80,8 @@ int rt_csv_survey(const char *path, int ntrks, float scale, int subsample, float
 int64_t rt_csv_load(const char *path, int ntrks, const int *perm, int invert, float scale, int subsample, float maxvolts,
                     int16_t *rows, int64_t capacity, int64_t *clipped) {
    char line[LINE_MAX_CHARS + 1];
+   if (ntrks < 1 || ntrks > RT_CSV_MAXTRKS) return -3;                          /* (v[] below holds RT_CSV_MAXTRKS columns) */
+   if (perm) for (int k = 0; k < ntrks; ++k) if (perm[k] < 0 || perm[k] >= ntrks) return -4;
    FILE *f = fopen(path, "r");
    if (!f) return -1;
    if (!next_line(f, line) || !next_line(f, line)) { fclose(f); return -2; }

@@ -30,22 +30,35 @@ def _lib():
 def read_csv(path: str, ntrks: int = 9, mode: int = tbin.MODE_NRZI, bpi: float = 0.0, ips: float = 0.0, order: str | None = None,
              invert: bool = False, scale: float = 1.0, subsample: int = 1, maxvolts: float = 0.0, descr: str = ""):
     """-> (TbinHeader, rows[n, ntrks] int16, {clipped_samples, columns}).  order = the converter's -order= string: column k of the file is that track, and
-    goes to that column of the rows (src/csvtbin.c:330-352) - the file is then in track order and says so (no TBIN_NO_REORDER)."""
+    goes to that column of the rows (src/csvtbin.c:330-352) - the file is then in track order and says so (no TBIN_NO_REORDER).  Without
+    an order the header is marked TBIN_NO_REORDER (src/csvtbin.c:804-807) and a decode's trkorder= applies; a Whirlwind order string is
+    kept in the header extension, columns unmoved (src/csvtbin.c:317-323)."""
     lib = _lib()
     info = _Info()
     rc = lib.rt_csv_survey(path.encode(), ntrks, scale, subsample, maxvolts, C.byref(info))
     if rc != 0:
         raise OSError(f"cannot read {path} as a CSV sample file ({rc})")
     perm = None
-    if order:
+    flags = tbin.FLAG_INVERTED if invert else 0
+    trkorder = ""
+    if order and mode == tbin.MODE_WW:
+        # Whirlwind: the string goes into the header extension as it is, no column moves (src/csvtbin.c:317-323)
+        if len(order) != ntrks:
+            raise ValueError(f"Whirlwind -order string {order!r} does not name {ntrks} tracks")
+        trkorder = order
+        flags |= tbin.FLAG_NO_REORDER                  # (write_tbin adds TRKORDER_INCLUDED for a header that carries a string)
+    elif order:
         h2t = frontend.parse_track_order(order)
         perm = (C.c_int * ntrks)(*h2t)
+    else:
+        flags |= tbin.FLAG_NO_REORDER                  # "marking the .tbin file to show it wasn't given" (src/csvtbin.c:804-807): a later -order= applies
     rows = np.empty((max(int(info.rows), 1), ntrks), dtype=np.int16)
     clipped = C.c_int64()
     n = lib.rt_csv_load(path.encode(), ntrks, perm, int(invert), scale, subsample, info.maxvolts, rows.ctypes.data, rows.shape[0], C.byref(clipped))
+    if n in (-3, -4):
+        raise ValueError(f"ntrks {ntrks} or the track order is out of range for a CSV sample file")
     if n < 0:
         raise OSError(f"cannot read {path}")
-    flags = tbin.FLAG_INVERTED if invert else 0
     hdr = tbin.TbinHeader(ntrks=ntrks, tdelta_ns=int(info.tdelta_ns), maxvolts=float(info.maxvolts), mode=mode, bpi=bpi, ips=ips, flags=flags,
-                          tstart_ns=int(info.tstart_ns), descr=descr)
+                          tstart_ns=int(info.tstart_ns), descr=descr, trkorder=trkorder)
     return hdr, rows[:n], dict(clipped_samples=int(clipped.value), columns=int(info.columns))

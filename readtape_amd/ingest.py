@@ -69,6 +69,7 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     fd = os.open(path, os.O_RDONLY)
     t_read = [0.0]
     data_end = [nrows]
+    end_lock = threading.Lock()
 
     def read_span(arr, r0, r1, lo):
         """rows [lo + r0, lo + r1) of the payload -> arr[r0:r1]; returns the first row (relative to lo) whose head-0 sample is the end
@@ -104,9 +105,10 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         lo, hi = spans[k]
         end = min(nrows, hi + halo_rows)
         first = read_rows(pinned[k % NP], lo, end)
-        if first >= 0:                                    # an end marker inside the payload: the tape ends there
-            data_end[0] = min(data_end[0], lo + first)
-        return min(end, data_end[0])
+        with end_lock:                                    # (the reader thread writes it for window k + 2 while the main thread clamps window k with it)
+            if first >= 0:                                # an end marker inside the payload: the tape ends there
+                data_end[0] = min(data_end[0], lo + first)
+            return min(end, data_end[0])
 
     def launch(k, end):
         lo, hi = spans[k]
@@ -184,8 +186,12 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                     stats["retries"] += 1
                     end_k = min(data_end[0], hi + halo)
                     host = torch.empty((end_k - lo, ntrks), dtype=torch.int16, pin_memory=True)
-                    read_rows(host, lo, end_k)
-                    piece = host.to(dev)
+                    first = read_rows(host, lo, end_k)
+                    if first >= 0:                            # an end marker inside the longer halo: the tape ends there (src/readtape.c:1410)
+                        with end_lock:
+                            data_end[0] = min(data_end[0], lo + first)
+                        end_k = min(end_k, data_end[0])
+                    piece = host[: end_k - lo].to(dev)
                     res, nb, bound = pipeline.scan_fragment(fes[k & 1], piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
                 stats["halo_rows_read"] += end_k - hi
                 if res.nbursts:
