@@ -1,0 +1,172 @@
+"""GPU parity at BASELINE.json's full sizes (run with -m gpu on an MI355X), through properties that need no oracle run of that length:
+
+* the base tape (a few 1e6 rows, the very tape bench.py tiles) is checked against the CPU oracle event for event;
+* tiling k copies of a tape gives k copies of its events (the front end is shift invariant: every burst starts from reset state inside
+  a dead-quiet zone) - so the FIRST, a MIDDLE and the LAST copy of the full-size scan must carry the base scan's events bit for bit,
+  also where the byte offsets into the rows pass 2^32;
+* the .tap of the tiled tape through the host replay is k times the base tape's records;
+* a tape cut into fragments at row 2^28 (what bench.py does for C3 / C4 and shard.py for C5) gives the unfragmented scan's bursts and
+  events.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from parity_util import check_tape, config_for, oracle_attempts
+from readtape_amd import frontend, pipeline, shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the workload generator of the benchmark line)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def gpu():
+    import gc
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    yield torch
+    gc.collect()                                   # (each test holds GBs of rows, workspace and event arena: hand them back before the next)
+    torch.cuda.empty_cache()
+
+
+def burst_lists(r, b):
+    """The event lists of burst b, all parameter sets and tracks, copied from the device arena on their own (a full-size scan's arena
+    holds tens of GB: only the bursts a check looks at travel) -> [P, T] lists of event records."""
+    fe = r.fe
+    P, T = len(fe.cfg.parmsets), fe.cfg.ntrks
+    B = r.bursts[b]
+    base, cap = int(B["event_base"]), int(B["event_cap"])
+    it = frontend.EVENT_DTYPE.itemsize
+    reg = fe.backend.to_numpy(r.bufs["events"][base * it: (base + P * T * cap) * it], frontend.EVENT_DTYPE)
+    return [[reg[(p * T + t) * cap: (p * T + t) * cap + int(r.counts[b, p, t])] for t in range(T)] for p in range(P)]
+
+
+def copy_events(r, lo, hi, nparm=1):
+    """Per parameter set: [(row - lo, trk, v_peak bits, agc_gain bits, left_distance, flags)] of the events at rows [lo, hi), sorted."""
+    rs = r.bursts["reset_sample"].astype(np.int64)
+    out = [[] for _ in range(nparm)]
+    for b in np.nonzero((rs >= lo - (1 << 17)) & (rs < hi))[0]:       # (a copy's first burst may restart in the gap that ends the copy in front)
+        lists = burst_lists(r, int(b))
+        for p in range(nparm):
+            ev = np.concatenate(lists[p])
+            a = rs[b] + ev["sample"].astype(np.int64)
+            m = (a >= lo) & (a < hi)
+            out[p].append(np.stack([a[m] - lo, ev["trk"][m].astype(np.int64), ev["v_peak"][m].view("u4").astype(np.int64), ev["agc_gain"][m].view("u4").astype(np.int64),
+                                    ev["left_distance"][m].astype(np.int64), ev["flags"][m].astype(np.int64)], 1))
+    res = []
+    for p in range(nparm):
+        e = np.concatenate(out[p]) if out[p] else np.zeros((0, 6), np.int64)
+        res.append(e[np.lexsort((e[:, 1], e[:, 0]))])
+    return res
+
+
+def tiled(torch, tape, total_rows):
+    base = torch.from_numpy(tape.rows).cuda()
+    k = max(3, int(round(total_rows / base.shape[0])))
+    return base.repeat(k, 1).contiguous(), k, int(base.shape[0])
+
+
+def check_copies(fe, rows, k, n, nparm=1, copies=None):
+    """The events of copy 1 of a three-copy scan in copies 1, k // 2 and k - 1 (or `copies`) of the full scan, bit for bit; no burst
+    flagged.  (Copy 0 begins at the tape's start - its first burst is an exact-start burst - so it is not the yardstick.)"""
+    r3 = fe.scan(rows[: 3 * n]).fetch(events=False)
+    ref = copy_events(r3, n, 2 * n, nparm)
+    assert all(x.shape[0] > 1000 for x in ref)
+    rk = fe.scan(rows).fetch(events=False)
+    assert not (rk.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START | frontend.F_STATE_AT_END)).any()
+    for j in (copies or (1, k // 2, k - 1)):
+        got = copy_events(rk, j * n, (j + 1) * n, nparm)
+        for p in range(nparm):
+            assert got[p].shape == ref[p].shape and (got[p] == ref[p]).all(), f"copy {j} parmset {p}"
+    return rk
+
+
+def test_c2_full_size(tmp_path, gpu):
+    """BASELINE configs[1]: 9-track NRZI, 1e8 rows, one parameter set - the tape bench.py times."""
+    torch = gpu
+    tape = bench.make_base_tape(seed=1000, target_rows=5e6, kind="nrzi")
+    hdr = tape.spec.header()
+    fe = frontend.FrontEnd(config_for(hdr, []))
+    msgs, stats = check_tape(fe, hdr, tape.rows, oracle_attempts(hdr, tape.rows, [], str(tmp_path)))
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["speculative"] == stats["attempts"] and stats["flags"] == 0
+    rows, k, n = tiled(torch, tape, 1e8)
+    assert rows.shape[0] >= 1e8
+    rk = check_copies(fe, rows, k, n)
+    st = fe.scan_stats(rk)
+    assert st["redone"] == 0 and st["parallel"] > 0.99 * int(rk.counts.sum()), st       # the peak path did the work, not a fallback
+    # the .tap through the host replay: k times the base tape's records, one end mark
+    base_tap, full_tap = str(tmp_path / "base.tap"), str(tmp_path / "full.tap")
+    pipeline.decode_tape(hdr, tape.rows, base_tap)
+    pipeline.decode_tape(hdr, rows, full_tap)
+    b = open(base_tap, "rb").read()
+    assert b.endswith(b"\xff\xff\xff\xff") and open(full_tap, "rb").read() == b[:-4] * k + b"\xff\xff\xff\xff"
+
+
+def test_nrzi_rows_beyond_4_gib(gpu):
+    """3e8 rows of 9 tracks = 5.4 GB: the byte offsets of the last copies do not fit 32 bits (C5 on few GPUs holds as much per rank)."""
+    torch = gpu
+    tape = bench.make_base_tape(seed=1001, target_rows=5e6, kind="nrzi")
+    fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(tape.spec.header()))
+    rows, k, n = tiled(torch, tape, 3e8)
+    assert rows.shape[0] * rows.shape[1] * 2 > (1 << 32) + (1 << 30)
+    check_copies(fe, rows, k, n, copies=(k // 2, k - 2, k - 1))
+
+
+@pytest.mark.parametrize("kind,nparm,zeros", [("pe", 1, True), ("gcr", 8, False)])
+def test_c3_c4_one_full_fragment(kind, nparm, zeros, gpu):
+    """BASELINE configs[2] and [3] at the size of one bench.py fragment (2^28 rows; 1e9 rows are four of them): PE -zeros through
+    k_zeros, GCR with the 8-set sweep through k_decode."""
+    torch = gpu
+    conf = bench.CONFIGS["C3" if kind == "pe" else "C4"]
+    tape = bench.make_base_tape(seed=1002, target_rows=5e6, kind=kind)
+    hdr = tape.spec.header()
+    parmsets = None
+    if nparm > len(frontend.DEFAULT_PARMSETS[hdr.mode]):
+        extra = [(1.4, 0.20, 0.2, 0.5, 0, 0.0), (1.6, 0.14, 0.0, 0.5, 0, 0.0), (1.5, 0.10, 0.1, 0.5, 0, 0.0), (1.3, 0.25, 0.2, 0.5, 0, 0.0)]
+        parmsets = (list(frontend.DEFAULT_PARMSETS[hdr.mode]) + extra)[:nparm]
+    fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr, nparmsets=conf["nparmsets"], find_zeros=zeros, parmsets=parmsets))
+    rows, k, n = tiled(torch, tape, 1 << 28)
+    rows = rows[: 1 << 28].contiguous() if rows.shape[0] > (1 << 28) else rows
+    k = rows.shape[0] // n
+    check_copies(fe, rows, k, n, nparm=nparm, copies=(1, k - 1))
+
+
+def test_fragments_cut_at_row_2_to_the_28(gpu):
+    """A 2^28 + 2^23-row NRZI tape scanned as bench.py / shard.py scan a long one - the fragment [0, 2^28) with its halo, then the
+    fragment from row 2^28 on with row_base = 2^28 - against the unfragmented scan: the same bursts, the same events."""
+    torch = gpu
+    tape = bench.make_base_tape(seed=1003, target_rows=5e6, kind="nrzi")
+    fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(tape.spec.header()))
+    rows, k, n = tiled(torch, tape, (1 << 28) + (1 << 23))
+    total, cut, halo = int(rows.shape[0]), 1 << 28, 1 << 18
+    assert total > cut + (1 << 22)
+    lo_w = cut - (1 << 23)                                     # compare the 2^24 rows around the cut (the rest is test_c2_full_size's business)
+
+    def near_cut(res, base):
+        ab = shard.absolute_bursts(res, base)
+        keep = np.nonzero(ab["reset_sample"] >= lo_w)[0]
+        ev = []
+        for b in keep:
+            e = np.concatenate(burst_lists(res, int(b))[0])
+            ev.append(np.stack([ab[b]["reset_sample"] + e["sample"].astype(np.int64), e["trk"].astype(np.int64), e["flags"].astype(np.int64), e["v_peak"].view("u4").astype(np.int64),
+                                e["agc_gain"].view("u4").astype(np.int64), e["left_distance"].astype(np.int64)], 1))
+        return ab[keep], (np.concatenate(ev) if ev else np.zeros((0, 6), np.int64))
+
+    wb, we = near_cut(fe.scan(rows).fetch(events=False), 0)
+    parts_b, parts_e = [], []
+    for a, b, first in ((0, cut, True), (cut, total, False)):
+        end = min(total, b + halo) if b < total else total
+        res = fe.scan(rows[a:end], row_base=a, first_is_tape_start=first, own_rows=b - a).fetch(events=False)
+        pb, pe = near_cut(res, a)
+        parts_b.append(pb); parts_e.append(pe)
+    got_b, got_e = np.concatenate(parts_b), np.concatenate(parts_e)
+    for f in ("zone_end", "reset_sample", "safe_last", "end_sample"):
+        assert list(got_b[f]) == list(wb[f]), f
+    key = lambda e: e[np.lexsort((e[:, 1], e[:, 0]))]
+    assert got_e.shape == we.shape and (key(got_e) == key(we)).all() and we.shape[0] > 100000
