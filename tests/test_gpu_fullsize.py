@@ -99,7 +99,7 @@ def test_c2_full_size(tmp_path, gpu):
     assert rows.shape[0] >= 1e8
     rk = check_copies(fe, rows, k, n)
     st = fe.scan_stats(rk)
-    assert st["redone"] == 0 and st["parallel"] > 0.99 * int(rk.counts.sum()), st       # the peak path did the work, not a fallback
+    assert st["redone"] == 0 and st["parallel"] > 0.95 * int(rk.counts.sum()) and st["parallel"] + st["sequential"] == int(rk.counts.sum()), st      # the peak path did the work, not a fallback
     # the .tap through the host replay: k times the base tape's records, one end mark
     base_tap, full_tap = str(tmp_path / "base.tap"), str(tmp_path / "full.tap")
     pipeline.decode_tape(hdr, tape.rows, base_tap)
