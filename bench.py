@@ -197,6 +197,15 @@ class Workload:
         if self.cuda:
             for f in set(self.fes): f.set_timing(True)
         self.kms = {k: 0.0 for k in self.fe.kernel_names()} if self.cuda else {}
+        self.scans_since_read = 0
+
+    def collect(self):
+        """The HIP-event times of the scans since the last call, added to kms (synchronises those scans - called once behind the timed
+        loop, so the steps run back to back)."""
+        for f in set(self.fes):
+            ms, _ = f.kernel_ms()
+            for k in self.kms: self.kms[k] += ms[k]
+        self.scans_since_read = 0
 
     def scan_frag(self, f, s, a, b):
         last = b >= self.nrows
@@ -218,9 +227,9 @@ class Workload:
                 res = self.scan_frag(f, s, a, b)
                 if each is not None:
                     each(res)
-                if timed and self.cuda and (len(self.frags) > 1 or not self.pipeline):
-                    ms = f.kernel_ms()               # HIP events on the scan's stream (synchronises this scan)
-                    for kk in self.kms: self.kms[kk] += ms[kk]
+                self.scans_since_read += 1
+                if timed and self.cuda and self.scans_since_read >= 48:      # (the front end keeps 64 scans' events: collect before they wrap - C3 / C4 at many steps)
+                    self.collect()
             return res
 
 
@@ -265,20 +274,17 @@ def main():
     for i in range(args.warmup):
         res = step(i)
     torch.cuda.synchronize(dev)
+    wl.collect()                                     # (the warm-up scans' events: discarded)
+    for k in kms: kms[k] = 0.0
     if world > 1: dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         res = step(i, timed=True)
-        if args.pipeline and len(frags) == 1 and i > 0:
-            ms = fes[(i - 1) & 1].kernel_ms()    # the previous step's events, on its own stream (waits for that step only)
-            for k in kms: kms[k] += ms[k]
-    if args.pipeline and len(frags) == 1 and args.steps > 0:
-        ms = fes[(args.steps - 1) & 1].kernel_ms()
-        for k in kms: kms[k] += ms[k]
     torch.cuda.synchronize(dev)
     if world > 1: dist.barrier()
     dt = time.perf_counter() - t0
+    wl.collect()                                     # the steps' HIP events, recorded on the stream as the scans ran
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -164,9 +164,10 @@ int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_
                     rtfe_burst *d_burst, uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,
                     void *stream);
 
-/* Per-kernel timing of the most recent rtfe_scan on this handle: with enable != 0, rtfe_scan records
- * HIP events on `stream` around each of its kernels; rtfe_kernel_ms synchronises those events and
- * returns the elapsed milliseconds per kernel (out[rtfe_kernel_count()]).  Used by bench.py. */
+/* Per-kernel timing: with enable != 0, rtfe_scan records HIP events on `stream` around each of its timed spans (rtfe_kernel_name), one
+ * set of events per scan in a ring of 64 sets - nothing waits, so scans queued back to back stay back to back.  rtfe_kernel_ms synchronises
+ * the sets recorded since its last call and returns, per span, the elapsed milliseconds SUMMED over those scans (out[rtfe_kernel_count()]);
+ * its return value is the number of scans summed (>= 0), or a negative error.  Used by bench.py. */
 int rtfe_set_timing(rtfe_handle *h, int enable);
 int rtfe_kernel_ms(rtfe_handle *h, float *out);
 

@@ -37,7 +37,8 @@ struct rtfe_handle {
    int lds_bytes;
    int num_cus;
    int timing;
-   hipEvent_t ev0[12], ev1[12];          // start / stop of each kernel of the last scan (on the stream it ran on)
+   hipEvent_t (*ev0)[12], (*ev1)[12];    // timing: a ring of kTimingRing sets of start / stop events, a set per scan (on the stream it ran on)
+   int ev_next, ev_pending;             // the set the next scan records into; sets recorded since rtfe_kernel_ms last looked
    int zeros_kernel;                   // -zeros scans run k_zeros (RTFE_ZEROS_KERNEL=0: k_decode's zero-crossing mode, kept for tests)
 };
 
@@ -77,7 +78,7 @@ extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
 // The timed spans of one rtfe_scan (rtfe_kernel_ms), in launch order.  The peak path (NRZI peak detection) runs
-//   k_sift | k_prep [k_qpack, k_sift_hard, k_pscan1/2, k_prep, k_prep2] | k_bursts | k_gain [k_zones, the chains' heads] | k_gain_s |
+//   k_sift | k_prep [k_qpack, k_sift_hard, k_pscan1/2, k_prep] | k_bursts | k_gain [k_zones, the chains' heads] | k_gain_s |
 //   k_gain_tail | k_emit [k_emit, k_publish] | k_decode [the bursts the chains gave up, on the samples]
 // the sample path (PE, GCR, differentiated peaks, density detection, parameter-set sweeps with too many widths) k_quiet | k_bursts | k_decode,
 // -zeros k_quiet | k_bursts | k_zeros.  A span a scan does not run reads 0.
@@ -128,7 +129,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    const float bpi_s = density_mode ? 1.0f / (c->ips * ((float)c->tdelta_ns / 1e9f) * 12.0f) : c->bpi;
    rtfe_handle *h = new rtfe_handle();
    h->cfg = *c;
-   h->timing = 0;
+   h->timing = 0; h->ev0 = nullptr; h->ev1 = nullptr; h->ev_next = 0; h->ev_pending = 0;
    DevCfg &d = h->dev;
    memset(&d, 0, sizeof d);
    d.mode = c->mode; d.ntrks = c->ntrks; d.invert = c->invert != 0; d.nparm = c->nparmsets;
@@ -311,23 +312,40 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    *out = h;
    return 0; }
 
+constexpr int kTimingRing = 64;
+static void timing_free(rtfe_handle *h) {
+   if (!h->ev0) return;
+   for (int r = 0; r < kTimingRing; ++r) for (int i = 0; i < kNumKernels; ++i) { (void)hipEventDestroy(h->ev0[r][i]); (void)hipEventDestroy(h->ev1[r][i]); }
+   delete[] h->ev0; delete[] h->ev1; h->ev0 = nullptr; h->ev1 = nullptr; }
+
 extern "C" int rtfe_set_timing(rtfe_handle *h, int enable) {
    if (!h) return fail(-1, "null argument");
-   if (enable && !h->timing) for (int i = 0; i < kNumKernels; ++i) if (hipEventCreate(&h->ev0[i]) != hipSuccess || hipEventCreate(&h->ev1[i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
-   if (!enable && h->timing) for (int i = 0; i < kNumKernels; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
+   if (enable && !h->timing) {
+      h->ev0 = new hipEvent_t[kTimingRing][12]; h->ev1 = new hipEvent_t[kTimingRing][12];
+      for (int r = 0; r < kTimingRing; ++r) for (int i = 0; i < kNumKernels; ++i)
+         if (hipEventCreate(&h->ev0[r][i]) != hipSuccess || hipEventCreate(&h->ev1[r][i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
+      h->ev_next = 0; h->ev_pending = 0; }
+   if (!enable && h->timing) timing_free(h);
    h->timing = enable != 0;
    return 0; }
 
 extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
    if (!h || !out || !h->timing) return fail(-41, "timing is not enabled");
-   for (int i = 0; i < kNumKernels; ++i) {
-      if (hipEventSynchronize(h->ev1[i]) != hipSuccess) return fail(-42, "hipEventSynchronize failed");
-      if (hipEventElapsedTime(&out[i], h->ev0[i], h->ev1[i]) != hipSuccess) return fail(-43, "hipEventElapsedTime failed"); }
-   return 0; }
+   const int n = h->ev_pending < kTimingRing ? h->ev_pending : kTimingRing;
+   for (int i = 0; i < kNumKernels; ++i) out[i] = 0;
+   for (int k = 0; k < n; ++k) {
+      const int r = ((h->ev_next - 1 - k) % kTimingRing + kTimingRing) % kTimingRing;
+      for (int i = 0; i < kNumKernels; ++i) {
+         float ms = 0;
+         if (hipEventSynchronize(h->ev1[r][i]) != hipSuccess) return fail(-42, "hipEventSynchronize failed");
+         if (hipEventElapsedTime(&ms, h->ev0[r][i], h->ev1[r][i]) != hipSuccess) return fail(-43, "hipEventElapsedTime failed");
+         out[i] += ms; } }
+   h->ev_pending = 0;
+   return n; }
 
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
-   if (h->timing) for (int i = 0; i < kNumKernels; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
+   if (h->timing) timing_free(h);
    (void)hipFree(h->d_dev);
    delete h; }
 
@@ -435,8 +453,10 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    const int dgrid = h->num_cus * per_cu;
    // every span's events are recorded by every scan (a span that does not run reads ~0)
    bool ran[kNumKernels] = {false};
-   auto t0 = [&](int k) { ran[k] = true; if (h->timing) (void)hipEventRecord(h->ev0[k], st); };
-   auto t1 = [&](int k) { if (h->timing) (void)hipEventRecord(h->ev1[k], st); };
+   const int evset = h->timing ? h->ev_next : 0;
+   if (h->timing) { h->ev_next = (h->ev_next + 1) % kTimingRing; ++h->ev_pending; }
+   auto t0 = [&](int k) { ran[k] = true; if (h->timing) (void)hipEventRecord(h->ev0[evset][k], st); };
+   auto t1 = [&](int k) { if (h->timing) (void)hipEventRecord(h->ev1[evset][k], st); };
    auto skip_rest = [&]() { for (int k = 0; k < kNumKernels; ++k) if (!ran[k]) { t0(k); t1(k); } };
    if (h->dev.peak_path) {
       // ---- the peak path: k_sift (quiet map + records) -> k_bursts -> k_zones -> k_gain -> k_emit -> k_publish -> whatever the chains gave up ----
@@ -488,7 +508,6 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
       hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
                          (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, crecp, erefp);
-      hipLaunchKernelGGL(k_prep2, dim3(nlists * ((h->num_cus * 8 + nlists - 1) / nlists)), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, crecp);
       t1(kTPrep);
       if (stop_after < 2) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTBursts);

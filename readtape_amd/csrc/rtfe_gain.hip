@@ -110,68 +110,111 @@ __global__ void __launch_bounds__(1024) k_pscan2(int nchunks, int nlists, const 
 __device__ __forceinline__ long long stream_pos(const uint32_t *tstart, const uint32_t *coff, int nlists, long long tile, int li) {
    return (long long)tstart[(size_t)tile * nlists + li] + (long long)coff[(size_t)(tile >> 10) * nlists + li]; }
 
+// inclusive prefix sum over each half of the wave (lanes 0-31, 32-63) on its own: the wave scan without its last step
+__device__ __forceinline__ int half_incl_scan(int v, int hl) {
+#ifdef RTFE_CPU_EMUL
+   for (int s2 = 1; s2 < 32; s2 <<= 1) { const int y = __shfl_up(v, s2); if (hl >= s2) v += y; }
+   return v;
+#else
+   (void)hl;
+   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+   return v;
+#endif
+}
+
+// k_prep: the tiles' lists -> the streams.  Half a wave per list (a clean NRZI tile holds ~21 records per head), the next list's
+// directory entry and records in flight while this one is written (a list is two dependent HBM round trips otherwise, and there is
+// little else to hide them).  Per record: its absolute row, its volts, where its margin entries are, and kCrClear - everything static
+// that the chains' steady path asks of it: a plain record with a sure stretch whose successor in the stream (the next record of the
+// list; the first of the next tile's list) begins after this record's owner has left the window.
 __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
                                               const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff,
                                               const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint32_t *__restrict__ eref) {
    const DevCfg &cfg = *cfgp;
    const int nlists = cfg.nscreens * cfg.ntrks, hcap = cfg.pk_slot;
    const float mv = cfg.maxvolts;
-   const int lane = threadIdx.x & 63;
+   const int lane = threadIdx.x & 63, hl = lane & 31, hbase = lane & 32;
    const long long nall = ntiles * nlists;
    const size_t ovf16 = (size_t)(ovf - pool) / 2;                         // the overflow slots, in the 2-byte units eref counts from the pool's start
-   for (long long li = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); li < nall; li += (long long)gridDim.x * 4) {
-      const PeakDir d = dir[li];
-      if (d.nrec == 0) continue;
+   const long long stride = (long long)gridDim.x * 8;                     // lists per sweep: four waves, two lists each
+   struct Pre { PeakDir d, dn; uint2 r, r1, rn; };
+   auto fetch = [&](long long l) -> Pre {
+      Pre p; p.d.nrec = 0; p.d.nent = 0; p.dn = p.d; p.r = make_uint2(0, 0); p.r1 = p.r; p.rn = p.r;
+      if (l < nall) {
+         const unsigned char *slot = pool + (size_t)l * hcap;
+         p.d = dir[l];
+         p.r = *reinterpret_cast<const uint2 *>(slot + min(8 * hl, hcap - 8));
+         p.r1 = *reinterpret_cast<const uint2 *>(slot + min(8 * (hl + 1), hcap - 8));
+         if (l + nlists < nall) { p.dn = dir[l + nlists]; p.rn = *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap); } }
+      return p; };
+   // where a record's successor begins: the first row it could fire at (kNoSucc: the stream ends; kBadSucc: cannot tell - not clear)
+   constexpr long long kNoSucc = 0x7fffffffffffffffll, kBadSucc = -1;
+   auto first_row = [&](uint2 q, long long pos0q) -> long long {
+      if (q.y == 0xffff8001u) {                                          // a deferred candidate: the first of its records (k_sift_hard)
+         const unsigned char *os = ovf + (size_t)q.x * kSfOvfBytes;
+         if (*reinterpret_cast<const int *>(os) <= 0) return kBadSucc;
+         q = *reinterpret_cast<const uint2 *>(os + 8); }
+      return pos0q + (long long)(q.x & 0x7ffu) + (long long)((q.x >> 12) & 63u); };
+   long long li = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+   Pre nx = fetch(li);
+   for (; __ballot(li < nall) != 0ull; li += stride) {
+      const Pre cu = nx;
+      nx = fetch(li + stride);
+      const PeakDir d = cu.d;
+      const bool on = li < nall && d.nrec != 0;
       const long long tile = li / nlists;
       const int sl = (int)(li - tile * nlists);
-      if ((long long)ctot[sl] > ccap) continue;                          // a stream that outgrew its capacity is not built: its chains give up (k_gain)
-      long long base = (long long)sl * ccap + stream_pos(tstart, coff, nlists, tile, sl);
-      if (d.nrec == 0xffffu) {                                          // a list that did not fit: one marker at the tile's first row
-         if (lane == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; eref[base] = 0; }
-         continue; }
-      const unsigned char *slot = pool + (size_t)li * hcap;
+      const bool built = on && (long long)ctot[on ? sl : 0] <= ccap;      // a stream that outgrew its capacity is not built: its chains give up (k_gain)
+      long long base = built ? (long long)sl * ccap + stream_pos(tstart, coff, nlists, tile, sl) : 0;
+      if (built && d.nrec == 0xffffu) {                                  // a list that did not fit: one marker at the tile's first row
+         if (hl == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; eref[base] = 0; } }
+      const int nrec = (built && d.nrec != 0xffffu) ? (int)d.nrec : 0;
+      const int W = cfg.screen[(on ? sl : 0) / cfg.ntrks].W;
+      const unsigned char *slot = pool + (size_t)(on ? li : 0) * hcap;
       const long long pos0 = tile * kSfTile - kSfPosBias;
+      // what follows this list in its stream
+      long long fn_list = kNoSucc;
+      if (nrec > 0 && tile + 1 < ntiles) {
+         if (cu.dn.nrec == 0xffffu) fn_list = (tile + 1) * kSfTile + 1;                       // (the marker of a list that is not there)
+         else if (cu.dn.nrec != 0) fn_list = first_row(cu.rn, pos0 + kSfTile);
+         /* an empty list: whatever comes behind it begins more than a tile's rows less the owners' reach further on */ }
       int ebase = 0;
-      for (int k0 = 0; k0 < (int)d.nrec; k0 += 64) {
-         const int k = k0 + lane;
-         const bool have = k < (int)d.nrec;
-         uint32_t w0 = 0, w1 = 0;
-         if (have) { const uint2 r = *reinterpret_cast<const uint2 *>(slot + 8 * k); w0 = r.x; w1 = r.y; }
+      int rounds = (nrec + 31) >> 5;
+      {  const int other = __shfl(rounds, lane ^ 32); if (other > rounds) rounds = other; }      // (both halves run the scans of every round)
+      for (int rd = 0; rd < rounds; ++rd) {
+         const int k = rd * 32 + hl;
+         const bool have = k < nrec;
+         uint2 q = cu.r, q1 = cu.r1;
+         if (rd > 0 && have) { q = *reinterpret_cast<const uint2 *>(slot + 8 * k); if (k + 1 < nrec) q1 = *reinterpret_cast<const uint2 *>(slot + 8 * (k + 1)); }
+         const uint32_t w0 = have ? q.x : 0u, w1 = have ? q.y : 0u;
          const bool deferred = have && w1 == 0xffff8001u;                  // its records are in overflow slot w0 (k_sift_hard): they take its place
-         const unsigned char *os = ovf + (size_t)w0 * kSfOvfBytes;
+         const unsigned char *os = ovf + (size_t)(deferred ? w0 : 0u) * kSfOvfBytes;
          const int cnt = deferred ? *reinterpret_cast<const int *>(os) : (have ? 1 : 0);
          const int ne = deferred || !have ? 0 : pk_nent(w0, w1);
-         const int ie = wave_incl_scan(ne, lane), ic = wave_incl_scan(cnt, lane);
-         long long o = base + ic - cnt;
+         const int ie = half_incl_scan(ne, hl), ic = half_incl_scan(cnt, hl);
+         const long long o = base + ic - cnt;
+         const long long fn = !have ? kNoSucc : (k + 1 < nrec ? first_row(q1, pos0) : fn_list);      // the successor of this list entry's last record
          if (deferred) {
             int se0 = 0;
             for (int j = 0; j < cnt; ++j) {
-               const uint2 r = *reinterpret_cast<const uint2 *>(os + 8 + 8 * j);
-               CRec c; c.pos = (uint32_t)(pos0 + (long long)(r.x & 0x7ffu)); c.w0 = r.x & ~0x7ffu; c.w1 = r.y; c.volt = volt((int)(int16_t)(r.y & 0xffffu), mv);
+               const uint2 e = *reinterpret_cast<const uint2 *>(os + 8 + 8 * j);
+               CRec c; c.pos = (uint32_t)(pos0 + (long long)(e.x & 0x7ffu)); c.w0 = e.x & ~0x7ffu; c.w1 = e.y; c.volt = volt((int)(int16_t)(e.y & 0xffffu), mv);
+               long long fj = fn;
+               if (j + 1 < cnt) { const uint2 e2 = *reinterpret_cast<const uint2 *>(os + 8 + 8 * (j + 1)); fj = pos0 + (long long)(e2.x & 0x7ffu) + (long long)((e2.x >> 12) & 63u); }
+               if (e.y != 0xffff8000u && (unsigned)((int)((e.x >> 22) & 63u) - 1) < 62u && fj != kBadSucc && fj > (long long)c.pos + W) c.w0 |= kCrClear;
                crec[o + j] = c;
                eref[o + j] = (uint32_t)(ovf16 + ((size_t)w0 * kSfOvfBytes + kSfOvfBytes) / 2 - (size_t)se0);
-               se0 += pk_nent(r.x, r.y); } }
+               se0 += pk_nent(e.x, e.y); } }
          else if (have) {
             CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
+            if (w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u && fn != kBadSucc && fn > (long long)c.pos + W) c.w0 |= kCrClear;
             crec[o] = c;
             eref[o] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(ebase + ie - ne)); }
-         ebase += wave_last(ie); base += wave_last(ic); } } }
-
-// k_prep2: the kCrClear flags - a lane per record, its successor right behind it in the stream
-__global__ void __launch_bounds__(256) k_prep2(const DevCfg *__restrict__ cfgp, const uint32_t *__restrict__ ctot, long long ccap, CRec *__restrict__ crec) {
-   const DevCfg &cfg = *cfgp;
-   const int nlists = cfg.nscreens * cfg.ntrks;
-   const int nper = (int)gridDim.x / nlists;                             // workgroups per stream (the grid is a multiple of the streams)
-   {  const int sl = (int)blockIdx.x / nper, bx = (int)blockIdx.x - sl * nper;
-      const int W = cfg.screen[sl / cfg.ntrks].W;
-      const long long n = (long long)ctot[sl] > ccap ? 0 : (long long)ctot[sl];
-      CRec *r = crec + (size_t)sl * ccap;
-      for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < n; i += (long long)nper * blockDim.x) {
-         const uint32_t w0 = r[i].w0, w1 = r[i].w1;
-         const int nsure = (int)((w0 >> 22) & 63u);
-         bool ok = !(w0 & kCrBad) && w1 != 0xffff8000u && (unsigned)(nsure - 1) < 62u;
-         if (ok && i + 1 < n) { const long long fn = (long long)r[i + 1].pos + (long long)((r[i + 1].w0 >> 12) & 63u); ok = fn > (long long)r[i].pos + W; }
-         if (ok) r[i].w0 = w0 | kCrClear; } } }
+         ebase += __shfl(ie, hbase + 31); base += __shfl(ic, hbase + 31); } } }
 
 // ------------------------------------------------------------------------------------------------
 // k_gain

@@ -77,19 +77,34 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
    __shared__ int lds[32];
    __shared__ int s_base;
    __shared__ u64 s_ebase;
-   if (threadIdx.x == 0) {
-      s_base = 0;
-      // a tape (or shard) that does not begin inside a qualifying zone gets an exact-start burst at row 0
-      bool starts_quiet = true;
-      for (int c = 0; c < gap_chunks; ++c) if (!quiet_at(qwords, c, nchunks)) { starts_quiet = false; break; }
-      if (first_is_start && !starts_quiet && max_bursts > 0) {
-         rtfe_burst b = {};
-         b.zone_first = 0; b.zone_end = 0; b.reset_sample = 0; b.safe_last = 0; b.flags = RTFE_F_EXACT_START;
-         bursts[0] = b;
-         s_base = 1; } }
-   __syncthreads();
+   // The quiet map goes through LDS a round (4096 words = 2^18 chunks) at a time, with 64 words in front of it (a zone may begin there;
+   // further back the walk reads HBM): the tests below are chains of dependent reads, a microsecond each from HBM, and there is one
+   // workgroup to hide them.
    constexpr int kPer = 4;                                          // consecutive words per thread per round (fewer block scans)
+   constexpr int kBack = 64, kWin = kBack + 1024 * kPer + 1;
+   __shared__ u64 s_q[kWin];
+   long long wbase = 0;
+   auto qword = [&](long long w) -> u64 {
+      if (w < 0 || w >= nwords) return 0;
+      const long long k = w - wbase;
+      return (k >= 0 && k < kWin) ? s_q[k] : qwords[w]; };
+   auto quiet = [&](long long c) -> bool { return c >= 0 && c < nchunks && ((qword(c >> 6) >> (c & 63)) & 1); };
+   if (threadIdx.x == 0) s_base = 0;
    for (long long w0 = 0; w0 < nwords; w0 += 1024 * kPer) {
+      __syncthreads();
+      wbase = w0 - kBack;
+      for (int k = threadIdx.x; k < kWin; k += blockDim.x) { const long long w = wbase + k; s_q[k] = (w >= 0 && w < nwords) ? qwords[w] : 0; }
+      __syncthreads();
+      if (w0 == 0 && threadIdx.x == 0) {
+         // a tape (or shard) that does not begin inside a qualifying zone gets an exact-start burst at row 0
+         bool starts_quiet = true;
+         for (int c = 0; c < gap_chunks; ++c) if (!quiet(c)) { starts_quiet = false; break; }
+         if (first_is_start && !starts_quiet && max_bursts > 0) {
+            rtfe_burst b = {};
+            b.zone_first = 0; b.zone_end = 0; b.reset_sample = 0; b.safe_last = 0; b.flags = RTFE_F_EXACT_START;
+            bursts[0] = b;
+            s_base = 1; } }
+      __syncthreads();
       u64 ends[kPer];
       int cnt = 0;
       #pragma unroll
@@ -97,8 +112,8 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
          const long long w = w0 + (long long)threadIdx.x * kPer + j;
          ends[j] = 0;
          if (w < nwords) {
-            const u64 q = qwords[w];
-            const u64 qn = (w + 1 < nwords) ? qwords[w + 1] : 0;
+            const u64 q = qword(w);
+            const u64 qn = qword(w + 1);
             const u64 next = (q >> 1) | (qn << 63);         // bit c = quiet[c+1]
             u64 cand = q & ~next;                           // quiet and successor not quiet
             while (cand) {
@@ -106,7 +121,7 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
                cand &= cand - 1;
                const long long c = w * 64 + bit;
                bool ok = true;
-               for (int k = 1; k < gap_chunks; ++k) if (!quiet_at(qwords, c - k, nchunks)) { ok = false; break; }
+               for (int k = 1; k < gap_chunks; ++k) if (!quiet(c - k)) { ok = false; break; }
                if (ok) ends[j] |= 1ull << bit; } }
          cnt += __popcll(ends[j]); }
       int total;
@@ -126,7 +141,7 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
                if (c0 == 0) break;
                const long long pw = (c0 - 1) >> 6; const int pb = (int)((c0 - 1) & 63);
                // bits pb..0 of word pw, shifted so that bit pb becomes bit 63: count the leading run of ones
-               const u64 run = ~(qwords[pw] << (63 - pb));
+               const u64 run = ~(qword(pw) << (63 - pb));
                const int ones = run ? __clzll((long long)run) : 64;
                const int take = ones < pb + 1 ? ones : pb + 1;
                c0 -= take;
@@ -140,8 +155,8 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
                b.zone_first = zf; b.zone_end = ze; b.reset_sample = -1; b.safe_last = -1;
                bursts[idx] = b; } } }
       __syncthreads();
-      if (threadIdx.x == 0) s_base = base + total;
-      __syncthreads(); }
+      if (threadIdx.x == 0) s_base = base + total; }
+   __syncthreads();
    int nb = s_base;
    if (nb > max_bursts) nb = (int)max_bursts;
    // time shards: keep the bursts that start in the owned rows, plus one more as the bound of the last of them
@@ -1243,6 +1258,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) k_decode(const DevCfg *__re
 #else
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
+   if (mode == kDecodeRedo && scratch->seg_failed == 0) return;      // nothing for the sample path to redo (k_publish counted): the usual case costs one load
    __shared__ DevCfg cfg;
    __shared__ int s_burst;
    __shared__ long long s_min;

@@ -327,11 +327,13 @@ class FrontEnd:
             raise RuntimeError(self.lib.rtfe_last_error().decode())
 
     def kernel_ms(self):
-        """Per-kernel elapsed ms of the last scan (HIP events on the scan's stream); synchronises."""
+        """Per-span elapsed ms (HIP events on the scans' stream) summed over the scans since the last call - at most 64 - and how many
+        scans that was: ({span: ms}, scans).  Synchronises those scans."""
         out = (C.c_float * self.lib.rtfe_kernel_count())()
-        if self.lib.rtfe_kernel_ms(self.h, out) != 0:
+        n = self.lib.rtfe_kernel_ms(self.h, out)
+        if n < 0:
             raise RuntimeError(self.lib.rtfe_last_error().decode())
-        return dict(zip(self.kernel_names(), [float(x) for x in out]))
+        return dict(zip(self.kernel_names(), [float(x) for x in out])), int(n)
 
     def scan_stats(self, result):
         """{'bursts', 'redone', 'record_bytes'} of the scan that produced `result` (synchronises; diagnostics)."""

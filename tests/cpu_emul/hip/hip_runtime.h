@@ -31,6 +31,7 @@ struct uint2 { unsigned int x, y; };
 struct uint4 { unsigned int x, y, z, w; };
 inline int4 make_int4(int a, int b, int c, int d) { int4 r = {a, b, c, d}; return r; }
 inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 r = {a, b, c, d}; return r; }
+inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; return r; }
 extern thread_local dim3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
 extern unsigned char g_dyn_smem[160 * 1024] __attribute__((aligned(64)));

@@ -14,7 +14,7 @@ def run(name, base, target_rows, **cfgkw):
     fe.set_timing(True)
     for _ in range(2):
         r = fe.scan(rows)
-        ms = fe.kernel_ms()
+        ms = fe.kernel_ms()[0]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):

@@ -9,7 +9,7 @@ def run(name, base, target, **kw):
     rows = torch.from_numpy(base.rows).cuda().repeat(k, 1).contiguous()
     fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr, **kw))
     fe.set_timing(True)
-    r = fe.scan(rows); ms = fe.kernel_ms(); r.fetch()
+    r = fe.scan(rows); ms = fe.kernel_ms()[0]; r.fetch()
     ws = r.bufs["ws"].cpu().numpy()
     dbg = ws[64:128].view(np.uint64)
     nt = max(int(dbg[3]), 1)

@@ -17,7 +17,7 @@ fe = frontend.FrontEnd(cfg)
 fe.set_timing(True)
 for i in range(2):
     r = fe.scan(rows)
-    ms = fe.kernel_ms()
+    ms = fe.kernel_ms()[0]
 st = fe.scan_stats(r)
 ph = st["phase_cycles"]
 waves = max(ph[5], 1)

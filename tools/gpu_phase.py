@@ -14,7 +14,7 @@ fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(tape.spec.header(), n
 fe.set_timing(True)
 for _ in range(2):
     r = fe.scan(rows)
-ms = fe.kernel_ms()
+ms = fe.kernel_ms()[0]
 r.fetch()
 ws = r.bufs["ws"].cpu().numpy()
 dbg = ws[64:128].view(np.uint64)
