@@ -151,14 +151,19 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
          p.r1 = *reinterpret_cast<const uint2 *>(slot + min(8 * (hl + 1), hcap - 8));
          if (l + nlists < nall) { p.dn = dir[l + nlists]; p.rn = *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap); } }
       return p; };
-   // where a record's successor begins: the first row it could fire at (kNoSucc: the stream ends; kBadSucc: cannot tell - not clear)
-   constexpr long long kNoSucc = 0x7fffffffffffffffll, kBadSucc = -1;
-   auto first_row = [&](uint2 q, long long pos0q) -> long long {
-      if (q.y == 0xffff8001u) {                                          // a deferred candidate: the first of its records (k_sift_hard)
-         const unsigned char *os = ovf + (size_t)q.x * kSfOvfBytes;
-         if (*reinterpret_cast<const int *>(os) <= 0) return kBadSucc;
-         q = *reinterpret_cast<const uint2 *>(os + 8); }
-      return pos0q + (long long)(q.x & 0x7ffu) + (long long)((q.x >> 12) & 63u); };
+   // where a record's successor begins: the first row of the first record at or behind entry k1 of a list (q1 = that entry, already
+   // loaded) - a deferred candidate stands for its records (k_sift_hard), and for nothing at all if it turned out to have none.
+   // kNoSucc: the stream ends; kOffList: the list has no further record; kBadSucc: cannot tell (the record is then not marked clear)
+   constexpr long long kNoSucc = 0x7fffffffffffffffll, kBadSucc = -1, kOffList = -2;
+   auto succ_row = [&](const unsigned char *lslot, int k1, int n1, uint2 q, long long pos0q) -> long long {
+      for (int j = k1; j < n1; ++j) {
+         if (j > k1) q = *reinterpret_cast<const uint2 *>(lslot + 8 * j);
+         if (q.y == 0xffff8001u) {
+            const unsigned char *os = ovf + (size_t)q.x * kSfOvfBytes;
+            if (*reinterpret_cast<const int *>(os) <= 0) continue;
+            q = *reinterpret_cast<const uint2 *>(os + 8); }
+         return pos0q + (long long)(q.x & 0x7ffu) + (long long)((q.x >> 12) & 63u); }
+      return kOffList; };
    long long li = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
    Pre nx = fetch(li);
    for (; __ballot(li < nall) != 0ull; li += stride) {
@@ -180,7 +185,7 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
       long long fn_list = kNoSucc;
       if (nrec > 0 && tile + 1 < ntiles) {
          if (cu.dn.nrec == 0xffffu) fn_list = (tile + 1) * kSfTile + 1;                       // (the marker of a list that is not there)
-         else if (cu.dn.nrec != 0) fn_list = first_row(cu.rn, pos0 + kSfTile);
+         else if (cu.dn.nrec != 0) { fn_list = succ_row(slot + (size_t)nlists * hcap, 0, (int)cu.dn.nrec, cu.rn, pos0 + kSfTile); if (fn_list == kOffList) fn_list = kBadSucc; }
          /* an empty list: whatever comes behind it begins more than a tile's rows less the owners' reach further on */ }
       int ebase = 0;
       int rounds = (nrec + 31) >> 5;
@@ -197,7 +202,8 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
          const int ne = deferred || !have ? 0 : pk_nent(w0, w1);
          const int ie = half_incl_scan(ne, hl), ic = half_incl_scan(cnt, hl);
          const long long o = base + ic - cnt;
-         const long long fn = !have ? kNoSucc : (k + 1 < nrec ? first_row(q1, pos0) : fn_list);      // the successor of this list entry's last record
+         long long fn = !have ? kNoSucc : succ_row(slot, k + 1, nrec, q1, pos0);      // the successor of this list entry's last record
+         if (fn == kOffList) fn = fn_list;
          if (deferred) {
             int se0 = 0;
             for (int j = 0; j < cnt; ++j) {
@@ -215,6 +221,25 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
             crec[o] = c;
             eref[o] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(ebase + ie - ne)); }
          ebase += __shfl(ie, hbase + 31); base += __shfl(ic, hbase + 31); } } }
+
+#ifdef RTFE_CPU_EMUL
+// (emulator only, RTFE_PREP_CHECK: kCrClear as a pass over the finished streams would set it)
+__global__ void __launch_bounds__(64) k_prep_check(const DevCfg *__restrict__ cfgp, const uint32_t *__restrict__ ctot, long long ccap, const CRec *__restrict__ crec) {
+   const DevCfg &cfg = *cfgp;
+   const int nlists = cfg.nscreens * cfg.ntrks;
+   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+   for (int sl = 0; sl < nlists; ++sl) {
+      const int W = cfg.screen[sl / cfg.ntrks].W;
+      const long long n = (long long)ctot[sl] > ccap ? 0 : (long long)ctot[sl];
+      const CRec *r = crec + (size_t)sl * ccap;
+      for (long long i = 0; i < n; ++i) {
+         const uint32_t w0 = r[i].w0, w1 = r[i].w1;
+         const int nsure = (int)((w0 >> 22) & 63u);
+         bool ok = !(w0 & kCrBad) && w1 != 0xffff8000u && (unsigned)(nsure - 1) < 62u;
+         if (ok && i + 1 < n) { const long long fn = (long long)r[i + 1].pos + (long long)((r[i + 1].w0 >> 12) & 63u); ok = fn > (long long)r[i].pos + W; }
+         if (ok != ((w0 & kCrClear) != 0)) fprintf(stderr, "prep_check: stream %d record %lld of %lld pos %u: clear %d, a pass over the stream says %d (next pos %u w0 %08x w1 %08x)\n", sl, i, n, r[i].pos, (int)((w0 & kCrClear) != 0), (int)ok,
+                                                   i + 1 < n ? r[i + 1].pos : 0u, i + 1 < n ? r[i + 1].w0 : 0u, i + 1 < n ? r[i + 1].w1 : 0u); } } }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // k_gain

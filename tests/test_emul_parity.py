@@ -96,6 +96,21 @@ def test_emulated_peak_path_equals_the_sample_path(name, monkeypatch):
                 assert r0.track_events(b, p, t).tobytes() == r1.track_events(b, p, t).tobytes(), (b, p, t)
 
 
+@pytest.mark.parametrize("name,peak", [("nrzi9", None), ("nrzi9_m", None), ("gcr", "1"), ("nrzi9_skew", None)])
+def test_emulated_clear_flags_equal_a_pass_over_the_streams(name, peak, monkeypatch, capfd):
+    """k_prep marks a record clear from its list neighbours (the next entry of its list, the first of the next tile's list, deferred
+    candidates resolved on the way); k_prep_check (emulator only) redoes that as a pass over the finished streams, record by record
+    with its successor, and reports every record the two disagree on."""
+    monkeypatch.setenv("RTFE_PREP_CHECK", "1")
+    if peak: monkeypatch.setenv("RTFE_PEAK_PATH", peak)
+    g = load_case(name)
+    fe = emul_frontend(config_for(g["hdr"], g["oracle_opts"]))
+    res = fe.scan(g["rows"]).fetch()
+    assert res.nbursts > 0
+    err = capfd.readouterr().err
+    assert "prep_check" not in err, err[:2000]
+
+
 @pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}])
 def test_emulated_long_blocks(knobs, tmp_path, monkeypatch):
     """Blocks of 500-640 bytes: chains that cross many tiles (k_gain's heads, k_gain_s' steady stretches, the tails)."""
