@@ -626,6 +626,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          cs.w = w; cs.i = i; cs.c = c; cs.status = kChSteady;
          for (int k = 0; k < 10; ++k) cs.heights[k] = heights[k];
          if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
+         if (w.nevents > n_slow) atomicAdd(&scratch->dbg[0], (unsigned long long)(w.nevents - n_slow));      // (statistics: the head's events on the fast path)
          continue; }
       cst[ci].status = kChDone;
       n_fast = w.nevents - n_slow - (mode == 1 ? cst[ci].w.nevents : 0u);

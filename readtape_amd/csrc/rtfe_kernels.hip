@@ -73,8 +73,9 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
                                                  long long nrows, long long own_rows, int ntrks, int gap_chunks, int first_is_start,
                                                  float cap_frac, int nparm, long long event_capacity,
                                                  rtfe_burst *__restrict__ bursts, long long max_bursts,
-                                                 BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out) {
+                                                 BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out, int prof) {
    __shared__ int lds[32];
+   long long pk0 = prof ? clock64() : 0, pk1 = 0, pk2 = 0, pa = 0, pb2 = 0, pc = 0, pd = 0, tq = 0;
    __shared__ int s_base;
    __shared__ u64 s_ebase;
    // The quiet map goes through LDS a round (4096 words = 2^18 chunks) at a time, with 64 words in front of it (a zone may begin there;
@@ -92,8 +93,13 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
    if (threadIdx.x == 0) s_base = 0;
    for (long long w0 = 0; w0 < nwords; w0 += 1024 * kPer) {
       __syncthreads();
+      if (prof) tq = clock64();
       wbase = w0 - kBack;
-      for (int k = threadIdx.x; k < kWin; k += blockDim.x) { const long long w = wbase + k; s_q[k] = (w >= 0 && w < nwords) ? qwords[w] : 0; }
+      {  u64 t[(kWin + 1023) / 1024];                                // (all loads in flight before the first is waited for)
+         #pragma unroll
+         for (int j = 0; j < (kWin + 1023) / 1024; ++j) { const long long w = wbase + j * 1024 + (int)threadIdx.x; t[j] = (w >= 0 && w < nwords) ? qwords[w] : 0; }
+         #pragma unroll
+         for (int j = 0; j < (kWin + 1023) / 1024; ++j) { const int k = j * 1024 + (int)threadIdx.x; if (k < kWin) s_q[k] = t[j]; } }
       __syncthreads();
       if (w0 == 0 && threadIdx.x == 0) {
          // a tape (or shard) that does not begin inside a qualifying zone gets an exact-start burst at row 0
@@ -105,6 +111,7 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
             bursts[0] = b;
             s_base = 1; } }
       __syncthreads();
+      if (prof) { const long long t2 = clock64(); pa += t2 - tq; tq = t2; }
       u64 ends[kPer];
       int cnt = 0;
       #pragma unroll
@@ -112,21 +119,29 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
          const long long w = w0 + (long long)threadIdx.x * kPer + j;
          ends[j] = 0;
          if (w < nwords) {
-            const u64 q = qword(w);
-            const u64 qn = qword(w + 1);
+            const u64 q = s_q[kBack + (int)threadIdx.x * kPer + j];            // (the round's own words, straight from the window: words behind the map read 0)
+            const u64 qn = s_q[kBack + (int)threadIdx.x * kPer + j + 1];
             const u64 next = (q >> 1) | (qn << 63);         // bit c = quiet[c+1]
             u64 cand = q & ~next;                           // quiet and successor not quiet
+            const u64 qp = s_q[kBack + (int)threadIdx.x * kPer + j - 1];      // (word -1 of the map reads 0: not quiet)
             while (cand) {
                const int bit = __ffsll((long long)cand) - 1;
                cand &= cand - 1;
-               const long long c = w * 64 + bit;
                bool ok = true;
-               for (int k = 1; k < gap_chunks; ++k) if (!quiet(c - k)) { ok = false; break; }
+               if (gap_chunks <= 64) {
+                  // chunks c, c - 1, ... from bit 63 downwards: the gap_chunks uppermost must all be quiet
+                  const u64 v = bit == 63 ? q : ((q << (63 - bit)) | (qp >> (bit + 1)));
+                  ok = ((~v) >> (64 - gap_chunks)) == 0; }
+               else {
+                  const long long c = w * 64 + bit;
+                  for (int k = 1; k < gap_chunks; ++k) if (!quiet(c - k)) { ok = false; break; } }
                if (ok) ends[j] |= 1ull << bit; } }
          cnt += __popcll(ends[j]); }
+      if (prof) { const long long t2 = clock64(); pb2 += t2 - tq; tq = t2; }
       int total;
       int off = block_excl_scan_1024(cnt, lds, &total);
       const int base = s_base;
+      if (prof) { const long long t2 = clock64(); pc += t2 - tq; tq = t2; }
       #pragma unroll
       for (int j = 0; j < kPer; ++j) {
          const long long w = w0 + (long long)threadIdx.x * kPer + j;
@@ -155,8 +170,10 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
                b.zone_first = zf; b.zone_end = ze; b.reset_sample = -1; b.safe_last = -1;
                bursts[idx] = b; } } }
       __syncthreads();
+      if (prof) { const long long t2 = clock64(); pd += t2 - tq; tq = t2; }
       if (threadIdx.x == 0) s_base = base + total; }
    __syncthreads();
+   if (prof) pk1 = clock64();
    int nb = s_base;
    if (nb > max_bursts) nb = (int)max_bursts;
    // time shards: keep the bursts that start in the owned rows, plus one more as the bound of the last of them
@@ -204,6 +221,7 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
    if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0;
    if (threadIdx.x >= 16 && threadIdx.x < 24) scratch->dbg2[threadIdx.x - 16] = 0;
    if (threadIdx.x >= 24 && threadIdx.x < 32) scratch->why[threadIdx.x - 24] = 0;
+   if (prof && threadIdx.x == 0) { pk2 = clock64(); scratch->scr[0] = (unsigned long long)(pk1 - pk0); scratch->scr[1] = (unsigned long long)(pk2 - pk1); scratch->scr[2] = (unsigned long long)pa; scratch->scr[3] = (unsigned long long)pb2; scratch->scr[4] = (unsigned long long)pc; scratch->scr[5] = (unsigned long long)pd; }      // (RTFE_DEBUG=5)
    }       // (scratch->scr: cleared with the rest of the scratch block when rtfe_scan starts)
 
 // ------------------------------------------------------------------------------------------------

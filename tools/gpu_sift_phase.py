@@ -23,5 +23,6 @@ ph = st["phase_cycles"]
 tiles = max(ph[7], 1)
 print("rows", rows.shape[0], {k: round(v, 3) for k, v in ms.items() if v > 0.01})
 print("k_sift wave-cycles per tile (5 waves): copy+quiet %d dense %d owners %d; deferred candidates %d, rounds %d, tiles %d" % (ph[0] // tiles, ph[1] // tiles, ph[2] // tiles, ph[4], ph[5], tiles))
+print("raw phase counters", ph)
 print({k: st[k] for k in ("bursts", "redone", "parallel", "sequential", "gave_up")})
 print("record bytes per row %.2f" % (ph[3] / rows.shape[0]))
