@@ -429,6 +429,9 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (h->dev.mode == RTFE_WW) return fail(-44, "Whirlwind tapes have no independent bursts: use rtfe_ww_scan");
    if (((uintptr_t)d_rows & 15) != 0) return fail(-31, "d_rows must be 16-byte aligned");
    if (workspace_bytes < rtfe_workspace_bytes(h, nrows)) return fail(-32, "workspace too small");
+   // the peak path addresses rows with 32 bits and a record's margin entries by a 32-bit index (2-byte units) into pool + overflow slots
+   if (h->dev.peak_path && (nrows >= 0x7ff00000ll || (ws_pkqtile_off(h, nrows) - ws_pkpool_off(h, nrows)) / 2 >= 0xffffffffull))
+      return fail(-36, "%lld rows are too many for one rtfe_scan on the peak path: scan the tape in fragments (own_rows)", (long long)nrows);
    if (nrows <= 0 || max_bursts < 1) return fail(-33, "nothing to scan");
    if (own_rows <= 0 || own_rows > nrows) return fail(-35, "own_rows must be in (0, nrows]");
    hipStream_t st = (hipStream_t)stream;
