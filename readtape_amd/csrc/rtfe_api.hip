@@ -78,7 +78,7 @@ extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
 // The timed spans of one rtfe_scan (rtfe_kernel_ms), in launch order.  The peak path (NRZI peak detection) runs
-//   k_sift | k_prep [k_qpack, k_sift_hard, k_pscan1/2, k_prep] | k_bursts | k_gain [k_zones, the chains' heads] | k_gain_s |
+//   k_sift | k_prep [k_qpack, k_sift_hard, k_pscan1/2, k_prep] | k_bursts | k_gain [k_zones, the chains' heads] | k_gain_s [k_segplan, k_gain_seg<0>, k_gain_join, k_gain_seg<1>] |
 //   k_gain_tail | k_emit [k_emit, k_publish] | k_decode [the bursts the chains gave up, on the samples]
 // the sample path (PE, GCR, differentiated peaks, density detection, parameter-set sweeps with too many widths) k_quiet | k_bursts | k_decode,
 // -zeros k_quiet | k_bursts | k_zeros.  A span a scan does not run reads 0.
@@ -251,6 +251,15 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       if (const char *e = getenv("RTFE_PEAK_PATH")) d.peak_path = !d.find_zeros && !d.differentiate && d.mode != RTFE_WW && atoi(e) != 0;
       d.pk_fast = 1;
       if (const char *e = getenv("RTFE_GAIN_FAST")) d.pk_fast = atoi(e) != 0;
+      // the chains' steady stretches in segments (k_gain_seg): 256 records each; the warm-up from the alpha filter's memory
+      d.pk_seg_recs = 256;
+      if (const char *e = getenv("RTFE_SEG_RECS")) { const int v = atoi(e); if (v == 0 || (v >= 8 && v <= 65536)) d.pk_seg_recs = v; }
+      for (int p = 0; p < c->nparmsets; ++p) {
+         const float a = c->parmset[p].agc_alpha;
+         int wm = (a > 0 && a < 1) ? (int)ceil(log(1.0 / 67108864.0) / log(1.0 - (double)a)) : 16;
+         wm = wm < 16 ? 16 : (wm > 1024 ? 1024 : wm);
+         if (const char *e = getenv("RTFE_SEG_WARM")) { const int v = atoi(e); if (v >= 0 && v <= 4096) wm = v; }
+         d.parm[p].seg_warm = wm; }
       const int wmax = sf_wmax(d);
       d.pk_hl = (kPkBack + 2 * wmax + 6 + 7) & ~7;
       d.pk_hr = (wmax + 2 + 7) & ~7;
@@ -409,8 +418,17 @@ static size_t ws_pkextra_off(const rtfe_handle *h, int64_t nrows) { return ws_pk
 static size_t ws_pkcst_off(const rtfe_handle *h, int64_t nrows) { return ws_pkextra_off(h, nrows) + pk_extra_bytes(h, nrows); }
 static size_t pk_cst_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks * sizeof(ChainSt) + 255) & ~(size_t)255) : 0; }
 
+// ... | the segments of the chains' steady stretches (k_segplan -> k_gain_seg -> k_gain_join)
+static long long pk_seg_cap(const rtfe_handle *h, int64_t nrows) {
+   if (!h->dev.peak_path) return 0;
+   const long long S = h->dev.pk_seg_recs > 0 ? h->dev.pk_seg_recs : 1 << 30;
+   const long long per_stream = pk_ccap(h, nrows) / S + 1;
+   return per_stream * h->dev.nscreens * h->dev.ntrks * (h->dev.nparm < 2 ? 1 : 2) + rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks + 64; }
+static size_t ws_pksegs_off(const rtfe_handle *h, int64_t nrows) { return ws_pkcst_off(h, nrows) + pk_cst_bytes(h, nrows); }
+static size_t pk_segs_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)pk_seg_cap(h, nrows) * sizeof(GsSeg) + 255) & ~(size_t)255; }
+
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pkcst_off(h, nrows) + pk_cst_bytes(h, nrows) + 256; }
+   return ws_pksegs_off(h, nrows) + pk_segs_bytes(h, nrows) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -534,8 +552,14 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                             (const unsigned char *)pkpool, ptiles);
          if (mode == 0) {
             t1(kTGain); t0(kTGainS);
-            hipLaunchKernelGGL(k_gain_s, dim3(h->num_cus * 4), dim3(64), 0, st, (const DevCfg *)h->d_dev, cstp, (long long)nrows, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp,
-                               d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap, ptiles);
+            // the steady stretches: in segments, every one on its own, joined where the states agree bit for bit (rtfe_gain.hip)
+            GsSeg *segp = reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows));
+            hipLaunchKernelGGL(k_segplan, dim3(1), dim3(1024), 0, st, (const DevCfg *)h->d_dev, cstp, (const BurstScratch *)scratch, (const BurstCtl *)ctlp, segp, pk_seg_cap(h, nrows), &scratch->nsegs);
+            hipLaunchKernelGGL(k_gain_seg<0>, dim3(h->num_cus * 8), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (long long)nrows, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
+                               (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, ccap, segp, (const int *)&scratch->nsegs);
+            hipLaunchKernelGGL(k_gain_join, dim3(h->num_cus * 2), dim3(64), 0, st, (const DevCfg *)h->d_dev, cstp, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp, d_counts, chainh, segp);
+            hipLaunchKernelGGL(k_gain_seg<1>, dim3(h->num_cus * 8), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (long long)nrows, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
+                               (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, ccap, segp, (const int *)&scratch->nsegs);
             t1(kTGainS); } }
       t1(kTGainTail);
       if (stop_after < 4) { skip_rest(); return launch_check("rtfe_scan"); }

@@ -25,6 +25,7 @@ struct DevParm {
    int   screen;        // index into DevCfg::screen
    float screen_rise_v; // the screen's loosest thresholds in volts (for the underflow check)
    float screen_minpk_v;
+   int   seg_warm;      // records a segment of the chains' steady stretch starts early (the alpha filter forgets its start value: (1 - alpha)^n < 2^-26)
 };
 
 struct DevScreen {
@@ -69,6 +70,7 @@ struct DevCfg {
    int   pk_wave_cap;             // candidates of one wave (two heads of a tile) k_sift can list in LDS; beyond: lists unavailable
    int   pk_lds;                  // dynamic LDS bytes of k_sift
    int   pk_fast;                 // k_gain: the steady-state fast path (0: every detection through the general step; tests)
+   int   pk_seg_recs;             // records per segment of a chain's steady stretch (k_gain_seg); 0: a chain is one segment
    DevParm   parm[RTFE_MAXPARMSETS];
    DevScreen screen[kMaxScreens];
 };

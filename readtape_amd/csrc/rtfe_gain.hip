@@ -333,7 +333,7 @@ __device__ __forceinline__ rtfe_event note_event(long long i, float g, float h) 
 // A chain between the kernels that walk it: k_gain (mode 0: from the burst's restart row until the baseline is fixed) -> k_gain_s (the
 // steady stretch: nothing but the common record) -> k_gain (mode 1: whatever k_gain_s stopped at, to the chain's end).
 enum { kChNone = 0, kChSteady = 1, kChGeneral = 2, kChDone = 3 };
-struct ChainSt { Walker w; float heights[10]; long long i, c; int status, pad; };
+struct ChainSt { Walker w; float heights[10]; long long i, c, iend; int status, seg0, nseg, pad; };      // (iend, seg0, nseg: the steady stretch and its segments)
 
 __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       if (!active) continue;
       if (handed && !failed) {                                             // (steady: everything the walker is, for k_gain_s)
          ChainSt &cs = cst[ci];
-         cs.w = w; cs.i = i; cs.c = c; cs.status = kChSteady;
+         cs.w = w; cs.i = i; cs.c = c; cs.iend = src.iend; cs.seg0 = 0; cs.nseg = 0; cs.status = kChSteady;
          for (int k = 0; k < 10; ++k) cs.heights[k] = heights[k];
          if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
          if (w.nevents > n_slow) atomicAdd(&scratch->dbg[0], (unsigned long long)(w.nevents - n_slow));      // (statistics: the head's events on the fast path)
@@ -638,33 +638,97 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       if (w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW) atomicOr(&ctl[b].bflags, w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW); } }
 
 // ------------------------------------------------------------------------------------------------
-// k_gain_s: the steady stretch of every chain (NRZI / GCR, alpha-filter AGC: peakcount > 15, the baseline fixed), and nothing but the
-// common record - straight-line code, every decision a select.  A lane per chain, 32 records at a time through LDS (the next 32 in
-// flight in registers), its notes through LDS too.  Per record: its rows are behind the countdown -> on; its extreme is below the
+// The steady stretch of every chain (NRZI / GCR, alpha-filter AGC: peakcount > 15, the baseline fixed), and nothing but the common
+// record - straight-line code, every decision a select.  Per record: its rows are behind the countdown -> on; its extreme is below the
 // amplitude test for sure -> on (it cannot fire while the thresholds stand, and they stand until something fires - behind which all its
 // rows are blind); kCrClear and the countdown over before its first row, the thresholds inside the band its sure stretch stands for,
 // amplitude clear -> it fires: note (k_emit finds the row), g = alpha h / lastheight + (1 - alpha) g (src/decoder.c:505-512), the
-// integer bands around the thresholds of src/decoder.c:785-786 from 1 / g.  Anything else: the lane stops there and k_gain (mode 1)
+// integer bands around the thresholds of src/decoder.c:785-786 from 1 / g.  Anything else: the walk stops there and k_gain (mode 1)
 // takes the chain from that record on.
+//
+// A chain is sequential, a 4 KB block's is 4 100 records long, and 18 k chains are 290 waves on 1 024 SIMDs - so the stretch is cut
+// into SEGMENTS of pk_seg_recs records, a lane each:
+//   k_segplan  the chains' segments (a prefix sum over the chains);
+//   k_gain_seg<0>  every segment on its own: segment 0 from the chain's true state, the others from a GUESS (the chain's gain and
+//              peaks at the hand-over, no countdown) a warm-up of pk_seg_warm records early - the countdown re-joins the true sequence
+//              at the first fired record, the peak memory after a top and a bottom, the alpha filter forgets its start value
+//              geometrically - noting the state at its first own record, at its end, and its number of events;
+//   k_gain_join  per chain: segment s stands if segment s - 1 stands, ran through, and ENDED in exactly the state segment s assumed
+//              at its start - every field the step reads, bit for bit; by induction from segment 0 every standing segment ran
+//              from the true state.  Event offsets (a running sum), the chain's state behind the last standing segment;
+//   k_gain_seg<1>  the standing segments again, now writing their notes where they belong.
+// From the first segment that does not stand the chain goes on in k_gain (mode 1) from the last proven state.  Nothing rests on
+// the convergence argument; a warm-up too short only costs time (RTFE_SEG_RECS / RTFE_SEG_WARM: tests force that).
 // ------------------------------------------------------------------------------------------------
 constexpr int kGsChunk = 32;
-__global__ void __launch_bounds__(64) k_gain_s(const DevCfg *__restrict__ cfgp, ChainSt *__restrict__ cst, long long nrows,
-                                               const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, const BurstCtl *__restrict__ ctl,
-                                               uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
-                                               const CRec *__restrict__ crec, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
-                                               long long ccap, long long ntiles) {
-   __shared__ uint4 s_notes[kGsChunk][64];
+struct GsState { float g, vlt, vlb; int c, rise_hi, min_lo, min_hi; };
+struct GsSeg {
+   int chain, sidx;                  // k_segplan
+   long long first, end;             // its own records [first, end) of the chain's stream
+   GsState at_first, at_end;         // k_gain_seg<0>: the state in front of record `first`; behind the last record it got through
+   long long stop;                   // the record it stopped at (the general step's business), or `end`
+   int cnt;                          // events of its own records
+   unsigned int evoff;               // k_gain_join: where its first note goes in the chain's event list
+   int stands, pad; };
+__device__ __forceinline__ bool gs_same(const GsState &a, const GsState &b) {
+   return __float_as_uint(a.g) == __float_as_uint(b.g) && __float_as_uint(a.vlt) == __float_as_uint(b.vlt) && __float_as_uint(a.vlb) == __float_as_uint(b.vlb)
+          && a.c == b.c && a.rise_hi == b.rise_hi && a.min_lo == b.min_lo && a.min_hi == b.min_hi; }
+
+// the chains' segments: nseg per chain, their places in the segment table (a block-wide prefix sum per 1024 chains), the entries
+__global__ void __launch_bounds__(1024) k_segplan(const DevCfg *__restrict__ cfgp, ChainSt *__restrict__ cst, const BurstScratch *__restrict__ scratch, const BurstCtl *__restrict__ ctl,
+                                                  GsSeg *__restrict__ segs, long long seg_cap, int *__restrict__ nsegs_out) {
+   __shared__ int lds[32];
+   __shared__ int s_base;
+   const DevCfg &cfg = *cfgp;
+   const int nwalk = cfg.nparm * cfg.ntrks;
+   const int nchains = scratch->nbursts * nwalk;
+   const int S = cfg.pk_seg_recs;
+   if (threadIdx.x == 0) s_base = 0;
+   __syncthreads();
+   for (int c0 = 0; c0 < nchains; c0 += 1024) {
+      const int ci = c0 + (int)threadIdx.x;
+      int nseg = 0;
+      long long i = 0, iend = 0;
+      if (ci < nchains && ctl[ci / nwalk].status == kBurstReady && cst[ci].status == kChSteady) {
+         i = cst[ci].i; iend = cst[ci].iend;
+         const long long len = iend > i ? iend - i : 0;
+         nseg = (S <= 0 || len <= (long long)S + S / 2) ? 1 : (int)((len + S - 1) / S); }
+      int total;
+      const int off = block_excl_scan_1024(nseg, lds, &total);
+      const int base = s_base;
+      if (nseg > 0 && (long long)base + off + nseg > seg_cap) nseg = 0;      // (no room in the table: the chain goes to k_gain, mode 1, as a whole)
+      if (ci < nchains) { cst[ci].seg0 = base + off; cst[ci].nseg = nseg; }
+      for (int sg = 0; sg < nseg; ++sg) {
+         GsSeg e; e.chain = ci; e.sidx = sg;
+         e.first = i + (long long)sg * S; e.end = sg + 1 == nseg ? iend : i + (long long)(sg + 1) * S;
+         e.stop = e.first; e.cnt = 0; e.evoff = 0; e.stands = 0; e.pad = 0;
+         e.at_first.g = 0; e.at_first.vlt = 0; e.at_first.vlb = 0; e.at_first.c = 0; e.at_first.rise_hi = 0; e.at_first.min_lo = 0; e.at_first.min_hi = 0; e.at_end = e.at_first;
+         segs[base + off + sg] = e; }
+      __syncthreads();
+      if (threadIdx.x == 0) s_base = base + total;
+      __syncthreads(); }
+   if (threadIdx.x == 0) *nsegs_out = s_base; }
+
+// PASS 0: every segment from its (true or guessed) start state, counting; PASS 1: the standing segments from their proven start state, noting
+template <int PASS>
+__global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, long long nrows,
+                                                 const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch, const BurstCtl *__restrict__ ctl,
+                                                 rtfe_event *__restrict__ events, const CRec *__restrict__ crec, long long ccap,
+                                                 GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p) {
+   __shared__ uint4 s_notes[PASS ? kGsChunk : 1][64];
    __shared__ uint4 s_rec[kGsChunk][64];
    const DevCfg &cfg = *cfgp;
-   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks, nlists = cfg.nscreens * ntrks;
+   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
    const int lane = threadIdx.x;
    const float lsb = cfg.lsb_per_volt;
-   const int nchains = scratch->nbursts * nwalk;
-   for (int cbase = blockIdx.x * 64; cbase < nchains; cbase += gridDim.x * 64) {
-      const int ci = cbase + lane < nchains ? cbase + lane : nchains - 1;
+   const int nsegs = *nsegs_p;
+   for (int sbase = blockIdx.x * 64; sbase < nsegs; sbase += gridDim.x * 64) {
+      const int si = sbase + lane < nsegs ? sbase + lane : nsegs - 1;
+      GsSeg sg = segs[si];
+      const bool active = sbase + lane < nsegs && (PASS == 0 || sg.stands);
+      const int ci = sg.chain;
       const int b = ci / nwalk;
       const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
-      const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady && cst[ci].status == kChSteady;
       const rtfe_burst B = bursts[b];
       const DevParm P = cfg.parm[pidx];
       const int sure_i = cfg.screen[P.screen].sure_i;
@@ -672,21 +736,10 @@ __global__ void __launch_bounds__(64) k_gain_s(const DevCfg *__restrict__ cfgp, 
       const long long stop = chain_stop(cfg, bursts, ctl, b, scratch->nbursts_total, nrows);
       const long long limit = stop - d;
       const int limit32 = limit > 0x7ffffff0ll ? 0x7ffffff0 : (int)limit;
-      rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
-      const unsigned int cap = B.event_cap;
       const int sl = P.screen * ntrks + head;
       const uint4 *rec4 = reinterpret_cast<const uint4 *>(crec + (size_t)sl * ccap);
-      long long iend;
-      {  long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;
-         iend = ge < ntiles ? stream_pos(tstart, coff, nlists, ge, sl) : (long long)ctot[sl]; }
-      // the chain as k_gain (mode 0) left it
-      long long i = active ? cst[ci].i : iend;
-      int c = active ? (int)cst[ci].c : 0;
-      float g = cst[ci].w.agc_gain, vlt = cst[ci].w.v_lasttop, vlb = cst[ci].w.v_lastbot;
+      rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
       const float h = cst[ci].w.v_avg_height;
-      unsigned int nev = cst[ci].w.nevents;
-      const unsigned int nev0 = nev;
-      int rise_hi = cst[ci].w.rise_hi, min_lo = cst[ci].w.min_lo, min_hi = cst[ci].w.min_hi;
       const bool amp_on = P.min_peak != 0;
       const float alpha = P.agc_alpha, beta = 1 - P.agc_alpha;
       const float hs = h * 0.25f;
@@ -695,69 +748,114 @@ __global__ void __launch_bounds__(64) k_gain_s(const DevCfg *__restrict__ cfgp, 
       if (P.rise * hs > 0) rg_min = P.screen_rise_v * 1.002f / (P.rise * hs);
       if (amp_on && P.min_peak * hs > 0) { const float b2 = P.screen_minpk_v * 1.002f / (P.min_peak * hs); if (b2 > rg_min) rg_min = b2; }
       const float g_min = 0.005f * lsb / 249.0f;
-      // run: 1 = in lock step; 0 = stopped at record i (k_gain, mode 1, goes on there) or at the chain's end
-      bool run = active, done = false;
-      uint4 q[kGsChunk];
-      #pragma unroll
-      for (int j = 0; j < kGsChunk; ++j) q[j] = make_uint4(0, kCrBad, 0, 0);
-      if (run) {
+      // where the walk begins and in which state
+      float g, vlt, vlb; int c, rise_hi, min_lo, min_hi;
+      long long i;
+      if (PASS == 0) {
+         g = cst[ci].w.agc_gain; vlt = cst[ci].w.v_lasttop; vlb = cst[ci].w.v_lastbot;
+         rise_hi = cst[ci].w.rise_hi; min_lo = cst[ci].w.min_lo; min_hi = cst[ci].w.min_hi;
+         c = sg.sidx == 0 ? (int)cst[ci].c : 0;
+         i = sg.first;
+         if (sg.sidx > 0) { i = sg.first - cfg.parm[pidx].seg_warm; if (i < cst[ci].i) i = cst[ci].i; } }
+      else { g = sg.at_first.g; vlt = sg.at_first.vlt; vlb = sg.at_first.vlb; c = sg.at_first.c; rise_hi = sg.at_first.rise_hi; min_lo = sg.at_first.min_lo; min_hi = sg.at_first.min_hi; i = sg.first; }
+      unsigned int nev = PASS ? sg.evoff : 0u;
+      // One phase of the walk: records [i, to) - `own`: the lane stops at a record that is not the step's business (else it passes over
+      // it: a warm-up only has to arrive in the right state, and the join says whether it did).  Wave-uniform loops; 32 records at a
+      // time through LDS, the next 32 in flight in registers.
+      auto walk = [&](const long long to, const bool own, const bool act) -> long long {
+         bool run = act && i < to;
+         uint4 q[kGsChunk];
          #pragma unroll
-         for (int j = 0; j < kGsChunk; ++j) if (i + j < iend) q[j] = rec4[i + j]; }
-      for (;;) {
-         #pragma unroll
-         for (int j = 0; j < kGsChunk; ++j) s_rec[j][lane] = q[j];
-         if (run) {                                                          // the next chunk travels while this one is stepped through
+         for (int j = 0; j < kGsChunk; ++j) q[j] = make_uint4(0, kCrBad, 0, 0);
+         if (run) {
             #pragma unroll
-            for (int j = 0; j < kGsChunk; ++j) if (i + kGsChunk + j < iend) q[j] = rec4[i + kGsChunk + j]; }
-         int nbuf = 0, adv = 0;
-         #pragma unroll 4
-         for (int j = 0; j < kGsChunk; ++j) {
-            const uint4 r = s_rec[j][lane];
-            const bool inr = run && i + j < iend;
-            const int pos = (int)r.x;
-            const uint32_t w0 = r.y;
-            const bool bad = w0 & kCrBad;
-            const bool dead = bad ? pos + kSfTile + W < c : pos + W - 2 < c;
-            const int val = (int)(int16_t)(r.z & 0xffffu);
-            const bool top = !(w0 & 0x800u);
-            const int a = top ? val : -val;
-            const bool ampdead = !bad && r.z != 0xffff8000u && amp_on && a <= min_lo;
-            const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
-            const bool fire = (w0 & kCrClear) && c <= f && fl < limit32 && rise_hi <= sure_i && (!amp_on || a >= min_hi) && nev < cap && g >= g_min;
-            const float lh = vlt - vlb, v = __uint_as_float(r.w);
-            float g2 = alpha * (h / lh) + beta * g;
-            g2 = g2 > 2.0f ? 2.0f : g2;
-            g2 = lh > 0 ? g2 : g;
-            const float rg = fast_rcp(g2);
-            const bool ok = inr && !dead && !ampdead && fire && g2 > 0 && rg >= rg_min;
-            if (ok) s_notes[nbuf][lane] = make_uint4((uint32_t)(i + j), __float_as_uint(g), __float_as_uint(h), 0xffffffffu);
-            nbuf += ok ? 1 : 0; nev += ok ? 1u : 0u;
-            c = ok ? pos + W + 1 : c;
-            vlt = ok && top ? v : vlt; vlb = ok && !top ? v : vlb;
-            g = ok ? g2 : g;
-            const int rr = (int)(kr * rg), mm = (int)(km * rg);
-            rise_hi = ok ? rr + 3 : rise_hi; min_lo = ok ? mm - 2 : min_lo; min_hi = ok ? mm + 3 : min_hi;
-            const bool on = inr && (dead || ampdead || ok);
-            if (run && !on) { run = false; done = i + j >= iend; adv = j; }
-            }
-         if (run) adv = kGsChunk;
-         // the notes leave; the lanes still running move on a chunk
-         #pragma unroll 4
-         for (int j = 0; j < kGsChunk; ++j) if (j < nbuf) reinterpret_cast<uint4 *>(ev)[nev - (unsigned)nbuf + (unsigned)j] = s_notes[j][lane];
-         i += adv;
-         if (__ballot(run) == 0) break; }
-      if (!active) continue;
-      // ---- the chain's end: publish; or hand the rest to k_gain (mode 1) ----
+            for (int j = 0; j < kGsChunk; ++j) if (i + j < to) q[j] = rec4[i + j]; }
+         while (__ballot(run) != 0ull) {
+            #pragma unroll
+            for (int j = 0; j < kGsChunk; ++j) s_rec[j][lane] = q[j];
+            if (run) {
+               #pragma unroll
+               for (int j = 0; j < kGsChunk; ++j) if (i + kGsChunk + j < to) q[j] = rec4[i + kGsChunk + j]; }
+            int nbuf = 0, adv = 0;
+            #pragma unroll 4
+            for (int j = 0; j < kGsChunk; ++j) {
+               const uint4 r = s_rec[j][lane];
+               const bool inr = run && i + j < to;
+               const int pos = (int)r.x;
+               const uint32_t w0 = r.y;
+               const bool bad = w0 & kCrBad;
+               const bool dead = bad ? pos + kSfTile + W < c : pos + W - 2 < c;
+               const int val = (int)(int16_t)(r.z & 0xffffu);
+               const bool top = !(w0 & 0x800u);
+               const int a = top ? val : -val;
+               const bool ampdead = !bad && r.z != 0xffff8000u && amp_on && a <= min_lo;
+               const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
+               const bool fire = (w0 & kCrClear) && c <= f && fl < limit32 && rise_hi <= sure_i && (!amp_on || a >= min_hi) && g >= g_min;
+               const float lh = vlt - vlb, v = __uint_as_float(r.w);
+               float g2 = alpha * (h / lh) + beta * g;
+               g2 = g2 > 2.0f ? 2.0f : g2;
+               g2 = lh > 0 ? g2 : g;
+               const float rg = fast_rcp(g2);
+               const bool ok = inr && !dead && !ampdead && fire && g2 > 0 && rg >= rg_min;
+               if (PASS == 1) { if (ok) s_notes[nbuf][lane] = make_uint4((uint32_t)(i + j), __float_as_uint(g), __float_as_uint(h), 0xffffffffu); }
+               nbuf += ok ? 1 : 0; nev += ok ? 1u : 0u;
+               c = ok ? pos + W + 1 : c;
+               vlt = ok && top ? v : vlt; vlb = ok && !top ? v : vlb;
+               g = ok ? g2 : g;
+               const int rr = (int)(kr * rg), mm = (int)(km * rg);
+               rise_hi = ok ? rr + 3 : rise_hi; min_lo = ok ? mm - 2 : min_lo; min_hi = ok ? mm + 3 : min_hi;
+               const bool on = inr && (dead || ampdead || ok || !own);
+               if (run && !on) { run = false; adv = j; } }
+            if (run) adv = kGsChunk;
+            if (PASS == 1) {
+               #pragma unroll 4
+               for (int j = 0; j < kGsChunk; ++j) if (j < nbuf) reinterpret_cast<uint4 *>(ev)[nev - (unsigned)nbuf + (unsigned)j] = s_notes[j][lane]; }
+            i += adv;
+            if (i >= to) run = false; }
+         return i; };
+      if (PASS == 0) {
+         walk(sg.first, false, active && sg.sidx > 0);                      // the warm-up: arrive at the first own record
+         i = sg.first; nev = 0;
+         GsState s0; s0.g = g; s0.vlt = vlt; s0.vlb = vlb; s0.c = c; s0.rise_hi = rise_hi; s0.min_lo = min_lo; s0.min_hi = min_hi;
+         const long long at = walk(sg.end, true, active);
+         if (active) {
+            GsSeg &o = segs[si];
+            o.at_first = s0;
+            o.at_end.g = g; o.at_end.vlt = vlt; o.at_end.vlb = vlb; o.at_end.c = c; o.at_end.rise_hi = rise_hi; o.at_end.min_lo = min_lo; o.at_end.min_hi = min_hi;
+            o.stop = at > sg.end ? sg.end : at; o.cnt = (int)nev; } }
+      else walk(sg.stop, true, active); } }
+
+// per chain: which segments stand, where their notes go, and where the chain stands behind them
+__global__ void __launch_bounds__(64) k_gain_join(const DevCfg *__restrict__ cfgp, ChainSt *__restrict__ cst, const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
+                                                  const BurstCtl *__restrict__ ctl, uint32_t *__restrict__ counts, float *__restrict__ chain_h, GsSeg *__restrict__ segs) {
+   const DevCfg &cfg = *cfgp;
+   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
+   const int nchains = scratch->nbursts * nwalk;
+   for (int ci = blockIdx.x * 64 + threadIdx.x; ci < nchains; ci += gridDim.x * 64) {
+      const int b = ci / nwalk;
+      if (ctl[b].status != kBurstReady || cst[ci].status != kChSteady) continue;
       ChainSt &cs = cst[ci];
+      const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
+      const unsigned int cap = bursts[b].event_cap;
+      const unsigned int nev0 = cs.w.nevents;
+      unsigned int nev = nev0;
+      long long resume = cs.i;                                            // where k_gain (mode 1) goes on, if it has to
+      GsState st; st.g = cs.w.agc_gain; st.vlt = cs.w.v_lasttop; st.vlb = cs.w.v_lastbot; st.c = (int)cs.c; st.rise_hi = cs.w.rise_hi; st.min_lo = cs.w.min_lo; st.min_hi = cs.w.min_hi;
+      bool through = cs.nseg > 0;
+      for (int k = 0; k < cs.nseg; ++k) {
+         GsSeg &sg = segs[cs.seg0 + k];
+         if (!gs_same(sg.at_first, st) || (unsigned long long)nev + (unsigned)sg.cnt > cap) { through = false; break; }      // (segment 0's start state IS the chain's; an event list that would overflow is the general step's to flag)
+         sg.stands = 1; sg.evoff = nev;
+         nev += (unsigned)sg.cnt; st = sg.at_end; resume = sg.stop;
+         if (sg.stop < sg.end) { through = false; break; } }
       if (nev > nev0) atomicAdd(&scratch->dbg[0], (unsigned long long)(nev - nev0));
-      if (done) {
+      cs.w.agc_gain = st.g; cs.w.v_lasttop = st.vlt; cs.w.v_lastbot = st.vlb; cs.w.v_top = st.vlt; cs.w.v_bot = st.vlb;
+      cs.w.peakcount += (int)(nev - nev0); cs.w.nevents = nev; cs.i = resume; cs.c = st.c;
+      if (through) {
          cs.status = kChDone;
          counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = nev < cap ? nev : cap;
-         chain_h[(size_t)b * nwalk + wi] = h; }
-      else {
-         cs.w.agc_gain = g; cs.w.v_lasttop = vlt; cs.w.v_lastbot = vlb; cs.w.v_top = vlt; cs.w.v_bot = vlb;
-         cs.w.peakcount += (int)(nev - nev0); cs.w.nevents = nev; cs.i = i; cs.c = c; cs.status = kChGeneral; } } }
-
+         chain_h[(size_t)b * nwalk + wi] = cs.w.v_avg_height; }
+      else cs.status = kChGeneral; } }
 // ------------------------------------------------------------------------------------------------
 // k_emit: the events the fast path noted -> the events the reference's callbacks see.  One workgroup per chain at a time,
 // a lane per event (16 bytes in, 16 bytes out, consecutive lanes consecutive events).

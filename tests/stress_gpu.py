@@ -130,6 +130,10 @@ for i in range(ntapes):
     os.environ["RTFE_GAIN_FAST"] = str(1 - seg)
     if warm: os.environ["RTFE_SIFT_GENERIC"] = "1"
     else: os.environ.pop("RTFE_SIFT_GENERIC", None)
+    # ... and the segments of the chains' steady stretches: short ones, warm-ups too short to join
+    os.environ["RTFE_SEG_RECS"] = str(rng.choice([256, 256, 32, 16, 0]))
+    if rng.random() < 0.3: os.environ["RTFE_SEG_WARM"] = str(rng.choice([0, 2, 8]))
+    else: os.environ.pop("RTFE_SEG_WARM", None)
     if os.environ.get("STRESS_ONLY") and int(os.environ["STRESS_ONLY"]) != i: continue
     if os.environ.get("STRESS_DRY"):
         print(i, kind, "seed", seed, "amp", amp, "noise", noise, "jit", jit, "opts", opts, "seg", seg, warm, "rows", tape.rows.shape[0], "spec", tape.spec.bpi, "parms", repr(parms_text), flush=True)
