@@ -251,13 +251,15 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       if (const char *e = getenv("RTFE_PEAK_PATH")) d.peak_path = !d.find_zeros && !d.differentiate && d.mode != RTFE_WW && atoi(e) != 0;
       d.pk_fast = 1;
       if (const char *e = getenv("RTFE_GAIN_FAST")) d.pk_fast = atoi(e) != 0;
-      // the chains' steady stretches in segments (k_gain_seg): 256 records each; the warm-up from the alpha filter's memory
-      d.pk_seg_recs = 256;
+      // the chains' steady stretches in segments (k_gain_seg): 128 records each (measured on C2: 64 .. 256 -> 0.65 0.57 0.53 0.55 0.59 ms); the warm-up from the alpha filter's memory
+      d.pk_seg_recs = 128;
       if (const char *e = getenv("RTFE_SEG_RECS")) { const int v = atoi(e); if (v == 0 || (v >= 8 && v <= 65536)) d.pk_seg_recs = v; }
       for (int p = 0; p < c->nparmsets; ++p) {
          const float a = c->parmset[p].agc_alpha;
-         int wm = (a > 0 && a < 1) ? (int)ceil(log(1.0 / 67108864.0) / log(1.0 - (double)a)) : 16;
-         wm = wm < 16 ? 16 : (wm > 1024 ? 1024 : wm);
+         // (1 - alpha)^n < 2^-26 brings two gains within an ulp; 64 records more for the last ulp to collapse under the filter's own
+         // rounding (round 2 measured the same on the old walk: ~50 records left 3 % of the joins a few ulps apart, ~200 none in 8 000)
+         int wm = ((a > 0 && a < 1) ? (int)ceil(log(1.0 / 67108864.0) / log(1.0 - (double)a)) : 16) + 64;
+         wm = wm > 1024 ? 1024 : wm;
          if (const char *e = getenv("RTFE_SEG_WARM")) { const int v = atoi(e); if (v >= 0 && v <= 4096) wm = v; }
          d.parm[p].seg_warm = wm; }
       const int wmax = sf_wmax(d);
@@ -555,11 +557,11 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
             // the steady stretches: in segments, every one on its own, joined where the states agree bit for bit (rtfe_gain.hip)
             GsSeg *segp = reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows));
             hipLaunchKernelGGL(k_segplan, dim3(1), dim3(1024), 0, st, (const DevCfg *)h->d_dev, cstp, (const BurstScratch *)scratch, (const BurstCtl *)ctlp, segp, pk_seg_cap(h, nrows), &scratch->nsegs);
-            hipLaunchKernelGGL(k_gain_seg<0>, dim3(h->num_cus * 8), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (long long)nrows, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
-                               (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, ccap, segp, (const int *)&scratch->nsegs);
+            hipLaunchKernelGGL(k_segfill, dim3(h->num_cus * 2), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstScratch *)scratch, segp);
+            const int seg_grid = h->num_cus * 16;      // (all of C2's segments resident at once; fewer resident workgroups measured slower)
+            hipLaunchKernelGGL(k_gain_seg<0>, dim3(seg_grid), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, scratch, d_events, (const CRec *)crecp, ccap, segp, (const int *)&scratch->nsegs);
             hipLaunchKernelGGL(k_gain_join, dim3(h->num_cus * 2), dim3(64), 0, st, (const DevCfg *)h->d_dev, cstp, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp, d_counts, chainh, segp);
-            hipLaunchKernelGGL(k_gain_seg<1>, dim3(h->num_cus * 8), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (long long)nrows, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
-                               (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, ccap, segp, (const int *)&scratch->nsegs);
+            hipLaunchKernelGGL(k_gain_seg<1>, dim3(seg_grid), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, scratch, d_events, (const CRec *)crecp, ccap, segp, (const int *)&scratch->nsegs);
             t1(kTGainS); } }
       t1(kTGainTail);
       if (stop_after < 4) { skip_rest(); return launch_check("rtfe_scan"); }
@@ -608,7 +610,7 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
    if (hipMemcpy(&sc, d_workspace, sizeof sc, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
    out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.scr[3]; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
    for (int i = 0; i < 8; ++i) out[5 + i] = (int64_t)sc.why[i];
-   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)(h->dev.debug == 4 ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
+   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)((h->dev.debug == 4 || h->dev.debug == 6) ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
    return 0; }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

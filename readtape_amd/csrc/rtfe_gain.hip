@@ -333,7 +333,11 @@ __device__ __forceinline__ rtfe_event note_event(long long i, float g, float h) 
 // A chain between the kernels that walk it: k_gain (mode 0: from the burst's restart row until the baseline is fixed) -> k_gain_s (the
 // steady stretch: nothing but the common record) -> k_gain (mode 1: whatever k_gain_s stopped at, to the chain's end).
 enum { kChNone = 0, kChSteady = 1, kChGeneral = 2, kChDone = 3 };
-struct ChainSt { Walker w; float heights[10]; long long i, c, iend; int status, seg0, nseg, pad; };      // (iend, seg0, nseg: the steady stretch and its segments)
+struct GsConst {                       // what a segment's lane needs to know about its chain (k_gain, mode 0, at the hand-over)
+   unsigned long long ev_index;        // the chain's event list in the event arena
+   float h, alpha, kr, km, rg_min, g_min;
+   int W, sure_i, limit32, amp_on, sl, pad; };
+struct ChainSt { Walker w; float heights[10]; long long i, c, iend; int status, seg0, nseg, pad; GsConst k; };      // (iend, seg0, nseg: the steady stretch and its segments)
 
 __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
@@ -624,6 +628,8 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       if (handed && !failed) {                                             // (steady: everything the walker is, for k_gain_s)
          ChainSt &cs = cst[ci];
          cs.w = w; cs.i = i; cs.c = c; cs.iend = src.iend; cs.seg0 = 0; cs.nseg = 0; cs.status = kChSteady;
+         cs.k.ev_index = (unsigned long long)(ev - events); cs.k.h = w.v_avg_height; cs.k.alpha = alpha; cs.k.kr = kr; cs.k.km = km; cs.k.rg_min = rg_min; cs.k.g_min = g_min;
+         cs.k.W = W; cs.k.sure_i = S.sure_i; cs.k.limit32 = limit32; cs.k.amp_on = amp_on ? 1 : 0; cs.k.sl = sl; cs.k.pad = 0;
          for (int k = 0; k < 10; ++k) cs.heights[k] = heights[k];
          if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
          if (w.nevents > n_slow) atomicAdd(&scratch->dbg[0], (unsigned long long)(w.nevents - n_slow));      // (statistics: the head's events on the fast path)
@@ -660,7 +666,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
 // From the first segment that does not stand the chain goes on in k_gain (mode 1) from the last proven state.  Nothing rests on
 // the convergence argument; a warm-up too short only costs time (RTFE_SEG_RECS / RTFE_SEG_WARM: tests force that).
 // ------------------------------------------------------------------------------------------------
-constexpr int kGsChunk = 32;
+constexpr int kGsChunk = 16;
 struct GsState { float g, vlt, vlb; int c, rise_hi, min_lo, min_hi; };
 struct GsSeg {
    int chain, sidx;                  // k_segplan
@@ -698,120 +704,146 @@ __global__ void __launch_bounds__(1024) k_segplan(const DevCfg *__restrict__ cfg
       const int base = s_base;
       if (nseg > 0 && (long long)base + off + nseg > seg_cap) nseg = 0;      // (no room in the table: the chain goes to k_gain, mode 1, as a whole)
       if (ci < nchains) { cst[ci].seg0 = base + off; cst[ci].nseg = nseg; }
-      for (int sg = 0; sg < nseg; ++sg) {
-         GsSeg e; e.chain = ci; e.sidx = sg;
-         e.first = i + (long long)sg * S; e.end = sg + 1 == nseg ? iend : i + (long long)(sg + 1) * S;
-         e.stop = e.first; e.cnt = 0; e.evoff = 0; e.stands = 0; e.pad = 0;
-         e.at_first.g = 0; e.at_first.vlt = 0; e.at_first.vlb = 0; e.at_first.c = 0; e.at_first.rise_hi = 0; e.at_first.min_lo = 0; e.at_first.min_hi = 0; e.at_end = e.at_first;
-         segs[base + off + sg] = e; }
       __syncthreads();
       if (threadIdx.x == 0) s_base = base + total;
       __syncthreads(); }
    if (threadIdx.x == 0) *nsegs_out = s_base; }
 
-// PASS 0: every segment from its (true or guessed) start state, counting; PASS 1: the standing segments from their proven start state, noting
+// ... and the table's entries: a lane per chain writes its segments' places
+__global__ void __launch_bounds__(256) k_segfill(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, const BurstScratch *__restrict__ scratch, GsSeg *__restrict__ segs) {
+   const DevCfg &cfg = *cfgp;
+   const int nchains = scratch->nbursts * cfg.nparm * cfg.ntrks;
+   const int S = cfg.pk_seg_recs;
+   for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < nchains; ci += gridDim.x * blockDim.x) {
+      const int nseg = cst[ci].nseg;                                     // (0 for a chain that is not in its steady stretch: k_segplan)
+      if (cst[ci].status != kChSteady || nseg <= 0) continue;
+      const long long i = cst[ci].i, iend = cst[ci].iend;
+      GsSeg *o = segs + cst[ci].seg0;
+      for (int sg = 0; sg < nseg; ++sg) {
+         o[sg].chain = ci; o[sg].sidx = sg;
+         o[sg].first = i + (long long)sg * S; o[sg].end = sg + 1 == nseg ? iend : i + (long long)(sg + 1) * S;
+         o[sg].stands = 0; } } }
+
+// PASS 0: every segment from its (true or guessed) start state, counting; PASS 1: the standing segments from their proven start state, noting.
+// A lane per segment, eight records at a time.  The wave loads and stores TOGETHER: a lane reading its own records (16 bytes here, 16
+// bytes 4 KB further on for the next lane) makes every load instruction 64 requests for a quarter of a line each, and 86 k segments
+// doing that at once are bound by the requests, not by the bytes.  So load instruction k fetches the 128-byte pieces of eight lanes'
+// segments (lanes 8k .. 8k+7: eight lanes per piece, 16 bytes each - whole lines), through registers (a chunk ahead) into LDS, where
+// every lane then finds its own eight records; the notes go the same way back (LDS, then eight lanes per segment's piece).
+constexpr int kGsRegs = 8, kGsDepth = 1;
+constexpr int kGsPitch = kGsRegs + 1;                                 // a lane's slot in LDS, in 16-byte units (odd: conflict-free 128-bit reads)
 template <int PASS>
-__global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, long long nrows,
-                                                 const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch, const BurstCtl *__restrict__ ctl,
+__global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, BurstScratch *__restrict__ scratch,
                                                  rtfe_event *__restrict__ events, const CRec *__restrict__ crec, long long ccap,
                                                  GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p) {
-   __shared__ uint4 s_notes[PASS ? kGsChunk : 1][64];
-   __shared__ uint4 s_rec[kGsChunk][64];
-   const DevCfg &cfg = *cfgp;
-   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
+   __shared__ uint4 s_rec[64 * kGsPitch];
+   __shared__ uint4 s_note[PASS ? 64 * kGsPitch : 1];
    const int lane = threadIdx.x;
-   const float lsb = cfg.lsb_per_volt;
    const int nsegs = *nsegs_p;
+   const bool prof = cfgp->debug == 6 && threadIdx.x == 0;
+   long long pt0 = 0, pt_setup = 0, pt_steps = 0, pn_chunks = 0, pn_items = 0;
    for (int sbase = blockIdx.x * 64; sbase < nsegs; sbase += gridDim.x * 64) {
       const int si = sbase + lane < nsegs ? sbase + lane : nsegs - 1;
-      GsSeg sg = segs[si];
+      if (prof) { pt0 = clock64(); ++pn_items; }
+      const GsSeg sg = segs[si];
       const bool active = sbase + lane < nsegs && (PASS == 0 || sg.stands);
-      const int ci = sg.chain;
-      const int b = ci / nwalk;
-      const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
-      const rtfe_burst B = bursts[b];
-      const DevParm P = cfg.parm[pidx];
-      const int sure_i = cfg.screen[P.screen].sure_i;
-      const int W = P.W, d = cfg.skew[trk], head = cfg.trk_to_head[trk];
-      const long long stop = chain_stop(cfg, bursts, ctl, b, scratch->nbursts_total, nrows);
-      const long long limit = stop - d;
-      const int limit32 = limit > 0x7ffffff0ll ? 0x7ffffff0 : (int)limit;
-      const int sl = P.screen * ntrks + head;
-      const uint4 *rec4 = reinterpret_cast<const uint4 *>(crec + (size_t)sl * ccap);
-      rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
-      const float h = cst[ci].w.v_avg_height;
-      const bool amp_on = P.min_peak != 0;
-      const float alpha = P.agc_alpha, beta = 1 - P.agc_alpha;
-      const float hs = h * 0.25f;
-      const float kr = P.rise * hs * lsb, km = P.min_peak * hs * lsb;
-      float rg_min = 0;
-      if (P.rise * hs > 0) rg_min = P.screen_rise_v * 1.002f / (P.rise * hs);
-      if (amp_on && P.min_peak * hs > 0) { const float b2 = P.screen_minpk_v * 1.002f / (P.min_peak * hs); if (b2 > rg_min) rg_min = b2; }
-      const float g_min = 0.005f * lsb / 249.0f;
+      const ChainSt &cs = cst[sg.chain];
+      const GsConst K = cs.k;
+      const int W = K.W, sure_i = K.sure_i, limit32 = K.limit32;
+      const bool amp_on = K.amp_on != 0;
+      const float h = K.h, alpha = K.alpha, beta = 1 - K.alpha, kr = K.kr, km = K.km, rg_min = K.rg_min, g_min = K.g_min;
+      const uint4 *rec4 = reinterpret_cast<const uint4 *>(crec + (size_t)K.sl * ccap);
+      uint4 *ev4 = reinterpret_cast<uint4 *>(events + K.ev_index);
       // where the walk begins and in which state
       float g, vlt, vlb; int c, rise_hi, min_lo, min_hi;
       long long i;
       if (PASS == 0) {
-         g = cst[ci].w.agc_gain; vlt = cst[ci].w.v_lasttop; vlb = cst[ci].w.v_lastbot;
-         rise_hi = cst[ci].w.rise_hi; min_lo = cst[ci].w.min_lo; min_hi = cst[ci].w.min_hi;
-         c = sg.sidx == 0 ? (int)cst[ci].c : 0;
+         g = cs.w.agc_gain; vlt = cs.w.v_lasttop; vlb = cs.w.v_lastbot;
+         rise_hi = cs.w.rise_hi; min_lo = cs.w.min_lo; min_hi = cs.w.min_hi;
+         c = sg.sidx == 0 ? (int)cs.c : 0;
          i = sg.first;
-         if (sg.sidx > 0) { i = sg.first - cfg.parm[pidx].seg_warm; if (i < cst[ci].i) i = cst[ci].i; } }
+         if (sg.sidx > 0) { i = sg.first - cfgp->parm[(sg.chain % (cfgp->nparm * cfgp->ntrks)) / cfgp->ntrks].seg_warm; if (i < cs.i) i = cs.i; } }
       else { g = sg.at_first.g; vlt = sg.at_first.vlt; vlb = sg.at_first.vlb; c = sg.at_first.c; rise_hi = sg.at_first.rise_hi; min_lo = sg.at_first.min_lo; min_hi = sg.at_first.min_hi; i = sg.first; }
       unsigned int nev = PASS ? sg.evoff : 0u;
+      if (prof) pt_setup += clock64() - pt0;
       // One phase of the walk: records [i, to) - `own`: the lane stops at a record that is not the step's business (else it passes over
-      // it: a warm-up only has to arrive in the right state, and the join says whether it did).  Wave-uniform loops; 32 records at a
-      // time through LDS, the next 32 in flight in registers.
+      // it: a warm-up only has to arrive in the right state, and the join says whether it did).  Wave-uniform loops.
       auto walk = [&](const long long to, const bool own, const bool act) -> long long {
          bool run = act && i < to;
-         uint4 q[kGsChunk];
+         const int piece = lane & 7, sub = lane >> 3;
+         // the pieces this lane fetches for the others: of lane 8k + sub's records [at, at + 8) the one numbered `piece`.  kGsDepth
+         // chunks are in flight (measured: 3 instead of 1 change nothing - the walk is bound by the step's dependent instructions).
+         uint4 q[kGsDepth][kGsRegs];
+         auto fetch = [&](uint4 (&dst)[kGsRegs], const long long at) {
+            const unsigned long long mine = reinterpret_cast<unsigned long long>(rec4 + at);
+            const int left = run ? (int)((to - at) < kGsRegs ? (to - at > 0 ? to - at : 0) : kGsRegs) : 0;
+            #pragma unroll
+            for (int k = 0; k < kGsRegs; ++k) {
+               const int src = 8 * k + sub;
+               const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, src), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), src);
+               const int n = __shfl(left, src);
+               dst[k] = make_uint4(0, kCrBad, 0, 0);
+               if (piece < n) dst[k] = reinterpret_cast<const uint4 *>(((unsigned long long)hi << 32) | lo)[piece]; } };
          #pragma unroll
-         for (int j = 0; j < kGsChunk; ++j) q[j] = make_uint4(0, kCrBad, 0, 0);
-         if (run) {
+         for (int dd = 0; dd < kGsDepth; ++dd) fetch(q[dd], i + dd * kGsRegs);
+         bool more = __ballot(run) != 0ull;
+         while (more) {
             #pragma unroll
-            for (int j = 0; j < kGsChunk; ++j) if (i + j < to) q[j] = rec4[i + j]; }
-         while (__ballot(run) != 0ull) {
-            #pragma unroll
-            for (int j = 0; j < kGsChunk; ++j) s_rec[j][lane] = q[j];
-            if (run) {
+            for (int dd = 0; dd < kGsDepth; ++dd) {
+               if (!more) break;
+               long long tc0 = 0;
+               if (prof) { tc0 = clock64(); ++pn_chunks; }
                #pragma unroll
-               for (int j = 0; j < kGsChunk; ++j) if (i + kGsChunk + j < to) q[j] = rec4[i + kGsChunk + j]; }
-            int nbuf = 0, adv = 0;
-            #pragma unroll 4
-            for (int j = 0; j < kGsChunk; ++j) {
-               const uint4 r = s_rec[j][lane];
-               const bool inr = run && i + j < to;
-               const int pos = (int)r.x;
-               const uint32_t w0 = r.y;
-               const bool bad = w0 & kCrBad;
-               const bool dead = bad ? pos + kSfTile + W < c : pos + W - 2 < c;
-               const int val = (int)(int16_t)(r.z & 0xffffu);
-               const bool top = !(w0 & 0x800u);
-               const int a = top ? val : -val;
-               const bool ampdead = !bad && r.z != 0xffff8000u && amp_on && a <= min_lo;
-               const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
-               const bool fire = (w0 & kCrClear) && c <= f && fl < limit32 && rise_hi <= sure_i && (!amp_on || a >= min_hi) && g >= g_min;
-               const float lh = vlt - vlb, v = __uint_as_float(r.w);
-               float g2 = alpha * (h / lh) + beta * g;
-               g2 = g2 > 2.0f ? 2.0f : g2;
-               g2 = lh > 0 ? g2 : g;
-               const float rg = fast_rcp(g2);
-               const bool ok = inr && !dead && !ampdead && fire && g2 > 0 && rg >= rg_min;
-               if (PASS == 1) { if (ok) s_notes[nbuf][lane] = make_uint4((uint32_t)(i + j), __float_as_uint(g), __float_as_uint(h), 0xffffffffu); }
-               nbuf += ok ? 1 : 0; nev += ok ? 1u : 0u;
-               c = ok ? pos + W + 1 : c;
-               vlt = ok && top ? v : vlt; vlb = ok && !top ? v : vlb;
-               g = ok ? g2 : g;
-               const int rr = (int)(kr * rg), mm = (int)(km * rg);
-               rise_hi = ok ? rr + 3 : rise_hi; min_lo = ok ? mm - 2 : min_lo; min_hi = ok ? mm + 3 : min_hi;
-               const bool on = inr && (dead || ampdead || ok || !own);
-               if (run && !on) { run = false; adv = j; } }
-            if (run) adv = kGsChunk;
-            if (PASS == 1) {
-               #pragma unroll 4
-               for (int j = 0; j < kGsChunk; ++j) if (j < nbuf) reinterpret_cast<uint4 *>(ev)[nev - (unsigned)nbuf + (unsigned)j] = s_notes[j][lane]; }
-            i += adv;
-            if (i >= to) run = false; }
+               for (int k = 0; k < kGsRegs; ++k) s_rec[(8 * k + sub) * kGsPitch + piece] = q[dd][k];
+               rtfe_wave_sync();
+               fetch(q[dd], i + kGsDepth * kGsRegs);                            // this set again, kGsDepth chunks on
+               int adv = 0, nbuf = 0;
+               const unsigned int nev_in = nev;
+               #pragma unroll
+               for (int j = 0; j < kGsRegs; ++j) {
+                  const uint4 r = s_rec[lane * kGsPitch + j];
+                  const bool inr = run && i + j < to;
+                  const int pos = (int)r.x;
+                  const uint32_t w0 = r.y;
+                  const bool bad = w0 & kCrBad;
+                  const bool dead = bad ? pos + kSfTile + W < c : pos + W - 2 < c;
+                  const int val = (int)(int16_t)(r.z & 0xffffu);
+                  const bool top = !(w0 & 0x800u);
+                  const int a = top ? val : -val;
+                  const bool ampdead = !bad && r.z != 0xffff8000u && amp_on && a <= min_lo;
+                  const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
+                  const bool fire = (w0 & kCrClear) && c <= f && fl < limit32 && rise_hi <= sure_i && (!amp_on || a >= min_hi) && g >= g_min;
+                  const float lh = vlt - vlb, v = __uint_as_float(r.w);
+                  float g2 = alpha * (h / lh) + beta * g;
+                  g2 = g2 > 2.0f ? 2.0f : g2;
+                  g2 = lh > 0 ? g2 : g;
+                  const float rg = fast_rcp(g2);
+                  const bool ok = inr && !dead && !ampdead && fire && g2 > 0 && rg >= rg_min;
+                  if (PASS == 1) { if (ok) s_note[lane * kGsPitch + nbuf] = make_uint4((uint32_t)(i + j), __float_as_uint(g), __float_as_uint(h), 0xffffffffu); }
+                  nbuf += ok ? 1 : 0; nev += ok ? 1u : 0u;
+                  c = ok ? pos + W + 1 : c;
+                  vlt = ok && top ? v : vlt; vlb = ok && !top ? v : vlb;
+                  g = ok ? g2 : g;
+                  const int rr = (int)(kr * rg), mm = (int)(km * rg);
+                  rise_hi = ok ? rr + 3 : rise_hi; min_lo = ok ? mm - 2 : min_lo; min_hi = ok ? mm + 3 : min_hi;
+                  const bool on = inr && (dead || ampdead || ok || !own);
+                  if (run && !on) { run = false; adv = j; } }
+               if (run) adv = kGsRegs;
+               if (PASS == 1) {
+                  // the chunk's notes leave: eight lanes per segment, a note each
+                  rtfe_wave_sync();
+                  const unsigned long long mine = reinterpret_cast<unsigned long long>(ev4 + nev_in);
+                  #pragma unroll
+                  for (int k = 0; k < kGsRegs; ++k) {
+                     const int src = 8 * k + sub;
+                     const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, src), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), src);
+                     const int n = __shfl(nbuf, src);
+                     if (piece < n) reinterpret_cast<uint4 *>(((unsigned long long)hi << 32) | lo)[piece] = s_note[src * kGsPitch + piece]; } }
+               rtfe_wave_sync();
+               i += adv;
+               if (i >= to) run = false;
+               more = __ballot(run) != 0ull;
+               if (prof) pt_steps += clock64() - tc0; } }
          return i; };
       if (PASS == 0) {
          walk(sg.first, false, active && sg.sidx > 0);                      // the warm-up: arrive at the first own record
@@ -823,7 +855,9 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
             o.at_first = s0;
             o.at_end.g = g; o.at_end.vlt = vlt; o.at_end.vlb = vlb; o.at_end.c = c; o.at_end.rise_hi = rise_hi; o.at_end.min_lo = min_lo; o.at_end.min_hi = min_hi;
             o.stop = at > sg.end ? sg.end : at; o.cnt = (int)nev; } }
-      else walk(sg.stop, true, active); } }
+      else walk(sg.stop, true, active); }
+   if (prof) { atomicAdd(&scratch->dbg2[0], (unsigned long long)pt_setup); atomicAdd(&scratch->dbg2[1], (unsigned long long)pt_steps);
+               atomicAdd(&scratch->dbg2[3], (unsigned long long)pn_chunks); atomicAdd(&scratch->dbg2[4], (unsigned long long)pn_items); } }
 
 // per chain: which segments stand, where their notes go, and where the chain stands behind them
 __global__ void __launch_bounds__(64) k_gain_join(const DevCfg *__restrict__ cfgp, ChainSt *__restrict__ cst, const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
