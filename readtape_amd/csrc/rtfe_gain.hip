@@ -337,7 +337,7 @@ struct GsConst {                       // what a segment's lane needs to know ab
    unsigned long long ev_index;        // the chain's event list in the event arena
    float h, alpha, kr, km, rg_min, g_min;
    int W, sure_i, limit32, amp_on, sl, pad; };
-struct ChainSt { Walker w; float heights[10]; long long i, c, iend; int status, seg0, nseg, pad; GsConst k; };      // (iend, seg0, nseg: the steady stretch and its segments)
+struct ChainSt { Walker w; float heights[10]; long long i, c, iend; int status, seg0, nseg, pad; unsigned int seg_ev0, seg_ev1; GsConst k; };      // (iend, seg0, nseg: the steady stretch and its segments)
 
 __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       if (!active) continue;
       if (handed && !failed) {                                             // (steady: everything the walker is, for k_gain_s)
          ChainSt &cs = cst[ci];
-         cs.w = w; cs.i = i; cs.c = c; cs.iend = src.iend; cs.seg0 = 0; cs.nseg = 0; cs.status = kChSteady;
+         cs.w = w; cs.i = i; cs.c = c; cs.iend = src.iend; cs.seg0 = 0; cs.nseg = 0; cs.status = kChSteady; cs.seg_ev0 = w.nevents; cs.seg_ev1 = w.nevents;
          cs.k.ev_index = (unsigned long long)(ev - events); cs.k.h = w.v_avg_height; cs.k.alpha = alpha; cs.k.kr = kr; cs.k.km = km; cs.k.rg_min = rg_min; cs.k.g_min = g_min;
          cs.k.W = W; cs.k.sure_i = S.sure_i; cs.k.limit32 = limit32; cs.k.amp_on = amp_on ? 1 : 0; cs.k.sl = sl; cs.k.pad = 0;
          for (int k = 0; k < 10; ++k) cs.heights[k] = heights[k];
@@ -635,6 +635,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          if (w.nevents > n_slow) atomicAdd(&scratch->dbg[0], (unsigned long long)(w.nevents - n_slow));      // (statistics: the head's events on the fast path)
          continue; }
       cst[ci].status = kChDone;
+      if (mode == 0) { cst[ci].seg_ev0 = 0; cst[ci].seg_ev1 = 0; }        // (no steady stretch: every event of the chain is k_emit's)
       n_fast = w.nevents - n_slow - (mode == 1 ? cst[ci].w.nevents : 0u);
       if (n_fast) atomicAdd(&scratch->dbg[0], (unsigned long long)n_fast);
       if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
@@ -698,7 +699,7 @@ __global__ void __launch_bounds__(1024) k_segplan(const DevCfg *__restrict__ cfg
       if (ci < nchains && ctl[ci / nwalk].status == kBurstReady && cst[ci].status == kChSteady) {
          i = cst[ci].i; iend = cst[ci].iend;
          const long long len = iend > i ? iend - i : 0;
-         nseg = (S <= 0 || len <= (long long)S + S / 2) ? 1 : (int)((len + S - 1) / S); }
+         nseg = len <= 0 ? 0 : (int)((len + S - 1) / S); }
       int total;
       const int off = block_excl_scan_1024(nseg, lds, &total);
       const int base = s_base;
@@ -724,50 +725,46 @@ __global__ void __launch_bounds__(256) k_segfill(const DevCfg *__restrict__ cfgp
          o[sg].first = i + (long long)sg * S; o[sg].end = sg + 1 == nseg ? iend : i + (long long)(sg + 1) * S;
          o[sg].stands = 0; } } }
 
-// PASS 0: every segment from its (true or guessed) start state, counting; PASS 1: the standing segments from their proven start state, noting.
-// A lane per segment, eight records at a time.  The wave loads and stores TOGETHER: a lane reading its own records (16 bytes here, 16
-// bytes 4 KB further on for the next lane) makes every load instruction 64 requests for a quarter of a line each, and 86 k segments
-// doing that at once are bound by the requests, not by the bytes.  So load instruction k fetches the 128-byte pieces of eight lanes'
-// segments (lanes 8k .. 8k+7: eight lanes per piece, 16 bytes each - whole lines), through registers (a chunk ahead) into LDS, where
-// every lane then finds its own eight records; the notes go the same way back (LDS, then eight lanes per segment's piece).
+// Every segment from its (true or guessed) start state.  What it leaves behind: the states at its first record and at its end, its event
+// count, and per own record the gain in force if the record fired, else 0 (gfire, pk_seg_recs floats per segment) - k_emit_seg makes the
+// events of the segments that stand from those.
+// A lane per segment, eight records at a time.  The wave loads TOGETHER: a lane reading its own records (16 bytes here, 16 bytes 2 KB
+// further on for the next lane) makes every load instruction 64 requests for a quarter of a line each; so load instruction k fetches the
+// 128-byte pieces of eight lanes' segments (lanes 8k .. 8k+7: eight lanes per piece, 16 bytes each - whole lines), through registers
+// (a chunk ahead) into LDS, where every lane then finds its own eight records.
 constexpr int kGsRegs = 8, kGsDepth = 1;
 constexpr int kGsPitch = kGsRegs + 1;                                 // a lane's slot in LDS, in 16-byte units (odd: conflict-free 128-bit reads)
-template <int PASS>
 __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, BurstScratch *__restrict__ scratch,
-                                                 rtfe_event *__restrict__ events, const CRec *__restrict__ crec, long long ccap,
-                                                 GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p) {
+                                                 const CRec *__restrict__ crec, long long ccap, GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, float *__restrict__ gfire) {
    __shared__ uint4 s_rec[64 * kGsPitch];
-   __shared__ uint4 s_note[PASS ? 64 * kGsPitch : 1];
    const int lane = threadIdx.x;
    const int nsegs = *nsegs_p;
+   const int S = cfgp->pk_seg_recs;
    const bool prof = cfgp->debug == 6 && threadIdx.x == 0;
    long long pt0 = 0, pt_setup = 0, pt_steps = 0, pn_chunks = 0, pn_items = 0;
    for (int sbase = blockIdx.x * 64; sbase < nsegs; sbase += gridDim.x * 64) {
       const int si = sbase + lane < nsegs ? sbase + lane : nsegs - 1;
       if (prof) { pt0 = clock64(); ++pn_items; }
       const GsSeg sg = segs[si];
-      const bool active = sbase + lane < nsegs && (PASS == 0 || sg.stands);
+      const bool active = sbase + lane < nsegs;
       const ChainSt &cs = cst[sg.chain];
       const GsConst K = cs.k;
       const int W = K.W, sure_i = K.sure_i, limit32 = K.limit32;
       const bool amp_on = K.amp_on != 0;
       const float h = K.h, alpha = K.alpha, beta = 1 - K.alpha, kr = K.kr, km = K.km, rg_min = K.rg_min, g_min = K.g_min;
       const uint4 *rec4 = reinterpret_cast<const uint4 *>(crec + (size_t)K.sl * ccap);
-      uint4 *ev4 = reinterpret_cast<uint4 *>(events + K.ev_index);
-      // where the walk begins and in which state
-      float g, vlt, vlb; int c, rise_hi, min_lo, min_hi;
-      long long i;
-      if (PASS == 0) {
-         g = cs.w.agc_gain; vlt = cs.w.v_lasttop; vlb = cs.w.v_lastbot;
-         rise_hi = cs.w.rise_hi; min_lo = cs.w.min_lo; min_hi = cs.w.min_hi;
-         c = sg.sidx == 0 ? (int)cs.c : 0;
-         i = sg.first;
-         if (sg.sidx > 0) { i = sg.first - cfgp->parm[(sg.chain % (cfgp->nparm * cfgp->ntrks)) / cfgp->ntrks].seg_warm; if (i < cs.i) i = cs.i; } }
-      else { g = sg.at_first.g; vlt = sg.at_first.vlt; vlb = sg.at_first.vlb; c = sg.at_first.c; rise_hi = sg.at_first.rise_hi; min_lo = sg.at_first.min_lo; min_hi = sg.at_first.min_hi; i = sg.first; }
-      unsigned int nev = PASS ? sg.evoff : 0u;
+      float *gout = gfire + (size_t)si * S;
+      // where the walk begins and in which state: the chain's as k_gain (mode 0) left it - segment 0's true state, the others' guess
+      float g = cs.w.agc_gain, vlt = cs.w.v_lasttop, vlb = cs.w.v_lastbot;
+      int rise_hi = cs.w.rise_hi, min_lo = cs.w.min_lo, min_hi = cs.w.min_hi;
+      int c = sg.sidx == 0 ? (int)cs.c : 0;
+      long long i = sg.first;
+      if (sg.sidx > 0) { i = sg.first - cfgp->parm[(sg.chain % (cfgp->nparm * cfgp->ntrks)) / cfgp->ntrks].seg_warm; if (i < cs.i) i = cs.i; }
+      unsigned int nev = 0;
       if (prof) pt_setup += clock64() - pt0;
-      // One phase of the walk: records [i, to) - `own`: the lane stops at a record that is not the step's business (else it passes over
-      // it: a warm-up only has to arrive in the right state, and the join says whether it did).  Wave-uniform loops.
+      // One phase of the walk: records [i, to) - `own`: the lane stops at a record that is not the step's business and leaves the gains
+      // behind (else it passes over such a record: a warm-up only has to arrive in the right state, and the join says whether it did).
+      // Wave-uniform loops.
       auto walk = [&](const long long to, const bool own, const bool act) -> long long {
          bool run = act && i < to;
          const int piece = lane & 7, sub = lane >> 3;
@@ -797,8 +794,9 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
                for (int k = 0; k < kGsRegs; ++k) s_rec[(8 * k + sub) * kGsPitch + piece] = q[dd][k];
                rtfe_wave_sync();
                fetch(q[dd], i + kGsDepth * kGsRegs);                            // this set again, kGsDepth chunks on
-               int adv = 0, nbuf = 0;
-               const unsigned int nev_in = nev;
+               int adv = 0;
+               const bool ran = run;
+               float gb[kGsRegs];
                #pragma unroll
                for (int j = 0; j < kGsRegs; ++j) {
                   const uint4 r = s_rec[lane * kGsPitch + j];
@@ -819,8 +817,8 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
                   g2 = lh > 0 ? g2 : g;
                   const float rg = fast_rcp(g2);
                   const bool ok = inr && !dead && !ampdead && fire && g2 > 0 && rg >= rg_min;
-                  if (PASS == 1) { if (ok) s_note[lane * kGsPitch + nbuf] = make_uint4((uint32_t)(i + j), __float_as_uint(g), __float_as_uint(h), 0xffffffffu); }
-                  nbuf += ok ? 1 : 0; nev += ok ? 1u : 0u;
+                  gb[j] = ok ? g : 0.0f;                                       // (the gain in force when it fired: what its event carries)
+                  nev += ok ? 1u : 0u;
                   c = ok ? pos + W + 1 : c;
                   vlt = ok && top ? v : vlt; vlb = ok && !top ? v : vlb;
                   g = ok ? g2 : g;
@@ -829,33 +827,24 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
                   const bool on = inr && (dead || ampdead || ok || !own);
                   if (run && !on) { run = false; adv = j; } }
                if (run) adv = kGsRegs;
-               if (PASS == 1) {
-                  // the chunk's notes leave: eight lanes per segment, a note each
-                  rtfe_wave_sync();
-                  const unsigned long long mine = reinterpret_cast<unsigned long long>(ev4 + nev_in);
-                  #pragma unroll
-                  for (int k = 0; k < kGsRegs; ++k) {
-                     const int src = 8 * k + sub;
-                     const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, src), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), src);
-                     const int n = __shfl(nbuf, src);
-                     if (piece < n) reinterpret_cast<uint4 *>(((unsigned long long)hi << 32) | lo)[piece] = s_note[src * kGsPitch + piece]; } }
+               if (own && ran) {                                               // (i - first is a multiple of eight here, and so is the segment's room)
+                  float4 *o4 = reinterpret_cast<float4 *>(gout + (i - sg.first));
+                  o4[0] = make_float4(gb[0], gb[1], gb[2], gb[3]); o4[1] = make_float4(gb[4], gb[5], gb[6], gb[7]); }
                rtfe_wave_sync();
                i += adv;
                if (i >= to) run = false;
                more = __ballot(run) != 0ull;
                if (prof) pt_steps += clock64() - tc0; } }
          return i; };
-      if (PASS == 0) {
-         walk(sg.first, false, active && sg.sidx > 0);                      // the warm-up: arrive at the first own record
-         i = sg.first; nev = 0;
-         GsState s0; s0.g = g; s0.vlt = vlt; s0.vlb = vlb; s0.c = c; s0.rise_hi = rise_hi; s0.min_lo = min_lo; s0.min_hi = min_hi;
-         const long long at = walk(sg.end, true, active);
-         if (active) {
-            GsSeg &o = segs[si];
-            o.at_first = s0;
-            o.at_end.g = g; o.at_end.vlt = vlt; o.at_end.vlb = vlb; o.at_end.c = c; o.at_end.rise_hi = rise_hi; o.at_end.min_lo = min_lo; o.at_end.min_hi = min_hi;
-            o.stop = at > sg.end ? sg.end : at; o.cnt = (int)nev; } }
-      else walk(sg.stop, true, active); }
+      walk(sg.first, false, active && sg.sidx > 0);                         // the warm-up: arrive at the first own record
+      i = sg.first; nev = 0;
+      GsState s0; s0.g = g; s0.vlt = vlt; s0.vlb = vlb; s0.c = c; s0.rise_hi = rise_hi; s0.min_lo = min_lo; s0.min_hi = min_hi;
+      const long long at = walk(sg.end, true, active);
+      if (active) {
+         GsSeg &o = segs[si];
+         o.at_first = s0;
+         o.at_end.g = g; o.at_end.vlt = vlt; o.at_end.vlb = vlb; o.at_end.c = c; o.at_end.rise_hi = rise_hi; o.at_end.min_lo = min_lo; o.at_end.min_hi = min_hi;
+         o.stop = at > sg.end ? sg.end : at; o.cnt = (int)nev; } }
    if (prof) { atomicAdd(&scratch->dbg2[0], (unsigned long long)pt_setup); atomicAdd(&scratch->dbg2[1], (unsigned long long)pt_steps);
                atomicAdd(&scratch->dbg2[3], (unsigned long long)pn_chunks); atomicAdd(&scratch->dbg2[4], (unsigned long long)pn_items); } }
 
@@ -885,6 +874,7 @@ __global__ void __launch_bounds__(64) k_gain_join(const DevCfg *__restrict__ cfg
       if (nev > nev0) atomicAdd(&scratch->dbg[0], (unsigned long long)(nev - nev0));
       cs.w.agc_gain = st.g; cs.w.v_lasttop = st.vlt; cs.w.v_lastbot = st.vlb; cs.w.v_top = st.vlt; cs.w.v_bot = st.vlb;
       cs.w.peakcount += (int)(nev - nev0); cs.w.nevents = nev; cs.i = resume; cs.c = st.c;
+      cs.seg_ev0 = nev0; cs.seg_ev1 = nev;                                // (events [nev0, nev): k_emit_seg's; the rest k_emit's)
       if (through) {
          cs.status = kChDone;
          counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = nev < cap ? nev : cap;
@@ -894,10 +884,69 @@ __global__ void __launch_bounds__(64) k_gain_join(const DevCfg *__restrict__ cfg
 // k_emit: the events the fast path noted -> the events the reference's callbacks see.  One workgroup per chain at a time,
 // a lane per event (16 bytes in, 16 bytes out, consecutive lanes consecutive events).
 // ------------------------------------------------------------------------------------------------
+// the event of a record that fired at gain `gain` (exact thresholds at that gain, the first lead row that passes, refine_peak)
+__device__ __forceinline__ rtfe_event emit_event(const DevCfg &cfg, const DevParm &P, Walker &wk, const CRec &r, const uint16_t *eend, float gain, int W, int d, long long reset,
+                                                 int trk, int pidx, float mv) {
+   const Run u = run_decode(r.w0, r.w1, (long long)r.pos);
+   wk.agc_gain = gain; wk.flags = 0;
+   update_thresholds(wk, P, cfg.lsb_per_volt);                      // the exact thresholds of src/decoder.c:785-786 at that gain
+   long long n = u.f + u.nlead;                                     // the first sure row, unless a lead row passes
+   for (int j = u.nlead - 1; j >= 0; --j) if (rise_pass(wk, u.top, u.val, (int)eend[-(j + 1)], mv)) n = u.f + j;
+   const int ld = (int)(u.pos - n) + W;
+   const int iprev = u.top ? u.val - u.dprev : u.val + u.dprev, inext = u.top ? u.val - u.dnext : u.val + u.dnext;
+   const int adjcode = refine_code(&cfg, u.val, iprev, inext, gain, u.top);
+   const float val = r.volt;
+   rtfe_event e;
+   e.sample = (uint32_t)(n + d - reset);
+   e.v_peak = (cfg.invert && val == 0.0f) ? -0.0f : val;
+   e.agc_gain = gain;
+   e.trk = (uint8_t)trk;
+   e.flags = (uint8_t)((u.top ? 0 : 1) | (adjcode << 1));
+   e.left_distance = (uint8_t)ld;
+   e.parmset = (uint8_t)pidx;
+   return e; }
+
+// the events of the steady stretches: a wave per standing segment, a lane per record - its gain says whether it fired, a prefix sum where
+// its event goes.  Records, entry references and gains are read in stream order.
+__global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, const BurstCtl *__restrict__ ctl, rtfe_event *__restrict__ events,
+                                                  const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap, const unsigned char *__restrict__ pool,
+                                                  const GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, const float *__restrict__ gfire) {
+   const DevCfg &cfg = *cfgp;
+   const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
+   const int lane = threadIdx.x & 63;
+   const int nsegs = *nsegs_p, S = cfg.pk_seg_recs;
+   const float mv = cfg.maxvolts;
+   for (int si = blockIdx.x * 4 + (threadIdx.x >> 6); si < nsegs; si += gridDim.x * 4) {
+      const GsSeg sg = segs[si];
+      if (!sg.stands) continue;
+      const ChainSt &cs = cst[sg.chain];
+      const int b = sg.chain / nwalk;
+      const int wi = sg.chain - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
+      const DevParm &P = cfg.parm[pidx];
+      const int W = P.W, d = cfg.skew[trk];
+      const long long reset = ctl[b].reset;
+      rtfe_event *ev = events + cs.k.ev_index;
+      const size_t sb = (size_t)cs.k.sl * ccap;
+      Walker wk = {};
+      wk.v_avg_height = cs.k.h;
+      const int n_own = (int)(sg.stop - sg.first);
+      unsigned int at = sg.evoff;
+      for (int k0 = 0; k0 < n_own; k0 += 64) {
+         const int k = k0 + lane;
+         const float gain = k < n_own ? gfire[(size_t)si * S + k] : 0.0f;
+         const int fired = gain != 0.0f ? 1 : 0;
+         const int incl = wave_incl_scan(fired, lane);
+         if (fired) {
+            const size_t ri = sb + (size_t)(sg.first + k);
+            const CRec r = crec[ri];
+            ev[at + (unsigned)(incl - 1)] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[ri], gain, W, d, reset, trk, pidx, mv); }
+         at += (unsigned)wave_last(incl); } } }
+
+// k_emit: the events k_gain's fast path only noted (the chains' heads and tails).  One workgroup per chain at a time, a lane per event.
 __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch,
                                               const BurstCtl *__restrict__ ctl, const uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                               const float *__restrict__ chain_h, const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap,
-                                              const unsigned char *__restrict__ pool) {
+                                              const unsigned char *__restrict__ pool, const ChainSt *__restrict__ cst) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
    const int nchains = scratch->nbursts * nwalk;
@@ -913,34 +962,19 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
       const unsigned int nev = counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk];
       rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
       const size_t sbase = (size_t)(P.screen * ntrks + head) * ccap;
+      const unsigned int skip0 = cst[ci].seg_ev0, skip1 = cst[ci].seg_ev1;      // (k_emit_seg's events)
       Walker wk = {};
       wk.v_avg_height = chain_h[(size_t)b * nwalk + wi];
-      for (unsigned int i = threadIdx.x; i < nev; i += blockDim.x) {
+      const unsigned int nmine = nev - (skip1 - skip0);
+      for (unsigned int t = threadIdx.x; t < nmine; t += blockDim.x) {
+         const unsigned int i = t < skip0 ? t : t + (skip1 - skip0);
          union { rtfe_event e; uint32_t w[4]; } in;
          in.e = ev[i];
          if (in.w[3] != 0xffffffffu) continue;                            // the general step wrote it out in full
          const float gain = __uint_as_float(in.w[1]);
          wk.v_avg_height = __uint_as_float(in.w[2]);
          const CRec r = crec[sbase + in.w[0]];
-         const uint16_t *eend = reinterpret_cast<const uint16_t *>(pool) + eref[sbase + in.w[0]];
-         const Run u = run_decode(r.w0, r.w1, (long long)r.pos);
-         wk.agc_gain = gain; wk.flags = 0;
-         update_thresholds(wk, P, cfg.lsb_per_volt);                      // the exact thresholds of src/decoder.c:785-786 at that gain
-         long long n = u.f + u.nlead;                                     // the first sure row, unless a lead row passes
-         for (int j = u.nlead - 1; j >= 0; --j) if (rise_pass(wk, u.top, u.val, (int)eend[-(j + 1)], mv)) n = u.f + j;
-         const int ld = (int)(u.pos - n) + W;
-         const int iprev = u.top ? u.val - u.dprev : u.val + u.dprev, inext = u.top ? u.val - u.dnext : u.val + u.dnext;
-         const int adjcode = refine_code(&cfg, u.val, iprev, inext, gain, u.top);
-         const float val = r.volt;
-         rtfe_event e;
-         e.sample = (uint32_t)(n + d - reset);
-         e.v_peak = (cfg.invert && val == 0.0f) ? -0.0f : val;
-         e.agc_gain = gain;
-         e.trk = (uint8_t)trk;
-         e.flags = (uint8_t)((u.top ? 0 : 1) | (adjcode << 1));
-         e.left_distance = (uint8_t)ld;
-         e.parmset = (uint8_t)pidx;
-         ev[i] = e; } } }
+         ev[i] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[sbase + in.w[0]], gain, W, d, reset, trk, pidx, mv); } } }
 
 // ------------------------------------------------------------------------------------------------
 // k_publish: burst table entries of the bursts the chains finished; stop rows for the ones the sample path redoes

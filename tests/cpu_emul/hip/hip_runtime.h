@@ -32,6 +32,8 @@ struct uint4 { unsigned int x, y, z, w; };
 inline int4 make_int4(int a, int b, int c, int d) { int4 r = {a, b, c, d}; return r; }
 inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 r = {a, b, c, d}; return r; }
 inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; return r; }
+struct float4 { float x, y, z, w; };
+inline float4 make_float4(float a, float b, float c, float d) { float4 r = {a, b, c, d}; return r; }
 extern thread_local dim3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
 extern unsigned char g_dyn_smem[160 * 1024] __attribute__((aligned(64)));

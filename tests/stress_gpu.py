@@ -131,7 +131,7 @@ for i in range(ntapes):
     if warm: os.environ["RTFE_SIFT_GENERIC"] = "1"
     else: os.environ.pop("RTFE_SIFT_GENERIC", None)
     # ... and the segments of the chains' steady stretches: short ones, warm-ups too short to join
-    os.environ["RTFE_SEG_RECS"] = str(rng.choice([256, 256, 32, 16, 0]))
+    os.environ["RTFE_SEG_RECS"] = str(rng.choice([128, 128, 32, 16, 1024]))
     if rng.random() < 0.3: os.environ["RTFE_SEG_WARM"] = str(rng.choice([0, 2, 8]))
     else: os.environ.pop("RTFE_SEG_WARM", None)
     if os.environ.get("STRESS_ONLY") and int(os.environ["STRESS_ONLY"]) != i: continue
