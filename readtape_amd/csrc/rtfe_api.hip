@@ -78,7 +78,7 @@ extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
 // The timed spans of one rtfe_scan (rtfe_kernel_ms), in launch order.  The peak path (NRZI peak detection) runs
-//   k_sift | k_prep [k_qpack, k_sift_hard, k_pscan1/2, k_prep] | k_bursts | k_gain [k_zones, the chains' heads] | k_gain_s [k_segplan, k_segfill, k_gain_seg, k_gain_join] |
+//   k_sift | k_prep [k_qpack, k_sift_hard, k_pscan1/2, k_prep] | k_bursts | k_gain [k_zones, the chains' heads] | k_gain_s [k_gain_seg, k_gain_join] |
 //   k_gain_tail | k_emit [k_emit_seg, k_emit, k_publish] | k_decode [the bursts the chains gave up, on the samples]
 // the sample path (PE, GCR, differentiated peaks, density detection, parameter-set sweeps with too many widths) k_quiet | k_bursts | k_decode,
 // -zeros k_quiet | k_bursts | k_zeros.  A span a scan does not run reads 0.
@@ -251,8 +251,8 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       if (const char *e = getenv("RTFE_PEAK_PATH")) d.peak_path = !d.find_zeros && !d.differentiate && d.mode != RTFE_WW && atoi(e) != 0;
       d.pk_fast = 1;
       if (const char *e = getenv("RTFE_GAIN_FAST")) d.pk_fast = atoi(e) != 0;
-      // the chains' steady stretches in segments (k_gain_seg): 128 records each (measured on C2: 64 .. 256 -> 0.65 0.57 0.53 0.55 0.59 ms); the warm-up from the alpha filter's memory
-      d.pk_seg_recs = 128;
+      // the chains' steady stretches in segments (k_gain_seg): 256 records each (measured on C2: 64 / 128 / 256 -> 2.61 / 2.43 / 2.39 ms per scan); the warm-up from the alpha filter's memory
+      d.pk_seg_recs = 256;
       if (const char *e = getenv("RTFE_SEG_RECS")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= 4096) d.pk_seg_recs = v; }
       for (int p = 0; p < c->nparmsets; ++p) {
          const float a = c->parmset[p].agc_alpha;
@@ -423,6 +423,7 @@ static size_t pk_cst_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.
 // ... | the segments of the chains' steady stretches (k_segplan -> k_gain_seg -> k_gain_join)
 static long long pk_seg_cap(const rtfe_handle *h, int64_t nrows) {
    if (!h->dev.peak_path) return 0;
+   if (const char *e = getenv("RTFE_SEG_CAP")) { const long long v = atoll(e); if (v >= 1) return v; }      // (tests: a table that runs full)
    const long long S = h->dev.pk_seg_recs;
    const long long per_stream = pk_ccap(h, nrows) / S + 1;
    return per_stream * h->dev.nscreens * h->dev.ntrks * (h->dev.nparm < 2 ? 1 : 2) + rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks + 64; }
@@ -555,22 +556,20 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          if (mode == 1) t0(kTGainTail);
          hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                             scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
-                            (const unsigned char *)pkpool, ptiles);
+                            (const unsigned char *)pkpool, ptiles, reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows)), pk_seg_cap(h, nrows));
          if (mode == 0) {
             t1(kTGain); t0(kTGainS);
             // the steady stretches: in segments, every one on its own, joined where the states agree bit for bit (rtfe_gain.hip)
             GsSeg *segp = reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows));
-            hipLaunchKernelGGL(k_segplan, dim3(1), dim3(1024), 0, st, (const DevCfg *)h->d_dev, cstp, (const BurstScratch *)scratch, (const BurstCtl *)ctlp, segp, pk_seg_cap(h, nrows), &scratch->nsegs);
-            hipLaunchKernelGGL(k_segfill, dim3(h->num_cus * 2), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstScratch *)scratch, segp);
             float *gfirep = reinterpret_cast<float *>(wsb + ws_pkgfire_off(h, nrows));
-            hipLaunchKernelGGL(k_gain_seg, dim3(h->num_cus * 16), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, scratch, (const CRec *)crecp, ccap, segp, (const int *)&scratch->nsegs, gfirep);
+            hipLaunchKernelGGL(k_gain_seg, dim3(h->num_cus * 16), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, scratch, (const CRec *)crecp, ccap, segp, (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), gfirep);
             hipLaunchKernelGGL(k_gain_join, dim3(h->num_cus * 2), dim3(64), 0, st, (const DevCfg *)h->d_dev, cstp, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp, d_counts, chainh, segp);
             t1(kTGainS); } }
       t1(kTGainTail);
       if (stop_after < 4) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTEmit);
       hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, (const uint32_t *)erefp, ccap,
-                         (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, (const float *)(wsb + ws_pkgfire_off(h, nrows)));
+                         (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks));
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
                          (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint32_t *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp);
       hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);

@@ -330,6 +330,20 @@ __device__ __forceinline__ rtfe_event note_event(long long i, float g, float h) 
    u.w[0] = (uint32_t)i; u.w[1] = __float_as_uint(g); u.w[2] = __float_as_uint(h); u.w[3] = 0xffffffffu;
    return u.e; }
 
+constexpr int kGsChunk = 16;
+struct GsState { float g, vlt, vlb; int c, rise_hi, min_lo, min_hi; };
+struct GsSeg {
+   int chain, sidx;                  // k_segplan
+   long long first, end;             // its own records [first, end) of the chain's stream
+   GsState at_first, at_end;         // k_gain_seg<0>: the state in front of record `first`; behind the last record it got through
+   long long stop;                   // the record it stopped at (the general step's business), or `end`
+   int cnt;                          // events of its own records
+   unsigned int evoff;               // k_gain_join: where its first note goes in the chain's event list
+   int stands, pad; };
+__device__ __forceinline__ bool gs_same(const GsState &a, const GsState &b) {
+   return __float_as_uint(a.g) == __float_as_uint(b.g) && __float_as_uint(a.vlt) == __float_as_uint(b.vlt) && __float_as_uint(a.vlb) == __float_as_uint(b.vlb)
+          && a.c == b.c && a.rise_hi == b.rise_hi && a.min_lo == b.min_lo && a.min_hi == b.min_hi; }
+
 // A chain between the kernels that walk it: k_gain (mode 0: from the burst's restart row until the baseline is fixed) -> k_gain_s (the
 // steady stretch: nothing but the common record) -> k_gain (mode 1: whatever k_gain_s stopped at, to the chain's end).
 enum { kChNone = 0, kChSteady = 1, kChGeneral = 2, kChDone = 3 };
@@ -343,7 +357,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
                                              const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
-                                             long long ccap, const unsigned char *__restrict__ pool, long long ntiles) {
+                                             long long ccap, const unsigned char *__restrict__ pool, long long ntiles, GsSeg *__restrict__ segs, long long seg_cap) {
    __shared__ float s_heights[64 * 10];
    __shared__ uint4 s_notes[kGainChunk][64];                           // the events the fast path notes, until the chunk's end
    __shared__ uint4 s_rec[kGainChunk + 1][64];                         // the lanes' records of the current chunk
@@ -630,6 +644,16 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          cs.w = w; cs.i = i; cs.c = c; cs.iend = src.iend; cs.seg0 = 0; cs.nseg = 0; cs.status = kChSteady; cs.seg_ev0 = w.nevents; cs.seg_ev1 = w.nevents;
          cs.k.ev_index = (unsigned long long)(ev - events); cs.k.h = w.v_avg_height; cs.k.alpha = alpha; cs.k.kr = kr; cs.k.km = km; cs.k.rg_min = rg_min; cs.k.g_min = g_min;
          cs.k.W = W; cs.k.sure_i = S.sure_i; cs.k.limit32 = limit32; cs.k.amp_on = amp_on ? 1 : 0; cs.k.sl = sl; cs.k.pad = 0;
+         // the steady stretch's segments: their places in the table (any order: one atomic per chain), their entries
+         {  const long long len = src.iend > i ? src.iend - i : 0;
+            const int SR = cfg.pk_seg_recs;
+            int nseg = len <= 0 ? 0 : (int)((len + SR - 1) / SR);
+            int seg0 = nseg > 0 ? atomicAdd(&scratch->nsegs, nseg) : 0;
+            if ((long long)seg0 + nseg > seg_cap) nseg = 0;                 // (no room in the table: the chain goes to k_gain, mode 1, as a whole; the count stays an upper bound)
+            cs.seg0 = seg0; cs.nseg = nseg;
+            for (int sg = 0; sg < nseg; ++sg) {
+               GsSeg &o = segs[seg0 + sg];
+               o.chain = ci; o.sidx = sg; o.first = i + (long long)sg * SR; o.end = sg + 1 == nseg ? src.iend : i + (long long)(sg + 1) * SR; o.stands = 0; } }
          for (int k = 0; k < 10; ++k) cs.heights[k] = heights[k];
          if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
          if (w.nevents > n_slow) atomicAdd(&scratch->dbg[0], (unsigned long long)(w.nevents - n_slow));      // (statistics: the head's events on the fast path)
@@ -655,7 +679,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
 //
 // A chain is sequential, a 4 KB block's is 4 100 records long, and 18 k chains are 290 waves on 1 024 SIMDs - so the stretch is cut
 // into SEGMENTS of pk_seg_recs records, a lane each:
-//   k_segplan  the chains' segments (a prefix sum over the chains);
+//   (k_gain, mode 0, gives every chain it hands over its place in the segment table - one atomic per chain - and writes the entries)
 //   k_gain_seg<0>  every segment on its own: segment 0 from the chain's true state, the others from a GUESS (the chain's gain and
 //              peaks at the hand-over, no countdown) a warm-up of pk_seg_warm records early - the countdown re-joins the true sequence
 //              at the first fired record, the peak memory after a top and a bottom, the alpha filter forgets its start value
@@ -667,64 +691,6 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
 // From the first segment that does not stand the chain goes on in k_gain (mode 1) from the last proven state.  Nothing rests on
 // the convergence argument; a warm-up too short only costs time (RTFE_SEG_RECS / RTFE_SEG_WARM: tests force that).
 // ------------------------------------------------------------------------------------------------
-constexpr int kGsChunk = 16;
-struct GsState { float g, vlt, vlb; int c, rise_hi, min_lo, min_hi; };
-struct GsSeg {
-   int chain, sidx;                  // k_segplan
-   long long first, end;             // its own records [first, end) of the chain's stream
-   GsState at_first, at_end;         // k_gain_seg<0>: the state in front of record `first`; behind the last record it got through
-   long long stop;                   // the record it stopped at (the general step's business), or `end`
-   int cnt;                          // events of its own records
-   unsigned int evoff;               // k_gain_join: where its first note goes in the chain's event list
-   int stands, pad; };
-__device__ __forceinline__ bool gs_same(const GsState &a, const GsState &b) {
-   return __float_as_uint(a.g) == __float_as_uint(b.g) && __float_as_uint(a.vlt) == __float_as_uint(b.vlt) && __float_as_uint(a.vlb) == __float_as_uint(b.vlb)
-          && a.c == b.c && a.rise_hi == b.rise_hi && a.min_lo == b.min_lo && a.min_hi == b.min_hi; }
-
-// the chains' segments: nseg per chain, their places in the segment table (a block-wide prefix sum per 1024 chains), the entries
-__global__ void __launch_bounds__(1024) k_segplan(const DevCfg *__restrict__ cfgp, ChainSt *__restrict__ cst, const BurstScratch *__restrict__ scratch, const BurstCtl *__restrict__ ctl,
-                                                  GsSeg *__restrict__ segs, long long seg_cap, int *__restrict__ nsegs_out) {
-   __shared__ int lds[32];
-   __shared__ int s_base;
-   const DevCfg &cfg = *cfgp;
-   const int nwalk = cfg.nparm * cfg.ntrks;
-   const int nchains = scratch->nbursts * nwalk;
-   const int S = cfg.pk_seg_recs;
-   if (threadIdx.x == 0) s_base = 0;
-   __syncthreads();
-   for (int c0 = 0; c0 < nchains; c0 += 1024) {
-      const int ci = c0 + (int)threadIdx.x;
-      int nseg = 0;
-      long long i = 0, iend = 0;
-      if (ci < nchains && ctl[ci / nwalk].status == kBurstReady && cst[ci].status == kChSteady) {
-         i = cst[ci].i; iend = cst[ci].iend;
-         const long long len = iend > i ? iend - i : 0;
-         nseg = len <= 0 ? 0 : (int)((len + S - 1) / S); }
-      int total;
-      const int off = block_excl_scan_1024(nseg, lds, &total);
-      const int base = s_base;
-      if (nseg > 0 && (long long)base + off + nseg > seg_cap) nseg = 0;      // (no room in the table: the chain goes to k_gain, mode 1, as a whole)
-      if (ci < nchains) { cst[ci].seg0 = base + off; cst[ci].nseg = nseg; }
-      __syncthreads();
-      if (threadIdx.x == 0) s_base = base + total;
-      __syncthreads(); }
-   if (threadIdx.x == 0) *nsegs_out = s_base; }
-
-// ... and the table's entries: a lane per chain writes its segments' places
-__global__ void __launch_bounds__(256) k_segfill(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, const BurstScratch *__restrict__ scratch, GsSeg *__restrict__ segs) {
-   const DevCfg &cfg = *cfgp;
-   const int nchains = scratch->nbursts * cfg.nparm * cfg.ntrks;
-   const int S = cfg.pk_seg_recs;
-   for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < nchains; ci += gridDim.x * blockDim.x) {
-      const int nseg = cst[ci].nseg;                                     // (0 for a chain that is not in its steady stretch: k_segplan)
-      if (cst[ci].status != kChSteady || nseg <= 0) continue;
-      const long long i = cst[ci].i, iend = cst[ci].iend;
-      GsSeg *o = segs + cst[ci].seg0;
-      for (int sg = 0; sg < nseg; ++sg) {
-         o[sg].chain = ci; o[sg].sidx = sg;
-         o[sg].first = i + (long long)sg * S; o[sg].end = sg + 1 == nseg ? iend : i + (long long)(sg + 1) * S;
-         o[sg].stands = 0; } } }
-
 // Every segment from its (true or guessed) start state.  What it leaves behind: the states at its first record and at its end, its event
 // count, and per own record the gain in force if the record fired, else 0 (gfire, pk_seg_recs floats per segment) - k_emit_seg makes the
 // events of the segments that stand from those.
@@ -735,19 +701,23 @@ __global__ void __launch_bounds__(256) k_segfill(const DevCfg *__restrict__ cfgp
 constexpr int kGsRegs = 8, kGsDepth = 1;
 constexpr int kGsPitch = kGsRegs + 1;                                 // a lane's slot in LDS, in 16-byte units (odd: conflict-free 128-bit reads)
 __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, BurstScratch *__restrict__ scratch,
-                                                 const CRec *__restrict__ crec, long long ccap, GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, float *__restrict__ gfire) {
+                                                 const CRec *__restrict__ crec, long long ccap, GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, long long seg_cap, float *__restrict__ gfire) {
    __shared__ uint4 s_rec[64 * kGsPitch];
    const int lane = threadIdx.x;
-   const int nsegs = *nsegs_p;
+   const int nsegs = (int)min((long long)*nsegs_p, seg_cap);      // (the count includes chains that found the table full: their entries were never written)
+   const int nchains = scratch->nbursts * cfgp->nparm * cfgp->ntrks;
    const int S = cfgp->pk_seg_recs;
    const bool prof = cfgp->debug == 6 && threadIdx.x == 0;
    long long pt0 = 0, pt_setup = 0, pt_steps = 0, pn_chunks = 0, pn_items = 0;
    for (int sbase = blockIdx.x * 64; sbase < nsegs; sbase += gridDim.x * 64) {
       const int si = sbase + lane < nsegs ? sbase + lane : nsegs - 1;
       if (prof) { pt0 = clock64(); ++pn_items; }
-      const GsSeg sg = segs[si];
-      const bool active = sbase + lane < nsegs;
+      GsSeg sg = segs[si];
+      bool active = sbase + lane < nsegs && (unsigned)sg.chain < (unsigned)nchains;
+      if (!active) sg.chain = 0;
       const ChainSt &cs = cst[sg.chain];
+      active = active && cs.status == kChSteady && si >= cs.seg0 && si < cs.seg0 + cs.nseg && sg.sidx == si - cs.seg0;      // (an entry its chain wrote)
+      if (!active) { sg.sidx = 0; sg.first = 0; sg.end = 0; }
       const GsConst K = cs.k;
       const int W = K.W, sure_i = K.sure_i, limit32 = K.limit32;
       const bool amp_on = K.amp_on != 0;
@@ -910,16 +880,17 @@ __device__ __forceinline__ rtfe_event emit_event(const DevCfg &cfg, const DevPar
 // its event goes.  Records, entry references and gains are read in stream order.
 __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, const BurstCtl *__restrict__ ctl, rtfe_event *__restrict__ events,
                                                   const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap, const unsigned char *__restrict__ pool,
-                                                  const GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, const float *__restrict__ gfire) {
+                                                  const GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, long long seg_cap, const float *__restrict__ gfire, int nchains_max) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
    const int lane = threadIdx.x & 63;
-   const int nsegs = *nsegs_p, S = cfg.pk_seg_recs;
+   const int nsegs = (int)min((long long)*nsegs_p, seg_cap), S = cfg.pk_seg_recs;
    const float mv = cfg.maxvolts;
    for (int si = blockIdx.x * 4 + (threadIdx.x >> 6); si < nsegs; si += gridDim.x * 4) {
       const GsSeg sg = segs[si];
-      if (!sg.stands) continue;
+      if ((unsigned)sg.chain >= (unsigned)nchains_max || sg.stands != 1) continue;
       const ChainSt &cs = cst[sg.chain];
+      if (si < cs.seg0 || si >= cs.seg0 + cs.nseg) continue;           // (not an entry its chain wrote: a stale one behind a full table)
       const int b = sg.chain / nwalk;
       const int wi = sg.chain - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
       const DevParm &P = cfg.parm[pidx];

@@ -111,11 +111,12 @@ def test_emulated_clear_flags_equal_a_pass_over_the_streams(name, peak, monkeypa
     assert "prep_check" not in err, err[:2000]
 
 
-@pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}, {"RTFE_SEG_RECS": "32"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_WARM": "3"}, {"RTFE_SEG_RECS": "1024"}])
+@pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}, {"RTFE_SEG_RECS": "32"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_WARM": "3"}, {"RTFE_SEG_RECS": "1024"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_CAP": "70"}])
 def test_emulated_long_blocks(knobs, tmp_path, monkeypatch):
     """Blocks of 500-640 bytes: chains that cross many tiles (k_gain's heads, the steady stretches in segments, the tails).
     RTFE_SEG_RECS=32: ~20 segments per chain; with a warm-up of 3 records the joins fail and k_gain (mode 1) finishes the chains from
-    the last proven state; 0: unsegmented.  The events are the oracle's whatever the joins do."""
+    the last proven state; RTFE_SEG_CAP: the segment table runs full and the chains that find no room are walked as a whole.  The events are
+    the oracle's whatever the joins do."""
     from readtape_amd import synth
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
