@@ -276,7 +276,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
          const bool rise_low = (double)d.screen[sidx].rise_i / lsb_per_volt < 0.03, amp_low = d.screen[sidx].minpk_i < 0 || (double)d.screen[sidx].minpk_i / lsb_per_volt < 0.03;
          if (rise_low && amp_low) noisy_screen = true; }
       if (noisy_screen) slot *= 3;
-      d.pk_wave_cap = noisy_screen ? 1792 : 384;                          // (a wave's two heads have 2 x 896 samples)
+      d.pk_wave_cap = noisy_screen ? 1792 : (getenv("RTFE_PK_WAVECAP") ? atoi(getenv("RTFE_PK_WAVECAP")) : 384);                          // (a wave's two heads have 2 x 896 samples)
       if (const char *e = getenv("RTFE_PK_SLOT")) { const int v = atoi(e); if (v >= 32 && v <= 65536) slot = v; }
       d.pk_slot = (slot + 15) & ~15;
       d.pk_lds = (int)sf_lds_layout(c->ntrks, d.pk_hl, d.pk_hr, d.pk_wave_cap, d.pk_slot).total + 64;

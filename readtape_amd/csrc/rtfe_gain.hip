@@ -22,6 +22,7 @@ namespace rtfe {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_zones(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
                                               const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl) {
+   __shared__ int16_t s_z[(kMarginRows + 2 * 50 + 2) * RTFE_MAXTRKS];
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks;
    const int nb = scratch->nbursts_total;
@@ -34,6 +35,13 @@ __global__ void __launch_bounds__(64) k_zones(const DevCfg *__restrict__ cfgp, c
       else if (B.zone_end - B.zone_first < kMarginRows + 64) { reset = B.zone_end - kMarginRows; bflags |= RTFE_F_UNSAFE; status = kBurstNeedsFull; }
       else {
          const long long z0 = B.zone_end - kMarginRows;
+         // the rows the walk below can read - the zone's last kMarginRows and up to 50 + 50 (window, skew) in front - through LDS: the
+         // walk is a chain of dependent reads, and there is nothing else in the wave to hide HBM's latency behind
+         const long long r0 = z0 - 2 * 50 - 2 > 0 ? z0 - 2 * 50 - 2 : 0;
+         const int nel = (int)(B.zone_end - r0) * ntrks;
+         __syncthreads();
+         for (int e = threadIdx.x; e < nel; e += 64) s_z[e] = rows[r0 * ntrks + e];
+         __syncthreads();
          long long lo = 0x7fffffffffffffffll;
          for (int i = threadIdx.x; i < cfg.nscreens * ntrks; i += 64) {
             const int sc = i / ntrks, t = i - sc * ntrks;
@@ -45,9 +53,10 @@ __global__ void __launch_bounds__(64) k_zones(const DevCfg *__restrict__ cfgp, c
             for (long long n = B.zone_end - 1; n >= z0; --n) {
                const long long s = n - d - W;
                if (s < 0) break;
-               const int v = sgn * (int)rows[s * ntrks + col];
+               if (s < r0) break;                                                 // (cannot happen: W, skew <= 50)
+               const int v = sgn * (int)s_z[(s - r0) * ntrks + col];
                bool dom = true;
-               for (int k = 1; k <= W; ++k) if (sgn * (int)rows[(s + k) * ntrks + col] > v) { dom = false; break; }      // (incl. the entering sample: src/decoder.c:763-767)
+               for (int k = 1; k <= W; ++k) if (sgn * (int)s_z[(s + k - r0) * ntrks + col] > v) { dom = false; break; }      // (incl. the entering sample: src/decoder.c:763-767)
                if (dom) { a = n; break; } }
             long long hi = a < 0 ? -1 : a - W - max(t, d) - 2;
             if (hi < z0) hi = -1;
@@ -165,14 +174,18 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
          return pos0q + (long long)(q.x & 0x7ffu) + (long long)((q.x >> 12) & 63u); }
       return kOffList; };
    long long li = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+   // (tile, stream) of the list, stepped along with li: no division in the loop
+   const long long dq = stride / nlists;
+   const int dr = (int)(stride - dq * nlists);
+   long long tile = li / nlists;
+   int sl = (int)(li - tile * nlists);
    Pre nx = fetch(li);
-   for (; __ballot(li < nall) != 0ull; li += stride) {
+   for (; __ballot(li < nall) != 0ull; li += stride, tile += dq, sl += dr) {
+      if (sl >= nlists) { sl -= nlists; ++tile; }
       const Pre cu = nx;
       nx = fetch(li + stride);
       const PeakDir d = cu.d;
       const bool on = li < nall && d.nrec != 0;
-      const long long tile = li / nlists;
-      const int sl = (int)(li - tile * nlists);
       const bool built = on && (long long)ctot[on ? sl : 0] <= ccap;      // a stream that outgrew its capacity is not built: its chains give up (k_gain)
       long long base = built ? (long long)sl * ccap + stream_pos(tstart, coff, nlists, tile, sl) : 0;
       if (built && d.nrec == 0xffffu) {                                  // a list that did not fit: one marker at the tile's first row
