@@ -519,7 +519,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                             qtile, dirm, pkpool, hardp, hard_cap, &scratch->hard_count, scratch->scr); }
       t1(kTSift); t0(kTPrep);
-      hipLaunchKernelGGL(k_qpack, dim3(64), dim3(256), 0, st, (const uint16_t *)qtile, ptiles, qwords, nwords);
+      hipLaunchKernelGGL(k_qpack, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, (const uint16_t *)qtile, ptiles, qwords, nwords);
       // the lists -> one stream of 16-byte records per (screen, head): the deferred candidates resolved (k_sift_hard), the streams' tile
       // offsets (k_pscan), the records copied over with their absolute rows, volts and entry references (k_prep)
       const int nlists = h->dev.nscreens * h->dev.ntrks;
@@ -572,7 +572,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                          (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks));
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
                          (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint32_t *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp);
-      hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
+      hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTEmit);
       if (stop_after < 5) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTDecode);

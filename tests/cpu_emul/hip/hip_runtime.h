@@ -43,7 +43,7 @@ typedef void *hipStream_t;
 enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipDeviceProp_t { int multiProcessorCount; };
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 2; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 1; return hipSuccess; }
 template <class T> inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)calloc(1, n); return *p ? hipSuccess : 1; }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
@@ -128,10 +128,15 @@ inline void hipemu_launch(F kernel, dim3 grid, dim3 block, size_t /*smem*/, hipS
    gridDim = grid; blockDim = block;
    hipemu::g_block_barrier.init(block.x);
    for (unsigned w = 0; w * 64 < block.x; ++w) hipemu::g_wave_barrier[w].init(std::min(64u, block.x - w * 64));
-   for (unsigned b = 0; b < grid.x; ++b) {
-      std::vector<std::thread> th;
-      th.reserve(block.x);
-      for (unsigned t = 0; t < block.x; ++t)
-         th.emplace_back([=]() { threadIdx = dim3(t); blockIdx = dim3(b); kernel(args...); });
-      for (auto &x : th) x.join(); } }
+   // one set of threads per launch; the blocks run one after the other on it (a block's __shared__ variables are the next block's too:
+   // a barrier between blocks)
+   std::vector<std::thread> th;
+   th.reserve(block.x);
+   for (unsigned t = 0; t < block.x; ++t)
+      th.emplace_back([=]() {
+         for (unsigned b = 0; b < grid.x; ++b) {
+            threadIdx = dim3(t); blockIdx = dim3(b);
+            kernel(args...);
+            if (b + 1 < grid.x) hipemu::g_block_barrier.wait(); } });
+   for (auto &x : th) x.join(); }
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu_launch(kernel, grid, block, smem, stream, __VA_ARGS__)
