@@ -112,13 +112,14 @@ def e2e_line(tape, copies, conf, dev):
         threads = max(1, min(int(os.environ.get("RT_E2E_REPLAY_THREADS", "16")), (os.cpu_count() or 1) - 1))
         rthreads = max(1, min(int(os.environ.get("RT_E2E_READ_THREADS", "4")), (os.cpu_count() or 2) // 2))
         wrows = int(os.environ.get("RT_E2E_WINDOW_ROWS", str(1 << 22)))
+        split = int(os.environ.get("RT_E2E_REPLAY_SPLIT", "4"))
         if True:                                        # one untimed pass over a short file first, as the device-resident line has its warm-up steps
             wpath = os.path.join(wd, "w.tbin")                # (first use of the replay pool, of the packing kernels, of the second scan context)
             tbin.write_tbin(wpath, hdr, tape.rows)
             ingest.decode_file_streaming(wpath, os.path.join(wd, "w.tap"), window_rows=wrows, halo_rows=1 << 18, opts=opts,
-                                         cfgkw=dict(find_zeros=True) if conf["find_zeros"] else None, device=str(dev), replay_threads=threads, read_threads=rthreads)
+                                         cfgkw=dict(find_zeros=True) if conf["find_zeros"] else None, device=str(dev), replay_threads=threads, read_threads=rthreads, replay_split=split)
         st = ingest.decode_file_streaming(path, os.path.join(wd, "e.tap"), window_rows=wrows, halo_rows=1 << 18, opts=opts,
-                                          cfgkw=dict(find_zeros=True) if conf["find_zeros"] else None, device=str(dev), replay_threads=threads, read_threads=rthreads)
+                                          cfgkw=dict(find_zeros=True) if conf["find_zeros"] else None, device=str(dev), replay_threads=threads, read_threads=rthreads, replay_split=split)
         same = None
         port = os.path.join(ROOT, "oracle", "_build", "oracle_readtape")
         if os.path.exists(port):
@@ -127,7 +128,7 @@ def e2e_line(tape, copies, conf, dev):
     return {"value": round(st["msamples_per_s"], 2), "unit": "Msamples/s", "rows": st["rows"], "windows": st["windows"], "seconds": round(st["seconds"], 3), "setup_seconds_not_included": round(st["setup_seconds"], 3),
             "warmup": "one untimed pass over the base tape as a file",
             "host_replay_seconds_summed": round(st["replay_seconds"], 3), "host_replay_events_per_s_per_thread": round(st["replay_events_per_s"] or 0),
-            "host_replay_threads": st["replay_threads"], "host_read_threads": rthreads, "window_rows": wrows, "host_cores": os.cpu_count(),
+            "host_replay_threads": st["replay_threads"], "host_read_threads": rthreads, "window_rows": wrows, "replay_split": split, "host_cores": os.cpu_count(),
             "file_read_seconds_overlapped": round(st["read_seconds"], 3), "scan_wait_seconds": round(st["scan_wait_seconds"], 3),
             "blocks": st["blocks"], "tapemarks": st["tapemarks"], "exact_rescans": st["exact_scans"], "tap_identical_to_cpu_port": same,
             "path": ".tbin in the page cache -> parallel positional reads into pinned buffers -> hipMemcpyAsync on a copy stream -> rtfe_scan (two contexts in flight) -> event arena packed on the device -> host replay of the windows (fragments) side by side -> .tap"}

@@ -31,13 +31,26 @@ def _payload_geometry(path):
     return hdr, off, int(nrows)
 
 
+class _All:
+    """Several futures waited for as one (a device window is free again when all replays of its sub-fragments are done)."""
+
+    def __init__(self, futs):
+        self.futs = futs
+
+    def result(self):
+        for f in self.futs:
+            f.result()
+
+
 def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17, opts: pipeline.DecodeOptions | None = None, cfgkw=None,
-                          device="cuda:0", replay_threads: int = 1, read_threads: int = 4):
+                          device="cuda:0", replay_threads: int = 1, read_threads: int = 4, replay_split: int = 1):
     """Decodes the .tbin file `path` to the SIMH file `tap_path` through device windows of `window_rows` rows (a multiple of 1024).
     Returns statistics incl. the end-to-end rate (disk -> .tap), the time spent in the host replay and the rows the halos re-read.
     replay_threads > 1: the windows' host replays run side by side (fragments are independent: each has its own decoder context
     and writes its own piece of the .tap; the pieces are concatenated in window order).  A window's device buffer is kept until
-    its replay is done (exact rescans read it), so replay_threads + 2 device windows are held."""
+    its replay is done (exact rescans read it), so replay_threads + 2 device windows are held.
+    replay_split > 1: a window's bursts are replayed as that many sub-fragments side by side (cut at burst boundaries, exactly as the
+    windows themselves are): the last window's replay is what the pipeline drains into, and a 4 M-row window takes one thread ~50 ms."""
     import torch
     assert window_rows % 1024 == 0
     t_enter = time.perf_counter()
@@ -129,10 +142,11 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     busy = [None] * depth
     pieces = []                                           # per window: bytes, or the future that returns (bytes, replay stats, seconds)
 
-    def replay(k, res, piece, lo, bound):
+    def replay(k, res, piece, lo, bound, start=None, tag=""):
         t0 = time.perf_counter()
-        frag = f"{tap_path}.frag{k}"
-        start = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
+        frag = f"{tap_path}.frag{k}{tag}"
+        if start is None:
+            start = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
         st = pipeline.decode_fragment(hdr, cfg, fe_exact, res, piece, lo, start, bound, frag, full, opts, exact_lock=exact_lock if pool else None)
         with open(frag, "rb") as g:
             data = g.read()
@@ -196,9 +210,14 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                 stats["halo_rows_read"] += end_k - hi
                 if res.nbursts:
                     if pool:
-                        fut = pool.submit(replay, k, res, piece, lo, bound)
-                        busy[k % depth] = fut
-                        pieces.append(fut)
+                        # sub-fragments: cut at the zone starts of evenly spaced bursts
+                        nsub = max(1, min(int(replay_split), res.nbursts // 8))
+                        cuts = [int(res.bursts[(res.nbursts * j) // nsub]["zone_first"]) for j in range(1, nsub)]
+                        first = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
+                        starts, stops = [first] + cuts, cuts + [bound]
+                        futs = [pool.submit(replay, k, res, piece, lo, stops[j], starts[j], f".{j}") for j in range(nsub) if stops[j] is None or stops[j] > starts[j]]
+                        busy[k % depth] = _All(futs)
+                        pieces.extend(futs)
                     else:
                         pieces.append(replay(k, res, piece, lo, bound))
             if reader is not None:

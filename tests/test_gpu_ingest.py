@@ -27,7 +27,8 @@ def test_streamed_windows_write_the_whole_tape_tap(kind, window, halo, threads, 
     want = _whole(hdr, tape.rows, str(tmp_path / "whole.tap"))
     path = str(tmp_path / "t.tbin")
     tbin.write_tbin(path, hdr, tape.rows)
-    st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=window, halo_rows=halo, replay_threads=threads)
+    st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=window, halo_rows=halo, replay_threads=threads,
+                                      replay_split=3 if threads > 1 else 1)      # (with threads: every window's bursts as three sub-fragments side by side)
     got = open(tmp_path / "s.tap", "rb").read()
     assert got == want
     assert st["rows"] == tape.rows.shape[0] and st["windows"] >= 3 and st["blocks"] > 0
