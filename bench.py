@@ -109,9 +109,9 @@ def e2e_line(tape, copies, conf, dev):
         tbin.write_tbin(path, hdr, rows)
         del rows
         opts = pipeline.DecodeOptions(multiple_tries=conf["nparmsets"] > 1, verbose=False)      # (-m: the reference's built-in sets)
-        threads = max(1, min(int(os.environ.get("RT_E2E_REPLAY_THREADS", "16")), (os.cpu_count() or 1) - 1))
+        threads = max(1, min(int(os.environ.get("RT_E2E_REPLAY_THREADS", "32")), (os.cpu_count() or 1) - 1))
         rthreads = max(1, min(int(os.environ.get("RT_E2E_READ_THREADS", "4")), (os.cpu_count() or 2) // 2))
-        wrows = int(os.environ.get("RT_E2E_WINDOW_ROWS", str(1 << 22)))
+        wrows = int(os.environ.get("RT_E2E_WINDOW_ROWS", str(1 << 23 if copies > 4 else 1 << 22)))      # (measured on the 9e7-row C2 sample: 2^22 / 2^23 / 2^24 rows -> 0.79 / 0.93 / 0.88 Gsamples/s)
         split = int(os.environ.get("RT_E2E_REPLAY_SPLIT", "4"))
         if True:                                        # one untimed pass over a short file first, as the device-resident line has its warm-up steps
             wpath = os.path.join(wd, "w.tbin")                # (first use of the replay pool, of the packing kernels, of the second scan context)
@@ -131,7 +131,7 @@ def e2e_line(tape, copies, conf, dev):
             "host_replay_threads": st["replay_threads"], "host_read_threads": rthreads, "window_rows": wrows, "replay_split": split, "host_cores": os.cpu_count(),
             "file_read_seconds_overlapped": round(st["read_seconds"], 3), "scan_wait_seconds": round(st["scan_wait_seconds"], 3),
             "blocks": st["blocks"], "tapemarks": st["tapemarks"], "exact_rescans": st["exact_scans"], "tap_identical_to_cpu_port": same,
-            "path": ".tbin in the page cache -> parallel positional reads into pinned buffers -> hipMemcpyAsync on a copy stream -> rtfe_scan (two contexts in flight) -> event arena packed on the device -> host replay of the windows (fragments) side by side -> .tap"}
+            "path": ".tbin in the page cache -> parallel positional reads into pinned buffers -> hipMemcpyAsync on a copy stream -> rtfe_scan (two contexts in flight) -> event arena packed on the device -> host replay of the windows (fragments), each as replay_split sub-fragments, side by side -> .tap"}
 
 
 class Workload:
