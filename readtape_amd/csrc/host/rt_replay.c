@@ -56,9 +56,13 @@ static int pred_gcr(const struct rt_dec *d, const struct rt_trk *t, double timen
 struct evsrc {
    const rtfe_event *list[RT_MAXTRKS];
    uint32_t n[RT_MAXTRKS], at[RT_MAXTRKS];
+   int64_t nr[RT_MAXTRKS];  /* absolute row of each track's next event, INT64_MAX when its list is used up (evsrc_sync keeps it) */
    int64_t reset;           /* absolute row of sample 0 */
    int64_t end;             /* rows >= end are not covered by this source */
 };
+
+static inline void evsrc_sync(struct evsrc *s, int t) {
+   s->nr[t] = s->at[t] < s->n[t] ? s->reset + (int64_t)s->list[t][s->at[t]].sample : INT64_MAX; }
 
 static void evsrc_from_burst(struct evsrc *s, const struct rt_replay *rp, int64_t b, int parmset) {
    const rtfe_burst *B = &rp->bursts[b];
@@ -68,17 +72,19 @@ static void evsrc_from_burst(struct evsrc *s, const struct rt_replay *rp, int64_
       s->n[t] = rp->counts[((size_t)b * rp->nparm + parmset) * rp->ntrks + t];
       s->at[t] = 0; }
    s->reset = B->reset_sample - rp->row_base;
-   s->end = B->end_sample - rp->row_base; }
+   s->end = B->end_sample - rp->row_base;
+   for (int t = 0; t < rp->ntrks; ++t) evsrc_sync(s, t); }
 
-static int64_t evsrc_next_row(const struct evsrc *s, int ntrks) {
+static inline int64_t evsrc_next_row(const struct evsrc *s, int ntrks) {
    int64_t best = INT64_MAX;
-   for (int t = 0; t < ntrks; ++t)
-      if (s->at[t] < s->n[t]) { int64_t r = s->reset + s->list[t][s->at[t]].sample; if (r < best) best = r; }
+   for (int t = 0; t < ntrks; ++t) if (s->nr[t] < best) best = s->nr[t];
    return best; }
 
 static void evsrc_skip_before(struct evsrc *s, int ntrks, int64_t row) {
    for (int t = 0; t < ntrks; ++t)
-      while (s->at[t] < s->n[t] && s->reset + s->list[t][s->at[t]].sample < row) ++s->at[t]; }
+      if (s->nr[t] < row) {
+         while (s->at[t] < s->n[t] && s->reset + s->list[t][s->at[t]].sample < row) ++s->at[t];
+         evsrc_sync(s, t); } }
 
 static int64_t find_burst(const struct rt_replay *rp, int64_t s0) {
    /* last burst whose zone starts at or before s0 */
@@ -204,6 +210,7 @@ restart:
          ++rp->device_failures; d->results[parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
       for (int t = 0; t < ntrks; ++t) { src.list[t] = exact_events + (uint64_t)t * cap; src.n[t] = cnt[t]; src.at[t] = 0; }
       src.reset = s0; src.end = ex_end;
+      for (int t = 0; t < ntrks; ++t) evsrc_sync(&src, t);
       using_exact = 1; ++rp->exact_scans; }
    else { evsrc_from_burst(&src, rp, b, parmset); evsrc_skip_before(&src, ntrks, s0); }
 
@@ -218,7 +225,8 @@ restart:
       else {
          if (ntrk_started < ntrks) { int64_t r = s0 + ntrk_started; if (r < next) next = r; }
          int64_t r = evsrc_next_row(&src, ntrks); if (r < next) next = r;
-         if (d->opt.mode == RT_NRZI && d->nrzi.datablock) {
+         if (d->opt.mode == RT_NRZI && d->nrzi.datablock && next > row && pred_nrzi(d, NULL, time_of_row(rp, next - 1))) {
+            /* (the mid-bit timer is monotone in time: it can only run out before `next` if it has at row next - 1) */
             r = first_row_where(rp, pred_nrzi, NULL, d->nrzi.t_lastclock + 2 * d->nrzi.clkavg.t_bitspaceavg, row, next);
             if (r < next) next = r; }
          if (d->opt.mode == RT_PE)
@@ -275,7 +283,7 @@ restart:
             tk->t_lastpeak = d->timenow;
             if (t >= ntrk_started) ntrk_started = t + 1;
             break; }
-         while (src.at[t] < src.n[t] && src.reset + src.list[t][src.at[t]].sample == row) {
+         while (src.nr[t] == row) {
             if (src.list[t][src.at[t]].flags & RTFE_EV_FATAL) {    /* "AGC gain bad in lookfor_peak" (src/decoder.c:782): the reference exits here */
                rp->reference_fatal = 1; d->fatal = 1; rp->fatal_row = row; rp->fatal_trk = t;
                d->results[parmset].blktype = RT_BS_ABORTED;
@@ -283,7 +291,7 @@ restart:
                rt_finish_attempt(d);
                return 0; }
             deliver(rp, &src, t, &src.list[t][src.at[t]], W);
-            ++src.at[t]; ++events_seen; }
+            ++src.at[t]; ++events_seen; evsrc_sync(&src, t); }
          if (d->opt.mode == RT_PE && rt_pe_idle_due(d, tk)) rt_pe_go_idle(d, tk);
          if (d->opt.mode == RT_GCR && rt_gcr_idle_due(d, tk)) if (rt_gcr_go_idle(d, tk)) stop_row = 1; }
       /* events of tracks the reference did not reach on this row cannot exist; drop anything stale */
@@ -449,6 +457,7 @@ static int ww_readblock(void *ctx, int retry) {
             ++rp->device_failures; d->results[d->parmset].blktype = RT_BS_ABORTED; rt_finish_attempt(d); return 0; }
          for (int t = 0; t < ntrks; ++t) { src.list[t] = rp->ww_events + (size_t)t * rp->ww_cap; src.n[t] = rp->ww_counts[t]; src.at[t] = 0; }
          src.reset = chunk_first; src.end = chunk_first + L;
+         for (int t = 0; t < ntrks; ++t) evsrc_sync(&src, t);
          ++rp->exact_scans;
          have_chunk = 1; }
       /* ---- the next row at which anything can happen ---- */
@@ -478,14 +487,14 @@ static int ww_readblock(void *ctx, int retry) {
             tk->v_lastpeak = 0;
             tk->t_lastpeak = d->timenow;
             break; }
-         while (src.at[t] < src.n[t] && src.reset + src.list[t][src.at[t]].sample == row) {
+         while (src.nr[t] == row) {
             if (src.list[t][src.at[t]].flags & RTFE_EV_FATAL) {
                rp->reference_fatal = 1; d->fatal = 1; rp->fatal_row = row; rp->fatal_trk = t;
                d->results[d->parmset].blktype = RT_BS_ABORTED;
                rt_finish_attempt(d);
                return 0; }
             deliver(rp, &src, t, &src.list[t][src.at[t]], W);
-            ++src.at[t]; } }
+            ++src.at[t]; evsrc_sync(&src, t); } }
       evsrc_skip_before(&src, ntrks, row + 1);
       if (rt_ww_end_due(d)) rt_ww_end_of_block(d);             /* src/decoder.c:892-894 */
       if (d->results[d->parmset].blktype != RT_BS_NONE) { rp->pos = row + 1; break; }
