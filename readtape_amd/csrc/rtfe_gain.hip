@@ -150,12 +150,13 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
    const long long nall = ntiles * nlists;
    const size_t ovf16 = (size_t)(ovf - pool) / 2;                         // the overflow slots, in the 2-byte units eref counts from the pool's start
    const long long stride = (long long)gridDim.x * 8;                     // lists per sweep: four waves, two lists each
-   struct Pre { PeakDir d, dn; uint2 r, r1, rn; };
-   auto fetch = [&](long long l) -> Pre {
-      Pre p; p.d.nrec = 0; p.d.nent = 0; p.dn = p.d; p.r = make_uint2(0, 0); p.r1 = p.r; p.rn = p.r;
+   struct Pre { PeakDir d, dn; uint2 r, r1, rn; uint32_t ts, co, ct; };
+   auto fetch = [&](long long l, long long tl, int s2) -> Pre {      // (everything the list's step reads, bar a deferred candidate's records: no load inside the step to wait for)
+      Pre p; p.d.nrec = 0; p.d.nent = 0; p.dn = p.d; p.r = make_uint2(0, 0); p.r1 = p.r; p.rn = p.r; p.ts = 0; p.co = 0; p.ct = 0;
       if (l < nall) {
          const unsigned char *slot = pool + (size_t)l * hcap;
          p.d = dir[l];
+         p.ts = tstart[(size_t)tl * nlists + s2]; p.co = coff[(size_t)(tl >> 10) * nlists + s2]; p.ct = ctot[s2];
          p.r = *reinterpret_cast<const uint2 *>(slot + min(8 * hl, hcap - 8));
          p.r1 = *reinterpret_cast<const uint2 *>(slot + min(8 * (hl + 1), hcap - 8));
          if (l + nlists < nall) { p.dn = dir[l + nlists]; p.rn = *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap); } }
@@ -179,15 +180,17 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
    const int dr = (int)(stride - dq * nlists);
    long long tile = li / nlists;
    int sl = (int)(li - tile * nlists);
-   Pre nx = fetch(li);
+   Pre nx = fetch(li, tile, sl);
    for (; __ballot(li < nall) != 0ull; li += stride, tile += dq, sl += dr) {
       if (sl >= nlists) { sl -= nlists; ++tile; }
       const Pre cu = nx;
-      nx = fetch(li + stride);
+      {  long long t2 = tile + dq; int s2 = sl + dr;
+         if (s2 >= nlists) { s2 -= nlists; ++t2; }
+         nx = fetch(li + stride, t2, s2); }
       const PeakDir d = cu.d;
       const bool on = li < nall && d.nrec != 0;
-      const bool built = on && (long long)ctot[on ? sl : 0] <= ccap;      // a stream that outgrew its capacity is not built: its chains give up (k_gain)
-      long long base = built ? (long long)sl * ccap + stream_pos(tstart, coff, nlists, tile, sl) : 0;
+      const bool built = on && (long long)cu.ct <= ccap;                  // a stream that outgrew its capacity is not built: its chains give up (k_gain)
+      long long base = built ? (long long)sl * ccap + (long long)cu.ts + (long long)cu.co : 0;
       if (built && d.nrec == 0xffffu) {                                  // a list that did not fit: one marker at the tile's first row
          if (hl == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; eref[base] = 0; } }
       const int nrec = (built && d.nrec != 0xffffu) ? (int)d.nrec : 0;
