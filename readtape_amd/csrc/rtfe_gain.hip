@@ -40,7 +40,12 @@ __global__ void __launch_bounds__(64) k_zones(const DevCfg *__restrict__ cfgp, c
          const long long r0 = z0 - 2 * 50 - 2 > 0 ? z0 - 2 * 50 - 2 : 0;
          const int nel = (int)(B.zone_end - r0) * ntrks;
          __syncthreads();
-         for (int e = threadIdx.x; e < nel; e += 64) s_z[e] = rows[r0 * ntrks + e];
+         for (int e0 = 0; e0 < nel; e0 += 64 * 16) {                       // (sixteen loads in flight per lane: the copy is a few round trips, not fifty)
+            int16_t t[16];
+            #pragma unroll
+            for (int k = 0; k < 16; ++k) { const int e = e0 + k * 64 + (int)threadIdx.x; t[k] = e < nel ? rows[r0 * ntrks + e] : (int16_t)0; }
+            #pragma unroll
+            for (int k = 0; k < 16; ++k) { const int e = e0 + k * 64 + (int)threadIdx.x; if (e < nel) s_z[e] = t[k]; } }
          __syncthreads();
          long long lo = 0x7fffffffffffffffll;
          for (int i = threadIdx.x; i < cfg.nscreens * ntrks; i += 64) {

@@ -96,6 +96,14 @@ struct PkTape {
       const long long n = t0 + r;
       return (n >= 0 && n < nrows) ? sg * (int)rows[n * ntrks + head] : 0; } };
 
+// ... or ONE head's samples around a candidate, copied to LDS by the candidate's wave (k_sift_hard), the tape behind them
+struct PkCol {
+   const int16_t *col; int r0, n, head;       // col[i] = the sample of `head` at row r0 + i (relative to the tile's first row), after -invert
+   PkTape tape;
+   __device__ __forceinline__ int at(int r, int hd) const {
+      const int i = r - r0;
+      return (hd == head && (unsigned)i < (unsigned)n) ? (int)col[i] : tape.at(r, hd); } };
+
 // LDS carve of k_sift.  ONE definition for the kernel and for the host's sizing.
 struct SfLds { unsigned xs, wl, stage, total; };
 __host__ __device__ inline SfLds sf_lds_layout(int ntrks, int hl, int hr, int wave_cap, int hcap) {
@@ -842,19 +850,32 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
 // HBM (a few hundred 2-byte reads each; 0.06 % of the candidates of a clean tape).  Out: the candidate's overflow slot - up to
 // four records and their margin entries in the layout of a list slot.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_sift_hard(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
-                                                  const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf, int *__restrict__ extra) {
+constexpr int kHardCol = 320;      // samples of a candidate's head its wave keeps in LDS: kPkBack + 3 W + 16 <= 230 for W <= 50, what is outside comes from HBM
+__global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
+                                                   const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf, int *__restrict__ extra) {
+   // A wave per candidate: its 64 lanes fetch the head's samples the walk can read - one round trip - and lane 0 walks (pk_bot is a chain
+   // of dependent reads: a few hundred, each an HBM round trip when a lane reads the tape itself: 74 us for C2's 10 k candidates).
+   __shared__ int16_t s_col[4][kHardCol];
    const DevCfg &cfg = *cfgp;
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
    int n = *hard_count;
    if (n > hard_cap) n = hard_cap;
-   for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
+   for (int i = blockIdx.x * 4 + wv; i < n; i += gridDim.x * 4) {
       const SfHard hd = hard[i];
-      PkCtxT<PkTape> cx;
-      cx.t.rows = rows; cx.t.t0 = (long long)hd.tile * kSfTile; cx.t.nrows = nrows; cx.t.ntrks = cfg.ntrks; cx.t.sg = cfg.invert ? -1 : 1;
       const DevScreen &S = cfg.screen[hd.screen];
+      PkCtxT<PkCol> cx;
+      cx.t.tape.rows = rows; cx.t.tape.t0 = (long long)hd.tile * kSfTile; cx.t.tape.nrows = nrows; cx.t.tape.ntrks = cfg.ntrks; cx.t.tape.sg = cfg.invert ? -1 : 1;
       cx.W = S.W; cx.lo_i = S.rise_i; cx.hi_i = S.sure_i;
-      const long long lastl = nrows - 1 - cx.t.t0;
+      const long long lastl = nrows - 1 - cx.t.tape.t0;
       cx.last = lastl > 0x3fffffff ? 0x3fffffff : (int)lastl;
+      const int r0 = (int)hd.pos - kPkBack - 2 * S.W - 8;
+      int ncol = kPkBack + 3 * S.W + 16;
+      if (ncol > kHardCol) ncol = kHardCol;
+      rtfe_wave_sync();
+      for (int k = lane; k < ncol; k += 64) s_col[wv][k] = (int16_t)cx.t.tape.at(r0 + k, (int)hd.head);
+      rtfe_wave_sync();
+      cx.t.col = s_col[wv]; cx.t.r0 = r0; cx.t.n = ncol; cx.t.head = (int)hd.head;
+      if (lane != 0) continue;
       PkSink sk; sk.n = 0;
       pk_bot(cx, sk, (int)hd.head, (int)hd.pos);
       unsigned char *slot = ovf + (size_t)i * kSfOvfBytes;
