@@ -530,7 +530,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       uint32_t *erefp = reinterpret_cast<uint32_t *>(wsb + ws_pkeref_off(h, nrows));
       int *extrap = reinterpret_cast<int *>(wsb + ws_pkextra_off(h, nrows));
       const long long ccap = pk_ccap(h, nrows);
-      hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus * 2), dim3(256), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
+      hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
                          (const int *)&scratch->hard_count, ovfp, extrap);
       hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (const int *)extrap, (int)ptiles, nlists, tstartp, ctotcp);
       hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
