@@ -40,6 +40,9 @@ struct rtfe_handle {
    hipEvent_t (*ev0)[12], (*ev1)[12];    // timing: a ring of kTimingRing sets of start / stop events, a set per scan (on the stream it ran on)
    int ev_next, ev_pending;             // the set the next scan records into; sets recorded since rtfe_kernel_ms last looked
    int zeros_kernel;                   // -zeros scans run k_zeros (RTFE_ZEROS_KERNEL=0: k_decode's zero-crossing mode, kept for tests)
+   hipStream_t side;                   // the peak path's quiet map -> bursts -> restart rows beside its lists -> streams (both only need k_sift): RTFE_OVERLAP=0 keeps them in line
+   hipEvent_t ev_fork, ev_join;
+   int overlap;
 };
 
 static thread_local char g_err[512] = "";
@@ -78,7 +81,7 @@ extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
 
 // The timed spans of one rtfe_scan (rtfe_kernel_ms), in launch order.  The peak path (NRZI peak detection) runs
-//   k_sift | k_prep [k_qpack, k_sift_hard, k_pscan1/2, k_prep] | k_bursts | k_gain [k_zones, the chains' heads] | k_gain_s [k_gain_seg, k_gain_join] |
+//   k_sift | k_prep [k_sift_hard, k_pscan1/2, k_prep] beside k_bursts [k_qpack, k_bursts, k_zones: on a stream of the handle's own] | k_gain [the chains' heads] | k_gain_s [k_gain_seg, k_gain_join] |
 //   k_gain_tail | k_emit [k_emit_seg, k_emit, k_publish] | k_decode [the bursts the chains gave up, on the samples]
 // the sample path (PE, GCR, differentiated peaks, density detection, parameter-set sweeps with too many widths) k_quiet | k_bursts | k_decode,
 // -zeros k_quiet | k_bursts | k_zeros.  A span a scan does not run reads 0.
@@ -311,6 +314,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (hipMemcpy(h->d_dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->d_dev); delete h; return fail(-22, "hipMemcpy failed"); }
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
    h->zeros_kernel = getenv("RTFE_ZEROS_KERNEL") ? atoi(getenv("RTFE_ZEROS_KERNEL")) != 0 : 1;
+   h->side = nullptr; h->overlap = getenv("RTFE_OVERLAP") ? atoi(getenv("RTFE_OVERLAP")) != 0 : 1;
    if (d.ntrks * (d.tile_rows / 64) > 128) h->zeros_kernel = 0;      // (its workgroup is two waves)
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zeros), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout_zeros(d).total + 64);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
@@ -357,6 +361,7 @@ extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
    if (h->timing) timing_free(h);
+   if (h->side) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->side); }
    (void)hipFree(h->d_dev);
    delete h; }
 
@@ -483,8 +488,10 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    bool ran[kNumKernels] = {false};
    const int evset = h->timing ? h->ev_next : 0;
    if (h->timing) { h->ev_next = (h->ev_next + 1) % kTimingRing; ++h->ev_pending; }
-   auto t0 = [&](int k) { ran[k] = true; if (h->timing) (void)hipEventRecord(h->ev0[evset][k], st); };
-   auto t1 = [&](int k) { if (h->timing) (void)hipEventRecord(h->ev1[evset][k], st); };
+   auto t0s = [&](int k, hipStream_t s2) { ran[k] = true; if (h->timing) (void)hipEventRecord(h->ev0[evset][k], s2); };
+   auto t1s = [&](int k, hipStream_t s2) { if (h->timing) (void)hipEventRecord(h->ev1[evset][k], s2); };
+   auto t0 = [&](int k) { t0s(k, st); };
+   auto t1 = [&](int k) { t1s(k, st); };
    auto skip_rest = [&]() { for (int k = 0; k < kNumKernels; ++k) if (!ran[k]) { t0(k); t1(k); } };
    if (h->dev.peak_path) {
       // ---- the peak path: k_sift (quiet map + records) -> k_bursts -> k_zones -> k_gain -> k_emit -> k_publish -> whatever the chains gave up ----
@@ -518,10 +525,30 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev));
          hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,
                             qtile, dirm, pkpool, hardp, hard_cap, &scratch->hard_count, scratch->scr); }
-      t1(kTSift); t0(kTPrep);
-      hipLaunchKernelGGL(k_qpack, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, (const uint16_t *)qtile, ptiles, qwords, nwords);
+      t1(kTSift);
+      // Two things only need k_sift's output and not each other: (a) quiet map -> burst table -> restart rows (k_qpack, k_bursts, k_zones:
+      // latency-bound, a workgroup or a wave per burst) and (b) the lists -> the streams (k_sift_hard, k_pscan, k_prep).  (a) runs on a
+      // stream of the handle's own beside (b) and joins in front of the chains (RTFE_OVERLAP=0: in line; its span then is work, else the
+      // time it shared the device).
+      hipStream_t sa = st;
+      if (h->overlap && stop_after >= 99) {
+         if (!h->side) {
+            if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; h->overlap = 0; }
+            else { (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming); } }
+         if (h->side) { sa = h->side; (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(sa, h->ev_fork, 0); } }
+      t0s(kTBursts, sa);
+      hipLaunchKernelGGL(k_qpack, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, sa, (const uint16_t *)qtile, ptiles, qwords, nwords);
+      hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, sa, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
+                         h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
+                         d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts, h->dev.debug == 5 ? 1 : 0);
+      if (stop_after >= 3)
+         hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, sa, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
+                            (const BurstScratch *)scratch, ctlp);
+      t1s(kTBursts, sa);
+      if (sa != st) (void)hipEventRecord(h->ev_join, sa);
       // the lists -> one stream of 16-byte records per (screen, head): the deferred candidates resolved (k_sift_hard), the streams' tile
       // offsets (k_pscan), the records copied over with their absolute rows, volts and entry references (k_prep)
+      t0(kTPrep);
       const int nlists = h->dev.nscreens * h->dev.ntrks;
       uint32_t *tstartp = reinterpret_cast<uint32_t *>(wsb + ws_pktstart_off(h, nrows));
       const int nsc = (int)((ptiles + 1023) / 1024);                    // chunks of 1024 tiles (k_pscan)
@@ -540,16 +567,9 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (getenv("RTFE_PREP_CHECK")) hipLaunchKernelGGL(k_prep_check, dim3(1), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, (const CRec *)crecp);
 #endif
       t1(kTPrep);
-      if (stop_after < 2) { skip_rest(); return launch_check("rtfe_scan"); }
-      t0(kTBursts);
-      hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
-                         h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
-                         d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts, h->dev.debug == 5 ? 1 : 0);
-      t1(kTBursts);
+      if (sa != st) (void)hipStreamWaitEvent(st, h->ev_join, 0);        // join: the chains need both
       if (stop_after < 3) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTGain);
-      hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
-                         (const BurstScratch *)scratch, ctlp);
       ChainSt *cstp = reinterpret_cast<ChainSt *>(wsb + ws_pkcst_off(h, nrows));
       // the chains: from the restart row until the baseline is fixed (k_gain, mode 0), the steady stretch (k_gain_s), whatever that stopped at (k_gain, mode 1)
       for (int mode = 0; mode < 2; ++mode) {
