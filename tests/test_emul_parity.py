@@ -148,8 +148,8 @@ def test_every_seam_position_inside_a_gap_keeps_every_burst(tmp_path):
     # every chunk position around the zone's two ends (where the ownership rule decides), every eighth one in between (the thread
     # emulation takes seconds per scan; the GPU test of the same name sweeps every position)
     ze, zf = int(zone["zone_end"]) // 64 * 64, int(zone["zone_first"]) // 64 * 64
-    cuts = sorted(set(range(lo // 64 * 64, hi, 2048)) | set(range(ze - 10 * 64, ze + 4 * 64, 128)) | set(range(zf - 128, zf + 192, 128)))
-    assert len(cuts) > 8
+    cuts = sorted(set(range(lo // 64 * 64, hi, 4096)) | set(range(ze - 10 * 64, ze + 4 * 64, 192)) | set(range(zf - 128, zf + 192, 192)))
+    assert len(cuts) > 5
     for cut in cuts:
         left = fe.scan(rows[: cut + 4096], row_base=0, first_is_tape_start=True, own_rows=cut).fetch()
         lb = shard.absolute_bursts(left, 0); le = shard.flatten_events(left, lb, 0)
