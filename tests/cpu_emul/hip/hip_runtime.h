@@ -1,18 +1,21 @@
 // TEST INFRASTRUCTURE — a minimal "HIP on pthreads" shim so that the UNMODIFIED kernel sources of
 // readtape_amd/csrc/*.hip can be compiled with g++ and exercised in the GPU-less build container
-// (tests/test_emul_*.py, marked not-gpu).  One workgroup runs at a time; its threads are real
-// std::threads that meet at a pthread barrier for __syncthreads(); wave intrinsics (__ballot,
-// __shfl_up) rendezvous per 64-thread wave.  It exists to debug kernel LOGIC on the CPU; it is never
+// (tests/test_emul_*.py, marked not-gpu).  One workgroup runs at a time; its threads are FIBERS
+// (ucontext) of one OS thread, run round robin: __syncthreads() and the wave intrinsics (__ballot,
+// __shfl_up, __shfl: a rendezvous per 64-thread wave) hand the processor to the next fiber until the
+// last one has arrived - a switch costs ~100 ns where a pthread barrier of 256 threads on 8 cores
+// costs ~100 us, and a run is deterministic.  It exists to debug kernel LOGIC on the CPU; it is never
 // loaded by the product (readtape_amd/frontend.py only opens librtfe.so and fails loudly without it).
 #pragma once
-#include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <ucontext.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
-#include <thread>
+#include <functional>
 #include <vector>
 
 #define __global__
@@ -34,7 +37,7 @@ inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 
 inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; return r; }
 struct float4 { float x, y, z, w; };
 inline float4 make_float4(float a, float b, float c, float d) { float4 r = {a, b, c, d}; return r; }
-extern thread_local dim3 threadIdx, blockIdx;
+extern dim3 threadIdx, blockIdx;      // (of the fiber that is running)
 extern dim3 blockDim, gridDim;
 extern unsigned char g_dyn_smem[160 * 1024] __attribute__((aligned(64)));
 
@@ -65,10 +68,14 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 
 namespace hipemu {
-struct Barrier {
-   pthread_barrier_t b; unsigned n = 0;
-   void init(unsigned k) { if (n) pthread_barrier_destroy(&b); pthread_barrier_init(&b, nullptr, k); n = k; }
-   void wait() { pthread_barrier_wait(&b); } };
+void fiber_yield();                    // give the processor to the next fiber of the block (emul_main.cpp)
+struct Barrier {                       // all n fibers of a block / a wave: the last to arrive opens it, the others yield until then
+   unsigned n = 0, arrived = 0, gen = 0;
+   void init(unsigned k) { n = k; arrived = 0; gen = 0; }
+   void wait() {
+      if (++arrived == n) { arrived = 0; ++gen; return; }
+      const unsigned g = gen;
+      while (gen == g) fiber_yield(); } };
 extern Barrier g_block_barrier;
 extern Barrier g_wave_barrier[16];
 extern unsigned long long g_wave_scratch[16][64];
@@ -123,20 +130,8 @@ inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v)
 using std::max;
 using std::min;
 
+namespace hipemu { void run_grid(dim3 grid, dim3 block, const std::function<void()> &body); }
 template <class F, class... A>
 inline void hipemu_launch(F kernel, dim3 grid, dim3 block, size_t /*smem*/, hipStream_t, A... args) {
-   gridDim = grid; blockDim = block;
-   hipemu::g_block_barrier.init(block.x);
-   for (unsigned w = 0; w * 64 < block.x; ++w) hipemu::g_wave_barrier[w].init(std::min(64u, block.x - w * 64));
-   // one set of threads per launch; the blocks run one after the other on it (a block's __shared__ variables are the next block's too:
-   // a barrier between blocks)
-   std::vector<std::thread> th;
-   th.reserve(block.x);
-   for (unsigned t = 0; t < block.x; ++t)
-      th.emplace_back([=]() {
-         for (unsigned b = 0; b < grid.x; ++b) {
-            threadIdx = dim3(t); blockIdx = dim3(b);
-            kernel(args...);
-            if (b + 1 < grid.x) hipemu::g_block_barrier.wait(); } });
-   for (auto &x : th) x.join(); }
+   hipemu::run_grid(grid, block, [=]() { kernel(args...); }); }
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu_launch(kernel, grid, block, smem, stream, __VA_ARGS__)

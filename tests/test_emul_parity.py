@@ -22,7 +22,8 @@ def test_emulated_kernels_match_oracle(name, tmp_path):
     assert stats["events"] > 0
 
 
-@pytest.mark.parametrize("name,parallel", [("nrzi9", "0"), ("nrzi9_skew", "0"), ("gcr", "0"), ("nrzi7_order", "0"), ("gcr", "1")])     # (NRZI with the fast path is test_emulated_kernels_match_oracle; pe and everything x both on the GPU: the thread emulation needs 30-50 s for those)
+@pytest.mark.parametrize("parallel", ["1", "0"])
+@pytest.mark.parametrize("name", PEAK_CASES)
 def test_emulated_peak_record_path_matches_oracle(name, parallel, tmp_path, monkeypatch):
     """The peak path (k_sift -> k_zones -> k_gain -> k_emit, rtfe_sift.hip / rtfe_gain.hip): same events as the oracle, with the
     chains' steady-state fast path (events noted by k_gain, finished by k_emit) and with every detection through the general step."""
@@ -37,7 +38,7 @@ def test_emulated_peak_record_path_matches_oracle(name, parallel, tmp_path, monk
     print(name, stats, st)
     assert not msgs, "\n".join(msgs[:12])
     assert stats["events"] > 0
-    assert st["parallel"] + st["sequential"] > 0, "the record chains did not run"
+    assert st["parallel"] + st["sequential"] > 0 or st["redone"] == st["bursts"], "the record chains did not run"
     if parallel == "0":
         assert st["parallel"] == 0
 
@@ -72,7 +73,7 @@ def test_emulated_paths_that_are_not_the_default(name, knobs, tmp_path, monkeypa
     assert stats["events"] > 0
 
 
-@pytest.mark.parametrize("name", ["gcr", "nrzi9_skew"])
+@pytest.mark.parametrize("name", PEAK_CASES)
 def test_emulated_peak_path_equals_the_sample_path(name, monkeypatch):
     """Both paths on one tape: the same burst table and, per (burst, parameter set, track), the same events byte for byte - also where no
     oracle attempt looks (behind the block ends; bursts the replay would rescan exactly).  gcr: a chain that reaches its steady state
@@ -86,7 +87,7 @@ def test_emulated_peak_path_equals_the_sample_path(name, monkeypatch):
         res.append((fe, fe.scan(g["rows"]).fetch()))
     (f0, r0), (f1, r1) = res
     st = f1.scan_stats(r1)
-    assert r0.nbursts == r1.nbursts and st["redone"] == 0 and st["parallel"] > 0, st
+    assert r0.nbursts == r1.nbursts and (st["parallel"] + st["sequential"] > 0 or st["redone"] == st["bursts"]), st
     for k in ("zone_first", "zone_end", "reset_sample", "safe_last", "end_sample", "flags"):
         assert (r0.bursts[k] == r1.bursts[k]).all(), k
     for b in range(r0.nbursts):
@@ -95,7 +96,7 @@ def test_emulated_peak_path_equals_the_sample_path(name, monkeypatch):
                 assert r0.track_events(b, p, t).tobytes() == r1.track_events(b, p, t).tobytes(), (b, p, t)
 
 
-@pytest.mark.parametrize("name,peak", [("nrzi9", None), ("nrzi9_m", None), ("gcr", "1"), ("nrzi9_skew", None)])
+@pytest.mark.parametrize("name,peak", [("nrzi9", None), ("nrzi9_m", None), ("gcr", "1"), ("nrzi9_skew", None), ("nrzi7", None), ("pe", "1"), ("gcr_m", "1"), ("nrzi9_invert", None)])
 def test_emulated_clear_flags_equal_a_pass_over_the_streams(name, peak, monkeypatch, capfd):
     """k_prep marks a record clear from its list neighbours (the next entry of its list, the first of the next tile's list, deferred
     candidates resolved on the way); k_prep_check (emulator only) redoes that as a pass over the finished streams, record by record
@@ -110,7 +111,8 @@ def test_emulated_clear_flags_equal_a_pass_over_the_streams(name, peak, monkeypa
     assert "prep_check" not in err, err[:2000]
 
 
-@pytest.mark.parametrize("knobs", [{}, {"RTFE_SEG_RECS": "32"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_WARM": "3"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_CAP": "70"}])      # (more of them on the GPU)
+@pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}, {"RTFE_SEG_RECS": "32"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_WARM": "3"}, {"RTFE_SEG_RECS": "1024"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_CAP": "70"},
+                                   {"RTFE_SIFT_GENERIC": "1"}, {"RTFE_PK_SLOT": "128"}])
 def test_emulated_long_blocks(knobs, tmp_path, monkeypatch):
     """Blocks of 500-640 bytes: chains that cross many tiles (k_gain's heads, the steady stretches in segments, the tails).
     RTFE_SEG_RECS=32: ~20 segments per chain; with a warm-up of 3 records the joins fail and k_gain (mode 1) finishes the chains from
@@ -148,8 +150,8 @@ def test_every_seam_position_inside_a_gap_keeps_every_burst(tmp_path):
     # every chunk position around the zone's two ends (where the ownership rule decides), every eighth one in between (the thread
     # emulation takes seconds per scan; the GPU test of the same name sweeps every position)
     ze, zf = int(zone["zone_end"]) // 64 * 64, int(zone["zone_first"]) // 64 * 64
-    cuts = sorted(set(range(lo // 64 * 64, hi, 4096)) | set(range(ze - 10 * 64, ze + 4 * 64, 192)) | set(range(zf - 128, zf + 192, 192)))
-    assert len(cuts) > 5
+    cuts = sorted(set(range(lo // 64 * 64, hi, 512)) | set(range(ze - 10 * 64, ze + 4 * 64, 64)) | set(range(zf - 128, zf + 192, 64)))
+    assert len(cuts) > 16
     for cut in cuts:
         left = fe.scan(rows[: cut + 4096], row_base=0, first_is_tape_start=True, own_rows=cut).fetch()
         lb = shard.absolute_bursts(left, 0); le = shard.flatten_events(left, lb, 0)
