@@ -759,6 +759,8 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
       auto walk = [&](const long long to, const bool own, const bool act) -> long long {
          bool run = act && i < to;
          const int piece = lane & 7, sub = lane >> 3;
+         float hq = h / (vlt - vlb);                                           // h / lastheight as of the last fired record (src/decoder.c:505-512)
+         bool lhpos = vlt - vlb > 0;
          // the pieces this lane fetches for the others: of lane 8k + sub's records [at, at + 8) the one numbered `piece`.  kGsDepth
          // chunks are in flight (measured: 3 instead of 1 change nothing - the walk is bound by the step's dependent instructions).
          uint4 q[kGsDepth][kGsRegs];
@@ -802,16 +804,21 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
                   const bool ampdead = !bad && r.z != 0xffff8000u && amp_on && a <= min_lo;
                   const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
                   const bool fire = (w0 & kCrClear) && c <= f && fl < limit32 && rise_hi <= sure_i && (!amp_on || a >= min_hi) && g >= g_min;
-                  const float lh = vlt - vlb, v = __uint_as_float(r.w);
-                  float g2 = alpha * (h / lh) + beta * g;
+                  // (h / lastheight for the NEXT fired record, should this one fire: its operands are this record's and the state's - the
+                  //  division runs beside the gain's chain instead of inside it)
+                  const float v = __uint_as_float(r.w);
+                  const float lh_f = top ? v - vlb : vlt - v;
+                  const float q_f = h / lh_f;
+                  float g2 = alpha * hq + beta * g;
                   g2 = g2 > 2.0f ? 2.0f : g2;
-                  g2 = lh > 0 ? g2 : g;
+                  g2 = lhpos ? g2 : g;
                   const float rg = fast_rcp(g2);
                   const bool ok = inr && !dead && !ampdead && fire && g2 > 0 && rg >= rg_min;
                   gb[j] = ok ? g : 0.0f;                                       // (the gain in force when it fired: what its event carries)
                   nev += ok ? 1u : 0u;
                   c = ok ? pos + W + 1 : c;
                   vlt = ok && top ? v : vlt; vlb = ok && !top ? v : vlb;
+                  hq = ok ? q_f : hq; lhpos = ok ? lh_f > 0 : lhpos;
                   g = ok ? g2 : g;
                   const int rr = (int)(kr * rg), mm = (int)(km * rg);
                   rise_hi = ok ? rr + 3 : rise_hi; min_lo = ok ? mm - 2 : min_lo; min_hi = ok ? mm + 3 : min_hi;
