@@ -59,18 +59,24 @@ template <int WM> static sf_kernel_t sf_kernel_t2(int threads, int nv) { return 
 static sf_kernel_t sf_kernel(int wmax, int threads, int nv) {
    return wmax <= 18 ? sf_kernel_t2<18>(threads, nv) : sf_kernel_t2<50>(threads, nv); }
 // one screen of a width and a track count the lean kernel is built for, a sure level that fits 16 bits: k_sift_s
-static sfs_kernel_t sfs_kernel(int w, int ntrks) {
-   if (ntrks == 9) switch (w) {
-      case 8:  return k_sift_s<8, 9, kSfWps>;
-      case 11: return k_sift_s<11, 9, kSfWps>;
-      case 13: return k_sift_s<13, 9, kSfWps>;
-      case 17: return k_sift_s<17, 9, kSfWps>;
-      default: break; }
-   if (ntrks == 7) switch (w) {
-      case 11: return k_sift_s<11, 7, kSfWps>;
-      case 13: return k_sift_s<13, 7, kSfWps>;
-      default: break; }
-   return nullptr; }
+template <int NT> static sfs_kernel_t sfs_kernel_w(int w) {
+   switch (w) {
+      case 6:  return k_sift_s<6, NT, kSfWps>;
+      case 7:  return k_sift_s<7, NT, kSfWps>;
+      case 8:  return k_sift_s<8, NT, kSfWps>;
+      case 9:  return k_sift_s<9, NT, kSfWps>;
+      case 10: return k_sift_s<10, NT, kSfWps>;
+      case 11: return k_sift_s<11, NT, kSfWps>;
+      case 12: return k_sift_s<12, NT, kSfWps>;
+      case 13: return k_sift_s<13, NT, kSfWps>;
+      case 14: return k_sift_s<14, NT, kSfWps>;
+      case 15: return k_sift_s<15, NT, kSfWps>;
+      case 16: return k_sift_s<16, NT, kSfWps>;
+      case 17: return k_sift_s<17, NT, kSfWps>;
+      default: return nullptr; } }
+// (every window width the packed derivation holds - 6 .. 17 samples - for nine and seven tracks: 800 / 556 BPI NRZI at 781 kHz are 13 / 19,
+//  at half that rate 6 / 9; wider windows and other track counts take the general kernel, ~10 x slower in the dense pass)
+static sfs_kernel_t sfs_kernel(int w, int ntrks) { return ntrks == 9 ? sfs_kernel_w<9>(w) : (ntrks == 7 ? sfs_kernel_w<7>(w) : nullptr); }
 static int sf_wmax(const DevCfg &d) { int w = 0; for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].W > w) w = d.screen[s].W; return w; }
 static int sf_threads(const DevCfg &d) { return 64 * ((d.ntrks + 1) / 2); }
 static int sf_nvec(const DevCfg &d) { return (d.pk_hl + kSfTile + d.pk_hr) * d.ntrks / 8; }

@@ -571,3 +571,23 @@ def test_packed_event_fetch_holds_the_same_lists(name, gpu, monkeypatch):
     for key, blob in plain.items():
         assert r.track_events(*key).tobytes() == blob, key
     assert sum(len(v) for v in plain.values()) > 0
+
+
+@pytest.mark.parametrize("tdelta_ns,ntrks", [(2600, 9), (2300, 9), (2000, 9), (1800, 7), (1600, 9), (1450, 7), (1400, 9), (1150, 9), (1100, 7), (1000, 9), (800, 9), (640, 9)])
+def test_sample_rates_and_the_lean_sift_kernels(tdelta_ns, ntrks, tmp_path, gpu):
+    """Other digitisers: 800 BPI NRZI sampled every 0.64 .. 2.6 us gives window widths of 6 .. 27 samples - every instantiation of k_sift_s
+    (6 .. 17, nine and seven tracks) and, above, the general kernel: the events are the oracle's and no burst needs the sample path."""
+    from readtape_amd import tbin
+    spec = synth.TapeSpec(mode=tbin.MODE_NRZI, ntrks=ntrks, bpi=800.0, ips=50.0, tdelta_ns=tdelta_ns, maxvolts=4.4, pulse_w=0.22, seed=tdelta_ns)
+    rng = np.random.default_rng(tdelta_ns)
+    items = [("block", pl) for pl in synth.random_payloads(rng, 8, 40, 1200, databits=ntrks - 1)]
+    tape = synth.make_tape(spec, items, gap_samples=int(3000 * 1280 / tdelta_ns))
+    hdr = tape.spec.header()
+    opts = ["-ntrks=7"] if ntrks == 7 else []
+    att = oracle_attempts(hdr, tape.rows, opts, str(tmp_path))
+    fe = frontend.FrontEnd(config_for(hdr, opts))
+    res = fe.scan(tape.rows).fetch()
+    st = fe.scan_stats(res)
+    msgs, stats = check_tape(fe, hdr, tape.rows, att)
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["events"] > 5000 and st["redone"] == 0 and st["parallel"] > 0, (stats, st)
