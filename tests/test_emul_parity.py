@@ -163,7 +163,7 @@ def test_every_seam_position_inside_a_gap_keeps_every_burst(tmp_path):
         assert got.shape == we.shape and (key(got) == key(we)).all(), cut
 
 
-@pytest.mark.parametrize("tdelta_ns,ntrks", [(2600, 9), (2300, 9), (2000, 9), (1800, 7), (1600, 9), (1450, 7), (1400, 9), (1150, 9), (1100, 7), (1000, 9), (800, 9)])
+@pytest.mark.parametrize("tdelta_ns,ntrks", [(2600, 9), (2300, 9), (2000, 9), (1800, 7), (1600, 9), (1500, 7), (1450, 7), (1200, 9), (1150, 9), (1060, 7), (1000, 9), (800, 9)])
 def test_emulated_sample_rates_and_the_lean_sift_kernels(tdelta_ns, ntrks, tmp_path):
     """Other digitisers: 800 BPI NRZI sampled every 0.8 .. 2.6 us gives window widths of 6 .. 21 samples - every instantiation of k_sift_s
     (6 .. 17, nine and seven tracks) and, at 21, the general kernel: the events are the oracle's."""

@@ -573,7 +573,7 @@ def test_packed_event_fetch_holds_the_same_lists(name, gpu, monkeypatch):
     assert sum(len(v) for v in plain.values()) > 0
 
 
-@pytest.mark.parametrize("tdelta_ns,ntrks", [(2600, 9), (2300, 9), (2000, 9), (1800, 7), (1600, 9), (1450, 7), (1400, 9), (1150, 9), (1100, 7), (1000, 9), (800, 9), (640, 9)])
+@pytest.mark.parametrize("tdelta_ns,ntrks", [(2600, 9), (2300, 9), (2000, 9), (1800, 7), (1600, 9), (1500, 7), (1450, 7), (1200, 9), (1150, 9), (1060, 7), (1000, 9), (800, 9), (640, 9)])
 def test_sample_rates_and_the_lean_sift_kernels(tdelta_ns, ntrks, tmp_path, gpu):
     """Other digitisers: 800 BPI NRZI sampled every 0.64 .. 2.6 us gives window widths of 6 .. 27 samples - every instantiation of k_sift_s
     (6 .. 17, nine and seven tracks) and, above, the general kernel: the events are the oracle's and no burst needs the sample path."""
