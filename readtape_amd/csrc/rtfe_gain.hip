@@ -518,13 +518,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          const bool fire = lean && plain && (unsigned)(nsure - 1) < 62u && c32 <= f && f + nlead < limit32 && fn > pos + W
                            && w.rise_hi <= S.sure_i && (!amp_on || a >= w.min_hi) && w.nevents < cap && g >= g_min;
          if (!fire) {
-#ifdef RTFE_CPU_EMUL
-            if (getenv("RTFE_GAIN_WHY")) fprintf(stderr, "why: pc %d pos %d f %d fn %d nlead %d nsure %d a %d min_hi %d c %d limit %d plain %d\n", w.peakcount, pos, f, fn, nlead, nsure, a, w.min_hi, c32, limit32, (int)plain);
-#endif
             return 1; }
-#ifdef RTFE_CPU_EMUL
-         if (getenv("RTFE_GAIN_TRACE") && b == atoi(getenv("RTFE_GAIN_TRACE")) && wi == (getenv("RTFE_GAIN_TRACE_WI") ? atoi(getenv("RTFE_GAIN_TRACE_WI")) : 0)) fprintf(stderr, "F ev %u f %d %s pos %d c %d g %.6f\n", w.nevents, f, top ? "top" : "bot", pos, c32, g);
-#endif
          const float v = __uint_as_float(cur4.w);
          s_notes[nbuf][lane] = make_uint4((uint32_t)idx, __float_as_uint(g), __float_as_uint(w.v_avg_height), 0xffffffffu);
          ++nbuf; ++w.nevents;
@@ -558,18 +552,10 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          for (RecIt j = alive; !(top_done && bot_done); it_next(j, src)) {
             if (j.end) { if (j.bad) bad_row0 = j.pos; break; }
             const Run u = run_decode(j.w0, j.w1, j.pos);
-#ifdef RTFE_CPU_EMUL
-            if (getenv("RTFE_GAIN_TRACE") && b == atoi(getenv("RTFE_GAIN_TRACE")) && wi == (getenv("RTFE_GAIN_TRACE_WI") ? atoi(getenv("RTFE_GAIN_TRACE_WI")) : 0) && w.nevents >= (unsigned)(getenv("RTFE_GAIN_TRACE_EV") ? atoi(getenv("RTFE_GAIN_TRACE_EV")) : 4) && w.nevents <= (unsigned)(getenv("RTFE_GAIN_TRACE_EV") ? atoi(getenv("RTFE_GAIN_TRACE_EV")) : 4) + 2)
-               fprintf(stderr, "   look i %lld pos %lld f %lld %s nlead %d nsure %d ntail %d w1 %08x done %d/%d best %lld\n", j.i, u.pos, u.f, u.top ? "top" : "bot", u.nlead, u.nsure, u.ntail, j.w1, (int)top_done, (int)bot_done, best == kNoRow ? -1 : best);
-#endif
             if (u.top ? top_done : bot_done) continue;
             if (u.f > best || u.f >= limit) { if (u.top) top_done = true; else bot_done = true; continue; }
             long long dr;
             const long long n = run_fire(w, u, j.eend, c, limit, W, S.sure_i, mv, dr);
-#ifdef RTFE_CPU_EMUL
-            if (getenv("RTFE_GAIN_TRACE") && b == atoi(getenv("RTFE_GAIN_TRACE")) && wi == (getenv("RTFE_GAIN_TRACE_WI") ? atoi(getenv("RTFE_GAIN_TRACE_WI")) : 0) && w.nevents >= (unsigned)(getenv("RTFE_GAIN_TRACE_EV") ? atoi(getenv("RTFE_GAIN_TRACE_EV")) : 4) && w.nevents <= (unsigned)(getenv("RTFE_GAIN_TRACE_EV") ? atoi(getenv("RTFE_GAIN_TRACE_EV")) : 4) + 2)
-               fprintf(stderr, "   scan i %lld pos %lld f %lld %s nlead %d nsure %d ntail %d unk %d val %d -> n %lld dr %lld (c %lld)\n", j.i, u.pos, u.f, u.top ? "top" : "bot", u.nlead, u.nsure, u.ntail, (int)u.unknown, u.val, n == kNoRow ? -1 : n, dr == kNoRow ? -1 : dr, c);
-#endif
             if (dr < best_doubt) best_doubt = dr;
             if (n != kNoRow) {
                if (u.top) top_done = true; else bot_done = true;         // (runs of one kind are ordered by row)
@@ -604,9 +590,6 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
             e.left_distance = (uint8_t)ld;
             e.parmset = (uint8_t)pidx;
             ev[w.nevents] = e; }
-#ifdef RTFE_CPU_EMUL
-         if (getenv("RTFE_GAIN_TRACE") && b == atoi(getenv("RTFE_GAIN_TRACE")) && wi == (getenv("RTFE_GAIN_TRACE_WI") ? atoi(getenv("RTFE_GAIN_TRACE_WI")) : 0)) fprintf(stderr, "G ev %u row %lld %s ld %d pos %lld c %lld g %.6f rise %.4f\n", w.nevents, ndet - reset, u.top ? "top" : "bot", ld, u.pos, c, g, w.rise);
-#endif
          if (u.top) w.v_top = val; else w.v_bot = val;
          ++w.nevents; ++n_slow;
          agc_after_peak_m(w, cmode, agc_off, P, heights, u.top, t_peak);

@@ -604,9 +604,6 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                      st = pk_fast<WM>(cx, half ? h_hi : h_lo, cpos, ckind != 0, w0, w1); }
                   if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
                      const int hidx = atomicAdd(hard_count, 1);
-#ifdef RTFE_CPU_EMUL
-                     if (getenv("RTFE_HARD_WHY")) fprintf(stderr, "defer: tile %lld pos %d half %d screen %d hidx %d cap %d\n", (long long)tile, cpos, half, (int)sc, hidx, hard_cap);
-#endif
                      if (hidx < hard_cap) {
                         SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)(half ? h_hi : h_lo); hd.screen = (uint8_t)sc;
                         hard[hidx] = hd;
@@ -883,9 +880,6 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       if (nrec > 4) nrec = -1;
       for (int j = 0; j < nrec; ++j) ne += pk_nent(sk.w0[j], sk.w1[j]);
       if (nrec > 0 && 8 + 8 * nrec + 2 * ne > kSfOvfBytes) nrec = -1;
-#ifdef RTFE_CPU_EMUL
-      if (getenv("RTFE_HARD_WHY")) { bool unk = false; for (int j = 0; j < nrec; ++j) unk = unk || sk.w1[j] == 0xffff8000u; fprintf(stderr, "hard: tile %u pos %d head %d screen %d W %d: sink %d nrec %d ne %d unknown-in-sink %d\n", hd.tile, (int)hd.pos, (int)hd.head, (int)hd.screen, cx.W, sk.n, nrec, ne, (int)unk); }
-#endif
       if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, cx.W - 2, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs or margins than a slot holds: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
       *reinterpret_cast<int *>(slot) = nrec;
       if (nrec != 1) atomicAdd(&extra[((size_t)hd.tile * cfg.nscreens + hd.screen) * cfg.ntrks + hd.head], nrec - 1);      // the list's length in its stream (k_pscan)
