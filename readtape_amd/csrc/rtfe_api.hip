@@ -321,12 +321,13 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
    h->zeros_kernel = getenv("RTFE_ZEROS_KERNEL") ? atoi(getenv("RTFE_ZEROS_KERNEL")) != 0 : 1;
    h->side = nullptr; h->overlap = getenv("RTFE_OVERLAP") ? atoi(getenv("RTFE_OVERLAP")) != 0 : 1;
-   if (d.ntrks * (d.tile_rows / 64) > 128) h->zeros_kernel = 0;      // (its workgroup is two waves)
-   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zeros), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout_zeros(d).total + 64);
+   // (k_zeros packs two tracks' 16-bit states into a lane and reads the rows where they lie: no -invert, no deskew delays, a threshold inside int16)
+   if (d.invert || d.maxskew > 0 || d.ntrks < 2 || d.zc_peak_i < 1 || d.zc_peak_i > 32767 || !d.zc_parallel) h->zeros_kernel = 0;      // (RTFE_ZC_PARALLEL=0: k_decode's sequential walk, for the tests)
+   if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
+      if (sf_special(d)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_special(d)), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds); }
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
-   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
-   if (sf_special(d)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_special(d)), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
-   if (getenv("RTFE_VERBOSE")) {
+   if (getenv("RTFE_VERBOSE") && d.peak_path) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sf_special(d) ? reinterpret_cast<const void *>(sf_special(d)) : reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), sf_threads(d), (size_t)d.pk_lds);
       fprintf(stderr, "rtfe: k_sift%s %d threads, %d bytes of LDS: %d workgroups per CU (occupancy API), %d CUs\n", sf_special(d) ? "_s" : "", sf_threads(d), d.pk_lds, nb, h->num_cus); }
@@ -617,13 +618,11 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                       d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts, h->dev.debug == 5 ? 1 : 0);
    t1(kTBursts);
    if (h->dev.find_zeros && !h->dev.differentiate && h->zeros_kernel) {          // -zeros: the lean kernel of its own (rtfe_zeros.hip)
-      const int zlds = (int)lds_layout_zeros(h->dev).total + 64;
-      int zpc = (160 * 1024) / (zlds + 4096);
-      if (zpc > 16) zpc = 16;
-      if (zpc < 1) zpc = 1;
       t0(kTZeros);
-      hipLaunchKernelGGL(k_zeros, dim3(h->num_cus * zpc), dim3(128), zlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base,
-                         d_bursts, scratch, d_counts, d_events);
+      const dim3 zg(h->num_cus * (1024 / kZpThreads)), zb(kZpThreads);                     // persistent workgroups, a burst at a time
+      if (h->dev.ntrks == 9) hipLaunchKernelGGL(k_zeros<9>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);
+      else if (h->dev.ntrks == 7) hipLaunchKernelGGL(k_zeros<7>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);
+      else hipLaunchKernelGGL(k_zeros<0>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);
       t1(kTZeros); }
    else {                                                             // PE, GCR, differentiated peaks, density detection
       t0(kTDecode);

@@ -368,11 +368,18 @@ class FrontEnd:
                 nbursts=be.empty(16), counts=be.empty(mb * P * T * 4), events=be.empty(cap * 16), max_bursts=mb, cap=cap, nrows=nrows)
         return self._cache[k]
 
+    def _rows(self, rows):
+        """The rows where the kernels can read them; the C ABI takes a pointer and a row count, so the row width is checked here."""
+        d_rows = self.backend.rows(rows)
+        if d_rows.ndim != 2 or int(d_rows.shape[1]) != self.cfg.ntrks:
+            raise ValueError(f"rows must be [n, {self.cfg.ntrks}] int16, got {tuple(d_rows.shape)}")
+        return d_rows
+
     def scan(self, rows, row_base=0, first_is_tape_start=True, stream=None, own_rows=None) -> ScanResult:
         """Launches the speculative scan of `rows` ([n, ntrks] int16, device tensor or numpy) — asynchronous.
         Time shards pass own_rows < n: the trailing rows are the right neighbour's halo (include/rt_frontend.h)."""
         be = self.backend
-        d_rows = be.rows(rows)
+        d_rows = self._rows(rows)
         nrows = int(d_rows.shape[0])
         b = self._buffers(nrows)
         rc = self.lib.rtfe_scan(self.h, be.ptr(d_rows), nrows, nrows if own_rows is None else int(own_rows), row_base, int(first_is_tape_start),
@@ -389,7 +396,7 @@ class FrontEnd:
 
     def scan_exact(self, rows, reset_row, end_row, parmset_mask=0xFFFFFFFF, screen_off=False, row_base=0, stream=None) -> ScanResult:
         be = self.backend
-        d_rows = be.rows(rows)
+        d_rows = self._rows(rows)
         nrows = int(d_rows.shape[0])
         b = self._buffers(max(int(end_row - reset_row), 1), key="exact")
         rc = self.lib.rtfe_scan_exact(self.h, be.ptr(d_rows), nrows, row_base, int(reset_row), int(end_row), parmset_mask, int(screen_off),
@@ -413,7 +420,7 @@ class FrontEnd:
     def ww_scan(self, rows, first_row, nscan, seed_row0, state: bytes, cap: int):
         """-> (counts[ntrks], events[ntrks, cap] (EVENT_DTYPE, sample relative to first_row), state after the last row, flags)"""
         be, T = self.backend, self.cfg.ntrks
-        d_rows = be.rows(rows)
+        d_rows = self._rows(rows)
         b = self._cache.get(("ww", cap))
         if b is None:
             b = self._cache[("ww", cap)] = dict(st_in=be.empty(T * self.WW_TRACK_BYTES), st_out=be.empty(T * self.WW_TRACK_BYTES), counts=be.empty(T * 4),

@@ -6,7 +6,7 @@ import pytest
 
 from emul_util import emul_frontend
 from golden_util import load_case
-from readtape_amd import pipeline
+from readtape_amd import frontend, pipeline
 
 CASES = ["nrzi9", "nrzi9_m", "nrzi9_correct", "nrzi7", "nrzi9_skew", "nrzi9_invert", "nrzi9_sub2", "pe", "pe_m", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_m", "gcr_zeros", "gcr_errs", "gcr_correct", "nrzi9_deskew", "nrzi9_deskew_long", "nrzi7_deskew_restart", "gcr_deskew", "nrzi9_nobpi", "nrzi9_nobpi_short", "nrzi9_diffz", "pe_diffz", "gcr_diffz", "nrzi9_diffpk", "nrzi9_diffpk_clean", "nrzi9_diffpk_skew", "gcr_diffpk", "pe_diffpk", "nrzi9_cut", "nrzi9_cut_zeros", "noise_only", "tiny", "nrzi9_nobpi_deskew", "nrzi7_order", "pe_order", "gcr_order_m", "nrzi7_order_ignored"]
 EMUL_CASES = ["nrzi9", "nrzi9_m", "nrzi9_skew", "nrzi9_sub2", "pe", "nrzi9_zeros", "pe_zeros", "gcr", "gcr_zeros", "gcr_correct", "nrzi9_deskew", "nrzi7_deskew_restart", "nrzi9_nobpi_short", "nrzi9_diffz", "pe_diffz", "gcr_diffz", "nrzi9_diffpk", "nrzi9_cut", "nrzi9_cut_zeros", "noise_only", "tiny", "nrzi7_order", "pe_order", "nrzi7_order_ignored"]     # the thread emulation is slow: a subset here, all on the GPU
@@ -186,15 +186,39 @@ def test_output_files_and_summary_match_the_reference(name, tmp_path, monkeypatc
 @pytest.mark.parametrize("name", ["nrzi9_zeros", "pe_zeros", "gcr_zeros", "nrzi9_cut_zeros"])
 @pytest.mark.parametrize("knobs", [{}, {"RTFE_ZEROS_KERNEL": "0"}, {"RTFE_ZC_WARM": "16"}, {"RTFE_ZC_PARALLEL": "0"}])
 def test_zeros_with_the_gpu_default_tile(name, knobs, tmp_path, monkeypatch):
-    """-zeros runs 896-row tiles on the GPU (14 sub-segments x 9 tracks = two full waves): the same tiles on the emulator - through
-    k_zeros (default) and through k_decode's zero-crossing mode, with a warm-up too short to converge (the joins fail and are
-    repaired) and without the concurrent sub-segments."""
+    """-zeros through k_zeros (default: two tracks per lane, 128-row sub-segments), through k_decode's zero-crossing mode with the GPU's
+    896-row tiles, with a warm-up too short to converge (the joins fail and are repaired) and as k_decode's sequential walk."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     g = load_case(name)
     tap, stats = decode_case(g, tmp_path, lambda cfg: emul_frontend(cfg, tile_rows=896))
     assert tap == g["tap"]
     assert not stats["event_diffs"], stats["event_diffs"]
+
+
+@pytest.mark.parametrize("ntrks,clip,order", [(9, True, None), (7, False, None), (8, True, None), (6, False, [5, 3, 1, 0, 2, 4]), (2, True, [1, 0]), (12, False, None), (19, True, None)])
+def test_zeros_kernel_against_the_decode_mode(ntrks, clip, order, monkeypatch):
+    """k_zeros for odd and even track counts (its three instantiations: 9, 7, any), a permuted column order, samples at the ends of the int16
+    range and exact zeros at sign changes, short and long warm-ups: the burst table and every event as k_decode's zero-crossing mode and
+    its sequential walk make them."""
+    import zeros_util
+    hdr, rows = zeros_util.zeros_rows(ntrks, nblocks=4, clip=clip)
+    variants = [{}, {"RTFE_ZC_WARM": "8"}, {"RTFE_ZC_WARM": "64"}, {"RTFE_ZEROS_KERNEL": "0"}, {"RTFE_ZC_PARALLEL": "0"}]
+    out = zeros_util.scan_variants(emul_frontend, hdr, rows, monkeypatch, variants, head_to_trk=order)
+    assert out[0].nbursts >= 4 and int(out[0].counts.sum()) > 5000
+    for r in out[1:]:
+        zeros_util.same_scan(out[0], r, ntrks)
+
+
+def test_rows_of_the_wrong_width_are_refused():
+    """The C ABI takes a pointer and a row count: the host wrapper is where a [n, 18] array for a 19-track configuration must stop."""
+    import zeros_util
+    hdr, rows = zeros_util.zeros_rows(9, nblocks=1)
+    fe = emul_frontend(frontend.FrontEndConfig.from_header(hdr, find_zeros=True))
+    with pytest.raises(ValueError):
+        fe.scan(rows[:, :8])
+    with pytest.raises(ValueError):
+        fe.scan(rows.reshape(-1))
 
 
 WW_CASES = ["ww", "ww_auto", "ww_pos", "ww_pos_auto", "ww_wrongdir", "ww_reverse", "ww_rough", "ww_close", "ww_deskew", "ww_deskew_long", "ww_deskew_pos"]

@@ -472,9 +472,9 @@ def test_zeros_kernel_variants(name, knobs, tmp_path, gpu, monkeypatch):
 
 @pytest.mark.parametrize("kind", ["pe", "nrzi", "gcr"])
 def test_zeros_kernel_equals_the_decode_mode_on_long_tapes(kind, gpu, monkeypatch):
-    """k_zeros (896-row tiles, samples read from HBM, short warm-up with repairs) against k_decode's zero-crossing mode (512-row tiles in
-    LDS, 64-row warm-up) and against the purely sequential walk, on tapes of a few million rows with weak and noisy stretches: the same
-    burst table and the same events, byte for byte."""
+    """k_zeros (two tracks per lane on packed 16-bit arithmetic, samples read from HBM, short warm-up with repairs) against k_decode's
+    zero-crossing mode (512-row tiles in LDS, 64-row warm-up) and against the purely sequential walk, on tapes of a few million rows with
+    weak and noisy stretches: the same burst table and the same events, byte for byte."""
     import torch
     make = {"pe": lambda: synth.pe_tape(seed=91, nblocks=60, minlen=300, maxlen=3000, gap_samples=7000, noise_mv=40.0, amp_slope=0.1),
             "nrzi": lambda: synth.nrzi_tape(seed=92, nblocks=60, minlen=300, maxlen=3000, marks_every=9, gap_samples=5000, noise_mv=40.0),
@@ -500,6 +500,19 @@ def test_zeros_kernel_equals_the_decode_mode_on_long_tapes(kind, gpu, monkeypatc
         for b in range(r0.nbursts):
             for t in range(cfg.ntrks):
                 assert r.track_events(b, 0, t).tobytes() == r0.track_events(b, 0, t).tobytes(), (b, t)
+
+
+@pytest.mark.parametrize("ntrks,clip,order", [(9, True, None), (7, False, None), (8, True, None), (6, False, [5, 3, 1, 0, 2, 4]), (2, True, [1, 0]), (12, False, None), (19, True, None)])
+def test_zeros_kernel_against_the_decode_mode(ntrks, clip, order, gpu, monkeypatch):
+    """See tests/test_emul_replay.py (the same check on tapes thirty times as long, and the widest row the ABI takes)."""
+    import torch
+    import zeros_util
+    hdr, rows = zeros_util.zeros_rows(ntrks, nblocks=120, clip=clip)
+    variants = [{}, {"RTFE_ZC_WARM": "8"}, {"RTFE_ZC_WARM": "64"}, {"RTFE_ZEROS_KERNEL": "0"}, {"RTFE_ZC_PARALLEL": "0"}]
+    out = zeros_util.scan_variants(frontend.FrontEnd, hdr, torch.from_numpy(rows).cuda(), monkeypatch, variants, head_to_trk=order)
+    assert out[0].nbursts >= 100 and int(out[0].counts.sum()) > 200000
+    for r in out[1:]:
+        zeros_util.same_scan(out[0], r, ntrks)
 
 
 @pytest.mark.parametrize("chunk_rows", [4096, 300])
