@@ -118,6 +118,18 @@ def test_nrzi_rows_beyond_4_gib(gpu):
     check_copies(fe, rows, k, n, copies=(k // 2, k - 2, k - 1))
 
 
+def test_c3_full_size(gpu):
+    """BASELINE configs[2]: 9-track PE -zeros, 1e9 rows in ONE scan (18 GB of rows: every row offset beyond 2^32 bytes after the first
+    quarter) through k_zeros - the first, a middle and the last copies carry the three-copy scan's events bit for bit."""
+    torch = gpu
+    tape = bench.make_base_tape(seed=1002, target_rows=5e6, kind="pe")
+    fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(tape.spec.header(), nparmsets=1, find_zeros=True))
+    rows, k, n = tiled(torch, tape, 1e9)
+    assert rows.shape[0] >= 9.9e8
+    rk = check_copies(fe, rows, k, n, copies=(1, k // 3, k // 2, k - 2, k - 1))
+    assert int(rk.counts.sum()) > 5e8
+
+
 @pytest.mark.parametrize("kind,nparm,zeros", [("pe", 1, True), ("gcr", 8, False)])
 def test_c3_c4_one_full_fragment(kind, nparm, zeros, gpu):
     """BASELINE configs[2] and [3] at the size of one bench.py fragment (2^28 rows; 1e9 rows are four of them): PE -zeros through
