@@ -237,7 +237,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    d.cap_frac = c->events_per_sample_cap > 0 ? c->events_per_sample_cap : 0.125f;
    {
       const char *e = getenv("RTFE_TILE_ROWS");            // tuning knob; the default is what bench.py measures
-      // (-zeros: a lane per (track, 64-row sub-segment) - 14 sub-segments x 9 tracks fill two waves, 8 leave 44 % of them idle)
+      // (-zeros in k_decode's zero-crossing mode - k_zeros does not tile -: a lane per (track, 64-row sub-segment), 14 sub-segments x 9 tracks fill two waves)
       int tr = tile_override > 0 ? tile_override : (e ? atoi(e) : ((c->find_zeros && !c->differentiate) ? 64 * (128 / (c->ntrks > 0 ? c->ntrks : 9)) : 512));
       tr = (tr / 64) * 64;
       if (tr < kMarginRows) tr = kMarginRows;
@@ -483,7 +483,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    // beat wide ones; it holds ~250 VGPRs => 2 waves/SIMD => 8 waves per CU
    const int nwalk = h->dev.nparm * h->dev.ntrks;
    int threads = nwalk <= 64 ? 64 : (nwalk <= 128 ? 128 : 256);
-   if (h->dev.find_zeros && !h->dev.differentiate) {                 // -zeros: a lane per (track, 64-row sub-segment) of the tile
+   if (h->dev.find_zeros && !h->dev.differentiate) {                 // -zeros through k_decode (rtfe_zeros.hip says when): a lane per (track, 64-row sub-segment) of the tile
       const int lanes = h->dev.ntrks * (h->dev.tile_rows / 64);
       while (threads < lanes && threads < 256) threads *= 2; }
    int per_cu = (160 * 1024) / (h->lds_bytes + 1024);

@@ -113,9 +113,9 @@ template <int NT> __device__ __forceinline__ void zp_lane(ZpState z, gptr8 base,
    for (int b = 0; b < nbw; ++b) {
       u32 v8[8];
       #pragma unroll
-      for (int k = 0; k < 8; ++k) { v8[k] = nx[0][k]; nx[0][k] = nx[1][k]; }
+      for (int k = 0; k < 8; ++k) { v8[k] = nx[0][k]; for (int a = 0; a + 1 < kZpAhead; ++a) nx[a][k] = nx[a + 1][k]; }
       #pragma unroll
-      for (int k = 0; k < 8; ++k) nx[1][k] = zp_load(base + off, (u32)k * stride);
+      for (int k = 0; k < 8; ++k) nx[kZpAhead - 1][k] = zp_load(base + off, (u32)k * stride);
       off = min(off + 8u * stride, off_last);
       #pragma unroll
       for (int k = 0; k < 8; ++k) zp_step(z, v8[k], Pm1, mP1, 0u, dummy_e, dummy_a); }
@@ -128,9 +128,9 @@ template <int NT> __device__ __forceinline__ void zp_lane(ZpState z, gptr8 base,
       for (int hb = 0; hb < 2; ++hb) {
          u32 v8[8];
          #pragma unroll
-         for (int k = 0; k < 8; ++k) { v8[k] = nx[0][k]; nx[0][k] = nx[1][k]; }
+         for (int k = 0; k < 8; ++k) { v8[k] = nx[0][k]; for (int a = 0; a + 1 < kZpAhead; ++a) nx[a][k] = nx[a + 1][k]; }
          #pragma unroll
-         for (int k = 0; k < 8; ++k) nx[1][k] = zp_load(base + off, (u32)k * stride);
+         for (int k = 0; k < 8; ++k) nx[kZpAhead - 1][k] = zp_load(base + off, (u32)k * stride);
          off = min(off + 8u * stride, off_last);
          #pragma unroll
          for (int k = 0; k < 8; ++k) zp_step(z, v8[k], Pm1, mP1, 0x10001u << (hb * 8 + k), evm, arm); }
