@@ -9,17 +9,18 @@
 // "crossing armed" (two words per 16 rows), and the events are made from the bitmaps afterwards - the sample is read again, the
 // row of the sign change is the last armed row in front of the event.
 //
-// A burst is one workgroup's (persistent workgroups take bursts from a queue).  Its rows [restart, stop) are
+// A burst is one workgroup's (persistent workgroups take bursts from a queue, the long ones first).  Its rows [restart, stop) are
 //   head   32 rows, sequentially (a walker per track: the tracks start staggered, src/decoder.c:855-861),
-//   chunks of up to nsub x 64 rows: a lane per (64-row sub-segment, column pair).  Sub-segment 0 continues from the walker's true
-//          state; the others start zc_warm rows early from a fresh state (what a restart would be).  The detector forgets: after a
-//          confirmed crossing in each direction its state is a function of the samples since.  A sub-segment's result stands if the
-//          state it reached at its first own row is EQUIVALENT to its predecessor's final state - the same pending flags, and the
-//          same extremes where they matter: an extreme that has not reached the threshold (top < P, bot > -P) takes part in
-//          nothing but max / min with later samples, so all such values are one state (quiet stretches, where the extremes
-//          never reset, join like the rest).  Where a join fails, that sub-segment alone is run again from the predecessor's end
-//          state - the true state, by induction from sub-segment 0 - and the check moves on,
-//   tail   the < 64 rows left, sequentially.
+//   chunks of up to 256 / (pairs of columns) sub-segments of 128 rows: a lane per (sub-segment, column pair).  Sub-segment 0 continues
+//          from the walkers' true state; the others start zc_warm rows early - from a fresh state inside the block (what a restart would
+//          be), from the walkers' state where the next dead-quiet zone has begun.  The detector forgets: after a confirmed crossing in
+//          each direction its state is a function of the samples since.  A sub-segment's result stands if the state it reached at its
+//          first own row is EQUIVALENT to its predecessor's final state - the same pending flags, and the same extremes where they
+//          matter: an extreme that has not reached the threshold (top < P, bot > -P) takes part in nothing but max / min with later
+//          samples, so all such values are one state (quiet stretches, where the extremes never reset, join like the rest).  Where
+//          joins fail, a track's first failing sub-segment is run again from its predecessor's end state - the true state, by
+//          induction from sub-segment 0; the check repeats until every join holds,
+//   tail   the < 128 rows left, sequentially.
 // Exact for every input: the parallel part changes who computes, never what.  -invert, -deskew, one track and thresholds beyond
 // int16 take k_decode's zero-crossing mode instead (rtfe_api.hip).  Included behind rtfe_kernels.hip.
 
@@ -97,8 +98,8 @@ __device__ __forceinline__ void zp_step(ZpState &z, u32 v, u32 Pm1, u32 mP1, u32
 // One lane's run: nbw batches of eight warm-up rows (no bitmaps), then - the state at that point noted in the record - the kZpSub own
 // rows, whose bitmaps and end state go to the record.  off = byte offset of the first row; the loads run kZpAhead batches ahead and
 // stop at the last own batch (that batch again: no row behind the sub-segment is read).
-// keep: the halves (0xffff each) whose record stands and is not to be touched (a lane runs again for its other half).
-template <int NT> __device__ __forceinline__ void zp_lane(ZpState z, gptr8 base, u32 off, int nbw, int ntrks, u32 Pm1, u32 mP1, u32 (*rec)[kZpThreads], int lane, u32 keep = 0) {
+// keep: the halves (0xffff each) whose record stands and is not to be touched (a lane runs again for its other half).  z: the end state on return.
+template <int NT> __device__ __forceinline__ void zp_lane(ZpState &z, gptr8 base, u32 off, int nbw, int ntrks, u32 Pm1, u32 mP1, u32 (*rec)[kZpThreads], int lane, u32 keep = 0) {
    auto put = [&](int f, u32 val) { rec[f][lane] = keep ? ((val & ~keep) | (rec[f][lane] & keep)) : val; };
    const u32 stride = 2u * (u32)(NT ? NT : ntrks);
    const u32 off_last = off + (u32)(nbw * 8 + kZpSub - 8) * stride;
@@ -281,12 +282,12 @@ template <int NT> __global__ void __launch_bounds__(kZpThreads, 4) k_zeros(const
             if (!any) break;
             if (dbgp && T == 0) atomicAdd(&dbgp[4], 1ull);
             const int fb0 = s_first[trk0], fb1 = s_first[trk1];
-            __syncthreads();
-            if (T <= ntrks) s_first[T] = ns;
             // who runs again: the failing halves, and - behind a track's first failure - every half whose rows lie in the next dead-quiet zone
             // (those assumed one and the same lingering state and so agree with each other, right or wrong)
             const bool in_gap = mine && j > 0 && c0 + (long long)j * kZpSub - cfg.zc_warm >= zq;
             const bool run0 = bad0 || (live0 && in_gap && fb0 < j), run1 = bad1 || (in_gap && fb1 < j);
+            __syncthreads();
+            if (T <= ntrks) s_first[T] = ns;
             if (run0 || run1) {
                if (dbgp) atomicAdd(&dbgp[3], 1ull);
                // a half that is its track's first failure must start exactly where its predecessor ended: no warm-up rows for the lane then
@@ -298,18 +299,20 @@ template <int NT> __global__ void __launch_bounds__(kZpThreads, 4) k_zeros(const
                z.pu = (rec[kZfPuE][l0] & 0xffffu) | (rec[kZfPuE][l1] & 0xffff0000u);    z.pd = (rec[kZfPdE][l0] & 0xffffu) | (rec[kZfPdE][l1] & 0xffff0000u);
                const int warm = exact ? 0 : cfg.zc_warm;
                const u32 off = (u32)(j * kZpSub - warm) * stride;
+               const u32 keep = (run0 ? 0u : 0xffffu) | (run1 ? 0u : 0xffff0000u);
                z.pv = zp_load(base, off); z.pnv = zq_subs(0u, z.pv);
-               zp_lane<NT>(z, base, off + stride, warm / 8, ntrks, Pm1, mP1, rec, T, (run0 ? 0u : 0xffffu) | (run1 ? 0u : 0xffff0000u)); }
+               zp_lane<NT>(z, base, off + stride, warm / 8, ntrks, Pm1, mP1, rec, T, keep); }
             __syncthreads(); }
          if (dbgp) k2 = clock64();
          // ---- events from the bitmaps, in row order; the last sub-segment's lanes move the walkers to the chunk's end ----
-         // The events' samples are read again - all of a half's loads first, then all of its stores: loads and stores share one in-order
-         // counter on this hardware, so a load issued behind a store waits for that store's acknowledgement.  The samples wait in LDS,
-         // in the space of the record fields that are no longer needed (start and end states: the own ones are in registers by now).
+         // The events' samples are read again, eight loads in flight at a time, and wait in LDS for the loop that makes the events - in the
+         // space of the record fields that are no longer needed (start and end states: the own ones are in registers by now).
          const u32 e_top = rec[kZfTopE][T], e_bot = rec[kZfBotE][T], e_pu = rec[kZfPuE][T], e_pd = rec[kZfPdE][T], e_pv = rec[kZfPvE][T];
          __syncthreads();
          unsigned short *const stg = reinterpret_cast<unsigned short *>(&rec[0][0]);     // [kZpStage][kZpThreads]
          if (mine) {
+            u32 before = 0;                                              // events of the sub-segments in front, both halves (a chunk holds fewer than 2^16 per track)
+            for (int k = 0; k < j; ++k) before += rec[kZfCnt][k * npair + p];
             #pragma nounroll
             for (int h = 0; h < 2; ++h) {
                if (h == 0 && !live0) continue;
@@ -321,8 +324,7 @@ template <int NT> __global__ void __launch_bounds__(kZpThreads, 4) k_zeros(const
                if (!cnt && !last) continue;
                const long long r0 = c0 + (long long)j * kZpSub;
                const gptr16 colp = (gptr16)rows + r0 * ntrks + col;
-               unsigned int idx = w.nevents;
-               for (int k = 0; k < j; ++k) idx += (rec[kZfCnt][k * npair + p] >> (16 * h)) & 0xffffu;
+               unsigned int idx = w.nevents + ((before >> (16 * h)) & 0xffffu);
                // the crossing that was pending when this sub-segment began - the last armed row of the sub-segments in front, or the walker's -
                // is asked for where an event lies in front of the sub-segment's first armed row, or where the pending crossing leaves it
                const int arm_first = zp_first(rec, kZfArm, T, h), ev_first = zp_first(rec, kZfEvm, T, h), arm_end = zp_last_below(rec, kZfArm, T, h, kZpSub);
