@@ -233,7 +233,7 @@ static enum rt_bstate process_sample(struct ofe *fe, const float *voltage) {
          if (d->opt.do_differentiate) lookfor_differentiated_zerocrossing(fe, t, w);
          else lookfor_zerocrossing(fe, t, w); }
       else lookfor_peak(fe, t, w);
-      if (fe->fatal) { d->fatal = 1; d->results[d->parmset].blktype = RT_BS_ABORTED; return RT_BS_ABORTED; }
+      if (fe->fatal || d->fatal) { d->fatal = 1; d->results[d->parmset].blktype = RT_BS_ABORTED; return RT_BS_ABORTED; }      /* (d->fatal: an assert inside the block decoder's callback, e.g. src/decode_nrzi.c:227) */
 
       if (d->opt.mode == RT_PE && rt_pe_idle_due(d, t)) rt_pe_go_idle(d, t);
       if (d->opt.mode == RT_GCR && rt_gcr_idle_due(d, t))

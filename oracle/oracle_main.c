@@ -226,4 +226,4 @@ int main(int argc, char **argv) {
    if (d->tapf) fclose(d->tapf);
    if (d->logf) fclose(d->logf);
    if (evtf) fclose(evtf);
-   return fe->fatal ? 99 : 0; }
+   return (fe->fatal || d->fatal) ? 99 : 0; }

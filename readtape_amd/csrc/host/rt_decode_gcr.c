@@ -89,7 +89,9 @@ static void transition(struct rt_dec *d, struct rt_trk *t, int is_top) {
    if (!is_top) { if (settled && t->v_avg_height_count == 0) rt_adjust_agc(d, t); return; }
    if (settled) {
       if (t->v_avg_height_count == 0) rt_adjust_agc(d, t);
-      else { t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count; t->v_avg_height_count = 0; }
+      else {
+         t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count; t->v_avg_height_count = 0;
+         if (!(t->v_avg_height > 0)) d->fatal = 1; }      /* "avg peak-to-peak voltage isn't positive" (src/decode_gcr.c:862): the reference exits here */
       return; }
    if (t->peakcount < AGC_STARTBASE) return;
    const float h = t->v_top - t->v_bot;

@@ -144,7 +144,9 @@ static void transition(struct rt_dec *d, struct rt_trk *t, int is_top) {
       if (++t->heightndx >= RT_PARM(d).agc_window) t->heightndx = 0; }
    else if (learned) {
       if (t->v_avg_height_count == 0) rt_adjust_agc(d, t);
-      else { t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count; t->v_avg_height_count = 0; } } }
+      else {
+         t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count; t->v_avg_height_count = 0;
+         if (!(t->v_avg_height > 0)) d->fatal = 1; } } }      /* "avg peak-to-peak voltage isn't positive" (src/decode_nrzi.c:227): the reference exits inside this callback */
 
 void rt_nrzi_top(struct rt_dec *d, struct rt_trk *t) { transition(d, t, 1); }
 void rt_nrzi_bot(struct rt_dec *d, struct rt_trk *t) { transition(d, t, 0); }

@@ -103,6 +103,7 @@ static void preamble_transition(struct rt_dec *d, struct rt_trk *t, int is_top, 
    if (a_one && t->peakcount > PREAMBLE_PEAKS && when - t->t_lastpeak > t->t_clkwindow) {
       t->datablock = 1;                          /* the marker: data follow */
       t->v_avg_height = t->v_avg_height_sum / t->v_avg_height_count;
+      if (!(t->v_avg_height > 0)) d->fatal = 1;      /* "avg peak-to-peak voltage isn't positive" (src/decode_pe.c:144): the reference exits here (0 / 0 where no height was learned) */
       return; }
    t->clknext = !a_one;
    if (t->peakcount < LEARN_FROM || t->peakcount > LEARN_TO || !(t->v_top > t->v_bot)) return;

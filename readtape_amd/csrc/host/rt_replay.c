@@ -291,6 +291,12 @@ restart:
                rt_finish_attempt(d);
                return 0; }
             deliver(rp, &src, t, &src.list[t][src.at[t]], W);
+            if (d->fatal) {                                      /* the decoder's callback met one of the reference's asserts (a learned peak height that is not positive): the run ends inside it */
+               rp->reference_fatal = 1; rp->fatal_row = row; rp->fatal_trk = t;
+               d->results[parmset].blktype = RT_BS_ABORTED;
+               if (exact_events && rp->exact_free) rp->exact_free(rp->exact_user, exact_events);
+               rt_finish_attempt(d);
+               return 0; }
             ++src.at[t]; ++events_seen; evsrc_sync(&src, t); }
          if (d->opt.mode == RT_PE && rt_pe_idle_due(d, tk)) rt_pe_go_idle(d, tk);
          if (d->opt.mode == RT_GCR && rt_gcr_idle_due(d, tk)) if (rt_gcr_go_idle(d, tk)) stop_row = 1; }

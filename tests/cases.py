@@ -241,6 +241,25 @@ def case_nrzi9_agcfatal_m(seed=412346456):
 case_nrzi9_agcfatal_m.parms_text = AGCFATAL_M_PARMS
 
 
+AVGHEIGHT_PARMS = ("parms active, clk_window, clk_alpha, agc_window, agc_alpha, min_peak, clk_factor, pulse_adj, pkww_bitfrac, pkww_rise, midbit, z1pt, z2pt, id\n"
+                   "{1, 0, 0.2, 10, 0.0, 0.1, 0, 0.3, 0.266, 0.3, 0.5, 1.45, 2.35, PRM}\n"
+                   "{1, 0, 0.2, 0, 0.5, 0.0, 0, 0.3, 0.42, 0.1, 0.5, 1.45, 2.35, PRM}\n"
+                   "{1, 0, 0.2, 0, 0.2, 1.0, 0, 0.3, 0.42, 0.1, 0.5, 1.45, 2.35, PRM}\n")
+
+
+def case_nrzi9_avgheight_fatal(seed=40247490):
+    # (found by tests/stress_gpu.py, seed 901 tape 85) 80 mV of noise on a 1 V signal and a second set without min_peak: a track's
+    # "peaks" 5 .. 15 are noise wiggles whose tops lie below their bottoms, the learned average peak height comes out negative and the
+    # reference dies INSIDE the block decoder's callback: "avg peak-to-peak voltage isn't positive" (src/decode_nrzi.c:227; the same
+    # assert in src/decode_gcr.c:862 and src/decode_pe.c:144).  3 000 rows of that tape: 11 813 transitions, then the assert.
+    import dataclasses
+    t = synth.nrzi_tape(seed=seed, nblocks=4, minlen=16, maxlen=7000, marks_every=3, ntrks=9, gap_samples=4000, amplitude=1.0, noise_mv=80.0, jitter=0.08)
+    return dataclasses.replace(t, rows=np.ascontiguousarray(t.rows[25000:28000]))
+
+
+case_nrzi9_avgheight_fatal.parms_text = AVGHEIGHT_PARMS
+
+
 # name -> (tape builder, reference options, oracle options); a builder's .parms_text, if any, is the NRZI/PE/GCR.parms file of the run
 CASES = {
     "nrzi9":        (case_nrzi9,      ["-nrzi"],                       []),
@@ -293,6 +312,7 @@ CASES = {
     "nrzi7_order_ignored": (case_nrzi7_order_ignored, ["-nrzi", "-ntrks=7", "-order=543210p"], ["-order=543210p"]),
     "nrzi7_agcfatal": (case_nrzi7_agcfatal, ["-nrzi", "-ntrks=7", "-invert", "-differentiate"], ["-invert", "-differentiate"]),
     "nrzi9_agcfatal_m": (case_nrzi9_agcfatal_m, ["-nrzi", "-m", "-even"],  ["-m", "-even"]),
+    "nrzi9_avgheight_fatal": (case_nrzi9_avgheight_fatal, ["-nrzi", "-m", "-even"],  ["-m", "-even"]),
     "gcr_errs":     (case_gcr_errors, ["-gcr"],                        []),
     "gcr_correct":  (case_gcr_errors, ["-gcr", "-correct"],            ["-correct"]),
 }

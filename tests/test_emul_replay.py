@@ -81,6 +81,25 @@ def test_agc_assert_inside_a_parameter_sweep_ends_everything(peak_path, tmp_path
     assert not refdump.compare(mine, g["events"])
 
 
+@pytest.mark.parametrize("peak_path", ["0", "1"])
+def test_a_learned_peak_height_that_is_not_positive_ends_everything(peak_path, tmp_path, monkeypatch):
+    """src/decode_nrzi.c:227 ("avg peak-to-peak voltage isn't positive"): noise wiggles taken for peaks make a track's learned average
+    height negative, and the reference exits INSIDE the block decoder's callback (stress seed 901 tape 85: the replay used to go on,
+    43 transitions further, to the next assert).  The transitions delivered up to there are the reference's, the last one included."""
+    import refdump
+    monkeypatch.setenv("RTFE_PEAK_PATH", peak_path)
+    g = load_case("nrzi9_avgheight_fatal")
+    assert g["returncode"] == 99
+    tap = os.path.join(str(tmp_path), "out.tap")
+    with pytest.raises(pipeline.ReferenceFatal) as ei:
+        pipeline.decode_tape(g["hdr"], g["rows"], tap, fe_factory=emul_frontend, evt_path=tap + ".evt", parms_text=g["parms_text"],
+                             opts=pipeline.DecodeOptions(multiple_tries=True, even_parity=True))
+    mine = refdump.load(tap + ".evt")
+    assert mine.size == g["events"].size and mine.size > 10000, (mine.size, g["events"].size)
+    assert not refdump.compare(mine, g["events"])
+    assert ei.value.stats["reference_fatal"]
+
+
 def test_short_burst_tails_do_not_change_the_tap(tmp_path, monkeypatch):
     """A burst's walkers stop tail_rows into the next quiet zone.  Even with an absurdly short tail
     the .tap must not change: a zone only starts a whole quiet KiB after the last flux transition, by when the block

@@ -248,6 +248,22 @@ def test_agc_assert_inside_a_parameter_sweep_ends_everything(peak_path, tmp_path
     assert mine.size == g["events"].size and not refdump.compare(mine, g["events"])
 
 
+@pytest.mark.parametrize("peak_path", ["0", "1"])
+def test_a_learned_peak_height_that_is_not_positive_ends_everything(peak_path, tmp_path, gpu, monkeypatch):
+    """src/decode_nrzi.c:227: the reference exits inside the block decoder's callback (stress seed 901 tape 85): see tests/test_emul_replay.py."""
+    import os
+    import refdump
+    from readtape_amd import pipeline
+    monkeypatch.setenv("RTFE_PEAK_PATH", peak_path)
+    g = load_case("nrzi9_avgheight_fatal")
+    tap = os.path.join(str(tmp_path), "out.tap")
+    with pytest.raises(pipeline.ReferenceFatal):
+        pipeline.decode_tape(g["hdr"], g["rows"], tap, evt_path=tap + ".evt", parms_text=g["parms_text"],
+                             opts=pipeline.DecodeOptions(multiple_tries=True, even_parity=True))
+    mine = refdump.load(tap + ".evt")
+    assert mine.size == g["events"].size and not refdump.compare(mine, g["events"])
+
+
 @pytest.mark.parametrize("name", PEAK_CASES + ["nrzi9_nobpi", "nrzi9_cut", "noise_only", "tiny", "gcr_errs"])
 def test_peak_record_path_equals_the_sample_path(name, gpu, monkeypatch):
     """The peak path (RTFE_PEAK_PATH=1: k_sift -> k_gain -> k_emit) against the sample path (RTFE_PEAK_PATH=0: k_decode): the same burst
