@@ -11,7 +11,7 @@
 //
 // A burst is one workgroup's (persistent workgroups take bursts from a queue, the long ones first).  Its rows [restart, stop) are
 //   head   32 rows, sequentially (a walker per track: the tracks start staggered, src/decoder.c:855-861),
-//   chunks of up to 256 / (pairs of columns) sub-segments of 128 rows: a lane per (sub-segment, column pair).  Sub-segment 0 continues
+//   chunks of up to 128 / (pairs of columns) sub-segments of 128 rows: a lane per (sub-segment, column pair).  Sub-segment 0 continues
 //          from the walkers' true state; the others start zc_warm rows early - from a fresh state inside the block (what a restart would
 //          be), from the walkers' state where the next dead-quiet zone has begun.  The detector forgets: after a confirmed crossing in
 //          each direction its state is a function of the samples since.  A sub-segment's result stands if the state it reached at its
@@ -38,7 +38,7 @@ typedef unsigned int u32;
 constexpr int kZpSub = 128;           // rows of a sub-segment (a multiple of 64)
 constexpr int kZpLong = 32768;        // bursts of that many rows and more are taken first, those under a quarter of it last
 constexpr int kZpHead = 32;           // rows walked sequentially at a burst's start (> RTFE_MAXTRKS: every track has started)
-constexpr int kZpThreads = 256;
+constexpr int kZpThreads = 128;         // (measured on C3: 64 / 128 / 256 / 512 threads -> 15.9 / 14.5 / 14.8 / 16.8 ms; sub-segments of 256 rows: 15.7)
 constexpr int kZpStage = 16;           // event samples a half stages in LDS (the 9 state fields of the records: 18 rows of 16 bits)
 constexpr int kZpAhead = 2;           // batches of eight rows on their way while a batch is stepped through
 enum { kZfTopS, kZfBotS, kZfPuS, kZfPdS, kZfTopE, kZfBotE, kZfPuE, kZfPdE, kZfPvE, kZfCnt, kZfEvm, kZfArm = kZfEvm + kZpSub / 16, kZfN = kZfArm + kZpSub / 16 };
