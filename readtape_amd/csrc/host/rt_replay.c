@@ -250,8 +250,18 @@ restart:
       if (!using_exact && !d->interblock_counter && next >= src.end && src.end < nrows) {
          /* still fresh: the next burst's fresh state is the same state.  During density detection the detector never
           * leaves its fresh AGC / baseline state (no decoder runs), so every proven restart is the same state */
-         if ((events_seen == 0 || d->doing_density_detection) && burst_usable(rp, b + 1)
-             && !(rp->find_zeros && (rp->bursts[b].flags & RTFE_F_STATE_AT_END))) {     /* (-zeros: an excursion without an event is history too) */
+         const int fresh = (events_seen == 0 || d->doing_density_detection)
+                           && !(rp->find_zeros && (rp->bursts[b].flags & RTFE_F_STATE_AT_END));     /* (-zeros: an excursion without an event is history too) */
+         if (fresh && rp->stop_row != INT64_MAX
+             && (b + 1 >= rp->nbursts || rp->bursts[b + 1].zone_first - rp->row_base >= rp->stop_row)) {
+            /* fragment decode: the burst behind this one belongs to the next fragment (it is the bounding entry of the table, or not in
+             * it at all), whose replay starts from the same fresh state at the start of that burst's zone - this attempt saw nothing
+             * and ends here without a block.  (chaining on, or redoing the attempt from an exact scan, decoded the
+             * neighbour's block a second time.) */
+            rp->pos = rp->stop_row;
+            rt_finish_attempt(d);
+            return 0; }
+         if (fresh && burst_usable(rp, b + 1)) {
             ++b; evsrc_from_burst(&src, rp, b, parmset); evsrc_skip_before(&src, ntrks, row); ++rp->chained;
             continue; }
          if (restarted) { ++rp->device_failures; d->results[parmset].blktype = RT_BS_ABORTED; break; }

@@ -267,3 +267,38 @@ def test_whirlwind_tap_bytes_match_reference(name, chunk_rows, tmp_path):
     assert tap == g["tap"]
     assert stats["agc_mismatches"] == 0 and stats["events_delivered"] > 0
     assert not stats["event_diffs"], stats["event_diffs"]
+
+
+def _tape_with_an_eventless_burst():
+    """A 9-track NRZI tape whose second gap holds a slow 1 V trapezoid on one track: rows that are not quiet (a burst boundary on
+    either side of it) but that the detector sees no peak in - a burst without events."""
+    import numpy as np
+    from readtape_amd import synth
+    tape = synth.nrzi_tape(seed=77, nblocks=4, minlen=60, maxlen=120, gap_samples=9000)
+    rows = tape.rows.copy()
+    (_, _, e1, _), (_, s2, _, _) = tape.blocks[1], tape.blocks[2]
+    mid = (e1 + s2) // 2
+    ramp = np.concatenate([np.linspace(0, 1.0, 600), np.full(300, 1.0), np.linspace(1.0, 0, 600)])
+    lo = mid - ramp.size // 2
+    rows[lo: lo + ramp.size, 4] += np.round(ramp / tape.spec.maxvolts * 32767).astype(np.int16)
+    return tape.spec.header(), rows, lo, lo + ramp.size
+
+
+@pytest.mark.parametrize("where", ["behind", "inside_gap_before", "far_behind"])
+def test_a_cut_behind_an_eventless_burst_does_not_duplicate_a_block(where, tmp_path):
+    """The replay of a fragment must not chain from a burst without events into a burst the NEXT fragment owns (rt_replay.c: the
+    chaining branch checks stop_row): [(0, n)] and [(0, cut), (cut, n)] write the same .tap for cuts around the eventless burst."""
+    hdr, rows, lo, hi = _tape_with_an_eventless_burst()
+    n = rows.shape[0]
+    whole = os.path.join(str(tmp_path), "whole.tap")
+    sts = pipeline.decode_tape_fragments(hdr, rows, whole, [(0, n)], fe_factory=emul_frontend)
+    ref = open(whole, "rb").read()
+    assert sum(s["blocks"] for s in sts) == 4
+    cut = {"behind": (hi + 640) // 64 * 64, "inside_gap_before": (lo - 1200) // 64 * 64, "far_behind": (hi + 2600) // 64 * 64}[where]
+    tap = os.path.join(str(tmp_path), "cut.tap")
+    sts = pipeline.decode_tape_fragments(hdr, rows, tap, [(0, cut), (cut, n)], fe_factory=emul_frontend, halo_rows=1 << 14)
+    assert open(tap, "rb").read() == ref, (where, [s["blocks"] for s in sts])
+    # three fragments, the middle one holding nothing but the eventless burst
+    a, b = (lo - 1200) // 64 * 64, (hi + 640) // 64 * 64
+    sts = pipeline.decode_tape_fragments(hdr, rows, tap, [(0, a), (a, b), (b, n)], fe_factory=emul_frontend, halo_rows=1 << 14)
+    assert open(tap, "rb").read() == ref, [s["blocks"] for s in sts]
