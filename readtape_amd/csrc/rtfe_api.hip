@@ -17,6 +17,7 @@
 #include "rtfe_zeros.hip"
 #include "rtfe_ww.hip"
 #include "rtfe_gain.hip"
+#include "rtfe_dense.hip"
 
 namespace rtfe {
 __global__ void k_setup_exact(rtfe_burst *burst, BurstScratch *scratch, long long reset_row, long long end_row,
@@ -91,9 +92,10 @@ extern "C" const char *rtfe_last_error(void) { return g_err; }
 //   k_gain_tail | k_emit [k_emit_seg, k_emit, k_publish] | k_decode [the bursts the chains gave up, on the samples]
 // the sample path (PE, GCR, differentiated peaks, density detection, parameter-set sweeps with too many widths) k_quiet | k_bursts | k_decode,
 // -zeros k_quiet | k_bursts | k_zeros.  A span a scan does not run reads 0.
-static const char *KNAMES[] = {"k_quiet", "k_sift", "k_prep", "k_bursts", "k_gain", "k_gain_s", "k_gain_tail", "k_emit", "k_decode", "k_zeros"};
-enum { kTQuiet, kTSift, kTPrep, kTBursts, kTGain, kTGainS, kTGainTail, kTEmit, kTDecode, kTZeros };
-constexpr int kNumKernels = 10;
+// the dense sample path (PE, GCR peak detection): k_quiet | k_bursts [k_bursts, k_zones] | k_dseg | k_dchain [k_dchain, k_publish] | k_decode [what the chains gave up]
+static const char *KNAMES[] = {"k_quiet", "k_sift", "k_prep", "k_bursts", "k_gain", "k_gain_s", "k_gain_tail", "k_emit", "k_decode", "k_zeros", "k_dseg", "k_dchain"};
+enum { kTQuiet, kTSift, kTPrep, kTBursts, kTGain, kTGainS, kTGainTail, kTEmit, kTDecode, kTZeros, kTDseg, kTDchain };
+constexpr int kNumKernels = 12;
 extern "C" int rtfe_kernel_count(void) { return kNumKernels; }
 extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < kNumKernels) ? KNAMES[i] : ""; }
 
@@ -290,6 +292,38 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       d.pk_slot = (slot + 15) & ~15;
       d.pk_lds = (int)sf_lds_layout(c->ntrks, d.pk_hl, d.pk_hr, d.pk_wave_cap, d.pk_slot).total + 64;
       if (d.pk_lds > 150 * 1024 || sf_nv(d) > 6) d.peak_path = 0; }
+   {  // ---- the dense sample path (rtfe_dense.hip) ----
+      // parameter sets the front end cannot tell apart are one chain (src/parmsets.c:77-110: four of the five GCR defaults, five of the eight PE ones)
+      d.nuset = 0;
+      for (int p = 0; p < c->nparmsets; ++p) {
+         int u;
+         for (u = 0; u < d.nuset; ++u) {
+            const DevParm &a = d.parm[d.uset_rep[u]], &b = d.parm[p];
+            if (a.W == b.W && a.rise == b.rise && a.min_peak == b.min_peak && a.agc_alpha == b.agc_alpha && a.agc_window == b.agc_window
+                && (c->mode != RTFE_PE || a.t_clkwindow == b.t_clkwindow)) break; }
+         if (u == d.nuset) { d.uset_rep[u] = p; d.uset_mask[u] = 0; ++d.nuset; }
+         d.uset_of[p] = u; d.uset_mask[u] |= 1u << p; }
+      if (getenv("RTFE_DENSE_DEDUP") && atoi(getenv("RTFE_DENSE_DEDUP")) == 0) {      // (tests: every set its own chain)
+         d.nuset = c->nparmsets;
+         for (int p = 0; p < c->nparmsets; ++p) { d.uset_of[p] = p; d.uset_rep[p] = p; d.uset_mask[p] = 1u << p; } }
+      d.dense_path = !d.peak_path && !d.find_zeros && !d.differentiate && !d.agc_off && (d.mode == RTFE_PE || d.mode == RTFE_GCR);
+      if (const char *e = getenv("RTFE_DENSE_PATH")) d.dense_path = !d.peak_path && !d.find_zeros && !d.differentiate && !d.agc_off && d.mode != RTFE_WW && atoi(e) != 0;
+      int wpad = 64;
+      for (int sidx = 0; sidx < d.nscreens; ++sidx) {
+         int wm = 3 * d.screen[sidx].W + 8; if (wm < 64) wm = 64;
+         if (const char *e = getenv("RTFE_DS_WARM")) { const int v = atoi(e); if (v >= 0 && v <= 192) wm = v; }      // (tests: joins that fail)
+         d.ds_warm[sidx] = wm; if (wm > wpad) wpad = wm; }
+      d.ds_pad = (wpad + 63) & ~63;
+      const float spbf = 1.0f / (bpi_s * c->ips * d.sample_deltat);
+      const float expect = (float)kDsSub * (c->mode == RTFE_PE ? 2.0f : 1.0f) / (spbf > 2 ? spbf : 2);
+      d.ds_cap = expect * 1.3f + 2 <= 15 ? 15 : (expect * 1.3f + 2 <= 31 ? 31 : 63);
+      if (const char *e = getenv("RTFE_DS_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 63) d.ds_cap = v; }      // (tests: lists that run full)
+      d.ds_slot = ((int)sizeof(DsHdr) + d.ds_cap * (int)sizeof(DsRec) + 15) & ~15;
+      d.ds_sfloor = (hfloor < 4.0f ? hfloor : 4.0f) / 4.0f / 2.0f;
+      d.ds_quiet_s = getenv("RTFE_DS_QUIET_S") ? (float)atof(getenv("RTFE_DS_QUIET_S")) : 0.6f;
+      d.ds_band_hi = getenv("RTFE_DS_BAND_HI") ? (float)atof(getenv("RTFE_DS_BAND_HI")) : 1.25f;
+      d.ds_band_lo = getenv("RTFE_DS_BAND_LO") ? (float)atof(getenv("RTFE_DS_BAND_LO")) : 1.0f / 3.0f;
+      if ((int)ds_lds_layout(c->ntrks, d.halo_rows, d.ds_pad + kDsTile).total + 64 > 150 * 1024) d.dense_path = 0; }
    {
       const int nwalk = c->nparmsets * c->ntrks;
       int rc = (24 * 1024) / (nwalk * 24);
@@ -326,6 +360,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
       if (sf_special(d)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_special(d)), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds); }
+   if (d.dense_path) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dseg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile).total + 64);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    if (getenv("RTFE_VERBOSE") && d.peak_path) {
       int nb = -1;
@@ -345,7 +380,11 @@ extern "C" int rtfe_set_timing(rtfe_handle *h, int enable) {
    if (enable && !h->timing) {
       h->ev0 = new hipEvent_t[kTimingRing][12]; h->ev1 = new hipEvent_t[kTimingRing][12];
       for (int r = 0; r < kTimingRing; ++r) for (int i = 0; i < kNumKernels; ++i)
-         if (hipEventCreate(&h->ev0[r][i]) != hipSuccess || hipEventCreate(&h->ev1[r][i]) != hipSuccess) return fail(-40, "hipEventCreate failed");
+         if (hipEventCreate(&h->ev0[r][i]) != hipSuccess || hipEventCreate(&h->ev1[r][i]) != hipSuccess) {
+            // (no half-made ring left behind - the events made so far are destroyed with it)
+            for (int r2 = 0; r2 <= r; ++r2) for (int i2 = 0; i2 < (r2 < r ? kNumKernels : i); ++i2) { (void)hipEventDestroy(h->ev0[r2][i2]); (void)hipEventDestroy(h->ev1[r2][i2]); }
+            delete[] h->ev0; delete[] h->ev1; h->ev0 = nullptr; h->ev1 = nullptr;
+            return fail(-40, "hipEventCreate failed"); }
       h->ev_next = 0; h->ev_pending = 0; }
    if (!enable && h->timing) timing_free(h);
    h->timing = enable != 0;
@@ -446,8 +485,17 @@ static size_t pk_segs_bytes(const rtfe_handle *h, int64_t nrows) { return ((size
 static size_t ws_pkgfire_off(const rtfe_handle *h, int64_t nrows) { return ws_pksegs_off(h, nrows) + pk_segs_bytes(h, nrows); }
 static size_t pk_gfire_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)pk_seg_cap(h, nrows) * (size_t)(h->dev.pk_seg_recs > 0 ? h->dev.pk_seg_recs : 0) * 4 + 255) & ~(size_t)255; }
 
+// ... | the dense sample path: per (tile, width) "nothing above the screen" | per (sub-segment, track) the band | the slots
+static long long ds_tiles_for(int64_t nrows) { return (nrows + kDsTile - 1) / kDsTile; }
+static size_t ws_dsdead_off(const rtfe_handle *h, int64_t nrows) { return (ws_pkgfire_off(h, nrows) + pk_gfire_bytes(h, nrows) + 255) & ~(size_t)255; }
+static size_t ds_dead_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.dense_path ? (((size_t)ds_tiles_for(nrows) * h->dev.nscreens + 255) & ~(size_t)255) : 0; }
+static size_t ws_dsband_off(const rtfe_handle *h, int64_t nrows) { return ws_dsdead_off(h, nrows) + ds_dead_bytes(h, nrows); }
+static size_t ds_band_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.dense_path ? (((size_t)ds_tiles_for(nrows) * kDsJ * h->dev.ntrks * sizeof(float2) + 255) & ~(size_t)255) : 0; }
+static size_t ws_dsslot_off(const rtfe_handle *h, int64_t nrows) { return ws_dsband_off(h, nrows) + ds_band_bytes(h, nrows); }
+static size_t ds_slot_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.dense_path ? (((size_t)ds_tiles_for(nrows) * kDsJ * h->dev.nuset * h->dev.ntrks * (size_t)h->dev.ds_slot + 255) & ~(size_t)255) : 0; }
+
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
-   return ws_pkgfire_off(h, nrows) + pk_gfire_bytes(h, nrows) + 256; }
+   return ws_dsslot_off(h, nrows) + ds_slot_bytes(h, nrows) + 256; }
 
 extern "C" int64_t rtfe_event_capacity(const rtfe_handle *h, int64_t nrows) {
    const double per_track = (double)nrows * h->dev.cap_frac + 128.0 * (double)rtfe_max_bursts(h, nrows) + (double)kMarginRows;
@@ -616,6 +664,9 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
                       d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts, h->dev.debug == 5 ? 1 : 0);
+   if (h->dev.dense_path)                                              // the restart rows of all bursts (rtfe_gain.hip)
+      hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
+                         (const BurstScratch *)scratch, ctlp);
    t1(kTBursts);
    if (h->dev.find_zeros && !h->dev.differentiate && h->zeros_kernel) {          // -zeros: the lean kernel of its own (rtfe_zeros.hip)
       t0(kTZeros);
@@ -624,7 +675,30 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       else if (h->dev.ntrks == 7) hipLaunchKernelGGL(k_zeros<7>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);
       else hipLaunchKernelGGL(k_zeros<0>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);
       t1(kTZeros); }
-   else {                                                             // PE, GCR, differentiated peaks, density detection
+   else if (h->dev.dense_path) {                                      // PE, GCR peak detection: sub-segment lists, then a lane per chain (rtfe_dense.hip)
+      const long long dtiles = ds_tiles_for(nrows);
+      unsigned char *deadp = reinterpret_cast<unsigned char *>(wsb + ws_dsdead_off(h, nrows));
+      float2 *bandp = reinterpret_cast<float2 *>(wsb + ws_dsband_off(h, nrows));
+      unsigned char *slotp = reinterpret_cast<unsigned char *>(wsb + ws_dsslot_off(h, nrows));
+      const int dlds = (int)ds_lds_layout(h->dev.ntrks, h->dev.halo_rows, h->dev.ds_pad + kDsTile).total + 64;
+      int dpc = (160 * 1024) / (dlds + 1024);
+      if (dpc > 8) dpc = 8;
+      if (const char *e = getenv("RTFE_DSEG_WGS")) { const int v = atoi(e); if (v >= 1 && v < dpc) dpc = v; }
+      if (dpc < 1) dpc = 1;
+      long long dg = (long long)h->num_cus * dpc;
+      if (dg > dtiles) dg = dtiles;
+      t0(kTDseg);
+      hipLaunchKernelGGL(k_dseg, dim3((unsigned)dg), dim3(kDsThreads), dlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, dtiles, deadp, bandp, slotp, scratch->scr);
+      t1(kTDseg); t0(kTDchain);
+      hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * 16), dim3(64), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+                         scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const float2 *)bandp, (const unsigned char *)slotp, dtiles);
+      hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
+      t1(kTDchain);
+      t0(kTDecode);
+      hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
+                         (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0, (int)kDecodeRedo, ctlp);
+      t1(kTDecode); }
+   else {                                                             // differentiated peaks, density detection (and PE / GCR with RTFE_DENSE_PATH=0)
       t0(kTDecode);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0, (int)kDecodeAll, ctlp);

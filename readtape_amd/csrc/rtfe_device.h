@@ -71,6 +71,18 @@ struct DevCfg {
    int   pk_lds;                  // dynamic LDS bytes of k_sift
    int   pk_fast;                 // k_gain: the steady-state fast path (0: every detection through the general step; tests)
    int   pk_seg_recs;             // records per segment of a chain's steady stretch (k_gain_seg); 0: a chain is one segment
+   // the dense sample path (rtfe_dense.hip): k_dseg -> k_dchain, for peak detection where a window holds a top and a bottom (PE, GCR)
+   int   dense_path;
+   int   nuset;                              // parameter sets that differ in what the FRONT END reads (window, thresholds, AGC flavour; PE: the clock window)
+   int   uset_of[RTFE_MAXPARMSETS];          // parameter set -> distinct set
+   int   uset_rep[RTFE_MAXPARMSETS];         // distinct set -> its first parameter set
+   unsigned uset_mask[RTFE_MAXPARMSETS];     // distinct set -> the parameter sets it stands for (their event regions all receive its events)
+   int   ds_pad;                             // rows in front of a k_dseg tile's own rows that only serve as warm-up (multiple of 64)
+   int   ds_warm[kMaxScreens];               // rows a sub-segment's lane starts early, per window width (>= 3 W)
+   int   ds_cap, ds_slot;                    // records per slot; bytes of a slot (header + records)
+   float ds_band_hi, ds_band_lo;             // a sub-segment's band: [ds_band_lo, 1] x ds_band_hi x (its peak-to-peak amplitude / 4)
+   float ds_quiet_s;                         // a small-signal sub-segment may use the band [its largest margin, infinity) if that starts at or below this scale
+   float ds_sfloor;                          // lower end of every band: the scale (v_avg_height / 4) / agc_gain the candidate screen is built for
    DevParm   parm[RTFE_MAXPARMSETS];
    DevScreen screen[kMaxScreens];
 };

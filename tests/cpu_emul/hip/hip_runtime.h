@@ -35,6 +35,8 @@ struct uint4 { unsigned int x, y, z, w; };
 inline int4 make_int4(int a, int b, int c, int d) { int4 r = {a, b, c, d}; return r; }
 inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 r = {a, b, c, d}; return r; }
 inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; return r; }
+struct float2 { float x, y; };
+inline float2 make_float2(float a, float b) { float2 r = {a, b}; return r; }
 struct float4 { float x, y, z, w; };
 inline float4 make_float4(float a, float b, float c, float d) { float4 r = {a, b, c, d}; return r; }
 extern dim3 threadIdx, blockIdx;      // (of the fiber that is running)
@@ -122,6 +124,7 @@ inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
 inline int atomicExch(int *p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicAnd(int *p, int v) { return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
+inline int atomicMax(int *p, int v) { int old = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (v > old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return old; }
 inline int atomicMin(int *p, int v) { int old = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return old; }
 inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) {
    unsigned long long old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
