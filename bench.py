@@ -304,6 +304,10 @@ def main():
         tally["bad"] += int(((r.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START | frontend.F_STATE_AT_END)) != 0).sum())
     step(0, each=count)
     nevents, bad = tally["events"], tally["bad"]
+    try:                                             # diagnostics of the last scan (what the chains left to the literal detector / the sample path)
+        sst = fe.scan_stats(res)
+    except Exception:
+        sst = None
     if world > 1:
         tot = torch.tensor([nevents, bad, nrows], device=dev, dtype=torch.int64)
         dist.all_reduce(tot)
@@ -331,7 +335,7 @@ def main():
             "vs_baseline": None, "dtype": "i16/f32", "data": "synthetic",
             "config": {"workload": conf["workload"], "rows_per_gpu": nrows, "rows_total": rows_all,
                        "bytes_per_gpu": nrows * cfg.ntrks * 2, "events_per_gpu": nevents, "events_total": nevents_all, "bursts": tally["bursts"],
-                       "flagged_bursts": bad, "parmsets": conf["nparmsets"], "launches_per_step": len(frags),
+                       "flagged_bursts": bad, "parmsets": conf["nparmsets"], "launches_per_step": len(frags), "last_scan_stats": sst,
                        "sharding": ("one tape, time shards (plan_shards), neighbour halo only" if strong else "time shards, neighbour halo only") if world > 1 else "none"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -306,7 +306,9 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       if (getenv("RTFE_DENSE_DEDUP") && atoi(getenv("RTFE_DENSE_DEDUP")) == 0) {      // (tests: every set its own chain)
          d.nuset = c->nparmsets;
          for (int p = 0; p < c->nparmsets; ++p) { d.uset_of[p] = p; d.uset_rep[p] = p; d.uset_mask[p] = 1u << p; } }
-      d.dense_path = !d.peak_path && !d.find_zeros && !d.differentiate && !d.agc_off && (d.mode == RTFE_PE || d.mode == RTFE_GCR);
+      // Opt-in (RTFE_DENSE_PATH=1) in round 4: bit-exact on every test and stress tape, but not yet faster than k_decode (62 vs 43 ms
+      // per 6.7e7 rows for the 8-set GCR sweep, 28 vs 24 ms for one set) - its classification pass and the chains' launch latency are next round's work
+      d.dense_path = 0;
       if (const char *e = getenv("RTFE_DENSE_PATH")) d.dense_path = !d.peak_path && !d.find_zeros && !d.differentiate && !d.agc_off && d.mode != RTFE_WW && atoi(e) != 0;
       int wpad = 64;
       for (int sidx = 0; sidx < d.nscreens; ++sidx) {
@@ -320,10 +322,12 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       if (const char *e = getenv("RTFE_DS_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 63) d.ds_cap = v; }      // (tests: lists that run full)
       d.ds_slot = ((int)sizeof(DsHdr) + d.ds_cap * (int)sizeof(DsRec) + 15) & ~15;
       d.ds_sfloor = (hfloor < 4.0f ? hfloor : 4.0f) / 4.0f / 2.0f;
+      d.ds_lean = getenv("RTFE_DS_LEAN") ? atoi(getenv("RTFE_DS_LEAN")) != 0 : 1;
       d.ds_quiet_s = getenv("RTFE_DS_QUIET_S") ? (float)atof(getenv("RTFE_DS_QUIET_S")) : 0.6f;
       d.ds_band_hi = getenv("RTFE_DS_BAND_HI") ? (float)atof(getenv("RTFE_DS_BAND_HI")) : 1.25f;
       d.ds_band_lo = getenv("RTFE_DS_BAND_LO") ? (float)atof(getenv("RTFE_DS_BAND_LO")) : 1.0f / 3.0f;
-      if ((int)ds_lds_layout(c->ntrks, d.halo_rows, d.ds_pad + kDsTile).total + 64 > 150 * 1024) d.dense_path = 0; }
+      if ((int)ds_lds_layout(c->ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight).total + 64 > 150 * 1024) d.dense_path = 0;
+      if ((d.ds_pad + kDsTile + kDsRight) / kStrip * c->ntrks > 8 * kDsThreads) d.dense_path = 0; }      // (k_dseg keeps a lane's strips of the stale-minimum map in eight registers)
    {
       const int nwalk = c->nparmsets * c->ntrks;
       int rc = (24 * 1024) / (nwalk * 24);
@@ -360,7 +364,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
       if (sf_special(d)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_special(d)), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds); }
-   if (d.dense_path) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dseg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile).total + 64);
+   if (d.dense_path) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dseg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight).total + 64);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    if (getenv("RTFE_VERBOSE") && d.peak_path) {
       int nb = -1;
@@ -680,7 +684,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       unsigned char *deadp = reinterpret_cast<unsigned char *>(wsb + ws_dsdead_off(h, nrows));
       float2 *bandp = reinterpret_cast<float2 *>(wsb + ws_dsband_off(h, nrows));
       unsigned char *slotp = reinterpret_cast<unsigned char *>(wsb + ws_dsslot_off(h, nrows));
-      const int dlds = (int)ds_lds_layout(h->dev.ntrks, h->dev.halo_rows, h->dev.ds_pad + kDsTile).total + 64;
+      const int dlds = (int)ds_lds_layout(h->dev.ntrks, h->dev.halo_rows, h->dev.ds_pad + kDsTile + kDsRight).total + 64;
       int dpc = (160 * 1024) / (dlds + 1024);
       if (dpc > 8) dpc = 8;
       if (const char *e = getenv("RTFE_DSEG_WGS")) { const int v = atoi(e); if (v >= 1 && v < dpc) dpc = v; }
@@ -689,11 +693,15 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (dg > dtiles) dg = dtiles;
       t0(kTDseg);
       hipLaunchKernelGGL(k_dseg, dim3((unsigned)dg), dim3(kDsThreads), dlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, dtiles, deadp, bandp, slotp, scratch->scr);
-      t1(kTDseg); t0(kTDchain);
-      hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * 16), dim3(64), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+      t1(kTDseg);
+      const int dstop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;      // (debugging: 1 = stop behind k_dseg, 2 = behind k_dchain)
+      if (dstop < 2) { skip_rest(); return launch_check("rtfe_scan"); }
+      t0(kTDchain);
+      hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * 16), dim3(64), (size_t)h->dev.ds_slot * 64 + (size_t)kDcCache * 64 * 2, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                          scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const float2 *)bandp, (const unsigned char *)slotp, dtiles);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTDchain);
+      if (dstop < 3) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTDecode);
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0, (int)kDecodeRedo, ctlp);
@@ -713,7 +721,7 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
    if (hipMemcpy(&sc, d_workspace, sizeof sc, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
    out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.scr[3]; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
    for (int i = 0; i < 8; ++i) out[5 + i] = (int64_t)sc.why[i];
-   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)((h->dev.debug == 4 || h->dev.debug == 6) ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
+   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)((h->dev.debug == 4 || h->dev.debug == 6 || h->dev.debug == 8) ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
    return 0; }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

@@ -30,8 +30,9 @@
 namespace rtfe {
 
 constexpr int kDsSub = 128;                    // rows of a sub-segment
-constexpr int kDsJ = 8;                        // sub-segments per tile
+constexpr int kDsJ = 4;                        // sub-segments per tile
 constexpr int kDsTile = kDsSub * kDsJ;         // own rows of a tile
+constexpr int kDsRight = 64;                   // rows behind a tile's own rows: a maybe that begins in the last sub-segment is settled there (multiple of 64)
 constexpr int kDsThreads = 256;
 constexpr int kDsMaxMaybe = 15;
 constexpr int kDsNoJoin = 0xff, kDsNoDoubt = 0xff;
@@ -45,20 +46,47 @@ __device__ __forceinline__ DsRec ds_pack(int nf, int nm, int kind, int ld, int v
    DsRec r; r.w0 = (uint32_t)nf | ((uint32_t)nm << 8) | ((uint32_t)kind << 12) | ((uint32_t)ld << 13);
    r.w1 = (uint32_t)(uint16_t)val | ((uint32_t)dp << 16) | ((uint32_t)dn << 24); return r; }
 
-struct DsLds { unsigned bits, ldpos, band, total; };
+constexpr int kDsUP = 3;                       // distinct sets of one window width classified together (more: further passes over the tile)
+constexpr int kDsPlanes = 6;                   // per (set, track) over the tile's rows: own rows F(ire) Y(maybe) D(oubt) K(ind); warm-up rows F K
+struct DsThr { int r_lo, r_hi, q_lo, q_hi; };  // margins / extremes in int16 codes: >= hi passes for every threshold of the band, <= lo for none
+struct DsLds { unsigned bits, ldpos, cls, thr, bdl, band, mmax, total; };
+__host__ __device__ inline unsigned ds_cstride(int tile_rows) { return (unsigned)(tile_rows / 8 + 8 + 7) & ~7u; }      // bytes of a plane's row of bits (64-bit words, one spare)
 __host__ __device__ inline DsLds ds_lds_layout(int ntrks, int halo_rows, int tile_rows) {
    DsLds L;
    unsigned off = lds_align16((unsigned)ntrks * (unsigned)(halo_rows + tile_rows + 8) * 2u + 16u);
-   L.bits = off;  off = lds_align16(off + (unsigned)ntrks * 5u * lds_bstride(tile_rows));       // (one screen at a time: five kinds as run_screens lays them out, three used)
-   L.ldpos = off; off = lds_align16(off + (unsigned)ntrks * 2u * lds_ldstride(tile_rows));
-   L.band = off;  off = lds_align16(off + (unsigned)kDsJ * RTFE_MAXTRKS * 12u);
+   L.bits = off;  off = lds_align16(off + (unsigned)ntrks * 3u * lds_bstride(tile_rows));       // (one screen at a time: top / bottom candidates, forced rescans)
+   L.ldpos = off; off = lds_align16(off + (unsigned)ntrks * 2u * lds_ldstride(tile_rows));       // left_distance of the window's first maximum | of the reference's (stale) minimum
+   L.cls = off;   off = lds_align16(off + (unsigned)kDsUP * kDsPlanes * (unsigned)ntrks * ds_cstride(tile_rows));
+   L.thr = off;   off = lds_align16(off + (unsigned)kDsUP * kDsJ * (unsigned)ntrks * (unsigned)sizeof(DsThr));
+   L.bdl = off;   off = lds_align16(off + (unsigned)kDsUP * kDsJ * (unsigned)ntrks * 8u);
+   L.band = off;  off = lds_align16(off + (unsigned)kDsJ * (unsigned)ntrks * 8u);
+   L.mmax = off;  off = lds_align16(off + (unsigned)kDsJ * (unsigned)ntrks * 4u);
    L.total = off;
    return L; }
 
+// the margins of a record's maybe rows - the extreme above the higher edge (tops) / the lower edge above it (bottoms), int16 codes: what the
+// reference's two edge comparisons come down to (the nearer edge decides) - four to an 8-byte word behind the record
+template <class ColT> __device__ __forceinline__ int ds_put_margins(DsRec *recs, int count, const ColT &yb, int W, int nf, int nm, int kind, int val) {
+   for (int m0 = 0; m0 < nm; m0 += 4) {
+      uint32_t wd[2] = {0, 0};
+      for (int m = m0; m < nm && m < m0 + 4; ++m) {
+         const int q = nf + m, vl = yb[q - W + 1], vr = yb[q];
+         int mg = kind == 0 ? val - max(vl, vr) : min(vl, vr) - val;
+         mg = mg < 0 ? 0 : (mg > 65535 ? 65535 : mg);
+         wd[(m - m0) >> 1] |= (uint32_t)mg << (16 * ((m - m0) & 1)); }
+      DsRec r; r.w0 = wd[0]; r.w1 = wd[1]; recs[count++] = r; }
+   return count; }
+
 enum { kDsMiss = 0, kDsMaybe = 1, kDsSure = 2 };
+__device__ __forceinline__ int ds_cls(const DsThr &h, bool amp_on, int m, int v) {
+   if (m <= h.r_lo || (amp_on && v <= h.q_lo)) return kDsMiss;
+   return (m >= h.r_hi && (!amp_on || v >= h.q_hi)) ? kDsSure : kDsMaybe; }
 
 // ------------------------------------------------------------------------------------------------
-// k_dseg
+// k_dseg.  Per tile and window width: (1) the candidate screen of rtfe_kernels.hip, all lanes; (2) per row, all lanes: the margins of
+// the window's maximum and of the reference's (possibly stale) minimum, and - per distinct set of that width - what the detector would do
+// at the row if it looked: fire / maybe / doubt / nothing, as bits over the rows; (3) a lane per (set, sub-segment, track) resolves what
+// is sequential - the countdown - on those bits: find the next set bit, one load for the extreme's place, jump behind the countdown.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
                                                      unsigned char *__restrict__ dead, float2 *__restrict__ band, unsigned char *__restrict__ slots,
@@ -68,23 +96,29 @@ __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ 
 #else
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
+   (void)band;
    __shared__ DevCfg cfg;
    __shared__ int s_any, s_amp[RTFE_MAXTRKS];
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
-   const int ntrks = cfg.ntrks, pad = cfg.ds_pad, T = pad + kDsTile, nu = cfg.nuset;
+   const int ntrks = cfg.ntrks, pad = cfg.ds_pad, T = pad + kDsTile + kDsRight, nu = cfg.nuset;
    const DsLds L = ds_lds_layout(ntrks, cfg.halo_rows, T);
    Tile tl;
    tl.x = reinterpret_cast<int16_t *>(smem); tl.halo = cfg.halo_rows; tl.ldw = 0; tl.colof = cfg.trk_to_head; tl.ntrks = ntrks; tl.skew = cfg.skew;
    tl.bits = smem + L.bits; tl.bstride = (int)lds_bstride(T); tl.ldpos = smem + L.ldpos; tl.ldstride = (int)lds_ldstride(T); tl.fd = nullptr;
    tl.reset = -(1ll << 40);                                           // (the regular deskew regime everywhere: k_dchain joins only behind the start-up rows)
-   float2 *s_band = reinterpret_cast<float2 *>(smem + L.band);
-   int *s_ampj = reinterpret_cast<int *>(smem + L.band + kDsJ * RTFE_MAXTRKS * 8);
+   float2 *s_band = reinterpret_cast<float2 *>(smem + L.band);         // [j][t]: the band from the amplitude
+   int *s_mmax = reinterpret_cast<int *>(smem + L.mmax);               // [j][t]: the largest margin of any candidate the sub-segment's lanes can meet
+   DsThr *s_thr = reinterpret_cast<DsThr *>(smem + L.thr);             // [ul][j][t]
+   float2 *s_bdl = reinterpret_cast<float2 *>(smem + L.bdl);           // [ul][j][t]: the band the lane decides against (its slot's header)
+   unsigned char *s_cls = smem + L.cls;                                // [ul][plane][t][cstride]
+   const int cstride = (int)ds_cstride(T);
    const float lsb = cfg.lsb_per_volt;
    const int slot_bytes = cfg.ds_slot, cap = cfg.ds_cap;
    const FastDiv fdn(ntrks);
-   long long t_load = 0, t_scr = 0, t_walk = 0, tq = 0;
+   long long t_load = 0, t_scr = 0, t_walk = 0, t_sld = 0, tq = 0;
    const bool prof = cfg.debug == 7;
+   const int wmax = cfg.halo_rows - kScreenHalo;                       // (>= widest window + 1 + max skew)
    for (long long g = blockIdx.x; g < ntiles; g += gridDim.x) {
       tl.row0 = g * kDsTile - pad; tl.nrows = T;
       __syncthreads();
@@ -93,24 +127,24 @@ __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ 
       load_tile(&cfg, tl, rows, nrows);
       __syncthreads();
       // ---- the band of every (sub-segment, track): from the amplitude of the rows the sub-segment's lanes can see ----
-      {  const int wmax = cfg.halo_rows - kScreenHalo;                  // (>= widest window + 1 + max skew)
-         for (int i = threadIdx.x; i < kDsJ * ntrks; i += blockDim.x) {
-            const int j = fdn.div(i), t = i - j * ntrks;
-            const Col yb = tile_col(tl, t, cfg.skew[t]);
-            int mx = -40000, mn = 40000;
-            #pragma nounroll
-            for (int q = j * kDsSub - wmax; q < pad + (j + 1) * kDsSub; ++q) { const int v = yb[q]; mx = max(mx, v); mn = min(mn, v); }
-            const int amp = mx - mn;
-            atomicMax(&s_amp[t], amp);
-            const float av = (float)amp / lsb;                          // volts, peak to peak
-            // the AGC makes the thresholds follow the signal: (v_avg_height / 4) / agc_gain ~ (recent peak-to-peak height) / 4 <= amplitude / 4
-            float hi = av * cfg.ds_band_hi * 0.25f;
-            float lo = hi * cfg.ds_band_lo; if (lo < cfg.ds_sfloor) lo = cfg.ds_sfloor;
-            if (hi < lo) hi = lo;
-            s_band[j * RTFE_MAXTRKS + t] = make_float2(lo, hi); s_ampj[j * RTFE_MAXTRKS + t] = amp; } }
+      for (int i = threadIdx.x; i < kDsJ * ntrks; i += blockDim.x) {
+         const int j = fdn.div(i), t = i - j * ntrks;
+         const Col yb = tile_col(tl, t, cfg.skew[t]);
+         int mx = -40000, mn = 40000;
+         #pragma nounroll
+         for (int q = j * kDsSub - wmax; q < pad + (j + 1) * kDsSub; q += 2) { const int v0 = yb[q], v1 = yb[q + 1]; mx = max(mx, max(v0, v1)); mn = min(mn, min(v0, v1)); }
+         const int amp = mx - mn;
+         atomicMax(&s_amp[t], amp);
+         const float av = (float)amp / lsb;                             // volts, peak to peak
+         // the AGC makes the thresholds follow the signal: (v_avg_height / 4) / agc_gain ~ (recent peak-to-peak height) / 4 <= amplitude / 4
+         float hi = av * cfg.ds_band_hi * 0.25f;
+         float lo = hi * cfg.ds_band_lo; if (lo < cfg.ds_sfloor) lo = cfg.ds_sfloor;
+         if (hi >= 0.6f && hi < 1.02f) hi = 1.02f;                      // (a block's first peaks meet the fresh detector - baseline 4 V, gain 1 -: its scale is in the band of every signal of usual height)
+         if (hi < lo) hi = lo;
+         s_band[i] = make_float2(lo, hi); }
       __syncthreads();
       if (prof) { const long long t2 = clock64(); t_load += t2 - tq; tq = t2; }
-      bool wrote_any = false;
+      const int tile_lim = (nrows - tl.row0 < (long long)T) ? (int)(nrows - tl.row0) : T;
       for (int s = 0; s < cfg.nscreens; ++s) {
          const DevScreen S = cfg.screen[s];
          // nothing in this tile can rise above the screen: no list (k_dchain reads the flag, not the slots)
@@ -118,134 +152,235 @@ __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ 
          for (int t = 0; t < ntrks; ++t) if (s_amp[t] > S.rise_i) flat = false;
          if (flat) { if (threadIdx.x == 0) dead[g * cfg.nscreens + s] = 1; continue; }
          if (threadIdx.x == 0) s_any = 0;
+         for (int i = threadIdx.x; i < kDsJ * ntrks; i += blockDim.x) s_mmax[i] = 0;
          __syncthreads();
+         const int W = S.W, warm = cfg.ds_warm[s];
          {  const int hs = kScreenHalo / kStrip, nstrips = T / kStrip + hs, per = nstrips * ntrks;
             int any = 0;
-            for (int i = (int)threadIdx.x; i < per; i += blockDim.x) { const int q = fdn.div(i); any |= screen_strip(tl, S, 0, i - q * ntrks, q - hs); }
+            for (int i = (int)threadIdx.x; i < per; i += blockDim.x) {
+               const int q = fdn.div(i), t = i - q * ntrks, strip = q - hs;
+               int mm = 0;
+               any |= screen_strip(tl, S, 0, t, strip, &mm);
+               if (mm > 0 && strip >= 0) {                                // whose lanes look at these rows: the sub-segment that owns them, the next one in its warm-up
+                  const int r0 = strip * kStrip;
+                  int jo = r0 < pad ? 0 : (r0 - pad) / kDsSub;
+                  if (jo > kDsJ - 1) jo = kDsJ - 1;
+                  atomicMax(&s_mmax[jo * ntrks + t], mm);
+                  if (r0 >= pad && jo + 1 < kDsJ && r0 + kStrip > pad + (jo + 1) * kDsSub - warm) atomicMax(&s_mmax[(jo + 1) * ntrks + t], mm); } }
             if (any) s_any = 1; }
          __syncthreads();
          if (prof) { const long long t2 = clock64(); t_scr += t2 - tq; tq = t2; }
          if (!s_any) { if (threadIdx.x == 0) dead[g * cfg.nscreens + s] = 1; __syncthreads(); continue; }
          if (threadIdx.x == 0) dead[g * cfg.nscreens + s] = 0;
-         wrote_any = true;
-         // ---- the lanes: (distinct set of this width, sub-segment, track) ----
-         int us[RTFE_MAXPARMSETS], nus = 0;
-         for (int u = 0; u < nu; ++u) if (cfg.parm[cfg.uset_rep[u]].screen == s) us[nus++] = u;
-         const int W = S.W, warm = cfg.ds_warm[s];
-         const int tile_lim = (nrows - tl.row0 < (long long)T) ? (int)(nrows - tl.row0) : T;
-         for (int task = threadIdx.x; task < nus * kDsJ * ntrks; task += blockDim.x) {
-            const int q = fdn.div(task), t = task - q * ntrks, ul = q / kDsJ, j = q - ul * kDsJ;
-            const int u = us[ul];
-            const DevParm P = cfg.parm[cfg.uset_rep[u]];
-            float2 bd = s_band[j * RTFE_MAXTRKS + t];
-            const bool amp_on = P.min_peak != 0;
-            const u64 *tm = tl.map(0, 0, t), *bm = tl.map(0, 1, t), *am = tl.map(0, 2, t);
-            const unsigned char *ldt = tl.ldmap(0, 0, t), *ldb = tl.ldmap(0, 1, t);
-            const Col yb = tile_col(tl, t, cfg.skew[t]);
-            const int o0 = pad + j * kDsSub, o1 = o0 + kDsSub;
-            const int lim = o1 < tile_lim ? o1 : tile_lim;
-            // A sub-segment of small signal (a gap, a block's first or last rows): the chain that passes through has thresholds from
-            // elsewhere.  If nothing here rises above a level that such thresholds clear, the band is [that level, infinity): no record.
-            if ((float)s_ampj[j * RTFE_MAXTRKS + t] < P.rise * cfg.ds_quiet_s * lsb * 2.0f) {
-               int mmax = 0;
-               #pragma nounroll
-               for (int q = o0 - warm; q < lim; ) {
-                  const int wd = q >> 6;
-                  const u64 c = (tm[wd] | bm[wd]) >> (q & 63);
-                  if (!c) { q = (wd + 1) << 6; continue; }
-                  q += __ffsll((long long)c) - 1;
-                  if (q >= lim) break;
-                  const int lo = q - W + 1, vl = yb[lo], vr = yb[q];
-                  if ((tm[q >> 6] >> (q & 63)) & 1) mmax = max(mmax, (int)yb[lo + ldt[q] - 1] - max(vl, vr));
-                  if ((bm[q >> 6] >> (q & 63)) & 1) mmax = max(mmax, min(vl, vr) - (int)yb[lo + ldb[q] - 1]);      // (the true minimum: the stale one's margin is no larger)
-                  ++q; }
-               const float lo_s = (float)(mmax + 4) / (P.rise * lsb);
-               if (lo_s <= cfg.ds_quiet_s) bd = make_float2(lo_s > cfg.ds_sfloor ? lo_s : cfg.ds_sfloor, 3.0e38f); }
-            // margins in int16 codes: >= r_hi passes for every threshold of the band, <= r_lo for none (k_dchain's exact test has a
-            // guard band of floor(thr * lsb) - 1 .. + 2 around every threshold; one code more on either side here)
-            const float fr = P.rise * bd.y * lsb, fq = P.min_peak * bd.y * lsb;
-            const int r_hi = fr > 1.0e9f ? 0x3fffffff : (int)floorf(fr) + 3, r_lo = (int)floorf(P.rise * bd.x * lsb) - 2;
-            const int q_hi = fq > 1.0e9f ? 0x3fffffff : (int)floorf(fq) + 3, q_lo = (int)floorf(P.min_peak * bd.x * lsb) - 2;
-            auto cls = [&](int m, int v) -> int {
-               if (m <= r_lo || (amp_on && v <= q_lo)) return kDsMiss;
-               return (m >= r_hi && (!amp_on || v >= q_hi)) ? kDsSure : kDsMaybe; };
-            unsigned char *slot = slots + (((size_t)(g * kDsJ + j) * nu + u) * ntrks + t) * (size_t)slot_bytes;
-            DsRec *recs = reinterpret_cast<DsRec *>(slot + sizeof(DsHdr));
-            int n = o0 - warm, blind_until = n - 1;
-            int pk = -1, ppos = 0, pfirst = 0;                            // a pending "maybe": kind, the extreme's row, the first maybe row
-            int count = 0, doubt = -1, start_blind = 0;
-            bool stop = false;
-            #pragma nounroll
-            for (int phase = 0; phase < 2 && !stop; ++phase) {
-               const int plim = phase == 0 ? (o0 < lim ? o0 : lim) : lim;
-               #pragma nounroll
-               while (!stop) {
-                  if (n <= blind_until) n = blind_until + 1;
-                  if (n >= plim) break;
-                  const int wd = n >> 6;
-                  const u64 c = (tm[wd] | bm[wd]) >> (n & 63);
-                  if (!c) { n = (wd + 1) << 6; continue; }
-                  n += __ffsll((long long)c) - 1;
-                  if (n >= plim) break;
-                  const int bit = n & 63, wd2 = n >> 6;
-                  const bool ctop = (tm[wd2] >> bit) & 1, cbot = (bm[wd2] >> bit) & 1;
-                  const int lo = n - W + 1;
-                  const int vl = yb[lo], vr = yb[n];
-                  int tcls = kDsMiss, bcls = kDsMiss, tpos = 0, tval = 0, bpos = 0, bval = 0;
-                  bool unknown = false;
-                  // (the warm-up rows only have to bring the countdown into step - the join checks that they did: a maybe there counts as a hit)
-                  if (ctop) { tpos = lo + ldt[n] - 1; tval = yb[tpos]; tcls = cls(tval - max(vl, vr), tval); if (phase == 0 && tcls == kDsMaybe) tcls = kDsSure; }
-                  if (tcls != kDsSure && cbot) {
-                     const int l = stale_ld(am, ldb, n);                 // the reference's (possibly stale) minimum, from the samples alone
-                     if (l == 0) unknown = phase != 0;
-                     else { bpos = lo + l - 1; bval = yb[bpos]; bcls = cls(min(vl, vr) - bval, -bval);
-                            if (phase == 0 && bcls == kDsMaybe) bcls = kDsSure;
-                            if (bcls != kDsMiss && (bpos <= lo || bpos >= n)) { unknown = phase != 0; bcls = kDsMiss; } } }      // (refine_peak's assert: the literal detector flags it)
-                  int fire = -1, fpos = 0, fval = 0, dbt = -1;
-                  if (unknown) dbt = pk >= 0 ? pfirst : n;
-                  else if (tcls == kDsSure) { fire = 0; fpos = tpos; fval = tval; }
-                  else if (tcls == kDsMaybe) {
-                     if (bcls != kDsMiss || (pk >= 0 && (pk != 0 || ppos != tpos))) dbt = pk >= 0 ? pfirst : n;
-                     else if (pk < 0) { pk = 0; ppos = tpos; pfirst = n; } }
-                  else if (bcls == kDsSure) { fire = 1; fpos = bpos; fval = bval; }
-                  else if (bcls == kDsMaybe) {
-                     if (pk >= 0 && (pk != 1 || ppos != bpos)) dbt = pfirst;
-                     else if (pk < 0) { pk = 1; ppos = bpos; pfirst = n; } }
-                  if (fire >= 0) {
-                     const int nf = pk >= 0 ? pfirst : n;
-                     if (pk >= 0 && (pk != fire || ppos != fpos)) dbt = pfirst;
-                     else if (n - nf > kDsMaxMaybe) dbt = nf;
-                     else if (phase == 1 && count >= cap) dbt = nf;
-                     else {
-                        if (phase == 1) {
-                           const int pv = yb[fpos - 1], nx = yb[fpos + 1];
-                           int dp = fire == 0 ? fval - pv : pv - fval, dn = fire == 0 ? fval - nx : nx - fval;
-                           dp = dp < 0 ? 0 : (dp > 255 ? 255 : dp); dn = dn < 0 ? 0 : (dn > 255 ? 255 : dn);
-                           recs[count++] = ds_pack(nf - o0, n - nf, fire, fpos - nf + W, fval, dp, dn); }
-                        blind_until = fpos + W; pk = -1; } }
-#ifdef RTFE_CPU_EMUL
-                  if (dbt >= 0 && getenv("RTFE_DS_TRACE")) fprintf(stderr, "doubt tile %lld s %d u %d trk %d j %d phase %d row %lld (n %d): unknown %d tcls %d bcls %d pk %d fire %d count %d r %d..%d q %d..%d tm %d bm %d\n", g, s, u, t, j, phase, tl.row0 + dbt, n, (int)unknown, tcls, bcls, pk, fire, count, r_lo, r_hi, q_lo, q_hi,
-                                                                    ctop ? tval - max(vl, vr) : -1, (cbot && !unknown) ? min(vl, vr) - bval : -1);
-#endif
-                  if (dbt >= 0) { doubt = dbt; stop = true; break; }
-                  ++n; }
-               if (phase == 0) {
-                  start_blind = blind_until + 1 - o0; if (start_blind < 0) start_blind = 0;
-                  if (stop || pk >= 0 || start_blind >= kDsNoJoin) { start_blind = kDsNoJoin; stop = true; doubt = -1; } } }
-            if (!stop && pk >= 0) doubt = pfirst;                        // a maybe that the sub-segment's rows did not settle
-            DsHdr h; h.count = (uint8_t)count; h.start_blind = (uint8_t)start_blind;
-            h.doubt = (uint8_t)((doubt >= o0 && start_blind != kDsNoJoin) ? doubt - o0 : kDsNoDoubt); h.flags = 0; h.pad = 0; h.s_lo = bd.x; h.s_hi = bd.y;
-            if (doubt >= 0 && doubt < o0) h.start_blind = kDsNoJoin;      // (cannot happen behind phase 0; belt and braces)
-            *reinterpret_cast<DsHdr *>(slot) = h; }
+         // ---- the reference's stale minimum at every row with a bottom candidate: its left_distance over the true minimum's (every lane its
+         // strips into registers, then - all done reading - over the map in place) ----
+         {  const int nst = T / kStrip, per = nst * ntrks;
+            u64 outs[8];                                                 // (kDsThreads x 8 strips cover the largest tile)
+            int no = 0;
+            for (int i = (int)threadIdx.x; i < per && no < 8; i += blockDim.x, ++no) {
+               const int q = fdn.div(i), t = i - q * ntrks;
+               const u64 *bm = tl.map(0, 1, t), *am = tl.map(0, 2, t);
+               const unsigned char *ldb = tl.ldmap(0, 1, t);
+               unsigned bb = (unsigned)((bm[q >> 3] >> ((q & 7) * 8)) & 0xff);
+               u64 out = 0;
+               while (bb) { const int k = __ffs((int)bb) - 1; bb &= bb - 1; out |= (u64)(unsigned)stale_ld(am, ldb, q * kStrip + k) << (8 * k); }
+               outs[no] = out; }
+            __syncthreads();
+            no = 0;
+            for (int i = (int)threadIdx.x; i < per && no < 8; i += blockDim.x, ++no) {
+               const int q = fdn.div(i), t = i - q * ntrks;
+               *reinterpret_cast<u64 *>(tl.ldmap(0, 1, t) + q * kStrip) = outs[no]; } }
          __syncthreads();
-         if (prof) { const long long t2 = clock64(); t_walk += t2 - tq; tq = t2; } }
-      if (wrote_any)
-         for (int i = threadIdx.x; i < kDsJ * ntrks; i += blockDim.x) { const int j = fdn.div(i), t = i - j * ntrks; band[(size_t)(g * kDsJ + j) * ntrks + t] = s_band[j * RTFE_MAXTRKS + t]; } }
-   if (prof && threadIdx.x == 0) { atomicAdd(&dbg[0], (unsigned long long)t_load); atomicAdd(&dbg[1], (unsigned long long)t_scr); atomicAdd(&dbg[2], (unsigned long long)t_walk); } }
+         if (prof) { const long long t2 = clock64(); t_sld += t2 - tq; tq = t2; }
+         // ---- the distinct sets of this width, kDsUP at a time ----
+         int us_all[RTFE_MAXPARMSETS], nus_all = 0;
+         for (int u = 0; u < nu; ++u) if (cfg.parm[cfg.uset_rep[u]].screen == s) us_all[nus_all++] = u;
+         for (int u0 = 0; u0 < nus_all; u0 += kDsUP) {
+            const int nus = nus_all - u0 < kDsUP ? nus_all - u0 : kDsUP;
+            // (a) every lane's band and thresholds.  A sub-segment of small signal (a gap, a block's first or last rows) is passed by chains
+            // whose thresholds come from elsewhere: if nothing in it rises above a level such thresholds clear, its band is [that level, infinity)
+            for (int i = threadIdx.x; i < nus * kDsJ * ntrks; i += blockDim.x) {
+               const int q = fdn.div(i), t = i - q * ntrks, ul = q / kDsJ, j = q - ul * kDsJ;
+               const DevParm &P = cfg.parm[cfg.uset_rep[us_all[u0 + ul]]];
+               float2 bd = s_band[j * ntrks + t];
+               const float lo_s = (float)(s_mmax[j * ntrks + t] + 4) / (P.rise * lsb);
+               if (lo_s <= cfg.ds_quiet_s) bd = make_float2(lo_s > cfg.ds_sfloor ? lo_s : cfg.ds_sfloor, 3.0e38f);
+               const float fr = P.rise * bd.y * lsb, fq = P.min_peak * bd.y * lsb;
+               DsThr h;
+               h.r_hi = fr > 1.0e9f ? 0x3fffffff : (int)floorf(fr) + 3; h.r_lo = (int)floorf(P.rise * bd.x * lsb) - 2;
+               h.q_hi = fq > 1.0e9f ? 0x3fffffff : (int)floorf(fq) + 3; h.q_lo = (int)floorf(P.min_peak * bd.x * lsb) - 2;
+               s_thr[i] = h; s_bdl[i] = bd; }
+            __syncthreads();
+            // (b) all lanes, a strip of 8 rows of a track each: margins once, then per set the row's outcome
+            {  const int nst = T / kStrip, per = nst * ntrks;
+               const int ppl = ntrks * cstride;                           // bytes of a plane
+               for (int i = (int)threadIdx.x; i < per; i += blockDim.x) {
+                  const int q = fdn.div(i), t = i - q * ntrks;
+                  const u64 *tm = tl.map(0, 0, t), *bm = tl.map(0, 1, t);
+                  const unsigned char *ldt = tl.ldmap(0, 0, t), *sld = tl.ldmap(0, 1, t);
+                  const Col yb = tile_col(tl, t, cfg.skew[t]);
+                  const unsigned tb = (unsigned)((tm[q >> 3] >> ((q & 7) * 8)) & 0xff), bb = (unsigned)((bm[q >> 3] >> ((q & 7) * 8)) & 0xff);
+                  const int r0 = q * kStrip;
+                  unsigned char *cp = s_cls + t * cstride + q;
+                  if (!(tb | bb)) {
+                     for (int ul = 0; ul < nus; ++ul) for (int pl = 0; pl < kDsPlanes; ++pl) cp[(ul * kDsPlanes + pl) * ppl] = 0;
+                     continue; }
+                  int mt[8], tv[8], mb[8], bv[8];
+                  unsigned unk = 0;                                       // rows whose bottom cannot be decided from the samples here (minimum out of reach, or at the window's edge)
+                  #pragma unroll
+                  for (int k = 0; k < 8; ++k) {
+                     const int n = r0 + k, lo = n - W + 1;
+                     const int vl = yb[lo], vr = yb[n];
+                     const int lt = ldt[n], ls = sld[n];
+                     const bool ct = (tb >> k) & 1, cb = (bb >> k) & 1;
+                     const int tpos = ct ? lo + lt - 1 : n, bpos = (cb && ls) ? lo + ls - 1 : n;
+                     const int tval = yb[tpos], bval = yb[bpos];
+                     mt[k] = ct ? tval - max(vl, vr) : -1; tv[k] = tval;
+                     const bool edge = cb && ls && (bpos <= lo || bpos >= n);
+                     mb[k] = (cb && ls && !edge) ? min(vl, vr) - bval : -1; bv[k] = -bval;
+                     if (cb && (!ls || (edge && min(vl, vr) - bval > 0))) unk |= 1u << k; }
+                  // whose band: the sub-segment that owns the rows; the next one where they are among its warm-up rows
+                  const int jo = r0 < pad ? -1 : ((r0 - pad) / kDsSub > kDsJ - 1 ? kDsJ - 1 : (r0 - pad) / kDsSub);
+                  int jw = jo + 1;
+                  if (jw >= kDsJ || r0 + kStrip <= pad + jw * kDsSub - warm) jw = -1;
+                  for (int ul = 0; ul < nus; ++ul) {
+                     const DevParm &P = cfg.parm[cfg.uset_rep[us_all[u0 + ul]]];
+                     const bool amp_on = P.min_peak != 0;
+                     unsigned F = 0, Y = 0, D = 0, K = 0, Fw = 0, Kw = 0;
+                     if (jo >= 0) {
+                        const DsThr h = s_thr[(ul * kDsJ + jo) * ntrks + t];
+                        #pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                           const int tc = ds_cls(h, amp_on, mt[k], tv[k]);
+                           const int bc = ds_cls(h, amp_on, mb[k], bv[k]);
+                           const bool uk = (unk >> k) & 1;
+                           if (tc == kDsSure) F |= 1u << k;
+                           else if (uk) D |= 1u << k;                    // (as the walk of one row did: an undecidable bottom behind a top that is not sure)
+                           else if (tc == kDsMaybe) { if (bc != kDsMiss) D |= 1u << k; else Y |= 1u << k; }
+                           else if (bc == kDsSure) { F |= 1u << k; K |= 1u << k; }
+                           else if (bc == kDsMaybe) { Y |= 1u << k; K |= 1u << k; } } }
+                     if (jw >= 0) {                                       // warm-up rows only bring the countdown into step (the join checks that they did): a maybe counts as a hit
+                        const DsThr h = s_thr[(ul * kDsJ + jw) * ntrks + t];
+                        #pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                           if (r0 + k < pad + jw * kDsSub - warm) continue;
+                           if (ds_cls(h, amp_on, mt[k], tv[k]) != kDsMiss) Fw |= 1u << k;
+                           else if (ds_cls(h, amp_on, mb[k], bv[k]) != kDsMiss) { Fw |= 1u << k; Kw |= 1u << k; } } }
+                     unsigned char *o = cp + ul * kDsPlanes * ppl;
+                     o[0] = (unsigned char)F; o[ppl] = (unsigned char)Y; o[2 * ppl] = (unsigned char)D; o[3 * ppl] = (unsigned char)K; o[4 * ppl] = (unsigned char)Fw; o[5 * ppl] = (unsigned char)Kw; } } }
+            __syncthreads();
+            if (prof) { const long long t2 = clock64(); t_sld += t2 - tq; tq = t2; }
+            // (c) the lanes: (distinct set, sub-segment, track) - the countdown on the bits
+            for (int task = threadIdx.x; task < nus * kDsJ * ntrks; task += blockDim.x) {
+               const int q = fdn.div(task), t = task - q * ntrks, ul = q / kDsJ, j = q - ul * kDsJ;
+               const int u = us_all[u0 + ul];
+               const DevParm P = cfg.parm[cfg.uset_rep[u]];
+               const bool amp_on = P.min_peak != 0;
+               const DsThr h = s_thr[task];
+               const float2 bd = s_bdl[task];
+               const int ppl = ntrks * cstride;
+               const u64 *pF = reinterpret_cast<const u64 *>(s_cls + (ul * kDsPlanes) * ppl + t * cstride);
+               const u64 *pY = reinterpret_cast<const u64 *>(s_cls + (ul * kDsPlanes + 1) * ppl + t * cstride), *pD = reinterpret_cast<const u64 *>(s_cls + (ul * kDsPlanes + 2) * ppl + t * cstride);
+               const u64 *pK = reinterpret_cast<const u64 *>(s_cls + (ul * kDsPlanes + 3) * ppl + t * cstride);
+               const u64 *pFw = reinterpret_cast<const u64 *>(s_cls + (ul * kDsPlanes + 4) * ppl + t * cstride), *pKw = reinterpret_cast<const u64 *>(s_cls + (ul * kDsPlanes + 5) * ppl + t * cstride);
+               const unsigned char *ldt = tl.ldmap(0, 0, t), *sld = tl.ldmap(0, 1, t);
+               const Col yb = tile_col(tl, t, cfg.skew[t]);
+               const int o0 = pad + j * kDsSub, o1 = o0 + kDsSub;
+               const int lim = o1 < tile_lim ? o1 : tile_lim;
+               unsigned char *slot = slots + (((size_t)(g * kDsJ + j) * nu + u) * ntrks + t) * (size_t)slot_bytes;
+               DsRec *recs = reinterpret_cast<DsRec *>(slot + sizeof(DsHdr));
+               int n_iter = 0, n_fire = 0;
+               const long long tw0 = prof ? clock64() : 0;
+               // warm-up: from o0 - warm, no countdown pending
+               int n = o0 - warm, blind_until = n - 1;
+               {  const int plim = o0 < lim ? o0 : lim;
+                  #pragma nounroll
+                  while (n < plim) {
+                     const int wd = n >> 6;
+                     const u64 c = pFw[wd] >> (n & 63);
+                     if (!c) { n = (wd + 1) << 6; continue; }
+                     n += __ffsll((long long)c) - 1;
+                     if (n >= plim) break;
+                     const int ld = ((pKw[n >> 6] >> (n & 63)) & 1) ? sld[n] : ldt[n];
+                     blind_until = n + ld;                               // = the extreme's row + W (src/decoder.c:741)
+                     n = blind_until + 1; ++n_iter; } }
+               int start_blind = blind_until + 1 - o0; if (start_blind < 0) start_blind = 0;
+               int count = 0, doubt = -1;
+               int pk = -1, ppos = 0, pfirst = 0;                         // a pending "maybe": kind, the extreme's row, the first maybe row
+               if (start_blind >= kDsNoJoin) start_blind = kDsNoJoin;
+               else {
+                  n = blind_until + 1 > o0 ? blind_until + 1 : o0;
+                  #pragma nounroll
+                  while (n < lim) {
+                     const int wd = n >> 6;
+                     const u64 wF = pF[wd], wY = pY[wd], wD = pD[wd];
+                     const u64 c = (wF | wY | wD) >> (n & 63);
+                     if (!c) { n = (wd + 1) << 6; continue; }
+                     n += __ffsll((long long)c) - 1;
+                     if (n >= lim) break;
+                     ++n_iter;
+                     const int bit = n & 63;
+                     if ((wD >> bit) & 1) { doubt = pk >= 0 ? pfirst : n; break; }
+                     const int kind = (int)((pK[wd] >> bit) & 1);
+                     const int pos = n - W + (kind ? (int)sld[n] : (int)ldt[n]);
+                     if ((wY >> bit) & 1) {
+                        if (pk >= 0 && (pk != kind || ppos != pos)) { doubt = pfirst; break; }
+                        if (pk < 0) { pk = kind; ppos = pos; pfirst = n; }
+                        ++n; continue; }
+                     const int nf = pk >= 0 ? pfirst : n;                 // it fires
+                     if ((pk >= 0 && (pk != kind || ppos != pos)) || n - nf > kDsMaxMaybe || count + 1 + (n - nf + 3) / 4 > cap) { doubt = nf; break; }
+                     {  const int fval = yb[pos], pv = yb[pos - 1], nx = yb[pos + 1];
+                        int dp = kind == 0 ? fval - pv : pv - fval, dn = kind == 0 ? fval - nx : nx - fval;
+                        dp = dp < 0 ? 0 : (dp > 255 ? 255 : dp); dn = dn < 0 ? 0 : (dn > 255 ? 255 : dn);
+                        recs[count++] = ds_pack(nf - o0, n - nf, kind, pos - nf + W, fval, dp, dn);
+                        if (n > nf) count = ds_put_margins(recs, count, yb, W, nf, n - nf, kind, fval); }
+                     pk = -1; ++n_fire;
+                     n = pos + W + 1; }
+                  // a maybe that began in the own rows is settled on the rows behind them (a record belongs to the sub-segment of its FIRST maybe row;
+                  // the next sub-segment's warm-up passes over the extreme as fired): those rows one at a time, against this lane's thresholds
+                  if (doubt < 0 && pk >= 0) {
+                     const u64 *tm = tl.map(0, 0, t), *bm = tl.map(0, 1, t);
+                     int plim = pfirst + kDsMaxMaybe + 1; if (plim > tile_lim) plim = tile_lim;
+                     bool fired = false;
+                     #pragma nounroll
+                     for (n = lim; n < plim && !fired && doubt < 0; ++n) {                  // (from the first row behind the own rows: what the bits say there is the NEXT sub-segment's view)
+                        const int lo = n - W + 1, vl = yb[lo], vr = yb[n];
+                        const bool ct = (tm[n >> 6] >> (n & 63)) & 1, cb = (bm[n >> 6] >> (n & 63)) & 1;
+                        const int ls = cb ? (int)sld[n] : 0;
+                        const int tpos = ct ? lo + ldt[n] - 1 : n, bpos = ls ? lo + ls - 1 : n;
+                        const int tval = yb[tpos], bval = yb[bpos];
+                        const int tc = ct ? ds_cls(h, amp_on, tval - max(vl, vr), tval) : kDsMiss;
+                        const bool edge = ls && (bpos <= lo || bpos >= n);
+                        const int bc = (ls && !edge) ? ds_cls(h, amp_on, min(vl, vr) - bval, -bval) : kDsMiss;
+                        const bool uk = cb && (!ls || (edge && min(vl, vr) - bval > 0));
+                        int fk = -1, fp = 0;
+                        if (tc == kDsSure) { fk = 0; fp = tpos; }
+                        else if (uk) doubt = pfirst;
+                        else if (tc == kDsMaybe) { if (bc != kDsMiss || pk != 0 || ppos != tpos) doubt = pfirst; }
+                        else if (bc == kDsSure) { fk = 1; fp = bpos; }
+                        else if (bc == kDsMaybe) { if (pk != 1 || ppos != bpos) doubt = pfirst; }
+                        if (fk >= 0) {
+                           if (pk != fk || ppos != fp || n - pfirst > kDsMaxMaybe || count + 1 + (n - pfirst + 3) / 4 > cap) doubt = pfirst;
+                           else {
+                              const int fval = yb[fp], pv = yb[fp - 1], nx = yb[fp + 1];
+                              int dp = fk == 0 ? fval - pv : pv - fval, dn = fk == 0 ? fval - nx : nx - fval;
+                              dp = dp < 0 ? 0 : (dp > 255 ? 255 : dp); dn = dn < 0 ? 0 : (dn > 255 ? 255 : dn);
+                              recs[count++] = ds_pack(pfirst - o0, n - pfirst, fk, fp - pfirst + W, fval, dp, dn);
+                              count = ds_put_margins(recs, count, yb, W, pfirst, n - pfirst, fk, fval);
+                              fired = true; pk = -1; } } }
+                     if (!fired && doubt < 0) doubt = pfirst; } }
+               DsHdr hd; hd.count = (uint8_t)count; hd.start_blind = (uint8_t)start_blind;
+               hd.doubt = (uint8_t)((doubt >= o0 && start_blind != kDsNoJoin) ? doubt - o0 : kDsNoDoubt); hd.flags = 0; hd.pad = 0; hd.s_lo = bd.x; hd.s_hi = bd.y;
+               *reinterpret_cast<DsHdr *>(slot) = hd;
+               if (prof) { atomicAdd(&dbg[3], (unsigned long long)n_iter); atomicAdd(&dbg[4], (unsigned long long)n_fire); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)(clock64() - tw0)); } }
+            __syncthreads();
+            if (prof) { const long long t2 = clock64(); t_walk += t2 - tq; tq = t2; } } } }
+   if (prof && threadIdx.x == 0) { atomicAdd(&dbg[0], (unsigned long long)t_load); atomicAdd(&dbg[1], (unsigned long long)t_scr); atomicAdd(&dbg[2], (unsigned long long)t_walk); atomicAdd(&dbg[7], (unsigned long long)t_sld); } }
 
 // ------------------------------------------------------------------------------------------------
 // k_dchain
 // ------------------------------------------------------------------------------------------------
+constexpr int kDcCache = kDsSub + 64;          // rows of a literal stretch a lane keeps in LDS: up to kDsSub rows and the window + 2 in front of them
 struct DcRows {                // the detector's input straight from HBM: row n of track t after -invert and the deskew FIFO (src/decoder.c:820-830)
    const int16_t *col; int P, sgn, d; long long reset;
    __device__ __forceinline__ int operator()(long long n) const {
@@ -257,6 +392,16 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                                                uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                                const unsigned char *__restrict__ dead, const float2 *__restrict__ band, const unsigned char *__restrict__ slots, long long ntiles) {
    __shared__ float s_heights[64 * 10];
+#ifdef RTFE_CPU_EMUL
+   unsigned char *smem = g_dyn_smem;
+#else
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
+   // a lane's slot goes through LDS (unit j of lane l at [j][l]: 16 bytes - the header, then two records each): all of its loads from HBM are
+   // in flight together, one round trip per sub-segment instead of one per record
+   uint4 *s_slot = reinterpret_cast<uint4 *>(smem);
+   // ... and so do the rows of a literal stretch: the detector's input of rows [cbase, cbase + kDcCache) of lane l at [k][l]
+   int16_t *s_y = reinterpret_cast<int16_t *>(smem + (size_t)cfgp->ds_slot * 64);
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nu = cfg.nuset, nwalk = nu * ntrks;
    const int lane = threadIdx.x;
@@ -314,21 +459,42 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
             else w.flags |= RTFE_F_EVENT_OVERFLOW;
             ++w.nevents; dead_chain = true; return; }
          update_thresholds(w, P, lsb); };
+      const bool lean_ok = !agc_off && P.agc_window == 0 && P.agc_alpha != 0 && cmode != RTFE_PE && cmode != RTFE_WW && cfg.ds_lean != 0;
+      auto fatal_marker = [&](long long n, int ld) {                      // src/decoder.c:782, as in fire()
+         w.flags |= RTFE_F_AGC_FATAL;
+         if (w.nevents < cap) {
+            rtfe_event e = {};
+            e.sample = (uint32_t)(n + ld + 1 - reset); e.trk = (uint8_t)trk; e.flags = RTFE_EV_FATAL;
+            for (unsigned m = pmask; m; m &= m - 1) { const int p = __ffs((int)m) - 1; e.parmset = (uint8_t)p; evb[(size_t)(p * ntrks + trk) * cap + w.nevents] = e; } }
+         else w.flags |= RTFE_F_EVENT_OVERFLOW;
+         ++w.nevents; dead_chain = true; };
       // ---- the literal detector (src/decoder.c:751-810 on the samples in HBM): state after the last row it processed ----
       int lmx = 0, lmn = 0, lcd = 0;
       bool synced = false;                                               // a forced rescan of a full, regular window was seen: from there the stale minimum is what k_dseg derives
+      long long cache0 = 0;                                              // first row of the lane's LDS cache
+      auto yc = [&](long long n) -> int { return (int)s_y[(int)(n - cache0) * 64 + lane]; };
+      auto fill_cache = [&](long long first, long long last) {           // rows [first, last): every load on its way before the first is waited for
+         cache0 = first;
+         #pragma nounroll
+         for (long long r = first; r < last; r += 16) {
+            int t16[16];
+            #pragma unroll
+            for (int k = 0; k < 16; ++k) t16[k] = r + k < last ? y(r + k) : 0;
+            #pragma unroll
+            for (int k = 0; k < 16; ++k) if (r + k < last) s_y[(int)(r + k - first) * 64 + lane] = (int16_t)t16[k]; } };
+      auto rescan_c = [&](long long lo, long long hi) { int mx = -0x7fffffff, mn = 0x7fffffff; for (long long j = lo; j <= hi; ++j) { const int v = yc(j); mx = max(mx, v); mn = min(mn, v); } lmx = mx; lmn = mn; };
       auto rescan = [&](long long lo, long long hi) { int mx = -0x7fffffff, mn = 0x7fffffff; for (long long j = lo; j <= hi; ++j) { const int v = y(j); mx = max(mx, v); mn = min(mn, v); } lmx = mx; lmn = mn; };
-      auto lit_step = [&](long long n) {
+      auto lit_step = [&](long long n) {                                  // (rows n - W - 1 .. n are in the cache)
          if (n < start) return;
-         if (n == start) { const int v = y(n); lmx = v; lmn = v; lcd = 0; w.t_lastpeak = time_of(&cfg, row_base + n); return; }      // src/decoder.c:855-861
+         if (n == start) { const int v = yc(n); lmx = v; lmn = v; lcd = 0; w.t_lastpeak = time_of(&cfg, row_base + n); return; }      // src/decoder.c:855-861
          const bool popped = n - start + 1 > W;
          const long long lo = popped ? n - W + 1 : start;
-         const int vnow = y(n);
-         const int old_left = popped ? y(n - W) : 0;
+         const int vnow = yc(n);
+         const int old_left = popped ? yc(n - W) : 0;
          if (vnow > lmx) lmx = vnow;
-         if (old_left == lmx || old_left == lmn) { if (popped && old_left == lmx && n >= fast_from) synced = true; rescan(lo, n); }
+         if (old_left == lmx || old_left == lmn) { if (popped && old_left == lmx && n >= fast_from) synced = true; rescan_c(lo, n); }
          if (lcd) { --lcd; return; }
-         const int vli = y(lo);
+         const int vli = yc(lo);
          // the reference's comparisons (src/decoder.c:788-805): on the codes where clear, in floats inside the guard band
          bool top = above_by(lmx, vli, w.rise, w.rise_lo, w.rise_hi, mv) && above_by(lmx, vnow, w.rise, w.rise_lo, w.rise_hi, mv)
                     && (w.reqmin == 0 || lmx >= w.min_hi || (lmx > w.min_lo && volt(lmx, mv) > w.reqmin));
@@ -337,10 +503,10 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
          if (top || bot) {
             const int val = top ? lmx : lmn;
             long long p = lo;
-            while (p <= n && y(p) != val) ++p;
+            while (p <= n && yc(p) != val) ++p;
             if (p > n || p == lo || p == n) { w.flags |= RTFE_F_DETECTOR_FATAL; return; }      // src/decoder.c:709-710,748
             const int ld = (int)(p - lo) + 1;
-            fire(n, ld, val, top, y(p - 1), y(p + 1));
+            fire(n, ld, val, top, yc(p - 1), yc(p + 1));
             lcd = ld; } };
       // the literal state behind row n0 - 1 from the samples alone: the last forced rescan in front of it (the sample leaving the window
       // is its maximum), the bookkeeping of src/decoder.c:757-775 from there
@@ -350,9 +516,9 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
          long long h = n0 - 1;
          for (; h >= lowlim; --h) {
             const int v = y(h - W);
-            bool dom = true;
-            for (int k = 1; k <= W; ++k) if (y(h - W + k) > v) { dom = false; break; }
-            if (dom) break; }
+            int mxw = -0x7fffffff;
+            for (int k = 1; k <= W; ++k) mxw = max(mxw, y(h - W + k));    // (no early way out: W independent loads, one round trip)
+            if (mxw <= v) break; }
          if (h < lowlim) return false;
          rescan(h - W + 1, h);
          for (long long r = h + 1; r <= n0 - 1; ++r) {
@@ -368,60 +534,117 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
       long long cur = reset;                                              // next row to process
       long long blind_until = -1;                                         // (record mode)
       bool lit = true;
+      long long no_join_before = 0;                                       // (behind a doubt the rest of its sub-segment is the literal detector's)
+      long long rounds_left = (stop > reset ? (stop - reset) : 0) / 2 + 64;     // (every round moves `cur` on; belt and braces against a loop that does not)
       unsigned n_lit_rows = 0, n_rec_ev = 0, n_doubt = 0, n_nojoin = 0;
       // (every lane of the wave goes through the same rounds: the emulator's ballot needs all of them)
+      const bool prof = cfg.debug == 8;
+      long long pt_join = 0, pt_rec = 0, pt_lit = 0, pn_rounds = 0, pn_litrounds = 0, ptq = 0;
       #pragma nounroll
       while (__ballot(!done) != 0ull) {
+         if (prof) { ptq = clock64(); ++pn_rounds; }
          if (done) continue;
          if (dead_chain || cur >= stop) { done = true; continue; }
+         if (--rounds_left < 0) { failed = true; done = true; continue; }
          const bool at_bnd = (cur % kDsSub) == 0;
          const long long seg = cur / kDsSub, tile = seg / kDsJ;
+         if (w.thr_dirty) update_thresholds(w, P, lsb);                   // (the join check and the literal detector read the exact thresholds)
          bool join = false;
-         const DsHdr *hp = nullptr;
+         int h_count = 0, h_sb = kDsNoJoin, h_doubt = kDsNoDoubt;
          float2 bd = make_float2(cfg.ds_sfloor, 3.0e38f);
          bool tile_dead = false;
-         if (at_bnd && cur >= fast_from && (synced || !lit) && tile < ntiles) {
-            tile_dead = dead[tile * cfg.nscreens + sc] != 0;
+         if (at_bnd && cur >= fast_from && cur >= no_join_before && (synced || !lit) && tile < ntiles) {
+            const unsigned char dflag = dead[tile * cfg.nscreens + sc];
+            {  // (the slot's loads beside the flag's: a dead tile's slot holds nothing, and nothing of it is used)
+               const uint4 *gp = reinterpret_cast<const uint4 *>(slots + (((size_t)seg * nu + u) * ntrks + trk) * (size_t)slot_bytes);
+               const int nq = slot_bytes >> 4;
+               #pragma nounroll
+               for (int j0 = 0; j0 < nq; j0 += 9) {
+                  uint4 tq[9];
+                  #pragma unroll
+                  for (int j = 0; j < 9; ++j) if (j0 + j < nq) tq[j] = gp[j0 + j];
+                  #pragma unroll
+                  for (int j = 0; j < 9; ++j) if (j0 + j < nq) s_slot[(j0 + j) * 64 + lane] = tq[j]; } }
+            tile_dead = dflag != 0;
             if (tile_dead) join = in_band(bd);                             // nothing can rise above the screen: no countdown to agree on
             else {
-               hp = reinterpret_cast<const DsHdr *>(slots + (((size_t)seg * nu + u) * ntrks + trk) * (size_t)slot_bytes);
-               bd = make_float2(hp->s_lo, hp->s_hi);
+               {  const uint4 h4 = s_slot[lane]; h_count = (int)(h4.x & 0xff); h_sb = (int)((h4.x >> 8) & 0xff); h_doubt = (int)((h4.x >> 16) & 0xff);
+                  bd = make_float2(__uint_as_float(h4.y), __uint_as_float(h4.z)); }
                long long mb = lit ? (long long)lcd : blind_until - cur + 1;
                if (mb < 0) mb = 0;
-               join = hp->start_blind != kDsNoJoin && mb == (long long)hp->start_blind && in_band(bd);
+               join = h_sb != kDsNoJoin && mb == (long long)h_sb && in_band(bd);
                if (!join) ++n_nojoin;
 #ifdef RTFE_CPU_EMUL
-               if (!join && getenv("RTFE_DS_TRACE")) fprintf(stderr, "nojoin b %d u %d trk %d row %lld lit %d: start_blind %d mine %lld band %.3f..%.3f rise %.4f (%.4f..%.4f)\n", b, u, trk, cur, (int)lit, (int)hp->start_blind, mb, bd.x, bd.y, w.rise, P.rise * bd.x, P.rise * bd.y);
+               if (!join && getenv("RTFE_DS_TRACE")) fprintf(stderr, "nojoin b %d u %d trk %d row %lld lit %d: start_blind %d mine %lld band %.3f..%.3f rise %.4f (%.4f..%.4f)\n", b, u, trk, cur, (int)lit, h_sb, mb, bd.x, bd.y, w.rise, P.rise * bd.x, P.rise * bd.y);
 #endif
                } }
+         if (prof) { const long long t2 = clock64(); pt_join += t2 - ptq; ptq = t2; }
          if (join) {
             if (lit) { blind_until = cur - 1 + lcd; lit = false; }
             const long long r0 = cur;
             long long next = r0 + kDsSub;                                 // where the chain goes on
             bool to_lit = false;
             if (!tile_dead) {
-               const DsHdr h = *hp;
-               const DsRec *recs = reinterpret_cast<const DsRec *>(reinterpret_cast<const unsigned char *>(hp) + sizeof(DsHdr));
+               // (the band's edges a little inside: an approximate threshold between them is an exact one inside the band)
+               const float band_rlo = P.rise * bd.x * 1.00001f, band_rhi = P.rise * bd.y * 0.99999f, band_qlo = P.min_peak * bd.x * 1.00001f, band_qhi = P.min_peak * bd.y * 0.99999f;
                #pragma nounroll
-               for (int k = 0; k < (int)h.count; ++k) {
-                  const DsRec rc = recs[k];
+               for (int k = 0; k < h_count; ++k) {
+                  const uint4 r4 = s_slot[(1 + (k >> 1)) * 64 + lane];
+                  DsRec rc; rc.w0 = (k & 1) ? r4.z : r4.x; rc.w1 = (k & 1) ? r4.w : r4.y;
                   const int nfr = (int)(rc.w0 & 0xff), nm = (int)((rc.w0 >> 8) & 0xf), kind = (int)((rc.w0 >> 12) & 1), ld0 = (int)((rc.w0 >> 13) & 0x3f);
                   const int val = (int)(int16_t)(rc.w1 & 0xffff), dp = (int)((rc.w1 >> 16) & 0xff), dn = (int)(rc.w1 >> 24);
                   const long long nf = r0 + nfr;
                   if (nf >= stop) { next = stop; break; }
-                  // which of the maybe rows fires: the reference's comparison on the two samples at the window's edges
-                  long long n = nf + nm;
-                  for (int m = 0; m < nm; ++m) {
-                     const long long q = nf + m;
-                     const int vl = y(q - W + 1), vr = y(q);
-                     const bool hit = kind == 0
-                        ? (above_by(val, vl, w.rise, w.rise_lo, w.rise_hi, mv) && above_by(val, vr, w.rise, w.rise_lo, w.rise_hi, mv)
-                           && (w.reqmin == 0 || val >= w.min_hi || (val > w.min_lo && volt(val, mv) > w.reqmin)))
-                        : (below_by(val, vl, w.rise, w.rise_lo, w.rise_hi, mv) && below_by(val, vr, w.rise, w.rise_lo, w.rise_hi, mv)
-                           && (w.reqmin == 0 || -val >= w.min_hi || (-val > w.min_lo && volt(val, mv) < -w.reqmin)));
-                     if (hit) { n = q; break; } }
+                  // which of the maybe rows fires: the reference's comparison against the nearer edge, from the margin the record carries
+                  // (the words behind it); exact thresholds for that
+                  long long n = nf;
+                  if (nm) {
+                     if (w.thr_dirty) update_thresholds(w, P, lsb);
+                     n = nf + nm;
+                     const bool amp_ok = w.reqmin == 0 || (kind == 0 ? (val >= w.min_hi || (val > w.min_lo && volt(val, mv) > w.reqmin))
+                                                                    : (-val >= w.min_hi || (-val > w.min_lo && volt(val, mv) < -w.reqmin)));
+                     for (int m = 0; m < nm; ++m) {
+                        const int kk = k + 1 + (m >> 2);
+                        const uint4 e4 = s_slot[(1 + (kk >> 1)) * 64 + lane];
+                        const uint32_t ew = (m & 2) ? ((kk & 1) ? e4.w : e4.y) : ((kk & 1) ? e4.z : e4.x);
+                        const int mg = (int)((ew >> (16 * (m & 1))) & 0xffff);
+                        const bool hit = amp_ok && (kind == 0 ? above_by(val, val - mg, w.rise, w.rise_lo, w.rise_hi, mv) : below_by(val, val + mg, w.rise, w.rise_lo, w.rise_hi, mv));
+                        if (hit) { n = nf + m; break; } }
+                     k += (nm + 3) >> 2; }
                   if (n >= stop) { next = stop; break; }
                   const int ld = ld0 - (int)(n - nf);
+                  // ---- the record in steady state (NRZI / GCR: the baseline fixed, the alpha filter): straight-line code.  refine_peak's threshold
+                  // from a 1-ulp reciprocal with a guard code more on either side (a neighbour inside the guard: the exact code); the thresholds only
+                  // as far as the band check needs them (exact ones are made when something reads them) ----
+                  if (lean_ok && w.peakcount > 15 && w.v_avg_height_count == 0 && w.nevents < cap) {
+                     const int ti = (int)(0.005f * fast_rcp(w.agc_gain) * lsb);
+                     const bool clear = (dp <= ti - 2 || dp >= ti + 3) && (dn <= ti - 2 || dn >= ti + 3) && ti >= 3 && ti + 4 < 255;
+                     int adjcode;
+                     if (clear) { const bool pclose = dp <= ti - 2, nclose = dn <= ti - 2; adjcode = (pclose && !nclose) ? 1 : ((nclose && !pclose) ? 2 : 0); }
+                     else {
+                        int iprev = kind == 0 ? val - dp : val + dp, inext = kind == 0 ? val - dn : val + dn;
+                        if (ti + 4 >= 255 || ti < 3) { const long long p = n - W + ld; iprev = y(p - 1); inext = y(p + 1); }
+                        adjcode = refine_code(&cfg, val, iprev, inext, w.agc_gain, kind == 0); }
+                     const float vp = (float)((double)val * (1.0 / 32767.0)) * mv;      // == volt(val, mv) for every int16 code (the quotient's rounding: checked for all 65 536)
+                     rtfe_event e;
+                     e.sample = (uint32_t)(n - reset); e.v_peak = (cfg.invert && vp == 0.0f) ? -0.0f : vp; e.agc_gain = w.agc_gain;
+                     e.trk = (uint8_t)trk; e.flags = (uint8_t)(kind | (adjcode << 1)); e.left_distance = (uint8_t)ld;
+                     for (unsigned m = pmask; m; m &= m - 1) { const int p = __ffs((int)m) - 1; e.parmset = (uint8_t)p; evb[(size_t)(p * ntrks + trk) * cap + w.nevents] = e; }
+                     if (kind == 0) w.v_top = vp; else w.v_bot = vp;
+                     ++w.nevents; ++w.peakcount;
+                     const float lastheight = w.v_lasttop - w.v_lastbot;            // src/decoder.c:505-512 (both callbacks adjust in steady state: src/decode_gcr.c:850,864)
+                     if (lastheight > 0) { float gain = w.v_avg_height / lastheight; gain = P.agc_alpha * gain + (1 - P.agc_alpha) * w.agc_gain; if (gain > 2.0f) gain = 2.0f; w.agc_gain = gain; }
+                     if (kind == 0) w.v_lasttop = vp; else w.v_lastbot = vp;
+                     ++n_rec_ev;
+                     blind_until = n + ld;
+                     if (!(w.agc_gain > 0)) { w.thr_dirty = true; fatal_marker(n, ld); break; }
+                     const float sa = w.v_avg_height * 0.25f * fast_rcp(w.agc_gain), ra = P.rise * sa, qa = P.min_peak * sa;
+                     w.thr_dirty = true;
+                     const bool inb = ra >= band_rlo && ra <= band_rhi && (!amp_on || (qa >= band_qlo && qa <= band_qhi));
+                     if (!inb) { update_thresholds(w, P, lsb); if (!in_band(bd)) { next = n + 1; to_lit = true; break; } }
+                     continue; }
+                  // ---- every other record (a block's first peaks, PE, the window AGC): the general step ----
+                  if (w.thr_dirty) update_thresholds(w, P, lsb);
                   const long long p = n - W + ld;
                   // refine_peak's neighbours from their distances; a clamped distance only matters if the threshold reaches it
                   int iprev = kind == 0 ? val - dp : val + dp, inext = kind == 0 ? val - dn : val + dn;
@@ -432,26 +655,35 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                   blind_until = n + ld;
                   if (dead_chain) break;
                   if (!in_band(bd)) { next = n + 1; to_lit = true; break; } }   // the thresholds left the band: what this list says about the rows behind n is not proven
-               if (!dead_chain && !to_lit && next == r0 + kDsSub && h.doubt != kDsNoDoubt) { next = r0 + h.doubt; to_lit = true; ++n_doubt; } }
+               if (!dead_chain && !to_lit && next == r0 + kDsSub && h_doubt != kDsNoDoubt) { next = r0 + h_doubt; to_lit = true; ++n_doubt; } }
             cur = next;
+            if (prof) { const long long t2 = clock64(); pt_rec += t2 - ptq; ptq = t2; }
             if (to_lit && cur < stop) {
                if (!resync(cur, blind_until)) { failed = true; done = true; }
+               no_join_before = (cur / kDsSub + 1) * kDsSub;
                lit = true; }
             continue; }
          // ---- literal rows up to the next sub-segment boundary ----
          if (!lit) { if (!resync(cur, blind_until)) { failed = true; done = true; continue; } lit = true; }
          long long end = (seg + 1) * kDsSub;
          if (end > stop) end = stop;
+         {  long long first = cur - W - 1; if (first < reset) first = reset;      // (nothing in front of the restart row is ever read)
+            fill_cache(first, end); }
          #pragma nounroll
          for (long long n = cur; n < end && !dead_chain; ++n) lit_step(n);
          n_lit_rows += (unsigned)(end - cur);
-         cur = end; }
+         cur = end;
+         if (prof) { const long long t2 = clock64(); pt_lit += t2 - ptq; ptq = t2; ++pn_litrounds; } }
+      if (prof && lane == 0) { atomicAdd(&scratch->dbg2[0], (unsigned long long)pt_join); atomicAdd(&scratch->dbg2[1], (unsigned long long)pt_rec); atomicAdd(&scratch->dbg2[2], (unsigned long long)pt_lit);
+                               atomicAdd(&scratch->dbg2[3], (unsigned long long)pn_rounds); atomicAdd(&scratch->dbg2[4], (unsigned long long)pn_litrounds); atomicAdd(&scratch->dbg2[5], 1ull); }
       // ---- publish ----
       if (!active) continue;
       if (failed) atomicExch(&ctl[b].status, (int)kBurstNeedsFull);
       const unsigned int ne = w.nevents < cap ? w.nevents : cap;
       for (unsigned m = pmask; m; m &= m - 1) { const int p = __ffs((int)m) - 1; counts[((size_t)b * cfg.nparm + p) * ntrks + trk] = ne; }
-      if (w.flags) atomicOr(&ctl[b].bflags, w.flags);
+      // (RTFE_F_SCREEN_UNDERFLOW - update_thresholds sets it - means nothing here: the lists are only used where the thresholds lie inside
+      //  their band, which starts at the screen's level, and the literal detector has no screen)
+      if (w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW) atomicOr(&ctl[b].bflags, w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW);
       if (n_lit_rows) atomicAdd(&scratch->dbg[0], (unsigned long long)n_lit_rows);
       if (n_rec_ev) atomicAdd(&scratch->dbg[1], (unsigned long long)n_rec_ev);
       if (n_doubt) atomicAdd(&scratch->why[0], (unsigned long long)n_doubt);

@@ -81,6 +81,7 @@ struct DevCfg {
    int   ds_warm[kMaxScreens];               // rows a sub-segment's lane starts early, per window width (>= 3 W)
    int   ds_cap, ds_slot;                    // records per slot; bytes of a slot (header + records)
    float ds_band_hi, ds_band_lo;             // a sub-segment's band: [ds_band_lo, 1] x ds_band_hi x (its peak-to-peak amplitude / 4)
+   int   ds_lean;                            // k_dchain: the steady-state record as straight-line code (0: every record through the general step; tests)
    float ds_quiet_s;                         // a small-signal sub-segment may use the band [its largest margin, infinity) if that starts at or below this scale
    float ds_sfloor;                          // lower end of every band: the scale (v_avg_height / 4) / agc_gain the candidate screen is built for
    DevParm   parm[RTFE_MAXPARMSETS];

@@ -1104,7 +1104,9 @@ struct FastDiv {
 
 // ---- candidate screen: one thread = one strip of 8 consecutive rows of one track ----
 // window max/min by prefix/suffix decomposition around the strip start (van Herk with one block edge)
-__device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc, int screen, int trk, int strip) {
+// mmax (optional): the largest margin any candidate of the strip has - the window maximum above both edges, or both edges above the TRUE
+// window minimum (the reference's stale minimum is no lower): an upper bound of every margin a walker of these rows can meet (rtfe_dense.hip)
+__device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc, int screen, int trk, int strip, int *mmax = nullptr) {
    // Keys carry the position so that max/min also yield the FIRST window element equal to the extreme
    // (what refine_peak looks for, src/decoder.c:707-708): r = index relative to the strip's leftmost
    // window element (s0 - W + 1);  kmax = v<<8 | (255 - r)  (max -> largest v, then smallest r),
@@ -1113,6 +1115,7 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
    const int d = tl.skew[trk];
    const Col base = tile_col(tl, trk, d);                          // y(n) = base[n - row0] in the regular regime
    const int s0 = strip * kStrip;
+   int mm = 0;
    int v[kStrip], L[kStrip];
    int topb = 0, botb = 0, resb = 0;
    u64 ldt = 0, ldb = 0;
@@ -1146,6 +1149,7 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
          const bool t = (mx - L[i] > sc.rise_i) && (mx - v[i] > sc.rise_i) && (sc.minpk_i < 0 || mx > sc.minpk_i);
          const bool b = (L[i] - mn > sc.rise_i) && (v[i] - mn > sc.rise_i) && (sc.minpk_i < 0 || mn < -sc.minpk_i);
          topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i;
+         if (mmax) { if (t) mm = max(mm, min(mx - L[i], mx - v[i])); if (b) mm = max(mm, min(L[i] - mn, v[i] - mn)); }
          ldt |= (u64)((255 - (kx & 255)) - i + 1) << (8 * i);        // left_distance of the first maximum
          ldb |= (u64)((kn & 255) - i + 1) << (8 * i);                 // ... and of the first (true) minimum
          popped = L[i]; } }
@@ -1163,6 +1167,7 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
          const bool t = (mx - L[i] > sc.rise_i) && (mx - v[i] > sc.rise_i) && (sc.minpk_i < 0 || mx > sc.minpk_i);
          const bool b = (L[i] - mn > sc.rise_i) && (v[i] - mn > sc.rise_i) && (sc.minpk_i < 0 || mn < -sc.minpk_i);
          topb |= (int)t << i; botb |= (int)b << i; resb |= (int)(popped >= mx) << i;
+         if (mmax) { if (t) mm = max(mm, min(mx - L[i], mx - v[i])); if (b) mm = max(mm, min(L[i] - mn, v[i] - mn)); }
          ldt |= (u64)((255 - (kx & 255)) + 1) << (8 * i);
          ldb |= (u64)((kn & 255) + 1) << (8 * i); } }
    const int ntb2 = tl.ntrks * tl.bstride;
@@ -1172,6 +1177,7 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
    o[2 * ntb2] = (unsigned char)resb;
    reinterpret_cast<u64 *>(tl.ldmap(screen, 0, trk))[strip] = ldt;
    reinterpret_cast<u64 *>(tl.ldmap(screen, 1, trk))[strip] = ldb;
+   if (mmax) *mmax = mm;
    return topb | botb; }
 
 // cooperative tile load: rows [row0 - halo, row0 + nrows) of the AoS payload -> LDS, as they are (16-byte vectors;

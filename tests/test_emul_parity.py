@@ -7,6 +7,7 @@ import pytest
 from emul_util import emul_frontend
 from golden_util import load_case
 from parity_util import check_tape, config_for, oracle_attempts
+from readtape_amd import frontend
 
 PEAK_CASES = ["nrzi9", "nrzi9_m", "nrzi7", "nrzi9_skew", "nrzi9_invert", "pe", "pe_m", "gcr", "gcr_m", "nrzi7_order", "pe_order"]
 
@@ -182,3 +183,65 @@ def test_emulated_sample_rates_and_the_lean_sift_kernels(tdelta_ns, ntrks, tmp_p
     print(tdelta_ns, fe.widths, stats, st)
     assert not msgs, "\n".join(msgs[:12])
     assert stats["events"] > 500 and st["redone"] == 0 and st["parallel"] > 0, (stats, st)
+
+
+def _same_results(cfg, r0, r1):
+    assert r0.nbursts == r1.nbursts
+    for k in ("zone_first", "zone_end", "reset_sample", "safe_last", "end_sample", "flags"):
+        assert (r0.bursts[k] == r1.bursts[k]).all(), (k, r0.bursts[k], r1.bursts[k])
+    assert (r0.counts == r1.counts).all()
+    for b in range(r0.nbursts):
+        for p in range(len(cfg.parmsets)):
+            for t in range(cfg.ntrks):
+                assert r0.track_events(b, p, t).tobytes() == r1.track_events(b, p, t).tobytes(), (b, p, t)
+
+
+DENSE_CASES = ["gcr", "gcr_m", "pe", "pe_m", "gcr_order_m", "pe_order", "gcr_deskew", "gcr_errs", "nrzi9", "nrzi9_m", "nrzi9_skew", "nrzi9_invert", "nrzi7", "noise_only", "tiny", "nrzi9_cut"]
+
+
+@pytest.mark.parametrize("name", DENSE_CASES)
+def test_emulated_dense_path_equals_the_sample_path(name, monkeypatch):
+    """rtfe_dense.hip (k_dseg + k_dchain) against k_decode on one tape: the same burst table and, per (burst, parameter set, track), the
+    same events byte for byte.  The NRZI tapes take the dense path by force (RTFE_DENSE_PATH=1 with the peak path off)."""
+    g = load_case(name)
+    cfg = config_for(g["hdr"], g["oracle_opts"])
+    monkeypatch.setenv("RTFE_PEAK_PATH", "0")
+    res = []
+    for dp in ("0", "1"):
+        monkeypatch.setenv("RTFE_DENSE_PATH", dp)
+        fe = emul_frontend(cfg)
+        res.append((fe, fe.scan(g["rows"]).fetch()))
+    (f0, r0), (f1, r1) = res
+    st = f1.scan_stats(r1)
+    assert st["parallel"] + st["sequential"] > 0 or st["redone"] == st["bursts"] or int(r1.counts.sum()) == 0, st      # (literal rows + events from records: the dense path ran)
+    _same_results(cfg, r0, r1)
+
+
+@pytest.mark.parametrize("kind,knobs", [("gcr", {}), ("pe", {}), ("gcr", {"RTFE_DS_WARM": "8"}), ("gcr", {"RTFE_DS_CAP": "3"}), ("pe", {"RTFE_DS_BAND_LO": "0.9"}),
+                                        ("gcr", {"RTFE_DS_BAND_HI": "0.6"}), ("pe", {"RTFE_DS_QUIET_S": "0.0"}), ("gcr", {"RTFE_DENSE_DEDUP": "0"}), ("nrzi", {}), ("gcr", {"RTFE_DS_LEAN": "0"})])
+def test_emulated_dense_sweep_equals_the_sample_path(kind, knobs, monkeypatch):
+    """The shape bench.py's C4 runs - an eight-set sweep with four window widths, sets that the front end cannot tell apart - on noisy
+    tapes with blocks long enough for chains to cross many sub-segments; knobs force what clean tapes rarely do: joins that fail (a
+    warm-up of 8 rows), lists that run full, thresholds outside the band (doubts and literal stretches), no small-signal bands."""
+    from readtape_amd import synth
+    make = {"gcr": lambda: synth.gcr_tape(seed=31, nblocks=3, minlen=300, maxlen=700, gap_samples=9000, noise_mv=11.0),
+            "pe": lambda: synth.pe_tape(seed=32, nblocks=3, minlen=150, maxlen=300, gap_samples=6000, noise_mv=7.0),
+            "nrzi": lambda: synth.nrzi_tape(seed=33, nblocks=3, minlen=150, maxlen=300, gap_samples=5000, noise_mv=25.0)}[kind]
+    tape = make()
+    hdr = tape.spec.header()
+    extra = [(1.4, 0.20, 0.2, 0.5, 0, 0.0), (1.6, 0.14, 0.0, 0.5, 0, 0.0), (1.5, 0.10, 0.1, 0.5, 0, 0.0), (1.3, 0.25, 0.2, 0.5, 0, 0.0)]
+    base = list(frontend.DEFAULT_PARMSETS[hdr.mode])
+    parmsets = (base + extra)[:8] if kind == "gcr" else base[:8]
+    cfg = frontend.FrontEndConfig.from_header(hdr, nparmsets=len(parmsets), parmsets=parmsets)
+    monkeypatch.setenv("RTFE_PEAK_PATH", "0")
+    for k, v in knobs.items(): monkeypatch.setenv(k, v)
+    res = []
+    for dp in ("0", "1"):
+        monkeypatch.setenv("RTFE_DENSE_PATH", dp)
+        fe = emul_frontend(cfg)
+        res.append((fe, fe.scan(tape.rows).fetch()))
+    (f0, r0), (f1, r1) = res
+    st = f1.scan_stats(r1)
+    print(kind, knobs, st, int(r1.counts.sum()))
+    assert st["redone"] == 0 and st["parallel"] + st["sequential"] > 0, st
+    _same_results(cfg, r0, r1)

@@ -45,6 +45,18 @@ def test_tap_bytes_match_reference(name, tmp_path):
     assert not stats["event_diffs"], stats["event_diffs"]
 
 
+@pytest.mark.parametrize("name", ["pe", "pe_m", "gcr", "gcr_m", "gcr_correct", "gcr_deskew", "pe_order", "gcr_order_m", "nrzi9", "nrzi9_m", "nrzi9_skew"])
+def test_tap_bytes_match_reference_on_the_dense_path(name, tmp_path, monkeypatch):
+    """rtfe_dense.hip (k_dseg + k_dchain; opt-in) end to end: the reference's .tap, its transitions and its block lines.  The NRZI cases take
+    it by force (the peak path off)."""
+    monkeypatch.setenv("RTFE_DENSE_PATH", "1")
+    monkeypatch.setenv("RTFE_PEAK_PATH", "0")
+    g = load_case(name)
+    tap, stats = decode_case(g, tmp_path, emul_frontend)
+    assert tap == g["tap"], f"{name}: .tap differs from the reference's ({len(tap)} vs {len(g['tap'])} bytes)"
+    assert stats["agc_mismatches"] == 0 and not stats["event_diffs"], stats
+
+
 def test_reference_agc_assert_stops_the_decode_where_the_reference_stops(tmp_path):
     """src/decoder.c:782 ("AGC gain bad in lookfor_peak") kills the reference after 104 transitions of this tape (found by
     tests/stress_gpu.py).  The device marks the row in the track's event list, the replay delivers everything in front of it -

@@ -620,3 +620,66 @@ def test_sample_rates_and_the_lean_sift_kernels(tdelta_ns, ntrks, tmp_path, gpu)
     msgs, stats = check_tape(fe, hdr, tape.rows, att)
     assert not msgs, "\n".join(msgs[:12])
     assert stats["events"] > 5000 and st["redone"] == 0 and st["parallel"] > 0, (stats, st)
+
+
+DENSE_GPU_CASES = ["pe", "pe_m", "gcr", "gcr_m", "gcr_errs", "gcr_deskew", "pe_order", "gcr_order_m", "nrzi9", "nrzi9_m", "nrzi9_skew", "nrzi9_invert", "nrzi7"]
+
+
+@pytest.mark.parametrize("name", DENSE_GPU_CASES)
+def test_dense_path_against_the_oracle_and_the_reference(name, tmp_path, gpu, monkeypatch):
+    """rtfe_dense.hip (k_dseg + k_dchain; opt-in this round) on the real kernels: every event field against the oracle's attempts, and end
+    to end the unmodified reference's .tap, transitions and block lines.  NRZI takes it by force (peak path off)."""
+    from test_emul_replay import decode_case
+    monkeypatch.setenv("RTFE_DENSE_PATH", "1")
+    monkeypatch.setenv("RTFE_PEAK_PATH", "0")
+    g = load_case(name)
+    if "-deskew" not in g["oracle_opts"]:
+        att = oracle_attempts(g["hdr"], g["rows"], g["oracle_opts"], str(tmp_path))
+        fe = frontend.FrontEnd(config_for(g["hdr"], g["oracle_opts"]))
+        msgs, stats = check_tape(fe, g["hdr"], g["rows"], att)
+        assert not msgs, "\n".join(msgs[:12])
+        assert stats["events"] > 0
+    tap, stats = decode_case(g, tmp_path, None)
+    assert tap == g["tap"]
+    assert stats["agc_mismatches"] == 0 and not stats["event_diffs"], stats
+
+
+@pytest.mark.parametrize("kind,nparm,knobs", [("gcr", 8, {}), ("gcr", 1, {}), ("pe", 8, {}), ("pe", 1, {}), ("gcr", 8, {"RTFE_DS_WARM": "8"}), ("gcr", 8, {"RTFE_DS_CAP": "5"}),
+                                             ("pe", 1, {"RTFE_DS_BAND_LO": "0.9"}), ("gcr", 8, {"RTFE_DS_LEAN": "0"}), ("gcr", 8, {"RTFE_DENSE_DEDUP": "0"})])
+def test_dense_path_equals_the_sample_path_at_bench_shape(kind, nparm, knobs, gpu, monkeypatch):
+    """One base tape of bench.py's C4 / C3 shapes (5e6 rows, blocks of 512..4096 bytes: chains that cross hundreds of sub-segments): the dense
+    path and k_decode give the same burst table, counts and events byte for byte; knobs force failing joins, full lists, thresholds outside
+    their bands, the general step for every record."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    torch = gpu
+    tape = bench.make_base_tape(seed=1002, target_rows=5e6, kind=kind)
+    hdr = tape.spec.header()
+    base = list(frontend.DEFAULT_PARMSETS[hdr.mode])
+    extra = [(1.4, 0.20, 0.2, 0.5, 0, 0.0), (1.6, 0.14, 0.0, 0.5, 0, 0.0), (1.5, 0.10, 0.1, 0.5, 0, 0.0), (1.3, 0.25, 0.2, 0.5, 0, 0.0)]
+    parmsets = ((base + extra)[:nparm] if kind == "gcr" else base[:nparm]) if nparm > 1 else None
+    cfg = frontend.FrontEndConfig.from_header(hdr, nparmsets=nparm, parmsets=parmsets)
+    rows = torch.from_numpy(tape.rows).cuda()
+    for k, v in knobs.items(): monkeypatch.setenv(k, v)
+    res = []
+    for dp in ("0", "1"):
+        monkeypatch.setenv("RTFE_DENSE_PATH", dp)
+        fe = frontend.FrontEnd(cfg)
+        res.append((fe, fe.scan(rows).fetch()))
+    (f0, r0), (f1, r1) = res
+    st = f1.scan_stats(r1)
+    assert st["redone"] == 0 and st["sequential"] > 0.5 * int(r1.counts.sum()) * (1 if nparm == 1 else 0.4), st      # (most events came from the lists)
+    assert r0.nbursts == r1.nbursts and r0.nbursts > 20
+    for k in ("zone_first", "zone_end", "reset_sample", "safe_last", "end_sample", "flags"):
+        assert (r0.bursts[k] == r1.bursts[k]).all(), k
+    assert (r0.counts == r1.counts).all()
+    e0 = f0.backend.to_numpy(r0.bufs["events"], frontend.EVENT_DTYPE)
+    e1 = f1.backend.to_numpy(r1.bufs["events"], frontend.EVENT_DTYPE)
+    for b in range(r0.nbursts):
+        B = r0.bursts[b]
+        base_i, cap = int(B["event_base"]), int(B["event_cap"])
+        for p in range(nparm):
+            for t in range(cfg.ntrks):
+                n = int(r0.counts[b, p, t]); o = base_i + (p * cfg.ntrks + t) * cap
+                assert e0[o: o + n].tobytes() == e1[o: o + n].tobytes(), (b, p, t)
