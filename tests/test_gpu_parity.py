@@ -669,17 +669,12 @@ def test_dense_path_equals_the_sample_path_at_bench_shape(kind, nparm, knobs, gp
         res.append((fe, fe.scan(rows).fetch()))
     (f0, r0), (f1, r1) = res
     st = f1.scan_stats(r1)
-    assert st["redone"] == 0 and st["sequential"] > 0.5 * int(r1.counts.sum()) * (1 if nparm == 1 else 0.4), st      # (most events came from the lists)
+    assert st["redone"] == 0 and (knobs or st["sequential"] > 0.5 * int(r1.counts.sum()) * (1 if nparm == 1 else 0.4)), st      # (no knob: most events came from the lists)
     assert r0.nbursts == r1.nbursts and r0.nbursts > 20
     for k in ("zone_first", "zone_end", "reset_sample", "safe_last", "end_sample", "flags"):
         assert (r0.bursts[k] == r1.bursts[k]).all(), k
     assert (r0.counts == r1.counts).all()
-    e0 = f0.backend.to_numpy(r0.bufs["events"], frontend.EVENT_DTYPE)
-    e1 = f1.backend.to_numpy(r1.bufs["events"], frontend.EVENT_DTYPE)
     for b in range(r0.nbursts):
-        B = r0.bursts[b]
-        base_i, cap = int(B["event_base"]), int(B["event_cap"])
         for p in range(nparm):
             for t in range(cfg.ntrks):
-                n = int(r0.counts[b, p, t]); o = base_i + (p * cfg.ntrks + t) * cap
-                assert e0[o: o + n].tobytes() == e1[o: o + n].tobytes(), (b, p, t)
+                assert r0.track_events(b, p, t).tobytes() == r1.track_events(b, p, t).tobytes(), (b, p, t)
