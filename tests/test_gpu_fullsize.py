@@ -182,3 +182,115 @@ def test_fragments_cut_at_row_2_to_the_28(gpu):
         assert list(got_b[f]) == list(wb[f]), f
     key = lambda e: e[np.lexsort((e[:, 1], e[:, 0]))]
     assert got_e.shape == we.shape and (key(got_e) == key(we)).all() and we.shape[0] > 100000
+
+
+C4_EXTRA = [(1.4, 0.20, 0.2, 0.5, 0, 0.0), (1.6, 0.14, 0.0, 0.5, 0, 0.0), (1.5, 0.10, 0.1, 0.5, 0, 0.0), (1.3, 0.25, 0.2, 0.5, 0, 0.0)]
+
+
+def test_bench_tape_c3_against_the_oracle(tmp_path, gpu):
+    """The very PE tape bench.py --config C3 tiles (seed 1000 of make_base_tape, -zeros), event for event against the oracle's attempts
+    (round 3 checked the bench's C3 / C4 tapes only against themselves)."""
+    tape = bench.make_base_tape(seed=1000, target_rows=5e6, kind="pe")
+    hdr = tape.spec.header()
+    fe = frontend.FrontEnd(config_for(hdr, ["-zeros"]))
+    msgs, stats = check_tape(fe, hdr, tape.rows, oracle_attempts(hdr, tape.rows, ["-zeros"], str(tmp_path)))
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["events"] > 1e6 and stats["speculative"] == stats["attempts"], stats
+
+
+def test_bench_tape_c4_all_eight_sets_against_the_oracle(tmp_path, gpu):
+    """The GCR tape bench.py --config C4 tiles (seed 1000) with the bench's eight parameter sets: every set's events of the ONE eight-set
+    scan equal the single-set front end's, and that one is checked event for event against the oracle run with the set as its only one -
+    all eight, not two."""
+    tape = bench.make_base_tape(seed=1000, target_rows=5e6, kind="gcr")
+    hdr = tape.spec.header()
+    sets = (list(frontend.DEFAULT_PARMSETS[hdr.mode]) + C4_EXTRA)[:8]
+    fe8 = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr, nparmsets=8, parmsets=sets))
+    r8 = fe8.scan(tape.rows).fetch()
+    assert r8.nbursts > 20
+    done = {}
+    for p, ps in enumerate(sets):
+        bf, rise, mp, al, aw, _ = ps
+        key = (bf, rise, mp, al, aw)
+        fe1 = frontend.FrontEnd(frontend.FrontEndConfig.from_header(hdr, parmsets=[ps]))
+        if key not in done:                                  # (four of the reference's five GCR sets differ only in what the host decoder reads: one oracle run serves them)
+            parms = ("parms active, clk_window, clk_alpha, agc_window, agc_alpha, min_peak, pulse_adj, pkww_bitfrac, pkww_rise, z1pt, z2pt, id\n"
+                     f"{{1, 0, 0.015, {aw}, {al}, {mp}, 0.3, {bf}, {rise}, 1.45, 2.35, PRM}}\n")
+            (tmp_path / f"p{p}.parms").write_text(parms)
+            att = oracle_attempts(hdr, tape.rows, [f"-parms={tmp_path}/p{p}.parms"], str(tmp_path))
+            msgs, stats = check_tape(fe1, hdr, tape.rows, att)
+            assert not msgs, f"set {p}: " + "\n".join(msgs[:8])
+            done[key] = fe1.scan(tape.rows).fetch()
+        r1 = done[key]
+        assert r1.nbursts == r8.nbursts
+        for b in range(r8.nbursts):
+            for t in range(hdr.ntrks):
+                a, c = r8.track_events(b, p, t), r1.track_events(b, 0, t)
+                a = a.copy(); a["parmset"] = 0
+                assert a.tobytes() == c.tobytes(), (p, b, t)
+
+
+def test_c4_full_size_through_the_bench_step(gpu):
+    """BASELINE configs[3] exactly as bench.py times it: 1e9 rows of GCR, eight sets, FOUR fragments of 2^28 rows through bench.Workload.step().
+    Shift invariance gives the expected totals: the events of the first, a middle and the last copy of a three-copy scan, the middle
+    one times (copies - 2); and no burst may be flagged."""
+    torch = gpu
+    conf = bench.CONFIGS["C4"]
+    wl = bench.Workload(conf, 0, 1, torch.device("cuda:0"), None, 1e9, 5e6)
+    assert len(wl.frags) == 4 and wl.nrows >= 9.9e8
+    n, k = int(wl.tape.rows.shape[0]), wl.copies
+    fe3 = frontend.FrontEnd(wl.cfg)
+    r3 = fe3.scan(wl.sr.buf[: 3 * n]).fetch(events=False)
+    rs = r3.bursts["reset_sample"].astype(np.int64)
+    per = np.zeros((3, 8), np.int64)                      # events per (copy, set), a burst counted where it restarts (as the fragments' union does)
+    for b in range(r3.nbursts):
+        c = 0 if rs[b] < n - (1 << 17) else (1 if rs[b] < 2 * n - (1 << 17) else 2)      # (a copy's first burst restarts in the gap that ends the copy in front)
+        per[c] += r3.counts[b].sum(axis=1).astype(np.int64)
+    fe3.close(); del r3
+    torch.cuda.empty_cache()
+    tot = np.zeros(8, np.int64)
+    tally = dict(bursts=0, bad=0)
+
+    def each(r):
+        r.fetch(events=False)
+        tot[:] += r.counts.sum(axis=(0, 2)).astype(np.int64)
+        tally["bursts"] += int(r.nbursts)
+        tally["bad"] += int(((r.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START | frontend.F_STATE_AT_END)) != 0).sum())
+    wl.step(0, each=each)
+    assert tally["bad"] == 0 and tally["bursts"] > 10000
+    expect = per[0] + (k - 2) * per[1] + per[2]
+    assert (tot == expect).all(), (tot, expect)
+
+
+def test_c5_shape_eight_shards_on_one_gpu(gpu):
+    """BASELINE configs[4]'s shape: ONE 5.55e8-row (10 GB) NRZI tape cut by shard.plan_shards(n, 8), every shard scanned with its halo and the
+    ownership rule on this one GPU (what eight ranks do side by side): the union of the shards' bursts and counts is the whole scan's, and
+    around every cut the events are the whole scan's byte for byte."""
+    torch = gpu
+    tape = bench.make_base_tape(seed=1000, target_rows=5e6, kind="nrzi")
+    fe = frontend.FrontEnd(frontend.FrontEndConfig.from_header(tape.spec.header()))
+    rows, k, n = tiled(torch, tape, 10e9 / 18)
+    total = int(rows.shape[0])
+    assert total >= 5.5e8
+    whole = fe.scan(rows).fetch(events=False)
+    wb = shard.absolute_bursts(whole, 0)
+    spans = shard.plan_shards(total, 8)
+    halo = 1 << 18
+    pos = 0
+    for r, (lo, hi) in enumerate(spans):
+        end = min(total, hi + halo) if hi < total else total
+        res = fe.scan(rows[lo:end], row_base=lo, first_is_tape_start=(lo == 0), own_rows=hi - lo).fetch(events=False)
+        ab = shard.absolute_bursts(res, lo)
+        m = res.nbursts
+        assert m > 0
+        for f in ("zone_first", "zone_end", "reset_sample", "safe_last", "end_sample"):
+            assert (ab[f][:m] == wb[f][pos: pos + m]).all(), (r, f)
+        assert (res.bursts["flags"][:m] & ~np.uint32(frontend.F_EXACT_START)).max() == 0
+        assert (res.counts[:m] == whole.counts[pos: pos + m]).all(), r
+        for b in (0, 1, m - 2, m - 1):                          # the bursts next to the cuts: their events, every track
+            if 0 <= b < m:
+                got, ref = burst_lists(res, b)[0], burst_lists(whole, pos + b)[0]
+                for t in range(9):
+                    assert got[t].tobytes() == ref[t].tobytes(), (r, b, t)
+        pos += m
+    assert pos == whole.nbursts
