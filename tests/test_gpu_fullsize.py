@@ -235,7 +235,7 @@ def test_bench_tape_c4_all_eight_sets_against_the_oracle(tmp_path, gpu):
             for t in range(hdr.ntrks):
                 a, c = r8.track_events(b, p, t).copy(), r1.track_events(b, 0, t).copy()
                 a["parmset"] = 0                                  # (a burst's restart row - the earliest over sets and tracks - differs between the sweep and a single set: absolute rows)
-                a["sample"] += np.uint32(int(r8.bursts[b]["reset_sample"]) - int(r1.bursts[b]["reset_sample"]))
+                a["sample"] = (a["sample"].astype(np.int64) + int(r8.bursts[b]["reset_sample"]) - int(r1.bursts[b]["reset_sample"])).astype(np.uint32)
                 assert a.tobytes() == c.tobytes(), (p, b, t)
 
 
