@@ -237,72 +237,47 @@ class Workload:
             return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="BASELINE.json configs[1..4]; default: C2 on one GPU, C5 (one tape, time-sharded: strong scaling) on several")
-    ap.add_argument("--rows", type=float, default=None, help="sample instants per GPU (C5: of the whole tape); default: the config's")
-    ap.add_argument("--window-rows", type=float, default=None)
-    ap.add_argument("--base-rows", type=float, default=5e6)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--pipeline", action="store_true", help="alternate two front-end contexts on two HIP streams (steps overlap; per-kernel times then include contention)")
-    args = ap.parse_args()
-    if args.config is None:
-        args.config = "C2" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "C5"
-    conf = CONFIGS[args.config]
-
+def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, total_rows=None):
+    """Times `steps` steps of configuration `name` (repeated until at least min_seconds are inside the timed region - the steps run back to
+    back, barrier + synchronize on both sides) and returns (line fields, workload, last result).  Collective when world > 1."""
     import torch
-    import torch.distributed as dist
-    from readtape_amd import frontend, shard
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    dev = torch.device(f"cuda:{local}")
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    from readtape_amd import frontend
+    conf = CONFIGS[name]
     strong = bool(conf.get("strong"))
-    total_rows = float(args.rows or conf["rows"])
-
-    # ---- synthetic tape, resident in HBM; the front end; step() ----
-    wl = Workload(conf, rank, world, dev, dist, total_rows, args.base_rows, window_rows=args.window_rows, pipeline=args.pipeline)
-    tape, cfg, fe, fes, frags, kms, nrows, copies, step = wl.tape, wl.cfg, wl.fe, wl.fes, wl.frags, wl.kms, wl.nrows, wl.copies, wl.step
-
+    wl = Workload(conf, rank, world, dev, dist, float(total_rows or conf["rows"]), args.base_rows, window_rows=args.window_rows, pipeline=args.pipeline)
+    cfg, fe, frags, kms, nrows = wl.cfg, wl.fe, wl.frags, wl.kms, wl.nrows
     torch.cuda.synchronize(dev)
-    for i in range(args.warmup):
-        res = step(i)
+    for i in range(warmup):
+        wl.step(i)
     torch.cuda.synchronize(dev)
     wl.collect()                                     # (the warm-up scans' events: discarded)
     for k in kms: kms[k] = 0.0
-    if world > 1: dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        res = step(i, timed=True)
-    torch.cuda.synchronize(dev)
-    if world > 1: dist.barrier()
-    dt = time.perf_counter() - t0
-    wl.collect()                                     # the steps' HIP events, recorded on the stream as the scans ran
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    done, dt = 0, 0.0
+    while True:                                      # rounds of `steps` steps until the timed region is long enough for the driver's clock to see it
+        if world > 1: dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            res = wl.step(done + i, timed=True)
+        torch.cuda.synchronize(dev)
+        if world > 1: dist.barrier()
+        d = time.perf_counter() - t0
+        wl.collect()                                 # the steps' HIP events, recorded on the stream as the scans ran
+        if world > 1:
+            t = torch.tensor([d], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        dt += d; done += steps
+        if dt >= min_seconds or done >= 64 * steps: break
     # what the step produced (one more, untimed pass: every fragment's tables are fetched before the next one reuses the buffers)
-    tally = dict(events=0, bursts=0, bad=0, redone=0)
+    tally = dict(events=0, bursts=0, bad=0)
 
     def count(r):
         r.fetch(events=False)
         tally["events"] += int(r.counts.sum())
         tally["bursts"] += int(r.nbursts)
         tally["bad"] += int(((r.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START | frontend.F_STATE_AT_END)) != 0).sum())
-    step(0, each=count)
+    res = wl.step(0, each=count)
     nevents, bad = tally["events"], tally["bad"]
     try:                                             # diagnostics of the last scan (what the chains left to the literal detector / the sample path)
         sst = fe.scan_stats(res)
@@ -314,41 +289,105 @@ def main():
         nevents_all, bad, rows_all = int(tot[0].item()), int(tot[1].item()), int(tot[2].item())
     else:
         nevents_all, rows_all = nevents, nrows
+    for k in kms: kms[k] /= max(done, 1)
+    # The dominant span.  Every span is bracketed by its own pair of HIP events on the stream it runs on; on the peak path k_bursts' span
+    # (quiet map -> bursts -> restart rows) runs on the handle's side stream BESIDE k_prep: its time is shared device time, not work of its
+    # own, so it never names the dominant kernel.
+    cand = {k: v for k, v in kms.items() if not (k == "k_bursts" and cfg.mode == frontend.NRZI and not conf["find_zeros"] and os.environ.get("RTFE_OVERLAP", "1") != "0")}
+    dom = max(cand, key=cand.get)
+    alg_bytes = 2 * cfg.ntrks * nrows + 16 * nevents        # 18 B per sample instant + 16 B per event
+    achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
+    step_s = dt / done
+    whole = alg_bytes / step_s / 1e9 if step_s > 0 else 0.0      # (this GPU's algorithmic bytes over the step's wall time)
+    traffic = None
+    try:                                         # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        own = os.path.join(ROOT, "profiles", f"pmc_{name}.json")
+        pm = json.load(open(own if os.path.exists(own) else os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if name == pm.get("config", "C2") and dom in pm and abs(pm["workload_rows"] - nrows) < 0.01 * nrows:      # (tools/gpu_traffic.sh wrote it)
+            traffic = (pm[dom]["fetch_bytes"] + pm[dom]["write_bytes"]) * len(frags)      # (per scan in the file; a step = len(frags) scans)
+    except Exception:
+        pass
+    fields = {
+        "value": round(rows_all * done / dt / 1e6, 1), "ms_per_step": round(step_s * 1e3, 4), "timed_steps": done, "timed_seconds": round(dt, 3),
+        "config": {"workload": conf["workload"], "rows_per_gpu": nrows, "rows_total": rows_all,
+                   "bytes_per_gpu": nrows * cfg.ntrks * 2, "events_per_gpu": nevents, "events_total": nevents_all, "bursts": tally["bursts"],
+                   "flagged_bursts": bad, "parmsets": conf["nparmsets"], "launches_per_step": len(frags), "last_scan_stats": sst,
+                   "sharding": ("one tape, time shards (plan_shards), neighbour halo only" if strong else "time shards, neighbour halo only") if world > 1 else "none"},
+        "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": alg_bytes,
+                     "whole_step": {"achieved": round(whole, 1), "frac": round(whole / HBM_PEAK_GBS, 4),
+                                    "what": "the same algorithmic bytes over the step's wall time (all kernels of a scan, launch gaps included)"}},
+    }
+    return fields, wl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="BASELINE.json configs[1..4]; default: C2 on one GPU, C5 (one tape, time-sharded: strong scaling) on several")
+    ap.add_argument("--rows", type=float, default=None, help="sample instants per GPU (C5: of the whole tape); default: the config's")
+    ap.add_argument("--window-rows", type=float, default=None)
+    ap.add_argument("--base-rows", type=float, default=5e6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact C3 / C4 / C5 lines the default single-GPU run adds to its line")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="the timed region repeats its --steps steps until it is at least this long")
+    ap.add_argument("--pipeline", action="store_true", help="alternate two front-end contexts on two HIP streams (steps overlap; per-kernel times then include contention)")
+    args = ap.parse_args()
+    default_line = args.config is None and int(os.environ.get("WORLD_SIZE", "1")) == 1
+    if args.config is None:
+        args.config = "C2" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "C5"
+    conf = CONFIGS[args.config]
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    strong = bool(conf.get("strong"))
+
+    fields, wl = measure(args.config, args, rank, world, dev, dist, args.steps, args.warmup, args.min_seconds, total_rows=args.rows)
+    tape, fes, copies = wl.tape, wl.fes, wl.copies
     if rank == 0:
-        for k in kms: kms[k] /= max(args.steps, 1)
-        # the dominant span: all spans of a scan run in line on one stream; each is bracketed by its own pair of HIP events there
-        dom = max(kms, key=kms.get)
-        alg_bytes = 2 * cfg.ntrks * nrows + 16 * nevents        # 18 B per sample instant + 16 B per event
-        achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
-        traffic = None
-        try:                                         # HBM bytes per launch from the committed rocprofv3 --pmc passes
-            own = os.path.join(ROOT, "profiles", f"pmc_{args.config}.json")
-            pm = json.load(open(own if os.path.exists(own) else os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if args.config == pm.get("config", "C2") and dom in pm and abs(pm["workload_rows"] - nrows) < 0.01 * nrows:      # (tools/gpu_traffic.sh wrote it)
-                traffic = (pm[dom]["fetch_bytes"] + pm[dom]["write_bytes"]) * len(frags)      # (per scan in the file; a step = len(frags) scans)
-        except Exception:
-            pass
-        line = {
-            "metric": "Msamples/sec (all tracks) 9-trk TBIN", "value": round(rows_all * args.steps / dt / 1e6, 1),
-            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "i16/f32", "data": "synthetic",
-            "config": {"workload": conf["workload"], "rows_per_gpu": nrows, "rows_total": rows_all,
-                       "bytes_per_gpu": nrows * cfg.ntrks * 2, "events_per_gpu": nevents, "events_total": nevents_all, "bursts": tally["bursts"],
-                       "flagged_bursts": bad, "parmsets": conf["nparmsets"], "launches_per_step": len(frags), "last_scan_stats": sst,
-                       "sharding": ("one tape, time shards (plan_shards), neighbour halo only" if strong else "time shards, neighbour halo only") if world > 1 else "none"},
-            "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes": alg_bytes},
-        }
+        line = {"metric": "Msamples/sec (all tracks) 9-trk TBIN", "value": fields["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": fields["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
+                "vs_baseline": None, "dtype": "i16/f32", "data": "synthetic", "timed_steps": fields["timed_steps"], "timed_seconds": fields["timed_seconds"],
+                "config": fields["config"], "kernel_ms": fields["kernel_ms"], "roofline": fields["roofline"]}
+    for f in set(fes): f.close()
+    del wl.sr, wl
+    torch.cuda.empty_cache()
+    # ---- the other BASELINE.json configurations, measured in this process (compact: value, ms per step, dominant kernel, fractions) ----
+    if default_line and not args.no_other_configs:
+        others = {}
+        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2)):
+            try:
+                f2, w2 = measure(name, args, rank, world, dev, dist, st, wu, args.min_seconds)
+                others[name] = {"workload": f2["config"]["workload"], "value": f2["value"], "unit": "Msamples/s", "ms_per_step": f2["ms_per_step"], "timed_steps": f2["timed_steps"],
+                                "rows": f2["config"]["rows_total"], "events": f2["config"]["events_total"], "parmsets": f2["config"]["parmsets"], "flagged_bursts": f2["config"]["flagged_bursts"],
+                                "launches_per_step": f2["config"]["launches_per_step"], "dominant_kernel": f2["roofline"]["kernel"], "dominant_kernel_ms": f2["kernel_ms"][f2["roofline"]["kernel"]],
+                                "frac": f2["roofline"]["frac"], "whole_step_frac": f2["roofline"]["whole_step"]["frac"], "traffic": f2["roofline"]["traffic"]}
+                for f in set(w2.fes): f.close()
+                del w2.sr, w2
+            except Exception as e:                    # the headline number must not depend on the other lines
+                others[name] = {"error": repr(e)[:300]}
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+        if rank == 0: line["other_configs"] = others
+    if rank == 0:
         ncopies = max(1, min(copies, 4))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(tape, ncopies, conf)
         if not args.no_e2e and world == 1:
-            for f in set(fes): f.close()
-            del wl.sr
-            torch.cuda.empty_cache()
             try:
                 # (C2, the driver's line: a sample long enough for the reader's pipeline to fill - 16 copies, ~9e7 rows, 1.6 GB; the
                 #  CPU port that checks its .tap needs ~13 s for it.  The slower formats keep the CPU baseline's sample.)
