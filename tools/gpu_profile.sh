@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py $args --no-cpu-baseline --no-e2e > $out/bench_under_rocprof.json 2> $out/rocprof_stderr.log
+rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py $args --min-seconds 0 --no-cpu-baseline --no-e2e > $out/bench_under_rocprof.json 2> $out/rocprof_stderr.log
 cd $GRAFT_REPO_ROOT
 python tools/prof_summary.py $out "$args" > $out/summary.txt 2>&1
 cat $out/summary.txt

@@ -9,8 +9,8 @@ rm -rf $out; mkdir -p $out
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE -d $out/calib_fetch -o c -- python $GRAFT_REPO_ROOT/tools/pmc_calib.py > $out/calib.log 2> $out/err.log
 rocprofv3 --pmc WRITE_SIZE -d $out/calib_write -o c -- python $GRAFT_REPO_ROOT/tools/pmc_calib.py >> $out/calib.log 2>> $out/err.log
-rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o b -- python $GRAFT_REPO_ROOT/bench.py --config $config --steps 2 --warmup 1 --no-cpu-baseline --no-e2e "$@" > $out/bench_fetch.json 2>> $out/err.log
-rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o b -- python $GRAFT_REPO_ROOT/bench.py --config $config --steps 2 --warmup 1 --no-cpu-baseline --no-e2e "$@" > $out/bench_write.json 2>> $out/err.log
+rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o b -- python $GRAFT_REPO_ROOT/bench.py --config $config --steps 2 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e "$@" > $out/bench_fetch.json 2>> $out/err.log
+rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o b -- python $GRAFT_REPO_ROOT/bench.py --config $config --steps 2 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-e2e "$@" > $out/bench_write.json 2>> $out/err.log
 cd $GRAFT_REPO_ROOT
 rows=$(python -c "import json,sys; print(json.loads(open('$out/bench_fetch.json').read().strip().splitlines()[-1])['config']['rows_per_gpu'])")
 python tools/pmc_json.py $out $config $rows $tag > $out/pmc_$config.json
