@@ -50,11 +50,12 @@ constexpr int kDsUP = 3;                       // distinct sets of one window wi
 constexpr int kDsPlanes = 6;                   // per (set, track) over the tile's rows: own rows F(ire) Y(maybe) D(oubt) K(ind); warm-up rows F K
 struct DsThr { int r_lo, r_hi, q_lo, q_hi; };  // margins / extremes in int16 codes: >= hi passes for every threshold of the band, <= lo for none
 struct DsLds { unsigned bits, ldpos, cls, thr, bdl, band, mmax, total; };
+__host__ __device__ inline unsigned ds_bstride(int tile_rows) { return (unsigned)((tile_rows + kScreenHalo) / 8 + 8 + 7) & ~7u; }      // bytes of a screen bitmap's row (the halo word in front, one spare)
 __host__ __device__ inline unsigned ds_cstride(int tile_rows) { return (unsigned)(tile_rows / 8 + 8 + 7) & ~7u; }      // bytes of a plane's row of bits (64-bit words, one spare)
 __host__ __device__ inline DsLds ds_lds_layout(int ntrks, int halo_rows, int tile_rows) {
    DsLds L;
    unsigned off = lds_align16((unsigned)ntrks * (unsigned)(halo_rows + tile_rows + 8) * 2u + 16u);
-   L.bits = off;  off = lds_align16(off + (unsigned)ntrks * 3u * lds_bstride(tile_rows));       // (one screen at a time: top / bottom candidates, forced rescans)
+   L.bits = off;  off = lds_align16(off + (unsigned)ntrks * 3u * ds_bstride(tile_rows));       // (one screen at a time: top / bottom candidates, forced rescans)
    L.ldpos = off; off = lds_align16(off + (unsigned)ntrks * 2u * lds_ldstride(tile_rows));       // left_distance of the window's first maximum | of the reference's (stale) minimum
    L.cls = off;   off = lds_align16(off + (unsigned)kDsUP * kDsPlanes * (unsigned)ntrks * ds_cstride(tile_rows));
    L.thr = off;   off = lds_align16(off + (unsigned)kDsUP * kDsJ * (unsigned)ntrks * (unsigned)sizeof(DsThr));
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ 
    const DsLds L = ds_lds_layout(ntrks, cfg.halo_rows, T);
    Tile tl;
    tl.x = reinterpret_cast<int16_t *>(smem); tl.halo = cfg.halo_rows; tl.ldw = 0; tl.colof = cfg.trk_to_head; tl.ntrks = ntrks; tl.skew = cfg.skew;
-   tl.bits = smem + L.bits; tl.bstride = (int)lds_bstride(T); tl.ldpos = smem + L.ldpos; tl.ldstride = (int)lds_ldstride(T); tl.fd = nullptr;
+   tl.bits = smem + L.bits; tl.bstride = (int)ds_bstride(T); tl.ldpos = smem + L.ldpos; tl.ldstride = (int)lds_ldstride(T); tl.fd = nullptr;
    tl.reset = -(1ll << 40);                                           // (the regular deskew regime everywhere: k_dchain joins only behind the start-up rows)
    float2 *s_band = reinterpret_cast<float2 *>(smem + L.band);         // [j][t]: the band from the amplitude
    int *s_mmax = reinterpret_cast<int *>(smem + L.mmax);               // [j][t]: the largest margin of any candidate the sub-segment's lanes can meet
@@ -172,26 +173,6 @@ __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ 
          if (prof) { const long long t2 = clock64(); t_scr += t2 - tq; tq = t2; }
          if (!s_any) { if (threadIdx.x == 0) dead[g * cfg.nscreens + s] = 1; __syncthreads(); continue; }
          if (threadIdx.x == 0) dead[g * cfg.nscreens + s] = 0;
-         // ---- the reference's stale minimum at every row with a bottom candidate: its left_distance over the true minimum's (every lane its
-         // strips into registers, then - all done reading - over the map in place) ----
-         {  const int nst = T / kStrip, per = nst * ntrks;
-            u64 outs[8];                                                 // (kDsThreads x 8 strips cover the largest tile)
-            int no = 0;
-            for (int i = (int)threadIdx.x; i < per && no < 8; i += blockDim.x, ++no) {
-               const int q = fdn.div(i), t = i - q * ntrks;
-               const u64 *bm = tl.map(0, 1, t), *am = tl.map(0, 2, t);
-               const unsigned char *ldb = tl.ldmap(0, 1, t);
-               unsigned bb = (unsigned)((bm[q >> 3] >> ((q & 7) * 8)) & 0xff);
-               u64 out = 0;
-               while (bb) { const int k = __ffs((int)bb) - 1; bb &= bb - 1; out |= (u64)(unsigned)stale_ld(am, ldb, q * kStrip + k) << (8 * k); }
-               outs[no] = out; }
-            __syncthreads();
-            no = 0;
-            for (int i = (int)threadIdx.x; i < per && no < 8; i += blockDim.x, ++no) {
-               const int q = fdn.div(i), t = i - q * ntrks;
-               *reinterpret_cast<u64 *>(tl.ldmap(0, 1, t) + q * kStrip) = outs[no]; } }
-         __syncthreads();
-         if (prof) { const long long t2 = clock64(); t_sld += t2 - tq; tq = t2; }
          // ---- the distinct sets of this width, kDsUP at a time ----
          int us_all[RTFE_MAXPARMSETS], nus_all = 0;
          for (int u = 0; u < nu; ++u) if (cfg.parm[cfg.uset_rep[u]].screen == s) us_all[nus_all++] = u;
@@ -211,61 +192,91 @@ __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ 
                h.q_hi = fq > 1.0e9f ? 0x3fffffff : (int)floorf(fq) + 3; h.q_lo = (int)floorf(P.min_peak * bd.x * lsb) - 2;
                s_thr[i] = h; s_bdl[i] = bd; }
             __syncthreads();
-            // (b) all lanes, a strip of 8 rows of a track each: margins once, then per set the row's outcome
+            // (b) all lanes, a strip of 8 rows of a track each, straight-line: the window's edges and extremes, the reference's stale minimum
+            // carried along the strip (a forced rescan, or the stale sample leaving the window, makes it the true minimum again: the chain of
+            // stale_ld, one step per row), the margins - then per set the row's outcome as bits.  The stale minimum's left_distance replaces
+            // the true one's in the map, in place: where another lane's stale_ld reads the map - at rescan rows - the two are the same.
             {  const int nst = T / kStrip, per = nst * ntrks;
                const int ppl = ntrks * cstride;                           // bytes of a plane
+               const bool first_pass = u0 == 0;
                for (int i = (int)threadIdx.x; i < per; i += blockDim.x) {
                   const int q = fdn.div(i), t = i - q * ntrks;
-                  const u64 *tm = tl.map(0, 0, t), *bm = tl.map(0, 1, t);
-                  const unsigned char *ldt = tl.ldmap(0, 0, t), *sld = tl.ldmap(0, 1, t);
+                  const u64 *tm = tl.map(0, 0, t), *bm = tl.map(0, 1, t), *am = tl.map(0, 2, t);
+                  const unsigned char *ldt = tl.ldmap(0, 0, t);
+                  unsigned char *ldb = tl.ldmap(0, 1, t);
                   const Col yb = tile_col(tl, t, cfg.skew[t]);
-                  const unsigned tb = (unsigned)((tm[q >> 3] >> ((q & 7) * 8)) & 0xff), bb = (unsigned)((bm[q >> 3] >> ((q & 7) * 8)) & 0xff);
+                  const int sh = (q & 7) * 8;
+                  const unsigned tb = (unsigned)((tm[q >> 3] >> sh) & 0xff), bb = (unsigned)((bm[q >> 3] >> sh) & 0xff), ab = (unsigned)((am[q >> 3] >> sh) & 0xff);
                   const int r0 = q * kStrip;
                   unsigned char *cp = s_cls + t * cstride + q;
-                  if (!(tb | bb)) {
+                  if (!(tb | bb)) {                                       // (no candidate in the strip: nobody asks for its stale minima)
                      for (int ul = 0; ul < nus; ++ul) for (int pl = 0; pl < kDsPlanes; ++pl) cp[(ul * kDsPlanes + pl) * ppl] = 0;
                      continue; }
+                  const u64 lt8 = *reinterpret_cast<const u64 *>(ldt + r0), lb8 = *reinterpret_cast<const u64 *>(ldb + r0);
+                  int vl[8], vr[8];
+                  #pragma unroll
+                  for (int k = 0; k < 8; ++k) { vl[k] = yb[r0 + k - W + 1]; vr[k] = yb[r0 + k]; }
+                  // the stale minimum's row along the strip (kNoSp: unknown; tile rows may be negative - the halo): a later pass over the same strip finds its own earlier result
+                  constexpr int kNoSp = -0x40000000;
+                  int sp[8];
+                  if (first_pass) {
+                     const int l0 = stale_ld(am, ldb, r0);
+                     sp[0] = l0 ? r0 - W + l0 : kNoSp;
+                     #pragma unroll
+                     for (int k = 1; k < 8; ++k) {
+                        const int lo = r0 + k - W + 1;
+                        const bool rescan = ((ab >> k) & 1) || (sp[k - 1] != kNoSp && sp[k - 1] < lo);
+                        sp[k] = rescan ? lo + (int)((lb8 >> (8 * k)) & 0xff) - 1 : sp[k - 1]; }
+                     u64 out = 0;
+                     #pragma unroll
+                     for (int k = 0; k < 8; ++k) out |= (u64)(unsigned)(sp[k] != kNoSp ? sp[k] - (r0 + k - W + 1) + 1 : 0) << (8 * k);
+                     *reinterpret_cast<u64 *>(ldb + r0) = out; }
+                  else {
+                     #pragma unroll
+                     for (int k = 0; k < 8; ++k) { const int l = (int)((lb8 >> (8 * k)) & 0xff); sp[k] = l ? r0 + k - W + l : kNoSp; } }
                   int mt[8], tv[8], mb[8], bv[8];
                   unsigned unk = 0;                                       // rows whose bottom cannot be decided from the samples here (minimum out of reach, or at the window's edge)
                   #pragma unroll
                   for (int k = 0; k < 8; ++k) {
                      const int n = r0 + k, lo = n - W + 1;
-                     const int vl = yb[lo], vr = yb[n];
-                     const int lt = ldt[n], ls = sld[n];
                      const bool ct = (tb >> k) & 1, cb = (bb >> k) & 1;
-                     const int tpos = ct ? lo + lt - 1 : n, bpos = (cb && ls) ? lo + ls - 1 : n;
+                     const int tpos = ct ? lo + (int)((lt8 >> (8 * k)) & 0xff) - 1 : n, bpos = (cb && sp[k] != kNoSp) ? sp[k] : n;
                      const int tval = yb[tpos], bval = yb[bpos];
-                     mt[k] = ct ? tval - max(vl, vr) : -1; tv[k] = tval;
-                     const bool edge = cb && ls && (bpos <= lo || bpos >= n);
-                     mb[k] = (cb && ls && !edge) ? min(vl, vr) - bval : -1; bv[k] = -bval;
-                     if (cb && (!ls || (edge && min(vl, vr) - bval > 0))) unk |= 1u << k; }
+                     const int mv2 = max(vl[k], vr[k]), mn2 = min(vl[k], vr[k]);
+                     mt[k] = ct ? tval - mv2 : -1; tv[k] = tval;
+                     const bool edge = cb && sp[k] != kNoSp && (bpos <= lo || bpos >= n);
+                     mb[k] = (cb && sp[k] != kNoSp && !edge) ? mn2 - bval : -1; bv[k] = -bval;
+                     if (cb && (sp[k] == kNoSp || (edge && mn2 - bval > 0))) unk |= 1u << k; }
                   // whose band: the sub-segment that owns the rows; the next one where they are among its warm-up rows
                   const int jo = r0 < pad ? -1 : ((r0 - pad) / kDsSub > kDsJ - 1 ? kDsJ - 1 : (r0 - pad) / kDsSub);
                   int jw = jo + 1;
                   if (jw >= kDsJ || r0 + kStrip <= pad + jw * kDsSub - warm) jw = -1;
+                  unsigned wmask = 0;                                     // rows of the strip inside that warm-up
+                  if (jw >= 0) { const int w0r = pad + jw * kDsSub - warm; wmask = r0 >= w0r ? 0xffu : (0xffu << (w0r - r0)) & 0xffu; }
                   for (int ul = 0; ul < nus; ++ul) {
                      const DevParm &P = cfg.parm[cfg.uset_rep[us_all[u0 + ul]]];
                      const bool amp_on = P.min_peak != 0;
                      unsigned F = 0, Y = 0, D = 0, K = 0, Fw = 0, Kw = 0;
                      if (jo >= 0) {
                         const DsThr h = s_thr[(ul * kDsJ + jo) * ntrks + t];
+                        const int qlo = amp_on ? h.q_lo : -0x40000000, qhi = amp_on ? h.q_hi : -0x40000000;
+                        unsigned tS = 0, tN = 0, bS = 0, bN = 0;          // sure / not-miss, tops and bottoms
                         #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                           const int tc = ds_cls(h, amp_on, mt[k], tv[k]);
-                           const int bc = ds_cls(h, amp_on, mb[k], bv[k]);
-                           const bool uk = (unk >> k) & 1;
-                           if (tc == kDsSure) F |= 1u << k;
-                           else if (uk) D |= 1u << k;                    // (as the walk of one row did: an undecidable bottom behind a top that is not sure)
-                           else if (tc == kDsMaybe) { if (bc != kDsMiss) D |= 1u << k; else Y |= 1u << k; }
-                           else if (bc == kDsSure) { F |= 1u << k; K |= 1u << k; }
-                           else if (bc == kDsMaybe) { Y |= 1u << k; K |= 1u << k; } } }
+                           tN |= (unsigned)(mt[k] > h.r_lo && tv[k] > qlo) << k; tS |= (unsigned)(mt[k] >= h.r_hi && tv[k] >= qhi) << k;
+                           bN |= (unsigned)(mb[k] > h.r_lo && bv[k] > qlo) << k; bS |= (unsigned)(mb[k] >= h.r_hi && bv[k] >= qhi) << k; }
+                        const unsigned tM = tN & ~tS, bM = bN & ~bS;
+                        F = tS | (~tN & ~unk & bS); K = ~tN & ~unk & bN;      // (a bottom only where the top misses for sure; K: the bottom's business)
+                        D = ~tS & (unk | (tM & bN));                          // an undecidable bottom behind a top that is not sure; a top maybe with a bottom in play
+                        Y = ~D & ~F & (tM | (~tN & bM));
+                        F &= ~D; K &= (F | Y); }
                      if (jw >= 0) {                                       // warm-up rows only bring the countdown into step (the join checks that they did): a maybe counts as a hit
                         const DsThr h = s_thr[(ul * kDsJ + jw) * ntrks + t];
+                        const int qlo = amp_on ? h.q_lo : -0x40000000;
+                        unsigned tN = 0, bN = 0;
                         #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                           if (r0 + k < pad + jw * kDsSub - warm) continue;
-                           if (ds_cls(h, amp_on, mt[k], tv[k]) != kDsMiss) Fw |= 1u << k;
-                           else if (ds_cls(h, amp_on, mb[k], bv[k]) != kDsMiss) { Fw |= 1u << k; Kw |= 1u << k; } } }
+                        for (int k = 0; k < 8; ++k) { tN |= (unsigned)(mt[k] > h.r_lo && tv[k] > qlo) << k; bN |= (unsigned)(mb[k] > h.r_lo && bv[k] > qlo) << k; }
+                        Fw = (tN | bN) & wmask; Kw = ~tN & bN & wmask; }
                      unsigned char *o = cp + ul * kDsPlanes * ppl;
                      o[0] = (unsigned char)F; o[ppl] = (unsigned char)Y; o[2 * ppl] = (unsigned char)D; o[3 * ppl] = (unsigned char)K; o[4 * ppl] = (unsigned char)Fw; o[5 * ppl] = (unsigned char)Kw; } } }
             __syncthreads();
@@ -437,7 +448,7 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
       auto fire = [&](long long n, int ld, int val, bool is_top, int iprev, int inext) {
          const int adjcode = refine_code(&cfg, val, iprev, inext, w.agc_gain, is_top);
          double t_peak = 0;
-         if (cmode == RTFE_PE) {
+         if (cmode == RTFE_PE && !w.datablock && w.peakcount >= 68) {      // PE decides the end of its preamble from peak times (src/decode_pe.c:136-138): only there is the time read
             const float adj = adjcode == 1 ? -0.5f : (adjcode == 2 ? 0.5f : 0.0f);
             t_peak = time_of(&cfg, row_base + n) - ((float)(W - ld) - adj) * cfg.sample_deltat; }
          const float vp = volt(val, mv);
@@ -459,7 +470,9 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
             else w.flags |= RTFE_F_EVENT_OVERFLOW;
             ++w.nevents; dead_chain = true; return; }
          update_thresholds(w, P, lsb); };
-      const bool lean_ok = !agc_off && P.agc_window == 0 && P.agc_alpha != 0 && cmode != RTFE_PE && cmode != RTFE_WW && cfg.ds_lean != 0;
+      // the steady state the lean step is for: every callback adjusts the AGC (NRZI / GCR: the baseline fixed, src/decode_gcr.c:850,864;
+      // PE: inside the data block, src/decode_pe.c:175,198), by the alpha filter or the minimum of the last agc_window heights
+      const bool lean_ok = !agc_off && (P.agc_window != 0 || P.agc_alpha != 0) && cmode != RTFE_WW && cfg.ds_lean != 0;
       auto fatal_marker = [&](long long n, int ld) {                      // src/decoder.c:782, as in fire()
          w.flags |= RTFE_F_AGC_FATAL;
          if (w.nevents < cap) {
@@ -616,7 +629,7 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                   // ---- the record in steady state (NRZI / GCR: the baseline fixed, the alpha filter): straight-line code.  refine_peak's threshold
                   // from a 1-ulp reciprocal with a guard code more on either side (a neighbour inside the guard: the exact code); the thresholds only
                   // as far as the band check needs them (exact ones are made when something reads them) ----
-                  if (lean_ok && w.peakcount > 15 && w.v_avg_height_count == 0 && w.nevents < cap) {
+                  if (lean_ok && (cmode == RTFE_PE ? w.datablock : (w.peakcount > 15 && w.v_avg_height_count == 0)) && w.nevents < cap) {
                      const int ti = (int)(0.005f * fast_rcp(w.agc_gain) * lsb);
                      const bool clear = (dp <= ti - 2 || dp >= ti + 3) && (dn <= ti - 2 || dn >= ti + 3) && ti >= 3 && ti + 4 < 255;
                      int adjcode;
@@ -633,7 +646,17 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                      if (kind == 0) w.v_top = vp; else w.v_bot = vp;
                      ++w.nevents; ++w.peakcount;
                      const float lastheight = w.v_lasttop - w.v_lastbot;            // src/decoder.c:505-512 (both callbacks adjust in steady state: src/decode_gcr.c:850,864)
-                     if (lastheight > 0) { float gain = w.v_avg_height / lastheight; gain = P.agc_alpha * gain + (1 - P.agc_alpha) * w.agc_gain; if (gain > 2.0f) gain = 2.0f; w.agc_gain = gain; }
+                     if (lastheight > 0) {
+                        float gain;
+                        if (P.agc_alpha) { gain = w.v_avg_height / lastheight; gain = P.agc_alpha * gain + (1 - P.agc_alpha) * w.agc_gain; }
+                        else {                                              // src/decoder.c:514-531
+                           heights[w.heightndx] = lastheight;
+                           if (++w.heightndx >= P.agc_window) w.heightndx = 0;
+                           float minheight = 99;
+                           for (int i2 = 0; i2 < P.agc_window; ++i2) if (heights[i2] < minheight) minheight = heights[i2];
+                           gain = w.v_avg_height / minheight; }
+                        if (gain > 2.0f) gain = 2.0f;
+                        w.agc_gain = gain; }
                      if (kind == 0) w.v_lasttop = vp; else w.v_lastbot = vp;
                      ++n_rec_ev;
                      blind_until = n + ld;

@@ -1094,6 +1094,9 @@ __device__ __forceinline__ int stale_ld(const u64 *am, const unsigned char *ldb,
    #pragma nounroll
    for (;;) {
       const int l = ldb[h];                                          // (a rescan row: its byte is never rewritten with another value)
+#ifdef RTFE_CPU_EMUL
+      if (l == 0) { fprintf(stderr, "stale_ld: zero left_distance at rescan row %d (asked for row %d)\n", h, q); abort(); }
+#endif
       if (h + l > q) return l - (q - h);                             // still the same sample at row q
       h += l; } }                                                    // it left the window at row h + l: rescan there
 

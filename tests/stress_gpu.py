@@ -143,11 +143,14 @@ for i in range(ntapes):
     if keep: os.makedirs(keep, exist_ok=True)
     with (contextlib.nullcontext(keep) if keep else tempfile.TemporaryDirectory()) as wd:
         att = oracle_attempts(hdr, tape.rows, opts, wd) if not any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3")) else []
-        r_peak = None
-        for rec in ("default", "1", "0"):                       # every format on both paths (peak path / sample path)
+        r_peak, r_samp = None, None
+        for rec in ("default", "1", "0", "0d"):                 # every format on all paths (peak path / sample path / the dense sample path, rtfe_dense.hip)
             t_case = time.perf_counter()
-            if rec != "default": os.environ["RTFE_PEAK_PATH"] = rec
+            if rec != "default": os.environ["RTFE_PEAK_PATH"] = rec[0]
             else: os.environ.pop("RTFE_PEAK_PATH", None)
+            os.environ["RTFE_DENSE_PATH"] = "1" if rec == "0d" else "0"
+            if rec == "0d" and rng.random() < 0.3: os.environ["RTFE_DS_WARM"] = str(rng.choice([8, 24]))      # (joins that fail)
+            else: os.environ.pop("RTFE_DS_WARM", None)
             e2e = any(o in opts for o in ("(parms)", "-zeros", "-differentiate", "-deskew", "(nobpi)", "-correct", "-even", "-subsample=2", "-subsample=3"))
             if e2e: msgs, stats = e2e_check(hdr, tape.rows, [o for o in opts if o not in ("(nobpi)", "(parms)")], wd, parms_text)
             else:
@@ -159,7 +162,9 @@ for i in range(ntapes):
                 if rec != "default":                                # the two paths against each other, byte for byte, everywhere (not only where an attempt looks)
                     r = fe.scan(tape.rows).fetch()
                     if rec == "1": r_peak = r
-                    elif r_peak is not None:
+                    elif rec == "0": r_samp = r
+                    if rec == "0d": r_peak = r_samp                  # (the dense path against the sample path)
+                    if rec != "1" and r_peak is not None:
                         cfgp = config_for(hdr, opts)
                         if r.nbursts != r_peak.nbursts or any((r.bursts[k] != r_peak.bursts[k]).any() for k in ("zone_end", "reset_sample", "safe_last", "end_sample", "flags")): msgs.append("burst tables of the two paths differ")
                         else:
