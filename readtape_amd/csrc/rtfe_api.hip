@@ -496,7 +496,7 @@ static size_t ds_dead_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev
 static size_t ws_dsband_off(const rtfe_handle *h, int64_t nrows) { return ws_dsdead_off(h, nrows) + ds_dead_bytes(h, nrows); }
 static size_t ds_band_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.dense_path ? (((size_t)ds_tiles_for(nrows) * kDsJ * h->dev.ntrks * sizeof(float2) + 255) & ~(size_t)255) : 0; }
 static size_t ws_dsslot_off(const rtfe_handle *h, int64_t nrows) { return ws_dsband_off(h, nrows) + ds_band_bytes(h, nrows); }
-static size_t ds_slot_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.dense_path ? (((size_t)ds_tiles_for(nrows) * kDsJ * h->dev.nuset * h->dev.ntrks * (size_t)h->dev.ds_slot + 255) & ~(size_t)255) : 0; }
+static size_t ds_slot_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.dense_path ? (((size_t)ds_tiles_for(nrows) * kDsJ * h->dev.nuset * h->dev.ntrks * (size_t)h->dev.ds_slot + 511) & ~(size_t)255) : 0; }      // (+ a slot's worth: k_dchain reads nine 16-byte units of the last slot)
 
 extern "C" size_t rtfe_workspace_bytes(const rtfe_handle *h, int64_t nrows) {
    return ws_dsslot_off(h, nrows) + ds_slot_bytes(h, nrows) + 256; }
@@ -697,7 +697,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       const int dstop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;      // (debugging: 1 = stop behind k_dseg, 2 = behind k_dchain)
       if (dstop < 2) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTDchain);
-      hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * 16), dim3(64), (size_t)h->dev.ds_slot * 64 + (size_t)kDcCache * 64 * 2, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+      hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * 16), dim3(64), (size_t)(h->dev.ds_slot < 144 ? 144 : h->dev.ds_slot) * 64 + (size_t)kDcCache * 64 * 2, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                          scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const float2 *)bandp, (const unsigned char *)slotp, dtiles);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTDchain);

@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
    // in flight together, one round trip per sub-segment instead of one per record
    uint4 *s_slot = reinterpret_cast<uint4 *>(smem);
    // ... and so do the rows of a literal stretch: the detector's input of rows [cbase, cbase + kDcCache) of lane l at [k][l]
-   int16_t *s_y = reinterpret_cast<int16_t *>(smem + (size_t)cfgp->ds_slot * 64);
+   int16_t *s_y = reinterpret_cast<int16_t *>(smem + (size_t)(cfgp->ds_slot < 144 ? 144 : cfgp->ds_slot) * 64);      // (nine units of a slot are always staged)
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nu = cfg.nuset, nwalk = nu * ntrks;
    const int lane = threadIdx.x;
@@ -547,6 +547,9 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
       long long cur = reset;                                              // next row to process
       long long blind_until = -1;                                         // (record mode)
       bool lit = true;
+      uint4 pf[9]; long long pf_seg = -1; unsigned char pf_dead = 0;
+      #pragma unroll
+      for (int j = 0; j < 9; ++j) pf[j] = make_uint4(0, 0, 0, 0);
       long long no_join_before = 0;                                       // (behind a doubt the rest of its sub-segment is the literal detector's)
       long long rounds_left = (stop > reset ? (stop - reset) : 0) / 2 + 64;     // (every round moves `cur` on; belt and braces against a loop that does not)
       unsigned n_lit_rows = 0, n_rec_ev = 0, n_doubt = 0, n_nojoin = 0;
@@ -567,17 +570,29 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
          float2 bd = make_float2(cfg.ds_sfloor, 3.0e38f);
          bool tile_dead = false;
          if (at_bnd && cur >= fast_from && cur >= no_join_before && (synced || !lit) && tile < ntiles) {
-            const unsigned char dflag = dead[tile * cfg.nscreens + sc];
-            {  // (the slot's loads beside the flag's: a dead tile's slot holds nothing, and nothing of it is used)
+            unsigned char dflag;
+            {  // (the slot's loads beside the flag's: a dead tile's slot holds nothing, and nothing of it is used).  The first nine units - a
+               // whole slot of 15 records - usually arrived a round ago (pf: asked for when the sub-segment in front was joined)
                const uint4 *gp = reinterpret_cast<const uint4 *>(slots + (((size_t)seg * nu + u) * ntrks + trk) * (size_t)slot_bytes);
                const int nq = slot_bytes >> 4;
+               uint4 tq[9];
+               if (pf_seg == seg) {
+                  dflag = pf_dead;
+                  #pragma unroll
+                  for (int j = 0; j < 9; ++j) tq[j] = pf[j]; }
+               else {
+                  dflag = dead[tile * cfg.nscreens + sc];
+                  #pragma unroll
+                  for (int j = 0; j < 9; ++j) tq[j] = gp[j]; }              // (nine units always: a slot is at least that long, and the pool is padded)
+               #pragma unroll
+               for (int j = 0; j < 9; ++j) s_slot[j * 64 + lane] = tq[j];
                #pragma nounroll
-               for (int j0 = 0; j0 < nq; j0 += 9) {
-                  uint4 tq[9];
+               for (int j0 = 9; j0 < nq; j0 += 4) {                        // (slots of 31 / 63 records)
+                  uint4 t4[4];
                   #pragma unroll
-                  for (int j = 0; j < 9; ++j) if (j0 + j < nq) tq[j] = gp[j0 + j];
+                  for (int j = 0; j < 4; ++j) t4[j] = gp[min(j0 + j, nq - 1)];
                   #pragma unroll
-                  for (int j = 0; j < 9; ++j) if (j0 + j < nq) s_slot[(j0 + j) * 64 + lane] = tq[j]; } }
+                  for (int j = 0; j < 4; ++j) if (j0 + j < nq) s_slot[(j0 + j) * 64 + lane] = t4[j]; } }
             tile_dead = dflag != 0;
             if (tile_dead) join = in_band(bd);                             // nothing can rise above the screen: no countdown to agree on
             else {
@@ -593,6 +608,11 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                } }
          if (prof) { const long long t2 = clock64(); pt_join += t2 - ptq; ptq = t2; }
          if (join) {
+            if (seg + 1 < ntiles * kDsJ) {                                  // the next sub-segment's slot: on its way while this one's records are worked through
+               const uint4 *gn = reinterpret_cast<const uint4 *>(slots + (((size_t)(seg + 1) * nu + u) * ntrks + trk) * (size_t)slot_bytes);
+               #pragma unroll
+               for (int j = 0; j < 9; ++j) pf[j] = gn[j];
+               pf_dead = dead[((seg + 1) / kDsJ) * cfg.nscreens + sc]; pf_seg = seg + 1; }
             if (lit) { blind_until = cur - 1 + lcd; lit = false; }
             const long long r0 = cur;
             long long next = r0 + kDsSub;                                 // where the chain goes on

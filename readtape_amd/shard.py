@@ -90,9 +90,10 @@ def exchange_halo(sr, halo_rows: int, rank: int, world: int, dist, lens=None):
         return sr.rows(), sr.n
     if lens is None:
         lens = gather_lens(sr.n, sr.buf.device, world, dist)
-    sr.reserve(halo_rows if rank < world - 1 else 0)
+    plan = halo_plan(lens, halo_rows)
+    sr.reserve(max([off + cnt for _, d, _, cnt, off in plan if d == rank], default=0))      # (what the plan delivers: the tape's end cuts the last halos short - ADVICE r3)
     ops, got = [], 0
-    for s, d, first, cnt, off in halo_plan(lens, halo_rows):
+    for s, d, first, cnt, off in plan:
         if s == rank:
             ops.append(dist.P2POp(dist.isend, sr.buf[first: first + cnt], d))
         elif d == rank:

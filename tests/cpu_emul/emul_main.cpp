@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE — builds the kernel sources against tests/cpu_emul/hip/hip_runtime.h (see there).
 #include <hip/hip_runtime.h>
+#include <mutex>
 dim3 threadIdx, blockIdx;
 dim3 blockDim, gridDim;
 unsigned char g_dyn_smem[160 * 1024] __attribute__((aligned(64)));
@@ -24,7 +25,9 @@ static void fiber_entry() {
    g_fibers[g_cur].done = true;
    swapcontext(&g_fibers[g_cur].ctx, &g_main); }
 
+static std::mutex g_run_mutex;      // the fibers' state is process-global: one emulated launch at a time (ctypes releases the GIL - ADVICE r3)
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body) {
+   std::lock_guard<std::mutex> lock(g_run_mutex);
    gridDim = grid; blockDim = block;
    if (g_fibers.size() < block.x) g_fibers.resize(block.x);
    g_body = &body;
