@@ -306,9 +306,9 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       if (getenv("RTFE_DENSE_DEDUP") && atoi(getenv("RTFE_DENSE_DEDUP")) == 0) {      // (tests: every set its own chain)
          d.nuset = c->nparmsets;
          for (int p = 0; p < c->nparmsets; ++p) { d.uset_of[p] = p; d.uset_rep[p] = p; d.uset_mask[p] = 1u << p; } }
-      // Opt-in (RTFE_DENSE_PATH=1) in round 4: bit-exact on every test and stress tape, but not yet faster than k_decode (62 vs 43 ms
-      // per 6.7e7 rows for the 8-set GCR sweep, 28 vs 24 ms for one set) - its classification pass and the chains' launch latency are next round's work
-      d.dense_path = 0;
+      // The default for PE and GCR peak detection (round 4): measured against k_decode on 1e7 .. 2.7e8 rows it is 1.05 - 2.4 x faster (DESIGN.md 4d;
+      // most where several parameter sets share a window width); RTFE_DENSE_PATH=0 keeps k_decode (the tests run both against each other)
+      d.dense_path = !d.peak_path && !d.find_zeros && !d.differentiate && !d.agc_off && (d.mode == RTFE_PE || d.mode == RTFE_GCR);
       if (const char *e = getenv("RTFE_DENSE_PATH")) d.dense_path = !d.peak_path && !d.find_zeros && !d.differentiate && !d.agc_off && d.mode != RTFE_WW && atoi(e) != 0;
       int wpad = 64;
       for (int sidx = 0; sidx < d.nscreens; ++sidx) {
