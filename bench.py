@@ -47,7 +47,7 @@ CONFIGS = {
                workload="C2: synthetic 9-track 800 BPI NRZI, 781.25 kHz, 1 parmset"),
     "C3": dict(kind="pe", rows=1e9, nparmsets=1, find_zeros=True, window_rows=None, ref_opts=["-nm", "-zeros"], port_opts=["-zeros"],
                workload="C3: synthetic 9-track 1600 BPI PE, 1.5625 MHz, -zeros (zero-crossing path), 1 parmset"),
-    "C4": dict(kind="gcr", rows=1e9, nparmsets=8, find_zeros=False, window_rows=1 << 28, ref_opts=[], port_opts=["-m"],
+    "C4": dict(kind="gcr", rows=1e9, nparmsets=8, find_zeros=False, window_rows=1 << 29,      # (two fragments: 9.6 GB of rows, 33 GB of lists, 77 GB of event arena each; a fragment's chains have a latency floor) ref_opts=[], port_opts=["-m"],
                workload="C4: synthetic 9-track 6250 BPI GCR (9042 fci), 6.25 MHz, 8-parmset batched sweep"),
     "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True,
                workload="C5: ONE 10 GB synthetic 9-track 800 BPI NRZI tape, time-sharded over the ranks (strong scaling)"),

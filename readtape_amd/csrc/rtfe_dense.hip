@@ -32,7 +32,7 @@ namespace rtfe {
 constexpr int kDsSub = 128;                    // rows of a sub-segment
 constexpr int kDsJ = 4;                        // sub-segments per tile
 constexpr int kDsTile = kDsSub * kDsJ;         // own rows of a tile
-constexpr int kDsRight = 64;                   // rows behind a tile's own rows: a maybe that begins in the last sub-segment is settled there (multiple of 64)
+constexpr int kDsRight = 16;                   // rows behind a tile's own rows: a maybe that begins in the last sub-segment is settled there (kDsMaxMaybe + 1, a multiple of 8)
 constexpr int kDsThreads = 256;
 constexpr int kDsMaxMaybe = 15;
 constexpr int kDsNoJoin = 0xff, kDsNoDoubt = 0xff;
