@@ -51,12 +51,13 @@ constexpr int kDsPlanes = 6;                   // per (set, track) over the tile
 struct DsThr { int r_lo, r_hi, q_lo, q_hi; };  // margins / extremes in int16 codes: >= hi passes for every threshold of the band, <= lo for none
 struct DsLds { unsigned bits, ldpos, cls, thr, bdl, band, mmax, total; };
 __host__ __device__ inline unsigned ds_bstride(int tile_rows) { return (unsigned)((tile_rows + kScreenHalo) / 8 + 8 + 7) & ~7u; }      // bytes of a screen bitmap's row (the halo word in front, one spare)
+__host__ __device__ inline unsigned ds_ldstride(int tile_rows) { return (unsigned)(tile_rows + kScreenHalo + 8 + 7) & ~7u; }      // bytes of a left-distance map's row
 __host__ __device__ inline unsigned ds_cstride(int tile_rows) { return (unsigned)(tile_rows / 8 + 8 + 7) & ~7u; }      // bytes of a plane's row of bits (64-bit words, one spare)
 __host__ __device__ inline DsLds ds_lds_layout(int ntrks, int halo_rows, int tile_rows) {
    DsLds L;
    unsigned off = lds_align16((unsigned)ntrks * (unsigned)(halo_rows + tile_rows + 8) * 2u + 16u);
    L.bits = off;  off = lds_align16(off + (unsigned)ntrks * 3u * ds_bstride(tile_rows));       // (one screen at a time: top / bottom candidates, forced rescans)
-   L.ldpos = off; off = lds_align16(off + (unsigned)ntrks * 2u * lds_ldstride(tile_rows));       // left_distance of the window's first maximum | of the reference's (stale) minimum
+   L.ldpos = off; off = lds_align16(off + (unsigned)ntrks * 2u * ds_ldstride(tile_rows));       // left_distance of the window's first maximum | of the reference's (stale) minimum
    L.cls = off;   off = lds_align16(off + (unsigned)kDsUP * kDsPlanes * (unsigned)ntrks * ds_cstride(tile_rows));
    L.thr = off;   off = lds_align16(off + (unsigned)kDsUP * kDsJ * (unsigned)ntrks * (unsigned)sizeof(DsThr));
    L.bdl = off;   off = lds_align16(off + (unsigned)kDsUP * kDsJ * (unsigned)ntrks * 8u);
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ 
    const DsLds L = ds_lds_layout(ntrks, cfg.halo_rows, T);
    Tile tl;
    tl.x = reinterpret_cast<int16_t *>(smem); tl.halo = cfg.halo_rows; tl.ldw = 0; tl.colof = cfg.trk_to_head; tl.ntrks = ntrks; tl.skew = cfg.skew;
-   tl.bits = smem + L.bits; tl.bstride = (int)ds_bstride(T); tl.ldpos = smem + L.ldpos; tl.ldstride = (int)lds_ldstride(T); tl.fd = nullptr;
+   tl.bits = smem + L.bits; tl.bstride = (int)ds_bstride(T); tl.ldpos = smem + L.ldpos; tl.ldstride = (int)ds_ldstride(T); tl.fd = nullptr;
    tl.reset = -(1ll << 40);                                           // (the regular deskew regime everywhere: k_dchain joins only behind the start-up rows)
    float2 *s_band = reinterpret_cast<float2 *>(smem + L.band);         // [j][t]: the band from the amplitude
    int *s_mmax = reinterpret_cast<int *>(smem + L.mmax);               // [j][t]: the largest margin of any candidate the sub-segment's lanes can meet
