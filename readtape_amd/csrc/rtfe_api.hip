@@ -323,12 +323,18 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       d.ds_cap = expect * 1.3f + 2 <= 15 ? 15 : (expect * 1.3f + 2 <= 31 ? 31 : 63);
       if (const char *e = getenv("RTFE_DS_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 63) d.ds_cap = v; }      // (tests: lists that run full)
       d.ds_slot = ((int)sizeof(DsHdr) + d.ds_cap * (int)sizeof(DsRec) + 15) & ~15;
+      {  // sets per classification pass: three only where a single width carries three or more (PE's default sweep: one pass at three workgroups per
+         // CU beats two passes at four - 8.4 vs 9.2 ms per 6.7e7 rows; bench C4's four widths: 18.5 vs 20.1 the other way)
+         int per[kMaxScreens] = {0, 0, 0, 0}, mx = 0;
+         for (int u = 0; u < d.nuset; ++u) { const int sidx = d.parm[d.uset_rep[u]].screen; if (++per[sidx] > mx) mx = per[sidx]; }
+         d.ds_up = (mx >= 3 && d.nscreens == 1) ? 3 : 2;
+         if (const char *e = getenv("RTFE_DS_UP")) { const int v = atoi(e); if (v >= 1 && v <= 3) d.ds_up = v; } }
       d.ds_sfloor = (hfloor < 4.0f ? hfloor : 4.0f) / 4.0f / 2.0f;
       d.ds_lean = getenv("RTFE_DS_LEAN") ? atoi(getenv("RTFE_DS_LEAN")) != 0 : 1;
       d.ds_quiet_s = getenv("RTFE_DS_QUIET_S") ? (float)atof(getenv("RTFE_DS_QUIET_S")) : 0.6f;
       d.ds_band_hi = getenv("RTFE_DS_BAND_HI") ? (float)atof(getenv("RTFE_DS_BAND_HI")) : 1.25f;
       d.ds_band_lo = getenv("RTFE_DS_BAND_LO") ? (float)atof(getenv("RTFE_DS_BAND_LO")) : 1.0f / 3.0f;
-      if ((int)ds_lds_layout(c->ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight).total + 64 > 150 * 1024) d.dense_path = 0;
+      if ((int)ds_lds_layout(c->ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, d.ds_up).total + 64 > 150 * 1024) d.dense_path = 0;
       if ((d.ds_pad + kDsTile + kDsRight) / kStrip * c->ntrks > 8 * kDsThreads) d.dense_path = 0; }      // (k_dseg keeps a lane's strips of the stale-minimum map in eight registers)
    {
       const int nwalk = c->nparmsets * c->ntrks;
@@ -366,7 +372,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
       if (sf_special(d)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_special(d)), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds); }
-   if (d.dense_path) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dseg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight).total + 64);
+   if (d.dense_path) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dseg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, d.ds_up).total + 64);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    if (getenv("RTFE_VERBOSE") && d.peak_path) {
       int nb = -1;
@@ -686,7 +692,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       unsigned char *deadp = reinterpret_cast<unsigned char *>(wsb + ws_dsdead_off(h, nrows));
       float2 *bandp = reinterpret_cast<float2 *>(wsb + ws_dsband_off(h, nrows));
       unsigned char *slotp = reinterpret_cast<unsigned char *>(wsb + ws_dsslot_off(h, nrows));
-      const int dlds = (int)ds_lds_layout(h->dev.ntrks, h->dev.halo_rows, h->dev.ds_pad + kDsTile + kDsRight).total + 64;
+      const int dlds = (int)ds_lds_layout(h->dev.ntrks, h->dev.halo_rows, h->dev.ds_pad + kDsTile + kDsRight, h->dev.ds_up).total + 64;
       int dpc = (160 * 1024) / (dlds + 1024);
       if (dpc > 8) dpc = 8;
       if (const char *e = getenv("RTFE_DSEG_WGS")) { const int v = atoi(e); if (v >= 1 && v < dpc) dpc = v; }

@@ -46,21 +46,22 @@ __device__ __forceinline__ DsRec ds_pack(int nf, int nm, int kind, int ld, int v
    DsRec r; r.w0 = (uint32_t)nf | ((uint32_t)nm << 8) | ((uint32_t)kind << 12) | ((uint32_t)ld << 13);
    r.w1 = (uint32_t)(uint16_t)val | ((uint32_t)dp << 16) | ((uint32_t)dn << 24); return r; }
 
-constexpr int kDsUP = 3;                       // distinct sets of one window width classified together (more: further passes over the tile)
+// (DevCfg::ds_up distinct sets of one window width are classified together - more take further passes over the tile: 2 leaves room for four
+//  workgroups per CU, 3 for three; rtfe_create picks by the configuration)
 constexpr int kDsPlanes = 6;                   // per (set, track) over the tile's rows: own rows F(ire) Y(maybe) D(oubt) K(ind); warm-up rows F K
 struct DsThr { int r_lo, r_hi, q_lo, q_hi; };  // margins / extremes in int16 codes: >= hi passes for every threshold of the band, <= lo for none
 struct DsLds { unsigned bits, ldpos, cls, thr, bdl, band, mmax, total; };
 __host__ __device__ inline unsigned ds_bstride(int tile_rows) { return (unsigned)((tile_rows + kScreenHalo) / 8 + 8 + 7) & ~7u; }      // bytes of a screen bitmap's row (the halo word in front, one spare)
 __host__ __device__ inline unsigned ds_ldstride(int tile_rows) { return (unsigned)(tile_rows + kScreenHalo + 8 + 7) & ~7u; }      // bytes of a left-distance map's row
 __host__ __device__ inline unsigned ds_cstride(int tile_rows) { return (unsigned)(tile_rows / 8 + 8 + 7) & ~7u; }      // bytes of a plane's row of bits (64-bit words, one spare)
-__host__ __device__ inline DsLds ds_lds_layout(int ntrks, int halo_rows, int tile_rows) {
+__host__ __device__ inline DsLds ds_lds_layout(int ntrks, int halo_rows, int tile_rows, int up) {
    DsLds L;
    unsigned off = lds_align16((unsigned)ntrks * (unsigned)(halo_rows + tile_rows + 8) * 2u + 16u);
    L.bits = off;  off = lds_align16(off + (unsigned)ntrks * 3u * ds_bstride(tile_rows));       // (one screen at a time: top / bottom candidates, forced rescans)
    L.ldpos = off; off = lds_align16(off + (unsigned)ntrks * 2u * ds_ldstride(tile_rows));       // left_distance of the window's first maximum | of the reference's (stale) minimum
-   L.cls = off;   off = lds_align16(off + (unsigned)kDsUP * kDsPlanes * (unsigned)ntrks * ds_cstride(tile_rows));
-   L.thr = off;   off = lds_align16(off + (unsigned)kDsUP * kDsJ * (unsigned)ntrks * (unsigned)sizeof(DsThr));
-   L.bdl = off;   off = lds_align16(off + (unsigned)kDsUP * kDsJ * (unsigned)ntrks * 8u);
+   L.cls = off;   off = lds_align16(off + (unsigned)up * kDsPlanes * (unsigned)ntrks * ds_cstride(tile_rows));
+   L.thr = off;   off = lds_align16(off + (unsigned)up * kDsJ * (unsigned)ntrks * (unsigned)sizeof(DsThr));
+   L.bdl = off;   off = lds_align16(off + (unsigned)up * kDsJ * (unsigned)ntrks * 8u);
    L.band = off;  off = lds_align16(off + (unsigned)kDsJ * (unsigned)ntrks * 8u);
    L.mmax = off;  off = lds_align16(off + (unsigned)kDsJ * (unsigned)ntrks * 4u);
    L.total = off;
@@ -90,7 +91,7 @@ __device__ __forceinline__ int ds_cls(const DsThr &h, bool amp_on, int m, int v)
 // at the row if it looked: fire / maybe / doubt / nothing, as bits over the rows; (3) a lane per (set, sub-segment, track) resolves what
 // is sequential - the countdown - on those bits: find the next set bit, one load for the extreme's place, jump behind the countdown.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
+__global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
                                                      unsigned char *__restrict__ dead, float2 *__restrict__ band, unsigned char *__restrict__ slots,
                                                      unsigned long long *__restrict__ dbg) {
 #ifdef RTFE_CPU_EMUL
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ 
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
    const int ntrks = cfg.ntrks, pad = cfg.ds_pad, T = pad + kDsTile + kDsRight, nu = cfg.nuset;
-   const DsLds L = ds_lds_layout(ntrks, cfg.halo_rows, T);
+   const DsLds L = ds_lds_layout(ntrks, cfg.halo_rows, T, cfg.ds_up);
    Tile tl;
    tl.x = reinterpret_cast<int16_t *>(smem); tl.halo = cfg.halo_rows; tl.ldw = 0; tl.colof = cfg.trk_to_head; tl.ntrks = ntrks; tl.skew = cfg.skew;
    tl.bits = smem + L.bits; tl.bstride = (int)ds_bstride(T); tl.ldpos = smem + L.ldpos; tl.ldstride = (int)ds_ldstride(T); tl.fd = nullptr;
@@ -174,11 +175,11 @@ __global__ void __launch_bounds__(kDsThreads) k_dseg(const DevCfg *__restrict__ 
          if (prof) { const long long t2 = clock64(); t_scr += t2 - tq; tq = t2; }
          if (!s_any) { if (threadIdx.x == 0) dead[g * cfg.nscreens + s] = 1; __syncthreads(); continue; }
          if (threadIdx.x == 0) dead[g * cfg.nscreens + s] = 0;
-         // ---- the distinct sets of this width, kDsUP at a time ----
+         // ---- the distinct sets of this width, ds_up at a time ----
          int us_all[RTFE_MAXPARMSETS], nus_all = 0;
          for (int u = 0; u < nu; ++u) if (cfg.parm[cfg.uset_rep[u]].screen == s) us_all[nus_all++] = u;
-         for (int u0 = 0; u0 < nus_all; u0 += kDsUP) {
-            const int nus = nus_all - u0 < kDsUP ? nus_all - u0 : kDsUP;
+         for (int u0 = 0; u0 < nus_all; u0 += cfg.ds_up) {
+            const int nus = nus_all - u0 < cfg.ds_up ? nus_all - u0 : cfg.ds_up;
             // (a) every lane's band and thresholds.  A sub-segment of small signal (a gap, a block's first or last rows) is passed by chains
             // whose thresholds come from elsewhere: if nothing in it rises above a level such thresholds clear, its band is [that level, infinity)
             for (int i = threadIdx.x; i < nus * kDsJ * ntrks; i += blockDim.x) {
