@@ -393,7 +393,8 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
 // ------------------------------------------------------------------------------------------------
 // k_dchain
 // ------------------------------------------------------------------------------------------------
-constexpr int kDcCache = kDsSub + 64;          // rows of a literal stretch a lane keeps in LDS: up to kDsSub rows and the window + 2 in front of them
+constexpr int kDcChunk = 32;                   // literal rows are worked through this many at a time ...
+constexpr int kDcCache = kDcChunk + 56;        // ... from a lane's LDS cache: the chunk's rows and the window + 1 in front of them (W <= 50; LDS per wave decides how many chains run side by side)
 struct DcRows {                // the detector's input straight from HBM: row n of track t after -invert and the deskew FIFO (src/decoder.c:820-830)
    const int16_t *col; int P, sgn, d; long long reset;
    __device__ __forceinline__ int operator()(long long n) const {
@@ -712,10 +713,13 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
          if (!lit) { if (!resync(cur, blind_until)) { failed = true; done = true; continue; } lit = true; }
          long long end = (seg + 1) * kDsSub;
          if (end > stop) end = stop;
-         {  long long first = cur - W - 1; if (first < reset) first = reset;      // (nothing in front of the restart row is ever read)
-            fill_cache(first, end); }
          #pragma nounroll
-         for (long long n = cur; n < end && !dead_chain; ++n) lit_step(n);
+         for (long long c0 = cur; c0 < end && !dead_chain; c0 += kDcChunk) {
+            const long long c1 = c0 + kDcChunk < end ? c0 + kDcChunk : end;
+            long long first = c0 - W - 1; if (first < reset) first = reset;      // (nothing in front of the restart row is ever read)
+            fill_cache(first, c1);
+            #pragma nounroll
+            for (long long n = c0; n < c1 && !dead_chain; ++n) lit_step(n); }
          n_lit_rows += (unsigned)(end - cur);
          cur = end;
          if (prof) { const long long t2 = clock64(); pt_lit += t2 - ptq; ptq = t2; ++pn_litrounds; } }
