@@ -92,7 +92,7 @@ extern "C" const char *rtfe_last_error(void) { return g_err; }
 //   k_gain_tail | k_emit [k_emit_seg, k_emit, k_publish] | k_decode [the bursts the chains gave up, on the samples]
 // the sample path (PE, GCR, differentiated peaks, density detection, parameter-set sweeps with too many widths) k_quiet | k_bursts | k_decode,
 // -zeros k_quiet | k_bursts | k_zeros.  A span a scan does not run reads 0.
-// the dense sample path (PE, GCR peak detection): k_quiet | k_bursts [k_bursts, k_zones] | k_dseg | k_dchain [k_dchain, k_publish] | k_decode [what the chains gave up]
+// the dense sample path (PE, GCR peak detection): k_dseg [quiet map folded in] | k_bursts [k_bursts, k_zones] | k_dchain [k_dchain, k_publish] | k_decode [what the chains gave up]
 static const char *KNAMES[] = {"k_quiet", "k_sift", "k_prep", "k_bursts", "k_gain", "k_gain_s", "k_gain_tail", "k_emit", "k_decode", "k_zeros", "k_dseg", "k_dchain"};
 enum { kTQuiet, kTSift, kTPrep, kTBursts, kTGain, kTGainS, kTGainTail, kTEmit, kTDecode, kTZeros, kTDseg, kTDchain };
 constexpr int kNumKernels = 12;
@@ -670,9 +670,28 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       return launch_check("rtfe_scan"); }
    // ---- the sample path: quiet map -> bursts -> every burst in one pass over its samples ----
    (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
-   t0(kTQuiet);
-   hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, st, d_rows, (long long)nrows, h->dev.ntrks, h->dev.quiet_i, qwords, nwords);
-   t1(kTQuiet); t0(kTBursts);
+   const long long dtiles = ds_tiles_for(nrows);
+   unsigned char *deadp = reinterpret_cast<unsigned char *>(wsb + ws_dsdead_off(h, nrows));
+   unsigned char *slotp = reinterpret_cast<unsigned char *>(wsb + ws_dsslot_off(h, nrows));
+   if (h->dev.dense_path) {
+      // PE, GCR peak detection (rtfe_dense.hip): the dense pass first - it reads every row anyway, and leaves the quiet map's bits as well
+      // (k_quiet folded in: one pass over the tape less); bursts and restart rows behind it, then a lane per chain
+      (void)hipMemsetAsync(qwords, 0, (size_t)nwords * 8, st);         // (a tile writes its own byte: the map's tail stays "not quiet")
+      const int dlds = (int)ds_lds_layout(h->dev.ntrks, h->dev.halo_rows, h->dev.ds_pad + kDsTile + kDsRight, h->dev.ds_up).total + 64;
+      int dpc = (160 * 1024) / (dlds + 1024);
+      if (dpc > 8) dpc = 8;
+      if (const char *e = getenv("RTFE_DSEG_WGS")) { const int v = atoi(e); if (v >= 1 && v < dpc) dpc = v; }
+      if (dpc < 1) dpc = 1;
+      long long dg = (long long)h->num_cus * dpc;
+      if (dg > dtiles) dg = dtiles;
+      t0(kTDseg);
+      hipLaunchKernelGGL(k_dseg, dim3((unsigned)dg), dim3(kDsThreads), dlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, dtiles, deadp, reinterpret_cast<unsigned char *>(qwords), slotp, scratch->scr);
+      t1(kTDseg); }
+   else {
+      t0(kTQuiet);
+      hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, st, d_rows, (long long)nrows, h->dev.ntrks, h->dev.quiet_i, qwords, nwords);
+      t1(kTQuiet); }
+   t0(kTBursts);
    hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                       h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
                       d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts, h->dev.debug == 5 ? 1 : 0);
@@ -688,25 +707,11 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       else hipLaunchKernelGGL(k_zeros<0>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);
       t1(kTZeros); }
    else if (h->dev.dense_path) {                                      // PE, GCR peak detection: sub-segment lists, then a lane per chain (rtfe_dense.hip)
-      const long long dtiles = ds_tiles_for(nrows);
-      unsigned char *deadp = reinterpret_cast<unsigned char *>(wsb + ws_dsdead_off(h, nrows));
-      float2 *bandp = reinterpret_cast<float2 *>(wsb + ws_dsband_off(h, nrows));
-      unsigned char *slotp = reinterpret_cast<unsigned char *>(wsb + ws_dsslot_off(h, nrows));
-      const int dlds = (int)ds_lds_layout(h->dev.ntrks, h->dev.halo_rows, h->dev.ds_pad + kDsTile + kDsRight, h->dev.ds_up).total + 64;
-      int dpc = (160 * 1024) / (dlds + 1024);
-      if (dpc > 8) dpc = 8;
-      if (const char *e = getenv("RTFE_DSEG_WGS")) { const int v = atoi(e); if (v >= 1 && v < dpc) dpc = v; }
-      if (dpc < 1) dpc = 1;
-      long long dg = (long long)h->num_cus * dpc;
-      if (dg > dtiles) dg = dtiles;
-      t0(kTDseg);
-      hipLaunchKernelGGL(k_dseg, dim3((unsigned)dg), dim3(kDsThreads), dlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, dtiles, deadp, bandp, slotp, scratch->scr);
-      t1(kTDseg);
       const int dstop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;      // (debugging: 1 = stop behind k_dseg, 2 = behind k_dchain)
       if (dstop < 2) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTDchain);
       hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * 16), dim3(64), (size_t)(h->dev.ds_slot < 144 ? 144 : h->dev.ds_slot) * 64 + (size_t)kDcCache * 64 * 2, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                         scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const float2 *)bandp, (const unsigned char *)slotp, dtiles);
+                         scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const float2 *)nullptr, (const unsigned char *)slotp, dtiles);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTDchain);
       if (dstop < 3) { skip_rest(); return launch_check("rtfe_scan"); }

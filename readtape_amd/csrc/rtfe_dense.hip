@@ -92,16 +92,16 @@ __device__ __forceinline__ int ds_cls(const DsThr &h, bool amp_on, int m, int v)
 // is sequential - the countdown - on those bits: find the next set bit, one load for the extreme's place, jump behind the countdown.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
-                                                     unsigned char *__restrict__ dead, float2 *__restrict__ band, unsigned char *__restrict__ slots,
+                                                     unsigned char *__restrict__ dead, unsigned char *__restrict__ qbytes, unsigned char *__restrict__ slots,
                                                      unsigned long long *__restrict__ dbg) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;
 #else
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
-   (void)band;
    __shared__ DevCfg cfg;
    __shared__ int s_any, s_amp[RTFE_MAXTRKS];
+   __shared__ unsigned int s_noisy;
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
    const int ntrks = cfg.ntrks, pad = cfg.ds_pad, T = pad + kDsTile + kDsRight, nu = cfg.nuset;
@@ -127,8 +127,17 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
       __syncthreads();
       if (prof) tq = clock64();
       if (threadIdx.x < RTFE_MAXTRKS) s_amp[threadIdx.x] = 0;
+      if (threadIdx.x == 0) s_noisy = 0;
       load_tile(&cfg, tl, rows, nrows);
       __syncthreads();
+      // ---- the quiet map's bits of the tile's own rows (k_quiet folded in: bit c = every sample of rows [64 c, 64 c + 64) inside the quiet band;
+      // a tile is kDsTile / 64 = 8 groups: one byte of the map) ----
+      {  unsigned noisy = 0;
+         const unsigned q = (unsigned)cfg.quiet_i;
+         const int16_t *own = tl.x + (tl.halo + pad) * ntrks;
+         const int gsz = kChunkRows * ntrks;
+         for (int e = threadIdx.x; e < kDsTile * ntrks; e += blockDim.x) if ((unsigned)((int)own[e] + (int)q) > 2u * q) noisy |= 1u << (e / gsz);
+         if (noisy) atomicOr(&s_noisy, noisy); }
       // ---- the band of every (sub-segment, track): from the amplitude of the rows the sub-segment's lanes can see ----
       for (int i = threadIdx.x; i < kDsJ * ntrks; i += blockDim.x) {
          const int j = fdn.div(i), t = i - j * ntrks;
@@ -146,6 +155,10 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
          if (hi < lo) hi = lo;
          s_band[i] = make_float2(lo, hi); }
       __syncthreads();
+      if (threadIdx.x == 0) {                                             // (groups that are not complete - the tape ends inside them - are not quiet, as k_quiet has it)
+         unsigned complete = 0;
+         for (int k = 0; k < kDsTile / kChunkRows; ++k) if (g * kDsTile + (long long)(k + 1) * kChunkRows <= nrows) complete |= 1u << k;
+         qbytes[g] = (unsigned char)(~s_noisy & complete); }
       if (prof) { const long long t2 = clock64(); t_load += t2 - tq; tq = t2; }
       const int tile_lim = (nrows - tl.row0 < (long long)T) ? (int)(nrows - tl.row0) : T;
       for (int s = 0; s < cfg.nscreens; ++s) {
