@@ -133,10 +133,14 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
       // ---- the quiet map's bits of the tile's own rows (k_quiet folded in: bit c = every sample of rows [64 c, 64 c + 64) inside the quiet band;
       // a tile is kDsTile / 64 = 8 groups: one byte of the map) ----
       {  unsigned noisy = 0;
-         const unsigned q = (unsigned)cfg.quiet_i;
-         const int16_t *own = tl.x + (tl.halo + pad) * ntrks;
-         const int gsz = kChunkRows * ntrks;
-         for (int e = threadIdx.x; e < kDsTile * ntrks; e += blockDim.x) if ((unsigned)((int)own[e] + (int)q) > 2u * q) noisy |= 1u << (e / gsz);
+         const uint32_t qpk = pk_dup(cfg.quiet_i), q2 = 2u * (uint32_t)cfg.quiet_i;
+         const int4 *own = reinterpret_cast<const int4 *>(tl.x + (tl.halo + pad) * ntrks);      // (16-byte vectors: halo and pad are multiples of 8 rows)
+         const int vpg = 8 * ntrks;                                       // vectors per group of 64 rows
+         const FastDiv fdg(vpg);
+         for (int v = threadIdx.x; v < (kDsTile / kChunkRows) * vpg; v += blockDim.x) {
+            const int4 x4 = own[v];
+            const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)x4.x, qpk), pk_addu((uint32_t)x4.y, qpk)), pk_maxu(pk_addu((uint32_t)x4.z, qpk), pk_addu((uint32_t)x4.w, qpk)));
+            if ((m & 0xffffu) > q2 || (m >> 16) > q2) noisy |= 1u << fdg.div(v); }
          if (noisy) atomicOr(&s_noisy, noisy); }
       // ---- the band of every (sub-segment, track): from the amplitude of the rows the sub-segment's lanes can see ----
       for (int i = threadIdx.x; i < kDsJ * ntrks; i += blockDim.x) {
