@@ -290,6 +290,8 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
                         Y = ~D & ~F & (tM | (~tN & bM));
                         F &= ~D; K &= (F | Y); }
                      if (jw >= 0) {                                       // warm-up rows only bring the countdown into step (the join checks that they did): a maybe counts as a hit
+                        // (counting it as a miss was tried for noisy tapes: on clean ones fifty times more joins fail - an extreme that stays
+                        //  "maybe" for all its rows usually does fire)
                         const DsThr h = s_thr[(ul * kDsJ + jw) * ntrks + t];
                         const int qlo = amp_on ? h.q_lo : -0x40000000;
                         unsigned tN = 0, bN = 0;
@@ -336,7 +338,20 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
                      n = blind_until + 1; ++n_iter; } }
                int start_blind = blind_until + 1 - o0; if (start_blind < 0) start_blind = 0;
                int count = 0, doubt = -1;
-               int pk = -1, ppos = 0, pfirst = 0;                         // a pending "maybe": kind, the extreme's row, the first maybe row
+               int pk = -1, ppos = 0, pfirst = 0, plast = 0;              // a pending run of "maybe" rows: kind, the extreme's row, the run's first and last row
+               // a record: the extreme fires for sure at row nf + nm, and may have fired at the nm maybe rows in front (their margins behind it).
+               // A CONDITIONAL record (bit 19) has no sure row: a run of maybe rows that ended - the extreme fires at one of them or not at all,
+               // which only the chain's exact thresholds can tell; the walk goes on as if it had not (k_dchain knows what to do if it has)
+               auto put_rec = [&](int nf, int nm, int kind, int pos, bool cond) -> bool {
+                  if (count + 1 + (nm + 3) / 4 > cap) return false;
+                  const int fval = yb[pos], pv = yb[pos - 1], nx = yb[pos + 1];
+                  int dp = kind == 0 ? fval - pv : pv - fval, dn = kind == 0 ? fval - nx : nx - fval;
+                  dp = dp < 0 ? 0 : (dp > 255 ? 255 : dp); dn = dn < 0 ? 0 : (dn > 255 ? 255 : dn);
+                  DsRec r = ds_pack(nf - o0, nm, kind, pos - nf + W, fval, dp, dn);
+                  if (cond) r.w0 |= 1u << 19;
+                  recs[count++] = r;
+                  if (nm) count = ds_put_margins(recs, count, yb, W, nf, nm, kind, fval);
+                  return true; };
                if (start_blind >= kDsNoJoin) start_blind = kDsNoJoin;
                else {
                   n = blind_until + 1 > o0 ? blind_until + 1 : o0;
@@ -350,55 +365,47 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
                      if (n >= lim) break;
                      ++n_iter;
                      const int bit = n & 63;
-                     if ((wD >> bit) & 1) { doubt = pk >= 0 ? pfirst : n; break; }
+                     const bool isD = (wD >> bit) & 1, isY = (wY >> bit) & 1;
                      const int kind = (int)((pK[wd] >> bit) & 1);
                      const int pos = n - W + (kind ? (int)sld[n] : (int)ldt[n]);
-                     if ((wY >> bit) & 1) {
-                        if (pk >= 0 && (pk != kind || ppos != pos)) { doubt = pfirst; break; }
+                     const bool same = pk >= 0 && !isD && pk == kind && ppos == pos && n == plast + 1;      // the pending run's extreme, the very next row
+                     if (pk >= 0 && !(same && (!isY || n - pfirst < kDsMaxMaybe))) {      // the run ends here without a sure row: a conditional record
+                        if (!put_rec(pfirst, plast - pfirst + 1, pk, ppos, true)) { doubt = pfirst; break; }
+                        pk = -1; }
+                     if (isD) { doubt = n; break; }
+                     if (isY) {
                         if (pk < 0) { pk = kind; ppos = pos; pfirst = n; }
-                        ++n; continue; }
+                        plast = n; ++n; continue; }
                      const int nf = pk >= 0 ? pfirst : n;                 // it fires
-                     if ((pk >= 0 && (pk != kind || ppos != pos)) || n - nf > kDsMaxMaybe || count + 1 + (n - nf + 3) / 4 > cap) { doubt = nf; break; }
-                     {  const int fval = yb[pos], pv = yb[pos - 1], nx = yb[pos + 1];
-                        int dp = kind == 0 ? fval - pv : pv - fval, dn = kind == 0 ? fval - nx : nx - fval;
-                        dp = dp < 0 ? 0 : (dp > 255 ? 255 : dp); dn = dn < 0 ? 0 : (dn > 255 ? 255 : dn);
-                        recs[count++] = ds_pack(nf - o0, n - nf, kind, pos - nf + W, fval, dp, dn);
-                        if (n > nf) count = ds_put_margins(recs, count, yb, W, nf, n - nf, kind, fval); }
+                     if (!put_rec(nf, n - nf, kind, pos, false)) { doubt = nf; break; }
                      pk = -1; ++n_fire;
                      n = pos + W + 1; }
-                  // a maybe that began in the own rows is settled on the rows behind them (a record belongs to the sub-segment of its FIRST maybe row;
-                  // the next sub-segment's warm-up passes over the extreme as fired): those rows one at a time, against this lane's thresholds
+                  // a run of maybe rows that reaches the end of the own rows is followed on the rows behind them (a record belongs to the sub-segment of
+                  // its FIRST maybe row; the next sub-segment's warm-up passes over the extreme as fired): those rows one at a time, against this
+                  // lane's thresholds - a sure row of the same extreme completes the record; anything else leaves a conditional one
                   if (doubt < 0 && pk >= 0) {
-                     const u64 *tm = tl.map(0, 0, t), *bm = tl.map(0, 1, t);
-                     int plim = pfirst + kDsMaxMaybe + 1; if (plim > tile_lim) plim = tile_lim;
                      bool fired = false;
-                     #pragma nounroll
-                     for (n = lim; n < plim && !fired && doubt < 0; ++n) {                  // (from the first row behind the own rows: what the bits say there is the NEXT sub-segment's view)
-                        const int lo = n - W + 1, vl = yb[lo], vr = yb[n];
-                        const bool ct = (tm[n >> 6] >> (n & 63)) & 1, cb = (bm[n >> 6] >> (n & 63)) & 1;
-                        const int ls = cb ? (int)sld[n] : 0;
-                        const int tpos = ct ? lo + ldt[n] - 1 : n, bpos = ls ? lo + ls - 1 : n;
-                        const int tval = yb[tpos], bval = yb[bpos];
-                        const int tc = ct ? ds_cls(h, amp_on, tval - max(vl, vr), tval) : kDsMiss;
-                        const bool edge = ls && (bpos <= lo || bpos >= n);
-                        const int bc = (ls && !edge) ? ds_cls(h, amp_on, min(vl, vr) - bval, -bval) : kDsMiss;
-                        const bool uk = cb && (!ls || (edge && min(vl, vr) - bval > 0));
-                        int fk = -1, fp = 0;
-                        if (tc == kDsSure) { fk = 0; fp = tpos; }
-                        else if (uk) doubt = pfirst;
-                        else if (tc == kDsMaybe) { if (bc != kDsMiss || pk != 0 || ppos != tpos) doubt = pfirst; }
-                        else if (bc == kDsSure) { fk = 1; fp = bpos; }
-                        else if (bc == kDsMaybe) { if (pk != 1 || ppos != bpos) doubt = pfirst; }
-                        if (fk >= 0) {
-                           if (pk != fk || ppos != fp || n - pfirst > kDsMaxMaybe || count + 1 + (n - pfirst + 3) / 4 > cap) doubt = pfirst;
-                           else {
-                              const int fval = yb[fp], pv = yb[fp - 1], nx = yb[fp + 1];
-                              int dp = fk == 0 ? fval - pv : pv - fval, dn = fk == 0 ? fval - nx : nx - fval;
-                              dp = dp < 0 ? 0 : (dp > 255 ? 255 : dp); dn = dn < 0 ? 0 : (dn > 255 ? 255 : dn);
-                              recs[count++] = ds_pack(pfirst - o0, n - pfirst, fk, fp - pfirst + W, fval, dp, dn);
-                              count = ds_put_margins(recs, count, yb, W, pfirst, n - pfirst, fk, fval);
-                              fired = true; pk = -1; } } }
-                     if (!fired && doubt < 0) doubt = pfirst; } }
+                     if (plast == lim - 1 && lim == o1) {
+                        const u64 *tm = tl.map(0, 0, t), *bm = tl.map(0, 1, t);
+                        int plim = pfirst + kDsMaxMaybe + 1; if (plim > tile_lim) plim = tile_lim;
+                        #pragma nounroll
+                        for (n = lim; n < plim; ++n) {                    // (what the bits say there is the NEXT sub-segment's view: not used)
+                           const int lo = n - W + 1, vl = yb[lo], vr = yb[n];
+                           const bool ct = (tm[n >> 6] >> (n & 63)) & 1, cb = (bm[n >> 6] >> (n & 63)) & 1;
+                           const int ls = cb ? (int)sld[n] : 0;
+                           const int tpos = ct ? lo + ldt[n] - 1 : n, bpos = ls ? lo + ls - 1 : n;
+                           const int tval = yb[tpos], bval = yb[bpos];
+                           const int tc = ct ? ds_cls(h, amp_on, tval - max(vl, vr), tval) : kDsMiss;
+                           const bool edge = ls && (bpos <= lo || bpos >= n);
+                           const int bc = (ls && !edge) ? ds_cls(h, amp_on, min(vl, vr) - bval, -bval) : kDsMiss;
+                           const bool uk = cb && (!ls || (edge && min(vl, vr) - bval > 0));
+                           // the same extreme and nothing else in play: sure -> the record is complete; maybe -> on; anything else -> the run has ended
+                           const bool mine_top = pk == 0 && ppos == tpos && !uk && bc == kDsMiss, mine_bot = pk == 1 && ppos == bpos && !uk && tc == kDsMiss;
+                           const int cl = mine_top ? tc : (mine_bot ? bc : kDsMiss);
+                           if (cl == kDsSure) { fired = put_rec(pfirst, n - pfirst, pk, ppos, false); if (!fired) doubt = pfirst; break; }
+                           if (cl != kDsMaybe) break; } }
+                     if (!fired && doubt < 0 && !put_rec(pfirst, plast - pfirst + 1, pk, ppos, true)) doubt = pfirst;
+                     pk = -1; } }
                DsHdr hd; hd.count = (uint8_t)count; hd.start_blind = (uint8_t)start_blind;
                hd.doubt = (uint8_t)((doubt >= o0 && start_blind != kDsNoJoin) ? doubt - o0 : kDsNoDoubt); hd.flags = 0; hd.pad = 0; hd.s_lo = bd.x; hd.s_hi = bd.y;
                *reinterpret_cast<DsHdr *>(slot) = hd;
@@ -635,6 +642,8 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                pf_dead = dead[((seg + 1) / kDsJ) * cfg.nscreens + sc]; pf_seg = seg + 1; }
             if (lit) { blind_until = cur - 1 + lcd; lit = false; }
             const long long r0 = cur;
+            if (blind_until < r0 - 1) blind_until = r0 - 1;                // ("not blind" has one value from here on)
+            long long lane_blind = r0 - 1 + (tile_dead ? 0 : h_sb);        // the countdown of the lane that made this list (the join: in step with the chain's, or both over)
             long long next = r0 + kDsSub;                                 // where the chain goes on
             bool to_lit = false;
             if (!tile_dead) {
@@ -647,23 +656,35 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                   const int nfr = (int)(rc.w0 & 0xff), nm = (int)((rc.w0 >> 8) & 0xf), kind = (int)((rc.w0 >> 12) & 1), ld0 = (int)((rc.w0 >> 13) & 0x3f);
                   const int val = (int)(int16_t)(rc.w1 & 0xffff), dp = (int)((rc.w1 >> 16) & 0xff), dn = (int)(rc.w1 >> 24);
                   const long long nf = r0 + nfr;
+                  const bool cond = (rc.w0 >> 19) & 1;                      // a run of maybe rows without a sure one: it fires at one of them, or not at all
+                  const int next_k = k + ((nm + 3) >> 2);                   // (the words with the maybe rows' margins lie behind the record)
                   if (nf >= stop) { next = stop; break; }
-                  // which of the maybe rows fires: the reference's comparison against the nearer edge, from the margin the record carries
-                  // (the words behind it); exact thresholds for that
+                  // Where the chain stands against the lane that made the list: in step as long as both countdowns end at the same row.  A
+                  // conditional record that fires here (the lane went on as if it had not) puts the chain's countdown ahead: records whose rows
+                  // it covers are passed over, and the list is taken up again at the first record the lane found with ITS countdown over no
+                  // later than the chain's - it then looked at every row the chain is not blind for.  A lane that was blind where the chain
+                  // is not proves nothing: the literal detector takes over.
+                  const long long last_row = cond ? nf + nm - 1 : nf + nm;  // the last row at which this record can fire
+                  if (last_row <= blind_until) { if (!cond) lane_blind = nf + ld0; k = next_k; continue; }
+                  if (lane_blind > blind_until) { next = blind_until + 1 > r0 ? blind_until + 1 : r0; to_lit = true; break; }
+                  if (!cond) lane_blind = nf + ld0;                         // (= the extreme's row + W, whichever of the record's rows fires)
+                  // which of the maybe rows fires: the reference's comparison against the nearer edge, from the margin the record carries;
+                  // exact thresholds for that
                   long long n = nf;
                   if (nm) {
                      if (w.thr_dirty) update_thresholds(w, P, lsb);
-                     n = nf + nm;
+                     n = cond ? -1 : nf + nm;
                      const bool amp_ok = w.reqmin == 0 || (kind == 0 ? (val >= w.min_hi || (val > w.min_lo && volt(val, mv) > w.reqmin))
                                                                     : (-val >= w.min_hi || (-val > w.min_lo && volt(val, mv) < -w.reqmin)));
-                     for (int m = 0; m < nm; ++m) {
+                     for (int m = (blind_until >= nf ? (int)(blind_until + 1 - nf) : 0); m < nm; ++m) {
                         const int kk = k + 1 + (m >> 2);
                         const uint4 e4 = s_slot[(1 + (kk >> 1)) * 64 + lane];
                         const uint32_t ew = (m & 2) ? ((kk & 1) ? e4.w : e4.y) : ((kk & 1) ? e4.z : e4.x);
                         const int mg = (int)((ew >> (16 * (m & 1))) & 0xffff);
                         const bool hit = amp_ok && (kind == 0 ? above_by(val, val - mg, w.rise, w.rise_lo, w.rise_hi, mv) : below_by(val, val + mg, w.rise, w.rise_lo, w.rise_hi, mv));
                         if (hit) { n = nf + m; break; } }
-                     k += (nm + 3) >> 2; }
+                     k = next_k;
+                     if (n < 0) continue; }                                 // (a conditional record that does not fire: nothing happens)
                   if (n >= stop) { next = stop; break; }
                   const int ld = ld0 - (int)(n - nf);
                   // ---- the record in steady state (NRZI / GCR: the baseline fixed, the alpha filter): straight-line code.  refine_peak's threshold
@@ -718,7 +739,13 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                   blind_until = n + ld;
                   if (dead_chain) break;
                   if (!in_band(bd)) { next = n + 1; to_lit = true; break; } }   // the thresholds left the band: what this list says about the rows behind n is not proven
-               if (!dead_chain && !to_lit && next == r0 + kDsSub && h_doubt != kDsNoDoubt) { next = r0 + h_doubt; to_lit = true; ++n_doubt; } }
+               if (!dead_chain && !to_lit && next == r0 + kDsSub) {
+                  // the list is through: a doubt ends it early; and a lane that was blind (a fire of its own the chain passed over) where the chain
+                  // is not has not looked at those rows
+                  long long lit_from = r0 + kDsSub;
+                  if (h_doubt != kDsNoDoubt) { lit_from = r0 + h_doubt; ++n_doubt; }
+                  if (lane_blind > blind_until) { const long long f = blind_until + 1 > r0 ? blind_until + 1 : r0; if (f < lit_from) lit_from = f; }
+                  if (lit_from < r0 + kDsSub) { next = lit_from; to_lit = true; } } }
             cur = next;
             if (prof) { const long long t2 = clock64(); pt_rec += t2 - ptq; ptq = t2; }
             if (to_lit && cur < stop) {
