@@ -1,8 +1,14 @@
 #!/bin/bash
+# scratch: the C4 full line with its stderr, then the default line
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; echo "gpu tests rc $?"; tail -3 gpurun_out/gpu_tests.log
-run() { PROBE_COPIES=$1 timeout -s INT 200 python -X faulthandler tools/gpu_dense_probe.py 5e6 $2 $3 2>&1 | grep -E "^scan 2|k_dchain|^bursts" | tr '\n' ' '; }
-echo -n "gcr 1 set copies 208: "; run 208 1 gcr; echo
-timeout 600 python bench.py --config C4 --no-cpu-baseline --no-e2e 2> /dev/null | python -c "
-import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C4:', j['value'], j['ms_per_step'], {k:v for k,v in j['kernel_ms'].items() if v>1}, j['config']['last_scan_stats'])"
-bash tools/gpu_stress.sh 960 4 60
+timeout 700 python bench.py --config C4 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4_full.err; echo "C4 full line rc $?"; tail -5 gpurun_out/bench_c4_full.err
+timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc $?"; tail -3 gpurun_out/bench_default.err
+python - <<'PY'
+import json
+for f in ("gpurun_out/bench_c4.json", "gpurun_out/bench_default.json"):
+    try: j = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e: print(f, "unreadable", e); continue
+    print(f, {k: j[k] for k in ("value", "ms_per_step", "timed_steps", "timed_seconds")}, j["roofline"]["kernel"], j["roofline"]["frac"], j["roofline"]["whole_step"]["frac"], j["kernel_ms"])
+    for k, v in j.get("other_configs", {}).items(): print(k, {kk: v.get(kk) for kk in ("value", "ms_per_step", "dominant_kernel", "dominant_kernel_ms", "frac", "whole_step_frac", "error")})
+    print("e2e", {k: j.get("e2e", {}).get(k) for k in ("value", "seconds", "tap_identical_to_cpu_port", "error")}, "cpu", j.get("cpu_baseline"))
+PY

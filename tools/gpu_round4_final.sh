@@ -17,5 +17,5 @@ for r in 5.54e8 6.9e7; do
   python -c "
 import json; j=json.loads(open('gpurun_out/bench_c5_rows_$r.json').read().strip().splitlines()[-1]); print('C5 rows $r:', j['config']['rows_per_gpu'], j['value'], j['ms_per_step'])"
 done
-timeout 600 python bench.py --config C4 > gpurun_out/bench_c4.json 2>/dev/null; echo "C4 full line rc $?"
-timeout 600 python bench.py --config C3 > gpurun_out/bench_c3.json 2>/dev/null; echo "C3 full line rc $?"
+timeout 600 python bench.py --config C4 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4_full.err; echo "C4 full line rc $?"
+timeout 600 python bench.py --config C3 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3_full.err; echo "C3 full line rc $?"
