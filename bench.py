@@ -56,6 +56,8 @@ CONFIGS = {
                workload="G1 (extra): synthetic 9-track 6250 BPI GCR (9042 fci), 6.25 MHz, 1 parmset, peak detection, one scan"),
     "P1": dict(kind="pe", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[],
                workload="P1 (extra): synthetic 9-track 1600 BPI PE, 1.5625 MHz, 1 parmset, peak detection (not -zeros), one scan"),
+    "M8": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, ref_opts=[], port_opts=["-m"],
+               workload="M8 (extra): C2's tape under the reference's default -m: the 8 built-in NRZI parameter sets (three window widths) in one scan"),
     "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True,
                workload="C5: ONE 10 GB synthetic 9-track 800 BPI NRZI tape, time-sharded over the ranks (strong scaling)"),
 }
@@ -377,7 +379,7 @@ def main():
     # ---- the other BASELINE.json configurations, measured in this process (compact: value, ms per step, dominant kernel, fractions) ----
     if default_line and not args.no_other_configs:
         others = {}
-        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1)):
+        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("M8", 5, 2)):
             try:
                 f2, w2 = measure(name, args, rank, world, dev, dist, st, wu, args.min_seconds)
                 others[name] = {"workload": f2["config"]["workload"], "value": f2["value"], "unit": "Msamples/s", "ms_per_step": f2["ms_per_step"], "timed_steps": f2["timed_steps"],

@@ -232,3 +232,16 @@ def test_two_ranks_drive_the_step_of_bench_py(config, halo, tmp_path):
         assert parts[1][0]["bursts"].shape[0] == whole.nbursts and parts[0][0]["bursts"].shape[0] >= whole.nbursts - 1
         assert parts[0][0]["got"] == halo and parts[1][0]["got"] == 0 and parts[1][0]["lo"] == parts[0][0]["n"]
         assert parts[0][1]["events"].shape == parts[0][0]["events"].shape and (parts[0][1]["events"] == parts[0][0]["events"]).all()
+
+
+def test_every_bench_configuration_is_complete():
+    """bench.py's CONFIGS: each entry carries every key the bench legs read (a comment once swallowed C4's ref_opts / port_opts and the
+    CPU baseline of `--config C4` died on the missing key)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    need = {"kind", "rows", "nparmsets", "find_zeros", "window_rows", "ref_opts", "port_opts", "workload"}
+    for name, conf in bench.CONFIGS.items():
+        assert need <= set(conf), (name, need - set(conf))
+        assert conf["workload"].startswith(name), name
+        assert isinstance(conf["ref_opts"], list) and isinstance(conf["port_opts"], list), name
