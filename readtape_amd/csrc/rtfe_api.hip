@@ -92,7 +92,7 @@ extern "C" const char *rtfe_last_error(void) { return g_err; }
 //   k_gain_tail | k_emit [k_emit_seg, k_emit, k_publish] | k_decode [the bursts the chains gave up, on the samples]
 // the sample path (PE, GCR, differentiated peaks, density detection, parameter-set sweeps with too many widths) k_quiet | k_bursts | k_decode,
 // -zeros k_quiet | k_bursts | k_zeros.  A span a scan does not run reads 0.
-// the dense sample path (PE, GCR peak detection): k_dseg [quiet map folded in] | k_bursts [k_bursts, k_zones] | k_dchain [k_dchain, k_publish] | k_decode [what the chains gave up]
+// the dense sample path (PE, GCR peak detection): k_dseg [quiet map folded in] | k_bursts [k_bursts, k_zones] | k_dchain [k_dorder, k_dchain, k_publish] | k_decode [what the chains gave up]
 static const char *KNAMES[] = {"k_quiet", "k_sift", "k_prep", "k_bursts", "k_gain", "k_gain_s", "k_gain_tail", "k_emit", "k_decode", "k_zeros", "k_dseg", "k_dchain"};
 enum { kTQuiet, kTSift, kTPrep, kTBursts, kTGain, kTGainS, kTGainTail, kTEmit, kTDecode, kTZeros, kTDseg, kTDchain };
 constexpr int kNumKernels = 12;
@@ -710,8 +710,15 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       const int dstop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;      // (debugging: 1 = stop behind k_dseg, 2 = behind k_dchain)
       if (dstop < 2) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTDchain);
-      hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * 16), dim3(64), (size_t)(h->dev.ds_slot < 144 ? 144 : h->dev.ds_slot) * 64 + (size_t)kDcCache * 64 * 2, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                         scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const float2 *)nullptr, (const unsigned char *)slotp, dtiles);
+      static const int ds_order = getenv("RTFE_DS_ORDER") ? atoi(getenv("RTFE_DS_ORDER")) : 1;      // (0: the chains in burst order)
+      if (ds_order) hipLaunchKernelGGL(k_dorder, dim3(1), dim3(1024), 0, st, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch, ctlp, (long long)nrows);
+      // (LDS per wave decides how many chains run side by side - the kernel holds ~240 VGPRs, eight waves per CU: the literal rows' cache is a chunk and the
+      //  widest window + 2, not the 88 rows the widest window the library accepts would need)
+      int wmax = 1;
+      for (int i = 0; i < h->dev.nparm; ++i) if (h->dev.parm[i].W > wmax) wmax = h->dev.parm[i].W;
+      const int dcache = wmax + 2 + kDcChunk < kDcCache ? ((wmax + 2 + kDcChunk + 7) & ~7) : kDcCache;
+      hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * 16), dim3(64), (size_t)(h->dev.ds_slot < 144 ? 144 : h->dev.ds_slot) * 64 + (size_t)dcache * 64 * 2, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+                         scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const float2 *)nullptr, (const unsigned char *)slotp, dtiles, ds_order);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTDchain);
       if (dstop < 3) { skip_rest(); return launch_check("rtfe_scan"); }

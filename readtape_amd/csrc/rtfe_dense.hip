@@ -425,10 +425,35 @@ struct DcRows {                // the detector's input straight from HBM: row n 
       const long long m = (n - reset < d) ? n : n - d;
       return sgn * (int)col[m * P]; } };
 
+// k_dorder: the bursts by falling length (a counting sort over classes of 256 rows; ctl[i].pad = the burst at place i).  A chain is a
+// dependent walk - what k_dchain takes is its longest chain's latency, and a wave is done when the longest of its lanes' chains is: its
+// waves take 64 chains at a time from a queue in this order, the long ones first and like with like.
+constexpr int kDoBins = 4096;
+__global__ void __launch_bounds__(1024) k_dorder(const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl, long long nrows) {
+   __shared__ int s_hist[kDoBins];
+   __shared__ int lds[32];
+   const int nb = scratch->nbursts, nt = scratch->nbursts_total;
+   for (int i = threadIdx.x; i < kDoBins; i += 1024) s_hist[i] = 0;
+   __syncthreads();
+   auto bin = [&](int b) -> int {                                      // bin 0: the longest
+      const long long end = b + 1 < nt ? bursts[b + 1].zone_end : nrows;
+      long long k = (end - bursts[b].zone_end) >> 8;
+      k = k < 0 ? 0 : (k > kDoBins - 1 ? kDoBins - 1 : k);
+      return kDoBins - 1 - (int)k; };
+   for (int b = threadIdx.x; b < nb; b += 1024) atomicAdd(&s_hist[bin(b)], 1);
+   __syncthreads();
+   int c[kDoBins / 1024], sum = 0;
+   for (int j = 0; j < kDoBins / 1024; ++j) { c[j] = s_hist[threadIdx.x * (kDoBins / 1024) + j]; sum += c[j]; }
+   int total;
+   int off = block_excl_scan_1024(sum, lds, &total);
+   for (int j = 0; j < kDoBins / 1024; ++j) { s_hist[threadIdx.x * (kDoBins / 1024) + j] = off; off += c[j]; }
+   __syncthreads();
+   for (int b = threadIdx.x; b < nb; b += 1024) ctl[atomicAdd(&s_hist[bin(b)], 1)].pad = b; }
+
 __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long row_base,
                                                const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                                uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
-                                               const unsigned char *__restrict__ dead, const float2 *__restrict__ band, const unsigned char *__restrict__ slots, long long ntiles) {
+                                               const unsigned char *__restrict__ dead, const float2 *__restrict__ band, const unsigned char *__restrict__ slots, long long ntiles, int ordered) {
    __shared__ float s_heights[64 * 10];
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;
@@ -447,10 +472,15 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
    const int nchains = scratch->nbursts * nwalk;
    float *heights = s_heights + lane * 10;
    const int slot_bytes = cfg.ds_slot;
-   for (int cbase = blockIdx.x * 64; cbase < nchains; cbase += gridDim.x * 64) {
+   for (;;) {
+      int cbase = 0;                                                   // the next 64 chains of the queue (k_dorder's order: the long bursts first)
+      if (lane == 0) cbase = atomicAdd(&scratch->queue_walk, 64);
+      cbase = __shfl(cbase, 0);
+      if (cbase >= nchains) break;
       const int ci = cbase + lane < nchains ? cbase + lane : nchains - 1;
-      const int b = ci / nwalk;
-      const int wi = ci - b * nwalk, u = wi / ntrks, trk = wi - u * ntrks;
+      const int place = ci / nwalk;
+      const int b = ordered ? ctl[place].pad : place;
+      const int wi = ci - place * nwalk, u = wi / ntrks, trk = wi - u * ntrks;
       const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady;
       const rtfe_burst B = bursts[b];
       const int pidx = cfg.uset_rep[u];
