@@ -16,10 +16,17 @@ EMUL_SO = os.path.join(EMUL_DIR, "librtfe_emul.so")
 def build_emul():
     srcs = [os.path.join(ROOT, "readtape_amd", "csrc", f) for f in ("rtfe_api.hip", "rtfe_kernels.hip", "rtfe_zeros.hip", "rtfe_ww.hip", "rtfe_sift.hip", "rtfe_gain.hip", "rtfe_dense.hip", "rtfe_pk.h", "rtfe_device.h")]
     srcs += [os.path.join(ROOT, "include", "rt_frontend.h"), os.path.join(EMUL_DIR, "hip", "hip_runtime.h"), os.path.join(EMUL_DIR, "emul_main.cpp")]
-    if not os.path.exists(EMUL_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMUL_SO) for s in srcs):
-        subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-x", "c++",
-                        f"-I{EMUL_DIR}", f"-I{ROOT}/include", f"-I{ROOT}/readtape_amd/csrc", "-o", EMUL_SO,
-                        os.path.join(EMUL_DIR, "emul_main.cpp")], check=True)
+    stale = lambda: not os.path.exists(EMUL_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMUL_SO) for s in srcs)
+    if stale():
+        import fcntl
+        with open(EMUL_SO + ".lock", "w") as lk:           # (pytest-xdist workers: one builds, the others wait and find it done; the library appears whole)
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                tmp = EMUL_SO + f".{os.getpid()}.tmp"
+                subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-x", "c++",
+                                f"-I{EMUL_DIR}", f"-I{ROOT}/include", f"-I{ROOT}/readtape_amd/csrc", "-o", tmp,
+                                os.path.join(EMUL_DIR, "emul_main.cpp")], check=True)
+                os.replace(tmp, EMUL_SO)
     return EMUL_SO
 
 
