@@ -610,6 +610,7 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
       long long no_join_before = 0;                                       // (behind a doubt the rest of its sub-segment is the literal detector's)
       long long rounds_left = (stop > reset ? (stop - reset) : 0) / 2 + 64;     // (every round moves `cur` on; belt and braces against a loop that does not)
       unsigned n_lit_rows = 0, n_rec_ev = 0, n_doubt = 0, n_nojoin = 0;
+      unsigned pc_rec = 0, pc_maybe = 0, pc_unclear = 0, pc_general = 0, pc_notinb = 0;      // (RTFE_DEBUG=8: records by the path they took)
       // (every lane of the wave goes through the same rounds: the emulator's ballot needs all of them)
       const bool prof = cfg.debug == 8;
       long long pt_join = 0, pt_rec = 0, pt_lit = 0, pn_rounds = 0, pn_litrounds = 0, ptq = 0;
@@ -673,9 +674,17 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
             if (lit) { blind_until = cur - 1 + lcd; lit = false; }
             const long long r0 = cur;
             if (blind_until < r0 - 1) blind_until = r0 - 1;                // ("not blind" has one value from here on)
-            long long lane_blind = r0 - 1 + (tile_dead ? 0 : h_sb);        // the countdown of the lane that made this list (the join: in step with the chain's, or both over)
-            long long next = r0 + kDsSub;                                 // where the chain goes on
+            // (rows inside the record loop are ints relative to r0, the sub-segment's first row: a chain is one lane's dependent instructions, and
+            //  64-bit row arithmetic doubles many of them; "_r" = relative)
+            int blind_r = (int)(blind_until - r0);                         // >= -1
+            int lane_blind_r = -1 + (tile_dead ? 0 : h_sb);                // the countdown of the lane that made this list (the join: in step with the chain's, or both over)
+            const int stop_r = stop - r0 < (long long)(4 * kDsSub) ? (int)(stop - r0) : 4 * kDsSub;
+            const uint32_t sample0 = (uint32_t)(r0 - reset);
+            int next_r = kDsSub;                                          // where the chain goes on
             bool to_lit = false;
+            // the event regions this chain writes: one set's in the usual case (no loop over the mask on the chain's path)
+            const bool one_set = (pmask & (pmask - 1)) == 0;
+            rtfe_event *ev1 = evb + (size_t)((__ffs((int)pmask) - 1) * ntrks + trk) * cap;
             if (!tile_dead) {
                // (the band's edges a little inside: an approximate threshold between them is an exact one inside the band)
                const float band_rlo = P.rise * bd.x * 1.00001f, band_rhi = P.rise * bd.y * 0.99999f, band_qlo = P.min_peak * bd.x * 1.00001f, band_qhi = P.min_peak * bd.y * 0.99999f;
@@ -683,30 +692,31 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                for (int k = 0; k < h_count; ++k) {
                   const uint4 r4 = s_slot[(1 + (k >> 1)) * 64 + lane];
                   DsRec rc; rc.w0 = (k & 1) ? r4.z : r4.x; rc.w1 = (k & 1) ? r4.w : r4.y;
-                  const int nfr = (int)(rc.w0 & 0xff), nm = (int)((rc.w0 >> 8) & 0xf), kind = (int)((rc.w0 >> 12) & 1), ld0 = (int)((rc.w0 >> 13) & 0x3f);
+                  const int nf = (int)(rc.w0 & 0xff), nm = (int)((rc.w0 >> 8) & 0xf), kind = (int)((rc.w0 >> 12) & 1), ld0 = (int)((rc.w0 >> 13) & 0x3f);
                   const int val = (int)(int16_t)(rc.w1 & 0xffff), dp = (int)((rc.w1 >> 16) & 0xff), dn = (int)(rc.w1 >> 24);
-                  const long long nf = r0 + nfr;
                   const bool cond = (rc.w0 >> 19) & 1;                      // a run of maybe rows without a sure one: it fires at one of them, or not at all
                   const int next_k = k + ((nm + 3) >> 2);                   // (the words with the maybe rows' margins lie behind the record)
-                  if (nf >= stop) { next = stop; break; }
+                  if (nf >= stop_r) { next_r = stop_r; break; }
                   // Where the chain stands against the lane that made the list: in step as long as both countdowns end at the same row.  A
                   // conditional record that fires here (the lane went on as if it had not) puts the chain's countdown ahead: records whose rows
                   // it covers are passed over, and the list is taken up again at the first record the lane found with ITS countdown over no
                   // later than the chain's - it then looked at every row the chain is not blind for.  A lane that was blind where the chain
                   // is not proves nothing: the literal detector takes over.
-                  const long long last_row = cond ? nf + nm - 1 : nf + nm;  // the last row at which this record can fire
-                  if (last_row <= blind_until) { if (!cond) lane_blind = nf + ld0; k = next_k; continue; }
-                  if (lane_blind > blind_until) { next = blind_until + 1 > r0 ? blind_until + 1 : r0; to_lit = true; break; }
-                  if (!cond) lane_blind = nf + ld0;                         // (= the extreme's row + W, whichever of the record's rows fires)
+                  const int last_row = cond ? nf + nm - 1 : nf + nm;        // the last row at which this record can fire
+                  if (last_row <= blind_r) { if (!cond) lane_blind_r = nf + ld0; k = next_k; continue; }
+                  if (lane_blind_r > blind_r) { next_r = blind_r + 1 > 0 ? blind_r + 1 : 0; to_lit = true; break; }
+                  if (!cond) lane_blind_r = nf + ld0;                       // (= the extreme's row + W, whichever of the record's rows fires)
                   // which of the maybe rows fires: the reference's comparison against the nearer edge, from the margin the record carries;
                   // exact thresholds for that
-                  long long n = nf;
+                  int n = nf;
+                  if (prof) ++pc_rec;
                   if (nm) {
+                     if (prof) ++pc_maybe;
                      if (w.thr_dirty) update_thresholds(w, P, lsb);
                      n = cond ? -1 : nf + nm;
                      const bool amp_ok = w.reqmin == 0 || (kind == 0 ? (val >= w.min_hi || (val > w.min_lo && volt(val, mv) > w.reqmin))
                                                                     : (-val >= w.min_hi || (-val > w.min_lo && volt(val, mv) < -w.reqmin)));
-                     for (int m = (blind_until >= nf ? (int)(blind_until + 1 - nf) : 0); m < nm; ++m) {
+                     for (int m = (blind_r >= nf ? blind_r + 1 - nf : 0); m < nm; ++m) {
                         const int kk = k + 1 + (m >> 2);
                         const uint4 e4 = s_slot[(1 + (kk >> 1)) * 64 + lane];
                         const uint32_t ew = (m & 2) ? ((kk & 1) ? e4.w : e4.y) : ((kk & 1) ? e4.z : e4.x);
@@ -715,8 +725,8 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                         if (hit) { n = nf + m; break; } }
                      k = next_k;
                      if (n < 0) continue; }                                 // (a conditional record that does not fire: nothing happens)
-                  if (n >= stop) { next = stop; break; }
-                  const int ld = ld0 - (int)(n - nf);
+                  if (n >= stop_r) { next_r = stop_r; break; }
+                  const int ld = ld0 - (n - nf);
                   // ---- the record in steady state (NRZI / GCR: the baseline fixed, the alpha filter): straight-line code.  refine_peak's threshold
                   // from a 1-ulp reciprocal with a guard code more on either side (a neighbour inside the guard: the exact code); the thresholds only
                   // as far as the band check needs them (exact ones are made when something reads them) ----
@@ -726,14 +736,16 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                      int adjcode;
                      if (clear) { const bool pclose = dp <= ti - 2, nclose = dn <= ti - 2; adjcode = (pclose && !nclose) ? 1 : ((nclose && !pclose) ? 2 : 0); }
                      else {
+                        if (prof) ++pc_unclear;
                         int iprev = kind == 0 ? val - dp : val + dp, inext = kind == 0 ? val - dn : val + dn;
-                        if (ti + 4 >= 255 || ti < 3) { const long long p = n - W + ld; iprev = y(p - 1); inext = y(p + 1); }
+                        if (ti + 4 >= 255 || ti < 3) { const long long p = r0 + (n - W + ld); iprev = y(p - 1); inext = y(p + 1); }
                         adjcode = refine_code(&cfg, val, iprev, inext, w.agc_gain, kind == 0); }
                      const float vp = (float)((double)val * (1.0 / 32767.0)) * mv;      // == volt(val, mv) for every int16 code (the quotient's rounding: checked for all 65 536)
                      rtfe_event e;
-                     e.sample = (uint32_t)(n - reset); e.v_peak = (cfg.invert && vp == 0.0f) ? -0.0f : vp; e.agc_gain = w.agc_gain;
+                     e.sample = sample0 + (uint32_t)n; e.v_peak = (cfg.invert && vp == 0.0f) ? -0.0f : vp; e.agc_gain = w.agc_gain;
                      e.trk = (uint8_t)trk; e.flags = (uint8_t)(kind | (adjcode << 1)); e.left_distance = (uint8_t)ld;
-                     for (unsigned m = pmask; m; m &= m - 1) { const int p = __ffs((int)m) - 1; e.parmset = (uint8_t)p; evb[(size_t)(p * ntrks + trk) * cap + w.nevents] = e; }
+                     if (one_set) { e.parmset = (uint8_t)(__ffs((int)pmask) - 1); ev1[w.nevents] = e; }
+                     else for (unsigned m = pmask; m; m &= m - 1) { const int p = __ffs((int)m) - 1; e.parmset = (uint8_t)p; evb[(size_t)(p * ntrks + trk) * cap + w.nevents] = e; }
                      if (kind == 0) w.v_top = vp; else w.v_bot = vp;
                      ++w.nevents; ++w.peakcount;
                      const float lastheight = w.v_lasttop - w.v_lastbot;            // src/decoder.c:505-512 (both callbacks adjust in steady state: src/decode_gcr.c:850,864)
@@ -750,32 +762,35 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                         w.agc_gain = gain; }
                      if (kind == 0) w.v_lasttop = vp; else w.v_lastbot = vp;
                      ++n_rec_ev;
-                     blind_until = n + ld;
-                     if (!(w.agc_gain > 0)) { w.thr_dirty = true; fatal_marker(n, ld); break; }
+                     blind_r = n + ld;
+                     if (!(w.agc_gain > 0)) { w.thr_dirty = true; fatal_marker(r0 + n, ld); break; }
                      const float sa = w.v_avg_height * 0.25f * fast_rcp(w.agc_gain), ra = P.rise * sa, qa = P.min_peak * sa;
                      w.thr_dirty = true;
                      const bool inb = ra >= band_rlo && ra <= band_rhi && (!amp_on || (qa >= band_qlo && qa <= band_qhi));
-                     if (!inb) { update_thresholds(w, P, lsb); if (!in_band(bd)) { next = n + 1; to_lit = true; break; } }
+                     if (!inb) { if (prof) ++pc_notinb; update_thresholds(w, P, lsb); if (!in_band(bd)) { next_r = n + 1; to_lit = true; break; } }
                      continue; }
                   // ---- every other record (a block's first peaks, PE, the window AGC): the general step ----
+                  if (prof) ++pc_general;
                   if (w.thr_dirty) update_thresholds(w, P, lsb);
-                  const long long p = n - W + ld;
+                  const long long p = r0 + (n - W + ld);
                   // refine_peak's neighbours from their distances; a clamped distance only matters if the threshold reaches it
                   int iprev = kind == 0 ? val - dp : val + dp, inext = kind == 0 ? val - dn : val + dn;
                   const int ti = (int)floorf(0.005f / w.agc_gain * lsb);
                   if (ti + 2 >= 255 || ti < 2) { iprev = y(p - 1); inext = y(p + 1); }
-                  fire(n, ld, val, kind == 0, iprev, inext);
+                  fire(r0 + n, ld, val, kind == 0, iprev, inext);
                   ++n_rec_ev;
-                  blind_until = n + ld;
+                  blind_r = n + ld;
                   if (dead_chain) break;
-                  if (!in_band(bd)) { next = n + 1; to_lit = true; break; } }   // the thresholds left the band: what this list says about the rows behind n is not proven
-               if (!dead_chain && !to_lit && next == r0 + kDsSub) {
+                  if (!in_band(bd)) { next_r = n + 1; to_lit = true; break; } }   // the thresholds left the band: what this list says about the rows behind n is not proven
+               if (!dead_chain && !to_lit && next_r == kDsSub) {
                   // the list is through: a doubt ends it early; and a lane that was blind (a fire of its own the chain passed over) where the chain
                   // is not has not looked at those rows
-                  long long lit_from = r0 + kDsSub;
-                  if (h_doubt != kDsNoDoubt) { lit_from = r0 + h_doubt; ++n_doubt; }
-                  if (lane_blind > blind_until) { const long long f = blind_until + 1 > r0 ? blind_until + 1 : r0; if (f < lit_from) lit_from = f; }
-                  if (lit_from < r0 + kDsSub) { next = lit_from; to_lit = true; } } }
+                  int lit_from = kDsSub;
+                  if (h_doubt != kDsNoDoubt) { lit_from = h_doubt; ++n_doubt; }
+                  if (lane_blind_r > blind_r) { const int f = blind_r + 1 > 0 ? blind_r + 1 : 0; if (f < lit_from) lit_from = f; }
+                  if (lit_from < kDsSub) { next_r = lit_from; to_lit = true; } } }
+            blind_until = r0 + blind_r;
+            const long long next = r0 + next_r;
             cur = next;
             if (prof) { const long long t2 = clock64(); pt_rec += t2 - ptq; ptq = t2; }
             if (to_lit && cur < stop) {
@@ -811,6 +826,8 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
       if (n_rec_ev) atomicAdd(&scratch->dbg[1], (unsigned long long)n_rec_ev);
       if (n_doubt) atomicAdd(&scratch->why[0], (unsigned long long)n_doubt);
       if (n_nojoin) atomicAdd(&scratch->why[1], (unsigned long long)n_nojoin);
-      if (failed) atomicAdd(&scratch->why[2], 1ull); } }
+      if (failed) atomicAdd(&scratch->why[2], 1ull);
+      if (prof) { atomicAdd(&scratch->why[3], (unsigned long long)pc_rec); atomicAdd(&scratch->why[4], (unsigned long long)pc_maybe); atomicAdd(&scratch->why[5], (unsigned long long)pc_unclear);
+                  atomicAdd(&scratch->why[6], (unsigned long long)pc_general); atomicAdd(&scratch->why[7], (unsigned long long)pc_notinb); } } }
 
 }  // namespace rtfe

@@ -1,12 +1,5 @@
 #!/bin/bash
-# scratch: G1 / P1 / C4 / C2 after a kernel change + the dense parity tests
 mkdir -p gpurun_out
-for c in G1 P1 C4 C2; do timeout 300 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs > gpurun_out/bench_$c.json 2>gpurun_out/bench_$c.err; echo "$c rc $?"; done
-python - <<'PY'
-import json
-for f in ("bench_G1", "bench_P1", "bench_C4", "bench_C2"):
-    try: j = json.loads(open("gpurun_out/%s.json" % f).read().strip().splitlines()[-1])
-    except Exception as e: print(f, "unreadable", e); continue
-    print(f, {k: j[k] for k in ("value", "ms_per_step", "timed_steps")}, {k: v for k, v in j["kernel_ms"].items() if v > 0.05})
-PY
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "dense or c4 or gcr or pe" 2>&1 | tail -3
+export PROBE_COPIES=200
+echo "== RTFE_DEBUG=8 gcr"; RTFE_DEBUG=8 timeout 300 python tools/gpu_dense_probe.py 5e6 1 gcr 2>&1 | tail -2
+echo "== RTFE_DEBUG=8 pe"; RTFE_DEBUG=8 timeout 300 python tools/gpu_dense_probe.py 5e6 1 pe 2>&1 | tail -2
