@@ -44,6 +44,7 @@ struct rtfe_handle {
    hipStream_t side;                   // the peak path's quiet map -> bursts -> restart rows beside its lists -> streams (both only need k_sift): RTFE_OVERLAP=0 keeps them in line
    hipEvent_t ev_fork, ev_join;
    int overlap;
+   int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
 };
 
 static thread_local char g_err[512] = "";
@@ -367,6 +368,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
    h->zeros_kernel = getenv("RTFE_ZEROS_KERNEL") ? atoi(getenv("RTFE_ZEROS_KERNEL")) != 0 : 1;
    h->side = nullptr; h->overlap = getenv("RTFE_OVERLAP") ? atoi(getenv("RTFE_OVERLAP")) != 0 : 1;
+   h->bursts_wpr = getenv("RTFE_BURSTS_WPR") ? atoi(getenv("RTFE_BURSTS_WPR")) : 0;
    // (k_zeros packs two tracks' 16-bit states into a lane and reads the rows where they lie: no -invert, no deskew delays, a threshold inside int16)
    if (d.invert || d.maxskew > 0 || d.ntrks < 2 || d.zc_peak_i < 1 || d.zc_peak_i > 32767 || !d.zc_parallel) h->zeros_kernel = 0;      // (RTFE_ZC_PARALLEL=0: k_decode's sequential walk, for the tests)
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
@@ -432,9 +434,11 @@ static long long nwords_for(const rtfe_handle *h, int64_t nrows) {
    return (nchunks + 63) / 64 + 1; }
 
 static long long ntiles_for(const rtfe_handle *h, int64_t nrows) { return (nrows + h->dev.tile_rows - 1) / h->dev.tile_rows; }
-// workspace: [0,kScratchBytes) scratch | quiet words | burst control blocks | the peak path's pieces
+// workspace: [0,kScratchBytes) scratch | quiet words | the zone search's counts per round | burst control blocks | the peak path's pieces
 static long long pk_tiles_for(int64_t nrows) { return (nrows + kSfTile - 1) / kSfTile; }
-static size_t ws_ctl_off(const rtfe_handle *h, int64_t nrows) { return (kScratchBytes + (size_t)nwords_for(h, nrows) * 8 + 255) & ~(size_t)255; }
+constexpr int kBrRoundsMax = 1024;                                  // k_bursts_cnt / _emit: a workgroup per round of the zone search, at most this many (else one workgroup does them all)
+static size_t ws_rtot_off(const rtfe_handle *h, int64_t nrows) { return kScratchBytes + (size_t)nwords_for(h, nrows) * 8; }      // ... | the rounds' counts
+static size_t ws_ctl_off(const rtfe_handle *h, int64_t nrows) { return (ws_rtot_off(h, nrows) + (size_t)kBrRoundsMax * 4 + 255) & ~(size_t)255; }
 
 extern "C" int64_t rtfe_max_bursts(const rtfe_handle *h, int64_t nrows) {
    return (nrows / kChunkRows) / h->dev.gap_chunks + 4; }
@@ -517,6 +521,22 @@ static int launch_check(const char *what) {
    hipError_t e = hipGetLastError();
    if (e != hipSuccess) return fail(-30, "%s: %s", what, hipGetErrorString(e));
    return 0; }
+
+// quiet map -> burst table.  Long maps: a workgroup per round of 2^24 rows in two passes and a tail (k_bursts_cnt / _emit / _tail); short ones
+// (or absurdly long ones): the single workgroup that does the rounds in turn.  RTFE_BURSTS_WPR: words per round (tests: many rounds on a short tape).
+static void launch_bursts(const rtfe_handle *h, hipStream_t s, const unsigned long long *qwords, long long nwords, long long nchunks, int64_t nrows, int64_t own_rows,
+                          int first_is_tape_start, int64_t event_capacity, rtfe_burst *d_bursts, long long maxb, BurstScratch *scratch, int32_t *d_nbursts, uint32_t *rtot) {
+   const int wpr_env = h->bursts_wpr;
+   const int wpr = (wpr_env >= 1 && wpr_env <= kBrWords) ? wpr_env : kBrWords;
+   const long long rounds = (nwords + wpr - 1) / wpr;
+   if ((wpr_env > 0 || rounds >= 3) && rounds <= kBrRoundsMax && h->dev.debug != 5) {
+      hipLaunchKernelGGL(k_bursts_cnt, dim3((unsigned)rounds), dim3(1024), 0, s, qwords, nwords, nchunks, wpr, h->dev.gap_chunks, first_is_tape_start, maxb, rtot);
+      hipLaunchKernelGGL(k_bursts_emit, dim3((unsigned)rounds), dim3(1024), 0, s, qwords, nwords, nchunks, (long long)nrows, wpr, h->dev.gap_chunks, first_is_tape_start, d_bursts, maxb, (const uint32_t *)rtot);
+      hipLaunchKernelGGL(k_bursts_tail, dim3(1), dim3(1024), 0, s, (int)rounds, (const uint32_t *)rtot, (long long)nrows, (long long)own_rows, h->dev.ntrks, h->dev.gap_chunks,
+                         h->dev.cap_frac, h->dev.nparm, (long long)event_capacity, d_bursts, maxb, scratch, d_nbursts); }
+   else
+      hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, s, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
+                         h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity, d_bursts, maxb, scratch, d_nbursts, h->dev.debug == 5 ? 1 : 0); }
 
 extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t own_rows, int64_t row_base, int first_is_tape_start,
                          void *d_workspace, size_t workspace_bytes,
@@ -605,9 +625,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          if (h->side) { sa = h->side; (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(sa, h->ev_fork, 0); } }
       t0s(kTBursts, sa);
       hipLaunchKernelGGL(k_qpack, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, sa, (const uint16_t *)qtile, ptiles, qwords, nwords);
-      hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, sa, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
-                         h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
-                         d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts, h->dev.debug == 5 ? 1 : 0);
+      launch_bursts(h, sa, qwords, nwords, nchunks, nrows, own_rows, first_is_tape_start, event_capacity, d_bursts,
+                    (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts, reinterpret_cast<uint32_t *>(wsb + ws_rtot_off(h, nrows)));
       if (stop_after >= 3)
          hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, sa, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                             (const BurstScratch *)scratch, ctlp);
@@ -692,9 +711,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_quiet, dim3(grid), dim3(256), 0, st, d_rows, (long long)nrows, h->dev.ntrks, h->dev.quiet_i, qwords, nwords);
       t1(kTQuiet); }
    t0(kTBursts);
-   hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, st, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
-                      h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity,
-                      d_bursts, (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts, h->dev.debug == 5 ? 1 : 0);
+   launch_bursts(h, st, qwords, nwords, nchunks, nrows, own_rows, first_is_tape_start, event_capacity, d_bursts,
+                 (long long)(max_bursts < rtfe_max_bursts(h, nrows) ? max_bursts : rtfe_max_bursts(h, nrows)), scratch, d_nbursts, reinterpret_cast<uint32_t *>(wsb + ws_rtot_off(h, nrows)));
    if (h->dev.dense_path)                                              // the restart rows of all bursts (rtfe_gain.hip)
       hipLaunchKernelGGL(k_zones, dim3(h->num_cus * 8), dim3(64), 0, st, h->d_dev, d_rows, (long long)nrows, (const rtfe_burst *)d_bursts,
                          (const BurstScratch *)scratch, ctlp);

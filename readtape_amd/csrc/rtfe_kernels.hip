@@ -69,115 +69,102 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int *lds, int *total)
    __syncthreads();
    return r; }
 
-__global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords, long long nwords, long long nchunks,
-                                                 long long nrows, long long own_rows, int ntrks, int gap_chunks, int first_is_start,
-                                                 float cap_frac, int nparm, long long event_capacity,
-                                                 rtfe_burst *__restrict__ bursts, long long max_bursts,
-                                                 BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out, int prof) {
-   __shared__ int lds[32];
-   long long pk0 = prof ? clock64() : 0, pk1 = 0, pk2 = 0, pa = 0, pb2 = 0, pc = 0, pd = 0, tq = 0;
-   __shared__ int s_base;
-   __shared__ u64 s_ebase;
-   // The quiet map goes through LDS a round (4096 words = 2^18 chunks) at a time, with 64 words in front of it (a zone may begin there;
-   // further back the walk reads HBM): the tests below are chains of dependent reads, a microsecond each from HBM, and there is one
-   // workgroup to hide them.
-   constexpr int kPer = 4;                                          // consecutive words per thread per round (fewer block scans)
-   constexpr int kBack = 64, kWin = kBack + 1024 * kPer + 1;
-   __shared__ u64 s_q[kWin];
-   long long wbase = 0;
-   auto qword = [&](long long w) -> u64 {
+// The zone search a round (4096 words of the quiet map = 2^18 chunks = 2^24 rows) at a time; a round's window goes through LDS with 64 words
+// in front of it (a zone may begin there; further back the walk reads HBM): the tests are chains of dependent reads, a microsecond each
+// from HBM.  One workgroup does all rounds in turn (k_bursts), or - long tapes - a workgroup per round in two passes (k_bursts_cnt: the
+// rounds' counts; k_bursts_emit: the entries, each round behind the sum of the counts in front of it) and k_bursts_tail.
+constexpr int kBrPer = 4;                                           // consecutive words per thread per round (fewer block scans)
+constexpr int kBrWords = 1024 * kBrPer;
+constexpr int kBrBack = 64, kBrWin = kBrBack + kBrWords + 1;
+struct BrWin {
+   const u64 *qwords; long long nwords, nchunks, wbase; const u64 *s_q;
+   __device__ __forceinline__ u64 qword(long long w) const {
       if (w < 0 || w >= nwords) return 0;
       const long long k = w - wbase;
-      return (k >= 0 && k < kWin) ? s_q[k] : qwords[w]; };
-   auto quiet = [&](long long c) -> bool { return c >= 0 && c < nchunks && ((qword(c >> 6) >> (c & 63)) & 1); };
-   if (threadIdx.x == 0) s_base = 0;
-   for (long long w0 = 0; w0 < nwords; w0 += 1024 * kPer) {
-      __syncthreads();
-      if (prof) tq = clock64();
-      wbase = w0 - kBack;
-      {  u64 t[(kWin + 1023) / 1024];                                // (all loads in flight before the first is waited for)
-         #pragma unroll
-         for (int j = 0; j < (kWin + 1023) / 1024; ++j) { const long long w = wbase + j * 1024 + (int)threadIdx.x; t[j] = (w >= 0 && w < nwords) ? qwords[w] : 0; }
-         #pragma unroll
-         for (int j = 0; j < (kWin + 1023) / 1024; ++j) { const int k = j * 1024 + (int)threadIdx.x; if (k < kWin) s_q[k] = t[j]; } }
-      __syncthreads();
-      if (w0 == 0 && threadIdx.x == 0) {
-         // a tape (or shard) that does not begin inside a qualifying zone gets an exact-start burst at row 0
-         bool starts_quiet = true;
-         for (int c = 0; c < gap_chunks; ++c) if (!quiet(c)) { starts_quiet = false; break; }
-         if (first_is_start && !starts_quiet && max_bursts > 0) {
-            rtfe_burst b = {};
-            b.zone_first = 0; b.zone_end = 0; b.reset_sample = 0; b.safe_last = 0; b.flags = RTFE_F_EXACT_START;
-            bursts[0] = b;
-            s_base = 1; } }
-      __syncthreads();
-      if (prof) { const long long t2 = clock64(); pa += t2 - tq; tq = t2; }
-      u64 ends[kPer];
-      int cnt = 0;
-      #pragma unroll
-      for (int j = 0; j < kPer; ++j) {
-         const long long w = w0 + (long long)threadIdx.x * kPer + j;
-         ends[j] = 0;
-         if (w < nwords) {
-            const u64 q = s_q[kBack + (int)threadIdx.x * kPer + j];            // (the round's own words, straight from the window: words behind the map read 0)
-            const u64 qn = s_q[kBack + (int)threadIdx.x * kPer + j + 1];
-            const u64 next = (q >> 1) | (qn << 63);         // bit c = quiet[c+1]
-            u64 cand = q & ~next;                           // quiet and successor not quiet
-            const u64 qp = s_q[kBack + (int)threadIdx.x * kPer + j - 1];      // (word -1 of the map reads 0: not quiet)
-            while (cand) {
-               const int bit = __ffsll((long long)cand) - 1;
-               cand &= cand - 1;
-               bool ok = true;
-               if (gap_chunks <= 64) {
-                  // chunks c, c - 1, ... from bit 63 downwards: the gap_chunks uppermost must all be quiet
-                  const u64 v = bit == 63 ? q : ((q << (63 - bit)) | (qp >> (bit + 1)));
-                  ok = ((~v) >> (64 - gap_chunks)) == 0; }
-               else {
-                  const long long c = w * 64 + bit;
-                  for (int k = 1; k < gap_chunks; ++k) if (!quiet(c - k)) { ok = false; break; } }
-               if (ok) ends[j] |= 1ull << bit; } }
-         cnt += __popcll(ends[j]); }
-      if (prof) { const long long t2 = clock64(); pb2 += t2 - tq; tq = t2; }
-      int total;
-      int off = block_excl_scan_1024(cnt, lds, &total);
-      const int base = s_base;
-      if (prof) { const long long t2 = clock64(); pc += t2 - tq; tq = t2; }
-      #pragma unroll
-      for (int j = 0; j < kPer; ++j) {
-         const long long w = w0 + (long long)threadIdx.x * kPer + j;
-         u64 e = ends[j];
-         while (e) {
-            const int bit = __ffsll((long long)e) - 1;
-            e &= e - 1;
-            const long long c1 = w * 64 + bit + 1;          // one past the last quiet chunk
-            // zone start: walk back over quiet chunks a 64-bit word at a time
-            long long c0 = c1 - 1;
-            for (;;) {
-               if (c0 == 0) break;
-               const long long pw = (c0 - 1) >> 6; const int pb = (int)((c0 - 1) & 63);
-               // bits pb..0 of word pw, shifted so that bit pb becomes bit 63: count the leading run of ones
-               const u64 run = ~(qword(pw) << (63 - pb));
-               const int ones = run ? __clzll((long long)run) : 64;
-               const int take = ones < pb + 1 ? ones : pb + 1;
-               c0 -= take;
-               if (take < pb + 1) break; }
-            const long long idx = (long long)base + off++;
-            if (idx < max_bursts) {
-               rtfe_burst b = {};
-               long long zf = c0 * kChunkRows;                          // first row of the zone (chunks are groups of 64 rows)
-               long long ze = c1 * kChunkRows;                          // one past its last row
-               if (ze > nrows) ze = nrows & ~63ll;
-               b.zone_first = zf; b.zone_end = ze; b.reset_sample = -1; b.safe_last = -1;
-               bursts[idx] = b; } } }
-      __syncthreads();
-      if (prof) { const long long t2 = clock64(); pd += t2 - tq; tq = t2; }
-      if (threadIdx.x == 0) s_base = base + total; }
+      return (k >= 0 && k < kBrWin) ? s_q[k] : qwords[w]; }
+   __device__ __forceinline__ bool quiet(long long c) const { return c >= 0 && c < nchunks && ((qword(c >> 6) >> (c & 63)) & 1); } };
+// the window of the round that begins at word w0 (all threads; barriers inside)
+__device__ __forceinline__ BrWin br_window(const u64 *__restrict__ qwords, long long nwords, long long nchunks, long long w0, u64 *s_q) {
+   BrWin bw; bw.qwords = qwords; bw.nwords = nwords; bw.nchunks = nchunks; bw.wbase = w0 - kBrBack; bw.s_q = s_q;
    __syncthreads();
-   if (prof) pk1 = clock64();
-   int nb = s_base;
+   {  u64 t[(kBrWin + 1023) / 1024];                                // (all loads in flight before the first is waited for)
+      #pragma unroll
+      for (int j = 0; j < (kBrWin + 1023) / 1024; ++j) { const long long w = bw.wbase + j * 1024 + (int)threadIdx.x; t[j] = (w >= 0 && w < nwords) ? qwords[w] : 0; }
+      #pragma unroll
+      for (int j = 0; j < (kBrWin + 1023) / 1024; ++j) { const int k = j * 1024 + (int)threadIdx.x; if (k < kBrWin) s_q[k] = t[j]; } }
+   __syncthreads();
+   return bw; }
+// a tape (or shard) that does not begin inside a qualifying zone gets an exact-start burst at row 0 (one thread, the window of round 0)
+__device__ __forceinline__ bool br_exact_start(const BrWin &bw, int gap_chunks, int first_is_start, long long max_bursts) {
+   bool starts_quiet = true;
+   for (int c = 0; c < gap_chunks; ++c) if (!bw.quiet(c)) { starts_quiet = false; break; }
+   return first_is_start && !starts_quiet && max_bursts > 0; }
+// this thread's words of the round [w0, w0 + wpr): the zone ends in them (a bit per chunk); returns their number
+__device__ __forceinline__ int br_ends(const BrWin &bw, long long w0, int wpr, int gap_chunks, u64 (&ends)[kBrPer]) {
+   int cnt = 0;
+   #pragma unroll
+   for (int j = 0; j < kBrPer; ++j) {
+      const int wi = (int)threadIdx.x * kBrPer + j;
+      const long long w = w0 + wi;
+      ends[j] = 0;
+      if (wi < wpr && w < bw.nwords) {
+         const u64 q = bw.s_q[kBrBack + wi];                          // (the round's own words, straight from the window: words behind the map read 0)
+         const u64 qn = bw.s_q[kBrBack + wi + 1];
+         const u64 next = (q >> 1) | (qn << 63);                    // bit c = quiet[c+1]
+         u64 cand = q & ~next;                                      // quiet and successor not quiet
+         const u64 qp = bw.s_q[kBrBack + wi - 1];                     // (word -1 of the map reads 0: not quiet)
+         while (cand) {
+            const int bit = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            bool ok = true;
+            if (gap_chunks <= 64) {
+               // chunks c, c - 1, ... from bit 63 downwards: the gap_chunks uppermost must all be quiet
+               const u64 v = bit == 63 ? q : ((q << (63 - bit)) | (qp >> (bit + 1)));
+               ok = ((~v) >> (64 - gap_chunks)) == 0; }
+            else {
+               const long long c = w * 64 + bit;
+               for (int k = 1; k < gap_chunks; ++k) if (!bw.quiet(c - k)) { ok = false; break; } }
+            if (ok) ends[j] |= 1ull << bit; } }
+      cnt += __popcll(ends[j]); }
+   return cnt; }
+// ... and their table entries, from index idx0 on
+__device__ __forceinline__ void br_emit(const BrWin &bw, long long w0, const u64 (&ends)[kBrPer], long long idx0, long long nrows, rtfe_burst *__restrict__ bursts, long long max_bursts) {
+   long long idx = idx0;
+   #pragma unroll
+   for (int j = 0; j < kBrPer; ++j) {
+      const long long w = w0 + (long long)threadIdx.x * kBrPer + j;
+      u64 e = ends[j];
+      while (e) {
+         const int bit = __ffsll((long long)e) - 1;
+         e &= e - 1;
+         const long long c1 = w * 64 + bit + 1;                     // one past the last quiet chunk
+         // zone start: walk back over quiet chunks a 64-bit word at a time
+         long long c0 = c1 - 1;
+         for (;;) {
+            if (c0 == 0) break;
+            const long long pw = (c0 - 1) >> 6; const int pb = (int)((c0 - 1) & 63);
+            // bits pb..0 of word pw, shifted so that bit pb becomes bit 63: count the leading run of ones
+            const u64 run = ~(bw.qword(pw) << (63 - pb));
+            const int ones = run ? __clzll((long long)run) : 64;
+            const int take = ones < pb + 1 ? ones : pb + 1;
+            c0 -= take;
+            if (take < pb + 1) break; }
+         if (idx < max_bursts) {
+            rtfe_burst b = {};
+            long long zf = c0 * kChunkRows;                          // first row of the zone (chunks are groups of 64 rows)
+            long long ze = c1 * kChunkRows;                          // one past its last row
+            if (ze > nrows) ze = nrows & ~63ll;
+            b.zone_first = zf; b.zone_end = ze; b.reset_sample = -1; b.safe_last = -1;
+            bursts[idx] = b; }
+         ++idx; } } }
+// behind the search: which bursts this scan owns (time shards), their coarse extents, event capacities and region bases (all threads of one workgroup)
+__device__ __forceinline__ void br_tail(int nb_found, long long nrows, long long own_rows, int ntrks, int gap_chunks, float cap_frac, int nparm, long long event_capacity,
+                                        rtfe_burst *__restrict__ bursts, long long max_bursts, BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out, int *lds) {
+   __shared__ u64 s_ebase;
+   __shared__ int s_owned;
+   int nb = nb_found;
    if (nb > max_bursts) nb = (int)max_bursts;
    // time shards: keep the bursts that start in the owned rows, plus one more as the bound of the last of them
-   __shared__ int s_owned;
    if (threadIdx.x == 0) s_owned = nb;
    __syncthreads();
    for (int b0 = 0; b0 < nb; b0 += 1024) {
@@ -188,8 +175,7 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
    __syncthreads();
    const int n_owned = s_owned;
    if (nb > n_owned + 1) nb = n_owned + 1;
-   // drop zones too short to hold a head tile (zone_end - zone_first < margin + 64): mark by flags later in decode
-   // ---- second pass: coarse extents, event capacities and region bases (parallel prefix sum) ----
+   // ---- coarse extents, event capacities and region bases (parallel prefix sum) ----
    if (threadIdx.x == 0) s_ebase = 0;
    __syncthreads();
    for (int b0 = 0; b0 < nb; b0 += 1024) {
@@ -220,9 +206,86 @@ __global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords,
       if (n_owned == nb && own_rows < nrows && n_owned > 0) bursts[n_owned - 1].flags |= RTFE_F_TRUNCATED; }
    if (threadIdx.x < 8) scratch->dbg[threadIdx.x] = 0;
    if (threadIdx.x >= 16 && threadIdx.x < 24) scratch->dbg2[threadIdx.x - 16] = 0;
-   if (threadIdx.x >= 24 && threadIdx.x < 32) scratch->why[threadIdx.x - 24] = 0;
-   if (prof && threadIdx.x == 0) { pk2 = clock64(); scratch->scr[0] = (unsigned long long)(pk1 - pk0); scratch->scr[1] = (unsigned long long)(pk2 - pk1); scratch->scr[2] = (unsigned long long)pa; scratch->scr[3] = (unsigned long long)pb2; scratch->scr[4] = (unsigned long long)pc; scratch->scr[5] = (unsigned long long)pd; }      // (RTFE_DEBUG=5)
+   if (threadIdx.x >= 24 && threadIdx.x < 32) scratch->why[threadIdx.x - 24] = 0; }
+
+__global__ void __launch_bounds__(1024) k_bursts(const u64 *__restrict__ qwords, long long nwords, long long nchunks,
+                                                 long long nrows, long long own_rows, int ntrks, int gap_chunks, int first_is_start,
+                                                 float cap_frac, int nparm, long long event_capacity,
+                                                 rtfe_burst *__restrict__ bursts, long long max_bursts,
+                                                 BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out, int prof) {
+   __shared__ int lds[32];
+   long long pk0 = prof ? clock64() : 0, pk1 = 0, pk2 = 0;
+   __shared__ int s_base;
+   __shared__ u64 s_q[kBrWin];
+   if (threadIdx.x == 0) s_base = 0;
+   for (long long w0 = 0; w0 < nwords; w0 += kBrWords) {
+      const BrWin bw = br_window(qwords, nwords, nchunks, w0, s_q);
+      if (w0 == 0 && threadIdx.x == 0 && br_exact_start(bw, gap_chunks, first_is_start, max_bursts)) {
+         rtfe_burst b = {};
+         b.zone_first = 0; b.zone_end = 0; b.reset_sample = 0; b.safe_last = 0; b.flags = RTFE_F_EXACT_START;
+         bursts[0] = b;
+         s_base = 1; }
+      __syncthreads();
+      u64 ends[kBrPer];
+      const int cnt = br_ends(bw, w0, kBrWords, gap_chunks, ends);
+      int total;
+      const int off = block_excl_scan_1024(cnt, lds, &total);
+      const int base = s_base;
+      br_emit(bw, w0, ends, (long long)base + off, nrows, bursts, max_bursts);
+      __syncthreads();
+      if (threadIdx.x == 0) s_base = base + total; }
+   __syncthreads();
+   if (prof) pk1 = clock64();
+   br_tail(s_base, nrows, own_rows, ntrks, gap_chunks, cap_frac, nparm, event_capacity, bursts, max_bursts, scratch, nbursts_out, lds);
+   if (prof && threadIdx.x == 0) { pk2 = clock64(); scratch->scr[0] = (unsigned long long)(pk1 - pk0); scratch->scr[1] = (unsigned long long)(pk2 - pk1); }      // (RTFE_DEBUG=5)
    }       // (scratch->scr: cleared with the rest of the scratch block when rtfe_scan starts)
+
+// The same search with a workgroup per round of wpr words (4096; fewer in tests).  k_bursts_cnt: rtot[r] = the zone ends of round r (+ the
+// exact-start burst in round 0); k_bursts_emit: round r's entries from index sum(rtot[0 .. r)) on; k_bursts_tail: the rest.
+__global__ void __launch_bounds__(1024) k_bursts_cnt(const u64 *__restrict__ qwords, long long nwords, long long nchunks, int wpr, int gap_chunks, int first_is_start,
+                                                     long long max_bursts, uint32_t *__restrict__ rtot) {
+   __shared__ int lds[32];
+   __shared__ u64 s_q[kBrWin];
+   const long long w0 = (long long)blockIdx.x * wpr;
+   const BrWin bw = br_window(qwords, nwords, nchunks, w0, s_q);
+   u64 ends[kBrPer];
+   const int cnt = br_ends(bw, w0, wpr, gap_chunks, ends);
+   int total;
+   (void)block_excl_scan_1024(cnt, lds, &total);
+   if (threadIdx.x == 0) rtot[blockIdx.x] = (uint32_t)total + ((blockIdx.x == 0 && br_exact_start(bw, gap_chunks, first_is_start, max_bursts)) ? 1u : 0u); }
+__global__ void __launch_bounds__(1024) k_bursts_emit(const u64 *__restrict__ qwords, long long nwords, long long nchunks, long long nrows, int wpr, int gap_chunks, int first_is_start,
+                                                      rtfe_burst *__restrict__ bursts, long long max_bursts, const uint32_t *__restrict__ rtot) {
+   __shared__ int lds[32];
+   __shared__ u64 s_q[kBrWin];
+   const long long w0 = (long long)blockIdx.x * wpr;
+   // the entries in front of this round's: the counts of the rounds before it (a sum over at most a few thousand numbers)
+   long long base;
+   {  long long mine = 0;
+      for (int r = threadIdx.x; r < (int)blockIdx.x; r += 1024) mine += rtot[r];
+      int total;
+      (void)block_excl_scan_1024((int)(mine > 0x3fffffll ? 0x3fffffll : mine), lds, &total);      // (saturates far beyond any table: nothing is written at or behind max_bursts)
+      base = total; }
+   const BrWin bw = br_window(qwords, nwords, nchunks, w0, s_q);
+   if (blockIdx.x == 0 && br_exact_start(bw, gap_chunks, first_is_start, max_bursts)) {      // (every thread decides alike)
+      if (threadIdx.x == 0) {
+         rtfe_burst b = {};
+         b.zone_first = 0; b.zone_end = 0; b.reset_sample = 0; b.safe_last = 0; b.flags = RTFE_F_EXACT_START;
+         bursts[0] = b; }
+      base = 1; }
+   u64 ends[kBrPer];
+   const int cnt = br_ends(bw, w0, wpr, gap_chunks, ends);
+   int total;
+   const int off = block_excl_scan_1024(cnt, lds, &total);
+   br_emit(bw, w0, ends, base + off, nrows, bursts, max_bursts); }
+__global__ void __launch_bounds__(1024) k_bursts_tail(int nrounds, const uint32_t *__restrict__ rtot, long long nrows, long long own_rows, int ntrks, int gap_chunks,
+                                                      float cap_frac, int nparm, long long event_capacity, rtfe_burst *__restrict__ bursts, long long max_bursts,
+                                                      BurstScratch *__restrict__ scratch, int32_t *__restrict__ nbursts_out) {
+   __shared__ int lds[32];
+   long long mine = 0;
+   for (int r = threadIdx.x; r < nrounds; r += 1024) mine += rtot[r];
+   int total;
+   (void)block_excl_scan_1024((int)(mine > 0x3fffffll ? 0x3fffffll : mine), lds, &total);      // (1024 x 2^22 stays inside an int; the table is shorter than that anyway)
+   br_tail(total, nrows, own_rows, ntrks, gap_chunks, cap_frac, nparm, event_capacity, bursts, max_bursts, scratch, nbursts_out, lds); }
 
 // ------------------------------------------------------------------------------------------------
 // k_decode

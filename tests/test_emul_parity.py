@@ -245,3 +245,40 @@ def test_emulated_dense_sweep_equals_the_sample_path(kind, knobs, monkeypatch):
     print(kind, knobs, st, int(r1.counts.sum()))
     assert st["redone"] == 0 and st["parallel"] + st["sequential"] > 0, st
     _same_results(cfg, r0, r1)
+
+
+def _wpr_pair(cfg, rows, wpr, monkeypatch):
+    monkeypatch.delenv("RTFE_BURSTS_WPR", raising=False)
+    f0 = emul_frontend(cfg)
+    r0 = f0.scan(rows).fetch()
+    monkeypatch.setenv("RTFE_BURSTS_WPR", wpr)
+    f1 = emul_frontend(cfg)
+    r1 = f1.scan(rows).fetch()
+    for k in ("event_base", "event_cap"):
+        assert (r0.bursts[k] == r1.bursts[k]).all(), k
+    _same_results(cfg, r0, r1)
+    return r1
+
+
+@pytest.mark.parametrize("wpr", ["1", "2"])
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "gcr", "pe", "pe_zeros", "nrzi9_cut", "noise_only", "tiny", "nrzi7"])
+def test_emulated_burst_search_a_workgroup_per_round(name, wpr, monkeypatch):
+    """The zone search with a workgroup per round (k_bursts_cnt / _emit / _tail: what tapes of 5e7 rows and more take) against the single
+    workgroup that does the rounds in turn: RTFE_BURSTS_WPR cuts the rounds down to a word or two of the quiet map (64 / 128 groups of 64
+    rows), so that short tapes have several."""
+    g = load_case(name)
+    _wpr_pair(config_for(g["hdr"], g["oracle_opts"]), g["rows"], wpr, monkeypatch)
+
+
+@pytest.mark.parametrize("wpr", ["1", "3", "8"])
+def test_emulated_burst_search_many_rounds(wpr, monkeypatch):
+    """... on a tape of 70 words of quiet map: zones that begin rounds in front of the round they end in (gaps of 3 .. 4 words), a tape that
+    does not begin in a gap (the exact-start burst of round 0), rounds without any zone end."""
+    from readtape_amd import synth
+    tape = synth.nrzi_tape(seed=77, nblocks=14, minlen=200, maxlen=1500, marks_every=5, gap_samples=14000)
+    hdr = tape.spec.header()
+    cfg = frontend.FrontEndConfig.from_header(hdr, nparmsets=1)
+    rows = tape.rows[15000:]                                   # (it begins inside the first block)
+    r1 = _wpr_pair(cfg, rows, wpr, monkeypatch)
+    assert rows.shape[0] >= 64 * 64 * 40 and r1.nbursts >= 14 and (int(r1.bursts["flags"][0]) & frontend.F_EXACT_START)
+    _wpr_pair(cfg, tape.rows, wpr, monkeypatch)                # ... and in its first gap
