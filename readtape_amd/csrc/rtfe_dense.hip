@@ -610,6 +610,7 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
       long long no_join_before = 0;                                       // (behind a doubt the rest of its sub-segment is the literal detector's)
       long long rounds_left = (stop > reset ? (stop - reset) : 0) / 2 + 64;     // (every round moves `cur` on; belt and braces against a loop that does not)
       unsigned n_lit_rows = 0, n_rec_ev = 0, n_doubt = 0, n_nojoin = 0;
+      int a_rlo = 0, a_rhi = 0, a_mlo = 0, a_mhi = 0;                      // the lean step's approximate integer guards (valid while w.thr_dirty)
       unsigned pc_rec = 0, pc_maybe = 0, pc_unclear = 0, pc_general = 0, pc_notinb = 0;      // (RTFE_DEBUG=8: records by the path they took)
       // (every lane of the wave goes through the same rounds: the emulator's ballot needs all of them)
       const bool prof = cfg.debug == 8;
@@ -712,17 +713,37 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                   if (prof) ++pc_rec;
                   if (nm) {
                      if (prof) ++pc_maybe;
-                     if (w.thr_dirty) update_thresholds(w, P, lsb);
+                     // First on integer guards alone - behind a lean step the approximate ones it left (a code wider on either side than the exact
+                     // thresholds' own): a margin at or above the upper guard passes the reference's float comparison, one at or below the
+                     // lower guard fails it.  Only a margin (or an extreme, for min_peak) between the guards needs the exact thresholds - two
+                     // IEEE divisions that a wave of 64 chains would otherwise go through for nearly every record one of its lanes holds.
+                     const int rlo = w.thr_dirty ? a_rlo : w.rise_lo, rhi = w.thr_dirty ? a_rhi : w.rise_hi, mlo = w.thr_dirty ? a_mlo : w.min_lo, mhi = w.thr_dirty ? a_mhi : w.min_hi;
+                     const int av = kind == 0 ? val : -val;
+                     const int m0 = blind_r >= nf ? blind_r + 1 - nf : 0;
+                     bool need_exact = amp_on && av < mhi && av > mlo;
+                     const bool amp_sure = !amp_on || av >= mhi;
                      n = cond ? -1 : nf + nm;
-                     const bool amp_ok = w.reqmin == 0 || (kind == 0 ? (val >= w.min_hi || (val > w.min_lo && volt(val, mv) > w.reqmin))
-                                                                    : (-val >= w.min_hi || (-val > w.min_lo && volt(val, mv) < -w.reqmin)));
-                     for (int m = (blind_r >= nf ? blind_r + 1 - nf : 0); m < nm; ++m) {
-                        const int kk = k + 1 + (m >> 2);
-                        const uint4 e4 = s_slot[(1 + (kk >> 1)) * 64 + lane];
-                        const uint32_t ew = (m & 2) ? ((kk & 1) ? e4.w : e4.y) : ((kk & 1) ? e4.z : e4.x);
-                        const int mg = (int)((ew >> (16 * (m & 1))) & 0xffff);
-                        const bool hit = amp_ok && (kind == 0 ? above_by(val, val - mg, w.rise, w.rise_lo, w.rise_hi, mv) : below_by(val, val + mg, w.rise, w.rise_lo, w.rise_hi, mv));
-                        if (hit) { n = nf + m; break; } }
+                     if (!need_exact && amp_sure) {
+                        for (int m = m0; m < nm; ++m) {
+                           const int kk = k + 1 + (m >> 2);
+                           const uint4 e4 = s_slot[(1 + (kk >> 1)) * 64 + lane];
+                           const uint32_t ew = (m & 2) ? ((kk & 1) ? e4.w : e4.y) : ((kk & 1) ? e4.z : e4.x);
+                           const int mg = (int)((ew >> (16 * (m & 1))) & 0xffff);
+                           if (mg >= rhi) { n = nf + m; break; }
+                           if (mg > rlo) { need_exact = true; break; } } }
+                     if (need_exact) {
+                        if (prof) ++pc_notinb;
+                        if (w.thr_dirty) update_thresholds(w, P, lsb);
+                        n = cond ? -1 : nf + nm;
+                        const bool amp_ok = w.reqmin == 0 || (kind == 0 ? (val >= w.min_hi || (val > w.min_lo && volt(val, mv) > w.reqmin))
+                                                                       : (-val >= w.min_hi || (-val > w.min_lo && volt(val, mv) < -w.reqmin)));
+                        for (int m = m0; m < nm; ++m) {
+                           const int kk = k + 1 + (m >> 2);
+                           const uint4 e4 = s_slot[(1 + (kk >> 1)) * 64 + lane];
+                           const uint32_t ew = (m & 2) ? ((kk & 1) ? e4.w : e4.y) : ((kk & 1) ? e4.z : e4.x);
+                           const int mg = (int)((ew >> (16 * (m & 1))) & 0xffff);
+                           const bool hit = amp_ok && (kind == 0 ? above_by(val, val - mg, w.rise, w.rise_lo, w.rise_hi, mv) : below_by(val, val + mg, w.rise, w.rise_lo, w.rise_hi, mv));
+                           if (hit) { n = nf + m; break; } } }
                      k = next_k;
                      if (n < 0) continue; }                                 // (a conditional record that does not fire: nothing happens)
                   if (n >= stop_r) { next_r = stop_r; break; }
@@ -766,8 +787,10 @@ __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, 
                      if (!(w.agc_gain > 0)) { w.thr_dirty = true; fatal_marker(r0 + n, ld); break; }
                      const float sa = w.v_avg_height * 0.25f * fast_rcp(w.agc_gain), ra = P.rise * sa, qa = P.min_peak * sa;
                      w.thr_dirty = true;
+                     {  const int ar = (int)(ra * lsb), aq = (int)(qa * lsb);      // (as approx_thresholds: rtfe_kernels.hip)
+                        a_rlo = ar - 2; a_rhi = ar + 3; a_mlo = aq - 2; a_mhi = aq + 3; }
                      const bool inb = ra >= band_rlo && ra <= band_rhi && (!amp_on || (qa >= band_qlo && qa <= band_qhi));
-                     if (!inb) { if (prof) ++pc_notinb; update_thresholds(w, P, lsb); if (!in_band(bd)) { next_r = n + 1; to_lit = true; break; } }
+                     if (!inb) { update_thresholds(w, P, lsb); if (!in_band(bd)) { next_r = n + 1; to_lit = true; break; } }
                      continue; }
                   // ---- every other record (a block's first peaks, PE, the window AGC): the general step ----
                   if (prof) ++pc_general;

@@ -22,7 +22,7 @@ namespace rtfe {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_zones(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
                                               const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl) {
-   __shared__ int16_t s_z[(kMarginRows + 2 * 50 + 2) * RTFE_MAXTRKS];
+   __shared__ __attribute__((aligned(16))) int16_t s_z[(kMarginRows + 2 * 50 + 2) * RTFE_MAXTRKS + 8];
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks;
    const int nb = scratch->nbursts_total;
@@ -39,13 +39,26 @@ __global__ void __launch_bounds__(64) k_zones(const DevCfg *__restrict__ cfgp, c
          // walk is a chain of dependent reads, and there is nothing else in the wave to hide HBM's latency behind
          const long long r0 = z0 - 2 * 50 - 2 > 0 ? z0 - 2 * 50 - 2 : 0;
          const int nel = (int)(B.zone_end - r0) * ntrks;
+         // (8 bytes a load, from the 8-byte boundary in front of the first row - the tape is 16-byte aligned -: sixteen in flight per lane
+         //  are a 9-track zone tail in one round trip; s_z mirrors HBM from that boundary on, `sh` elements in front of the first row)
+         const long long base_e = r0 * ntrks, a0 = base_e & ~3ll, tot_e = nrows * ntrks;
+         const int sh = (int)(base_e - a0), nq = (nel + sh + 3) >> 2;
          __syncthreads();
-         for (int e0 = 0; e0 < nel; e0 += 64 * 16) {                       // (sixteen loads in flight per lane: the copy is a few round trips, not fifty)
-            int16_t t[16];
+         for (int q0 = 0; q0 < nq; q0 += 64 * 16) {
+            uint2 t[16];
             #pragma unroll
-            for (int k = 0; k < 16; ++k) { const int e = e0 + k * 64 + (int)threadIdx.x; t[k] = e < nel ? rows[r0 * ntrks + e] : (int16_t)0; }
+            for (int k = 0; k < 16; ++k) {
+               const int q = q0 + k * 64 + (int)threadIdx.x;
+               t[k] = make_uint2(0, 0);
+               if (q < nq) {
+                  const long long e = a0 + 4ll * q;
+                  if (e + 4 <= tot_e) t[k] = *reinterpret_cast<const uint2 *>(rows + e);
+                  else {                                                 // (the tape's last elements: no byte behind it is read)
+                     uint16_t x[4] = {0, 0, 0, 0};
+                     for (int j = 0; j < 4; ++j) if (e + j < tot_e) x[j] = (uint16_t)rows[e + j];
+                     t[k] = make_uint2((uint32_t)x[0] | ((uint32_t)x[1] << 16), (uint32_t)x[2] | ((uint32_t)x[3] << 16)); } } }
             #pragma unroll
-            for (int k = 0; k < 16; ++k) { const int e = e0 + k * 64 + (int)threadIdx.x; if (e < nel) s_z[e] = t[k]; } }
+            for (int k = 0; k < 16; ++k) { const int q = q0 + k * 64 + (int)threadIdx.x; if (q < nq) reinterpret_cast<uint2 *>(s_z)[q] = t[k]; } }
          __syncthreads();
          long long lo = 0x7fffffffffffffffll;
          for (int i = threadIdx.x; i < cfg.nscreens * ntrks; i += 64) {
@@ -59,9 +72,9 @@ __global__ void __launch_bounds__(64) k_zones(const DevCfg *__restrict__ cfgp, c
                const long long s = n - d - W;
                if (s < 0) break;
                if (s < r0) break;                                                 // (cannot happen: W, skew <= 50)
-               const int v = sgn * (int)s_z[(s - r0) * ntrks + col];
+               const int v = sgn * (int)s_z[(s - r0) * ntrks + col + sh];
                bool dom = true;
-               for (int k = 1; k <= W; ++k) if (sgn * (int)s_z[(s + k - r0) * ntrks + col] > v) { dom = false; break; }      // (incl. the entering sample: src/decoder.c:763-767)
+               for (int k = 1; k <= W; ++k) if (sgn * (int)s_z[(s + k - r0) * ntrks + col + sh] > v) { dom = false; break; }      // (incl. the entering sample: src/decoder.c:763-767)
                if (dom) { a = n; break; } }
             long long hi = a < 0 ? -1 : a - W - max(t, d) - 2;
             if (hi < z0) hi = -1;

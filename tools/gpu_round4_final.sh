@@ -19,3 +19,5 @@ import json; j=json.loads(open('gpurun_out/bench_c5_rows_$r.json').read().strip(
 done
 timeout 600 python bench.py --config C4 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4_full.err; echo "C4 full line rc $?"
 timeout 600 python bench.py --config C3 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3_full.err; echo "C3 full line rc $?"
+timeout 600 bash tools/gpu_profile.sh r04_g1 --config G1 --steps 2 --warmup 1 > gpurun_out/profile_g1.log 2>&1; echo "profile G1 rc $?"; head -8 gpurun_out/profile_g1.log
+timeout 600 bash tools/gpu_profile.sh r04_c5 --config C5 --steps 5 --warmup 2 > gpurun_out/profile_c5.log 2>&1; echo "profile C5 rc $?"; head -6 gpurun_out/profile_c5.log
