@@ -735,7 +735,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       int wmax = 1;
       for (int i = 0; i < h->dev.nparm; ++i) if (h->dev.parm[i].W > wmax) wmax = h->dev.parm[i].W;
       const int dcache = wmax + 2 + kDcChunk < kDcCache ? ((wmax + 2 + kDcChunk + 7) & ~7) : kDcCache;
-      hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * 16), dim3(64), (size_t)(h->dev.ds_slot < 144 ? 144 : h->dev.ds_slot) * 64 + (size_t)dcache * 64 * 2, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+      static const int dc_wgs = getenv("RTFE_DCHAIN_WGS") ? atoi(getenv("RTFE_DCHAIN_WGS")) : 16;      // (waves per CU that take chains from the queue)
+      hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * (dc_wgs >= 1 && dc_wgs <= 64 ? dc_wgs : 16)), dim3(64), (size_t)(h->dev.ds_slot < 144 ? 144 : h->dev.ds_slot) * 64 + (size_t)dcache * 64 * 2, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                          scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const float2 *)nullptr, (const unsigned char *)slotp, dtiles, ds_order);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTDchain);
