@@ -30,10 +30,10 @@
 namespace rtfe {
 
 constexpr int kDsSub = 128;                    // rows of a sub-segment
-constexpr int kDsJ = 4;                        // sub-segments per tile
+constexpr int kDsJ = 8;                        // sub-segments per tile (8 x 128 own rows behind one warm-up and one halo: 7.8 % of the rows are screened and classified twice; 4 x 128: 15.6 %)
 constexpr int kDsTile = kDsSub * kDsJ;         // own rows of a tile
 constexpr int kDsRight = 16;                   // rows behind a tile's own rows: a maybe that begins in the last sub-segment is settled there (kDsMaxMaybe + 1, a multiple of 8)
-constexpr int kDsThreads = 256;
+constexpr int kDsThreads = 512;
 constexpr int kDsMaxMaybe = 15;
 constexpr int kDsNoJoin = 0xff, kDsNoDoubt = 0xff;
 struct DsHdr { uint8_t count, start_blind, doubt, flags; float s_lo, s_hi; uint32_t pad; };      // 16 bytes in front of a slot's records; [s_lo, s_hi]: the band the lane decided against
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
       load_tile(&cfg, tl, rows, nrows);
       __syncthreads();
       // ---- the quiet map's bits of the tile's own rows (k_quiet folded in: bit c = every sample of rows [64 c, 64 c + 64) inside the quiet band;
-      // a tile is kDsTile / 64 = 8 groups: one byte of the map) ----
+      // a tile is kDsTile / 64 = 16 groups: two bytes of the map) ----
       {  unsigned noisy = 0;
          const uint32_t qpk = pk_dup(cfg.quiet_i), q2 = 2u * (uint32_t)cfg.quiet_i;
          const int4 *own = reinterpret_cast<const int4 *>(tl.x + (tl.halo + pad) * ntrks);      // (16-byte vectors: halo and pad are multiples of 8 rows)
@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
       if (threadIdx.x == 0) {                                             // (groups that are not complete - the tape ends inside them - are not quiet, as k_quiet has it)
          unsigned complete = 0;
          for (int k = 0; k < kDsTile / kChunkRows; ++k) if (g * kDsTile + (long long)(k + 1) * kChunkRows <= nrows) complete |= 1u << k;
-         qbytes[g] = (unsigned char)(~s_noisy & complete); }
+         if (kDsTile / kChunkRows == 8) qbytes[g] = (unsigned char)(~s_noisy & complete);
+         else reinterpret_cast<uint16_t *>(qbytes)[g] = (uint16_t)(~s_noisy & complete); }      // (16 groups: two bytes of the map)
       if (prof) { const long long t2 = clock64(); t_load += t2 - tq; tq = t2; }
       const int tile_lim = (nrows - tl.row0 < (long long)T) ? (int)(nrows - tl.row0) : T;
       for (int s = 0; s < cfg.nscreens; ++s) {
