@@ -174,6 +174,15 @@ for i in range(ntapes):
                         if r.nbursts != r_peak.nbursts or any((r.bursts[k] != r_peak.bursts[k]).any() for k in ("zone_end", "reset_sample", "safe_last", "end_sample")) or ((r.bursts["flags"] & fmask) != (r_peak.bursts["flags"] & fmask)).any(): msgs.append("burst tables of the two paths differ")
                         else:
                             for bb in range(r.nbursts):
+                                # (a burst k_decode flagged RTFE_F_SCREEN_UNDERFLOW holds what its screen let through - the host rescans it exactly, and
+                                #  check_tape above compared THAT with the oracle; the dense path's events of the same burst are the exact ones already)
+                                if rec == "0d" and (int(r_peak.bursts["flags"][bb]) & frontend.F_SCREEN_UNDERFLOW):
+                                    # ... so the dense path's burst is held against an exact rescan with the screen off: the literal detector from the same restart row
+                                    rx = fe.scan_exact(tape.rows, int(r.bursts["reset_sample"][bb]), int(r.bursts["end_sample"][bb]), screen_off=True).fetch()
+                                    for pp in range(len(cfgp.parmsets)):
+                                        for tt in range(cfgp.ntrks):
+                                            if r.track_events(bb, pp, tt).tobytes() != rx.track_events(0, pp, tt).tobytes(): msgs.append(f"dense path differs from the exact rescan: burst {bb} parmset {pp} track {tt}")
+                                    continue
                                 for pp in range(len(cfgp.parmsets)):
                                     for tt in range(cfgp.ntrks):
                                         if r.track_events(bb, pp, tt).tobytes() != r_peak.track_events(bb, pp, tt).tobytes(): msgs.append(f"paths differ: burst {bb} parmset {pp} track {tt}")

@@ -282,3 +282,19 @@ def test_emulated_burst_search_many_rounds(wpr, monkeypatch):
     r1 = _wpr_pair(cfg, rows, wpr, monkeypatch)
     assert rows.shape[0] >= 64 * 64 * 40 and r1.nbursts >= 14 and (int(r1.bursts["flags"][0]) & frontend.F_EXACT_START)
     _wpr_pair(cfg, tape.rows, wpr, monkeypatch)                # ... and in its first gap
+
+
+@pytest.mark.parametrize("seed,index", [(1001, 32), (974, 74)])
+def test_emulated_dense_path_where_the_sample_path_underflows(seed, index):
+    """Two tapes of the round-4 GPU stress sweeps (tests/stress_gpu.py, replayed here on the emulator): small signals whose thresholds sink
+    below the candidate screen.  k_decode flags such a burst RTFE_F_SCREEN_UNDERFLOW - its events are what the screen let through, the host
+    rescans it exactly - while the dense path uses its lists only inside their band and the literal detector elsewhere: no flag, and its
+    events must be the exact rescan's (screen off) byte for byte, which is what the stress script checks for flagged bursts."""
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_EMUL="1", STRESS_ONLY=str(index))
+    for k in ("RTFE_PEAK_PATH", "RTFE_DENSE_PATH", "RTFE_DS_WARM"): env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stress_gpu.py"), str(seed), str(index + 1)], capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in p.stdout.splitlines() if l.startswith(("ok", "FAIL"))]
+    assert p.returncode == 0 and len(lines) == 4 and all(l.startswith("ok") for l in lines), p.stdout[-2000:] + p.stderr[-2000:]
+    assert "peak_path 0d" in lines[-1] and "flags 0" in lines[-1] and "flags 8" in lines[-2], lines
