@@ -324,11 +324,12 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       d.ds_cap = expect * 1.3f + 2 <= 15 ? 15 : (expect * 1.3f + 2 <= 31 ? 31 : 63);
       if (const char *e = getenv("RTFE_DS_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 63) d.ds_cap = v; }      // (tests: lists that run full)
       d.ds_slot = ((int)sizeof(DsHdr) + d.ds_cap * (int)sizeof(DsRec) + 15) & ~15;
-      {  // sets per classification pass: three only where a single width carries three or more (PE's default sweep: one pass beats two - 8.4 vs
-         // 9.2 ms per 6.7e7 rows; bench C4's four widths: 18.5 vs 20.1 the other way) and two workgroups of 512 still fit a CU's 160 KB of LDS
+      {  // sets per classification pass: three where a width carries three or more (one pass over the tile's margins instead of two: PE's default
+         // sweep 26.5 -> 24.3 ms per 6.5e7 rows, bench C4 - its width 1.5 carries three distinct sets - 308 -> 280 ms) and two workgroups of 512
+         // still fit a CU's 160 KB of LDS.  (With tiles of 512 rows three sets cost a workgroup per CU - three instead of four - and lost on C4.)
          int per[kMaxScreens] = {0, 0, 0, 0}, mx = 0;
          for (int u = 0; u < d.nuset; ++u) { const int sidx = d.parm[d.uset_rep[u]].screen; if (++per[sidx] > mx) mx = per[sidx]; }
-         d.ds_up = (mx >= 3 && d.nscreens == 1) ? 3 : 2;
+         d.ds_up = mx >= 3 ? 3 : 2;
          if (d.ds_up == 3 && (size_t)ds_lds_layout(c->ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, 3).total + sizeof(DevCfg) + 1024 > 80 * 1024) d.ds_up = 2;
          if (const char *e = getenv("RTFE_DS_UP")) { const int v = atoi(e); if (v >= 1 && v <= 3) d.ds_up = v; } }
       d.ds_sfloor = (hfloor < 4.0f ? hfloor : 4.0f) / 4.0f / 2.0f;

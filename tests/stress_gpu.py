@@ -176,7 +176,7 @@ for i in range(ntapes):
                             for bb in range(r.nbursts):
                                 # (a burst k_decode flagged RTFE_F_SCREEN_UNDERFLOW holds what its screen let through - the host rescans it exactly, and
                                 #  check_tape above compared THAT with the oracle; the dense path's events of the same burst are the exact ones already)
-                                if rec == "0d" and (int(r_peak.bursts["flags"][bb]) & frontend.F_SCREEN_UNDERFLOW):
+                                if rec == "0d" and (int(r_peak.bursts["flags"][bb]) & frontend.F_SCREEN_UNDERFLOW) and not (int(r.bursts["flags"][bb]) & frontend.F_SCREEN_UNDERFLOW):      # (flagged on both paths: k_decode's burst on both - an exact start, a chain that gave up)
                                     # ... so the dense path's burst is held against an exact rescan with the screen off: the literal detector from the same restart row
                                     rx = fe.scan_exact(tape.rows, int(r.bursts["reset_sample"][bb]), int(r.bursts["end_sample"][bb]), screen_off=True).fetch()
                                     for pp in range(len(cfgp.parmsets)):
