@@ -45,6 +45,7 @@ struct rtfe_handle {
    hipEvent_t ev_fork, ev_join;
    int overlap;
    int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
+   int sift_defer;                     // RTFE_SIFT_DEFER=0: k_sift_s stores a tile's lists at the end of its own step (experiments)
 };
 
 static thread_local char g_err[512] = "";
@@ -265,6 +266,8 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       if (const char *e = getenv("RTFE_GAIN_FAST")) d.pk_fast = atoi(e) != 0;
       // the chains' steady stretches in segments (k_gain_seg): 256 records each (measured on C2: 64 / 128 / 256 -> 2.61 / 2.43 / 2.39 ms per scan); the warm-up from the alpha filter's memory
       d.pk_seg_recs = 256;
+      d.pk_mar = kPkMar;
+      if (const char *e = getenv("RTFE_PK_MAR")) { const int v = atoi(e); if (v >= 0 && v <= kPkMar) d.pk_mar = v; }      // (tests: margins from the samples)
       if (const char *e = getenv("RTFE_SEG_RECS")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= 4096) d.pk_seg_recs = v; }
       for (int p = 0; p < c->nparmsets; ++p) {
          const float a = c->parmset[p].agc_alpha;
@@ -277,11 +280,11 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       const int wmax = sf_wmax(d);
       d.pk_hl = (kPkBack + 2 * wmax + 6 + 7) & ~7;
       d.pk_hr = (wmax + 2 + 7) & ~7;
-      // pool slots: flux transitions per tile and head from the bit cell (PE: up to two per cell), ~14 bytes each (a record and three
-      // margins), half as much again for noise and weak peaks.  RTFE_PK_SLOT: tests force the capacity path.
+      // pool slots: flux transitions per tile and head from the bit cell (PE: up to two per cell), 16 bytes each (a record and its margin
+      // block), half as much again for noise and weak peaks.  RTFE_PK_SLOT: tests force the capacity path.
       const float spbf = 1.0f / (bpi_s * c->ips * d.sample_deltat);
       const float ppb = c->mode == RTFE_PE ? 2.0f : 1.0f;
-      int slot = (int)((float)kSfTile / (spbf > 2 ? spbf : 2) * ppb * 14.0f * 1.5f) + 160;
+      int slot = (int)((float)kSfTile / (spbf > 2 ? spbf : 2) * ppb * 16.0f * 1.5f) + 160;
       // a screen below the noise floor - no amplitude test, or one as low as the rise test: noise wiggles become runs, every row explicit
       bool noisy_screen = false;
       for (int sidx = 0; sidx < d.nscreens; ++sidx) {
@@ -371,6 +374,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    h->zeros_kernel = getenv("RTFE_ZEROS_KERNEL") ? atoi(getenv("RTFE_ZEROS_KERNEL")) != 0 : 1;
    h->side = nullptr; h->overlap = getenv("RTFE_OVERLAP") ? atoi(getenv("RTFE_OVERLAP")) != 0 : 1;
    h->bursts_wpr = getenv("RTFE_BURSTS_WPR") ? atoi(getenv("RTFE_BURSTS_WPR")) : 0;
+   h->sift_defer = getenv("RTFE_SIFT_DEFER") ? atoi(getenv("RTFE_SIFT_DEFER")) != 0 : 1;
    // (k_zeros packs two tracks' 16-bit states into a lane and reads the rows where they lie: no -invert, no deskew delays, a threshold inside int16)
    if (d.invert || d.maxskew > 0 || d.ntrks < 2 || d.zc_peak_i < 1 || d.zc_peak_i > 32767 || !d.zc_parallel) h->zeros_kernel = 0;      // (RTFE_ZC_PARALLEL=0: k_decode's sequential walk, for the tests)
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
@@ -608,7 +612,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          a.rows = d_rows; a.nrows = nrows; a.ntiles = (int)ptiles; a.qtile = qtile; a.dir = dirm; a.pool = pkpool; a.hard = hardp; a.hard_cap = hard_cap;
          a.hard_count = &scratch->hard_count; a.dbg = scratch->scr; a.hcap = h->dev.pk_slot; a.wave_cap = h->dev.pk_wave_cap; a.invert = h->dev.invert;
          a.quiet_i = h->dev.quiet_i; a.lo_i = h->dev.screen[0].rise_i; a.hi_i = h->dev.screen[0].sure_i; a.minpk_i = h->dev.screen[0].minpk_i;
-         a.cut = h->dev.cut; a.debug = h->dev.debug;
+         a.cut = h->dev.cut; a.debug = h->dev.debug; a.defer = h->sift_defer;
          hipLaunchKernelGGL(sfs, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, a); }
       else {
          const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev));
@@ -664,7 +668,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
          if (mode == 1) t0(kTGainTail);
          hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                             scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
-                            (const unsigned char *)pkpool, ptiles, reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows)), pk_seg_cap(h, nrows));
+                            (const unsigned char *)pkpool, ptiles, reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows)), pk_seg_cap(h, nrows), d_rows);
          if (mode == 0) {
             t1(kTGain); t0(kTGainS);
             // the steady stretches: in segments, every one on its own, joined where the states agree bit for bit (rtfe_gain.hip)
@@ -677,9 +681,9 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (stop_after < 4) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTEmit);
       hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, (const uint32_t *)erefp, ccap,
-                         (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks));
+                         (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks), d_rows, (long long)nrows);
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
-                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint32_t *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp);
+                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint32_t *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp, d_rows, (long long)nrows);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTEmit);
       if (stop_after < 5) { skip_rest(); return launch_check("rtfe_scan"); }

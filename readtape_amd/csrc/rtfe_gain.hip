@@ -221,7 +221,6 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
          if (cu.dn.nrec == 0xffffu) fn_list = (tile + 1) * kSfTile + 1;                       // (the marker of a list that is not there)
          else if (cu.dn.nrec != 0) { fn_list = succ_row(slot + (size_t)nlists * hcap, 0, (int)cu.dn.nrec, cu.rn, pos0 + kSfTile); if (fn_list == kOffList) fn_list = kBadSucc; }
          /* an empty list: whatever comes behind it begins more than a tile's rows less the owners' reach further on */ }
-      int ebase = 0;
       int rounds = (nrec + 31) >> 5;
       {  const int other = __shfl(rounds, lane ^ 32); if (other > rounds) rounds = other; }      // (both halves run the scans of every round)
       for (int rd = 0; rd < rounds; ++rd) {
@@ -233,13 +232,11 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
          const bool deferred = have && w1 == 0xffff8001u;                  // its records are in overflow slot w0 (k_sift_hard): they take its place
          const unsigned char *os = ovf + (size_t)(deferred ? w0 : 0u) * kSfOvfBytes;
          const int cnt = deferred ? *reinterpret_cast<const int *>(os) : (have ? 1 : 0);
-         const int ne = deferred || !have ? 0 : pk_nent(w0, w1);
-         const int ie = half_incl_scan(ne, hl), ic = half_incl_scan(cnt, hl);
+         const int ic = half_incl_scan(cnt, hl);
          const long long o = base + ic - cnt;
          long long fn = !have ? kNoSucc : succ_row(slot, k + 1, nrec, q1, pos0);      // the successor of this list entry's last record
          if (fn == kOffList) fn = fn_list;
          if (deferred) {
-            int se0 = 0;
             for (int j = 0; j < cnt; ++j) {
                const uint2 e = *reinterpret_cast<const uint2 *>(os + 8 + 8 * j);
                CRec c; c.pos = (uint32_t)(pos0 + (long long)(e.x & 0x7ffu)); c.w0 = e.x & ~0x7ffu; c.w1 = e.y; c.volt = volt((int)(int16_t)(e.y & 0xffffu), mv);
@@ -247,14 +244,13 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
                if (j + 1 < cnt) { const uint2 e2 = *reinterpret_cast<const uint2 *>(os + 8 + 8 * (j + 1)); fj = pos0 + (long long)(e2.x & 0x7ffu) + (long long)((e2.x >> 12) & 63u); }
                if (e.y != 0xffff8000u && (unsigned)((int)((e.x >> 22) & 63u) - 1) < 62u && fj != kBadSucc && fj > (long long)c.pos + W) c.w0 |= kCrClear;
                crec[o + j] = c;
-               eref[o + j] = (uint32_t)(ovf16 + ((size_t)w0 * kSfOvfBytes + kSfOvfBytes) / 2 - (size_t)se0);
-               se0 += pk_nent(e.x, e.y); } }
+               eref[o + j] = (uint32_t)(ovf16 + ((size_t)w0 * kSfOvfBytes + kSfOvfBytes) / 2 - (size_t)(kPkMar * j)); } }
          else if (have) {
             CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
             if (w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u && fn != kBadSucc && fn > (long long)c.pos + W) c.w0 |= kCrClear;
             crec[o] = c;
-            eref[o] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(ebase + ie - ne)); }
-         ebase += __shfl(ie, hbase + 31); base += __shfl(ic, hbase + 31); } } }
+            eref[o] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(kPkMar * k)); }      // (where its margin block ends: record k's, 8 k bytes in front of the slot's end)
+         base += __shfl(ic, hbase + 31); } } }
 
 #ifdef RTFE_CPU_EMUL
 // (emulator only, RTFE_PREP_CHECK: kCrClear as a pass over the finished streams would set it)
@@ -313,9 +309,20 @@ __device__ __forceinline__ bool amp_pass(const Walker &w, const Run &u, float mv
 
 constexpr long long kNoRow = 0x7fffffffffffffffll;
 constexpr int kGainChunk = 32;      // records a lane steps through between two general steps (multiple of 4)
+// The margin of row f + j of a record: the first kPkMar rows' margins came with the record (eend[-(j + 1)]); for any other row the walker
+// makes it from the samples, as k_sift does (pk_margin: the extreme against the nearer window edge, clamped at 0; rows outside the tape
+// read as zeros).  Column rows: the detector's row n reads sample n - d of the head's column, and records count in column rows.
+struct MarSrc { const int16_t *rows; long long nrows; int ntrks, head, sg, W, nmar; };
+__device__ __forceinline__ int mar_sample(const MarSrc &m, long long r) { return (r >= 0 && r < m.nrows) ? m.sg * (int)m.rows[r * m.ntrks + m.head] : 0; }
+__device__ __forceinline__ int run_margin(const MarSrc &m, const Run &u, const uint16_t *eend, int j) {
+   if (j < m.nmar) return (int)eend[-(j + 1)];
+   const long long n = u.f + j;
+   const int xl = mar_sample(m, n - m.W + 1), xr = mar_sample(m, n);
+   const int mg = u.top ? u.val - max(xl, xr) : min(xl, xr) - u.val;
+   return mg < 0 ? 0 : (mg > 65535 ? 65535 : mg); }
+
 // first row >= c (and < limit) at which this run makes the detector fire, or kNoRow; doubt = first row >= c that the record cannot decide.
-// eend: entry e of the record lives at eend[-(e + 1)]
-__device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, const uint16_t *eend, long long c, long long limit, int W, int sure_i, float mv, long long &doubt) {
+__device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, const uint16_t *eend, const MarSrc &ms, long long c, long long limit, int W, int sure_i, float mv, long long &doubt) {
    doubt = kNoRow;
    const long long last_row = u.pos + W - 2;                         // the owner is strictly inside the window up to here
    if (last_row < c || u.f >= limit) return kNoRow;
@@ -325,7 +332,7 @@ __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, con
       const long long n = u.f + i;
       if (n < c) continue;
       if (n >= limit) return kNoRow;
-      if (rise_pass(w, u.top, u.val, (int)eend[-(i + 1)], mv)) return n; }
+      if (rise_pass(w, u.top, u.val, run_margin(ms, u, eend, i), mv)) return n; }
    const long long s0 = u.f + u.nlead;
    if (u.nsure) {
       const long long n = max(c, s0);
@@ -337,7 +344,7 @@ __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, con
       const long long n = s0 + u.nsure + i;
       if (n < c) continue;
       if (n >= limit) return kNoRow;
-      if (rise_pass(w, u.top, u.val, (int)eend[-(u.nlead + i + 1)], mv)) return n; }
+      if (rise_pass(w, u.top, u.val, run_margin(ms, u, eend, u.nlead + u.nsure + i), mv)) return n; }
    return kNoRow; }
 
 // a lane's place in its stream for the general step
@@ -391,7 +398,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
                                              const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
-                                             long long ccap, const unsigned char *__restrict__ pool, long long ntiles, GsSeg *__restrict__ segs, long long seg_cap) {
+                                             long long ccap, const unsigned char *__restrict__ pool, long long ntiles, GsSeg *__restrict__ segs, long long seg_cap, const int16_t *__restrict__ rows) {
    __shared__ float s_heights[64 * 10];
    __shared__ uint4 s_notes[kGainChunk][64];                           // the events the fast path notes, until the chunk's end
    __shared__ uint4 s_rec[kGainChunk + 1][64];                         // the lanes' records of the current chunk
@@ -436,6 +443,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       const int sl = P.screen * ntrks + head;
       RecSrc src;
       src.rec = crec + (size_t)sl * ccap; src.eref = eref + (size_t)sl * ccap; src.pool = pool;
+      MarSrc msrc; msrc.rows = rows; msrc.nrows = nrows; msrc.ntrks = ntrks; msrc.head = head; msrc.sg = cfg.invert ? -1 : 1; msrc.W = W; msrc.nmar = cfg.pk_mar;
       long long i;
       {  long long g0 = (c - W) / kSfTile; if (c - W < 0) g0 = 0; if (g0 >= ntiles) g0 = ntiles - 1;
          long long ge = limit <= 0 ? 0 : (limit + kSfTile - 1) / kSfTile;       // first tile whose candidates all lie at or behind the limit
@@ -568,7 +576,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
             if (u.top ? top_done : bot_done) continue;
             if (u.f > best || u.f >= limit) { if (u.top) top_done = true; else bot_done = true; continue; }
             long long dr;
-            const long long n = run_fire(w, u, j.eend, c, limit, W, S.sure_i, mv, dr);
+            const long long n = run_fire(w, u, j.eend, msrc, c, limit, W, S.sure_i, mv, dr);
             if (dr < best_doubt) best_doubt = dr;
             if (n != kNoRow) {
                if (u.top) top_done = true; else bot_done = true;         // (runs of one kind are ordered by row)
@@ -879,13 +887,13 @@ __global__ void __launch_bounds__(64) k_gain_join(const DevCfg *__restrict__ cfg
 // a lane per event (16 bytes in, 16 bytes out, consecutive lanes consecutive events).
 // ------------------------------------------------------------------------------------------------
 // the event of a record that fired at gain `gain` (exact thresholds at that gain, the first lead row that passes, refine_peak)
-__device__ __forceinline__ rtfe_event emit_event(const DevCfg &cfg, const DevParm &P, Walker &wk, const CRec &r, const uint16_t *eend, float gain, int W, int d, long long reset,
+__device__ __forceinline__ rtfe_event emit_event(const DevCfg &cfg, const DevParm &P, Walker &wk, const CRec &r, const uint16_t *eend, const MarSrc &ms, float gain, int W, int d, long long reset,
                                                  int trk, int pidx, float mv) {
    const Run u = run_decode(r.w0, r.w1, (long long)r.pos);
    wk.agc_gain = gain; wk.flags = 0;
    update_thresholds(wk, P, cfg.lsb_per_volt);                      // the exact thresholds of src/decoder.c:785-786 at that gain
    long long n = u.f + u.nlead;                                     // the first sure row, unless a lead row passes
-   for (int j = u.nlead - 1; j >= 0; --j) if (rise_pass(wk, u.top, u.val, (int)eend[-(j + 1)], mv)) n = u.f + j;
+   for (int j = u.nlead - 1; j >= 0; --j) if (rise_pass(wk, u.top, u.val, run_margin(ms, u, eend, j), mv)) n = u.f + j;
    const int ld = (int)(u.pos - n) + W;
    const int iprev = u.top ? u.val - u.dprev : u.val + u.dprev, inext = u.top ? u.val - u.dnext : u.val + u.dnext;
    const int adjcode = refine_code(&cfg, u.val, iprev, inext, gain, u.top);
@@ -904,7 +912,8 @@ __device__ __forceinline__ rtfe_event emit_event(const DevCfg &cfg, const DevPar
 // its event goes.  Records, entry references and gains are read in stream order.
 __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, const BurstCtl *__restrict__ ctl, rtfe_event *__restrict__ events,
                                                   const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap, const unsigned char *__restrict__ pool,
-                                                  const GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, long long seg_cap, const float *__restrict__ gfire, int nchains_max) {
+                                                  const GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, long long seg_cap, const float *__restrict__ gfire, int nchains_max,
+                                                  const int16_t *__restrict__ rows, long long nrows) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
    const int lane = threadIdx.x & 63;
@@ -919,6 +928,7 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
       const int wi = sg.chain - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
       const DevParm &P = cfg.parm[pidx];
       const int W = P.W, d = cfg.skew[trk];
+      MarSrc msrc; msrc.rows = rows; msrc.nrows = nrows; msrc.ntrks = ntrks; msrc.head = cfg.trk_to_head[trk]; msrc.sg = cfg.invert ? -1 : 1; msrc.W = W; msrc.nmar = cfg.pk_mar;
       const long long reset = ctl[b].reset;
       rtfe_event *ev = events + cs.k.ev_index;
       const size_t sb = (size_t)cs.k.sl * ccap;
@@ -934,14 +944,14 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
          if (fired) {
             const size_t ri = sb + (size_t)(sg.first + k);
             const CRec r = crec[ri];
-            ev[at + (unsigned)(incl - 1)] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[ri], gain, W, d, reset, trk, pidx, mv); }
+            ev[at + (unsigned)(incl - 1)] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[ri], msrc, gain, W, d, reset, trk, pidx, mv); }
          at += (unsigned)wave_last(incl); } } }
 
 // k_emit: the events k_gain's fast path only noted (the chains' heads and tails).  One workgroup per chain at a time, a lane per event.
 __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch,
                                               const BurstCtl *__restrict__ ctl, const uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                               const float *__restrict__ chain_h, const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap,
-                                              const unsigned char *__restrict__ pool, const ChainSt *__restrict__ cst) {
+                                              const unsigned char *__restrict__ pool, const ChainSt *__restrict__ cst, const int16_t *__restrict__ rows, long long nrows) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
    const int nchains = scratch->nbursts * nwalk;
@@ -953,6 +963,7 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
       const rtfe_burst B = bursts[b];
       const DevParm &P = cfg.parm[pidx];
       const int W = P.W, d = cfg.skew[trk], head = cfg.trk_to_head[trk];
+      MarSrc msrc; msrc.rows = rows; msrc.nrows = nrows; msrc.ntrks = ntrks; msrc.head = head; msrc.sg = cfg.invert ? -1 : 1; msrc.W = W; msrc.nmar = cfg.pk_mar;
       const long long reset = ctl[b].reset;
       const unsigned int nev = counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk];
       rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
@@ -969,7 +980,7 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
          const float gain = __uint_as_float(in.w[1]);
          wk.v_avg_height = __uint_as_float(in.w[2]);
          const CRec r = crec[sbase + in.w[0]];
-         ev[i] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[sbase + in.w[0]], gain, W, d, reset, trk, pidx, mv); } } }
+         ev[i] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[sbase + in.w[0]], msrc, gain, W, d, reset, trk, pidx, mv); } } }
 
 // ------------------------------------------------------------------------------------------------
 // k_publish: burst table entries of the bursts the chains finished; stop rows for the ones the sample path redoes

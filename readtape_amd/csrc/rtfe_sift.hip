@@ -135,12 +135,12 @@ template <class C> __device__ __forceinline__ int pk_margin(const C &c, int head
    const int xl = c.t.at(n - c.W + 1, head), xr = c.t.at(n, head);
    return top ? val - max(xl, xr) : min(xl, xr) - val; }
 
-// number of margin entries a record carries (the walkers read the same encoding)
-__host__ __device__ __forceinline__ int pk_nent(uint32_t w0, uint32_t w1) {
-   if ((w1 & 0xfffffffeu) == 0xffff8000u) return 0;                    // unknown minimum / deferred candidate
-   const int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u), ntail = (int)((w0 >> 28) & 15u);
-   return nsure == 63 ? (nlead << 4 | ntail) : nlead + ntail; }
-
+// Every record carries the margins of its first kPkMar rows from f on (uint16 entries, clamped at 0: entry j - row f + j - lives at
+// end[-(j + 1)] of the record's margin block; the blocks grow from a slot's back, record r's block ends 8 r bytes in front of the slot's
+// end).  A clean NRZI peak has two lead rows (99.5 % of C2's records: nlead <= 2); what a walker asks beyond the block - lead rows
+// from the fifth on, tail rows - it makes from the samples (run_margin, rtfe_gain.hip).  Round 4 stored one entry per lead and tail row,
+// variable per record: a second prefix sum, a predicated store per window row and a 4-byte reference per record downstream.
+constexpr int kPkMar = 4;
 __device__ __forceinline__ uint32_t pk_w0(int pos, bool top, int f, int nlead, int nsure, int ntail) {
    return (uint32_t)(pos + kSfPosBias) | ((top ? 0u : 1u) << 11) | ((uint32_t)(f - pos) << 12) | ((uint32_t)nlead << 18) | ((uint32_t)nsure << 22) | ((uint32_t)ntail << 28); }
 __device__ __forceinline__ uint32_t pk_w1(int val, int prev, int nxt, bool top) {
@@ -169,17 +169,13 @@ template <class C> __device__ __forceinline__ void pk_emit(const C &c, PkSink &o
       if (nlead > 15 || ntail > 15 || nsure > 62) { const int all = l - f + 1; nlead = all >> 4; ntail = all & 15; nsure = 63; } }
    sink_add(o, pk_w0(pos, top, f, nlead, nsure, ntail), unknown ? 0xffff8000u : pk_w1(val, c.t.at(pos - 1, head), c.t.at(pos + 1, head), top)); }
 
-// the margin entries of a record (lead rows, then tail rows; or every row), recomputed from the samples where the record goes:
-// entry i of the record lives at end[-(i + 1)] (the entries of a slot grow from its back)
-template <class C, class P16> __device__ __forceinline__ void pk_entries(const C &c, int head, uint32_t w0, uint32_t w1, P16 e16) {
-   if ((w1 & 0xfffffffeu) == 0xffff8000u) return;
+// the margin block of a record (rows f .. f + kPkMar - 1), from the samples where the record goes: entry j lives at e16[-(j + 1)]
+template <class C, class P16> __device__ __forceinline__ void pk_margins(const C &c, int head, uint32_t w0, uint32_t w1, P16 e16) {
+   if ((w1 & 0xfffffffeu) == 0xffff8000u) { for (int j = 0; j < kPkMar; ++j) e16[-(j + 1)] = 0; return; }
    const int pos = (int)(w0 & 0x7ffu) - kSfPosBias, f = pos + (int)((w0 >> 12) & 63u);
    const bool top = !((w0 >> 11) & 1u);
    const int val = (int)(int16_t)(w1 & 0xffffu);
-   int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u), ntail = (int)((w0 >> 28) & 15u);
-   if (nsure == 63) { nlead = nlead << 4 | ntail; nsure = 0; ntail = 0; }
-   for (int i = 0; i < nlead; ++i) { const int m = pk_margin(c, head, f + i, val, top); e16[-(i + 1)] = (uint16_t)(m < 0 ? 0 : m); }
-   for (int i = 0; i < ntail; ++i) { const int m = pk_margin(c, head, f + nlead + nsure + i, val, top); e16[-(nlead + i + 1)] = (uint16_t)(m < 0 ? 0 : m); } }
+   for (int j = 0; j < kPkMar; ++j) { const int m = pk_margin(c, head, f + j, val, top); e16[-(j + 1)] = (uint16_t)(m < 0 ? 0 : m); } }
 
 // "a rescan is forced at row r whatever happened before": the sample that leaves the window is
 //   (a) the maximum of the old window AND not exceeded by the sample that enters (src/decoder.c:763-767: the new sample is
@@ -308,9 +304,9 @@ __device__ __forceinline__ int pk_fast(const PkCtx &c, int head, int p, bool bot
 // ---- the same for a window width known at compile time, two samples per operation: row k's left and right window edge share a
 // register (v_perm_b32), a bottom is a top of y = ~x (order-reversing, no overflow), and every test is the sign bit of a packed
 // saturating difference (v_pk_sub_i16 clamp) shifted into a mask.  Needs sure_i <= 32767 (margins below the sure level are then exact
-// in 16 bits).  mm[k] = the margin of row k in both halves (what the record's explicit entries hold).
+// in 16 bits).
 template <int W>
-__device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool bot, uint32_t &w0, uint32_t &w1, uint32_t (&mm)[W - 1]) {
+__device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool bot, uint32_t &w0, uint32_t &w1) {
    static_assert(W >= 4 && W <= 17, "the row masks live in the 16-bit halves of a register");
    const int rb_ = c.t.row_bytes;
    const uint32_t m2 = (bot != (c.t.sg < 0)) ? 0xffffffffu : 0u;
@@ -326,7 +322,6 @@ __device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool b
       const uint32_t d = pk_subs(vv, LR[k]);                           // (extreme - left edge, extreme - right edge)
       a1 = (a1 >> 1) | (pk_subs(d, c10) & kPkSigns);                   // sign: left edge not strictly below / right edge above the extreme
       const uint32_t mn = pk_min(d, (d >> 16) | (d << 16));            // the margin of row k, in both halves
-      mm[k] = mn;
       a2 = (a2 >> 1) | (pk_subs(mn, thr) & kPkSigns); }                // sign: margin not above the screen / below the sure level
    constexpr int SH = 17 - W;                                          // bit k of a half sits at 17 - W + k
    constexpr uint32_t ALL = (1u << (W - 1)) - 1u;
@@ -352,7 +347,7 @@ __device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool b
       C &= ~((1u << n0) - 1u); }
    const int raw = lds_i16(pr);
    const int val = c.t.sg < 0 ? -raw : raw;                            // the sample as the detector sees it
-   int dp = (int)(int16_t)(mm[W - 2] & 0xffffu), dn;                   // (mm[W-2] = min(extreme - x[p-1], ...): not what is needed; the differences proper:)
+   int dp, dn;                                                         // the extreme's distance to its two neighbours
    {  const uint32_t dl = pk_subs(vv, LR[W - 2]), dr = pk_subs(vv, LR[1]);
       dp = (int)(int16_t)(dl & 0xffffu); dn = (int)(int16_t)(dr >> 16); }
    dp = dp < -1 ? -1 : (dp > 253 ? 253 : dp); dn = dn < -1 ? -1 : (dn > 253 ? 253 : dn);      // (253: a bottom at -32768 between far neighbours must not read as 0xffff8000, "minimum unknown")
@@ -368,18 +363,22 @@ __device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool b
    w0 = pk_w0(p, !bot, p + f, nlead, nsure, ntail);
    return 1; }
 
-// the explicit margins of a record built by pk_fast_w, from the registers they are in: entry i lives at e16[-(i + 1)]
-template <int W, class P16>
-__device__ __forceinline__ void pk_entries_w(uint32_t w0, uint32_t w1, const uint32_t (&mm)[W - 1], P16 e16) {
-   if ((w1 & 0xfffffffeu) == 0xffff8000u) return;
-   const int fo = (int)((w0 >> 12) & 63u);                              // first row above the screen, as an offset from the owner
-   int nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u), ntail = (int)((w0 >> 28) & 15u);
-   if (nsure == 63) { nlead = nlead << 4 | ntail; nsure = 0; ntail = 0; }
+// the margin block of a record built by pk_fast_w: rows f .. f + kPkMar - 1, two aligned 16-bit LDS reads a row (y = x or ~x as in
+// pk_fast_w: differences of y are the detector's margins).  Returns the block as it lies in memory (8 bytes at block end - 8).
+template <int W>
+__device__ __forceinline__ uint2 pk_margins_w(const PkCtx &c, int head, int p, bool bot, uint32_t w0) {
+   const int rb_ = c.t.row_bytes;
+   const int m2 = (bot != (c.t.sg < 0)) ? -1 : 0;
+   const int fo = (int)((w0 >> 12) & 63u);
+   lds_cp pv = c.t.xs + head * 2 + (p + c.t.hl) * rb_, pr = pv + fo * rb_, pl = pr - (W - 1) * rb_;
+   const int vy = lds_i16(pv) ^ m2;
+   uint32_t e[kPkMar];
    #pragma unroll
-   for (int k = 1; k < W - 1; ++k) {
-      const int i = k - fo;                                              // position in the run
-      const bool lead = (unsigned)i < (unsigned)nlead, tail = (unsigned)(i - nlead - nsure) < (unsigned)ntail;
-      if (lead || tail) { const int m = (int)(int16_t)(mm[k] & 0xffffu); e16[-((lead ? i : i - nsure) + 1)] = (uint16_t)(m < 0 ? 0 : m); } } }
+   for (int j = 0; j < kPkMar; ++j) {
+      const int ly = lds_i16(pl + j * rb_) ^ m2, ry = lds_i16(pr + j * rb_) ^ m2;
+      const int m = vy - max(ly, ry);
+      e[j] = (uint32_t)(m < 0 ? 0 : m); }
+   return make_uint2(e[3] | (e[2] << 16), e[1] | (e[0] << 16)); }
 
 // ---- wave-wide inclusive prefix sum: DPP row shifts and broadcasts (seven dependent VALU operations; __shfl_up would be six
 // ds_bpermute round trips through the LDS pipeline) ----
@@ -577,7 +576,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
          // their lists, and records and margin entries go to the lists' staging slots in LDS.  More than pk_wave_cap candidates (noise
          // above the screen), or a list that outgrows its slot: the list is marked unavailable and the bursts that need it take the sample path.
          // A candidate that needs the general walk leaves a placeholder that k_sift_hard resolves. ----
-         int rec_lo = 0, rec_hi = 0, ent_lo = 0, ent_hi = 0;                   // records / margin entries in this wave's two lists
+         int rec_lo = 0, rec_hi = 0;                                           // records in this wave's two lists
          bool bad = false;
          if (cut != 2) {                                                   // (RTFE_CUT=2: stop behind the dense pre-filter)
             uint32_t mlo = (tm | bm) & 0xffffu, mhi = (tm | bm) >> 16;
@@ -612,17 +611,17 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                      st = 1; }
                   if (prof) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
                   if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
-                  const int vr = st, ve = st ? pk_nent(w0, w1) : 0;
+                  const int vr = st;
                   const int sh = 16 * half;
-                  const int ir = wave_incl_scan(vr << sh, lane), ie = wave_incl_scan(ve << sh, lane);
-                  const int myr = (((ir >> sh) & 0xffff) - vr) + (half ? rec_hi : rec_lo), mye = (((ie >> sh) & 0xffff) - ve) + (half ? ent_hi : ent_lo);
-                  if (vr && 8 * (myr + 1) + 2 * (mye + ve) <= hcap) {
+                  const int ir = wave_incl_scan(vr << sh, lane);
+                  const int myr = (((ir >> sh) & 0xffff) - vr) + (half ? rec_hi : rec_lo);
+                  if (vr && 16 * (myr + 1) <= hcap) {                         // the record from the slot's front, its margin block from the back
                      const lds_p slot = half ? slot_hi : slot_lo;
                      lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 2 * myr;
                      rp[0] = w0; rp[1] = w1;
-                     if (cut != 5) pk_entries(cx, half ? h_hi : h_lo, w0, w1, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye)); }
-                  const int tr = wave_last(ir), te = wave_last(ie);
-                  rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; ent_lo += te & 0xffff; ent_hi += (te >> 16) & 0xffff; } } }
+                     if (cut != 5) pk_margins(cx, half ? h_hi : h_lo, w0, w1, reinterpret_cast<lds_u16p>(slot + hcap - 8 * myr)); }
+                  const int tr = wave_last(ir);
+                  rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; } } }
          if (prof) { tk0 = clock64(); pc_own += tk0 - tk1; }
          // ---- 5. this wave's two lists leave: records from the front of each head's slot, margin entries from its back, 16 bytes per
          // lane; the directory ----
@@ -633,16 +632,16 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
             for (int hh = 0; hh < 2; ++hh) {
                if (hh && !has_hi) break;
                const int h = h_lo + hh;
-               const int nr = hh ? rec_hi : rec_lo, ne = hh ? ent_hi : ent_lo;
-               const bool over = bad || 8 * nr + 2 * ne > hcap || nr >= 0xff00 || ne >= 0xff00;
+               const int nr = hh ? rec_hi : rec_lo;
+               const bool over = bad || 16 * nr > hcap;
                unsigned char *gslot = pool + ((size_t)(tile * nscreens + sc) * ntrks + h) * (size_t)hcap;
                if (!over && nr > 0 && cut != 6) {
-                  const int fv = (8 * nr + 15) >> 4, bv = (2 * ne + 15) >> 4;        // vectors in use at the front / at the back
+                  const int fv = (8 * nr + 15) >> 4, bv = (8 * nr + 15) >> 4;        // vectors in use at the front / at the back
                   const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
                   for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
-                  if (prof) pn_bytes += (unsigned)(8 * nr + 2 * ne); }
+                  if (prof) pn_bytes += (unsigned)(16 * nr); }
                if (lane == 0) {
-                  PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = over ? (uint16_t)0 : (uint16_t)ne;
+                  PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
                   dir[(size_t)(tile * nscreens + sc) * ntrks + h] = d; } } }
          rtfe_wave_sync(); }
       __syncthreads(); }
@@ -659,7 +658,9 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
 struct SfArgs {
    const int16_t *rows; long long nrows; int ntiles;
    uint16_t *qtile; PeakDir *dir; unsigned char *pool; SfHard *hard; int hard_cap; int *hard_count; unsigned long long *dbg;
-   int hcap, wave_cap, invert, quiet_i, lo_i, hi_i, minpk_i, cut, debug; };
+   int hcap, wave_cap, invert, quiet_i, lo_i, hi_i, minpk_i, cut, debug;
+   int defer;      // 1: a tile's lists leave LDS at the start of the NEXT tile step (the stores' acknowledgements are then old when the step's first s_waitcnt vmcnt(0) - the prefetched rows - asks)
+};
 
 template <int W, int NT, int WPS>
 __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArgs a) {
@@ -713,6 +714,28 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
    if (tid < 2) s_noisy[tid] = 0;
    int par = 0, last_tile = -1;
    unsigned int pn_hard = 0, pn_rounds = 0, pn_bytes = 0;
+   // a wave's two lists leave LDS: records from the front of each head's slot, margin entries from its back, 16 bytes per lane; the
+   // directory.  Deferred (a.defer) to the start of the next tile step: the step's first instruction is s_waitcnt vmcnt(0) for the
+   // prefetched rows, and gfx9 counts stores in vmcnt too - stores issued just in front of it are waited for in full.
+   int p_tile = -1, p_rec_lo = 0, p_rec_hi = 0;
+   bool p_bad = false;
+   auto copy_out = [&](const int tile, const int rec_lo, const int rec_hi, const bool bad) {
+      const int vps = hcap >> 4;                                         // 16-byte vectors per slot
+      #pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+         if (hh && !has_hi) break;
+         const int h = h_lo + hh;
+         const int nr = hh ? rec_hi : rec_lo;
+         const bool over = bad || 16 * nr > hcap;
+         unsigned char *gslot = a.pool + ((size_t)tile * NT + h) * (size_t)hcap;
+         if (!over && nr > 0 && cut != 6) {
+            const int fv = (8 * nr + 15) >> 4, bv = fv;                        // vectors in use at the front (records) / at the back (margin blocks)
+            const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
+            for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
+            if (a.debug == 3) pn_bytes += (unsigned)(16 * nr); }
+         if (lane == 0) {
+            PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
+            a.dir[(size_t)tile * NT + h] = d; } } };
    for (int tile = tile_lo; tile < ntiles; tile += G, par ^= 1) {
       last_tile = tile;
       const long long lastl = a.nrows - 1 - (long long)tile * kSfTile;
@@ -725,6 +748,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
       __syncthreads();
       if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G);
       if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
+      if (p_tile >= 0) { copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad); p_tile = -1; rtfe_wave_sync(); }      // (the lists of the tile in front: a.defer)
       // ---- 2. quiet groups: flat 16-byte reads of the tile proper; a ballot of 64 vectors lies in one or two groups ----
       #pragma unroll
       for (int it = 0; it < NQIT; ++it) {
@@ -766,7 +790,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                const uint32_t mk = keep >= kSfStrip ? 0x3fffu : (keep <= 0 ? 0u : ((1u << keep) - 1u));
                tm &= mk | (mk << 16); bm &= mk | (mk << 16); } }
          // ---- 4. the wave's candidates, compacted into a list ordered by (head, row); rounds of 64 ----
-         int rec_lo = 0, rec_hi = 0, ent_lo = 0, ent_hi = 0;                   // records / margin entries in this wave's two lists
+         int rec_lo = 0, rec_hi = 0;                                           // records in this wave's two lists
          bool bad = false;
          if (cut != 2) {
             uint32_t mlo = (tm | bm) & 0xffffu, mhi = (tm | bm) >> 16;
@@ -790,8 +814,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                   const int half = (int)(cd >> 15), cpos = (int)(cd & 0x3ffu);
                   const bool cbot = (cd >> 14) & 1u;
                   uint32_t w0 = 0, w1 = 0;
-                  uint32_t mm[W - 1];
-                  int st = pk_fast_w<W>(cx, half ? h_hi : h_lo, cpos, cbot, w0, w1, mm);
+                  int st = pk_fast_w<W>(cx, half ? h_hi : h_lo, cpos, cbot, w0, w1);
                   if (!live) st = 0;
                   if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
                      const int hidx = atomicAdd(a.hard_count, 1);
@@ -803,39 +826,27 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                      st = 1; }
                   if (a.debug == 3) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
                   if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
-                  const int vr = st, ve = st ? pk_nent(w0, w1) : 0;
+                  const int vr = st;
                   const int sh = 16 * half;
-                  const int ir = wave_incl_scan(vr << sh, lane), ie = wave_incl_scan(ve << sh, lane);
-                  const int myr = (((ir >> sh) & 0xffff) - vr) + (half ? rec_hi : rec_lo), mye = (((ie >> sh) & 0xffff) - ve) + (half ? ent_hi : ent_lo);
-                  if (vr && 8 * (myr + 1) + 2 * (mye + ve) <= hcap) {
+                  const int ir = wave_incl_scan(vr << sh, lane);
+                  const int myr = (((ir >> sh) & 0xffff) - vr) + (half ? rec_hi : rec_lo);
+                  if (vr && 16 * (myr + 1) <= hcap) {                         // the record from the slot's front, its margin block from the back
                      const lds_p slot = half ? slot_hi : slot_lo;
                      lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 2 * myr;
                      rp[0] = w0; rp[1] = w1;
-                     if (cut != 5) pk_entries_w<W>(w0, w1, mm, reinterpret_cast<lds_u16p>(slot + hcap - 2 * mye)); }
-                  const int tr = wave_last(ir), te = wave_last(ie);
-                  rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; ent_lo += te & 0xffff; ent_hi += (te >> 16) & 0xffff; } } }
-         // ---- 5. this wave's two lists leave: records from the front of each head's slot, margin entries from its back, 16 bytes per
-         // lane; the directory ----
+                     if (cut != 5) {
+                        const uint2 mb = (w1 & 0xfffffffeu) == 0xffff8000u ? make_uint2(0, 0) : pk_margins_w<W>(cx, half ? h_hi : h_lo, cpos, cbot, w0);
+                        lds_u32p mp = reinterpret_cast<lds_u32p>(slot + hcap - 8 * (myr + 1));
+                        mp[0] = mb.x; mp[1] = mb.y; } }
+                  const int tr = wave_last(ir);
+                  rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; } } }
+         // ---- 5. this wave's two lists leave (now, or - a.defer - at the start of the next tile step) ----
          rtfe_wave_sync();
-         {
-            const int vps = hcap >> 4;                                         // 16-byte vectors per slot
-            #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-               if (hh && !has_hi) break;
-               const int h = h_lo + hh;
-               const int nr = hh ? rec_hi : rec_lo, ne = hh ? ent_hi : ent_lo;
-               const bool over = bad || 8 * nr + 2 * ne > hcap || nr >= 0xff00 || ne >= 0xff00;
-               unsigned char *gslot = a.pool + ((size_t)tile * NT + h) * (size_t)hcap;
-               if (!over && nr > 0 && cut != 6) {
-                  const int fv = (8 * nr + 15) >> 4, bv = (2 * ne + 15) >> 4;        // vectors in use at the front / at the back
-                  const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
-                  for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
-                  if (a.debug == 3) pn_bytes += (unsigned)(8 * nr + 2 * ne); }
-               if (lane == 0) {
-                  PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = over ? (uint16_t)0 : (uint16_t)ne;
-                  a.dir[(size_t)tile * NT + h] = d; } } }
+         if (a.defer) { p_tile = tile; p_rec_lo = rec_lo; p_rec_hi = rec_hi; p_bad = bad; }
+         else copy_out(tile, rec_lo, rec_hi, bad);
          rtfe_wave_sync(); }
       __syncthreads(); }
+   if (p_tile >= 0) copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad);
    if (tid == 0 && last_tile >= 0) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);
    if (a.debug == 3 && lane == 0) {
       atomicAdd(&a.dbg[3], (unsigned long long)pn_bytes); atomicAdd(&a.dbg[4], (unsigned long long)pn_hard); atomicAdd(&a.dbg[5], (unsigned long long)pn_rounds);
@@ -876,17 +887,13 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       PkSink sk; sk.n = 0;
       pk_bot(cx, sk, (int)hd.head, (int)hd.pos);
       unsigned char *slot = ovf + (size_t)i * kSfOvfBytes;
-      int nrec = sk.n, ne = 0;
+      int nrec = sk.n;
       if (nrec > 4) nrec = -1;
-      for (int j = 0; j < nrec; ++j) ne += pk_nent(sk.w0[j], sk.w1[j]);
-      if (nrec > 0 && 8 + 8 * nrec + 2 * ne > kSfOvfBytes) nrec = -1;
-      if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, cx.W - 2, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs or margins than a slot holds: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
+      if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, cx.W - 2, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs than a slot holds: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
       *reinterpret_cast<int *>(slot) = nrec;
       if (nrec != 1) atomicAdd(&extra[((size_t)hd.tile * cfg.nscreens + hd.screen) * cfg.ntrks + hd.head], nrec - 1);      // the list's length in its stream (k_pscan)
-      int e0 = 0;
-      for (int j = 0; j < nrec; ++j) {
+      for (int j = 0; j < nrec; ++j) {                                      // (8 + 4 x 8 + 4 x 8 bytes fit the slot)
          reinterpret_cast<uint32_t *>(slot + 8)[2 * j] = sk.w0[j]; reinterpret_cast<uint32_t *>(slot + 8)[2 * j + 1] = sk.w1[j];
-         pk_entries(cx, (int)hd.head, sk.w0[j], sk.w1[j], reinterpret_cast<uint16_t *>(slot + kSfOvfBytes) - e0);
-         e0 += pk_nent(sk.w0[j], sk.w1[j]); } } }
+         pk_margins(cx, (int)hd.head, sk.w0[j], sk.w1[j], reinterpret_cast<uint16_t *>(slot + kSfOvfBytes) - kPkMar * j); } } }
 
 }  // namespace rtfe

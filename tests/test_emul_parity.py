@@ -44,6 +44,23 @@ def test_emulated_peak_record_path_matches_oracle(name, parallel, tmp_path, monk
         assert st["parallel"] == 0
 
 
+@pytest.mark.parametrize("name", ["nrzi9_m", "nrzi9_invert", "nrzi9_skew", "gcr_m", "pe"])
+@pytest.mark.parametrize("fast", ["1", "0"])
+def test_emulated_margins_from_the_samples(name, fast, tmp_path, monkeypatch):
+    """A record carries the margins of its first four rows; what a walker asks beyond them it makes from the samples (run_margin,
+    rtfe_gain.hip).  RTFE_PK_MAR=0: every margin from the samples - with -invert, deskew delays, a parameter sweep, and GCR / PE by force
+    on the peak path (their windows hold a top and a bottom: long lead runs, tail rows that fire)."""
+    monkeypatch.setenv("RTFE_PEAK_PATH", "1")
+    monkeypatch.setenv("RTFE_PK_MAR", "0")
+    monkeypatch.setenv("RTFE_GAIN_FAST", fast)
+    g = load_case(name)
+    att = oracle_attempts(g["hdr"], g["rows"], g["oracle_opts"], str(tmp_path))
+    fe = emul_frontend(config_for(g["hdr"], g["oracle_opts"]))
+    msgs, stats = check_tape(fe, g["hdr"], g["rows"], att)
+    assert not msgs, "\n".join(msgs[:12])
+    assert stats["events"] > 0
+
+
 @pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_PK_SLOT": "64"}), ("gcr", {"RTFE_PK_SLOT": "256"})])
 def test_emulated_peak_record_path_gives_up_cleanly(name, knobs, tmp_path, monkeypatch):
     """Lists that outgrow their pool slot are marked unavailable; the bursts that need them are redone on the samples: same events."""
@@ -113,12 +130,13 @@ def test_emulated_clear_flags_equal_a_pass_over_the_streams(name, peak, monkeypa
 
 
 @pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}, {"RTFE_SEG_RECS": "32"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_WARM": "3"}, {"RTFE_SEG_RECS": "1024"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_CAP": "70"},
-                                   {"RTFE_SIFT_GENERIC": "1"}, {"RTFE_PK_SLOT": "128"}])
+                                   {"RTFE_SIFT_GENERIC": "1"}, {"RTFE_PK_SLOT": "128"}, {"RTFE_PK_MAR": "0"}, {"RTFE_PK_MAR": "1", "RTFE_GAIN_FAST": "0"}])
 def test_emulated_long_blocks(knobs, tmp_path, monkeypatch):
     """Blocks of 500-640 bytes: chains that cross many tiles (k_gain's heads, the steady stretches in segments, the tails).
     RTFE_SEG_RECS=32: ~20 segments per chain; with a warm-up of 3 records the joins fail and k_gain (mode 1) finishes the chains from
     the last proven state; RTFE_SEG_CAP: the segment table runs full and the chains that find no room are walked as a whole.  The events are
-    the oracle's whatever the joins do."""
+    the oracle's whatever the joins do.  RTFE_PK_MAR: the walkers trust fewer rows of a record's margin block than it holds (none; one) and make
+    the other rows' margins from the samples - as they do for a fifth lead row and for tail rows."""
     from readtape_amd import synth
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
