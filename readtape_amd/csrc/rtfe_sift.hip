@@ -104,6 +104,10 @@ struct PkCol {
       const int i = r - r0;
       return (hd == head && (unsigned)i < (unsigned)n) ? (int)col[i] : tape.at(r, hd); } };
 
+// ... the same with the two things the general walk asks of every row - "is a rescan forced here" and "where is the window's leftmost
+// minimum" - made beforehand by all lanes of the wave for the rows around the candidate (k_sift_hard): as[i] / am[i] for row r0 + i, i in [k0, n)
+struct PkColPre : PkCol { const unsigned char *as; const int16_t *am; int k0; };
+
 // LDS carve of k_sift.  ONE definition for the kernel and for the host's sizing.
 struct SfLds { unsigned xs, wl, stage, total; };
 __host__ __device__ inline SfLds sf_lds_layout(int ntrks, int hl, int hr, int wave_cap, int hcap) {
@@ -184,7 +188,7 @@ template <class C, class P16> __device__ __forceinline__ void pk_margins(const C
 //       minimum, and it was the minimum of an earlier window that already held the leaving sample (a sample that entered
 //       later would have to be to the right of it), hence <= it: equal, and old_left == pkww_minv fires.
 // x[r-W] >= all of x[r-W+1 .. r], or <= all of x[r-W+1 .. r-1].
-template <class C> __device__ __forceinline__ bool pk_async(const C &c, int head, int r) {
+template <class C> __device__ __forceinline__ bool pk_async_g(const C &c, int head, int r) {
    const int s = r - c.W;
    const int v = c.t.at(s, head);
    bool dom = true, sub = true;
@@ -193,10 +197,19 @@ template <class C> __device__ __forceinline__ bool pk_async(const C &c, int head
       dom = dom && y <= v; sub = sub && y >= v; }
    return sub || (dom && c.t.at(r, head) <= v); }
 // leftmost minimum of the window that ends at row r (the rescan of src/decoder.c:768-775)
-template <class C> __device__ __forceinline__ int pk_argmin(const C &c, int head, int r) {
+template <class C> __device__ __forceinline__ int pk_argmin_g(const C &c, int head, int r) {
    int best = r - c.W + 1, bv = c.t.at(best, head);
    for (int j = best + 1; j <= r; ++j) { const int v = c.t.at(j, head); if (v < bv) { bv = v; best = j; } }
    return best; }
+template <class C> __device__ __forceinline__ bool pk_async(const C &c, int head, int r) { return pk_async_g(c, head, r); }
+template <class C> __device__ __forceinline__ int pk_argmin(const C &c, int head, int r) { return pk_argmin_g(c, head, r); }
+// (k_sift_hard: looked up where the wave made them beforehand)
+__device__ __forceinline__ bool pk_async(const PkCtxT<PkColPre> &c, int head, int r) {
+   const int i = r - c.t.r0;
+   return (head == c.t.head && i >= c.t.k0 && i < c.t.n) ? c.t.as[i] != 0 : pk_async_g(c, head, r); }
+__device__ __forceinline__ int pk_argmin(const PkCtxT<PkColPre> &c, int head, int r) {
+   const int i = r - c.t.r0;
+   return (head == c.t.head && i >= c.t.k0 && i < c.t.n) ? c.t.r0 + (int)c.t.am[i] : pk_argmin_g(c, head, r); }
 
 // a bottom candidate, general walk: sample q is the true window minimum (first from the left) at rows [ra, rb]; what the
 // reference tests there is its own minimum, refreshed only by rescans (src/decoder.c:765-775).
@@ -865,9 +878,12 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
 constexpr int kHardCol = 320;      // samples of a candidate's head its wave keeps in LDS: kPkBack + 3 W + 16 <= 230 for W <= 50, what is outside comes from HBM
 __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
                                                    const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf, int *__restrict__ extra) {
-   // A wave per candidate: its 64 lanes fetch the head's samples the walk can read - one round trip - and lane 0 walks (pk_bot is a chain
-   // of dependent reads: a few hundred, each an HBM round trip when a lane reads the tape itself: 74 us for C2's 10 k candidates).
+   // A wave per candidate: its 64 lanes fetch the head's samples the walk can read - one round trip -, make "rescan forced" and "leftmost
+   // window minimum" for every row around the candidate (a few rows a lane), and lane 0 walks on those tables.  (Round 4: lane 0 made them
+   // as it went - pk_async over a window at every row it stepped back: ~1 500 dependent LDS reads, 60 - 100 us a candidate, 0.11 ms per C2 scan.)
    __shared__ int16_t s_col[4][kHardCol];
+   __shared__ int16_t s_am[4][kHardCol];
+   __shared__ unsigned char s_as[4][kHardCol];
    const DevCfg &cfg = *cfgp;
    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
    int n = *hard_count;
@@ -875,7 +891,7 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
    for (int i = blockIdx.x * 4 + wv; i < n; i += gridDim.x * 4) {
       const SfHard hd = hard[i];
       const DevScreen &S = cfg.screen[hd.screen];
-      PkCtxT<PkCol> cx;
+      PkCtxT<PkColPre> cx;
       cx.t.tape.rows = rows; cx.t.tape.t0 = (long long)hd.tile * kSfTile; cx.t.tape.nrows = nrows; cx.t.tape.ntrks = cfg.ntrks; cx.t.tape.sg = cfg.invert ? -1 : 1;
       cx.W = S.W; cx.lo_i = S.rise_i; cx.hi_i = S.sure_i;
       const long long lastl = nrows - 1 - cx.t.tape.t0;
@@ -887,6 +903,20 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       for (int k = lane; k < ncol; k += 64) s_col[wv][k] = (int16_t)cx.t.tape.at(r0 + k, (int)hd.head);
       rtfe_wave_sync();
       cx.t.col = s_col[wv]; cx.t.r0 = r0; cx.t.n = ncol; cx.t.head = (int)hd.head;
+      cx.t.as = s_as[wv]; cx.t.am = s_am[wv]; cx.t.k0 = S.W;
+      {  // row r0 + k, k >= W: its window is col[k - W + 1 .. k], the sample leaving it col[k - W] (pk_async_g / pk_argmin_g on the column)
+         const int W = S.W;
+         for (int k = W + lane; k < ncol; k += 64) {
+            const int16_t *c0 = s_col[wv] + (k - W);
+            const int v = c0[0];
+            bool dom = true, sub = true;
+            int best = 1, bv = c0[1];
+            for (int j = 1; j < W; ++j) { const int y = c0[j]; dom = dom && y <= v; sub = sub && y >= v; if (y < bv) { bv = y; best = j; } }
+            const int ye = c0[W];
+            if (ye < bv) best = W;
+            s_as[wv][k] = (unsigned char)(sub || (dom && ye <= v));
+            s_am[wv][k] = (int16_t)(k - W + best); } }
+      rtfe_wave_sync();
       if (lane != 0) continue;
       PkSink sk; sk.n = 0;
       pk_bot(cx, sk, (int)hd.head, (int)hd.pos);
