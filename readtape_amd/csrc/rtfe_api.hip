@@ -294,9 +294,6 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       d.pk_wave_cap = noisy_screen ? 1792 : (getenv("RTFE_PK_WAVECAP") ? atoi(getenv("RTFE_PK_WAVECAP")) : 384);                          // (a wave's two heads have 2 x 896 samples)
       if (const char *e = getenv("RTFE_PK_SLOT")) { const int v = atoi(e); if (v >= 32 && v <= 65536) slot = v; }
       d.pk_slot = (slot + 15) & ~15;
-      d.pk_cshift = 0;
-      while ((16 << d.pk_cshift) < d.pk_slot) ++d.pk_cshift;                 // the pool's slots: the power of two above (a stream entry is tile << pk_cshift | record)
-      d.pk_gslot = 16 << d.pk_cshift;
       d.pk_lds = (int)sf_lds_layout(c->ntrks, d.pk_hl, d.pk_hr, d.pk_wave_cap, d.pk_slot).total + 64;
       if (d.pk_lds > 150 * 1024 || sf_nv(d) > 6) d.peak_path = 0; }
    {  // ---- the dense sample path (rtfe_dense.hip) ----
@@ -461,7 +458,7 @@ static size_t ws_pkchain_off(const rtfe_handle *h, int64_t nrows) { return ws_pk
 static size_t ws_pkpool_off(const rtfe_handle *h, int64_t nrows) { return ws_pkchain_off(h, nrows) + (h->dev.peak_path ? pk_chain_bytes(h, nrows) : 0); }
 static size_t pk_pool_bytes(const rtfe_handle *h, int64_t nrows) {      // one slot per (tile, screen, head)
    if (!h->dev.peak_path) return 0;
-   return (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * (size_t)h->dev.pk_gslot) + 255) & ~(size_t)255; }
+   return (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * (size_t)h->dev.pk_slot) + 255) & ~(size_t)255; }
 // ... | the candidates k_sift deferred (k_sift_hard) | their overflow slots
 // (two per tile and list: a clean NRZI tape defers 0.05 % of its candidates, a noisy parameter sweep with wide windows one or two per tile and list;
 //  past the capacity a candidate becomes a "minimum unknown" record, and the chain that gets there gives up)
@@ -473,23 +470,23 @@ static size_t pk_ovf_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.
 // ... | the tiles' quiet bits (k_sift -> k_qpack)
 static size_t ws_pkqtile_off(const rtfe_handle *h, int64_t nrows) { return (ws_pkovf_off(h, nrows) + pk_ovf_bytes(h, nrows) + 255) & ~(size_t)255; }
 static size_t pk_qtile_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_tiles_for(nrows) * 2 + 255) & ~(size_t)255) : 0; }
-// ... | the streams' tile offsets and totals (k_pscan) | the index streams (k_prep): a 4-byte entry per record
+// ... | the streams' tile offsets and totals (k_pscan) | the streams (k_prep): 16-byte records, entry references
 static long long pk_hard_cap(const rtfe_handle *h, int64_t nrows);
 // (a stream's capacity: every slot's worth of records and a marker per tile.  Deferred candidates add up to three records each; a stream
 //  that outgrows the capacity through them - its slots would have to be full of records without margins as well - is not built, and its
 //  chains give up)
-static long long pk_ccap(const rtfe_handle *h, int64_t nrows) { return pk_tiles_for(nrows) * (h->dev.pk_slot / 16 + 1) + 64; }
+static long long pk_ccap(const rtfe_handle *h, int64_t nrows) { return pk_tiles_for(nrows) * (h->dev.pk_slot / 8 + 1) + 64; }
 static size_t ws_pktstart_off(const rtfe_handle *h, int64_t nrows) { return ws_pkqtile_off(h, nrows) + pk_qtile_bytes(h, nrows); }
 static size_t pk_tstart_bytes(const rtfe_handle *h, int64_t nrows) {      // tile offsets | chunk totals | chunk offsets | stream totals
    const size_t nl = (size_t)h->dev.nscreens * h->dev.ntrks, nch = (size_t)(pk_tiles_for(nrows) + 1023) / 1024;
    return h->dev.peak_path ? ((((size_t)pk_tiles_for(nrows) + 2 * nch + 2) * nl * 4 + 255) & ~(size_t)255) : 0; }
 static size_t ws_pkcrec_off(const rtfe_handle *h, int64_t nrows) { return ws_pktstart_off(h, nrows) + pk_tstart_bytes(h, nrows); }
-static size_t pk_crec_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * 4 + 255) & ~(size_t)255) : 0; }
+static size_t pk_crec_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * sizeof(CRec) + 255) & ~(size_t)255) : 0; }
 static size_t ws_pkeref_off(const rtfe_handle *h, int64_t nrows) { return ws_pkcrec_off(h, nrows) + pk_crec_bytes(h, nrows); }
 // ... | how many records a list's deferred candidates add to (or take from) its stream (k_sift_hard -> k_pscan)
 static size_t ws_pkextra_off(const rtfe_handle *h, int64_t nrows);
 static size_t pk_extra_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * 4 + 255) & ~(size_t)255) : 0; }
-static size_t pk_eref_bytes(const rtfe_handle *h, int64_t nrows) { (void)h; (void)nrows; return 0; }      // (round 4's entry references: gone with the variable margin entries)
+static size_t pk_eref_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * 4 + 255) & ~(size_t)255) : 0; }
 
 static size_t ws_pkextra_off(const rtfe_handle *h, int64_t nrows) { return ws_pkeref_off(h, nrows) + pk_eref_bytes(h, nrows); }
 // ... | the chains between k_gain (heads), k_gain_s (steady stretches) and k_gain (tails)
@@ -555,8 +552,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    if (h->dev.mode == RTFE_WW) return fail(-44, "Whirlwind tapes have no independent bursts: use rtfe_ww_scan");
    if (((uintptr_t)d_rows & 15) != 0) return fail(-31, "d_rows must be 16-byte aligned");
    if (workspace_bytes < rtfe_workspace_bytes(h, nrows)) return fail(-32, "workspace too small");
-   // the peak path addresses rows with 32 bits and a record by a 32-bit stream entry (tile << pk_cshift | record; overflow slot << 2 | record)
-   if (h->dev.peak_path && (nrows >= 0x7ff00000ll || pk_tiles_for(nrows) >= (1ll << (30 - h->dev.pk_cshift)) || pk_hard_cap(h, nrows) >= (1ll << 28)))
+   // the peak path addresses rows with 32 bits and a record's margin entries by a 32-bit index (2-byte units) into pool + overflow slots
+   if (h->dev.peak_path && (nrows >= 0x7ff00000ll || (ws_pkqtile_off(h, nrows) - ws_pkpool_off(h, nrows)) / 2 >= 0xffffffffull))
       return fail(-36, "%lld rows are too many for one rtfe_scan on the peak path: scan the tape in fragments (own_rows)", (long long)nrows);
    if (nrows <= 0 || max_bursts < 1) return fail(-33, "nothing to scan");
    if (own_rows <= 0 || own_rows > nrows) return fail(-35, "own_rows must be in (0, nrows]");
@@ -613,7 +610,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (const sfs_kernel_t sfs = sf_special(h->dev)) {
          SfArgs a;
          a.rows = d_rows; a.nrows = nrows; a.ntiles = (int)ptiles; a.qtile = qtile; a.dir = dirm; a.pool = pkpool; a.hard = hardp; a.hard_cap = hard_cap;
-         a.hard_count = &scratch->hard_count; a.dbg = scratch->scr; a.hcap = h->dev.pk_slot; a.gcap = h->dev.pk_gslot; a.wave_cap = h->dev.pk_wave_cap; a.invert = h->dev.invert;
+         a.hard_count = &scratch->hard_count; a.dbg = scratch->scr; a.hcap = h->dev.pk_slot; a.wave_cap = h->dev.pk_wave_cap; a.invert = h->dev.invert;
          a.quiet_i = h->dev.quiet_i; a.lo_i = h->dev.screen[0].rise_i; a.hi_i = h->dev.screen[0].sure_i; a.minpk_i = h->dev.screen[0].minpk_i;
          a.cut = h->dev.cut; a.debug = h->dev.debug; a.defer = h->sift_defer;
          hipLaunchKernelGGL(sfs, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, a); }
@@ -648,7 +645,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       uint32_t *tstartp = reinterpret_cast<uint32_t *>(wsb + ws_pktstart_off(h, nrows));
       const int nsc = (int)((ptiles + 1023) / 1024);                    // chunks of 1024 tiles (k_pscan)
       uint32_t *ctotcp = tstartp + (size_t)ptiles * nlists, *coffp = ctotcp + (size_t)nsc * nlists, *ctotp = coffp + (size_t)nsc * nlists;
-      uint32_t *sidxp = reinterpret_cast<uint32_t *>(wsb + ws_pkcrec_off(h, nrows));
+      CRec *crecp = reinterpret_cast<CRec *>(wsb + ws_pkcrec_off(h, nrows));
+      uint32_t *erefp = reinterpret_cast<uint32_t *>(wsb + ws_pkeref_off(h, nrows));
       int *extrap = reinterpret_cast<int *>(wsb + ws_pkextra_off(h, nrows));
       const long long ccap = pk_ccap(h, nrows);
       hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
@@ -656,7 +654,10 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (const int *)extrap, (int)ptiles, nlists, tstartp, ctotcp);
       hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
       hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
-                         (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, sidxp);
+                         (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, crecp, erefp);
+#ifdef RTFE_CPU_EMUL
+      if (getenv("RTFE_PREP_CHECK")) hipLaunchKernelGGL(k_prep_check, dim3(1), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, (const CRec *)crecp);
+#endif
       t1(kTPrep);
       if (sa != st) (void)hipStreamWaitEvent(st, h->ev_join, 0);        // join: the chains need both
       if (stop_after < 3) { skip_rest(); return launch_check("rtfe_scan"); }
@@ -666,23 +667,23 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       for (int mode = 0; mode < 2; ++mode) {
          if (mode == 1) t0(kTGainTail);
          hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                            scratch, ctlp, d_counts, d_events, chainh, (const uint32_t *)sidxp, (const unsigned char *)ovfp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
+                            scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
                             (const unsigned char *)pkpool, ptiles, reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows)), pk_seg_cap(h, nrows), d_rows);
          if (mode == 0) {
             t1(kTGain); t0(kTGainS);
             // the steady stretches: in segments, every one on its own, joined where the states agree bit for bit (rtfe_gain.hip)
             GsSeg *segp = reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows));
             float *gfirep = reinterpret_cast<float *>(wsb + ws_pkgfire_off(h, nrows));
-            hipLaunchKernelGGL(k_gain_seg, dim3(h->num_cus * 16), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, scratch, (const uint32_t *)sidxp, (const unsigned char *)pkpool, (const unsigned char *)ovfp, (const uint32_t *)ctotp, ccap, segp, (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), gfirep);
+            hipLaunchKernelGGL(k_gain_seg, dim3(h->num_cus * 16), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, scratch, (const CRec *)crecp, ccap, segp, (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), gfirep);
             hipLaunchKernelGGL(k_gain_join, dim3(h->num_cus * 2), dim3(64), 0, st, (const DevCfg *)h->d_dev, cstp, (const rtfe_burst *)d_bursts, scratch, (const BurstCtl *)ctlp, d_counts, chainh, segp);
             t1(kTGainS); } }
       t1(kTGainTail);
       if (stop_after < 4) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTEmit);
-      hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const uint32_t *)sidxp, (const unsigned char *)ovfp, (const uint32_t *)ctotp, ccap,
+      hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, (const uint32_t *)erefp, ccap,
                          (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks), d_rows, (long long)nrows);
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
-                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const uint32_t *)sidxp, (const unsigned char *)ovfp, (const uint32_t *)ctotp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp, d_rows, (long long)nrows);
+                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint32_t *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp, d_rows, (long long)nrows);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTEmit);
       if (stop_after < 5) { skip_rest(); return launch_check("rtfe_scan"); }

@@ -66,8 +66,7 @@ struct DevCfg {
    int   cut;                     // RTFE_CUT: k_sift stops after a phase (timing experiments, tools/ only; results are then garbage)
    int   peak_path;               // k_sift -> k_gain -> k_emit serve rtfe_scan (peak detection on the undifferentiated signal)
    int   pk_hl, pk_hr;            // rows kept in front of / behind a k_sift tile in LDS (multiples of 8)
-   int   pk_slot;                 // bytes of a list's staging slot in k_sift's LDS (capacity of one (tile, screen, head): pk_slot / 16 records); multiple of 16
-   int   pk_gslot, pk_cshift;     // bytes of its slot in the pool: the power of two >= pk_slot, = 16 << pk_cshift (a stream entry is tile << pk_cshift | record)
+   int   pk_slot;                 // bytes of a pool slot: the list of one (tile, screen, head); multiple of 16
    int   pk_wave_cap;             // candidates of one wave (two heads of a tile) k_sift can list in LDS; beyond: lists unavailable
    int   pk_lds;                  // dynamic LDS bytes of k_sift
    int   pk_fast;                 // k_gain: the steady-state fast path (0: every detection through the general step; tests)
@@ -127,9 +126,9 @@ struct PeakRec { uint32_t w0, w1; };
 // entries from the back (entry e at slot_end - 2 (e + 1)); a list that does not fit is marked unavailable in the directory.
 //   w1 == 0xffff8001: a candidate k_sift deferred; w0 = its index in the hard list = its overflow slot (k_sift_hard)
 struct SfHard { uint32_t tile; uint16_t pos; uint8_t head, screen; };      // a deferred candidate: tile, row within it, head, screen
-constexpr int kSfOvfBytes = 128;     // an overflow slot: int32 records, int32 tile, <= 4 records from byte 8, their margin blocks from the back
+constexpr int kSfOvfBytes = 128;     // an overflow slot: int32 records (-1: not representable), pad, <= 4 records from byte 8, margin entries from the back
 struct PeakDir {               // per (tile, screen, head): 4 bytes
    uint16_t nrec;              // 0xFFFF: not available (capacity)
-   uint16_t ndef;              // how many of them are deferred candidates (placeholders k_sift_hard resolves: k_prep expands those lists entry by entry)
+   uint16_t nent;
 };
 }  // namespace rtfe

@@ -99,21 +99,16 @@ __device__ __forceinline__ long long chain_stop(const DevCfg &cfg, const rtfe_bu
    return stop; }
 
 // ------------------------------------------------------------------------------------------------
-// k_pscan / k_prep: k_sift's lists (one slot per tile and head in the pool) -> ONE index stream per (screen, head): a 4-byte entry per
-// record, in row order, that says where the record lies.  (Rounds 3 and 4 copied every record into a stream of 16-byte records with its
-// absolute row, its volts and a static verdict - 1.0 GB of traffic and 0.35 ms per C2 scan; now the walkers make those from the 8-byte
-// record where they read it - rec_at - and the pass writes 4 bytes per record without reading the records at all.)
-//   entry = tile << pk_cshift | record        a record of the tile's list (the stream knows its screen and head)
-//           kIxOvf | slot << 2 | record       a record of a deferred candidate's overflow slot (k_sift_hard)
-//           kIxBad | tile                     the tile's list is not there (capacity): a marker at the tile's first row
-// k_pscan: the streams' tile offsets (a prefix sum per stream over the tile directory).
+// k_pscan / k_prep: k_sift's lists (one fixed slot per tile and head) -> ONE contiguous stream of 16-byte records per (screen, head),
+// in row order, with everything a chain's lane would otherwise recompute per record on its critical path: the owner's absolute
+// row, volt() of its value, where its margin entries are.  k_pscan: the streams' tile offsets (a prefix sum per stream over the
+// tile directory); k_prep: a wave per list copies its records over.
 // ------------------------------------------------------------------------------------------------
 // flags in CRec::w0 bits 0-10 (the tile-relative row of PeakRec::w0 is replaced by the absolute CRec::pos)
 enum { kCrBad = 1,                        // the tile's list is not there (capacity)
        kCrClear = 2 };                    // a record with a sure stretch (1..62 rows), its minimum known, and no other record's first row at or before the row
-                                          // its owner leaves the window at (pos + W): whatever fires in it fires before anything else can
-struct CRec { uint32_t pos, w0, w1; float volt; };      // a stream record as the walkers see it (rec_at makes it; round 4 stored it)
-constexpr uint32_t kIxOvf = 0x80000000u, kIxBad = 0x40000000u;
+                                          // its owner leaves the window at (pos + W): whatever fires in it fires before anything else can (k_prep's second pass)
+struct CRec { uint32_t pos, w0, w1; float volt; };
 
 // k_pscan1: a workgroup per chunk of 1024 tiles, a thread per tile: per stream the prefix within the chunk and the chunk's total;
 // k_pscan2: the chunks' offsets (one workgroup).  A stream's position of tile t = tstart[t][stream] + coff[t >> 10][stream].
@@ -158,50 +153,123 @@ __device__ __forceinline__ int half_incl_scan(int v, int hl) {
 #endif
 }
 
-// k_prep: the tiles' lists -> the index streams.  Half a wave per list; a list without deferred candidates (all but a few in a thousand:
-// the directory says) is its tile and 0 .. nrec - 1, written without a look at the pool; one with deferred candidates is read, and every
-// placeholder expands into the records of its overflow slot (none, if the candidate turned out to have no rows).
+// k_prep: the tiles' lists -> the streams.  Half a wave per list (a clean NRZI tile holds ~21 records per head), the next list's
+// directory entry and records in flight while this one is written (a list is two dependent HBM round trips otherwise, and there is
+// little else to hide them).  Per record: its absolute row, its volts, where its margin entries are, and kCrClear - everything static
+// that the chains' steady path asks of it: a plain record with a sure stretch whose successor in the stream (the next record of the
+// list; the first of the next tile's list) begins after this record's owner has left the window.
 __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
                                               const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff,
-                                              const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, uint32_t *__restrict__ sidx) {
+                                              const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint32_t *__restrict__ eref) {
    const DevCfg &cfg = *cfgp;
-   const int nlists = cfg.nscreens * cfg.ntrks, gcap = cfg.pk_gslot, cs = cfg.pk_cshift;
+   const int nlists = cfg.nscreens * cfg.ntrks, hcap = cfg.pk_slot;
+   const float mv = cfg.maxvolts;
    const int lane = threadIdx.x & 63, hl = lane & 31, hbase = lane & 32;
    const long long nall = ntiles * nlists;
+   const size_t ovf16 = (size_t)(ovf - pool) / 2;                         // the overflow slots, in the 2-byte units eref counts from the pool's start
    const long long stride = (long long)gridDim.x * 8;                     // lists per sweep: four waves, two lists each
+   struct Pre { PeakDir d, dn; uint2 r, r1, rn; uint32_t ts, co, ct; };
+   auto fetch = [&](long long l, long long tl, int s2) -> Pre {      // (everything the list's step reads, bar a deferred candidate's records: no load inside the step to wait for)
+      Pre p; p.d.nrec = 0; p.d.nent = 0; p.dn = p.d; p.r = make_uint2(0, 0); p.r1 = p.r; p.rn = p.r; p.ts = 0; p.co = 0; p.ct = 0;
+      if (l < nall) {
+         const unsigned char *slot = pool + (size_t)l * hcap;
+         p.d = dir[l];
+         p.ts = tstart[(size_t)tl * nlists + s2]; p.co = coff[(size_t)(tl >> 10) * nlists + s2]; p.ct = ctot[s2];
+         p.r = *reinterpret_cast<const uint2 *>(slot + min(8 * hl, hcap - 8));
+         p.r1 = *reinterpret_cast<const uint2 *>(slot + min(8 * (hl + 1), hcap - 8));
+         if (l + nlists < nall) { p.dn = dir[l + nlists]; p.rn = *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap); } }
+      return p; };
+   // where a record's successor begins: the first row of the first record at or behind entry k1 of a list (q1 = that entry, already
+   // loaded) - a deferred candidate stands for its records (k_sift_hard), and for nothing at all if it turned out to have none.
+   // kNoSucc: the stream ends; kOffList: the list has no further record; kBadSucc: cannot tell (the record is then not marked clear)
+   constexpr long long kNoSucc = 0x7fffffffffffffffll, kBadSucc = -1, kOffList = -2;
+   auto succ_row = [&](const unsigned char *lslot, int k1, int n1, uint2 q, long long pos0q) -> long long {
+      for (int j = k1; j < n1; ++j) {
+         if (j > k1) q = *reinterpret_cast<const uint2 *>(lslot + 8 * j);
+         if (q.y == 0xffff8001u) {
+            const unsigned char *os = ovf + (size_t)q.x * kSfOvfBytes;
+            if (*reinterpret_cast<const int *>(os) <= 0) continue;
+            q = *reinterpret_cast<const uint2 *>(os + 8); }
+         return pos0q + (long long)(q.x & 0x7ffu) + (long long)((q.x >> 12) & 63u); }
+      return kOffList; };
+   long long li = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+   // (tile, stream) of the list, stepped along with li: no division in the loop
    const long long dq = stride / nlists;
    const int dr = (int)(stride - dq * nlists);
-   long long li = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
    long long tile = li / nlists;
    int sl = (int)(li - tile * nlists);
-   for (; __ballot(li < nall) != 0ull; li += stride, tile += dq, sl += dr) {      // (wave-uniform control flow: the two halves' lists differ, the scans below are the wave's)
+   Pre nx = fetch(li, tile, sl);
+   for (; __ballot(li < nall) != 0ull; li += stride, tile += dq, sl += dr) {
       if (sl >= nlists) { sl -= nlists; ++tile; }
-      const bool on = li < nall;
-      PeakDir d; d.nrec = 0; d.ndef = 0;
-      if (on) d = dir[li];
-      const bool built = on && d.nrec != 0 && (long long)ctot[on ? sl : 0] <= ccap;      // a stream that outgrew its capacity is not built: its chains give up (k_gain)
-      uint32_t *out = sidx;
-      if (built) out += (size_t)sl * ccap + (size_t)tstart[(size_t)tile * nlists + sl] + (size_t)coff[(size_t)(tile >> 10) * nlists + sl];
-      const uint32_t tb = (uint32_t)tile << cs;
+      const Pre cu = nx;
+      {  long long t2 = tile + dq; int s2 = sl + dr;
+         if (s2 >= nlists) { s2 -= nlists; ++t2; }
+         nx = fetch(li + stride, t2, s2); }
+      const PeakDir d = cu.d;
+      const bool on = li < nall && d.nrec != 0;
+      const bool built = on && (long long)cu.ct <= ccap;                  // a stream that outgrew its capacity is not built: its chains give up (k_gain)
+      long long base = built ? (long long)sl * ccap + (long long)cu.ts + (long long)cu.co : 0;
+      if (built && d.nrec == 0xffffu) {                                  // a list that did not fit: one marker at the tile's first row
+         if (hl == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; eref[base] = 0; } }
       const int nrec = (built && d.nrec != 0xffffu) ? (int)d.nrec : 0;
-      if (built && d.nrec == 0xffffu && hl == 0) out[0] = kIxBad | (uint32_t)tile;      // a list that did not fit: one marker
-      const bool slow = nrec > 0 && d.ndef != 0;
-      if (nrec > 0 && !slow) for (int k = hl; k < nrec; k += 32) out[k] = tb | (uint32_t)k;
-      int rounds = slow ? (nrec + 31) >> 5 : 0;
-      {  const int other = __shfl(rounds, lane ^ 32); if (other > rounds) rounds = other; }
-      const unsigned char *slot = pool + (size_t)(slow ? li : 0) * gcap;
-      int base = 0;
+      const int W = cfg.screen[(on ? sl : 0) / cfg.ntrks].W;
+      const unsigned char *slot = pool + (size_t)(on ? li : 0) * hcap;
+      const long long pos0 = tile * kSfTile - kSfPosBias;
+      // what follows this list in its stream
+      long long fn_list = kNoSucc;
+      if (nrec > 0 && tile + 1 < ntiles) {
+         if (cu.dn.nrec == 0xffffu) fn_list = (tile + 1) * kSfTile + 1;                       // (the marker of a list that is not there)
+         else if (cu.dn.nrec != 0) { fn_list = succ_row(slot + (size_t)nlists * hcap, 0, (int)cu.dn.nrec, cu.rn, pos0 + kSfTile); if (fn_list == kOffList) fn_list = kBadSucc; }
+         /* an empty list: whatever comes behind it begins more than a tile's rows less the owners' reach further on */ }
+      int rounds = (nrec + 31) >> 5;
+      {  const int other = __shfl(rounds, lane ^ 32); if (other > rounds) rounds = other; }      // (both halves run the scans of every round)
       for (int rd = 0; rd < rounds; ++rd) {
          const int k = rd * 32 + hl;
-         const bool have = slow && k < nrec;
-         const uint2 q = have ? *reinterpret_cast<const uint2 *>(slot + 8 * k) : make_uint2(0, 0);
-         const bool deferred = have && q.y == 0xffff8001u;                  // its records are in overflow slot q.x (k_sift_hard): they take its place
-         const int cnt = deferred ? *reinterpret_cast<const int *>(ovf + (size_t)q.x * kSfOvfBytes) : (have ? 1 : 0);
+         const bool have = k < nrec;
+         uint2 q = cu.r, q1 = cu.r1;
+         if (rd > 0 && have) { q = *reinterpret_cast<const uint2 *>(slot + 8 * k); if (k + 1 < nrec) q1 = *reinterpret_cast<const uint2 *>(slot + 8 * (k + 1)); }
+         const uint32_t w0 = have ? q.x : 0u, w1 = have ? q.y : 0u;
+         const bool deferred = have && w1 == 0xffff8001u;                  // its records are in overflow slot w0 (k_sift_hard): they take its place
+         const unsigned char *os = ovf + (size_t)(deferred ? w0 : 0u) * kSfOvfBytes;
+         const int cnt = deferred ? *reinterpret_cast<const int *>(os) : (have ? 1 : 0);
          const int ic = half_incl_scan(cnt, hl);
-         const int o = base + ic - cnt;
-         if (deferred) { for (int j = 0; j < cnt; ++j) out[o + j] = kIxOvf | (q.x << 2) | (uint32_t)j; }
-         else if (have) out[o] = tb | (uint32_t)k;
+         const long long o = base + ic - cnt;
+         long long fn = !have ? kNoSucc : succ_row(slot, k + 1, nrec, q1, pos0);      // the successor of this list entry's last record
+         if (fn == kOffList) fn = fn_list;
+         if (deferred) {
+            for (int j = 0; j < cnt; ++j) {
+               const uint2 e = *reinterpret_cast<const uint2 *>(os + 8 + 8 * j);
+               CRec c; c.pos = (uint32_t)(pos0 + (long long)(e.x & 0x7ffu)); c.w0 = e.x & ~0x7ffu; c.w1 = e.y; c.volt = volt((int)(int16_t)(e.y & 0xffffu), mv);
+               long long fj = fn;
+               if (j + 1 < cnt) { const uint2 e2 = *reinterpret_cast<const uint2 *>(os + 8 + 8 * (j + 1)); fj = pos0 + (long long)(e2.x & 0x7ffu) + (long long)((e2.x >> 12) & 63u); }
+               if (e.y != 0xffff8000u && (unsigned)((int)((e.x >> 22) & 63u) - 1) < 62u && fj != kBadSucc && fj > (long long)c.pos + W) c.w0 |= kCrClear;
+               crec[o + j] = c;
+               eref[o + j] = (uint32_t)(ovf16 + ((size_t)w0 * kSfOvfBytes + kSfOvfBytes) / 2 - (size_t)(kPkMar * j)); } }
+         else if (have) {
+            CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
+            if (w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u && fn != kBadSucc && fn > (long long)c.pos + W) c.w0 |= kCrClear;
+            crec[o] = c;
+            eref[o] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(kPkMar * k)); }      // (where its margin block ends: record k's, 8 k bytes in front of the slot's end)
          base += __shfl(ic, hbase + 31); } } }
+
+#ifdef RTFE_CPU_EMUL
+// (emulator only, RTFE_PREP_CHECK: kCrClear as a pass over the finished streams would set it)
+__global__ void __launch_bounds__(64) k_prep_check(const DevCfg *__restrict__ cfgp, const uint32_t *__restrict__ ctot, long long ccap, const CRec *__restrict__ crec) {
+   const DevCfg &cfg = *cfgp;
+   const int nlists = cfg.nscreens * cfg.ntrks;
+   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+   for (int sl = 0; sl < nlists; ++sl) {
+      const int W = cfg.screen[sl / cfg.ntrks].W;
+      const long long n = (long long)ctot[sl] > ccap ? 0 : (long long)ctot[sl];
+      const CRec *r = crec + (size_t)sl * ccap;
+      for (long long i = 0; i < n; ++i) {
+         const uint32_t w0 = r[i].w0, w1 = r[i].w1;
+         const int nsure = (int)((w0 >> 22) & 63u);
+         bool ok = !(w0 & kCrBad) && w1 != 0xffff8000u && (unsigned)(nsure - 1) < 62u;
+         if (ok && i + 1 < n) { const long long fn = (long long)r[i + 1].pos + (long long)((r[i + 1].w0 >> 12) & 63u); ok = fn > (long long)r[i].pos + W; }
+         if (ok != ((w0 & kCrClear) != 0)) fprintf(stderr, "prep_check: stream %d record %lld of %lld pos %u: clear %d, a pass over the stream says %d (next pos %u w0 %08x w1 %08x)\n", sl, i, n, r[i].pos, (int)((w0 & kCrClear) != 0), (int)ok,
+                                                   i + 1 < n ? r[i + 1].pos : 0u, i + 1 < n ? r[i + 1].w0 : 0u, i + 1 < n ? r[i + 1].w1 : 0u); } } }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // k_gain
@@ -279,81 +347,19 @@ __device__ __forceinline__ long long run_fire(const Walker &w, const Run &u, con
       if (rise_pass(w, u.top, u.val, run_margin(ms, u, eend, u.nlead + u.nsure + i), mv)) return n; }
    return kNoRow; }
 
-// ---- a stream as the walkers read it: entry i of the index stream -> the 8-byte record where k_sift left it -> the stream record
-// (absolute owner row, flags, the extreme in volts; kCrClear from the record and its successor in the stream) ----
-struct RecSrc {
-   const uint32_t *sidx;             // this stream's entries (k_prep)
-   const unsigned char *slots;       // the pool from this stream's slot of tile 0 on: tile t's slot lies t * tstride bytes further
-   const unsigned char *ovf;         // the overflow slots (k_sift_hard)
-   size_t tstride;                   // bytes between two tiles' slots of one stream (lists per tile x pk_gslot)
-   int cs, gcap, W;
-   float mv;
-   long long iend;                   // where this chain's piece of the stream ends
-   long long total; };               // entries in the stream (the last one has no successor)
-struct RawRec { uint32_t pos, w0, w1; };      // absolute owner row; w0 without the tile-relative row (kCrBad: the marker of a list that is not there); w1
-// entry i: the record, and where its margin block ends (mend, may be null)
-__device__ __forceinline__ RawRec raw_at(const RecSrc &S, long long i, const unsigned char **mend) {
-   const uint32_t v = S.sidx[i];
-   RawRec r;
-   if (v & kIxBad) {                                                     // (k_prep's marker of round 4: the tile's first row, first test row one further)
-      r.pos = (uint32_t)((long long)(v & 0x3fffffffu) * kSfTile); r.w0 = kCrBad | (1u << 12); r.w1 = 0xffff8000u;
-      if (mend) *mend = S.slots;
-      return r; }
-   uint2 q; long long tile; const unsigned char *me;
-   if (v & kIxOvf) {
-      const unsigned char *slot = S.ovf + (size_t)((v & 0x3fffffffu) >> 2) * kSfOvfBytes;
-      const int j = (int)(v & 3u);
-      tile = reinterpret_cast<const int *>(slot)[1];
-      q = *reinterpret_cast<const uint2 *>(slot + 8 + 8 * j);
-      me = slot + kSfOvfBytes - 8 * j; }
-   else {
-      tile = (long long)(v >> S.cs);
-      const int k = (int)(v & ((1u << S.cs) - 1u));
-      const unsigned char *slot = S.slots + (size_t)tile * S.tstride;
-      q = *reinterpret_cast<const uint2 *>(slot + 8 * k);
-      me = slot + S.gcap - 8 * k; }
-   r.pos = (uint32_t)(tile * kSfTile - kSfPosBias + (long long)(q.x & 0x7ffu)); r.w0 = q.x & ~0x7ffu; r.w1 = q.y;
-   if (mend) *mend = me;
-   return r; }
-// the first row of a record's run (what "its successor begins at" means)
-__device__ __forceinline__ long long raw_first(const RawRec &r) { return (long long)r.pos + (long long)((r.w0 >> 12) & 63u); }
-constexpr long long kNoSuccRow = 0x7fffffffffffffffll;
-// the stream record: kCrClear = a plain record with a sure stretch whose successor in the stream begins only after this record's owner
-// has left the window (fn: the successor's first row; kNoSuccRow: there is none)
-__device__ __forceinline__ uint4 crec_make(const RawRec &r, long long fn, int W, float mv) {
-   uint32_t w0 = r.w0;
-   if (!(w0 & kCrBad) && r.w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u && fn > (long long)r.pos + W) w0 |= kCrClear;
-   const float v = (w0 & kCrBad) ? 0.0f : volt((int)(int16_t)(r.w1 & 0xffffu), mv);
-   return make_uint4(r.pos, w0, r.w1, __float_as_uint(v)); }
-__device__ __forceinline__ CRec rec_at(const RecSrc &S, long long i, const unsigned char **mend, bool with_clear) {
-   const RawRec r = raw_at(S, i, mend);
-   long long fn = kNoSuccRow;
-   if (with_clear && i + 1 < S.total) { const RawRec nx = raw_at(S, i + 1, nullptr); fn = raw_first(nx); }
-   const uint4 c4 = crec_make(r, with_clear ? fn : 0, S.W, S.mv);
-   CRec c; c.pos = c4.x; c.w0 = c4.y; c.w1 = c4.z; c.volt = __uint_as_float(c4.w);
-   return c; }
-
-__device__ __forceinline__ RecSrc recsrc_make(const DevCfg &cfg, const uint32_t *sidx, const unsigned char *pool, const unsigned char *ovf, long long ccap, const uint32_t *ctot, int sl, int W) {
-   RecSrc S;
-   S.sidx = sidx + (size_t)sl * ccap; S.slots = pool + (size_t)sl * cfg.pk_gslot; S.ovf = ovf;
-   S.tstride = (size_t)(cfg.nscreens * cfg.ntrks) * cfg.pk_gslot; S.cs = cfg.pk_cshift; S.gcap = cfg.pk_gslot; S.W = W; S.mv = cfg.maxvolts;
-   S.total = (long long)ctot[sl] > ccap ? 0 : (long long)ctot[sl];      // (a stream that outgrew its capacity was not built)
-   S.iend = S.total;
-   return S; }
-
 // a lane's place in its stream for the general step
 struct RecIt {
    long long i;
    uint32_t w0, w1; long long pos;
    const uint16_t *eend;
    bool end, bad; };
+struct RecSrc { const CRec *rec; const uint32_t *eref; const unsigned char *pool; long long iend; };
 __device__ __forceinline__ void it_land(RecIt &it, const RecSrc &S) {
    if (it.i >= S.iend) { it.end = true; return; }
-   const unsigned char *me = nullptr;
-   const RawRec r = raw_at(S, it.i, &me);
+   const CRec r = S.rec[it.i];
    it.pos = r.pos; it.w0 = r.w0; it.w1 = r.w1;
    if (r.w0 & kCrBad) { it.end = true; it.bad = true; return; }
-   it.eend = reinterpret_cast<const uint16_t *>(me); }
+   it.eend = reinterpret_cast<const uint16_t *>(S.pool) + S.eref[it.i]; }
 __device__ __forceinline__ void it_open(RecIt &it, const RecSrc &S, long long i) {
    it.end = false; it.bad = false; it.i = i; it.eend = nullptr; it.w0 = 0; it.w1 = 0; it.pos = 0;
    it_land(it, S); }
@@ -391,7 +397,7 @@ struct ChainSt { Walker w; float heights[10]; long long i, c, iend; int status, 
 __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
-                                             const uint32_t *__restrict__ sidx, const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
+                                             const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
                                              long long ccap, const unsigned char *__restrict__ pool, long long ntiles, GsSeg *__restrict__ segs, long long seg_cap, const int16_t *__restrict__ rows) {
    __shared__ float s_heights[64 * 10];
    __shared__ uint4 s_notes[kGainChunk][64];                           // the events the fast path notes, until the chunk's end
@@ -435,7 +441,8 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       unsigned int n_fast = 0, n_slow = 0;
       // this chain's piece of its head's stream: from the tile that holds row c - W to the tile behind the limit
       const int sl = P.screen * ntrks + head;
-      RecSrc src = recsrc_make(cfg, sidx, pool, ovf, ccap, ctot, sl, W);
+      RecSrc src;
+      src.rec = crec + (size_t)sl * ccap; src.eref = eref + (size_t)sl * ccap; src.pool = pool;
       MarSrc msrc; msrc.rows = rows; msrc.nrows = nrows; msrc.ntrks = ntrks; msrc.head = head; msrc.sg = cfg.invert ? -1 : 1; msrc.W = W; msrc.nmar = cfg.pk_mar;
       long long i;
       {  long long g0 = (c - W) / kSfTile; if (c - W < 0) g0 = 0; if (g0 >= ntiles) g0 = ntiles - 1;
@@ -524,7 +531,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          // (a record whose extreme is below the amplitude test for sure cannot fire while the thresholds stand, and they stand until something
          //  fires - behind which all of this record's rows are blind: it is passed over)
          if (lean && plain && amp_on && a <= w.min_lo) return 0;
-         const int fn = idx + 1 < src.iend ? (int)nxt4.x + (int)((nxt4.y >> 12) & 63u) : 0x7fffffff;      // (the chain's last record: whatever follows it in the stream lies behind the chain's limit)
+         const int fn = idx + 1 < src.iend ? (int)nxt4.x + (int)((nxt4.y >> 12) & 63u) : 0x7fffffff;
          // ---- the fast path: a record with a sure stretch, the countdown over before its first row, the thresholds inside the band the sure
          // level stands for, a clear amplitude, and nothing else that could fire before this record's owner has left the window.  Then it
          // fires - at one of its lead rows or at its first sure row, k_emit will say which - and all that feeds back is the extreme's value. ----
@@ -614,20 +621,16 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          i = alive.i;
          if (!steady && lean && alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) enter_steady();
          return 1; };
-      // (the chunk's records as they lie in the pool - three registers each, and one more record: the last one's successor, for kCrClear -
-      //  a chunk ahead; the stream records are made where they go to LDS)
-      RawRec rq[kGainChunk + 2];
+      uint4 q[kGainChunk + 1];
       #pragma unroll
-      for (int j = 0; j <= kGainChunk + 1; ++j) { rq[j].pos = 0; rq[j].w0 = kCrBad; rq[j].w1 = 0; }
-      long long rq_i0 = 0;
-      const long long rq_end = src.iend + 1 < src.total ? src.iend + 1 : src.total;
+      for (int j = 0; j <= kGainChunk; ++j) q[j] = make_uint4(0, 0, 0, 0);
+      const uint4 *rec4 = reinterpret_cast<const uint4 *>(src.rec);
       auto fetch = [&](long long i0) {
-         rq_i0 = i0;
          #pragma unroll
-         for (int j = 0; j <= kGainChunk + 1; ++j) if (i0 + j < rq_end) rq[j] = raw_at(src, i0 + j, nullptr); };
+         for (int j = 0; j <= kGainChunk; ++j) if (i0 + j < src.iend) q[j] = rec4[i0 + j]; };
       auto put = [&]() {
          #pragma unroll
-         for (int j = 0; j <= kGainChunk; ++j) s_rec[j][lane] = crec_make(rq[j], rq_i0 + j + 1 < src.total ? raw_first(rq[j + 1]) : kNoSuccRow, W, mv); };
+         for (int j = 0; j <= kGainChunk; ++j) s_rec[j][lane] = q[j]; };
       int st2 = active ? 0 : 2;                                            // 0: in lock step, 1: waiting for the general step, 2: done, 3: (mode 0) steady from here
       bool handed = false;
       if (st2 == 0) fetch(i);
@@ -723,8 +726,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
 constexpr int kGsRegs = 8, kGsDepth = 1;
 constexpr int kGsPitch = kGsRegs + 1;                                 // a lane's slot in LDS, in 16-byte units (odd: conflict-free 128-bit reads)
 __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, BurstScratch *__restrict__ scratch,
-                                                 const uint32_t *__restrict__ sidx, const unsigned char *__restrict__ pool, const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ ctot,
-                                                 long long ccap, GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, long long seg_cap, float *__restrict__ gfire) {
+                                                 const CRec *__restrict__ crec, long long ccap, GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, long long seg_cap, float *__restrict__ gfire) {
    __shared__ uint4 s_rec[64 * kGsPitch];
    const int lane = threadIdx.x;
    const int nsegs = (int)min((long long)*nsegs_p, seg_cap);      // (the count includes chains that found the table full: their entries were never written)
@@ -745,7 +747,7 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
       const int W = K.W, sure_i = K.sure_i, limit32 = K.limit32;
       const bool amp_on = K.amp_on != 0;
       const float h = K.h, alpha = K.alpha, beta = 1 - K.alpha, kr = K.kr, km = K.km, rg_min = K.rg_min, g_min = K.g_min;
-      const RecSrc src = recsrc_make(*cfgp, sidx, pool, ovf, ccap, ctot, active ? K.sl : 0, W);
+      const uint4 *rec4 = reinterpret_cast<const uint4 *>(crec + (size_t)K.sl * ccap);
       float *gout = gfire + (size_t)si * S;
       // where the walk begins and in which state: the chain's as k_gain (mode 0) left it - segment 0's true state, the others' guess
       float g = cs.w.agc_gain, vlt = cs.w.v_lasttop, vlb = cs.w.v_lastbot;
@@ -766,31 +768,16 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
          // the pieces this lane fetches for the others: of lane 8k + sub's records [at, at + 8) the one numbered `piece`.  kGsDepth
          // chunks are in flight (measured: 3 instead of 1 change nothing - the walk is bound by the step's dependent instructions).
          uint4 q[kGsDepth][kGsRegs];
-         // (piece p of lane L's chunk is entry at_L + p of L's stream: the helper reads the entry, the 8-byte record it points at, and makes
-         //  the stream record - its successor's first row comes from the neighbour lane that holds piece p + 1, or, for a chunk's last
-         //  piece, from a read of its own)
          auto fetch = [&](uint4 (&dst)[kGsRegs], const long long at) {
+            const unsigned long long mine = reinterpret_cast<unsigned long long>(rec4 + at);
             const int left = run ? (int)((to - at) < kGsRegs ? (to - at > 0 ? to - at : 0) : kGsRegs) : 0;
             #pragma unroll
             for (int k = 0; k < kGsRegs; ++k) {
-               const int srcl = 8 * k + sub;
-               const long long at_s = ((long long)__shfl((int)(at >> 32), srcl) << 32) | (unsigned)__shfl((int)(unsigned)at, srcl);
-               const int n = __shfl(left, srcl);
-               // the helped lane's stream (lanes of a wave may serve different streams: K.sl is per lane)
-               RecSrc hs = src;
-               {  const unsigned long long sp = reinterpret_cast<unsigned long long>(src.sidx), lp = reinterpret_cast<unsigned long long>(src.slots);
-                  hs.sidx = reinterpret_cast<const uint32_t *>(((unsigned long long)(unsigned)__shfl((int)(sp >> 32), srcl) << 32) | (unsigned)__shfl((int)(unsigned)sp, srcl));
-                  hs.slots = reinterpret_cast<const unsigned char *>(((unsigned long long)(unsigned)__shfl((int)(lp >> 32), srcl) << 32) | (unsigned)__shfl((int)(unsigned)lp, srcl));
-                  hs.total = ((long long)__shfl((int)(src.total >> 32), srcl) << 32) | (unsigned)__shfl((int)(unsigned)src.total, srcl);
-                  hs.W = __shfl(src.W, srcl); }
-               const bool valid = piece < n;
-               RawRec r; r.pos = 0; r.w0 = kCrBad; r.w1 = 0;
-               if (valid) r = raw_at(hs, at_s + piece, nullptr);
-               long long fn = raw_first(r);
-               {  const int flo = __shfl((int)(unsigned)fn, (lane + 1) & 63), fhi = __shfl((int)(fn >> 32), (lane + 1) & 63);      // (lane + 1: piece + 1 of the same chunk)
-                  fn = ((long long)fhi << 32) | (unsigned)flo; }
-               if (valid && (piece == 7 || piece + 1 >= n)) fn = at_s + piece + 1 < hs.total ? raw_first(raw_at(hs, at_s + piece + 1, nullptr)) : kNoSuccRow;
-               dst[k] = valid ? crec_make(r, fn, hs.W, hs.mv) : make_uint4(0, kCrBad, 0, 0); } };
+               const int src = 8 * k + sub;
+               const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, src), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), src);
+               const int n = __shfl(left, src);
+               dst[k] = make_uint4(0, kCrBad, 0, 0);
+               if (piece < n) dst[k] = reinterpret_cast<const uint4 *>(((unsigned long long)hi << 32) | lo)[piece]; } };
          #pragma unroll
          for (int dd = 0; dd < kGsDepth; ++dd) fetch(q[dd], i + dd * kGsRegs);
          bool more = __ballot(run) != 0ull;
@@ -924,7 +911,7 @@ __device__ __forceinline__ rtfe_event emit_event(const DevCfg &cfg, const DevPar
 // the events of the steady stretches: a wave per standing segment, a lane per record - its gain says whether it fired, a prefix sum where
 // its event goes.  Records, entry references and gains are read in stream order.
 __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, const BurstCtl *__restrict__ ctl, rtfe_event *__restrict__ events,
-                                                  const uint32_t *__restrict__ sidx, const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ ctot, long long ccap, const unsigned char *__restrict__ pool,
+                                                  const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap, const unsigned char *__restrict__ pool,
                                                   const GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, long long seg_cap, const float *__restrict__ gfire, int nchains_max,
                                                   const int16_t *__restrict__ rows, long long nrows) {
    const DevCfg &cfg = *cfgp;
@@ -944,7 +931,7 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
       MarSrc msrc; msrc.rows = rows; msrc.nrows = nrows; msrc.ntrks = ntrks; msrc.head = cfg.trk_to_head[trk]; msrc.sg = cfg.invert ? -1 : 1; msrc.W = W; msrc.nmar = cfg.pk_mar;
       const long long reset = ctl[b].reset;
       rtfe_event *ev = events + cs.k.ev_index;
-      const RecSrc src = recsrc_make(cfg, sidx, pool, ovf, ccap, ctot, cs.k.sl, W);
+      const size_t sb = (size_t)cs.k.sl * ccap;
       Walker wk = {};
       wk.v_avg_height = cs.k.h;
       const int n_own = (int)(sg.stop - sg.first);
@@ -955,15 +942,15 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
          const int fired = gain != 0.0f ? 1 : 0;
          const int incl = wave_incl_scan(fired, lane);
          if (fired) {
-            const unsigned char *me = nullptr;
-            const CRec r = rec_at(src, sg.first + k, &me, false);
-            ev[at + (unsigned)(incl - 1)] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(me), msrc, gain, W, d, reset, trk, pidx, mv); }
+            const size_t ri = sb + (size_t)(sg.first + k);
+            const CRec r = crec[ri];
+            ev[at + (unsigned)(incl - 1)] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[ri], msrc, gain, W, d, reset, trk, pidx, mv); }
          at += (unsigned)wave_last(incl); } } }
 
 // k_emit: the events k_gain's fast path only noted (the chains' heads and tails).  One workgroup per chain at a time, a lane per event.
 __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch,
                                               const BurstCtl *__restrict__ ctl, const uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
-                                              const float *__restrict__ chain_h, const uint32_t *__restrict__ sidx, const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ ctot, long long ccap,
+                                              const float *__restrict__ chain_h, const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap,
                                               const unsigned char *__restrict__ pool, const ChainSt *__restrict__ cst, const int16_t *__restrict__ rows, long long nrows) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
@@ -980,7 +967,7 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
       const long long reset = ctl[b].reset;
       const unsigned int nev = counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk];
       rtfe_event *ev = events + B.event_base + (size_t)(pidx * ntrks + trk) * B.event_cap;
-      const RecSrc src = recsrc_make(cfg, sidx, pool, ovf, ccap, ctot, P.screen * ntrks + head, W);
+      const size_t sbase = (size_t)(P.screen * ntrks + head) * ccap;
       const unsigned int skip0 = cst[ci].seg_ev0, skip1 = cst[ci].seg_ev1;      // (k_emit_seg's events)
       Walker wk = {};
       wk.v_avg_height = chain_h[(size_t)b * nwalk + wi];
@@ -992,9 +979,8 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
          if (in.w[3] != 0xffffffffu) continue;                            // the general step wrote it out in full
          const float gain = __uint_as_float(in.w[1]);
          wk.v_avg_height = __uint_as_float(in.w[2]);
-         const unsigned char *me = nullptr;
-         const CRec r = rec_at(src, (long long)in.w[0], &me, false);
-         ev[i] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(me), msrc, gain, W, d, reset, trk, pidx, mv); } } }
+         const CRec r = crec[sbase + in.w[0]];
+         ev[i] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[sbase + in.w[0]], msrc, gain, W, d, reset, trk, pidx, mv); } } }
 
 // ------------------------------------------------------------------------------------------------
 // k_publish: burst table entries of the bursts the chains finished; stop rows for the ones the sample path redoes

@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
    const int HL = cfgp->pk_hl, HR = cfgp->pk_hr;
    const int row_bytes = ntrks * 2;
-   const int hcap = cfgp->pk_slot, gcap = cfgp->pk_gslot, wave_cap = cfgp->pk_wave_cap;
+   const int hcap = cfgp->pk_slot, wave_cap = cfgp->pk_wave_cap;
    const int cut = cfgp->cut;
    const bool inv = cfgp->invert != 0;
    const SfLds L = sf_lds_layout(ntrks, HL, HR, wave_cap, hcap);
@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
          // their lists, and records and margin entries go to the lists' staging slots in LDS.  More than pk_wave_cap candidates (noise
          // above the screen), or a list that outgrows its slot: the list is marked unavailable and the bursts that need it take the sample path.
          // A candidate that needs the general walk leaves a placeholder that k_sift_hard resolves. ----
-         int rec_lo = 0, rec_hi = 0, def_lo = 0, def_hi = 0;                   // records in this wave's two lists; deferred candidates among them
+         int rec_lo = 0, rec_hi = 0;                                           // records in this wave's two lists
          bool bad = false;
          if (cut != 2) {                                                   // (RTFE_CUT=2: stop behind the dense pre-filter)
             uint32_t mlo = (tm | bm) & 0xffffu, mhi = (tm | bm) >> 16;
@@ -622,9 +622,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                         w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
                      else { w0 = pk_w0(cpos, false, cpos + 1, 0, cx.W - 2, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
                      st = 1; }
-                  {  const u64 db = __ballot(w1 == 0xffff8001u);
-                     if (db) { const u64 hb = __ballot(half != 0); def_lo += __popcll(db & ~hb); def_hi += __popcll(db & hb); }
-                     if (prof) { pn_hard += (unsigned)__popcll(db); ++pn_rounds; } }
+                  if (prof) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
                   if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
                   const int vr = st;
                   const int sh = 16 * half;
@@ -649,14 +647,14 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                const int h = h_lo + hh;
                const int nr = hh ? rec_hi : rec_lo;
                const bool over = bad || 16 * nr > hcap;
-               unsigned char *gslot = pool + ((size_t)(tile * nscreens + sc) * ntrks + h) * (size_t)gcap;
+               unsigned char *gslot = pool + ((size_t)(tile * nscreens + sc) * ntrks + h) * (size_t)hcap;
                if (!over && nr > 0 && cut != 6) {
                   const int fv = (8 * nr + 15) >> 4, bv = (8 * nr + 15) >> 4;        // vectors in use at the front / at the back
                   const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
-                  for (int v = lane; v < fv + bv; v += 64) { const int back = v - fv; reinterpret_cast<int4 *>(gslot)[v < fv ? v : (gcap >> 4) - 1 - back] = src[v < fv ? v : vps - 1 - back]; }
+                  for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
                   if (prof) pn_bytes += (unsigned)(16 * nr); }
                if (lane == 0) {
-                  PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.ndef = over ? (uint16_t)0 : (uint16_t)(hh ? def_hi : def_lo);
+                  PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
                   dir[(size_t)(tile * nscreens + sc) * ntrks + h] = d; } } }
          rtfe_wave_sync(); }
       __syncthreads(); }
@@ -673,7 +671,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
 struct SfArgs {
    const int16_t *rows; long long nrows; int ntiles;
    uint16_t *qtile; PeakDir *dir; unsigned char *pool; SfHard *hard; int hard_cap; int *hard_count; unsigned long long *dbg;
-   int hcap, gcap, wave_cap, invert, quiet_i, lo_i, hi_i, minpk_i, cut, debug;
+   int hcap, wave_cap, invert, quiet_i, lo_i, hi_i, minpk_i, cut, debug;
    int defer;      // 1: a tile's lists leave LDS at the start of the NEXT tile step (the stores' acknowledgements are then old when the step's first s_waitcnt vmcnt(0) - the prefetched rows - asks)
 };
 
@@ -695,7 +693,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
 #else
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-   const int hcap = a.hcap, gcap = a.gcap, wave_cap = a.wave_cap, cut = a.cut;
+   const int hcap = a.hcap, wave_cap = a.wave_cap, cut = a.cut;
    const SfLds L = sf_lds_layout(NT, HL, HR, wave_cap, hcap);
    unsigned char *xs = smem + L.xs;
    const lds_p xsl = to_lds(xs);
@@ -732,9 +730,9 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
    // a wave's two lists leave LDS: records from the front of each head's slot, margin entries from its back, 16 bytes per lane; the
    // directory.  Deferred (a.defer) to the start of the next tile step: the step's first instruction is s_waitcnt vmcnt(0) for the
    // prefetched rows, and gfx9 counts stores in vmcnt too - stores issued just in front of it are waited for in full.
-   int p_tile = -1, p_rec_lo = 0, p_rec_hi = 0, p_def = 0;
+   int p_tile = -1, p_rec_lo = 0, p_rec_hi = 0;
    bool p_bad = false;
-   auto copy_out = [&](const int tile, const int rec_lo, const int rec_hi, const int def, const bool bad) {      // def: deferred candidates, lo | hi << 16
+   auto copy_out = [&](const int tile, const int rec_lo, const int rec_hi, const bool bad) {
       const int vps = hcap >> 4;                                         // 16-byte vectors per slot
       #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -742,14 +740,14 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
          const int h = h_lo + hh;
          const int nr = hh ? rec_hi : rec_lo;
          const bool over = bad || 16 * nr > hcap;
-         unsigned char *gslot = a.pool + ((size_t)tile * NT + h) * (size_t)gcap;
+         unsigned char *gslot = a.pool + ((size_t)tile * NT + h) * (size_t)hcap;
          if (!over && nr > 0 && cut != 6) {
             const int fv = (8 * nr + 15) >> 4, bv = fv;                        // vectors in use at the front (records) / at the back (margin blocks)
             const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
-            for (int v = lane; v < fv + bv; v += 64) { const int back = v - fv; reinterpret_cast<int4 *>(gslot)[v < fv ? v : (gcap >> 4) - 1 - back] = src[v < fv ? v : vps - 1 - back]; }
+            for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
             if (a.debug == 3) pn_bytes += (unsigned)(16 * nr); }
          if (lane == 0) {
-            PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.ndef = over ? (uint16_t)0 : (uint16_t)(hh ? def >> 16 : def & 0xffff);
+            PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
             a.dir[(size_t)tile * NT + h] = d; } } };
    for (int tile = tile_lo; tile < ntiles; tile += G, par ^= 1) {
       last_tile = tile;
@@ -763,7 +761,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
       __syncthreads();
       if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G);
       if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
-      if (p_tile >= 0) { copy_out(p_tile, p_rec_lo, p_rec_hi, p_def, p_bad); p_tile = -1; rtfe_wave_sync(); }      // (the lists of the tile in front: a.defer)
+      if (p_tile >= 0) { copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad); p_tile = -1; rtfe_wave_sync(); }      // (the lists of the tile in front: a.defer)
       // ---- 2. quiet groups: flat 16-byte reads of the tile proper; a ballot of 64 vectors lies in one or two groups ----
       #pragma unroll
       for (int it = 0; it < NQIT; ++it) {
@@ -805,7 +803,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                const uint32_t mk = keep >= kSfStrip ? 0x3fffu : (keep <= 0 ? 0u : ((1u << keep) - 1u));
                tm &= mk | (mk << 16); bm &= mk | (mk << 16); } }
          // ---- 4. the wave's candidates, compacted into a list ordered by (head, row); rounds of 64 ----
-         int rec_lo = 0, rec_hi = 0, def = 0;                                  // records in this wave's two lists; deferred candidates among them (lo | hi << 16)
+         int rec_lo = 0, rec_hi = 0;                                           // records in this wave's two lists
          bool bad = false;
          if (cut != 2) {
             uint32_t mlo = (tm | bm) & 0xffffu, mhi = (tm | bm) >> 16;
@@ -839,9 +837,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                         w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
                      else { w0 = pk_w0(cpos, false, cpos + 1, 0, cx.W - 2, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
                      st = 1; }
-                  {  const u64 db = __ballot(w1 == 0xffff8001u);
-                     if (db) { const u64 hb = __ballot(half != 0); def += __popcll(db & ~hb) + (__popcll(db & hb) << 16); }
-                     if (a.debug == 3) { pn_hard += (unsigned)__popcll(db); ++pn_rounds; } }
+                  if (a.debug == 3) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
                   if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
                   const int vr = st;
                   const int sh = 16 * half;
@@ -859,11 +855,11 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                   rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; } } }
          // ---- 5. this wave's two lists leave (now, or - a.defer - at the start of the next tile step) ----
          rtfe_wave_sync();
-         if (a.defer) { p_tile = tile; p_rec_lo = rec_lo; p_rec_hi = rec_hi; p_def = def; p_bad = bad; }
-         else copy_out(tile, rec_lo, rec_hi, def, bad);
+         if (a.defer) { p_tile = tile; p_rec_lo = rec_lo; p_rec_hi = rec_hi; p_bad = bad; }
+         else copy_out(tile, rec_lo, rec_hi, bad);
          rtfe_wave_sync(); }
       __syncthreads(); }
-   if (p_tile >= 0) copy_out(p_tile, p_rec_lo, p_rec_hi, p_def, p_bad);
+   if (p_tile >= 0) copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad);
    if (tid == 0 && last_tile >= 0) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);
    if (a.debug == 3 && lane == 0) {
       atomicAdd(&a.dbg[3], (unsigned long long)pn_bytes); atomicAdd(&a.dbg[4], (unsigned long long)pn_hard); atomicAdd(&a.dbg[5], (unsigned long long)pn_rounds);
@@ -924,7 +920,7 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       int nrec = sk.n;
       if (nrec > 4) nrec = -1;
       if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, cx.W - 2, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs than a slot holds: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
-      reinterpret_cast<int *>(slot)[0] = nrec; reinterpret_cast<int *>(slot)[1] = (int)hd.tile;
+      *reinterpret_cast<int *>(slot) = nrec;
       if (nrec != 1) atomicAdd(&extra[((size_t)hd.tile * cfg.nscreens + hd.screen) * cfg.ntrks + hd.head], nrec - 1);      // the list's length in its stream (k_pscan)
       for (int j = 0; j < nrec; ++j) {                                      // (8 + 4 x 8 + 4 x 8 bytes fit the slot)
          reinterpret_cast<uint32_t *>(slot + 8)[2 * j] = sk.w0[j]; reinterpret_cast<uint32_t *>(slot + 8)[2 * j + 1] = sk.w1[j];
