@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
    __shared__ DevCfg cfg;
-   __shared__ int s_any, s_amp[RTFE_MAXTRKS];
+   __shared__ int s_any, s_amp[RTFE_MAXTRKS], s_bmx[kDsJ * RTFE_MAXTRKS], s_bmn[kDsJ * RTFE_MAXTRKS];
    __shared__ unsigned int s_noisy;
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
@@ -142,14 +142,27 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
             const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)x4.x, qpk), pk_addu((uint32_t)x4.y, qpk)), pk_maxu(pk_addu((uint32_t)x4.z, qpk), pk_addu((uint32_t)x4.w, qpk)));
             if ((m & 0xffffu) > q2 || (m >> 16) > q2) noisy |= 1u << fdg.div(v); }
          if (noisy) atomicOr(&s_noisy, noisy); }
-      // ---- the band of every (sub-segment, track): from the amplitude of the rows the sub-segment's lanes can see ----
+      // ---- the band of every (sub-segment, track): from the amplitude of the rows the sub-segment's lanes can see, [j kDsSub - wmax,
+      // pad + (j + 1) kDsSub).  All lanes: the extremes of 8 rows of a track each, into the one or two sub-segments that see them (round 4:
+      // a lane per (sub-segment, track) walked its ~200 rows alone - 72 lanes of 512 busy for a tenth of the tile's time) ----
+      for (int i = threadIdx.x; i < kDsJ * ntrks; i += blockDim.x) { s_bmx[i] = -40000; s_bmn[i] = 40000; }
+      __syncthreads();
+      {  const int nch = (wmax + pad + kDsTile) / 8;                     // (wmax, pad: multiples of 8)
+         for (int i = threadIdx.x; i < nch * ntrks; i += blockDim.x) {
+            const int ch = fdn.div(i), t = i - ch * ntrks;
+            const Col yb = tile_col(tl, t, cfg.skew[t]);
+            const int a = ch * 8 - wmax;
+            int mx = -40000, mn = 40000;
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) { const int v = yb[a + k]; mx = max(mx, v); mn = min(mn, v); }
+            // sub-segment j sees rows [j kDsSub - wmax, pad + (j + 1) kDsSub)
+            int j_hi = (a + wmax) / kDsSub; if (j_hi > kDsJ - 1) j_hi = kDsJ - 1;
+            int j_lo = a + 8 - pad - kDsSub <= 0 ? 0 : (a + 8 - pad - kDsSub + kDsSub - 1) / kDsSub;
+            for (int j = j_lo; j <= j_hi; ++j) { atomicMax(&s_bmx[j * ntrks + t], mx); atomicMin(&s_bmn[j * ntrks + t], mn); } } }
+      __syncthreads();
       for (int i = threadIdx.x; i < kDsJ * ntrks; i += blockDim.x) {
          const int j = fdn.div(i), t = i - j * ntrks;
-         const Col yb = tile_col(tl, t, cfg.skew[t]);
-         int mx = -40000, mn = 40000;
-         #pragma nounroll
-         for (int q = j * kDsSub - wmax; q < pad + (j + 1) * kDsSub; q += 2) { const int v0 = yb[q], v1 = yb[q + 1]; mx = max(mx, max(v0, v1)); mn = min(mn, min(v0, v1)); }
-         const int amp = mx - mn;
+         const int amp = s_bmx[i] - s_bmn[i];
          atomicMax(&s_amp[t], amp);
          const float av = (float)amp / lsb;                             // volts, peak to peak
          // the AGC makes the thresholds follow the signal: (v_avg_height / 4) / agc_gain ~ (recent peak-to-peak height) / 4 <= amplitude / 4
