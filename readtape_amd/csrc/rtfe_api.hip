@@ -486,7 +486,7 @@ static size_t ws_pkeref_off(const rtfe_handle *h, int64_t nrows) { return ws_pkc
 // ... | how many records a list's deferred candidates add to (or take from) its stream (k_sift_hard -> k_pscan)
 static size_t ws_pkextra_off(const rtfe_handle *h, int64_t nrows);
 static size_t pk_extra_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * 4 + 255) & ~(size_t)255) : 0; }
-static size_t pk_eref_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * 4 + 255) & ~(size_t)255) : 0; }
+static size_t pk_eref_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.peak_path ? (((size_t)pk_ccap(h, nrows) * h->dev.nscreens * h->dev.ntrks * 8 + 255) & ~(size_t)255) : 0; }      // (a margin block per record, in stream order)
 
 static size_t ws_pkextra_off(const rtfe_handle *h, int64_t nrows) { return ws_pkeref_off(h, nrows) + pk_eref_bytes(h, nrows); }
 // ... | the chains between k_gain (heads), k_gain_s (steady stretches) and k_gain (tails)
@@ -646,7 +646,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       const int nsc = (int)((ptiles + 1023) / 1024);                    // chunks of 1024 tiles (k_pscan)
       uint32_t *ctotcp = tstartp + (size_t)ptiles * nlists, *coffp = ctotcp + (size_t)nsc * nlists, *ctotp = coffp + (size_t)nsc * nlists;
       CRec *crecp = reinterpret_cast<CRec *>(wsb + ws_pkcrec_off(h, nrows));
-      uint32_t *erefp = reinterpret_cast<uint32_t *>(wsb + ws_pkeref_off(h, nrows));
+      uint2 *erefp = reinterpret_cast<uint2 *>(wsb + ws_pkeref_off(h, nrows));
       int *extrap = reinterpret_cast<int *>(wsb + ws_pkextra_off(h, nrows));
       const long long ccap = pk_ccap(h, nrows);
       hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
@@ -667,7 +667,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       for (int mode = 0; mode < 2; ++mode) {
          if (mode == 1) t0(kTGainTail);
          hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                            scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint32_t *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
+                            scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint2 *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
                             (const unsigned char *)pkpool, ptiles, reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows)), pk_seg_cap(h, nrows), d_rows);
          if (mode == 0) {
             t1(kTGain); t0(kTGainS);
@@ -680,10 +680,10 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t1(kTGainTail);
       if (stop_after < 4) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTEmit);
-      hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, (const uint32_t *)erefp, ccap,
+      hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, (const uint2 *)erefp, ccap,
                          (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks), d_rows, (long long)nrows);
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
-                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint32_t *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp, d_rows, (long long)nrows);
+                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint2 *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp, d_rows, (long long)nrows);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTEmit);
       if (stop_after < 5) { skip_rest(); return launch_check("rtfe_scan"); }

@@ -160,23 +160,23 @@ __device__ __forceinline__ int half_incl_scan(int v, int hl) {
 // list; the first of the next tile's list) begins after this record's owner has left the window.
 __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
                                               const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff,
-                                              const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint32_t *__restrict__ eref) {
+                                              const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint2 *__restrict__ cmar) {
    const DevCfg &cfg = *cfgp;
    const int nlists = cfg.nscreens * cfg.ntrks, hcap = cfg.pk_slot;
    const float mv = cfg.maxvolts;
    const int lane = threadIdx.x & 63, hl = lane & 31, hbase = lane & 32;
    const long long nall = ntiles * nlists;
-   const size_t ovf16 = (size_t)(ovf - pool) / 2;                         // the overflow slots, in the 2-byte units eref counts from the pool's start
    const long long stride = (long long)gridDim.x * 8;                     // lists per sweep: four waves, two lists each
-   struct Pre { PeakDir d, dn; uint2 r, r1, rn; uint32_t ts, co, ct; };
+   struct Pre { PeakDir d, dn; uint2 r, r1, rn, m; uint32_t ts, co, ct; };
    auto fetch = [&](long long l, long long tl, int s2) -> Pre {      // (everything the list's step reads, bar a deferred candidate's records: no load inside the step to wait for)
-      Pre p; p.d.nrec = 0; p.d.nent = 0; p.dn = p.d; p.r = make_uint2(0, 0); p.r1 = p.r; p.rn = p.r; p.ts = 0; p.co = 0; p.ct = 0;
+      Pre p; p.d.nrec = 0; p.d.nent = 0; p.dn = p.d; p.r = make_uint2(0, 0); p.r1 = p.r; p.rn = p.r; p.m = p.r; p.ts = 0; p.co = 0; p.ct = 0;
       if (l < nall) {
          const unsigned char *slot = pool + (size_t)l * hcap;
          p.d = dir[l];
          p.ts = tstart[(size_t)tl * nlists + s2]; p.co = coff[(size_t)(tl >> 10) * nlists + s2]; p.ct = ctot[s2];
          p.r = *reinterpret_cast<const uint2 *>(slot + min(8 * hl, hcap - 8));
          p.r1 = *reinterpret_cast<const uint2 *>(slot + min(8 * (hl + 1), hcap - 8));
+         p.m = *reinterpret_cast<const uint2 *>(slot + max(hcap - 8 * (hl + 1), 0));      // (record hl's margin block)
          if (l + nlists < nall) { p.dn = dir[l + nlists]; p.rn = *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap); } }
       return p; };
    // where a record's successor begins: the first row of the first record at or behind entry k1 of a list (q1 = that entry, already
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
       const bool built = on && (long long)cu.ct <= ccap;                  // a stream that outgrew its capacity is not built: its chains give up (k_gain)
       long long base = built ? (long long)sl * ccap + (long long)cu.ts + (long long)cu.co : 0;
       if (built && d.nrec == 0xffffu) {                                  // a list that did not fit: one marker at the tile's first row
-         if (hl == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; eref[base] = 0; } }
+         if (hl == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; cmar[base] = make_uint2(0, 0); } }
       const int nrec = (built && d.nrec != 0xffffu) ? (int)d.nrec : 0;
       const int W = cfg.screen[(on ? sl : 0) / cfg.ntrks].W;
       const unsigned char *slot = pool + (size_t)(on ? li : 0) * hcap;
@@ -244,12 +244,12 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
                if (j + 1 < cnt) { const uint2 e2 = *reinterpret_cast<const uint2 *>(os + 8 + 8 * (j + 1)); fj = pos0 + (long long)(e2.x & 0x7ffu) + (long long)((e2.x >> 12) & 63u); }
                if (e.y != 0xffff8000u && (unsigned)((int)((e.x >> 22) & 63u) - 1) < 62u && fj != kBadSucc && fj > (long long)c.pos + W) c.w0 |= kCrClear;
                crec[o + j] = c;
-               eref[o + j] = (uint32_t)(ovf16 + ((size_t)w0 * kSfOvfBytes + kSfOvfBytes) / 2 - (size_t)(kPkMar * j)); } }
+               cmar[o + j] = *reinterpret_cast<const uint2 *>(os + kSfOvfBytes - 8 * (j + 1)); } }
          else if (have) {
             CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
             if (w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u && fn != kBadSucc && fn > (long long)c.pos + W) c.w0 |= kCrClear;
             crec[o] = c;
-            eref[o] = (uint32_t)(((size_t)li * hcap + hcap) / 2 - (size_t)(kPkMar * k)); }      // (where its margin block ends: record k's, 8 k bytes in front of the slot's end)
+            cmar[o] = rd == 0 ? cu.m : *reinterpret_cast<const uint2 *>(slot + hcap - 8 * (k + 1)); }      // (its margin block: record k's ends 8 k bytes in front of the slot's end)
          base += __shfl(ic, hbase + 31); } } }
 
 #ifdef RTFE_CPU_EMUL
@@ -353,13 +353,13 @@ struct RecIt {
    uint32_t w0, w1; long long pos;
    const uint16_t *eend;
    bool end, bad; };
-struct RecSrc { const CRec *rec; const uint32_t *eref; const unsigned char *pool; long long iend; };
+struct RecSrc { const CRec *rec; const uint2 *cmar; long long iend; };      // a stream's records, their margin blocks (entry j of record i at ((uint16 *)(cmar + i + 1))[-(j + 1)])
 __device__ __forceinline__ void it_land(RecIt &it, const RecSrc &S) {
    if (it.i >= S.iend) { it.end = true; return; }
    const CRec r = S.rec[it.i];
    it.pos = r.pos; it.w0 = r.w0; it.w1 = r.w1;
    if (r.w0 & kCrBad) { it.end = true; it.bad = true; return; }
-   it.eend = reinterpret_cast<const uint16_t *>(S.pool) + S.eref[it.i]; }
+   it.eend = reinterpret_cast<const uint16_t *>(S.cmar + it.i + 1); }
 __device__ __forceinline__ void it_open(RecIt &it, const RecSrc &S, long long i) {
    it.end = false; it.bad = false; it.i = i; it.eend = nullptr; it.w0 = 0; it.w1 = 0; it.pos = 0;
    it_land(it, S); }
@@ -397,7 +397,7 @@ struct ChainSt { Walker w; float heights[10]; long long i, c, iend; int status, 
 __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
-                                             const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
+                                             const CRec *__restrict__ crec, const uint2 *__restrict__ cmar, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
                                              long long ccap, const unsigned char *__restrict__ pool, long long ntiles, GsSeg *__restrict__ segs, long long seg_cap, const int16_t *__restrict__ rows) {
    __shared__ float s_heights[64 * 10];
    __shared__ uint4 s_notes[kGainChunk][64];                           // the events the fast path notes, until the chunk's end
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       // this chain's piece of its head's stream: from the tile that holds row c - W to the tile behind the limit
       const int sl = P.screen * ntrks + head;
       RecSrc src;
-      src.rec = crec + (size_t)sl * ccap; src.eref = eref + (size_t)sl * ccap; src.pool = pool;
+      src.rec = crec + (size_t)sl * ccap; src.cmar = cmar + (size_t)sl * ccap;
       MarSrc msrc; msrc.rows = rows; msrc.nrows = nrows; msrc.ntrks = ntrks; msrc.head = head; msrc.sg = cfg.invert ? -1 : 1; msrc.W = W; msrc.nmar = cfg.pk_mar;
       long long i;
       {  long long g0 = (c - W) / kSfTile; if (c - W < 0) g0 = 0; if (g0 >= ntiles) g0 = ntiles - 1;
@@ -911,7 +911,7 @@ __device__ __forceinline__ rtfe_event emit_event(const DevCfg &cfg, const DevPar
 // the events of the steady stretches: a wave per standing segment, a lane per record - its gain says whether it fired, a prefix sum where
 // its event goes.  Records, entry references and gains are read in stream order.
 __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, const BurstCtl *__restrict__ ctl, rtfe_event *__restrict__ events,
-                                                  const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap, const unsigned char *__restrict__ pool,
+                                                  const CRec *__restrict__ crec, const uint2 *__restrict__ cmar, long long ccap, const unsigned char *__restrict__ pool,
                                                   const GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, long long seg_cap, const float *__restrict__ gfire, int nchains_max,
                                                   const int16_t *__restrict__ rows, long long nrows) {
    const DevCfg &cfg = *cfgp;
@@ -944,13 +944,13 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
          if (fired) {
             const size_t ri = sb + (size_t)(sg.first + k);
             const CRec r = crec[ri];
-            ev[at + (unsigned)(incl - 1)] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[ri], msrc, gain, W, d, reset, trk, pidx, mv); }
+            ev[at + (unsigned)(incl - 1)] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(cmar + ri + 1), msrc, gain, W, d, reset, trk, pidx, mv); }
          at += (unsigned)wave_last(incl); } } }
 
 // k_emit: the events k_gain's fast path only noted (the chains' heads and tails).  One workgroup per chain at a time, a lane per event.
 __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch,
                                               const BurstCtl *__restrict__ ctl, const uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
-                                              const float *__restrict__ chain_h, const CRec *__restrict__ crec, const uint32_t *__restrict__ eref, long long ccap,
+                                              const float *__restrict__ chain_h, const CRec *__restrict__ crec, const uint2 *__restrict__ cmar, long long ccap,
                                               const unsigned char *__restrict__ pool, const ChainSt *__restrict__ cst, const int16_t *__restrict__ rows, long long nrows) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
@@ -980,7 +980,7 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
          const float gain = __uint_as_float(in.w[1]);
          wk.v_avg_height = __uint_as_float(in.w[2]);
          const CRec r = crec[sbase + in.w[0]];
-         ev[i] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(pool) + eref[sbase + in.w[0]], msrc, gain, W, d, reset, trk, pidx, mv); } } }
+         ev[i] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(cmar + sbase + in.w[0] + 1), msrc, gain, W, d, reset, trk, pidx, mv); } } }
 
 // ------------------------------------------------------------------------------------------------
 // k_publish: burst table entries of the bursts the chains finished; stop rows for the ones the sample path redoes

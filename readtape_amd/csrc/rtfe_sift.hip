@@ -298,8 +298,10 @@ __device__ __forceinline__ int pk_fast(const PkCtx &c, int head, int p, bool bot
    if (bot) {
       // the reference's minimum is this sample from the first forced rescan at or behind aq = q + max(0, W-1-J) on: the common case is
       // a rescan at the very first candidate row
-      const int n0 = pk_ctz(C);
-      if (!pk_async(c, head, p + n0)) return 2;
+      const int n0 = pk_ctz(C), aq = W - 1 - J > 0 ? W - 1 - J : 0;
+      bool ok = pk_async(c, head, p + n0);
+      for (int r = n0 - 1; r >= aq && !ok; --r) ok = pk_async(c, head, p + r);      // (any rescan in [aq, n0] will do: pk_bot's first case)
+      if (!ok) return 2;
       C &= ~((one << n0) - 1); }
    const int val = bot ? -v2 : v2;                                      // (the sample as the detector sees it)
    w1 = pk_w1(val, c.t.sg * lds_i16(pr - rb_), c.t.sg * lds_i16(pr + rb_), !bot);
@@ -355,8 +357,12 @@ __device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool b
    if (klast < 31) C &= klast < 0 ? 0u : ((2u << klast) - 1u);
    if (!C) return 0;
    if (bot) {
-      const int n0 = pk_ctz(C);
-      if (!pk_async(c, head, p + n0)) return 2;
+      // the reference's minimum is this sample from the first forced rescan at or behind aq = p + max(0, W-1-J) on: a rescan at any row of
+      // [aq, n0] will do (pk_bot's first case) - the first candidate row itself nearly always, else the few rows in front of it
+      const int n0 = pk_ctz(C), aq = W - 1 - J > 0 ? W - 1 - J : 0;
+      bool ok = pk_async(c, head, p + n0);
+      for (int r = n0 - 1; r >= aq && !ok; --r) ok = pk_async(c, head, p + r);
+      if (!ok) return 2;
       C &= ~((1u << n0) - 1u); }
    const int raw = lds_i16(pr);
    const int val = c.t.sg < 0 ? -raw : raw;                            // the sample as the detector sees it
