@@ -46,9 +46,21 @@ struct rtfe_handle {
    int overlap;
    int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
    int sift_defer;                     // RTFE_SIFT_DEFER=0: k_sift_s stores a tile's lists at the end of its own step (experiments)
+   int ds_order, dchain_wgs, prep_wgs, dense_stop, dseg_wgs;      // RTFE_DS_ORDER (0: chains in burst order), RTFE_DCHAIN_WGS / RTFE_PREP_WGS / RTFE_DSEG_WGS (workgroups per CU), RTFE_DENSE_STOP (debugging): read once, at create
 };
 
 static thread_local char g_err[512] = "";
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel in the process, not of a handle: a second handle with a smaller LDS
+// layout must not lower what a first one's launches need.  A table of the largest size asked for so far, per kernel.
+static void raise_dynamic_lds(const void *kernel, int bytes) {
+   static struct { const void *k; int b; } seen[64];
+   static int nseen = 0;
+   for (int i = 0; i < nseen; ++i) if (seen[i].k == kernel) {
+      if (bytes <= seen[i].b) return;
+      seen[i].b = bytes; (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); return; }
+   if (nseen < 64) { seen[nseen].k = kernel; seen[nseen].b = bytes; ++nseen; }
+   (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
 static int fail(int code, const char *fmt, ...) {
    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
    return code; }
@@ -98,6 +110,7 @@ extern "C" const char *rtfe_last_error(void) { return g_err; }
 static const char *KNAMES[] = {"k_quiet", "k_sift", "k_prep", "k_bursts", "k_gain", "k_gain_s", "k_gain_tail", "k_emit", "k_decode", "k_zeros", "k_dseg", "k_dchain"};
 enum { kTQuiet, kTSift, kTPrep, kTBursts, kTGain, kTGainS, kTGainTail, kTEmit, kTDecode, kTZeros, kTDseg, kTDchain };
 constexpr int kNumKernels = 12;
+static_assert(kNumKernels <= 12, "rtfe_handle::ev0 / ev1 hold 12 events a set");
 extern "C" int rtfe_kernel_count(void) { return kNumKernels; }
 extern "C" const char *rtfe_kernel_name(int i) { return (i >= 0 && i < kNumKernels) ? KNAMES[i] : ""; }
 
@@ -370,17 +383,22 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    h->num_cus = prop.multiProcessorCount;
    if (hipMalloc(&h->d_dev, sizeof(DevCfg)) != hipSuccess) { delete h; return fail(-21, "hipMalloc failed"); }
    if (hipMemcpy(h->d_dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->d_dev); delete h; return fail(-22, "hipMemcpy failed"); }
-   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+   raise_dynamic_lds(reinterpret_cast<const void *>(k_decode), h->lds_bytes);
    h->zeros_kernel = getenv("RTFE_ZEROS_KERNEL") ? atoi(getenv("RTFE_ZEROS_KERNEL")) != 0 : 1;
    h->side = nullptr; h->overlap = getenv("RTFE_OVERLAP") ? atoi(getenv("RTFE_OVERLAP")) != 0 : 1;
    h->bursts_wpr = getenv("RTFE_BURSTS_WPR") ? atoi(getenv("RTFE_BURSTS_WPR")) : 0;
    h->sift_defer = getenv("RTFE_SIFT_DEFER") ? atoi(getenv("RTFE_SIFT_DEFER")) != 0 : 1;
+   h->ds_order = getenv("RTFE_DS_ORDER") ? atoi(getenv("RTFE_DS_ORDER")) : 1;
+   h->dchain_wgs = getenv("RTFE_DCHAIN_WGS") ? atoi(getenv("RTFE_DCHAIN_WGS")) : 16;
+   h->prep_wgs = getenv("RTFE_PREP_WGS") ? atoi(getenv("RTFE_PREP_WGS")) : 16;
+   h->dense_stop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;
+   h->dseg_wgs = getenv("RTFE_DSEG_WGS") ? atoi(getenv("RTFE_DSEG_WGS")) : 0;
    // (k_zeros packs two tracks' 16-bit states into a lane and reads the rows where they lie: no -invert, no deskew delays, a threshold inside int16)
    if (d.invert || d.maxskew > 0 || d.ntrks < 2 || d.zc_peak_i < 1 || d.zc_peak_i > 32767 || !d.zc_parallel) h->zeros_kernel = 0;      // (RTFE_ZC_PARALLEL=0: k_decode's sequential walk, for the tests)
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds);
-      if (sf_special(d)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sf_special(d)), hipFuncAttributeMaxDynamicSharedMemorySize, d.pk_lds); }
-   if (d.dense_path) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dseg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, d.ds_up).total + 64);
+      raise_dynamic_lds(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), d.pk_lds);
+      if (sf_special(d)) raise_dynamic_lds(reinterpret_cast<const void *>(sf_special(d)), d.pk_lds); }
+   if (d.dense_path) raise_dynamic_lds(reinterpret_cast<const void *>(k_dseg), (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, d.ds_up).total + 64);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    if (getenv("RTFE_VERBOSE") && d.peak_path) {
       int nb = -1;
@@ -400,11 +418,15 @@ extern "C" int rtfe_set_timing(rtfe_handle *h, int enable) {
    if (enable && !h->timing) {
       h->ev0 = new hipEvent_t[kTimingRing][12]; h->ev1 = new hipEvent_t[kTimingRing][12];
       for (int r = 0; r < kTimingRing; ++r) for (int i = 0; i < kNumKernels; ++i)
-         if (hipEventCreate(&h->ev0[r][i]) != hipSuccess || hipEventCreate(&h->ev1[r][i]) != hipSuccess) {
-            // (no half-made ring left behind - the events made so far are destroyed with it)
+      {
+         const bool ok0 = hipEventCreate(&h->ev0[r][i]) == hipSuccess;
+         const bool ok1 = ok0 && hipEventCreate(&h->ev1[r][i]) == hipSuccess;
+         if (!ok1) {
+            // (no half-made ring left behind - the events made so far are destroyed with it, the lone ev0 of this slot too)
+            if (ok0) (void)hipEventDestroy(h->ev0[r][i]);
             for (int r2 = 0; r2 <= r; ++r2) for (int i2 = 0; i2 < (r2 < r ? kNumKernels : i); ++i2) { (void)hipEventDestroy(h->ev0[r2][i2]); (void)hipEventDestroy(h->ev1[r2][i2]); }
             delete[] h->ev0; delete[] h->ev1; h->ev0 = nullptr; h->ev1 = nullptr;
-            return fail(-40, "hipEventCreate failed"); }
+            return fail(-40, "hipEventCreate failed"); } }
       h->ev_next = 0; h->ev_pending = 0; }
    if (!enable && h->timing) timing_free(h);
    h->timing = enable != 0;
@@ -512,7 +534,7 @@ static long long ds_tiles_for(int64_t nrows) { return (nrows + kDsTile - 1) / kD
 static size_t ws_dsdead_off(const rtfe_handle *h, int64_t nrows) { return (ws_pkgfire_off(h, nrows) + pk_gfire_bytes(h, nrows) + 255) & ~(size_t)255; }
 static size_t ds_dead_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.dense_path ? (((size_t)ds_tiles_for(nrows) * h->dev.nscreens + 255) & ~(size_t)255) : 0; }
 static size_t ws_dsband_off(const rtfe_handle *h, int64_t nrows) { return ws_dsdead_off(h, nrows) + ds_dead_bytes(h, nrows); }
-static size_t ds_band_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.dense_path ? (((size_t)ds_tiles_for(nrows) * kDsJ * h->dev.ntrks * sizeof(float2) + 255) & ~(size_t)255) : 0; }
+static size_t ds_band_bytes(const rtfe_handle *h, int64_t nrows) { (void)h; (void)nrows; return 0; }      // (the bands travel in the slots' headers: the region of their own is gone - ADVICE r4)
 static size_t ws_dsslot_off(const rtfe_handle *h, int64_t nrows) { return ws_dsband_off(h, nrows) + ds_band_bytes(h, nrows); }
 static size_t ds_slot_bytes(const rtfe_handle *h, int64_t nrows) { return h->dev.dense_path ? (((size_t)ds_tiles_for(nrows) * kDsJ * h->dev.nuset * h->dev.ntrks * (size_t)h->dev.ds_slot + 511) & ~(size_t)255) : 0; }      // (+ a slot's worth: k_dchain reads nine 16-byte units of the last slot)
 
@@ -653,7 +675,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
                          (const int *)&scratch->hard_count, ovfp, extrap);
       hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (const int *)extrap, (int)ptiles, nlists, tstartp, ctotcp);
       hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
-      hipLaunchKernelGGL(k_prep, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
+      // (workgroups per CU: 4 / 8 / 16 measured 0.51 / 0.47 / 0.42 ms for the span on C2 - half a wave per list, the more lists in flight the better)
+      hipLaunchKernelGGL(k_prep, dim3(h->num_cus * (h->prep_wgs >= 1 && h->prep_wgs <= 64 ? h->prep_wgs : 16)), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
                          (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, crecp, erefp);
 #ifdef RTFE_CPU_EMUL
       if (getenv("RTFE_PREP_CHECK")) hipLaunchKernelGGL(k_prep_check, dim3(1), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, (const CRec *)crecp);
@@ -705,7 +728,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       const int dlds = (int)ds_lds_layout(h->dev.ntrks, h->dev.halo_rows, h->dev.ds_pad + kDsTile + kDsRight, h->dev.ds_up).total + 64;
       int dpc = (160 * 1024) / (dlds + 1024);
       if (dpc > 8) dpc = 8;
-      if (const char *e = getenv("RTFE_DSEG_WGS")) { const int v = atoi(e); if (v >= 1 && v < dpc) dpc = v; }
+      if (h->dseg_wgs >= 1 && h->dseg_wgs < dpc) dpc = h->dseg_wgs;
       if (dpc < 1) dpc = 1;
       long long dg = (long long)h->num_cus * dpc;
       if (dg > dtiles) dg = dtiles;
@@ -731,19 +754,19 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       else hipLaunchKernelGGL(k_zeros<0>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);
       t1(kTZeros); }
    else if (h->dev.dense_path) {                                      // PE, GCR peak detection: sub-segment lists, then a lane per chain (rtfe_dense.hip)
-      const int dstop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;      // (debugging: 1 = stop behind k_dseg, 2 = behind k_dchain)
+      const int dstop = h->dense_stop;      // (debugging: 1 = stop behind k_dseg, 2 = behind k_dchain)
       if (dstop < 2) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTDchain);
-      static const int ds_order = getenv("RTFE_DS_ORDER") ? atoi(getenv("RTFE_DS_ORDER")) : 1;      // (0: the chains in burst order)
+      const int ds_order = h->ds_order;      // (0: the chains in burst order)
       if (ds_order) hipLaunchKernelGGL(k_dorder, dim3(1), dim3(1024), 0, st, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch, ctlp, (long long)nrows);
       // (LDS per wave decides how many chains run side by side - the kernel holds ~240 VGPRs, eight waves per CU: the literal rows' cache is a chunk and the
       //  widest window + 2, not the 88 rows the widest window the library accepts would need)
       int wmax = 1;
       for (int i = 0; i < h->dev.nparm; ++i) if (h->dev.parm[i].W > wmax) wmax = h->dev.parm[i].W;
       const int dcache = wmax + 2 + kDcChunk < kDcCache ? ((wmax + 2 + kDcChunk + 7) & ~7) : kDcCache;
-      static const int dc_wgs = getenv("RTFE_DCHAIN_WGS") ? atoi(getenv("RTFE_DCHAIN_WGS")) : 16;      // (waves per CU that take chains from the queue)
+      const int dc_wgs = h->dchain_wgs;      // (waves per CU that take chains from the queue)
       hipLaunchKernelGGL(k_dchain, dim3(h->num_cus * (dc_wgs >= 1 && dc_wgs <= 64 ? dc_wgs : 16)), dim3(64), (size_t)(h->dev.ds_slot < 144 ? 144 : h->dev.ds_slot) * 64 + (size_t)dcache * 64 * 2, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
-                         scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const float2 *)nullptr, (const unsigned char *)slotp, dtiles, ds_order);
+                         scratch, ctlp, d_counts, d_events, (const unsigned char *)deadp, (const unsigned char *)slotp, dtiles, ds_order);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTDchain);
       if (dstop < 3) { skip_rest(); return launch_check("rtfe_scan"); }

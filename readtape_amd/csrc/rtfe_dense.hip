@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(1024) k_dorder(const rtfe_burst *__restrict__ 
 __global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long row_base,
                                                const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                                uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
-                                               const unsigned char *__restrict__ dead, const float2 *__restrict__ band, const unsigned char *__restrict__ slots, long long ntiles, int ordered) {
+                                               const unsigned char *__restrict__ dead, const unsigned char *__restrict__ slots, long long ntiles, int ordered) {
    __shared__ float s_heights[64 * 10];
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;

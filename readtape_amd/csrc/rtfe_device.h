@@ -79,7 +79,7 @@ struct DevCfg {
    int   uset_rep[RTFE_MAXPARMSETS];         // distinct set -> its first parameter set
    unsigned uset_mask[RTFE_MAXPARMSETS];     // distinct set -> the parameter sets it stands for (their event regions all receive its events)
    int   ds_pad;                             // rows in front of a k_dseg tile's own rows that only serve as warm-up (multiple of 64)
-   int   ds_warm[kMaxScreens];               // rows a sub-segment's lane starts early, per window width (>= 3 W)
+   int   ds_warm[kMaxScreens];               // rows a sub-segment's lane starts early, per window width (2 W + 16, at least 48)
    int   ds_up;                              // distinct sets of one width k_dseg classifies in one pass over a tile (2 or 3)
    int   ds_cap, ds_slot;                    // records per slot; bytes of a slot (header + records)
    float ds_band_hi, ds_band_lo;             // a sub-segment's band: [ds_band_lo, 1] x ds_band_hi x (its peak-to-peak amplitude / 4)

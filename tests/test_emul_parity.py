@@ -236,7 +236,7 @@ def test_emulated_dense_path_equals_the_sample_path(name, monkeypatch):
 
 
 @pytest.mark.parametrize("kind,knobs", [("gcr", {}), ("pe", {}), ("gcr", {"RTFE_DS_WARM": "8"}), ("gcr", {"RTFE_DS_CAP": "3"}), ("pe", {"RTFE_DS_BAND_LO": "0.9"}),
-                                        ("gcr", {"RTFE_DS_BAND_HI": "0.6"}), ("pe", {"RTFE_DS_QUIET_S": "0.0"}), ("gcr", {"RTFE_DENSE_DEDUP": "0"}), ("nrzi", {}), ("gcr", {"RTFE_DS_LEAN": "0"}), ("gcr", {"RTFE_DS_UP": "1"}), ("pe", {"RTFE_DS_UP": "3"}), ("pe", {"RTFE_DS_UP": "2"})])
+                                        ("gcr", {"RTFE_DS_BAND_HI": "0.6"}), ("pe", {"RTFE_DS_QUIET_S": "0.0"}), ("gcr", {"RTFE_DENSE_DEDUP": "0"}), ("nrzi", {}), ("gcr", {"RTFE_DS_LEAN": "0"}), ("gcr", {"RTFE_DS_UP": "1"}), ("pe", {"RTFE_DS_UP": "3"}), ("pe", {"RTFE_DS_UP": "2"}), ("gcr", {"RTFE_DS_ORDER": "0"})])
 def test_emulated_dense_sweep_equals_the_sample_path(kind, knobs, monkeypatch):
     """The shape bench.py's C4 runs - an eight-set sweep with four window widths, sets that the front end cannot tell apart - on noisy
     tapes with blocks long enough for chains to cross many sub-segments; knobs force what clean tapes rarely do: joins that fail (a
