@@ -58,18 +58,25 @@ CONFIGS = {
                workload="P1 (extra): synthetic 9-track 1600 BPI PE, 1.5625 MHz, 1 parmset, peak detection (not -zeros), one scan"),
     "M8": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, ref_opts=[], port_opts=["-m"],
                workload="M8 (extra): C2's tape under the reference's default -m: the 8 built-in NRZI parameter sets (three window widths) in one scan"),
+    # the same tapes with noise (every other line is 10 mV rms): what the speculation costs when the signal is not clean -
+    # flagged bursts, bursts redone on the samples and what the chains left to the literal detector are on the line
+    "N1": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=60.0,
+               workload="N1 (extra): C2's tape with 60 mV rms of noise on 2-3 V peaks (C2: 10 mV), 1 parmset"),
+    "N2": dict(kind="gcr", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=30.0,
+               workload="N2 (extra): G1's tape with 30 mV rms of noise on 1.8 V peaks (G1: 10 mV), 1 parmset, one scan"),
     "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True,
                workload="C5: ONE 10 GB synthetic 9-track 800 BPI NRZI tape, time-sharded over the ranks (strong scaling)"),
 }
 
 
-def make_base_tape(seed, target_rows, kind="nrzi"):
+def make_base_tape(seed, target_rows, kind="nrzi", noise_mv=None):
     """Unique synthetic tape of about target_rows rows: 512..4096-byte blocks, >= 6 ms gaps (NRZI: a tapemark every 16 blocks)
     (SURVEY.md 8d)."""
     from readtape_amd import synth
-    make = {"nrzi": lambda n: synth.nrzi_tape(seed=seed, nblocks=n, minlen=512, maxlen=4096, marks_every=16, gap_samples=6000),
-            "pe": lambda n: synth.pe_tape(seed=seed, nblocks=n, minlen=512, maxlen=4096, gap_samples=8000),
-            "gcr": lambda n: synth.gcr_tape(seed=seed, nblocks=n, minlen=512, maxlen=4096, gap_samples=30000)}[kind]
+    kw = {} if noise_mv is None else {"noise_mv": float(noise_mv)}
+    make = {"nrzi": lambda n: synth.nrzi_tape(seed=seed, nblocks=n, minlen=512, maxlen=4096, marks_every=16, gap_samples=6000, **kw),
+            "pe": lambda n: synth.pe_tape(seed=seed, nblocks=n, minlen=512, maxlen=4096, gap_samples=8000, **kw),
+            "gcr": lambda n: synth.gcr_tape(seed=seed, nblocks=n, minlen=512, maxlen=4096, gap_samples=30000, **kw)}[kind]
     probe = make(4)
     nblocks = max(4, int(target_rows / (probe.rows.shape[0] / 4)))
     return make(nblocks)
@@ -161,7 +168,7 @@ class Workload:
         self.strong = bool(conf.get("strong"))
         # weak (C2..C4): every rank holds its own tape of `rows` rows (its own seed) - N tapes of a collection decoded side by side is
         # what the shards of a longer tape look like; strong (C5): ONE tape (same seed everywhere), rank r holds plan_shards()[r].
-        self.tape = tape or make_base_tape(seed=1000 + (0 if self.strong else rank), target_rows=int(base_rows), kind=conf["kind"])
+        self.tape = tape or make_base_tape(seed=1000 + (0 if self.strong else rank), target_rows=int(base_rows), kind=conf["kind"], noise_mv=conf.get("noise_mv"))
         hdr = self.tape.spec.header()
         base = torch.from_numpy(self.tape.rows).to(dev)
         self.copies = max(1, int(round(total_rows / base.shape[0])))
@@ -308,14 +315,17 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
     achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
     step_s = dt / done
     whole = alg_bytes / step_s / 1e9 if step_s > 0 else 0.0      # (this GPU's algorithmic bytes over the step's wall time)
-    traffic = None
-    try:                                         # HBM bytes per launch from the committed rocprofv3 --pmc passes
+    traffic = traffic_all = traffic_src = None
+    try:                                         # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/gpu_traffic.sh: the counters cannot be read from inside this process)
         own = os.path.join(ROOT, "profiles", f"pmc_{name}.json")
         pm = json.load(open(own if os.path.exists(own) else os.path.join(ROOT, "profiles", "pmc_latest.json")))
         if name == pm.get("config", "C2") and dom in pm and abs(pm["workload_rows"] - nrows) < 0.01 * nrows:      # (tools/gpu_traffic.sh wrote it)
             traffic = (pm[dom]["fetch_bytes"] + pm[dom]["write_bytes"]) * len(frags)      # (per scan in the file; a step = len(frags) scans)
+            traffic_all = sum(v["fetch_bytes"] + v["write_bytes"] for v in pm.get("kernels", {}).values()) * len(frags) or None      # every kernel of the step
+            traffic_src = f"profiles/{os.path.basename(own)} (round {pm.get('round')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line, not this run"
     except Exception:
         pass
+    own_rows_bytes = 2 * cfg.ntrks * nrows                    # what the dominant kernel streams if it writes no events itself (k_dseg: the chains' kernel writes them)
     fields = {
         "value": round(rows_all * done / dt / 1e6, 1), "ms_per_step": round(step_s * 1e3, 4), "timed_steps": done, "timed_seconds": round(dt, 3),
         "config": {"workload": conf["workload"], "rows_per_gpu": nrows, "rows_total": rows_all,
@@ -324,7 +334,8 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
                    "sharding": ("one tape, time shards (plan_shards), neighbour halo only" if strong else "time shards, neighbour halo only") if world > 1 else "none"},
         "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": alg_bytes,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_all_kernels": traffic_all, "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
+                     "frac_rows_only": round(own_rows_bytes / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms[dom] > 0 else None,
                      "whole_step": {"achieved": round(whole, 1), "frac": round(whole / HBM_PEAK_GBS, 4),
                                     "what": "the same algorithmic bytes over the step's wall time (all kernels of a scan, launch gaps included)"}},
     }
@@ -343,7 +354,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact C3 / C4 / C5 lines the default single-GPU run adds to its line")
-    ap.add_argument("--min-seconds", type=float, default=0.5, help="the timed region repeats its --steps steps until it is at least this long")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="the timed region repeats its --steps steps until it is at least this long")
     ap.add_argument("--pipeline", action="store_true", help="alternate two front-end contexts on two HIP streams (steps overlap; per-kernel times then include contention)")
     args = ap.parse_args()
     default_line = args.config is None and int(os.environ.get("WORLD_SIZE", "1")) == 1
@@ -379,13 +390,15 @@ def main():
     # ---- the other BASELINE.json configurations, measured in this process (compact: value, ms per step, dominant kernel, fractions) ----
     if default_line and not args.no_other_configs:
         others = {}
-        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("M8", 5, 2)):
+        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("M8", 5, 2), ("N1", 10, 2), ("N2", 2, 1)):
             try:
                 f2, w2 = measure(name, args, rank, world, dev, dist, st, wu, args.min_seconds)
                 others[name] = {"workload": f2["config"]["workload"], "value": f2["value"], "unit": "Msamples/s", "ms_per_step": f2["ms_per_step"], "timed_steps": f2["timed_steps"],
                                 "rows": f2["config"]["rows_total"], "events": f2["config"]["events_total"], "parmsets": f2["config"]["parmsets"], "flagged_bursts": f2["config"]["flagged_bursts"],
                                 "launches_per_step": f2["config"]["launches_per_step"], "dominant_kernel": f2["roofline"]["kernel"], "dominant_kernel_ms": f2["kernel_ms"][f2["roofline"]["kernel"]],
-                                "frac": f2["roofline"]["frac"], "whole_step_frac": f2["roofline"]["whole_step"]["frac"], "traffic": f2["roofline"]["traffic"]}
+                                "frac": f2["roofline"]["frac"], "frac_rows_only": f2["roofline"]["frac_rows_only"], "whole_step_frac": f2["roofline"]["whole_step"]["frac"],
+                                "traffic": f2["roofline"]["traffic"], "traffic_all_kernels": f2["roofline"]["traffic_all_kernels"], "kernel_ms": {k: v for k, v in f2["kernel_ms"].items() if v > 0.02},
+                                "last_scan_stats": {k: f2["config"]["last_scan_stats"].get(k) for k in ("bursts", "redone", "parallel", "sequential", "gave_up")} if f2["config"]["last_scan_stats"] else None}
                 for f in set(w2.fes): f.close()
                 del w2.sr, w2
             except Exception as e:                    # the headline number must not depend on the other lines

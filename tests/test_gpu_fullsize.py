@@ -206,6 +206,31 @@ def test_bench_tape_c3_against_the_oracle(tmp_path, gpu):
     assert int(r1.counts.sum()) > 1e6 and not (r1.bursts["flags"] & ~np.uint32(frontend.F_EXACT_START | frontend.F_STATE_AT_END)).any()
 
 
+def test_bench_tape_p1_against_the_oracle(tmp_path, gpu):
+    """The PE tape of bench.py's P1 line (seed 1000 of make_base_tape, PEAK detection - the dense path, not -zeros) against the CPU oracle,
+    attempt by attempt, event for event (P1's shape had only met k_decode)."""
+    tape = bench.make_base_tape(seed=1000, target_rows=5e6, kind="pe")
+    hdr = tape.spec.header()
+    att = oracle_attempts(hdr, tape.rows, [], str(tmp_path))
+    fe = frontend.FrontEnd(config_for(hdr, []))
+    msgs, stats = check_tape(fe, hdr, tape.rows, att)
+    assert not msgs, "\n".join(msgs[:8])
+    assert stats["events"] > 2e6, stats
+
+
+@pytest.mark.parametrize("kind,noise", [("nrzi", 60.0), ("gcr", 30.0)])
+def test_bench_noise_tapes_against_the_oracle(kind, noise, tmp_path, gpu):
+    """The noisy lines of bench.py (N1: C2's tape at 60 mV rms, N2: G1's at 30 mV - other_configs): whatever the speculation costs there,
+    the events are the oracle's."""
+    tape = bench.make_base_tape(seed=1000, target_rows=2e6, kind=kind, noise_mv=noise)
+    hdr = tape.spec.header()
+    att = oracle_attempts(hdr, tape.rows, [], str(tmp_path))
+    fe = frontend.FrontEnd(config_for(hdr, []))
+    msgs, stats = check_tape(fe, hdr, tape.rows, att)
+    assert not msgs, "\n".join(msgs[:8])
+    assert stats["events"] > 1e5, stats
+
+
 def test_bench_tape_c4_all_eight_sets_against_the_oracle(tmp_path, gpu):
     """The GCR tape bench.py --config C4 tiles (seed 1000) with the bench's eight parameter sets: every set's events of the ONE eight-set
     scan equal the single-set front end's, and that one is checked event for event against the oracle run with the set as its only one -
