@@ -62,6 +62,8 @@ CONFIGS = {
     # flagged bursts, bursts redone on the samples and what the chains left to the literal detector are on the line
     "N1": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=60.0,
                workload="N1 (extra): C2's tape with 60 mV rms of noise on 2-3 V peaks (C2: 10 mV), 1 parmset"),
+    "N1c": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=60.0, calibrate_floor=True,
+               workload="N1c (extra): N1 with the candidate screen's floor calibrated on the tape: one scan with the default floor (1 V), then screen_floor_height = half the smallest peak height a chain learned - what a decode of the tape does after its first window"),
     "N2": dict(kind="gcr", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=30.0,
                workload="N2 (extra): G1's tape with 30 mV rms of noise on 1.8 V peaks (G1: 10 mV), 1 parmset, one scan"),
     "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True,
@@ -196,6 +198,8 @@ class Workload:
             extra = [(1.4, 0.20, 0.2, 0.5, 0, 0.0), (1.6, 0.14, 0.0, 0.5, 0, 0.0), (1.5, 0.10, 0.1, 0.5, 0, 0.0), (1.3, 0.25, 0.2, 0.5, 0, 0.0)]
             parmsets = (list(frontend.DEFAULT_PARMSETS[hdr.mode]) + extra)[: conf["nparmsets"]]
         self.cfg = frontend.FrontEndConfig.from_header(hdr, nparmsets=conf["nparmsets"], find_zeros=conf["find_zeros"], parmsets=parmsets)
+        if os.environ.get("RT_BENCH_SCREEN_FLOOR"):                     # (experiments: the candidate screen's assumed lower bound of the learned peak height, volts)
+            self.cfg.screen_floor_height = float(os.environ["RT_BENCH_SCREEN_FLOOR"])
         make = (lambda: frontend.FrontEnd(self.cfg, device=str(dev))) if fe_factory is None else (lambda: fe_factory(self.cfg))
         self.fe = make()
         # fragments of the resident rows (one when the workspace fits)
@@ -263,6 +267,15 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
     wl = Workload(conf, rank, world, dev, dist, float(total_rows or conf["rows"]), args.base_rows, window_rows=args.window_rows, pipeline=args.pipeline)
     cfg, fe, frags, kms, nrows = wl.cfg, wl.fe, wl.frags, wl.kms, wl.nrows
     torch.cuda.synchronize(dev)
+    calibrated = None
+    if conf.get("calibrate_floor") and wl.cuda:      # the first scan of a tape learns the peak heights; the scans behind it screen against half the smallest one
+        st0 = fe.scan_stats(wl.step(0))
+        if st0.get("min_learned_height"):
+            calibrated = min(4.0, 0.5 * st0["min_learned_height"])
+            for f in set(wl.fes): f.close()
+            wl.cfg.screen_floor_height = calibrated
+            wl.fe = frontend.FrontEnd(wl.cfg, device=str(dev)); wl.fes = [wl.fe, wl.fe]; wl.fe.set_timing(True)
+            cfg, fe = wl.cfg, wl.fe
     for i in range(warmup):
         wl.step(i)
     torch.cuda.synchronize(dev)
@@ -330,7 +343,7 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
         "value": round(rows_all * done / dt / 1e6, 1), "ms_per_step": round(step_s * 1e3, 4), "timed_steps": done, "timed_seconds": round(dt, 3),
         "config": {"workload": conf["workload"], "rows_per_gpu": nrows, "rows_total": rows_all,
                    "bytes_per_gpu": nrows * cfg.ntrks * 2, "events_per_gpu": nevents, "events_total": nevents_all, "bursts": tally["bursts"],
-                   "flagged_bursts": bad, "parmsets": conf["nparmsets"], "launches_per_step": len(frags), "last_scan_stats": sst,
+                   "flagged_bursts": bad, "parmsets": conf["nparmsets"], "launches_per_step": len(frags), "last_scan_stats": sst, "screen_floor_height": calibrated,
                    "sharding": ("one tape, time shards (plan_shards), neighbour halo only" if strong else "time shards, neighbour halo only") if world > 1 else "none"},
         "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -390,7 +403,7 @@ def main():
     # ---- the other BASELINE.json configurations, measured in this process (compact: value, ms per step, dominant kernel, fractions) ----
     if default_line and not args.no_other_configs:
         others = {}
-        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("M8", 5, 2), ("N1", 10, 2), ("N2", 2, 1)):
+        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("M8", 5, 2), ("N1", 3, 1), ("N1c", 10, 2), ("N2", 2, 1)):
             try:
                 f2, w2 = measure(name, args, rank, world, dev, dist, st, wu, args.min_seconds)
                 others[name] = {"workload": f2["config"]["workload"], "value": f2["value"], "unit": "Msamples/s", "ms_per_step": f2["ms_per_step"], "timed_steps": f2["timed_steps"],
@@ -398,7 +411,8 @@ def main():
                                 "launches_per_step": f2["config"]["launches_per_step"], "dominant_kernel": f2["roofline"]["kernel"], "dominant_kernel_ms": f2["kernel_ms"][f2["roofline"]["kernel"]],
                                 "frac": f2["roofline"]["frac"], "frac_rows_only": f2["roofline"]["frac_rows_only"], "whole_step_frac": f2["roofline"]["whole_step"]["frac"],
                                 "traffic": f2["roofline"]["traffic"], "traffic_all_kernels": f2["roofline"]["traffic_all_kernels"], "kernel_ms": {k: v for k, v in f2["kernel_ms"].items() if v > 0.02},
-                                "last_scan_stats": {k: f2["config"]["last_scan_stats"].get(k) for k in ("bursts", "redone", "parallel", "sequential", "gave_up")} if f2["config"]["last_scan_stats"] else None}
+                                "last_scan_stats": {k: f2["config"]["last_scan_stats"].get(k) for k in ("bursts", "redone", "parallel", "sequential", "gave_up", "min_learned_height")} if f2["config"]["last_scan_stats"] else None,
+                                "screen_floor_height": f2["config"]["screen_floor_height"]}
                 for f in set(w2.fes): f.close()
                 del w2.sr, w2
             except Exception as e:                    # the headline number must not depend on the other lines

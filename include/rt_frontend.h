@@ -174,7 +174,10 @@ int rtfe_kernel_ms(rtfe_handle *h, float *out);
 /* Statistics of the most recent rtfe_scan that used d_workspace (synchronous, call after the stream has finished):
  * out[0] = bursts decoded, out[1] = of which the record chains handed to the exact sample path, out[2] = bytes of peak
  * records written, out[3] / out[4] = detections the chains decided 64 runs at a time / one at a time.  Diagnostics for bench.py
- * and the tests; no effect on results.  out[5..12] = chains that gave up, by reason; out[13..20] = cycle counters of k_sift / k_gain / k_bursts / k_gain_seg (RTFE_DEBUG=3 / 4 / 5 / 6).  out must hold 24 values. */
+ * and the tests; no effect on results.  out[5..12] = chains that gave up, by reason; out[13..20] = cycle counters of k_sift / k_gain / k_bursts / k_gain_seg (RTFE_DEBUG=3 / 4 / 5 / 6).
+ * out[21] = 0x7fffffff - the IEEE bits of the smallest v_avg_height (src/decode_nrzi.c:224-229) a chain of the scan learned, 0 if none did (peak path):
+ * what a caller may raise rtfe_config::screen_floor_height towards for the next scans of the same tape - a floor above a later chain's learned height is
+ * flagged RTFE_F_SCREEN_UNDERFLOW and costs an exact rescan, never a wrong event.  out must hold 24 values. */
 int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out);
 
 /* Names and launch-order of the kernels of one scan, for profilers (static strings). */

@@ -676,7 +676,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (const int *)extrap, (int)ptiles, nlists, tstartp, ctotcp);
       hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
       // (workgroups per CU: 4 / 8 / 16 measured 0.51 / 0.47 / 0.42 ms for the span on C2 - half a wave per list, the more lists in flight the better)
-      hipLaunchKernelGGL(k_prep, dim3(h->num_cus * (h->prep_wgs >= 1 && h->prep_wgs <= 64 ? h->prep_wgs : 16)), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
+      hipLaunchKernelGGL(k_prep, dim3(h->num_cus * (h->prep_wgs >= 1 && h->prep_wgs <= 4096 ? h->prep_wgs : 16)), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
                          (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, crecp, erefp);
 #ifdef RTFE_CPU_EMUL
       if (getenv("RTFE_PREP_CHECK")) hipLaunchKernelGGL(k_prep_check, dim3(1), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, (const CRec *)crecp);
@@ -789,6 +789,7 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
    if (hipMemcpy(&sc, d_workspace, sizeof sc, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
    out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.scr[3]; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
    for (int i = 0; i < 8; ++i) out[5 + i] = (int64_t)sc.why[i];
+   out[21] = (int64_t)sc.min_height_key;      // 0x7fffffff - float bits of the smallest learned v_avg_height, 0: none (the Python binding turns it back)
    for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)((h->dev.debug == 4 || h->dev.debug == 6 || h->dev.debug == 8) ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
    return 0; }
 

@@ -680,6 +680,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
                GsSeg &o = segs[seg0 + sg];
                o.chain = ci; o.sidx = sg; o.first = i + (long long)sg * SR; o.end = sg + 1 == nseg ? src.iend : i + (long long)(sg + 1) * SR; o.stands = 0; } }
          for (int k = 0; k < 10; ++k) cs.heights[k] = heights[k];
+         if (w.v_avg_height > 0) atomicMax(&scratch->min_height_key, 0x7fffffff - (int)__float_as_uint(w.v_avg_height));      // (a chain that is handed over has learned its height)
          if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
          if (w.nevents > n_slow) atomicAdd(&scratch->dbg[0], (unsigned long long)(w.nevents - n_slow));      // (statistics: the head's events on the fast path)
          continue; }
@@ -691,6 +692,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       if (failed) { atomicExch(&ctl[b].status, (int)kBurstNeedsFull); atomicAdd(&scratch->why[why & 7], 1ull); }
       counts[((size_t)b * cfg.nparm + pidx) * ntrks + trk] = w.nevents < cap ? w.nevents : cap;
       chain_h[(size_t)b * nwalk + wi] = w.v_avg_height;
+      if (mode == 0 && !agc_off && w.peakcount > 15 && w.v_avg_height_count == 0 && w.v_avg_height > 0) atomicMax(&scratch->min_height_key, 0x7fffffff - (int)__float_as_uint(w.v_avg_height));
       if (w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW) atomicOr(&ctl[b].bflags, w.flags & ~(unsigned)RTFE_F_SCREEN_UNDERFLOW); } }
 
 // ------------------------------------------------------------------------------------------------

@@ -42,7 +42,9 @@ struct BurstScratch {            // lives in the workspace (first kScratchBytes 
    int   queue_stitch;           // (unused)
    int   seg_failed;             // bursts whose segments did not join (statistics)
    int   hard_count;             // candidates k_sift deferred to k_sift_hard (cleared with the scratch block when rtfe_scan starts)
-   int   pad[6];
+   int   min_height_key;         // 0x7fffffff - the bits of the smallest v_avg_height any chain of this scan LEARNED (0: none did): what a caller may
+                                 // raise rtfe_config::screen_floor_height towards for the tape's next scans (rtfe_scan_stats)
+   int   pad[5];
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
    unsigned long long pool_cursor;   // (unused)
    unsigned long long dbg2[8];   // dbg[8..15] (contiguous with dbg through pool_cursor is NOT assumed: indexed separately)

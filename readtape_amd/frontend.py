@@ -100,6 +100,11 @@ class FrontEndConfig:
     screen_floor_height: float = 0.0
     events_per_sample_cap: float = 0.0
 
+    def peak_detection_floor_applies(self) -> bool:
+        """True where a scan learns peak heights and screens candidates against screen_floor_height: NRZI peak detection on the undifferentiated signal
+        (the peak path; the caller has not set a floor of its own)."""
+        return self.mode == NRZI and not self.find_zeros and not self.differentiate and self.bpi > 0 and not self.screen_floor_height
+
     @classmethod
     def from_header(cls, h: tbin.TbinHeader, nparmsets: int = 1, **kw) -> "FrontEndConfig":
         mode = kw.pop("mode", h.mode)
@@ -341,7 +346,10 @@ class FrontEnd:
         out = (C.c_int64 * 24)()
         if self.lib.rtfe_scan_stats(self.h, self.backend.ptr(result.bufs["ws"]), out) != 0:
             raise RuntimeError(self.lib.rtfe_last_error().decode())
-        return dict(bursts=int(out[0]), redone=int(out[1]), record_bytes=int(out[2]), parallel=int(out[3]), sequential=int(out[4]), gave_up=[int(out[5 + i]) for i in range(8)], phase_cycles=[int(out[13 + i]) for i in range(8)])
+        key = int(out[21])
+        min_height = float(np.array([0x7fffffff - key], dtype=np.uint32).view(np.float32)[0]) if key > 0 else None      # smallest v_avg_height a chain of the scan learned (peak path)
+        return dict(bursts=int(out[0]), redone=int(out[1]), record_bytes=int(out[2]), parallel=int(out[3]), sequential=int(out[4]), gave_up=[int(out[5 + i]) for i in range(8)], phase_cycles=[int(out[13 + i]) for i in range(8)],
+                    min_learned_height=min_height)
 
     def _buffers(self, nrows, key="scan"):
         """Allocates (once per size) the workspace and output buffers for a scan of nrows rows.  Exact rescans share ONE

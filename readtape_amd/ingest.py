@@ -140,6 +140,8 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         return piece, fin, end
 
     busy = [None] * depth
+    retired = []                                          # scan contexts replaced by ones with a calibrated screen floor (closed at the end: a scan of theirs may still be in flight)
+    floor_state = {"tries": 2, "floor": None}
     pieces = []                                           # per window: bytes, or the future that returns (bytes, replay stats, seconds)
 
     def replay(k, res, piece, lo, bound, start=None, tag=""):
@@ -194,6 +196,20 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                 t0 = time.perf_counter()
                 res, nb, bound = fin()
                 t_wait += time.perf_counter() - t0
+                if floor_state["tries"] > 0 and cfg.peak_detection_floor_applies():
+                    # The candidate screen is built for the loosest thresholds any AGC state could ask for - a learned peak height of 1 V -, and on a
+                    # noisy tape every wiggle above THAT becomes a record (lists outgrow their slots, the bursts are redone on the samples).  The first
+                    # windows say how high the tape's peaks really are: the scans behind them screen against half the smallest height a chain learned
+                    # (a later chain below that floor is flagged RTFE_F_SCREEN_UNDERFLOW and rescanned exactly: slower, never wrong).
+                    floor_state["tries"] -= 1
+                    st_k = fes[k & 1].scan_stats(res)
+                    if st_k["bursts"] > 0 and st_k["redone"] * 4 > st_k["bursts"] and st_k.get("min_learned_height"):
+                        import dataclasses
+                        cfg2 = dataclasses.replace(cfg, screen_floor_height=min(4.0, 0.5 * st_k["min_learned_height"]))
+                        retired.extend(fes)
+                        fes[:] = [frontend.FrontEnd(cfg2, device=device) for _ in range(2)]
+                        for f in fes: f._buffers(cap)
+                        floor_state["tries"] = 0; floor_state["floor"] = cfg2.screen_floor_height
                 halo = halo_rows
                 while nb is None and end_k < data_end[0]:    # the last own burst runs past the halo: read more (rare; synchronous)
                     halo *= 4
@@ -240,8 +256,8 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         if pool:
             pool.shutdown(wait=True, cancel_futures=True)
         fe_exact.close()
-        for f in fes:
+        for f in list(fes) + retired:
             f.close()
     stats.update(setup_seconds=t_start - t_enter, rows=data_end[0], seconds=dt, msamples_per_s=data_end[0] / dt / 1e6, replay_seconds=t_replay, read_seconds=t_read[0], scan_wait_seconds=t_wait,
-                 replay_events_per_s=(stats["events_delivered"] / t_replay) if t_replay > 0 else None, tap_bytes=total + (4 if total else 0))
+                 replay_events_per_s=(stats["events_delivered"] / t_replay) if t_replay > 0 else None, tap_bytes=total + (4 if total else 0), screen_floor_height=floor_state["floor"])
     return stats
