@@ -71,3 +71,18 @@ def test_windows_read_in_parallel_pieces_with_an_end_marker_in_one_of_them(threa
     st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=win, halo_rows=1 << 15, replay_threads=threads, read_threads=4)
     assert st["rows"] == cut and st["windows"] >= 4
     assert open(tmp_path / "s.tap", "rb").read() == want
+
+
+def test_a_noisy_tape_raises_the_screen_floor_after_its_first_windows(tmp_path):
+    """60 mV rms of noise on 2 - 3 V peaks: with the default candidate screen (built for a learned peak height of 1 V) the lists outgrow their
+    slots and the bursts are redone on the samples; the reader sees that in the first windows' statistics and screens the windows behind them
+    against half the smallest peak height a chain learned.  Same bytes as the whole-tape decode (whose events the oracle pins), and the floor was raised."""
+    tape = synth.nrzi_tape(seed=76, nblocks=60, minlen=400, maxlen=1500, marks_every=9, gap_samples=3000, noise_mv=60.0)
+    hdr = tape.spec.header()
+    want = _whole(hdr, tape.rows, str(tmp_path / "whole.tap"))
+    path = str(tmp_path / "t.tbin")
+    tbin.write_tbin(path, hdr, tape.rows)
+    st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=1 << 17, halo_rows=1 << 14, replay_threads=4, replay_split=2)
+    assert open(tmp_path / "s.tap", "rb").read() == want
+    assert st["windows"] >= 4 and st["blocks"] > 50
+    assert st["screen_floor_height"] is not None and 1.0 < st["screen_floor_height"] <= 4.0, st
