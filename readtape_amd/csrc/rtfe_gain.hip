@@ -158,12 +158,12 @@ __device__ __forceinline__ int half_incl_scan(int v, int hl) {
 // little else to hide them).  Per record: its absolute row, its volts, where its margin entries are, and kCrClear - everything static
 // that the chains' steady path asks of it: a plain record with a sure stretch whose successor in the stream (the next record of the
 // list; the first of the next tile's list) begins after this record's owner has left the window.
-__global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
+struct PrepArgs { int nlists, ntrks, hcap; float mv; int W[kMaxScreens]; };      // (by value: a wave's first loads do not wait for a read of the configuration block)
+__global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
                                               const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff,
                                               const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint2 *__restrict__ cmar) {
-   const DevCfg &cfg = *cfgp;
-   const int nlists = cfg.nscreens * cfg.ntrks, hcap = cfg.pk_slot;
-   const float mv = cfg.maxvolts;
+   const int nlists = pa.nlists, hcap = pa.hcap;
+   const float mv = pa.mv;
    const int lane = threadIdx.x & 63, hl = lane & 31, hbase = lane & 32;
    const long long nall = ntiles * nlists;
    const long long stride = (long long)gridDim.x * 8;                     // lists per sweep: four waves, two lists each
@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(256) k_prep(const DevCfg *__restrict__ cfgp, c
       if (built && d.nrec == 0xffffu) {                                  // a list that did not fit: one marker at the tile's first row
          if (hl == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; cmar[base] = make_uint2(0, 0); } }
       const int nrec = (built && d.nrec != 0xffffu) ? (int)d.nrec : 0;
-      const int W = cfg.screen[(on ? sl : 0) / cfg.ntrks].W;
+      const int scn = (on ? sl : 0) / pa.ntrks;
+      const int W = scn == 0 ? pa.W[0] : (scn == 1 ? pa.W[1] : (scn == 2 ? pa.W[2] : pa.W[3]));
       const unsigned char *slot = pool + (size_t)(on ? li : 0) * hcap;
       const long long pos0 = tile * kSfTile - kSfPosBias;
       // what follows this list in its stream
@@ -938,16 +939,27 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
       wk.v_avg_height = cs.k.h;
       const int n_own = (int)(sg.stop - sg.first);
       unsigned int at = sg.evoff;
-      for (int k0 = 0; k0 < n_own; k0 += 64) {
-         const int k = k0 + lane;
-         const float gain = k < n_own ? gfire[(size_t)si * S + k] : 0.0f;
-         const int fired = gain != 0.0f ? 1 : 0;
-         const int incl = wave_incl_scan(fired, lane);
-         if (fired) {
-            const size_t ri = sb + (size_t)(sg.first + k);
-            const CRec r = crec[ri];
-            ev[at + (unsigned)(incl - 1)] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(cmar + ri + 1), msrc, gain, W, d, reset, trk, pidx, mv); }
-         at += (unsigned)wave_last(incl); } } }
+      // (a lane's gain, record and margin block for up to kEsAhead rounds of 64 records are loaded TOGETHER and whether the record fired or not -
+      //  93 % do: one round trip per batch instead of two dependent ones per round; the kernel waits for memory 85 % of its time)
+      constexpr int kEsAhead = 4;
+      for (int k0 = 0; k0 < n_own; k0 += 64 * kEsAhead) {
+         float gain[kEsAhead]; CRec rec[kEsAhead]; uint2 mar[kEsAhead];
+         #pragma unroll
+         for (int u = 0; u < kEsAhead; ++u) {
+            const int k = k0 + 64 * u + lane;
+            gain[u] = 0.0f; rec[u].pos = 0; rec[u].w0 = 0; rec[u].w1 = 0; rec[u].volt = 0; mar[u] = make_uint2(0, 0);
+            if (k < n_own) {
+               const size_t ri = sb + (size_t)(sg.first + k);
+               gain[u] = gfire[(size_t)si * S + k]; rec[u] = crec[ri]; mar[u] = cmar[ri]; } }
+         #pragma unroll
+         for (int u = 0; u < kEsAhead; ++u) {
+            if (k0 + 64 * u >= n_own) break;
+            const int fired = gain[u] != 0.0f ? 1 : 0;
+            const int incl = wave_incl_scan(fired, lane);
+            if (fired) {
+               uint16_t mb[4] = {(uint16_t)(mar[u].x & 0xffffu), (uint16_t)(mar[u].x >> 16), (uint16_t)(mar[u].y & 0xffffu), (uint16_t)(mar[u].y >> 16)};      // (entry j at end[-(j + 1)]: the block as it lies in memory)
+               ev[at + (unsigned)(incl - 1)] = emit_event(cfg, P, wk, rec[u], mb + 4, msrc, gain[u], W, d, reset, trk, pidx, mv); }
+            at += (unsigned)wave_last(incl); } } } }
 
 // k_emit: the events k_gain's fast path only noted (the chains' heads and tails).  One workgroup per chain at a time, a lane per event.
 __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch,
