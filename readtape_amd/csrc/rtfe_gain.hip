@@ -453,8 +453,11 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          src.iend = ge < ntiles ? stream_pos(tstart, coff, nlists, ge, sl) : (long long)ctot[sl];
          if ((long long)ctot[sl] > ccap) { failed = true; why = 6; src.iend = i; } }      // (the stream was not built: k_prep)
       const bool lean = cfg.pk_fast && cmode != RTFE_PE;                // (PE decides the end of its preamble from peak TIMES: the general step)
-      const bool alpha_agc = !agc_off && P.agc_window == 0;           // steady state = the three-flop alpha filter
-      const float alpha = P.agc_alpha, beta = 1 - P.agc_alpha;
+      // steady state = the three-flop alpha filter.  A window AGC over ONE height (src/decoder.c:513-527 with agc_window = 1: the reference's NRZI
+      // sets 5 - 8, src/parmsets.c:83-86) is the same arithmetic with alpha = 1: gain = h / lastheight, and 1 x q + 0 x g = q exactly; the ring's one
+      // slot is overwritten before it is read, so nothing of it survives a detection
+      const bool alpha_agc = !agc_off && (P.agc_window == 0 || P.agc_window == 1);
+      const float alpha = P.agc_window == 1 ? 1.0f : P.agc_alpha, beta = 1 - alpha;
       // The stream goes through LDS a chunk of kGainChunk records a lane at a time (+ one: the record behind the chunk's last is what
       // its fast path looks at).  While the lanes step through a chunk - LDS reads only, and the notes they take go to LDS too - the
       // next chunk's 16-byte loads travel into registers; at the chunk's end they go to LDS.  (Loads issued inside the steps would
