@@ -43,9 +43,9 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0
 # 8-parmset event arena would not fit beside the tape (C4).  C3's single parameter set does: one scan of 1e9 rows (18 GB of rows,
 # as much event arena) - four scans of 2^28 rows each ended on their longest bursts, 16.2 instead of 15.0 ms.
 CONFIGS = {
-    "C2": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[],
+    "C2": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], overlap=True,
                workload="C2: synthetic 9-track 800 BPI NRZI, 781.25 kHz, 1 parmset"),
-    "C3": dict(kind="pe", rows=1e9, nparmsets=1, find_zeros=True, window_rows=None, ref_opts=["-nm", "-zeros"], port_opts=["-zeros"],
+    "C3": dict(kind="pe", rows=1e9, nparmsets=1, find_zeros=True, window_rows=None, ref_opts=["-nm", "-zeros"], port_opts=["-zeros"], overlap=True,
                workload="C3: synthetic 9-track 1600 BPI PE, 1.5625 MHz, -zeros (zero-crossing path), 1 parmset"),
     # (C4 in three fragments: a fragment's chains have a latency floor, and its worst-case event arena - 1/8 event per track-sample and set plus 128
     #  per possible burst - is 162 GiB at 4.0e8 rows; two fragments of 2^29 rows ask for 216 GiB each and leave no room beside the tape)
@@ -66,6 +66,8 @@ CONFIGS = {
                workload="N1c (extra): N1 with the candidate screen's floor calibrated on the tape: one scan with the default floor (1 V), then screen_floor_height = half the smallest peak height a chain learned - what a decode of the tape does after its first window"),
     "N2": dict(kind="gcr", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=30.0,
                workload="N2 (extra): G1's tape with 30 mV rms of noise on 1.8 V peaks (G1: 10 mV), 1 parmset, one scan"),
+    "M8c": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, ref_opts=[], port_opts=["-m"], calibrate_floor=True,
+                workload="M8c (extra): M8 with the candidate screen's floor calibrated on the tape (one scan with the default floor of 1 V, then half the smallest learned peak height): the four 0.05 V-rise sets' screens stop passing every wiggle"),
     "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True,
                workload="C5: ONE 10 GB synthetic 9-track 800 BPI NRZI tape, time-sharded over the ranks (strong scaling)"),
 }
@@ -201,6 +203,7 @@ class Workload:
         if os.environ.get("RT_BENCH_SCREEN_FLOOR"):                     # (experiments: the candidate screen's assumed lower bound of the learned peak height, volts)
             self.cfg.screen_floor_height = float(os.environ["RT_BENCH_SCREEN_FLOOR"])
         make = (lambda: frontend.FrontEnd(self.cfg, device=str(dev))) if fe_factory is None else (lambda: fe_factory(self.cfg))
+        self.make = make
         self.fe = make()
         # fragments of the resident rows (one when the workspace fits)
         wrows = int(window_rows or conf["window_rows"] or 0)
@@ -264,7 +267,11 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
     from readtape_amd import frontend
     conf = CONFIGS[name]
     strong = bool(conf.get("strong"))
-    wl = Workload(conf, rank, world, dev, dist, float(total_rows or conf["rows"]), args.base_rows, window_rows=args.window_rows, pipeline=args.pipeline)
+    # overlap: two scan contexts (front end, workspace, outputs, HIP stream) take the steps in turn, so that step i + 1's dense pass (VALU-bound)
+    # runs beside step i's record chains (latency-bound) - as the streaming reader runs a tape's windows (ingest.py).  Every step is still a whole
+    # scan of the resident tape and all of them are inside the timed region.  The per-kernel times (roofline) come from a serial pass of their own.
+    overlap = (bool(conf.get("overlap")) and not args.no_overlap) or args.pipeline
+    wl = Workload(conf, rank, world, dev, dist, float(total_rows or conf["rows"]), args.base_rows, window_rows=args.window_rows, pipeline=overlap)
     cfg, fe, frags, kms, nrows = wl.cfg, wl.fe, wl.frags, wl.kms, wl.nrows
     torch.cuda.synchronize(dev)
     calibrated = None
@@ -274,13 +281,26 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
             calibrated = min(4.0, 0.5 * st0["min_learned_height"])
             for f in set(wl.fes): f.close()
             wl.cfg.screen_floor_height = calibrated
-            wl.fe = frontend.FrontEnd(wl.cfg, device=str(dev)); wl.fes = [wl.fe, wl.fe]; wl.fe.set_timing(True)
+            wl.fe = wl.make(); wl.fes = [wl.fe, wl.make() if overlap else wl.fe]
+            for f in set(wl.fes): f.set_timing(True)
             cfg, fe = wl.cfg, wl.fe
     for i in range(warmup):
         wl.step(i)
     torch.cuda.synchronize(dev)
     wl.collect()                                     # (the warm-up scans' events: discarded)
     for k in kms: kms[k] = 0.0
+    # ---- the serial pass: one context, steps back to back on one stream - contention-free HIP-event spans for kernel_ms / roofline ----
+    n_serial = max(3, min(steps, 10))
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(n_serial):
+        wl.step(0, timed=True)                       # (always context 0)
+    torch.cuda.synchronize(dev)
+    serial_s = (time.perf_counter() - t0) / n_serial
+    wl.collect()
+    for k in kms: kms[k] /= n_serial
+    kms_serial = dict(kms)
     done, dt = 0, 0.0
     while True:                                      # rounds of `steps` steps until the timed region is long enough for the driver's clock to see it
         if world > 1: dist.barrier()
@@ -298,6 +318,8 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
             d = float(t.item())
         dt += d; done += steps
         if dt >= min_seconds or done >= 64 * steps: break
+    kms_timed = {k: (v - kms_serial[k]) / max(done, 1) for k, v in kms.items()}      # (under overlap: spans that share the device)
+    for k in kms: kms[k] = kms_serial[k]
     # what the step produced (one more, untimed pass: every fragment's tables are fetched before the next one reuses the buffers)
     tally = dict(events=0, bursts=0, bad=0)
 
@@ -318,7 +340,6 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
         nevents_all, bad, rows_all = int(tot[0].item()), int(tot[1].item()), int(tot[2].item())
     else:
         nevents_all, rows_all = nevents, nrows
-    for k in kms: kms[k] /= max(done, 1)
     # The dominant span.  Every span is bracketed by its own pair of HIP events on the stream it runs on; on the peak path k_bursts' span
     # (quiet map -> bursts -> restart rows) runs on the handle's side stream BESIDE k_prep: its time is shared device time, not work of its
     # own, so it never names the dominant kernel.
@@ -341,11 +362,15 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
     own_rows_bytes = 2 * cfg.ntrks * nrows                    # what the dominant kernel streams if it writes no events itself (k_dseg: the chains' kernel writes them)
     fields = {
         "value": round(rows_all * done / dt / 1e6, 1), "ms_per_step": round(step_s * 1e3, 4), "timed_steps": done, "timed_seconds": round(dt, 3),
+        "ms_per_step_serial": round(serial_s * 1e3, 4),
+        "overlap": ("two scan contexts on two HIP streams take the steps in turn (step i + 1's dense pass beside step i's chains); kernel_ms / roofline from a serial pass of "
+                    f"{n_serial} steps on one context") if overlap else "none: one context, steps back to back",
         "config": {"workload": conf["workload"], "rows_per_gpu": nrows, "rows_total": rows_all,
                    "bytes_per_gpu": nrows * cfg.ntrks * 2, "events_per_gpu": nevents, "events_total": nevents_all, "bursts": tally["bursts"],
                    "flagged_bursts": bad, "parmsets": conf["nparmsets"], "launches_per_step": len(frags), "last_scan_stats": sst, "screen_floor_height": calibrated,
                    "sharding": ("one tape, time shards (plan_shards), neighbour halo only" if strong else "time shards, neighbour halo only") if world > 1 else "none"},
         "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
+        "kernel_ms_in_timed_region": {k: round(v, 4) for k, v in kms_timed.items()} if overlap else None,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_all_kernels": traffic_all, "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
                      "frac_rows_only": round(own_rows_bytes / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms[dom] > 0 else None,
@@ -368,6 +393,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact C3 / C4 / C5 lines the default single-GPU run adds to its line")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="the timed region repeats its --steps steps until it is at least this long")
+    ap.add_argument("--no-overlap", action="store_true", help="one scan context, steps back to back, also for the configurations that overlap two by default")
     ap.add_argument("--pipeline", action="store_true", help="alternate two front-end contexts on two HIP streams (steps overlap; per-kernel times then include contention)")
     args = ap.parse_args()
     default_line = args.config is None and int(os.environ.get("WORLD_SIZE", "1")) == 1
@@ -393,9 +419,9 @@ def main():
     tape, fes, copies = wl.tape, wl.fes, wl.copies
     if rank == 0:
         line = {"metric": "Msamples/sec (all tracks) 9-trk TBIN", "value": fields["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": fields["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
+                "ms_per_step": fields["ms_per_step"], "ms_per_step_serial": fields["ms_per_step_serial"], "overlap": fields["overlap"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
                 "vs_baseline": None, "dtype": "i16/f32", "data": "synthetic", "timed_steps": fields["timed_steps"], "timed_seconds": fields["timed_seconds"],
-                "config": fields["config"], "kernel_ms": fields["kernel_ms"], "roofline": fields["roofline"]}
+                "config": fields["config"], "kernel_ms": fields["kernel_ms"], "kernel_ms_in_timed_region": fields["kernel_ms_in_timed_region"], "roofline": fields["roofline"]}
     for f in set(fes): f.close()
     del wl.sr, wl
     import gc
@@ -403,10 +429,10 @@ def main():
     # ---- the other BASELINE.json configurations, measured in this process (compact: value, ms per step, dominant kernel, fractions) ----
     if default_line and not args.no_other_configs:
         others = {}
-        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("M8", 5, 2), ("N1", 3, 1), ("N1c", 10, 2), ("N2", 2, 1)):
+        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("M8", 5, 2), ("M8c", 5, 2), ("N1", 3, 1), ("N1c", 10, 2), ("N2", 2, 1)):
             try:
                 f2, w2 = measure(name, args, rank, world, dev, dist, st, wu, args.min_seconds)
-                others[name] = {"workload": f2["config"]["workload"], "value": f2["value"], "unit": "Msamples/s", "ms_per_step": f2["ms_per_step"], "timed_steps": f2["timed_steps"],
+                others[name] = {"workload": f2["config"]["workload"], "value": f2["value"], "unit": "Msamples/s", "ms_per_step": f2["ms_per_step"], "ms_per_step_serial": f2["ms_per_step_serial"], "overlap": f2["overlap"][:40], "timed_steps": f2["timed_steps"],
                                 "rows": f2["config"]["rows_total"], "events": f2["config"]["events_total"], "parmsets": f2["config"]["parmsets"], "flagged_bursts": f2["config"]["flagged_bursts"],
                                 "launches_per_step": f2["config"]["launches_per_step"], "dominant_kernel": f2["roofline"]["kernel"], "dominant_kernel_ms": f2["kernel_ms"][f2["roofline"]["kernel"]],
                                 "frac": f2["roofline"]["frac"], "frac_rows_only": f2["roofline"]["frac_rows_only"], "whole_step_frac": f2["roofline"]["whole_step"]["frac"],

@@ -6,7 +6,7 @@ python - <<'PY'
 import json
 try:
     j = json.loads(open("/tmp/try.json").read().strip().splitlines()[-1])
-    print(j["config"]["workload"][:40], "|", j["value"], "Msamples/s", j["ms_per_step"], "ms", {k: v for k, v in j["kernel_ms"].items() if v > 0.01}, "frac", j["roofline"]["frac"], j["roofline"]["kernel"], "flagged", j["config"]["flagged_bursts"], "events", j["config"]["events_per_gpu"])
+    print(j["config"]["workload"][:40], "|", j["value"], "Msamples/s", j["ms_per_step"], "ms (serial", j.get("ms_per_step_serial"), ")", {k: v for k, v in j["kernel_ms"].items() if v > 0.01}, "frac", j["roofline"]["frac"], j["roofline"]["kernel"], "flagged", j["config"]["flagged_bursts"], "events", j["config"]["events_per_gpu"])
 except Exception as e:
     print("no line:", e)
 PY
