@@ -56,17 +56,17 @@ CONFIGS = {
                workload="G1 (extra): synthetic 9-track 6250 BPI GCR (9042 fci), 6.25 MHz, 1 parmset, peak detection, one scan"),
     "P1": dict(kind="pe", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[],
                workload="P1 (extra): synthetic 9-track 1600 BPI PE, 1.5625 MHz, 1 parmset, peak detection (not -zeros), one scan"),
-    "M8": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, ref_opts=[], port_opts=["-m"],
+    "M8": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, overlap=True, ref_opts=[], port_opts=["-m"],
                workload="M8 (extra): C2's tape under the reference's default -m: the 8 built-in NRZI parameter sets (three window widths) in one scan"),
     # the same tapes with noise (every other line is 10 mV rms): what the speculation costs when the signal is not clean -
     # flagged bursts, bursts redone on the samples and what the chains left to the literal detector are on the line
     "N1": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=60.0,
                workload="N1 (extra): C2's tape with 60 mV rms of noise on 2-3 V peaks (C2: 10 mV), 1 parmset"),
-    "N1c": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=60.0, calibrate_floor=True,
+    "N1c": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, overlap=True, ref_opts=["-nm"], port_opts=[], noise_mv=60.0, calibrate_floor=True,
                workload="N1c (extra): N1 with the candidate screen's floor calibrated on the tape: one scan with the default floor (1 V), then screen_floor_height = half the smallest peak height a chain learned - what a decode of the tape does after its first window"),
     "N2": dict(kind="gcr", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=30.0,
                workload="N2 (extra): G1's tape with 30 mV rms of noise on 1.8 V peaks (G1: 10 mV), 1 parmset, one scan"),
-    "M8c": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, ref_opts=[], port_opts=["-m"], calibrate_floor=True,
+    "M8c": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, overlap=True, ref_opts=[], port_opts=["-m"], calibrate_floor=True,
                 workload="M8c (extra): M8 with the candidate screen's floor calibrated on the tape (one scan with the default floor of 1 V, then half the smallest learned peak height): the four 0.05 V-rise sets' screens stop passing every wiggle"),
     "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True,
                workload="C5: ONE 10 GB synthetic 9-track 800 BPI NRZI tape, time-sharded over the ranks (strong scaling)"),

@@ -174,9 +174,9 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
          const unsigned char *slot = pool + (size_t)l * hcap;
          p.d = dir[l];
          p.ts = tstart[(size_t)tl * nlists + s2]; p.co = coff[(size_t)(tl >> 10) * nlists + s2]; p.ct = ctot[s2];
-         p.r = *reinterpret_cast<const uint2 *>(slot + min(8 * hl, hcap - 8));
-         p.r1 = *reinterpret_cast<const uint2 *>(slot + min(8 * (hl + 1), hcap - 8));
-         p.m = *reinterpret_cast<const uint2 *>(slot + max(hcap - 8 * (hl + 1), 0));      // (record hl's margin block)
+         {  const uint4 r4 = *reinterpret_cast<const uint4 *>(slot + min(16 * hl, hcap - 16));      // (16 bytes: the record, its margin block behind it)
+            p.r = make_uint2(r4.x, r4.y); p.m = make_uint2(r4.z, r4.w); }
+         p.r1 = *reinterpret_cast<const uint2 *>(slot + min(16 * (hl + 1), hcap - 16));
          if (l + nlists < nall) { p.dn = dir[l + nlists]; p.rn = *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap); } }
       return p; };
    // where a record's successor begins: the first row of the first record at or behind entry k1 of a list (q1 = that entry, already
@@ -185,11 +185,11 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
    constexpr long long kNoSucc = 0x7fffffffffffffffll, kBadSucc = -1, kOffList = -2;
    auto succ_row = [&](const unsigned char *lslot, int k1, int n1, uint2 q, long long pos0q) -> long long {
       for (int j = k1; j < n1; ++j) {
-         if (j > k1) q = *reinterpret_cast<const uint2 *>(lslot + 8 * j);
+         if (j > k1) q = *reinterpret_cast<const uint2 *>(lslot + 16 * j);
          if (q.y == 0xffff8001u) {
             const unsigned char *os = ovf + (size_t)q.x * kSfOvfBytes;
             if (*reinterpret_cast<const int *>(os) <= 0) continue;
-            q = *reinterpret_cast<const uint2 *>(os + 8); }
+            q = *reinterpret_cast<const uint2 *>(os + 8); }      // (its first record)
          return pos0q + (long long)(q.x & 0x7ffu) + (long long)((q.x >> 12) & 63u); }
       return kOffList; };
    long long li = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
          const int k = rd * 32 + hl;
          const bool have = k < nrec;
          uint2 q = cu.r, q1 = cu.r1;
-         if (rd > 0 && have) { q = *reinterpret_cast<const uint2 *>(slot + 8 * k); if (k + 1 < nrec) q1 = *reinterpret_cast<const uint2 *>(slot + 8 * (k + 1)); }
+         if (rd > 0 && have) { q = *reinterpret_cast<const uint2 *>(slot + 16 * k); if (k + 1 < nrec) q1 = *reinterpret_cast<const uint2 *>(slot + 16 * (k + 1)); }
          const uint32_t w0 = have ? q.x : 0u, w1 = have ? q.y : 0u;
          const bool deferred = have && w1 == 0xffff8001u;                  // its records are in overflow slot w0 (k_sift_hard): they take its place
          const unsigned char *os = ovf + (size_t)(deferred ? w0 : 0u) * kSfOvfBytes;
@@ -239,18 +239,20 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
          if (fn == kOffList) fn = fn_list;
          if (deferred) {
             for (int j = 0; j < cnt; ++j) {
-               const uint2 e = *reinterpret_cast<const uint2 *>(os + 8 + 8 * j);
+               const uint2 e = *reinterpret_cast<const uint2 *>(os + 8 + 16 * j);
                CRec c; c.pos = (uint32_t)(pos0 + (long long)(e.x & 0x7ffu)); c.w0 = e.x & ~0x7ffu; c.w1 = e.y; c.volt = volt((int)(int16_t)(e.y & 0xffffu), mv);
                long long fj = fn;
-               if (j + 1 < cnt) { const uint2 e2 = *reinterpret_cast<const uint2 *>(os + 8 + 8 * (j + 1)); fj = pos0 + (long long)(e2.x & 0x7ffu) + (long long)((e2.x >> 12) & 63u); }
+               if (j + 1 < cnt) { const uint2 e2 = *reinterpret_cast<const uint2 *>(os + 8 + 16 * (j + 1)); fj = pos0 + (long long)(e2.x & 0x7ffu) + (long long)((e2.x >> 12) & 63u); }
                if (e.y != 0xffff8000u && (unsigned)((int)((e.x >> 22) & 63u) - 1) < 62u && fj != kBadSucc && fj > (long long)c.pos + W) c.w0 |= kCrClear;
                crec[o + j] = c;
-               cmar[o + j] = *reinterpret_cast<const uint2 *>(os + kSfOvfBytes - 8 * (j + 1)); } }
+               cmar[o + j] = *reinterpret_cast<const uint2 *>(os + 8 + 16 * j + 8); } }
          else if (have) {
             CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
             if (w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u && fn != kBadSucc && fn > (long long)c.pos + W) c.w0 |= kCrClear;
             crec[o] = c;
-            cmar[o] = rd == 0 ? cu.m : *reinterpret_cast<const uint2 *>(slot + hcap - 8 * (k + 1)); }      // (its margin block: record k's ends 8 k bytes in front of the slot's end)
+            uint2 mk2 = cu.m;
+            if (rd > 0) mk2 = *reinterpret_cast<const uint2 *>(slot + 16 * k + 8);
+            cmar[o] = mk2; }      // (its margin block)
          base += __shfl(ic, hbase + 31); } } }
 
 #ifdef RTFE_CPU_EMUL

@@ -634,11 +634,11 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                   const int sh = 16 * half;
                   const int ir = wave_incl_scan(vr << sh, lane);
                   const int myr = (((ir >> sh) & 0xffff) - vr) + (half ? rec_hi : rec_lo);
-                  if (vr && 16 * (myr + 1) <= hcap) {                         // the record from the slot's front, its margin block from the back
+                  if (vr && 16 * (myr + 1) <= hcap) {                         // 16 bytes: the record, its margin block behind it
                      const lds_p slot = half ? slot_hi : slot_lo;
-                     lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 2 * myr;
+                     lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 4 * myr;
                      rp[0] = w0; rp[1] = w1;
-                     if (cut != 5) pk_margins(cx, half ? h_hi : h_lo, w0, w1, reinterpret_cast<lds_u16p>(slot + hcap - 8 * myr)); }
+                     if (cut != 5) pk_margins(cx, half ? h_hi : h_lo, w0, w1, reinterpret_cast<lds_u16p>(slot + 16 * (myr + 1))); }
                   const int tr = wave_last(ir);
                   rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; } } }
          if (prof) { tk0 = clock64(); pc_own += tk0 - tk1; }
@@ -646,7 +646,6 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
          // lane; the directory ----
          rtfe_wave_sync();
          {
-            const int vps = hcap >> 4;                                         // 16-byte vectors per slot
             #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                if (hh && !has_hi) break;
@@ -655,9 +654,8 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
                const bool over = bad || 16 * nr > hcap;
                unsigned char *gslot = pool + ((size_t)(tile * nscreens + sc) * ntrks + h) * (size_t)hcap;
                if (!over && nr > 0 && cut != 6) {
-                  const int fv = (8 * nr + 15) >> 4, bv = (8 * nr + 15) >> 4;        // vectors in use at the front / at the back
                   const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
-                  for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
+                  for (int v = lane; v < nr; v += 64) reinterpret_cast<int4 *>(gslot)[v] = src[v];      // (a 16-byte vector a record)
                   if (prof) pn_bytes += (unsigned)(16 * nr); }
                if (lane == 0) {
                   PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
@@ -739,7 +737,6 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
    int p_tile = -1, p_rec_lo = 0, p_rec_hi = 0;
    bool p_bad = false;
    auto copy_out = [&](const int tile, const int rec_lo, const int rec_hi, const bool bad) {
-      const int vps = hcap >> 4;                                         // 16-byte vectors per slot
       #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
          if (hh && !has_hi) break;
@@ -748,9 +745,8 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
          const bool over = bad || 16 * nr > hcap;
          unsigned char *gslot = a.pool + ((size_t)tile * NT + h) * (size_t)hcap;
          if (!over && nr > 0 && cut != 6) {
-            const int fv = (8 * nr + 15) >> 4, bv = fv;                        // vectors in use at the front (records) / at the back (margin blocks)
             const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
-            for (int v = lane; v < fv + bv; v += 64) { const int vv = v < fv ? v : vps - 1 - (v - fv); reinterpret_cast<int4 *>(gslot)[vv] = src[vv]; }
+            for (int v = lane; v < nr; v += 64) reinterpret_cast<int4 *>(gslot)[v] = src[v];      // (a 16-byte vector a record)
             if (a.debug == 3) pn_bytes += (unsigned)(16 * nr); }
          if (lane == 0) {
             PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
@@ -849,14 +845,11 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                   const int sh = 16 * half;
                   const int ir = wave_incl_scan(vr << sh, lane);
                   const int myr = (((ir >> sh) & 0xffff) - vr) + (half ? rec_hi : rec_lo);
-                  if (vr && 16 * (myr + 1) <= hcap) {                         // the record from the slot's front, its margin block from the back
+                  if (vr && 16 * (myr + 1) <= hcap) {                         // 16 bytes: the record, its margin block behind it
                      const lds_p slot = half ? slot_hi : slot_lo;
-                     lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 2 * myr;
-                     rp[0] = w0; rp[1] = w1;
-                     if (cut != 5) {
-                        const uint2 mb = (w1 & 0xfffffffeu) == 0xffff8000u ? make_uint2(0, 0) : pk_margins_w<W>(cx, half ? h_hi : h_lo, cpos, cbot, w0);
-                        lds_u32p mp = reinterpret_cast<lds_u32p>(slot + hcap - 8 * (myr + 1));
-                        mp[0] = mb.x; mp[1] = mb.y; } }
+                     lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 4 * myr;
+                     const uint2 mb = (cut == 5 || (w1 & 0xfffffffeu) == 0xffff8000u) ? make_uint2(0, 0) : pk_margins_w<W>(cx, half ? h_hi : h_lo, cpos, cbot, w0);
+                     rp[0] = w0; rp[1] = w1; rp[2] = mb.x; rp[3] = mb.y; }
                   const int tr = wave_last(ir);
                   rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; } } }
          // ---- 5. this wave's two lists leave (now, or - a.defer - at the start of the next tile step) ----
@@ -928,8 +921,8 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, cx.W - 2, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs than a slot holds: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
       *reinterpret_cast<int *>(slot) = nrec;
       if (nrec != 1) atomicAdd(&extra[((size_t)hd.tile * cfg.nscreens + hd.screen) * cfg.ntrks + hd.head], nrec - 1);      // the list's length in its stream (k_pscan)
-      for (int j = 0; j < nrec; ++j) {                                      // (8 + 4 x 8 + 4 x 8 bytes fit the slot)
-         reinterpret_cast<uint32_t *>(slot + 8)[2 * j] = sk.w0[j]; reinterpret_cast<uint32_t *>(slot + 8)[2 * j + 1] = sk.w1[j];
-         pk_margins(cx, (int)hd.head, sk.w0[j], sk.w1[j], reinterpret_cast<uint16_t *>(slot + kSfOvfBytes) - kPkMar * j); } } }
+      for (int j = 0; j < nrec; ++j) {                                      // (8 + 4 x 16 bytes fit the slot)
+         reinterpret_cast<uint32_t *>(slot + 8)[4 * j] = sk.w0[j]; reinterpret_cast<uint32_t *>(slot + 8)[4 * j + 1] = sk.w1[j];
+         pk_margins(cx, (int)hd.head, sk.w0[j], sk.w1[j], reinterpret_cast<uint16_t *>(slot + 8 + 16 * (j + 1))); } } }
 
 }  // namespace rtfe
