@@ -38,7 +38,7 @@ extern "C" {
 
 #define RTFE_MAXTRKS     19   /* src/csvtbin.h:29  MAXTRKS      */
 #define RTFE_MAXPARMSETS 15   /* src/decoder.h:92  MAXPARMSETS  */
-#define RTFE_ABI_VERSION 2   /* 2: rtfe_kernel_ms returns the number of scans summed; twelve timed spans (k_dseg, k_dchain) */
+#define RTFE_ABI_VERSION 3   /* 3: rtfe_scan_stats out[21] = the smallest learned peak height (screen-floor calibration); 2: rtfe_kernel_ms returns the number of scans summed; twelve timed spans (k_dseg, k_dchain) */
 
 enum { RTFE_PE = 1, RTFE_NRZI = 2, RTFE_GCR = 4, RTFE_WW = 8 };      /* enum mode_t, src/csvtbin.h:47-49 */
 

@@ -390,7 +390,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    h->sift_defer = getenv("RTFE_SIFT_DEFER") ? atoi(getenv("RTFE_SIFT_DEFER")) != 0 : 1;
    h->ds_order = getenv("RTFE_DS_ORDER") ? atoi(getenv("RTFE_DS_ORDER")) : 1;
    h->dchain_wgs = getenv("RTFE_DCHAIN_WGS") ? atoi(getenv("RTFE_DCHAIN_WGS")) : 16;
-   h->prep_wgs = getenv("RTFE_PREP_WGS") ? atoi(getenv("RTFE_PREP_WGS")) : 16;
+   h->prep_wgs = getenv("RTFE_PREP_WGS") ? atoi(getenv("RTFE_PREP_WGS")) : 32;
    h->dense_stop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;
    h->dseg_wgs = getenv("RTFE_DSEG_WGS") ? atoi(getenv("RTFE_DSEG_WGS")) : 0;
    // (k_zeros packs two tracks' 16-bit states into a lane and reads the rows where they lie: no -invert, no deskew delays, a threshold inside int16)
@@ -678,7 +678,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       PrepArgs ppa; ppa.nlists = nlists; ppa.ntrks = h->dev.ntrks; ppa.hcap = h->dev.pk_slot; ppa.mv = h->dev.maxvolts;
       for (int sc2 = 0; sc2 < kMaxScreens; ++sc2) ppa.W[sc2] = h->dev.screen[sc2].W;
       // (workgroups per CU: 4 / 8 / 16 measured 0.51 / 0.47 / 0.42 ms for the span on C2 - half a wave per list, the more lists in flight the better)
-      hipLaunchKernelGGL(k_prep, dim3(h->num_cus * (h->prep_wgs >= 1 && h->prep_wgs <= 4096 ? h->prep_wgs : 16)), dim3(256), 0, st, ppa, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
+      hipLaunchKernelGGL(k_prep, dim3(h->num_cus * (h->prep_wgs >= 1 && h->prep_wgs <= 4096 ? h->prep_wgs : 32)), dim3(256), 0, st, ppa, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
                          (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, crecp, erefp);
 #ifdef RTFE_CPU_EMUL
       if (getenv("RTFE_PREP_CHECK")) hipLaunchKernelGGL(k_prep_check, dim3(1), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, (const CRec *)crecp);

@@ -122,11 +122,13 @@ constexpr int kPkBack    = 64;       // rows k_sift looks back for the last forc
 // margin of a row = val - max(left edge, right edge) (tops) / min(edges) - val (bottoms), int16 code differences.
 // A list holds the records of the candidates of ONE tile in candidate order; their rows may run on into the next tile.
 struct PeakRec { uint32_t w0, w1; };
-// The pool: one fixed slot of pk_slot bytes per (tile, screen, head).  Inside a slot the records grow from the front, the margin
-// entries from the back (entry e at slot_end - 2 (e + 1)); a list that does not fit is marked unavailable in the directory.
+// The pool: one fixed slot of pk_slot bytes per (tile, screen, head), 16 bytes a record: the PeakRec and, behind it, its MARGIN BLOCK - the margins
+// (uint16, clamped at 0) of the run's first kPkMar = 4 rows from f on, entry j (row f + j) at block end - 2 (j + 1).  A list that does not fit its
+// slot is marked unavailable in the directory.  (Rounds 3 / 4: 8-byte records from the slot's front, one 2-byte entry per lead and tail row from its
+// back - variable per record: a second prefix sum and a predicated store per window row in k_sift, an entry reference per record downstream.)
 //   w1 == 0xffff8001: a candidate k_sift deferred; w0 = its index in the hard list = its overflow slot (k_sift_hard)
 struct SfHard { uint32_t tile; uint16_t pos; uint8_t head, screen; };      // a deferred candidate: tile, row within it, head, screen
-constexpr int kSfOvfBytes = 128;     // an overflow slot: int32 records (-1: not representable), pad, <= 4 records from byte 8, margin entries from the back
+constexpr int kSfOvfBytes = 128;     // an overflow slot: int32 records, pad, <= 4 records of 16 bytes (record + margin block) from byte 8
 struct PeakDir {               // per (tile, screen, head): 4 bytes
    uint16_t nrec;              // 0xFFFF: not available (capacity)
    uint16_t nent;

@@ -198,13 +198,12 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
    const int dr = (int)(stride - dq * nlists);
    long long tile = li / nlists;
    int sl = (int)(li - tile * nlists);
-   Pre nx = fetch(li, tile, sl);
+   // (no software prefetch of the next list: gfx9 counts loads and stores in ONE counter, the stores of a list's records are conditional, and
+   //  hipcc then waits for everything in flight before the first use of a prefetched value - measured: the loads of list i + 1 were waited for
+   //  right behind their issue.  Eight waves per SIMD hide the round trip instead: the registers the second set of values took are free.)
    for (; __ballot(li < nall) != 0ull; li += stride, tile += dq, sl += dr) {
       if (sl >= nlists) { sl -= nlists; ++tile; }
-      const Pre cu = nx;
-      {  long long t2 = tile + dq; int s2 = sl + dr;
-         if (s2 >= nlists) { s2 -= nlists; ++t2; }
-         nx = fetch(li + stride, t2, s2); }
+      const Pre cu = fetch(li, tile, sl);
       const PeakDir d = cu.d;
       const bool on = li < nall && d.nrec != 0;
       const bool built = on && (long long)cu.ct <= ccap;                  // a stream that outgrew its capacity is not built: its chains give up (k_gain)

@@ -235,7 +235,7 @@ def _load_library(path=None):
     lib.rtfe_scan_stats.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.rtfe_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rtfe_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-    if lib.rtfe_abi_version() != 2:
+    if lib.rtfe_abi_version() != 3:
         raise RuntimeError("librtfe.so ABI mismatch")
     return lib
 
