@@ -422,9 +422,13 @@ def main():
                 "ms_per_step": fields["ms_per_step"], "ms_per_step_serial": fields["ms_per_step_serial"], "overlap": fields["overlap"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
                 "vs_baseline": None, "dtype": "i16/f32", "data": "synthetic", "timed_steps": fields["timed_steps"], "timed_seconds": fields["timed_seconds"],
                 "config": fields["config"], "kernel_ms": fields["kernel_ms"], "kernel_ms_in_timed_region": fields["kernel_ms_in_timed_region"], "roofline": fields["roofline"]}
-    for f in set(fes): f.close()
-    del wl.sr, wl
     import gc
+
+    def release(w):                                  # a workload's device memory: its scan contexts' buffers, its rows
+        for f in set(w.fes): f.close()
+        w.fes, w.fe, w.make, w.sr = [], None, None, None
+    release(wl)
+    del wl, fes
     gc.collect(); torch.cuda.empty_cache()
     # ---- the other BASELINE.json configurations, measured in this process (compact: value, ms per step, dominant kernel, fractions) ----
     if default_line and not args.no_other_configs:
@@ -439,10 +443,11 @@ def main():
                                 "traffic": f2["roofline"]["traffic"], "traffic_all_kernels": f2["roofline"]["traffic_all_kernels"], "kernel_ms": {k: v for k, v in f2["kernel_ms"].items() if v > 0.02},
                                 "last_scan_stats": {k: f2["config"]["last_scan_stats"].get(k) for k in ("bursts", "redone", "parallel", "sequential", "gave_up", "min_learned_height")} if f2["config"]["last_scan_stats"] else None,
                                 "screen_floor_height": f2["config"]["screen_floor_height"]}
-                for f in set(w2.fes): f.close()
-                del w2.sr, w2
+                release(w2)
+                del w2
             except Exception as e:                    # the headline number must not depend on the other lines
                 others[name] = {"error": repr(e)[:300]}
+                e.__traceback__ = None               # (the frames of a failed measure() hold its workload: let the collector below have them)
             gc.collect(); torch.cuda.empty_cache()
         if rank == 0: line["other_configs"] = others
     if rank == 0:

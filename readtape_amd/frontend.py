@@ -317,6 +317,8 @@ class FrontEnd:
         if getattr(self, "h", None):
             self.lib.rtfe_destroy(self.h)
             self.h = None
+        if getattr(self, "_cache", None):                   # the workspaces and output buffers go with the handle (not when the garbage collector finds the object)
+            self._cache.clear()
 
     def __del__(self):
         try:
