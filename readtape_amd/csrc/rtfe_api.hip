@@ -46,7 +46,7 @@ struct rtfe_handle {
    int overlap;
    int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
    int sift_defer;                     // RTFE_SIFT_DEFER=0: k_sift_s stores a tile's lists at the end of its own step (experiments)
-   int ds_order, dchain_wgs, prep_wgs, dense_stop, dseg_wgs;      // RTFE_DS_ORDER (0: chains in burst order), RTFE_DCHAIN_WGS / RTFE_PREP_WGS / RTFE_DSEG_WGS (workgroups per CU), RTFE_DENSE_STOP (debugging): read once, at create
+   int ds_order, dchain_wgs, prep_wgs, dense_stop, dseg_wgs, dseg_threads;      // RTFE_DS_ORDER (0: chains in burst order), RTFE_DCHAIN_WGS / RTFE_PREP_WGS / RTFE_DSEG_WGS (workgroups per CU), RTFE_DENSE_STOP (debugging): read once, at create
 };
 
 static thread_local char g_err[512] = "";
@@ -393,6 +393,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    h->prep_wgs = getenv("RTFE_PREP_WGS") ? atoi(getenv("RTFE_PREP_WGS")) : 32;
    h->dense_stop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;
    h->dseg_wgs = getenv("RTFE_DSEG_WGS") ? atoi(getenv("RTFE_DSEG_WGS")) : 0;
+   h->dseg_threads = getenv("RTFE_DSEG_THREADS") ? atoi(getenv("RTFE_DSEG_THREADS")) : 0;
    // (k_zeros packs two tracks' 16-bit states into a lane and reads the rows where they lie: no -invert, no deskew delays, a threshold inside int16)
    if (d.invert || d.maxskew > 0 || d.ntrks < 2 || d.zc_peak_i < 1 || d.zc_peak_i > 32767 || !d.zc_parallel) h->zeros_kernel = 0;      // (RTFE_ZC_PARALLEL=0: k_decode's sequential walk, for the tests)
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
@@ -735,7 +736,11 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       long long dg = (long long)h->num_cus * dpc;
       if (dg > dtiles) dg = dtiles;
       t0(kTDseg);
-      hipLaunchKernelGGL(k_dseg, dim3((unsigned)dg), dim3(kDsThreads), dlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, dtiles, deadp, reinterpret_cast<unsigned char *>(qwords), slotp, scratch->scr);
+      // (threads: fewer waves that fill the rounds of the all-lane phases better - 448 / 384 / 320 threads for 9 tracks - are SLOWER: G1's k_dseg 84.8 / 92.1 / 93.8 ms
+      //  against 78.3 with 512: the kernel lives on its resident waves, not on its lane-task count; RTFE_DSEG_THREADS for experiments)
+      int dthreads = kDsThreads;
+      if (h->dseg_threads >= 64 && h->dseg_threads <= kDsThreads) dthreads = h->dseg_threads / 64 * 64;
+      hipLaunchKernelGGL(k_dseg, dim3((unsigned)dg), dim3(dthreads), dlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, dtiles, deadp, reinterpret_cast<unsigned char *>(qwords), slotp, scratch->scr);
       t1(kTDseg); }
    else {
       t0(kTQuiet);
