@@ -134,6 +134,8 @@ for i in range(ntapes):
     os.environ["RTFE_SEG_RECS"] = str(rng.choice([128, 128, 32, 16, 1024]))
     if rng.random() < 0.3: os.environ["RTFE_SEG_WARM"] = str(rng.choice([0, 2, 8]))
     else: os.environ.pop("RTFE_SEG_WARM", None)
+    if rng.random() < 0.25: os.environ["RTFE_PK_MAR"] = str(rng.choice([0, 1, 2]))      # (round 5: the walkers trust fewer rows of a record's margin block and make the rest from the samples)
+    else: os.environ.pop("RTFE_PK_MAR", None)
     if os.environ.get("STRESS_ONLY") and int(os.environ["STRESS_ONLY"]) != i:
         if rng.random() < 0.3: rng.choice([8, 24])             # (the draws the dense path's run of a tape makes below: the tapes behind it stay the same)
         continue
