@@ -708,7 +708,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t0(kTEmit);
       hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, (const uint2 *)erefp, ccap,
                          (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks), d_rows, (long long)nrows);
-      hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
+      hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 32), dim3(64), 0, st,      // (a wave per chain at a time: a chain's head and tail hold a few dozen noted events - 256-thread workgroups left three waves of four idle; 40 -> 20 us on C2)
+                         h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
                          (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint2 *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp, d_rows, (long long)nrows);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTEmit);
