@@ -42,7 +42,7 @@ struct rtfe_handle {
    int ev_next, ev_pending;             // the set the next scan records into; sets recorded since rtfe_kernel_ms last looked
    int zeros_kernel;                   // -zeros scans run k_zeros (RTFE_ZEROS_KERNEL=0: k_decode's zero-crossing mode, kept for tests)
    hipStream_t side;                   // the peak path's quiet map -> bursts -> restart rows beside its lists -> streams (both only need k_sift): RTFE_OVERLAP=0 keeps them in line
-   hipEvent_t ev_fork, ev_join;
+   hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2;
    int overlap;
    int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
    int sift_defer;                     // RTFE_SIFT_DEFER=0: k_sift_s stores a tile's lists at the end of its own step (experiments)
@@ -450,7 +450,7 @@ extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
    if (h->timing) timing_free(h);
-   if (h->side) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->side); }
+   if (h->side) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2); (void)hipStreamDestroy(h->side); }
    (void)hipFree(h->d_dev);
    delete h; }
 
@@ -650,7 +650,8 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (h->overlap && stop_after >= 99) {
          if (!h->side) {
             if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; h->overlap = 0; }
-            else { (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming); } }
+            else { (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+                   (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming); } }
          if (h->side) { sa = h->side; (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(sa, h->ev_fork, 0); } }
       t0s(kTBursts, sa);
       hipLaunchKernelGGL(k_qpack, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, sa, (const uint16_t *)qtile, ptiles, qwords, nwords);
@@ -706,11 +707,17 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t1(kTGainTail);
       if (stop_after < 4) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTEmit);
-      hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, (const uint2 *)erefp, ccap,
-                         (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks), d_rows, (long long)nrows);
-      hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 32), dim3(64), 0, st,      // (a wave per chain at a time: a chain's head and tail hold a few dozen noted events - 256-thread workgroups left three waves of four idle; 40 -> 20 us on C2)
+      // the heads' and tails' noted events (k_emit: a wave per chain at a time - a chain's head and tail hold a few dozen) are finished on the side stream
+      // beside the segments' events (k_emit_seg): disjoint parts of the event lists, both only need the chains
+      hipStream_t se = st;
+      if (sa != st) { se = sa; (void)hipEventRecord(h->ev_fork2, st); (void)hipStreamWaitEvent(se, h->ev_fork2, 0); }
+      hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 32), dim3(64), 0, se,
                          h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
                          (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint2 *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp, d_rows, (long long)nrows);
+      if (se != st) (void)hipEventRecord(h->ev_join2, se);
+      hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, (const uint2 *)erefp, ccap,
+                         (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks), d_rows, (long long)nrows);
+      if (se != st) (void)hipStreamWaitEvent(st, h->ev_join2, 0);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
       t1(kTEmit);
       if (stop_after < 5) { skip_rest(); return launch_check("rtfe_scan"); }

@@ -106,7 +106,11 @@ __device__ __forceinline__ long long chain_stop(const DevCfg &cfg, const rtfe_bu
 // ------------------------------------------------------------------------------------------------
 // flags in CRec::w0 bits 0-10 (the tile-relative row of PeakRec::w0 is replaced by the absolute CRec::pos)
 enum { kCrBad = 1,                        // the tile's list is not there (capacity)
-       kCrClear = 2 };                    // a record with a sure stretch (1..62 rows), its minimum known, and no other record's first row at or before the row
+       kCrClear = 2,
+       kCrWeak = 4 };                     // every row of the run has an explicit margin and the largest of them is <= 16 x (bits 3-10): while a chain's rise threshold
+                                          // is above that for sure (rise_lo) no row of the record can pass the rise test (src/decoder.c:790-791 / 800-801) - it is passed over
+                                          // like a record below the amplitude test (what noise wiggles between a screen and the thresholds turn into)
+__device__ __forceinline__ bool crec_weak_dead(uint32_t w0, int rise_lo) { return (w0 & kCrWeak) && (int)(16u * ((w0 >> 3) & 255u)) <= rise_lo; }                    // a record with a sure stretch (1..62 rows), its minimum known, and no other record's first row at or before the row
                                           // its owner leaves the window at (pos + W): whatever fires in it fires before anything else can (k_prep's second pass)
 struct CRec { uint32_t pos, w0, w1; float volt; };
 
@@ -248,6 +252,17 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
          else if (have) {
             CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
             if (w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u && fn != kBadSucc && fn > (long long)c.pos + W) c.w0 |= kCrClear;
+            {  // kCrWeak: no sure row, at most kPkMar rows - all their margins are in the block (first round of the list only: the block came with the record)
+               const int ns = (int)((w0 >> 22) & 63u), nl = (int)((w0 >> 18) & 15u), nt = (int)((w0 >> 28) & 15u);
+               const int nrows_run = ns == 63 ? (nl << 4 | nt) : (ns == 0 ? nl + nt : 99);
+               if (rd == 0 && w1 != 0xffff8000u && nrows_run >= 1 && nrows_run <= kPkMar) {
+                  const uint32_t e0 = cu.m.y >> 16, e1 = cu.m.y & 0xffffu, e2 = cu.m.x >> 16, e3 = cu.m.x & 0xffffu;      // (entry j at block end - 2 (j + 1))
+                  uint32_t M = e0;
+                  if (nrows_run > 1 && e1 > M) M = e1;
+                  if (nrows_run > 2 && e2 > M) M = e2;
+                  if (nrows_run > 3 && e3 > M) M = e3;
+                  const uint32_t mq = (M + 15u) >> 4;
+                  if (mq <= 255u) c.w0 |= kCrWeak | (mq << 3); } }
             crec[o] = c;
             uint2 mk2 = cu.m;
             if (rd > 0) mk2 = *reinterpret_cast<const uint2 *>(slot + 16 * k + 8);
@@ -499,6 +514,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
             const bool top = !(w0 & 0x800u);
             const int a = top ? val : -val;
             if (!(w0 & kCrBad) && cur4.z != 0xffff8000u && amp_on && a <= w.min_lo) return 0;      // below the amplitude test for sure: passed over (see below)
+            if (crec_weak_dead(w0, w.rise_lo)) return 0;                                          // no row can pass the rise test: passed over likewise
             const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
             const float g = w.agc_gain;
             if ((w0 & kCrClear) && c32 <= f && fl < limit32 && w.rise_hi <= S.sure_i && (!amp_on || a >= w.min_hi) && w.nevents < cap && g >= g_min) {
@@ -536,6 +552,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          // (a record whose extreme is below the amplitude test for sure cannot fire while the thresholds stand, and they stand until something
          //  fires - behind which all of this record's rows are blind: it is passed over)
          if (lean && plain && amp_on && a <= w.min_lo) return 0;
+         if (lean && plain && crec_weak_dead(w0, w.rise_lo)) return 0;
          const int fn = idx + 1 < src.iend ? (int)nxt4.x + (int)((nxt4.y >> 12) & 63u) : 0x7fffffff;
          // ---- the fast path: a record with a sure stretch, the countdown over before its first row, the thresholds inside the band the sure
          // level stands for, a clear amplitude, and nothing else that could fire before this record's owner has left the window.  Then it
@@ -812,7 +829,7 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
                   const int val = (int)(int16_t)(r.z & 0xffffu);
                   const bool top = !(w0 & 0x800u);
                   const int a = top ? val : -val;
-                  const bool ampdead = !bad && r.z != 0xffff8000u && amp_on && a <= min_lo;
+                  const bool ampdead = (!bad && r.z != 0xffff8000u && amp_on && a <= min_lo) || crec_weak_dead(w0, rise_hi - 5);      // (rise_lo = rise_hi - 5: the band around the threshold)
                   const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
                   const bool fire = (w0 & kCrClear) && c <= f && fl < limit32 && rise_hi <= sure_i && (!amp_on || a >= min_hi) && g >= g_min;
                   // (h / lastheight for the NEXT fired record, should this one fire: its operands are this record's and the state's - the

@@ -134,7 +134,10 @@ for i in range(ntapes):
     os.environ["RTFE_SEG_RECS"] = str(rng.choice([128, 128, 32, 16, 1024]))
     if rng.random() < 0.3: os.environ["RTFE_SEG_WARM"] = str(rng.choice([0, 2, 8]))
     else: os.environ.pop("RTFE_SEG_WARM", None)
-    if rng.random() < 0.25: os.environ["RTFE_PK_MAR"] = str(rng.choice([0, 1, 2]))      # (round 5: the walkers trust fewer rows of a record's margin block and make the rest from the samples)
+    # (round 5: the walkers trust fewer rows of a record's margin block and make the rest from the samples.  A generator of its own: the tapes of
+    #  a seed stay the tapes earlier rounds' findings are replayed by - test_emulated_dense_path_where_the_sample_path_underflows)
+    rng2 = np.random.default_rng((int(sys.argv[1]) if len(sys.argv) > 1 else 1) * 100003 + i)
+    if rng2.random() < 0.25: os.environ["RTFE_PK_MAR"] = str(rng2.choice([0, 1, 2]))
     else: os.environ.pop("RTFE_PK_MAR", None)
     if os.environ.get("STRESS_ONLY") and int(os.environ["STRESS_ONLY"]) != i:
         if rng.random() < 0.3: rng.choice([8, 24])             # (the draws the dense path's run of a tape makes below: the tapes behind it stay the same)
