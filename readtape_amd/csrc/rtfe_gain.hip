@@ -397,7 +397,9 @@ struct GsSeg {
    long long stop;                   // the record it stopped at (the general step's business), or `end`
    int cnt;                          // events of its own records
    unsigned int evoff;               // k_gain_join: where its first note goes in the chain's event list
-   int stands, pad; };
+   int stands, pad;
+   // what k_emit_seg needs of the chain, with the entry (k_gain writes it at the hand-over): its loads of records and gains start behind ONE read, not behind a chain of three
+   unsigned long long ev_index; long long reset; float h; int sl; };
 __device__ __forceinline__ bool gs_same(const GsState &a, const GsState &b) {
    return __float_as_uint(a.g) == __float_as_uint(b.g) && __float_as_uint(a.vlt) == __float_as_uint(b.vlt) && __float_as_uint(a.vlb) == __float_as_uint(b.vlb)
           && a.c == b.c && a.rise_hi == b.rise_hi && a.min_lo == b.min_lo && a.min_hi == b.min_hi; }
@@ -700,7 +702,8 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
             cs.seg0 = seg0; cs.nseg = nseg;
             for (int sg = 0; sg < nseg; ++sg) {
                GsSeg &o = segs[seg0 + sg];
-               o.chain = ci; o.sidx = sg; o.first = i + (long long)sg * SR; o.end = sg + 1 == nseg ? src.iend : i + (long long)(sg + 1) * SR; o.stands = 0; } }
+               o.chain = ci; o.sidx = sg; o.first = i + (long long)sg * SR; o.end = sg + 1 == nseg ? src.iend : i + (long long)(sg + 1) * SR; o.stands = 0;
+               o.ev_index = (unsigned long long)(ev - events); o.reset = reset; o.h = w.v_avg_height; o.sl = sl; } }
          for (int k = 0; k < 10; ++k) cs.heights[k] = heights[k];
          if (w.v_avg_height > 0) atomicMax(&scratch->min_height_key, 0x7fffffff - (int)__float_as_uint(w.v_avg_height));      // (a chain that is handed over has learned its height)
          if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
@@ -947,18 +950,21 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
       const GsSeg sg = segs[si];
       if ((unsigned)sg.chain >= (unsigned)nchains_max || sg.stands != 1) continue;
       const ChainSt &cs = cst[sg.chain];
-      if (si < cs.seg0 || si >= cs.seg0 + cs.nseg) continue;           // (not an entry its chain wrote: a stale one behind a full table)
+      const int cs_seg0 = cs.seg0, cs_nseg = cs.nseg;                    // (read beside the records: the entry itself says where they are)
       const int b = sg.chain / nwalk;
       const int wi = sg.chain - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
       const DevParm &P = cfg.parm[pidx];
       const int W = P.W, d = cfg.skew[trk];
       MarSrc msrc; msrc.rows = rows; msrc.nrows = nrows; msrc.ntrks = ntrks; msrc.head = cfg.trk_to_head[trk]; msrc.sg = cfg.invert ? -1 : 1; msrc.W = W; msrc.nmar = cfg.pk_mar;
-      const long long reset = ctl[b].reset;
-      rtfe_event *ev = events + cs.k.ev_index;
-      const size_t sb = (size_t)cs.k.sl * ccap;
+      const long long reset = sg.reset;
+      const size_t sb = (size_t)((unsigned)sg.sl < (unsigned)(cfg.nscreens * ntrks) ? sg.sl : 0) * ccap;      // (a stale entry may hold anything: its loads stay inside the streams, its events are not stored)
+      rtfe_event *ev = events + sg.ev_index;
       Walker wk = {};
-      wk.v_avg_height = cs.k.h;
-      const int n_own = (int)(sg.stop - sg.first);
+      wk.v_avg_height = sg.h;
+      // (whatever a stale entry holds, the speculative loads stay inside the stream and the gains' table)
+      const long long seg_first = sg.first < 0 ? 0 : (sg.first > ccap - S ? (ccap > S ? ccap - S : 0) : sg.first);
+      const long long n_own_l = sg.stop - sg.first;
+      const int n_own = n_own_l < 0 ? 0 : (n_own_l > S ? S : (int)n_own_l);
       unsigned int at = sg.evoff;
       // (a lane's gain, record and margin block for up to kEsAhead rounds of 64 records are loaded TOGETHER and whether the record fired or not -
       //  93 % do: one round trip per batch instead of two dependent ones per round; the kernel waits for memory 85 % of its time)
@@ -970,8 +976,9 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
             const int k = k0 + 64 * u + lane;
             gain[u] = 0.0f; rec[u].pos = 0; rec[u].w0 = 0; rec[u].w1 = 0; rec[u].volt = 0; mar[u] = make_uint2(0, 0);
             if (k < n_own) {
-               const size_t ri = sb + (size_t)(sg.first + k);
+               const size_t ri = sb + (size_t)(seg_first + k);
                gain[u] = gfire[(size_t)si * S + k]; rec[u] = crec[ri]; mar[u] = cmar[ri]; } }
+         if (si < cs_seg0 || si >= cs_seg0 + cs_nseg) break;              // (not an entry its chain wrote: a stale one behind a full table)
          #pragma unroll
          for (int u = 0; u < kEsAhead; ++u) {
             if (k0 + 64 * u >= n_own) break;
