@@ -216,8 +216,9 @@ class Workload:
         # roofline line needs).  --pipeline alternates two front-end contexts (own HIP stream, workspace and outputs) so that
         # the latency-bound sequential pass of step i overlaps the dense pass of step i+1.
         if pipeline and self.cuda:
-            self.fes = [self.fe, make()]
-            self.streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            nctx = max(2, int(os.environ.get("RT_BENCH_CONTEXTS", "2")))
+            self.fes = [self.fe] + [make() for _ in range(nctx - 1)]
+            self.streams = [torch.cuda.Stream(dev) for _ in range(nctx)]
         else:
             self.fes = [self.fe, self.fe]
             self.streams = [torch.cuda.current_stream(dev)] * 2 if self.cuda else [None, None]
@@ -245,7 +246,7 @@ class Workload:
 
     def step(self, i, timed=False, each=None):
         import contextlib
-        s, f = self.streams[i & 1], self.fes[i & 1]
+        s, f = self.streams[i % len(self.streams)], self.fes[i % len(self.fes)]
         with (self.torch.cuda.stream(s) if self.cuda else contextlib.nullcontext()):
             # the seam halo is the only exchange: neighbour isend/irecv over RCCL (xGMI), no collective on the data path
             self.shard.exchange_halo(self.sr, self.halo_rows, self.rank, self.world, self.dist, lens=self.lens)
@@ -281,7 +282,7 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
             calibrated = min(4.0, 0.5 * st0["min_learned_height"])
             for f in set(wl.fes): f.close()
             wl.cfg.screen_floor_height = calibrated
-            wl.fe = wl.make(); wl.fes = [wl.fe, wl.make() if overlap else wl.fe]
+            wl.fe = wl.make(); wl.fes = [wl.fe] + [wl.make() if overlap else wl.fe for _ in range(len(wl.streams) - 1)]
             for f in set(wl.fes): f.set_timing(True)
             cfg, fe = wl.cfg, wl.fe
     for i in range(warmup):
