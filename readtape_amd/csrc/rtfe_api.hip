@@ -97,6 +97,9 @@ static int sf_threads(const DevCfg &d) { return 64 * ((d.ntrks + 1) / 2); }
 static int sf_nvec(const DevCfg &d) { return (d.pk_hl + kSfTile + d.pk_hr) * d.ntrks / 8; }
 static int sf_nv(const DevCfg &d) { return (sf_nvec(d) + sf_threads(d) - 1) / sf_threads(d); }
 static sfs_kernel_t sf_special(const DevCfg &d) { return (d.nscreens == 1 && d.screen[0].sure_i <= 32767 && !getenv("RTFE_SIFT_GENERIC")) ? sfs_kernel(d.screen[0].W, d.ntrks) : nullptr; }
+// k_sift_s has a geometry of its own: a wave per pair of heads with an odd last head's tile split among them, only the window's rows in front of a tile
+static int sfs_threads(const DevCfg &d) { return 64 * sfs_waves(d.ntrks); }
+static int sfs_lds(const DevCfg &d) { return (int)sfs_lds_layout(d.ntrks, d.screen[0].W, d.pk_wave_cap, d.pk_slot).total + 64; }
 
 extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
@@ -398,13 +401,14 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (d.invert || d.maxskew > 0 || d.ntrks < 2 || d.zc_peak_i < 1 || d.zc_peak_i > 32767 || !d.zc_parallel) h->zeros_kernel = 0;      // (RTFE_ZC_PARALLEL=0: k_decode's sequential walk, for the tests)
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
       raise_dynamic_lds(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), d.pk_lds);
-      if (sf_special(d)) raise_dynamic_lds(reinterpret_cast<const void *>(sf_special(d)), d.pk_lds); }
+      if (sf_special(d)) raise_dynamic_lds(reinterpret_cast<const void *>(sf_special(d)), sfs_lds(d)); }
    if (d.dense_path) raise_dynamic_lds(reinterpret_cast<const void *>(k_dseg), (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, d.ds_up).total + 64);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    if (getenv("RTFE_VERBOSE") && d.peak_path) {
       int nb = -1;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sf_special(d) ? reinterpret_cast<const void *>(sf_special(d)) : reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), sf_threads(d), (size_t)d.pk_lds);
-      fprintf(stderr, "rtfe: k_sift%s %d threads, %d bytes of LDS: %d workgroups per CU (occupancy API), %d CUs\n", sf_special(d) ? "_s" : "", sf_threads(d), d.pk_lds, nb, h->num_cus); }
+      const int thr = sf_special(d) ? sfs_threads(d) : sf_threads(d), lds = sf_special(d) ? sfs_lds(d) : d.pk_lds;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sf_special(d) ? reinterpret_cast<const void *>(sf_special(d)) : reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), thr, (size_t)lds);
+      fprintf(stderr, "rtfe: k_sift%s %d threads, %d bytes of LDS: %d workgroups per CU (occupancy API), %d CUs\n", sf_special(d) ? "_s" : "", thr, lds, nb, h->num_cus); }
    *out = h;
    return 0; }
 
@@ -622,21 +626,22 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       (void)hipMemsetAsync(wsb + ws_pkextra_off(h, nrows), 0, pk_extra_bytes(h, nrows), st);
       const int stop_after = getenv("RTFE_PEAK_STOP") ? atoi(getenv("RTFE_PEAK_STOP")) : 99;      // (debugging: launch only the first n kernels of the path)
       t0(kTSift);
-      const int pthreads = sf_threads(h->dev);
-      int spc = (160 * 1024) / (h->dev.pk_lds + 512);
+      const sfs_kernel_t sfs = sf_special(h->dev);
+      const int pthreads = sfs ? sfs_threads(h->dev) : sf_threads(h->dev), plds = sfs ? sfs_lds(h->dev) : h->dev.pk_lds;
+      int spc = (160 * 1024) / (plds + 512);
       if (spc * (pthreads / 64) > 32) spc = 32 / (pthreads / 64);
       if (const char *e = getenv("RTFE_SIFT_WGS")) { const int v = atoi(e); if (v >= 1 && v < spc) spc = v; }
       if (spc < 1) spc = 1;
       long long pgrid = (long long)h->num_cus * spc;
       if (pgrid > ptiles) pgrid = ptiles;
       uint16_t *qtile = reinterpret_cast<uint16_t *>(wsb + ws_pkqtile_off(h, nrows));
-      if (const sfs_kernel_t sfs = sf_special(h->dev)) {
+      if (sfs) {
          SfArgs a;
          a.rows = d_rows; a.nrows = nrows; a.ntiles = (int)ptiles; a.qtile = qtile; a.dir = dirm; a.pool = pkpool; a.hard = hardp; a.hard_cap = hard_cap;
          a.hard_count = &scratch->hard_count; a.dbg = scratch->scr; a.hcap = h->dev.pk_slot; a.wave_cap = h->dev.pk_wave_cap; a.invert = h->dev.invert;
          a.quiet_i = h->dev.quiet_i; a.lo_i = h->dev.screen[0].rise_i; a.hi_i = h->dev.screen[0].sure_i; a.minpk_i = h->dev.screen[0].minpk_i;
          a.cut = h->dev.cut; a.debug = h->dev.debug; a.defer = h->sift_defer;
-         hipLaunchKernelGGL(sfs, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, a); }
+         hipLaunchKernelGGL(sfs, dim3((unsigned)pgrid), dim3(pthreads), plds, st, a); }
       else {
          const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev));
          hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,

@@ -120,6 +120,33 @@ __host__ __device__ inline SfLds sf_lds_layout(int ntrks, int hl, int hr, int wa
    L.total = (o + 15) & ~15u;
    return L; }
 
+// k_sift_s on an odd track count (nine- and seven-track tapes): a wave per PAIR of heads left the last head a wave of its own whose packed
+// arithmetic ran half empty and whose round of owner derivations had a third of its lanes at work.  The last head's tile is SPLIT into one
+// part per pair wave instead (NT / 2 waves, each: its pair over the whole tile + 1 / (NT / 2) of the last head's rows); the part's candidates
+// join the wave's list and fill lanes of its rounds that idled anyway.
+#ifndef RTFE_SFS_SPLIT
+#define RTFE_SFS_SPLIT 1
+#endif
+__host__ __device__ constexpr bool sfs_split(int nt) { return RTFE_SFS_SPLIT && (nt & 1) && nt >= 5; }
+__host__ __device__ constexpr int sfs_waves(int nt) { return sfs_split(nt) ? nt / 2 : (nt + 1) / 2; }
+__host__ __device__ constexpr int sfs_part_strip(int nt) { return ((kSfTile + sfs_waves(nt) - 1) / sfs_waves(nt) + 63) / 64; }                 // rows of the last head a lane screens
+__host__ __device__ constexpr int sfs_part_rows(int nt) { return ((kSfTile + sfs_waves(nt) - 1) / sfs_waves(nt) + sfs_part_strip(nt) - 1) / sfs_part_strip(nt) * sfs_part_strip(nt); }      // ... a wave
+__host__ __device__ constexpr int sfs_hl(int w) { return (w + 7) & ~7; }            // rows in front of the tile k_sift_s reads: the window (the general walk's look-back is k_sift_hard's business)
+__host__ __device__ constexpr int sfs_hr(int w) { return (w + 2 + 7) & ~7; }
+__host__ __device__ inline int sfs_part_cap(int nt, int hcap) { return (hcap / sfs_waves(nt) + 64 + 15) & ~15; }      // bytes of a wave's part of the last head's staging slot
+// ONE definition for the kernel and for the host's sizing: [pair waves][wave_cap] candidates; the pairs' slots, then - split - the parts of the last head's
+struct SfsLds { unsigned xs, wl, stage, part, total; };
+__host__ __device__ inline SfsLds sfs_lds_layout(int ntrks, int w, int wave_cap, int hcap) {
+   SfsLds L;
+   const int nw = sfs_waves(ntrks);
+   unsigned o = 0;
+   L.xs = o;    o += (unsigned)(sfs_hl(w) + kSfTile + sfs_hr(w)) * (unsigned)(ntrks * 2) + 32;  o = (o + 15) & ~15u;
+   L.wl = o;    o += (unsigned)nw * wave_cap * 2;  o = (o + 15) & ~15u;
+   L.stage = o; o += (unsigned)(sfs_split(ntrks) ? ntrks - 1 : ntrks) * hcap;
+   L.part = o;  if (sfs_split(ntrks)) o += (unsigned)nw * sfs_part_cap(ntrks, hcap);
+   L.total = (o + 15) & ~15u;
+   return L; }
+
 template <class TileT> struct PkCtxT {
    TileT t;
    int W, lo_i, hi_i;            // window, screen threshold (margin > lo_i), sure threshold (margin >= hi_i)
@@ -680,17 +707,20 @@ struct SfArgs {
 };
 
 template <int W, int NT, int WPS>
-__global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArgs a) {
+__global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs a) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;
 #else
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
    __shared__ unsigned int s_noisy[2];
-   constexpr int NP = (NT + 1) / 2, NTH = 64 * NP, RB = 2 * NT;
-   constexpr int HL = (kPkBack + 2 * W + 6 + 7) & ~7, HR = (W + 2 + 7) & ~7;
+   __shared__ unsigned short s_part[2][8];                               // split: records in each wave's part of the last head's list (0xffff: the list is unavailable), by tile parity
+   constexpr bool SPL = sfs_split(NT);
+   constexpr int NP = sfs_waves(NT), NTH = 64 * NP, RB = 2 * NT;
+   constexpr int HL = sfs_hl(W), HR = sfs_hr(W);
    constexpr int NVEC = (HL + kSfTile + HR) * NT / 8, VPG = 8 * NT, VOWN0 = HL * NT / 8, NQ = kSfGroups * VPG;
    constexpr int NV = (NVEC + NTH - 1) / NTH, NQIT = (NQ + NTH - 1) / NTH;
+   constexpr int H3 = NT - 1, R3 = sfs_part_strip(NT), PR3 = sfs_part_rows(NT), LA3 = PR3 / R3;      // split: the last head, rows a lane / a wave screens of it, lanes at work
    const int tid = threadIdx.x, lane = tid & 63;
 #ifdef RTFE_CPU_EMUL
    const int wave = tid >> 6;
@@ -698,7 +728,8 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
    const int hcap = a.hcap, wave_cap = a.wave_cap, cut = a.cut;
-   const SfLds L = sf_lds_layout(NT, HL, HR, wave_cap, hcap);
+   const int cap3 = sfs_part_cap(NT, hcap);
+   const SfsLds L = sfs_lds_layout(NT, W, wave_cap, hcap);
    unsigned char *xs = smem + L.xs;
    const lds_p xsl = to_lds(xs);
    PkCtx cx;
@@ -718,6 +749,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
    const bool has_hi = h_hi < NT;
    const lds_u16p wlist = reinterpret_cast<lds_u16p>(to_lds(smem + L.wl)) + wave * wave_cap;
    const lds_p slot_lo = to_lds(smem + L.stage) + h_lo * hcap, slot_hi = slot_lo + hcap;
+   const lds_p slot_3 = to_lds(smem + L.part) + wave * cap3;
    const uint32_t at = a.minpk_i < 0 ? pk_dup(-32768) : pk_dup(a.minpk_i), ab = a.minpk_i < 0 ? pk_dup(32767) : pk_dup(-a.minpk_i);
    const uint32_t qpk = pk_dup(a.quiet_i), q2 = 2u * (uint32_t)a.quiet_i;
    int4 q[NV];
@@ -751,7 +783,27 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
          if (lane == 0) {
             PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
             a.dir[(size_t)tile * NT + h] = d; } } };
+   // split: the last head's list is the waves' parts one behind the other.  Every wave copies its own part once all counts are known: behind the
+   // workgroup barrier that ends the tile's step, i.e. at the start of the next one (or behind the loop).
+   auto copy_out3 = [&](const int tile, const int pp) {
+      int off = 0, tot = 0;
+      bool over = false;
+      #pragma unroll
+      for (int w2 = 0; w2 < NP; ++w2) {
+         const int c = s_part[pp][w2];
+         over = over || c == 0xffff;
+         tot += c; if (w2 < wave) off += c; }
+      over = over || 16 * tot > hcap;
+      const int mine = s_part[pp][wave];
+      unsigned char *gslot = a.pool + ((size_t)tile * NT + H3) * (size_t)hcap;
+      if (!over && cut != 6) {
+         const int4 *src = reinterpret_cast<const int4 *>(smem + L.part + wave * cap3);
+         for (int v = lane; v < mine; v += 64) reinterpret_cast<int4 *>(gslot)[off + v] = src[v]; }
+      if (wave == 0 && lane == 0) {
+         PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)tot; d.nent = 0;
+         a.dir[(size_t)tile * NT + H3] = d; } };
    for (int tile = tile_lo; tile < ntiles; tile += G, par ^= 1) {
+      const int prev_tile = last_tile;
       last_tile = tile;
       const long long lastl = a.nrows - 1 - (long long)tile * kSfTile;
       cx.last = lastl > 0x3fffffff ? 0x3fffffff : (int)lastl;
@@ -764,6 +816,7 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
       if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G);
       if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
       if (p_tile >= 0) { copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad); p_tile = -1; rtfe_wave_sync(); }      // (the lists of the tile in front: a.defer)
+      if (SPL && prev_tile >= 0 && cut != 1) { copy_out3(prev_tile, par ^ 1); rtfe_wave_sync(); }
       // ---- 2. quiet groups: flat 16-byte reads of the tile proper; a ballot of 64 vectors lies in one or two groups ----
       #pragma unroll
       for (int it = 0; it < NQIT; ++it) {
@@ -804,37 +857,67 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                const int keep = cx.last + 1 - kSfStrip * lane;
                const uint32_t mk = keep >= kSfStrip ? 0x3fffu : (keep <= 0 ? 0u : ((1u << keep) - 1u));
                tm &= mk | (mk << 16); bm &= mk | (mk << 16); } }
+         // split: the same for this wave's part of the last head - R3 rows a lane, the sample in the low half of the packed operations
+         uint32_t m3 = 0, b3 = 0;                                             // candidates / the bottoms among them, bit i = row r3 + i
+         const int r3 = wave * PR3 + R3 * (lane < LA3 ? lane : LA3 - 1);
+         if (SPL) {
+            const lds_cp base = xsl + (HL + r3) * RB + 2 * H3;
+            uint32_t x[R3 + 2];
+            #pragma unroll
+            for (int i = 0; i < R3 + 2; ++i) x[i] = (uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB);
+            uint32_t yc = pk_max(x[1], at), zc = pk_min(x[1], ab);
+            uint32_t uy = pk_subs(pk_max(x[0], at), yc), dz = pk_subs(zc, pk_min(x[0], ab));
+            uint32_t t3 = 0;
+            #pragma unroll
+            for (int i = 0; i < R3; ++i) {
+               const uint32_t yn = pk_max(x[i + 2], at), zn = pk_min(x[i + 2], ab);
+               const uint32_t uyn = pk_subs(yc, yn), dzn = pk_subs(zn, zc);
+               t3 = (t3 >> 1) | (uy & ~uyn & 0x8000u);
+               b3 = (b3 >> 1) | (dz & ~dzn & 0x8000u);
+               yc = yn; zc = zn; uy = uyn; dz = dzn; }
+            t3 >>= 16 - R3; b3 >>= 16 - R3;
+            if (a.invert) { const uint32_t s2 = t3; t3 = b3; b3 = s2; }
+            int keep = kSfTile - r3;                                          // the part's last lanes reach into the next tile (seven tracks) or behind the tape's end
+            if (cx.last + 1 - r3 < keep) keep = cx.last + 1 - r3;
+            if (lane >= LA3) keep = 0;
+            const uint32_t mk = keep >= R3 ? (1u << R3) - 1u : (keep <= 0 ? 0u : ((1u << keep) - 1u));
+            m3 = (t3 | b3) & mk; b3 &= mk; }
          // ---- 4. the wave's candidates, compacted into a list ordered by (head, row); rounds of 64 ----
-         int rec_lo = 0, rec_hi = 0;                                           // records in this wave's two lists
+         int rec_lo = 0, rec_hi = 0, rec_3 = 0;                                // records in this wave's lists
          bool bad = false;
          if (cut != 2) {
             uint32_t mlo = (tm | bm) & 0xffffu, mhi = (tm | bm) >> 16;
-            const int cnt = __popc(mlo) | (__popc(mhi) << 16);
+            const int cnt = __popc(mlo) | (__popc(mhi) << 10) | (__popc(m3) << 20);      // (a head's 896 rows hold fewer than 1 024 extrema)
             const int incl = wave_incl_scan(cnt, lane);
             const int totc = wave_last(incl);
-            const int n_lo = totc & 0xffff, ncw = n_lo + (totc >> 16);
+            const int n_lo = totc & 0x3ff, n_hi = (totc >> 10) & 0x3ff, ncw = n_lo + n_hi + (totc >> 20);
             bad = ncw > wave_cap;
             if (!bad && ncw > 0) {
                const int excl = incl - cnt;
-               int o2 = excl & 0xffff;
+               int o2 = excl & 0x3ff;
                for (; mlo; mlo &= mlo - 1) { const int b2 = __ffs((int)mlo) - 1; wlist[o2++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> b2) & 1u) << 14)); }
-               o2 = n_lo + (excl >> 16);
+               o2 = n_lo + ((excl >> 10) & 0x3ff);
                for (; mhi; mhi &= mhi - 1) { const int b2 = __ffs((int)mhi) - 1; wlist[o2++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> (16 + b2)) & 1u) << 14) | 0x8000u); }
+               if (SPL) {
+                  o2 = n_lo + n_hi + (excl >> 20);
+                  for (; m3; m3 &= m3 - 1) { const int b2 = __ffs((int)m3) - 1; wlist[o2++] = (uint16_t)((r3 + b2) | (((b3 >> b2) & 1u) << 14) | 0x2000u); } }
                rtfe_wave_sync();
                #pragma nounroll
                for (int r0 = 0; r0 < (cut == 3 ? 0 : ncw); r0 += 64) {
                   const int i = r0 + lane;
                   const bool live = i < ncw;
                   const uint32_t cd = live ? wlist[i] : 0u;
-                  const int half = (int)(cd >> 15), cpos = (int)(cd & 0x3ffu);
+                  const int sel = SPL && (cd & 0x2000u) ? 2 : (int)(cd >> 15);      // the pair's lower / upper head, the last head's part
+                  const int cpos = (int)(cd & 0x3ffu);
+                  const int head = sel == 2 ? H3 : h_lo + sel;
                   const bool cbot = (cd >> 14) & 1u;
                   uint32_t w0 = 0, w1 = 0;
-                  int st = pk_fast_w<W>(cx, half ? h_hi : h_lo, cpos, cbot, w0, w1);
+                  int st = pk_fast_w<W>(cx, head, cpos, cbot, w0, w1);
                   if (!live) st = 0;
                   if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
                      const int hidx = atomicAdd(a.hard_count, 1);
                      if (hidx < a.hard_cap) {
-                        SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)(half ? h_hi : h_lo); hd.screen = 0;
+                        SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)head; hd.screen = 0;
                         a.hard[hidx] = hd;
                         w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
                      else { w0 = pk_w0(cpos, false, cpos + 1, 0, cx.W - 2, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
@@ -842,23 +925,25 @@ __global__ void __launch_bounds__(64 * ((NT + 1) / 2), WPS) k_sift_s(const SfArg
                   if (a.debug == 3) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
                   if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
                   const int vr = st;
-                  const int sh = 16 * half;
+                  const int sh = 8 * sel;                                      // (a round adds at most 64 to a list)
                   const int ir = wave_incl_scan(vr << sh, lane);
-                  const int myr = (((ir >> sh) & 0xffff) - vr) + (half ? rec_hi : rec_lo);
-                  if (vr && 16 * (myr + 1) <= hcap) {                         // 16 bytes: the record, its margin block behind it
-                     const lds_p slot = half ? slot_hi : slot_lo;
+                  const int myr = (((ir >> sh) & 0xff) - vr) + (sel == 2 ? rec_3 : (sel ? rec_hi : rec_lo));
+                  if (vr && 16 * (myr + 1) <= (sel == 2 ? cap3 : hcap)) {      // 16 bytes: the record, its margin block behind it
+                     const lds_p slot = sel == 2 ? slot_3 : (sel ? slot_hi : slot_lo);
                      lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 4 * myr;
-                     const uint2 mb = (cut == 5 || (w1 & 0xfffffffeu) == 0xffff8000u) ? make_uint2(0, 0) : pk_margins_w<W>(cx, half ? h_hi : h_lo, cpos, cbot, w0);
+                     const uint2 mb = (cut == 5 || (w1 & 0xfffffffeu) == 0xffff8000u) ? make_uint2(0, 0) : pk_margins_w<W>(cx, head, cpos, cbot, w0);
                      rp[0] = w0; rp[1] = w1; rp[2] = mb.x; rp[3] = mb.y; }
                   const int tr = wave_last(ir);
-                  rec_lo += tr & 0xffff; rec_hi += (tr >> 16) & 0xffff; } } }
-         // ---- 5. this wave's two lists leave (now, or - a.defer - at the start of the next tile step) ----
+                  rec_lo += tr & 0xff; rec_hi += (tr >> 8) & 0xff; rec_3 += (tr >> 16) & 0xff; } } }
+         // ---- 5. this wave's two lists leave (now, or - a.defer - at the start of the next tile step); its part of the last head's waits for the others' counts ----
          rtfe_wave_sync();
+         if (SPL && lane == 0) s_part[par][wave] = (unsigned short)((bad || 16 * rec_3 > cap3) ? 0xffff : rec_3);
          if (a.defer) { p_tile = tile; p_rec_lo = rec_lo; p_rec_hi = rec_hi; p_bad = bad; }
          else copy_out(tile, rec_lo, rec_hi, bad);
          rtfe_wave_sync(); }
       __syncthreads(); }
    if (p_tile >= 0) copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad);
+   if (SPL && last_tile >= 0 && cut != 1) copy_out3(last_tile, par ^ 1);
    if (tid == 0 && last_tile >= 0) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);
    if (a.debug == 3 && lane == 0) {
       atomicAdd(&a.dbg[3], (unsigned long long)pn_bytes); atomicAdd(&a.dbg[4], (unsigned long long)pn_hard); atomicAdd(&a.dbg[5], (unsigned long long)pn_rounds);
