@@ -38,7 +38,7 @@ extern "C" {
 
 #define RTFE_MAXTRKS     19   /* src/csvtbin.h:29  MAXTRKS      */
 #define RTFE_MAXPARMSETS 15   /* src/decoder.h:92  MAXPARMSETS  */
-#define RTFE_ABI_VERSION 3   /* 3: rtfe_scan_stats out[21] = the smallest learned peak height (screen-floor calibration); 2: rtfe_kernel_ms returns the number of scans summed; twelve timed spans (k_dseg, k_dchain) */
+#define RTFE_ABI_VERSION 4   /* 4: rtfe_pack_events; 3: rtfe_scan_stats out[21] = the smallest learned peak height (screen-floor calibration); 2: rtfe_kernel_ms returns the number of scans summed; twelve timed spans (k_dseg, k_dchain) */
 
 enum { RTFE_PE = 1, RTFE_NRZI = 2, RTFE_GCR = 4, RTFE_WW = 8 };      /* enum mode_t, src/csvtbin.h:47-49 */
 
@@ -163,6 +163,22 @@ int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_
                     void *d_workspace, size_t workspace_bytes,
                     rtfe_burst *d_burst, uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,
                     void *stream);
+
+/* The event lists of a scan, packed on the device (what crosses PCIe to the host replay: the arena is laid out for the worst case, event_cap
+ * records per list; the lists hold a fraction of it).  Queued on `stream` behind the rtfe_scan whose outputs it reads:
+ *   d_plan[b], b < *d_nbursts: burst b's lists in d_packed under the burst table's own addressing rule -
+ *     d_packed[plan.event_base + (p * ntrks + t) * plan.event_cap + i], plan.event_cap = the burst's longest list (>= 1);
+ *   d_plan[*d_nbursts].event_base = records of d_packed in use (.reserved = the burst count the plan was made for).  If that exceeds
+ *     packed_capacity nothing was copied: fetch the arena as it is, or pack again into a larger buffer.
+ * d_plan holds max_bursts + 1 entries.  The scan's own outputs are not changed. */
+typedef struct rtfe_pack_entry { uint64_t event_base; uint32_t event_cap; uint32_t reserved; } rtfe_pack_entry;      /* 16 bytes */
+int rtfe_pack_events(rtfe_handle *h, const rtfe_burst *d_bursts, const int32_t *d_nbursts, int64_t max_bursts, const uint32_t *d_counts,
+                     const rtfe_event *d_events, rtfe_event *d_packed, uint64_t packed_capacity, rtfe_pack_entry *d_plan, void *stream);
+
+/* The end of the data inside a window of the payload: *d_first = the first row of d_rows[0 .. nrows) whose head-0 sample is 0x8000 (the reader of
+ * src/readtape.c:1410 stops there), INT64_MAX if there is none.  Queued on `stream`; a streaming reader runs it behind a window's upload instead of
+ * passing over the window on the host. */
+int rtfe_find_end_mark(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t *d_first, void *stream);
 
 /* Per-kernel timing: with enable != 0, rtfe_scan records HIP events on `stream` around each of its timed spans (rtfe_kernel_name), one
  * set of events per scan in a ring of 64 sets - nothing waits, so scans queued back to back stay back to back.  rtfe_kernel_ms synchronises

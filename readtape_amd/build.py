@@ -30,7 +30,7 @@ def _newer(target, deps):
 
 def build_frontend(force=False, verbose=False):
     out = os.path.join(HERE, "librtfe.so")
-    deps = [os.path.join(CSRC, f) for f in ("rtfe_api.hip", "rtfe_kernels.hip", "rtfe_zeros.hip", "rtfe_ww.hip", "rtfe_sift.hip", "rtfe_gain.hip", "rtfe_dense.hip", "rtfe_pk.h", "rtfe_device.h")] + [os.path.join(ROOT, "include", "rt_frontend.h")]
+    deps = [os.path.join(CSRC, f) for f in ("rtfe_api.hip", "rtfe_kernels.hip", "rtfe_zeros.hip", "rtfe_ww.hip", "rtfe_sift.hip", "rtfe_gain.hip", "rtfe_dense.hip", "rtfe_pack.hip", "rtfe_pk.h", "rtfe_device.h")] + [os.path.join(ROOT, "include", "rt_frontend.h")]
     if force or _newer(out, deps):
         cmd = [HIPCC] + HIP_FLAGS + os.environ.get("RTFE_EXTRA_HIPFLAGS", "").split() + ["-o", out, os.path.join(CSRC, "rtfe_api.hip")]
         if verbose:

@@ -18,6 +18,7 @@
 #include "rtfe_ww.hip"
 #include "rtfe_gain.hip"
 #include "rtfe_dense.hip"
+#include "rtfe_pack.hip"
 
 namespace rtfe {
 __global__ void k_setup_exact(rtfe_burst *burst, BurstScratch *scratch, long long reset_row, long long end_row,
@@ -803,6 +804,30 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
    return launch_check("rtfe_scan"); }
 
 // Synchronous (copies three words back): what the last rtfe_scan on this workspace did.
+extern "C" int rtfe_pack_events(rtfe_handle *h, const rtfe_burst *d_bursts, const int32_t *d_nbursts, int64_t max_bursts, const uint32_t *d_counts,
+                                const rtfe_event *d_events, rtfe_event *d_packed, uint64_t packed_capacity, rtfe_pack_entry *d_plan, void *stream) {
+   if (!h || !d_bursts || !d_nbursts || !d_counts || !d_events || !d_packed || !d_plan || max_bursts < 1) return fail(-2, "rtfe_pack_events: null argument");
+   hipStream_t st = (hipStream_t)stream;
+   const int lists = h->cfg.nparmsets * h->cfg.ntrks;
+   hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(1024), 0, st, d_bursts, d_nbursts, (long long)max_bursts, d_counts, lists, d_plan);
+   hipLaunchKernelGGL(k_pack_copy, dim3((unsigned)(h->num_cus * 8)), dim3(256), 0, st, d_bursts, d_nbursts, (long long)max_bursts, d_counts, lists, (const rtfe_pack_entry *)d_plan,
+                      reinterpret_cast<const uint4 *>(d_events), reinterpret_cast<uint4 *>(d_packed), (unsigned long long)packed_capacity);
+   const hipError_t e = hipGetLastError();
+   if (e != hipSuccess) return fail(-30, "rtfe_pack_events: %s", hipGetErrorString(e));
+   return 0; }
+
+extern "C" int rtfe_find_end_mark(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t *d_first, void *stream) {
+   if (!h || !d_rows || !d_first || nrows < 0) return fail(-2, "rtfe_find_end_mark: bad argument");
+   hipStream_t st = (hipStream_t)stream;
+   hipLaunchKernelGGL(k_end_mark_init, dim3(1), dim3(1), 0, st, reinterpret_cast<long long *>(d_first));
+   if (nrows > 0) {
+      long long blocks = (nrows + 255) / 256;
+      if (blocks > (long long)h->num_cus * 16) blocks = (long long)h->num_cus * 16;
+      hipLaunchKernelGGL(k_end_mark, dim3((unsigned)blocks), dim3(256), 0, st, d_rows, (long long)nrows, h->cfg.ntrks, reinterpret_cast<long long *>(d_first)); }
+   const hipError_t e = hipGetLastError();
+   if (e != hipSuccess) return fail(-30, "rtfe_find_end_mark: %s", hipGetErrorString(e));
+   return 0; }
+
 extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out) {
    if (!h || !d_workspace || !out) return fail(-1, "null argument");
    BurstScratch sc;

@@ -27,7 +27,8 @@ EVENT_DTYPE = np.dtype([("sample", "<u4"), ("v_peak", "<f4"), ("agc_gain", "<f4"
                         ("flags", "u1"), ("left_distance", "u1"), ("parmset", "u1")])
 BURST_DTYPE = np.dtype([("zone_first", "<i8"), ("zone_end", "<i8"), ("reset_sample", "<i8"), ("safe_last", "<i8"),
                         ("end_sample", "<i8"), ("event_base", "<u8"), ("event_cap", "<u4"), ("flags", "<u4")])
-assert EVENT_DTYPE.itemsize == 16 and BURST_DTYPE.itemsize == 56
+PLAN_DTYPE = np.dtype([("event_base", "<u8"), ("event_cap", "<u4"), ("reserved", "<u4")])      # rtfe_pack_entry
+assert EVENT_DTYPE.itemsize == 16 and BURST_DTYPE.itemsize == 56 and PLAN_DTYPE.itemsize == 16
 
 
 class _Parmset(C.Structure):
@@ -166,28 +167,34 @@ class TorchBackend:
         assert t.dtype == self.torch.int16 and t.is_contiguous() and t.is_cuda
         return t
 
+    def _host(self, t):
+        """The tensor on the host.  Large ones through page-locked memory (PyTorch's caching host allocator: power-of-two blocks, reused), on the
+        current stream: a pageable destination goes through the runtime's staging buffers at a third of the rate."""
+        if t.numel() * t.element_size() < (1 << 12):
+            return t.cpu()
+        h = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return h
+
     def to_numpy(self, t, dtype, count=None):
-        a = t.cpu().numpy().view(dtype)
+        a = self._host(t).numpy().view(dtype)
         return a if count is None else a[:count]
 
-    def gather_lists(self, events_u8, base, cap, cap2, nlists, dtype):
-        """Packs every burst's `nlists` event lists (cap[b] records apart in the arena, from base[b]) to cap2[b] records each, burst
-        after burst, on the device, and returns the packed records on the host.  (Index arithmetic and one index_select: plumbing.)"""
+    def pinned(self, nbytes):
+        return self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, pin_memory=True)
+
+    def mirror_async(self, host, pieces, stream_handle):
+        """Device buffers -> consecutive slices of the page-locked tensor `host`, queued on the stream (behind the scan that fills them): the tables
+        are on the host when the scan's event fires - a copy issued by the fetching thread later would queue behind the next windows' uploads."""
         torch = self.torch
-        rec = dtype.itemsize // 4
-        ev = events_u8.view(torch.int32).view(-1, rec)
-        n_b = nlists * cap2
-        total = int(n_b.sum())
-        dev = self.device
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev, non_blocking=True)
-        d_base, d_cap, d_cap2, d_nb, d_off = t(base), t(cap), t(cap2), t(n_b), t(np.cumsum(n_b) - n_b)
-        b = torch.repeat_interleave(torch.arange(len(n_b), device=dev), d_nb, output_size=total)
-        e = torch.arange(total, device=dev) - d_off[b]
-        c2 = d_cap2[b]
-        lst = torch.div(e, c2, rounding_mode="floor")
-        src = d_base[b] + lst * d_cap[b] + (e - lst * c2)
-        out = ev.index_select(0, src)
-        return out.cpu().numpy().view(dtype).reshape(-1)
+        st = torch.cuda.current_stream(self.device) if stream_handle is None else torch.cuda.ExternalStream(int(stream_handle), device=self.device)
+        with torch.cuda.stream(st):
+            off = 0
+            for t in pieces:
+                n = t.numel()
+                host[off: off + n].copy_(t, non_blocking=True)
+                off += n
 
     def upload(self, t, host_bytes):
         t[: len(host_bytes)].copy_(self.torch.frombuffer(bytearray(host_bytes), dtype=self.torch.uint8))
@@ -233,9 +240,11 @@ def _load_library(path=None):
     lib.rtfe_ww_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.rtfe_scan_stats.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.rtfe_find_end_mark.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.rtfe_pack_events.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.rtfe_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rtfe_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-    if lib.rtfe_abi_version() != 3:
+    if lib.rtfe_abi_version() != 4:
         raise RuntimeError("librtfe.so ABI mismatch")
     return lib
 
@@ -250,14 +259,30 @@ class ScanResult:
 
     def fetch(self, events=True):
         fe, be = self.fe, self.fe.backend
+        import time
+        tt = [time.perf_counter()]
         if getattr(self, "done", None) is not None:
             be.wait(self.done)
         else:
             be.sync()
-        nb = 1 if self.single else int(be.to_numpy(self.bufs["nbursts"], np.int32)[0])
-        self.bursts = be.to_numpy(self.bufs["bursts"], BURST_DTYPE)[:nb].copy()
+        tt.append(time.perf_counter())
         P, T = len(fe.cfg.parmsets), fe.cfg.ntrks
-        self.counts = be.to_numpy(self.bufs["counts"], np.uint32)[: nb * P * T].reshape(nb, P, T).copy()
+        mirror = None
+        if getattr(self, "mirrored", False):              # the tables came with the scan (TorchBackend.mirror_async)
+            m, off, mirror = self.bufs["mirror"].numpy(), 0, {}
+            for name, t in zip(("nbursts", "bursts", "counts", "plan", "endmark"), self.bufs["mirror_of"]):
+                mirror[name] = m[off: off + int(t.numel())]
+                off += int(t.numel())
+        tab = (lambda name, dtype: mirror[name][: (len(mirror[name]) // dtype.itemsize) * dtype.itemsize].view(dtype)) if mirror else (lambda name, dtype: be.to_numpy(self.bufs[name], dtype))
+        if mirror and getattr(self, "end_mark_checked", False):      # rtfe_find_end_mark ran in front of the scan: the first row with the reader's end marker, or None
+            m = int(mirror["endmark"][:8].view(np.int64)[0])
+            self.end_mark = None if m == np.iinfo(np.int64).max else m
+            self.end_mark_valid = True
+        nb = 1 if self.single else int(tab("nbursts", np.dtype(np.int32))[0])
+        allb = tab("bursts", BURST_DTYPE)
+        self.bursts = allb[:nb].copy()
+        self.next_burst = allb[nb: nb + 1].copy()          # time shards: the burst that bounds the last own one (rtfe_scan writes it behind the table's own entries)
+        self.counts = tab("counts", np.dtype(np.uint32))[: nb * P * T].reshape(nb, P, T).copy()
         # the used part of the event arena: bursts are laid out one after the other (event_base, P*T regions of event_cap each)
         used = int((self.bursts["event_base"].astype(np.int64) + P * T * self.bursts["event_cap"].astype(np.int64)).max()) if nb else 0
         if not events:
@@ -267,17 +292,25 @@ class ScanResult:
         # per 2^21 rows).  Where the backend can gather on the device, every burst's P*T lists are packed to the burst's longest
         # list before the copy, and the host copy of the burst table is re-based to the packed layout (same addressing rule:
         # event_base + (p * T + t) * event_cap) - the device table is left alone.
-        cap2 = np.maximum(self.counts.reshape(nb, -1).max(axis=1), 1).astype(np.int64) if nb else np.zeros(0, np.int64)
-        dense = int(P * T * cap2.sum())
+        tt.append(time.perf_counter())
+        # The arena is laid out for the worst case (event_cap per list); what the lists hold is a fraction of it (C2: 6.7 of 38 MB
+        # per 2^21 rows).  rtfe_pack_events - queued behind the scan - has packed every burst's P*T lists to the burst's longest
+        # list; the host copy of the burst table is re-based to the packed layout (same addressing rule:
+        # event_base + (p * T + t) * event_cap) - the device table is left alone.
         pack = os.environ.get("RTFE_PACK_EVENTS")                   # (tests: "1" packs whatever the size, "0" never)
-        if nb and hasattr(be, "gather_lists") and pack != "0" and (pack == "1" or (used >= (1 << 16) and 2 * dense < used)):
-            self._events = be.gather_lists(self.bufs["events"], self.bursts["event_base"].astype(np.int64), self.bursts["event_cap"].astype(np.int64),
-                                           cap2, P * T, EVENT_DTYPE)
-            n_b = P * T * cap2
-            self.bursts["event_base"] = (np.cumsum(n_b) - n_b).astype(np.uint64)
-            self.bursts["event_cap"] = cap2.astype(np.uint32)
-        else:
+        packed = False
+        if nb and getattr(self, "packed", False) and pack != "0":
+            plan = tab("plan", PLAN_DTYPE)[: nb + 1].copy()
+            total = int(plan[nb]["event_base"])
+            if int(plan[nb]["reserved"]) == nb and total <= self.bufs["packed_cap"] and (pack == "1" or (used >= (1 << 16) and 2 * total < used)):
+                self._events = be.to_numpy(self.bufs["packed"][: max(total, 1) * EVENT_DTYPE.itemsize], EVENT_DTYPE)
+                self.bursts["event_base"] = plan[:nb]["event_base"]
+                self.bursts["event_cap"] = plan[:nb]["event_cap"]
+                packed = True
+        if not packed:
             self._events = be.to_numpy(self.bufs["events"][: max(used, 1) * EVENT_DTYPE.itemsize], EVENT_DTYPE)
+        tt.append(time.perf_counter())
+        self.fetch_times = tt                              # (wait for the scan, the tables, the events)
         return self
 
     @property
@@ -376,6 +409,13 @@ class FrontEnd:
             self._cache[k] = dict(
                 ws=be.empty(lib.rtfe_workspace_bytes(self.h, nrows)), bursts=be.empty(mb * BURST_DTYPE.itemsize),
                 nbursts=be.empty(16), counts=be.empty(mb * P * T * 4), events=be.empty(cap * 16), max_bursts=mb, cap=cap, nrows=nrows)
+            if key == "scan":                             # the lists packed behind the scan (rtfe_pack_events): half the arena is room for every tape seen so far
+                self._cache[k].update(plan=be.empty((mb + 1) * PLAN_DTYPE.itemsize), packed=be.empty((cap // 2) * 16), packed_cap=cap // 2)
+                if hasattr(be, "pinned"):                   # the small tables' host mirror (nbursts | bursts | counts | plan), filled behind the scan on its stream
+                    c = self._cache[k]
+                    c["endmark"] = be.empty(16)
+                    c["mirror_of"] = [c["nbursts"], c["bursts"], c["counts"], c["plan"], c["endmark"]]
+                    c["mirror"] = be.pinned(sum(int(t.numel()) for t in c["mirror_of"]))
         return self._cache[k]
 
     def _rows(self, rows):
@@ -392,6 +432,11 @@ class FrontEnd:
         d_rows = self._rows(rows)
         nrows = int(d_rows.shape[0])
         b = self._buffers(nrows)
+        marked = False
+        if getattr(self, "find_end_mark", False) and "endmark" in b:      # (the streaming reader: the window's end-of-data check on the device, in front of the scan)
+            if self.lib.rtfe_find_end_mark(self.h, be.ptr(d_rows), nrows, be.ptr(b["endmark"]), stream if stream is not None else be.stream()) != 0:
+                raise RuntimeError(f"rtfe_find_end_mark failed: {self.lib.rtfe_last_error().decode()}")
+            marked = True
         rc = self.lib.rtfe_scan(self.h, be.ptr(d_rows), nrows, nrows if own_rows is None else int(own_rows), row_base, int(first_is_tape_start),
                                 be.ptr(b["ws"]), b["ws"].numel() if hasattr(b["ws"], "numel") else b["ws"].size,
                                 be.ptr(b["bursts"]), b["max_bursts"], be.ptr(b["nbursts"]), be.ptr(b["counts"]),
@@ -400,6 +445,16 @@ class FrontEnd:
             raise RuntimeError(f"rtfe_scan failed ({rc}): {self.lib.rtfe_last_error().decode()}")
         r = ScanResult(self, b, b["max_bursts"])
         r._rows_keepalive = d_rows
+        r.end_mark_checked, r.end_mark, r.end_mark_valid = marked, None, False
+        if "plan" in b and os.environ.get("RTFE_PACK_EVENTS") != "0":
+            rc = self.lib.rtfe_pack_events(self.h, be.ptr(b["bursts"]), be.ptr(b["nbursts"]), b["max_bursts"], be.ptr(b["counts"]), be.ptr(b["events"]),
+                                           be.ptr(b["packed"]), b["packed_cap"], be.ptr(b["plan"]), stream if stream is not None else be.stream())
+            if rc != 0:
+                raise RuntimeError(f"rtfe_pack_events failed ({rc}): {self.lib.rtfe_last_error().decode()}")
+            r.packed = True
+            if "mirror" in b:
+                be.mirror_async(b["mirror"], b["mirror_of"], stream)
+                r.mirrored = True
         if hasattr(be, "record"):
             r.done = be.record(stream)
         return r

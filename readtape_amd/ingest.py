@@ -43,14 +43,17 @@ class _All:
 
 
 def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17, opts: pipeline.DecodeOptions | None = None, cfgkw=None,
-                          device="cuda:0", replay_threads: int = 1, read_threads: int = 4, replay_split: int = 1):
+                          device="cuda:0", replay_threads: int = 1, read_threads: int = 4, replay_split: int = 1, scan_contexts: int = 3, ramp: bool = True):
     """Decodes the .tbin file `path` to the SIMH file `tap_path` through device windows of `window_rows` rows (a multiple of 1024).
     Returns statistics incl. the end-to-end rate (disk -> .tap), the time spent in the host replay and the rows the halos re-read.
     replay_threads > 1: the windows' host replays run side by side (fragments are independent: each has its own decoder context
     and writes its own piece of the .tap; the pieces are concatenated in window order).  A window's device buffer is kept until
     its replay is done (exact rescans read it), so replay_threads + 2 device windows are held.
     replay_split > 1: a window's bursts are replayed as that many sub-fragments side by side (cut at burst boundaries, exactly as the
-    windows themselves are): the last window's replay is what the pipeline drains into, and a 4 M-row window takes one thread ~50 ms."""
+    windows themselves are); the last two windows - what the pipeline drains into - as four times as many.
+    scan_contexts: scans in flight (a context = a front end with its workspace and output buffers; a context is free again once its window's
+    results have been fetched).  ramp: the first two windows are a quarter and a half of `window_rows` (the pipeline fills sooner)."""
+    import queue
     import torch
     assert window_rows % 1024 == 0
     t_enter = time.perf_counter()
@@ -61,15 +64,21 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     ntrks = hdr.ntrks
     full = pipeline.default_parmsets(hdr.mode, opts.nparmsets or (15 if opts.multiple_tries else 1))
     cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=pipeline.frontend_parmsets(full), **(cfgkw or {}))
-    fes = [frontend.FrontEnd(cfg, device=device) for _ in range(2)]      # two scans are in flight: window k is fetched while k + 1 is copied and scanned
+    nctx = max(2, int(scan_contexts))
+    fes = [frontend.FrontEnd(cfg, device=device) for _ in range(nctx)]      # window k is fetched while k + 1 .. are copied and scanned
     fe = fes[0]
     dev = torch.device(device)
-    spans = [(lo, min(nrows, lo + window_rows)) for lo in range(0, nrows, window_rows)]
+    spans, lo = [], 0
+    sizes = [window_rows // 4 & ~1023, window_rows // 2 & ~1023] if (ramp and window_rows >= (1 << 20) and nrows > 2 * window_rows) else []
+    while lo < nrows:
+        w = sizes.pop(0) if sizes else window_rows
+        spans.append((lo, min(nrows, lo + w)))
+        lo += w
     cap = window_rows + halo_rows
     from concurrent.futures import ThreadPoolExecutor
     nthreads = max(1, int(replay_threads))
-    depth = 2 if nthreads == 1 else nthreads + 2
-    NP = 3                                                # pinned buffers: one being read into, one being copied from, one in between
+    depth = max(2 if nthreads == 1 else nthreads + 2, nctx + 2)
+    NP = nctx + 1                                         # pinned buffers: one being read into, the others being copied from / waiting for their context
     pinned = [torch.empty((cap, ntrks), dtype=torch.int16, pin_memory=True) for _ in range(NP)]      # hipHostMalloc
     dwin = [torch.empty((cap, ntrks), dtype=torch.int16, device=dev) for _ in range(depth)]
     pool = ThreadPoolExecutor(nthreads) if nthreads > 1 else None
@@ -81,10 +90,20 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     copied = [torch.cuda.Event() for _ in range(NP)]
     fd = os.open(path, os.O_RDONLY)
     t_read = [0.0]
+    trace = [] if os.environ.get("RT_INGEST_TRACE") else None      # (stage, window, start, end) in seconds since the timed region began
+    t_base = [0.0]
+
+    def mark(stage, k, t0):
+        if trace is not None:
+            trace.append((stage, k, round(t0 - t_base[0], 5), round(time.perf_counter() - t_base[0], 5)))
     data_end = [nrows]
     end_lock = threading.Lock()
 
-    def read_span(arr, r0, r1, lo):
+    gpu_mark = hasattr(fe.backend, "pinned") and os.environ.get("RTFE_PACK_EVENTS") != "0" and not os.environ.get("RT_INGEST_HOST_MARK")
+    for f in fes:                                          # the end-of-data marker is looked for on the device, in front of each window's scan (rtfe_find_end_mark)
+        f.find_end_mark = gpu_mark
+
+    def read_span(arr, r0, r1, lo, check=True):
         """rows [lo + r0, lo + r1) of the payload -> arr[r0:r1]; returns the first row (relative to lo) whose head-0 sample is the end
         marker, or -1 (looked for here, by the thread that has just read the rows: a strided pass over the whole window in one
         thread had become the longest stage of the pipeline)."""
@@ -95,20 +114,22 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
             if got <= 0:
                 raise IOError("short read")
             done += got
+        if not check:
+            return -1
         marks = np.flatnonzero(arr[r0:r1, 0] == tbin.END_MARK)
         return r0 + int(marks[0]) if marks.size else -1
 
-    def read_rows(dst, lo, end):
+    def read_rows(dst, lo, end, check=True):
         """rows [lo, end) of the payload -> the pinned tensor dst (positional reads: safe beside the other thread's), in `read_threads`
         pieces side by side (from the page cache one thread copies ~13 GB/s).  Returns the first end-marker row (relative to lo) or -1."""
         t0 = time.perf_counter()
         arr = dst.numpy()
         n = end - lo
         if readers is None or n * 2 * ntrks < (8 << 20):
-            first = read_span(arr, 0, n, lo)
+            first = read_span(arr, 0, n, lo, check)
         else:
             step = -(-n // read_threads)
-            futs = [readers.submit(read_span, arr, a, min(n, a + step), lo) for a in range(0, n, step)]
+            futs = [readers.submit(read_span, arr, a, min(n, a + step), lo, check) for a in range(0, n, step)]
             hits = [h for h in (f.result() for f in futs) if h >= 0]
             first = min(hits) if hits else -1
         t_read[0] += time.perf_counter() - t0
@@ -117,29 +138,70 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     def read_window(k):
         lo, hi = spans[k]
         end = min(nrows, hi + halo_rows)
-        first = read_rows(pinned[k % NP], lo, end)
-        with end_lock:                                    # (the reader thread writes it for window k + 2 while the main thread clamps window k with it)
+        t0 = time.perf_counter()
+        first = read_rows(pinned[k % NP], lo, end, check=not gpu_mark)
+        mark("read", k, t0)
+        with end_lock:                                    # (the producer writes it while the main thread clamps a window with it)
             if first >= 0:                                # an end marker inside the payload: the tape ends there
                 data_end[0] = min(data_end[0], lo + first)
             return min(end, data_end[0])
+
+    busy = [None] * depth
+    ctx_free = [threading.Semaphore(1) for _ in range(nctx)]
+    stop = threading.Event()
 
     def launch(k, end):
         lo, hi = spans[k]
         hi = min(hi, data_end[0])
         if hi <= lo:
             return None, None, lo
+        t0 = time.perf_counter()
+        ctx_free[k % nctx].acquire()                      # the results of the window that used this context have been fetched
         if busy[k % depth] is not None:                   # the replay that still reads this device window
             busy[k % depth].result()
             busy[k % depth] = None
+        mark("wait_ctx", k, t0)
+        t0 = time.perf_counter()
         with torch.cuda.stream(copy_stream):
+            if trace is not None:
+                gpu_ev[("copy0", k)] = torch.cuda.Event(enable_timing=True); gpu_ev[("copy0", k)].record(copy_stream)
             dwin[k % depth][: end - lo].copy_(pinned[k % NP][: end - lo], non_blocking=True)
             copied[k % NP].record(copy_stream)
+            if trace is not None:
+                gpu_ev[("copy1", k)] = torch.cuda.Event(enable_timing=True); gpu_ev[("copy1", k)].record(copy_stream)
         scan_stream.wait_event(copied[k % NP])
         piece = dwin[k % depth][: end - lo]
-        fin = pipeline.scan_fragment(fes[k & 1], piece, hi - lo, lo, lo == 0, hi >= data_end[0], stream=scan_stream.cuda_stream)
+        fin = pipeline.scan_fragment(fes[k % nctx], piece, hi - lo, lo, lo == 0, hi >= data_end[0], stream=scan_stream.cuda_stream)
+        if trace is not None:
+            gpu_ev[("scan1", k)] = torch.cuda.Event(enable_timing=True); gpu_ev[("scan1", k)].record(scan_stream)
+        mark("launch", k, t0)
         return piece, fin, end
 
-    busy = [None] * depth
+    launched = queue.Queue()
+
+    def producer():
+        """reads window after window into the ring of pinned buffers and queues each one's copy and scan behind its predecessor's"""
+        try:
+            for k, (lo, hi) in enumerate(spans):
+                if stop.is_set() or lo >= data_end[0]:
+                    break
+                if k >= NP:
+                    copied[k % NP].synchronize()           # the pinned buffer's last copy (window k - NP) has left it
+                end = read_window(k)
+                if stop.is_set():
+                    break
+                item = launch(k, end)
+                if item[1] is None:
+                    marks_seen[k].set()
+                launched.put((k, fetchers.submit(stage2, k, item) if item[1] is not None else None))
+            launched.put((None, None))
+        except BaseException as e:                         # the main thread raises it
+            launched.put((None, e))
+        finally:
+            for ev in marks_seen:                          # (windows that were never launched hold nobody up)
+                if stop.is_set():
+                    ev.set()
+
     retired = []                                          # scan contexts replaced by ones with a calibrated screen floor (closed at the end: a scan of theirs may still be in flight)
     floor_state = {"tries": 2, "floor": None}
     pieces = []                                           # per window: bytes, or the future that returns (bytes, replay stats, seconds)
@@ -153,91 +215,131 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         with open(frag, "rb") as g:
             data = g.read()
         os.remove(frag)
+        mark("replay" + tag, k, t0)
         return data, st, time.perf_counter() - t0
 
     stats = dict(rows=nrows, windows=len(spans), halo_rows_read=0, blocks=0, tapemarks=0, events_delivered=0, exact_scans=0, retries=0, replay_threads=nthreads)
-    t_replay = t_wait = 0.0
+    t_replay = 0.0
     for f in fes:                                         # set-up, like the pinned buffers and the device windows: the scan contexts' workspaces
         f._buffers(cap)
-    if hasattr(fe.backend, "gather_lists"):               # (and the first use of the device-side packing: PyTorch loads its kernels then)
-        one = np.ones(1, np.int64)
-        fe.backend.gather_lists(fe._buffers(cap)["events"], 0 * one, 4 * one, 2 * one, 3, frontend.EVENT_DTYPE)
+    # (and page-locked blocks for the windows' event lists in the host allocator's cache: a window's packed events are ~1 / 40 of its arena)
+    blk = [torch.empty(max(1 << 20, cap * ntrks * 16 // 40), dtype=torch.uint8, pin_memory=True) for _ in range(min(depth, 12))]
+    del blk
     torch.cuda.synchronize(dev)
+    gpu_ev = {}
+    if trace is not None:
+        gpu_ev["base"] = torch.cuda.Event(enable_timing=True); gpu_ev["base"].record(copy_stream); copy_stream.synchronize()
     t_start = time.perf_counter()
+    t_base[0] = t_start
     total = 0
+    calib_lock = threading.Lock()
+    marks_seen = [threading.Event() for _ in spans]
+    fetchers = ThreadPoolExecutor(nctx)                    # a window's results are fetched (and its replays queued) beside its neighbours': a fetch is ~6 ms of host-side work
+    fetch_streams = [torch.cuda.Stream(dev) for _ in range(nctx)]
+    wait_s = [0.0]
+
+    def stage2(k, item):
+        """window k: its results to the host, its bursts to the replay threads -> the replays' futures (or results), in order"""
+        piece, fin, end_k = item
+        out = []
+        try:
+            lo, hi = spans[k]
+            hi = min(hi, data_end[0])
+            t0 = time.perf_counter()
+            with torch.cuda.stream(fetch_streams[k % nctx]):
+                res, nb, bound = fin()
+            wait_s[0] += time.perf_counter() - t0
+            mark("fetch", k, t0)
+            if gpu_mark:
+                # the window's end-of-data check came back with its tables.  The windows are looked at in order (a marker ends the tape for every window
+                # behind it); a window that holds one - rows behind the data's end were scanned with it - is scanned again up to the marker.
+                if k > 0:
+                    marks_seen[k - 1].wait()
+                try:
+                    assert res.end_mark_valid
+                    if lo >= data_end[0]:
+                        return []
+                    if res.end_mark is not None and res.end_mark < end_k - lo:
+                        with end_lock:
+                            data_end[0] = min(data_end[0], lo + res.end_mark)
+                        end_k = min(end_k, data_end[0])
+                        hi = min(hi, data_end[0])
+                        if hi <= lo:
+                            return []
+                        piece = piece[: end_k - lo]
+                        with torch.cuda.stream(fetch_streams[k % nctx]):
+                            res, nb, bound = pipeline.scan_fragment(res.fe, piece, hi - lo, lo, lo == 0, True)()
+                finally:
+                    marks_seen[k].set()
+            if trace is not None and getattr(res, "fetch_times", None):
+                ft = res.fetch_times
+                for name, a, b in (("f_wait", ft[0], ft[1]), ("f_tables", ft[1], ft[2]), ("f_events", ft[2], ft[3])):
+                    trace.append((name, k, round(a - t_base[0], 5), round(b - t_base[0], 5)))
+            if floor_state["tries"] > 0 and cfg.peak_detection_floor_applies():
+                # The candidate screen is built for the loosest thresholds any AGC state could ask for - a learned peak height of 1 V -, and on a
+                # noisy tape every wiggle above THAT becomes a record (lists outgrow their slots, the bursts are redone on the samples).  The first
+                # windows say how high the tape's peaks really are: the scans behind them screen against half the smallest height a chain learned
+                # (a later chain below that floor is flagged RTFE_F_SCREEN_UNDERFLOW and rescanned exactly: slower, never wrong).
+                with calib_lock:
+                    if floor_state["tries"] > 0:
+                        floor_state["tries"] -= 1
+                        st_k = res.fe.scan_stats(res)
+                        if st_k["bursts"] > 0 and st_k["redone"] * 4 > st_k["bursts"] and st_k.get("min_learned_height"):
+                            import dataclasses
+                            cfg2 = dataclasses.replace(cfg, screen_floor_height=min(4.0, 0.5 * st_k["min_learned_height"]))
+                            new = [frontend.FrontEnd(cfg2, device=device) for _ in range(nctx)]
+                            for f in new: f._buffers(cap); f.find_end_mark = gpu_mark
+                            retired.extend(fes)
+                            fes[:] = new                     # (the producer takes a window's context from the list when it launches it)
+                            floor_state["tries"] = 0; floor_state["floor"] = cfg2.screen_floor_height
+            halo = halo_rows
+            while nb is None and end_k < data_end[0]:    # the last own burst runs past the halo: read more (rare; synchronous)
+                halo *= 4
+                stats["retries"] += 1
+                end_k = min(data_end[0], hi + halo)
+                host = torch.empty((end_k - lo, ntrks), dtype=torch.int16, pin_memory=True)
+                first = read_rows(host, lo, end_k)
+                if first >= 0:                            # an end marker inside the longer halo: the tape ends there (src/readtape.c:1410)
+                    with end_lock:
+                        data_end[0] = min(data_end[0], lo + first)
+                    end_k = min(end_k, data_end[0])
+                piece = host[: end_k - lo].to(dev)
+                res, nb, bound = pipeline.scan_fragment(res.fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
+            stats["halo_rows_read"] += end_k - hi
+            if res.nbursts:
+                if pool:
+                    # sub-fragments: cut at the zone starts of evenly spaced bursts
+                    split = int(replay_split) * (4 if k + 2 >= len(spans) else 1)
+                    nsub = max(1, min(split, nthreads, res.nbursts // 8))
+                    cuts = [int(res.bursts[(res.nbursts * j) // nsub]["zone_first"]) for j in range(1, nsub)]
+                    first = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
+                    starts, stops = [first] + cuts, cuts + [bound]
+                    out = [pool.submit(replay, k, res, piece, lo, stops[j], starts[j], f".{j}") for j in range(nsub) if stops[j] is None or stops[j] > starts[j]]
+                    busy[k % depth] = _All(out)
+                else:
+                    out = [replay(k, res, piece, lo, bound)]
+        finally:
+            marks_seen[k].set()
+            ctx_free[k % nctx].release()
+        return out
+
+    prod = threading.Thread(target=producer, name="rt-ingest-producer")
+    import sys
+    switch = sys.getswitchinterval()
+    sys.setswitchinterval(float(os.environ.get("RT_INGEST_SWITCH", "0.0002")))      # a dozen threads hand the interpreter lock around between system calls: at the default 5 ms a stage waits longer for the lock than it works
     try:
         with open(tap_path, "wb") as tapf:
-            # software pipeline: while window k is fetched and handed to its replay, window k + 1 is being copied and scanned (queued
-            # behind k on the device) and window k + 2 is being read
-            pend = {0: launch(0, read_window(0))} if spans else {}
-            reader, nxt, reading = None, [0], -1
-
-            def start_read(kk):
-                def work():
-                    nxt[0] = read_window(kk)
-                th = threading.Thread(target=work)
-                th.start()
-                return th
-            if len(spans) > 1:
-                reader, reading = start_read(1), 1
-            for k, (lo, hi) in enumerate(spans):
-                if lo >= data_end[0]:
+            # software pipeline: the producer thread reads window after window and queues each one's copy and scan on the device; the fetchers bring
+            # the windows' results to the host and hand them to the replay threads; this thread collects the pieces in window order
+            prod.start()
+            while True:
+                k, fut = launched.get()
+                if k is None:
+                    if isinstance(fut, BaseException):
+                        raise fut
                     break
-                hi = min(hi, data_end[0])
-                if reader is not None and reading == k + 1:     # window k + 1 has been read: queue its copy and scan behind window k's
-                    reader.join()
-                    reader = None
-                    pend[k + 1] = launch(k + 1, nxt[0])          # (its device window and scan context were window k - 1's: fetched and replayed, or waited for in launch)
-                    if k + 2 < len(spans):
-                        reader, reading = start_read(k + 2), k + 2      # (its pinned buffer was window k - 1's: copied long ago)
-                piece, fin, end_k = pend.pop(k)
-                if fin is None:
-                    continue
-                t0 = time.perf_counter()
-                res, nb, bound = fin()
-                t_wait += time.perf_counter() - t0
-                if floor_state["tries"] > 0 and cfg.peak_detection_floor_applies():
-                    # The candidate screen is built for the loosest thresholds any AGC state could ask for - a learned peak height of 1 V -, and on a
-                    # noisy tape every wiggle above THAT becomes a record (lists outgrow their slots, the bursts are redone on the samples).  The first
-                    # windows say how high the tape's peaks really are: the scans behind them screen against half the smallest height a chain learned
-                    # (a later chain below that floor is flagged RTFE_F_SCREEN_UNDERFLOW and rescanned exactly: slower, never wrong).
-                    floor_state["tries"] -= 1
-                    st_k = fes[k & 1].scan_stats(res)
-                    if st_k["bursts"] > 0 and st_k["redone"] * 4 > st_k["bursts"] and st_k.get("min_learned_height"):
-                        import dataclasses
-                        cfg2 = dataclasses.replace(cfg, screen_floor_height=min(4.0, 0.5 * st_k["min_learned_height"]))
-                        retired.extend(fes)
-                        fes[:] = [frontend.FrontEnd(cfg2, device=device) for _ in range(2)]
-                        for f in fes: f._buffers(cap)
-                        floor_state["tries"] = 0; floor_state["floor"] = cfg2.screen_floor_height
-                halo = halo_rows
-                while nb is None and end_k < data_end[0]:    # the last own burst runs past the halo: read more (rare; synchronous)
-                    halo *= 4
-                    stats["retries"] += 1
-                    end_k = min(data_end[0], hi + halo)
-                    host = torch.empty((end_k - lo, ntrks), dtype=torch.int16, pin_memory=True)
-                    first = read_rows(host, lo, end_k)
-                    if first >= 0:                            # an end marker inside the longer halo: the tape ends there (src/readtape.c:1410)
-                        with end_lock:
-                            data_end[0] = min(data_end[0], lo + first)
-                        end_k = min(end_k, data_end[0])
-                    piece = host[: end_k - lo].to(dev)
-                    res, nb, bound = pipeline.scan_fragment(fes[k & 1], piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
-                stats["halo_rows_read"] += end_k - hi
-                if res.nbursts:
-                    if pool:
-                        # sub-fragments: cut at the zone starts of evenly spaced bursts
-                        nsub = max(1, min(int(replay_split), res.nbursts // 8))
-                        cuts = [int(res.bursts[(res.nbursts * j) // nsub]["zone_first"]) for j in range(1, nsub)]
-                        first = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
-                        starts, stops = [first] + cuts, cuts + [bound]
-                        futs = [pool.submit(replay, k, res, piece, lo, stops[j], starts[j], f".{j}") for j in range(nsub) if stops[j] is None or stops[j] > starts[j]]
-                        busy[k % depth] = _All(futs)
-                        pieces.extend(futs)
-                    else:
-                        pieces.append(replay(k, res, piece, lo, bound))
-            if reader is not None:
-                reader.join()
+                if fut is not None:
+                    pieces.extend(fut.result())
             for pc in pieces:                                 # in window order
                 data, st, secs = pc.result() if hasattr(pc, "result") else pc
                 t_replay += secs
@@ -250,14 +352,28 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t_start
     finally:                                              # (also when a replay raised: no thread, file or device context is left behind)
+        sys.setswitchinterval(switch)
+        stop.set()
+        for sem in ctx_free:                              # (a producer waiting for a context wakes up and sees the stop flag)
+            sem.release()
+        if prod.is_alive():
+            prod.join()
+        fetchers.shutdown(wait=True)
         if readers:
             readers.shutdown(wait=True)
         os.close(fd)
         if pool:
             pool.shutdown(wait=True, cancel_futures=True)
+        torch.cuda.synchronize(dev)
         fe_exact.close()
         for f in list(fes) + retired:
             f.close()
-    stats.update(setup_seconds=t_start - t_enter, rows=data_end[0], seconds=dt, msamples_per_s=data_end[0] / dt / 1e6, replay_seconds=t_replay, read_seconds=t_read[0], scan_wait_seconds=t_wait,
+    if trace is not None:
+        for k in range(len(spans)):                       # the device's own clock: a window's copy and the end of its scan, ms behind the start of the timed region
+            if ("copy0", k) in gpu_ev:
+                c0, c1, s1 = (gpu_ev["base"].elapsed_time(gpu_ev[(n, k)]) for n in ("copy0", "copy1", "scan1"))
+                trace.append(("gpu_copy", k, c0 / 1e3, c1 / 1e3)); trace.append(("gpu_scan_done", k, c1 / 1e3, s1 / 1e3))
+        stats["trace"] = sorted(trace, key=lambda x: x[2])
+    stats.update(setup_seconds=t_start - t_enter, rows=data_end[0], seconds=dt, msamples_per_s=data_end[0] / dt / 1e6, replay_seconds=t_replay, read_seconds=t_read[0], scan_wait_seconds=wait_s[0],
                  replay_events_per_s=(stats["events_delivered"] / t_replay) if t_replay > 0 else None, tap_bytes=total + (4 if total else 0), screen_floor_height=floor_state["floor"])
     return stats

@@ -416,11 +416,10 @@ def scan_fragment(fe, rows_with_halo, own_rows, lo, is_first, is_last, stream=No
         nb = res.nbursts
         bound = None
         if not is_last:
-            tab = be.to_numpy(res.bufs["bursts"], frontend.BURST_DTYPE)[: nb + 1].copy()
             truncated = nb > 0 and bool(int(res.bursts[nb - 1]["flags"]) & frontend.F_TRUNCATED)
-            if truncated or nb + 1 > tab.shape[0]:
+            if truncated or res.next_burst.shape[0] < 1:
                 return res, None, None                 # the halo holds no further zone: the caller retries with a longer one
-            bound = int(tab[nb]["zone_first"])          # relative to the fragment
+            bound = int(res.next_burst[0]["zone_first"])          # relative to the fragment
         return res, nb, bound
     return finish
 

@@ -14,7 +14,7 @@ EMUL_SO = os.path.join(EMUL_DIR, "librtfe_emul.so")
 
 
 def build_emul():
-    srcs = [os.path.join(ROOT, "readtape_amd", "csrc", f) for f in ("rtfe_api.hip", "rtfe_kernels.hip", "rtfe_zeros.hip", "rtfe_ww.hip", "rtfe_sift.hip", "rtfe_gain.hip", "rtfe_dense.hip", "rtfe_pk.h", "rtfe_device.h")]
+    srcs = [os.path.join(ROOT, "readtape_amd", "csrc", f) for f in ("rtfe_api.hip", "rtfe_kernels.hip", "rtfe_zeros.hip", "rtfe_ww.hip", "rtfe_sift.hip", "rtfe_gain.hip", "rtfe_dense.hip", "rtfe_pack.hip", "rtfe_pk.h", "rtfe_device.h")]
     srcs += [os.path.join(ROOT, "include", "rt_frontend.h"), os.path.join(EMUL_DIR, "hip", "hip_runtime.h"), os.path.join(EMUL_DIR, "emul_main.cpp")]
     stale = lambda: not os.path.exists(EMUL_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMUL_SO) for s in srcs)
     if stale():

@@ -23,6 +23,33 @@ def test_emulated_kernels_match_oracle(name, tmp_path):
     assert stats["events"] > 0
 
 
+@pytest.mark.parametrize("name", ["nrzi9_m", "pe", "gcr_m", "nrzi9_zeros", "tiny", "noise_only"])
+def test_emulated_event_lists_packed_on_the_device(name, tmp_path, monkeypatch):
+    """rtfe_pack_events (k_pack_plan + k_pack_copy behind the scan): the host reads every list from the packed buffer under the re-based burst table -
+    the oracle's events, and the lists of the arena itself."""
+    import numpy as np
+    g = load_case(name)
+    cfg = config_for(g["hdr"], g["oracle_opts"])
+    monkeypatch.setenv("RTFE_PACK_EVENTS", "0")
+    fe = emul_frontend(cfg)
+    plain = fe.scan(g["rows"]).fetch()
+    lists0 = [[[plain.track_events(b, p, t).copy() for t in range(cfg.ntrks)] for p in range(len(cfg.parmsets))] for b in range(plain.nbursts)]
+    monkeypatch.setenv("RTFE_PACK_EVENTS", "1")
+    res = fe.scan(g["rows"]).fetch()
+    assert res.nbursts == plain.nbursts
+    if res.nbursts:
+        assert res._events.shape[0] == int((res.bursts["event_cap"].astype(np.int64) * len(cfg.parmsets) * cfg.ntrks).sum())
+        assert res._events.shape[0] <= plain._events.shape[0]
+    for b in range(res.nbursts):
+        for p in range(len(cfg.parmsets)):
+            for t in range(cfg.ntrks):
+                assert np.array_equal(res.track_events(b, p, t), lists0[b][p][t]), (b, p, t)
+    if "-zeros" not in g["oracle_opts"]:
+        att = oracle_attempts(g["hdr"], g["rows"], g["oracle_opts"], str(tmp_path))
+        msgs, stats = check_tape(fe, g["hdr"], g["rows"], att)
+        assert not msgs, "\n".join(msgs[:12])
+
+
 @pytest.mark.parametrize("parallel", ["1", "0"])
 @pytest.mark.parametrize("name", PEAK_CASES)
 def test_emulated_peak_record_path_matches_oracle(name, parallel, tmp_path, monkeypatch):
