@@ -130,15 +130,16 @@ def e2e_line(tape, copies, conf, dev):
         tbin.write_tbin(path, hdr, rows)
         del rows
         opts = pipeline.DecodeOptions(multiple_tries=conf["nparmsets"] > 1, verbose=False)      # (-m: the reference's built-in sets)
-        threads = max(1, min(int(os.environ.get("RT_E2E_REPLAY_THREADS", "32")), (os.cpu_count() or 1) - 1))
-        rthreads = max(1, min(int(os.environ.get("RT_E2E_READ_THREADS", "4")), (os.cpu_count() or 2) // 2))
+        threads = max(1, min(int(os.environ.get("RT_E2E_REPLAY_THREADS", "64")), (os.cpu_count() or 1) - 1))
+        rthreads = max(1, min(int(os.environ.get("RT_E2E_READ_THREADS", "16")), (os.cpu_count() or 2) // 2))
         wrows = int(os.environ.get("RT_E2E_WINDOW_ROWS", str(1 << 23 if copies > 4 else 1 << 22)))      # (measured on the 9e7-row C2 sample: 2^22 / 2^23 / 2^24 rows -> 0.79 / 0.93 / 0.88 Gsamples/s)
-        split = int(os.environ.get("RT_E2E_REPLAY_SPLIT", "4"))
+        split = int(os.environ.get("RT_E2E_REPLAY_SPLIT", "8"))
         if True:                                        # one untimed pass over a short file first, as the device-resident line has its warm-up steps
             wpath = os.path.join(wd, "w.tbin")                # (first use of the replay pool, of the packing kernels, of the second scan context)
             tbin.write_tbin(wpath, hdr, tape.rows)
             ingest.decode_file_streaming(wpath, os.path.join(wd, "w.tap"), window_rows=wrows, halo_rows=1 << 18, opts=opts,
                                          cfgkw=dict(find_zeros=True) if conf["find_zeros"] else None, device=str(dev), replay_threads=threads, read_threads=rthreads, replay_split=split)
+        os.sync()                                       # (the sample was written a moment ago: its dirty pages' write-back would run beside the timed decode)
         st = ingest.decode_file_streaming(path, os.path.join(wd, "e.tap"), window_rows=wrows, halo_rows=1 << 18, opts=opts,
                                           cfgkw=dict(find_zeros=True) if conf["find_zeros"] else None, device=str(dev), replay_threads=threads, read_threads=rthreads, replay_split=split)
         same = None
@@ -152,7 +153,7 @@ def e2e_line(tape, copies, conf, dev):
             "host_replay_threads": st["replay_threads"], "host_read_threads": rthreads, "window_rows": wrows, "replay_split": split, "host_cores": os.cpu_count(),
             "file_read_seconds_overlapped": round(st["read_seconds"], 3), "scan_wait_seconds": round(st["scan_wait_seconds"], 3),
             "blocks": st["blocks"], "tapemarks": st["tapemarks"], "exact_rescans": st["exact_scans"], "tap_identical_to_cpu_port": same,
-            "path": ".tbin in the page cache -> parallel positional reads into pinned buffers -> hipMemcpyAsync on a copy stream -> rtfe_scan (two contexts in flight) -> event arena packed on the device -> host replay of the windows (fragments), each as replay_split sub-fragments, side by side -> .tap"}
+            "path": ".tbin in the page cache -> a producer thread: native parallel positional reads into a ring of pinned buffers, hipMemcpyAsync on a copy stream, rtfe_find_end_mark + rtfe_scan + rtfe_pack_events (three contexts in flight), the tables mirrored to pinned memory on the scan's stream -> fetcher threads: the packed event lists to the host -> host replay of the windows (fragments), each as replay_split sub-fragments on native threads -> .tap"}
 
 
 class Workload:

@@ -44,7 +44,7 @@ def build_host(force=False):
     srcs = [os.path.join(CSRC, "host", f) for f in HOST_SRCS]
     if force or _newer(out, srcs + [os.path.join(CSRC, "host", "rt_decode.h"), os.path.join(CSRC, "host", "rt_replay.h")]):
         subprocess.run(["gcc", "-std=gnu99", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-D_DEFAULT_SOURCE",
-                        "-Wall", f"-I{os.path.join(CSRC, 'host')}", f"-I{os.path.join(ROOT, 'include')}", "-o", out] + srcs + ["-lm"], check=True)
+                        "-Wall", f"-I{os.path.join(CSRC, 'host')}", f"-I{os.path.join(ROOT, 'include')}", "-o", out] + srcs + ["-lm", "-lpthread"], check=True)
     return out
 
 

@@ -406,6 +406,72 @@ int rt_replay_run_fragment(const struct rt_options *opt, const struct rt_parms *
    return replay_any(opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events,
                      exact, exact_free, user, tap_path, log_path, evt_path, stats, 0, NULL, start_row, stop_row, 1, NULL, NULL); }
 
+/* ---- fragments side by side: native threads (the caller is one Python thread per window, not one per fragment) ---- */
+#include <pthread.h>
+struct frag_job {
+   const struct rt_options *opt; const struct rt_parms *parmsets; int nparm; int64_t tdelta_ns, tstart_ns, nrows, row_base; const int *W;
+   const rtfe_burst *bursts; int64_t nbursts; const uint32_t *counts; const rtfe_event *events;
+   rt_exact_fn exact; rt_exact_free_fn exact_free; void *user;
+   const char *tap_path; int64_t start_row, stop_row; struct rt_replay_stats *stats; double *seconds; int rc; };
+static void *frag_thread(void *p) {
+   struct frag_job *j = (struct frag_job *)p;
+   struct timespec a, b;
+   clock_gettime(CLOCK_MONOTONIC, &a);
+   j->rc = rt_replay_run_fragment(j->opt, j->parmsets, j->nparm, j->tdelta_ns, j->tstart_ns, j->nrows, j->row_base, j->W, j->bursts, j->nbursts, j->counts, j->events,
+                                  j->exact, j->exact_free, j->user, j->tap_path, NULL, NULL, j->stats, j->start_row, j->stop_row);
+   clock_gettime(CLOCK_MONOTONIC, &b);
+   *j->seconds = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+   return NULL; }
+int rt_replay_run_fragments(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  int nfrag, const char *const *tap_paths, const int64_t *start_rows, const int64_t *stop_rows, struct rt_replay_stats *stats, double *seconds) {
+   if (nfrag < 1 || nfrag > 256) return -1;
+   struct frag_job *jobs = (struct frag_job *)calloc((size_t)nfrag, sizeof *jobs);
+   pthread_t *th = (pthread_t *)calloc((size_t)nfrag, sizeof *th);
+   if (!jobs || !th) { free(jobs); free(th); return -1; }
+   for (int i = 0; i < nfrag; ++i) {
+      struct frag_job j = { opt, parmsets, nparm, tdelta_ns, tstart_ns, nrows, row_base, W, bursts, nbursts, counts, events, exact, exact_free, user,
+                            tap_paths[i], start_rows[i], stop_rows[i], &stats[i], &seconds[i], 0 };
+      jobs[i] = j; }
+   int started = 0, rc = 0;
+   for (int i = 1; i < nfrag; ++i) { if (pthread_create(&th[i], NULL, frag_thread, &jobs[i]) != 0) break; started = i; }
+   frag_thread(&jobs[0]);                                       /* (the caller's thread takes the first) */
+   for (int i = started + 1; i < nfrag; ++i) frag_thread(&jobs[i]);      /* (threads that could not be made: in line) */
+   for (int i = 1; i <= started; ++i) pthread_join(th[i], NULL);
+   for (int i = 0; i < nfrag; ++i) if (jobs[i].rc != 0 && rc == 0) rc = jobs[i].rc;
+   free(jobs); free(th);
+   return rc; }
+
+struct read_job { int fd; char *dst; int64_t off, n; int rc; };
+static void *read_thread(void *p) {
+   struct read_job *j = (struct read_job *)p;
+   int64_t done = 0;
+   while (done < j->n) {
+      const int64_t want = j->n - done > (1ll << 30) ? (1ll << 30) : j->n - done;
+      const ssize_t got = pread(j->fd, j->dst + done, (size_t)want, (off_t)(j->off + done));
+      if (got <= 0) { j->rc = -1; return NULL; }
+      done += got; }
+   return NULL; }
+int rt_read_mt(int fd, void *dst, int64_t off, int64_t nbytes, int nthreads) {
+   if (nbytes <= 0) return 0;
+   if (nthreads < 1) nthreads = 1;
+   if (nthreads > 64) nthreads = 64;
+   if (nbytes < (8ll << 20)) nthreads = 1;
+   struct read_job jobs[64];
+   pthread_t th[64];
+   const int64_t step = ((nbytes + nthreads - 1) / nthreads + 4095) & ~4095ll;
+   int n = 0;
+   for (int64_t a = 0; a < nbytes; a += step, ++n) { struct read_job j = { fd, (char *)dst + a, off + a, nbytes - a < step ? nbytes - a : step, 0 }; jobs[n] = j; }
+   int started = 0;
+   for (int i = 1; i < n; ++i) { if (pthread_create(&th[i], NULL, read_thread, &jobs[i]) != 0) break; started = i; }
+   read_thread(&jobs[0]);
+   for (int i = started + 1; i < n; ++i) read_thread(&jobs[i]);
+   for (int i = 1; i <= started; ++i) pthread_join(th[i], NULL);
+   for (int i = 0; i < n; ++i) if (jobs[i].rc != 0) return -1;
+   return 0; }
+
 int rt_replay_run_after_deskew(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
                   const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,

@@ -88,6 +88,17 @@ int rt_replay_run_fragment(const struct rt_options *opt, const struct rt_parms *
                   rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
                   const char *tap_path, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,
                   int64_t start_row, int64_t stop_row);
+/* The same for nfrag fragments of one scan side by side, a thread each (the streaming reader's sub-fragments of a window: cut at burst
+ * boundaries, each with its own decoder context and its own piece of the .tap).  stats[nfrag], seconds[nfrag] (each fragment's own time).
+ * Returns 0, or the first failing fragment's code. */
+int rt_replay_run_fragments(const struct rt_options *opt, const struct rt_parms *parmsets, int nparm,
+                  int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int64_t row_base, const int *W,
+                  const rtfe_burst *bursts, int64_t nbursts, const uint32_t *counts, const rtfe_event *events,
+                  rt_exact_fn exact, rt_exact_free_fn exact_free, void *user,
+                  int nfrag, const char *const *tap_paths, const int64_t *start_rows, const int64_t *stop_rows, struct rt_replay_stats *stats, double *seconds);
+/* The reader's positional read of nbytes at file offset `off` into dst, as nthreads pieces side by side (from the page cache one thread copies
+ * ~13 GB/s).  Returns 0, -1 on a short read or an error. */
+int rt_read_mt(int fd, void *dst, int64_t off, int64_t nbytes, int nthreads);
 int rt_replay_run_ww(const struct rt_options *opt, const struct rt_parms *parmsets,
                   int64_t tdelta_ns, int64_t tstart_ns, int64_t nrows, int W0, rt_ww_scan_fn scan, void *user, const void *initial_state, int64_t chunk_rows,
                   const char *tap_path, const char *out_base, const char *in_name, const char *log_path, const char *evt_path, struct rt_replay_stats *stats,

@@ -299,6 +299,16 @@ class ScanResult:
         # event_base + (p * T + t) * event_cap) - the device table is left alone.
         pack = os.environ.get("RTFE_PACK_EVENTS")                   # (tests: "1" packs whatever the size, "0" never)
         packed = False
+        if nb and not getattr(self, "packed", False) and not self.single and pack != "0":
+            # not packed behind the scan (a resident tape's scans are not fetched as a rule): now, if it pays - the lists' sizes are known
+            cap2 = np.maximum(self.counts.reshape(nb, -1).max(axis=1), 1).astype(np.int64)
+            dense = int(P * T * cap2.sum())
+            if pack == "1" or (used >= (1 << 16) and 2 * dense < used):
+                fe._pack_buffers(self.bufs, dense)
+                fe._pack(self.bufs, None)
+                be.sync()
+                self.packed, mirror = True, None
+                tab = lambda name, dtype: be.to_numpy(self.bufs[name], dtype)
         if nb and getattr(self, "packed", False) and pack != "0":
             plan = tab("plan", PLAN_DTYPE)[: nb + 1].copy()
             total = int(plan[nb]["event_base"])
@@ -409,14 +419,28 @@ class FrontEnd:
             self._cache[k] = dict(
                 ws=be.empty(lib.rtfe_workspace_bytes(self.h, nrows)), bursts=be.empty(mb * BURST_DTYPE.itemsize),
                 nbursts=be.empty(16), counts=be.empty(mb * P * T * 4), events=be.empty(cap * 16), max_bursts=mb, cap=cap, nrows=nrows)
-            if key == "scan":                             # the lists packed behind the scan (rtfe_pack_events): half the arena is room for every tape seen so far
-                self._cache[k].update(plan=be.empty((mb + 1) * PLAN_DTYPE.itemsize), packed=be.empty((cap // 2) * 16), packed_cap=cap // 2)
-                if hasattr(be, "pinned"):                   # the small tables' host mirror (nbursts | bursts | counts | plan), filled behind the scan on its stream
-                    c = self._cache[k]
-                    c["endmark"] = be.empty(16)
-                    c["mirror_of"] = [c["nbursts"], c["bursts"], c["counts"], c["plan"], c["endmark"]]
-                    c["mirror"] = be.pinned(sum(int(t.numel()) for t in c["mirror_of"]))
         return self._cache[k]
+
+    def _pack_buffers(self, b, records):
+        """The buffers of rtfe_pack_events beside a scan's: the plan, room for `records` packed events, and - where the backend has page-locked
+        memory - the host mirror of the small tables (nbursts | bursts | counts | plan | end mark), filled behind the scan on its stream."""
+        be = self.backend
+        if "plan" not in b:
+            b["plan"] = be.empty((b["max_bursts"] + 1) * PLAN_DTYPE.itemsize)
+            b["endmark"] = be.empty(16)
+            if hasattr(be, "pinned"):
+                b["mirror_of"] = [b["nbursts"], b["bursts"], b["counts"], b["plan"], b["endmark"]]
+                b["mirror"] = be.pinned(sum(int(t.numel()) for t in b["mirror_of"]))
+        if b.get("packed_cap", 0) < records:
+            b["packed"], b["packed_cap"] = be.empty(records * 16), int(records)
+        return b
+
+    def _pack(self, b, stream):
+        be = self.backend
+        rc = self.lib.rtfe_pack_events(self.h, be.ptr(b["bursts"]), be.ptr(b["nbursts"]), b["max_bursts"], be.ptr(b["counts"]), be.ptr(b["events"]),
+                                       be.ptr(b["packed"]), b["packed_cap"], be.ptr(b["plan"]), stream if stream is not None else be.stream())
+        if rc != 0:
+            raise RuntimeError(f"rtfe_pack_events failed ({rc}): {self.lib.rtfe_last_error().decode()}")
 
     def _rows(self, rows):
         """The rows where the kernels can read them; the C ABI takes a pointer and a row count, so the row width is checked here."""
@@ -432,8 +456,13 @@ class FrontEnd:
         d_rows = self._rows(rows)
         nrows = int(d_rows.shape[0])
         b = self._buffers(nrows)
+        pack_now = getattr(self, "pack_on_scan", False) and os.environ.get("RTFE_PACK_EVENTS") != "0"      # (the streaming reader: every window's lists cross PCIe)
+        if pack_now:
+            self._pack_buffers(b, b["cap"] // 2)          # half the arena is room for every tape seen so far; a window that needs more is fetched as it is
         marked = False
-        if getattr(self, "find_end_mark", False) and "endmark" in b:      # (the streaming reader: the window's end-of-data check on the device, in front of the scan)
+        import time
+        lt = [time.perf_counter()]
+        if getattr(self, "find_end_mark", False) and pack_now:      # (the streaming reader: the window's end-of-data check on the device, in front of the scan)
             if self.lib.rtfe_find_end_mark(self.h, be.ptr(d_rows), nrows, be.ptr(b["endmark"]), stream if stream is not None else be.stream()) != 0:
                 raise RuntimeError(f"rtfe_find_end_mark failed: {self.lib.rtfe_last_error().decode()}")
             marked = True
@@ -443,20 +472,21 @@ class FrontEnd:
                                 be.ptr(b["events"]), b["cap"], stream if stream is not None else be.stream())
         if rc != 0:
             raise RuntimeError(f"rtfe_scan failed ({rc}): {self.lib.rtfe_last_error().decode()}")
+        lt.append(time.perf_counter())
         r = ScanResult(self, b, b["max_bursts"])
         r._rows_keepalive = d_rows
         r.end_mark_checked, r.end_mark, r.end_mark_valid = marked, None, False
-        if "plan" in b and os.environ.get("RTFE_PACK_EVENTS") != "0":
-            rc = self.lib.rtfe_pack_events(self.h, be.ptr(b["bursts"]), be.ptr(b["nbursts"]), b["max_bursts"], be.ptr(b["counts"]), be.ptr(b["events"]),
-                                           be.ptr(b["packed"]), b["packed_cap"], be.ptr(b["plan"]), stream if stream is not None else be.stream())
-            if rc != 0:
-                raise RuntimeError(f"rtfe_pack_events failed ({rc}): {self.lib.rtfe_last_error().decode()}")
+        if pack_now:
+            self._pack(b, stream)
             r.packed = True
+            lt.append(time.perf_counter())
             if "mirror" in b:
                 be.mirror_async(b["mirror"], b["mirror_of"], stream)
                 r.mirrored = True
         if hasattr(be, "record"):
             r.done = be.record(stream)
+        lt.append(time.perf_counter())
+        r.launch_times = lt                                # (the scan queued, the packing queued, the mirror copies and the event queued)
         return r
 
     def scan_exact(self, rows, reset_row, end_row, parmset_mask=0xFFFFFFFF, screen_off=False, row_base=0, stream=None) -> ScanResult:

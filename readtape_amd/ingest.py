@@ -5,12 +5,16 @@ Replaces the reference's read loop (two fread()s per row into a stack buffer, sr
     disk --(reader thread, readinto)--> pinned host buffer --(hipMemcpyAsync, copy stream)--> device window
          --(rtfe_scan, compute stream)--> events --(host replay of the window's own bursts)--> piece of the .tap
 
-A three-stage software pipeline: window k + 2 is being read (three pinned buffers; the read itself in `read_threads` pieces side by
-side), window k + 1 is being copied and scanned behind window k on the device (two scan contexts), window k is fetched - event arena
-packed on the device first - and handed to the replay threads.  A window is a FRAGMENT in the sense of pipeline.decode_fragment: it
-carries a halo of the following rows, owns the bursts whose zone ends inside it, and its .tap piece concatenates with its
-neighbours' (DESIGN.md 6).  PyTorch supplies the pinned allocation (hipHostMalloc), the streams and the events; nothing here
-computes on the CPU except the block decoders.
+A software pipeline of threads (the interpreter lock is the scarce resource: whatever runs per row or per event runs in native code):
+  - the producer reads window after window into a ring of pinned buffers (rt_read_mt: native threads, positional reads) and queues each
+    window's upload (copy stream) and, behind it on the scan stream, rtfe_find_end_mark (the reader's end-of-data check, on the device),
+    rtfe_scan, rtfe_pack_events and the copies of the small tables into page-locked memory - `scan_contexts` windows are in flight;
+  - a fetcher per context waits for its window's event, copies the packed event lists to the host and hands the window to the replay pool;
+  - a replay task per window runs its sub-fragments on native threads (rt_replay_run_fragments) and collects their pieces of the .tap;
+  - the caller's thread concatenates the pieces in window order.
+A window is a FRAGMENT in the sense of pipeline.decode_fragment: it carries a halo of the following rows, owns the bursts whose zone ends
+inside it, and its .tap piece concatenates with its neighbours' (DESIGN.md 6).  PyTorch supplies the pinned allocation (hipHostMalloc), the
+streams and the events; nothing here computes on the CPU except the block decoders.
 """
 from __future__ import annotations
 
@@ -81,7 +85,7 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     NP = nctx + 1                                         # pinned buffers: one being read into, the others being copied from / waiting for their context
     pinned = [torch.empty((cap, ntrks), dtype=torch.int16, pin_memory=True) for _ in range(NP)]      # hipHostMalloc
     dwin = [torch.empty((cap, ntrks), dtype=torch.int16, device=dev) for _ in range(depth)]
-    pool = ThreadPoolExecutor(nthreads) if nthreads > 1 else None
+    pool = ThreadPoolExecutor(max(2, -(-nthreads // max(1, int(replay_split))))) if nthreads > 1 else None      # a task is a window: its sub-fragments are native threads
     read_threads = max(1, int(read_threads))
     readers = ThreadPoolExecutor(read_threads) if read_threads > 1 else None
     fe_exact = frontend.FrontEnd(cfg, device=device)       # exact rescans of the replays: their own context, one at a time
@@ -89,6 +93,7 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     copy_stream, scan_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     copied = [torch.cuda.Event() for _ in range(NP)]
     fd = os.open(path, os.O_RDONLY)
+    dlib = pipeline._load_decode_lib()
     t_read = [0.0]
     trace = [] if os.environ.get("RT_INGEST_TRACE") else None      # (stage, window, start, end) in seconds since the timed region began
     t_base = [0.0]
@@ -101,7 +106,7 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
 
     gpu_mark = hasattr(fe.backend, "pinned") and os.environ.get("RTFE_PACK_EVENTS") != "0" and not os.environ.get("RT_INGEST_HOST_MARK")
     for f in fes:                                          # the end-of-data marker is looked for on the device, in front of each window's scan (rtfe_find_end_mark)
-        f.find_end_mark = gpu_mark
+        f.pack_on_scan, f.find_end_mark = True, gpu_mark
 
     def read_span(arr, r0, r1, lo, check=True):
         """rows [lo + r0, lo + r1) of the payload -> arr[r0:r1]; returns the first row (relative to lo) whose head-0 sample is the end
@@ -125,7 +130,11 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         t0 = time.perf_counter()
         arr = dst.numpy()
         n = end - lo
-        if readers is None or n * 2 * ntrks < (8 << 20):
+        if not check:                                      # (the end marker is looked for on the device: the read is one call into native threads)
+            if dlib.rt_read_mt(fd, arr.ctypes.data, off + lo * 2 * ntrks, n * 2 * ntrks, read_threads) != 0:
+                raise IOError("short read")
+            first = -1
+        elif readers is None or n * 2 * ntrks < (8 << 20):
             first = read_span(arr, 0, n, lo, check)
         else:
             step = -(-n // read_threads)
@@ -169,12 +178,17 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
             copied[k % NP].record(copy_stream)
             if trace is not None:
                 gpu_ev[("copy1", k)] = torch.cuda.Event(enable_timing=True); gpu_ev[("copy1", k)].record(copy_stream)
+        mark("l_h2d", k, t0)
         scan_stream.wait_event(copied[k % NP])
         piece = dwin[k % depth][: end - lo]
         fin = pipeline.scan_fragment(fes[k % nctx], piece, hi - lo, lo, lo == 0, hi >= data_end[0], stream=scan_stream.cuda_stream)
         if trace is not None:
             gpu_ev[("scan1", k)] = torch.cuda.Event(enable_timing=True); gpu_ev[("scan1", k)].record(scan_stream)
         mark("launch", k, t0)
+        if trace is not None and getattr(fin.res, "launch_times", None):
+            lt = fin.res.launch_times
+            for name, a, b in (("l_scan", lt[0], lt[1]), ("l_pack", lt[1], lt[2]), ("l_mirror", lt[2], lt[3])) if len(lt) == 4 else ():
+                trace.append((name, k, round(a - t_base[0], 5), round(b - t_base[0], 5)))
         return piece, fin, end
 
     launched = queue.Queue()
@@ -218,10 +232,23 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         mark("replay" + tag, k, t0)
         return data, st, time.perf_counter() - t0
 
+    def replay_window(k, res, piece, lo, starts, stops):
+        """-> [(bytes, replay statistics, seconds), ...] of the window's sub-fragments, in order"""
+        t0 = time.perf_counter()
+        frags = [f"{tap_path}.frag{k}.{j}" for j in range(len(starts))]
+        sts = pipeline.decode_fragments(hdr, cfg, fe_exact, res, piece, lo, starts, stops, frags, full, opts, exact_lock=exact_lock)
+        out = []
+        for frag, (st, secs) in zip(frags, sts):
+            with open(frag, "rb") as g:
+                out.append((g.read(), st, secs))
+            os.remove(frag)
+        mark("replay", k, t0)
+        return out
+
     stats = dict(rows=nrows, windows=len(spans), halo_rows_read=0, blocks=0, tapemarks=0, events_delivered=0, exact_scans=0, retries=0, replay_threads=nthreads)
     t_replay = 0.0
     for f in fes:                                         # set-up, like the pinned buffers and the device windows: the scan contexts' workspaces
-        f._buffers(cap)
+        f._pack_buffers(f._buffers(cap), f._buffers(cap)["cap"] // 2)
     # (and page-locked blocks for the windows' event lists in the host allocator's cache: a window's packed events are ~1 / 40 of its arena)
     blk = [torch.empty(max(1 << 20, cap * ntrks * 16 // 40), dtype=torch.uint8, pin_memory=True) for _ in range(min(depth, 12))]
     del blk
@@ -288,7 +315,7 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                             import dataclasses
                             cfg2 = dataclasses.replace(cfg, screen_floor_height=min(4.0, 0.5 * st_k["min_learned_height"]))
                             new = [frontend.FrontEnd(cfg2, device=device) for _ in range(nctx)]
-                            for f in new: f._buffers(cap); f.find_end_mark = gpu_mark
+                            for f in new: f._pack_buffers(f._buffers(cap), f._buffers(cap)["cap"] // 2); f.pack_on_scan, f.find_end_mark = True, gpu_mark
                             retired.extend(fes)
                             fes[:] = new                     # (the producer takes a window's context from the list when it launches it)
                             floor_state["tries"] = 0; floor_state["floor"] = cfg2.screen_floor_height
@@ -308,13 +335,14 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
             stats["halo_rows_read"] += end_k - hi
             if res.nbursts:
                 if pool:
-                    # sub-fragments: cut at the zone starts of evenly spaced bursts
-                    split = int(replay_split) * (4 if k + 2 >= len(spans) else 1)
+                    # sub-fragments: cut at the zone starts of evenly spaced bursts; one task (a Python thread) per window, native threads for its sub-fragments
+                    split = int(replay_split) * (2 if k + 2 >= len(spans) else 1)
                     nsub = max(1, min(split, nthreads, res.nbursts // 8))
                     cuts = [int(res.bursts[(res.nbursts * j) // nsub]["zone_first"]) for j in range(1, nsub)]
                     first = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
                     starts, stops = [first] + cuts, cuts + [bound]
-                    out = [pool.submit(replay, k, res, piece, lo, stops[j], starts[j], f".{j}") for j in range(nsub) if stops[j] is None or stops[j] > starts[j]]
+                    keep = [j for j in range(nsub) if stops[j] is None or stops[j] > starts[j]]
+                    out = [pool.submit(replay_window, k, res, piece, lo, [starts[j] for j in keep], [stops[j] for j in keep])]
                     busy[k % depth] = _All(out)
                 else:
                     out = [replay(k, res, piece, lo, bound)]
@@ -326,6 +354,10 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     prod = threading.Thread(target=producer, name="rt-ingest-producer")
     import sys
     switch = sys.getswitchinterval()
+    import gc
+    gc_was = gc.isenabled()
+    if not os.environ.get("RT_INGEST_GC"):
+        gc.disable()                                      # a full collection walks every object of the process (PyTorch is loaded: tens of ms) with the interpreter lock held - every stage stalls at once
     sys.setswitchinterval(float(os.environ.get("RT_INGEST_SWITCH", "0.0002")))      # a dozen threads hand the interpreter lock around between system calls: at the default 5 ms a stage waits longer for the lock than it works
     try:
         with open(tap_path, "wb") as tapf:
@@ -341,18 +373,21 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                 if fut is not None:
                     pieces.extend(fut.result())
             for pc in pieces:                                 # in window order
-                data, st, secs = pc.result() if hasattr(pc, "result") else pc
-                t_replay += secs
-                tapf.write(data)
-                total += len(data)
-                for key in ("blocks", "tapemarks", "events_delivered", "exact_scans"):
-                    stats[key] += int(st[key])
+                got = pc.result() if hasattr(pc, "result") else [pc]
+                for data, st, secs in got:
+                    t_replay += secs
+                    tapf.write(data)
+                    total += len(data)
+                    for key in ("blocks", "tapemarks", "events_delivered", "exact_scans"):
+                        stats[key] += int(st[key])
             if total > 0:
                 tapf.write(b"\xff\xff\xff\xff")                   # src/readtape.c:1885
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t_start
     finally:                                              # (also when a replay raised: no thread, file or device context is left behind)
         sys.setswitchinterval(switch)
+        if gc_was:
+            gc.enable()
         stop.set()
         for sem in ctx_free:                              # (a producer waiting for a context wakes up and sees the stop flag)
             sem.release()

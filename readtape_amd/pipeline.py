@@ -46,7 +46,17 @@ _FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 _WW_SCAN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32)
 
 
+_DECODE_LIB = None
+
+
 def _load_decode_lib():
+    global _DECODE_LIB
+    if _DECODE_LIB is None:
+        _DECODE_LIB = _open_decode_lib()
+    return _DECODE_LIB
+
+
+def _open_decode_lib():
     path = os.path.join(HERE, "librtdecode.so")
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
@@ -61,6 +71,8 @@ def _load_decode_lib():
                                      C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Stats), C.c_int, C.POINTER(C.c_int)]
     lib.rt_replay_run_named.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_Stats)]
     lib.rt_replay_run_fragment.argtypes = lib.rt_replay_run.argtypes + [C.c_int64, C.c_int64]
+    lib.rt_replay_run_fragments.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_Stats), C.POINTER(C.c_double)]
+    lib.rt_read_mt.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int]
     lib.rt_replay_deskew.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.rt_replay_density.argtypes = lib.rt_replay_run.argtypes[:15] + [C.c_char_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return lib
@@ -421,6 +433,7 @@ def scan_fragment(fe, rows_with_halo, own_rows, lo, is_first, is_last, stream=No
                 return res, None, None                 # the halo holds no further zone: the caller retries with a longer one
             bound = int(res.next_burst[0]["zone_first"])          # relative to the fragment
         return res, nb, bound
+    finish.res = res
     return finish
 
 
@@ -451,6 +464,40 @@ def decode_fragment(hdr, cfg, fe, res, rows_with_halo, lo, start_row, stop_row, 
     if stats["reference_fatal"] or stats["device_failures"]:
         raise RuntimeError(f"fragment at row {lo}: the decode stopped early ({stats})")
     return stats
+
+
+def decode_fragments(hdr, cfg, fe, res, rows_with_halo, lo, start_rows, stop_rows, tap_paths, full, opts, fe_factory=None, exact_lock=None):
+    """decode_fragment for several fragments of ONE scan side by side - native threads inside librtdecode.so, this thread takes the first
+    (rt_replay_run_fragments): the streaming reader hands a window's sub-fragments over in one call.  Returns [(statistics, seconds), ...]."""
+    from readtape_amd import shard
+    lib = _load_decode_lib()
+    o = _Options(mode=hdr.mode, ntrks=hdr.ntrks, bpi=cfg.bpi, ips=cfg.ips, specified_parity=0 if opts.even_parity else 1,
+                 revparity=opts.revparity, do_correction=int(opts.correct), find_zeros=int(cfg.find_zeros), do_differentiate=int(cfg.differentiate),
+                 multiple_tries=int(opts.multiple_tries), tap_format=1, add_parity=0, verbose=int(opts.verbose))
+    parr = (_Parms * len(full))(*full)
+    W = (C.c_int * len(full))(*fe.widths)
+    exact, free, keep = _exact_callbacks(fe, rows_with_halo, hdr.ntrks, fe_factory, lock=exact_lock)
+    n = len(tap_paths)
+    st = (_Stats * n)()
+    secs = (C.c_double * n)()
+    paths = (C.c_char_p * n)(*[p.encode() for p in tap_paths])
+    starts = (C.c_int64 * n)(*[int(a) for a in start_rows])
+    stops = (C.c_int64 * n)(*[I64MAX if b is None else int(b) for b in stop_rows])
+    bursts = np.ascontiguousarray(shard.absolute_bursts(res, lo))
+    counts = np.ascontiguousarray(res.counts)
+    rc = lib.rt_replay_run_fragments(C.byref(o), parr, len(full), hdr.tdelta_ns, hdr.tstart_ns, int(rows_with_halo.shape[0]), lo, W,
+                                     bursts.ctypes.data, len(bursts), counts.ctypes.data, res._events.ctypes.data, exact, free, None,
+                                     n, paths, starts, stops, st, secs)
+    _release(keep)
+    if rc != 0:
+        raise RuntimeError("rt_replay_run_fragments failed")
+    out = []
+    for i in range(n):
+        stats = {k: getattr(st[i], k) for k, _ in _Stats._fields_}
+        if stats["reference_fatal"] or stats["device_failures"]:
+            raise RuntimeError(f"fragment at row {lo}: the decode stopped early ({stats})")
+        out.append((stats, float(secs[i])))
+    return out
 
 
 def decode_tape_fragments(hdr, rows, tap_path, spans, opts: DecodeOptions | None = None, fe_factory=None, halo_rows=1 << 16, cfgkw=None):
