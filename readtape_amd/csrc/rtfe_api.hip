@@ -97,10 +97,17 @@ static int sf_wmax(const DevCfg &d) { int w = 0; for (int s = 0; s < d.nscreens;
 static int sf_threads(const DevCfg &d) { return 64 * ((d.ntrks + 1) / 2); }
 static int sf_nvec(const DevCfg &d) { return (d.pk_hl + kSfTile + d.pk_hr) * d.ntrks / 8; }
 static int sf_nv(const DevCfg &d) { return (sf_nvec(d) + sf_threads(d) - 1) / sf_threads(d); }
-static sfs_kernel_t sf_special(const DevCfg &d) { return (d.nscreens == 1 && d.screen[0].sure_i <= 32767 && !getenv("RTFE_SIFT_GENERIC")) ? sfs_kernel(d.screen[0].W, d.ntrks) : nullptr; }
+// (several window widths - a parameter sweep -: a launch of the lean kernel per screen, if every screen has one: NRZI -m is three widths, 1.5 ms each where the
+//  general kernel's loop over the screens took 15.8)
+static sfs_kernel_t sf_special_sc(const DevCfg &d, int sc) { return (d.screen[sc].sure_i <= 32767 && !getenv("RTFE_SIFT_GENERIC")) ? sfs_kernel(d.screen[sc].W, d.ntrks) : nullptr; }
+static sfs_kernel_t sf_special(const DevCfg &d) {
+   if (d.nscreens > 1 && getenv("RTFE_SIFT_PER_SCREEN") && atoi(getenv("RTFE_SIFT_PER_SCREEN")) == 0) return nullptr;
+   for (int sc = 0; sc < d.nscreens; ++sc) if (!sf_special_sc(d, sc)) return nullptr;
+   return d.nscreens >= 1 ? sf_special_sc(d, 0) : nullptr; }
 // k_sift_s has a geometry of its own: a wave per pair of heads with an odd last head's tile split among them, only the window's rows in front of a tile
 static int sfs_threads(const DevCfg &d) { return 64 * sfs_waves(d.ntrks); }
-static int sfs_lds(const DevCfg &d) { return (int)sfs_lds_layout(d.ntrks, d.screen[0].W, d.pk_wave_cap, d.pk_slot).total + 64; }
+static int sfs_lds_sc(const DevCfg &d, int sc) { return (int)sfs_lds_layout(d.ntrks, d.screen[sc].W, d.pk_wave_cap, d.pk_slot).total + 64; }
+static int sfs_lds(const DevCfg &d) { int m = 0; for (int sc = 0; sc < d.nscreens; ++sc) { const int v = sfs_lds_sc(d, sc); if (v > m) m = v; } return m; }
 
 extern "C" int rtfe_abi_version(void) { return RTFE_ABI_VERSION; }
 extern "C" const char *rtfe_last_error(void) { return g_err; }
@@ -402,7 +409,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (d.invert || d.maxskew > 0 || d.ntrks < 2 || d.zc_peak_i < 1 || d.zc_peak_i > 32767 || !d.zc_parallel) h->zeros_kernel = 0;      // (RTFE_ZC_PARALLEL=0: k_decode's sequential walk, for the tests)
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
       raise_dynamic_lds(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), d.pk_lds);
-      if (sf_special(d)) raise_dynamic_lds(reinterpret_cast<const void *>(sf_special(d)), sfs_lds(d)); }
+      if (sf_special(d)) for (int sc = 0; sc < d.nscreens; ++sc) raise_dynamic_lds(reinterpret_cast<const void *>(sf_special_sc(d, sc)), sfs_lds_sc(d, sc)); }
    if (d.dense_path) raise_dynamic_lds(reinterpret_cast<const void *>(k_dseg), (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, d.ds_up).total + 64);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    if (getenv("RTFE_VERBOSE") && d.peak_path) {
@@ -637,12 +644,19 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       if (pgrid > ptiles) pgrid = ptiles;
       uint16_t *qtile = reinterpret_cast<uint16_t *>(wsb + ws_pkqtile_off(h, nrows));
       if (sfs) {
-         SfArgs a;
-         a.rows = d_rows; a.nrows = nrows; a.ntiles = (int)ptiles; a.qtile = qtile; a.dir = dirm; a.pool = pkpool; a.hard = hardp; a.hard_cap = hard_cap;
-         a.hard_count = &scratch->hard_count; a.dbg = scratch->scr; a.hcap = h->dev.pk_slot; a.wave_cap = h->dev.pk_wave_cap; a.invert = h->dev.invert;
-         a.quiet_i = h->dev.quiet_i; a.lo_i = h->dev.screen[0].rise_i; a.hi_i = h->dev.screen[0].sure_i; a.minpk_i = h->dev.screen[0].minpk_i;
-         a.cut = h->dev.cut; a.debug = h->dev.debug; a.defer = h->sift_defer;
-         hipLaunchKernelGGL(sfs, dim3((unsigned)pgrid), dim3(pthreads), plds, st, a); }
+         for (int sc = 0; sc < h->dev.nscreens; ++sc) {
+            SfArgs a;
+            a.rows = d_rows; a.nrows = nrows; a.ntiles = (int)ptiles; a.qtile = sc == 0 ? qtile : nullptr; a.dir = dirm; a.pool = pkpool; a.hard = hardp; a.hard_cap = hard_cap;
+            a.hard_count = &scratch->hard_count; a.dbg = scratch->scr; a.hcap = h->dev.pk_slot; a.wave_cap = h->dev.pk_wave_cap; a.invert = h->dev.invert;
+            a.quiet_i = h->dev.quiet_i; a.lo_i = h->dev.screen[sc].rise_i; a.hi_i = h->dev.screen[sc].sure_i; a.minpk_i = h->dev.screen[sc].minpk_i;
+            a.cut = h->dev.cut; a.debug = h->dev.debug; a.defer = h->sift_defer; a.nscreens = h->dev.nscreens; a.sc = sc;
+            const int lds_sc = sfs_lds_sc(h->dev, sc);
+            int spc_sc = (160 * 1024) / (lds_sc + 512);
+            if (spc_sc > spc) spc_sc = spc;
+            if (spc_sc < 1) spc_sc = 1;
+            long long grid_sc = (long long)h->num_cus * spc_sc;
+            if (grid_sc > ptiles) grid_sc = ptiles;
+            hipLaunchKernelGGL(sf_special_sc(h->dev, sc), dim3((unsigned)grid_sc), dim3(pthreads), lds_sc, st, a); } }
       else {
          const sf_kernel_t sfk = sf_kernel(sf_wmax(h->dev), pthreads, sf_nv(h->dev));
          hipLaunchKernelGGL(sfk, dim3((unsigned)pgrid), dim3(pthreads), h->dev.pk_lds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, ptiles,

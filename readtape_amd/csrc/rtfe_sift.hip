@@ -703,6 +703,7 @@ struct SfArgs {
    const int16_t *rows; long long nrows; int ntiles;
    uint16_t *qtile; PeakDir *dir; unsigned char *pool; SfHard *hard; int hard_cap; int *hard_count; unsigned long long *dbg;
    int hcap, wave_cap, invert, quiet_i, lo_i, hi_i, minpk_i, cut, debug;
+   int nscreens, sc;      // several window widths: a launch per screen `sc` of `nscreens` (lists and directory are [tile][screen][head]); the quiet map comes from the launch that is given qtile
    int defer;      // 1: a tile's lists leave LDS at the start of the NEXT tile step (the stores' acknowledgements are then old when the step's first s_waitcnt vmcnt(0) - the prefetched rows - asks)
 };
 
@@ -775,14 +776,15 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          const int h = h_lo + hh;
          const int nr = hh ? rec_hi : rec_lo;
          const bool over = bad || 16 * nr > hcap;
-         unsigned char *gslot = a.pool + ((size_t)tile * NT + h) * (size_t)hcap;
+         const size_t li = ((size_t)tile * a.nscreens + a.sc) * NT + h;      // the list's place: [tile][screen][head]
+         unsigned char *gslot = a.pool + li * (size_t)hcap;
          if (!over && nr > 0 && cut != 6) {
             const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
             for (int v = lane; v < nr; v += 64) reinterpret_cast<int4 *>(gslot)[v] = src[v];      // (a 16-byte vector a record)
             if (a.debug == 3) pn_bytes += (unsigned)(16 * nr); }
          if (lane == 0) {
             PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
-            a.dir[(size_t)tile * NT + h] = d; } } };
+            a.dir[li] = d; } } };
    // split: the last head's list is the waves' parts one behind the other.  Every wave copies its own part once all counts are known: behind the
    // workgroup barrier that ends the tile's step, i.e. at the start of the next one (or behind the loop).
    auto copy_out3 = [&](const int tile, const int pp) {
@@ -795,13 +797,14 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          tot += c; if (w2 < wave) off += c; }
       over = over || 16 * tot > hcap;
       const int mine = s_part[pp][wave];
-      unsigned char *gslot = a.pool + ((size_t)tile * NT + H3) * (size_t)hcap;
+      const size_t li = ((size_t)tile * a.nscreens + a.sc) * NT + H3;
+      unsigned char *gslot = a.pool + li * (size_t)hcap;
       if (!over && cut != 6) {
          const int4 *src = reinterpret_cast<const int4 *>(smem + L.part + wave * cap3);
          for (int v = lane; v < mine; v += 64) reinterpret_cast<int4 *>(gslot)[off + v] = src[v]; }
       if (wave == 0 && lane == 0) {
          PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)tot; d.nent = 0;
-         a.dir[(size_t)tile * NT + H3] = d; } };
+         a.dir[li] = d; } };
    for (int tile = tile_lo; tile < ntiles; tile += G, par ^= 1) {
       const int prev_tile = last_tile;
       last_tile = tile;
@@ -814,10 +817,11 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       else sf_fill_edge(xsl, a.rows, ((long long)tile * kSfTile - HL) * NT, a.nrows * NT, NVEC * 8, tid, NTH);
       __syncthreads();
       if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G);
-      if (tid == 0 && tile > tile_lo) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
+      if (tid == 0 && tile > tile_lo && a.qtile) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
       if (p_tile >= 0) { copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad); p_tile = -1; rtfe_wave_sync(); }      // (the lists of the tile in front: a.defer)
       if (SPL && prev_tile >= 0 && cut != 1) { copy_out3(prev_tile, par ^ 1); rtfe_wave_sync(); }
-      // ---- 2. quiet groups: flat 16-byte reads of the tile proper; a ballot of 64 vectors lies in one or two groups ----
+      // ---- 2. quiet groups: flat 16-byte reads of the tile proper; a ballot of 64 vectors lies in one or two groups (several screens: the first launch's business) ----
+      if (a.qtile)
       #pragma unroll
       for (int it = 0; it < NQIT; ++it) {
          bool noisy = false;
@@ -917,7 +921,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
                   if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
                      const int hidx = atomicAdd(a.hard_count, 1);
                      if (hidx < a.hard_cap) {
-                        SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)head; hd.screen = 0;
+                        SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)head; hd.screen = (uint8_t)a.sc;
                         a.hard[hidx] = hd;
                         w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
                      else { w0 = pk_w0(cpos, false, cpos + 1, 0, cx.W - 2, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
@@ -944,7 +948,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       __syncthreads(); }
    if (p_tile >= 0) copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad);
    if (SPL && last_tile >= 0 && cut != 1) copy_out3(last_tile, par ^ 1);
-   if (tid == 0 && last_tile >= 0) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);
+   if (tid == 0 && last_tile >= 0 && a.qtile) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);
    if (a.debug == 3 && lane == 0) {
       atomicAdd(&a.dbg[3], (unsigned long long)pn_bytes); atomicAdd(&a.dbg[4], (unsigned long long)pn_hard); atomicAdd(&a.dbg[5], (unsigned long long)pn_rounds);
       if (wave == 0) atomicAdd(&a.dbg[7], (unsigned long long)(last_tile >= 0 ? (last_tile - tile_lo) / G + 1 : 0)); } }
