@@ -71,8 +71,10 @@ typedef struct rtfe_config {
    int32_t gap_min_samples;               /* quiet run treated as an inter-block gap; 0 = 32 bit cells */
    float   quiet_volts;                   /* |v| band of the dead-quiet test; 0 = default         */
    float   screen_floor_height;           /* assumed lower bound of the AGC baseline (v_avg_height) for
-                                             the candidate screen; 0 = default 1.0 V.  A burst whose
-                                             measured baseline is lower is flagged RTFE_F_SCREEN_UNDERFLOW */
+                                             the candidate screen.  A burst whose measured baseline is lower is
+                                             flagged RTFE_F_SCREEN_UNDERFLOW.  0 = the handle starts at 1.0 V and
+                                             follows the tape: behind each scan of the peak path the floor moves to
+                                             half the smallest peak height the scan learned (rtfe_scan_stats out[22]) */
    float   events_per_sample_cap;         /* per-track event capacity as a fraction of the burst length;
                                              0 = default 1/8 */
 } rtfe_config;
@@ -193,7 +195,9 @@ int rtfe_kernel_ms(rtfe_handle *h, float *out);
  * and the tests; no effect on results.  out[5..12] = chains that gave up, by reason; out[13..20] = cycle counters of k_sift / k_gain / k_bursts / k_gain_seg (RTFE_DEBUG=3 / 4 / 5 / 6).
  * out[21] = 0x7fffffff - the IEEE bits of the smallest v_avg_height (src/decode_nrzi.c:224-229) a chain of the scan learned, 0 if none did (peak path):
  * what a caller may raise rtfe_config::screen_floor_height towards for the next scans of the same tape - a floor above a later chain's learned height is
- * flagged RTFE_F_SCREEN_UNDERFLOW and costs an exact rescan, never a wrong event.  out must hold 24 values. */
+ * flagged RTFE_F_SCREEN_UNDERFLOW and costs an exact rescan, never a wrong event.  out[22] = the IEEE bits of the floor the handle's next scan screens against:
+ * with rtfe_config::screen_floor_height == 0 the handle starts at 1 V and, behind every scan of the peak path, moves the floor to half the smallest height that
+ * scan's chains learned (on the device, nothing waits; a floor the caller gives stands).  out must hold 24 values. */
 int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out);
 
 /* Names and launch-order of the kernels of one scan, for profilers (static strings). */

@@ -198,26 +198,22 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       if (ps.agc_window && ps.agc_alpha != 0) { delete h; return fail(-12, "parmset %d: inconsistent AGC parameters", p); }   // src/decoder.c:502
       dp.W = W; dp.rise = ps.pkww_rise; dp.min_peak = ps.min_peak; dp.agc_alpha = ps.agc_alpha; dp.agc_window = ps.agc_window;
       dp.t_clkwindow = bitspace / 2 * ps.clk_factor;                      // src/decoder.c:449
-      // loosest thresholds the AGC can ever ask for, given v_avg_height >= hfloor and agc_gain <= 2
-      const float scale = (hfloor < 4.0f ? hfloor : 4.0f) / 4.0f / 2.0f;
-      dp.screen_rise_v = ps.pkww_rise * scale;
-      dp.screen_minpk_v = ps.min_peak * scale;
       int s;
       for (s = 0; s < d.nscreens; ++s) if (d.screen[s].W == W) break;
       if (s == d.nscreens) {
          if (s == kMaxScreens) { delete h; return fail(-13, "more than %d distinct window widths", kMaxScreens); }
          d.screen[s].W = W; d.screen[s].rise_i = 1 << 30; d.screen[s].minpk_i = 1 << 30; ++d.nscreens; }
       dp.screen = s;
-      int ri = (int)floor(dp.screen_rise_v * lsb_per_volt * (1.0 - 1e-5)) - 2;
-      int mi = ps.min_peak > 0 ? (int)floor(dp.screen_minpk_v * lsb_per_volt * (1.0 - 1e-5)) - 2 : -1;
-      if (ri < -1) ri = -1;
-      if (ri < d.screen[s].rise_i) d.screen[s].rise_i = ri;
-      if (mi < d.screen[s].minpk_i) d.screen[s].minpk_i = mi;
       // dead-quiet band: no detection is possible from a freshly reset detector (agc 1, baseline 4 V) while
       // |v| < min_peak, or while the signal range 2|v| < pkww_rise
       float q = ps.min_peak > ps.pkww_rise / 2 ? ps.min_peak : ps.pkww_rise / 2;
       if (q < quiet_v) quiet_v = q; }
-   for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].minpk_i < 0) d.screen[s].minpk_i = -1;
+   // the candidate screens: the loosest thresholds the AGC can ever ask for, given v_avg_height >= hfloor and agc_gain <= 2 (screen_thresholds, rtfe_kernels.hip).
+   // A floor the caller gave stands; the default (1 V: every tape clears it) is where the handle starts, and behind each scan of the peak path the
+   // floor moves to half the smallest peak height the scan's chains learned (k_adapt_floor; RTFE_ADAPT_FLOOR=0: never)
+   d.floor_cfg = hfloor;
+   d.adapt_floor = !(c->screen_floor_height > 0) && !(getenv("RTFE_ADAPT_FLOOR") && atoi(getenv("RTFE_ADAPT_FLOOR")) == 0);
+   screen_thresholds(d, hfloor);
    // k_peaks: a row whose margin reaches sure_i passes the rise test for every threshold the chains accept without asking
    // (tightest: baseline 1.5 x full scale at half gain); k_chain hands a burst whose threshold climbs beyond that to the sample path
    for (int s = 0; s < d.nscreens; ++s) {
@@ -648,7 +644,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
             SfArgs a;
             a.rows = d_rows; a.nrows = nrows; a.ntiles = (int)ptiles; a.qtile = sc == 0 ? qtile : nullptr; a.dir = dirm; a.pool = pkpool; a.hard = hardp; a.hard_cap = hard_cap;
             a.hard_count = &scratch->hard_count; a.dbg = scratch->scr; a.hcap = h->dev.pk_slot; a.wave_cap = h->dev.pk_wave_cap; a.invert = h->dev.invert;
-            a.quiet_i = h->dev.quiet_i; a.lo_i = h->dev.screen[sc].rise_i; a.hi_i = h->dev.screen[sc].sure_i; a.minpk_i = h->dev.screen[sc].minpk_i;
+            a.quiet_i = h->dev.quiet_i; a.cfg = h->d_dev; a.hi_i = h->dev.screen[sc].sure_i;
             a.cut = h->dev.cut; a.debug = h->dev.debug; a.defer = h->sift_defer; a.nscreens = h->dev.nscreens; a.sc = sc;
             const int lds_sc = sfs_lds_sc(h->dev, sc);
             int spc_sc = (160 * 1024) / (lds_sc + 512);
@@ -745,6 +741,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(threads), h->lds_bytes, st, h->d_dev, d_rows, (long long)nrows,
                          (long long)row_base, d_bursts, scratch, d_counts, d_events, 0xffffffffu, 0, 0, (int)kDecodeRedo, ctlp);
       t1(kTDecode);
+      if (h->dev.adapt_floor) hipLaunchKernelGGL(k_adapt_floor, dim3(1), dim3(1), 0, st, h->d_dev, (const BurstScratch *)scratch);      // (the NEXT scan's screen)
       skip_rest();
       return launch_check("rtfe_scan"); }
    // ---- the sample path: quiet map -> bursts -> every burst in one pass over its samples ----
@@ -849,6 +846,9 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
    out[0] = sc.nbursts; out[1] = sc.seg_failed; out[2] = (int64_t)sc.scr[3]; out[3] = (int64_t)sc.dbg[0]; out[4] = (int64_t)sc.dbg[1];
    for (int i = 0; i < 8; ++i) out[5 + i] = (int64_t)sc.why[i];
    out[21] = (int64_t)sc.min_height_key;      // 0x7fffffff - float bits of the smallest learned v_avg_height, 0: none (the Python binding turns it back)
+   {  float fl = 0;                                // the floor the handle's NEXT scan screens against (k_adapt_floor has moved it behind this one), as float bits
+      if (hipMemcpy(&fl, &h->d_dev->floor_now, sizeof fl, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
+      uint32_t fb; memcpy(&fb, &fl, 4); out[22] = (int64_t)fb; }
    for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)((h->dev.debug == 4 || h->dev.debug == 6 || h->dev.debug == 8) ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
    return 0; }
 

@@ -86,6 +86,10 @@ struct DevCfg {
    int   ds_lean;                            // k_dchain: the steady-state record as straight-line code (0: every record through the general step; tests)
    float ds_quiet_s;                         // a small-signal sub-segment may use the band [its largest margin, infinity) if that starts at or below this scale
    float ds_sfloor;                          // lower end of every band: the scale (v_avg_height / 4) / agc_gain the candidate screen is built for
+   // the candidate screen's floor follows the tape (k_adapt_floor, behind a scan of the peak path): floor_now = what the screen thresholds above stand for
+   // at the moment (the assumed lower bound of a learned peak height), floor_cfg = what the handle was made with, adapt_floor = 1: it may rise
+   float floor_cfg, floor_now;
+   int   adapt_floor;
    DevParm   parm[RTFE_MAXPARMSETS];
    DevScreen screen[kMaxScreens];
 };

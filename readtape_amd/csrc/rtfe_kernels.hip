@@ -53,6 +53,39 @@ struct BurstScratch {            // lives in the workspace (first kScratchBytes 
 };
 static_assert(sizeof(BurstScratch) <= kScratchBytes, "scratch region too small");
 
+// The candidate screen's thresholds for an assumed floor of the learned peak height (v_avg_height >= hfloor, agc_gain <= 2): the loosest thresholds a
+// chain can ask for.  ONE definition for rtfe_create (host) and k_adapt_floor (device): src/decoder.c:785-786 scaled by (hfloor / 4) / 2.
+__host__ __device__ inline void screen_thresholds(DevCfg &d, float hfloor) {
+   const double lsb_per_volt = 32767.0 / (double)d.maxvolts;
+   const float scale = (hfloor < 4.0f ? hfloor : 4.0f) / 4.0f / 2.0f;
+   for (int s = 0; s < d.nscreens; ++s) { d.screen[s].rise_i = 1 << 30; d.screen[s].minpk_i = 1 << 30; }
+   for (int p = 0; p < d.nparm; ++p) {
+      DevParm &dp = d.parm[p];
+      dp.screen_rise_v = dp.rise * scale;
+      dp.screen_minpk_v = dp.min_peak * scale;
+      int ri = (int)floor((double)dp.screen_rise_v * lsb_per_volt * (1.0 - 1e-5)) - 2;
+      const int mi = dp.min_peak > 0 ? (int)floor((double)dp.screen_minpk_v * lsb_per_volt * (1.0 - 1e-5)) - 2 : -1;
+      if (ri < -1) ri = -1;
+      DevScreen &S = d.screen[dp.screen];
+      if (ri < S.rise_i) S.rise_i = ri;
+      if (mi < S.minpk_i) S.minpk_i = mi; }
+   for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].minpk_i < 0) d.screen[s].minpk_i = -1;
+   d.floor_now = hfloor; }
+
+// Behind a scan of the peak path: the chains have learned how high this tape's peaks are (BurstScratch::min_height_key); the next scan of the handle
+// screens its candidates against half the smallest such height instead of the 1 V every tape clears - on a parameter sweep with low rise thresholds the
+// default lets every noise wiggle through (NRZI -m: 15 ms of k_sift against 2.4).  Never wrong: a chain whose thresholds fall below the screen's is
+// flagged RTFE_F_SCREEN_UNDERFLOW (update_thresholds reads the same fields) and rescanned exactly; a scan in which that happened moves the floor down again.
+__global__ void k_adapt_floor(DevCfg *cfg, const BurstScratch *scratch) {
+   if (threadIdx.x != 0 || blockIdx.x != 0 || !cfg->adapt_floor || cfg->differentiate || cfg->find_zeros) return;
+   const int key = scratch->min_height_key;
+   if (key <= 0) return;
+   float want = 0.5f * __uint_as_float((unsigned)(0x7fffffff - key));
+   if (want > 4.0f) want = 4.0f;
+   if (want < cfg->floor_cfg) want = cfg->floor_cfg;
+   if (want == cfg->floor_now) return;
+   screen_thresholds(*cfg, want); }
+
 __device__ __forceinline__ bool quiet_at(const u64 *q, long long c, long long nchunks) {
    return c >= 0 && c < nchunks && ((q[c >> 6] >> (c & 63)) & 1); }
 

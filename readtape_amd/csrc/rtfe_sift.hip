@@ -702,7 +702,8 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
 struct SfArgs {
    const int16_t *rows; long long nrows; int ntiles;
    uint16_t *qtile; PeakDir *dir; unsigned char *pool; SfHard *hard; int hard_cap; int *hard_count; unsigned long long *dbg;
-   int hcap, wave_cap, invert, quiet_i, lo_i, hi_i, minpk_i, cut, debug;
+   const DevCfg *cfg;      // the screen's thresholds are read where they live on the device (k_adapt_floor moves them between scans); hi_i does not depend on the floor
+   int hcap, wave_cap, invert, quiet_i, hi_i, cut, debug;
    int nscreens, sc;      // several window widths: a launch per screen `sc` of `nscreens` (lists and directory are [tile][screen][head]); the quiet map comes from the launch that is given qtile
    int defer;      // 1: a tile's lists leave LDS at the start of the NEXT tile step (the stores' acknowledgements are then old when the step's first s_waitcnt vmcnt(0) - the prefetched rows - asks)
 };
@@ -735,7 +736,8 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    const lds_p xsl = to_lds(xs);
    PkCtx cx;
    cx.t.xs = xsl; cx.t.row_bytes = RB; cx.t.hl = HL; cx.t.sg = a.invert ? -1 : 1;
-   cx.W = W; cx.lo_i = a.lo_i; cx.hi_i = a.hi_i;
+   const int lo_i = a.cfg->screen[a.sc].rise_i, minpk_i = a.cfg->screen[a.sc].minpk_i;
+   cx.W = W; cx.lo_i = lo_i; cx.hi_i = a.hi_i;
    const int G = (int)gridDim.x, ntiles = a.ntiles;
    const int tile_lo = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
    // a tile is "inside" when every row of it and of its halo exists (its bytes then come as 16-byte vectors, one tile ahead)
@@ -751,7 +753,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    const lds_u16p wlist = reinterpret_cast<lds_u16p>(to_lds(smem + L.wl)) + wave * wave_cap;
    const lds_p slot_lo = to_lds(smem + L.stage) + h_lo * hcap, slot_hi = slot_lo + hcap;
    const lds_p slot_3 = to_lds(smem + L.part) + wave * cap3;
-   const uint32_t at = a.minpk_i < 0 ? pk_dup(-32768) : pk_dup(a.minpk_i), ab = a.minpk_i < 0 ? pk_dup(32767) : pk_dup(-a.minpk_i);
+   const uint32_t at = minpk_i < 0 ? pk_dup(-32768) : pk_dup(minpk_i), ab = minpk_i < 0 ? pk_dup(32767) : pk_dup(-minpk_i);
    const uint32_t qpk = pk_dup(a.quiet_i), q2 = 2u * (uint32_t)a.quiet_i;
    int4 q[NV];
    #pragma unroll

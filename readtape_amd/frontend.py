@@ -394,7 +394,7 @@ class FrontEnd:
         key = int(out[21])
         min_height = float(np.array([0x7fffffff - key], dtype=np.uint32).view(np.float32)[0]) if key > 0 else None      # smallest v_avg_height a chain of the scan learned (peak path)
         return dict(bursts=int(out[0]), redone=int(out[1]), record_bytes=int(out[2]), parallel=int(out[3]), sequential=int(out[4]), gave_up=[int(out[5 + i]) for i in range(8)], phase_cycles=[int(out[13 + i]) for i in range(8)],
-                    min_learned_height=min_height)
+                    min_learned_height=min_height, screen_floor_now=float(np.array([int(out[22])], dtype=np.uint32).view(np.float32)[0]))
 
     def _buffers(self, nrows, key="scan"):
         """Allocates (once per size) the workspace and output buffers for a scan of nrows rows.  Exact rescans share ONE

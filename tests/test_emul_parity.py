@@ -50,6 +50,37 @@ def test_emulated_event_lists_packed_on_the_device(name, tmp_path, monkeypatch):
         assert not msgs, "\n".join(msgs[:12])
 
 
+def test_emulated_screen_floor_follows_the_tape(tmp_path):
+    """k_adapt_floor: behind a scan of the peak path the handle's candidate screen moves to half the smallest peak height the scan learned.  The events of
+    the scans behind it are the oracle's all the same - also when the next tape is far weaker than the one the floor was learned on (its chains are flagged
+    RTFE_F_SCREEN_UNDERFLOW, checked through exact rescans, and the floor comes down again) - and a floor the caller gave stands."""
+    import dataclasses
+    from readtape_amd import synth
+    loud = synth.nrzi_tape(seed=311, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, amplitude=3.2)
+    weak = synth.nrzi_tape(seed=312, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, amplitude=0.9)
+    hdr = loud.spec.header()
+    opts = ["-m"]
+    cfg = config_for(hdr, opts)
+    fe = emul_frontend(cfg)
+    att_loud = oracle_attempts(hdr, loud.rows, opts, str(tmp_path))
+    att_weak = oracle_attempts(hdr, weak.rows, opts, str(tmp_path))
+    floors = []
+    for rows, att in ((loud.rows, att_loud), (loud.rows, att_loud), (weak.rows, att_weak), (weak.rows, att_weak), (loud.rows, att_loud)):
+        msgs, stats = check_tape(fe, hdr, rows, att)
+        assert not msgs, "\n".join(msgs[:12])
+        assert stats["events"] > 0
+        st = fe.scan_stats(fe.scan(rows).fetch())
+        floors.append((st["screen_floor_now"], stats["exact"], bool(stats["flags"] & frontend.F_SCREEN_UNDERFLOW)))
+    print(floors)
+    assert floors[0][0] > 1.5 and floors[1][0] == floors[0][0]            # learned on the loud tape (peaks of 6.4 V peak to peak: the floor is capped at 4 V)
+    assert floors[2][0] < floors[1][0]                                     # the weak tape brought it down
+    fixed = emul_frontend(dataclasses.replace(cfg, screen_floor_height=1.25))
+    for rows, att in ((loud.rows, att_loud), (loud.rows, att_loud)):
+        msgs, stats = check_tape(fixed, hdr, rows, att)
+        assert not msgs
+        assert fixed.scan_stats(fixed.scan(rows).fetch())["screen_floor_now"] == 1.25
+
+
 @pytest.mark.parametrize("parallel", ["1", "0"])
 @pytest.mark.parametrize("name", PEAK_CASES)
 def test_emulated_peak_record_path_matches_oracle(name, parallel, tmp_path, monkeypatch):
