@@ -93,6 +93,9 @@ template <int NT> static sfs_kernel_t sfs_kernel_w(int w) {
 // (every window width the packed derivation holds - 6 .. 17 samples - for nine and seven tracks: 800 / 556 BPI NRZI at 781 kHz are 13 / 19,
 //  at half that rate 6 / 9; wider windows, several widths and other track counts take the general kernel: 2.1 instead of 0.93 ms on C2)
 static sfs_kernel_t sfs_kernel(int w, int ntrks) { return ntrks == 9 ? sfs_kernel_w<9>(w) : (ntrks == 7 ? sfs_kernel_w<7>(w) : nullptr); }
+// k_dseg with the track count at compile time for the usual tapes
+typedef void (*ds_kernel_t)(const DevCfg *, const int16_t *, long long, long long, unsigned char *, unsigned char *, unsigned char *, unsigned long long *);
+static ds_kernel_t ds_kernel(int ntrks) { return getenv("RTFE_DSEG_GENERIC") ? k_dseg<0> : (ntrks == 9 ? k_dseg<9> : (ntrks == 7 ? k_dseg<7> : k_dseg<0>)); }
 static int sf_wmax(const DevCfg &d) { int w = 0; for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].W > w) w = d.screen[s].W; return w; }
 static int sf_threads(const DevCfg &d) { return 64 * ((d.ntrks + 1) / 2); }
 static int sf_nvec(const DevCfg &d) { return (d.pk_hl + kSfTile + d.pk_hr) * d.ntrks / 8; }
@@ -406,7 +409,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
       raise_dynamic_lds(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), d.pk_lds);
       if (sf_special(d)) for (int sc = 0; sc < d.nscreens; ++sc) raise_dynamic_lds(reinterpret_cast<const void *>(sf_special_sc(d, sc)), sfs_lds_sc(d, sc)); }
-   if (d.dense_path) raise_dynamic_lds(reinterpret_cast<const void *>(k_dseg), (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, d.ds_up).total + 64);
+   if (d.dense_path) raise_dynamic_lds(reinterpret_cast<const void *>(ds_kernel(d.ntrks)), (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, d.ds_up).total + 64);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    if (getenv("RTFE_VERBOSE") && d.peak_path) {
       int nb = -1;
@@ -765,7 +768,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       //  against 78.3 with 512: the kernel lives on its resident waves, not on its lane-task count; RTFE_DSEG_THREADS for experiments)
       int dthreads = kDsThreads;
       if (h->dseg_threads >= 64 && h->dseg_threads <= kDsThreads) dthreads = h->dseg_threads / 64 * 64;
-      hipLaunchKernelGGL(k_dseg, dim3((unsigned)dg), dim3(dthreads), dlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, dtiles, deadp, reinterpret_cast<unsigned char *>(qwords), slotp, scratch->scr);
+      hipLaunchKernelGGL(ds_kernel(h->dev.ntrks), dim3((unsigned)dg), dim3(dthreads), dlds, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, dtiles, deadp, reinterpret_cast<unsigned char *>(qwords), slotp, scratch->scr);
       t1(kTDseg); }
    else {
       t0(kTQuiet);

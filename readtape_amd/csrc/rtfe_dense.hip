@@ -91,6 +91,9 @@ __device__ __forceinline__ int ds_cls(const DsThr &h, bool amp_on, int m, int v)
 // at the row if it looked: fire / maybe / doubt / nothing, as bits over the rows; (3) a lane per (set, sub-segment, track) resolves what
 // is sequential - the countdown - on those bits: find the next set bit, one load for the extreme's place, jump behind the countdown.
 // ------------------------------------------------------------------------------------------------
+// NT: the track count at compile time (0: whatever the configuration says) - the rows' stride in the tile is then a constant, and every sample of a strip an
+// immediate offset from one address instead of an addition each
+template <int NT>
 __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long ntiles,
                                                      unsigned char *__restrict__ dead, unsigned char *__restrict__ qbytes, unsigned char *__restrict__ slots,
                                                      unsigned long long *__restrict__ dbg) {
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(kDsThreads, 4) k_dseg(const DevCfg *__restrict
    __shared__ unsigned int s_noisy;
    for (int i = threadIdx.x; i < (int)(sizeof(DevCfg) / 4); i += blockDim.x) reinterpret_cast<int *>(&cfg)[i] = reinterpret_cast<const int *>(cfgp)[i];
    __syncthreads();
-   const int ntrks = cfg.ntrks, pad = cfg.ds_pad, T = pad + kDsTile + kDsRight, nu = cfg.nuset;
+   const int ntrks = NT ? NT : cfg.ntrks, pad = cfg.ds_pad, T = pad + kDsTile + kDsRight, nu = cfg.nuset;
    const DsLds L = ds_lds_layout(ntrks, cfg.halo_rows, T, cfg.ds_up);
    Tile tl;
    tl.x = reinterpret_cast<int16_t *>(smem); tl.halo = cfg.halo_rows; tl.ldw = 0; tl.colof = cfg.trk_to_head; tl.ntrks = ntrks; tl.skew = cfg.skew;

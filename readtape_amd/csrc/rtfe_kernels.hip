@@ -1284,7 +1284,7 @@ __device__ __forceinline__ int screen_strip(const Tile &tl, const DevScreen &sc,
 // cooperative tile load: rows [row0 - halo, row0 + nrows) of the AoS payload -> LDS, as they are (16-byte vectors;
 // the tile starts on a multiple of 8 rows, so vectors are aligned in HBM and in LDS).  -invert negates on the way.
 __device__ __forceinline__ void load_tile(const DevCfg *cfg, Tile &tl, const int16_t *__restrict__ rows, long long total_rows) {
-   const int ntrks = cfg->ntrks;
+   const int ntrks = tl.ntrks;      // (the caller may know it at compile time)
    const long long first = tl.row0 - tl.halo;
    const int nelem = (tl.halo + tl.nrows) * ntrks;
    const int nvec = (nelem + 7) >> 3;
