@@ -668,7 +668,11 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       hipStream_t sa = st;
       if (h->overlap && stop_after >= 99) {
          if (!h->side) {
-            if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; h->overlap = 0; }
+            // (the side stream's kernels are a few workgroups each, the main stream's fill the chip: at the default priority k_bursts_tail sat behind k_prep's
+            //  workgroups for 0.25 ms once k_sift_hard - fewer deferred candidates under the raised floor - no longer held k_prep back)
+            int pr_least = 0, pr_greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+            if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr_greatest) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; h->overlap = 0; }
             else { (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
                    (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming); } }
          if (h->side) { sa = h->side; (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(sa, h->ev_fork, 0); } }

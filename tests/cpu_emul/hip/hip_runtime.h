@@ -62,6 +62,8 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;       // (launches are synchronous here: a second stream is the first)
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return 1; }      // "no side stream": the caller stays in line
+inline hipError_t hipDeviceGetStreamPriorityRange(int *a, int *b) { *a = 0; *b = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = nullptr; return 1; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
