@@ -203,6 +203,10 @@ class Workload:
             extra = [(1.4, 0.20, 0.2, 0.5, 0, 0.0), (1.6, 0.14, 0.0, 0.5, 0, 0.0), (1.5, 0.10, 0.1, 0.5, 0, 0.0), (1.3, 0.25, 0.2, 0.5, 0, 0.0)]
             parmsets = (list(frontend.DEFAULT_PARMSETS[hdr.mode]) + extra)[: conf["nparmsets"]]
         self.cfg = frontend.FrontEndConfig.from_header(hdr, nparmsets=conf["nparmsets"], find_zeros=conf["find_zeros"], parmsets=parmsets)
+        if os.environ.get("RT_BENCH_EVENT_CAP"):                         # (experiments: the event regions' share of a burst's rows; the library's default is 1 / 8)
+            self.cfg.events_per_sample_cap = float(os.environ["RT_BENCH_EVENT_CAP"])
+        elif conf.get("event_cap"):
+            self.cfg.events_per_sample_cap = float(conf["event_cap"])
         if conf.get("fixed_floor"):
             self.cfg.screen_floor_height = float(conf["fixed_floor"])
         if os.environ.get("RT_BENCH_SCREEN_FLOOR"):                     # (experiments: the candidate screen's assumed lower bound of the learned peak height, volts)

@@ -197,6 +197,53 @@ def test_fragments_concatenate_to_the_whole_tap(name, nshards, tmp_path):
     assert sum(s["blocks"] + s["tapemarks"] for s in sts) > 0
 
 
+@pytest.mark.parametrize("name,nsub", [("nrzi9", 2), ("nrzi9", 4), ("gcr", 2), ("pe", 3)])
+def test_sub_fragments_on_native_threads_concatenate_to_the_whole_tap(name, nsub, tmp_path):
+    """rt_replay_run_fragments (what the streaming reader hands a window to): ONE scan's bursts replayed as nsub sub-fragments side by side, a native thread each,
+    cut at the zone starts of evenly spaced bursts - the pieces are the reference's .tap, and each piece is what the one-fragment call writes."""
+    g = load_case(name)
+    if g["oracle_opts"]:
+        pytest.skip("options")
+    hdr, rows = g["hdr"], g["rows"]
+    opts = pipeline.DecodeOptions()
+    full = pipeline.default_parmsets(hdr.mode, 1)
+    cfg = frontend.FrontEndConfig.from_header(hdr, parmsets=pipeline.frontend_parmsets(full))
+    fe = emul_frontend(cfg)
+    res, nb, bound = pipeline.scan_fragment(fe, rows, rows.shape[0], 0, True, True)()
+    assert res.nbursts >= nsub
+    cuts = [int(res.bursts[(res.nbursts * j) // nsub]["zone_first"]) for j in range(1, nsub)]
+    starts, stops = [0] + cuts, cuts + [None]
+    paths = [os.path.join(str(tmp_path), f"p{j}.tap") for j in range(nsub)]
+    sts = pipeline.decode_fragments(hdr, cfg, fe, res, rows, 0, starts, stops, paths, full, opts)
+    pieces = [open(p, "rb").read() for p in paths]
+    assert b"".join(pieces) + b"\xff\xff\xff\xff" == g["tap"]
+    assert sum(st["blocks"] + st["tapemarks"] for st, _ in sts) > 0 and all(secs >= 0 for _, secs in sts)
+    for j in range(nsub):
+        one = os.path.join(str(tmp_path), f"one{j}.tap")
+        pipeline.decode_fragment(hdr, cfg, fe, res, rows, 0, starts[j], stops[j], one, full, opts)
+        assert open(one, "rb").read() == pieces[j]
+
+
+def test_native_positional_read_in_pieces(tmp_path):
+    """rt_read_mt: a window's bytes as pieces read side by side - any offset, any length, more threads than megabytes; a read past the file's end fails."""
+    import ctypes as C
+    import numpy as np
+    lib = pipeline._load_decode_lib()
+    data = np.random.default_rng(5).integers(0, 256, size=(40 << 20) + 12345, dtype=np.uint8)
+    path = os.path.join(str(tmp_path), "f.bin")
+    data.tofile(path)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        for off, n, th in ((0, data.size, 8), (777, (33 << 20) + 5, 16), (12345, 1 << 20, 4), (5, 100, 64), (data.size - 10, 10, 3), (0, 0, 4)):
+            buf = np.zeros(n + 8, np.uint8)
+            assert lib.rt_read_mt(fd, buf.ctypes.data, off, n, th) == 0
+            assert np.array_equal(buf[:n], data[off: off + n]) and not buf[n:].any()
+        buf = np.zeros(16 << 20, np.uint8)
+        assert lib.rt_read_mt(fd, buf.ctypes.data, data.size - (9 << 20), 16 << 20, 4) != 0
+    finally:
+        os.close(fd)
+
+
 @pytest.mark.parametrize("name", ["files_nrzi9_bin", "files_nrzi9_tap", "files_nrzi7_bin", "files_pe_m_tap", "files_gcr_bin"])
 def test_output_files_and_summary_match_the_reference(name, tmp_path, monkeypatch):
     """f3: the numbered .bin files (a new one behind every tapemark, src/readtape.c:1091-1111), the lazily created .tap, and the log
