@@ -38,7 +38,7 @@ extern "C" {
 
 #define RTFE_MAXTRKS     19   /* src/csvtbin.h:29  MAXTRKS      */
 #define RTFE_MAXPARMSETS 15   /* src/decoder.h:92  MAXPARMSETS  */
-#define RTFE_ABI_VERSION 4   /* 4: rtfe_pack_events; 3: rtfe_scan_stats out[21] = the smallest learned peak height (screen-floor calibration); 2: rtfe_kernel_ms returns the number of scans summed; twelve timed spans (k_dseg, k_dchain) */
+#define RTFE_ABI_VERSION 5   /* 5: rtfe_set_graphs; 4: rtfe_pack_events; 3: rtfe_scan_stats out[21] = the smallest learned peak height (screen-floor calibration); 2: rtfe_kernel_ms returns the number of scans summed; twelve timed spans (k_dseg, k_dchain) */
 
 enum { RTFE_PE = 1, RTFE_NRZI = 2, RTFE_GCR = 4, RTFE_WW = 8 };      /* enum mode_t, src/csvtbin.h:47-49 */
 
@@ -187,6 +187,14 @@ int rtfe_find_end_mark(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
  * the sets recorded since its last call and returns, per span, the elapsed milliseconds SUMMED over those scans (out[rtfe_kernel_count()]);
  * its return value is the number of scans summed (>= 0), or a negative error.  Used by bench.py. */
 int rtfe_set_timing(rtfe_handle *h, int enable);
+
+/* HIP graphs (ABI 5).  enable != 0: rtfe_scan captures its launches - about twenty kernels and memsets on the caller's stream and a stream of the handle's
+ * own - into a hipGraph the first time it meets a set of arguments (pointers, sizes, flags) and replays that graph for every later scan with the same
+ * arguments: one launch on the host, no gaps between the kernels on the device.  The handle keeps the eight most recently used graphs (a streaming reader's
+ * ring of windows).  Results are the same either way.  Scans on the legacy default stream (stream == NULL), with per-kernel timing on or with debug
+ * counters are launched directly; so is everything if the runtime refuses the capture.  The buffers a graph names must stay allocated while scans with
+ * those arguments may still come; rtfe_destroy frees the graphs.  Environment default: RTFE_GRAPHS. */
+int rtfe_set_graphs(rtfe_handle *h, int enable);
 int rtfe_kernel_ms(rtfe_handle *h, float *out);
 
 /* Statistics of the most recent rtfe_scan that used d_workspace (synchronous, call after the stream has finished):

@@ -32,6 +32,7 @@ __global__ void k_setup_exact(rtfe_burst *burst, BurstScratch *scratch, long lon
 
 using namespace rtfe;
 
+constexpr int kGraphCache = 8;
 struct rtfe_handle {
    rtfe_config cfg;
    DevCfg dev;
@@ -48,9 +49,18 @@ struct rtfe_handle {
    int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
    int sift_defer;                     // RTFE_SIFT_DEFER=0: k_sift_s stores a tile's lists at the end of its own step (experiments)
    int ds_order, dchain_wgs, prep_wgs, dense_stop, dseg_wgs, dseg_threads;      // RTFE_DS_ORDER (0: chains in burst order), RTFE_DCHAIN_WGS / RTFE_PREP_WGS / RTFE_DSEG_WGS (workgroups per CU), RTFE_DENSE_STOP (debugging): read once, at create
+   // rtfe_set_graphs: a scan's launches (about twenty, on two streams) captured once per set of arguments into a HIP graph and replayed - what a scan of the same
+   // buffers costs the host, and the gaps between its kernels on the device, shrink to one launch
+   int graphs;
+   struct GraphEnt { unsigned long long key[13]; hipGraphExec_t exec; unsigned long long stamp; } gcache[kGraphCache];
+   unsigned long long gstamp;
 };
 
 static thread_local char g_err[512] = "";
+
+static void drop_graphs(rtfe_handle *h) {
+   for (int i = 0; i < kGraphCache; ++i) if (h->gcache[i].exec) { (void)hipGraphExecDestroy(h->gcache[i].exec); h->gcache[i].exec = nullptr; } }
+
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel in the process, not of a handle: a second handle with a smaller LDS
 // layout must not lower what a first one's launches need.  A table of the largest size asked for so far, per kernel.
@@ -396,6 +406,8 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    raise_dynamic_lds(reinterpret_cast<const void *>(k_decode), h->lds_bytes);
    h->zeros_kernel = getenv("RTFE_ZEROS_KERNEL") ? atoi(getenv("RTFE_ZEROS_KERNEL")) != 0 : 1;
    h->side = nullptr; h->overlap = getenv("RTFE_OVERLAP") ? atoi(getenv("RTFE_OVERLAP")) != 0 : 1;
+   h->graphs = getenv("RTFE_GRAPHS") ? atoi(getenv("RTFE_GRAPHS")) != 0 : 0;
+   memset(h->gcache, 0, sizeof h->gcache); h->gstamp = 0;
    h->bursts_wpr = getenv("RTFE_BURSTS_WPR") ? atoi(getenv("RTFE_BURSTS_WPR")) : 0;
    h->sift_defer = getenv("RTFE_SIFT_DEFER") ? atoi(getenv("RTFE_SIFT_DEFER")) != 0 : 1;
    h->ds_order = getenv("RTFE_DS_ORDER") ? atoi(getenv("RTFE_DS_ORDER")) : 1;
@@ -461,6 +473,7 @@ extern "C" int rtfe_kernel_ms(rtfe_handle *h, float *out) {
 extern "C" void rtfe_destroy(rtfe_handle *h) {
    if (!h) return;
    if (h->timing) timing_free(h);
+   drop_graphs(h);
    if (h->side) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2); (void)hipStreamDestroy(h->side); }
    (void)hipFree(h->d_dev);
    delete h; }
@@ -578,10 +591,21 @@ static void launch_bursts(const rtfe_handle *h, hipStream_t s, const unsigned lo
       hipLaunchKernelGGL(k_bursts, dim3(1), dim3(1024), 0, s, qwords, nwords, nchunks, (long long)nrows, (long long)own_rows, h->dev.ntrks,
                          h->dev.gap_chunks, first_is_tape_start, h->dev.cap_frac, h->dev.nparm, (long long)event_capacity, d_bursts, maxb, scratch, d_nbursts, h->dev.debug == 5 ? 1 : 0); }
 
-extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t own_rows, int64_t row_base, int first_is_tape_start,
-                         void *d_workspace, size_t workspace_bytes,
-                         rtfe_burst *d_bursts, int64_t max_bursts, int32_t *d_nbursts,
-                         uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity, void *stream) {
+// the handle's side stream (made at the first scan that wants it - outside any stream capture)
+static void ensure_side(rtfe_handle *h) {
+   if (h->side || !h->overlap) return;
+   // (the side stream's kernels are a few workgroups each, the main stream's fill the chip: at the default priority k_bursts_tail sat behind k_prep's
+   //  workgroups for 0.25 ms once k_sift_hard - fewer deferred candidates under the raised floor - no longer held k_prep back)
+   int pr_least = 0, pr_greatest = 0;
+   (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+   if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr_greatest) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; h->overlap = 0; }
+   else { (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+          (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming); } }
+
+static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t own_rows, int64_t row_base, int first_is_tape_start,
+                       void *d_workspace, size_t workspace_bytes,
+                       rtfe_burst *d_bursts, int64_t max_bursts, int32_t *d_nbursts,
+                       uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity, void *stream) {
    if (!h || !d_rows || !d_workspace || !d_bursts || !d_nbursts || !d_counts || !d_events) return fail(-1, "null argument");
    if (h->dev.mode == RTFE_WW) return fail(-44, "Whirlwind tapes have no independent bursts: use rtfe_ww_scan");
    if (((uintptr_t)d_rows & 15) != 0) return fail(-31, "d_rows must be 16-byte aligned");
@@ -667,14 +691,7 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       // time it shared the device).
       hipStream_t sa = st;
       if (h->overlap && stop_after >= 99) {
-         if (!h->side) {
-            // (the side stream's kernels are a few workgroups each, the main stream's fill the chip: at the default priority k_bursts_tail sat behind k_prep's
-            //  workgroups for 0.25 ms once k_sift_hard - fewer deferred candidates under the raised floor - no longer held k_prep back)
-            int pr_least = 0, pr_greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
-            if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr_greatest) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; h->overlap = 0; }
-            else { (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
-                   (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming); } }
+         ensure_side(h);
          if (h->side) { sa = h->side; (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(sa, h->ev_fork, 0); } }
       t0s(kTBursts, sa);
       hipLaunchKernelGGL(k_qpack, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, sa, (const uint16_t *)qtile, ptiles, qwords, nwords);
@@ -820,6 +837,55 @@ extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, i
       t1(kTDecode); }
    skip_rest();
    return launch_check("rtfe_scan"); }
+
+extern "C" int rtfe_set_graphs(rtfe_handle *h, int enable) {
+   if (!h) return fail(-1, "null argument");
+   h->graphs = enable != 0;
+   return 0; }
+
+extern "C" int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t own_rows, int64_t row_base, int first_is_tape_start,
+                         void *d_workspace, size_t workspace_bytes,
+                         rtfe_burst *d_bursts, int64_t max_bursts, int32_t *d_nbursts,
+                         uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity, void *stream) {
+   // (per-kernel timing records events between the launches, the debug counters are read by tools between scans, the legacy default stream cannot be
+   //  captured: those scans are launched directly)
+   if (!h || !h->graphs || h->timing || h->dev.debug || !stream)
+      return scan_launch(h, d_rows, nrows, own_rows, row_base, first_is_tape_start, d_workspace, workspace_bytes, d_bursts, max_bursts, d_nbursts, d_counts, d_events, event_capacity, stream);
+   hipStream_t st = (hipStream_t)stream;
+   const unsigned long long key[13] = {(unsigned long long)(uintptr_t)d_rows, (unsigned long long)nrows, (unsigned long long)own_rows, (unsigned long long)row_base, (unsigned long long)first_is_tape_start,
+                                       (unsigned long long)(uintptr_t)d_workspace, (unsigned long long)workspace_bytes, (unsigned long long)(uintptr_t)d_bursts, (unsigned long long)max_bursts,
+                                       (unsigned long long)(uintptr_t)d_nbursts, (unsigned long long)(uintptr_t)d_counts, (unsigned long long)(uintptr_t)d_events, (unsigned long long)event_capacity};
+   for (int i = 0; i < kGraphCache; ++i) {
+      rtfe_handle::GraphEnt &e = h->gcache[i];
+      if (e.exec && memcmp(e.key, key, sizeof key) == 0) {
+         e.stamp = ++h->gstamp;
+         if (hipGraphLaunch(e.exec, st) != hipSuccess) return fail(-30, "rtfe_scan: hipGraphLaunch: %s", hipGetErrorString(hipGetLastError()));
+         return 0; } }
+   int slot = 0;                                                       // an empty place, else the least recently used
+   for (int i = 0; i < kGraphCache; ++i) {
+      if (!h->gcache[i].exec) { slot = i; break; }
+      if (h->gcache[i].stamp < h->gcache[slot].stamp) slot = i; }
+   // a new set of arguments: its launches captured (nothing runs while they are), instantiated, launched - into the least recently used place
+   ensure_side(h);
+   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError(); h->graphs = 0;
+      return scan_launch(h, d_rows, nrows, own_rows, row_base, first_is_tape_start, d_workspace, workspace_bytes, d_bursts, max_bursts, d_nbursts, d_counts, d_events, event_capacity, stream); }
+   const int rc = scan_launch(h, d_rows, nrows, own_rows, row_base, first_is_tape_start, d_workspace, workspace_bytes, d_bursts, max_bursts, d_nbursts, d_counts, d_events, event_capacity, stream);
+   hipGraph_t g = nullptr;
+   const hipError_t ec = hipStreamEndCapture(st, &g);
+   if (rc != 0) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return rc; }      // (an argument the scan refuses: nothing was enqueued, the message stands)
+   hipGraphExec_t ex = nullptr;
+   if (ec != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+      // (a runtime that cannot capture this sequence: the scan is launched directly, now and from here on)
+      if (g) (void)hipGraphDestroy(g);
+      (void)hipGetLastError(); h->graphs = 0;
+      return scan_launch(h, d_rows, nrows, own_rows, row_base, first_is_tape_start, d_workspace, workspace_bytes, d_bursts, max_bursts, d_nbursts, d_counts, d_events, event_capacity, stream); }
+   (void)hipGraphDestroy(g);
+   rtfe_handle::GraphEnt &e = h->gcache[slot];
+   if (e.exec) (void)hipGraphExecDestroy(e.exec);
+   memcpy(e.key, key, sizeof key); e.exec = ex; e.stamp = ++h->gstamp;
+   if (hipGraphLaunch(ex, st) != hipSuccess) return fail(-30, "rtfe_scan: hipGraphLaunch: %s", hipGetErrorString(hipGetLastError()));
+   return 0; }
 
 // Synchronous (copies three words back): what the last rtfe_scan on this workspace did.
 extern "C" int rtfe_pack_events(rtfe_handle *h, const rtfe_burst *d_bursts, const int32_t *d_nbursts, int64_t max_bursts, const uint32_t *d_counts,

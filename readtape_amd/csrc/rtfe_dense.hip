@@ -467,7 +467,10 @@ __global__ void __launch_bounds__(1024) k_dorder(const rtfe_burst *__restrict__ 
    __syncthreads();
    for (int b = threadIdx.x; b < nb; b += 1024) ctl[atomicAdd(&s_hist[bin(b)], 1)].pad = b; }
 
-__global__ void __launch_bounds__(64) k_dchain(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long row_base,
+#ifndef RTFE_DC_WAVES
+#define RTFE_DC_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, RTFE_DC_WAVES) k_dchain(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long row_base,
                                                const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                                uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                                const unsigned char *__restrict__ dead, const unsigned char *__restrict__ slots, long long ntiles, int ordered) {

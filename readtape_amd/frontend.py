@@ -243,8 +243,9 @@ def _load_library(path=None):
     lib.rtfe_find_end_mark.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.rtfe_pack_events.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.rtfe_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.rtfe_set_graphs.argtypes = [C.c_void_p, C.c_int]
     lib.rtfe_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-    if lib.rtfe_abi_version() != 4:
+    if lib.rtfe_abi_version() != 5:
         raise RuntimeError("librtfe.so ABI mismatch")
     return lib
 
@@ -374,6 +375,11 @@ class FrontEnd:
 
     def set_timing(self, enable=True):
         if self.lib.rtfe_set_timing(self.h, int(enable)) != 0:
+            raise RuntimeError(self.lib.rtfe_last_error().decode())
+
+    def set_graphs(self, enable=True):
+        """rtfe_set_graphs: scans with the same arguments (the same buffers) replay one captured HIP graph instead of launching their ~20 kernels one by one."""
+        if self.lib.rtfe_set_graphs(self.h, int(enable)) != 0:
             raise RuntimeError(self.lib.rtfe_last_error().decode())
 
     def kernel_ms(self):

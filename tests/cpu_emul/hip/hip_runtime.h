@@ -65,6 +65,16 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = null
 inline hipError_t hipDeviceGetStreamPriorityRange(int *a, int *b) { *a = 0; *b = 0; return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = nullptr; return 1; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+// HIP graphs: the emulator cannot capture - rtfe_scan falls back to direct launches (the path a runtime that refuses a capture takes)
+typedef void *hipGraph_t;
+typedef void *hipGraphExec_t;
+enum { hipStreamCaptureModeThreadLocal = 1 };
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 1; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = nullptr; return 1; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return 1; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 1; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }

@@ -678,3 +678,36 @@ def test_dense_path_equals_the_sample_path_at_bench_shape(kind, nparm, knobs, gp
         for p in range(nparm):
             for t in range(cfg.ntrks):
                 assert r0.track_events(b, p, t).tobytes() == r1.track_events(b, p, t).tobytes(), (b, p, t)
+
+
+@pytest.mark.parametrize("name", ["nrzi9", "nrzi9_m", "pe", "gcr_m", "pe_zeros"])
+def test_graph_replayed_scans_equal_direct_launches(name, gpu):
+    """rtfe_set_graphs: a scan's launches captured into a HIP graph at the first scan of a set of arguments and replayed afterwards - the capture, the
+    replays, a second set of buffers, and more sets than the handle keeps graphs for (the least recently used one is captured again) all leave
+    the burst table and every event list the direct launches leave."""
+    torch = gpu
+    g = load_case(name)
+    cfg = config_for(g["hdr"], g["oracle_opts"])
+
+    def lists(r):
+        r.fetch()
+        return r.nbursts, r.bursts.tobytes(), {(b, p, t): r.track_events(b, p, t).tobytes() for b in range(r.nbursts) for p in range(len(cfg.parmsets)) for t in range(cfg.ntrks)}
+    fe0 = frontend.FrontEnd(cfg)
+    want = lists(fe0.scan(g["rows"]))
+    assert want[0] > 0 and sum(len(v) for v in want[2].values()) > 0
+    fe = frontend.FrontEnd(cfg)
+    fe.set_graphs(True)
+    st = torch.cuda.Stream()
+    rows = torch.from_numpy(np.ascontiguousarray(g["rows"])).cuda()
+    with torch.cuda.stream(st):
+        for i in range(3):                                   # capture, replay, replay
+            assert lists(fe.scan(rows, stream=st.cuda_stream)) == want, i
+        n = rows.shape[0]
+        cut = max(64, (n * 3 // 4) // 64 * 64)
+        part = lists(fe0.scan(rows[:cut]))
+        others = [rows[:cut].clone() for _ in range(9)]      # nine more sets of arguments: more than the handle keeps
+        for rep in range(2):
+            for o in others:
+                assert lists(fe.scan(o, stream=st.cuda_stream)) == part
+        assert lists(fe.scan(rows, stream=st.cuda_stream)) == want      # (evicted in between: captured again)
+    st.synchronize()
