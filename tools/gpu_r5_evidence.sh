@@ -10,7 +10,7 @@ print({k: j[k] for k in ("value", "ms_per_step", "ms_per_step_serial", "timed_st
 for k, v in j.get("other_configs", {}).items(): print(k, {kk: v.get(kk) for kk in ("value", "ms_per_step", "ms_per_step_serial", "dominant_kernel", "dominant_kernel_ms", "frac", "frac_rows_only", "flagged_bursts", "screen_floor_height", "error")})
 print("e2e", {k: j["e2e"].get(k) for k in ("value", "seconds", "tap_identical_to_cpu_port", "error")}, "cpu", j.get("cpu_baseline", {}).get("value"), j.get("cpu_baseline", {}).get("kind"))
 PY
-for spec in "c2:--steps 20 --warmup 5 --no-other-configs --no-overlap" "c3:--config C3 --steps 4 --warmup 1 --no-overlap" "c4:--config C4 --steps 2 --warmup 1" "g1:--config G1 --steps 2 --warmup 1" "p1:--config P1 --steps 2 --warmup 1" "m8:--config M8 --steps 5 --warmup 2 --no-overlap" "m8f:--config M8f --steps 3 --warmup 1 --no-overlap" "n1:--config N1 --steps 5 --warmup 2 --no-overlap" "c5:--config C5 --steps 5 --warmup 2"; do
+for spec in "c2:--steps 20 --warmup 5 --no-other-configs --no-overlap" "c3:--config C3 --steps 4 --warmup 1 --no-overlap" "c4:--config C4 --steps 2 --warmup 1" "g1:--config G1 --steps 2 --warmup 1" "p1:--config P1 --steps 2 --warmup 1" "m8:--config M8 --steps 5 --warmup 2 --no-overlap" "m8f:--config M8f --steps 3 --warmup 1 --no-overlap" "n1:--config N1 --steps 5 --warmup 2 --no-overlap" "c5:--config C5 --steps 5 --warmup 2 --no-graphs"; do
   tag=${spec%%:*}; args=${spec#*:}
   timeout 900 bash tools/gpu_profile.sh r05_$tag $args > gpurun_out/r05/profile_$tag.log 2>&1; echo "profile $tag rc $?"; cp gpurun_out/prof_r05_$tag/summary.txt gpurun_out/r05/rocprof_summary_$tag.txt; cp gpurun_out/prof_r05_$tag/bench_under_rocprof.json gpurun_out/r05/bench_under_rocprof_$tag.json; rm -rf gpurun_out/prof_r05_$tag
 done
