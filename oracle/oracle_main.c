@@ -152,7 +152,14 @@ int main(int argc, char **argv) {
       char hdr_order[21] = {0};
       if (flags & 2) memcpy(hdr_order, buf + 240 + 8, 20);
       const char *ord = orderarg ? orderarg : (hdr_order[0] ? hdr_order : "CMLcml");
-      if ((int)strlen(ord) != nheads || strchr(ord, 'x')) { fprintf(stderr, "Whirlwind -order must name every head\n"); return 2; }
+      if ((int)strlen(ord) != nheads) { fprintf(stderr, "Whirlwind -order must name every head\n"); return 2; }
+      char used_order[21] = {0};
+      if (strchr(ord, 'x')) {                                /* heads that are not tracks (src/readtape.c:891 parks their samples in a spare track nobody reads): left out here */
+         int used[RT_MAXTRKS], nu = 0;
+         for (int h = 0; h < nheads; ++h) if (ord[h] != 'x') { used_order[nu] = ord[h]; used[nu++] = h; }
+         int16_t *pk = (int16_t *)malloc((size_t)(nrows > 0 ? nrows : 1) * (size_t)(nu > 0 ? nu : 1) * 2);
+         for (int64_t k = 0; k < nrows; ++k) for (int j = 0; j < nu; ++j) pk[k * nu + j] = rows[k * nheads + used[j]];
+         rows = pk; nheads = nu; ord = used_order; }
       snprintf(opt.ww_order, sizeof opt.ww_order, "%s", ord);
       opt.ntrks = nheads;
       orderarg = NULL; flags &= ~3u;                         /* (no permutation below: head h is track h) */

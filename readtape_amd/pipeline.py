@@ -355,8 +355,17 @@ def decode_tape_ww(hdr, rows, tap_path, log_path=None, order: str | None = None,
     come back as stats["skew_delays"]).  Returns the statistics."""
     lib = _load_decode_lib()
     order = order or hdr.trkorder or "CMLcml"
-    if len(order) != hdr.ntrks or "x" in order:
+    if len(order) != hdr.ntrks:
         raise ValueError("the Whirlwind order string must name every head of the file")
+    if "x" in order:
+        # heads that are not Whirlwind tracks ('x', src/readtape.c:891: the reference parks their samples in a spare track nobody reads): their
+        # columns never reach the device - the detector sees the used heads side by side, in file order, as the reference numbers its tracks
+        used = [i for i, ch in enumerate(order) if ch != "x"]
+        rows = rows[:, used]
+        rows = rows.contiguous() if hasattr(rows, "contiguous") else np.ascontiguousarray(rows)
+        order = "".join(order[i] for i in used)
+        import dataclasses as _dc
+        hdr = _dc.replace(hdr, ntrks=len(used))
     bpi, ips = (hdr.bpi or 100.0), (hdr.ips or 50.0)
     full = default_parmsets(tbin.MODE_WW, 1)
     import dataclasses

@@ -42,6 +42,19 @@ def case_ww(seed=41):
     return synth.ww_tape(seed=seed, nblocks=5, minwords=3, maxwords=14, marks_every=2, gap_samples=700)
 
 
+def case_ww_unused(seed=47):
+    # eight heads of which two are not Whirlwind tracks ('x' in the order string, src/readtape.c:891): one carries noise, one a copy of a data track
+    import dataclasses
+    t = synth.ww_tape(seed=seed, nblocks=5, minwords=3, maxwords=12, marks_every=2, gap_samples=650)
+    rng = np.random.default_rng(seed)
+    n = t.rows.shape[0]
+    noise = np.round(rng.normal(0.0, 0.4 / t.spec.maxvolts * 32767, n)).astype(np.int16)
+    cols = [t.rows[:, 0], noise, t.rows[:, 1], t.rows[:, 2], t.rows[:, 3], t.rows[:, 4], t.rows[:, 1].copy(), t.rows[:, 5]]      # C x M L c m x l
+    t.rows = np.ascontiguousarray(np.stack(cols, 1))
+    t.spec = dataclasses.replace(t.spec, ntrks=8, trkorder="CxMLcmxl")
+    return t
+
+
 def case_ww_pos(seed=42):
     # the other polarity: the positive half of every pulse first
     t = synth.ww_tape(seed=seed, nblocks=4, minwords=3, maxwords=12, marks_every=3, gap_samples=700)
@@ -297,6 +310,7 @@ CASES = {
     "tiny":         (case_tiny,       ["-nrzi"],                       []),
     "ww":           (case_ww,         [],                              []),
     "ww_auto":      (case_ww,         ["-fluxdir=auto"],               ["-fluxdir=auto"]),
+    "ww_unused":    (case_ww_unused,  ["-fluxdir=auto"],               ["-fluxdir=auto"]),
     "ww_pos":       (case_ww_pos,     ["-fluxdir=pos"],                ["-fluxdir=pos"]),
     "ww_pos_auto":  (case_ww_pos,     ["-fluxdir=auto"],               ["-fluxdir=auto"]),
     "ww_wrongdir":  (case_ww_pos,     [],                              []),

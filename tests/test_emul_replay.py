@@ -299,7 +299,7 @@ def test_rows_of_the_wrong_width_are_refused():
         fe.scan(rows.reshape(-1))
 
 
-WW_CASES = ["ww", "ww_auto", "ww_pos", "ww_pos_auto", "ww_wrongdir", "ww_reverse", "ww_rough", "ww_close", "ww_deskew", "ww_deskew_long", "ww_deskew_pos"]
+WW_CASES = ["ww", "ww_auto", "ww_unused", "ww_pos", "ww_pos_auto", "ww_wrongdir", "ww_reverse", "ww_rough", "ww_close", "ww_deskew", "ww_deskew_long", "ww_deskew_pos"]
 
 
 def decode_ww_case(g, tmp_path, fe_factory, chunk_rows):

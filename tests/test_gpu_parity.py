@@ -532,7 +532,7 @@ def test_zeros_kernel_against_the_decode_mode(ntrks, clip, order, gpu, monkeypat
 
 
 @pytest.mark.parametrize("chunk_rows", [4096, 300])
-@pytest.mark.parametrize("name", ["ww", "ww_auto", "ww_pos", "ww_pos_auto", "ww_wrongdir", "ww_reverse", "ww_rough", "ww_close", "ww_deskew", "ww_deskew_long", "ww_deskew_pos"])
+@pytest.mark.parametrize("name", ["ww", "ww_auto", "ww_unused", "ww_pos", "ww_pos_auto", "ww_wrongdir", "ww_reverse", "ww_rough", "ww_close", "ww_deskew", "ww_deskew_long", "ww_deskew_pos"])
 def test_whirlwind_tap_bytes_match_reference(name, chunk_rows, tmp_path, gpu):
     """Whirlwind through k_ww (rtfe_ww_scan: detector state handed from attempt to attempt): see tests/test_emul_replay.py."""
     from test_emul_replay import decode_ww_case
