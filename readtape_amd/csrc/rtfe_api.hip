@@ -85,24 +85,26 @@ template <int WM> static sf_kernel_t sf_kernel_t2(int threads, int nv) { return 
 static sf_kernel_t sf_kernel(int wmax, int threads, int nv) {
    return wmax <= 18 ? sf_kernel_t2<18>(threads, nv) : sf_kernel_t2<50>(threads, nv); }
 // one screen of a width and a track count the lean kernel is built for, a sure level that fits 16 bits: k_sift_s
-template <int NT> static sfs_kernel_t sfs_kernel_w(int w) {
+template <int NT, bool PL> static sfs_kernel_t sfs_kernel_w(int w) {
    switch (w) {
-      case 6:  return k_sift_s<6, NT, kSfWps>;
-      case 7:  return k_sift_s<7, NT, kSfWps>;
-      case 8:  return k_sift_s<8, NT, kSfWps>;
-      case 9:  return k_sift_s<9, NT, kSfWps>;
-      case 10: return k_sift_s<10, NT, kSfWps>;
-      case 11: return k_sift_s<11, NT, kSfWps>;
-      case 12: return k_sift_s<12, NT, kSfWps>;
-      case 13: return k_sift_s<13, NT, kSfWps>;
-      case 14: return k_sift_s<14, NT, kSfWps>;
-      case 15: return k_sift_s<15, NT, kSfWps>;
-      case 16: return k_sift_s<16, NT, kSfWps>;
-      case 17: return k_sift_s<17, NT, kSfWps>;
+      case 6:  return k_sift_s<6, NT, kSfWps, PL>;
+      case 7:  return k_sift_s<7, NT, kSfWps, PL>;
+      case 8:  return k_sift_s<8, NT, kSfWps, PL>;
+      case 9:  return k_sift_s<9, NT, kSfWps, PL>;
+      case 10: return k_sift_s<10, NT, kSfWps, PL>;
+      case 11: return k_sift_s<11, NT, kSfWps, PL>;
+      case 12: return k_sift_s<12, NT, kSfWps, PL>;
+      case 13: return k_sift_s<13, NT, kSfWps, PL>;
+      case 14: return k_sift_s<14, NT, kSfWps, PL>;
+      case 15: return k_sift_s<15, NT, kSfWps, PL>;
+      case 16: return k_sift_s<16, NT, kSfWps, PL>;
+      case 17: return k_sift_s<17, NT, kSfWps, PL>;
       default: return nullptr; } }
 // (every window width the packed derivation holds - 6 .. 17 samples - for nine and seven tracks: 800 / 556 BPI NRZI at 781 kHz are 13 / 19,
 //  at half that rate 6 / 9; wider windows, several widths and other track counts take the general kernel: 2.1 instead of 0.93 ms on C2)
-static sfs_kernel_t sfs_kernel(int w, int ntrks) { return ntrks == 9 ? sfs_kernel_w<9>(w) : (ntrks == 7 ? sfs_kernel_w<7>(w) : nullptr); }
+static sfs_kernel_t sfs_kernel(int w, int ntrks, bool plain) {
+   if (plain) return ntrks == 9 ? sfs_kernel_w<9, true>(w) : (ntrks == 7 ? sfs_kernel_w<7, true>(w) : nullptr);
+   return ntrks == 9 ? sfs_kernel_w<9, false>(w) : (ntrks == 7 ? sfs_kernel_w<7, false>(w) : nullptr); }
 // k_dseg with the track count at compile time for the usual tapes
 typedef void (*ds_kernel_t)(const DevCfg *, const int16_t *, long long, long long, unsigned char *, unsigned char *, unsigned char *, unsigned long long *);
 static ds_kernel_t ds_kernel(int ntrks) { return getenv("RTFE_DSEG_GENERIC") ? k_dseg<0> : (ntrks == 9 ? k_dseg<9> : (ntrks == 7 ? k_dseg<7> : k_dseg<0>)); }
@@ -112,7 +114,7 @@ static int sf_nvec(const DevCfg &d) { return (d.pk_hl + kSfTile + d.pk_hr) * d.n
 static int sf_nv(const DevCfg &d) { return (sf_nvec(d) + sf_threads(d) - 1) / sf_threads(d); }
 // (several window widths - a parameter sweep -: a launch of the lean kernel per screen, if every screen has one: NRZI -m is three widths, 1.5 ms each where the
 //  general kernel's loop over the screens took 15.8)
-static sfs_kernel_t sf_special_sc(const DevCfg &d, int sc) { return (d.screen[sc].sure_i <= 32767 && !getenv("RTFE_SIFT_GENERIC")) ? sfs_kernel(d.screen[sc].W, d.ntrks) : nullptr; }
+static sfs_kernel_t sf_special_sc(const DevCfg &d, int sc) { return (d.screen[sc].sure_i <= 32767 && !getenv("RTFE_SIFT_GENERIC")) ? sfs_kernel(d.screen[sc].W, d.ntrks, d.pk_plain != 0) : nullptr; }
 static sfs_kernel_t sf_special(const DevCfg &d) {
    if (d.nscreens > 1 && getenv("RTFE_SIFT_PER_SCREEN") && atoi(getenv("RTFE_SIFT_PER_SCREEN")) == 0) return nullptr;
    for (int sc = 0; sc < d.nscreens; ++sc) if (!sf_special_sc(d, sc)) return nullptr;
@@ -289,6 +291,8 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    d.lsb_per_volt = (float)(32767.0 / (double)c->maxvolts);
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
    d.cut = getenv("RTFE_CUT") ? atoi(getenv("RTFE_CUT")) : 0;
+   // (k_sift_s's plain build: none of the knobs it would otherwise carry as run-time values; RTFE_SIFT_PLAIN=0: the general build everywhere - tests)
+   d.pk_plain = !d.invert && d.cut == 0 && d.debug != 3 && !(getenv("RTFE_SIFT_DEFER") && atoi(getenv("RTFE_SIFT_DEFER")) == 0) && !(getenv("RTFE_SIFT_PLAIN") && atoi(getenv("RTFE_SIFT_PLAIN")) == 0);
    {  // The peak path (k_sift -> k_gain -> k_emit): peak detection on the undifferentiated signal.  It pays where flux transitions are a
       // bit cell apart (NRZI): most peaks then have the window to themselves and the chains stay on their steady path.  PE and GCR put
       // a top and a bottom into one window; their bursts take the sample path (k_decode) - RTFE_PEAK_PATH=0/1 overrides (tests keep both

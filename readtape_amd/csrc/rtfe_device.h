@@ -64,6 +64,7 @@ struct DevCfg {
    int   rec_cap;                 // deferred-event records per walker per tile (LDS)
    int   debug;                   // RTFE_DEBUG=1: per-phase cycle counters in the workspace (tools/ only)
    int   cut;                     // RTFE_CUT: k_sift stops after a phase (timing experiments, tools/ only; results are then garbage)
+   int   pk_plain;                // k_sift_s: the build without -invert, cut-offs, counters and with deferred copy-out (host side only: picks the instantiation)
    int   peak_path;               // k_sift -> k_gain -> k_emit serve rtfe_scan (peak detection on the undifferentiated signal)
    int   pk_hl, pk_hr;            // rows kept in front of / behind a k_sift tile in LDS (multiples of 8)
    int   pk_slot;                 // bytes of a pool slot: the list of one (tile, screen, head); multiple of 16

@@ -708,7 +708,9 @@ struct SfArgs {
    int defer;      // 1: a tile's lists leave LDS at the start of the NEXT tile step (the stores' acknowledgements are then old when the step's first s_waitcnt vmcnt(0) - the prefetched rows - asks)
 };
 
-template <int W, int NT, int WPS>
+// PL ("plain"): no -invert, no experiment cut-offs, no cycle counters, the lists leave deferred - what every scan but a test's or a tool's is; the knobs are
+// compile-time constants then (as run-time values they are a dozen wave-uniform masks the compiler keeps in - and reloads from - spilled scalar registers)
+template <int W, int NT, int WPS, bool PL>
 __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs a) {
 #ifdef RTFE_CPU_EMUL
    unsigned char *smem = g_dyn_smem;
@@ -729,13 +731,14 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
 #else
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-   const int hcap = a.hcap, wave_cap = a.wave_cap, cut = a.cut;
+   const int hcap = a.hcap, wave_cap = a.wave_cap, cut = PL ? 0 : a.cut;
+   const bool dbg3 = PL ? false : a.debug == 3, inv = PL ? false : a.invert != 0, defer = PL ? true : a.defer != 0;
    const int cap3 = sfs_part_cap(NT, hcap);
    const SfsLds L = sfs_lds_layout(NT, W, wave_cap, hcap);
    unsigned char *xs = smem + L.xs;
    const lds_p xsl = to_lds(xs);
    PkCtx cx;
-   cx.t.xs = xsl; cx.t.row_bytes = RB; cx.t.hl = HL; cx.t.sg = a.invert ? -1 : 1;
+   cx.t.xs = xsl; cx.t.row_bytes = RB; cx.t.hl = HL; cx.t.sg = inv ? -1 : 1;
    const int lo_i = a.cfg->screen[a.sc].rise_i, minpk_i = a.cfg->screen[a.sc].minpk_i;
    cx.W = W; cx.lo_i = lo_i; cx.hi_i = a.hi_i;
    const int G = (int)gridDim.x, ntiles = a.ntiles;
@@ -783,7 +786,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          if (!over && nr > 0 && cut != 6) {
             const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
             for (int v = lane; v < nr; v += 64) reinterpret_cast<int4 *>(gslot)[v] = src[v];      // (a 16-byte vector a record)
-            if (a.debug == 3) pn_bytes += (unsigned)(16 * nr); }
+            if (dbg3) pn_bytes += (unsigned)(16 * nr); }
          if (lane == 0) {
             PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
             a.dir[li] = d; } } };
@@ -857,7 +860,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
                bm = (bm >> 1) | (dz & ~dzn & kPkSigns);
                yc = yn; zc = zn; uy = uyn; dz = dzn; }
             tm = (tm >> (16 - kSfStrip)) & 0x3fff3fffu; bm = (bm >> (16 - kSfStrip)) & 0x3fff3fffu;
-            if (a.invert) { const uint32_t s2 = tm; tm = bm; bm = s2; }
+            if (inv) { const uint32_t s2 = tm; tm = bm; bm = s2; }
             if (!has_hi) { tm &= 0xffffu; bm &= 0xffffu; }                  // odd track count: the last pair's upper half is the next row
             if (cx.last < kSfTile - 1) {                                      // rows that do not exist cannot own a run
                const int keep = cx.last + 1 - kSfStrip * lane;
@@ -882,7 +885,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
                b3 = (b3 >> 1) | (dz & ~dzn & 0x8000u);
                yc = yn; zc = zn; uy = uyn; dz = dzn; }
             t3 >>= 16 - R3; b3 >>= 16 - R3;
-            if (a.invert) { const uint32_t s2 = t3; t3 = b3; b3 = s2; }
+            if (inv) { const uint32_t s2 = t3; t3 = b3; b3 = s2; }
             int keep = kSfTile - r3;                                          // the part's last lanes reach into the next tile (seven tracks) or behind the tape's end
             if (cx.last + 1 - r3 < keep) keep = cx.last + 1 - r3;
             if (lane >= LA3) keep = 0;
@@ -928,7 +931,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
                         w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
                      else { w0 = pk_w0(cpos, false, cpos + 1, 0, cx.W - 2, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
                      st = 1; }
-                  if (a.debug == 3) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
+                  if (dbg3) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
                   if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
                   const int vr = st;
                   const int sh = 8 * sel;                                      // (a round adds at most 64 to a list)
@@ -944,14 +947,14 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          // ---- 5. this wave's two lists leave (now, or - a.defer - at the start of the next tile step); its part of the last head's waits for the others' counts ----
          rtfe_wave_sync();
          if (SPL && lane == 0) s_part[par][wave] = (unsigned short)((bad || 16 * rec_3 > cap3) ? 0xffff : rec_3);
-         if (a.defer) { p_tile = tile; p_rec_lo = rec_lo; p_rec_hi = rec_hi; p_bad = bad; }
+         if (defer) { p_tile = tile; p_rec_lo = rec_lo; p_rec_hi = rec_hi; p_bad = bad; }
          else copy_out(tile, rec_lo, rec_hi, bad);
          rtfe_wave_sync(); }
       __syncthreads(); }
    if (p_tile >= 0) copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad);
    if (SPL && last_tile >= 0 && cut != 1) copy_out3(last_tile, par ^ 1);
    if (tid == 0 && last_tile >= 0 && a.qtile) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);
-   if (a.debug == 3 && lane == 0) {
+   if (dbg3 && lane == 0) {
       atomicAdd(&a.dbg[3], (unsigned long long)pn_bytes); atomicAdd(&a.dbg[4], (unsigned long long)pn_hard); atomicAdd(&a.dbg[5], (unsigned long long)pn_rounds);
       if (wave == 0) atomicAdd(&a.dbg[7], (unsigned long long)(last_tile >= 0 ? (last_tile - tile_lo) / G + 1 : 0)); } }
 
