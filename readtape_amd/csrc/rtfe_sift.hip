@@ -761,11 +761,11 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    int4 q[NV];
    #pragma unroll
    for (int k = 0; k < NV; ++k) q[k] = make_int4(0, 0, 0, 0);
-   auto fetch = [&](int tile) {
+   auto fetch = [&](int tile, int tidx) {
       const int4 *src = reinterpret_cast<const int4 *>(a.rows + ((long long)tile * kSfTile - HL) * NT);
       #pragma unroll
-      for (int k = 0; k < NV; ++k) if (k * NTH + tid < NVEC) q[k] = src[k * NTH + tid]; };
-   if (tile_lo < ntiles && tile_lo >= inside_lo && tile_lo <= inside_hi) fetch(tile_lo);
+      for (int k = 0; k < NV; ++k) if (k * NTH + tidx < NVEC) q[k] = src[k * NTH + tid]; };
+   if (tile_lo < ntiles && tile_lo >= inside_lo && tile_lo <= inside_hi) fetch(tile_lo, tid);
    if (tid < 2) s_noisy[tid] = 0;
    int par = 0, last_tile = -1;
    unsigned int pn_hard = 0, pn_rounds = 0, pn_bytes = 0;
@@ -797,7 +797,11 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       bool over = false;
       #pragma unroll
       for (int w2 = 0; w2 < NP; ++w2) {
+#ifdef RTFE_CPU_EMUL
          const int c = s_part[pp][w2];
+#else
+         const int c = __builtin_amdgcn_readfirstlane((int)s_part[pp][w2]);      // (the same for every lane: the sums below stay in scalar registers)
+#endif
          over = over || c == 0xffff;
          tot += c; if (w2 < wave) off += c; }
       over = over || 16 * tot > hcap;
@@ -811,6 +815,13 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)tot; d.nent = 0;
          a.dir[li] = d; } };
    for (int tile = tile_lo; tile < ntiles; tile += G, par ^= 1) {
+      // (conditions on the thread index alone are the same in every tile step: the compiler computes them once, as wave masks in scalar registers - more than
+      //  it has, so it parks them in a vector register's lanes and fetches each back with two v_readlane where one v_cmp would do.  An index it cannot see
+      //  through keeps the comparisons where they are used.)
+      int tidl = tid, lanel = lane;
+#ifndef RTFE_CPU_EMUL
+      asm volatile("" : "+v"(tidl), "+v"(lanel));
+#endif
       const int prev_tile = last_tile;
       last_tile = tile;
       const long long lastl = a.nrows - 1 - (long long)tile * kSfTile;
@@ -818,10 +829,10 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       // ---- 1. the prefetched bytes -> LDS; the next tile's loads go out at once and travel while this tile is worked on ----
       if (tile >= inside_lo && tile <= inside_hi) {
          #pragma unroll
-         for (int k = 0; k < NV; ++k) if (k * NTH + tid < NVEC) reinterpret_cast<int4 *>(xs)[k * NTH + tid] = q[k]; }
+         for (int k = 0; k < NV; ++k) if (k * NTH + tidl < NVEC) reinterpret_cast<int4 *>(xs)[k * NTH + tid] = q[k]; }
       else sf_fill_edge(xsl, a.rows, ((long long)tile * kSfTile - HL) * NT, a.nrows * NT, NVEC * 8, tid, NTH);
       __syncthreads();
-      if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G);
+      if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G, tidl);
       if (tid == 0 && tile > tile_lo && a.qtile) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
       if (p_tile >= 0) { copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad); p_tile = -1; rtfe_wave_sync(); }      // (the lists of the tile in front: a.defer)
       if (SPL && prev_tile >= 0 && cut != 1) { copy_out3(prev_tile, par ^ 1); rtfe_wave_sync(); }
@@ -830,15 +841,15 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       #pragma unroll
       for (int it = 0; it < NQIT; ++it) {
          bool noisy = false;
-         if (it * NTH + tid < NQ) {
+         if (it * NTH + tidl < NQ) {
             const int4 v = reinterpret_cast<const int4 *>(xs)[VOWN0 + it * NTH + tid];
             const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)v.x, qpk), pk_addu((uint32_t)v.y, qpk)),
                                        pk_maxu(pk_addu((uint32_t)v.z, qpk), pk_addu((uint32_t)v.w, qpk)));
             noisy = (m & 0xffffu) > q2 || (m >> 16) > q2; }
-         const u64 nb = __ballot(noisy);
-         if (nb) {
-            const u64 lowm = qsplit[it] >= 64 ? ~0ull : ((1ull << qsplit[it]) - 1ull);
-            const unsigned int bits = ((nb & lowm) ? 1u << qg[it] : 0u) | ((nb & ~lowm) ? 2u << qg[it] : 0u);
+         const bool upper = lanel >= qsplit[it];                                  // the wave's 64 vectors lie in group qg[it] (lanes below qsplit[it]) and the next one
+         const u64 nb_lo = __ballot(noisy && !upper), nb_hi = __ballot(noisy && upper);
+         if (nb_lo | nb_hi) {
+            const unsigned int bits = (nb_lo ? 1u << qg[it] : 0u) | (nb_hi ? 2u << qg[it] : 0u);
             if (lane == 0) atomicOr(&s_noisy[par], bits); } }
       if (cut != 1) {
          // ---- 3. candidate samples: local extremum + amplitude, one lane per 14-row strip of a pair of heads.  The rows of a pair are
