@@ -306,6 +306,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
       d.pk_mar = kPkMar;
       if (const char *e = getenv("RTFE_PK_MAR")) { const int v = atoi(e); if (v >= 0 && v <= kPkMar) d.pk_mar = v; }      // (tests: margins from the samples)
       if (const char *e = getenv("RTFE_SEG_RECS")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= 4096) d.pk_seg_recs = v; }
+      d.pk_rejoin = getenv("RTFE_SEG_REJOIN") ? atoi(getenv("RTFE_SEG_REJOIN")) != 0 : 1;      // (0: a chain that breaks is walked to its end by one lane, as before round 5's last part; tests)
       for (int p = 0; p < c->nparmsets; ++p) {
          const float a = c->parmset[p].agc_alpha;
          // (1 - alpha)^n < 2^-26 brings two gains within an ulp; 64 records more for the last ulp to collapse under the filter's own
@@ -757,7 +758,7 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
       if (sa != st) { se = sa; (void)hipEventRecord(h->ev_fork2, st); (void)hipStreamWaitEvent(se, h->ev_fork2, 0); }
       hipLaunchKernelGGL(k_emit, dim3(h->num_cus * 32), dim3(64), 0, se,
                          h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch,
-                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint2 *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp, d_rows, (long long)nrows);
+                         (const BurstCtl *)ctlp, (const uint32_t *)d_counts, d_events, (const float *)chainh, (const CRec *)crecp, (const uint2 *)erefp, ccap, (const unsigned char *)pkpool, (const ChainSt *)cstp, d_rows, (long long)nrows, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)));
       if (se != st) (void)hipEventRecord(h->ev_join2, se);
       hipLaunchKernelGGL(k_emit_seg, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const ChainSt *)cstp, (const BurstCtl *)ctlp, d_events, (const CRec *)crecp, (const uint2 *)erefp, ccap,
                          (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks), d_rows, (long long)nrows);

@@ -72,6 +72,7 @@ struct DevCfg {
    int   pk_lds;                  // dynamic LDS bytes of k_sift
    int   pk_fast;                 // k_gain: the steady-state fast path (0: every detection through the general step; tests)
    int   pk_seg_recs;             // records per segment of a chain's steady stretch (k_gain_seg); 0: a chain is one segment
+   int   pk_rejoin;               // k_gain (mode 1): a chain that broke inside its segmented stretch re-joins the segments behind the break where the states agree (1)
    int   pk_mar;                  // rows of a record's margin block the walkers read (kPkMar; RTFE_PK_MAR < 4: the rest is made from the samples - tests)
    // the dense sample path (rtfe_dense.hip): k_dseg -> k_dchain, for peak detection where a window holds a top and a bottom (PE, GCR)
    int   dense_path;

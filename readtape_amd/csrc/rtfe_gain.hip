@@ -504,8 +504,24 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          if (P.rise * hs > 0) rg_min = P.screen_rise_v * 1.002f / (P.rise * hs);
          if (amp_on && P.min_peak * hs > 0) { const float b2 = P.screen_minpk_v * 1.002f / (P.min_peak * hs); if (b2 > rg_min) rg_min = b2; } };
       if (lean && alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) enter_steady();      // (mode 1: a chain that comes back from k_gain_s)
+      // mode 1, a chain that did not get through its segments (one of them stopped at a record that is the general step's, or did not start in the state it had
+      // assumed): this lane walks on from there - but only to the END OF THAT SEGMENT.  The segments behind it were walked from guessed states that their joins
+      // could not check once the chain in front of them had broken; if the walker arrives at the next segment's first record in exactly the state that segment
+      // assumed there (gs_same: every field the step reads), the segment's result is the true one (it ran from the true state) and the induction of k_gain_join goes
+      // on from here: the walker takes the segment's end state and event count and looks at the next one.  A chain with a handful of such records costs a handful
+      // of segment remainders (<= pk_seg_recs records each) instead of everything behind the first (a 4 KB block: 4 100 records, 2.7 ms of dependent steps).
+      int rj_seg0 = 0, rj_nseg = 0, kseg = 0;
+      long long i_lim = 0x7fffffffffffffffll;
+      bool rejoined = false;
+      if (mode == 1 && active && steady && cst[ci].nseg > 0 && cfg.pk_rejoin) {
+         rj_seg0 = cst[ci].seg0; rj_nseg = cst[ci].nseg;
+         const long long f0 = segs[rj_seg0].first;
+         kseg = (int)((cst[ci].i - f0) / cfg.pk_seg_recs);
+         if (kseg < 0) kseg = 0;
+         if (kseg >= rj_nseg) { rj_nseg = 0; } else i_lim = segs[rj_seg0 + kseg].end; }
       auto step = [&](const int j, const long long idx) -> int {
          if (idx >= src.iend) return 2;
+         if (idx >= i_lim) return 4;                                        // (mode 1: at the next segment's first record - see rejoin)
          const uint4 cur4 = s_rec[j][lane];
          if (steady) {
             // ---- steady state, the common record: everything static about it is in its kCrClear flag ----
@@ -645,6 +661,24 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          i = alive.i;
          if (!steady && lean && alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) enter_steady();
          return 1; };
+      // ---- mode 1 at a segment boundary: i = the next segment's first record ----
+      auto rejoin = [&]() {
+         int k2 = kseg + 1;
+         GsState cur; cur.g = w.agc_gain; cur.vlt = w.v_lasttop; cur.vlb = w.v_lastbot; cur.c = (int)c; cur.rise_hi = w.rise_hi; cur.min_lo = w.min_lo; cur.min_hi = w.min_hi;
+         bool adopted = false;
+         while (k2 < rj_nseg) {
+            GsSeg &sg = segs[rj_seg0 + k2];
+            if (sg.first != i || !gs_same(sg.at_first, cur) || (unsigned long long)w.nevents + (unsigned)sg.cnt > cap) break;
+            sg.stands = 1; sg.evoff = w.nevents;
+            w.nevents += (unsigned)sg.cnt; w.peakcount += sg.cnt; cur = sg.at_end; i = sg.stop; adopted = true;
+            if (sg.stop < sg.end) break;                                   // (it stopped at a record of its own: the walk goes on from there, to its end)
+            ++k2; }
+         if (adopted) {
+            w.agc_gain = cur.g; w.v_lasttop = cur.vlt; w.v_lastbot = cur.vlb; w.v_top = cur.vlt; w.v_bot = cur.vlb; c = cur.c;
+            w.rise_hi = cur.rise_hi; w.rise_lo = cur.rise_hi - 5; w.min_lo = cur.min_lo; w.min_hi = cur.min_hi; w.thr_dirty = true;
+            rejoined = true; }
+         kseg = k2;
+         i_lim = k2 < rj_nseg ? segs[rj_seg0 + k2].end : 0x7fffffffffffffffll; };
       uint4 q[kGainChunk + 1];
       #pragma unroll
       for (int j = 0; j <= kGainChunk; ++j) q[j] = make_uint4(0, 0, 0, 0);
@@ -674,7 +708,8 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
             if (__ballot(st2 == 0) == 0) break; }
          bool resync = false;
          if (prof) { tk1 = clock64(); pc_steps += tk1 - tk0; ++pn_chunks; if (__ballot(st2 == 1)) ++pn_gen; }
-         if (st2 == 1) { i += jp; jp = 0; flush_notes(); st2 = general(); if (st2 != 2) st2 = 0; resync = true; if (st2 == 0 && mode == 0 && steady) st2 = 3; }      // (the general step leaves i at the record to go on with)
+         if (st2 == 4) { i += jp; jp = 0; flush_notes(); rejoin(); st2 = 0; resync = true; }      // (mode 1: the next segment's first record)
+         else if (st2 == 1) { i += jp; jp = 0; flush_notes(); st2 = general(); if (st2 != 2) st2 = 0; resync = true; if (st2 == 0 && mode == 0 && steady) st2 = 3; }      // (the general step leaves i at the record to go on with)
          else if (st2 == 0) i += kGainChunk;
          if (st2 == 3) { i += jp; flush_notes(); handed = true; st2 = 2; }      // the baseline is fixed: the chain waits for k_gain_s
          if (prof) { tk2 = clock64(); pc_gen += tk2 - tk1; }
@@ -690,7 +725,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
       if (!active) continue;
       if (handed && !failed) {                                             // (steady: everything the walker is, for k_gain_s)
          ChainSt &cs = cst[ci];
-         cs.w = w; cs.i = i; cs.c = c; cs.iend = src.iend; cs.seg0 = 0; cs.nseg = 0; cs.status = kChSteady; cs.seg_ev0 = w.nevents; cs.seg_ev1 = w.nevents;
+         cs.w = w; cs.i = i; cs.c = c; cs.iend = src.iend; cs.seg0 = 0; cs.nseg = 0; cs.status = kChSteady; cs.seg_ev0 = w.nevents; cs.seg_ev1 = w.nevents; cs.pad = 0;
          cs.k.ev_index = (unsigned long long)(ev - events); cs.k.h = w.v_avg_height; cs.k.alpha = alpha; cs.k.kr = kr; cs.k.km = km; cs.k.rg_min = rg_min; cs.k.g_min = g_min;
          cs.k.W = W; cs.k.sure_i = S.sure_i; cs.k.limit32 = limit32; cs.k.amp_on = amp_on ? 1 : 0; cs.k.sl = sl; cs.k.pad = 0;
          // the steady stretch's segments: their places in the table (any order: one atomic per chain), their entries
@@ -710,7 +745,8 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          if (w.nevents > n_slow) atomicAdd(&scratch->dbg[0], (unsigned long long)(w.nevents - n_slow));      // (statistics: the head's events on the fast path)
          continue; }
       cst[ci].status = kChDone;
-      if (mode == 0) { cst[ci].seg_ev0 = 0; cst[ci].seg_ev1 = 0; }        // (no steady stretch: every event of the chain is k_emit's)
+      if (mode == 0) { cst[ci].seg_ev0 = 0; cst[ci].seg_ev1 = 0; cst[ci].pad = 0; }        // (no steady stretch: every event of the chain is k_emit's)
+      if (rejoined) cst[ci].pad = 1;                                      // (k_emit: the chain's notes lie between several runs of k_emit_seg's events)
       n_fast = w.nevents - n_slow - (mode == 1 ? cst[ci].w.nevents : 0u);
       if (n_fast) atomicAdd(&scratch->dbg[0], (unsigned long long)n_fast);
       if (n_slow) atomicAdd(&scratch->dbg[1], (unsigned long long)n_slow);
@@ -993,7 +1029,8 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
 __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch,
                                               const BurstCtl *__restrict__ ctl, const uint32_t *__restrict__ counts, rtfe_event *__restrict__ events,
                                               const float *__restrict__ chain_h, const CRec *__restrict__ crec, const uint2 *__restrict__ cmar, long long ccap,
-                                              const unsigned char *__restrict__ pool, const ChainSt *__restrict__ cst, const int16_t *__restrict__ rows, long long nrows) {
+                                              const unsigned char *__restrict__ pool, const ChainSt *__restrict__ cst, const int16_t *__restrict__ rows, long long nrows,
+                                              const GsSeg *__restrict__ segs) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
    const int nchains = scratch->nbursts * nwalk;
@@ -1013,16 +1050,28 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
       const unsigned int skip0 = cst[ci].seg_ev0, skip1 = cst[ci].seg_ev1;      // (k_emit_seg's events)
       Walker wk = {};
       wk.v_avg_height = chain_h[(size_t)b * nwalk + wi];
-      const unsigned int nmine = nev - (skip1 - skip0);
-      for (unsigned int t = threadIdx.x; t < nmine; t += blockDim.x) {
-         const unsigned int i = t < skip0 ? t : t + (skip1 - skip0);
+      auto one = [&](const unsigned int i) {
          union { rtfe_event e; uint32_t w[4]; } in;
          in.e = ev[i];
-         if (in.w[3] != 0xffffffffu) continue;                            // the general step wrote it out in full
+         if (in.w[3] != 0xffffffffu) return;                              // the general step wrote it out in full
          const float gain = __uint_as_float(in.w[1]);
          wk.v_avg_height = __uint_as_float(in.w[2]);
          const CRec r = crec[sbase + in.w[0]];
-         ev[i] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(cmar + sbase + in.w[0] + 1), msrc, gain, W, d, reset, trk, pidx, mv); } } }
+         ev[i] = emit_event(cfg, P, wk, r, reinterpret_cast<const uint16_t *>(cmar + sbase + in.w[0] + 1), msrc, gain, W, d, reset, trk, pidx, mv); };
+      if (cst[ci].pad == 1) {
+         // a chain k_gain (mode 1) re-joined to its segments: its notes lie in front of, between and behind the standing segments' events (k_emit_seg's,
+         // written beside this kernel: not to be looked at) - the gaps between them, in segment order
+         const int seg0 = cst[ci].seg0, nseg = cst[ci].nseg;
+         unsigned int pos = 0;
+         for (int k = 0; k <= nseg; ++k) {
+            unsigned int ge = nev;
+            unsigned int next = nev;
+            if (k < nseg) { const GsSeg &sg = segs[seg0 + k]; if (sg.stands != 1) continue; ge = sg.evoff < nev ? sg.evoff : nev; next = sg.evoff + (unsigned)sg.cnt; }
+            for (unsigned int i = pos + threadIdx.x; i < ge; i += blockDim.x) one(i);
+            pos = next < nev ? next : nev; }
+         continue; }
+      const unsigned int nmine = nev - (skip1 - skip0);
+      for (unsigned int t = threadIdx.x; t < nmine; t += blockDim.x) one(t < skip0 ? t : t + (skip1 - skip0)); } }
 
 // ------------------------------------------------------------------------------------------------
 // k_publish: burst table entries of the bursts the chains finished; stop rows for the ones the sample path redoes

@@ -187,7 +187,7 @@ def test_emulated_clear_flags_equal_a_pass_over_the_streams(name, peak, monkeypa
     assert "prep_check" not in err, err[:2000]
 
 
-@pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}, {"RTFE_SEG_RECS": "32"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_WARM": "3"}, {"RTFE_SEG_RECS": "1024"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_CAP": "70"},
+@pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}, {"RTFE_SEG_RECS": "32"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_WARM": "3"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_WARM": "3", "RTFE_SEG_REJOIN": "0"}, {"RTFE_SEG_RECS": "16", "RTFE_SEG_WARM": "40"}, {"RTFE_SEG_RECS": "1024"}, {"RTFE_SEG_RECS": "32", "RTFE_SEG_CAP": "70"},
                                    {"RTFE_SIFT_GENERIC": "1"}, {"RTFE_PK_SLOT": "128"}, {"RTFE_PK_MAR": "0"}, {"RTFE_PK_MAR": "1", "RTFE_GAIN_FAST": "0"}])
 def test_emulated_long_blocks(knobs, tmp_path, monkeypatch):
     """Blocks of 500-640 bytes: chains that cross many tiles (k_gain's heads, the steady stretches in segments, the tails).

@@ -84,7 +84,7 @@ def test_parameter_sweep_on_the_peak_path(knobs, gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [{}, {"RTFE_GAIN_FAST": "0"}, {"RTFE_SIFT_GENERIC": "1"}, {"RTFE_PK_SLOT": "128"}, {"RTFE_PEAK_PATH": "0"},
-                                   {"RTFE_SEG_RECS": "64"}, {"RTFE_SEG_RECS": "64", "RTFE_SEG_WARM": "4"}, {"RTFE_SEG_RECS": "512", "RTFE_SEG_WARM": "16"}, {"RTFE_SEG_RECS": "1024"}, {"RTFE_SEG_RECS": "64", "RTFE_SEG_CAP": "300"}])
+                                   {"RTFE_SEG_RECS": "64"}, {"RTFE_SEG_RECS": "64", "RTFE_SEG_WARM": "4"}, {"RTFE_SEG_RECS": "64", "RTFE_SEG_WARM": "4", "RTFE_SEG_REJOIN": "0"}, {"RTFE_SEG_REJOIN": "0"}, {"RTFE_SEG_RECS": "512", "RTFE_SEG_WARM": "16"}, {"RTFE_SEG_RECS": "1024"}, {"RTFE_SEG_RECS": "64", "RTFE_SEG_CAP": "300"}])
 def test_long_blocks(knobs, tmp_path, gpu, monkeypatch):
     """Blocks of 1500-4096 bytes (chains of tens of thousands of records: k_gain's heads, k_gain_s' steady stretches across many
     tiles, the tails): the events are the oracle's, every block start speculative."""
