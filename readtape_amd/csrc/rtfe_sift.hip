@@ -33,23 +33,40 @@ __global__ void __launch_bounds__(256) k_quiet(const int16_t *__restrict__ rows,
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    const long long ngroups = nrows / 64;                  // complete groups
    const int vpg = 8 * ntrks;                             // 16-byte vectors per group
+   const int nv1 = vpg < 8 ? vpg : 8;                     // ... of which the first pass looks at these
    const uint32_t qpk = pk_dup(quiet_i);
    const uint32_t q2 = 2u * (uint32_t)quiet_i;
    for (long long w = blockIdx.x; w < nwords; w += gridDim.x) {
-      unsigned int bits = 0;
-      for (int k = 0; k < 16; ++k) {
+      // A group is quiet only if EVERY sample of its 64 rows is - so one that is not shows it in any part of it, and inside a block every part of a group
+      // carries signal: the first 128 bytes of each of the wave's sixteen groups are looked at first (eight 16-byte vectors - seven rows of nine tracks -, all
+      // sixteen loads in flight), and only the groups whose first samples are quiet - the gaps, a few per cent of a tape - are read in full.  The map is the
+      // same; the pass reads one 128-byte line of a group's nine (nine tracks) instead of all of them.
+      unsigned int cand = 0, bits = 0;
+      {  int4 q1[16];
+         #pragma unroll
+         for (int k = 0; k < 16; ++k) {
+            const long long c = w * 64 + wave * 16 + k;
+            q1[k] = make_int4(0, 0, 0, 0);
+            if (c < ngroups && lane < nv1) q1[k] = reinterpret_cast<const int4 *>(rows + c * 64 * ntrks)[lane]; }
+         #pragma unroll
+         for (int k = 0; k < 16; ++k) {
+            const long long c = w * 64 + wave * 16 + k;
+            const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)q1[k].x, qpk), pk_addu((uint32_t)q1[k].y, qpk)), pk_maxu(pk_addu((uint32_t)q1[k].z, qpk), pk_addu((uint32_t)q1[k].w, qpk)));
+            const bool noisy = lane < nv1 && ((m & 0xffffu) > q2 || (m >> 16) > q2);
+            const u64 b = __ballot(noisy);
+            if (c < ngroups && b == 0) cand |= 1u << k; } }
+      for (unsigned int cm = cand; cm; cm &= cm - 1) {
+         const int k = __ffs((int)cm) - 1;
          const long long c = w * 64 + wave * 16 + k;
-         bool noisy = false;
-         if (c < ngroups) {
-            const int4 *src = reinterpret_cast<const int4 *>(rows + c * 64 * ntrks);
-            uint32_t m = 0;
-            for (int v = lane; v < vpg; v += 64) {
-               const int4 q = src[v];
-               m = pk_maxu(m, pk_maxu(pk_maxu(pk_addu((uint32_t)q.x, qpk), pk_addu((uint32_t)q.y, qpk)),
-                                      pk_maxu(pk_addu((uint32_t)q.z, qpk), pk_addu((uint32_t)q.w, qpk)))); }
-            noisy = (m & 0xffffu) > q2 || (m >> 16) > q2; }
+         const int4 *src = reinterpret_cast<const int4 *>(rows + c * 64 * ntrks);
+         uint32_t m = 0;
+         for (int v = nv1 + lane; v < vpg; v += 64) {
+            const int4 q = src[v];
+            m = pk_maxu(m, pk_maxu(pk_maxu(pk_addu((uint32_t)q.x, qpk), pk_addu((uint32_t)q.y, qpk)),
+                                   pk_maxu(pk_addu((uint32_t)q.z, qpk), pk_addu((uint32_t)q.w, qpk)))); }
+         const bool noisy = (m & 0xffffu) > q2 || (m >> 16) > q2;
          const u64 b = __ballot(noisy);
-         if (c < ngroups && b == 0) bits |= 1u << k; }
+         if (b == 0) bits |= 1u << k; }
       if (lane == 0) part[wave] = bits;
       __syncthreads();
       if (threadIdx.x == 0)
