@@ -230,7 +230,8 @@ class Workload:
             self.streams = [torch.cuda.Stream(dev) for _ in range(nctx)]
         else:
             self.fes = [self.fe, self.fe]
-            self.streams = [torch.cuda.current_stream(dev)] * 2 if self.cuda else [None, None]
+            # (a stream of its own, not the legacy default stream: that one cannot be captured - rtfe_set_graphs would quietly launch directly)
+            self.streams = [torch.cuda.Stream(dev)] * 2 if self.cuda else [None, None]
         if self.cuda:
             for f in set(self.fes): f.set_timing(True)
         self.kms = {k: 0.0 for k in self.fe.kernel_names()} if self.cuda else {}
@@ -313,8 +314,9 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
     for k in kms: kms[k] /= n_serial
     kms_serial = dict(kms)
     graphs = (bool(getattr(args, "graphs", False)) or bool(conf.get("graphs"))) and not getattr(args, "no_graphs", False) and wl.cuda and not overlap      # (graphs of two contexts do not run beside each other: measured)
-    if graphs:                                       # the timed region replays captured HIP graphs: no events between the kernels (kernel_ms: the serial pass above)
-        for f in set(wl.fes): f.set_timing(False); f.set_graphs(True)
+    no_events = bool(getattr(args, "no_kernel_events", False)) and wl.cuda      # (experiments: what the 24 event records per scan cost by themselves)
+    if graphs or no_events:                          # the timed region replays captured HIP graphs: no events between the kernels (kernel_ms: the serial pass above)
+        for f in set(wl.fes): f.set_timing(False); f.set_graphs(bool(graphs))
         wl.graphs_on = True
         for i in range(2 * len(wl.fes)): wl.step(i)  # (capture + instantiate: once per context, outside the timed region - as a tape's first window pays it)
         torch.cuda.synchronize(dev)
@@ -335,7 +337,7 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
             d = float(t.item())
         dt += d; done += steps
         if dt >= min_seconds or done >= 64 * steps: break
-    if graphs:
+    if graphs or no_events:
         for f in set(wl.fes): f.set_graphs(False); f.set_timing(True)
         wl.graphs_on = False
         for k in kms: kms[k] = kms_serial[k]
@@ -391,7 +393,7 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
                    "flagged_bursts": bad, "parmsets": conf["nparmsets"], "launches_per_step": len(frags), "last_scan_stats": sst, "screen_floor_height": calibrated,
                    "sharding": ("one tape, time shards (plan_shards), neighbour halo only" if strong else "time shards, neighbour halo only") if world > 1 else "none"},
         "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
-        "kernel_ms_in_timed_region": {k: round(v, 4) for k, v in kms_timed.items()} if overlap and not graphs else None,
+        "kernel_ms_in_timed_region": {k: round(v, 4) for k, v in kms_timed.items()} if overlap and not graphs and not no_events else None,
         "graphs": ("rtfe_set_graphs: every timed step replays the HIP graph its context captured at its first scan of these buffers" if graphs else None),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_all_kernels": traffic_all, "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
@@ -417,6 +419,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=2.0, help="the timed region repeats its --steps steps until it is at least this long")
     ap.add_argument("--no-overlap", action="store_true", help="one scan context, steps back to back, also for the configurations that overlap two by default")
     ap.add_argument("--no-graphs", action="store_true", help="direct launches also where a configuration replays graphs by default (C5: a rank's share is a short scan)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="experiments: no per-kernel HIP events in the timed region (direct launches; kernel_ms from the serial pass)")
     ap.add_argument("--graphs", action="store_true", help="rtfe_set_graphs: the timed steps replay captured HIP graphs (no per-kernel events in the timed region; kernel_ms from the serial pass)")
     ap.add_argument("--pipeline", action="store_true", help="alternate two front-end contexts on two HIP streams (steps overlap; per-kernel times then include contention)")
     args = ap.parse_args()
