@@ -70,7 +70,7 @@ CONFIGS = {
                 workload="N1f (extra): N1 with the candidate screen pinned at the 1 V floor a handle starts from (a tape's first scan): the lists outgrow their slots, the bursts are redone on the samples"),
     "N2": dict(kind="gcr", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=30.0,
                workload="N2 (extra): G1's tape with 30 mV rms of noise on 1.8 V peaks (G1: 10 mV), 1 parmset, one scan"),
-    "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True, graphs=True,
+    "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True, no_events=True,
                workload="C5: ONE 10 GB synthetic 9-track 800 BPI NRZI tape, time-sharded over the ranks (strong scaling)"),
 }
 
@@ -314,7 +314,9 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
     for k in kms: kms[k] /= n_serial
     kms_serial = dict(kms)
     graphs = (bool(getattr(args, "graphs", False)) or bool(conf.get("graphs"))) and not getattr(args, "no_graphs", False) and wl.cuda and not overlap      # (graphs of two contexts do not run beside each other: measured)
-    no_events = bool(getattr(args, "no_kernel_events", False)) and wl.cuda      # (experiments: what the 24 event records per scan cost by themselves)
+    # C5 - what --gpus N runs, a rank's share is a short scan - records no per-kernel events in its timed region (24 records per scan: 1.32 -> 1.21 ms on a 6.9e7-row
+    # scan; kernel_ms from the serial pass above).  Graph replay (--graphs) buys another 0.6 % there: not the default - its capture beside RCCL's threads is untested
+    no_events = (bool(getattr(args, "no_kernel_events", False)) or bool(conf.get("no_events"))) and wl.cuda
     if graphs or no_events:                          # the timed region replays captured HIP graphs: no events between the kernels (kernel_ms: the serial pass above)
         for f in set(wl.fes): f.set_timing(False); f.set_graphs(bool(graphs))
         wl.graphs_on = True
@@ -395,6 +397,7 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
         "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
         "kernel_ms_in_timed_region": {k: round(v, 4) for k, v in kms_timed.items()} if overlap and not graphs and not no_events else None,
         "graphs": ("rtfe_set_graphs: every timed step replays the HIP graph its context captured at its first scan of these buffers" if graphs else None),
+        "kernel_events_in_timed_region": not (graphs or no_events),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_all_kernels": traffic_all, "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
                      "frac_rows_only": round(own_rows_bytes / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms[dom] > 0 else None,
@@ -418,7 +421,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact C3 / C4 / C5 lines the default single-GPU run adds to its line")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="the timed region repeats its --steps steps until it is at least this long")
     ap.add_argument("--no-overlap", action="store_true", help="one scan context, steps back to back, also for the configurations that overlap two by default")
-    ap.add_argument("--no-graphs", action="store_true", help="direct launches also where a configuration replays graphs by default (C5: a rank's share is a short scan)")
+    ap.add_argument("--no-graphs", action="store_true", help="direct launches (the default everywhere; kept for the experiment scripts)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiments: no per-kernel HIP events in the timed region (direct launches; kernel_ms from the serial pass)")
     ap.add_argument("--graphs", action="store_true", help="rtfe_set_graphs: the timed steps replay captured HIP graphs (no per-kernel events in the timed region; kernel_ms from the serial pass)")
     ap.add_argument("--pipeline", action="store_true", help="alternate two front-end contexts on two HIP streams (steps overlap; per-kernel times then include contention)")
@@ -448,7 +451,7 @@ def main():
         line = {"metric": "Msamples/sec (all tracks) 9-trk TBIN", "value": fields["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": fields["ms_per_step"], "ms_per_step_serial": fields["ms_per_step_serial"], "overlap": fields["overlap"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
                 "vs_baseline": None, "dtype": "i16/f32", "data": "synthetic", "timed_steps": fields["timed_steps"], "timed_seconds": fields["timed_seconds"],
-                "config": fields["config"], "kernel_ms": fields["kernel_ms"], "kernel_ms_in_timed_region": fields["kernel_ms_in_timed_region"], "graphs": fields["graphs"], "roofline": fields["roofline"]}
+                "config": fields["config"], "kernel_ms": fields["kernel_ms"], "kernel_ms_in_timed_region": fields["kernel_ms_in_timed_region"], "graphs": fields["graphs"], "kernel_events_in_timed_region": fields["kernel_events_in_timed_region"], "roofline": fields["roofline"]}
     import gc
 
     def release(w):                                  # a workload's device memory: its scan contexts' buffers, its rows
@@ -463,7 +466,7 @@ def main():
         for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("M8", 5, 2), ("M8f", 3, 1), ("N1", 10, 2), ("N1f", 2, 1), ("N2", 2, 1)):
             try:
                 f2, w2 = measure(name, args, rank, world, dev, dist, st, wu, args.min_seconds)
-                others[name] = {"workload": f2["config"]["workload"], "value": f2["value"], "unit": "Msamples/s", "ms_per_step": f2["ms_per_step"], "ms_per_step_serial": f2["ms_per_step_serial"], "overlap": f2["overlap"][:40], "graphs": bool(f2["graphs"]), "timed_steps": f2["timed_steps"],
+                others[name] = {"workload": f2["config"]["workload"], "value": f2["value"], "unit": "Msamples/s", "ms_per_step": f2["ms_per_step"], "ms_per_step_serial": f2["ms_per_step_serial"], "overlap": f2["overlap"][:40], "graphs": bool(f2["graphs"]), "kernel_events_in_timed_region": f2["kernel_events_in_timed_region"], "timed_steps": f2["timed_steps"],
                                 "rows": f2["config"]["rows_total"], "events": f2["config"]["events_total"], "parmsets": f2["config"]["parmsets"], "flagged_bursts": f2["config"]["flagged_bursts"],
                                 "launches_per_step": f2["config"]["launches_per_step"], "dominant_kernel": f2["roofline"]["kernel"], "dominant_kernel_ms": f2["kernel_ms"][f2["roofline"]["kernel"]],
                                 "frac": f2["roofline"]["frac"], "frac_rows_only": f2["roofline"]["frac_rows_only"], "whole_step_frac": f2["roofline"]["whole_step"]["frac"],

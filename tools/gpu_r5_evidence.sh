@@ -21,5 +21,5 @@ done
 timeout 600 bash tools/gpu_pmc.sh --no-other-configs --no-overlap > gpurun_out/r05/sq_counters_c2_a.txt 2>&1
 timeout 600 bash tools/gpu_pmc2.sh --no-other-configs --no-overlap > gpurun_out/r05/sq_counters_c2_b.txt 2>&1
 rm -rf gpurun_out/pmc_sq gpurun_out/pmc_sq2
-for r in 5.54e8 6.9e7; do timeout 300 python bench.py --config C5 --rows $r --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > gpurun_out/r05/bench_c5_rows_$r.json 2>/dev/null; done
+for r in 5.54e8 6.9e7; do timeout 300 python bench.py --config C5 --rows $r --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > gpurun_out/r05/bench_c5_rows_$r.json 2>/dev/null; timeout 300 python bench.py --config C5 --rows $r --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --graphs > gpurun_out/r05/bench_c5_rows_${r}_graphs.json 2>/dev/null; done
 ls gpurun_out/r05
