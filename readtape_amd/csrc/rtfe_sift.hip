@@ -29,49 +29,48 @@ namespace rtfe {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_quiet(const int16_t *__restrict__ rows, long long nrows, int ntrks, int quiet_i,
                                                u64 *__restrict__ qwords, long long nwords) {
-   __shared__ unsigned int part[4];
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    const long long ngroups = nrows / 64;                  // complete groups
-   const int vpg = 8 * ntrks;                             // 16-byte vectors per group
-   const int nv1 = vpg < 8 ? vpg : 8;                     // ... of which the first pass looks at these
+   const int vpg = 8 * ntrks;                             // 16-byte vectors per group (>= 8)
    const uint32_t qpk = pk_dup(quiet_i);
    const uint32_t q2 = 2u * (uint32_t)quiet_i;
-   for (long long w = blockIdx.x; w < nwords; w += gridDim.x) {
-      // A group is quiet only if EVERY sample of its 64 rows is - so one that is not shows it in any part of it, and inside a block every part of a group
-      // carries signal: the first 128 bytes of each of the wave's sixteen groups are looked at first (eight 16-byte vectors - seven rows of nine tracks -, all
-      // sixteen loads in flight), and only the groups whose first samples are quiet - the gaps, a few per cent of a tape - are read in full.  The map is the
-      // same; the pass reads one 128-byte line of a group's nine (nine tracks) instead of all of them.
-      unsigned int cand = 0, bits = 0;
-      {  int4 q1[16];
-         #pragma unroll
-         for (int k = 0; k < 16; ++k) {
-            const long long c = w * 64 + wave * 16 + k;
-            q1[k] = make_int4(0, 0, 0, 0);
-            if (c < ngroups && lane < nv1) q1[k] = reinterpret_cast<const int4 *>(rows + c * 64 * ntrks)[lane]; }
-         #pragma unroll
-         for (int k = 0; k < 16; ++k) {
-            const long long c = w * 64 + wave * 16 + k;
-            const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)q1[k].x, qpk), pk_addu((uint32_t)q1[k].y, qpk)), pk_maxu(pk_addu((uint32_t)q1[k].z, qpk), pk_addu((uint32_t)q1[k].w, qpk)));
-            const bool noisy = lane < nv1 && ((m & 0xffffu) > q2 || (m >> 16) > q2);
-            const u64 b = __ballot(noisy);
-            if (c < ngroups && b == 0) cand |= 1u << k; } }
-      for (unsigned int cm = cand; cm; cm &= cm - 1) {
-         const int k = __ffs((int)cm) - 1;
-         const long long c = w * 64 + wave * 16 + k;
-         const int4 *src = reinterpret_cast<const int4 *>(rows + c * 64 * ntrks);
-         uint32_t m = 0;
-         for (int v = nv1 + lane; v < vpg; v += 64) {
-            const int4 q = src[v];
-            m = pk_maxu(m, pk_maxu(pk_maxu(pk_addu((uint32_t)q.x, qpk), pk_addu((uint32_t)q.y, qpk)),
-                                   pk_maxu(pk_addu((uint32_t)q.z, qpk), pk_addu((uint32_t)q.w, qpk)))); }
-         const bool noisy = (m & 0xffffu) > q2 || (m >> 16) > q2;
-         const u64 b = __ballot(noisy);
-         if (b == 0) bits |= 1u << k; }
-      if (lane == 0) part[wave] = bits;
-      __syncthreads();
-      if (threadIdx.x == 0)
-         qwords[w] = (u64)part[0] | ((u64)part[1] << 16) | ((u64)part[2] << 32) | ((u64)part[3] << 48);
-      __syncthreads(); } }
+   auto noisy4 = [&](const int4 q) -> bool {
+      const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)q.x, qpk), pk_addu((uint32_t)q.y, qpk)), pk_maxu(pk_addu((uint32_t)q.z, qpk), pk_addu((uint32_t)q.w, qpk)));
+      return (m & 0xffffu) > q2 || (m >> 16) > q2; };
+   // A group is quiet only if EVERY sample of its 64 rows is - so one that is not shows it in any part of it, and inside a block every part of a group carries
+   // signal: a group's first 128 bytes (eight 16-byte vectors: seven rows of nine tracks) are looked at first, and the group is read in full only where they are
+   // quiet - the gaps, a few per cent of a tape.  The map is bit for bit the same.  A WAVE makes a word of the map: eight lanes a group, eight load instructions
+   // for the word's 64 first lines (all in flight together), a vote per instruction; the pass is bound by its dependent rounds (loads, votes), not by the lines -
+   // so a round does as much as a wave's registers hold (round 5's first cut: a workgroup a word, sixteen groups a wave and two barriers a round - 1.35 ms per
+   // 9.98e8 rows where this takes a third of the rounds).
+   const int sub = lane >> 3, v8 = lane & 7;
+   for (long long wv = (long long)blockIdx.x * 4 + wave; wv < nwords; wv += (long long)gridDim.x * 4) {
+      const long long base = wv * 64;
+      int4 q1[8];
+      #pragma unroll
+      for (int k = 0; k < 8; ++k) {
+         const long long c = base + k * 8 + sub;
+         q1[k] = make_int4(0, 0, 0, 0);
+         if (c < ngroups) q1[k] = reinterpret_cast<const int4 *>(rows + c * 64 * ntrks)[v8]; }
+      u64 cand = 0;                                                    // groups whose first line is quiet
+      #pragma unroll
+      for (int k = 0; k < 8; ++k) {
+         const u64 b = __ballot(noisy4(q1[k]));                        // byte g: the eight lanes of group base + 8 k + g
+         u64 z = ~b;                                                   // a byte of ones = a quiet first line
+         z &= z >> 4; z &= z >> 2; z &= z >> 1;                       // bit 8 g = all eight bits of byte g
+         z &= 0x0101010101010101ull;
+         // gather bits 0, 8, 16 ... 56 into bits 0 .. 7
+         const u64 g8 = (z * 0x0102040810204080ull) >> 56;
+         cand |= g8 << (8 * k); }
+      if (base + 64 > ngroups) cand &= ngroups > base ? ((ngroups - base >= 64) ? ~0ull : ((1ull << (ngroups - base)) - 1ull)) : 0ull;      // (groups behind the tape's end are not quiet)
+      u64 bits = 0;
+      for (u64 cm = cand; cm; cm &= cm - 1) {                          // the rest of such a group, the whole wave on it
+         const int idx = __ffsll((long long)cm) - 1;
+         const int4 *src = reinterpret_cast<const int4 *>(rows + (base + idx) * 64 * ntrks);
+         bool noisy = false;
+         for (int v = 8 + lane; v < vpg; v += 64) noisy = noisy || noisy4(src[v]);
+         if (__ballot(noisy) == 0) bits |= 1ull << idx; }
+      if (lane == 0) qwords[wv] = bits; } }
 
 // ------------------------------------------------------------------------------------------------
 // LDS access with LDS-typed pointers: a generic pointer makes every access a FLAT instruction that counts against both
