@@ -38,7 +38,7 @@ extern "C" {
 
 #define RTFE_MAXTRKS     19   /* src/csvtbin.h:29  MAXTRKS      */
 #define RTFE_MAXPARMSETS 15   /* src/decoder.h:92  MAXPARMSETS  */
-#define RTFE_ABI_VERSION 5   /* 5: rtfe_set_graphs; 4: rtfe_pack_events; 3: rtfe_scan_stats out[21] = the smallest learned peak height (screen-floor calibration); 2: rtfe_kernel_ms returns the number of scans summed; twelve timed spans (k_dseg, k_dchain) */
+#define RTFE_ABI_VERSION 6   /* 6: rtfe_reset_floor (a handle's first scan estimates the candidate screen's floor from the samples); 5: rtfe_set_graphs; 4: rtfe_pack_events; 3: rtfe_scan_stats out[21] = the smallest learned peak height (screen-floor calibration); 2: rtfe_kernel_ms returns the number of scans summed; twelve timed spans (k_dseg, k_dchain) */
 
 enum { RTFE_PE = 1, RTFE_NRZI = 2, RTFE_GCR = 4, RTFE_WW = 8 };      /* enum mode_t, src/csvtbin.h:47-49 */
 
@@ -72,9 +72,11 @@ typedef struct rtfe_config {
    float   quiet_volts;                   /* |v| band of the dead-quiet test; 0 = default         */
    float   screen_floor_height;           /* assumed lower bound of the AGC baseline (v_avg_height) for
                                              the candidate screen.  A burst whose measured baseline is lower is
-                                             flagged RTFE_F_SCREEN_UNDERFLOW.  0 = the handle starts at 1.0 V and
-                                             follows the tape: behind each scan of the peak path the floor moves to
-                                             half the smallest peak height the scan learned (rtfe_scan_stats out[22]) */
+                                             flagged RTFE_F_SCREEN_UNDERFLOW.  0 = the handle follows the tape: its first
+                                             scan of the peak path estimates the floor from the samples before it screens
+                                             (0.45 x the smallest peak-to-peak range inside a block; 1.0 V where it finds
+                                             no block), and behind each scan the floor moves to half the smallest peak
+                                             height the scan's chains learned (rtfe_scan_stats out[22]; rtfe_reset_floor) */
    float   events_per_sample_cap;         /* per-track event capacity as a fraction of the burst length;
                                              0 = default 1/8 */
 } rtfe_config;
@@ -157,6 +159,11 @@ int rtfe_scan(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t own_
               uint32_t *d_counts, rtfe_event *d_events, int64_t event_capacity,
               void *stream);
 
+/* The scans of ONE handle read and move its device-resident screen (above): queue them on one stream, or order the streams yourself.
+ * rtfe_reset_floor: the screen back to what rtfe_create made (queued on `stream`) - the next scan is a tape's first scan again (a new tape on an old
+ * handle; bench.py's "...f" lines time exactly that). */
+int rtfe_reset_floor(rtfe_handle *h, void *stream);
+
 /* Exact scan of one block attempt: detector state restarts at `reset_row` (index into d_rows) and
  * rows [reset_row, end_row) are scanned; parmset_mask selects parameter sets.  With screen_off != 0
  * every sample is examined (use after RTFE_F_SCREEN_UNDERFLOW).  Writes one rtfe_burst. */
@@ -204,8 +211,9 @@ int rtfe_kernel_ms(rtfe_handle *h, float *out);
  * out[21] = 0x7fffffff - the IEEE bits of the smallest v_avg_height (src/decode_nrzi.c:224-229) a chain of the scan learned, 0 if none did (peak path):
  * what a caller may raise rtfe_config::screen_floor_height towards for the next scans of the same tape - a floor above a later chain's learned height is
  * flagged RTFE_F_SCREEN_UNDERFLOW and costs an exact rescan, never a wrong event.  out[22] = the IEEE bits of the floor the handle's next scan screens against:
- * with rtfe_config::screen_floor_height == 0 the handle starts at 1 V and, behind every scan of the peak path, moves the floor to half the smallest height that
- * scan's chains learned (on the device, nothing waits; a floor the caller gives stands).  out must hold 24 values. */
+ * with rtfe_config::screen_floor_height == 0 the handle's first scan estimates it from the samples and every scan of the peak path moves it, behind itself, to half
+ * the smallest height its chains learned (on the device, nothing waits; a floor the caller gives stands).  out[23] = the IEEE bits of the floor THIS scan's screen was built for (peak path).
+ * out must hold 24 values. */
 int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out);
 
 /* Names and launch-order of the kernels of one scan, for profilers (static strings). */

@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "rt_frontend.h"
 #include "rtfe_device.h"
 
@@ -62,15 +64,20 @@ static void drop_graphs(rtfe_handle *h) {
    for (int i = 0; i < kGraphCache; ++i) if (h->gcache[i].exec) { (void)hipGraphExecDestroy(h->gcache[i].exec); h->gcache[i].exec = nullptr; } }
 
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel in the process, not of a handle: a second handle with a smaller LDS
-// layout must not lower what a first one's launches need.  A table of the largest size asked for so far, per kernel.
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel on the CURRENT DEVICE, not of a handle: a second handle with a smaller LDS
+// layout must not lower what a first one's launches need, a handle made on a second device must set it there too, and handles are made
+// from several threads (ingest.py) - a table of the largest size asked for so far per (device, kernel), behind a mutex.
 static void raise_dynamic_lds(const void *kernel, int bytes) {
-   static struct { const void *k; int b; } seen[64];
+   static std::mutex mu;
+   static struct { const void *k; int dev, b; } seen[256];
    static int nseen = 0;
-   for (int i = 0; i < nseen; ++i) if (seen[i].k == kernel) {
-      if (bytes <= seen[i].b) return;
-      seen[i].b = bytes; (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); return; }
-   if (nseen < 64) { seen[nseen].k = kernel; seen[nseen].b = bytes; ++nseen; }
+   int dev = 0;
+   (void)hipGetDevice(&dev);
+   std::lock_guard<std::mutex> lock(mu);
+   for (int i = 0; i < nseen; ++i) if (seen[i].k == kernel && seen[i].dev == dev) {
+      if (bytes > seen[i].b) seen[i].b = bytes;
+      (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seen[i].b); return; }
+   if (nseen < 256) { seen[nseen].k = kernel; seen[nseen].dev = dev; seen[nseen].b = bytes; ++nseen; }
    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
 static int fail(int code, const char *fmt, ...) {
    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
@@ -226,7 +233,8 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    // the candidate screens: the loosest thresholds the AGC can ever ask for, given v_avg_height >= hfloor and agc_gain <= 2 (screen_thresholds, rtfe_kernels.hip).
    // A floor the caller gave stands; the default (1 V: every tape clears it) is where the handle starts, and behind each scan of the peak path the
    // floor moves to half the smallest peak height the scan's chains learned (k_adapt_floor; RTFE_ADAPT_FLOOR=0: never)
-   d.floor_cfg = hfloor;
+   d.floor_cfg = hfloor; d.floor_probed = 0; d.probe_min = 0x7fffffff; d.probe_ticket = 0;
+   d.probe_on = !(getenv("RTFE_FLOOR_PROBE") && atoi(getenv("RTFE_FLOOR_PROBE")) == 0);
    d.adapt_floor = !(c->screen_floor_height > 0) && !(getenv("RTFE_ADAPT_FLOOR") && atoi(getenv("RTFE_ADAPT_FLOOR")) == 0);
    screen_thresholds(d, hfloor);
    // k_peaks: a row whose margin reaches sure_i passes the rise test for every threshold the chains accept without asking
@@ -658,8 +666,8 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
       unsigned char *ovfp = reinterpret_cast<unsigned char *>(wsb + ws_pkovf_off(h, nrows));
       const int hard_cap = (int)pk_hard_cap(h, nrows);
       const long long ptiles = pk_tiles_for(nrows);
-      (void)hipMemsetAsync(scratch, 0, kScratchBytes, st);
-      (void)hipMemsetAsync(wsb + ws_pkextra_off(h, nrows), 0, pk_extra_bytes(h, nrows), st);
+      // the scratch block and the deferred candidates' counts cleared, and - a handle's first scan - the screen's floor estimated from the samples (k_scan_begin)
+      hipLaunchKernelGGL(k_scan_begin, dim3(h->num_cus * 4), dim3(256), 0, st, h->d_dev, scratch, reinterpret_cast<uint4 *>(wsb + ws_pkextra_off(h, nrows)), (long long)(pk_extra_bytes(h, nrows) / 16), d_rows, (long long)nrows);
       const int stop_after = getenv("RTFE_PEAK_STOP") ? atoi(getenv("RTFE_PEAK_STOP")) : 99;      // (debugging: launch only the first n kernels of the path)
       t0(kTSift);
       const sfs_kernel_t sfs = sf_special(h->dev);
@@ -917,6 +925,11 @@ extern "C" int rtfe_find_end_mark(rtfe_handle *h, const int16_t *d_rows, int64_t
    if (e != hipSuccess) return fail(-30, "rtfe_find_end_mark: %s", hipGetErrorString(e));
    return 0; }
 
+extern "C" int rtfe_reset_floor(rtfe_handle *h, void *stream) {
+   if (!h) return fail(-1, "null argument");
+   hipLaunchKernelGGL(k_reset_floor, dim3(1), dim3(1), 0, (hipStream_t)stream, h->d_dev);
+   return launch_check("rtfe_reset_floor"); }
+
 extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t *out) {
    if (!h || !d_workspace || !out) return fail(-1, "null argument");
    BurstScratch sc;
@@ -926,7 +939,8 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
    out[21] = (int64_t)sc.min_height_key;      // 0x7fffffff - float bits of the smallest learned v_avg_height, 0: none (the Python binding turns it back)
    {  float fl = 0;                                // the floor the handle's NEXT scan screens against (k_adapt_floor has moved it behind this one), as float bits
       if (hipMemcpy(&fl, &h->d_dev->floor_now, sizeof fl, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
-      uint32_t fb; memcpy(&fb, &fl, 4); out[22] = (int64_t)fb; }
+      uint32_t fb; memcpy(&fb, &fl, 4); out[22] = (int64_t)fb;
+      memcpy(&fb, &sc.floor_used, 4); out[23] = (int64_t)fb; }      // the floor this scan's screen was built for
    for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)((h->dev.debug == 4 || h->dev.debug == 6 || h->dev.debug == 8) ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
    return 0; }
 

@@ -92,6 +92,10 @@ struct DevCfg {
    // at the moment (the assumed lower bound of a learned peak height), floor_cfg = what the handle was made with, adapt_floor = 1: it may rise
    float floor_cfg, floor_now;
    int   adapt_floor;
+   // ... and is first ESTIMATED from the samples, at the head of a handle's first scan (k_scan_begin): floor_probed = 1 once an estimate or a learned height
+   // moved the floor; probe_min / probe_ticket: the probe's reduction over its workgroups (left as they were found: INT_MAX / 0)
+   int   floor_probed, probe_min, probe_on;      // (probe_on = 0: RTFE_FLOOR_PROBE=0, round 5's behaviour - tests, experiments)
+   unsigned probe_ticket;
    DevParm   parm[RTFE_MAXPARMSETS];
    DevScreen screen[kMaxScreens];
 };

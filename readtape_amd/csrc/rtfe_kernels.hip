@@ -44,7 +44,8 @@ struct BurstScratch {            // lives in the workspace (first kScratchBytes 
    int   hard_count;             // candidates k_sift deferred to k_sift_hard (cleared with the scratch block when rtfe_scan starts)
    int   min_height_key;         // 0x7fffffff - the bits of the smallest v_avg_height any chain of this scan LEARNED (0: none did): what a caller may
                                  // raise rtfe_config::screen_floor_height towards for the tape's next scans (rtfe_scan_stats)
-   int   pad[5];
+   float floor_used;             // the floor the scan's screen was built for (k_scan_begin: the handle's, or - its first scan - the estimate from the samples)
+   int   pad[4];
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
    unsigned long long pool_cursor;   // (unused)
    unsigned long long dbg2[8];   // dbg[8..15] (contiguous with dbg through pool_cursor is NOT assumed: indexed separately)
@@ -58,18 +59,21 @@ static_assert(sizeof(BurstScratch) <= kScratchBytes, "scratch region too small")
 __host__ __device__ inline void screen_thresholds(DevCfg &d, float hfloor) {
    const double lsb_per_volt = 32767.0 / (double)d.maxvolts;
    const float scale = (hfloor < 4.0f ? hfloor : 4.0f) / 4.0f / 2.0f;
-   for (int s = 0; s < d.nscreens; ++s) { d.screen[s].rise_i = 1 << 30; d.screen[s].minpk_i = 1 << 30; }
+   // (the new thresholds are made in locals and stored once: a kernel of another stream that reads the live configuration never sees a half-made
+   //  screen - ADVICE r5; a handle's scans are still to be serialised on one stream, include/rt_frontend.h)
+   int rise_i[kMaxScreens], minpk_i[kMaxScreens];
+   for (int s = 0; s < kMaxScreens; ++s) { rise_i[s] = 1 << 30; minpk_i[s] = 1 << 30; }
    for (int p = 0; p < d.nparm; ++p) {
       DevParm &dp = d.parm[p];
-      dp.screen_rise_v = dp.rise * scale;
-      dp.screen_minpk_v = dp.min_peak * scale;
-      int ri = (int)floor((double)dp.screen_rise_v * lsb_per_volt * (1.0 - 1e-5)) - 2;
-      const int mi = dp.min_peak > 0 ? (int)floor((double)dp.screen_minpk_v * lsb_per_volt * (1.0 - 1e-5)) - 2 : -1;
+      const float srv = dp.rise * scale, smv = dp.min_peak * scale;
+      int ri = (int)floor((double)srv * lsb_per_volt * (1.0 - 1e-5)) - 2;
+      const int mi = dp.min_peak > 0 ? (int)floor((double)smv * lsb_per_volt * (1.0 - 1e-5)) - 2 : -1;
       if (ri < -1) ri = -1;
-      DevScreen &S = d.screen[dp.screen];
-      if (ri < S.rise_i) S.rise_i = ri;
-      if (mi < S.minpk_i) S.minpk_i = mi; }
-   for (int s = 0; s < d.nscreens; ++s) if (d.screen[s].minpk_i < 0) d.screen[s].minpk_i = -1;
+      dp.screen_rise_v = srv;
+      dp.screen_minpk_v = smv;
+      if (ri < rise_i[dp.screen]) rise_i[dp.screen] = ri;
+      if (mi < minpk_i[dp.screen]) minpk_i[dp.screen] = mi; }
+   for (int s = 0; s < d.nscreens; ++s) { d.screen[s].rise_i = rise_i[s]; d.screen[s].minpk_i = minpk_i[s] < 0 ? -1 : minpk_i[s]; }
    d.floor_now = hfloor; }
 
 // Behind a scan of the peak path: the chains have learned how high this tape's peaks are (BurstScratch::min_height_key); the next scan of the handle
@@ -80,11 +84,86 @@ __global__ void k_adapt_floor(DevCfg *cfg, const BurstScratch *scratch) {
    if (threadIdx.x != 0 || blockIdx.x != 0 || !cfg->adapt_floor || cfg->differentiate || cfg->find_zeros) return;
    const int key = scratch->min_height_key;
    if (key <= 0) return;
+   cfg->floor_probed = 1;                                   // (what the chains learned stands from here on: no estimate from the samples replaces it)
    float want = 0.5f * __uint_as_float((unsigned)(0x7fffffff - key));
    if (want > 4.0f) want = 4.0f;
    if (want < cfg->floor_cfg) want = cfg->floor_cfg;
    if (want == cfg->floor_now) return;
    screen_thresholds(*cfg, want); }
+
+// rtfe_reset_floor: the handle's screen as rtfe_create left it (a new tape; bench.py's "first scan of a tape" lines)
+__global__ void k_reset_floor(DevCfg *cfg) {
+   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+   cfg->floor_probed = 0; cfg->probe_min = 0x7fffffff; cfg->probe_ticket = 0;
+   if (cfg->floor_now != cfg->floor_cfg) screen_thresholds(*cfg, cfg->floor_cfg); }
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_begin: the head of a peak-path scan, ONE launch for what used to be two memsets - the scratch block and the deferred candidates' per-list
+// counts cleared - and, while the handle's candidate screen still stands at the floor it was made with (a tape's FIRST scan), an estimate of how high
+// this tape's peaks are, from the samples themselves: the screen is then built for THAT before k_sift reads it.
+//
+// Why: the screen must pass every sample a chain could accept given v_avg_height >= floor (src/decoder.c:785-786, agc_gain <= 2).  At the 1 V every
+// tape clears it lets noise wiggles of a low-rise parameter set through by the million (the reference's default -m on a clean tape: 24 ms instead of 6;
+// a tape with 60 mV rms: 144 instead of 12).  Round 5 learned the floor BEHIND a scan (k_adapt_floor) - a tape's first scan paid the default.
+// The estimate: kProbeWindows windows of kProbeRows rows spread evenly over the tape; a window counts if it lies inside a block (every 64-row group
+// of it is outside the quiet band); per track of such a window the peak-to-peak range max - min, if the track shows both polarities; the smallest of
+// all of them.  v_avg_height is the mean of eleven top-to-bottom heights at a block's start (src/decode_nrzi.c:218-229), the range of 25 bit cells is
+// an upper bound of any single one: the floor is put at 0.45 x the estimate (k_adapt_floor behind the scan: 0.5 x the smallest height actually learned).
+// Exactness does not rest on any of this: a chain whose thresholds fall below the screen's flags RTFE_F_SCREEN_UNDERFLOW as before.
+// ------------------------------------------------------------------------------------------------
+constexpr int kProbeRows = 512, kProbeWindows = 4096;
+__global__ void __launch_bounds__(256) k_scan_begin(DevCfg *cfg, BurstScratch *scratch, uint4 *extra, long long extra_vecs, const int16_t *__restrict__ rows, long long nrows) {
+   __shared__ int s_mx[RTFE_MAXTRKS], s_mn[RTFE_MAXTRKS];
+   __shared__ unsigned int s_noisy;
+   const int tid = threadIdx.x;
+   for (long long v = (long long)blockIdx.x * 256 + tid; v < extra_vecs; v += (long long)gridDim.x * 256) extra[v] = make_uint4(0, 0, 0, 0);
+   if (blockIdx.x == 0) for (int i = tid; i < kScratchBytes / 4; i += 256) reinterpret_cast<int *>(scratch)[i] = 0;
+   // (the same answer in every workgroup of the launch: the flag is only written behind the last ticket)
+   const bool probe = cfg->adapt_floor && !cfg->floor_probed && cfg->probe_on && !cfg->differentiate && !cfg->find_zeros && nrows >= 4 * kChunkRows;
+   if (!probe) {
+      __syncthreads();
+      if (blockIdx.x == 0 && tid == 0) scratch->floor_used = cfg->floor_now;
+      return; }
+   const int ntrks = cfg->ntrks, q = cfg->quiet_i;
+   const long long nwin = nrows / kProbeRows < 1 ? 1 : (nrows / kProbeRows > kProbeWindows ? kProbeWindows : nrows / kProbeRows);
+   for (long long w = blockIdx.x; w < nwin; w += gridDim.x) {
+      const long long r0 = ((w * nrows) / nwin) & ~63ll;
+      const int len = (int)(nrows - r0 < kProbeRows ? nrows - r0 : kProbeRows);
+      if (tid < ntrks) { s_mx[tid] = -0x10000; s_mn[tid] = 0x10000; }
+      if (tid == 0) s_noisy = 0;
+      __syncthreads();
+      for (int i = tid; i < len; i += 256) {
+         const int16_t *row = rows + (r0 + i) * ntrks;
+         bool loud = false;
+         for (int t = 0; t < ntrks; ++t) {
+            const int x = row[t];
+            loud = loud || x > q || x < -q;
+            if (x > s_mx[t]) atomicMax(&s_mx[t], x);
+            if (x < s_mn[t]) atomicMin(&s_mn[t], x); }
+         if (loud) atomicOr(&s_noisy, 1u << (i >> 6)); }
+      __syncthreads();
+      if (tid == 0) {
+         const int ngroups = len >> 6;
+         const unsigned all = (1u << ngroups) - 1u;
+         if (ngroups >= 4 && (s_noisy & all) == all) {
+            int est = 0x7fffffff;
+            for (int t = 0; t < ntrks; ++t) if (s_mx[t] > q && s_mn[t] < -q && s_mx[t] - s_mn[t] < est) est = s_mx[t] - s_mn[t];
+            if (est != 0x7fffffff) atomicMin(&cfg->probe_min, est); } }
+      __syncthreads(); }
+   __syncthreads();                                                    // (workgroup 0: the scratch block is cleared before its ticket says so)
+   if (tid != 0) return;
+   __threadfence();
+   if (atomicAdd(&cfg->probe_ticket, 1u) != gridDim.x - 1) return;
+   __threadfence();
+   const int m = atomicMin(&cfg->probe_min, 0x7fffffff);              // (every workgroup's estimate is in)
+   cfg->probe_min = 0x7fffffff; cfg->probe_ticket = 0;
+   if (m != 0x7fffffff) {                                             // (else: no window inside a block - the next scan looks again)
+      cfg->floor_probed = 1;
+      float want = 0.45f * ((float)m / 32767.0f * cfg->maxvolts);
+      if (want > 4.0f) want = 4.0f;
+      if (want < cfg->floor_cfg) want = cfg->floor_cfg;
+      if (want != cfg->floor_now) screen_thresholds(*cfg, want); }
+   scratch->floor_used = cfg->floor_now; }
 
 __device__ __forceinline__ bool quiet_at(const u64 *q, long long c, long long nchunks) {
    return c >= 0 && c < nchunks && ((q[c >> 6] >> (c & 63)) & 1); }

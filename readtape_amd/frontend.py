@@ -245,7 +245,8 @@ def _load_library(path=None):
     lib.rtfe_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rtfe_set_graphs.argtypes = [C.c_void_p, C.c_int]
     lib.rtfe_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-    if lib.rtfe_abi_version() != 5:
+    lib.rtfe_reset_floor.argtypes = [C.c_void_p, C.c_void_p]
+    if lib.rtfe_abi_version() != 6:
         raise RuntimeError("librtfe.so ABI mismatch")
     return lib
 
@@ -382,6 +383,12 @@ class FrontEnd:
         if self.lib.rtfe_set_graphs(self.h, int(enable)) != 0:
             raise RuntimeError(self.lib.rtfe_last_error().decode())
 
+    def reset_floor(self, stream=None):
+        """rtfe_reset_floor: the candidate screen back to what the handle was made with - the next scan is a tape's first scan again (it estimates the floor
+        from the samples before it screens)."""
+        if self.lib.rtfe_reset_floor(self.h, C.c_void_p(stream) if stream else None) != 0:
+            raise RuntimeError(self.lib.rtfe_last_error().decode())
+
     def kernel_ms(self):
         """Per-span elapsed ms (HIP events on the scans' stream) summed over the scans since the last call - at most 64 - and how many
         scans that was: ({span: ms}, scans).  Synchronises those scans."""
@@ -400,7 +407,8 @@ class FrontEnd:
         key = int(out[21])
         min_height = float(np.array([0x7fffffff - key], dtype=np.uint32).view(np.float32)[0]) if key > 0 else None      # smallest v_avg_height a chain of the scan learned (peak path)
         return dict(bursts=int(out[0]), redone=int(out[1]), record_bytes=int(out[2]), parallel=int(out[3]), sequential=int(out[4]), gave_up=[int(out[5 + i]) for i in range(8)], phase_cycles=[int(out[13 + i]) for i in range(8)],
-                    min_learned_height=min_height, screen_floor_now=float(np.array([int(out[22])], dtype=np.uint32).view(np.float32)[0]))
+                    min_learned_height=min_height, screen_floor_now=float(np.array([int(out[22])], dtype=np.uint32).view(np.float32)[0]),
+                    screen_floor_used=float(np.array([int(out[23])], dtype=np.uint32).view(np.float32)[0]))
 
     def _buffers(self, nrows, key="scan"):
         """Allocates (once per size) the workspace and output buffers for a scan of nrows rows.  Exact rescans share ONE

@@ -225,7 +225,7 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
         frag = f"{tap_path}.frag{k}{tag}"
         if start is None:
             start = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
-        st = pipeline.decode_fragment(hdr, cfg, fe_exact, res, piece, lo, start, bound, frag, full, opts, exact_lock=exact_lock if pool else None)
+        st = pipeline.decode_fragment(hdr, cfg, fe_exact, res, piece, lo, start, bound, frag, full, opts, exact_lock=exact_lock)      # (always: the fetcher threads replay side by side on ONE exact-rescan handle - ADVICE r5)
         with open(frag, "rb") as g:
             data = g.read()
         os.remove(frag)
@@ -295,7 +295,9 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                             return []
                         piece = piece[: end_k - lo]
                         with torch.cuda.stream(fetch_streams[k % nctx]):
-                            res, nb, bound = pipeline.scan_fragment(res.fe, piece, hi - lo, lo, lo == 0, True)()
+                            # (a marker inside this window's HALO leaves the window its own rows [lo, hi) only: it keeps its bounding burst, and the
+                            #  window behind it decodes [hi, data_end) - ADVICE r5: is_last = True there decoded that range twice)
+                            res, nb, bound = pipeline.scan_fragment(res.fe, piece, hi - lo, lo, lo == 0, hi >= data_end[0])()
                 finally:
                     marks_seen[k].set()
             if trace is not None and getattr(res, "fetch_times", None):

@@ -96,6 +96,7 @@ extern unsigned long long g_wave_scratch[16][64];
 }  // namespace hipemu
 
 inline long long clock64() { return 0; }
+inline void __threadfence() {}
 inline void __syncthreads() { hipemu::g_block_barrier.wait(); }
 inline unsigned long long __ballot(int pred) {
    const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;

@@ -29,7 +29,7 @@ def test_frontend_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(os.path.join(ROOT, "readtape_amd", "librtfe.so"))
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.rtfe_abi_version() == 5
+    assert lib.rtfe_abi_version() == 6
     assert lib.rtfe_kernel_count() == 12
 
 

@@ -81,6 +81,48 @@ def test_emulated_screen_floor_follows_the_tape(tmp_path):
         assert fixed.scan_stats(fixed.scan(rows).fetch())["screen_floor_now"] == 1.25
 
 
+def test_emulated_first_scan_estimates_the_screen_floor_from_the_samples(tmp_path, monkeypatch):
+    """k_scan_begin: a handle's FIRST scan of the peak path looks at the samples before it screens them - windows inside blocks, the smallest peak-to-peak
+    range of a track - and builds its candidate screen for 0.45 x that instead of the 1 V every tape clears (round 5 learned the floor behind a scan: a tape's
+    first scan paid the default).  The events are the oracle's whatever the estimate; rtfe_reset_floor makes the next scan a first scan again;
+    RTFE_FLOOR_PROBE=0 is round 5's behaviour; a floor the caller gave stands."""
+    import dataclasses
+    from readtape_amd import synth
+    loud = synth.nrzi_tape(seed=321, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, amplitude=3.2)
+    weak = synth.nrzi_tape(seed=322, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, amplitude=0.9)
+    noisy = synth.nrzi_tape(seed=323, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, noise_mv=60.0)
+    hdr = loud.spec.header()
+    opts = ["-m"]
+    cfg = config_for(hdr, opts)
+    for tape, lo, hi in ((loud, 1.8, 4.0), (weak, 1.0, 1.0), (noisy, 1.2, 4.0)):
+        att = oracle_attempts(hdr, tape.rows, opts, str(tmp_path))
+        fe = emul_frontend(cfg)                                        # a fresh handle
+        res = fe.scan(tape.rows).fetch()
+        st = fe.scan_stats(res)
+        print(st["screen_floor_used"], st["screen_floor_now"], st["min_learned_height"], st["redone"], st["bursts"])
+        assert lo <= st["screen_floor_used"] <= hi, st
+        # the estimate stays below what the chains then learn (else they would flag an underflow and be redone on the samples)
+        assert st["min_learned_height"] is None or st["screen_floor_used"] <= 0.5 * st["min_learned_height"] * 1.2 or st["screen_floor_used"] == 1.0, st
+        assert not (res.bursts["flags"] & frontend.F_SCREEN_UNDERFLOW).any()
+        msgs, stats = check_tape(fe, hdr, tape.rows, att)
+        assert not msgs, "\n".join(msgs[:12])
+        assert stats["events"] > 0
+    # the second scan uses what the first one's chains learned, a reset makes the next one a first scan again
+    fe = emul_frontend(cfg)
+    a = fe.scan_stats(fe.scan(loud.rows).fetch())
+    b = fe.scan_stats(fe.scan(loud.rows).fetch())
+    assert b["screen_floor_used"] == a["screen_floor_now"]
+    fe.reset_floor()
+    c = fe.scan_stats(fe.scan(loud.rows).fetch())
+    assert c["screen_floor_used"] == a["screen_floor_used"] and c["screen_floor_now"] == a["screen_floor_now"]
+    monkeypatch.setenv("RTFE_FLOOR_PROBE", "0")
+    old = emul_frontend(cfg)
+    assert old.scan_stats(old.scan(loud.rows).fetch())["screen_floor_used"] == 1.0
+    monkeypatch.delenv("RTFE_FLOOR_PROBE")
+    fixed = emul_frontend(dataclasses.replace(cfg, screen_floor_height=1.25))
+    assert fixed.scan_stats(fixed.scan(loud.rows).fetch())["screen_floor_used"] == 1.25
+
+
 @pytest.mark.parametrize("parallel", ["1", "0"])
 @pytest.mark.parametrize("name", PEAK_CASES)
 def test_emulated_peak_record_path_matches_oracle(name, parallel, tmp_path, monkeypatch):

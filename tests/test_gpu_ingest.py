@@ -51,6 +51,29 @@ def test_end_marker_inside_the_payload_ends_the_tape(tmp_path):
     assert open(tmp_path / "s.tap", "rb").read() == want
 
 
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("behind", [700, 2000, 4090])
+def test_end_marker_inside_a_windows_halo(behind, threads, tmp_path):
+    """a marker `behind` rows behind a window boundary lies in the halo of the window in front of it.  That window keeps its own rows only
+    (its bounding burst, its stop row); the window behind it decodes what is left in front of the marker - no block twice, none missing."""
+    tape = synth.nrzi_tape(seed=77, nblocks=40, minlen=200, maxlen=900, marks_every=9, gap_samples=1500)
+    hdr = tape.spec.header()
+    win, halo = 1 << 15, 1 << 12
+    assert tape.rows.shape[0] > 4 * win
+    for k in (2, 3):
+        cut = k * win + behind
+        want = _whole(hdr, tape.rows[:cut], str(tmp_path / "whole.tap"))
+        rows = tape.rows.copy()
+        rows[cut, 0] = tbin.END_MARK
+        path = str(tmp_path / "t.tbin")
+        with open(path, "wb") as f:
+            f.write(tbin.pack_header(hdr))
+            f.write(rows.tobytes())
+        st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=win, halo_rows=halo, replay_threads=threads, replay_split=2 if threads > 1 else 1)
+        assert st["rows"] == cut
+        assert open(tmp_path / "s.tap", "rb").read() == want
+
+
 @pytest.mark.parametrize("threads", [1, 6])
 def test_windows_read_in_parallel_pieces_with_an_end_marker_in_one_of_them(threads, tmp_path):
     """Windows of 9.4 MB are read as four pieces side by side, each piece looks for the end marker in its own rows; two scans are in
