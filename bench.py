@@ -56,18 +56,25 @@ CONFIGS = {
                workload="G1 (extra): synthetic 9-track 6250 BPI GCR (9042 fci), 6.25 MHz, 1 parmset, peak detection, one scan"),
     "P1": dict(kind="pe", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[],
                workload="P1 (extra): synthetic 9-track 1600 BPI PE, 1.5625 MHz, 1 parmset, peak detection (not -zeros), one scan"),
-    # The handle's candidate screen follows the tape (k_adapt_floor: behind each scan the floor moves to half the smallest peak height the scan's chains
-    # learned; the warm-up scans are the tape's first windows).  The ...f lines pin the floor at the 1 V a handle starts from: what the FIRST scan of a tape costs.
+    # The handle's candidate screen follows the tape: a handle's FIRST scan estimates the floor from the samples before it screens them (k_scan_begin), and behind
+    # each scan the floor moves to half the smallest peak height the scan's chains learned (k_adapt_floor).  The ...f lines time a tape's FIRST scan: every step
+    # resets the handle's screen to what rtfe_create made (rtfe_reset_floor, inside the timed region) and scans - what INTEGRATION.md's one rtfe_scan per tape costs.
+    "C2f": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], overlap=True, fresh=True,
+                workload="C2f (extra): C2, every step a tape's FIRST scan (rtfe_reset_floor + rtfe_scan: the screen floor estimated from the samples inside the scan)"),
     "M8": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, overlap=True, ref_opts=[], port_opts=["-m"],
                workload="M8 (extra): C2's tape under the reference's default -m: the 8 built-in NRZI parameter sets (three window widths) in one scan; default configuration (the screen floor follows the tape)"),
-    "M8f": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, overlap=True, ref_opts=[], port_opts=["-m"], fixed_floor=1.0,
-                workload="M8f (extra): M8 with the candidate screen pinned at the 1 V floor a handle starts from (a tape's first scan): the four 0.05 V-rise sets' screens pass every wiggle"),
+    "M8f": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, overlap=True, ref_opts=[], port_opts=["-m"], fresh=True,
+                workload="M8f (extra): M8, every step a tape's FIRST scan (rtfe_reset_floor + rtfe_scan)"),
+    "M8p": dict(kind="nrzi", rows=1e8, nparmsets=8, find_zeros=False, window_rows=None, overlap=True, ref_opts=[], port_opts=["-m"], fixed_floor=1.0,
+                workload="M8p (extra): M8 with the candidate screen pinned at 1 V (round 5's first scan: the four 0.05 V-rise sets' screens pass every wiggle)"),
     # the same tapes with noise (every other line is 10 mV rms): what the speculation costs when the signal is not clean -
     # flagged bursts, bursts redone on the samples and what the chains left to the literal detector are on the line
     "N1": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, overlap=True, ref_opts=["-nm"], port_opts=[], noise_mv=60.0,
                workload="N1 (extra): C2's tape with 60 mV rms of noise on 2-3 V peaks (C2: 10 mV), 1 parmset; default configuration (the screen floor follows the tape)"),
-    "N1f": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=60.0, fixed_floor=1.0,
-                workload="N1f (extra): N1 with the candidate screen pinned at the 1 V floor a handle starts from (a tape's first scan): the lists outgrow their slots, the bursts are redone on the samples"),
+    "N1f": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=60.0, fresh=True,
+                workload="N1f (extra): N1, every step a tape's FIRST scan (rtfe_reset_floor + rtfe_scan)"),
+    "N1p": dict(kind="nrzi", rows=1e8, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=60.0, fixed_floor=1.0,
+                workload="N1p (extra): N1 with the candidate screen pinned at 1 V (round 5's first scan: the lists outgrow their slots, the bursts are redone on the samples)"),
     "N2": dict(kind="gcr", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], noise_mv=30.0,
                workload="N2 (extra): G1's tape with 30 mV rms of noise on 1.8 V peaks (G1: 10 mV), 1 parmset, one scan"),
     "C5": dict(kind="nrzi", rows=10e9 / 18, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[], strong=True, no_events=True,
@@ -262,6 +269,8 @@ class Workload:
             # the seam halo is the only exchange: neighbour isend/irecv over RCCL (xGMI), no collective on the data path
             self.shard.exchange_halo(self.sr, self.halo_rows, self.rank, self.world, self.dist, lens=self.lens)
             res = None
+            if self.conf.get("fresh") and self.cuda:      # a tape's first scan: the handle's screen as rtfe_create left it
+                f.reset_floor(s.cuda_stream)
             for a, b in self.frags:
                 res = self.scan_frag(f, s, a, b)
                 if each is not None:
@@ -463,7 +472,7 @@ def main():
     # ---- the other BASELINE.json configurations, measured in this process (compact: value, ms per step, dominant kernel, fractions) ----
     if default_line and not args.no_other_configs:
         others = {}
-        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("M8", 5, 2), ("M8f", 3, 1), ("N1", 10, 2), ("N1f", 2, 1), ("N2", 2, 1)):
+        for name, st, wu in (("C3", 8, 2), ("C4", 1, 1), ("C5", 10, 2), ("G1", 2, 1), ("P1", 2, 1), ("C2f", 10, 2), ("M8", 5, 2), ("M8f", 5, 2), ("N1", 10, 2), ("N1f", 5, 2), ("N2", 2, 1)):
             try:
                 f2, w2 = measure(name, args, rank, world, dev, dist, st, wu, args.min_seconds)
                 others[name] = {"workload": f2["config"]["workload"], "value": f2["value"], "unit": "Msamples/s", "ms_per_step": f2["ms_per_step"], "ms_per_step_serial": f2["ms_per_step_serial"], "overlap": f2["overlap"][:40], "graphs": bool(f2["graphs"]), "kernel_events_in_timed_region": f2["kernel_events_in_timed_region"], "timed_steps": f2["timed_steps"],
@@ -471,7 +480,7 @@ def main():
                                 "launches_per_step": f2["config"]["launches_per_step"], "dominant_kernel": f2["roofline"]["kernel"], "dominant_kernel_ms": f2["kernel_ms"][f2["roofline"]["kernel"]],
                                 "frac": f2["roofline"]["frac"], "frac_rows_only": f2["roofline"]["frac_rows_only"], "whole_step_frac": f2["roofline"]["whole_step"]["frac"],
                                 "traffic": f2["roofline"]["traffic"], "traffic_all_kernels": f2["roofline"]["traffic_all_kernels"], "kernel_ms": {k: v for k, v in f2["kernel_ms"].items() if v > 0.02},
-                                "last_scan_stats": {k: f2["config"]["last_scan_stats"].get(k) for k in ("bursts", "redone", "parallel", "sequential", "gave_up", "min_learned_height", "screen_floor_now")} if f2["config"]["last_scan_stats"] else None,
+                                "last_scan_stats": {k: f2["config"]["last_scan_stats"].get(k) for k in ("bursts", "redone", "parallel", "sequential", "gave_up", "min_learned_height", "screen_floor_now", "screen_floor_used")} if f2["config"]["last_scan_stats"] else None,
                                 "screen_floor_height": f2["config"]["screen_floor_height"]}
                 release(w2)
                 del w2

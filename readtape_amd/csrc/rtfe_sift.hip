@@ -369,22 +369,33 @@ __device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool b
    const int rb_ = c.t.row_bytes;
    const uint32_t m2 = (bot != (c.t.sg < 0)) ? 0xffffffffu : 0u;
    lds_cp pr = c.t.xs + head * 2 + (p + c.t.hl) * rb_, pl = pr - (W - 1) * rb_;
-   uint32_t LR[W - 1];                                                 // low half: x[p + k - W + 1], high half: x[p + k]   (as y)
+   // (round 6: rows k and k + H share a register - the left edges of the two in one, the right edges in another - where rounds 3 - 5 paired a row's own two edges:
+   //  the margin is then a plain packed minimum of the two differences (no half swap), the four tests gather each its own mask, and a mask's two halves
+   //  are the rows 0 .. H - 1 and H .. 2 H - 1 one behind the other: 7 instead of 9 vector instructions a row)
+   constexpr int H = W / 2;                                            // = ceil((W - 1) / 2) rows a half
+   uint32_t L2[H], R2[H];                                              // x[p + k - W + 1] / x[p + k] for k = j (low half) and k = j + H (high half)   (as y)
    #pragma unroll
-   for (int k = 0; k < W - 1; ++k) LR[k] = ((uint32_t)(uint16_t)lds_i16(pl + k * rb_) | ((uint32_t)(uint16_t)lds_i16(pr + k * rb_) << 16)) ^ m2;
-   const uint32_t vv = (LR[0] >> 16) | (LR[0] & 0xffff0000u);          // the extreme in both halves
-   const uint32_t c10 = 1u, thr = (uint32_t)(uint16_t)(c.lo_i + 1) | ((uint32_t)(uint16_t)c.hi_i << 16);
-   uint32_t a1 = 0, a2 = 0;
+   for (int j = 0; j < H; ++j) {
+      const int k2 = j + H < W - 1 ? j + H : W - 2;                    // (an even W has one row less than its halves hold: the last is there twice, its bit W - 1 is masked off)
+      L2[j] = ((uint32_t)(uint16_t)lds_i16(pl + j * rb_) | ((uint32_t)(uint16_t)lds_i16(pl + k2 * rb_) << 16)) ^ m2;
+      R2[j] = ((uint32_t)(uint16_t)lds_i16(pr + j * rb_) | ((uint32_t)(uint16_t)lds_i16(pr + k2 * rb_) << 16)) ^ m2; }
+   const uint32_t vv = (R2[0] & 0xffffu) | (R2[0] << 16);              // the extreme in both halves
+   const uint32_t ones = 0x00010001u, thrlo = pk_dup(c.lo_i + 1), thrhi = pk_dup(c.hi_i);
+   uint32_t aL = 0, aR = 0, aLo = 0, aHi = 0, dl_prev = 0, dr_next = 0;
    #pragma unroll
-   for (int k = 0; k < W - 1; ++k) {
-      const uint32_t d = pk_subs(vv, LR[k]);                           // (extreme - left edge, extreme - right edge)
-      a1 = (a1 >> 1) | (pk_subs(d, c10) & kPkSigns);                   // sign: left edge not strictly below / right edge above the extreme
-      const uint32_t mn = pk_min(d, (d >> 16) | (d << 16));            // the margin of row k, in both halves
-      a2 = (a2 >> 1) | (pk_subs(mn, thr) & kPkSigns); }                // sign: margin not above the screen / below the sure level
-   constexpr int SH = 17 - W;                                          // bit k of a half sits at 17 - W + k
+   for (int j = 0; j < H; ++j) {
+      const uint32_t dl = pk_subs(vv, L2[j]), dr = pk_subs(vv, R2[j]);  // extreme - left edge, extreme - right edge
+      aL = (aL >> 1) | (pk_subs(dl, ones) & kPkSigns);                 // sign: left edge not strictly below the extreme
+      aR = (aR >> 1) | (dr & kPkSigns);                                // sign: right edge above it
+      const uint32_t mn = pk_min(dl, dr);                              // the rows' margins
+      aLo = (aLo >> 1) | (pk_subs(mn, thrlo) & kPkSigns);              // sign: margin not above the screen
+      aHi = (aHi >> 1) | (pk_subs(mn, thrhi) & kPkSigns);              // sign: margin below the sure level
+      if (j == W - 2 - H) dl_prev = dl;                                // (row W - 2's left edge is x[p - 1], row 1's right edge x[p + 1]: the extreme's neighbours)
+      if (j == 1) dr_next = dr; }
    constexpr uint32_t ALL = (1u << (W - 1)) - 1u;
-   const uint32_t lm = ~((a1 & 0xffffu) >> SH) & ALL, rm = ~(a1 >> (16 + SH)) & ALL & ~1u;
-   const uint32_t lom = ~((a2 & 0xffffu) >> SH) & ALL, him = ~(a2 >> (16 + SH)) & ALL;
+   auto gather = [](const uint32_t a2) -> uint32_t { return ((a2 & 0xffffu) >> (16 - H)) | ((a2 >> (32 - H)) << H); };      // bit j of a half sits at 16 - H + j
+   const uint32_t lm = ~gather(aL) & ALL, rm = ~gather(aR) & ALL & ~1u;
+   const uint32_t lom = ~gather(aLo) & ALL, him = ~gather(aHi) & ALL;
    // J: consecutive left samples below the extreme, from distance 1 (k = W-2) outwards (tops: up to W-2, bottoms: W-1, i.e. k = 0 too)
    const uint32_t lsh = lm << (31 - (W - 2));                          // top bit = k = W-2
    int J = pk_clz((uint32_t)~lsh);
@@ -410,8 +421,7 @@ __device__ __forceinline__ int pk_fast_w(const PkCtx &c, int head, int p, bool b
    const int raw = lds_i16(pr);
    const int val = c.t.sg < 0 ? -raw : raw;                            // the sample as the detector sees it
    int dp, dn;                                                         // the extreme's distance to its two neighbours
-   {  const uint32_t dl = pk_subs(vv, LR[W - 2]), dr = pk_subs(vv, LR[1]);
-      dp = (int)(int16_t)(dl & 0xffffu); dn = (int)(int16_t)(dr >> 16); }
+   dp = (int)(int16_t)(dl_prev >> 16); dn = (int)(int16_t)(dr_next & 0xffffu);
    dp = dp < -1 ? -1 : (dp > 253 ? 253 : dp); dn = dn < -1 ? -1 : (dn > 253 ? 253 : dn);      // (253: a bottom at -32768 between far neighbours must not read as 0xffff8000, "minimum unknown")
    w1 = (uint32_t)(uint16_t)val | ((uint32_t)(dp + 1) << 16) | ((uint32_t)(dn + 1) << 24);
    const int f = pk_ctz(C), l = 31 - pk_clz(C);
@@ -466,6 +476,25 @@ __device__ __forceinline__ int wave_last(int v) {
    return __builtin_amdgcn_readlane(v, 63);
 #endif
 }
+
+// a pointer that is the same in every lane, kept in scalar registers as it is: an address made of it and a lane's 32-bit offset is the
+// global_load ... v_off, s[base] form - the compiler would otherwise fold a constant part of the base into a 64-bit vector addition per access
+// (the pointer keeps its address space - global, 1 - through the empty asm: a generic one would make every access a FLAT instruction)
+#ifdef RTFE_CPU_EMUL
+typedef const char *glb_cp;
+typedef char *glb_p;
+__device__ __forceinline__ glb_cp sgpr_ptr(glb_cp p) { return p; }
+__device__ __forceinline__ glb_p sgpr_ptr(glb_p p) { return p; }
+__device__ __forceinline__ int4 glb_ld16(glb_cp p) { int4 v; memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void glb_st16(glb_p p, const int4 v) { memcpy(p, &v, 16); }
+#else
+typedef const __attribute__((address_space(1))) char *glb_cp;
+typedef __attribute__((address_space(1))) char *glb_p;
+__device__ __forceinline__ glb_cp sgpr_ptr(glb_cp p) { asm volatile("" : "+s"(p)); return p; }
+__device__ __forceinline__ glb_p sgpr_ptr(glb_p p) { asm volatile("" : "+s"(p)); return p; }
+__device__ __forceinline__ int4 glb_ld16(glb_cp p) { return *reinterpret_cast<const __attribute__((address_space(1))) int4 *>(p); }
+__device__ __forceinline__ void glb_st16(glb_p p, const int4 v) { *reinterpret_cast<__attribute__((address_space(1))) int4 *>(p) = v; }
+#endif
 
 #ifdef RTFE_CPU_EMUL
 typedef uint16_t *lds_u16p;
@@ -738,8 +767,8 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    constexpr bool SPL = sfs_split(NT);
    constexpr int NP = sfs_waves(NT), NTH = 64 * NP, RB = 2 * NT;
    constexpr int HL = sfs_hl(W), HR = sfs_hr(W);
-   constexpr int NVEC = (HL + kSfTile + HR) * NT / 8, VPG = 8 * NT, VOWN0 = HL * NT / 8, NQ = kSfGroups * VPG;
-   constexpr int NV = (NVEC + NTH - 1) / NTH, NQIT = (NQ + NTH - 1) / NTH;
+   constexpr int NVEC = (HL + kSfTile + HR) * NT / 8, VPG = 8 * NT, VOWN0 = HL * NT / 8;
+   constexpr int NV = (NVEC + NTH - 1) / NTH;
    constexpr int H3 = NT - 1, R3 = sfs_part_strip(NT), PR3 = sfs_part_rows(NT), LA3 = PR3 / R3;      // split: the last head, rows a lane / a wave screens of it, lanes at work
    const int tid = threadIdx.x, lane = tid & 63;
 #ifdef RTFE_CPU_EMUL
@@ -763,10 +792,6 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    const int inside_lo = (HL + kSfTile - 1) / kSfTile;
    const long long ih = (a.nrows - HR - 15) / kSfTile - 1;
    const int inside_hi = ih > 0x7ffffff0 ? 0x7ffffff0 : (int)ih;
-   // the quiet pass: which group(s) of 64 rows the 64 vectors of this wave's round `it` lie in (wave-uniform)
-   int qg[NQIT], qsplit[NQIT];
-   #pragma unroll
-   for (int it = 0; it < NQIT; ++it) { const int vfirst = it * NTH + wave * 64; qg[it] = vfirst / VPG; qsplit[it] = (qg[it] + 1) * VPG - vfirst; }
    const int pair = wave, h_lo = 2 * pair, h_hi = 2 * pair + 1;
    const bool has_hi = h_hi < NT;
    const lds_u16p wlist = reinterpret_cast<lds_u16p>(to_lds(smem + L.wl)) + wave * wave_cap;
@@ -777,11 +802,16 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    int4 q[NV];
    #pragma unroll
    for (int k = 0; k < NV; ++k) q[k] = make_int4(0, 0, 0, 0);
-   auto fetch = [&](int tile, int tidx) {
-      const int4 *src = reinterpret_cast<const int4 *>(a.rows + ((long long)tile * kSfTile - HL) * NT);
+   // (round 6: every round of the copy but the last is whole - no test, no branch; a round's address is a scalar base - the tile's, moved by the round's 4 KB
+   //  on the scalar unit - and the lane's 32-bit offset, made once: no vector instruction per load)
+   const unsigned voff = (unsigned)tid * 16u;
+   auto fetch = [&](int tile, int tidx, unsigned voff) {
+      const glb_cp src = (glb_cp)(a.rows + ((long long)tile * kSfTile - HL) * NT);
       #pragma unroll
-      for (int k = 0; k < NV; ++k) if (k * NTH + tidx < NVEC) q[k] = src[k * NTH + tid]; };
-   if (tile_lo < ntiles && tile_lo >= inside_lo && tile_lo <= inside_hi) fetch(tile_lo, tid);
+      for (int k = 0; k < NV; ++k) {
+         const glb_cp sk = sgpr_ptr(src + (size_t)k * NTH * 16);
+         if ((k + 1) * NTH <= NVEC || k * NTH + tidx < NVEC) q[k] = glb_ld16(sk + voff); } };
+   if (tile_lo < ntiles && tile_lo >= inside_lo && tile_lo <= inside_hi) fetch(tile_lo, tid, voff);
    if (tid < 2) s_noisy[tid] = 0;
    int par = 0, last_tile = -1;
    unsigned int pn_hard = 0, pn_rounds = 0, pn_bytes = 0;
@@ -798,10 +828,11 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          const int nr = hh ? rec_hi : rec_lo;
          const bool over = bad || 16 * nr > hcap;
          const size_t li = ((size_t)tile * a.nscreens + a.sc) * NT + h;      // the list's place: [tile][screen][head]
-         unsigned char *gslot = a.pool + li * (size_t)hcap;
+         const glb_p gslot = sgpr_ptr((glb_p)(a.pool + li * (size_t)hcap));      // (a scalar base and the lane's 32-bit offset: no 64-bit vector arithmetic per store)
          if (!over && nr > 0 && cut != 6) {
             const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
-            for (int v = lane; v < nr; v += 64) reinterpret_cast<int4 *>(gslot)[v] = src[v];      // (a 16-byte vector a record)
+            #pragma nounroll
+            for (int v0 = 0; v0 < nr; v0 += 64) if (v0 + lane < nr) glb_st16(gslot + (unsigned)(v0 + lane) * 16u, src[v0 + lane]);      // (a 16-byte vector a record)
             if (dbg3) pn_bytes += (unsigned)(16 * nr); }
          if (lane == 0) {
             PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
@@ -821,12 +852,17 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          over = over || c == 0xffff;
          tot += c; if (w2 < wave) off += c; }
       over = over || 16 * tot > hcap;
+#ifdef RTFE_CPU_EMUL
       const int mine = s_part[pp][wave];
+#else
+      const int mine = __builtin_amdgcn_readfirstlane((int)s_part[pp][wave]);
+#endif
       const size_t li = ((size_t)tile * a.nscreens + a.sc) * NT + H3;
-      unsigned char *gslot = a.pool + li * (size_t)hcap;
+      const glb_p gslot = sgpr_ptr((glb_p)(a.pool + li * (size_t)hcap + (size_t)off * 16));
       if (!over && cut != 6) {
          const int4 *src = reinterpret_cast<const int4 *>(smem + L.part + wave * cap3);
-         for (int v = lane; v < mine; v += 64) reinterpret_cast<int4 *>(gslot)[off + v] = src[v]; }
+         #pragma nounroll
+         for (int v0 = 0; v0 < mine; v0 += 64) if (v0 + lane < mine) glb_st16(gslot + (unsigned)(v0 + lane) * 16u, src[v0 + lane]); }
       if (wave == 0 && lane == 0) {
          PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)tot; d.nent = 0;
          a.dir[li] = d; } };
@@ -835,8 +871,9 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       //  it has, so it parks them in a vector register's lanes and fetches each back with two v_readlane where one v_cmp would do.  An index it cannot see
       //  through keeps the comparisons where they are used.)
       int tidl = tid, lanel = lane;
+      unsigned voffl = voff;      // (... and the 32-bit offset stays one: hoisted as a 64-bit value it costs a 64-bit vector addition per load)
 #ifndef RTFE_CPU_EMUL
-      asm volatile("" : "+v"(tidl), "+v"(lanel));
+      asm volatile("" : "+v"(tidl), "+v"(lanel), "+v"(voffl));
 #endif
       const int prev_tile = last_tile;
       last_tile = tile;
@@ -845,28 +882,37 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       // ---- 1. the prefetched bytes -> LDS; the next tile's loads go out at once and travel while this tile is worked on ----
       if (tile >= inside_lo && tile <= inside_hi) {
          #pragma unroll
-         for (int k = 0; k < NV; ++k) if (k * NTH + tidl < NVEC) reinterpret_cast<int4 *>(xs)[k * NTH + tid] = q[k]; }
+         for (int k = 0; k < NV; ++k) if ((k + 1) * NTH <= NVEC || k * NTH + tidl < NVEC) reinterpret_cast<int4 *>(xs)[k * NTH + tid] = q[k]; }
       else sf_fill_edge(xsl, a.rows, ((long long)tile * kSfTile - HL) * NT, a.nrows * NT, NVEC * 8, tid, NTH);
       __syncthreads();
-      if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G, tidl);
+      if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G, tidl, voffl);
       if (tid == 0 && tile > tile_lo && a.qtile) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
       if (p_tile >= 0) { copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad); p_tile = -1; rtfe_wave_sync(); }      // (the lists of the tile in front: a.defer)
       if (SPL && prev_tile >= 0 && cut != 1) { copy_out3(prev_tile, par ^ 1); rtfe_wave_sync(); }
       // ---- 2. quiet groups: flat 16-byte reads of the tile proper; a ballot of 64 vectors lies in one or two groups (several screens: the first launch's business) ----
-      if (a.qtile)
-      #pragma unroll
-      for (int it = 0; it < NQIT; ++it) {
-         bool noisy = false;
-         if (it * NTH + tidl < NQ) {
-            const int4 v = reinterpret_cast<const int4 *>(xs)[VOWN0 + it * NTH + tid];
+      // (round 6: a group is quiet only if EVERY sample of it is, and inside a block every part of a group carries signal - as k_quiet does, a group's first
+      //  128 bytes are looked at first, eight lanes a group, and the rest of it - one more round of the wave - only where those are quiet: the gaps.  A wave
+      //  takes three or four of the tile's fourteen groups.  The same bits; a tile inside a block costs one round of the old four.)
+      if (a.qtile) {
+         static_assert(VPG - 8 <= 64 && (kSfGroups + NP - 1) / NP + 1 <= 8, "a group's rest is one round of a wave; a wave's groups' first lines, eight lanes each, too");
+         const int g0 = wave * kSfGroups / NP, ng = (wave + 1) * kSfGroups / NP - g0;      // (3 4 3 4 of the fourteen groups for four waves, 4 5 5 for three)
+         const int4 *tv = reinterpret_cast<const int4 *>(xs) + VOWN0;
+         const uint32_t q2pk = pk_dup((int)q2);
+         auto noisy4 = [&](const int4 v) -> bool {
             const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)v.x, qpk), pk_addu((uint32_t)v.y, qpk)),
                                        pk_maxu(pk_addu((uint32_t)v.z, qpk), pk_addu((uint32_t)v.w, qpk)));
-            noisy = (m & 0xffffu) > q2 || (m >> 16) > q2; }
-         const bool upper = lanel >= qsplit[it];                                  // the wave's 64 vectors lie in group qg[it] (lanes below qsplit[it]) and the next one
-         const u64 nb_lo = __ballot(noisy && !upper), nb_hi = __ballot(noisy && upper);
-         if (nb_lo | nb_hi) {
-            const unsigned int bits = (nb_lo ? 1u << qg[it] : 0u) | (nb_hi ? 2u << qg[it] : 0u);
-            if (lane == 0) atomicOr(&s_noisy[par], bits); } }
+            return pk_maxu(m, q2pk) != q2pk; };
+         bool n1 = false;
+         if (lanel < 8 * ng) n1 = noisy4(tv[(g0 + (lanel >> 3)) * VPG + (lanel & 7)]);
+         const u64 nb = __ballot(n1);
+         unsigned int bits = 0;
+         #pragma nounroll
+         for (int b = 0; b < ng; ++b) {
+            if ((nb >> (8 * b)) & 0xffull) { bits |= 1u << (g0 + b); continue; }
+            bool n2 = false;                                                        // the first line is quiet: the rest of the group
+            if (lanel < VPG - 8) n2 = noisy4(tv[(g0 + b) * VPG + 8 + lanel]);
+            if (__ballot(n2)) bits |= 1u << (g0 + b); }
+         if (lane == 0 && bits) atomicOr(&s_noisy[par], bits); }
       if (cut != 1) {
          // ---- 3. candidate samples: local extremum + amplitude, one lane per 14-row strip of a pair of heads.  The rows of a pair are
          // only 2-byte aligned in LDS (rows are 2 NT bytes apart), and a misaligned ds_read_b32 costs 33 cycles a wave: two aligned
@@ -877,16 +923,19 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
             uint32_t x[kSfStrip + 2];
             #pragma unroll
             for (int i = 0; i < kSfStrip + 2; ++i) x[i] = (uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB) | ((uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB + 2) << 16);
-            uint32_t yc = pk_max(x[1], at), zc = pk_min(x[1], ab);
-            uint32_t uy = pk_subs(pk_max(x[0], at), yc), dz = pk_subs(zc, pk_min(x[0], ab));      // sign: rising into this row above the floor / falling into it below the ceiling
+            // (round 6: the rows' "rising into" / "falling into" bits are gathered first - bit j of a half: x[j] lies above x[j - 1] on the signal clamped at the
+            //  floor / below it on the signal clamped at the ceiling - and "rises into the row and not out of it" is made once per strip from the two masks,
+            //  not per row: 8 instead of 11 vector instructions a row)
+            uint32_t yc = pk_max(x[0], at), zc = pk_min(x[0], ab), ru = 0, fd = 0;
             #pragma unroll
-            for (int i = 0; i < kSfStrip; ++i) {
-               const uint32_t yn = pk_max(x[i + 2], at), zn = pk_min(x[i + 2], ab);
-               const uint32_t uyn = pk_subs(yc, yn), dzn = pk_subs(zn, zc);
-               tm = (tm >> 1) | (uy & ~uyn & kPkSigns);
-               bm = (bm >> 1) | (dz & ~dzn & kPkSigns);
-               yc = yn; zc = zn; uy = uyn; dz = dzn; }
-            tm = (tm >> (16 - kSfStrip)) & 0x3fff3fffu; bm = (bm >> (16 - kSfStrip)) & 0x3fff3fffu;
+            for (int i = 1; i < kSfStrip + 2; ++i) {
+               const uint32_t yn = pk_max(x[i], at), zn = pk_min(x[i], ab);
+               ru = (ru >> 1) | (pk_subs(yc, yn) & kPkSigns);
+               fd = (fd >> 1) | (pk_subs(zn, zc) & kPkSigns);
+               yc = yn; zc = zn; }
+            // x[1 .. kSfStrip + 1] sit at bits 1 .. 15 of each half (16 - (kSfStrip + 1) = 1 from the top: kSfStrip = 14), bit 0 is clear: row r = x[r + 1]
+            static_assert(kSfStrip == 14, "the strip's masks fill the halves of a register");
+            tm = ((ru & ~(ru >> 1)) >> 1) & 0x3fff3fffu; bm = ((fd & ~(fd >> 1)) >> 1) & 0x3fff3fffu;
             if (inv) { const uint32_t s2 = tm; tm = bm; bm = s2; }
             if (!has_hi) { tm &= 0xffffu; bm &= 0xffffu; }                  // odd track count: the last pair's upper half is the next row
             if (cx.last < kSfTile - 1) {                                      // rows that do not exist cannot own a run
@@ -901,17 +950,16 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
             uint32_t x[R3 + 2];
             #pragma unroll
             for (int i = 0; i < R3 + 2; ++i) x[i] = (uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB);
-            uint32_t yc = pk_max(x[1], at), zc = pk_min(x[1], ab);
-            uint32_t uy = pk_subs(pk_max(x[0], at), yc), dz = pk_subs(zc, pk_min(x[0], ab));
-            uint32_t t3 = 0;
+            uint32_t yc = pk_max(x[0], at), zc = pk_min(x[0], ab), ru = 0, fd = 0;
             #pragma unroll
-            for (int i = 0; i < R3; ++i) {
-               const uint32_t yn = pk_max(x[i + 2], at), zn = pk_min(x[i + 2], ab);
-               const uint32_t uyn = pk_subs(yc, yn), dzn = pk_subs(zn, zc);
-               t3 = (t3 >> 1) | (uy & ~uyn & 0x8000u);
-               b3 = (b3 >> 1) | (dz & ~dzn & 0x8000u);
-               yc = yn; zc = zn; uy = uyn; dz = dzn; }
-            t3 >>= 16 - R3; b3 >>= 16 - R3;
+            for (int i = 1; i < R3 + 2; ++i) {
+               const uint32_t yn = pk_max(x[i], at), zn = pk_min(x[i], ab);
+               ru = (ru >> 1) | (pk_subs(yc, yn) & 0x8000u);
+               fd = (fd >> 1) | (pk_subs(zn, zc) & 0x8000u);
+               yc = yn; zc = zn; }
+            static_assert(R3 <= 14, "the part's masks fill the low half of a register");
+            uint32_t t3 = ((ru & ~(ru >> 1)) >> (15 - R3)) & ((1u << R3) - 1u);      // (x[1 .. R3 + 1] sit at bits 15 - R3 .. 15: row i = x[i + 1])
+            b3 = ((fd & ~(fd >> 1)) >> (15 - R3)) & ((1u << R3) - 1u);
             if (inv) { const uint32_t s2 = t3; t3 = b3; b3 = s2; }
             int keep = kSfTile - r3;                                          // the part's last lanes reach into the next tile (seven tracks) or behind the tape's end
             if (cx.last + 1 - r3 < keep) keep = cx.last + 1 - r3;

@@ -313,6 +313,8 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
                     if floor_state["tries"] > 0:
                         floor_state["tries"] -= 1
                         st_k = res.fe.scan_stats(res)
+                        if floor_state["floor"] is None:      # (what the window's own first scan estimated from its samples, k_scan_begin)
+                            floor_state["floor"] = st_k.get("screen_floor_used")
                         if st_k["bursts"] > 0 and st_k["redone"] * 4 > st_k["bursts"] and st_k.get("min_learned_height"):
                             import dataclasses
                             cfg2 = dataclasses.replace(cfg, screen_floor_height=min(4.0, 0.5 * st_k["min_learned_height"]))

@@ -96,10 +96,11 @@ def test_windows_read_in_parallel_pieces_with_an_end_marker_in_one_of_them(threa
     assert open(tmp_path / "s.tap", "rb").read() == want
 
 
-def test_a_noisy_tape_raises_the_screen_floor_after_its_first_windows(tmp_path):
-    """60 mV rms of noise on 2 - 3 V peaks: with the default candidate screen (built for a learned peak height of 1 V) the lists outgrow their
-    slots and the bursts are redone on the samples; the reader sees that in the first windows' statistics and screens the windows behind them
-    against half the smallest peak height a chain learned.  Same bytes as the whole-tape decode (whose events the oracle pins), and the floor was raised."""
+def test_a_noisy_tape_raises_the_screen_floor(tmp_path):
+    """60 mV rms of noise on 2 - 3 V peaks: with a candidate screen built for a learned peak height of 1 V the lists outgrow their slots and the bursts are
+    redone on the samples.  A scan context's first window estimates the floor from its samples (k_scan_begin), the windows behind it screen against half the
+    smallest peak height a chain learned (and, should a quarter of the first windows' bursts be redone all the same, the reader makes contexts with a
+    calibrated floor).  Same bytes as the whole-tape decode (whose events the oracle pins), and the floor was above the default."""
     tape = synth.nrzi_tape(seed=76, nblocks=60, minlen=400, maxlen=1500, marks_every=9, gap_samples=3000, noise_mv=60.0)
     hdr = tape.spec.header()
     want = _whole(hdr, tape.rows, str(tmp_path / "whole.tap"))
