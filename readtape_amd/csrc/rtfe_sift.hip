@@ -492,8 +492,9 @@ typedef const __attribute__((address_space(1))) char *glb_cp;
 typedef __attribute__((address_space(1))) char *glb_p;
 __device__ __forceinline__ glb_cp sgpr_ptr(glb_cp p) { asm volatile("" : "+s"(p)); return p; }
 __device__ __forceinline__ glb_p sgpr_ptr(glb_p p) { asm volatile("" : "+s"(p)); return p; }
-__device__ __forceinline__ int4 glb_ld16(glb_cp p) { return *reinterpret_cast<const __attribute__((address_space(1))) int4 *>(p); }
-__device__ __forceinline__ void glb_st16(glb_p p, const int4 v) { *reinterpret_cast<__attribute__((address_space(1))) int4 *>(p) = v; }
+typedef int glb_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 glb_ld16(glb_cp p) { const glb_v4 v = *reinterpret_cast<const __attribute__((address_space(1))) glb_v4 *>(p); return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void glb_st16(glb_p p, const int4 v) { glb_v4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *reinterpret_cast<__attribute__((address_space(1))) glb_v4 *>(p) = w; }
 #endif
 
 #ifdef RTFE_CPU_EMUL
