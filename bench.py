@@ -323,6 +323,9 @@ def measure(name, args, rank, world, dev, dist, steps, warmup, min_seconds=0.5, 
     for k in kms: kms[k] /= n_serial
     kms_serial = dict(kms)
     graphs = (bool(getattr(args, "graphs", False)) or bool(conf.get("graphs"))) and not getattr(args, "no_graphs", False) and wl.cuda and not overlap      # (graphs of two contexts do not run beside each other: measured)
+    if graphs and world > 1:                         # a stream capture beside RCCL's own threads and the halo's send / receive has never run anywhere: refused, not risked
+        if rank == 0: print("bench.py: --graphs is refused with --gpus > 1 (HIP graph capture beside RCCL is untested); direct launches", file=sys.stderr)
+        graphs = False
     # C5 - what --gpus N runs, a rank's share is a short scan - records no per-kernel events in its timed region (24 records per scan: 1.32 -> 1.21 ms on a 6.9e7-row
     # scan; kernel_ms from the serial pass above).  Graph replay (--graphs) buys another 0.6 % there: not the default - its capture beside RCCL's threads is untested
     no_events = (bool(getattr(args, "no_kernel_events", False)) or bool(conf.get("no_events"))) and wl.cuda

@@ -126,21 +126,25 @@ __global__ void __launch_bounds__(256) k_scan_begin(DevCfg *cfg, BurstScratch *s
       return; }
    const int ntrks = cfg->ntrks, q = cfg->quiet_i;
    const long long nwin = nrows / kProbeRows < 1 ? 1 : (nrows / kProbeRows > kProbeWindows ? kProbeWindows : nrows / kProbeRows);
+   // a thread a (track, every nstr-th row) of the window: its own maximum, minimum and which 64-row groups it saw outside the quiet band, in registers;
+   // three LDS atomics a thread at the end (round 6's first cut had every thread at the tracks' nine cells for every sample: 0.27 ms a scan)
+   const int nstr = 256 / ntrks, trk = tid % ntrks, rg = tid / ntrks;
    for (long long w = blockIdx.x; w < nwin; w += gridDim.x) {
       const long long r0 = ((w * nrows) / nwin) & ~63ll;
       const int len = (int)(nrows - r0 < kProbeRows ? nrows - r0 : kProbeRows);
       if (tid < ntrks) { s_mx[tid] = -0x10000; s_mn[tid] = 0x10000; }
       if (tid == 0) s_noisy = 0;
       __syncthreads();
-      for (int i = tid; i < len; i += 256) {
-         const int16_t *row = rows + (r0 + i) * ntrks;
-         bool loud = false;
-         for (int t = 0; t < ntrks; ++t) {
-            const int x = row[t];
-            loud = loud || x > q || x < -q;
-            if (x > s_mx[t]) atomicMax(&s_mx[t], x);
-            if (x < s_mn[t]) atomicMin(&s_mn[t], x); }
-         if (loud) atomicOr(&s_noisy, 1u << (i >> 6)); }
+      if (rg < nstr) {
+         int mx = -0x10000, mn = 0x10000;
+         unsigned int loud = 0;
+         const int16_t *col = rows + r0 * ntrks + trk;
+         for (int i = rg; i < len; i += nstr) {
+            const int x = col[(long long)i * ntrks];
+            mx = x > mx ? x : mx; mn = x < mn ? x : mn;
+            if (x > q || x < -q) loud |= 1u << (i >> 6); }
+         atomicMax(&s_mx[trk], mx); atomicMin(&s_mn[trk], mn);
+         if (loud) atomicOr(&s_noisy, loud); }
       __syncthreads();
       if (tid == 0) {
          const int ngroups = len >> 6;

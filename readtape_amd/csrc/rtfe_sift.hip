@@ -756,6 +756,18 @@ struct SfArgs {
 
 // PL ("plain"): no -invert, no experiment cut-offs, no cycle counters, the lists leave deferred - what every scan but a test's or a tool's is; the knobs are
 // compile-time constants then (as run-time values they are a dozen wave-uniform masks the compiler keeps in - and reloads from - spilled scalar registers)
+// RTFE_SIFT_PROF (a build of its own, tools/gpu_r6_prof.sh): where a wave's cycles of a tile step go - lane 0 of every wave reads the shader clock at the
+// phase boundaries and adds the intervals up into SfArgs::dbg[0..7] = { tile -> LDS (with the wait for the prefetched rows), barrier 1, next tile's loads +
+// the lists' copy-out, quiet groups, strips, compaction, owner rounds + tail, barrier 2 }
+#ifdef RTFE_SIFT_PROF
+#define SF_PROF_DECL long long pf_t = clock64(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SF_PROF(i) { const long long pf_n = clock64(); pf_acc[i] += pf_n - pf_t; pf_t = pf_n; }
+#define SF_PROF_END if (lane == 0) { for (int pf_i = 0; pf_i < 8; ++pf_i) atomicAdd(&a.dbg[pf_i], (unsigned long long)pf_acc[pf_i]); }
+#else
+#define SF_PROF_DECL
+#define SF_PROF(i)
+#define SF_PROF_END
+#endif
 template <int W, int NT, int WPS, bool PL>
 __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs a) {
 #ifdef RTFE_CPU_EMUL
@@ -867,6 +879,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       if (wave == 0 && lane == 0) {
          PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)tot; d.nent = 0;
          a.dir[li] = d; } };
+   SF_PROF_DECL
    for (int tile = tile_lo; tile < ntiles; tile += G, par ^= 1) {
       // (conditions on the thread index alone are the same in every tile step: the compiler computes them once, as wave masks in scalar registers - more than
       //  it has, so it parks them in a vector register's lanes and fetches each back with two v_readlane where one v_cmp would do.  An index it cannot see
@@ -885,12 +898,15 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          #pragma unroll
          for (int k = 0; k < NV; ++k) if ((k + 1) * NTH <= NVEC || k * NTH + tidl < NVEC) reinterpret_cast<int4 *>(xs)[k * NTH + tid] = q[k]; }
       else sf_fill_edge(xsl, a.rows, ((long long)tile * kSfTile - HL) * NT, a.nrows * NT, NVEC * 8, tid, NTH);
+      SF_PROF(0)
       __syncthreads();
+      SF_PROF(1)
       if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G, tidl, voffl);
       if (tid == 0 && tile > tile_lo && a.qtile) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
       if (p_tile >= 0) { copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad); p_tile = -1; rtfe_wave_sync(); }      // (the lists of the tile in front: a.defer)
       if (SPL && prev_tile >= 0 && cut != 1) { copy_out3(prev_tile, par ^ 1); rtfe_wave_sync(); }
       // ---- 2. quiet groups: flat 16-byte reads of the tile proper; a ballot of 64 vectors lies in one or two groups (several screens: the first launch's business) ----
+      SF_PROF(2)
       // (round 6: a group is quiet only if EVERY sample of it is, and inside a block every part of a group carries signal - as k_quiet does, a group's first
       //  128 bytes are looked at first, eight lanes a group, and the rest of it - one more round of the wave - only where those are quiet: the gaps.  A wave
       //  takes three or four of the tile's fourteen groups.  The same bits; a tile inside a block costs one round of the old four.)
@@ -914,6 +930,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
             if (lanel < VPG - 8) n2 = noisy4(tv[(g0 + b) * VPG + 8 + lanel]);
             if (__ballot(n2)) bits |= 1u << (g0 + b); }
          if (lane == 0 && bits) atomicOr(&s_noisy[par], bits); }
+      SF_PROF(3)
       if (cut != 1) {
          // ---- 3. candidate samples: local extremum + amplitude, one lane per 14-row strip of a pair of heads.  The rows of a pair are
          // only 2-byte aligned in LDS (rows are 2 NT bytes apart), and a misaligned ds_read_b32 costs 33 cycles a wave: two aligned
@@ -967,6 +984,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
             if (lane >= LA3) keep = 0;
             const uint32_t mk = keep >= R3 ? (1u << R3) - 1u : (keep <= 0 ? 0u : ((1u << keep) - 1u));
             m3 = (t3 | b3) & mk; b3 &= mk; }
+         SF_PROF(4)
          // ---- 4. the wave's candidates, compacted into a list ordered by (head, row); rounds of 64 ----
          int rec_lo = 0, rec_hi = 0, rec_3 = 0;                                // records in this wave's lists
          bool bad = false;
@@ -987,6 +1005,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
                   o2 = n_lo + n_hi + (excl >> 20);
                   for (; m3; m3 &= m3 - 1) { const int b2 = __ffs((int)m3) - 1; wlist[o2++] = (uint16_t)((r3 + b2) | (((b3 >> b2) & 1u) << 14) | 0x2000u); } }
                rtfe_wave_sync();
+               SF_PROF(5)
                #pragma nounroll
                for (int r0 = 0; r0 < (cut == 3 ? 0 : ncw); r0 += 64) {
                   const int i = r0 + lane;
@@ -1026,7 +1045,10 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          if (defer) { p_tile = tile; p_rec_lo = rec_lo; p_rec_hi = rec_hi; p_bad = bad; }
          else copy_out(tile, rec_lo, rec_hi, bad);
          rtfe_wave_sync(); }
-      __syncthreads(); }
+      SF_PROF(6)
+      __syncthreads();
+      SF_PROF(7) }
+   SF_PROF_END
    if (p_tile >= 0) copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad);
    if (SPL && last_tile >= 0 && cut != 1) copy_out3(last_tile, par ^ 1);
    if (tid == 0 && last_tile >= 0 && a.qtile) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);

@@ -219,7 +219,7 @@ class TorchBackend:
 
 
 def _load_library(path=None):
-    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtfe.so")
+    path = path or os.environ.get("RTFE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtfe.so")      # (RTFE_LIB_PATH: tools/ only - a build with other compile-time knobs, side by side)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                            "The front end has no CPU fallback.")

@@ -169,10 +169,11 @@ import bench
 from emul_util import emul_frontend
 from readtape_amd import shard, synth
 config, out, halo = sys.argv[2], sys.argv[3], int(sys.argv[4])
+copies = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 tape = synth.nrzi_tape(seed=77, nblocks=5, minlen=64, maxlen=300, marks_every=3, gap_samples=3000)
-wl = bench.Workload(bench.CONFIGS[config], rank, world, torch.device("cpu"), dist, total_rows=3 * tape.rows.shape[0], base_rows=0,
+wl = bench.Workload(bench.CONFIGS[config], rank, world, torch.device("cpu"), dist, total_rows=copies * tape.rows.shape[0], base_rows=0,
                     fe_factory=emul_frontend, halo=halo, tape=tape)
 parts = []
 for i in range(2):                                   # two steps: the halo exchange repeats into the same buffer
@@ -232,6 +233,43 @@ def test_two_ranks_drive_the_step_of_bench_py(config, halo, tmp_path):
         assert parts[1][0]["bursts"].shape[0] == whole.nbursts and parts[0][0]["bursts"].shape[0] >= whole.nbursts - 1
         assert parts[0][0]["got"] == halo and parts[1][0]["got"] == 0 and parts[1][0]["lo"] == parts[0][0]["n"]
         assert parts[0][1]["events"].shape == parts[0][0]["events"].shape and (parts[0][1]["events"] == parts[0][0]["events"]).all()
+
+
+def test_eight_ranks_drive_the_step_of_bench_py_on_c5s_shape(tmp_path):
+    """What `bench.py --gpus 8` runs: ONE tape cut into eight time shards by plan_shards, every rank but the last receives its seam halo
+    from the rank behind it (neighbour isend / irecv, no collective on the data path), rtfe_scan with the ownership rule - eight gloo ranks with the
+    emulated kernels, two steps (the halo lands in the same buffer again).  The ranks' bursts and events together are the single scan of the whole tape."""
+    import pickle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    from emul_util import build_emul, emul_frontend
+    from readtape_amd import frontend, shard, synth
+    build_emul()
+    world, halo, copies = 8, 1 << 13, 8
+    out = str(tmp_path / "res.pkl")
+    wfile = tmp_path / "bench_worker.py"
+    wfile.write_text(BENCH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(30100 + os.getpid() % 1000), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(wfile), ROOT, "C5", out, str(halo), str(copies)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=1500) == 0
+    parts = pickle.load(open(out, "rb"))
+    tape = synth.nrzi_tape(seed=77, nblocks=5, minlen=64, maxlen=300, marks_every=3, gap_samples=3000)
+    rows = np.tile(tape.rows, (copies, 1))
+    assert [(p[0]["lo"], p[0]["lo"] + p[0]["n"]) for p in parts] == shard.plan_shards(rows.shape[0], world)
+    assert all(p[0]["got"] == halo for p in parts[:-1]) and parts[-1][0]["got"] == 0
+    fe = emul_frontend(frontend.FrontEndConfig.from_header(tape.spec.header()))
+    whole = fe.scan(rows).fetch()
+    wb = shard.absolute_bursts(whole, 0)
+    we = shard.flatten_events(whole, wb, 0)
+    key = lambda e: e[np.lexsort((e[:, 1], e[:, 0]))]
+    for i in range(2):
+        got_b = np.concatenate([p[i]["bursts"] for p in parts])
+        got_e = np.concatenate([p[i]["events"] for p in parts])
+        for f in ("zone_end", "reset_sample", "safe_last", "end_sample"):
+            assert list(got_b[f]) == list(wb[f]), f
+        assert got_e.shape == we.shape and (key(got_e) == key(we)).all()
+    assert we.shape[0] > 12000 and all(p[0]["bursts"].shape[0] > 0 for p in parts)
 
 
 def test_every_bench_configuration_is_complete():
