@@ -49,7 +49,7 @@ struct rtfe_handle {
    hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2;
    int overlap;
    int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
-   int sift_defer;                     // RTFE_SIFT_DEFER=0: k_sift_s stores a tile's lists at the end of its own step (experiments)
+   int sfs_occ[kMaxScreens];           // k_sift_s: workgroups of a screen's instantiation a CU holds at once (the occupancy API, at create)
    int ds_order, dchain_wgs, prep_wgs, dense_stop, dseg_wgs, dseg_threads;      // RTFE_DS_ORDER (0: chains in burst order), RTFE_DCHAIN_WGS / RTFE_PREP_WGS / RTFE_DSEG_WGS (workgroups per CU), RTFE_DENSE_STOP (debugging): read once, at create
    // rtfe_set_graphs: a scan's launches (about twenty, on two streams) captured once per set of arguments into a HIP graph and replayed - what a scan of the same
    // buffers costs the host, and the gaps between its kernels on the device, shrink to one launch
@@ -87,6 +87,8 @@ static int fail(int code, const char *fmt, ...) {
 typedef void (*sf_kernel_t)(const DevCfg *, const int16_t *, long long, long long, uint16_t *, PeakDir *, unsigned char *, SfHard *, int, int *, unsigned long long *);
 typedef void (*sfs_kernel_t)(const SfArgs);
 constexpr int kSfWps = 5;          // waves per SIMD k_sift's register allocation is held to: four 5-wave workgroups per CU
+constexpr int kSfsWps = 6;         // ... and k_sift_s': six four-wave workgroups per CU, 80 registers (round 6: 21.5 KB of LDS a workgroup - no staging slots - would let a seventh reside; at
+                                   // 72 registers a prefetched vector spills, and the seventh workgroup is worth under 1 %: measured 0.6376 / 0.6428 ms)
 template <int WM, int MAXT> static sf_kernel_t sf_kernel_nv(int nv) { return nv <= 4 ? k_sift<WM, MAXT, 4, kSfWps> : k_sift<WM, MAXT, 6, kSfWps>; }
 template <int WM> static sf_kernel_t sf_kernel_t2(int threads, int nv) { return threads <= 320 ? sf_kernel_nv<WM, 320>(nv) : sf_kernel_nv<WM, 640>(nv); }
 static sf_kernel_t sf_kernel(int wmax, int threads, int nv) {
@@ -94,18 +96,18 @@ static sf_kernel_t sf_kernel(int wmax, int threads, int nv) {
 // one screen of a width and a track count the lean kernel is built for, a sure level that fits 16 bits: k_sift_s
 template <int NT, bool PL> static sfs_kernel_t sfs_kernel_w(int w) {
    switch (w) {
-      case 6:  return k_sift_s<6, NT, kSfWps, PL>;
-      case 7:  return k_sift_s<7, NT, kSfWps, PL>;
-      case 8:  return k_sift_s<8, NT, kSfWps, PL>;
-      case 9:  return k_sift_s<9, NT, kSfWps, PL>;
-      case 10: return k_sift_s<10, NT, kSfWps, PL>;
-      case 11: return k_sift_s<11, NT, kSfWps, PL>;
-      case 12: return k_sift_s<12, NT, kSfWps, PL>;
-      case 13: return k_sift_s<13, NT, kSfWps, PL>;
-      case 14: return k_sift_s<14, NT, kSfWps, PL>;
-      case 15: return k_sift_s<15, NT, kSfWps, PL>;
-      case 16: return k_sift_s<16, NT, kSfWps, PL>;
-      case 17: return k_sift_s<17, NT, kSfWps, PL>;
+      case 6:  return k_sift_s<6, NT, kSfsWps, PL>;
+      case 7:  return k_sift_s<7, NT, kSfsWps, PL>;
+      case 8:  return k_sift_s<8, NT, kSfsWps, PL>;
+      case 9:  return k_sift_s<9, NT, kSfsWps, PL>;
+      case 10: return k_sift_s<10, NT, kSfsWps, PL>;
+      case 11: return k_sift_s<11, NT, kSfsWps, PL>;
+      case 12: return k_sift_s<12, NT, kSfsWps, PL>;
+      case 13: return k_sift_s<13, NT, kSfsWps, PL>;
+      case 14: return k_sift_s<14, NT, kSfsWps, PL>;
+      case 15: return k_sift_s<15, NT, kSfsWps, PL>;
+      case 16: return k_sift_s<16, NT, kSfsWps, PL>;
+      case 17: return k_sift_s<17, NT, kSfsWps, PL>;
       default: return nullptr; } }
 // (every window width the packed derivation holds - 6 .. 17 samples - for nine and seven tracks: 800 / 556 BPI NRZI at 781 kHz are 13 / 19,
 //  at half that rate 6 / 9; wider windows, several widths and other track counts take the general kernel: 2.1 instead of 0.93 ms on C2)
@@ -300,7 +302,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    d.debug = getenv("RTFE_DEBUG") ? atoi(getenv("RTFE_DEBUG")) : 0;
    d.cut = getenv("RTFE_CUT") ? atoi(getenv("RTFE_CUT")) : 0;
    // (k_sift_s's plain build: none of the knobs it would otherwise carry as run-time values; RTFE_SIFT_PLAIN=0: the general build everywhere - tests)
-   d.pk_plain = !d.invert && d.cut == 0 && d.debug != 3 && !(getenv("RTFE_SIFT_DEFER") && atoi(getenv("RTFE_SIFT_DEFER")) == 0) && !(getenv("RTFE_SIFT_PLAIN") && atoi(getenv("RTFE_SIFT_PLAIN")) == 0);
+   d.pk_plain = !d.invert && d.cut == 0 && d.debug != 3 && !(getenv("RTFE_SIFT_PLAIN") && atoi(getenv("RTFE_SIFT_PLAIN")) == 0);
    {  // The peak path (k_sift -> k_gain -> k_emit): peak detection on the undifferentiated signal.  It pays where flux transitions are a
       // bit cell apart (NRZI): most peaks then have the window to themselves and the chains stay on their steady path.  PE and GCR put
       // a top and a bottom into one window; their bursts take the sample path (k_decode) - RTFE_PEAK_PATH=0/1 overrides (tests keep both
@@ -422,7 +424,6 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    h->graphs = getenv("RTFE_GRAPHS") ? atoi(getenv("RTFE_GRAPHS")) != 0 : 0;
    memset(h->gcache, 0, sizeof h->gcache); h->gstamp = 0;
    h->bursts_wpr = getenv("RTFE_BURSTS_WPR") ? atoi(getenv("RTFE_BURSTS_WPR")) : 0;
-   h->sift_defer = getenv("RTFE_SIFT_DEFER") ? atoi(getenv("RTFE_SIFT_DEFER")) != 0 : 1;
    h->ds_order = getenv("RTFE_DS_ORDER") ? atoi(getenv("RTFE_DS_ORDER")) : 1;
    h->dchain_wgs = getenv("RTFE_DCHAIN_WGS") ? atoi(getenv("RTFE_DCHAIN_WGS")) : 16;
    h->prep_wgs = getenv("RTFE_PREP_WGS") ? atoi(getenv("RTFE_PREP_WGS")) : 32;
@@ -433,7 +434,11 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    if (d.invert || d.maxskew > 0 || d.ntrks < 2 || d.zc_peak_i < 1 || d.zc_peak_i > 32767 || !d.zc_parallel) h->zeros_kernel = 0;      // (RTFE_ZC_PARALLEL=0: k_decode's sequential walk, for the tests)
    if (d.peak_path) {                 // (wide rows - 16 tracks and more - do not fit k_sift's tile into LDS: peak_path is off then and the kernel is never launched)
       raise_dynamic_lds(reinterpret_cast<const void *>(sf_kernel(sf_wmax(d), sf_threads(d), sf_nv(d))), d.pk_lds);
-      if (sf_special(d)) for (int sc = 0; sc < d.nscreens; ++sc) raise_dynamic_lds(reinterpret_cast<const void *>(sf_special_sc(d, sc)), sfs_lds_sc(d, sc)); }
+      for (int sc = 0; sc < kMaxScreens; ++sc) h->sfs_occ[sc] = 0;
+      if (sf_special(d)) for (int sc = 0; sc < d.nscreens; ++sc) {
+         raise_dynamic_lds(reinterpret_cast<const void *>(sf_special_sc(d, sc)), sfs_lds_sc(d, sc));
+         int nb = 0;
+         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(sf_special_sc(d, sc)), sfs_threads(d), (size_t)sfs_lds_sc(d, sc)) == hipSuccess && nb >= 1) h->sfs_occ[sc] = nb; } }
    if (d.dense_path) raise_dynamic_lds(reinterpret_cast<const void *>(ds_kernel(d.ntrks)), (int)ds_lds_layout(d.ntrks, d.halo_rows, d.ds_pad + kDsTile + kDsRight, d.ds_up).total + 64);
    (void)hipGetLastError();          // (a refused attribute must not linger as the process' "last error": the caller's runtime would report it as its own)
    if (getenv("RTFE_VERBOSE") && d.peak_path) {
@@ -685,10 +690,11 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
             a.rows = d_rows; a.nrows = nrows; a.ntiles = (int)ptiles; a.qtile = sc == 0 ? qtile : nullptr; a.dir = dirm; a.pool = pkpool; a.hard = hardp; a.hard_cap = hard_cap;
             a.hard_count = &scratch->hard_count; a.dbg = scratch->scr; a.hcap = h->dev.pk_slot; a.wave_cap = h->dev.pk_wave_cap; a.invert = h->dev.invert;
             a.quiet_i = h->dev.quiet_i; a.cfg = h->d_dev; a.hi_i = h->dev.screen[sc].sure_i;
-            a.cut = h->dev.cut; a.debug = h->dev.debug; a.defer = h->sift_defer; a.nscreens = h->dev.nscreens; a.sc = sc;
+            a.cut = h->dev.cut; a.debug = h->dev.debug; a.defer = 1; a.nscreens = h->dev.nscreens; a.sc = sc;
             const int lds_sc = sfs_lds_sc(h->dev, sc);
             int spc_sc = (160 * 1024) / (lds_sc + 512);
             if (spc_sc > spc) spc_sc = spc;
+            if (h->sfs_occ[sc] >= 1 && spc_sc > h->sfs_occ[sc]) spc_sc = h->sfs_occ[sc];      // (persistent workgroups: never more than are resident at once - the registers may allow fewer than the LDS)
             if (spc_sc < 1) spc_sc = 1;
             long long grid_sc = (long long)h->num_cus * spc_sc;
             if (grid_sc > ptiles) grid_sc = ptiles;

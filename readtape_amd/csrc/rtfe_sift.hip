@@ -157,8 +157,8 @@ __host__ __device__ inline SfsLds sfs_lds_layout(int ntrks, int w, int wave_cap,
    const int nw = sfs_waves(ntrks);
    unsigned o = 0;
    L.xs = o;    o += (unsigned)(sfs_hl(w) + kSfTile + sfs_hr(w)) * (unsigned)(ntrks * 2) + 32;  o = (o + 15) & ~15u;
-   L.wl = o;    o += (unsigned)nw * wave_cap * 2;  o = (o + 15) & ~15u;
-   L.stage = o; o += (unsigned)(sfs_split(ntrks) ? ntrks - 1 : ntrks) * hcap;
+   L.wl = o;    o += (unsigned)nw * (wave_cap + 8) * 2;  o = (o + 15) & ~15u;      // (+ 8: entry wave_cap of a wave's list takes the stores of lanes that have nothing to list)
+   L.stage = o;      // (round 6: a pair's records leave straight from the round that makes them - no staging slots: 10 KB less, seven workgroups a CU)
    L.part = o;  if (sfs_split(ntrks)) o += (unsigned)nw * sfs_part_cap(ntrks, hcap);
    L.total = (o + 15) & ~15u;
    return L; }
@@ -487,6 +487,7 @@ __device__ __forceinline__ glb_cp sgpr_ptr(glb_cp p) { return p; }
 __device__ __forceinline__ glb_p sgpr_ptr(glb_p p) { return p; }
 __device__ __forceinline__ int4 glb_ld16(glb_cp p) { int4 v; memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void glb_st16(glb_p p, const int4 v) { memcpy(p, &v, 16); }
+__device__ __forceinline__ void glb_st4(glb_p p, const uint32_t v) { memcpy(p, &v, 4); }
 #else
 typedef const __attribute__((address_space(1))) char *glb_cp;
 typedef __attribute__((address_space(1))) char *glb_p;
@@ -494,6 +495,7 @@ __device__ __forceinline__ glb_cp sgpr_ptr(glb_cp p) { asm volatile("" : "+s"(p)
 __device__ __forceinline__ glb_p sgpr_ptr(glb_p p) { asm volatile("" : "+s"(p)); return p; }
 typedef int glb_v4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int4 glb_ld16(glb_cp p) { const glb_v4 v = *reinterpret_cast<const __attribute__((address_space(1))) glb_v4 *>(p); return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void glb_st4(glb_p p, const uint32_t v) { *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(p) = v; }
 __device__ __forceinline__ void glb_st16(glb_p p, const int4 v) { glb_v4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *reinterpret_cast<__attribute__((address_space(1))) glb_v4 *>(p) = w; }
 #endif
 
@@ -586,7 +588,7 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
    // this wave's pair of heads, its candidate list and its two staging slots
    const int pair = wave, h_lo = 2 * pair, h_hi = 2 * pair + 1;
    const bool has_hi = h_hi < ntrks;
-   const lds_u16p wlist = reinterpret_cast<lds_u16p>(to_lds(smem + L.wl)) + wave * wave_cap;
+   const lds_u16p wlist = reinterpret_cast<lds_u16p>(to_lds(smem + L.wl)) + wave * (wave_cap + 8);
    const lds_p slot_lo = to_lds(smem + L.stage) + h_lo * hcap, slot_hi = slot_lo + hcap;
    int4 q[NV];
    #pragma unroll
@@ -759,13 +761,23 @@ struct SfArgs {
 // RTFE_SIFT_PROF (a build of its own, tools/gpu_r6_prof.sh): where a wave's cycles of a tile step go - lane 0 of every wave reads the shader clock at the
 // phase boundaries and adds the intervals up into SfArgs::dbg[0..7] = { tile -> LDS (with the wait for the prefetched rows), barrier 1, next tile's loads +
 // the lists' copy-out, quiet groups, strips, compaction, owner rounds + tail, barrier 2 }
+// RTFE_SIFT_PROF=2: the two largest of those again, in parts - { the next tile's loads, the quiet word, the pairs' lists out, the split head's out, a round's
+// derivation, its placement, the step's tail, everything else }
 #ifdef RTFE_SIFT_PROF
 #define SF_PROF_DECL long long pf_t = clock64(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define SF_PROF(i) { const long long pf_n = clock64(); pf_acc[i] += pf_n - pf_t; pf_t = pf_n; }
+#define SF_PROF_AT(i) { const long long pf_n = clock64(); pf_acc[i] += pf_n - pf_t; pf_t = pf_n; }
 #define SF_PROF_END if (lane == 0) { for (int pf_i = 0; pf_i < 8; ++pf_i) atomicAdd(&a.dbg[pf_i], (unsigned long long)pf_acc[pf_i]); }
+#if RTFE_SIFT_PROF == 2
+#define SF_PROF(i) SF_PROF_AT(7)
+#define SF_PROF2(i) SF_PROF_AT(i)
+#else
+#define SF_PROF(i) SF_PROF_AT(i)
+#define SF_PROF2(i)
+#endif
 #else
 #define SF_PROF_DECL
 #define SF_PROF(i)
+#define SF_PROF2(i)
 #define SF_PROF_END
 #endif
 template <int W, int NT, int WPS, bool PL>
@@ -790,7 +802,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
    const int hcap = a.hcap, wave_cap = a.wave_cap, cut = PL ? 0 : a.cut;
-   const bool dbg3 = PL ? false : a.debug == 3, inv = PL ? false : a.invert != 0, defer = PL ? true : a.defer != 0;
+   const bool dbg3 = PL ? false : a.debug == 3, inv = PL ? false : a.invert != 0;
    const int cap3 = sfs_part_cap(NT, hcap);
    const SfsLds L = sfs_lds_layout(NT, W, wave_cap, hcap);
    unsigned char *xs = smem + L.xs;
@@ -807,9 +819,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    const int inside_hi = ih > 0x7ffffff0 ? 0x7ffffff0 : (int)ih;
    const int pair = wave, h_lo = 2 * pair, h_hi = 2 * pair + 1;
    const bool has_hi = h_hi < NT;
-   const lds_u16p wlist = reinterpret_cast<lds_u16p>(to_lds(smem + L.wl)) + wave * wave_cap;
-   const lds_p slot_lo = to_lds(smem + L.stage) + h_lo * hcap, slot_hi = slot_lo + hcap;
-   const lds_p slot_3 = to_lds(smem + L.part) + wave * cap3;
+   const lds_u16p wlist = reinterpret_cast<lds_u16p>(to_lds(smem + L.wl)) + wave * (wave_cap + 8);
    const uint32_t at = minpk_i < 0 ? pk_dup(-32768) : pk_dup(minpk_i), ab = minpk_i < 0 ? pk_dup(32767) : pk_dup(-minpk_i);
    const uint32_t qpk = pk_dup(a.quiet_i), q2 = 2u * (uint32_t)a.quiet_i;
    int4 q[NV];
@@ -828,57 +838,49 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    if (tid < 2) s_noisy[tid] = 0;
    int par = 0, last_tile = -1;
    unsigned int pn_hard = 0, pn_rounds = 0, pn_bytes = 0;
-   // a wave's two lists leave LDS: records from the front of each head's slot, margin entries from its back, 16 bytes per lane; the
-   // directory.  Deferred (a.defer) to the start of the next tile step: the step's first instruction is s_waitcnt vmcnt(0) for the
-   // prefetched rows, and gfx9 counts stores in vmcnt too - stores issued just in front of it are waited for in full.
+   // Round 6: where a tile's lists go.  A wave's tile step is a CHAIN of dependent instructions and round trips, not a queue of work (tools/gpu_sift_prof.py:
+   // every instruction of a wave, scalar ones and waits included, costs it 10 - 12 cycles beside the four other waves of its SIMD; the vector unit idles 28 %
+   // of the time).  Rounds 3 - 5 staged every record in LDS and copied the three lists out at the start of the next step - a round trip to LDS, a store and a
+   // directory store per list, the other waves' counts through LDS and v_readfirstlane: a quarter of the step.  Now a PAIR's records are stored where they
+   // belong by the round that makes them (one store instruction a round, scalar base + the lane's offset); only the wave's part of the split head's list -
+   // whose place depends on the other waves' counts - waits in LDS, and leaves with the tile's three directory entries behind the next step's barrier
+   // (stores issued in front of a step's first s_waitcnt vmcnt(0) would be waited for in full: gfx9 counts loads and stores in one counter).
    int p_tile = -1, p_rec_lo = 0, p_rec_hi = 0;
    bool p_bad = false;
-   auto copy_out = [&](const int tile, const int rec_lo, const int rec_hi, const bool bad) {
-      #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-         if (hh && !has_hi) break;
-         const int h = h_lo + hh;
-         const int nr = hh ? rec_hi : rec_lo;
-         const bool over = bad || 16 * nr > hcap;
-         const size_t li = ((size_t)tile * a.nscreens + a.sc) * NT + h;      // the list's place: [tile][screen][head]
-         const glb_p gslot = sgpr_ptr((glb_p)(a.pool + li * (size_t)hcap));      // (a scalar base and the lane's 32-bit offset: no 64-bit vector arithmetic per store)
-         if (!over && nr > 0 && cut != 6) {
-            const int4 *src = reinterpret_cast<const int4 *>(smem + L.stage + h * hcap);
-            #pragma nounroll
-            for (int v0 = 0; v0 < nr; v0 += 64) if (v0 + lane < nr) glb_st16(gslot + (unsigned)(v0 + lane) * 16u, src[v0 + lane]);      // (a 16-byte vector a record)
-            if (dbg3) pn_bytes += (unsigned)(16 * nr); }
-         if (lane == 0) {
-            PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)nr; d.nent = 0;
-            a.dir[li] = d; } } };
-   // split: the last head's list is the waves' parts one behind the other.  Every wave copies its own part once all counts are known: behind the
-   // workgroup barrier that ends the tile's step, i.e. at the start of the next one (or behind the loop).
-   auto copy_out3 = [&](const int tile, const int pp) {
-      int off = 0, tot = 0;
-      bool over = false;
-      #pragma unroll
-      for (int w2 = 0; w2 < NP; ++w2) {
+   // (measured and not kept: the pair's records of a step's last round held in registers until that point too - their acknowledgements are on the way when the
+   //  next step asks for its prefetched rows, ~1 000 cycles of its s_waitcnt vmcnt(0) -: the wait shrank, the store behind the barrier cost more: 0.643 / 0.632 ms)
+   auto tile_pool = [&](const int tile) -> glb_p {      // the pool slot of the tile's head 0: [tile][screen][head]
+      const unsigned li0 = ((unsigned)tile * (unsigned)a.nscreens + (unsigned)a.sc) * (unsigned)NT;
+      return sgpr_ptr((glb_p)a.pool + (size_t)li0 * (size_t)(unsigned)hcap); };
+   auto copy_part = [&](const int tile, const int rec_lo, const int rec_hi, const bool bad, const int pp, const int lanev) {
+      const unsigned li0 = ((unsigned)tile * (unsigned)a.nscreens + (unsigned)a.sc) * (unsigned)NT;
+      int off3 = 0, tot3 = 0, mine3 = 0;
+      bool over3 = !SPL;
+      if (SPL) {
+         #pragma unroll
+         for (int w2 = 0; w2 < NP; ++w2) {
 #ifdef RTFE_CPU_EMUL
-         const int c = s_part[pp][w2];
+            const int c = s_part[pp][w2];
 #else
-         const int c = __builtin_amdgcn_readfirstlane((int)s_part[pp][w2]);      // (the same for every lane: the sums below stay in scalar registers)
+            const int c = __builtin_amdgcn_readfirstlane((int)s_part[pp][w2]);      // (the same for every lane: the sums below stay in scalar registers)
 #endif
-         over = over || c == 0xffff;
-         tot += c; if (w2 < wave) off += c; }
-      over = over || 16 * tot > hcap;
-#ifdef RTFE_CPU_EMUL
-      const int mine = s_part[pp][wave];
-#else
-      const int mine = __builtin_amdgcn_readfirstlane((int)s_part[pp][wave]);
-#endif
-      const size_t li = ((size_t)tile * a.nscreens + a.sc) * NT + H3;
-      const glb_p gslot = sgpr_ptr((glb_p)(a.pool + li * (size_t)hcap + (size_t)off * 16));
-      if (!over && cut != 6) {
+            over3 = over3 || c == 0xffff;
+            tot3 += c; if (w2 < wave) off3 += c; if (w2 == wave) mine3 = c; }
+         over3 = over3 || 16 * tot3 > hcap; }
+      if (!over3 && mine3 > 0 && cut != 6) {
+         const glb_p g3 = sgpr_ptr((glb_p)a.pool + ((size_t)li0 + (size_t)H3) * (size_t)(unsigned)hcap + (size_t)off3 * 16);
          const int4 *src = reinterpret_cast<const int4 *>(smem + L.part + wave * cap3);
          #pragma nounroll
-         for (int v0 = 0; v0 < mine; v0 += 64) if (v0 + lane < mine) glb_st16(gslot + (unsigned)(v0 + lane) * 16u, src[v0 + lane]); }
-      if (wave == 0 && lane == 0) {
-         PeakDir d; d.nrec = over ? (uint16_t)0xffff : (uint16_t)tot; d.nent = 0;
-         a.dir[li] = d; } };
+         for (int v0 = 0; v0 < mine3; v0 += 64) if (v0 + lanev < mine3) glb_st16(g3 + (unsigned)(v0 + lanev) * 16u, src[v0 + lanev]); }
+      // the directory: lane 0 the pair's lower head, lane 1 its upper one, the next lane of wave 0 the split head
+      const int ndir = (has_hi ? 2 : 1) + ((SPL && wave == 0) ? 1 : 0);
+      if (lanev < 3) {
+         const uint32_t d_lo = (bad || 16 * rec_lo > hcap) ? 0xffffu : (uint32_t)rec_lo, d_hi = (bad || 16 * rec_hi > hcap) ? 0xffffu : (uint32_t)rec_hi, d_3 = over3 ? 0xffffu : (uint32_t)tot3;
+         const bool third = lanev == (has_hi ? 2 : 1);
+         const uint32_t dv = third ? d_3 : (lanev == 0 ? d_lo : d_hi);      // (PeakDir: nrec in the low half, nent = 0)
+         const int hd = third ? H3 : h_lo + lanev;
+         const glb_p gdir = sgpr_ptr((glb_p)a.dir + (size_t)li0 * sizeof(PeakDir));
+         if (lanev < ndir) glb_st4(gdir + (unsigned)hd * (unsigned)sizeof(PeakDir), dv); } };
    SF_PROF_DECL
    for (int tile = tile_lo; tile < ntiles; tile += G, par ^= 1) {
       // (conditions on the thread index alone are the same in every tile step: the compiler computes them once, as wave masks in scalar registers - more than
@@ -901,35 +903,51 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       SF_PROF(0)
       __syncthreads();
       SF_PROF(1)
+      // (round 6: the stores of the lists in front FIRST, the next tile's loads behind them.  The memory pipeline of a CU is in order: behind the loads - twenty
+      //  waves' 5 KB each, every line of them a miss - a store waited until the misses had drained, 1 500 cycles a list; a quarter of a tile step's time)
+      if (tid == 0 && tile > tile_lo && a.qtile) {      // (every tile in front of the tape's last one is whole: its word is the complement of what the waves saw)
+         a.qtile[tile - G] = (uint16_t)(~s_noisy[par ^ 1] & ((1u << kSfGroups) - 1u)); s_noisy[par ^ 1] = 0; }
+      SF_PROF2(1)
+      if (p_tile >= 0) { copy_part(p_tile, p_rec_lo, p_rec_hi, p_bad, par ^ 1, lanel); p_tile = -1; rtfe_wave_sync(); }      // (of the tile in front)
+      SF_PROF2(2)
       if (tile + G < ntiles && tile + G >= inside_lo && tile + G <= inside_hi) fetch(tile + G, tidl, voffl);
-      if (tid == 0 && tile > tile_lo && a.qtile) { sf_publish_quiet(s_noisy[par ^ 1], tile - G, a.nrows, a.qtile); s_noisy[par ^ 1] = 0; }
-      if (p_tile >= 0) { copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad); p_tile = -1; rtfe_wave_sync(); }      // (the lists of the tile in front: a.defer)
-      if (SPL && prev_tile >= 0 && cut != 1) { copy_out3(prev_tile, par ^ 1); rtfe_wave_sync(); }
+      SF_PROF2(0)
       // ---- 2. quiet groups: flat 16-byte reads of the tile proper; a ballot of 64 vectors lies in one or two groups (several screens: the first launch's business) ----
       SF_PROF(2)
       // (round 6: a group is quiet only if EVERY sample of it is, and inside a block every part of a group carries signal - as k_quiet does, a group's first
       //  128 bytes are looked at first, eight lanes a group, and the rest of it - one more round of the wave - only where those are quiet: the gaps.  A wave
       //  takes three or four of the tile's fourteen groups.  The same bits; a tile inside a block costs one round of the old four.)
+      // The step's LDS reads that depend on nothing but the tile are issued TOGETHER, ahead of the arithmetic on any of them - the groups' first lines, the
+      // strips' rows, the split head's rows: one round trip for the three passes instead of three (a wave's step is a chain of latencies).
+      static_assert(VPG - 8 <= 64 && (kSfGroups + NP - 1) / NP + 1 <= 8, "a group's rest is one round of a wave; a wave's groups' first lines, eight lanes each, too");
+      const int g0 = wave * kSfGroups / NP, ng = (wave + 1) * kSfGroups / NP - g0;      // (3 4 3 4 of the fourteen groups for four waves, 4 5 5 for three)
+      const int4 *tv = reinterpret_cast<const int4 *>(xs) + VOWN0;
+      int4 qv = make_int4(0, 0, 0, 0);
+      if (a.qtile && lanel < 8 * ng) qv = tv[(g0 + (lanel >> 3)) * VPG + (lanel & 7)];
+      uint32_t x[kSfStrip + 2];
+      const int r3 = wave * PR3 + R3 * (lane < LA3 ? lane : LA3 - 1);
+      {  const lds_cp base = xsl + (HL + kSfStrip * lane) * RB + 4 * pair;
+         // (the rows of a pair are only 2-byte aligned in LDS - rows are 2 NT bytes apart -, and a misaligned ds_read_b32 costs 33 cycles a wave: two aligned 16-bit reads per row)
+         #pragma unroll
+         for (int i = 0; i < kSfStrip + 2; ++i) x[i] = (uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB) | ((uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB + 2) << 16);
+      }
       if (a.qtile) {
-         static_assert(VPG - 8 <= 64 && (kSfGroups + NP - 1) / NP + 1 <= 8, "a group's rest is one round of a wave; a wave's groups' first lines, eight lanes each, too");
-         const int g0 = wave * kSfGroups / NP, ng = (wave + 1) * kSfGroups / NP - g0;      // (3 4 3 4 of the fourteen groups for four waves, 4 5 5 for three)
-         const int4 *tv = reinterpret_cast<const int4 *>(xs) + VOWN0;
          const uint32_t q2pk = pk_dup((int)q2);
          auto noisy4 = [&](const int4 v) -> bool {
             const uint32_t m = pk_maxu(pk_maxu(pk_addu((uint32_t)v.x, qpk), pk_addu((uint32_t)v.y, qpk)),
                                        pk_maxu(pk_addu((uint32_t)v.z, qpk), pk_addu((uint32_t)v.w, qpk)));
             return pk_maxu(m, q2pk) != q2pk; };
-         bool n1 = false;
-         if (lanel < 8 * ng) n1 = noisy4(tv[(g0 + (lanel >> 3)) * VPG + (lanel & 7)]);
-         const u64 nb = __ballot(n1);
-         unsigned int bits = 0;
-         #pragma nounroll
-         for (int b = 0; b < ng; ++b) {
-            if ((nb >> (8 * b)) & 0xffull) { bits |= 1u << (g0 + b); continue; }
-            bool n2 = false;                                                        // the first line is quiet: the rest of the group
+         const u64 nb = __ballot(noisy4(qv));                                       // (lanes that read nothing hold zeros: quiet)
+         // byte b of nb = the eight lanes of group g0 + b: "any bit of the byte" folded into its lowest bit, the eight of them gathered (scalar, no branch)
+         u64 z = nb | (nb >> 4); z |= z >> 2; z |= z >> 1; z &= 0x0101010101010101ull;
+         unsigned int bits = (unsigned int)((z * 0x0102040810204080ull) >> 56);      // (relative to g0) groups known to be noisy
+         unsigned int redo = ~bits & ((1u << ng) - 1u);                             // ... whose first line is quiet
+         for (; redo; redo &= redo - 1) {                                            // (a gap): the rest of the group
+            const int b = __ffs((int)redo) - 1;
+            bool n2 = false;
             if (lanel < VPG - 8) n2 = noisy4(tv[(g0 + b) * VPG + 8 + lanel]);
-            if (__ballot(n2)) bits |= 1u << (g0 + b); }
-         if (lane == 0 && bits) atomicOr(&s_noisy[par], bits); }
+            if (__ballot(n2)) bits |= 1u << b; }
+         if (lane == 0 && bits) atomicOr(&s_noisy[par], bits << g0); }
       SF_PROF(3)
       if (cut != 1) {
          // ---- 3. candidate samples: local extremum + amplitude, one lane per 14-row strip of a pair of heads.  The rows of a pair are
@@ -937,10 +955,6 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          // 16-bit reads per row instead ----
          uint32_t tm = 0, bm = 0;
          {
-            const lds_cp base = xsl + (HL + kSfStrip * lane) * RB + 4 * pair;
-            uint32_t x[kSfStrip + 2];
-            #pragma unroll
-            for (int i = 0; i < kSfStrip + 2; ++i) x[i] = (uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB) | ((uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB + 2) << 16);
             // (round 6: the rows' "rising into" / "falling into" bits are gathered first - bit j of a half: x[j] lies above x[j - 1] on the signal clamped at the
             //  floor / below it on the signal clamped at the ceiling - and "rises into the row and not out of it" is made once per strip from the two masks,
             //  not per row: 8 instead of 11 vector instructions a row)
@@ -962,16 +976,15 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
                tm &= mk | (mk << 16); bm &= mk | (mk << 16); } }
          // split: the same for this wave's part of the last head - R3 rows a lane, the sample in the low half of the packed operations
          uint32_t m3 = 0, b3 = 0;                                             // candidates / the bottoms among them, bit i = row r3 + i
-         const int r3 = wave * PR3 + R3 * (lane < LA3 ? lane : LA3 - 1);
          if (SPL) {
-            const lds_cp base = xsl + (HL + r3) * RB + 2 * H3;
-            uint32_t x[R3 + 2];
+            uint32_t x3[R3 + 2];      // (these six reads stay here: hoisted with the others they cost the kernel its seventh wave per SIMD - a prefetched vector spilled)
+            const lds_cp base3 = xsl + (HL + r3) * RB + 2 * H3;
             #pragma unroll
-            for (int i = 0; i < R3 + 2; ++i) x[i] = (uint32_t)(uint16_t)lds_i16(base + (i - 1) * RB);
-            uint32_t yc = pk_max(x[0], at), zc = pk_min(x[0], ab), ru = 0, fd = 0;
+            for (int i = 0; i < R3 + 2; ++i) x3[i] = (uint32_t)(uint16_t)lds_i16(base3 + (i - 1) * RB);
+            uint32_t yc = pk_max(x3[0], at), zc = pk_min(x3[0], ab), ru = 0, fd = 0;
             #pragma unroll
             for (int i = 1; i < R3 + 2; ++i) {
-               const uint32_t yn = pk_max(x[i], at), zn = pk_min(x[i], ab);
+               const uint32_t yn = pk_max(x3[i], at), zn = pk_min(x3[i], ab);
                ru = (ru >> 1) | (pk_subs(yc, yn) & 0x8000u);
                fd = (fd >> 1) | (pk_subs(zn, zc) & 0x8000u);
                yc = yn; zc = zn; }
@@ -987,6 +1000,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
          SF_PROF(4)
          // ---- 4. the wave's candidates, compacted into a list ordered by (head, row); rounds of 64 ----
          int rec_lo = 0, rec_hi = 0, rec_3 = 0;                                // records in this wave's lists
+         const glb_p gtile = tile_pool(tile);
          bool bad = false;
          if (cut != 2) {
             uint32_t mlo = (tm | bm) & 0xffffu, mhi = (tm | bm) >> 16;
@@ -997,13 +1011,28 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
             bad = ncw > wave_cap;
             if (!bad && ncw > 0) {
                const int excl = incl - cnt;
-               int o2 = excl & 0x3ff;
-               for (; mlo; mlo &= mlo - 1) { const int b2 = __ffs((int)mlo) - 1; wlist[o2++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> b2) & 1u) << 14)); }
-               o2 = n_lo + ((excl >> 10) & 0x3ff);
-               for (; mhi; mhi &= mhi - 1) { const int b2 = __ffs((int)mhi) - 1; wlist[o2++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> (16 + b2)) & 1u) << 14) | 0x8000u); }
-               if (SPL) {
-                  o2 = n_lo + n_hi + (excl >> 20);
-                  for (; m3; m3 &= m3 - 1) { const int b2 = __ffs((int)m3) - 1; wlist[o2++] = (uint16_t)((r3 + b2) | (((b3 >> b2) & 1u) << 14) | 0x2000u); } }
+               // (round 6: a lane's first two candidates of each list are listed by straight-line code - a lane without one stores to the spare entry behind the
+               //  list -, what is left by the loops: a strip of 14 rows seldom holds more than two flux transitions, and the loops' branches were a tenth of
+               //  a step's instructions)
+               auto put2 = [&](uint32_t &m, int &o2, const int rowbase, const uint32_t bots, const uint32_t tag) {
+                  #pragma unroll
+                  for (int u = 0; u < 2; ++u) {
+                     const bool has = m != 0u;
+                     const int b2 = has ? __ffs((int)m) - 1 : 0;
+                     wlist[has ? o2 : wave_cap] = (uint16_t)((uint32_t)(rowbase + b2) | (((bots >> b2) & 1u) << 14) | tag);
+                     o2 += has ? 1 : 0; m &= m - 1u; } };
+               int o_lo = excl & 0x3ff, o_hi = n_lo + ((excl >> 10) & 0x3ff), o_3 = n_lo + n_hi + (excl >> 20);
+#ifndef RTFE_SF_PUT2
+#define RTFE_SF_PUT2 0      /* measured: 0.645 ms with it, 0.632 without - the straight-line code costs more vector instructions than the loops' branches it saves */
+#endif
+               if (RTFE_SF_PUT2) {
+                  put2(mlo, o_lo, kSfStrip * lane, bm, 0u);
+                  put2(mhi, o_hi, kSfStrip * lane, bm >> 16, 0x8000u);
+                  if (SPL) put2(m3, o_3, r3, b3, 0x2000u); }
+               if (__ballot((mlo | mhi | m3) != 0u)) {
+                  for (; mlo; mlo &= mlo - 1) { const int b2 = __ffs((int)mlo) - 1; wlist[o_lo++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> b2) & 1u) << 14)); }
+                  for (; mhi; mhi &= mhi - 1) { const int b2 = __ffs((int)mhi) - 1; wlist[o_hi++] = (uint16_t)((kSfStrip * lane + b2) | (((bm >> (16 + b2)) & 1u) << 14) | 0x8000u); }
+                  if (SPL) for (; m3; m3 &= m3 - 1) { const int b2 = __ffs((int)m3) - 1; wlist[o_3++] = (uint16_t)((r3 + b2) | (((b3 >> b2) & 1u) << 14) | 0x2000u); } }
                rtfe_wave_sync();
                SF_PROF(5)
                #pragma nounroll
@@ -1018,6 +1047,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
                   uint32_t w0 = 0, w1 = 0;
                   int st = pk_fast_w<W>(cx, head, cpos, cbot, w0, w1);
                   if (!live) st = 0;
+                  SF_PROF2(4)
                   if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
                      const int hidx = atomicAdd(a.hard_count, 1);
                      if (hidx < a.hard_cap) {
@@ -1033,24 +1063,24 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
                   const int ir = wave_incl_scan(vr << sh, lane);
                   const int myr = (((ir >> sh) & 0xff) - vr) + (sel == 2 ? rec_3 : (sel ? rec_hi : rec_lo));
                   if (vr && 16 * (myr + 1) <= (sel == 2 ? cap3 : hcap)) {      // 16 bytes: the record, its margin block behind it
-                     const lds_p slot = sel == 2 ? slot_3 : (sel ? slot_hi : slot_lo);
-                     lds_u32p rp = reinterpret_cast<lds_u32p>(slot) + 4 * myr;
                      const uint2 mb = (cut == 5 || (w1 & 0xfffffffeu) == 0xffff8000u) ? make_uint2(0, 0) : pk_margins_w<W>(cx, head, cpos, cbot, w0);
-                     rp[0] = w0; rp[1] = w1; rp[2] = mb.x; rp[3] = mb.y; }
+                     const int4 rec = make_int4((int)w0, (int)w1, (int)mb.x, (int)mb.y);
+                     if (sel == 2) *reinterpret_cast<int4 *>(smem + L.part + wave * cap3 + 16 * myr) = rec;      // (the split head's part: staged)
+                     else if (cut != 6) glb_st16(gtile + (unsigned)((h_lo + sel) * hcap + 16 * myr), rec); }         // (the pair's lists: where they belong)
                   const int tr = wave_last(ir);
-                  rec_lo += tr & 0xff; rec_hi += (tr >> 8) & 0xff; rec_3 += (tr >> 16) & 0xff; } } }
+                  rec_lo += tr & 0xff; rec_hi += (tr >> 8) & 0xff; rec_3 += (tr >> 16) & 0xff;
+                  SF_PROF2(5) } } }
          // ---- 5. this wave's two lists leave (now, or - a.defer - at the start of the next tile step); its part of the last head's waits for the others' counts ----
          rtfe_wave_sync();
          if (SPL && lane == 0) s_part[par][wave] = (unsigned short)((bad || 16 * rec_3 > cap3) ? 0xffff : rec_3);
-         if (defer) { p_tile = tile; p_rec_lo = rec_lo; p_rec_hi = rec_hi; p_bad = bad; }
-         else copy_out(tile, rec_lo, rec_hi, bad);
+         p_tile = tile; p_rec_lo = rec_lo; p_rec_hi = rec_hi; p_bad = bad;
          rtfe_wave_sync(); }
+      SF_PROF2(6)
       SF_PROF(6)
       __syncthreads();
       SF_PROF(7) }
    SF_PROF_END
-   if (p_tile >= 0) copy_out(p_tile, p_rec_lo, p_rec_hi, p_bad);
-   if (SPL && last_tile >= 0 && cut != 1) copy_out3(last_tile, par ^ 1);
+   if (p_tile >= 0) copy_part(p_tile, p_rec_lo, p_rec_hi, p_bad, par ^ 1, lane);
    if (tid == 0 && last_tile >= 0 && a.qtile) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);
    if (dbg3 && lane == 0) {
       atomicAdd(&a.dbg[3], (unsigned long long)pn_bytes); atomicAdd(&a.dbg[4], (unsigned long long)pn_hard); atomicAdd(&a.dbg[5], (unsigned long long)pn_rounds);

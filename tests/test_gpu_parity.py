@@ -32,7 +32,7 @@ def test_golden_tapes(name, tmp_path, gpu):
 
 @pytest.mark.parametrize("name,knobs", [("nrzi9", {"RTFE_PK_SLOT": "64"}), ("nrzi9_m", {"RTFE_PK_SLOT": "96"}),      # lists that outgrow their slot: bursts redone on the samples
                                         ("nrzi9", {"RTFE_SIFT_GENERIC": "1"}), ("nrzi7", {"RTFE_SIFT_GENERIC": "1"}),  # the general k_sift where k_sift_s would run
-                                        ("nrzi9", {"RTFE_SIFT_PLAIN": "0"}), ("nrzi7", {"RTFE_SIFT_PLAIN": "0"}), ("nrzi9_m", {"RTFE_SIFT_DEFER": "0"}),  # k_sift_s with its knobs at run time (what -invert, the tools' counters and cut-offs take)
+                                        ("nrzi9", {"RTFE_SIFT_PLAIN": "0"}), ("nrzi7", {"RTFE_SIFT_PLAIN": "0"}), ("nrzi9_m", {"RTFE_SIFT_PLAIN": "0"}),  # k_sift_s with its knobs at run time (what -invert, the tools' counters and cut-offs take)
                                         ("nrzi9", {"RTFE_GAIN_FAST": "0"}), ("nrzi9_m", {"RTFE_GAIN_FAST": "0"}),      # every detection through the chains' general step
                                         ("nrzi9_skew", {"RTFE_GAIN_FAST": "0", "RTFE_SIFT_GENERIC": "1"}),
                                         ("gcr", {"RTFE_PEAK_PATH": "1"}), ("gcr_m", {"RTFE_PEAK_PATH": "1", "RTFE_PK_SLOT": "256"}),

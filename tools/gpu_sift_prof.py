@@ -17,6 +17,8 @@ for i in range(3):
 torch.cuda.synchronize()
 st = wl.fe.scan_stats(res)
 names = ["tile->LDS (+wait rows)", "barrier 1", "loads + copy-out", "quiet", "strips", "compaction", "rounds + tail", "barrier 2"]
+if "prof2" in os.environ.get("RTFE_LIB_PATH", ""):
+    names = ["next tile's loads", "quiet word out", "pairs' lists out", "split head's list out", "round: derivation", "round: placement", "tail", "everything else"]
 tiles = (wl.nrows + 895) // 896
 waves = 4 if wl.cfg.ntrks == 9 else 3
 pc = st["phase_cycles"]

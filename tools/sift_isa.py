@@ -19,7 +19,7 @@ def main():
     os.makedirs("/tmp/isa", exist_ok=True)
     src = "/tmp/isa/sift_one.hip"
     with open(src, "w") as f:
-        f.write('#include "rtfe_sift.hip"\nnamespace rtfe { template __global__ void k_sift_s<%d, %d, 5, true>(const SfArgs); }\n' % (W, NT))
+        f.write('#include "rtfe_sift.hip"\nnamespace rtfe { template __global__ void k_sift_s<%d, %d, 6, true>(const SfArgs); }\n' % (W, NT))
     flags = [x for x in b.HIP_FLAGS if x not in ("-shared", "-fPIC")]
     cmd = [b.HIPCC] + flags + extra + ["-gline-tables-only", "-S", "--cuda-device-only", "-o", "/tmp/isa/sift.s", src]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
