@@ -47,9 +47,10 @@ CONFIGS = {
                workload="C2: synthetic 9-track 800 BPI NRZI, 781.25 kHz, 1 parmset"),
     "C3": dict(kind="pe", rows=1e9, nparmsets=1, find_zeros=True, window_rows=None, ref_opts=["-nm", "-zeros"], port_opts=["-zeros"], overlap=True,
                workload="C3: synthetic 9-track 1600 BPI PE, 1.5625 MHz, -zeros (zero-crossing path), 1 parmset"),
-    # (C4 in three fragments: a fragment's chains have a latency floor, and its worst-case event arena - 1/8 event per track-sample and set plus 128
-    #  per possible burst - is 162 GiB at 4.0e8 rows; two fragments of 2^29 rows ask for 216 GiB each and leave no room beside the tape)
-    "C4": dict(kind="gcr", rows=1e9, nparmsets=8, find_zeros=False, window_rows=3 << 27, ref_opts=[], port_opts=["-m"],
+    # (C4 in ONE launch since round 6.  rtfe_event_capacity is the worst case - every gap-length quiet run a burst, 128 events of slack per list and burst: 288 GB of slack
+    #  alone at 1e9 rows x 8 sets, which forced three fragments (262 ms; a fragment's chains have a latency floor).  The arena is now sized for one burst per 1e4 rows
+    #  (bursts_per_row: the tape holds one per ~4e5; an arena that is too small is flagged RTFE_F_EVENT_OVERFLOW per burst, never silent - flagged_bursts on the line): 159 GB)
+    "C4": dict(kind="gcr", rows=1e9, nparmsets=8, find_zeros=False, window_rows=None, bursts_per_row=1e-4, ref_opts=[], port_opts=["-m"],
                workload="C4: synthetic 9-track 6250 BPI GCR (9042 fci), 6.25 MHz, 8-parmset batched sweep"),
     # not BASELINE.json configurations: the single-set shapes of C4 / C3's formats on the peak detector (VERDICT r3 item 1 asks for them), compact lines only
     "G1": dict(kind="gcr", rows=1e9, nparmsets=1, find_zeros=False, window_rows=None, ref_opts=["-nm"], port_opts=[],
@@ -218,7 +219,13 @@ class Workload:
             self.cfg.screen_floor_height = float(conf["fixed_floor"])
         if os.environ.get("RT_BENCH_SCREEN_FLOOR"):                     # (experiments: the candidate screen's assumed lower bound of the learned peak height, volts)
             self.cfg.screen_floor_height = float(os.environ["RT_BENCH_SCREEN_FLOOR"])
-        make = (lambda: frontend.FrontEnd(self.cfg, device=str(dev))) if fe_factory is None else (lambda: fe_factory(self.cfg))
+        def _make_gpu():
+            f = frontend.FrontEnd(self.cfg, device=str(dev))
+            bpr = os.environ.get("RT_BENCH_BURSTS_PER_ROW") or conf.get("bursts_per_row")
+            if bpr:                           # (the event arena for this many bursts instead of the worst case; an overflow would be flagged and is on the line)
+                f.bursts_hint = max(1024, int(float(total_rows) * float(bpr)))
+            return f
+        make = _make_gpu if fe_factory is None else (lambda: fe_factory(self.cfg))
         self.make = make
         self.fe = make()
         # fragments of the resident rows (one when the workspace fits)

@@ -430,6 +430,13 @@ class FrontEnd:
             mb = int(lib.rtfe_max_bursts(self.h, nrows))
             cap = int(lib.rtfe_event_capacity(self.h, nrows))
             P, T = len(self.cfg.parmsets), self.cfg.ntrks
+            hint = getattr(self, "bursts_hint", None)
+            if key == "scan" and hint:
+                # rtfe_event_capacity is the worst case: every run of gap-length quiet rows a burst (nrows / 512 of them), 128 events of slack each.  A caller who
+                # knows its tape holds far fewer may bring a smaller arena - the scan flags a burst that no longer fits RTFE_F_EVENT_OVERFLOW (its lists stay
+                # empty, nothing is written outside the arena) and the caller comes back with the full size.  1e9 rows x 8 sets: 288 GB of slack alone.
+                frac = self.cfg.events_per_sample_cap or 0.125
+                cap = min(cap, int((nrows * frac + 128.0 * int(hint) + 256) * P * T) + 4096)
             self._cache[k] = dict(
                 ws=be.empty(lib.rtfe_workspace_bytes(self.h, nrows)), bursts=be.empty(mb * BURST_DTYPE.itemsize),
                 nbursts=be.empty(16), counts=be.empty(mb * P * T * 4), events=be.empty(cap * 16), max_bursts=mb, cap=cap, nrows=nrows)
