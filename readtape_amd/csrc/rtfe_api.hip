@@ -527,7 +527,10 @@ static size_t pk_pool_bytes(const rtfe_handle *h, int64_t nrows) {      // one s
 // ... | the candidates k_sift deferred (k_sift_hard) | their overflow slots
 // (two per tile and list: a clean NRZI tape defers 0.05 % of its candidates, a noisy parameter sweep with wide windows one or two per tile and list;
 //  past the capacity a candidate becomes a "minimum unknown" record, and the chain that gets there gives up)
-static long long pk_hard_cap(const rtfe_handle *h, int64_t nrows) { const long long c = pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * 2 + 4096; return c > 0x3fffffffll ? 0x3fffffffll : c; }
+static long long pk_hard_cap(const rtfe_handle *h, int64_t nrows) {
+   const long long wgs = pk_tiles_for(nrows) < (long long)h->num_cus * 8 ? pk_tiles_for(nrows) : (long long)h->num_cus * 8;      // (k_sift_s: a wave takes the list's places a chunk at a time)
+   const long long c = pk_tiles_for(nrows) * h->dev.nscreens * h->dev.ntrks * 2 + 4096 + wgs * 4 * kSfHardChunk * h->dev.nscreens;
+   return c > 0x3fffffffll ? 0x3fffffffll : c; }
 static size_t ws_pkhard_off(const rtfe_handle *h, int64_t nrows) { return ws_pkpool_off(h, nrows) + pk_pool_bytes(h, nrows); }
 static size_t ws_pkqtile_off(const rtfe_handle *h, int64_t nrows);
 static size_t ws_pkovf_off(const rtfe_handle *h, int64_t nrows) { return ws_pkhard_off(h, nrows) + (h->dev.peak_path ? (((size_t)pk_hard_cap(h, nrows) * sizeof(SfHard) + 255) & ~(size_t)255) : 0); }

@@ -747,6 +747,8 @@ __global__ void __launch_bounds__(MAXT, WPS) k_sift(const DevCfg *__restrict__ c
 // k_sift_s: k_sift for ONE window width W and a track count NT known at compile time (every LDS address an immediate offset, no
 // loop over screens, no division), straight-line predicated code in the per-candidate part.  Same tile order, same lists.
 // ------------------------------------------------------------------------------------------------
+constexpr int kSfHardChunk = 32;      // places of the hard list a wave of k_sift_s takes at a time (<= 64: a wave marks what it leaves unused with one store)
+__device__ __forceinline__ SfHard sf_hard_none() { SfHard h; h.tile = 0; h.pos = 0; h.head = 0xff; h.screen = 0; return h; }      // a place nobody took (k_sift_hard passes over it)
 struct SfArgs {
    const int16_t *rows; long long nrows; int ntiles;
    uint16_t *qtile; PeakDir *dir; unsigned char *pool; SfHard *hard; int hard_cap; int *hard_count; unsigned long long *dbg;
@@ -847,6 +849,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
    // (stores issued in front of a step's first s_waitcnt vmcnt(0) would be waited for in full: gfx9 counts loads and stores in one counter).
    int p_tile = -1, p_rec_lo = 0, p_rec_hi = 0;
    bool p_bad = false;
+   int h_next = 0, h_end = 0;      // the wave's chunk of the hard list: [h_next, h_end) are its free places
    // (measured and not kept: the pair's records of a step's last round held in registers until that point too - their acknowledgements are on the way when the
    //  next step asks for its prefetched rows, ~1 000 cycles of its s_waitcnt vmcnt(0) -: the wait shrank, the store behind the barrier cost more: 0.643 / 0.632 ms)
    auto tile_pool = [&](const int tile) -> glb_p {      // the pool slot of the tile's head 0: [tile][screen][head]
@@ -1048,14 +1051,32 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
                   int st = pk_fast_w<W>(cx, head, cpos, cbot, w0, w1);
                   if (!live) st = 0;
                   SF_PROF2(4)
-                  if (st == 2) {                                             // (0.06 % of the candidates of a clean NRZI tape)
-                     const int hidx = atomicAdd(a.hard_count, 1);
-                     if (hidx < a.hard_cap) {
-                        SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)head; hd.screen = (uint8_t)a.sc;
-                        a.hard[hidx] = hd;
-                        w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
-                     else { w0 = pk_w0(cpos, false, cpos + 1, 0, cx.W - 2, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
-                     st = 1; }
+                  // Deferred candidates (0.004 % of a clean NRZI tape's, 5 % at 60 mV rms of noise: 2.5 a wave and tile step) take their places in the hard list
+                  // from a CHUNK the wave owns: one atomic on the list's counter per kSfHardChunk of them.  (Round 6: an atomic a round - 800 000 of them on one
+                  // address, each waited for with the prefetched rows in flight - was what a noisy tape's k_sift_s spent its time on: 7.4 ms against 0.63.)
+                  const u64 hm = __ballot(st == 2);
+                  if (hm) {
+                     const int nh = __popcll(hm);
+                     if (h_next + nh > h_end) {
+                        if (h_next + lane < h_end && h_next + lane < a.hard_cap) a.hard[h_next + lane] = sf_hard_none();      // (what is left of the old chunk: nobody's)
+                        const int want = nh > kSfHardChunk ? nh : kSfHardChunk;
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(a.hard_count, want);
+#ifdef RTFE_CPU_EMUL
+                        base = __shfl(base, 0);
+#else
+                        base = __builtin_amdgcn_readfirstlane(base);
+#endif
+                        h_next = base; h_end = base + want; }
+                     if (st == 2) {
+                        const int hidx = h_next + __popcll(hm & ((1ull << lane) - 1ull));
+                        if (hidx < a.hard_cap) {
+                           SfHard hd; hd.tile = (uint32_t)tile; hd.pos = (uint16_t)cpos; hd.head = (uint8_t)head; hd.screen = (uint8_t)a.sc;
+                           a.hard[hidx] = hd;
+                           w0 = (uint32_t)hidx; w1 = 0xffff8001u; }
+                        else { w0 = pk_w0(cpos, false, cpos + 1, 0, cx.W - 2, 0); w1 = 0xffff8000u; }      // (no room: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
+                        st = 1; }
+                     h_next += nh; }
                   if (dbg3) { pn_hard += (unsigned)__popcll(__ballot(w1 == 0xffff8001u)); ++pn_rounds; }
                   if (cut == 4) { rec_lo += (int)(w0 & 1u); continue; }        // (RTFE_CUT=4: the evaluation without the placement)
                   const int vr = st;
@@ -1081,6 +1102,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
       SF_PROF(7) }
    SF_PROF_END
    if (p_tile >= 0) copy_part(p_tile, p_rec_lo, p_rec_hi, p_bad, par ^ 1, lane);
+   if (h_next + lane < h_end && h_next + lane < a.hard_cap) a.hard[h_next + lane] = sf_hard_none();      // (the unused places of the wave's last chunk)
    if (tid == 0 && last_tile >= 0 && a.qtile) sf_publish_quiet(s_noisy[par ^ 1], last_tile, a.nrows, a.qtile);
    if (dbg3 && lane == 0) {
       atomicAdd(&a.dbg[3], (unsigned long long)pn_bytes); atomicAdd(&a.dbg[4], (unsigned long long)pn_hard); atomicAdd(&a.dbg[5], (unsigned long long)pn_rounds);
@@ -1107,6 +1129,7 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
    if (n > hard_cap) n = hard_cap;
    for (int i = blockIdx.x * 4 + wv; i < n; i += gridDim.x * 4) {
       const SfHard hd = hard[i];
+      if (hd.head == 0xff) continue;                                       // (a place of a wave's chunk that no candidate took)
       const DevScreen &S = cfg.screen[hd.screen];
       PkCtxT<PkColPre> cx;
       cx.t.tape.rows = rows; cx.t.tape.t0 = (long long)hd.tile * kSfTile; cx.t.tape.nrows = nrows; cx.t.tape.ntrks = cfg.ntrks; cx.t.tape.sg = cfg.invert ? -1 : 1;

@@ -23,6 +23,9 @@ tiles = (wl.nrows + 895) // 896
 waves = 4 if wl.cfg.ntrks == 9 else 3
 pc = st["phase_cycles"]
 tot = sum(pc)
+if os.environ.get("RTFE_DEBUG") == "3":      # (the product build with its counters on: deferred candidates and rounds)
+    print("deferred candidates", pc[4], "rounds", pc[5], "per wave-step %.2f" % (pc[5] / (tiles * waves)), "tile steps of wave 0", pc[7], "redone", st["redone"], "of", st["bursts"])
+    sys.exit(0)
 print("rows", wl.nrows, "tiles", tiles, "wave-steps", tiles * waves, "sum of cycles per wave-step", round(tot / (tiles * waves)))
 for n, c in zip(names, pc):
     print(f"  {n:26s} {c / (tiles * waves):9.0f} cycles per wave and tile step  {100.0 * c / tot:5.1f} %")
