@@ -1117,19 +1117,25 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
 constexpr int kHardCol = 320;      // samples of a candidate's head its wave keeps in LDS: kPkBack + 3 W + 16 <= 230 for W <= 50, what is outside comes from HBM
 __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
                                                    const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf, int *__restrict__ extra) {
-   // A wave per candidate: its 64 lanes fetch the head's samples the walk can read - one round trip -, make "rescan forced" and "leftmost
-   // window minimum" for every row around the candidate (a few rows a lane), and lane 0 walks on those tables.  (Round 4: lane 0 made them
-   // as it went - pk_async over a window at every row it stepped back: ~1 500 dependent LDS reads, 60 - 100 us a candidate, 0.11 ms per C2 scan.)
-   __shared__ int16_t s_col[4][kHardCol];
-   __shared__ int16_t s_am[4][kHardCol];
-   __shared__ unsigned char s_as[4][kHardCol];
+   // SIXTEEN LANES per candidate (round 6; a wave per candidate before): they fetch the head's samples the walk can read - one round trip -, make "rescan
+   // forced" and "leftmost window minimum" for every row around the candidate (a few rows a lane), and the first of them walks on those tables.  What a
+   // candidate costs is that walk - one lane's loops over table entries, tens of microseconds -, so four of them share a wave: a tape with 60 mV rms of noise
+   // defers 1.2 million candidates per 1e8 rows (k_sift_hard 3.9 ms of a 9 ms scan), a clean one a few dozen.
+   // (Round 4: the walking lane made the tables as it went - pk_async over a window at every row it stepped back: ~1 500 dependent LDS reads, 60 - 100 us a candidate.)
+   constexpr int kSub = 16, kGroups = 256 / kSub;
+   __shared__ int16_t s_col[kGroups][kHardCol];
+   __shared__ int16_t s_am[kGroups][kHardCol];
+   __shared__ unsigned char s_as[kGroups][kHardCol];
    const DevCfg &cfg = *cfgp;
-   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+   const int sl = threadIdx.x & (kSub - 1), wv = threadIdx.x / kSub;
    int n = *hard_count;
    if (n > hard_cap) n = hard_cap;
-   for (int i = blockIdx.x * 4 + wv; i < n; i += gridDim.x * 4) {
-      const SfHard hd = hard[i];
-      if (hd.head == 0xff) continue;                                       // (a place of a wave's chunk that no candidate took)
+   for (int i0 = blockIdx.x * kGroups; i0 < n; i0 += gridDim.x * kGroups) {      // (the same trips for every lane of the workgroup: the wave-level fences below)
+      const int i = i0 + wv;
+      SfHard hd = sf_hard_none();
+      if (i < n) hd = hard[i];
+      const bool live = hd.head != 0xff;                                  // (0xff: a place of a wave's chunk that no candidate took, or none at all)
+      if (!live) { hd.head = 0; hd.screen = 0; }
       const DevScreen &S = cfg.screen[hd.screen];
       PkCtxT<PkColPre> cx;
       cx.t.tape.rows = rows; cx.t.tape.t0 = (long long)hd.tile * kSfTile; cx.t.tape.nrows = nrows; cx.t.tape.ntrks = cfg.ntrks; cx.t.tape.sg = cfg.invert ? -1 : 1;
@@ -1140,13 +1146,13 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       int ncol = kPkBack + 3 * S.W + 16;
       if (ncol > kHardCol) ncol = kHardCol;
       rtfe_wave_sync();
-      for (int k = lane; k < ncol; k += 64) s_col[wv][k] = (int16_t)cx.t.tape.at(r0 + k, (int)hd.head);
+      if (live) for (int k = sl; k < ncol; k += kSub) s_col[wv][k] = (int16_t)cx.t.tape.at(r0 + k, (int)hd.head);
       rtfe_wave_sync();
       cx.t.col = s_col[wv]; cx.t.r0 = r0; cx.t.n = ncol; cx.t.head = (int)hd.head;
       cx.t.as = s_as[wv]; cx.t.am = s_am[wv]; cx.t.k0 = S.W;
-      {  // row r0 + k, k >= W: its window is col[k - W + 1 .. k], the sample leaving it col[k - W] (pk_async_g / pk_argmin_g on the column)
+      if (live) {  // row r0 + k, k >= W: its window is col[k - W + 1 .. k], the sample leaving it col[k - W] (pk_async_g / pk_argmin_g on the column)
          const int W = S.W;
-         for (int k = W + lane; k < ncol; k += 64) {
+         for (int k = W + sl; k < ncol; k += kSub) {
             const int16_t *c0 = s_col[wv] + (k - W);
             const int v = c0[0];
             bool dom = true, sub = true;
@@ -1157,7 +1163,7 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
             s_as[wv][k] = (unsigned char)(sub || (dom && ye <= v));
             s_am[wv][k] = (int16_t)(k - W + best); } }
       rtfe_wave_sync();
-      if (lane != 0) continue;
+      if (!live || sl != 0) continue;
       PkSink sk; sk.n = 0;
       pk_bot(cx, sk, (int)hd.head, (int)hd.pos);
       unsigned char *slot = ovf + (size_t)i * kSfOvfBytes;

@@ -13,7 +13,6 @@ PY
 }
 EXTRA="--config N1 --steps 10 --warmup 2" one n1 A=1
 EXTRA="--config N1f --steps 5 --warmup 2" one n1f A=1
-EXTRA="--steps 20 --warmup 5" one c2 A=1
 EXTRA="--config M8 --steps 5 --warmup 2" one m8 A=1
-RTFE_LIB_PATH=$PWD/readtape_amd/librtfe_prof.so timeout 300 python tools/gpu_sift_prof.py N1 2>&1 | tail -9
+timeout 600 bash tools/gpu_profile.sh r06g_n1 --config N1 --steps 5 --warmup 2 --no-overlap 2>&1 | head -14
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_ingest.py -x -q -k "nrzi or peak or golden or c2 or C2 or nois or rare or floor" 2>&1 | tail -3
