@@ -826,7 +826,7 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
    t1(kTBursts);
    if (h->dev.find_zeros && !h->dev.differentiate && h->zeros_kernel) {          // -zeros: the lean kernel of its own (rtfe_zeros.hip)
       t0(kTZeros);
-      const dim3 zg(h->num_cus * (1024 / kZpThreads)), zb(kZpThreads);                     // persistent workgroups, a burst at a time
+      const dim3 zg(h->num_cus * (RTFE_ZP_WPS * 256 / kZpThreads)), zb(kZpThreads);                     // persistent workgroups, a burst at a time
       if (h->dev.ntrks == 9) hipLaunchKernelGGL(k_zeros<9>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);
       else if (h->dev.ntrks == 7) hipLaunchKernelGGL(k_zeros<7>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);
       else hipLaunchKernelGGL(k_zeros<0>, zg, zb, 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (long long)row_base, d_bursts, scratch, d_counts, d_events);

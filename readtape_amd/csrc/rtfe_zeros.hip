@@ -164,7 +164,10 @@ __device__ __forceinline__ int zp_first(u32 (*rec)[kZpThreads], int f, int lane,
 __device__ __forceinline__ u32 zp_canon_top(u32 top, u32 Pm1) { return top & zq_sar15(zq_sub(Pm1, top)); }
 __device__ __forceinline__ u32 zp_canon_bot(u32 bot, u32 Pm1) { return bot & zq_sar15(zq_add(bot, Pm1)); }
 
-template <int NT> __global__ void __launch_bounds__(kZpThreads, 4) k_zeros(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long row_base,
+#ifndef RTFE_ZP_WPS
+#define RTFE_ZP_WPS 4      /* waves per SIMD the register allocation is held to (experiments: tools/build_variant.py zpN -DRTFE_ZP_WPS=N) */
+#endif
+template <int NT> __global__ void __launch_bounds__(kZpThreads, RTFE_ZP_WPS) k_zeros(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows, long long row_base,
                                                                            rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch,
                                                                            uint32_t *__restrict__ counts, rtfe_event *__restrict__ events) {
    __shared__ DevCfg cfg;
