@@ -76,6 +76,16 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     sizes = [window_rows // 4 & ~1023, window_rows // 2 & ~1023] if (ramp and window_rows >= (1 << 20) and nrows > 2 * window_rows) else []
     while lo < nrows:
         w = sizes.pop(0) if sizes else window_rows
+        if ramp and not sizes and window_rows >= (1 << 20) and len(spans) >= 2 and nrows - lo <= 2 * window_rows and nrows - lo > (1 << 20):
+            # ... and drains sooner behind short last windows: what follows the last upload - its scan, its fetch, its replay - is in nobody's shadow.  The last
+            # two windows' worth of rows go as a half, a quarter and two eighths of what is left.
+            rest = nrows - lo
+            for frac in (2, 4, 8):
+                w2 = max(1 << 18, rest // frac & ~1023)
+                if lo + w2 < nrows:
+                    spans.append((lo, lo + w2)); lo += w2
+            spans.append((lo, nrows)); lo = nrows
+            break
         spans.append((lo, min(nrows, lo + w)))
         lo += w
     cap = window_rows + halo_rows
@@ -249,8 +259,10 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
     t_replay = 0.0
     for f in fes:                                         # set-up, like the pinned buffers and the device windows: the scan contexts' workspaces
         f._pack_buffers(f._buffers(cap), f._buffers(cap)["cap"] // 2)
-    # (and page-locked blocks for the windows' event lists in the host allocator's cache: a window's packed events are ~1 / 40 of its arena)
-    blk = [torch.empty(max(1 << 20, cap * ntrks * 16 // 40), dtype=torch.uint8, pin_memory=True) for _ in range(min(depth, 12))]
+    # (and page-locked blocks for the windows' event lists in the host allocator's cache.  A window's packed events are ~1 / 40 of its arena - C2: 27 MB of events in
+    #  31 - 35 MB of packed lists -, the allocator's blocks are powers of two, and a request one byte over 32 MB is a hipHostMalloc of 64 MB in the middle of the
+    #  pipeline: ~12 ms during which every thread that talks to the runtime waits (round 6's trace: the producer's event wait, the fetchers).  Blocks of the NEXT power of two.)
+    blk = [torch.empty(max(1 << 20, cap * ntrks * 16 // 20), dtype=torch.uint8, pin_memory=True) for _ in range(min(depth, 12))]
     del blk
     torch.cuda.synchronize(dev)
     gpu_ev = {}
@@ -340,7 +352,7 @@ def decode_file_streaming(path, tap_path, window_rows=1 << 24, halo_rows=1 << 17
             if res.nbursts:
                 if pool:
                     # sub-fragments: cut at the zone starts of evenly spaced bursts; one task (a Python thread) per window, native threads for its sub-fragments
-                    split = int(replay_split) * (2 if k + 2 >= len(spans) else 1)
+                    split = int(replay_split) * (4 if k + 3 >= len(spans) else (2 if k + 5 >= len(spans) else 1))      # (the last windows' replays have the threads to themselves)
                     nsub = max(1, min(split, nthreads, res.nbursts // 8))
                     cuts = [int(res.bursts[(res.nbursts * j) // nsub]["zone_first"]) for j in range(1, nsub)]
                     first = 0 if lo == 0 else int(res.bursts[0]["zone_first"])
