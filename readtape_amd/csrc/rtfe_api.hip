@@ -781,6 +781,8 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
                          (const unsigned char *)pkpool, (const GsSeg *)(wsb + ws_pksegs_off(h, nrows)), (const int *)&scratch->nsegs, pk_seg_cap(h, nrows), (const float *)(wsb + ws_pkgfire_off(h, nrows)), (int)(rtfe_max_bursts(h, nrows) * h->dev.nparm * h->dev.ntrks), d_rows, (long long)nrows);
       if (se != st) (void)hipStreamWaitEvent(st, h->ev_join2, 0);
       hipLaunchKernelGGL(k_publish, dim3(h->num_cus < 64 ? h->num_cus : 64), dim3(256), 0, st, h->d_dev, (long long)nrows, d_bursts, scratch, ctlp);
+      if (h->dev.nuset < h->dev.nparm)      // parameter sets the front end cannot tell apart were ONE chain: its events into the other sets' regions
+         hipLaunchKernelGGL(k_dup_sets, dim3(h->num_cus * 8), dim3(256), 0, st, (const DevCfg *)h->d_dev, (const rtfe_burst *)d_bursts, (const BurstScratch *)scratch, (const BurstCtl *)ctlp, d_counts, d_events);
       t1(kTEmit);
       if (stop_after < 5) { skip_rest(); return launch_check("rtfe_scan"); }
       t0(kTDecode);

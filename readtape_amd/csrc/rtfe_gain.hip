@@ -407,6 +407,18 @@ __device__ __forceinline__ bool gs_same(const GsState &a, const GsState &b) {
 // A chain between the kernels that walk it: k_gain (mode 0: from the burst's restart row until the baseline is fixed) -> k_gain_s (the
 // steady stretch: nothing but the common record) -> k_gain (mode 1: whatever k_gain_s stopped at, to the chain's end).
 enum { kChNone = 0, kChSteady = 1, kChGeneral = 2, kChDone = 3 };
+// The chains of a scan: (burst, DISTINCT parameter set, track).  Parameter sets that differ only in what the host decoders read are one chain (round 6 on this path; the
+// dense path since round 4: DevCfg::uset_*) - the reference's eight NRZI defaults are six (src/parmsets.c:77-88: sets 1 / 3 and 2 / 4 differ in clk_window alone); k_dup_sets
+// copies the chain's events into the other sets' regions behind k_publish.  Everything addresses a chain as before, ci = (b * nparm + pidx) * ntrks + trk, pidx = the chain's first set.
+struct ChainIx { int b, wi, pidx, trk, ci; };
+__device__ __forceinline__ int chain_count(const DevCfg &cfg, int nbursts) { return nbursts * cfg.nuset * cfg.ntrks; }
+__device__ __forceinline__ ChainIx chain_ix(const DevCfg &cfg, int cu) {
+   const int ntrks = cfg.ntrks, nwu = cfg.nuset * ntrks;
+   ChainIx x;
+   x.b = cu / nwu;
+   const int wu = cu - x.b * nwu, u = wu / ntrks;
+   x.trk = wu - u * ntrks; x.pidx = cfg.uset_rep[u]; x.wi = x.pidx * ntrks + x.trk; x.ci = x.b * cfg.nparm * ntrks + x.wi;
+   return x; }
 struct GsConst {                       // what a segment's lane needs to know about its chain (k_gain, mode 0, at the hand-over)
    unsigned long long ev_index;        // the chain's event list in the event arena
    float h, alpha, kr, km, rg_min, g_min;
@@ -425,13 +437,12 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks, nlists = cfg.nscreens * ntrks;
    const int lane = threadIdx.x;
    const float mv = cfg.maxvolts, lsb = cfg.lsb_per_volt;
-   const int nchains = scratch->nbursts * nwalk;
+   const int nchains = chain_count(cfg, scratch->nbursts);
    float *heights = s_heights + lane * 10;
    // (every lane of a wave goes through the same rounds - the wave votes on them - so a lane without a chain walks a finished one)
    for (int cbase = blockIdx.x * 64; cbase < nchains; cbase += gridDim.x * 64) {
-      const int ci = cbase + lane < nchains ? cbase + lane : nchains - 1;
-      const int b = ci / nwalk;
-      const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
+      const ChainIx cx_ = chain_ix(cfg, cbase + lane < nchains ? cbase + lane : nchains - 1);
+      const int ci = cx_.ci, b = cx_.b, wi = cx_.wi, pidx = cx_.pidx, trk = cx_.trk;
       const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady && (mode == 0 || cst[ci].status == kChGeneral);
       const rtfe_burst B = bursts[b];
       // (the chain's constants by value: a reference into the configuration block would be loaded again - a vector load, the lanes'
@@ -918,12 +929,12 @@ __global__ void __launch_bounds__(64) k_gain_join(const DevCfg *__restrict__ cfg
                                                   const BurstCtl *__restrict__ ctl, uint32_t *__restrict__ counts, float *__restrict__ chain_h, GsSeg *__restrict__ segs) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
-   const int nchains = scratch->nbursts * nwalk;
-   for (int ci = blockIdx.x * 64 + threadIdx.x; ci < nchains; ci += gridDim.x * 64) {
-      const int b = ci / nwalk;
+   const int nchains = chain_count(cfg, scratch->nbursts);
+   for (int cu = blockIdx.x * 64 + threadIdx.x; cu < nchains; cu += gridDim.x * 64) {
+      const ChainIx cx_ = chain_ix(cfg, cu);
+      const int ci = cx_.ci, b = cx_.b, wi = cx_.wi, pidx = cx_.pidx, trk = cx_.trk;
       if (ctl[b].status != kBurstReady || cst[ci].status != kChSteady) continue;
       ChainSt &cs = cst[ci];
-      const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
       const unsigned int cap = bursts[b].event_cap;
       const unsigned int nev0 = cs.w.nevents;
       unsigned int nev = nev0;
@@ -1033,11 +1044,11 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
                                               const GsSeg *__restrict__ segs) {
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks;
-   const int nchains = scratch->nbursts * nwalk;
+   const int nchains = chain_count(cfg, scratch->nbursts);
    const float mv = cfg.maxvolts;
-   for (int ci = blockIdx.x; ci < nchains; ci += gridDim.x) {
-      const int b = ci / nwalk;
-      const int wi = ci - b * nwalk, pidx = wi / ntrks, trk = wi - pidx * ntrks;
+   for (int cu = blockIdx.x; cu < nchains; cu += gridDim.x) {
+      const ChainIx cx_ = chain_ix(cfg, cu);
+      const int ci = cx_.ci, b = cx_.b, wi = cx_.wi, pidx = cx_.pidx, trk = cx_.trk;
       if (ctl[b].status != kBurstReady) continue;                        // (a burst the sample path redoes)
       const rtfe_burst B = bursts[b];
       const DevParm &P = cfg.parm[pidx];
@@ -1072,6 +1083,27 @@ __global__ void __launch_bounds__(256) k_emit(const DevCfg *__restrict__ cfgp, c
          continue; }
       const unsigned int nmine = nev - (skip1 - skip0);
       for (unsigned int t = threadIdx.x; t < nmine; t += blockDim.x) one(t < skip0 ? t : t + (skip1 - skip0)); } }
+
+// ------------------------------------------------------------------------------------------------
+// k_dup_sets: a chain's events into the regions of the other parameter sets it stands for (chain_ix) - a wave per (burst, such set, track), 16 bytes a lane,
+// the event's parameter-set byte its own.  Bursts the sample path redoes are left alone: k_decode walks every set of them.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dup_sets(const DevCfg *__restrict__ cfgp, const rtfe_burst *__restrict__ bursts, const BurstScratch *__restrict__ scratch,
+                                                  const BurstCtl *__restrict__ ctl, uint32_t *__restrict__ counts, rtfe_event *__restrict__ events) {
+   const DevCfg &cfg = *cfgp;
+   const int ntrks = cfg.ntrks, nparm = cfg.nparm, lane = threadIdx.x & 63;
+   const long long nlists = (long long)scratch->nbursts * nparm * ntrks;
+   for (long long li = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); li < nlists; li += (long long)gridDim.x * 4) {
+      const int b = (int)(li / (nparm * ntrks));
+      const int wi = (int)(li - (long long)b * nparm * ntrks), p = wi / ntrks, trk = wi - p * ntrks;
+      const int rep = cfg.uset_rep[cfg.uset_of[p]];
+      if (rep == p || ctl[b].status != kBurstDone) continue;      // (kBurstDone: k_publish's mark on a burst the chains finished)
+      const rtfe_burst B = bursts[b];
+      const uint32_t n = counts[((size_t)b * nparm + rep) * ntrks + trk];
+      const uint4 *src = reinterpret_cast<const uint4 *>(events + B.event_base + (size_t)(rep * ntrks + trk) * B.event_cap);
+      uint4 *dst = reinterpret_cast<uint4 *>(events + B.event_base + (size_t)(p * ntrks + trk) * B.event_cap);
+      for (uint32_t i = (uint32_t)lane; i < n; i += 64) { uint4 e = src[i]; e.w = (e.w & 0x00ffffffu) | ((uint32_t)p << 24); dst[i] = e; }      // (rtfe_event: trk, flags, left_distance, parmset)
+      if (lane == 0) counts[((size_t)b * nparm + p) * ntrks + trk] = n; } }
 
 // ------------------------------------------------------------------------------------------------
 // k_publish: burst table entries of the bursts the chains finished; stop rows for the ones the sample path redoes

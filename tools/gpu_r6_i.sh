@@ -1,6 +1,18 @@
 #!/bin/bash
 mkdir -p gpurun_out/r06i
-for i in 1 2 3 4 5; do timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --min-seconds 0.2 2>/dev/null | python -c "
-import json,sys
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); e=j['e2e']; print('e2e', e.get('value'), e.get('seconds'), 'windows', e.get('windows'), 'replay ev/s/thread', e.get('host_replay_events_per_s_per_thread'), 'identical', e.get('tap_identical_to_cpu_port'), e.get('error'))"; done
-timeout 900 python -m pytest tests/test_gpu_ingest.py -x -q 2>&1 | tail -2
+one() { local label=$1; shift
+   env "$@" timeout 900 python bench.py --no-cpu-baseline --no-e2e --no-other-configs $EXTRA > gpurun_out/r06i/$label.json 2> gpurun_out/r06i/$label.err
+   python - <<PY
+import json
+try:
+    j = json.loads(open("gpurun_out/r06i/$label.json").read().strip().splitlines()[-1])
+    print("$label value", j["value"], "ms", j["ms_per_step"], "serial", j["ms_per_step_serial"], "frac", j["roofline"]["frac"], "flagged", j["config"]["flagged_bursts"], "events", j["config"]["events_total"], {k: v for k, v in j["kernel_ms"].items() if v > 0.02})
+except Exception as e:
+    print("$label FAILED", e); print(open("gpurun_out/r06i/$label.err").read()[-600:])
+PY
+}
+EXTRA="--config M8 --steps 5 --warmup 2" one m8 A=1
+EXTRA="--config M8 --steps 5 --warmup 2" one m8_nodedup RTFE_DENSE_DEDUP=0
+EXTRA="--config M8f --steps 5 --warmup 2" one m8f A=1
+EXTRA="--steps 20 --warmup 5" one c2 A=1
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
