@@ -894,7 +894,6 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
 #ifndef RTFE_CPU_EMUL
       asm volatile("" : "+v"(tidl), "+v"(lanel), "+v"(voffl));
 #endif
-      const int prev_tile = last_tile;
       last_tile = tile;
       const long long lastl = a.nrows - 1 - (long long)tile * kSfTile;
       cx.last = lastl > 0x3fffffff ? 0x3fffffff : (int)lastl;
