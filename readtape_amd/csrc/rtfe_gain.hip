@@ -163,7 +163,15 @@ __device__ __forceinline__ int half_incl_scan(int v, int hl) {
 // that the chains' steady path asks of it: a plain record with a sure stretch whose successor in the stream (the next record of the
 // list; the first of the next tile's list) begins after this record's owner has left the window.
 struct PrepArgs { int nlists, ntrks, hcap; float mv; int W[kMaxScreens]; };      // (by value: a wave's first loads do not wait for a read of the configuration block)
-__global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
+#ifndef RTFE_PREP_WAVES
+#define RTFE_PREP_WAVES 7      // k_prep hides its round trips behind waves: seven a SIMD (72 registers; the look ahead took it to 74 - one 8-byte spill instead of a wave)
+#endif
+#if RTFE_PREP_WAVES > 0 && !defined(RTFE_CPU_EMUL)
+#define RTFE_PREP_ATTR __attribute__((amdgpu_waves_per_eu(RTFE_PREP_WAVES)))
+#else
+#define RTFE_PREP_ATTR
+#endif
+__global__ void __launch_bounds__(256) RTFE_PREP_ATTR k_prep(const PrepArgs pa, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
                                               const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff,
                                               const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint2 *__restrict__ cmar) {
    const int nlists = pa.nlists, hcap = pa.hcap;
@@ -183,19 +191,6 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
          p.r1 = *reinterpret_cast<const uint2 *>(slot + min(16 * (hl + 1), hcap - 16));
          if (l + nlists < nall) { p.dn = dir[l + nlists]; p.rn = *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap); } }
       return p; };
-   // where a record's successor begins: the first row of the first record at or behind entry k1 of a list (q1 = that entry, already
-   // loaded) - a deferred candidate stands for its records (k_sift_hard), and for nothing at all if it turned out to have none.
-   // kNoSucc: the stream ends; kOffList: the list has no further record; kBadSucc: cannot tell (the record is then not marked clear)
-   constexpr long long kNoSucc = 0x7fffffffffffffffll, kBadSucc = -1, kOffList = -2;
-   auto succ_row = [&](const unsigned char *lslot, int k1, int n1, uint2 q, long long pos0q) -> long long {
-      for (int j = k1; j < n1; ++j) {
-         if (j > k1) q = *reinterpret_cast<const uint2 *>(lslot + 16 * j);
-         if (q.y == 0xffff8001u) {
-            const unsigned char *os = ovf + (size_t)q.x * kSfOvfBytes;
-            if (*reinterpret_cast<const int *>(os) <= 0) continue;
-            q = *reinterpret_cast<const uint2 *>(os + 8); }      // (its first record)
-         return pos0q + (long long)(q.x & 0x7ffu) + (long long)((q.x >> 12) & 63u); }
-      return kOffList; };
    long long li = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
    // (tile, stream) of the list, stepped along with li: no division in the loop
    const long long dq = stride / nlists;
@@ -215,16 +210,41 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
       if (built && d.nrec == 0xffffu) {                                  // a list that did not fit: one marker at the tile's first row
          if (hl == 0) { CRec m; m.pos = (uint32_t)(tile * kSfTile); m.w0 = kCrBad | (1u << 12); m.w1 = 0xffff8000u; m.volt = 0; crec[base] = m; cmar[base] = make_uint2(0, 0); } }
       const int nrec = (built && d.nrec != 0xffffu) ? (int)d.nrec : 0;
-      const int scn = (on ? sl : 0) / pa.ntrks;
-      const int W = scn == 0 ? pa.W[0] : (scn == 1 ? pa.W[1] : (scn == 2 ? pa.W[2] : pa.W[3]));
       const unsigned char *slot = pool + (size_t)(on ? li : 0) * hcap;
       const long long pos0 = tile * kSfTile - kSfPosBias;
-      // what follows this list in its stream
-      long long fn_list = kNoSucc;
-      if (nrec > 0 && tile + 1 < ntiles) {
-         if (cu.dn.nrec == 0xffffu) fn_list = (tile + 1) * kSfTile + 1;                       // (the marker of a list that is not there)
-         else if (cu.dn.nrec != 0) { fn_list = succ_row(slot + (size_t)nlists * hcap, 0, (int)cu.dn.nrec, cu.rn, pos0 + kSfTile); if (fn_list == kOffList) fn_list = kBadSucc; }
-         /* an empty list: whatever comes behind it begins more than a tile's rows less the owners' reach further on */ }
+      // kCrClear: does every record BEHIND an entry of this list have all its rows behind row X (the last row the entry's record can fire at)?  A stream is in the order of
+      // its CANDIDATES, a candidate's records have their rows behind the candidate (k_sift: rows q + 1 .. q + W - 2), so the look ahead ends - yes - at the first
+      // entry whose candidate is at or behind X, or two lists on (a tile is longer than a window); every entry it passes on the way must begin behind X.  A deferred
+      // candidate stands for its records (k_sift_hard; none at all, maybe), the first of them the earliest - its own row is not in the entry: the look goes on.
+      // (Rounds 3 - 6a asked this of the record's successor alone: a bottom whose successor - the next bottom - began behind its window was marked although the top
+      //  between those two, the record after next, fired at the very row the bottom did, and tops go first: tools/fuzz_shapes.py.)
+      const int nrec_l = (on && d.nrec != 0xffffu) ? (int)d.nrec : 0;
+      // (rows in 32 bits: rtfe_scan hands this path fragments of less than 2^31 rows)
+      const int p32 = (int)pos0;
+      auto rows_behind = [&](const int k1, const uint2 q1, const int X) -> bool {
+         #pragma nounroll
+         for (int j = k1, hop = 0; hop < 12; ++j, ++hop) {
+            uint2 q;
+            int p0 = p32;
+            if (j < nrec_l) q = j == k1 ? q1 : *reinterpret_cast<const uint2 *>(slot + 16 * j);
+            else {
+               if (tile + 1 >= ntiles) return true;                        // the stream ends
+               const int nn = (int)cu.dn.nrec;
+               if (nn == 0xffff) return p32 + kSfPosBias + kSfTile >= X;    // a list that is not there: whatever its tile holds has its rows behind the tile's first
+               const int j2 = j - nrec_l;
+               if (j2 >= nn) return true;                                  // two lists on: a tile is longer than a window
+               q = j2 == 0 ? cu.rn : *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap + 16 * j2);
+               p0 = p32 + kSfTile; }
+            if (q.y == 0xffff8001u) {
+               const unsigned char *os = ovf + (size_t)q.x * kSfOvfBytes;
+               if (*reinterpret_cast<const int *>(os) <= 0) continue;
+               q = *reinterpret_cast<const uint2 *>(os + 8);
+               if (p0 + (int)(q.x & 0x7ffu) + (int)((q.x >> 12) & 63u) <= X) return false;
+               continue; }
+            const int pj = p0 + (int)(q.x & 0x7ffu);
+            if (pj + (int)((q.x >> 12) & 63u) <= X) return false;
+            if (pj >= X) return true; }
+         return false; };
       int rounds = (nrec + 31) >> 5;
       {  const int other = __shfl(rounds, lane ^ 32); if (other > rounds) rounds = other; }      // (both halves run the scans of every round)
       for (int rd = 0; rd < rounds; ++rd) {
@@ -238,20 +258,28 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
          const int cnt = deferred ? *reinterpret_cast<const int *>(os) : (have ? 1 : 0);
          const int ic = half_incl_scan(cnt, hl);
          const long long o = base + ic - cnt;
-         long long fn = !have ? kNoSucc : succ_row(slot, k + 1, nrec, q1, pos0);      // the successor of this list entry's last record
-         if (fn == kOffList) fn = fn_list;
+         // kCrClear, ONE look ahead per entry (a deferred candidate's records are in row order: what is behind the entry must be behind the last row its LAST record can
+         // fire at).  A plain record's successor settles it nine times in ten - a plain entry that begins behind X, its candidate at or behind X: from the registers; what
+         // it does not settle, and the deferred candidates, wait until the entry's records are stored (the loop's registers beside the records' cost k_prep two waves a SIMD).
+         int Xe = 0;
+         bool behind = false, slow = false;
+         if (deferred) { if (cnt > 0) { const uint32_t el = *reinterpret_cast<const uint32_t *>(os + 8 + 16 * (cnt - 1)); Xe = p32 + (int)(el & 0x7ffu) + (int)((el >> 12) & 63u) + (int)((el >> 18) & 15u); slow = true; } }
+         else if (have && w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u) {
+            Xe = p32 + (int)(w0 & 0x7ffu) + (int)((w0 >> 12) & 63u) + (int)((w0 >> 18) & 15u);
+            slow = true;
+            if (k + 1 < nrec_l && q1.y != 0xffff8001u) {
+               const int pj = p32 + (int)(q1.x & 0x7ffu);
+               if (pj + (int)((q1.x >> 12) & 63u) <= Xe) slow = false;
+               else if (pj >= Xe) { behind = true; slow = false; } } }
          if (deferred) {
             for (int j = 0; j < cnt; ++j) {
                const uint2 e = *reinterpret_cast<const uint2 *>(os + 8 + 16 * j);
                CRec c; c.pos = (uint32_t)(pos0 + (long long)(e.x & 0x7ffu)); c.w0 = e.x & ~0x7ffu; c.w1 = e.y; c.volt = volt((int)(int16_t)(e.y & 0xffffu), mv);
-               long long fj = fn;
-               if (j + 1 < cnt) { const uint2 e2 = *reinterpret_cast<const uint2 *>(os + 8 + 16 * (j + 1)); fj = pos0 + (long long)(e2.x & 0x7ffu) + (long long)((e2.x >> 12) & 63u); }
-               if (e.y != 0xffff8000u && (unsigned)((int)((e.x >> 22) & 63u) - 1) < 62u && fj != kBadSucc && fj > (long long)c.pos + W) c.w0 |= kCrClear;
                crec[o + j] = c;
                cmar[o + j] = *reinterpret_cast<const uint2 *>(os + 8 + 16 * j + 8); } }
          else if (have) {
             CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
-            if (w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u && fn != kBadSucc && fn > (long long)c.pos + W) c.w0 |= kCrClear;
+            if (behind) c.w0 |= kCrClear;
             {  // kCrWeak: no sure row, at most kPkMar rows - all their margins are in the block (first round of the list only: the block came with the record)
                const int ns = (int)((w0 >> 22) & 63u), nl = (int)((w0 >> 18) & 15u), nt = (int)((w0 >> 28) & 15u);
                const int nrows_run = ns == 63 ? (nl << 4 | nt) : (ns == 0 ? nl + nt : 99);
@@ -267,25 +295,46 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
             uint2 mk2 = cu.m;
             if (rd > 0) mk2 = *reinterpret_cast<const uint2 *>(slot + 16 * k + 8);
             cmar[o] = mk2; }      // (its margin block)
+         if (slow && rows_behind(k + 1, q1, Xe)) {                          // (the same lane's second store to the word: in order)
+            if (!deferred) crec[o].w0 = (w0 & ~0x7ffu) | kCrClear;           // (a record with a sure stretch is not kCrWeak)
+            else {
+               // (a stale minimum's record is owned by a sample in front of its candidate: further than two rows in front, the countdown it leaves when it fires ends before
+               //  the rows of a record the chain has passed over do - such a record is the general step's, which looks back: k_gain)
+               const long long qrel = (long long)kSfPosBias + (long long)*reinterpret_cast<const int *>(os + 4);
+               for (int j = 0; j < cnt; ++j) {
+                  const uint2 e = *reinterpret_cast<const uint2 *>(os + 8 + 16 * j);
+                  if (e.y == 0xffff8000u || (unsigned)((int)((e.x >> 22) & 63u) - 1) >= 62u || qrel > (long long)(e.x & 0x7ffu) + 2) continue;
+                  if (j + 1 < cnt) { const uint32_t e2 = *reinterpret_cast<const uint32_t *>(os + 8 + 16 * (j + 1));      // (the candidate's next record)
+                                     if ((long long)(e2 & 0x7ffu) + (long long)((e2 >> 12) & 63u) <= (long long)(e.x & 0x7ffu) + (long long)((e.x >> 12) & 63u) + (long long)((e.x >> 18) & 15u)) continue; }
+                  crec[o + j].w0 = (e.x & ~0x7ffu) | kCrClear; } } }
          base += __shfl(ic, hbase + 31); } } }
 
 #ifdef RTFE_CPU_EMUL
-// (emulator only, RTFE_PREP_CHECK: kCrClear as a pass over the finished streams would set it)
+// (emulator only, RTFE_PREP_CHECK: what kCrClear promises, checked by a pass over the finished streams - no record behind a marked one has a row at or before the
+//  last row the marked one can fire at; RTFE_DUMP_SL / _LO / _HI: the records of a stream between two rows)
 __global__ void __launch_bounds__(64) k_prep_check(const DevCfg *__restrict__ cfgp, const uint32_t *__restrict__ ctot, long long ccap, const CRec *__restrict__ crec) {
    const DevCfg &cfg = *cfgp;
    const int nlists = cfg.nscreens * cfg.ntrks;
    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+   long long nclear = 0, nall = 0;
    for (int sl = 0; sl < nlists; ++sl) {
-      const int W = cfg.screen[sl / cfg.ntrks].W;
       const long long n = (long long)ctot[sl] > ccap ? 0 : (long long)ctot[sl];
       const CRec *r = crec + (size_t)sl * ccap;
       for (long long i = 0; i < n; ++i) {
          const uint32_t w0 = r[i].w0, w1 = r[i].w1;
          const int nsure = (int)((w0 >> 22) & 63u);
-         bool ok = !(w0 & kCrBad) && w1 != 0xffff8000u && (unsigned)(nsure - 1) < 62u;
-         if (ok && i + 1 < n) { const long long fn = (long long)r[i + 1].pos + (long long)((r[i + 1].w0 >> 12) & 63u); ok = fn > (long long)r[i].pos + W; }
-         if (ok != ((w0 & kCrClear) != 0)) fprintf(stderr, "prep_check: stream %d record %lld of %lld pos %u: clear %d, a pass over the stream says %d (next pos %u w0 %08x w1 %08x)\n", sl, i, n, r[i].pos, (int)((w0 & kCrClear) != 0), (int)ok,
-                                                   i + 1 < n ? r[i + 1].pos : 0u, i + 1 < n ? r[i + 1].w0 : 0u, i + 1 < n ? r[i + 1].w1 : 0u); } } }
+         if (getenv("RTFE_DUMP_LO") && sl == atoi(getenv("RTFE_DUMP_SL")) && (long long)r[i].pos >= atoll(getenv("RTFE_DUMP_LO")) && (long long)r[i].pos <= atoll(getenv("RTFE_DUMP_HI")))
+            fprintf(stderr, "DUMP sl %d i %lld pos %u %s f +%u nlead %u nsure %u ntail %u val %d w1 %08x flags %x\n", sl, i, r[i].pos, (w0 & 0x800u) ? "bot" : "top", (w0 >> 12) & 63u, (w0 >> 18) & 15u, nsure, (w0 >> 28) & 15u, (int)(int16_t)(w1 & 0xffff), w1, w0 & 0x7ffu);
+         ++nall;
+         if (!(w0 & kCrClear)) continue;
+         ++nclear;
+         if ((w0 & kCrBad) || w1 == 0xffff8000u || (unsigned)(nsure - 1) >= 62u) fprintf(stderr, "prep_check: stream %d record %lld pos %u is marked clear and has no sure stretch (w0 %08x w1 %08x)\n", sl, i, r[i].pos, w0, w1);
+         const long long X = (long long)r[i].pos + (long long)((w0 >> 12) & 63u) + (long long)((w0 >> 18) & 15u);
+         for (long long j = i + 1; j < n && j < i + 600; ++j) {
+            if ((long long)r[j].pos - 2 * kSfPosBias > X) break;            // (owners lie less than kSfPosBias rows in front of their candidates, rows behind them)
+            const long long fj = (long long)r[j].pos + (long long)((r[j].w0 >> 12) & 63u);
+            if (fj <= X) fprintf(stderr, "prep_check: stream %d record %lld pos %u marked clear (fires by row %lld), record %lld pos %u begins at row %lld\n", sl, i, r[i].pos, X, j, r[j].pos, fj); } } }
+   if (getenv("RTFE_PREP_CHECK") && atoi(getenv("RTFE_PREP_CHECK")) > 1) fprintf(stderr, "prep_check: %lld of %lld records marked clear\n", nclear, nall); }
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -568,13 +617,12 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
                if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; }
                return 0; }
             return 1; }
-         const uint4 nxt4 = s_rec[j + 1][lane];                             // (the record behind it: only the start-up path looks at it itself)
          const int pos = (int)cur4.x;
          const uint32_t w0 = cur4.y, w1 = cur4.z;
          const int c32 = (int)c;
          const bool plain = !(w0 & kCrBad) && w1 != 0xffff8000u;
          if ((w0 & kCrBad) ? pos + kSfTile + W < c32 : pos + W - 2 < c32) return 0;      // its rows are behind the countdown for good
-         const int f = pos + (int)((w0 >> 12) & 63u), nlead = (int)((w0 >> 18) & 15u), nsure = (int)((w0 >> 22) & 63u);
+         const int f = pos + (int)((w0 >> 12) & 63u), nlead = (int)((w0 >> 18) & 15u);
          const bool top = !(w0 & 0x800u);
          const int val = (int)(int16_t)(w1 & 0xffffu);
          const int a = top ? val : -val;
@@ -582,12 +630,11 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          //  fires - behind which all of this record's rows are blind: it is passed over)
          if (lean && plain && amp_on && a <= w.min_lo) return 0;
          if (lean && plain && crec_weak_dead(w0, w.rise_lo)) return 0;
-         const int fn = idx + 1 < src.iend ? (int)nxt4.x + (int)((nxt4.y >> 12) & 63u) : 0x7fffffff;
          // ---- the fast path: a record with a sure stretch, the countdown over before its first row, the thresholds inside the band the sure
          // level stands for, a clear amplitude, and nothing else that could fire before this record's owner has left the window.  Then it
          // fires - at one of its lead rows or at its first sure row, k_emit will say which - and all that feeds back is the extreme's value. ----
          const float g = w.agc_gain;
-         const bool fire = lean && plain && (unsigned)(nsure - 1) < 62u && c32 <= f && f + nlead < limit32 && fn > pos + W
+         const bool fire = lean && plain && (w0 & kCrClear) && c32 <= f && f + nlead < limit32
                            && w.rise_hi <= S.sure_i && (!amp_on || a >= w.min_hi) && w.nevents < cap && g >= g_min;
          if (!fire) {
             return 1; }
@@ -670,6 +717,16 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          if (w.flags & RTFE_F_SCREEN_UNDERFLOW) { failed = true; why = 5; return 2; }
          c = u.pos + W + 1;
          i = alive.i;
+         // A record the lean steps passed over (below the amplitude or the rise test for sure: it could not fire while the thresholds stood) is done with if its rows end
+         // before the new countdown does - its owner at most two rows behind the fired record's, and a stream being in the order of its candidates that holds whenever
+         // the fired record is its own candidate.  A stale minimum's record is owned by a sample in front of its candidate: then the walk goes back to the
+         // first record whose first row says that every candidate in front of it ends before the countdown (candidates lie in front of their rows).
+         for (int back = 0; i > 0; ++back) {
+            const CRec pr = src.rec[i - 1];
+            const long long bound = (pr.w0 & kCrBad) ? (long long)pr.pos : (long long)pr.pos + (long long)((pr.w0 >> 12) & 63u) - 1;      // its candidate's row at most
+            if (bound + W - 2 < c) break;
+            if (back >= 64) { failed = true; why = 7; return 2; }
+            --i; }
          if (!steady && lean && alpha_agc && w.peakcount > 15 && w.v_avg_height_count == 0) enter_steady();
          return 1; };
       // ---- mode 1 at a segment boundary: i = the next segment's first record ----

@@ -1170,6 +1170,7 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       if (nrec > 4) nrec = -1;
       if (nrec < 0) { nrec = 1; sk.w0[0] = pk_w0((int)hd.pos, false, (int)hd.pos + 1, 0, cx.W - 2, 0); sk.w1[0] = 0xffff8000u; }      // (more epochs than a slot holds: "minimum unknown" at every row the sample could be tested at - the chain that gets there gives up)
       *reinterpret_cast<int *>(slot) = nrec;
+      *reinterpret_cast<int *>(slot + 4) = (int)hd.pos;                   // (the candidate's row in its tile: k_prep - a stale minimum's record is owned by a sample in front of it)
       if (nrec != 1) atomicAdd(&extra[((size_t)hd.tile * cfg.nscreens + hd.screen) * cfg.ntrks + hd.head], nrec - 1);      // the list's length in its stream (k_pscan)
       for (int j = 0; j < nrec; ++j) {                                      // (8 + 4 x 16 bytes fit the slot)
          reinterpret_cast<uint32_t *>(slot + 8)[4 * j] = sk.w0[j]; reinterpret_cast<uint32_t *>(slot + 8)[4 * j + 1] = sk.w1[j];
