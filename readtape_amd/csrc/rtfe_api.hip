@@ -50,6 +50,7 @@ struct rtfe_handle {
    int overlap;
    int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
    int sfs_occ[kMaxScreens];           // k_sift_s: workgroups of a screen's instantiation a CU holds at once (the occupancy API, at create)
+   int tail_lanes;      // RTFE_TAIL_LANES
    int ds_order, dchain_wgs, prep_wgs, dense_stop, dseg_wgs, dseg_threads;      // RTFE_DS_ORDER (0: chains in burst order), RTFE_DCHAIN_WGS / RTFE_PREP_WGS / RTFE_DSEG_WGS (workgroups per CU), RTFE_DENSE_STOP (debugging): read once, at create
    // rtfe_set_graphs: a scan's launches (about twenty, on two streams) captured once per set of arguments into a HIP graph and replayed - what a scan of the same
    // buffers costs the host, and the gaps between its kernels on the device, shrink to one launch
@@ -427,6 +428,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    h->ds_order = getenv("RTFE_DS_ORDER") ? atoi(getenv("RTFE_DS_ORDER")) : 1;
    h->dchain_wgs = getenv("RTFE_DCHAIN_WGS") ? atoi(getenv("RTFE_DCHAIN_WGS")) : 16;
    h->prep_wgs = getenv("RTFE_PREP_WGS") ? atoi(getenv("RTFE_PREP_WGS")) : 32;
+   h->tail_lanes = getenv("RTFE_TAIL_LANES") ? atoi(getenv("RTFE_TAIL_LANES")) : 16;      // chains a wave of k_gain's tails (64: as the heads; 16; 8)
    h->dense_stop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;
    h->dseg_wgs = getenv("RTFE_DSEG_WGS") ? atoi(getenv("RTFE_DSEG_WGS")) : 0;
    h->dseg_threads = getenv("RTFE_DSEG_THREADS") ? atoi(getenv("RTFE_DSEG_THREADS")) : 0;
@@ -574,6 +576,9 @@ static size_t pk_segs_bytes(const rtfe_handle *h, int64_t nrows) { return ((size
 // ... | per record of a segment: the gain in force if it fired (k_gain_seg -> k_emit_seg)
 static size_t ws_pkgfire_off(const rtfe_handle *h, int64_t nrows) { return ws_pksegs_off(h, nrows) + pk_segs_bytes(h, nrows); }
 static size_t pk_gfire_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)pk_seg_cap(h, nrows) * (size_t)(h->dev.pk_seg_recs > 0 ? h->dev.pk_seg_recs : 0) * 4 + 255) & ~(size_t)255; }
+
+// (k_prep's work list for k_clear lives in the gains' region - nothing reads it behind k_clear; 8 bytes a place, counted in an int)
+static long long pk_work_cap(const rtfe_handle *h, int64_t nrows) { const long long c = (long long)(pk_gfire_bytes(h, nrows) / 8); return c > 0x7ffffe00ll ? 0x7ffffe00ll : c; }
 
 // ... | the dense sample path: per (tile, width) "nothing above the screen" | per (sub-segment, track) the band | the slots
 static long long ds_tiles_for(int64_t nrows) { return (nrows + kDsTile - 1) / kDsTile; }
@@ -743,7 +748,11 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
       for (int sc2 = 0; sc2 < kMaxScreens; ++sc2) ppa.W[sc2] = h->dev.screen[sc2].W;
       // (workgroups per CU: 4 / 8 / 16 measured 0.51 / 0.47 / 0.42 ms for the span on C2 - half a wave per list, the more lists in flight the better)
       hipLaunchKernelGGL(k_prep, dim3(h->num_cus * (h->prep_wgs >= 1 && h->prep_wgs <= 4096 ? h->prep_wgs : 32)), dim3(256), 0, st, ppa, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
-                         (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, crecp, erefp);
+                         (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, crecp, erefp,
+                         reinterpret_cast<unsigned long long *>(wsb + ws_pkgfire_off(h, nrows)), pk_work_cap(h, nrows), &scratch->prep_work);
+      // (the work list lives where k_gain_seg's gains will: nothing reads it behind k_clear)
+      hipLaunchKernelGGL(k_clear, dim3(h->num_cus * 4), dim3(256), 0, st, (const unsigned long long *)(wsb + ws_pkgfire_off(h, nrows)), pk_work_cap(h, nrows), (const int *)&scratch->prep_work,
+                         (const uint32_t *)ctotp, ccap, crecp);
 #ifdef RTFE_CPU_EMUL
       if (getenv("RTFE_PREP_CHECK")) hipLaunchKernelGGL(k_prep_check, dim3(1), dim3(64), 0, st, (const DevCfg *)h->d_dev, (const uint32_t *)ctotp, ccap, (const CRec *)crecp);
 #endif
@@ -755,9 +764,12 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
       // the chains: from the restart row until the baseline is fixed (k_gain, mode 0), the steady stretch (k_gain_s), whatever that stopped at (k_gain, mode 1)
       for (int mode = 0; mode < 2; ++mode) {
          if (mode == 1) t0(kTGainTail);
-         hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+         // (the tails: sixteen chains a wave, more workgroups than the chip holds at once - a wave is done when its slowest chain is)
+         const int tl = mode == 0 ? 64 : h->tail_lanes;
+         auto kg = tl == 64 ? k_gain<64> : (tl == 8 ? k_gain<8> : k_gain<16>);
+         hipLaunchKernelGGL(kg, dim3(h->num_cus * (mode == 0 ? 4 : 8)), dim3(tl == 64 ? 64 : (tl == 8 ? 8 : 16)), 0, st, (const DevCfg *)h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                             scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint2 *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
-                            (const unsigned char *)pkpool, ptiles, reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows)), pk_seg_cap(h, nrows), d_rows);
+                            (const unsigned char *)pkpool, ptiles, reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows)), pk_seg_cap(h, nrows), (const int16_t *)d_rows);
          if (mode == 0) {
             t1(kTGain); t0(kTGainS);
             // the steady stretches: in segments, every one on its own, joined where the states agree bit for bit (rtfe_gain.hip)

@@ -105,13 +105,7 @@ __device__ __forceinline__ long long chain_stop(const DevCfg &cfg, const rtfe_bu
 // tile directory); k_prep: a wave per list copies its records over.
 // ------------------------------------------------------------------------------------------------
 // flags in CRec::w0 bits 0-10 (the tile-relative row of PeakRec::w0 is replaced by the absolute CRec::pos)
-enum { kCrBad = 1,                        // the tile's list is not there (capacity)
-       kCrClear = 2,
-       kCrWeak = 4 };                     // every row of the run has an explicit margin and the largest of them is <= 16 x (bits 3-10): while a chain's rise threshold
-                                          // is above that for sure (rise_lo) no row of the record can pass the rise test (src/decoder.c:790-791 / 800-801) - it is passed over
-                                          // like a record below the amplitude test (what noise wiggles between a screen and the thresholds turn into)
-__device__ __forceinline__ bool crec_weak_dead(uint32_t w0, int rise_lo) { return (w0 & kCrWeak) && (int)(16u * ((w0 >> 3) & 255u)) <= rise_lo; }                    // a record with a sure stretch (1..62 rows), its minimum known, and no other record's first row at or before the row
-                                          // its owner leaves the window at (pos + W): whatever fires in it fires before anything else can (k_prep's second pass)
+// (kCrBad / kCrClear / kCrWeak and the helpers that read them: rtfe_sift.hip, beside the records' layout - k_sift_hard makes kCrWeak for its records)
 struct CRec { uint32_t pos, w0, w1; float volt; };
 
 // k_pscan1: a workgroup per chunk of 1024 tiles, a thread per tile: per stream the prefix within the chunk and the chunk's total;
@@ -162,18 +156,17 @@ __device__ __forceinline__ int half_incl_scan(int v, int hl) {
 // little else to hide them).  Per record: its absolute row, its volts, where its margin entries are, and kCrClear - everything static
 // that the chains' steady path asks of it: a plain record with a sure stretch whose successor in the stream (the next record of the
 // list; the first of the next tile's list) begins after this record's owner has left the window.
-struct PrepArgs { int nlists, ntrks, hcap; float mv; int W[kMaxScreens]; };      // (by value: a wave's first loads do not wait for a read of the configuration block)
-#ifndef RTFE_PREP_WAVES
-#define RTFE_PREP_WAVES 7      // k_prep hides its round trips behind waves: seven a SIMD (72 registers; the look ahead took it to 74 - one 8-byte spill instead of a wave)
-#endif
-#if RTFE_PREP_WAVES > 0 && !defined(RTFE_CPU_EMUL)
-#define RTFE_PREP_ATTR __attribute__((amdgpu_waves_per_eu(RTFE_PREP_WAVES)))
+#ifdef RTFE_CPU_EMUL
+__device__ __forceinline__ int rtfe_uniform(int v) { return v; }
 #else
-#define RTFE_PREP_ATTR
+__device__ __forceinline__ int rtfe_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value every lane of the wave holds: into a scalar register
 #endif
-__global__ void __launch_bounds__(256) RTFE_PREP_ATTR k_prep(const PrepArgs pa, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
+constexpr int kPrepWorkChunk = 256;      // places of the work list a wave of k_prep takes at a time (a round puts up to 64 x 4 records on it)
+struct PrepArgs { int nlists, ntrks, hcap; float mv; int W[kMaxScreens]; };      // (by value: a wave's first loads do not wait for a read of the configuration block)
+__global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
                                               const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff,
-                                              const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint2 *__restrict__ cmar) {
+                                              const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint2 *__restrict__ cmar,
+                                              unsigned long long *__restrict__ work, long long work_cap, int *__restrict__ work_count) {
    const int nlists = pa.nlists, hcap = pa.hcap;
    const float mv = pa.mv;
    const int lane = threadIdx.x & 63, hl = lane & 31, hbase = lane & 32;
@@ -191,6 +184,8 @@ __global__ void __launch_bounds__(256) RTFE_PREP_ATTR k_prep(const PrepArgs pa, 
          p.r1 = *reinterpret_cast<const uint2 *>(slot + min(16 * (hl + 1), hcap - 16));
          if (l + nlists < nall) { p.dn = dir[l + nlists]; p.rn = *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap); } }
       return p; };
+   const unsigned wcap = (unsigned)work_cap;                             // (< 2^31; a count that ran over reads as a place behind it)
+   int wk_next = 0, wk_end = 0;                                          // the wave's places on the work list (k_clear); wave-uniform (work_cap < 2^31: the host)
    long long li = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
    // (tile, stream) of the list, stepped along with li: no division in the loop
    const long long dq = stride / nlists;
@@ -212,39 +207,15 @@ __global__ void __launch_bounds__(256) RTFE_PREP_ATTR k_prep(const PrepArgs pa, 
       const int nrec = (built && d.nrec != 0xffffu) ? (int)d.nrec : 0;
       const unsigned char *slot = pool + (size_t)(on ? li : 0) * hcap;
       const long long pos0 = tile * kSfTile - kSfPosBias;
-      // kCrClear: does every record BEHIND an entry of this list have all its rows behind row X (the last row the entry's record can fire at)?  A stream is in the order of
-      // its CANDIDATES, a candidate's records have their rows behind the candidate (k_sift: rows q + 1 .. q + W - 2), so the look ahead ends - yes - at the first
-      // entry whose candidate is at or behind X, or two lists on (a tile is longer than a window); every entry it passes on the way must begin behind X.  A deferred
-      // candidate stands for its records (k_sift_hard; none at all, maybe), the first of them the earliest - its own row is not in the entry: the look goes on.
-      // (Rounds 3 - 6a asked this of the record's successor alone: a bottom whose successor - the next bottom - began behind its window was marked although the top
-      //  between those two, the record after next, fired at the very row the bottom did, and tops go first: tools/fuzz_shapes.py.)
+      // kCrClear: nothing behind the record in its stream has a row at or before X, the last row the record can fire at.  A stream is in the order of its
+      // CANDIDATES and a candidate's records have their rows behind the candidate, so the look ahead from the record ends - yes - at the first record whose candidate (its owner at
+      // the least) lies at or behind X; every record it passes on the way must begin behind X.  The successor settles it nine times in ten: a plain entry of this list - or the first
+      // of the next tile's - straight from the registers.  What it does not settle, and the records of deferred candidates, go on a work list: k_clear looks ahead in the finished
+      // stream (the loop in here, beside the records' registers, cost k_prep two waves a SIMD: 0.33 -> 0.43 ms on C2).
+      // (Rounds 3 - 6a asked this of the record's successor alone: a bottom whose successor - the next bottom - began behind its window was marked although the top between those
+      //  two, the record after next, fired at the very row the bottom did, and tops go first: tools/fuzz_shapes.py.)
       const int nrec_l = (on && d.nrec != 0xffffu) ? (int)d.nrec : 0;
-      // (rows in 32 bits: rtfe_scan hands this path fragments of less than 2^31 rows)
-      const int p32 = (int)pos0;
-      auto rows_behind = [&](const int k1, const uint2 q1, const int X) -> bool {
-         #pragma nounroll
-         for (int j = k1, hop = 0; hop < 12; ++j, ++hop) {
-            uint2 q;
-            int p0 = p32;
-            if (j < nrec_l) q = j == k1 ? q1 : *reinterpret_cast<const uint2 *>(slot + 16 * j);
-            else {
-               if (tile + 1 >= ntiles) return true;                        // the stream ends
-               const int nn = (int)cu.dn.nrec;
-               if (nn == 0xffff) return p32 + kSfPosBias + kSfTile >= X;    // a list that is not there: whatever its tile holds has its rows behind the tile's first
-               const int j2 = j - nrec_l;
-               if (j2 >= nn) return true;                                  // two lists on: a tile is longer than a window
-               q = j2 == 0 ? cu.rn : *reinterpret_cast<const uint2 *>(slot + (size_t)nlists * hcap + 16 * j2);
-               p0 = p32 + kSfTile; }
-            if (q.y == 0xffff8001u) {
-               const unsigned char *os = ovf + (size_t)q.x * kSfOvfBytes;
-               if (*reinterpret_cast<const int *>(os) <= 0) continue;
-               q = *reinterpret_cast<const uint2 *>(os + 8);
-               if (p0 + (int)(q.x & 0x7ffu) + (int)((q.x >> 12) & 63u) <= X) return false;
-               continue; }
-            const int pj = p0 + (int)(q.x & 0x7ffu);
-            if (pj + (int)((q.x >> 12) & 63u) <= X) return false;
-            if (pj >= X) return true; }
-         return false; };
+      const int p32 = (int)pos0;                                           // (rows in 32 bits: rtfe_scan hands this path fragments of less than 2^31 rows)
       int rounds = (nrec + 31) >> 5;
       {  const int other = __shfl(rounds, lane ^ 32); if (other > rounds) rounds = other; }      // (both halves run the scans of every round)
       for (int rd = 0; rd < rounds; ++rd) {
@@ -258,56 +229,88 @@ __global__ void __launch_bounds__(256) RTFE_PREP_ATTR k_prep(const PrepArgs pa, 
          const int cnt = deferred ? *reinterpret_cast<const int *>(os) : (have ? 1 : 0);
          const int ic = half_incl_scan(cnt, hl);
          const long long o = base + ic - cnt;
-         // kCrClear, ONE look ahead per entry (a deferred candidate's records are in row order: what is behind the entry must be behind the last row its LAST record can
-         // fire at).  A plain record's successor settles it nine times in ten - a plain entry that begins behind X, its candidate at or behind X: from the registers; what
-         // it does not settle, and the deferred candidates, wait until the entry's records are stored (the loop's registers beside the records' cost k_prep two waves a SIMD).
-         int Xe = 0;
-         bool behind = false, slow = false;
-         if (deferred) { if (cnt > 0) { const uint32_t el = *reinterpret_cast<const uint32_t *>(os + 8 + 16 * (cnt - 1)); Xe = p32 + (int)(el & 0x7ffu) + (int)((el >> 12) & 63u) + (int)((el >> 18) & 15u); slow = true; } }
-         else if (have && w1 != 0xffff8000u && (unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u) {
-            Xe = p32 + (int)(w0 & 0x7ffu) + (int)((w0 >> 12) & 63u) + (int)((w0 >> 18) & 15u);
-            slow = true;
-            if (k + 1 < nrec_l && q1.y != 0xffff8001u) {
-               const int pj = p32 + (int)(q1.x & 0x7ffu);
-               if (pj + (int)((q1.x >> 12) & 63u) <= Xe) slow = false;
-               else if (pj >= Xe) { behind = true; slow = false; } } }
+         uint32_t todo = 0;                                                // bit j: record j of this entry goes on the work list
          if (deferred) {
+            // (a stale minimum's record is owned by a sample in front of its candidate: further than two rows in front, the countdown it leaves when it fires ends before
+            //  the rows of a record the chain has passed over do - such a record is never marked: it is the general step's, which looks back - k_gain)
+            const int qrel = kSfPosBias + *reinterpret_cast<const int *>(os + 4);
+            #pragma nounroll
             for (int j = 0; j < cnt; ++j) {
                const uint2 e = *reinterpret_cast<const uint2 *>(os + 8 + 16 * j);
-               CRec c; c.pos = (uint32_t)(pos0 + (long long)(e.x & 0x7ffu)); c.w0 = e.x & ~0x7ffu; c.w1 = e.y; c.volt = volt((int)(int16_t)(e.y & 0xffffu), mv);
+               const uint2 em = *reinterpret_cast<const uint2 *>(os + 8 + 16 * j + 8);
+               const uint32_t ew = *reinterpret_cast<const uint32_t *>(os + 72 + 4 * j);      // (kCrWeak and its bits: k_sift_hard made them beside the margins - made here, they cost k_prep 22 registers)
+               CRec c; c.pos = (uint32_t)(pos0 + (long long)(e.x & 0x7ffu)); c.w0 = (e.x & ~0x7ffu) | ew; c.w1 = e.y; c.volt = volt((int)(int16_t)(e.y & 0xffffu), mv);
+               if (crec_can_clear(e.x, e.y, ew) && qrel <= (int)(e.x & 0x7ffu) + 2) todo |= 1u << j;
                crec[o + j] = c;
-               cmar[o + j] = *reinterpret_cast<const uint2 *>(os + 8 + 16 * j + 8); } }
+               cmar[o + j] = em; } }
          else if (have) {
-            CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = w0 & ~0x7ffu; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
-            if (behind) c.w0 |= kCrClear;
-            {  // kCrWeak: no sure row, at most kPkMar rows - all their margins are in the block (first round of the list only: the block came with the record)
-               const int ns = (int)((w0 >> 22) & 63u), nl = (int)((w0 >> 18) & 15u), nt = (int)((w0 >> 28) & 15u);
-               const int nrows_run = ns == 63 ? (nl << 4 | nt) : (ns == 0 ? nl + nt : 99);
-               if (rd == 0 && w1 != 0xffff8000u && nrows_run >= 1 && nrows_run <= kPkMar) {
-                  const uint32_t e0 = cu.m.y >> 16, e1 = cu.m.y & 0xffffu, e2 = cu.m.x >> 16, e3 = cu.m.x & 0xffffu;      // (entry j at block end - 2 (j + 1))
-                  uint32_t M = e0;
-                  if (nrows_run > 1 && e1 > M) M = e1;
-                  if (nrows_run > 2 && e2 > M) M = e2;
-                  if (nrows_run > 3 && e3 > M) M = e3;
-                  const uint32_t mq = (M + 15u) >> 4;
-                  if (mq <= 255u) c.w0 |= kCrWeak | (mq << 3); } }
-            crec[o] = c;
-            uint2 mk2 = cu.m;
+            uint2 mk2 = cu.m;                                              // (its margin block: with the record in the first round)
             if (rd > 0) mk2 = *reinterpret_cast<const uint2 *>(slot + 16 * k + 8);
-            cmar[o] = mk2; }      // (its margin block)
-         if (slow && rows_behind(k + 1, q1, Xe)) {                          // (the same lane's second store to the word: in order)
-            if (!deferred) crec[o].w0 = (w0 & ~0x7ffu) | kCrClear;           // (a record with a sure stretch is not kCrWeak)
-            else {
-               // (a stale minimum's record is owned by a sample in front of its candidate: further than two rows in front, the countdown it leaves when it fires ends before
-               //  the rows of a record the chain has passed over do - such a record is the general step's, which looks back: k_gain)
-               const long long qrel = (long long)kSfPosBias + (long long)*reinterpret_cast<const int *>(os + 4);
-               for (int j = 0; j < cnt; ++j) {
-                  const uint2 e = *reinterpret_cast<const uint2 *>(os + 8 + 16 * j);
-                  if (e.y == 0xffff8000u || (unsigned)((int)((e.x >> 22) & 63u) - 1) >= 62u || qrel > (long long)(e.x & 0x7ffu) + 2) continue;
-                  if (j + 1 < cnt) { const uint32_t e2 = *reinterpret_cast<const uint32_t *>(os + 8 + 16 * (j + 1));      // (the candidate's next record)
-                                     if ((long long)(e2 & 0x7ffu) + (long long)((e2 >> 12) & 63u) <= (long long)(e.x & 0x7ffu) + (long long)((e.x >> 12) & 63u) + (long long)((e.x >> 18) & 15u)) continue; }
-                  crec[o + j].w0 = (e.x & ~0x7ffu) | kCrClear; } } }
-         base += __shfl(ic, hbase + 31); } } }
+            const uint32_t wk = crec_weak_bits(w0, w1, mk2);
+            CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = (w0 & ~0x7ffu) | wk; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
+            if (crec_can_clear(w0, w1, wk)) {
+               const int X = p32 + (int)(w0 & 0x7ffu) + (int)((w0 >> 12) & 63u) + (int)((w0 >> 18) & 15u);      // (kCrWeak: one behind its last row)
+               // its successor: the list's next entry, the next tile's first, none
+               uint2 sq = q1; int sp0 = p32; int kind = 0;                 // 0: an entry, 1: nothing behind it that could matter, 2: cannot tell from here
+               if (k + 1 >= nrec_l) {
+                  const int nn = (int)cu.dn.nrec;
+                  if (tile + 1 >= ntiles || nn == 0) kind = 1;              // (the stream ends; an empty list: two lists on, and a tile is longer than a window)
+                  else if (nn == 0xffff) kind = p32 + kSfPosBias + kSfTile >= X ? 1 : 3;      // a list that is not there: whatever its tile holds has its rows behind the tile's first
+                  else { sq = cu.rn; sp0 = p32 + kSfTile; } }
+               if (kind == 0) {
+                  if (sq.y == 0xffff8001u) kind = 2;
+                  else {
+                     const int pj = sp0 + (int)(sq.x & 0x7ffu);
+                     if (pj + (int)((sq.x >> 12) & 63u) <= X) kind = 3;     // (3: not clear)
+                     else kind = pj >= X ? 1 : 2; } }
+               if (kind == 1) c.w0 |= kCrClear;
+               if (kind == 2) todo = 1u; }
+            crec[o] = c;
+            cmar[o] = mk2; }
+         // the work list: a wave takes its places a chunk at a time (one atomic per record and wave round on ONE address: a 60 mV-noise tape's 1.2 M deferred candidates made
+         // k_prep 5 ms longer - as k_sift_s's list of deferred candidates had, before it took chunks); what it leaves of a chunk it marks empty
+         if (__ballot(todo != 0u) != 0ull) {
+            const int nt = __popc(todo);
+            const int incl = wave_incl_scan(nt, lane);
+            const int total = wave_last(incl);
+            if (wk_next + total > wk_end) {
+               for (int x = wk_next + lane; x < wk_end; x += 64) if ((unsigned)x < wcap) work[x] = ~0ull;
+               int nb = 0;
+               if (lane == 0) nb = atomicAdd(work_count, kPrepWorkChunk);
+               wk_next = rtfe_uniform(__shfl(nb, 0)); wk_end = wk_next + kPrepWorkChunk; }
+            int wbase = wk_next + incl - nt;
+            wk_next = rtfe_uniform(wk_next + total);
+            for (int j = 0; j < 4; ++j) if (todo & (1u << j)) { if ((unsigned)wbase < wcap) work[wbase] = (unsigned long long)(o + j); ++wbase; } }
+         base += __shfl(ic, hbase + 31); } }
+   for (int x = wk_next + lane; x < wk_end; x += 64) if ((unsigned)x < wcap) work[x] = ~0ull; }
+
+// k_clear: kCrClear for the records k_prep could not settle from a record's successor - a thread per work list entry looks ahead in the finished stream.  Every record behind
+// it must begin behind X until one's owner - its candidate lies at or behind its owner, the later candidates behind that - is at or behind X; a marker stands for a tile's
+// unknown candidates (all behind the tile's first row).  (The flag bit of a word is written by the one thread that owns the record; the others read the word's other bits.)
+__global__ void __launch_bounds__(256) k_clear(const unsigned long long *__restrict__ work, long long work_cap, const int *__restrict__ work_count, const uint32_t *__restrict__ ctot,
+                                               long long ccap, CRec *__restrict__ crec) {
+   long long n = *work_count;
+   if (n > work_cap) n = work_cap;                                        // (what did not fit stays unmarked: the general step's)
+   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+      const unsigned long long gw = work[t];
+      if (gw == ~0ull) continue;                                          // (a place nobody took)
+      const long long g = (long long)gw;
+      const long long sl = g / ccap, i = g - sl * ccap;
+      const long long ne = (long long)ctot[sl];
+      const CRec *r = crec + (size_t)sl * ccap;
+      const uint32_t w0 = r[i].w0;
+      const int X = (int)r[i].pos + (int)((w0 >> 12) & 63u) + (int)((w0 >> 18) & 15u);
+      bool ok = false;
+      #pragma nounroll
+      for (long long j = i + 1; ; ++j) {
+         if (j >= ne) { ok = true; break; }
+         if (j > i + 16) break;
+         const int pj = (int)r[j].pos;
+         const uint32_t wj = r[j].w0;
+         if (wj & kCrBad) { ok = pj >= X; break; }
+         if (pj + (int)((wj >> 12) & 63u) <= X) break;
+         if (pj >= X) { ok = true; break; } }
+      if (ok) crec[(size_t)g].w0 = w0 | kCrClear; } }
 
 #ifdef RTFE_CPU_EMUL
 // (emulator only, RTFE_PREP_CHECK: what kCrClear promises, checked by a pass over the finished streams - no record behind a marked one has a row at or before the
@@ -328,7 +331,7 @@ __global__ void __launch_bounds__(64) k_prep_check(const DevCfg *__restrict__ cf
          ++nall;
          if (!(w0 & kCrClear)) continue;
          ++nclear;
-         if ((w0 & kCrBad) || w1 == 0xffff8000u || (unsigned)(nsure - 1) >= 62u) fprintf(stderr, "prep_check: stream %d record %lld pos %u is marked clear and has no sure stretch (w0 %08x w1 %08x)\n", sl, i, r[i].pos, w0, w1);
+         if ((w0 & kCrBad) || w1 == 0xffff8000u || ((unsigned)(nsure - 1) >= 62u && !(w0 & kCrWeak))) fprintf(stderr, "prep_check: stream %d record %lld pos %u is marked clear and has no sure stretch (w0 %08x w1 %08x)\n", sl, i, r[i].pos, w0, w1);
          const long long X = (long long)r[i].pos + (long long)((w0 >> 12) & 63u) + (long long)((w0 >> 18) & 15u);
          for (long long j = i + 1; j < n && j < i + 600; ++j) {
             if ((long long)r[j].pos - 2 * kSfPosBias > X) break;            // (owners lie less than kSfPosBias rows in front of their candidates, rows behind them)
@@ -474,14 +477,18 @@ struct GsConst {                       // what a segment's lane needs to know ab
    int W, sure_i, limit32, amp_on, sl, pad; };
 struct ChainSt { Walker w; float heights[10]; long long i, c, iend; int status, seg0, nseg, pad; unsigned int seg_ev0, seg_ev1; GsConst k; };      // (iend, seg0, nseg: the steady stretch and its segments)
 
-__global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
+// LANES chains a wave (a workgroup of LANES threads).  The heads (mode 0) walk in lock step, 64 a wave; the tails (mode 1) do not: every general step a lane takes - a chain of
+// dependent loads, ~10 us - is paid by its whole wave, and a 60 mV-noise tape's chains come with two or three each: 64 lanes a wave were 150 general steps in a row (2.1 ms
+// for 18 k chains on a chip that runs 1 024 such waves at once); sixteen lanes a wave are a quarter of that.
+template <int LANES>
+__global__ void __launch_bounds__(LANES) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
                                              const CRec *__restrict__ crec, const uint2 *__restrict__ cmar, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
                                              long long ccap, const unsigned char *__restrict__ pool, long long ntiles, GsSeg *__restrict__ segs, long long seg_cap, const int16_t *__restrict__ rows) {
-   __shared__ float s_heights[64 * 10];
-   __shared__ uint4 s_notes[kGainChunk][64];                           // the events the fast path notes, until the chunk's end
-   __shared__ uint4 s_rec[kGainChunk + 1][64];                         // the lanes' records of the current chunk
+   __shared__ float s_heights[LANES * 10];
+   __shared__ uint4 s_notes[kGainChunk][LANES];                           // the events the fast path notes, until the chunk's end
+   __shared__ uint4 s_rec[kGainChunk + 1][LANES];                         // the lanes' records of the current chunk
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks, nlists = cfg.nscreens * ntrks;
    const int lane = threadIdx.x;
@@ -489,7 +496,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
    const int nchains = chain_count(cfg, scratch->nbursts);
    float *heights = s_heights + lane * 10;
    // (every lane of a wave goes through the same rounds - the wave votes on them - so a lane without a chain walks a finished one)
-   for (int cbase = blockIdx.x * 64; cbase < nchains; cbase += gridDim.x * 64) {
+   for (int cbase = blockIdx.x * LANES; cbase < nchains; cbase += gridDim.x * LANES) {
       const ChainIx cx_ = chain_ix(cfg, cbase + lane < nchains ? cbase + lane : nchains - 1);
       const int ci = cx_.ci, b = cx_.b, wi = cx_.wi, pidx = cx_.pidx, trk = cx_.trk;
       const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady && (mode == 0 || cst[ci].status == kChGeneral);
@@ -595,7 +602,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
             if (crec_weak_dead(w0, w.rise_lo)) return 0;                                          // no row can pass the rise test: passed over likewise
             const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
             const float g = w.agc_gain;
-            if ((w0 & kCrClear) && c32 <= f && fl < limit32 && w.rise_hi <= S.sure_i && (!amp_on || a >= w.min_hi) && w.nevents < cap && g >= g_min) {
+            if ((w0 & kCrClear) && c32 <= f && fl < limit32 && w.rise_hi <= crec_level(w0, S.sure_i) && (!amp_on || a >= w.min_hi) && w.nevents < cap && g >= g_min) {
                s_notes[nbuf][lane] = make_uint4((uint32_t)idx, __float_as_uint(g), __float_as_uint(w.v_avg_height), 0xffffffffu);
                ++nbuf; ++w.nevents; ++w.peakcount;
                c = pos + W + 1;
@@ -635,7 +642,7 @@ __global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, in
          // fires - at one of its lead rows or at its first sure row, k_emit will say which - and all that feeds back is the extreme's value. ----
          const float g = w.agc_gain;
          const bool fire = lean && plain && (w0 & kCrClear) && c32 <= f && f + nlead < limit32
-                           && w.rise_hi <= S.sure_i && (!amp_on || a >= w.min_hi) && w.nevents < cap && g >= g_min;
+                           && w.rise_hi <= crec_level(w0, S.sure_i) && (!amp_on || a >= w.min_hi) && w.nevents < cap && g >= g_min;
          if (!fire) {
             return 1; }
          const float v = __uint_as_float(cur4.w);
@@ -938,7 +945,7 @@ __global__ void __launch_bounds__(64) k_gain_seg(const DevCfg *__restrict__ cfgp
                   const int a = top ? val : -val;
                   const bool ampdead = (!bad && r.z != 0xffff8000u && amp_on && a <= min_lo) || crec_weak_dead(w0, rise_hi - 5);      // (rise_lo = rise_hi - 5: the band around the threshold)
                   const int f = pos + (int)((w0 >> 12) & 63u), fl = f + (int)((w0 >> 18) & 15u);
-                  const bool fire = (w0 & kCrClear) && c <= f && fl < limit32 && rise_hi <= sure_i && (!amp_on || a >= min_hi) && g >= g_min;
+                  const bool fire = (w0 & kCrClear) && c <= f && fl < limit32 && rise_hi <= crec_level(w0, sure_i) && (!amp_on || a >= min_hi) && g >= g_min;
                   // (h / lastheight for the NEXT fired record, should this one fire: its operands are this record's and the state's - the
                   //  division runs beside the gain's chain instead of inside it)
                   const float v = __uint_as_float(r.w);

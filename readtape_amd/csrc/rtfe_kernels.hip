@@ -36,7 +36,7 @@ struct BurstScratch {            // lives in the workspace (first kScratchBytes 
    int   nbursts;                // bursts to decode (owned by this scan)
    int   queue;                  // next burst to decode
    int   nbursts_total;          // owned bursts + (time shards) the first burst of the halo, which only bounds the last owned one
-   int   queue_walk;             // (unused)
+   int   queue_walk;             // the dense path's chain queue (k_dchain)
    int   queue_resume;           // ... of the second k_decode pass
    int   queue_seg, nsegs;       // (unused)
    int   queue_stitch;           // (unused)
@@ -45,7 +45,8 @@ struct BurstScratch {            // lives in the workspace (first kScratchBytes 
    int   min_height_key;         // 0x7fffffff - the bits of the smallest v_avg_height any chain of this scan LEARNED (0: none did): what a caller may
                                  // raise rtfe_config::screen_floor_height towards for the tape's next scans (rtfe_scan_stats)
    float floor_used;             // the floor the scan's screen was built for (k_scan_begin: the handle's, or - its first scan - the estimate from the samples)
-   int   pad[4];
+   int   prep_work;              // records on k_prep's work list (k_clear); zeroed with the block by k_scan_begin, not by k_bursts - that runs beside k_prep
+   int   pad[3];
    unsigned long long dbg[8];    // at byte 64: optional per-phase cycle counters of k_decode (DevCfg::debug)
    unsigned long long pool_cursor;   // (unused)
    unsigned long long dbg2[8];   // dbg[8..15] (contiguous with dbg through pool_cursor is NOT assumed: indexed separately)

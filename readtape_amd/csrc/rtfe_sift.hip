@@ -224,6 +224,28 @@ template <class C, class P16> __device__ __forceinline__ void pk_margins(const C
    const int val = (int)(int16_t)(w1 & 0xffffu);
    for (int j = 0; j < kPkMar; ++j) { const int m = pk_margin(c, head, f + j, val, top); e16[-(j + 1)] = (uint16_t)(m < 0 ? 0 : m); } }
 
+// ---- what k_prep adds to a record on its way into a stream (CRec::w0 bits 0-10: the tile-relative row of PeakRec::w0 is replaced by the absolute CRec::pos) ----
+enum { kCrBad = 1,                        // the tile's list is not there (capacity)
+       kCrClear = 2,                      // nothing behind it in the stream has a row at or before the last row it can fire at: if it fires it fires first (k_prep)
+       kCrWeak = 4 };                     // a record without a sure stretch, at most kPkMar rows: every row's margin is in its block, the largest of them M quantised in
+                                          // bits 3-10: mq = min(ceil(M / 16), 255), so 16 (mq - 1) < M, and M <= 16 mq unless mq = 255.  While a chain's rise threshold is above
+                                          // 16 mq for sure (rise_lo) no row of the record can pass the rise test (src/decoder.c:790-791 / 800-801) - it is passed over like a
+                                          // record below the amplitude test (what noise wiggles between a screen and the thresholds turn into); while the threshold is at most
+                                          // 16 (mq - 1) for sure (rise_hi) its largest row passes - it FIRES, at the first of its rows that passes (k_emit: the margins, exactly)
+__device__ __forceinline__ bool crec_weak_dead(uint32_t w0, int rise_lo) { return (w0 & kCrWeak) && ((w0 >> 3) & 255u) != 255u && (int)(16u * ((w0 >> 3) & 255u)) <= rise_lo; }
+// the margin a record's rows reach for sure: the sure level of its screen, or - kCrWeak - what its largest row is known to exceed
+__device__ __forceinline__ int crec_level(uint32_t w0, int sure_i) { return (w0 & kCrWeak) ? 16 * (int)((w0 >> 3) & 255u) - 16 : sure_i; }
+// kCrWeak and its bits from a record as k_sift left it and its margin block (entry j - row f + j - at the block's end - 2 (j + 1))
+__device__ __forceinline__ uint32_t crec_weak_bits(uint32_t w0, uint32_t w1, uint2 mar) {
+   const uint32_t ns = (w0 >> 22) & 63u, nl = (w0 >> 18) & 15u;          // (no sure stretch: nl rows, no tail; "every row explicit", ns = 63, means sixteen rows and more)
+   const uint32_t my = nl >= 2u ? mar.y : (mar.y & 0xffff0000u), mx = nl >= 4u ? mar.x : (nl == 3u ? (mar.x & 0xffff0000u) : 0u);
+   const uint32_t a = max(my >> 16, my & 0xffffu), b = max(mx >> 16, mx & 0xffffu);
+   uint32_t mq = (max(a, b) + 15u) >> 4;
+   if (mq > 255u) mq = 255u;
+   return (ns == 0u && w1 != 0xffff8000u && nl - 1u < (uint32_t)kPkMar) ? (kCrWeak | (mq << 3)) : 0u; }
+// a record that can fire on the lean step at all: a sure stretch (1..62 rows) with its minimum known, or kCrWeak
+__device__ __forceinline__ bool crec_can_clear(uint32_t w0, uint32_t w1, uint32_t weak) { return w1 != 0xffff8000u && ((unsigned)((int)((w0 >> 22) & 63u) - 1) < 62u || weak != 0u); }
+
 // "a rescan is forced at row r whatever happened before": the sample that leaves the window is
 //   (a) the maximum of the old window AND not exceeded by the sample that enters (src/decoder.c:763-767: the new sample is
 //       folded into pkww_maxv before old_left is compared with it; the maximum is always exact), or
@@ -1172,8 +1194,12 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       *reinterpret_cast<int *>(slot) = nrec;
       *reinterpret_cast<int *>(slot + 4) = (int)hd.pos;                   // (the candidate's row in its tile: k_prep - a stale minimum's record is owned by a sample in front of it)
       if (nrec != 1) atomicAdd(&extra[((size_t)hd.tile * cfg.nscreens + hd.screen) * cfg.ntrks + hd.head], nrec - 1);      // the list's length in its stream (k_pscan)
-      for (int j = 0; j < nrec; ++j) {                                      // (8 + 4 x 16 bytes fit the slot)
+      for (int j = 0; j < nrec; ++j) {                                      // (8 + 4 x 16 bytes fit the slot; behind them, from byte 72, kCrWeak and its bits per record)
          reinterpret_cast<uint32_t *>(slot + 8)[4 * j] = sk.w0[j]; reinterpret_cast<uint32_t *>(slot + 8)[4 * j + 1] = sk.w1[j];
-         pk_margins(cx, (int)hd.head, sk.w0[j], sk.w1[j], reinterpret_cast<uint16_t *>(slot + 8 + 16 * (j + 1))); } } }
+         uint16_t mb[kPkMar];
+         pk_margins(cx, (int)hd.head, sk.w0[j], sk.w1[j], mb + kPkMar);
+         const uint2 blk = make_uint2((uint32_t)mb[0] | ((uint32_t)mb[1] << 16), (uint32_t)mb[2] | ((uint32_t)mb[3] << 16));      // (the block as it lies in memory: entry j at its end - 2 (j + 1))
+         *reinterpret_cast<uint2 *>(slot + 8 + 16 * j + 8) = blk;
+         reinterpret_cast<uint32_t *>(slot + 72)[j] = crec_weak_bits(sk.w0[j], sk.w1[j], blk); } } }
 
 }  // namespace rtfe
