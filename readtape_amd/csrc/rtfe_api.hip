@@ -50,7 +50,6 @@ struct rtfe_handle {
    int overlap;
    int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
    int sfs_occ[kMaxScreens];           // k_sift_s: workgroups of a screen's instantiation a CU holds at once (the occupancy API, at create)
-   int tail_lanes;      // RTFE_TAIL_LANES
    int ds_order, dchain_wgs, prep_wgs, dense_stop, dseg_wgs, dseg_threads;      // RTFE_DS_ORDER (0: chains in burst order), RTFE_DCHAIN_WGS / RTFE_PREP_WGS / RTFE_DSEG_WGS (workgroups per CU), RTFE_DENSE_STOP (debugging): read once, at create
    // rtfe_set_graphs: a scan's launches (about twenty, on two streams) captured once per set of arguments into a HIP graph and replayed - what a scan of the same
    // buffers costs the host, and the gaps between its kernels on the device, shrink to one launch
@@ -428,7 +427,6 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    h->ds_order = getenv("RTFE_DS_ORDER") ? atoi(getenv("RTFE_DS_ORDER")) : 1;
    h->dchain_wgs = getenv("RTFE_DCHAIN_WGS") ? atoi(getenv("RTFE_DCHAIN_WGS")) : 16;
    h->prep_wgs = getenv("RTFE_PREP_WGS") ? atoi(getenv("RTFE_PREP_WGS")) : 32;
-   h->tail_lanes = getenv("RTFE_TAIL_LANES") ? atoi(getenv("RTFE_TAIL_LANES")) : 16;      // chains a wave of k_gain's tails (64: as the heads; 16; 8)
    h->dense_stop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;
    h->dseg_wgs = getenv("RTFE_DSEG_WGS") ? atoi(getenv("RTFE_DSEG_WGS")) : 0;
    h->dseg_threads = getenv("RTFE_DSEG_THREADS") ? atoi(getenv("RTFE_DSEG_THREADS")) : 0;
@@ -741,7 +739,7 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
       int *extrap = reinterpret_cast<int *>(wsb + ws_pkextra_off(h, nrows));
       const long long ccap = pk_ccap(h, nrows);
       hipLaunchKernelGGL(k_sift_hard, dim3(h->num_cus * 16), dim3(256), 0, st, (const DevCfg *)h->d_dev, d_rows, (long long)nrows, (const SfHard *)hardp, hard_cap,
-                         (const int *)&scratch->hard_count, ovfp, extrap);
+                         (const int *)&scratch->hard_count, ovfp, extrap, scratch->dbg2);
       hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (const int *)extrap, (int)ptiles, nlists, tstartp, ctotcp);
       hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
       PrepArgs ppa; ppa.nlists = nlists; ppa.ntrks = h->dev.ntrks; ppa.hcap = h->dev.pk_slot; ppa.mv = h->dev.maxvolts;
@@ -764,10 +762,7 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
       // the chains: from the restart row until the baseline is fixed (k_gain, mode 0), the steady stretch (k_gain_s), whatever that stopped at (k_gain, mode 1)
       for (int mode = 0; mode < 2; ++mode) {
          if (mode == 1) t0(kTGainTail);
-         // (the tails: sixteen chains a wave, more workgroups than the chip holds at once - a wave is done when its slowest chain is)
-         const int tl = mode == 0 ? 64 : h->tail_lanes;
-         auto kg = tl == 64 ? k_gain<64> : (tl == 8 ? k_gain<8> : k_gain<16>);
-         hipLaunchKernelGGL(kg, dim3(h->num_cus * (mode == 0 ? 4 : 8)), dim3(tl == 64 ? 64 : (tl == 8 ? 8 : 16)), 0, st, (const DevCfg *)h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
+         hipLaunchKernelGGL(k_gain, dim3(h->num_cus * 4), dim3(64), 0, st, (const DevCfg *)h->d_dev, mode, cstp, (long long)nrows, (long long)row_base, (const rtfe_burst *)d_bursts,
                             scratch, ctlp, d_counts, d_events, chainh, (const CRec *)crecp, (const uint2 *)erefp, (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ccap,
                             (const unsigned char *)pkpool, ptiles, reinterpret_cast<GsSeg *>(wsb + ws_pksegs_off(h, nrows)), pk_seg_cap(h, nrows), (const int16_t *)d_rows);
          if (mode == 0) {
@@ -964,7 +959,7 @@ extern "C" int rtfe_scan_stats(rtfe_handle *h, const void *d_workspace, int64_t 
       if (hipMemcpy(&fl, &h->d_dev->floor_now, sizeof fl, hipMemcpyDeviceToHost) != hipSuccess) return fail(-44, "hipMemcpy failed");
       uint32_t fb; memcpy(&fb, &fl, 4); out[22] = (int64_t)fb;
       memcpy(&fb, &sc.floor_used, 4); out[23] = (int64_t)fb; }      // the floor this scan's screen was built for
-   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)((h->dev.debug == 4 || h->dev.debug == 6 || h->dev.debug == 8) ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
+   for (int i = 0; i < 8; ++i) out[13 + i] = (int64_t)((h->dev.debug == 4 || h->dev.debug == 6 || h->dev.debug == 8 || h->dev.debug == 9) ? sc.dbg2[i] : sc.scr[i]);      // (RTFE_DEBUG=4: k_gain's cycle counters instead)      // RTFE_DEBUG=3: k_sift cycles per phase (copy, dense, owners, record bytes, hard candidates, rounds, rounds with one, tiles)
    return 0; }
 
 extern "C" int rtfe_scan_exact(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int64_t row_base,

@@ -477,18 +477,17 @@ struct GsConst {                       // what a segment's lane needs to know ab
    int W, sure_i, limit32, amp_on, sl, pad; };
 struct ChainSt { Walker w; float heights[10]; long long i, c, iend; int status, seg0, nseg, pad; unsigned int seg_ev0, seg_ev1; GsConst k; };      // (iend, seg0, nseg: the steady stretch and its segments)
 
-// LANES chains a wave (a workgroup of LANES threads).  The heads (mode 0) walk in lock step, 64 a wave; the tails (mode 1) do not: every general step a lane takes - a chain of
-// dependent loads, ~10 us - is paid by its whole wave, and a 60 mV-noise tape's chains come with two or three each: 64 lanes a wave were 150 general steps in a row (2.1 ms
-// for 18 k chains on a chip that runs 1 024 such waves at once); sixteen lanes a wave are a quarter of that.
-template <int LANES>
-__global__ void __launch_bounds__(LANES) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
+// (Chains a wave: 64, also for the tails.  Their time is the slowest wave's - every general step a lane takes, every record it walks alone is paid by its whole wave - but the
+//  kernel's 480 registers leave the chip 1 024 waves at once and a 60 mV-noise tape's 18 k chains are 290: sixteen or eight chains a wave took 2.9 / 3.7 ms instead of 2.2,
+//  measured - more waves than slots, and the slowest of sixteen lanes walks 36 chunks where the slowest of 64 walks 48.)
+__global__ void __launch_bounds__(64) k_gain(const DevCfg *__restrict__ cfgp, int mode, ChainSt *__restrict__ cst, long long nrows, long long row_base,
                                              const rtfe_burst *__restrict__ bursts, BurstScratch *__restrict__ scratch, BurstCtl *__restrict__ ctl,
                                              uint32_t *__restrict__ counts, rtfe_event *__restrict__ events, float *__restrict__ chain_h,
                                              const CRec *__restrict__ crec, const uint2 *__restrict__ cmar, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ ctot,
                                              long long ccap, const unsigned char *__restrict__ pool, long long ntiles, GsSeg *__restrict__ segs, long long seg_cap, const int16_t *__restrict__ rows) {
-   __shared__ float s_heights[LANES * 10];
-   __shared__ uint4 s_notes[kGainChunk][LANES];                           // the events the fast path notes, until the chunk's end
-   __shared__ uint4 s_rec[kGainChunk + 1][LANES];                         // the lanes' records of the current chunk
+   __shared__ float s_heights[64 * 10];
+   __shared__ uint4 s_notes[kGainChunk][64];                           // the events the fast path notes, until the chunk's end
+   __shared__ uint4 s_rec[kGainChunk + 1][64];                         // the lanes' records of the current chunk
    const DevCfg &cfg = *cfgp;
    const int ntrks = cfg.ntrks, nwalk = cfg.nparm * ntrks, nlists = cfg.nscreens * ntrks;
    const int lane = threadIdx.x;
@@ -496,7 +495,7 @@ __global__ void __launch_bounds__(LANES) k_gain(const DevCfg *__restrict__ cfgp,
    const int nchains = chain_count(cfg, scratch->nbursts);
    float *heights = s_heights + lane * 10;
    // (every lane of a wave goes through the same rounds - the wave votes on them - so a lane without a chain walks a finished one)
-   for (int cbase = blockIdx.x * LANES; cbase < nchains; cbase += gridDim.x * LANES) {
+   for (int cbase = blockIdx.x * 64; cbase < nchains; cbase += gridDim.x * 64) {
       const ChainIx cx_ = chain_ix(cfg, cbase + lane < nchains ? cbase + lane : nchains - 1);
       const int ci = cx_.ci, b = cx_.b, wi = cx_.wi, pidx = cx_.pidx, trk = cx_.trk;
       const bool active = cbase + lane < nchains && ctl[b].status == kBurstReady && (mode == 0 || cst[ci].status == kChGeneral);

@@ -317,6 +317,95 @@ __device__ __forceinline__ int pk_ctz(uint64_t m) { return m ? __ffsll((long lon
 __device__ __forceinline__ int pk_clz(uint32_t m) { return m ? __clz((int)m) : 32; }
 __device__ __forceinline__ int pk_clz(uint64_t m) { return m ? __clzll((long long)m) : 64; }
 
+// ---- the general walk with the SIXTEEN LANES of a candidate's group at work (k_sift_hard; round 6).  pk_bot / pk_emit above are one lane's loops over rows - up to W - 2 margin
+// tests a pass, several passes a record, 64 table look-ups back to the last forced rescan: a few hundred dependent LDS reads a candidate.  Here a lane takes a ROW: a pass over a
+// run's rows is one step (three for the widest windows) whose verdicts a ballot gathers into a mask, and the counts are bit scans of the masks (as pk_fast_w does for the common
+// candidate).  Control flow is the WAVE's (its four groups go through the same loops; a group that has nothing to do in a step votes with zeros), the results are each group's own,
+// the same in all its lanes.  gsh: the group's first lane in its wave.
+template <class C> __device__ __forceinline__ uint64_t pk_grp_ballot(bool p, int gsh) { return (uint64_t)((__ballot(p) >> gsh) & 0xffffull); }
+template <class C> __device__ __forceinline__ void pk_emit_grp(const C &c, PkSink &o, int head, bool ev, int pos, int val, int ra, int rb, bool unknown, int sl, int gsh) {
+   if (rb > c.last) rb = c.last;
+   ev = ev && ra <= rb;
+   uint64_t lo = 0, hi = 0;                                          // row ra + k: its margin above the screen / at the sure level
+   for (int k0 = 0; __ballot(ev && ra + k0 <= rb) != 0ull; k0 += 16) {
+      const int n = ra + k0 + sl;
+      const bool in = ev && n <= rb;
+      const int m = in ? pk_margin(c, head, n, val, false) : 0;
+      lo |= pk_grp_ballot<C>(in && m > c.lo_i, gsh) << k0;
+      hi |= pk_grp_ballot<C>(in && m >= c.hi_i, gsh) << k0; }
+   if (!ev || !lo) return;
+   const int f = pk_ctz(lo), l = 63 - pk_clz(lo), span = l - f + 1;
+   int nlead = 0, nsure = 0, ntail = 0;
+   if (unknown) nsure = span;                                        // (runs are shorter than 63 rows)
+   else {
+      const uint64_t h = hi >> f;
+      nlead = pk_ctz(h);
+      if (nlead > span) nlead = span;
+      nsure = nlead >= span ? 0 : pk_ctz((uint64_t)~(h >> nlead));
+      if (nsure > span - nlead) nsure = span - nlead;
+      ntail = span - nlead - nsure;
+      if (nlead > 15 || ntail > 15 || nsure > 62) { nlead = span >> 4; ntail = span & 15; nsure = 63; } }
+   sink_add(o, pk_w0(pos, false, ra + f, nlead, nsure, ntail), unknown ? 0xffff8000u : pk_w1(val, c.t.at(pos - 1, head), c.t.at(pos + 1, head), false)); }
+
+template <class C> __device__ __forceinline__ void pk_bot_grp(const C &c, PkSink &out, int head, int q, bool live, int sl, int gsh) {
+   const int W = c.W;
+   const int val = live ? c.t.at(q, head) : 0;
+   uint64_t mj = 0, md = 0;                                          // x[q - 1 - j] > val / x[q + 1 + j] >= val
+   for (int j0 = 0; __ballot(live && j0 < W - 1) != 0ull; j0 += 16) {
+      const int j = j0 + sl;
+      const bool in = live && j < W - 1;
+      mj |= pk_grp_ballot<C>(in && c.t.at(q - j - 1, head) > val, gsh) << j0;
+      md |= pk_grp_ballot<C>(in && j < W - 2 && c.t.at(q + j + 1, head) >= val, gsh) << j0; }
+   const int J = pk_ctz((uint64_t)~mj), D = pk_ctz((uint64_t)~md);    // (bits from W - 1 / W - 2 on are clear: the counts stop there)
+   const int aq = q + (W - 1 - J > 0 ? W - 1 - J : 0);                // first row at which q is the first window minimum
+   const int ra = aq > q + 1 ? aq : q + 1, rb = q + D;
+   bool act = live && ra <= rb;
+   uint64_t mlo = 0;                                                // rows ra + k at which the true minimum would pass the screen
+   for (int k0 = 0; __ballot(act && ra + k0 <= rb) != 0ull; k0 += 16) {
+      const int n = ra + k0 + sl;
+      const bool in = act && n <= rb;
+      mlo |= pk_grp_ballot<C>(in && pk_margin(c, head, n, val, false) > c.lo_i, gsh) << k0; }
+   act = act && mlo != 0;
+   const int n0 = ra + pk_ctz(mlo);
+   uint64_t ma = 0;                                                 // a rescan at any row of [aq, n0] makes q the reference's minimum from then on
+   for (int k0 = 0; __ballot(act && aq + k0 <= n0) != 0ull; k0 += 16) {
+      const int r = aq + k0 + sl;
+      const bool in = act && r <= n0;
+      ma |= pk_grp_ballot<C>(in && pk_async(c, head, r), gsh) << k0; }
+   // 0: the minimum the reference holds at n0 comes from further back; 1: one last record for q; 2: on the chain of rescans; 3: done
+   int mode = !act ? 3 : (ma ? 1 : 0);
+   bool fin_unknown = false;
+   int r0 = aq - 1;
+   {  bool found = false;                                            // last forced rescan in front of aq, kPkBack rows back at the most
+      for (int b0 = 0; __ballot(mode == 0 && !found && b0 < kPkBack) != 0ull; b0 += 16) {
+         const int r = aq - 1 - b0 - sl;
+         const bool in = mode == 0 && !found && b0 + sl < kPkBack;
+         const uint64_t m = pk_grp_ballot<C>(in && pk_async(c, head, r), gsh);
+         if (mode == 0 && !found && m) { r0 = aq - 1 - b0 - pk_ctz(m); found = true; } }
+      if (mode == 0 && !found) { mode = 1; fin_unknown = true; } }
+   uint64_t m1 = 0;                                                 // first forced rescan behind n0 (within the run)
+   for (int k0 = 0; __ballot(mode == 0 && n0 + 1 + k0 <= rb) != 0ull; k0 += 16) {
+      const int r = n0 + 1 + k0 + sl;
+      const bool in = mode == 0 && r <= rb;
+      m1 |= pk_grp_ballot<C>(in && pk_async(c, head, r), gsh) << k0; }
+   const int r1 = m1 ? n0 + 1 + pk_ctz(m1) : rb + 1;
+   int start = r0, o = 0, hop = 0;
+   if (mode == 0) { o = pk_argmin(c, head, r0); mode = 2; }
+   while (__ballot(mode == 1 || mode == 2) != 0ull) {
+      bool ev = false, eunk = false;
+      int epos = q, eval = val, era = 0, erb = rb;
+      if (mode == 1) { ev = true; eunk = fin_unknown; era = n0; mode = 3; }
+      else if (mode == 2) {
+         if (hop >= kPkBack + 64) { ev = true; eunk = true; era = n0 > start ? n0 : start; mode = 3; }      // (on a rising slope the minimum is the sample about to leave: a rescan per row)
+         else if (o == q) { ev = true; era = n0 > start ? n0 : start; mode = 3; }
+         else {
+            const int next = o + W < r1 ? o + W : r1;                // the epoch of owner o covers rows [start, next - 1]
+            if (next - 1 >= n0) { ev = true; epos = o; eval = c.t.at(o, head); era = n0 > start ? n0 : start; erb = rb < next - 1 ? rb : next - 1; }
+            if (next > rb) mode = 3;
+            else { start = next; o = pk_argmin(c, head, next); } }
+         ++hop; }
+      pk_emit_grp(c, out, head, ev, epos, eval, era, erb, eunk, sl, gsh); } }
+
 // ---- the common case in registers: every sample a candidate's rows can see is loaded with independent LDS reads, and the run
 // and its record follow from bit masks over the rows.  WM >= W.
 // Returns 0: no record; 1: the record (w0, w1); 2: the candidate needs the general walk (a bottom whose first rows precede every
@@ -1137,7 +1226,7 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
 // ------------------------------------------------------------------------------------------------
 constexpr int kHardCol = 320;      // samples of a candidate's head its wave keeps in LDS: kPkBack + 3 W + 16 <= 230 for W <= 50, what is outside comes from HBM
 __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
-                                                   const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf, int *__restrict__ extra) {
+                                                   const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf, int *__restrict__ extra, unsigned long long *__restrict__ dbg) {
    // SIXTEEN LANES per candidate (round 6; a wave per candidate before): they fetch the head's samples the walk can read - one round trip -, make "rescan
    // forced" and "leftmost window minimum" for every row around the candidate (a few rows a lane), and the first of them walks on those tables.  What a
    // candidate costs is that walk - one lane's loops over table entries, tens of microseconds -, so four of them share a wave: a tape with 60 mV rms of noise
@@ -1151,8 +1240,11 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
    const int sl = threadIdx.x & (kSub - 1), wv = threadIdx.x / kSub;
    int n = *hard_count;
    if (n > hard_cap) n = hard_cap;
+   const bool prof = cfg.debug == 9 && threadIdx.x == 0;                  // (RTFE_DEBUG=9: cycles of the first wave's phases - fetch, tables, walk - and its trips)
+   long long pt[4] = {0, 0, 0, 0};
    for (int i0 = blockIdx.x * kGroups; i0 < n; i0 += gridDim.x * kGroups) {      // (the same trips for every lane of the workgroup: the wave-level fences below)
       const int i = i0 + wv;
+      long long tq = prof ? clock64() : 0;
       SfHard hd = sf_hard_none();
       if (i < n) hd = hard[i];
       const bool live = hd.head != 0xff;                                  // (0xff: a place of a wave's chunk that no candidate took, or none at all)
@@ -1169,6 +1261,7 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       rtfe_wave_sync();
       if (live) for (int k = sl; k < ncol; k += kSub) s_col[wv][k] = (int16_t)cx.t.tape.at(r0 + k, (int)hd.head);
       rtfe_wave_sync();
+      if (prof) { const long long t = clock64(); pt[0] += t - tq; tq = t; }
       cx.t.col = s_col[wv]; cx.t.r0 = r0; cx.t.n = ncol; cx.t.head = (int)hd.head;
       cx.t.as = s_as[wv]; cx.t.am = s_am[wv]; cx.t.k0 = S.W;
       if (live) {  // row r0 + k, k >= W: its window is col[k - W + 1 .. k], the sample leaving it col[k - W] (pk_async_g / pk_argmin_g on the column)
@@ -1184,9 +1277,18 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
             s_as[wv][k] = (unsigned char)(sub || (dom && ye <= v));
             s_am[wv][k] = (int16_t)(k - W + best); } }
       rtfe_wave_sync();
-      if (!live || sl != 0) continue;
+      if (prof) { const long long t = clock64(); pt[1] += t - tq; tq = t; ++pt[3]; }
       PkSink sk; sk.n = 0;
-      pk_bot(cx, sk, (int)hd.head, (int)hd.pos);
+      pk_bot_grp(cx, sk, (int)hd.head, (int)hd.pos, live, sl, (int)(threadIdx.x & 63 & ~(kSub - 1)));
+#ifdef RTFE_CPU_EMUL
+      if (live && sl == 0 && getenv("RTFE_HARD_CHECK")) {             // (emulator: the group's walk against one lane's)
+         PkSink s2; s2.n = 0;
+         pk_bot(cx, s2, (int)hd.head, (int)hd.pos);
+         bool same = s2.n == sk.n;
+         for (int j = 0; same && j < s2.n && j < 4; ++j) same = s2.w0[j] == sk.w0[j] && s2.w1[j] == sk.w1[j];
+         if (!same) fprintf(stderr, "hard_check: candidate %d (tile %u pos %d head %d): the group's walk made %d records (%08x %08x ..), one lane's %d (%08x %08x ..)\n", i, hd.tile, (int)hd.pos, (int)hd.head, sk.n, sk.w0[0], sk.w1[0], s2.n, s2.w0[0], s2.w1[0]); }
+#endif
+      if (!live || sl != 0) continue;
       unsigned char *slot = ovf + (size_t)i * kSfOvfBytes;
       int nrec = sk.n;
       if (nrec > 4) nrec = -1;
@@ -1200,6 +1302,8 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
          pk_margins(cx, (int)hd.head, sk.w0[j], sk.w1[j], mb + kPkMar);
          const uint2 blk = make_uint2((uint32_t)mb[0] | ((uint32_t)mb[1] << 16), (uint32_t)mb[2] | ((uint32_t)mb[3] << 16));      // (the block as it lies in memory: entry j at its end - 2 (j + 1))
          *reinterpret_cast<uint2 *>(slot + 8 + 16 * j + 8) = blk;
-         reinterpret_cast<uint32_t *>(slot + 72)[j] = crec_weak_bits(sk.w0[j], sk.w1[j], blk); } } }
+         reinterpret_cast<uint32_t *>(slot + 72)[j] = crec_weak_bits(sk.w0[j], sk.w1[j], blk); }
+      if (prof) pt[2] += clock64() - tq; }
+   if (prof) { atomicAdd(&dbg[0], (unsigned long long)pt[0]); atomicAdd(&dbg[1], (unsigned long long)pt[1]); atomicAdd(&dbg[2], (unsigned long long)pt[2]); atomicAdd(&dbg[3], (unsigned long long)pt[3]); atomicAdd(&dbg[4], 1ull); } }
 
 }  // namespace rtfe

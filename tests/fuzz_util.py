@@ -23,16 +23,14 @@ def base_tape(kind, seed, noise_mv):
     return tape, (["-m"] if kind.endswith("_m") else [])
 
 
-def shape_tape(seed, density=0.25, noise_mv=5.0, reach=14, kind="nrzi9", wild=1.0):
-    """A clean tape with random shapes written over a share of its peaks (from the 24th peak of a track's block on: the chains are steady there).
+def shape_rows(rows0, rng, density=0.25, reach=14, wild=1.0):
+    """rows0 with random shapes written over a share of its peaks (from the 24th peak of a track's block on: the chains are steady there); returns (rows, sites).
     wild: the share of sites drawn from the full mixture; the others only move samples by a few per cent of the peak (what a real head could deliver)."""
-    tape, opts = base_tape(kind, seed, noise_mv)
-    rows = tape.rows.copy()
-    rng = np.random.default_rng(seed * 7919 + 13)
+    rows = rows0.copy()
     nrows, ntrks = rows.shape
     nsites = 0
     for t in range(ntrks):
-        x = tape.rows[:, t].astype(np.int64)
+        x = rows0[:, t].astype(np.int64)
         amp = np.abs(x).max()
         # local extremes well above the noise
         mid = x[1:-1]
@@ -78,6 +76,13 @@ def shape_tape(seed, density=0.25, noise_mv=5.0, reach=14, kind="nrzi9", wild=1.
                     y = v - s * int(round(mag * u))
                     rows[r, t] = np.clip(y, -32767, 32767)
                 nsites += 1
+    return rows, nsites
+
+
+def shape_tape(seed, density=0.25, noise_mv=5.0, reach=14, kind="nrzi9", wild=1.0):
+    """A clean tape of one of KINDS with shape_rows() over it: (tape, rows, sites, oracle options)."""
+    tape, opts = base_tape(kind, seed, noise_mv)
+    rows, nsites = shape_rows(tape.rows, np.random.default_rng(seed * 7919 + 13), density=density, reach=reach, wild=wild)
     return tape, rows, nsites, opts
 
 

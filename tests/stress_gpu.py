@@ -124,6 +124,13 @@ for i in range(ntapes):
         import dataclasses
         n = tape.rows.shape[0]; a, b = sorted(int(x) for x in rng.integers(0, n, size=2))
         if b - a > 2000: tape = dataclasses.replace(tape, rows=np.ascontiguousarray(tape.rows[a:b]))
+    if os.environ.get("STRESS_SHAPES"):                        # (round 6: tests/fuzz_util.py's shapes over a share of the tapes - a generator of its own, off by default: see rng2 below)
+        import dataclasses
+        from fuzz_util import shape_rows
+        rng3 = np.random.default_rng((int(sys.argv[1]) if len(sys.argv) > 1 else 1) * 200003 + i)
+        if rng3.random() < 0.6:
+            rows3, _ = shape_rows(tape.rows, rng3, density=float(rng3.choice([0.05, 0.15, 0.4])), wild=float(rng3.choice([0.0, 0.5, 1.0])))
+            tape = dataclasses.replace(tape, rows=rows3); kind += "+shapes"
     hdr = tape.spec.header()
     # the peak path's knobs: the chains' general step for every detection / the general sift kernel, at random
     seg, warm = int(rng.choice([0, 1])), int(rng.choice([0, 1]))
