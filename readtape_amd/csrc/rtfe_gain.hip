@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *
             const uint32_t wk = crec_weak_bits(w0, w1, mk2);
             CRec c; c.pos = (uint32_t)(pos0 + (long long)(w0 & 0x7ffu)); c.w0 = (w0 & ~0x7ffu) | wk; c.w1 = w1; c.volt = volt((int)(int16_t)(w1 & 0xffffu), mv);
             if (crec_can_clear(w0, w1, wk)) {
-               const int X = p32 + (int)(w0 & 0x7ffu) + (int)((w0 >> 12) & 63u) + (int)((w0 >> 18) & 15u);      // (kCrWeak: one behind its last row)
+               const int X = p32 + (int)(w0 & 0x7ffu) + (int)((w0 >> 12) & 63u) + (int)((w0 >> 18) & 15u) - (wk ? 1 : 0);      // the first sure row; kCrWeak: its last row
                // its successor: the list's next entry, the next tile's first, none
                uint2 sq = q1; int sp0 = p32; int kind = 0;                 // 0: an entry, 1: nothing behind it that could matter, 2: cannot tell from here
                if (k + 1 >= nrec_l) {
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) k_clear(const unsigned long long *__restr
       const long long ne = (long long)ctot[sl];
       const CRec *r = crec + (size_t)sl * ccap;
       const uint32_t w0 = r[i].w0;
-      const int X = (int)r[i].pos + (int)((w0 >> 12) & 63u) + (int)((w0 >> 18) & 15u);
+      const int X = (int)r[i].pos + (int)((w0 >> 12) & 63u) + (int)((w0 >> 18) & 15u) - ((w0 & kCrWeak) ? 1 : 0);      // the last row it can fire at: its first sure row; kCrWeak: its last row
       bool ok = false;
       #pragma nounroll
       for (long long j = i + 1; ; ++j) {
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(64) k_prep_check(const DevCfg *__restrict__ cf
          if (!(w0 & kCrClear)) continue;
          ++nclear;
          if ((w0 & kCrBad) || w1 == 0xffff8000u || ((unsigned)(nsure - 1) >= 62u && !(w0 & kCrWeak))) fprintf(stderr, "prep_check: stream %d record %lld pos %u is marked clear and has no sure stretch (w0 %08x w1 %08x)\n", sl, i, r[i].pos, w0, w1);
-         const long long X = (long long)r[i].pos + (long long)((w0 >> 12) & 63u) + (long long)((w0 >> 18) & 15u);
+         const long long X = (long long)r[i].pos + (long long)((w0 >> 12) & 63u) + (long long)((w0 >> 18) & 15u) - ((w0 & kCrWeak) ? 1 : 0);
          for (long long j = i + 1; j < n && j < i + 600; ++j) {
             if ((long long)r[j].pos - 2 * kSfPosBias > X) break;            // (owners lie less than kSfPosBias rows in front of their candidates, rows behind them)
             const long long fj = (long long)r[j].pos + (long long)((r[j].w0 >> 12) & 63u);

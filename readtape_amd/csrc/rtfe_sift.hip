@@ -120,9 +120,11 @@ struct PkCol {
       const int i = r - r0;
       return (hd == head && (unsigned)i < (unsigned)n) ? (int)col[i] : tape.at(r, hd); } };
 
-// ... the same with the two things the general walk asks of every row - "is a rescan forced here" and "where is the window's leftmost
-// minimum" - made beforehand by all lanes of the wave for the rows around the candidate (k_sift_hard): as[i] / am[i] for row r0 + i, i in [k0, n)
-struct PkColPre : PkCol { const unsigned char *as; const int16_t *am; int k0; };
+// ... the same without the tape behind it: every row the general walk can ask for is in the copy (k_sift_hard, W <= 50: kPkBack + 3 W + 16 <= kHardCol samples from
+// kPkBack + 2 W + 8 rows in front of the candidate) - no test, no branch to a global load between two LDS reads
+struct PkColFast {
+   const int16_t *col; int r0;
+   __device__ __forceinline__ int at(int r, int) const { return (int)col[r - r0]; } };
 
 // LDS carve of k_sift.  ONE definition for the kernel and for the host's sizing.
 struct SfLds { unsigned xs, wl, stage, total; };
@@ -268,14 +270,6 @@ template <class C> __device__ __forceinline__ int pk_argmin_g(const C &c, int he
    return best; }
 template <class C> __device__ __forceinline__ bool pk_async(const C &c, int head, int r) { return pk_async_g(c, head, r); }
 template <class C> __device__ __forceinline__ int pk_argmin(const C &c, int head, int r) { return pk_argmin_g(c, head, r); }
-// (k_sift_hard: looked up where the wave made them beforehand)
-__device__ __forceinline__ bool pk_async(const PkCtxT<PkColPre> &c, int head, int r) {
-   const int i = r - c.t.r0;
-   return (head == c.t.head && i >= c.t.k0 && i < c.t.n) ? c.t.as[i] != 0 : pk_async_g(c, head, r); }
-__device__ __forceinline__ int pk_argmin(const PkCtxT<PkColPre> &c, int head, int r) {
-   const int i = r - c.t.r0;
-   return (head == c.t.head && i >= c.t.k0 && i < c.t.n) ? c.t.r0 + (int)c.t.am[i] : pk_argmin_g(c, head, r); }
-
 // a bottom candidate, general walk: sample q is the true window minimum (first from the left) at rows [ra, rb]; what the
 // reference tests there is its own minimum, refreshed only by rescans (src/decoder.c:765-775).
 template <class C> __device__ __forceinline__ void pk_bot(const C &c, PkSink &out, int head, int q) {
@@ -1234,23 +1228,24 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
    // (Round 4: the walking lane made the tables as it went - pk_async over a window at every row it stepped back: ~1 500 dependent LDS reads, 60 - 100 us a candidate.)
    constexpr int kSub = 16, kGroups = 256 / kSub;
    __shared__ int16_t s_col[kGroups][kHardCol];
-   __shared__ int16_t s_am[kGroups][kHardCol];
-   __shared__ unsigned char s_as[kGroups][kHardCol];
    const DevCfg &cfg = *cfgp;
    const int sl = threadIdx.x & (kSub - 1), wv = threadIdx.x / kSub;
    int n = *hard_count;
    if (n > hard_cap) n = hard_cap;
    const bool prof = cfg.debug == 9 && threadIdx.x == 0;                  // (RTFE_DEBUG=9: cycles of the first wave's phases - fetch, tables, walk - and its trips)
    long long pt[4] = {0, 0, 0, 0};
+   SfHard hd_next = sf_hard_none();                                      // (the next trip's candidate: its load travels beside this trip's samples, not in front of its own)
+   if (blockIdx.x * kGroups + wv < n) hd_next = hard[blockIdx.x * kGroups + wv];
    for (int i0 = blockIdx.x * kGroups; i0 < n; i0 += gridDim.x * kGroups) {      // (the same trips for every lane of the workgroup: the wave-level fences below)
       const int i = i0 + wv;
       long long tq = prof ? clock64() : 0;
-      SfHard hd = sf_hard_none();
-      if (i < n) hd = hard[i];
+      SfHard hd = hd_next;
+      hd_next = sf_hard_none();
+      {  const long long i2 = (long long)i + (long long)gridDim.x * kGroups; if (i2 < n) hd_next = hard[i2]; }
       const bool live = hd.head != 0xff;                                  // (0xff: a place of a wave's chunk that no candidate took, or none at all)
       if (!live) { hd.head = 0; hd.screen = 0; }
       const DevScreen &S = cfg.screen[hd.screen];
-      PkCtxT<PkColPre> cx;
+      PkCtxT<PkCol> cx;
       cx.t.tape.rows = rows; cx.t.tape.t0 = (long long)hd.tile * kSfTile; cx.t.tape.nrows = nrows; cx.t.tape.ntrks = cfg.ntrks; cx.t.tape.sg = cfg.invert ? -1 : 1;
       cx.W = S.W; cx.lo_i = S.rise_i; cx.hi_i = S.sure_i;
       const long long lastl = nrows - 1 - cx.t.tape.t0;
@@ -1263,23 +1258,15 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       rtfe_wave_sync();
       if (prof) { const long long t = clock64(); pt[0] += t - tq; tq = t; }
       cx.t.col = s_col[wv]; cx.t.r0 = r0; cx.t.n = ncol; cx.t.head = (int)hd.head;
-      cx.t.as = s_as[wv]; cx.t.am = s_am[wv]; cx.t.k0 = S.W;
-      if (live) {  // row r0 + k, k >= W: its window is col[k - W + 1 .. k], the sample leaving it col[k - W] (pk_async_g / pk_argmin_g on the column)
-         const int W = S.W;
-         for (int k = W + sl; k < ncol; k += kSub) {
-            const int16_t *c0 = s_col[wv] + (k - W);
-            const int v = c0[0];
-            bool dom = true, sub = true;
-            int best = 1, bv = c0[1];
-            for (int j = 1; j < W; ++j) { const int y = c0[j]; dom = dom && y <= v; sub = sub && y >= v; if (y < bv) { bv = y; best = j; } }
-            const int ye = c0[W];
-            if (ye < bv) best = W;
-            s_as[wv][k] = (unsigned char)(sub || (dom && ye <= v));
-            s_am[wv][k] = (int16_t)(k - W + best); } }
-      rtfe_wave_sync();
+      // (no tables of "rescan forced" / "leftmost window minimum" for every row around the candidate any more: sixteen lanes made 106 rows' worth - 7.6 us of a trip's 17.7 -
+      //  and the group's walk asks for a pass or two of them: each lane makes its row's answer when it is asked, W LDS reads)
       if (prof) { const long long t = clock64(); pt[1] += t - tq; tq = t; ++pt[3]; }
       PkSink sk; sk.n = 0;
-      pk_bot_grp(cx, sk, (int)hd.head, (int)hd.pos, live, sl, (int)(threadIdx.x & 63 & ~(kSub - 1)));
+      if (__ballot(live && kPkBack + 3 * S.W + 16 > kHardCol) == 0ull) {     // (every window of the wave's candidates fits its copy: always, for the windows the front end takes)
+         PkCtxT<PkColFast> cf;
+         cf.t.col = s_col[wv]; cf.t.r0 = r0; cf.W = cx.W; cf.lo_i = cx.lo_i; cf.hi_i = cx.hi_i; cf.last = cx.last;
+         pk_bot_grp(cf, sk, (int)hd.head, (int)hd.pos, live, sl, (int)(threadIdx.x & 63 & ~(kSub - 1))); }
+      else pk_bot_grp(cx, sk, (int)hd.head, (int)hd.pos, live, sl, (int)(threadIdx.x & 63 & ~(kSub - 1)));
 #ifdef RTFE_CPU_EMUL
       if (live && sl == 0 && getenv("RTFE_HARD_CHECK")) {             // (emulator: the group's walk against one lane's)
          PkSink s2; s2.n = 0;
