@@ -8,7 +8,7 @@ root, config, rows, tag = sys.argv[1], sys.argv[2], int(float(sys.argv[3])), sys
 CAL_BYTES = 1 << 30
 
 # kernel -> the span of rtfe_scan that times it (readtape_amd/csrc/rtfe_api.hip KNAMES)
-SPANS = [("k_scan_begin", "k_sift"), ("k_reset_floor", "k_sift"), ("k_adapt_floor", "k_decode"), ("k_dseg", "k_dseg"), ("k_dorder", "k_dchain"), ("k_dchain", "k_dchain"), ("k_sift_hard", "k_prep"), ("k_sift", "k_sift"), ("k_qpack", "k_bursts"), ("k_pscan", "k_prep"), ("k_prep", "k_prep"), ("k_bursts", "k_bursts"),
+SPANS = [("k_scan_begin", "k_sift"), ("k_reset_floor", "k_sift"), ("k_adapt_floor", "k_decode"), ("k_dseg", "k_dseg"), ("k_dorder", "k_dchain"), ("k_dchain", "k_dchain"), ("k_sift_hard", "k_prep"), ("k_clear", "k_prep"), ("k_sift", "k_sift"), ("k_qpack", "k_bursts"), ("k_pscan", "k_prep"), ("k_prep", "k_prep"), ("k_bursts", "k_bursts"),
          ("k_zones", "k_bursts"), ("k_segplan", "k_gain_s"), ("k_gain_seg", "k_gain_s"), ("k_gain_join", "k_gain_s"), ("k_gain", "k_gain"), ("k_emit_seg", "k_emit"), ("k_emit", "k_emit"), ("k_publish", "k_emit"), ("k_decode", "k_decode"),
          ("k_zeros", "k_zeros"), ("k_quiet", "k_quiet")]
 
