@@ -50,6 +50,7 @@ struct rtfe_handle {
    int overlap;
    int bursts_wpr;                     // RTFE_BURSTS_WPR: words of the quiet map per round of the zone search (tests: many rounds on a short tape); 0 = 4096
    int sfs_occ[kMaxScreens];           // k_sift_s: workgroups of a screen's instantiation a CU holds at once (the occupancy API, at create)
+   long long work_cap;      // RTFE_WORK_CAP
    int ds_order, dchain_wgs, prep_wgs, dense_stop, dseg_wgs, dseg_threads;      // RTFE_DS_ORDER (0: chains in burst order), RTFE_DCHAIN_WGS / RTFE_PREP_WGS / RTFE_DSEG_WGS (workgroups per CU), RTFE_DENSE_STOP (debugging): read once, at create
    // rtfe_set_graphs: a scan's launches (about twenty, on two streams) captured once per set of arguments into a HIP graph and replayed - what a scan of the same
    // buffers costs the host, and the gaps between its kernels on the device, shrink to one launch
@@ -427,6 +428,7 @@ static int create_impl(const rtfe_config *c, rtfe_handle **out, int tile_overrid
    h->ds_order = getenv("RTFE_DS_ORDER") ? atoi(getenv("RTFE_DS_ORDER")) : 1;
    h->dchain_wgs = getenv("RTFE_DCHAIN_WGS") ? atoi(getenv("RTFE_DCHAIN_WGS")) : 16;
    h->prep_wgs = getenv("RTFE_PREP_WGS") ? atoi(getenv("RTFE_PREP_WGS")) : 32;
+   h->work_cap = getenv("RTFE_WORK_CAP") ? atoll(getenv("RTFE_WORK_CAP")) : -1;
    h->dense_stop = getenv("RTFE_DENSE_STOP") ? atoi(getenv("RTFE_DENSE_STOP")) : 99;
    h->dseg_wgs = getenv("RTFE_DSEG_WGS") ? atoi(getenv("RTFE_DSEG_WGS")) : 0;
    h->dseg_threads = getenv("RTFE_DSEG_THREADS") ? atoi(getenv("RTFE_DSEG_THREADS")) : 0;
@@ -576,7 +578,10 @@ static size_t ws_pkgfire_off(const rtfe_handle *h, int64_t nrows) { return ws_pk
 static size_t pk_gfire_bytes(const rtfe_handle *h, int64_t nrows) { return ((size_t)pk_seg_cap(h, nrows) * (size_t)(h->dev.pk_seg_recs > 0 ? h->dev.pk_seg_recs : 0) * 4 + 255) & ~(size_t)255; }
 
 // (k_prep's work list for k_clear lives in the gains' region - nothing reads it behind k_clear; 8 bytes a place, counted in an int)
-static long long pk_work_cap(const rtfe_handle *h, int64_t nrows) { const long long c = (long long)(pk_gfire_bytes(h, nrows) / 8); return c > 0x7ffffe00ll ? 0x7ffffe00ll : c; }
+static long long pk_work_cap(const rtfe_handle *h, int64_t nrows) {
+   long long c = (long long)(pk_gfire_bytes(h, nrows) / 8);
+   if (h->work_cap >= 0 && h->work_cap < c) c = h->work_cap;      // (RTFE_WORK_CAP, tests: a list that runs full - what does not fit stays unmarked, the general step's)
+   return c > 0x7ffffe00ll ? 0x7ffffe00ll : c; }
 
 // ... | the dense sample path: per (tile, width) "nothing above the screen" | per (sub-segment, track) the band | the slots
 static long long ds_tiles_for(int64_t nrows) { return (nrows + kDsTile - 1) / kDsTile; }

@@ -26,3 +26,22 @@ def test_emulated_lean_step_on_shaped_peaks(seed, tmp_path, monkeypatch, capfd):
     st = fe.scan_stats(fe.scan(rows).fetch())
     assert st["parallel"] > 2 * st["sequential"]          # the lean step still takes most of the tape
     assert "prep_check:" not in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("cap", [0, 300])
+def test_emulated_work_list_that_runs_full(cap, tmp_path, monkeypatch):
+    """k_prep's work list for k_clear with no room (RTFE_WORK_CAP): the records it could not take stay unmarked - more general steps, the same events."""
+    seed = 79
+    d = draw(seed)
+    tape, rows, nsites, opts = shape_tape(seed, **d)
+    hdr = tape.spec.header()
+    att = oracle_attempts(hdr, rows, opts, str(tmp_path))
+    full = emul_frontend(config_for(hdr, opts))
+    st_full = full.scan_stats(full.scan(rows).fetch())
+    monkeypatch.setenv("RTFE_WORK_CAP", str(cap))
+    monkeypatch.setenv("RTFE_PREP_CHECK", "1")
+    fe = emul_frontend(config_for(hdr, opts))
+    msgs, stats = check_tape(fe, hdr, rows, att)
+    assert not msgs, "\n".join(msgs[:12])
+    st = fe.scan_stats(fe.scan(rows).fetch())
+    assert st["sequential"] > st_full["sequential"] and st["parallel"] + st["sequential"] == st_full["parallel"] + st_full["sequential"]

@@ -22,3 +22,20 @@ def test_shaped_peaks(seed, tmp_path):
         msgs, stats = check_tape(fe, hdr, rows, att)
         assert not msgs, "\n".join(msgs[:12])
         assert stats["events"] > 0
+
+
+def test_work_list_that_runs_full(tmp_path, monkeypatch):
+    """k_prep's work list for k_clear with no room (RTFE_WORK_CAP): what it could not take stays unmarked - more general steps, the same events."""
+    seed = 79
+    d = draw(seed)
+    tape, rows, nsites, opts = shape_tape(seed, **d)
+    hdr = tape.spec.header()
+    att = oracle_attempts(hdr, rows, opts, str(tmp_path))
+    full = frontend.FrontEnd(config_for(hdr, opts))
+    st_full = full.scan_stats(full.scan(rows).fetch())
+    monkeypatch.setenv("RTFE_WORK_CAP", "300")
+    fe = frontend.FrontEnd(config_for(hdr, opts))
+    msgs, stats = check_tape(fe, hdr, rows, att)
+    assert not msgs, "\n".join(msgs[:12])
+    st = fe.scan_stats(fe.scan(rows).fetch())
+    assert st["sequential"] > st_full["sequential"] and st["parallel"] + st["sequential"] == st_full["parallel"] + st_full["sequential"]
