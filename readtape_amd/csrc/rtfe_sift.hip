@@ -1254,33 +1254,9 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       int ncol = kPkBack + 3 * S.W + 16;
       if (ncol > kHardCol) ncol = kHardCol;
       rtfe_wave_sync();
-      // the head's samples of rows r0 .. r0 + ncol - 1.  A 2-byte load a row is a cache line a lane (119 requests a candidate, 12 k cycles a trip); the rows' bytes are ONE
-      // contiguous range - ncol x ntrks samples - so the group reads it in aligned 16-byte pieces, two lines an instruction, and each piece holds the head's sample of at most
-      // one row (two on tapes of fewer than eight tracks).  A candidate within two rows of the tape's ends takes the row loads (rows outside the tape read as zeros).
-      const int ntk = cfg.ntrks;
-      const long long rowb = cx.t.tape.t0 + r0 - 2;                        // the piece arithmetic counts from two rows in front of the first
-      const bool inside = !live || (ntk >= 4 && rowb >= 0 && (rowb + 2 + ncol) * ntk + 8 <= nrows * (long long)ntk);      // (the aligned pieces: up to 7 samples either side of the rows)
-      if (__ballot(!inside) == 0ull) {
-         if (live) {
-            const long long gb = rowb * ntk, gf = gb + 2 * ntk;             // (sample indices: of row rowb, of row r0)
-            const long long a0 = gf & ~7ll;
-            const int d0 = (int)(a0 - gb), nch = (int)((gf + (long long)ncol * ntk - a0 + 7) >> 3);
-            const int sgn = cx.t.tape.sg;
-            for (int ci = sl; ci < nch; ci += kSub) {
-               const uint4 v = *reinterpret_cast<const uint4 *>(rows + a0 + 8ll * ci);
-               const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-               const unsigned d = (unsigned)(d0 + 8 * ci);
-               const unsigned rr = d / (unsigned)ntk, rem = d - rr * (unsigned)ntk;      // sample 0 of the piece: row rowb + rr, track rem
-               int j = (int)hd.head - (int)rem;
-               if (j < 0) j += ntk;
-               for (; j < 8; j += ntk) {
-                  const int k = (int)(rr + (rem + (unsigned)j) / (unsigned)ntk) - 2;
-                  if ((unsigned)k < (unsigned)ncol) {
-                     uint32_t x = 0;
-                     #pragma unroll
-                     for (int q2 = 0; q2 < 4; ++q2) if ((j >> 1) == q2) x = w[q2];
-                     s_col[wv][k] = (int16_t)(sgn * (int)(int16_t)((j & 1) ? (x >> 16) : (x & 0xffffu))); } } } } }
-      else if (live) for (int k = sl; k < ncol; k += kSub) s_col[wv][k] = (int16_t)cx.t.tape.at(r0 + k, (int)hd.head);
+      // (a 2-byte load a row - 119 requests a candidate, 12 k cycles a trip; the rows' bytes read as ONE range in aligned 16-byte pieces, each holding the head's sample of
+      //  one row, took 15.9 k: finding the sample in its piece costs more than the requests it saves - measured, round 6)
+      if (live) for (int k = sl; k < ncol; k += kSub) s_col[wv][k] = (int16_t)cx.t.tape.at(r0 + k, (int)hd.head);
       rtfe_wave_sync();
       if (prof) { const long long t = clock64(); pt[0] += t - tq; tq = t; }
       cx.t.col = s_col[wv]; cx.t.r0 = r0; cx.t.n = ncol; cx.t.head = (int)hd.head;
