@@ -39,3 +39,20 @@ def test_work_list_that_runs_full(tmp_path, monkeypatch):
     assert not msgs, "\n".join(msgs[:12])
     st = fe.scan_stats(fe.scan(rows).fetch())
     assert st["sequential"] > st_full["sequential"] and st["parallel"] + st["sequential"] == st_full["parallel"] + st_full["sequential"]
+
+
+@pytest.mark.parametrize("seed,window,halo", [(14, 1 << 13, 1 << 11), (79, 1 << 12, 1 << 10), (6, 1 << 13, 1 << 10)])
+def test_shaped_tape_in_streamed_windows(seed, window, halo, tmp_path):
+    """The shapes across fragment boundaries: a shaped tape through device windows far shorter than its blocks (the halo has to grow) writes the .tap of the
+    whole-tape decode - whose events test_shaped_peaks holds against the oracle."""
+    from readtape_amd import ingest, pipeline, tbin
+    d = draw(seed)
+    tape, rows, nsites, opts = shape_tape(seed, **d)
+    hdr = tape.spec.header()
+    pipeline.decode_tape(hdr, rows, str(tmp_path / "whole.tap"))
+    want = open(tmp_path / "whole.tap", "rb").read()
+    path = str(tmp_path / "t.tbin")
+    tbin.write_tbin(path, hdr, rows)
+    st = ingest.decode_file_streaming(path, str(tmp_path / "s.tap"), window_rows=window, halo_rows=halo, replay_threads=4, replay_split=3)
+    assert open(tmp_path / "s.tap", "rb").read() == want
+    assert st["rows"] == rows.shape[0] and st["windows"] >= 3
