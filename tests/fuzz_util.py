@@ -23,8 +23,9 @@ def base_tape(kind, seed, noise_mv):
     return tape, (["-m"] if kind.endswith("_m") else [])
 
 
-def shape_rows(rows0, rng, density=0.25, reach=14, wild=1.0):
-    """rows0 with random shapes written over a share of its peaks (from the 24th peak of a track's block on: the chains are steady there); returns (rows, sites).
+def shape_rows(rows0, rng, density=0.25, reach=14, wild=1.0, first=24):
+    """rows0 with random shapes written over a share of its peaks (from peak `first` of a track's block on - from the 24th the chains are steady, before it they learn
+    their baseline: the start-up path); returns (rows, sites).
     wild: the share of sites drawn from the full mixture; the others only move samples by a few per cent of the peak (what a real head could deliver)."""
     rows = rows0.copy()
     nrows, ntrks = rows.shape
@@ -42,7 +43,7 @@ def shape_rows(rows0, rng, density=0.25, reach=14, wild=1.0):
         # blocks: a gap of more than 200 rows between peaks
         starts = np.concatenate([[0], np.flatnonzero(np.diff(peaks) > 200) + 1, [peaks.size]])
         for a, b in zip(starts[:-1], starts[1:]):
-            for k in range(a + 24, b - 2):
+            for k in range(a + first, b - 2):
                 if rng.random() >= density:
                     continue
                 P = int(peaks[k])
@@ -79,15 +80,18 @@ def shape_rows(rows0, rng, density=0.25, reach=14, wild=1.0):
     return rows, nsites
 
 
-def shape_tape(seed, density=0.25, noise_mv=5.0, reach=14, kind="nrzi9", wild=1.0):
+def shape_tape(seed, density=0.25, noise_mv=5.0, reach=14, kind="nrzi9", wild=1.0, first=24):
     """A clean tape of one of KINDS with shape_rows() over it: (tape, rows, sites, oracle options)."""
     tape, opts = base_tape(kind, seed, noise_mv)
-    rows, nsites = shape_rows(tape.rows, np.random.default_rng(seed * 7919 + 13), density=density, reach=reach, wild=wild)
+    rows, nsites = shape_rows(tape.rows, np.random.default_rng(seed * 7919 + 13), density=density, reach=reach, wild=wild, first=first)
     return tape, rows, nsites, opts
 
 
 def draw(seed):
     """the parameters of tape `seed` (one place: the tool and tests/test_*fuzz* draw the same tapes)"""
     rng = np.random.default_rng(seed)
-    return dict(kind=str(rng.choice(KINDS)), density=float(rng.choice([0.05, 0.15, 0.4])), noise_mv=float(rng.choice([2.0, 10.0, 40.0])),
-                wild=float(rng.choice([0.0, 0.5, 1.0])))
+    d = dict(kind=str(rng.choice(KINDS)), density=float(rng.choice([0.05, 0.15, 0.4])), noise_mv=float(rng.choice([2.0, 10.0, 40.0])),
+             wild=float(rng.choice([0.0, 0.5, 1.0])))
+    if seed >= 100000:                                     # (later seeds: shapes over a block's first peaks too - the chains' start-up; the earlier seeds' tapes stay what they were)
+        d["first"] = int(rng.choice([0, 3, 24]))
+    return d

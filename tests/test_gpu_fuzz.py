@@ -9,7 +9,7 @@ from readtape_amd import frontend
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [6, 14, 23, 42, 47, 49, 57, 61, 63, 79] + list(range(900, 930)))
+@pytest.mark.parametrize("seed", [6, 14, 23, 42, 47, 49, 57, 61, 63, 79] + list(range(900, 930)) + list(range(100000, 100016)))      # (from 100000 on: shapes over a block's first peaks too)
 def test_shaped_peaks(seed, tmp_path):
     import torch
     assert torch.cuda.is_available(), "these tests need the MI355X"
