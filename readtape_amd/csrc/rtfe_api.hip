@@ -748,7 +748,6 @@ static int scan_launch(rtfe_handle *h, const int16_t *d_rows, int64_t nrows, int
       hipLaunchKernelGGL(k_pscan1, dim3(nsc), dim3(1024), 0, st, (const PeakDir *)dirm, (const int *)extrap, (int)ptiles, nlists, tstartp, ctotcp);
       hipLaunchKernelGGL(k_pscan2, dim3(1), dim3(1024), 0, st, nsc, nlists, (const uint32_t *)ctotcp, coffp, ctotp);
       PrepArgs ppa; ppa.nlists = nlists; ppa.ntrks = h->dev.ntrks; ppa.hcap = h->dev.pk_slot; ppa.mv = h->dev.maxvolts;
-      for (int sc2 = 0; sc2 < kMaxScreens; ++sc2) ppa.W[sc2] = h->dev.screen[sc2].W;
       // (workgroups per CU: 4 / 8 / 16 measured 0.51 / 0.47 / 0.42 ms for the span on C2 - half a wave per list, the more lists in flight the better)
       hipLaunchKernelGGL(k_prep, dim3(h->num_cus * (h->prep_wgs >= 1 && h->prep_wgs <= 4096 ? h->prep_wgs : 32)), dim3(256), 0, st, ppa, (const PeakDir *)dirm, (const unsigned char *)pkpool, (const unsigned char *)ovfp,
                          (const uint32_t *)tstartp, (const uint32_t *)coffp, (const uint32_t *)ctotp, ptiles, ccap, crecp, erefp,

@@ -153,16 +153,15 @@ __device__ __forceinline__ int half_incl_scan(int v, int hl) {
 
 // k_prep: the tiles' lists -> the streams.  Half a wave per list (a clean NRZI tile holds ~21 records per head), the next list's
 // directory entry and records in flight while this one is written (a list is two dependent HBM round trips otherwise, and there is
-// little else to hide them).  Per record: its absolute row, its volts, where its margin entries are, and kCrClear - everything static
-// that the chains' steady path asks of it: a plain record with a sure stretch whose successor in the stream (the next record of the
-// list; the first of the next tile's list) begins after this record's owner has left the window.
+// little else to hide them).  Per record: its absolute row, its volts, its margin block, kCrWeak, and kCrClear where the record's successor in the stream (the
+// list's next entry; the first of the next tile's list) settles it - the rest on a work list for k_clear (below).
 #ifdef RTFE_CPU_EMUL
 __device__ __forceinline__ int rtfe_uniform(int v) { return v; }
 #else
 __device__ __forceinline__ int rtfe_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value every lane of the wave holds: into a scalar register
 #endif
 constexpr int kPrepWorkChunk = 256;      // places of the work list a wave of k_prep takes at a time (a round puts up to 64 x 4 records on it)
-struct PrepArgs { int nlists, ntrks, hcap; float mv; int W[kMaxScreens]; };      // (by value: a wave's first loads do not wait for a read of the configuration block)
+struct PrepArgs { int nlists, ntrks, hcap; float mv; };      // (by value: a wave's first loads do not wait for a read of the configuration block)
 __global__ void __launch_bounds__(256) k_prep(const PrepArgs pa, const PeakDir *__restrict__ dir, const unsigned char *__restrict__ pool,
                                               const unsigned char *__restrict__ ovf, const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ coff,
                                               const uint32_t *__restrict__ ctot, long long ntiles, long long ccap, CRec *__restrict__ crec, uint2 *__restrict__ cmar,
