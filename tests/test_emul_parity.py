@@ -56,8 +56,8 @@ def test_emulated_screen_floor_follows_the_tape(tmp_path):
     RTFE_F_SCREEN_UNDERFLOW, checked through exact rescans, and the floor comes down again) - and a floor the caller gave stands."""
     import dataclasses
     from readtape_amd import synth
-    loud = synth.nrzi_tape(seed=311, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, amplitude=3.2)
-    weak = synth.nrzi_tape(seed=312, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, amplitude=0.9)
+    loud = synth.nrzi_tape(seed=311, nblocks=4, minlen=120, maxlen=300, gap_samples=3000, amplitude=3.2)
+    weak = synth.nrzi_tape(seed=312, nblocks=4, minlen=120, maxlen=300, gap_samples=3000, amplitude=0.9)
     hdr = loud.spec.header()
     opts = ["-m"]
     cfg = config_for(hdr, opts)
@@ -88,9 +88,9 @@ def test_emulated_first_scan_estimates_the_screen_floor_from_the_samples(tmp_pat
     RTFE_FLOOR_PROBE=0 is round 5's behaviour; a floor the caller gave stands."""
     import dataclasses
     from readtape_amd import synth
-    loud = synth.nrzi_tape(seed=321, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, amplitude=3.2)
-    weak = synth.nrzi_tape(seed=322, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, amplitude=0.9)
-    noisy = synth.nrzi_tape(seed=323, nblocks=6, minlen=120, maxlen=400, gap_samples=3000, noise_mv=60.0)
+    loud = synth.nrzi_tape(seed=321, nblocks=4, minlen=120, maxlen=300, gap_samples=3000, amplitude=3.2)
+    weak = synth.nrzi_tape(seed=322, nblocks=4, minlen=120, maxlen=300, gap_samples=3000, amplitude=0.9)
+    noisy = synth.nrzi_tape(seed=323, nblocks=4, minlen=120, maxlen=300, gap_samples=3000, noise_mv=60.0)
     hdr = loud.spec.header()
     opts = ["-m"]
     cfg = config_for(hdr, opts)
