@@ -1218,8 +1218,16 @@ __global__ void __launch_bounds__(64 * sfs_waves(NT), WPS) k_sift_s(const SfArgs
 // HBM (a few hundred 2-byte reads each; 0.06 % of the candidates of a clean tape).  Out: the candidate's overflow slot - up to
 // four records and their margin entries in the layout of a list slot.
 // ------------------------------------------------------------------------------------------------
+#ifndef RTFE_HARD_PROF
+#define RTFE_HARD_PROF 0
+#endif
 constexpr int kHardCol = 320;      // samples of a candidate's head its wave keeps in LDS: kPkBack + 3 W + 16 <= 230 for W <= 50, what is outside comes from HBM
-__global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
+#ifdef RTFE_CPU_EMUL
+#define RTFE_HARD_ATTR
+#else
+#define RTFE_HARD_ATTR __attribute__((amdgpu_waves_per_eu(6)))      // 79 registers, nothing spilled (82 without the hint): six waves a SIMD - the walk waits on LDS, waves hide it
+#endif
+__global__ void __launch_bounds__(256) RTFE_HARD_ATTR k_sift_hard(const DevCfg *__restrict__ cfgp, const int16_t *__restrict__ rows, long long nrows,
                                                    const SfHard *__restrict__ hard, int hard_cap, const int *__restrict__ hard_count, unsigned char *__restrict__ ovf, int *__restrict__ extra, unsigned long long *__restrict__ dbg) {
    // SIXTEEN LANES per candidate (round 6; a wave per candidate before): they fetch the head's samples the walk can read - one round trip -, make "rescan
    // forced" and "leftmost window minimum" for every row around the candidate (a few rows a lane), and the first of them walks on those tables.  What a
@@ -1232,16 +1240,17 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
    const int sl = threadIdx.x & (kSub - 1), wv = threadIdx.x / kSub;
    int n = *hard_count;
    if (n > hard_cap) n = hard_cap;
-   const bool prof = cfg.debug == 9 && threadIdx.x == 0;                  // (RTFE_DEBUG=9: cycles of the first wave's phases - fetch, tables, walk - and its trips)
+#if RTFE_HARD_PROF
+   const bool prof = cfg.debug == 9 && threadIdx.x == 0;                  // (a build with -DRTFE_HARD_PROF=1, RTFE_DEBUG=9: cycles of the first wave's phases - fetch, walk - and its trips)
+#else
+   constexpr bool prof = false;                                          // (the counters' registers cost the kernel a wave a SIMD)
+#endif
    long long pt[4] = {0, 0, 0, 0};
-   SfHard hd_next = sf_hard_none();                                      // (the next trip's candidate: its load travels beside this trip's samples, not in front of its own)
-   if (blockIdx.x * kGroups + wv < n) hd_next = hard[blockIdx.x * kGroups + wv];
    for (int i0 = blockIdx.x * kGroups; i0 < n; i0 += gridDim.x * kGroups) {      // (the same trips for every lane of the workgroup: the wave-level fences below)
       const int i = i0 + wv;
       long long tq = prof ? clock64() : 0;
-      SfHard hd = hd_next;
-      hd_next = sf_hard_none();
-      {  const long long i2 = (long long)i + (long long)gridDim.x * kGroups; if (i2 < n) hd_next = hard[i2]; }
+      SfHard hd = sf_hard_none();                                         // (loaded a trip ahead it changed nothing: 12.0 k cycles of fetch either way)
+      if (i < n) hd = hard[i];
       const bool live = hd.head != 0xff;                                  // (0xff: a place of a wave's chunk that no candidate took, or none at all)
       if (!live) { hd.head = 0; hd.screen = 0; }
       const DevScreen &S = cfg.screen[hd.screen];
@@ -1264,11 +1273,11 @@ __global__ void __launch_bounds__(256) k_sift_hard(const DevCfg *__restrict__ cf
       //  and the group's walk asks for a pass or two of them: each lane makes its row's answer when it is asked, W LDS reads)
       if (prof) { const long long t = clock64(); pt[1] += t - tq; tq = t; ++pt[3]; }
       PkSink sk; sk.n = 0;
-      if (__ballot(live && kPkBack + 3 * S.W + 16 > kHardCol) == 0ull) {     // (every window of the wave's candidates fits its copy: always, for the windows the front end takes)
+      {  // (every row the walk can ask for is in the copy - kPkBack + 3 W + 16 <= kHardCol for the windows the peak path takes, W <= 50 - rows outside the tape as zeros)
          PkCtxT<PkColFast> cf;
          cf.t.col = s_col[wv]; cf.t.r0 = r0; cf.W = cx.W; cf.lo_i = cx.lo_i; cf.hi_i = cx.hi_i; cf.last = cx.last;
-         pk_bot_grp(cf, sk, (int)hd.head, (int)hd.pos, live, sl, (int)(threadIdx.x & 63 & ~(kSub - 1))); }
-      else pk_bot_grp(cx, sk, (int)hd.head, (int)hd.pos, live, sl, (int)(threadIdx.x & 63 & ~(kSub - 1)));
+         pk_bot_grp(cf, sk, (int)hd.head, (int)hd.pos, live && kPkBack + 3 * cx.W + 16 <= kHardCol, sl, (int)(threadIdx.x & 63 & ~(kSub - 1))); }
+      if (live && kPkBack + 3 * cx.W + 16 > kHardCol) sk.n = 5;             // (a window wider than the front end takes: "minimum unknown" below, never silence)
 #ifdef RTFE_CPU_EMUL
       if (live && sl == 0 && getenv("RTFE_HARD_CHECK")) {             // (emulator: the group's walk against one lane's)
          PkSink s2; s2.n = 0;

@@ -182,7 +182,9 @@ for i in range(ntapes):
                         cfgp = config_for(hdr, opts)
                         # (the dense path never raises RTFE_F_SCREEN_UNDERFLOW: its lists are used only where the thresholds lie inside their band, which begins at
                         #  the screen's level, and its literal detector has no screen - k_decode's flag only asks for an exact rescan of what is exact already)
-                        fmask = np.uint32(0xffffffff ^ (frontend.F_SCREEN_UNDERFLOW if rec == "0d" else 0))
+                        # (... and since round 6 a handle's first scan of the PEAK path builds its screen for a floor it estimates from the samples, the sample path's for the floor the
+                        #  handle was made with: a tape the estimate is too high for - 80 mV of noise under the fuzzer's shapes, seed 3300 tape 29 - is flagged on one path alone)
+                        fmask = np.uint32(0xffffffff ^ frontend.F_SCREEN_UNDERFLOW)
                         if r.nbursts != r_peak.nbursts or any((r.bursts[k] != r_peak.bursts[k]).any() for k in ("zone_end", "reset_sample", "safe_last", "end_sample")) or ((r.bursts["flags"] & fmask) != (r_peak.bursts["flags"] & fmask)).any(): msgs.append("burst tables of the two paths differ")
                         else:
                             for bb in range(r.nbursts):
@@ -195,6 +197,7 @@ for i in range(ntapes):
                                         for tt in range(cfgp.ntrks):
                                             if r.track_events(bb, pp, tt).tobytes() != rx.track_events(0, pp, tt).tobytes(): msgs.append(f"dense path differs from the exact rescan: burst {bb} parmset {pp} track {tt}")
                                     continue
+                                if (int(r.bursts["flags"][bb]) ^ int(r_peak.bursts["flags"][bb])) & frontend.F_SCREEN_UNDERFLOW: continue      # (one of them holds what its screen let through: check_tape held the exact rescan against the oracle)
                                 for pp in range(len(cfgp.parmsets)):
                                     for tt in range(cfgp.ntrks):
                                         if r.track_events(bb, pp, tt).tobytes() != r_peak.track_events(bb, pp, tt).tobytes(): msgs.append(f"paths differ: burst {bb} parmset {pp} track {tt}")

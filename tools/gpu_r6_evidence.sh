@@ -26,7 +26,7 @@ timeout 900 bash tools/gpu_pmc.sh --config G1 > gpurun_out/r06/sq_counters_g1_a.
 timeout 900 bash tools/gpu_pmc2.sh --config G1 > gpurun_out/r06/sq_counters_g1_b.txt 2>&1
 rm -rf gpurun_out/pmc_sq gpurun_out/pmc_sq2
 for r in 5.54e8 6.9e7; do timeout 300 python bench.py --config C5 --rows $r --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > gpurun_out/r06/bench_c5_rows_$r.json 2>/dev/null; done
-RTFE_DEBUG=9 timeout 300 python bench.py --config N1 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs 2>/dev/null | python -c "
+RTFE_LIB_PATH=$PWD/readtape_amd/librtfe_hprof.so RTFE_DEBUG=9 timeout 300 python bench.py --config N1      `# (python tools/build_variant.py hprof -DRTFE_HARD_PROF=1)` --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs 2>/dev/null | python -c "
 import json, sys
 j = json.loads(sys.stdin.read().strip().splitlines()[-1]); p = j['config']['last_scan_stats']['phase_cycles']
 print('k_sift_hard on N1 (RTFE_DEBUG=9), cycles of the workgroups\' first waves: fetch', p[0], 'walk', p[2], 'trips', p[3], 'workgroups', p[4], '-> per trip', p[0] // max(p[3], 1), '+', p[2] // max(p[3], 1))" | tee gpurun_out/r06/sift_hard_phases.txt
