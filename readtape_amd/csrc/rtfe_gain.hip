@@ -1046,7 +1046,20 @@ __device__ __forceinline__ rtfe_event emit_event(const DevCfg &cfg, const DevPar
 
 // the events of the steady stretches: a wave per standing segment, a lane per record - its gain says whether it fired, a prefix sum where
 // its event goes.  Records, entry references and gains are read in stream order.
-__global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, const BurstCtl *__restrict__ ctl, rtfe_event *__restrict__ events,
+// (rounds of 64 records a wave loads together against waves a SIMD: 4 rounds at 84 registers = five waves: k_emit_seg 0.253 - 0.267 ms on C2, 1.64 - 1.66 on M8; 2 rounds, seven waves:
+//  0.238, 1.50 - 1.54; 1 round, 64 registers, eight waves: 0.236, 1.60, and C2's scan 1.34 against 1.35 ms - more waves hide the round trips better than a wave's own batch)
+#ifndef RTFE_ES_AHEAD
+#define RTFE_ES_AHEAD 1
+#endif
+#ifndef RTFE_ES_WAVES
+#define RTFE_ES_WAVES 8
+#endif
+#if RTFE_ES_WAVES > 0 && !defined(RTFE_CPU_EMUL)
+#define RTFE_ES_ATTR __attribute__((amdgpu_waves_per_eu(RTFE_ES_WAVES)))
+#else
+#define RTFE_ES_ATTR
+#endif
+__global__ void __launch_bounds__(256) RTFE_ES_ATTR k_emit_seg(const DevCfg *__restrict__ cfgp, const ChainSt *__restrict__ cst, const BurstCtl *__restrict__ ctl, rtfe_event *__restrict__ events,
                                                   const CRec *__restrict__ crec, const uint2 *__restrict__ cmar, long long ccap, const unsigned char *__restrict__ pool,
                                                   const GsSeg *__restrict__ segs, const int *__restrict__ nsegs_p, long long seg_cap, const float *__restrict__ gfire, int nchains_max,
                                                   const int16_t *__restrict__ rows, long long nrows) {
@@ -1075,9 +1088,9 @@ __global__ void __launch_bounds__(256) k_emit_seg(const DevCfg *__restrict__ cfg
       const long long n_own_l = sg.stop - sg.first;
       const int n_own = n_own_l < 0 ? 0 : (n_own_l > S ? S : (int)n_own_l);
       unsigned int at = sg.evoff;
-      // (a lane's gain, record and margin block for up to kEsAhead rounds of 64 records are loaded TOGETHER and whether the record fired or not -
-      //  93 % do: one round trip per batch instead of two dependent ones per round; the kernel waits for memory 85 % of its time)
-      constexpr int kEsAhead = 4;
+      // (a lane's gain, record and margin block of a round of 64 records are loaded TOGETHER and whether the record fired or not - 93 % do: one round trip
+      //  instead of two dependent ones; the kernel waits for memory 85 % of its time - RTFE_ES_AHEAD rounds a batch, see above)
+      constexpr int kEsAhead = RTFE_ES_AHEAD;
       for (int k0 = 0; k0 < n_own; k0 += 64 * kEsAhead) {
          float gain[kEsAhead]; CRec rec[kEsAhead]; uint2 mar[kEsAhead];
          #pragma unroll
